@@ -1,0 +1,130 @@
+"""ctypes binding of libhifihr.so (the C ABI in include/hifihr.h).
+
+`get_lib()` loads the in-tree HIP build and FAILS LOUDLY when it is missing -- there is no CPU or
+PyTorch fallback for the hot path.  `HifihrLib` itself only marshals pointers, so the test-suite can also
+point it at tests/hostsim/libhifihr_hostsim.so (the same kernel sources compiled against a HIP
+execution-model emulator) to exercise the kernels without a GPU; the package never does that.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must be imported first: the library binds to torch's libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhifihr.so")
+
+_c_float_p = POINTER(c_float)
+_c_int_p = POINTER(c_int32)
+
+
+class HifihrError(RuntimeError):
+    pass
+
+
+def _fp(t):
+    """Device (or host) pointer of a contiguous fp32 tensor, or NULL for None."""
+    if t is None:
+        return None
+    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return ctypes.cast(t.data_ptr(), _c_float_p)
+
+
+def _ip(t):
+    if t is None:
+        return None
+    assert t.dtype == torch.int32 and t.is_contiguous()
+    return ctypes.cast(t.data_ptr(), _c_int_p)
+
+
+def _stream_of(t):
+    if t.is_cuda:
+        return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return c_void_p(0)
+
+
+def _np_fp(a):
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_c_float_p)
+
+
+class HifihrLib:
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise HifihrError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or `make -C hifihr_amd/csrc`). The HIP extension is mandatory; there is no fallback path.")
+        self.path = path
+        self.c = ctypes.CDLL(path)
+        c = self.c
+        c.hifihr_last_error.restype = c_char_p
+        c.hifihr_version.restype = c_int
+        c.hifihr_device_count.restype = c_int
+        c.hifihr_mano_create.argtypes = [POINTER(c_void_p)] + [_c_float_p] * 7
+        c.hifihr_mano_destroy.argtypes = [c_void_p]
+        c.hifihr_mano_lbs_fwd.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, _c_float_p, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_mano_lbs_bwd.argtypes = [c_void_p] + [_c_float_p] * 5 + [c_int, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_mano_joints_fwd.argtypes = [c_void_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_mano_joints_bwd.argtypes = [c_void_p, _c_float_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p, c_void_p]
+        self._bind_optional()
+
+    def _bind_optional(self):
+        pass
+
+    # ------------------------------------------------------------------
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            raise HifihrError(f"{what} failed ({rc}): {self.c.hifihr_last_error().decode()}")
+
+    # ---- MANO --------------------------------------------------------
+    def mano_create(self, tables) -> c_void_p:
+        h = c_void_p()
+        keep = [_np_fp(a) for a in (tables.v_template, tables.shapedirs, tables.posedirs, tables.J_regressor,
+                                    tables.weights, tables.hands_components, tables.hands_mean)]
+        self.check(self.c.hifihr_mano_create(ctypes.byref(h), *[k[1] for k in keep]), "hifihr_mano_create")
+        return h
+
+    def mano_destroy(self, h):
+        self.c.hifihr_mano_destroy(h)
+
+    def mano_lbs_fwd(self, h, pose, beta, verts, jtr, saved):
+        B = pose.shape[0]
+        assert pose.shape == (B, 48) and beta.shape == (B, 10) and verts.shape == (B, 778, 3)
+        self.check(self.c.hifihr_mano_lbs_fwd(h, _fp(pose), _fp(beta), B, _fp(verts), _fp(jtr), _fp(saved),
+                                              _stream_of(pose)), "hifihr_mano_lbs_fwd")
+
+    def mano_lbs_bwd(self, h, pose, beta, saved, gverts, gjtr, gpose, gbeta):
+        B = pose.shape[0]
+        self.check(self.c.hifihr_mano_lbs_bwd(h, _fp(pose), _fp(beta), _fp(saved), _fp(gverts), _fp(gjtr), B,
+                                              _fp(gpose), _fp(gbeta), _stream_of(pose)), "hifihr_mano_lbs_bwd")
+
+    def mano_joints_fwd(self, h, verts, root_id, joints_rel, verts_rel, root):
+        B = verts.shape[0]
+        self.check(self.c.hifihr_mano_joints_fwd(h, _fp(verts), B, root_id, _fp(joints_rel), _fp(verts_rel), _fp(root),
+                                                 _stream_of(verts)), "hifihr_mano_joints_fwd")
+
+    def mano_joints_bwd(self, h, gjoints_rel, gverts_rel, groot, root_id, gverts):
+        B = gverts.shape[0]
+        self.check(self.c.hifihr_mano_joints_bwd(h, _fp(gjoints_rel), _fp(gverts_rel), _fp(groot), B, root_id,
+                                                 _fp(gverts), _stream_of(gverts)), "hifihr_mano_joints_bwd")
+
+
+_LIB = None
+
+
+def get_lib() -> HifihrLib:
+    """The product library (HIP, in-tree).  Raises HifihrError when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        _LIB = HifihrLib(LIB_PATH)
+    return _LIB
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HifihrError("hifihr_amd ops run on the GPU only (HIP kernels); got a CPU tensor. "
+                              "There is no CPU fallback: use oracle/ only from tests.")

@@ -1,0 +1,151 @@
+// C ABI of libhifihr.so (see include/hifihr.h).  Thin: argument checks, table upload at create time,
+// kernel launches on the caller's stream.  No allocation and no synchronisation in compute calls.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/hifihr.h"
+#include "hifihr_internal.h"
+#include "mano_math.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess) return fail(HIFIHR_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+int upload(DevBuf& b, const std::vector<float>& h) {
+  HIP_TRY(hipMalloc(&b.p, h.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(b.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  return HIFIHR_OK;
+}
+
+}  // namespace
+
+struct hifihr_mano {
+  DevBuf tmpl, sd, pd, w, jreg, comps, mean, jt, jsd;
+  hifihr::ManoDev dev;
+};
+
+extern "C" {
+
+int hifihr_version(void) { return 1; }
+const char* hifihr_last_error(void) { return g_err; }
+
+int hifihr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int hifihr_mano_create(hifihr_mano_t** out, const float* v_template, const float* shapedirs, const float* posedirs,
+                       const float* j_regressor, const float* weights, const float* comps, const float* mean) {
+  using namespace hifihr;
+  if (!out || !v_template || !shapedirs || !posedirs || !j_regressor || !weights || !comps || !mean)
+    return fail(HIFIHR_EINVAL, "hifihr_mano_create: null argument");
+  hifihr_mano* h = new (std::nothrow) hifihr_mano();
+  if (!h) return fail(HIFIHR_ENOMEM, "hifihr_mano_create: out of host memory");
+  // host re-layout: [v][c][k] -> [k][c][vpad]
+  std::vector<float> tm(3 * kNVP, 0.f), sd((size_t)kNB * 3 * kNVP, 0.f), pd((size_t)kNP * 3 * kNVP, 0.f),
+      w((size_t)kNJ * kNVP, 0.f), jr((size_t)kNJ * kNVP, 0.f), jt(kNJ * 3), jsd((size_t)kNJ * 3 * kNB);
+  for (int v = 0; v < kNV; ++v)
+    for (int c = 0; c < 3; ++c) {
+      tm[c * kNVP + v] = v_template[v * 3 + c];
+      for (int k = 0; k < kNB; ++k) sd[((size_t)k * 3 + c) * kNVP + v] = shapedirs[((size_t)v * 3 + c) * kNB + k];
+      for (int k = 0; k < kNP; ++k) pd[((size_t)k * 3 + c) * kNVP + v] = posedirs[((size_t)v * 3 + c) * kNP + k];
+    }
+  for (int v = 0; v < kNV; ++v)
+    for (int j = 0; j < kNJ; ++j) {
+      w[(size_t)j * kNVP + v] = weights[v * kNJ + j];
+      jr[(size_t)j * kNVP + v] = j_regressor[(size_t)j * kNV + v];
+    }
+  // J = J_regressor (v_template + shapedirs beta) is linear in beta: fold the regressor into 16x3 (+16x3x10)
+  // tables once, accumulated in double (reference my_mano.py:386-389 does the 778-term sums per call).
+  for (int j = 0; j < kNJ; ++j)
+    for (int c = 0; c < 3; ++c) {
+      double a = 0.0;
+      for (int v = 0; v < kNV; ++v) a += (double)j_regressor[(size_t)j * kNV + v] * (double)v_template[v * 3 + c];
+      jt[j * 3 + c] = (float)a;
+      for (int k = 0; k < kNB; ++k) {
+        double s = 0.0;
+        for (int v = 0; v < kNV; ++v) s += (double)j_regressor[(size_t)j * kNV + v] * (double)shapedirs[((size_t)v * 3 + c) * kNB + k];
+        jsd[((size_t)j * 3 + c) * kNB + k] = (float)s;
+      }
+    }
+  std::vector<float> cm(comps, comps + kNPCA * kNPCA), mn(mean, mean + kNPCA);
+  int rc;
+  if ((rc = upload(h->tmpl, tm)) || (rc = upload(h->sd, sd)) || (rc = upload(h->pd, pd)) || (rc = upload(h->w, w)) ||
+      (rc = upload(h->jreg, jr)) || (rc = upload(h->comps, cm)) || (rc = upload(h->mean, mn)) ||
+      (rc = upload(h->jt, jt)) || (rc = upload(h->jsd, jsd))) {
+    delete h;
+    return rc;
+  }
+  h->dev = ManoDev{(const float*)h->tmpl.p, (const float*)h->sd.p,   (const float*)h->pd.p,
+                   (const float*)h->w.p,    (const float*)h->jreg.p, (const float*)h->comps.p,
+                   (const float*)h->mean.p, (const float*)h->jt.p,   (const float*)h->jsd.p};
+  *out = h;
+  return HIFIHR_OK;
+}
+
+int hifihr_mano_destroy(hifihr_mano_t* h) {
+  delete h;
+  return HIFIHR_OK;
+}
+
+int hifihr_mano_lbs_fwd(const hifihr_mano_t* h, const float* pose, const float* beta, int B, float* verts, float* jtr,
+                        float* saved, void* stream) {
+  if (!h || !pose || !beta || !verts || B < 0) return fail(HIFIHR_EINVAL, "hifihr_mano_lbs_fwd: bad argument");
+  if (B == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_mano_fwd(h->dev, pose, beta, B, verts, jtr, saved, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_mano_lbs_bwd(const hifihr_mano_t* h, const float* pose, const float* beta, const float* saved,
+                        const float* gverts, const float* gjtr, int B, float* gpose, float* gbeta, void* stream) {
+  if (!h || !pose || !beta || !saved || !gpose || !gbeta || B < 0)
+    return fail(HIFIHR_EINVAL, "hifihr_mano_lbs_bwd: bad argument");
+  if (B == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_mano_bwd(h->dev, pose, beta, saved, gverts, gjtr, B, gpose, gbeta, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_mano_joints_fwd(const hifihr_mano_t* h, const float* verts, int B, int root_id, float* joints_rel,
+                           float* verts_rel, float* root, void* stream) {
+  if (!h || !verts || !joints_rel || B < 0 || root_id >= 21) return fail(HIFIHR_EINVAL, "hifihr_mano_joints_fwd: bad argument");
+  if (B == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_mano_joints_fwd(h->dev, verts, B, root_id, joints_rel, verts_rel, root, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_mano_joints_bwd(const hifihr_mano_t* h, const float* gjoints_rel, const float* gverts_rel, const float* groot,
+                           int B, int root_id, float* gverts, void* stream) {
+  if (!h || !gverts || B < 0 || root_id >= 21) return fail(HIFIHR_EINVAL, "hifihr_mano_joints_bwd: bad argument");
+  if (B == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_mano_joints_bwd(h->dev, gjoints_rel, gverts_rel, groot, B, root_id, gverts, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+}  // extern "C"

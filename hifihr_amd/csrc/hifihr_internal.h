@@ -1,0 +1,33 @@
+// Internal declarations shared by the HIP translation units of libhifihr.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hifihr {
+
+constexpr int kNVP = 800;   // padded vertex count of the SoA MANO tables (rows are 16-byte aligned)
+
+// Device-resident MANO tables, structure-of-arrays over the vertex index so that a wave reads 256
+// contiguous bytes per table row.  Padding entries are zero.
+struct ManoDev {
+  const float* tmpl;   // [3][kNVP]
+  const float* sd;     // [10][3][kNVP]    shapedirs
+  const float* pd;     // [135][3][kNVP]   posedirs
+  const float* w;      // [16][kNVP]       skinning weights, transposed
+  const float* jreg;   // [16][kNVP]       joint regressor (dense)
+  const float* comps;  // [45][45]
+  const float* mean;   // [45]
+  const float* jt;     // [16*3]           J_regressor @ v_template
+  const float* jsd;    // [16*3][10]       J_regressor @ shapedirs
+};
+
+hipError_t launch_mano_fwd(const ManoDev& t, const float* pose, const float* beta, int B, float* verts, float* jtr,
+                           float* saved, hipStream_t st);
+hipError_t launch_mano_bwd(const ManoDev& t, const float* pose, const float* beta, const float* saved,
+                           const float* gverts, const float* gjtr, int B, float* gpose, float* gbeta, hipStream_t st);
+hipError_t launch_mano_joints_fwd(const ManoDev& t, const float* verts, int B, int root_id, float* joints_rel,
+                                  float* verts_rel, float* root, hipStream_t st);
+hipError_t launch_mano_joints_bwd(const ManoDev& t, const float* gjoints_rel, const float* gverts_rel,
+                                  const float* groot, int B, int root_id, float* gverts, hipStream_t st);
+
+}  // namespace hifihr

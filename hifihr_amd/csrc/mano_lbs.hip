@@ -1,0 +1,462 @@
+// MANO linear-blend skinning for gfx950: forward, backward, joint regression.
+//
+// Replaces ManoLayer.forward (reference utils/my_mano.py:315-483), which issues ~60 small ATen launches
+// and one host sync per call, with ONE launch per direction:
+//   mano_fwd_kernel   grid (kTiles, B) x 256 threads.  Every workgroup redoes the tiny per-hand
+//                     prologue (PCA 45x45, 16 Rodrigues, kinematic chain) in LDS, then each thread blends and
+//                     skins one vertex.  Tables are stored structure-of-arrays over the vertex index
+//                     ([row][xyz][vertex]) so a wave reads 256 contiguous bytes per table row; the 1.4 MB of
+//                     tables stay L2-resident across the batch.  HBM-bound on verts/v_posed writes.
+//   mano_bwd_kernel   grid B x 512 threads, deterministic (no float atomics): per-joint reductions are done
+//                     as an in-LDS (16x778)x(778x12) product, the blend-shape transposes as wave dot products.
+//   mano_joints_*     xyz_from_vertice + root-relative step (models_res_nimble.py:153,160-166).
+#include <hip/hip_runtime.h>
+
+#include "hifihr_internal.h"
+#include "mano_math.h"
+
+namespace hifihr {
+
+__device__ __constant__ int c_reorder21[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
+// xyz_from_vertice: FreiHAND slot -> regressed MANO joint id (>=0) or -(vertex id) - 1 for the five tips
+__device__ __constant__ int c_xyz_src[21] = {0, 13, 14, 15, -744 - 1, 1, 2, 3, -320 - 1, 4, 5, 6, -443 - 1,
+                                             10, 11, 12, -555 - 1, 7, 8, 9, -672 - 1};
+
+struct ManoSmall {          // per-hand state kept in LDS
+  float pose[48];
+  float beta[kNB];
+  float fp[48];             // full axis-angle pose
+  float Rl[kNJ * 9];
+  float Rg[kNJ * 9];
+  float tg[kNJ * 3];
+  float J[kNJ * 3];
+  float Ap[kNJ * 12];
+  float pm[kNP];            // pose_map = R - I for joints 1..15
+};
+
+// Prologue shared by forward and backward.  Needs >= 128 threads; ends with a barrier.
+__device__ __forceinline__ void mano_prologue(const ManoDev& t, const float* __restrict__ pose,
+                                              const float* __restrict__ beta, int b, ManoSmall& s) {
+  const int tid = threadIdx.x;
+  if (tid < 48) s.pose[tid] = pose[b * 48 + tid];
+  if (tid >= 64 && tid < 64 + kNB) s.beta[tid - 64] = beta[b * kNB + tid - 64];
+  __syncthreads();
+  if (tid < kNPCA) {                       // my_mano.py:340-348: coeffs.mm(selected_comps) + hands_mean
+    float acc = 0.f;
+    for (int k = 0; k < kNPCA; ++k) acc += s.pose[3 + k] * t.comps[k * kNPCA + tid];
+    s.fp[3 + tid] = t.mean[tid] + acc;
+  } else if (tid < 48) {
+    s.fp[tid - kNPCA] = s.pose[tid - kNPCA];
+  }
+  if (tid >= 64 && tid < 64 + 48) {        // J = J_regressor (v_template + shapedirs beta), my_mano.py:386-389
+    const int e = tid - 64;
+    float acc = t.jt[e];
+    for (int k = 0; k < kNB; ++k) acc += t.jsd[e * kNB + k] * s.beta[k];
+    s.J[e] = acc;
+  }
+  __syncthreads();
+  if (tid < kNJ) {
+    rodrigues_fwd(s.fp + 3 * tid, s.Rl + 9 * tid, nullptr);
+    if (tid >= 1) {
+      for (int k = 0; k < 9; ++k) s.pm[(tid - 1) * 9 + k] = s.Rl[9 * tid + k] - ((k % 4 == 0) ? 1.f : 0.f);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) chain_fwd_root(s.Rl, s.J, s.Rg, s.tg);
+  __syncthreads();
+  if (tid < 5) chain_fwd_finger(tid, s.Rl, s.J, s.Rg, s.tg);
+  __syncthreads();
+  if (tid < kNJ) chain_make_ap(tid, s.J, s.Rg, s.tg, s.Ap);
+  __syncthreads();
+}
+
+constexpr int kFwdTiles = 4;
+constexpr int kFwdTileV = 195;   // 4 x 195 = 780 >= 778
+
+__global__ __launch_bounds__(256) void mano_fwd_kernel(ManoDev t, const float* __restrict__ pose,
+                                                      const float* __restrict__ beta, float* __restrict__ verts,
+                                                      float* __restrict__ jtr, float* __restrict__ saved_vposed) {
+  __shared__ ManoSmall s;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  mano_prologue(t, pose, beta, b, s);
+
+  const float cx = s.tg[12], cy = s.tg[13], cz = s.tg[14];   // centre = joint 9 of the 21 = MANO joint 4
+  if (blockIdx.x == 0 && tid < 21 && jtr) {
+    const int src = c_reorder21[tid];
+    if (src < kNJ) {
+      float* o = jtr + ((size_t)b * 21 + tid) * 3;
+      o[0] = s.tg[3 * src] - cx; o[1] = s.tg[3 * src + 1] - cy; o[2] = s.tg[3 * src + 2] - cz;
+    }
+  }
+  const int v = blockIdx.x * kFwdTileV + tid;
+  if (tid >= kFwdTileV || v >= kNV) return;
+
+  // v_posed = v_template + shapedirs.beta + posedirs.pose_map      (my_mano.py:386-393)
+  float vp[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) vp[c] = t.tmpl[c * kNVP + v];
+  for (int k = 0; k < kNB; ++k) {
+    const float bk = s.beta[k];
+    const float* row = t.sd + (size_t)k * 3 * kNVP + v;
+    vp[0] += row[0] * bk; vp[1] += row[kNVP] * bk; vp[2] += row[2 * kNVP] * bk;
+  }
+#pragma unroll 5
+  for (int p = 0; p < kNP; ++p) {
+    const float pk = s.pm[p];
+    const float* row = t.pd + (size_t)p * 3 * kNVP + v;
+    vp[0] += row[0] * pk; vp[1] += row[kNVP] * pk; vp[2] += row[2 * kNVP] * pk;
+  }
+  // T = sum_i w_i A'_i ; vert = T [v_posed;1]                        (my_mano.py:441-451)
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = 0.f;
+  for (int i = 0; i < kNJ; ++i) {
+    const float w = t.w[i * kNVP + v];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] += w * s.Ap[12 * i + k];
+  }
+  float o[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) o[r] = T[4 * r] * vp[0] + T[4 * r + 1] * vp[1] + T[4 * r + 2] * vp[2] + T[4 * r + 3];
+  o[0] -= cx; o[1] -= cy; o[2] -= cz;
+  float* ov = verts + ((size_t)b * kNV + v) * 3;
+  ov[0] = o[0]; ov[1] = o[1]; ov[2] = o[2];
+  if (saved_vposed) {
+    float* sv = saved_vposed + ((size_t)b * kNV + v) * 3;
+    sv[0] = vp[0]; sv[1] = vp[1]; sv[2] = vp[2];
+  }
+  if (jtr) {                                                        // finger tips, my_mano.py:457
+    int tip = -1;
+    if (v == 745) tip = 0; else if (v == 317) tip = 1; else if (v == 444) tip = 2; else if (v == 556) tip = 3; else if (v == 673) tip = 4;
+    if (tip >= 0) {
+      float* oj = jtr + ((size_t)b * 21 + 4 + 4 * tip) * 3;         // slot with REORDER21[slot] == 16 + tip
+      oj[0] = o[0]; oj[1] = o[1]; oj[2] = o[2];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+constexpr int kBwdThreads = 512;
+
+struct ManoBwdLds {
+  ManoSmall s;
+  alignas(16) float gv[3 * kNVP];      // incoming vertex gradient (incl. tips and centring), SoA
+  alignas(16) float vp[3 * kNVP];      // saved v_posed, SoA
+  alignas(16) float gvp[3 * kNVP];     // gradient wrt v_posed, SoA (same indexing as a table row)
+  float gAp[kNJ * 12];
+  float gRg[kNJ * 9];
+  float gtg[kNJ * 3];
+  float gJ[kNJ * 3];
+  float gRl[kNJ * 9];
+  float gpm[kNP];
+  float gbeta_blend[kNB];
+  float gfp[48];
+  float root_acc[5 * 15];  // per finger: gRg0[9], gtg0[3], gJ0[3]
+  float gcenter[3];
+  float red[kBwdThreads / 64 * 3];
+};
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+  return x;
+}
+
+__global__ __launch_bounds__(kBwdThreads) void mano_bwd_kernel(ManoDev t, const float* __restrict__ pose,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ saved_vposed,
+                                                             const float* __restrict__ gverts,
+                                                             const float* __restrict__ gjtr,
+                                                             float* __restrict__ gpose, float* __restrict__ gbeta) {
+  HIP_DYNAMIC_SHARED(float4, smem_raw)   // float4: 16-byte aligned base (ds_read_b128 in phase 3)
+  ManoBwdLds& L = *reinterpret_cast<ManoBwdLds*>(smem_raw);
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  mano_prologue(t, pose, beta, b, L.s);
+
+  // ---- phase 1: stage gv (+ tip gradients) and v_posed; centre gradient = -(sum gverts + sum gjtr) ----
+  float csum[3] = {0.f, 0.f, 0.f};
+  for (int v = tid; v < kNVP; v += kBwdThreads) {
+    float g[3] = {0.f, 0.f, 0.f}, p[3] = {0.f, 0.f, 0.f};
+    if (v < kNV) {
+      if (gverts) {
+        const float* gp = gverts + ((size_t)b * kNV + v) * 3;
+        g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+      }
+      const float* sp = saved_vposed + ((size_t)b * kNV + v) * 3;
+      p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+      csum[0] += g[0]; csum[1] += g[1]; csum[2] += g[2];           // centring acts on verts before tips are read
+      if (gjtr) {
+        int tip = -1;
+        if (v == 745) tip = 0; else if (v == 317) tip = 1; else if (v == 444) tip = 2; else if (v == 556) tip = 3; else if (v == 673) tip = 4;
+        if (tip >= 0) {
+          const float* gj = gjtr + ((size_t)b * 21 + 4 + 4 * tip) * 3;
+          g[0] += gj[0]; g[1] += gj[1]; g[2] += gj[2];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { L.gv[c * kNVP + v] = g[c]; L.vp[c * kNVP + v] = p[c]; }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float r = wave_sum(csum[c]);
+    if (lane == 0) L.red[wave * 3 + c] = r;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    float acc = 0.f;
+    for (int w = 0; w < kBwdThreads / 64; ++w) acc += L.red[w * 3 + tid];
+    if (gjtr)
+      for (int j = 0; j < 21; ++j) acc += gjtr[((size_t)b * 21 + j) * 3 + tid];
+    L.gcenter[tid] = -acc;        // d/d(centre): every output had the centre subtracted
+  }
+  // ---- phase 2a: gAp[i][4r+c] = sum_v w[v,i] gv[r][v] [vp;1][c][v]  (192 threads, fixed order) ----
+  if (tid < kNJ * 12) {
+    const int i = tid / 12, k = tid % 12, r = k / 4, c = k % 4;
+    const float* wrow = t.w + i * kNVP;
+    const float* gr = L.gv + r * kNVP;
+    float acc = 0.f;
+    if (c < 3) {
+      const float* pc = L.vp + c * kNVP;
+      for (int v = 0; v < kNV; ++v) acc += wrow[v] * gr[v] * pc[v];
+    } else {
+      for (int v = 0; v < kNV; ++v) acc += wrow[v] * gr[v];
+    }
+    L.gAp[tid] = acc;
+  }
+  // ---- phase 2b: gvp[v] = sum_i w[v,i] Rg_i^T gv[v]  (threads >= 192 so both halves overlap) ----
+  for (int v = (tid >= 192) ? tid - 192 : kNVP; v < kNVP; v += kBwdThreads - 192) {
+    float o[3] = {0.f, 0.f, 0.f};
+    if (v < kNV) {
+      const float g[3] = {L.gv[v], L.gv[kNVP + v], L.gv[2 * kNVP + v]};
+      for (int i = 0; i < kNJ; ++i) {
+        const float w = t.w[i * kNVP + v];
+        const float* R = L.s.Rg + 9 * i;
+        o[0] += w * (R[0] * g[0] + R[3] * g[1] + R[6] * g[2]);
+        o[1] += w * (R[1] * g[0] + R[4] * g[1] + R[7] * g[2]);
+        o[2] += w * (R[2] * g[0] + R[5] * g[1] + R[8] * g[2]);
+      }
+    }
+    L.gvp[v] = o[0]; L.gvp[kNVP + v] = o[1]; L.gvp[2 * kNVP + v] = o[2];
+  }
+  __syncthreads();
+
+  // ---- phase 3: blend-shape transposes: gpm[p] = <posedirs row p, gvp>, gbeta[k] = <shapedirs row k, gvp> ----
+  {
+    constexpr int kRow4 = 3 * kNVP / 4;     // float4 per table row
+    const float4* g4 = reinterpret_cast<const float4*>(L.gvp);
+    for (int row = wave; row < kNP + kNB; row += kBwdThreads / 64) {
+      const float* base = (row < kNP) ? t.pd + (size_t)row * 3 * kNVP : t.sd + (size_t)(row - kNP) * 3 * kNVP;
+      const float4* r4 = reinterpret_cast<const float4*>(base);
+      float acc = 0.f;
+      for (int e = lane; e < kRow4; e += 64) {
+        const float4 a = r4[e];
+        const float4 g = g4[e];
+        acc += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        if (row < kNP) L.gpm[row] = acc; else L.gbeta_blend[row - kNP] = acc;
+      }
+    }
+  }
+  // ---- phase 4: fold gAp into the chain, walk the chain backwards ----
+  if (tid < kNJ * 9) L.gRg[tid] = 0.f;
+  if (tid < kNJ * 3) { L.gtg[tid] = 0.f; L.gJ[tid] = 0.f; }
+  if (tid < 5 * 15) L.root_acc[tid] = 0.f;
+  __syncthreads();
+  if (tid < kNJ) {
+    chain_make_ap_bwd(tid, L.s.J, L.s.Rg, L.gAp, L.gRg, L.gtg, L.gJ);
+    // joints of the 21-vector that are chain translations: slot s has source REORDER21[s] < 16
+    if (gjtr) {
+      for (int sl = 0; sl < 21; ++sl) {
+        if (c_reorder21[sl] == tid) {
+          const float* gj = gjtr + ((size_t)b * 21 + sl) * 3;
+          L.gtg[3 * tid] += gj[0]; L.gtg[3 * tid + 1] += gj[1]; L.gtg[3 * tid + 2] += gj[2];
+        }
+      }
+    }
+    if (tid == 4) { L.gtg[12] += L.gcenter[0]; L.gtg[13] += L.gcenter[1]; L.gtg[14] += L.gcenter[2]; }
+  }
+  __syncthreads();
+  if (tid < 5) {
+    float* acc = L.root_acc + 15 * tid;
+    chain_bwd_finger(tid, L.s.Rl, L.s.J, L.s.Rg, L.gRg, L.gtg, L.gRl, L.gJ, acc, acc + 9, acc + 12);
+  }
+  __syncthreads();
+  if (tid < 15) {               // root: Rg_0 = Rl_0, tg_0 = J_0
+    float a = 0.f;
+    for (int f = 0; f < 5; ++f) a += L.root_acc[15 * f + tid];
+    if (tid < 9) L.gRl[tid] = L.gRg[tid] + a;
+    else if (tid < 12) L.root_acc[tid] = L.gtg[tid - 9] + a;      // reuse slot: total g(tg_0)
+    else L.root_acc[tid] = L.gJ[tid - 12] + a;                    // gJ_0 (chain part)
+  }
+  __syncthreads();
+  if (tid < 3) L.gJ[tid] = L.root_acc[12 + tid] + L.root_acc[9 + tid];
+  // pose_map gradient goes to the local rotations of joints 1..15 (pose_map = Rl - I)
+  if (tid >= 64 && tid < 64 + kNP) L.gRl[9 + (tid - 64)] += L.gpm[tid - 64];
+  __syncthreads();
+  if (tid < kNJ) rodrigues_bwd(L.s.fp + 3 * tid, L.gRl + 9 * tid, L.gfp + 3 * tid);
+  __syncthreads();
+  // ---- phase 5: PCA transpose and shape gradient ----
+  if (tid < 3) {
+    gpose[b * 48 + tid] = L.gfp[tid];
+  } else if (tid < 48) {
+    const int k = tid - 3;
+    float acc = 0.f;
+    for (int j = 0; j < kNPCA; ++j) acc += t.comps[k * kNPCA + j] * L.gfp[3 + j];
+    gpose[b * 48 + tid] = acc;
+  } else if (tid >= 64 && tid < 64 + kNB) {
+    const int k = tid - 64;
+    float acc = L.gbeta_blend[k];
+    for (int e = 0; e < kNJ * 3; ++e) acc += t.jsd[e * kNB + k] * L.gJ[e];
+    gbeta[b * kNB + k] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// xyz_from_vertice + root-relative
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mano_joints_fwd_kernel(ManoDev t, const float* __restrict__ verts, int root_id,
+                                                             float* __restrict__ joints_rel, float* __restrict__ verts_rel,
+                                                             float* __restrict__ root_out) {
+  __shared__ float sv[3 * kNVP];
+  __shared__ float j16[kNJ * 3];
+  __shared__ float j21[21 * 3];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int v = tid; v < kNV; v += 256) {
+    const float* p = verts + ((size_t)b * kNV + v) * 3;
+    sv[v] = p[0]; sv[kNVP + v] = p[1]; sv[2 * kNVP + v] = p[2];
+  }
+  __syncthreads();
+  for (int o = wave; o < kNJ * 3; o += 4) {           // 48 dot products of length 778, one wave each
+    const int j = o / 3, c = o % 3;
+    const float* jr = t.jreg + j * kNVP;
+    float acc = 0.f;
+    for (int v = lane; v < kNV; v += 64) acc += jr[v] * sv[c * kNVP + v];
+    acc = wave_sum(acc);
+    if (lane == 0) j16[o] = acc;
+  }
+  __syncthreads();
+  if (tid < 63) {
+    const int sl = tid / 3, c = tid % 3;
+    const int src = c_xyz_src[sl];
+    j21[tid] = (src >= 0) ? j16[src * 3 + c] : sv[c * kNVP + (-src - 1)];
+  }
+  __syncthreads();
+  float r[3] = {0.f, 0.f, 0.f};
+  if (root_id >= 0) { r[0] = j21[root_id * 3]; r[1] = j21[root_id * 3 + 1]; r[2] = j21[root_id * 3 + 2]; }
+  if (tid < 63) joints_rel[(size_t)b * 63 + tid] = j21[tid] - r[tid % 3];
+  if (tid < 3 && root_out) root_out[b * 3 + tid] = r[tid];
+  if (verts_rel) {
+    for (int e = tid; e < kNV * 3; e += 256) {
+      const int v = e / 3, c = e % 3;
+      verts_rel[(size_t)b * kNV * 3 + e] = sv[c * kNVP + v] - r[c];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mano_joints_bwd_kernel(ManoDev t, const float* __restrict__ gjoints_rel,
+                                                             const float* __restrict__ gverts_rel,
+                                                             const float* __restrict__ groot, int root_id,
+                                                             float* __restrict__ gverts) {
+  __shared__ float gj21[63];
+  __shared__ float gj16[kNJ * 3];
+  __shared__ float red[4 * 3];
+  __shared__ float gr[3];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // gradient wrt the root joint: groot - sum(gjoints_rel) - sum(gverts_rel)
+  float cs[3] = {0.f, 0.f, 0.f};
+  if (gverts_rel && root_id >= 0) {
+    for (int v = tid; v < kNV; v += 256) {
+      const float* p = gverts_rel + ((size_t)b * kNV + v) * 3;
+      cs[0] += p[0]; cs[1] += p[1]; cs[2] += p[2];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float s = wave_sum(cs[c]);
+    if (lane == 0) red[wave * 3 + c] = s;
+  }
+  if (tid < 63) gj21[tid] = gjoints_rel ? gjoints_rel[(size_t)b * 63 + tid] : 0.f;
+  __syncthreads();
+  if (tid < 3) {
+    float a = groot ? groot[b * 3 + tid] : 0.f;
+    if (root_id >= 0) {
+      for (int w = 0; w < 4; ++w) a -= red[w * 3 + tid];
+      for (int j = 0; j < 21; ++j) a -= gj21[j * 3 + tid];
+    } else {
+      a = 0.f;
+    }
+    gr[tid] = a;
+  }
+  __syncthreads();
+  if (tid < 3 && root_id >= 0) gj21[root_id * 3 + tid] += gr[tid];
+  __syncthreads();
+  if (tid < kNJ * 3) {
+    const int j = tid / 3, c = tid % 3;
+    float a = 0.f;
+    for (int sl = 0; sl < 21; ++sl)
+      if (c_xyz_src[sl] == j) a += gj21[sl * 3 + c];
+    gj16[tid] = a;
+  }
+  __syncthreads();
+  for (int v = tid; v < kNV; v += 256) {
+    float g[3] = {0.f, 0.f, 0.f};
+    if (gverts_rel) {
+      const float* p = gverts_rel + ((size_t)b * kNV + v) * 3;
+      g[0] = p[0]; g[1] = p[1]; g[2] = p[2];
+    }
+    for (int j = 0; j < kNJ; ++j) {
+      const float w = t.jreg[j * kNVP + v];
+      g[0] += w * gj16[j * 3]; g[1] += w * gj16[j * 3 + 1]; g[2] += w * gj16[j * 3 + 2];
+    }
+    for (int sl = 4; sl < 21; sl += 4) {
+      if (-c_xyz_src[sl] - 1 == v) { g[0] += gj21[sl * 3]; g[1] += gj21[sl * 3 + 1]; g[2] += gj21[sl * 3 + 2]; }
+    }
+    float* o = gverts + ((size_t)b * kNV + v) * 3;
+    o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called by the C ABI in hifihr_api.hip)
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_mano_fwd(const ManoDev& t, const float* pose, const float* beta, int B, float* verts, float* jtr,
+                           float* saved, hipStream_t st) {
+  hipLaunchKernelGGL(mano_fwd_kernel, dim3(kFwdTiles, B), dim3(256), 0, st, t, pose, beta, verts, jtr, saved);
+  return hipGetLastError();
+}
+
+hipError_t launch_mano_bwd(const ManoDev& t, const float* pose, const float* beta, const float* saved,
+                           const float* gverts, const float* gjtr, int B, float* gpose, float* gbeta, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mano_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ManoBwdLds));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mano_bwd_kernel, dim3(B), dim3(kBwdThreads), sizeof(ManoBwdLds), st, t, pose, beta, saved,
+                     gverts, gjtr, gpose, gbeta);
+  return hipGetLastError();
+}
+
+hipError_t launch_mano_joints_fwd(const ManoDev& t, const float* verts, int B, int root_id, float* joints_rel,
+                                  float* verts_rel, float* root, hipStream_t st) {
+  hipLaunchKernelGGL(mano_joints_fwd_kernel, dim3(B), dim3(256), 0, st, t, verts, root_id, joints_rel, verts_rel, root);
+  return hipGetLastError();
+}
+
+hipError_t launch_mano_joints_bwd(const ManoDev& t, const float* gjoints_rel, const float* gverts_rel,
+                                  const float* groot, int B, int root_id, float* gverts, hipStream_t st) {
+  hipLaunchKernelGGL(mano_joints_bwd_kernel, dim3(B), dim3(256), 0, st, t, gjoints_rel, gverts_rel, groot, root_id, gverts);
+  return hipGetLastError();
+}
+
+}  // namespace hifihr

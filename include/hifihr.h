@@ -1,0 +1,84 @@
+/*
+ * libhifihr.so -- C ABI of the MI355X-native HiFiHR training hot path.
+ *
+ * The reference (viridityzhu/HiFiHR) has no FFI layer: its hot path is reached through plain Python
+ * call sites.  Every entry point below replaces one of those call sites and
+ * cites it.  Conventions:
+ *   - every function returns 0 on success, a negative HIFIHR_E* code on failure;
+ *     hifihr_last_error() returns a thread-local message.  No exceptions cross the ABI.
+ *   - pointers named *_d are DEVICE pointers (HBM), *_h are HOST pointers; fp32 unless stated.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  No hidden syncs, no
+ *     allocation inside compute calls: the caller owns every buffer; handles own only their tables.
+ *   - handles are immutable after create; compute calls are re-entrant on different streams.
+ */
+#ifndef HIFIHR_H
+#define HIFIHR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIFIHR_OK 0
+#define HIFIHR_EINVAL (-1)   /* bad argument */
+#define HIFIHR_EHIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
+#define HIFIHR_ENOMEM (-3)
+
+#define HIFIHR_MANO_NV 778
+#define HIFIHR_MANO_NF 1538
+#define HIFIHR_MANO_NJ 16
+
+int hifihr_version(void);
+const char* hifihr_last_error(void);
+/* number of HIP devices visible to the library (<=0: the library cannot be used for compute) */
+int hifihr_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * MANO linear-blend skinning.
+ * Replaces ManoLayer.__init__/forward   reference utils/my_mano.py:231-313, 315-483
+ *          (as configured by MyMANOLayer, utils/my_mano.py:35-36: center_idx=9, flat_hand_mean=False,
+ *           side='right', use_pca=True, ncomps=48 => 45 effective PCA coefficients, axis-angle root)
+ *          batch_rodrigues/quat2mat      reference utils/manopth/rodrigues_layer.py:43-54,15-40
+ *          xyz_from_vertice              reference utils/Freihand_GNN_mano/Freihand_trainer_mano_fullsup.py:175-215
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hifihr_mano hifihr_mano_t;
+
+/* Tables are host arrays in the layout ManoLayer registers them (my_mano.py:283-313):
+ * v_template[778][3], shapedirs[778][3][10], posedirs[778][3][135], j_regressor[16][778] (dense),
+ * weights[778][16], hands_components[45][45] (row k = component k), hands_mean[45]. */
+int hifihr_mano_create(hifihr_mano_t** out, const float* v_template_h, const float* shapedirs_h,
+                       const float* posedirs_h, const float* j_regressor_h, const float* weights_h,
+                       const float* hands_components_h, const float* hands_mean_h);
+int hifihr_mano_destroy(hifihr_mano_t* h);
+
+/* ManoLayer.forward(th_pose_coeffs=pose[B][48], th_betas=beta[B][10]) -> th_verts[B][778][3],
+ * th_jtr[B][21][3] (both centred on joint 9; th_trans==0 branch, my_mano.py:471-475).
+ * saved_vposed_d[B][778][3] receives v_posed (my_mano.py:392) for the backward pass; may be NULL when
+ * no backward follows. */
+int hifihr_mano_lbs_fwd(const hifihr_mano_t* h, const float* pose_d, const float* beta_d, int B,
+                        float* verts_d, float* jtr_d, float* saved_vposed_d, void* stream);
+
+/* Gradient of the above: gverts[B][778][3], gjtr[B][21][3] (either may be NULL = zero) ->
+ * gpose[B][48], gbeta[B][10] (overwritten).  Deterministic (no float atomics). */
+int hifihr_mano_lbs_bwd(const hifihr_mano_t* h, const float* pose_d, const float* beta_d,
+                        const float* saved_vposed_d, const float* gverts_d, const float* gjtr_d, int B,
+                        float* gpose_d, float* gbeta_d, void* stream);
+
+/* xyz_from_vertice(verts).permute(1,0,2) followed by the root-relative step of Model.forward
+ * (reference models_res_nimble.py:153,160-166, training branch):
+ *   joints21 = regress(verts); root = joints21[:, root_id]; joints_rel = joints21 - root;
+ *   verts_rel = verts - root.   root_id < 0 skips the subtraction (root_d then receives zeros).
+ * Outputs joints_rel_d[B][21][3], verts_rel_d[B][778][3] (may alias verts_d), root_d[B][3]. */
+int hifihr_mano_joints_fwd(const hifihr_mano_t* h, const float* verts_d, int B, int root_id,
+                           float* joints_rel_d, float* verts_rel_d, float* root_d, void* stream);
+/* Gradient: gjoints_rel[B][21][3], gverts_rel[B][778][3], groot[B][3] (any may be NULL) ->
+ * gverts[B][778][3] (overwritten). */
+int hifihr_mano_joints_bwd(const hifihr_mano_t* h, const float* gjoints_rel_d, const float* gverts_rel_d,
+                           const float* groot_d, int B, int root_id, float* gverts_d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIFIHR_H */

@@ -1,0 +1,145 @@
+// tests/hostsim: a small HIP execution-model emulator (TEST INFRASTRUCTURE ONLY).
+//
+// There is no GPU in the build container, so the kernels in hifihr_amd/csrc/*.hip would otherwise be
+// written blind.  This header stands in for <hip/hip_runtime.h> when those SAME source files are compiled
+// with g++ (see tests/hostsim/Makefile): every workgroup runs as a set of cooperatively scheduled fibers
+// (one per work-item) on one OS thread, __syncthreads() and the 64-wide wave primitives are real
+// rendezvous points, __shared__ is per-worker storage and atomics are real atomics.  It exists to catch
+// indexing, barrier and gradient-formula bugs before GPU time is spent; it is slow, it is never loaded by
+// the hifihr_amd package, it is not an oracle and it is not a fallback.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define HIFIHR_HOSTSIM 1
+#define __global__
+#define __device__
+#define __host__
+#define __constant__ const
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(::hostsim::dyn_smem());
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+
+namespace hostsim {
+struct Fiber;
+struct Ctx {           // what the kernel sees as threadIdx/blockIdx/...
+  dim3 tid, bid, bdim, gdim;
+};
+Ctx& cur();
+char* dyn_smem();
+void syncthreads();
+uint32_t wave_exchange(uint32_t v, int src_lane);                 // value of src_lane (or own if out of range)
+unsigned long long wave_ballot(bool p);
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+int lane_id();
+}  // namespace hostsim
+
+#define threadIdx (::hostsim::cur().tid)
+#define blockIdx (::hostsim::cur().bid)
+#define blockDim (::hostsim::cur().bdim)
+#define gridDim (::hostsim::cur().gdim)
+#define warpSize 64
+
+static inline void __syncthreads() { ::hostsim::syncthreads(); }
+
+template <typename T>
+static inline T hs_shfl_(T v, int src) {
+  static_assert(sizeof(T) == 4, "4-byte shuffles only");
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  u = ::hostsim::wave_exchange(u, src);
+  T r;
+  std::memcpy(&r, &u, 4);
+  return r;
+}
+template <typename T> static inline T __shfl(T v, int src, int w = 64) { return hs_shfl_(v, (::hostsim::lane_id() & ~(w - 1)) + (src & (w - 1))); }
+template <typename T> static inline T __shfl_down(T v, unsigned d, int w = 64) {
+  const int l = ::hostsim::lane_id();
+  const int s = ((l & (w - 1)) + (int)d < w) ? l + (int)d : l;
+  return hs_shfl_(v, s);
+}
+template <typename T> static inline T __shfl_up(T v, unsigned d, int w = 64) {
+  const int l = ::hostsim::lane_id();
+  const int s = ((l & (w - 1)) >= (int)d) ? l - (int)d : l;
+  return hs_shfl_(v, s);
+}
+template <typename T> static inline T __shfl_xor(T v, int m, int w = 64) { return hs_shfl_(v, ::hostsim::lane_id() ^ m); }
+static inline unsigned long long __ballot(int p) { return ::hostsim::wave_ballot(p != 0); }
+static inline int __any(int p) { return __ballot(p) != 0ull; }
+static inline int __all(int p) { return ::hostsim::wave_ballot(p == 0) == 0ull; }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+
+static inline float atomicAdd(float* p, float v) {
+  uint32_t* ip = reinterpret_cast<uint32_t*>(p);
+  uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), nw;
+  float f;
+  do {
+    std::memcpy(&f, &old, 4);
+    f += v;
+    std::memcpy(&nw, &f, 4);
+  } while (!__atomic_compare_exchange_n(ip, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  std::memcpy(&f, &old, 4);
+  return f;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline int atomicMax(int* p, int v) {
+  int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+static inline int atomicMin(int* p, int v) {
+  int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __fdividef(float a, float b) { return a / b; }
+#define __expf expf
+#define __powf powf
+static inline float __saturatef(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); }
+
+// ---- runtime API subset (host memory plays device memory) ----
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hostsim error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
+  ::hostsim::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
