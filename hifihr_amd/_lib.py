@@ -72,7 +72,16 @@ class HifihrLib:
         self._bind_optional()
 
     def _bind_optional(self):
-        pass
+        c = self.c
+        c.hifihr_renderer_create.argtypes = [POINTER(c_void_p), _c_int_p, c_int, c_int, c_int, c_int, _c_float_p, _c_float_p,
+                                             _c_float_p, c_float, _c_float_p]
+        c.hifihr_renderer_destroy.argtypes = [c_void_p]
+        c.hifihr_render_workspace_bytes.argtypes = [c_void_p, c_int]
+        c.hifihr_render_workspace_bytes.restype = c_size_t
+        c.hifihr_render_fwd.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, _c_float_p, _c_float_p, _c_float_p, c_int,
+                                        _c_float_p, _c_int_p, c_void_p, c_void_p]
+        c.hifihr_render_bwd.argtypes = [c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_int_p, _c_float_p, c_int,
+                                        _c_float_p, _c_float_p, _c_float_p, _c_float_p, c_void_p, c_void_p]
 
     # ------------------------------------------------------------------
     def check(self, rc: int, what: str):
@@ -110,6 +119,38 @@ class HifihrLib:
         B = gverts.shape[0]
         self.check(self.c.hifihr_mano_joints_bwd(h, _fp(gjoints_rel), _fp(gverts_rel), _fp(groot), B, root_id,
                                                  _fp(gverts), _stream_of(gverts)), "hifihr_mano_joints_bwd")
+
+
+    # ---- renderer ----------------------------------------------------
+    def renderer_create(self, faces, V, image_size=224, aa=3, ambient=(0.5, 0.5, 0.5), mat_diffuse=(0.8, 0.8, 0.8),
+                        specular=(0.04, 0.04, 0.04), shininess=30.0, background=(1.0, 1.0, 1.0)) -> c_void_p:
+        import numpy as np
+        f = np.ascontiguousarray(faces, dtype=np.int32)
+        h = c_void_p()
+        a, m, s, b = (_np_fp(x) for x in (ambient, mat_diffuse, specular, background))
+        self.check(self.c.hifihr_renderer_create(ctypes.byref(h), f.ctypes.data_as(_c_int_p), int(V), int(f.shape[0]),
+                                                 int(image_size), int(aa), a[1], m[1], s[1], c_float(shininess), b[1]),
+                   "hifihr_renderer_create")
+        return h
+
+    def renderer_destroy(self, h):
+        self.c.hifihr_renderer_destroy(h)
+
+    def render_workspace_bytes(self, h, B) -> int:
+        return int(self.c.hifihr_render_workspace_bytes(h, int(B)))
+
+    def render_fwd(self, h, verts, vcolors, cam, light_color, light_dir, rgba, face_id, ws):
+        B = verts.shape[0]
+        batched = 1 if vcolors.dim() == 3 else 0
+        self.check(self.c.hifihr_render_fwd(h, _fp(verts), _fp(vcolors), batched, _fp(cam), _fp(light_color), _fp(light_dir), B,
+                                            _fp(rgba), _ip(face_id), c_void_p(ws.data_ptr()), _stream_of(verts)),
+                   "hifihr_render_fwd")
+
+    def render_bwd(self, h, verts, cam, light_color, light_dir, face_id, grad_rgba, gverts, gvcolors, glc, gld, ws):
+        B = verts.shape[0]
+        self.check(self.c.hifihr_render_bwd(h, _fp(verts), _fp(cam), _fp(light_color), _fp(light_dir), _ip(face_id),
+                                            _fp(grad_rgba), B, _fp(gverts), _fp(gvcolors), _fp(glc), _fp(gld),
+                                            c_void_p(ws.data_ptr()), _stream_of(verts)), "hifihr_render_bwd")
 
 
 _LIB = None

@@ -50,6 +50,19 @@ struct hifihr_mano {
   hifihr::ManoDev dev;
 };
 
+struct hifihr_renderer {
+  DevBuf faces, vf_off, vf_idx;
+  hifihr::RenderDev dev;
+};
+
+namespace {
+int upload_i(DevBuf& b, const std::vector<int>& h) {
+  HIP_TRY(hipMalloc(&b.p, (h.size() ? h.size() : 1) * sizeof(int)));
+  HIP_TRY(hipMemcpy(b.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  return HIFIHR_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int hifihr_version(void) { return 1; }
@@ -145,6 +158,72 @@ int hifihr_mano_joints_bwd(const hifihr_mano_t* h, const float* gjoints_rel, con
   if (!h || !gverts || B < 0 || root_id >= 21) return fail(HIFIHR_EINVAL, "hifihr_mano_joints_bwd: bad argument");
   if (B == 0) return HIFIHR_OK;
   HIP_TRY(hifihr::launch_mano_joints_bwd(h->dev, gjoints_rel, gverts_rel, groot, B, root_id, gverts, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_renderer_create(hifihr_renderer_t** out, const int32_t* faces, int V, int F, int image_size, int aa,
+                           const float* ambient3, const float* mat_diffuse3, const float* specular3, float shininess,
+                           const float* background3) {
+  if (!out || !faces || V <= 0 || F <= 0 || image_size <= 0 || aa < 1 || aa > 3 || !ambient3 || !mat_diffuse3 || !specular3 ||
+      !background3)
+    return fail(HIFIHR_EINVAL, "hifihr_renderer_create: bad argument");
+  std::vector<int> fv(faces, faces + (size_t)F * 3), off(V + 1, 0), idx((size_t)F * 3);
+  for (int i = 0; i < F * 3; ++i) {
+    if (fv[i] < 0 || fv[i] >= V) return fail(HIFIHR_EINVAL, "hifihr_renderer_create: face index out of range");
+    off[fv[i] + 1]++;
+  }
+  for (int v = 0; v < V; ++v) off[v + 1] += off[v];
+  std::vector<int> cur(off.begin(), off.end() - 1);
+  for (int f = 0; f < F; ++f)            // incident faces in ascending face order => deterministic normal sums
+    for (int k = 0; k < 3; ++k) idx[cur[fv[3 * f + k]]++] = f * 4 + k;
+  hifihr_renderer* h = new (std::nothrow) hifihr_renderer();
+  if (!h) return fail(HIFIHR_ENOMEM, "hifihr_renderer_create: out of host memory");
+  int rc;
+  if ((rc = upload_i(h->faces, fv)) || (rc = upload_i(h->vf_off, off)) || (rc = upload_i(h->vf_idx, idx))) {
+    delete h;
+    return rc;
+  }
+  hifihr::RenderDev& d = h->dev;
+  d.V = V; d.F = F; d.H = image_size; d.aa = aa;
+  d.faces = (const int*)h->faces.p; d.vf_off = (const int*)h->vf_off.p; d.vf_idx = (const int*)h->vf_idx.p;
+  for (int k = 0; k < 3; ++k) {
+    d.sc.amb[k] = ambient3[k]; d.sc.mdiff[k] = mat_diffuse3[k]; d.sc.spec[k] = specular3[k]; d.bg[k] = background3[k];
+  }
+  d.sc.shininess = shininess;
+  *out = h;
+  return HIFIHR_OK;
+}
+
+int hifihr_renderer_destroy(hifihr_renderer_t* h) {
+  delete h;
+  return HIFIHR_OK;
+}
+
+size_t hifihr_render_workspace_bytes(const hifihr_renderer_t* h, int B) {
+  if (!h || B < 0) return 0;
+  return hifihr::render_workspace_bytes(h->dev, B);
+}
+
+int hifihr_render_fwd(const hifihr_renderer_t* h, const float* verts, const float* vcolors, int vcolors_batched, const float* cam,
+                      const float* light_color, const float* light_dir, int B, float* rgba, int32_t* face_id, void* ws,
+                      void* stream) {
+  if (!h || !verts || !vcolors || !cam || !light_color || !light_dir || !rgba || !face_id || !ws || B < 0)
+    return fail(HIFIHR_EINVAL, "hifihr_render_fwd: bad argument");
+  if (B == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_render_fwd(h->dev, verts, vcolors, vcolors_batched ? (long)h->dev.V * 3 : 0L, cam, light_color,
+                                    light_dir, B, rgba, face_id, ws, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_render_bwd(const hifihr_renderer_t* h, const float* verts, const float* cam, const float* light_color,
+                      const float* light_dir, const int32_t* face_id, const float* grad_rgba, int B, float* gverts,
+                      float* gvcolors, float* glight_color, float* glight_dir, void* ws, void* stream) {
+  if (!h || !verts || !cam || !light_color || !light_dir || !face_id || !grad_rgba || !gverts || !glight_color || !glight_dir ||
+      !ws || B < 0)
+    return fail(HIFIHR_EINVAL, "hifihr_render_bwd: bad argument");
+  if (B == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_render_bwd(h->dev, verts, cam, light_color, light_dir, face_id, grad_rgba, B, gverts, gvcolors,
+                                    glight_color, glight_dir, ws, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "render_math.h"
+
 namespace hifihr {
 
 constexpr int kNVP = 800;   // padded vertex count of the SoA MANO tables (rows are 16-byte aligned)
@@ -29,5 +31,23 @@ hipError_t launch_mano_joints_fwd(const ManoDev& t, const float* verts, int B, i
                                   float* verts_rel, float* root, hipStream_t st);
 hipError_t launch_mano_joints_bwd(const ManoDev& t, const float* gjoints_rel, const float* gverts_rel,
                                   const float* groot, int B, int root_id, float* gverts, hipStream_t st);
+
+// Renderer handle contents (device pointers + constants); passed to kernels by value.
+struct RenderDev {
+  int V, F, H, aa;
+  const int* faces;    // [F][3]
+  const int* vf_off;   // [V+1]   CSR vertex -> incident faces
+  const int* vf_idx;   // [3F]    face * 4 + role (0,1,2 = which corner of the face the vertex is)
+  ShadeConsts sc;
+  float bg[3];
+};
+
+size_t render_workspace_bytes(const RenderDev& r, int B);
+hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float* vcolors, long vcol_bstride, const float* cam,
+                             const float* light_color, const float* light_dir, int B, float* rgba, int* face_id, void* ws,
+                             hipStream_t st);
+hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float* cam, const float* light_color,
+                             const float* light_dir, const int* face_id, const float* grad_rgba, int B, float* gverts,
+                             float* gvcolors, float* glight_color, float* glight_dir, void* ws, hipStream_t st);
 
 }  // namespace hifihr

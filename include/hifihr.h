@@ -78,6 +78,46 @@ int hifihr_mano_joints_fwd(const hifihr_mano_t* h, const float* verts_d, int B, 
 int hifihr_mano_joints_bwd(const hifihr_mano_t* h, const float* gjoints_rel_d, const float* gverts_rel_d,
                            const float* groot_d, int B, int root_id, float* gverts_d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Hard rasteriser + Phong shader + anti-aliasing resolve.
+ * Replaces  rendered = self.renderer_p3d(skin_meshes, cameras=cameras, lights=lighting)
+ *           rendered = F.avg_pool2d(rendered.permute(0,3,1,2), aa, aa)      reference models_res_nimble.py:208-211
+ * with the renderer built as in models_res_nimble.py:70-96 (MeshRasterizer(image_size*aa, blur 0, 1 face per
+ * pixel) + HardPhongShader) and cameras/lights as in :184-190.  PyTorch3D semantics are restated in
+ * oracle/raster_oracle.c and oracle/render_oracle.py (parity unpinned at that third-party boundary).
+ * Meshes share one topology (faces) across the batch, as MyMANOLayer/MyNIMBLELayer produce them.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hifihr_renderer hifihr_renderer_t;
+
+/* faces_h[F][3] int32 (host); image_size = output edge H (224), aa = samples per pixel edge (3; 1..3 supported);
+ * ambient3 = materials.ambient * lights.ambient, mat_diffuse3 = materials.diffuse,
+ * specular3 = materials.specular * lights.specular, background3 = BlendParams.background_color. */
+int hifihr_renderer_create(hifihr_renderer_t** out, const int32_t* faces_h, int V, int F, int image_size, int aa,
+                           const float* ambient3, const float* mat_diffuse3, const float* specular3, float shininess,
+                           const float* background3);
+int hifihr_renderer_destroy(hifihr_renderer_t* h);
+/* bytes of scratch the caller must pass to render_fwd/bwd for batch B; the SAME buffer, untouched in between,
+ * must be passed to the backward call of a forward call (it carries the packed per-vertex records). */
+size_t hifihr_render_workspace_bytes(const hifihr_renderer_t* h, int B);
+
+/* verts_d[B][V][3] view-space vertices (R = I, T = 0); vcolors_d per-vertex RGB ([B][V][3] when vcolors_batched,
+ * else [V][3] shared); cam_d[B][4] = (fx, fy, px, py) exactly as handed to PerspectiveCameras (i.e. the
+ * NEGATED ndc focal lengths, models_res_nimble.py:184-186); light_color_d[B][3] = DirectionalLights.diffuse_color,
+ * light_dir_d[B][3] = DirectionalLights.direction (un-normalised).
+ * Outputs: rgba_d[B][4][H][H] (NCHW, after the aa x aa average pool; channel 3 = coverage),
+ *          face_id_d[B][H*aa][H*aa] int32 = pix_to_face minus the b*F packing offset (-1 = background). */
+int hifihr_render_fwd(const hifihr_renderer_t* h, const float* verts_d, const float* vcolors_d, int vcolors_batched,
+                      const float* cam_d, const float* light_color_d, const float* light_dir_d, int B, float* rgba_d,
+                      int32_t* face_id_d, void* workspace_d, void* stream);
+
+/* grad_rgba_d[B][4][H][H] (the coverage channel carries no gradient, as in the reference: SURVEY.md F7) ->
+ * gverts_d[B][V][3], gvcolors_d[B][V][3] (may be NULL), glight_color_d[B][3], glight_dir_d[B][3]; all overwritten.
+ * Uses float atomics: results are reproducible to rounding, not bitwise. */
+int hifihr_render_bwd(const hifihr_renderer_t* h, const float* verts_d, const float* cam_d, const float* light_color_d,
+                      const float* light_dir_d, const int32_t* face_id_d, const float* grad_rgba_d, int B,
+                      float* gverts_d, float* gvcolors_d, float* glight_color_d, float* glight_dir_d, void* workspace_d,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,6 +121,10 @@ static inline int atomicMin(int* p, int v) {
   return old;
 }
 
+static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __expf expf

@@ -89,3 +89,66 @@ def mano_joints_case(lib, tables, device, B, seed, root_id=9):
         np.testing.assert_allclose(gv.cpu().numpy(), verts.grad.numpy(), atol=2e-4, rtol=1e-4)
     finally:
         lib.mano_destroy(h)
+
+
+# ------------------------------------------------------------------------------------------------
+# renderer
+# ------------------------------------------------------------------------------------------------
+def make_render_inputs(tables, B, seed, image_size, z=0.6):
+    """Posed synthetic hands in front of a FreiHAND-like camera (scaled to `image_size`)."""
+    from oracle import render_oracle as ro
+    gen = torch.Generator().manual_seed(seed)
+    pose = 0.4 * torch.randn(B, 48, generator=gen)
+    pose[:, :3] = torch.randn(B, 3, generator=gen)             # arbitrary global orientation
+    beta = 0.5 * torch.randn(B, 10, generator=gen)
+    verts, _, _ = mo.mano_forward(tables, pose, beta)
+    root = torch.stack([0.05 * (torch.rand(B, generator=gen) - 0.5), 0.05 * (torch.rand(B, generator=gen) - 0.5),
+                        z + 0.2 * torch.rand(B, generator=gen)], dim=1)
+    verts = (verts + root.unsqueeze(1)).detach()
+    f = 450.0 + 200.0 * torch.rand(B, generator=gen)
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0] = f; K[:, 1, 1] = f; K[:, 2, 2] = 1
+    K[:, 0, 2] = 112 + 20 * (torch.rand(B, generator=gen) - 0.5)
+    K[:, 1, 2] = 112 + 20 * (torch.rand(B, generator=gen) - 0.5)
+    cam = ro.ndc_camera_from_K(K)                             # NDC camera: independent of the raster size
+    vcol = 0.3 + 0.6 * torch.rand(B, 778, 3, generator=gen)
+    lc = torch.rand(B, 3, generator=gen) * 1.6 - 0.6           # hardtanh range [-1,1]
+    ld = torch.randn(B, 3, generator=gen)
+    return verts, vcol, cam, lc, ld
+
+
+def render_case(lib, tables, device, B, seed, image_size, aa, check_grad=True, rgb_atol=2e-5, gtol=2e-3):
+    from oracle import render_oracle as ro
+    verts, vcol, cam, lc, ld = make_render_inputs(tables, B, seed, image_size)
+    faces = torch.as_tensor(tables.faces).long()
+    vr, cr, lcr, ldr = (t.clone().requires_grad_(True) for t in (verts, vcol, lc, ld))
+    rgba_ref, p2f_ref = ro.render(vr, cr, cam, lcr, ldr, faces, image_size=image_size, aa=aa)
+    S = image_size * aa
+    h = lib.renderer_create(tables.faces, 778, image_size=image_size, aa=aa)
+    try:
+        ws = torch.empty(lib.render_workspace_bytes(h, B), dtype=torch.uint8, device=device)
+        d = lambda t: t.to(device).contiguous()
+        rgba = torch.empty(B, 4, image_size, image_size, device=device)
+        fid = torch.empty(B, S, S, dtype=torch.int32, device=device)
+        dv, dc, dcam, dlc, dld = d(verts), d(vcol), d(cam), d(lc), d(ld)
+        lib.render_fwd(h, dv, dc, dcam, dlc, dld, rgba, fid, ws)
+        fid_np = fid.cpu().numpy()
+        assert (p2f_ref >= 0).mean() > 0.02, "test mesh barely visible"
+        np.testing.assert_array_equal(fid_np, p2f_ref)             # bit-exact face indices
+        np.testing.assert_allclose(rgba.cpu().numpy(), rgba_ref.detach().numpy(), atol=rgb_atol, rtol=0)
+        if not check_grad:
+            return
+        gen = torch.Generator().manual_seed(seed + 1)
+        w = torch.randn(B, 4, image_size, image_size, generator=gen)
+        (rgba_ref * w).sum().backward()
+        gv = torch.empty(B, 778, 3, device=device); gc = torch.empty(B, 778, 3, device=device)
+        glc = torch.empty(B, 3, device=device); gld = torch.empty(B, 3, device=device)
+        lib.render_bwd(h, dv, dcam, dlc, dld, fid, d(w), gv, gc, glc, gld, ws)
+        for name, got, ref in (("verts", gv, vr.grad), ("vcolors", gc, cr.grad), ("light_color", glc, lcr.grad),
+                               ("light_dir", gld, ldr.grad)):
+            ref = ref.numpy()
+            scale = np.abs(ref).max() + 1e-12
+            err = np.abs(got.cpu().numpy() - ref).max() / scale
+            assert err < gtol, f"grad {name}: max err / max |ref| = {err:.3e} (scale {scale:.3e})"
+    finally:
+        lib.renderer_destroy(h)

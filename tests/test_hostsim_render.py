@@ -1,0 +1,15 @@
+"""Runs the renderer HIP kernel SOURCES on the CPU through tests/hostsim and checks them against
+oracle/raster_oracle.c (face indices, bit-exact) and oracle/render_oracle.py (pixels, gradients)."""
+import pytest
+
+import kernel_cases as kc
+
+
+@pytest.fixture(scope="module")
+def hostsim_lib():
+    return kc.build_hostsim()
+
+
+@pytest.mark.parametrize("image_size,aa", [(32, 3), (40, 2), (24, 1)])
+def test_render_fwd_bwd(hostsim_lib, synth_tables, image_size, aa):
+    kc.render_case(hostsim_lib, synth_tables, "cpu", B=2, seed=10 + aa, image_size=image_size, aa=aa)
