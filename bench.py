@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training-step images/sec on FreiHAND-shaped 224x224 batches (BASELINE.json configs[1]:
+batch 32 per GPU, ResNet-18 encoder + MANO LBS + render + silhouette/texture losses), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the dominant hand-written
+kernel and, at N=1, `cpu_baseline` (the oracle step timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2, help="sample size of the CPU baseline (images)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args_ns, examples, tables, nimg):
+    """The oracle training step (oracle/model_oracle.py) on the host cores, on `nimg` images of the same batch."""
+    from oracle.model_oracle import OracleModel, oracle_step
+    torch.manual_seed(0)
+    model = OracleModel(tables).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-6)
+    ex = {k: (v[:nimg].detach().cpu() if torch.is_tensor(v) else v) for k, v in examples.items()}
+    t0 = time.time()
+    oracle_step(model, ex, args_ns, opt)
+    dt = time.time() - t0
+    return {"value": nimg / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"one oracle training step (torch-CPU encoder + C/torch oracle MANO/render/losses + Adam) on {nimg} "
+                      f"images of the same synthetic batch, {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    from hifihr_amd import dist as hdist, ops, options, synth
+    from hifihr_amd.losses import LossFunction
+    from hifihr_amd.mano_tables import synthetic_mano_tables
+    from hifihr_amd.models import Model
+    from hifihr_amd.optim import FlatParams, FusedAdam
+    from hifihr_amd.traineval import data_dic, train_step
+
+    rank, local_rank, world = hdist.init_process_group_from_env()
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP hot path has no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    args_ns = options.baseline_config2_args(train_batch=a.batch)
+    tables = synthetic_mano_tables(0)
+    torch.manual_seed(0)
+    model = Model(ifRender=True, device=dev, if_4c=False, hand_model="mano", use_mean_shape=False, pretrain="res18",
+                  mano_tables=tables).to(dev).train()
+    flat = FlatParams(model)
+    hdist.broadcast_params(flat)
+    reducer = hdist.GradReducer(flat, num_buckets=4)
+    lr = args_ns.force_init_lr if args_ns.force_init_lr > 0 else args_ns.init_lr
+    opt = FusedAdam(flat, lr=lr, betas=(0.9, 0.999), grad_scale=reducer.grad_scale)
+    loss_func = LossFunction()
+
+    # rank r owns samples [r*B, (r+1)*B) of the global batch; inputs are resident in HBM before timing starts
+    sample = synth.make_batch(model.hand_layer.handle, model.renderer_p3d, a.batch, first_index=rank * a.batch, device=dev)
+    examples = data_dic(sample, "FreiHand", "training", args_ns, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        return train_step(model, loss_func, opt, examples, args_ns, backward_hook=reducer.finish)
+
+    for _ in range(a.warmup):
+        step()
+    ops.PROFILE.enable()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, loss_dic = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ops.PROFILE.disable()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern = ops.PROFILE.summary()                       # {name: (avg_us, launches)}
+
+    if rank == 0:
+        B = a.batch
+        ms = dt / a.steps * 1e3
+        out = {
+            "metric": "train images/sec, FreiHAND 224x224 (ResNet-18 + MANO LBS + render + losses + Adam)",
+            "value": world * B * a.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (FreiHAND-shaped, seeded; synthetic MANO-shaped tables; random-init weights)",
+            "config": {"workload": "BASELINE configs[1]: FreiHAND batch=32/GPU, ResNet-18 encoder + MANO LBS + "
+                                   "silhouette/texture render losses, 224x224, aa=3 (672^2 samples)",
+                       "per_gpu_batch": B, "global_batch": world * B, "losses": args_ns.losses, "parallelism": f"dp{world}"},
+            "loss": float(loss.detach()),
+        }
+        # roofline of the dominant hand-written kernel: the fused rasterise+shade+resolve forward.
+        # algorithmic bytes per image (SURVEY.md 8d / DESIGN.md): verts 778*12 + faces 1538*12 + attrs 778*24 +
+        # RGBA 224^2*16 + face-id side buffer 672^2*4
+        alg = 778 * 12 + 1538 * 12 + 778 * 24 + 224 * 224 * 16 + 672 * 672 * 4
+        if "render_fwd" in kern:
+            us = kern["render_fwd"][0]
+            ach = alg * B / (us * 1e-6) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                               "traffic": None, "kernel": "render_fwd_kernel<3> (+ render_vertex_kernel)",
+                               "avg_us": us, "algorithmic_bytes_per_launch": alg * B}
+        out["kernels_avg_us"] = {k: round(v[0], 2) for k, v in kern.items()}
+        out["render_ms_per_frame"] = {"fwd": kern.get("render_fwd", (0,))[0] / B / 1e3,
+                                      "fwd+bwd": (kern.get("render_fwd", (0,))[0] + kern.get("render_bwd", (0,))[0]) / B / 1e3}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args_ns, examples, tables, a.cpu_batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

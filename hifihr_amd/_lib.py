@@ -75,6 +75,8 @@ class HifihrLib:
         c = self.c
         c.hifihr_renderer_create.argtypes = [POINTER(c_void_p), _c_int_p, c_int, c_int, c_int, c_int, _c_float_p, _c_float_p,
                                              _c_float_p, c_float, _c_float_p]
+        c.hifihr_adam_step.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
+                                       c_float, c_float, c_float, c_int, c_void_p]
         c.hifihr_renderer_destroy.argtypes = [c_void_p]
         c.hifihr_render_workspace_bytes.argtypes = [c_void_p, c_int]
         c.hifihr_render_workspace_bytes.restype = c_size_t
@@ -120,6 +122,14 @@ class HifihrLib:
         self.check(self.c.hifihr_mano_joints_bwd(h, _fp(gjoints_rel), _fp(gverts_rel), _fp(groot), B, root_id,
                                                  _fp(gverts), _stream_of(gverts)), "hifihr_mano_joints_bwd")
 
+
+    # ---- optimizer ---------------------------------------------------
+    def adam_step(self, p, g, m, v, grad_scale, lr, beta1, beta2, eps, weight_decay, step):
+        n = p.numel()
+        assert g.numel() == n and m.numel() == n and v.numel() == n
+        self.check(self.c.hifihr_adam_step(_fp(p), _fp(g), _fp(m), _fp(v), c_size_t(n), c_float(grad_scale), c_float(lr),
+                                           c_float(beta1), c_float(beta2), c_float(eps), c_float(weight_decay), int(step),
+                                           _stream_of(p)), "hifihr_adam_step")
 
     # ---- renderer ----------------------------------------------------
     def renderer_create(self, faces, V, image_size=224, aa=3, ambient=(0.5, 0.5, 0.5), mat_diffuse=(0.8, 0.8, 0.8),

@@ -227,4 +227,15 @@ int hifihr_render_bwd(const hifihr_renderer_t* h, const float* verts, const floa
   return HIFIHR_OK;
 }
 
+int hifihr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float grad_scale,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || step < 1) return fail(HIFIHR_EINVAL, "hifihr_adam_step: bad argument");
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
+    return fail(HIFIHR_EINVAL, "hifihr_adam_step: buffers must be 16-byte aligned");
+  if (n == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_adam(params, grads, exp_avg, exp_avg_sq, n, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
+                              (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 }  // extern "C"

@@ -50,4 +50,7 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
                              const float* light_dir, const int* face_id, const float* grad_rgba, int B, float* gverts,
                              float* gvcolors, float* glight_color, float* glight_dir, void* ws, hipStream_t st);
 
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int step, hipStream_t st);
+
 }  // namespace hifihr

@@ -1,0 +1,125 @@
+"""`LossFunction` with the reference's call signature, loss names and formulas
+(reference losses.py:226-453; helpers utils/losses_util.py:217-301,366-378; utils/pytorch_ssim:17-37).
+
+Round-1 status: the terms are evaluated with torch ops on the GPU; the image-sized ones (texture / mrgb /
+ssim_tex) are the next candidates for fused HIP kernels.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+# bones of the 21-joint FreiHAND skeleton, (parent, child) per row of mat_20_21 (utils/losses_util.py:226-245)
+_BONES = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 5), (5, 6), (6, 7), (7, 8), (0, 9), (9, 10), (10, 11), (11, 12),
+          (0, 13), (13, 14), (14, 15), (15, 16), (0, 17), (17, 18), (18, 19), (19, 20)]
+
+
+def bone_direction_loss(j, j_gt, conf=None):
+    """utils/losses_util.py:217-283 with confidence 1 (as both call sites in losses.py:269-282 pass)."""
+    p = torch.tensor([b[0] for b in _BONES], device=j.device)
+    c = torch.tensor([b[1] for b in _BONES], device=j.device)
+    v = j[:, c] - j[:, p]
+    vg = j_gt[:, c] - j_gt[:, p]
+    vn = v / (torch.sqrt((v ** 2).sum(-1, keepdim=True)) + 1e-4)
+    vgn = vg / (torch.sqrt((vg ** 2).sum(-1, keepdim=True)) + 1e-4)
+    return ((vn - vgn) ** 2).sum(-1).mean()
+
+
+def edge_length_loss(pred, gt, face):
+    """utils/losses_util.py:285-301."""
+    f = face[0].long()
+    def lens(x):
+        a, b, c = x[:, f[:, 0]], x[:, f[:, 1]], x[:, f[:, 2]]
+        return torch.cat([torch.sqrt(((a - b) ** 2).sum(2, keepdim=True)), torch.sqrt(((a - c) ** 2).sum(2, keepdim=True)),
+                          torch.sqrt(((b - c) ** 2).sum(2, keepdim=True))], 1)
+    return torch.abs(lens(pred) - lens(gt)).mean()
+
+
+def iou(s_gt, s_est):
+    """utils/losses_util.py:366-378."""
+    b = s_gt.shape[0]
+    mul = (s_gt * s_est).reshape(b, -1).sum(1)
+    add = (s_gt + s_est).reshape(b, -1).sum(1)
+    return 1 - torch.mean(mul / (add - mul))
+
+
+_WINDOWS = {}
+
+
+def _window(channel, device, dtype, size=11, sigma=1.5):
+    key = (channel, str(device), dtype)
+    if key not in _WINDOWS:
+        g = torch.tensor([math.exp(-(x - size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(size)])
+        g = (g / g.sum()).unsqueeze(1)
+        w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+        _WINDOWS[key] = w2.expand(channel, 1, size, size).contiguous().to(device=device, dtype=dtype)
+    return _WINDOWS[key]
+
+
+def ssim(img1, img2, window_size=11):
+    """utils/pytorch_ssim/__init__.py:17-37,65-73."""
+    ch = img1.shape[1]
+    w = _window(ch, img1.device, img1.dtype, window_size)
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, w, padding=pad, groups=ch)
+    mu2 = F.conv2d(img2, w, padding=pad, groups=ch)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = F.conv2d(img1 * img1, w, padding=pad, groups=ch) - mu1_sq
+    s2 = F.conv2d(img2 * img2, w, padding=pad, groups=ch) - mu2_sq
+    s12 = F.conv2d(img1 * img2, w, padding=pad, groups=ch) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()
+
+
+class LossFunction:
+    def __init__(self, perceptual=None):
+        self.perceptual_loss = perceptual            # VGG19 weights are not available offline
+
+    def __call__(self, examples, outputs, loss_used, dat_name, args) -> dict:
+        loss_dic = {}
+        base = F.l1_loss if args.base_loss_fn == "L1" else F.mse_loss
+        if "joint_2d" in loss_used:
+            loss_dic["joint_2d"] = args.lambda_j2d_gt * base(examples["j2d_gt"], outputs["j2d"])
+        if "joint_3d" in loss_used:
+            loss_dic["joint_3d"] = args.lambda_j3d * base(outputs["joints"], examples["joints"])
+        if "vert_3d" in loss_used:
+            loss_dic["vert_3d"] = args.lambda_vert_3d * base(outputs["mano_verts"], examples["verts"])
+        if "bone_direc" in loss_used:
+            loss_dic["bone_direc"] = args.lambda_bone_direc * bone_direction_loss(outputs["j2d"], examples["j2d_gt"])
+        if "bone_direc_3d" in loss_used:
+            loss_dic["bone_direc_3d"] = args.lambda_bone_direc_3d * bone_direction_loss(outputs["joints"], examples["joints"])
+        if "edge_length" in loss_used:
+            loss_dic["edge_length"] = args.lambda_edge_len * edge_length_loss(outputs["mano_verts"], examples["verts"], outputs["mano_faces"])
+        if "mscale" in loss_used:
+            bl = torch.sqrt(torch.sum((outputs["joints"][:, 9] - outputs["joints"][:, 10]) ** 2, 1))
+            loss_dic["mscale"] = args.lambda_mscale * F.l1_loss(bl, torch.ones_like(bl) * 0.0282)
+        if "scale" in loss_used and dat_name in ("FreiHand", "RHD"):
+            bl = torch.sqrt(torch.sum((outputs["joints"][:, 9] - outputs["joints"][:, 10]) ** 2, 1))
+            loss_dic["scale"] = args.lambda_scale * F.mse_loss(bl, examples["scales"].to(bl.device))
+        if "re_img" in outputs and "re_sil" in outputs:
+            # photometric block, computed whenever a render exists (losses.py:355-378)
+            seg = examples["segms_gt"].unsqueeze(1).to(outputs["re_img"].dtype)
+            mask_rgbs = seg * examples["imgs"]
+            re_img = outputs["re_img"] * (outputs["re_sil"] / 255.0)
+            loss_dic["texture"] = args.lambda_texture * F.l1_loss(re_img, mask_rgbs)
+            loss_dic["mrgb"] = args.lambda_mrgb * F.mse_loss(torch.mean(mask_rgbs), torch.mean(re_img))
+            loss_dic["ssim_tex"] = args.lambda_ssim_tex * (1 - ssim(re_img, mask_rgbs))
+        if "perceptual" in loss_used:
+            if self.perceptual_loss is None:
+                raise NotImplementedError("perceptual loss needs VGG19 weights, which are not available offline")
+            seg = examples["segms_gt"].unsqueeze(1)
+            loss_dic["perceptual"] = args.lambda_percep * self.perceptual_loss(
+                outputs["re_img"] * seg + examples["imgs"] * (1 - seg), examples["imgs"])
+        if "sil" in loss_used:
+            loss_dic["sil"] = args.lambda_silhouette * F.l1_loss(outputs["re_sil"], examples["segms_gt"].unsqueeze(1).float())
+        if "iou" in loss_used:
+            loss_dic["iou"] = args.lambda_iou * iou(outputs["re_sil"], examples["segms_gt"].unsqueeze(1).float())
+        if "mshape" in loss_used:
+            loss_dic["mshape"] = args.lambda_shape * F.mse_loss(outputs["shape_params"], torch.zeros_like(outputs["shape_params"]))
+        if "mpose" in loss_used:
+            loss_dic["mpose"] = args.lambda_pose * F.mse_loss(outputs["pose_params"], torch.zeros_like(outputs["pose_params"]))
+        if "mtex" in loss_used and outputs.get("texture_params") is not None:
+            loss_dic["mtex"] = args.lambda_tex_reg * F.mse_loss(outputs["texture_params"], torch.zeros_like(outputs["texture_params"]))
+        return loss_dic

@@ -1,0 +1,97 @@
+"""`Model` with the reference's constructor signature, forward signature and output-dict keys
+(reference models_res_nimble.py:32-225), assembled from this package's HIP ops.
+
+hand_model == 'mano' with render=True is a composition the reference cannot run (MyMANOLayer
+builds a Meshes without textures); this build defines it with a constant per-vertex skin colour as the
+TexturesVertex stand-in.  hand_model == 'nimble' needs the un-vendored NIMBLE submodule + assets and is
+not built ("parity unpinned").
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .mano_tables import ManoTables, synthetic_mano_tables
+from .network import HandEncoder, LightEstimator, ResEncoder
+
+SKIN_TONE = (0.78, 0.60, 0.50)
+
+
+class MyMANOLayer(nn.Module):
+    """reference utils/my_mano.py:22-54.  Returns mano_verts (and the face table instead of a pytorch3d Meshes)."""
+
+    def __init__(self, ifRender, device, shape_ncomp=10, pose_ncomp=48, tex_ncomp=None, tables: ManoTables | None = None):
+        super().__init__()
+        self.tables = tables if tables is not None else synthetic_mano_tables(0)
+        self.handle = ops.ManoLayerHandle(self.tables)
+        self.register_buffer("mesh_face", torch.as_tensor(self.tables.faces, dtype=torch.int32).unsqueeze(0), persistent=False)
+
+    def forward(self, hand_params, handle_collision=True):
+        verts, _ = ops.mano_lbs(self.handle, hand_params["pose_params"], hand_params["shape_params"])
+        return {"mano_verts": verts, "skin_verts": verts}
+
+
+class Model(nn.Module):
+    def __init__(self, ifRender, device, if_4c, hand_model, use_mean_shape, pretrain, root_id=9, root_id_nimble=11,
+                 ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3):
+        super().__init__()
+        if hand_model != "mano":
+            raise NotImplementedError(f"hand_model='{hand_model}': only 'mano' is built (NIMBLE assets are not available)")
+        self.hand_model, self.root_id, self.root_id_nimble = hand_model, root_id, root_id_nimble
+        if pretrain == "res18":
+            self.features_dim, self.low_feat_dim = 512, 128          # SURVEY.md F6 (reference's 2048/512 is broken)
+        else:
+            raise NotImplementedError(f"pretrain='{pretrain}' is not built yet")
+        self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=if_4c)
+        self.ncomps = [10, 48, None]
+        self.hand_layer = MyMANOLayer(ifRender, device, shape_ncomp=10, pose_ncomp=48, tables=mano_tables)
+        self.hand_encoder = HandEncoder(hand_model=hand_model, ncomps=self.ncomps, in_dim=self.features_dim,
+                                        ifRender=ifRender, use_mean_shape=use_mean_shape)
+        self.register_buffer("mano_face", self.hand_layer.mesh_face.clone().to(torch.int16), persistent=False)
+        self.ifRender, self.ifLight, self.aa_factor, self.image_size = ifRender, ifLight, aa_factor, image_size
+        if ifRender:
+            # Materials(diffuse .8, specular .2, shininess 30) + DirectionalLights defaults (ambient .5, specular .2)
+            self.renderer_p3d = ops.RendererHandle(self.hand_layer.tables.faces, 778, image_size=image_size, aa=aa_factor,
+                                                   ambient=(0.5,) * 3, mat_diffuse=(0.8,) * 3, specular=(0.04,) * 3,
+                                                   shininess=30.0, background=(1.0,) * 3)
+            self.register_buffer("vertex_colors", torch.tensor(SKIN_TONE).repeat(778, 1), persistent=False)
+        if ifLight:
+            self.light_estimator = LightEstimator(self.low_feat_dim)
+
+    def get_ndc_fx_fy_cx_cy(self, Ks):
+        s = float(self.image_size)
+        focal = torch.stack([Ks[:, 0, 0] * 2 / s, Ks[:, 1, 1] * 2 / s], dim=-1)
+        prp = torch.stack([-(Ks[:, 0, 2] - s / 2) * 2 / s, -(Ks[:, 1, 2] - s / 2) * 2 / s], dim=-1)
+        return focal, prp
+
+    def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):
+        low_features, features = self.base_encoder(images)
+        if self.ifLight:
+            light_params = self.light_estimator(low_features)
+        hand_params = self.hand_encoder(features)
+        outputs = self.hand_layer(hand_params, handle_collision=False)
+        outputs.update(hand_params)
+        # joints regressed from the posed verts + root-relative (models_res_nimble.py:150-166), one HIP launch
+        root_id = 0 if (dat_name == "HO3D" and not mode_train) else self.root_id
+        joints, mano_verts, pred_root = ops.mano_joints_root_relative(self.hand_layer.handle, outputs["mano_verts"], root_id)
+        outputs["joints"], outputs["mano_verts"] = joints, mano_verts
+        if self.ifRender:
+            fcl, prp = self.get_ndc_fx_fy_cx_cy(Ks)
+            cam = torch.cat([-fcl, prp], dim=-1)                          # PerspectiveCameras(focal_length=-fcl, ...)
+            if self.ifLight:
+                colors, directions = light_params["colors"], light_params["directions"]
+            else:
+                raise NotImplementedError("PointLights default lighting (light_estimation=false) is not built")
+            # skin_meshes.offset_verts_(-pred_root); .offset_verts_(+root_xyz)   (models_res_nimble.py:203-205)
+            verts_cam = mano_verts + root_xyz
+            rgba, face_id = ops.render(self.renderer_p3d, verts_cam, self.vertex_colors, cam, colors, directions)
+            outputs["re_img"] = rgba[:, :3]
+            re_sil = rgba[:, 3:4].detach()
+            re_sil = torch.where(re_sil > 0, torch.full_like(re_sil, 255.0), re_sil)   # :219
+            outputs["re_sil"] = re_sil
+            outputs["maskRGBs"] = images * (re_sil > 0).float()                          # :220
+            outputs["face_id"] = face_id
+            outputs["skin_verts"] = verts_cam
+        outputs["mano_faces"] = self.mano_face.repeat(images.shape[0], 1, 1)
+        return outputs

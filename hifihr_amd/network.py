@@ -1,0 +1,197 @@
+"""Encoder and regression heads with the reference's module structure and state-dict names.
+
+  ResEncoder / Resnet_4C(res18)   reference network/res_encoder.py:10-50, 345-373 (layer4 strides forced to 1)
+  MMPool                          reference network/res_encoder.py:247-265
+  HandEncoder                     reference network/res_encoder.py:53-167
+  LightEstimator                  reference network/res_encoder.py:169-209
+  normalize_batch_3C              reference network/res_encoder.py:212-216
+
+Round-1 status: these layers are expressed with torch.nn (ATen dispatches the convolutions to MIOpen on
+ROCm).  They are the declared interim for SURVEY.md section 8 rows A2/A5/A6 until the MFMA implicit-GEMM
+kernels land; MANO LBS, the renderer and the fused losses already run as hand-written HIP (hifihr_amd/ops.py).
+The reference's res18 dimensions are broken; this build uses feat 512 / low 128.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import init
+
+
+def weights_init(m):
+    """reference network/res_encoder.py:225-237."""
+    name = m.__class__.__name__
+    if name.find("Block") == -1 and name.find("Conv") != -1:
+        init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
+    elif name.find("Linear") != -1:
+        init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
+    elif name.find("BatchNorm") != -1:
+        init.normal_(m.weight.data, 1.0, 0.02)
+    if hasattr(m, "bias") and m.bias is not None:
+        init.constant_(m.bias.data, 0.0)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class ResNet18Trunk(nn.Module):
+    """torchvision-layout ResNet-18 without avgpool/fc; `layer4_stride=1` = the three stride edits of
+    reference network/res_encoder.py:360-362."""
+
+    def __init__(self, in_ch=3, layer4_stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_ch, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.inplanes = 64
+        self.layer1 = self._make(64, 2, 1)
+        self.layer2 = self._make(128, 2, 2)
+        self.layer3 = self._make(256, 2, 2)
+        self.layer4 = self._make(512, 2, layer4_stride)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, down)]
+        self.inplanes = planes
+        layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+
+class Resnet_4C(nn.Module):
+    def __init__(self, pretrain="res18", if_4c=False):
+        super().__init__()
+        if pretrain != "res18":
+            raise NotImplementedError(f"encoder '{pretrain}' is not built yet (res18 only in this round)")
+        self.model = ResNet18Trunk(in_ch=4 if if_4c else 3, layer4_stride=1)
+
+    def forward(self, x):
+        m = self.model
+        x = m.maxpool(m.relu(m.bn1(m.conv1(x))))
+        x = m.layer1(x)
+        x_low = m.layer2(x)
+        x = m.layer4(m.layer3(x_low))
+        return x_low, x
+
+
+class MMPool(nn.Module):
+    def __init__(self, shape=(1, 1), dim=1, p=0.0, eps=1e-6):
+        super().__init__()
+        self.p = nn.Parameter(torch.ones(dim) * p, requires_grad=True)
+        self.shape = shape
+
+    def forward(self, x):
+        x_max = F.adaptive_max_pool2d(x, self.shape)
+        x_avg = F.adaptive_avg_pool2d(x, self.shape)
+        w = torch.sigmoid(self.p)
+        return x_max * w + x_avg * (1 - w)
+
+
+def normalize_batch_3C(batch):
+    mean = batch.new_tensor([0.485, 0.456, 0.406]).view(-1, 1, 1)
+    std = batch.new_tensor([0.229, 0.224, 0.225]).view(-1, 1, 1)
+    return (batch - mean) / std
+
+
+class ResEncoder(nn.Module):
+    def __init__(self, pretrain="res18", if_4c=False):
+        super().__init__()
+        self.mmpool = MMPool((1, 1))
+        self.encoder1 = Resnet_4C(pretrain, if_4c=if_4c)
+        if if_4c:
+            raise NotImplementedError("four_channel input is not used by any new_model config")
+
+    def forward(self, x):
+        x = normalize_batch_3C(x)
+        low, features = self.encoder1(x)
+        features = self.mmpool(features).view(features.shape[0], -1)
+        return low, features
+
+
+def _mlp(dims, relu_after_first=True):
+    layers = [nn.Linear(dims[0], dims[1])]
+    if relu_after_first:
+        layers.append(nn.ReLU(inplace=True))
+    for a, b in zip(dims[1:-1], dims[2:]):
+        layers.append(nn.Linear(a, b))
+    seq = nn.Sequential(*layers)
+    seq.apply(weights_init)
+    return seq
+
+
+class HandEncoder(nn.Module):
+    def __init__(self, hand_model, ncomps, in_dim=1024, use_mean_shape=False, ifRender=True):
+        super().__init__()
+        self.use_mean_shape, self.ifRender, self.hand_model = use_mean_shape, ifRender, hand_model
+        self.shape_ncomp, self.pose_ncomp, self.tex_ncomp = ncomps
+        self.base_layers = nn.Sequential(nn.Linear(in_dim, 1024), nn.BatchNorm1d(1024), nn.ReLU(inplace=True),
+                                         nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(inplace=True))
+        self.base_layers.apply(weights_init)
+        self.pose_reg = _mlp([512, 128, self.pose_ncomp])
+        self.shape_reg = _mlp([512, 128, self.shape_ncomp])
+        if hand_model == "nimble":
+            self.tex_reg = _mlp([512, 128, self.tex_ncomp])
+        self.trans_reg = _mlp([512, 128, 32, 3])
+        if hand_model == "mano":
+            self.rot_reg = _mlp([512, 128, 32, 3])
+        self.scale_reg = _mlp([512, 128, 32, 1])
+
+    def forward(self, features):
+        bs, device = features.shape[0], features.device
+        base = self.base_layers(features)
+        pose_params = self.pose_reg(base)
+        scale = self.scale_reg(base)
+        trans = self.trans_reg(base)
+        rot = self.rot_reg(base) if self.hand_model == "mano" else None
+        if self.ifRender and self.hand_model == "nimble":
+            texture_params = self.tex_reg(base)
+        elif self.hand_model == "nimble":
+            texture_params = torch.zeros(bs, self.tex_ncomp, device=device)
+        else:
+            texture_params = None
+        shape_params = torch.zeros(bs, self.shape_ncomp, device=device) if self.use_mean_shape else self.shape_reg(base)
+        return {"pose_params": pose_params, "shape_params": shape_params, "texture_params": texture_params,
+                "scale": scale, "trans": trans, "rot": rot}
+
+
+class LightEstimator(nn.Module):
+    def __init__(self, in_dim=512):
+        super().__init__()
+        if in_dim == 32:                       # efficientnet-b3 low features [b,32,56,56]
+            conv1 = nn.Conv2d(32, 48, kernel_size=1, stride=4)
+        else:                                  # [b,in_dim,28,28] (512 in the reference; 128 for res18)
+            conv1 = nn.Conv2d(in_dim, 48, kernel_size=1, stride=2)
+        self.base_layers = nn.Sequential(conv1, nn.ReLU(inplace=True), nn.Conv2d(48, 48, 3, 1), nn.ReLU(inplace=True),
+                                         nn.MaxPool2d(3, 1, 1), nn.Conv2d(48, 64, 3, 2), nn.ReLU(inplace=True),
+                                         nn.MaxPool2d(2, 2))
+        self.light_reg = nn.Sequential(nn.Linear(256, 64), nn.ReLU(inplace=True), nn.Linear(64, 6))
+        self.light_reg.apply(weights_init)
+        self.hardtanh = nn.Hardtanh()
+
+    def forward(self, low_features):
+        base = self.base_layers(low_features)
+        lights = self.light_reg(base.view(base.shape[0], -1))
+        # the reference checks `torch.any(colors.isnan())` here with a host sync every step (:205); omitted on purpose
+        return {"colors": self.hardtanh(lights[:, :3]), "directions": lights[:, 3:]}

@@ -1,0 +1,184 @@
+"""torch.autograd bindings of the HIP hot-path kernels (C ABI in include/hifihr.h).
+
+Every op here runs ONLY on the GPU through libhifihr.so; a CPU tensor raises (there is no fallback).
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import get_lib, require_cuda
+
+
+class _Profile:
+    """Optional HIP-event brackets around the C-ABI launches (recorded on the stream the kernels are launched on,
+    i.e. torch's current stream).  No synchronisation until summary() is called."""
+
+    def __init__(self):
+        self.on = False
+        self.events = []
+
+    def enable(self):
+        self.on, self.events = True, []
+
+    def disable(self):
+        self.on = False
+
+    def bracket(self, name, fn):
+        if not self.on:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.events.append((name, e0, e1))
+        return r
+
+    def summary(self):
+        torch.cuda.synchronize()
+        acc = {}
+        for name, e0, e1 in self.events:
+            t, n = acc.get(name, (0.0, 0))
+            acc[name] = (t + e0.elapsed_time(e1) * 1e3, n + 1)
+        return {k: (t / n, n) for k, (t, n) in acc.items()}
+
+
+PROFILE = _Profile()
+
+
+class ManoLayerHandle:
+    """Device-resident MANO tables (replaces the buffers ManoLayer.__init__ registers, my_mano.py:283-313)."""
+
+    def __init__(self, tables):
+        self.lib = get_lib()
+        self.tables = tables
+        self.h = self.lib.mano_create(tables)
+
+    def __del__(self):
+        try:
+            self.lib.mano_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _ManoLBS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, handle, pose, beta):
+        require_cuda(pose, beta)
+        pose = pose.contiguous().float()
+        beta = beta.contiguous().float()
+        B = pose.shape[0]
+        verts = torch.empty(B, 778, 3, device=pose.device)
+        jtr = torch.empty(B, 21, 3, device=pose.device)
+        saved = torch.empty(B, 778, 3, device=pose.device)
+        PROFILE.bracket("mano_lbs_fwd", lambda: handle.lib.mano_lbs_fwd(handle.h, pose, beta, verts, jtr, saved))
+        ctx.handle = handle
+        ctx.save_for_backward(pose, beta, saved)
+        return verts, jtr
+
+    @staticmethod
+    def backward(ctx, gverts, gjtr):
+        pose, beta, saved = ctx.saved_tensors
+        B = pose.shape[0]
+        gpose = torch.empty(B, 48, device=pose.device)
+        gbeta = torch.empty(B, 10, device=pose.device)
+        gv = gverts.contiguous() if gverts is not None else None
+        gj = gjtr.contiguous() if gjtr is not None else None
+        PROFILE.bracket("mano_lbs_bwd", lambda: ctx.handle.lib.mano_lbs_bwd(ctx.handle.h, pose, beta, saved, gv, gj, gpose, gbeta))
+        return None, gpose, gbeta
+
+
+def mano_lbs(handle: ManoLayerHandle, pose, beta):
+    """ManoLayer.forward (reference utils/my_mano.py:315-483): pose [B,48], beta [B,10] -> verts, jtr."""
+    return _ManoLBS.apply(handle, pose, beta)
+
+
+class _ManoJoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, handle, verts, root_id):
+        require_cuda(verts)
+        verts = verts.contiguous()
+        B = verts.shape[0]
+        joints_rel = torch.empty(B, 21, 3, device=verts.device)
+        verts_rel = torch.empty(B, 778, 3, device=verts.device)
+        root = torch.empty(B, 3, device=verts.device)
+        PROFILE.bracket("mano_joints_fwd", lambda: handle.lib.mano_joints_fwd(handle.h, verts, root_id, joints_rel, verts_rel, root))
+        ctx.handle, ctx.root_id, ctx.B = handle, root_id, B
+        return joints_rel, verts_rel, root
+
+    @staticmethod
+    def backward(ctx, gj, gv, gr):
+        dev = (gj if gj is not None else gv if gv is not None else gr).device
+        gverts = torch.empty(ctx.B, 778, 3, device=dev)
+        c = lambda t: t.contiguous() if t is not None else None
+        PROFILE.bracket("mano_joints_bwd", lambda: ctx.handle.lib.mano_joints_bwd(ctx.handle.h, c(gj), c(gv), c(gr), ctx.root_id, gverts))
+        return None, gverts, None
+
+
+def mano_joints_root_relative(handle: ManoLayerHandle, verts, root_id=9):
+    """xyz_from_vertice(verts).permute(1,0,2) + the root-relative step (models_res_nimble.py:153,160-166).
+    -> joints_rel [B,21,3], verts_rel [B,778,3], pred_root [B,3]."""
+    return _ManoJoints.apply(handle, verts, root_id)
+
+
+class RendererHandle:
+    """Replaces MeshRenderer(MeshRasterizer(...), HardPhongShader(...)) of models_res_nimble.py:70-96."""
+
+    def __init__(self, faces, num_verts, image_size=224, aa=3, **consts):
+        self.lib = get_lib()
+        self.V, self.H, self.aa = int(num_verts), int(image_size), int(aa)
+        self.F = int(len(faces))
+        self.h = self.lib.renderer_create(faces, num_verts, image_size=image_size, aa=aa, **consts)
+
+    def workspace(self, B, device):
+        # one scratch buffer per forward call (it carries the packed vertex records to that call's backward);
+        # torch's caching allocator makes this a free-list pop, not a hipMalloc
+        return torch.empty(self.lib.render_workspace_bytes(self.h, B), dtype=torch.uint8, device=device)
+
+    def __del__(self):
+        try:
+            self.lib.renderer_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _Render(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, handle, verts, vcolors, cam, light_color, light_dir):
+        require_cuda(verts, vcolors, cam, light_color, light_dir)
+        verts, vcolors, cam = verts.contiguous(), vcolors.contiguous(), cam.contiguous()
+        light_color, light_dir = light_color.contiguous(), light_dir.contiguous()
+        B, H, S = verts.shape[0], handle.H, handle.H * handle.aa
+        rgba = torch.empty(B, 4, H, H, device=verts.device)
+        face_id = torch.empty(B, S, S, dtype=torch.int32, device=verts.device)
+        ws = handle.workspace(B, verts.device)
+        PROFILE.bracket("render_fwd", lambda: handle.lib.render_fwd(handle.h, verts, vcolors, cam, light_color, light_dir, rgba, face_id, ws))
+        ctx.handle = handle
+        ctx.vcol_batched = vcolors.dim() == 3
+        ctx.ws = ws
+        ctx.save_for_backward(verts, cam, light_color, light_dir, face_id)
+        ctx.mark_non_differentiable(face_id)
+        return rgba, face_id
+
+    @staticmethod
+    def backward(ctx, grad_rgba, _):
+        verts, cam, light_color, light_dir, face_id = ctx.saved_tensors
+        handle = ctx.handle
+        B = verts.shape[0]
+        gverts = torch.empty_like(verts)
+        need_col = ctx.needs_input_grad[2]
+        gvcol = torch.empty_like(verts) if need_col else None
+        glc = torch.empty(B, 3, device=verts.device)
+        gld = torch.empty(B, 3, device=verts.device)
+        ws = ctx.ws                                  # holds this call's packed vertex records
+        g = grad_rgba.contiguous()
+        PROFILE.bracket("render_bwd", lambda: handle.lib.render_bwd(handle.h, verts, cam, light_color, light_dir, face_id, g,
+                                                                    gverts, gvcol, glc, gld, ws))
+        if need_col and not ctx.vcol_batched:
+            gvcol = gvcol.sum(0)
+        return None, gverts, gvcol, None, glc, gld
+
+
+def render(handle: RendererHandle, verts, vcolors, cam, light_color, light_dir):
+    """renderer_p3d(meshes, cameras, lights) + avg_pool2d(aa) (models_res_nimble.py:208-211).
+    -> rgba [B,4,H,H], face_id int32 [B,H*aa,H*aa]."""
+    return _Render.apply(handle, verts, vcolors, cam, light_color, light_dir)

@@ -1,0 +1,84 @@
+"""Flat parameter / gradient buffers and the fused Adam step.
+
+MI355X-first layout: all trainable parameters of the model live in ONE contiguous fp32 buffer and all their
+gradients in another (parameters and .grad are views), so that
+  * zero_grad is one memset, the optimizer step is one HBM-bound kernel launch (hifihr_adam_step), and
+  * the data-parallel all-reduce runs on contiguous slices of the gradient buffer with no packing copies
+    (hifihr_amd/dist.py).
+Semantics: torch.optim.Adam as configured at reference train_hrnet.py:546-551.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import get_lib, require_cuda
+
+
+class FlatParams:
+    """Re-homes module parameters into a flat buffer (registration order) and pins their .grad to views of a
+    flat gradient buffer."""
+
+    def __init__(self, module: torch.nn.Module, align: int = 64):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + align - 1) // align * align        # keep every tensor 256-byte aligned
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view_as(p)
+            p.grad = self.grad[o:o + n].view_as(p)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):                # re-pin (a None grad would detach the view)
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def param_count(self):
+        return sum(p.numel() for p in self.params)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics on a FlatParams (one kernel launch per step).  Subclasses Optimizer so that
+    torch.optim.lr_scheduler.MultiStepLR (train_hrnet.py:551) drives param_groups[0]['lr'] unchanged."""
+
+    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+        self.flatp = flat
+        super().__init__([flat.flat], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.exp_avg = torch.zeros_like(flat.flat)
+        self.exp_avg_sq = torch.zeros_like(flat.flat)
+        self.step_count = 0
+        self.grad_scale = grad_scale
+        self._lib = None
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flatp.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self._lib is None:
+            self._lib = get_lib()
+        require_cuda(self.flatp.flat)
+        g = self.param_groups[0]
+        self.step_count += 1
+        from .ops import PROFILE
+        PROFILE.bracket("adam", lambda: self._lib.adam_step(self.flatp.flat, self.flatp.grad, self.exp_avg, self.exp_avg_sq,
+                                                            self.grad_scale, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                                            g["weight_decay"], self.step_count))
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)

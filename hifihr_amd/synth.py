@@ -1,0 +1,65 @@
+"""Synthetic FreiHAND-shaped training batches (the datasets are not available offline); generator per
+SURVEY.md section 8(d).  Sample keys and shapes follow the reference's training queries
+(reference data/dataset.py:153-289): trans_images f32[3,224,224] in [0,1), trans_Ks f32[3,3],
+trans_joints f32[21,3], trans_verts f32[778,3], trans_masks f32[3,224,224] in {0,1}, scales, idxs."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+
+
+@torch.no_grad()
+def make_batch(mano_handle: ops.ManoLayerHandle, renderer: ops.RendererHandle, B: int, first_index: int = 0,
+               device="cuda", image_size=224):
+    """Deterministic in (first_index, B): sample i uses seed 1234 + first_index + i."""
+    rows = []
+    for i in range(B):
+        g = torch.Generator().manual_seed(1234 + first_index + i)
+        f = 450.0 + 200.0 * torch.rand(1, generator=g)
+        d = 20.0 * torch.rand(2, generator=g) - 10.0
+        theta = (2 * torch.rand(1, generator=g) - 1) * math.pi
+        pose = torch.cat([0.5 * torch.randn(3, generator=g), 0.8 * torch.randn(45, generator=g)])
+        beta = 0.5 * torch.randn(10, generator=g)
+        root = torch.stack([0.1 * torch.rand(1, generator=g) - 0.05, 0.1 * torch.rand(1, generator=g) - 0.05,
+                            0.45 + 0.3 * torch.rand(1, generator=g)]).view(3)
+        rows.append((f, d, theta, pose, beta, root, int(g.initial_seed())))
+    f = torch.cat([r[0] for r in rows]); d = torch.stack([r[1] for r in rows]); th = torch.cat([r[2] for r in rows])
+    pose = torch.stack([r[3] for r in rows]).to(device); beta = torch.stack([r[4] for r in rows]).to(device)
+    root = torch.stack([r[5] for r in rows]).to(device)
+    c = image_size / 2
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0] = f; K[:, 1, 1] = f; K[:, 0, 2] = c + d[:, 0]; K[:, 1, 2] = c + d[:, 1]; K[:, 2, 2] = 1
+    # in-plane rotation about the image centre, as reference data/dataset.py:237-260 (post_rot_trans . K)
+    cs, sn = torch.cos(th), torch.sin(th)
+    R = torch.zeros(B, 3, 3)
+    R[:, 0, 0] = cs; R[:, 0, 1] = -sn; R[:, 1, 0] = sn; R[:, 1, 1] = cs; R[:, 2, 2] = 1
+    T = torch.eye(3).repeat(B, 1, 1); T[:, 0, 2] = c; T[:, 1, 2] = c
+    Ti = torch.eye(3).repeat(B, 1, 1); Ti[:, 0, 2] = -c; Ti[:, 1, 2] = -c
+    K = (T @ R @ Ti @ K).to(device)
+    # the rotated intrinsics are no longer upper-triangular; the reference rotates the 3-D points by R_z as well
+    # (data/dataset.py:271-280) so that K stays a plain pinhole.  Do the same: rotate points, keep pinhole K.
+    Kp = torch.zeros(B, 3, 3, device=device)
+    Kp[:, 0, 0] = f.to(device); Kp[:, 1, 1] = f.to(device); Kp[:, 2, 2] = 1
+    Kp[:, 0, 2] = K[:, 0, 2]; Kp[:, 1, 2] = K[:, 1, 2]
+    verts, _ = ops.mano_lbs(mano_handle, pose, beta)
+    joints, verts_rel, _ = ops.mano_joints_root_relative(mano_handle, verts, 9)
+    Rz = R.to(device)
+    verts_w = torch.einsum("bij,bvj->bvi", Rz, verts_rel) + root.unsqueeze(1)
+    joints_w = torch.einsum("bij,bvj->bvi", Rz, joints) + root.unsqueeze(1)
+    s = float(image_size)
+    cam = torch.stack([-(Kp[:, 0, 0] * 2 / s), -(Kp[:, 1, 1] * 2 / s), -(Kp[:, 0, 2] - s / 2) * 2 / s,
+                       -(Kp[:, 1, 2] - s / 2) * 2 / s], dim=-1).contiguous()
+    lc = torch.zeros(B, 3, device=device); ld = torch.tensor([0.0, 0.0, -1.0], device=device).repeat(B, 1)
+    col = torch.ones(778, 3, device=device)
+    rgba, _ = ops.render(renderer, verts_w.contiguous(), col, cam, lc, ld)
+    mask = (rgba[:, 3:4] > 0).float().repeat(1, 3, 1, 1)
+    gi = torch.Generator(device="cpu").manual_seed(1234 + first_index)
+    imgs = torch.rand(B, 3, image_size, image_size, generator=gi)
+    scales = (joints_w[:, 9] - joints_w[:, 10]).norm(dim=-1)
+    return {
+        "trans_images": imgs, "trans_Ks": Kp.cpu(), "trans_joints": joints_w.cpu(), "trans_verts": verts_w.cpu(),
+        "trans_masks": mask.cpu(), "scales": scales.cpu(), "idxs": torch.arange(first_index, first_index + B),
+    }

@@ -1,0 +1,63 @@
+"""The step of the reference's train loop (reference train_hrnet.py:50-113) and the batch plumbing around it
+(reference utils/traineval_util.py:21-111 data_dic FreiHand branch, :338-354 trans_proj_j2d;
+utils/fh_utils.py:30-39 proj_func)."""
+from __future__ import annotations
+
+import torch
+
+
+def proj_func(xyz, K):
+    """fh_utils.py:30-39: uv = (K xyz)_xy / (K xyz)_z."""
+    uv = torch.bmm(K, xyz.permute(0, 2, 1)).permute(0, 2, 1)
+    return uv[:, :, :2] / uv[:, :, 2:3]
+
+
+def trans_proj_j2d(outputs, Ks, root_xyz=None, which_joints="joints"):
+    """traineval_util.py:338-354, the `scales is None` branch the step uses."""
+    j3d = outputs[which_joints]
+    if root_xyz is not None:
+        j3d = j3d + root_xyz
+    return proj_func(j3d, Ks)
+
+
+def data_dic(sample, dat_name, set_name, args, device="cuda"):
+    """FreiHand branch of traineval_util.py:21-111 for the training queries
+    [trans_images, trans_Ks, trans_joints, scales, trans_verts, trans_masks]."""
+    assert dat_name == "FreiHand"
+    ex = {}
+    g = lambda k: sample["trans_" + k] if ("trans_" + k) in sample else sample[k]
+    ex["imgs"] = g("images").to(device, non_blocking=True)
+    Ks = g("Ks").to(device, non_blocking=True)
+    ex["Ks"] = Ks
+    ex["Ps"] = torch.cat([Ks, torch.zeros_like(Ks[:, :, :1])], dim=2)       # Ks @ [I|0]
+    if "scales" in sample:
+        ex["scales"] = sample["scales"].float().to(device, non_blocking=True)
+    ex["idxs"] = sample["idxs"].to(device, non_blocking=True)
+    ex["joints"] = g("joints").to(device, non_blocking=True)
+    ex["j2d_gt"] = proj_func(ex["joints"], Ks)
+    ex["verts"] = g("verts").to(device, non_blocking=True)
+    masks = g("masks").to(device, non_blocking=True)
+    ex["masks"] = masks
+    ex["segms_gt"] = masks[:, 0].long()
+    return ex
+
+
+def train_step(model, loss_func, optimizer, examples, args, dat_name="FreiHand", backward_hook=None):
+    """One iteration of train_an_epoch (train_hrnet.py:50-113), mode_train=True.  Returns (loss, loss_dic)."""
+    root_xyz = examples["joints"][:, args.ROOT, :].unsqueeze(1)
+    outputs = model(dat_name, True, examples["imgs"], Ks=examples["Ps"], root_xyz=root_xyz)
+    ex = dict(examples)
+    ex["joints"] = examples["joints"] - root_xyz
+    ex["verts"] = examples["verts"] - root_xyz
+    outputs["j2d"] = trans_proj_j2d(outputs, examples["Ks"], root_xyz=root_xyz)
+    loss_dic = loss_func(ex, outputs, args.losses, dat_name, args)
+    loss = None
+    for k in args.losses:
+        loss = loss_dic[k] if loss is None else loss + loss_dic[k]
+    loss_dic["loss"] = loss
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if backward_hook is not None:
+        backward_hook()                      # data-parallel gradient all-reduce (hifihr_amd/dist.py)
+    optimizer.step()
+    return loss, loss_dic

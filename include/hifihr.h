@@ -118,6 +118,16 @@ int hifihr_render_bwd(const hifihr_renderer_t* h, const float* verts_d, const fl
                       float* gverts_d, float* gvcolors_d, float* glight_color_d, float* glight_dir_d, void* workspace_d,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused Adam over ONE flat parameter buffer.
+ * Replaces optimizer.step() of torch.optim.Adam(betas=(0.9,0.999), eps=1e-8, weight_decay=0|0.01)
+ * reference train_hrnet.py:111-113, 546-551.  All four buffers are device fp32[n], 16-byte aligned.
+ * grads are multiplied by grad_scale before use (1/world_size after a sum all-reduce).  `step` counts from 1.
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_adam_step(float* params_d, const float* grads_d, float* exp_avg_d, float* exp_avg_sq_d, size_t n,
+                     float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

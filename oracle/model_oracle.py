@@ -1,0 +1,67 @@
+"""ORACLE (test infrastructure, not product code): the whole training step on the CPU.
+
+Composes the oracle pieces (oracle/mano_oracle.py, oracle/render_oracle.py) with torch-CPU ATen for the
+encoder / heads, following reference models_res_nimble.py:102-225 (Model.forward), train_hrnet.py:50-113 (the
+step) and losses.py:234-453.  Used by tests/ (end-to-end loss parity of the HIP path), by
+__graft_entry__.smoke() and as bench.py's cpu_baseline ("port").  Never imported by hifihr_amd.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from hifihr_amd.losses import LossFunction
+from hifihr_amd.network import HandEncoder, LightEstimator, ResEncoder
+from hifihr_amd.traineval import trans_proj_j2d
+from oracle import mano_oracle as mo
+from oracle import render_oracle as ro
+
+SKIN_TONE = (0.78, 0.60, 0.50)
+
+
+class OracleModel(nn.Module):
+    def __init__(self, tables, pretrain="res18", image_size=224, aa=3, root_id=9):
+        super().__init__()
+        assert pretrain == "res18"
+        self.tables, self.image_size, self.aa, self.root_id = tables, image_size, aa, root_id
+        self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=False)
+        self.hand_encoder = HandEncoder(hand_model="mano", ncomps=[10, 48, None], in_dim=512, ifRender=True, use_mean_shape=False)
+        self.light_estimator = LightEstimator(128)
+        self.faces = torch.as_tensor(tables.faces).long()
+
+    def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):
+        low, feat = self.base_encoder(images)
+        light = self.light_estimator(low)
+        hp = self.hand_encoder(feat)
+        verts, _, _ = mo.mano_forward(self.tables, hp["pose_params"], hp["shape_params"])
+        outputs = {"mano_verts": verts}
+        outputs.update(hp)
+        joints = mo.xyz_from_vertice(self.tables, verts)
+        joints, mano_verts, pred_root = mo.root_relative(joints, verts, self.root_id)
+        outputs["joints"], outputs["mano_verts"] = joints, mano_verts
+        cam = ro.ndc_camera_from_K(Ks, float(self.image_size))
+        verts_cam = mano_verts + root_xyz
+        vcol = torch.tensor(SKIN_TONE).repeat(images.shape[0], 778, 1)
+        rgba, p2f = ro.render(verts_cam, vcol, cam, light["colors"], light["directions"], self.faces,
+                              image_size=self.image_size, aa=self.aa)
+        re_img, re_sil, mask_rgbs = ro.model_render_outputs(rgba, images)
+        outputs.update({"re_img": re_img, "re_sil": re_sil, "maskRGBs": mask_rgbs, "face_id": torch.from_numpy(p2f)})
+        outputs["mano_faces"] = torch.as_tensor(self.tables.faces, dtype=torch.int16).unsqueeze(0).repeat(images.shape[0], 1, 1)
+        return outputs
+
+
+def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None):
+    """train_hrnet.py:50-113 on the CPU.  Returns (loss, loss_dic, outputs)."""
+    root_xyz = examples_cpu["joints"][:, args.ROOT, :].unsqueeze(1)
+    outputs = model("FreiHand", True, examples_cpu["imgs"], Ks=examples_cpu["Ps"], root_xyz=root_xyz)
+    ex = dict(examples_cpu)
+    ex["joints"] = examples_cpu["joints"] - root_xyz
+    ex["verts"] = examples_cpu["verts"] - root_xyz
+    outputs["j2d"] = trans_proj_j2d(outputs, examples_cpu["Ks"], root_xyz=root_xyz)
+    loss_dic = LossFunction()(ex, outputs, args.losses, "FreiHand", args)
+    loss = sum(loss_dic[k] for k in args.losses)
+    if optimizer is not None:
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+    return loss, loss_dic, outputs

@@ -152,3 +152,20 @@ def render_case(lib, tables, device, B, seed, image_size, aa, check_grad=True, r
             assert err < gtol, f"grad {name}: max err / max |ref| = {err:.3e} (scale {scale:.3e})"
     finally:
         lib.renderer_destroy(h)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused Adam
+# ------------------------------------------------------------------------------------------------
+def adam_case(lib, device, n, wd, steps, grad_scale=0.5, lr=1e-3):
+    gen = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=gen)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    p = p0.clone().to(device); m = torch.zeros(n, device=device); v = torch.zeros(n, device=device)
+    for s in range(1, steps + 1):
+        g = torch.randn(n, generator=gen)
+        ref.grad = (g * grad_scale).clone()
+        opt.step()
+        lib.adam_step(p, g.to(device), m, v, grad_scale, lr, 0.9, 0.999, 1e-8, wd, s)
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-5)

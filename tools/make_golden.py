@@ -29,6 +29,7 @@ REF = os.environ.get("HIFIHR_REFERENCE", "/root/reference")
 OUT = os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, REPO)
 sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REPO, "tools"))
 
 from hifihr_amd.mano_tables import load_mano_pkl, synthetic_mano_tables  # noqa: E402
 
@@ -149,19 +150,21 @@ def gen_ssim():
 
 
 def gen_resnet18():
+    """Reference's vendored torchvision ResNet-18 (utils/Freihand_GNN_mano/network/resnet.py) with the three stride
+    edits of network/res_encoder.py:360-362, name-seeded weights (tools/seeded_init.py), train mode, fwd + bwd."""
+    from seeded_init import seeded_state_dict
     spec = importlib.util.spec_from_file_location(
         "ref_resnet", os.path.join(REF, "utils", "Freihand_GNN_mano", "network", "resnet.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    torch.manual_seed(1234)
-    net = mod.resnet18(pretrained=False) if "pretrained" in mod.resnet18.__code__.co_varnames else mod.resnet18()
-    # the three stride edits of reference network/res_encoder.py:360-362
+    net = mod.resnet18()
     net.layer4[0].downsample[0].stride = (1, 1)
     net.layer4[0].conv1.stride = (1, 1)
     net.layer4[0].conv2.stride = (1, 1)
+    net.load_state_dict(seeded_state_dict(net))
     net.train()
     g = torch.Generator().manual_seed(99)
-    x = torch.rand(2, 3, 64, 64, generator=g)
+    x = torch.rand(2, 3, 96, 96, generator=g)
     mean = torch.tensor([0.485, 0.456, 0.406]).view(-1, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(-1, 1, 1)
     xn = (x - mean) / std                                        # normalize_batch_3C, res_encoder.py:212-216
@@ -169,15 +172,12 @@ def gen_resnet18():
     h = net.layer1(h)
     low = net.layer2(h)
     feat = net.layer4(net.layer3(low))
-    sd = {k: v.detach().numpy() for k, v in net.state_dict().items() if "num_batches" not in k and not k.startswith("fc.")}
-    # weights are needed to reproduce the activations; keep the fixture small with fp16-exact weights?  No:
-    # store full fp32 weights compressed only for the first two stages; later stages checked by shape/sums.
-    np.savez_compressed(os.path.join(OUT, "resnet18_small.npz"), x=x.numpy(),
-                        low_mean=low.mean().item(), low_absmean=low.abs().mean().item(),
-                        feat_mean=feat.mean().item(), feat_absmean=feat.abs().mean().item(),
-                        low_shape=np.array(low.shape), feat_shape=np.array(feat.shape),
-                        low_samples=low.detach().flatten()[::997].numpy(), feat_samples=feat.detach().flatten()[::997].numpy(),
-                        param_names=np.array(sorted(sd.keys())), param_shapes=np.array([str(sd[k].shape) for k in sorted(sd.keys())]))
+    wl = torch.randn(low.shape, generator=g); wf = torch.randn(feat.shape, generator=g)
+    ((low * wl).sum() + (feat * wf).sum()).backward()
+    np.savez_compressed(os.path.join(OUT, "resnet18_small.npz"), x=x.numpy(), low=low.detach().numpy(),
+                        feat=feat.detach().numpy(), wl=wl.numpy(), wf=wf.numpy(),
+                        g_conv1=net.conv1.weight.grad.numpy(), g_bn1=net.bn1.weight.grad.numpy(),
+                        g_l4c2=net.layer4[1].conv2.weight.grad.numpy()[:8], g_l2ds=net.layer2[0].downsample[0].weight.grad.numpy())
     print("resnet18", tuple(low.shape), tuple(feat.shape))
 
 
@@ -194,7 +194,49 @@ def main():
     gen_rodrigues()
     gen_ssim()
     gen_resnet18()
+    gen_losses()
+
+
+# ---- loss helpers: the reference functions cannot be imported (module-level pytorch3d / torchvision imports in
+# utils/losses_util.py, skimage in utils/fh_utils.py), so their SOURCE is extracted with ast and executed here,
+# in the build container, to produce vectors.  Only the vectors are committed.
+def _extract_functions(path, names):
+    import ast
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = {"torch": torch, "np": np, "nn": torch.nn}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def gen_losses():
+    lu = _extract_functions(os.path.join(REF, "utils", "losses_util.py"), {"bone_direction_loss", "edge_length_loss", "IOU", "iou"})
+    fh = _extract_functions(os.path.join(REF, "utils", "fh_utils.py"), {"proj_func", "Mano2Frei"})
+    g = torch.Generator().manual_seed(21)
+    B = 3
+    j = 0.1 * torch.randn(B, 21, 3, generator=g); jg = 0.1 * torch.randn(B, 21, 3, generator=g)
+    j2 = 100 * torch.rand(B, 21, 2, generator=g); j2g = 100 * torch.rand(B, 21, 2, generator=g)
+    con = torch.ones(B, 21, 1)
+    v = 0.1 * torch.randn(B, 778, 3, generator=g); vg = 0.1 * torch.randn(B, 778, 3, generator=g)
+    faces = torch.as_tensor(synthetic_mano_tables(0).faces.astype(np.int16)).unsqueeze(0).repeat(B, 1, 1)
+    m1 = (torch.rand(B, 1, 32, 32, generator=g) > 0.5).float(); m2 = (torch.rand(B, 1, 32, 32, generator=g) > 0.5).float()
+    K = torch.tensor([[500.0, 0, 112], [0, 510.0, 100], [0, 0, 1]]).repeat(B, 1, 1)
+    xyz = torch.randn(B, 21, 3, generator=g) * 0.05 + torch.tensor([0.0, 0.0, 0.6])
+    out = dict(
+        j=j.numpy(), jg=jg.numpy(), j2=j2.numpy(), j2g=j2g.numpy(), v=v.numpy(), vg=vg.numpy(), m1=m1.numpy(), m2=m2.numpy(),
+        K=K.numpy(), xyz=xyz.numpy(),
+        bone3d=lu["bone_direction_loss"](j, jg, con).numpy(), bone2d=lu["bone_direction_loss"](j2, j2g, con).numpy(),
+        edge=lu["edge_length_loss"](v, vg, faces).numpy(), iou=lu["iou"](m1, m2).numpy(),
+        proj=fh["proj_func"](xyz, K).numpy(), mano2frei=fh["Mano2Frei"](xyz).numpy())
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
+    print("losses ok", float(out["bone3d"]), float(out["edge"]), float(out["iou"]))
 
 
 if __name__ == "__main__":
-    main()
+    if os.environ.get("GOLDEN_ONLY") == "losses":
+        os.makedirs(OUT, exist_ok=True)
+        gen_losses()
+    else:
+        main()
