@@ -67,6 +67,10 @@ class Model(nn.Module):
 
     def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):
         low_features, features = self.base_encoder(images)
+        return self.forward_from_features(dat_name, mode_train, images, low_features, features, Ks=Ks, root_xyz=root_xyz)
+
+    def forward_from_features(self, dat_name, mode_train, images, low_features, features, Ks=None, root_xyz=None):
+        """Everything after the image encoder (models_res_nimble.py:118-225)."""
         if self.ifLight:
             light_params = self.light_estimator(low_features)
         hand_params = self.hand_encoder(features)

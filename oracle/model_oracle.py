@@ -31,6 +31,9 @@ class OracleModel(nn.Module):
 
     def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):
         low, feat = self.base_encoder(images)
+        return self.forward_from_features(dat_name, mode_train, images, low, feat, Ks=Ks, root_xyz=root_xyz)
+
+    def forward_from_features(self, dat_name, mode_train, images, low, feat, Ks=None, root_xyz=None):
         light = self.light_estimator(low)
         hp = self.hand_encoder(feat)
         verts, _, _ = mo.mano_forward(self.tables, hp["pose_params"], hp["shape_params"])
@@ -50,10 +53,15 @@ class OracleModel(nn.Module):
         return outputs
 
 
-def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None):
-    """train_hrnet.py:50-113 on the CPU.  Returns (loss, loss_dic, outputs)."""
+def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None, features=None):
+    """train_hrnet.py:50-113 on the CPU.  Returns (loss, loss_dic, outputs).  `features=(low, feat)` skips the
+    image encoder (tests isolate the HIP kernels from conv back-end rounding that way)."""
     root_xyz = examples_cpu["joints"][:, args.ROOT, :].unsqueeze(1)
-    outputs = model("FreiHand", True, examples_cpu["imgs"], Ks=examples_cpu["Ps"], root_xyz=root_xyz)
+    if features is None:
+        outputs = model("FreiHand", True, examples_cpu["imgs"], Ks=examples_cpu["Ps"], root_xyz=root_xyz)
+    else:
+        outputs = model.forward_from_features("FreiHand", True, examples_cpu["imgs"], features[0], features[1],
+                                              Ks=examples_cpu["Ps"], root_xyz=root_xyz)
     ex = dict(examples_cpu)
     ex["joints"] = examples_cpu["joints"] - root_xyz
     ex["verts"] = examples_cpu["verts"] - root_xyz
