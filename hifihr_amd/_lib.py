@@ -75,6 +75,11 @@ class HifihrLib:
         c = self.c
         c.hifihr_renderer_create.argtypes = [POINTER(c_void_p), _c_int_p, c_int, c_int, c_int, c_int, _c_float_p, _c_float_p,
                                              _c_float_p, c_float, _c_float_p]
+        ci = [c_int] * 9
+        c.hifihr_conv2d_fwd.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
+        c.hifihr_conv2d_bwd_data.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
+        c.hifihr_conv2d_bwd_weight.argtypes = [_c_float_p] * 3 + ci + [c_void_p]
+        c.hifihr_image_to_nhwc4.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_adam_step.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
                                        c_float, c_float, c_float, c_int, c_void_p]
         c.hifihr_renderer_destroy.argtypes = [c_void_p]
@@ -122,6 +127,23 @@ class HifihrLib:
         self.check(self.c.hifihr_mano_joints_bwd(h, _fp(gjoints_rel), _fp(gverts_rel), _fp(groot), B, root_id,
                                                  _fp(gverts), _stream_of(gverts)), "hifihr_mano_joints_bwd")
 
+
+    # ---- convolution (NHWC, f32 MFMA implicit GEMM) --------------------
+    def conv2d_fwd(self, x, w, bias, y, N, H, W, C, K, R, S, stride, pad):
+        self.check(self.c.hifihr_conv2d_fwd(_fp(x), _fp(w), _fp(bias), _fp(y), N, H, W, C, K, R, S, stride, pad, _stream_of(x)),
+                   "hifihr_conv2d_fwd")
+
+    def conv2d_bwd_data(self, dy, w, dx, scratch, N, H, W, C, K, R, S, stride, pad):
+        self.check(self.c.hifihr_conv2d_bwd_data(_fp(dy), _fp(w), _fp(dx), _fp(scratch), N, H, W, C, K, R, S, stride, pad,
+                                                 _stream_of(dy)), "hifihr_conv2d_bwd_data")
+
+    def conv2d_bwd_weight(self, x, dy, dw, N, H, W, C, K, R, S, stride, pad):
+        self.check(self.c.hifihr_conv2d_bwd_weight(_fp(x), _fp(dy), _fp(dw), N, H, W, C, K, R, S, stride, pad, _stream_of(x)),
+                   "hifihr_conv2d_bwd_weight")
+
+    def image_to_nhwc4(self, images, out):
+        B, _, H, W = images.shape
+        self.check(self.c.hifihr_image_to_nhwc4(_fp(images), _fp(out), B, H, W, _stream_of(images)), "hifihr_image_to_nhwc4")
 
     # ---- optimizer ---------------------------------------------------
     def adam_step(self, p, g, m, v, grad_scale, lr, beta1, beta2, eps, weight_decay, step):

@@ -238,4 +238,44 @@ int hifihr_adam_step(float* params, const float* grads, float* exp_avg, float* e
   return HIFIHR_OK;
 }
 
+static int conv_dims_ok(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+  return N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0 && (H + 2 * pad - R) >= 0 &&
+         (W + 2 * pad - S) >= 0;
+}
+
+int hifihr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int K, int R,
+                      int S, int stride, int pad, void* stream) {
+  if (!x || !w || !y || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4)
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_fwd: bad argument (C must be a multiple of 4)");
+  hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
+  HIP_TRY(hifihr::launch_conv_igemm(g, x, w, bias, y, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, int N, int H, int W, int C, int K,
+                           int R, int S, int stride, int pad, void* stream) {
+  if (!dy || !w || !dx || !wt_scratch || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || K % 4)
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_data: bad argument (K must be a multiple of 4)");
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+  HIP_TRY(hifihr::launch_weight_transpose(w, wt_scratch, K, R * S, C, (hipStream_t)stream));
+  hifihr::ConvGeom g{N, OH, OW, K, H, W, C, R, S, stride, pad, 1};
+  HIP_TRY(hifihr::launch_conv_igemm(g, dy, wt_scratch, nullptr, dx, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                             int stride, int pad, void* stream) {
+  if (!x || !dy || !dw || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4 || K % 4)
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_weight: bad argument (C and K must be multiples of 4)");
+  hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
+  HIP_TRY(hifihr::launch_conv_wgrad(g, x, dy, dw, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_image_to_nhwc4(const float* images, float* out, int B, int H, int W, void* stream) {
+  if (!images || !out || B <= 0 || H <= 0 || W <= 0) return fail(HIFIHR_EINVAL, "hifihr_image_to_nhwc4: bad argument");
+  HIP_TRY(hifihr::launch_image_to_nhwc4(images, out, B, H * W, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 }  // extern "C"

@@ -50,6 +50,16 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
                              const float* light_dir, const int* face_id, const float* grad_rgba, int B, float* gverts,
                              float* gvcolors, float* glight_color, float* glight_dir, void* ws, hipStream_t st);
 
+// Implicit-GEMM convolution geometry.  src [N][IH][IW][IC] is gathered, dst [N][OH][OW][OC] is written.
+// forward: src = x, dst = y (ih = oh*stride - pad + r); dgrad = 1: src = dy, dst = dx (ih = (oh + pad - r)/stride).
+struct ConvGeom {
+  int N, IH, IW, IC, OH, OW, OC, R, S, stride, pad, dgrad;
+};
+hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, hipStream_t st);
+hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
+hipError_t launch_weight_transpose(const float* w, float* wt, int K, int RS, int C, hipStream_t st);
+hipError_t launch_image_to_nhwc4(const float* img, float* out, int B, int HW, hipStream_t st);
+
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, hipStream_t st);
 

@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
   const int b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = r.H, S = H * AA;
-  const int tx = tid % kTile, ty = tid / kTile;
+  // each wave owns a compact 8x8-pixel quadrant of the tile (a face then touches ~1 wave, not a 16x4 strip of 2-3)
+  const int tx = (lane & 7) + 8 * (wave & 1), ty = (lane >> 3) + 8 * (wave >> 1);
   const int ox = blockIdx.x * kTile, oy = blockIdx.y * kTile;
   const int px = ox + tx, py = oy + ty;
   const bool live = (px < H) && (py < H);
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
   const int b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = r.H, S = H * AA;
-  const int px = blockIdx.x * kTile + tid % kTile, py = blockIdx.y * kTile + tid / kTile;
+  const int px = blockIdx.x * kTile + (lane & 7) + 8 * (wave & 1), py = blockIdx.y * kTile + (lane >> 3) + 8 * (wave >> 1);
   const bool live = (px < H) && (py < H);
   float glc[3] = {0.f, 0.f, 0.f}, gl[3] = {0.f, 0.f, 0.f};
   LightDir Ld;

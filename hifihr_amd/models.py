@@ -34,7 +34,7 @@ class MyMANOLayer(nn.Module):
 
 class Model(nn.Module):
     def __init__(self, ifRender, device, if_4c, hand_model, use_mean_shape, pretrain, root_id=9, root_id_nimble=11,
-                 ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3):
+                 ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3, conv_impl="mfma"):
         super().__init__()
         if hand_model != "mano":
             raise NotImplementedError(f"hand_model='{hand_model}': only 'mano' is built (NIMBLE assets are not available)")
@@ -43,7 +43,7 @@ class Model(nn.Module):
             self.features_dim, self.low_feat_dim = 512, 128          # SURVEY.md F6 (reference's 2048/512 is broken)
         else:
             raise NotImplementedError(f"pretrain='{pretrain}' is not built yet")
-        self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=if_4c)
+        self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=if_4c, conv_impl=conv_impl)
         self.ncomps = [10, 48, None]
         self.hand_layer = MyMANOLayer(ifRender, device, shape_ncomp=10, pose_ncomp=48, tables=mano_tables)
         self.hand_encoder = HandEncoder(hand_model=hand_model, ncomps=self.ncomps, in_dim=self.features_dim,

@@ -32,15 +32,42 @@ def weights_init(m):
         init.constant_(m.bias.data, 0.0)
 
 
+class Conv2dMFMA(nn.Module):
+    """Bias-free nn.Conv2d whose forward / backward-data / backward-weight run as hand-written f32-MFMA implicit
+    GEMM kernels (hifihr_amd/csrc/conv.hip).  The weight keeps torch's logical [K,C,R,S] shape (state-dict
+    compatible with the reference) in channels_last memory format = the kernel's physical [K][R][S][C]."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0):
+        super().__init__()
+        self.stride, self.pad = stride, pad
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last))
+
+    def forward(self, x):
+        from . import ops
+        w = self.weight
+        if w.shape[1] % 4 != 0:                       # the 3-channel stem: input arrives as NHWC4, pad the weight
+            w = F.pad(w, (0, 0, 0, 0, 0, 4 - w.shape[1] % 4)).contiguous(memory_format=torch.channels_last)
+        return ops.conv2d(x, w, self.stride, self.pad)
+
+
+_CONV_IMPL = {"impl": "mfma"}      # "mfma": hand-written kernels; "aten": nn.Conv2d (CPU oracle path / comparisons)
+
+
+def _conv(cin, cout, k, stride, pad):
+    if _CONV_IMPL["impl"] == "mfma":
+        return Conv2dMFMA(cin, cout, k, stride, pad)
+    return nn.Conv2d(cin, cout, k, stride, pad, bias=False)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.conv1 = _conv(inplanes, planes, 3, stride, 1)
         self.bn1 = nn.BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.conv2 = _conv(planes, planes, 3, 1, 1)
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
@@ -55,9 +82,11 @@ class ResNet18Trunk(nn.Module):
     """torchvision-layout ResNet-18 without avgpool/fc; `layer4_stride=1` = the three stride edits of
     reference network/res_encoder.py:360-362."""
 
-    def __init__(self, in_ch=3, layer4_stride=1):
+    def __init__(self, in_ch=3, layer4_stride=1, conv_impl="aten"):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_ch, 64, 7, 2, 3, bias=False)
+        _CONV_IMPL["impl"] = conv_impl
+        self.conv_impl = conv_impl
+        self.conv1 = _conv(in_ch, 64, 7, 2, 3)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
@@ -66,14 +95,15 @@ class ResNet18Trunk(nn.Module):
         self.layer2 = self._make(128, 2, 2)
         self.layer3 = self._make(256, 2, 2)
         self.layer4 = self._make(512, 2, layer4_stride)
+        _CONV_IMPL["impl"] = "aten"
         for m in self.modules():
-            if isinstance(m, nn.Conv2d):
+            if isinstance(m, (nn.Conv2d, Conv2dMFMA)):
                 init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def _make(self, planes, blocks, stride):
         down = None
         if stride != 1 or self.inplanes != planes:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+            down = nn.Sequential(_conv(self.inplanes, planes, 1, stride, 0), nn.BatchNorm2d(planes))
         layers = [BasicBlock(self.inplanes, planes, stride, down)]
         self.inplanes = planes
         layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
@@ -81,11 +111,11 @@ class ResNet18Trunk(nn.Module):
 
 
 class Resnet_4C(nn.Module):
-    def __init__(self, pretrain="res18", if_4c=False):
+    def __init__(self, pretrain="res18", if_4c=False, conv_impl="aten"):
         super().__init__()
         if pretrain != "res18":
             raise NotImplementedError(f"encoder '{pretrain}' is not built yet (res18 only in this round)")
-        self.model = ResNet18Trunk(in_ch=4 if if_4c else 3, layer4_stride=1)
+        self.model = ResNet18Trunk(in_ch=4 if if_4c else 3, layer4_stride=1, conv_impl=conv_impl)
 
     def forward(self, x):
         m = self.model
@@ -116,15 +146,24 @@ def normalize_batch_3C(batch):
 
 
 class ResEncoder(nn.Module):
-    def __init__(self, pretrain="res18", if_4c=False):
+    """conv_impl="mfma": the trunk's 20 convolutions run as hand-written MFMA kernels on channels_last (NHWC)
+    activations and the input normalisation is fused with the NCHW->NHWC4 repack; "aten": plain torch modules
+    (used by the CPU oracle and for A/B comparisons)."""
+
+    def __init__(self, pretrain="res18", if_4c=False, conv_impl="aten"):
         super().__init__()
         self.mmpool = MMPool((1, 1))
-        self.encoder1 = Resnet_4C(pretrain, if_4c=if_4c)
+        self.conv_impl = conv_impl
+        self.encoder1 = Resnet_4C(pretrain, if_4c=if_4c, conv_impl=conv_impl)
         if if_4c:
             raise NotImplementedError("four_channel input is not used by any new_model config")
 
     def forward(self, x):
-        x = normalize_batch_3C(x)
+        if self.conv_impl == "mfma":
+            from . import ops
+            x = ops.image_to_nhwc4(x)
+        else:
+            x = normalize_batch_3C(x)
         low, features = self.encoder1(x)
         features = self.mmpool(features).view(features.shape[0], -1)
         return low, features

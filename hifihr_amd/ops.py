@@ -182,3 +182,64 @@ def render(handle: RendererHandle, verts, vcolors, cam, light_color, light_dir):
     """renderer_p3d(meshes, cameras, lights) + avg_pool2d(aa) (models_res_nimble.py:208-211).
     -> rgba [B,4,H,H], face_id int32 [B,H*aa,H*aa]."""
     return _Render.apply(handle, verts, vcolors, cam, light_color, light_dir)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution on the f32 matrix cores (tensors are logical NCHW in channels_last memory format = physical NHWC)
+# ------------------------------------------------------------------------------------------------
+_CL = torch.channels_last
+
+
+class _Conv2dMFMA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        require_cuda(x, w)
+        lib = get_lib()
+        x = x.contiguous(memory_format=_CL)
+        wk = w.contiguous(memory_format=_CL)                      # physical [K][R][S][C]
+        N, C, H, W = x.shape
+        K, Cw, R, S = wk.shape
+        assert Cw == C and C % 4 == 0, (x.shape, w.shape)
+        OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
+        PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, None, y, N, H, W, C, K, R, S, stride, pad))
+        ctx.geom = (N, H, W, C, K, R, S, stride, pad)
+        ctx.save_for_backward(x, wk)
+        ctx.w_param = w
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wk = ctx.saved_tensors
+        lib = get_lib()
+        N, H, W, C, K, R, S, stride, pad = ctx.geom
+        gy = gy.contiguous(memory_format=_CL)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=_CL)
+            scratch = torch.empty(wk.numel(), device=x.device, dtype=torch.float32)
+            PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data(gy, wk, dx, scratch, N, H, W, C, K, R, S, stride, pad))
+        if ctx.needs_input_grad[1]:
+            w = ctx.w_param
+            tgt = w.grad if (getattr(w, "_hifihr_direct_grad", False) and w.grad is not None
+                             and w.grad.is_contiguous(memory_format=_CL)) else None
+            if tgt is None:
+                dw = torch.zeros_like(wk, memory_format=_CL)
+                tgt = dw
+            # accumulates (fp32 atomics) straight into the flat gradient buffer when the parameter lives in one
+            PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, tgt, N, H, W, C, K, R, S, stride, pad))
+        return dx, dw, None, None
+
+
+def conv2d(x, w, stride=1, pad=0):
+    """F.conv2d(x, w, None, stride, pad) for channels_last fp32 tensors (reference network/res_encoder.py:364-373)."""
+    return _Conv2dMFMA.apply(x, w, stride, pad)
+
+
+def image_to_nhwc4(images):
+    """normalize_batch_3C + repack: [B,3,H,W] -> logical [B,4,H,W] channels_last (4th channel zero)."""
+    require_cuda(images)
+    B, _, H, W = images.shape
+    out = torch.empty((B, 4, H, W), device=images.device, dtype=torch.float32, memory_format=_CL)
+    get_lib().image_to_nhwc4(images.contiguous(), out)
+    return out

@@ -30,16 +30,29 @@ class FlatParams:
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         for p, o in zip(self.params, self.offsets):
-            n = p.numel()
-            self.flat[o:o + n].copy_(p.data.reshape(-1))
-            p.data = self.flat[o:o + n].view_as(p)
-            p.grad = self.grad[o:o + n].view_as(p)
+            p.data = self._view(self.flat, p, o, init=p.data)
+            p.grad = self._view(self.grad, p, o)
+            p._hifihr_direct_grad = True          # kernels may accumulate straight into this (pre-zeroed) buffer
+
+    @staticmethod
+    def _view(buf, p, o, init=None):
+        """A view of buf[o:o+n] with p's logical shape; conv weights kept in channels_last (physical [K][R][S][C]) stay so."""
+        n = p.numel()
+        seg = buf[o:o + n]
+        if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
+            K, C, R, S = p.shape
+            v = seg.view(K, R, S, C).permute(0, 3, 1, 2)
+        else:
+            v = seg.view(p.shape)
+        if init is not None:
+            v.copy_(init)
+        return v
 
     def zero_grad(self):
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):                # re-pin (a None grad would detach the view)
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].view_as(p)
+                p.grad = self._view(self.grad, p, o)
 
     def param_count(self):
         return sum(p.numel() for p in self.params)

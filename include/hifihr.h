@@ -128,6 +128,25 @@ int hifihr_adam_step(float* params_d, const float* grads_d, float* exp_avg_d, fl
                      float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * NHWC fp32 convolution on the f32 matrix cores (implicit GEMM, exact fp32 accumulate).
+ * Replaces the cuDNN/MIOpen dispatches of the encoder's nn.Conv2d layers (forward, backward-data,
+ * backward-weight): reference network/res_encoder.py:364-373 (ResNet trunk built at :345-362).
+ * Layouts: x[N][H][W][C], w[K][R][S][C] (= a torch [K,C,R,S] tensor in channels_last memory format),
+ * y[N][OH][OW][K] with OH = (H + 2 pad - R)/stride + 1.  C (and K for the backward calls) % 4 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_conv2d_fwd(const float* x_d, const float* w_d, const float* bias_d /* [K] or NULL */, float* y_d, int N, int H,
+                      int W, int C, int K, int R, int S, int stride, int pad, void* stream);
+/* dx[N][H][W][C] (overwritten).  wt_scratch_d: K*R*S*C floats of scratch (receives the [C][R][S][K] transpose). */
+int hifihr_conv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, float* wt_scratch_d, int N, int H, int W, int C,
+                           int K, int R, int S, int stride, int pad, void* stream);
+/* dw[K][R][S][C] += sum over pixels (ACCUMULATES with fp32 atomics: zero it, or pass the gradient buffer). */
+int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int K, int R, int S,
+                             int stride, int pad, void* stream);
+/* normalize_batch_3C (reference network/res_encoder.py:212-216) fused with NCHW[B][3][H][W] -> NHWC4 [B][H][W][4]
+ * (4th channel zero) for the first convolution. */
+int hifihr_image_to_nhwc4(const float* images_d, float* out_d, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,7 @@ uint32_t wave_exchange(uint32_t v, int src_lane);                 // value of sr
 unsigned long long wave_ballot(bool p);
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
 int lane_id();
+void wave_gather2(float a, float b, float* A64, float* B64);      // every lane's (a, b), lane-indexed
 }  // namespace hostsim
 
 #define threadIdx (::hostsim::cur().tid)
@@ -144,6 +145,24 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+
+// ---- MFMA emulation (exact: the hardware result is a k-ordered fmaf chain, cdna_hip_programming.md section 3) ----
+typedef float hs_floatx16 __attribute__((vector_size(64)));
+typedef float hs_floatx4 __attribute__((vector_size(16)));
+static inline hs_floatx16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hs_floatx16 c, int, int, int) {
+  float A[64], B[64];
+  ::hostsim::wave_gather2(a, b, A, B);
+  const int l = ::hostsim::lane_id();
+  const int j = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float d = c[r];
+    d = fmaf(A[i], B[j], d);                 // k = 0: A[i][0] from lane i, B[0][j] from lane j
+    d = fmaf(A[i + 32], B[j + 32], d);       // k = 1
+    c[r] = d;
+  }
+  return c;
+}
 
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
   ::hostsim::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })

@@ -25,6 +25,7 @@ struct Wave {
   int arrived = 0;
   unsigned gen = 0;
   uint32_t slot[64];
+  float fa[64], fb[64];
   unsigned long long ballot_acc = 0, ballot_res = 0;
 };
 
@@ -77,6 +78,16 @@ uint32_t wave_exchange(uint32_t v, int src_lane) {
   const uint32_t r = (src_lane >= 0 && src_lane < 64) ? wv.slot[src_lane] : v;
   wave_barrier(wv);
   return r;
+}
+
+void wave_gather2(float a, float b, float* A64, float* B64) {
+  Fiber* f = tw->cur;
+  Wave& wv = tw->waves[f->wave];
+  wv.fa[f->lane] = a;
+  wv.fb[f->lane] = b;
+  wave_barrier(wv);
+  for (int i = 0; i < 64; ++i) { A64[i] = wv.fa[i]; B64[i] = wv.fb[i]; }
+  wave_barrier(wv);
 }
 
 unsigned long long wave_ballot(bool p) {

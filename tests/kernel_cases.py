@@ -169,3 +169,48 @@ def adam_case(lib, device, n, wd, steps, grad_scale=0.5, lr=1e-3):
         opt.step()
         lib.adam_step(p, g.to(device), m, v, grad_scale, lr, 0.9, 0.999, 1e-8, wd, s)
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution (NHWC implicit GEMM on the f32 matrix cores) vs plain PyTorch fp32 conv2d
+# ------------------------------------------------------------------------------------------------
+def conv_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0, bias=False, rtol=2e-5):
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=gen)
+    w = torch.randn(K, C, R, R, generator=gen) / (C * R * R) ** 0.5
+    b = torch.randn(K, generator=gen) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, b, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    OH, OW = y.shape[2], y.shape[3]
+    d = lambda t: t.to(device).contiguous()
+    x_nhwc = d(x.permute(0, 2, 3, 1)); w_krsc = d(w.permute(0, 2, 3, 1)); gy_nhwc = d(gy.permute(0, 2, 3, 1))
+    out = torch.empty(N, OH, OW, K, device=device)
+    lib.conv2d_fwd(x_nhwc, w_krsc, d(b) if bias else None, out, N, H, W, C, K, R, R, stride, pad)
+    ref = y.detach().permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    assert float((out.cpu() - ref).abs().max()) <= rtol * scale + 1e-6, "conv fwd"
+    dx = torch.empty(N, H, W, C, device=device)
+    scratch = torch.empty(K * R * R * C, device=device)
+    lib.conv2d_bwd_data(gy_nhwc, w_krsc, dx, scratch, N, H, W, C, K, R, R, stride, pad)
+    refx = xr.grad.permute(0, 2, 3, 1)
+    assert float((dx.cpu() - refx).abs().max()) <= rtol * float(refx.abs().max()) + 1e-6, "conv bwd data"
+    dw = torch.zeros(K, R, R, C, device=device)
+    lib.conv2d_bwd_weight(x_nhwc, gy_nhwc, dw, N, H, W, C, K, R, R, stride, pad)
+    refw = wr.grad.permute(0, 2, 3, 1)
+    assert float((dw.cpu() - refw).abs().max()) <= 5 * rtol * float(refw.abs().max()) + 1e-6, "conv bwd weight"
+    # accumulation semantics: a second call adds
+    lib.conv2d_bwd_weight(x_nhwc, gy_nhwc, dw, N, H, W, C, K, R, R, stride, pad)
+    assert float((dw.cpu() - 2 * refw).abs().max()) <= 1e-4 * float(refw.abs().max()) + 1e-6, "conv bwd weight accumulate"
+
+
+def image_to_nhwc4_case(lib, device):
+    from hifihr_amd.network import normalize_batch_3C
+    img = torch.rand(3, 3, 20, 12)
+    out = torch.empty(3, 20, 12, 4, device=device)
+    lib.image_to_nhwc4(img.to(device), out)
+    ref = normalize_batch_3C(img).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(out.cpu()[..., :3].numpy(), ref.numpy(), atol=1e-6)
+    assert float(out.cpu()[..., 3].abs().max()) == 0.0

@@ -1,0 +1,62 @@
+"""GPU parity: MFMA implicit-GEMM convolution through the C ABI vs plain PyTorch fp32 conv2d (CPU), on every
+distinct (Cin,Cout,k,stride,HW) shape of the modified ResNet-18 plus edge cases."""
+import pytest
+import torch
+
+import kernel_cases as kc
+
+pytestmark = pytest.mark.gpu
+
+# (H_in, C, K, R, stride, pad) of ResNet-18 with layer4 strides forced to 1, at 224x224 input
+RESNET18_SHAPES = [(224, 4, 64, 7, 2, 3), (56, 64, 64, 3, 1, 1), (56, 64, 128, 3, 2, 1), (28, 128, 128, 3, 1, 1),
+                   (56, 64, 128, 1, 2, 0), (28, 128, 256, 3, 2, 1), (14, 256, 256, 3, 1, 1), (28, 128, 256, 1, 2, 0),
+                   (14, 256, 512, 3, 1, 1), (14, 512, 512, 3, 1, 1), (14, 256, 512, 1, 1, 0)]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hifihr_amd._lib import get_lib
+    assert torch.cuda.is_available()
+    return get_lib()
+
+
+@pytest.mark.parametrize("shape", RESNET18_SHAPES)
+def test_resnet18_conv_shapes(lib, shape):
+    H, C, K, R, s, p = shape
+    kc.conv_case(lib, "cuda", 4, H, H, C, K, R, s, p, seed=H + C, rtol=3e-5)
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(3, 9, 7, 16, 64, 3, 1, 1), (1, 6, 6, 48, 20, 3, 1, 0), (32, 14, 14, 512, 512, 3, 1, 1)])
+def test_conv_edge_and_full_batch(lib, N, H, W, C, K, R, stride, pad):
+    kc.conv_case(lib, "cuda", N, H, W, C, K, R, stride, pad, seed=1, bias=(K == 20), rtol=5e-5)
+
+
+def test_image_to_nhwc4(lib):
+    kc.image_to_nhwc4_case(lib, "cuda")
+
+
+def test_resnet18_trunk_mfma_vs_reference_golden(golden_dir):
+    """The trunk running on the hand-written MFMA convolutions reproduces the reference's vendored ResNet-18 (with the
+    layer4 stride edits) forward and backward from name-seeded weights -- same fixture as the CPU test."""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from seeded_init import seeded_state_dict
+    from hifihr_amd import ops
+    from hifihr_amd.network import ResNet18Trunk
+    g = np.load(os.path.join(golden_dir, "resnet18_small.npz"))
+    net = ResNet18Trunk(layer4_stride=1, conv_impl="mfma")
+    net.load_state_dict(seeded_state_dict(net))
+    net = net.cuda().train()
+    x = ops.image_to_nhwc4(torch.tensor(g["x"]).cuda())
+    h = net.maxpool(net.relu(net.bn1(net.conv1(x))))
+    low = net.layer2(net.layer1(h))
+    feat = net.layer4(net.layer3(low))
+    np.testing.assert_allclose(low.detach().cpu().numpy(), g["low"], atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), g["feat"], atol=5e-5, rtol=1e-4)
+    ((low * torch.tensor(g["wl"]).cuda()).sum() + (feat * torch.tensor(g["wf"]).cuda()).sum()).backward()
+    for key, grad in (("g_conv1", net.conv1.weight.grad), ("g_bn1", net.bn1.weight.grad),
+                      ("g_l4c2", net.layer4[1].conv2.weight.grad[:8]), ("g_l2ds", net.layer2[0].downsample[0].weight.grad)):
+        ref = g[key]
+        err = np.abs(grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 5e-3, (key, err)

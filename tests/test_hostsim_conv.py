@@ -1,0 +1,24 @@
+"""MFMA implicit-GEMM conv kernel SOURCES on the hostsim emulator (exact MFMA emulation) vs torch conv2d."""
+import pytest
+
+import kernel_cases as kc
+
+
+@pytest.fixture(scope="module")
+def hostsim_lib():
+    return kc.build_hostsim()
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [
+    (2, 9, 7, 16, 64, 3, 1, 1),     # 3x3 s1, ragged M (126 rows), 64x64 tile path
+    (1, 12, 12, 32, 128, 3, 2, 1),  # 3x3 s2 (dgrad divisibility path)
+    (2, 8, 8, 64, 128, 1, 2, 0),    # 1x1 s2 downsample
+    (1, 16, 16, 4, 64, 7, 2, 3),    # conv1 shape: C = 4 (NHWC4), Q = 196 not a multiple of 16
+    (1, 6, 6, 48, 20, 3, 1, 0),     # K not a multiple of 64, no padding, bias
+])
+def test_conv_fwd_bwd(hostsim_lib, N, H, W, C, K, R, stride, pad):
+    kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, seed=H, bias=(K == 20))
+
+
+def test_image_to_nhwc4(hostsim_lib):
+    kc.image_to_nhwc4_case(hostsim_lib, "cpu")
