@@ -28,7 +28,8 @@ def _fp(t):
     """Device (or host) pointer of a contiguous fp32 tensor, or NULL for None."""
     if t is None:
         return None
-    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    dense = t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+    assert t.dtype == torch.float32 and dense, (t.dtype, t.shape, t.stride())
     return ctypes.cast(t.data_ptr(), _c_float_p)
 
 
@@ -75,6 +76,11 @@ class HifihrLib:
         c = self.c
         c.hifihr_renderer_create.argtypes = [POINTER(c_void_p), _c_int_p, c_int, c_int, c_int, c_int, _c_float_p, _c_float_p,
                                              _c_float_p, c_float, _c_float_p]
+        c.hifihr_ssim_partial_count.argtypes = [c_int, c_int, c_int]
+        c.hifihr_ssim_partial_count.restype = c_int
+        c.hifihr_ssim_fwd.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_float_p, _c_float_p,
+                                      _c_float_p, c_void_p]
+        c.hifihr_ssim_bwd.argtypes = [_c_float_p] * 7 + [c_int, c_int, c_int, _c_float_p, c_void_p]
         ci = [c_int] * 9
         c.hifihr_conv2d_fwd.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
         c.hifihr_conv2d_bwd_data.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
@@ -144,6 +150,20 @@ class HifihrLib:
     def image_to_nhwc4(self, images, out):
         B, _, H, W = images.shape
         self.check(self.c.hifihr_image_to_nhwc4(_fp(images), _fp(out), B, H, W, _stream_of(images)), "hifihr_image_to_nhwc4")
+
+    # ---- SSIM ----------------------------------------------------------
+    def ssim_partial_count(self, planes, H, W):
+        return int(self.c.hifihr_ssim_partial_count(planes, H, W))
+
+    def ssim_fwd(self, window, img1, img2, partial, dA, dB, dC):
+        planes, H, W = img1.shape[0] * img1.shape[1], img1.shape[2], img1.shape[3]
+        self.check(self.c.hifihr_ssim_fwd(window, _fp(img1), _fp(img2), planes, H, W, _fp(partial), _fp(dA), _fp(dB), _fp(dC),
+                                          _stream_of(img1)), "hifihr_ssim_fwd")
+
+    def ssim_bwd(self, window, img1, img2, dA, dB, dC, grad_out, gimg1):
+        planes, H, W = img1.shape[0] * img1.shape[1], img1.shape[2], img1.shape[3]
+        self.check(self.c.hifihr_ssim_bwd(window, _fp(img1), _fp(img2), _fp(dA), _fp(dB), _fp(dC), _fp(grad_out), planes, H, W,
+                                          _fp(gimg1), _stream_of(img1)), "hifihr_ssim_bwd")
 
     # ---- optimizer ---------------------------------------------------
     def adam_step(self, p, g, m, v, grad_scale, lr, beta1, beta2, eps, weight_decay, step):

@@ -278,4 +278,30 @@ int hifihr_image_to_nhwc4(const float* images, float* out, int B, int H, int W, 
   return HIFIHR_OK;
 }
 
+int hifihr_ssim_partial_count(int planes, int H, int W) {
+  if (planes <= 0 || H <= 0 || W <= 0) return 0;
+  return planes * ((H + 15) / 16) * ((W + 15) / 16);
+}
+
+int hifihr_ssim_fwd(const float* window11, const float* img1, const float* img2, int planes, int H, int W, float* partial,
+                    float* dA, float* dB, float* dC, void* stream) {
+  if (!window11 || !img1 || !img2 || !partial || planes <= 0 || H <= 0 || W <= 0 || ((dA != nullptr) != (dB != nullptr)) ||
+      ((dA != nullptr) != (dC != nullptr)))
+    return fail(HIFIHR_EINVAL, "hifihr_ssim_fwd: bad argument");
+  hifihr::SsimWindow win;
+  for (int k = 0; k < 11; ++k) win.g[k] = window11[k];
+  HIP_TRY(hifihr::launch_ssim_fwd(win, img1, img2, planes, H, W, partial, dA, dB, dC, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_ssim_bwd(const float* window11, const float* img1, const float* img2, const float* dA, const float* dB, const float* dC,
+                    const float* grad_out, int planes, int H, int W, float* gimg1, void* stream) {
+  if (!window11 || !img1 || !img2 || !dA || !dB || !dC || !grad_out || !gimg1 || planes <= 0 || H <= 0 || W <= 0)
+    return fail(HIFIHR_EINVAL, "hifihr_ssim_bwd: bad argument");
+  hifihr::SsimWindow win;
+  for (int k = 0; k < 11; ++k) win.g[k] = window11[k];
+  HIP_TRY(hifihr::launch_ssim_bwd(win, img1, img2, dA, dB, dC, grad_out, planes, H, W, gimg1, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 }  // extern "C"

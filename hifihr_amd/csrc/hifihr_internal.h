@@ -60,6 +60,14 @@ hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy,
 hipError_t launch_weight_transpose(const float* w, float* wt, int K, int RS, int C, hipStream_t st);
 hipError_t launch_image_to_nhwc4(const float* img, float* out, int B, int HW, hipStream_t st);
 
+struct SsimWindow {
+  float g[11];      // normalised 1-D gaussian (sigma 1.5), as pytorch_ssim.gaussian builds it
+};
+hipError_t launch_ssim_fwd(const SsimWindow& win, const float* img1, const float* img2, int planes, int H, int W, float* partial,
+                           float* dA, float* dB, float* dC, hipStream_t st);
+hipError_t launch_ssim_bwd(const SsimWindow& win, const float* img1, const float* img2, const float* dA, const float* dB,
+                           const float* dC, const float* gscale, int planes, int H, int W, float* gimg1, hipStream_t st);
+
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, hipStream_t st);
 

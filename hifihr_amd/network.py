@@ -165,7 +165,7 @@ class ResEncoder(nn.Module):
         else:
             x = normalize_batch_3C(x)
         low, features = self.encoder1(x)
-        features = self.mmpool(features).view(features.shape[0], -1)
+        features = self.mmpool(features).reshape(features.shape[0], -1)
         return low, features
 
 
@@ -231,6 +231,6 @@ class LightEstimator(nn.Module):
 
     def forward(self, low_features):
         base = self.base_layers(low_features)
-        lights = self.light_reg(base.view(base.shape[0], -1))
+        lights = self.light_reg(base.reshape(base.shape[0], -1))
         # the reference checks `torch.any(colors.isnan())` here with a host sync every step (:205); omitted on purpose
         return {"colors": self.hardtanh(lights[:, :3]), "directions": lights[:, 3:]}

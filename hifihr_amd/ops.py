@@ -243,3 +243,54 @@ def image_to_nhwc4(images):
     out = torch.empty((B, 4, H, W), device=images.device, dtype=torch.float32, memory_format=_CL)
     get_lib().image_to_nhwc4(images.contiguous(), out)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# fused SSIM
+# ------------------------------------------------------------------------------------------------
+def _ssim_window():
+    """The 1-D window exactly as pytorch_ssim.gaussian(11, 1.5) builds it (float32 tensor ops), as a ctypes array."""
+    import ctypes
+    import math
+    g = torch.Tensor([math.exp(-(x - 11 // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)])
+    g = g / g.sum()
+    return (ctypes.c_float * 11)(*[float(v) for v in g])
+
+
+_SSIM_WIN = None
+
+
+class _SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2):
+        global _SSIM_WIN
+        require_cuda(img1, img2)
+        lib = get_lib()
+        if _SSIM_WIN is None:
+            _SSIM_WIN = _ssim_window()
+        img1, img2 = img1.contiguous(), img2.contiguous()
+        B, C, H, W = img1.shape
+        need = ctx.needs_input_grad[0]
+        partial = torch.empty(lib.ssim_partial_count(B * C, H, W), device=img1.device)
+        maps = torch.empty(3, B, C, H, W, device=img1.device) if need else None
+        PROFILE.bracket("ssim_fwd", lambda: lib.ssim_fwd(_SSIM_WIN, img1, img2, partial, maps[0] if need else None,
+                                                          maps[1] if need else None, maps[2] if need else None))
+        if need:
+            ctx.save_for_backward(img1, img2, maps)
+        return partial.sum() / float(B * C * H * W)
+
+    @staticmethod
+    def backward(ctx, g):
+        img1, img2, maps = ctx.saved_tensors
+        gimg1 = torch.empty_like(img1)
+        gs = g.reshape(1).contiguous().float()
+        PROFILE.bracket("ssim_bwd", lambda: get_lib().ssim_bwd(_SSIM_WIN, img1, img2, maps[0], maps[1], maps[2], gs, gimg1))
+        return gimg1, None
+
+
+def ssim(img1, img2):
+    """pytorch_ssim.ssim(img1, img2) (reference utils/pytorch_ssim/__init__.py:65-73); gradient flows to img1 only
+    (img2 is ground-truth data at the reference's call site, losses.py:375)."""
+    if img2.requires_grad:
+        raise NotImplementedError("fused SSIM differentiates with respect to img1 only")
+    return _SSIM.apply(img1, img2)

@@ -147,6 +147,22 @@ int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, i
  * (4th channel zero) for the first convolution. */
 int hifihr_image_to_nhwc4(const float* images_d, float* out_d, int B, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused SSIM (11x11 gaussian window sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements).
+ * Replaces pytorch_ssim.ssim(img1, img2)   reference utils/pytorch_ssim/__init__.py:17-37,65-73
+ * (called at reference losses.py:375 for the ssim_tex term) and its autograd w.r.t. img1.
+ * img1/img2: [planes][H][W] with planes = B*C (contiguous NCHW); window11_h: the 11 normalised taps (HOST).
+ * fwd writes one partial sum per 16x16 tile: SSIM = sum(partial[0..hifihr_ssim_partial_count)) / (planes*H*W)
+ * (summed by the caller; deterministic).  dA/dB/dC ([planes][H][W] each, all three or none) receive the
+ * derivative maps the backward call consumes.  bwd: gimg1 = grad_out[0] * d mean(SSIM) / d img1; grad_out_d is
+ * a DEVICE scalar (no host sync).
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_ssim_partial_count(int planes, int H, int W);
+int hifihr_ssim_fwd(const float* window11_h, const float* img1_d, const float* img2_d, int planes, int H, int W,
+                    float* partial_d, float* dA_d, float* dB_d, float* dC_d, void* stream);
+int hifihr_ssim_bwd(const float* window11_h, const float* img1_d, const float* img2_d, const float* dA_d, const float* dB_d,
+                    const float* dC_d, const float* grad_out_d, int planes, int H, int W, float* gimg1_d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

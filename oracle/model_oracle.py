@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from hifihr_amd.losses import LossFunction
+from hifihr_amd.losses import LossFunction, ssim_torch
 from hifihr_amd.network import HandEncoder, LightEstimator, ResEncoder
 from hifihr_amd.traineval import trans_proj_j2d
 from oracle import mano_oracle as mo
@@ -66,7 +66,7 @@ def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None, fe
     ex["joints"] = examples_cpu["joints"] - root_xyz
     ex["verts"] = examples_cpu["verts"] - root_xyz
     outputs["j2d"] = trans_proj_j2d(outputs, examples_cpu["Ks"], root_xyz=root_xyz)
-    loss_dic = LossFunction()(ex, outputs, args.losses, "FreiHand", args)
+    loss_dic = LossFunction(ssim_fn=ssim_torch)(ex, outputs, args.losses, "FreiHand", args)
     loss = sum(loss_dic[k] for k in args.losses)
     if optimizer is not None:
         optimizer.zero_grad()

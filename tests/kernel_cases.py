@@ -214,3 +214,30 @@ def image_to_nhwc4_case(lib, device):
     ref = normalize_batch_3C(img).permute(0, 2, 3, 1)
     np.testing.assert_allclose(out.cpu()[..., :3].numpy(), ref.numpy(), atol=1e-6)
     assert float(out.cpu()[..., 3].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# fused SSIM vs vectors produced by the reference's utils/pytorch_ssim (tests/golden/ssim.npz) and vs the
+# torch restatement in hifihr_amd/losses.py (itself pinned to the same vectors on the CPU)
+# ------------------------------------------------------------------------------------------------
+def ssim_case(lib, device, a, b, ref_val=None, ref_grad=None):
+    from hifihr_amd import losses as L
+    from hifihr_amd.ops import _ssim_window
+    win = _ssim_window()
+    a_t, b_t = torch.as_tensor(a), torch.as_tensor(b)
+    if ref_val is None:
+        ar = a_t.clone().requires_grad_(True)
+        v = L.ssim(ar, b_t)
+        v.backward()
+        ref_val, ref_grad = float(v), ar.grad.numpy()
+    B, C, H, W = a_t.shape
+    da, db = a_t.to(device).contiguous(), b_t.to(device).contiguous()
+    partial = torch.empty(lib.ssim_partial_count(B * C, H, W), device=device)
+    maps = torch.empty(3, B, C, H, W, device=device)
+    lib.ssim_fwd(win, da, db, partial, maps[0], maps[1], maps[2])
+    val = float(partial.sum()) / (B * C * H * W)
+    assert abs(val - float(ref_val)) <= 2e-6 * max(1.0, abs(float(ref_val))), (val, float(ref_val))
+    g = torch.empty_like(da)
+    lib.ssim_bwd(win, da, db, maps[0], maps[1], maps[2], torch.full((1,), 2.0, device=device), g)
+    ref = 2.0 * np.asarray(ref_grad)
+    assert np.abs(g.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-10

@@ -121,3 +121,28 @@ def test_adam_kernel_vs_torch():
     from hifihr_amd._lib import get_lib
     kc.adam_case(get_lib(), "cuda", n=12_600_003, wd=0.0, steps=3)
     kc.adam_case(get_lib(), "cuda", n=1003, wd=0.01, steps=3)
+
+
+def test_ssim_kernel_full_size(golden_dir):
+    """Fused SSIM at the BASELINE size (32x3x224x224) vs the torch restatement, and vs the reference's own scalar for
+    the seeded 2x3x224x224 pair of tests/golden/ssim.npz."""
+    import os
+    from hifihr_amd import ops
+    from hifihr_amd._lib import get_lib
+    from hifihr_amd.losses import ssim_torch
+    g = np.load(os.path.join(golden_dir, "ssim.npz"))
+    kc.ssim_case(get_lib(), "cuda", g["a"], g["b"], g["ssim"], g["ga"])
+    gen = torch.Generator().manual_seed(12)
+    A = torch.rand(2, 3, 224, 224, generator=gen); B = torch.rand(2, 3, 224, 224, generator=gen)
+    assert abs(float(ops.ssim(A.cuda(), B.cuda())) - float(g["ssim224"])) < 2e-6
+    gen = torch.Generator().manual_seed(3)
+    a = torch.rand(32, 3, 224, 224, generator=gen)
+    b = (a * (torch.rand(32, 1, 224, 224, generator=gen) > 0.7)).contiguous()
+    ac = a.cuda().requires_grad_(True)
+    v = ops.ssim(ac, b.cuda())
+    v.backward()
+    ar = a.cuda().requires_grad_(True)
+    vr = ssim_torch(ar, b.cuda())
+    vr.backward()
+    assert abs(float(v) - float(vr)) < 5e-6
+    assert float((ac.grad - ar.grad).abs().max()) <= 5e-4 * float(ar.grad.abs().max())
