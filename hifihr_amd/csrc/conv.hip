@@ -17,6 +17,8 @@
 //                              NCHW(3) -> NHWC(4, zero padded) repack the first convolution consumes.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "hifihr_internal.h"
 
 namespace hifihr {
@@ -27,10 +29,54 @@ typedef hs_floatx16 floatx16;
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 #endif
 
+#if defined(HIFIHR_HOSTSIM)
+#define HIFIHR_KEEP(x) ((void)0)
+#define HIFIHR_SCHED_FENCE() ((void)0)
+#else
+// nothing may be scheduled across this point (keeps the masked LDS stores of the prefetched chunk, and therefore
+// their vmcnt wait, BEHIND the MFMA block that hides the load latency)
+#define HIFIHR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define HIFIHR_KEEP(x) asm volatile("" : "+v"(x))
+#endif
+
 constexpr int kBK = 16;     // K-chunk depth (8 MFMA k-steps of 2)
 constexpr int kLD = 20;     // LDS row stride in floats (80 B: ds_read_b128 conflict-free, 16-B aligned)
 
-template <int BM, int BN>
+// How one launch (or one parity class of a strided dgrad launch) walks rows and taps.
+//   forward : rows = output pixels, tap j reads src row  oy*stride - pad + j
+//   dgrad   : rows = the input pixels of parity class (ph, pw) = (oy*st + ph, ox*st + pw); only taps
+//             r = r0 + st*j with r0 = (ph + pad) % st can contribute, and they read dy row  oy + aof - j  with
+//             no divisibility test left in the loop (a stride-2 3x3 dgrad does 1/4 of the naive MFMA work).
+struct GatherPlan {
+  int OHs, OWs;            // row sub-grid
+  int dmul, dofh, dofw;    // dst pixel = (oy*dmul + dofh, ox*dmul + dofw)
+  int amul, aofh, aofw;    // src base  = oy*amul + aofh
+  int nr, ns, r0, s0, rstep, sign;
+};
+
+__device__ __forceinline__ GatherPlan make_plan(const ConvGeom& g, int cls) {
+  GatherPlan p;
+  if (!g.dgrad) {
+    p.OHs = g.OH; p.OWs = g.OW; p.dmul = 1; p.dofh = 0; p.dofw = 0; p.amul = g.stride; p.aofh = -g.pad; p.aofw = -g.pad;
+    p.nr = g.R; p.ns = g.S; p.r0 = 0; p.s0 = 0; p.rstep = 1; p.sign = 1;
+  } else {
+    const int st = g.stride, ph = cls / st, pw = cls % st;
+    p.OHs = (g.OH - ph + st - 1) / st; p.OWs = (g.OW - pw + st - 1) / st;
+    if (p.OHs < 0) p.OHs = 0;
+    if (p.OWs < 0) p.OWs = 0;
+    p.dmul = st; p.dofh = ph; p.dofw = pw; p.amul = 1;
+    p.r0 = (ph + g.pad) % st; p.s0 = (pw + g.pad) % st;
+    p.nr = (p.r0 < g.R) ? (g.R - p.r0 + st - 1) / st : 0;
+    p.ns = (p.s0 < g.S) ? (g.S - p.s0 + st - 1) / st : 0;
+    p.aofh = (ph + g.pad - p.r0) / st; p.aofw = (pw + g.pad - p.s0) / st;
+    p.rstep = st; p.sign = -1;
+  }
+  return p;
+}
+
+// GENERIC = false requires IC % 16 == 0 (a 16-deep K chunk never straddles a tap: tap bookkeeping is scalar and
+// division-free).  GENERIC = true (forward only) handles any IC % 4 == 0 with per-chunk divisions (the 4-channel stem).
+template <int BM, int BN, bool GENERIC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float* __restrict__ src,
                                                         const float* __restrict__ wgt, const float* __restrict__ bias,
                                                         float* __restrict__ dst) {
@@ -40,63 +86,71 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, r31 = lane & 31;
-  const int M = g.N * g.OH * g.OW;
-  const int Q = g.R * g.S * g.IC;
+  const GatherPlan P = make_plan(g, blockIdx.z);
+  const int M = g.N * P.OHs * P.OWs;
   const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  if (bm0 >= M) return;                           // parity classes can be smaller than the launch grid
+  const int Qw = g.R * g.S * g.IC;                // row length of the weight matrix
   const int lrow = tid >> 2, seg = (tid & 3) * 4;
 
   // per-thread row bookkeeping for the gather (constant over the K loop)
-  int a_n[TM], a_h[TM], a_w[TM];
+  size_t a_base[TM];
+  int a_h[TM], a_w[TM];
   bool a_ok[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = bm0 + lrow + 64 * i;
     a_ok[i] = m < M;
     const int mm = a_ok[i] ? m : 0;
-    const int n = mm / (g.OH * g.OW);
-    const int rem = mm - n * (g.OH * g.OW);
-    const int oh = rem / g.OW, ow = rem - oh * g.OW;
-    a_n[i] = n;
-    a_h[i] = g.dgrad ? oh + g.pad : oh * g.stride - g.pad;
-    a_w[i] = g.dgrad ? ow + g.pad : ow * g.stride - g.pad;
+    const int n = mm / (P.OHs * P.OWs);
+    const int rem = mm - n * (P.OHs * P.OWs);
+    const int oy = rem / P.OWs, ox = rem - oy * P.OWs;
+    a_base[i] = (size_t)n * g.IH * g.IW * g.IC;
+    a_h[i] = oy * P.amul + P.aofh;
+    a_w[i] = ox * P.amul + P.aofw;
   }
 
+  const int nch = GENERIC ? (Qw + kBK - 1) / kBK : P.nr * P.ns * (g.IC / kBK);
+  int jr = 0, js = 0, c0 = 0, qgen = 0;           // tap state of the NEXT chunk to load
+
   float4 ra[TM], rb[TN];
-  auto load_global = [&](int q0) {
-    const int q = q0 + seg;
-    int r = 0, s = 0, c = 0;
-    const bool qok = q < Q;
-    if (qok) {
-      const int t = q / g.IC;
-      c = q - t * g.IC;
-      r = t / g.S;
-      s = t - r * g.S;
+  bool va[TM], vb[TN];
+  auto load_global = [&]() {
+    int dr, ds, c, wq;
+    bool qok = true;
+    if (GENERIC) {
+      const int q = qgen + seg;
+      qok = q < Qw;
+      const int t = qok ? q / g.IC : 0;
+      c = qok ? q - t * g.IC : 0;
+      dr = t / g.S; ds = t - dr * g.S;
+      wq = q;
+      qgen += kBK;
+    } else {
+      qok = jr < P.nr;                       // false only for the (masked) prefetch issued by the last iteration
+      dr = jr; ds = js; c = c0 + seg;
+      wq = ((P.r0 + P.rstep * jr) * g.S + (P.s0 + P.rstep * js)) * g.IC + c;
+      c0 += kBK;
+      if (c0 >= g.IC) { c0 = 0; if (++js == P.ns) { js = 0; ++jr; } }
     }
+    // Loads are UNCONDITIONAL (out-of-range taps read a clamped, valid address) and masked when they are written to
+    // LDS after the MFMA block: a load inside a branch makes the compiler wait for it right there, which exposes
+    // the full memory latency in every K chunk.
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (qok && a_ok[i]) {
-        int ih, iw;
-        bool ok;
-        if (g.dgrad) {
-          const int th = a_h[i] - r, tw = a_w[i] - s;
-          ok = (th >= 0) && (tw >= 0) && (th % g.stride == 0) && (tw % g.stride == 0);
-          ih = th / g.stride; iw = tw / g.stride;
-          ok = ok && (ih < g.IH) && (iw < g.IW);
-        } else {
-          ih = a_h[i] + r; iw = a_w[i] + s;
-          ok = (ih >= 0) && (ih < g.IH) && (iw >= 0) && (iw < g.IW);
-        }
-        if (ok) v = *reinterpret_cast<const float4*>(src + (((size_t)a_n[i] * g.IH + ih) * g.IW + iw) * g.IC + c);
-      }
-      ra[i] = v;
+      const int ih = a_h[i] + P.sign * dr, iw = a_w[i] + P.sign * ds;
+      const bool ok = qok && a_ok[i] && ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW;
+      const size_t off = ok ? a_base[i] + ((size_t)ih * g.IW + iw) * g.IC + c : 0;
+      ra[i] = *reinterpret_cast<const float4*>(src + off);
+      va[i] = ok;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int k = bn0 + lrow + 64 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (qok && k < g.OC) v = *reinterpret_cast<const float4*>(wgt + (size_t)k * Q + q);
-      rb[j] = v;
+      const bool ok = qok && k < g.OC;
+      const size_t off = ok ? (size_t)k * Qw + wq : 0;
+      rb[j] = *reinterpret_cast<const float4*>(wgt + off);
+      vb[j] = ok;
     }
   };
   auto store_lds = [&](int buf) {
@@ -104,14 +158,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float* p = &As[buf][(lrow + 64 * i) * kLD];
-      *reinterpret_cast<float2*>(p + seg / 2) = make_float2(ra[i].x, ra[i].z);
-      *reinterpret_cast<float2*>(p + 8 + seg / 2) = make_float2(ra[i].y, ra[i].w);
+      const float4 v = va[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float2*>(p + seg / 2) = make_float2(v.x, v.z);
+      *reinterpret_cast<float2*>(p + 8 + seg / 2) = make_float2(v.y, v.w);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float* p = &Bs[buf][(lrow + 64 * j) * kLD];
-      *reinterpret_cast<float2*>(p + seg / 2) = make_float2(rb[j].x, rb[j].z);
-      *reinterpret_cast<float2*>(p + 8 + seg / 2) = make_float2(rb[j].y, rb[j].w);
+      const float4 v = vb[j] ? rb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float2*>(p + seg / 2) = make_float2(v.x, v.z);
+      *reinterpret_cast<float2*>(p + 8 + seg / 2) = make_float2(v.y, v.w);
     }
   };
 
@@ -123,13 +179,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nch = (Q + kBK - 1) / kBK;
-  load_global(0);
-  store_lds(0);
+  if (nch > 0) {
+    load_global();
+    store_lds(0);
+  }
   __syncthreads();
   for (int ch = 0; ch < nch; ++ch) {
     const int buf = ch & 1;
-    if (ch + 1 < nch) load_global((ch + 1) * kBK);
+    // prefetch the next chunk; issued unconditionally (past the last tap the plan yields masked, clamped loads):
+    // a conditional here turns ra/rb into loop-carried phis whose register copies wait for the load at once
+    load_global();
+    HIFIHR_SCHED_FENCE();                 // loads first, then the whole MFMA block covers their latency
     float a[TM][8], b[TN][8];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -149,23 +209,66 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
-    if (ch + 1 < nch) store_lds(buf ^ 1);
+    HIFIHR_SCHED_FENCE();
+    store_lds(buf ^ 1);
     __syncthreads();
   }
 
-  // epilogue: D[i][j], i = pixel row, j = output channel; lanes 0..31 hold 32 consecutive channels of one row
+  // epilogue: D[i][j], i = pixel row, j = output channel; lanes 0..31 hold 32 consecutive channels of one row, so
+  // every store instruction writes two 128-byte row segments.  The bias is fetched ONCE up front: a load inside the
+  // store loop makes the compiler wait vmcnt(0) per element, which also drains the previous store (16 serialised
+  // round trips per tile).
+  float bv[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) {
+    const int k = bn0 + wn * (BN / 2) + j * 32 + r31;
+    bv[j] = (bias != nullptr && k < g.OC) ? bias[k] : 0.f;
+  }
+  if (P.dmul == 1) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int k = bn0 + wn * (BN / 2) + j * 32 + r31;
-      const float bv = (bias && k < g.OC) ? bias[k] : 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int k = bn0 + wn * (BN / 2) + j * 32 + r31;
+        float* col = dst + k;
+        if (bias != nullptr) {              // uniform; the bias-free path below contains no load at all
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            acc[i][j][e] += bv[j];
+            HIFIHR_KEEP(acc[i][j][e]);      // keep the add (and its one vmcnt wait) out of the per-element branches
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = bm0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (m < M && k < g.OC) col[(size_t)m * g.OC] = acc[i][j][e];
+        }
+      }
+  } else {
+    // parity class of a strided dgrad: scatter rows to the strided destination pixels
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      size_t rowoff[16];
+      bool rok[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = bm0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (m < M && k < g.OC) dst[(size_t)m * g.OC + k] = acc[i][j][e] + bv;
+        rok[e] = m < M;
+        const int mm = rok[e] ? m : 0;
+        const int n = mm / (P.OHs * P.OWs);
+        const int rem = mm - n * (P.OHs * P.OWs);
+        const int oy = rem / P.OWs, ox = rem - oy * P.OWs;
+        rowoff[e] = (((size_t)n * g.OH + (oy * P.dmul + P.dofh)) * g.OW + (ox * P.dmul + P.dofw)) * g.OC;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int k = bn0 + wn * (BN / 2) + j * 32 + r31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (rok[e] && k < g.OC) dst[rowoff[e] + k] = acc[i][j][e];
       }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -208,36 +311,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float
     qs = t - qr * g.S;
   }
   float4 ra[AL], rb[BL];
+  bool va[AL], vb[BL];
+  // unconditional, clamped loads + masking at LDS-store time (see conv_igemm_kernel)
   auto load_global = [&](int ch) {
     const int m0 = ch * kBK;
+    const bool chok = ch < ch_hi;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
       const int m = m0 + a_row + AROWS * i;
       const int k = bk0 + a_col;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M && k < K) v = *reinterpret_cast<const float4*>(dy + (size_t)m * K + k);
-      ra[i] = v;
+      const bool ok = chok && m < M && k < K;
+      ra[i] = *reinterpret_cast<const float4*>(dy + (ok ? (size_t)m * K + k : 0));
+      va[i] = ok;
     }
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
       const int m = m0 + b_row + BROWS * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M && qok) {
-        const int n = m / (g.OH * g.OW);
-        const int rem = m - n * (g.OH * g.OW);
-        const int oh = rem / g.OW, ow = rem - oh * g.OW;
-        const int ih = oh * g.stride - g.pad + qr, iw = ow * g.stride - g.pad + qs;
-        if (ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW)
-          v = *reinterpret_cast<const float4*>(x + (((size_t)n * g.IH + ih) * g.IW + iw) * g.IC + qc);
-      }
-      rb[i] = v;
+      const int mm = (m < M) ? m : 0;
+      const int n = mm / (g.OH * g.OW);
+      const int rem = mm - n * (g.OH * g.OW);
+      const int oh = rem / g.OW, ow = rem - oh * g.OW;
+      const int ih = oh * g.stride - g.pad + qr, iw = ow * g.stride - g.pad + qs;
+      const bool ok = chok && m < M && qok && ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW;
+      rb[i] = *reinterpret_cast<const float4*>(x + (ok ? (((size_t)n * g.IH + ih) * g.IW + iw) * g.IC + qc : 0));
+      vb[i] = ok;
     }
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AL; ++i) *reinterpret_cast<float4*>(&As[buf][(a_row + AROWS * i) * LA + a_col]) = ra[i];
+    for (int i = 0; i < AL; ++i)
+      *reinterpret_cast<float4*>(&As[buf][(a_row + AROWS * i) * LA + a_col]) = va[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < BL; ++i) *reinterpret_cast<float4*>(&Bs[buf][(b_row + BROWS * i) * LB + b_col]) = rb[i];
+    for (int i = 0; i < BL; ++i)
+      *reinterpret_cast<float4*>(&Bs[buf][(b_row + BROWS * i) * LB + b_col]) = vb[i] ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
   floatx16 acc[TM][TN];
@@ -253,7 +359,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float
   __syncthreads();
   for (int ch = ch_lo; ch < ch_hi; ++ch) {
     const int buf = (ch - ch_lo) & 1;
-    if (ch + 1 < ch_hi) load_global(ch + 1);
+    load_global(ch + 1);                  // unconditional prefetch (masked past the end of this split)
+    HIFIHR_SCHED_FENCE();
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       float a[TM], b[TN];
@@ -266,7 +373,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (ch + 1 < ch_hi) store_lds(buf ^ 1);
+    HIFIHR_SCHED_FENCE();
+    store_lds(buf ^ 1);
     __syncthreads();
   }
 #pragma unroll
@@ -308,27 +416,35 @@ __global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static int pick_tile(long M, int OC) {
-  // 0: 128x128, 1: 128x64, 2: 64x64 -- the largest tile that still gives ~2 workgroups per CU
-  if (OC % 128 == 0 || OC > 128) {
-    if ((M / 128) * ((OC + 127) / 128) >= 512) return 0;
-  }
-  if ((M / 128) * ((OC + 63) / 64) >= 400) return 1;
-  return 2;
+static int pick_tile(long M, int OC, bool generic) {
+  // 0: 128x128, 1: 128x64, 2: 64x64.  Measured on MI355X at B = 32 (tools/time_conv.py, round 1): the 64x64 tile wins
+  // on every ResNet-18 layer (7 resident workgroups per CU hide the per-chunk barrier), except the 4-channel stem.
+  if (const char* e = getenv("HIFIHR_CONV_TILE")) return atoi(e);     // tuning/diagnostic override
+  (void)M; (void)OC;
+  return generic ? 1 : 2;
+}
+
+template <int BM, int BN>
+static void launch_igemm_tile(const ConvGeom& g, long Mmax, int classes, bool generic, const float* src, const float* wgt,
+                              const float* bias, float* dst, hipStream_t st) {
+  const dim3 grid((unsigned)((Mmax + BM - 1) / BM), (g.OC + BN - 1) / BN, classes);
+  if (generic)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true>), grid, dim3(256), 0, st, g, src, wgt, bias, dst);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst);
 }
 
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, hipStream_t st) {
-  const long M = (long)g.N * g.OH * g.OW;
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
-  switch (pick_tile(M, g.OC)) {
-    case 0:
-      hipLaunchKernelGGL((conv_igemm_kernel<128, 128>), dim3((unsigned)((M + 127) / 128), (g.OC + 127) / 128), dim3(256), 0, st, g, src, wgt, bias, dst);
-      break;
-    case 1:
-      hipLaunchKernelGGL((conv_igemm_kernel<128, 64>), dim3((unsigned)((M + 127) / 128), (g.OC + 63) / 64), dim3(256), 0, st, g, src, wgt, bias, dst);
-      break;
-    default:
-      hipLaunchKernelGGL((conv_igemm_kernel<64, 64>), dim3((unsigned)((M + 63) / 64), (g.OC + 63) / 64), dim3(256), 0, st, g, src, wgt, bias, dst);
+  const bool generic = (g.IC % kBK) != 0;
+  if (generic && g.dgrad) return hipErrorInvalidValue;      // dgrad needs the source channel count % 16 == 0
+  const int classes = g.dgrad ? g.stride * g.stride : 1;
+  const int st_ = g.dgrad ? g.stride : 1;
+  const long Mmax = (long)g.N * ((g.OH + st_ - 1) / st_) * ((g.OW + st_ - 1) / st_);   // rows of the largest class
+  switch (pick_tile(Mmax * classes, g.OC, generic)) {
+    case 0: launch_igemm_tile<128, 128>(g, Mmax, classes, generic, src, wgt, bias, dst, st); break;
+    case 1: launch_igemm_tile<128, 64>(g, Mmax, classes, generic, src, wgt, bias, dst, st); break;
+    default: launch_igemm_tile<64, 64>(g, Mmax, classes, generic, src, wgt, bias, dst, st);
   }
   return hipGetLastError();
 }

@@ -254,8 +254,8 @@ int hifihr_conv2d_fwd(const float* x, const float* w, const float* bias, float* 
 
 int hifihr_conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, int N, int H, int W, int C, int K,
                            int R, int S, int stride, int pad, void* stream) {
-  if (!dy || !w || !dx || !wt_scratch || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || K % 4)
-    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_data: bad argument (K must be a multiple of 4)");
+  if (!dy || !w || !dx || !wt_scratch || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || K % 16)
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_data: bad argument (K must be a multiple of 16)");
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
   HIP_TRY(hifihr::launch_weight_transpose(w, wt_scratch, K, R * S, C, (hipStream_t)stream));
   hifihr::ConvGeom g{N, OH, OW, K, H, W, C, R, S, stride, pad, 1};

@@ -133,7 +133,7 @@ int hifihr_adam_step(float* params_d, const float* grads_d, float* exp_avg_d, fl
  * Replaces the cuDNN/MIOpen dispatches of the encoder's nn.Conv2d layers (forward, backward-data,
  * backward-weight): reference network/res_encoder.py:364-373 (ResNet trunk built at :345-362).
  * Layouts: x[N][H][W][C], w[K][R][S][C] (= a torch [K,C,R,S] tensor in channels_last memory format),
- * y[N][OH][OW][K] with OH = (H + 2 pad - R)/stride + 1.  C (and K for the backward calls) % 4 == 0.
+ * y[N][OH][OW][K] with OH = (H + 2 pad - R)/stride + 1.  C % 4 == 0; bwd_data needs K % 16 == 0, bwd_weight K % 4 == 0.
  * ---------------------------------------------------------------------------------------------- */
 int hifihr_conv2d_fwd(const float* x_d, const float* w_d, const float* bias_d /* [K] or NULL */, float* y_d, int N, int H,
                       int W, int C, int K, int R, int S, int stride, int pad, void* stream);

@@ -14,10 +14,10 @@ def hostsim_lib():
     (1, 12, 12, 32, 128, 3, 2, 1),  # 3x3 s2 (dgrad divisibility path)
     (2, 8, 8, 64, 128, 1, 2, 0),    # 1x1 s2 downsample
     (1, 16, 16, 4, 64, 7, 2, 3),    # conv1 shape: C = 4 (NHWC4), Q = 196 not a multiple of 16
-    (1, 6, 6, 48, 20, 3, 1, 0),     # K not a multiple of 64, no padding, bias
+    (1, 6, 6, 48, 48, 3, 1, 0),     # K not a multiple of 64, no padding, bias
 ])
 def test_conv_fwd_bwd(hostsim_lib, N, H, W, C, K, R, stride, pad):
-    kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, seed=H, bias=(K == 20))
+    kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, seed=H, bias=(K == 48))
 
 
 def test_image_to_nhwc4(hostsim_lib):
