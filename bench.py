@@ -29,6 +29,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as one hipGraph, 0: eager, -1: auto (on for 1 GPU)")
     ap.add_argument("--cpu-batch", type=int, default=2, help="sample size of the CPU baseline (images)")
     return ap.parse_args()
 
@@ -85,7 +86,27 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    # per-kernel HIP-event timing (eager, a few steps, outside the headline timing)
     ops.PROFILE.enable()
+    for _ in range(min(5, a.steps)):
+        step()
+    ops.PROFILE.disable()
+    kern = ops.PROFILE.summary()                       # {name: (avg_us, launches)}
+
+    use_graph = (a.graph == 1) or (a.graph == -1 and world == 1)
+    graph_note = "eager"
+    if use_graph:
+        try:
+            from hifihr_amd.traineval import GraphedTrainStep
+            gstep = GraphedTrainStep(model, loss_func, opt, examples, args_ns)
+            step = gstep
+            graph_note = "hipGraph replay (whole step captured)"
+            for _ in range(2):
+                step()
+        except Exception as e:                          # capture is an optimisation; never fail the bench on it
+            graph_note = f"eager (hipGraph capture failed: {type(e).__name__}: {str(e)[:200]})"
+            opt.graph_mode = False
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -96,13 +117,10 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    ops.PROFILE.disable()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kern = ops.PROFILE.summary()                       # {name: (avg_us, launches)}
-
     if rank == 0:
         B = a.batch
         ms = dt / a.steps * 1e3
@@ -114,7 +132,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: FreiHAND batch=32/GPU, ResNet-18 encoder + MANO LBS + "
                                    "silhouette/texture render losses, 224x224, aa=3 (672^2 samples)",
                        "per_gpu_batch": B, "global_batch": world * B, "losses": args_ns.losses, "parallelism": f"dp{world}"},
-            "loss": float(loss.detach()),
+            "loss": float(loss.detach()), "launch_mode": graph_note,
         }
         # roofline of the dominant hand-written kernel: the fused rasterise+shade+resolve forward.
         # algorithmic bytes per image (SURVEY.md 8d / DESIGN.md): verts 778*12 + faces 1538*12 + attrs 778*24 +

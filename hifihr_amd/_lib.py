@@ -88,6 +88,8 @@ class HifihrLib:
         c.hifihr_image_to_nhwc4.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_adam_step.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
                                        c_float, c_float, c_float, c_int, c_void_p]
+        c.hifihr_adam_step_dyn.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
+                                           c_float, c_float, _c_float_p, c_void_p]
         c.hifihr_renderer_destroy.argtypes = [c_void_p]
         c.hifihr_render_workspace_bytes.argtypes = [c_void_p, c_int]
         c.hifihr_render_workspace_bytes.restype = c_size_t
@@ -172,6 +174,12 @@ class HifihrLib:
         self.check(self.c.hifihr_adam_step(_fp(p), _fp(g), _fp(m), _fp(v), c_size_t(n), c_float(grad_scale), c_float(lr),
                                            c_float(beta1), c_float(beta2), c_float(eps), c_float(weight_decay), int(step),
                                            _stream_of(p)), "hifihr_adam_step")
+
+    def adam_step_dyn(self, p, g, m, v, grad_scale, beta1, beta2, eps, weight_decay, dyn):
+        n = p.numel()
+        self.check(self.c.hifihr_adam_step_dyn(_fp(p), _fp(g), _fp(m), _fp(v), c_size_t(n), c_float(grad_scale), c_float(beta1),
+                                               c_float(beta2), c_float(eps), c_float(weight_decay), _fp(dyn), _stream_of(p)),
+                   "hifihr_adam_step_dyn")
 
     # ---- renderer ----------------------------------------------------
     def renderer_create(self, faces, V, image_size=224, aa=3, ambient=(0.5, 0.5, 0.5), mat_diffuse=(0.8, 0.8, 0.8),

@@ -11,7 +11,11 @@ namespace hifihr {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, size_t n, float grad_scale, float beta1, float beta2,
-                                                  float eps, float weight_decay, float step_size, float inv_sqrt_bc2) {
+                                                  float eps, float weight_decay, float step_size, float inv_sqrt_bc2,
+                                                  const float* __restrict__ dyn) {
+  // dyn (optional, device float[2] = {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)}): lets a captured hipGraph replay
+  // the step with per-step scalars that the host refreshes outside the graph
+  if (dyn) { step_size = dyn[0]; inv_sqrt_bc2 = dyn[1]; }
   const size_t n4 = n / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   float4* p4 = reinterpret_cast<float4*>(p);
@@ -45,16 +49,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, int step, hipStream_t st) {
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
-  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+                       float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st) {
+  float step_size = 0.f, inv_sqrt_bc2 = 0.f;
+  if (!dyn) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    step_size = (float)((double)lr / bc1);
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  }
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;        // grid-stride: ~8 workgroups per CU
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, grad_scale, beta1, beta2, eps,
-                     weight_decay, step_size, inv_sqrt_bc2);
+                     weight_decay, step_size, inv_sqrt_bc2, dyn);
   return hipGetLastError();
 }
 

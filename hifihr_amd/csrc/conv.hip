@@ -113,9 +113,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
   const int nch = GENERIC ? (Qw + kBK - 1) / kBK : P.nr * P.ns * (g.IC / kBK);
   int jr = 0, js = 0, c0 = 0, qgen = 0;           // tap state of the NEXT chunk to load
 
-  float4 ra[TM], rb[TN];
-  bool va[TM], vb[TN];
-  auto load_global = [&]() {
+  // kPF register stages: the chunk consumed now was loaded kPF - 1 chunk-computations ago, so ~2 MFMA blocks (plus the
+  // other resident workgroups) cover the L2/HBM latency even when only 2-3 workgroups fit the grid per CU.
+  constexpr int kPF = 3;
+  float4 ra[kPF][TM], rb[kPF][TN];
+  bool va[kPF][TM], vb[kPF][TN];
+  auto load_global = [&](const int st) {
     int dr, ds, c, wq;
     bool qok = true;
     if (GENERIC) {
@@ -141,31 +144,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
       const int ih = a_h[i] + P.sign * dr, iw = a_w[i] + P.sign * ds;
       const bool ok = qok && a_ok[i] && ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW;
       const size_t off = ok ? a_base[i] + ((size_t)ih * g.IW + iw) * g.IC + c : 0;
-      ra[i] = *reinterpret_cast<const float4*>(src + off);
-      va[i] = ok;
+      ra[st][i] = *reinterpret_cast<const float4*>(src + off);
+      va[st][i] = ok;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int k = bn0 + lrow + 64 * j;
       const bool ok = qok && k < g.OC;
       const size_t off = ok ? (size_t)k * Qw + wq : 0;
-      rb[j] = *reinterpret_cast<const float4*>(wgt + off);
-      vb[j] = ok;
+      rb[st][j] = *reinterpret_cast<const float4*>(wgt + off);
+      vb[st][j] = ok;
     }
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](const int st, int buf) {
     // k-interleave: even columns of the chunk -> floats [0,8), odd columns -> [8,16) of the row
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float* p = &As[buf][(lrow + 64 * i) * kLD];
-      const float4 v = va[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = va[st][i] ? ra[st][i] : make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float2*>(p + seg / 2) = make_float2(v.x, v.z);
       *reinterpret_cast<float2*>(p + 8 + seg / 2) = make_float2(v.y, v.w);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float* p = &Bs[buf][(lrow + 64 * j) * kLD];
-      const float4 v = vb[j] ? rb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = vb[st][j] ? rb[st][j] : make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float2*>(p + seg / 2) = make_float2(v.x, v.z);
       *reinterpret_cast<float2*>(p + 8 + seg / 2) = make_float2(v.y, v.w);
     }
@@ -179,39 +182,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (nch > 0) {
-    load_global();
-    store_lds(0);
-  }
+  // prologue: chunks 0, 1, 2 in flight (masked past the end), chunk 0 to LDS
+  load_global(0);
+  load_global(1);
+  load_global(2);
+  store_lds(0, 0);
   __syncthreads();
-  for (int ch = 0; ch < nch; ++ch) {
-    const int buf = ch & 1;
-    // prefetch the next chunk; issued unconditionally (past the last tap the plan yields masked, clamped loads):
-    // a conditional here turns ra/rb into loop-carried phis whose register copies wait for the load at once
-    load_global();
-    HIFIHR_SCHED_FENCE();                 // loads first, then the whole MFMA block covers their latency
-    float a[TM][8], b[TN][8];
+  for (int ch0 = 0; ch0 < nch; ch0 += kPF) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const float* p = &As[buf][(wm * (BM / 2) + i * 32 + r31) * kLD + half * 8];
-      const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-      a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w; a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+    for (int u = 0; u < kPF; ++u) {
+      const int ch = ch0 + u;
+      if (ch >= nch) break;
+      const int buf = ch & 1;
+      // stage u held chunk ch (already in LDS): refill it with chunk ch + 3.  Issued unconditionally (masked, clamped
+      // loads past the last tap): a conditional load turns the registers into phis whose copies wait at once.
+      load_global(u);
+      HIFIHR_SCHED_FENCE();               // loads first, then the MFMA block
+      float a[TM][8], b[TN][8];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float* p = &As[buf][(wm * (BM / 2) + i * 32 + r31) * kLD + half * 8];
+        const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+        a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w; a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float* p = &Bs[buf][(wn * (BN / 2) + j * 32 + r31) * kLD + half * 8];
+        const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+        b[j][0] = lo.x; b[j][1] = lo.y; b[j][2] = lo.z; b[j][3] = lo.w; b[j][4] = hi.x; b[j][5] = hi.y; b[j][6] = hi.z; b[j][7] = hi.w;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+      HIFIHR_SCHED_FENCE();
+      store_lds((u + 1) % kPF, buf ^ 1);  // chunk ch + 1 (loaded two chunk-computations ago) -> the other LDS buffer
+      __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const float* p = &Bs[buf][(wn * (BN / 2) + j * 32 + r31) * kLD + half * 8];
-      const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-      b[j][0] = lo.x; b[j][1] = lo.y; b[j][2] = lo.z; b[j][3] = lo.w; b[j][4] = hi.x; b[j][5] = hi.y; b[j][6] = hi.z; b[j][7] = hi.w;
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
-    HIFIHR_SCHED_FENCE();
-    store_lds(buf ^ 1);
-    __syncthreads();
   }
 
   // epilogue: D[i][j], i = pixel row, j = output channel; lanes 0..31 hold 32 consecutive channels of one row, so

@@ -234,6 +234,17 @@ int hifihr_adam_step(float* params, const float* grads, float* exp_avg, float* e
     return fail(HIFIHR_EINVAL, "hifihr_adam_step: buffers must be 16-byte aligned");
   if (n == 0) return HIFIHR_OK;
   HIP_TRY(hifihr::launch_adam(params, grads, exp_avg, exp_avg_sq, n, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
+                              nullptr, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_adam_step_dyn(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float grad_scale,
+                         float beta1, float beta2, float eps, float weight_decay, const float* dyn_d, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !dyn_d) return fail(HIFIHR_EINVAL, "hifihr_adam_step_dyn: bad argument");
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
+    return fail(HIFIHR_EINVAL, "hifihr_adam_step_dyn: buffers must be 16-byte aligned");
+  if (n == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_adam(params, grads, exp_avg, exp_avg_sq, n, grad_scale, 0.f, beta1, beta2, eps, weight_decay, 1, dyn_d,
                               (hipStream_t)stream));
   return HIFIHR_OK;
 }

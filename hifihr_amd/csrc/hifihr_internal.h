@@ -69,6 +69,6 @@ hipError_t launch_ssim_bwd(const SsimWindow& win, const float* img1, const float
                            const float* dC, const float* gscale, int planes, int H, int W, float* gimg1, hipStream_t st);
 
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, int step, hipStream_t st);
+                       float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st);
 
 }  // namespace hifihr

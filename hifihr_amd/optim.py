@@ -70,6 +70,24 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = 0
         self.grad_scale = grad_scale
         self._lib = None
+        # graph mode: the per-step scalars live in device memory and are refreshed by prepare_step() outside the graph
+        self.graph_mode = False
+        self._dyn = None
+        self._dyn_host = None
+
+    def enable_graph_mode(self):
+        self.graph_mode = True
+        self._dyn = torch.zeros(2, device=self.flatp.flat.device)
+        self._dyn_host = torch.zeros(2).pin_memory() if self.flatp.flat.is_cuda else torch.zeros(2)
+
+    def prepare_step(self):
+        """Graph mode: advance the step counter and upload {lr/(1-b1^t), 1/sqrt(1-b2^t)}; call before each replay."""
+        g = self.param_groups[0]
+        self.step_count += 1
+        b1, b2 = g["betas"]
+        self._dyn_host[0] = g["lr"] / (1.0 - b1 ** self.step_count)
+        self._dyn_host[1] = 1.0 / (1.0 - b2 ** self.step_count) ** 0.5
+        self._dyn.copy_(self._dyn_host, non_blocking=True)
 
     def zero_grad(self, set_to_none: bool = False):
         self.flatp.zero_grad()
@@ -80,6 +98,10 @@ class FusedAdam(torch.optim.Optimizer):
             self._lib = get_lib()
         require_cuda(self.flatp.flat)
         g = self.param_groups[0]
+        if self.graph_mode:
+            self._lib.adam_step_dyn(self.flatp.flat, self.flatp.grad, self.exp_avg, self.exp_avg_sq, self.grad_scale,
+                                    g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._dyn)
+            return
         self.step_count += 1
         from .ops import PROFILE
         PROFILE.bracket("adam", lambda: self._lib.adam_step(self.flatp.flat, self.flatp.grad, self.exp_avg, self.exp_avg_sq,

@@ -61,3 +61,39 @@ def train_step(model, loss_func, optimizer, examples, args, dat_name="FreiHand",
         backward_hook()                      # data-parallel gradient all-reduce (hifihr_amd/dist.py)
     optimizer.step()
     return loss, loss_dic
+
+
+class GraphedTrainStep:
+    """The whole training iteration (forward, losses, backward, fused Adam) captured once into a hipGraph and
+    replayed: ~700 kernel launches per step collapse into one graph launch, which removes the host-side launch gaps
+    (the step is launch-bound in places: DESIGN.md section 6).  The batch lives in static device tensors that
+    `load_batch` overwrites in place; per-step Adam scalars are refreshed outside the graph (FusedAdam.prepare_step).
+    Single-process use; with data parallel ranks the eager `train_step` (bucketed all-reduce overlapped with
+    backward) is used instead."""
+
+    def __init__(self, model, loss_func, optimizer, examples, args, dat_name="FreiHand", warmup=3):
+        self.model, self.loss_func, self.opt, self.args, self.dat_name = model, loss_func, optimizer, args, dat_name
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in examples.items()}
+        optimizer.enable_graph_mode()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up on a side stream (allocator + MIOpen/rocBLAS init)
+            for _ in range(warmup):
+                optimizer.prepare_step()
+                train_step(model, loss_func, optimizer, self.static, args, dat_name)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.prepare_step()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.loss_dic = train_step(model, loss_func, optimizer, self.static, args, dat_name)
+
+    def load_batch(self, examples):
+        for k, v in examples.items():
+            if torch.is_tensor(v):
+                self.static[k].copy_(v, non_blocking=True)
+
+    def __call__(self):
+        self.opt.prepare_step()
+        self.graph.replay()
+        return self.loss, self.loss_dic

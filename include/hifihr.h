@@ -127,6 +127,12 @@ int hifihr_render_bwd(const hifihr_renderer_t* h, const float* verts_d, const fl
 int hifihr_adam_step(float* params_d, const float* grads_d, float* exp_avg_d, float* exp_avg_sq_d, size_t n,
                      float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                      void* stream);
+/* Same update with the two per-step scalars read from DEVICE memory, dyn_d[2] = { lr / (1 - beta1^t),
+ * 1 / sqrt(1 - beta2^t) }: the launch can be captured in a hipGraph and replayed while the host refreshes dyn_d
+ * (a 8-byte async copy) outside the graph before each replay. */
+int hifihr_adam_step_dyn(float* params_d, const float* grads_d, float* exp_avg_d, float* exp_avg_sq_d, size_t n,
+                         float grad_scale, float beta1, float beta2, float eps, float weight_decay, const float* dyn_d,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NHWC fp32 convolution on the f32 matrix cores (implicit GEMM, exact fp32 accumulate).

@@ -167,7 +167,11 @@ def adam_case(lib, device, n, wd, steps, grad_scale=0.5, lr=1e-3):
         g = torch.randn(n, generator=gen)
         ref.grad = (g * grad_scale).clone()
         opt.step()
-        lib.adam_step(p, g.to(device), m, v, grad_scale, lr, 0.9, 0.999, 1e-8, wd, s)
+        if s % 2:
+            lib.adam_step(p, g.to(device), m, v, grad_scale, lr, 0.9, 0.999, 1e-8, wd, s)
+        else:           # the graph-replayable variant: scalars from device memory
+            dyn = torch.tensor([lr / (1 - 0.9 ** s), 1.0 / (1 - 0.999 ** s) ** 0.5], dtype=torch.float32).to(device)
+            lib.adam_step_dyn(p, g.to(device), m, v, grad_scale, 0.9, 0.999, 1e-8, wd, dyn)
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-5)
 
 
