@@ -63,6 +63,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP hot path has no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    # Work on a non-default stream from the start: autograd pins each parameter's gradient accumulation to the stream
+    # of its first use, and a step that ever ran on the legacy default stream cannot be captured into a hipGraph later
+    # (capture_end crashed / replays produced NaN in round 1: DESIGN.md section 6).
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
     args_ns = options.baseline_config2_args(train_batch=a.batch)
     tables = synthetic_mano_tables(0)

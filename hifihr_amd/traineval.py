@@ -69,7 +69,9 @@ class GraphedTrainStep:
     (the step is launch-bound in places: DESIGN.md section 6).  The batch lives in static device tensors that
     `load_batch` overwrites in place; per-step Adam scalars are refreshed outside the graph (FusedAdam.prepare_step).
     Single-process use; with data parallel ranks the eager `train_step` (bucketed all-reduce overlapped with
-    backward) is used instead."""
+    backward) is used instead.
+    The model must never have run a step on the legacy default stream (autograd pins gradient accumulation to the
+    stream of first use): callers do `torch.cuda.set_stream(torch.cuda.Stream())` before the first step."""
 
     def __init__(self, model, loss_func, optimizer, examples, args, dat_name="FreiHand", warmup=3):
         self.model, self.loss_func, self.opt, self.args, self.dat_name = model, loss_func, optimizer, args, dat_name

@@ -150,25 +150,32 @@ def test_ssim_kernel_full_size(golden_dir):
 
 def test_graphed_step_matches_eager_step():
     """The hipGraph-replayed training step performs the same update as the eager step (same weights, same batch)."""
-    import copy
     from hifihr_amd.losses import LossFunction
+    from hifihr_amd.models import Model
     from hifihr_amd.optim import FlatParams, FusedAdam
     from hifihr_amd.traineval import GraphedTrainStep, train_step
-    B = 4
-    tables, args, model, ref, ex, ex_cpu = _setup(B)
-    model2 = copy.deepcopy(model)
-    # eager: 4 steps (3 = the warm-up steps GraphedTrainStep runs before capture, + 1)
-    flat = FlatParams(model); opt = FusedAdam(flat, lr=1e-4)
-    for _ in range(4):
-        loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
-    # graphed: construction runs 3 eager warm-up steps, then one replay
-    flat2 = FlatParams(model2); opt2 = FusedAdam(flat2, lr=1e-4)
-    g = GraphedTrainStep(model2, LossFunction(), opt2, ex, args, warmup=3)
-    loss_g, _ = g()
-    torch.cuda.synchronize()
-    assert abs(float(loss_e) - float(loss_g)) <= 2e-4 * max(1.0, abs(float(loss_e))), (float(loss_e), float(loss_g))
-    d = (flat.flat - flat2.flat).abs().max()
-    assert float(d) <= 2.5e-4, float(d)          # 4 Adam steps of lr 1e-4; atomics make the two runs differ by rounding only
-    loss_g2, _ = g()                             # replays keep training
-    torch.cuda.synchronize()
-    assert np.isfinite(float(loss_g2)) and opt2.step_count == 5
+    prev = torch.cuda.current_stream()
+    torch.cuda.set_stream(torch.cuda.Stream())            # never the legacy default stream before a capture
+    try:
+        B = 4
+        tables, args, model, ref, ex, ex_cpu = _setup(B)
+        model2 = Model(True, torch.device("cuda"), False, "mano", False, "res18", mano_tables=tables).cuda().train()
+        model2.load_state_dict(model.state_dict())
+        # eager: 4 steps (3 = the warm-up steps GraphedTrainStep runs before capture, + 1)
+        flat = FlatParams(model); opt = FusedAdam(flat, lr=1e-4)
+        for _ in range(4):
+            loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
+        flat2 = FlatParams(model2); opt2 = FusedAdam(flat2, lr=1e-4)
+        g = GraphedTrainStep(model2, LossFunction(), opt2, ex, args, warmup=3)
+        loss_g, _ = g()
+        torch.cuda.synchronize()
+        assert abs(float(loss_e) - float(loss_g)) <= 2e-4 * max(1.0, abs(float(loss_e))), (float(loss_e), float(loss_g))
+        # Adam normalises every gradient to ~+-lr per step, so weights whose gradient is rounding noise (float atomics
+        # order) may move in opposite directions: bound = 2 * lr * steps for those, tiny on average
+        d = (flat.flat - flat2.flat).abs()
+        assert float(d.max()) <= 8.01e-4 and float(d.mean()) <= 2e-5, (float(d.max()), float(d.mean()))
+        loss_g2, _ = g()                         # replays keep training
+        torch.cuda.synchronize()
+        assert np.isfinite(float(loss_g2)) and opt2.step_count == 5
+    finally:
+        torch.cuda.set_stream(prev)
