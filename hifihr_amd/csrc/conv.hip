@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
   }
 
   const int nch = GENERIC ? (Qw + kBK - 1) / kBK : P.nr * P.ns * (g.IC / kBK);
-  int jr = 0, js = 0, c0 = 0, qgen = 0;           // tap state of the NEXT chunk to load
+  int jr = 0, js = 0, c0 = 0, qgen = 0, issued = 0;   // tap state of the NEXT chunk to load
 
   // kPF register stages: the chunk consumed now was loaded kPF - 1 chunk-computations ago, so ~2 MFMA blocks (plus the
   // other resident workgroups) cover the L2/HBM latency even when only 2-3 workgroups fit the grid per CU.
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
       wq = q;
       qgen += kBK;
     } else {
-      qok = jr < P.nr;                       // false only for the (masked) prefetch issued by the last iteration
+      qok = issued < nch;                    // false for the (masked) prefetches issued past the last chunk; note a
+      ++issued;                              // parity class can have nr > 0 but ns == 0 (no chunk at all)
       dr = jr; ds = js; c = c0 + seg;
       wq = ((P.r0 + P.rstep * jr) * g.S + (P.s0 + P.rstep * js)) * g.IC + c;
       c0 += kBK;

@@ -9,6 +9,11 @@ import torch
 from ._lib import get_lib, require_cuda
 
 
+import os as _os
+
+_DEBUG_SYNC = _os.environ.get("HIFIHR_DEBUG_SYNC", "0") == "1"
+
+
 class _Profile:
     """Optional HIP-event brackets around the C-ABI launches (recorded on the stream the kernels are launched on,
     i.e. torch's current stream).  No synchronisation until summary() is called."""
@@ -24,6 +29,12 @@ class _Profile:
         self.on = False
 
     def bracket(self, name, fn):
+        if _DEBUG_SYNC:                      # HIFIHR_DEBUG_SYNC=1: name every launch and synchronise after it
+            print(f"[hifihr] {name} ...", flush=True)
+            r = fn()
+            torch.cuda.synchronize()
+            print(f"[hifihr] {name} done", flush=True)
+            return r
         if not self.on:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

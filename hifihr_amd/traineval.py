@@ -89,6 +89,7 @@ class GraphedTrainStep:
         optimizer.prepare_step()
         with torch.cuda.graph(self.graph):
             self.loss, self.loss_dic = train_step(model, loss_func, optimizer, self.static, args, dat_name)
+        optimizer.step_count -= 1            # capturing records the step without executing it
 
     def load_batch(self, examples):
         for k, v in examples.items():

@@ -162,10 +162,10 @@ def test_graphed_step_matches_eager_step():
         model2 = Model(True, torch.device("cuda"), False, "mano", False, "res18", mano_tables=tables).cuda().train()
         model2.load_state_dict(model.state_dict())
         # eager: 4 steps (3 = the warm-up steps GraphedTrainStep runs before capture, + 1)
-        flat = FlatParams(model); opt = FusedAdam(flat, lr=1e-4)
+        flat = FlatParams(model); opt = FusedAdam(flat, lr=1e-6)     # tiny lr: isolates the graph mechanics from Adam's sign noise
         for _ in range(4):
             loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
-        flat2 = FlatParams(model2); opt2 = FusedAdam(flat2, lr=1e-4)
+        flat2 = FlatParams(model2); opt2 = FusedAdam(flat2, lr=1e-6)
         g = GraphedTrainStep(model2, LossFunction(), opt2, ex, args, warmup=3)
         loss_g, _ = g()
         torch.cuda.synchronize()
@@ -173,7 +173,7 @@ def test_graphed_step_matches_eager_step():
         # Adam normalises every gradient to ~+-lr per step, so weights whose gradient is rounding noise (float atomics
         # order) may move in opposite directions: bound = 2 * lr * steps for those, tiny on average
         d = (flat.flat - flat2.flat).abs()
-        assert float(d.max()) <= 8.01e-4 and float(d.mean()) <= 2e-5, (float(d.max()), float(d.mean()))
+        assert float(d.max()) <= 8.01e-6 and float(d.mean()) <= 2e-7, (float(d.max()), float(d.mean()))
         loss_g2, _ = g()                         # replays keep training
         torch.cuda.synchronize()
         assert np.isfinite(float(loss_g2)) and opt2.step_count == 5
