@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
 
 import torch  # noqa: F401  (must be imported first: the library binds to torch's libamdhip64)
 
@@ -84,6 +84,10 @@ class HifihrLib:
         ci = [c_int] * 9
         c.hifihr_conv2d_fwd.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
         c.hifihr_conv2d_bwd_data.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
+        c.hifihr_conv2d_fwd_bnstats.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
+        c.hifihr_bn_stats.argtypes = [_c_float_p, c_long, c_int, _c_float_p, c_void_p]
+        c.hifihr_bn_act_fwd.argtypes = [_c_float_p] * 5 + [c_int, c_long, c_int, c_float, c_float] + [_c_float_p] * 5 + [c_void_p]
+        c.hifihr_bn_act_bwd.argtypes = [_c_float_p] * 6 + [c_int, c_long, c_int] + [_c_float_p] * 5 + [c_void_p]
         c.hifihr_conv2d_bwd_weight.argtypes = [_c_float_p] * 3 + ci + [c_void_p]
         c.hifihr_image_to_nhwc4.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_adam_step.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
@@ -140,6 +144,23 @@ class HifihrLib:
     def conv2d_fwd(self, x, w, bias, y, N, H, W, C, K, R, S, stride, pad):
         self.check(self.c.hifihr_conv2d_fwd(_fp(x), _fp(w), _fp(bias), _fp(y), N, H, W, C, K, R, S, stride, pad, _stream_of(x)),
                    "hifihr_conv2d_fwd")
+
+    def conv2d_fwd_bnstats(self, x, w, y, stats, N, H, W, C, K, R, S, stride, pad):
+        self.check(self.c.hifihr_conv2d_fwd_bnstats(_fp(x), _fp(w), _fp(y), _fp(stats), N, H, W, C, K, R, S, stride, pad,
+                                                    _stream_of(x)), "hifihr_conv2d_fwd_bnstats")
+
+    def bn_stats(self, x, M, C, stats):
+        self.check(self.c.hifihr_bn_stats(_fp(x), c_long(M), C, _fp(stats), _stream_of(x)), "hifihr_bn_stats")
+
+    def bn_act_fwd(self, x, stats, gamma, beta, residual, relu, M, C, eps, momentum, y, save_mean, save_invstd, rmean, rvar):
+        self.check(self.c.hifihr_bn_act_fwd(_fp(x), _fp(stats), _fp(gamma), _fp(beta), _fp(residual), int(relu), c_long(M), C,
+                                            c_float(eps), c_float(momentum), _fp(y), _fp(save_mean), _fp(save_invstd), _fp(rmean),
+                                            _fp(rvar), _stream_of(x)), "hifihr_bn_act_fwd")
+
+    def bn_act_bwd(self, dy, y, x, save_mean, save_invstd, gamma, relu, M, C, red, dx, dres, dgamma_acc, dbeta_acc):
+        self.check(self.c.hifihr_bn_act_bwd(_fp(dy), _fp(y), _fp(x), _fp(save_mean), _fp(save_invstd), _fp(gamma), int(relu),
+                                            c_long(M), C, _fp(red), _fp(dx), _fp(dres), _fp(dgamma_acc), _fp(dbeta_acc),
+                                            _stream_of(dy)), "hifihr_bn_act_bwd")
 
     def conv2d_bwd_data(self, dy, w, dx, scratch, N, H, W, C, K, R, S, stride, pad):
         self.check(self.c.hifihr_conv2d_bwd_data(_fp(dy), _fp(w), _fp(dx), _fp(scratch), N, H, W, C, K, R, S, stride, pad,

@@ -79,7 +79,9 @@ __device__ __forceinline__ GatherPlan make_plan(const ConvGeom& g, int cls) {
 template <int BM, int BN, bool GENERIC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float* __restrict__ src,
                                                         const float* __restrict__ wgt, const float* __restrict__ bias,
-                                                        float* __restrict__ dst) {
+                                                        float* __restrict__ dst, float* __restrict__ stats) {
+  // stats (optional, forward only): [2][OC] per-channel sum and sum of squares of the output, accumulated with
+  // atomics from the accumulator registers -- the batch-norm that follows needs no separate pass over y
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves are arranged 2 x 2)
   __shared__ __attribute__((aligned(16))) float As[2][BM * kLD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLD];
@@ -248,10 +250,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
             HIFIHR_KEEP(acc[i][j][e]);      // keep the add (and its one vmcnt wait) out of the per-element branches
           }
         }
+        float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = bm0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-          if (m < M && k < g.OC) col[(size_t)m * g.OC] = acc[i][j][e];
+          if (m < M && k < g.OC) {
+            col[(size_t)m * g.OC] = acc[i][j][e];
+            ssum += acc[i][j][e];
+            ssq += acc[i][j][e] * acc[i][j][e];
+          }
+        }
+        if (stats != nullptr) {                  // uniform
+          ssum += __shfl_down(ssum, 32, 64);     // lanes l and l + 32 hold the same channel, different rows
+          ssq += __shfl_down(ssq, 32, 64);
+          if (half == 0 && k < g.OC) {           // 32 consecutive channels: two 128-byte atomic segments per wave
+            atomicAdd(stats + k, ssum);
+            atomicAdd(stats + g.OC + k, ssq);
+          }
         }
       }
   } else {
@@ -436,15 +451,21 @@ static int pick_tile(long M, int OC, bool generic) {
 
 template <int BM, int BN>
 static void launch_igemm_tile(const ConvGeom& g, long Mmax, int classes, bool generic, const float* src, const float* wgt,
-                              const float* bias, float* dst, hipStream_t st) {
+                              const float* bias, float* dst, float* stats, hipStream_t st) {
   const dim3 grid((unsigned)((Mmax + BM - 1) / BM), (g.OC + BN - 1) / BN, classes);
   if (generic)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true>), grid, dim3(256), 0, st, g, src, wgt, bias, dst);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats);
 }
 
-hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, hipStream_t st) {
+hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
+                             hipStream_t st) {
+  if (stats != nullptr) {
+    if (g.dgrad) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(stats, 0, (size_t)2 * g.OC * sizeof(float), st);
+    if (e != hipSuccess) return e;
+  }
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
   const bool generic = (g.IC % kBK) != 0;
   if (generic && g.dgrad) return hipErrorInvalidValue;      // dgrad needs the source channel count % 16 == 0
@@ -452,9 +473,9 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   const int st_ = g.dgrad ? g.stride : 1;
   const long Mmax = (long)g.N * ((g.OH + st_ - 1) / st_) * ((g.OW + st_ - 1) / st_);   // rows of the largest class
   switch (pick_tile(Mmax * classes, g.OC, generic)) {
-    case 0: launch_igemm_tile<128, 128>(g, Mmax, classes, generic, src, wgt, bias, dst, st); break;
-    case 1: launch_igemm_tile<128, 64>(g, Mmax, classes, generic, src, wgt, bias, dst, st); break;
-    default: launch_igemm_tile<64, 64>(g, Mmax, classes, generic, src, wgt, bias, dst, st);
+    case 0: launch_igemm_tile<128, 128>(g, Mmax, classes, generic, src, wgt, bias, dst, stats, st); break;
+    case 1: launch_igemm_tile<128, 64>(g, Mmax, classes, generic, src, wgt, bias, dst, stats, st); break;
+    default: launch_igemm_tile<64, 64>(g, Mmax, classes, generic, src, wgt, bias, dst, stats, st);
   }
   return hipGetLastError();
 }

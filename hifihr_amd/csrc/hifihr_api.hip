@@ -259,7 +259,16 @@ int hifihr_conv2d_fwd(const float* x, const float* w, const float* bias, float* 
   if (!x || !w || !y || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4)
     return fail(HIFIHR_EINVAL, "hifihr_conv2d_fwd: bad argument (C must be a multiple of 4)");
   hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
-  HIP_TRY(hifihr::launch_conv_igemm(g, x, w, bias, y, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_conv_igemm(g, x, w, bias, y, nullptr, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_conv2d_fwd_bnstats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int C, int K, int R,
+                              int S, int stride, int pad, void* stream) {
+  if (!x || !w || !y || !stats || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4)
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_fwd_bnstats: bad argument (C must be a multiple of 4)");
+  hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
+  HIP_TRY(hifihr::launch_conv_igemm(g, x, w, nullptr, y, stats, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
@@ -270,7 +279,7 @@ int hifihr_conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
   HIP_TRY(hifihr::launch_weight_transpose(w, wt_scratch, K, R * S, C, (hipStream_t)stream));
   hifihr::ConvGeom g{N, OH, OW, K, H, W, C, R, S, stride, pad, 1};
-  HIP_TRY(hifihr::launch_conv_igemm(g, dy, wt_scratch, nullptr, dx, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_conv_igemm(g, dy, wt_scratch, nullptr, dx, nullptr, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
@@ -312,6 +321,35 @@ int hifihr_ssim_bwd(const float* window11, const float* img1, const float* img2,
   hifihr::SsimWindow win;
   for (int k = 0; k < 11; ++k) win.g[k] = window11[k];
   HIP_TRY(hifihr::launch_ssim_bwd(win, img1, img2, dA, dB, dC, grad_out, planes, H, W, gimg1, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+static int bn_dims_ok(long M, int C) { return M > 0 && C >= 4 && C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0; }
+
+int hifihr_bn_stats(const float* x, long M, int C, float* stats, void* stream) {
+  if (!x || !stats || !bn_dims_ok(M, C)) return fail(HIFIHR_EINVAL, "hifihr_bn_stats: bad argument (C/4 must divide 256)");
+  HIP_TRY(hifihr::launch_bn_stats(x, M, C, stats, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_bn_act_fwd(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual, int relu,
+                      long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,
+                      float* running_mean, float* running_var, void* stream) {
+  if (!x || !stats || !gamma || !beta || !y || !save_mean || !save_invstd || !bn_dims_ok(M, C) ||
+      ((running_mean != nullptr) != (running_var != nullptr)))
+    return fail(HIFIHR_EINVAL, "hifihr_bn_act_fwd: bad argument (C/4 must divide 256)");
+  HIP_TRY(hifihr::launch_bn_act_fwd(x, stats, gamma, beta, residual, relu, M, C, eps, momentum, y, save_mean, save_invstd,
+                                    running_mean, running_var, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_bn_act_bwd(const float* dy, const float* y, const float* x, const float* save_mean, const float* save_invstd,
+                      const float* gamma, int relu, long M, int C, float* red_scratch, float* dx, float* dres, float* dgamma_acc,
+                      float* dbeta_acc, void* stream) {
+  if (!dy || !x || !save_mean || !save_invstd || !gamma || !red_scratch || !dx || !bn_dims_ok(M, C) || (relu && !y))
+    return fail(HIFIHR_EINVAL, "hifihr_bn_act_bwd: bad argument (C/4 must divide 256)");
+  HIP_TRY(hifihr::launch_bn_act_bwd(dy, y, x, save_mean, save_invstd, gamma, relu, M, C, red_scratch, dx, dres, dgamma_acc,
+                                    dbeta_acc, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

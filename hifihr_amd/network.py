@@ -42,12 +42,12 @@ class Conv2dMFMA(nn.Module):
         self.stride, self.pad = stride, pad
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last))
 
-    def forward(self, x):
+    def forward(self, x, want_stats=False):
         from . import ops
         w = self.weight
         if w.shape[1] % 4 != 0:                       # the 3-channel stem: input arrives as NHWC4, pad the weight
             w = F.pad(w, (0, 0, 0, 0, 0, 4 - w.shape[1] % 4)).contiguous(memory_format=torch.channels_last)
-        return ops.conv2d(x, w, self.stride, self.pad)
+        return ops.conv2d(x, w, self.stride, self.pad, want_stats)
 
 
 _CONV_IMPL = {"impl": "mfma"}      # "mfma": hand-written kernels; "aten": nn.Conv2d (CPU oracle path / comparisons)
@@ -72,6 +72,17 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if isinstance(self.conv1, Conv2dMFMA):
+            # hand-written path: conv (MFMA, BN statistics from its epilogue) -> fused BN (+ identity) + ReLU
+            from . import ops
+            out, st = self.conv1(x, want_stats=True)
+            out = ops.bn_act(out, st, self.bn1, None, True)
+            out, st = self.conv2(out, want_stats=True)
+            idt = x
+            if self.downsample is not None:
+                idt, st2 = self.downsample[0](x, want_stats=True)
+                idt = ops.bn_act(idt, st2, self.downsample[1], None, False)
+            return ops.bn_act(out, st, self.bn2, idt, True)
         idt = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
@@ -119,7 +130,12 @@ class Resnet_4C(nn.Module):
 
     def forward(self, x):
         m = self.model
-        x = m.maxpool(m.relu(m.bn1(m.conv1(x))))
+        if isinstance(m.conv1, Conv2dMFMA):
+            from . import ops
+            h, st = m.conv1(x, want_stats=True)
+            x = m.maxpool(ops.bn_act(h, st, m.bn1, None, True))
+        else:
+            x = m.maxpool(m.relu(m.bn1(m.conv1(x))))
         x = m.layer1(x)
         x_low = m.layer2(x)
         x = m.layer4(m.layer3(x_low))

@@ -203,7 +203,7 @@ _CL = torch.channels_last
 
 class _Conv2dMFMA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, pad):
+    def forward(ctx, x, w, stride, pad, want_stats=False):
         require_cuda(x, w)
         lib = get_lib()
         x = x.contiguous(memory_format=_CL)
@@ -213,14 +213,22 @@ class _Conv2dMFMA(torch.autograd.Function):
         assert Cw == C and C % 4 == 0, (x.shape, w.shape)
         OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
-        PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, None, y, N, H, W, C, K, R, S, stride, pad))
+        stats = None
+        if want_stats:       # per-channel sum / sum of squares of y from the conv epilogue, for the batch-norm that follows
+            stats = torch.empty(2, K, device=x.device, dtype=torch.float32)
+            PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd_bnstats(x, wk, y, stats, N, H, W, C, K, R, S, stride, pad))
+        else:
+            PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, None, y, N, H, W, C, K, R, S, stride, pad))
         ctx.geom = (N, H, W, C, K, R, S, stride, pad)
         ctx.save_for_backward(x, wk)
         ctx.w_param = w
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gstats=None):
         x, wk = ctx.saved_tensors
         lib = get_lib()
         N, H, W, C, K, R, S, stride, pad = ctx.geom
@@ -239,12 +247,66 @@ class _Conv2dMFMA(torch.autograd.Function):
                 tgt = dw
             # accumulates (fp32 atomics) straight into the flat gradient buffer when the parameter lives in one
             PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, tgt, N, H, W, C, K, R, S, stride, pad))
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
-def conv2d(x, w, stride=1, pad=0):
-    """F.conv2d(x, w, None, stride, pad) for channels_last fp32 tensors (reference network/res_encoder.py:364-373)."""
-    return _Conv2dMFMA.apply(x, w, stride, pad)
+def conv2d(x, w, stride=1, pad=0, want_stats=False):
+    """F.conv2d(x, w, None, stride, pad) for channels_last fp32 tensors (reference network/res_encoder.py:364-373).
+    want_stats=True additionally returns the [2,K] (sum, sum of squares) of the output for `bn_act`."""
+    return _Conv2dMFMA.apply(x, w, stride, pad, want_stats)
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stats, gamma, beta, residual, relu, eps, momentum, running_mean, running_var):
+        require_cuda(x, stats, gamma, beta)
+        lib = get_lib()
+        x = x.contiguous(memory_format=_CL)
+        N, C, H, W = x.shape
+        M = N * H * W
+        res = residual.contiguous(memory_format=_CL) if residual is not None else None
+        y = torch.empty_like(x, memory_format=_CL)
+        save_mean = torch.empty(C, device=x.device)
+        save_invstd = torch.empty(C, device=x.device)
+        PROFILE.bracket("bn_fwd", lambda: lib.bn_act_fwd(x, stats, gamma, beta, res, relu, M, C, eps, momentum, y, save_mean,
+                                                         save_invstd, running_mean, running_var))
+        ctx.save_for_backward(x, y, gamma, save_mean, save_invstd)
+        ctx.relu, ctx.has_res, ctx.M, ctx.C = relu, residual is not None, M, C
+        ctx.gamma_param, ctx.beta_param = gamma, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, save_mean, save_invstd = ctx.saved_tensors
+        lib = get_lib()
+        dy = dy.contiguous(memory_format=_CL)
+        dx = torch.empty_like(x, memory_format=_CL)
+        dres = torch.empty_like(x, memory_format=_CL) if ctx.has_res else None
+        red = torch.empty(2, ctx.C, device=x.device)
+
+        def acc_target(p):
+            if getattr(p, "_hifihr_direct_grad", False) and p.grad is not None:
+                return p.grad, None                 # accumulate straight into the flat gradient buffer
+            t = torch.zeros(ctx.C, device=x.device)
+            return t, t
+        dg_t, dg_ret = acc_target(ctx.gamma_param)
+        db_t, db_ret = acc_target(ctx.beta_param)
+        PROFILE.bracket("bn_bwd", lambda: lib.bn_act_bwd(dy, y, x, save_mean, save_invstd, gamma, ctx.relu, ctx.M, ctx.C, red, dx,
+                                                         dres, dg_t, db_t))
+        return dx, None, dg_ret, db_ret, dres, None, None, None, None, None
+
+
+def bn_act(x, stats, bn: torch.nn.BatchNorm2d, residual=None, relu=True):
+    """relu?(bn(x) + residual?) with train-mode batch statistics (reference trunk: nn.BatchNorm2d + `out += identity`
+    + nn.ReLU).  `stats` comes from conv2d(..., want_stats=True).  Eval mode uses the running statistics (torch ops).
+    bn.num_batches_tracked is not advanced (it only matters for momentum=None, which the reference never uses)."""
+    if not bn.training:
+        out = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+        if residual is not None:
+            out = out + residual
+        return torch.relu(out) if relu else out
+    return _BNAct.apply(x, stats, bn.weight, bn.bias, residual, bool(relu), float(bn.eps), float(bn.momentum),
+                        bn.running_mean, bn.running_var)
 
 
 def image_to_nhwc4(images):

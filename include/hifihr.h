@@ -149,6 +149,30 @@ int hifihr_conv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, flo
 /* dw[K][R][S][C] += sum over pixels (ACCUMULATES with fp32 atomics: zero it, or pass the gradient buffer). */
 int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, void* stream);
+/* conv2d_fwd that also accumulates the per-channel sum and sum of squares of y into stats_d[2][K] (zeroed by the
+ * call) from the accumulator registers, so the batch-norm that follows needs no pass over y. */
+int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, float* stats_d, int N, int H, int W, int C, int K,
+                              int R, int S, int stride, int pad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm2d fused with the residual add and ReLU of a ResNet BasicBlock, NHWC: x[M][C], M = N*H*W.
+ * Replaces nn.BatchNorm2d(training=True) + `out += identity` + nn.ReLU and their autograd in the trunk
+ * (reference network/res_encoder.py:364-373; vendored BasicBlock utils/Freihand_GNN_mano/network/resnet.py).
+ * C % 4 == 0 and (C/4) | 256.  stats_d[2][C] = (sum, sum of squares) over the M rows (from
+ * hifihr_conv2d_fwd_bnstats, or hifihr_bn_stats for any other producer).
+ *   fwd: y = relu?( (x - mean) * invstd * gamma + beta + residual? ); writes save_mean/save_invstd[C] and updates
+ *        running_mean/var (momentum, unbiased variance) when given.
+ *   bwd: g = dy * (y > 0) when relu; dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (may be NULL) = g;
+ *        dgamma_acc[C] += sum g*xhat, dbeta_acc[C] += sum g (either may be NULL); red_scratch_d: 2*C floats.
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_bn_stats(const float* x_d, long M, int C, float* stats_d, void* stream);
+int hifihr_bn_act_fwd(const float* x_d, const float* stats_d, const float* gamma_d, const float* beta_d,
+                      const float* residual_d /* or NULL */, int relu, long M, int C, float eps, float momentum, float* y_d,
+                      float* save_mean_d, float* save_invstd_d, float* running_mean_d, float* running_var_d, void* stream);
+int hifihr_bn_act_bwd(const float* dy_d, const float* y_d, const float* x_d, const float* save_mean_d,
+                      const float* save_invstd_d, const float* gamma_d, int relu, long M, int C, float* red_scratch_d,
+                      float* dx_d, float* dres_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
+
 /* normalize_batch_3C (reference network/res_encoder.py:212-216) fused with NCHW[B][3][H][W] -> NHWC4 [B][H][W][4]
  * (4th channel zero) for the first convolution. */
 int hifihr_image_to_nhwc4(const float* images_d, float* out_d, int B, int H, int W, void* stream);

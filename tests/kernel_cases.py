@@ -245,3 +245,63 @@ def ssim_case(lib, device, a, b, ref_val=None, ref_grad=None):
     lib.ssim_bwd(win, da, db, maps[0], maps[1], maps[2], torch.full((1,), 2.0, device=device), g)
     ref = 2.0 * np.asarray(ref_grad)
     assert np.abs(g.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-10
+
+
+# ------------------------------------------------------------------------------------------------
+# fused train-mode BatchNorm (+ residual add + ReLU), NHWC, vs plain PyTorch fp32 (F.batch_norm + add + relu autograd)
+# ------------------------------------------------------------------------------------------------
+def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False):
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    M = N * H * W
+    x = torch.randn(N, C, H, W, generator=gen) * 1.5 + 0.3
+    gamma = 1 + 0.1 * torch.randn(C, generator=gen); beta = 0.1 * torch.randn(C, generator=gen)
+    res = torch.randn(N, C, H, W, generator=gen) if residual else None
+    rm0, rv0 = torch.randn(C, generator=gen) * 0.1, 1 + 0.1 * torch.rand(C, generator=gen)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if residual else None
+    rm, rv = rm0.clone(), rv0.clone()
+    out = F.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)
+    if residual:
+        out = out + rr
+    if relu:
+        out = F.relu(out)
+    gy = torch.randn(out.shape, generator=gen)
+    out.backward(gy)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(device)
+    dx_in = nhwc(x)
+    stats = torch.empty(2, C, device=device)
+    lib.bn_stats(dx_in, M, C, stats)
+    np.testing.assert_allclose(stats[0].cpu().numpy(), x.permute(1, 0, 2, 3).reshape(C, -1).sum(1).numpy(), rtol=1e-4, atol=1e-3)
+    y = torch.empty(N, H, W, C, device=device); sm = torch.empty(C, device=device); si = torch.empty(C, device=device)
+    rmd, rvd = rm0.clone().to(device), rv0.clone().to(device)
+    lib.bn_act_fwd(dx_in, stats, gamma.to(device), beta.to(device), nhwc(res) if residual else None, relu, M, C, 1e-5, 0.1, y, sm, si, rmd, rvd)
+    ref = out.detach().permute(0, 2, 3, 1)
+    assert float((y.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), "bn fwd"
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
+    red = torch.empty(2, C, device=device); dxo = torch.empty_like(y); dres = torch.empty_like(y) if residual else None
+    dg = torch.full((C,), 0.5, device=device); db = torch.full((C,), -0.25, device=device)     # accumulate semantics
+    lib.bn_act_bwd(nhwc(gy), y, dx_in, sm, si, gamma.to(device), relu, M, C, red, dxo, dres, dg, db)
+    refdx = xr.grad.permute(0, 2, 3, 1)
+    assert float((dxo.cpu() - refdx).abs().max()) <= 2e-4 * float(refdx.abs().max()) + 1e-7, "bn bwd dx"
+    assert float((dg.cpu() - 0.5 - gr.grad).abs().max()) <= 2e-4 * float(gr.grad.abs().max()) + 1e-5, "bn dgamma"
+    assert float((db.cpu() + 0.25 - br.grad).abs().max()) <= 2e-4 * float(br.grad.abs().max()) + 1e-5, "bn dbeta"
+    if residual:
+        assert float((dres.cpu() - rr.grad.permute(0, 2, 3, 1)).abs().max()) <= 1e-6, "bn dres"
+
+
+def conv_bnstats_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0):
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=gen); w = torch.randn(K, C, R, R, generator=gen) / (C * R * R) ** 0.5
+    y = F.conv2d(x, w, None, stride, pad)
+    OH, OW = y.shape[2], y.shape[3]
+    d = lambda t: t.to(device).contiguous()
+    out = torch.empty(N, OH, OW, K, device=device); stats = torch.full((2, K), 7.0, device=device)
+    lib.conv2d_fwd_bnstats(d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), out, stats, N, H, W, C, K, R, R, stride, pad)
+    ref = y.permute(0, 2, 3, 1)
+    assert float((out.cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6
+    s_ref = y.permute(1, 0, 2, 3).reshape(K, -1)
+    np.testing.assert_allclose(stats[0].cpu().numpy(), s_ref.sum(1).numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(stats[1].cpu().numpy(), (s_ref ** 2).sum(1).numpy(), rtol=1e-4, atol=2e-3)

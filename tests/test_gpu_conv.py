@@ -43,15 +43,14 @@ def test_resnet18_trunk_mfma_vs_reference_golden(golden_dir):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from seeded_init import seeded_state_dict
     from hifihr_amd import ops
-    from hifihr_amd.network import ResNet18Trunk
+    from hifihr_amd.network import Resnet_4C
     g = np.load(os.path.join(golden_dir, "resnet18_small.npz"))
-    net = ResNet18Trunk(layer4_stride=1, conv_impl="mfma")
-    net.load_state_dict(seeded_state_dict(net))
-    net = net.cuda().train()
+    enc = Resnet_4C("res18", conv_impl="mfma")          # stem + blocks on the MFMA convs and the fused BN/add/ReLU kernels
+    enc.model.load_state_dict(seeded_state_dict(enc.model))
+    enc = enc.cuda().train()
+    net = enc.model
     x = ops.image_to_nhwc4(torch.tensor(g["x"]).cuda())
-    h = net.maxpool(net.relu(net.bn1(net.conv1(x))))
-    low = net.layer2(net.layer1(h))
-    feat = net.layer4(net.layer3(low))
+    low, feat = enc(x)
     np.testing.assert_allclose(low.detach().cpu().numpy(), g["low"], atol=5e-5, rtol=1e-4)
     np.testing.assert_allclose(feat.detach().cpu().numpy(), g["feat"], atol=5e-5, rtol=1e-4)
     ((low * torch.tensor(g["wl"]).cuda()).sum() + (feat * torch.tensor(g["wf"]).cuda()).sum()).backward()
@@ -60,3 +59,13 @@ def test_resnet18_trunk_mfma_vs_reference_golden(golden_dir):
         ref = g[key]
         err = np.abs(grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
         assert err < 5e-3, (key, err)
+
+
+@pytest.mark.parametrize("C,relu,residual,N,H", [(64, True, False, 32, 56), (128, True, True, 8, 28), (512, False, False, 32, 14), (256, True, True, 4, 14)])
+def test_bn_act_kernels(lib, C, relu, residual, N, H):
+    kc.bn_act_case(lib, "cuda", N, H, H, C, relu, residual, seed=C + N)
+
+
+def test_conv_epilogue_bn_statistics(lib):
+    kc.conv_bnstats_case(lib, "cuda", 8, 56, 56, 64, 64, 3, 1, 1)
+    kc.conv_bnstats_case(lib, "cuda", 4, 224, 224, 4, 64, 7, 2, 3)

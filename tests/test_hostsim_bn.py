@@ -1,0 +1,19 @@
+"""Fused BatchNorm(+add+ReLU) kernel SOURCES and the conv epilogue statistics on the hostsim emulator vs torch."""
+import pytest
+
+import kernel_cases as kc
+
+
+@pytest.fixture(scope="module")
+def hostsim_lib():
+    return kc.build_hostsim()
+
+
+@pytest.mark.parametrize("C,relu,residual", [(64, True, False), (128, True, True), (256, False, False), (16, True, True)])
+def test_bn_act_fwd_bwd(hostsim_lib, C, relu, residual):
+    kc.bn_act_case(hostsim_lib, "cpu", 3, 5, 7, C, relu, residual, seed=C)
+
+
+def test_conv_epilogue_bn_statistics(hostsim_lib):
+    kc.conv_bnstats_case(hostsim_lib, "cpu", 2, 9, 7, 16, 64, 3, 1, 1)
+    kc.conv_bnstats_case(hostsim_lib, "cpu", 1, 16, 16, 4, 64, 7, 2, 3)
