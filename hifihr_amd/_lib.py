@@ -85,6 +85,8 @@ class HifihrLib:
         c.hifihr_conv2d_fwd.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
         c.hifihr_conv2d_bwd_data.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
         c.hifihr_conv2d_fwd_bnstats.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
+        c.hifihr_bn_stats_floats.argtypes = [c_int]
+        c.hifihr_bn_stats_floats.restype = c_int
         c.hifihr_bn_stats.argtypes = [_c_float_p, c_long, c_int, _c_float_p, c_void_p]
         c.hifihr_bn_act_fwd.argtypes = [_c_float_p] * 5 + [c_int, c_long, c_int, c_float, c_float] + [_c_float_p] * 5 + [c_void_p]
         c.hifihr_bn_act_bwd.argtypes = [_c_float_p] * 6 + [c_int, c_long, c_int] + [_c_float_p] * 5 + [c_void_p]
@@ -148,6 +150,9 @@ class HifihrLib:
     def conv2d_fwd_bnstats(self, x, w, y, stats, N, H, W, C, K, R, S, stride, pad):
         self.check(self.c.hifihr_conv2d_fwd_bnstats(_fp(x), _fp(w), _fp(y), _fp(stats), N, H, W, C, K, R, S, stride, pad,
                                                     _stream_of(x)), "hifihr_conv2d_fwd_bnstats")
+
+    def bn_stats_floats(self, C):
+        return int(self.c.hifihr_bn_stats_floats(int(C)))
 
     def bn_stats(self, x, M, C, stats):
         self.check(self.c.hifihr_bn_stats(_fp(x), c_long(M), C, _fp(stats), _stream_of(x)), "hifihr_bn_stats")

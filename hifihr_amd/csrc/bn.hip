@@ -16,7 +16,7 @@
 
 namespace hifihr {
 
-// standalone statistics (used when the producer is not one of our convolutions): stats[2][C] += sums (pre-zeroed)
+// standalone statistics (used when the producer is not one of our convolutions): stats[kStatSlots][2][C] += sums
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long M, int C, float* __restrict__ stats) {
   __shared__ float4 red[2][256];
   const int C4 = C / 4;
@@ -35,43 +35,53 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
       const float4 a = red[0][r * C4 + cg], b = red[1][r * C4 + cg];
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
     }
-    float* ps = stats + cg * 4;
-    float* pq = stats + C + cg * 4;
+    float* ps = stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * C + cg * 4;
+    float* pq = ps + C;
     atomicAdd(ps, s.x); atomicAdd(ps + 1, s.y); atomicAdd(ps + 2, s.z); atomicAdd(ps + 3, s.w);
     atomicAdd(pq, q.x); atomicAdd(pq + 1, q.y); atomicAdd(pq + 2, q.z); atomicAdd(pq + 3, q.w);
   }
 }
 
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const float* __restrict__ residual, int relu, long M, int C, float eps,
-                                                        float momentum, float* __restrict__ y, float* __restrict__ save_mean,
-                                                        float* __restrict__ save_invstd, float* __restrict__ running_mean,
-                                                        float* __restrict__ running_var) {
+// sum of the kStatSlots partial copies of entry `idx` of a [kStatSlots][2][C] buffer
+__device__ __forceinline__ float slot_sum(const float* __restrict__ buf, int C, int idx) {
+  float a = 0.f;
+#pragma unroll 8
+  for (int sl = 0; sl < kStatSlots; ++sl) a += buf[(size_t)sl * 2 * C + idx];
+  return a;
+}
+
+// one thread per channel: fold the slot partials into mean / invstd, update the running statistics
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ stats, long M, int C, float eps, float momentum,
+                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float invM = 1.0f / (float)M;
+  const float mu = slot_sum(stats, C, c) * invM;
+  float var = slot_sum(stats, C, C + c) * invM - mu * mu;   // biased batch variance
+  var = fmaxf(var, 0.f);
+  save_mean[c] = mu;
+  save_invstd[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    const float unbiased = (M > 1) ? var * ((float)M / (float)(M - 1)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ save_mean,
+                                                        const float* __restrict__ save_invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ residual,
+                                                        int relu, long M, int C, float* __restrict__ y) {
   const int C4 = C / 4;
   const int cg = threadIdx.x % C4;
   const int rl = threadIdx.x / C4, RL = 256 / C4;
-  const float invM = 1.0f / (float)M;
-  float mean[4], scale[4], shift[4];
+  float scale[4], shift[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = cg * 4 + k;
-    const float mu = stats[c] * invM;
-    float var = stats[C + c] * invM - mu * mu;            // biased batch variance
-    var = fmaxf(var, 0.f);
-    const float istd = 1.0f / sqrtf(var + eps);
-    mean[k] = mu;
-    scale[k] = istd * gamma[c];
-    shift[k] = beta[c] - mu * scale[k];
-    if (blockIdx.x == 0 && rl == 0) {
-      save_mean[c] = mu;
-      save_invstd[c] = istd;
-      if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-        const float unbiased = (M > 1) ? var * ((float)M / (float)(M - 1)) : var;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-      }
-    }
+    scale[k] = save_invstd[c] * gamma[c];
+    shift[k] = beta[c] - save_mean[c] * scale[k];
   }
   for (long m = (long)blockIdx.x * RL + rl; m < M; m += (long)gridDim.x * RL) {
     const size_t o = (size_t)m * C + cg * 4;
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
 }
 
-// red[2][C] += (sum g, sum g * xhat), g = dy * (y > 0 if relu)
+// red[kStatSlots][2][C] += (sum g, sum g * xhat), g = dy * (y > 0 if relu)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ x, const float* __restrict__ save_mean,
                                                            const float* __restrict__ save_invstd, int relu, long M, int C,
@@ -117,21 +127,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       const float4 a = lds[0][r * C4 + cg], b = lds[1][r * C4 + cg];
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
     }
-    float* ps = red + cg * 4;
-    float* pq = red + C + cg * 4;
+    float* ps = red + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * C + cg * 4;
+    float* pq = ps + C;
     atomicAdd(ps, s.x); atomicAdd(ps + 1, s.y); atomicAdd(ps + 2, s.z); atomicAdd(ps + 3, s.w);
     atomicAdd(pq, q.x); atomicAdd(pq + 1, q.y); atomicAdd(pq + 2, q.z); atomicAdd(pq + 3, q.w);
   }
 }
 
-// dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  dres = g (when the block has an identity branch);
-// block 0 adds dgamma = sum g*xhat and dbeta = sum g into the parameter-gradient buffers.
+// one thread per channel: fold the slot partials of the backward reduction into tot[2][C]; dgamma / dbeta accumulate
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ red, int C, float* __restrict__ tot,
+                                                             float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float sg = slot_sum(red, C, c), sgx = slot_sum(red, C, C + c);
+  tot[c] = sg;
+  tot[C + c] = sgx;
+  if (dgamma_acc) dgamma_acc[c] += sgx;
+  if (dbeta_acc) dbeta_acc[c] += sg;
+}
+
+// dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  dres = g (when the block has an identity branch)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                           const float* __restrict__ x, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, const float* __restrict__ gamma,
-                                                          const float* __restrict__ red, int relu, long M, int C,
-                                                          float* __restrict__ dx, float* __restrict__ dres,
-                                                          float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
+                                                          const float* __restrict__ tot, int relu, long M, int C,
+                                                          float* __restrict__ dx, float* __restrict__ dres) {
   const int C4 = C / 4;
   const int cg = threadIdx.x % C4;
   const int rl = threadIdx.x / C4, RL = 256 / C4;
@@ -142,11 +162,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int c = cg * 4 + k;
     mu[k] = save_mean[c]; is[k] = save_invstd[c];
     k1[k] = gamma[c] * is[k];
-    mg[k] = red[c] * invM; mgx[k] = red[C + c] * invM;
-    if (blockIdx.x == 0 && rl == 0) {
-      if (dgamma_acc) dgamma_acc[c] += red[C + c];
-      if (dbeta_acc) dbeta_acc[c] += red[c];
-    }
+    mg[k] = tot[c] * invM; mgx[k] = tot[C + c] * invM;
   }
   for (long m = (long)blockIdx.x * RL + rl; m < M; m += (long)gridDim.x * RL) {
     const size_t o = (size_t)m * C + cg * 4;
@@ -177,7 +193,7 @@ static bool bn_c_ok(int C) { return C >= 4 && C % 4 == 0 && (256 % (C / 4)) == 0
 
 hipError_t launch_bn_stats(const float* x, long M, int C, float* stats, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st);
+  hipError_t e = hipMemsetAsync(stats, 0, (size_t)kStatSlots * 2 * C * sizeof(float), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, x, M, C, stats);
   return hipGetLastError();
@@ -187,8 +203,10 @@ hipError_t launch_bn_act_fwd(const float* x, const float* stats, const float* ga
                              int relu, long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,
                              float* running_mean, float* running_var, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, x, stats, gamma, beta, residual, relu, M, C, eps,
-                     momentum, y, save_mean, save_invstd, running_mean, running_var);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, M, C, eps, momentum, save_mean,
+                     save_invstd, running_mean, running_var);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual,
+                     relu, M, C, y);
   return hipGetLastError();
 }
 
@@ -196,11 +214,14 @@ hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, co
                              const float* gamma, int relu, long M, int C, float* red, float* dx, float* dres, float* dgamma_acc,
                              float* dbeta_acc, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(red, 0, (size_t)2 * C * sizeof(float), st);
+  // red: kStatSlots slot partials followed by the [2][C] totals
+  hipError_t e = hipMemsetAsync(red, 0, (size_t)kStatSlots * 2 * C * sizeof(float), st);
   if (e != hipSuccess) return e;
+  float* tot = red + (size_t)kStatSlots * 2 * C;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, relu, M, C, red);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, red, relu,
-                     M, C, dx, dres, dgamma_acc, dbeta_acc);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, red, C, tot, dgamma_acc, dbeta_acc);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, tot, relu,
+                     M, C, dx, dres);
   return hipGetLastError();
 }
 

@@ -80,7 +80,7 @@ template <int BM, int BN, bool GENERIC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float* __restrict__ src,
                                                         const float* __restrict__ wgt, const float* __restrict__ bias,
                                                         float* __restrict__ dst, float* __restrict__ stats) {
-  // stats (optional, forward only): [2][OC] per-channel sum and sum of squares of the output, accumulated with
+  // stats (optional, forward only): [kStatSlots][2][OC] per-channel sum and sum of squares of the output, accumulated with
   // atomics from the accumulator registers -- the batch-norm that follows needs no separate pass over y
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves are arranged 2 x 2)
   __shared__ __attribute__((aligned(16))) float As[2][BM * kLD];
@@ -264,8 +264,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
           ssum += __shfl_down(ssum, 32, 64);     // lanes l and l + 32 hold the same channel, different rows
           ssq += __shfl_down(ssq, 32, 64);
           if (half == 0 && k < g.OC) {           // 32 consecutive channels: two 128-byte atomic segments per wave
-            atomicAdd(stats + k, ssum);
-            atomicAdd(stats + g.OC + k, ssq);
+            float* sp = stats + (size_t)((blockIdx.x * 2 + wm) & (kStatSlots - 1)) * 2 * g.OC;   // slot by row tile
+            atomicAdd(sp + k, ssum);
+            atomicAdd(sp + g.OC + k, ssq);
           }
         }
       }
@@ -463,7 +464,7 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
                              hipStream_t st) {
   if (stats != nullptr) {
     if (g.dgrad) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(stats, 0, (size_t)2 * g.OC * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(stats, 0, (size_t)kStatSlots * 2 * g.OC * sizeof(float), st);
     if (e != hipSuccess) return e;
   }
   if (g.IC % 4 != 0) return hipErrorInvalidValue;

@@ -324,6 +324,8 @@ int hifihr_ssim_bwd(const float* window11, const float* img1, const float* img2,
   return HIFIHR_OK;
 }
 
+int hifihr_bn_stats_floats(int C) { return C > 0 ? (hifihr::kStatSlots + 1) * 2 * C : 0; }
+
 static int bn_dims_ok(long M, int C) { return M > 0 && C >= 4 && C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0; }
 
 int hifihr_bn_stats(const float* x, long M, int C, float* stats, void* stream) {

@@ -57,7 +57,10 @@ struct ConvGeom {
 };
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
                              hipStream_t st);
-// batch-norm (+ residual add + ReLU) on NHWC activations, x[M][C]
+// batch-norm (+ residual add + ReLU) on NHWC activations, x[M][C].  Statistics buffers are [kStatSlots][2][C]: partial
+// sums are spread over kStatSlots copies so that at most ~1/32 of the contributing workgroups hit one address with a
+// float atomic (thousands of atomics on ONE address serialise at ~100 ns each: 200 us per reduction in round 1).
+constexpr int kStatSlots = 32;
 hipError_t launch_bn_stats(const float* x, long M, int C, float* stats, hipStream_t st);
 hipError_t launch_bn_act_fwd(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
                              int relu, long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,

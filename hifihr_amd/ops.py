@@ -215,7 +215,7 @@ class _Conv2dMFMA(torch.autograd.Function):
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
         stats = None
         if want_stats:       # per-channel sum / sum of squares of y from the conv epilogue, for the batch-norm that follows
-            stats = torch.empty(2, K, device=x.device, dtype=torch.float32)
+            stats = torch.empty(lib.bn_stats_floats(K), device=x.device, dtype=torch.float32)
             PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd_bnstats(x, wk, y, stats, N, H, W, C, K, R, S, stride, pad))
         else:
             PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, None, y, N, H, W, C, K, R, S, stride, pad))
@@ -282,7 +282,7 @@ class _BNAct(torch.autograd.Function):
         dy = dy.contiguous(memory_format=_CL)
         dx = torch.empty_like(x, memory_format=_CL)
         dres = torch.empty_like(x, memory_format=_CL) if ctx.has_res else None
-        red = torch.empty(2, ctx.C, device=x.device)
+        red = torch.empty(lib.bn_stats_floats(ctx.C), device=x.device)
 
         def acc_target(p):
             if getattr(p, "_hifihr_direct_grad", False) and p.grad is not None:

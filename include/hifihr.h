@@ -149,8 +149,8 @@ int hifihr_conv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, flo
 /* dw[K][R][S][C] += sum over pixels (ACCUMULATES with fp32 atomics: zero it, or pass the gradient buffer). */
 int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, void* stream);
-/* conv2d_fwd that also accumulates the per-channel sum and sum of squares of y into stats_d[2][K] (zeroed by the
- * call) from the accumulator registers, so the batch-norm that follows needs no pass over y. */
+/* conv2d_fwd that also accumulates the per-channel sum and sum of squares of y into stats_d (hifihr_bn_stats_floats(K)
+ * floats, zeroed by the call) from the accumulator registers, so the batch-norm that follows needs no pass over y. */
 int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, float* stats_d, int N, int H, int W, int C, int K,
                               int R, int S, int stride, int pad, void* stream);
 
@@ -158,13 +158,15 @@ int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, fl
  * Train-mode BatchNorm2d fused with the residual add and ReLU of a ResNet BasicBlock, NHWC: x[M][C], M = N*H*W.
  * Replaces nn.BatchNorm2d(training=True) + `out += identity` + nn.ReLU and their autograd in the trunk
  * (reference network/res_encoder.py:364-373; vendored BasicBlock utils/Freihand_GNN_mano/network/resnet.py).
- * C % 4 == 0 and (C/4) | 256.  stats_d[2][C] = (sum, sum of squares) over the M rows (from
+ * C % 4 == 0 and (C/4) | 256.  stats_d / red_scratch_d hold hifihr_bn_stats_floats(C) floats: partial (sum, sum of
+ * squares) over the M rows, spread over several slots to keep float-atomic contention low (from
  * hifihr_conv2d_fwd_bnstats, or hifihr_bn_stats for any other producer).
  *   fwd: y = relu?( (x - mean) * invstd * gamma + beta + residual? ); writes save_mean/save_invstd[C] and updates
  *        running_mean/var (momentum, unbiased variance) when given.
  *   bwd: g = dy * (y > 0) when relu; dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (may be NULL) = g;
- *        dgamma_acc[C] += sum g*xhat, dbeta_acc[C] += sum g (either may be NULL); red_scratch_d: 2*C floats.
+ *        dgamma_acc[C] += sum g*xhat, dbeta_acc[C] += sum g (either may be NULL).
  * ---------------------------------------------------------------------------------------------- */
+int hifihr_bn_stats_floats(int C);
 int hifihr_bn_stats(const float* x_d, long M, int C, float* stats_d, void* stream);
 int hifihr_bn_act_fwd(const float* x_d, const float* stats_d, const float* gamma_d, const float* beta_d,
                       const float* residual_d /* or NULL */, int relu, long M, int C, float eps, float momentum, float* y_d,

@@ -270,9 +270,10 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
     out.backward(gy)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(device)
     dx_in = nhwc(x)
-    stats = torch.empty(2, C, device=device)
+    stats = torch.empty(lib.bn_stats_floats(C), device=device)
     lib.bn_stats(dx_in, M, C, stats)
-    np.testing.assert_allclose(stats[0].cpu().numpy(), x.permute(1, 0, 2, 3).reshape(C, -1).sum(1).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(stats.view(-1, 2, C)[:-1].sum(0)[0].cpu().numpy(), x.permute(1, 0, 2, 3).reshape(C, -1).sum(1).numpy(),
+                               rtol=1e-4, atol=1e-3)
     y = torch.empty(N, H, W, C, device=device); sm = torch.empty(C, device=device); si = torch.empty(C, device=device)
     rmd, rvd = rm0.clone().to(device), rv0.clone().to(device)
     lib.bn_act_fwd(dx_in, stats, gamma.to(device), beta.to(device), nhwc(res) if residual else None, relu, M, C, 1e-5, 0.1, y, sm, si, rmd, rvd)
@@ -280,7 +281,7 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
     assert float((y.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), "bn fwd"
     np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
-    red = torch.empty(2, C, device=device); dxo = torch.empty_like(y); dres = torch.empty_like(y) if residual else None
+    red = torch.empty(lib.bn_stats_floats(C), device=device); dxo = torch.empty_like(y); dres = torch.empty_like(y) if residual else None
     dg = torch.full((C,), 0.5, device=device); db = torch.full((C,), -0.25, device=device)     # accumulate semantics
     lib.bn_act_bwd(nhwc(gy), y, dx_in, sm, si, gamma.to(device), relu, M, C, red, dxo, dres, dg, db)
     refdx = xr.grad.permute(0, 2, 3, 1)
@@ -298,10 +299,11 @@ def conv_bnstats_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0):
     y = F.conv2d(x, w, None, stride, pad)
     OH, OW = y.shape[2], y.shape[3]
     d = lambda t: t.to(device).contiguous()
-    out = torch.empty(N, OH, OW, K, device=device); stats = torch.full((2, K), 7.0, device=device)
+    out = torch.empty(N, OH, OW, K, device=device); stats = torch.full((lib.bn_stats_floats(K),), 7.0, device=device)
     lib.conv2d_fwd_bnstats(d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), out, stats, N, H, W, C, K, R, R, stride, pad)
     ref = y.permute(0, 2, 3, 1)
     assert float((out.cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6
     s_ref = y.permute(1, 0, 2, 3).reshape(K, -1)
-    np.testing.assert_allclose(stats[0].cpu().numpy(), s_ref.sum(1).numpy(), rtol=1e-4, atol=2e-3)
-    np.testing.assert_allclose(stats[1].cpu().numpy(), (s_ref ** 2).sum(1).numpy(), rtol=1e-4, atol=2e-3)
+    st = stats.view(-1, 2, K)[:-1].sum(0)
+    np.testing.assert_allclose(st[0].cpu().numpy(), s_ref.sum(1).numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(st[1].cpu().numpy(), (s_ref ** 2).sum(1).numpy(), rtol=1e-4, atol=2e-3)
