@@ -57,16 +57,22 @@ class GradReducer:
                 self.param_bucket[i] = b
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._done = [False] * n                         # a parameter may be reported twice (autograd hook + direct writer)
         self._handles = []
         if self.world > 1:
             for i, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                hook = self._make_hook(i)
+                p.register_post_accumulate_grad_hook(hook)
+                # kernels that accumulate straight into the flat gradient buffer (conv wgrad, BN dgamma/dbeta) bypass
+                # autograd's AccumulateGrad, so hifihr_amd.ops calls this instead once the parameter's gradient is enqueued
+                p._hifihr_grad_ready = hook
         self.reset()
 
     def reset(self):
         for b, (lo, hi, _, _) in enumerate(self.buckets):
             self._pending[b] = hi - lo
             self._launched[b] = False
+        self._done = [False] * len(self._done)
         self._handles = []
 
     def _launch(self, b):
@@ -76,6 +82,9 @@ class GradReducer:
 
     def _make_hook(self, i):
         def hook(_param):
+            if self._done[i]:
+                return
+            self._done[i] = True
             b = self.param_bucket[i]
             self._pending[b] -= 1
             if self._pending[b] == 0 and not self._launched[b]:

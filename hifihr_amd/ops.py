@@ -201,6 +201,14 @@ def render(handle: RendererHandle, verts, vcolors, cam, light_color, light_dir):
 _CL = torch.channels_last
 
 
+def _grad_ready(p):
+    """Tell the data-parallel reducer (hifihr_amd/dist.py) that this parameter's gradient has been enqueued by a kernel
+    that wrote it directly (no autograd AccumulateGrad, hence no post-accumulate hook)."""
+    cb = getattr(p, "_hifihr_grad_ready", None)
+    if cb is not None:
+        cb(p)
+
+
 class _Conv2dMFMA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, pad, want_stats=False):
@@ -247,6 +255,8 @@ class _Conv2dMFMA(torch.autograd.Function):
                 tgt = dw
             # accumulates (fp32 atomics) straight into the flat gradient buffer when the parameter lives in one
             PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, tgt, N, H, W, C, K, R, S, stride, pad))
+            if dw is None:
+                _grad_ready(w)
         return dx, dw, None, None, None
 
 
@@ -293,6 +303,10 @@ class _BNAct(torch.autograd.Function):
         db_t, db_ret = acc_target(ctx.beta_param)
         PROFILE.bracket("bn_bwd", lambda: lib.bn_act_bwd(dy, y, x, save_mean, save_invstd, gamma, ctx.relu, ctx.M, ctx.C, red, dx,
                                                          dres, dg_t, db_t))
+        if dg_ret is None:
+            _grad_ready(ctx.gamma_param)
+        if db_ret is None:
+            _grad_ready(ctx.beta_param)
         return dx, None, dg_ret, db_ret, dres, None, None, None, None, None
 
 
