@@ -145,8 +145,12 @@ def main():
         if "render_fwd" in kern:
             us = kern["render_fwd"][0]
             ach = alg * B / (us * 1e-6) / 1e9
+            traffic = None
+            tf = os.path.join(REPO, "profiles", "r01_render_fwd_traffic.json")
+            if B == 32 and os.path.exists(tf):      # PMC-measured HBM bytes per launch of this exact workload (separate --pmc passes)
+                traffic = json.load(open(tf))["traffic_bytes_per_launch"]
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                               "traffic": None, "kernel": "render_fwd_kernel<3> (+ render_vertex_kernel)",
+                               "traffic": traffic, "kernel": "render_fwd_kernel<3> (+ render_vertex_kernel)",
                                "avg_us": us, "algorithmic_bytes_per_launch": alg * B}
         out["kernels_avg_us"] = {k: round(v[0], 2) for k, v in kern.items()}
         out["render_ms_per_frame"] = {"fwd": kern.get("render_fwd", (0,))[0] / B / 1e3,
