@@ -28,6 +28,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--encoder", default="res18", choices=["res18", "effb3"], help="res18 = BASELINE configs[1] (headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as one hipGraph, 0: eager, -1: auto (on for 1 GPU)")
     ap.add_argument("--cpu-batch", type=int, default=2, help="sample size of the CPU baseline (images)")
@@ -71,7 +72,7 @@ def main():
     args_ns = options.baseline_config2_args(train_batch=a.batch)
     tables = synthetic_mano_tables(0)
     torch.manual_seed(0)
-    model = Model(ifRender=True, device=dev, if_4c=False, hand_model="mano", use_mean_shape=False, pretrain="res18",
+    model = Model(ifRender=True, device=dev, if_4c=False, hand_model="mano", use_mean_shape=False, pretrain=a.encoder,
                   mano_tables=tables).to(dev).train()
     flat = FlatParams(model)
     hdist.broadcast_params(flat)
@@ -134,7 +135,8 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (FreiHAND-shaped, seeded; synthetic MANO-shaped tables; random-init weights)",
             "config": {"workload": "BASELINE configs[1]: FreiHAND batch=32/GPU, ResNet-18 encoder + MANO LBS + "
-                                   "silhouette/texture render losses, 224x224, aa=3 (672^2 samples)",
+                                   "silhouette/texture render losses, 224x224, aa=3 (672^2 samples)"
+                                   + ("" if a.encoder == "res18" else f" [encoder swapped to {a.encoder}: NOT the headline config]"),
                        "per_gpu_batch": B, "global_batch": world * B, "losses": args_ns.losses, "parallelism": f"dp{world}"},
             "loss": float(loss.detach()), "launch_mode": graph_note,
         }

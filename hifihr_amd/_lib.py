@@ -89,7 +89,7 @@ class HifihrLib:
         c.hifihr_bn_stats_floats.restype = c_int
         c.hifihr_bn_stats.argtypes = [_c_float_p, c_long, c_int, _c_float_p, c_void_p]
         c.hifihr_bn_act_fwd.argtypes = [_c_float_p] * 5 + [c_int, c_long, c_int, c_float, c_float] + [_c_float_p] * 5 + [c_void_p]
-        c.hifihr_bn_act_bwd.argtypes = [_c_float_p] * 6 + [c_int, c_long, c_int] + [_c_float_p] * 5 + [c_void_p]
+        c.hifihr_bn_act_bwd.argtypes = [_c_float_p] * 7 + [c_int, c_long, c_int] + [_c_float_p] * 5 + [c_void_p]
         c.hifihr_conv2d_bwd_weight.argtypes = [_c_float_p] * 3 + ci + [c_void_p]
         c.hifihr_image_to_nhwc4.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_adam_step.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
@@ -157,13 +157,13 @@ class HifihrLib:
     def bn_stats(self, x, M, C, stats):
         self.check(self.c.hifihr_bn_stats(_fp(x), c_long(M), C, _fp(stats), _stream_of(x)), "hifihr_bn_stats")
 
-    def bn_act_fwd(self, x, stats, gamma, beta, residual, relu, M, C, eps, momentum, y, save_mean, save_invstd, rmean, rvar):
-        self.check(self.c.hifihr_bn_act_fwd(_fp(x), _fp(stats), _fp(gamma), _fp(beta), _fp(residual), int(relu), c_long(M), C,
+    def bn_act_fwd(self, x, stats, gamma, beta, residual, act, M, C, eps, momentum, y, save_mean, save_invstd, rmean, rvar):
+        self.check(self.c.hifihr_bn_act_fwd(_fp(x), _fp(stats), _fp(gamma), _fp(beta), _fp(residual), int(act), c_long(M), C,
                                             c_float(eps), c_float(momentum), _fp(y), _fp(save_mean), _fp(save_invstd), _fp(rmean),
                                             _fp(rvar), _stream_of(x)), "hifihr_bn_act_fwd")
 
-    def bn_act_bwd(self, dy, y, x, save_mean, save_invstd, gamma, relu, M, C, red, dx, dres, dgamma_acc, dbeta_acc):
-        self.check(self.c.hifihr_bn_act_bwd(_fp(dy), _fp(y), _fp(x), _fp(save_mean), _fp(save_invstd), _fp(gamma), int(relu),
+    def bn_act_bwd(self, dy, y, x, save_mean, save_invstd, gamma, beta, act, M, C, red, dx, dres, dgamma_acc, dbeta_acc):
+        self.check(self.c.hifihr_bn_act_bwd(_fp(dy), _fp(y), _fp(x), _fp(save_mean), _fp(save_invstd), _fp(gamma), _fp(beta), int(act),
                                             c_long(M), C, _fp(red), _fp(dx), _fp(dres), _fp(dgamma_acc), _fp(dbeta_acc),
                                             _stream_of(dy)), "hifihr_bn_act_bwd")
 

@@ -1,53 +1,113 @@
-// Train-mode batch normalisation fused with the residual add and ReLU, NHWC (x[M][C], M = N*H*W), fp32.
+// Train-mode batch normalisation fused with the residual add and the activation (ReLU / swish), NHWC (x[M][C],
+// M = N*H*W), fp32, any C % 4 == 0 (C <= 4096).
 //
-// Replaces, per BasicBlock of the reference's ResNet trunk (reference network/res_encoder.py:364-373, the vendored
-// torchvision BasicBlock): nn.BatchNorm2d in training mode (batch statistics, running-stat update with momentum
-// 0.1, unbiased running variance) + `out += identity` + ReLU and their autograd -- in ATen/MIOpen 3 + 1 + 1 forward
-// and 3 + 1 + 1 backward launches with a full HBM round trip each -- with
-//   forward : per-channel sum / sum-of-squares come out of the convolution epilogue (conv.hip), then ONE apply kernel
-//   backward: ONE reduction kernel (sum g, sum g*xhat with the ReLU mask applied on the fly) + ONE apply kernel that
-//             writes dx (and the masked gradient for the identity branch) and accumulates dgamma / dbeta straight
-//             into the flat gradient buffer.
-// All kernels are HBM-bound: every lane moves float4 (4 consecutive channels), a thread keeps the same channel group
-// for its whole grid-stride loop so mean / invstd / gamma / beta live in registers.
+// Replaces, per block of the reference's encoders (ResNet BasicBlock: reference network/res_encoder.py:364-373 +
+// vendored utils/Freihand_GNN_mano/network/resnet.py; EfficientNet MBConv: network/efficientnet_pt/model.py:67-94):
+// nn.BatchNorm2d in training mode (batch statistics, running-stat update, unbiased running variance) + `out += identity`
+// + ReLU, or + MemoryEfficientSwish (utils.py:36-52), and their autograd, with
+//   forward : per-channel sum / sum-of-squares come out of the convolution epilogue (conv.hip) or bn_stats_kernel, a
+//             one-thread-per-channel finalize kernel folds them into mean / invstd (+ running stats), then ONE apply kernel
+//   backward: ONE reduction kernel (sum g, sum g*xhat, activation derivative applied on the fly), finalize (dgamma / dbeta
+//             accumulated straight into the flat gradient buffer), ONE apply kernel writing dx (and the masked gradient of
+//             the identity branch).
+// All kernels are HBM-bound: every lane moves float4 (4 consecutive channels) and keeps the same channel group(s) for
+// its whole grid-stride loop, so scale / shift live in registers.  Partial sums use float atomics spread over
+// kStatSlots copies (thousands of atomics on ONE address serialise at ~100 ns each).
 #include <hip/hip_runtime.h>
 
 #include "hifihr_internal.h"
 
 namespace hifihr {
 
-// standalone statistics (used when the producer is not one of our convolutions): stats[kStatSlots][2][C] += sums
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long M, int C, float* __restrict__ stats) {
-  __shared__ float4 red[2][256];
+constexpr int kMaxNG = 4;        // channel groups (of 4 channels) per thread: C <= 4 * 256 * kMaxNG = 4096
+
+// Thread -> (row lane, channel groups).  C4 <= 256: CT = C4 threads cover a row, RL = 256 / CT rows per pass, one
+// group per thread.  C4 > 256: one row per pass, thread t owns groups t, t + 256, ...
+struct BnMap {
+  int CT, RL, NG, cg0, rl;
+  bool active;
+};
+__device__ __forceinline__ BnMap bn_map(int C) {
+  BnMap m;
   const int C4 = C / 4;
-  const int cg = threadIdx.x % C4;            // channel group of this thread
-  const int rl = threadIdx.x / C4, RL = 256 / C4;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long m = (long)blockIdx.x * RL + rl; m < M; m += (long)gridDim.x * RL) {
-    const float4 v = *reinterpret_cast<const float4*>(x + m * C + cg * 4);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+  if (C4 <= 256) {
+    m.CT = C4; m.RL = 256 / C4; m.NG = 1;
+    m.cg0 = threadIdx.x % C4; m.rl = threadIdx.x / C4;
+    m.active = m.rl < m.RL;
+  } else {
+    m.CT = 256; m.RL = 1; m.NG = (C4 + 255) / 256;
+    m.cg0 = threadIdx.x; m.rl = 0; m.active = true;
   }
-  red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
-  __syncthreads();
-  if (rl == 0) {
-    for (int r = 1; r < RL; ++r) {
-      const float4 a = red[0][r * C4 + cg], b = red[1][r * C4 + cg];
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
-    }
-    float* ps = stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * C + cg * 4;
-    float* pq = ps + C;
-    atomicAdd(ps, s.x); atomicAdd(ps + 1, s.y); atomicAdd(ps + 2, s.z); atomicAdd(ps + 3, s.w);
-    atomicAdd(pq, q.x); atomicAdd(pq + 1, q.y); atomicAdd(pq + 2, q.z); atomicAdd(pq + 3, q.w);
-  }
+  return m;
 }
 
-// sum of the kStatSlots partial copies of entry `idx` of a [kStatSlots][2][C] buffer
 __device__ __forceinline__ float slot_sum(const float* __restrict__ buf, int C, int idx) {
   float a = 0.f;
 #pragma unroll 8
   for (int sl = 0; sl < kStatSlots; ++sl) a += buf[(size_t)sl * 2 * C + idx];
   return a;
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, const float4& v) {
+  atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+__device__ __forceinline__ void acc4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// d act(z) / dz
+__device__ __forceinline__ float act_grad(int act, float z, float y) {
+  if (act == 1) return y > 0.f ? 1.f : 0.f;
+  if (act == 2) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    return s * (1.f + z * (1.f - s));
+  }
+  return 1.f;
+}
+
+// block-level reduction of the per-thread (sum, sumsq)-like pairs over the row lanes + slot-spread atomics
+__device__ __forceinline__ void reduce_and_add(const BnMap& mp, int C, float4 (&s)[kMaxNG], float4 (&q)[kMaxNG],
+                                               float4 (*lds)[256], float* __restrict__ out) {
+  const int slot = blockIdx.x & (kStatSlots - 1);
+  float* base = out + (size_t)slot * 2 * C;
+  if (mp.NG == 1 && mp.RL > 1) {
+    lds[0][threadIdx.x] = s[0]; lds[1][threadIdx.x] = q[0];
+    __syncthreads();
+    if (mp.active && mp.rl == 0) {
+      for (int r = 1; r < mp.RL; ++r) { acc4(s[0], lds[0][r * mp.CT + mp.cg0]); acc4(q[0], lds[1][r * mp.CT + mp.cg0]); }
+      atomic_add4(base + mp.cg0 * 4, s[0]);
+      atomic_add4(base + C + mp.cg0 * 4, q[0]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kMaxNG; ++j) {
+      const int cg = mp.cg0 + 256 * j;
+      if (j < mp.NG && cg * 4 < C && mp.active) {
+        atomic_add4(base + cg * 4, s[j]);
+        atomic_add4(base + C + cg * 4, q[j]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long M, int C, float* __restrict__ stats) {
+  __shared__ float4 lds[2][256];
+  const BnMap mp = bn_map(C);
+  float4 s[kMaxNG], q[kMaxNG];
+#pragma unroll
+  for (int j = 0; j < kMaxNG; ++j) { s[j] = make_float4(0.f, 0.f, 0.f, 0.f); q[j] = s[j]; }
+  if (mp.active) {
+    for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+#pragma unroll
+      for (int j = 0; j < kMaxNG; ++j) {
+        const int cg = mp.cg0 + 256 * j;
+        if (j < mp.NG && cg * 4 < C) {
+          const float4 v = *reinterpret_cast<const float4*>(x + m * C + cg * 4);
+          acc4(s[j], v);
+          q[j].x += v.x * v.x; q[j].y += v.y * v.y; q[j].z += v.z * v.z; q[j].w += v.w * v.w;
+        }
+      }
+    }
+  }
+  reduce_and_add(mp, C, s, q, lds, stats);
 }
 
 // one thread per channel: fold the slot partials into mean / invstd, update the running statistics
@@ -72,66 +132,95 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ save_mean,
                                                         const float* __restrict__ save_invstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ residual,
-                                                        int relu, long M, int C, float* __restrict__ y) {
-  const int C4 = C / 4;
-  const int cg = threadIdx.x % C4;
-  const int rl = threadIdx.x / C4, RL = 256 / C4;
-  float scale[4], shift[4];
+                                                        int act, long M, int C, float* __restrict__ y) {
+  const BnMap mp = bn_map(C);
+  if (!mp.active) return;
+  float4 scale[kMaxNG], shift[kMaxNG];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = cg * 4 + k;
-    scale[k] = save_invstd[c] * gamma[c];
-    shift[k] = beta[c] - save_mean[c] * scale[k];
-  }
-  for (long m = (long)blockIdx.x * RL + rl; m < M; m += (long)gridDim.x * RL) {
-    const size_t o = (size_t)m * C + cg * 4;
-    const float4 v = *reinterpret_cast<const float4*>(x + o);
-    float4 r = make_float4(v.x * scale[0] + shift[0], v.y * scale[1] + shift[1], v.z * scale[2] + shift[2], v.w * scale[3] + shift[3]);
-    if (residual) {
-      const float4 a = *reinterpret_cast<const float4*>(residual + o);
-      r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+  for (int j = 0; j < kMaxNG; ++j) {
+    const int cg = mp.cg0 + 256 * j;
+    if (j < mp.NG && cg * 4 < C) {
+      const float4 is = *reinterpret_cast<const float4*>(save_invstd + cg * 4), mu = *reinterpret_cast<const float4*>(save_mean + cg * 4);
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + cg * 4), be = *reinterpret_cast<const float4*>(beta + cg * 4);
+      scale[j] = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
+      shift[j] = make_float4(be.x - mu.x * scale[j].x, be.y - mu.y * scale[j].y, be.z - mu.z * scale[j].z, be.w - mu.w * scale[j].w);
     }
-    if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-    *reinterpret_cast<float4*>(y + o) = r;
+  }
+  for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+#pragma unroll
+    for (int j = 0; j < kMaxNG; ++j) {
+      const int cg = mp.cg0 + 256 * j;
+      if (j < mp.NG && cg * 4 < C) {
+        const size_t o = (size_t)m * C + cg * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + o);
+        float4 r = make_float4(v.x * scale[j].x + shift[j].x, v.y * scale[j].y + shift[j].y, v.z * scale[j].z + shift[j].z,
+                               v.w * scale[j].w + shift[j].w);
+        if (residual) acc4(r, *reinterpret_cast<const float4*>(residual + o));
+        if (act == 1) {
+          r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+        } else if (act == 2) {
+          r.x = r.x / (1.f + expf(-r.x)); r.y = r.y / (1.f + expf(-r.y)); r.z = r.z / (1.f + expf(-r.z)); r.w = r.w / (1.f + expf(-r.w));
+        }
+        *reinterpret_cast<float4*>(y + o) = r;
+      }
+    }
   }
 }
 
-// red[kStatSlots][2][C] += (sum g, sum g * xhat), g = dy * (y > 0 if relu)
+// g = dy * act'(z); z (needed by swish only) is recomputed from x: z = (x - mean) * invstd * gamma + beta
+__device__ __forceinline__ float4 masked_grad(int act, const float4& dy, const float* __restrict__ y, size_t o, const float4& v,
+                                              const float4& sc, const float4& sh) {
+  float4 g = dy;
+  if (act == 1) {
+    const float4 yy = *reinterpret_cast<const float4*>(y + o);
+    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+  } else if (act == 2) {
+    g.x *= act_grad(2, v.x * sc.x + sh.x, 0.f); g.y *= act_grad(2, v.y * sc.y + sh.y, 0.f);
+    g.z *= act_grad(2, v.z * sc.z + sh.z, 0.f); g.w *= act_grad(2, v.w * sc.w + sh.w, 0.f);
+  }
+  return g;
+}
+
+// red[kStatSlots][2][C] += (sum g, sum g * xhat)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ x, const float* __restrict__ save_mean,
-                                                           const float* __restrict__ save_invstd, int relu, long M, int C,
+                                                           const float* __restrict__ save_invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int act, long M, int C,
                                                            float* __restrict__ red) {
   __shared__ float4 lds[2][256];
-  const int C4 = C / 4;
-  const int cg = threadIdx.x % C4;
-  const int rl = threadIdx.x / C4, RL = 256 / C4;
-  const float4 mu = *reinterpret_cast<const float4*>(save_mean + cg * 4);
-  const float4 is = *reinterpret_cast<const float4*>(save_invstd + cg * 4);
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long m = (long)blockIdx.x * RL + rl; m < M; m += (long)gridDim.x * RL) {
-    const size_t o = (size_t)m * C + cg * 4;
-    float4 g = *reinterpret_cast<const float4*>(dy + o);
-    if (relu) {
-      const float4 yy = *reinterpret_cast<const float4*>(y + o);
-      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+  const BnMap mp = bn_map(C);
+  float4 s[kMaxNG], q[kMaxNG], mu[kMaxNG], is[kMaxNG], sc[kMaxNG], sh[kMaxNG];
+#pragma unroll
+  for (int j = 0; j < kMaxNG; ++j) {
+    s[j] = make_float4(0.f, 0.f, 0.f, 0.f); q[j] = s[j]; mu[j] = s[j]; is[j] = s[j]; sc[j] = s[j]; sh[j] = s[j];
+    const int cg = mp.cg0 + 256 * j;
+    if (j < mp.NG && cg * 4 < C && mp.active) {
+      mu[j] = *reinterpret_cast<const float4*>(save_mean + cg * 4);
+      is[j] = *reinterpret_cast<const float4*>(save_invstd + cg * 4);
+      if (act == 2) {
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + cg * 4), be = *reinterpret_cast<const float4*>(beta + cg * 4);
+        sc[j] = make_float4(is[j].x * ga.x, is[j].y * ga.y, is[j].z * ga.z, is[j].w * ga.w);
+        sh[j] = make_float4(be.x - mu[j].x * sc[j].x, be.y - mu[j].y * sc[j].y, be.z - mu[j].z * sc[j].z, be.w - mu[j].w * sc[j].w);
+      }
     }
-    const float4 v = *reinterpret_cast<const float4*>(x + o);
-    s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
-    q.x += g.x * ((v.x - mu.x) * is.x); q.y += g.y * ((v.y - mu.y) * is.y);
-    q.z += g.z * ((v.z - mu.z) * is.z); q.w += g.w * ((v.w - mu.w) * is.w);
   }
-  lds[0][threadIdx.x] = s; lds[1][threadIdx.x] = q;
-  __syncthreads();
-  if (rl == 0) {
-    for (int r = 1; r < RL; ++r) {
-      const float4 a = lds[0][r * C4 + cg], b = lds[1][r * C4 + cg];
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+  if (mp.active) {
+    for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+#pragma unroll
+      for (int j = 0; j < kMaxNG; ++j) {
+        const int cg = mp.cg0 + 256 * j;
+        if (j < mp.NG && cg * 4 < C) {
+          const size_t o = (size_t)m * C + cg * 4;
+          const float4 v = *reinterpret_cast<const float4*>(x + o);
+          const float4 g = masked_grad(act, *reinterpret_cast<const float4*>(dy + o), y, o, v, sc[j], sh[j]);
+          acc4(s[j], g);
+          q[j].x += g.x * ((v.x - mu[j].x) * is[j].x); q[j].y += g.y * ((v.y - mu[j].y) * is[j].y);
+          q[j].z += g.z * ((v.z - mu[j].z) * is[j].z); q[j].w += g.w * ((v.w - mu[j].w) * is[j].w);
+        }
+      }
     }
-    float* ps = red + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * C + cg * 4;
-    float* pq = ps + C;
-    atomicAdd(ps, s.x); atomicAdd(ps + 1, s.y); atomicAdd(ps + 2, s.z); atomicAdd(ps + 3, s.w);
-    atomicAdd(pq, q.x); atomicAdd(pq + 1, q.y); atomicAdd(pq + 2, q.z); atomicAdd(pq + 3, q.w);
   }
+  reduce_and_add(mp, C, s, q, lds, red);
 }
 
 // one thread per channel: fold the slot partials of the backward reduction into tot[2][C]; dgamma / dbeta accumulate
@@ -150,46 +239,59 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                           const float* __restrict__ x, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, const float* __restrict__ gamma,
-                                                          const float* __restrict__ tot, int relu, long M, int C,
-                                                          float* __restrict__ dx, float* __restrict__ dres) {
-  const int C4 = C / 4;
-  const int cg = threadIdx.x % C4;
-  const int rl = threadIdx.x / C4, RL = 256 / C4;
+                                                          const float* __restrict__ beta, const float* __restrict__ tot, int act,
+                                                          long M, int C, float* __restrict__ dx, float* __restrict__ dres) {
+  const BnMap mp = bn_map(C);
+  if (!mp.active) return;
   const float invM = 1.0f / (float)M;
-  float mu[4], is[4], k1[4], mg[4], mgx[4];
+  float4 mu[kMaxNG], is[kMaxNG], k1[kMaxNG], mg[kMaxNG], mgx[kMaxNG], sh[kMaxNG];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = cg * 4 + k;
-    mu[k] = save_mean[c]; is[k] = save_invstd[c];
-    k1[k] = gamma[c] * is[k];
-    mg[k] = tot[c] * invM; mgx[k] = tot[C + c] * invM;
-  }
-  for (long m = (long)blockIdx.x * RL + rl; m < M; m += (long)gridDim.x * RL) {
-    const size_t o = (size_t)m * C + cg * 4;
-    float4 g = *reinterpret_cast<const float4*>(dy + o);
-    if (relu) {
-      const float4 yy = *reinterpret_cast<const float4*>(y + o);
-      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+  for (int j = 0; j < kMaxNG; ++j) {
+    const int cg = mp.cg0 + 256 * j;
+    if (j < mp.NG && cg * 4 < C) {
+      mu[j] = *reinterpret_cast<const float4*>(save_mean + cg * 4);
+      is[j] = *reinterpret_cast<const float4*>(save_invstd + cg * 4);
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + cg * 4);
+      k1[j] = make_float4(ga.x * is[j].x, ga.y * is[j].y, ga.z * is[j].z, ga.w * is[j].w);
+      const float4 a = *reinterpret_cast<const float4*>(tot + cg * 4), b = *reinterpret_cast<const float4*>(tot + C + cg * 4);
+      mg[j] = make_float4(a.x * invM, a.y * invM, a.z * invM, a.w * invM);
+      mgx[j] = make_float4(b.x * invM, b.y * invM, b.z * invM, b.w * invM);
+      sh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (act == 2) {
+        const float4 be = *reinterpret_cast<const float4*>(beta + cg * 4);
+        sh[j] = make_float4(be.x - mu[j].x * k1[j].x, be.y - mu[j].y * k1[j].y, be.z - mu[j].z * k1[j].z, be.w - mu[j].w * k1[j].w);
+      }
     }
-    const float4 v = *reinterpret_cast<const float4*>(x + o);
-    float4 r;
-    r.x = k1[0] * (g.x - mg[0] - (v.x - mu[0]) * is[0] * mgx[0]);
-    r.y = k1[1] * (g.y - mg[1] - (v.y - mu[1]) * is[1] * mgx[1]);
-    r.z = k1[2] * (g.z - mg[2] - (v.z - mu[2]) * is[2] * mgx[2]);
-    r.w = k1[3] * (g.w - mg[3] - (v.w - mu[3]) * is[3] * mgx[3]);
-    *reinterpret_cast<float4*>(dx + o) = r;
-    if (dres) *reinterpret_cast<float4*>(dres + o) = g;
+  }
+  for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+#pragma unroll
+    for (int j = 0; j < kMaxNG; ++j) {
+      const int cg = mp.cg0 + 256 * j;
+      if (j < mp.NG && cg * 4 < C) {
+        const size_t o = (size_t)m * C + cg * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + o);
+        const float4 g = masked_grad(act, *reinterpret_cast<const float4*>(dy + o), y, o, v, k1[j], sh[j]);
+        float4 r;
+        r.x = k1[j].x * (g.x - mg[j].x - (v.x - mu[j].x) * is[j].x * mgx[j].x);
+        r.y = k1[j].y * (g.y - mg[j].y - (v.y - mu[j].y) * is[j].y * mgx[j].y);
+        r.z = k1[j].z * (g.z - mg[j].z - (v.z - mu[j].z) * is[j].z * mgx[j].z);
+        r.w = k1[j].w * (g.w - mg[j].w - (v.w - mu[j].w) * is[j].w * mgx[j].w);
+        *reinterpret_cast<float4*>(dx + o) = r;
+        if (dres) *reinterpret_cast<float4*>(dres + o) = g;
+      }
+    }
   }
 }
 
 static unsigned bn_grid(long M, int C) {
-  const int RL = 256 / (C / 4);
+  const int C4 = C / 4;
+  const int RL = C4 <= 256 ? 256 / C4 : 1;
   long blocks = (M + RL - 1) / RL;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
 }
-static bool bn_c_ok(int C) { return C >= 4 && C % 4 == 0 && (256 % (C / 4)) == 0; }
+static bool bn_c_ok(int C) { return C >= 4 && C % 4 == 0 && C <= 4 * 256 * kMaxNG; }
 
 hipError_t launch_bn_stats(const float* x, long M, int C, float* stats, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
@@ -200,27 +302,28 @@ hipError_t launch_bn_stats(const float* x, long M, int C, float* stats, hipStrea
 }
 
 hipError_t launch_bn_act_fwd(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
-                             int relu, long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,
+                             int act, long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,
                              float* running_mean, float* running_var, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, M, C, eps, momentum, save_mean,
                      save_invstd, running_mean, running_var);
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual,
-                     relu, M, C, y);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, act,
+                     M, C, y);
   return hipGetLastError();
 }
 
 hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, const float* save_mean, const float* save_invstd,
-                             const float* gamma, int relu, long M, int C, float* red, float* dx, float* dres, float* dgamma_acc,
-                             float* dbeta_acc, hipStream_t st) {
+                             const float* gamma, const float* beta, int act, long M, int C, float* red, float* dx, float* dres,
+                             float* dgamma_acc, float* dbeta_acc, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
   // red: kStatSlots slot partials followed by the [2][C] totals
   hipError_t e = hipMemsetAsync(red, 0, (size_t)kStatSlots * 2 * C * sizeof(float), st);
   if (e != hipSuccess) return e;
   float* tot = red + (size_t)kStatSlots * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, relu, M, C, red);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta, act,
+                     M, C, red);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, red, C, tot, dgamma_acc, dbeta_acc);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, tot, relu,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta, tot, act,
                      M, C, dx, dres);
   return hipGetLastError();
 }

@@ -40,7 +40,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #endif
 
 constexpr int kBK = 16;     // K-chunk depth (8 MFMA k-steps of 2)
-constexpr int kLD = 20;     // LDS row stride in floats (80 B: ds_read_b128 conflict-free, 16-B aligned)
 
 // How one launch (or one parity class of a strided dgrad launch) walks rows and taps.
 //   forward : rows = output pixels, tap j reads src row  oy*stride - pad + j
@@ -74,17 +73,22 @@ __device__ __forceinline__ GatherPlan make_plan(const ConvGeom& g, int cls) {
   return p;
 }
 
-// GENERIC = false requires IC % 16 == 0 (a 16-deep K chunk never straddles a tap: tap bookkeeping is scalar and
-// division-free).  GENERIC = true (forward only) handles any IC % 4 == 0 with per-chunk divisions (the 4-channel stem).
-template <int BM, int BN, bool GENERIC>
+// GENERIC = false requires IC % BK == 0 (a BK-deep K chunk never straddles a tap: tap bookkeeping is scalar and
+// division-free).  BK = 16 or 32: depth of one K chunk = BK/2 MFMA k-steps between two barriers.  GENERIC = true (forward only) handles any IC % 4 == 0 with per-chunk divisions (the 4-channel stem).
+template <int BM, int BN, bool GENERIC, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float* __restrict__ src,
                                                         const float* __restrict__ wgt, const float* __restrict__ bias,
                                                         float* __restrict__ dst, float* __restrict__ stats) {
   // stats (optional, forward only): [kStatSlots][2][OC] per-channel sum and sum of squares of the output, accumulated with
   // atomics from the accumulator registers -- the batch-norm that follows needs no separate pass over y
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves are arranged 2 x 2)
-  __shared__ __attribute__((aligned(16))) float As[2][BM * kLD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLD];
+  constexpr int LD = BK + 4;                     // LDS row stride: 80 B / 144 B keep ds_read_b128 conflict-free
+  constexpr int SEGS = BK / 4;                   // float4 segments per row
+  constexpr int RP = 256 / SEGS;                 // rows covered by one load pass of the workgroup
+  constexpr int AL = BM / RP, BL = BN / RP;      // load passes per chunk
+  constexpr int HK = BK / 2;                     // k-steps per chunk = floats per lane-half per row
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, r31 = lane & 31;
@@ -93,15 +97,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
   const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
   if (bm0 >= M) return;                           // parity classes can be smaller than the launch grid
   const int Qw = g.R * g.S * g.IC;                // row length of the weight matrix
-  const int lrow = tid >> 2, seg = (tid & 3) * 4;
+  const int lrow = tid / SEGS, seg = (tid % SEGS) * 4;
 
   // per-thread row bookkeeping for the gather (constant over the K loop)
-  size_t a_base[TM];
-  int a_h[TM], a_w[TM];
-  bool a_ok[TM];
+  size_t a_base[AL];
+  int a_h[AL], a_w[AL];
+  bool a_ok[AL];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = bm0 + lrow + 64 * i;
+  for (int i = 0; i < AL; ++i) {
+    const int m = bm0 + lrow + RP * i;
     a_ok[i] = m < M;
     const int mm = a_ok[i] ? m : 0;
     const int n = mm / (P.OHs * P.OWs);
@@ -112,14 +116,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
     a_w[i] = ox * P.amul + P.aofw;
   }
 
-  const int nch = GENERIC ? (Qw + kBK - 1) / kBK : P.nr * P.ns * (g.IC / kBK);
+  const int nch = GENERIC ? (Qw + BK - 1) / BK : P.nr * P.ns * (g.IC / BK);
   int jr = 0, js = 0, c0 = 0, qgen = 0, issued = 0;   // tap state of the NEXT chunk to load
 
   // kPF register stages: the chunk consumed now was loaded kPF - 1 chunk-computations ago, so ~2 MFMA blocks (plus the
   // other resident workgroups) cover the L2/HBM latency even when only 2-3 workgroups fit the grid per CU.
   constexpr int kPF = 3;
-  float4 ra[kPF][TM], rb[kPF][TN];
-  bool va[kPF][TM], vb[kPF][TN];
+  float4 ra[kPF][AL], rb[kPF][BL];
+  bool va[kPF][AL], vb[kPF][BL];
   auto load_global = [&](const int st) {
     int dr, ds, c, wq;
     bool qok = true;
@@ -130,20 +134,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
       c = qok ? q - t * g.IC : 0;
       dr = t / g.S; ds = t - dr * g.S;
       wq = q;
-      qgen += kBK;
+      qgen += BK;
     } else {
       qok = issued < nch;                    // false for the (masked) prefetches issued past the last chunk; note a
       ++issued;                              // parity class can have nr > 0 but ns == 0 (no chunk at all)
       dr = jr; ds = js; c = c0 + seg;
       wq = ((P.r0 + P.rstep * jr) * g.S + (P.s0 + P.rstep * js)) * g.IC + c;
-      c0 += kBK;
+      c0 += BK;
       if (c0 >= g.IC) { c0 = 0; if (++js == P.ns) { js = 0; ++jr; } }
     }
     // Loads are UNCONDITIONAL (out-of-range taps read a clamped, valid address) and masked when they are written to
     // LDS after the MFMA block: a load inside a branch makes the compiler wait for it right there, which exposes
     // the full memory latency in every K chunk.
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < AL; ++i) {
       const int ih = a_h[i] + P.sign * dr, iw = a_w[i] + P.sign * ds;
       const bool ok = qok && a_ok[i] && ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW;
       const size_t off = ok ? a_base[i] + ((size_t)ih * g.IW + iw) * g.IC + c : 0;
@@ -151,8 +155,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
       va[st][i] = ok;
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int k = bn0 + lrow + 64 * j;
+    for (int j = 0; j < BL; ++j) {
+      const int k = bn0 + lrow + RP * j;
       const bool ok = qok && k < g.OC;
       const size_t off = ok ? (size_t)k * Qw + wq : 0;
       rb[st][j] = *reinterpret_cast<const float4*>(wgt + off);
@@ -160,20 +164,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
     }
   };
   auto store_lds = [&](const int st, int buf) {
-    // k-interleave: even columns of the chunk -> floats [0,8), odd columns -> [8,16) of the row
+    // k-interleave: even columns of the chunk -> floats [0,HK), odd columns -> [HK,BK) of the row
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float* p = &As[buf][(lrow + 64 * i) * kLD];
+    for (int i = 0; i < AL; ++i) {
+      float* p = &As[buf][(lrow + RP * i) * LD];
       const float4 v = va[st][i] ? ra[st][i] : make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float2*>(p + seg / 2) = make_float2(v.x, v.z);
-      *reinterpret_cast<float2*>(p + 8 + seg / 2) = make_float2(v.y, v.w);
+      *reinterpret_cast<float2*>(p + HK + seg / 2) = make_float2(v.y, v.w);
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float* p = &Bs[buf][(lrow + 64 * j) * kLD];
+    for (int j = 0; j < BL; ++j) {
+      float* p = &Bs[buf][(lrow + RP * j) * LD];
       const float4 v = vb[st][j] ? rb[st][j] : make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float2*>(p + seg / 2) = make_float2(v.x, v.z);
-      *reinterpret_cast<float2*>(p + 8 + seg / 2) = make_float2(v.y, v.w);
+      *reinterpret_cast<float2*>(p + HK + seg / 2) = make_float2(v.y, v.w);
     }
   };
 
@@ -201,21 +205,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
       // loads past the last tap): a conditional load turns the registers into phis whose copies wait at once.
       load_global(u);
       HIFIHR_SCHED_FENCE();               // loads first, then the MFMA block
-      float a[TM][8], b[TN][8];
+      float a[TM][HK], b[TN][HK];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const float* p = &As[buf][(wm * (BM / 2) + i * 32 + r31) * kLD + half * 8];
-        const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-        a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w; a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+        const float* p = &As[buf][(wm * (BM / 2) + i * 32 + r31) * LD + half * HK];
+#pragma unroll
+        for (int v4 = 0; v4 < HK / 4; ++v4) {
+          const float4 q = *reinterpret_cast<const float4*>(p + 4 * v4);
+          a[i][4 * v4] = q.x; a[i][4 * v4 + 1] = q.y; a[i][4 * v4 + 2] = q.z; a[i][4 * v4 + 3] = q.w;
+        }
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const float* p = &Bs[buf][(wn * (BN / 2) + j * 32 + r31) * kLD + half * 8];
-        const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-        b[j][0] = lo.x; b[j][1] = lo.y; b[j][2] = lo.z; b[j][3] = lo.w; b[j][4] = hi.x; b[j][5] = hi.y; b[j][6] = hi.z; b[j][7] = hi.w;
+        const float* p = &Bs[buf][(wn * (BN / 2) + j * 32 + r31) * LD + half * HK];
+#pragma unroll
+        for (int v4 = 0; v4 < HK / 4; ++v4) {
+          const float4 q = *reinterpret_cast<const float4*>(p + 4 * v4);
+          b[j][4 * v4] = q.x; b[j][4 * v4 + 1] = q.y; b[j][4 * v4 + 2] = q.z; b[j][4 * v4 + 3] = q.w;
+        }
       }
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
+      for (int t = 0; t < HK; ++t)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -451,13 +461,15 @@ static int pick_tile(long M, int OC, bool generic) {
 }
 
 template <int BM, int BN>
-static void launch_igemm_tile(const ConvGeom& g, long Mmax, int classes, bool generic, const float* src, const float* wgt,
+static void launch_igemm_tile(const ConvGeom& g, long Mmax, int classes, bool generic, int bk, const float* src, const float* wgt,
                               const float* bias, float* dst, float* stats, hipStream_t st) {
   const dim3 grid((unsigned)((Mmax + BM - 1) / BM), (g.OC + BN - 1) / BN, classes);
   if (generic)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true, 16>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats);
+  else if (bk == 32)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, 32>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, 16>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats);
 }
 
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
@@ -468,15 +480,17 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
     if (e != hipSuccess) return e;
   }
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
-  const bool generic = (g.IC % kBK) != 0;
-  if (generic && g.dgrad) return hipErrorInvalidValue;      // dgrad needs the source channel count % 16 == 0
+  const bool generic = (g.IC % 16) != 0;
+  if (generic && g.dgrad && g.stride != 1) return hipErrorInvalidValue;   // strided dgrad needs source channels % 16 == 0
+  int bk = (g.IC % 32 == 0) ? 32 : 16;
+  if (const char* e = getenv("HIFIHR_CONV_BK")) bk = (atoi(e) == 32 && g.IC % 32 == 0) ? 32 : 16;   // tuning override
   const int classes = g.dgrad ? g.stride * g.stride : 1;
   const int st_ = g.dgrad ? g.stride : 1;
   const long Mmax = (long)g.N * ((g.OH + st_ - 1) / st_) * ((g.OW + st_ - 1) / st_);   // rows of the largest class
   switch (pick_tile(Mmax * classes, g.OC, generic)) {
-    case 0: launch_igemm_tile<128, 128>(g, Mmax, classes, generic, src, wgt, bias, dst, stats, st); break;
-    case 1: launch_igemm_tile<128, 64>(g, Mmax, classes, generic, src, wgt, bias, dst, stats, st); break;
-    default: launch_igemm_tile<64, 64>(g, Mmax, classes, generic, src, wgt, bias, dst, stats, st);
+    case 0: launch_igemm_tile<128, 128>(g, Mmax, classes, generic, bk, src, wgt, bias, dst, stats, st); break;
+    case 1: launch_igemm_tile<128, 64>(g, Mmax, classes, generic, bk, src, wgt, bias, dst, stats, st); break;
+    default: launch_igemm_tile<64, 64>(g, Mmax, classes, generic, bk, src, wgt, bias, dst, stats, st);
   }
   return hipGetLastError();
 }

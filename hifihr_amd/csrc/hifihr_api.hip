@@ -274,8 +274,8 @@ int hifihr_conv2d_fwd_bnstats(const float* x, const float* w, float* y, float* s
 
 int hifihr_conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, int N, int H, int W, int C, int K,
                            int R, int S, int stride, int pad, void* stream) {
-  if (!dy || !w || !dx || !wt_scratch || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || K % 16)
-    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_data: bad argument (K must be a multiple of 16)");
+  if (!dy || !w || !dx || !wt_scratch || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || K % 4 || (K % 16 && stride != 1))
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_data: bad argument (K % 4 == 0; K % 16 == 0 when stride > 1)");
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
   HIP_TRY(hifihr::launch_weight_transpose(w, wt_scratch, K, R * S, C, (hipStream_t)stream));
   hifihr::ConvGeom g{N, OH, OW, K, H, W, C, R, S, stride, pad, 1};
@@ -326,31 +326,33 @@ int hifihr_ssim_bwd(const float* window11, const float* img1, const float* img2,
 
 int hifihr_bn_stats_floats(int C) { return C > 0 ? (hifihr::kStatSlots + 1) * 2 * C : 0; }
 
-static int bn_dims_ok(long M, int C) { return M > 0 && C >= 4 && C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0; }
+static int bn_dims_ok(long M, int C) { return M > 0 && C >= 4 && C % 4 == 0 && C <= 4096; }
 
 int hifihr_bn_stats(const float* x, long M, int C, float* stats, void* stream) {
-  if (!x || !stats || !bn_dims_ok(M, C)) return fail(HIFIHR_EINVAL, "hifihr_bn_stats: bad argument (C/4 must divide 256)");
+  if (!x || !stats || !bn_dims_ok(M, C)) return fail(HIFIHR_EINVAL, "hifihr_bn_stats: bad argument (C % 4 == 0, C <= 4096)");
   HIP_TRY(hifihr::launch_bn_stats(x, M, C, stats, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
-int hifihr_bn_act_fwd(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual, int relu,
+int hifihr_bn_act_fwd(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual, int act,
                       long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,
                       float* running_mean, float* running_var, void* stream) {
   if (!x || !stats || !gamma || !beta || !y || !save_mean || !save_invstd || !bn_dims_ok(M, C) ||
       ((running_mean != nullptr) != (running_var != nullptr)))
-    return fail(HIFIHR_EINVAL, "hifihr_bn_act_fwd: bad argument (C/4 must divide 256)");
-  HIP_TRY(hifihr::launch_bn_act_fwd(x, stats, gamma, beta, residual, relu, M, C, eps, momentum, y, save_mean, save_invstd,
+    return fail(HIFIHR_EINVAL, "hifihr_bn_act_fwd: bad argument (C % 4 == 0, C <= 4096)");
+  if (act < 0 || act > 2 || (act == 2 && residual)) return fail(HIFIHR_EINVAL, "hifihr_bn_act_fwd: act must be 0/1/2 (swish takes no residual)");
+  HIP_TRY(hifihr::launch_bn_act_fwd(x, stats, gamma, beta, residual, act, M, C, eps, momentum, y, save_mean, save_invstd,
                                     running_mean, running_var, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
 int hifihr_bn_act_bwd(const float* dy, const float* y, const float* x, const float* save_mean, const float* save_invstd,
-                      const float* gamma, int relu, long M, int C, float* red_scratch, float* dx, float* dres, float* dgamma_acc,
-                      float* dbeta_acc, void* stream) {
-  if (!dy || !x || !save_mean || !save_invstd || !gamma || !red_scratch || !dx || !bn_dims_ok(M, C) || (relu && !y))
-    return fail(HIFIHR_EINVAL, "hifihr_bn_act_bwd: bad argument (C/4 must divide 256)");
-  HIP_TRY(hifihr::launch_bn_act_bwd(dy, y, x, save_mean, save_invstd, gamma, relu, M, C, red_scratch, dx, dres, dgamma_acc,
+                      const float* gamma, const float* beta, int act, long M, int C, float* red_scratch, float* dx, float* dres,
+                      float* dgamma_acc, float* dbeta_acc, void* stream) {
+  if (!dy || !x || !save_mean || !save_invstd || !gamma || !red_scratch || !dx || !bn_dims_ok(M, C) || (act == 1 && !y) ||
+      (act == 2 && !beta) || act < 0 || act > 2)
+    return fail(HIFIHR_EINVAL, "hifihr_bn_act_bwd: bad argument (C % 4 == 0, C <= 4096; act 1 needs y, act 2 needs beta)");
+  HIP_TRY(hifihr::launch_bn_act_bwd(dy, y, x, save_mean, save_invstd, gamma, beta, act, M, C, red_scratch, dx, dres, dgamma_acc,
                                     dbeta_acc, (hipStream_t)stream));
   return HIFIHR_OK;
 }

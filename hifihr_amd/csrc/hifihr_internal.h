@@ -66,8 +66,8 @@ hipError_t launch_bn_act_fwd(const float* x, const float* stats, const float* ga
                              int relu, long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,
                              float* running_mean, float* running_var, hipStream_t st);
 hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, const float* save_mean, const float* save_invstd,
-                             const float* gamma, int relu, long M, int C, float* red, float* dx, float* dres, float* dgamma_acc,
-                             float* dbeta_acc, hipStream_t st);
+                             const float* gamma, const float* beta, int act, long M, int C, float* red, float* dx, float* dres,
+                             float* dgamma_acc, float* dbeta_acc, hipStream_t st);
 hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
 hipError_t launch_weight_transpose(const float* w, float* wt, int K, int RS, int C, hipStream_t st);
 hipError_t launch_image_to_nhwc4(const float* img, float* out, int B, int HW, hipStream_t st);

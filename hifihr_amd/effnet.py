@@ -1,0 +1,199 @@
+"""EfficientNet-b3 feature extractor with the reference's structure and state-dict names.
+
+Mirrors reference network/efficientnet_pt/model.py (MBConvBlock :17-94, EfficientNet.__init__ :97-188,
+extract_features :195-215), network/efficientnet_pt/utils.py (round_filters :57-69, round_repeats :72-77,
+drop_connect :82-91, Conv2dStaticSamePadding :122-145, MemoryEfficientSwish :36-52) and
+network/effnet_encoder.py (EffiEncoder :6-18).  Built table-driven from the block table of SURVEY.md Appendix A:
+width 1.2 / depth 1.4 / "image_size" 300 (the STATIC same-padding is computed for a 300-pixel input at EVERY layer
+and applied unchanged to the 224-pixel input: k3 s1 -> (1,1), k3 s2 -> (0,1), k5 s1 -> (2,2), k5 s2 -> (1,2)),
+BN eps 1e-3 / torch-momentum 0.01, SE ratio 1/4 of the block INPUT filters, drop-connect 0.2 * idx / 26 in training.
+
+conv_impl="mfma": the 1x1 expand / project / head convolutions (96 % of the FLOPs) and every BatchNorm (+ swish) run
+on the hand-written kernels (hifihr_amd/csrc/conv.hip, bn.hip); depthwise convolutions, squeeze-excite and the 3x3
+stem are torch ops for now (bandwidth-bound, next to port).  conv_impl="aten": plain torch (CPU oracle / A-B runs).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# (kernel, stride, expand, in, out, repeats) of efficientnet-b0; b3 scales width x1.2 and depth x1.4
+_B0_BLOCKS = [(3, 1, 1, 32, 16, 1), (3, 2, 6, 16, 24, 2), (5, 2, 6, 24, 40, 2), (3, 2, 6, 40, 80, 3), (5, 1, 6, 80, 112, 3),
+              (5, 2, 6, 112, 192, 4), (3, 1, 6, 192, 320, 1)]
+_WIDTH, _DEPTH, _STATIC_SIZE = 1.2, 1.4, 300
+_BN_EPS, _BN_MOM = 1e-3, 0.01
+_DROP_CONNECT = 0.2
+
+
+def round_filters(f, width=_WIDTH, divisor=8):
+    f *= width
+    nf = max(divisor, int(f + divisor / 2) // divisor * divisor)
+    if nf < 0.9 * f:
+        nf += divisor
+    return int(nf)
+
+
+def round_repeats(r, depth=_DEPTH):
+    return int(math.ceil(depth * r))
+
+
+def static_same_pad(k, s, size=_STATIC_SIZE):
+    """(left, right, top, bottom) exactly as Conv2dStaticSamePadding computes it for a `size`-pixel input."""
+    o = math.ceil(size / s)
+    p = max((o - 1) * s + (k - 1) + 1 - size, 0)
+    return (p // 2, p - p // 2, p // 2, p - p // 2)
+
+
+def b3_block_table():
+    """[(k, stride, expand, in, out)] for the 26 blocks of efficientnet-b3."""
+    out = []
+    for k, s, e, i, o, r in _B0_BLOCKS:
+        i, o, r = round_filters(i), round_filters(o), round_repeats(r)
+        out.append((k, s, e, i, o))
+        out += [(k, 1, e, o, o)] * (r - 1)
+    return out
+
+
+class _SwishFn(torch.autograd.Function):
+    """utils.py:36-47 (memory-efficient swish: only the input is saved)."""
+
+    @staticmethod
+    def forward(ctx, i):
+        ctx.save_for_backward(i)
+        return i * torch.sigmoid(i)
+
+    @staticmethod
+    def backward(ctx, g):
+        i, = ctx.saved_tensors
+        s = torch.sigmoid(i)
+        return g * (s * (1 + i * (1 - s)))
+
+
+def swish(x):
+    return _SwishFn.apply(x)
+
+
+class SamePadConv2d(nn.Conv2d):
+    """nn.Conv2d with the reference's STATIC TensorFlow-style padding (state-dict compatible: weight[, bias])."""
+
+    def __init__(self, cin, cout, k, stride=1, groups=1, bias=True):
+        super().__init__(cin, cout, k, stride, 0, 1, groups, bias)
+        self.pad4 = static_same_pad(k, stride)
+
+    def forward(self, x):
+        if any(self.pad4):
+            x = F.pad(x, self.pad4)
+        return F.conv2d(x, self.weight, self.bias, self.stride, 0, 1, self.groups)
+
+
+class PointwiseConvMFMA(nn.Module):
+    """Bias-free 1x1 convolution on the hand-written MFMA implicit-GEMM kernel (weight: logical [K,C,1,1])."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 1, 1).contiguous(memory_format=torch.channels_last))
+
+    def forward(self, x, want_stats=False):
+        from . import ops
+        return ops.conv2d(x, self.weight, 1, 0, want_stats)
+
+
+def _pointwise(cin, cout, impl):
+    return PointwiseConvMFMA(cin, cout) if impl == "mfma" else SamePadConv2d(cin, cout, 1, bias=False)
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, momentum=_BN_MOM, eps=_BN_EPS)
+
+
+def _conv_bn_swish(conv, bn, x, act=True):
+    """conv -> BN (train-mode statistics) -> swish, fused on the HIP path."""
+    if isinstance(conv, PointwiseConvMFMA):
+        from . import ops
+        y, st = conv(x, want_stats=True)
+        return ops.bn_act(y, st, bn, None, "swish" if act else None)
+    y = bn(conv(x))
+    return swish(y) if act else y
+
+
+class MBConvBlock(nn.Module):
+    def __init__(self, k, stride, expand, cin, cout, impl):
+        super().__init__()
+        self.stride, self.cin, self.cout, self.expand = stride, cin, cout, expand
+        mid = cin * expand
+        if expand != 1:
+            self._expand_conv = _pointwise(cin, mid, impl)
+            self._bn0 = _bn(mid)
+        self._depthwise_conv = SamePadConv2d(mid, mid, k, stride, groups=mid, bias=False)
+        self._bn1 = _bn(mid)
+        sq = max(1, int(cin * 0.25))
+        self._se_reduce = SamePadConv2d(mid, sq, 1)
+        self._se_expand = SamePadConv2d(sq, mid, 1)
+        self._project_conv = _pointwise(mid, cout, impl)
+        self._bn2 = _bn(cout)
+
+    def forward(self, inputs, drop_connect_rate=None):
+        x = inputs
+        if self.expand != 1:
+            x = _conv_bn_swish(self._expand_conv, self._bn0, x)
+        x = swish(self._bn1(self._depthwise_conv(x)))
+        s = F.adaptive_avg_pool2d(x, 1)
+        s = self._se_expand(swish(self._se_reduce(s)))
+        x = torch.sigmoid(s) * x
+        x = _conv_bn_swish(self._project_conv, self._bn2, x, act=False)
+        if self.stride == 1 and self.cin == self.cout:
+            if drop_connect_rate and self.training:                       # utils.py:82-91
+                keep = 1 - drop_connect_rate
+                mask = torch.floor(keep + torch.rand([x.shape[0], 1, 1, 1], dtype=x.dtype, device=x.device))
+                x = x / keep * mask
+            x = x + inputs
+        return x
+
+
+class EfficientNetB3(nn.Module):
+    """`extract_features` of EfficientNet.from_name('efficientnet-b3') (the unused classifier `_fc` is omitted)."""
+
+    def __init__(self, conv_impl="aten"):
+        super().__init__()
+        self.conv_impl = conv_impl
+        stem = round_filters(32)
+        self._conv_stem = SamePadConv2d(3, stem, 3, 2, bias=False)
+        self._bn0 = _bn(stem)
+        table = b3_block_table()
+        assert len(table) == 26 and table[0][3] == stem
+        self._blocks = nn.ModuleList([MBConvBlock(k, s, e, i, o, conv_impl) for (k, s, e, i, o) in table])
+        head = round_filters(1280)
+        self._conv_head = _pointwise(table[-1][4], head, conv_impl)
+        self._bn1 = _bn(head)
+        self.out_channels, self.low_channels = head, table[4][4]
+
+    def extract_features(self, x):
+        if self.conv_impl == "mfma":
+            x = x.contiguous(memory_format=torch.channels_last)
+        x = swish(self._bn0(self._conv_stem(x)))
+        low = None
+        n = len(self._blocks)
+        for idx, blk in enumerate(self._blocks):
+            x = blk(x, drop_connect_rate=_DROP_CONNECT * float(idx) / n)
+            if idx == 4:
+                low = x                                                   # model.py:209-210
+        x = _conv_bn_swish(self._conv_head, self._bn1, x)
+        return x, low
+
+
+class EffiEncoder(nn.Module):
+    """reference network/effnet_encoder.py:6-18 (no input normalisation; AvgPool2d(7) on the 7x7 head features)."""
+
+    def __init__(self, pretrain="effb3", conv_impl="aten"):
+        super().__init__()
+        assert pretrain == "effb3"
+        self.encoder = EfficientNetB3(conv_impl)
+        self.pool = nn.AvgPool2d(7, stride=1)
+
+    def forward(self, x):
+        features, low = self.encoder.extract_features(x)
+        features = self.pool(features)
+        return low, features.reshape(features.shape[0], -1)

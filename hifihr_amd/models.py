@@ -41,9 +41,13 @@ class Model(nn.Module):
         self.hand_model, self.root_id, self.root_id_nimble = hand_model, root_id, root_id_nimble
         if pretrain == "res18":
             self.features_dim, self.low_feat_dim = 512, 128          # SURVEY.md F6 (reference's 2048/512 is broken)
+            self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=if_4c, conv_impl=conv_impl)
+        elif pretrain == "effb3":                                    # models_res_nimble.py:50-53
+            from .effnet import EffiEncoder
+            self.features_dim, self.low_feat_dim = 1536, 32
+            self.base_encoder = EffiEncoder(pretrain=pretrain, conv_impl=conv_impl)
         else:
             raise NotImplementedError(f"pretrain='{pretrain}' is not built yet")
-        self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=if_4c, conv_impl=conv_impl)
         self.ncomps = [10, 48, None]
         self.hand_layer = MyMANOLayer(ifRender, device, shape_ncomp=10, pose_ncomp=48, tables=mano_tables)
         self.hand_encoder = HandEncoder(hand_model=hand_model, ncomps=self.ncomps, in_dim=self.features_dim,

@@ -268,7 +268,7 @@ def conv2d(x, w, stride=1, pad=0, want_stats=False):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stats, gamma, beta, residual, relu, eps, momentum, running_mean, running_var):
+    def forward(ctx, x, stats, gamma, beta, residual, act, eps, momentum, running_mean, running_var):
         require_cuda(x, stats, gamma, beta)
         lib = get_lib()
         x = x.contiguous(memory_format=_CL)
@@ -278,16 +278,17 @@ class _BNAct(torch.autograd.Function):
         y = torch.empty_like(x, memory_format=_CL)
         save_mean = torch.empty(C, device=x.device)
         save_invstd = torch.empty(C, device=x.device)
-        PROFILE.bracket("bn_fwd", lambda: lib.bn_act_fwd(x, stats, gamma, beta, res, relu, M, C, eps, momentum, y, save_mean,
+        PROFILE.bracket("bn_fwd", lambda: lib.bn_act_fwd(x, stats, gamma, beta, res, act, M, C, eps, momentum, y, save_mean,
                                                          save_invstd, running_mean, running_var))
-        ctx.save_for_backward(x, y, gamma, save_mean, save_invstd)
-        ctx.relu, ctx.has_res, ctx.M, ctx.C = relu, residual is not None, M, C
+        ctx.save_for_backward(x, y if act == 1 else x.new_empty(0), gamma, beta, save_mean, save_invstd)
+        ctx.act, ctx.has_res, ctx.M, ctx.C = act, residual is not None, M, C
         ctx.gamma_param, ctx.beta_param = gamma, beta
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, save_mean, save_invstd = ctx.saved_tensors
+        x, y, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        y = y if ctx.act == 1 else None
         lib = get_lib()
         dy = dy.contiguous(memory_format=_CL)
         dx = torch.empty_like(x, memory_format=_CL)
@@ -301,8 +302,8 @@ class _BNAct(torch.autograd.Function):
             return t, t
         dg_t, dg_ret = acc_target(ctx.gamma_param)
         db_t, db_ret = acc_target(ctx.beta_param)
-        PROFILE.bracket("bn_bwd", lambda: lib.bn_act_bwd(dy, y, x, save_mean, save_invstd, gamma, ctx.relu, ctx.M, ctx.C, red, dx,
-                                                         dres, dg_t, db_t))
+        PROFILE.bracket("bn_bwd", lambda: lib.bn_act_bwd(dy, y, x, save_mean, save_invstd, gamma, beta, ctx.act, ctx.M, ctx.C, red,
+                                                         dx, dres, dg_t, db_t))
         if dg_ret is None:
             _grad_ready(ctx.gamma_param)
         if db_ret is None:
@@ -310,16 +311,21 @@ class _BNAct(torch.autograd.Function):
         return dx, None, dg_ret, db_ret, dres, None, None, None, None, None
 
 
+_ACT = {None: 0, False: 0, True: 1, "relu": 1, "swish": 2}
+
+
 def bn_act(x, stats, bn: torch.nn.BatchNorm2d, residual=None, relu=True):
-    """relu?(bn(x) + residual?) with train-mode batch statistics (reference trunk: nn.BatchNorm2d + `out += identity`
-    + nn.ReLU).  `stats` comes from conv2d(..., want_stats=True).  Eval mode uses the running statistics (torch ops).
+    """act(bn(x) + residual?) with train-mode batch statistics; `relu` is True/"relu", "swish", or False/None
+    (reference trunks: nn.BatchNorm2d + `out += identity` + nn.ReLU; EfficientNet: BN + MemoryEfficientSwish).
+    `stats` comes from conv2d(..., want_stats=True).  Eval mode uses the running statistics (torch ops).
     bn.num_batches_tracked is not advanced (it only matters for momentum=None, which the reference never uses)."""
+    act = _ACT[relu]
     if not bn.training:
         out = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
         if residual is not None:
             out = out + residual
-        return torch.relu(out) if relu else out
-    return _BNAct.apply(x, stats, bn.weight, bn.bias, residual, bool(relu), float(bn.eps), float(bn.momentum),
+        return torch.relu(out) if act == 1 else (out * torch.sigmoid(out) if act == 2 else out)
+    return _BNAct.apply(x, stats, bn.weight, bn.bias, residual, act, float(bn.eps), float(bn.momentum),
                         bn.running_mean, bn.running_var)
 
 

@@ -139,7 +139,7 @@ int hifihr_adam_step_dyn(float* params_d, const float* grads_d, float* exp_avg_d
  * Replaces the cuDNN/MIOpen dispatches of the encoder's nn.Conv2d layers (forward, backward-data,
  * backward-weight): reference network/res_encoder.py:364-373 (ResNet trunk built at :345-362).
  * Layouts: x[N][H][W][C], w[K][R][S][C] (= a torch [K,C,R,S] tensor in channels_last memory format),
- * y[N][OH][OW][K] with OH = (H + 2 pad - R)/stride + 1.  C % 4 == 0; bwd_data needs K % 16 == 0, bwd_weight K % 4 == 0.
+ * y[N][OH][OW][K] with OH = (H + 2 pad - R)/stride + 1.  C % 4 == 0; bwd_data needs K % 4 == 0 (K % 16 == 0 when stride > 1), bwd_weight K % 4 == 0.
  * ---------------------------------------------------------------------------------------------- */
 int hifihr_conv2d_fwd(const float* x_d, const float* w_d, const float* bias_d /* [K] or NULL */, float* y_d, int N, int H,
                       int W, int C, int K, int R, int S, int stride, int pad, void* stream);
@@ -158,22 +158,23 @@ int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, fl
  * Train-mode BatchNorm2d fused with the residual add and ReLU of a ResNet BasicBlock, NHWC: x[M][C], M = N*H*W.
  * Replaces nn.BatchNorm2d(training=True) + `out += identity` + nn.ReLU and their autograd in the trunk
  * (reference network/res_encoder.py:364-373; vendored BasicBlock utils/Freihand_GNN_mano/network/resnet.py).
- * C % 4 == 0 and (C/4) | 256.  stats_d / red_scratch_d hold hifihr_bn_stats_floats(C) floats: partial (sum, sum of
+ * C % 4 == 0, C <= 4096.  act: 0 = none, 1 = ReLU, 2 = swish (x * sigmoid(x); MemoryEfficientSwish of the reference's
+ * EfficientNet, network/efficientnet_pt/utils.py:36-52; no residual with swish).  stats_d / red_scratch_d hold hifihr_bn_stats_floats(C) floats: partial (sum, sum of
  * squares) over the M rows, spread over several slots to keep float-atomic contention low (from
  * hifihr_conv2d_fwd_bnstats, or hifihr_bn_stats for any other producer).
- *   fwd: y = relu?( (x - mean) * invstd * gamma + beta + residual? ); writes save_mean/save_invstd[C] and updates
+ *   fwd: y = act( (x - mean) * invstd * gamma + beta + residual? ); writes save_mean/save_invstd[C] and updates
  *        running_mean/var (momentum, unbiased variance) when given.
- *   bwd: g = dy * (y > 0) when relu; dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (may be NULL) = g;
+ *   bwd: g = dy * act'(z) (ReLU: y > 0, needs y_d; swish: z recomputed from x, needs beta_d); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (may be NULL) = g;
  *        dgamma_acc[C] += sum g*xhat, dbeta_acc[C] += sum g (either may be NULL).
  * ---------------------------------------------------------------------------------------------- */
 int hifihr_bn_stats_floats(int C);
 int hifihr_bn_stats(const float* x_d, long M, int C, float* stats_d, void* stream);
 int hifihr_bn_act_fwd(const float* x_d, const float* stats_d, const float* gamma_d, const float* beta_d,
-                      const float* residual_d /* or NULL */, int relu, long M, int C, float eps, float momentum, float* y_d,
+                      const float* residual_d /* or NULL */, int act, long M, int C, float eps, float momentum, float* y_d,
                       float* save_mean_d, float* save_invstd_d, float* running_mean_d, float* running_var_d, void* stream);
-int hifihr_bn_act_bwd(const float* dy_d, const float* y_d, const float* x_d, const float* save_mean_d,
-                      const float* save_invstd_d, const float* gamma_d, int relu, long M, int C, float* red_scratch_d,
-                      float* dx_d, float* dres_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
+int hifihr_bn_act_bwd(const float* dy_d, const float* y_d /* act 1 */, const float* x_d, const float* save_mean_d,
+                      const float* save_invstd_d, const float* gamma_d, const float* beta_d /* act 2 */, int act, long M, int C,
+                      float* red_scratch_d, float* dx_d, float* dres_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
 
 /* normalize_batch_3C (reference network/res_encoder.py:212-216) fused with NCHW[B][3][H][W] -> NHWC4 [B][H][W][4]
  * (4th channel zero) for the first convolution. */

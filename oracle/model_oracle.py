@@ -22,11 +22,14 @@ SKIN_TONE = (0.78, 0.60, 0.50)
 class OracleModel(nn.Module):
     def __init__(self, tables, pretrain="res18", image_size=224, aa=3, root_id=9):
         super().__init__()
-        assert pretrain == "res18"
         self.tables, self.image_size, self.aa, self.root_id = tables, image_size, aa, root_id
-        self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=False)
-        self.hand_encoder = HandEncoder(hand_model="mano", ncomps=[10, 48, None], in_dim=512, ifRender=True, use_mean_shape=False)
-        self.light_estimator = LightEstimator(128)
+        if pretrain == "res18":
+            self.base_encoder, feat_dim, low_dim = ResEncoder(pretrain=pretrain, if_4c=False), 512, 128
+        else:
+            from hifihr_amd.effnet import EffiEncoder
+            self.base_encoder, feat_dim, low_dim = EffiEncoder(pretrain, conv_impl="aten"), 1536, 32
+        self.hand_encoder = HandEncoder(hand_model="mano", ncomps=[10, 48, None], in_dim=feat_dim, ifRender=True, use_mean_shape=False)
+        self.light_estimator = LightEstimator(low_dim)
         self.faces = torch.as_tensor(tables.faces).long()
 
     def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):

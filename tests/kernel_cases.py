@@ -251,6 +251,8 @@ def ssim_case(lib, device, a, b, ref_val=None, ref_grad=None):
 # fused train-mode BatchNorm (+ residual add + ReLU), NHWC, vs plain PyTorch fp32 (F.batch_norm + add + relu autograd)
 # ------------------------------------------------------------------------------------------------
 def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False):
+    """relu: True / False / "swish"."""
+    act = {False: 0, True: 1, "swish": 2}[relu]
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(seed)
     M = N * H * W
@@ -264,8 +266,10 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
     out = F.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)
     if residual:
         out = out + rr
-    if relu:
+    if act == 1:
         out = F.relu(out)
+    elif act == 2:
+        out = out * torch.sigmoid(out)
     gy = torch.randn(out.shape, generator=gen)
     out.backward(gy)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(device)
@@ -276,14 +280,14 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
                                rtol=1e-4, atol=1e-3)
     y = torch.empty(N, H, W, C, device=device); sm = torch.empty(C, device=device); si = torch.empty(C, device=device)
     rmd, rvd = rm0.clone().to(device), rv0.clone().to(device)
-    lib.bn_act_fwd(dx_in, stats, gamma.to(device), beta.to(device), nhwc(res) if residual else None, relu, M, C, 1e-5, 0.1, y, sm, si, rmd, rvd)
+    lib.bn_act_fwd(dx_in, stats, gamma.to(device), beta.to(device), nhwc(res) if residual else None, act, M, C, 1e-5, 0.1, y, sm, si, rmd, rvd)
     ref = out.detach().permute(0, 2, 3, 1)
     assert float((y.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), "bn fwd"
     np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
     red = torch.empty(lib.bn_stats_floats(C), device=device); dxo = torch.empty_like(y); dres = torch.empty_like(y) if residual else None
     dg = torch.full((C,), 0.5, device=device); db = torch.full((C,), -0.25, device=device)     # accumulate semantics
-    lib.bn_act_bwd(nhwc(gy), y, dx_in, sm, si, gamma.to(device), relu, M, C, red, dxo, dres, dg, db)
+    lib.bn_act_bwd(nhwc(gy), y if act == 1 else None, dx_in, sm, si, gamma.to(device), beta.to(device), act, M, C, red, dxo, dres, dg, db)
     refdx = xr.grad.permute(0, 2, 3, 1)
     assert float((dxo.cpu() - refdx).abs().max()) <= 2e-4 * float(refdx.abs().max()) + 1e-7, "bn bwd dx"
     assert float((dg.cpu() - 0.5 - gr.grad).abs().max()) <= 2e-4 * float(gr.grad.abs().max()) + 1e-5, "bn dgamma"

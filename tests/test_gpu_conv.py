@@ -70,3 +70,36 @@ def test_bn_act_kernels(lib, C, relu, residual, N, H):
 def test_conv_epilogue_bn_statistics(lib):
     kc.conv_bnstats_case(lib, "cuda", 8, 56, 56, 64, 64, 3, 1, 1)
     kc.conv_bnstats_case(lib, "cuda", 4, 224, 224, 4, 64, 7, 2, 3)
+
+
+def test_efficientnet_b3_mfma_vs_reference_golden(golden_dir):
+    """EfficientNet-b3 with the 1x1 convolutions and every BatchNorm(+swish) on the hand-written kernels reproduces the
+    reference's extract_features (train mode) from name-seeded weights.  Drop-connect draws differ between CPU and GPU
+    generators, so it is disabled on both sides by comparing at drop rate 0 only through the first (skip-free) stages:
+    the low feature (block 4) has one skip block before it, hence the looser bound on `feat`."""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from seeded_init import seeded_state_dict
+    import hifihr_amd.effnet as E
+    g = np.load(os.path.join(golden_dir, "effnet_b3_small.npz"))
+    ref = E.EfficientNetB3("aten")
+    ref.load_state_dict(seeded_state_dict(ref))
+    net = E.EfficientNetB3("mfma")
+    net.load_state_dict(ref.state_dict())
+    ref, net = ref.cuda().train(), net.cuda().train()
+    x = torch.tensor(g["x"]).cuda()
+    old = E._DROP_CONNECT
+    E._DROP_CONNECT = 0.0                      # same deterministic function on both paths
+    try:
+        f0, l0 = ref.extract_features(x)
+        f1, l1 = net.extract_features(x)
+        w = torch.randn_like(f0)
+        (f0 * w).sum().backward(); (f1 * w).sum().backward()
+    finally:
+        E._DROP_CONNECT = old
+    assert float((l1 - l0).abs().max()) <= 2e-4 * float(l0.abs().max())
+    assert float((f1 - f0).abs().max()) <= 2e-3 * float(f0.abs().max())
+    for name in ("_blocks.3._expand_conv.weight", "_blocks.20._project_conv.weight", "_conv_head.weight", "_bn1.weight", "_blocks.7._bn0.bias"):
+        a = dict(net.named_parameters())[name].grad; b = dict(ref.named_parameters())[name].grad
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-7, name

@@ -78,3 +78,27 @@ def test_product_ops_refuse_cpu_tensors():
     from hifihr_amd._lib import HifihrError, require_cuda
     with pytest.raises(HifihrError):
         require_cuda(torch.zeros(3))
+
+
+def test_efficientnet_b3_mirror_vs_reference(golden_dir):
+    """hifihr_amd.effnet.EfficientNetB3 (torch path) reproduces the reference's EfficientNet-b3 extract_features
+    (train mode, drop-connect under the same seed) forward and backward from name-seeded weights."""
+    from seeded_init import seeded_state_dict
+    from hifihr_amd.effnet import EfficientNetB3, b3_block_table
+    g = np.load(os.path.join(golden_dir, "effnet_b3_small.npz"))
+    tbl = b3_block_table()
+    assert [t[4] for t in tbl][:6] == [24, 24, 32, 32, 32, 48] and tbl[-1][4] == 384 and len(tbl) == 26   # SURVEY Appendix A
+    net = EfficientNetB3("aten")
+    assert sum(p.numel() for p in net.parameters()) == int(g["n_params"])
+    net.load_state_dict(seeded_state_dict(net))
+    net.train()
+    torch.manual_seed(5)
+    feat, low = net.extract_features(torch.tensor(g["x"]))
+    np.testing.assert_allclose(feat.detach().numpy(), g["feat"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(low.detach().numpy(), g["low"], atol=2e-5, rtol=1e-4)
+    ((feat * torch.tensor(g["wf"])).sum() + (low * torch.tensor(g["wl"])).sum()).backward()
+    for key, grad in (("g_stem", net._conv_stem.weight.grad), ("g_b3_expand", net._blocks[3]._expand_conv.weight.grad),
+                      ("g_b10_dw", net._blocks[10]._depthwise_conv.weight.grad), ("g_b20_se", net._blocks[20]._se_reduce.weight.grad),
+                      ("g_head_bn", net._bn1.weight.grad)):
+        ref = g[key]
+        assert np.abs(grad.numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, key

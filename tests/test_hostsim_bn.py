@@ -9,7 +9,8 @@ def hostsim_lib():
     return kc.build_hostsim()
 
 
-@pytest.mark.parametrize("C,relu,residual", [(64, True, False), (128, True, True), (256, False, False), (16, True, True)])
+@pytest.mark.parametrize("C,relu,residual", [(64, True, False), (128, True, True), (256, False, False), (16, True, True), (40, "swish", False), (1392, "swish", False),
+                                               (136, False, False), (2304, True, True)])
 def test_bn_act_fwd_bwd(hostsim_lib, C, relu, residual):
     kc.bn_act_case(hostsim_lib, "cpu", 3, 5, 7, C, relu, residual, seed=C)
 

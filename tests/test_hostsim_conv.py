@@ -15,6 +15,8 @@ def hostsim_lib():
     (2, 8, 8, 64, 128, 1, 2, 0),    # 1x1 s2 downsample
     (1, 16, 16, 4, 64, 7, 2, 3),    # conv1 shape: C = 4 (NHWC4), Q = 196 not a multiple of 16
     (1, 6, 6, 48, 48, 3, 1, 0),     # K not a multiple of 64, no padding, bias
+    (2, 5, 5, 24, 40, 1, 1, 0),     # EfficientNet-style 1x1 with C, K not multiples of 16 (generic gather, generic dgrad)
+    (1, 7, 7, 136, 816, 1, 1, 0),   # 1x1 expand 136 -> 816
 ])
 def test_conv_fwd_bwd(hostsim_lib, N, H, W, C, K, R, stride, pad):
     kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, seed=H, bias=(K == 48))

@@ -181,6 +181,29 @@ def gen_resnet18():
     print("resnet18", tuple(low.shape), tuple(feat.shape))
 
 
+def gen_effnet():
+    """Reference EfficientNet.from_name('efficientnet-b3').extract_features with name-seeded weights (tools/seeded_init.py):
+    train mode (batch statistics + drop-connect under torch.manual_seed(5)), forward + gradients."""
+    from seeded_init import seeded_state_dict
+    from network.efficientnet_pt.model import EfficientNet
+    net = EfficientNet.from_name("efficientnet-b3")
+    net.load_state_dict(seeded_state_dict(net))
+    net.train()
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(2, 3, 96, 96, generator=g)
+    torch.manual_seed(5)
+    feat, low = net.extract_features(x)
+    wf = torch.randn(feat.shape, generator=g); wl = torch.randn(low.shape, generator=g)
+    ((feat * wf).sum() + (low * wl).sum()).backward()
+    np.savez_compressed(os.path.join(OUT, "effnet_b3_small.npz"), x=x.numpy(), feat=feat.detach().numpy(), low=low.detach().numpy(),
+                        wf=wf.numpy(), wl=wl.numpy(), g_stem=net._conv_stem.weight.grad.numpy(),
+                        g_b3_expand=net._blocks[3]._expand_conv.weight.grad.numpy(),
+                        g_b10_dw=net._blocks[10]._depthwise_conv.weight.grad.numpy(),
+                        g_b20_se=net._blocks[20]._se_reduce.weight.grad.numpy(), g_head_bn=net._bn1.weight.grad.numpy(),
+                        n_params=sum(p.numel() for n, p in net.named_parameters() if not n.startswith("_fc")))
+    print("effnet", tuple(feat.shape), tuple(low.shape))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_standins()
@@ -195,6 +218,7 @@ def main():
     gen_ssim()
     gen_resnet18()
     gen_losses()
+    gen_effnet()
 
 
 # ---- loss helpers: the reference functions cannot be imported (module-level pytorch3d / torchvision imports in
@@ -238,5 +262,7 @@ if __name__ == "__main__":
     if os.environ.get("GOLDEN_ONLY") == "losses":
         os.makedirs(OUT, exist_ok=True)
         gen_losses()
+    elif os.environ.get("GOLDEN_ONLY") == "effnet":
+        gen_effnet()
     else:
         main()

@@ -13,6 +13,6 @@ for (N, H, C) in [(32, 112, 64), (32, 56, 64), (32, 28, 128), (32, 14, 256), (32
     dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
     ts = timeit(lambda: lib.bn_stats(x, M, C, stats))
     tf = timeit(lambda: lib.bn_act_fwd(x, stats, g, b, res, True, M, C, 1e-5, 0.1, y, sm, si, rm, rv))
-    tb = timeit(lambda: lib.bn_act_bwd(dy, y, x, sm, si, g, True, M, C, red, dx, dres, dg, db))
+    tb = timeit(lambda: lib.bn_act_bwd(dy, y, x, sm, si, g, b, 1, M, C, red, dx, dres, dg, db))
     mb = M * C * 4 / 1e6
     print(f"M={M} C={C} ({mb:.1f} MB/tensor): stats {ts:.1f} us ({mb/ts:.2f} TB/s)  fwd {tf:.1f} us ({3*mb/tf:.2f} TB/s)  bwd {tb:.1f} us ({(3+3+2)*mb/tb:.2f} TB/s)")
