@@ -85,6 +85,8 @@ class HifihrLib:
         c.hifihr_conv2d_fwd.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
         c.hifihr_conv2d_bwd_data.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
         c.hifihr_conv2d_fwd_bnstats.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
+        for fn in (c.hifihr_dwconv2d_fwd, c.hifihr_dwconv2d_bwd_data, c.hifihr_dwconv2d_bwd_weight):
+            fn.argtypes = [_c_float_p] * 3 + [c_int] * 10 + [c_void_p]
         c.hifihr_bn_stats_floats.argtypes = [c_int]
         c.hifihr_bn_stats_floats.restype = c_int
         c.hifihr_bn_stats.argtypes = [_c_float_p, c_long, c_int, _c_float_p, c_void_p]
@@ -166,6 +168,18 @@ class HifihrLib:
         self.check(self.c.hifihr_bn_act_bwd(_fp(dy), _fp(y), _fp(x), _fp(save_mean), _fp(save_invstd), _fp(gamma), _fp(beta), int(act),
                                             c_long(M), C, _fp(red), _fp(dx), _fp(dres), _fp(dgamma_acc), _fp(dbeta_acc),
                                             _stream_of(dy)), "hifihr_bn_act_bwd")
+
+    def dwconv2d_fwd(self, x, w, y, N, H, W, C, OH, OW, K, stride, pt, pl):
+        self.check(self.c.hifihr_dwconv2d_fwd(_fp(x), _fp(w), _fp(y), N, H, W, C, OH, OW, K, stride, pt, pl, _stream_of(x)),
+                   "hifihr_dwconv2d_fwd")
+
+    def dwconv2d_bwd_data(self, dy, w, dx, N, H, W, C, OH, OW, K, stride, pt, pl):
+        self.check(self.c.hifihr_dwconv2d_bwd_data(_fp(dy), _fp(w), _fp(dx), N, H, W, C, OH, OW, K, stride, pt, pl, _stream_of(dy)),
+                   "hifihr_dwconv2d_bwd_data")
+
+    def dwconv2d_bwd_weight(self, x, dy, dw, N, H, W, C, OH, OW, K, stride, pt, pl):
+        self.check(self.c.hifihr_dwconv2d_bwd_weight(_fp(x), _fp(dy), _fp(dw), N, H, W, C, OH, OW, K, stride, pt, pl, _stream_of(x)),
+                   "hifihr_dwconv2d_bwd_weight")
 
     def conv2d_bwd_data(self, dy, w, dx, scratch, N, H, W, C, K, R, S, stride, pad):
         self.check(self.c.hifihr_conv2d_bwd_data(_fp(dy), _fp(w), _fp(dx), _fp(scratch), N, H, W, C, K, R, S, stride, pad,

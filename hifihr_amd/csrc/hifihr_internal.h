@@ -80,6 +80,14 @@ hipError_t launch_ssim_fwd(const SsimWindow& win, const float* img1, const float
 hipError_t launch_ssim_bwd(const SsimWindow& win, const float* img1, const float* img2, const float* dA, const float* dB,
                            const float* dC, const float* gscale, int planes, int H, int W, float* gimg1, hipStream_t st);
 
+// depthwise convolution geometry: x[N][H][W][C] -> y[N][OH][OW][C], k x k taps, padding top/left = pt/pl
+struct DwGeom {
+  int N, H, W, C, OH, OW, K, stride, pt, pl;
+};
+hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, hipStream_t st);
+hipError_t launch_dwconv_bwd_data(const DwGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
+hipError_t launch_dwconv_bwd_weight(const DwGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
+
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st);
 

@@ -8,9 +8,10 @@ width 1.2 / depth 1.4 / "image_size" 300 (the STATIC same-padding is computed fo
 and applied unchanged to the 224-pixel input: k3 s1 -> (1,1), k3 s2 -> (0,1), k5 s1 -> (2,2), k5 s2 -> (1,2)),
 BN eps 1e-3 / torch-momentum 0.01, SE ratio 1/4 of the block INPUT filters, drop-connect 0.2 * idx / 26 in training.
 
-conv_impl="mfma": the 1x1 expand / project / head convolutions (96 % of the FLOPs) and every BatchNorm (+ swish) run
-on the hand-written kernels (hifihr_amd/csrc/conv.hip, bn.hip); depthwise convolutions, squeeze-excite and the 3x3
-stem are torch ops for now (bandwidth-bound, next to port).  conv_impl="aten": plain torch (CPU oracle / A-B runs).
+conv_impl="mfma": the 1x1 expand / project / head convolutions (96 % of the FLOPs), the depthwise convolutions and the
+BatchNorm (+ swish) after the 1x1 convolutions run on the hand-written kernels (hifihr_amd/csrc/conv.hip, dwconv.hip,
+bn.hip); the BatchNorm after a depthwise convolution, squeeze-excite and the 3x3 stem are torch ops for now
+(bandwidth-bound, next to port).  conv_impl="aten": plain torch (CPU oracle / A-B runs).
 """
 from __future__ import annotations
 
@@ -95,10 +96,25 @@ class PointwiseConvMFMA(nn.Module):
     def __init__(self, cin, cout):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(cout, cin, 1, 1).contiguous(memory_format=torch.channels_last))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))          # nn.Conv2d's default initialisation
 
     def forward(self, x, want_stats=False):
         from . import ops
         return ops.conv2d(x, self.weight, 1, 0, want_stats)
+
+
+class DepthwiseConvHIP(nn.Module):
+    """Depthwise k x k convolution with the static same padding on the hand-written kernels (weight [C,1,k,k])."""
+
+    def __init__(self, c, k, stride):
+        super().__init__()
+        self.stride, self.pad4 = stride, static_same_pad(k, stride)
+        self.weight = nn.Parameter(torch.empty(c, 1, k, k))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def forward(self, x):
+        from . import ops
+        return ops.dwconv2d(x, self.weight, self.stride, self.pad4)
 
 
 def _pointwise(cin, cout, impl):
@@ -127,7 +143,8 @@ class MBConvBlock(nn.Module):
         if expand != 1:
             self._expand_conv = _pointwise(cin, mid, impl)
             self._bn0 = _bn(mid)
-        self._depthwise_conv = SamePadConv2d(mid, mid, k, stride, groups=mid, bias=False)
+        self._depthwise_conv = (DepthwiseConvHIP(mid, k, stride) if impl == "mfma"
+                                else SamePadConv2d(mid, mid, k, stride, groups=mid, bias=False))
         self._bn1 = _bn(mid)
         sq = max(1, int(cin * 0.25))
         self._se_reduce = SamePadConv2d(mid, sq, 1)

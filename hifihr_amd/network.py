@@ -41,6 +41,7 @@ class Conv2dMFMA(nn.Module):
         super().__init__()
         self.stride, self.pad = stride, pad
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last))
+        init.kaiming_uniform_(self.weight, a=5 ** 0.5)                 # nn.Conv2d's default initialisation
 
     def forward(self, x, want_stats=False):
         from . import ops

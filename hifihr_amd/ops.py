@@ -387,3 +387,51 @@ def ssim(img1, img2):
     if img2.requires_grad:
         raise NotImplementedError("fused SSIM differentiates with respect to img1 only")
     return _SSIM.apply(img1, img2)
+
+
+# ------------------------------------------------------------------------------------------------
+# depthwise convolution (EfficientNet MBConv), channels_last activations, weight [C,1,K,K]
+# ------------------------------------------------------------------------------------------------
+class _DwConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, pad4):
+        require_cuda(x, w)
+        lib = get_lib()
+        x = x.contiguous(memory_format=_CL)
+        w = w.contiguous()
+        N, C, H, W = x.shape
+        K = w.shape[-1]
+        pl, pr, pt, pb = pad4
+        OH, OW = (H + pt + pb - K) // stride + 1, (W + pl + pr - K) // stride + 1
+        y = torch.empty((N, C, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
+        PROFILE.bracket("dwconv_fwd", lambda: lib.dwconv2d_fwd(x, w, y, N, H, W, C, OH, OW, K, stride, pt, pl))
+        ctx.geom = (N, H, W, C, OH, OW, K, stride, pt, pl)
+        ctx.save_for_backward(x, w)
+        ctx.w_param = w
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        lib = get_lib()
+        gy = gy.contiguous(memory_format=_CL)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=_CL)
+            PROFILE.bracket("dwconv_dgrad", lambda: lib.dwconv2d_bwd_data(gy, w, dx, *ctx.geom))
+        if ctx.needs_input_grad[1]:
+            p = ctx.w_param
+            tgt = p.grad if (getattr(p, "_hifihr_direct_grad", False) and p.grad is not None and p.grad.is_contiguous()) else None
+            if tgt is None:
+                dw = torch.zeros_like(w)
+                tgt = dw
+            PROFILE.bracket("dwconv_wgrad", lambda: lib.dwconv2d_bwd_weight(x, gy, tgt, *ctx.geom))
+            if dw is None:
+                _grad_ready(p)
+        return dx, dw, None, None
+
+
+def dwconv2d(x, w, stride, pad4):
+    """F.conv2d(F.pad(x, pad4), w, groups=C, stride=stride) for channels_last fp32 tensors; pad4 = (left, right, top, bottom)
+    (reference network/efficientnet_pt/utils.py:122-145 with groups = channels)."""
+    return _DwConv.apply(x, w, stride, tuple(pad4))

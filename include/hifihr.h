@@ -176,6 +176,20 @@ int hifihr_bn_act_bwd(const float* dy_d, const float* y_d /* act 1 */, const flo
                       const float* save_invstd_d, const float* gamma_d, const float* beta_d /* act 2 */, int act, long M, int C,
                       float* red_scratch_d, float* dx_d, float* dres_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Depthwise convolution (groups == channels), NHWC fp32, k = 3 or 5, TensorFlow-style asymmetric zero padding.
+ * Replaces the depthwise Conv2dStaticSamePadding of the reference's EfficientNet MBConv blocks
+ * (reference network/efficientnet_pt/model.py:49-55,80; utils.py:122-145) and its autograd.
+ * x[N][H][W][C], w[C][K][K] (= torch [C,1,K,K]), y[N][OH][OW][C]; pad_top/pad_left explicit, bottom/right implied by
+ * OH/OW.  bwd_weight ACCUMULATES into dw (fp32 atomics).
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_dwconv2d_fwd(const float* x_d, const float* w_d, float* y_d, int N, int H, int W, int C, int OH, int OW, int K,
+                        int stride, int pad_top, int pad_left, void* stream);
+int hifihr_dwconv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, int N, int H, int W, int C, int OH, int OW, int K,
+                             int stride, int pad_top, int pad_left, void* stream);
+int hifihr_dwconv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int OH, int OW,
+                               int K, int stride, int pad_top, int pad_left, void* stream);
+
 /* normalize_batch_3C (reference network/res_encoder.py:212-216) fused with NCHW[B][3][H][W] -> NHWC4 [B][H][W][4]
  * (4th channel zero) for the first convolution. */
 int hifihr_image_to_nhwc4(const float* images_d, float* out_d, int B, int H, int W, void* stream);

@@ -311,3 +311,33 @@ def conv_bnstats_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0):
     st = stats.view(-1, 2, K)[:-1].sum(0)
     np.testing.assert_allclose(st[0].cpu().numpy(), s_ref.sum(1).numpy(), rtol=1e-4, atol=2e-3)
     np.testing.assert_allclose(st[1].cpu().numpy(), (s_ref ** 2).sum(1).numpy(), rtol=1e-4, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# depthwise convolution (EfficientNet MBConv) vs plain PyTorch fp32 (F.pad + grouped F.conv2d autograd)
+# ------------------------------------------------------------------------------------------------
+def dwconv_case(lib, device, N, H, W, C, K, stride, seed=0):
+    import torch.nn.functional as F
+    from hifihr_amd.effnet import static_same_pad
+    gen = torch.Generator().manual_seed(seed)
+    pl, pr, pt, pb = static_same_pad(K, stride)
+    x = torch.randn(N, C, H, W, generator=gen); w = torch.randn(C, 1, K, K, generator=gen) / K
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(F.pad(xr, (pl, pr, pt, pb)), wr, None, stride, 0, 1, C)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    OH, OW = y.shape[2], y.shape[3]
+    d = lambda t: t.to(device).contiguous()
+    xd, wd, gyd = d(x.permute(0, 2, 3, 1)), d(w.reshape(C, K, K)), d(gy.permute(0, 2, 3, 1))
+    out = torch.empty(N, OH, OW, C, device=device)
+    lib.dwconv2d_fwd(xd, wd, out, N, H, W, C, OH, OW, K, stride, pt, pl)
+    ref = y.detach().permute(0, 2, 3, 1)
+    assert float((out.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, "dw fwd"
+    dx = torch.empty(N, H, W, C, device=device)
+    lib.dwconv2d_bwd_data(gyd, wd, dx, N, H, W, C, OH, OW, K, stride, pt, pl)
+    refx = xr.grad.permute(0, 2, 3, 1)
+    assert float((dx.cpu() - refx).abs().max()) <= 2e-5 * float(refx.abs().max()) + 1e-6, "dw bwd data"
+    dw = torch.zeros(C, K, K, device=device)
+    lib.dwconv2d_bwd_weight(xd, gyd, dw, N, H, W, C, OH, OW, K, stride, pt, pl)
+    refw = wr.grad.reshape(C, K, K)
+    assert float((dw.cpu() - refw).abs().max()) <= 1e-4 * float(refw.abs().max()) + 1e-6, "dw bwd weight"

@@ -103,3 +103,8 @@ def test_efficientnet_b3_mfma_vs_reference_golden(golden_dir):
     for name in ("_blocks.3._expand_conv.weight", "_blocks.20._project_conv.weight", "_conv_head.weight", "_bn1.weight", "_blocks.7._bn0.bias"):
         a = dict(net.named_parameters())[name].grad; b = dict(ref.named_parameters())[name].grad
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-7, name
+
+
+@pytest.mark.parametrize("N,H,C,K,stride", [(32, 56, 192, 3, 1), (32, 56, 192, 5, 2), (8, 14, 816, 5, 1), (32, 7, 2304, 3, 1)])
+def test_dwconv_kernels(lib, N, H, C, K, stride):
+    kc.dwconv_case(lib, "cuda", N, H, H, C, K, stride, seed=C + K)
