@@ -10,7 +10,7 @@ BN eps 1e-3 / torch-momentum 0.01, SE ratio 1/4 of the block INPUT filters, drop
 
 conv_impl="mfma": the 1x1 expand / project / head convolutions (96 % of the FLOPs), the depthwise convolutions and the
 BatchNorm (+ swish) after the 1x1 convolutions run on the hand-written kernels (hifihr_amd/csrc/conv.hip, dwconv.hip,
-bn.hip); the BatchNorm after a depthwise convolution, squeeze-excite and the 3x3 stem are torch ops for now
+bn.hip, every BatchNorm + swish included); squeeze-excite and the 3x3 stem are torch ops for now
 (bandwidth-bound, next to port).  conv_impl="aten": plain torch (CPU oracle / A-B runs).
 """
 from __future__ import annotations
@@ -156,7 +156,11 @@ class MBConvBlock(nn.Module):
         x = inputs
         if self.expand != 1:
             x = _conv_bn_swish(self._expand_conv, self._bn0, x)
-        x = swish(self._bn1(self._depthwise_conv(x)))
+        if isinstance(self._depthwise_conv, DepthwiseConvHIP):
+            from . import ops
+            x = ops.bn_act(self._depthwise_conv(x), None, self._bn1, None, "swish")      # statistics pass + fused BN/swish
+        else:
+            x = swish(self._bn1(self._depthwise_conv(x)))
         s = F.adaptive_avg_pool2d(x, 1)
         s = self._se_expand(swish(self._se_reduce(s)))
         x = torch.sigmoid(s) * x

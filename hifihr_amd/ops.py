@@ -320,6 +320,14 @@ def bn_act(x, stats, bn: torch.nn.BatchNorm2d, residual=None, relu=True):
     `stats` comes from conv2d(..., want_stats=True).  Eval mode uses the running statistics (torch ops).
     bn.num_batches_tracked is not advanced (it only matters for momentum=None, which the reference never uses)."""
     act = _ACT[relu]
+    if stats is None and bn.training:       # producer was not one of our convolutions: one HBM-bound statistics pass
+        require_cuda(x)
+        lib = get_lib()
+        xc = x.contiguous(memory_format=_CL)
+        N, C, H, W = xc.shape
+        stats = torch.empty(lib.bn_stats_floats(C), device=x.device, dtype=torch.float32)
+        PROFILE.bracket("bn_stats", lambda: lib.bn_stats(xc, N * H * W, C, stats))
+        x = xc
     if not bn.training:
         out = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
         if residual is not None:
