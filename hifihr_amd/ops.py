@@ -21,6 +21,7 @@ class _Profile:
     def __init__(self):
         self.on = False
         self.events = []
+        self.last_render = None
 
     def enable(self):
         self.on, self.events = True, []
@@ -163,6 +164,8 @@ class _Render(torch.autograd.Function):
         face_id = torch.empty(B, S, S, dtype=torch.int32, device=verts.device)
         ws = handle.workspace(B, verts.device)
         PROFILE.bracket("render_fwd", lambda: handle.lib.render_fwd(handle.h, verts, vcolors, cam, light_color, light_dir, rgba, face_id, ws))
+        if PROFILE.on:                       # kept for bench.py's back-to-back timing of the roofline kernel
+            PROFILE.last_render = (handle, verts.detach(), vcolors.detach(), cam.detach(), light_color.detach(), light_dir.detach())
         ctx.handle = handle
         ctx.vcol_batched = vcolors.dim() == 3
         ctx.ws = ws
