@@ -94,6 +94,19 @@ class HifihrLib:
         c.hifihr_bn_act_bwd.argtypes = [_c_float_p] * 7 + [c_int, c_long, c_int] + [_c_float_p] * 5 + [c_void_p]
         c.hifihr_conv2d_bwd_weight.argtypes = [_c_float_p] * 3 + ci + [c_void_p]
         c.hifihr_image_to_nhwc4.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
+        c.hifihr_geom_loss_fwd.argtypes = [_c_float_p] * 6 + [_c_int_p] + [c_int] * 7 + [_c_float_p] * 3 + [c_void_p]
+        c.hifihr_geom_loss_bwd.argtypes = [_c_float_p] * 6 + [_c_int_p] * 3 + [c_int] * 7 + [_c_float_p] * 6 + [c_void_p]
+        c.hifihr_photo_loss_partial_floats.argtypes = []
+        c.hifihr_photo_loss_partial_floats.restype = c_int
+        c.hifihr_photo_loss_fwd.argtypes = [_c_float_p, _c_float_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float] + \
+            [_c_float_p] * 4 + [c_void_p]
+        c.hifihr_photo_loss_bwd.argtypes = [_c_float_p] * 6 + [c_int, c_int, c_int, c_float, c_float, _c_float_p, c_void_p]
+        c.hifihr_sil_post.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_mmpool_fwd.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_mmpool_bwd.argtypes = [_c_float_p, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p,
+                                        _c_float_p, c_void_p]
+        c.hifihr_maxpool3x3s2_fwd.argtypes = [_c_float_p, c_int, c_int, c_int, c_int, _c_float_p, c_void_p, c_void_p]
+        c.hifihr_maxpool3x3s2_bwd.argtypes = [_c_float_p, c_void_p, c_int, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_adam_step.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
                                        c_float, c_float, c_float, c_int, c_void_p]
         c.hifihr_adam_step_dyn.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
@@ -180,6 +193,66 @@ class HifihrLib:
     def dwconv2d_bwd_weight(self, x, dy, dw, N, H, W, C, OH, OW, K, stride, pt, pl):
         self.check(self.c.hifihr_dwconv2d_bwd_weight(_fp(x), _fp(dy), _fp(dw), N, H, W, C, OH, OW, K, stride, pt, pl, _stream_of(x)),
                    "hifihr_dwconv2d_bwd_weight")
+
+    @staticmethod
+    def _lambda5(lam):
+        return (c_float * 5)(*[float(v) for v in lam])
+
+    def geom_loss_fwd(self, joints, joints_gt, verts, verts_gt, shape, pose, faces, mse, lam, partial, out):
+        B, J, V = joints.shape[0], joints.shape[1], verts.shape[1]
+        F = 0 if faces is None else faces.shape[0]
+        NS = 0 if shape is None else shape.shape[1]
+        NP = 0 if pose is None else pose.shape[1]
+        self.check(self.c.hifihr_geom_loss_fwd(_fp(joints), _fp(joints_gt), _fp(verts), _fp(verts_gt), _fp(shape), _fp(pose), _ip(faces),
+                                               B, J, V, F, NS, NP, int(mse), self._lambda5(lam), _fp(partial), _fp(out),
+                                               _stream_of(joints)), "hifihr_geom_loss_fwd")
+
+    def geom_loss_bwd(self, joints, joints_gt, verts, verts_gt, shape, pose, faces, vf_off, vf_idx, mse, lam, gout, gj, gv, gshape,
+                      gpose):
+        B, J, V = joints.shape[0], joints.shape[1], verts.shape[1]
+        F = 0 if faces is None else faces.shape[0]
+        NS = 0 if shape is None else shape.shape[1]
+        NP = 0 if pose is None else pose.shape[1]
+        self.check(self.c.hifihr_geom_loss_bwd(_fp(joints), _fp(joints_gt), _fp(verts), _fp(verts_gt), _fp(shape), _fp(pose), _ip(faces),
+                                               _ip(vf_off), _ip(vf_idx), B, J, V, F, NS, NP, int(mse), self._lambda5(lam), _fp(gout),
+                                               _fp(gj), _fp(gv), _fp(gshape), _fp(gpose), _stream_of(joints)), "hifihr_geom_loss_bwd")
+
+    def photo_loss_partial_floats(self):
+        return int(self.c.hifihr_photo_loss_partial_floats())
+
+    def photo_loss_fwd(self, rgba, imgs, seg, l_tex, l_mrgb, l_sil, re_img_m, mask_rgbs, partial, out):
+        B, _, H, W = rgba.shape
+        assert seg.dtype == torch.int64 and seg.is_contiguous() and rgba.is_contiguous() and imgs.is_contiguous()
+        self.check(self.c.hifihr_photo_loss_fwd(_fp(rgba), _fp(imgs), c_void_p(seg.data_ptr()), B, H, W, float(l_tex), float(l_mrgb),
+                                                float(l_sil), _fp(re_img_m), _fp(mask_rgbs), _fp(partial), _fp(out),
+                                                _stream_of(rgba)), "hifihr_photo_loss_fwd")
+
+    def photo_loss_bwd(self, rgba, re_img_m, mask_rgbs, g_re_img, gout, fwd_out, l_tex, l_mrgb, grad_rgba):
+        B, _, H, W = rgba.shape
+        self.check(self.c.hifihr_photo_loss_bwd(_fp(rgba), _fp(re_img_m), _fp(mask_rgbs), _fp(g_re_img), _fp(gout), _fp(fwd_out), B, H, W,
+                                                float(l_tex), float(l_mrgb), _fp(grad_rgba), _stream_of(rgba)), "hifihr_photo_loss_bwd")
+
+    def sil_post(self, rgba, imgs, re_sil, mask_rgbs):
+        B, _, H, W = rgba.shape
+        assert rgba.is_contiguous() and (imgs is None or imgs.is_contiguous())
+        self.check(self.c.hifihr_sil_post(_fp(rgba), _fp(imgs), B, H, W, _fp(re_sil), _fp(mask_rgbs), _stream_of(rgba)), "hifihr_sil_post")
+
+    def mmpool_fwd(self, x, p, B, HW, C, y, argmax, xmax, xavg):
+        self.check(self.c.hifihr_mmpool_fwd(_fp(x), _fp(p), B, HW, C, _fp(y), _ip(argmax), _fp(xmax), _fp(xavg), _stream_of(x)),
+                   "hifihr_mmpool_fwd")
+
+    def mmpool_bwd(self, gy, p, argmax, xmax, xavg, B, HW, C, dx, dp_acc):
+        self.check(self.c.hifihr_mmpool_bwd(_fp(gy), _fp(p), _ip(argmax), _fp(xmax), _fp(xavg), B, HW, C, _fp(dx), _fp(dp_acc),
+                                            _stream_of(gy)), "hifihr_mmpool_bwd")
+
+    def maxpool3x3s2_fwd(self, x, N, H, W, C, y, tap):
+        assert tap.dtype == torch.uint8 and tap.is_contiguous()
+        self.check(self.c.hifihr_maxpool3x3s2_fwd(_fp(x), N, H, W, C, _fp(y), c_void_p(tap.data_ptr()), _stream_of(x)),
+                   "hifihr_maxpool3x3s2_fwd")
+
+    def maxpool3x3s2_bwd(self, gy, tap, N, H, W, C, dx):
+        self.check(self.c.hifihr_maxpool3x3s2_bwd(_fp(gy), c_void_p(tap.data_ptr()), N, H, W, C, _fp(dx), _stream_of(gy)),
+                   "hifihr_maxpool3x3s2_bwd")
 
     def conv2d_bwd_data(self, dy, w, dx, scratch, N, H, W, C, K, R, S, stride, pad):
         self.check(self.c.hifihr_conv2d_bwd_data(_fp(dy), _fp(w), _fp(dx), _fp(scratch), N, H, W, C, K, R, S, stride, pad,

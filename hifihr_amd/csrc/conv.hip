@@ -41,6 +41,12 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBK = 16;     // K-chunk depth (8 MFMA k-steps of 2)
 
+// Ablation builds for tools/conv_ablate.py only (results are wrong for any value but 0): 1 = no global loads in the main
+// loop, 2 = also no LDS stores, 3 = also no barrier, 4 = also no LDS reads (MFMA + epilogue only).
+#ifndef HIFIHR_CONV_PROBE
+#define HIFIHR_CONV_PROBE 0
+#endif
+
 // How one launch (or one parity class of a strided dgrad launch) walks rows and taps.
 //   forward : rows = output pixels, tap j reads src row  oy*stride - pad + j
 //   dgrad   : rows = the input pixels of parity class (ph, pw) = (oy*st + ph, ox*st + pw); only taps
@@ -203,9 +209,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
       const int buf = ch & 1;
       // stage u held chunk ch (already in LDS): refill it with chunk ch + 3.  Issued unconditionally (masked, clamped
       // loads past the last tap): a conditional load turns the registers into phis whose copies wait at once.
-      load_global(u);
+      if (HIFIHR_CONV_PROBE < 1) load_global(u);
       HIFIHR_SCHED_FENCE();               // loads first, then the MFMA block
       float a[TM][HK], b[TN][HK];
+#if HIFIHR_CONV_PROBE >= 4
+#pragma unroll
+      for (int t = 0; t < HK; ++t) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i][t] = ra[0][0].x + (float)(t + ch);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j][t] = rb[0][0].x;
+      }
+#else
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const float* p = &As[buf][(wm * (BM / 2) + i * 32 + r31) * LD + half * HK];
@@ -224,6 +239,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
           b[j][4 * v4] = q.x; b[j][4 * v4 + 1] = q.y; b[j][4 * v4 + 2] = q.z; b[j][4 * v4 + 3] = q.w;
         }
       }
+#endif
 #pragma unroll
       for (int t = 0; t < HK; ++t)
 #pragma unroll
@@ -231,8 +247,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
       HIFIHR_SCHED_FENCE();
-      store_lds((u + 1) % kPF, buf ^ 1);  // chunk ch + 1 (loaded two chunk-computations ago) -> the other LDS buffer
-      __syncthreads();
+      if (HIFIHR_CONV_PROBE < 2) store_lds((u + 1) % kPF, buf ^ 1);  // chunk ch + 1 (loaded two chunk-computations ago) -> the other LDS buffer
+      if (HIFIHR_CONV_PROBE < 3) __syncthreads();
     }
   }
 
@@ -474,11 +490,7 @@ static void launch_igemm_tile(const ConvGeom& g, long Mmax, int classes, bool ge
 
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
                              hipStream_t st) {
-  if (stats != nullptr) {
-    if (g.dgrad) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(stats, 0, (size_t)kStatSlots * 2 * g.OC * sizeof(float), st);
-    if (e != hipSuccess) return e;
-  }
+  if (stats != nullptr && g.dgrad) return hipErrorInvalidValue;   // stats: all zero on entry (self-cleaning, see bn.hip)
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
   const bool generic = (g.IC % 16) != 0;
   if (generic && g.dgrad && g.stride != 1) return hipErrorInvalidValue;   // strided dgrad needs source channels % 16 == 0

@@ -334,7 +334,7 @@ int hifihr_bn_stats(const float* x, long M, int C, float* stats, void* stream) {
   return HIFIHR_OK;
 }
 
-int hifihr_bn_act_fwd(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual, int act,
+int hifihr_bn_act_fwd(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, int act,
                       long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,
                       float* running_mean, float* running_var, void* stream) {
   if (!x || !stats || !gamma || !beta || !y || !save_mean || !save_invstd || !bn_dims_ok(M, C) ||
@@ -382,6 +382,99 @@ int hifihr_dwconv2d_bwd_weight(const float* x, const float* dy, float* dw, int N
   if (!x || !dy || !dw || !dw_ok(N, H, W, C, OH, OW, K, stride, pad_top, pad_left)) return fail(HIFIHR_EINVAL, "hifihr_dwconv2d_bwd_weight: bad argument");
   hifihr::DwGeom g{N, H, W, C, OH, OW, K, stride, pad_top, pad_left};
   HIP_TRY(hifihr::launch_dwconv_bwd_weight(g, x, dy, dw, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_mmpool_fwd(const float* x, const float* p, int B, int HW, int C, float* y, int* argmax, float* xmax, float* xavg,
+                      void* stream) {
+  if (!x || !p || !y || !argmax || !xmax || !xavg || B <= 0 || HW <= 0 || C < 4 || C % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_mmpool_fwd: bad argument (C % 4 == 0)");
+  HIP_TRY(hifihr::launch_mmpool_fwd(x, p, B, HW, C, y, argmax, xmax, xavg, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_mmpool_bwd(const float* gy, const float* p, const int* argmax, const float* xmax, const float* xavg, int B, int HW, int C,
+                      float* dx, float* dp_acc, void* stream) {
+  if (!gy || !p || !argmax || !xmax || !xavg || !dx || B <= 0 || HW <= 0 || C < 4 || C % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_mmpool_bwd: bad argument (C % 4 == 0)");
+  HIP_TRY(hifihr::launch_mmpool_bwd(gy, p, argmax, xmax, xavg, B, HW, C, dx, dp_acc, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* tap, void* stream) {
+  if (!x || !y || !tap || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_maxpool3x3s2_fwd: bad argument (C % 4 == 0)");
+  HIP_TRY(hifihr::launch_maxpool3x3s2_fwd(x, N, H, W, C, y, tap, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_maxpool3x3s2_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, float* dx, void* stream) {
+  if (!gy || !tap || !dx || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_maxpool3x3s2_bwd: bad argument (C % 4 == 0)");
+  HIP_TRY(hifihr::launch_maxpool3x3s2_bwd(gy, tap, N, H, W, C, dx, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+static int geom_args(hifihr::GeomLossArgs& a, const float* joints, const float* joints_gt, const float* verts, const float* verts_gt,
+                     const float* shape, const float* pose, const int32_t* faces, int B, int J, int V, int F, int NS, int NP, int mse,
+                     const float* lambda5) {
+  if (!joints || !joints_gt || !verts || !verts_gt || !lambda5 || B <= 0 || J <= 0 || V <= 0 || F < 0 || NS < 0 || NP < 0 ||
+      (F > 0 && !faces) || (NS > 0 && !shape) || (NP > 0 && !pose))
+    return 0;
+  a.joints = joints; a.joints_gt = joints_gt; a.verts = verts; a.verts_gt = verts_gt; a.shape = shape; a.pose = pose;
+  a.faces = F > 0 ? faces : nullptr; a.vf_off = nullptr; a.vf_idx = nullptr;
+  a.B = B; a.J = J; a.V = V; a.F = F; a.NS = NS; a.NP = NP; a.mse = mse ? 1 : 0;
+  for (int k = 0; k < 5; ++k) a.lambda[k] = lambda5[k];
+  return 1;
+}
+
+int hifihr_geom_loss_fwd(const float* joints, const float* joints_gt, const float* verts, const float* verts_gt, const float* shape,
+                         const float* pose, const int32_t* faces, int B, int J, int V, int F, int NS, int NP, int mse,
+                         const float* lambda5, float* partial, float* out, void* stream) {
+  hifihr::GeomLossArgs a;
+  if (!partial || !out || !geom_args(a, joints, joints_gt, verts, verts_gt, shape, pose, faces, B, J, V, F, NS, NP, mse, lambda5))
+    return fail(HIFIHR_EINVAL, "hifihr_geom_loss_fwd: bad argument");
+  HIP_TRY(hifihr::launch_geom_loss_fwd(a, partial, out, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_geom_loss_bwd(const float* joints, const float* joints_gt, const float* verts, const float* verts_gt, const float* shape,
+                         const float* pose, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_idx, int B, int J, int V,
+                         int F, int NS, int NP, int mse, const float* lambda5, const float* gout, float* gj, float* gv, float* gshape,
+                         float* gpose, void* stream) {
+  hifihr::GeomLossArgs a;
+  if (!gout || (F > 0 && (!vf_off || !vf_idx)) ||
+      !geom_args(a, joints, joints_gt, verts, verts_gt, shape, pose, faces, B, J, V, F, NS, NP, mse, lambda5))
+    return fail(HIFIHR_EINVAL, "hifihr_geom_loss_bwd: bad argument");
+  a.vf_off = vf_off; a.vf_idx = vf_idx;
+  HIP_TRY(hifihr::launch_geom_loss_bwd(a, gout, gj, gv, gshape, gpose, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_photo_loss_partial_floats(void) { return hifihr::photo_loss_partial_floats(); }
+
+int hifihr_photo_loss_fwd(const float* rgba, const float* imgs, const int64_t* seg, int B, int H, int W, float l_tex, float l_mrgb,
+                          float l_sil, float* re_img_m, float* mask_rgbs, float* partial, float* out, void* stream) {
+  if (!rgba || !imgs || !seg || !re_img_m || !mask_rgbs || !partial || !out || B <= 0 || H <= 0 || W <= 0 || (H * W) % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_photo_loss_fwd: bad argument (H*W % 4 == 0)");
+  HIP_TRY(hifihr::launch_photo_loss_fwd(rgba, imgs, (const long long*)seg, B, H * W, l_tex, l_mrgb, l_sil, re_img_m, mask_rgbs, partial,
+                                        out, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_photo_loss_bwd(const float* rgba, const float* re_img_m, const float* mask_rgbs, const float* g_re_img, const float* gout,
+                          const float* fwd_out, int B, int H, int W, float l_tex, float l_mrgb, float* grad_rgba, void* stream) {
+  if (!rgba || !re_img_m || !mask_rgbs || !fwd_out || !grad_rgba || B <= 0 || H <= 0 || W <= 0 || (H * W) % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_photo_loss_bwd: bad argument (H*W % 4 == 0)");
+  HIP_TRY(hifihr::launch_photo_loss_bwd(rgba, re_img_m, mask_rgbs, g_re_img, gout, fwd_out, B, H * W, l_tex, l_mrgb, grad_rgba,
+                                        (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_sil_post(const float* rgba, const float* imgs, int B, int H, int W, float* re_sil, float* mask_rgbs, void* stream) {
+  if (!rgba || !re_sil || (mask_rgbs && !imgs) || B <= 0 || H <= 0 || W <= 0 || (H * W) % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_sil_post: bad argument (H*W % 4 == 0)");
+  HIP_TRY(hifihr::launch_sil_post(rgba, imgs, B, H * W, re_sil, mask_rgbs, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

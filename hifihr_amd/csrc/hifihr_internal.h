@@ -62,7 +62,7 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
 // float atomic (thousands of atomics on ONE address serialise at ~100 ns each: 200 us per reduction in round 1).
 constexpr int kStatSlots = 32;
 hipError_t launch_bn_stats(const float* x, long M, int C, float* stats, hipStream_t st);
-hipError_t launch_bn_act_fwd(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
+hipError_t launch_bn_act_fwd(const float* x, float* stats, const float* gamma, const float* beta, const float* residual,
                              int relu, long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,
                              float* running_mean, float* running_var, hipStream_t st);
 hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, const float* save_mean, const float* save_invstd,
@@ -87,6 +87,31 @@ struct DwGeom {
 hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, hipStream_t st);
 hipError_t launch_dwconv_bwd_data(const DwGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
 hipError_t launch_dwconv_bwd_weight(const DwGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
+
+hipError_t launch_mmpool_fwd(const float* x, const float* p, int B, int HW, int C, float* y, int* argmax, float* xmax, float* xavg,
+                             hipStream_t st);
+hipError_t launch_mmpool_bwd(const float* gy, const float* p, const int* argmax, const float* xmax, const float* xavg, int B, int HW,
+                             int C, float* dx, float* dp_acc, hipStream_t st);
+hipError_t launch_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* tap, hipStream_t st);
+hipError_t launch_maxpool3x3s2_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, float* dx, hipStream_t st);
+
+// geometry loss terms (losses.hip): k = 0 joint_3d, 1 vert_3d, 2 edge_length, 3 mshape, 4 mpose
+struct GeomLossArgs {
+  const float *joints, *joints_gt, *verts, *verts_gt, *shape, *pose;
+  const int *faces, *vf_off, *vf_idx;     // faces [F][3]; vertex -> incident (face * 4 + corner) CSR (backward only)
+  int B, J, V, F, NS, NP, mse;            // mse = 1: F.mse_loss, 0: F.l1_loss for the joint / vertex terms
+  float lambda[5];
+};
+hipError_t launch_geom_loss_fwd(const GeomLossArgs& a, float* partial, float* out, hipStream_t st);
+hipError_t launch_geom_loss_bwd(const GeomLossArgs& a, const float* gout, float* gj, float* gv, float* gshape, float* gpose,
+                                hipStream_t st);
+int photo_loss_partial_floats();
+hipError_t launch_photo_loss_fwd(const float* rgba, const float* imgs, const long long* seg, int B, int HW, float l_tex, float l_mrgb,
+                                 float l_sil, float* re_img_m, float* mask_rgbs, float* partial, float* out, hipStream_t st);
+hipError_t launch_photo_loss_bwd(const float* rgba, const float* re_img_m, const float* mask_rgbs, const float* g_re_img,
+                                 const float* gout, const float* fwd_out, int B, int HW, float l_tex, float l_mrgb, float* grad_rgba,
+                                 hipStream_t st);
+hipError_t launch_sil_post(const float* rgba, const float* imgs, int B, int HW, float* re_sil, float* mask_rgbs, hipStream_t st);
 
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st);

@@ -1,0 +1,287 @@
+// The training losses of the step as a handful of fused kernels (they were ~250 ATen launches of ~4.6 us each in
+// round 1's steady-state profile: every term is a tiny reduction, so the cost was pure launch count).
+//
+// Replaces, for reference losses.py:226-453 (LossFunction.forward) and its autograd:
+//   geom_loss_fwd/bwd    joint_3d, vert_3d (F.l1_loss / F.mse_loss by base_loss_fn), edge_length
+//                        (utils/losses_util.py:285-301), mshape, mpose (F.mse_loss against zeros)
+//   photo_loss_fwd/bwd   the photometric block (losses.py:355-378): re_img = re_img * re_sil / 255,
+//                        mask_rgbs = seg * imgs, texture (L1), mrgb (MSE of the two means), and the `sil` L1 term
+//   sil_post             re_sil = where(alpha > 0, 255, alpha), maskRGBs = images * (re_sil > 0)
+//                        (models_res_nimble.py:219-220)
+// Every forward writes per-workgroup partial sums; a one-workgroup finisher folds them in a fixed order (deterministic)
+// into the lambda-weighted loss values.  The backward kernels take the incoming gradient of each term as a DEVICE
+// vector (no host sync) and recompute the cheap per-element derivatives.
+#include <hip/hip_runtime.h>
+
+#include "hifihr_internal.h"
+
+namespace hifihr {
+
+// block-wide sums of K values per thread (256 threads); result valid in thread 0
+template <int K>
+__device__ __forceinline__ void block_sum(float (&v)[K], float* lds /* [K][4] */) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) lds[k * 4 + wave] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = (lds[k * 4] + lds[k * 4 + 1]) + (lds[k * 4 + 2] + lds[k * 4 + 3]);
+  }
+}
+
+__device__ __forceinline__ float base_term(int mse, float d) { return mse ? d * d : fabsf(d); }
+__device__ __forceinline__ float base_grad(int mse, float d) { return mse ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)); }
+
+__device__ __forceinline__ float edge_len(const float* __restrict__ v, int a, int b) {
+  const float dx = v[3 * a] - v[3 * b], dy = v[3 * a + 1] - v[3 * b + 1], dz = v[3 * a + 2] - v[3 * b + 2];
+  return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry terms: one workgroup per sample
+// ------------------------------------------------------------------------------------------------
+// partial[b][5] = (sum base(joints), sum base(verts), sum |edge_pred - edge_gt|, sum shape^2, sum pose^2)
+__global__ __launch_bounds__(256) void geom_loss_fwd_kernel(GeomLossArgs a, float* __restrict__ partial) {
+  __shared__ float lds[5 * 4];
+  const int b = blockIdx.x;
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* j = a.joints + (size_t)b * a.J * 3, *jg = a.joints_gt + (size_t)b * a.J * 3;
+  for (int i = threadIdx.x; i < a.J * 3; i += 256) s[0] += base_term(a.mse, j[i] - jg[i]);
+  const float* v = a.verts + (size_t)b * a.V * 3, *vg = a.verts_gt + (size_t)b * a.V * 3;
+  for (int i = threadIdx.x; i < a.V * 3; i += 256) s[1] += base_term(a.mse, v[i] - vg[i]);
+  if (a.faces != nullptr) {
+    for (int f = threadIdx.x; f < a.F; f += 256) {
+      const int i0 = a.faces[3 * f], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
+      s[2] += fabsf(edge_len(v, i0, i1) - edge_len(vg, i0, i1)) + fabsf(edge_len(v, i0, i2) - edge_len(vg, i0, i2)) +
+              fabsf(edge_len(v, i1, i2) - edge_len(vg, i1, i2));
+    }
+  }
+  for (int i = threadIdx.x; i < a.NS; i += 256) { const float t = a.shape[(size_t)b * a.NS + i]; s[3] += t * t; }
+  for (int i = threadIdx.x; i < a.NP; i += 256) { const float t = a.pose[(size_t)b * a.NP + i]; s[4] += t * t; }
+  block_sum<5>(s, lds);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) partial[b * 5 + k] = s[k];
+  }
+}
+
+// out[k] = lambda[k] * sum_b partial[b][k] / count[k]
+__global__ __launch_bounds__(64) void geom_loss_finish_kernel(GeomLossArgs a, const float* __restrict__ partial, float* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= 5) return;
+  float s = 0.f;
+  for (int b = 0; b < a.B; ++b) s += partial[b * 5 + k];
+  const float cnt[5] = {(float)a.B * a.J * 3, (float)a.B * a.V * 3, (float)a.B * a.F * 3, (float)a.B * a.NS, (float)a.B * a.NP};
+  out[k] = (cnt[k] > 0.f) ? a.lambda[k] * s / cnt[k] : 0.f;
+}
+
+// gout[5]: gradient of each (already lambda-weighted) term.  One workgroup per sample; the edge term is gathered per
+// vertex through the vertex -> (face, corner) table, so every output element has exactly one writer (deterministic).
+__global__ __launch_bounds__(256) void geom_loss_bwd_kernel(GeomLossArgs a, const float* __restrict__ gout, float* __restrict__ gj,
+                                                           float* __restrict__ gv, float* __restrict__ gshape, float* __restrict__ gpose) {
+  const int b = blockIdx.x;
+  const float cj = gout[0] * a.lambda[0] / ((float)a.B * a.J * 3), cv = gout[1] * a.lambda[1] / ((float)a.B * a.V * 3);
+  const float ce = (a.F > 0) ? gout[2] * a.lambda[2] / ((float)a.B * a.F * 3) : 0.f;
+  const float cs = gout[3] * a.lambda[3] * 2.f / ((float)a.B * a.NS), cp = gout[4] * a.lambda[4] * 2.f / ((float)a.B * a.NP);
+  const float* j = a.joints + (size_t)b * a.J * 3, *jg = a.joints_gt + (size_t)b * a.J * 3;
+  if (gj)
+    for (int i = threadIdx.x; i < a.J * 3; i += 256) gj[(size_t)b * a.J * 3 + i] = cj * base_grad(a.mse, j[i] - jg[i]);
+  const float* v = a.verts + (size_t)b * a.V * 3, *vg = a.verts_gt + (size_t)b * a.V * 3;
+  if (gv) {
+    for (int vi = threadIdx.x; vi < a.V; vi += 256) {
+      float g[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) g[d] = cv * base_grad(a.mse, v[3 * vi + d] - vg[3 * vi + d]);
+      if (a.faces != nullptr) {
+        for (int e = a.vf_off[vi]; e < a.vf_off[vi + 1]; ++e) {
+          const int f = a.vf_idx[e] >> 2, role = a.vf_idx[e] & 3;
+#pragma unroll
+          for (int o = 1; o <= 2; ++o) {                       // the two edges of face f that touch this corner
+            const int u = a.faces[3 * f + (role + o) % 3];
+            const float lp = edge_len(v, vi, u), lg = edge_len(vg, vi, u);
+            const float sg = (lp > lg) ? 1.f : ((lp < lg) ? -1.f : 0.f);
+            if (lp > 0.f) {
+              const float k = ce * sg / lp;
+#pragma unroll
+              for (int d = 0; d < 3; ++d) g[d] += k * (v[3 * vi + d] - v[3 * u + d]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) gv[((size_t)b * a.V + vi) * 3 + d] = g[d];
+    }
+  }
+  if (gshape)
+    for (int i = threadIdx.x; i < a.NS; i += 256) gshape[(size_t)b * a.NS + i] = cs * a.shape[(size_t)b * a.NS + i];
+  if (gpose)
+    for (int i = threadIdx.x; i < a.NP; i += 256) gpose[(size_t)b * a.NP + i] = cp * a.pose[(size_t)b * a.NP + i];
+}
+
+hipError_t launch_geom_loss_fwd(const GeomLossArgs& a, float* partial, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(geom_loss_fwd_kernel, dim3(a.B), dim3(256), 0, st, a, partial);
+  hipLaunchKernelGGL(geom_loss_finish_kernel, dim3(1), dim3(64), 0, st, a, partial, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_geom_loss_bwd(const GeomLossArgs& a, const float* gout, float* gj, float* gv, float* gshape, float* gpose,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(geom_loss_bwd_kernel, dim3(a.B), dim3(256), 0, st, a, gout, gj, gv, gshape, gpose);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// photometric terms: thread = 4 consecutive pixels of one image (float4), grid-stride
+// ------------------------------------------------------------------------------------------------
+constexpr int kPhotoBlocks = 512;
+
+__device__ __forceinline__ float sil_scale(float alpha) { return alpha > 0.f ? 1.0f : alpha / 255.0f; }   // re_sil / 255
+
+// re_img_m[B][3][HW], mask_rgbs[B][3][HW]; partial[blk][4] = (sum |r - m|, sum r, sum m, sum |re_sil - seg|)
+__global__ __launch_bounds__(256) void photo_loss_fwd_kernel(const float* __restrict__ rgba, const float* __restrict__ imgs,
+                                                            const long long* __restrict__ seg, int B, int HW,
+                                                            float* __restrict__ re_img_m, float* __restrict__ mask_rgbs,
+                                                            float* __restrict__ partial) {
+  __shared__ float lds[4 * 4];
+  const int Q = HW / 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)B * Q; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / Q, p = (i - b * Q) * 4;
+    const float4 al = *reinterpret_cast<const float4*>(rgba + (b * 4 + 3) * HW + p);
+    const float a4[4] = {al.x, al.y, al.z, al.w};
+    float sc[4], sg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc[e] = sil_scale(a4[e]);
+      sg[e] = (float)seg[b * HW + p + e];
+      const float re_sil = a4[e] > 0.f ? 255.0f : a4[e];
+      s[3] += fabsf(re_sil - sg[e]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float4 r = *reinterpret_cast<const float4*>(rgba + (b * 4 + c) * HW + p);
+      const float4 im = *reinterpret_cast<const float4*>(imgs + (b * 3 + c) * HW + p);
+      const float4 rr = make_float4(r.x * sc[0], r.y * sc[1], r.z * sc[2], r.w * sc[3]);
+      const float4 mm = make_float4(sg[0] * im.x, sg[1] * im.y, sg[2] * im.z, sg[3] * im.w);
+      *reinterpret_cast<float4*>(re_img_m + (b * 3 + c) * HW + p) = rr;
+      *reinterpret_cast<float4*>(mask_rgbs + (b * 3 + c) * HW + p) = mm;
+      s[0] += fabsf(rr.x - mm.x) + fabsf(rr.y - mm.y) + fabsf(rr.z - mm.z) + fabsf(rr.w - mm.w);
+      s[1] += (rr.x + rr.y) + (rr.z + rr.w);
+      s[2] += (mm.x + mm.y) + (mm.z + mm.w);
+    }
+  }
+  block_sum<4>(s, lds);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) partial[blockIdx.x * 4 + k] = s[k];
+  }
+}
+
+// out[0] = l_tex * mean|r - m|, out[1] = l_mrgb * (mean m - mean r)^2, out[2] = l_sil * mean|re_sil - seg|,
+// out[3] = mean r - mean m (kept for the backward)
+__global__ __launch_bounds__(256) void photo_loss_finish_kernel(const float* __restrict__ partial, int nblk, float n3, float n1,
+                                                               float l_tex, float l_mrgb, float l_sil, float* __restrict__ out) {
+  __shared__ float lds[4 * 4];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < nblk; i += 256) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += partial[i * 4 + k];
+  }
+  block_sum<4>(s, lds);
+  if (threadIdx.x == 0) {
+    const float dm = s[1] / n3 - s[2] / n3;
+    out[0] = l_tex * s[0] / n3;
+    out[1] = l_mrgb * dm * dm;
+    out[2] = l_sil * s[3] / n1;
+    out[3] = dm;
+  }
+}
+
+// grad_rgba[B][4][HW]: rgb channels = scale * (g_re_img + gout[0] l_tex sign(r - m) / n3 + gout[1] l_mrgb 2 dm / n3); alpha = 0
+__global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const float* __restrict__ rgba, const float* __restrict__ re_img_m,
+                                                            const float* __restrict__ mask_rgbs, const float* __restrict__ g_re_img,
+                                                            const float* __restrict__ gout, const float* __restrict__ fwd_out, int B,
+                                                            int HW, float n3, float l_tex, float l_mrgb, float* __restrict__ grad_rgba) {
+  const int Q = HW / 4;
+  const float kt = (gout ? gout[0] : 0.f) * l_tex / n3;
+  const float km = (gout ? gout[1] : 0.f) * l_mrgb * 2.f * fwd_out[3] / n3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)B * Q; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / Q, p = (i - b * Q) * 4;
+    const float4 al = *reinterpret_cast<const float4*>(rgba + (b * 4 + 3) * HW + p);
+    const float sc[4] = {sil_scale(al.x), sil_scale(al.y), sil_scale(al.z), sil_scale(al.w)};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t o = (b * 3 + c) * HW + p;
+      const float4 r = *reinterpret_cast<const float4*>(re_img_m + o), m = *reinterpret_cast<const float4*>(mask_rgbs + o);
+      float4 g = g_re_img ? *reinterpret_cast<const float4*>(g_re_img + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      g.x += kt * base_grad(0, r.x - m.x) + km; g.y += kt * base_grad(0, r.y - m.y) + km;
+      g.z += kt * base_grad(0, r.z - m.z) + km; g.w += kt * base_grad(0, r.w - m.w) + km;
+      *reinterpret_cast<float4*>(grad_rgba + (b * 4 + c) * HW + p) = make_float4(g.x * sc[0], g.y * sc[1], g.z * sc[2], g.w * sc[3]);
+    }
+    *reinterpret_cast<float4*>(grad_rgba + (b * 4 + 3) * HW + p) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// re_sil[B][HW] = alpha > 0 ? 255 : alpha;  maskRGBs[B][3][HW] = images * (alpha > 0)
+__global__ __launch_bounds__(256) void sil_post_kernel(const float* __restrict__ rgba, const float* __restrict__ imgs, int B, int HW,
+                                                      float* __restrict__ re_sil, float* __restrict__ mask_rgbs) {
+  const int Q = HW / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)B * Q; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / Q, p = (i - b * Q) * 4;
+    const float4 al = *reinterpret_cast<const float4*>(rgba + (b * 4 + 3) * HW + p);
+    *reinterpret_cast<float4*>(re_sil + b * HW + p) =
+        make_float4(al.x > 0.f ? 255.f : al.x, al.y > 0.f ? 255.f : al.y, al.z > 0.f ? 255.f : al.z, al.w > 0.f ? 255.f : al.w);
+    if (mask_rgbs != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float4 im = *reinterpret_cast<const float4*>(imgs + (b * 3 + c) * HW + p);
+        *reinterpret_cast<float4*>(mask_rgbs + (b * 3 + c) * HW + p) =
+            make_float4(al.x > 0.f ? im.x : 0.f, al.y > 0.f ? im.y : 0.f, al.z > 0.f ? im.z : 0.f, al.w > 0.f ? im.w : 0.f);
+      }
+    }
+  }
+}
+
+int photo_loss_partial_floats() { return kPhotoBlocks * 4; }
+
+static unsigned photo_grid(int B, int HW) {
+  size_t blocks = ((size_t)B * (HW / 4) + 255) / 256;
+  if (blocks > (size_t)kPhotoBlocks) blocks = kPhotoBlocks;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+hipError_t launch_photo_loss_fwd(const float* rgba, const float* imgs, const long long* seg, int B, int HW, float l_tex, float l_mrgb,
+                                 float l_sil, float* re_img_m, float* mask_rgbs, float* partial, float* out, hipStream_t st) {
+  if (HW % 4 != 0) return hipErrorInvalidValue;
+  const unsigned nblk = photo_grid(B, HW);
+  hipLaunchKernelGGL(photo_loss_fwd_kernel, dim3(nblk), dim3(256), 0, st, rgba, imgs, seg, B, HW, re_img_m, mask_rgbs, partial);
+  hipLaunchKernelGGL(photo_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial, (int)nblk, (float)B * 3.f * HW, (float)B * HW, l_tex,
+                     l_mrgb, l_sil, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_photo_loss_bwd(const float* rgba, const float* re_img_m, const float* mask_rgbs, const float* g_re_img,
+                                 const float* gout, const float* fwd_out, int B, int HW, float l_tex, float l_mrgb, float* grad_rgba,
+                                 hipStream_t st) {
+  if (HW % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(photo_loss_bwd_kernel, dim3(photo_grid(B, HW) * 4), dim3(256), 0, st, rgba, re_img_m, mask_rgbs, g_re_img, gout,
+                     fwd_out, B, HW, (float)B * 3.f * HW, l_tex, l_mrgb, grad_rgba);
+  return hipGetLastError();
+}
+
+hipError_t launch_sil_post(const float* rgba, const float* imgs, int B, int HW, float* re_sil, float* mask_rgbs, hipStream_t st) {
+  if (HW % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sil_post_kernel, dim3(photo_grid(B, HW) * 4), dim3(256), 0, st, rgba, imgs, B, HW, re_sil, mask_rgbs);
+  return hipGetLastError();
+}
+
+}  // namespace hifihr

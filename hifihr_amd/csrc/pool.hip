@@ -1,0 +1,215 @@
+// Pooling layers of the encoder on NHWC fp32 activations (HBM-bound, float4 = 4 channels per lane, no atomics).
+//
+//   mmpool_fwd/bwd     MMPool((1,1)) of the reference (network/res_encoder.py:247-265, called at :49):
+//                      y = max_hw(x) * w + mean_hw(x) * (1 - w), w = sigmoid(p), p a learned scalar.  One kernel per
+//                      direction instead of adaptive_max_pool2d + adaptive_avg_pool2d + sigmoid + 4 elementwise ops
+//                      (the ATen adaptive max pool alone took 143 us per step in round 1's profile).
+//   maxpool3x3s2_fwd/bwd   nn.MaxPool2d(3, 2, 1) after the ResNet stem (torchvision resnet18.maxpool as the reference
+//                      builds it, network/res_encoder.py:345-373).  The forward stores the winning tap (0..8, first
+//                      maximum in scan order like ATen) as one byte; the backward GATHERS (every input pixel looks at
+//                      the <= 4 windows that contain it), so dx is written exactly once and needs no zero fill.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "hifihr_internal.h"
+
+namespace hifihr {
+
+// ------------------------------------------------------------------------------------------------
+// MMPool: workgroup = (image b, 64 channels); thread = (row lane 0..15, float4 channel lane 0..15)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void take_max(float& m, int& mi, float v, int i) {
+  if (v > m || (v == m && i < mi)) { m = v; mi = i; }
+}
+
+__global__ __launch_bounds__(256) void mmpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ p, int HW, int C,
+                                                        float* __restrict__ y, int* __restrict__ argmax, float* __restrict__ xmax,
+                                                        float* __restrict__ xavg) {
+  __shared__ float4 s_max[16][16], s_sum[16][16];
+  __shared__ int4 s_idx[16][16];
+  const int b = blockIdx.y, cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cl * 4;
+  const bool cok = c < C;
+  float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX), s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int4 mi = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
+  if (cok) {
+    const float* xb = x + (size_t)b * HW * C + c;
+    for (int r = rl; r < HW; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)r * C);
+      take_max(m.x, mi.x, v.x, r); take_max(m.y, mi.y, v.y, r); take_max(m.z, mi.z, v.z, r); take_max(m.w, mi.w, v.w, r);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  s_max[rl][cl] = m; s_sum[rl][cl] = s; s_idx[rl][cl] = mi;
+  __syncthreads();
+  if (rl == 0 && cok) {
+    for (int r = 1; r < 16; ++r) {
+      const float4 om = s_max[r][cl], os = s_sum[r][cl];
+      const int4 oi = s_idx[r][cl];
+      take_max(m.x, mi.x, om.x, oi.x); take_max(m.y, mi.y, om.y, oi.y); take_max(m.z, mi.z, om.z, oi.z); take_max(m.w, mi.w, om.w, oi.w);
+      s.x += os.x; s.y += os.y; s.z += os.z; s.w += os.w;
+    }
+    const float w = 1.0f / (1.0f + expf(-p[0])), inv = 1.0f / (float)HW;
+    const float4 avg = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    const size_t o = (size_t)b * C + c;
+    *reinterpret_cast<float4*>(y + o) = make_float4(m.x * w + avg.x * (1.f - w), m.y * w + avg.y * (1.f - w),
+                                                     m.z * w + avg.z * (1.f - w), m.w * w + avg.w * (1.f - w));
+    *reinterpret_cast<int4*>(argmax + o) = mi;
+    *reinterpret_cast<float4*>(xmax + o) = m;
+    *reinterpret_cast<float4*>(xavg + o) = avg;
+  }
+}
+
+// dx = gy * (1 - w) / HW + [row == argmax] * gy * w;   dp_acc += sum gy * (max - avg) * w * (1 - w)   (block 0 alone)
+__global__ __launch_bounds__(256) void mmpool_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ p,
+                                                        const int* __restrict__ argmax, const float* __restrict__ xmax,
+                                                        const float* __restrict__ xavg, int B, int HW, int C,
+                                                        float* __restrict__ dx, float* __restrict__ dp_acc) {
+  const int b = blockIdx.y, cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cl * 4;
+  const float w = 1.0f / (1.0f + expf(-p[0]));
+  if (c < C) {
+    const size_t o = (size_t)b * C + c;
+    const float4 g = *reinterpret_cast<const float4*>(gy + o);
+    const int4 mi = *reinterpret_cast<const int4*>(argmax + o);
+    const float ka = (1.f - w) / (float)HW;
+    float* xb = dx + (size_t)b * HW * C + c;
+    for (int r = rl; r < HW; r += 16) {
+      float4 v = make_float4(g.x * ka, g.y * ka, g.z * ka, g.w * ka);
+      if (r == mi.x) v.x += g.x * w;
+      if (r == mi.y) v.y += g.y * w;
+      if (r == mi.z) v.z += g.z * w;
+      if (r == mi.w) v.w += g.w * w;
+      *reinterpret_cast<float4*>(xb + (size_t)r * C) = v;
+    }
+  }
+  if (dp_acc != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {      // one deterministic writer for the scalar gradient
+    __shared__ float red[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < B * C; i += 256) a += gy[i] * (xmax[i] - xavg[i]);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dp_acc[0] += red[0] * w * (1.f - w);
+  }
+}
+
+hipError_t launch_mmpool_fwd(const float* x, const float* p, int B, int HW, int C, float* y, int* argmax, float* xmax, float* xavg,
+                             hipStream_t st) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mmpool_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, p, HW, C, y, argmax, xmax, xavg);
+  return hipGetLastError();
+}
+
+hipError_t launch_mmpool_bwd(const float* gy, const float* p, const int* argmax, const float* xmax, const float* xavg, int B, int HW,
+                             int C, float* dx, float* dp_acc, hipStream_t st) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mmpool_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, gy, p, argmax, xmax, xavg, B, HW, C, dx, dp_acc);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, padding 1): thread = (output pixel, 4 channels)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int OH, int OW,
+                                                              float* __restrict__ y, unsigned char* __restrict__ tap) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)N * OH * OW * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % C4);
+    size_t rest = i / C4;
+    const int ow = (int)(rest % OW); rest /= OW;
+    const int oh = (int)(rest % OH);
+    const int n = (int)(rest / OH);
+    float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+    int4 mt = make_int4(0, 0, 0, 0);
+    bool first = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ih = oh * 2 - 1 + r;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int iw = ow * 2 - 1 + s;
+        if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + ih) * W + iw) * C + cg * 4);
+        const int t = r * 3 + s;
+        // ATen: (val > maxval) || isnan(val), starting from the first in-range tap
+        if (first || v.x > m.x || v.x != v.x) { m.x = v.x; mt.x = t; }
+        if (first || v.y > m.y || v.y != v.y) { m.y = v.y; mt.y = t; }
+        if (first || v.z > m.z || v.z != v.z) { m.z = v.z; mt.z = t; }
+        if (first || v.w > m.w || v.w != v.w) { m.w = v.w; mt.w = t; }
+        first = false;
+      }
+    }
+    *reinterpret_cast<float4*>(y + i * 4) = m;
+    *reinterpret_cast<uchar4*>(tap + i * 4) = make_uchar4((unsigned char)mt.x, (unsigned char)mt.y, (unsigned char)mt.z, (unsigned char)mt.w);
+  }
+}
+
+// thread = (input pixel, 4 channels): sum gy over the windows whose winning tap is this pixel
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ tap, int N,
+                                                              int H, int W, int C, int OH, int OW, float* __restrict__ dx) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % C4);
+    size_t rest = i / C4;
+    const int iw = (int)(rest % W); rest /= W;
+    const int ih = (int)(rest % H);
+    const int n = (int)(rest / H);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    // windows oh with oh*2 - 1 + r == ih, r in 0..2  ->  oh in {(ih+1)/2 (r = ih+1-2*oh), ...}
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int th = ih + 1 - r;
+      if (th < 0 || (th & 1)) continue;
+      const int oh = th >> 1;
+      if (oh >= OH) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int tw = iw + 1 - s;
+        if (tw < 0 || (tw & 1)) continue;
+        const int ow = tw >> 1;
+        if (ow >= OW) continue;
+        const size_t o = ((((size_t)n * OH + oh) * OW + ow) * C4 + cg) * 4;
+        const uchar4 t = *reinterpret_cast<const uchar4*>(tap + o);
+        const float4 g = *reinterpret_cast<const float4*>(gy + o);
+        const unsigned char me = (unsigned char)(r * 3 + s);
+        if (t.x == me) a.x += g.x;
+        if (t.y == me) a.y += g.y;
+        if (t.z == me) a.z += g.z;
+        if (t.w == me) a.w += g.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = a;
+  }
+}
+
+static unsigned pool_grid(size_t total) {
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+hipError_t launch_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* tap, hipStream_t st) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(pool_grid((size_t)N * OH * OW * (C / 4))), dim3(256), 0, st, x, N, H, W, C, OH, OW, y,
+                     tap);
+  return hipGetLastError();
+}
+
+hipError_t launch_maxpool3x3s2_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, float* dx, hipStream_t st) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(pool_grid((size_t)N * H * W * (C / 4))), dim3(256), 0, st, gy, tap, N, H, W, C, OH, OW,
+                     dx);
+  return hipGetLastError();
+}
+
+}  // namespace hifihr

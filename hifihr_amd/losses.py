@@ -1,8 +1,11 @@
 """`LossFunction` with the reference's call signature, loss names and formulas
 (reference losses.py:226-453; helpers utils/losses_util.py:217-301,366-378; utils/pytorch_ssim:17-37).
 
-The SSIM term runs as one fused HIP kernel per direction (hifihr_amd/csrc/ssim.hip); the remaining terms are
-small reductions evaluated with torch ops on the GPU (next candidates for fusion: DESIGN.md).
+On the GPU the step's terms run as fused HIP kernels: SSIM (csrc/ssim.hip), the photometric block and the joint /
+vertex / edge-length / shape / pose terms (csrc/losses.hip: two launches per group instead of ~250 ATen launches).
+`fused=False` (and any CPU tensor) takes the plain torch-op restatement below, which the CPU oracle step uses and the
+tests pin the kernels against.  Terms no config of BASELINE.json uses (joint_2d, bone_direc, mscale, scale, iou, mtex)
+are torch ops on either path.
 """
 from __future__ import annotations
 
@@ -78,16 +81,38 @@ ssim = ssim_torch      # backwards-compatible name used by tests
 
 
 class LossFunction:
-    def __init__(self, perceptual=None, ssim_fn=None):
+    def __init__(self, perceptual=None, ssim_fn=None, fused=True):
         self.perceptual_loss = perceptual            # VGG19 weights are not available offline
         if ssim_fn is None:
             from . import ops
             ssim_fn = ops.ssim                       # fused HIP kernel (GPU only, no fallback)
         self.ssim_fn = ssim_fn
+        self.fused = fused
+
+    def _fused_geometry(self, examples, outputs, loss_used, args, loss_dic):
+        """joint_3d / vert_3d / edge_length / mshape / mpose in one kernel pair (csrc/losses.hip)."""
+        from . import ops
+        lam = [args.lambda_j3d if "joint_3d" in loss_used else 0.0, args.lambda_vert_3d if "vert_3d" in loss_used else 0.0,
+               args.lambda_edge_len if "edge_length" in loss_used else 0.0, args.lambda_shape if "mshape" in loss_used else 0.0,
+               args.lambda_pose if "mpose" in loss_used else 0.0]
+        faces = None
+        if "edge_length" in loss_used:
+            faces = outputs.get("_faces_i32")
+            if faces is None:
+                faces = outputs["mano_faces"][0].int().contiguous()
+        vals = ops.geom_losses(outputs["joints"], examples["joints"], outputs["mano_verts"], examples["verts"],
+                               outputs["shape_params"], outputs["pose_params"], faces, args.base_loss_fn != "L1", lam).unbind(0)
+        for k, v in zip(ops.GEOM_TERMS, vals):
+            if k in loss_used:
+                loss_dic[k] = v
 
     def __call__(self, examples, outputs, loss_used, dat_name, args) -> dict:
         loss_dic = {}
         base = F.l1_loss if args.base_loss_fn == "L1" else F.mse_loss
+        fused = self.fused and outputs["joints"].is_cuda
+        if fused and any(k in loss_used for k in ("joint_3d", "vert_3d", "edge_length", "mshape", "mpose")):
+            self._fused_geometry(examples, outputs, loss_used, args, loss_dic)
+            loss_used = [k for k in loss_used if k not in loss_dic]
         if "joint_2d" in loss_used:
             loss_dic["joint_2d"] = args.lambda_j2d_gt * base(examples["j2d_gt"], outputs["j2d"])
         if "joint_3d" in loss_used:
@@ -106,7 +131,18 @@ class LossFunction:
         if "scale" in loss_used and dat_name in ("FreiHand", "RHD"):
             bl = torch.sqrt(torch.sum((outputs["joints"][:, 9] - outputs["joints"][:, 10]) ** 2, 1))
             loss_dic["scale"] = args.lambda_scale * F.mse_loss(bl, examples["scales"].to(bl.device))
-        if "re_img" in outputs and "re_sil" in outputs:
+        if fused and outputs.get("_rgba") is not None and "re_sil" in outputs:
+            # photometric block (losses.py:355-378) + `sil` (:388-390) from the renderer's rgba in one kernel pair
+            from . import ops
+            out, re_img, mask_rgbs = ops.photo_losses(outputs["_rgba"], examples["imgs"], examples["segms_gt"], args.lambda_texture,
+                                                      args.lambda_mrgb, args.lambda_silhouette)
+            tex, mrgb, sil, _ = out.unbind(0)
+            loss_dic["texture"], loss_dic["mrgb"] = tex, mrgb
+            loss_dic["ssim_tex"] = args.lambda_ssim_tex * (1 - self.ssim_fn(re_img, mask_rgbs))
+            if "sil" in loss_used:
+                loss_dic["sil"] = sil
+                loss_used = [k for k in loss_used if k != "sil"]
+        elif "re_img" in outputs and "re_sil" in outputs:
             # photometric block, computed whenever a render exists (losses.py:355-378)
             seg = examples["segms_gt"].unsqueeze(1).to(outputs["re_img"].dtype)
             mask_rgbs = seg * examples["imgs"]

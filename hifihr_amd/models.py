@@ -95,11 +95,10 @@ class Model(nn.Module):
             verts_cam = mano_verts + root_xyz
             rgba, face_id = ops.render(self.renderer_p3d, verts_cam, self.vertex_colors, cam, colors, directions)
             outputs["re_img"] = rgba[:, :3]
-            re_sil = rgba[:, 3:4].detach()
-            re_sil = torch.where(re_sil > 0, torch.full_like(re_sil, 255.0), re_sil)   # :219
-            outputs["re_sil"] = re_sil
-            outputs["maskRGBs"] = images * (re_sil > 0).float()                          # :220
+            outputs["_rgba"] = rgba                                                      # for the fused photometric losses
+            outputs["re_sil"], outputs["maskRGBs"] = ops.sil_post(rgba, images)          # :219-220, one launch
             outputs["face_id"] = face_id
             outputs["skin_verts"] = verts_cam
-        outputs["mano_faces"] = self.mano_face.repeat(images.shape[0], 1, 1)
+        outputs["mano_faces"] = self.mano_face.expand(images.shape[0], -1, -1)           # a view (the reference repeats)
+        outputs["_faces_i32"] = self.hand_layer.mesh_face[0]
         return outputs

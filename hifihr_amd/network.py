@@ -134,7 +134,7 @@ class Resnet_4C(nn.Module):
         if isinstance(m.conv1, Conv2dMFMA):
             from . import ops
             h, st = m.conv1(x, want_stats=True)
-            x = m.maxpool(ops.bn_act(h, st, m.bn1, None, True))
+            x = ops.maxpool3x3s2(ops.bn_act(h, st, m.bn1, None, True))
         else:
             x = m.maxpool(m.relu(m.bn1(m.conv1(x))))
         x = m.layer1(x)
@@ -150,6 +150,9 @@ class MMPool(nn.Module):
         self.shape = shape
 
     def forward(self, x):
+        if x.is_cuda and tuple(self.shape) == (1, 1) and x.shape[1] % 4 == 0:
+            from . import ops
+            return ops.mmpool(x, self.p).reshape(x.shape[0], x.shape[1], 1, 1)       # one HIP kernel per direction
         x_max = F.adaptive_max_pool2d(x, self.shape)
         x_avg = F.adaptive_avg_pool2d(x, self.shape)
         w = torch.sigmoid(self.p)

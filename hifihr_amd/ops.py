@@ -171,10 +171,13 @@ class _Render(torch.autograd.Function):
         ctx.ws = ws
         ctx.save_for_backward(verts, cam, light_color, light_dir, face_id)
         ctx.mark_non_differentiable(face_id)
+        ctx.set_materialize_grads(False)
         return rgba, face_id
 
     @staticmethod
     def backward(ctx, grad_rgba, _):
+        if grad_rgba is None:
+            return (None,) * 6
         verts, cam, light_color, light_dir, face_id = ctx.saved_tensors
         handle = ctx.handle
         B = verts.shape[0]
@@ -204,6 +207,27 @@ def render(handle: RendererHandle, verts, vcolors, cam, light_color, light_dir):
 _CL = torch.channels_last
 
 
+class _ZeroPool:
+    """Zero-initialised scratch for the self-cleaning batch-norm slot buffers (include/hifihr.h, bn section): `acquire`
+    hands out an all-zero tensor; the consumer kernel zeroes it again and `release` returns it for the next producer.
+    A buffer that is never consumed (exception between producer and consumer) is simply dropped."""
+
+    def __init__(self):
+        self.free = {}
+
+    def acquire(self, n, device):
+        lst = self.free.get((n, device))
+        if lst:
+            return lst.pop()
+        return torch.zeros(n, device=device, dtype=torch.float32)
+
+    def release(self, t):
+        self.free.setdefault((t.numel(), t.device), []).append(t)
+
+
+_ZERO_POOL = _ZeroPool()
+
+
 def _grad_ready(p):
     """Tell the data-parallel reducer (hifihr_amd/dist.py) that this parameter's gradient has been enqueued by a kernel
     that wrote it directly (no autograd AccumulateGrad, hence no post-accumulate hook)."""
@@ -226,13 +250,14 @@ class _Conv2dMFMA(torch.autograd.Function):
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
         stats = None
         if want_stats:       # per-channel sum / sum of squares of y from the conv epilogue, for the batch-norm that follows
-            stats = torch.empty(lib.bn_stats_floats(K), device=x.device, dtype=torch.float32)
+            stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device)
             PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd_bnstats(x, wk, y, stats, N, H, W, C, K, R, S, stride, pad))
         else:
             PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, None, y, N, H, W, C, K, R, S, stride, pad))
         ctx.geom = (N, H, W, C, K, R, S, stride, pad)
         ctx.save_for_backward(x, wk)
         ctx.w_param = w
+        ctx.set_materialize_grads(False)         # no zero-fill launch for the (non-differentiable) stats output
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -243,6 +268,8 @@ class _Conv2dMFMA(torch.autograd.Function):
         x, wk = ctx.saved_tensors
         lib = get_lib()
         N, H, W, C, K, R, S, stride, pad = ctx.geom
+        if gy is None:
+            return None, None, None, None, None
         gy = gy.contiguous(memory_format=_CL)
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -283,6 +310,7 @@ class _BNAct(torch.autograd.Function):
         save_invstd = torch.empty(C, device=x.device)
         PROFILE.bracket("bn_fwd", lambda: lib.bn_act_fwd(x, stats, gamma, beta, res, act, M, C, eps, momentum, y, save_mean,
                                                          save_invstd, running_mean, running_var))
+        _ZERO_POOL.release(stats)                # consumed and zeroed by the kernel
         ctx.save_for_backward(x, y if act == 1 else x.new_empty(0), gamma, beta, save_mean, save_invstd)
         ctx.act, ctx.has_res, ctx.M, ctx.C = act, residual is not None, M, C
         ctx.gamma_param, ctx.beta_param = gamma, beta
@@ -296,7 +324,7 @@ class _BNAct(torch.autograd.Function):
         dy = dy.contiguous(memory_format=_CL)
         dx = torch.empty_like(x, memory_format=_CL)
         dres = torch.empty_like(x, memory_format=_CL) if ctx.has_res else None
-        red = torch.empty(lib.bn_stats_floats(ctx.C), device=x.device)
+        red = _ZERO_POOL.acquire(lib.bn_stats_floats(ctx.C), x.device)
 
         def acc_target(p):
             if getattr(p, "_hifihr_direct_grad", False) and p.grad is not None:
@@ -307,6 +335,7 @@ class _BNAct(torch.autograd.Function):
         db_t, db_ret = acc_target(ctx.beta_param)
         PROFILE.bracket("bn_bwd", lambda: lib.bn_act_bwd(dy, y, x, save_mean, save_invstd, gamma, beta, ctx.act, ctx.M, ctx.C, red,
                                                          dx, dres, dg_t, db_t))
+        _ZERO_POOL.release(red)
         if dg_ret is None:
             _grad_ready(ctx.gamma_param)
         if db_ret is None:
@@ -328,7 +357,7 @@ def bn_act(x, stats, bn: torch.nn.BatchNorm2d, residual=None, relu=True):
         lib = get_lib()
         xc = x.contiguous(memory_format=_CL)
         N, C, H, W = xc.shape
-        stats = torch.empty(lib.bn_stats_floats(C), device=x.device, dtype=torch.float32)
+        stats = _ZERO_POOL.acquire(lib.bn_stats_floats(C), x.device)
         PROFILE.bracket("bn_stats", lambda: lib.bn_stats(xc, N * H * W, C, stats))
         x = xc
     if not bn.training:
@@ -338,6 +367,198 @@ def bn_act(x, stats, bn: torch.nn.BatchNorm2d, residual=None, relu=True):
         return torch.relu(out) if act == 1 else (out * torch.sigmoid(out) if act == 2 else out)
     return _BNAct.apply(x, stats, bn.weight, bn.bias, residual, act, float(bn.eps), float(bn.momentum),
                         bn.running_mean, bn.running_var)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused losses (csrc/losses.hip)
+# ------------------------------------------------------------------------------------------------
+GEOM_TERMS = ("joint_3d", "vert_3d", "edge_length", "mshape", "mpose")
+_VF_CACHE = {}
+
+
+def _vertex_face_csr(faces, V):
+    """faces [F,3] int32 (device) -> (vf_off [V+1], vf_idx [3F]) int32 on the same device: for every vertex the incident
+    (face * 4 + corner) entries in ascending face order (same table as the renderer builds, hifihr_api.hip)."""
+    key = (faces.data_ptr(), int(faces.shape[0]), V, str(faces.device))
+    hit = _VF_CACHE.get(key)
+    if hit is None:
+        import numpy as np
+        f = faces.detach().cpu().numpy().astype(np.int64)
+        flat = f.reshape(-1)
+        order = np.argsort(flat, kind="stable")                      # stable: ascending face order within a vertex
+        off = np.zeros(V + 1, dtype=np.int32)
+        np.add.at(off, flat + 1, 1)
+        off = np.cumsum(off).astype(np.int32)
+        idx = ((order // 3) * 4 + (order % 3)).astype(np.int32)
+        hit = (torch.from_numpy(off).to(faces.device), torch.from_numpy(idx).to(faces.device))
+        _VF_CACHE[key] = hit
+    return hit
+
+
+class _GeomLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, joints, joints_gt, verts, verts_gt, shape, pose, faces, mse, lam):
+        require_cuda(joints, verts)
+        lib = get_lib()
+        joints, joints_gt, verts, verts_gt = (t.contiguous().float() for t in (joints, joints_gt, verts, verts_gt))
+        shape = shape.contiguous() if shape is not None else None
+        pose = pose.contiguous() if pose is not None else None
+        B = joints.shape[0]
+        partial = torch.empty(B * 5, device=joints.device)
+        out = torch.empty(5, device=joints.device)
+        PROFILE.bracket("geom_loss_fwd", lambda: lib.geom_loss_fwd(joints, joints_gt, verts, verts_gt, shape, pose, faces, mse, lam,
+                                                                  partial, out))
+        ctx.save_for_backward(joints, joints_gt, verts, verts_gt, shape, pose, faces)
+        ctx.mse, ctx.lam = mse, tuple(lam)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        joints, joints_gt, verts, verts_gt, shape, pose, faces = ctx.saved_tensors
+        lib = get_lib()
+        need = ctx.needs_input_grad
+        gj = torch.empty_like(joints) if need[0] else None
+        gv = torch.empty_like(verts) if need[2] else None
+        gs = torch.empty_like(shape) if (shape is not None and need[4]) else None
+        gp = torch.empty_like(pose) if (pose is not None and need[5]) else None
+        vf_off, vf_idx = _vertex_face_csr(faces, verts.shape[1]) if faces is not None else (None, None)
+        gout = gout.contiguous()
+        PROFILE.bracket("geom_loss_bwd", lambda: lib.geom_loss_bwd(joints, joints_gt, verts, verts_gt, shape, pose, faces, vf_off, vf_idx,
+                                                                  ctx.mse, ctx.lam, gout, gj, gv, gs, gp))
+        return gj, None, gv, None, gs, gp, None, None, None
+
+
+def geom_losses(joints, joints_gt, verts, verts_gt, shape, pose, faces, mse, lam):
+    """[5] = lambda-weighted (joint_3d, vert_3d, edge_length, mshape, mpose) of reference losses.py:259-266, 283-284,
+    398-406 in one launch (+ finisher); `faces` [F,3] int32 or None, `lam` the five lambdas (0 for unused terms)."""
+    return _GeomLoss.apply(joints, joints_gt, verts, verts_gt, shape, pose, faces, bool(mse), tuple(float(v) for v in lam))
+
+
+class _PhotoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgba, imgs, seg, l_tex, l_mrgb, l_sil):
+        require_cuda(rgba, imgs, seg)
+        lib = get_lib()
+        rgba, imgs, seg = rgba.contiguous(), imgs.contiguous(), seg.contiguous()
+        B, _, H, W = rgba.shape
+        re_img_m = torch.empty(B, 3, H, W, device=rgba.device)
+        mask_rgbs = torch.empty_like(re_img_m)
+        partial = torch.empty(lib.photo_loss_partial_floats(), device=rgba.device)
+        out = torch.empty(4, device=rgba.device)
+        PROFILE.bracket("photo_loss_fwd", lambda: lib.photo_loss_fwd(rgba, imgs, seg, l_tex, l_mrgb, l_sil, re_img_m, mask_rgbs, partial,
+                                                                    out))
+        ctx.save_for_backward(rgba, re_img_m, mask_rgbs, out)
+        ctx.lams = (l_tex, l_mrgb)
+        ctx.mark_non_differentiable(mask_rgbs)
+        ctx.set_materialize_grads(False)
+        return out, re_img_m, mask_rgbs
+
+    @staticmethod
+    def backward(ctx, gout, g_re_img, _gm):
+        if gout is None and g_re_img is None:
+            return (None,) * 6
+        rgba, re_img_m, mask_rgbs, out = ctx.saved_tensors
+        grad = torch.empty_like(rgba)
+        gout = gout.contiguous() if gout is not None else None
+        g_re_img = g_re_img.contiguous() if g_re_img is not None else None
+        PROFILE.bracket("photo_loss_bwd", lambda: get_lib().photo_loss_bwd(rgba, re_img_m, mask_rgbs, g_re_img, gout, out, ctx.lams[0],
+                                                                          ctx.lams[1], grad))
+        return grad, None, None, None, None, None
+
+
+def photo_losses(rgba, imgs, seg, l_tex, l_mrgb, l_sil):
+    """The photometric block of reference losses.py:355-378 (+ the `sil` term, :388-390) from the renderer's rgba:
+    returns (out[4] = lambda-weighted texture, mrgb, sil and mean(re_img) - mean(mask_rgbs); re_img (masked, feeds SSIM);
+    mask_rgbs)."""
+    return _PhotoLoss.apply(rgba, imgs, seg, float(l_tex), float(l_mrgb), float(l_sil))
+
+
+def sil_post(rgba, images):
+    """re_sil = where(alpha > 0, 255, alpha) [B,1,H,W] and maskRGBs = images * (re_sil > 0) (models_res_nimble.py:219-220);
+    no gradient (the reference detaches the silhouette)."""
+    require_cuda(rgba, images)
+    rgba = rgba.detach().contiguous()
+    B, _, H, W = rgba.shape
+    re_sil = torch.empty(B, 1, H, W, device=rgba.device)
+    mask_rgbs = torch.empty(B, 3, H, W, device=rgba.device)
+    get_lib().sil_post(rgba, images.contiguous(), re_sil, mask_rgbs)
+    return re_sil, mask_rgbs
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling (csrc/pool.hip)
+# ------------------------------------------------------------------------------------------------
+def _acc_target(p, shape, device):
+    """(tensor the kernel accumulates into, tensor to hand back to autograd or None): straight into the flat gradient
+    buffer when the parameter lives in one (hifihr_amd/optim.py FlatParams)."""
+    if getattr(p, "_hifihr_direct_grad", False) and p.grad is not None:
+        return p.grad, None
+    t = torch.zeros(shape, device=device)
+    return t, t
+
+
+class _MMPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        require_cuda(x, p)
+        lib = get_lib()
+        x = x.contiguous(memory_format=_CL)
+        B, C, H, W = x.shape
+        y = torch.empty(B, C, device=x.device)
+        argmax = torch.empty(B, C, dtype=torch.int32, device=x.device)
+        xmax, xavg = torch.empty_like(y), torch.empty_like(y)
+        PROFILE.bracket("mmpool_fwd", lambda: lib.mmpool_fwd(x, p, B, H * W, C, y, argmax, xmax, xavg))
+        ctx.save_for_backward(p, argmax, xmax, xavg)
+        ctx.shape, ctx.p_param = (B, C, H, W), p
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        p, argmax, xmax, xavg = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        dx = torch.empty((B, C, H, W), device=gy.device, memory_format=_CL) if ctx.needs_input_grad[0] else None
+        dp_t, dp_ret = _acc_target(ctx.p_param, p.shape, gy.device) if ctx.needs_input_grad[1] else (None, None)
+        if dx is None:
+            raise NotImplementedError("mmpool backward without an input gradient")
+        PROFILE.bracket("mmpool_bwd", lambda: get_lib().mmpool_bwd(gy, p, argmax, xmax, xavg, B, H * W, C, dx, dp_t))
+        if dp_t is not None and dp_ret is None:
+            _grad_ready(ctx.p_param)
+        return dx, dp_ret
+
+
+def mmpool(x, p):
+    """MMPool((1,1)) (reference network/res_encoder.py:247-265): [B,C,H,W] channels_last -> [B,C]."""
+    return _MMPool.apply(x, p)
+
+
+class _MaxPool3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x)
+        x = x.contiguous(memory_format=_CL)
+        N, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, C, OH, OW), device=x.device, memory_format=_CL)
+        tap = torch.empty(N * OH * OW * C, dtype=torch.uint8, device=x.device)
+        PROFILE.bracket("maxpool_fwd", lambda: get_lib().maxpool3x3s2_fwd(x, N, H, W, C, y, tap))
+        ctx.save_for_backward(tap)
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        tap, = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous(memory_format=_CL)
+        dx = torch.empty((N, C, H, W), device=gy.device, memory_format=_CL)
+        PROFILE.bracket("maxpool_bwd", lambda: get_lib().maxpool3x3s2_bwd(gy, tap, N, H, W, C, dx))
+        return dx
+
+
+def maxpool3x3s2(x):
+    """nn.MaxPool2d(3, 2, 1) on channels_last activations (the ResNet stem pool)."""
+    return _MaxPool3x3s2.apply(x)
 
 
 def image_to_nhwc4(images):

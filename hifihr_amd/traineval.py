@@ -49,11 +49,11 @@ def train_step(model, loss_func, optimizer, examples, args, dat_name="FreiHand",
     ex = dict(examples)
     ex["joints"] = examples["joints"] - root_xyz
     ex["verts"] = examples["verts"] - root_xyz
-    outputs["j2d"] = trans_proj_j2d(outputs, examples["Ks"], root_xyz=root_xyz)
+    if any(k in args.losses for k in ("joint_2d", "bone_direc")):
+        outputs["j2d"] = trans_proj_j2d(outputs, examples["Ks"], root_xyz=root_xyz)      # only these terms read it
     loss_dic = loss_func(ex, outputs, args.losses, dat_name, args)
-    loss = None
-    for k in args.losses:
-        loss = loss_dic[k] if loss is None else loss + loss_dic[k]
+    terms = [loss_dic[k] for k in args.losses]
+    loss = terms[0] if len(terms) == 1 else torch.stack(terms).sum()      # 2 launches instead of a chain of adds
     loss_dic["loss"] = loss
     optimizer.zero_grad(set_to_none=True)
     loss.backward()

@@ -150,7 +150,8 @@ int hifihr_conv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, flo
 int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, void* stream);
 /* conv2d_fwd that also accumulates the per-channel sum and sum of squares of y into stats_d (hifihr_bn_stats_floats(K)
- * floats, zeroed by the call) from the accumulator registers, so the batch-norm that follows needs no pass over y. */
+ * floats, ALL ZERO on entry: see the self-cleaning rule below) from the accumulator registers, so the batch-norm that
+ * follows needs no pass over y. */
 int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, float* stats_d, int N, int H, int W, int C, int K,
                               int R, int S, int stride, int pad, void* stream);
 
@@ -162,6 +163,9 @@ int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, fl
  * EfficientNet, network/efficientnet_pt/utils.py:36-52; no residual with swish).  stats_d / red_scratch_d hold hifihr_bn_stats_floats(C) floats: partial (sum, sum of
  * squares) over the M rows, spread over several slots to keep float-atomic contention low (from
  * hifihr_conv2d_fwd_bnstats, or hifihr_bn_stats for any other producer).
+ * SELF-CLEANING: producers (hifihr_conv2d_fwd_bnstats, hifihr_bn_stats, the reduction inside hifihr_bn_act_bwd) ADD into
+ * stats_d / red_scratch_d, which must be all zero on entry; hifihr_bn_act_fwd / hifihr_bn_act_bwd fold the slots and
+ * write the zeros back, so one zero-initialised buffer serves every step without a memset launch.
  *   fwd: y = act( (x - mean) * invstd * gamma + beta + residual? ); writes save_mean/save_invstd[C] and updates
  *        running_mean/var (momentum, unbiased variance) when given.
  *   bwd: g = dy * act'(z) (ReLU: y > 0, needs y_d; swish: z recomputed from x, needs beta_d); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (may be NULL) = g;
@@ -169,7 +173,7 @@ int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, fl
  * ---------------------------------------------------------------------------------------------- */
 int hifihr_bn_stats_floats(int C);
 int hifihr_bn_stats(const float* x_d, long M, int C, float* stats_d, void* stream);
-int hifihr_bn_act_fwd(const float* x_d, const float* stats_d, const float* gamma_d, const float* beta_d,
+int hifihr_bn_act_fwd(const float* x_d, float* stats_d /* consumed: zero on return */, const float* gamma_d, const float* beta_d,
                       const float* residual_d /* or NULL */, int act, long M, int C, float eps, float momentum, float* y_d,
                       float* save_mean_d, float* save_invstd_d, float* running_mean_d, float* running_var_d, void* stream);
 int hifihr_bn_act_bwd(const float* dy_d, const float* y_d /* act 1 */, const float* x_d, const float* save_mean_d,
@@ -190,6 +194,23 @@ int hifihr_dwconv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, i
 int hifihr_dwconv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int OH, int OW,
                                int K, int stride, int pad_top, int pad_left, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pooling on NHWC fp32 activations (C % 4 == 0).
+ * mmpool: MMPool((1,1)) of the reference encoder (network/res_encoder.py:247-265, called at :49):
+ *   y[B][C] = max_hw(x) * w + mean_hw(x) * (1 - w), w = sigmoid(p_d[0]); x[B][HW][C].  fwd also writes argmax[B][C] (first
+ *   maximum in scan order, like adaptive_max_pool2d), xmax[B][C], xavg[B][C] for the backward.
+ *   bwd: dx[B][HW][C] (overwritten) and dp_acc_d[0] += d loss / d p (may be NULL).
+ * maxpool3x3s2: nn.MaxPool2d(3, 2, 1) after the ResNet stem (network/res_encoder.py:345-373, torchvision resnet18.maxpool):
+ *   y[N][OH][OW][C], OH = (H-1)/2 + 1; tap_d[N][OH][OW][C] bytes = winning tap 0..8 (first maximum in scan order).
+ *   bwd gathers: dx[N][H][W][C] is overwritten (no zero fill needed).
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_mmpool_fwd(const float* x_d, const float* p_d, int B, int HW, int C, float* y_d, int* argmax_d, float* xmax_d,
+                      float* xavg_d, void* stream);
+int hifihr_mmpool_bwd(const float* gy_d, const float* p_d, const int* argmax_d, const float* xmax_d, const float* xavg_d, int B,
+                      int HW, int C, float* dx_d, float* dp_acc_d, void* stream);
+int hifihr_maxpool3x3s2_fwd(const float* x_d, int N, int H, int W, int C, float* y_d, unsigned char* tap_d, void* stream);
+int hifihr_maxpool3x3s2_bwd(const float* gy_d, const unsigned char* tap_d, int N, int H, int W, int C, float* dx_d, void* stream);
+
 /* normalize_batch_3C (reference network/res_encoder.py:212-216) fused with NCHW[B][3][H][W] -> NHWC4 [B][H][W][4]
  * (4th channel zero) for the first convolution. */
 int hifihr_image_to_nhwc4(const float* images_d, float* out_d, int B, int H, int W, void* stream);
@@ -209,6 +230,43 @@ int hifihr_ssim_fwd(const float* window11_h, const float* img1_d, const float* i
                     float* partial_d, float* dA_d, float* dB_d, float* dC_d, void* stream);
 int hifihr_ssim_bwd(const float* window11_h, const float* img1_d, const float* img2_d, const float* dA_d, const float* dB_d,
                     const float* dC_d, const float* grad_out_d, int planes, int H, int W, float* gimg1_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused training losses.  Replaces the torch-op evaluation of reference losses.py:226-453 (LossFunction.forward) and its
+ * autograd for the terms below; every value comes back already multiplied by its lambda, as loss_dic holds it.
+ *
+ * geom_loss: out_d[5] = (joint_3d, vert_3d, edge_length, mshape, mpose)
+ *   joint_3d / vert_3d = lambda * F.l1_loss or F.mse_loss (mse = 0 / 1: args.base_loss_fn, losses.py:259-266),
+ *   edge_length = lambda * mean |edge(pred) - edge(gt)| over the 3 edges of every face (utils/losses_util.py:285-301),
+ *   mshape / mpose = lambda * F.mse_loss(params, 0) (losses.py:398-406).
+ *   joints[B][J][3], verts[B][V][3], shape[B][NS], pose[B][NP], faces_d[F][3] (F = 0 / NULL: no edge term);
+ *   lambda5_h: HOST.  partial_d: B*5 floats of scratch.  bwd: gout_d[5] = gradient of each out element (DEVICE);
+ *   vf_off_d[V+1] / vf_idx_d[3F] = vertex -> (face * 4 + corner) incidence lists in ascending face order (the edge
+ *   gradient is gathered per vertex: deterministic, no atomics); any of gj/gv/gshape/gpose may be NULL.
+ * photo_loss (the photometric block, losses.py:355-378, plus the `sil` term :388-390), from the renderer's rgba[B][4][H][W]:
+ *   re_img_m = rgb * re_sil / 255 with re_sil = (alpha > 0 ? 255 : alpha); mask_rgbs = seg * imgs  (both written:
+ *   the SSIM term consumes them); out_d[4] = (texture, mrgb, sil, mean(re_img_m) - mean(mask_rgbs)).
+ *   seg_d: int64 [B][H][W] (segms_gt).  H*W % 4 == 0.  partial_d: hifihr_photo_loss_partial_floats() floats.
+ *   bwd: grad_rgba[B][4][H][W] (overwritten; alpha channel 0: re_sil is detached in the reference) from gout_d[>=2]
+ *   (texture, mrgb; may be NULL) and g_re_img_d (gradient arriving at re_img_m, e.g. from SSIM; may be NULL).
+ * sil_post (models_res_nimble.py:219-220): re_sil[B][H][W] and maskRGBs[B][3][H][W] = images * (re_sil > 0) (may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_geom_loss_fwd(const float* joints_d, const float* joints_gt_d, const float* verts_d, const float* verts_gt_d,
+                         const float* shape_d, const float* pose_d, const int32_t* faces_d, int B, int J, int V, int F, int NS,
+                         int NP, int mse, const float* lambda5_h, float* partial_d, float* out_d, void* stream);
+int hifihr_geom_loss_bwd(const float* joints_d, const float* joints_gt_d, const float* verts_d, const float* verts_gt_d,
+                         const float* shape_d, const float* pose_d, const int32_t* faces_d, const int32_t* vf_off_d,
+                         const int32_t* vf_idx_d, int B, int J, int V, int F, int NS, int NP, int mse, const float* lambda5_h,
+                         const float* gout_d, float* gj_d, float* gv_d, float* gshape_d, float* gpose_d, void* stream);
+int hifihr_photo_loss_partial_floats(void);
+int hifihr_photo_loss_fwd(const float* rgba_d, const float* imgs_d, const int64_t* seg_d, int B, int H, int W, float l_tex,
+                          float l_mrgb, float l_sil, float* re_img_m_d, float* mask_rgbs_d, float* partial_d, float* out_d,
+                          void* stream);
+int hifihr_photo_loss_bwd(const float* rgba_d, const float* re_img_m_d, const float* mask_rgbs_d, const float* g_re_img_d,
+                          const float* gout_d, const float* fwd_out_d, int B, int H, int W, float l_tex, float l_mrgb,
+                          float* grad_rgba_d, void* stream);
+int hifihr_sil_post(const float* rgba_d, const float* imgs_d, int B, int H, int W, float* re_sil_d, float* mask_rgbs_d,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,9 @@ struct float3 { float x, y, z; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(4) uchar4 { unsigned char x, y, z, w; };
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { return uchar4{x, y, z, w}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }

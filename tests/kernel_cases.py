@@ -274,20 +274,22 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
     out.backward(gy)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(device)
     dx_in = nhwc(x)
-    stats = torch.empty(lib.bn_stats_floats(C), device=device)
+    stats = torch.zeros(lib.bn_stats_floats(C), device=device)      # zero on entry (self-cleaning contract)
     lib.bn_stats(dx_in, M, C, stats)
     np.testing.assert_allclose(stats.view(-1, 2, C)[:-1].sum(0)[0].cpu().numpy(), x.permute(1, 0, 2, 3).reshape(C, -1).sum(1).numpy(),
                                rtol=1e-4, atol=1e-3)
     y = torch.empty(N, H, W, C, device=device); sm = torch.empty(C, device=device); si = torch.empty(C, device=device)
     rmd, rvd = rm0.clone().to(device), rv0.clone().to(device)
     lib.bn_act_fwd(dx_in, stats, gamma.to(device), beta.to(device), nhwc(res) if residual else None, act, M, C, 1e-5, 0.1, y, sm, si, rmd, rvd)
+    assert float(stats.view(-1, 2, C)[:-1].abs().max()) == 0.0, "bn_act_fwd must leave the slot buffer zeroed"
     ref = out.detach().permute(0, 2, 3, 1)
     assert float((y.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), "bn fwd"
     np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
-    red = torch.empty(lib.bn_stats_floats(C), device=device); dxo = torch.empty_like(y); dres = torch.empty_like(y) if residual else None
+    red = torch.zeros(lib.bn_stats_floats(C), device=device); dxo = torch.empty_like(y); dres = torch.empty_like(y) if residual else None
     dg = torch.full((C,), 0.5, device=device); db = torch.full((C,), -0.25, device=device)     # accumulate semantics
     lib.bn_act_bwd(nhwc(gy), y if act == 1 else None, dx_in, sm, si, gamma.to(device), beta.to(device), act, M, C, red, dxo, dres, dg, db)
+    assert float(red.view(-1, 2, C)[:-1].abs().max()) == 0.0, "bn_act_bwd must leave the slot buffer zeroed"
     refdx = xr.grad.permute(0, 2, 3, 1)
     assert float((dxo.cpu() - refdx).abs().max()) <= 2e-4 * float(refdx.abs().max()) + 1e-7, "bn bwd dx"
     assert float((dg.cpu() - 0.5 - gr.grad).abs().max()) <= 2e-4 * float(gr.grad.abs().max()) + 1e-5, "bn dgamma"
@@ -303,7 +305,7 @@ def conv_bnstats_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0):
     y = F.conv2d(x, w, None, stride, pad)
     OH, OW = y.shape[2], y.shape[3]
     d = lambda t: t.to(device).contiguous()
-    out = torch.empty(N, OH, OW, K, device=device); stats = torch.full((lib.bn_stats_floats(K),), 7.0, device=device)
+    out = torch.empty(N, OH, OW, K, device=device); stats = torch.zeros(lib.bn_stats_floats(K), device=device)
     lib.conv2d_fwd_bnstats(d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), out, stats, N, H, W, C, K, R, R, stride, pad)
     ref = y.permute(0, 2, 3, 1)
     assert float((out.cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6
@@ -341,3 +343,134 @@ def dwconv_case(lib, device, N, H, W, C, K, stride, seed=0):
     lib.dwconv2d_bwd_weight(xd, gyd, dw, N, H, W, C, OH, OW, K, stride, pt, pl)
     refw = wr.grad.reshape(C, K, K)
     assert float((dw.cpu() - refw).abs().max()) <= 1e-4 * float(refw.abs().max()) + 1e-6, "dw bwd weight"
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling (csrc/pool.hip) vs plain PyTorch fp32
+# ------------------------------------------------------------------------------------------------
+def mmpool_case(lib, device, B, H, W, C, p0=0.3, seed=0, ties=False):
+    """MMPool((1,1)): adaptive max + adaptive avg mixed by sigmoid(p) (reference network/res_encoder.py:247-265)."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=gen)
+    if ties:
+        x = torch.relu(x - 1.5)                    # mostly zeros with repeated maxima: first-index tie rule
+    xr = x.clone().requires_grad_(True); pr = torch.tensor([p0], requires_grad=True)
+    w = torch.sigmoid(pr)
+    y = (F.adaptive_max_pool2d(xr, (1, 1)) * w + F.adaptive_avg_pool2d(xr, (1, 1)) * (1 - w)).reshape(B, C)
+    gy = torch.randn(B, C, generator=gen)
+    y.backward(gy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device); pd = torch.tensor([p0], device=device)
+    out = torch.empty(B, C, device=device); am = torch.empty(B, C, dtype=torch.int32, device=device)
+    xmax, xavg = torch.empty_like(out), torch.empty_like(out)
+    lib.mmpool_fwd(xd, pd, B, H * W, C, out, am, xmax, xavg)
+    assert float((out.cpu() - y.detach()).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max())), "mmpool fwd"
+    _, ref_idx = F.adaptive_max_pool2d(x, (1, 1), return_indices=True)
+    assert torch.equal(am.cpu().long(), ref_idx.reshape(B, C)), "mmpool argmax (first maximum in scan order)"
+    dx = torch.empty(B, H, W, C, device=device); dp = torch.full((1,), 0.25, device=device)
+    lib.mmpool_bwd(gy.to(device), pd, am, xmax, xavg, B, H * W, C, dx, dp)
+    refdx = xr.grad.permute(0, 2, 3, 1)
+    assert float((dx.cpu() - refdx).abs().max()) <= 1e-6 + 1e-5 * float(refdx.abs().max()), "mmpool dx"
+    assert abs(float(dp.cpu()) - 0.25 - float(pr.grad)) <= 1e-4 * max(1.0, abs(float(pr.grad))), "mmpool dp (accumulates)"
+
+
+def maxpool_case(lib, device, N, H, W, C, seed=0, ties=False):
+    """nn.MaxPool2d(3, 2, 1) forward / backward on NHWC."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=gen)
+    if ties:
+        x = torch.relu(x)                          # post-ReLU activations: many exact zeros tie inside a window
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 3, 2, 1)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    OH, OW = y.shape[2], y.shape[3]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    out = torch.empty(N, OH, OW, C, device=device); tap = torch.empty(N * OH * OW * C, dtype=torch.uint8, device=device)
+    lib.maxpool3x3s2_fwd(xd, N, H, W, C, out, tap)
+    assert torch.equal(out.cpu(), y.detach().permute(0, 2, 3, 1)), "maxpool fwd (exact)"
+    dx = torch.full((N, H, W, C), 7.0, device=device)          # overwritten, not accumulated
+    lib.maxpool3x3s2_bwd(gy.permute(0, 2, 3, 1).contiguous().to(device), tap, N, H, W, C, dx)
+    refdx = xr.grad.permute(0, 2, 3, 1)
+    assert float((dx.cpu() - refdx).abs().max()) <= 1e-6, "maxpool bwd"
+
+
+# ------------------------------------------------------------------------------------------------
+# fused losses (csrc/losses.hip) vs the torch-op restatement in hifihr_amd/losses.py (pinned against the reference's
+# LossFunction by tests/golden/losses.npz in test_host_logic.py)
+# ------------------------------------------------------------------------------------------------
+def vertex_face_csr(faces, V):
+    f = np.asarray(faces, dtype=np.int64).reshape(-1)
+    order = np.argsort(f, kind="stable")
+    off = np.zeros(V + 1, dtype=np.int32)
+    np.add.at(off, f + 1, 1)
+    return np.cumsum(off).astype(np.int32), ((order // 3) * 4 + (order % 3)).astype(np.int32)
+
+
+def geom_loss_case(lib, device, B, V, F, mse, seed=0, J=21, NS=10, NP=48):
+    import torch.nn.functional as Fn
+    from hifihr_amd.losses import edge_length_loss
+    gen = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=gen)
+    joints, jgt, verts, vgt = rnd(B, J, 3) * 0.05, rnd(B, J, 3) * 0.05, rnd(B, V, 3) * 0.05, rnd(B, V, 3) * 0.05
+    shape, pose = rnd(B, NS), rnd(B, NP)
+    faces = torch.stack([torch.randperm(V, generator=gen)[:3] for _ in range(F)]).int() if F else None
+    lam = [1e4, 1e4, 1e2, 0.25, 0.5]
+    base = Fn.mse_loss if mse else Fn.l1_loss
+    jr, vr, sr, pr = (t.clone().requires_grad_(True) for t in (joints, verts, shape, pose))
+    ref = [lam[0] * base(jr, jgt), lam[1] * base(vr, vgt),
+           lam[2] * edge_length_loss(vr, vgt, faces.unsqueeze(0)) if F else torch.zeros(()),
+           lam[3] * Fn.mse_loss(sr, torch.zeros_like(sr)), lam[4] * Fn.mse_loss(pr, torch.zeros_like(pr))]
+    gout = torch.tensor([0.7, 1.3, 0.9, 1.1, 0.6])
+    sum(g * r for g, r in zip(gout, ref)).backward()
+    d = lambda t: t.to(device).contiguous() if t is not None else None
+    partial = torch.empty(B * 5, device=device); out = torch.empty(5, device=device)
+    args = (d(joints), d(jgt), d(verts), d(vgt), d(shape), d(pose), d(faces))
+    lib.geom_loss_fwd(*args, mse, lam, partial, out)
+    refv = torch.stack([r.detach() for r in ref])
+    np.testing.assert_allclose(out.cpu().numpy(), refv.numpy(), rtol=2e-5, atol=1e-7)
+    off, idx = vertex_face_csr(faces.numpy(), V) if F else (None, None)
+    gj, gv, gs, gp = (torch.full(t.shape, 7.0, device=device) for t in (joints, verts, shape, pose))
+    lib.geom_loss_bwd(*args, d(torch.from_numpy(off)) if F else None, d(torch.from_numpy(idx)) if F else None, mse, lam, d(gout), gj, gv, gs, gp)
+    for got, want, name in ((gj, jr.grad, "joints"), (gv, vr.grad, "verts"), (gs, sr.grad, "shape"), (gp, pr.grad, "pose")):
+        assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-9, f"geom loss grad {name}"
+
+
+def photo_loss_case(lib, device, B, H, W, seed=0, with_g=True):
+    import torch.nn.functional as Fn
+    gen = torch.Generator().manual_seed(seed)
+    rgba = torch.rand(B, 4, H, W, generator=gen)
+    rgba[:, 3] = torch.where(torch.rand(B, H, W, generator=gen) > 0.5, rgba[:, 3], torch.zeros(B, H, W))     # holes: alpha == 0
+    imgs = torch.rand(B, 3, H, W, generator=gen)
+    seg = (torch.rand(B, H, W, generator=gen) > 0.4).long()
+    l_tex, l_mrgb, l_sil = 0.005, 0.005, 0.1
+    rr = rgba.clone().requires_grad_(True)
+    re_sil = rr[:, 3:4].detach()
+    re_sil = torch.where(re_sil > 0, torch.full_like(re_sil, 255.0), re_sil)
+    segf = seg.unsqueeze(1).float()
+    mask_rgbs = segf * imgs
+    re_img = rr[:, :3] * (re_sil / 255.0)
+    tex = l_tex * Fn.l1_loss(re_img, mask_rgbs)
+    mrgb = l_mrgb * Fn.mse_loss(torch.mean(mask_rgbs), torch.mean(re_img))
+    sil = l_sil * Fn.l1_loss(re_sil, segf)
+    g_re = torch.randn(B, 3, H, W, generator=gen) * 1e-6 if with_g else None
+    gout = torch.tensor([0.8, 1.7, 0.0, 0.0])
+    tot = gout[0] * tex + gout[1] * mrgb
+    if with_g:
+        tot = tot + (re_img * g_re).sum()
+    tot.backward()
+    d = lambda t: t.to(device).contiguous() if t is not None else None
+    rd, idd, sd = d(rgba), d(imgs), d(seg)
+    re_m = torch.empty(B, 3, H, W, device=device); mk = torch.empty_like(re_m)
+    partial = torch.empty(lib.photo_loss_partial_floats(), device=device); out = torch.empty(4, device=device)
+    lib.photo_loss_fwd(rd, idd, sd, l_tex, l_mrgb, l_sil, re_m, mk, partial, out)
+    assert float((re_m.cpu() - re_img.detach()).abs().max()) <= 1e-6 and torch.equal(mk.cpu(), mask_rgbs)
+    want = torch.stack([tex.detach(), mrgb.detach(), sil, (re_img.mean() - mask_rgbs.mean()).detach()])
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=3e-5, atol=1e-9)
+    grad = torch.full((B, 4, H, W), 7.0, device=device)
+    lib.photo_loss_bwd(rd, re_m, mk, d(g_re), d(gout), out, l_tex, l_mrgb, grad)
+    assert float((grad.cpu() - rr.grad).abs().max()) <= 2e-5 * float(rr.grad.abs().max()) + 1e-12, "photo loss grad"
+    rs = torch.empty(B, 1, H, W, device=device); mrgbs = torch.empty(B, 3, H, W, device=device)
+    lib.sil_post(rd, idd, rs, mrgbs)
+    assert torch.equal(rs.cpu(), re_sil) and torch.equal(mrgbs.cpu(), imgs * (re_sil > 0).float())

@@ -1,0 +1,35 @@
+"""GPU parity of the pooling and fused-loss kernels (csrc/pool.hip, csrc/losses.hip) at the sizes of BASELINE configs[1]
+against plain PyTorch fp32 (CPU) -- through the C ABI."""
+import pytest
+import torch
+
+import kernel_cases as kc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hifihr_amd._lib import get_lib
+    assert torch.cuda.is_available()
+    return get_lib()
+
+
+@pytest.mark.parametrize("B,H,C,ties", [(32, 14, 512, True), (4, 7, 1536, False)])
+def test_mmpool(lib, B, H, C, ties):
+    kc.mmpool_case(lib, "cuda", B, H, H, C, seed=C, ties=ties)
+
+
+@pytest.mark.parametrize("N,H,C,ties", [(8, 112, 64, True), (2, 57, 64, False)])
+def test_maxpool3x3s2(lib, N, H, C, ties):
+    kc.maxpool_case(lib, "cuda", N, H, H, C, seed=H, ties=ties)
+
+
+@pytest.mark.parametrize("B,mse", [(32, False), (6, True)])
+def test_geom_losses(lib, B, mse):
+    kc.geom_loss_case(lib, "cuda", B, 778, 1538, mse, seed=B)
+
+
+@pytest.mark.parametrize("B,with_g", [(8, True), (3, False)])
+def test_photo_losses(lib, B, with_g):
+    kc.photo_loss_case(lib, "cuda", B, 224, 224, seed=B, with_g=with_g)

@@ -8,8 +8,8 @@ lib = get_lib()
 for (N, H, C) in [(32, 112, 64), (32, 56, 64), (32, 28, 128), (32, 14, 256), (32, 14, 512)]:
     M = N * H * H
     x = torch.randn(M, C, device="cuda"); y = torch.empty_like(x); res = torch.randn_like(x); dy = torch.randn_like(x); dx = torch.empty_like(x); dres = torch.empty_like(x)
-    stats = torch.empty(lib.bn_stats_floats(C), device="cuda"); g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
-    sm = torch.empty(C, device="cuda"); si = torch.empty(C, device="cuda"); rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda"); red = torch.empty(lib.bn_stats_floats(C), device="cuda")
+    stats = torch.zeros(lib.bn_stats_floats(C), device="cuda"); g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
+    sm = torch.empty(C, device="cuda"); si = torch.empty(C, device="cuda"); rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda"); red = torch.zeros(lib.bn_stats_floats(C), device="cuda")
     dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
     ts = timeit(lambda: lib.bn_stats(x, M, C, stats))
     tf = timeit(lambda: lib.bn_act_fwd(x, stats, g, b, res, True, M, C, 1e-5, 0.1, y, sm, si, rm, rv))
