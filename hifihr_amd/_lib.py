@@ -102,6 +102,8 @@ class HifihrLib:
             [_c_float_p] * 4 + [c_void_p]
         c.hifihr_photo_loss_bwd.argtypes = [_c_float_p] * 6 + [c_int, c_int, c_int, c_float, c_float, _c_float_p, c_void_p]
         c.hifihr_sil_post.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_linear_fwd.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [_c_float_p] * 2 + [c_float, c_float] + [_c_float_p] * 6 + [c_void_p]
+        c.hifihr_linear_bwd.argtypes = [_c_float_p] * 4 + [c_int] * 4 + [_c_float_p] * 10 + [c_void_p]
         c.hifihr_mmpool_fwd.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mmpool_bwd.argtypes = [_c_float_p, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p,
                                         _c_float_p, c_void_p]
@@ -236,6 +238,23 @@ class HifihrLib:
         B, _, H, W = rgba.shape
         assert rgba.is_contiguous() and (imgs is None or imgs.is_contiguous())
         self.check(self.c.hifihr_sil_post(_fp(rgba), _fp(imgs), B, H, W, _fp(re_sil), _fp(mask_rgbs), _stream_of(rgba)), "hifihr_sil_post")
+
+    def linear_fwd(self, x, w, b, act, y, bn=None):
+        """bn: None or (gamma, beta, eps, momentum, running_mean, running_var, z, save_mean, save_invstd)."""
+        B, I = x.shape
+        O = w.shape[0]
+        gamma, beta, eps, mom, rm, rv, z, sm, si = bn if bn is not None else (None, None, 0.0, 0.0, None, None, None, None, None)
+        self.check(self.c.hifihr_linear_fwd(_fp(x), _fp(w), _fp(b), B, I, O, int(act), _fp(gamma), _fp(beta), float(eps), float(mom),
+                                            _fp(rm), _fp(rv), _fp(y), _fp(z), _fp(sm), _fp(si), _stream_of(x)), "hifihr_linear_fwd")
+
+    def linear_bwd(self, dy, y, x, w, act, dz, dW_acc, db_acc, dx, bn=None):
+        """bn: None or (gamma, z, save_mean, save_invstd, dgamma_acc, dbeta_acc)."""
+        B, I = x.shape
+        O = w.shape[0]
+        gamma, z, sm, si, dg, dbt = bn if bn is not None else (None,) * 6
+        self.check(self.c.hifihr_linear_bwd(_fp(dy), _fp(y), _fp(x), _fp(w), B, I, O, int(act), _fp(gamma), _fp(z), _fp(sm), _fp(si),
+                                            _fp(dz), _fp(dW_acc), _fp(db_acc), _fp(dg), _fp(dbt), _fp(dx), _stream_of(x)),
+                   "hifihr_linear_bwd")
 
     def mmpool_fwd(self, x, p, B, HW, C, y, argmax, xmax, xavg):
         self.check(self.c.hifihr_mmpool_fwd(_fp(x), _fp(p), B, HW, C, _fp(y), _ip(argmax), _fp(xmax), _fp(xavg), _stream_of(x)),

@@ -478,4 +478,30 @@ int hifihr_sil_post(const float* rgba, const float* imgs, int B, int H, int W, f
   return HIFIHR_OK;
 }
 
+int hifihr_linear_fwd(const float* x, const float* w, const float* b, int B, int I, int O, int act, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var, float* y, float* z, float* save_mean,
+                      float* save_invstd, void* stream) {
+  if (!x || !w || !y || B <= 0 || I <= 0 || O <= 0 || I % 4 != 0 || act < 0 || act > 1)
+    return fail(HIFIHR_EINVAL, "hifihr_linear_fwd: bad argument (I % 4 == 0, act 0/1)");
+  if (gamma && (!beta || !z || !save_mean || !save_invstd || B > 64 || ((running_mean != nullptr) != (running_var != nullptr))))
+    return fail(HIFIHR_EINVAL, "hifihr_linear_fwd: batch-norm needs beta, z, save_mean, save_invstd and B <= 64");
+  hifihr::LinearArgs a{x, w, b, y, z, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps, momentum, B, I, O, act};
+  HIP_TRY(hifihr::launch_linear_fwd(a, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_linear_bwd(const float* dy, const float* y, const float* x, const float* w, int B, int I, int O, int act, const float* gamma,
+                      const float* z, const float* save_mean, const float* save_invstd, float* dz_scratch, float* dW_acc, float* db_acc,
+                      float* dgamma_acc, float* dbeta_acc, float* dx, void* stream) {
+  if (!dy || !x || !w || B <= 0 || I <= 0 || O <= 0 || I % 4 != 0 || act < 0 || act > 1 || (act == 1 && !y) || (dx && !dz_scratch))
+    return fail(HIFIHR_EINVAL, "hifihr_linear_bwd: bad argument (I % 4 == 0; act 1 needs y; dx needs dz_scratch)");
+  if (gamma && (!z || !save_mean || !save_invstd || B > 64))
+    return fail(HIFIHR_EINVAL, "hifihr_linear_bwd: batch-norm needs z, save_mean, save_invstd and B <= 64");
+  hifihr::LinearArgs a{x, w, nullptr, const_cast<float*>(y), const_cast<float*>(z), gamma, nullptr, const_cast<float*>(save_mean),
+                       const_cast<float*>(save_invstd), nullptr, nullptr, 0.f, 0.f, B, I, O, act};
+  hifihr::LinearGrads g{dy, dz_scratch, dW_acc, db_acc, dgamma_acc, dbeta_acc, dx};
+  HIP_TRY(hifihr::launch_linear_bwd(a, g, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 }  // extern "C"

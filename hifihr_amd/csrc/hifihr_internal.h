@@ -113,6 +113,22 @@ hipError_t launch_photo_loss_bwd(const float* rgba, const float* re_img_m, const
                                  hipStream_t st);
 hipError_t launch_sil_post(const float* rgba, const float* imgs, int B, int HW, float* re_sil, float* mask_rgbs, hipStream_t st);
 
+// small-batch fully connected layer (mlp.hip): y[B][O] = act(BN1d?(x[B][I] W[O][I]^T + b)); gamma == nullptr: no batch-norm
+struct LinearArgs {
+  const float *x, *W, *b;
+  float *y, *z;                         // z[B][O]: pre-batch-norm output (batch-norm layers only)
+  const float *gamma, *beta;
+  float *save_mean, *save_invstd, *running_mean, *running_var;
+  float eps, momentum;
+  int B, I, O, act;                     // act 0 none, 1 ReLU
+};
+struct LinearGrads {
+  const float* dy;
+  float *dz, *dW_acc, *db_acc, *dgamma_acc, *dbeta_acc, *dx;    // *_acc accumulate (+=); dz scratch [B][O]; dx overwritten
+};
+hipError_t launch_linear_fwd(const LinearArgs& a, hipStream_t st);
+hipError_t launch_linear_bwd(const LinearArgs& a, const LinearGrads& g, hipStream_t st);
+
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st);
 

@@ -1,0 +1,349 @@
+// Small-batch fully connected layers of the regression heads: y = act(BN1d?(x W^T + b)), fp32.
+// Replaces nn.Linear (+ nn.BatchNorm1d in training mode) (+ nn.ReLU) and their autograd in the reference's HandEncoder /
+// LightEstimator heads (reference network/res_encoder.py:52-145 base_layers, *_reg, :150-210 light_reg).  At B = 32 these
+// layers are <= 34 MFLOP each: rocBLAS + ATen spent 8-9 launches of ~5 us per layer per direction on them (GEMM, bias,
+// clamp, four batch-norm kernels, two AccumulateGrad adds); here a layer is ONE launch forward and TWO backward:
+//   linear_fwd_kernel     workgroup = 16 output features x all rows; x / W staged through LDS in chunks of up to 512 input
+//                         features with every global load of a chunk in flight at once (the layers are latency-bound:
+//                         round 1's first version exposed one HBM latency per 64-feature chunk and ran 15-30 us); bias,
+//                         train-mode BatchNorm1d (batch statistics are local: the workgroup owns its features for every
+//                         row) and ReLU in the epilogue.
+//   linear_bwd_w_kernel   same ownership: activation mask + BatchNorm backward per feature, db / dgamma / dbeta, then
+//                         dW[16][I] += dz^T x (dz held in registers, x in LDS) accumulated STRAIGHT into the (flat)
+//                         gradient buffer; also zero-fills dx.
+//   linear_bwd_x_kernel   dx = dz W, split over the output features (grid.y) with fp32 atomics into the zeroed dx; W is
+//                         fetched in batches of 16 independent loads.
+// The FLOP count is irrelevant here (fp32 MFMA would buy 2x on microseconds of math); launch count, loads in flight and
+// >= 64 workgroups per launch are what these kernels are shaped for.
+#include <hip/hip_runtime.h>
+
+#include "hifihr_internal.h"
+
+namespace hifihr {
+
+constexpr int kFT = 16;       // output features per workgroup
+
+template <int RB>
+struct MlpCfg {
+  static constexpr int IC = (RB == 32) ? 512 : 256;   // input features per LDS chunk
+  static constexpr int LD = IC + 4;                   // LDS row stride: float4 reads of 16 different rows hit 64 banks
+  static constexpr int XL = RB * IC / 1024;           // float4 loads of x per thread per chunk
+  static constexpr int WL = kFT * IC / 1024;          // float4 loads of W per thread per chunk
+  static constexpr size_t lds_bytes = (size_t)(RB + kFT) * LD * sizeof(float);
+};
+
+template <int RB>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
+  using C = MlpCfg<RB>;
+  constexpr int KR = RB / 16;                     // rows per thread
+  HIP_DYNAMIC_SHARED(float, smem);
+  float* xs = smem;                               // [RB][LD]
+  float* ws = smem + RB * C::LD;                  // [kFT][LD]
+  __shared__ float zs[RB][kFT + 1];
+  __shared__ float sc[kFT], sh[kFT];
+  const int tid = threadIdx.x, ol = tid & 15, rg = tid >> 4;
+  const int o0 = blockIdx.x * kFT, row0 = blockIdx.y * RB;
+  const int nrow = min(RB, a.B - row0);
+  float acc[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) acc[k] = 0.f;
+  constexpr int CPR = C::IC / 4;                  // float4 per LDS row
+  for (int i0 = 0; i0 < a.I; i0 += C::IC) {
+    const int ilen = min(C::IC, a.I - i0);
+    float4 xr[C::XL], wr[C::WL];
+#pragma unroll
+    for (int p = 0; p < C::XL; ++p) {             // all loads of the chunk first ...
+      const int e = tid + 256 * p, r = e / CPR, c4 = (e % CPR) * 4;
+      xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nrow && c4 < ilen) xr[p] = *reinterpret_cast<const float4*>(a.x + (size_t)(row0 + r) * a.I + i0 + c4);
+    }
+#pragma unroll
+    for (int p = 0; p < C::WL; ++p) {
+      const int e = tid + 256 * p, r = e / CPR, c4 = (e % CPR) * 4;
+      wr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o0 + r < a.O && c4 < ilen) wr[p] = *reinterpret_cast<const float4*>(a.W + (size_t)(o0 + r) * a.I + i0 + c4);
+    }
+#pragma unroll
+    for (int p = 0; p < C::XL; ++p) {             // ... then the LDS stores
+      const int e = tid + 256 * p, r = e / CPR, c4 = (e % CPR) * 4;
+      *reinterpret_cast<float4*>(&xs[r * C::LD + c4]) = xr[p];
+    }
+#pragma unroll
+    for (int p = 0; p < C::WL; ++p) {
+      const int e = tid + 256 * p, r = e / CPR, c4 = (e % CPR) * 4;
+      *reinterpret_cast<float4*>(&ws[r * C::LD + c4]) = wr[p];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < ilen; kk += 4) {
+      const float4 w = *reinterpret_cast<const float4*>(&ws[ol * C::LD + kk]);
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        const float4 x = *reinterpret_cast<const float4*>(&xs[(rg + 16 * k) * C::LD + kk]);
+        acc[k] = fmaf(x.x, w.x, acc[k]); acc[k] = fmaf(x.y, w.y, acc[k]); acc[k] = fmaf(x.z, w.z, acc[k]); acc[k] = fmaf(x.w, w.w, acc[k]);
+      }
+    }
+    __syncthreads();
+  }
+  const int o = o0 + ol;
+  const bool ook = o < a.O;
+  const float bias = (a.b != nullptr && ook) ? a.b[o] : 0.f;
+#pragma unroll
+  for (int k = 0; k < KR; ++k) acc[k] += bias;
+  if (a.gamma != nullptr) {                       // train-mode BatchNorm1d over the B rows (all of them in this workgroup)
+#pragma unroll
+    for (int k = 0; k < KR; ++k) zs[rg + 16 * k][ol] = acc[k];
+    __syncthreads();
+    if (tid < kFT && o0 + tid < a.O) {
+      float s = 0.f;
+      for (int r = 0; r < nrow; ++r) s += zs[r][tid];
+      const float mu = s / (float)nrow;
+      float q = 0.f;
+      for (int r = 0; r < nrow; ++r) { const float d = zs[r][tid] - mu; q += d * d; }
+      const float var = q / (float)nrow;
+      const float is = 1.0f / sqrtf(var + a.eps);
+      const int oo = o0 + tid;
+      sc[tid] = is * a.gamma[oo];
+      sh[tid] = a.beta[oo] - mu * sc[tid];
+      a.save_mean[oo] = mu;
+      a.save_invstd[oo] = is;
+      if (a.running_mean != nullptr) {
+        a.running_mean[oo] = (1.f - a.momentum) * a.running_mean[oo] + a.momentum * mu;
+        const float unb = nrow > 1 ? var * ((float)nrow / (float)(nrow - 1)) : var;
+        a.running_var[oo] = (1.f - a.momentum) * a.running_var[oo] + a.momentum * unb;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int r = rg + 16 * k;
+      if (r < nrow && ook) a.z[(size_t)(row0 + r) * a.O + o] = acc[k];
+      acc[k] = acc[k] * sc[ol] + sh[ol];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int r = rg + 16 * k;
+    if (r < nrow && ook) a.y[(size_t)(row0 + r) * a.O + o] = (a.act == 1) ? fmaxf(acc[k], 0.f) : acc[k];
+  }
+}
+
+// per 16 output features: dz = BN'(dy * act'(y)); db, dgamma, dbeta, dW += dz^T x; writes dz[B][O]; zero-fills dx
+constexpr int kWC = 512;      // input features per x chunk of the dW phase (32 rows x 512 in LDS)
+constexpr int kWLD = kWC + 4;
+constexpr int kRowsMax = 64;  // rows per pass (batch-norm layers: one pass)
+
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearGrads g) {
+  HIP_DYNAMIC_SHARED(float, xs);                  // [32][kWLD]
+  __shared__ float dzs[kRowsMax][kFT + 1];
+  __shared__ float red[2][kFT];
+  const int tid = threadIdx.x, ol = tid & 15, rg = tid >> 4;
+  const int o0 = blockIdx.x * kFT;
+  const int o = o0 + ol;
+  const bool ook = o < a.O;
+  // the dx zero fill rides along (linear_bwd_x_kernel adds into it): each workgroup clears an equal slice
+  if (g.dx != nullptr) {
+    const size_t n4 = (size_t)a.B * a.I / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+    for (size_t i = lo + tid; i < hi; i += 256) reinterpret_cast<float4*>(g.dx)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const bool bn = a.gamma != nullptr;
+  for (int row0 = 0; row0 < a.B; row0 += kRowsMax) {     // batch-norm layers have B <= 64 (checked by the launcher): one pass
+    const int nrow = min(kRowsMax, a.B - row0);
+    float gv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = rg + 16 * k;
+      float v = 0.f;
+      if (r < nrow && ook) {
+        const size_t off = (size_t)(row0 + r) * a.O + o;
+        v = g.dy[off];
+        if (a.act == 1 && !(a.y[off] > 0.f)) v = 0.f;
+      }
+      gv[k] = v;
+    }
+    if (bn) {
+      float xh[4];                                   // xhat of this thread's elements (loads issued before the reduction)
+      if (ook) {
+        const float mu = a.save_mean[o], is = a.save_invstd[o];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = rg + 16 * k;
+          xh[k] = (r < nrow) ? (a.z[(size_t)(row0 + r) * a.O + o] - mu) * is : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xh[k] = 0.f;
+      }
+      // per-feature sums over the rows: 16 row groups x 4 rows each -> LDS -> 16 threads
+      float sg = 0.f, sgx = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { sg += gv[k]; sgx += gv[k] * xh[k]; }
+      dzs[rg][ol] = sg; dzs[16 + rg][ol] = sgx;
+      __syncthreads();
+      if (tid < kFT) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0 += dzs[r][tid]; s1 += dzs[16 + r][tid]; }
+        red[0][tid] = s0 / (float)nrow;
+        red[1][tid] = s1 / (float)nrow;
+        if (o0 + tid < a.O) {
+          if (g.dgamma_acc) g.dgamma_acc[o0 + tid] += s1;
+          if (g.dbeta_acc) g.dbeta_acc[o0 + tid] += s0;
+        }
+      }
+      __syncthreads();
+      if (ook) {
+        const float k1 = a.gamma[o] * a.save_invstd[o];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gv[k] = (rg + 16 * k < nrow) ? k1 * (gv[k] - red[0][ol] - xh[k] * red[1][ol]) : 0.f;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = rg + 16 * k;
+      dzs[r][ol] = gv[k];
+      if (r < nrow && ook && g.dz != nullptr) g.dz[(size_t)(row0 + r) * a.O + o] = gv[k];
+    }
+    __syncthreads();
+    if (tid < kFT && o0 + tid < a.O && g.db_acc != nullptr) {
+      float s = 0.f;
+      for (int r = 0; r < nrow; ++r) s += dzs[r][tid];
+      g.db_acc[o0 + tid] += s;
+    }
+    if (g.dW_acc == nullptr) { __syncthreads(); continue; }
+    // dW[o0 + 4*og + j][i] += sum_r dz[r][4*og + j] * x[r][i];  thread = (i lane 0..63, feature group og 0..3)
+    const int il = tid & 63, og = tid >> 6;
+    for (int i0 = 0; i0 < a.I; i0 += kWC) {
+      const int ilen = min(kWC, a.I - i0);
+      float w[kWC / 64][4];
+#pragma unroll
+      for (int c = 0; c < kWC / 64; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[c][j] = 0.f;
+      for (int rh = 0; rh < nrow; rh += 32) {        // 32 rows of x at a time through LDS, their dz in registers
+        const int nr = min(32, nrow - rh);
+        float4 xr[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          const int e = tid + 256 * p, r = e / (kWC / 4), c4 = (e % (kWC / 4)) * 4;
+          xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (r < nr && c4 < ilen) xr[p] = *reinterpret_cast<const float4*>(a.x + (size_t)(row0 + rh + r) * a.I + i0 + c4);
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          const int e = tid + 256 * p, r = e / (kWC / 4), c4 = (e % (kWC / 4)) * 4;
+          *reinterpret_cast<float4*>(&xs[r * kWLD + c4]) = xr[p];
+        }
+        float dzr[32][4];
+#pragma unroll
+        for (int r = 0; r < 32; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dzr[r][j] = (r < nr) ? dzs[rh + r][og * 4 + j] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kWC / 64; ++c) {
+          if (c * 64 < ilen) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+              const float xv = xs[r * kWLD + c * 64 + il];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) w[c][j] = fmaf(dzr[r][j], xv, w[c][j]);
+            }
+          }
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int c = 0; c < kWC / 64; ++c) {
+        const int i = i0 + c * 64 + il;
+        if (i < a.I) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int oo = o0 + og * 4 + j;
+            if (oo < a.O) g.dW_acc[(size_t)oo * a.I + i] += w[c][j];
+          }
+        }
+      }
+    }
+  }
+}
+
+constexpr int kOS = 64;       // output features per split of the dx kernel
+
+// dx[b][i] += sum_{o in split} dz[b][o] * W[o][i];  workgroup = 64 input features x one split; thread = (i, row group 0..3)
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(LinearArgs a, LinearGrads g) {
+  __shared__ float dzs[kRowsMax][kOS + 1];
+  const int tid = threadIdx.x, il = tid & 63, rg = tid >> 6;
+  const int i = blockIdx.x * 64 + il;
+  const int ic = i < a.I ? i : a.I - 1;           // clamped: the loads below stay unconditional
+  const int os0 = blockIdx.y * kOS, on = min(kOS, a.O - os0);
+  for (int row0 = 0; row0 < a.B; row0 += kRowsMax) {
+    const int nrow = min(kRowsMax, a.B - row0);
+    for (int e = tid; e < kRowsMax * kOS; e += 256) {
+      const int r = e / kOS, c = e - r * kOS;
+      dzs[r][c] = (r < nrow && c < on) ? g.dz[(size_t)(row0 + r) * a.O + os0 + c] : 0.f;
+    }
+    __syncthreads();
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < kOS; c0 += 16) {
+      float wv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {              // 16 independent loads in flight (rows past `on` re-read the last row: dz is 0 there)
+        const int oc = os0 + c0 + c < a.O ? os0 + c0 + c : a.O - 1;
+        wv[c] = a.W[(size_t)oc * a.I + ic];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = fmaf(dzs[rg + 4 * k][c0 + c], wv[c], acc[k]);
+    }
+    if (i < a.I) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int r = rg + 4 * k;
+        if (r < nrow) atomicAdd(g.dx + (size_t)(row0 + r) * a.I + i, acc[k]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int RB>
+static hipError_t launch_fwd_rb(const LinearArgs& a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_fwd_kernel<RB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)MlpCfg<RB>::lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((linear_fwd_kernel<RB>), dim3((a.O + kFT - 1) / kFT, (a.B + RB - 1) / RB), dim3(256), MlpCfg<RB>::lds_bytes, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_linear_fwd(const LinearArgs& a, hipStream_t st) {
+  if (a.I % 4 != 0 || (a.gamma != nullptr && a.B > kRowsMax)) return hipErrorInvalidValue;
+  return a.B <= 32 ? launch_fwd_rb<32>(a, st) : launch_fwd_rb<64>(a, st);
+}
+
+hipError_t launch_linear_bwd(const LinearArgs& a, const LinearGrads& g, hipStream_t st) {
+  if (a.I % 4 != 0 || (a.gamma != nullptr && a.B > kRowsMax) || (g.dx != nullptr && g.dz == nullptr)) return hipErrorInvalidValue;
+  constexpr size_t lds = (size_t)32 * kWLD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bwd_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((a.O + kFT - 1) / kFT), dim3(256), lds, st, a, g);
+  if (g.dx != nullptr)
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((a.I + 63) / 64, (a.O + kOS - 1) / kOS), dim3(256), 0, st, a, g);
+  return hipGetLastError();
+}
+
+}  // namespace hifihr

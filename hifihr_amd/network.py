@@ -217,20 +217,39 @@ class HandEncoder(nn.Module):
             self.rot_reg = _mlp([512, 128, 32, 3])
         self.scale_reg = _mlp([512, 128, 32, 1])
 
+    @staticmethod
+    def _run_mlp(seq, x):
+        """An `_mlp` Sequential (Linear, ReLU?, Linear, ...) on the fused HIP layers (one launch per Linear)."""
+        from . import ops
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = ops.linear(x, mods[i], act=relu)
+            i += 2 if relu else 1
+        return x
+
     def forward(self, features):
         bs, device = features.shape[0], features.device
-        base = self.base_layers(features)
-        pose_params = self.pose_reg(base)
-        scale = self.scale_reg(base)
-        trans = self.trans_reg(base)
-        rot = self.rot_reg(base) if self.hand_model == "mano" else None
+        if features.is_cuda:
+            from . import ops
+            bl = self.base_layers
+            base = ops.linear(ops.linear(features, bl[0], act=True, bn=bl[1]), bl[3], act=True, bn=bl[4])
+            run = self._run_mlp
+        else:
+            base = self.base_layers(features)
+            run = lambda seq, x: seq(x)
+        pose_params = run(self.pose_reg, base)
+        scale = run(self.scale_reg, base)
+        trans = run(self.trans_reg, base)
+        rot = run(self.rot_reg, base) if self.hand_model == "mano" else None
         if self.ifRender and self.hand_model == "nimble":
-            texture_params = self.tex_reg(base)
+            texture_params = run(self.tex_reg, base)
         elif self.hand_model == "nimble":
             texture_params = torch.zeros(bs, self.tex_ncomp, device=device)
         else:
             texture_params = None
-        shape_params = torch.zeros(bs, self.shape_ncomp, device=device) if self.use_mean_shape else self.shape_reg(base)
+        shape_params = torch.zeros(bs, self.shape_ncomp, device=device) if self.use_mean_shape else run(self.shape_reg, base)
         return {"pose_params": pose_params, "shape_params": shape_params, "texture_params": texture_params,
                 "scale": scale, "trans": trans, "rot": rot}
 
@@ -251,6 +270,11 @@ class LightEstimator(nn.Module):
 
     def forward(self, low_features):
         base = self.base_layers(low_features)
-        lights = self.light_reg(base.reshape(base.shape[0], -1))
+        flat = base.reshape(base.shape[0], -1)
+        if flat.is_cuda:
+            from . import ops
+            lights = ops.linear(ops.linear(flat, self.light_reg[0], act=True), self.light_reg[2])
+        else:
+            lights = self.light_reg(flat)
         # the reference checks `torch.any(colors.isnan())` here with a host sync every step (:205); omitted on purpose
         return {"colors": self.hardtanh(lights[:, :3]), "directions": lights[:, 3:]}

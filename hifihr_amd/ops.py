@@ -486,6 +486,67 @@ def sil_post(rgba, images):
 
 
 # ------------------------------------------------------------------------------------------------
+# small-batch fully connected layers of the heads (csrc/mlp.hip)
+# ------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, act, eps, momentum, running_mean, running_var):
+        require_cuda(x, w)
+        lib = get_lib()
+        x, w = x.contiguous(), w.contiguous()
+        B, O = x.shape[0], w.shape[0]
+        y = torch.empty(B, O, device=x.device)
+        bn = None
+        z = sm = si = None
+        if gamma is not None:
+            z, sm, si = torch.empty(B, O, device=x.device), torch.empty(O, device=x.device), torch.empty(O, device=x.device)
+            bn = (gamma, beta, eps, momentum, running_mean, running_var, z, sm, si)
+        PROFILE.bracket("linear_fwd", lambda: lib.linear_fwd(x, w, b, act, y, bn))
+        ctx.save_for_backward(x, w, y if act == 1 else None, gamma, z, sm, si)
+        ctx.act = act
+        ctx.params = (w, b, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, gamma, z, sm, si = ctx.saved_tensors
+        pw, pb, pg, pbeta = ctx.params
+        lib = get_lib()
+        dy = dy.contiguous()
+        B, O = dy.shape
+        need_dx = ctx.needs_input_grad[0]
+        dz = torch.empty(B, O, device=dy.device)
+        dx = torch.empty_like(x) if need_dx else None
+        dw_t, dw_ret = _acc_target(pw, pw.shape, dy.device)
+        db_t, db_ret = _acc_target(pb, pb.shape, dy.device) if pb is not None else (None, None)
+        bn = None
+        dg_ret = dbt_ret = None
+        if gamma is not None:
+            dg_t, dg_ret = _acc_target(pg, pg.shape, dy.device)
+            dbt_t, dbt_ret = _acc_target(pbeta, pbeta.shape, dy.device)
+            bn = (gamma, z, sm, si, dg_t, dbt_t)
+        PROFILE.bracket("linear_bwd", lambda: lib.linear_bwd(dy, y, x, w, ctx.act, dz, dw_t, db_t, dx, bn))
+        for p, ret in ((pw, dw_ret), (pb, db_ret), (pg, dg_ret), (pbeta, dbt_ret)):
+            if p is not None and ret is None:
+                _grad_ready(p)
+        return dx, dw_ret, db_ret, dg_ret, dbt_ret, None, None, None, None, None
+
+
+def linear(x, lin: torch.nn.Linear, act=None, bn: torch.nn.BatchNorm1d | None = None):
+    """act(bn(lin(x))) for a [B, I] activation in ONE launch (two backward): nn.Linear (+ nn.BatchNorm1d, batch statistics
+    in training mode) (+ nn.ReLU) of the reference's regression heads.  Eval-mode batch-norm and B > 64 with batch-norm
+    take the torch modules."""
+    a = 1 if act in (True, "relu", 1) else 0
+    if bn is not None and (not bn.training or x.shape[0] > 64):
+        out = bn(lin(x))
+        return torch.relu(out) if a else out
+    if bn is None:
+        return _Linear.apply(x, lin.weight, lin.bias, None, None, a, 0.0, 0.0, None, None)
+    return _Linear.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, a, float(bn.eps), float(bn.momentum), bn.running_mean,
+                         bn.running_var)
+
+
+# ------------------------------------------------------------------------------------------------
 # pooling (csrc/pool.hip)
 # ------------------------------------------------------------------------------------------------
 def _acc_target(p, shape, device):

@@ -268,6 +268,24 @@ int hifihr_photo_loss_bwd(const float* rgba_d, const float* re_img_m_d, const fl
 int hifihr_sil_post(const float* rgba_d, const float* imgs_d, int B, int H, int W, float* re_sil_d, float* mask_rgbs_d,
                     void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Small-batch fully connected layer of the regression heads: y[B][O] = act( BN1d?( x[B][I] W[O][I]^T + b ) ).
+ * Replaces nn.Linear (+ nn.BatchNorm1d, training mode) (+ nn.ReLU) and their autograd in the reference's HandEncoder /
+ * LightEstimator heads (reference network/res_encoder.py:52-145, 150-210).  I % 4 == 0; act 0 = none, 1 = ReLU.
+ * Batch-norm (gamma_d != NULL, B <= 64): batch statistics over the B rows, running statistics updated with `momentum`
+ * (unbiased variance), z_d[B][O] receives the pre-normalisation output, save_mean_d / save_invstd_d[O] the statistics.
+ * bwd: dy_d = gradient of y; y_d (act 1) gives the ReLU mask; dz_scratch_d[B][O]; dW_acc_d[O][I], db_acc_d[O],
+ *      dgamma_acc_d[O], dbeta_acc_d[O] ACCUMULATE (pass the gradient buffers); dx_d[B][I] is overwritten (NULL: skipped).
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_linear_fwd(const float* x_d, const float* w_d, const float* b_d /* or NULL */, int B, int I, int O, int act,
+                      const float* gamma_d /* or NULL: no batch-norm */, const float* beta_d, float eps, float momentum,
+                      float* running_mean_d, float* running_var_d, float* y_d, float* z_d, float* save_mean_d,
+                      float* save_invstd_d, void* stream);
+int hifihr_linear_bwd(const float* dy_d, const float* y_d, const float* x_d, const float* w_d, int B, int I, int O, int act,
+                      const float* gamma_d, const float* z_d, const float* save_mean_d, const float* save_invstd_d,
+                      float* dz_scratch_d, float* dW_acc_d, float* db_acc_d, float* dgamma_acc_d, float* dbeta_acc_d,
+                      float* dx_d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -474,3 +474,57 @@ def photo_loss_case(lib, device, B, H, W, seed=0, with_g=True):
     rs = torch.empty(B, 1, H, W, device=device); mrgbs = torch.empty(B, 3, H, W, device=device)
     lib.sil_post(rd, idd, rs, mrgbs)
     assert torch.equal(rs.cpu(), re_sil) and torch.equal(mrgbs.cpu(), imgs * (re_sil > 0).float())
+
+
+# ------------------------------------------------------------------------------------------------
+# small-batch fully connected layer (csrc/mlp.hip) vs nn.Linear (+ BatchNorm1d training mode) (+ ReLU)
+# ------------------------------------------------------------------------------------------------
+def linear_case(lib, device, B, I, O, act, bn, seed=0, need_dx=True):
+    import torch.nn.functional as Fn
+    gen = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=gen)
+    x, w, b = rnd(B, I), rnd(O, I) / I ** 0.5, rnd(O) * 0.1
+    gamma, beta = 1 + 0.2 * rnd(O), 0.1 * rnd(O)
+    rm0, rv0 = 0.1 * rnd(O), 1 + 0.1 * torch.rand(O, generator=gen)
+    xr, wr, br, gr, ber = (t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta))
+    rm, rv = rm0.clone(), rv0.clone()
+    out = Fn.linear(xr, wr, br)
+    if bn:
+        out = Fn.batch_norm(out, rm, rv, gr, ber, training=True, momentum=0.1, eps=1e-5)
+    if act:
+        out = Fn.relu(out)
+    gy = rnd(B, O)
+    out.backward(gy)
+    d = lambda t: t.to(device).contiguous()
+    xd, wd, bd = d(x), d(w), d(b)
+    y = torch.empty(B, O, device=device)
+    bnf = bnb = None
+    if bn:
+        z, sm, si = torch.empty(B, O, device=device), torch.empty(O, device=device), torch.empty(O, device=device)
+        rmd, rvd = d(rm0), d(rv0)
+        bnf = (d(gamma), d(beta), 1e-5, 0.1, rmd, rvd, z, sm, si)
+    lib.linear_fwd(xd, wd, bd, act, y, bnf)
+    tol = 3e-5 * max(1.0, float(out.detach().abs().max()))
+    assert float((y.cpu() - out.detach()).abs().max()) <= tol, "linear fwd"
+    if bn:
+        np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
+    dz = torch.empty(B, O, device=device)
+    dW = torch.full((O, I), 0.5, device=device); db = torch.full((O,), -0.25, device=device)       # accumulate semantics
+    dx = torch.full((B, I), 7.0, device=device) if need_dx else None                               # overwritten
+    if bn:
+        dg, dbt = torch.full((O,), 0.125, device=device), torch.full((O,), 2.0, device=device)
+        bnb = (bnf[0], z, sm, si, dg, dbt)
+    lib.linear_bwd(d(gy), y if act else None, xd, wd, act, dz, dW, db, dx, bnb)
+    rel = lambda got, want, name, t=2e-4: (float((got.cpu() - want).abs().max()) <= t * float(want.abs().max()) + 1e-6) or \
+        (_ for _ in ()).throw(AssertionError(f"linear {name}: {float((got.cpu() - want).abs().max())} vs {float(want.abs().max())}"))
+    rel(dW - 0.5, wr.grad, "dW")
+    if bn:       # the true bias gradient under batch-norm is zero (the batch mean removes it): absolute check
+        assert float((db.cpu() + 0.25).abs().max()) <= 1e-4, "linear db (batch-norm: ~0)"
+    else:
+        rel(db + 0.25, br.grad, "db")
+    if need_dx:
+        rel(dx, xr.grad, "dx")
+    if bn:
+        rel(dg - 0.125, gr.grad, "dgamma")
+        rel(dbt - 2.0, ber.grad, "dbeta")

@@ -33,3 +33,9 @@ def test_geom_losses(lib, B, mse):
 @pytest.mark.parametrize("B,with_g", [(8, True), (3, False)])
 def test_photo_losses(lib, B, with_g):
     kc.photo_loss_case(lib, "cuda", B, 224, 224, seed=B, with_g=with_g)
+
+
+@pytest.mark.parametrize("B,I,O,act,bn", [(32, 512, 1024, 1, True), (32, 1024, 512, 1, True), (32, 512, 128, 1, False), (32, 128, 48, 0, False),
+                                          (32, 32, 3, 0, False), (128, 512, 128, 1, False), (64, 1536, 1024, 1, True)])
+def test_linear_heads(lib, B, I, O, act, bn):
+    kc.linear_case(lib, "cuda", B, I, O, act, bn, seed=I + O)
