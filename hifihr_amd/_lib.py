@@ -82,9 +82,11 @@ class HifihrLib:
                                       _c_float_p, c_void_p]
         c.hifihr_ssim_bwd.argtypes = [_c_float_p] * 7 + [c_int, c_int, c_int, _c_float_p, c_void_p]
         ci = [c_int] * 9
-        c.hifihr_conv2d_fwd.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
-        c.hifihr_conv2d_bwd_data.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
-        c.hifihr_conv2d_fwd_bnstats.argtypes = [_c_float_p] * 4 + ci + [c_void_p]
+        c.hifihr_conv2d_fwd.argtypes = [_c_float_p] * 4 + ci + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_conv2d_workspace_bytes.argtypes = [c_int] * 10
+        c.hifihr_conv2d_workspace_bytes.restype = c_size_t
+        c.hifihr_conv2d_bwd_data.argtypes = [_c_float_p] * 4 + ci + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_conv2d_fwd_bnstats.argtypes = [_c_float_p] * 4 + ci + [c_void_p, c_size_t, c_void_p]
         for fn in (c.hifihr_dwconv2d_fwd, c.hifihr_dwconv2d_bwd_data, c.hifihr_dwconv2d_bwd_weight):
             fn.argtypes = [_c_float_p] * 3 + [c_int] * 10 + [c_void_p]
         c.hifihr_bn_stats_floats.argtypes = [c_int]
@@ -160,13 +162,24 @@ class HifihrLib:
 
 
     # ---- convolution (NHWC, f32 MFMA implicit GEMM) --------------------
-    def conv2d_fwd(self, x, w, bias, y, N, H, W, C, K, R, S, stride, pad):
-        self.check(self.c.hifihr_conv2d_fwd(_fp(x), _fp(w), _fp(bias), _fp(y), N, H, W, C, K, R, S, stride, pad, _stream_of(x)),
-                   "hifihr_conv2d_fwd")
+    @staticmethod
+    def _ws(ws):
+        """(pointer, bytes) of an optional zero-initialised, self-cleaning workspace tensor (any dtype, contiguous)."""
+        if ws is None:
+            return c_void_p(0), c_size_t(0)
+        assert ws.is_contiguous()
+        return c_void_p(ws.data_ptr()), c_size_t(ws.numel() * ws.element_size())
 
-    def conv2d_fwd_bnstats(self, x, w, y, stats, N, H, W, C, K, R, S, stride, pad):
+    def conv2d_workspace_bytes(self, N, H, W, C, K, R, S, stride, pad, bwd_data=False):
+        return int(self.c.hifihr_conv2d_workspace_bytes(N, H, W, C, K, R, S, stride, pad, int(bool(bwd_data))))
+
+    def conv2d_fwd(self, x, w, bias, y, N, H, W, C, K, R, S, stride, pad, ws=None):
+        self.check(self.c.hifihr_conv2d_fwd(_fp(x), _fp(w), _fp(bias), _fp(y), N, H, W, C, K, R, S, stride, pad, *self._ws(ws),
+                                            _stream_of(x)), "hifihr_conv2d_fwd")
+
+    def conv2d_fwd_bnstats(self, x, w, y, stats, N, H, W, C, K, R, S, stride, pad, ws=None):
         self.check(self.c.hifihr_conv2d_fwd_bnstats(_fp(x), _fp(w), _fp(y), _fp(stats), N, H, W, C, K, R, S, stride, pad,
-                                                    _stream_of(x)), "hifihr_conv2d_fwd_bnstats")
+                                                    *self._ws(ws), _stream_of(x)), "hifihr_conv2d_fwd_bnstats")
 
     def bn_stats_floats(self, C):
         return int(self.c.hifihr_bn_stats_floats(int(C)))
@@ -273,9 +286,9 @@ class HifihrLib:
         self.check(self.c.hifihr_maxpool3x3s2_bwd(_fp(gy), c_void_p(tap.data_ptr()), N, H, W, C, _fp(dx), _stream_of(gy)),
                    "hifihr_maxpool3x3s2_bwd")
 
-    def conv2d_bwd_data(self, dy, w, dx, scratch, N, H, W, C, K, R, S, stride, pad):
+    def conv2d_bwd_data(self, dy, w, dx, scratch, N, H, W, C, K, R, S, stride, pad, ws=None):
         self.check(self.c.hifihr_conv2d_bwd_data(_fp(dy), _fp(w), _fp(dx), _fp(scratch), N, H, W, C, K, R, S, stride, pad,
-                                                 _stream_of(dy)), "hifihr_conv2d_bwd_data")
+                                                 *self._ws(ws), _stream_of(dy)), "hifihr_conv2d_bwd_data")
 
     def conv2d_bwd_weight(self, x, dy, dw, N, H, W, C, K, R, S, stride, pad):
         self.check(self.c.hifihr_conv2d_bwd_weight(_fp(x), _fp(dy), _fp(dw), N, H, W, C, K, R, S, stride, pad, _stream_of(x)),

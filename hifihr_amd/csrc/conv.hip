@@ -41,6 +41,20 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBK = 16;     // K-chunk depth (8 MFMA k-steps of 2)
 
+// Balanced ("stream-K") schedule.  The dispatcher spreads a grid evenly over the 256 CUs and 4 of these workgroups are
+// resident per CU, so a launch of T tiles costs ceil(T / 1024) full rounds: 784 tiles (layer 4 at batch 32) take as long as
+// 1024 (tools/conv_quant_probe.py).  With SK = true the grid is exactly CUs x 4 persistent workgroups and each one walks an
+// equal share of the T x nch (tile, K-chunk) iterations.  A tile whose chunks are shared by several workgroups is summed in
+// a zero-initialised, SELF-CLEANING fp32 workspace with atomics (accumulator layout = the adders' own register layout, so
+// every wave instruction adds 256 contiguous bytes); a per-tile arrival counter elects the LAST workgroup to arrive, which
+// swaps the sums back out (atomicExch leaves zeros behind) and runs the normal epilogue -- no workgroup ever waits for
+// another one, and all cross-workgroup traffic is device-scope read-modify-write at the memory side (no stale-cache window).
+struct SkArgs {
+  int tiles_x, nch, per, total;   // row tiles, K chunks per tile, iterations per workgroup, tiles * nch
+  float* ws;                      // [tiles][BM * BN]
+  unsigned* cnt;                  // [tiles] arrival counters (zero between launches)
+};
+
 // Ablation builds for tools/conv_ablate.py only (results are wrong for any value but 0): 1 = no global loads in the main
 // loop, 2 = also no LDS stores, 3 = also no barrier, 4 = also no LDS reads (MFMA + epilogue only).
 #ifndef HIFIHR_CONV_PROBE
@@ -81,10 +95,23 @@ __device__ __forceinline__ GatherPlan make_plan(const ConvGeom& g, int cls) {
 
 // GENERIC = false requires IC % BK == 0 (a BK-deep K chunk never straddles a tap: tap bookkeeping is scalar and
 // division-free).  BK = 16 or 32: depth of one K chunk = BK/2 MFMA k-steps between two barriers.  GENERIC = true (forward only) handles any IC % 4 == 0 with per-chunk divisions (the 4-channel stem).
-template <int BM, int BN, bool GENERIC, int BK>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float* __restrict__ src,
+// waves_per_eu: the 64x64 kernels must stay at <= 128 VGPRs so that 4 workgroups share a CU (the balanced schedule launches
+// exactly CUs x 4 persistent workgroups; at 136 registers only 3 fit and the fourth quarter of the grid runs as a second round)
+#if defined(HIFIHR_HOSTSIM)
+#define HIFIHR_WAVES_PER_EU(n)
+#define HIFIHR_WAIT_VMEM() ((void)0)
+#else
+#define HIFIHR_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+// Wait until this wave's outstanding vector-memory operations (here: its device-scope atomic adds, which execute at the
+// memory side) have been acknowledged.  NOT __threadfence(): an agent-scope fence also writes back and invalidates this
+// XCD's L2 (buffer_wbl2 / buffer_inv sc1), which nothing here needs -- the hand-off below consists of atomics only -- and
+// which cost ~200 us per launch when every pass of every workgroup did it.
+#define HIFIHR_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+template <int BM, int BN, bool GENERIC, int BK, bool SK>
+__global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU(SK ? 4 : 1) void conv_igemm_kernel(ConvGeom g, const float* __restrict__ src,
                                                         const float* __restrict__ wgt, const float* __restrict__ bias,
-                                                        float* __restrict__ dst, float* __restrict__ stats) {
+                                                        float* __restrict__ dst, float* __restrict__ stats, SkArgs sk) {
   // stats (optional, forward only): [kStatSlots][2][OC] per-channel sum and sum of squares of the output, accumulated with
   // atomics from the accumulator registers -- the batch-norm that follows needs no separate pass over y
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves are arranged 2 x 2)
@@ -98,12 +125,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, r31 = lane & 31;
-  const GatherPlan P = make_plan(g, blockIdx.z);
+  const GatherPlan P = make_plan(g, SK ? 0 : blockIdx.z);
   const int M = g.N * P.OHs * P.OWs;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
-  if (bm0 >= M) return;                           // parity classes can be smaller than the launch grid
   const int Qw = g.R * g.S * g.IC;                // row length of the weight matrix
   const int lrow = tid / SEGS, seg = (tid % SEGS) * 4;
+  const int nch_tile = GENERIC ? (Qw + BK - 1) / BK : P.nr * P.ns * (g.IC / BK);
+  __shared__ int sk_last;
+  int it = SK ? (int)blockIdx.x * sk.per : 0;
+  const int it_end = SK ? min(it + sk.per, sk.total) : 0;
+  do {                                            // SK: one pass per (tile, chunk range) of this workgroup's share
+  int tile = 0, c_begin = 0, c_end = nch_tile, tx = blockIdx.x, ty = blockIdx.y;
+  if (SK) {
+    if (it >= it_end) break;
+    tile = it / nch_tile;
+    c_begin = it - tile * nch_tile;
+    c_end = min(nch_tile, c_begin + (it_end - it));
+    ty = tile / sk.tiles_x; tx = tile - ty * sk.tiles_x;
+    it += c_end - c_begin;
+  }
+  const int bm0 = tx * BM, bn0 = ty * BN;
+  if (!SK && bm0 >= M) return;                    // parity classes can be smaller than the launch grid
 
   // per-thread row bookkeeping for the gather (constant over the K loop)
   size_t a_base[AL];
@@ -122,8 +163,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
     a_w[i] = ox * P.amul + P.aofw;
   }
 
-  const int nch = GENERIC ? (Qw + BK - 1) / BK : P.nr * P.ns * (g.IC / BK);
+  const int nch = c_end - c_begin;                // chunks of this pass
   int jr = 0, js = 0, c0 = 0, qgen = 0, issued = 0;   // tap state of the NEXT chunk to load
+  if (SK && c_begin > 0) {                        // (SK is never GENERIC) chunk -> (tap row, tap column, channel block)
+    const int cb = g.IC / BK, t2 = c_begin / cb;
+    c0 = (c_begin - t2 * cb) * BK;
+    jr = t2 / P.ns; js = t2 - jr * P.ns;
+  }
 
   // kPF register stages: the chunk consumed now was loaded kPF - 1 chunk-computations ago, so ~2 MFMA blocks (plus the
   // other resident workgroups) cover the L2/HBM latency even when only 2-3 workgroups fit the grid per CU.
@@ -252,6 +298,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
     }
   }
 
+  if (SK && nch != nch_tile) {
+    // This pass covered part of the tile's K range: add the partial sums to the tile's workspace, then count arrivals.
+    const int gfirst = (tile * nch_tile) / sk.per, glast = ((tile + 1) * nch_tile - 1) / sk.per;
+    float* wt = sk.ws + (size_t)tile * (BM * BN) + wave * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) atomicAdd(wt + ((i * TN + j) * 16 + e) * 256, acc[i][j][e]);
+    HIFIHR_WAIT_VMEM();                           // every add of this workgroup is performed before it is counted
+    __syncthreads();
+    if (tid == 0) sk_last = (atomicAdd(sk.cnt + tile, 1u) == (unsigned)(glast - gfirst)) ? 1 : 0;
+    __syncthreads();
+    const bool last = sk_last != 0;
+    __syncthreads();                              // sk_last may be rewritten by the next pass
+    if (!last) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = atomicExch(wt + ((i * TN + j) * 16 + e) * 256, 0.f);   // read and clean
+    if (tid == 0) sk.cnt[tile] = 0u;              // nobody else touches this counter in this launch any more
+  }
+
   // epilogue: D[i][j], i = pixel row, j = output channel; lanes 0..31 hold 32 consecutive channels of one row, so
   // every store instruction writes two 128-byte row segments.  The bias is fetched ONCE up front: a load inside the
   // store loop makes the compiler wait vmcnt(0) per element, which also drains the previous store (16 serialised
@@ -290,7 +362,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
           ssum += __shfl_down(ssum, 32, 64);     // lanes l and l + 32 hold the same channel, different rows
           ssq += __shfl_down(ssq, 32, 64);
           if (half == 0 && k < g.OC) {           // 32 consecutive channels: two 128-byte atomic segments per wave
-            float* sp = stats + (size_t)((blockIdx.x * 2 + wm) & (kStatSlots - 1)) * 2 * g.OC;   // slot by row tile
+            float* sp = stats + (size_t)((tx * 2 + wm) & (kStatSlots - 1)) * 2 * g.OC;   // slot by row tile
             atomicAdd(sp + k, ssum);
             atomicAdd(sp + g.OC + k, ssq);
           }
@@ -321,6 +393,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom g, const float
       }
     }
   }
+  } while (SK);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -480,16 +553,65 @@ template <int BM, int BN>
 static void launch_igemm_tile(const ConvGeom& g, long Mmax, int classes, bool generic, int bk, const float* src, const float* wgt,
                               const float* bias, float* dst, float* stats, hipStream_t st) {
   const dim3 grid((unsigned)((Mmax + BM - 1) / BM), (g.OC + BN - 1) / BN, classes);
+  const SkArgs none{0, 0, 0, 0, nullptr, nullptr};
   if (generic)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true, 16>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true, 16, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats, none);
   else if (bk == 32)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, 32>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, 32, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats, none);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, 16>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, 16, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats, none);
+}
+
+// ---- balanced schedule (64x64 tile, BK = 32, one gather class) ----
+constexpr int kSkWgPerCu = 4;            // resident 64x64 workgroups per CU (36.9 KB LDS each)
+constexpr int kSkMinChunks = 16;         // K chunks per tile below which splitting is not worth a workspace round trip
+
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+struct SkPlan {
+  bool use;
+  int tiles_x, tiles, nch, wgs, per;
+};
+
+static SkPlan sk_plan(const ConvGeom& g) {
+  SkPlan p{false, 0, 0, 0, 0, 0};
+  if (const char* e = getenv("HIFIHR_CONV_SK")) { if (atoi(e) == 0) return p; }
+  const bool one_class = !g.dgrad || g.stride == 1;
+  if (!one_class || g.IC % 32 != 0) return p;
+  const long M = (long)g.N * g.OH * g.OW;
+  p.tiles_x = (int)((M + 63) / 64);
+  p.tiles = p.tiles_x * ((g.OC + 63) / 64);
+  p.nch = g.R * g.S * (g.IC / 32);
+  const int slots = device_cus() * kSkWgPerCu;
+  if (p.nch < kSkMinChunks || p.tiles < slots / 4) return p;
+  // rounds the data-parallel grid costs vs the balanced share: only switch when > 5 % is on the table
+  const double dp = (double)((p.tiles + slots - 1) / slots), sk = (double)p.tiles / slots;
+  if (dp < 1.05 * sk) return p;
+  const long total = (long)p.tiles * p.nch;
+  p.wgs = slots;
+  p.per = (int)((total + slots - 1) / slots);
+  p.wgs = (int)((total + p.per - 1) / p.per);
+  p.use = true;
+  return p;
+}
+
+size_t conv_sk_workspace_bytes(const ConvGeom& g) {
+  const SkPlan p = sk_plan(g);
+  if (!p.use) return 0;
+  return (size_t)((p.tiles * sizeof(unsigned) + 255) / 256 * 256) + (size_t)p.tiles * 64 * 64 * sizeof(float);
 }
 
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
-                             hipStream_t st) {
+                             void* sk_ws, size_t sk_ws_bytes, hipStream_t st) {
   if (stats != nullptr && g.dgrad) return hipErrorInvalidValue;   // stats: all zero on entry (self-cleaning, see bn.hip)
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
   const bool generic = (g.IC % 16) != 0;
@@ -499,7 +621,18 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   const int classes = g.dgrad ? g.stride * g.stride : 1;
   const int st_ = g.dgrad ? g.stride : 1;
   const long Mmax = (long)g.N * ((g.OH + st_ - 1) / st_) * ((g.OW + st_ - 1) / st_);   // rows of the largest class
-  switch (pick_tile(Mmax * classes, g.OC, generic)) {
+  const int tile = pick_tile(Mmax * classes, g.OC, generic);
+  if (sk_ws != nullptr && tile == 2 && bk == 32 && bias == nullptr) {
+    const SkPlan p = sk_plan(g);
+    if (p.use && sk_ws_bytes >= conv_sk_workspace_bytes(g)) {
+      const size_t cnt_bytes = (p.tiles * sizeof(unsigned) + 255) / 256 * 256;
+      const SkArgs a{p.tiles_x, p.nch, p.per, p.tiles * p.nch, reinterpret_cast<float*>(static_cast<char*>(sk_ws) + cnt_bytes),
+                     static_cast<unsigned*>(sk_ws)};
+      hipLaunchKernelGGL((conv_igemm_kernel<64, 64, false, 32, true>), dim3(p.wgs), dim3(256), 0, st, g, src, wgt, bias, dst, stats, a);
+      return hipGetLastError();
+    }
+  }
+  switch (tile) {
     case 0: launch_igemm_tile<128, 128>(g, Mmax, classes, generic, bk, src, wgt, bias, dst, stats, st); break;
     case 1: launch_igemm_tile<128, 64>(g, Mmax, classes, generic, bk, src, wgt, bias, dst, stats, st); break;
     default: launch_igemm_tile<64, 64>(g, Mmax, classes, generic, bk, src, wgt, bias, dst, stats, st);
@@ -514,7 +647,9 @@ hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy,
   const int nch = (int)((M + kBK - 1) / kBK);
   const bool big = (g.OC % 128 == 0);
   const int tiles = big ? ((g.OC + 127) / 128) * ((Q + 127) / 128) : ((g.OC + 63) / 64) * ((Q + 127) / 128);
-  int splits = (1024 + tiles - 1) / tiles;
+  // tiles * splits workgroups, 4 resident per CU (34 KB LDS): stay at or just below 256 * 4 so that every CU gets the same
+  // number (the dispatcher spreads a grid evenly; 1152 workgroups cost five rounds on some CUs: tools/conv_quant_probe.py)
+  int splits = 1024 / tiles;
   if (splits > nch / 4) splits = nch / 4;
   if (splits < 1) splits = 1;
   const int cps = (nch + splits - 1) / splits;

@@ -254,32 +254,40 @@ static int conv_dims_ok(int N, int H, int W, int C, int K, int R, int S, int str
          (W + 2 * pad - S) >= 0;
 }
 
+size_t hifihr_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int bwd_data) {
+  if (!conv_dims_ok(N, H, W, C, K, R, S, stride, pad)) return 0;
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+  const hifihr::ConvGeom f{N, H, W, C, OH, OW, K, R, S, stride, pad, 0};
+  const hifihr::ConvGeom b{N, OH, OW, K, H, W, C, R, S, stride, pad, 1};
+  return hifihr::conv_sk_workspace_bytes(bwd_data ? b : f);
+}
+
 int hifihr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int K, int R,
-                      int S, int stride, int pad, void* stream) {
+                      int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !w || !y || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4)
     return fail(HIFIHR_EINVAL, "hifihr_conv2d_fwd: bad argument (C must be a multiple of 4)");
   hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
-  HIP_TRY(hifihr::launch_conv_igemm(g, x, w, bias, y, nullptr, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_conv_igemm(g, x, w, bias, y, nullptr, ws, ws_bytes, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
 int hifihr_conv2d_fwd_bnstats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int C, int K, int R,
-                              int S, int stride, int pad, void* stream) {
+                              int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !w || !y || !stats || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4)
     return fail(HIFIHR_EINVAL, "hifihr_conv2d_fwd_bnstats: bad argument (C must be a multiple of 4)");
   hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
-  HIP_TRY(hifihr::launch_conv_igemm(g, x, w, nullptr, y, stats, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_conv_igemm(g, x, w, nullptr, y, stats, ws, ws_bytes, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
 int hifihr_conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, int N, int H, int W, int C, int K,
-                           int R, int S, int stride, int pad, void* stream) {
+                           int R, int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
   if (!dy || !w || !dx || !wt_scratch || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || K % 4 || (K % 16 && stride != 1))
     return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_data: bad argument (K % 4 == 0; K % 16 == 0 when stride > 1)");
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
   HIP_TRY(hifihr::launch_weight_transpose(w, wt_scratch, K, R * S, C, (hipStream_t)stream));
   hifihr::ConvGeom g{N, OH, OW, K, H, W, C, R, S, stride, pad, 1};
-  HIP_TRY(hifihr::launch_conv_igemm(g, dy, wt_scratch, nullptr, dx, nullptr, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_conv_igemm(g, dy, wt_scratch, nullptr, dx, nullptr, ws, ws_bytes, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

@@ -55,8 +55,10 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
 struct ConvGeom {
   int N, IH, IW, IC, OH, OW, OC, R, S, stride, pad, dgrad;
 };
+// sk_ws (may be NULL): zero-initialised, self-cleaning workspace of conv_sk_workspace_bytes(g) bytes for the balanced schedule
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
-                             hipStream_t st);
+                             void* sk_ws, size_t sk_ws_bytes, hipStream_t st);
+size_t conv_sk_workspace_bytes(const ConvGeom& g);
 // batch-norm (+ residual add + ReLU) on NHWC activations, x[M][C].  Statistics buffers are [kStatSlots][2][C]: partial
 // sums are spread over kStatSlots copies so that at most ~1/32 of the contributing workgroups hit one address with a
 // float atomic (thousands of atomics on ONE address serialise at ~100 ns each: 200 us per reduction in round 1).

@@ -236,6 +236,28 @@ def _grad_ready(p):
         cb(p)
 
 
+_CONV_WS = {}          # device -> zero-initialised, self-cleaning workspace of the balanced convolution schedule
+_CONV_WS_BYTES = {}    # (geometry, direction) -> bytes the library wants for it
+
+
+def _conv_ws(lib, device, geom, bwd):
+    """The shared convolution workspace if this shape uses the balanced (stream-K) schedule, else None
+    (include/hifihr.h, convolution section).  One buffer per device serves every layer: launches are stream-ordered and
+    each one hands the buffer back all zero."""
+    key = (geom, bwd)
+    nb = _CONV_WS_BYTES.get(key)
+    if nb is None:
+        nb = lib.conv2d_workspace_bytes(*geom, bwd)
+        _CONV_WS_BYTES[key] = nb
+    if nb == 0:
+        return None
+    ws = _CONV_WS.get(device)
+    if ws is None or ws.numel() * 4 < nb:
+        ws = torch.zeros(max(nb, 32 << 20) // 4 + 64, dtype=torch.float32, device=device)
+        _CONV_WS[device] = ws
+    return ws
+
+
 class _Conv2dMFMA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, pad, want_stats=False):
@@ -251,9 +273,11 @@ class _Conv2dMFMA(torch.autograd.Function):
         stats = None
         if want_stats:       # per-channel sum / sum of squares of y from the conv epilogue, for the batch-norm that follows
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device)
-            PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd_bnstats(x, wk, y, stats, N, H, W, C, K, R, S, stride, pad))
+            ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), False)
+            PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd_bnstats(x, wk, y, stats, N, H, W, C, K, R, S, stride, pad, ws=ws))
         else:
-            PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, None, y, N, H, W, C, K, R, S, stride, pad))
+            ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), False)
+            PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, None, y, N, H, W, C, K, R, S, stride, pad, ws=ws))
         ctx.geom = (N, H, W, C, K, R, S, stride, pad)
         ctx.save_for_backward(x, wk)
         ctx.w_param = w
@@ -275,7 +299,8 @@ class _Conv2dMFMA(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=_CL)
             scratch = torch.empty(wk.numel(), device=x.device, dtype=torch.float32)
-            PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data(gy, wk, dx, scratch, N, H, W, C, K, R, S, stride, pad))
+            ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), True)
+            PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data(gy, wk, dx, scratch, N, H, W, C, K, R, S, stride, pad, ws=ws))
         if ctx.needs_input_grad[1]:
             w = ctx.w_param
             tgt = w.grad if (getattr(w, "_hifihr_direct_grad", False) and w.grad is not None

@@ -140,12 +140,21 @@ int hifihr_adam_step_dyn(float* params_d, const float* grads_d, float* exp_avg_d
  * backward-weight): reference network/res_encoder.py:364-373 (ResNet trunk built at :345-362).
  * Layouts: x[N][H][W][C], w[K][R][S][C] (= a torch [K,C,R,S] tensor in channels_last memory format),
  * y[N][OH][OW][K] with OH = (H + 2 pad - R)/stride + 1.  C % 4 == 0; bwd_data needs K % 4 == 0 (K % 16 == 0 when stride > 1), bwd_weight K % 4 == 0.
+ *
+ * Workspace (ws_d / ws_bytes, may be NULL / 0): fwd, fwd_bnstats and bwd_data can run a BALANCED schedule -- exactly
+ * 4 persistent workgroups per CU, each walking an equal share of the (tile, K-chunk) iterations, partial tiles summed
+ * through ws_d -- instead of one workgroup per output tile, whose cost is quantised to whole rounds of 1024 workgroups
+ * (784 tiles cost as much as 1024).  ws_d must hold hifihr_conv2d_workspace_bytes(...) bytes (0 = this shape never uses
+ * one), be ALL ZERO before its first use and is returned all zero (self-cleaning); calls sharing a workspace must be
+ * ordered on one stream.  Without a workspace the calls fall back to the data-parallel grid (same results up to fp32
+ * summation order across K segments).
  * ---------------------------------------------------------------------------------------------- */
+size_t hifihr_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int bwd_data);
 int hifihr_conv2d_fwd(const float* x_d, const float* w_d, const float* bias_d /* [K] or NULL */, float* y_d, int N, int H,
-                      int W, int C, int K, int R, int S, int stride, int pad, void* stream);
+                      int W, int C, int K, int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
 /* dx[N][H][W][C] (overwritten).  wt_scratch_d: K*R*S*C floats of scratch (receives the [C][R][S][K] transpose). */
 int hifihr_conv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, float* wt_scratch_d, int N, int H, int W, int C,
-                           int K, int R, int S, int stride, int pad, void* stream);
+                           int K, int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
 /* dw[K][R][S][C] += sum over pixels (ACCUMULATES with fp32 atomics: zero it, or pass the gradient buffer). */
 int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, void* stream);
@@ -153,7 +162,7 @@ int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, i
  * floats, ALL ZERO on entry: see the self-cleaning rule below) from the accumulator registers, so the batch-norm that
  * follows needs no pass over y. */
 int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, float* stats_d, int N, int H, int W, int C, int K,
-                              int R, int S, int stride, int pad, void* stream);
+                              int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Train-mode BatchNorm2d fused with the residual add and ReLU of a ResNet BasicBlock, NHWC: x[M][C], M = N*H*W.

@@ -112,6 +112,15 @@ static inline float atomicAdd(float* p, float v) {
   std::memcpy(&f, &old, 4);
   return f;
 }
+static inline float atomicExch(float* p, float v) {
+  uint32_t nw, old;
+  std::memcpy(&nw, &v, 4);
+  old = __atomic_exchange_n(reinterpret_cast<uint32_t*>(p), nw, __ATOMIC_RELAXED);
+  float f;
+  std::memcpy(&f, &old, 4);
+  return f;
+}
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) {
@@ -150,6 +159,10 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+// 4 "CUs": the balanced convolution schedule (conv.hip) then runs 16 persistent workgroups, so small test shapes split tiles
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 4; return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

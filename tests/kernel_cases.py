@@ -208,6 +208,24 @@ def conv_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0, bias=False, rt
     # accumulation semantics: a second call adds
     lib.conv2d_bwd_weight(x_nhwc, gy_nhwc, dw, N, H, W, C, K, R, R, stride, pad)
     assert float((dw.cpu() - 2 * refw).abs().max()) <= 1e-4 * float(refw.abs().max()) + 1e-6, "conv bwd weight accumulate"
+    # balanced (stream-K) schedule through a zero-initialised, self-cleaning workspace: same results, workspace zero again
+    nb_f = lib.conv2d_workspace_bytes(N, H, W, C, K, R, R, stride, pad, False)
+    nb_b = lib.conv2d_workspace_bytes(N, H, W, C, K, R, R, stride, pad, True)
+    used = 0
+    if nb_f and not bias:
+        ws = torch.zeros(nb_f // 4, device=device); out2 = torch.full_like(out, 7.0)
+        for _ in range(2):                                  # twice: the second call must find the workspace clean
+            lib.conv2d_fwd(x_nhwc, w_krsc, None, out2, N, H, W, C, K, R, R, stride, pad, ws=ws)
+            assert float((out2.cpu() - ref).abs().max()) <= rtol * scale + 1e-6, "conv fwd (balanced schedule)"
+            assert float(ws.abs().max()) == 0.0, "workspace not cleaned"
+        used += 1
+    if nb_b:
+        ws = torch.zeros(nb_b // 4, device=device); dx2 = torch.full_like(dx, 7.0)
+        lib.conv2d_bwd_data(gy_nhwc, w_krsc, dx2, scratch, N, H, W, C, K, R, R, stride, pad, ws=ws)
+        assert float((dx2.cpu() - refx).abs().max()) <= rtol * float(refx.abs().max()) + 1e-6, "conv bwd data (balanced schedule)"
+        assert float(ws.abs().max()) == 0.0, "workspace not cleaned"
+        used += 1
+    return used
 
 
 def image_to_nhwc4_case(lib, device):
@@ -298,7 +316,7 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
         assert float((dres.cpu() - rr.grad.permute(0, 2, 3, 1)).abs().max()) <= 1e-6, "bn dres"
 
 
-def conv_bnstats_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0):
+def conv_bnstats_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0, use_ws=False):
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(seed)
     x = torch.randn(N, C, H, W, generator=gen); w = torch.randn(K, C, R, R, generator=gen) / (C * R * R) ** 0.5
@@ -306,7 +324,11 @@ def conv_bnstats_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0):
     OH, OW = y.shape[2], y.shape[3]
     d = lambda t: t.to(device).contiguous()
     out = torch.empty(N, OH, OW, K, device=device); stats = torch.zeros(lib.bn_stats_floats(K), device=device)
-    lib.conv2d_fwd_bnstats(d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), out, stats, N, H, W, C, K, R, R, stride, pad)
+    nb = lib.conv2d_workspace_bytes(N, H, W, C, K, R, R, stride, pad, False) if use_ws else 0
+    ws = torch.zeros(nb // 4, device=device) if nb else None
+    assert not use_ws or nb > 0, "this case was meant to exercise the balanced schedule"
+    lib.conv2d_fwd_bnstats(d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), out, stats, N, H, W, C, K, R, R, stride, pad, ws=ws)
+    assert ws is None or float(ws.abs().max()) == 0.0
     ref = y.permute(0, 2, 3, 1)
     assert float((out.cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6
     s_ref = y.permute(1, 0, 2, 3).reshape(K, -1)

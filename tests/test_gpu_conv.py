@@ -108,3 +108,13 @@ def test_efficientnet_b3_mfma_vs_reference_golden(golden_dir):
 @pytest.mark.parametrize("N,H,C,K,stride", [(32, 56, 192, 3, 1), (32, 56, 192, 5, 2), (8, 14, 816, 5, 1), (32, 7, 2304, 3, 1)])
 def test_dwconv_kernels(lib, N, H, C, K, stride):
     kc.dwconv_case(lib, "cuda", N, H, H, C, K, stride, seed=C + K)
+
+
+@pytest.mark.parametrize("N,H,C,K", [(32, 14, 512, 512), (32, 28, 128, 128), (32, 14, 256, 256), (32, 56, 64, 64)])
+def test_balanced_schedule_full_batch(lib, N, H, C, K):
+    """The stream-K schedule at BASELINE's batch: forward and backward-data through the shared workspace."""
+    assert kc.conv_case(lib, "cuda", N, H, H, C, K, 3, 1, 1, seed=C, rtol=3e-5) == 2
+
+
+def test_balanced_schedule_bnstats(lib):
+    kc.conv_bnstats_case(lib, "cuda", 32, 14, 14, 512, 512, 3, 1, 1, use_ws=True)

@@ -22,5 +22,20 @@ def test_conv_fwd_bwd(hostsim_lib, N, H, W, C, K, R, stride, pad):
     kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, seed=H, bias=(K == 48))
 
 
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [
+    (2, 9, 7, 128, 192, 3, 1, 1),   # fwd 6 tiles x 36 chunks, dgrad 4 tiles x 54 chunks over 16 persistent workgroups: split tiles
+    (3, 8, 8, 32, 128, 3, 1, 1),    # 6 tiles x 9 ... below the chunk minimum: must NOT take a workspace
+    (4, 20, 20, 64, 64, 3, 2, 1),   # strided forward (one gather class) balanced, strided dgrad not
+])
+def test_conv_balanced_schedule(hostsim_lib, N, H, W, C, K, R, stride, pad):
+    """hostsim reports 4 CUs -> 16 persistent workgroups (tests/hostsim/hip/hip_runtime.h)."""
+    used = kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, seed=C + H)
+    assert used == {192: 2, 128: 0, 64: 1}[K]
+
+
+def test_conv_balanced_schedule_bnstats(hostsim_lib):
+    kc.conv_bnstats_case(hostsim_lib, "cpu", 2, 9, 7, 64, 192, 3, 1, 1, use_ws=True)
+
+
 def test_image_to_nhwc4(hostsim_lib):
     kc.image_to_nhwc4_case(hostsim_lib, "cpu")
