@@ -49,8 +49,12 @@ constexpr int kBK = 16;     // K-chunk depth (8 MFMA k-steps of 2)
 // every wave instruction adds 256 contiguous bytes); a per-tile arrival counter elects the LAST workgroup to arrive, which
 // swaps the sums back out (atomicExch leaves zeros behind) and runs the normal epilogue -- no workgroup ever waits for
 // another one, and all cross-workgroup traffic is device-scope read-modify-write at the memory side (no stale-cache window).
+// XCD locality: workgroup b runs on XCD b % 8 (each XCD has its own 4 MB L2), so the persistent workgroups are renumbered to
+// give every XCD ONE contiguous eighth of the iteration space, and tiles are ordered column-tile fastest: an XCD then works
+// on a band of pixel rows (its slice of the activations stays in its L2 across the 9 taps and all column tiles) while the
+// column tiles that run side by side stream the same weight slab.
 struct SkArgs {
-  int tiles_x, nch, per, total;   // row tiles, K chunks per tile, iterations per workgroup, tiles * nch
+  int tiles_x, tiles_y, nch, per, total;   // row / column tiles, K chunks per tile, iterations per workgroup, tiles * nch
   float* ws;                      // [tiles][BM * BN]
   unsigned* cnt;                  // [tiles] arrival counters (zero between launches)
 };
@@ -101,7 +105,11 @@ __device__ __forceinline__ GatherPlan make_plan(const ConvGeom& g, int cls) {
 #define HIFIHR_WAVES_PER_EU(n)
 #define HIFIHR_WAIT_VMEM() ((void)0)
 #else
+#if defined(HIFIHR_CONV_NO_CAP)       /* tuning builds (tools/build_conv_probes.sh) */
+#define HIFIHR_WAVES_PER_EU(n)
+#else
 #define HIFIHR_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
 // Wait until this wave's outstanding vector-memory operations (here: its device-scope atomic adds, which execute at the
 // memory side) have been acknowledged.  NOT __threadfence(): an agent-scope fence also writes back and invalidates this
 // XCD's L2 (buffer_wbl2 / buffer_inv sc1), which nothing here needs -- the hand-off below consists of atomics only -- and
@@ -109,7 +117,7 @@ __device__ __forceinline__ GatherPlan make_plan(const ConvGeom& g, int cls) {
 #define HIFIHR_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 template <int BM, int BN, bool GENERIC, int BK, bool SK>
-__global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU(SK ? 4 : 1) void conv_igemm_kernel(ConvGeom g, const float* __restrict__ src,
+__global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) void conv_igemm_kernel(ConvGeom g, const float* __restrict__ src,
                                                         const float* __restrict__ wgt, const float* __restrict__ bias,
                                                         float* __restrict__ dst, float* __restrict__ stats, SkArgs sk) {
   // stats (optional, forward only): [kStatSlots][2][OC] per-channel sum and sum of squares of the output, accumulated with
@@ -131,7 +139,9 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU(SK ? 4 : 1) void conv_igem
   const int lrow = tid / SEGS, seg = (tid % SEGS) * 4;
   const int nch_tile = GENERIC ? (Qw + BK - 1) / BK : P.nr * P.ns * (g.IC / BK);
   __shared__ int sk_last;
-  int it = SK ? (int)blockIdx.x * sk.per : 0;
+  int wg = blockIdx.x;
+  if (SK && (gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);     // XCD b % 8 -> contiguous eighth
+  int it = SK ? wg * sk.per : 0;
   const int it_end = SK ? min(it + sk.per, sk.total) : 0;
   do {                                            // SK: one pass per (tile, chunk range) of this workgroup's share
   int tile = 0, c_begin = 0, c_end = nch_tile, tx = blockIdx.x, ty = blockIdx.y;
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU(SK ? 4 : 1) void conv_igem
     tile = it / nch_tile;
     c_begin = it - tile * nch_tile;
     c_end = min(nch_tile, c_begin + (it_end - it));
-    ty = tile / sk.tiles_x; tx = tile - ty * sk.tiles_x;
+    tx = tile / sk.tiles_y; ty = tile - tx * sk.tiles_y;
     it += c_end - c_begin;
   }
   const int bm0 = tx * BM, bn0 = ty * BN;
@@ -553,7 +563,7 @@ template <int BM, int BN>
 static void launch_igemm_tile(const ConvGeom& g, long Mmax, int classes, bool generic, int bk, const float* src, const float* wgt,
                               const float* bias, float* dst, float* stats, hipStream_t st) {
   const dim3 grid((unsigned)((Mmax + BM - 1) / BM), (g.OC + BN - 1) / BN, classes);
-  const SkArgs none{0, 0, 0, 0, nullptr, nullptr};
+  const SkArgs none{0, 0, 0, 0, 0, nullptr, nullptr};
   if (generic)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true, 16, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats, none);
   else if (bk == 32)
@@ -562,8 +572,7 @@ static void launch_igemm_tile(const ConvGeom& g, long Mmax, int classes, bool ge
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, 16, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats, none);
 }
 
-// ---- balanced schedule (64x64 tile, BK = 32, one gather class) ----
-constexpr int kSkWgPerCu = 4;            // resident 64x64 workgroups per CU (36.9 KB LDS each)
+// ---- balanced schedule (one gather class, source channels % 32 == 0) ----
 constexpr int kSkMinChunks = 16;         // K chunks per tile below which splitting is not worth a workspace round trip
 
 static int device_cus() {
@@ -577,27 +586,42 @@ static int device_cus() {
   return cus;
 }
 
+// variant of the persistent kernel: tile, K-chunk depth and the number of workgroups that are resident per CU
+struct SkVariant {
+  int bm, bn, bk, occ;
+};
+static SkVariant sk_variant() {
+  // 0: 64x64 BK32 (36.9 KB LDS, <= 128 VGPRs: 4 per CU).  Others are tuning experiments (HIFIHR_CONV_SK_VARIANT).
+  static const SkVariant v[] = {{64, 64, 32, 4}, {128, 64, 16, 3}, {128, 64, 32, 2}, {128, 128, 16, 2}};
+  int i = 0;
+  if (const char* e = getenv("HIFIHR_CONV_SK_VARIANT")) i = atoi(e);
+  if (i < 0 || i > 3) i = 0;
+  SkVariant r = v[i];
+  if (const char* e = getenv("HIFIHR_CONV_SK_OCC")) r.occ = atoi(e) > 0 ? atoi(e) : r.occ;
+  return r;
+}
+
 struct SkPlan {
   bool use;
   int tiles_x, tiles, nch, wgs, per;
+  SkVariant v;
 };
 
 static SkPlan sk_plan(const ConvGeom& g) {
-  SkPlan p{false, 0, 0, 0, 0, 0};
+  SkPlan p{false, 0, 0, 0, 0, 0, sk_variant()};
   if (const char* e = getenv("HIFIHR_CONV_SK")) { if (atoi(e) == 0) return p; }
   const bool one_class = !g.dgrad || g.stride == 1;
   if (!one_class || g.IC % 32 != 0) return p;
   const long M = (long)g.N * g.OH * g.OW;
-  p.tiles_x = (int)((M + 63) / 64);
-  p.tiles = p.tiles_x * ((g.OC + 63) / 64);
-  p.nch = g.R * g.S * (g.IC / 32);
-  const int slots = device_cus() * kSkWgPerCu;
-  if (p.nch < kSkMinChunks || p.tiles < slots / 4) return p;
+  p.tiles_x = (int)((M + p.v.bm - 1) / p.v.bm);
+  p.tiles = p.tiles_x * ((g.OC + p.v.bn - 1) / p.v.bn);
+  p.nch = g.R * g.S * (g.IC / p.v.bk);
+  const int slots = device_cus() * p.v.occ;
+  if (p.nch * p.v.bk < kSkMinChunks * 32 || p.tiles < slots / 4) return p;
   // rounds the data-parallel grid costs vs the balanced share: only switch when > 5 % is on the table
   const double dp = (double)((p.tiles + slots - 1) / slots), sk = (double)p.tiles / slots;
-  if (dp < 1.05 * sk) return p;
+  if (dp < 1.05 * sk && p.v.bm == 64) return p;
   const long total = (long)p.tiles * p.nch;
-  p.wgs = slots;
   p.per = (int)((total + slots - 1) / slots);
   p.wgs = (int)((total + p.per - 1) / p.per);
   p.use = true;
@@ -607,7 +631,16 @@ static SkPlan sk_plan(const ConvGeom& g) {
 size_t conv_sk_workspace_bytes(const ConvGeom& g) {
   const SkPlan p = sk_plan(g);
   if (!p.use) return 0;
-  return (size_t)((p.tiles * sizeof(unsigned) + 255) / 256 * 256) + (size_t)p.tiles * 64 * 64 * sizeof(float);
+  return (size_t)((p.tiles * sizeof(unsigned) + 255) / 256 * 256) + (size_t)p.tiles * p.v.bm * p.v.bn * sizeof(float);
+}
+
+template <int BM, int BN, int BK>
+static void launch_sk(const SkPlan& p, const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, void* sk_ws,
+                      hipStream_t st) {
+  const size_t cnt_bytes = (p.tiles * sizeof(unsigned) + 255) / 256 * 256;
+  const SkArgs a{p.tiles_x, p.tiles / p.tiles_x, p.nch, p.per, p.tiles * p.nch, reinterpret_cast<float*>(static_cast<char*>(sk_ws) + cnt_bytes),
+                 static_cast<unsigned*>(sk_ws)};
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, BK, true>), dim3(p.wgs), dim3(256), 0, st, g, src, wgt, nullptr, dst, stats, a);
 }
 
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
@@ -625,10 +658,10 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   if (sk_ws != nullptr && tile == 2 && bk == 32 && bias == nullptr) {
     const SkPlan p = sk_plan(g);
     if (p.use && sk_ws_bytes >= conv_sk_workspace_bytes(g)) {
-      const size_t cnt_bytes = (p.tiles * sizeof(unsigned) + 255) / 256 * 256;
-      const SkArgs a{p.tiles_x, p.nch, p.per, p.tiles * p.nch, reinterpret_cast<float*>(static_cast<char*>(sk_ws) + cnt_bytes),
-                     static_cast<unsigned*>(sk_ws)};
-      hipLaunchKernelGGL((conv_igemm_kernel<64, 64, false, 32, true>), dim3(p.wgs), dim3(256), 0, st, g, src, wgt, bias, dst, stats, a);
+      if (p.v.bm == 64) launch_sk<64, 64, 32>(p, g, src, wgt, dst, stats, sk_ws, st);
+      else if (p.v.bn == 128) launch_sk<128, 128, 16>(p, g, src, wgt, dst, stats, sk_ws, st);
+      else if (p.v.bk == 16) launch_sk<128, 64, 16>(p, g, src, wgt, dst, stats, sk_ws, st);
+      else launch_sk<128, 64, 32>(p, g, src, wgt, dst, stats, sk_ws, st);
       return hipGetLastError();
     }
   }
