@@ -82,7 +82,8 @@ class HifihrLib:
                                       _c_float_p, c_void_p]
         c.hifihr_ssim_bwd.argtypes = [_c_float_p] * 7 + [c_int, c_int, c_int, _c_float_p, c_void_p]
         ci = [c_int] * 9
-        c.hifihr_conv2d_fwd.argtypes = [_c_float_p] * 4 + ci + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_conv2d_fwd.argtypes = [_c_float_p] * 3 + [c_int, _c_float_p] + ci + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_bias_relu_bwd.argtypes = [_c_float_p, _c_float_p, c_long, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_conv2d_workspace_bytes.argtypes = [c_int] * 10
         c.hifihr_conv2d_workspace_bytes.restype = c_size_t
         c.hifihr_conv2d_bwd_data.argtypes = [_c_float_p] * 4 + ci + [c_void_p, c_size_t, c_void_p]
@@ -109,8 +110,8 @@ class HifihrLib:
         c.hifihr_mmpool_fwd.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mmpool_bwd.argtypes = [_c_float_p, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p,
                                         _c_float_p, c_void_p]
-        c.hifihr_maxpool3x3s2_fwd.argtypes = [_c_float_p, c_int, c_int, c_int, c_int, _c_float_p, c_void_p, c_void_p]
-        c.hifihr_maxpool3x3s2_bwd.argtypes = [_c_float_p, c_void_p, c_int, c_int, c_int, c_int, _c_float_p, c_void_p]
+        c.hifihr_maxpool2d_fwd.argtypes = [_c_float_p] + [c_int] * 7 + [_c_float_p, c_void_p, c_void_p]
+        c.hifihr_maxpool2d_bwd.argtypes = [_c_float_p, c_void_p] + [c_int] * 7 + [_c_float_p, c_void_p]
         c.hifihr_adam_step.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
                                        c_float, c_float, c_float, c_int, c_void_p]
         c.hifihr_adam_step_dyn.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
@@ -173,9 +174,13 @@ class HifihrLib:
     def conv2d_workspace_bytes(self, N, H, W, C, K, R, S, stride, pad, bwd_data=False):
         return int(self.c.hifihr_conv2d_workspace_bytes(N, H, W, C, K, R, S, stride, pad, int(bool(bwd_data))))
 
-    def conv2d_fwd(self, x, w, bias, y, N, H, W, C, K, R, S, stride, pad, ws=None):
-        self.check(self.c.hifihr_conv2d_fwd(_fp(x), _fp(w), _fp(bias), _fp(y), N, H, W, C, K, R, S, stride, pad, *self._ws(ws),
-                                            _stream_of(x)), "hifihr_conv2d_fwd")
+    def conv2d_fwd(self, x, w, bias, y, N, H, W, C, K, R, S, stride, pad, ws=None, act=0):
+        self.check(self.c.hifihr_conv2d_fwd(_fp(x), _fp(w), _fp(bias), int(act), _fp(y), N, H, W, C, K, R, S, stride, pad,
+                                            *self._ws(ws), _stream_of(x)), "hifihr_conv2d_fwd")
+
+    def bias_relu_bwd(self, dy, y, M, C, g, db_acc):
+        self.check(self.c.hifihr_bias_relu_bwd(_fp(dy), _fp(y), c_long(M), C, _fp(g), _fp(db_acc), _stream_of(dy)),
+                   "hifihr_bias_relu_bwd")
 
     def conv2d_fwd_bnstats(self, x, w, y, stats, N, H, W, C, K, R, S, stride, pad, ws=None):
         self.check(self.c.hifihr_conv2d_fwd_bnstats(_fp(x), _fp(w), _fp(y), _fp(stats), N, H, W, C, K, R, S, stride, pad,
@@ -277,14 +282,14 @@ class HifihrLib:
         self.check(self.c.hifihr_mmpool_bwd(_fp(gy), _fp(p), _ip(argmax), _fp(xmax), _fp(xavg), B, HW, C, _fp(dx), _fp(dp_acc),
                                             _stream_of(gy)), "hifihr_mmpool_bwd")
 
-    def maxpool3x3s2_fwd(self, x, N, H, W, C, y, tap):
+    def maxpool2d_fwd(self, x, N, H, W, C, k, s, p, y, tap):
         assert tap.dtype == torch.uint8 and tap.is_contiguous()
-        self.check(self.c.hifihr_maxpool3x3s2_fwd(_fp(x), N, H, W, C, _fp(y), c_void_p(tap.data_ptr()), _stream_of(x)),
-                   "hifihr_maxpool3x3s2_fwd")
+        self.check(self.c.hifihr_maxpool2d_fwd(_fp(x), N, H, W, C, k, s, p, _fp(y), c_void_p(tap.data_ptr()), _stream_of(x)),
+                   "hifihr_maxpool2d_fwd")
 
-    def maxpool3x3s2_bwd(self, gy, tap, N, H, W, C, dx):
-        self.check(self.c.hifihr_maxpool3x3s2_bwd(_fp(gy), c_void_p(tap.data_ptr()), N, H, W, C, _fp(dx), _stream_of(gy)),
-                   "hifihr_maxpool3x3s2_bwd")
+    def maxpool2d_bwd(self, gy, tap, N, H, W, C, k, s, p, dx):
+        self.check(self.c.hifihr_maxpool2d_bwd(_fp(gy), c_void_p(tap.data_ptr()), N, H, W, C, k, s, p, _fp(dx), _stream_of(gy)),
+                   "hifihr_maxpool2d_bwd")
 
     def conv2d_bwd_data(self, dy, w, dx, scratch, N, H, W, C, K, R, S, stride, pad, ws=None):
         self.check(self.c.hifihr_conv2d_bwd_data(_fp(dy), _fp(w), _fp(dx), _fp(scratch), N, H, W, C, K, R, S, stride, pad,

@@ -358,6 +358,10 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
             HIFIHR_KEEP(acc[i][j][e]);      // keep the add (and its one vmcnt wait) out of the per-element branches
           }
         }
+        if (g.relu) {                       // uniform (LightEstimator's conv + bias + ReLU in one launch)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+        }
         float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {

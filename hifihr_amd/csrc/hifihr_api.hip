@@ -262,11 +262,11 @@ size_t hifihr_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, i
   return hifihr::conv_sk_workspace_bytes(bwd_data ? b : f);
 }
 
-int hifihr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int K, int R,
+int hifihr_conv2d_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int H, int W, int C, int K, int R,
                       int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
-  if (!x || !w || !y || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4)
-    return fail(HIFIHR_EINVAL, "hifihr_conv2d_fwd: bad argument (C must be a multiple of 4)");
-  hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
+  if (!x || !w || !y || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4 || act < 0 || act > 1)
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_fwd: bad argument (C must be a multiple of 4; act 0/1)");
+  hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0, act};
   HIP_TRY(hifihr::launch_conv_igemm(g, x, w, bias, y, nullptr, ws, ws_bytes, (hipStream_t)stream));
   return HIFIHR_OK;
 }
@@ -409,17 +409,27 @@ int hifihr_mmpool_bwd(const float* gy, const float* p, const int* argmax, const 
   return HIFIHR_OK;
 }
 
-int hifihr_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* tap, void* stream) {
-  if (!x || !y || !tap || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0)
-    return fail(HIFIHR_EINVAL, "hifihr_maxpool3x3s2_fwd: bad argument (C % 4 == 0)");
-  HIP_TRY(hifihr::launch_maxpool3x3s2_fwd(x, N, H, W, C, y, tap, (hipStream_t)stream));
+static int pool_ok(int k, int s, int p) { return (k == 3 && s == 2 && p == 1) || (k == 3 && s == 1 && p == 1) || (k == 2 && s == 2 && p == 0); }
+
+int hifihr_maxpool2d_fwd(const float* x, int N, int H, int W, int C, int k, int s, int p, float* y, unsigned char* tap, void* stream) {
+  if (!x || !y || !tap || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0 || !pool_ok(k, s, p) || H + 2 * p < k || W + 2 * p < k)
+    return fail(HIFIHR_EINVAL, "hifihr_maxpool2d_fwd: bad argument (C % 4 == 0; (k,s,p) in {(3,2,1), (3,1,1), (2,2,0)})");
+  HIP_TRY(hifihr::launch_maxpool_fwd(x, N, H, W, C, k, s, p, y, tap, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
-int hifihr_maxpool3x3s2_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, float* dx, void* stream) {
-  if (!gy || !tap || !dx || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0)
-    return fail(HIFIHR_EINVAL, "hifihr_maxpool3x3s2_bwd: bad argument (C % 4 == 0)");
-  HIP_TRY(hifihr::launch_maxpool3x3s2_bwd(gy, tap, N, H, W, C, dx, (hipStream_t)stream));
+int hifihr_maxpool2d_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, int k, int s, int p, float* dx,
+                         void* stream) {
+  if (!gy || !tap || !dx || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0 || !pool_ok(k, s, p) || H + 2 * p < k || W + 2 * p < k)
+    return fail(HIFIHR_EINVAL, "hifihr_maxpool2d_bwd: bad argument (C % 4 == 0; (k,s,p) in {(3,2,1), (3,1,1), (2,2,0)})");
+  HIP_TRY(hifihr::launch_maxpool_bwd(gy, tap, N, H, W, C, k, s, p, dx, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_bias_relu_bwd(const float* dy, const float* y, long M, int C, float* g, float* db_acc, void* stream) {
+  if (!dy || !y || !g || M <= 0 || C < 4 || C % 4 != 0 || C > 256)
+    return fail(HIFIHR_EINVAL, "hifihr_bias_relu_bwd: bad argument (C % 4 == 0, C <= 256)");
+  HIP_TRY(hifihr::launch_bias_relu_bwd(dy, y, M, C, g, db_acc, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

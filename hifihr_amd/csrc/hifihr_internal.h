@@ -54,6 +54,7 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
 // forward: src = x, dst = y (ih = oh*stride - pad + r); dgrad = 1: src = dy, dst = dx (ih = (oh + pad - r)/stride).
 struct ConvGeom {
   int N, IH, IW, IC, OH, OW, OC, R, S, stride, pad, dgrad;
+  int relu;      // forward only: clamp the output at 0 after the bias
 };
 // sk_ws (may be NULL): zero-initialised, self-cleaning workspace of conv_sk_workspace_bytes(g) bytes for the balanced schedule
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
@@ -94,8 +95,13 @@ hipError_t launch_mmpool_fwd(const float* x, const float* p, int B, int HW, int 
                              hipStream_t st);
 hipError_t launch_mmpool_bwd(const float* gy, const float* p, const int* argmax, const float* xmax, const float* xavg, int B, int HW,
                              int C, float* dx, float* dp_acc, hipStream_t st);
-hipError_t launch_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* tap, hipStream_t st);
-hipError_t launch_maxpool3x3s2_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, float* dx, hipStream_t st);
+// nn.MaxPool2d(k, s, p) for (k, s, p) in {(3, 2, 1), (3, 1, 1), (2, 2, 0)}
+hipError_t launch_maxpool_fwd(const float* x, int N, int H, int W, int C, int k, int s, int p, float* y, unsigned char* tap,
+                              hipStream_t st);
+hipError_t launch_maxpool_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, int k, int s, int p, float* dx,
+                              hipStream_t st);
+// g = dy * (y > 0), db_acc[c] += sum over rows of g   (conv + bias + ReLU backward; g may alias dy)
+hipError_t launch_bias_relu_bwd(const float* dy, const float* y, long M, int C, float* g, float* db_acc, hipStream_t st);
 
 // geometry loss terms (losses.hip): k = 0 joint_3d, 1 vert_3d, 2 edge_length, 3 mshape, 4 mpose
 struct GeomLossArgs {

@@ -4,10 +4,12 @@
 //                      y = max_hw(x) * w + mean_hw(x) * (1 - w), w = sigmoid(p), p a learned scalar.  One kernel per
 //                      direction instead of adaptive_max_pool2d + adaptive_avg_pool2d + sigmoid + 4 elementwise ops
 //                      (the ATen adaptive max pool alone took 143 us per step in round 1's profile).
-//   maxpool3x3s2_fwd/bwd   nn.MaxPool2d(3, 2, 1) after the ResNet stem (torchvision resnet18.maxpool as the reference
-//                      builds it, network/res_encoder.py:345-373).  The forward stores the winning tap (0..8, first
+//   maxpool_fwd/bwd    nn.MaxPool2d(3, 2, 1) after the ResNet stem (torchvision resnet18.maxpool as the reference
+//                      builds it, network/res_encoder.py:345-373) and the MaxPool2d(3, 1, 1) / MaxPool2d(2, 2) of the
+//                      LightEstimator (network/res_encoder.py:150-210).  The forward stores the winning tap (first
 //                      maximum in scan order like ATen) as one byte; the backward GATHERS (every input pixel looks at
-//                      the <= 4 windows that contain it), so dx is written exactly once and needs no zero fill.
+//                      the windows that contain it), so dx is written exactly once and needs no zero fill.
+//   bias_relu_bwd      backward of the LightEstimator's conv + bias + ReLU epilogue: masked gradient + bias gradient.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -113,10 +115,11 @@ hipError_t launch_mmpool_bwd(const float* gy, const float* p, const int* argmax,
 }
 
 // ------------------------------------------------------------------------------------------------
-// MaxPool2d(kernel 3, stride 2, padding 1): thread = (output pixel, 4 channels)
+// MaxPool2d(K, S, P): thread = (output pixel, 4 channels)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int OH, int OW,
-                                                              float* __restrict__ y, unsigned char* __restrict__ tap) {
+template <int K, int S, int P>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int OH, int OW,
+                                                         float* __restrict__ y, unsigned char* __restrict__ tap) {
   const int C4 = C / 4;
   const size_t total = (size_t)N * OH * OW * C4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -129,14 +132,14 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const float* __re
     int4 mt = make_int4(0, 0, 0, 0);
     bool first = true;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int ih = oh * 2 - 1 + r;
+    for (int r = 0; r < K; ++r) {
+      const int ih = oh * S - P + r;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int iw = ow * 2 - 1 + s;
+      for (int s = 0; s < K; ++s) {
+        const int iw = ow * S - P + s;
         if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
         const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + ih) * W + iw) * C + cg * 4);
-        const int t = r * 3 + s;
+        const int t = r * K + s;
         // ATen: (val > maxval) || isnan(val), starting from the first in-range tap
         if (first || v.x > m.x || v.x != v.x) { m.x = v.x; mt.x = t; }
         if (first || v.y > m.y || v.y != v.y) { m.y = v.y; mt.y = t; }
@@ -151,8 +154,9 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const float* __re
 }
 
 // thread = (input pixel, 4 channels): sum gy over the windows whose winning tap is this pixel
-__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ tap, int N,
-                                                              int H, int W, int C, int OH, int OW, float* __restrict__ dx) {
+template <int K, int S, int P>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ tap, int N, int H,
+                                                         int W, int C, int OH, int OW, float* __restrict__ dx) {
   const int C4 = C / 4;
   const size_t total = (size_t)N * H * W * C4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -162,23 +166,23 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __re
     const int ih = (int)(rest % H);
     const int n = (int)(rest / H);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    // windows oh with oh*2 - 1 + r == ih, r in 0..2  ->  oh in {(ih+1)/2 (r = ih+1-2*oh), ...}
+    // windows oh with oh * S - P + r == ih, r in 0..K-1
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int th = ih + 1 - r;
-      if (th < 0 || (th & 1)) continue;
-      const int oh = th >> 1;
+    for (int r = 0; r < K; ++r) {
+      const int th = ih + P - r;
+      if (th < 0 || (th % S) != 0) continue;
+      const int oh = th / S;
       if (oh >= OH) continue;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int tw = iw + 1 - s;
-        if (tw < 0 || (tw & 1)) continue;
-        const int ow = tw >> 1;
+      for (int s = 0; s < K; ++s) {
+        const int tw = iw + P - s;
+        if (tw < 0 || (tw % S) != 0) continue;
+        const int ow = tw / S;
         if (ow >= OW) continue;
         const size_t o = ((((size_t)n * OH + oh) * OW + ow) * C4 + cg) * 4;
         const uchar4 t = *reinterpret_cast<const uchar4*>(tap + o);
         const float4 g = *reinterpret_cast<const float4*>(gy + o);
-        const unsigned char me = (unsigned char)(r * 3 + s);
+        const unsigned char me = (unsigned char)(r * K + s);
         if (t.x == me) a.x += g.x;
         if (t.y == me) a.y += g.y;
         if (t.z == me) a.z += g.z;
@@ -196,19 +200,65 @@ static unsigned pool_grid(size_t total) {
   return (unsigned)blocks;
 }
 
-hipError_t launch_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* tap, hipStream_t st) {
+hipError_t launch_maxpool_fwd(const float* x, int N, int H, int W, int C, int k, int s, int p, float* y, unsigned char* tap,
+                              hipStream_t st) {
   if (C % 4 != 0) return hipErrorInvalidValue;
-  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(pool_grid((size_t)N * OH * OW * (C / 4))), dim3(256), 0, st, x, N, H, W, C, OH, OW, y,
-                     tap);
+  const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+  const dim3 grid(pool_grid((size_t)N * OH * OW * (C / 4)));
+  if (k == 3 && s == 2 && p == 1) hipLaunchKernelGGL((maxpool_fwd_kernel<3, 2, 1>), grid, dim3(256), 0, st, x, N, H, W, C, OH, OW, y, tap);
+  else if (k == 3 && s == 1 && p == 1) hipLaunchKernelGGL((maxpool_fwd_kernel<3, 1, 1>), grid, dim3(256), 0, st, x, N, H, W, C, OH, OW, y, tap);
+  else if (k == 2 && s == 2 && p == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<2, 2, 0>), grid, dim3(256), 0, st, x, N, H, W, C, OH, OW, y, tap);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
-hipError_t launch_maxpool3x3s2_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, float* dx, hipStream_t st) {
+hipError_t launch_maxpool_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, int k, int s, int p, float* dx,
+                              hipStream_t st) {
   if (C % 4 != 0) return hipErrorInvalidValue;
-  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(pool_grid((size_t)N * H * W * (C / 4))), dim3(256), 0, st, gy, tap, N, H, W, C, OH, OW,
-                     dx);
+  const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+  const dim3 grid(pool_grid((size_t)N * H * W * (C / 4)));
+  if (k == 3 && s == 2 && p == 1) hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, st, gy, tap, N, H, W, C, OH, OW, dx);
+  else if (k == 3 && s == 1 && p == 1) hipLaunchKernelGGL((maxpool_bwd_kernel<3, 1, 1>), grid, dim3(256), 0, st, gy, tap, N, H, W, C, OH, OW, dx);
+  else if (k == 2 && s == 2 && p == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<2, 2, 0>), grid, dim3(256), 0, st, gy, tap, N, H, W, C, OH, OW, dx);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv + bias + ReLU backward: g = dy * (y > 0), db_acc[c] += sum_rows g      (tiny tensors: LightEstimator)
+// workgroup = 64 rows x all channels; thread = (row lane, float4 channel group); per-channel sums through LDS + atomics
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long M, int C,
+                                                           float* __restrict__ g, float* __restrict__ db_acc) {
+  __shared__ float sums[256];
+  const int C4 = C / 4;                              // C4 <= 64 (checked by the launcher): RL = 256 / C4 rows per pass
+  const int RL = 256 / C4;
+  const int cg = threadIdx.x % C4, rl = threadIdx.x / C4;
+  for (int c = threadIdx.x; c < C; c += 256) sums[c] = 0.f;
+  __syncthreads();
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rl < RL) {
+    for (long m = (long)blockIdx.x * RL + rl; m < M; m += (long)gridDim.x * RL) {
+      const size_t o = (size_t)m * C + cg * 4;
+      float4 v = *reinterpret_cast<const float4*>(dy + o);
+      const float4 yy = *reinterpret_cast<const float4*>(y + o);
+      v.x = yy.x > 0.f ? v.x : 0.f; v.y = yy.y > 0.f ? v.y : 0.f; v.z = yy.z > 0.f ? v.z : 0.f; v.w = yy.w > 0.f ? v.w : 0.f;
+      *reinterpret_cast<float4*>(g + o) = v;
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    atomicAdd(&sums[cg * 4], a.x); atomicAdd(&sums[cg * 4 + 1], a.y); atomicAdd(&sums[cg * 4 + 2], a.z); atomicAdd(&sums[cg * 4 + 3], a.w);
+  }
+  __syncthreads();
+  if (db_acc != nullptr)
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(db_acc + c, sums[c]);
+}
+
+hipError_t launch_bias_relu_bwd(const float* dy, const float* y, long M, int C, float* g, float* db_acc, hipStream_t st) {
+  if (C % 4 != 0 || C > 256) return hipErrorInvalidValue;
+  const int RL = 256 / (C / 4);
+  long blocks = (M + RL - 1) / RL;
+  if (blocks > 64) blocks = 64;                      // few workgroups: the per-channel atomics stay uncontended
+  hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, M, C, g, db_acc);
   return hipGetLastError();
 }
 

@@ -61,7 +61,7 @@ class Model(nn.Module):
                                                    shininess=30.0, background=(1.0,) * 3)
             self.register_buffer("vertex_colors", torch.tensor(SKIN_TONE).repeat(778, 1), persistent=False)
         if ifLight:
-            self.light_estimator = LightEstimator(self.low_feat_dim)
+            self.light_estimator = LightEstimator(self.low_feat_dim, conv_impl=conv_impl)
 
     def get_ndc_fx_fy_cx_cy(self, Ks):
         s = float(self.image_size)

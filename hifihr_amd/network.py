@@ -37,15 +37,21 @@ class Conv2dMFMA(nn.Module):
     GEMM kernels (hifihr_amd/csrc/conv.hip).  The weight keeps torch's logical [K,C,R,S] shape (state-dict
     compatible with the reference) in channels_last memory format = the kernel's physical [K][R][S][C]."""
 
-    def __init__(self, cin, cout, k, stride=1, pad=0):
+    def __init__(self, cin, cout, k, stride=1, pad=0, bias=False):
         super().__init__()
         self.stride, self.pad = stride, pad
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last))
         init.kaiming_uniform_(self.weight, a=5 ** 0.5)                 # nn.Conv2d's default initialisation
+        self.bias = None
+        if bias:                                                       # LightEstimator convolutions (always followed by ReLU)
+            bound = 1.0 / (cin * k * k) ** 0.5
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
 
     def forward(self, x, want_stats=False):
         from . import ops
         w = self.weight
+        if self.bias is not None:
+            return ops.conv2d_bias_relu(x, w, self.bias, self.stride, self.pad)      # conv + bias + ReLU, one launch
         if w.shape[1] % 4 != 0:                       # the 3-channel stem: input arrives as NHWC4, pad the weight
             w = F.pad(w, (0, 0, 0, 0, 0, 4 - w.shape[1] % 4)).contiguous(memory_format=torch.channels_last)
         return ops.conv2d(x, w, self.stride, self.pad, want_stats)
@@ -255,21 +261,34 @@ class HandEncoder(nn.Module):
 
 
 class LightEstimator(nn.Module):
-    def __init__(self, in_dim=512):
+    """conv_impl="mfma": the three convolutions (+ bias + ReLU fused) and the two max-pools run on the hand-written
+    kernels on channels_last activations; same module indices / state-dict names as the reference's nn.Sequential."""
+
+    def __init__(self, in_dim=512, conv_impl="aten"):
         super().__init__()
+        self.conv_impl = conv_impl
+        mk = (lambda ci, co, k, s: Conv2dMFMA(ci, co, k, s, 0, bias=True)) if conv_impl == "mfma" else \
+            (lambda ci, co, k, s: nn.Conv2d(ci, co, k, s))
         if in_dim == 32:                       # efficientnet-b3 low features [b,32,56,56]
-            conv1 = nn.Conv2d(32, 48, kernel_size=1, stride=4)
+            conv1 = mk(32, 48, 1, 4)
         else:                                  # [b,in_dim,28,28] (512 in the reference; 128 for res18, SURVEY.md F6)
-            conv1 = nn.Conv2d(in_dim, 48, kernel_size=1, stride=2)
-        self.base_layers = nn.Sequential(conv1, nn.ReLU(inplace=True), nn.Conv2d(48, 48, 3, 1), nn.ReLU(inplace=True),
-                                         nn.MaxPool2d(3, 1, 1), nn.Conv2d(48, 64, 3, 2), nn.ReLU(inplace=True),
+            conv1 = mk(in_dim, 48, 1, 2)
+        self.base_layers = nn.Sequential(conv1, nn.ReLU(inplace=True), mk(48, 48, 3, 1), nn.ReLU(inplace=True),
+                                         nn.MaxPool2d(3, 1, 1), mk(48, 64, 3, 2), nn.ReLU(inplace=True),
                                          nn.MaxPool2d(2, 2))
         self.light_reg = nn.Sequential(nn.Linear(256, 64), nn.ReLU(inplace=True), nn.Linear(64, 6))
         self.light_reg.apply(weights_init)
         self.hardtanh = nn.Hardtanh()
 
     def forward(self, low_features):
-        base = self.base_layers(low_features)
+        if self.conv_impl == "mfma":
+            from . import ops
+            bl = self.base_layers
+            x = bl[2](bl[0](low_features))                      # conv + bias + ReLU each
+            x = bl[5](ops.maxpool2d(x, 3, 1, 1))
+            base = ops.maxpool2d(x, 2, 2, 0)
+        else:
+            base = self.base_layers(low_features)
         flat = base.reshape(base.shape[0], -1)
         if flat.is_cuda:
             from . import ops

@@ -260,7 +260,7 @@ def _conv_ws(lib, device, geom, bwd):
 
 class _Conv2dMFMA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, pad, want_stats=False):
+    def forward(ctx, x, w, stride, pad, want_stats=False, bias=None, relu=False):
         require_cuda(x, w)
         lib = get_lib()
         x = x.contiguous(memory_format=_CL)
@@ -276,11 +276,12 @@ class _Conv2dMFMA(torch.autograd.Function):
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), False)
             PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd_bnstats(x, wk, y, stats, N, H, W, C, K, R, S, stride, pad, ws=ws))
         else:
-            ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), False)
-            PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, None, y, N, H, W, C, K, R, S, stride, pad, ws=ws))
+            ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), False) if (bias is None and not relu) else None
+            PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, bias, y, N, H, W, C, K, R, S, stride, pad, ws=ws,
+                                                              act=1 if relu else 0))
         ctx.geom = (N, H, W, C, K, R, S, stride, pad)
-        ctx.save_for_backward(x, wk)
-        ctx.w_param = w
+        ctx.save_for_backward(x, wk, y if relu else None)
+        ctx.w_param, ctx.b_param, ctx.relu = w, bias, relu
         ctx.set_materialize_grads(False)         # no zero-fill launch for the (non-differentiable) stats output
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -289,13 +290,25 @@ class _Conv2dMFMA(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gstats=None):
-        x, wk = ctx.saved_tensors
+        x, wk, y = ctx.saved_tensors
         lib = get_lib()
         N, H, W, C, K, R, S, stride, pad = ctx.geom
         if gy is None:
-            return None, None, None, None, None
+            return (None,) * 7
         gy = gy.contiguous(memory_format=_CL)
-        dx = dw = None
+        dx = dw = db_ret = None
+        if ctx.relu or ctx.b_param is not None:
+            # conv + bias (+ ReLU) epilogue: masked gradient and the bias gradient in one small launch
+            b = ctx.b_param
+            db_t, db_ret = _acc_target(b, b.shape, gy.device) if (b is not None and ctx.needs_input_grad[5]) else (None, None)
+            if not ctx.relu:
+                raise NotImplementedError("conv bias without ReLU")           # no layer of the reference needs it
+            g = torch.empty_like(gy, memory_format=_CL)
+            M = gy.numel() // K
+            PROFILE.bracket("bias_relu_bwd", lambda: lib.bias_relu_bwd(gy, y, M, K, g, db_t))
+            gy = g
+            if b is not None and db_t is not None and db_ret is None:
+                _grad_ready(b)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=_CL)
             scratch = torch.empty(wk.numel(), device=x.device, dtype=torch.float32)
@@ -312,7 +325,12 @@ class _Conv2dMFMA(torch.autograd.Function):
             PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, tgt, N, H, W, C, K, R, S, stride, pad))
             if dw is None:
                 _grad_ready(w)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, db_ret, None
+
+
+def conv2d_bias_relu(x, w, bias, stride=1, pad=0):
+    """relu(F.conv2d(x, w, bias, stride, pad)) in one launch (LightEstimator, reference network/res_encoder.py:150-210)."""
+    return _Conv2dMFMA.apply(x, w, stride, pad, False, bias, True)
 
 
 def conv2d(x, w, stride=1, pad=0, want_stats=False):
@@ -618,33 +636,38 @@ def mmpool(x, p):
     return _MMPool.apply(x, p)
 
 
-class _MaxPool3x3s2(torch.autograd.Function):
+class _MaxPool2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, k, s, p):
         require_cuda(x)
         x = x.contiguous(memory_format=_CL)
         N, C, H, W = x.shape
-        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         y = torch.empty((N, C, OH, OW), device=x.device, memory_format=_CL)
         tap = torch.empty(N * OH * OW * C, dtype=torch.uint8, device=x.device)
-        PROFILE.bracket("maxpool_fwd", lambda: get_lib().maxpool3x3s2_fwd(x, N, H, W, C, y, tap))
+        PROFILE.bracket("maxpool_fwd", lambda: get_lib().maxpool2d_fwd(x, N, H, W, C, k, s, p, y, tap))
         ctx.save_for_backward(tap)
-        ctx.shape = (N, C, H, W)
+        ctx.cfg = (N, C, H, W, k, s, p)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         tap, = ctx.saved_tensors
-        N, C, H, W = ctx.shape
+        N, C, H, W, k, s, p = ctx.cfg
         gy = gy.contiguous(memory_format=_CL)
         dx = torch.empty((N, C, H, W), device=gy.device, memory_format=_CL)
-        PROFILE.bracket("maxpool_bwd", lambda: get_lib().maxpool3x3s2_bwd(gy, tap, N, H, W, C, dx))
-        return dx
+        PROFILE.bracket("maxpool_bwd", lambda: get_lib().maxpool2d_bwd(gy, tap, N, H, W, C, k, s, p, dx))
+        return dx, None, None, None
+
+
+def maxpool2d(x, k, s, p):
+    """nn.MaxPool2d(k, s, p) on channels_last activations, (k, s, p) in {(3,2,1), (3,1,1), (2,2,0)}."""
+    return _MaxPool2d.apply(x, k, s, p)
 
 
 def maxpool3x3s2(x):
     """nn.MaxPool2d(3, 2, 1) on channels_last activations (the ResNet stem pool)."""
-    return _MaxPool3x3s2.apply(x)
+    return _MaxPool2d.apply(x, 3, 2, 1)
 
 
 def image_to_nhwc4(images):

@@ -150,8 +150,12 @@ int hifihr_adam_step_dyn(float* params_d, const float* grads_d, float* exp_avg_d
  * summation order across K segments).
  * ---------------------------------------------------------------------------------------------- */
 size_t hifihr_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int bwd_data);
-int hifihr_conv2d_fwd(const float* x_d, const float* w_d, const float* bias_d /* [K] or NULL */, float* y_d, int N, int H,
-                      int W, int C, int K, int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
+/* act: 0 = none, 1 = ReLU after the bias (nn.Conv2d + nn.ReLU of the LightEstimator, network/res_encoder.py:150-210; its
+ * backward first runs hifihr_bias_relu_bwd: g = dy * (y > 0) (g_d may alias dy_d), db_acc_d[K] += column sums of g). */
+int hifihr_conv2d_fwd(const float* x_d, const float* w_d, const float* bias_d /* [K] or NULL */, int act, float* y_d, int N,
+                      int H, int W, int C, int K, int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
+int hifihr_bias_relu_bwd(const float* dy_d, const float* y_d, long M, int C, float* g_d, float* db_acc_d /* or NULL */,
+                         void* stream);
 /* dx[N][H][W][C] (overwritten).  wt_scratch_d: K*R*S*C floats of scratch (receives the [C][R][S][K] transpose). */
 int hifihr_conv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, float* wt_scratch_d, int N, int H, int W, int C,
                            int K, int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
@@ -209,16 +213,19 @@ int hifihr_dwconv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d,
  *   y[B][C] = max_hw(x) * w + mean_hw(x) * (1 - w), w = sigmoid(p_d[0]); x[B][HW][C].  fwd also writes argmax[B][C] (first
  *   maximum in scan order, like adaptive_max_pool2d), xmax[B][C], xavg[B][C] for the backward.
  *   bwd: dx[B][HW][C] (overwritten) and dp_acc_d[0] += d loss / d p (may be NULL).
- * maxpool3x3s2: nn.MaxPool2d(3, 2, 1) after the ResNet stem (network/res_encoder.py:345-373, torchvision resnet18.maxpool):
- *   y[N][OH][OW][C], OH = (H-1)/2 + 1; tap_d[N][OH][OW][C] bytes = winning tap 0..8 (first maximum in scan order).
+ * maxpool2d: nn.MaxPool2d(k, s, p) for (k, s, p) = (3, 2, 1) (after the ResNet stem, network/res_encoder.py:345-373,
+ *   torchvision resnet18.maxpool), (3, 1, 1) and (2, 2, 0) (LightEstimator, network/res_encoder.py:150-210):
+ *   y[N][OH][OW][C], OH = (H + 2p - k)/s + 1; tap_d[N][OH][OW][C] bytes = winning tap (first maximum in scan order).
  *   bwd gathers: dx[N][H][W][C] is overwritten (no zero fill needed).
  * ---------------------------------------------------------------------------------------------- */
 int hifihr_mmpool_fwd(const float* x_d, const float* p_d, int B, int HW, int C, float* y_d, int* argmax_d, float* xmax_d,
                       float* xavg_d, void* stream);
 int hifihr_mmpool_bwd(const float* gy_d, const float* p_d, const int* argmax_d, const float* xmax_d, const float* xavg_d, int B,
                       int HW, int C, float* dx_d, float* dp_acc_d, void* stream);
-int hifihr_maxpool3x3s2_fwd(const float* x_d, int N, int H, int W, int C, float* y_d, unsigned char* tap_d, void* stream);
-int hifihr_maxpool3x3s2_bwd(const float* gy_d, const unsigned char* tap_d, int N, int H, int W, int C, float* dx_d, void* stream);
+int hifihr_maxpool2d_fwd(const float* x_d, int N, int H, int W, int C, int k, int s, int p, float* y_d, unsigned char* tap_d,
+                         void* stream);
+int hifihr_maxpool2d_bwd(const float* gy_d, const unsigned char* tap_d, int N, int H, int W, int C, int k, int s, int p,
+                         float* dx_d, void* stream);
 
 /* normalize_batch_3C (reference network/res_encoder.py:212-216) fused with NCHW[B][3][H][W] -> NHWC4 [B][H][W][4]
  * (4th channel zero) for the first convolution. */

@@ -386,7 +386,7 @@ def mmpool_case(lib, device, B, H, W, C, p0=0.3, seed=0, ties=False):
     out = torch.empty(B, C, device=device); am = torch.empty(B, C, dtype=torch.int32, device=device)
     xmax, xavg = torch.empty_like(out), torch.empty_like(out)
     lib.mmpool_fwd(xd, pd, B, H * W, C, out, am, xmax, xavg)
-    assert float((out.cpu() - y.detach()).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max())), "mmpool fwd"
+    assert float((out.cpu() - y.detach()).abs().max()) <= 1e-5 * max(1.0, float(y.detach().abs().max())), "mmpool fwd"
     _, ref_idx = F.adaptive_max_pool2d(x, (1, 1), return_indices=True)
     assert torch.equal(am.cpu().long(), ref_idx.reshape(B, C)), "mmpool argmax (first maximum in scan order)"
     dx = torch.empty(B, H, W, C, device=device); dp = torch.full((1,), 0.25, device=device)
@@ -396,26 +396,28 @@ def mmpool_case(lib, device, B, H, W, C, p0=0.3, seed=0, ties=False):
     assert abs(float(dp.cpu()) - 0.25 - float(pr.grad)) <= 1e-4 * max(1.0, abs(float(pr.grad))), "mmpool dp (accumulates)"
 
 
-def maxpool_case(lib, device, N, H, W, C, seed=0, ties=False):
-    """nn.MaxPool2d(3, 2, 1) forward / backward on NHWC."""
+def maxpool_case(lib, device, N, H, W, C, seed=0, ties=False, ksp=(3, 2, 1)):
+    """nn.MaxPool2d(k, s, p) forward / backward on NHWC."""
+    k, s_, p_ = ksp
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(seed)
     x = torch.randn(N, C, H, W, generator=gen)
     if ties:
         x = torch.relu(x)                          # post-ReLU activations: many exact zeros tie inside a window
     xr = x.clone().requires_grad_(True)
-    y = F.max_pool2d(xr, 3, 2, 1)
+    y = F.max_pool2d(xr, k, s_, p_)
     gy = torch.randn(y.shape, generator=gen)
     y.backward(gy)
     OH, OW = y.shape[2], y.shape[3]
     xd = x.permute(0, 2, 3, 1).contiguous().to(device)
     out = torch.empty(N, OH, OW, C, device=device); tap = torch.empty(N * OH * OW * C, dtype=torch.uint8, device=device)
-    lib.maxpool3x3s2_fwd(xd, N, H, W, C, out, tap)
+    lib.maxpool2d_fwd(xd, N, H, W, C, k, s_, p_, out, tap)
     assert torch.equal(out.cpu(), y.detach().permute(0, 2, 3, 1)), "maxpool fwd (exact)"
     dx = torch.full((N, H, W, C), 7.0, device=device)          # overwritten, not accumulated
-    lib.maxpool3x3s2_bwd(gy.permute(0, 2, 3, 1).contiguous().to(device), tap, N, H, W, C, dx)
+    lib.maxpool2d_bwd(gy.permute(0, 2, 3, 1).contiguous().to(device), tap, N, H, W, C, k, s_, p_, dx)
     refdx = xr.grad.permute(0, 2, 3, 1)
-    assert float((dx.cpu() - refdx).abs().max()) <= 1e-6, "maxpool bwd"
+    # overlapping windows (stride < kernel): several gradients are summed per input pixel, in a different order than ATen
+    assert float((dx.cpu() - refdx).abs().max()) <= 1e-6 + 2e-6 * float(refdx.abs().max()), "maxpool bwd"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -550,3 +552,31 @@ def linear_case(lib, device, B, I, O, act, bn, seed=0, need_dx=True):
     if bn:
         rel(dg - 0.125, gr.grad, "dgamma")
         rel(dbt - 2.0, ber.grad, "dbeta")
+
+
+def conv_bias_relu_case(lib, device, N, H, W, C, K, R, stride, seed=0):
+    """conv + bias + ReLU in one launch (act = 1) and its backward prologue bias_relu_bwd, vs torch."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=gen); w = torch.randn(K, C, R, R, generator=gen) / (C * R * R) ** 0.5
+    b = torch.randn(K, generator=gen) * 0.3
+    br = b.clone().requires_grad_(True)
+    z = F.conv2d(x, w, br, stride=stride)
+    z.retain_grad()
+    y = F.relu(z)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    OH, OW = y.shape[2], y.shape[3]
+    d = lambda t: t.to(device).contiguous()
+    out = torch.empty(N, OH, OW, K, device=device)
+    lib.conv2d_fwd(d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), d(b), out, N, H, W, C, K, R, R, stride, 0, act=1)
+    ref = y.detach().permute(0, 2, 3, 1)
+    assert float((out.cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6, "conv+bias+relu fwd"
+    g = torch.full_like(out, 7.0); db = torch.full((K,), 0.5, device=device)
+    lib.bias_relu_bwd(d(gy.permute(0, 2, 3, 1)), out, N * OH * OW, K, g, db)
+    # the mask comes from OUR y (elements within rounding of 0 may differ from torch's): compare where |z| is not tiny
+    zr = z.detach().permute(0, 2, 3, 1)
+    safe = zr.abs() > 1e-5
+    refg = z.grad.permute(0, 2, 3, 1)
+    assert float(((g.cpu() - refg) * safe).abs().max()) <= 1e-6, "masked gradient"
+    assert float((db.cpu() - 0.5 - br.grad).abs().max()) <= 1e-4 * float(br.grad.abs().max()) + 1e-5, "bias gradient (accumulates)"

@@ -39,3 +39,14 @@ def test_photo_losses(lib, B, with_g):
                                           (32, 32, 3, 0, False), (128, 512, 128, 1, False), (64, 1536, 1024, 1, True)])
 def test_linear_heads(lib, B, I, O, act, bn):
     kc.linear_case(lib, "cuda", B, I, O, act, bn, seed=I + O)
+
+
+@pytest.mark.parametrize("N,H,C,K,R,stride", [(32, 28, 128, 48, 1, 2), (32, 14, 48, 48, 3, 1), (32, 12, 48, 64, 3, 2), (32, 56, 32, 48, 1, 4)])
+def test_light_estimator_convs(lib, N, H, C, K, R, stride):
+    kc.conv_bias_relu_case(lib, "cuda", N, H, H, C, K, R, stride, seed=C + K)
+    kc.conv_case(lib, "cuda", N, H, H, C, K, R, stride, 0, seed=K)          # dgrad / wgrad of the same geometry
+
+
+@pytest.mark.parametrize("N,H,C,ksp", [(32, 12, 48, (3, 1, 1)), (32, 5, 64, (2, 2, 0))])
+def test_light_estimator_pools(lib, N, H, C, ksp):
+    kc.maxpool_case(lib, "cuda", N, H, H, C, seed=C, ties=True, ksp=ksp)

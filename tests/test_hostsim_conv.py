@@ -39,3 +39,9 @@ def test_conv_balanced_schedule_bnstats(hostsim_lib):
 
 def test_image_to_nhwc4(hostsim_lib):
     kc.image_to_nhwc4_case(hostsim_lib, "cpu")
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride", [(2, 8, 8, 128, 48, 1, 2), (1, 7, 7, 48, 48, 3, 1), (2, 6, 6, 48, 64, 3, 2), (1, 8, 8, 32, 48, 1, 4)])
+def test_conv_bias_relu(hostsim_lib, N, H, W, C, K, R, stride):
+    """LightEstimator layers: conv + bias + ReLU in one launch and the masked-gradient / bias-gradient kernel."""
+    kc.conv_bias_relu_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, seed=C + K)

@@ -17,3 +17,8 @@ def test_mmpool(hostsim_lib, B, H, W, C, ties):
 @pytest.mark.parametrize("N,H,W,C,ties", [(2, 12, 12, 16, False), (1, 9, 7, 8, True), (2, 5, 6, 4, True), (1, 1, 1, 4, False)])
 def test_maxpool3x3s2(hostsim_lib, N, H, W, C, ties):
     kc.maxpool_case(hostsim_lib, "cpu", N, H, W, C, seed=H, ties=ties)
+
+
+@pytest.mark.parametrize("N,H,W,C,ksp", [(2, 12, 12, 48, (3, 1, 1)), (1, 5, 5, 64, (2, 2, 0)), (2, 7, 6, 8, (3, 1, 1)), (1, 4, 6, 4, (2, 2, 0))])
+def test_maxpool_light_estimator_shapes(hostsim_lib, N, H, W, C, ksp):
+    kc.maxpool_case(hostsim_lib, "cpu", N, H, W, C, seed=H + C, ties=True, ksp=ksp)
