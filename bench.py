@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--encoder", default="res18", choices=["res18", "effb3"], help="res18 = BASELINE configs[1] (headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as one hipGraph, 0: eager, -1: auto (on for 1 GPU)")
+    ap.add_argument("--graph", type=int, default=-1, help="0: eager; -1 or 1: hipGraph replay (N = 1: whole step; N > 1: forward + backward, then all-reduce + Adam); 2: force the N > 1 form")
     ap.add_argument("--cpu-batch", type=int, default=8, help="sample size of the CPU baseline (images)")
     return ap.parse_args()
 
@@ -118,19 +118,22 @@ def main():
         torch.cuda.synchronize()
         render_us = e0.elapsed_time(e1) * 1e3 / 20
 
-    use_graph = (a.graph == 1) or (a.graph == -1 and world == 1)
+    use_graph = a.graph != 0
+    split = world > 1 or a.graph == 2        # data parallel: graph = forward + backward, then all-reduce + Adam eagerly
     graph_note = "eager"
     if use_graph:
         try:
             from hifihr_amd.traineval import GraphedTrainStep
-            gstep = GraphedTrainStep(model, loss_func, opt, examples, args_ns)
+            gstep = GraphedTrainStep(model, loss_func, opt, examples, args_ns, reducer=reducer if split else None)
             step = gstep
-            graph_note = "hipGraph replay (whole step captured)"
+            graph_note = ("hipGraph replay of forward + backward, then bucketed all-reduce + fused Adam" if split
+                          else "hipGraph replay (whole step captured)")
             for _ in range(2):
                 step()
         except Exception as e:                          # capture is an optimisation; never fail the bench on it
             graph_note = f"eager (hipGraph capture failed: {type(e).__name__}: {str(e)[:200]})"
             opt.graph_mode = False
+            reducer.pause_hooks(False)
             torch.cuda.synchronize()
     torch.cuda.synchronize()
     if world > 1:

@@ -59,6 +59,7 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._done = [False] * n                         # a parameter may be reported twice (autograd hook + direct writer)
         self._handles = []
+        self._paused = False
         if self.world > 1:
             for i, p in enumerate(flat.params):
                 hook = self._make_hook(i)
@@ -82,7 +83,7 @@ class GradReducer:
 
     def _make_hook(self, i):
         def hook(_param):
-            if self._done[i]:
+            if self._paused or self._done[i]:
                 return
             self._done[i] = True
             b = self.param_bucket[i]
@@ -100,6 +101,20 @@ class GradReducer:
             for h in self._handles:
                 h.wait()
         self.reset()
+
+    def pause_hooks(self, paused: bool = True):
+        """Graph-replayed steps (traineval.GraphedTrainStep) exchange the gradients after the graph: the per-parameter
+        hooks must then neither count nor launch anything while backward is being captured."""
+        self._paused = paused
+        self.reset()
+
+    def all_reduce_flat(self):
+        """SUM all-reduce of the whole flat gradient buffer, one asynchronous call per bucket (pipelined), then wait."""
+        if self.world > 1:
+            handles = [dist.all_reduce(self.flat.grad[e_lo:e_hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                       for (_, _, e_lo, e_hi) in self.buckets]
+            for h in handles:
+                h.wait()
 
     @property
     def grad_scale(self) -> float:

@@ -42,8 +42,8 @@ def data_dic(sample, dat_name, set_name, args, device="cuda"):
     return ex
 
 
-def train_step(model, loss_func, optimizer, examples, args, dat_name="FreiHand", backward_hook=None):
-    """One iteration of train_an_epoch (train_hrnet.py:50-113), mode_train=True.  Returns (loss, loss_dic)."""
+def forward_backward(model, loss_func, optimizer, examples, args, dat_name="FreiHand"):
+    """Forward, losses, zero_grad and backward of one iteration (train_hrnet.py:50-104).  Returns (loss, loss_dic)."""
     root_xyz = examples["joints"][:, args.ROOT, :].unsqueeze(1)
     outputs = model(dat_name, True, examples["imgs"], Ks=examples["Ps"], root_xyz=root_xyz)
     ex = dict(examples)
@@ -57,6 +57,12 @@ def train_step(model, loss_func, optimizer, examples, args, dat_name="FreiHand",
     loss_dic["loss"] = loss
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
+    return loss, loss_dic
+
+
+def train_step(model, loss_func, optimizer, examples, args, dat_name="FreiHand", backward_hook=None):
+    """One iteration of train_an_epoch (train_hrnet.py:50-113), mode_train=True.  Returns (loss, loss_dic)."""
+    loss, loss_dic = forward_backward(model, loss_func, optimizer, examples, args, dat_name)
     if backward_hook is not None:
         backward_hook()                      # data-parallel gradient all-reduce (hifihr_amd/dist.py)
     optimizer.step()
@@ -64,32 +70,51 @@ def train_step(model, loss_func, optimizer, examples, args, dat_name="FreiHand",
 
 
 class GraphedTrainStep:
-    """The whole training iteration (forward, losses, backward, fused Adam) captured once into a hipGraph and
-    replayed: ~700 kernel launches per step collapse into one graph launch, which removes the host-side launch gaps
-    (the step is launch-bound in places: DESIGN.md section 6).  The batch lives in static device tensors that
-    `load_batch` overwrites in place; per-step Adam scalars are refreshed outside the graph (FusedAdam.prepare_step).
-    Single-process use; with data parallel ranks the eager `train_step` (bucketed all-reduce overlapped with
-    backward) is used instead.
+    """The training iteration captured once into a hipGraph and replayed: ~350 kernel launches per step collapse into one
+    graph launch, which removes the host-side launch gaps (the eager step is launch-bound in places: DESIGN.md section 6).
+    The batch lives in static device tensors that `load_batch` overwrites in place.
+
+    Single process (`reducer=None`): forward, losses, backward AND the fused Adam are in the graph; the per-step Adam
+    scalars are refreshed outside it (FusedAdam.prepare_step).
+    Data parallel (`reducer` = hifihr_amd.dist.GradReducer): the graph ends after backward; the flat gradient buffer is
+    then all-reduced (bucketed, asynchronous, RCCL) and the fused Adam step is launched eagerly -- no collective is ever
+    captured, each rank replays its own graph.  The exchange is not overlapped with backward in this mode (about 0.4 ms
+    for 47 MB over xGMI against the ~3.5 ms the launch gaps of the eager step cost).
+
     The model must never have run a step on the legacy default stream (autograd pins gradient accumulation to the
     stream of first use): callers do `torch.cuda.set_stream(torch.cuda.Stream())` before the first step."""
 
-    def __init__(self, model, loss_func, optimizer, examples, args, dat_name="FreiHand", warmup=3):
+    def __init__(self, model, loss_func, optimizer, examples, args, dat_name="FreiHand", warmup=3, reducer=None):
         self.model, self.loss_func, self.opt, self.args, self.dat_name = model, loss_func, optimizer, args, dat_name
+        self.reducer = reducer
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in examples.items()}
-        optimizer.enable_graph_mode()
+        split = reducer is not None
+        if split:
+            reducer.pause_hooks(True)                           # the graph must not contain (or trigger) collectives
+        else:
+            optimizer.enable_graph_mode()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up on a side stream (allocator + MIOpen/rocBLAS init)
             for _ in range(warmup):
-                optimizer.prepare_step()
-                train_step(model, loss_func, optimizer, self.static, args, dat_name)
+                if split:
+                    forward_backward(model, loss_func, optimizer, self.static, args, dat_name)
+                    reducer.all_reduce_flat()
+                    optimizer.step()
+                else:
+                    optimizer.prepare_step()
+                    train_step(model, loss_func, optimizer, self.static, args, dat_name)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        optimizer.prepare_step()
-        with torch.cuda.graph(self.graph):
-            self.loss, self.loss_dic = train_step(model, loss_func, optimizer, self.static, args, dat_name)
-        optimizer.step_count -= 1            # capturing records the step without executing it
+        if split:
+            with torch.cuda.graph(self.graph):
+                self.loss, self.loss_dic = forward_backward(model, loss_func, optimizer, self.static, args, dat_name)
+        else:
+            optimizer.prepare_step()
+            with torch.cuda.graph(self.graph):
+                self.loss, self.loss_dic = train_step(model, loss_func, optimizer, self.static, args, dat_name)
+            optimizer.step_count -= 1            # capturing records the step without executing it
 
     def load_batch(self, examples):
         for k, v in examples.items():
@@ -97,6 +122,11 @@ class GraphedTrainStep:
                 self.static[k].copy_(v, non_blocking=True)
 
     def __call__(self):
-        self.opt.prepare_step()
-        self.graph.replay()
+        if self.reducer is not None:
+            self.graph.replay()
+            self.reducer.all_reduce_flat()
+            self.opt.step()
+        else:
+            self.opt.prepare_step()
+            self.graph.replay()
         return self.loss, self.loss_dic

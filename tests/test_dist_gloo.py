@@ -79,7 +79,16 @@ def _worker(rank, world, port, ret):
         loss = torch.nn.functional.mse_loss(model(xs), ys)
         loss.backward()
         red.finish()
-    ret[rank] = (flat.grad * red.grad_scale).clone().numpy(), flat.flat.clone().numpy()
+    hooked = (flat.grad * red.grad_scale).clone()
+    # the graph-replay form of the step (traineval.GraphedTrainStep with a reducer): hooks paused during backward, the whole
+    # flat buffer exchanged afterwards -- must give the same gradient
+    red.pause_hooks(True)
+    flat.zero_grad()
+    torch.nn.functional.mse_loss(model(xs), ys).backward()
+    red.all_reduce_flat()
+    assert torch.allclose(flat.grad * red.grad_scale, hooked, atol=1e-7), "paused hooks + all_reduce_flat differs"
+    red.pause_hooks(False)
+    ret[rank] = hooked.numpy(), flat.flat.clone().numpy()
     dist.destroy_process_group()
 
 
