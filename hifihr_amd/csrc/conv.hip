@@ -677,24 +677,34 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   return hipGetLastError();
 }
 
+template <int BM, int BN>
+static void launch_wgrad_tile(const ConvGeom& g, int Q, int nch, int slots, const float* x, const float* dy, float* dw, hipStream_t st) {
+  const int tiles = ((g.OC + BM - 1) / BM) * ((Q + BN - 1) / BN);
+  // tiles * splits workgroups: stay at or just below the resident slots so that every CU gets the same number (the
+  // dispatcher spreads a grid evenly; 1152 workgroups on 1024 slots cost five rounds on some CUs: tools/conv_quant_probe.py)
+  int splits = slots / tiles;
+  if (const char* e = getenv("HIFIHR_WGRAD_SPLITS")) splits = atoi(e);
+  if (splits > nch / 4) splits = nch / 4;
+  if (splits < 1) splits = 1;
+  const int cps = (nch + splits - 1) / splits;
+  splits = (nch + cps - 1) / cps;
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN>), dim3((Q + BN - 1) / BN, (g.OC + BM - 1) / BM, splits), dim3(256), 0, st, g, x, dy, dw, cps);
+}
+
 hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {
   const long M = (long)g.N * g.OH * g.OW;
   const int Q = g.R * g.S * g.IC;
   if (g.IC % 4 != 0 || g.OC % 4 != 0) return hipErrorInvalidValue;
   const int nch = (int)((M + kBK - 1) / kBK);
-  const bool big = (g.OC % 128 == 0);
-  const int tiles = big ? ((g.OC + 127) / 128) * ((Q + 127) / 128) : ((g.OC + 63) / 64) * ((Q + 127) / 128);
-  // tiles * splits workgroups, 4 resident per CU (34 KB LDS): stay at or just below 256 * 4 so that every CU gets the same
-  // number (the dispatcher spreads a grid evenly; 1152 workgroups cost five rounds on some CUs: tools/conv_quant_probe.py)
-  int splits = 1024 / tiles;
-  if (splits > nch / 4) splits = nch / 4;
-  if (splits < 1) splits = 1;
-  const int cps = (nch + splits - 1) / splits;
-  splits = (nch + cps - 1) / cps;
-  if (big)
-    hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), dim3((Q + 127) / 128, (g.OC + 127) / 128, splits), dim3(256), 0, st, g, x, dy, dw, cps);
-  else
-    hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), dim3((Q + 127) / 128, (g.OC + 63) / 64, splits), dim3(256), 0, st, g, x, dy, dw, cps);
+  // 0: 128x128 (4 resident per CU), 1: 64x128, n >= 2: 64x64 with n workgroups per CU.  Measured at B = 32 (tools/time_wgrad.py):
+  // the atomic epilogue moves (workgroups x tile bytes), so below 512 output channels the 64x64 tile (a quarter of the atomic
+  // volume, 8 per CU) wins by 5-15 %; the 29.6 GFLOP layer-4 shapes keep the 128x128 tile (100 vs 81 TF).
+  int tile = (g.OC % 128 == 0 && g.OC >= 512) ? 0 : 8;
+  if (const char* e = getenv("HIFIHR_WGRAD_TILE")) tile = atoi(e);
+  const int cus = device_cus();
+  if (tile == 0) launch_wgrad_tile<128, 128>(g, Q, nch, cus * 4, x, dy, dw, st);
+  else if (tile == 1) launch_wgrad_tile<64, 128>(g, Q, nch, cus * 4, x, dy, dw, st);
+  else launch_wgrad_tile<64, 64>(g, Q, nch, cus * (tile == 2 ? 4 : tile), x, dy, dw, st);
   return hipGetLastError();
 }
 

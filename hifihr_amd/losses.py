@@ -83,9 +83,11 @@ ssim = ssim_torch      # backwards-compatible name used by tests
 class LossFunction:
     def __init__(self, perceptual=None, ssim_fn=None, fused=True):
         self.perceptual_loss = perceptual            # VGG19 weights are not available offline
+        self.ssim_loss_fn = None
         if ssim_fn is None:
             from . import ops
             ssim_fn = ops.ssim                       # fused HIP kernel (GPU only, no fallback)
+            self.ssim_loss_fn = ops.ssim_loss        # lambda * (1 - ssim) with the scalar glue folded in
         self.ssim_fn = ssim_fn
         self.fused = fused
 
@@ -138,7 +140,10 @@ class LossFunction:
                                                       args.lambda_mrgb, args.lambda_silhouette)
             tex, mrgb, sil, _ = out.unbind(0)
             loss_dic["texture"], loss_dic["mrgb"] = tex, mrgb
-            loss_dic["ssim_tex"] = args.lambda_ssim_tex * (1 - self.ssim_fn(re_img, mask_rgbs))
+            if self.ssim_loss_fn is not None:
+                loss_dic["ssim_tex"] = self.ssim_loss_fn(re_img, mask_rgbs, args.lambda_ssim_tex)
+            else:
+                loss_dic["ssim_tex"] = args.lambda_ssim_tex * (1 - self.ssim_fn(re_img, mask_rgbs))
             if "sil" in loss_used:
                 loss_dic["sil"] = sil
                 loss_used = [k for k in loss_used if k != "sil"]

@@ -69,6 +69,21 @@ class Model(nn.Module):
         prp = torch.stack([-(Ks[:, 0, 2] - s / 2) * 2 / s, -(Ks[:, 1, 2] - s / 2) * 2 / s], dim=-1)
         return focal, prp
 
+    def camera_from_K(self, Ks):
+        """cat([-fcl, prp]) of get_ndc_fx_fy_cx_cy as ONE affine map of the flattened intrinsics (an addmm launch instead of
+        ten elementwise ones): (fx, fy, px, py) = (-2 K00 / s, -2 K11 / s, 1 - 2 K02 / s, 1 - 2 K12 / s)."""
+        B, cols = Ks.shape[0], Ks.shape[2]
+        key = (cols, Ks.device)
+        if getattr(self, "_cam_key", None) != key:
+            s = float(self.image_size)
+            w = torch.zeros(3 * cols, 4)
+            w[0 * cols + 0, 0] = -2.0 / s
+            w[1 * cols + 1, 1] = -2.0 / s
+            w[0 * cols + 2, 2] = -2.0 / s
+            w[1 * cols + 2, 3] = -2.0 / s
+            self._cam_w, self._cam_b, self._cam_key = w.to(Ks.device), torch.tensor([0.0, 0.0, 1.0, 1.0], device=Ks.device), key
+        return torch.addmm(self._cam_b, Ks.reshape(B, -1), self._cam_w)
+
     def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):
         low_features, features = self.base_encoder(images)
         return self.forward_from_features(dat_name, mode_train, images, low_features, features, Ks=Ks, root_xyz=root_xyz)
@@ -85,8 +100,7 @@ class Model(nn.Module):
         joints, mano_verts, pred_root = ops.mano_joints_root_relative(self.hand_layer.handle, outputs["mano_verts"], root_id)
         outputs["joints"], outputs["mano_verts"] = joints, mano_verts
         if self.ifRender:
-            fcl, prp = self.get_ndc_fx_fy_cx_cy(Ks)
-            cam = torch.cat([-fcl, prp], dim=-1)                          # PerspectiveCameras(focal_length=-fcl, ...)
+            cam = self.camera_from_K(Ks)                                  # PerspectiveCameras(focal_length=-fcl, principal_point=prp)
             if self.ifLight:
                 colors, directions = light_params["colors"], light_params["directions"]
             else:

@@ -696,7 +696,9 @@ _SSIM_WIN = None
 
 class _SSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img1, img2):
+    def forward(ctx, img1, img2, loss_lambda):
+        """loss_lambda None: the SSIM value; a float: lambda * (1 - SSIM) (the ssim_tex term) with the scalar glue folded
+        into two launches forward and one backward instead of eight."""
         global _SSIM_WIN
         require_cuda(img1, img2)
         lib = get_lib()
@@ -711,15 +713,21 @@ class _SSIM(torch.autograd.Function):
                                                           maps[1] if need else None, maps[2] if need else None))
         if need:
             ctx.save_for_backward(img1, img2, maps)
-        return partial.sum() / float(B * C * H * W)
+        n = float(B * C * H * W)
+        s = partial.sum()
+        if loss_lambda is None:
+            ctx.gscale = 1.0 / n
+            return s * ctx.gscale                                          # SSIM = sum / n
+        ctx.gscale = -loss_lambda / n
+        return torch.add(s.new_full((), loss_lambda), s, alpha=ctx.gscale)  # lambda - lambda * sum / n
 
     @staticmethod
     def backward(ctx, g):
         img1, img2, maps = ctx.saved_tensors
         gimg1 = torch.empty_like(img1)
-        gs = g.reshape(1).contiguous().float()
+        gs = (g * (ctx.gscale * float(img1.numel()))).reshape(1).float()   # the kernel divides by the element count itself
         PROFILE.bracket("ssim_bwd", lambda: get_lib().ssim_bwd(_SSIM_WIN, img1, img2, maps[0], maps[1], maps[2], gs, gimg1))
-        return gimg1, None
+        return gimg1, None, None
 
 
 def ssim(img1, img2):
@@ -727,7 +735,14 @@ def ssim(img1, img2):
     (img2 is ground-truth data at the reference's call site, losses.py:375)."""
     if img2.requires_grad:
         raise NotImplementedError("fused SSIM differentiates with respect to img1 only")
-    return _SSIM.apply(img1, img2)
+    return _SSIM.apply(img1, img2, None)
+
+
+def ssim_loss(img1, img2, lam):
+    """lam * (1 - ssim(img1, img2)): the `ssim_tex` term of reference losses.py:375-377 with the scalar arithmetic folded in."""
+    if img2.requires_grad:
+        raise NotImplementedError("fused SSIM differentiates with respect to img1 only")
+    return _SSIM.apply(img1, img2, float(lam))
 
 
 # ------------------------------------------------------------------------------------------------
