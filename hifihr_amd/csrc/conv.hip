@@ -53,8 +53,15 @@ constexpr int kBK = 16;     // K-chunk depth (8 MFMA k-steps of 2)
 // give every XCD ONE contiguous eighth of the iteration space, and tiles are ordered column-tile fastest: an XCD then works
 // on a band of pixel rows (its slice of the activations stays in its L2 across the 9 taps and all column tiles) while the
 // column tiles that run side by side stream the same weight slab.
+// In-phase variant (mode 1, used when tiles % 8 == 0 and tiles <= workgroups): per XCD, workgroup `slot` < Tx owns chunks
+// [0, S) of tile `slot` of the XCD's band -- all of them walk the K loop IN STEP, so the column tiles of a pixel band read
+// the same activation chunk and the row tiles the same weight chunk within the L2 residency window -- and the remaining
+// Gx - Tx workgroups share the tails [S, nch) of the band's tiles.  The plain stream-K split (mode 0) staggers every
+// workgroup's phase; PMC showed an 11 % L2 hit rate for it (TCC_HIT / TCC_REQ, layer 4) against 76 % in phase, and 4.5x the
+// fabric reads -- which bought only 1.5 % of time: the kernel is not bound by L2 misses.
 struct SkArgs {
   int tiles_x, tiles_y, nch, per, total;   // row / column tiles, K chunks per tile, iterations per workgroup, tiles * nch
+  int mode, Tx, S, tper;                   // mode 1: tiles per XCD, chunk split point, tail iterations per tail workgroup
   float* ws;                      // [tiles][BM * BN]
   unsigned* cnt;                  // [tiles] arrival counters (zero between launches)
 };
@@ -140,16 +147,37 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
   const int nch_tile = GENERIC ? (Qw + BK - 1) / BK : P.nr * P.ns * (g.IC / BK);
   __shared__ int sk_last;
   int wg = blockIdx.x;
-  if (SK && (gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);     // XCD b % 8 -> contiguous eighth
-  int it = SK ? wg * sk.per : 0;
-  const int it_end = SK ? min(it + sk.per, sk.total) : 0;
+  int it = 0, it_end = 0, tile_base = 0, L = 0;
+  bool tail_wg = false;
+  if (SK) {
+    if (sk.mode == 1) {
+      const int xcd = wg & 7, slot = wg >> 3;
+      tile_base = xcd * sk.Tx;
+      L = nch_tile - sk.S;
+      tail_wg = slot >= sk.Tx;
+      if (!tail_wg) { it = slot * nch_tile; it_end = it + sk.S; }                    // chunks [0, S) of tile tile_base + slot
+      else { it = (slot - sk.Tx) * sk.tper; it_end = min(it + sk.tper, sk.Tx * L); }  // range of the band's tail space
+    } else {
+      if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);       // XCD b % 8 -> contiguous eighth
+      it = wg * sk.per;
+      it_end = min(it + sk.per, sk.total);
+    }
+  }
   do {                                            // SK: one pass per (tile, chunk range) of this workgroup's share
   int tile = 0, c_begin = 0, c_end = nch_tile, tx = blockIdx.x, ty = blockIdx.y;
   if (SK) {
     if (it >= it_end) break;
-    tile = it / nch_tile;
-    c_begin = it - tile * nch_tile;
-    c_end = min(nch_tile, c_begin + (it_end - it));
+    if (sk.mode == 1 && tail_wg) {
+      const int tl = it / L;
+      tile = tile_base + tl;
+      c_begin = sk.S + (it - tl * L);
+      c_end = min(nch_tile, c_begin + (it_end - it));
+    } else {
+      tile = it / nch_tile;
+      c_begin = it - tile * nch_tile;
+      c_end = min(sk.mode == 1 ? sk.S : nch_tile, c_begin + (it_end - it));
+      if (sk.mode == 1) tile += tile_base;
+    }
     tx = tile / sk.tiles_y; ty = tile - tx * sk.tiles_y;
     it += c_end - c_begin;
   }
@@ -173,6 +201,31 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
     a_w[i] = ox * P.amul + P.aofw;
   }
 
+  // Non-GENERIC fast path: everything that depends on the row is folded into a 32-bit element offset of the (tap 0, 0)
+  // position and a bit mask of the taps that fall inside the image, so a load costs one add, one bit test and one select
+  // in the K loop (the loop was VALU-bound on address arithmetic: 75 vector instructions per 16 MFMAs in round 1).
+  // Rows past M and output channels past OC read valid memory and produce values nobody stores; only padding taps must
+  // contribute exact zeros, which the mask takes care of at LDS-store time.
+  int a_off[AL], w_off[BL];
+  unsigned long long a_mask[AL];
+  if (!GENERIC) {
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      a_off[i] = (int)((long)a_base[i] + ((long)a_h[i] * g.IW + a_w[i]) * g.IC) + seg;
+      unsigned rbits = 0;
+      unsigned long long cbits = 0, m = 0;
+      for (int r = 0; r < P.nr; ++r) { const int ih = a_h[i] + P.sign * r; if (ih >= 0 && ih < g.IH) rbits |= 1u << r; }
+      for (int c = 0; c < P.ns; ++c) { const int iw = a_w[i] + P.sign * c; if (iw >= 0 && iw < g.IW) cbits |= 1ull << c; }
+      for (int r = 0; r < P.nr; ++r) if ((rbits >> r) & 1u) m |= cbits << (r * P.ns);
+      a_mask[i] = a_ok[i] ? (m & 0x7fffffffffffffffull) : 0ull;   // bit 63 stays clear: the "no tap" bit of prefetches past the end
+    }
+#pragma unroll
+    for (int j = 0; j < BL; ++j) {
+      const int k = bn0 + lrow + RP * j;
+      w_off[j] = (k < g.OC ? k : 0) * Qw + seg;
+    }
+  }
+
   const int nch = c_end - c_begin;                // chunks of this pass
   int jr = 0, js = 0, c0 = 0, qgen = 0, issued = 0;   // tap state of the NEXT chunk to load
   if (SK && c_begin > 0) {                        // (SK is never GENERIC) chunk -> (tap row, tap column, channel block)
@@ -187,42 +240,52 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
   float4 ra[kPF][AL], rb[kPF][BL];
   bool va[kPF][AL], vb[kPF][BL];
   auto load_global = [&](const int st) {
-    int dr, ds, c, wq;
-    bool qok = true;
-    if (GENERIC) {
-      const int q = qgen + seg;
-      qok = q < Qw;
-      const int t = qok ? q / g.IC : 0;
-      c = qok ? q - t * g.IC : 0;
-      dr = t / g.S; ds = t - dr * g.S;
-      wq = q;
-      qgen += BK;
-    } else {
-      qok = issued < nch;                    // false for the (masked) prefetches issued past the last chunk; note a
-      ++issued;                              // parity class can have nr > 0 but ns == 0 (no chunk at all)
-      dr = jr; ds = js; c = c0 + seg;
-      wq = ((P.r0 + P.rstep * jr) * g.S + (P.s0 + P.rstep * js)) * g.IC + c;
-      c0 += BK;
-      if (c0 >= g.IC) { c0 = 0; if (++js == P.ns) { js = 0; ++jr; } }
-    }
     // Loads are UNCONDITIONAL (out-of-range taps read a clamped, valid address) and masked when they are written to
     // LDS after the MFMA block: a load inside a branch makes the compiler wait for it right there, which exposes
     // the full memory latency in every K chunk.
+    if (GENERIC) {
+      const int q = qgen + seg;
+      const bool qok = q < Qw;
+      const int t = qok ? q / g.IC : 0;
+      const int c = qok ? q - t * g.IC : 0;
+      const int dr = t / g.S, ds = t - dr * g.S;
+      qgen += BK;
 #pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int ih = a_h[i] + P.sign * dr, iw = a_w[i] + P.sign * ds;
-      const bool ok = qok && a_ok[i] && ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW;
-      const size_t off = ok ? a_base[i] + ((size_t)ih * g.IW + iw) * g.IC + c : 0;
-      ra[st][i] = *reinterpret_cast<const float4*>(src + off);
-      va[st][i] = ok;
-    }
+      for (int i = 0; i < AL; ++i) {
+        const int ih = a_h[i] + P.sign * dr, iw = a_w[i] + P.sign * ds;
+        const bool ok = qok && a_ok[i] && ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW;
+        const size_t off = ok ? a_base[i] + ((size_t)ih * g.IW + iw) * g.IC + c : 0;
+        ra[st][i] = *reinterpret_cast<const float4*>(src + off);
+        va[st][i] = ok;
+      }
 #pragma unroll
-    for (int j = 0; j < BL; ++j) {
-      const int k = bn0 + lrow + RP * j;
-      const bool ok = qok && k < g.OC;
-      const size_t off = ok ? (size_t)k * Qw + wq : 0;
-      rb[st][j] = *reinterpret_cast<const float4*>(wgt + off);
-      vb[st][j] = ok;
+      for (int j = 0; j < BL; ++j) {
+        const int k = bn0 + lrow + RP * j;
+        const bool ok = qok && k < g.OC;
+        const size_t off = ok ? (size_t)k * Qw + q : 0;
+        rb[st][j] = *reinterpret_cast<const float4*>(wgt + off);
+        vb[st][j] = ok;
+      }
+    } else {
+      const bool qok = issued < nch;         // false for the prefetches issued past the last chunk (their data is never used;
+      ++issued;                              // a parity class can also have nr > 0 but ns == 0: no chunk at all)
+      const int tbit = qok ? jr * P.ns + js : 63;                                               // wave-uniform (SALU)
+      const int toff = qok ? P.sign * (jr * g.IW + js) * g.IC + c0 : 0;
+      const int wq = qok ? ((P.r0 + P.rstep * jr) * g.S + (P.s0 + P.rstep * js)) * g.IC + c0 : 0;
+      c0 += BK;
+      if (c0 >= g.IC) { c0 = 0; if (++js == P.ns) { js = 0; ++jr; } }
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const bool ok = ((a_mask[i] >> tbit) & 1ull) != 0;
+        const unsigned off = ok ? (unsigned)(a_off[i] + toff) : 0u;
+        ra[st][i] = *reinterpret_cast<const float4*>(src + off);
+        va[st][i] = ok;
+      }
+#pragma unroll
+      for (int j = 0; j < BL; ++j) {
+        rb[st][j] = *reinterpret_cast<const float4*>(wgt + (unsigned)(w_off[j] + wq));
+        vb[st][j] = true;
+      }
     }
   };
   auto store_lds = [&](const int st, int buf) {
@@ -237,7 +300,7 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
 #pragma unroll
     for (int j = 0; j < BL; ++j) {
       float* p = &Bs[buf][(lrow + RP * j) * LD];
-      const float4 v = vb[st][j] ? rb[st][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = (!GENERIC || vb[st][j]) ? rb[st][j] : make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float2*>(p + seg / 2) = make_float2(v.x, v.z);
       *reinterpret_cast<float2*>(p + HK + seg / 2) = make_float2(v.y, v.w);
     }
@@ -304,13 +367,19 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
       HIFIHR_SCHED_FENCE();
       if (HIFIHR_CONV_PROBE < 2) store_lds((u + 1) % kPF, buf ^ 1);  // chunk ch + 1 (loaded two chunk-computations ago) -> the other LDS buffer
-      if (HIFIHR_CONV_PROBE < 3) __syncthreads();
+      if (HIFIHR_CONV_PROBE < 3 && HIFIHR_CONV_PROBE != -1) __syncthreads();     // -1: everything but the barrier
     }
   }
 
   if (SK && nch != nch_tile) {
     // This pass covered part of the tile's K range: add the partial sums to the tile's workspace, then count arrivals.
-    const int gfirst = (tile * nch_tile) / sk.per, glast = ((tile + 1) * nch_tile - 1) / sk.per;
+    int nseg;                                     // workgroups that share this tile
+    if (sk.mode == 1) {
+      const int tl = tile - tile_base;
+      nseg = 1 + ((tl + 1) * L - 1) / sk.tper - (tl * L) / sk.tper + 1;
+    } else {
+      nseg = ((tile + 1) * nch_tile - 1) / sk.per - (tile * nch_tile) / sk.per + 1;
+    }
     float* wt = sk.ws + (size_t)tile * (BM * BN) + wave * 64 + lane;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -320,7 +389,7 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
         for (int e = 0; e < 16; ++e) atomicAdd(wt + ((i * TN + j) * 16 + e) * 256, acc[i][j][e]);
     HIFIHR_WAIT_VMEM();                           // every add of this workgroup is performed before it is counted
     __syncthreads();
-    if (tid == 0) sk_last = (atomicAdd(sk.cnt + tile, 1u) == (unsigned)(glast - gfirst)) ? 1 : 0;
+    if (tid == 0) sk_last = (atomicAdd(sk.cnt + tile, 1u) == (unsigned)(nseg - 1)) ? 1 : 0;
     __syncthreads();
     const bool last = sk_last != 0;
     __syncthreads();                              // sk_last may be rewritten by the next pass
@@ -567,7 +636,7 @@ template <int BM, int BN>
 static void launch_igemm_tile(const ConvGeom& g, long Mmax, int classes, bool generic, int bk, const float* src, const float* wgt,
                               const float* bias, float* dst, float* stats, hipStream_t st) {
   const dim3 grid((unsigned)((Mmax + BM - 1) / BM), (g.OC + BN - 1) / BN, classes);
-  const SkArgs none{0, 0, 0, 0, 0, nullptr, nullptr};
+  const SkArgs none{0, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr};
   if (generic)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true, 16, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats, none);
   else if (bk == 32)
@@ -642,16 +711,34 @@ template <int BM, int BN, int BK>
 static void launch_sk(const SkPlan& p, const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, void* sk_ws,
                       hipStream_t st) {
   const size_t cnt_bytes = (p.tiles * sizeof(unsigned) + 255) / 256 * 256;
-  const SkArgs a{p.tiles_x, p.tiles / p.tiles_x, p.nch, p.per, p.tiles * p.nch, reinterpret_cast<float*>(static_cast<char*>(sk_ws) + cnt_bytes),
-                 static_cast<unsigned*>(sk_ws)};
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, BK, true>), dim3(p.wgs), dim3(256), 0, st, g, src, wgt, nullptr, dst, stats, a);
+  SkArgs a{p.tiles_x, p.tiles / p.tiles_x, p.nch, p.per, p.tiles * p.nch, 0, 0, 0, 0,
+           reinterpret_cast<float*>(static_cast<char*>(sk_ws) + cnt_bytes), static_cast<unsigned*>(sk_ws)};
+  int wgs = p.wgs;
+  const int slots = device_cus() * p.v.occ;
+  // measured (tools/time_conv_sk.py): +1.5 % on the 144-chunk layer-4 shapes, -9 % on 36-chunk layer 2 (short tails): long K only
+  bool inphase = p.tiles % 8 == 0 && slots % 8 == 0 && p.tiles <= slots && (p.nch >= 100 || device_cus() < 16);
+  if (const char* e = getenv("HIFIHR_CONV_SK_INPHASE")) inphase = inphase && atoi(e) != 0;
+  if (inphase) {
+    const int Tx = p.tiles / 8, Gx = slots / 8;
+    int S = (int)(((long)Tx * p.nch + Gx - 1) / Gx);
+    if (S > p.nch) S = p.nch;
+    const int L = p.nch - S;
+    if (Tx == Gx || L == 0) { S = p.nch; }
+    a.mode = 1; a.Tx = Tx; a.S = S;
+    const int ntail = Gx - Tx;
+    a.tper = (S < p.nch && ntail > 0) ? (int)(((long)Tx * (p.nch - S) + ntail - 1) / ntail) : 1;
+    wgs = slots;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, BK, true>), dim3(wgs), dim3(256), 0, st, g, src, wgt, nullptr, dst, stats, a);
 }
 
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
                              void* sk_ws, size_t sk_ws_bytes, hipStream_t st) {
   if (stats != nullptr && g.dgrad) return hipErrorInvalidValue;   // stats: all zero on entry (self-cleaning, see bn.hip)
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
-  const bool generic = (g.IC % 16) != 0;
+  // the fast gather uses 32-bit element offsets (scaled by 4 in the address) and a 63-bit tap mask
+  if ((long)g.N * g.IH * g.IW * g.IC >= (1L << 30) || (long)g.OC * g.R * g.S * g.IC >= (1L << 30)) return hipErrorInvalidValue;
+  const bool generic = (g.IC % 16) != 0 || g.R * g.S > 63;
   if (generic && g.dgrad && g.stride != 1) return hipErrorInvalidValue;   // strided dgrad needs source channels % 16 == 0
   int bk = (g.IC % 32 == 0) ? 32 : 16;
   if (const char* e = getenv("HIFIHR_CONV_BK")) bk = (atoi(e) == 32 && g.IC % 32 == 0) ? 32 : 16;   // tuning override

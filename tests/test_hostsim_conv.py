@@ -26,11 +26,12 @@ def test_conv_fwd_bwd(hostsim_lib, N, H, W, C, K, R, stride, pad):
     (2, 9, 7, 128, 192, 3, 1, 1),   # fwd 6 tiles x 36 chunks, dgrad 4 tiles x 54 chunks over 16 persistent workgroups: split tiles
     (3, 8, 8, 32, 128, 3, 1, 1),    # 6 tiles x 9 ... below the chunk minimum: must NOT take a workspace
     (4, 20, 20, 64, 64, 3, 2, 1),   # strided forward (one gather class) balanced, strided dgrad not
+    (2, 16, 16, 64, 64, 3, 1, 1),   # 8 tiles on 16 workgroups: the in-phase split (one tile per "XCD": main part + one tail workgroup)
 ])
 def test_conv_balanced_schedule(hostsim_lib, N, H, W, C, K, R, stride, pad):
     """hostsim reports 4 CUs -> 16 persistent workgroups (tests/hostsim/hip/hip_runtime.h)."""
     used = kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, seed=C + H)
-    assert used == {192: 2, 128: 0, 64: 1}[K]
+    assert used == {192: 2, 128: 0, 64: 1 if stride == 2 else 2}[K]
 
 
 def test_conv_balanced_schedule_bnstats(hostsim_lib):
