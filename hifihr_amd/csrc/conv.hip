@@ -71,6 +71,15 @@ struct SkArgs {
 #ifndef HIFIHR_CONV_PROBE
 #define HIFIHR_CONV_PROBE 0
 #endif
+// HIFIHR_CONV_STAMP (diagnostic build, tools/build_conv_probes.sh): per-wave s_memtime stamps around the four phases of a
+// K chunk, summed into g_conv_stamp[0..3] = cycles in (load issue, LDS reads + MFMA block, vmcnt wait + LDS stores, barrier),
+// [4] = chunks.  The stamps sit where no LDS operation is outstanding, so their lgkmcnt wait perturbs little.
+#if defined(HIFIHR_CONV_STAMP)
+__device__ unsigned long long g_conv_stamp[8];
+#define HIFIHR_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define HIFIHR_STAMP(var) ((void)0)
+#endif
 
 // How one launch (or one parity class of a strided dgrad launch) walks rows and taps.
 //   forward : rows = output pixels, tap j reads src row  oy*stride - pad + j
@@ -314,6 +323,9 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+#if defined(HIFIHR_CONV_STAMP)
+  unsigned long long stamp_acc[5] = {0, 0, 0, 0, 0};
+#endif
   // prologue: chunks 0, 1, 2 in flight (masked past the end), chunk 0 to LDS
   load_global(0);
   load_global(1);
@@ -328,8 +340,10 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
       const int buf = ch & 1;
       // stage u held chunk ch (already in LDS): refill it with chunk ch + 3.  Issued unconditionally (masked, clamped
       // loads past the last tap): a conditional load turns the registers into phis whose copies wait at once.
+      HIFIHR_STAMP(t0);
       if (HIFIHR_CONV_PROBE < 1) load_global(u);
       HIFIHR_SCHED_FENCE();               // loads first, then the MFMA block
+      HIFIHR_STAMP(t1);
       float a[TM][HK], b[TN][HK];
 #if HIFIHR_CONV_PROBE >= 4
 #pragma unroll
@@ -366,11 +380,29 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
       HIFIHR_SCHED_FENCE();
+#if defined(HIFIHR_CONV_STAMP)
+      HIFIHR_KEEP(acc[0][0][0]);          // the stamp must not be taken before the last MFMA has delivered
+#endif
+      HIFIHR_STAMP(t2);
       if (HIFIHR_CONV_PROBE < 2) store_lds((u + 1) % kPF, buf ^ 1);  // chunk ch + 1 (loaded two chunk-computations ago) -> the other LDS buffer
+#if defined(HIFIHR_CONV_STAMP)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      HIFIHR_STAMP(t3);
       if (HIFIHR_CONV_PROBE < 3 && HIFIHR_CONV_PROBE != -1) __syncthreads();     // -1: everything but the barrier
+#if defined(HIFIHR_CONV_STAMP)
+      {
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        stamp_acc[0] += t1 - t0; stamp_acc[1] += t2 - t1; stamp_acc[2] += t3 - t2; stamp_acc[3] += t4 - t3; stamp_acc[4] += 1ull;
+      }
+#endif
     }
   }
 
+#if defined(HIFIHR_CONV_STAMP)
+  if (lane == 0)
+    for (int k = 0; k < 5; ++k) atomicAdd(&g_conv_stamp[k], stamp_acc[k]);
+#endif
   if (SK && nch != nch_tile) {
     // This pass covered part of the tile's K range: add the partial sums to the tile's workspace, then count arrivals.
     int nseg;                                     // workgroups that share this tile
@@ -794,6 +826,19 @@ hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy,
   else launch_wgrad_tile<64, 64>(g, Q, nch, cus * (tile == 2 ? 4 : tile), x, dy, dw, st);
   return hipGetLastError();
 }
+
+#if defined(HIFIHR_CONV_STAMP)
+}  // namespace hifihr
+extern "C" int hifihr_conv_stamp_read(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hifihr::g_conv_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hifihr::g_conv_stamp), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+namespace hifihr {
+#endif
 
 hipError_t launch_weight_transpose(const float* w, float* wt, int K, int RS, int C, hipStream_t st) {
   const size_t n = (size_t)K * RS * C;
