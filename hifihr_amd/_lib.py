@@ -88,8 +88,9 @@ class HifihrLib:
         c.hifihr_conv2d_workspace_bytes.restype = c_size_t
         c.hifihr_conv2d_bwd_data.argtypes = [_c_float_p] * 4 + ci + [c_void_p, c_size_t, c_void_p]
         c.hifihr_conv2d_fwd_bnstats.argtypes = [_c_float_p] * 4 + ci + [c_void_p, c_size_t, c_void_p]
-        for fn in (c.hifihr_dwconv2d_fwd, c.hifihr_dwconv2d_bwd_data, c.hifihr_dwconv2d_bwd_weight):
+        for fn in (c.hifihr_dwconv2d_bwd_data, c.hifihr_dwconv2d_bwd_weight):
             fn.argtypes = [_c_float_p] * 3 + [c_int] * 10 + [c_void_p]
+        c.hifihr_dwconv2d_fwd.argtypes = [_c_float_p] * 4 + [c_int] * 10 + [c_void_p]
         c.hifihr_bn_stats_floats.argtypes = [c_int]
         c.hifihr_bn_stats_floats.restype = c_int
         c.hifihr_bn_stats.argtypes = [_c_float_p, c_long, c_int, _c_float_p, c_void_p]
@@ -202,9 +203,9 @@ class HifihrLib:
                                             c_long(M), C, _fp(red), _fp(dx), _fp(dres), _fp(dgamma_acc), _fp(dbeta_acc),
                                             _stream_of(dy)), "hifihr_bn_act_bwd")
 
-    def dwconv2d_fwd(self, x, w, y, N, H, W, C, OH, OW, K, stride, pt, pl):
-        self.check(self.c.hifihr_dwconv2d_fwd(_fp(x), _fp(w), _fp(y), N, H, W, C, OH, OW, K, stride, pt, pl, _stream_of(x)),
-                   "hifihr_dwconv2d_fwd")
+    def dwconv2d_fwd(self, x, w, y, N, H, W, C, OH, OW, K, stride, pt, pl, stats=None):
+        self.check(self.c.hifihr_dwconv2d_fwd(_fp(x), _fp(w), _fp(y), _fp(stats), N, H, W, C, OH, OW, K, stride, pt, pl,
+                                              _stream_of(x)), "hifihr_dwconv2d_fwd")
 
     def dwconv2d_bwd_data(self, dy, w, dx, N, H, W, C, OH, OW, K, stride, pt, pl):
         self.check(self.c.hifihr_dwconv2d_bwd_data(_fp(dy), _fp(w), _fp(dx), N, H, W, C, OH, OW, K, stride, pt, pl, _stream_of(dy)),

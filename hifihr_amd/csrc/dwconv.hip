@@ -3,156 +3,267 @@
 // Replaces the depthwise `Conv2dStaticSamePadding(groups=oup)` of the reference's EfficientNet MBConv blocks (reference
 // network/efficientnet_pt/model.py:49-55,80; utils.py:122-145) -- k = 3 or 5, stride 1 or 2, TensorFlow-style
 // asymmetric zero padding (top/left given explicitly; bottom/right implied by the output size).  0.2 % of the network's
-// FLOPs but, unfused in MIOpen's fp32 NHWC path, >90 % of its time on this GPU (naive kernels, ~13 ms per launch).
-// Bandwidth-bound: every lane owns 4 consecutive channels (float4) of one output pixel; the k*k taps of neighbouring
-// pixels overlap, so re-reads come from L1/L2.  Weight layout [C][k][k] (= torch's [C,1,k,k]).
+// FLOPs but, unfused in MIOpen's fp32 NHWC path, >90 % of its time on this GPU.  HBM/L1-bound streaming kernels:
+//
+//   workgroup = 64 channels (16 float4 lanes) x 16 pixel lanes; blockIdx.y = channel block, whose k*k x 64 weights sit in
+//   LDS transposed to [tap][channel] so every tap is one float4 read.  A thread produces FOUR horizontally adjacent
+//   outputs per step: the 3*stride + k input columns of a row are loaded once (unconditionally, clamped, masked) and
+//   feed all four -- 10 loads per output at k = 5 instead of 25, none of them inside a branch (round 1's first
+//   version ran 3-7x off the bandwidth bound on exactly those two points).
+//   forward   optionally adds the per-channel sum / sum of squares of y to the batch-norm slot buffer (bn.hip) from the
+//             registers, which removes a full read of y by bn_stats_kernel per MBConv block.
+//   bwd-data  the same walk over input pixels; stride 2 contributes only taps of matching parity (resolved at compile
+//             time per parity of the first column).
+//   bwd-weight register accumulators [k*k] x float4 per thread over a grid-stride loop, folded over the pixel lanes
+//             through LDS, then one atomic per (channel, tap) per workgroup (<= 128 workgroups per channel block).
+// Weight layout [C][k][k] (= torch's [C,1,k,k]).
 #include <hip/hip_runtime.h>
 
 #include "hifihr_internal.h"
 
 namespace hifihr {
 
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* __restrict__ x, const float* __restrict__ w,
-                                                        float* __restrict__ y) {
-  const int C4 = g.C / 4;
-  const long total = (long)g.N * g.OH * g.OW * C4;
-  const int KK = g.K * g.K;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int cg = (int)(idx % C4);
-    long m = idx / C4;
-    const int ow = (int)(m % g.OW); m /= g.OW;
-    const int oh = (int)(m % g.OH);
-    const int n = (int)(m / g.OH);
-    const float* wc = w + (size_t)cg * 4 * KK;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < g.K; ++r) {
-      const int ih = oh * g.stride - g.pt + r;
-      if (ih < 0 || ih >= g.H) continue;
-      for (int s = 0; s < g.K; ++s) {
-        const int iw = ow * g.stride - g.pl + s;
-        if (iw < 0 || iw >= g.W) continue;
-        const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * g.H + ih) * g.W + iw) * g.C + cg * 4);
-        const int t = r * g.K + s;
-        acc.x += v.x * wc[t]; acc.y += v.y * wc[KK + t]; acc.z += v.z * wc[2 * KK + t]; acc.w += v.w * wc[3 * KK + t];
-      }
-    }
-    *reinterpret_cast<float4*>(y + idx * 4) = acc;
+constexpr int kPW = 4;        // outputs per thread per step (horizontally adjacent)
+
+__device__ __forceinline__ float4 fma4(const float4& a, const float4& b, const float4& c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// weights of this workgroup's 64 channels -> LDS [k*k][64]
+template <int KK>
+__device__ __forceinline__ void stage_weights(const float* __restrict__ w, int C, int c0, float (*wl)[64]) {
+  for (int e = threadIdx.x; e < KK * 64; e += 256) {
+    const int c = e / KK, t = e - c * KK;
+    wl[t][c] = (c0 + c < C) ? w[(size_t)(c0 + c) * KK + t] : 0.f;
   }
 }
 
-__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(DwGeom g, const float* __restrict__ dy, const float* __restrict__ w,
-                                                             float* __restrict__ dx) {
-  const int C4 = g.C / 4;
-  const long total = (long)g.N * g.H * g.W * C4;
-  const int KK = g.K * g.K;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int cg = (int)(idx % C4);
-    long m = idx / C4;
-    const int iw = (int)(m % g.W); m /= g.W;
-    const int ih = (int)(m % g.H);
-    const int n = (int)(m / g.H);
-    const float* wc = w + (size_t)cg * 4 * KK;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < g.K; ++r) {
-      const int th = ih + g.pt - r;
-      if (th < 0 || th % g.stride != 0) continue;
-      const int oh = th / g.stride;
-      if (oh >= g.OH) continue;
-      for (int s = 0; s < g.K; ++s) {
-        const int tw = iw + g.pl - s;
-        if (tw < 0 || tw % g.stride != 0) continue;
-        const int ow = tw / g.stride;
-        if (ow >= g.OW) continue;
-        const float4 v = *reinterpret_cast<const float4*>(dy + (((size_t)n * g.OH + oh) * g.OW + ow) * g.C + cg * 4);
-        const int t = r * g.K + s;
-        acc.x += v.x * wc[t]; acc.y += v.y * wc[KK + t]; acc.z += v.z * wc[2 * KK + t]; acc.w += v.w * wc[3 * KK + t];
-      }
-    }
-    *reinterpret_cast<float4*>(dx + idx * 4) = acc;
-  }
-}
-
-// dw[c][r][s] += sum over output pixels of dy * x.  Threads own a channel group and a row lane (as the batch-norm
-// kernels do); the k*k partial sums live in registers, row lanes are folded through LDS, one atomic per value per block.
-template <int K>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwGeom g, const float* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ dw) {
-  constexpr int KK = K * K;
-  __shared__ float lds[256 * 4];
-  const int C4 = g.C / 4;
-  // channel groups are tiled over blockIdx.y in chunks of <= 256 groups
-  const int cgs = min(C4 - (int)blockIdx.y * 256, 256);
-  const int CT = cgs, RL = 256 / CT;
-  const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
-  const bool active = rl < RL;
-  const int cg = blockIdx.y * 256 + cl;
-  const long M = (long)g.N * g.OH * g.OW;
-  float4 acc[KK];
+// one input row segment: NC float4 columns starting at column iw0, zero outside [0, W) or when the row is invalid
+template <int NC>
+__device__ __forceinline__ void load_row(const float* __restrict__ base, bool rowok, int iw0, int W, int C, float4 (&v)[NC]) {
 #pragma unroll
-  for (int t = 0; t < KK; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active) {
-    for (long m = (long)blockIdx.x * RL + rl; m < M; m += (long)gridDim.x * RL) {
-      long q = m;
-      const int ow = (int)(q % g.OW); q /= g.OW;
-      const int oh = (int)(q % g.OH);
-      const int n = (int)(q / g.OH);
-      const float4 d = *reinterpret_cast<const float4*>(dy + m * g.C + cg * 4);
+  for (int j = 0; j < NC; ++j) {
+    const int iw = iw0 + j;
+    const bool ok = rowok && iw >= 0 && iw < W;
+    const float4 t = *reinterpret_cast<const float4*>(base + (size_t)(ok ? iw : 0) * C);     // unconditional, clamped
+    v[j] = ok ? t : zero4();
+  }
+}
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, float* __restrict__ stats) {
+  constexpr int KK = K * K, NC = (kPW - 1) * S + K;
+  __shared__ float wl[KK][64];
+  __shared__ float4 red[2][16][16];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c0 = blockIdx.y * 64, c = c0 + cl * 4;
+  const bool cok = c < g.C;
+  stage_weights<KK>(w, g.C, c0, wl);
+  __syncthreads();
+  const int OWB = (g.OW + kPW - 1) / kPW;
+  const long nb = (long)g.N * g.OH * OWB;
+  float4 s1 = zero4(), s2 = zero4();
+  if (cok) {
+    for (long pb = (long)blockIdx.x * 16 + pl; pb < nb; pb += (long)gridDim.x * 16) {
+      const int owb = (int)(pb % OWB);
+      const long q = pb / OWB;
+      const int oh = (int)(q % g.OH), n = (int)(q / g.OH);
+      const int ow0 = owb * kPW;
+      float4 acc[kPW];
+#pragma unroll
+      for (int p = 0; p < kPW; ++p) acc[p] = zero4();
 #pragma unroll
       for (int r = 0; r < K; ++r) {
-        const int ih = oh * g.stride - g.pt + r;
+        const int ih = oh * S - g.pt + r;
+        const bool rowok = ih >= 0 && ih < g.H;
+        float4 v[NC];
+        load_row<NC>(x + ((size_t)n * g.H + (rowok ? ih : 0)) * g.W * g.C + c, rowok, ow0 * S - g.pl, g.W, g.C, v);
 #pragma unroll
         for (int s = 0; s < K; ++s) {
-          const int iw = ow * g.stride - g.pl + s;
-          if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) {
-            const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * g.H + ih) * g.W + iw) * g.C + cg * 4);
-            float4& a = acc[r * K + s];
-            a.x += d.x * v.x; a.y += d.y * v.y; a.z += d.z * v.z; a.w += d.w * v.w;
-          }
+          const float4 wt = *reinterpret_cast<const float4*>(&wl[r * K + s][cl * 4]);
+#pragma unroll
+          for (int p = 0; p < kPW; ++p) acc[p] = fma4(v[p * S + s], wt, acc[p]);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < kPW; ++p) {
+        if (ow0 + p < g.OW) {
+          *reinterpret_cast<float4*>(y + (((size_t)n * g.OH + oh) * g.OW + ow0 + p) * g.C + c) = acc[p];
+          s1.x += acc[p].x; s1.y += acc[p].y; s1.z += acc[p].z; s1.w += acc[p].w;
+          s2 = fma4(acc[p], acc[p], s2);
         }
       }
     }
   }
-  // fold the row lanes tap by tap, then one atomic per (channel, tap) per block
-  for (int t = 0; t < KK; ++t) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < KK; ++u)
-      if (u == t) a = acc[u];
+  if (stats != nullptr) {                           // uniform: fold the 16 pixel lanes, one atomic per channel per workgroup
+    red[0][pl][cl] = s1; red[1][pl][cl] = s2;
     __syncthreads();
-    lds[threadIdx.x * 4 + 0] = a.x; lds[threadIdx.x * 4 + 1] = a.y; lds[threadIdx.x * 4 + 2] = a.z; lds[threadIdx.x * 4 + 3] = a.w;
-    __syncthreads();
-    if (active && rl == 0) {
-      for (int r = 1; r < RL; ++r) {
-        const float* p = lds + (r * CT + cl) * 4;
-        a.x += p[0]; a.y += p[1]; a.z += p[2]; a.w += p[3];
+    if (pl == 0 && cok) {
+      for (int r = 1; r < 16; ++r) {
+        const float4 a = red[0][r][cl], b = red[1][r][cl];
+        s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+        s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
       }
-      float* o = dw + (size_t)cg * 4 * KK + t;
+      float* sp = stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * g.C;
+      atomicAdd(sp + c, s1.x); atomicAdd(sp + c + 1, s1.y); atomicAdd(sp + c + 2, s1.z); atomicAdd(sp + c + 3, s1.w);
+      atomicAdd(sp + g.C + c, s2.x); atomicAdd(sp + g.C + c + 1, s2.y); atomicAdd(sp + g.C + c + 2, s2.z); atomicAdd(sp + g.C + c + 3, s2.w);
+    }
+  }
+}
+
+// dx[n][ih][iw] = sum_{r,s} dy[n][(ih + pt - r)/S][(iw + pl - s)/S] * w[r][s] over the taps where the divisions are exact.
+// Four adjacent iw per thread, first one a multiple of 4.  With tw = iw + pl - s = base + u, base = iw0 + pl - (K-1),
+// u = p + K-1 - s: for S = 2 a tap contributes iff (u & 1) == PAR (PAR = parity of base) and reads column (u + PAR) / 2
+// of the dy row segment that starts at floor(base / 2).
+template <int K, int S, int PAR>
+__device__ __forceinline__ void dgrad_block(const DwGeom& g, const float* __restrict__ dy, const float (*wl)[64], int cl, int n, int ih,
+                                            int iw0, int c, float* __restrict__ dx) {
+  constexpr int NC = (S == 1) ? (K + kPW - 1) : ((K + kPW - 2 + PAR) / 2 + 1);
+  const int base = iw0 + g.pl - (K - 1);
+  const int owb0 = (S == 1) ? base : ((base - PAR) / 2);      // floor(base / 2): base - PAR is even
+  float4 acc[kPW];
+#pragma unroll
+  for (int p = 0; p < kPW; ++p) acc[p] = zero4();
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    const int th = ih + g.pt - r;
+    const bool rowok = th >= 0 && (S == 1 || (th & 1) == 0) && (th / S) < g.OH;
+    const int oh = rowok ? th / S : 0;
+    float4 d[NC];
+    load_row<NC>(dy + ((size_t)n * g.OH + oh) * g.OW * g.C + c, rowok, owb0, g.OW, g.C, d);
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      const float4 wt = *reinterpret_cast<const float4*>(&wl[r * K + s][cl * 4]);
+#pragma unroll
+      for (int p = 0; p < kPW; ++p) {
+        const int u = p + K - 1 - s;
+        if constexpr (S == 1) {
+          acc[p] = fma4(d[u], wt, acc[p]);
+        } else {
+          if ((u & 1) == PAR) acc[p] = fma4(d[((u + PAR) / 2) < NC ? (u + PAR) / 2 : 0], wt, acc[p]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < kPW; ++p)
+    if (iw0 + p < g.W) *reinterpret_cast<float4*>(dx + (((size_t)n * g.H + ih) * g.W + iw0 + p) * g.C + c) = acc[p];
+}
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(DwGeom g, const float* __restrict__ dy, const float* __restrict__ w,
+                                                             float* __restrict__ dx) {
+  constexpr int KK = K * K;
+  __shared__ float wl[KK][64];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c0 = blockIdx.y * 64, c = c0 + cl * 4;
+  stage_weights<KK>(w, g.C, c0, wl);
+  __syncthreads();
+  if (c >= g.C) return;
+  const int WB = (g.W + kPW - 1) / kPW;
+  const long nb = (long)g.N * g.H * WB;
+  const bool odd = ((g.pl - (K - 1)) & 1) != 0;      // parity of base (iw0 is a multiple of 4); uniform
+  for (long pb = (long)blockIdx.x * 16 + pl; pb < nb; pb += (long)gridDim.x * 16) {
+    const int iwb = (int)(pb % WB);
+    const long q = pb / WB;
+    const int ih = (int)(q % g.H), n = (int)(q / g.H);
+    if (S == 1 || !odd) dgrad_block<K, S, 0>(g, dy, wl, cl, n, ih, iwb * kPW, c, dx);
+    else dgrad_block<K, S, 1>(g, dy, wl, cl, n, ih, iwb * kPW, c, dx);
+  }
+}
+
+// dw[c][r][s] += sum over output pixels of dy * x
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwGeom g, const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ dw) {
+  constexpr int KK = K * K, NC = (kPW - 1) * S + K;
+  __shared__ float4 red[16][16];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.y * 64 + cl * 4;
+  const bool cok = c < g.C;
+  const int OWB = (g.OW + kPW - 1) / kPW;
+  const long nb = (long)g.N * g.OH * OWB;
+  float4 acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) acc[t] = zero4();
+  if (cok) {
+    for (long pb = (long)blockIdx.x * 16 + pl; pb < nb; pb += (long)gridDim.x * 16) {
+      const int owb = (int)(pb % OWB);
+      const long q = pb / OWB;
+      const int oh = (int)(q % g.OH), n = (int)(q / g.OH);
+      const int ow0 = owb * kPW;
+      float4 d[kPW];
+      {
+        const float* dp = dy + (((size_t)n * g.OH + oh) * g.OW) * g.C + c;
+#pragma unroll
+        for (int p = 0; p < kPW; ++p) {
+          const bool ok = ow0 + p < g.OW;
+          const float4 t = *reinterpret_cast<const float4*>(dp + (size_t)(ok ? ow0 + p : 0) * g.C);
+          d[p] = ok ? t : zero4();
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        const int ih = oh * S - g.pt + r;
+        const bool rowok = ih >= 0 && ih < g.H;
+        float4 v[NC];
+        load_row<NC>(x + ((size_t)n * g.H + (rowok ? ih : 0)) * g.W * g.C + c, rowok, ow0 * S - g.pl, g.W, g.C, v);
+#pragma unroll
+        for (int s = 0; s < K; ++s)
+#pragma unroll
+          for (int p = 0; p < kPW; ++p) acc[r * K + s] = fma4(d[p], v[p * S + s], acc[r * K + s]);
+      }
+    }
+  }
+  // fold the 16 pixel lanes tap by tap, then one atomic per (channel, tap) per workgroup
+#pragma unroll
+  for (int t = 0; t < KK; ++t) {
+    __syncthreads();
+    red[pl][cl] = acc[t];
+    __syncthreads();
+    if (pl == 0 && cok) {
+      float4 a = acc[t];
+      for (int r = 1; r < 16; ++r) { const float4 b = red[r][cl]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+      float* o = dw + (size_t)c * KK + t;
       atomicAdd(o, a.x); atomicAdd(o + KK, a.y); atomicAdd(o + 2 * KK, a.z); atomicAdd(o + 3 * KK, a.w);
     }
   }
 }
 
-static unsigned ew_grid(long total) {
-  long b = (total + 255) / 256;
-  if (b > 4096) b = 4096;
+static unsigned dw_grid_x(long nb, long cap) {
+  long b = (nb + 15) / 16;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (unsigned)b;
 }
 
-hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, hipStream_t st) {
-  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(ew_grid((long)g.N * g.OH * g.OW * (g.C / 4))), dim3(256), 0, st, g, x, w, y);
+#define HIFIHR_DW_DISPATCH(KERNEL, GRID, ...)                                                                  \
+  do {                                                                                                          \
+    if (g.K == 3 && g.stride == 1) hipLaunchKernelGGL((KERNEL<3, 1>), GRID, dim3(256), 0, st, __VA_ARGS__);      \
+    else if (g.K == 3 && g.stride == 2) hipLaunchKernelGGL((KERNEL<3, 2>), GRID, dim3(256), 0, st, __VA_ARGS__); \
+    else if (g.K == 5 && g.stride == 1) hipLaunchKernelGGL((KERNEL<5, 1>), GRID, dim3(256), 0, st, __VA_ARGS__); \
+    else if (g.K == 5 && g.stride == 2) hipLaunchKernelGGL((KERNEL<5, 2>), GRID, dim3(256), 0, st, __VA_ARGS__); \
+    else return hipErrorInvalidValue;                                                                           \
+  } while (0)
+
+hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, float* stats, hipStream_t st) {
+  const long nb = (long)g.N * g.OH * ((g.OW + kPW - 1) / kPW);
+  const dim3 grid(dw_grid_x(nb, 2048), (g.C + 63) / 64);
+  HIFIHR_DW_DISPATCH(dwconv_fwd_kernel, grid, g, x, w, y, stats);
   return hipGetLastError();
 }
 hipError_t launch_dwconv_bwd_data(const DwGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
-  hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(ew_grid((long)g.N * g.H * g.W * (g.C / 4))), dim3(256), 0, st, g, dy, w, dx);
+  const long nb = (long)g.N * g.H * ((g.W + kPW - 1) / kPW);
+  const dim3 grid(dw_grid_x(nb, 2048), (g.C + 63) / 64);
+  HIFIHR_DW_DISPATCH(dwconv_bwd_data_kernel, grid, g, dy, w, dx);
   return hipGetLastError();
 }
 hipError_t launch_dwconv_bwd_weight(const DwGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {
-  const int C4 = g.C / 4;
-  const dim3 grid(256, (C4 + 255) / 256);      // <= 256 row slabs: at most 256 atomics land on one address
-  if (g.K == 3) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<3>, grid, dim3(256), 0, st, g, x, dy, dw);
-  else if (g.K == 5) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<5>, grid, dim3(256), 0, st, g, x, dy, dw);
-  else return hipErrorInvalidValue;
+  const long nb = (long)g.N * g.OH * ((g.OW + kPW - 1) / kPW);
+  const dim3 grid(dw_grid_x(nb, 128), (g.C + 63) / 64);      // <= 128 workgroups add into one weight
+  HIFIHR_DW_DISPATCH(dwconv_bwd_weight_kernel, grid, g, x, dy, dw);
   return hipGetLastError();
 }
 

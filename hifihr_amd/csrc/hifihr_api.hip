@@ -366,14 +366,14 @@ int hifihr_bn_act_bwd(const float* dy, const float* y, const float* x, const flo
 }
 
 static int dw_ok(int N, int H, int W, int C, int OH, int OW, int K, int stride, int pt, int pl) {
-  return N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && OH > 0 && OW > 0 && (K == 3 || K == 5) && stride >= 1 && pt >= 0 && pl >= 0;
+  return N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && OH > 0 && OW > 0 && (K == 3 || K == 5) && (stride == 1 || stride == 2) && pt >= 0 && pl >= 0;
 }
 
-int hifihr_dwconv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int OH, int OW, int K, int stride,
-                        int pad_top, int pad_left, void* stream) {
+int hifihr_dwconv2d_fwd(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int C, int OH, int OW, int K,
+                        int stride, int pad_top, int pad_left, void* stream) {
   if (!x || !w || !y || !dw_ok(N, H, W, C, OH, OW, K, stride, pad_top, pad_left)) return fail(HIFIHR_EINVAL, "hifihr_dwconv2d_fwd: bad argument");
   hifihr::DwGeom g{N, H, W, C, OH, OW, K, stride, pad_top, pad_left};
-  HIP_TRY(hifihr::launch_dwconv_fwd(g, x, w, y, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_dwconv_fwd(g, x, w, y, stats, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

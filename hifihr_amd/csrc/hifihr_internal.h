@@ -87,7 +87,7 @@ hipError_t launch_ssim_bwd(const SsimWindow& win, const float* img1, const float
 struct DwGeom {
   int N, H, W, C, OH, OW, K, stride, pt, pl;
 };
-hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, hipStream_t st);
+hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, float* stats, hipStream_t st);
 hipError_t launch_dwconv_bwd_data(const DwGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
 hipError_t launch_dwconv_bwd_weight(const DwGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
 

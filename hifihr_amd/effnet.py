@@ -112,9 +112,9 @@ class DepthwiseConvHIP(nn.Module):
         self.weight = nn.Parameter(torch.empty(c, 1, k, k))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
-    def forward(self, x):
+    def forward(self, x, want_stats=False):
         from . import ops
-        return ops.dwconv2d(x, self.weight, self.stride, self.pad4)
+        return ops.dwconv2d(x, self.weight, self.stride, self.pad4, want_stats)
 
 
 def _pointwise(cin, cout, impl):
@@ -158,7 +158,11 @@ class MBConvBlock(nn.Module):
             x = _conv_bn_swish(self._expand_conv, self._bn0, x)
         if isinstance(self._depthwise_conv, DepthwiseConvHIP):
             from . import ops
-            x = ops.bn_act(self._depthwise_conv(x), None, self._bn1, None, "swish")      # statistics pass + fused BN/swish
+            if self._bn1.training:
+                y, st = self._depthwise_conv(x, want_stats=True)                          # statistics from the kernel's epilogue
+                x = ops.bn_act(y, st, self._bn1, None, "swish")
+            else:
+                x = ops.bn_act(self._depthwise_conv(x), None, self._bn1, None, "swish")
         else:
             x = swish(self._bn1(self._depthwise_conv(x)))
         s = F.adaptive_avg_pool2d(x, 1)

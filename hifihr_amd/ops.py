@@ -750,7 +750,7 @@ def ssim_loss(img1, img2, lam):
 # ------------------------------------------------------------------------------------------------
 class _DwConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, pad4):
+    def forward(ctx, x, w, stride, pad4, want_stats=False):
         require_cuda(x, w)
         lib = get_lib()
         x = x.contiguous(memory_format=_CL)
@@ -760,14 +760,21 @@ class _DwConv(torch.autograd.Function):
         pl, pr, pt, pb = pad4
         OH, OW = (H + pt + pb - K) // stride + 1, (W + pl + pr - K) // stride + 1
         y = torch.empty((N, C, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
-        PROFILE.bracket("dwconv_fwd", lambda: lib.dwconv2d_fwd(x, w, y, N, H, W, C, OH, OW, K, stride, pt, pl))
+        stats = _ZERO_POOL.acquire(lib.bn_stats_floats(C), x.device) if want_stats else None
+        PROFILE.bracket("dwconv_fwd", lambda: lib.dwconv2d_fwd(x, w, y, N, H, W, C, OH, OW, K, stride, pt, pl, stats=stats))
         ctx.geom = (N, H, W, C, OH, OW, K, stride, pt, pl)
         ctx.save_for_backward(x, w)
         ctx.w_param = w
+        ctx.set_materialize_grads(False)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gstats=None):
+        if gy is None:
+            return (None,) * 5
         x, w = ctx.saved_tensors
         lib = get_lib()
         gy = gy.contiguous(memory_format=_CL)
@@ -784,10 +791,11 @@ class _DwConv(torch.autograd.Function):
             PROFILE.bracket("dwconv_wgrad", lambda: lib.dwconv2d_bwd_weight(x, gy, tgt, *ctx.geom))
             if dw is None:
                 _grad_ready(p)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
-def dwconv2d(x, w, stride, pad4):
+def dwconv2d(x, w, stride, pad4, want_stats=False):
     """F.conv2d(F.pad(x, pad4), w, groups=C, stride=stride) for channels_last fp32 tensors; pad4 = (left, right, top, bottom)
-    (reference network/efficientnet_pt/utils.py:122-145 with groups = channels)."""
-    return _DwConv.apply(x, w, stride, tuple(pad4))
+    (reference network/efficientnet_pt/utils.py:122-145 with groups = channels).  want_stats=True also returns the batch-norm
+    statistics of the output (for `bn_act`), accumulated in the kernel's epilogue."""
+    return _DwConv.apply(x, w, stride, tuple(pad4), want_stats)

@@ -197,11 +197,13 @@ int hifihr_bn_act_bwd(const float* dy_d, const float* y_d /* act 1 */, const flo
  * Depthwise convolution (groups == channels), NHWC fp32, k = 3 or 5, TensorFlow-style asymmetric zero padding.
  * Replaces the depthwise Conv2dStaticSamePadding of the reference's EfficientNet MBConv blocks
  * (reference network/efficientnet_pt/model.py:49-55,80; utils.py:122-145) and its autograd.
- * x[N][H][W][C], w[C][K][K] (= torch [C,1,K,K]), y[N][OH][OW][C]; pad_top/pad_left explicit, bottom/right implied by
- * OH/OW.  bwd_weight ACCUMULATES into dw (fp32 atomics).
+ * x[N][H][W][C], w[C][K][K] (= torch [C,1,K,K]), y[N][OH][OW][C]; stride 1 or 2; pad_top/pad_left explicit, bottom/right
+ * implied by OH/OW.  bwd_weight ACCUMULATES into dw (fp32 atomics).  fwd: stats_d (may be NULL) = batch-norm slot buffer
+ * (hifihr_bn_stats_floats(C) floats, all zero on entry, self-cleaning: see the batch-norm section) that receives the
+ * per-channel sum / sum of squares of y, so the BatchNorm that follows needs no statistics pass.
  * ---------------------------------------------------------------------------------------------- */
-int hifihr_dwconv2d_fwd(const float* x_d, const float* w_d, float* y_d, int N, int H, int W, int C, int OH, int OW, int K,
-                        int stride, int pad_top, int pad_left, void* stream);
+int hifihr_dwconv2d_fwd(const float* x_d, const float* w_d, float* y_d, float* stats_d /* or NULL */, int N, int H, int W, int C,
+                        int OH, int OW, int K, int stride, int pad_top, int pad_left, void* stream);
 int hifihr_dwconv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, int N, int H, int W, int C, int OH, int OW, int K,
                              int stride, int pad_top, int pad_left, void* stream);
 int hifihr_dwconv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int OH, int OW,

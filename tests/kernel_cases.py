@@ -354,9 +354,17 @@ def dwconv_case(lib, device, N, H, W, C, K, stride, seed=0):
     d = lambda t: t.to(device).contiguous()
     xd, wd, gyd = d(x.permute(0, 2, 3, 1)), d(w.reshape(C, K, K)), d(gy.permute(0, 2, 3, 1))
     out = torch.empty(N, OH, OW, C, device=device)
-    lib.dwconv2d_fwd(xd, wd, out, N, H, W, C, OH, OW, K, stride, pt, pl)
+    stats = torch.zeros(lib.bn_stats_floats(C), device=device)
+    lib.dwconv2d_fwd(xd, wd, out, N, H, W, C, OH, OW, K, stride, pt, pl, stats=stats)
     ref = y.detach().permute(0, 2, 3, 1)
     assert float((out.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, "dw fwd"
+    st = stats.view(-1, 2, C)[:-1].sum(0).cpu()
+    flat = ref.reshape(-1, C)
+    np.testing.assert_allclose(st[0].numpy(), flat.sum(0).numpy(), rtol=1e-4, atol=2e-3, err_msg="dw fwd: batch-norm sum")
+    np.testing.assert_allclose(st[1].numpy(), (flat ** 2).sum(0).numpy(), rtol=1e-4, atol=2e-3, err_msg="dw fwd: batch-norm sum of squares")
+    out2 = torch.empty_like(out)
+    lib.dwconv2d_fwd(xd, wd, out2, N, H, W, C, OH, OW, K, stride, pt, pl)            # without statistics
+    assert torch.equal(out2, out)
     dx = torch.empty(N, H, W, C, device=device)
     lib.dwconv2d_bwd_data(gyd, wd, dx, N, H, W, C, OH, OW, K, stride, pt, pl)
     refx = xr.grad.permute(0, 2, 3, 1)
