@@ -108,6 +108,9 @@ class HifihrLib:
         c.hifihr_sil_post.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_linear_fwd.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [_c_float_p] * 2 + [c_float, c_float] + [_c_float_p] * 6 + [c_void_p]
         c.hifihr_linear_bwd.argtypes = [_c_float_p] * 4 + [c_int] * 4 + [_c_float_p] * 10 + [c_void_p]
+        c.hifihr_se_pool.argtypes = [_c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
+        c.hifihr_se_scale.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_int, c_int, _c_float_p, c_void_p]
+        c.hifihr_se_bwd_gate.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_mmpool_fwd.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mmpool_bwd.argtypes = [_c_float_p, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p,
                                         _c_float_p, c_void_p]
@@ -258,19 +261,31 @@ class HifihrLib:
         assert rgba.is_contiguous() and (imgs is None or imgs.is_contiguous())
         self.check(self.c.hifihr_sil_post(_fp(rgba), _fp(imgs), B, H, W, _fp(re_sil), _fp(mask_rgbs), _stream_of(rgba)), "hifihr_sil_post")
 
-    def linear_fwd(self, x, w, b, act, y, bn=None):
-        """bn: None or (gamma, beta, eps, momentum, running_mean, running_var, z, save_mean, save_invstd)."""
+    def se_pool(self, x, B, HW, C, mean_zeroed):
+        self.check(self.c.hifihr_se_pool(_fp(x), B, HW, C, _fp(mean_zeroed), _stream_of(x)), "hifihr_se_pool")
+
+    def se_scale(self, x, gate, add, add_scale, B, HW, C, y):
+        self.check(self.c.hifihr_se_scale(_fp(x), _fp(gate), _fp(add), float(add_scale), B, HW, C, _fp(y), _stream_of(x)), "hifihr_se_scale")
+
+    def se_bwd_gate(self, dy, x, B, HW, C, dgate_zeroed):
+        self.check(self.c.hifihr_se_bwd_gate(_fp(dy), _fp(x), B, HW, C, _fp(dgate_zeroed), _stream_of(x)), "hifihr_se_bwd_gate")
+
+    def linear_fwd(self, x, w, b, act, y, bn=None, z=None):
+        """bn: None or (gamma, beta, eps, momentum, running_mean, running_var, z, save_mean, save_invstd); z: pre-activation
+        buffer for act 2 (swish) without batch-norm."""
         B, I = x.shape
         O = w.shape[0]
-        gamma, beta, eps, mom, rm, rv, z, sm, si = bn if bn is not None else (None, None, 0.0, 0.0, None, None, None, None, None)
+        gamma, beta, eps, mom, rm, rv, z_bn, sm, si = bn if bn is not None else (None, None, 0.0, 0.0, None, None, None, None, None)
+        z = z_bn if bn is not None else z
         self.check(self.c.hifihr_linear_fwd(_fp(x), _fp(w), _fp(b), B, I, O, int(act), _fp(gamma), _fp(beta), float(eps), float(mom),
                                             _fp(rm), _fp(rv), _fp(y), _fp(z), _fp(sm), _fp(si), _stream_of(x)), "hifihr_linear_fwd")
 
-    def linear_bwd(self, dy, y, x, w, act, dz, dW_acc, db_acc, dx, bn=None):
-        """bn: None or (gamma, z, save_mean, save_invstd, dgamma_acc, dbeta_acc)."""
+    def linear_bwd(self, dy, y, x, w, act, dz, dW_acc, db_acc, dx, bn=None, z=None):
+        """bn: None or (gamma, z, save_mean, save_invstd, dgamma_acc, dbeta_acc); z: pre-activation of an act-2 layer."""
         B, I = x.shape
         O = w.shape[0]
-        gamma, z, sm, si, dg, dbt = bn if bn is not None else (None,) * 6
+        gamma, z_bn, sm, si, dg, dbt = bn if bn is not None else (None,) * 6
+        z = z_bn if bn is not None else z
         self.check(self.c.hifihr_linear_bwd(_fp(dy), _fp(y), _fp(x), _fp(w), B, I, O, int(act), _fp(gamma), _fp(z), _fp(sm), _fp(si),
                                             _fp(dz), _fp(dW_acc), _fp(db_acc), _fp(dg), _fp(dbt), _fp(dx), _stream_of(x)),
                    "hifihr_linear_bwd")

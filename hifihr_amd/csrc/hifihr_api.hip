@@ -499,8 +499,8 @@ int hifihr_sil_post(const float* rgba, const float* imgs, int B, int H, int W, f
 int hifihr_linear_fwd(const float* x, const float* w, const float* b, int B, int I, int O, int act, const float* gamma, const float* beta,
                       float eps, float momentum, float* running_mean, float* running_var, float* y, float* z, float* save_mean,
                       float* save_invstd, void* stream) {
-  if (!x || !w || !y || B <= 0 || I <= 0 || O <= 0 || I % 4 != 0 || act < 0 || act > 1)
-    return fail(HIFIHR_EINVAL, "hifihr_linear_fwd: bad argument (I % 4 == 0, act 0/1)");
+  if (!x || !w || !y || B <= 0 || I <= 0 || O <= 0 || act < 0 || act > 3 || (act >= 2 && gamma) || (act == 2 && !z))
+    return fail(HIFIHR_EINVAL, "hifihr_linear_fwd: bad argument (act 0..3; swish / sigmoid take no batch-norm; swish needs z)");
   if (gamma && (!beta || !z || !save_mean || !save_invstd || B > 64 || ((running_mean != nullptr) != (running_var != nullptr))))
     return fail(HIFIHR_EINVAL, "hifihr_linear_fwd: batch-norm needs beta, z, save_mean, save_invstd and B <= 64");
   hifihr::LinearArgs a{x, w, b, y, z, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps, momentum, B, I, O, act};
@@ -511,14 +511,34 @@ int hifihr_linear_fwd(const float* x, const float* w, const float* b, int B, int
 int hifihr_linear_bwd(const float* dy, const float* y, const float* x, const float* w, int B, int I, int O, int act, const float* gamma,
                       const float* z, const float* save_mean, const float* save_invstd, float* dz_scratch, float* dW_acc, float* db_acc,
                       float* dgamma_acc, float* dbeta_acc, float* dx, void* stream) {
-  if (!dy || !x || !w || B <= 0 || I <= 0 || O <= 0 || I % 4 != 0 || act < 0 || act > 1 || (act == 1 && !y) || (dx && !dz_scratch))
-    return fail(HIFIHR_EINVAL, "hifihr_linear_bwd: bad argument (I % 4 == 0; act 1 needs y; dx needs dz_scratch)");
+  if (!dy || !x || !w || B <= 0 || I <= 0 || O <= 0 || act < 0 || act > 3 || ((act == 1 || act == 3) && !y) ||
+      (act == 2 && !z) || (dx && !dz_scratch))
+    return fail(HIFIHR_EINVAL, "hifihr_linear_bwd: bad argument (act 1 / 3 need y, act 2 needs z; dx needs dz_scratch)");
   if (gamma && (!z || !save_mean || !save_invstd || B > 64))
     return fail(HIFIHR_EINVAL, "hifihr_linear_bwd: batch-norm needs z, save_mean, save_invstd and B <= 64");
   hifihr::LinearArgs a{x, w, nullptr, const_cast<float*>(y), const_cast<float*>(z), gamma, nullptr, const_cast<float*>(save_mean),
                        const_cast<float*>(save_invstd), nullptr, nullptr, 0.f, 0.f, B, I, O, act};
   hifihr::LinearGrads g{dy, dz_scratch, dW_acc, db_acc, dgamma_acc, dbeta_acc, dx};
   HIP_TRY(hifihr::launch_linear_bwd(a, g, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_se_pool(const float* x, int B, int HW, int C, float* mean_zeroed, void* stream) {
+  if (!x || !mean_zeroed || B <= 0 || HW <= 0 || C < 4 || C % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_se_pool: bad argument (C % 4 == 0)");
+  HIP_TRY(hifihr::launch_se_pool(x, B, HW, C, mean_zeroed, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_se_scale(const float* x, const float* gate, const float* add, float add_scale, int B, int HW, int C, float* y, void* stream) {
+  if (!x || !gate || !y || B <= 0 || HW <= 0 || C < 4 || C % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_se_scale: bad argument (C % 4 == 0)");
+  HIP_TRY(hifihr::launch_se_scale(x, gate, add, add_scale, B, HW, C, y, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_se_bwd_gate(const float* dy, const float* x, int B, int HW, int C, float* dgate_zeroed, void* stream) {
+  if (!dy || !x || !dgate_zeroed || B <= 0 || HW <= 0 || C < 4 || C % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_se_bwd_gate: bad argument (C % 4 == 0)");
+  HIP_TRY(hifihr::launch_se_bwd_gate(dy, x, B, HW, C, dgate_zeroed, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

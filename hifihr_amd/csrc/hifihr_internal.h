@@ -128,7 +128,7 @@ struct LinearArgs {
   const float *gamma, *beta;
   float *save_mean, *save_invstd, *running_mean, *running_var;
   float eps, momentum;
-  int B, I, O, act;                     // act 0 none, 1 ReLU
+  int B, I, O, act;                     // act 0 none, 1 ReLU, 2 swish (z = pre-activation kept), 3 sigmoid (no batch-norm with 2 / 3)
 };
 struct LinearGrads {
   const float* dy;
@@ -136,6 +136,11 @@ struct LinearGrads {
 };
 hipError_t launch_linear_fwd(const LinearArgs& a, hipStream_t st);
 hipError_t launch_linear_bwd(const LinearArgs& a, const LinearGrads& g, hipStream_t st);
+
+// squeeze-and-excitation pieces (se.hip); the two fully connected layers in between are launch_linear_* (act 2 = swish, 3 = sigmoid)
+hipError_t launch_se_pool(const float* x, int B, int HW, int C, float* mean_zeroed, hipStream_t st);
+hipError_t launch_se_bwd_gate(const float* dy, const float* x, int B, int HW, int C, float* dgate_zeroed, hipStream_t st);
+hipError_t launch_se_scale(const float* x, const float* gate, const float* add, float ascale, int B, int HW, int C, float* y, hipStream_t st);
 
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st);

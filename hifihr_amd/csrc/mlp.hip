@@ -23,6 +23,18 @@ namespace hifihr {
 
 constexpr int kFT = 16;       // output features per workgroup
 
+// 4 consecutive floats of a row of length `len` starting at column c4 (zero past the end); rows are only 16-byte aligned
+// when the row length is a multiple of 4 (the squeeze-excite layers have 6, 10, 34, 58 ... input features)
+__device__ __forceinline__ float4 load4_guarded(const float* __restrict__ row, int c4, int len, bool aligned) {
+  if (aligned) return *reinterpret_cast<const float4*>(row + c4);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < len) v.x = row[c4];
+  if (c4 + 1 < len) v.y = row[c4 + 1];
+  if (c4 + 2 < len) v.z = row[c4 + 2];
+  if (c4 + 3 < len) v.w = row[c4 + 3];
+  return v;
+}
+
 template <int RB>
 struct MlpCfg {
   static constexpr int IC = (RB == 32) ? 512 : 256;   // input features per LDS chunk
@@ -48,6 +60,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
 #pragma unroll
   for (int k = 0; k < KR; ++k) acc[k] = 0.f;
   constexpr int CPR = C::IC / 4;                  // float4 per LDS row
+  const bool al4 = (a.I & 3) == 0;
   for (int i0 = 0; i0 < a.I; i0 += C::IC) {
     const int ilen = min(C::IC, a.I - i0);
     float4 xr[C::XL], wr[C::WL];
@@ -55,13 +68,13 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
     for (int p = 0; p < C::XL; ++p) {             // all loads of the chunk first ...
       const int e = tid + 256 * p, r = e / CPR, c4 = (e % CPR) * 4;
       xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < nrow && c4 < ilen) xr[p] = *reinterpret_cast<const float4*>(a.x + (size_t)(row0 + r) * a.I + i0 + c4);
+      if (r < nrow && c4 < ilen) xr[p] = load4_guarded(a.x + (size_t)(row0 + r) * a.I + i0, c4, ilen, al4);
     }
 #pragma unroll
     for (int p = 0; p < C::WL; ++p) {
       const int e = tid + 256 * p, r = e / CPR, c4 = (e % CPR) * 4;
       wr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (o0 + r < a.O && c4 < ilen) wr[p] = *reinterpret_cast<const float4*>(a.W + (size_t)(o0 + r) * a.I + i0 + c4);
+      if (o0 + r < a.O && c4 < ilen) wr[p] = load4_guarded(a.W + (size_t)(o0 + r) * a.I + i0, c4, ilen, al4);
     }
 #pragma unroll
     for (int p = 0; p < C::XL; ++p) {             // ... then the LDS stores
@@ -124,7 +137,14 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
 #pragma unroll
   for (int k = 0; k < KR; ++k) {
     const int r = rg + 16 * k;
-    if (r < nrow && ook) a.y[(size_t)(row0 + r) * a.O + o] = (a.act == 1) ? fmaxf(acc[k], 0.f) : acc[k];
+    if (r < nrow && ook) {
+      const size_t off = (size_t)(row0 + r) * a.O + o;
+      float v = acc[k];
+      if (a.act == 1) v = fmaxf(v, 0.f);
+      else if (a.act == 2) { if (a.gamma == nullptr) a.z[off] = v; v = v / (1.f + expf(-v)); }     // swish keeps z for the backward
+      else if (a.act == 3) v = 1.f / (1.f + expf(-v));
+      a.y[off] = v;
+    }
   }
 }
 
@@ -142,10 +162,17 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearG
   const int o = o0 + ol;
   const bool ook = o < a.O;
   // the dx zero fill rides along (linear_bwd_x_kernel adds into it): each workgroup clears an equal slice
+  const bool al4 = (a.I & 3) == 0;
   if (g.dx != nullptr) {
-    const size_t n4 = (size_t)a.B * a.I / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
-    const size_t lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
-    for (size_t i = lo + tid; i < hi; i += 256) reinterpret_cast<float4*>(g.dx)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (al4) {
+      const size_t n4 = (size_t)a.B * a.I / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
+      const size_t lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+      for (size_t i = lo + tid; i < hi; i += 256) reinterpret_cast<float4*>(g.dx)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const size_t n = (size_t)a.B * a.I, per = (n + gridDim.x - 1) / gridDim.x;
+      const size_t lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+      for (size_t i = lo + tid; i < hi; i += 256) g.dx[i] = 0.f;
+    }
   }
   const bool bn = a.gamma != nullptr;
   for (int row0 = 0; row0 < a.B; row0 += kRowsMax) {     // batch-norm layers have B <= 64 (checked by the launcher): one pass
@@ -158,7 +185,9 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearG
       if (r < nrow && ook) {
         const size_t off = (size_t)(row0 + r) * a.O + o;
         v = g.dy[off];
-        if (a.act == 1 && !(a.y[off] > 0.f)) v = 0.f;
+        if (a.act == 1) { if (!(a.y[off] > 0.f)) v = 0.f; }
+        else if (a.act == 2) { const float z = a.z[off], sg = 1.f / (1.f + expf(-z)); v *= sg * (1.f + z * (1.f - sg)); }
+        else if (a.act == 3) { const float yy = a.y[off]; v *= yy * (1.f - yy); }
       }
       gv[k] = v;
     }
@@ -229,7 +258,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearG
         for (int p = 0; p < 16; ++p) {
           const int e = tid + 256 * p, r = e / (kWC / 4), c4 = (e % (kWC / 4)) * 4;
           xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (r < nr && c4 < ilen) xr[p] = *reinterpret_cast<const float4*>(a.x + (size_t)(row0 + rh + r) * a.I + i0 + c4);
+          if (r < nr && c4 < ilen) xr[p] = load4_guarded(a.x + (size_t)(row0 + rh + r) * a.I + i0, c4, ilen, al4);
         }
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
@@ -327,12 +356,12 @@ static hipError_t launch_fwd_rb(const LinearArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_linear_fwd(const LinearArgs& a, hipStream_t st) {
-  if (a.I % 4 != 0 || (a.gamma != nullptr && a.B > kRowsMax)) return hipErrorInvalidValue;
+  if (a.gamma != nullptr && a.B > kRowsMax) return hipErrorInvalidValue;
   return a.B <= 32 ? launch_fwd_rb<32>(a, st) : launch_fwd_rb<64>(a, st);
 }
 
 hipError_t launch_linear_bwd(const LinearArgs& a, const LinearGrads& g, hipStream_t st) {
-  if (a.I % 4 != 0 || (a.gamma != nullptr && a.B > kRowsMax) || (g.dx != nullptr && g.dz == nullptr)) return hipErrorInvalidValue;
+  if ((a.gamma != nullptr && a.B > kRowsMax) || (g.dx != nullptr && g.dz == nullptr)) return hipErrorInvalidValue;
   constexpr size_t lds = (size_t)32 * kWLD * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

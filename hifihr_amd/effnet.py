@@ -165,9 +165,13 @@ class MBConvBlock(nn.Module):
                 x = ops.bn_act(self._depthwise_conv(x), None, self._bn1, None, "swish")
         else:
             x = swish(self._bn1(self._depthwise_conv(x)))
-        s = F.adaptive_avg_pool2d(x, 1)
-        s = self._se_expand(swish(self._se_reduce(s)))
-        x = torch.sigmoid(s) * x
+        if isinstance(self._depthwise_conv, DepthwiseConvHIP) and x.shape[1] % 4 == 0:
+            from . import ops
+            x = ops.squeeze_excite(x, self._se_reduce, self._se_expand)        # pool + 2 small linears + scale, fused
+        else:
+            s = F.adaptive_avg_pool2d(x, 1)
+            s = self._se_expand(swish(self._se_reduce(s)))
+            x = torch.sigmoid(s) * x
         x = _conv_bn_swish(self._project_conv, self._bn2, x, act=False)
         if self.stride == 1 and self.cin == self.cout:
             if drop_connect_rate and self.training:                       # utils.py:82-91

@@ -590,6 +590,63 @@ def linear(x, lin: torch.nn.Linear, act=None, bn: torch.nn.BatchNorm1d | None = 
 
 
 # ------------------------------------------------------------------------------------------------
+# squeeze-and-excitation (csrc/se.hip + the small-batch linear kernels)
+# ------------------------------------------------------------------------------------------------
+class _SqueezeExcite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        require_cuda(x, w1, w2)
+        lib = get_lib()
+        x = x.contiguous(memory_format=_CL)
+        B, C, H, W = x.shape
+        HW, SQ = H * W, w1.shape[0]
+        dev = x.device
+        mean = torch.zeros(B, C, device=dev)
+        PROFILE.bracket("se_pool", lambda: lib.se_pool(x, B, HW, C, mean))
+        h1, z1, gate = torch.empty(B, SQ, device=dev), torch.empty(B, SQ, device=dev), torch.empty(B, C, device=dev)
+        PROFILE.bracket("linear_fwd", lambda: lib.linear_fwd(mean, w1, b1, 2, h1, z=z1))          # swish
+        PROFILE.bracket("linear_fwd", lambda: lib.linear_fwd(h1, w2, b2, 3, gate))                 # sigmoid
+        y = torch.empty_like(x, memory_format=_CL)
+        PROFILE.bracket("se_scale", lambda: lib.se_scale(x, gate, None, 0.0, B, HW, C, y))
+        ctx.save_for_backward(x, mean, h1, z1, gate, w1, w2)
+        ctx.params = (w1, b1, w2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, h1, z1, gate, w1, w2 = ctx.saved_tensors
+        pw1, pb1, pw2, pb2 = ctx.params
+        lib = get_lib()
+        dy = dy.contiguous(memory_format=_CL)
+        B, C, H, W = x.shape
+        HW, SQ = H * W, w1.shape[0]
+        dev = x.device
+        dgate = torch.zeros(B, C, device=dev)
+        PROFILE.bracket("se_bwd_gate", lambda: lib.se_bwd_gate(dy, x, B, HW, C, dgate))
+        rets = []
+        tgts = []
+        for p in (pw1, pb1, pw2, pb2):
+            t, r = _acc_target(p, p.shape, dev)
+            tgts.append(t); rets.append(r)
+        dh1, dmean = torch.empty(B, SQ, device=dev), torch.empty(B, C, device=dev)
+        dz2, dz1 = torch.empty(B, C, device=dev), torch.empty(B, SQ, device=dev)
+        PROFILE.bracket("linear_bwd", lambda: lib.linear_bwd(dgate, gate, h1, w2, 3, dz2, tgts[2], tgts[3], dh1))
+        PROFILE.bracket("linear_bwd", lambda: lib.linear_bwd(dh1, None, mean, w1, 2, dz1, tgts[0], tgts[1], dmean, z=z1))
+        dx = torch.empty_like(x, memory_format=_CL)
+        PROFILE.bracket("se_bwd_dx", lambda: lib.se_scale(dy, gate, dmean, 1.0 / HW, B, HW, C, dx))
+        for p, r in zip((pw1, pb1, pw2, pb2), rets):
+            if r is None:
+                _grad_ready(p)
+        return dx, rets[0], rets[1], rets[2], rets[3]
+
+
+def squeeze_excite(x, reduce_conv, expand_conv):
+    """x * sigmoid(expand(swish(reduce(mean_hw(x))))) for channels_last x; reduce / expand are the block's 1x1 nn.Conv2d with
+    bias (reference network/efficientnet_pt/model.py:82-86): 4 launches forward, 7 backward."""
+    return _SqueezeExcite.apply(x, reduce_conv.weight, reduce_conv.bias, expand_conv.weight, expand_conv.bias)
+
+
+# ------------------------------------------------------------------------------------------------
 # pooling (csrc/pool.hip)
 # ------------------------------------------------------------------------------------------------
 def _acc_target(p, shape, device):

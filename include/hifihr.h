@@ -289,7 +289,9 @@ int hifihr_sil_post(const float* rgba_d, const float* imgs_d, int B, int H, int 
 /* ------------------------------------------------------------------------------------------------
  * Small-batch fully connected layer of the regression heads: y[B][O] = act( BN1d?( x[B][I] W[O][I]^T + b ) ).
  * Replaces nn.Linear (+ nn.BatchNorm1d, training mode) (+ nn.ReLU) and their autograd in the reference's HandEncoder /
- * LightEstimator heads (reference network/res_encoder.py:52-145, 150-210).  I % 4 == 0; act 0 = none, 1 = ReLU.
+ * LightEstimator heads (reference network/res_encoder.py:52-145, 150-210).  Any I (16-byte loads when I % 4 == 0); act 0 = none, 1 = ReLU,
+ * 2 = swish (z_d receives the pre-activation, needed by the backward), 3 = sigmoid -- 2 / 3 serve the squeeze-excite
+ * layers below and take no batch-norm.
  * Batch-norm (gamma_d != NULL, B <= 64): batch statistics over the B rows, running statistics updated with `momentum`
  * (unbiased variance), z_d[B][O] receives the pre-normalisation output, save_mean_d / save_invstd_d[O] the statistics.
  * bwd: dy_d = gradient of y; y_d (act 1) gives the ReLU mask; dz_scratch_d[B][O]; dW_acc_d[O][I], db_acc_d[O],
@@ -303,6 +305,19 @@ int hifihr_linear_bwd(const float* dy_d, const float* y_d, const float* x_d, con
                       const float* gamma_d, const float* z_d, const float* save_mean_d, const float* save_invstd_d,
                       float* dz_scratch_d, float* dW_acc_d, float* db_acc_d, float* dgamma_acc_d, float* dbeta_acc_d,
                       float* dx_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Squeeze-and-excitation of the EfficientNet MBConv block (reference network/efficientnet_pt/model.py:82-86):
+ *   y = x * sigmoid( W2 swish( W1 mean_hw(x) + b1 ) + b2 ),  x[B][HW][C] NHWC, C % 4 == 0.
+ * se_pool: mean_d[B][C] += mean over HW (mean_d must be ZERO on entry: partial sums are added with atomics).
+ * The two layers are hifihr_linear_fwd / _bwd with act 2 and 3.  se_scale: y = x * gate[b][c] (+ add[b][c] * add_scale when
+ * add_d != NULL).  Backward: se_bwd_gate: dgate_d[B][C] += sum_hw dy * x (zero on entry); then the linear backwards give
+ * dmean; finally dx = se_scale(dy, gate, add = dmean, add_scale = 1 / HW) folds the pooling branch into the same pass.
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_se_pool(const float* x_d, int B, int HW, int C, float* mean_zeroed_d, void* stream);
+int hifihr_se_scale(const float* x_d, const float* gate_d, const float* add_d /* or NULL */, float add_scale, int B, int HW, int C,
+                    float* y_d, void* stream);
+int hifihr_se_bwd_gate(const float* dy_d, const float* x_d, int B, int HW, int C, float* dgate_zeroed_d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -588,3 +588,50 @@ def conv_bias_relu_case(lib, device, N, H, W, C, K, R, stride, seed=0):
     refg = z.grad.permute(0, 2, 3, 1)
     assert float(((g.cpu() - refg) * safe).abs().max()) <= 1e-6, "masked gradient"
     assert float((db.cpu() - 0.5 - br.grad).abs().max()) <= 1e-4 * float(br.grad.abs().max()) + 1e-5, "bias gradient (accumulates)"
+
+
+# ------------------------------------------------------------------------------------------------
+# squeeze-and-excitation (csrc/se.hip + the linear kernels with swish / sigmoid epilogues) vs torch autograd
+# ------------------------------------------------------------------------------------------------
+def se_case(lib, device, B, H, W, C, SQ, seed=0):
+    import torch.nn.functional as Fn
+    gen = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=gen)
+    x = rnd(B, C, H, W); w1 = rnd(SQ, C) / C ** 0.5; b1 = rnd(SQ) * 0.1; w2 = rnd(C, SQ) / SQ ** 0.5; b2 = rnd(C) * 0.1
+    xr, w1r, b1r, w2r, b2r = (t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2))
+    m = xr.mean((2, 3))
+    z1 = Fn.linear(m, w1r, b1r)
+    h1 = z1 * torch.sigmoid(z1)
+    gate = torch.sigmoid(Fn.linear(h1, w2r, b2r))
+    y = xr * gate[:, :, None, None]
+    gy = rnd(B, C, H, W)
+    y.backward(gy)
+    d = lambda t: t.to(device).contiguous()
+    HW = H * W
+    xd = d(x.permute(0, 2, 3, 1)); gyd = d(gy.permute(0, 2, 3, 1))
+    mean = torch.zeros(B, C, device=device)
+    lib.se_pool(xd, B, HW, C, mean)
+    assert float((mean.cpu() - m.detach()).abs().max()) <= 1e-5, "se pool"
+    h1d, z1d, gd = torch.empty(B, SQ, device=device), torch.empty(B, SQ, device=device), torch.empty(B, C, device=device)
+    w1d, b1d, w2d, b2d = d(w1), d(b1), d(w2), d(b2)
+    lib.linear_fwd(mean, w1d, b1d, 2, h1d, z=z1d)
+    lib.linear_fwd(h1d, w2d, b2d, 3, gd)
+    assert float((gd.cpu() - gate.detach()).abs().max()) <= 2e-5, "se gate"
+    yd = torch.empty(B, H, W, C, device=device)
+    lib.se_scale(xd, gd, None, 0.0, B, HW, C, yd)
+    ref = y.detach().permute(0, 2, 3, 1)
+    assert float((yd.cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()), "se fwd"
+    dgate = torch.zeros(B, C, device=device)
+    lib.se_bwd_gate(gyd, xd, B, HW, C, dgate)
+    dw1, db1, dw2, db2 = (torch.zeros_like(t) for t in (w1d, b1d, w2d, b2d))
+    dh1, dmean = torch.empty(B, SQ, device=device), torch.empty(B, C, device=device)
+    dz2, dz1 = torch.empty(B, C, device=device), torch.empty(B, SQ, device=device)
+    lib.linear_bwd(dgate, gd, h1d, w2d, 3, dz2, dw2, db2, dh1)
+    lib.linear_bwd(dh1, None, mean, w1d, 2, dz1, dw1, db1, dmean, z=z1d)
+    dx = torch.empty(B, H, W, C, device=device)
+    lib.se_scale(gyd, gd, dmean, 1.0 / HW, B, HW, C, dx)
+    def rel(got, want, name, t=3e-4):
+        err, mag = float((got.cpu() - want).abs().max()), float(want.abs().max())
+        assert err <= t * mag + 1e-7, f"se {name}: {err} vs {mag}"
+    rel(dx, xr.grad.permute(0, 2, 3, 1), "dx")
+    rel(dw1, w1r.grad, "dw1"); rel(db1, b1r.grad, "db1"); rel(dw2, w2r.grad, "dw2"); rel(db2, b2r.grad, "db2")

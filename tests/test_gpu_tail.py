@@ -50,3 +50,8 @@ def test_light_estimator_convs(lib, N, H, C, K, R, stride):
 @pytest.mark.parametrize("N,H,C,ksp", [(32, 12, 48, (3, 1, 1)), (32, 5, 64, (2, 2, 0))])
 def test_light_estimator_pools(lib, N, H, C, ksp):
     kc.maxpool_case(lib, "cuda", N, H, H, C, seed=C, ties=True, ksp=ksp)
+
+
+@pytest.mark.parametrize("B,H,C,SQ", [(32, 112, 40, 10), (32, 28, 288, 12), (32, 14, 816, 34), (8, 7, 2304, 96)])
+def test_squeeze_excite(lib, B, H, C, SQ):
+    kc.se_case(lib, "cuda", B, H, H, C, SQ, seed=C)
