@@ -161,16 +161,21 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearG
   const int o0 = blockIdx.x * kFT;
   const int o = o0 + ol;
   const bool ook = o < a.O;
+  // blockIdx.y = 512-wide slice of the input features: the squeeze-excite "reduce" layers have 6-96 outputs and up to 2304
+  // inputs, i.e. 1-6 feature blocks only; every slice recomputes the (tiny) dz part and slice 0 alone accumulates db / dgamma /
+  // dbeta and writes dz.
+  const bool first_slice = blockIdx.y == 0;
   // the dx zero fill rides along (linear_bwd_x_kernel adds into it): each workgroup clears an equal slice
   const bool al4 = (a.I & 3) == 0;
   if (g.dx != nullptr) {
+    const unsigned nwg = gridDim.x * gridDim.y, wgi = blockIdx.y * gridDim.x + blockIdx.x;
     if (al4) {
-      const size_t n4 = (size_t)a.B * a.I / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
-      const size_t lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+      const size_t n4 = (size_t)a.B * a.I / 4, per = (n4 + nwg - 1) / nwg;
+      const size_t lo = per * wgi, hi = lo + per < n4 ? lo + per : n4;
       for (size_t i = lo + tid; i < hi; i += 256) reinterpret_cast<float4*>(g.dx)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-      const size_t n = (size_t)a.B * a.I, per = (n + gridDim.x - 1) / gridDim.x;
-      const size_t lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+      const size_t n = (size_t)a.B * a.I, per = (n + nwg - 1) / nwg;
+      const size_t lo = per * wgi, hi = lo + per < n ? lo + per : n;
       for (size_t i = lo + tid; i < hi; i += 256) g.dx[i] = 0.f;
     }
   }
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearG
         for (int r = 0; r < 16; ++r) { s0 += dzs[r][tid]; s1 += dzs[16 + r][tid]; }
         red[0][tid] = s0 / (float)nrow;
         red[1][tid] = s1 / (float)nrow;
-        if (o0 + tid < a.O) {
+        if (o0 + tid < a.O && first_slice) {
           if (g.dgamma_acc) g.dgamma_acc[o0 + tid] += s1;
           if (g.dbeta_acc) g.dbeta_acc[o0 + tid] += s0;
         }
@@ -233,10 +238,10 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearG
     for (int k = 0; k < 4; ++k) {
       const int r = rg + 16 * k;
       dzs[r][ol] = gv[k];
-      if (r < nrow && ook && g.dz != nullptr) g.dz[(size_t)(row0 + r) * a.O + o] = gv[k];
+      if (r < nrow && ook && g.dz != nullptr && first_slice) g.dz[(size_t)(row0 + r) * a.O + o] = gv[k];
     }
     __syncthreads();
-    if (tid < kFT && o0 + tid < a.O && g.db_acc != nullptr) {
+    if (tid < kFT && o0 + tid < a.O && g.db_acc != nullptr && first_slice) {
       float s = 0.f;
       for (int r = 0; r < nrow; ++r) s += dzs[r][tid];
       g.db_acc[o0 + tid] += s;
@@ -244,7 +249,8 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearG
     if (g.dW_acc == nullptr) { __syncthreads(); continue; }
     // dW[o0 + 4*og + j][i] += sum_r dz[r][4*og + j] * x[r][i];  thread = (i lane 0..63, feature group og 0..3)
     const int il = tid & 63, og = tid >> 6;
-    for (int i0 = 0; i0 < a.I; i0 += kWC) {
+    {
+      const int i0 = blockIdx.y * kWC;
       const int ilen = min(kWC, a.I - i0);
       float w[kWC / 64][4];
 #pragma unroll
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(LinearArgs a, LinearG
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.f;
 #pragma unroll 1
-    for (int c0 = 0; c0 < kOS; c0 += 16) {
+    for (int c0 = 0; c0 < on; c0 += 16) {
       float wv[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {              // 16 independent loads in flight (rows past `on` re-read the last row: dz is 0 there)
@@ -369,7 +375,7 @@ hipError_t launch_linear_bwd(const LinearArgs& a, const LinearGrads& g, hipStrea
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((a.O + kFT - 1) / kFT), dim3(256), lds, st, a, g);
+  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((a.O + kFT - 1) / kFT, (a.I + kWC - 1) / kWC), dim3(256), lds, st, a, g);
   if (g.dx != nullptr)
     hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((a.I + 63) / 64, (a.O + kOS - 1) / kOS), dim3(256), 0, st, a, g);
   return hipGetLastError();

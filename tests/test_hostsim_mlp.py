@@ -11,6 +11,6 @@ def hostsim_lib():
 
 @pytest.mark.parametrize("B,I,O,act,bn,need_dx", [(32, 128, 48, 0, False, True), (6, 512, 40, 1, True, True), (4, 32, 3, 0, False, True),
                                                   (5, 128, 1, 0, False, False), (64, 72, 33, 1, True, True), (70, 36, 20, 1, False, True),
-                                                  (3, 256, 300, 1, False, True)])
+                                                  (3, 256, 300, 1, False, True), (5, 1100, 20, 1, False, True), (4, 1038, 6, 1, True, True)])
 def test_linear(hostsim_lib, B, I, O, act, bn, need_dx):
     kc.linear_case(hostsim_lib, "cpu", B, I, O, act, bn, seed=B + O, need_dx=need_dx)
