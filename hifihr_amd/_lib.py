@@ -98,6 +98,7 @@ class HifihrLib:
         c.hifihr_bn_act_bwd.argtypes = [_c_float_p] * 7 + [c_int, c_long, c_int] + [_c_float_p] * 5 + [c_void_p]
         c.hifihr_conv2d_bwd_weight.argtypes = [_c_float_p] * 3 + ci + [c_void_p]
         c.hifihr_image_to_nhwc4.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
+        c.hifihr_image_to_nhwc4_padded.argtypes = [_c_float_p, _c_float_p] + [c_int] * 8 + [c_void_p]
         c.hifihr_geom_loss_fwd.argtypes = [_c_float_p] * 6 + [_c_int_p] + [c_int] * 7 + [_c_float_p] * 3 + [c_void_p]
         c.hifihr_geom_loss_bwd.argtypes = [_c_float_p] * 6 + [_c_int_p] * 3 + [c_int] * 7 + [_c_float_p] * 6 + [c_void_p]
         c.hifihr_photo_loss_partial_floats.argtypes = []
@@ -318,6 +319,13 @@ class HifihrLib:
     def image_to_nhwc4(self, images, out):
         B, _, H, W = images.shape
         self.check(self.c.hifihr_image_to_nhwc4(_fp(images), _fp(out), B, H, W, _stream_of(images)), "hifihr_image_to_nhwc4")
+
+    def image_to_nhwc4_padded(self, images, out, pad4, normalize):
+        """pad4 = (left, right, top, bottom) like F.pad."""
+        B, _, H, W = images.shape
+        pl, pr, pt, pb = pad4
+        self.check(self.c.hifihr_image_to_nhwc4_padded(_fp(images), _fp(out), B, H, W, pt, pl, pb, pr, int(bool(normalize)),
+                                                       _stream_of(images)), "hifihr_image_to_nhwc4_padded")
 
     # ---- SSIM ----------------------------------------------------------
     def ssim_partial_count(self, planes, H, W):

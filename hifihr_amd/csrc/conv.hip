@@ -642,13 +642,22 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
   }
 }
 
-// images NCHW [B][3][H][W] in [0,1] -> NHWC4 [B][H][W][4] = ((x - mean) / std, 0)
-__global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float* __restrict__ img, float4* __restrict__ out, int B, int HW) {
-  const size_t n = (size_t)B * HW;
+// images NCHW [B][3][H][W] in [0,1] -> NHWC4 [B][OH][OW][4]; output pixel (oy, ox) = input pixel (oy - pt, ox - pl) or zero
+// (explicit zero border: the EfficientNet stem's asymmetric "same" padding); normalize: ((x - mean) / std, 0)
+__global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float* __restrict__ img, float4* __restrict__ out, int B, int H, int W,
+                                                            int OH, int OW, int pt, int pl, int normalize) {
+  const size_t n = (size_t)B * OH * OW, HW = (size_t)H * W;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const size_t b = i / HW, p = i - b * HW;
-    const float* s = img + b * 3 * HW + p;
-    out[i] = make_float4((s[0] - 0.485f) / 0.229f, (s[HW] - 0.456f) / 0.224f, (s[2 * (size_t)HW] - 0.406f) / 0.225f, 0.f);
+    const size_t b = i / ((size_t)OH * OW), p = i - b * OH * OW;
+    const int oy = (int)(p / OW), ox = (int)(p - (size_t)oy * OW);
+    const int iy = oy - pt, ix = ox - pl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+      const float* s = img + b * 3 * HW + (size_t)iy * W + ix;
+      v = normalize ? make_float4((s[0] - 0.485f) / 0.229f, (s[HW] - 0.456f) / 0.224f, (s[2 * HW] - 0.406f) / 0.225f, 0.f)
+                    : make_float4(s[0], s[HW], s[2 * HW], 0.f);
+    }
+    out[i] = v;
   }
 }
 // gradient of the above is never needed (images carry no gradient)
@@ -848,11 +857,13 @@ hipError_t launch_weight_transpose(const float* w, float* wt, int K, int RS, int
   return hipGetLastError();
 }
 
-hipError_t launch_image_to_nhwc4(const float* img, float* out, int B, int HW, hipStream_t st) {
-  const size_t n = (size_t)B * HW;
+hipError_t launch_image_to_nhwc4(const float* img, float* out, int B, int H, int W, int OH, int OW, int pt, int pl, int normalize,
+                                 hipStream_t st) {
+  const size_t n = (size_t)B * OH * OW;
   unsigned blocks = (unsigned)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(image_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, st, img, reinterpret_cast<float4*>(out), B, HW);
+  hipLaunchKernelGGL(image_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, st, img, reinterpret_cast<float4*>(out), B, H, W, OH, OW, pt, pl,
+                     normalize);
   return hipGetLastError();
 }
 

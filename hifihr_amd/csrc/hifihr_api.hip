@@ -302,7 +302,16 @@ int hifihr_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int N, 
 
 int hifihr_image_to_nhwc4(const float* images, float* out, int B, int H, int W, void* stream) {
   if (!images || !out || B <= 0 || H <= 0 || W <= 0) return fail(HIFIHR_EINVAL, "hifihr_image_to_nhwc4: bad argument");
-  HIP_TRY(hifihr::launch_image_to_nhwc4(images, out, B, H * W, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_image_to_nhwc4(images, out, B, H, W, H, W, 0, 0, 1, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_image_to_nhwc4_padded(const float* images, float* out, int B, int H, int W, int pad_top, int pad_left, int pad_bottom,
+                                 int pad_right, int normalize, void* stream) {
+  if (!images || !out || B <= 0 || H <= 0 || W <= 0 || pad_top < 0 || pad_left < 0 || pad_bottom < 0 || pad_right < 0)
+    return fail(HIFIHR_EINVAL, "hifihr_image_to_nhwc4_padded: bad argument");
+  HIP_TRY(hifihr::launch_image_to_nhwc4(images, out, B, H, W, H + pad_top + pad_bottom, W + pad_left + pad_right, pad_top, pad_left,
+                                        normalize ? 1 : 0, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

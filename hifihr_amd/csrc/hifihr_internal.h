@@ -73,7 +73,8 @@ hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, co
                              float* dgamma_acc, float* dbeta_acc, hipStream_t st);
 hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
 hipError_t launch_weight_transpose(const float* w, float* wt, int K, int RS, int C, hipStream_t st);
-hipError_t launch_image_to_nhwc4(const float* img, float* out, int B, int HW, hipStream_t st);
+hipError_t launch_image_to_nhwc4(const float* img, float* out, int B, int H, int W, int OH, int OW, int pt, int pl, int normalize,
+                                 hipStream_t st);
 
 struct SsimWindow {
   float g[11];      // normalised 1-D gaussian (sigma 1.5), as pytorch_ssim.gaussian builds it

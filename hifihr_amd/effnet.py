@@ -189,7 +189,11 @@ class EfficientNetB3(nn.Module):
         super().__init__()
         self.conv_impl = conv_impl
         stem = round_filters(32)
-        self._conv_stem = SamePadConv2d(3, stem, 3, 2, bias=False)
+        if conv_impl == "mfma":
+            from .network import Conv2dMFMA
+            self._conv_stem = Conv2dMFMA(3, stem, 3, stride=2, pad=0)      # the static same padding goes into the NHWC4 repack
+        else:
+            self._conv_stem = SamePadConv2d(3, stem, 3, 2, bias=False)
         self._bn0 = _bn(stem)
         table = b3_block_table()
         assert len(table) == 26 and table[0][3] == stem
@@ -201,8 +205,15 @@ class EfficientNetB3(nn.Module):
 
     def extract_features(self, x):
         if self.conv_impl == "mfma":
-            x = x.contiguous(memory_format=torch.channels_last)
-        x = swish(self._bn0(self._conv_stem(x)))
+            from . import ops
+            x4 = ops.image_to_nhwc4(x, pad4=static_same_pad(3, 2), normalize=False)      # model.py:197-199 (no normalisation)
+            if self._bn0.training:
+                y, st = self._conv_stem(x4, want_stats=True)
+                x = ops.bn_act(y, st, self._bn0, None, "swish")
+            else:
+                x = ops.bn_act(self._conv_stem(x4), None, self._bn0, None, "swish")
+        else:
+            x = swish(self._bn0(self._conv_stem(x)))
         low = None
         n = len(self._blocks)
         for idx, blk in enumerate(self._blocks):

@@ -727,12 +727,18 @@ def maxpool3x3s2(x):
     return _MaxPool2d.apply(x, 3, 2, 1)
 
 
-def image_to_nhwc4(images):
-    """normalize_batch_3C + repack: [B,3,H,W] -> logical [B,4,H,W] channels_last (4th channel zero)."""
+def image_to_nhwc4(images, pad4=None, normalize=True):
+    """normalize_batch_3C + repack: [B,3,H,W] -> logical [B,4,H,W] channels_last (4th channel zero).  pad4 = (left, right, top,
+    bottom) adds an explicit zero border (EfficientNet stem: static "same" padding), normalize=False skips the normalisation."""
     require_cuda(images)
     B, _, H, W = images.shape
-    out = torch.empty((B, 4, H, W), device=images.device, dtype=torch.float32, memory_format=_CL)
-    get_lib().image_to_nhwc4(images.contiguous(), out)
+    if pad4 is None and normalize:
+        out = torch.empty((B, 4, H, W), device=images.device, dtype=torch.float32, memory_format=_CL)
+        get_lib().image_to_nhwc4(images.contiguous(), out)
+        return out
+    pl, pr, pt, pb = pad4 if pad4 is not None else (0, 0, 0, 0)
+    out = torch.empty((B, 4, H + pt + pb, W + pl + pr), device=images.device, dtype=torch.float32, memory_format=_CL)
+    get_lib().image_to_nhwc4_padded(images.contiguous(), out, (pl, pr, pt, pb), normalize)
     return out
 
 

@@ -232,6 +232,11 @@ int hifihr_maxpool2d_bwd(const float* gy_d, const unsigned char* tap_d, int N, i
 /* normalize_batch_3C (reference network/res_encoder.py:212-216) fused with NCHW[B][3][H][W] -> NHWC4 [B][H][W][4]
  * (4th channel zero) for the first convolution. */
 int hifihr_image_to_nhwc4(const float* images_d, float* out_d, int B, int H, int W, void* stream);
+/* Same repack with an explicit zero border and optional normalisation: out[B][H + pt + pb][W + pl + pr][4].  Serves the
+ * EfficientNet stem (reference network/efficientnet_pt/model.py:197-199: no input normalisation, Conv2dStaticSamePadding
+ * k3 s2 pads (left 0, right 1, top 0, bottom 1)), which then runs on hifihr_conv2d_fwd with pad = 0. */
+int hifihr_image_to_nhwc4_padded(const float* images_d, float* out_d, int B, int H, int W, int pad_top, int pad_left,
+                                 int pad_bottom, int pad_right, int normalize, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused SSIM (11x11 gaussian window sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements).

@@ -236,6 +236,17 @@ def image_to_nhwc4_case(lib, device):
     ref = normalize_batch_3C(img).permute(0, 2, 3, 1)
     np.testing.assert_allclose(out.cpu()[..., :3].numpy(), ref.numpy(), atol=1e-6)
     assert float(out.cpu()[..., 3].abs().max()) == 0.0
+    # padded, un-normalised variant (EfficientNet stem): F.pad(img, (left, right, top, bottom)) as NHWC4
+    import torch.nn.functional as F
+    pad4 = (0, 1, 0, 1)
+    out2 = torch.full((3, 21, 13, 4), 7.0, device=device)
+    lib.image_to_nhwc4_padded(img.to(device), out2, pad4, False)
+    ref2 = F.pad(img, pad4).permute(0, 2, 3, 1)
+    assert torch.equal(out2.cpu()[..., :3], ref2) and float(out2.cpu()[..., 3].abs().max()) == 0.0
+    out3 = torch.full((3, 23, 15, 4), 7.0, device=device)
+    lib.image_to_nhwc4_padded(img.to(device), out3, (2, 1, 1, 2), True)
+    ref3 = F.pad(normalize_batch_3C(img), (2, 1, 1, 2)).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(out3.cpu()[..., :3].numpy(), ref3.numpy(), atol=1e-6)
 
 
 # ------------------------------------------------------------------------------------------------
