@@ -17,6 +17,8 @@
 // kernel that folds the slots writes the zeros back -- no memset launch per batch-norm (40 per ResNet-18 step).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "hifihr_internal.h"
 
 namespace hifihr {
@@ -304,7 +306,8 @@ static unsigned bn_reduce_grid(long M, int C) {
   const int C4 = C / 4;
   const int RL = C4 <= 256 ? 256 / C4 : 1;
   long blocks = (M + RL - 1) / RL;
-  long cap = (1L << 19) / C;                       // <= 512 K atomically added floats per statistic per launch
+  long cap = (1L << 17) / C;                       // <= 128 K atomically added floats per statistic per launch (swept 2^16..2^20)
+  if (const char* e = getenv("HIFIHR_BN_CAP_LOG2")) cap = (1L << atoi(e)) / C;
   if (cap > 2048) cap = 2048;
   if (cap < 128) cap = 128;
   if (blocks > cap) blocks = cap;
