@@ -39,7 +39,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define HIFIHR_KEEP(x) asm volatile("" : "+v"(x))
 #endif
 
-constexpr int kBK = 16;     // K-chunk depth (8 MFMA k-steps of 2)
+// (the K-chunk depth is a template parameter of both kernels: BK for the implicit GEMM, BKW for the weight gradient)
 
 // Balanced ("stream-K") schedule.  The dispatcher spreads a grid evenly over the 256 CUs and 4 of these workgroups are
 // resident per CU, so a launch of T tiles costs ceil(T / 1024) full rounds: 784 tiles (layer 4 at batch 32) take as long as
@@ -514,14 +514,14 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
 // ------------------------------------------------------------------------------------------------
 // backward weight
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, int BKW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float* __restrict__ x, const float* __restrict__ dy,
                                                         float* __restrict__ dw, int chunks_per_split) {
   // GEMM: dW[k][q] (BM x BN tile) = sum over pixels m of dy[m][k] * patch[m][q];  g describes the FORWARD conv
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int LA = BM + 4, LB = BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[2][kBK * LA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][kBK * LB];
+  __shared__ __attribute__((aligned(16))) float As[2][BKW * LA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BKW * LB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, r31 = lane & 31;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float
   const int Q = g.R * g.S * g.IC;
   const int K = g.OC;
   const int bq0 = blockIdx.x * BN, bk0 = blockIdx.y * BM;
-  const int nch_total = (M + kBK - 1) / kBK;
+  const int nch_total = (M + BKW - 1) / BKW;
   const int ch_lo = blockIdx.z * chunks_per_split;
   const int ch_hi = min(ch_lo + chunks_per_split, nch_total);
   if (ch_lo >= ch_hi) return;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float
   // load mapping: a row of the tile is one pixel m; BM/4 (BN/4) float4 per row
   constexpr int APR = BM / 4, BPR = BN / 4;            // float4 per row
   constexpr int AROWS = 256 / APR, BROWS = 256 / BPR;  // rows covered per pass
-  constexpr int AL = kBK / AROWS, BL = kBK / BROWS;    // passes
+  constexpr int AL = BKW / AROWS, BL = BKW / BROWS;    // passes
   const int a_row = tid / APR, a_col = (tid % APR) * 4;
   const int b_row = tid / BPR, b_col = (tid % BPR) * 4;
   // the q coordinates of this thread's patch column are constant over the loop
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float
   bool va[AL], vb[BL];
   // unconditional, clamped loads + masking at LDS-store time (see conv_igemm_kernel)
   auto load_global = [&](int ch) {
-    const int m0 = ch * kBK;
+    const int m0 = ch * BKW;
     const bool chok = ch < ch_hi;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float
     load_global(ch + 1);                  // unconditional prefetch (masked past the end of this split)
     HIFIHR_SCHED_FENCE();
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < BKW / 2; ++t) {
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = As[buf][(2 * t + half) * LA + wm * (BM / 2) + i * 32 + r31];
@@ -805,8 +805,9 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   return hipGetLastError();
 }
 
-template <int BM, int BN>
-static void launch_wgrad_tile(const ConvGeom& g, int Q, int nch, int slots, const float* x, const float* dy, float* dw, hipStream_t st) {
+template <int BM, int BN, int BKW>
+static void launch_wgrad_tile(const ConvGeom& g, int Q, long M, int slots, const float* x, const float* dy, float* dw, hipStream_t st) {
+  const int nch = (int)((M + BKW - 1) / BKW);
   const int tiles = ((g.OC + BM - 1) / BM) * ((Q + BN - 1) / BN);
   // tiles * splits workgroups: stay at or just below the resident slots so that every CU gets the same number (the
   // dispatcher spreads a grid evenly; 1152 workgroups on 1024 slots cost five rounds on some CUs: tools/conv_quant_probe.py)
@@ -816,23 +817,30 @@ static void launch_wgrad_tile(const ConvGeom& g, int Q, int nch, int slots, cons
   if (splits < 1) splits = 1;
   const int cps = (nch + splits - 1) / splits;
   splits = (nch + cps - 1) / cps;
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN>), dim3((Q + BN - 1) / BN, (g.OC + BM - 1) / BM, splits), dim3(256), 0, st, g, x, dy, dw, cps);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, BKW>), dim3((Q + BN - 1) / BN, (g.OC + BM - 1) / BM, splits), dim3(256), 0, st, g, x, dy, dw, cps);
 }
 
 hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {
   const long M = (long)g.N * g.OH * g.OW;
   const int Q = g.R * g.S * g.IC;
   if (g.IC % 4 != 0 || g.OC % 4 != 0) return hipErrorInvalidValue;
-  const int nch = (int)((M + kBK - 1) / kBK);
   // 0: 128x128 (4 resident per CU), 1: 64x128, n >= 2: 64x64 with n workgroups per CU.  Measured at B = 32 (tools/time_wgrad.py):
   // the atomic epilogue moves (workgroups x tile bytes), so below 512 output channels the 64x64 tile (a quarter of the atomic
   // volume, 8 per CU) wins by 5-15 %; the 29.6 GFLOP layer-4 shapes keep the 128x128 tile (100 vs 81 TF).
   int tile = (g.OC % 128 == 0 && g.OC >= 512) ? 0 : 8;
   if (const char* e = getenv("HIFIHR_WGRAD_TILE")) tile = atoi(e);
   const int cus = device_cus();
-  if (tile == 0) launch_wgrad_tile<128, 128>(g, Q, nch, cus * 4, x, dy, dw, st);
-  else if (tile == 1) launch_wgrad_tile<64, 128>(g, Q, nch, cus * 4, x, dy, dw, st);
-  else launch_wgrad_tile<64, 64>(g, Q, nch, cus * (tile == 2 ? 4 : tile), x, dy, dw, st);
+  int bkw = 16;
+  if (const char* e = getenv("HIFIHR_WGRAD_BK")) bkw = atoi(e);
+  if (tile == 0) {
+    if (bkw == 32) launch_wgrad_tile<128, 128, 32>(g, Q, M, cus * 2, x, dy, dw, st);
+    else launch_wgrad_tile<128, 128, 16>(g, Q, M, cus * 4, x, dy, dw, st);
+  } else if (tile == 1) {
+    launch_wgrad_tile<64, 128, 16>(g, Q, M, cus * 4, x, dy, dw, st);
+  } else {
+    if (bkw == 32) launch_wgrad_tile<64, 64, 32>(g, Q, M, cus * (tile == 2 ? 4 : tile), x, dy, dw, st);
+    else launch_wgrad_tile<64, 64, 16>(g, Q, M, cus * (tile == 2 ? 4 : tile), x, dy, dw, st);
+  }
   return hipGetLastError();
 }
 

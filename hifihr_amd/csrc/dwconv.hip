@@ -250,7 +250,8 @@ static unsigned dw_grid_x(long nb, long cap) {
 
 hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, float* stats, hipStream_t st) {
   const long nb = (long)g.N * g.OH * ((g.OW + kPW - 1) / kPW);
-  const dim3 grid(dw_grid_x(nb, 2048), (g.C + 63) / 64);
+  // with statistics every workgroup ends with 128 float atomics: bound (workgroups x channels) like bn.hip does
+  const dim3 grid(dw_grid_x(nb, stats != nullptr ? 256 : 2048), (g.C + 63) / 64);
   HIFIHR_DW_DISPATCH(dwconv_fwd_kernel, grid, g, x, w, y, stats);
   return hipGetLastError();
 }
