@@ -22,6 +22,7 @@ class _Profile:
         self.on = False
         self.events = []
         self.last_render = None
+        self.conv_log = []          # (geometry, "fwd" | "dgrad") of every implicit-GEMM launch while enabled (bench.py roofline)
 
     def enable(self):
         self.on, self.events = True, []
@@ -279,6 +280,8 @@ class _Conv2dMFMA(torch.autograd.Function):
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), False) if (bias is None and not relu) else None
             PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, bias, y, N, H, W, C, K, R, S, stride, pad, ws=ws,
                                                               act=1 if relu else 0))
+        if PROFILE.on:
+            PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "fwd"))
         ctx.geom = (N, H, W, C, K, R, S, stride, pad)
         ctx.save_for_backward(x, wk, y if relu else None)
         ctx.w_param, ctx.b_param, ctx.relu = w, bias, relu
@@ -313,6 +316,8 @@ class _Conv2dMFMA(torch.autograd.Function):
             dx = torch.empty_like(x, memory_format=_CL)
             scratch = torch.empty(wk.numel(), device=x.device, dtype=torch.float32)
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), True)
+            if PROFILE.on:
+                PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "dgrad"))
             PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data(gy, wk, dx, scratch, N, H, W, C, K, R, S, stride, pad, ws=ws))
         if ctx.needs_input_grad[1]:
             w = ctx.w_param
