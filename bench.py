@@ -128,6 +128,28 @@ def main():
         counts = Counter(ops.PROFILE.conv_log)
         tot_flop = tot_us = tot_n = 0.0
         for (geom, direction), cnt in counts.items():
+            if direction == "gemm":                    # the 16 batched GEMMs of a Winograd convolution (same kernel, batch = 16)
+                _, N_, H_, W_, C_, K_ = geom
+                T_ = N_ * ((H_ + 1) // 2) * ((W_ + 1) // 2)
+                Vs = torch.randn(16 * T_ * C_, device=dev); Us = torch.randn(16 * K_ * C_, device=dev) * 0.05
+                Ms = torch.empty(16 * T_ * K_, device=dev)
+                nbw = lib.wino_gemm_workspace_bytes(N_, H_, W_, C_, K_)
+                wsb = ops._CONV_WS.get(dev) if nbw else None
+                if nbw and (wsb is None or wsb.numel() * 4 < nbw):
+                    wsb = torch.zeros(nbw // 4 + 64, device=dev); ops._CONV_WS[dev] = wsb
+                fn = lambda: lib.wino_gemm(Vs, Us, Ms, N_, H_, W_, C_, K_, ws=wsb)
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 10
+                per_step = cnt / nprof
+                tot_flop += 2.0 * 16 * T_ * C_ * K_ * per_step; tot_us += us * per_step; tot_n += per_step
+                continue
             N_, H_, W_, C_, K_, R_, S_, st_, pd_ = geom
             OH_, OW_ = (H_ + 2 * pd_ - R_) // st_ + 1, (W_ + 2 * pd_ - S_) // st_ + 1
             xs = torch.randn(N_, H_, W_, C_, device=dev); wsrc = torch.randn(K_, R_, S_, C_, device=dev) * 0.05
@@ -152,7 +174,8 @@ def main():
             tot_flop += flop * per_step; tot_us += us * per_step; tot_n += per_step
         conv_roof = {"bound": "mfma", "achieved": tot_flop / (tot_us * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                      "frac": tot_flop / (tot_us * 1e-6) / 1e12 / 157.3, "traffic": None,
-                     "kernel": "conv_igemm_kernel (all instantiations: forward + backward-data of the encoder's convolutions)",
+                     "kernel": "conv_igemm_kernel (all instantiations: direct forward / backward-data convolutions and the batched GEMMs of "
+                               "the Winograd F(2x2,3x3) layers, counted with the FLOPs they actually execute)",
                      "launches_per_step": tot_n, "avg_us": tot_us / max(tot_n, 1.0), "us_per_step": tot_us,
                      "algorithmic_flop_per_step": tot_flop,
                      "timing": "HIP events over 10 back-to-back launches of every distinct (shape, direction) of the step, weighted by "

@@ -109,6 +109,13 @@ class HifihrLib:
         c.hifihr_sil_post.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_linear_fwd.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [_c_float_p] * 2 + [c_float, c_float] + [_c_float_p] * 6 + [c_void_p]
         c.hifihr_linear_bwd.argtypes = [_c_float_p] * 4 + [c_int] * 4 + [_c_float_p] * 10 + [c_void_p]
+        c.hifihr_wino_gemm_workspace_bytes.argtypes = [c_int] * 5
+        c.hifihr_wino_gemm_workspace_bytes.restype = c_size_t
+        c.hifihr_wino_weight_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
+        c.hifihr_wino_input_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
+        c.hifihr_wino_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_wino_output_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
+        c.hifihr_weight_transpose.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_se_pool.argtypes = [_c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_scale.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_bwd_gate.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
@@ -261,6 +268,25 @@ class HifihrLib:
         B, _, H, W = rgba.shape
         assert rgba.is_contiguous() and (imgs is None or imgs.is_contiguous())
         self.check(self.c.hifihr_sil_post(_fp(rgba), _fp(imgs), B, H, W, _fp(re_sil), _fp(mask_rgbs), _stream_of(rgba)), "hifihr_sil_post")
+
+    # ---- Winograd F(2x2, 3x3) ------------------------------------------
+    def wino_gemm_workspace_bytes(self, N, H, W, C, K):
+        return int(self.c.hifihr_wino_gemm_workspace_bytes(N, H, W, C, K))
+
+    def wino_weight_transform(self, w, U, K, C, flip):
+        self.check(self.c.hifihr_wino_weight_transform(_fp(w), _fp(U), K, C, int(flip), _stream_of(w)), "hifihr_wino_weight_transform")
+
+    def wino_input_transform(self, x, V, N, H, W, C):
+        self.check(self.c.hifihr_wino_input_transform(_fp(x), _fp(V), N, H, W, C, _stream_of(x)), "hifihr_wino_input_transform")
+
+    def wino_gemm(self, V, U, M, N, H, W, C, K, ws=None):
+        self.check(self.c.hifihr_wino_gemm(_fp(V), _fp(U), _fp(M), N, H, W, C, K, *self._ws(ws), _stream_of(V)), "hifihr_wino_gemm")
+
+    def wino_output_transform(self, M, y, stats, N, H, W, K):
+        self.check(self.c.hifihr_wino_output_transform(_fp(M), _fp(y), _fp(stats), N, H, W, K, _stream_of(M)), "hifihr_wino_output_transform")
+
+    def weight_transpose(self, w, wt, K, RS, C):
+        self.check(self.c.hifihr_weight_transpose(_fp(w), _fp(wt), K, RS, C, _stream_of(w)), "hifihr_weight_transpose")
 
     def se_pool(self, x, B, HW, C, mean_zeroed):
         self.check(self.c.hifihr_se_pool(_fp(x), B, HW, C, _fp(mean_zeroed), _stream_of(x)), "hifihr_se_pool")

@@ -62,6 +62,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 struct SkArgs {
   int tiles_x, tiles_y, nch, per, total;   // row / column tiles, K chunks per tile, iterations per workgroup, tiles * nch
   int mode, Tx, S, tper;                   // mode 1: tiles per XCD, chunk split point, tail iterations per tail workgroup
+  int tiles_pb;                            // tiles per batch entry (tiles_x * tiles_y); tile / tiles_pb = batch index
   float* ws;                      // [tiles][BM * BN]
   unsigned* cnt;                  // [tiles] arrival counters (zero between launches)
 };
@@ -133,9 +134,9 @@ __device__ __forceinline__ GatherPlan make_plan(const ConvGeom& g, int cls) {
 #define HIFIHR_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 template <int BM, int BN, bool GENERIC, int BK, bool SK>
-__global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) void conv_igemm_kernel(ConvGeom g, const float* __restrict__ src,
-                                                        const float* __restrict__ wgt, const float* __restrict__ bias,
-                                                        float* __restrict__ dst, float* __restrict__ stats, SkArgs sk) {
+__global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) void conv_igemm_kernel(ConvGeom g, const float* __restrict__ src0,
+                                                        const float* __restrict__ wgt0, const float* __restrict__ bias,
+                                                        float* __restrict__ dst0, float* __restrict__ stats, SkArgs sk) {
   // stats (optional, forward only): [kStatSlots][2][OC] per-channel sum and sum of squares of the output, accumulated with
   // atomics from the accumulator registers -- the batch-norm that follows needs no separate pass over y
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves are arranged 2 x 2)
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, r31 = lane & 31;
-  const GatherPlan P = make_plan(g, SK ? 0 : blockIdx.z);
+  const GatherPlan P = make_plan(g, (SK || g.batch > 1) ? 0 : blockIdx.z);
   const int M = g.N * P.OHs * P.OWs;
   const int Qw = g.R * g.S * g.IC;                // row length of the weight matrix
   const int lrow = tid / SEGS, seg = (tid % SEGS) * 4;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
     }
   }
   do {                                            // SK: one pass per (tile, chunk range) of this workgroup's share
-  int tile = 0, c_begin = 0, c_end = nch_tile, tx = blockIdx.x, ty = blockIdx.y;
+  int tile = 0, c_begin = 0, c_end = nch_tile, tx = blockIdx.x, ty = blockIdx.y, bz = (!SK && g.batch > 1) ? (int)blockIdx.z : 0;
   if (SK) {
     if (it >= it_end) break;
     if (sk.mode == 1 && tail_wg) {
@@ -187,9 +188,15 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
       c_end = min(sk.mode == 1 ? sk.S : nch_tile, c_begin + (it_end - it));
       if (sk.mode == 1) tile += tile_base;
     }
-    tx = tile / sk.tiles_y; ty = tile - tx * sk.tiles_y;
+    bz = tile / sk.tiles_pb;
+    const int tin = tile - bz * sk.tiles_pb;
+    tx = tin / sk.tiles_y; ty = tin - tx * sk.tiles_y;
     it += c_end - c_begin;
   }
+  // batched use: this pass's problem
+  const float* __restrict__ src = src0 + (size_t)bz * g.src_bs;
+  const float* __restrict__ wgt = wgt0 + (size_t)bz * g.wgt_bs;
+  float* __restrict__ dst = dst0 + (size_t)bz * g.dst_bs;
   const int bm0 = tx * BM, bn0 = ty * BN;
   if (!SK && bm0 >= M) return;                    // parity classes can be smaller than the launch grid
 
@@ -676,8 +683,8 @@ static int pick_tile(long M, int OC, bool generic) {
 template <int BM, int BN>
 static void launch_igemm_tile(const ConvGeom& g, long Mmax, int classes, bool generic, int bk, const float* src, const float* wgt,
                               const float* bias, float* dst, float* stats, hipStream_t st) {
-  const dim3 grid((unsigned)((Mmax + BM - 1) / BM), (g.OC + BN - 1) / BN, classes);
-  const SkArgs none{0, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr};
+  const dim3 grid((unsigned)((Mmax + BM - 1) / BM), (g.OC + BN - 1) / BN, g.batch > 1 ? g.batch : classes);
+  const SkArgs none{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr};
   if (generic)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true, 16, false>), grid, dim3(256), 0, st, g, src, wgt, bias, dst, stats, none);
   else if (bk == 32)
@@ -728,7 +735,7 @@ static SkPlan sk_plan(const ConvGeom& g) {
   if (!one_class || g.IC % 32 != 0) return p;
   const long M = (long)g.N * g.OH * g.OW;
   p.tiles_x = (int)((M + p.v.bm - 1) / p.v.bm);
-  p.tiles = p.tiles_x * ((g.OC + p.v.bn - 1) / p.v.bn);
+  p.tiles = p.tiles_x * ((g.OC + p.v.bn - 1) / p.v.bn) * (g.batch > 1 ? g.batch : 1);
   p.nch = g.R * g.S * (g.IC / p.v.bk);
   const int slots = device_cus() * p.v.occ;
   if (p.nch * p.v.bk < kSkMinChunks * 32 || p.tiles < slots / 4) return p;
@@ -752,7 +759,8 @@ template <int BM, int BN, int BK>
 static void launch_sk(const SkPlan& p, const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, void* sk_ws,
                       hipStream_t st) {
   const size_t cnt_bytes = (p.tiles * sizeof(unsigned) + 255) / 256 * 256;
-  SkArgs a{p.tiles_x, p.tiles / p.tiles_x, p.nch, p.per, p.tiles * p.nch, 0, 0, 0, 0,
+  const int nb = g.batch > 1 ? g.batch : 1;
+  SkArgs a{p.tiles_x, p.tiles / nb / p.tiles_x, p.nch, p.per, p.tiles * p.nch, 0, 0, 0, 0, p.tiles / nb,
            reinterpret_cast<float*>(static_cast<char*>(sk_ws) + cnt_bytes), static_cast<unsigned*>(sk_ws)};
   int wgs = p.wgs;
   const int slots = device_cus() * p.v.occ;
@@ -784,6 +792,7 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   int bk = (g.IC % 32 == 0) ? 32 : 16;
   if (const char* e = getenv("HIFIHR_CONV_BK")) bk = (atoi(e) == 32 && g.IC % 32 == 0) ? 32 : 16;   // tuning override
   const int classes = g.dgrad ? g.stride * g.stride : 1;
+  if (g.batch > 1 && (classes != 1 || bias != nullptr || stats != nullptr)) return hipErrorInvalidValue;
   const int st_ = g.dgrad ? g.stride : 1;
   const long Mmax = (long)g.N * ((g.OH + st_ - 1) / st_) * ((g.OW + st_ - 1) / st_);   // rows of the largest class
   const int tile = pick_tile(Mmax * classes, g.OC, generic);

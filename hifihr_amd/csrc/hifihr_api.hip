@@ -551,4 +551,48 @@ int hifihr_se_bwd_gate(const float* dy, const float* x, int B, int HW, int C, fl
   return HIFIHR_OK;
 }
 
+int hifihr_weight_transpose(const float* w, float* wt, int K, int RS, int C, void* stream) {
+  if (!w || !wt || K <= 0 || RS <= 0 || C <= 0) return fail(HIFIHR_EINVAL, "hifihr_weight_transpose: bad argument");
+  HIP_TRY(hifihr::launch_weight_transpose(w, wt, K, RS, C, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+/* ---- Winograd F(2x2, 3x3) ---- */
+static hifihr::ConvGeom wino_gemm_geom(long T, int C, int K) {
+  hifihr::ConvGeom g{1, (int)T, 1, C, (int)T, 1, K, 1, 1, 1, 0, 0, 0, 16, T * (long)C, (long)K * C, T * (long)K};
+  return g;
+}
+
+size_t hifihr_wino_gemm_workspace_bytes(int N, int H, int W, int C, int K) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
+  const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+  return hifihr::conv_sk_workspace_bytes(wino_gemm_geom(T, C, K));
+}
+
+int hifihr_wino_weight_transform(const float* w, float* U, int K, int C, int flip, void* stream) {
+  if (!w || !U || K <= 0 || C < 4 || C % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_weight_transform: bad argument (C % 4 == 0)");
+  HIP_TRY(hifihr::launch_wino_weight_transform(w, U, K, C, flip ? 1 : 0, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream) {
+  if (!x || !V || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_input_transform: bad argument");
+  HIP_TRY(hifihr::launch_wino_input_transform(x, V, N, H, W, C, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_gemm(const float* V, const float* U, float* M, int N, int H, int W, int C, int K, void* ws, size_t ws_bytes, void* stream) {
+  if (!V || !U || !M || N <= 0 || H <= 0 || W <= 0 || C < 32 || C % 32 != 0 || K < 4 || K % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_gemm: bad argument (C % 32 == 0, K % 4 == 0)");
+  const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+  HIP_TRY(hifihr::launch_conv_igemm(wino_gemm_geom(T, C, K), V, U, nullptr, M, nullptr, ws, ws_bytes, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_output_transform(const float* M, float* y, float* stats, int N, int H, int W, int K, void* stream) {
+  if (!M || !y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform: bad argument");
+  HIP_TRY(hifihr::launch_wino_output_transform(M, y, stats, N, H, W, K, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 }  // extern "C"

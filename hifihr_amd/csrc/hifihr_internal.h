@@ -55,6 +55,9 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
 struct ConvGeom {
   int N, IH, IW, IC, OH, OW, OC, R, S, stride, pad, dgrad;
   int relu;      // forward only: clamp the output at 0 after the bias
+  // batched GEMM use (Winograd): `batch` independent problems of this geometry, element strides between them
+  int batch;
+  long src_bs, wgt_bs, dst_bs;
 };
 // sk_ws (may be NULL): zero-initialised, self-cleaning workspace of conv_sk_workspace_bytes(g) bytes for the balanced schedule
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
@@ -142,6 +145,11 @@ hipError_t launch_linear_bwd(const LinearArgs& a, const LinearGrads& g, hipStrea
 hipError_t launch_se_pool(const float* x, int B, int HW, int C, float* mean_zeroed, hipStream_t st);
 hipError_t launch_se_bwd_gate(const float* dy, const float* x, int B, int HW, int C, float* dgate_zeroed, hipStream_t st);
 hipError_t launch_se_scale(const float* x, const float* gate, const float* add, float ascale, int B, int HW, int C, float* y, hipStream_t st);
+
+// Winograd F(2x2, 3x3) glue (wino.hip)
+hipError_t launch_wino_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st);
+hipError_t launch_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, hipStream_t st);
+hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats, int N, int H, int W, int K, hipStream_t st);
 
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st);

@@ -1,0 +1,187 @@
+// Winograd F(2x2, 3x3) transforms for the stride-1 3x3 convolutions with many channels (ResNet-18 layers 3 and 4 at 14x14:
+// 60 % of the network's FLOPs).  out = A^T [ (G g G^T) . (B^T d B) ] A turns a 3x3 convolution over 2x2 output tiles into 16
+// independent [tiles x C] x [C x K] GEMMs with 2.25x fewer multiplications; the GEMMs run on the MFMA implicit-GEMM kernel
+// (conv.hip, batch = 16, balanced schedule), these kernels are the HBM-bound glue:
+//   wino_weight_transform   U[16][K][C]  = G g G^T     (flip = 1: g rotated by 180 degrees, for backward-data on the
+//                                                        [C][3][3][K] transposed weights)
+//   wino_input_transform    V[16][T][C]  = B^T d B     d = 4x4 input patch of tile t (zero outside the image), T = N*ceil(H/2)*ceil(W/2)
+//   wino_output_transform   y[N][H][W][K] = A^T m A    m = M[.][t][.]; optionally adds the batch-norm sum / sum of squares of y
+//                                                        to the slot buffer (bn.hip), like the direct kernel's epilogue does
+// Replaces (together with the batched GEMM) the same cuDNN/MIOpen dispatches as conv.hip (reference network/res_encoder.py:364-373).
+// fp32 throughout: F(2,3) has transform constants {0, +-1, +-1/2}, its rounding error stays at a few ulp of the direct result.
+#include <hip/hip_runtime.h>
+
+#include "hifihr_internal.h"
+
+namespace hifihr {
+
+__device__ __forceinline__ float4 add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// thread = (output channel k, 4 input channels); w[K][3][3][C] -> U[16][K][C]
+__global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int flip) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)K * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % C4), k = (int)(i / C4);
+    float4 g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
+        g[r][s] = *reinterpret_cast<const float4*>(w + (((size_t)k * 3 + rr) * 3 + ss) * C + cg * 4);
+      }
+    // t = G g (4x3), u = t G^T (4x4);  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+    float4 t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const float4 sum02 = add4(g[0][s], g[2][s]);
+      t[0][s] = g[0][s];
+      t[1][s] = make_float4(0.5f * (sum02.x + g[1][s].x), 0.5f * (sum02.y + g[1][s].y), 0.5f * (sum02.z + g[1][s].z), 0.5f * (sum02.w + g[1][s].w));
+      t[2][s] = make_float4(0.5f * (sum02.x - g[1][s].x), 0.5f * (sum02.y - g[1][s].y), 0.5f * (sum02.z - g[1][s].z), 0.5f * (sum02.w - g[1][s].w));
+      t[3][s] = g[2][s];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4 sum02 = add4(t[r][0], t[r][2]);
+      float4 u[4];
+      u[0] = t[r][0];
+      u[1] = make_float4(0.5f * (sum02.x + t[r][1].x), 0.5f * (sum02.y + t[r][1].y), 0.5f * (sum02.z + t[r][1].z), 0.5f * (sum02.w + t[r][1].w));
+      u[2] = make_float4(0.5f * (sum02.x - t[r][1].x), 0.5f * (sum02.y - t[r][1].y), 0.5f * (sum02.z - t[r][1].z), 0.5f * (sum02.w - t[r][1].w));
+      u[3] = t[r][2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(U + ((size_t)(r * 4 + c) * K + k) * C + cg * 4) = u[c];
+    }
+  }
+}
+
+// thread = (tile, 4 channels); x[N][H][W][C] -> V[16][T][C]
+__global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C,
+                                                                  int TH, int TW) {
+  const int C4 = C / 4;
+  const size_t T = (size_t)N * TH * TW, total = T * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % C4);
+    const size_t t = i / C4;
+    const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ih = 2 * th - 1 + r;
+      const bool rok = ih >= 0 && ih < H;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int iw = 2 * tw - 1 + c;
+        const bool ok = rok && iw >= 0 && iw < W;
+        const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + (rok ? ih : 0)) * W + (ok ? iw : 0)) * C + cg * 4);
+        d[r][c] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // t = B^T d,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1];  v = t B
+    float4 tt[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      tt[0][c] = sub4(d[0][c], d[2][c]);
+      tt[1][c] = add4(d[1][c], d[2][c]);
+      tt[2][c] = sub4(d[2][c], d[1][c]);
+      tt[3][c] = sub4(d[1][c], d[3][c]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4 v0 = sub4(tt[r][0], tt[r][2]), v1 = add4(tt[r][1], tt[r][2]), v2 = sub4(tt[r][2], tt[r][1]), v3 = sub4(tt[r][1], tt[r][3]);
+      float* o = V + ((size_t)(r * 4) * T + t) * C + cg * 4;
+      *reinterpret_cast<float4*>(o) = v0;
+      *reinterpret_cast<float4*>(o + T * C) = v1;
+      *reinterpret_cast<float4*>(o + 2 * T * C) = v2;
+      *reinterpret_cast<float4*>(o + 3 * T * C) = v3;
+    }
+  }
+}
+
+// workgroup = 16 tile lanes x 16 float4 channel lanes (64 channels, blockIdx.y); M[16][T][K] -> y[N][H][W][K] (+ stats)
+__global__ __launch_bounds__(256) void wino_output_transform_kernel(const float* __restrict__ Mm, float* __restrict__ y, float* __restrict__ stats,
+                                                                   int N, int H, int W, int K, int TH, int TW) {
+  __shared__ float4 red[2][16][16];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int k = blockIdx.y * 64 + cl * 4;
+  const bool kok = k < K;
+  const size_t T = (size_t)N * TH * TW;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (kok) {
+    for (size_t t = (size_t)blockIdx.x * 16 + tl; t < T; t += (size_t)gridDim.x * 16) {
+      const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+      float4 m[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m[r][c] = *reinterpret_cast<const float4*>(Mm + ((size_t)(r * 4 + c) * T + t) * K + k);
+      // s = A^T m,  A^T = [1 1 1 0; 0 1 -1 -1];  out = s A
+      float4 s[2][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s[0][c] = add4(add4(m[0][c], m[1][c]), m[2][c]);
+        s[1][c] = sub4(sub4(m[1][c], m[2][c]), m[3][c]);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int oh = 2 * th + a;
+        const float4 o0 = add4(add4(s[a][0], s[a][1]), s[a][2]), o1 = sub4(sub4(s[a][1], s[a][2]), s[a][3]);
+        if (oh < H) {
+          float* p = y + (((size_t)n * H + oh) * W + 2 * tw) * K + k;
+          *reinterpret_cast<float4*>(p) = o0;
+          s1 = add4(s1, o0);
+          s2.x = fmaf(o0.x, o0.x, s2.x); s2.y = fmaf(o0.y, o0.y, s2.y); s2.z = fmaf(o0.z, o0.z, s2.z); s2.w = fmaf(o0.w, o0.w, s2.w);
+          if (2 * tw + 1 < W) {
+            *reinterpret_cast<float4*>(p + K) = o1;
+            s1 = add4(s1, o1);
+            s2.x = fmaf(o1.x, o1.x, s2.x); s2.y = fmaf(o1.y, o1.y, s2.y); s2.z = fmaf(o1.z, o1.z, s2.z); s2.w = fmaf(o1.w, o1.w, s2.w);
+          }
+        }
+      }
+    }
+  }
+  if (stats != nullptr) {                           // uniform
+    red[0][tl][cl] = s1; red[1][tl][cl] = s2;
+    __syncthreads();
+    if (tl == 0 && kok) {
+      for (int r = 1; r < 16; ++r) { s1 = add4(s1, red[0][r][cl]); s2 = add4(s2, red[1][r][cl]); }
+      float* sp = stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * K;
+      atomicAdd(sp + k, s1.x); atomicAdd(sp + k + 1, s1.y); atomicAdd(sp + k + 2, s1.z); atomicAdd(sp + k + 3, s1.w);
+      atomicAdd(sp + K + k, s2.x); atomicAdd(sp + K + k + 1, s2.y); atomicAdd(sp + K + k + 2, s2.z); atomicAdd(sp + K + k + 3, s2.w);
+    }
+  }
+}
+
+static unsigned wino_grid(size_t total) {
+  size_t b = (total + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+hipError_t launch_wino_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(wino_weight_transform_kernel, dim3(wino_grid((size_t)K * (C / 4))), dim3(256), 0, st, w, U, K, C, flip);
+  return hipGetLastError();
+}
+
+hipError_t launch_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, hipStream_t st) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  hipLaunchKernelGGL(wino_input_transform_kernel, dim3(wino_grid((size_t)N * TH * TW * (C / 4))), dim3(256), 0, st, x, V, N, H, W, C, TH, TW);
+  return hipGetLastError();
+}
+
+hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats, int N, int H, int W, int K, hipStream_t st) {
+  if (K % 4 != 0) return hipErrorInvalidValue;
+  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  const size_t T = (size_t)N * TH * TW;
+  size_t bx = (T + 15) / 16;
+  const size_t cap = stats != nullptr ? 256 : 2048;       // with statistics: bound (workgroups x channels) atomics (bn.hip)
+  if (bx > cap) bx = cap;
+  hipLaunchKernelGGL(wino_output_transform_kernel, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, N, H, W, K, TH, TW);
+  return hipGetLastError();
+}
+
+}  // namespace hifihr

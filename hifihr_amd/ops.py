@@ -4,6 +4,8 @@ Every op here runs ONLY on the GPU through libhifihr.so; a CPU tensor raises (th
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import get_lib, require_cuda
@@ -259,6 +261,52 @@ def _conv_ws(lib, device, geom, bwd):
     return ws
 
 
+_WINO_SCRATCH = {}     # (device, name) -> grow-only scratch tensor shared by every Winograd convolution (stream-ordered reuse)
+
+
+def _wino_scratch(device, name, numel):
+    t = _WINO_SCRATCH.get((device, name))
+    if t is None or t.numel() < numel:
+        t = torch.empty(numel, device=device, dtype=torch.float32)
+        _WINO_SCRATCH[(device, name)] = t
+    return t
+
+
+def _wino_ok(C, K, R, S, stride, pad):
+    """Winograd F(2x2, 3x3) instead of the direct kernel: stride-1, pad-1 3x3 with >= 128 channels on both sides (measured at
+    B = 32, tools/time_wino.py: 295 -> 180 us at 512 channels, 91 -> 69 at 256, 97 -> 81 at 128; HIFIHR_WINOGRAD=0 disables)."""
+    if os.environ.get("HIFIHR_WINOGRAD", "1") == "0":
+        return False
+    return R == 3 and S == 3 and stride == 1 and pad == 1 and C >= 128 and K >= 128 and C % 32 == 0 and K % 32 == 0
+
+
+def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip):
+    """y[N][H][W][K] = conv3x3(x[N][H][W][C], w[K][3][3][C]) through weight / input transform, 16 batched GEMMs, output
+    transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter)."""
+    dev = x.device
+    T = N * ((H + 1) // 2) * ((W + 1) // 2)
+    U = _wino_scratch(dev, "U", 16 * K * C)
+    V = _wino_scratch(dev, "V", 16 * T * C)
+    M = _wino_scratch(dev, "M", 16 * T * K)
+    key = ("wino", N, H, W, C, K)
+    nb = _CONV_WS_BYTES.get(key)
+    if nb is None:
+        nb = lib.wino_gemm_workspace_bytes(N, H, W, C, K)
+        _CONV_WS_BYTES[key] = nb
+    ws = None
+    if nb:
+        ws = _CONV_WS.get(dev)
+        if ws is None or ws.numel() * 4 < nb:
+            ws = torch.zeros(max(nb, 32 << 20) // 4 + 64, dtype=torch.float32, device=dev)
+            _CONV_WS[dev] = ws
+    if PROFILE.on:
+        PROFILE.conv_log.append((("wino", N, H, W, C, K), "gemm"))
+    lib.wino_weight_transform(w_krsc, U, K, C, flip)
+    lib.wino_input_transform(x, V, N, H, W, C)
+    lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)
+    lib.wino_output_transform(M, y, stats, N, H, W, K)
+
+
 class _Conv2dMFMA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, pad, want_stats=False, bias=None, relu=False):
@@ -272,7 +320,11 @@ class _Conv2dMFMA(torch.autograd.Function):
         OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
         stats = None
-        if want_stats:       # per-channel sum / sum of squares of y from the conv epilogue, for the batch-norm that follows
+        wino = bias is None and not relu and _wino_ok(C, K, R, S, stride, pad)
+        if wino:
+            stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device) if want_stats else None
+            PROFILE.bracket("conv_fwd_wino", lambda: _wino_conv(lib, x, wk, y, stats, N, H, W, C, K, 0))
+        elif want_stats:       # per-channel sum / sum of squares of y from the conv epilogue, for the batch-norm that follows
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device)
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), False)
             PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd_bnstats(x, wk, y, stats, N, H, W, C, K, R, S, stride, pad, ws=ws))
@@ -280,7 +332,7 @@ class _Conv2dMFMA(torch.autograd.Function):
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), False) if (bias is None and not relu) else None
             PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, bias, y, N, H, W, C, K, R, S, stride, pad, ws=ws,
                                                               act=1 if relu else 0))
-        if PROFILE.on:
+        if PROFILE.on and not wino:
             PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "fwd"))
         ctx.geom = (N, H, W, C, K, R, S, stride, pad)
         ctx.save_for_backward(x, wk, y if relu else None)
@@ -312,7 +364,16 @@ class _Conv2dMFMA(torch.autograd.Function):
             gy = g
             if b is not None and db_t is not None and db_ret is None:
                 _grad_ready(b)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not ctx.relu and ctx.b_param is None and _wino_ok(C, K, R, S, stride, pad):
+            # backward-data of a stride-1 3x3 = the same Winograd pipeline on dy with the transposed, rotated filter
+            dx = torch.empty_like(x, memory_format=_CL)
+            wt = _wino_scratch(x.device, "wt", wk.numel())
+
+            def run():
+                lib.weight_transpose(wk, wt, K, R * S, C)
+                _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1)
+            PROFILE.bracket("conv_dgrad_wino", run)
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=_CL)
             scratch = torch.empty(wk.numel(), device=x.device, dtype=torch.float32)
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), True)

@@ -162,6 +162,23 @@ int hifihr_conv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, flo
 /* dw[K][R][S][C] += sum over pixels (ACCUMULATES with fp32 atomics: zero it, or pass the gradient buffer). */
 int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, void* stream);
+/* Winograd F(2x2, 3x3) path for stride-1, pad-1 3x3 convolutions with many channels (ResNet-18 layers 3-4): 2.25x fewer
+ * multiplications than the direct kernel, same results up to a few ulp.  Forward:
+ *   hifihr_wino_weight_transform(w[K][3][3][C], U[16][K][C], K, C, flip = 0)
+ *   hifihr_wino_input_transform (x[N][H][W][C], V[16][T][C]),  T = N * ceil(H/2) * ceil(W/2)
+ *   hifihr_wino_gemm            (V, U, M[16][T][K])  -- 16 GEMMs on the MFMA kernel; ws as for hifihr_conv2d_fwd
+ *   hifihr_wino_output_transform(M, y[N][H][W][K], stats_d or NULL)   -- stats_d: batch-norm slot buffer (zero on entry)
+ * Backward-data is the same sequence on dy with the weights of the transposed, 180-degree rotated filter:
+ *   weight_transform(wt[C][3][3][K] (= the [C][R][S][K] transpose hifihr_conv2d_bwd_data also builds), U[16][C][K], C, K, flip = 1). */
+size_t hifihr_wino_gemm_workspace_bytes(int N, int H, int W, int C, int K);
+int hifihr_wino_weight_transform(const float* w_d, float* u_d, int K, int C, int flip, void* stream);
+int hifihr_wino_input_transform(const float* x_d, float* v_d, int N, int H, int W, int C, void* stream);
+int hifihr_wino_gemm(const float* v_d, const float* u_d, float* m_d, int N, int H, int W, int C, int K, void* ws_d, size_t ws_bytes,
+                     void* stream);
+int hifihr_wino_output_transform(const float* m_d, float* y_d, float* stats_d /* or NULL */, int N, int H, int W, int K, void* stream);
+/* [K][RS][C] -> [C][RS][K] (the transpose backward-data consumes). */
+int hifihr_weight_transpose(const float* w_d, float* wt_d, int K, int RS, int C, void* stream);
+
 /* conv2d_fwd that also accumulates the per-channel sum and sum of squares of y into stats_d (hifihr_bn_stats_floats(K)
  * floats, ALL ZERO on entry: see the self-cleaning rule below) from the accumulator registers, so the batch-norm that
  * follows needs no pass over y. */

@@ -646,3 +646,50 @@ def se_case(lib, device, B, H, W, C, SQ, seed=0):
         assert err <= t * mag + 1e-7, f"se {name}: {err} vs {mag}"
     rel(dx, xr.grad.permute(0, 2, 3, 1), "dx")
     rel(dw1, w1r.grad, "dw1"); rel(db1, b1r.grad, "db1"); rel(dw2, w2r.grad, "dw2"); rel(db2, b2r.grad, "db2")
+
+
+# ------------------------------------------------------------------------------------------------
+# Winograd F(2x2, 3x3) path (csrc/wino.hip + the batched MFMA GEMM) vs torch conv2d, forward and backward-data
+# ------------------------------------------------------------------------------------------------
+def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=gen); w = torch.randn(K, C, 3, 3, generator=gen) / (9 * C) ** 0.5
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(xr, w, None, 1, 1)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    d = lambda t: t.to(device).contiguous()
+    T = N * ((H + 1) // 2) * ((W + 1) // 2)
+    xd, wd, gyd = d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), d(gy.permute(0, 2, 3, 1))
+    nb = max(lib.wino_gemm_workspace_bytes(N, H, W, C, K), lib.wino_gemm_workspace_bytes(N, H, W, K, C)) if use_ws else 0
+    ws = torch.zeros(nb // 4, device=device) if nb else None
+    # forward
+    U = torch.empty(16, K, C, device=device); V = torch.empty(16, T, C, device=device); M = torch.empty(16, T, K, device=device)
+    out = torch.full((N, H, W, K), 7.0, device=device)
+    stats = torch.zeros(lib.bn_stats_floats(K), device=device) if with_stats else None
+    lib.wino_weight_transform(wd, U, K, C, 0)
+    lib.wino_input_transform(xd, V, N, H, W, C)
+    lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)
+    lib.wino_output_transform(M, out, stats, N, H, W, K)
+    ref = y.detach().permute(0, 2, 3, 1)
+    err = float((out.cpu() - ref).abs().max())
+    assert err <= 3e-5 * float(ref.abs().max()) + 1e-6, f"winograd fwd: {err} vs {float(ref.abs().max())}"
+    if with_stats:
+        st = stats.view(-1, 2, K)[:-1].sum(0).cpu(); flat = ref.reshape(-1, K)
+        np.testing.assert_allclose(st[0].numpy(), flat.sum(0).numpy(), rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(st[1].numpy(), (flat ** 2).sum(0).numpy(), rtol=1e-4, atol=2e-3)
+    # backward-data: the same pipeline on dy with the transposed, rotated filter
+    wt = torch.empty(C, 3, 3, K, device=device)
+    lib.weight_transpose(wd, wt, K, 9, C)
+    U2 = torch.empty(16, C, K, device=device); V2 = torch.empty(16, T, K, device=device); M2 = torch.empty(16, T, C, device=device)
+    dx = torch.full((N, H, W, C), 7.0, device=device)
+    lib.wino_weight_transform(wt, U2, C, K, 1)
+    lib.wino_input_transform(gyd, V2, N, H, W, K)
+    lib.wino_gemm(V2, U2, M2, N, H, W, K, C, ws=ws)
+    lib.wino_output_transform(M2, dx, None, N, H, W, C)
+    refx = xr.grad.permute(0, 2, 3, 1)
+    err = float((dx.cpu() - refx).abs().max())
+    assert err <= 3e-5 * float(refx.abs().max()) + 1e-6, f"winograd bwd data: {err} vs {float(refx.abs().max())}"
+    assert ws is None or float(ws.abs().max()) == 0.0
+    return 0 if ws is None else 1

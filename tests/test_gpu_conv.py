@@ -118,3 +118,9 @@ def test_balanced_schedule_full_batch(lib, N, H, C, K):
 
 def test_balanced_schedule_bnstats(lib):
     kc.conv_bnstats_case(lib, "cuda", 32, 14, 14, 512, 512, 3, 1, 1, use_ws=True)
+
+
+@pytest.mark.parametrize("N,H,C,K", [(32, 14, 256, 256), (32, 14, 512, 512), (8, 28, 128, 128), (3, 9, 128, 160)])
+def test_winograd_path(lib, N, H, C, K):
+    """Winograd F(2x2, 3x3) forward and backward-data (the layers 2-4 path) vs torch conv2d."""
+    kc.wino_case(lib, "cuda", N, H, H, C, K, seed=C + K)
