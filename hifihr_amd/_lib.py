@@ -115,6 +115,9 @@ class HifihrLib:
         c.hifihr_wino_input_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
         c.hifihr_wino_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_wino_output_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
+        c.hifihr_wino_dy_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
+        c.hifihr_wino_wgrad_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
+        c.hifihr_wino_dw_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_weight_transpose.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_se_pool.argtypes = [_c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_scale.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_int, c_int, _c_float_p, c_void_p]
@@ -284,6 +287,15 @@ class HifihrLib:
 
     def wino_output_transform(self, M, y, stats, N, H, W, K):
         self.check(self.c.hifihr_wino_output_transform(_fp(M), _fp(y), _fp(stats), N, H, W, K, _stream_of(M)), "hifihr_wino_output_transform")
+
+    def wino_dy_transform(self, dy, Y, N, H, W, K):
+        self.check(self.c.hifihr_wino_dy_transform(_fp(dy), _fp(Y), N, H, W, K, _stream_of(dy)), "hifihr_wino_dy_transform")
+
+    def wino_wgrad_gemm(self, V, Y, dU_zeroed, N, H, W, C, K):
+        self.check(self.c.hifihr_wino_wgrad_gemm(_fp(V), _fp(Y), _fp(dU_zeroed), N, H, W, C, K, _stream_of(V)), "hifihr_wino_wgrad_gemm")
+
+    def wino_dw_transform(self, dU, dw_acc, K, C, clear=True):
+        self.check(self.c.hifihr_wino_dw_transform(_fp(dU), _fp(dw_acc), K, C, int(bool(clear)), _stream_of(dU)), "hifihr_wino_dw_transform")
 
     def weight_transpose(self, w, wt, K, RS, C):
         self.check(self.c.hifihr_weight_transpose(_fp(w), _fp(wt), K, RS, C, _stream_of(w)), "hifihr_weight_transpose")

@@ -537,7 +537,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float
   const int K = g.OC;
   const int bq0 = blockIdx.x * BN, bk0 = blockIdx.y * BM;
   const int nch_total = (M + BKW - 1) / BKW;
-  const int ch_lo = blockIdx.z * chunks_per_split;
+  int zsplit = blockIdx.z;
+  if (g.batch > 1) {                               // batched use (Winograd weight gradient): blockIdx.z = batch * splits + split
+    const int nsplit = gridDim.z / g.batch, bz = blockIdx.z / nsplit;
+    zsplit = blockIdx.z - bz * nsplit;
+    x += (size_t)bz * g.src_bs; dy += (size_t)bz * g.dst_bs; dw += (size_t)bz * g.wgt_bs;
+  }
+  const int ch_lo = zsplit * chunks_per_split;
   const int ch_hi = min(ch_lo + chunks_per_split, nch_total);
   if (ch_lo >= ch_hi) return;
 
@@ -817,7 +823,8 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
 template <int BM, int BN, int BKW>
 static void launch_wgrad_tile(const ConvGeom& g, int Q, long M, int slots, const float* x, const float* dy, float* dw, hipStream_t st) {
   const int nch = (int)((M + BKW - 1) / BKW);
-  const int tiles = ((g.OC + BM - 1) / BM) * ((Q + BN - 1) / BN);
+  const int nbatch = g.batch > 1 ? g.batch : 1;
+  const int tiles = ((g.OC + BM - 1) / BM) * ((Q + BN - 1) / BN) * nbatch;
   // tiles * splits workgroups: stay at or just below the resident slots so that every CU gets the same number (the
   // dispatcher spreads a grid evenly; 1152 workgroups on 1024 slots cost five rounds on some CUs: tools/conv_quant_probe.py)
   int splits = slots / tiles;
@@ -826,7 +833,8 @@ static void launch_wgrad_tile(const ConvGeom& g, int Q, long M, int slots, const
   if (splits < 1) splits = 1;
   const int cps = (nch + splits - 1) / splits;
   splits = (nch + cps - 1) / cps;
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, BKW>), dim3((Q + BN - 1) / BN, (g.OC + BM - 1) / BM, splits), dim3(256), 0, st, g, x, dy, dw, cps);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, BKW>), dim3((Q + BN - 1) / BN, (g.OC + BM - 1) / BM, splits * nbatch), dim3(256), 0, st, g, x, dy,
+                     dw, cps);
 }
 
 hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {

@@ -589,6 +589,26 @@ int hifihr_wino_gemm(const float* V, const float* U, float* M, int N, int H, int
   return HIFIHR_OK;
 }
 
+int hifihr_wino_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, void* stream) {
+  if (!dy || !Y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_dy_transform: bad argument");
+  HIP_TRY(hifihr::launch_wino_dy_transform(dy, Y, N, H, W, K, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_wgrad_gemm(const float* V, const float* Y, float* dU_zeroed, int N, int H, int W, int C, int K, void* stream) {
+  if (!V || !Y || !dU_zeroed || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0 || K < 4 || K % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_wgrad_gemm: bad argument (C % 4 == 0, K % 4 == 0)");
+  const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+  HIP_TRY(hifihr::launch_conv_wgrad(wino_gemm_geom(T, C, K), V, Y, dU_zeroed, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_dw_transform(float* dU, float* dw_acc, int K, int C, int clear_du, void* stream) {
+  if (!dU || !dw_acc || K <= 0 || C < 4 || C % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_dw_transform: bad argument");
+  HIP_TRY(hifihr::launch_wino_dw_transform(dU, dw_acc, K, C, clear_du ? 1 : 0, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_output_transform(const float* M, float* y, float* stats, int N, int H, int W, int K, void* stream) {
   if (!M || !y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform: bad argument");
   HIP_TRY(hifihr::launch_wino_output_transform(M, y, stats, N, H, W, K, (hipStream_t)stream));

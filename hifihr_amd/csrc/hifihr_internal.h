@@ -150,6 +150,8 @@ hipError_t launch_se_scale(const float* x, const float* gate, const float* add, 
 hipError_t launch_wino_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st);
 hipError_t launch_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, hipStream_t st);
 hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats, int N, int H, int W, int K, hipStream_t st);
+hipError_t launch_wino_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st);
+hipError_t launch_wino_dw_transform(float* dU, float* dw, int K, int C, int clear, hipStream_t st);
 
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st);

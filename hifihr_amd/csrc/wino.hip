@@ -7,6 +7,8 @@
 //   wino_input_transform    V[16][T][C]  = B^T d B     d = 4x4 input patch of tile t (zero outside the image), T = N*ceil(H/2)*ceil(W/2)
 //   wino_output_transform   y[N][H][W][K] = A^T m A    m = M[.][t][.]; optionally adds the batch-norm sum / sum of squares of y
 //                                                        to the slot buffer (bn.hip), like the direct kernel's epilogue does
+//   wino_dy_transform       Y'[16][T][K] = A dy A^T    backward-weight: dU[pos][k][c] = sum_t Y'[pos][t][k] V[pos][t][c] (16 batched
+//   wino_dw_transform       dw[K][3][3][C] += G^T dU G  reductions on conv_wgrad_kernel), then back to the 3x3 filter
 // Replaces (together with the batched GEMM) the same cuDNN/MIOpen dispatches as conv.hip (reference network/res_encoder.py:364-373).
 // fp32 throughout: F(2,3) has transform constants {0, +-1, +-1/2}, its rounding error stays at a few ulp of the direct result.
 #include <hip/hip_runtime.h>
@@ -153,6 +155,82 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
   }
 }
 
+// backward-weight glue.  thread = (tile, 4 channels): Y'[16][T][K] = A dy A^T with A = [1 0; 1 1; 1 -1; 0 -1] (dy outside the image = 0)
+__global__ __launch_bounds__(256) void wino_dy_transform_kernel(const float* __restrict__ dy, float* __restrict__ Y, int N, int H, int W, int K, int TH,
+                                                               int TW) {
+  const int K4 = K / 4;
+  const size_t T = (size_t)N * TH * TW, total = T * K4;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int kg = (int)(i % K4);
+    const size_t t = i / K4;
+    const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+    float4 d[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oh = 2 * th + a, ow = 2 * tw + b;
+        const bool ok = oh < H && ow < W;
+        const float4 v = *reinterpret_cast<const float4*>(dy + (((size_t)n * H + (ok ? oh : 0)) * W + (ok ? ow : 0)) * K + kg * 4);
+        d[a][b] = ok ? v : z;
+      }
+    float4 tt[4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      tt[0][b] = d[0][b];
+      tt[1][b] = add4(d[0][b], d[1][b]);
+      tt[2][b] = sub4(d[0][b], d[1][b]);
+      tt[3][b] = sub4(z, d[1][b]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* o = Y + ((size_t)(r * 4) * T + t) * K + kg * 4;
+      *reinterpret_cast<float4*>(o) = tt[r][0];
+      *reinterpret_cast<float4*>(o + T * K) = add4(tt[r][0], tt[r][1]);
+      *reinterpret_cast<float4*>(o + 2 * T * K) = sub4(tt[r][0], tt[r][1]);
+      *reinterpret_cast<float4*>(o + 3 * T * K) = sub4(z, tt[r][1]);
+    }
+  }
+}
+
+// thread = (k, 4 channels): dw[K][3][3][C] += G^T dU G,  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+__global__ __launch_bounds__(256) void wino_dw_transform_kernel(float* __restrict__ dU, float* __restrict__ dw, int K, int C, int clear) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)K * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % C4), k = (int)(i / C4);
+    float4 u[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float4* p = reinterpret_cast<float4*>(dU + ((size_t)(r * 4 + c) * K + k) * C + cg * 4);
+        u[r][c] = *p;
+        if (clear) *p = make_float4(0.f, 0.f, 0.f, 0.f);      // self-cleaning accumulator: zero again for the next reduction
+      }
+    float4 t[3][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 h12 = add4(u[1][c], u[2][c]), d12 = sub4(u[1][c], u[2][c]);
+      t[0][c] = make_float4(u[0][c].x + 0.5f * h12.x, u[0][c].y + 0.5f * h12.y, u[0][c].z + 0.5f * h12.z, u[0][c].w + 0.5f * h12.w);
+      t[1][c] = make_float4(0.5f * d12.x, 0.5f * d12.y, 0.5f * d12.z, 0.5f * d12.w);
+      t[2][c] = make_float4(u[3][c].x + 0.5f * h12.x, u[3][c].y + 0.5f * h12.y, u[3][c].z + 0.5f * h12.z, u[3][c].w + 0.5f * h12.w);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float4 h12 = add4(t[r][1], t[r][2]), d12 = sub4(t[r][1], t[r][2]);
+      const float4 g0 = make_float4(t[r][0].x + 0.5f * h12.x, t[r][0].y + 0.5f * h12.y, t[r][0].z + 0.5f * h12.z, t[r][0].w + 0.5f * h12.w);
+      const float4 g1 = make_float4(0.5f * d12.x, 0.5f * d12.y, 0.5f * d12.z, 0.5f * d12.w);
+      const float4 g2 = make_float4(t[r][3].x + 0.5f * h12.x, t[r][3].y + 0.5f * h12.y, t[r][3].z + 0.5f * h12.z, t[r][3].w + 0.5f * h12.w);
+      float* o = dw + (((size_t)k * 3 + r) * 3) * C + cg * 4;
+      float4 a = *reinterpret_cast<float4*>(o);          *reinterpret_cast<float4*>(o) = add4(a, g0);
+      a = *reinterpret_cast<float4*>(o + C);             *reinterpret_cast<float4*>(o + C) = add4(a, g1);
+      a = *reinterpret_cast<float4*>(o + 2 * C);         *reinterpret_cast<float4*>(o + 2 * C) = add4(a, g2);
+    }
+  }
+}
+
 static unsigned wino_grid(size_t total) {
   size_t b = (total + 255) / 256;
   if (b > 4096) b = 4096;
@@ -181,6 +259,19 @@ hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats,
   const size_t cap = stats != nullptr ? 256 : 2048;       // with statistics: bound (workgroups x channels) atomics (bn.hip)
   if (bx > cap) bx = cap;
   hipLaunchKernelGGL(wino_output_transform_kernel, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, N, H, W, K, TH, TW);
+  return hipGetLastError();
+}
+
+hipError_t launch_wino_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st) {
+  if (K % 4 != 0) return hipErrorInvalidValue;
+  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  hipLaunchKernelGGL(wino_dy_transform_kernel, dim3(wino_grid((size_t)N * TH * TW * (K / 4))), dim3(256), 0, st, dy, Y, N, H, W, K, TH, TW);
+  return hipGetLastError();
+}
+
+hipError_t launch_wino_dw_transform(float* dU, float* dw, int K, int C, int clear, hipStream_t st) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(wino_dw_transform_kernel, dim3(wino_grid((size_t)K * (C / 4))), dim3(256), 0, st, dU, dw, K, C, clear);
   return hipGetLastError();
 }
 

@@ -280,13 +280,14 @@ def _wino_ok(C, K, R, S, stride, pad):
     return R == 3 and S == 3 and stride == 1 and pad == 1 and C >= 128 and K >= 128 and C % 32 == 0 and K % 32 == 0
 
 
-def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip):
+def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False):
     """y[N][H][W][K] = conv3x3(x[N][H][W][C], w[K][3][3][C]) through weight / input transform, 16 batched GEMMs, output
-    transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter)."""
+    transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter).
+    keep_v: return the transformed input V[16][T][C] in a tensor of its own (the Winograd weight gradient consumes it)."""
     dev = x.device
     T = N * ((H + 1) // 2) * ((W + 1) // 2)
     U = _wino_scratch(dev, "U", 16 * K * C)
-    V = _wino_scratch(dev, "V", 16 * T * C)
+    V = torch.empty(16 * T * C, device=dev, dtype=torch.float32) if keep_v else _wino_scratch(dev, "V", 16 * T * C)
     M = _wino_scratch(dev, "M", 16 * T * K)
     key = ("wino", N, H, W, C, K)
     nb = _CONV_WS_BYTES.get(key)
@@ -305,6 +306,7 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip):
     lib.wino_input_transform(x, V, N, H, W, C)
     lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)
     lib.wino_output_transform(M, y, stats, N, H, W, K)
+    return V if keep_v else None
 
 
 class _Conv2dMFMA(torch.autograd.Function):
@@ -321,9 +323,13 @@ class _Conv2dMFMA(torch.autograd.Function):
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
         stats = None
         wino = bias is None and not relu and _wino_ok(C, K, R, S, stride, pad)
+        v_saved = None
         if wino:
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device) if want_stats else None
-            PROFILE.bracket("conv_fwd_wino", lambda: _wino_conv(lib, x, wk, y, stats, N, H, W, C, K, 0))
+            keep = bool(ctx.needs_input_grad[1])
+            box = []
+            PROFILE.bracket("conv_fwd_wino", lambda: box.append(_wino_conv(lib, x, wk, y, stats, N, H, W, C, K, 0, keep_v=keep)))
+            v_saved = box[0]
         elif want_stats:       # per-channel sum / sum of squares of y from the conv epilogue, for the batch-norm that follows
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device)
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), False)
@@ -335,7 +341,9 @@ class _Conv2dMFMA(torch.autograd.Function):
         if PROFILE.on and not wino:
             PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "fwd"))
         ctx.geom = (N, H, W, C, K, R, S, stride, pad)
-        ctx.save_for_backward(x, wk, y if relu else None)
+        # Winograd layers keep the transformed input V (4x the size of x, 288 GB of HBM do not care) instead of x: the weight
+        # gradient reduces Y' . V in the transform domain and backward-data needs neither
+        ctx.save_for_backward(x if v_saved is None else None, wk, y if relu else None, v_saved)
         ctx.w_param, ctx.b_param, ctx.relu = w, bias, relu
         ctx.set_materialize_grads(False)         # no zero-fill launch for the (non-differentiable) stats output
         if want_stats:
@@ -345,7 +353,7 @@ class _Conv2dMFMA(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gstats=None):
-        x, wk, y = ctx.saved_tensors
+        x, wk, y, v_saved = ctx.saved_tensors
         lib = get_lib()
         N, H, W, C, K, R, S, stride, pad = ctx.geom
         if gy is None:
@@ -366,8 +374,8 @@ class _Conv2dMFMA(torch.autograd.Function):
                 _grad_ready(b)
         if ctx.needs_input_grad[0] and not ctx.relu and ctx.b_param is None and _wino_ok(C, K, R, S, stride, pad):
             # backward-data of a stride-1 3x3 = the same Winograd pipeline on dy with the transposed, rotated filter
-            dx = torch.empty_like(x, memory_format=_CL)
-            wt = _wino_scratch(x.device, "wt", wk.numel())
+            dx = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32, memory_format=_CL)
+            wt = _wino_scratch(gy.device, "wt", wk.numel())
 
             def run():
                 lib.weight_transpose(wk, wt, K, R * S, C)
@@ -388,7 +396,22 @@ class _Conv2dMFMA(torch.autograd.Function):
                 dw = torch.zeros_like(wk, memory_format=_CL)
                 tgt = dw
             # accumulates (fp32 atomics) straight into the flat gradient buffer when the parameter lives in one
-            PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, tgt, N, H, W, C, K, R, S, stride, pad))
+            if v_saved is not None:
+                T = N * ((H + 1) // 2) * ((W + 1) // 2)
+                Yt = _wino_scratch(gy.device, "Yt", 16 * T * K)
+                key = (gy.device, "dU", 16 * K * C)
+                dU = _WINO_SCRATCH.get(key)
+                if dU is None:                                   # zero-initialised once; wino_dw_transform hands it back zeroed
+                    dU = torch.zeros(16 * K * C, device=gy.device, dtype=torch.float32)
+                    _WINO_SCRATCH[key] = dU
+
+                def run_w():
+                    lib.wino_dy_transform(gy, Yt, N, H, W, K)
+                    lib.wino_wgrad_gemm(v_saved, Yt, dU, N, H, W, C, K)
+                    lib.wino_dw_transform(dU, tgt, K, C, clear=True)
+                PROFILE.bracket("conv_wgrad_wino", run_w)
+            else:
+                PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, tgt, N, H, W, C, K, R, S, stride, pad))
             if dw is None:
                 _grad_ready(w)
         return dx, dw, None, None, None, db_ret, None

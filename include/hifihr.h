@@ -169,8 +169,15 @@ int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, i
  *   hifihr_wino_gemm            (V, U, M[16][T][K])  -- 16 GEMMs on the MFMA kernel; ws as for hifihr_conv2d_fwd
  *   hifihr_wino_output_transform(M, y[N][H][W][K], stats_d or NULL)   -- stats_d: batch-norm slot buffer (zero on entry)
  * Backward-data is the same sequence on dy with the weights of the transposed, 180-degree rotated filter:
- *   weight_transform(wt[C][3][3][K] (= the [C][R][S][K] transpose hifihr_conv2d_bwd_data also builds), U[16][C][K], C, K, flip = 1). */
+ *   weight_transform(wt[C][3][3][K] (= the [C][R][S][K] transpose hifihr_conv2d_bwd_data also builds), U[16][C][K], C, K, flip = 1).
+ * Backward-weight: dU[16][K][C] (ZERO on entry) += the 16 batched reductions over the tiles of
+ *   Y'[16][T][K] = hifihr_wino_dy_transform(dy)  and  V[16][T][C] (the forward's input transform of x), then
+ *   hifihr_wino_dw_transform: dw[K][3][3][C] += G^T dU G  (accumulates, like hifihr_conv2d_bwd_weight). */
 size_t hifihr_wino_gemm_workspace_bytes(int N, int H, int W, int C, int K);
+int hifihr_wino_dy_transform(const float* dy_d, float* yt_d, int N, int H, int W, int K, void* stream);
+int hifihr_wino_wgrad_gemm(const float* v_d, const float* yt_d, float* du_zeroed_d, int N, int H, int W, int C, int K, void* stream);
+int hifihr_wino_dw_transform(float* du_d, float* dw_acc_d, int K, int C, int clear_du /* 1: leave du_d all zero (self-cleaning) */,
+                             void* stream);
 int hifihr_wino_weight_transform(const float* w_d, float* u_d, int K, int C, int flip, void* stream);
 int hifihr_wino_input_transform(const float* x_d, float* v_d, int N, int H, int W, int C, void* stream);
 int hifihr_wino_gemm(const float* v_d, const float* u_d, float* m_d, int N, int H, int W, int C, int K, void* ws_d, size_t ws_bytes,

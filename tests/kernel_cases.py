@@ -655,8 +655,8 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(seed)
     x = torch.randn(N, C, H, W, generator=gen); w = torch.randn(K, C, 3, 3, generator=gen) / (9 * C) ** 0.5
-    xr = x.clone().requires_grad_(True)
-    y = F.conv2d(xr, w, None, 1, 1)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, 1, 1)
     gy = torch.randn(y.shape, generator=gen)
     y.backward(gy)
     d = lambda t: t.to(device).contiguous()
@@ -692,4 +692,15 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
     err = float((dx.cpu() - refx).abs().max())
     assert err <= 3e-5 * float(refx.abs().max()) + 1e-6, f"winograd bwd data: {err} vs {float(refx.abs().max())}"
     assert ws is None or float(ws.abs().max()) == 0.0
+    # backward-weight: dU = sum over tiles of (A dy A^T) . (B^T d B), then dw += G^T dU G
+    lib.wino_input_transform(xd, V, N, H, W, C)
+    Yt = torch.empty(16, T, K, device=device); dU = torch.zeros(16, K, C, device=device)
+    lib.wino_dy_transform(gyd, Yt, N, H, W, K)
+    lib.wino_wgrad_gemm(V, Yt, dU, N, H, W, C, K)
+    dw = torch.full((K, 3, 3, C), 0.5, device=device)                    # accumulate semantics
+    lib.wino_dw_transform(dU, dw, K, C)
+    assert float(dU.abs().max()) == 0.0, "the dU accumulator must come back zeroed"
+    refw = wr.grad.permute(0, 2, 3, 1)
+    err = float((dw.cpu() - 0.5 - refw).abs().max())
+    assert err <= 1e-4 * float(refw.abs().max()) + 1e-6, f"winograd bwd weight: {err} vs {float(refw.abs().max())}"
     return 0 if ws is None else 1
