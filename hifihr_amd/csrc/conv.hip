@@ -744,7 +744,9 @@ static SkPlan sk_plan(const ConvGeom& g) {
   p.tiles = p.tiles_x * ((g.OC + p.v.bn - 1) / p.v.bn) * (g.batch > 1 ? g.batch : 1);
   p.nch = g.R * g.S * (g.IC / p.v.bk);
   const int slots = device_cus() * p.v.occ;
-  if (p.nch * p.v.bk < kSkMinChunks * 32 || p.tiles < slots / 4) return p;
+  int minch = kSkMinChunks;
+  if (const char* e = getenv("HIFIHR_CONV_SK_MINCH")) minch = atoi(e);
+  if (p.nch * p.v.bk < minch * 32 || p.tiles < slots / 4) return p;
   // rounds the data-parallel grid costs vs the balanced share: only switch when > 5 % is on the table
   const double dp = (double)((p.tiles + slots - 1) / slots), sk = (double)p.tiles / slots;
   if (dp < 1.05 * sk && p.v.bm == 64) return p;
