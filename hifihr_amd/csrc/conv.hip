@@ -831,6 +831,7 @@ static void launch_wgrad_tile(const ConvGeom& g, int Q, long M, int slots, const
   // dispatcher spreads a grid evenly; 1152 workgroups on 1024 slots cost five rounds on some CUs: tools/conv_quant_probe.py)
   int splits = slots / tiles;
   if (const char* e = getenv("HIFIHR_WGRAD_SPLITS")) splits = atoi(e);
+  if (const char* e = getenv("HIFIHR_WGRAD_MAXSPLIT")) { if (splits > atoi(e)) splits = atoi(e); }
   if (splits > nch / 4) splits = nch / 4;
   if (splits < 1) splits = 1;
   const int cps = (nch + splits - 1) / splits;

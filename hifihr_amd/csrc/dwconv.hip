@@ -19,6 +19,8 @@
 // Weight layout [C][k][k] (= torch's [C,1,k,k]).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "hifihr_internal.h"
 
 namespace hifihr {
@@ -179,7 +181,6 @@ template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwGeom g, const float* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ dw) {
   constexpr int KK = K * K, NC = (kPW - 1) * S + K;
-  __shared__ float4 red[16][16];
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int c = blockIdx.y * 64 + cl * 4;
   const bool cok = c < g.C;
@@ -217,17 +218,27 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwGeom g, const 
       }
     }
   }
-  // fold the 16 pixel lanes tap by tap, then one atomic per (channel, tap) per workgroup
+  // Fold the 16 pixel lanes: the 4 lanes of a wave with shuffles, the 4 waves through LDS (one barrier), then the k*k x 16
+  // (tap, channel group) sums are spread over the threads for the atomics (the first version walked the taps one by one:
+  // 2 barriers per tap and 100 atomics in a row from 16 threads).
+  __shared__ float4 red[4][KK][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int t = 0; t < KK; ++t) {
-    __syncthreads();
-    red[pl][cl] = acc[t];
-    __syncthreads();
-    if (pl == 0 && cok) {
-      float4 a = acc[t];
-      for (int r = 1; r < 16; ++r) { const float4 b = red[r][cl]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-      float* o = dw + (size_t)c * KK + t;
-      atomicAdd(o, a.x); atomicAdd(o + KK, a.y); atomicAdd(o + 2 * KK, a.z); atomicAdd(o + 3 * KK, a.w);
+    float4 a = acc[t];
+    a.x += __shfl_down(a.x, 32, 64); a.y += __shfl_down(a.y, 32, 64); a.z += __shfl_down(a.z, 32, 64); a.w += __shfl_down(a.w, 32, 64);
+    a.x += __shfl_down(a.x, 16, 64); a.y += __shfl_down(a.y, 16, 64); a.z += __shfl_down(a.z, 16, 64); a.w += __shfl_down(a.w, 16, 64);
+    if (lane < 16) red[wave][t][lane] = a;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < KK * 16; e += 256) {
+    const int t = e >> 4, l = e & 15;
+    const int cc = blockIdx.y * 64 + l * 4;
+    if (cc < g.C) {
+      const float4 a0 = red[0][t][l], a1 = red[1][t][l], a2 = red[2][t][l], a3 = red[3][t][l];
+      float* o = dw + (size_t)cc * KK + t;
+      atomicAdd(o, (a0.x + a1.x) + (a2.x + a3.x)); atomicAdd(o + KK, (a0.y + a1.y) + (a2.y + a3.y));
+      atomicAdd(o + 2 * KK, (a0.z + a1.z) + (a2.z + a3.z)); atomicAdd(o + 3 * KK, (a0.w + a1.w) + (a2.w + a3.w));
     }
   }
 }
@@ -263,7 +274,12 @@ hipError_t launch_dwconv_bwd_data(const DwGeom& g, const float* dy, const float*
 }
 hipError_t launch_dwconv_bwd_weight(const DwGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {
   const long nb = (long)g.N * g.OH * ((g.OW + kPW - 1) / kPW);
-  const dim3 grid(dw_grid_x(nb, 128), (g.C + 63) / 64);      // <= 128 workgroups add into one weight
+  // every workgroup ends with k*k x 64 atomics: give each pixel lane ~8 steps before that, between 8 and 128 workgroups per block
+  long gx = nb / (16 * 8);
+  if (const char* e = getenv("HIFIHR_DW_WGRAD_STEPS")) gx = nb / (16 * (atoi(e) > 0 ? atoi(e) : 8));
+  if (gx < 8) gx = 8;
+  if (gx > 128) gx = 128;
+  const dim3 grid((unsigned)gx, (g.C + 63) / 64);
   HIFIHR_DW_DISPATCH(dwconv_bwd_weight_kernel, grid, g, x, dy, dw);
   return hipGetLastError();
 }
