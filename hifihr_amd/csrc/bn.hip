@@ -5,11 +5,15 @@
 // vendored utils/Freihand_GNN_mano/network/resnet.py; EfficientNet MBConv: network/efficientnet_pt/model.py:67-94):
 // nn.BatchNorm2d in training mode (batch statistics, running-stat update, unbiased running variance) + `out += identity`
 // + ReLU, or + MemoryEfficientSwish (utils.py:36-52), and their autograd, with
-//   forward : per-channel sum / sum-of-squares come out of the convolution epilogue (conv.hip) or bn_stats_kernel, a
-//             one-thread-per-channel finalize kernel folds them into mean / invstd (+ running stats), then ONE apply kernel
-//   backward: ONE reduction kernel (sum g, sum g*xhat, activation derivative applied on the fly), finalize (dgamma / dbeta
-//             accumulated straight into the flat gradient buffer), ONE apply kernel writing dx (and the masked gradient of
-//             the identity branch).
+//   forward : per-channel sum / sum-of-squares come out of the convolution epilogue (conv.hip, dwconv.hip, wino.hip) or
+//             bn_stats_kernel; ONE apply kernel whose workgroups each fold the slot partials into scale / shift in LDS
+//             (workgroup 0 also writes mean / invstd and the running statistics)
+//   backward: ONE reduction kernel (sum g, sum g*xhat, activation derivative applied on the fly), ONE apply kernel that
+//             folds the slots the same way (workgroup 0 accumulates dgamma / dbeta straight into the flat gradient buffer)
+//             and writes dx (and the masked gradient of the identity branch).
+//   Up to 256 channels the separate one-thread-per-channel finalize launches of the first version (2 per layer, ~6.8 us
+//   each in a replayed graph) are gone: the LAST workgroup of an apply kernel to finish -- elected through 32 + 1 arrival
+//   counters behind the slots -- zeroes the slots for the next producer.  Wider layers keep the finalize launch (kFuseMaxC).
 // All kernels are HBM-bound: every lane moves float4 (4 consecutive channels) and keeps the same channel group(s) for
 // its whole grid-stride loop, so scale / shift live in registers.  Partial sums use float atomics spread over
 // kStatSlots copies (thousands of atomics on ONE address serialise at ~100 ns each).
@@ -43,17 +47,6 @@ __device__ __forceinline__ BnMap bn_map(int C) {
     m.cg0 = threadIdx.x; m.rl = 0; m.active = true;
   }
   return m;
-}
-
-// sum of the kStatSlots partials of one entry; the slots are left zeroed for the next producer
-__device__ __forceinline__ float slot_sum_and_clear(float* __restrict__ buf, int C, int idx) {
-  float a = 0.f;
-#pragma unroll 8
-  for (int sl = 0; sl < kStatSlots; ++sl) {
-    a += buf[(size_t)sl * 2 * C + idx];
-    buf[(size_t)sl * 2 * C + idx] = 0.f;
-  }
-  return a;
 }
 
 __device__ __forceinline__ void atomic_add4(float* p, const float4& v) {
@@ -118,16 +111,59 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   reduce_and_add(mp, C, s, q, lds, stats);
 }
 
-// one thread per channel: fold the slot partials into mean / invstd, update the running statistics
+constexpr int kMaxC = 4 * 256 * kMaxNG;     // 4096 channels: scale / shift tables of the apply kernels (2 x 16 KB of LDS)
+constexpr int kBnCounters = 64;              // uint32 arrival counters stored behind the slot partials (33 used)
+
+// True in every thread of exactly ONE workgroup of the launch: the last one to get here.  Called after the workgroup's last
+// read of the slot buffer; the elected workgroup may then overwrite it.  32 first-level counters keep the same-address
+// atomic traffic at <= grid / 32 per counter.
+__device__ __forceinline__ bool last_workgroup(unsigned* __restrict__ cnt) {
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned slot = blockIdx.x & 31u, nslots = gridDim.x < 32u ? gridDim.x : 32u;
+    const unsigned in_slot = (gridDim.x + 31u - slot) / 32u;
+    int last = 0;
+    if (atomicAdd(cnt + slot, 1u) == in_slot - 1u) last = (atomicAdd(cnt + 32, 1u) == nslots - 1u) ? 1 : 0;
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+__device__ __forceinline__ void clear_slots(float* __restrict__ buf, int C, unsigned* __restrict__ cnt) {
+  float4* p = reinterpret_cast<float4*>(buf);
+  const int n4 = kStatSlots * 2 * C / 4;
+  for (int i = threadIdx.x; i < n4; i += 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x < 33) cnt[threadIdx.x] = 0u;
+}
+
+__device__ __forceinline__ float slot_sum(const float* __restrict__ buf, int C, int idx) {
+  float a = 0.f;
+#pragma unroll 8
+  for (int sl = 0; sl < kStatSlots; ++sl) a += buf[(size_t)sl * 2 * C + idx];
+  return a;
+}
+
+// Wide layers (C > kFuseMaxC): folding 256 C bytes of partials in EVERY workgroup costs more than it saves (EfficientNet's
+// 1392-channel layers: +1.2 ms per step measured), so they keep a one-thread-per-channel finalize launch that also cleans the slots.
+constexpr int kFuseMaxC = 256;
+
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(float* __restrict__ stats, long M, int C, float eps, float momentum,
                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                              float* __restrict__ running_mean, float* __restrict__ running_var) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const float invM = 1.0f / (float)M;
-  const float mu = slot_sum_and_clear(stats, C, c) * invM;
-  float var = slot_sum_and_clear(stats, C, C + c) * invM - mu * mu;   // biased batch variance
-  var = fmaxf(var, 0.f);
+  float s = 0.f, q = 0.f;
+#pragma unroll 8
+  for (int sl = 0; sl < kStatSlots; ++sl) {
+    float* p = stats + (size_t)sl * 2 * C;
+    s += p[c]; q += p[C + c];
+    p[c] = 0.f; p[C + c] = 0.f;
+  }
+  const float mu = s * invM;
+  const float var = fmaxf(q * invM - mu * mu, 0.f);
   save_mean[c] = mu;
   save_invstd[c] = 1.0f / sqrtf(var + eps);
   if (running_mean) {
@@ -137,41 +173,91 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ save_mean,
-                                                        const float* __restrict__ save_invstd, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, const float* __restrict__ residual,
-                                                        int act, long M, int C, float* __restrict__ y) {
+// tot[2][C] = slot sums of the backward reduction (behind the slots), slots cleaned, dgamma / dbeta accumulated
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(float* __restrict__ red, int C, float* __restrict__ dgamma_acc,
+                                                             float* __restrict__ dbeta_acc) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll 8
+  for (int sl = 0; sl < kStatSlots; ++sl) {
+    float* p = red + (size_t)sl * 2 * C;
+    sg += p[c]; sgx += p[C + c];
+    p[c] = 0.f; p[C + c] = 0.f;
+  }
+  float* tot = red + (size_t)kStatSlots * 2 * C;
+  tot[c] = sg;
+  tot[C + c] = sgx;
+  if (dgamma_acc) dgamma_acc[c] += sgx;
+  if (dbeta_acc) dbeta_acc[c] += sg;
+}
+
+// PRE = true: mean / invstd (forward) or the totals behind the slots (backward) were produced by a finalize launch
+template <bool PRE>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ residual, int act, long M,
+                                                        int C, float eps, float momentum, float* __restrict__ y, float* __restrict__ save_mean,
+                                                        float* __restrict__ save_invstd, float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var) {
+  __shared__ float s_sc[kMaxC], s_sh[kMaxC];
   const BnMap mp = bn_map(C);
-  if (!mp.active) return;
-  float4 scale[kMaxNG], shift[kMaxNG];
-#pragma unroll
-  for (int j = 0; j < kMaxNG; ++j) {
-    const int cg = mp.cg0 + 256 * j;
-    if (j < mp.NG && cg * 4 < C) {
-      const float4 is = *reinterpret_cast<const float4*>(save_invstd + cg * 4), mu = *reinterpret_cast<const float4*>(save_mean + cg * 4);
-      const float4 ga = *reinterpret_cast<const float4*>(gamma + cg * 4), be = *reinterpret_cast<const float4*>(beta + cg * 4);
-      scale[j] = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
-      shift[j] = make_float4(be.x - mu.x * scale[j].x, be.y - mu.y * scale[j].y, be.z - mu.z * scale[j].z, be.w - mu.w * scale[j].w);
+  const float invM = 1.0f / (float)M;
+  for (int c = threadIdx.x; c < C; c += 256) {            // every workgroup folds the slot partials itself (L2-resident)
+    float mu, is, var = 0.f;
+    if (PRE) {
+      mu = save_mean[c]; is = save_invstd[c];
+    } else {
+      mu = slot_sum(stats, C, c) * invM;
+      var = fmaxf(slot_sum(stats, C, C + c) * invM - mu * mu, 0.f);       // biased batch variance
+      is = 1.0f / sqrtf(var + eps);
+    }
+    const float sc = is * gamma[c];
+    s_sc[c] = sc;
+    s_sh[c] = beta[c] - mu * sc;
+    if (!PRE && blockIdx.x == 0) {
+      save_mean[c] = mu;
+      save_invstd[c] = is;
+      if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        const float unbiased = (M > 1) ? var * ((float)M / (float)(M - 1)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
     }
   }
-  for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+  __syncthreads();
+  if (mp.active) {
+    float4 scale[kMaxNG], shift[kMaxNG];
 #pragma unroll
     for (int j = 0; j < kMaxNG; ++j) {
       const int cg = mp.cg0 + 256 * j;
       if (j < mp.NG && cg * 4 < C) {
-        const size_t o = (size_t)m * C + cg * 4;
-        const float4 v = *reinterpret_cast<const float4*>(x + o);
-        float4 r = make_float4(v.x * scale[j].x + shift[j].x, v.y * scale[j].y + shift[j].y, v.z * scale[j].z + shift[j].z,
-                               v.w * scale[j].w + shift[j].w);
-        if (residual) acc4(r, *reinterpret_cast<const float4*>(residual + o));
-        if (act == 1) {
-          r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
-        } else if (act == 2) {
-          r.x = r.x / (1.f + expf(-r.x)); r.y = r.y / (1.f + expf(-r.y)); r.z = r.z / (1.f + expf(-r.z)); r.w = r.w / (1.f + expf(-r.w));
-        }
-        *reinterpret_cast<float4*>(y + o) = r;
+        scale[j] = *reinterpret_cast<const float4*>(&s_sc[cg * 4]);
+        shift[j] = *reinterpret_cast<const float4*>(&s_sh[cg * 4]);
       }
     }
+    for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+#pragma unroll
+      for (int j = 0; j < kMaxNG; ++j) {
+        const int cg = mp.cg0 + 256 * j;
+        if (j < mp.NG && cg * 4 < C) {
+          const size_t o = (size_t)m * C + cg * 4;
+          const float4 v = *reinterpret_cast<const float4*>(x + o);
+          float4 r = make_float4(v.x * scale[j].x + shift[j].x, v.y * scale[j].y + shift[j].y, v.z * scale[j].z + shift[j].z,
+                                 v.w * scale[j].w + shift[j].w);
+          if (residual) acc4(r, *reinterpret_cast<const float4*>(residual + o));
+          if (act == 1) {
+            r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+          } else if (act == 2) {
+            r.x = r.x / (1.f + expf(-r.x)); r.y = r.y / (1.f + expf(-r.y)); r.z = r.z / (1.f + expf(-r.z)); r.w = r.w / (1.f + expf(-r.w));
+          }
+          *reinterpret_cast<float4*>(y + o) = r;
+        }
+      }
+    }
+  }
+  if (!PRE) {
+    unsigned* cnt = reinterpret_cast<unsigned*>(stats + (size_t)(kStatSlots + 1) * 2 * C);
+    if (last_workgroup(cnt)) clear_slots(stats, C, cnt);
   }
 }
 
@@ -231,71 +317,89 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   reduce_and_add(mp, C, s, q, lds, red);
 }
 
-// one thread per channel: fold the slot partials of the backward reduction into tot[2][C]; dgamma / dbeta accumulate
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(float* __restrict__ red, int C, float* __restrict__ tot,
-                                                             float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float sg = slot_sum_and_clear(red, C, c), sgx = slot_sum_and_clear(red, C, C + c);
-  tot[c] = sg;
-  tot[C + c] = sgx;
-  if (dgamma_acc) dgamma_acc[c] += sgx;
-  if (dbeta_acc) dbeta_acc[c] += sg;
-}
-
-// dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  dres = g (when the block has an identity branch)
+// dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  dres = g (when the block has an identity branch).
+// Every workgroup folds the slot partials of the reduction into mean(g), mean(g * xhat) in LDS; workgroup 0 accumulates
+// dgamma / dbeta; the last workgroup to finish zeroes the slots.
+template <bool PRE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                           const float* __restrict__ x, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ tot, int act,
-                                                          long M, int C, float* __restrict__ dx, float* __restrict__ dres) {
+                                                          const float* __restrict__ beta, float* __restrict__ red, int act,
+                                                          long M, int C, float* __restrict__ dx, float* __restrict__ dres,
+                                                          float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
+  __shared__ float s_mg[kMaxC], s_mgx[kMaxC];
   const BnMap mp = bn_map(C);
-  if (!mp.active) return;
   const float invM = 1.0f / (float)M;
-  float4 mu[kMaxNG], is[kMaxNG], k1[kMaxNG], mg[kMaxNG], mgx[kMaxNG], sh[kMaxNG];
-#pragma unroll
-  for (int j = 0; j < kMaxNG; ++j) {
-    const int cg = mp.cg0 + 256 * j;
-    if (j < mp.NG && cg * 4 < C) {
-      mu[j] = *reinterpret_cast<const float4*>(save_mean + cg * 4);
-      is[j] = *reinterpret_cast<const float4*>(save_invstd + cg * 4);
-      const float4 ga = *reinterpret_cast<const float4*>(gamma + cg * 4);
-      k1[j] = make_float4(ga.x * is[j].x, ga.y * is[j].y, ga.z * is[j].z, ga.w * is[j].w);
-      const float4 a = *reinterpret_cast<const float4*>(tot + cg * 4), b = *reinterpret_cast<const float4*>(tot + C + cg * 4);
-      mg[j] = make_float4(a.x * invM, a.y * invM, a.z * invM, a.w * invM);
-      mgx[j] = make_float4(b.x * invM, b.y * invM, b.z * invM, b.w * invM);
-      sh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (act == 2) {
-        const float4 be = *reinterpret_cast<const float4*>(beta + cg * 4);
-        sh[j] = make_float4(be.x - mu[j].x * k1[j].x, be.y - mu[j].y * k1[j].y, be.z - mu[j].z * k1[j].z, be.w - mu[j].w * k1[j].w);
-      }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sg, sgx;
+    if (PRE) {
+      const float* tot = red + (size_t)kStatSlots * 2 * C;
+      sg = tot[c]; sgx = tot[C + c];
+    } else {
+      sg = slot_sum(red, C, c); sgx = slot_sum(red, C, C + c);
+    }
+    s_mg[c] = sg * invM;
+    s_mgx[c] = sgx * invM;
+    if (!PRE && blockIdx.x == 0) {
+      if (dgamma_acc) dgamma_acc[c] += sgx;
+      if (dbeta_acc) dbeta_acc[c] += sg;
     }
   }
-  for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+  __syncthreads();
+  if (mp.active) {
+    float4 mu[kMaxNG], is[kMaxNG], k1[kMaxNG], mg[kMaxNG], mgx[kMaxNG], sh[kMaxNG];
 #pragma unroll
     for (int j = 0; j < kMaxNG; ++j) {
       const int cg = mp.cg0 + 256 * j;
       if (j < mp.NG && cg * 4 < C) {
-        const size_t o = (size_t)m * C + cg * 4;
-        const float4 v = *reinterpret_cast<const float4*>(x + o);
-        const float4 g = masked_grad(act, *reinterpret_cast<const float4*>(dy + o), y, o, v, k1[j], sh[j]);
-        float4 r;
-        r.x = k1[j].x * (g.x - mg[j].x - (v.x - mu[j].x) * is[j].x * mgx[j].x);
-        r.y = k1[j].y * (g.y - mg[j].y - (v.y - mu[j].y) * is[j].y * mgx[j].y);
-        r.z = k1[j].z * (g.z - mg[j].z - (v.z - mu[j].z) * is[j].z * mgx[j].z);
-        r.w = k1[j].w * (g.w - mg[j].w - (v.w - mu[j].w) * is[j].w * mgx[j].w);
-        *reinterpret_cast<float4*>(dx + o) = r;
-        if (dres) *reinterpret_cast<float4*>(dres + o) = g;
+        mu[j] = *reinterpret_cast<const float4*>(save_mean + cg * 4);
+        is[j] = *reinterpret_cast<const float4*>(save_invstd + cg * 4);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + cg * 4);
+        k1[j] = make_float4(ga.x * is[j].x, ga.y * is[j].y, ga.z * is[j].z, ga.w * is[j].w);
+        mg[j] = *reinterpret_cast<const float4*>(&s_mg[cg * 4]);
+        mgx[j] = *reinterpret_cast<const float4*>(&s_mgx[cg * 4]);
+        sh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act == 2) {
+          const float4 be = *reinterpret_cast<const float4*>(beta + cg * 4);
+          sh[j] = make_float4(be.x - mu[j].x * k1[j].x, be.y - mu[j].y * k1[j].y, be.z - mu[j].z * k1[j].z, be.w - mu[j].w * k1[j].w);
+        }
+      }
+    }
+    for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+#pragma unroll
+      for (int j = 0; j < kMaxNG; ++j) {
+        const int cg = mp.cg0 + 256 * j;
+        if (j < mp.NG && cg * 4 < C) {
+          const size_t o = (size_t)m * C + cg * 4;
+          const float4 v = *reinterpret_cast<const float4*>(x + o);
+          const float4 g = masked_grad(act, *reinterpret_cast<const float4*>(dy + o), y, o, v, k1[j], sh[j]);
+          float4 r;
+          r.x = k1[j].x * (g.x - mg[j].x - (v.x - mu[j].x) * is[j].x * mgx[j].x);
+          r.y = k1[j].y * (g.y - mg[j].y - (v.y - mu[j].y) * is[j].y * mgx[j].y);
+          r.z = k1[j].z * (g.z - mg[j].z - (v.z - mu[j].z) * is[j].z * mgx[j].z);
+          r.w = k1[j].w * (g.w - mg[j].w - (v.w - mu[j].w) * is[j].w * mgx[j].w);
+          *reinterpret_cast<float4*>(dx + o) = r;
+          if (dres) *reinterpret_cast<float4*>(dres + o) = g;
+        }
       }
     }
   }
+  if (!PRE) {
+    unsigned* cnt = reinterpret_cast<unsigned*>(red + (size_t)(kStatSlots + 1) * 2 * C);
+    if (last_workgroup(cnt)) clear_slots(red, C, cnt);
+  }
 }
 
-static unsigned bn_grid(long M, int C) {
+// Apply kernels: every workgroup re-reads the 32 x 2 x C slot partials (256 C bytes, L2-resident), so the grid is also bounded by
+// the tensor size: at most one workgroup per 128 rows (and at least 256 so that the GPU stays busy on small layers).
+static unsigned bn_grid(long M, int C, bool fused) {
   const int C4 = C / 4;
   const int RL = C4 <= 256 ? 256 / C4 : 1;
   long blocks = (M + RL - 1) / RL;
-  if (blocks > 2048) blocks = 2048;
+  long cap = fused ? M / 128 : 2048;
+  if (cap < 256) cap = 256;
+  if (cap > 2048) cap = 2048;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
 }
@@ -326,10 +430,15 @@ hipError_t launch_bn_act_fwd(const float* x, float* stats, const float* gamma, c
                              int act, long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,
                              float* running_mean, float* running_var, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, M, C, eps, momentum, save_mean,
-                     save_invstd, running_mean, running_var);
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, act,
-                     M, C, y);
+  if (C <= kFuseMaxC) {
+    hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(bn_grid(M, C, true)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
+                       momentum, y, save_mean, save_invstd, running_mean, running_var);
+  } else {
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, M, C, eps, momentum, save_mean,
+                       save_invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(bn_grid(M, C, false)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
+                       momentum, y, save_mean, save_invstd, running_mean, running_var);
+  }
   return hipGetLastError();
 }
 
@@ -337,13 +446,17 @@ hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, co
                              const float* gamma, const float* beta, int act, long M, int C, float* red, float* dx, float* dres,
                              float* dgamma_acc, float* dbeta_acc, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
-  // red: kStatSlots slot partials (zero on entry, zero again on return) followed by the [2][C] totals
-  float* tot = red + (size_t)kStatSlots * 2 * C;
+  // red: kStatSlots slot partials + arrival counters (all zero on entry, all zero again on return)
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(bn_reduce_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta, act,
                      M, C, red);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, red, C, tot, dgamma_acc, dbeta_acc);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta, tot, act,
-                     M, C, dx, dres);
+  if (C <= kFuseMaxC) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_grid(M, C, true)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
+                       red, act, M, C, dx, dres, dgamma_acc, dbeta_acc);
+  } else {
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, red, C, dgamma_acc, dbeta_acc);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_grid(M, C, false)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
+                       red, act, M, C, dx, dres, dgamma_acc, dbeta_acc);
+  }
   return hipGetLastError();
 }
 

@@ -341,7 +341,7 @@ int hifihr_ssim_bwd(const float* window11, const float* img1, const float* img2,
   return HIFIHR_OK;
 }
 
-int hifihr_bn_stats_floats(int C) { return C > 0 ? (hifihr::kStatSlots + 1) * 2 * C : 0; }
+int hifihr_bn_stats_floats(int C) { return C > 0 ? (hifihr::kStatSlots + 1) * 2 * C + 64 : 0; }   // slots, spare [2][C], 64 counter words
 
 static int bn_dims_ok(long M, int C) { return M > 0 && C >= 4 && C % 4 == 0 && C <= 4096; }
 

@@ -200,9 +200,11 @@ int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, fl
  * EfficientNet, network/efficientnet_pt/utils.py:36-52; no residual with swish).  stats_d / red_scratch_d hold hifihr_bn_stats_floats(C) floats: partial (sum, sum of
  * squares) over the M rows, spread over several slots to keep float-atomic contention low (from
  * hifihr_conv2d_fwd_bnstats, or hifihr_bn_stats for any other producer).
- * SELF-CLEANING: producers (hifihr_conv2d_fwd_bnstats, hifihr_bn_stats, the reduction inside hifihr_bn_act_bwd) ADD into
- * stats_d / red_scratch_d, which must be all zero on entry; hifihr_bn_act_fwd / hifihr_bn_act_bwd fold the slots and
- * write the zeros back, so one zero-initialised buffer serves every step without a memset launch.
+ * SELF-CLEANING: producers (hifihr_conv2d_fwd_bnstats, hifihr_dwconv2d_fwd, hifihr_wino_output_transform, hifihr_bn_stats,
+ * the reduction inside hifihr_bn_act_bwd) ADD into stats_d / red_scratch_d, which must be all zero on entry;
+ * hifihr_bn_act_fwd / hifihr_bn_act_bwd fold the slots inside their apply kernel (no separate finalize launch) and the
+ * last workgroup of that kernel to finish -- elected through arrival counters stored behind the slots -- writes the zeros
+ * back, so one zero-initialised buffer serves every step without a memset launch.
  *   fwd: y = act( (x - mean) * invstd * gamma + beta + residual? ); writes save_mean/save_invstd[C] and updates
  *        running_mean/var (momentum, unbiased variance) when given.
  *   bwd: g = dy * act'(z) (ReLU: y > 0, needs y_d; swish: z recomputed from x, needs beta_d); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (may be NULL) = g;

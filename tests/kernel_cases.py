@@ -17,6 +17,11 @@ HOSTSIM_DIR = os.path.join(REPO, "tests", "hostsim")
 HOSTSIM_LIB = os.path.join(HOSTSIM_DIR, "libhifihr_hostsim.so")
 
 
+def bn_slots(stats, C, slots=32):
+    """[slots][2][C] partial (sum, sum of squares) view of a batch-norm slot buffer (include/hifihr.h: hifihr_bn_stats_floats)."""
+    return stats[:slots * 2 * C].view(slots, 2, C)
+
+
 def build_hostsim() -> HifihrLib:
     subprocess.run(["make", "-s", "-C", HOSTSIM_DIR, "-j8"], check=True)
     return HifihrLib(HOSTSIM_LIB)
@@ -305,12 +310,12 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
     dx_in = nhwc(x)
     stats = torch.zeros(lib.bn_stats_floats(C), device=device)      # zero on entry (self-cleaning contract)
     lib.bn_stats(dx_in, M, C, stats)
-    np.testing.assert_allclose(stats.view(-1, 2, C)[:-1].sum(0)[0].cpu().numpy(), x.permute(1, 0, 2, 3).reshape(C, -1).sum(1).numpy(),
+    np.testing.assert_allclose(bn_slots(stats, C).sum(0)[0].cpu().numpy(), x.permute(1, 0, 2, 3).reshape(C, -1).sum(1).numpy(),
                                rtol=1e-4, atol=1e-3)
     y = torch.empty(N, H, W, C, device=device); sm = torch.empty(C, device=device); si = torch.empty(C, device=device)
     rmd, rvd = rm0.clone().to(device), rv0.clone().to(device)
     lib.bn_act_fwd(dx_in, stats, gamma.to(device), beta.to(device), nhwc(res) if residual else None, act, M, C, 1e-5, 0.1, y, sm, si, rmd, rvd)
-    assert float(stats.view(-1, 2, C)[:-1].abs().max()) == 0.0, "bn_act_fwd must leave the slot buffer zeroed"
+    assert float(bn_slots(stats, C).abs().max()) == 0.0 and float(stats[-64:].abs().max()) == 0.0, "bn_act_fwd must leave the slots and arrival counters zeroed"
     ref = out.detach().permute(0, 2, 3, 1)
     assert float((y.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), "bn fwd"
     np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
@@ -318,7 +323,7 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
     red = torch.zeros(lib.bn_stats_floats(C), device=device); dxo = torch.empty_like(y); dres = torch.empty_like(y) if residual else None
     dg = torch.full((C,), 0.5, device=device); db = torch.full((C,), -0.25, device=device)     # accumulate semantics
     lib.bn_act_bwd(nhwc(gy), y if act == 1 else None, dx_in, sm, si, gamma.to(device), beta.to(device), act, M, C, red, dxo, dres, dg, db)
-    assert float(red.view(-1, 2, C)[:-1].abs().max()) == 0.0, "bn_act_bwd must leave the slot buffer zeroed"
+    assert float(bn_slots(red, C).abs().max()) == 0.0 and float(red[-64:].abs().max()) == 0.0, "bn_act_bwd must leave the slots and arrival counters zeroed"
     refdx = xr.grad.permute(0, 2, 3, 1)
     assert float((dxo.cpu() - refdx).abs().max()) <= 2e-4 * float(refdx.abs().max()) + 1e-7, "bn bwd dx"
     assert float((dg.cpu() - 0.5 - gr.grad).abs().max()) <= 2e-4 * float(gr.grad.abs().max()) + 1e-5, "bn dgamma"
@@ -343,7 +348,7 @@ def conv_bnstats_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0, use_ws
     ref = y.permute(0, 2, 3, 1)
     assert float((out.cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6
     s_ref = y.permute(1, 0, 2, 3).reshape(K, -1)
-    st = stats.view(-1, 2, K)[:-1].sum(0)
+    st = bn_slots(stats, K).sum(0)
     np.testing.assert_allclose(st[0].cpu().numpy(), s_ref.sum(1).numpy(), rtol=1e-4, atol=2e-3)
     np.testing.assert_allclose(st[1].cpu().numpy(), (s_ref ** 2).sum(1).numpy(), rtol=1e-4, atol=2e-3)
 
@@ -369,7 +374,7 @@ def dwconv_case(lib, device, N, H, W, C, K, stride, seed=0):
     lib.dwconv2d_fwd(xd, wd, out, N, H, W, C, OH, OW, K, stride, pt, pl, stats=stats)
     ref = y.detach().permute(0, 2, 3, 1)
     assert float((out.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, "dw fwd"
-    st = stats.view(-1, 2, C)[:-1].sum(0).cpu()
+    st = bn_slots(stats, C).sum(0).cpu()
     flat = ref.reshape(-1, C)
     np.testing.assert_allclose(st[0].numpy(), flat.sum(0).numpy(), rtol=1e-4, atol=2e-3, err_msg="dw fwd: batch-norm sum")
     np.testing.assert_allclose(st[1].numpy(), (flat ** 2).sum(0).numpy(), rtol=1e-4, atol=2e-3, err_msg="dw fwd: batch-norm sum of squares")
@@ -676,7 +681,7 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
     err = float((out.cpu() - ref).abs().max())
     assert err <= 3e-5 * float(ref.abs().max()) + 1e-6, f"winograd fwd: {err} vs {float(ref.abs().max())}"
     if with_stats:
-        st = stats.view(-1, 2, K)[:-1].sum(0).cpu(); flat = ref.reshape(-1, K)
+        st = bn_slots(stats, K).sum(0).cpu(); flat = ref.reshape(-1, K)
         np.testing.assert_allclose(st[0].numpy(), flat.sum(0).numpy(), rtol=1e-4, atol=2e-3)
         np.testing.assert_allclose(st[1].numpy(), (flat ** 2).sum(0).numpy(), rtol=1e-4, atol=2e-3)
     # backward-data: the same pipeline on dy with the transposed, rotated filter
