@@ -3,8 +3,8 @@
 
 On the GPU the step's terms run as fused HIP kernels: SSIM (csrc/ssim.hip), the photometric block and the joint /
 vertex / edge-length / shape / pose terms (csrc/losses.hip: two launches per group instead of ~250 ATen launches).
-`fused=False` (and any CPU tensor) takes the plain torch-op restatement below, which the CPU oracle step uses and the
-tests pin the kernels against.  Terms no config of BASELINE.json uses (joint_2d, bone_direc, mscale, scale, iou, mtex)
+`fused=False` takes the plain torch-op restatement below, which the CPU oracle step uses and the tests pin the kernels
+against (with `fused=True` a CPU tensor raises: there is no silent fallback).  Terms no config of BASELINE.json uses (joint_2d, bone_direc, mscale, scale, iou, mtex)
 are torch ops on either path.
 """
 from __future__ import annotations
@@ -111,7 +111,7 @@ class LossFunction:
     def __call__(self, examples, outputs, loss_used, dat_name, args) -> dict:
         loss_dic = {}
         base = F.l1_loss if args.base_loss_fn == "L1" else F.mse_loss
-        fused = self.fused and outputs["joints"].is_cuda
+        fused = self.fused                      # the fused kernels run on GPU tensors only; a CPU tensor raises (no silent fallback)
         if fused and any(k in loss_used for k in ("joint_3d", "vert_3d", "edge_length", "mshape", "mpose")):
             self._fused_geometry(examples, outputs, loss_used, args, loss_dic)
             loss_used = [k for k in loss_used if k not in loss_dic]

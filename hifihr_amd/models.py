@@ -51,7 +51,8 @@ class Model(nn.Module):
         self.ncomps = [10, 48, None]
         self.hand_layer = MyMANOLayer(ifRender, device, shape_ncomp=10, pose_ncomp=48, tables=mano_tables)
         self.hand_encoder = HandEncoder(hand_model=hand_model, ncomps=self.ncomps, in_dim=self.features_dim,
-                                        ifRender=ifRender, use_mean_shape=use_mean_shape)
+                                        ifRender=ifRender, use_mean_shape=use_mean_shape,
+                                        impl="hip" if conv_impl == "mfma" else "torch")
         self.register_buffer("mano_face", self.hand_layer.mesh_face.clone().to(torch.int16), persistent=False)
         self.ifRender, self.ifLight, self.aa_factor, self.image_size = ifRender, ifLight, aa_factor, image_size
         if ifRender:

@@ -150,13 +150,16 @@ class Resnet_4C(nn.Module):
 
 
 class MMPool(nn.Module):
-    def __init__(self, shape=(1, 1), dim=1, p=0.0, eps=1e-6):
+    """impl="hip": the fused kernel (GPU tensors only: a CPU tensor raises); impl="torch": the reference's torch ops."""
+
+    def __init__(self, shape=(1, 1), dim=1, p=0.0, eps=1e-6, impl="torch"):
         super().__init__()
         self.p = nn.Parameter(torch.ones(dim) * p, requires_grad=True)
         self.shape = shape
+        self.impl = impl
 
     def forward(self, x):
-        if x.is_cuda and tuple(self.shape) == (1, 1) and x.shape[1] % 4 == 0:
+        if self.impl == "hip" and tuple(self.shape) == (1, 1) and x.shape[1] % 4 == 0:
             from . import ops
             return ops.mmpool(x, self.p).reshape(x.shape[0], x.shape[1], 1, 1)       # one HIP kernel per direction
         x_max = F.adaptive_max_pool2d(x, self.shape)
@@ -178,7 +181,7 @@ class ResEncoder(nn.Module):
 
     def __init__(self, pretrain="res18", if_4c=False, conv_impl="aten"):
         super().__init__()
-        self.mmpool = MMPool((1, 1))
+        self.mmpool = MMPool((1, 1), impl="hip" if conv_impl == "mfma" else "torch")
         self.conv_impl = conv_impl
         self.encoder1 = Resnet_4C(pretrain, if_4c=if_4c, conv_impl=conv_impl)
         if if_4c:
@@ -207,8 +210,11 @@ def _mlp(dims, relu_after_first=True):
 
 
 class HandEncoder(nn.Module):
-    def __init__(self, hand_model, ncomps, in_dim=1024, use_mean_shape=False, ifRender=True):
+    def __init__(self, hand_model, ncomps, in_dim=1024, use_mean_shape=False, ifRender=True, impl="torch"):
+        """impl="hip": every Linear (+ BatchNorm1d + ReLU) is one fused HIP launch (GPU tensors only: a CPU tensor raises);
+        impl="torch": the plain torch modules (what the CPU oracle step runs)."""
         super().__init__()
+        self.impl = impl
         self.use_mean_shape, self.ifRender, self.hand_model = use_mean_shape, ifRender, hand_model
         self.shape_ncomp, self.pose_ncomp, self.tex_ncomp = ncomps
         self.base_layers = nn.Sequential(nn.Linear(in_dim, 1024), nn.BatchNorm1d(1024), nn.ReLU(inplace=True),
@@ -237,7 +243,7 @@ class HandEncoder(nn.Module):
 
     def forward(self, features):
         bs, device = features.shape[0], features.device
-        if features.is_cuda:
+        if self.impl == "hip":
             from . import ops
             bl = self.base_layers
             base = ops.linear(ops.linear(features, bl[0], act=True, bn=bl[1]), bl[3], act=True, bn=bl[4])
@@ -290,7 +296,7 @@ class LightEstimator(nn.Module):
         else:
             base = self.base_layers(low_features)
         flat = base.reshape(base.shape[0], -1)
-        if flat.is_cuda:
+        if self.conv_impl == "mfma":
             from . import ops
             lights = ops.linear(ops.linear(flat, self.light_reg[0], act=True), self.light_reg[2])
         else:

@@ -69,7 +69,7 @@ def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None, fe
     ex["joints"] = examples_cpu["joints"] - root_xyz
     ex["verts"] = examples_cpu["verts"] - root_xyz
     outputs["j2d"] = trans_proj_j2d(outputs, examples_cpu["Ks"], root_xyz=root_xyz)
-    loss_dic = LossFunction(ssim_fn=ssim_torch)(ex, outputs, args.losses, "FreiHand", args)
+    loss_dic = LossFunction(ssim_fn=ssim_torch, fused=False)(ex, outputs, args.losses, "FreiHand", args)
     loss = sum(loss_dic[k] for k in args.losses)
     if optimizer is not None:
         optimizer.zero_grad()

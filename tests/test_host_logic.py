@@ -78,6 +78,21 @@ def test_product_ops_refuse_cpu_tensors():
     from hifihr_amd._lib import HifihrError, require_cuda
     with pytest.raises(HifihrError):
         require_cuda(torch.zeros(3))
+    # the host-side mirror of the reference modules dispatches by construction (impl / conv_impl / fused), never by device:
+    # the HIP flavours refuse CPU tensors as well
+    from hifihr_amd import options
+    from hifihr_amd.losses import LossFunction
+    from hifihr_amd.network import HandEncoder, MMPool
+    with pytest.raises(HifihrError):
+        HandEncoder("mano", [10, 48, None], in_dim=512, impl="hip").train()(torch.zeros(4, 512))
+    with pytest.raises(HifihrError):
+        MMPool((1, 1), impl="hip")(torch.zeros(2, 8, 3, 3))
+    args = options.baseline_config2_args(train_batch=2)
+    outs = {"joints": torch.zeros(2, 21, 3), "mano_verts": torch.zeros(2, 778, 3), "shape_params": torch.zeros(2, 10),
+            "pose_params": torch.zeros(2, 48), "mano_faces": torch.zeros(2, 4, 3, dtype=torch.int16)}
+    ex = {"joints": torch.zeros(2, 21, 3), "verts": torch.zeros(2, 778, 3)}
+    with pytest.raises(HifihrError):
+        LossFunction(fused=True)(ex, outs, ["joint_3d", "vert_3d", "mshape", "mpose"], "FreiHand", args)
 
 
 def test_efficientnet_b3_mirror_vs_reference(golden_dir):
