@@ -6,9 +6,9 @@
   LightEstimator                  reference network/res_encoder.py:169-209
   normalize_batch_3C              reference network/res_encoder.py:212-216
 
-Round-1 status: these layers are expressed with torch.nn (ATen dispatches the convolutions to MIOpen on
-ROCm).  They are the declared interim for SURVEY.md section 8 rows A2/A5/A6 until the MFMA implicit-GEMM
-kernels land; MANO LBS, the renderer and the fused losses already run as hand-written HIP (hifihr_amd/ops.py).
+Every module takes its flavour by construction (conv_impl="mfma" / impl="hip": the hand-written kernels of
+hifihr_amd/csrc through hifihr_amd/ops.py, GPU tensors only; "aten" / "torch": torch.nn, used by the CPU oracle step and
+in comparisons) -- never by looking at the device of its input.
 The reference's res18 dimensions are broken; this build uses feat 512 / low 128.
 """
 from __future__ import annotations
@@ -37,23 +37,23 @@ class Conv2dMFMA(nn.Module):
     GEMM kernels (hifihr_amd/csrc/conv.hip).  The weight keeps torch's logical [K,C,R,S] shape (state-dict
     compatible with the reference) in channels_last memory format = the kernel's physical [K][R][S][C]."""
 
-    def __init__(self, cin, cout, k, stride=1, pad=0, bias=False):
+    def __init__(self, cin, cout, k, stride=1, pad=0, bias=False, relu=True):
         super().__init__()
-        self.stride, self.pad = stride, pad
+        self.stride, self.pad, self.relu = stride, pad, relu
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last))
         init.kaiming_uniform_(self.weight, a=5 ** 0.5)                 # nn.Conv2d's default initialisation
         self.bias = None
-        if bias:                                                       # LightEstimator convolutions (always followed by ReLU)
+        if bias:                                       # LightEstimator / VGG convolutions: bias (+ ReLU unless relu=False) epilogue
             bound = 1.0 / (cin * k * k) ** 0.5
             self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
 
     def forward(self, x, want_stats=False):
         from . import ops
         w = self.weight
-        if self.bias is not None:
-            return ops.conv2d_bias_relu(x, w, self.bias, self.stride, self.pad)      # conv + bias + ReLU, one launch
         if w.shape[1] % 4 != 0:                       # the 3-channel stem: input arrives as NHWC4, pad the weight
             w = F.pad(w, (0, 0, 0, 0, 0, 4 - w.shape[1] % 4)).contiguous(memory_format=torch.channels_last)
+        if self.bias is not None:
+            return ops.conv2d_bias_act(x, w, self.bias, self.stride, self.pad, self.relu)   # conv + bias (+ ReLU), one launch
         return ops.conv2d(x, w, self.stride, self.pad, want_stats)
 
 

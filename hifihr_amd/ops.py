@@ -364,12 +364,13 @@ class _Conv2dMFMA(torch.autograd.Function):
             # conv + bias (+ ReLU) epilogue: masked gradient and the bias gradient in one small launch
             b = ctx.b_param
             db_t, db_ret = _acc_target(b, b.shape, gy.device) if (b is not None and ctx.needs_input_grad[5]) else (None, None)
-            if not ctx.relu:
-                raise NotImplementedError("conv bias without ReLU")           # no layer of the reference needs it
-            g = torch.empty_like(gy, memory_format=_CL)
-            M = gy.numel() // K
-            PROFILE.bracket("bias_relu_bwd", lambda: lib.bias_relu_bwd(gy, y, M, K, g, db_t))
-            gy = g
+            if ctx.relu:
+                g = torch.empty_like(gy, memory_format=_CL)
+                M = gy.numel() // K
+                PROFILE.bracket("bias_relu_bwd", lambda: lib.bias_relu_bwd(gy, y, M, K, g, db_t))
+                gy = g
+            elif db_t is not None:
+                raise NotImplementedError("gradient of a conv bias without ReLU")   # only the frozen VGG19 has such a layer
             if b is not None and db_t is not None and db_ret is None:
                 _grad_ready(b)
         if ctx.needs_input_grad[0] and not ctx.relu and ctx.b_param is None and _wino_ok(C, K, R, S, stride, pad):
@@ -417,9 +418,14 @@ class _Conv2dMFMA(torch.autograd.Function):
         return dx, dw, None, None, None, db_ret, None
 
 
+def conv2d_bias_act(x, w, bias, stride=1, pad=0, relu=True):
+    """F.conv2d(x, w, bias, stride, pad) followed by ReLU if `relu`, in one launch (LightEstimator, reference
+    network/res_encoder.py:150-210; VGG19 features of the perceptual loss, utils/perceptual_loss.py:27-36)."""
+    return _Conv2dMFMA.apply(x, w, stride, pad, False, bias, relu)
+
+
 def conv2d_bias_relu(x, w, bias, stride=1, pad=0):
-    """relu(F.conv2d(x, w, bias, stride, pad)) in one launch (LightEstimator, reference network/res_encoder.py:150-210)."""
-    return _Conv2dMFMA.apply(x, w, stride, pad, False, bias, True)
+    return conv2d_bias_act(x, w, bias, stride, pad, True)
 
 
 def conv2d(x, w, stride=1, pad=0, want_stats=False):
