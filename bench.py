@@ -29,6 +29,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--encoder", default="res18", choices=["res18", "effb3"], help="res18 = BASELINE configs[1] (headline)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3],
+                    help="2 = BASELINE configs[1] (headline); 3 = configs[2] full_rhd_freihand.json: effb3, batch 48, texture + "
+                         "perceptual losses, MANO + texture stand-in for the unavailable NIMBLE layer (not a headline line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=-1, help="0: eager; -1 or 1: hipGraph replay (N = 1: whole step; N > 1: forward + backward, then all-reduce + Adam); 2: force the N > 1 form")
     ap.add_argument("--cpu-batch", type=int, default=8, help="sample size of the CPU baseline (images)")
@@ -71,10 +74,16 @@ def main():
     # (capture_end crashed / replays produced NaN in round 1: DESIGN.md section 6).
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
-    args_ns = options.baseline_config2_args(train_batch=a.batch)
+    if a.config == 3:
+        a.encoder, a.no_cpu_baseline = "effb3", True
+        if a.batch == 32:
+            a.batch = 48
+        args_ns = options.baseline_config3_args(train_batch=a.batch)
+    else:
+        args_ns = options.baseline_config2_args(train_batch=a.batch)
     tables = synthetic_mano_tables(0)
     torch.manual_seed(0)
-    model = Model(ifRender=True, device=dev, if_4c=False, hand_model="mano", use_mean_shape=False, pretrain=a.encoder,
+    model = Model(ifRender=True, device=dev, if_4c=False, hand_model="mano", use_mean_shape=False, pretrain=a.encoder, texture_stand_in=10 if a.config == 3 else 0,
                   mano_tables=tables).to(dev).train()
     flat = FlatParams(model)
     hdist.broadcast_params(flat)
@@ -222,7 +231,9 @@ def main():
             "data": "synthetic (FreiHAND-shaped, seeded; synthetic MANO-shaped tables; random-init weights)",
             "config": {"workload": "BASELINE configs[1]: FreiHAND batch=32/GPU, ResNet-18 encoder + MANO LBS + "
                                    "silhouette/texture render losses, 224x224, aa=3 (672^2 samples)"
-                                   + ("" if a.encoder == "res18" else f" [encoder swapped to {a.encoder}: NOT the headline config]"),
+                                   + ("" if a.encoder == "res18" else f" [encoder swapped to {a.encoder}: NOT the headline config]")
+                                   + ("" if a.config == 2 else " [BASELINE configs[2] composition: full_rhd_freihand.json losses incl. VGG19 "
+                                      "perceptual (seeded random weights), MANO + vertex-colour texture stand-in for NIMBLE]"),
                        "per_gpu_batch": B, "global_batch": world * B, "losses": args_ns.losses, "parallelism": f"dp{world}"},
             "loss": float(loss.detach()), "launch_mode": graph_note,
         }

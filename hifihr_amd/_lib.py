@@ -115,6 +115,7 @@ class HifihrLib:
         c.hifihr_wino_input_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
         c.hifihr_wino_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_wino_output_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
+        c.hifihr_wino_output_transform_act.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_dy_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
         c.hifihr_wino_wgrad_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_dw_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
@@ -285,7 +286,12 @@ class HifihrLib:
     def wino_gemm(self, V, U, M, N, H, W, C, K, ws=None):
         self.check(self.c.hifihr_wino_gemm(_fp(V), _fp(U), _fp(M), N, H, W, C, K, *self._ws(ws), _stream_of(V)), "hifihr_wino_gemm")
 
-    def wino_output_transform(self, M, y, stats, N, H, W, K):
+    def wino_output_transform(self, M, y, stats, N, H, W, K, bias=None, act=0):
+        if bias is not None or act:
+            assert stats is None
+            self.check(self.c.hifihr_wino_output_transform_act(_fp(M), _fp(y), _fp(bias), act, N, H, W, K, _stream_of(M)),
+                       "hifihr_wino_output_transform_act")
+            return
         self.check(self.c.hifihr_wino_output_transform(_fp(M), _fp(y), _fp(stats), N, H, W, K, _stream_of(M)), "hifihr_wino_output_transform")
 
     def wino_dy_transform(self, dy, Y, N, H, W, K):

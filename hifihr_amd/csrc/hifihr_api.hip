@@ -611,7 +611,14 @@ int hifihr_wino_dw_transform(float* dU, float* dw_acc, int K, int C, int clear_d
 
 int hifihr_wino_output_transform(const float* M, float* y, float* stats, int N, int H, int W, int K, void* stream) {
   if (!M || !y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform: bad argument");
-  HIP_TRY(hifihr::launch_wino_output_transform(M, y, stats, N, H, W, K, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_wino_output_transform(M, y, stats, nullptr, 0, N, H, W, K, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_output_transform_act(const float* M, float* y, const float* bias, int act, int N, int H, int W, int K, void* stream) {
+  if (!M || !y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0 || act < 0 || act > 1)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform_act: bad argument");
+  HIP_TRY(hifihr::launch_wino_output_transform(M, y, nullptr, bias, act, N, H, W, K, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

@@ -149,7 +149,8 @@ hipError_t launch_se_scale(const float* x, const float* gate, const float* add, 
 // Winograd F(2x2, 3x3) glue (wino.hip)
 hipError_t launch_wino_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st);
 hipError_t launch_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, hipStream_t st);
-hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats, int N, int H, int W, int K, hipStream_t st);
+hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
+                                        hipStream_t st);
 hipError_t launch_wino_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st);
 hipError_t launch_wino_dw_transform(float* dU, float* dw, int K, int C, int clear, hipStream_t st);
 

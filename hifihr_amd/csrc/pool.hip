@@ -257,7 +257,10 @@ hipError_t launch_bias_relu_bwd(const float* dy, const float* y, long M, int C, 
   if (C % 4 != 0 || C > 256) return hipErrorInvalidValue;
   const int RL = 256 / (C / 4);
   long blocks = (M + RL - 1) / RL;
-  if (blocks > 64) blocks = 64;                      // few workgroups: the per-channel atomics stay uncontended
+  // with a bias gradient: few workgroups so the per-channel atomics stay uncontended (LightEstimator, tiny tensors);
+  // without one (frozen VGG19 of the perceptual loss, hundreds of MB per layer): a plain streaming pass over the whole chip
+  const long cap = db_acc != nullptr ? 64 : 8192;
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, M, C, g, db_acc);
   return hipGetLastError();
 }

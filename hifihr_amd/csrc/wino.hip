@@ -6,7 +6,8 @@
 //                                                        [C][3][3][K] transposed weights)
 //   wino_input_transform    V[16][T][C]  = B^T d B     d = 4x4 input patch of tile t (zero outside the image), T = N*ceil(H/2)*ceil(W/2)
 //   wino_output_transform   y[N][H][W][K] = A^T m A    m = M[.][t][.]; optionally adds the batch-norm sum / sum of squares of y
-//                                                        to the slot buffer (bn.hip), like the direct kernel's epilogue does
+//                                                        to the slot buffer (bn.hip), like the direct kernel's epilogue does,
+//                                                        or applies bias (+ ReLU) like the direct kernel's act epilogue (VGG19)
 //   wino_dy_transform       Y'[16][T][K] = A dy A^T    backward-weight: dU[pos][k][c] = sum_t Y'[pos][t][k] V[pos][t][c] (16 batched
 //   wino_dw_transform       dw[K][3][3][C] += G^T dU G  reductions on conv_wgrad_kernel), then back to the 3x3 filter
 // Replaces (together with the batched GEMM) the same cuDNN/MIOpen dispatches as conv.hip (reference network/res_encoder.py:364-373).
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* 
 
 // workgroup = 16 tile lanes x 16 float4 channel lanes (64 channels, blockIdx.y); M[16][T][K] -> y[N][H][W][K] (+ stats)
 __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float* __restrict__ Mm, float* __restrict__ y, float* __restrict__ stats,
-                                                                   int N, int H, int W, int K, int TH, int TW) {
+                                                                   const float* __restrict__ bias, int relu, int N, int H, int W, int K,
+                                                                   int TH, int TW) {
   __shared__ float4 red[2][16][16];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int k = blockIdx.y * 64 + cl * 4;
@@ -111,6 +113,8 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
   const size_t T = (size_t)N * TH * TW;
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   if (kok) {
+    const float4 bv = bias != nullptr ? *reinterpret_cast<const float4*>(bias + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float lo = relu ? 0.f : -3.402823466e38f;
     for (size_t t = (size_t)blockIdx.x * 16 + tl; t < T; t += (size_t)gridDim.x * 16) {
       const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
       float4 m[4][4];
@@ -128,7 +132,9 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int oh = 2 * th + a;
-        const float4 o0 = add4(add4(s[a][0], s[a][1]), s[a][2]), o1 = sub4(sub4(s[a][1], s[a][2]), s[a][3]);
+        float4 o0 = add4(add4(add4(s[a][0], s[a][1]), s[a][2]), bv), o1 = add4(sub4(sub4(s[a][1], s[a][2]), s[a][3]), bv);
+        o0 = make_float4(fmaxf(o0.x, lo), fmaxf(o0.y, lo), fmaxf(o0.z, lo), fmaxf(o0.w, lo));
+        o1 = make_float4(fmaxf(o1.x, lo), fmaxf(o1.y, lo), fmaxf(o1.z, lo), fmaxf(o1.w, lo));
         if (oh < H) {
           float* p = y + (((size_t)n * H + oh) * W + 2 * tw) * K + k;
           *reinterpret_cast<float4*>(p) = o0;
@@ -251,14 +257,15 @@ hipError_t launch_wino_input_transform(const float* x, float* V, int N, int H, i
   return hipGetLastError();
 }
 
-hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats, int N, int H, int W, int K, hipStream_t st) {
+hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
+                                        hipStream_t st) {
   if (K % 4 != 0) return hipErrorInvalidValue;
   const int TH = (H + 1) / 2, TW = (W + 1) / 2;
   const size_t T = (size_t)N * TH * TW;
   size_t bx = (T + 15) / 16;
   const size_t cap = stats != nullptr ? 256 : 2048;       // with statistics: bound (workgroups x channels) atomics (bn.hip)
   if (bx > cap) bx = cap;
-  hipLaunchKernelGGL(wino_output_transform_kernel, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, N, H, W, K, TH, TW);
+  hipLaunchKernelGGL(wino_output_transform_kernel, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, bias, relu, N, H, W, K, TH, TW);
   return hipGetLastError();
 }
 

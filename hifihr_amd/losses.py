@@ -19,10 +19,14 @@ _BONES = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 5), (5, 6), (6, 7), (7, 8), (0, 9)
           (0, 13), (13, 14), (14, 15), (15, 16), (0, 17), (17, 18), (18, 19), (19, 20)]
 
 
+_BONE_IDX = {}
+
+
 def bone_direction_loss(j, j_gt, conf=None):
     """utils/losses_util.py:217-283 with confidence 1 (as both call sites in losses.py:269-282 pass)."""
-    p = torch.tensor([b[0] for b in _BONES], device=j.device)
-    c = torch.tensor([b[1] for b in _BONES], device=j.device)
+    if j.device not in _BONE_IDX:            # built once per device: a hipGraph capture of the step must not copy from the host
+        _BONE_IDX[j.device] = (torch.tensor([b[0] for b in _BONES], device=j.device), torch.tensor([b[1] for b in _BONES], device=j.device))
+    p, c = _BONE_IDX[j.device]
     v = j[:, c] - j[:, p]
     vg = j_gt[:, c] - j_gt[:, p]
     vn = v / (torch.sqrt((v ** 2).sum(-1, keepdim=True)) + 1e-4)
@@ -82,7 +86,9 @@ ssim = ssim_torch      # backwards-compatible name used by tests
 
 class LossFunction:
     def __init__(self, perceptual=None, ssim_fn=None, fused=True):
-        self.perceptual_loss = perceptual            # VGG19 weights are not available offline
+        # PerceptualLoss instance; None = built on first use (hifihr_amd/perceptual.py: seeded torchvision-style
+        # initialisation unless the caller loads VGG19 weights -- they cannot be downloaded offline)
+        self.perceptual_loss = perceptual
         self.ssim_loss_fn = None
         if ssim_fn is None:
             from . import ops
@@ -102,7 +108,10 @@ class LossFunction:
             faces = outputs.get("_faces_i32")
             if faces is None:
                 faces = outputs["mano_faces"][0].int().contiguous()
-        vals = ops.geom_losses(outputs["joints"], examples["joints"], outputs["mano_verts"], examples["verts"],
+        # a term that is not requested has weight 0: any tensor of the right shape serves as its (absent) ground truth
+        joints_gt = examples["joints"] if "joints" in examples else outputs["joints"].detach()
+        verts_gt = examples["verts"] if "verts" in examples else outputs["mano_verts"].detach()
+        vals = ops.geom_losses(outputs["joints"], joints_gt, outputs["mano_verts"], verts_gt,
                                outputs["shape_params"], outputs["pose_params"], faces, args.base_loss_fn != "L1", lam).unbind(0)
         for k, v in zip(ops.GEOM_TERMS, vals):
             if k in loss_used:
@@ -157,7 +166,8 @@ class LossFunction:
             loss_dic["ssim_tex"] = args.lambda_ssim_tex * (1 - self.ssim_fn(re_img, mask_rgbs))
         if "perceptual" in loss_used:
             if self.perceptual_loss is None:
-                raise NotImplementedError("perceptual loss needs VGG19 weights, which are not available offline")
+                from .perceptual import PerceptualLoss
+                self.perceptual_loss = PerceptualLoss(impl="hip" if fused else "torch").to(outputs["re_img"].device)
             seg = examples["segms_gt"].unsqueeze(1)
             loss_dic["perceptual"] = args.lambda_percep * self.perceptual_loss(
                 outputs["re_img"] * seg + examples["imgs"] * (1 - seg), examples["imgs"])

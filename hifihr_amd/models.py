@@ -4,7 +4,10 @@
 hand_model == 'mano' with render=True is a composition the reference cannot run (MyMANOLayer
 builds a Meshes without textures); this build defines it with a constant per-vertex skin colour as the
 TexturesVertex stand-in.  hand_model == 'nimble' needs the un-vendored NIMBLE submodule + assets and is
-not built ("parity unpinned").
+not built ("parity unpinned").  The NIMBLE configurations (full_rhd_freihand.json,
+weak_rhd_ho3d.json) run here as "MANO + a texture stand-in" (SURVEY.md section 8(c)): `texture_stand_in=T` adds the
+T-component texture head of the NIMBLE HandEncoder and turns it into per-vertex colours through a fixed seeded linear
+basis (skin tone + basis . texture_params), so `texture_params`, the `mtex` term and the texture gradient exist.
 """
 from __future__ import annotations
 
@@ -16,6 +19,12 @@ from .mano_tables import ManoTables, synthetic_mano_tables
 from .network import HandEncoder, LightEstimator, ResEncoder
 
 SKIN_TONE = (0.78, 0.60, 0.50)
+
+
+def texture_stand_in_basis(ncomp: int) -> torch.Tensor:
+    """[ncomp, 778*3] fixed linear map texture_params -> per-vertex colour offsets of the NIMBLE texture stand-in."""
+    gen = torch.Generator().manual_seed(7)
+    return 0.05 * torch.randn(int(ncomp), 778 * 3, generator=gen)
 
 
 class MyMANOLayer(nn.Module):
@@ -34,7 +43,8 @@ class MyMANOLayer(nn.Module):
 
 class Model(nn.Module):
     def __init__(self, ifRender, device, if_4c, hand_model, use_mean_shape, pretrain, root_id=9, root_id_nimble=11,
-                 ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3, conv_impl="mfma"):
+                 ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3, conv_impl="mfma",
+                 texture_stand_in=0):
         super().__init__()
         if hand_model != "mano":
             raise NotImplementedError(f"hand_model='{hand_model}': only 'mano' is built (NIMBLE assets are not available)")
@@ -48,7 +58,7 @@ class Model(nn.Module):
             self.base_encoder = EffiEncoder(pretrain=pretrain, conv_impl=conv_impl)
         else:
             raise NotImplementedError(f"pretrain='{pretrain}' is not built yet")
-        self.ncomps = [10, 48, None]
+        self.ncomps = [10, 48, int(texture_stand_in) if texture_stand_in else None]
         self.hand_layer = MyMANOLayer(ifRender, device, shape_ncomp=10, pose_ncomp=48, tables=mano_tables)
         self.hand_encoder = HandEncoder(hand_model=hand_model, ncomps=self.ncomps, in_dim=self.features_dim,
                                         ifRender=ifRender, use_mean_shape=use_mean_shape,
@@ -61,6 +71,8 @@ class Model(nn.Module):
                                                    ambient=(0.5,) * 3, mat_diffuse=(0.8,) * 3, specular=(0.04,) * 3,
                                                    shininess=30.0, background=(1.0,) * 3)
             self.register_buffer("vertex_colors", torch.tensor(SKIN_TONE).repeat(778, 1), persistent=False)
+            if texture_stand_in:
+                self.register_buffer("texture_basis", texture_stand_in_basis(texture_stand_in), persistent=False)
         if ifLight:
             self.light_estimator = LightEstimator(self.low_feat_dim, conv_impl=conv_impl)
 
@@ -108,7 +120,10 @@ class Model(nn.Module):
                 raise NotImplementedError("PointLights default lighting (light_estimation=false) is not built")
             # skin_meshes.offset_verts_(-pred_root); .offset_verts_(+root_xyz)   (models_res_nimble.py:203-205)
             verts_cam = mano_verts + root_xyz
-            rgba, face_id = ops.render(self.renderer_p3d, verts_cam, self.vertex_colors, cam, colors, directions)
+            vcolors = self.vertex_colors
+            if self.ncomps[2]:                   # texture stand-in: per-sample vertex colours = skin tone + basis . texture_params
+                vcolors = torch.addmm(vcolors.reshape(1, -1), outputs["texture_params"], self.texture_basis).view(-1, 778, 3)
+            rgba, face_id = ops.render(self.renderer_p3d, verts_cam, vcolors, cam, colors, directions)
             outputs["re_img"] = rgba[:, :3]
             outputs["_rgba"] = rgba                                                      # for the fused photometric losses
             outputs["re_sil"], outputs["maskRGBs"] = ops.sil_post(rgba, images)          # :219-220, one launch

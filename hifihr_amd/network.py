@@ -222,7 +222,7 @@ class HandEncoder(nn.Module):
         self.base_layers.apply(weights_init)
         self.pose_reg = _mlp([512, 128, self.pose_ncomp])
         self.shape_reg = _mlp([512, 128, self.shape_ncomp])
-        if hand_model == "nimble":
+        if hand_model == "nimble" or self.tex_ncomp:       # nimble, or MANO with the vertex-colour texture stand-in (models.py)
             self.tex_reg = _mlp([512, 128, self.tex_ncomp])
         self.trans_reg = _mlp([512, 128, 32, 3])
         if hand_model == "mano":
@@ -255,7 +255,7 @@ class HandEncoder(nn.Module):
         scale = run(self.scale_reg, base)
         trans = run(self.trans_reg, base)
         rot = run(self.rot_reg, base) if self.hand_model == "mano" else None
-        if self.ifRender and self.hand_model == "nimble":
+        if self.ifRender and (self.hand_model == "nimble" or self.tex_ncomp):
             texture_params = run(self.tex_reg, base)
         elif self.hand_model == "nimble":
             texture_params = torch.zeros(bs, self.tex_ncomp, device=device)

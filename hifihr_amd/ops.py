@@ -280,7 +280,7 @@ def _wino_ok(C, K, R, S, stride, pad):
     return R == 3 and S == 3 and stride == 1 and pad == 1 and C >= 128 and K >= 128 and C % 32 == 0 and K % 32 == 0
 
 
-def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False):
+def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0):
     """y[N][H][W][K] = conv3x3(x[N][H][W][C], w[K][3][3][C]) through weight / input transform, 16 batched GEMMs, output
     transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter).
     keep_v: return the transformed input V[16][T][C] in a tensor of its own (the Winograd weight gradient consumes it)."""
@@ -305,7 +305,7 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False):
     lib.wino_weight_transform(w_krsc, U, K, C, flip)
     lib.wino_input_transform(x, V, N, H, W, C)
     lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)
-    lib.wino_output_transform(M, y, stats, N, H, W, K)
+    lib.wino_output_transform(M, y, stats, N, H, W, K, bias=bias, act=act)
     return V if keep_v else None
 
 
@@ -322,13 +322,14 @@ class _Conv2dMFMA(torch.autograd.Function):
         OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
         stats = None
-        wino = bias is None and not relu and _wino_ok(C, K, R, S, stride, pad)
+        wino = _wino_ok(C, K, R, S, stride, pad) and not (want_stats and (bias is not None or relu))
         v_saved = None
         if wino:
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device) if want_stats else None
             keep = bool(ctx.needs_input_grad[1])
             box = []
-            PROFILE.bracket("conv_fwd_wino", lambda: box.append(_wino_conv(lib, x, wk, y, stats, N, H, W, C, K, 0, keep_v=keep)))
+            PROFILE.bracket("conv_fwd_wino", lambda: box.append(_wino_conv(lib, x, wk, y, stats, N, H, W, C, K, 0, keep_v=keep,
+                                                                            bias=bias, act=1 if relu else 0)))
             v_saved = box[0]
         elif want_stats:       # per-channel sum / sum of squares of y from the conv epilogue, for the batch-norm that follows
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device)
@@ -373,7 +374,7 @@ class _Conv2dMFMA(torch.autograd.Function):
                 raise NotImplementedError("gradient of a conv bias without ReLU")   # only the frozen VGG19 has such a layer
             if b is not None and db_t is not None and db_ret is None:
                 _grad_ready(b)
-        if ctx.needs_input_grad[0] and not ctx.relu and ctx.b_param is None and _wino_ok(C, K, R, S, stride, pad):
+        if ctx.needs_input_grad[0] and _wino_ok(C, K, R, S, stride, pad):
             # backward-data of a stride-1 3x3 = the same Winograd pipeline on dy with the transposed, rotated filter
             dx = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32, memory_format=_CL)
             wt = _wino_scratch(gy.device, "wt", wk.numel())

@@ -65,3 +65,39 @@ def baseline_config2_args(**overrides):
     kw = dict(FREIHAND_FULL_LAMBDAS)
     kw.update(overrides)
     return make_args(None, **kw)
+
+
+# reference config/FreiHAND/full_rhd_freihand.json ("losses", "train_batch", "pretrain"; hand_model is "nimble" there)
+FREIHAND_FULL_LOSSES = ["joint_3d", "vert_3d", "mpose", "mshape", "mtex", "bone_direc_3d", "edge_length",
+                        "texture", "mrgb", "sil", "ssim_tex", "perceptual"]
+
+
+def baseline_config3_args(**overrides):
+    """BASELINE.json configs[2]: full_rhd_freihand.json -- EfficientNet-b3, batch 48, texture + perceptual losses.  The
+    NIMBLE layer is not available: the composition runs with MANO + the texture stand-in of models.Model
+    and a VGG19 carrying seeded random weights."""
+    kw = dict(FREIHAND_FULL_LAMBDAS)
+    kw.update(pretrain="effb3", train_batch=48, losses=list(FREIHAND_FULL_LOSSES), hand_model="mano")
+    kw.update(overrides)
+    return make_args(None, **kw)
+
+
+# reference config/HO3D/weak_rhd_ho3d.json
+HO3D_WEAK_LAMBDAS = dict(
+    lambda_j3d=200, lambda_vert_3d=200, lambda_edge_len=100, lambda_silhouette=0.00001, lambda_iou=0.0008,
+    lambda_tex_reg_steps=[260, 270], lambda_tex_reg_list=[5e-3, 5e-5, 5e-7], lambda_pose_steps=[260, 270, 280],
+    lambda_pose_list=[0.01, 0.001, 0.0001, 0.00001], lambda_shape_steps=[270, 300], lambda_shape_list=[0.1, 0.001, 0.00001],
+    lambda_j2d_gt_list=[0.01], lambda_bone_direc=0.1, lambda_percep=1e-8, lambda_ssim_tex=0.002, lambda_texture=0.01,
+    init_lr=0.001, lr_steps=[80, 160, 200, 300, 350, 400, 450], lr_gamma=0.5,
+)
+HO3D_WEAK_LOSSES = ["joint_2d", "bone_direc", "mpose", "mshape", "mtex", "texture", "mrgb", "sil", "ssim_tex", "perceptual"]
+
+
+def baseline_config5_args(**overrides):
+    """BASELINE.json configs[4]: HO-3D weak supervision (2-D joints + photometric terms), 16 images per GPU.  Same
+    stand-ins as `baseline_config3_args`; dat_name is "HO3D" (no scale term, absolute ground truth, OpenGL-convention
+    intrinsics flipped by data_dic)."""
+    kw = dict(HO3D_WEAK_LAMBDAS)
+    kw.update(pretrain="effb3", train_batch=16, losses=list(HO3D_WEAK_LOSSES), hand_model="mano")
+    kw.update(overrides)
+    return make_args(None, **kw)

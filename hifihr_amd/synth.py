@@ -63,3 +63,23 @@ def make_batch(mano_handle: ops.ManoLayerHandle, renderer: ops.RendererHandle, B
         "trans_images": imgs, "trans_Ks": Kp.cpu(), "trans_joints": joints_w.cpu(), "trans_verts": verts_w.cpu(),
         "trans_masks": mask.cpu(), "scales": scales.cpu(), "idxs": torch.arange(first_index, first_index + B),
     }
+
+
+def to_ho3d_sample(sample: dict, crop: int = 448) -> dict:
+    """The same synthetic batch in the HO-3D loader's keys and conventions (what utils/traineval_util.py:156-201 undoes):
+    OpenGL camera (columns 2-3 of K and the joints' y / z negated), HO-3D joint order, a `crop`-pixel image crop that
+    nearest-neighbour resizing brings back to 224 (crop = 2 x 224: every pixel repeated 2 x 2)."""
+    from .traineval import Frei2HO3D, proj_func
+    assert crop % 224 == 0
+    r = crop // 224
+    flip = torch.tensor([1.0, -1.0, -1.0])
+    K, joints = sample["trans_Ks"], sample["trans_joints"]
+    return {
+        "img_crop": sample["trans_images"].repeat_interleave(r, dim=2).repeat_interleave(r, dim=3),
+        "K_crop": K * flip.view(1, 1, 3),
+        "xyz21": Frei2HO3D(joints * flip.view(1, 1, 3)),
+        "uv21_crop": Frei2HO3D(proj_func(joints, K)),
+        "root_xyz": joints[:, 0] * flip,
+        "hand_mask_crop": sample["trans_masks"],
+        "idxs": sample["idxs"],
+    }

@@ -4,6 +4,7 @@ utils/fh_utils.py:30-39 proj_func)."""
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
 
 
 def proj_func(xyz, K):
@@ -20,25 +21,61 @@ def trans_proj_j2d(outputs, Ks, root_xyz=None, which_joints="joints"):
     return proj_func(j3d, Ks)
 
 
+_HO3D_TO_FREI = [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]   # FreiHAND joint i <- HO-3D joint [i]
+
+
+def HO3D2Frei(ho3d_joints):
+    """utils/fh_utils.py:604-616: HO-3D joint order -> FreiHAND joint order (one gather instead of 21 slice copies)."""
+    return ho3d_joints[:, _HO3D_TO_FREI]
+
+
+def Frei2HO3D(frei_joints):
+    """utils/fh_utils.py:618-629 (inverse permutation; the HO-3D evaluation dump uses it)."""
+    inv = [0] * 21
+    for frei, ho in enumerate(_HO3D_TO_FREI):
+        inv[ho] = frei
+    return frei_joints[:, inv]
+
+
 def data_dic(sample, dat_name, set_name, args, device="cuda"):
-    """FreiHand branch of traineval_util.py:21-111 for the training queries
-    [trans_images, trans_Ks, trans_joints, scales, trans_verts, trans_masks]."""
-    assert dat_name == "FreiHand"
+    """utils/traineval_util.py:21-111 (FreiHand branch; training queries [trans_images, trans_Ks, trans_joints, scales,
+    trans_verts, trans_masks], evaluation queries without the prefix) and :156-201 (HO3D branch: crop resized to 224 with
+    nearest-neighbour `interpolate`, the OpenGL -> image convention flip of K's columns and of the joints' y / z by
+    (1, -1, -1), HO-3D -> FreiHAND joint order).  Host tensors go to `device`; `Ps = Ks . [I|0]` is a zero column."""
     ex = {}
-    g = lambda k: sample["trans_" + k] if ("trans_" + k) in sample else sample[k]
-    ex["imgs"] = g("images").to(device, non_blocking=True)
-    Ks = g("Ks").to(device, non_blocking=True)
+    to = lambda t: t.to(device, non_blocking=True)
+    if dat_name == "FreiHand":
+        training = "training" in set_name
+        g = lambda k: sample["trans_" + k] if ("trans_" + k) in sample and (training or k in ("images", "Ks")) else sample.get(k)
+        ex["imgs"] = to(g("images"))
+        Ks = to(g("Ks"))
+        if "scales" in sample:
+            ex["scales"] = to(sample["scales"].float())
+        ex["idxs"] = to(sample["idxs"])
+        joints, verts, masks = g("joints"), g("verts"), g("masks")
+    elif dat_name == "HO3D":
+        ex["imgs"] = F.interpolate(to(sample["img_crop"]), (224, 224))
+        flip = torch.tensor([1.0, -1.0, -1.0], device=device)
+        Ks = to(sample["K_crop"]) * flip.view(1, 1, 3)
+        if "root_xyz" in sample:
+            ex["root_xyz"] = to(sample["root_xyz"])
+        if "uv21_crop" in sample:
+            ex["j2d_gt"] = HO3D2Frei(to(sample["uv21_crop"].float()))
+        joints = HO3D2Frei(to(sample["xyz21"])) * flip.view(1, 1, 3) if "xyz21" in sample else None
+        verts, masks = None, sample.get("hand_mask_crop")
+    else:
+        raise NotImplementedError(f"dat_name='{dat_name}': FreiHand and HO3D are built (RHD / Obman need their datasets)")
     ex["Ks"] = Ks
     ex["Ps"] = torch.cat([Ks, torch.zeros_like(Ks[:, :, :1])], dim=2)       # Ks @ [I|0]
-    if "scales" in sample:
-        ex["scales"] = sample["scales"].float().to(device, non_blocking=True)
-    ex["idxs"] = sample["idxs"].to(device, non_blocking=True)
-    ex["joints"] = g("joints").to(device, non_blocking=True)
-    ex["j2d_gt"] = proj_func(ex["joints"], Ks)
-    ex["verts"] = g("verts").to(device, non_blocking=True)
-    masks = g("masks").to(device, non_blocking=True)
-    ex["masks"] = masks
-    ex["segms_gt"] = masks[:, 0].long()
+    if joints is not None:
+        ex["joints"] = to(joints)
+        if dat_name == "FreiHand":
+            ex["j2d_gt"] = proj_func(ex["joints"], Ks)
+    if verts is not None:
+        ex["verts"] = to(verts)
+    if masks is not None:
+        ex["masks"] = to(masks)
+        ex["segms_gt"] = ex["masks"][:, 0].long()
     return ex
 
 
@@ -47,8 +84,10 @@ def forward_backward(model, loss_func, optimizer, examples, args, dat_name="Frei
     root_xyz = examples["joints"][:, args.ROOT, :].unsqueeze(1)
     outputs = model(dat_name, True, examples["imgs"], Ks=examples["Ps"], root_xyz=root_xyz)
     ex = dict(examples)
-    ex["joints"] = examples["joints"] - root_xyz
-    ex["verts"] = examples["verts"] - root_xyz
+    if dat_name != "HO3D":                   # train_hrnet.py:64-68: HO-3D keeps its absolute ground truth
+        ex["joints"] = examples["joints"] - root_xyz
+        if "verts" in examples:
+            ex["verts"] = examples["verts"] - root_xyz
     if any(k in args.losses for k in ("joint_2d", "bone_direc")):
         outputs["j2d"] = trans_proj_j2d(outputs, examples["Ks"], root_xyz=root_xyz)      # only these terms read it
     loss_dic = loss_func(ex, outputs, args.losses, dat_name, args)

@@ -20,7 +20,7 @@ SKIN_TONE = (0.78, 0.60, 0.50)
 
 
 class OracleModel(nn.Module):
-    def __init__(self, tables, pretrain="res18", image_size=224, aa=3, root_id=9):
+    def __init__(self, tables, pretrain="res18", image_size=224, aa=3, root_id=9, texture_stand_in=0):
         super().__init__()
         self.tables, self.image_size, self.aa, self.root_id = tables, image_size, aa, root_id
         if pretrain == "res18":
@@ -28,7 +28,12 @@ class OracleModel(nn.Module):
         else:
             from hifihr_amd.effnet import EffiEncoder
             self.base_encoder, feat_dim, low_dim = EffiEncoder(pretrain, conv_impl="aten"), 1536, 32
-        self.hand_encoder = HandEncoder(hand_model="mano", ncomps=[10, 48, None], in_dim=feat_dim, ifRender=True, use_mean_shape=False)
+        self.hand_encoder = HandEncoder(hand_model="mano", ncomps=[10, 48, int(texture_stand_in) or None], in_dim=feat_dim,
+                                        ifRender=True, use_mean_shape=False)
+        if texture_stand_in:                   # hifihr_amd/models.py: vertex colours = skin tone + basis . texture_params
+            from hifihr_amd.models import texture_stand_in_basis
+            self.register_buffer("texture_basis", texture_stand_in_basis(texture_stand_in), persistent=False)
+        self.texture_stand_in = int(texture_stand_in)
         self.light_estimator = LightEstimator(low_dim)
         self.faces = torch.as_tensor(tables.faces).long()
 
@@ -43,11 +48,13 @@ class OracleModel(nn.Module):
         outputs = {"mano_verts": verts}
         outputs.update(hp)
         joints = mo.xyz_from_vertice(self.tables, verts)
-        joints, mano_verts, pred_root = mo.root_relative(joints, verts, self.root_id)
+        joints, mano_verts, pred_root = mo.root_relative(joints, verts, 0 if (dat_name == "HO3D" and not mode_train) else self.root_id)
         outputs["joints"], outputs["mano_verts"] = joints, mano_verts
         cam = ro.ndc_camera_from_K(Ks, float(self.image_size))
         verts_cam = mano_verts + root_xyz
         vcol = torch.tensor(SKIN_TONE).repeat(images.shape[0], 778, 1)
+        if self.texture_stand_in:
+            vcol = vcol + (hp["texture_params"] @ self.texture_basis).view(-1, 778, 3)
         rgba, p2f = ro.render(verts_cam, vcol, cam, light["colors"], light["directions"], self.faces,
                               image_size=self.image_size, aa=self.aa)
         re_img, re_sil, mask_rgbs = ro.model_render_outputs(rgba, images)
@@ -56,20 +63,22 @@ class OracleModel(nn.Module):
         return outputs
 
 
-def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None, features=None):
+def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None, features=None, dat_name="FreiHand"):
     """train_hrnet.py:50-113 on the CPU.  Returns (loss, loss_dic, outputs).  `features=(low, feat)` skips the
     image encoder (tests isolate the HIP kernels from conv back-end rounding that way)."""
     root_xyz = examples_cpu["joints"][:, args.ROOT, :].unsqueeze(1)
     if features is None:
-        outputs = model("FreiHand", True, examples_cpu["imgs"], Ks=examples_cpu["Ps"], root_xyz=root_xyz)
+        outputs = model(dat_name, True, examples_cpu["imgs"], Ks=examples_cpu["Ps"], root_xyz=root_xyz)
     else:
-        outputs = model.forward_from_features("FreiHand", True, examples_cpu["imgs"], features[0], features[1],
+        outputs = model.forward_from_features(dat_name, True, examples_cpu["imgs"], features[0], features[1],
                                               Ks=examples_cpu["Ps"], root_xyz=root_xyz)
     ex = dict(examples_cpu)
-    ex["joints"] = examples_cpu["joints"] - root_xyz
-    ex["verts"] = examples_cpu["verts"] - root_xyz
+    if dat_name != "HO3D":                 # train_hrnet.py:64-68
+        ex["joints"] = examples_cpu["joints"] - root_xyz
+        if "verts" in examples_cpu:
+            ex["verts"] = examples_cpu["verts"] - root_xyz
     outputs["j2d"] = trans_proj_j2d(outputs, examples_cpu["Ks"], root_xyz=root_xyz)
-    loss_dic = LossFunction(ssim_fn=ssim_torch, fused=False)(ex, outputs, args.losses, "FreiHand", args)
+    loss_dic = LossFunction(ssim_fn=ssim_torch, fused=False)(ex, outputs, args.losses, dat_name, args)
     loss = sum(loss_dic[k] for k in args.losses)
     if optimizer is not None:
         optimizer.zero_grad()

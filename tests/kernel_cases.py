@@ -684,6 +684,14 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
         st = bn_slots(stats, K).sum(0).cpu(); flat = ref.reshape(-1, K)
         np.testing.assert_allclose(st[0].numpy(), flat.sum(0).numpy(), rtol=1e-4, atol=2e-3)
         np.testing.assert_allclose(st[1].numpy(), (flat ** 2).sum(0).numpy(), rtol=1e-4, atol=2e-3)
+    # bias (+ ReLU) epilogue of the output transform (VGG19 layers): same M
+    bias = torch.randn(K, generator=gen) * 0.3
+    for act in (0, 1):
+        out2 = torch.full((N, H, W, K), 7.0, device=device)
+        lib.wino_output_transform(M, out2, None, N, H, W, K, bias=d(bias), act=act)
+        ref2 = ref + bias
+        ref2 = F.relu(ref2) if act else ref2
+        assert float((out2.cpu() - ref2).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6, f"winograd bias/act epilogue (act={act})"
     # backward-data: the same pipeline on dy with the transposed, rotated filter
     wt = torch.empty(C, 3, 3, K, device=device)
     lib.weight_transpose(wd, wt, K, 9, C)

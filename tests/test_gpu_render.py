@@ -16,7 +16,7 @@ def lib():
     return get_lib()
 
 
-@pytest.mark.parametrize("image_size,aa,B", [(224, 3, 2), (64, 3, 5), (100, 2, 3), (37, 1, 2)])
+@pytest.mark.parametrize("image_size,aa,B", [(224, 3, 2), (64, 3, 5), (100, 2, 3), (37, 1, 2), (512, 1, 2), (512, 3, 1)])
 def test_render_vs_oracle(lib, synth_tables, image_size, aa, B):
     kc.render_case(lib, synth_tables, "cuda", B=B, seed=20 + image_size, image_size=image_size, aa=aa, rgb_atol=1e-4)
 

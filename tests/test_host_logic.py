@@ -117,3 +117,67 @@ def test_efficientnet_b3_mirror_vs_reference(golden_dir):
                       ("g_head_bn", net._bn1.weight.grad)):
         ref = g[key]
         assert np.abs(grad.numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, key
+
+
+def test_perceptual_loss_layout_and_loss_term():
+    """utils/perceptual_loss.py:27-45 cannot be imported (torchvision is absent): pin the restatement by known answers --
+    torchvision's VGG19 `features` indices / channel widths up to layer 14, the state-dict names, and the loss term of
+    losses.py:392-396 (fake = re_img * seg + imgs * (1 - seg))."""
+    from types import SimpleNamespace
+    from hifihr_amd.perceptual import PerceptualLoss, vgg19_feature_layout
+    lay = vgg19_feature_layout(14)
+    assert [(i, k) for i, k, _, _ in lay if k != "relu"] == [(0, "conv"), (2, "conv"), (4, "pool"), (5, "conv"), (7, "conv"), (9, "pool"),
+                                                           (10, "conv"), (12, "conv"), (14, "conv")]
+    assert [(ci, co) for _, k, ci, co in lay if k == "conv"] == [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256)]
+    assert lay[-1][1] == "conv"                               # features[:15] ends on conv3_3 WITHOUT its ReLU
+    pl = PerceptualLoss(impl="torch", seed=1)
+    assert sum(p.numel() for p in pl.parameters()) == 1_735_488 and not any(p.requires_grad for p in pl.parameters())
+    sd = {"features." + k: v + 0.01 for k, v in pl.model.state_dict().items()}
+    sd["classifier.0.weight"] = torch.zeros(1)                # whole-model state dicts carry more than the features
+    pl2 = PerceptualLoss(impl="torch", seed=2)
+    pl2.load_vgg19_features(sd)
+    assert torch.equal(pl2.model[14].bias, pl.model[14].bias + 0.01)
+    gen = torch.Generator().manual_seed(0)
+    imgs, re_img = torch.rand(2, 3, 32, 32, generator=gen), torch.rand(2, 3, 32, 32, generator=gen)
+    seg = (torch.rand(2, 32, 32, generator=gen) > 0.5).long()
+    args = SimpleNamespace(lambda_percep=0.5, base_loss_fn="L2")
+    dic = L.LossFunction(perceptual=pl, ssim_fn=L.ssim_torch, fused=False)({"imgs": imgs, "segms_gt": seg}, {"re_img": re_img},
+                                                                             ["perceptual"], "FreiHand", args)
+    s = seg.unsqueeze(1)
+    norm = lambda t: (t - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    want = 0.5 * torch.nn.functional.mse_loss(pl.model(norm(re_img * s + imgs * (1 - s))), pl.model(norm(imgs)))
+    assert abs(dic["perceptual"].item() - want.item()) <= 1e-7
+    # identical inputs: exactly zero
+    assert pl(imgs, imgs).item() == 0.0
+
+
+def test_data_dic_ho3d_branch_known_answers():
+    """utils/traineval_util.py:156-201 + utils/fh_utils.py:604-629 (not importable: skimage): the joint permutation table
+    as written there, the (1, -1, -1) flips, and the round trip synthetic FreiHAND batch -> HO-3D conventions -> data_dic."""
+    from hifihr_amd.traineval import HO3D2Frei, Frei2HO3D, data_dic
+    from hifihr_amd.synth import to_ho3d_sample
+    mapping = {0: 0, 1: 13, 2: 14, 3: 15, 4: 16, 5: 1, 6: 2, 7: 3, 8: 17, 9: 4, 10: 5, 11: 6, 12: 18, 13: 10, 14: 11, 15: 12, 16: 19,
+               17: 7, 18: 8, 19: 9, 20: 20}                      # myId -> ho3dId, fh_utils.py:607-612
+    ho = torch.arange(21.0).view(1, 21, 1).repeat(2, 1, 3)
+    fr = HO3D2Frei(ho)
+    for my, hid in mapping.items():
+        assert float(fr[0, my, 0]) == hid
+    assert torch.equal(Frei2HO3D(fr), ho)
+    gen = torch.Generator().manual_seed(5)
+    B = 3
+    K = torch.zeros(B, 3, 3); K[:, 0, 0] = K[:, 1, 1] = 500.0; K[:, 0, 2] = 110.0; K[:, 1, 2] = 115.0; K[:, 2, 2] = 1.0
+    joints = torch.randn(B, 21, 3, generator=gen) * 0.05 + torch.tensor([0.0, 0.0, 0.6])
+    frei = {"trans_images": torch.rand(B, 3, 224, 224, generator=gen), "trans_Ks": K, "trans_joints": joints,
+            "trans_verts": torch.randn(B, 778, 3, generator=gen), "trans_masks": (torch.rand(B, 3, 224, 224, generator=gen) > 0.5).float(),
+            "scales": torch.ones(B), "idxs": torch.arange(B)}
+    args = options.make_args()
+    a = data_dic(frei, "FreiHand", "training", args, device="cpu")
+    h = data_dic(to_ho3d_sample(frei), "HO3D", "training", args, device="cpu")
+    for k in ("imgs", "Ks", "Ps", "joints", "masks", "segms_gt"):
+        assert torch.equal(a[k], h[k]), k
+    assert torch.allclose(a["j2d_gt"], h["j2d_gt"], atol=1e-4)
+    assert "verts" not in h and "scales" not in h and h["root_xyz"].shape == (B, 3)
+    assert h["segms_gt"].dtype == torch.int64 and tuple(h["Ps"].shape) == (B, 3, 4) and float(h["Ps"][:, :, 3].abs().max()) == 0.0
+    # evaluation queries carry no trans_ prefix
+    ev = data_dic({"images": frei["trans_images"], "Ks": K, "joints": joints, "idxs": torch.arange(B)}, "FreiHand", "evaluation", args, "cpu")
+    assert torch.equal(ev["joints"], joints) and "verts" not in ev and "segms_gt" not in ev
