@@ -8,7 +8,10 @@ output vectors it writes are committed.  What is imported from the reference, un
   utils/manopth/*             batch_rodrigues                      -> rodrigues.npz
   utils/pytorch_ssim          ssim                                 -> ssim.npz
   utils/Freihand_GNN_mano/network/resnet.py  (vendored torchvision ResNet) -> resnet18.npz
-  network/efficientnet_pt     (not used yet)
+  network/efficientnet_pt     EfficientNet.from_name('efficientnet-b3')  -> effnet_b3_small.npz, state_dict_names.json
+  utils/handutils.py          get_affine_transform, transform_img  -> data_path.npz
+  (from source, see _extract_functions / _extract_defs: loss helpers, align_w_scale, HO3D2Frei / Frei2HO3D, and the
+   HandEncoder / LightEstimator / MMPool classes for their state-dict names)
 
 Stand-ins are installed ONLY for bookkeeping modules the container lacks (chumpy pickle classes,
 pytorch3d.structures.Meshes container, cv2) and for the chumpy-based table loader
@@ -219,6 +222,9 @@ def main():
     gen_resnet18()
     gen_losses()
     gen_effnet()
+    gen_state_dict_names()
+    gen_data_path()
+    gen_eval()
 
 
 # ---- loss helpers: the reference functions cannot be imported (module-level pytorch3d / torchvision imports in
@@ -258,8 +264,112 @@ def gen_losses():
     print("losses ok", float(out["bone3d"]), float(out["edge"]), float(out["iou"]))
 
 
+def _extract_defs(path, names, ns):
+    """Like _extract_functions, for classes too: executes the named top-level defs of a reference file in `ns`."""
+    import ast
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def gen_state_dict_names():
+    """Names and shapes of the reference modules' state dicts (the .t7 checkpoint layout of utils/train_utils.py:116-202).
+    network/res_encoder.py imports torchvision / timm at module level, so its classes are executed from source;
+    Resnet_4C wraps torchvision's resnet18 = the vendored utils/Freihand_GNN_mano/network/resnet.py."""
+    import json
+    import io
+    import contextlib
+    from torch import nn
+    from torch.nn import init
+    import torch.nn.functional as F
+    ns = {"torch": torch, "nn": nn, "init": init, "F": F}
+    _extract_defs(os.path.join(REF, "network", "res_encoder.py"), {"HandEncoder", "LightEstimator", "MMPool", "weights_init"}, ns)
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        mods = {
+            "hand_encoder[mano,1536]": ns["HandEncoder"]("mano", [10, 48, None], in_dim=1536),
+            "hand_encoder[nimble,1536]": ns["HandEncoder"]("nimble", [20, 30, 10], in_dim=1536),
+            "hand_encoder[mano,512]": ns["HandEncoder"]("mano", [10, 48, None], in_dim=512),
+            "light_estimator[32]": ns["LightEstimator"](32),
+            "light_estimator[512]": ns["LightEstimator"](512),
+            "mmpool": ns["MMPool"]((1, 1)),
+        }
+        from network.efficientnet_pt.model import EfficientNet
+        mods["efficientnet-b3"] = EfficientNet.from_name("efficientnet-b3")
+        spec = importlib.util.spec_from_file_location("ref_resnet", os.path.join(REF, "utils", "Freihand_GNN_mano", "network", "resnet.py"))
+        rn = importlib.util.module_from_spec(spec); spec.loader.exec_module(rn)
+        mods["resnet18"] = rn.resnet18()
+    for k, m in mods.items():
+        out[k] = {"state": [[n, list(t.shape)] for n, t in m.state_dict().items()],
+                  "params": [n for n, _ in m.named_parameters()]}
+    with open(os.path.join(OUT, "state_dict_names.json"), "w") as fh:
+        json.dump(out, fh)
+    print("state dict names", {k: len(v["state"]) for k, v in out.items()})
+
+
+def gen_data_path():
+    """utils/handutils.py get_affine_transform + transform_img (PIL nearest-neighbour affine), as FreiHAND training samples
+    use them (data/dataset.py:223-280), on seeded uint8 images; plus the K / joint updates of the same lines."""
+    from PIL import Image
+    import utils.handutils as hu
+    rng = np.random.RandomState(11)
+    out = {}
+    for i, (res, rot) in enumerate([(224, 0.3), (96, -2.1), (96, 3.0), (96, 0.0), (64, 1.5707963)]):
+        img = rng.randint(0, 256, size=(res, res, 3)).astype(np.uint8)
+        mask = (rng.rand(res, res) > 0.5).astype(np.uint8)[:, :, None].repeat(3, 2) * 255
+        center = np.asarray([res // 2, res // 2])
+        aff, post = hu.get_affine_transform(center, res, [res, res], rot=rot)
+        timg = np.asarray(hu.transform_img(Image.fromarray(img), aff, [res, res]))
+        tmask = np.asarray(hu.transform_img(Image.fromarray(mask), aff, [res, res]))
+        K = np.array([[500.0 + 10 * i, 0, res / 2 + 3], [0, 505.0, res / 2 - 2], [0, 0, 1]], dtype=np.float32)
+        joints = (rng.randn(21, 3) * 0.05 + np.array([0, 0, 0.6])).astype(np.float32)
+        rot_mat = np.array([[np.cos(rot), -np.sin(rot), 0], [np.sin(rot), np.cos(rot), 0], [0, 0, 1]]).astype(np.float32)
+        out.update({f"img{i}": img, f"mask{i}": mask[:, :, 0], f"rot{i}": np.float64(rot), f"aff{i}": aff, f"post{i}": post,
+                    f"timg{i}": timg, f"tmask{i}": tmask[:, :, 0], f"K{i}": K, f"tK{i}": post.dot(K).astype(np.float32),
+                    f"joints{i}": joints, f"tjoints{i}": rot_mat.dot(joints.transpose(1, 0)).transpose()})
+    out["n"] = np.int64(5)
+    np.savez_compressed(os.path.join(OUT, "data_path.npz"), **out)
+    print("data path ok")
+
+
+def gen_eval():
+    """utils/train_utils.py align_w_scale (scipy orthogonal_procrustes) + the MPJPE / MPVPE reduction of
+    train_hrnet.py:227-243, and the HO-3D joint maps of utils/fh_utils.py:604-629."""
+    from scipy.linalg import orthogonal_procrustes
+    tu = _extract_functions(os.path.join(REF, "utils", "train_utils.py"), {"align_w_scale"})
+    tu["orthogonal_procrustes"] = orthogonal_procrustes
+    fh = _extract_functions(os.path.join(REF, "utils", "fh_utils.py"), {"HO3D2Frei", "Frei2HO3D"})
+    rng = np.random.RandomState(5)
+    B = 6
+    gt_j = (rng.randn(B, 21, 3) * 0.04).astype(np.float64); gt_v = (rng.randn(B, 778, 3) * 0.04).astype(np.float64)
+    def perturb(x):
+        out = []
+        for b in range(x.shape[0]):
+            q, _ = np.linalg.qr(rng.randn(3, 3))
+            if b % 2 == 0 and np.linalg.det(q) < 0:
+                q[:, 0] *= -1
+            out.append((x[b] @ q.T) * (0.7 + 0.6 * rng.rand()) + rng.randn(3) * 0.1 + rng.randn(*x[b].shape) * 0.004)
+        return np.stack(out).astype(np.float32)
+    pr_j, pr_v = perturb(gt_j), perturb(gt_v)
+    al_j = np.stack([tu["align_w_scale"](gt_j[b], pr_j[b]) for b in range(B)])
+    al_v = np.stack([tu["align_w_scale"](gt_v[b], pr_v[b]) for b in range(B)])
+    mpjpe = np.linalg.norm(al_j - gt_j, ord=2, axis=-1).mean()
+    mpvpe = np.linalg.norm(al_v - gt_v, ord=2, axis=-1).mean()
+    j = torch.arange(2 * 21 * 3, dtype=torch.float32).view(2, 21, 3)
+    np.savez_compressed(os.path.join(OUT, "eval.npz"), gt_j=gt_j, gt_v=gt_v.astype(np.float32), pr_j=pr_j, pr_v=pr_v, al_j=al_j,
+                        al_v=al_v.astype(np.float32), mpjpe=mpjpe, mpvpe=mpvpe, j=j.numpy(), ho3d2frei=fh["HO3D2Frei"](j).numpy(),
+                        frei2ho3d=fh["Frei2HO3D"](j).numpy())
+    print("eval ok", mpjpe, mpvpe)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "losses":
+    only = os.environ.get("GOLDEN_ONLY")
+    if only in ("names", "data", "eval"):
+        os.makedirs(OUT, exist_ok=True)
+        {"names": gen_state_dict_names, "data": gen_data_path, "eval": gen_eval}[only]()
+    elif os.environ.get("GOLDEN_ONLY") == "losses":
         os.makedirs(OUT, exist_ok=True)
         gen_losses()
     elif os.environ.get("GOLDEN_ONLY") == "effnet":
