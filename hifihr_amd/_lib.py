@@ -115,6 +115,8 @@ class HifihrLib:
         c.hifihr_wino_input_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
         c.hifihr_wino_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_wino_output_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
+        c.hifihr_freihand_augment.argtypes = [c_void_p, c_void_p, _c_int_p, _c_int_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_procrustes_error.argtypes = [_c_float_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_wino_output_transform_act.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_dy_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
         c.hifihr_wino_wgrad_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
@@ -285,6 +287,19 @@ class HifihrLib:
 
     def wino_gemm(self, V, U, M, N, H, W, C, K, ws=None):
         self.check(self.c.hifihr_wino_gemm(_fp(V), _fp(U), _fp(M), N, H, W, C, K, *self._ws(ws), _stream_of(V)), "hifihr_wino_gemm")
+
+    def freihand_augment(self, img_rgbx, mask, idx, coef_fix, out_img, out_mask):
+        """img_rgbx int32/uint8x4 [n,H,W], mask uint8 [n,H,W] (either None with its output), idx int32 [B], coef_fix int32 [B,6]."""
+        ref = img_rgbx if img_rgbx is not None else mask
+        H, W = ref.shape[1], ref.shape[2]
+        ptr = lambda t: None if t is None else c_void_p(t.data_ptr())
+        self.check(self.c.hifihr_freihand_augment(ptr(img_rgbx), ptr(mask), _ip(idx), _ip(coef_fix), idx.shape[0], H, W, _fp(out_img),
+                                                  _fp(out_mask), _stream_of(idx)), "hifihr_freihand_augment")
+
+    def procrustes_error(self, pred, gt, aligned, err_sum):
+        B, N = pred.shape[0], pred.shape[1]
+        self.check(self.c.hifihr_procrustes_error(_fp(pred), _fp(gt), B, N, _fp(aligned), _fp(err_sum), _stream_of(pred)),
+                   "hifihr_procrustes_error")
 
     def wino_output_transform(self, M, y, stats, N, H, W, K, bias=None, act=0):
         if bias is not None or act:

@@ -615,6 +615,20 @@ int hifihr_wino_output_transform(const float* M, float* y, float* stats, int N, 
   return HIFIHR_OK;
 }
 
+int hifihr_freihand_augment(const uint32_t* img_rgbx, const uint8_t* mask, const int* idx, const int* coef_fix, int B, int H, int W,
+                            float* out_img, float* out_mask, void* stream) {
+  if (!idx || !coef_fix || (!out_img && !out_mask) || (out_img && !img_rgbx) || (out_mask && !mask) || B <= 0 || H <= 0 || W <= 0)
+    return fail(HIFIHR_EINVAL, "hifihr_freihand_augment: bad argument");
+  HIP_TRY(hifihr::launch_freihand_augment(img_rgbx, mask, idx, coef_fix, B, H, W, out_img, out_mask, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_procrustes_error(const float* pred, const float* gt, int B, int N, float* aligned, float* err_sum, void* stream) {
+  if (!pred || !gt || !err_sum || B <= 0 || N <= 0) return fail(HIFIHR_EINVAL, "hifihr_procrustes_error: bad argument");
+  HIP_TRY(hifihr::launch_procrustes(pred, gt, B, N, aligned, err_sum, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_output_transform_act(const float* M, float* y, const float* bias, int act, int N, int H, int W, int K, void* stream) {
   if (!M || !y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0 || act < 0 || act > 1)
     return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform_act: bad argument");

@@ -1,6 +1,8 @@
 // Internal declarations shared by the HIP translation units of libhifihr.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <cstdint>
 #include <stdint.h>
 
 #include "render_math.h"
@@ -149,6 +151,9 @@ hipError_t launch_se_scale(const float* x, const float* gate, const float* add, 
 // Winograd F(2x2, 3x3) glue (wino.hip)
 hipError_t launch_wino_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st);
 hipError_t launch_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, hipStream_t st);
+hipError_t launch_freihand_augment(const uint32_t* img, const uint8_t* mask, const int* idx, const int* coef, int B, int H, int W,
+                                   float* out_img, float* out_mask, hipStream_t st);
+hipError_t launch_procrustes(const float* pred, const float* gt, int B, int N, float* aligned, float* err_sum, hipStream_t st);
 hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
                                         hipStream_t st);
 hipError_t launch_wino_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st);

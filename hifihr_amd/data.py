@@ -1,0 +1,112 @@
+"""FreiHAND training samples assembled on the device.
+
+The reference decodes a JPEG, rotates image and mask in the plane with PIL and rotates the 3-D annotations, per sample,
+in CPU DataLoader workers (reference data/dataset.py:153-289 `get_sample`, utils/handutils.py:48-101), then copies the
+batch to the GPU.  At several thousand images per second per GPU that pipeline is the bottleneck, so here the decoded
+dataset is kept in HBM as uint8 (32 560 training images x 224 x 224 x RGBX = 6.5 GB + masks 1.6 GB, out of 288 GB) and
+a batch is one gather-and-warp launch (csrc/augment.hip) plus two small batched products for K / joints / verts:
+no host pixels, no H2D copy in the step.  JPEG decoding itself (done once, offline or at start-up) is not part of this.
+
+`affine_for_rotation` restates utils/handutils.py:63-101 get_affine_transform for the call the dataset makes
+(centre = image centre, scale = res); the warp coefficients go through the same float32 -> numpy inverse -> PIL 16.16
+fixed-point chain as the reference, which makes the device warp bit-exact with PIL (tests/golden/data_path.npz).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from ._lib import get_lib, require_cuda
+
+
+def _no_rot(center, scale, res):
+    """utils/handutils.py:104-111: crop of `scale` pixels around `center` resized to `res` (rows, cols)."""
+    t = np.zeros((3, 3))
+    t[0, 0] = float(res[1]) / scale
+    t[1, 1] = float(res[0]) / scale
+    t[0, 2] = res[1] * (-float(center[0]) / scale + 0.5)
+    t[1, 2] = res[0] * (-float(center[1]) / scale + 0.5)
+    t[2, 2] = 1
+    return t
+
+
+def affine_for_rotation(center, scale, res, rot):
+    """utils/handutils.py:63-101.  Returns (total_trans, post_rot_trans) as float32 3x3: the image warp (rotation about the
+    origin followed by the crop around the rotated centre) and the crop that stays to be applied to K once the 3-D points
+    have been rotated about the optical axis."""
+    sn, cs = np.sin(rot), np.cos(rot)
+    rot_mat = np.array([[cs, -sn, 0.0], [sn, cs, 0.0], [0.0, 0.0, 1.0]])
+    c = np.array([center[0], center[1], 1.0])
+    origin_rot_center = rot_mat.dot(c)[:2]
+    shift = np.eye(3); shift[0, 2] = -res[1] / 2; shift[1, 2] = -res[0] / 2
+    back = np.eye(3); back[0, 2] = res[1] / 2; back[1, 2] = res[0] / 2
+    centre_after = back.dot(rot_mat).dot(shift).dot(c)
+    total = _no_rot(origin_rot_center, scale, res).dot(rot_mat)
+    post = _no_rot(centre_after[:2], scale, res)
+    return total.astype(np.float32), post.astype(np.float32)
+
+
+def pil_affine_fixed_terms(affine_trans):
+    """The six 16.16 fixed-point integers PIL's nearest-neighbour AFFINE transform derives from transform_img's coefficients
+    (utils/handutils.py:55-59: rows 0-1 of the float32 inverse of `affine_trans`)."""
+    inv = np.linalg.inv(affine_trans)
+    a, b, c, d, e, f = (float(inv[0, 0]), float(inv[0, 1]), float(inv[0, 2]), float(inv[1, 0]), float(inv[1, 1]), float(inv[1, 2]))
+    fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+    return [fix(a), fix(b), fix(c + a * 0.5 + b * 0.5), fix(d), fix(e), fix(f + d * 0.5 + e * 0.5)]
+
+
+class FreiHandDeviceCache:
+    """The decoded training set resident in device memory + per-batch augmentation on the device.
+
+    images_u8 [n,H,W,3] uint8, masks_u8 [n,H,W] (or [n,H,W,3]) uint8 in {0,255}, Ks [n,3,3], joints [n,21,3], verts [n,778,3]
+    (host tensors / arrays; moved once).  `batch(idxs, rots)` returns the reference's training sample dict
+    {trans_images, trans_Ks, trans_joints, trans_verts, trans_masks, scales, idxs} with every tensor on the device."""
+
+    def __init__(self, images_u8, masks_u8, Ks, joints, verts, scales=None, device="cuda", max_rot=math.pi):
+        images_u8 = torch.as_tensor(images_u8)
+        n, H, W, _ = images_u8.shape
+        rgbx = torch.zeros(n, H, W, 4, dtype=torch.uint8)
+        rgbx[..., :3] = images_u8
+        self.images = rgbx.to(device).view(torch.int32).reshape(n, H, W)
+        masks_u8 = torch.as_tensor(masks_u8)
+        if masks_u8.dim() == 4:
+            masks_u8 = masks_u8[..., 0]
+        self.masks = masks_u8.contiguous().to(device)
+        require_cuda(self.images, self.masks)
+        f32 = lambda t: torch.as_tensor(t, dtype=torch.float32).to(device)
+        self.Ks, self.joints, self.verts = f32(Ks), f32(joints), f32(verts)
+        self.scales = f32(scales) if scales is not None else (self.joints[:, 9] - self.joints[:, 10]).norm(dim=-1)
+        self.n, self.H, self.W, self.device, self.max_rot = n, H, W, torch.device(device), max_rot
+        self.lib = get_lib()
+
+    def batch(self, idxs, rots=None, generator=None):
+        idxs = torch.as_tensor(idxs, dtype=torch.int64)
+        B = idxs.shape[0]
+        if rots is None:                       # np.random.uniform(-max_rot, max_rot) per sample (data/dataset.py:237)
+            rots = (2 * torch.rand(B, generator=generator, dtype=torch.float64) - 1) * self.max_rot
+        rots = np.asarray(rots, dtype=np.float64)
+        center, res = np.asarray([self.W // 2, self.H // 2]), [self.H, self.W]
+        fixed, post, rmat = [], [], []
+        for r in rots:
+            total, post_rot = affine_for_rotation(center, self.H, res, r)
+            fixed.append(pil_affine_fixed_terms(total))
+            post.append(post_rot)
+            rmat.append(np.array([[np.cos(r), -np.sin(r), 0], [np.sin(r), np.cos(r), 0], [0, 0, 1]]).astype(np.float32))
+        dev = self.device
+        idx_d = idxs.to(torch.int32).to(dev)
+        coef_d = torch.tensor(fixed, dtype=torch.int32).to(dev)
+        imgs = torch.empty(B, 3, self.H, self.W, device=dev)
+        masks = torch.empty(B, 3, self.H, self.W, device=dev)
+        self.lib.freihand_augment(self.images, self.masks, idx_d, coef_d, imgs, masks)
+        idx_l = idxs.to(dev)
+        post_d = torch.from_numpy(np.stack(post)).to(dev)
+        rmat_d = torch.from_numpy(np.stack(rmat)).to(dev)
+        return {
+            "trans_images": imgs, "trans_masks": masks,
+            "trans_Ks": torch.bmm(post_d, self.Ks[idx_l]),                                         # post_rot_trans . K  (:258-260)
+            "trans_joints": torch.bmm(self.joints[idx_l], rmat_d.transpose(1, 2)),                 # (R j^T)^T          (:271-275)
+            "trans_verts": torch.bmm(self.verts[idx_l], rmat_d.transpose(1, 2)),
+            "scales": self.scales[idx_l], "idxs": idx_l,
+        }

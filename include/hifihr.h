@@ -354,6 +354,31 @@ int hifihr_se_scale(const float* x_d, const float* gate_d, const float* add_d /*
                     float* y_d, void* stream);
 int hifihr_se_bwd_gate(const float* dy_d, const float* x_d, int B, int HW, int C, float* dgate_zeroed_d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Evaluation: Procrustes-with-scale alignment of pred_d[B][N][3] to gt_d[B][N][3] and the
+ * aligned error, one workgroup per sample, fp64 inside.  Replaces the per-sample numpy loop of reference
+ * train_hrnet.py:227-243 over utils/train_utils.py:267-290 (align_w_scale: centre, Frobenius-normalise,
+ * scipy.linalg.orthogonal_procrustes -- no determinant correction --, apply).
+ *   aligned_d[B][N][3] (or NULL) = the aligned prediction;  err_sum_d[B] = sum_n || aligned_n - gt_n ||_2
+ * (MPJPE / MPVPE = sum_b err_sum_d[b] / (B N), in the unit of the inputs).
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_procrustes_error(const float* pred_d, const float* gt_d, int B, int N, float* aligned_d /* or NULL */,
+                            float* err_sum_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FreiHAND training augmentation: gathers B samples from a uint8 dataset cache resident in
+ * device memory and applies the reference's nearest-neighbour affine warp (reference data/dataset.py:223-270,
+ * utils/handutils.py:48-60 = PIL Image.transform(AFFINE), zero fill) + to_tensor (+ torch.round for masks).
+ *   img_rgbx_d[n][H][W]   uint32, bytes R, G, B, X     mask_d[n][H][W] uint8 (0 / 255)
+ *   idx_d[B]              sample indices into the cache
+ *   coef_fix_d[B][6]      PIL's 16.16 fixed-point terms of the six AFFINE coefficients (a b c; d e f):
+ *                         {FIX(a), FIX(b), FIX(c + a/2 + b/2), FIX(d), FIX(e), FIX(f + d/2 + e/2)}, FIX(v) = floor(v * 65536 + 0.5)
+ *   out_img_d[B][3][H][W] = u8 / 255,  out_mask_d[B][3][H][W] = round(u8 / 255) repeated over 3 channels (either may be NULL)
+ * Bit-exact with PIL for the same coefficients.
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_freihand_augment(const uint32_t* img_rgbx_d, const uint8_t* mask_d, const int* idx_d, const int* coef_fix_d, int B, int H,
+                            int W, float* out_img_d, float* out_mask_d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -717,3 +717,61 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
     err = float((dw.cpu() - 0.5 - refw).abs().max())
     assert err <= 1e-4 * float(refw.abs().max()) + 1e-6, f"winograd bwd weight: {err} vs {float(refw.abs().max())}"
     return 0 if ws is None else 1
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation: batched Procrustes-with-scale alignment (csrc/eval.hip) vs the reference's align_w_scale vectors
+# ------------------------------------------------------------------------------------------------
+def procrustes_case(lib, device, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "eval.npz"))
+    for pr, gt, al, key in ((g["pr_j"], g["gt_j"], g["al_j"], "mpjpe"), (g["pr_v"], g["gt_v"], g["al_v"], "mpvpe")):
+        pred = torch.from_numpy(pr).float().to(device).contiguous(); gtt = torch.from_numpy(gt).float().to(device).contiguous()
+        aligned = torch.full_like(pred, 7.0); err = torch.full((pred.shape[0],), 7.0, device=device)
+        lib.procrustes_error(pred, gtt, aligned, err)
+        np.testing.assert_allclose(aligned.cpu().numpy(), al, atol=2e-7, rtol=0)     # metres; fp32 storage of ~0.1 m values
+        got = float(err.sum()) / (pred.shape[0] * pred.shape[1])
+        assert abs(got - float(g[key])) <= 1e-6 * float(g[key]), (key, got, float(g[key]))
+        err2 = torch.full((pred.shape[0],), 7.0, device=device)
+        lib.procrustes_error(pred, gtt, None, err2)                                  # error only
+        assert torch.equal(err, err2)
+    # properties: a similarity transform (incl. a reflection) of the ground truth aligns back exactly; coplanar input is finite
+    gen = torch.Generator().manual_seed(3)
+    gt = torch.randn(4, 50, 3, generator=gen) * 0.05
+    q, _ = torch.linalg.qr(torch.randn(4, 3, 3, generator=gen))
+    pred = 1.7 * gt @ q.transpose(1, 2) + torch.randn(4, 1, 3, generator=gen)
+    flat = gt.clone(); flat[3, :, 2] = 0.0; pflat = pred.clone(); pflat[3] = flat[3] * 2.0 + 0.3
+    for p_, g_ in ((pred, gt), (pflat, flat)):
+        aligned = torch.empty(4, 50, 3, device=device); err = torch.empty(4, device=device)
+        lib.procrustes_error(p_.to(device).contiguous(), g_.to(device).contiguous(), aligned, err)
+        assert float((aligned.cpu() - g_).abs().max()) <= 2e-6 and float(err.max()) <= 50 * 2e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# FreiHAND augmentation warp (csrc/augment.hip) vs the reference's PIL path (tests/golden/data_path.npz)
+# ------------------------------------------------------------------------------------------------
+def augment_case(lib, device, golden_dir):
+    import os
+    from hifihr_amd.data import affine_for_rotation, pil_affine_fixed_terms
+    g = np.load(os.path.join(golden_dir, "data_path.npz"))
+    for i in range(int(g["n"])):
+        img, mask, rot = g[f"img{i}"], g[f"mask{i}"], float(g[f"rot{i}"])
+        res = img.shape[0]
+        total, post = affine_for_rotation(np.asarray([res // 2, res // 2]), res, [res, res], rot)
+        assert np.array_equal(total, g[f"aff{i}"]) and np.array_equal(post, g[f"post{i}"]), "get_affine_transform restatement"
+        # a cache of three images with the wanted one in the middle: the gather index is exercised too
+        rgbx = np.zeros((3, res, res, 4), np.uint8); rgbx[1, :, :, :3] = img; rgbx[0] = 9; rgbx[2] = 17
+        mk = np.zeros((3, res, res), np.uint8); mk[1] = mask; mk[0] = 255
+        cache = torch.from_numpy(rgbx).to(device).view(torch.int32).reshape(3, res, res)
+        out_i = torch.full((2, 3, res, res), 7.0, device=device); out_m = torch.full((2, 3, res, res), 7.0, device=device)
+        idx = torch.tensor([1, 1], dtype=torch.int32, device=device)
+        ident = pil_affine_fixed_terms(np.eye(3, dtype=np.float32))
+        coef = torch.tensor([pil_affine_fixed_terms(total), ident], dtype=torch.int32, device=device)
+        lib.freihand_augment(cache, torch.from_numpy(mk).to(device), idx, coef, out_i, out_m)
+        want = torch.from_numpy(g[f"timg{i}"]).permute(2, 0, 1).float().div(255)
+        assert torch.equal(out_i[0].cpu(), want), f"image warp case {i} (rot {rot})"
+        wm = torch.round(torch.from_numpy(g[f"tmask{i}"]).float().div(255))
+        assert torch.equal(out_m[0].cpu(), wm.unsqueeze(0).repeat(3, 1, 1)), f"mask warp case {i}"
+        assert torch.equal(out_i[1].cpu(), torch.from_numpy(img).permute(2, 0, 1).float().div(255)), "identity warp"
+        # K and joints (data/dataset.py:258-260, 271-275)
+        np.testing.assert_array_equal(post.dot(g[f"K{i}"]).astype(np.float32), g[f"tK{i}"])

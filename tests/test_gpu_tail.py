@@ -1,5 +1,6 @@
 """GPU parity of the pooling and fused-loss kernels (csrc/pool.hip, csrc/losses.hip) at the sizes of BASELINE configs[1]
 against plain PyTorch fp32 (CPU) -- through the C ABI."""
+import numpy as np
 import pytest
 import torch
 
@@ -86,3 +87,64 @@ def test_perceptual_loss_matches_torch_flavour(B, H, kind):
     assert float(err.norm()) <= 2e-2 * float(gr.norm()), (float(err.norm()), float(gr.norm()))
     assert float(err.median()) <= 1e-5 * float(gr.abs().max())
     assert float((err > 1e-3 * float(gr.abs().max())).float().mean()) <= 0.02
+
+
+def test_procrustes_alignment_vs_reference(lib, golden_dir):
+    kc.procrustes_case(lib, "cuda", golden_dir)
+
+
+def test_freihand_augment_vs_reference_pil(lib, golden_dir):
+    kc.augment_case(lib, "cuda", golden_dir)
+
+
+def test_device_cache_batch_matches_reference_sample(golden_dir):
+    """hifihr_amd.data.FreiHandDeviceCache.batch == the reference's per-sample augmentation (data/dataset.py:223-280) for the
+    golden rotations: pixels bit-exact, K / joints to fp32 rounding; and it feeds data_dic unchanged."""
+    import os
+    from hifihr_amd import options
+    from hifihr_amd.data import FreiHandDeviceCache
+    from hifihr_amd.traineval import data_dic
+    g = np.load(os.path.join(golden_dir, "data_path.npz"))
+    ids = [1, 2, 3]                                    # the three 96 x 96 cases
+    cache = FreiHandDeviceCache(np.stack([g[f"img{i}"] for i in ids]), np.stack([g[f"mask{i}"] for i in ids]),
+                                np.stack([g[f"K{i}"] for i in ids]), np.stack([g[f"joints{i}"] for i in ids]),
+                                np.zeros((3, 778, 3), np.float32))
+    order = [2, 0, 1]
+    s = cache.batch(order, rots=[float(g[f"rot{ids[k]}"]) for k in order])
+    for b, k in enumerate(order):
+        i = ids[k]
+        assert torch.equal(s["trans_images"][b].cpu(), torch.from_numpy(g[f"timg{i}"]).permute(2, 0, 1).float().div(255))
+        assert torch.equal(s["trans_masks"][b, 1].cpu(), torch.round(torch.from_numpy(g[f"tmask{i}"]).float().div(255)))
+        np.testing.assert_allclose(s["trans_Ks"][b].cpu().numpy(), g[f"tK{i}"], rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(s["trans_joints"][b].cpu().numpy(), g[f"tjoints{i}"], rtol=1e-6, atol=1e-7)
+    ex = data_dic(s, "FreiHand", "training", options.make_args(), device="cuda")
+    assert ex["imgs"].data_ptr() == s["trans_images"].data_ptr() and ex["segms_gt"].dtype == torch.int64     # no copies on the way
+
+
+def test_evaluator_summary_matches_formulas(golden_dir):
+    """hifihr_amd.evaluate.Evaluator vs the formulas of train_hrnet.py:149-161, 227-243 written out with torch."""
+    import os
+    from hifihr_amd import ops
+    from hifihr_amd.evaluate import Evaluator, align_w_scale
+    g = np.load(os.path.join(golden_dir, "eval.npz"))
+    gen = torch.Generator().manual_seed(2)
+    ev = Evaluator()
+    B = 3
+    for half in (0, 1):
+        sl = slice(half * B, half * B + B)
+        out = {"joints": torch.from_numpy(g["pr_j"][sl]).cuda(), "mano_verts": torch.from_numpy(g["pr_v"][sl]).cuda(),
+               "re_img": torch.rand(B, 3, 224, 224, generator=gen).cuda()}
+        ex = {"imgs": torch.rand(B, 3, 224, 224, generator=gen).cuda(), "segms_gt": (torch.rand(B, 224, 224, generator=gen) > 0.6).long().cuda()}
+        ev.collect(out, ex, "FreiHand")
+        if half == 1:
+            m = ex["segms_gt"].unsqueeze(1).float()
+            last = (out["re_img"] * m, m * ex["imgs"])
+    s = ev.summary(g["gt_j"], g["gt_v"])
+    assert abs(s["pose_3d"] - float(g["mpjpe"])) <= 1e-6 * float(g["mpjpe"]) and abs(s["vert_3d"] - float(g["mpvpe"])) <= 1e-6 * float(g["mpvpe"])
+    assert s["lpips"] is None and 0 < s["psnr"] < 30 and 0 < s["l1"] < 1
+    mse = torch.nn.functional.mse_loss(*last)
+    assert s["l2"] > 0 and abs(float(ops.ssim(*[t.contiguous() for t in last])) - float(ev.texture[-1]["ssim"])) < 1e-7
+    assert abs(float(-10 * mse.log10()) - float(ev.texture[-1]["psnr"])) < 1e-5
+    al, err = align_w_scale(torch.from_numpy(g["gt_j"]).float().cuda(), torch.from_numpy(g["pr_j"]).cuda(), return_error=True)
+    np.testing.assert_allclose(al.cpu().numpy(), g["al_j"], atol=2e-7)
+    assert abs(float(err.mean()) - float(g["mpjpe"])) <= 1e-6 * float(g["mpjpe"])

@@ -1,0 +1,13 @@
+"""csrc/augment.hip on the host emulator: bit-exact with the reference's PIL warp (tests/golden/data_path.npz)."""
+import pytest
+
+import kernel_cases as kc
+
+
+@pytest.fixture(scope="module")
+def hostsim_lib():
+    return kc.build_hostsim()
+
+
+def test_freihand_augment_vs_reference_pil(hostsim_lib, golden_dir):
+    kc.augment_case(hostsim_lib, "cpu", golden_dir)
