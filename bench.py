@@ -55,6 +55,44 @@ def cpu_baseline(args_ns, examples, tables, nimg):
                       f"rasteriser is single-threaded) on {nimg} images of the same synthetic batch, {dt:.1f} s"}
 
 
+def data_path_probe(B, dev, args_ns, n_cache=512, reps=20):
+    """Batch assembly on the device (hifihr_amd/data.py, csrc/augment.hip: SURVEY.md 8(f) N1): a synthetic uint8 cache resident
+    in HBM, one gather-and-warp launch + the K / joint / vertex products per batch, then data_dic.  Reported next to the step
+    (the timed step above replays a resident batch); wall time per batch including the host-side coefficient arithmetic."""
+    import numpy as np
+    from hifihr_amd.data import FreiHandDeviceCache
+    from hifihr_amd.traineval import data_dic
+    rng = np.random.RandomState(0)
+    cache = FreiHandDeviceCache(rng.randint(0, 256, size=(n_cache, 224, 224, 3)).astype(np.uint8),
+                                (rng.rand(n_cache, 224, 224) > 0.5).astype(np.uint8) * 255,
+                                np.tile(np.array([[500.0, 0, 112], [0, 500.0, 112], [0, 0, 1]], np.float32), (n_cache, 1, 1)),
+                                rng.randn(n_cache, 21, 3).astype(np.float32), rng.randn(n_cache, 778, 3).astype(np.float32), device=dev)
+    gen = torch.Generator().manual_seed(0)
+    idx = torch.randint(0, n_cache, (B,), generator=gen)
+    for _ in range(3):
+        data_dic(cache.batch(idx, generator=gen), "FreiHand", "training", args_ns, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        data_dic(cache.batch(idx, generator=gen), "FreiHand", "training", args_ns, device=dev)
+    torch.cuda.synchronize()
+    wall_us = (time.perf_counter() - t0) / reps * 1e6
+    coef = torch.zeros(B, 6, dtype=torch.int32, device=dev); coef[:, 0] = 65536; coef[:, 4] = 65536; coef[:, 2] = 32768; coef[:, 5] = 32768
+    oi = torch.empty(B, 3, 224, 224, device=dev); om = torch.empty(B, 3, 224, 224, device=dev)
+    idx_d = idx.to(torch.int32).to(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        cache.lib.freihand_augment(cache.images, cache.masks, idx_d, coef, oi, om)
+    e1.record()
+    torch.cuda.synchronize()
+    k_us = e0.elapsed_time(e1) * 1e3 / reps
+    alg = B * 224 * 224 * (4 + 1 + 2 * 3 * 4)                  # RGBX + mask byte read, two float [3,H,W] tensors written
+    return {"wall_us_per_batch": wall_us, "augment_kernel_us": k_us, "augment_algorithmic_bytes": alg,
+            "augment_GBps": alg / (k_us * 1e-6) / 1e9, "images_per_sec_wall": B / (wall_us * 1e-6),
+            "note": "uint8 dataset cache resident in HBM; gather + nearest-neighbour affine warp + to_tensor on the device, bit-exact with the reference's PIL path"}
+
+
 def main():
     a = parse()
     from hifihr_amd import dist as hdist, ops, options, synth
@@ -261,6 +299,8 @@ def main():
         out["kernels_avg_us_eager"] = {k: round(v[0], 2) for k, v in kern.items()}     # single-launch brackets, incl. launch latency
         rf = render_us if render_us is not None else kern.get("render_fwd", (0,))[0]
         out["render_ms_per_frame"] = {"fwd": rf / B / 1e3, "fwd+bwd": (rf + kern.get("render_bwd", (0,))[0]) / B / 1e3}
+        if world == 1:
+            out["data_path"] = data_path_probe(B, dev, args_ns)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args_ns, examples, tables, a.cpu_batch)
         print(json.dumps(out))

@@ -57,6 +57,38 @@ def pil_affine_fixed_terms(affine_trans):
     return [fix(a), fix(b), fix(c + a * 0.5 + b * 0.5), fix(d), fix(e), fix(f + d * 0.5 + e * 0.5)]
 
 
+def batch_affine_terms(center, scale, res, rots):
+    """`affine_for_rotation` + `pil_affine_fixed_terms` for a whole batch in stacked numpy calls (the per-sample Python loop
+    costs ~1 ms per 32 samples, a tenth of a training step).  Returns (fixed int32 [B,6], post_rot_trans f32 [B,3,3],
+    rot_mat f32 [B,3,3]).  Same operations in the same order on stacked arrays; tests compare it with the per-sample path."""
+    rots = np.asarray(rots, dtype=np.float64)
+    B = rots.shape[0]
+    sn, cs = np.sin(rots), np.cos(rots)
+    rot_mat = np.zeros((B, 3, 3))
+    rot_mat[:, 0, 0] = cs; rot_mat[:, 0, 1] = -sn; rot_mat[:, 1, 0] = sn; rot_mat[:, 1, 1] = cs; rot_mat[:, 2, 2] = 1.0
+    c = np.array([center[0], center[1], 1.0])
+    origin = np.matmul(rot_mat, c)[:, :2]
+    shift = np.eye(3); shift[0, 2] = -res[1] / 2; shift[1, 2] = -res[0] / 2
+    back = np.eye(3); back[0, 2] = res[1] / 2; back[1, 2] = res[0] / 2
+    centre_after = np.matmul(np.matmul(np.matmul(back, rot_mat), shift), c)
+
+    def no_rot(cen):
+        t = np.zeros((B, 3, 3))
+        t[:, 0, 0] = float(res[1]) / scale
+        t[:, 1, 1] = float(res[0]) / scale
+        t[:, 0, 2] = res[1] * (-cen[:, 0] / scale + 0.5)
+        t[:, 1, 2] = res[0] * (-cen[:, 1] / scale + 0.5)
+        t[:, 2, 2] = 1
+        return t
+    total = np.matmul(no_rot(origin), rot_mat).astype(np.float32)
+    post = no_rot(centre_after[:, :2]).astype(np.float32)
+    inv = np.linalg.inv(total).astype(np.float64)
+    a, b, cc, d, e, f = inv[:, 0, 0], inv[:, 0, 1], inv[:, 0, 2], inv[:, 1, 0], inv[:, 1, 1], inv[:, 1, 2]
+    fix = lambda v: np.floor(v * 65536.0 + 0.5).astype(np.int64)
+    fixed = np.stack([fix(a), fix(b), fix(cc + a * 0.5 + b * 0.5), fix(d), fix(e), fix(f + d * 0.5 + e * 0.5)], axis=1).astype(np.int32)
+    return fixed, post, rot_mat.astype(np.float32)
+
+
 class FreiHandDeviceCache:
     """The decoded training set resident in device memory + per-batch augmentation on the device.
 
@@ -87,22 +119,16 @@ class FreiHandDeviceCache:
         if rots is None:                       # np.random.uniform(-max_rot, max_rot) per sample (data/dataset.py:237)
             rots = (2 * torch.rand(B, generator=generator, dtype=torch.float64) - 1) * self.max_rot
         rots = np.asarray(rots, dtype=np.float64)
-        center, res = np.asarray([self.W // 2, self.H // 2]), [self.H, self.W]
-        fixed, post, rmat = [], [], []
-        for r in rots:
-            total, post_rot = affine_for_rotation(center, self.H, res, r)
-            fixed.append(pil_affine_fixed_terms(total))
-            post.append(post_rot)
-            rmat.append(np.array([[np.cos(r), -np.sin(r), 0], [np.sin(r), np.cos(r), 0], [0, 0, 1]]).astype(np.float32))
+        fixed, post, rmat = batch_affine_terms(np.asarray([self.W // 2, self.H // 2]), self.H, [self.H, self.W], rots)
         dev = self.device
         idx_d = idxs.to(torch.int32).to(dev)
-        coef_d = torch.tensor(fixed, dtype=torch.int32).to(dev)
+        coef_d = torch.from_numpy(fixed).to(dev)
         imgs = torch.empty(B, 3, self.H, self.W, device=dev)
         masks = torch.empty(B, 3, self.H, self.W, device=dev)
         self.lib.freihand_augment(self.images, self.masks, idx_d, coef_d, imgs, masks)
         idx_l = idxs.to(dev)
-        post_d = torch.from_numpy(np.stack(post)).to(dev)
-        rmat_d = torch.from_numpy(np.stack(rmat)).to(dev)
+        post_d = torch.from_numpy(post).to(dev)
+        rmat_d = torch.from_numpy(rmat).to(dev)
         return {
             "trans_images": imgs, "trans_masks": masks,
             "trans_Ks": torch.bmm(post_d, self.Ks[idx_l]),                                         # post_rot_trans . K  (:258-260)

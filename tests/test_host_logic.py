@@ -181,3 +181,24 @@ def test_data_dic_ho3d_branch_known_answers():
     # evaluation queries carry no trans_ prefix
     ev = data_dic({"images": frei["trans_images"], "Ks": K, "joints": joints, "idxs": torch.arange(B)}, "FreiHand", "evaluation", args, "cpu")
     assert torch.equal(ev["joints"], joints) and "verts" not in ev and "segms_gt" not in ev
+
+
+def test_batched_affine_terms_equal_per_sample_path():
+    """hifihr_amd.data.batch_affine_terms (stacked numpy) == the per-sample restatement of utils/handutils.py:63-101 that the
+    golden PIL vectors pin, bit for bit, over many rotations (incl. the ones of tests/golden/data_path.npz)."""
+    import time
+    from hifihr_amd.data import affine_for_rotation, batch_affine_terms, pil_affine_fixed_terms
+    rng = np.random.RandomState(0)
+    for res in (224, 96):
+        rots = np.concatenate([rng.uniform(-np.pi, np.pi, 3000), [0.3, -2.1, 3.0, 0.0, 1.5707963, np.pi, -np.pi]])
+        center = np.asarray([res // 2, res // 2])
+        fixed, post, rmat = batch_affine_terms(center, res, [res, res], rots)
+        for i, r in enumerate(rots):
+            total, p = affine_for_rotation(center, res, [res, res], r)
+            assert pil_affine_fixed_terms(total) == fixed[i].tolist(), (res, r)
+            assert np.array_equal(p, post[i])
+            want = np.array([[np.cos(r), -np.sin(r), 0], [np.sin(r), np.cos(r), 0], [0, 0, 1]]).astype(np.float32)
+            assert np.array_equal(rmat[i], want)
+    t0 = time.perf_counter()
+    batch_affine_terms(np.asarray([112, 112]), 224, [224, 224], rots[:32])
+    assert time.perf_counter() - t0 < 0.01
