@@ -202,3 +202,22 @@ def test_batched_affine_terms_equal_per_sample_path():
     t0 = time.perf_counter()
     batch_affine_terms(np.asarray([112, 112]), 224, [224, 224], rots[:32])
     assert time.perf_counter() - t0 < 0.01
+
+
+def test_train_front_end_reads_reference_configs(tmp_path):
+    """train_hrnet.py --config_json: JSON overlay with unknown keys accepted (reference train_hrnet.py:505-510), lambda_* from
+    the first list element, nimble configs mapped to the declared MANO + texture stand-in."""
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import train_hrnet as T
+    cfg = {"train_datasets": ["FreiHand"], "hand_model": "nimble", "pretrain": "effb3", "train_batch": 48, "some_unknown_key": 1,
+           "lambda_pose_list": [0.01, 0.001], "lambda_pose_steps": [10], "losses": ["joint_3d", "mtex", "perceptual"],
+           "base_out_path": str(tmp_path), "save_interval": 5, "optimizer": "AdamW"}
+    f = tmp_path / "c.json"
+    f.write_text(json.dumps(cfg))
+    args = T.build_args(T.parse(["--config_json", str(f), "--override", '{"total_epochs": 3}']))
+    assert args.hand_model == "mano" and args.texture_stand_in == 10 and args.pretrain == "effb3" and args.train_batch == 48
+    assert args.lambda_pose == 0.01 and args.some_unknown_key == 1 and args.total_epochs == 3 and args.save_interval == 5
+    assert args.state_output == os.path.join(str(tmp_path), "model") and args.mode == ["training"] and args.optimizer == "AdamW"
+    d = T.build_args(T.parse([]))
+    assert d.hand_model == "mano" and d.texture_stand_in == 0 and d.pretrain == "res18" and d.if_test is True

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Training / evaluation front-end with the reference's command line:  python train_hrnet.py --config_json <file>.json
+
+Mirrors the flow of the reference's train_hrnet.py (argument overlay :503-519, model / optimizer / scheduler / checkpoint
+set-up :537-566, epoch driver :449-485 with the lambda schedules, periodic test + save, evaluation mode :487-496) on this
+package's device-resident pieces:
+
+  data        hifihr_amd.data.FreiHandDeviceCache -- the decoded set lives in HBM, a batch is one gather-and-warp launch.
+              Source: --freihand_cache <npz with images u8 [n,224,224,3], masks u8, Ks, joints, verts> (pre-decoded by the user;
+              JPEG decoding is outside the hot path) or, by default, a seeded synthetic FreiHAND-shaped set (--synthetic_size).
+  step        hifihr_amd.traineval.GraphedTrainStep (hipGraph replay) or the eager step (--graph 0)
+  multi-GPU   one process per GPU under torch.distributed.run; rank r takes every world-th batch slice; RCCL all-reduce of the
+              flat gradient buffer (hifihr_amd/dist.py).  Replaces nn.DataParallel (:560).
+  checkpoints the reference's .t7 layout (hifihr_amd/checkpoint.py); --pretrain_model resumes a reference file.
+
+hand_model "nimble" configs run with MANO + the texture stand-in (hifihr_amd/models.py) and say so: the NIMBLE submodule
+and its assets are not part of the reference tree.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--config_json", default=None)
+    ap.add_argument("--freihand_cache", default=None, help="npz: images, masks, Ks, joints, verts [, eval_* counterparts]")
+    ap.add_argument("--synthetic_size", type=int, default=512)
+    ap.add_argument("--mano_pkl", default=None, help="MANO_RIGHT.pkl (licensed, user supplied); default: synthetic MANO-shaped tables")
+    ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--max_iters", type=int, default=0, help="stop after this many iterations (0 = run the epochs)")
+    ap.add_argument("--print_freq", type=int, default=50)
+    ap.add_argument("--override", default=None, help='JSON object of option overrides, e.g. \'{"total_epochs": 2}\'')
+    return ap.parse_args(argv)
+
+
+def build_args(cli):
+    from hifihr_amd import options
+    over = json.loads(cli.override) if cli.override else {}
+    defaults = dict(mode=["training"], save_interval=10, if_test=True, save_mode="only_latest", pretrain_model=None,
+                    base_out_path="outputs/run", val_batch=16)
+    defaults.update(over)
+    args = options.make_args(cli.config_json, **{k: v for k, v in defaults.items() if cli.config_json is None or k in over})
+    for k, v in defaults.items():                      # keys a JSON may leave out
+        if not hasattr(args, k):
+            setattr(args, k, v)
+    args.state_output = os.path.join(args.base_out_path, "model")       # options/train_options.py:208-220
+    args.texture_stand_in = 0
+    if args.hand_model == "nimble":
+        print("[train_hrnet] hand_model 'nimble': the NIMBLE layer is not available; running MANO + the 10-component "
+              "vertex-colour texture stand-in (SURVEY.md section 8 A9)")
+        args.hand_model, args.texture_stand_in = "mano", 10
+    if isinstance(args.mode, str):
+        args.mode = [args.mode]
+    return args
+
+
+def load_or_make_dataset(cli, model, device):
+    """-> (train arrays, eval arrays) as dicts of numpy arrays: images u8 [n,H,W,3], masks u8 [n,H,W], Ks, joints, verts."""
+    if cli.freihand_cache:
+        z = np.load(cli.freihand_cache)
+        tr = {k: z[k] for k in ("images", "masks", "Ks", "joints", "verts")}
+        ev = {k: z["eval_" + k] for k in tr} if "eval_images" in z else None
+        return tr, ev
+    from hifihr_amd import synth
+    parts, n = [], cli.synthetic_size + 64
+    for first in range(0, n, 64):
+        s = synth.make_batch(model.hand_layer.handle, model.renderer_p3d, min(64, n - first), first_index=first, device=device)
+        parts.append({"images": (s["trans_images"].permute(0, 2, 3, 1) * 255).round().to(torch.uint8).numpy(),
+                      "masks": (s["trans_masks"][:, 0] * 255).to(torch.uint8).numpy(), "Ks": s["trans_Ks"].numpy(),
+                      "joints": s["trans_joints"].numpy(), "verts": s["trans_verts"].numpy()})
+    full = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    cut = cli.synthetic_size
+    return {k: v[:cut] for k, v in full.items()}, {k: v[cut:] for k, v in full.items()}
+
+
+def run_evaluation(model, cache, arrays, args, device):
+    from hifihr_amd.evaluate import Evaluator
+    from hifihr_amd.traineval import data_dic
+    ev = Evaluator()
+    model.eval()
+    n = cache.n
+    with torch.no_grad():
+        for lo in range(0, n, args.val_batch):
+            idx = torch.arange(lo, min(n, lo + args.val_batch))
+            ex = data_dic(cache.batch(idx, rots=np.zeros(len(idx))), "FreiHand", "training", args, device=device)
+            root = ex["joints"][:, args.ROOT, :].unsqueeze(1)
+            out = model("FreiHand", False, ex["imgs"], Ks=ex["Ps"], root_xyz=root)
+            ev.collect(out, ex, "FreiHand", render=args.render)
+    model.train()
+    return ev.summary(arrays["joints"], arrays["verts"])
+
+
+def main(argv=None):
+    cli = parse(argv)
+    args = build_args(cli)
+    from hifihr_amd import dist as hdist
+    from hifihr_amd import options
+    from hifihr_amd.checkpoint import load_model, save_model
+    from hifihr_amd.data import FreiHandDeviceCache
+    from hifihr_amd.losses import LossFunction
+    from hifihr_amd.mano_tables import load_mano_pkl, synthetic_mano_tables
+    from hifihr_amd.models import Model
+    from hifihr_amd.optim import FlatParams, FusedAdam
+    from hifihr_amd.traineval import GraphedTrainStep, data_dic, train_step
+
+    rank, local_rank, world = hdist.init_process_group_from_env()
+    assert torch.cuda.is_available(), "the hot path has no CPU fallback"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    torch.cuda.set_stream(torch.cuda.Stream(device=device))            # see GraphedTrainStep: never step on the legacy default stream
+    args.device = device
+    say = print if rank == 0 else (lambda *a, **k: None)
+
+    tables = load_mano_pkl(cli.mano_pkl) if cli.mano_pkl else synthetic_mano_tables(0)
+    torch.manual_seed(0)
+    model = Model(ifRender=args.render, device=device, if_4c=args.four_channel, hand_model=args.hand_model,
+                  use_mean_shape=args.use_mean_shape, pretrain=args.pretrain, root_id=args.ROOT, root_id_nimble=args.ROOT_NIMBLE,
+                  ifLight=args.light_estimation, mano_tables=tables, texture_stand_in=args.texture_stand_in).to(device).train()
+    flat = FlatParams(model)
+    hdist.broadcast_params(flat)
+    reducer = hdist.GradReducer(flat, num_buckets=4)
+    wd = 0.01 if args.optimizer == "AdamW" else 0.0                   # train_hrnet.py:549-550: "AdamW" is Adam with L2 0.01
+    opt = FusedAdam(flat, lr=args.init_lr, betas=(0.9, 0.999), weight_decay=wd, grad_scale=reducer.grad_scale)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=args.lr_steps, gamma=args.lr_gamma)
+    model, current_epoch, opt, sched = load_model(model, opt, sched, args)
+    if args.force_init_lr > 0:
+        opt.param_groups[0]["lr"] = args.force_init_lr
+    loss_func = LossFunction()
+
+    train_arrays, eval_arrays = load_or_make_dataset(cli, model, device)
+    cache = FreiHandDeviceCache(train_arrays["images"], train_arrays["masks"], train_arrays["Ks"], train_arrays["joints"],
+                                train_arrays["verts"], device=device)
+    eval_cache = None
+    if eval_arrays is not None and len(eval_arrays["images"]):
+        eval_cache = FreiHandDeviceCache(eval_arrays["images"], eval_arrays["masks"], eval_arrays["Ks"], eval_arrays["joints"],
+                                         eval_arrays["verts"], device=device)
+    say(f"[train_hrnet] {cache.n} training samples resident on {device}; world {world}; encoder {args.pretrain}; losses {args.losses}")
+
+    if "evaluation" in args.mode:
+        say("[train_hrnet] evaluation:", run_evaluation(model, eval_cache or cache, eval_arrays or train_arrays, args, device))
+        return 0
+
+    B = args.train_batch
+    gen = torch.Generator().manual_seed(1000 + current_epoch)         # same permutation on every rank
+    rot_gen = torch.Generator().manual_seed(77 + rank)                # ... different rotations
+    stepper, stepper_key, it, t_last = None, None, 0, time.perf_counter()
+    for epoch in range(1, args.total_epochs + 1 - current_epoch):
+        options.update_lambdas_for_epoch(args, epoch + current_epoch)
+        lam_key = (args.lambda_pose, args.lambda_j2d_gt, args.lambda_shape, args.lambda_tex_reg)
+        if stepper is not None and lam_key != stepper_key:
+            stepper = None                        # the loss weights are kernel arguments baked into the captured graph: re-capture
+        perm = torch.randperm(cache.n, generator=gen)
+        per_step = B * world
+        for lo in range(0, cache.n - per_step + 1, per_step):
+            idx = perm[lo + rank * B: lo + (rank + 1) * B]
+            ex = data_dic(cache.batch(idx, generator=rot_gen), "FreiHand", "training", args, device=device)
+            if cli.graph and stepper is None:
+                try:
+                    stepper = GraphedTrainStep(model, loss_func, opt, ex, args, reducer=reducer if world > 1 else None)
+                    stepper_key = lam_key
+                except Exception as e:            # noqa: BLE001  -- report and continue eagerly
+                    say(f"[train_hrnet] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+                    cli.graph = 0
+            if stepper is not None:
+                stepper.load_batch(ex)
+                loss, dic = stepper()
+            else:
+                loss, dic = train_step(model, loss_func, opt, ex, args, backward_hook=reducer.finish)
+            it += 1
+            if it % cli.print_freq == 0 or it == cli.max_iters:
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t_last
+                t_last = time.perf_counter()
+                n_it = cli.print_freq if it % cli.print_freq == 0 else it % cli.print_freq
+                terms = " ".join(f"{k}={float(dic[k].detach()):.4g}" for k in args.losses)
+                say(f"[train_hrnet] epoch {epoch + current_epoch} it {it} loss {float(loss.detach()):.5f} ({terms}) {n_it * per_step / dt:.0f} img/s")
+            if cli.max_iters and it >= cli.max_iters:
+                break
+        if (epoch + current_epoch) % args.save_interval == 0 or (cli.max_iters and it >= cli.max_iters):
+            if args.if_test and eval_cache is not None:
+                say("[train_hrnet] test:", run_evaluation(model, eval_cache, eval_arrays, args, device))
+            if rank == 0:
+                say("[train_hrnet] saved", save_model(model, opt, sched, epoch, current_epoch, args))
+        sched.step()
+        if cli.max_iters and it >= cli.max_iters:
+            break
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    say("Done!")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
