@@ -147,7 +147,9 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         if split:
-            with torch.cuda.graph(self.graph):
+            # thread-local capture: the process-group watchdog thread queries events while we capture; in the default (global)
+            # mode any such call from another thread invalidates the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss, self.loss_dic = forward_backward(model, loss_func, optimizer, self.static, args, dat_name)
         else:
             optimizer.prepare_step()
