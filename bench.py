@@ -105,7 +105,7 @@ def main():
     rank, local_rank, world = hdist.init_process_group_from_env()
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP hot path has no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     # Work on a non-default stream from the start: autograd pins each parameter's gradient accumulation to the stream
     # of its first use, and a step that ever ran on the legacy default stream cannot be captured into a hipGraph later

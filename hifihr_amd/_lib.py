@@ -115,6 +115,8 @@ class HifihrLib:
         c.hifihr_wino_input_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
         c.hifihr_wino_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_wino_output_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
+        c.hifihr_conv2d_bwd_data_pre.argtypes = [_c_float_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_weight_prep.argtypes = [c_void_p, c_int, c_int, c_void_p]
         c.hifihr_freihand_augment.argtypes = [c_void_p, c_void_p, _c_int_p, _c_int_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_procrustes_error.argtypes = [_c_float_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_wino_output_transform_act.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
@@ -287,6 +289,21 @@ class HifihrLib:
 
     def wino_gemm(self, V, U, M, N, H, W, C, K, ws=None):
         self.check(self.c.hifihr_wino_gemm(_fp(V), _fp(U), _fp(M), N, H, W, C, K, *self._ws(ws), _stream_of(V)), "hifihr_wino_gemm")
+
+    def conv2d_bwd_data_pre(self, dy, wt, dx, N, H, W, C, K, R, S, stride, pad, ws=None):
+        wsp, wsb = self._ws(ws)
+        self.check(self.c.hifihr_conv2d_bwd_data_pre(_fp(dy), _fp(wt), _fp(dx), N, H, W, C, K, R, S, stride, pad, wsp, wsb, _stream_of(dy)),
+                   "hifihr_conv2d_bwd_data_pre")
+
+    @staticmethod
+    def prep_jobs(jobs, device):
+        """[(src tensor, dst tensor, K, C, RS, kind)] -> device table of hifihr_prep_job (two pointers + four ints = 32 bytes)."""
+        import struct
+        raw = b"".join(struct.pack("<QQiiii", s.data_ptr(), d.data_ptr(), K, C, RS, kind) for s, d, K, C, RS, kind in jobs)
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+    def weight_prep(self, table, njobs, blocks_per_job=64):
+        self.check(self.c.hifihr_weight_prep(c_void_p(table.data_ptr()), njobs, blocks_per_job, _stream_of(table)), "hifihr_weight_prep")
 
     def freihand_augment(self, img_rgbx, mask, idx, coef_fix, out_img, out_mask):
         """img_rgbx int32/uint8x4 [n,H,W], mask uint8 [n,H,W] (either None with its output), idx int32 [B], coef_fix int32 [B,6]."""

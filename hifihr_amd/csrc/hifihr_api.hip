@@ -291,6 +291,23 @@ int hifihr_conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt
   return HIFIHR_OK;
 }
 
+int hifihr_conv2d_bwd_data_pre(const float* dy, const float* wt, float* dx, int N, int H, int W, int C, int K, int R, int S, int stride,
+                               int pad, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !wt || !dx || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || K % 4 || (K % 16 && stride != 1))
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_data_pre: bad argument (K % 4 == 0; K % 16 == 0 when stride > 1)");
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+  hifihr::ConvGeom g{N, OH, OW, K, H, W, C, R, S, stride, pad, 1};
+  HIP_TRY(hifihr::launch_conv_igemm(g, dy, wt, nullptr, dx, nullptr, ws, ws_bytes, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_weight_prep(const hifihr_prep_job* jobs, int njobs, int blocks_per_job, void* stream) {
+  static_assert(sizeof(hifihr_prep_job) == sizeof(hifihr::PrepJob), "hifihr_prep_job layout");
+  if (!jobs || njobs <= 0 || blocks_per_job <= 0) return fail(HIFIHR_EINVAL, "hifihr_weight_prep: bad argument");
+  HIP_TRY(hifihr::launch_weight_prep(reinterpret_cast<const hifihr::PrepJob*>(jobs), njobs, blocks_per_job, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, void* stream) {
   if (!x || !dy || !dw || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4 || K % 4)

@@ -151,6 +151,14 @@ hipError_t launch_se_scale(const float* x, const float* gate, const float* add, 
 // Winograd F(2x2, 3x3) glue (wino.hip)
 hipError_t launch_wino_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st);
 hipError_t launch_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, hipStream_t st);
+// one per-step weight re-layout job (include/hifihr.h: hifihr_weight_prep); kind 0: [K][RS][C] -> [C][RS][K], 1: Winograd U[16][K][C],
+// 2: Winograd U'[16][C][K] of the transposed, rotated 3x3 filter (backward-data)
+struct PrepJob {
+  const float* src;
+  float* dst;
+  int K, C, RS, kind;
+};
+hipError_t launch_weight_prep(const PrepJob* jobs, int njobs, int blocks_per_job, hipStream_t st);
 hipError_t launch_freihand_augment(const uint32_t* img, const uint8_t* mask, const int* idx, const int* coef, int B, int H, int W,
                                    float* out_img, float* out_mask, hipStream_t st);
 hipError_t launch_procrustes(const float* pred, const float* gt, int B, int N, float* aligned, float* err_sum, hipStream_t st);

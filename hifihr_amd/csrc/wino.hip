@@ -21,11 +21,37 @@ namespace hifihr {
 __device__ __forceinline__ float4 add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 sub4(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-// thread = (output channel k, 4 input channels); w[K][3][3][C] -> U[16][K][C]
-__global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int flip) {
+// u = G g G^T for one (k, 4 channels) column of 3x3 taps, stored to U[pos][k][c..c+3] (row stride `ld` floats between k)
+__device__ __forceinline__ void wino_weight_tile(const float4 (&g)[3][3], float* __restrict__ U, size_t plane, size_t off) {
+  // t = G g (4x3), u = t G^T (4x4);  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+  float4 t[4][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const float4 sum02 = add4(g[0][s], g[2][s]);
+    t[0][s] = g[0][s];
+    t[1][s] = make_float4(0.5f * (sum02.x + g[1][s].x), 0.5f * (sum02.y + g[1][s].y), 0.5f * (sum02.z + g[1][s].z), 0.5f * (sum02.w + g[1][s].w));
+    t[2][s] = make_float4(0.5f * (sum02.x - g[1][s].x), 0.5f * (sum02.y - g[1][s].y), 0.5f * (sum02.z - g[1][s].z), 0.5f * (sum02.w - g[1][s].w));
+    t[3][s] = g[2][s];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float4 sum02 = add4(t[r][0], t[r][2]);
+    float4 u[4];
+    u[0] = t[r][0];
+    u[1] = make_float4(0.5f * (sum02.x + t[r][1].x), 0.5f * (sum02.y + t[r][1].y), 0.5f * (sum02.z + t[r][1].z), 0.5f * (sum02.w + t[r][1].w));
+    u[2] = make_float4(0.5f * (sum02.x - t[r][1].x), 0.5f * (sum02.y - t[r][1].y), 0.5f * (sum02.z - t[r][1].z), 0.5f * (sum02.w - t[r][1].w));
+    u[3] = t[r][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(U + (size_t)(r * 4 + c) * plane + off) = u[c];
+  }
+}
+
+// thread = (output channel k, 4 input channels); w[K][3][3][C] -> U[16][K][C]   (bid / nblk: this job's block index / count)
+__device__ __forceinline__ void wino_weight_transform_body(const float* __restrict__ w, float* __restrict__ U, int K, int C, int flip,
+                                                           unsigned bid, unsigned nblk) {
   const int C4 = C / 4;
   const size_t total = (size_t)K * C4;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+  for (size_t i = (size_t)bid * 256 + threadIdx.x; i < total; i += (size_t)nblk * 256) {
     const int cg = (int)(i % C4), k = (int)(i / C4);
     float4 g[3][3];
 #pragma unroll
@@ -35,28 +61,71 @@ __global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float*
         const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
         g[r][s] = *reinterpret_cast<const float4*>(w + (((size_t)k * 3 + rr) * 3 + ss) * C + cg * 4);
       }
-    // t = G g (4x3), u = t G^T (4x4);  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-    float4 t[4][3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const float4 sum02 = add4(g[0][s], g[2][s]);
-      t[0][s] = g[0][s];
-      t[1][s] = make_float4(0.5f * (sum02.x + g[1][s].x), 0.5f * (sum02.y + g[1][s].y), 0.5f * (sum02.z + g[1][s].z), 0.5f * (sum02.w + g[1][s].w));
-      t[2][s] = make_float4(0.5f * (sum02.x - g[1][s].x), 0.5f * (sum02.y - g[1][s].y), 0.5f * (sum02.z - g[1][s].z), 0.5f * (sum02.w - g[1][s].w));
-      t[3][s] = g[2][s];
+    wino_weight_tile(g, U, (size_t)K * C, (size_t)k * C + cg * 4);
+  }
+}
+
+// backward-data weights straight from w[K][3][3][C]: U'[16][C][K] = G g' G^T with g'[c][r][s][k] = w[k][2-r][2-s][c] (the transposed,
+// 180-degree rotated filter) -- the same values wino_weight_transform(flip = 1) computes from the [C][3][3][K] transpose, without
+// materialising it.  A workgroup stages a (64 k) x (16 c) block of w through LDS (coalesced 64-byte runs along c), then thread
+// (4 consecutive k, c) reads its taps from LDS and writes float4 along k: 256 contiguous bytes per 16 lanes.
+constexpr int kWtLd = 17;                                  // padded c stride of the staged block (bank spread)
+__device__ __forceinline__ void wino_weight_transform_t_body(const float* __restrict__ w, float* __restrict__ U, int K, int C, unsigned bid,
+                                                             unsigned nblk, float* __restrict__ lds /* [64 * 9 * kWtLd] */) {
+  const int kt = (K + 63) / 64, ct = (C + 15) / 16;
+  for (int tile = (int)bid; tile < kt * ct; tile += (int)nblk) {
+    const int k0 = (tile % kt) * 64, c0 = (tile / kt) * 16;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 9 * 4; i += 256) {           // row = (k, rs), 4 float4 per row
+      const int q = i & 3, row = i >> 2;
+      const int k = k0 + row / 9, c = c0 + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K && c < C) v = *reinterpret_cast<const float4*>(w + ((size_t)k * 9 + row % 9) * C + c);
+      float* d = lds + row * kWtLd + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
+    __syncthreads();
+    const int kg = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int k = k0 + kg * 4, c = c0 + cl;
+    if (k < K && c < C) {
+      float4 g[3][3];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float4 sum02 = add4(t[r][0], t[r][2]);
-      float4 u[4];
-      u[0] = t[r][0];
-      u[1] = make_float4(0.5f * (sum02.x + t[r][1].x), 0.5f * (sum02.y + t[r][1].y), 0.5f * (sum02.z + t[r][1].z), 0.5f * (sum02.w + t[r][1].w));
-      u[2] = make_float4(0.5f * (sum02.x - t[r][1].x), 0.5f * (sum02.y - t[r][1].y), 0.5f * (sum02.z - t[r][1].z), 0.5f * (sum02.w - t[r][1].w));
-      u[3] = t[r][2];
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(U + ((size_t)(r * 4 + c) * K + k) * C + cg * 4) = u[c];
+        for (int s2 = 0; s2 < 3; ++s2) {
+          const float* p = lds + ((kg * 4) * 9 + (2 - r) * 3 + (2 - s2)) * kWtLd + cl;
+          g[r][s2] = make_float4(p[0], p[9 * kWtLd], p[18 * kWtLd], p[27 * kWtLd]);
+        }
+      wino_weight_tile(g, U, (size_t)C * K, (size_t)c * K + k);
     }
   }
+}
+
+// [K][RS][C] -> [C][RS][K]
+__device__ __forceinline__ void weight_transpose_body(const float* __restrict__ w, float* __restrict__ wt, int K, int RS, int C, unsigned bid,
+                                                      unsigned nblk) {
+  const size_t n = (size_t)K * RS * C;
+  for (size_t i = (size_t)bid * 256 + threadIdx.x; i < n; i += (size_t)nblk * 256) {
+    const int k = (int)(i % K);
+    const size_t rest = i / K;
+    const int rs = (int)(rest % RS);
+    const int c = (int)(rest / RS);
+    wt[i] = w[((size_t)k * RS + rs) * C + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int flip) {
+  wino_weight_transform_body(w, U, K, C, flip, blockIdx.x, gridDim.x);
+}
+
+// Every per-step weight re-layout of a model in ONE launch (the weights change once per step, the ~40 separate transposes /
+// transforms of a ResNet-18 step cost ~5 us of launch floor each): blockIdx.y = job, blockIdx.x strides over the job's elements.
+__global__ __launch_bounds__(256) void weight_prep_kernel(const PrepJob* __restrict__ jobs) {
+  __shared__ float lds[64 * 9 * kWtLd];
+  const PrepJob j = jobs[blockIdx.y];
+  if (j.kind == 0) weight_transpose_body(j.src, j.dst, j.K, j.RS, j.C, blockIdx.x, gridDim.x);
+  else if (j.kind == 1) wino_weight_transform_body(j.src, j.dst, j.K, j.C, 0, blockIdx.x, gridDim.x);
+  else wino_weight_transform_t_body(j.src, j.dst, j.K, j.C, blockIdx.x, gridDim.x, lds);
 }
 
 // thread = (tile, 4 channels); x[N][H][W][C] -> V[16][T][C]
@@ -247,6 +316,12 @@ static unsigned wino_grid(size_t total) {
 hipError_t launch_wino_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st) {
   if (C % 4 != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(wino_weight_transform_kernel, dim3(wino_grid((size_t)K * (C / 4))), dim3(256), 0, st, w, U, K, C, flip);
+  return hipGetLastError();
+}
+
+hipError_t launch_weight_prep(const PrepJob* jobs, int njobs, int blocks_per_job, hipStream_t st) {
+  if (njobs <= 0 || njobs > 65535 || blocks_per_job <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(weight_prep_kernel, dim3((unsigned)blocks_per_job, (unsigned)njobs), dim3(256), 0, st, jobs);
   return hipGetLastError();
 }
 

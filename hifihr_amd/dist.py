@@ -26,7 +26,9 @@ def init_process_group_from_env(backend: str | None = None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # HIFIHR_DIST_BACKEND=gloo: functional runs of the multi-process path on fewer GPUs than ranks (RCCL refuses two ranks
+            # on one device); never used for measurements
+            backend = os.environ.get("HIFIHR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

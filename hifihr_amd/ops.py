@@ -280,13 +280,74 @@ def _wino_ok(C, K, R, S, stride, pad):
     return R == 3 and S == 3 and stride == 1 and pad == 1 and C >= 128 and K >= 128 and C % 32 == 0 and K % 32 == 0
 
 
-def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0):
+class _WeightPrep:
+    """The per-step re-layouts of convolution weights (transpose for backward-data, Winograd U / U') as ONE launch
+    (hifihr_weight_prep) instead of ~40 tiny ones.  The weights change once per optimizer step, so the step brackets its forward
+    and backward in `prepared_weights()`: on entry every re-layout registered so far is recomputed into per-layer buffers, inside
+    the scope the convolutions pick those up (`get`), outside it (plain op calls, evaluation) they launch their own transform
+    as before.  A layer seen for the first time registers itself and is served from the next scope on."""
+
+    def __init__(self):
+        self.entries = {}          # (data_ptr, kind) -> [parameter, K, C, RS, kind, buffer]
+        self.table, self.njobs, self.dirty, self.active, self.served = None, 0, False, False, set()
+
+    def get(self, w, wk, kind):
+        """The prepared buffer of `kind` for the parameter `w` (physical [K][R][S][C] = wk), or None (caller does it itself)."""
+        if not isinstance(w, torch.nn.Parameter) or wk.data_ptr() != w.data_ptr():
+            return None                                        # temporaries (the padded stem weight) have no stable address
+        key = (w.data_ptr(), kind)
+        e = self.entries.get(key)
+        if e is None:
+            K, C, R, S = w.shape
+            n = K * C * R * S * (1 if kind == 0 else 16) // (1 if kind == 0 else 9)
+            self.entries[key] = [w, K, C, R * S, kind, torch.empty(n, device=w.device, dtype=torch.float32)]
+            self.dirty = True
+            return None
+        return e[5] if (self.active and key in self.served) else None
+
+    def begin(self):
+        live = {k: e for k, e in self.entries.items() if e[0].data_ptr() == k[0]}      # parameters re-homed since (FlatParams)
+        if len(live) != len(self.entries):
+            self.entries, self.dirty = live, True
+        if not self.entries:
+            return
+        lib = get_lib()
+        if self.dirty:
+            jobs = [(e[0], e[5], e[1], e[2], e[3], e[4]) for e in self.entries.values()]
+            self.table, self.njobs = lib.prep_jobs(jobs, jobs[0][0].device), len(jobs)
+            self.served, self.dirty = set(self.entries.keys()), False
+        PROFILE.bracket("weight_prep", lambda: lib.weight_prep(self.table, self.njobs, 256))
+        self.active = True
+
+    def end(self):
+        self.active = False
+
+
+_WEIGHT_PREP = _WeightPrep()
+
+
+class prepared_weights:
+    """`with prepared_weights():` around forward + backward of one step (hifihr_amd/traineval.forward_backward)."""
+
+    def __enter__(self):
+        if os.environ.get("HIFIHR_WEIGHT_PREP", "1") != "0":
+            _WEIGHT_PREP.begin()
+        return self
+
+    def __exit__(self, *exc):
+        _WEIGHT_PREP.end()
+        return False
+
+
+def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None):
     """y[N][H][W][K] = conv3x3(x[N][H][W][C], w[K][3][3][C]) through weight / input transform, 16 batched GEMMs, output
     transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter).
     keep_v: return the transformed input V[16][T][C] in a tensor of its own (the Winograd weight gradient consumes it)."""
     dev = x.device
     T = N * ((H + 1) // 2) * ((W + 1) // 2)
-    U = _wino_scratch(dev, "U", 16 * K * C)
+    prepared = U is not None                          # Winograd-domain weights already computed by the step's weight_prep launch
+    if not prepared:
+        U = _wino_scratch(dev, "U", 16 * K * C)
     V = torch.empty(16 * T * C, device=dev, dtype=torch.float32) if keep_v else _wino_scratch(dev, "V", 16 * T * C)
     M = _wino_scratch(dev, "M", 16 * T * K)
     key = ("wino", N, H, W, C, K)
@@ -302,7 +363,8 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias
             _CONV_WS[dev] = ws
     if PROFILE.on:
         PROFILE.conv_log.append((("wino", N, H, W, C, K), "gemm"))
-    lib.wino_weight_transform(w_krsc, U, K, C, flip)
+    if not prepared:
+        lib.wino_weight_transform(w_krsc, U, K, C, flip)
     lib.wino_input_transform(x, V, N, H, W, C)
     lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)
     lib.wino_output_transform(M, y, stats, N, H, W, K, bias=bias, act=act)
@@ -328,8 +390,9 @@ class _Conv2dMFMA(torch.autograd.Function):
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device) if want_stats else None
             keep = bool(ctx.needs_input_grad[1])
             box = []
+            U = _WEIGHT_PREP.get(w, wk, 1)
             PROFILE.bracket("conv_fwd_wino", lambda: box.append(_wino_conv(lib, x, wk, y, stats, N, H, W, C, K, 0, keep_v=keep,
-                                                                            bias=bias, act=1 if relu else 0)))
+                                                                            bias=bias, act=1 if relu else 0, U=U)))
             v_saved = box[0]
         elif want_stats:       # per-channel sum / sum of squares of y from the conv epilogue, for the batch-norm that follows
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device)
@@ -377,19 +440,27 @@ class _Conv2dMFMA(torch.autograd.Function):
         if ctx.needs_input_grad[0] and _wino_ok(C, K, R, S, stride, pad):
             # backward-data of a stride-1 3x3 = the same Winograd pipeline on dy with the transposed, rotated filter
             dx = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32, memory_format=_CL)
-            wt = _wino_scratch(gy.device, "wt", wk.numel())
+            U2 = _WEIGHT_PREP.get(ctx.w_param, wk, 2)
 
             def run():
-                lib.weight_transpose(wk, wt, K, R * S, C)
-                _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1)
+                if U2 is not None:
+                    _wino_conv(lib, gy, None, dx, None, N, H, W, K, C, 1, U=U2)
+                else:
+                    wt = _wino_scratch(gy.device, "wt", wk.numel())
+                    lib.weight_transpose(wk, wt, K, R * S, C)
+                    _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1)
             PROFILE.bracket("conv_dgrad_wino", run)
         elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=_CL)
-            scratch = torch.empty(wk.numel(), device=x.device, dtype=torch.float32)
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), True)
             if PROFILE.on:
                 PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "dgrad"))
-            PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data(gy, wk, dx, scratch, N, H, W, C, K, R, S, stride, pad, ws=ws))
+            wt = _WEIGHT_PREP.get(ctx.w_param, wk, 0)
+            if wt is not None:                     # [C][R][S][K] transpose from the step's weight_prep launch
+                PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data_pre(gy, wt, dx, N, H, W, C, K, R, S, stride, pad, ws=ws))
+            else:
+                scratch = torch.empty(wk.numel(), device=x.device, dtype=torch.float32)
+                PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data(gy, wk, dx, scratch, N, H, W, C, K, R, S, stride, pad, ws=ws))
         if ctx.needs_input_grad[1]:
             w = ctx.w_param
             tgt = w.grad if (getattr(w, "_hifihr_direct_grad", False) and w.grad is not None

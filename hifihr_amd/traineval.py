@@ -81,6 +81,12 @@ def data_dic(sample, dat_name, set_name, args, device="cuda"):
 
 def forward_backward(model, loss_func, optimizer, examples, args, dat_name="FreiHand"):
     """Forward, losses, zero_grad and backward of one iteration (train_hrnet.py:50-104).  Returns (loss, loss_dic)."""
+    from .ops import prepared_weights
+    with prepared_weights():                 # one launch re-lays every convolution weight out for this step (ops._WeightPrep)
+        return _forward_backward(model, loss_func, optimizer, examples, args, dat_name)
+
+
+def _forward_backward(model, loss_func, optimizer, examples, args, dat_name):
     root_xyz = examples["joints"][:, args.ROOT, :].unsqueeze(1)
     outputs = model(dat_name, True, examples["imgs"], Ks=examples["Ps"], root_xyz=root_xyz)
     ex = dict(examples)

@@ -189,6 +189,22 @@ int hifihr_wino_output_transform_act(const float* m_d, float* y_d, const float* 
                                      int K, void* stream);
 /* [K][RS][C] -> [C][RS][K] (the transpose backward-data consumes). */
 int hifihr_weight_transpose(const float* w_d, float* wt_d, int K, int RS, int C, void* stream);
+/* hifihr_conv2d_bwd_data on weights that are ALREADY transposed to [C][R][S][K] (hifihr_weight_transpose / hifihr_weight_prep). */
+int hifihr_conv2d_bwd_data_pre(const float* dy_d, const float* wt_d, float* dx_d, int N, int H, int W, int C, int K, int R, int S,
+                               int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
+/* Every per-step weight re-layout of a model in ONE launch.  The weights change once per optimizer step; a ResNet-18 step
+ * otherwise spends ~40 tiny launches (~5 us of launch floor each) on transposes and Winograd weight transforms.
+ * jobs_d: DEVICE array of njobs descriptors (src / dst are device pointers);
+ *   kind 0: dst[C][RS][K] = transpose of src[K][RS][C]                                   (= hifihr_weight_transpose)
+ *   kind 1: dst = U[16][K][C] of src[K][3][3][C]                                         (= hifihr_wino_weight_transform, flip 0)
+ *   kind 2: dst = U'[16][C][K], the backward-data weights of src[K][3][3][C]              (= weight_transpose + transform, flip 1)
+ * blocks_per_job: workgroups per job (each job is a grid-stride loop). */
+typedef struct hifihr_prep_job {
+  const float* src;
+  float* dst;
+  int K, C, RS, kind;
+} hifihr_prep_job;
+int hifihr_weight_prep(const hifihr_prep_job* jobs_d, int njobs, int blocks_per_job, void* stream);
 
 /* conv2d_fwd that also accumulates the per-channel sum and sum of squares of y into stats_d (hifihr_bn_stats_floats(K)
  * floats, ALL ZERO on entry: see the self-cleaning rule below) from the accumulator registers, so the batch-norm that

@@ -775,3 +775,27 @@ def augment_case(lib, device, golden_dir):
         assert torch.equal(out_i[1].cpu(), torch.from_numpy(img).permute(2, 0, 1).float().div(255)), "identity warp"
         # K and joints (data/dataset.py:258-260, 271-275)
         np.testing.assert_array_equal(post.dot(g[f"K{i}"]).astype(np.float32), g[f"tK{i}"])
+
+
+# ------------------------------------------------------------------------------------------------
+# one-launch weight re-layout (hifihr_weight_prep) == the separate transpose / Winograd weight transforms, bit for bit
+# ------------------------------------------------------------------------------------------------
+def weight_prep_case(lib, device, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    shapes = [(32, 64, 3), (64, 32, 3), (48, 16, 1), (16, 4, 7), (128, 128, 3)]
+    jobs, want = [], []
+    for K, C, R in shapes:
+        w = torch.randn(K, R, R, C, generator=gen).to(device)
+        wt = torch.empty(C, R, R, K, device=device)
+        lib.weight_transpose(w, wt, K, R * R, C)
+        jobs.append((w, torch.full((K * R * R * C,), 7.0, device=device), K, C, R * R, 0)); want.append(wt.reshape(-1))
+        if R == 3:
+            U = torch.empty(16 * K * C, device=device); U2 = torch.empty(16 * K * C, device=device)
+            lib.wino_weight_transform(w, U, K, C, 0)
+            lib.wino_weight_transform(wt, U2, C, K, 1)
+            jobs.append((w, torch.full((16 * K * C,), 7.0, device=device), K, C, 9, 1)); want.append(U)
+            jobs.append((w, torch.full((16 * K * C,), 7.0, device=device), K, C, 9, 2)); want.append(U2)
+    table = lib.prep_jobs(jobs, device)
+    lib.weight_prep(table, len(jobs), 3)
+    for (_, dst, K, C, RS, kind), ref in zip(jobs, want):
+        assert torch.equal(dst.cpu(), ref.cpu()), (K, C, RS, kind)

@@ -124,3 +124,7 @@ def test_balanced_schedule_bnstats(lib):
 def test_winograd_path(lib, N, H, C, K):
     """Winograd F(2x2, 3x3) forward and backward-data (the layers 2-4 path) vs torch conv2d."""
     kc.wino_case(lib, "cuda", N, H, H, C, K, seed=C + K)
+
+
+def test_weight_prep_equals_separate_transforms(lib):
+    kc.weight_prep_case(lib, "cuda")

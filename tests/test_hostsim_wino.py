@@ -12,3 +12,7 @@ def hostsim_lib():
 @pytest.mark.parametrize("N,H,W,C,K", [(2, 6, 6, 32, 64), (1, 7, 5, 64, 32), (3, 4, 4, 32, 96)])
 def test_winograd_fwd_bwd(hostsim_lib, N, H, W, C, K):
     kc.wino_case(hostsim_lib, "cpu", N, H, W, C, K, seed=C + K)
+
+
+def test_weight_prep_equals_separate_transforms(hostsim_lib):
+    kc.weight_prep_case(hostsim_lib, "cpu")

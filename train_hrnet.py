@@ -113,7 +113,7 @@ def main(argv=None):
 
     rank, local_rank, world = hdist.init_process_group_from_env()
     assert torch.cuda.is_available(), "the hot path has no CPU fallback"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     torch.cuda.set_stream(torch.cuda.Stream(device=device))            # see GraphedTrainStep: never step on the legacy default stream
     args.device = device
