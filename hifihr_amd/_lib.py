@@ -115,6 +115,7 @@ class HifihrLib:
         c.hifihr_wino_input_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
         c.hifihr_wino_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_wino_output_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
+        c.hifihr_wino_input_dy_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
         c.hifihr_conv2d_bwd_data_pre.argtypes = [_c_float_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_weight_prep.argtypes = [c_void_p, c_int, c_int, c_void_p]
         c.hifihr_freihand_augment.argtypes = [c_void_p, c_void_p, _c_int_p, _c_int_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
@@ -289,6 +290,9 @@ class HifihrLib:
 
     def wino_gemm(self, V, U, M, N, H, W, C, K, ws=None):
         self.check(self.c.hifihr_wino_gemm(_fp(V), _fp(U), _fp(M), N, H, W, C, K, *self._ws(ws), _stream_of(V)), "hifihr_wino_gemm")
+
+    def wino_input_dy_transform(self, dy, V, Yt, N, H, W, K):
+        self.check(self.c.hifihr_wino_input_dy_transform(_fp(dy), _fp(V), _fp(Yt), N, H, W, K, _stream_of(dy)), "hifihr_wino_input_dy_transform")
 
     def conv2d_bwd_data_pre(self, dy, wt, dx, N, H, W, C, K, R, S, stride, pad, ws=None):
         wsp, wsb = self._ws(ws)

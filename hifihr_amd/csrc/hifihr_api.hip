@@ -594,7 +594,7 @@ int hifihr_wino_weight_transform(const float* w, float* U, int K, int C, int fli
 
 int hifihr_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream) {
   if (!x || !V || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_input_transform: bad argument");
-  HIP_TRY(hifihr::launch_wino_input_transform(x, V, N, H, W, C, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_wino_input_transform(x, V, nullptr, N, H, W, C, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
@@ -637,6 +637,13 @@ int hifihr_freihand_augment(const uint32_t* img_rgbx, const uint8_t* mask, const
   if (!idx || !coef_fix || (!out_img && !out_mask) || (out_img && !img_rgbx) || (out_mask && !mask) || B <= 0 || H <= 0 || W <= 0)
     return fail(HIFIHR_EINVAL, "hifihr_freihand_augment: bad argument");
   HIP_TRY(hifihr::launch_freihand_augment(img_rgbx, mask, idx, coef_fix, B, H, W, out_img, out_mask, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_input_dy_transform(const float* dy, float* V, float* Yt, int N, int H, int W, int K, void* stream) {
+  if (!dy || !V || !Yt || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_input_dy_transform: bad argument");
+  HIP_TRY(hifihr::launch_wino_input_transform(dy, V, Yt, N, H, W, K, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

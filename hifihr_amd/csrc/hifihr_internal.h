@@ -150,7 +150,7 @@ hipError_t launch_se_scale(const float* x, const float* gate, const float* add, 
 
 // Winograd F(2x2, 3x3) glue (wino.hip)
 hipError_t launch_wino_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st);
-hipError_t launch_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, hipStream_t st);
+hipError_t launch_wino_input_transform(const float* x, float* V, float* Y /* or nullptr */, int N, int H, int W, int C, hipStream_t st);
 // one per-step weight re-layout job (include/hifihr.h: hifihr_weight_prep); kind 0: [K][RS][C] -> [C][RS][K], 1: Winograd U[16][K][C],
 // 2: Winograd U'[16][C][K] of the transposed, rotated 3x3 filter (backward-data)
 struct PrepJob {

@@ -129,8 +129,11 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const PrepJob* __restr
 }
 
 // thread = (tile, 4 channels); x[N][H][W][C] -> V[16][T][C]
-__global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C,
-                                                                  int TH, int TW) {
+// DUAL: x is a gradient dy that backward-data (V = B^T d B of the padded 4x4 patch) AND backward-weight (Y' = A dy A^T of the patch's
+// central 2x2 block = this tile's outputs) both consume: one read of dy produces both (saves the wino_dy_transform launch + pass)
+template <bool DUAL>
+__global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V, float* __restrict__ Y, int N,
+                                                                  int H, int W, int C, int TH, int TW) {
   const int C4 = C / 4;
   const size_t T = (size_t)N * TH * TW, total = T * C4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -148,6 +151,25 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* 
         const bool ok = rok && iw >= 0 && iw < W;
         const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + (rok ? ih : 0)) * W + (ok ? iw : 0)) * C + cg * 4);
         d[r][c] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (DUAL) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 ty[4][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        ty[0][b] = d[1][1 + b];
+        ty[1][b] = add4(d[1][1 + b], d[2][1 + b]);
+        ty[2][b] = sub4(d[1][1 + b], d[2][1 + b]);
+        ty[3][b] = sub4(z, d[2][1 + b]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* o = Y + ((size_t)(r * 4) * T + t) * C + cg * 4;
+        *reinterpret_cast<float4*>(o) = ty[r][0];
+        *reinterpret_cast<float4*>(o + T * C) = add4(ty[r][0], ty[r][1]);
+        *reinterpret_cast<float4*>(o + 2 * T * C) = sub4(ty[r][0], ty[r][1]);
+        *reinterpret_cast<float4*>(o + 3 * T * C) = sub4(z, ty[r][1]);
       }
     }
     // t = B^T d,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1];  v = t B
@@ -325,10 +347,12 @@ hipError_t launch_weight_prep(const PrepJob* jobs, int njobs, int blocks_per_job
   return hipGetLastError();
 }
 
-hipError_t launch_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, hipStream_t st) {
+hipError_t launch_wino_input_transform(const float* x, float* V, float* Y, int N, int H, int W, int C, hipStream_t st) {
   if (C % 4 != 0) return hipErrorInvalidValue;
   const int TH = (H + 1) / 2, TW = (W + 1) / 2;
-  hipLaunchKernelGGL(wino_input_transform_kernel, dim3(wino_grid((size_t)N * TH * TW * (C / 4))), dim3(256), 0, st, x, V, N, H, W, C, TH, TW);
+  const dim3 grid(wino_grid((size_t)N * TH * TW * (C / 4)));
+  if (Y != nullptr) hipLaunchKernelGGL(wino_input_transform_kernel<true>, grid, dim3(256), 0, st, x, V, Y, N, H, W, C, TH, TW);
+  else hipLaunchKernelGGL(wino_input_transform_kernel<false>, grid, dim3(256), 0, st, x, V, Y, N, H, W, C, TH, TW);
   return hipGetLastError();
 }
 

@@ -339,7 +339,7 @@ class prepared_weights:
         return False
 
 
-def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None):
+def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None, dy_out=None):
     """y[N][H][W][K] = conv3x3(x[N][H][W][C], w[K][3][3][C]) through weight / input transform, 16 batched GEMMs, output
     transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter).
     keep_v: return the transformed input V[16][T][C] in a tensor of its own (the Winograd weight gradient consumes it)."""
@@ -365,7 +365,10 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias
         PROFILE.conv_log.append((("wino", N, H, W, C, K), "gemm"))
     if not prepared:
         lib.wino_weight_transform(w_krsc, U, K, C, flip)
-    lib.wino_input_transform(x, V, N, H, W, C)
+    if dy_out is not None:                            # backward: x is dy, the backward-weight transform Y' comes out of the same read
+        lib.wino_input_dy_transform(x, V, dy_out, N, H, W, C)
+    else:
+        lib.wino_input_transform(x, V, N, H, W, C)
     lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)
     lib.wino_output_transform(M, y, stats, N, H, W, K, bias=bias, act=act)
     return V if keep_v else None
@@ -423,7 +426,7 @@ class _Conv2dMFMA(torch.autograd.Function):
         if gy is None:
             return (None,) * 7
         gy = gy.contiguous(memory_format=_CL)
-        dx = dw = db_ret = None
+        dx = dw = db_ret = Yt_done = None
         if ctx.relu or ctx.b_param is not None:
             # conv + bias (+ ReLU) epilogue: masked gradient and the bias gradient in one small launch
             b = ctx.b_param
@@ -441,14 +444,17 @@ class _Conv2dMFMA(torch.autograd.Function):
             # backward-data of a stride-1 3x3 = the same Winograd pipeline on dy with the transposed, rotated filter
             dx = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32, memory_format=_CL)
             U2 = _WEIGHT_PREP.get(ctx.w_param, wk, 2)
+            if ctx.needs_input_grad[1] and v_saved is not None:      # the Winograd backward-weight below wants A dy A^T: same read of dy
+                T = N * ((H + 1) // 2) * ((W + 1) // 2)
+                Yt_done = _wino_scratch(gy.device, "Yt", 16 * T * K)
 
             def run():
                 if U2 is not None:
-                    _wino_conv(lib, gy, None, dx, None, N, H, W, K, C, 1, U=U2)
+                    _wino_conv(lib, gy, None, dx, None, N, H, W, K, C, 1, U=U2, dy_out=Yt_done)
                 else:
                     wt = _wino_scratch(gy.device, "wt", wk.numel())
                     lib.weight_transpose(wk, wt, K, R * S, C)
-                    _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1)
+                    _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1, dy_out=Yt_done)
             PROFILE.bracket("conv_dgrad_wino", run)
         elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=_CL)
@@ -471,7 +477,7 @@ class _Conv2dMFMA(torch.autograd.Function):
             # accumulates (fp32 atomics) straight into the flat gradient buffer when the parameter lives in one
             if v_saved is not None:
                 T = N * ((H + 1) // 2) * ((W + 1) // 2)
-                Yt = _wino_scratch(gy.device, "Yt", 16 * T * K)
+                Yt = Yt_done if Yt_done is not None else _wino_scratch(gy.device, "Yt", 16 * T * K)
                 key = (gy.device, "dU", 16 * K * C)
                 dU = _WINO_SCRATCH.get(key)
                 if dU is None:                                   # zero-initialised once; wino_dw_transform hands it back zeroed
@@ -479,7 +485,8 @@ class _Conv2dMFMA(torch.autograd.Function):
                     _WINO_SCRATCH[key] = dU
 
                 def run_w():
-                    lib.wino_dy_transform(gy, Yt, N, H, W, K)
+                    if Yt_done is None:
+                        lib.wino_dy_transform(gy, Yt, N, H, W, K)
                     lib.wino_wgrad_gemm(v_saved, Yt, dU, N, H, W, C, K)
                     lib.wino_dw_transform(dU, tgt, K, C, clear=True)
                 PROFILE.bracket("conv_wgrad_wino", run_w)

@@ -183,6 +183,9 @@ int hifihr_wino_input_transform(const float* x_d, float* v_d, int N, int H, int 
 int hifihr_wino_gemm(const float* v_d, const float* u_d, float* m_d, int N, int H, int W, int C, int K, void* ws_d, size_t ws_bytes,
                      void* stream);
 int hifihr_wino_output_transform(const float* m_d, float* y_d, float* stats_d /* or NULL */, int N, int H, int W, int K, void* stream);
+/* Backward of a Winograd layer reads dy twice (input transform for backward-data, hifihr_wino_dy_transform for backward-weight);
+ * this does both from one read: v_d[16][T][K] = B^T d B of the padded 4x4 patches, yt_d[16][T][K] = A dy A^T of their central 2x2. */
+int hifihr_wino_input_dy_transform(const float* dy_d, float* v_d, float* yt_d, int N, int H, int W, int K, void* stream);
 /* Output transform with the act epilogue of hifihr_conv2d_fwd: y = act(A^T m A + bias[K] (or NULL)), act 0 = none, 1 = ReLU
  * (VGG19 layers of the perceptual loss, reference utils/perceptual_loss.py:27-36). */
 int hifihr_wino_output_transform_act(const float* m_d, float* y_d, const float* bias_d /* or NULL */, int act, int N, int H, int W,

@@ -699,6 +699,11 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
     dx = torch.full((N, H, W, C), 7.0, device=device)
     lib.wino_weight_transform(wt, U2, C, K, 1)
     lib.wino_input_transform(gyd, V2, N, H, W, K)
+    # one read of dy for both backward transforms == the two separate kernels, bit for bit
+    V2b = torch.full_like(V2, 7.0); Ytb = torch.full((16, T, K), 7.0, device=device); Yt_ref = torch.empty(16, T, K, device=device)
+    lib.wino_input_dy_transform(gyd, V2b, Ytb, N, H, W, K)
+    lib.wino_dy_transform(gyd, Yt_ref, N, H, W, K)
+    assert torch.equal(V2b, V2) and torch.equal(Ytb, Yt_ref), "dual dy transform"
     lib.wino_gemm(V2, U2, M2, N, H, W, K, C, ws=ws)
     lib.wino_output_transform(M2, dx, None, N, H, W, C)
     refx = xr.grad.permute(0, 2, 3, 1)
