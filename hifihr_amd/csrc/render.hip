@@ -180,6 +180,50 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
   const int px = ox + tx, py = oy + ty;
   const bool live = (px < H) && (py < H);
   const int cols = min(kTile, H - ox), rows = min(kTile, H - oy);      // pixel columns / rows of the tile inside the image
+  const float4* vb = vndc + (size_t)b * r.V;
+  // ---- early out: a tile that the mesh's screen bounding box misses is background.  Most tiles of a hand image are (the hand
+  // covers ~1/4 of it), and finding that out by culling all F faces costs 3 dependent gathers per face; the V vertices are one
+  // coalesced pass (V/256 loads per lane).  Non-finite coordinates (a vertex on the camera plane) disable the shortcut.
+  {
+    float bx0 = 3.4e38f, bx1 = -3.4e38f, by0 = 3.4e38f, by1 = -3.4e38f;
+    bool bad = false;
+    for (int v = tid; v < r.V; v += 256) {
+      const float4 p = vb[v];
+      bad |= !(fabsf(p.x) <= 3.0e38f && fabsf(p.y) <= 3.0e38f);      // false for NaN and +-inf
+      bx0 = fminf(bx0, p.x); bx1 = fmaxf(bx1, p.x); by0 = fminf(by0, p.y); by1 = fmaxf(by1, p.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      bx0 = fminf(bx0, __shfl_down(bx0, o, 64)); bx1 = fmaxf(bx1, __shfl_down(bx1, o, 64));
+      by0 = fminf(by0, __shfl_down(by0, o, 64)); by1 = fmaxf(by1, __shfl_down(by1, o, 64));
+    }
+    const bool wave_bad = __ballot(bad) != 0ull;
+    if (lane == 0) { L.rec[wave * 5] = bx0; L.rec[wave * 5 + 1] = bx1; L.rec[wave * 5 + 2] = by0; L.rec[wave * 5 + 3] = by1; L.rec[wave * 5 + 4] = wave_bad ? 1.f : 0.f; }
+    __syncthreads();
+    bx0 = fminf(fminf(L.rec[0], L.rec[5]), fminf(L.rec[10], L.rec[15])); bx1 = fmaxf(fmaxf(L.rec[1], L.rec[6]), fmaxf(L.rec[11], L.rec[16]));
+    by0 = fminf(fminf(L.rec[2], L.rec[7]), fminf(L.rec[12], L.rec[17])); by1 = fmaxf(fmaxf(L.rec[3], L.rec[8]), fmaxf(L.rec[13], L.rec[18]));
+    const bool any_bad = (L.rec[4] + L.rec[9] + L.rec[14] + L.rec[19]) != 0.f;
+    __syncthreads();                                                   // rec is reused by the face list below
+    // NDC bounds of the tile's samples (index 0 is the largest coordinate), as sxs / sys hold them below
+    const float thx = pix_to_ndc(S - 1 - min(ox * AA, S - 1), S), tlx = pix_to_ndc(S - 1 - min(ox * AA + cols * AA - 1, S - 1), S);
+    const float thy = pix_to_ndc(S - 1 - min(oy * AA, S - 1), S), tly = pix_to_ndc(S - 1 - min(oy * AA + rows * AA - 1, S - 1), S);
+    if (!any_bad && (bx0 > thx || bx1 < tlx || by0 > thy || by1 < tly)) {
+      if (!live) return;
+      float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < AA; ++i)
+#pragma unroll
+        for (int j = 0; j < AA; ++j) {
+          face_id[((size_t)b * S + (py * AA + i)) * S + (px * AA + j)] = -1;
+          acc[0] += r.bg[0]; acc[1] += r.bg[1]; acc[2] += r.bg[2];          // the same sums the full path forms: bit-identical output
+        }
+      const float inv = (float)(AA * AA);
+      const size_t plane = (size_t)H * H;
+      float* o = rgba + (size_t)b * 4 * plane + (size_t)py * H + px;
+      o[0] = acc[0] / inv; o[plane] = acc[1] / inv; o[2 * plane] = acc[2] / inv; o[3 * plane] = 0.f / inv;
+      return;
+    }
+  }
   // NDC coordinates of the tile's samples (indices past the image edge are clamped; they are never candidates)
   for (int e = tid; e < 2 * SW; e += 256) {
     const int idx = e < SW ? e : e - SW;
@@ -194,7 +238,6 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
   const float txhi = L.sxs[0], txlo = L.sxs[cols * AA - 1];
   const float tyhi = L.sys[0], tylo = L.sys[rows * AA - 1];
 
-  const float4* vb = vndc + (size_t)b * r.V;
   for (int base = 0; base < r.F; base += 256) {
     // ---- cull one chunk of 256 faces against the tile; ordered compaction into LDS ----
     const int f = base + tid;
