@@ -261,12 +261,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
 }
 
-// g = dy * act'(z); z (needed by swish only) is recomputed from x: z = (x - mean) * invstd * gamma + beta
+// g = dy * act'(z).  ReLU: the mask is y > 0 read from the forward's output when the layer had a residual input; without one
+// y = max(z, 0) with z = x * sc + sh recomputed from x by the forward's own expression (same bits), so y is not read at all
+// (y == nullptr: a third less traffic in both backward passes).  Swish recomputes z the same way.
 __device__ __forceinline__ float4 masked_grad(int act, const float4& dy, const float* __restrict__ y, size_t o, const float4& v,
                                               const float4& sc, const float4& sh) {
   float4 g = dy;
   if (act == 1) {
-    const float4 yy = *reinterpret_cast<const float4*>(y + o);
+    float4 yy;
+    if (y != nullptr) yy = *reinterpret_cast<const float4*>(y + o);
+    else yy = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
     g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
   } else if (act == 2) {
     g.x *= act_grad(2, v.x * sc.x + sh.x, 0.f); g.y *= act_grad(2, v.y * sc.y + sh.y, 0.f);
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (j < mp.NG && cg * 4 < C && mp.active) {
       mu[j] = *reinterpret_cast<const float4*>(save_mean + cg * 4);
       is[j] = *reinterpret_cast<const float4*>(save_invstd + cg * 4);
-      if (act == 2) {
+      if (act == 2 || (act == 1 && y == nullptr)) {
         const float4 ga = *reinterpret_cast<const float4*>(gamma + cg * 4), be = *reinterpret_cast<const float4*>(beta + cg * 4);
         sc[j] = make_float4(is[j].x * ga.x, is[j].y * ga.y, is[j].z * ga.z, is[j].w * ga.w);
         sh[j] = make_float4(be.x - mu[j].x * sc[j].x, be.y - mu[j].y * sc[j].y, be.z - mu[j].z * sc[j].z, be.w - mu[j].w * sc[j].w);
@@ -355,11 +359,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         mu[j] = *reinterpret_cast<const float4*>(save_mean + cg * 4);
         is[j] = *reinterpret_cast<const float4*>(save_invstd + cg * 4);
         const float4 ga = *reinterpret_cast<const float4*>(gamma + cg * 4);
-        k1[j] = make_float4(ga.x * is[j].x, ga.y * is[j].y, ga.z * is[j].z, ga.w * is[j].w);
+        k1[j] = make_float4(is[j].x * ga.x, is[j].y * ga.y, is[j].z * ga.z, is[j].w * ga.w);
         mg[j] = *reinterpret_cast<const float4*>(&s_mg[cg * 4]);
         mgx[j] = *reinterpret_cast<const float4*>(&s_mgx[cg * 4]);
         sh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act == 2) {
+        if (act == 2 || (act == 1 && y == nullptr)) {
           const float4 be = *reinterpret_cast<const float4*>(beta + cg * 4);
           sh[j] = make_float4(be.x - mu[j].x * k1[j].x, be.y - mu[j].y * k1[j].y, be.z - mu[j].z * k1[j].z, be.w - mu[j].w * k1[j].w);
         }

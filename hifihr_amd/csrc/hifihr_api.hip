@@ -383,9 +383,9 @@ int hifihr_bn_act_fwd(const float* x, float* stats, const float* gamma, const fl
 int hifihr_bn_act_bwd(const float* dy, const float* y, const float* x, const float* save_mean, const float* save_invstd,
                       const float* gamma, const float* beta, int act, long M, int C, float* red_scratch, float* dx, float* dres,
                       float* dgamma_acc, float* dbeta_acc, void* stream) {
-  if (!dy || !x || !save_mean || !save_invstd || !gamma || !red_scratch || !dx || !bn_dims_ok(M, C) || (act == 1 && !y) ||
+  if (!dy || !x || !save_mean || !save_invstd || !gamma || !red_scratch || !dx || !bn_dims_ok(M, C) || (act == 1 && !y && !beta) ||
       (act == 2 && !beta) || act < 0 || act > 2)
-    return fail(HIFIHR_EINVAL, "hifihr_bn_act_bwd: bad argument (C % 4 == 0, C <= 4096; act 1 needs y, act 2 needs beta)");
+    return fail(HIFIHR_EINVAL, "hifihr_bn_act_bwd: bad argument (C % 4 == 0, C <= 4096; act 1 needs y or beta, act 2 needs beta)");
   HIP_TRY(hifihr::launch_bn_act_bwd(dy, y, x, save_mean, save_invstd, gamma, beta, act, M, C, red_scratch, dx, dres, dgamma_acc,
                                     dbeta_acc, (hipStream_t)stream));
   return HIFIHR_OK;

@@ -528,7 +528,8 @@ class _BNAct(torch.autograd.Function):
         PROFILE.bracket("bn_fwd", lambda: lib.bn_act_fwd(x, stats, gamma, beta, res, act, M, C, eps, momentum, y, save_mean,
                                                          save_invstd, running_mean, running_var))
         _ZERO_POOL.release(stats)                # consumed and zeroed by the kernel
-        ctx.save_for_backward(x, y if act == 1 else x.new_empty(0), gamma, beta, save_mean, save_invstd)
+        # ReLU without a residual input: the backward recomputes the mask from x (csrc/bn.hip masked_grad), y is not kept for it
+        ctx.save_for_backward(x, y if (act == 1 and residual is not None) else x.new_empty(0), gamma, beta, save_mean, save_invstd)
         ctx.act, ctx.has_res, ctx.M, ctx.C = act, residual is not None, M, C
         ctx.gamma_param, ctx.beta_param = gamma, beta
         return y
@@ -536,7 +537,7 @@ class _BNAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
-        y = y if ctx.act == 1 else None
+        y = y if (ctx.act == 1 and ctx.has_res) else None
         lib = get_lib()
         dy = dy.contiguous(memory_format=_CL)
         dx = torch.empty_like(x, memory_format=_CL)

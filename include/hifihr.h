@@ -230,7 +230,7 @@ int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, fl
  * back, so one zero-initialised buffer serves every step without a memset launch.
  *   fwd: y = act( (x - mean) * invstd * gamma + beta + residual? ); writes save_mean/save_invstd[C] and updates
  *        running_mean/var (momentum, unbiased variance) when given.
- *   bwd: g = dy * act'(z) (ReLU: y > 0, needs y_d; swish: z recomputed from x, needs beta_d); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (may be NULL) = g;
+ *   bwd: g = dy * act'(z) (ReLU: y > 0 from y_d -- or, with y_d NULL and no residual input in the forward, the mask recomputed from x, needs beta_d; swish: z recomputed from x, needs beta_d); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (may be NULL) = g;
  *        dgamma_acc[C] += sum g*xhat, dbeta_acc[C] += sum g (either may be NULL).
  * ---------------------------------------------------------------------------------------------- */
 int hifihr_bn_stats_floats(int C);
@@ -238,7 +238,7 @@ int hifihr_bn_stats(const float* x_d, long M, int C, float* stats_d, void* strea
 int hifihr_bn_act_fwd(const float* x_d, float* stats_d /* consumed: zero on return */, const float* gamma_d, const float* beta_d,
                       const float* residual_d /* or NULL */, int act, long M, int C, float eps, float momentum, float* y_d,
                       float* save_mean_d, float* save_invstd_d, float* running_mean_d, float* running_var_d, void* stream);
-int hifihr_bn_act_bwd(const float* dy_d, const float* y_d /* act 1 */, const float* x_d, const float* save_mean_d,
+int hifihr_bn_act_bwd(const float* dy_d, const float* y_d /* act 1; NULL: recompute the mask (no-residual layers) */, const float* x_d, const float* save_mean_d,
                       const float* save_invstd_d, const float* gamma_d, const float* beta_d /* act 2 */, int act, long M, int C,
                       float* red_scratch_d, float* dx_d, float* dres_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
 

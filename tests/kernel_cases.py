@@ -324,6 +324,16 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
     dg = torch.full((C,), 0.5, device=device); db = torch.full((C,), -0.25, device=device)     # accumulate semantics
     lib.bn_act_bwd(nhwc(gy), y if act == 1 else None, dx_in, sm, si, gamma.to(device), beta.to(device), act, M, C, red, dxo, dres, dg, db)
     assert float(bn_slots(red, C).abs().max()) == 0.0 and float(red[-64:].abs().max()) == 0.0, "bn_act_bwd must leave the slots and arrival counters zeroed"
+    if act == 1 and not residual:       # ReLU mask recomputed from x instead of read from y: the same gradients (the slot sums
+        #                                 are float atomics, so two launches agree to rounding, not to the bit)
+        dxo2 = torch.full_like(dxo, 7.0); dg2 = torch.zeros_like(dg); db2 = torch.zeros_like(db)
+        lib.bn_act_bwd(nhwc(gy), None, dx_in, sm, si, gamma.to(device), beta.to(device), act, M, C, red, dxo2, None, dg2, db2)
+        dg1 = torch.zeros_like(dg); db1 = torch.zeros_like(db); dxo1 = torch.full_like(dxo, 7.0)
+        lib.bn_act_bwd(nhwc(gy), y, dx_in, sm, si, gamma.to(device), beta.to(device), act, M, C, red, dxo1, None, dg1, db1)
+        scale = float(dxo1.abs().max())
+        assert float((dxo1 - dxo2).abs().max()) <= 2e-6 * scale, "mask recomputed from x: dx"
+        assert float(((dxo1 == 0) != (dxo2 == 0)).float().mean()) <= 1e-5, "mask recomputed from x: same zero pattern"
+        assert float((dg1 - dg2).abs().max()) <= 1e-5 * float(dg1.abs().max()) + 1e-6 and float((db1 - db2).abs().max()) <= 1e-5 * float(db1.abs().max()) + 1e-6
     refdx = xr.grad.permute(0, 2, 3, 1)
     assert float((dxo.cpu() - refdx).abs().max()) <= 2e-4 * float(refdx.abs().max()) + 1e-7, "bn bwd dx"
     assert float((dg.cpu() - 0.5 - gr.grad).abs().max()) <= 2e-4 * float(gr.grad.abs().max()) + 1e-5, "bn dgamma"
