@@ -17,6 +17,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhifihr.so")
 
 _c_float_p = POINTER(c_float)
+
+
+class _LinearDesc(ctypes.Structure):          # include/hifihr.h: hifihr_linear_desc
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("b", c_void_p), ("y", c_void_p), ("B", c_int), ("I", c_int), ("O", c_int), ("act", c_int),
+                ("dy", c_void_p), ("dz_scratch", c_void_p), ("dW_acc", c_void_p), ("db_acc", c_void_p), ("dx", c_void_p)]
+
 _c_int_p = POINTER(c_int32)
 
 
@@ -115,6 +121,8 @@ class HifihrLib:
         c.hifihr_wino_input_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
         c.hifihr_wino_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_wino_output_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
+        c.hifihr_linear_fwd_group.argtypes = [POINTER(_LinearDesc), c_int, c_void_p]
+        c.hifihr_linear_bwd_group.argtypes = [POINTER(_LinearDesc), c_int, c_void_p]
         c.hifihr_wino_input_dy_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
         c.hifihr_conv2d_bwd_data_pre.argtypes = [_c_float_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_weight_prep.argtypes = [c_void_p, c_int, c_int, c_void_p]
@@ -370,6 +378,23 @@ class HifihrLib:
         self.check(self.c.hifihr_linear_bwd(_fp(dy), _fp(y), _fp(x), _fp(w), B, I, O, int(act), _fp(gamma), _fp(z), _fp(sm), _fp(si),
                                             _fp(dz), _fp(dW_acc), _fp(db_acc), _fp(dg), _fp(dbt), _fp(dx), _stream_of(x)),
                    "hifihr_linear_bwd")
+
+    @staticmethod
+    def _descs(members):
+        """members: list of dicts with tensors x, w, b, y and act (+ dy, dz, dW, db, dx for the backward) -> ctypes array."""
+        arr = (_LinearDesc * len(members))()
+        p = lambda t: None if t is None else t.data_ptr()
+        for d, m in zip(arr, members):
+            d.x, d.w, d.b, d.y = p(m["x"]), p(m["w"]), p(m.get("b")), p(m["y"])
+            d.B, d.I, d.O, d.act = m["x"].shape[0], m["x"].shape[1], m["w"].shape[0], int(m["act"])
+            d.dy, d.dz_scratch, d.dW_acc, d.db_acc, d.dx = p(m.get("dy")), p(m.get("dz")), p(m.get("dW")), p(m.get("db")), p(m.get("dx"))
+        return arr
+
+    def linear_fwd_group(self, members):
+        self.check(self.c.hifihr_linear_fwd_group(self._descs(members), len(members), _stream_of(members[0]["x"])), "hifihr_linear_fwd_group")
+
+    def linear_bwd_group(self, members):
+        self.check(self.c.hifihr_linear_bwd_group(self._descs(members), len(members), _stream_of(members[0]["x"])), "hifihr_linear_bwd_group")
 
     def mmpool_fwd(self, x, p, B, HW, C, y, argmax, xmax, xavg):
         self.check(self.c.hifihr_mmpool_fwd(_fp(x), _fp(p), B, HW, C, _fp(y), _ip(argmax), _fp(xmax), _fp(xavg), _stream_of(x)),

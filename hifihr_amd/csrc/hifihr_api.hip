@@ -534,6 +534,38 @@ int hifihr_linear_fwd(const float* x, const float* w, const float* b, int B, int
   return HIFIHR_OK;
 }
 
+static int group_member_ok(const hifihr_linear_desc& d) {
+  return d.x && d.w && d.y && d.B > 0 && d.I > 0 && d.O > 0 && (d.act == 0 || d.act == 1);
+}
+
+int hifihr_linear_fwd_group(const hifihr_linear_desc* descs, int n, void* stream) {
+  if (!descs || n <= 0 || n > hifihr::kMaxLinearGroup) return fail(HIFIHR_EINVAL, "hifihr_linear_fwd_group: 1..6 members");
+  hifihr::LinearGroup grp{};
+  grp.n = n;
+  for (int i = 0; i < n; ++i) {
+    const hifihr_linear_desc& d = descs[i];
+    if (!group_member_ok(d)) return fail(HIFIHR_EINVAL, "hifihr_linear_fwd_group: bad member (x, w, y, sizes; act 0 / 1)");
+    grp.a[i] = hifihr::LinearArgs{d.x, d.w, d.b, d.y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, d.B, d.I, d.O, d.act};
+  }
+  HIP_TRY(hifihr::launch_linear_fwd_group(grp, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_linear_bwd_group(const hifihr_linear_desc* descs, int n, void* stream) {
+  if (!descs || n <= 0 || n > hifihr::kMaxLinearGroup) return fail(HIFIHR_EINVAL, "hifihr_linear_bwd_group: 1..6 members");
+  hifihr::LinearGroup grp{};
+  hifihr::LinearGradsGroup gg{};
+  grp.n = n;
+  for (int i = 0; i < n; ++i) {
+    const hifihr_linear_desc& d = descs[i];
+    if (!group_member_ok(d) || !d.dy || !d.dz_scratch) return fail(HIFIHR_EINVAL, "hifihr_linear_bwd_group: bad member (dy, dz_scratch, y for act 1)");
+    grp.a[i] = hifihr::LinearArgs{d.x, d.w, nullptr, d.y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, d.B, d.I, d.O, d.act};
+    gg.g[i] = hifihr::LinearGrads{d.dy, d.dz_scratch, d.dW_acc, d.db_acc, nullptr, nullptr, d.dx};
+  }
+  HIP_TRY(hifihr::launch_linear_bwd_group(grp, gg, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_linear_bwd(const float* dy, const float* y, const float* x, const float* w, int B, int I, int O, int act, const float* gamma,
                       const float* z, const float* save_mean, const float* save_invstd, float* dz_scratch, float* dW_acc, float* db_acc,
                       float* dgamma_acc, float* dbeta_acc, float* dx, void* stream) {

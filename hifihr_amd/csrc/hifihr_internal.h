@@ -140,6 +140,16 @@ struct LinearGrads {
   const float* dy;
   float *dz, *dW_acc, *db_acc, *dgamma_acc, *dbeta_acc, *dx;    // *_acc accumulate (+=); dz scratch [B][O]; dx overwritten
 };
+constexpr int kMaxLinearGroup = 6;
+struct LinearGroup {
+  LinearArgs a[kMaxLinearGroup];
+  int n;
+};
+struct LinearGradsGroup {
+  LinearGrads g[kMaxLinearGroup];
+};
+hipError_t launch_linear_fwd_group(const LinearGroup& grp, hipStream_t st);
+hipError_t launch_linear_bwd_group(const LinearGroup& grp, const LinearGradsGroup& gg, hipStream_t st);
 hipError_t launch_linear_fwd(const LinearArgs& a, hipStream_t st);
 hipError_t launch_linear_bwd(const LinearArgs& a, const LinearGrads& g, hipStream_t st);
 

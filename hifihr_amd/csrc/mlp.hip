@@ -45,7 +45,7 @@ struct MlpCfg {
 };
 
 template <int RB>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
+__device__ __forceinline__ void linear_fwd_body(const LinearArgs& a, const int bx, const int by) {
   using C = MlpCfg<RB>;
   constexpr int KR = RB / 16;                     // rows per thread
   HIP_DYNAMIC_SHARED(float, smem);
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
   __shared__ float zs[RB][kFT + 1];
   __shared__ float sc[kFT], sh[kFT];
   const int tid = threadIdx.x, ol = tid & 15, rg = tid >> 4;
-  const int o0 = blockIdx.x * kFT, row0 = blockIdx.y * RB;
+  const int o0 = bx * kFT, row0 = by * RB;
   const int nrow = min(RB, a.B - row0);
   float acc[KR];
 #pragma unroll
@@ -153,22 +153,23 @@ constexpr int kWC = 512;      // input features per x chunk of the dW phase (32 
 constexpr int kWLD = kWC + 4;
 constexpr int kRowsMax = 64;  // rows per pass (batch-norm layers: one pass)
 
-__global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearGrads g) {
+__device__ __forceinline__ void linear_bwd_w_body(const LinearArgs& a, const LinearGrads& g, const int bx, const int by, const int ngx,
+                                                  const int ngy) {
   HIP_DYNAMIC_SHARED(float, xs);                  // [32][kWLD]
   __shared__ float dzs[kRowsMax][kFT + 1];
   __shared__ float red[2][kFT];
   const int tid = threadIdx.x, ol = tid & 15, rg = tid >> 4;
-  const int o0 = blockIdx.x * kFT;
+  const int o0 = bx * kFT;
   const int o = o0 + ol;
   const bool ook = o < a.O;
   // blockIdx.y = 512-wide slice of the input features: the squeeze-excite "reduce" layers have 6-96 outputs and up to 2304
   // inputs, i.e. 1-6 feature blocks only; every slice recomputes the (tiny) dz part and slice 0 alone accumulates db / dgamma /
   // dbeta and writes dz.
-  const bool first_slice = blockIdx.y == 0;
+  const bool first_slice = by == 0;
   // the dx zero fill rides along (linear_bwd_x_kernel adds into it): each workgroup clears an equal slice
   const bool al4 = (a.I & 3) == 0;
   if (g.dx != nullptr) {
-    const unsigned nwg = gridDim.x * gridDim.y, wgi = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned nwg = ngx * ngy, wgi = by * ngx + bx;
     if (al4) {
       const size_t n4 = (size_t)a.B * a.I / 4, per = (n4 + nwg - 1) / nwg;
       const size_t lo = per * wgi, hi = lo + per < n4 ? lo + per : n4;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearG
     // dW[o0 + 4*og + j][i] += sum_r dz[r][4*og + j] * x[r][i];  thread = (i lane 0..63, feature group og 0..3)
     const int il = tid & 63, og = tid >> 6;
     {
-      const int i0 = blockIdx.y * kWC;
+      const int i0 = by * kWC;
       const int ilen = min(kWC, a.I - i0);
       float w[kWC / 64][4];
 #pragma unroll
@@ -308,12 +309,12 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearG
 constexpr int kOS = 64;       // output features per split of the dx kernel
 
 // dx[b][i] += sum_{o in split} dz[b][o] * W[o][i];  workgroup = 64 input features x one split; thread = (i, row group 0..3)
-__global__ __launch_bounds__(256) void linear_bwd_x_kernel(LinearArgs a, LinearGrads g) {
+__device__ __forceinline__ void linear_bwd_x_body(const LinearArgs& a, const LinearGrads& g, const int bx, const int by) {
   __shared__ float dzs[kRowsMax][kOS + 1];
   const int tid = threadIdx.x, il = tid & 63, rg = tid >> 6;
-  const int i = blockIdx.x * 64 + il;
+  const int i = bx * 64 + il;
   const int ic = i < a.I ? i : a.I - 1;           // clamped: the loads below stay unconditional
-  const int os0 = blockIdx.y * kOS, on = min(kOS, a.O - os0);
+  const int os0 = by * kOS, on = min(kOS, a.O - os0);
   for (int row0 = 0; row0 < a.B; row0 += kRowsMax) {
     const int nrow = min(kRowsMax, a.B - row0);
     for (int e = tid; e < kRowsMax * kOS; e += 256) {
@@ -349,6 +350,35 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(LinearArgs a, LinearG
 }
 
 template <int RB>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) { linear_fwd_body<RB>(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinearArgs a, LinearGrads g) {
+  linear_bwd_w_body(a, g, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(LinearArgs a, LinearGrads g) { linear_bwd_x_body(a, g, blockIdx.x, blockIdx.y); }
+
+// Grouped launches: the regression heads are five to six independent little MLPs of the same depth (reference
+// network/res_encoder.py:112-131); each layer alone is a latency-bound ~8 us launch on 8-32 workgroups.  blockIdx.z picks the member,
+// the grid covers the largest member and workgroups outside a member's own extent leave at once.
+template <int RB>
+__global__ __launch_bounds__(256) void linear_fwd_group_kernel(LinearGroup grp) {
+  const LinearArgs& a = grp.a[blockIdx.z];
+  if ((int)blockIdx.x * kFT >= a.O || (int)blockIdx.y * RB >= a.B) return;
+  linear_fwd_body<RB>(a, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void linear_bwd_w_group_kernel(LinearGroup grp, LinearGradsGroup gg) {
+  const LinearArgs& a = grp.a[blockIdx.z];
+  const int ngx = (a.O + kFT - 1) / kFT, ngy = (a.I + kWC - 1) / kWC;
+  if ((int)blockIdx.x >= ngx || (int)blockIdx.y >= ngy) return;
+  linear_bwd_w_body(a, gg.g[blockIdx.z], blockIdx.x, blockIdx.y, ngx, ngy);
+}
+__global__ __launch_bounds__(256) void linear_bwd_x_group_kernel(LinearGroup grp, LinearGradsGroup gg) {
+  const LinearArgs& a = grp.a[blockIdx.z];
+  const LinearGrads& g = gg.g[blockIdx.z];
+  if (g.dx == nullptr || (int)blockIdx.x * 64 >= a.I || (int)blockIdx.y * kOS >= a.O) return;
+  linear_bwd_x_body(a, g, blockIdx.x, blockIdx.y);
+}
+
+template <int RB>
 static hipError_t launch_fwd_rb(const LinearArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -378,6 +408,53 @@ hipError_t launch_linear_bwd(const LinearArgs& a, const LinearGrads& g, hipStrea
   hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((a.O + kFT - 1) / kFT, (a.I + kWC - 1) / kWC), dim3(256), lds, st, a, g);
   if (g.dx != nullptr)
     hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((a.I + 63) / 64, (a.O + kOS - 1) / kOS), dim3(256), 0, st, a, g);
+  return hipGetLastError();
+}
+
+template <int RB>
+static hipError_t launch_fwd_group_rb(const LinearGroup& grp, dim3 grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_fwd_group_kernel<RB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)MlpCfg<RB>::lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((linear_fwd_group_kernel<RB>), grid, dim3(256), MlpCfg<RB>::lds_bytes, st, grp);
+  return hipGetLastError();
+}
+
+hipError_t launch_linear_fwd_group(const LinearGroup& grp, hipStream_t st) {
+  if (grp.n <= 0 || grp.n > kMaxLinearGroup) return hipErrorInvalidValue;
+  int gx = 0, maxB = 0;
+  for (int i = 0; i < grp.n; ++i) {
+    if (grp.a[i].gamma != nullptr) return hipErrorInvalidValue;          // batch-norm members go through launch_linear_fwd
+    gx = max(gx, (grp.a[i].O + kFT - 1) / kFT);
+    maxB = max(maxB, grp.a[i].B);
+  }
+  if (maxB <= 32) return launch_fwd_group_rb<32>(grp, dim3(gx, (maxB + 31) / 32, grp.n), st);
+  return launch_fwd_group_rb<64>(grp, dim3(gx, (maxB + 63) / 64, grp.n), st);
+}
+
+hipError_t launch_linear_bwd_group(const LinearGroup& grp, const LinearGradsGroup& gg, hipStream_t st) {
+  if (grp.n <= 0 || grp.n > kMaxLinearGroup) return hipErrorInvalidValue;
+  constexpr size_t lds = (size_t)32 * kWLD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bwd_w_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  int wx = 0, wy = 0, xx = 0, xy = 0;
+  bool any_dx = false;
+  for (int i = 0; i < grp.n; ++i) {
+    const LinearArgs& a = grp.a[i];
+    if (a.gamma != nullptr || (gg.g[i].dx != nullptr && gg.g[i].dz == nullptr)) return hipErrorInvalidValue;
+    wx = max(wx, (a.O + kFT - 1) / kFT); wy = max(wy, (a.I + kWC - 1) / kWC);
+    if (gg.g[i].dx != nullptr) { any_dx = true; xx = max(xx, (a.I + 63) / 64); xy = max(xy, (a.O + kOS - 1) / kOS); }
+  }
+  hipLaunchKernelGGL(linear_bwd_w_group_kernel, dim3(wx, wy, grp.n), dim3(256), lds, st, grp, gg);
+  if (any_dx) hipLaunchKernelGGL(linear_bwd_x_group_kernel, dim3(xx, xy, grp.n), dim3(256), 0, st, grp, gg);
   return hipGetLastError();
 }
 

@@ -750,6 +750,60 @@ class _Linear(torch.autograd.Function):
         return dx, dw_ret, db_ret, dg_ret, dbt_ret, None, None, None, None, None
 
 
+class _LinearGroup(torch.autograd.Function):
+    """n independent act(x_i W_i^T + b_i) in ONE launch forward and TWO backward (csrc/mlp.hip grouped kernels)."""
+
+    @staticmethod
+    def forward(ctx, n, acts, *tensors):
+        xs, ws, bs = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        require_cuda(*xs, *ws)
+        lib = get_lib()
+        xs = [x.contiguous() for x in xs]
+        ws_c = [w.contiguous() for w in ws]
+        ys = [torch.empty(x.shape[0], w.shape[0], device=x.device) for x, w in zip(xs, ws_c)]
+        members = [dict(x=x, w=w, b=b, y=y, act=a) for x, w, b, y, a in zip(xs, ws_c, bs, ys, acts)]
+        PROFILE.bracket("linear_fwd", lambda: lib.linear_fwd_group(members))
+        ctx.n, ctx.acts, ctx.params = n, acts, (ws, bs)
+        ctx.save_for_backward(*xs, *ws_c, *ys)
+        ctx.set_materialize_grads(False)           # heads whose output no loss reads get no backward work at all
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        xs, ws_c, ys = saved[:n], saved[n:2 * n], saved[2 * n:3 * n]
+        pws, pbs = ctx.params
+        lib = get_lib()
+        dxs, dws, dbs = [None] * n, [None] * n, [None] * n
+        members, ready = [], []
+        for i in range(n):
+            if dys[i] is None:
+                continue
+            dy = dys[i].contiguous()
+            dx = torch.empty_like(xs[i]) if ctx.needs_input_grad[2 + i] else None
+            dw_t, dws[i] = _acc_target(pws[i], pws[i].shape, dy.device)
+            db_t = None
+            if pbs[i] is not None:
+                db_t, dbs[i] = _acc_target(pbs[i], pbs[i].shape, dy.device)
+            dxs[i] = dx
+            members.append(dict(x=xs[i], w=ws_c[i], y=ys[i], act=ctx.acts[i], dy=dy, dz=torch.empty_like(dy), dW=dw_t, db=db_t, dx=dx))
+            ready += [p for p, ret in ((pws[i], dws[i]), (pbs[i], dbs[i])) if p is not None and ret is None]
+        if members:
+            PROFILE.bracket("linear_bwd", lambda: lib.linear_bwd_group(members))
+        for p in ready:
+            _grad_ready(p)
+        return (None, None, *dxs, *dws, *dbs)
+
+
+def linear_group(members):
+    """[(x, nn.Linear, relu?)] -> [act(lin(x))]: up to six independent layers of the same depth as one launch (the regression
+    heads of the HandEncoder, reference network/res_encoder.py:112-131)."""
+    n = len(members)
+    acts = tuple(1 if m[2] in (True, "relu", 1) else 0 for m in members)
+    return list(_LinearGroup.apply(n, acts, *[m[0] for m in members], *[m[1].weight for m in members], *[m[1].bias for m in members]))
+
+
 def linear(x, lin: torch.nn.Linear, act=None, bn: torch.nn.BatchNorm1d | None = None):
     """act(bn(lin(x))) for a [B, I] activation in ONE launch (two backward): nn.Linear (+ nn.BatchNorm1d, batch statistics
     in training mode) (+ nn.ReLU) of the reference's regression heads.  Eval-mode batch-norm and B > 64 with batch-norm

@@ -360,6 +360,20 @@ int hifihr_linear_bwd(const float* dy_d, const float* y_d, const float* x_d, con
                       float* dz_scratch_d, float* dW_acc_d, float* db_acc_d, float* dgamma_acc_d, float* dbeta_acc_d,
                       float* dx_d, void* stream);
 
+/* Grouped launches for independent layers of the same depth (the HandEncoder's five to six heads, reference
+ * network/res_encoder.py:112-131, 146-160): up to 6 members per call, no batch-norm, act 0 / 1; one launch forward, two backward
+ * instead of one / two PER LAYER (each is a latency-bound ~8 us kernel on 8-32 workgroups).  `descs` is a HOST array.
+ * bwd members: dy, y (act 1), dz_scratch[B][O] required; dW_acc / db_acc accumulate (NULL: skipped); dx overwritten (NULL: skipped). */
+typedef struct hifihr_linear_desc {
+  const float *x, *w, *b; /* b may be NULL */
+  float* y;
+  int B, I, O, act;
+  const float* dy;
+  float *dz_scratch, *dW_acc, *db_acc, *dx;
+} hifihr_linear_desc;
+int hifihr_linear_fwd_group(const hifihr_linear_desc* descs, int n, void* stream);
+int hifihr_linear_bwd_group(const hifihr_linear_desc* descs, int n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Squeeze-and-excitation of the EfficientNet MBConv block (reference network/efficientnet_pt/model.py:82-86):
  *   y = x * sigmoid( W2 swish( W1 mean_hw(x) + b1 ) + b2 ),  x[B][HW][C] NHWC, C % 4 == 0.

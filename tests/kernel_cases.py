@@ -814,3 +814,34 @@ def weight_prep_case(lib, device, seed=0):
     lib.weight_prep(table, len(jobs), 3)
     for (_, dst, K, C, RS, kind), ref in zip(jobs, want):
         assert torch.equal(dst.cpu(), ref.cpu()), (K, C, RS, kind)
+
+
+# ------------------------------------------------------------------------------------------------
+# grouped linear layers (csrc/mlp.hip *_group_kernel) == the single-layer launches
+# ------------------------------------------------------------------------------------------------
+def linear_group_case(lib, device, B=32, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    shapes = [(512, 128, 1), (512, 128, 1), (128, 48, 0), (128, 10, 0), (32, 3, 0), (32, 1, 0)]
+    d = lambda t: t.to(device).contiguous()
+    mem, ref = [], []
+    for I, O, act in shapes:
+        x = torch.randn(B, I, generator=gen); w = torch.randn(O, I, generator=gen) / I ** 0.5; b = torch.randn(O, generator=gen) * 0.1
+        dy = torch.randn(B, O, generator=gen)
+        m = dict(x=d(x), w=d(w), b=d(b), y=torch.full((B, O), 7.0, device=device), act=act)
+        y1 = torch.empty(B, O, device=device)
+        lib.linear_fwd(m["x"], m["w"], m["b"], act, y1)
+        dz = torch.empty(B, O, device=device); dW = torch.full((O, I), 0.5, device=device); db = torch.full((O,), -0.5, device=device)
+        dx = torch.full((B, I), 7.0, device=device)
+        lib.linear_bwd(d(dy), y1, m["x"], m["w"], act, dz, dW, db, dx)
+        m.update(dy=d(dy), dz=torch.empty(B, O, device=device), dW=torch.full((O, I), 0.5, device=device), db=torch.full((O,), -0.5, device=device),
+                 dx=torch.full((B, I), 7.0, device=device))
+        mem.append(m); ref.append((y1, dW, db, dx))
+    mem[3]["dx"] = None                                   # a member without an input gradient
+    lib.linear_fwd_group(mem)
+    for m, r in zip(mem, ref):
+        assert torch.equal(m["y"], r[0]), "grouped forward"
+    lib.linear_bwd_group(mem)
+    for i, (m, r) in enumerate(zip(mem, ref)):
+        assert float((m["dW"] - r[1]).abs().max()) <= 1e-5 * float(r[1].abs().max()) and float((m["db"] - r[2]).abs().max()) <= 1e-4, i
+        if m["dx"] is not None:
+            assert float((m["dx"] - r[3]).abs().max()) <= 1e-5 * float(r[3].abs().max()) + 1e-6, i

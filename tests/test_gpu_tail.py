@@ -148,3 +148,7 @@ def test_evaluator_summary_matches_formulas(golden_dir):
     al, err = align_w_scale(torch.from_numpy(g["gt_j"]).float().cuda(), torch.from_numpy(g["pr_j"]).cuda(), return_error=True)
     np.testing.assert_allclose(al.cpu().numpy(), g["al_j"], atol=2e-7)
     assert abs(float(err.mean()) - float(g["mpjpe"])) <= 1e-6 * float(g["mpjpe"])
+
+
+def test_grouped_linear_layers_equal_single_launches(lib):
+    kc.linear_group_case(lib, "cuda")

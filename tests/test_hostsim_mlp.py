@@ -14,3 +14,7 @@ def hostsim_lib():
                                                   (3, 256, 300, 1, False, True), (5, 1100, 20, 1, False, True), (4, 1038, 6, 1, True, True)])
 def test_linear(hostsim_lib, B, I, O, act, bn, need_dx):
     kc.linear_case(hostsim_lib, "cpu", B, I, O, act, bn, seed=B + O, need_dx=need_dx)
+
+
+def test_grouped_linear_layers_equal_single_launches(hostsim_lib):
+    kc.linear_group_case(hostsim_lib, "cpu")
