@@ -322,19 +322,21 @@ __global__ __launch_bounds__(kBwdThreads) void mano_bwd_kernel(ManoDev t, const 
 // ------------------------------------------------------------------------------------------------
 // xyz_from_vertice + root-relative
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mano_joints_fwd_kernel(ManoDev t, const float* __restrict__ verts, int root_id,
+constexpr int kJointsFwdThreads = 1024;   // 16 waves: the 48 regressor dot products (one wave each) take 3 rounds instead of 12; one
+                                          // workgroup per hand is all the parallelism a batch of 32 offers, so the kernel is a latency chain
+__global__ __launch_bounds__(kJointsFwdThreads) void mano_joints_fwd_kernel(ManoDev t, const float* __restrict__ verts, int root_id,
                                                              float* __restrict__ joints_rel, float* __restrict__ verts_rel,
                                                              float* __restrict__ root_out) {
   __shared__ float sv[3 * kNVP];
   __shared__ float j16[kNJ * 3];
   __shared__ float j21[21 * 3];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int v = tid; v < kNV; v += 256) {
+  for (int v = tid; v < kNV; v += kJointsFwdThreads) {
     const float* p = verts + ((size_t)b * kNV + v) * 3;
     sv[v] = p[0]; sv[kNVP + v] = p[1]; sv[2 * kNVP + v] = p[2];
   }
   __syncthreads();
-  for (int o = wave; o < kNJ * 3; o += 4) {           // 48 dot products of length 778, one wave each
+  for (int o = wave; o < kNJ * 3; o += kJointsFwdThreads / 64) {   // 48 dot products of length 778, one wave each
     const int j = o / 3, c = o % 3;
     const float* jr = t.jreg + j * kNVP;
     float acc = 0.f;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void mano_joints_fwd_kernel(ManoDev t, const f
   if (tid < 63) joints_rel[(size_t)b * 63 + tid] = j21[tid] - r[tid % 3];
   if (tid < 3 && root_out) root_out[b * 3 + tid] = r[tid];
   if (verts_rel) {
-    for (int e = tid; e < kNV * 3; e += 256) {
+    for (int e = tid; e < kNV * 3; e += kJointsFwdThreads) {
       const int v = e / 3, c = e % 3;
       verts_rel[(size_t)b * kNV * 3 + e] = sv[c * kNVP + v] - r[c];
     }
@@ -449,7 +451,7 @@ hipError_t launch_mano_bwd(const ManoDev& t, const float* pose, const float* bet
 
 hipError_t launch_mano_joints_fwd(const ManoDev& t, const float* verts, int B, int root_id, float* joints_rel,
                                   float* verts_rel, float* root, hipStream_t st) {
-  hipLaunchKernelGGL(mano_joints_fwd_kernel, dim3(B), dim3(256), 0, st, t, verts, root_id, joints_rel, verts_rel, root);
+  hipLaunchKernelGGL(mano_joints_fwd_kernel, dim3(B), dim3(kJointsFwdThreads), 0, st, t, verts, root_id, joints_rel, verts_rel, root);
   return hipGetLastError();
 }
 

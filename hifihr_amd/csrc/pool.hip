@@ -86,17 +86,23 @@ __global__ __launch_bounds__(256) void mmpool_bwd_kernel(const float* __restrict
       *reinterpret_cast<float4*>(xb + (size_t)r * C) = v;
     }
   }
-  if (dp_acc != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {      // one deterministic writer for the scalar gradient
-    __shared__ float red[256];
+  // d/dp = w (1 - w) sum_{b,c} gy (xmax - xavg): the first workgroup of every image folds that image's C values (one float4 per
+  // lane, shuffle tree + 4 partials through LDS) and adds one float: B atomics.  (A single workgroup walking all B*C values was
+  // a 64-step latency chain = most of this kernel's time while the other workgroups had long finished.)
+  if (dp_acc != nullptr && blockIdx.x == 0) {
+    __shared__ float red[4];
     float a = 0.f;
-    for (int i = threadIdx.x; i < B * C; i += 256) a += gy[i] * (xmax[i] - xavg[i]);
-    red[threadIdx.x] = a;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-      __syncthreads();
+    for (int c4 = threadIdx.x; c4 * 4 < C; c4 += 256) {
+      const size_t o = (size_t)b * C + c4 * 4;
+      const float4 g = *reinterpret_cast<const float4*>(gy + o);
+      const float4 xm = *reinterpret_cast<const float4*>(xmax + o), xa = *reinterpret_cast<const float4*>(xavg + o);
+      a += g.x * (xm.x - xa.x) + g.y * (xm.y - xa.y) + g.z * (xm.z - xa.z) + g.w * (xm.w - xa.w);
     }
-    if (threadIdx.x == 0) dp_acc[0] += red[0] * w * (1.f - w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dp_acc, (red[0] + red[1] + red[2] + red[3]) * w * (1.f - w));
   }
 }
 
@@ -166,29 +172,43 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     const int ih = (int)(rest % H);
     const int n = (int)(rest / H);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    // windows oh with oh * S - P + r == ih, r in 0..K-1
+    // windows oh with oh * S - P + r == ih: r = (ih + P) % S + j * S, j = 0 .. ceil(K / S) - 1.  All candidate loads are issued
+    // unconditionally (clamped addresses) before any is used: loads behind a branch serialise into one HBM latency each.
+    constexpr int NR = (K + S - 1) / S;
+    int ohc[NR], owc[NR], rc[NR], sc[NR];
+    bool vh[NR], vw[NR];
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-      const int th = ih + P - r;
-      if (th < 0 || (th % S) != 0) continue;
-      const int oh = th / S;
-      if (oh >= OH) continue;
-#pragma unroll
-      for (int s = 0; s < K; ++s) {
-        const int tw = iw + P - s;
-        if (tw < 0 || (tw % S) != 0) continue;
-        const int ow = tw / S;
-        if (ow >= OW) continue;
-        const size_t o = ((((size_t)n * OH + oh) * OW + ow) * C4 + cg) * 4;
-        const uchar4 t = *reinterpret_cast<const uchar4*>(tap + o);
-        const float4 g = *reinterpret_cast<const float4*>(gy + o);
-        const unsigned char me = (unsigned char)(r * K + s);
-        if (t.x == me) a.x += g.x;
-        if (t.y == me) a.y += g.y;
-        if (t.z == me) a.z += g.z;
-        if (t.w == me) a.w += g.w;
-      }
+    for (int j = 0; j < NR; ++j) {
+      rc[j] = (ih + P) % S + j * S;
+      const int th = ih + P - rc[j];
+      vh[j] = rc[j] < K && th >= 0 && th / S < OH;
+      ohc[j] = vh[j] ? th / S : 0;
+      sc[j] = (iw + P) % S + j * S;
+      const int tw = iw + P - sc[j];
+      vw[j] = sc[j] < K && tw >= 0 && tw / S < OW;
+      owc[j] = vw[j] ? tw / S : 0;
     }
+    uchar4 t[NR][NR];
+    float4 g[NR][NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const size_t o = ((((size_t)n * OH + ohc[j]) * OW + owc[k]) * C4 + cg) * 4;
+        t[j][k] = *reinterpret_cast<const uchar4*>(tap + o);
+        g[j][k] = *reinterpret_cast<const float4*>(gy + o);
+      }
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const bool ok = vh[j] && vw[k];
+        const unsigned char me = (unsigned char)(rc[j] * K + sc[k]);
+        if (ok && t[j][k].x == me) a.x += g[j][k].x;
+        if (ok && t[j][k].y == me) a.y += g[j][k].y;
+        if (ok && t[j][k].z == me) a.z += g[j][k].z;
+        if (ok && t[j][k].w == me) a.w += g[j][k].w;
+      }
     *reinterpret_cast<float4*>(dx + i * 4) = a;
   }
 }
