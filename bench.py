@@ -275,6 +275,31 @@ def main():
                 graph_note = "eager (hipGraph capture failed on another rank)"
                 reducer.pause_hooks(False)
                 gstep, step = None, eager_step
+        if world > 1 and gstep is not None and a.graph == -1:
+            # Data parallel has two forms of the step: the hipGraph replay followed by the (not overlapped) bucketed all-reduce, and
+            # the eager step whose all-reduce buckets overlap the rest of backward.  On one GPU they run within 0.5 % of each other
+            # (the step is GPU-bound, the host runs ahead), so which one wins at N > 1 depends on the exchange time and on the host:
+            # measure both for a few steps (max over ranks) and keep the faster -- every rank takes the same decision.
+            def timed(fn, n=3):
+                fn()
+                torch.cuda.synchronize(); dist.barrier()
+                t_start = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize(); dist.barrier()
+                t = torch.tensor([time.perf_counter() - t_start], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item()) / n
+            t_graph = timed(gstep)
+            reducer.pause_hooks(False)
+            t_eager = timed(eager_step)
+            if t_eager < t_graph:
+                step = eager_step
+                graph_note = (f"eager step, bucketed all-reduce overlapped with backward (chosen over the hipGraph form: "
+                              f"{t_eager * 1e3:.2f} vs {t_graph * 1e3:.2f} ms/step in a 3-step trial)")
+            else:
+                reducer.pause_hooks(True)
+                graph_note += f" (chosen over the eager overlapped form: {t_graph * 1e3:.2f} vs {t_eager * 1e3:.2f} ms/step in a 3-step trial)"
         for _ in range(2):
             step()
     torch.cuda.synchronize()
