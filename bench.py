@@ -173,7 +173,7 @@ def main():
         from collections import Counter
         lib = ops.get_lib()
         counts = Counter(ops.PROFILE.conv_log)
-        tot_flop = tot_us = tot_n = 0.0
+        tot_flop = tot_us = tot_n = tot_bytes = 0.0
         alg_flop = alg_us = 0.0                        # SURVEY 8(d) accounting: direct-convolution FLOPs of the same layers, and the
         #                                                time of everything that computes them (Winograd: transforms + GEMMs)
         for (geom, direction), cnt in counts.items():
@@ -198,6 +198,7 @@ def main():
                 us = e0.elapsed_time(e1) * 1e3 / 10
                 per_step = cnt / nprof
                 tot_flop += 2.0 * 16 * T_ * C_ * K_ * per_step; tot_us += us * per_step; tot_n += per_step
+                tot_bytes += 4.0 * 16 * (T_ * C_ + K_ * C_ + T_ * K_) * per_step          # V + U read, M written, once each
                 xs = torch.randn(N_ * H_ * W_ * C_, device=dev); wsrc = torch.randn(K_ * 9 * C_, device=dev) * 0.05
                 ys = torch.empty(N_ * H_ * W_ * K_, device=dev)
                 full = lambda: ops._wino_conv(lib, xs, wsrc, ys, None, N_, H_, W_, C_, K_, 0, U=Us)     # U comes from weight_prep in the step
@@ -232,11 +233,18 @@ def main():
             per_step = cnt / nprof
             flop = 2.0 * N_ * OH_ * OW_ * K_ * R_ * S_ * (3 if C_ == 4 else C_)       # the NHWC4 stem has 3 real channels
             tot_flop += flop * per_step; tot_us += us * per_step; tot_n += per_step
+            tot_bytes += 4.0 * (N_ * H_ * W_ * C_ + K_ * R_ * S_ * C_ + N_ * OH_ * OW_ * K_) * per_step    # input, weights, output once each
             alg_flop += flop * per_step; alg_us += us * per_step
         if "weight_prep" in kern:                      # the step's one weight re-layout launch serves all of these layers
             alg_us += kern["weight_prep"][0]
+        conv_traffic = None
+        tfile = os.path.join(REPO, "profiles", "r01_conv_igemm_traffic.json")
+        if a.batch == 32 and a.encoder == "res18" and a.config == 2 and os.path.exists(tfile):
+            # PMC-measured HBM bytes per launch of this exact workload (separate FETCH_SIZE / WRITE_SIZE passes, tools/conv_traffic.sh)
+            conv_traffic = json.load(open(tfile))["traffic_bytes_per_launch"]
         conv_roof = {"bound": "mfma", "achieved": tot_flop / (tot_us * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                     "frac": tot_flop / (tot_us * 1e-6) / 1e12 / 157.3, "traffic": None,
+                     "frac": tot_flop / (tot_us * 1e-6) / 1e12 / 157.3, "traffic": conv_traffic,
+                     "compulsory_bytes_per_launch": tot_bytes / max(tot_n, 1.0),
                      "kernel": "conv_igemm_kernel (all instantiations: direct forward / backward-data convolutions and the batched GEMMs of "
                                "the Winograd F(2x2,3x3) layers, counted with the FLOPs they actually execute)",
                      "launches_per_step": tot_n, "avg_us": tot_us / max(tot_n, 1.0), "us_per_step": tot_us,
