@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(ManoDev t, const float* _
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-constexpr int kBwdThreads = 512;
+constexpr int kBwdThreads = 1024;   // 16 waves: the kernel is a chain of load latencies on ONE workgroup per hand; more waves and all loads of a
+                                    // table row in flight at once (phase 3) are what shorten it
 
 struct ManoBwdLds {
   ManoSmall s;
@@ -215,22 +216,31 @@ __global__ __launch_bounds__(kBwdThreads) void mano_bwd_kernel(ManoDev t, const 
       for (int j = 0; j < 21; ++j) acc += gjtr[((size_t)b * 21 + j) * 3 + tid];
     L.gcenter[tid] = -acc;        // d/d(centre): every output had the centre subtracted
   }
-  // ---- phase 2a: gAp[i][4r+c] = sum_v w[v,i] gv[r][v] [vp;1][c][v]  (192 threads, fixed order) ----
-  if (tid < kNJ * 12) {
-    const int i = tid / 12, k = tid % 12, r = k / 4, c = k % 4;
+  // ---- phase 2a: gAp[i][4r+c] = sum_v w[v,i] gv[r][v] [vp;1][c][v]  (192 sums x 4 lanes each: a quarter of the vertices per
+  //      lane, fixed order, folded with two shuffles -- a single lane per sum was a 778-step chain) ----
+  constexpr int k2aThreads = kNJ * 12 * 4;
+  if (tid < k2aThreads) {
+    const int d = tid >> 2, q = tid & 3;
+    const int i = d / 12, k = d % 12, r = k / 4, c = k % 4;
     const float* wrow = t.w + i * kNVP;
     const float* gr = L.gv + r * kNVP;
+    constexpr int kQ = (kNV + 3) / 4;
+    const int v0 = q * kQ, v1 = (v0 + kQ < kNV) ? v0 + kQ : kNV;
     float acc = 0.f;
     if (c < 3) {
       const float* pc = L.vp + c * kNVP;
-      for (int v = 0; v < kNV; ++v) acc += wrow[v] * gr[v] * pc[v];
+#pragma unroll 8
+      for (int v = v0; v < v1; ++v) acc += wrow[v] * gr[v] * pc[v];
     } else {
-      for (int v = 0; v < kNV; ++v) acc += wrow[v] * gr[v];
+#pragma unroll 8
+      for (int v = v0; v < v1; ++v) acc += wrow[v] * gr[v];
     }
-    L.gAp[tid] = acc;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (q == 0) L.gAp[d] = acc;
   }
-  // ---- phase 2b: gvp[v] = sum_i w[v,i] Rg_i^T gv[v]  (threads >= 192 so both halves overlap) ----
-  for (int v = (tid >= 192) ? tid - 192 : kNVP; v < kNVP; v += kBwdThreads - 192) {
+  // ---- phase 2b: gvp[v] = sum_i w[v,i] Rg_i^T gv[v]  (the remaining threads, so both halves overlap) ----
+  for (int v = (tid >= k2aThreads) ? tid - k2aThreads : kNVP; v < kNVP; v += kBwdThreads - k2aThreads) {
     float o[3] = {0.f, 0.f, 0.f};
     if (v < kNV) {
       const float g[3] = {L.gv[v], L.gv[kNVP + v], L.gv[2 * kNVP + v]};
@@ -253,11 +263,21 @@ __global__ __launch_bounds__(kBwdThreads) void mano_bwd_kernel(ManoDev t, const 
     for (int row = wave; row < kNP + kNB; row += kBwdThreads / 64) {
       const float* base = (row < kNP) ? t.pd + (size_t)row * 3 * kNVP : t.sd + (size_t)(row - kNP) * 3 * kNVP;
       const float4* r4 = reinterpret_cast<const float4*>(base);
+      constexpr int kIt = (kRow4 + 63) / 64;       // 10 float4 per lane per row: all issued before the first is used
+      float4 a[kIt];
+#pragma unroll
+      for (int i = 0; i < kIt; ++i) {
+        const int e = lane + 64 * i;
+        a[i] = r4[e < kRow4 ? e : kRow4 - 1];
+      }
       float acc = 0.f;
-      for (int e = lane; e < kRow4; e += 64) {
-        const float4 a = r4[e];
-        const float4 g = g4[e];
-        acc += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+#pragma unroll
+      for (int i = 0; i < kIt; ++i) {
+        const int e = lane + 64 * i;
+        if (e < kRow4) {
+          const float4 g = g4[e];
+          acc += a[i].x * g.x + a[i].y * g.y + a[i].z * g.z + a[i].w * g.w;
+        }
       }
       acc = wave_sum(acc);
       if (lane == 0) {

@@ -24,3 +24,12 @@ gy = torch.randn(B, C, device=dev); p = torch.zeros(1, device=dev); am = torch.r
 xm = torch.randn(B, C, device=dev); xa = torch.randn(B, C, device=dev); dx = torch.empty(B, HW, C, device=dev); dp = torch.zeros(1, device=dev)
 print("mmpool_bwd", timeit(lambda: lib.mmpool_bwd(gy, p, am, xm, xa, B, HW, C, dx, dp)))
 print("mmpool_bwd (no dp)", timeit(lambda: lib.mmpool_bwd(gy, p, am, xm, xa, B, HW, C, dx, None)))
+
+from hifihr_amd import ops
+from hifihr_amd.mano_tables import synthetic_mano_tables
+h = ops.ManoLayerHandle(synthetic_mano_tables(0))
+pose = (0.5 * torch.randn(B, 48, device=dev)).requires_grad_(True); beta = (0.5 * torch.randn(B, 10, device=dev)).requires_grad_(True)
+verts, jtr = ops.mano_lbs(h, pose, beta)
+gv = torch.randn_like(verts)
+print("mano fwd+bwd (autograd)", timeit(lambda: torch.autograd.grad(ops.mano_lbs(h, pose, beta)[0], (pose, beta), gv)))
+print("mano fwd only", timeit(lambda: ops.mano_lbs(h, pose, beta)))
