@@ -326,16 +326,64 @@ class _WeightPrep:
 _WEIGHT_PREP = _WeightPrep()
 
 
+class _AsyncWgrad:
+    """Weight gradients on a second HIP stream.  In backward the data gradient is the critical path (the previous layer waits for
+    it); the weight gradient of a layer is needed only by the optimizer.  Launched on a side stream, the MFMA-bound backward-
+    weight kernels run next to the latency-bound kernels of the main stream (batch-norm backward on the small layers, Winograd
+    transforms, gradient adds: 10 us kernels that leave the matrix cores idle) instead of queueing between them.  The side
+    stream forks after the layer's dy is complete and joins before the optimizer (`join`, called by the step); tensors it
+    reads are kept referenced until the join, so neither the caching allocator nor a hipGraph capture needs record_stream.
+    Only used while no data-parallel hook can fire in between (the all-reduce of a bucket must not start before its weight
+    gradients are complete), and only for gradients accumulated straight into the flat gradient buffer."""
+
+    def __init__(self):
+        self.active, self.streams, self.refs = False, {}, []
+
+    def stream(self, device):
+        s = self.streams.get(device)
+        if s is None:
+            s = torch.cuda.Stream(device=device)
+            self.streams[device] = s
+        return s
+
+    def launch(self, device, fn, keep):
+        cur = torch.cuda.current_stream(device)
+        side = self.stream(device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            fn()
+        self.refs.append(keep)
+
+    def join(self):
+        for dev, s in self.streams.items():
+            torch.cuda.current_stream(dev).wait_stream(s)
+        self.refs.clear()
+
+
+_ASYNC_WGRAD = _AsyncWgrad()
+
+
 class prepared_weights:
-    """`with prepared_weights():` around forward + backward of one step (hifihr_amd/traineval.forward_backward)."""
+    """`with prepared_weights():` around forward + backward of one step (hifihr_amd/traineval.forward_backward): the per-step
+    weight re-layout launch on entry; `async_wgrad=True` additionally moves weight gradients to a side stream that is joined on
+    exit (before the optimizer runs)."""
+
+    def __init__(self, async_wgrad=False):
+        self.async_wgrad = bool(async_wgrad) and os.environ.get("HIFIHR_ASYNC_WGRAD", "1") != "0"
 
     def __enter__(self):
         if os.environ.get("HIFIHR_WEIGHT_PREP", "1") != "0":
             _WEIGHT_PREP.begin()
+        # not inside a hipGraph capture: forked branches of a replayed graph ran SLOWER here (8.03 vs 7.74 ms/step) while the same
+        # fork in the eager step gains (7.69 vs 7.83)
+        _ASYNC_WGRAD.active = self.async_wgrad and not torch.cuda.is_current_stream_capturing()
         return self
 
     def __exit__(self, *exc):
         _WEIGHT_PREP.end()
+        if _ASYNC_WGRAD.active:
+            _ASYNC_WGRAD.active = False
+            _ASYNC_WGRAD.join()
         return False
 
 
@@ -446,7 +494,8 @@ class _Conv2dMFMA(torch.autograd.Function):
             U2 = _WEIGHT_PREP.get(ctx.w_param, wk, 2)
             if ctx.needs_input_grad[1] and v_saved is not None:      # the Winograd backward-weight below wants A dy A^T: same read of dy
                 T = N * ((H + 1) // 2) * ((W + 1) // 2)
-                Yt_done = _wino_scratch(gy.device, "Yt", 16 * T * K)
+                # a side-stream weight gradient reads it while the next layer's backward-data already runs: a buffer of its own
+                Yt_done = _wino_scratch(gy.device, ("Yt", ctx.w_param.data_ptr()) if _ASYNC_WGRAD.active else "Yt", 16 * T * K)
 
             def run():
                 if U2 is not None:
@@ -477,7 +526,8 @@ class _Conv2dMFMA(torch.autograd.Function):
             # accumulates (fp32 atomics) straight into the flat gradient buffer when the parameter lives in one
             if v_saved is not None:
                 T = N * ((H + 1) // 2) * ((W + 1) // 2)
-                Yt = Yt_done if Yt_done is not None else _wino_scratch(gy.device, "Yt", 16 * T * K)
+                Yt = Yt_done if Yt_done is not None else _wino_scratch(
+                    gy.device, ("Yt", w.data_ptr()) if _ASYNC_WGRAD.active else "Yt", 16 * T * K)
                 key = (gy.device, "dU", 16 * K * C)
                 dU = _WINO_SCRATCH.get(key)
                 if dU is None:                                   # zero-initialised once; wino_dw_transform hands it back zeroed
@@ -489,9 +539,15 @@ class _Conv2dMFMA(torch.autograd.Function):
                         lib.wino_dy_transform(gy, Yt, N, H, W, K)
                     lib.wino_wgrad_gemm(v_saved, Yt, dU, N, H, W, C, K)
                     lib.wino_dw_transform(dU, tgt, K, C, clear=True)
-                PROFILE.bracket("conv_wgrad_wino", run_w)
+                go = lambda: PROFILE.bracket("conv_wgrad_wino", run_w)
+                keep = (gy, v_saved, Yt, tgt)
             else:
-                PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, tgt, N, H, W, C, K, R, S, stride, pad))
+                go = lambda: PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, tgt, N, H, W, C, K, R, S, stride, pad))
+                keep = (gy, x, tgt)
+            if _ASYNC_WGRAD.active and dw is None:
+                _ASYNC_WGRAD.launch(gy.device, go, keep)
+            else:
+                go()
             if dw is None:
                 _grad_ready(w)
         return dx, dw, None, None, None, db_ret, None

@@ -82,7 +82,10 @@ def data_dic(sample, dat_name, set_name, args, device="cuda"):
 def forward_backward(model, loss_func, optimizer, examples, args, dat_name="FreiHand"):
     """Forward, losses, zero_grad and backward of one iteration (train_hrnet.py:50-104).  Returns (loss, loss_dic)."""
     from .ops import prepared_weights
-    with prepared_weights():                 # one launch re-lays every convolution weight out for this step (ops._WeightPrep)
+    # one launch re-lays every convolution weight out for this step (ops._WeightPrep); weight gradients go to a side stream
+    # (ops._AsyncWgrad) unless data-parallel hooks may launch a bucket's all-reduce in the middle of backward
+    dp = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    with prepared_weights(async_wgrad=not dp):
         return _forward_backward(model, loss_func, optimizer, examples, args, dat_name)
 
 
