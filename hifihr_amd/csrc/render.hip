@@ -5,11 +5,15 @@
 // interpolate_face_attributes x3, ~25 elementwise lighting launches over [B,672,672,*] tensors,
 // hard_rgb_blend and the pooling, with:
 //   render_vertex_kernel      per vertex: NDC projection, area-weighted vertex normal (CSR gather), packing
-//   render_fwd_kernel         one workgroup per 16x16 output-pixel tile (48x48 samples at aa=3): faces are
-//                             culled against the tile and compacted IN FACE ORDER into LDS, every lane walks the
-//                             tile's face list for its aa*aa samples (nearest depth, ties keep the lower face
-//                             index), shades the winners and writes the resolved RGBA pixel plus the per-sample
-//                             face id side buffer (the only per-sample HBM traffic: 4 B/sample).
+//   render_bin_kernel         per (face, image): the face's screen bounding box against the tile grid; the face id is appended
+//                             to the list of every 16x16-pixel tile it overlaps (same predicate the tiles used to evaluate for
+//                             ALL faces: 196 tiles x 1538 faces x 3 gathers per image, most of the forward's time)
+//   render_fwd_kernel         one workgroup per 16x16 output-pixel tile (48x48 samples at aa=3): the tile's face list is
+//                             staged in LDS, (face, pixel) candidates are enumerated densely over the lanes (nearest depth,
+//                             ties keep the lower face index -- a 64-bit atomicMin on (depth, face id), so the list order
+//                             does not matter), winners are shaded, and the resolved RGBA pixel plus the per-sample face id
+//                             side buffer (the only per-sample HBM traffic: 4 B/sample) are written.  A tile with an empty
+//                             list writes background and leaves.
 //   render_bwd_kernel         same tiling, no rasterisation: reads the face ids, recomputes barycentrics and
 //                             shading, back-propagates to per-vertex records with float atomics
 //   render_vertex_bwd_kernel  per vertex: folds NDC / position / normal gradients into d(verts)
@@ -38,9 +42,11 @@ __global__ __launch_bounds__(256) void render_vertex_kernel(RenderDev r, const f
                                                            const float* __restrict__ vcolors, long vcol_bstride,
                                                            const float* __restrict__ cam, float4* __restrict__ vndc,
                                                            float4* __restrict__ vpos, float4* __restrict__ vnrm,
-                                                           float4* __restrict__ vcol) {
+                                                           float4* __restrict__ vcol, int* __restrict__ tile_cnt, int ntiles) {
   const int b = blockIdx.y;
   const int v = blockIdx.x * 256 + threadIdx.x;
+  // the per-tile face counters of this image start at zero for render_bin_kernel (the workspace arrives uninitialised)
+  for (int t = v; t < ntiles; t += gridDim.x * 256) tile_cnt[(size_t)b * ntiles + t] = 0;
   if (v >= r.V) return;
   const float* vb = verts + (size_t)b * r.V * 3;
   const float X = vb[3 * v], Y = vb[3 * v + 1], Z = vb[3 * v + 2];
@@ -63,6 +69,40 @@ __global__ __launch_bounds__(256) void render_vertex_kernel(RenderDev r, const f
   vnrm[o] = make_float4(n[0], n[1], n[2], inv);
   const float* cb = vcolors + (size_t)b * vcol_bstride + 3 * v;
   vcol[o] = make_float4(cb[0], cb[1], cb[2], 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-image face binning: tile_cnt[b][ty][tx] faces in tile_list[b][ty][tx][0 .. F)
+// ------------------------------------------------------------------------------------------------
+template <int AA>
+__global__ __launch_bounds__(256) void render_bin_kernel(RenderDev r, const float4* __restrict__ vndc, int* __restrict__ tile_cnt,
+                                                        int* __restrict__ tile_list) {
+  const int b = blockIdx.y;
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= r.F) return;
+  const int H = r.H, S = H * AA, tiles = (H + kTile - 1) / kTile;
+  const float4* vb = vndc + (size_t)b * r.V;
+  const float4 a = vb[r.faces[3 * f]], c = vb[r.faces[3 * f + 1]], d = vb[r.faces[3 * f + 2]];
+  FaceXYZ fc;
+  fc.x0 = a.x; fc.y0 = a.y; fc.z0 = a.z; fc.x1 = c.x; fc.y1 = c.y; fc.z1 = c.z; fc.x2 = d.x; fc.y2 = d.y; fc.z2 = d.z;
+  if (face_is_rejected(fc)) return;
+  const float xmin = fminf(fc.x0, fminf(fc.x1, fc.x2)), xmax = fmaxf(fc.x0, fmaxf(fc.x1, fc.x2));
+  const float ymin = fminf(fc.y0, fminf(fc.y1, fc.y2)), ymax = fmaxf(fc.y0, fmaxf(fc.y1, fc.y2));
+  // tile t spans samples [t * kTile * AA, t * kTile * AA + n * AA - 1]; its NDC bounds are the ones render_fwd_kernel tests against
+  // (index 0 holds the largest coordinate).  Negated comparisons keep a face with a NaN coordinate in every tile, as before.
+  int tx0 = tiles, tx1 = -1, ty0 = tiles, ty1 = -1;
+  for (int t = 0; t < tiles; ++t) {
+    const int o = t * kTile, n = min(kTile, H - o);
+    const float hi = pix_to_ndc(S - 1 - min(o * AA, S - 1), S), lo = pix_to_ndc(S - 1 - min(o * AA + n * AA - 1, S - 1), S);
+    if (!(xmin > hi || xmax < lo)) { tx0 = min(tx0, t); tx1 = t; }
+    if (!(ymin > hi || ymax < lo)) { ty0 = min(ty0, t); ty1 = t; }
+  }
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      const size_t tile = ((size_t)b * tiles + ty) * tiles + tx;
+      const int slot = atomicAdd(tile_cnt + tile, 1);
+      tile_list[tile * r.F + slot] = f;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -167,7 +207,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
                                                         const float4* __restrict__ vpos, const float4* __restrict__ vnrm,
                                                         const float4* __restrict__ vcol, const float* __restrict__ light_color,
                                                         const float* __restrict__ light_dir, float* __restrict__ rgba,
-                                                        int* __restrict__ face_id) {
+                                                        int* __restrict__ face_id, int* __restrict__ tile_cnt,
+                                                        const int* __restrict__ tile_list) {
   HIP_DYNAMIC_SHARED(float4, smem_raw)
   FwdLds<AA>& L = *reinterpret_cast<FwdLds<AA>*>(smem_raw);
   constexpr int SW = kTile * AA;
@@ -181,48 +222,26 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
   const bool live = (px < H) && (py < H);
   const int cols = min(kTile, H - ox), rows = min(kTile, H - oy);      // pixel columns / rows of the tile inside the image
   const float4* vb = vndc + (size_t)b * r.V;
-  // ---- early out: a tile that the mesh's screen bounding box misses is background.  Most tiles of a hand image are (the hand
-  // covers ~1/4 of it), and finding that out by culling all F faces costs 3 dependent gathers per face; the V vertices are one
-  // coalesced pass (V/256 loads per lane).  Non-finite coordinates (a vertex on the camera plane) disable the shortcut.
-  {
-    float bx0 = 3.4e38f, bx1 = -3.4e38f, by0 = 3.4e38f, by1 = -3.4e38f;
-    bool bad = false;
-    for (int v = tid; v < r.V; v += 256) {
-      const float4 p = vb[v];
-      bad |= !(fabsf(p.x) <= 3.0e38f && fabsf(p.y) <= 3.0e38f);      // false for NaN and +-inf
-      bx0 = fminf(bx0, p.x); bx1 = fmaxf(bx1, p.x); by0 = fminf(by0, p.y); by1 = fmaxf(by1, p.y);
-    }
+  // ---- this tile's face list (render_bin_kernel); an empty one means background ----
+  const int tiles = (H + kTile - 1) / kTile;
+  const size_t tile = ((size_t)b * tiles + blockIdx.y) * tiles + blockIdx.x;
+  const int nlist = tile_cnt[tile];
+  const int* flist = tile_list + tile * r.F;
+  if (nlist == 0) {
+    if (!live) return;
+    float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      bx0 = fminf(bx0, __shfl_down(bx0, o, 64)); bx1 = fmaxf(bx1, __shfl_down(bx1, o, 64));
-      by0 = fminf(by0, __shfl_down(by0, o, 64)); by1 = fmaxf(by1, __shfl_down(by1, o, 64));
-    }
-    const bool wave_bad = __ballot(bad) != 0ull;
-    if (lane == 0) { L.rec[wave * 5] = bx0; L.rec[wave * 5 + 1] = bx1; L.rec[wave * 5 + 2] = by0; L.rec[wave * 5 + 3] = by1; L.rec[wave * 5 + 4] = wave_bad ? 1.f : 0.f; }
-    __syncthreads();
-    bx0 = fminf(fminf(L.rec[0], L.rec[5]), fminf(L.rec[10], L.rec[15])); bx1 = fmaxf(fmaxf(L.rec[1], L.rec[6]), fmaxf(L.rec[11], L.rec[16]));
-    by0 = fminf(fminf(L.rec[2], L.rec[7]), fminf(L.rec[12], L.rec[17])); by1 = fmaxf(fmaxf(L.rec[3], L.rec[8]), fmaxf(L.rec[13], L.rec[18]));
-    const bool any_bad = (L.rec[4] + L.rec[9] + L.rec[14] + L.rec[19]) != 0.f;
-    __syncthreads();                                                   // rec is reused by the face list below
-    // NDC bounds of the tile's samples (index 0 is the largest coordinate), as sxs / sys hold them below
-    const float thx = pix_to_ndc(S - 1 - min(ox * AA, S - 1), S), tlx = pix_to_ndc(S - 1 - min(ox * AA + cols * AA - 1, S - 1), S);
-    const float thy = pix_to_ndc(S - 1 - min(oy * AA, S - 1), S), tly = pix_to_ndc(S - 1 - min(oy * AA + rows * AA - 1, S - 1), S);
-    if (!any_bad && (bx0 > thx || bx1 < tlx || by0 > thy || by1 < tly)) {
-      if (!live) return;
-      float acc[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < AA; ++i)
 #pragma unroll
-      for (int i = 0; i < AA; ++i)
-#pragma unroll
-        for (int j = 0; j < AA; ++j) {
-          face_id[((size_t)b * S + (py * AA + i)) * S + (px * AA + j)] = -1;
-          acc[0] += r.bg[0]; acc[1] += r.bg[1]; acc[2] += r.bg[2];          // the same sums the full path forms: bit-identical output
-        }
-      const float inv = (float)(AA * AA);
-      const size_t plane = (size_t)H * H;
-      float* o = rgba + (size_t)b * 4 * plane + (size_t)py * H + px;
-      o[0] = acc[0] / inv; o[plane] = acc[1] / inv; o[2 * plane] = acc[2] / inv; o[3 * plane] = 0.f / inv;
-      return;
-    }
+      for (int j = 0; j < AA; ++j) {
+        face_id[((size_t)b * S + (py * AA + i)) * S + (px * AA + j)] = -1;
+        acc[0] += r.bg[0]; acc[1] += r.bg[1]; acc[2] += r.bg[2];          // the same sums the full path forms: bit-identical output
+      }
+    const float inv = (float)(AA * AA);
+    const size_t plane = (size_t)H * H;
+    float* o = rgba + (size_t)b * 4 * plane + (size_t)py * H + px;
+    o[0] = acc[0] / inv; o[plane] = acc[1] / inv; o[2 * plane] = acc[2] / inv; o[3 * plane] = 0.f / inv;
+    return;
   }
   // NDC coordinates of the tile's samples (indices past the image edge are clamped; they are never candidates)
   for (int e = tid; e < 2 * SW; e += 256) {
@@ -234,38 +253,24 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
   for (int e = tid; e < SW * SW; e += 256) L.zbuf[e] = ~0ull;
   if (tid == 0) L.list_n = 0;
   __syncthreads();
-  // tile bounds in NDC (index 0 of the tile is the largest coordinate)
-  const float txhi = L.sxs[0], txlo = L.sxs[cols * AA - 1];
-  const float tyhi = L.sys[0], tylo = L.sys[rows * AA - 1];
 
-  for (int base = 0; base < r.F; base += 256) {
-    // ---- cull one chunk of 256 faces against the tile; ordered compaction into LDS ----
-    const int f = base + tid;
-    bool keep = false;
-    FaceXYZ fc;
-    float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
-    if (f < r.F) {
+  for (int base = 0; base < nlist; base += 256) {
+    // ---- stage the next 256 listed faces in LDS (vertex gathers + bounding box) ----
+    const int k = base + tid;
+    const int cnt = min(256, nlist - base);
+    if (k < nlist) {
+      const int f = flist[k];
       const float4 a = vb[r.faces[3 * f]], c = vb[r.faces[3 * f + 1]], d = vb[r.faces[3 * f + 2]];
-      fc.x0 = a.x; fc.y0 = a.y; fc.z0 = a.z; fc.x1 = c.x; fc.y1 = c.y; fc.z1 = c.z; fc.x2 = d.x; fc.y2 = d.y; fc.z2 = d.z;
-      xmin = fminf(fc.x0, fminf(fc.x1, fc.x2)); xmax = fmaxf(fc.x0, fmaxf(fc.x1, fc.x2));
-      ymin = fminf(fc.y0, fminf(fc.y1, fc.y2)); ymax = fmaxf(fc.y0, fmaxf(fc.y1, fc.y2));
-      keep = !(xmin > txhi || xmax < txlo || ymin > tyhi || ymax < tylo) && !face_is_rejected(fc);
-    }
-    const unsigned long long m = __ballot(keep);
-    if (lane == 0) L.wave_cnt[wave] = __popcll(m);
-    __syncthreads();
-    int off = L.list_n;
-    for (int w = 0; w < wave; ++w) off += L.wave_cnt[w];
-    off += __popcll(m & ((1ull << lane) - 1ull));
-    if (keep) {
-      float* q = L.rec + off * kRecW;
-      q[0] = fc.x0; q[1] = fc.y0; q[2] = fc.x1; q[3] = fc.y1; q[4] = fc.x2; q[5] = fc.y2; q[6] = fc.z0; q[7] = fc.z1;
-      q[8] = fc.z2; q[9] = __int_as_float(f); q[10] = 0.f; q[11] = 0.f; q[12] = xmin; q[13] = xmax; q[14] = ymin; q[15] = ymax;
+      float* q = L.rec + (L.list_n + tid) * kRecW;
+      q[0] = a.x; q[1] = a.y; q[2] = c.x; q[3] = c.y; q[4] = d.x; q[5] = d.y; q[6] = a.z; q[7] = c.z;
+      q[8] = d.z; q[9] = __int_as_float(f); q[10] = 0.f; q[11] = 0.f;
+      q[12] = fminf(a.x, fminf(c.x, d.x)); q[13] = fmaxf(a.x, fmaxf(c.x, d.x));
+      q[14] = fminf(a.y, fminf(c.y, d.y)); q[15] = fmaxf(a.y, fmaxf(c.y, d.y));
     }
     __syncthreads();
-    const int n = L.list_n + L.wave_cnt[0] + L.wave_cnt[1] + L.wave_cnt[2] + L.wave_cnt[3];
-    const bool last = (base + 256 >= r.F);
-    const bool flush = (n > 0) && (last || (n + 256 > kCap));
+    const int n = L.list_n + cnt;
+    const bool last = (base + 256 >= nlist);
+    const bool flush = last || (n + 256 > kCap);
     if (flush) raster_candidates<AA>(L, n, cols, rows);
     __syncthreads();
     if (tid == 0) L.list_n = flush ? 0 : n;
@@ -295,6 +300,11 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
   }
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const size_t vo = (size_t)b * r.V;
+  int cur_f = -1;
+  FaceXYZ fc;
+  float4 p0, p1, p2, n0, n1, n2, c0, c1, c2;
+  fc.x0 = fc.y0 = fc.z0 = fc.x1 = fc.y1 = fc.z1 = fc.x2 = fc.y2 = fc.z2 = 0.f;
+  p0 = p1 = p2 = n0 = n1 = n2 = c0 = c1 = c2 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < AA; ++i) {
 #pragma unroll
@@ -306,15 +316,17 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
         acc[0] += r.bg[0]; acc[1] += r.bg[1]; acc[2] += r.bg[2];
         continue;
       }
-      const int i0 = r.faces[3 * f], i1 = r.faces[3 * f + 1], i2 = r.faces[3 * f + 2];
-      const float4 a = vndc[vo + i0], c = vndc[vo + i1], d = vndc[vo + i2];
-      FaceXYZ fc;
-      fc.x0 = a.x; fc.y0 = a.y; fc.z0 = a.z; fc.x1 = c.x; fc.y1 = c.y; fc.z1 = c.z; fc.x2 = d.x; fc.y2 = d.y; fc.z2 = d.z;
+      if (f != cur_f) {          // the aa x aa samples of an interior pixel share one face: its 12 vertex records are gathered once
+        cur_f = f;
+        const int i0 = r.faces[3 * f], i1 = r.faces[3 * f + 1], i2 = r.faces[3 * f + 2];
+        const float4 a = vndc[vo + i0], c = vndc[vo + i1], d = vndc[vo + i2];
+        fc.x0 = a.x; fc.y0 = a.y; fc.z0 = a.z; fc.x1 = c.x; fc.y1 = c.y; fc.z1 = c.z; fc.x2 = d.x; fc.y2 = d.y; fc.z2 = d.z;
+        p0 = vpos[vo + i0]; p1 = vpos[vo + i1]; p2 = vpos[vo + i2];
+        n0 = vnrm[vo + i0]; n1 = vnrm[vo + i1]; n2 = vnrm[vo + i2];
+        c0 = vcol[vo + i0]; c1 = vcol[vo + i1]; c2 = vcol[vo + i2];
+      }
       float bary[3];
       bary_of(fc, sx[j], sy[i], bary);
-      const float4 p0 = vpos[vo + i0], p1 = vpos[vo + i1], p2 = vpos[vo + i2];
-      const float4 n0 = vnrm[vo + i0], n1 = vnrm[vo + i1], n2 = vnrm[vo + i2];
-      const float4 c0 = vcol[vo + i0], c1 = vcol[vo + i1], c2 = vcol[vo + i2];
       const float P[3] = {bary[0] * p0.x + bary[1] * p1.x + bary[2] * p2.x, bary[0] * p0.y + bary[1] * p1.y + bary[2] * p2.y,
                           bary[0] * p0.z + bary[1] * p1.z + bary[2] * p2.z};
       const float N[3] = {bary[0] * n0.x + bary[1] * n1.x + bary[2] * n2.x, bary[0] * n0.y + bary[1] * n1.y + bary[2] * n2.y,
@@ -545,15 +557,26 @@ __global__ __launch_bounds__(256) void render_vertex_bwd_kernel(RenderDev r, con
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// workspace: four float4[B][V] vertex arrays, the float[B][V][12] gradient records of the backward, then the forward's per-tile face
+// lists: int cnt[B][tiles^2] and int list[B][tiles^2][F] (worst case: the whole mesh inside one tile)
+static size_t vertex_part_bytes(const RenderDev& r, int B) { return (size_t)B * r.V * (4 * sizeof(float4) + 12 * sizeof(float)); }
+
 size_t render_workspace_bytes(const RenderDev& r, int B) {
-  return (size_t)B * r.V * (4 * sizeof(float4) + 12 * sizeof(float));
+  const size_t tiles = (size_t)((r.H + kTile - 1) / kTile) * ((r.H + kTile - 1) / kTile);
+  return vertex_part_bytes(r, B) + (size_t)B * tiles * sizeof(int) * (1 + (size_t)r.F);
 }
 
-static void carve(const RenderDev& r, int B, void* ws, float4** vndc, float4** vpos, float4** vnrm, float4** vcol, float** gvrec) {
+static void carve(const RenderDev& r, int B, void* ws, float4** vndc, float4** vpos, float4** vnrm, float4** vcol, float** gvrec,
+                  int** tile_cnt = nullptr, int** tile_list = nullptr) {
   float4* p = reinterpret_cast<float4*>(ws);
   const size_t n = (size_t)B * r.V;
   *vndc = p; *vpos = p + n; *vnrm = p + 2 * n; *vcol = p + 3 * n;
   *gvrec = reinterpret_cast<float*>(p + 4 * n);
+  if (tile_cnt != nullptr) {
+    const size_t tiles = (size_t)((r.H + kTile - 1) / kTile) * ((r.H + kTile - 1) / kTile);
+    *tile_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + vertex_part_bytes(r, B));
+    *tile_list = *tile_cnt + (size_t)B * tiles;
+  }
 }
 
 hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float* vcolors, long vcol_bstride, const float* cam,
@@ -561,17 +584,23 @@ hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float
                              hipStream_t st) {
   float4 *vndc, *vpos, *vnrm, *vcol;
   float* gvrec;
-  carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec);
-  hipLaunchKernelGGL(render_vertex_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, vcolors, vcol_bstride, cam,
-                     vndc, vpos, vnrm, vcol);
+  int *tile_cnt, *tile_list;
+  carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec, &tile_cnt, &tile_list);
   const int tiles = (r.H + kTile - 1) / kTile;
-  const dim3 grid(tiles, tiles, B);
+  hipLaunchKernelGGL(render_vertex_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, vcolors, vcol_bstride, cam,
+                     vndc, vpos, vnrm, vcol, tile_cnt, tiles * tiles);
+  const dim3 grid(tiles, tiles, B), bgrid((r.F + 255) / 256, B);
+#define HIFIHR_RENDER_FWD(AA_)                                                                                                          \
+  hipLaunchKernelGGL(render_bin_kernel<AA_>, bgrid, dim3(256), 0, st, r, vndc, tile_cnt, tile_list);                                    \
+  hipLaunchKernelGGL(render_fwd_kernel<AA_>, grid, dim3(256), sizeof(FwdLds<AA_>), st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, \
+                     rgba, face_id, tile_cnt, tile_list);
   switch (r.aa) {
-    case 1: hipLaunchKernelGGL(render_fwd_kernel<1>, grid, dim3(256), sizeof(FwdLds<1>), st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, rgba, face_id); break;
-    case 2: hipLaunchKernelGGL(render_fwd_kernel<2>, grid, dim3(256), sizeof(FwdLds<2>), st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, rgba, face_id); break;
-    case 3: hipLaunchKernelGGL(render_fwd_kernel<3>, grid, dim3(256), sizeof(FwdLds<3>), st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, rgba, face_id); break;
+    case 1: HIFIHR_RENDER_FWD(1) break;
+    case 2: HIFIHR_RENDER_FWD(2) break;
+    case 3: HIFIHR_RENDER_FWD(3) break;
     default: return hipErrorInvalidValue;
   }
+#undef HIFIHR_RENDER_FWD
   return hipGetLastError();
 }
 
