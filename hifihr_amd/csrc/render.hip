@@ -117,6 +117,10 @@ struct FwdLds {
   int wave_cnt[4];
   int wave_tot[4];
   int list_n;
+  int wq[4][128];                                        // per-wave queue of surviving (face, pixel) candidates
+#ifdef HIFIHR_RENDER_STAMP
+  long long dbg[4];     // cycles in candidate rectangles, scan, candidate loop; sum of `total`
+#endif
 };
 
 // Rasterise the n faces currently listed in LDS.  Work items are (face, candidate pixel) pairs -- the pixels of the
@@ -128,6 +132,12 @@ template <int AA>
 __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols, int rows) {
   constexpr int SW = kTile * AA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef HIFIHR_RENDER_STAMP
+  long long rc_t = clock64();
+#define HIFIHR_RC_STAMP(i) { const long long now_ = clock64(); if (tid == 0) L.dbg[i] += now_ - rc_t; rc_t = now_; }
+#else
+#define HIFIHR_RC_STAMP(i)
+#endif
   // (1) candidate rectangle of every listed face (2 faces per lane), packed into rec[10]
   int cnt[2] = {0, 0};
 #pragma unroll
@@ -151,6 +161,7 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
       }
     }
   }
+  HIFIHR_RC_STAMP(0)
   // (2) block-wide exclusive scan of the counts
   const int pair = cnt[0] + cnt[1];
   int incl = pair;
@@ -169,20 +180,21 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
   const int total = L.wave_tot[0] + L.wave_tot[1] + L.wave_tot[2] + L.wave_tot[3];
   if (tid == 0) L.coff[n] = total;
   __syncthreads();
-  // (3) one (face, pixel) candidate per lane per round
-  for (int c = tid; c < total; c += 256) {
-    int lo = 0, hi = n - 1;                    // largest k with coff[k] <= c
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (L.coff[mid] <= c) lo = mid; else hi = mid - 1;
-    }
-    const int k = lo;
+  HIFIHR_RC_STAMP(1)
+#ifdef HIFIHR_RENDER_STAMP
+  if (tid == 0) L.dbg[3] += total;
+#endif
+  // (3) (face, pixel) candidates, one per lane per round, in two stages.  Stage A is cheap and runs on every candidate: find the
+  //     face (binary search in the prefix sums), then two conservative rejects -- the pixel's sample square misses the triangle
+  //     (render_math.h square_misses_face), or the face's nearest vertex lies behind what all aa x aa samples of the pixel already
+  //     hold (interpolated depth is a convex combination of the vertex depths; 1e-5 margin, strict, so a tie is never decided
+  //     here; a stale, farther depth only rejects less).  Survivors are compacted per wave into an LDS queue, and stage B -- the
+  //     aa x aa exact sample tests with their six IEEE divisions each, ~2500 instructions that a wave executes in full as soon as
+  //     ONE of its lanes needs them -- runs on dense waves of 64 survivors.  Overlapping layers (front / back of the hand, fingers
+  //     over the palm) made stage B the critical path of the whole kernel: a tile with 60 candidates per pixel took 280 us.
+  const auto stage_b = [&](int entry) {
+    const int k = entry >> 8, cy = (entry >> 4) & 15, cx = entry & 15;
     const float* q = L.rec + k * kRecW;
-    const int info = __float_as_int(q[10]);
-    const int x0 = info & 15, y0 = (info >> 4) & 15, w = info >> 8;
-    const int local = c - L.coff[k];
-    const int dy = local / w, dx = local - dy * w;
-    const int cx = x0 + dx, cy = y0 + dy;
     FaceXYZ f;
     f.x0 = q[0]; f.y0 = q[1]; f.x1 = q[2]; f.y1 = q[3]; f.x2 = q[4]; f.y2 = q[5]; f.z0 = q[6]; f.z1 = q[7]; f.z2 = q[8];
     const unsigned fidu = (unsigned)__float_as_int(q[9]);
@@ -198,8 +210,61 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
         }
       }
     }
+  };
+  int* wq = L.wq[wave];
+  int qn = 0;                                    // entries queued by this wave (wave-uniform)
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int base = 0; base < total; base += 256) {
+    const int c = base + tid;
+    bool survive = false;
+    int packed = 0;
+    if (c < total) {
+      int lo = 0, hi = n - 1;                    // largest k with coff[k] <= c
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (L.coff[mid] <= c) lo = mid; else hi = mid - 1;
+      }
+      const int k = lo;
+      const float* q = L.rec + k * kRecW;
+      const int info = __float_as_int(q[10]);
+      const int x0 = info & 15, y0 = (info >> 4) & 15, w = info >> 8;
+      const int local = c - L.coff[k];
+      const int dy = local / w, dx = local - dy * w;
+      const int cx = x0 + dx, cy = y0 + dy;
+      FaceXYZ f;
+      f.x0 = q[0]; f.y0 = q[1]; f.x1 = q[2]; f.y1 = q[3]; f.x2 = q[4]; f.y2 = q[5]; f.z0 = q[6]; f.z1 = q[7]; f.z2 = q[8];
+      survive = !square_misses_face(f, L.sxs[cx * AA + AA - 1], L.sxs[cx * AA], L.sys[cy * AA + AA - 1], L.sys[cy * AA]);
+      if (survive) {
+        const float znear = fminf(f.z0, fminf(f.z1, f.z2)) * (1.0f - 1e-5f);
+        bool behind = true;
+#pragma unroll
+        for (int i = 0; i < AA; ++i)
+#pragma unroll
+          for (int j = 0; j < AA; ++j) {
+            const unsigned long long key = L.zbuf[(cy * AA + i) * SW + cx * AA + j];
+            behind = behind && (key != ~0ull) && (__int_as_float((int)(unsigned)(key >> 32)) < znear);
+          }
+        survive = !behind;
+      }
+      packed = (k << 8) | (cy << 4) | cx;
+    }
+    const unsigned long long m = __ballot(survive);
+    if (survive) wq[qn + __popcll(m & lt)] = packed;
+    qn += __popcll(m);
+    (void)__ballot(true);                        // wave-level rendezvous: this wave's LDS writes are ordered before the reads below
+    if (qn >= 64) {
+      stage_b(wq[lane]);
+      const int rest = qn - 64;
+      const int moved = lane < rest ? wq[64 + lane] : 0;
+      (void)__ballot(true);
+      if (lane < rest) wq[lane] = moved;
+      qn = rest;
+      (void)__ballot(true);
+    }
   }
+  if (lane < qn) stage_b(wq[lane]);
   __syncthreads();
+  HIFIHR_RC_STAMP(2)
 }
 
 template <int AA>
@@ -227,6 +292,15 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
   const size_t tile = ((size_t)b * tiles + blockIdx.y) * tiles + blockIdx.x;
   const int nlist = tile_cnt[tile];
   const int* flist = tile_list + tile * r.F;
+#ifdef HIFIHR_RENDER_STAMP        // diagnostic build (tools/render_stamp.py): per-tile duration replaces the face count in the workspace
+  const long long stamp0 = clock64();
+  long long stamp_raster = 0, stamp_stage = 0, stamp_t;
+#define HIFIHR_STAMP_BEGIN stamp_t = clock64();
+#define HIFIHR_STAMP_END(acc) acc += clock64() - stamp_t;
+#else
+#define HIFIHR_STAMP_BEGIN
+#define HIFIHR_STAMP_END(acc)
+#endif
   if (nlist == 0) {
     if (!live) return;
     float acc[3] = {0.f, 0.f, 0.f};
@@ -252,10 +326,14 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
   }
   for (int e = tid; e < SW * SW; e += 256) L.zbuf[e] = ~0ull;
   if (tid == 0) L.list_n = 0;
+#ifdef HIFIHR_RENDER_STAMP
+  if (tid < 4) L.dbg[tid] = 0;
+#endif
   __syncthreads();
 
   for (int base = 0; base < nlist; base += 256) {
     // ---- stage the next 256 listed faces in LDS (vertex gathers + bounding box) ----
+    HIFIHR_STAMP_BEGIN
     const int k = base + tid;
     const int cnt = min(256, nlist - base);
     if (k < nlist) {
@@ -271,8 +349,11 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
     const int n = L.list_n + cnt;
     const bool last = (base + 256 >= nlist);
     const bool flush = last || (n + 256 > kCap);
+    HIFIHR_STAMP_END(stamp_stage)
+    HIFIHR_STAMP_BEGIN
     if (flush) raster_candidates<AA>(L, n, cols, rows);
     __syncthreads();
+    HIFIHR_STAMP_END(stamp_raster)
     if (tid == 0) L.list_n = flush ? 0 : n;
     __syncthreads();
   }
@@ -342,6 +423,14 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
   const size_t plane = (size_t)H * H;
   float* o = rgba + (size_t)b * 4 * plane + (size_t)py * H + px;
   o[0] = acc[0] / inv; o[plane] = acc[1] / inv; o[2 * plane] = acc[2] / inv; o[3 * plane] = acc[3] / inv;
+#ifdef HIFIHR_RENDER_STAMP
+  if (tid == 0) {
+    tile_cnt[tile] = (nlist << 20) | (int)min((clock64() - stamp0) >> 6, (long long)0xfffff);    // faces, cycles / 64
+    int* dbg = const_cast<int*>(flist);
+    dbg[0] = (int)(stamp_stage >> 6); dbg[1] = (int)(stamp_raster >> 6);
+    dbg[2] = (int)(L.dbg[0] >> 6); dbg[3] = (int)(L.dbg[1] >> 6); dbg[4] = (int)(L.dbg[2] >> 6); dbg[5] = (int)L.dbg[3];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -76,6 +76,28 @@ HIFIHR_HD bool sample_face(const FaceXYZ& f, float xmin, float xmax, float ymin,
   return true;
 }
 
+// Conservative pixel reject: true only when NO point of the axis-aligned square [xlo, xhi] x [ylo, yhi] (a pixel's sample span) can
+// pass sample_face's inside test.  Each edge function is affine, so its extreme over the square sits at a corner; if that extreme
+// is on the outside by more than the rounding error of the evaluation (16 ulp of the two products: generous), every sample of the
+// square fails `e > 0` (or `e < 0` for the other orientation) in sample_face as well: skipping them leaves the result unchanged.
+HIFIHR_HD bool edge_outside_square(float ax, float ay, float bx, float by, float xlo, float xhi, float ylo, float yhi, bool pos) {
+  const float dx = bx - ax, dy = by - ay;
+  // e(p) = (px - ax) dy - (py - ay) dx grows with px iff dy > 0 and with py iff dx < 0; take the max corner (pos) or the min corner
+  const float px = ((dy > 0.f) == pos) ? xhi : xlo;
+  const float py = ((dx < 0.f) == pos) ? yhi : ylo;
+  const float u = px - ax, v = py - ay;
+  const float e = u * dy - v * dx;                       // same expression as edge_fn
+  const float tol = 1e-6f * (fabsf(u * dy) + fabsf(v * dx));
+  return pos ? (e < -tol) : (e > tol);
+}
+HIFIHR_HD bool square_misses_face(const FaceXYZ& f, float xlo, float xhi, float ylo, float yhi) {
+  const float area = edge_fn(f.x2, f.y2, f.x0, f.y0, f.x1, f.y1) + kRasterEps;
+  const bool pos = area > 0.f;
+  return edge_outside_square(f.x1, f.y1, f.x2, f.y2, xlo, xhi, ylo, yhi, pos) ||
+         edge_outside_square(f.x2, f.y2, f.x0, f.y0, xlo, xhi, ylo, yhi, pos) ||
+         edge_outside_square(f.x0, f.y0, f.x1, f.y1, xlo, xhi, ylo, yhi, pos);
+}
+
 // Barycentrics of a sample known to be covered by face f (backward pass recomputation).
 HIFIHR_HD void bary_of(const FaceXYZ& f, float px, float py, float* bary) {
   const float area = edge_fn(f.x2, f.y2, f.x0, f.y0, f.x1, f.y1) + kRasterEps;
