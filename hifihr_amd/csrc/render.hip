@@ -26,6 +26,10 @@
 namespace hifihr {
 
 constexpr int kTile = 16;            // output pixels per tile edge
+constexpr int kFwdThreads = 512;     // forward tile kernel: 8 waves.  The kernel's duration is its slowest tile (a tile where the hand's
+                                     // layers pile up holds 10-16 k (face, pixel) candidates); candidates are independent, so more waves
+                                     // per tile shorten exactly that critical path.  Staging, the scan and shading use the first 256 lanes.
+constexpr int kFwdWaves = kFwdThreads / 64;
 constexpr int kCap = 512;            // faces held in LDS per pass (2 per lane in the candidate expansion)
 constexpr int kRecW = 16;            // floats per face record in LDS
 
@@ -115,9 +119,9 @@ struct FwdLds {
   int coff[kCap + 1];                                    // exclusive prefix sum of candidate pixels per listed face
   float sxs[kTile * AA], sys[kTile * AA];                // NDC coordinates of the tile's sample columns / rows
   int wave_cnt[4];
-  int wave_tot[4];
+  int wave_tot[kFwdWaves];
   int list_n;
-  int wq[4][128];                                        // per-wave queue of surviving (face, pixel) candidates
+  int wq[kFwdWaves][128];                                // per-wave queue of surviving (face, pixel) candidates
 #ifdef HIFIHR_RENDER_STAMP
   long long dbg[4];     // cycles in candidate rectangles, scan, candidate loop; sum of `total`
 #endif
@@ -138,11 +142,11 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
 #else
 #define HIFIHR_RC_STAMP(i)
 #endif
-  // (1) candidate rectangle of every listed face (2 faces per lane), packed into rec[10]
-  int cnt[2] = {0, 0};
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int k = tid * 2 + q;
+  // (1) candidate rectangle of every listed face (one face per lane: kCap == kFwdThreads), packed into rec[10]
+  static_assert(kCap == kFwdThreads, "one listed face per lane");
+  int cnt = 0;
+  {
+    const int k = tid;
     if (k < n) {
       const float xmin = L.rec[k * kRecW + 12], xmax = L.rec[k * kRecW + 13], ymin = L.rec[k * kRecW + 14], ymax = L.rec[k * kRecW + 15];
       int x0 = 16, x1 = -1, y0 = 16, y1 = -1;
@@ -156,15 +160,14 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
       }
       const int w = x1 - x0 + 1, h = y1 - y0 + 1;
       if (w > 0 && h > 0) {
-        cnt[q] = w * h;
+        cnt = w * h;
         L.rec[k * kRecW + 10] = __int_as_float(x0 | (y0 << 4) | (w << 8));
       }
     }
   }
   HIFIHR_RC_STAMP(0)
   // (2) block-wide exclusive scan of the counts
-  const int pair = cnt[0] + cnt[1];
-  int incl = pair;
+  int incl = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int v = __shfl_up(incl, o, 64);
@@ -174,10 +177,10 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
   __syncthreads();
   int base = 0;
   for (int w = 0; w < wave; ++w) base += L.wave_tot[w];
-  const int excl = base + incl - pair;
-  if (tid * 2 < n) L.coff[tid * 2] = excl;
-  if (tid * 2 + 1 < n) L.coff[tid * 2 + 1] = excl + cnt[0];
-  const int total = L.wave_tot[0] + L.wave_tot[1] + L.wave_tot[2] + L.wave_tot[3];
+  if (tid < n) L.coff[tid] = base + incl - cnt;
+  int total = 0;
+#pragma unroll
+  for (int w = 0; w < kFwdWaves; ++w) total += L.wave_tot[w];
   if (tid == 0) L.coff[n] = total;
   __syncthreads();
   HIFIHR_RC_STAMP(1)
@@ -214,7 +217,7 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
   int* wq = L.wq[wave];
   int qn = 0;                                    // entries queued by this wave (wave-uniform)
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int base = 0; base < total; base += 256) {
+  for (int base = 0; base < total; base += kFwdThreads) {
     const int c = base + tid;
     bool survive = false;
     int packed = 0;
@@ -268,7 +271,7 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
 }
 
 template <int AA>
-__global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const float4* __restrict__ vndc,
+__global__ __launch_bounds__(kFwdThreads) void render_fwd_kernel(RenderDev r, const float4* __restrict__ vndc,
                                                         const float4* __restrict__ vpos, const float4* __restrict__ vnrm,
                                                         const float4* __restrict__ vcol, const float* __restrict__ light_color,
                                                         const float* __restrict__ light_dir, float* __restrict__ rgba,
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
   const int tx = (lane & 7) + 8 * (wave & 1), ty = (lane >> 3) + 8 * (wave >> 1);
   const int ox = blockIdx.x * kTile, oy = blockIdx.y * kTile;
   const int px = ox + tx, py = oy + ty;
-  const bool live = (px < H) && (py < H);
+  const bool live = (tid < kTile * kTile) && (px < H) && (py < H);      // one pixel per lane of the first four waves
   const int cols = min(kTile, H - ox), rows = min(kTile, H - oy);      // pixel columns / rows of the tile inside the image
   const float4* vb = vndc + (size_t)b * r.V;
   // ---- this tile's face list (render_bin_kernel); an empty one means background ----
@@ -318,13 +321,13 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
     return;
   }
   // NDC coordinates of the tile's samples (indices past the image edge are clamped; they are never candidates)
-  for (int e = tid; e < 2 * SW; e += 256) {
+  for (int e = tid; e < 2 * SW; e += kFwdThreads) {
     const int idx = e < SW ? e : e - SW;
     const int g = min((e < SW ? ox : oy) * AA + idx, S - 1);
     const float v = pix_to_ndc(S - 1 - g, S);
     if (e < SW) L.sxs[idx] = v; else L.sys[idx] = v;
   }
-  for (int e = tid; e < SW * SW; e += 256) L.zbuf[e] = ~0ull;
+  for (int e = tid; e < SW * SW; e += kFwdThreads) L.zbuf[e] = ~0ull;
   if (tid == 0) L.list_n = 0;
 #ifdef HIFIHR_RENDER_STAMP
   if (tid < 4) L.dbg[tid] = 0;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderDev r, const floa
     HIFIHR_STAMP_BEGIN
     const int k = base + tid;
     const int cnt = min(256, nlist - base);
-    if (k < nlist) {
+    if (tid < 256 && k < nlist) {
       const int f = flist[k];
       const float4 a = vb[r.faces[3 * f]], c = vb[r.faces[3 * f + 1]], d = vb[r.faces[3 * f + 2]];
       float* q = L.rec + (L.list_n + tid) * kRecW;
@@ -681,7 +684,7 @@ hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float
   const dim3 grid(tiles, tiles, B), bgrid((r.F + 255) / 256, B);
 #define HIFIHR_RENDER_FWD(AA_)                                                                                                          \
   hipLaunchKernelGGL(render_bin_kernel<AA_>, bgrid, dim3(256), 0, st, r, vndc, tile_cnt, tile_list);                                    \
-  hipLaunchKernelGGL(render_fwd_kernel<AA_>, grid, dim3(256), sizeof(FwdLds<AA_>), st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, \
+  hipLaunchKernelGGL(render_fwd_kernel<AA_>, grid, dim3(kFwdThreads), sizeof(FwdLds<AA_>), st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, \
                      rgba, face_id, tile_cnt, tile_list);
   switch (r.aa) {
     case 1: HIFIHR_RENDER_FWD(1) break;
