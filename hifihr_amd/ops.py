@@ -290,6 +290,7 @@ class _WeightPrep:
     def __init__(self):
         self.entries = {}          # (data_ptr, kind) -> [parameter, K, C, RS, kind, buffer]
         self.table, self.njobs, self.dirty, self.active, self.served = None, 0, False, False, set()
+        self._retired = []         # superseded job tables stay allocated: a captured hipGraph may still replay a launch that reads one
 
     def get(self, w, wk, kind):
         """The prepared buffer of `kind` for the parameter `w` (physical [K][R][S][C] = wk), or None (caller does it itself)."""
@@ -314,6 +315,8 @@ class _WeightPrep:
         lib = get_lib()
         if self.dirty:
             jobs = [(e[0], e[5], e[1], e[2], e[3], e[4]) for e in self.entries.values()]
+            if self.table is not None:
+                self._retired.append((self.table, [e[5] for e in self.entries.values()]))
             self.table, self.njobs = lib.prep_jobs(jobs, jobs[0][0].device), len(jobs)
             self.served, self.dirty = set(self.entries.keys()), False
         PROFILE.bracket("weight_prep", lambda: lib.weight_prep(self.table, self.njobs, 256))
