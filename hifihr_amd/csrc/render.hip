@@ -458,7 +458,11 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
                                                         const float* __restrict__ light_dir, const int* __restrict__ face_id,
                                                         const float* __restrict__ grad_rgba, float* __restrict__ gvrec,
                                                         float* __restrict__ glight_color, float* __restrict__ glight_dir,
-                                                        int use_lds) {
+                                                        int use_lds
+#ifdef HIFIHR_RENDER_STAMP
+                                                        , int* __restrict__ dbg_tiles
+#endif
+                                                        ) {
   // use_lds: the per-vertex gradient records of ONE image (V x 12 floats, 37 KB for MANO) are accumulated in LDS with
   // ds_add_f32 and flushed once per tile with contiguous global atomics.  Scattering one global float atomic per lane
   // per value instead (64 different rows per wave instruction) ran at ~0.08 TB/s and was 85 % of this kernel's time.
@@ -485,11 +489,18 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
   if (lane == 0) any_hit[wave] = (hm != 0ull);
   __syncthreads();
   if (!(any_hit[0] | any_hit[1] | any_hit[2] | any_hit[3])) return;
+#ifdef HIFIHR_RENDER_STAMP
+  const long long bs0 = clock64();
+  long long bs1 = 0, bs2 = 0;
+#endif
   const int nacc = r.V * 12;
   if (use_lds) {
     for (int e = tid; e < nacc; e += 256) lacc[e] = 0.f;
     __syncthreads();
   }
+#ifdef HIFIHR_RENDER_STAMP
+  bs1 = clock64();
+#endif
   float glc[3] = {0.f, 0.f, 0.f}, gl[3] = {0.f, 0.f, 0.f};
   LightDir Ld;
   const float raw[3] = {light_dir[3 * b], light_dir[3 * b + 1], light_dir[3 * b + 2]};
@@ -565,6 +576,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
   }
   if (use_lds) {
     __syncthreads();
+#ifdef HIFIHR_RENDER_STAMP
+    bs2 = clock64();
+#endif
     float* gdst = gvrec + (size_t)b * r.V * 12;
     for (int e = tid; e < nacc; e += 256) {
       const float v = lacc[e];
@@ -588,6 +602,11 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
       normalize3_bwd(raw, Ld.l, Ld.inv_norm, t + 3, gd);       // through F.normalize(direction)
       for (int k = 0; k < 3; ++k) atomicAdd(glight_dir + 3 * b + k, gd[k]);
     }
+#ifdef HIFIHR_RENDER_STAMP
+    const long long bs3 = clock64();
+    int* d = dbg_tiles + (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+    d[0] = (int)((bs1 - bs0) >> 6); d[1] = (int)((bs2 - bs1) >> 6); d[2] = (int)((bs3 - bs2) >> 6); d[3] = 1;
+#endif
   }
 }
 
@@ -701,7 +720,14 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
                              float* gvcolors, float* glight_color, float* glight_dir, void* ws, hipStream_t st) {
   float4 *vndc, *vpos, *vnrm, *vcol;
   float* gvrec;
+#ifdef HIFIHR_RENDER_STAMP
+  int *dbg_cnt, *dbg_list;
+  carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec, &dbg_cnt, &dbg_list);
+#define HIFIHR_BWD_DBG , dbg_list
+#else
   carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec);
+#define HIFIHR_BWD_DBG
+#endif
   hipError_t e = hipMemsetAsync(gvrec, 0, (size_t)B * r.V * 12 * sizeof(float), st);
   if (e != hipSuccess) return e;
   if ((e = hipMemsetAsync(glight_color, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
@@ -712,9 +738,9 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
   const int use_lds = lds <= 60 * 1024;               // MANO: 37 KB; larger meshes fall back to direct global atomics
   const size_t dyn = use_lds ? lds : 0;
   switch (r.aa) {
-    case 1: hipLaunchKernelGGL(render_bwd_kernel<1>, grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds); break;
-    case 2: hipLaunchKernelGGL(render_bwd_kernel<2>, grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds); break;
-    case 3: hipLaunchKernelGGL(render_bwd_kernel<3>, grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds); break;
+    case 1: hipLaunchKernelGGL(render_bwd_kernel<1>, grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds HIFIHR_BWD_DBG); break;
+    case 2: hipLaunchKernelGGL(render_bwd_kernel<2>, grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds HIFIHR_BWD_DBG); break;
+    case 3: hipLaunchKernelGGL(render_bwd_kernel<3>, grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds HIFIHR_BWD_DBG); break;
     default: return hipErrorInvalidValue;
   }
   hipLaunchKernelGGL(render_vertex_bwd_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, cam, vndc, vnrm, gvrec, gverts, gvcolors);
