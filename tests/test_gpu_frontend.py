@@ -14,6 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_train_then_evaluate_from_checkpoint(tmp_path, capsys):
     sys.path.insert(0, ROOT)
     import train_hrnet as T
+    prev = torch.cuda.current_stream()
+    try:
+        _run(T, tmp_path, capsys)
+    finally:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(prev)          # main() switches to a non-default stream for graph capture
+
+
+def _run(T, tmp_path, capsys):
     cfg = json.load(open(os.path.join(ROOT, "tests", "data", "nimble_style_config.json")))
     cfg.update(base_out_path=str(tmp_path / "run"), train_batch=8, val_batch=8, total_epochs=1, pretrain="res18",
                losses=["joint_3d", "vert_3d", "mpose", "mshape", "mtex", "edge_length", "texture", "mrgb", "sil", "ssim_tex"])
