@@ -236,3 +236,31 @@ def test_nimble_config_compositions_match_oracle_from_features(config):
     for name, g, r in (("d/d feat", feat_g.grad, feat_c.grad), ("d/d low", low_g.grad, low_c.grad)):
         err = float((g.cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-12)
         assert err < 5e-3, (name, err)
+
+
+def test_overfitting_one_batch_reduces_every_supervised_term():
+    """System-level check of the gradients and the fused Adam: 80 steps on ONE fixed batch (graph replay) must drive the
+    3-D supervision terms down by a large factor -- the encoder can memorise 8 images even though they are noise."""
+    from hifihr_amd.losses import LossFunction
+    from hifihr_amd.optim import FlatParams, FusedAdam
+    from hifihr_amd.traineval import GraphedTrainStep
+    B = 8
+    tables, args, model, ref, ex, ex_cpu = _setup(B)
+    prev = torch.cuda.current_stream()
+    torch.cuda.set_stream(torch.cuda.Stream())
+    try:
+        flat = FlatParams(model)
+        opt = FusedAdam(flat, lr=1e-3)
+        step = GraphedTrainStep(model, LossFunction(), opt, ex, args)
+        loss0, dic0 = step()
+        first = {k: float(dic0[k]) for k in ("joint_3d", "vert_3d")}
+        for _ in range(80):
+            loss, dic = step()
+        last = {k: float(dic[k]) for k in ("joint_3d", "vert_3d")}
+        torch.cuda.synchronize()
+    finally:
+        torch.cuda.set_stream(prev)
+    print("overfit:", first, "->", last)
+    assert all(torch.isfinite(torch.tensor(v)) for v in last.values())
+    for k in first:
+        assert last[k] < 0.5 * first[k], (k, first[k], last[k])
