@@ -177,11 +177,27 @@ def main():
         alg_flop = alg_us = 0.0                        # SURVEY 8(d) accounting: direct-convolution FLOPs of the same layers, and the
         #                                                time of everything that computes them (Winograd: transforms + GEMMs)
         for (geom, direction), cnt in counts.items():
-            if direction == "gemm":                    # the 16 batched GEMMs of a Winograd convolution (same kernel, batch = 16)
+            if direction in ("gemm", "gemm-blas"):     # the 16 batched GEMMs of a Winograd convolution (same kernel, batch = 16)
                 _, N_, H_, W_, C_, K_ = geom
                 T_ = N_ * ((H_ + 1) // 2) * ((W_ + 1) // 2)
                 Vs = torch.randn(16 * T_ * C_, device=dev); Us = torch.randn(16 * K_ * C_, device=dev) * 0.05
                 Ms = torch.empty(16 * T_ * K_, device=dev)
+                if direction == "gemm-blas":           # these GEMMs run on the vendor library (ops._blas_gemm): not part of the
+                    #                                    conv_igemm_kernel roofline, but part of the convolution path's time
+                    per_step = cnt / nprof
+                    xs = torch.randn(N_ * H_ * W_ * C_, device=dev); wsrc = torch.randn(K_ * 9 * C_, device=dev) * 0.05
+                    ys = torch.empty(N_ * H_ * W_ * K_, device=dev)
+                    full = lambda: ops._wino_conv(lib, xs, wsrc, ys, None, N_, H_, W_, C_, K_, 0, U=Us)
+                    for _ in range(3):
+                        full()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        full()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    alg_flop += 2.0 * N_ * H_ * W_ * K_ * 9 * C_ * per_step; alg_us += e0.elapsed_time(e1) * 1e3 / 10 * per_step
+                    continue
                 nbw = lib.wino_gemm_workspace_bytes(N_, H_, W_, C_, K_)
                 wsb = ops._CONV_WS.get(dev) if nbw else None
                 if nbw and (wsb is None or wsb.numel() * 4 < nbw):
@@ -245,8 +261,9 @@ def main():
         conv_roof = {"bound": "mfma", "achieved": tot_flop / (tot_us * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                      "frac": tot_flop / (tot_us * 1e-6) / 1e12 / 157.3, "traffic": conv_traffic,
                      "compulsory_bytes_per_launch": tot_bytes / max(tot_n, 1.0),
-                     "kernel": "conv_igemm_kernel (all instantiations: direct forward / backward-data convolutions and the batched GEMMs of "
-                               "the Winograd F(2x2,3x3) layers, counted with the FLOPs they actually execute)",
+                     "kernel": "conv_igemm_kernel (all instantiations: direct forward / backward-data convolutions and those batched GEMMs of "
+                               "the Winograd F(2x2,3x3) layers that run on it -- the square 256 / 512-channel ones go to the vendor "
+                               "library, ops._blas_gemm --, counted with the FLOPs they actually execute)",
                      "launches_per_step": tot_n, "avg_us": tot_us / max(tot_n, 1.0), "us_per_step": tot_us,
                      "executed_flop_per_step": tot_flop,
                      "algorithmic": {"flop_per_step": alg_flop, "us_per_step": alg_us, "achieved": alg_flop / (alg_us * 1e-6) / 1e12,

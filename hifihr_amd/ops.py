@@ -390,6 +390,18 @@ class prepared_weights:
         return False
 
 
+def _blas_gemm(kind, C, K):
+    """The 16 Winograd GEMMs of a layer are plain batched fp32 GEMMs (no fusion, no gather), so where the vendor library's
+    kernel is faster than conv_igemm_kernel / conv_wgrad_kernel on that shape it is used (torch.bmm -> rocBLAS / hipBLASLt, exact
+    fp32 MFMA like ours).  Measured at B = 32 (tools/time_bmm.py, own vs library, us): backward-weight dU = Y'^T V always wins --
+    128 ch 54 / 42, 256 ch 53 / 30, 256 -> 512 91 / 53, 512 ch 144 / 96 (137 TFLOP/s); forward / backward-data M = V U^T wins for
+    the square 256- and 512-channel layers (50 / 42, 148 / 133) and loses at 128 channels (52 / 69); 256 <-> 512 is a tie.
+    HIFIHR_BLAS_GEMM=0 keeps everything on the hand-written kernels (the C-ABI entry points are unchanged)."""
+    if os.environ.get("HIFIHR_BLAS_GEMM", "1") == "0":
+        return False
+    return True if kind == "wgrad" else (C == K and C >= 256)
+
+
 def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None, dy_out=None):
     """y[N][H][W][K] = conv3x3(x[N][H][W][C], w[K][3][3][C]) through weight / input transform, 16 batched GEMMs, output
     transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter).
@@ -412,15 +424,19 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias
         if ws is None or ws.numel() * 4 < nb:
             ws = torch.zeros(max(nb, 32 << 20) // 4 + 64, dtype=torch.float32, device=dev)
             _CONV_WS[dev] = ws
+    blas = _blas_gemm("fwd", C, K)
     if PROFILE.on:
-        PROFILE.conv_log.append((("wino", N, H, W, C, K), "gemm"))
+        PROFILE.conv_log.append((("wino", N, H, W, C, K), "gemm-blas" if blas else "gemm"))
     if not prepared:
         lib.wino_weight_transform(w_krsc, U, K, C, flip)
     if dy_out is not None:                            # backward: x is dy, the backward-weight transform Y' comes out of the same read
         lib.wino_input_dy_transform(x, V, dy_out, N, H, W, C)
     else:
         lib.wino_input_transform(x, V, N, H, W, C)
-    lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)
+    if blas:
+        torch.bmm(V[:16 * T * C].view(16, T, C), U[:16 * K * C].view(16, K, C).transpose(1, 2), out=M[:16 * T * K].view(16, T, K))
+    else:
+        lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)
     lib.wino_output_transform(M, y, stats, N, H, W, K, bias=bias, act=act)
     return V if keep_v else None
 
@@ -540,7 +556,11 @@ class _Conv2dMFMA(torch.autograd.Function):
                 def run_w():
                     if Yt_done is None:
                         lib.wino_dy_transform(gy, Yt, N, H, W, K)
-                    lib.wino_wgrad_gemm(v_saved, Yt, dU, N, H, W, C, K)
+                    if _blas_gemm("wgrad", C, K):
+                        torch.bmm(Yt[:16 * T * K].view(16, T, K).transpose(1, 2), v_saved[:16 * T * C].view(16, T, C),
+                                  out=dU.view(16, K, C))
+                    else:
+                        lib.wino_wgrad_gemm(v_saved, Yt, dU, N, H, W, C, K)
                     lib.wino_dw_transform(dU, tgt, K, C, clear=True)
                 go = lambda: PROFILE.bracket("conv_wgrad_wino", run_w)
                 keep = (gy, v_saved, Yt, tgt)
