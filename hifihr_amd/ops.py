@@ -395,11 +395,12 @@ def _blas_gemm(kind, C, K):
     kernel is faster than conv_igemm_kernel / conv_wgrad_kernel on that shape it is used (torch.bmm -> rocBLAS / hipBLASLt, exact
     fp32 MFMA like ours).  Measured at B = 32 (tools/time_bmm.py, own vs library, us): backward-weight dU = Y'^T V always wins --
     128 ch 54 / 42, 256 ch 53 / 30, 256 -> 512 91 / 53, 512 ch 144 / 96 (137 TFLOP/s); forward / backward-data M = V U^T wins for
-    the square 256- and 512-channel layers (50 / 42, 148 / 133) and loses at 128 channels (52 / 69); 256 <-> 512 is a tie.
+    the 256- and 512-channel layers (256: 50 / 42, 512: 148 / 133, 512 -> 256: 82 / 68) and loses at 128 channels (52 / 69) and for
+    256 -> 512 (85 / 88).
     HIFIHR_BLAS_GEMM=0 keeps everything on the hand-written kernels (the C-ABI entry points are unchanged)."""
     if os.environ.get("HIFIHR_BLAS_GEMM", "1") == "0":
         return False
-    return True if kind == "wgrad" else (C == K and C >= 256)
+    return True if kind == "wgrad" else (C >= 256 and K >= 256 and not (C == 256 and K == 512))
 
 
 def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None, dy_out=None):
