@@ -36,16 +36,26 @@ def init_process_group_from_env(backend: str | None = None):
 
 
 class GradReducer:
-    def __init__(self, flat: FlatParams, num_buckets: int = 4, group=None):
+    def __init__(self, flat: FlatParams, num_buckets: int = 4, group=None, first_fraction: float = 0.08):
+        """Buckets are contiguous in registration (= forward) order, so backward completes them last-to-first and the exchange of
+        bucket 0 is the only one that cannot hide behind backward work: it gets `first_fraction` of the elements (the stem and the
+        first stages are small anyway), the other buckets share the rest equally."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = len(flat.params)
-        # bucket boundaries in parameter index space, ~equal element counts
         total = flat.param_count()
-        bounds, acc, target = [0], 0, total / max(1, num_buckets)
+        if num_buckets > 1:
+            fr = [first_fraction] + [(1.0 - first_fraction) / (num_buckets - 1)] * (num_buckets - 1)
+        else:
+            fr = [1.0]
+        cuts, c = [], 0.0
+        for f in fr[:-1]:
+            c += f
+            cuts.append(c * total)                     # cumulative element targets of the bucket ends
+        bounds, acc = [0], 0
         for i, p in enumerate(flat.params):
             acc += p.numel()
-            if acc >= target * len(bounds) and len(bounds) < num_buckets and i + 1 < n:
+            if len(bounds) - 1 < len(cuts) and acc >= cuts[len(bounds) - 1] and i + 1 < n:
                 bounds.append(i + 1)
         bounds.append(n)
         self.buckets = []                                          # (param lo, param hi, elem lo, elem hi)
