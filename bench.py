@@ -28,7 +28,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
-    ap.add_argument("--encoder", default="res18", choices=["res18", "effb3"], help="res18 = BASELINE configs[1] (headline)")
+    ap.add_argument("--encoder", default="res18", choices=["res18", "res50", "res101", "effb3"], help="res18 = BASELINE configs[1] (headline)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="2 = BASELINE configs[1] (headline); 3 = configs[2] full_rhd_freihand.json: effb3, batch 48, texture + "
                          "perceptual losses, MANO + texture stand-in for the unavailable NIMBLE layer (not a headline line)")

@@ -22,6 +22,14 @@ import torch
 
 _SUBMODULES = ("base_encoder", "hand_encoder", "light_estimator")
 _HEADS = {"encoder1.model.fc": (1000, 512), "encoder._fc": (1000, 1536)}          # unused classifier heads of the reference encoders
+#                                                                                   (512 = ResNet-18; 2048 for ResNet-50 / -101: _head_shape)
+
+
+def _head_shape(head, base_encoder_state):
+    o, i = _HEADS[head]
+    if head == "encoder1.model.fc" and any(".bn3." in k for k in base_encoder_state):     # bottleneck trunk
+        i = 2048
+    return o, i
 
 
 def _head_prefix(base_encoder_state):
@@ -101,7 +109,7 @@ def model_state(model):
         sd = {k: v.detach().clone().contiguous() for k, v in getattr(model, sub).state_dict().items()}
         if sub == "base_encoder":
             head = _head_prefix(sd)
-            o, i = _HEADS[head]
+            o, i = _head_shape(head, sd)
             sd[head + ".weight"] = extra.get(head + ".weight", torch.zeros(o, i))
             sd[head + ".bias"] = extra.get(head + ".bias", torch.zeros(o))
         out[sub] = sd

@@ -49,8 +49,9 @@ class Model(nn.Module):
         if hand_model != "mano":
             raise NotImplementedError(f"hand_model='{hand_model}': only 'mano' is built (NIMBLE assets are not available)")
         self.hand_model, self.root_id, self.root_id_nimble = hand_model, root_id, root_id_nimble
-        if pretrain == "res18":
-            self.features_dim, self.low_feat_dim = 512, 128          # SURVEY.md F6 (reference's 2048/512 is broken)
+        if pretrain in ("res18", "res50", "res101"):
+            # res18: SURVEY.md F6 (the reference hard-codes 2048 / 512, the ResNet-50 / -101 widths, and is broken for res18)
+            self.features_dim, self.low_feat_dim = (512, 128) if pretrain == "res18" else (2048, 512)
             self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=if_4c, conv_impl=conv_impl)
         elif pretrain == "effb3":                                    # models_res_nimble.py:50-53
             from .effnet import EffiEncoder

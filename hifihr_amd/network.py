@@ -96,12 +96,52 @@ class BasicBlock(nn.Module):
         return self.relu(out + idt)
 
 
-class ResNet18Trunk(nn.Module):
-    """torchvision-layout ResNet-18 without avgpool/fc; `layer4_stride=1` = the three stride edits of
-    reference network/res_encoder.py:360-362."""
+class Bottleneck(nn.Module):
+    """torchvision's ResNet v1.5 bottleneck (1x1 -> 3x3 carrying the stride -> 1x1, expansion 4), the block of the reference's
+    res50 / res101 encoders (reference network/res_encoder.py:349-362 through torchvision.models.resnet50 / resnet101; the same
+    class as the vendored utils/Freihand_GNN_mano/network/resnet.py:75-122)."""
+    expansion = 4
 
-    def __init__(self, in_ch=3, layer4_stride=1, conv_impl="aten"):
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
+        self.conv1 = _conv(inplanes, planes, 1, 1, 0)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _conv(planes, planes, 3, stride, 1)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = _conv(planes, planes * 4, 1, 1, 0)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        if isinstance(self.conv1, Conv2dMFMA):
+            from . import ops
+            out, st = self.conv1(x, want_stats=True)
+            out = ops.bn_act(out, st, self.bn1, None, True)
+            out, st = self.conv2(out, want_stats=True)
+            out = ops.bn_act(out, st, self.bn2, None, True)
+            out, st = self.conv3(out, want_stats=True)
+            idt = x
+            if self.downsample is not None:
+                idt, st2 = self.downsample[0](x, want_stats=True)
+                idt = ops.bn_act(idt, st2, self.downsample[1], None, False)
+            return ops.bn_act(out, st, self.bn3, idt, True)
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class ResNet18Trunk(nn.Module):
+    """torchvision-layout ResNet without avgpool/fc (ResNet-18 by default; block=Bottleneck, layers=(3,4,6,3) / (3,4,23,3) give
+    ResNet-50 / -101); `layer4_stride=1` = the three stride edits of reference network/res_encoder.py:360-362."""
+    block, layers = BasicBlock, (2, 2, 2, 2)
+
+    def __init__(self, in_ch=3, layer4_stride=1, conv_impl="aten", block=None, layers=None):
+        super().__init__()
+        if block is not None:
+            self.block, self.layers = block, tuple(layers)
         _CONV_IMPL["impl"] = conv_impl
         self.conv_impl = conv_impl
         self.conv1 = _conv(in_ch, 64, 7, 2, 3)
@@ -109,31 +149,34 @@ class ResNet18Trunk(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         self.inplanes = 64
-        self.layer1 = self._make(64, 2, 1)
-        self.layer2 = self._make(128, 2, 2)
-        self.layer3 = self._make(256, 2, 2)
-        self.layer4 = self._make(512, 2, layer4_stride)
+        self.layer1 = self._make(64, self.layers[0], 1)
+        self.layer2 = self._make(128, self.layers[1], 2)
+        self.layer3 = self._make(256, self.layers[2], 2)
+        self.layer4 = self._make(512, self.layers[3], layer4_stride)
         _CONV_IMPL["impl"] = "aten"
         for m in self.modules():
             if isinstance(m, (nn.Conv2d, Conv2dMFMA)):
                 init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def _make(self, planes, blocks, stride):
+        blk, out = self.block, planes * self.block.expansion
         down = None
-        if stride != 1 or self.inplanes != planes:
-            down = nn.Sequential(_conv(self.inplanes, planes, 1, stride, 0), nn.BatchNorm2d(planes))
-        layers = [BasicBlock(self.inplanes, planes, stride, down)]
-        self.inplanes = planes
-        layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        if stride != 1 or self.inplanes != out:
+            down = nn.Sequential(_conv(self.inplanes, out, 1, stride, 0), nn.BatchNorm2d(out))
+        layers = [blk(self.inplanes, planes, stride, down)]
+        self.inplanes = out
+        layers += [blk(out, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
 
 class Resnet_4C(nn.Module):
     def __init__(self, pretrain="res18", if_4c=False, conv_impl="aten"):
         super().__init__()
-        if pretrain != "res18":
-            raise NotImplementedError(f"encoder '{pretrain}' is not built yet (res18 only in this round)")
-        self.model = ResNet18Trunk(in_ch=4 if if_4c else 3, layer4_stride=1, conv_impl=conv_impl)
+        arch = {"res18": (BasicBlock, (2, 2, 2, 2)), "res50": (Bottleneck, (3, 4, 6, 3)), "res101": (Bottleneck, (3, 4, 23, 3))}
+        if pretrain not in arch:
+            raise NotImplementedError(f"encoder '{pretrain}' is not built (res18 / res50 / res101; the HRNet variants need timm)")
+        self.model = ResNet18Trunk(in_ch=4 if if_4c else 3, layer4_stride=1, conv_impl=conv_impl, block=arch[pretrain][0],
+                                   layers=arch[pretrain][1])
 
     def forward(self, x):
         m = self.model

@@ -40,6 +40,10 @@ def test_submodule_state_dicts_match_reference_classes(names):
         res = ResEncoder(pretrain="res18", if_4c=False, conv_impl=flavour)
         want = [["mmpool.p", [1]]] + [["encoder1.model." + n, s] for n, s in names["resnet18"]["state"] if not n.startswith("fc.")]
         assert _shapes(res) == want, flavour
+    res50 = ResEncoder(pretrain="res50", if_4c=False, conv_impl="aten")
+    want = [["mmpool.p", [1]]] + [["encoder1.model." + n, s] for n, s in names["resnet50"]["state"] if not n.startswith("fc.")]
+    assert _shapes(res50) == want
+    assert names["resnet50"]["state"][-2:] == [["fc.weight", [1000, 2048]], ["fc.bias", [1000]]]
     assert names["mmpool"]["state"] == [["p", [1]]]
     assert names["resnet18"]["state"][-2:] == [["fc.weight", [1000, 512]], ["fc.bias", [1000]]]
     assert names["efficientnet-b3"]["state"][-2:] == [["_fc.weight", [1000, 1536]], ["_fc.bias", [1000]]]
@@ -52,8 +56,9 @@ class _Mine(nn.Module):
         super().__init__()
         from hifihr_amd.effnet import EffiEncoder
         from hifihr_amd.network import HandEncoder, LightEstimator, ResEncoder
-        if pretrain == "res18":
-            self.base_encoder, feat, low = ResEncoder(pretrain="res18", if_4c=False, conv_impl="aten"), 512, 128
+        if pretrain in ("res18", "res50"):
+            self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=False, conv_impl="aten")
+            feat, low = (512, 128) if pretrain == "res18" else (2048, 512)
         else:
             self.base_encoder, feat, low = EffiEncoder("effb3", conv_impl="aten"), 1536, 32
         self.hand_encoder = HandEncoder("mano", [10, 48, None], in_dim=feat)
@@ -70,13 +75,13 @@ class _RefSide(nn.Module):
         holder = self.base_encoder
         for part in head.split(".")[:-1]:
             holder = getattr(holder, part)
-        o, i = ck._HEADS[head]
+        o, i = ck._head_shape(head, model.base_encoder.state_dict())
         setattr(holder, head.split(".")[-1], nn.Linear(i, o))
         self.hand_encoder = copy.deepcopy(model.hand_encoder)
         self.light_estimator = copy.deepcopy(model.light_estimator)
 
 
-@pytest.mark.parametrize("pretrain,head", [("res18", "encoder1.model.fc"), ("effb3", "encoder._fc")])
+@pytest.mark.parametrize("pretrain,head", [("res18", "encoder1.model.fc"), ("res50", "encoder1.model.fc"), ("effb3", "encoder._fc")])
 def test_t7_round_trip_with_reference_side(tmp_path, pretrain, head):
     torch.manual_seed(0)
     model = _Mine(pretrain)

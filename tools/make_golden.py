@@ -301,6 +301,7 @@ def gen_state_dict_names():
         spec = importlib.util.spec_from_file_location("ref_resnet", os.path.join(REF, "utils", "Freihand_GNN_mano", "network", "resnet.py"))
         rn = importlib.util.module_from_spec(spec); spec.loader.exec_module(rn)
         mods["resnet18"] = rn.resnet18()
+        mods["resnet50"] = rn.resnet50()
     for k, m in mods.items():
         out[k] = {"state": [[n, list(t.shape)] for n, t in m.state_dict().items()],
                   "params": [n for n, _ in m.named_parameters()]}
