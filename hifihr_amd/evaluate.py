@@ -65,6 +65,19 @@ class Evaluator:
                 rec["lpips"] = self.lpips_fn(mask_re * 2 - 1, mask_rgbs * 2 - 1).mean()
             self.texture.append(rec)              # device scalars: one host sync at `summary`, not one per batch
 
+    def dump(self, pred_out_path):
+        """utils/train_utils.py:242-254: `[xyz_pred_list, verts_pred_list]` as JSON -- the file the HO-3D challenge server takes
+        (train_hrnet.py:277-293; HO-3D joints were already put back into the HO-3D order / OpenGL axes by `collect`) and the
+        reference's `pred.json` for FreiHAND."""
+        import json
+        import os
+        xyz = torch.cat(self.xyz_pred).cpu().tolist() if self.xyz_pred else []
+        verts = torch.cat(self.verts_pred).cpu().tolist() if self.verts_pred else []
+        os.makedirs(os.path.dirname(os.path.abspath(pred_out_path)), exist_ok=True)
+        with open(pred_out_path, "w") as fo:
+            json.dump([xyz, verts], fo)
+        return len(xyz), len(verts)
+
     def summary(self, xyz_gt=None, verts_gt=None):
         """xyz_gt [n,21,3] / verts_gt [n,778,3]: evaluation_xyz.json / evaluation_verts.json.  Returns a dict with
         'pose_3d' / 'vert_3d' (MPJPE / MPVPE in the inputs' unit, metres in FreiHAND; the reference prints x100 = cm) and

@@ -145,6 +145,12 @@ def test_evaluator_summary_matches_formulas(golden_dir):
     mse = torch.nn.functional.mse_loss(*last)
     assert s["l2"] > 0 and abs(float(ops.ssim(*[t.contiguous() for t in last])) - float(ev.texture[-1]["ssim"])) < 1e-7
     assert abs(float(-10 * mse.log10()) - float(ev.texture[-1]["psnr"])) < 1e-5
+    import json as _json
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:                       # utils/train_utils.py:242-254
+        assert ev.dump(os.path.join(td, "test", "3", "pred.json")) == (6, 6)
+        xyz, verts = _json.load(open(os.path.join(td, "test", "3", "pred.json")))
+        assert len(xyz) == 6 and len(xyz[0]) == 21 and len(verts[0]) == 778 and abs(xyz[4][7][2] - float(g["pr_j"][4, 7, 2])) < 1e-7
     al, err = align_w_scale(torch.from_numpy(g["gt_j"]).float().cuda(), torch.from_numpy(g["pr_j"]).cuda(), return_error=True)
     np.testing.assert_allclose(al.cpu().numpy(), g["al_j"], atol=2e-7)
     assert abs(float(err.mean()) - float(g["mpjpe"])) <= 1e-6 * float(g["mpjpe"])
