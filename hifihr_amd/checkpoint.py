@@ -162,3 +162,30 @@ def load_model(model, optimizer, scheduler, args):
     if scheduler is not None and sd.get("scheduler"):
         scheduler.load_state_dict(sd["scheduler"])
     return model, int(sd.get("epoch", 0)), optimizer, scheduler
+
+
+def rec_freeze(module):
+    """utils/visualize_util.py:932-939: batch-norm momentum 0 everywhere below `module` (running statistics stop moving; batch
+    statistics are still used in train mode) and requires_grad off for every parameter that lives in a CHILD of `module`
+    (parameters held directly by `module` itself keep their flag -- the reference's recursion has that quirk)."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.momentum = 0
+    for child in module.children():
+        for p in child.parameters():
+            p.requires_grad = False
+        rec_freeze(child)
+
+
+def freeze_model_modules(model, args):
+    """utils/train_utils.py:205-240 for the sub-modules this build has.  Call BEFORE optim.FlatParams is built: frozen parameters
+    then stay out of the flat buffers, get no gradient kernels (the ops look at needs_input_grad) and no Adam update."""
+    frozen = []
+    if getattr(args, "only_train_regressor", False) and hasattr(model, "light_estimator"):
+        rec_freeze(model.light_estimator); frozen.append("light_estimator")
+    if getattr(args, "only_train_texture", False):
+        if hasattr(model, "base_encoder"):
+            rec_freeze(model.base_encoder); frozen.append("base_encoder")
+        for name in ("base_layers", "pose_reg", "shape_reg"):
+            rec_freeze(getattr(model.hand_encoder, name)); frozen.append("hand_encoder." + name)
+    return frozen

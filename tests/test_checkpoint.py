@@ -135,3 +135,26 @@ def test_t7_round_trip_with_reference_side(tmp_path, pretrain, head):
         for f in ("exp_avg", "exp_avg_sq"):
             assert torch.equal(s1["state"][k][f], s2["state"][k][f])
         assert float(s1["state"][k]["step"]) == float(s2["state"][k]["step"])
+
+
+def test_freeze_model_modules_semantics():
+    """utils/train_utils.py:205-240 + utils/visualize_util.py:932-939: only_train_texture freezes the image encoder and the
+    pose / shape path of the HandEncoder (batch-norm momentum 0, requires_grad off), the texture / light heads keep training;
+    parameters held directly by the frozen root keep their flag (the reference's quirk: ResEncoder... has none, MMPool.p sits in a child)."""
+    import argparse
+    m = _Mine("res18")
+    m.hand_encoder.tex_reg = nn.Sequential(nn.Linear(512, 128), nn.ReLU(), nn.Linear(128, 10))
+    frozen = ck.freeze_model_modules(m, argparse.Namespace(only_train_texture=True, only_train_regressor=False))
+    assert frozen == ["base_encoder", "hand_encoder.base_layers", "hand_encoder.pose_reg", "hand_encoder.shape_reg"]
+    assert not any(p.requires_grad for p in m.base_encoder.parameters())
+    assert all(b.momentum == 0 for b in m.base_encoder.modules() if isinstance(b, nn.BatchNorm2d))
+    assert not any(p.requires_grad for p in m.hand_encoder.pose_reg.parameters())
+    assert m.hand_encoder.base_layers[1].momentum == 0
+    assert all(p.requires_grad for p in m.hand_encoder.tex_reg.parameters()) and all(p.requires_grad for p in m.hand_encoder.trans_reg.parameters())
+    assert all(p.requires_grad for p in m.light_estimator.parameters())
+    flat = FlatParams(m)                                   # frozen parameters stay out of the flat buffers
+    assert flat.param_count() == sum(p.numel() for p in m.parameters() if p.requires_grad) < 2_000_000
+    lone = nn.Linear(4, 4)
+    ck.rec_freeze(lone)                                    # no children: nothing is frozen
+    assert lone.weight.requires_grad
+    assert ck.freeze_model_modules(_Mine("res18"), argparse.Namespace()) == []

@@ -103,7 +103,7 @@ def main(argv=None):
     args = build_args(cli)
     from hifihr_amd import dist as hdist
     from hifihr_amd import options
-    from hifihr_amd.checkpoint import load_model, save_model
+    from hifihr_amd.checkpoint import freeze_model_modules, load_model, save_model
     from hifihr_amd.data import FreiHandDeviceCache
     from hifihr_amd.losses import LossFunction
     from hifihr_amd.mano_tables import load_mano_pkl, synthetic_mano_tables
@@ -124,6 +124,9 @@ def main(argv=None):
     model = Model(ifRender=args.render, device=device, if_4c=args.four_channel, hand_model=args.hand_model,
                   use_mean_shape=args.use_mean_shape, pretrain=args.pretrain, root_id=args.ROOT, root_id_nimble=args.ROOT_NIMBLE,
                   ifLight=args.light_estimation, mano_tables=tables, texture_stand_in=args.texture_stand_in).to(device).train()
+    frozen = freeze_model_modules(model, args)          # only_train_regressor / only_train_texture (train_hrnet.py:566)
+    if frozen:
+        say("[train_hrnet] frozen:", ", ".join(frozen))
     flat = FlatParams(model)
     hdist.broadcast_params(flat)
     reducer = hdist.GradReducer(flat, num_buckets=4)
