@@ -101,6 +101,7 @@ class HifihrLib:
         c.hifihr_bn_stats_floats.restype = c_int
         c.hifihr_bn_stats.argtypes = [_c_float_p, c_long, c_int, _c_float_p, c_void_p]
         c.hifihr_bn_act_fwd.argtypes = [_c_float_p] * 5 + [c_int, c_long, c_int, c_float, c_float] + [_c_float_p] * 5 + [c_void_p]
+        c.hifihr_bn_act_eval.argtypes = [_c_float_p] * 6 + [c_int, c_long, c_int, c_float, _c_float_p, c_void_p]
         c.hifihr_bn_act_bwd.argtypes = [_c_float_p] * 7 + [c_int, c_long, c_int] + [_c_float_p] * 5 + [c_void_p]
         c.hifihr_conv2d_bwd_weight.argtypes = [_c_float_p] * 3 + ci + [c_void_p]
         c.hifihr_image_to_nhwc4.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
@@ -133,6 +134,12 @@ class HifihrLib:
         c.hifihr_wino_wgrad_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_dw_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_weight_transpose.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
+        c.hifihr_bgemm_nt.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
+        c.hifihr_bgemm_tn_parts.argtypes = [c_int] * 4
+        c.hifihr_bgemm_tn.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
+        c.hifihr_wino_wgrad_parts.argtypes = [c_int] * 5
+        c.hifihr_wino_wgrad_gemm_parts.argtypes = [_c_float_p] * 3 + [c_int] * 6 + [c_void_p]
+        c.hifihr_wino_dw_transform_parts.argtypes = [_c_float_p, c_int, _c_float_p, c_int, c_int, c_void_p]
         c.hifihr_se_pool.argtypes = [_c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_scale.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_bwd_gate.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
@@ -225,6 +232,10 @@ class HifihrLib:
         self.check(self.c.hifihr_bn_act_fwd(_fp(x), _fp(stats), _fp(gamma), _fp(beta), _fp(residual), int(act), c_long(M), C,
                                             c_float(eps), c_float(momentum), _fp(y), _fp(save_mean), _fp(save_invstd), _fp(rmean),
                                             _fp(rvar), _stream_of(x)), "hifihr_bn_act_fwd")
+
+    def bn_act_eval(self, x, rmean, rvar, gamma, beta, residual, act, M, C, eps, y):
+        self.check(self.c.hifihr_bn_act_eval(_fp(x), _fp(rmean), _fp(rvar), _fp(gamma), _fp(beta), _fp(residual), int(act), c_long(M), C,
+                                             c_float(eps), _fp(y), _stream_of(x)), "hifihr_bn_act_eval")
 
     def bn_act_bwd(self, dy, y, x, save_mean, save_invstd, gamma, beta, act, M, C, red, dx, dres, dgamma_acc, dbeta_acc):
         self.check(self.c.hifihr_bn_act_bwd(_fp(dy), _fp(y), _fp(x), _fp(save_mean), _fp(save_invstd), _fp(gamma), _fp(beta), int(act),
@@ -346,6 +357,26 @@ class HifihrLib:
 
     def wino_dw_transform(self, dU, dw_acc, K, C, clear=True):
         self.check(self.c.hifihr_wino_dw_transform(_fp(dU), _fp(dw_acc), K, C, int(bool(clear)), _stream_of(dU)), "hifihr_wino_dw_transform")
+
+    def bgemm_nt(self, A, B, C, M, N, K, batch):
+        self.check(self.c.hifihr_bgemm_nt(_fp(A), _fp(B), _fp(C), M, N, K, batch, _stream_of(A)), "hifihr_bgemm_nt")
+
+    def bgemm_tn_parts(self, M, N, T, batch):
+        return int(self.c.hifihr_bgemm_tn_parts(M, N, T, batch))
+
+    def bgemm_tn(self, A, B, Cparts, M, N, T, batch, parts):
+        self.check(self.c.hifihr_bgemm_tn(_fp(A), _fp(B), _fp(Cparts), M, N, T, batch, parts, _stream_of(A)), "hifihr_bgemm_tn")
+
+    def wino_wgrad_parts(self, N, H, W, C, K):
+        return int(self.c.hifihr_wino_wgrad_parts(N, H, W, C, K))
+
+    def wino_wgrad_gemm_parts(self, V, Y, dU_parts, N, H, W, C, K, parts):
+        self.check(self.c.hifihr_wino_wgrad_gemm_parts(_fp(V), _fp(Y), _fp(dU_parts), N, H, W, C, K, parts, _stream_of(V)),
+                   "hifihr_wino_wgrad_gemm_parts")
+
+    def wino_dw_transform_parts(self, dU_parts, parts, dw_acc, K, C):
+        self.check(self.c.hifihr_wino_dw_transform_parts(_fp(dU_parts), parts, _fp(dw_acc), K, C, _stream_of(dU_parts)),
+                   "hifihr_wino_dw_transform_parts")
 
     def weight_transpose(self, w, wt, K, RS, C):
         self.check(self.c.hifihr_weight_transpose(_fp(w), _fp(wt), K, RS, C, _stream_of(w)), "hifihr_weight_transpose")

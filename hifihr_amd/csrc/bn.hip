@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     float mu, is, var = 0.f;
     if (PRE) {
       mu = save_mean[c]; is = save_invstd[c];
+      if (stats == nullptr) is = 1.0f / sqrtf(is + eps);       // evaluation mode: (running_mean, running_var) were passed in
     } else {
       mu = slot_sum(stats, C, c) * invM;
       var = fmaxf(slot_sum(stats, C, C + c) * invM - mu * mu, 0.f);       // biased batch variance
@@ -443,6 +444,15 @@ hipError_t launch_bn_act_fwd(const float* x, float* stats, const float* gamma, c
     hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(bn_grid(M, C, false)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
                        momentum, y, save_mean, save_invstd, running_mean, running_var);
   }
+  return hipGetLastError();
+}
+
+// evaluation mode (module.eval(): running statistics, nothing updated): y = act((x - running_mean) / sqrt(running_var + eps) * gamma + beta + residual)
+hipError_t launch_bn_act_eval(const float* x, const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                              const float* residual, int act, long M, int C, float eps, float* y, hipStream_t st) {
+  if (!bn_c_ok(C)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(bn_grid(M, C, false)), dim3(256), 0, st, x, (float*)nullptr, gamma, beta, residual, act, M, C,
+                     eps, 0.f, y, const_cast<float*>(running_mean), const_cast<float*>(running_var), (float*)nullptr, (float*)nullptr);
   return hipGetLastError();
 }
 

@@ -1,0 +1,347 @@
+// Batched fp32 GEMM for gfx950 on the f32 matrix cores (v_mfma_f32_16x16x4_f32): the 16 independent products a Winograd
+// F(2x2, 3x3) layer consists of (wino.hip).  Replaces the GEMM half of what the reference's encoder dispatches to one vendor
+// library call per convolution (reference network/res_encoder.py:364-373: conv2d forward / backward-data / backward-weight of the
+// stride-1 3x3 layers with >= 128 channels); round 1 ran these products on the implicit-GEMM gather kernel (conv.hip) or on
+// rocBLAS.  Plain GEMMs need no tap bookkeeping, so this kernel spends its instructions on the matrix pipe:
+//
+//   bgemm_nt_kernel   C[p][m][n] = sum_k A[p][m][k] B[p][n][k]      forward / backward-data  (A = V[16][T][C], B = U[16][K][C])
+//   bgemm_tn_kernel   C[z][p][m][n] = sum_{t in split z} A[p][t][m] B[p][t][n]   backward-weight  (A = Y'[16][T][K], B = V[16][T][C]);
+//                     the reduction over tiles t is split over blockIdx (z) into slabs that wino_dw_transform sums while it reads
+//                     them -- no atomics, no zero-initialised accumulator, bit-reproducible.
+//
+// Structure (both): 128x128 (or 64-wide) macro-tile per 256-thread workgroup, 2 x 2 waves of 64x64, 4 x 4 MFMA 16x16 tiles with
+// independent accumulators per wave (the 16x16x4 form issues every 32 cycles with a 40-cycle dependent latency: 16 accumulators
+// keep the pipe full); 32-deep K chunks = 128 MFMAs = 4096 matrix-pipe cycles per wave between two barriers; operands go
+// global -> LDS with direct-to-LDS loads (global_load_lds_dwordx4: no VGPR staging, no ds_write pass), two LDS stages of 32 KB,
+// so the loads of chunk c + 1 have a whole chunk of MFMAs to land; two workgroups share a CU and cover each other's barrier.
+// LDS images: NT rows are 128 B (32 k), XOR-swizzled at load time on the SOURCE address (an LDS-DMA destination is lane-linear) so
+// that the fragment ds_read_b128 (lane (r, g): row r, k-segment g) are bank-conflict-free; the lane's float4 holds k = 4g .. 4g+3,
+// i.e. the operands of 4 consecutive MFMAs whose hardware k index g stands for k = 4g + s (both operands permuted alike: any
+// bijection of k is a valid reduction order).  TN rows are the 128 output columns of one t (512 B), read with one ds_read_b128
+// per k-step for the lane-indexed operand (lane r supplies rows 4r .. 4r+3 to MFMA tiles 0 .. 3: a row permutation the epilogue
+// undoes) and 4 ds_read_b32 for the register-indexed one.
+// MFMA orientation: the D tile has its rows in registers (4 consecutive per lane) and its column on the lane, so the operand that
+// indexes the CONTIGUOUS output dimension n is fed as MFMA "A": every lane then owns 4 consecutive n and stores them as one float4.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "hifihr_internal.h"
+
+namespace hifihr {
+
+#if defined(HIFIHR_HOSTSIM)
+typedef hs_floatx4 floatx4;
+// emulation of an LDS-DMA: lane `lane` of the wave copies 16 bytes to (wave-uniform base) + 16 * lane
+#define HIFIHR_GLDS16(gptr, lds_wave_base, lane) std::memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * (lane), (gptr), 16)
+#define HIFIHR_WAIT_LOADS() ((void)0)
+#define HIFIHR_PIN() ((void)0)
+#else
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+#define HIFIHR_GLDS16(gptr, lds_wave_base, lane)                                                     \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
+                                   (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+#define HIFIHR_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// MFMAs touch registers only, so the scheduler would otherwise sink the whole block below the wait + barrier that follow it
+// (seen in the ISA: 1 MFMA, vmcnt(0), s_barrier, 127 MFMAs), exposing the load latency the block is there to hide
+#define HIFIHR_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// XCD-aware workgroup renumbering: blocks b and b + 8 share an XCD (its own 4 MB L2), so give every XCD one contiguous eighth
+// of the tile list (consecutive tiles share an operand panel).  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT: C[m][n] = sum_k A[m][k] B[n][k]   (both operands K-contiguous; K % 32 == 0, N % BN == 0, any M)
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void bgemm_nt_kernel(BgemmArgs a) {
+  constexpr int WM = BM / 2, WN = BN / 2;        // per-wave sub-tile (waves 2 x 2)
+  constexpr int TI = WN / 16, TJ = WM / 16;      // MFMA tiles: i over n (D rows, registers), j over m (D columns, lanes)
+  constexpr int STAGE = (BM + BN) * 32;          // floats per LDS stage
+  constexpr int PA = BM / 32, PB = BN / 32;      // 1 KiB pieces (8 rows x 128 B) per wave per chunk
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+
+  int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tiles_pb = a.tiles_m * a.tiles_n;
+  const int p = wg / tiles_pb;
+  wg -= p * tiles_pb;
+  const int tn = wg / a.tiles_m, tm = wg - tn * a.tiles_m;      // m-tiles fastest: neighbours share the B panel
+  const int m0 = tm * BM, n0 = tn * BN;
+  const float* __restrict__ A = a.A + (size_t)p * a.sa;
+  const float* __restrict__ B = a.B + (size_t)p * a.sb;
+  float* __restrict__ C = a.C + (size_t)p * a.sc;
+
+  // loader: piece i of this wave covers rows 8 * (wave + 4 i) .. + 7 of the A (i < PA) or B tile; lane -> (row lane >> 3, physical
+  // 16-byte segment lane & 7), which holds logical segment (lane & 7) ^ ((row >> 1) & 7).  Rows past M read row M - 1 (discarded).
+  unsigned goff[PA + PB];
+#pragma unroll
+  for (int i = 0; i < PA + PB; ++i) {
+    const bool isA = i < PA;
+    const int row = 8 * (wave + 4 * (isA ? i : i - PA)) + (lane >> 3);
+    const int seg = (lane & 7) ^ ((row >> 1) & 7);
+    int grow = (isA ? m0 : n0) + row;
+    const int lim = isA ? a.M : a.N;
+    grow = grow < lim ? grow : lim - 1;
+    goff[i] = (unsigned)grow * (unsigned)(isA ? a.lda : a.ldb) + seg * 4;
+  }
+  auto issue = [&](int chunk, int stage) {
+    float* base = lds + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < PA + PB; ++i) {
+      const bool isA = i < PA;
+      const float* src = (isA ? A : B) + goff[i] + chunk * 32;
+      float* dst = base + (isA ? 0 : BM * 32) + 256 * (wave + 4 * (isA ? i : i - PA));
+      HIFIHR_GLDS16(src, dst, lane);
+    }
+  };
+
+  floatx4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int nch = a.K / 32;
+  const int sw = (r >> 1) & 7;
+  const int offA = (wm * WM + r) * 32, offB = BM * 32 + (wn * WN + r) * 32;
+  issue(0, 0);
+  HIFIHR_WAIT_LOADS();
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const float* s = lds + (c & 1) * STAGE;
+    float4 fa[TJ][2], fb[TI][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ps = ((g + 4 * h) ^ sw) * 4;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) fb[i][h] = *reinterpret_cast<const float4*>(s + offB + i * 512 + ps);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fa[j][h] = *reinterpret_cast<const float4*>(s + offA + j * 512 + ps);
+    }
+    if (c + 1 < nch) issue(c + 1, (c + 1) & 1);          // lands during the 128 MFMAs below
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) {
+            const float bv = k4 == 0 ? fb[i][h].x : k4 == 1 ? fb[i][h].y : k4 == 2 ? fb[i][h].z : fb[i][h].w;
+            const float av = k4 == 0 ? fa[j][h].x : k4 == 1 ? fa[j][h].y : k4 == 2 ? fa[j][h].z : fa[j][h].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
+          }
+    }
+    HIFIHR_PIN();
+    HIFIHR_WAIT_LOADS();
+    __syncthreads();
+  }
+
+  // D[i][j]: register e of lane (r, g) = C[m = .. 16 j + r][n = .. 16 i + 4 g + e]
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int m = m0 + wm * WM + 16 * j + r;
+    if (m < a.M) {
+      float* row = C + (size_t)m * a.ldc + n0 + wn * WN + 4 * g;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+        *reinterpret_cast<float4*>(row + 16 * i) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: C[z][m][n] = sum_{t in split z} A[t][m] B[t][n]   (both operands stored t-major; M % BM == 0, N % BN == 0, any T)
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void bgemm_tn_kernel(BgemmArgs a) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TI = WN / 16, TJ = WM / 16;      // i over n (registers), j over m (lanes, row-permuted: m = TJ * r + j)
+  constexpr int STAGE = (BM + BN) * 32;
+  constexpr int PA = BM / 32, PB = BN / 32;      // pieces per wave per chunk
+  constexpr int RA = 256 / BM, RB = 256 / BN;    // t rows per 1 KiB piece
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+
+  int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tiles_pb = a.tiles_m * a.tiles_n;
+  const int per_split = tiles_pb * a.batch;
+  const int z = wg / per_split;
+  wg -= z * per_split;
+  const int p = wg / tiles_pb;
+  wg -= p * tiles_pb;
+  const int tn = wg / a.tiles_m, tm = wg - tn * a.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const float* __restrict__ A = a.A + (size_t)p * a.sa + m0;
+  const float* __restrict__ B = a.B + (size_t)p * a.sb + n0;
+  float* __restrict__ C = a.C + (size_t)z * a.sc_split + (size_t)p * a.sc;
+
+  const int nch_total = (a.K + 31) / 32;
+  const int c_lo = z * a.cps, c_hi = min(c_lo + a.cps, nch_total);
+
+  // piece i of this wave: t rows R * (wave + 4 i') .. of the chunk, 16 bytes per lane along the tile's columns
+  const int tA = lane / (BM / 4), cA = (lane % (BM / 4)) * 4;
+  const int tB = lane / (BN / 4), cB = (lane % (BN / 4)) * 4;
+  auto issue = [&](int chunk, int stage) {
+    float* base = lds + stage * STAGE;
+    const int t0 = chunk * 32;
+    if (t0 + 32 <= a.K) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int q = wave + 4 * i;
+        HIFIHR_GLDS16(A + (size_t)(t0 + RA * q + tA) * a.lda + cA, base + 256 * q, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int q = wave + 4 * i;
+        HIFIHR_GLDS16(B + (size_t)(t0 + RB * q + tB) * a.ldb + cB, base + BM * 32 + 256 * q, lane);
+      }
+    } else {
+      // ragged last chunk (T % 32 != 0): rows past T must contribute zeros, which an LDS-DMA cannot produce
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int q = wave + 4 * i, t = t0 + RA * q + tA;
+        const float4 v = t < a.K ? *reinterpret_cast<const float4*>(A + (size_t)t * a.lda + cA) : zero;
+        *reinterpret_cast<float4*>(base + 256 * q + 4 * lane) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int q = wave + 4 * i, t = t0 + RB * q + tB;
+        const float4 v = t < a.K ? *reinterpret_cast<const float4*>(B + (size_t)t * a.ldb + cB) : zero;
+        *reinterpret_cast<float4*>(base + BM * 32 + 256 * q + 4 * lane) = v;
+      }
+    }
+  };
+
+  floatx4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  if (c_lo < c_hi) {
+    issue(c_lo, 0);
+    HIFIHR_PIN();
+    HIFIHR_WAIT_LOADS();
+    __syncthreads();
+  }
+  for (int c = c_lo; c < c_hi; ++c) {
+    const float* s = lds + ((c - c_lo) & 1) * STAGE;
+    float fa[8][TJ], fb[8][TI];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float* rowA = s + (4 * k + g) * BM + wm * WM + TJ * r;
+      const float* rowB = s + BM * 32 + (4 * k + g) * BN + wn * WN + r;
+      if constexpr (TJ == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(rowA);
+        fa[k][0] = v.x; fa[k][1] = v.y; fa[k][2] = v.z; fa[k][3] = v.w;
+      } else {
+        const float2 v = *reinterpret_cast<const float2*>(rowA);
+        fa[k][0] = v.x; fa[k][1] = v.y;
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i) fb[k][i] = rowB[16 * i];
+    }
+    if (c + 1 < c_hi) issue(c + 1, (c + 1 - c_lo) & 1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[k][i], fa[k][j], acc[i][j], 0, 0, 0);
+    HIFIHR_PIN();
+    HIFIHR_WAIT_LOADS();
+    __syncthreads();
+  }
+
+  // D[i][j]: register e of lane (r, g) = C[m = .. TJ r + j][n = .. 16 i + 4 g + e]
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    float* row = C + (size_t)(m0 + wm * WM + TJ * r + j) * a.ldc + n0 + wn * WN + 4 * g;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+      *reinterpret_cast<float4*>(row + 16 * i) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static int gemm_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+bool bgemm_nt_supported(int M, int N, int K) { return M > 0 && K >= 32 && K % 32 == 0 && N >= 64 && N % 64 == 0; }
+bool bgemm_tn_supported(int M, int N, int T) { return T > 0 && M >= 64 && M % 64 == 0 && N >= 64 && N % 64 == 0; }
+
+hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, hipStream_t st) {
+  if (!bgemm_nt_supported(M, N, K) || batch <= 0) return hipErrorInvalidValue;
+  if ((long)M * K >= (1L << 31) || (long)N * K >= (1L << 31)) return hipErrorInvalidValue;      // 32-bit element offsets
+  BgemmArgs a{};
+  a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
+  a.sa = (long)M * K; a.sb = (long)N * K; a.sc = (long)M * N; a.batch = batch;
+  int bn = (N % 128 == 0) ? 128 : 64;
+  int bm = 128;
+  if (const char* e = getenv("HIFIHR_GEMM_NT_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (N % bn) bn = 64; }
+  a.tiles_m = (M + bm - 1) / bm; a.tiles_n = N / bn; a.splits = 1; a.cps = K / 32; a.sc_split = 0;
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * batch));
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((bgemm_nt_kernel<128, 128>), grid, dim3(256), 0, st, a);
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((bgemm_nt_kernel<128, 64>), grid, dim3(256), 0, st, a);
+  else if (bm == 64 && bn == 128) hipLaunchKernelGGL((bgemm_nt_kernel<64, 128>), grid, dim3(256), 0, st, a);
+  else if (bm == 64 && bn == 64) hipLaunchKernelGGL((bgemm_nt_kernel<64, 64>), grid, dim3(256), 0, st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// number of K-split slabs launch_bgemm_tn writes for this shape (the caller provides parts * batch * M * N floats)
+int bgemm_tn_parts(int M, int N, int T, int batch) {
+  if (const char* e = getenv("HIFIHR_GEMM_TN_PARTS")) { const int v = atoi(e); if (v > 0) return v; }
+  const int bm = (M % 128 == 0) ? 128 : 64, bn = (N % 128 == 0) ? 128 : 64;
+  const int tiles = (M / bm) * (N / bn) * batch, nch = (T + 31) / 32;
+  // fill the chip's 2 x CUs workgroup slots once; at least 8 chunks per split so that a slab round trip stays small
+  int splits = (2 * gemm_cus()) / tiles;
+  if (splits > nch / 8) splits = nch / 8;
+  if (splits < 1) splits = 1;
+  const int cps = (nch + splits - 1) / splits;
+  return (nch + cps - 1) / cps;
+}
+
+hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st) {
+  if (!bgemm_tn_supported(M, N, T) || batch <= 0 || parts <= 0) return hipErrorInvalidValue;
+  BgemmArgs a{};
+  a.A = A; a.B = B; a.C = Cparts; a.M = M; a.N = N; a.K = T; a.lda = M; a.ldb = N; a.ldc = N;
+  a.sa = (long)T * M; a.sb = (long)T * N; a.sc = (long)M * N; a.batch = batch;
+  int bm = (M % 128 == 0) ? 128 : 64, bn = (N % 128 == 0) ? 128 : 64;
+  if (const char* e = getenv("HIFIHR_GEMM_TN_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (M % bm) bm = 64; if (N % bn) bn = 64; }
+  a.tiles_m = M / bm; a.tiles_n = N / bn;
+  const int nch = (T + 31) / 32;
+  a.cps = (nch + parts - 1) / parts;
+  if ((nch + a.cps - 1) / a.cps != parts) return hipErrorInvalidValue;       // parts must come from bgemm_tn_parts
+  a.splits = parts; a.sc_split = (long)batch * M * N;
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * batch * parts));
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((bgemm_tn_kernel<128, 128>), grid, dim3(256), 0, st, a);
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((bgemm_tn_kernel<128, 64>), grid, dim3(256), 0, st, a);
+  else if (bm == 64 && bn == 128) hipLaunchKernelGGL((bgemm_tn_kernel<64, 128>), grid, dim3(256), 0, st, a);
+  else if (bm == 64 && bn == 64) hipLaunchKernelGGL((bgemm_tn_kernel<64, 64>), grid, dim3(256), 0, st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace hifihr

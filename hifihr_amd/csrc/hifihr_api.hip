@@ -380,6 +380,14 @@ int hifihr_bn_act_fwd(const float* x, float* stats, const float* gamma, const fl
   return HIFIHR_OK;
 }
 
+int hifihr_bn_act_eval(const float* x, const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                       const float* residual, int act, long M, int C, float eps, float* y, void* stream) {
+  if (!x || !running_mean || !running_var || !gamma || !beta || !y || !bn_dims_ok(M, C) || act < 0 || act > 2 || (act == 2 && residual))
+    return fail(HIFIHR_EINVAL, "hifihr_bn_act_eval: bad argument (C % 4 == 0, C <= 4096; swish takes no residual)");
+  HIP_TRY(hifihr::launch_bn_act_eval(x, running_mean, running_var, gamma, beta, residual, act, M, C, eps, y, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_bn_act_bwd(const float* dy, const float* y, const float* x, const float* save_mean, const float* save_invstd,
                       const float* gamma, const float* beta, int act, long M, int C, float* red_scratch, float* dx, float* dres,
                       float* dgamma_acc, float* dbeta_acc, void* stream) {
@@ -612,10 +620,60 @@ static hifihr::ConvGeom wino_gemm_geom(long T, int C, int K) {
   return g;
 }
 
+// HIFIHR_BGEMM=0 keeps the Winograd products on round 1's gather kernels (conv.hip); tuning / A-B runs only
+static bool use_bgemm() {
+  const char* e = getenv("HIFIHR_BGEMM");
+  return e == nullptr || atoi(e) != 0;
+}
+
 size_t hifihr_wino_gemm_workspace_bytes(int N, int H, int W, int C, int K) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
   const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+  if (use_bgemm() && T < (1L << 30) && hifihr::bgemm_nt_supported((int)T, K, C)) return 0;     // gemm.hip needs no workspace
   return hifihr::conv_sk_workspace_bytes(wino_gemm_geom(T, C, K));
+}
+
+int hifihr_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* stream) {
+  if (!A || !B || !C || batch <= 0 || !hifihr::bgemm_nt_supported(M, N, K))
+    return fail(HIFIHR_EINVAL, "hifihr_bgemm_nt: bad argument (K % 32 == 0, N % 64 == 0)");
+  HIP_TRY(hifihr::launch_bgemm_nt(A, B, C, M, N, K, batch, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_bgemm_tn_parts(int M, int N, int T, int batch) {
+  if (batch <= 0 || !hifihr::bgemm_tn_supported(M, N, T)) return 0;
+  return hifihr::bgemm_tn_parts(M, N, T, batch);
+}
+
+int hifihr_bgemm_tn(const float* A, const float* B, float* C_parts, int M, int N, int T, int batch, int parts, void* stream) {
+  if (!A || !B || !C_parts || batch <= 0 || parts <= 0 || !hifihr::bgemm_tn_supported(M, N, T))
+    return fail(HIFIHR_EINVAL, "hifihr_bgemm_tn: bad argument (M % 64 == 0, N % 64 == 0)");
+  HIP_TRY(hifihr::launch_bgemm_tn(A, B, C_parts, M, N, T, batch, parts, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_wgrad_parts(int N, int H, int W, int C, int K) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || !use_bgemm()) return 0;
+  const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+  if (T >= (1L << 30) || !hifihr::bgemm_tn_supported(K, C, (int)T)) return 0;
+  return hifihr::bgemm_tn_parts(K, C, (int)T, 16);
+}
+
+int hifihr_wino_wgrad_gemm_parts(const float* V, const float* Y, float* dU_parts, int N, int H, int W, int C, int K, int parts, void* stream) {
+  if (!V || !Y || !dU_parts || N <= 0 || H <= 0 || W <= 0 || parts <= 0)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_wgrad_gemm_parts: bad argument");
+  const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+  if (T >= (1L << 30) || !hifihr::bgemm_tn_supported(K, C, (int)T) || parts != hifihr::bgemm_tn_parts(K, C, (int)T, 16))
+    return fail(HIFIHR_EINVAL, "hifihr_wino_wgrad_gemm_parts: parts must be hifihr_wino_wgrad_parts(N, H, W, C, K) > 0");
+  HIP_TRY(hifihr::launch_bgemm_tn(Y, V, dU_parts, K, C, (int)T, 16, parts, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw_acc, int K, int C, void* stream) {
+  if (!dU_parts || !dw_acc || parts <= 0 || K <= 0 || C < 4 || C % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_dw_transform_parts: bad argument");
+  HIP_TRY(hifihr::launch_wino_dw_transform_parts(dU_parts, parts, dw_acc, K, C, (hipStream_t)stream));
+  return HIFIHR_OK;
 }
 
 int hifihr_wino_weight_transform(const float* w, float* U, int K, int C, int flip, void* stream) {
@@ -634,6 +692,10 @@ int hifihr_wino_gemm(const float* V, const float* U, float* M, int N, int H, int
   if (!V || !U || !M || N <= 0 || H <= 0 || W <= 0 || C < 32 || C % 32 != 0 || K < 4 || K % 4 != 0)
     return fail(HIFIHR_EINVAL, "hifihr_wino_gemm: bad argument (C % 32 == 0, K % 4 == 0)");
   const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+  if (use_bgemm() && T < (1L << 30) && hifihr::bgemm_nt_supported((int)T, K, C)) {
+    HIP_TRY(hifihr::launch_bgemm_nt(V, U, M, (int)T, K, C, 16, (hipStream_t)stream));
+    return HIFIHR_OK;
+  }
   HIP_TRY(hifihr::launch_conv_igemm(wino_gemm_geom(T, C, K), V, U, nullptr, M, nullptr, ws, ws_bytes, (hipStream_t)stream));
   return HIFIHR_OK;
 }

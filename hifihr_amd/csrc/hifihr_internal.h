@@ -73,6 +73,8 @@ hipError_t launch_bn_stats(const float* x, long M, int C, float* stats, hipStrea
 hipError_t launch_bn_act_fwd(const float* x, float* stats, const float* gamma, const float* beta, const float* residual,
                              int relu, long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,
                              float* running_mean, float* running_var, hipStream_t st);
+hipError_t launch_bn_act_eval(const float* x, const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                              const float* residual, int act, long M, int C, float eps, float* y, hipStream_t st);
 hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, const float* save_mean, const float* save_invstd,
                              const float* gamma, const float* beta, int act, long M, int C, float* red, float* dx, float* dres,
                              float* dgamma_acc, float* dbeta_acc, hipStream_t st);
@@ -176,6 +178,23 @@ hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats,
                                         hipStream_t st);
 hipError_t launch_wino_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st);
 hipError_t launch_wino_dw_transform(float* dU, float* dw, int K, int C, int clear, hipStream_t st);
+
+// batched fp32 GEMM on the 16x16x4 f32 MFMA (gemm.hip): the 16 products of a Winograd layer
+struct BgemmArgs {
+  const float* A; const float* B; float* C;
+  int M, N, K;                 // NT: C[M][N] = A[M][K] B[N][K]^T;  TN: C[M][N] = sum_t A[t][M] B[t][N], K = number of t rows
+  int lda, ldb, ldc;
+  long sa, sb, sc;             // element strides between the problems of a batch
+  int batch, tiles_m, tiles_n;
+  int splits, cps;             // TN: slabs of the t range, K chunks (32 rows) per slab
+  long sc_split;               // element stride between slabs of C
+};
+bool bgemm_nt_supported(int M, int N, int K);
+bool bgemm_tn_supported(int M, int N, int T);
+hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, hipStream_t st);
+int bgemm_tn_parts(int M, int N, int T, int batch);
+hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st);
+hipError_t launch_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st);
 
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st);

@@ -256,6 +256,8 @@ def _conv_ws(lib, device, geom, bwd):
         return None
     ws = _CONV_WS.get(device)
     if ws is None or ws.numel() * 4 < nb:
+        if ws is not None:
+            _RETIRED_SCRATCH.append(ws)
         ws = torch.zeros(max(nb, 32 << 20) // 4 + 64, dtype=torch.float32, device=device)
         _CONV_WS[device] = ws
     return ws
@@ -264,9 +266,14 @@ def _conv_ws(lib, device, geom, bwd):
 _WINO_SCRATCH = {}     # (device, name) -> grow-only scratch tensor shared by every Winograd convolution (stream-ordered reuse)
 
 
+_RETIRED_SCRATCH = []  # superseded scratch tensors stay allocated: a captured hipGraph may still replay launches that use their addresses
+
+
 def _wino_scratch(device, name, numel):
     t = _WINO_SCRATCH.get((device, name))
     if t is None or t.numel() < numel:
+        if t is not None:
+            _RETIRED_SCRATCH.append(t)
         t = torch.empty(numel, device=device, dtype=torch.float32)
         _WINO_SCRATCH[(device, name)] = t
     return t
@@ -390,19 +397,6 @@ class prepared_weights:
         return False
 
 
-def _blas_gemm(kind, C, K):
-    """The 16 Winograd GEMMs of a layer are plain batched fp32 GEMMs (no fusion, no gather), so where the vendor library's
-    kernel is faster than conv_igemm_kernel / conv_wgrad_kernel on that shape it is used (torch.bmm -> rocBLAS / hipBLASLt, exact
-    fp32 MFMA like ours).  Measured at B = 32 (tools/time_bmm.py, own vs library, us): backward-weight dU = Y'^T V always wins --
-    128 ch 54 / 42, 256 ch 53 / 30, 256 -> 512 91 / 53, 512 ch 144 / 96 (137 TFLOP/s); forward / backward-data M = V U^T wins for
-    the 256- and 512-channel layers (256: 50 / 42, 512: 148 / 133, 512 -> 256: 82 / 68) and loses at 128 channels (52 / 69) and for
-    256 -> 512 (85 / 88).
-    HIFIHR_BLAS_GEMM=0 keeps everything on the hand-written kernels (the C-ABI entry points are unchanged)."""
-    if os.environ.get("HIFIHR_BLAS_GEMM", "1") == "0":
-        return False
-    return True if kind == "wgrad" else (C >= 256 and K >= 256 and not (C == 256 and K == 512))
-
-
 def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None, dy_out=None):
     """y[N][H][W][K] = conv3x3(x[N][H][W][C], w[K][3][3][C]) through weight / input transform, 16 batched GEMMs, output
     transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter).
@@ -423,21 +417,19 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias
     if nb:
         ws = _CONV_WS.get(dev)
         if ws is None or ws.numel() * 4 < nb:
+            if ws is not None:
+                _RETIRED_SCRATCH.append(ws)
             ws = torch.zeros(max(nb, 32 << 20) // 4 + 64, dtype=torch.float32, device=dev)
             _CONV_WS[dev] = ws
-    blas = _blas_gemm("fwd", C, K)
     if PROFILE.on:
-        PROFILE.conv_log.append((("wino", N, H, W, C, K), "gemm-blas" if blas else "gemm"))
+        PROFILE.conv_log.append((("wino", N, H, W, C, K), "gemm"))
     if not prepared:
         lib.wino_weight_transform(w_krsc, U, K, C, flip)
     if dy_out is not None:                            # backward: x is dy, the backward-weight transform Y' comes out of the same read
         lib.wino_input_dy_transform(x, V, dy_out, N, H, W, C)
     else:
         lib.wino_input_transform(x, V, N, H, W, C)
-    if blas:
-        torch.bmm(V[:16 * T * C].view(16, T, C), U[:16 * K * C].view(16, K, C).transpose(1, 2), out=M[:16 * T * K].view(16, T, K))
-    else:
-        lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)
+    lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)          # csrc/gemm.hip (16x16x4 f32 MFMA); odd channel counts: conv.hip
     lib.wino_output_transform(M, y, stats, N, H, W, K, bias=bias, act=act)
     return V if keep_v else None
 
@@ -548,21 +540,25 @@ class _Conv2dMFMA(torch.autograd.Function):
                 T = N * ((H + 1) // 2) * ((W + 1) // 2)
                 Yt = Yt_done if Yt_done is not None else _wino_scratch(
                     gy.device, ("Yt", w.data_ptr()) if _ASYNC_WGRAD.active else "Yt", 16 * T * K)
-                key = (gy.device, "dU", 16 * K * C)
-                dU = _WINO_SCRATCH.get(key)
-                if dU is None:                                   # zero-initialised once; wino_dw_transform hands it back zeroed
-                    dU = torch.zeros(16 * K * C, device=gy.device, dtype=torch.float32)
-                    _WINO_SCRATCH[key] = dU
+                parts = lib.wino_wgrad_parts(N, H, W, C, K)      # > 0: the slab form on csrc/gemm.hip (no atomics, nothing to zero)
+                if parts > 0:
+                    dU = _wino_scratch(gy.device, ("dUp", w.data_ptr()) if _ASYNC_WGRAD.active else "dUp", parts * 16 * K * C)
+                else:
+                    key = (gy.device, "dU", 16 * K * C)
+                    dU = _WINO_SCRATCH.get(key)
+                    if dU is None:                               # zero-initialised once; wino_dw_transform hands it back zeroed
+                        dU = torch.zeros(16 * K * C, device=gy.device, dtype=torch.float32)
+                        _WINO_SCRATCH[key] = dU
 
                 def run_w():
                     if Yt_done is None:
                         lib.wino_dy_transform(gy, Yt, N, H, W, K)
-                    if _blas_gemm("wgrad", C, K):
-                        torch.bmm(Yt[:16 * T * K].view(16, T, K).transpose(1, 2), v_saved[:16 * T * C].view(16, T, C),
-                                  out=dU.view(16, K, C))
+                    if parts > 0:
+                        lib.wino_wgrad_gemm_parts(v_saved, Yt, dU, N, H, W, C, K, parts)
+                        lib.wino_dw_transform_parts(dU, parts, tgt, K, C)
                     else:
                         lib.wino_wgrad_gemm(v_saved, Yt, dU, N, H, W, C, K)
-                    lib.wino_dw_transform(dU, tgt, K, C, clear=True)
+                        lib.wino_dw_transform(dU, tgt, K, C, clear=True)
                 go = lambda: PROFILE.bracket("conv_wgrad_wino", run_w)
                 keep = (gy, v_saved, Yt, tgt)
             else:
@@ -650,7 +646,21 @@ def bn_act(x, stats, bn: torch.nn.BatchNorm2d, residual=None, relu=True):
     `stats` comes from conv2d(..., want_stats=True).  Eval mode uses the running statistics (torch ops).
     bn.num_batches_tracked is not advanced (it only matters for momentum=None, which the reference never uses)."""
     act = _ACT[relu]
-    if stats is None and bn.training:       # producer was not one of our convolutions: one HBM-bound statistics pass
+    if not bn.training:
+        # evaluation mode (reference train_hrnet.py:119-161: model.eval()): the same fused kernel on the running statistics.
+        # A producer must not have been asked for batch statistics (callers pass want_stats=bn.training): a slot buffer that
+        # nobody consumes would go back to the allocator dirty while a captured hipGraph still holds its address.
+        assert stats is None, "bn_act in eval mode: the producer was asked for batch statistics (pass want_stats=bn.training)"
+        require_cuda(x)
+        lib = get_lib()
+        xc = x.contiguous(memory_format=_CL)
+        N, C, H, W = xc.shape
+        res = residual.contiguous(memory_format=_CL) if residual is not None else None
+        y = torch.empty_like(xc, memory_format=_CL)
+        with torch.no_grad():
+            lib.bn_act_eval(xc, bn.running_mean, bn.running_var, bn.weight, bn.bias, res, act, N * H * W, C, float(bn.eps), y)
+        return y
+    if stats is None:                       # producer was not one of our convolutions: one HBM-bound statistics pass
         require_cuda(x)
         lib = get_lib()
         xc = x.contiguous(memory_format=_CL)
@@ -658,11 +668,6 @@ def bn_act(x, stats, bn: torch.nn.BatchNorm2d, residual=None, relu=True):
         stats = _ZERO_POOL.acquire(lib.bn_stats_floats(C), x.device)
         PROFILE.bracket("bn_stats", lambda: lib.bn_stats(xc, N * H * W, C, stats))
         x = xc
-    if not bn.training:
-        out = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
-        if residual is not None:
-            out = out + residual
-        return torch.relu(out) if act == 1 else (out * torch.sigmoid(out) if act == 2 else out)
     return _BNAct.apply(x, stats, bn.weight, bn.bias, residual, act, float(bn.eps), float(bn.momentum),
                         bn.running_mean, bn.running_var)
 

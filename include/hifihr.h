@@ -190,6 +190,22 @@ int hifihr_wino_input_dy_transform(const float* dy_d, float* v_d, float* yt_d, i
  * (VGG19 layers of the perceptual loss, reference utils/perceptual_loss.py:27-36). */
 int hifihr_wino_output_transform_act(const float* m_d, float* y_d, const float* bias_d /* or NULL */, int act, int N, int H, int W,
                                      int K, void* stream);
+/* Batched fp32 GEMM on the f32 matrix cores (csrc/gemm.hip): the plain products a Winograd layer consists of -- the GEMM half of
+ * the vendor-library call behind one conv2d of the reference (network/res_encoder.py:364-373).  hifihr_wino_gemm dispatches here
+ * when the shape allows (C % 32 == 0, K % 64 == 0; hifihr_wino_gemm_workspace_bytes then returns 0).
+ *   hifihr_bgemm_nt: c[b][M][N] = a[b][M][K] . b[b][N][K]^T          (K % 32 == 0, N % 64 == 0, any M)
+ *   hifihr_bgemm_tn: c_parts[z][b][M][N] = sum over the t rows of slab z of a[b][t][M] (x) b[b][t][N]   (M, N % 64 == 0, any T);
+ *                    `parts` = hifihr_bgemm_tn_parts(M, N, T, batch) slabs, to be summed by the consumer (no atomics).
+ * Winograd backward-weight on it: parts = hifihr_wino_wgrad_parts(N, H, W, C, K) (0: shape unsupported, use hifihr_wino_wgrad_gemm),
+ *   hifihr_wino_wgrad_gemm_parts(V, Y', du_parts[parts][16][K][C])  then
+ *   hifihr_wino_dw_transform_parts: dw[K][3][3][C] += G^T (sum of the slabs) G   -- nothing zero-initialised, bit-reproducible. */
+int hifihr_bgemm_nt(const float* a_d, const float* b_d, float* c_d, int M, int N, int K, int batch, void* stream);
+int hifihr_bgemm_tn_parts(int M, int N, int T, int batch);
+int hifihr_bgemm_tn(const float* a_d, const float* b_d, float* c_parts_d, int M, int N, int T, int batch, int parts, void* stream);
+int hifihr_wino_wgrad_parts(int N, int H, int W, int C, int K);
+int hifihr_wino_wgrad_gemm_parts(const float* v_d, const float* yt_d, float* du_parts_d, int N, int H, int W, int C, int K, int parts,
+                                 void* stream);
+int hifihr_wino_dw_transform_parts(const float* du_parts_d, int parts, float* dw_acc_d, int K, int C, void* stream);
 /* [K][RS][C] -> [C][RS][K] (the transpose backward-data consumes). */
 int hifihr_weight_transpose(const float* w_d, float* wt_d, int K, int RS, int C, void* stream);
 /* hifihr_conv2d_bwd_data on weights that are ALREADY transposed to [C][R][S][K] (hifihr_weight_transpose / hifihr_weight_prep). */
@@ -238,6 +254,10 @@ int hifihr_bn_stats(const float* x_d, long M, int C, float* stats_d, void* strea
 int hifihr_bn_act_fwd(const float* x_d, float* stats_d /* consumed: zero on return */, const float* gamma_d, const float* beta_d,
                       const float* residual_d /* or NULL */, int act, long M, int C, float eps, float momentum, float* y_d,
                       float* save_mean_d, float* save_invstd_d, float* running_mean_d, float* running_var_d, void* stream);
+/* Evaluation mode (module.eval(), reference train_hrnet.py:119-161): the same fused apply with the running statistics; nothing
+ * is updated, no statistics buffer is involved. */
+int hifihr_bn_act_eval(const float* x_d, const float* running_mean_d, const float* running_var_d, const float* gamma_d, const float* beta_d,
+                       const float* residual_d /* or NULL */, int act, long M, int C, float eps, float* y_d, void* stream);
 int hifihr_bn_act_bwd(const float* dy_d, const float* y_d /* act 1; NULL: recompute the mask (no-residual layers) */, const float* x_d, const float* save_mean_d,
                       const float* save_invstd_d, const float* gamma_d, const float* beta_d /* act 2 */, int act, long M, int C,
                       float* red_scratch_d, float* dx_d, float* dres_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);

@@ -185,5 +185,21 @@ static inline hs_floatx16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b,
   return c;
 }
 
+// v_mfma_f32_16x16x4_f32: lane l supplies A[row l & 15][k l >> 4] and B[k l >> 4][col l & 15]; D register e of lane l is
+// D[row 4 (l >> 4) + e][col l & 15]
+static inline hs_floatx4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hs_floatx4 c, int, int, int) {
+  float A[64], B[64];
+  ::hostsim::wave_gather2(a, b, A, B);
+  const int l = ::hostsim::lane_id();
+  const int col = l & 15;
+  for (int e = 0; e < 4; ++e) {
+    const int row = 4 * (l >> 4) + e;
+    float d = c[e];
+    for (int k = 0; k < 4; ++k) d = fmaf(A[16 * k + row], B[16 * k + col], d);
+    c[e] = d;
+  }
+  return c;
+}
+
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
   ::hostsim::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })

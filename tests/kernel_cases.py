@@ -731,7 +731,40 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
     refw = wr.grad.permute(0, 2, 3, 1)
     err = float((dw.cpu() - 0.5 - refw).abs().max())
     assert err <= 1e-4 * float(refw.abs().max()) + 1e-6, f"winograd bwd weight: {err} vs {float(refw.abs().max())}"
+    # the same reduction as slabs on csrc/gemm.hip (no atomics, nothing zero-initialised), summed by the slab form of the transform
+    parts = lib.wino_wgrad_parts(N, H, W, C, K)
+    if parts > 0:
+        dUp = torch.full((parts, 16, K, C), 7.0, device=device)
+        lib.wino_wgrad_gemm_parts(V, Yt, dUp, N, H, W, C, K, parts)
+        dw2 = torch.full((K, 3, 3, C), 0.5, device=device)
+        lib.wino_dw_transform_parts(dUp, parts, dw2, K, C)
+        err = float((dw2.cpu() - 0.5 - refw).abs().max())
+        assert err <= 1e-4 * float(refw.abs().max()) + 1e-6, f"winograd bwd weight (slabs): {err} vs {float(refw.abs().max())}"
     return 0 if ws is None else 1
+
+
+def bgemm_case(lib, device, M, N, K, batch, seed=0):
+    """csrc/gemm.hip through the C ABI vs torch matmul (fp64 reference): NT (c = a b^T) and TN (slabs of a^T b)."""
+    gen = torch.Generator().manual_seed(seed)
+    a = torch.randn(batch, M, K, generator=gen); b = torch.randn(batch, N, K, generator=gen)
+    c = torch.full((batch, M, N), 7.0, device=device)
+    lib.bgemm_nt(a.to(device).contiguous(), b.to(device).contiguous(), c, M, N, K, batch)
+    ref = torch.matmul(a.double(), b.double().transpose(1, 2))
+    err = float((c.cpu().double() - ref).abs().max())
+    assert err <= 2e-6 * K ** 0.5 * float(ref.abs().max()) + 1e-6, f"bgemm_nt {M}x{N}x{K}x{batch}: {err}"
+
+
+def bgemm_tn_case(lib, device, M, N, T, batch, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    a = torch.randn(batch, T, M, generator=gen); b = torch.randn(batch, T, N, generator=gen)
+    parts = lib.bgemm_tn_parts(M, N, T, batch)
+    assert parts >= 1
+    cp = torch.full((parts, batch, M, N), 7.0, device=device)
+    lib.bgemm_tn(a.to(device).contiguous(), b.to(device).contiguous(), cp, M, N, T, batch, parts)
+    ref = torch.matmul(a.double().transpose(1, 2), b.double())
+    err = float((cp.cpu().double().sum(0) - ref).abs().max())
+    assert err <= 2e-6 * T ** 0.5 * float(ref.abs().max()) + 1e-6, f"bgemm_tn {M}x{N}x{T}x{batch} ({parts} parts): {err}"
+    return parts
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,36 @@
+"""csrc/gemm.hip through the C ABI on the GPU: the Winograd GEMM shapes of the ResNet-18 step at B = 32 and ragged / small ones."""
+import pytest
+import torch
+
+import kernel_cases as kc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hifihr_amd._lib import get_lib
+    return get_lib()
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(6272, 128, 128, 16), (1568, 256, 256, 16), (1568, 512, 256, 16), (1568, 256, 512, 16),
+                                         (1568, 512, 512, 16), (98, 128, 64, 2), (130, 192, 32, 3), (40, 64, 96, 1)])
+def test_bgemm_nt(lib, M, N, K, batch):
+    kc.bgemm_case(lib, "cuda", M, N, K, batch, seed=M + N + K)
+
+
+@pytest.mark.parametrize("M,N,T,batch", [(128, 128, 6272, 16), (256, 256, 1568, 16), (512, 256, 1568, 16), (512, 512, 1568, 16),
+                                         (64, 128, 98, 2), (128, 64, 40, 1), (64, 64, 777, 1)])
+def test_bgemm_tn(lib, M, N, T, batch):
+    kc.bgemm_tn_case(lib, "cuda", M, N, T, batch, seed=M + T)
+
+
+def test_bgemm_tn_is_bit_reproducible(lib):
+    """No atomics: two launches give identical slabs."""
+    gen = torch.Generator().manual_seed(5)
+    M, N, T, batch = 256, 256, 1568, 16
+    a = torch.randn(batch, T, M, generator=gen).cuda(); b = torch.randn(batch, T, N, generator=gen).cuda()
+    parts = lib.bgemm_tn_parts(M, N, T, batch)
+    c1 = torch.empty(parts, batch, M, N, device="cuda"); c2 = torch.empty_like(c1)
+    lib.bgemm_tn(a, b, c1, M, N, T, batch, parts); lib.bgemm_tn(a, b, c2, M, N, T, batch, parts)
+    assert torch.equal(c1, c2)
