@@ -275,6 +275,263 @@ __global__ __launch_bounds__(256) void bgemm_tn_kernel(BgemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wave-specialised form (both layouts): 4 MFMA waves + NLOAD loader waves per workgroup, one workgroup per CU.
+// Measured on MI355X (tools/time_gemm.py, round 2): in the kernels above every MFMA wave also issues its share of the LDS-DMA
+// loads, and an LDS-DMA instruction costs its wave 60-185 cycles of issue time (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"):
+// 8 per chunk in front of 128 MFMAs (4096 matrix-pipe cycles) leave the pipe idle ~35 % of the time, and two co-resident workgroups
+// run in lockstep and stall together.  Here the loads are issued by waves that do nothing else, so the MFMA waves' instruction
+// stream is ds_read + MFMA only:
+//   LDS: 4 stages of (BM + BN) x 32 floats (128 KB at 128x128).
+//   loader, iteration c : issue chunk c + 3 into stage (c + 3) & 3 (last read in iteration c - 1, released by barrier c - 1);
+//                         wait until chunk c + 2 has landed (counted vmcnt: only chunk c + 3's pieces may stay in flight);
+//                         barrier c.                                       -> a load has two iterations (~8000 cycles) to land
+//   MFMA wave, iteration c : MFMAs of half 0 of chunk c while the fragments of half 1 load from LDS, MFMAs of half 1 while the
+//                         fragments of half 0 of chunk c + 1 load (landed: confirmed at barrier c - 1); barrier c.
+//   The barrier is a raw s_barrier: __syncthreads() would drain the loader's in-flight DMA (its fence waits vmcnt(0)).
+// ------------------------------------------------------------------------------------------------
+#if defined(HIFIHR_HOSTSIM)
+#define HIFIHR_RAW_BARRIER() __syncthreads()
+#define HIFIHR_WAIT_VM(n) ((void)0)
+#define HIFIHR_WAIT_LGKM0() ((void)0)
+#define HIFIHR_TOUCH(x) ((void)0)
+#else
+#define HIFIHR_TOUCH(x) asm volatile("" : "+v"(x))
+#define HIFIHR_RAW_BARRIER()                     \
+  do {                                           \
+    asm volatile("" ::: "memory");               \
+    __builtin_amdgcn_s_barrier();                \
+    asm volatile("" ::: "memory");               \
+  } while (0)
+#define HIFIHR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define HIFIHR_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
+// HIFIHR_GEMM_STAMP (diagnostic build, tools/build_gemm_probe.sh): wave 0 of every workgroup adds to g_gemm_stamp
+// [0] shader cycles in the main loop, [1] 100 MHz real-time ticks of the same span (-> clock held under load), [2] chunks,
+// [3] cycles spent at the per-chunk barrier, [4] waves counted, [5] cycles from kernel entry to the end of the epilogue
+#if defined(HIFIHR_GEMM_STAMP)
+__device__ unsigned long long g_gemm_stamp[8];
+#endif
+
+template <int BM, int BN, bool TNL, int NLOAD>
+__global__ __launch_bounds__(256 + 64 * NLOAD) void bgemm_ws_kernel(BgemmArgs a) {
+#if defined(HIFIHR_GEMM_STAMP)
+  const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
+#endif
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TI = WN / 16, TJ = WM / 16;
+  constexpr int STAGE = (BM + BN) * 32;
+  constexpr int NPA = BM / 8, NP = (BM + BN) / 8;          // 1 KiB pieces per chunk: A, total
+  constexpr int PL = NP / NLOAD;                            // pieces per loader wave per chunk
+  static_assert(NP % NLOAD == 0 && (PL == 8 || PL == 16 || PL == 32), "loader split");
+  constexpr int RA = 256 / BM, RB = 256 / BN;               // TN: t rows per piece
+  __shared__ __attribute__((aligned(1024))) float lds[4 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tiles_pb = a.tiles_m * a.tiles_n;
+  const int per_split = tiles_pb * a.batch;
+  const int z = wg / per_split;
+  wg -= z * per_split;
+  const int p = wg / tiles_pb;
+  wg -= p * tiles_pb;
+  const int tn = wg / a.tiles_m, tm = wg - tn * a.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const float* __restrict__ A = a.A + (size_t)p * a.sa;
+  const float* __restrict__ B = a.B + (size_t)p * a.sb;
+  const int nch_total = TNL ? (a.K + 31) / 32 : a.K / 32;
+  const int c_lo = z * a.cps, c_hi = min(c_lo + a.cps, nch_total);
+  const int nch = c_hi - c_lo;
+  if (nch <= 0) return;                                      // (uniform over the workgroup)
+
+  if (wave >= 4) {
+    // ---------------- loader ----------------
+    const int l = wave - 4;
+    unsigned goff[PL];
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int q = l + NLOAD * i;
+      const bool isA = q < NPA;
+      const int qq = isA ? q : q - NPA;
+      if (TNL) {
+        const int bw = isA ? BM : BN, rp = isA ? RA : RB;
+        const int t = rp * qq + lane / (bw / 4), col = (lane % (bw / 4)) * 4;
+        goff[i] = (unsigned)t * (unsigned)(isA ? a.lda : a.ldb) + (isA ? m0 : n0) + col;
+      } else {
+        const int row = 8 * qq + (lane >> 3);
+        const int seg = (lane & 7) ^ ((row >> 1) & 7);
+        int grow = (isA ? m0 : n0) + row;
+        const int lim = isA ? a.M : a.N;
+        grow = grow < lim ? grow : lim - 1;
+        goff[i] = (unsigned)grow * (unsigned)(isA ? a.lda : a.ldb) + seg * 4;
+      }
+    }
+    auto issue = [&](int c) {                                // chunk c of this split -> stage c & 3
+      float* base = lds + (c & 3) * STAGE;
+      const int cg = c_lo + c;
+      if (!TNL || cg * 32 + 32 <= a.K) {
+        const size_t adv_a = TNL ? (size_t)cg * 32 * a.lda : (size_t)cg * 32;
+        const size_t adv_b = TNL ? (size_t)cg * 32 * a.ldb : (size_t)cg * 32;
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+          const int q = l + NLOAD * i;
+          const bool isA = q < NPA;
+          HIFIHR_GLDS16((isA ? A + adv_a : B + adv_b) + goff[i], base + (isA ? 256 * q : BM * 32 + 256 * (q - NPA)), lane);
+        }
+      } else {
+        // ragged last chunk of the t range (TN): rows past T contribute zeros, which an LDS-DMA cannot produce
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+          const int q = l + NLOAD * i;
+          const bool isA = q < NPA;
+          const int qq = isA ? q : q - NPA;
+          const int bw = isA ? BM : BN, rp = isA ? RA : RB;
+          const int t = cg * 32 + rp * qq + lane / (bw / 4);
+          const float* src = (isA ? A : B) + (size_t)cg * 32 * (isA ? a.lda : a.ldb) + goff[i];
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (t < a.K) v = *reinterpret_cast<const float4*>(src);
+          *reinterpret_cast<float4*>(base + (isA ? 256 * q : BM * 32 + 256 * qq) + 4 * lane) = v;
+        }
+        HIFIHR_WAIT_VM(0);
+        HIFIHR_WAIT_LGKM0();
+      }
+    };
+    issue(0);
+    if (nch > 1) issue(1);
+    if (nch > 2) issue(2);
+    // chunks 0 and 1 landed: only chunk 2's pieces may stay in flight
+    if (nch > 2) { if (PL == 16) HIFIHR_WAIT_VM(16); else if (PL == 8) HIFIHR_WAIT_VM(8); else HIFIHR_WAIT_VM(32); }
+    else HIFIHR_WAIT_VM(0);
+    HIFIHR_RAW_BARRIER();                                    // barrier -1
+    for (int c = 0; c < nch; ++c) {
+      if (c + 3 < nch) {
+        issue(c + 3);
+        if (PL == 16) HIFIHR_WAIT_VM(16); else if (PL == 8) HIFIHR_WAIT_VM(8); else HIFIHR_WAIT_VM(32);
+      } else {
+        HIFIHR_WAIT_VM(0);
+      }
+      HIFIHR_RAW_BARRIER();                                  // barrier c
+    }
+    return;
+  }
+
+  // ---------------- MFMA waves ----------------
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+  floatx4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // fragments of one half chunk (16 k): fm[j][s] = operand of D column tile j (lane-indexed, m) at k-step s, fn[i][s] likewise for n
+  float fm[2][TJ][4], fn[2][TI][4];
+  auto read_half = [&](int c, int h, int slot) {
+    const float* s = lds + (c & 3) * STAGE;
+    if (TNL) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* rowA = s + (16 * h + 4 * k + g) * BM + wm * WM + TJ * r;
+        const float* rowB = s + BM * 32 + (16 * h + 4 * k + g) * BN + wn * WN + r;
+        if constexpr (TJ == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(rowA);
+          fm[slot][0][k] = v.x; fm[slot][1][k] = v.y; fm[slot][2][k] = v.z; fm[slot][3][k] = v.w;
+        } else {
+          const float2 v = *reinterpret_cast<const float2*>(rowA);
+          fm[slot][0][k] = v.x; fm[slot][1][k] = v.y;
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i) fn[slot][i][k] = rowB[16 * i];
+      }
+    } else {
+      const int ps = ((g + 4 * h) ^ ((r >> 1) & 7)) * 4;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(s + BM * 32 + (wn * WN + 16 * i + r) * 32 + ps);
+        fn[slot][i][0] = v.x; fn[slot][i][1] = v.y; fn[slot][i][2] = v.z; fn[slot][i][3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(s + (wm * WM + 16 * j + r) * 32 + ps);
+        fm[slot][j][0] = v.x; fm[slot][j][1] = v.y; fm[slot][j][2] = v.z; fm[slot][j][3] = v.w;
+      }
+    }
+  };
+  auto mfma_half = [&](int slot) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fn[slot][i][k], fm[slot][j][k], acc[i][j], 0, 0, 0);
+  };
+
+  HIFIHR_RAW_BARRIER();                                      // barrier -1: chunks 0 and 1 are in LDS
+  read_half(0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                              // (see the end of the loop body)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) HIFIHR_TOUCH(fn[0][i][k]);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) HIFIHR_TOUCH(fm[0][j][k]);
+  }
+#if defined(HIFIHR_GEMM_STAMP)
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_bar = 0;
+#endif
+  for (int c = 0; c < nch; ++c) {
+    read_half(c, 1, 1);
+    HIFIHR_PIN();                                            // reads FIRST: the scheduler otherwise sinks them below the MFMA block
+    mfma_half(0);
+    HIFIHR_PIN();
+    read_half(c + 1, 0, 0);                                  // unconditional (past the last chunk: a stale stage, never used): a branch
+    HIFIHR_PIN();                                            // here makes the waits in front of the next MFMA block conservative
+    mfma_half(1);
+    HIFIHR_PIN();
+    // "use" the prefetched fragments here, where their data has long arrived: hipcc's waitcnt pass is imprecise across the loop
+    // back-edge (it emitted lgkmcnt(0) in front of the next iteration's first MFMA, i.e. waited for the reads issued just before
+    // it); with nothing pending at the loop head the waits inside the iteration are exact counted ones
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) HIFIHR_TOUCH(fn[0][i][k]);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) HIFIHR_TOUCH(fm[0][j][k]);
+    }
+#if defined(HIFIHR_GEMM_STAMP)
+    HIFIHR_TOUCH(acc[0][0][0]);
+    const unsigned long long st_b0 = __builtin_amdgcn_s_memtime();
+#endif
+    HIFIHR_RAW_BARRIER();                                    // barrier c
+#if defined(HIFIHR_GEMM_STAMP)
+    st_bar += __builtin_amdgcn_s_memtime() - st_b0;
+#endif
+  }
+#if defined(HIFIHR_GEMM_STAMP)
+  const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  float* __restrict__ C = a.C + (size_t)z * a.sc_split + (size_t)p * a.sc;
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int m = m0 + wm * WM + (TNL ? TJ * r + j : 16 * j + r);
+    if (m < a.M) {
+      float* row = C + (size_t)m * a.ldc + n0 + wn * WN + 4 * g;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+        *reinterpret_cast<float4*>(row + 16 * i) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  }
+#if defined(HIFIHR_GEMM_STAMP)
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    atomicAdd(&g_gemm_stamp[0], st_t1 - st_t0); atomicAdd(&g_gemm_stamp[1], st_r1 - st_r0); atomicAdd(&g_gemm_stamp[2], (unsigned long long)nch);
+    atomicAdd(&g_gemm_stamp[3], st_bar); atomicAdd(&g_gemm_stamp[4], 1ull); atomicAdd(&g_gemm_stamp[5], __builtin_amdgcn_s_memtime() - st_entry);
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static int gemm_cus() {
@@ -288,6 +545,28 @@ static int gemm_cus() {
   return cus;
 }
 
+// loader waves of the wave-specialised kernels (0: the 4-wave kernels); HIFIHR_GEMM_WS overrides (tuning)
+static int gemm_ws_loaders() {
+  if (const char* e = getenv("HIFIHR_GEMM_WS")) return atoi(e);
+  return 4;
+}
+
+// Tile choice, measured on MI355X at B = 32 (tools/time_gemm.py, profiles/r02_time_gemm.txt):
+//   NT  reduction length >= 512: 128x128 wave-specialised (4 loader waves); shorter reductions (4-8 chunks per tile): the 4-wave
+//       64x64 kernel -- a tile's fixed cost (first loads, store tail) then weighs more than the macro-tile's operand reuse, and
+//       four small workgroups per CU overlap it.
+//   TN  >= 512 x 256 outputs: 128x128 wave-specialised, one workgroup per CU (slabs = 256 / tiles); smaller outputs: 64x64 tiles
+//       with the t range split until ~512 workgroups exist.
+static void nt_tile(int M, int N, int K, int* bm, int* bn) {
+  (void)M;
+  if (K >= 512 && N % 128 == 0) { *bm = 128; *bn = 128; }
+  else { *bm = 64; *bn = 64; }
+}
+static void tn_tile(int M, int N, int* bm, int* bn) {
+  if ((long)M * N >= 512L * 256 && M % 128 == 0 && N % 128 == 0) { *bm = 128; *bn = 128; }
+  else { *bm = 64; *bn = 64; }
+}
+
 bool bgemm_nt_supported(int M, int N, int K) { return M > 0 && K >= 32 && K % 32 == 0 && N >= 64 && N % 64 == 0; }
 bool bgemm_tn_supported(int M, int N, int T) { return T > 0 && M >= 64 && M % 64 == 0 && N >= 64 && N % 64 == 0; }
 
@@ -297,11 +576,18 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
   BgemmArgs a{};
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
   a.sa = (long)M * K; a.sb = (long)N * K; a.sc = (long)M * N; a.batch = batch;
-  int bn = (N % 128 == 0) ? 128 : 64;
-  int bm = 128;
+  int bm, bn;
+  nt_tile(M, N, K, &bm, &bn);
   if (const char* e = getenv("HIFIHR_GEMM_NT_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (N % bn) bn = 64; }
   a.tiles_m = (M + bm - 1) / bm; a.tiles_n = N / bn; a.splits = 1; a.cps = K / 32; a.sc_split = 0;
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * batch));
+  const int nload = gemm_ws_loaders();
+  if (nload > 0 && bm == 128 && bn == 128) {
+    if (nload == 1) hipLaunchKernelGGL((bgemm_ws_kernel<128, 128, false, 1>), grid, dim3(320), 0, st, a);
+    else if (nload == 4) hipLaunchKernelGGL((bgemm_ws_kernel<128, 128, false, 4>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((bgemm_ws_kernel<128, 128, false, 2>), grid, dim3(384), 0, st, a);
+    return hipGetLastError();
+  }
   if (bm == 128 && bn == 128) hipLaunchKernelGGL((bgemm_nt_kernel<128, 128>), grid, dim3(256), 0, st, a);
   else if (bm == 128 && bn == 64) hipLaunchKernelGGL((bgemm_nt_kernel<128, 64>), grid, dim3(256), 0, st, a);
   else if (bm == 64 && bn == 128) hipLaunchKernelGGL((bgemm_nt_kernel<64, 128>), grid, dim3(256), 0, st, a);
@@ -313,10 +599,13 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
 // number of K-split slabs launch_bgemm_tn writes for this shape (the caller provides parts * batch * M * N floats)
 int bgemm_tn_parts(int M, int N, int T, int batch) {
   if (const char* e = getenv("HIFIHR_GEMM_TN_PARTS")) { const int v = atoi(e); if (v > 0) return v; }
-  const int bm = (M % 128 == 0) ? 128 : 64, bn = (N % 128 == 0) ? 128 : 64;
+  int bm, bn;
+  tn_tile(M, N, &bm, &bn);
+  if (const char* e = getenv("HIFIHR_GEMM_TN_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (M % bm) bm = 64; if (N % bn) bn = 64; }
   const int tiles = (M / bm) * (N / bn) * batch, nch = (T + 31) / 32;
-  // fill the chip's 2 x CUs workgroup slots once; at least 8 chunks per split so that a slab round trip stays small
-  int splits = (2 * gemm_cus()) / tiles;
+  // 128x128 (one workgroup per CU): fill the CUs once; 64x64: ~2 workgroups per CU; at least 8 chunks per slab so that the slab
+  // round trip (written here, summed by wino_dw_transform_parts) stays small next to the reduction
+  int splits = ((bm == 128 && bn == 128) ? gemm_cus() : 2 * gemm_cus()) / tiles;
   if (splits > nch / 8) splits = nch / 8;
   if (splits < 1) splits = 1;
   const int cps = (nch + splits - 1) / splits;
@@ -328,7 +617,8 @@ hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M,
   BgemmArgs a{};
   a.A = A; a.B = B; a.C = Cparts; a.M = M; a.N = N; a.K = T; a.lda = M; a.ldb = N; a.ldc = N;
   a.sa = (long)T * M; a.sb = (long)T * N; a.sc = (long)M * N; a.batch = batch;
-  int bm = (M % 128 == 0) ? 128 : 64, bn = (N % 128 == 0) ? 128 : 64;
+  int bm, bn;
+  tn_tile(M, N, &bm, &bn);
   if (const char* e = getenv("HIFIHR_GEMM_TN_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (M % bm) bm = 64; if (N % bn) bn = 64; }
   a.tiles_m = M / bm; a.tiles_n = N / bn;
   const int nch = (T + 31) / 32;
@@ -336,6 +626,13 @@ hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M,
   if ((nch + a.cps - 1) / a.cps != parts) return hipErrorInvalidValue;       // parts must come from bgemm_tn_parts
   a.splits = parts; a.sc_split = (long)batch * M * N;
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * batch * parts));
+  const int nload = gemm_ws_loaders();
+  if (nload > 0 && bm == 128 && bn == 128) {
+    if (nload == 1) hipLaunchKernelGGL((bgemm_ws_kernel<128, 128, true, 1>), grid, dim3(320), 0, st, a);
+    else if (nload == 4) hipLaunchKernelGGL((bgemm_ws_kernel<128, 128, true, 4>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((bgemm_ws_kernel<128, 128, true, 2>), grid, dim3(384), 0, st, a);
+    return hipGetLastError();
+  }
   if (bm == 128 && bn == 128) hipLaunchKernelGGL((bgemm_tn_kernel<128, 128>), grid, dim3(256), 0, st, a);
   else if (bm == 128 && bn == 64) hipLaunchKernelGGL((bgemm_tn_kernel<128, 64>), grid, dim3(256), 0, st, a);
   else if (bm == 64 && bn == 128) hipLaunchKernelGGL((bgemm_tn_kernel<64, 128>), grid, dim3(256), 0, st, a);
@@ -345,3 +642,14 @@ hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M,
 }
 
 }  // namespace hifihr
+
+#if defined(HIFIHR_GEMM_STAMP)
+extern "C" int hifihr_gemm_stamp_read(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hifihr::g_gemm_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hifihr::g_gemm_stamp), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

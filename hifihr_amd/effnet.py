@@ -8,10 +8,10 @@ width 1.2 / depth 1.4 / "image_size" 300 (the STATIC same-padding is computed fo
 and applied unchanged to the 224-pixel input: k3 s1 -> (1,1), k3 s2 -> (0,1), k5 s1 -> (2,2), k5 s2 -> (1,2)),
 BN eps 1e-3 / torch-momentum 0.01, SE ratio 1/4 of the block INPUT filters, drop-connect 0.2 * idx / 26 in training.
 
-conv_impl="mfma": the 1x1 expand / project / head convolutions (96 % of the FLOPs), the depthwise convolutions and the
-BatchNorm (+ swish) after the 1x1 convolutions run on the hand-written kernels (hifihr_amd/csrc/conv.hip, dwconv.hip,
-bn.hip, every BatchNorm + swish included); squeeze-excite and the 3x3 stem are torch ops for now
-(bandwidth-bound, next to port).  conv_impl="aten": plain torch (CPU oracle / A-B runs).
+ONE path, on the hand-written kernels (GPU tensors only, a CPU tensor raises): the stem and the 1x1 expand / project / head
+convolutions (96 % of the FLOPs) on the MFMA kernel, the depthwise convolutions (csrc/dwconv.hip), every BatchNorm (+ swish)
+(csrc/bn.hip) and squeeze-excite (csrc/se.hip + mlp.hip).  The torch restatement the tests compare against is
+oracle/torch_modules.EfficientNetB3Ref (pinned by the reference's own network/efficientnet_pt, tests/golden/effnet_b3_small.npz).
 """
 from __future__ import annotations
 
@@ -58,36 +58,15 @@ def b3_block_table():
     return out
 
 
-class _SwishFn(torch.autograd.Function):
-    """utils.py:36-47 (memory-efficient swish: only the input is saved)."""
+class SqueezeExciteConv(nn.Conv2d):
+    """The 1x1 `_se_reduce` / `_se_expand` convolutions: parameter holders with nn.Conv2d's state-dict names (weight, bias);
+    the arithmetic runs inside ops.squeeze_excite."""
 
-    @staticmethod
-    def forward(ctx, i):
-        ctx.save_for_backward(i)
-        return i * torch.sigmoid(i)
-
-    @staticmethod
-    def backward(ctx, g):
-        i, = ctx.saved_tensors
-        s = torch.sigmoid(i)
-        return g * (s * (1 + i * (1 - s)))
-
-
-def swish(x):
-    return _SwishFn.apply(x)
-
-
-class SamePadConv2d(nn.Conv2d):
-    """nn.Conv2d with the reference's STATIC TensorFlow-style padding (state-dict compatible: weight[, bias])."""
-
-    def __init__(self, cin, cout, k, stride=1, groups=1, bias=True):
-        super().__init__(cin, cout, k, stride, 0, 1, groups, bias)
-        self.pad4 = static_same_pad(k, stride)
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, 1, 1, 0, 1, 1, True)
 
     def forward(self, x):
-        if any(self.pad4):
-            x = F.pad(x, self.pad4)
-        return F.conv2d(x, self.weight, self.bias, self.stride, 0, 1, self.groups)
+        raise RuntimeError("squeeze-excite convolutions run fused (ops.squeeze_excite), not on their own")
 
 
 class PointwiseConvMFMA(nn.Module):
@@ -117,8 +96,8 @@ class DepthwiseConvHIP(nn.Module):
         return ops.dwconv2d(x, self.weight, self.stride, self.pad4, want_stats)
 
 
-def _pointwise(cin, cout, impl):
-    return PointwiseConvMFMA(cin, cout) if impl == "mfma" else SamePadConv2d(cin, cout, 1, bias=False)
+def _pointwise(cin, cout):
+    return PointwiseConvMFMA(cin, cout)
 
 
 def _bn(c):
@@ -126,52 +105,39 @@ def _bn(c):
 
 
 def _conv_bn_swish(conv, bn, x, act=True):
-    """conv -> BN (train-mode statistics) -> swish, fused on the HIP path."""
-    if isinstance(conv, PointwiseConvMFMA):
-        from . import ops
+    """conv -> BN -> swish: batch statistics from the convolution's epilogue in training mode (none requested in evaluation mode:
+    only a training batch-norm consumes and cleans the slot buffer), BN + swish one fused launch."""
+    from . import ops
+    if bn.training:
         y, st = conv(x, want_stats=True)
-        return ops.bn_act(y, st, bn, None, "swish" if act else None)
-    y = bn(conv(x))
-    return swish(y) if act else y
+    else:
+        y, st = conv(x), None
+    return ops.bn_act(y, st, bn, None, "swish" if act else None)
 
 
 class MBConvBlock(nn.Module):
-    def __init__(self, k, stride, expand, cin, cout, impl):
+    def __init__(self, k, stride, expand, cin, cout):
         super().__init__()
         self.stride, self.cin, self.cout, self.expand = stride, cin, cout, expand
         mid = cin * expand
         if expand != 1:
-            self._expand_conv = _pointwise(cin, mid, impl)
+            self._expand_conv = _pointwise(cin, mid)
             self._bn0 = _bn(mid)
-        self._depthwise_conv = (DepthwiseConvHIP(mid, k, stride) if impl == "mfma"
-                                else SamePadConv2d(mid, mid, k, stride, groups=mid, bias=False))
+        self._depthwise_conv = DepthwiseConvHIP(mid, k, stride)
         self._bn1 = _bn(mid)
         sq = max(1, int(cin * 0.25))
-        self._se_reduce = SamePadConv2d(mid, sq, 1)
-        self._se_expand = SamePadConv2d(sq, mid, 1)
-        self._project_conv = _pointwise(mid, cout, impl)
+        self._se_reduce = SqueezeExciteConv(mid, sq)
+        self._se_expand = SqueezeExciteConv(sq, mid)
+        self._project_conv = _pointwise(mid, cout)
         self._bn2 = _bn(cout)
 
     def forward(self, inputs, drop_connect_rate=None):
         x = inputs
         if self.expand != 1:
             x = _conv_bn_swish(self._expand_conv, self._bn0, x)
-        if isinstance(self._depthwise_conv, DepthwiseConvHIP):
-            from . import ops
-            if self._bn1.training:
-                y, st = self._depthwise_conv(x, want_stats=True)                          # statistics from the kernel's epilogue
-                x = ops.bn_act(y, st, self._bn1, None, "swish")
-            else:
-                x = ops.bn_act(self._depthwise_conv(x), None, self._bn1, None, "swish")
-        else:
-            x = swish(self._bn1(self._depthwise_conv(x)))
-        if isinstance(self._depthwise_conv, DepthwiseConvHIP) and x.shape[1] % 4 == 0:
-            from . import ops
-            x = ops.squeeze_excite(x, self._se_reduce, self._se_expand)        # pool + 2 small linears + scale, fused
-        else:
-            s = F.adaptive_avg_pool2d(x, 1)
-            s = self._se_expand(swish(self._se_reduce(s)))
-            x = torch.sigmoid(s) * x
+        from . import ops
+        x = _conv_bn_swish(self._depthwise_conv, self._bn1, x)             # statistics from the depthwise kernel's epilogue
+        x = ops.squeeze_excite(x, self._se_reduce, self._se_expand)        # pool + 2 small linears + scale, fused
         x = _conv_bn_swish(self._project_conv, self._bn2, x, act=False)
         if self.stride == 1 and self.cin == self.cout:
             if drop_connect_rate and self.training:                       # utils.py:82-91
@@ -185,35 +151,24 @@ class MBConvBlock(nn.Module):
 class EfficientNetB3(nn.Module):
     """`extract_features` of EfficientNet.from_name('efficientnet-b3') (the unused classifier `_fc` is omitted)."""
 
-    def __init__(self, conv_impl="aten"):
+    def __init__(self):
         super().__init__()
-        self.conv_impl = conv_impl
         stem = round_filters(32)
-        if conv_impl == "mfma":
-            from .network import Conv2dMFMA
-            self._conv_stem = Conv2dMFMA(3, stem, 3, stride=2, pad=0)      # the static same padding goes into the NHWC4 repack
-        else:
-            self._conv_stem = SamePadConv2d(3, stem, 3, 2, bias=False)
+        from .network import Conv2dMFMA
+        self._conv_stem = Conv2dMFMA(3, stem, 3, stride=2, pad=0)          # the static same padding goes into the NHWC4 repack
         self._bn0 = _bn(stem)
         table = b3_block_table()
         assert len(table) == 26 and table[0][3] == stem
-        self._blocks = nn.ModuleList([MBConvBlock(k, s, e, i, o, conv_impl) for (k, s, e, i, o) in table])
+        self._blocks = nn.ModuleList([MBConvBlock(k, s, e, i, o) for (k, s, e, i, o) in table])
         head = round_filters(1280)
-        self._conv_head = _pointwise(table[-1][4], head, conv_impl)
+        self._conv_head = _pointwise(table[-1][4], head)
         self._bn1 = _bn(head)
         self.out_channels, self.low_channels = head, table[4][4]
 
     def extract_features(self, x):
-        if self.conv_impl == "mfma":
-            from . import ops
-            x4 = ops.image_to_nhwc4(x, pad4=static_same_pad(3, 2), normalize=False)      # model.py:197-199 (no normalisation)
-            if self._bn0.training:
-                y, st = self._conv_stem(x4, want_stats=True)
-                x = ops.bn_act(y, st, self._bn0, None, "swish")
-            else:
-                x = ops.bn_act(self._conv_stem(x4), None, self._bn0, None, "swish")
-        else:
-            x = swish(self._bn0(self._conv_stem(x)))
+        from . import ops
+        x4 = ops.image_to_nhwc4(x, pad4=static_same_pad(3, 2), normalize=False)          # model.py:197-199 (no normalisation)
+        x = _conv_bn_swish(self._conv_stem, self._bn0, x4)
         low = None
         n = len(self._blocks)
         for idx, blk in enumerate(self._blocks):
@@ -227,10 +182,10 @@ class EfficientNetB3(nn.Module):
 class EffiEncoder(nn.Module):
     """reference network/effnet_encoder.py:6-18 (no input normalisation; AvgPool2d(7) on the 7x7 head features)."""
 
-    def __init__(self, pretrain="effb3", conv_impl="aten"):
+    def __init__(self, pretrain="effb3"):
         super().__init__()
         assert pretrain == "effb3"
-        self.encoder = EfficientNetB3(conv_impl)
+        self.encoder = EfficientNetB3()
         self.pool = nn.AvgPool2d(7, stride=1)
 
     def forward(self, x):

@@ -1,15 +1,13 @@
 """`LossFunction` with the reference's call signature, loss names and formulas
 (reference losses.py:226-453; helpers utils/losses_util.py:217-301,366-378; utils/pytorch_ssim:17-37).
 
-On the GPU the step's terms run as fused HIP kernels: SSIM (csrc/ssim.hip), the photometric block and the joint /
-vertex / edge-length / shape / pose terms (csrc/losses.hip: two launches per group instead of ~250 ATen launches).
-`fused=False` takes the plain torch-op restatement below, which the CPU oracle step uses and the tests pin the kernels
-against (with `fused=True` a CPU tensor raises: there is no silent fallback).  Terms no config of BASELINE.json uses (joint_2d, bone_direc, mscale, scale, iou, mtex)
-are torch ops on either path.
+ONE path: the step's terms run as fused HIP kernels -- SSIM (csrc/ssim.hip), the photometric block and the joint / vertex /
+edge-length / shape / pose terms (csrc/losses.hip: two launches per group instead of ~250 ATen launches) -- on GPU tensors; a CPU
+tensor raises (no fallback).  The rarely used terms (joint_2d, bone_direc, mscale, scale, iou, mtex and the self-supervised
+`*_self` terms) are a handful of torch ops on the same GPU tensors.  The torch restatement of the whole function that the tests
+compare against is oracle/loss_oracle.py (pinned by the reference's own LossFunction.__call__, tests/golden/loss_dict.npz).
 """
 from __future__ import annotations
-
-import math
 
 import torch
 import torch.nn.functional as F
@@ -52,50 +50,11 @@ def iou(s_gt, s_est):
     return 1 - torch.mean(mul / (add - mul))
 
 
-_WINDOWS = {}
-
-
-def _window(channel, device, dtype, size=11, sigma=1.5):
-    key = (channel, str(device), dtype)
-    if key not in _WINDOWS:
-        g = torch.tensor([math.exp(-(x - size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(size)])
-        g = (g / g.sum()).unsqueeze(1)
-        w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
-        _WINDOWS[key] = w2.expand(channel, 1, size, size).contiguous().to(device=device, dtype=dtype)
-    return _WINDOWS[key]
-
-
-def ssim_torch(img1, img2, window_size=11):
-    """utils/pytorch_ssim/__init__.py:17-37,65-73 restated with torch ops.  The product path uses the fused HIP
-    kernel (hifihr_amd.ops.ssim); this restatement serves the CPU oracle step and pins the kernel in tests."""
-    ch = img1.shape[1]
-    w = _window(ch, img1.device, img1.dtype, window_size)
-    pad = window_size // 2
-    mu1 = F.conv2d(img1, w, padding=pad, groups=ch)
-    mu2 = F.conv2d(img2, w, padding=pad, groups=ch)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-    s1 = F.conv2d(img1 * img1, w, padding=pad, groups=ch) - mu1_sq
-    s2 = F.conv2d(img2 * img2, w, padding=pad, groups=ch) - mu2_sq
-    s12 = F.conv2d(img1 * img2, w, padding=pad, groups=ch) - mu1_mu2
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    return (((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()
-
-
-ssim = ssim_torch      # backwards-compatible name used by tests
-
-
 class LossFunction:
-    def __init__(self, perceptual=None, ssim_fn=None, fused=True):
+    def __init__(self, perceptual=None):
         # PerceptualLoss instance; None = built on first use (hifihr_amd/perceptual.py: seeded torchvision-style
         # initialisation unless the caller loads VGG19 weights -- they cannot be downloaded offline, SURVEY.md A16)
         self.perceptual_loss = perceptual
-        self.ssim_loss_fn = None
-        if ssim_fn is None:
-            from . import ops
-            ssim_fn = ops.ssim                       # fused HIP kernel (GPU only, no fallback)
-            self.ssim_loss_fn = ops.ssim_loss        # lambda * (1 - ssim) with the scalar glue folded in
-        self.ssim_fn = ssim_fn
-        self.fused = fused
 
     def _fused_geometry(self, examples, outputs, loss_used, args, loss_dic):
         """joint_3d / vert_3d / edge_length / mshape / mpose in one kernel pair (csrc/losses.hip)."""
@@ -118,67 +77,56 @@ class LossFunction:
                 loss_dic[k] = v
 
     def __call__(self, examples, outputs, loss_used, dat_name, args) -> dict:
+        from . import ops
         loss_dic = {}
         base = F.l1_loss if args.base_loss_fn == "L1" else F.mse_loss
-        fused = self.fused                      # the fused kernels run on GPU tensors only; a CPU tensor raises (no silent fallback)
-        if fused and any(k in loss_used for k in ("joint_3d", "vert_3d", "edge_length", "mshape", "mpose")):
+        if any(k in loss_used for k in ("joint_3d", "vert_3d", "edge_length", "mshape", "mpose")):
             self._fused_geometry(examples, outputs, loss_used, args, loss_dic)
             loss_used = [k for k in loss_used if k not in loss_dic]
         if "joint_2d" in loss_used:
             loss_dic["joint_2d"] = args.lambda_j2d_gt * base(examples["j2d_gt"], outputs["j2d"])
-        if "joint_3d" in loss_used:
-            loss_dic["joint_3d"] = args.lambda_j3d * base(outputs["joints"], examples["joints"])
-        if "vert_3d" in loss_used:
-            loss_dic["vert_3d"] = args.lambda_vert_3d * base(outputs["mano_verts"], examples["verts"])
         if "bone_direc" in loss_used:
             loss_dic["bone_direc"] = args.lambda_bone_direc * bone_direction_loss(outputs["j2d"], examples["j2d_gt"])
         if "bone_direc_3d" in loss_used:
             loss_dic["bone_direc_3d"] = args.lambda_bone_direc_3d * bone_direction_loss(outputs["joints"], examples["joints"])
-        if "edge_length" in loss_used:
-            loss_dic["edge_length"] = args.lambda_edge_len * edge_length_loss(outputs["mano_verts"], examples["verts"], outputs["mano_faces"])
         if "mscale" in loss_used:
             bl = torch.sqrt(torch.sum((outputs["joints"][:, 9] - outputs["joints"][:, 10]) ** 2, 1))
             loss_dic["mscale"] = args.lambda_mscale * F.l1_loss(bl, torch.ones_like(bl) * 0.0282)
         if "scale" in loss_used and dat_name in ("FreiHand", "RHD"):
             bl = torch.sqrt(torch.sum((outputs["joints"][:, 9] - outputs["joints"][:, 10]) ** 2, 1))
             loss_dic["scale"] = args.lambda_scale * F.mse_loss(bl, examples["scales"].to(bl.device))
-        if fused and outputs.get("_rgba") is not None and "re_sil" in outputs:
-            # photometric block (losses.py:355-378) + `sil` (:388-390) from the renderer's rgba in one kernel pair
-            from . import ops
-            out, re_img, mask_rgbs = ops.photo_losses(outputs["_rgba"], examples["imgs"], examples["segms_gt"], args.lambda_texture,
+        if "re_img" in outputs and "re_sil" in outputs and "texture_con" in examples:
+            # self-supervised photometric terms (losses.py:317-340): confidence-weighted, against the image masked by the RENDERED
+            # silhouette (outputs['maskRGBs']) and with the unmasked render
+            mask_rgbs, re_img, con = outputs["maskRGBs"], outputs["re_img"], examples["texture_con"]
+            b = re_img.shape[0]
+            c2 = con.view(-1) ** 2
+            per = torch.abs(re_img - mask_rgbs).reshape(b, -1).sum(1)
+            loss_dic["texture_self"] = args.lambda_texture * (torch.sum(per * c2) / (torch.sum(c2) * (re_img.numel() // b)))
+            dm = torch.abs(torch.mean(re_img.reshape(b, -1), 1) - torch.mean(mask_rgbs.reshape(b, -1), 1))
+            loss_dic["mrgb_self"] = args.lambda_mrgb * (torch.sum(dm * c2) / torch.sum(c2))
+            loss_dic["ssim_tex_self"] = ops.ssim_loss(re_img, mask_rgbs, args.lambda_ssim_tex)
+        if "re_img" in outputs and "re_sil" in outputs:
+            # photometric block (losses.py:355-378) + `sil` (:398-403) from the renderer's rgba in one kernel pair
+            rgba = outputs.get("_rgba")
+            if rgba is None:                     # outputs that did not come from models.Model: alpha = the binarised silhouette
+                rgba = torch.cat([outputs["re_img"], (outputs["re_sil"] > 0).to(outputs["re_img"].dtype)], 1)
+            out, re_img, mask_rgbs = ops.photo_losses(rgba, examples["imgs"], examples["segms_gt"], args.lambda_texture,
                                                       args.lambda_mrgb, args.lambda_silhouette)
             tex, mrgb, sil, _ = out.unbind(0)
             loss_dic["texture"], loss_dic["mrgb"] = tex, mrgb
-            if self.ssim_loss_fn is not None:
-                loss_dic["ssim_tex"] = self.ssim_loss_fn(re_img, mask_rgbs, args.lambda_ssim_tex)
-            else:
-                loss_dic["ssim_tex"] = args.lambda_ssim_tex * (1 - self.ssim_fn(re_img, mask_rgbs))
+            loss_dic["ssim_tex"] = ops.ssim_loss(re_img, mask_rgbs, args.lambda_ssim_tex)   # lambda * (1 - ssim), scalar glue folded in
             if "sil" in loss_used:
                 loss_dic["sil"] = sil
-                loss_used = [k for k in loss_used if k != "sil"]
-        elif "re_img" in outputs and "re_sil" in outputs:
-            # photometric block, computed whenever a render exists (losses.py:355-378)
-            seg = examples["segms_gt"].unsqueeze(1).to(outputs["re_img"].dtype)
-            mask_rgbs = seg * examples["imgs"]
-            re_img = outputs["re_img"] * (outputs["re_sil"] / 255.0)
-            loss_dic["texture"] = args.lambda_texture * F.l1_loss(re_img, mask_rgbs)
-            loss_dic["mrgb"] = args.lambda_mrgb * F.mse_loss(torch.mean(mask_rgbs), torch.mean(re_img))
-            loss_dic["ssim_tex"] = args.lambda_ssim_tex * (1 - self.ssim_fn(re_img, mask_rgbs))
         if "perceptual" in loss_used:
             if self.perceptual_loss is None:
                 from .perceptual import PerceptualLoss
-                self.perceptual_loss = PerceptualLoss(impl="hip" if fused else "torch").to(outputs["re_img"].device)
+                self.perceptual_loss = PerceptualLoss().to(outputs["re_img"].device)
             seg = examples["segms_gt"].unsqueeze(1)
             loss_dic["perceptual"] = args.lambda_percep * self.perceptual_loss(
                 outputs["re_img"] * seg + examples["imgs"] * (1 - seg), examples["imgs"])
-        if "sil" in loss_used:
-            loss_dic["sil"] = args.lambda_silhouette * F.l1_loss(outputs["re_sil"], examples["segms_gt"].unsqueeze(1).float())
         if "iou" in loss_used:
             loss_dic["iou"] = args.lambda_iou * iou(outputs["re_sil"], examples["segms_gt"].unsqueeze(1).float())
-        if "mshape" in loss_used:
-            loss_dic["mshape"] = args.lambda_shape * F.mse_loss(outputs["shape_params"], torch.zeros_like(outputs["shape_params"]))
-        if "mpose" in loss_used:
-            loss_dic["mpose"] = args.lambda_pose * F.mse_loss(outputs["pose_params"], torch.zeros_like(outputs["pose_params"]))
         if "mtex" in loss_used and outputs.get("texture_params") is not None:
             loss_dic["mtex"] = args.lambda_tex_reg * F.mse_loss(outputs["texture_params"], torch.zeros_like(outputs["texture_params"]))
         return loss_dic

@@ -43,8 +43,7 @@ class MyMANOLayer(nn.Module):
 
 class Model(nn.Module):
     def __init__(self, ifRender, device, if_4c, hand_model, use_mean_shape, pretrain, root_id=9, root_id_nimble=11,
-                 ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3, conv_impl="mfma",
-                 texture_stand_in=0):
+                 ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3, texture_stand_in=0):
         super().__init__()
         if hand_model != "mano":
             raise NotImplementedError(f"hand_model='{hand_model}': only 'mano' is built (NIMBLE assets are not available)")
@@ -52,18 +51,17 @@ class Model(nn.Module):
         if pretrain in ("res18", "res50", "res101"):
             # res18: SURVEY.md F6 (the reference hard-codes 2048 / 512, the ResNet-50 / -101 widths, and is broken for res18)
             self.features_dim, self.low_feat_dim = (512, 128) if pretrain == "res18" else (2048, 512)
-            self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=if_4c, conv_impl=conv_impl)
+            self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=if_4c)
         elif pretrain == "effb3":                                    # models_res_nimble.py:50-53
             from .effnet import EffiEncoder
             self.features_dim, self.low_feat_dim = 1536, 32
-            self.base_encoder = EffiEncoder(pretrain=pretrain, conv_impl=conv_impl)
+            self.base_encoder = EffiEncoder(pretrain=pretrain)
         else:
             raise NotImplementedError(f"pretrain='{pretrain}' is not built yet")
         self.ncomps = [10, 48, int(texture_stand_in) if texture_stand_in else None]
         self.hand_layer = MyMANOLayer(ifRender, device, shape_ncomp=10, pose_ncomp=48, tables=mano_tables)
         self.hand_encoder = HandEncoder(hand_model=hand_model, ncomps=self.ncomps, in_dim=self.features_dim,
-                                        ifRender=ifRender, use_mean_shape=use_mean_shape,
-                                        impl="hip" if conv_impl == "mfma" else "torch")
+                                        ifRender=ifRender, use_mean_shape=use_mean_shape)
         self.register_buffer("mano_face", self.hand_layer.mesh_face.clone().to(torch.int16), persistent=False)
         self.ifRender, self.ifLight, self.aa_factor, self.image_size = ifRender, ifLight, aa_factor, image_size
         if ifRender:
@@ -75,7 +73,7 @@ class Model(nn.Module):
             if texture_stand_in:
                 self.register_buffer("texture_basis", texture_stand_in_basis(texture_stand_in), persistent=False)
         if ifLight:
-            self.light_estimator = LightEstimator(self.low_feat_dim, conv_impl=conv_impl)
+            self.light_estimator = LightEstimator(self.low_feat_dim)
 
     def get_ndc_fx_fy_cx_cy(self, Ks):
         s = float(self.image_size)

@@ -637,13 +637,45 @@ class _BNAct(torch.autograd.Function):
         return dx, None, dg_ret, db_ret, dres, None, None, None, None, None
 
 
+class _BNActEval(torch.autograd.Function):
+    """act(batch_norm(x; running statistics) + residual): evaluation mode (reference train_hrnet.py:119-161 runs model.eval()).
+    Forward: one launch of the fused apply kernel (hifihr_bn_act_eval).  Backward (a frozen-statistics layer inside a graph that
+    still needs gradients -- not on the training hot path): per-channel affine map, a handful of elementwise torch ops."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, rmean, rvar, act, eps):
+        require_cuda(x, gamma, beta)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x, memory_format=_CL)
+        get_lib().bn_act_eval(x, rmean, rvar, gamma, beta, residual, act, N * H * W, C, eps, y)
+        ctx.save_for_backward(x, y, gamma, beta, rmean, rvar)
+        ctx.act, ctx.eps, ctx.has_res = act, eps, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, beta, rmean, rvar = ctx.saved_tensors
+        invstd = torch.rsqrt(rvar + ctx.eps).view(1, -1, 1, 1)
+        sc = gamma.view(1, -1, 1, 1) * invstd
+        if ctx.act == 1:
+            g = dy * (y > 0)
+        elif ctx.act == 2:
+            z = (x - rmean.view(1, -1, 1, 1)) * sc + beta.view(1, -1, 1, 1)
+            sg = torch.sigmoid(z)
+            g = dy * (sg * (1 + z * (1 - sg)))
+        else:
+            g = dy
+        xhat = (x - rmean.view(1, -1, 1, 1)) * invstd
+        return g * sc, (g * xhat).sum((0, 2, 3)), g.sum((0, 2, 3)), (g if ctx.has_res else None), None, None, None, None
+
+
 _ACT = {None: 0, False: 0, True: 1, "relu": 1, "swish": 2}
 
 
 def bn_act(x, stats, bn: torch.nn.BatchNorm2d, residual=None, relu=True):
     """act(bn(x) + residual?) with train-mode batch statistics; `relu` is True/"relu", "swish", or False/None
     (reference trunks: nn.BatchNorm2d + `out += identity` + nn.ReLU; EfficientNet: BN + MemoryEfficientSwish).
-    `stats` comes from conv2d(..., want_stats=True).  Eval mode uses the running statistics (torch ops).
+    `stats` comes from conv2d(..., want_stats=True).  Eval mode: the same fused kernel on the running statistics (`stats` must be None).
     bn.num_batches_tracked is not advanced (it only matters for momentum=None, which the reference never uses)."""
     act = _ACT[relu]
     if not bn.training:
@@ -656,10 +688,7 @@ def bn_act(x, stats, bn: torch.nn.BatchNorm2d, residual=None, relu=True):
         xc = x.contiguous(memory_format=_CL)
         N, C, H, W = xc.shape
         res = residual.contiguous(memory_format=_CL) if residual is not None else None
-        y = torch.empty_like(xc, memory_format=_CL)
-        with torch.no_grad():
-            lib.bn_act_eval(xc, bn.running_mean, bn.running_var, bn.weight, bn.bias, res, act, N * H * W, C, float(bn.eps), y)
-        return y
+        return _BNActEval.apply(xc, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, act, float(bn.eps))
     if stats is None:                       # producer was not one of our convolutions: one HBM-bound statistics pass
         require_cuda(x)
         lib = get_lib()
@@ -891,12 +920,14 @@ def linear_group(members):
 
 def linear(x, lin: torch.nn.Linear, act=None, bn: torch.nn.BatchNorm1d | None = None):
     """act(bn(lin(x))) for a [B, I] activation in ONE launch (two backward): nn.Linear (+ nn.BatchNorm1d, batch statistics
-    in training mode) (+ nn.ReLU) of the reference's regression heads.  Eval-mode batch-norm and B > 64 with batch-norm
-    take the torch modules."""
+    in training mode) (+ nn.ReLU) of the reference's regression heads.  The fused batch-norm epilogue needs every row of the batch
+    in one workgroup (B <= 64); larger batches and evaluation mode run the layer as linear -> bn_act (csrc/bn.hip on a [B, O, 1, 1]
+    view: the same train- / eval-mode batch-norm kernels the trunk uses), still hand-written kernels only."""
     a = 1 if act in (True, "relu", 1) else 0
     if bn is not None and (not bn.training or x.shape[0] > 64):
-        out = bn(lin(x))
-        return torch.relu(out) if a else out
+        z = _Linear.apply(x, lin.weight, lin.bias, None, None, 0, 0.0, 0.0, None, None)
+        B, O = z.shape
+        return bn_act(z.view(B, O, 1, 1), None, bn, None, bool(a)).reshape(B, O)
     if bn is None:
         return _Linear.apply(x, lin.weight, lin.bias, None, None, a, 0.0, 0.0, None, None)
     return _Linear.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, a, float(bn.eps), float(bn.momentum), bn.running_mean,

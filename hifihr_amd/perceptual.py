@@ -6,10 +6,11 @@ ImageNet-normalised fake and real images and returns the MSE (or L1, or both) of
 detached.  VGG parameters never reach the optimizer, so they are frozen here (the reference computes their gradients
 and throws them away).
 
-impl="hip": seven 3x3 convolutions with the bias (+ ReLU) epilogue on the f32-MFMA implicit-GEMM kernels and the 2x2
-max-pools of csrc/pool.hip, channels_last activations, GPU tensors only.  impl="torch": nn.Conv2d / F.max_pool2d,
-the comparison flavour (CPU oracle step, tests).  Both hold `model.<i>.weight / .bias` at torchvision's indices, so
-`load_vgg19_features(state_dict)` accepts torchvision's `vgg19().features.state_dict()` (or the full model's) as is.
+ONE path: seven 3x3 convolutions with the bias (+ ReLU) epilogue on the f32-MFMA kernels (the >= 128-channel ones through
+Winograd + csrc/gemm.hip) and the 2x2 max-pools of csrc/pool.hip, channels_last activations, GPU tensors only (a CPU tensor
+raises).  The torch restatement the tests compare against is oracle/torch_modules.PerceptualLossRef.  `model.<i>.weight / .bias`
+sit at torchvision's indices, so `load_vgg19_features(state_dict)` accepts torchvision's `vgg19().features.state_dict()` (or the
+full model's) as is.
 
 Pretrained weights cannot be downloaded here (no network): without a state dict the layers carry torchvision's own
 initialisation (kaiming_normal fan_out / zero bias) from a seeded generator -- SURVEY.md section 8(d), config 3.
@@ -54,22 +55,19 @@ class _NormalizeToNHWC4(torch.autograd.Function):
 
 
 class PerceptualLoss(nn.Module):
-    def __init__(self, type="l2", reduction="mean", final_layer=14, impl="hip", seed=0):
+    def __init__(self, type="l2", reduction="mean", final_layer=14, seed=0):
         super().__init__()
         if type not in ("l1", "l2", "both"):
             raise NotImplementedError(type)
-        self.type, self.reduction, self.impl = type, reduction, impl
+        self.type, self.reduction = type, reduction
         self.layout = vgg19_feature_layout(final_layer)
         gen = torch.Generator().manual_seed(seed)
         layers = []
         for idx, (i, kind, cin, cout) in enumerate(self.layout):
             if kind == "conv":
                 fused_relu = idx + 1 < len(self.layout) and self.layout[idx + 1][1] == "relu"
-                if impl == "hip":
-                    from .network import Conv2dMFMA
-                    m = Conv2dMFMA(cin, cout, 3, 1, 1, bias=True, relu=fused_relu)
-                else:
-                    m = nn.Conv2d(cin, cout, 3, 1, 1)
+                from .network import Conv2dMFMA
+                m = Conv2dMFMA(cin, cout, 3, 1, 1, bias=True, relu=fused_relu)
                 with torch.no_grad():          # torchvision's VGG initialisation, drawn in the standard NCHW order
                     w = torch.empty(cout, cin, 3, 3)
                     nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu", generator=gen)
@@ -84,8 +82,6 @@ class PerceptualLoss(nn.Module):
         self.model.eval()
         for p in self.model.parameters():
             p.requires_grad_(False)
-        self.register_buffer("mean", torch.tensor(_MEAN).view(1, 3, 1, 1), persistent=False)
-        self.register_buffer("std", torch.tensor(_STD).view(1, 3, 1, 1), persistent=False)
 
     def load_vgg19_features(self, state_dict):
         """torchvision vgg19 weights: keys `features.<i>.weight` (whole model) or `<i>.weight` (features only)."""
@@ -105,8 +101,6 @@ class PerceptualLoss(nn.Module):
                 getattr(self.model[int(i)], n).copy_(v)
 
     def features(self, images):
-        if self.impl != "hip":
-            return self.model((images - self.mean) / self.std)
         from . import ops
         x = _NormalizeToNHWC4.apply(images)
         skip = False

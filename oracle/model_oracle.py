@@ -1,40 +1,47 @@
 """ORACLE (test infrastructure, not product code): the whole training step on the CPU.
 
-Composes the oracle pieces (oracle/mano_oracle.py, oracle/render_oracle.py) with torch-CPU ATen for the
-encoder / heads, following reference models_res_nimble.py:102-225 (Model.forward), train_hrnet.py:50-113 (the
-step) and losses.py:234-453.  Used by tests/ (end-to-end loss parity of the HIP path), by
-__graft_entry__.smoke() and as bench.py's cpu_baseline ("port").  Never imported by hifihr_amd.
+Composes the oracle pieces -- oracle/torch_modules.py (encoder / heads / VGG restated in plain torch), oracle/mano_oracle.py,
+oracle/render_oracle.py + oracle/raster_oracle.c, oracle/loss_oracle.py -- following reference models_res_nimble.py:102-225
+(Model.forward), train_hrnet.py:50-113 (the step) and losses.py:234-453.  Independent of the product: nothing under oracle/ imports
+`hifihr_amd` (tests/test_host_logic.py::test_oracle_is_independent_of_the_product checks it).  Used by tests/ (end-to-end loss
+parity of the HIP path), by __graft_entry__.smoke() and as bench.py's cpu_baseline ("port").
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
-from hifihr_amd.losses import LossFunction, ssim_torch
-from hifihr_amd.network import HandEncoder, LightEstimator, ResEncoder
-from hifihr_amd.traineval import trans_proj_j2d
 from oracle import mano_oracle as mo
 from oracle import render_oracle as ro
+from oracle.loss_oracle import LossFunctionRef, trans_proj_j2d
+from oracle.torch_modules import EffiEncoderRef, HandEncoderRef, LightEstimatorRef, ResEncoderRef
 
 SKIN_TONE = (0.78, 0.60, 0.50)
+
+
+def texture_stand_in_basis(ncomp: int) -> torch.Tensor:
+    """The fixed seeded map texture_params -> per-vertex colour offsets of the declared NIMBLE texture stand-in (DESIGN.md section 2,
+    A9): 0.05 * randn(ncomp, 778 * 3) from generator seed 7.  A data definition, restated here so that the oracle does not import
+    the product; tests check that both sides hold the same numbers."""
+    gen = torch.Generator().manual_seed(7)
+    return 0.05 * torch.randn(int(ncomp), 778 * 3, generator=gen)
 
 
 class OracleModel(nn.Module):
     def __init__(self, tables, pretrain="res18", image_size=224, aa=3, root_id=9, texture_stand_in=0):
         super().__init__()
         self.tables, self.image_size, self.aa, self.root_id = tables, image_size, aa, root_id
-        if pretrain == "res18":
-            self.base_encoder, feat_dim, low_dim = ResEncoder(pretrain=pretrain, if_4c=False), 512, 128
+        if pretrain in ("res18", "res50", "res101"):
+            self.base_encoder = ResEncoderRef(pretrain=pretrain)
+            feat_dim, low_dim = (512, 128) if pretrain == "res18" else (2048, 512)
         else:
-            from hifihr_amd.effnet import EffiEncoder
-            self.base_encoder, feat_dim, low_dim = EffiEncoder(pretrain, conv_impl="aten"), 1536, 32
-        self.hand_encoder = HandEncoder(hand_model="mano", ncomps=[10, 48, int(texture_stand_in) or None], in_dim=feat_dim,
-                                        ifRender=True, use_mean_shape=False)
-        if texture_stand_in:                   # hifihr_amd/models.py: vertex colours = skin tone + basis . texture_params
-            from hifihr_amd.models import texture_stand_in_basis
+            self.base_encoder, feat_dim, low_dim = EffiEncoderRef(pretrain), 1536, 32
+        self.hand_encoder = HandEncoderRef(hand_model="mano", ncomps=[10, 48, int(texture_stand_in) or None], in_dim=feat_dim,
+                                           ifRender=True, use_mean_shape=False)
+        if texture_stand_in:                   # vertex colours = skin tone + basis . texture_params
             self.register_buffer("texture_basis", texture_stand_in_basis(texture_stand_in), persistent=False)
         self.texture_stand_in = int(texture_stand_in)
-        self.light_estimator = LightEstimator(low_dim)
+        self.light_estimator = LightEstimatorRef(low_dim)
         self.faces = torch.as_tensor(tables.faces).long()
 
     def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):
@@ -63,7 +70,7 @@ class OracleModel(nn.Module):
         return outputs
 
 
-def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None, features=None, dat_name="FreiHand"):
+def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None, features=None, dat_name="FreiHand", perceptual=None):
     """train_hrnet.py:50-113 on the CPU.  Returns (loss, loss_dic, outputs).  `features=(low, feat)` skips the
     image encoder (tests isolate the HIP kernels from conv back-end rounding that way)."""
     root_xyz = examples_cpu["joints"][:, args.ROOT, :].unsqueeze(1)
@@ -78,7 +85,7 @@ def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None, fe
         if "verts" in examples_cpu:
             ex["verts"] = examples_cpu["verts"] - root_xyz
     outputs["j2d"] = trans_proj_j2d(outputs, examples_cpu["Ks"], root_xyz=root_xyz)
-    loss_dic = LossFunction(ssim_fn=ssim_torch, fused=False)(ex, outputs, args.losses, dat_name, args)
+    loss_dic = LossFunctionRef(perceptual)(ex, outputs, args.losses, dat_name, args)
     loss = sum(loss_dic[k] for k in args.losses)
     if optimizer is not None:
         optimizer.zero_grad()

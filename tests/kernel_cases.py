@@ -234,7 +234,7 @@ def conv_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0, bias=False, rt
 
 
 def image_to_nhwc4_case(lib, device):
-    from hifihr_amd.network import normalize_batch_3C
+    from oracle.torch_modules import normalize_batch_3C
     img = torch.rand(3, 3, 20, 12)
     out = torch.empty(3, 20, 12, 4, device=device)
     lib.image_to_nhwc4(img.to(device), out)
@@ -256,10 +256,10 @@ def image_to_nhwc4_case(lib, device):
 
 # ------------------------------------------------------------------------------------------------
 # fused SSIM vs vectors produced by the reference's utils/pytorch_ssim (tests/golden/ssim.npz) and vs the
-# torch restatement in hifihr_amd/losses.py (itself pinned to the same vectors on the CPU)
+# torch restatement in oracle/loss_oracle.py (itself pinned to the same vectors on the CPU)
 # ------------------------------------------------------------------------------------------------
 def ssim_case(lib, device, a, b, ref_val=None, ref_grad=None):
-    from hifihr_amd import losses as L
+    from oracle import loss_oracle as L
     from hifihr_amd.ops import _ssim_window
     win = _ssim_window()
     a_t, b_t = torch.as_tensor(a), torch.as_tensor(b)
@@ -455,8 +455,8 @@ def maxpool_case(lib, device, N, H, W, C, seed=0, ties=False, ksp=(3, 2, 1)):
 
 
 # ------------------------------------------------------------------------------------------------
-# fused losses (csrc/losses.hip) vs the torch-op restatement in hifihr_amd/losses.py (pinned against the reference's
-# LossFunction by tests/golden/losses.npz in test_host_logic.py)
+# fused losses (csrc/losses.hip) vs the torch-op restatement in oracle/loss_oracle.py (pinned against the reference's
+# own functions by tests/golden/losses.npz and loss_dict.npz in test_host_logic.py / test_oracle_losses.py)
 # ------------------------------------------------------------------------------------------------
 def vertex_face_csr(faces, V):
     f = np.asarray(faces, dtype=np.int64).reshape(-1)
@@ -468,7 +468,7 @@ def vertex_face_csr(faces, V):
 
 def geom_loss_case(lib, device, B, V, F, mse, seed=0, J=21, NS=10, NP=48):
     import torch.nn.functional as Fn
-    from hifihr_amd.losses import edge_length_loss
+    from oracle.loss_oracle import edge_length_loss
     gen = torch.Generator().manual_seed(seed)
     rnd = lambda *s: torch.randn(*s, generator=gen)
     joints, jgt, verts, vgt = rnd(B, J, 3) * 0.05, rnd(B, J, 3) * 0.05, rnd(B, V, 3) * 0.05, rnd(B, V, 3) * 0.05

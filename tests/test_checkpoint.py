@@ -29,20 +29,23 @@ def test_submodule_state_dicts_match_reference_classes(names):
     assert _shapes(HandEncoder("mano", [10, 48, None], in_dim=1536)) == names["hand_encoder[mano,1536]"]["state"]
     assert _shapes(HandEncoder("nimble", [20, 30, 10], in_dim=1536)) == names["hand_encoder[nimble,1536]"]["state"]
     assert _shapes(HandEncoder("mano", [10, 48, None], in_dim=512)) == names["hand_encoder[mano,512]"]["state"]
-    for flavour in ("aten", "mfma"):
-        assert _shapes(LightEstimator(32, conv_impl=flavour)) == names["light_estimator[32]"]["state"], flavour
-        assert _shapes(LightEstimator(512, conv_impl=flavour)) == names["light_estimator[512]"]["state"], flavour
+    from oracle.torch_modules import EffiEncoderRef, LightEstimatorRef, ResEncoderRef
+    # the product modules (hand-written kernels) and their torch restatements (oracle/) both carry the reference's names
+    for flavour, (LE, EE, RE) in (("product", (LightEstimator, EffiEncoder, ResEncoder)),
+                                  ("oracle", (LightEstimatorRef, EffiEncoderRef, ResEncoderRef))):
+        assert _shapes(LE(32)) == names["light_estimator[32]"]["state"], flavour
+        assert _shapes(LE(512)) == names["light_estimator[512]"]["state"], flavour
         # image encoders: the reference's names minus the unused classifier head, in the same order (parameters too)
-        eff = EffiEncoder("effb3", conv_impl=flavour)
+        eff = EE("effb3")
         want = [["encoder." + n, s] for n, s in names["efficientnet-b3"]["state"] if not n.startswith("_fc.")]
         assert _shapes(eff) == want, flavour
         assert [n for n, _ in eff.named_parameters()] == ["encoder." + n for n in names["efficientnet-b3"]["params"] if not n.startswith("_fc.")]
-        res = ResEncoder(pretrain="res18", if_4c=False, conv_impl=flavour)
+        res = RE(pretrain="res18")
         want = [["mmpool.p", [1]]] + [["encoder1.model." + n, s] for n, s in names["resnet18"]["state"] if not n.startswith("fc.")]
         assert _shapes(res) == want, flavour
-    res50 = ResEncoder(pretrain="res50", if_4c=False, conv_impl="aten")
-    want = [["mmpool.p", [1]]] + [["encoder1.model." + n, s] for n, s in names["resnet50"]["state"] if not n.startswith("fc.")]
-    assert _shapes(res50) == want
+        res50 = RE(pretrain="res50")
+        want = [["mmpool.p", [1]]] + [["encoder1.model." + n, s] for n, s in names["resnet50"]["state"] if not n.startswith("fc.")]
+        assert _shapes(res50) == want, flavour
     assert names["resnet50"]["state"][-2:] == [["fc.weight", [1000, 2048]], ["fc.bias", [1000]]]
     assert names["mmpool"]["state"] == [["p", [1]]]
     assert names["resnet18"]["state"][-2:] == [["fc.weight", [1000, 512]], ["fc.bias", [1000]]]
@@ -57,12 +60,12 @@ class _Mine(nn.Module):
         from hifihr_amd.effnet import EffiEncoder
         from hifihr_amd.network import HandEncoder, LightEstimator, ResEncoder
         if pretrain in ("res18", "res50"):
-            self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=False, conv_impl="aten")
+            self.base_encoder = ResEncoder(pretrain=pretrain, if_4c=False)
             feat, low = (512, 128) if pretrain == "res18" else (2048, 512)
         else:
-            self.base_encoder, feat, low = EffiEncoder("effb3", conv_impl="aten"), 1536, 32
+            self.base_encoder, feat, low = EffiEncoder("effb3"), 1536, 32
         self.hand_encoder = HandEncoder("mano", [10, 48, None], in_dim=feat)
-        self.light_estimator = LightEstimator(low, conv_impl="aten")
+        self.light_estimator = LightEstimator(low)
 
 
 class _RefSide(nn.Module):

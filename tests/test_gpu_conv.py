@@ -45,7 +45,7 @@ def test_resnet18_trunk_mfma_vs_reference_golden(golden_dir):
     from hifihr_amd import ops
     from hifihr_amd.network import Resnet_4C
     g = np.load(os.path.join(golden_dir, "resnet18_small.npz"))
-    enc = Resnet_4C("res18", conv_impl="mfma")          # stem + blocks on the MFMA convs and the fused BN/add/ReLU kernels
+    enc = Resnet_4C("res18")                            # stem + blocks on the MFMA convs and the fused BN/add/ReLU kernels
     enc.model.load_state_dict(seeded_state_dict(enc.model))
     enc = enc.cuda().train()
     net = enc.model
@@ -82,16 +82,19 @@ def test_efficientnet_b3_mfma_vs_reference_golden(golden_dir):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from seeded_init import seeded_state_dict
     import hifihr_amd.effnet as E
+    from oracle.torch_modules import EfficientNetB3Ref
     g = np.load(os.path.join(golden_dir, "effnet_b3_small.npz"))
-    ref = E.EfficientNetB3("aten")
+    ref = EfficientNetB3Ref()                  # the torch restatement (pinned to the reference's extract_features on the CPU)
     ref.load_state_dict(seeded_state_dict(ref))
-    net = E.EfficientNetB3("mfma")
+    net = E.EfficientNetB3()
     net.load_state_dict(ref.state_dict())
     ref, net = ref.cuda().train(), net.cuda().train()
     x = torch.tensor(g["x"]).cuda()
     old = E._DROP_CONNECT
     E._DROP_CONNECT = 0.0                      # same deterministic function on both paths
     try:
+        for blk in ref._blocks:                # drop-connect off in the restatement too
+            blk.forward = (lambda b: (lambda inputs, drop_connect_rate=None: type(b).forward(b, inputs, None)))(blk)
         f0, l0 = ref.extract_features(x)
         f1, l1 = net.extract_features(x)
         w = torch.randn_like(f0)
@@ -145,16 +148,17 @@ def test_resnet50_convolution_shapes(lib, H, C, K, R, stride, pad):
     kc.conv_case(lib, "cuda", 2, H, H, C, K, R, stride, pad, seed=H + C + K, rtol=3e-5)
 
 
-def test_resnet50_trunk_mfma_matches_aten_flavour():
+def test_resnet50_trunk_mfma_matches_torch_restatement():
     """The bottleneck trunk of the reference's res50 / res101 encoders (torchvision v1.5 bottleneck, layer-4 stride edits) on the
-    hand-written kernels vs the torch.nn flavour with the same weights.  Train mode: features and low-level features.  Gradients
+    hand-written kernels vs the torch restatement (oracle/torch_modules.py) with the same weights.  Train mode: features and low-level features.  Gradients
     are compared with batch-norm in eval mode and loosely: a randomly initialised 50-layer trunk is chaotic in train mode
     (perturbing the input of the torch flavour by 1e-7 moves its own layer-4 gradients by 10-20 %, tools/debug_res50.py) and
     still amplifies ReLU-boundary flips in eval mode; the kernels themselves are pinned shape by shape above."""
     from hifihr_amd.network import ResEncoder
+    from oracle.torch_modules import ResEncoderRef
     torch.manual_seed(5)
-    ref = ResEncoder(pretrain="res50", conv_impl="aten").train()
-    hip = ResEncoder(pretrain="res50", conv_impl="mfma").cuda().train()
+    ref = ResEncoderRef(pretrain="res50").train()
+    hip = ResEncoder(pretrain="res50").cuda().train()
     hip.load_state_dict(ref.state_dict())
     x = torch.rand(4, 3, 96, 96)
     with torch.no_grad():

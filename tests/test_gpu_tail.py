@@ -59,12 +59,13 @@ def test_squeeze_excite(lib, B, H, C, SQ):
 
 
 @pytest.mark.parametrize("B,H,kind", [(2, 64, "l2"), (3, 40, "both")])
-def test_perceptual_loss_matches_torch_flavour(B, H, kind):
-    """VGG19 features[0:15] on the MFMA convolutions (bias / bias+ReLU epilogues, 2x2 max-pools) vs the torch.nn flavour
-    with the same weights (reference utils/perceptual_loss.py:38-45): loss and dL/dfake."""
+def test_perceptual_loss_matches_torch_restatement(B, H, kind):
+    """VGG19 features[0:15] on the MFMA convolutions (bias / bias+ReLU epilogues, 2x2 max-pools) vs the torch restatement
+    (oracle/torch_modules.PerceptualLossRef) with the same weights (reference utils/perceptual_loss.py:38-45): loss and dL/dfake."""
     from hifihr_amd.perceptual import PerceptualLoss
-    hip = PerceptualLoss(type=kind, impl="hip", seed=3).cuda()
-    ref = PerceptualLoss(type=kind, impl="torch", seed=3)
+    from oracle.torch_modules import PerceptualLossRef
+    hip = PerceptualLoss(type=kind, seed=3).cuda()
+    ref = PerceptualLossRef(type=kind, seed=3)
     gen = torch.Generator().manual_seed(B)
     with torch.no_grad():                       # non-zero biases so the epilogue is exercised
         for m in ref.model:

@@ -1,6 +1,6 @@
-"""CPU tests of the host-side mirror of the reference interface (pure torch code, no HIP): loss formulas and
-projection helpers against vectors produced by executing the reference's own function sources
-(tools/make_golden.py gen_losses / gen_ssim / gen_resnet18), config handling, synthetic-table loader."""
+"""CPU tests: the oracle's torch restatements (oracle/) and the product's host-side helpers against vectors produced by executing
+the reference's own sources (tools/make_golden.py gen_losses / gen_ssim / gen_resnet18 / gen_effnet), config handling, that the
+product refuses CPU tensors, and that nothing under oracle/ imports the product."""
 import os
 import sys
 
@@ -9,8 +9,9 @@ import torch
 
 from hifihr_amd import losses as L
 from hifihr_amd import options
-from hifihr_amd.network import ResNet18Trunk, normalize_batch_3C
 from hifihr_amd.traineval import proj_func
+from oracle import loss_oracle as LO
+from oracle.torch_modules import normalize_batch_3C
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
@@ -24,33 +25,40 @@ def test_loss_helpers_vs_reference(golden_dir, synth_tables):
     np.testing.assert_allclose(L.edge_length_loss(t("v"), t("vg"), faces).numpy(), g["edge"], rtol=1e-5)
     np.testing.assert_allclose(L.iou(t("m1"), t("m2")).numpy(), g["iou"], rtol=1e-6)
     np.testing.assert_allclose(proj_func(t("xyz"), t("K")).numpy(), g["proj"], rtol=1e-5, atol=1e-4)
+    # the oracle's independent restatements of the same helpers
+    con = torch.ones(t("j").shape[0], 21, 1)
+    np.testing.assert_allclose(LO.bone_direction_loss(t("j"), t("jg"), con).numpy(), g["bone3d"], rtol=1e-5)
+    np.testing.assert_allclose(LO.bone_direction_loss(t("j2"), t("j2g"), con).numpy(), g["bone2d"], rtol=1e-5)
+    np.testing.assert_allclose(LO.edge_length_loss(t("v"), t("vg"), faces).numpy(), g["edge"], rtol=1e-5)
+    np.testing.assert_allclose(LO.iou(t("m1"), t("m2")).numpy(), g["iou"], rtol=1e-6)
+    np.testing.assert_allclose(LO.proj_func(t("xyz"), t("K")).numpy(), g["proj"], rtol=1e-5, atol=1e-4)
 
 
 def test_ssim_vs_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "ssim.npz"))
     a = torch.tensor(g["a"], requires_grad=True)
-    val = L.ssim(a, torch.tensor(g["b"]))
+    val = LO.ssim(a, torch.tensor(g["b"]))
     val.backward()
     np.testing.assert_allclose(val.item(), g["ssim"], rtol=1e-6)
     np.testing.assert_allclose(a.grad.numpy(), g["ga"], atol=1e-9, rtol=1e-4)
     gen = torch.Generator().manual_seed(12)
     A = torch.rand(2, 3, 224, 224, generator=gen); B = torch.rand(2, 3, 224, 224, generator=gen)
-    np.testing.assert_allclose(L.ssim(A, B).item(), g["ssim224"], rtol=1e-5)
+    np.testing.assert_allclose(LO.ssim(A, B).item(), g["ssim224"], rtol=1e-5)
 
 
 def test_resnet18_trunk_vs_reference(golden_dir):
-    """This package's ResNet-18 trunk (same state-dict names as torchvision) reproduces the reference's vendored
-    ResNet with the layer4 stride edits, forward and backward, from name-seeded weights."""
+    """The oracle's ResNet-18 trunk restatement (same state-dict names as torchvision) reproduces the reference's vendored
+    ResNet with the layer4 stride edits, forward and backward, from name-seeded weights (the product trunk is checked against
+    the same vectors on the GPU: tests/test_gpu_conv.py)."""
     from seeded_init import seeded_state_dict
+    from oracle.torch_modules import Resnet4CRef
     g = np.load(os.path.join(golden_dir, "resnet18_small.npz"))
-    net = ResNet18Trunk(layer4_stride=1)
+    enc = Resnet4CRef("res18")
+    net = enc.model
     sd = seeded_state_dict(net)
     net.load_state_dict(sd)
-    net.train()
-    x = normalize_batch_3C(torch.tensor(g["x"]))
-    h = net.maxpool(net.relu(net.bn1(net.conv1(x))))
-    low = net.layer2(net.layer1(h))
-    feat = net.layer4(net.layer3(low))
+    enc.train()
+    low, feat = enc(normalize_batch_3C(torch.tensor(g["x"])))
     np.testing.assert_allclose(low.detach().numpy(), g["low"], atol=2e-5, rtol=1e-4)
     np.testing.assert_allclose(feat.detach().numpy(), g["feat"], atol=2e-5, rtol=1e-4)
     ((low * torch.tensor(g["wl"])).sum() + (feat * torch.tensor(g["wf"])).sum()).backward()
@@ -78,32 +86,60 @@ def test_product_ops_refuse_cpu_tensors():
     from hifihr_amd._lib import HifihrError, require_cuda
     with pytest.raises(HifihrError):
         require_cuda(torch.zeros(3))
-    # the host-side mirror of the reference modules dispatches by construction (impl / conv_impl / fused), never by device:
-    # the HIP flavours refuse CPU tensors as well
+    # the product modules have ONE path (the hand-written kernels): every one of them refuses CPU tensors
     from hifihr_amd import options
     from hifihr_amd.losses import LossFunction
-    from hifihr_amd.network import HandEncoder, MMPool
+    from hifihr_amd.network import HandEncoder, LightEstimator, MMPool, ResEncoder
+    from hifihr_amd.perceptual import PerceptualLoss
     with pytest.raises(HifihrError):
-        HandEncoder("mano", [10, 48, None], in_dim=512, impl="hip").train()(torch.zeros(4, 512))
+        HandEncoder("mano", [10, 48, None], in_dim=512).train()(torch.zeros(4, 512))
     with pytest.raises(HifihrError):
-        MMPool((1, 1), impl="hip")(torch.zeros(2, 8, 3, 3))
+        MMPool((1, 1))(torch.zeros(2, 8, 3, 3))
+    with pytest.raises(HifihrError):
+        ResEncoder("res18")(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(HifihrError):
+        LightEstimator(128)(torch.zeros(1, 128, 28, 28))
+    with pytest.raises(HifihrError):
+        PerceptualLoss()(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32))
     args = options.baseline_config2_args(train_batch=2)
     outs = {"joints": torch.zeros(2, 21, 3), "mano_verts": torch.zeros(2, 778, 3), "shape_params": torch.zeros(2, 10),
             "pose_params": torch.zeros(2, 48), "mano_faces": torch.zeros(2, 4, 3, dtype=torch.int16)}
     ex = {"joints": torch.zeros(2, 21, 3), "verts": torch.zeros(2, 778, 3)}
     with pytest.raises(HifihrError):
-        LossFunction(fused=True)(ex, outs, ["joint_3d", "vert_3d", "mshape", "mpose"], "FreiHand", args)
+        LossFunction()(ex, outs, ["joint_3d", "vert_3d", "mshape", "mpose"], "FreiHand", args)
+
+
+def test_oracle_is_independent_of_the_product():
+    """Nothing under oracle/ imports hifihr_amd (the checker must not share code with what it checks), and the one data
+    definition both sides carry -- the declared NIMBLE texture stand-in basis -- holds the same numbers."""
+    import ast
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    for fn in sorted(os.listdir(root)):
+        if not fn.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(root, fn)).read())
+        for node in ast.walk(tree):
+            mods = []
+            if isinstance(node, ast.Import):
+                mods = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                mods = [node.module or ""]
+            assert not any(m.split(".")[0] == "hifihr_amd" for m in mods), (fn, mods)
+    from hifihr_amd.models import texture_stand_in_basis as mine
+    from oracle.model_oracle import texture_stand_in_basis as theirs
+    assert torch.equal(mine(10), theirs(10))
 
 
 def test_efficientnet_b3_mirror_vs_reference(golden_dir):
-    """hifihr_amd.effnet.EfficientNetB3 (torch path) reproduces the reference's EfficientNet-b3 extract_features
-    (train mode, drop-connect under the same seed) forward and backward from name-seeded weights."""
+    """The oracle's EfficientNet-b3 restatement reproduces the reference's extract_features (train mode, drop-connect under
+    the same seed) forward and backward from name-seeded weights; the product's block table matches SURVEY Appendix A."""
     from seeded_init import seeded_state_dict
-    from hifihr_amd.effnet import EfficientNetB3, b3_block_table
+    from hifihr_amd.effnet import b3_block_table
+    from oracle.torch_modules import EfficientNetB3Ref
     g = np.load(os.path.join(golden_dir, "effnet_b3_small.npz"))
     tbl = b3_block_table()
     assert [t[4] for t in tbl][:6] == [24, 24, 32, 32, 32, 48] and tbl[-1][4] == 384 and len(tbl) == 26   # SURVEY Appendix A
-    net = EfficientNetB3("aten")
+    net = EfficientNetB3Ref()
     assert sum(p.numel() for p in net.parameters()) == int(g["n_params"])
     net.load_state_dict(seeded_state_dict(net))
     net.train()
@@ -130,25 +166,29 @@ def test_perceptual_loss_layout_and_loss_term():
                                                            (10, "conv"), (12, "conv"), (14, "conv")]
     assert [(ci, co) for _, k, ci, co in lay if k == "conv"] == [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256)]
     assert lay[-1][1] == "conv"                               # features[:15] ends on conv3_3 WITHOUT its ReLU
-    pl = PerceptualLoss(impl="torch", seed=1)
+    from oracle.torch_modules import PerceptualLossRef
+    pl = PerceptualLoss(seed=1)                                # product module: parameters / names / loader (its forward needs a GPU)
     assert sum(p.numel() for p in pl.parameters()) == 1_735_488 and not any(p.requires_grad for p in pl.parameters())
     sd = {"features." + k: v + 0.01 for k, v in pl.model.state_dict().items()}
     sd["classifier.0.weight"] = torch.zeros(1)                # whole-model state dicts carry more than the features
-    pl2 = PerceptualLoss(impl="torch", seed=2)
+    pl2 = PerceptualLoss(seed=2)
     pl2.load_vgg19_features(sd)
     assert torch.equal(pl2.model[14].bias, pl.model[14].bias + 0.01)
+    ref = PerceptualLossRef(seed=1)                            # the torch restatement draws the same seeded weights, same names
+    assert list(ref.model.state_dict().keys()) == list(pl.model.state_dict().keys())
+    for (k, a), (_, b) in zip(ref.model.state_dict().items(), pl.model.state_dict().items()):
+        assert torch.equal(a, b), k
     gen = torch.Generator().manual_seed(0)
     imgs, re_img = torch.rand(2, 3, 32, 32, generator=gen), torch.rand(2, 3, 32, 32, generator=gen)
     seg = (torch.rand(2, 32, 32, generator=gen) > 0.5).long()
     args = SimpleNamespace(lambda_percep=0.5, base_loss_fn="L2")
-    dic = L.LossFunction(perceptual=pl, ssim_fn=L.ssim_torch, fused=False)({"imgs": imgs, "segms_gt": seg}, {"re_img": re_img},
-                                                                             ["perceptual"], "FreiHand", args)
+    dic = LO.LossFunctionRef(perceptual=ref)({"imgs": imgs, "segms_gt": seg}, {"re_img": re_img}, ["perceptual"], "FreiHand", args)
     s = seg.unsqueeze(1)
     norm = lambda t: (t - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
-    want = 0.5 * torch.nn.functional.mse_loss(pl.model(norm(re_img * s + imgs * (1 - s))), pl.model(norm(imgs)))
+    want = 0.5 * torch.nn.functional.mse_loss(ref.model(norm(re_img * s + imgs * (1 - s))), ref.model(norm(imgs)))
     assert abs(dic["perceptual"].item() - want.item()) <= 1e-7
     # identical inputs: exactly zero
-    assert pl(imgs, imgs).item() == 0.0
+    assert ref(imgs, imgs).item() == 0.0
 
 
 def test_data_dic_ho3d_branch_known_answers():

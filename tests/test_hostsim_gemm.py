@@ -17,3 +17,17 @@ def test_bgemm_nt(hostsim_lib, M, N, K, batch):
 @pytest.mark.parametrize("M,N,T,batch", [(128, 128, 64, 1), (64, 128, 98, 2), (128, 64, 40, 1), (64, 64, 33, 2), (256, 128, 320, 1), (64, 64, 777, 1)])
 def test_bgemm_tn(hostsim_lib, M, N, T, batch):
     kc.bgemm_tn_case(hostsim_lib, "cpu", M, N, T, batch, seed=M + T)
+
+
+@pytest.mark.parametrize("ws", [0, 1, 2, 4])
+def test_bgemm_wave_specialised_forms(hostsim_lib, ws, monkeypatch):
+    """128x128 tiles forced (the shape heuristic picks them only for long reductions): the 4-wave kernel (ws = 0) and the
+    wave-specialised one with 1 / 2 / 4 loader waves, ragged M, ragged T, several slabs."""
+    monkeypatch.setenv("HIFIHR_GEMM_NT_TILE", "128128")
+    monkeypatch.setenv("HIFIHR_GEMM_TN_TILE", "128128")
+    monkeypatch.setenv("HIFIHR_GEMM_WS", str(ws))
+    kc.bgemm_case(hostsim_lib, "cpu", 200, 128, 160, 2, seed=ws)
+    kc.bgemm_case(hostsim_lib, "cpu", 128, 256, 32, 1, seed=ws + 10)
+    kc.bgemm_tn_case(hostsim_lib, "cpu", 128, 128, 300, 2, seed=ws + 20)
+    monkeypatch.setenv("HIFIHR_GEMM_TN_PARTS", "3")
+    assert kc.bgemm_tn_case(hostsim_lib, "cpu", 128, 256, 32 * 9 + 5, 1, seed=ws + 30) == 3

@@ -12,6 +12,9 @@ output vectors it writes are committed.  What is imported from the reference, un
   utils/handutils.py          get_affine_transform, transform_img  -> data_path.npz
   (from source, see _extract_functions / _extract_defs: loss helpers, align_w_scale, HO3D2Frei / Frei2HO3D, and the
    HandEncoder / LightEstimator / MMPool classes for their state-dict names)
+  losses.py                   LossFunction.__call__ (:226-453) + utils/perceptual_loss.py PerceptualLoss, from source
+                              (torchvision's VGG19 replaced by a seeded VGG19-shaped stack)        -> loss_dict.npz
+  models_res_nimble.py        the resolve / re_sil / maskRGBs lines (:209-220) and get_ndc_fx_fy_cx_cy (:228-235) -> model_tail.npz
 
 Stand-ins are installed ONLY for bookkeeping modules the container lacks (chumpy pickle classes,
 pytorch3d.structures.Meshes container, cv2) and for the chumpy-based table loader
@@ -33,6 +36,7 @@ OUT = os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, REPO)
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(REPO, "tools"))
+sys.path.insert(0, os.path.join(REPO, "tests"))
 
 from hifihr_amd.mano_tables import load_mano_pkl, synthetic_mano_tables  # noqa: E402
 
@@ -225,6 +229,8 @@ def main():
     gen_state_dict_names()
     gen_data_path()
     gen_eval()
+    gen_loss_dict()
+    gen_model_tail()
 
 
 # ---- loss helpers: the reference functions cannot be imported (module-level pytorch3d / torchvision imports in
@@ -365,11 +371,136 @@ def gen_eval():
     print("eval ok", mpjpe, mpvpe)
 
 
+def _vgg19_features_seeded(seed=0):
+    """A torchvision-vgg19().features-shaped nn.Sequential with torchvision's own initialisation (kaiming_normal fan_out, zero bias)
+    drawn from a seeded generator in layer order: stands in for the downloaded weights, which do not exist offline."""
+    from torch import nn
+    cfg = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M")
+    gen = torch.Generator().manual_seed(seed)
+    layers, cin = [], 3
+    for v in cfg:
+        if v == "M":
+            layers.append(nn.MaxPool2d(2, 2))
+        else:
+            conv = nn.Conv2d(cin, v, 3, 1, 1)
+            with torch.no_grad():
+                w = torch.empty(v, cin, 3, 3)
+                nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu", generator=gen)
+                conv.weight.copy_(w)
+                conv.bias.zero_()
+            layers += [conv, nn.ReLU(inplace=False)]
+            cin = v
+    return nn.Sequential(*layers)
+
+
+def reference_loss_function():
+    """The reference's OWN `LossFunction` (losses.py:226-453) and `PerceptualLoss` (utils/perceptual_loss.py), executed from
+    source.  Stand-ins only for what the container lacks: torchvision (vgg19 -> the seeded stack above, transforms.Normalize ->
+    (x - mean) / std) and `.cuda()` (identity on this CPU-only box)."""
+    import torch.nn as nn
+    import torch.nn.functional as torch_f
+    import utils.pytorch_ssim as pytorch_ssim
+    tv = types.ModuleType("torchvision")
+    tv.models = types.ModuleType("torchvision.models")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+
+    class _Weights:
+        DEFAULT = None
+
+    class _VGG:
+        def __init__(self):
+            self.features = _vgg19_features_seeded(0)
+
+    class _Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(1, 3, 1, 1), torch.tensor(std).view(1, 3, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
+
+    tv.models.vgg19 = lambda weights=None: _VGG()
+    tv.models.VGG19_Weights = _Weights
+    tv.transforms.Normalize = _Normalize
+    nn.Module.cuda = lambda self, *a, **k: self                 # build container only (no GPU): the reference calls .cuda() at init
+    ns = {"torch": torch, "nn": nn, "F": torch_f, "torchvision": tv, "transforms": tv.transforms}
+    _extract_defs(os.path.join(REF, "utils", "perceptual_loss.py"), {"PerceptualLoss"}, ns)
+    lu = _extract_functions(os.path.join(REF, "utils", "losses_util.py"), {"bone_direction_loss", "edge_length_loss", "IOU", "iou"})
+    ns2 = {"torch": torch, "nn": nn, "torch_f": torch_f, "pytorch_ssim": pytorch_ssim, "PerceptualLoss": ns["PerceptualLoss"],
+           "bone_direction_loss": lu["bone_direction_loss"], "edge_length_loss": lu["edge_length_loss"], "iou": lu["iou"]}
+    _extract_defs(os.path.join(REF, "losses.py"), {"LossFunction"}, ns2)
+    return ns2["LossFunction"]()
+
+
+from loss_cases import loss_dict_case  # noqa: E402  (tests/loss_cases.py: the seeded inputs, shared with the tests)
+
+
+def gen_loss_dict():
+    """tests/golden/loss_dict.npz: every term the reference's LossFunction.__call__ returns for the loss lists of BASELINE
+    configs[1] (cfg2, L2 base loss), configs[2] (cfg3 + scale / mscale / iou) and configs[4] (ho3d + texture_con), plus
+    d(sum of the selected terms)/d(re_img, joints, mano_verts, pose_params) for the first list."""
+    lf = reference_loss_function()
+    out = {}
+    for name in ("cfg2", "cfg3", "ho3d"):
+        args, ex, o, dat = loss_dict_case(name)
+        leaves = {}
+        if name != "cfg3":
+            for k in ("re_img", "joints", "mano_verts", "pose_params", "shape_params"):
+                o[k] = o[k].clone().requires_grad_(True)
+                leaves[k] = o[k]
+        d = lf(ex, o, args.losses, dat, args)
+        for k, v in d.items():
+            out[f"{name}/{k}"] = np.float64(v.detach().double().item())
+        if leaves:
+            total = sum(d[k] for k in args.losses if k in d)
+            total.backward()
+            for k, t in leaves.items():
+                if t.grad is not None:
+                    out[f"{name}/grad/{k}"] = t.grad.numpy()
+        out[f"{name}/keys"] = np.array(sorted(d.keys()))
+        print("loss_dict", name, {k: float(v) for k, v in d.items()})
+    np.savez_compressed(os.path.join(OUT, "loss_dict.npz"), **out)
+
+
+def gen_model_tail():
+    """tests/golden/model_tail.npz: the reference's resolve + output lines (models_res_nimble.py:209-220) and its
+    get_ndc_fx_fy_cx_cy (:228-235), executed from source on seeded inputs."""
+    import ast
+    import textwrap
+    import torch.nn.functional as F
+    path = os.path.join(REF, "models_res_nimble.py")
+    lines = open(path).read().split("\n")
+    body = textwrap.dedent("\n".join(lines[209:220]))             # rendered_images.permute ... outputs['maskRGBs'] = ...
+    assert "avg_pool2d" in body and "maskRGBs" in body and "permute" in body, body
+    g = torch.Generator().manual_seed(31)
+    B, H, aa = 2, 16, 3
+    rgba = torch.rand(B, H * aa, H * aa, 4, generator=g)
+    rgba[..., 3] = (torch.rand(B, H * aa, H * aa, generator=g) > 0.7).float()        # hard alpha
+    images = torch.rand(B, 3, H, H, generator=g)
+
+    class _Self:
+        aa_factor = aa
+    ns = {"rendered_images": rgba.clone(), "images": images, "self": _Self(), "F": F, "outputs": {}, "torch": torch}
+    exec(body, ns)
+    o = ns["outputs"]
+    tree = ast.parse(open(path).read())
+    fn = [n for c in tree.body if isinstance(c, ast.ClassDef) and c.name == "Model" for n in c.body
+          if isinstance(n, ast.FunctionDef) and n.name == "get_ndc_fx_fy_cx_cy"][0]
+    ns2 = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns2)
+    Ks = torch.tensor([[[520.0, 0, 118.5, 0], [0, 498.0, 101.25, 0], [0, 0, 1, 0]], [[610.0, 0, 112.0, 0], [0, 611.5, 95.0, 0], [0, 0, 1, 0]]])
+    fl, pp = ns2["get_ndc_fx_fy_cx_cy"](None, Ks)
+    np.savez_compressed(os.path.join(OUT, "model_tail.npz"), rgba=rgba.numpy(), images=images.numpy(), re_img=o["re_img"].numpy(),
+                        re_sil=o["re_sil"].numpy(), maskRGBs=o["maskRGBs"].numpy(), Ks=Ks.numpy(), focal=fl.numpy(), principal=pp.numpy())
+    print("model tail ok", float(o["re_sil"].max()))
+
+
 if __name__ == "__main__":
     only = os.environ.get("GOLDEN_ONLY")
-    if only in ("names", "data", "eval"):
+    if only in ("names", "data", "eval", "loss_dict", "model_tail"):
         os.makedirs(OUT, exist_ok=True)
-        {"names": gen_state_dict_names, "data": gen_data_path, "eval": gen_eval}[only]()
+        install_standins()
+        {"names": gen_state_dict_names, "data": gen_data_path, "eval": gen_eval, "loss_dict": gen_loss_dict,
+         "model_tail": gen_model_tail}[only]()
     elif os.environ.get("GOLDEN_ONLY") == "losses":
         os.makedirs(OUT, exist_ok=True)
         gen_losses()
