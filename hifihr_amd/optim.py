@@ -75,19 +75,38 @@ class FusedAdam(torch.optim.Optimizer):
         self._dyn = None
         self._dyn_host = None
 
+    _RING = 32        # pinned staging slots for the per-step scalars
+
     def enable_graph_mode(self):
         self.graph_mode = True
         self._dyn = torch.zeros(2, device=self.flatp.flat.device)
-        self._dyn_host = torch.zeros(2).pin_memory() if self.flatp.flat.is_cuda else torch.zeros(2)
+        cuda = self.flatp.flat.is_cuda
+        self._dyn_host = torch.zeros(self._RING, 2).pin_memory() if cuda else torch.zeros(self._RING, 2)
+        self._dyn_events = [None] * self._RING
+
+    def disable_graph_mode(self):
+        """Back to the eager step (scalars passed by value, step counter advanced by step())."""
+        self.graph_mode = False
 
     def prepare_step(self):
-        """Graph mode: advance the step counter and upload {lr/(1-b1^t), 1/sqrt(1-b2^t)}; call before each replay."""
+        """Graph mode: advance the step counter and upload {lr/(1-b1^t), 1/sqrt(1-b2^t)}; call before each replay.
+        The asynchronous copy reads a pinned host slot when the GPU gets to it, possibly many host steps later: every step
+        writes a slot of its own (ring), and a slot is rewritten only after the copy that read it has completed (event) --
+        a single staging buffer let a pending copy pick up a LATER step's scalars when the host ran ahead."""
         g = self.param_groups[0]
         self.step_count += 1
         b1, b2 = g["betas"]
-        self._dyn_host[0] = g["lr"] / (1.0 - b1 ** self.step_count)
-        self._dyn_host[1] = 1.0 / (1.0 - b2 ** self.step_count) ** 0.5
-        self._dyn.copy_(self._dyn_host, non_blocking=True)
+        slot = self.step_count % self._RING
+        ev = self._dyn_events[slot]
+        if ev is not None:
+            ev.synchronize()
+        self._dyn_host[slot, 0] = g["lr"] / (1.0 - b1 ** self.step_count)
+        self._dyn_host[slot, 1] = 1.0 / (1.0 - b2 ** self.step_count) ** 0.5
+        self._dyn.copy_(self._dyn_host[slot], non_blocking=True)
+        if self._dyn.is_cuda:
+            ev = self._dyn_events[slot] or torch.cuda.Event()
+            ev.record()
+            self._dyn_events[slot] = ev
 
     def zero_grad(self, set_to_none: bool = False):
         self.flatp.zero_grad()

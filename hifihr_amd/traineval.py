@@ -137,34 +137,67 @@ class GraphedTrainStep:
         self.reducer = reducer
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in examples.items()}
         split = reducer is not None
+        # Warm-up and capture must leave the training state exactly as they found it (the warm-up runs real steps on one batch;
+        # a re-capture happens whenever a lambda schedule fires): parameters, Adam moments, step counter and every module buffer
+        # (batch-norm running statistics) are snapshotted here and restored below.
+        flat = optimizer.flatp
+        snap = (flat.flat.clone(), optimizer.exp_avg.clone(), optimizer.exp_avg_sq.clone(), optimizer.step_count,
+                [b.clone() for b in model.buffers()])
         if split:
             reducer.pause_hooks(True)                           # the graph must not contain (or trigger) collectives
         else:
             optimizer.enable_graph_mode()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                       # warm-up on a side stream (allocator + MIOpen/rocBLAS init)
-            for _ in range(warmup):
-                if split:
-                    forward_backward(model, loss_func, optimizer, self.static, args, dat_name)
-                    reducer.all_reduce_flat()
-                    optimizer.step()
-                else:
-                    optimizer.prepare_step()
-                    train_step(model, loss_func, optimizer, self.static, args, dat_name)
-        torch.cuda.current_stream().wait_stream(side)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                       # warm-up on a side stream (allocator / workspace growth)
+                for _ in range(warmup):
+                    if split:
+                        forward_backward(model, loss_func, optimizer, self.static, args, dat_name)
+                        reducer.all_reduce_flat()
+                        optimizer.step()
+                    else:
+                        optimizer.prepare_step()
+                        train_step(model, loss_func, optimizer, self.static, args, dat_name)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            if split:
+                # thread-local capture: the process-group watchdog thread queries events while we capture; in the default (global)
+                # mode any such call from another thread invalidates the capture
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.loss, self.loss_dic = forward_backward(model, loss_func, optimizer, self.static, args, dat_name)
+            else:
+                optimizer.prepare_step()
+                with torch.cuda.graph(self.graph):
+                    self.loss, self.loss_dic = train_step(model, loss_func, optimizer, self.static, args, dat_name)
+        except BaseException:
+            # leave the optimizer / reducer usable by the eager step (a half-enabled graph mode froze lr and bias correction)
+            if split:
+                reducer.pause_hooks(False)
+            else:
+                optimizer.disable_graph_mode()
+            self._restore(snap)
+            raise
+        self._restore(snap)
+
+    def _restore(self, snap):
+        flat_w, m, v, step, bufs = snap
+        with torch.no_grad():
+            self.opt.flatp.flat.copy_(flat_w)
+            self.opt.exp_avg.copy_(m)
+            self.opt.exp_avg_sq.copy_(v)
+            for b, s in zip(self.model.buffers(), bufs):
+                b.copy_(s)
+        self.opt.step_count = step
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        if split:
-            # thread-local capture: the process-group watchdog thread queries events while we capture; in the default (global)
-            # mode any such call from another thread invalidates the capture
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.loss, self.loss_dic = forward_backward(model, loss_func, optimizer, self.static, args, dat_name)
+
+    def release(self):
+        """Hand the optimizer / reducer back to the eager step (train_hrnet.py drops a stepper when a lambda schedule fires)."""
+        if self.reducer is not None:
+            self.reducer.pause_hooks(False)
         else:
-            optimizer.prepare_step()
-            with torch.cuda.graph(self.graph):
-                self.loss, self.loss_dic = train_step(model, loss_func, optimizer, self.static, args, dat_name)
-            optimizer.step_count -= 1            # capturing records the step without executing it
+            self.opt.disable_graph_mode()
 
     def load_batch(self, examples):
         for k, v in examples.items():

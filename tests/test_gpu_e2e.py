@@ -163,22 +163,71 @@ def test_graphed_step_matches_eager_step():
         tables, args, model, ref, ex, ex_cpu = _setup(B)
         model2 = Model(True, torch.device("cuda"), False, "mano", False, "res18", mano_tables=tables).cuda().train()
         model2.load_state_dict(model.state_dict())
-        # eager: 4 steps (3 = the warm-up steps GraphedTrainStep runs before capture, + 1)
         flat = FlatParams(model); opt = FusedAdam(flat, lr=1e-6)     # tiny lr: isolates the graph mechanics from Adam's sign noise
-        for _ in range(4):
-            loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
         flat2 = FlatParams(model2); opt2 = FusedAdam(flat2, lr=1e-6)
+        before = flat2.flat.clone()
+        rm_before = model2.base_encoder.encoder1.model.bn1.running_mean.clone()
         g = GraphedTrainStep(model2, LossFunction(), opt2, ex, args, warmup=3)
-        loss_g, _ = g()
         torch.cuda.synchronize()
-        assert abs(float(loss_e) - float(loss_g)) <= 2e-4 * max(1.0, abs(float(loss_e))), (float(loss_e), float(loss_g))
+        # warm-up + capture are free of side effects: weights, Adam state, step counter, batch-norm running statistics
+        assert torch.equal(flat2.flat, before) and opt2.step_count == 0 and float(opt2.exp_avg.abs().max()) == 0.0
+        assert torch.equal(model2.base_encoder.encoder1.model.bn1.running_mean, rm_before)
+        for _ in range(2):
+            loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
+            loss_g, _ = g()
+            torch.cuda.synchronize()
+            assert abs(float(loss_e) - float(loss_g)) <= 2e-4 * max(1.0, abs(float(loss_e))), (float(loss_e), float(loss_g))
         # Adam normalises every gradient to ~+-lr per step, so weights whose gradient is rounding noise (float atomics
         # order) may move in opposite directions: bound = 2 * lr * steps for those, tiny on average
         d = (flat.flat - flat2.flat).abs()
-        assert float(d.max()) <= 8.01e-6 and float(d.mean()) <= 2e-7, (float(d.max()), float(d.mean()))
-        loss_g2, _ = g()                         # replays keep training
+        assert float(d.max()) <= 4.01e-6 and float(d.mean()) <= 2e-7, (float(d.max()), float(d.mean()))
+        assert opt2.step_count == 2 and opt.step_count == 2
+    finally:
+        torch.cuda.set_stream(prev)
+
+
+def test_graph_replay_survives_an_evaluation_pass_in_between():
+    """train (graph) -> evaluate (model.eval(), a LARGER batch) -> train (graph) == the same sequence on the eager step.
+    An evaluation forward must not disturb what the captured graph holds: it requests no batch-norm statistics buffer (round 1
+    leaked a dirty one into the pool whose address the graph had baked in) and scratch that grows keeps the old tensor alive."""
+    from hifihr_amd import synth
+    from hifihr_amd.losses import LossFunction
+    from hifihr_amd.models import Model
+    from hifihr_amd.optim import FlatParams, FusedAdam
+    from hifihr_amd.traineval import GraphedTrainStep, data_dic, train_step
+    prev = torch.cuda.current_stream()
+    torch.cuda.set_stream(torch.cuda.Stream())
+    try:
+        B = 8
+        tables, args, model, ref, ex, ex_cpu = _setup(B)
+        model2 = Model(True, torch.device("cuda"), False, "mano", False, "res18", mano_tables=tables).cuda().train()
+        model2.load_state_dict(model.state_dict())
+        big = data_dic(synth.make_batch(model.hand_layer.handle, model.renderer_p3d, 2 * B, first_index=100, device=torch.device("cuda")),
+                       "FreiHand", "training", args, device=torch.device("cuda"))
+        flat = FlatParams(model); opt = FusedAdam(flat, lr=1e-6)
+        flat2 = FlatParams(model2); opt2 = FusedAdam(flat2, lr=1e-6)
+        g = GraphedTrainStep(model2, LossFunction(), opt2, ex, args)
+
+        def evaluate(m):
+            m.eval()
+            with torch.no_grad():
+                root = big["joints"][:, args.ROOT, :].unsqueeze(1)
+                out = m("FreiHand", False, big["imgs"], Ks=big["Ps"], root_xyz=root)
+            m.train()
+            return out["joints"]
+        for rnd in range(2):
+            loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
+            loss_g, _ = g()
+            torch.cuda.synchronize()
+            assert abs(float(loss_e) - float(loss_g)) <= 2e-4 * max(1.0, abs(float(loss_e))), (rnd, float(loss_e), float(loss_g))
+            je, jg = evaluate(model), evaluate(model2)
+            assert float((je - jg).abs().max()) <= 1e-4, float((je - jg).abs().max())
+        loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
+        loss_g, _ = g()
         torch.cuda.synchronize()
-        assert np.isfinite(float(loss_g2)) and opt2.step_count == 5
+        assert abs(float(loss_e) - float(loss_g)) <= 2e-4 * max(1.0, abs(float(loss_e))), (float(loss_e), float(loss_g))
+        d = (flat.flat - flat2.flat).abs()
+        assert float(d.max()) <= 6.01e-6 and float(d.mean()) <= 3e-7, (float(d.max()), float(d.mean()))
     finally:
         torch.cuda.set_stream(prev)
 

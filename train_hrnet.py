@@ -159,6 +159,7 @@ def main(argv=None):
         options.update_lambdas_for_epoch(args, epoch + current_epoch)
         lam_key = (args.lambda_pose, args.lambda_j2d_gt, args.lambda_shape, args.lambda_tex_reg)
         if stepper is not None and lam_key != stepper_key:
+            stepper.release()
             stepper = None                        # the loss weights are kernel arguments baked into the captured graph: re-capture
         perm = torch.randperm(cache.n, generator=gen)
         per_step = B * world
@@ -166,12 +167,21 @@ def main(argv=None):
             idx = perm[lo + rank * B: lo + (rank + 1) * B]
             ex = data_dic(cache.batch(idx, generator=rot_gen), "FreiHand", "training", args, device=device)
             if cli.graph and stepper is None:
+                ok = 1
                 try:
                     stepper = GraphedTrainStep(model, loss_func, opt, ex, args, reducer=reducer if world > 1 else None)
                     stepper_key = lam_key
-                except Exception as e:            # noqa: BLE001  -- report and continue eagerly
+                except Exception as e:            # noqa: BLE001  -- report and continue eagerly (GraphedTrainStep restored the state)
                     say(f"[train_hrnet] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
-                    cli.graph = 0
+                    ok = 0
+                if world > 1:                     # the two step forms issue their bucket all-reduces in different orders: all ranks
+                    flag = torch.tensor([ok], device=device, dtype=torch.int32)       # must take the same one
+                    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                    ok = int(flag.item())
+                if not ok:
+                    if stepper is not None:
+                        stepper.release()
+                    stepper, cli.graph = None, 0
             if stepper is not None:
                 stepper.load_batch(ex)
                 loss, dic = stepper()
