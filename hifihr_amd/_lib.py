@@ -134,7 +134,10 @@ class HifihrLib:
         c.hifihr_wino_wgrad_gemm.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_dw_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_weight_transpose.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
-        c.hifihr_bgemm_nt.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
+        c.hifihr_bgemm_nt.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_bgemm_nt_workspace_bytes.argtypes = [c_int] * 4
+        c.hifihr_bgemm_nt_workspace_bytes.restype = c_size_t
+        c.hifihr_bgemm_describe.argtypes = [c_int] * 4 + [ctypes.c_char_p, c_int]
         c.hifihr_bgemm_tn_parts.argtypes = [c_int] * 4
         c.hifihr_bgemm_tn.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_wgrad_parts.argtypes = [c_int] * 5
@@ -358,8 +361,16 @@ class HifihrLib:
     def wino_dw_transform(self, dU, dw_acc, K, C, clear=True):
         self.check(self.c.hifihr_wino_dw_transform(_fp(dU), _fp(dw_acc), K, C, int(bool(clear)), _stream_of(dU)), "hifihr_wino_dw_transform")
 
-    def bgemm_nt(self, A, B, C, M, N, K, batch):
-        self.check(self.c.hifihr_bgemm_nt(_fp(A), _fp(B), _fp(C), M, N, K, batch, _stream_of(A)), "hifihr_bgemm_nt")
+    def bgemm_nt_workspace_bytes(self, M, N, K, batch):
+        return int(self.c.hifihr_bgemm_nt_workspace_bytes(M, N, K, batch))
+
+    def bgemm_nt(self, A, B, C, M, N, K, batch, ws=None):
+        self.check(self.c.hifihr_bgemm_nt(_fp(A), _fp(B), _fp(C), M, N, K, batch, *self._ws(ws), _stream_of(A)), "hifihr_bgemm_nt")
+
+    def bgemm_describe(self, tn, M, N, K):
+        buf = ctypes.create_string_buffer(96)
+        self.check(self.c.hifihr_bgemm_describe(int(bool(tn)), M, N, K, buf, 96), "hifihr_bgemm_describe")
+        return buf.value.decode()
 
     def bgemm_tn_parts(self, M, N, T, batch):
         return int(self.c.hifihr_bgemm_tn_parts(M, N, T, batch))

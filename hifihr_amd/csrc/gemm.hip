@@ -24,6 +24,7 @@
 // indexes the CONTIGUOUS output dimension n is fed as MFMA "A": every lane then owns 4 consecutive n and stores them as one float4.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "hifihr_internal.h"
@@ -294,7 +295,11 @@ __global__ __launch_bounds__(256) void bgemm_tn_kernel(BgemmArgs a) {
 #define HIFIHR_WAIT_VM(n) ((void)0)
 #define HIFIHR_WAIT_LGKM0() ((void)0)
 #define HIFIHR_TOUCH(x) ((void)0)
+// the emulator runs the lanes of a wave one after the other between rendezvous points: a wave-level rendezvous where the hardware's
+// lockstep execution is relied on (all lanes have stored before lane 0 raises a flag; all lanes have polled before it is lowered)
+#define HIFIHR_WAVE_SYNC() ((void)__ballot(1))
 #else
+#define HIFIHR_WAVE_SYNC() ((void)0)
 #define HIFIHR_TOUCH(x) asm volatile("" : "+v"(x))
 #define HIFIHR_RAW_BARRIER()                     \
   do {                                           \
@@ -532,6 +537,232 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void bgemm_ws_kernel(BgemmArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent, balanced NT form (forward / backward-data products: 4-16 chunks per tile).
+// Measured on MI355X (tools/gemm_stamp.py, round 2) on the 512-channel product: a tile's main loop is 76 600 cycles, its first
+// loads and its store tail 13 300 more (15 %), and 832 tiles on 256 CUs leave the last quarter-round mostly idle (3.25 rounds):
+// bgemm_ws_kernel reaches 0.58 of the matrix peak there while the same inner loop runs at 0.75 on the long reductions of the
+// weight gradient.  Here ONE workgroup per CU (grid = CUs) walks an equal share of the (tile, chunk) sequence:
+//   * the loader waves' chunk stream runs across tile boundaries, so the first chunks of the next tile land while the MFMA waves
+//     still compute / store the current one (no per-tile load latency);
+//   * every workgroup gets ceil(tiles x chunks / CUs) chunks (stream-K): nobody idles in a last partial round.  A share starts and
+//     ends mid-tile, so a tile is split between at most TWO neighbouring workgroups (shares are at least one tile long): the one
+//     that owns the tile's TAIL (its share starts there, so it is done with it early) parks its partial sums in a slab of its own
+//     and raises a flag; the one that owns the HEAD reaches it at the END of its share, adds the slab and stores the tile.
+//     Hand-off per MFMA wave (each wave owns a 64 x 64 quarter of the tile on both sides, no workgroup barrier involved, which
+//     keeps the loader waves' barrier count untouched): plain 16-byte slab stores, s_waitcnt vmcnt(0), agent-scope release, flag
+//     store -- relaxed poll of the flag, agent-scope acquire, plain loads (cdna_hip_programming.md Guideline 16).  The consumer
+//     zeroes the flag again: the workspace is zero-initialised once and self-cleaning, like conv.hip's.
+//     No deadlock: workgroup w only ever waits for w + 1, the last one waits for nobody, and a producer writes its slab before
+//     anything else, so whatever order the dispatcher picks, the highest unfinished workgroup can always complete.
+// ------------------------------------------------------------------------------------------------
+template <int NLOAD>
+__global__ __launch_bounds__(256 + 64 * NLOAD) void bgemm_nt_sk_kernel(BgemmArgs a, float* __restrict__ slabs, unsigned* __restrict__ flags) {
+  constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TI = 4, TJ = 4;
+  constexpr int STAGE = (BM + BN) * 32;
+  constexpr int NPA = BM / 8, NP = (BM + BN) / 8;
+  constexpr int PL = NP / NLOAD;
+  static_assert(PL == 8 || PL == 16 || PL == 32, "loader split");
+  __shared__ __attribute__((aligned(1024))) float lds[4 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nch = a.K / 32;
+  const int tiles_pb = a.tiles_m * a.tiles_n;
+  const long total = (long)tiles_pb * a.batch * nch;
+  const int G = (int)gridDim.x;
+  const int per = (int)((total + G - 1) / G);
+  const int wg = xcd_remap((int)blockIdx.x, G);               // neighbouring shares (the two halves of a split tile) on one XCD
+  const long it0 = (long)wg * per;
+  const long it1 = it0 + per < total ? it0 + per : total;
+  const int n_it = (int)(it1 - it0);
+  if (n_it <= 0) return;
+  const int tile0 = (int)(it0 / nch), c0 = (int)(it0 - (long)tile0 * nch);
+
+  if (wave >= 4) {
+    // ---------------- loader ----------------
+    const int l = wave - 4;
+    unsigned goff[PL];
+    const float* __restrict__ Ap = a.A;
+    const float* __restrict__ Bp = a.B;
+    auto setup = [&](int tile) {
+      const int p = tile / tiles_pb, rem = tile - p * tiles_pb;
+      const int tn = rem / a.tiles_m, tm = rem - tn * a.tiles_m;
+      Ap = a.A + (size_t)p * a.sa; Bp = a.B + (size_t)p * a.sb;
+#pragma unroll
+      for (int i = 0; i < PL; ++i) {
+        const int q = l + NLOAD * i;
+        const bool isA = q < NPA;
+        const int row = 8 * (isA ? q : q - NPA) + (lane >> 3);
+        const int seg = (lane & 7) ^ ((row >> 1) & 7);
+        int grow = (isA ? tm * BM : tn * BN) + row;
+        const int lim = isA ? a.M : a.N;
+        grow = grow < lim ? grow : lim - 1;
+        goff[i] = (unsigned)grow * (unsigned)(isA ? a.lda : a.ldb) + seg * 4;
+      }
+    };
+    int tile = tile0, c = c0;
+    setup(tile);
+    auto issue = [&](int j) {                                  // local iteration j -> stage j & 3; advances (tile, c)
+      float* base = lds + (j & 3) * STAGE;
+#pragma unroll
+      for (int i = 0; i < PL; ++i) {
+        const int q = l + NLOAD * i;
+        const bool isA = q < NPA;
+        HIFIHR_GLDS16((isA ? Ap : Bp) + goff[i] + c * 32, base + (isA ? 256 * q : BM * 32 + 256 * (q - NPA)), lane);
+      }
+      if (++c == nch) { c = 0; ++tile; if (j + 1 < n_it) setup(tile); }
+    };
+    issue(0);
+    if (n_it > 1) issue(1);
+    if (n_it > 2) issue(2);
+    if (n_it > 2) { if (PL == 16) HIFIHR_WAIT_VM(16); else if (PL == 8) HIFIHR_WAIT_VM(8); else HIFIHR_WAIT_VM(32); }
+    else HIFIHR_WAIT_VM(0);
+    HIFIHR_RAW_BARRIER();
+    for (int j = 0; j < n_it; ++j) {
+      if (j + 3 < n_it) {
+        issue(j + 3);
+        if (PL == 16) HIFIHR_WAIT_VM(16); else if (PL == 8) HIFIHR_WAIT_VM(8); else HIFIHR_WAIT_VM(32);
+      } else {
+        HIFIHR_WAIT_VM(0);
+      }
+      HIFIHR_RAW_BARRIER();
+    }
+    return;
+  }
+
+  // ---------------- MFMA waves ----------------
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+  floatx4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float fm[2][TJ][4], fn[2][TI][4];
+  auto read_half = [&](int j, int h, int slot) {
+    const float* s = lds + (j & 3) * STAGE;
+    const int ps = ((g + 4 * h) ^ ((r >> 1) & 7)) * 4;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(s + BM * 32 + (wn * WN + 16 * i + r) * 32 + ps);
+      fn[slot][i][0] = v.x; fn[slot][i][1] = v.y; fn[slot][i][2] = v.z; fn[slot][i][3] = v.w;
+    }
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj) {
+      const float4 v = *reinterpret_cast<const float4*>(s + (wm * WM + 16 * jj + r) * 32 + ps);
+      fm[slot][jj][0] = v.x; fm[slot][jj][1] = v.y; fm[slot][jj][2] = v.z; fm[slot][jj][3] = v.w;
+    }
+  };
+  auto mfma_half = [&](int slot) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fn[slot][i][k], fm[slot][jj][k], acc[i][jj], 0, 0, 0);
+  };
+  // slab layout: [workgroup][wave][reg 0..63][lane] float4-granular: quarter-tile of this wave in its own register order
+  auto slab_of = [&](int w) { return slabs + ((size_t)w * 4 + wave) * (64 * 64); };
+
+  HIFIHR_RAW_BARRIER();
+  read_half(0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i) HIFIHR_TOUCH(fn[0][i][k]);
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj) HIFIHR_TOUCH(fm[0][jj][k]);
+  }
+  int tile = tile0, c = c0, seg_c0 = c0;
+  for (int j = 0; j < n_it; ++j) {
+    read_half(j, 1, 1);
+    HIFIHR_PIN();
+    mfma_half(0);
+    HIFIHR_PIN();
+    read_half(j + 1, 0, 0);
+    HIFIHR_PIN();
+    mfma_half(1);
+    HIFIHR_PIN();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) HIFIHR_TOUCH(fn[0][i][k]);
+#pragma unroll
+      for (int jj = 0; jj < TJ; ++jj) HIFIHR_TOUCH(fm[0][jj][k]);
+    }
+    HIFIHR_RAW_BARRIER();                                      // stage j & 3 goes back to the loader before the tile's epilogue
+    const bool tile_end = c == nch - 1;
+    if (tile_end || j == n_it - 1) {
+      if (seg_c0 > 0) {
+        // this share started inside the tile: park the partial sums for the owner of the tile's head
+        float* sl = slab_of(wg);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int jj = 0; jj < TJ; ++jj)
+            *reinterpret_cast<float4*>(sl + ((i * TJ + jj) * 64 + lane) * 4) = make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
+#if !defined(HIFIHR_HOSTSIM)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(flags + wg * 4 + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        HIFIHR_WAVE_SYNC();
+        if (lane == 0) __atomic_store_n(flags + wg * 4 + wave, 1u, __ATOMIC_SEQ_CST);
+#endif
+      } else {
+        if (!tile_end) {
+          // this share ends inside the tile: the next workgroup owns the rest and has parked it long ago
+          unsigned* fl = flags + (wg + 1) * 4 + wave;
+#if !defined(HIFIHR_HOSTSIM)
+          while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+          while (__atomic_load_n(fl, __ATOMIC_SEQ_CST) == 0u) ::hostsim::yield_now();
+          HIFIHR_WAVE_SYNC();
+#endif
+          float* sl = slab_of(wg + 1);
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TJ; ++jj) {
+              float4* q = reinterpret_cast<float4*>(sl + ((i * TJ + jj) * 64 + lane) * 4);
+              const float4 v = *q;
+              acc[i][jj][0] += v.x; acc[i][jj][1] += v.y; acc[i][jj][2] += v.z; acc[i][jj][3] += v.w;
+              *q = make_float4(0.f, 0.f, 0.f, 0.f);          // the workspace goes back all zero (it is shared with conv.hip's schedule)
+            }
+#if !defined(HIFIHR_HOSTSIM)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // clean for the next launch
+#else
+          HIFIHR_WAVE_SYNC();
+          if (lane == 0) __atomic_store_n(fl, 0u, __ATOMIC_SEQ_CST);
+#endif
+        }
+        const int p = tile / tiles_pb, rem = tile - p * tiles_pb;
+        const int tn = rem / a.tiles_m, tm = rem - tn * a.tiles_m;
+        float* __restrict__ C = a.C + (size_t)p * a.sc;
+#pragma unroll
+        for (int jj = 0; jj < TJ; ++jj) {
+          const int m = tm * BM + wm * WM + 16 * jj + r;
+          if (m < a.M) {
+            float* row = C + (size_t)m * a.ldc + tn * BN + wn * WN + 4 * g;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+              *reinterpret_cast<float4*>(row + 16 * i) = make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TJ; ++jj) acc[i][jj] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tile_end) { c = 0; ++tile; seg_c0 = 0; } else { ++c; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static int gemm_cus() {
@@ -567,10 +798,51 @@ static void tn_tile(int M, int N, int* bm, int* bn) {
   else { *bm = 64; *bn = 64; }
 }
 
+size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch);
+
+// which kernel instantiation a shape runs on, as rocprof names it (bench.py groups its roofline lines by this)
+void bgemm_describe(int tn, int M, int N, int K, char* out, int cap) {
+  int bm, bn;
+  const char* e;
+  if (tn) {
+    tn_tile(M, N, &bm, &bn);
+    if ((e = getenv("HIFIHR_GEMM_TN_TILE")) != nullptr) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (M % bm) bm = 64; if (N % bn) bn = 64; }
+  } else {
+    nt_tile(M, N, K, &bm, &bn);
+    if ((e = getenv("HIFIHR_GEMM_NT_TILE")) != nullptr) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (N % bn) bn = 64; }
+  }
+  const int nload = gemm_ws_loaders();
+  if (!tn && bm == 128 && bn == 128 && nload > 0 && bgemm_nt_workspace_bytes(M, N, K, 16) > 0) snprintf(out, cap, "bgemm_nt_sk_kernel<%d>", nload == 2 ? 2 : 4);
+  else if (bm == 128 && bn == 128 && nload > 0) snprintf(out, cap, "bgemm_ws_kernel<128, 128, %s, %d>", tn ? "true" : "false", nload == 1 ? 1 : nload == 4 ? 4 : 2);
+  else snprintf(out, cap, "%s<%d, %d>", tn ? "bgemm_tn_kernel" : "bgemm_nt_kernel", bm, bn);
+}
+
 bool bgemm_nt_supported(int M, int N, int K) { return M > 0 && K >= 32 && K % 32 == 0 && N >= 64 && N % 64 == 0; }
 bool bgemm_tn_supported(int M, int N, int T) { return T > 0 && M >= 64 && M % 64 == 0 && N >= 64 && N % 64 == 0; }
 
-hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, hipStream_t st) {
+static size_t sk_flag_bytes(int G) { return (size_t)((G + 1) * 4 * sizeof(unsigned) + 255) / 256 * 256; }
+
+// bytes of zero-initialised, self-cleaning workspace the persistent NT kernel wants for this shape (0: the shape runs on a
+// kernel that needs none)
+size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch) {
+  if (!bgemm_nt_supported(M, N, K) || batch <= 0 || gemm_ws_loaders() <= 0) return 0;
+  if (const char* e = getenv("HIFIHR_GEMM_SK")) { if (atoi(e) == 0) return 0; }
+  int bm, bn;
+  nt_tile(M, N, K, &bm, &bn);
+  if (const char* e = getenv("HIFIHR_GEMM_NT_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (N % bn) bn = 64; }
+  if (bm != 128 || bn != 128) return 0;
+  const int G = gemm_cus(), nch = K / 32;
+  const long total = (long)((M + 127) / 128) * (N / 128) * batch * nch;
+  const long per = (total + G - 1) / G;
+  if (per < nch) return 0;                    // shares shorter than a tile would split it three ways: the per-tile kernel instead
+  // measured (tools/time_gemm.py, profiles/r02_time_gemm.txt): 832 tiles x 16 chunks 141.5 -> 132.7 us, but 416 x 16 71.7 -> 76.3 and the
+  // 4- / 8-chunk tiles much worse (the tile epilogue stalls the whole workgroup, nothing else is resident on the CU to cover it):
+  // only where the per-tile kernel would run >= 3 rounds
+  if (total / nch < 3L * G) return 0;
+  return sk_flag_bytes(G) + (size_t)G * 128 * 128 * sizeof(float);
+}
+
+hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!bgemm_nt_supported(M, N, K) || batch <= 0) return hipErrorInvalidValue;
   if ((long)M * K >= (1L << 31) || (long)N * K >= (1L << 31)) return hipErrorInvalidValue;      // 32-bit element offsets
   BgemmArgs a{};
@@ -582,6 +854,15 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
   a.tiles_m = (M + bm - 1) / bm; a.tiles_n = N / bn; a.splits = 1; a.cps = K / 32; a.sc_split = 0;
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * batch));
   const int nload = gemm_ws_loaders();
+  if (nload > 0 && bm == 128 && bn == 128 && ws != nullptr && ws_bytes >= bgemm_nt_workspace_bytes(M, N, K, batch) &&
+      bgemm_nt_workspace_bytes(M, N, K, batch) > 0) {
+    const int G = gemm_cus();
+    unsigned* flags = static_cast<unsigned*>(ws);
+    float* slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + sk_flag_bytes(G));
+    if (nload == 2) hipLaunchKernelGGL((bgemm_nt_sk_kernel<2>), dim3(G), dim3(384), 0, st, a, slabs, flags);
+    else hipLaunchKernelGGL((bgemm_nt_sk_kernel<4>), dim3(G), dim3(512), 0, st, a, slabs, flags);
+    return hipGetLastError();
+  }
   if (nload > 0 && bm == 128 && bn == 128) {
     if (nload == 1) hipLaunchKernelGGL((bgemm_ws_kernel<128, 128, false, 1>), grid, dim3(320), 0, st, a);
     else if (nload == 4) hipLaunchKernelGGL((bgemm_ws_kernel<128, 128, false, 4>), grid, dim3(512), 0, st, a);

@@ -629,14 +629,24 @@ static bool use_bgemm() {
 size_t hifihr_wino_gemm_workspace_bytes(int N, int H, int W, int C, int K) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
   const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
-  if (use_bgemm() && T < (1L << 30) && hifihr::bgemm_nt_supported((int)T, K, C)) return 0;     // gemm.hip needs no workspace
+  if (use_bgemm() && T < (1L << 30) && hifihr::bgemm_nt_supported((int)T, K, C))
+    return hifihr::bgemm_nt_workspace_bytes((int)T, K, C, 16);       // the persistent (balanced) kernel's slabs + flags, or 0
   return hifihr::conv_sk_workspace_bytes(wino_gemm_geom(T, C, K));
 }
 
-int hifihr_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* stream) {
+size_t hifihr_bgemm_nt_workspace_bytes(int M, int N, int K, int batch) { return hifihr::bgemm_nt_workspace_bytes(M, N, K, batch); }
+
+int hifihr_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, void* stream) {
   if (!A || !B || !C || batch <= 0 || !hifihr::bgemm_nt_supported(M, N, K))
     return fail(HIFIHR_EINVAL, "hifihr_bgemm_nt: bad argument (K % 32 == 0, N % 64 == 0)");
-  HIP_TRY(hifihr::launch_bgemm_nt(A, B, C, M, N, K, batch, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_bgemm_nt(A, B, C, M, N, K, batch, ws, ws_bytes, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_bgemm_describe(int tn, int M, int N, int K, char* out, int cap) {
+  if (!out || cap < 8) return fail(HIFIHR_EINVAL, "hifihr_bgemm_describe: bad argument");
+  if (tn ? !hifihr::bgemm_tn_supported(M, N, K) : !hifihr::bgemm_nt_supported(M, N, K)) { out[0] = 0; return HIFIHR_OK; }
+  hifihr::bgemm_describe(tn, M, N, K, out, cap);
   return HIFIHR_OK;
 }
 
@@ -693,7 +703,7 @@ int hifihr_wino_gemm(const float* V, const float* U, float* M, int N, int H, int
     return fail(HIFIHR_EINVAL, "hifihr_wino_gemm: bad argument (C % 32 == 0, K % 4 == 0)");
   const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
   if (use_bgemm() && T < (1L << 30) && hifihr::bgemm_nt_supported((int)T, K, C)) {
-    HIP_TRY(hifihr::launch_bgemm_nt(V, U, M, (int)T, K, C, 16, (hipStream_t)stream));
+    HIP_TRY(hifihr::launch_bgemm_nt(V, U, M, (int)T, K, C, 16, ws, ws_bytes, (hipStream_t)stream));
     return HIFIHR_OK;
   }
   HIP_TRY(hifihr::launch_conv_igemm(wino_gemm_geom(T, C, K), V, U, nullptr, M, nullptr, ws, ws_bytes, (hipStream_t)stream));

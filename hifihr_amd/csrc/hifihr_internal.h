@@ -189,9 +189,11 @@ struct BgemmArgs {
   int splits, cps;             // TN: slabs of the t range, K chunks (32 rows) per slab
   long sc_split;               // element stride between slabs of C
 };
+void bgemm_describe(int tn, int M, int N, int K, char* out, int cap);
 bool bgemm_nt_supported(int M, int N, int K);
 bool bgemm_tn_supported(int M, int N, int T);
-hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, hipStream_t st);
+size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch);
+hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st);
 int bgemm_tn_parts(int M, int N, int T, int batch);
 hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st);
 hipError_t launch_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st);

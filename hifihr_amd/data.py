@@ -113,7 +113,22 @@ class FreiHandDeviceCache:
         self.n, self.H, self.W, self.device, self.max_rot = n, H, W, torch.device(device), max_rot
         self.lib = get_lib()
 
-    def batch(self, idxs, rots=None, generator=None):
+    _RING = 8          # pinned staging slots (an asynchronous copy reads its slot when the GPU gets to it)
+
+    def _stage(self, nwords):
+        if not hasattr(self, "_slots"):
+            self._slots, self._events, self._turn = [None] * self._RING, [None] * self._RING, 0
+        i = self._turn = (self._turn + 1) % self._RING
+        if self._events[i] is not None:
+            self._events[i].synchronize()            # the copy that last read this slot has completed
+        if self._slots[i] is None or self._slots[i].numel() < nwords:
+            self._slots[i] = torch.empty(nwords, dtype=torch.int32).pin_memory()
+        return i, self._slots[i][:nwords]
+
+    def batch(self, idxs, rots=None, generator=None, out_images=None, out_masks=None):
+        """One training batch assembled on the device.  Host work: the affine coefficients (numpy, stacked) and ONE pinned
+        staging buffer (indices + 16.16 warp terms + the two 3x3 matrices per sample) that goes over in ONE asynchronous copy.
+        out_images / out_masks: write the warped planes straight into caller-owned tensors (the static inputs of a captured step)."""
         idxs = torch.as_tensor(idxs, dtype=torch.int64)
         B = idxs.shape[0]
         if rots is None:                       # np.random.uniform(-max_rot, max_rot) per sample (data/dataset.py:237)
@@ -121,18 +136,29 @@ class FreiHandDeviceCache:
         rots = np.asarray(rots, dtype=np.float64)
         fixed, post, rmat = batch_affine_terms(np.asarray([self.W // 2, self.H // 2]), self.H, [self.H, self.W], rots)
         dev = self.device
-        idx_d = idxs.to(torch.int32).to(dev)
-        coef_d = torch.from_numpy(fixed).to(dev)
-        imgs = torch.empty(B, 3, self.H, self.W, device=dev)
-        masks = torch.empty(B, 3, self.H, self.W, device=dev)
+        slot, host = self._stage(25 * B)
+        hv = host.numpy()
+        hv[:B] = idxs.numpy().astype(np.int32)
+        hv[B:7 * B] = fixed.reshape(-1)
+        hv[7 * B:16 * B] = post.reshape(-1).view(np.int32)
+        hv[16 * B:25 * B] = rmat.reshape(-1).view(np.int32)
+        packed = torch.empty(25 * B, dtype=torch.int32, device=dev)
+        packed.copy_(host, non_blocking=True)
+        ev = self._events[slot] or torch.cuda.Event()
+        ev.record()
+        self._events[slot] = ev
+        idx_d, coef_d = packed[:B], packed[B:7 * B].view(B, 6)
+        post_d = packed[7 * B:16 * B].view(torch.float32).view(B, 3, 3)
+        rmat_d = packed[16 * B:25 * B].view(torch.float32).view(B, 3, 3)
+        imgs = out_images if out_images is not None else torch.empty(B, 3, self.H, self.W, device=dev)
+        masks = out_masks if out_masks is not None else torch.empty(B, 3, self.H, self.W, device=dev)
         self.lib.freihand_augment(self.images, self.masks, idx_d, coef_d, imgs, masks)
-        idx_l = idxs.to(dev)
-        post_d = torch.from_numpy(post).to(dev)
-        rmat_d = torch.from_numpy(rmat).to(dev)
+        idx_l = idx_d.long()
+        # 3x3 products as broadcast multiply-adds (a batched-GEMM call would put a vendor-library kernel on the step's path)
+        Ks = (post_d.unsqueeze(3) * self.Ks[idx_l].unsqueeze(1)).sum(2)                            # post_rot_trans . K  (:258-260)
+        rot = lambda pts: (pts.unsqueeze(2) * rmat_d.unsqueeze(1)).sum(3)                          # (R p^T)^T          (:271-275)
         return {
-            "trans_images": imgs, "trans_masks": masks,
-            "trans_Ks": torch.bmm(post_d, self.Ks[idx_l]),                                         # post_rot_trans . K  (:258-260)
-            "trans_joints": torch.bmm(self.joints[idx_l], rmat_d.transpose(1, 2)),                 # (R j^T)^T          (:271-275)
-            "trans_verts": torch.bmm(self.verts[idx_l], rmat_d.transpose(1, 2)),
+            "trans_images": imgs, "trans_masks": masks, "trans_Ks": Ks,
+            "trans_joints": rot(self.joints[idx_l]), "trans_verts": rot(self.verts[idx_l]),
             "scales": self.scales[idx_l], "idxs": idx_l,
         }

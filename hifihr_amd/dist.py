@@ -128,6 +128,25 @@ class GradReducer:
             for h in handles:
                 h.wait()
 
+    def time_buckets(self, reps: int = 5):
+        """Average microseconds of one SUM all-reduce per bucket (device events around `reps` back-to-back collectives on a scratch
+        copy of the bucket; every rank must call it).  bench.py records it next to the step time when N > 1."""
+        if self.world <= 1:
+            return []
+        out = []
+        for (_, _, e_lo, e_hi) in self.buckets:
+            buf = torch.zeros(e_hi - e_lo, device=self.flat.grad.device)
+            dist.all_reduce(buf, group=self.group)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                dist.all_reduce(buf, group=self.group)
+            e1.record()
+            torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1) * 1e3 / reps)
+        return out
+
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world

@@ -72,6 +72,7 @@ class Model(nn.Module):
             self.register_buffer("vertex_colors", torch.tensor(SKIN_TONE).repeat(778, 1), persistent=False)
             if texture_stand_in:
                 self.register_buffer("texture_basis", texture_stand_in_basis(texture_stand_in), persistent=False)
+                self.register_buffer("texture_basis_t", self.texture_basis.t().contiguous(), persistent=False)   # [778 * 3, T]: the kernel's W[O][I]
         if ifLight:
             self.light_estimator = LightEstimator(self.low_feat_dim)
 
@@ -82,19 +83,16 @@ class Model(nn.Module):
         return focal, prp
 
     def camera_from_K(self, Ks):
-        """cat([-fcl, prp]) of get_ndc_fx_fy_cx_cy as ONE affine map of the flattened intrinsics (an addmm launch instead of
-        ten elementwise ones): (fx, fy, px, py) = (-2 K00 / s, -2 K11 / s, 1 - 2 K02 / s, 1 - 2 K12 / s)."""
+        """cat([-fcl, prp]) of get_ndc_fx_fy_cx_cy as one gather + one multiply-add of the flattened intrinsics (instead of ten
+        elementwise launches; not a GEMM call either): (fx, fy, px, py) = (-2 K00 / s, -2 K11 / s, 1 - 2 K02 / s, 1 - 2 K12 / s)."""
         B, cols = Ks.shape[0], Ks.shape[2]
         key = (cols, Ks.device)
         if getattr(self, "_cam_key", None) != key:
             s = float(self.image_size)
-            w = torch.zeros(3 * cols, 4)
-            w[0 * cols + 0, 0] = -2.0 / s
-            w[1 * cols + 1, 1] = -2.0 / s
-            w[0 * cols + 2, 2] = -2.0 / s
-            w[1 * cols + 2, 3] = -2.0 / s
-            self._cam_w, self._cam_b, self._cam_key = w.to(Ks.device), torch.tensor([0.0, 0.0, 1.0, 1.0], device=Ks.device), key
-        return torch.addmm(self._cam_b, Ks.reshape(B, -1), self._cam_w)
+            self._cam_idx = torch.tensor([0, cols + 1, 2, cols + 2], device=Ks.device)
+            self._cam_scale = torch.full((4,), -2.0 / s, device=Ks.device)
+            self._cam_b, self._cam_key = torch.tensor([0.0, 0.0, 1.0, 1.0], device=Ks.device), key
+        return torch.addcmul(self._cam_b, Ks.reshape(B, -1).index_select(1, self._cam_idx), self._cam_scale)
 
     def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):
         low_features, features = self.base_encoder(images)
@@ -121,7 +119,8 @@ class Model(nn.Module):
             verts_cam = mano_verts + root_xyz
             vcolors = self.vertex_colors
             if self.ncomps[2]:                   # texture stand-in: per-sample vertex colours = skin tone + basis . texture_params
-                vcolors = torch.addmm(vcolors.reshape(1, -1), outputs["texture_params"], self.texture_basis).view(-1, 778, 3)
+                # one launch of the small-batch linear kernel (csrc/mlp.hip): [B, T] x [T, 778 * 3] + skin tone
+                vcolors = ops.affine(outputs["texture_params"], self.texture_basis_t, self.vertex_colors.reshape(-1)).view(-1, 778, 3)
             rgba, face_id = ops.render(self.renderer_p3d, verts_cam, vcolors, cam, colors, directions)
             outputs["re_img"] = rgba[:, :3]
             outputs["_rgba"] = rgba                                                      # for the fused photometric losses

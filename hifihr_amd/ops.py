@@ -550,6 +550,9 @@ class _Conv2dMFMA(torch.autograd.Function):
                         dU = torch.zeros(16 * K * C, device=gy.device, dtype=torch.float32)
                         _WINO_SCRATCH[key] = dU
 
+                if PROFILE.on:
+                    PROFILE.conv_log.append((("wino", N, H, W, C, K), "gemm-tn"))
+
                 def run_w():
                     if Yt_done is None:
                         lib.wino_dy_transform(gy, Yt, N, H, W, K)
@@ -562,6 +565,8 @@ class _Conv2dMFMA(torch.autograd.Function):
                 go = lambda: PROFILE.bracket("conv_wgrad_wino", run_w)
                 keep = (gy, v_saved, Yt, tgt)
             else:
+                if PROFILE.on:
+                    PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "wgrad"))
                 go = lambda: PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, tgt, N, H, W, C, K, R, S, stride, pad))
                 keep = (gy, x, tgt)
             if _ASYNC_WGRAD.active and dw is None:
@@ -916,6 +921,11 @@ def linear_group(members):
     n = len(members)
     acts = tuple(1 if m[2] in (True, "relu", 1) else 0 for m in members)
     return list(_LinearGroup.apply(n, acts, *[m[0] for m in members], *[m[1].weight for m in members], *[m[1].bias for m in members]))
+
+
+def affine(x, w, b):
+    """x[B, I] . w[O, I]^T + b[O] with constant (buffer) w and b, one launch of the small-batch linear kernel."""
+    return _Linear.apply(x, w, b, None, None, 0, 0.0, 0.0, None, None)
 
 
 def linear(x, lin: torch.nn.Linear, act=None, bn: torch.nn.BatchNorm1d | None = None):

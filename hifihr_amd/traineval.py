@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 def proj_func(xyz, K):
     """fh_utils.py:30-39: uv = (K xyz)_xy / (K xyz)_z."""
-    uv = torch.bmm(K, xyz.permute(0, 2, 1)).permute(0, 2, 1)
+    uv = (xyz.unsqueeze(2) * K.unsqueeze(1)).sum(3)          # [B,N,3]: row n = K . xyz_n, as broadcast multiply-adds (no BLAS call)
     return uv[:, :, :2] / uv[:, :, 2:3]
 
 

@@ -193,14 +193,20 @@ int hifihr_wino_output_transform_act(const float* m_d, float* y_d, const float* 
 /* Batched fp32 GEMM on the f32 matrix cores (csrc/gemm.hip): the plain products a Winograd layer consists of -- the GEMM half of
  * the vendor-library call behind one conv2d of the reference (network/res_encoder.py:364-373).  hifihr_wino_gemm dispatches here
  * when the shape allows (C % 32 == 0, K % 64 == 0; hifihr_wino_gemm_workspace_bytes then returns 0).
- *   hifihr_bgemm_nt: c[b][M][N] = a[b][M][K] . b[b][N][K]^T          (K % 32 == 0, N % 64 == 0, any M)
+ *   hifihr_bgemm_nt: c[b][M][N] = a[b][M][K] . b[b][N][K]^T          (K % 32 == 0, N % 64 == 0, any M); with a workspace of
+ *                    hifihr_bgemm_nt_workspace_bytes (zero-initialised once, handed back all zero) large shapes run on the persistent,
+ *                    balanced kernel (one workgroup per CU, stream-K shares), else one workgroup per tile
  *   hifihr_bgemm_tn: c_parts[z][b][M][N] = sum over the t rows of slab z of a[b][t][M] (x) b[b][t][N]   (M, N % 64 == 0, any T);
  *                    `parts` = hifihr_bgemm_tn_parts(M, N, T, batch) slabs, to be summed by the consumer (no atomics).
  * Winograd backward-weight on it: parts = hifihr_wino_wgrad_parts(N, H, W, C, K) (0: shape unsupported, use hifihr_wino_wgrad_gemm),
  *   hifihr_wino_wgrad_gemm_parts(V, Y', du_parts[parts][16][K][C])  then
  *   hifihr_wino_dw_transform_parts: dw[K][3][3][C] += G^T (sum of the slabs) G   -- nothing zero-initialised, bit-reproducible. */
-int hifihr_bgemm_nt(const float* a_d, const float* b_d, float* c_d, int M, int N, int K, int batch, void* stream);
+size_t hifihr_bgemm_nt_workspace_bytes(int M, int N, int K, int batch);
+int hifihr_bgemm_nt(const float* a_d, const float* b_d, float* c_d, int M, int N, int K, int batch,
+                    void* ws_d /* zero-initialised, self-cleaning; or NULL */, size_t ws_bytes, void* stream);
 int hifihr_bgemm_tn_parts(int M, int N, int T, int batch);
+/* Name of the kernel instantiation a shape runs on, as a profiler lists it ("" when the shape is not supported): measurement only. */
+int hifihr_bgemm_describe(int tn, int M, int N, int K_or_T, char* out, int cap);
 int hifihr_bgemm_tn(const float* a_d, const float* b_d, float* c_parts_d, int M, int N, int T, int batch, int parts, void* stream);
 int hifihr_wino_wgrad_parts(int N, int H, int W, int C, int K);
 int hifihr_wino_wgrad_gemm_parts(const float* v_d, const float* yt_d, float* du_parts_d, int N, int H, int W, int C, int K, int parts,

@@ -60,6 +60,7 @@ unsigned long long wave_ballot(bool p);
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
 int lane_id();
 void wave_gather2(float a, float b, float* A64, float* B64);      // every lane's (a, b), lane-indexed
+void yield_now();                                                 // spin loops on another workgroup's flag: let the OS run it
 }  // namespace hostsim
 
 #define threadIdx (::hostsim::cur().tid)

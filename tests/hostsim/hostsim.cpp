@@ -48,6 +48,7 @@ char* dyn_smem() { return tw->smem.data(); }
 int lane_id() { return tw->cur->lane; }
 
 static void yield() { swapcontext(&tw->cur->uc, &tw->sched); }
+void yield_now() { std::this_thread::yield(); }
 
 void syncthreads() {
   Worker* w = tw;

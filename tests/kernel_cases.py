@@ -748,10 +748,17 @@ def bgemm_case(lib, device, M, N, K, batch, seed=0):
     gen = torch.Generator().manual_seed(seed)
     a = torch.randn(batch, M, K, generator=gen); b = torch.randn(batch, N, K, generator=gen)
     c = torch.full((batch, M, N), 7.0, device=device)
-    lib.bgemm_nt(a.to(device).contiguous(), b.to(device).contiguous(), c, M, N, K, batch)
+    nb = lib.bgemm_nt_workspace_bytes(M, N, K, batch)          # > 0: the persistent, balanced kernel (zero-initialised, self-cleaning)
+    ws = torch.zeros(nb // 4, device=device) if nb else None
+    ad, bd = a.to(device).contiguous(), b.to(device).contiguous()
     ref = torch.matmul(a.double(), b.double().transpose(1, 2))
-    err = float((c.cpu().double() - ref).abs().max())
-    assert err <= 2e-6 * K ** 0.5 * float(ref.abs().max()) + 1e-6, f"bgemm_nt {M}x{N}x{K}x{batch}: {err}"
+    for rep in range(2 if nb else 1):                         # twice on the same workspace: it must come back clean
+        c.fill_(7.0)
+        lib.bgemm_nt(ad, bd, c, M, N, K, batch, ws=ws)
+        err = float((c.cpu().double() - ref).abs().max())
+        assert err <= 2e-6 * K ** 0.5 * float(ref.abs().max()) + 1e-6, f"bgemm_nt {M}x{N}x{K}x{batch} (rep {rep}, ws {nb}): {err}"
+        assert ws is None or float(ws.abs().max()) == 0.0, "workspace not handed back clean"
+    return nb
 
 
 def bgemm_tn_case(lib, device, M, N, T, batch, seed=0):

@@ -31,3 +31,17 @@ def test_bgemm_wave_specialised_forms(hostsim_lib, ws, monkeypatch):
     kc.bgemm_tn_case(hostsim_lib, "cpu", 128, 128, 300, 2, seed=ws + 20)
     monkeypatch.setenv("HIFIHR_GEMM_TN_PARTS", "3")
     assert kc.bgemm_tn_case(hostsim_lib, "cpu", 128, 256, 32 * 9 + 5, 1, seed=ws + 30) == 3
+
+
+@pytest.mark.parametrize("ws", [2, 4])
+def test_bgemm_persistent_balanced_form(hostsim_lib, ws, monkeypatch):
+    """128x128 tiles + a workspace: the persistent kernel (4 workgroups on the emulator's 4 CUs), stream-K shares that split tiles
+    between neighbouring workgroups (slab + flag hand-off), ragged M, several problems per batch; the workspace comes back clean."""
+    monkeypatch.setenv("HIFIHR_GEMM_NT_TILE", "128128")
+    monkeypatch.setenv("HIFIHR_GEMM_WS", str(ws))
+    assert kc.bgemm_case(hostsim_lib, "cpu", 300, 128, 96, 5, seed=ws) > 0          # 15 tiles x 3 chunks over 4 workgroups
+    assert kc.bgemm_case(hostsim_lib, "cpu", 128, 256, 160, 6, seed=ws + 1) > 0     # 12 tiles x 5 chunks
+    assert kc.bgemm_case(hostsim_lib, "cpu", 130, 128, 64, 7, seed=ws + 2) > 0      # 14 tiles x 2 chunks
+    assert kc.bgemm_case(hostsim_lib, "cpu", 300, 128, 96, 3, seed=ws) == 0         # 9 tiles < 3 rounds: one workgroup per tile
+    monkeypatch.setenv("HIFIHR_GEMM_SK", "0")
+    assert kc.bgemm_case(hostsim_lib, "cpu", 300, 128, 96, 5, seed=ws) == 0         # switched off

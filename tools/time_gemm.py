@@ -38,14 +38,19 @@ for H, C, K in shapes:
     t_old = timeit(lambda: lib.wino_gemm(V, U, M, B, H, H, C, K, ws=ws))
     setenv("HIFIHR_BGEMM", None)
     line = f"T={T:5d} C={C:3d} K={K:3d} {gf:5.1f} GF | bmm {t_bmm:6.1f} us ({gf / t_bmm * 1e3:5.1f} TF) | r1 kernel {t_old:6.1f} |"
-    for tile, ws_ in ((128128, 0), (128128, 1), (128128, 2), (128128, 4), (128064, 0), (64128, 0), (64064, 0)):
-        setenv("HIFIHR_GEMM_NT_TILE", tile); setenv("HIFIHR_GEMM_WS", ws_)
+    for tile, ws_, sk in ((128128, 4, 1), (128128, 2, 1), (128128, 4, 0), (128128, 2, 0), (128128, 0, 0), (64064, 0, 0)):
+        setenv("HIFIHR_GEMM_NT_TILE", tile); setenv("HIFIHR_GEMM_WS", ws_); setenv("HIFIHR_GEMM_SK", sk)
+        nbk = lib.wino_gemm_workspace_bytes(B, H, H, C, K)
+        wsk = torch.zeros(nbk // 4 + 64, device="cuda") if nbk else None
+        if sk and not nbk:
+            continue
         M.fill_(7.0)
-        lib.wino_gemm(V, U, M, B, H, H, C, K)
+        lib.wino_gemm(V, U, M, B, H, H, C, K, ws=wsk)
         err = float((M - ref).abs().max() / ref.abs().max())
-        t = timeit(lambda: lib.wino_gemm(V, U, M, B, H, H, C, K))
-        line += f" {tile // 1000}x{tile % 1000}/ws{ws_}: {t:6.1f} us ({gf / t * 1e3:5.1f} TF, err {err:.1e})"
-    setenv("HIFIHR_GEMM_NT_TILE", None); setenv("HIFIHR_GEMM_WS", None)
+        t = timeit(lambda: lib.wino_gemm(V, U, M, B, H, H, C, K, ws=wsk))
+        clean = "" if wsk is None or float(wsk.abs().max()) == 0.0 else " WS-DIRTY"
+        line += f" {tile // 1000}x{tile % 1000}/ws{ws_}/{'sk' if sk else 'tile'}: {t:6.1f} us ({gf / t * 1e3:5.1f} TF, err {err:.1e}{clean})"
+    setenv("HIFIHR_GEMM_NT_TILE", None); setenv("HIFIHR_GEMM_WS", None); setenv("HIFIHR_GEMM_SK", None)
     print(line, flush=True)
 
 print("== TN: dU[16][K][C] = Y'[16][T][K]^T . V[16][T][C]   (slabs, summed by the dw transform)")
@@ -61,9 +66,9 @@ for H, C, K in shapes:
         lib.wino_wgrad_gemm(V, Y, dU, B, H, H, C, K); lib.wino_dw_transform(dU, dw, K, C, clear=True)
     t_old = timeit(old)
     line = f"T={T:5d} C={C:3d} K={K:3d} {gf:5.1f} GF | bmm {t_bmm:6.1f} us ({gf / t_bmm * 1e3:5.1f} TF) | r1 gemm+dw {t_old:6.1f} |"
-    for tile, ws_ in ((128128, 0), (128128, 1), (128128, 2), (128128, 4), (64064, 0), (128064, 0)):
+    for tile, ws_ in ((128128, 4), (64064, 0)):
         setenv("HIFIHR_GEMM_TN_TILE", tile); setenv("HIFIHR_GEMM_WS", ws_)
-        for parts_req in (None, 1, 2, 4, 8, 16):
+        for parts_req in (None,):
             setenv("HIFIHR_GEMM_TN_PARTS", parts_req)
             parts = lib.wino_wgrad_parts(B, H, H, C, K)
             if parts_req is not None and parts != parts_req:
