@@ -137,6 +137,12 @@ class HifihrLib:
         c.hifihr_bgemm_nt.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_bgemm_nt_workspace_bytes.argtypes = [c_int] * 4
         c.hifihr_bgemm_nt_workspace_bytes.restype = c_size_t
+        c.hifihr_comm_last_error.restype = c_char_p
+        c.hifihr_comm_get_unique_id.argtypes = [c_void_p]
+        c.hifihr_comm_init.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p]
+        c.hifihr_comm_allreduce_f32.argtypes = [c_void_p, _c_float_p, c_size_t, c_void_p]
+        c.hifihr_comm_broadcast_f32.argtypes = [c_void_p, _c_float_p, c_size_t, c_int, c_void_p]
+        c.hifihr_comm_destroy.argtypes = [c_void_p]
         c.hifihr_bgemm_describe.argtypes = [c_int] * 4 + [ctypes.c_char_p, c_int]
         c.hifihr_bgemm_tn_parts.argtypes = [c_int] * 4
         c.hifihr_bgemm_tn.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
@@ -366,6 +372,31 @@ class HifihrLib:
 
     def bgemm_nt(self, A, B, C, M, N, K, batch, ws=None):
         self.check(self.c.hifihr_bgemm_nt(_fp(A), _fp(B), _fp(C), M, N, K, batch, *self._ws(ws), _stream_of(A)), "hifihr_bgemm_nt")
+
+    # ---- RCCL wrapper (csrc/comm.hip); torch.distributed drives the exchange in this package, these bindings serve tests / other hosts
+    def comm_unique_id(self) -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        if self.c.hifihr_comm_get_unique_id(buf) != 0:
+            raise HifihrError("hifihr_comm_get_unique_id: " + (self.c.hifihr_comm_last_error() or b"").decode())
+        return buf.raw
+
+    def comm_init(self, rank, world, uid: bytes):
+        h = c_void_p()
+        buf = ctypes.create_string_buffer(uid, 128)
+        if self.c.hifihr_comm_init(ctypes.byref(h), rank, world, buf) != 0:
+            raise HifihrError("hifihr_comm_init: " + (self.c.hifihr_comm_last_error() or b"").decode())
+        return h
+
+    def comm_allreduce(self, h, buf):
+        if self.c.hifihr_comm_allreduce_f32(h, _fp(buf), buf.numel(), _stream_of(buf)) != 0:
+            raise HifihrError("hifihr_comm_allreduce_f32: " + (self.c.hifihr_comm_last_error() or b"").decode())
+
+    def comm_broadcast(self, h, buf, root=0):
+        if self.c.hifihr_comm_broadcast_f32(h, _fp(buf), buf.numel(), root, _stream_of(buf)) != 0:
+            raise HifihrError("hifihr_comm_broadcast_f32: " + (self.c.hifihr_comm_last_error() or b"").decode())
+
+    def comm_destroy(self, h):
+        self.c.hifihr_comm_destroy(h)
 
     def bgemm_describe(self, tn, M, N, K):
         buf = ctypes.create_string_buffer(96)

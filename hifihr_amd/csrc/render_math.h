@@ -41,12 +41,16 @@ struct FaceXYZ {
   float x0, y0, x1, y1, x2, y2, z0, z1, z2;
 };
 
-// Face-level rejection (independent of the sample): degenerate area or a vertex at/behind the image plane.
+// Face-level rejection (independent of the sample): degenerate area, or the WHOLE face at / behind the image plane
+// (faces are kept when zmax >= 1e-8; a face that merely straddles the plane is NOT dropped here -- its
+// samples go through the per-sample test, which rejects them by pz < 0 when one vertex is behind the camera).  Round 1 dropped
+// faces with zmin < 1e-8; the two rules differ only for geometry with vertices behind the camera (never a hand at 0.3-0.8 m),
+// tests/golden/raster_known.json case "two_vertices_behind_camera" pins the chosen one.
 HIFIHR_HD bool face_is_rejected(const FaceXYZ& f) {
   const float face_area = edge_fn(f.x0, f.y0, f.x1, f.y1, f.x2, f.y2);
   const bool zero_area = (face_area <= kRasterEps) && (face_area >= -kRasterEps);
-  const float zmin = fminf(f.z0, fminf(f.z1, f.z2));
-  return zero_area || (zmin < kRasterEps);
+  const float zmax = fmaxf(f.z0, fmaxf(f.z1, f.z2));
+  return zero_area || (zmax < kRasterEps);
 }
 
 // One sample against one face.  Returns true when the sample is covered; then bary[3] are the

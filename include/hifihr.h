@@ -119,6 +119,25 @@ int hifihr_render_bwd(const hifihr_renderer_t* h, const float* verts_d, const fl
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Gradient exchange of the data-parallel step (RCCL over xGMI), for callers that do not go through torch.distributed.
+ * Replaces nn.DataParallel (reference train_hrnet.py:560): one process per GPU, the ONE collective
+ * of a step is a SUM all-reduce of the flat fp32 gradient buffer (the 1 / world scale is hifihr_adam_step's grad_scale),
+ * parameters are broadcast once at start.  librccl is resolved with dlopen at the first call (no link-time dependency).
+ *   rank 0: hifihr_comm_get_unique_id(&uid), ship the 128 bytes to the other ranks out of band;
+ *   every rank (its device current): hifihr_comm_init(&comm, rank, world, &uid); per step hifihr_comm_allreduce_f32(comm, grads_d,
+ *   n, stream) -- any number of calls on slices of the buffer (buckets) -- then hifihr_adam_step; hifihr_comm_destroy at the end.
+ * Errors: HIFIHR_EHIP with the RCCL message in hifihr_comm_last_error().
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hifihr_comm hifihr_comm;
+typedef struct { char bytes[128]; } hifihr_comm_uid;
+const char* hifihr_comm_last_error(void);
+int hifihr_comm_get_unique_id(hifihr_comm_uid* out);
+int hifihr_comm_init(hifihr_comm** out, int rank, int world, const hifihr_comm_uid* uid);
+int hifihr_comm_allreduce_f32(hifihr_comm* comm, float* buf_d /* in place */, size_t n, void* stream);
+int hifihr_comm_broadcast_f32(hifihr_comm* comm, float* buf_d, size_t n, int root, void* stream);
+int hifihr_comm_destroy(hifihr_comm* comm);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused Adam over ONE flat parameter buffer.
  * Replaces optimizer.step() of torch.optim.Adam(betas=(0.9,0.999), eps=1e-8, weight_decay=0|0.01)
  * reference train_hrnet.py:111-113, 546-551.  All four buffers are device fp32[n], 16-byte aligned.

@@ -6,7 +6,10 @@
  * (:184-186); no back-face culling, no z-clipping, clip_barycentric_coords = False).
  * PyTorch3D is a pip dependency of the reference (README.md:70-71, unpinned git HEAD, a 0.7.x snapshot);
  * its source is not under /root/reference, so this file restates its published algorithm from memory:
- * PARITY UNPINNED at the PyTorch3D boundary.  It IS the bit-exact target for the
+ * PARITY UNPINNED at the PyTorch3D boundary.  The rule set itself (sample centres, bounding-box test,
+ * strict w > 0, perspective correction with the 1e-8 clamp, nearest depth with the lower face index on ties, zero-area and
+ * behind-the-plane faces) is pinned by hand-derived known answers: tests/golden/raster_known.json, derived in exact rational
+ * arithmetic from the statement of SURVEY.md A12 by tools/make_raster_known.py (not from this file).  It IS the bit-exact target for the
  * HIP rasteriser's face indices: both are built with -ffp-contract=off and evaluate the same fp32
  * expressions in the same order.
  *
@@ -54,9 +57,10 @@ void raster_oracle(const float* verts_ndc, const int32_t* faces, int B, int V, i
           const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
           /* sample outside the face bounding box (blur_radius = 0) */
           if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
-          /* faces with a vertex at/behind the image plane, or of ~zero area, are skipped */
-          const float zmin = fminf(z0, fminf(z1, z2));
-          if (zmin < K_EPS) continue;
+          /* faces wholly at / behind the image plane (zmax < eps), or of ~zero area, are skipped; a face that
+           * straddles the plane goes on to the per-sample pz >= 0 test below */
+          const float zmax = fmaxf(z0, fmaxf(z1, z2));
+          if (zmax < K_EPS) continue;
           const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
           if (face_area <= K_EPS && face_area >= -K_EPS) continue;
           /* BarycentricCoordsForward */

@@ -195,3 +195,13 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
 }
 
 }  // namespace hostsim
+
+// The RCCL wrapper (csrc/comm.hip) has no kernels and is not emulated: its entry points exist so that the binding loads, and fail.
+extern "C" {
+const char* hifihr_comm_last_error(void) { return "hostsim: no RCCL"; }
+int hifihr_comm_get_unique_id(void*) { return -2; }
+int hifihr_comm_init(void**, int, int, const void*) { return -2; }
+int hifihr_comm_allreduce_f32(void*, float*, size_t, void*) { return -2; }
+int hifihr_comm_broadcast_f32(void*, float*, size_t, int, void*) { return -2; }
+int hifihr_comm_destroy(void*) { return 0; }
+}

@@ -16,7 +16,7 @@ rank, local_rank, world = hdist.init_process_group_from_env()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
-B = 32
+B = int(os.environ.get("DP_CHECK_BATCH", 32))
 args = options.baseline_config2_args(train_batch=B)
 torch.manual_seed(0)
 model = Model(True, dev, False, "mano", False, "res18", mano_tables=synthetic_mano_tables(0)).to(dev).train()
@@ -56,6 +56,20 @@ if rank == 0:
     print(f"eager hooks: reduced gradient vs sum of local gradients, relative max error = {err:.3e} "
           f"(run-to-run noise of one rank's own gradient: {noise:.3e} -- float atomics, amplified by train-mode batch-norm)")
 assert err < max(20 * noise, 1e-5), (err, noise)
+# ... and == what ONE process computes for the global batch of 2 B with per-replica batch-norm statistics: rank 0 runs every rank's
+# half itself (same weights, no hooks) and averages
+reducer.pause_hooks(True)
+mean_local = torch.zeros_like(flat.grad)
+for r in range(world):
+    ex_r = ex if r == rank else data_dic(synth.make_batch(model.hand_layer.handle, model.renderer_p3d, B, first_index=r * B, device=dev),
+                                       "FreiHand", "training", args, device=dev)
+    forward_backward(model, lf, opt, ex_r, args)
+    mean_local += flat.grad / world
+reducer.pause_hooks(False)
+err1 = float((mean_local - summed / world).abs().max()) / max(float(summed.abs().max()) / world, 1e-12)
+if rank == 0:
+    print(f"single process on the concatenated batch (per-replica batch-norm) vs the averaged exchanged gradient: {err1:.3e}")
+assert err1 < max(20 * noise, 1e-5), (err1, noise)
 for _ in range(3):
     train_step(model, lf, opt, ex, args, backward_hook=reducer.finish)
 params_in_sync("eager form, 3 steps")
