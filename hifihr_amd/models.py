@@ -94,8 +94,17 @@ class Model(nn.Module):
             self._cam_b, self._cam_key = torch.tensor([0.0, 0.0, 1.0, 1.0], device=Ks.device), key
         return torch.addcmul(self._cam_b, Ks.reshape(B, -1).index_select(1, self._cam_idx), self._cam_scale)
 
+    ENCODER_SIZE = 224          # the encoders' input resolution (the LightEstimator's flatten fixes it: 256 = 64 x 2 x 2 from 28 x 28 / 56 x 56)
+
+    def encode(self, images):
+        """base_encoder on the images; a render resolution other than 224 (BASELINE configs[4]) is resized first (nearest, as data_dic's
+        HO-3D branch resizes the crop, utils/traineval_util.py:157)."""
+        if images.shape[-1] != self.ENCODER_SIZE:
+            images = torch.nn.functional.interpolate(images, (self.ENCODER_SIZE, self.ENCODER_SIZE))
+        return self.base_encoder(images)
+
     def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):
-        low_features, features = self.base_encoder(images)
+        low_features, features = self.encode(images)
         return self.forward_from_features(dat_name, mode_train, images, low_features, features, Ks=Ks, root_xyz=root_xyz)
 
     def forward_from_features(self, dat_name, mode_train, images, low_features, features, Ks=None, root_xyz=None):

@@ -18,8 +18,8 @@ def make_batch(mano_handle: ops.ManoLayerHandle, renderer: ops.RendererHandle, B
     rows = []
     for i in range(B):
         g = torch.Generator().manual_seed(1234 + first_index + i)
-        f = 450.0 + 200.0 * torch.rand(1, generator=g)
-        d = 20.0 * torch.rand(2, generator=g) - 10.0
+        f = (450.0 + 200.0 * torch.rand(1, generator=g)) * (image_size / 224.0)      # focal / principal-point offset in pixels of THIS image size
+        d = (20.0 * torch.rand(2, generator=g) - 10.0) * (image_size / 224.0)
         theta = (2 * torch.rand(1, generator=g) - 1) * math.pi
         pose = torch.cat([0.5 * torch.randn(3, generator=g), 0.8 * torch.randn(45, generator=g)])
         beta = 0.5 * torch.randn(10, generator=g)
@@ -70,8 +70,9 @@ def to_ho3d_sample(sample: dict, crop: int = 448) -> dict:
     OpenGL camera (columns 2-3 of K and the joints' y / z negated), HO-3D joint order, a `crop`-pixel image crop that
     nearest-neighbour resizing brings back to 224 (crop = 2 x 224: every pixel repeated 2 x 2)."""
     from .traineval import Frei2HO3D, proj_func
-    assert crop % 224 == 0
-    r = crop // 224
+    base = sample["trans_images"].shape[-1]
+    assert crop % base == 0
+    r = crop // base
     flip = torch.tensor([1.0, -1.0, -1.0])
     K, joints = sample["trans_Ks"], sample["trans_joints"]
     return {

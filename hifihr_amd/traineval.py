@@ -37,7 +37,7 @@ def Frei2HO3D(frei_joints):
     return frei_joints[:, inv]
 
 
-def data_dic(sample, dat_name, set_name, args, device="cuda"):
+def data_dic(sample, dat_name, set_name, args, device="cuda", image_size=224):
     """utils/traineval_util.py:21-111 (FreiHand branch; training queries [trans_images, trans_Ks, trans_joints, scales,
     trans_verts, trans_masks], evaluation queries without the prefix) and :156-201 (HO3D branch: crop resized to 224 with
     nearest-neighbour `interpolate`, the OpenGL -> image convention flip of K's columns and of the joints' y / z by
@@ -54,7 +54,9 @@ def data_dic(sample, dat_name, set_name, args, device="cuda"):
         ex["idxs"] = to(sample["idxs"])
         joints, verts, masks = g("joints"), g("verts"), g("masks")
     elif dat_name == "HO3D":
-        ex["imgs"] = F.interpolate(to(sample["img_crop"]), (224, 224))
+        # the reference resizes the crop to 224 (its render resolution is hard-wired to 224); `image_size` is the build-side
+        # render resolution of BASELINE configs[4] (512): the photometric terms then run at that size, the encoder reads a 224 resize
+        ex["imgs"] = F.interpolate(to(sample["img_crop"]), (image_size, image_size))
         flip = torch.tensor([1.0, -1.0, -1.0], device=device)
         Ks = to(sample["K_crop"]) * flip.view(1, 1, 3)
         if "root_xyz" in sample:

@@ -232,8 +232,8 @@ def test_graph_replay_survives_an_evaluation_pass_in_between():
         torch.cuda.set_stream(prev)
 
 
-@pytest.mark.parametrize("config", [3, 5])
-def test_nimble_config_compositions_match_oracle_from_features(config):
+@pytest.mark.parametrize("config,B,image_size,aa", [(3, 4, 224, 3), (5, 4, 224, 3), (3, 48, 224, 3), (5, 16, 512, 1), (5, 16, 512, 3)])
+def test_nimble_config_compositions_match_oracle_from_features(config, B, image_size, aa):
     """BASELINE configs[2] / configs[4] as they run here (EfficientNet-b3, MANO + the vertex-colour texture stand-in for the
     unavailable NIMBLE layer, VGG19 perceptual loss with seeded weights; configs[4] in the HO-3D conventions): every loss
     term of the reference's JSON loss list within 1e-4 of the CPU oracle and the gradients w.r.t. the encoder features,
@@ -244,23 +244,24 @@ def test_nimble_config_compositions_match_oracle_from_features(config):
     from hifihr_amd.models import Model
     from hifihr_amd.traineval import data_dic, trans_proj_j2d
     from oracle.model_oracle import OracleModel, oracle_step
-    B = 4
+    # (3, 48, 224, 3) = BASELINE configs[2] at its real batch; (5, 16, 512, *) = configs[4] per GPU at its 512^2 render resolution
     dat = "FreiHand" if config == 3 else "HO3D"
     args = options.baseline_config3_args(train_batch=B) if config == 3 else options.baseline_config5_args(train_batch=B)
     tables = synthetic_mano_tables(0)
     torch.manual_seed(0)
     dev = torch.device("cuda")
-    model = Model(True, dev, False, "mano", False, "effb3", mano_tables=tables, texture_stand_in=10).to(dev).train()
-    ref = OracleModel(tables, pretrain="effb3", texture_stand_in=10).train()
+    model = Model(True, dev, False, "mano", False, "effb3", mano_tables=tables, texture_stand_in=10, image_size=image_size,
+                  aa_factor=aa).to(dev).train()
+    ref = OracleModel(tables, pretrain="effb3", texture_stand_in=10, image_size=image_size, aa=aa).train()
     missing, _ = ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=False)
     assert not missing, missing
-    sample = synth.make_batch(model.hand_layer.handle, model.renderer_p3d, B, first_index=40, device=dev)
+    sample = synth.make_batch(model.hand_layer.handle, model.renderer_p3d, B, first_index=40, device=dev, image_size=image_size)
     if dat == "HO3D":
-        sample = synth.to_ho3d_sample(sample)
-    ex = data_dic(sample, dat, "training", args, device=dev)
+        sample = synth.to_ho3d_sample(sample, crop=2 * image_size if image_size == 224 else image_size)
+    ex = data_dic(sample, dat, "training", args, device=dev, image_size=image_size)
     ex_cpu = {k: v.cpu() for k, v in ex.items()}
     with torch.no_grad():
-        low, feat = model.base_encoder(ex["imgs"])
+        low, feat = model.encode(ex["imgs"])
     low_g, feat_g = low.clone().requires_grad_(True), feat.clone().requires_grad_(True)
     low_c, feat_c = low.cpu().clone().requires_grad_(True), feat.cpu().clone().requires_grad_(True)
     rloss, rdic, _ = oracle_step(ref, ex_cpu, args, None, features=(low_c, feat_c), dat_name=dat)

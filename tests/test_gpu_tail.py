@@ -159,3 +159,35 @@ def test_evaluator_summary_matches_formulas(golden_dir):
 
 def test_grouped_linear_layers_equal_single_launches(lib):
     kc.linear_group_case(lib, "cuda")
+
+
+@pytest.mark.parametrize("B,in_dim,train", [(80, 1536, True), (128, 512, True), (48, 1536, True), (16, 512, False)])
+def test_hand_encoder_module_matches_torch_restatement(B, in_dim, train):
+    """The product HandEncoder (fused linear + BatchNorm1d + ReLU launches, grouped heads; B > 64 and evaluation mode: linear ->
+    csrc/bn.hip batch-norm) against oracle/torch_modules.HandEncoderRef with the same weights: every output and the gradients of the
+    first layer / a head, at the batch sizes the reference's configs use per GPU (48-128) -- no torch.nn fallback at any size."""
+    from hifihr_amd.network import HandEncoder
+    from oracle.torch_modules import HandEncoderRef
+    torch.manual_seed(B)
+    ref = HandEncoderRef("mano", [10, 48, 10], in_dim=in_dim)
+    hip = HandEncoder("mano", [10, 48, 10], in_dim=in_dim).cuda()
+    hip.load_state_dict(ref.state_dict())
+    ref.train(train); hip.train(train)
+    x = torch.randn(B, in_dim)
+    xr = x.clone().requires_grad_(True); xh = x.cuda().requires_grad_(True)
+    o_r, o_h = ref(xr), hip(xh)
+    keys = ("pose_params", "shape_params", "texture_params", "scale", "trans", "rot")
+    for k in keys:
+        a, b = o_h[k].detach().cpu(), o_r[k].detach()
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), k
+    gen = torch.Generator().manual_seed(1)
+    ws = {k: torch.randn(o_r[k].shape, generator=gen) for k in keys}
+    sum((o_r[k] * ws[k]).sum() for k in keys).backward()
+    sum((o_h[k] * ws[k].cuda()).sum() for k in keys).backward()
+    torch.cuda.synchronize()
+    for name in ("base_layers.0.weight", "base_layers.1.weight", "pose_reg.2.weight", "trans_reg.3.bias"):
+        a = dict(hip.named_parameters())[name].grad.cpu(); b = dict(ref.named_parameters())[name].grad
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-7, name
+    assert float((xh.grad.cpu() - xr.grad).abs().max()) <= 2e-3 * float(xr.grad.abs().max()) + 1e-7
+    if train:                                               # running statistics advanced identically
+        assert float((hip.base_layers[1].running_mean.cpu() - ref.base_layers[1].running_mean).abs().max()) <= 1e-5
