@@ -137,6 +137,9 @@ class HifihrLib:
         c.hifihr_bgemm_nt.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_bgemm_nt_workspace_bytes.argtypes = [c_int] * 4
         c.hifihr_bgemm_nt_workspace_bytes.restype = c_size_t
+        c.hifihr_renderer_set_light_mode.argtypes = [c_void_p, c_int]
+        c.hifihr_texture_pca_fwd.argtypes = [_c_float_p] * 3 + [c_int, c_int, c_long, _c_float_p, c_void_p]
+        c.hifihr_texture_pca_bwd.argtypes = [_c_float_p] * 2 + [c_int, c_int, c_long, _c_float_p, c_void_p]
         c.hifihr_comm_last_error.restype = c_char_p
         c.hifihr_comm_get_unique_id.argtypes = [c_void_p]
         c.hifihr_comm_init.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p]
@@ -544,6 +547,19 @@ class HifihrLib:
                                                  int(image_size), int(aa), a[1], m[1], s[1], c_float(shininess), b[1]),
                    "hifihr_renderer_create")
         return h
+
+    def texture_pca_fwd(self, coef, basis, mean, out):
+        B, K = coef.shape
+        n = basis.shape[1]
+        self.check(self.c.hifihr_texture_pca_fwd(_fp(coef), _fp(basis), _fp(mean), B, K, c_long(n), _fp(out), _stream_of(coef)), "hifihr_texture_pca_fwd")
+
+    def texture_pca_bwd(self, gtex, basis, dcoef_zeroed):
+        B, K = dcoef_zeroed.shape
+        n = basis.shape[1]
+        self.check(self.c.hifihr_texture_pca_bwd(_fp(gtex), _fp(basis), B, K, c_long(n), _fp(dcoef_zeroed), _stream_of(gtex)), "hifihr_texture_pca_bwd")
+
+    def renderer_set_light_mode(self, h, point_lights):
+        self.check(self.c.hifihr_renderer_set_light_mode(h, int(bool(point_lights))), "hifihr_renderer_set_light_mode")
 
     def renderer_destroy(self, h):
         self.c.hifihr_renderer_destroy(h)

@@ -190,7 +190,28 @@ int hifihr_renderer_create(hifihr_renderer_t** out, const int32_t* faces, int V,
     d.sc.amb[k] = ambient3[k]; d.sc.mdiff[k] = mat_diffuse3[k]; d.sc.spec[k] = specular3[k]; d.bg[k] = background3[k];
   }
   d.sc.shininess = shininess;
+  d.sc.point_light = 0;
   *out = h;
+  return HIFIHR_OK;
+}
+
+int hifihr_texture_pca_fwd(const float* coef, const float* basis, const float* mean, int B, int K, long n, float* out, void* stream) {
+  if (!coef || !basis || !out || B <= 0 || K <= 0 || K > 32 || n < 4 || n % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_texture_pca_fwd: bad argument (1 <= K <= 32, n % 4 == 0)");
+  HIP_TRY(hifihr::launch_texpca_fwd(coef, basis, mean, B, K, n, out, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_texture_pca_bwd(const float* gtex, const float* basis, int B, int K, long n, float* dcoef_zeroed, void* stream) {
+  if (!gtex || !basis || !dcoef_zeroed || B <= 0 || K <= 0 || K > 32 || n < 4 || n % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_texture_pca_bwd: bad argument (1 <= K <= 32, n % 4 == 0)");
+  HIP_TRY(hifihr::launch_texpca_bwd(gtex, basis, B, K, n, dcoef_zeroed, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_renderer_set_light_mode(hifihr_renderer_t* h, int point_lights) {
+  if (!h || point_lights < 0 || point_lights > 1) return fail(HIFIHR_EINVAL, "hifihr_renderer_set_light_mode: bad argument");
+  h->dev.sc.point_light = point_lights;
   return HIFIHR_OK;
 }
 

@@ -380,6 +380,7 @@ __global__ __launch_bounds__(kFwdThreads) void render_fwd_kernel(RenderDev r, co
   {
     const float raw[3] = {light_dir[3 * b], light_dir[3 * b + 1], light_dir[3 * b + 2]};
     normalize3(raw, Ld.l, &Ld.inv_norm);
+    if (r.sc.point_light) { Ld.l[0] = raw[0]; Ld.l[1] = raw[1]; Ld.l[2] = raw[2]; }     // PointLights: the location, as given
     Ld.lc[0] = light_color[3 * b]; Ld.lc[1] = light_color[3 * b + 1]; Ld.lc[2] = light_color[3 * b + 2];
   }
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
   LightDir Ld;
   const float raw[3] = {light_dir[3 * b], light_dir[3 * b + 1], light_dir[3 * b + 2]};
   normalize3(raw, Ld.l, &Ld.inv_norm);
+  if (r.sc.point_light) { Ld.l[0] = raw[0]; Ld.l[1] = raw[1]; Ld.l[2] = raw[2]; }
   Ld.lc[0] = light_color[3 * b]; Ld.lc[1] = light_color[3 * b + 1]; Ld.lc[2] = light_color[3 * b + 2];
   if (live) {
     const size_t plane = (size_t)H * H;

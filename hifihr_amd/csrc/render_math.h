@@ -155,10 +155,12 @@ struct ShadeConsts {       // per renderer
   float mdiff[3];          // materials.diffuse_color
   float spec[3];           // materials.specular_color * lights.specular_color
   float shininess;
+  int point_light;         // 0: DirectionalLights (models_res_nimble.py:188-190); 1: PointLights (:191-198, light_estimation = false):
+                           //    the "direction" input is the light's LOCATION and the direction of a sample is location - P
 };
 struct LightDir {          // per image
   float lc[3];             // lights.diffuse_color
-  float l[3];              // normalised direction
+  float l[3];              // normalised direction (directional), or the raw location (point)
   float inv_norm;          // 1 / max(|direction|, eps)
 };
 
@@ -180,7 +182,7 @@ HIFIHR_HD void normalize3_bwd(const float* v, const float* o, float inv, const f
 }
 
 struct ShadeTmp {
-  float nh[3], inv_n, vh[3], inv_v, cosang, r[3], d, alpha, pw, tex[3], N[3], Vd[3];
+  float nh[3], inv_n, vh[3], inv_v, cosang, r[3], d, alpha, pw, tex[3], N[3], Vd[3], lh[3], Lraw[3], inv_l;
 };
 
 // P, N, T: interpolated position, normal, texel.  rgb out.
@@ -188,11 +190,16 @@ HIFIHR_HD void shade_fwd(const ShadeConsts& c, const LightDir& L, const float* P
                          float* rgb, ShadeTmp* t) {
   float nh[3], inv_n, vh[3], inv_v;
   normalize3(N, nh, &inv_n);
-  const float cosang = nh[0] * L.l[0] + nh[1] * L.l[1] + nh[2] * L.l[2];
+  float lh[3] = {L.l[0], L.l[1], L.l[2]}, inv_l = 1.f, Lraw[3] = {0.f, 0.f, 0.f};
+  if (c.point_light) {                                // PointLights: direction = location - point, normalised per sample
+    Lraw[0] = L.l[0] - P[0]; Lraw[1] = L.l[1] - P[1]; Lraw[2] = L.l[2] - P[2];
+    normalize3(Lraw, lh, &inv_l);
+  }
+  const float cosang = nh[0] * lh[0] + nh[1] * lh[1] + nh[2] * lh[2];
   const float angle = fmaxf(cosang, 0.f);
   const float Vd[3] = {-P[0], -P[1], -P[2]};          // camera centre (0,0,0) - point
   normalize3(Vd, vh, &inv_v);
-  const float r[3] = {-L.l[0] + 2.f * (cosang * nh[0]), -L.l[1] + 2.f * (cosang * nh[1]), -L.l[2] + 2.f * (cosang * nh[2])};
+  const float r[3] = {-lh[0] + 2.f * (cosang * nh[0]), -lh[1] + 2.f * (cosang * nh[1]), -lh[2] + 2.f * (cosang * nh[2])};
   const float d = vh[0] * r[0] + vh[1] * r[1] + vh[2] * r[2];
   const float alpha = (cosang > 0.f) ? fmaxf(d, 0.f) : 0.f;
   const float pw = powf(alpha, c.shininess);
@@ -201,6 +208,8 @@ HIFIHR_HD void shade_fwd(const ShadeConsts& c, const LightDir& L, const float* P
   if (t) {
     for (int k = 0; k < 3; ++k) { t->nh[k] = nh[k]; t->vh[k] = vh[k]; t->r[k] = r[k]; t->tex[k] = T[k]; t->N[k] = N[k]; t->Vd[k] = Vd[k]; }
     t->inv_n = inv_n; t->inv_v = inv_v; t->cosang = cosang; t->d = d; t->alpha = alpha; t->pw = pw;
+    for (int k = 0; k < 3; ++k) { t->lh[k] = lh[k]; t->Lraw[k] = Lraw[k]; }
+    t->inv_l = inv_l;
   }
 }
 
@@ -229,15 +238,23 @@ HIFIHR_HD void shade_bwd(const ShadeConsts& c, const LightDir& L, const float* P
   for (int k = 0; k < 3; ++k) { g_vh[k] = g_d * t.r[k]; g_r[k] = g_d * t.vh[k]; }
   // r = -l + 2 cos nh
   g_cos += 2.f * (g_r[0] * t.nh[0] + g_r[1] * t.nh[1] + g_r[2] * t.nh[2]);
+  float g_lh[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    g_nh[k] = 2.f * t.cosang * g_r[k] + g_cos * L.l[k];
-    gl[k] += -g_r[k] + g_cos * t.nh[k];
+    g_nh[k] = 2.f * t.cosang * g_r[k] + g_cos * t.lh[k];
+    g_lh[k] = -g_r[k] + g_cos * t.nh[k];
   }
   normalize3_bwd(N, t.nh, t.inv_n, g_nh, gN);
   float gVd[3];
   normalize3_bwd(t.Vd, t.vh, t.inv_v, g_vh, gVd);
   gP[0] = -gVd[0]; gP[1] = -gVd[1]; gP[2] = -gVd[2];
+  if (c.point_light) {                                // the direction depends on the point: d(location - P)/dP = -I; the location is constant
+    float gL[3];
+    normalize3_bwd(t.Lraw, t.lh, t.inv_l, g_lh, gL);
+    gP[0] -= gL[0]; gP[1] -= gL[1]; gP[2] -= gL[2];
+  } else {
+    gl[0] += g_lh[0]; gl[1] += g_lh[1]; gl[2] += g_lh[2];
+  }
 }
 
 }  // namespace hifihr

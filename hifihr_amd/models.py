@@ -66,13 +66,18 @@ class Model(nn.Module):
         self.ifRender, self.ifLight, self.aa_factor, self.image_size = ifRender, ifLight, aa_factor, image_size
         if ifRender:
             # Materials(diffuse .8, specular .2, shininess 30) + DirectionalLights defaults (ambient .5, specular .2)
-            self.renderer_p3d = ops.RendererHandle(self.hand_layer.tables.faces, 778, image_size=image_size, aa=aa_factor,
+            if not ifLight:
+                self.register_buffer("_pl_color", torch.tensor([[0.3, 0.3, 0.3]]), persistent=False)
+                self.register_buffer("_pl_location", torch.tensor([[0.0, 1.0, 0.0]]), persistent=False)
+            self.renderer_p3d = ops.RendererHandle(self.hand_layer.tables.faces, 778, image_size=image_size, aa=aa_factor, point_lights=not ifLight,
                                                    ambient=(0.5,) * 3, mat_diffuse=(0.8,) * 3, specular=(0.04,) * 3,
                                                    shininess=30.0, background=(1.0,) * 3)
             self.register_buffer("vertex_colors", torch.tensor(SKIN_TONE).repeat(778, 1), persistent=False)
             if texture_stand_in:
                 self.register_buffer("texture_basis", texture_stand_in_basis(texture_stand_in), persistent=False)
-                self.register_buffer("texture_basis_t", self.texture_basis.t().contiguous(), persistent=False)   # [778 * 3, T]: the kernel's W[O][I]
+                pad = (-778 * 3) % 4                                                # the decode kernel moves float4
+                self.register_buffer("texture_basis_pad", torch.nn.functional.pad(self.texture_basis, (0, pad)).contiguous(), persistent=False)
+                self.register_buffer("texture_mean_pad", torch.nn.functional.pad(self.vertex_colors.reshape(-1), (0, pad)).contiguous(), persistent=False)
         if ifLight:
             self.light_estimator = LightEstimator(self.low_feat_dim)
 
@@ -123,13 +128,16 @@ class Model(nn.Module):
             if self.ifLight:
                 colors, directions = light_params["colors"], light_params["directions"]
             else:
-                raise NotImplementedError("PointLights default lighting (light_estimation=false) is not built")
+                # PointLights() defaults (models_res_nimble.py:191-198; PyTorch3D [recalled]: ambient .5, diffuse .3, specular .2,
+                # location (0, 1, 0)): constant, the renderer was created in point-light mode and reads `directions` as the location
+                colors, directions = self._pl_color.expand(images.shape[0], -1), self._pl_location.expand(images.shape[0], -1)
             # skin_meshes.offset_verts_(-pred_root); .offset_verts_(+root_xyz)   (models_res_nimble.py:203-205)
             verts_cam = mano_verts + root_xyz
             vcolors = self.vertex_colors
             if self.ncomps[2]:                   # texture stand-in: per-sample vertex colours = skin tone + basis . texture_params
-                # one launch of the small-batch linear kernel (csrc/mlp.hip): [B, T] x [T, 778 * 3] + skin tone
-                vcolors = ops.affine(outputs["texture_params"], self.texture_basis_t, self.vertex_colors.reshape(-1)).view(-1, 778, 3)
+                # the texture-PCA decode kernel (csrc/texpca.hip): skin tone + texture_params . basis, [B, T] x [T, 778 * 3 (+ 2 pad)]
+                tex = ops.texture_pca_decode(outputs["texture_params"], self.texture_basis_pad, self.texture_mean_pad)
+                vcolors = tex[:, :778 * 3].reshape(-1, 778, 3)
             rgba, face_id = ops.render(self.renderer_p3d, verts_cam, vcolors, cam, colors, directions)
             outputs["re_img"] = rgba[:, :3]
             outputs["_rgba"] = rgba                                                      # for the fused photometric losses

@@ -138,11 +138,14 @@ def mano_joints_root_relative(handle: ManoLayerHandle, verts, root_id=9):
 class RendererHandle:
     """Replaces MeshRenderer(MeshRasterizer(...), HardPhongShader(...)) of models_res_nimble.py:70-96."""
 
-    def __init__(self, faces, num_verts, image_size=224, aa=3, **consts):
+    def __init__(self, faces, num_verts, image_size=224, aa=3, point_lights=False, **consts):
         self.lib = get_lib()
         self.V, self.H, self.aa = int(num_verts), int(image_size), int(aa)
         self.F = int(len(faces))
         self.h = self.lib.renderer_create(faces, num_verts, image_size=image_size, aa=aa, **consts)
+        self.point_lights = bool(point_lights)
+        if point_lights:                      # PointLights: `light_dir` of render() is the location (models_res_nimble.py:191-198)
+            self.lib.renderer_set_light_mode(self.h, True)
 
     def workspace(self, B, device):
         # one scratch buffer per forward call (it carries the packed vertex records to that call's backward);
@@ -921,6 +924,32 @@ def linear_group(members):
     n = len(members)
     acts = tuple(1 if m[2] in (True, "relu", 1) else 0 for m in members)
     return list(_LinearGroup.apply(n, acts, *[m[0] for m in members], *[m[1].weight for m in members], *[m[1].bias for m in members]))
+
+
+class _TexturePCA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coef, basis, mean):
+        require_cuda(coef, basis)
+        coef, basis = coef.contiguous(), basis.contiguous()
+        out = torch.empty(coef.shape[0], basis.shape[1], device=coef.device)
+        PROFILE.bracket("texture_pca_fwd", lambda: get_lib().texture_pca_fwd(coef, basis, mean, out))
+        ctx.save_for_backward(basis)
+        ctx.K = coef.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        basis, = ctx.saved_tensors
+        g = g.contiguous()
+        dcoef = torch.zeros(g.shape[0], ctx.K, device=g.device)
+        PROFILE.bracket("texture_pca_bwd", lambda: get_lib().texture_pca_bwd(g, basis, dcoef))
+        return dcoef, None, None
+
+
+def texture_pca_decode(coef, basis, mean=None):
+    """mean + coef . basis: coef [B,K], basis [K,n] (constant), mean [n] -> [B,n]; n % 4 == 0.  The NIMBLE texture decode (reference
+    models_res_nimble.py:133-142 consumes its result), one HBM-bound launch per direction (csrc/texpca.hip)."""
+    return _TexturePCA.apply(coef, basis, mean)
 
 
 def affine(x, w, b):

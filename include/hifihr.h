@@ -95,6 +95,10 @@ typedef struct hifihr_renderer hifihr_renderer_t;
 int hifihr_renderer_create(hifihr_renderer_t** out, const int32_t* faces_h, int V, int F, int image_size, int aa,
                            const float* ambient3, const float* mat_diffuse3, const float* specular3, float shininess,
                            const float* background3);
+/* point_lights = 1: PointLights instead of DirectionalLights (the reference's light_estimation = false branch,
+ * models_res_nimble.py:191-198): light_dir_d[B][3] of render_fwd / bwd is then the light's LOCATION, the direction of a sample is
+ * location - point (normalised); the location gets no gradient (glight_dir_d comes back zero). */
+int hifihr_renderer_set_light_mode(hifihr_renderer_t* h, int point_lights);
 int hifihr_renderer_destroy(hifihr_renderer_t* h);
 /* bytes of scratch the caller must pass to render_fwd/bwd for batch B; the SAME buffer, untouched in between,
  * must be passed to the backward call of a forward call (it carries the packed per-vertex records). */
@@ -117,6 +121,17 @@ int hifihr_render_bwd(const hifihr_renderer_t* h, const float* verts_d, const fl
                       const float* light_dir_d, const int32_t* face_id_d, const float* grad_rgba_d, int B,
                       float* gverts_d, float* gvcolors_d, float* glight_color_d, float* glight_dir_d, void* workspace_d,
                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Texture-PCA decode (csrc/texpca.hip): tex[b][n] = mean[n] (or 0 when NULL) + sum_k coef[b][k] basis[k][n], K <= 32, n % 4 == 0.
+ * The texture half of the NIMBLE layer as the reference consumes it (models_res_nimble.py:57,133-142: texture_params [B,10] -> the
+ * hand's texture).  NIMBLE's own basis is not available: the caller supplies one (n = 778 * 3 vertex
+ * colours for the declared stand-in, n = 1024 * 1024 * 3 for a UV map).  HBM-bound: 4 n (K + 1 + B) algorithmic bytes.
+ * bwd: dcoef_zeroed_d[B][K] (ZERO on entry) += sum_n gtex[b][n] basis[k][n]   (float atomics: reproducible to rounding).
+ * ---------------------------------------------------------------------------------------------- */
+int hifihr_texture_pca_fwd(const float* coef_d, const float* basis_d, const float* mean_d /* or NULL */, int B, int K, long n,
+                           float* tex_d, void* stream);
+int hifihr_texture_pca_bwd(const float* gtex_d, const float* basis_d, int B, int K, long n, float* dcoef_zeroed_d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gradient exchange of the data-parallel step (RCCL over xGMI), for callers that do not go through torch.distributed.

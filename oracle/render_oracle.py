@@ -141,7 +141,7 @@ def _interp(attr, faces, idx, bary):
     return (bary.unsqueeze(-1) * g).sum(-2)
 
 
-def render(verts, vcolors, cam, light_color, light_dir, faces, image_size=224, aa=3, consts=ShadeConsts()):
+def render(verts, vcolors, cam, light_color, light_dir, faces, image_size=224, aa=3, consts=ShadeConsts(), point_lights=False):
     """verts [B,V,3] (view space), vcolors [B,V,3] (TexturesVertex stand-in), cam [B,4], light_color/dir [B,3],
     faces LongTensor [F,3].  -> rgba [B,4,H,H] after the aa x aa average pool, pix_to_face [B,S,S] (numpy)."""
     faces = torch.as_tensor(faces).long()
@@ -159,7 +159,10 @@ def render(verts, vcolors, cam, light_color, light_dir, faces, image_size=224, a
     md = torch.tensor(consts.mat_diffuse, dtype=dt)
     sp = torch.tensor(consts.specular, dtype=dt)
     lc = light_color.view(-1, 1, 1, 3)
-    ld = F.normalize(light_dir, p=2, dim=-1, eps=1e-6).view(-1, 1, 1, 3)
+    if point_lights:       # PointLights [recalled]: direction = location - point, normalised per sample (lighting.py PointLights.diffuse)
+        ld = F.normalize(light_dir.view(-1, 1, 1, 3) - P, p=2, dim=-1, eps=1e-6)
+    else:
+        ld = F.normalize(light_dir, p=2, dim=-1, eps=1e-6).view(-1, 1, 1, 3)
     nh = F.normalize(N, p=2, dim=-1, eps=1e-6)
     cosang = (nh * ld).sum(-1)
     diffuse = lc * F.relu(cosang)[..., None]

@@ -122,14 +122,78 @@ def make_render_inputs(tables, B, seed, image_size, z=0.6):
     return verts, vcol, cam, lc, ld
 
 
-def render_case(lib, tables, device, B, seed, image_size, aa, check_grad=True, rgb_atol=2e-5, gtol=2e-3):
+def texture_pca_case(lib, device, B, K, n, seed=0, with_mean=True):
+    """csrc/texpca.hip vs torch: tex = mean + coef . basis and d(sum(tex * w))/dcoef."""
+    gen = torch.Generator().manual_seed(seed)
+    coef = torch.randn(B, K, generator=gen); basis = torch.randn(K, n, generator=gen) * 0.1
+    mean = torch.rand(n, generator=gen) if with_mean else None
+    w = torch.randn(B, n, generator=gen)
+    cr = coef.clone().requires_grad_(True)
+    ref = cr @ basis + (mean if with_mean else 0.0)
+    (ref * w).sum().backward()
+    d = lambda t: t.to(device).contiguous() if t is not None else None
+    out = torch.full((B, n), 7.0, device=device)
+    lib.texture_pca_fwd(d(coef), d(basis), d(mean), out)
+    assert float((out.cpu() - ref.detach()).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    dc = torch.zeros(B, K, device=device)
+    lib.texture_pca_bwd(d(w), d(basis), dc)
+    assert float((dc.cpu() - cr.grad).abs().max()) <= 2e-5 * float(cr.grad.abs().max()) * max(1.0, (n / 4096) ** 0.5)
+
+
+def nimble_sized_mesh(B, seed, V=5990):
+    """A closed genus-0 mesh with the NIMBLE skin's counts (V = 5990 vertices, F = 2 V - 4 = 11976 faces; reference
+    models_res_nimble.py:135-136): a UV sphere of 499 rings x 12 segments + 2 poles, hand-sized (about 0.1 x 0.06 x 0.18 m), with a
+    seeded bumpy radial displacement per batch item so that layers of surface overlap in the image like fingers do.  Synthetic: the
+    real NIMBLE assets are not available."""
+    rings, segs = (V - 2) // 12, 12
+    assert rings * segs + 2 == V
+    gen = torch.Generator().manual_seed(seed)
+    th = (torch.arange(rings, dtype=torch.float32) + 1) / (rings + 1) * np.pi
+    ph = torch.arange(segs, dtype=torch.float32) / segs * 2 * np.pi
+    T, P = torch.meshgrid(th, ph, indexing="ij")
+    base = torch.stack([torch.sin(T) * torch.cos(P), torch.sin(T) * torch.sin(P), torch.cos(T)], -1).reshape(-1, 3)
+    base = torch.cat([torch.tensor([[0.0, 0.0, 1.0]]), base, torch.tensor([[0.0, 0.0, -1.0]])], 0)                       # [V,3]
+    faces = []
+    for j in range(segs):
+        faces.append((0, 1 + j, 1 + (j + 1) % segs))
+        last = 1 + (rings - 1) * segs
+        faces.append((V - 1, last + (j + 1) % segs, last + j))
+    for i in range(rings - 1):
+        for j in range(segs):
+            a, b = 1 + i * segs + j, 1 + i * segs + (j + 1) % segs
+            c, d = a + segs, b + segs
+            faces.append((a, c, b)); faces.append((b, c, d))
+    faces = np.asarray(faces, dtype=np.int32)
+    assert faces.shape[0] == 2 * V - 4
+    k = torch.randn(B, 6, 3, generator=gen) * 3.0
+    amp = 0.25 * torch.rand(B, 6, generator=gen)
+    bump = 1.0 + (amp.unsqueeze(1) * torch.sin(torch.einsum("vc,bkc->bvk", base, k))).sum(-1)                                # [B,V]
+    verts = base.unsqueeze(0) * bump.unsqueeze(-1) * torch.tensor([0.05, 0.03, 0.09])
+    return verts, faces
+
+
+def render_case(lib, tables, device, B, seed, image_size, aa, check_grad=True, rgb_atol=2e-5, gtol=2e-3, mesh=None, point_lights=False):
     from oracle import render_oracle as ro
     verts, vcol, cam, lc, ld = make_render_inputs(tables, B, seed, image_size)
-    faces = torch.as_tensor(tables.faces).long()
+    if point_lights:                            # PointLights defaults: diffuse .3, location (0, 1, 0) (+ a second, closer location)
+        lc = torch.full((B, 3), 0.3)
+        ld = torch.tensor([[0.0, 1.0, 0.0]]).repeat(B, 1)
+        if B > 1:
+            ld[1] = torch.tensor([0.1, -0.2, 0.3])
+    faces_np, V = tables.faces, 778
+    if mesh is not None:                        # another mesh in place of the hand: (verts [B,V,3] around the origin, faces [F,3])
+        mv, faces_np = mesh
+        V = mv.shape[1]
+        gen = torch.Generator().manual_seed(seed + 5)
+        verts = mv + verts.mean(1, keepdim=True)                    # same placements in front of the camera
+        vcol = 0.3 + 0.6 * torch.rand(B, V, 3, generator=gen)
+    faces = torch.as_tensor(faces_np).long()
     vr, cr, lcr, ldr = (t.clone().requires_grad_(True) for t in (verts, vcol, lc, ld))
-    rgba_ref, p2f_ref = ro.render(vr, cr, cam, lcr, ldr, faces, image_size=image_size, aa=aa)
+    rgba_ref, p2f_ref = ro.render(vr, cr, cam, lcr, ldr, faces, image_size=image_size, aa=aa, point_lights=point_lights)
     S = image_size * aa
-    h = lib.renderer_create(tables.faces, 778, image_size=image_size, aa=aa)
+    h = lib.renderer_create(faces_np, V, image_size=image_size, aa=aa)
+    if point_lights:
+        lib.renderer_set_light_mode(h, True)
     try:
         ws = torch.empty(lib.render_workspace_bytes(h, B), dtype=torch.uint8, device=device)
         d = lambda t: t.to(device).contiguous()
@@ -146,11 +210,15 @@ def render_case(lib, tables, device, B, seed, image_size, aa, check_grad=True, r
         gen = torch.Generator().manual_seed(seed + 1)
         w = torch.randn(B, 4, image_size, image_size, generator=gen)
         (rgba_ref * w).sum().backward()
-        gv = torch.empty(B, 778, 3, device=device); gc = torch.empty(B, 778, 3, device=device)
+        gv = torch.empty(B, V, 3, device=device); gc = torch.empty(B, V, 3, device=device)
         glc = torch.empty(B, 3, device=device); gld = torch.empty(B, 3, device=device)
         lib.render_bwd(h, dv, dcam, dlc, dld, fid, d(w), gv, gc, glc, gld, ws)
-        for name, got, ref in (("verts", gv, vr.grad), ("vcolors", gc, cr.grad), ("light_color", glc, lcr.grad),
-                               ("light_dir", gld, ldr.grad)):
+        checks = [("verts", gv, vr.grad), ("vcolors", gc, cr.grad), ("light_color", glc, lcr.grad)]
+        if point_lights:
+            assert float(gld.abs().max()) == 0.0           # the location is a constant of the default-lighting branch
+        else:
+            checks.append(("light_dir", gld, ldr.grad))
+        for name, got, ref in checks:
             ref = ref.numpy()
             scale = np.abs(ref).max() + 1e-12
             err = np.abs(got.cpu().numpy() - ref).max() / scale

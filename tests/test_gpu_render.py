@@ -21,6 +21,21 @@ def test_render_vs_oracle(lib, synth_tables, image_size, aa, B):
     kc.render_case(lib, synth_tables, "cuda", B=B, seed=20 + image_size, image_size=image_size, aa=aa, rgb_atol=1e-4)
 
 
+@pytest.mark.parametrize("image_size,aa,B", [(224, 3, 2), (512, 1, 1), (64, 3, 3)])
+def test_render_nimble_sized_mesh_vs_oracle(lib, synth_tables, image_size, aa, B):
+    """The renderer on a mesh with the NIMBLE skin's size (5990 vertices, 11976 faces: 7.8x the MANO mesh -- per-tile face lists, list
+    passes and the LDS budget all scale with it): face ids bit-exact, pixels and gradients against the oracle."""
+    mesh = kc.nimble_sized_mesh(B, seed=image_size + aa)
+    kc.render_case(lib, synth_tables, "cuda", B=B, seed=60 + image_size, image_size=image_size, aa=aa, rgb_atol=1e-4, mesh=mesh)
+
+
+@pytest.mark.parametrize("image_size,aa,B", [(224, 3, 2), (64, 1, 3)])
+def test_render_point_lights_vs_oracle(lib, synth_tables, image_size, aa, B):
+    """The light_estimation = false branch (reference models_res_nimble.py:191-198): PointLights, direction = location - point per
+    sample; pixels and the vertex / colour gradients (the direction now depends on the position) against the oracle."""
+    kc.render_case(lib, synth_tables, "cuda", B=B, seed=80 + image_size, image_size=image_size, aa=aa, rgb_atol=1e-4, point_lights=True)
+
+
 def _render(lib, h, verts, vcol, cam, lc, ld, H, aa):
     B = verts.shape[0]
     ws = torch.empty(lib.render_workspace_bytes(h, B), dtype=torch.uint8, device="cuda")

@@ -191,3 +191,9 @@ def test_hand_encoder_module_matches_torch_restatement(B, in_dim, train):
     assert float((xh.grad.cpu() - xr.grad).abs().max()) <= 2e-3 * float(xr.grad.abs().max()) + 1e-7
     if train:                                               # running statistics advanced identically
         assert float((hip.base_layers[1].running_mean.cpu() - ref.base_layers[1].running_mean).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("B,K,n", [(32, 10, 2336), (48, 10, 1024 * 1024 * 3), (16, 10, 256 * 256 * 3)])
+def test_texture_pca_decode(lib, B, K, n):
+    """csrc/texpca.hip: the stand-in's 778 x 3 vertex colours and UV-map sizes (NIMBLE's texture maps are 1024^2 [recalled])."""
+    kc.texture_pca_case(lib, "cuda", B, K, n, seed=K + B)
