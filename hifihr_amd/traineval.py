@@ -37,6 +37,14 @@ def Frei2HO3D(frei_joints):
     return frei_joints[:, inv]
 
 
+_RHD_TO_FREI = [0, 4, 3, 2, 1, 8, 7, 6, 5, 12, 11, 10, 9, 16, 15, 14, 13, 20, 19, 18, 17]       # FreiHAND joint i <- RHD joint [i]
+
+
+def RHD2Frei(rhd_joints):
+    """utils/fh_utils.py:590-602: RHD joint order (wrist, then tip -> base per finger) -> FreiHAND order, as one gather."""
+    return rhd_joints[:, _RHD_TO_FREI]
+
+
 def data_dic(sample, dat_name, set_name, args, device="cuda", image_size=224):
     """utils/traineval_util.py:21-111 (FreiHand branch; training queries [trans_images, trans_Ks, trans_joints, scales,
     trans_verts, trans_masks], evaluation queries without the prefix) and :156-201 (HO3D branch: crop resized to 224 with
@@ -65,13 +73,29 @@ def data_dic(sample, dat_name, set_name, args, device="cuda", image_size=224):
             ex["j2d_gt"] = HO3D2Frei(to(sample["uv21_crop"].float()))
         joints = HO3D2Frei(to(sample["xyz21"])) * flip.view(1, 1, 3) if "xyz21" in sample else None
         verts, masks = None, sample.get("hand_mask_crop")
+    elif dat_name == "RHD":
+        # utils/traineval_util.py:204-256: cropped image and intrinsics as loaded, 2-D / 3-D joints re-ordered RHD -> FreiHAND,
+        # keypoint_scale doubles as `scales`, visibility flags re-ordered; no vertices, no masks (the mask lines are commented out there)
+        ex["imgs"] = to(sample["img_crop"])
+        Ks = to(sample["K_crop"])
+        if "uv21_crop" in sample:
+            ex["j2d_gt"] = RHD2Frei(to(sample["uv21_crop"]))
+        joints = RHD2Frei(to(sample["xyz21"])) if "xyz21" in sample else None
+        if "keypoint_scale" in sample:
+            ex["keypoint_scale"] = to(sample["keypoint_scale"])
+            ex["scales"] = ex["keypoint_scale"]
+        if "uv_vis" in sample:
+            ex["uv_vis"] = RHD2Frei(sample["uv_vis"])
+        if "open_2dj" in sample:
+            ex["open_2dj"], ex["open_2dj_con"] = to(sample["open_2dj_crop"]), to(sample["open_2dj_con"])
+        verts, masks = None, None
     else:
-        raise NotImplementedError(f"dat_name='{dat_name}': FreiHand and HO3D are built (RHD / Obman need their datasets)")
+        raise NotImplementedError(f"dat_name='{dat_name}': FreiHand, HO3D and RHD are built (Obman / Dart need their datasets)")
     ex["Ks"] = Ks
     ex["Ps"] = torch.cat([Ks, torch.zeros_like(Ks[:, :, :1])], dim=2)       # Ks @ [I|0]
     if joints is not None:
         ex["joints"] = to(joints)
-        if dat_name == "FreiHand":
+        if dat_name == "FreiHand":                 # (the RHD branch's projected 2-D joints are commented out in the reference, :239)
             ex["j2d_gt"] = proj_func(ex["joints"], Ks)
     if verts is not None:
         ex["verts"] = to(verts)

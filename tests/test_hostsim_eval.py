@@ -1,5 +1,7 @@
 """csrc/eval.hip on the host emulator vs the reference's align_w_scale golden vectors (tests/golden/eval.npz)."""
+import numpy as np
 import pytest
+import torch
 
 import kernel_cases as kc
 
@@ -21,3 +23,23 @@ def test_ho3d_joint_maps_vs_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "eval.npz"))
     j = torch.from_numpy(g["j"])
     assert np.array_equal(HO3D2Frei(j).numpy(), g["ho3d2frei"]) and np.array_equal(Frei2HO3D(j).numpy(), g["frei2ho3d"])
+    from hifihr_amd.traineval import RHD2Frei
+    assert np.array_equal(RHD2Frei(j).numpy(), g["rhd2frei"])            # reference utils/fh_utils.py:590-602, executed from source
+
+
+def test_data_dic_rhd_branch():
+    """utils/traineval_util.py:204-256: keys, joint re-ordering, keypoint_scale -> scales, Ps = Ks [I|0]."""
+    from types import SimpleNamespace
+    from hifihr_amd.traineval import RHD2Frei, data_dic
+    gen = torch.Generator().manual_seed(3)
+    B = 3
+    sample = {"img_crop": torch.rand(B, 3, 224, 224, generator=gen), "K_crop": torch.rand(B, 3, 3, generator=gen) + 1.0,
+              "uv21_crop": 224 * torch.rand(B, 21, 2, generator=gen), "xyz21": torch.randn(B, 21, 3, generator=gen),
+              "keypoint_scale": torch.rand(B, generator=gen), "uv_vis": torch.rand(B, 21, generator=gen) > 0.3}
+    ex = data_dic(sample, "RHD", "training", SimpleNamespace(), device="cpu")
+    assert torch.equal(ex["imgs"], sample["img_crop"]) and torch.equal(ex["Ks"], sample["K_crop"])
+    assert torch.equal(ex["Ps"][:, :, :3], sample["K_crop"]) and float(ex["Ps"][:, :, 3].abs().max()) == 0.0
+    assert torch.equal(ex["joints"], RHD2Frei(sample["xyz21"])) and torch.equal(ex["j2d_gt"], RHD2Frei(sample["uv21_crop"]))
+    assert torch.equal(ex["scales"], sample["keypoint_scale"]) and torch.equal(ex["uv_vis"], RHD2Frei(sample["uv_vis"]))
+    assert ex["joints"][0, 1].tolist() == sample["xyz21"][0, 4].tolist()   # FreiHAND index-finger base <- RHD joint 4
+    assert "verts" not in ex and "segms_gt" not in ex

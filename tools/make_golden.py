@@ -347,7 +347,7 @@ def gen_eval():
     from scipy.linalg import orthogonal_procrustes
     tu = _extract_functions(os.path.join(REF, "utils", "train_utils.py"), {"align_w_scale"})
     tu["orthogonal_procrustes"] = orthogonal_procrustes
-    fh = _extract_functions(os.path.join(REF, "utils", "fh_utils.py"), {"HO3D2Frei", "Frei2HO3D"})
+    fh = _extract_functions(os.path.join(REF, "utils", "fh_utils.py"), {"HO3D2Frei", "Frei2HO3D", "RHD2Frei"})
     rng = np.random.RandomState(5)
     B = 6
     gt_j = (rng.randn(B, 21, 3) * 0.04).astype(np.float64); gt_v = (rng.randn(B, 778, 3) * 0.04).astype(np.float64)
@@ -367,7 +367,7 @@ def gen_eval():
     j = torch.arange(2 * 21 * 3, dtype=torch.float32).view(2, 21, 3)
     np.savez_compressed(os.path.join(OUT, "eval.npz"), gt_j=gt_j, gt_v=gt_v.astype(np.float32), pr_j=pr_j, pr_v=pr_v, al_j=al_j,
                         al_v=al_v.astype(np.float32), mpjpe=mpjpe, mpvpe=mpvpe, j=j.numpy(), ho3d2frei=fh["HO3D2Frei"](j).numpy(),
-                        frei2ho3d=fh["Frei2HO3D"](j).numpy())
+                        frei2ho3d=fh["Frei2HO3D"](j).numpy(), rhd2frei=fh["RHD2Frei"](j).numpy())
     print("eval ok", mpjpe, mpvpe)
 
 
