@@ -76,6 +76,10 @@ class HifihrLib:
         c.hifihr_mano_lbs_bwd.argtypes = [c_void_p] + [_c_float_p] * 5 + [c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mano_joints_fwd.argtypes = [c_void_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mano_joints_bwd.argtypes = [c_void_p, _c_float_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p, c_void_p]
+        c.hifihr_lbs_create.argtypes = [POINTER(c_void_p), c_int, c_int, c_int] + [_c_float_p] * 4 + [_c_int_p]
+        c.hifihr_lbs_destroy.argtypes = [c_void_p]
+        c.hifihr_lbs_fwd.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_lbs_bwd.argtypes = [c_void_p] + [_c_float_p] * 4 + [c_int] + [_c_float_p] * 3 + [c_void_p]
         self._bind_optional()
 
     def _bind_optional(self):
@@ -209,6 +213,27 @@ class HifihrLib:
         self.check(self.c.hifihr_mano_joints_bwd(h, _fp(gjoints_rel), _fp(gverts_rel), _fp(groot), B, root_id,
                                                  _fp(gverts), _stream_of(gverts)), "hifihr_mano_joints_bwd")
 
+
+    # ---- generic LBS (NIMBLE-shaped layer) -----------------------------
+    def lbs_create(self, v_template, shapedirs, j_regressor, weights, parents) -> c_void_p:
+        V, J, S = int(v_template.shape[0]), int(weights.shape[1]), int(shapedirs.shape[2])
+        assert shapedirs.shape == (V, 3, S) and j_regressor.shape == (J, V) and weights.shape == (V, J) and len(parents) == J
+        h = c_void_p()
+        keep = [_np_fp(a) for a in (v_template, shapedirs, j_regressor, weights)]
+        import numpy as np
+        par = np.ascontiguousarray(np.asarray(parents, dtype=np.int32))
+        self.check(self.c.hifihr_lbs_create(ctypes.byref(h), V, J, S, *[k[1] for k in keep], par.ctypes.data_as(_c_int_p)), "hifihr_lbs_create")
+        return h
+
+    def lbs_destroy(self, h):
+        self.c.hifihr_lbs_destroy(h)
+
+    def lbs_fwd(self, h, theta, beta, verts, joints):
+        self.check(self.c.hifihr_lbs_fwd(h, _fp(theta), _fp(beta), theta.shape[0], _fp(verts), _fp(joints), _stream_of(theta)), "hifihr_lbs_fwd")
+
+    def lbs_bwd(self, h, theta, beta, gverts, gjoints, scratch, gtheta, gbeta):
+        self.check(self.c.hifihr_lbs_bwd(h, _fp(theta), _fp(beta), _fp(gverts), _fp(gjoints), theta.shape[0], _fp(scratch), _fp(gtheta),
+                                         _fp(gbeta), _stream_of(theta)), "hifihr_lbs_bwd")
 
     # ---- convolution (NHWC, f32 MFMA implicit GEMM) --------------------
     @staticmethod

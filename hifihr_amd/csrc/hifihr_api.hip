@@ -50,6 +50,11 @@ struct hifihr_mano {
   hifihr::ManoDev dev;
 };
 
+struct hifihr_lbs {
+  DevBuf tmpl, sd, widx, wval, jt, jsd, parent;
+  hifihr::LbsDev dev;
+};
+
 struct hifihr_renderer {
   DevBuf faces, vf_off, vf_idx;
   hifihr::RenderDev dev;
@@ -125,6 +130,80 @@ int hifihr_mano_create(hifihr_mano_t** out, const float* v_template, const float
 
 int hifihr_mano_destroy(hifihr_mano_t* h) {
   delete h;
+  return HIFIHR_OK;
+}
+
+int hifihr_lbs_create(hifihr_lbs_t** out, int V, int J, int S, const float* v_template, const float* shapedirs, const float* j_regressor,
+                      const float* weights, const int* parents) {
+  using namespace hifihr;
+  if (!out || !v_template || (S > 0 && !shapedirs) || !j_regressor || !weights || !parents)
+    return fail(HIFIHR_EINVAL, "hifihr_lbs_create: null argument");
+  if (V < 1 || J < 1 || J > kLbsMaxJ || S < 0 || S > kLbsMaxS) return fail(HIFIHR_EINVAL, "hifihr_lbs_create: V >= 1, 1 <= J <= 32, 0 <= S <= 32");
+  if (parents[0] != -1) return fail(HIFIHR_EINVAL, "hifihr_lbs_create: parents[0] must be -1");
+  for (int j = 1; j < J; ++j)
+    if (parents[j] < 0 || parents[j] >= j) return fail(HIFIHR_EINVAL, "hifihr_lbs_create: parents must be topologically ordered (0 <= parents[j] < j)");
+  int K = 1;
+  for (int v = 0; v < V; ++v) {
+    int nz = 0;
+    for (int j = 0; j < J; ++j) nz += weights[(size_t)v * J + j] != 0.f;
+    if (nz > K) K = nz;
+  }
+  if (K > kLbsMaxK) return fail(HIFIHR_EINVAL, "hifihr_lbs_create: more than 8 non-zero skin weights on a vertex");
+  hifihr_lbs* h = new (std::nothrow) hifihr_lbs();
+  if (!h) return fail(HIFIHR_ENOMEM, "hifihr_lbs_create: out of host memory");
+  const int Vp = (V + 63) / 64 * 64;
+  std::vector<float> tm((size_t)3 * Vp, 0.f), sd((size_t)(S ? S : 1) * 3 * Vp, 0.f), wv((size_t)K * Vp, 0.f), jt((size_t)J * 3), jsd((size_t)J * 3 * (S ? S : 1), 0.f);
+  std::vector<int> wi((size_t)K * Vp, 0), par(parents, parents + J);
+  for (int v = 0; v < V; ++v) {
+    for (int c = 0; c < 3; ++c) {
+      tm[(size_t)c * Vp + v] = v_template[v * 3 + c];
+      for (int k = 0; k < S; ++k) sd[((size_t)k * 3 + c) * Vp + v] = shapedirs[((size_t)v * 3 + c) * S + k];
+    }
+    int n = 0;
+    for (int j = 0; j < J; ++j)
+      if (weights[(size_t)v * J + j] != 0.f) { wi[(size_t)n * Vp + v] = j; wv[(size_t)n * Vp + v] = weights[(size_t)v * J + j]; ++n; }
+  }
+  for (int j = 0; j < J; ++j)            // J = J_regressor (v_template + shapedirs beta), folded once in double
+    for (int c = 0; c < 3; ++c) {
+      double a = 0.0;
+      for (int v = 0; v < V; ++v) a += (double)j_regressor[(size_t)j * V + v] * (double)v_template[v * 3 + c];
+      jt[j * 3 + c] = (float)a;
+      for (int k = 0; k < S; ++k) {
+        double s = 0.0;
+        for (int v = 0; v < V; ++v) s += (double)j_regressor[(size_t)j * V + v] * (double)shapedirs[((size_t)v * 3 + c) * S + k];
+        jsd[((size_t)j * 3 + c) * S + k] = (float)s;
+      }
+    }
+  int rc;
+  if ((rc = upload(h->tmpl, tm)) || (rc = upload(h->sd, sd)) || (rc = upload(h->wval, wv)) || (rc = upload(h->jt, jt)) ||
+      (rc = upload(h->jsd, jsd)) || (rc = upload_i(h->widx, wi)) || (rc = upload_i(h->parent, par))) {
+    delete h;
+    return rc;
+  }
+  h->dev = LbsDev{V, Vp, J, S, K, (const float*)h->tmpl.p, (const float*)h->sd.p, (const int*)h->widx.p, (const float*)h->wval.p,
+                  (const float*)h->jt.p, (const float*)h->jsd.p, (const int*)h->parent.p};
+  *out = h;
+  return HIFIHR_OK;
+}
+
+int hifihr_lbs_destroy(hifihr_lbs_t* h) {
+  delete h;
+  return HIFIHR_OK;
+}
+
+int hifihr_lbs_fwd(const hifihr_lbs_t* h, const float* theta, const float* beta, int B, float* verts, float* joints, void* stream) {
+  if (!h || !theta || (h->dev.S > 0 && !beta) || !verts || B < 0) return fail(HIFIHR_EINVAL, "hifihr_lbs_fwd: bad argument");
+  if (B == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_lbs_fwd(h->dev, theta, beta, B, verts, joints, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_lbs_bwd(const hifihr_lbs_t* h, const float* theta, const float* beta, const float* gverts, const float* gjoints, int B,
+                   float* scratch_zeroed, float* gtheta, float* gbeta_zeroed, void* stream) {
+  if (!h || !theta || !gverts || !scratch_zeroed || !gtheta || (h->dev.S > 0 && (!beta || !gbeta_zeroed)) || B < 0)
+    return fail(HIFIHR_EINVAL, "hifihr_lbs_bwd: bad argument");
+  if (B == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_lbs_bwd(h->dev, theta, beta, gverts, gjoints, B, scratch_zeroed, gtheta, gbeta_zeroed, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

@@ -34,6 +34,22 @@ hipError_t launch_mano_joints_fwd(const ManoDev& t, const float* verts, int B, i
 hipError_t launch_mano_joints_bwd(const ManoDev& t, const float* gjoints_rel, const float* gverts_rel,
                                   const float* groot, int B, int root_id, float* gverts, hipStream_t st);
 
+// Generic linear-blend skinning (csrc/lbs.hip): any vertex / joint / shape-component count, sparse skin weights.
+constexpr int kLbsMaxJ = 32, kLbsMaxS = 32, kLbsMaxK = 8;
+struct LbsDev {
+  int V, Vp, J, S, K;   // vertices, padded vertices (multiple of 64), joints, shape components, skin weights kept per vertex
+  const float* tmpl;    // [3][Vp]
+  const float* sd;      // [S][3][Vp]
+  const int* widx;      // [K][Vp]   joint index of the k-th weight
+  const float* wval;    // [K][Vp]   (zero padded)
+  const float* jt;      // [J*3]
+  const float* jsd;     // [J*3][S]
+  const int* parent;    // [J]       parent[0] = -1, parent[i] < i
+};
+hipError_t launch_lbs_fwd(const LbsDev& t, const float* theta, const float* beta, int B, float* verts, float* joints, hipStream_t st);
+hipError_t launch_lbs_bwd(const LbsDev& t, const float* theta, const float* beta, const float* gverts, const float* gjoints, int B,
+                          float* gA_zeroed, float* gtheta, float* gbeta_zeroed, hipStream_t st);
+
 // Renderer handle contents (device pointers + constants); passed to kernels by value.
 struct RenderDev {
   int V, F, H, aa;

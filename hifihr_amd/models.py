@@ -3,11 +3,14 @@
 
 hand_model == 'mano' with render=True is a composition the reference cannot run (MyMANOLayer
 builds a Meshes without textures); this build defines it with a constant per-vertex skin colour as the
-TexturesVertex stand-in.  hand_model == 'nimble' needs the un-vendored NIMBLE submodule + assets and is
-not built ("parity unpinned").  The NIMBLE configurations (full_rhd_freihand.json,
-weak_rhd_ho3d.json) run here as "MANO + a texture stand-in" (SURVEY.md section 8(c)): `texture_stand_in=T` adds the
-T-component texture head of the NIMBLE HandEncoder and turns it into per-vertex colours through a fixed seeded linear
-basis (skin tone + basis . texture_params), so `texture_params`, the `mtex` term and the texture gradient exist.
+TexturesVertex stand-in.  hand_model == 'nimble': the reference's MyNIMBLELayer is an un-vendored submodule whose source and assets
+are absent, so `MyNIMBLELayer` here is a layer of NIMBLE's SHAPE (20 / 30 / 10 components, 25 joints, 5 990
+skin vertices, a 778-vertex MANO-topology regression, per-vertex colours from the texture PCA) on caller-supplied `NimbleTables`
+(hifihr_amd/nimble_tables.py; seeded synthetic ones by default) -- "parity unpinned" for NIMBLE's own numbers, checked against
+oracle/lbs_oracle.py.  The NIMBLE configurations (full_rhd_freihand.json, weak_rhd_ho3d.json) also run as "MANO + a texture stand-in"
+(SURVEY.md section 8(c)): `texture_stand_in=T` adds the T-component texture head of the NIMBLE HandEncoder and turns it into per-vertex
+colours through a fixed seeded linear basis (skin tone + basis . texture_params), so `texture_params`, the `mtex` term and the texture
+gradient exist.
 """
 from __future__ import annotations
 
@@ -16,6 +19,7 @@ import torch.nn as nn
 
 from . import ops
 from .mano_tables import ManoTables, synthetic_mano_tables
+from .nimble_tables import NimbleTables, synthetic_nimble_tables
 from .network import HandEncoder, LightEstimator, ResEncoder
 
 SKIN_TONE = (0.78, 0.60, 0.50)
@@ -41,12 +45,53 @@ class MyMANOLayer(nn.Module):
         return {"mano_verts": verts, "skin_verts": verts}
 
 
+# Mano2Frei as a gather: FreiHAND joint i = MANO-ordered joint _FREI_FROM_MANO[i] (reference utils/fh_utils.py:542-556)
+_MANO_TO_FREI = {0: 0, 1: 5, 2: 6, 3: 7, 4: 8, 5: 9, 6: 10, 7: 11, 8: 12, 9: 17, 10: 18, 11: 19, 12: 20, 13: 13, 14: 14, 15: 15, 16: 16,
+                 17: 1, 18: 2, 19: 3, 20: 4}
+_FREI_FROM_MANO = [k for k, _ in sorted(_MANO_TO_FREI.items(), key=lambda kv: kv[1])]
+
+
+class MyNIMBLELayer(nn.Module):
+    """A hand layer of NIMBLE's shape (what reference models_res_nimble.py:133-142 consumes): pose PCA decode (csrc/texpca.hip) ->
+    generic LBS over the 25-joint tree (csrc/lbs.hip) -> the 778-vertex MANO-topology regression (barycentric on skin faces), the 21
+    MANO-ordered joints, per-vertex colours from the texture PCA (csrc/texpca.hip)."""
+
+    def __init__(self, ifRender, device, shape_ncomp=20, pose_ncomp=30, tex_ncomp=10, tables: NimbleTables | None = None):
+        super().__init__()
+        t = self.tables = tables if tables is not None else synthetic_nimble_tables(0)
+        assert t.shapedirs.shape[2] == shape_ncomp and t.pose_basis.shape[0] == pose_ncomp and t.tex_basis.shape[0] == tex_ncomp
+        self.handle = ops.LbsHandle(t.v_template, t.shapedirs, t.J_regressor, t.weights, t.parents)
+        self.V, self.J, self.ifRender = t.v_template.shape[0], t.weights.shape[1], ifRender
+        pad4 = lambda a: torch.nn.functional.pad(torch.as_tensor(a, dtype=torch.float32), (0, (-a.shape[-1]) % 4)).contiguous()
+        self.register_buffer("pose_basis", pad4(t.pose_basis), persistent=False)        # the decode kernel moves float4
+        self.register_buffer("pose_mean", pad4(t.pose_mean), persistent=False)
+        self.register_buffer("tex_basis", pad4(t.tex_basis), persistent=False)
+        self.register_buffer("tex_mean", pad4(t.tex_mean), persistent=False)
+        self.register_buffer("mesh_face", torch.as_tensor(t.faces, dtype=torch.int32).unsqueeze(0), persistent=False)
+        corner = torch.as_tensor(t.faces, dtype=torch.long)[torch.as_tensor(t.mano_vreg_fidx, dtype=torch.long)]          # [778,3]
+        self.register_buffer("vreg_corner", corner.reshape(-1), persistent=False)
+        self.register_buffer("vreg_bc", torch.as_tensor(t.mano_vreg_bc, dtype=torch.float32).view(1, 778, 3, 1), persistent=False)
+        self.register_buffer("joint21", torch.as_tensor(t.joint21, dtype=torch.long), persistent=False)
+
+    def forward(self, hand_params, handle_collision=True):
+        B = hand_params["pose_params"].shape[0]
+        theta = ops.texture_pca_decode(hand_params["pose_params"], self.pose_basis, self.pose_mean)[:, :self.J * 3]
+        verts, joints = ops.lbs(self.handle, theta.reshape(B, self.J, 3), hand_params["shape_params"])
+        mano_verts = (verts.index_select(1, self.vreg_corner).view(B, 778, 3, 3) * self.vreg_bc).sum(2)
+        out = {"nimble_joints": joints, "verts": verts, "faces": None, "mano_verts": mano_verts,
+               "joints": joints.index_select(1, self.joint21), "rot": None}
+        if self.ifRender and hand_params.get("texture_params") is not None:
+            out["textures"] = ops.texture_pca_decode(hand_params["texture_params"], self.tex_basis, self.tex_mean)[:, :self.V * 3].reshape(B, self.V, 3)
+        return out
+
+
 class Model(nn.Module):
     def __init__(self, ifRender, device, if_4c, hand_model, use_mean_shape, pretrain, root_id=9, root_id_nimble=11,
-                 ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3, texture_stand_in=0):
+                 ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3, texture_stand_in=0,
+                 nimble_tables: NimbleTables | None = None):
         super().__init__()
-        if hand_model != "mano":
-            raise NotImplementedError(f"hand_model='{hand_model}': only 'mano' is built (NIMBLE assets are not available)")
+        if hand_model not in ("mano", "nimble"):
+            raise NotImplementedError(f"hand_model='{hand_model}': 'mano' and 'nimble' are built")
         self.hand_model, self.root_id, self.root_id_nimble = hand_model, root_id, root_id_nimble
         if pretrain in ("res18", "res50", "res101"):
             # res18: SURVEY.md F6 (the reference hard-codes 2048 / 512, the ResNet-50 / -101 widths, and is broken for res18)
@@ -58,18 +103,27 @@ class Model(nn.Module):
             self.base_encoder = EffiEncoder(pretrain=pretrain)
         else:
             raise NotImplementedError(f"pretrain='{pretrain}' is not built yet")
-        self.ncomps = [10, 48, int(texture_stand_in) if texture_stand_in else None]
-        self.hand_layer = MyMANOLayer(ifRender, device, shape_ncomp=10, pose_ncomp=48, tables=mano_tables)
+        if hand_model == "nimble":                                   # models_res_nimble.py:55-57
+            assert not texture_stand_in, "texture_stand_in is the MANO-topology stand-in; hand_model='nimble' has its own texture PCA"
+            self.ncomps = [20, 30, 10]
+            self.hand_layer = MyNIMBLELayer(ifRender, device, shape_ncomp=20, pose_ncomp=30, tex_ncomp=10, tables=nimble_tables)
+            mano_faces = (mano_tables if mano_tables is not None else synthetic_mano_tables(0)).faces       # :62-64 (MANO_RIGHT.pkl 'f')
+            self.register_buffer("_mano_face_i32", torch.as_tensor(mano_faces, dtype=torch.int32), persistent=False)
+            self.register_buffer("_frei_from_mano", torch.tensor(_FREI_FROM_MANO), persistent=False)
+        else:
+            self.ncomps = [10, 48, int(texture_stand_in) if texture_stand_in else None]
+            self.hand_layer = MyMANOLayer(ifRender, device, shape_ncomp=10, pose_ncomp=48, tables=mano_tables)
+            self.register_buffer("_mano_face_i32", self.hand_layer.mesh_face[0].clone(), persistent=False)
         self.hand_encoder = HandEncoder(hand_model=hand_model, ncomps=self.ncomps, in_dim=self.features_dim,
                                         ifRender=ifRender, use_mean_shape=use_mean_shape)
-        self.register_buffer("mano_face", self.hand_layer.mesh_face.clone().to(torch.int16), persistent=False)
+        self.register_buffer("mano_face", self._mano_face_i32.unsqueeze(0).to(torch.int16), persistent=False)
         self.ifRender, self.ifLight, self.aa_factor, self.image_size = ifRender, ifLight, aa_factor, image_size
         if ifRender:
             # Materials(diffuse .8, specular .2, shininess 30) + DirectionalLights defaults (ambient .5, specular .2)
             if not ifLight:
                 self.register_buffer("_pl_color", torch.tensor([[0.3, 0.3, 0.3]]), persistent=False)
                 self.register_buffer("_pl_location", torch.tensor([[0.0, 1.0, 0.0]]), persistent=False)
-            self.renderer_p3d = ops.RendererHandle(self.hand_layer.tables.faces, 778, image_size=image_size, aa=aa_factor, point_lights=not ifLight,
+            self.renderer_p3d = ops.RendererHandle(self.hand_layer.tables.faces, int(self.hand_layer.tables.v_template.shape[0]), image_size=image_size, aa=aa_factor, point_lights=not ifLight,
                                                    ambient=(0.5,) * 3, mat_diffuse=(0.8,) * 3, specular=(0.04,) * 3,
                                                    shininess=30.0, background=(1.0,) * 3)
             self.register_buffer("vertex_colors", torch.tensor(SKIN_TONE).repeat(778, 1), persistent=False)
@@ -119,6 +173,8 @@ class Model(nn.Module):
         hand_params = self.hand_encoder(features)
         outputs = self.hand_layer(hand_params, handle_collision=False)
         outputs.update(hand_params)
+        if self.hand_model == "nimble":
+            return self._nimble_tail(dat_name, mode_train, images, outputs, light_params if self.ifLight else None, Ks, root_xyz)
         # joints regressed from the posed verts + root-relative (models_res_nimble.py:150-166), one HIP launch
         root_id = 0 if (dat_name == "HO3D" and not mode_train) else self.root_id
         joints, mano_verts, pred_root = ops.mano_joints_root_relative(self.hand_layer.handle, outputs["mano_verts"], root_id)
@@ -145,5 +201,30 @@ class Model(nn.Module):
             outputs["face_id"] = face_id
             outputs["skin_verts"] = verts_cam
         outputs["mano_faces"] = self.mano_face.expand(images.shape[0], -1, -1)           # a view (the reference repeats)
-        outputs["_faces_i32"] = self.hand_layer.mesh_face[0]
+        outputs["_faces_i32"] = self._mano_face_i32
+        return outputs
+
+    def _nimble_tail(self, dat_name, mode_train, images, outputs, light_params, Ks, root_xyz):
+        """models_res_nimble.py:156-225 for hand_model == 'nimble': Mano2Frei on the layer's 21 joints, root-relative joints / MANO-topology
+        verts / the 25 bone joints, the SKIN mesh rendered with its texture."""
+        B = images.shape[0]
+        joints = outputs["joints"].index_select(1, self._frei_from_mano)                 # Mano2Frei (:157)
+        eval_ho3d = dat_name == "HO3D" and not mode_train
+        pred_root = joints[:, 0 if eval_ho3d else self.root_id].unsqueeze(1)             # :161-166
+        outputs["joints"], outputs["mano_verts"] = joints - pred_root, outputs["mano_verts"] - pred_root
+        nroot = outputs["nimble_joints"][:, 0 if eval_ho3d else self.root_id_nimble].unsqueeze(1)      # :167-172
+        outputs["nimble_joints"] = outputs["nimble_joints"] - nroot
+        if self.ifRender:
+            cam = self.camera_from_K(Ks)
+            if self.ifLight:
+                colors, directions = light_params["colors"], light_params["directions"]
+            else:
+                colors, directions = self._pl_color.expand(B, -1), self._pl_location.expand(B, -1)
+            verts_cam = outputs["verts"] - pred_root + root_xyz                          # :203-205
+            rgba, face_id = ops.render(self.renderer_p3d, verts_cam, outputs["textures"], cam, colors, directions)
+            outputs["re_img"], outputs["_rgba"] = rgba[:, :3], rgba
+            outputs["re_sil"], outputs["maskRGBs"] = ops.sil_post(rgba, images)
+            outputs["face_id"], outputs["skin_verts"] = face_id, verts_cam
+        outputs["mano_faces"] = self.mano_face.expand(B, -1, -1)
+        outputs["_faces_i32"] = self._mano_face_i32
         return outputs

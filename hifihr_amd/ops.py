@@ -135,6 +135,54 @@ def mano_joints_root_relative(handle: ManoLayerHandle, verts, root_id=9):
     return _ManoJoints.apply(handle, verts, root_id)
 
 
+class LbsHandle:
+    """Device-resident tables of a generic skinned mesh (csrc/lbs.hip): v_template [V,3], shapedirs [V,3,S], J_regressor [J,V],
+    weights [V,J] (<= 8 non-zeros per vertex), parents [J]."""
+
+    def __init__(self, v_template, shapedirs, j_regressor, weights, parents):
+        self.lib = get_lib()
+        self.V, self.J, self.S = int(v_template.shape[0]), int(weights.shape[1]), int(shapedirs.shape[2])
+        self.h = self.lib.lbs_create(v_template, shapedirs, j_regressor, weights, parents)
+
+    def __del__(self):
+        try:
+            self.lib.lbs_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _Lbs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, handle, theta, beta):
+        require_cuda(theta, beta)
+        theta, beta = theta.contiguous().float(), beta.contiguous().float()
+        B = theta.shape[0]
+        assert theta.shape == (B, handle.J, 3) and beta.shape == (B, handle.S)
+        verts = torch.empty(B, handle.V, 3, device=theta.device)
+        joints = torch.empty(B, handle.J, 3, device=theta.device)
+        PROFILE.bracket("lbs_fwd", lambda: handle.lib.lbs_fwd(handle.h, theta, beta, verts, joints))
+        ctx.handle = handle
+        ctx.save_for_backward(theta, beta)
+        return verts, joints
+
+    @staticmethod
+    def backward(ctx, gverts, gjoints):
+        theta, beta = ctx.saved_tensors
+        h, B = ctx.handle, theta.shape[0]
+        zero = torch.zeros(B * (h.J * 12 + h.S), device=theta.device)       # one fill: [d(A) scratch | dbeta]
+        scratch, gbeta = zero[:B * h.J * 12], zero[B * h.J * 12:].view(B, h.S)
+        gtheta = torch.empty(B, h.J, 3, device=theta.device)
+        gv = gverts.contiguous() if gverts is not None else torch.zeros(B, h.V, 3, device=theta.device)
+        gj = gjoints.contiguous() if gjoints is not None else None
+        PROFILE.bracket("lbs_bwd", lambda: h.lib.lbs_bwd(h.h, theta, beta, gv, gj, scratch, gtheta, gbeta))
+        return None, gtheta, gbeta
+
+
+def lbs(handle: LbsHandle, theta, beta):
+    """Generic linear-blend skinning: theta [B,J,3], beta [B,S] -> verts [B,V,3], posed joints [B,J,3]."""
+    return _Lbs.apply(handle, theta, beta)
+
+
 class RendererHandle:
     """Replaces MeshRenderer(MeshRasterizer(...), HardPhongShader(...)) of models_res_nimble.py:70-96."""
 

@@ -79,6 +79,32 @@ int hifihr_mano_joints_bwd(const hifihr_mano_t* h, const float* gjoints_rel_d, c
                            const float* groot_d, int B, int root_id, float* gverts_d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Generic linear-blend skinning (any mesh size / kinematic tree): the NIMBLE-shaped hand layer.
+ * Replaces the skinning step of  self.hand_layer(hand_params, handle_collision=False)  when `hand_model: "nimble"`
+ *          (reference models_res_nimble.py:56-57,133-142; MyNIMBLELayer itself is an un-vendored submodule -- SURVEY.md section 8 A9 --
+ *          so the formulation is the MANO one of utils/my_mano.py:386-451 without pose-corrective blend shapes:
+ *          v_shaped = v_template + shapedirs . beta;  J = j_regressor . v_shaped;  R = Rodrigues(theta);
+ *          global transforms down `parents`;  v = sum_j weights[v][j] (G_j [v_shaped; 1] - G_j [J_j; 0])).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hifihr_lbs hifihr_lbs_t;
+
+/* Host tables: v_template[V][3], shapedirs[V][3][S], j_regressor[J][V] (dense), weights[V][J] (dense; at most 8 non-zeros per
+ * row, kept exactly), parents[J] (parents[0] = -1, parents[j] < j).  1 <= J <= 32, 0 <= S <= 32. */
+int hifihr_lbs_create(hifihr_lbs_t** out, int V, int J, int S, const float* v_template_h, const float* shapedirs_h,
+                      const float* j_regressor_h, const float* weights_h, const int* parents_h);
+int hifihr_lbs_destroy(hifihr_lbs_t* h);
+
+/* theta[B][J][3] (axis-angle per joint, joint 0 = global rotation), beta[B][S] -> verts[B][V][3], joints[B][J][3] (posed joint
+ * positions; may be NULL).  No centring. */
+int hifihr_lbs_fwd(const hifihr_lbs_t* h, const float* theta_d, const float* beta_d, int B, float* verts_d, float* joints_d, void* stream);
+
+/* Gradient: gverts[B][V][3], gjoints[B][J][3] (may be NULL = zero) -> gtheta[B][J][3] (overwritten), gbeta[B][S] (ACCUMULATED: the
+ * caller passes it zeroed).  scratch[B][J][12] must be zero on entry; it is left holding d(loss)/d(A_j).  Sums over vertices use float
+ * atomics: results vary in the last bits from run to run. */
+int hifihr_lbs_bwd(const hifihr_lbs_t* h, const float* theta_d, const float* beta_d, const float* gverts_d, const float* gjoints_d,
+                   int B, float* scratch_zeroed_d, float* gtheta_d, float* gbeta_zeroed_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Hard rasteriser + Phong shader + anti-aliasing resolve.
  * Replaces  rendered = self.renderer_p3d(skin_meshes, cameras=cameras, lights=lighting)
  *           rendered = F.avg_pool2d(rendered.permute(0,3,1,2), aa, aa)      reference models_res_nimble.py:208-211

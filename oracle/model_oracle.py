@@ -92,3 +92,37 @@ def oracle_step(model: OracleModel, examples_cpu: dict, args, optimizer=None, fe
         loss.backward()
         optimizer.step()
     return loss, loss_dic, outputs
+
+
+_MANO_TO_FREI = {0: 0, 1: 5, 2: 6, 3: 7, 4: 8, 5: 9, 6: 10, 7: 11, 8: 12, 9: 17, 10: 18, 11: 19, 12: 20, 13: 13, 14: 14, 15: 15, 16: 16,
+                 17: 1, 18: 2, 19: 3, 20: 4}
+
+
+def mano2frei(mano_joints):
+    """reference utils/fh_utils.py:542-556."""
+    out = torch.zeros_like(mano_joints)
+    for mano_id, frei_id in _MANO_TO_FREI.items():
+        out[:, frei_id] = mano_joints[:, mano_id]
+    return out
+
+
+def nimble_forward_tail(t, hand_params, images, Ks, root_xyz, light, dat_name="FreiHand", mode_train=True, root_id=9, root_id_nimble=11,
+                        image_size=224, aa=3, point_lights=False):
+    """Model.forward after the heads for hand_model == 'nimble' (reference models_res_nimble.py:133-225) on the NIMBLE-shaped layer of
+    oracle/lbs_oracle.py: Mano2Frei, root-relative outputs, the skin mesh rendered with its per-vertex texture."""
+    from oracle import lbs_oracle as lo
+    out = lo.nimble_layer(t, hand_params["pose_params"], hand_params["shape_params"], hand_params.get("texture_params"))
+    out.update(hand_params)
+    out["joints"] = mano2frei(out["joints"])
+    eval_ho3d = dat_name == "HO3D" and not mode_train
+    pred_root = out["joints"][:, 0 if eval_ho3d else root_id].unsqueeze(1)
+    out["joints"], out["mano_verts"] = out["joints"] - pred_root, out["mano_verts"] - pred_root
+    nroot = out["nimble_joints"][:, 0 if eval_ho3d else root_id_nimble].unsqueeze(1)
+    out["nimble_joints"] = out["nimble_joints"] - nroot
+    cam = ro.ndc_camera_from_K(Ks, float(image_size))
+    verts_cam = out["verts"] - pred_root + root_xyz
+    rgba, p2f = ro.render(verts_cam, out["textures"], cam, light["colors"], light["directions"], torch.as_tensor(t.faces).long(),
+                          image_size=image_size, aa=aa, point_lights=point_lights)
+    out["re_img"], out["re_sil"], out["maskRGBs"] = ro.model_render_outputs(rgba, images)
+    out["face_id"], out["skin_verts"] = torch.from_numpy(p2f), verts_cam
+    return out

@@ -953,3 +953,68 @@ def linear_group_case(lib, device, B=32, seed=0):
         assert float((m["dW"] - r[1]).abs().max()) <= 1e-5 * float(r[1].abs().max()) and float((m["db"] - r[2]).abs().max()) <= 1e-4, i
         if m["dx"] is not None:
             assert float((m["dx"] - r[3]).abs().max()) <= 1e-5 * float(r[3].abs().max()) + 1e-6, i
+
+
+MANO_PARENTS16 = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14]     # ManoLayer's tree in its re-ordered joint index space (my_mano.py:395-434)
+
+
+def random_lbs_tables(V, J, S, seed, K=4):
+    """Small random skinned mesh: a random tree, <= K weights per vertex, a sparse convex joint regressor."""
+    rng = np.random.RandomState(seed)
+    vt = rng.randn(V, 3) * 0.05
+    sd = rng.randn(V, 3, S) * 0.004
+    parents = np.array([-1] + [rng.randint(0, j) for j in range(1, J)], dtype=np.int32)
+    w = np.zeros((V, J))
+    for v in range(V):
+        idx = rng.choice(J, size=min(J, rng.randint(1, K + 1)), replace=False)
+        w[v, idx] = rng.rand(idx.size) + 0.05
+    w /= w.sum(1, keepdims=True)
+    jr = np.zeros((J, V))
+    for j in range(J):
+        idx = rng.choice(V, size=min(V, 24), replace=False)
+        jr[j, idx] = rng.rand(idx.size)
+    jr /= jr.sum(1, keepdims=True)
+    return tuple(np.ascontiguousarray(a, dtype=np.float32) for a in (vt, sd, jr, w)) + (parents,)
+
+
+def lbs_case(lib, device, tabs, B, seed, pose_scale=0.6, vtol=2e-6, gtol=2e-4):
+    """csrc/lbs.hip through the C-ABI vs oracle/lbs_oracle.py: verts, posed joints, d/dtheta, d/dbeta of a random scalar of both
+    outputs.  (The backward's vertex sums are float atomics: gtol is relative to the largest gradient entry.)"""
+    from oracle import lbs_oracle as lo
+    vt, sd, jr, w, parents = tabs
+    V, J, S = vt.shape[0], w.shape[1], sd.shape[2]
+    gen = torch.Generator().manual_seed(seed)
+    theta = torch.randn(B, J, 3, generator=gen) * pose_scale
+    theta[0, min(1, J - 1)] = 0.0                           # the zero-angle branch of Rodrigues
+    beta = torch.randn(B, S, generator=gen)
+    wv, wj = torch.randn(B, V, 3, generator=gen), torch.randn(B, J, 3, generator=gen)
+    th, be = theta.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rv, rj = lo.lbs_forward(vt, sd, jr, w, parents, th, be)
+    ((rv * wv).sum() + (rj * wj).sum()).backward()
+    h = lib.lbs_create(vt, sd, jr, w, parents)
+    try:
+        d = lambda t: t.to(device).contiguous()
+        verts, joints = torch.empty(B, V, 3, device=device), torch.empty(B, J, 3, device=device)
+        lib.lbs_fwd(h, d(theta), d(beta), verts, joints)
+        scale = float(rv.detach().abs().max())
+        assert float((verts.cpu() - rv.detach()).abs().max()) <= vtol * max(1.0, scale / 0.1), float((verts.cpu() - rv.detach()).abs().max())
+        assert float((joints.cpu() - rj.detach()).abs().max()) <= vtol * max(1.0, scale / 0.1)
+        scratch = torch.zeros(B, J, 12, device=device)
+        gtheta, gbeta = torch.full((B, J, 3), 9.0, device=device), torch.zeros(B, S, device=device)
+        lib.lbs_bwd(h, d(theta), d(beta), d(wv), d(wj), scratch, gtheta, gbeta)
+        for got, ref, name in ((gtheta, th.grad, "gtheta"), (gbeta, be.grad, "gbeta")):
+            if ref is None or ref.numel() == 0:
+                continue
+            err, mag = float((got.cpu() - ref).abs().max()), float(ref.abs().max())
+            assert err <= gtol * mag, (name, err, mag)
+        gtheta2, gbeta2 = torch.empty(B, J, 3, device=device), torch.zeros(B, S, device=device)      # gjoints = NULL
+        scratch.zero_()
+        lib.lbs_bwd(h, d(theta), d(beta), d(wv), None, scratch, gtheta2, gbeta2)
+        th.grad = None; be.grad = None
+        rv2, _ = lo.lbs_forward(vt, sd, jr, w, parents, th, be)
+        (rv2 * wv).sum().backward()
+        assert float((gtheta2.cpu() - th.grad).abs().max()) <= gtol * float(th.grad.abs().max())
+        if S:
+            assert float((gbeta2.cpu() - be.grad).abs().max()) <= gtol * float(be.grad.abs().max())
+    finally:
+        lib.lbs_destroy(h)

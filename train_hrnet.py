@@ -34,6 +34,9 @@ def parse(argv=None):
     ap.add_argument("--freihand_cache", default=None, help="npz: images, masks, Ks, joints, verts [, eval_* counterparts]")
     ap.add_argument("--synthetic_size", type=int, default=512)
     ap.add_argument("--mano_pkl", default=None, help="MANO_RIGHT.pkl (licensed, user supplied); default: synthetic MANO-shaped tables")
+    ap.add_argument("--nimble_layer", choices=["mano-stand-in", "synthetic"], default="mano-stand-in",
+                    help="what hand_model 'nimble' runs on: MANO + the vertex-colour texture stand-in, or the NIMBLE-shaped layer "
+                         "(csrc/lbs.hip: 25 joints, 5990 skin vertices, texture PCA) on seeded synthetic tables")
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--max_iters", type=int, default=0, help="stop after this many iterations (0 = run the epochs)")
     ap.add_argument("--print_freq", type=int, default=50)
@@ -53,7 +56,10 @@ def build_args(cli):
             setattr(args, k, v)
     args.state_output = os.path.join(args.base_out_path, "model")       # options/train_options.py:208-220
     args.texture_stand_in = 0
-    if args.hand_model == "nimble":
+    if args.hand_model == "nimble" and cli.nimble_layer == "synthetic":
+        print("[train_hrnet] hand_model 'nimble': NIMBLE-shaped layer on seeded synthetic tables (hifihr_amd/nimble_tables.py); the real "
+              "NIMBLE assets are not available (SURVEY.md section 8 A9)")
+    elif args.hand_model == "nimble":
         print("[train_hrnet] hand_model 'nimble': the NIMBLE layer is not available; running MANO + the 10-component "
               "vertex-colour texture stand-in (SURVEY.md section 8 A9)")
         args.hand_model, args.texture_stand_in = "mano", 10
@@ -71,8 +77,15 @@ def load_or_make_dataset(cli, model, device):
         return tr, ev
     from hifihr_amd import synth
     parts, n = [], cli.synthetic_size + 64
+    if model.hand_model == "nimble":                  # the data side is MANO either way (FreiHAND's ground truth)
+        from hifihr_amd import ops
+        from hifihr_amd.mano_tables import synthetic_mano_tables
+        mt = synthetic_mano_tables(0)
+        mano, rend = ops.ManoLayerHandle(mt), ops.RendererHandle(mt.faces, 778, image_size=224, aa=3)
+    else:
+        mano, rend = model.hand_layer.handle, model.renderer_p3d
     for first in range(0, n, 64):
-        s = synth.make_batch(model.hand_layer.handle, model.renderer_p3d, min(64, n - first), first_index=first, device=device)
+        s = synth.make_batch(mano, rend, min(64, n - first), first_index=first, device=device)
         parts.append({"images": (s["trans_images"].permute(0, 2, 3, 1) * 255).round().to(torch.uint8).numpy(),
                       "masks": (s["trans_masks"][:, 0] * 255).to(torch.uint8).numpy(), "Ks": s["trans_Ks"].numpy(),
                       "joints": s["trans_joints"].numpy(), "verts": s["trans_verts"].numpy()})
