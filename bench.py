@@ -194,7 +194,8 @@ def conv_path_rooflines(ops, lib, dev, nprof):
             wt = torch.empty(w.numel(), device=dev)            # the step gets this transpose from its one weight_prep launch
             lib.weight_transpose(w, wt, K_, R_ * S_, C_)
             fn = lambda: lib.conv2d_bwd_data_pre(y, wt, x, N_, H_, W_, C_, K_, R_, S_, st_, pd_, ws=ws)
-        add("conv_igemm_kernel", per_step, hip_us(fn), flop, nbytes, f"{direction} N{N_} {H_}x{W_} C{C_}->K{K_} {R_}x{S_} s{st_}")
+        add(lib.conv2d_describe(N_, H_, W_, C_, K_, R_, S_, st_, pd_, direction == "dgrad"), per_step, hip_us(fn), flop, nbytes,
+            f"{direction} N{N_} {H_}x{W_} C{C_}->K{K_} {R_}x{S_} s{st_}")
     out = {}
     for name, e in table.items():
         ach = e["flop_per_step"] / (e["us_per_step"] * 1e-6) / 1e12

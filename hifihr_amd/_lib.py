@@ -151,6 +151,7 @@ class HifihrLib:
         c.hifihr_comm_broadcast_f32.argtypes = [c_void_p, _c_float_p, c_size_t, c_int, c_void_p]
         c.hifihr_comm_destroy.argtypes = [c_void_p]
         c.hifihr_bgemm_describe.argtypes = [c_int] * 4 + [ctypes.c_char_p, c_int]
+        c.hifihr_conv2d_describe.argtypes = [c_int] * 10 + [ctypes.c_char_p, c_int]
         c.hifihr_bgemm_tn_parts.argtypes = [c_int] * 4
         c.hifihr_bgemm_tn.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_wgrad_parts.argtypes = [c_int] * 5
@@ -425,6 +426,11 @@ class HifihrLib:
 
     def comm_destroy(self, h):
         self.c.hifihr_comm_destroy(h)
+
+    def conv2d_describe(self, N, H, W, C, K, R, S, stride, pad, dgrad):
+        buf = ctypes.create_string_buffer(64)
+        self.check(self.c.hifihr_conv2d_describe(N, H, W, C, K, R, S, stride, pad, int(bool(dgrad)), buf, 64), "hifihr_conv2d_describe")
+        return buf.value.decode()
 
     def bgemm_describe(self, tn, M, N, K):
         buf = ctypes.create_string_buffer(96)

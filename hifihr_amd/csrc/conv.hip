@@ -795,6 +795,9 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
   // the fast gather uses 32-bit element offsets (scaled by 4 in the address) and a 63-bit tap mask
   if ((long)g.N * g.IH * g.IW * g.IC >= (1L << 30) || (long)g.OC * g.R * g.S * g.IC >= (1L << 30)) return hipErrorInvalidValue;
+  if (conv_halo_supported(g, bias)) {
+    if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_halo(g, src, wgt, dst, stats, zeros, st);
+  }
   const bool generic = (g.IC % 16) != 0 || g.R * g.S > 63;
   if (generic && g.dgrad && g.stride != 1) return hipErrorInvalidValue;   // strided dgrad needs source channels % 16 == 0
   int bk = (g.IC % 32 == 0) ? 32 : 16;

@@ -1,0 +1,404 @@
+// 3x3 / stride 1 / pad 1 NHWC fp32 convolution with 64 input and 64 output channels (ResNet layer 1: reference
+// network/res_encoder.py:364-373 dispatches these to cuDNN / MIOpen): forward and backward-data on the f32 matrix cores
+// (v_mfma_f32_16x16x4_f32), input staged ONCE per output tile.
+//
+// Why a second kernel beside conv_igemm_kernel (csrc/conv.hip): as an implicit GEMM this layer is M = 100 352 pixels x N = 64 x K = 576
+// at batch 32 -- the narrow N makes every MFMA pay for 1.5x the operand bytes of a square tile, the gather re-reads every input pixel
+// once per tap (9x), and round 1's ablation put 28 % of the main loop into register-staged loads + LDS stores.  Here
+//   * an output tile is 8 rows x 14 columns (112 pixels = 7 MFMA row blocks) x all 64 output channels; its 10 x 16-pixel input halo
+//     (40 KB) goes to LDS once, by LDS-DMA, and the nine taps read it at shifted addresses;
+//   * the weights stream through a 4-stage ring of one tap each ([2 channel halves][64 n][32 c], 16 KB, 9 per tile), laid out like the
+//     B operand of bgemm_ws_kernel (csrc/gemm.hip): 4 dedicated loader waves, counted vmcnt waits, one raw s_barrier per tap;
+//   * 4 MFMA waves (one 16-channel column block each, 7 accumulators) see only ds_read_b128 + MFMA;
+//   * workgroups are persistent (one per CU) and walk equal shares of the (image, column tile, row) strips, cut into tiles of 8 rows
+//     (or 4 at the end of a share: 7 168 strips / 256 CUs = 28 = 8 + 8 + 8 + 4 at batch 32), so no quantisation round is lost;
+//     the next tile's halo is loaded while the current one is multiplied (two halo buffers).
+// LDS: 2 x 44 KB halo + 4 x 16 KB weight stages = 152 KB.  Per tile 187 KB come from L2 (implicit GEMM, 128 x 64 tile: 442 KB).
+// Halo image: pixel-major rows of 64 floats + 4 floats of padding (272 B): an MFMA operand read touches 16 (nearly always)
+// consecutive halo pixels at one 16-byte segment each -> 16-byte bank units (pixel + segment) mod 16, at most one 2-way conflict per
+// ds_read_b128 lane group -- and, unlike an XOR swizzle, a tap or channel offset is a plain addition to a lane's address.  The
+// LDS-DMA writes the image in lane-linear 1 KiB pieces (43 per halo); lanes that fall on padding, on pixels outside the image or
+// past the halo's end read a zero buffer.
+// Backward-data = the same kernel on dy with the [C][R][S][K] transposed filter and mirrored tap offsets (sign = -1).
+// Forward epilogue: per-channel sum / sum of squares of the outputs for the following batch norm, accumulated in registers over
+// the workgroup's tiles and added once to stats slot (workgroup & 31) (same buffers as conv_igemm_kernel's epilogue, csrc/bn.hip).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "hifihr_internal.h"
+#include "lds_dma.h"
+
+namespace hifihr {
+
+namespace {
+
+constexpr int kTW = 14, kTH = 8;                 // output tile: columns, rows
+constexpr int kHP = 16;                          // halo pitch (pixels): 14 + 2
+constexpr int kHaloPix = (kTH + 2) * kHP;        // 160
+constexpr int kPixF = 68;                        // floats per halo pixel row: 64 channels + 4 of padding (272 B)
+constexpr int kHaloPieces = (kHaloPix * kPixF * 4 + 1023) / 1024;    // 1 KiB LDS-DMA pieces that cover a halo buffer: 43
+constexpr int kHalo = (kHaloPieces + 1) / 2 * 2 * 256;               // floats per halo buffer (44 pieces = 44 KB)
+constexpr int kWStage = 64 * 64;                 // floats per weight stage: one tap, [2 channel halves][64 n][32 c] (16 KB)
+constexpr int kStages = 4;                       // weight stages (a power of two)
+constexpr int kTaps = 9;
+constexpr int kNL = 4;                           // loader waves
+constexpr int kHaloPer = (kHaloPieces + kNL - 1) / kNL;             // halo pieces per loader wave: 11 (the last wave: 10)
+static_assert(2 * (kTaps - 3) >= kHaloPer, "the next tile's halo is issued two pieces per tap and must land two taps before the tile ends");
+
+struct HaloArgs {
+  const float* src;     // [N][H][W][64]
+  const float* wgt;     // [64][9][64]: row n, q = tap * 64 + c
+  float* dst;           // [N][H][W][64]
+  float* stats;         // [kStatSlots][2][64] or null
+  const float* zeros;   // >= 16 bytes of zeros
+  int N, H, W, sign;    // sign = +1: tap (r, s) reads (y + r - 1, x + s - 1); -1: (y + 1 - r, x + 1 - s)
+  int ctiles, total, per;   // W / 14; N * ctiles * H strips ordered (n, column tile, y); strips per workgroup
+};
+
+struct Tile { int n, x0, y0, rows; };
+
+// the tile that starts at strip `cur` of a share ending at `end`
+__device__ __forceinline__ Tile tile_at(const HaloArgs& a, int cur, int end) {
+  const int col = cur / a.H, y = cur - col * a.H;
+  const int n = col / a.ctiles, ct = col - n * a.ctiles;
+  int rows = min(min(kTH, a.H - y), end - cur);
+  return Tile{n, ct * kTW, y, rows};
+}
+
+}  // namespace
+
+// HIFIHR_HALO_STAMP (diagnostic build, tools/build_halo_probe.sh + tools/halo_stamp.py): MFMA wave 0 of every workgroup adds to
+// g_halo_stamp [0] cycles inside the chunk loops, [1] 100 MHz ticks of the same spans, [2] chunks, [3] cycles at the per-chunk
+// barrier, [4] workgroups, [5] cycles kernel entry -> exit, [6] cycles in the epilogues, [7] loader wave 0: cycles waiting on vmcnt
+// HIFIHR_HALO_ABLATE (timing experiments only, results are wrong): 1 = no loader waves and no barriers (the MFMA waves' own
+// instruction stream alone), 2 = also no LDS reads (MFMA only), 3 = loaders and barriers kept, LDS reads removed
+#ifndef HIFIHR_HALO_ABLATE
+#define HIFIHR_HALO_ABLATE 0
+#endif
+#if defined(HIFIHR_HALO_STAMP)
+__device__ unsigned long long g_halo_stamp[8];
+#define HALO_T() __builtin_amdgcn_s_memtime()
+#endif
+#if HIFIHR_HALO_ABLATE == 1 || HIFIHR_HALO_ABLATE == 2
+#define HALO_BARRIER() ((void)0)
+#else
+#define HALO_BARRIER() HIFIHR_RAW_BARRIER()
+#endif
+
+__global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
+#if defined(HIFIHR_HALO_STAMP)
+  const unsigned long long st_entry = HALO_T();
+  unsigned long long st_loop = 0, st_real = 0, st_bar = 0, st_epi = 0, st_vm = 0;
+#endif
+  __shared__ __attribute__((aligned(1024))) float lds[2 * kHalo + kStages * kWStage];
+  float* const halo = lds;
+  float* const wst = lds + 2 * kHalo;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int s_lo = wg * a.per, s_hi = min(s_lo + a.per, a.total);
+  if (s_lo >= s_hi) return;                                  // (uniform)
+  int ntiles = 0;
+  for (int cur = s_lo; cur < s_hi; cur += tile_at(a, cur, s_hi).rows) ++ntiles;
+  const int ntaps = ntiles * kTaps;                          // iterations of this workgroup: one per (tile, tap)
+
+  if (wave >= 4) {
+    if (HIFIHR_HALO_ABLATE == 1 || HIFIHR_HALO_ABLATE == 2) return;
+    // ---------------- loader ----------------
+    const int l = wave - 4;
+    // weights of one tap: 16 pieces; piece q = l + 4 i: channel half q >> 3, rows 8 (q & 7) .. + 7 of that [64][32] half;
+    // lane -> (row, physical 16-byte segment), which holds logical segment (lane & 7) ^ ((row >> 1) & 7)
+    unsigned woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = l + kNL * i;
+      const int row = 8 * (q & 7) + (lane >> 3);
+      woff[i] = (unsigned)row * 576u + (unsigned)((q >> 3) * 32) + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 4);
+    }
+    auto issue_w = [&](int gt) {                             // global tap gt -> stage gt & 3
+      float* base = wst + (gt & (kStages - 1)) * kWStage;
+      const float* src = a.wgt + (gt % kTaps) * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) HIFIHR_GLDS16(src + woff[i], base + 256 * (l + kNL * i), lane);
+    };
+    // halo: piece hq = l + 4 i fills LDS bytes [1024 hq, 1024 hq + 1024) of the buffer; lane -> 16 bytes at 1024 hq + 16 lane =
+    // segment (that offset % 272) / 16 of halo pixel (that offset / 272); the padding and the bytes past pixel 159 read zeros.
+    // The (pixel, segment) of a lane's share of piece i does not depend on the tile: packed once, (dy << 12 | dx << 8 | seg) or -1.
+    int hpk[kHaloPer];
+#pragma unroll
+    for (int i = 0; i < kHaloPer; ++i) {
+      const int o = (l + kNL * i) * 1024 + lane * 16;
+      const int hp = o / (kPixF * 4), within = o - hp * (kPixF * 4);
+      hpk[i] = (hp < kHaloPix && within < 256) ? ((hp >> 4) << 12) | ((hp & 15) << 8) | (within >> 4) : -1;
+    }
+    auto issue_h1 = [&](const Tile& t, int buf, int i) {     // (i: compile-time after unrolling)
+      const int hq = l + kNL * i;
+      const int pk = hpk[i];
+      const int iy = t.y0 - 1 + (pk >> 12), ix = t.x0 - 1 + ((pk >> 8) & 15);
+      const bool ok = pk >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float* src = ok ? a.src + (((size_t)t.n * a.H + iy) * a.W + ix) * 64 + (pk & 15) * 4 : a.zeros;
+      HIFIHR_GLDS16(src, halo + buf * kHalo + 256 * hq, lane);
+    };
+    const int nh = (kHaloPieces - l + kNL - 1) / kNL;        // halo pieces of this wave: 11, 11, 11, 10
+    int cur = s_lo;
+    Tile t = tile_at(a, cur, s_hi);
+#pragma unroll
+    for (int i = 0; i < kHaloPer; ++i)
+      if (i < nh) issue_h1(t, 0, i);
+    issue_w(0);
+    issue_w(1);
+    issue_w(2);
+    HIFIHR_WAIT_VM(4);                                       // halo 0 and taps 0, 1 landed; tap 2 may be in flight
+    HIFIHR_RAW_BARRIER();                                    // barrier -1
+    int gt = 0;
+    for (int ti = 0; ti < ntiles; ++ti) {
+      cur += t.rows;
+      const bool more = ti + 1 < ntiles;
+      Tile nt = t;
+      if (more) nt = tile_at(a, cur, s_hi);
+      const int nbuf = (ti + 1) & 1;
+#pragma unroll
+      for (int tap = 0; tap < kTaps; ++tap, ++gt) {
+        // tap gt + 3 -> the stage tap gt - 1 was read from (released by barrier gt - 1); two pieces of the next tile's halo
+        const bool w = gt + 3 < ntaps;
+        if (w) issue_w(gt + 3);
+        int hcnt = 0;
+        if (more && 2 * tap < kHaloPer) {
+          issue_h1(nt, nbuf, 2 * tap);
+          hcnt = 1;
+          if (2 * tap + 1 < nh) { issue_h1(nt, nbuf, 2 * tap + 1); hcnt = 2; }
+        }
+        // tap gt + 2 (issued one iteration ago) must have landed before barrier gt: the MFMA waves prefetch from it during iteration
+        // gt + 1.  Loads land in order, so exactly this iteration's pieces may stay in flight.
+#if defined(HIFIHR_HALO_STAMP)
+        const unsigned long long v0 = HALO_T();
+#endif
+        const int out = (w ? 4 : 0) + hcnt;
+        if (out == 6) HIFIHR_WAIT_VM(6);
+        else if (out == 5) HIFIHR_WAIT_VM(5);
+        else if (out == 4) HIFIHR_WAIT_VM(4);
+        else if (out == 2) HIFIHR_WAIT_VM(2);
+        else if (out == 1) HIFIHR_WAIT_VM(1);
+        else HIFIHR_WAIT_VM(0);
+#if defined(HIFIHR_HALO_STAMP)
+        st_vm += HALO_T() - v0;
+#endif
+        HIFIHR_RAW_BARRIER();                                // barrier gt
+      }
+      t = nt;
+    }
+#if defined(HIFIHR_HALO_STAMP)
+    if (tid == 256) atomicAdd(&g_halo_stamp[7], st_vm);
+#endif
+    return;
+  }
+
+  // ---------------- MFMA waves ----------------
+  const int r = lane & 15, g = lane >> 4;
+  // LDS byte addresses are (lane part) + (wave-uniform part): the halo rows are padded, not XOR-swizzled, so that a tap / channel
+  // offset is a plain addition.  hoff[j]: halo pixel of tile pixel 16 j + r at tap offset (0, 0), segment g; woff[h]: this lane's
+  // weight row (swizzled like the GEMM tiles), segment g + 4 h.
+  int hoff[7], woff[2];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int p = 16 * j + r, ty = p / kTW;
+    hoff[j] = (ty * kHP + (p - ty * kTW)) * (kPixF * 4) + g * 16;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) woff[h] = (16 * wave + r) * 128 + (((g + 4 * h) ^ ((r >> 1) & 7)) * 16);
+  const char* const halo_b = reinterpret_cast<const char*>(halo);
+  const char* const wst_b = reinterpret_cast<const char*>(wst);
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+
+  HALO_BARRIER();                                            // barrier -1
+  int cur = s_lo, gt = 0;
+  // one tile with NB MFMA row blocks (7: up to 8 rows, 4: up to 4 rows = 56 pixels)
+  auto run_tile = [&](auto nbc, const Tile& t, int hbuf) {
+    constexpr int NB = decltype(nbc)::value;
+    float fm[2][NB][4], fn[2][4];
+    // fragments of quarter qd = 2 * (channel half) + h (16 input channels) of tap `tap` of this tile; weights of global tap gtt
+    auto read_q = [&](int gtt, int tap, int qd, int slot) {
+      if (HIFIHR_HALO_ABLATE >= 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          HIFIHR_TOUCH(fn[slot][k]);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) HIFIHR_TOUCH(fm[slot][j][k]);
+        }
+        return;
+      }
+      const int tr = tap / 3, ts = tap - 3 * tr;
+      const int toff = (1 + a.sign * (tr - 1)) * kHP + (1 + a.sign * (ts - 1));
+      const int hu = hbuf * (kHalo * 4) + toff * (kPixF * 4) + qd * 64;                               // (uniform)
+      {
+        const float4 v = *reinterpret_cast<const float4*>(wst_b + (gtt & (kStages - 1)) * (kWStage * 4) + (qd >> 1) * 8192 + woff[qd & 1]);
+        fn[slot][0] = v.x; fn[slot][1] = v.y; fn[slot][2] = v.z; fn[slot][3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(halo_b + hu + hoff[j]);
+        fm[slot][j][0] = v.x; fm[slot][j][1] = v.y; fm[slot][j][2] = v.z; fm[slot][j][3] = v.w;
+      }
+    };
+    floatx4 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    auto mfma_q = [&](int slot) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fn[slot][k], fm[slot][j][k], acc[j], 0, 0, 0);
+    };
+    auto touch = [&]() {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        HIFIHR_TOUCH(fn[0][k]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) HIFIHR_TOUCH(fm[0][j][k]);
+      }
+    };
+    // the (NB + 1) LDS reads of the NEXT quarter are spread between the 4 NB MFMAs of the current one
+    auto interleave = [&]() {
+#pragma unroll
+      for (int i = 0; i < NB + 1; ++i) {
+        HIFIHR_SCHED_GROUP(0x008, 3);                        // MFMA
+        HIFIHR_SCHED_GROUP(0x100, 1);                        // DS read
+        HIFIHR_SCHED_GROUP(0x002, 2);                        // VALU
+      }
+      HIFIHR_SCHED_GROUP(0x008, 4 * NB - 3 * (NB + 1));
+    };
+    read_q(gt, 0, 0, 0);
+    touch();
+#if defined(HIFIHR_HALO_STAMP)
+    const unsigned long long l0 = HALO_T(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int tap = 0; tap < kTaps; ++tap, ++gt) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        // quarter qd + 1 of this tap, or quarter 0 of the next one (landed: confirmed at barrier gt - 1; past the tile's last tap the
+        // addresses stay inside the LDS array and the values are never used -- no branch: see bgemm_ws_kernel)
+        if (qd < 3) read_q(gt, tap, qd + 1, (qd + 1) & 1);
+        else read_q(gt + 1, tap + 1, 0, 0);
+        mfma_q(qd & 1);
+        interleave();
+        HIFIHR_PIN();
+      }
+      touch();
+#if defined(HIFIHR_HALO_STAMP)
+      HIFIHR_TOUCH(acc[0][0]);
+      const unsigned long long b0 = HALO_T();
+#endif
+      HALO_BARRIER();                                        // barrier gt
+#if defined(HIFIHR_HALO_STAMP)
+      st_bar += HALO_T() - b0;
+#endif
+    }
+#if defined(HIFIHR_HALO_STAMP)
+    const unsigned long long l1 = HALO_T();
+    st_loop += l1 - l0; st_real += __builtin_amdgcn_s_memrealtime() - r0;
+#endif
+    // epilogue: register e of lane (r, g) of block j = out[pixel 16 j + r][channel 16 wave + 4 g + e]
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int p = 16 * j + r, ty = p / kTW, tx = p - ty * kTW;
+      if (ty < t.rows) {
+        float* o = a.dst + (((size_t)t.n * a.H + t.y0 + ty) * a.W + t.x0 + tx) * 64 + 16 * wave + 4 * g;
+        *reinterpret_cast<float4*>(o) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ssum[e] += acc[j][e]; ssq[e] += acc[j][e] * acc[j][e]; }
+      }
+    }
+#if defined(HIFIHR_HALO_STAMP)
+    st_epi += HALO_T() - l1;
+#endif
+  };
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const Tile t = tile_at(a, cur, s_hi);
+    cur += t.rows;
+    if (t.rows > 4) run_tile(std::integral_constant<int, 7>{}, t, ti & 1);
+    else run_tile(std::integral_constant<int, 4>{}, t, ti & 1);
+  }
+#if defined(HIFIHR_HALO_STAMP)
+  if (tid == 0) {
+    atomicAdd(&g_halo_stamp[0], st_loop); atomicAdd(&g_halo_stamp[1], st_real); atomicAdd(&g_halo_stamp[2], (unsigned long long)ntaps);
+    atomicAdd(&g_halo_stamp[3], st_bar); atomicAdd(&g_halo_stamp[4], 1ull); atomicAdd(&g_halo_stamp[5], HALO_T() - st_entry);
+    atomicAdd(&g_halo_stamp[6], st_epi);
+  }
+#endif
+  if (a.stats != nullptr) {                                  // (uniform)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      for (int o = 1; o < 16; o <<= 1) { ssum[e] += __shfl_xor(ssum[e], o, 64); ssq[e] += __shfl_xor(ssq[e], o, 64); }
+    if (r == 0) {
+      float* sp = a.stats + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 16 * wave + 4 * g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { atomicAdd(sp + e, ssum[e]); atomicAdd(sp + 64 + e, ssq[e]); }
+    }
+  }
+}
+
+#if defined(HIFIHR_HALO_STAMP)
+}  // namespace hifihr
+extern "C" int hifihr_halo_stamp_read(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hifihr::g_halo_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hifihr::g_halo_stamp), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+namespace hifihr {
+#endif
+
+static int halo_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+// 256 zero bytes the halo's out-of-image pixels are read from.  Allocated on first use (never inside a stream capture: the caller
+// then falls back to conv_igemm_kernel for that launch).
+const float* conv_halo_zero_page(hipStream_t st) {
+  static float* page[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (page[dev] == nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    page[dev] = static_cast<float*>(p);
+  }
+  return page[dev];
+}
+
+bool conv_halo_supported(const ConvGeom& g, const float* bias) {
+  static const int on = [] { const char* e = getenv("HIFIHR_CONV_HALO"); return e ? atoi(e) : 1; }();
+  return on && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.IC == 64 && g.OC == 64 && g.batch <= 1 && !g.relu && bias == nullptr &&
+         g.IH == g.OH && g.IW == g.OW && g.OW % kTW == 0 && (long)g.N * g.OH * g.OW * 64 < (1L << 31);
+}
+
+hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros,
+                            hipStream_t st) {
+  if (!conv_halo_supported(g, nullptr) || zeros == nullptr || (stats != nullptr && g.dgrad)) return hipErrorInvalidValue;
+  HaloArgs a;
+  a.src = src; a.wgt = wgt; a.dst = dst; a.stats = stats; a.zeros = zeros;
+  a.N = g.N; a.H = g.OH; a.W = g.OW; a.sign = g.dgrad ? -1 : 1;
+  a.ctiles = g.OW / kTW;
+  a.total = g.N * a.ctiles * g.OH;
+  int G = halo_cus();
+  a.per = (a.total + G - 1) / G;
+  if (a.per < 4) a.per = 4;                                  // tiny problems: fewer workgroups, tiles of >= 4 rows
+  G = (a.total + a.per - 1) / a.per;
+  hipLaunchKernelGGL(conv_halo_kernel, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace hifihr

@@ -28,32 +28,9 @@
 #include <cstdlib>
 
 #include "hifihr_internal.h"
+#include "lds_dma.h"
 
 namespace hifihr {
-
-#if defined(HIFIHR_HOSTSIM)
-typedef hs_floatx4 floatx4;
-// emulation of an LDS-DMA: lane `lane` of the wave copies 16 bytes to (wave-uniform base) + 16 * lane
-#define HIFIHR_GLDS16(gptr, lds_wave_base, lane) std::memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * (lane), (gptr), 16)
-#define HIFIHR_WAIT_LOADS() ((void)0)
-#define HIFIHR_PIN() ((void)0)
-#else
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-#define HIFIHR_GLDS16(gptr, lds_wave_base, lane)                                                     \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
-                                   (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
-#define HIFIHR_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-// MFMAs touch registers only, so the scheduler would otherwise sink the whole block below the wait + barrier that follow it
-// (seen in the ISA: 1 MFMA, vmcnt(0), s_barrier, 127 MFMAs), exposing the load latency the block is there to hide
-#define HIFIHR_PIN() __builtin_amdgcn_sched_barrier(0)
-#endif
-
-// XCD-aware workgroup renumbering: blocks b and b + 8 share an XCD (its own 4 MB L2), so give every XCD one contiguous eighth
-// of the tile list (consecutive tiles share an operand panel).  Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int b, int n) {
-  const int q = n >> 3, r = n & 7, x = b & 7;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
 
 // ------------------------------------------------------------------------------------------------
 // NT: C[m][n] = sum_k A[m][k] B[n][k]   (both operands K-contiguous; K % 32 == 0, N % BN == 0, any M)
@@ -290,27 +267,6 @@ __global__ __launch_bounds__(256) void bgemm_tn_kernel(BgemmArgs a) {
 //                         fragments of half 0 of chunk c + 1 load (landed: confirmed at barrier c - 1); barrier c.
 //   The barrier is a raw s_barrier: __syncthreads() would drain the loader's in-flight DMA (its fence waits vmcnt(0)).
 // ------------------------------------------------------------------------------------------------
-#if defined(HIFIHR_HOSTSIM)
-#define HIFIHR_RAW_BARRIER() __syncthreads()
-#define HIFIHR_WAIT_VM(n) ((void)0)
-#define HIFIHR_WAIT_LGKM0() ((void)0)
-#define HIFIHR_TOUCH(x) ((void)0)
-// the emulator runs the lanes of a wave one after the other between rendezvous points: a wave-level rendezvous where the hardware's
-// lockstep execution is relied on (all lanes have stored before lane 0 raises a flag; all lanes have polled before it is lowered)
-#define HIFIHR_WAVE_SYNC() ((void)__ballot(1))
-#else
-#define HIFIHR_WAVE_SYNC() ((void)0)
-#define HIFIHR_TOUCH(x) asm volatile("" : "+v"(x))
-#define HIFIHR_RAW_BARRIER()                     \
-  do {                                           \
-    asm volatile("" ::: "memory");               \
-    __builtin_amdgcn_s_barrier();                \
-    asm volatile("" ::: "memory");               \
-  } while (0)
-#define HIFIHR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define HIFIHR_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#endif
-
 // HIFIHR_GEMM_STAMP (diagnostic build, tools/build_gemm_probe.sh): wave 0 of every workgroup adds to g_gemm_stamp
 // [0] shader cycles in the main loop, [1] 100 MHz real-time ticks of the same span (-> clock held under load), [2] chunks,
 // [3] cycles spent at the per-chunk barrier, [4] waves counted, [5] cycles from kernel entry to the end of the epilogue

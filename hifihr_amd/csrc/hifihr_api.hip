@@ -371,6 +371,14 @@ int hifihr_conv2d_fwd(const float* x, const float* w, const float* bias, int act
   return HIFIHR_OK;
 }
 
+int hifihr_conv2d_describe(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dgrad, char* out, int cap) {
+  if (!out || cap < 24 || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad)) return fail(HIFIHR_EINVAL, "hifihr_conv2d_describe: bad argument");
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+  const hifihr::ConvGeom g = dgrad ? hifihr::ConvGeom{N, OH, OW, K, H, W, C, R, S, stride, pad, 1} : hifihr::ConvGeom{N, H, W, C, OH, OW, K, R, S, stride, pad, 0};
+  snprintf(out, cap, "%s", hifihr::conv_halo_supported(g, nullptr) ? "conv_halo_kernel" : "conv_igemm_kernel");
+  return HIFIHR_OK;
+}
+
 int hifihr_conv2d_fwd_bnstats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int C, int K, int R,
                               int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !w || !y || !stats || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4)

@@ -81,6 +81,10 @@ struct ConvGeom {
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
                              void* sk_ws, size_t sk_ws_bytes, hipStream_t st);
 size_t conv_sk_workspace_bytes(const ConvGeom& g);
+// 3x3 / stride 1 / 64 -> 64 channels with the input halo staged once per tile (csrc/conv_halo.hip); forward (+ BN statistics) and dgrad
+bool conv_halo_supported(const ConvGeom& g, const float* bias);
+const float* conv_halo_zero_page(hipStream_t st);
+hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st);
 // batch-norm (+ residual add + ReLU) on NHWC activations, x[M][C].  Statistics buffers are [kStatSlots][2][C]: partial
 // sums are spread over kStatSlots copies so that at most ~1/32 of the contributing workgroups hit one address with a
 // float atomic (thousands of atomics on ONE address serialise at ~100 ns each: 200 us per reduction in round 1).

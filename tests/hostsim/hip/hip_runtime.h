@@ -167,6 +167,8 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->mu
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 
 // ---- MFMA emulation (exact: the hardware result is a k-ordered fmaf chain, cdna_hip_programming.md section 3) ----
 typedef float hs_floatx16 __attribute__((vector_size(64)));

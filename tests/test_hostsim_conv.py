@@ -46,3 +46,14 @@ def test_image_to_nhwc4(hostsim_lib):
 def test_conv_bias_relu(hostsim_lib, N, H, W, C, K, R, stride):
     """LightEstimator layers: conv + bias + ReLU in one launch and the masked-gradient / bias-gradient kernel."""
     kc.conv_bias_relu_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, seed=C + K)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 10, 14), (1, 5, 28), (2, 24, 14), (1, 3, 42)])
+def test_conv_halo_layer1_shape(hostsim_lib, N, H, W):
+    """3x3 / stride 1 / 64 -> 64 channels with W % 14 == 0: conv_halo_kernel (csrc/conv_halo.hip), forward and backward-data.
+    hostsim reports 4 CUs: shares of 5 rows (one 7-block tile), shares that cross a column-tile boundary, 8 + 4 row tiles, 3-row images."""
+    kc.conv_case(hostsim_lib, "cpu", N, H, W, 64, 64, 3, 1, 1, seed=H + W)
+
+
+def test_conv_halo_bnstats(hostsim_lib):
+    kc.conv_bnstats_case(hostsim_lib, "cpu", 2, 12, 14, 64, 64, 3, 1, 1)
