@@ -27,6 +27,7 @@
 
 namespace hifihr {
 
+constexpr int kBnUnroll = 4;    // rows per trip of the streaming loops (independent 16-byte loads in flight per lane)
 constexpr int kMaxNG = 4;        // channel groups (of 4 channels) per thread: C <= 4 * 256 * kMaxNG = 4096
 
 // Thread -> (row lane, channel groups).  C4 <= 256: CT = C4 threads cover a row, RL = 256 / CT rows per pass, one
@@ -138,11 +139,15 @@ __device__ __forceinline__ void clear_slots(float* __restrict__ buf, int C, unsi
   if (threadIdx.x < 33) cnt[threadIdx.x] = 0u;
 }
 
-__device__ __forceinline__ float slot_sum(const float* __restrict__ buf, int C, int idx) {
-  float a = 0.f;
-#pragma unroll 8
-  for (int sl = 0; sl < kStatSlots; ++sl) a += buf[(size_t)sl * 2 * C + idx];
-  return a;
+// both statistics of channel c with all 64 loads in flight at once: this fold is the prologue of every workgroup of an apply kernel,
+// and in groups of 8 dependent-latency batches it cost ~5 us of the ~9 us a small layer's launch takes (tools/time_bn.py)
+__device__ __forceinline__ void slot_sum2(const float* __restrict__ buf, int C, int c, float& s0, float& s1) {
+  float a[kStatSlots], b[kStatSlots];
+#pragma unroll
+  for (int sl = 0; sl < kStatSlots; ++sl) { a[sl] = buf[(size_t)sl * 2 * C + c]; b[sl] = buf[(size_t)sl * 2 * C + C + c]; }
+  s0 = 0.f; s1 = 0.f;
+#pragma unroll
+  for (int sl = 0; sl < kStatSlots; ++sl) { s0 += a[sl]; s1 += b[sl]; }
 }
 
 // Wide layers (C > kFuseMaxC): folding 256 C bytes of partials in EVERY workgroup costs more than it saves (EfficientNet's
@@ -208,8 +213,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
       mu = save_mean[c]; is = save_invstd[c];
       if (stats == nullptr) is = 1.0f / sqrtf(is + eps);       // evaluation mode: (running_mean, running_var) were passed in
     } else {
-      mu = slot_sum(stats, C, c) * invM;
-      var = fmaxf(slot_sum(stats, C, C + c) * invM - mu * mu, 0.f);       // biased batch variance
+      float s0, s1;
+      slot_sum2(stats, C, c, s0, s1);
+      mu = s0 * invM;
+      var = fmaxf(s1 * invM - mu * mu, 0.f);                              // biased batch variance
       is = 1.0f / sqrtf(var + eps);
     }
     const float sc = is * gamma[c];
@@ -236,22 +243,46 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
         shift[j] = *reinterpret_cast<const float4*>(&s_sh[cg * 4]);
       }
     }
-    for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+    auto finish = [&](float4 r, const float4& res, size_t o) {
+      if (residual) acc4(r, res);
+      if (act == 1) {
+        r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+      } else if (act == 2) {
+        r.x = r.x / (1.f + expf(-r.x)); r.y = r.y / (1.f + expf(-r.y)); r.z = r.z / (1.f + expf(-r.z)); r.w = r.w / (1.f + expf(-r.w));
+      }
+      *reinterpret_cast<float4*>(y + o) = r;
+    };
+    const long stride = (long)gridDim.x * mp.RL;
+    long m = (long)blockIdx.x * mp.RL + mp.rl;
+    if (mp.NG == 1) {
+      // four rows per trip, their loads issued before the first use: one float4 in flight per lane left the small grids of the
+      // deep layers latency-bound (kBnUnroll independent 16-byte loads per lane instead)
+      const float4 sc = scale[0], sh = shift[0];
+      const int cb = mp.cg0 * 4;
+      for (; m + (kBnUnroll - 1) * stride < M; m += kBnUnroll * stride) {
+        float4 v[kBnUnroll], rs[kBnUnroll];
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) {
+          const size_t o = (size_t)(m + u * stride) * C + cb;
+          v[u] = *reinterpret_cast<const float4*>(x + o);
+          rs[u] = residual ? *reinterpret_cast<const float4*>(residual + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u)
+          finish(make_float4(v[u].x * sc.x + sh.x, v[u].y * sc.y + sh.y, v[u].z * sc.z + sh.z, v[u].w * sc.w + sh.w), rs[u],
+                 (size_t)(m + u * stride) * C + cb);
+      }
+    }
+    for (; m < M; m += stride) {
 #pragma unroll
       for (int j = 0; j < kMaxNG; ++j) {
         const int cg = mp.cg0 + 256 * j;
         if (j < mp.NG && cg * 4 < C) {
           const size_t o = (size_t)m * C + cg * 4;
           const float4 v = *reinterpret_cast<const float4*>(x + o);
-          float4 r = make_float4(v.x * scale[j].x + shift[j].x, v.y * scale[j].y + shift[j].y, v.z * scale[j].z + shift[j].z,
-                                 v.w * scale[j].w + shift[j].w);
-          if (residual) acc4(r, *reinterpret_cast<const float4*>(residual + o));
-          if (act == 1) {
-            r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
-          } else if (act == 2) {
-            r.x = r.x / (1.f + expf(-r.x)); r.y = r.y / (1.f + expf(-r.y)); r.z = r.z / (1.f + expf(-r.z)); r.w = r.w / (1.f + expf(-r.w));
-          }
-          *reinterpret_cast<float4*>(y + o) = r;
+          finish(make_float4(v.x * scale[j].x + shift[j].x, v.y * scale[j].y + shift[j].y, v.z * scale[j].z + shift[j].z,
+                             v.w * scale[j].w + shift[j].w),
+                 residual ? *reinterpret_cast<const float4*>(residual + o) : make_float4(0.f, 0.f, 0.f, 0.f), o);
         }
       }
     }
@@ -265,12 +296,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 // g = dy * act'(z).  ReLU: the mask is y > 0 read from the forward's output when the layer had a residual input; without one
 // y = max(z, 0) with z = x * sc + sh recomputed from x by the forward's own expression (same bits), so y is not read at all
 // (y == nullptr: a third less traffic in both backward passes).  Swish recomputes z the same way.
-__device__ __forceinline__ float4 masked_grad(int act, const float4& dy, const float* __restrict__ y, size_t o, const float4& v,
+__device__ __forceinline__ float4 masked_grad(int act, const float4& dy, bool have_y, const float4& yv, const float4& v,
                                               const float4& sc, const float4& sh) {
   float4 g = dy;
   if (act == 1) {
     float4 yy;
-    if (y != nullptr) yy = *reinterpret_cast<const float4*>(y + o);
+    if (have_y) yy = yv;
     else yy = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
     g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
   } else if (act == 2) {
@@ -304,17 +335,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
   }
   if (mp.active) {
-    for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+    const bool have_y = act == 1 && y != nullptr;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto accum = [&](int j, const float4& g, const float4& v) {
+      acc4(s[j], g);
+      q[j].x += g.x * ((v.x - mu[j].x) * is[j].x); q[j].y += g.y * ((v.y - mu[j].y) * is[j].y);
+      q[j].z += g.z * ((v.z - mu[j].z) * is[j].z); q[j].w += g.w * ((v.w - mu[j].w) * is[j].w);
+    };
+    const long stride = (long)gridDim.x * mp.RL;
+    long m = (long)blockIdx.x * mp.RL + mp.rl;
+    if (mp.NG == 1) {
+      const int cb = mp.cg0 * 4;
+      for (; m + (kBnUnroll - 1) * stride < M; m += kBnUnroll * stride) {
+        float4 v[kBnUnroll], d[kBnUnroll], yv[kBnUnroll];
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) {
+          const size_t o = (size_t)(m + u * stride) * C + cb;
+          v[u] = *reinterpret_cast<const float4*>(x + o);
+          d[u] = *reinterpret_cast<const float4*>(dy + o);
+          yv[u] = have_y ? *reinterpret_cast<const float4*>(y + o) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) accum(0, masked_grad(act, d[u], have_y, yv[u], v[u], sc[0], sh[0]), v[u]);
+      }
+    }
+    for (; m < M; m += stride) {
 #pragma unroll
       for (int j = 0; j < kMaxNG; ++j) {
         const int cg = mp.cg0 + 256 * j;
         if (j < mp.NG && cg * 4 < C) {
           const size_t o = (size_t)m * C + cg * 4;
           const float4 v = *reinterpret_cast<const float4*>(x + o);
-          const float4 g = masked_grad(act, *reinterpret_cast<const float4*>(dy + o), y, o, v, sc[j], sh[j]);
-          acc4(s[j], g);
-          q[j].x += g.x * ((v.x - mu[j].x) * is[j].x); q[j].y += g.y * ((v.y - mu[j].y) * is[j].y);
-          q[j].z += g.z * ((v.z - mu[j].z) * is[j].z); q[j].w += g.w * ((v.w - mu[j].w) * is[j].w);
+          accum(j, masked_grad(act, *reinterpret_cast<const float4*>(dy + o), have_y,
+                               have_y ? *reinterpret_cast<const float4*>(y + o) : zero4, v, sc[j], sh[j]), v);
         }
       }
     }
@@ -341,7 +394,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       const float* tot = red + (size_t)kStatSlots * 2 * C;
       sg = tot[c]; sgx = tot[C + c];
     } else {
-      sg = slot_sum(red, C, c); sgx = slot_sum(red, C, C + c);
+      slot_sum2(red, C, c, sg, sgx);
     }
     s_mg[c] = sg * invM;
     s_mgx[c] = sgx * invM;
@@ -370,21 +423,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         }
       }
     }
-    for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+    const bool have_y = act == 1 && y != nullptr;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto emit = [&](int j, const float4& g, const float4& v, size_t o) {
+      float4 r;
+      r.x = k1[j].x * (g.x - mg[j].x - (v.x - mu[j].x) * is[j].x * mgx[j].x);
+      r.y = k1[j].y * (g.y - mg[j].y - (v.y - mu[j].y) * is[j].y * mgx[j].y);
+      r.z = k1[j].z * (g.z - mg[j].z - (v.z - mu[j].z) * is[j].z * mgx[j].z);
+      r.w = k1[j].w * (g.w - mg[j].w - (v.w - mu[j].w) * is[j].w * mgx[j].w);
+      *reinterpret_cast<float4*>(dx + o) = r;
+      if (dres) *reinterpret_cast<float4*>(dres + o) = g;
+    };
+    const long stride = (long)gridDim.x * mp.RL;
+    long m = (long)blockIdx.x * mp.RL + mp.rl;
+    if (mp.NG == 1) {
+      const int cb = mp.cg0 * 4;
+      for (; m + (kBnUnroll - 1) * stride < M; m += kBnUnroll * stride) {
+        float4 v[kBnUnroll], d[kBnUnroll], yv[kBnUnroll];
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) {
+          const size_t o = (size_t)(m + u * stride) * C + cb;
+          v[u] = *reinterpret_cast<const float4*>(x + o);
+          d[u] = *reinterpret_cast<const float4*>(dy + o);
+          yv[u] = have_y ? *reinterpret_cast<const float4*>(y + o) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u)
+          emit(0, masked_grad(act, d[u], have_y, yv[u], v[u], k1[0], sh[0]), v[u], (size_t)(m + u * stride) * C + cb);
+      }
+    }
+    for (; m < M; m += stride) {
 #pragma unroll
       for (int j = 0; j < kMaxNG; ++j) {
         const int cg = mp.cg0 + 256 * j;
         if (j < mp.NG && cg * 4 < C) {
           const size_t o = (size_t)m * C + cg * 4;
           const float4 v = *reinterpret_cast<const float4*>(x + o);
-          const float4 g = masked_grad(act, *reinterpret_cast<const float4*>(dy + o), y, o, v, k1[j], sh[j]);
-          float4 r;
-          r.x = k1[j].x * (g.x - mg[j].x - (v.x - mu[j].x) * is[j].x * mgx[j].x);
-          r.y = k1[j].y * (g.y - mg[j].y - (v.y - mu[j].y) * is[j].y * mgx[j].y);
-          r.z = k1[j].z * (g.z - mg[j].z - (v.z - mu[j].z) * is[j].z * mgx[j].z);
-          r.w = k1[j].w * (g.w - mg[j].w - (v.w - mu[j].w) * is[j].w * mgx[j].w);
-          *reinterpret_cast<float4*>(dx + o) = r;
-          if (dres) *reinterpret_cast<float4*>(dres + o) = g;
+          emit(j, masked_grad(act, *reinterpret_cast<const float4*>(dy + o), have_y, have_y ? *reinterpret_cast<const float4*>(y + o) : zero4,
+                              v, k1[j], sh[j]), v, o);
         }
       }
     }

@@ -331,40 +331,48 @@ __global__ __launch_bounds__(256) void wino_dw_transform_kernel(float* __restric
 // dw[K][3][3][C] += G^T (sum over slabs of dU) G: the backward-weight reduction of gemm.hip arrives as `parts` slabs
 // dU_parts[part][16][K][C] (one per split of the tile range), summed here while they are read -- in a fixed order, so the weight
 // gradient is bit-reproducible and nothing has to be zero-initialised or cleaned.
+// One thread per (item = (k, channel group), Winograd position): the 16 positions of an item are summed over the slabs by 16 threads
+// (parts loads in flight each) and exchanged through LDS; 9 of them then apply G^T . G with the arithmetic order of
+// wino_dw_transform_kernel.  (One thread per item summing 16 x parts strided float4 ran 16 - 256 workgroups: 18 us per layer at
+// 1.1 TB/s, tools/kernel_traffic.sh.)
 __global__ __launch_bounds__(256) void wino_dw_transform_parts_kernel(const float* __restrict__ dU, int parts, float* __restrict__ dw, int K, int C) {
+  __shared__ float4 su[16][16];
   const int C4 = C / 4;
   const size_t total = (size_t)K * C4, plane = (size_t)K * C, slab = 16 * plane;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cg = (int)(i % C4), k = (int)(i / C4);
-    float4 u[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
+  const int il = threadIdx.x & 15, pos = threadIdx.x >> 4;
+  for (size_t base = (size_t)blockIdx.x * 16; base < total; base += (size_t)gridDim.x * 16) {      // (uniform)
+    const size_t i = base + il;
+    const bool ok = i < total;
+    const int cg = ok ? (int)(i % C4) : 0, k = ok ? (int)(i / C4) : 0;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      const float* p = dU + (size_t)pos * plane + (size_t)k * C + cg * 4;
+      a = *reinterpret_cast<const float4*>(p);
+#pragma unroll 4
+      for (int z = 1; z < parts; ++z) a = add4(a, *reinterpret_cast<const float4*>(p + z * slab));
+    }
+    su[pos][il] = a;
+    __syncthreads();
+    if (pos < 9 && ok) {
+      const int r = pos / 3, c2 = pos - 3 * r;
+      float4 t[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float* p = dU + (size_t)(r * 4 + c) * plane + (size_t)k * C + cg * 4;
-        float4 a = *reinterpret_cast<const float4*>(p);
-        for (int z = 1; z < parts; ++z) a = add4(a, *reinterpret_cast<const float4*>(p + z * slab));
-        u[r][c] = a;
+        const float4 u0 = su[c][il], u1 = su[4 + c][il], u2 = su[8 + c][il], u3 = su[12 + c][il];
+        const float4 h12 = add4(u1, u2), d12 = sub4(u1, u2);
+        if (r == 0) t[c] = make_float4(u0.x + 0.5f * h12.x, u0.y + 0.5f * h12.y, u0.z + 0.5f * h12.z, u0.w + 0.5f * h12.w);
+        else if (r == 1) t[c] = make_float4(0.5f * d12.x, 0.5f * d12.y, 0.5f * d12.z, 0.5f * d12.w);
+        else t[c] = make_float4(u3.x + 0.5f * h12.x, u3.y + 0.5f * h12.y, u3.z + 0.5f * h12.z, u3.w + 0.5f * h12.w);
       }
-    float4 t[3][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float4 h12 = add4(u[1][c], u[2][c]), d12 = sub4(u[1][c], u[2][c]);
-      t[0][c] = make_float4(u[0][c].x + 0.5f * h12.x, u[0][c].y + 0.5f * h12.y, u[0][c].z + 0.5f * h12.z, u[0][c].w + 0.5f * h12.w);
-      t[1][c] = make_float4(0.5f * d12.x, 0.5f * d12.y, 0.5f * d12.z, 0.5f * d12.w);
-      t[2][c] = make_float4(u[3][c].x + 0.5f * h12.x, u[3][c].y + 0.5f * h12.y, u[3][c].z + 0.5f * h12.z, u[3][c].w + 0.5f * h12.w);
+      const float4 h12 = add4(t[1], t[2]), d12 = sub4(t[1], t[2]);
+      float4 gq;
+      if (c2 == 0) gq = make_float4(t[0].x + 0.5f * h12.x, t[0].y + 0.5f * h12.y, t[0].z + 0.5f * h12.z, t[0].w + 0.5f * h12.w);
+      else if (c2 == 1) gq = make_float4(0.5f * d12.x, 0.5f * d12.y, 0.5f * d12.z, 0.5f * d12.w);
+      else gq = make_float4(t[3].x + 0.5f * h12.x, t[3].y + 0.5f * h12.y, t[3].z + 0.5f * h12.z, t[3].w + 0.5f * h12.w);
+      float* o = dw + (((size_t)k * 3 + r) * 3 + c2) * C + cg * 4;
+      *reinterpret_cast<float4*>(o) = add4(*reinterpret_cast<float4*>(o), gq);
     }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const float4 h12 = add4(t[r][1], t[r][2]), d12 = sub4(t[r][1], t[r][2]);
-      const float4 g0 = make_float4(t[r][0].x + 0.5f * h12.x, t[r][0].y + 0.5f * h12.y, t[r][0].z + 0.5f * h12.z, t[r][0].w + 0.5f * h12.w);
-      const float4 g1 = make_float4(0.5f * d12.x, 0.5f * d12.y, 0.5f * d12.z, 0.5f * d12.w);
-      const float4 g2 = make_float4(t[r][3].x + 0.5f * h12.x, t[r][3].y + 0.5f * h12.y, t[r][3].z + 0.5f * h12.z, t[r][3].w + 0.5f * h12.w);
-      float* o = dw + (((size_t)k * 3 + r) * 3) * C + cg * 4;
-      float4 a = *reinterpret_cast<float4*>(o);          *reinterpret_cast<float4*>(o) = add4(a, g0);
-      a = *reinterpret_cast<float4*>(o + C);             *reinterpret_cast<float4*>(o + C) = add4(a, g1);
-      a = *reinterpret_cast<float4*>(o + 2 * C);         *reinterpret_cast<float4*>(o + 2 * C) = add4(a, g2);
-    }
+    __syncthreads();
   }
 }
 
@@ -423,7 +431,7 @@ hipError_t launch_wino_dw_transform(float* dU, float* dw, int K, int C, int clea
 
 hipError_t launch_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st) {
   if (C % 4 != 0 || parts < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(wino_dw_transform_parts_kernel, dim3(wino_grid((size_t)K * (C / 4))), dim3(256), 0, st, dU_parts, parts, dw, K, C);
+  hipLaunchKernelGGL(wino_dw_transform_parts_kernel, dim3(wino_grid((size_t)K * (C / 4) * 16)), dim3(256), 0, st, dU_parts, parts, dw, K, C);
   return hipGetLastError();
 }
 
