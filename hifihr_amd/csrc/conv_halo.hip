@@ -338,6 +338,173 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward-weight of the same layer: dW[k][tap][c] += sum over pixels dy[p][k] x[p + tap][c].
+// The reduction runs over PIXELS, so a workgroup keeps the whole 9 x 64 x 64 gradient in its accumulators (MFMA wave w: the 16 output
+// channels 4 i + w, all 64 input channels, 9 taps = 36 accumulator tiles, 144 registers) while it walks its share of the image in the
+// same 8 x 14 tiles as the forward: per tile the input halo (44 KB) and the dy tile (28 KB) go to LDS once (two buffers: the loader
+// waves fill the next tile while this one is multiplied; ONE barrier per tile), and every MFMA k-step is 4 pixels:
+//   A[i][kk] = dy[pixel kk][4 i + w]            one ds_read_b32 per 4-pixel group
+//   B[kk][j] = x[pixel kk + tap][4 j + m]       one ds_read_b128 per (group, tap): its 4 components feed the 4 input-channel tiles m
+// (the channel <-> tile-row permutation 4 i + w / 4 j + m is undone by the slab store).  36 MFMAs per 10 LDS reads.
+// Each workgroup writes its partial gradient to its own slab [9][64][64]; conv_halo_wgrad_reduce_kernel adds the slabs to dW in a
+// fixed order (no atomics: the weight gradient is bit-reproducible, unlike conv_wgrad_kernel's atomic epilogue).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kDyT = kTH * kTW * 64;             // floats of a dy tile: 112 pixels x 64 channels (28 KB)
+constexpr int kWgBuf = kHalo + kDyT;             // floats per buffer
+constexpr int kWgPieces = kHaloPieces + kTH * kTW / 4;      // LDS-DMA pieces per tile: 43 + 28
+constexpr int kWgPer = (kWgPieces + kNL - 1) / kNL;        // per loader wave: 18
+struct HaloWgradArgs {
+  const float* x;       // [N][H][W][64]
+  const float* dy;      // [N][H][W][64]
+  float* slabs;         // [workgroups][9][64][64]
+  const float* zeros;
+  int N, H, W;
+  int ctiles, total, per;
+};
+}  // namespace
+
+__global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_wgrad_kernel(HaloWgradArgs a) {
+  __shared__ __attribute__((aligned(1024))) float lds[2 * kWgBuf];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  HaloArgs sh;                                               // (tile_at only reads H, ctiles)
+  sh.H = a.H; sh.ctiles = a.ctiles;
+  const int s_lo = wg * a.per, s_hi = min(s_lo + a.per, a.total);
+  int ntiles = 0;
+  for (int cur = s_lo; cur < s_hi; cur += tile_at(sh, cur, s_hi).rows) ++ntiles;
+
+  if (wave >= 4) {
+    // ---------------- loader ----------------
+    const int l = wave - 4;
+    auto issue_tile = [&](const Tile& t, int buf) {
+      float* base = lds + buf * kWgBuf;
+#pragma unroll 2
+      for (int i = 0; i < kWgPer; ++i) {
+        const int q = l + kNL * i;
+        if (q < kHaloPieces) {                               // (uniform) halo piece: see conv_halo_kernel
+          const int o = q * 1024 + lane * 16;
+          const int hp = o / (kPixF * 4), within = o - hp * (kPixF * 4);
+          const int iy = t.y0 - 1 + (hp >> 4), ix = t.x0 - 1 + (hp & 15);
+          const bool ok = hp < kHaloPix && within < 256 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          const float* src = ok ? a.x + (((size_t)t.n * a.H + iy) * a.W + ix) * 64 + (within >> 2) : a.zeros;
+          HIFIHR_GLDS16(src, base + 256 * q, lane);
+        } else if (q < kWgPieces) {                          // dy piece: tile pixels 4 (q - 43) .. + 3, rows past the tile read zeros
+          const int p = 4 * (q - kHaloPieces) + (lane >> 4);
+          const int ty = p / kTW, tx = p - ty * kTW;
+          const float* src = ty < t.rows ? a.dy + (((size_t)t.n * a.H + t.y0 + ty) * a.W + t.x0 + tx) * 64 + (lane & 15) * 4 : a.zeros;
+          HIFIHR_GLDS16(src, base + kHalo + 256 * (q - kHaloPieces), lane);
+        }
+      }
+    };
+    int cur = s_lo;
+    Tile t = tile_at(sh, cur, s_hi);
+    if (ntiles > 0) issue_tile(t, 0);
+    HIFIHR_WAIT_VM(0);
+    HIFIHR_RAW_BARRIER();                                    // barrier -1
+    for (int ti = 0; ti < ntiles; ++ti) {
+      cur += t.rows;
+      if (ti + 1 < ntiles) {
+        t = tile_at(sh, cur, s_hi);
+        issue_tile(t, (ti + 1) & 1);                         // (its buffer was last read in iteration ti - 1: released by barrier ti - 1)
+      }
+      HIFIHR_WAIT_VM(0);
+      HIFIHR_RAW_BARRIER();                                  // barrier ti: tile ti + 1 is in LDS, buffer ti & 1 is free
+    }
+    return;
+  }
+
+  // ---------------- MFMA waves ----------------
+  const int r = lane & 15, g = lane >> 4;
+  floatx4 acc[kTaps][4];
+#pragma unroll
+  for (int tp = 0; tp < kTaps; ++tp)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[tp][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const char* const lds_b = reinterpret_cast<const char*>(lds);
+  const int dy_lane = kHalo * 4 + (4 * r + wave) * 4;        // byte offset of this lane's dy channel inside a buffer (+ 256 * pixel)
+  const int hx_lane = r * 16;                                // ... of its 16-byte input-channel segment (+ 272 * halo pixel)
+
+  HIFIHR_RAW_BARRIER();                                      // barrier -1
+  int cur = s_lo;
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const Tile t = tile_at(sh, cur, s_hi);
+    cur += t.rows;
+    const char* const buf = lds_b + (ti & 1) * (kWgBuf * 4);
+    const int ngroups = (t.rows * kTW + 3) >> 2;             // 4-pixel groups that hold pixels of this tile (dy is zero past its rows)
+    float fy[2];
+    float4 fx[2][kTaps];
+    auto read_group = [&](int P, int slot) {
+      P = min(P, kTH * kTW / 4 - 1);                         // (the software pipeline reads one or two groups past the last: stay inside the tile)
+      const int tpix = 4 * P + g, ty = tpix / kTW;
+      const int hpix = ty * kHP + (tpix - ty * kTW);
+      fy[slot] = *reinterpret_cast<const float*>(buf + dy_lane + tpix * 256);
+      const char* hb = buf + hx_lane + hpix * (kPixF * 4);
+#pragma unroll
+      for (int tp = 0; tp < kTaps; ++tp) fx[slot][tp] = *reinterpret_cast<const float4*>(hb + ((tp / 3) * kHP + (tp % 3)) * (kPixF * 4));
+    };
+    auto mfma_group = [&](int slot) {
+#pragma unroll
+      for (int tp = 0; tp < kTaps; ++tp) {
+        acc[tp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[slot], fx[slot][tp].x, acc[tp][0], 0, 0, 0);
+        acc[tp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[slot], fx[slot][tp].y, acc[tp][1], 0, 0, 0);
+        acc[tp][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[slot], fx[slot][tp].z, acc[tp][2], 0, 0, 0);
+        acc[tp][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[slot], fx[slot][tp].w, acc[tp][3], 0, 0, 0);
+      }
+    };
+    auto interleave = [&]() {                                // 10 LDS reads of the next group between the 36 MFMAs of this one
+#pragma unroll
+      for (int i = 0; i < kTaps + 1; ++i) {
+        HIFIHR_SCHED_GROUP(0x008, 3);
+        HIFIHR_SCHED_GROUP(0x100, 1);
+        HIFIHR_SCHED_GROUP(0x002, 2);
+      }
+      HIFIHR_SCHED_GROUP(0x008, 4 * kTaps - 3 * (kTaps + 1));
+    };
+    read_group(0, 0);
+    for (int P = 0; P < ngroups; P += 2) {                   // (ngroups is even: rows * 14 / 4 with the tile heights used, else padded)
+      read_group(P + 1, 1);                                  // (past the last group: inside the buffer, zero dy or never used)
+      mfma_group(0);
+      interleave();
+      HIFIHR_PIN();
+      read_group(P + 2, 0);
+      if (P + 1 < ngroups) mfma_group(1);
+      interleave();
+      HIFIHR_PIN();
+    }
+    HIFIHR_RAW_BARRIER();                                    // barrier ti
+  }
+  // slab[tap][k][c]: register e of lane (r, g) of tile (tap, m) = dW[k = 4 (4 g + e) + wave][c = 4 r + m]
+  float* slab = a.slabs + (size_t)wg * (kTaps * 64 * 64);
+#pragma unroll
+  for (int tp = 0; tp < kTaps; ++tp)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * (4 * g + e) + wave;
+      *reinterpret_cast<float4*>(slab + ((size_t)tp * 64 + k) * 64 + 4 * r) = make_float4(acc[tp][0][e], acc[tp][1][e], acc[tp][2][e], acc[tp][3][e]);
+    }
+}
+
+// dw[k][tap][c] += sum over the slabs, in slab order
+__global__ __launch_bounds__(256) void conv_halo_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;              // index into a slab: (tap * 64 + k) * 64 + c
+  if (i >= kTaps * 64 * 64) return;
+  // 32 independent loads in flight per lane (the slabs are 147 KB apart: with 8 the launch was latency-bound at ~20 us for 38 MB)
+  float s = 0.f;
+  int z = 0;
+  for (; z + 32 <= nslab; z += 32) {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = slabs[(size_t)(z + u) * (kTaps * 64 * 64) + i];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s += v[u];
+  }
+  for (; z < nslab; ++z) s += slabs[(size_t)z * (kTaps * 64 * 64) + i];
+  const int c = i & 63, k = (i >> 6) & 63, tp = i >> 12;
+  dw[((size_t)k * kTaps + tp) * 64 + c] += s;
+}
+
 #if defined(HIFIHR_HALO_STAMP)
 }  // namespace hifihr
 extern "C" int hifihr_halo_stamp_read(unsigned long long* out8, int reset) {
@@ -383,6 +550,49 @@ bool conv_halo_supported(const ConvGeom& g, const float* bias) {
   static const int on = [] { const char* e = getenv("HIFIHR_CONV_HALO"); return e ? atoi(e) : 1; }();
   return on && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.IC == 64 && g.OC == 64 && g.batch <= 1 && !g.relu && bias == nullptr &&
          g.IH == g.OH && g.IW == g.OW && g.OW % kTW == 0 && (long)g.N * g.OH * g.OW * 64 < (1L << 31);
+}
+
+// slabs of conv_halo_wgrad_kernel: library-owned scratch, one per (device, stream) that ever ran the kernel (weight gradients may run
+// on a side stream beside the main one).  Allocated on first use, never inside a stream capture (the caller falls back then).
+static float* halo_wgrad_scratch(hipStream_t st, size_t bytes) {
+  struct Entry { int dev; hipStream_t st; float* p; size_t bytes; };
+  static Entry tab[16] = {};
+  static int n = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  for (int i = 0; i < n; ++i)
+    if (tab[i].dev == dev && tab[i].st == st && tab[i].bytes >= bytes) return tab[i].p;
+  if (n >= 16) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  tab[n++] = Entry{dev, st, static_cast<float*>(p), bytes};
+  return static_cast<float*>(p);
+}
+
+bool conv_halo_wgrad_supported(const ConvGeom& g) {
+  static const int on = [] { const char* e = getenv("HIFIHR_CONV_HALO_WGRAD"); return e ? atoi(e) : 1; }();
+  return on && conv_halo_supported(g, nullptr) && !g.dgrad;
+}
+
+hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {
+  if (!conv_halo_wgrad_supported(g)) return hipErrorInvalidValue;
+  const float* zeros = conv_halo_zero_page(st);
+  if (zeros == nullptr) return hipErrorNotReady;
+  HaloWgradArgs a;
+  a.x = x; a.dy = dy; a.zeros = zeros; a.N = g.N; a.H = g.OH; a.W = g.OW;
+  a.ctiles = g.OW / kTW;
+  a.total = g.N * a.ctiles * g.OH;
+  int G = halo_cus();
+  a.per = (a.total + G - 1) / G;
+  if (a.per < 4) a.per = 4;
+  G = (a.total + a.per - 1) / a.per;
+  a.slabs = halo_wgrad_scratch(st, (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float));
+  if (a.slabs == nullptr) return hipErrorNotReady;
+  hipLaunchKernelGGL(conv_halo_wgrad_kernel, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+  hipLaunchKernelGGL(conv_halo_wgrad_reduce_kernel, dim3(kTaps * 64 * 64 / 256), dim3(256), 0, st, a.slabs, G, dw);
+  return hipGetLastError();
 }
 
 hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros,

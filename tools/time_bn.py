@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from hifihr_amd._lib import get_lib  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32

@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import os  # noqa: E402
 
 from hifihr_amd._lib import HifihrLib, get_lib  # noqa: E402
@@ -19,6 +19,7 @@ w = torch.randn(64, 3, 3, 64, device=dev) / 24.0
 out = torch.empty(B, H, W, 64, device=dev)
 dx = torch.empty(B, H, W, 64, device=dev)
 scratch = torch.empty(64 * 9 * 64, device=dev)
+dw = torch.zeros(64, 3, 3, 64, device=dev)
 stats = torch.zeros(lib.bn_stats_floats(64), device=dev)
 nb_f = lib.conv2d_workspace_bytes(B, H, W, 64, 64, 3, 3, 1, 1, False)
 nb_b = lib.conv2d_workspace_bytes(B, H, W, 64, 64, 3, 3, 1, 1, True)
@@ -39,6 +40,7 @@ def bench(fn, n=50):
 flop = 2.0 * B * H * W * 64 * 64 * 9
 for name, fn in (("fwd+bnstats", lambda: lib.conv2d_fwd_bnstats(x, w, out, stats, B, H, W, 64, 64, 3, 3, 1, 1, ws=ws)),
                  ("fwd", lambda: lib.conv2d_fwd(x, w, None, out, B, H, W, 64, 64, 3, 3, 1, 1, ws=ws)),
-                 ("dgrad", lambda: lib.conv2d_bwd_data(x, w, dx, scratch, B, H, W, 64, 64, 3, 3, 1, 1, ws=ws))):
+                 ("dgrad", lambda: lib.conv2d_bwd_data(x, w, dx, scratch, B, H, W, 64, 64, 3, 3, 1, 1, ws=ws)),
+                 ("wgrad", lambda: lib.conv2d_bwd_weight(x, out, dw, B, H, W, 64, 64, 3, 3, 1, 1))):
     us = bench(fn)
     print(f"{name:12s} B={B}: {us:7.1f} us  {flop / us / 1e6:6.1f} TFLOP/s  ({flop / us / 1e6 / 157.3:.2f} of the f32 MFMA peak)")

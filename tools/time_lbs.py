@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from hifihr_amd import ops                                    # noqa: E402
 from hifihr_amd.nimble_tables import synthetic_nimble_tables  # noqa: E402
 
