@@ -185,7 +185,7 @@ def conv_path_rooflines(ops, lib, dev, nprof):
         if direction == "wgrad":
             dw = torch.zeros(K_, R_, S_, C_, device=dev)
             us = hip_us(lambda: lib.conv2d_bwd_weight(x, y, dw, N_, H_, W_, C_, K_, R_, S_, st_, pd_))
-            add("conv_wgrad_kernel", per_step, us, flop, nbytes, f"wgrad N{N_} {H_}x{W_} C{C_}->K{K_} {R_}x{S_} s{st_}")
+            add(lib.conv2d_describe(N_, H_, W_, C_, K_, R_, S_, st_, pd_, 2), per_step, us, flop, nbytes, f"wgrad N{N_} {H_}x{W_} C{C_}->K{K_} {R_}x{S_} s{st_}")
             continue
         ws = ops._conv_ws(lib, dev, geom, direction == "dgrad")
         if direction == "fwd":

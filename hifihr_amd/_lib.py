@@ -427,9 +427,10 @@ class HifihrLib:
     def comm_destroy(self, h):
         self.c.hifihr_comm_destroy(h)
 
-    def conv2d_describe(self, N, H, W, C, K, R, S, stride, pad, dgrad):
+    def conv2d_describe(self, N, H, W, C, K, R, S, stride, pad, direction):
+        """direction: 0 / False forward, 1 / True backward-data, 2 backward-weight."""
         buf = ctypes.create_string_buffer(64)
-        self.check(self.c.hifihr_conv2d_describe(N, H, W, C, K, R, S, stride, pad, int(bool(dgrad)), buf, 64), "hifihr_conv2d_describe")
+        self.check(self.c.hifihr_conv2d_describe(N, H, W, C, K, R, S, stride, pad, int(direction), buf, 64), "hifihr_conv2d_describe")
         return buf.value.decode()
 
     def bgemm_describe(self, tn, M, N, K):

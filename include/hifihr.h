@@ -291,9 +291,10 @@ typedef struct hifihr_prep_job {
 } hifihr_prep_job;
 int hifihr_weight_prep(const hifihr_prep_job* jobs_d, int njobs, int blocks_per_job, void* stream);
 
-/* Name of the kernel a bias-free convolution of this shape runs on, as a profiler lists it ("conv_halo_kernel": 3x3 / stride 1 /
- * 64 -> 64 channels with the width a multiple of 14, csrc/conv_halo.hip; else "conv_igemm_kernel"): measurement only. */
-int hifihr_conv2d_describe(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dgrad, char* out, int cap);
+/* Name of the kernel a bias-free convolution of this shape runs on, as a profiler lists it: direction 0 forward, 1 backward-data
+ * ("conv_halo_kernel": 3x3 / stride 1 / 64 -> 64 channels with the width a multiple of 14, csrc/conv_halo.hip; else
+ * "conv_igemm_kernel"), 2 backward-weight ("conv_halo_wgrad_kernel" / "conv_wgrad_kernel").  Measurement only. */
+int hifihr_conv2d_describe(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int direction, char* out, int cap);
 
 /* conv2d_fwd that also accumulates the per-channel sum and sum of squares of y into stats_d (hifihr_bn_stats_floats(K)
  * floats, ALL ZERO on entry: see the self-cleaning rule below) from the accumulator registers, so the batch-norm that
