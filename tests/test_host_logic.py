@@ -130,6 +130,28 @@ def test_oracle_is_independent_of_the_product():
     assert torch.equal(mine(10), theirs(10))
 
 
+def test_step_path_calls_no_library_gemm():
+    """The modules the training step runs through contain no GEMM call that would dispatch to rocBLAS / hipBLASLt (torch.bmm, matmul,
+    mm, einsum, the @ operator, F.linear / nn.Linear.forward, F.conv2d): every matrix product of the step is a hand-written kernel
+    behind the C-ABI (round 1 ended with the Winograd GEMMs on torch.bmm).  Checked on the syntax tree, so comments and docstrings
+    do not count.  hifihr_amd/synth.py (the synthetic-data generator, runs before the timed region) is not on the step's path."""
+    import ast
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hifihr_amd")
+    banned = {"bmm", "matmul", "mm", "einsum", "baddbmm", "addmm", "linear", "conv2d", "tensordot"}
+    for fn in ("models.py", "network.py", "effnet.py", "perceptual.py", "losses.py", "ops.py", "traineval.py", "optim.py", "dist.py", "data.py"):
+        tree = ast.parse(open(os.path.join(root, fn)).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.BinOp) and isinstance(node.op, ast.MatMult):
+                raise AssertionError(f"{fn}:{node.lineno}: '@' matrix product")
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr in banned:
+                owner = node.func.value
+                name = owner.id if isinstance(owner, ast.Name) else getattr(owner, "attr", "")
+                if name == "np":          # 3x3 host-side numpy products of the augmentation parameters: not a device GEMM
+                    continue
+                if name in ("torch", "F", "functional") or node.func.attr in ("bmm", "matmul", "mm", "einsum"):
+                    raise AssertionError(f"{fn}:{node.lineno}: {name}.{node.func.attr}(...)")
+
+
 def test_efficientnet_b3_mirror_vs_reference(golden_dir):
     """The oracle's EfficientNet-b3 restatement reproduces the reference's extract_features (train mode, drop-connect under
     the same seed) forward and backward from name-seeded weights; the product's block table matches SURVEY Appendix A."""
