@@ -552,23 +552,32 @@ bool conv_halo_supported(const ConvGeom& g, const float* bias) {
          g.IH == g.OH && g.IW == g.OW && g.OW % kTW == 0 && (long)g.N * g.OH * g.OW * 64 < (1L << 31);
 }
 
-// slabs of conv_halo_wgrad_kernel: library-owned scratch, one per (device, stream) that ever ran the kernel (weight gradients may run
-// on a side stream beside the main one).  Allocated on first use, never inside a stream capture (the caller falls back then).
+// slabs of conv_halo_wgrad_kernel: library-owned scratch.  Weight gradients may run on a side stream beside the main one and the
+// captured step runs on yet another, so a device owns a small POOL of slab buffers, all allocated at the first (eager) use, and a stream
+// is bound to a free one the first time it shows up -- which needs no allocation and is therefore legal inside a stream capture.
 static float* halo_wgrad_scratch(hipStream_t st, size_t bytes) {
-  struct Entry { int dev; hipStream_t st; float* p; size_t bytes; };
-  static Entry tab[16] = {};
-  static int n = 0;
+  constexpr int kPool = 3;
+  struct Dev { bool ready; size_t bytes; float* buf[kPool]; hipStream_t owner[kPool]; int used; };
+  static Dev devs[16] = {};
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  for (int i = 0; i < n; ++i)
-    if (tab[i].dev == dev && tab[i].st == st && tab[i].bytes >= bytes) return tab[i].p;
-  if (n >= 16) return nullptr;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-  void* p = nullptr;
-  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-  tab[n++] = Entry{dev, st, static_cast<float*>(p), bytes};
-  return static_cast<float*>(p);
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  Dev& d = devs[dev];
+  if (!d.ready) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    for (int i = 0; i < kPool; ++i) {
+      void* p = nullptr;
+      if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+      d.buf[i] = static_cast<float*>(p);
+    }
+    d.bytes = bytes; d.used = 0; d.ready = true;
+  }
+  if (bytes > d.bytes) return nullptr;
+  for (int i = 0; i < d.used; ++i)
+    if (d.owner[i] == st) return d.buf[i];
+  if (d.used >= kPool) return nullptr;
+  d.owner[d.used] = st;
+  return d.buf[d.used++];
 }
 
 bool conv_halo_wgrad_supported(const ConvGeom& g) {
