@@ -26,6 +26,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "hifihr_internal.h"
 #include "lds_dma.h"
@@ -721,6 +722,181 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void bgemm_nt_sk_kernel(BgemmArgs
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Persistent row-share NT form: C[p][m][n] = sum_k A[p][m][k] B[p][n][k], N a multiple of 128.
+// What conv_halo_kernel (csrc/conv_halo.hip) showed for the layer-1 convolution carries over to the Winograd products: one workgroup per
+// CU that walks an EQUAL share of the work as one continuous chunk stream -- its loader waves run three chunks ahead ACROSS tile
+// boundaries, so no tile pays a pipeline fill or drain -- beats both the per-tile grid (3.06 rounds of 784 tiles, a fill and a drain
+// per 4-16 chunk tile) and the stream-K split above (tiles shared through slabs and flags).  The share is a range of the flattened
+// (problem p, 128-column tile, row) space, cut into tiles of up to 128 rows (the last one of a share may be shorter: the MFMA waves
+// split the COLUMNS of a tile, 32 each, and take all of its 16-row blocks, so a short tile simply has fewer blocks); whole tiles
+// only: nothing is exchanged between workgroups and nothing needs a workspace.  LDS: 4 stages x (A 128x32 + B 128x32) = 128 KB.
+// ------------------------------------------------------------------------------------------------
+struct RowsTile { int p, nt, m0, rows; };
+__device__ __forceinline__ RowsTile rows_tile_at(const BgemmArgs& a, long cur, long end) {
+  const long col = cur / a.M;                                // (p, nt) pair
+  const int m0 = (int)(cur - col * a.M);
+  const int p = (int)(col / a.tiles_n), nt = (int)(col - (long)p * a.tiles_n);
+  const long lim = min((long)a.M - m0, end - cur);
+  return RowsTile{p, nt, m0, (int)min(128L, lim)};
+}
+
+__global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long per) {
+  constexpr int STAGE = 256 * 32;                            // floats per stage: A rows 0..127, B rows 128..255
+  __shared__ __attribute__((aligned(1024))) float lds[4 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const long total = (long)a.batch * a.tiles_n * a.M;
+  const long s_lo = (long)wg * per, s_hi = min(s_lo + per, total);
+  if (s_lo >= s_hi) return;                                  // (uniform)
+  const int nch = a.K / 32;
+  int ntiles = 0;
+  for (long cur = s_lo; cur < s_hi; cur += rows_tile_at(a, cur, s_hi).rows) ++ntiles;
+  const int nchunks = ntiles * nch;
+
+  if (wave >= 4) {
+    // ---------------- loader: piece q = l + 4 i (i < 8) of a chunk: q < 16 rows 8 q .. + 7 of A, else rows 8 (q - 16) .. of B ----------------
+    const int l = wave - 4;
+    long cur = s_lo;
+    RowsTile t = rows_tile_at(a, cur, s_hi);
+    const float* src[8];
+    auto bind = [&](const RowsTile& tt) {                    // per-lane source row of every piece for this tile (k offset added per chunk)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = l + 4 * i;
+        const bool isA = q < 16;
+        const int row = 8 * (q & 15) + (lane >> 3);
+        const int seg = (lane & 7) ^ ((row >> 1) & 7);
+        if (isA) src[i] = a.A + (size_t)tt.p * a.sa + (size_t)(tt.m0 + min(row, tt.rows - 1)) * a.lda + seg * 4;   // rows past the tile: discarded
+        else src[i] = a.B + (size_t)tt.p * a.sb + (size_t)(tt.nt * 128 + row) * a.ldb + seg * 4;
+      }
+    };
+    bind(t);
+    int li = 0, lc = 0;                                      // tile / chunk-in-tile the NEXT issue belongs to
+    auto issue_next = [&](int gc) {
+      float* base = lds + (gc & 3) * STAGE;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) HIFIHR_GLDS16(src[i] + lc * 32, base + 256 * (l + 4 * i), lane);
+      if (++lc == nch) {
+        lc = 0;
+        cur += t.rows;
+        if (++li < ntiles) { t = rows_tile_at(a, cur, s_hi); bind(t); }
+      }
+    };
+    issue_next(0);
+    if (nchunks > 1) issue_next(1);
+    if (nchunks > 2) issue_next(2);
+    if (nchunks > 2) HIFIHR_WAIT_VM(8); else HIFIHR_WAIT_VM(0);      // chunks 0 and 1 landed
+    HIFIHR_RAW_BARRIER();                                    // barrier -1
+    for (int gc = 0; gc < nchunks; ++gc) {
+      if (gc + 3 < nchunks) { issue_next(gc + 3); HIFIHR_WAIT_VM(8); }   // chunk gc + 2 landed; only chunk gc + 3's pieces in flight
+      else HIFIHR_WAIT_VM(0);
+      HIFIHR_RAW_BARRIER();                                  // barrier gc
+    }
+    return;
+  }
+
+  // ---------------- MFMA waves: wave w = columns 32 w .. 32 w + 31 of the tile, every 16-row block ----------------
+  const int r = lane & 15, g = lane >> 4;
+  const char* const lds_b = reinterpret_cast<const char*>(lds);
+  int aoff[2], boff[2];                                      // lane part of the fragment addresses (h = 0, 1); + 2048 per row block
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int sw = ((g + 4 * h) ^ ((r >> 1) & 7)) * 16;
+    aoff[h] = r * 128 + sw;
+    boff[h] = (128 + 32 * wave + r) * 128 + sw;
+  }
+  HIFIHR_RAW_BARRIER();                                      // barrier -1
+  long cur = s_lo;
+  int gc = 0;
+  auto run_tile = [&](auto nbc, const RowsTile& t) {
+    constexpr int NB = decltype(nbc)::value;
+    float fm[2][NB][4], fn[2][2][4];
+    auto read_half = [&](int gcc, int h, int slot) {
+      const char* st = lds_b + (gcc & 3) * (STAGE * 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(st + boff[h] + i * 2048);
+        fn[slot][i][0] = v.x; fn[slot][i][1] = v.y; fn[slot][i][2] = v.z; fn[slot][i][3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(st + aoff[h] + j * 2048);
+        fm[slot][j][0] = v.x; fm[slot][j][1] = v.y; fm[slot][j][2] = v.z; fm[slot][j][3] = v.w;
+      }
+    };
+    floatx4 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    auto mfma_half = [&](int slot) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fn[slot][i][k], fm[slot][j][k], acc[i][j], 0, 0, 0);
+    };
+    auto touch = [&]() {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        HIFIHR_TOUCH(fn[0][0][k]); HIFIHR_TOUCH(fn[0][1][k]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) HIFIHR_TOUCH(fm[0][j][k]);
+      }
+    };
+    auto interleave = [&]() {                                // NB + 2 LDS reads of the next half between the 8 NB MFMAs of this one
+#pragma unroll
+      for (int i = 0; i < NB + 2; ++i) {
+        HIFIHR_SCHED_GROUP(0x008, NB >= 4 ? 4 : 2);
+        HIFIHR_SCHED_GROUP(0x100, 1);
+        HIFIHR_SCHED_GROUP(0x002, 1);
+      }
+      HIFIHR_SCHED_GROUP(0x008, 8 * NB - (NB >= 4 ? 4 : 2) * (NB + 2) > 0 ? 8 * NB - (NB >= 4 ? 4 : 2) * (NB + 2) : 0);
+    };
+    read_half(gc, 0, 0);
+    touch();
+    for (int c = 0; c < nch; ++c, ++gc) {
+      read_half(gc, 1, 1);
+      mfma_half(0);
+      interleave();
+      HIFIHR_PIN();
+      read_half(gc + 1, 0, 0);                               // (landed: barrier gc - 1; past the tile's last chunk: the next tile's first, or a
+      mfma_half(1);                                          //  stale stage that is never used) -- unconditional, see bgemm_ws_kernel
+      interleave();
+      HIFIHR_PIN();
+      touch();
+      HIFIHR_RAW_BARRIER();                                  // barrier gc
+    }
+    // register e of lane (r, g) of block (i, j) = C[m0 + 16 j + r][128 nt + 32 wave + 16 i + 4 g + e]
+    float* C = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int m = 16 * j + r;
+      if (m < t.rows) {
+        float* row = C + (size_t)(t.m0 + m) * a.ldc;
+        *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
+        *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
+      }
+    }
+  };
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const RowsTile t = rows_tile_at(a, cur, s_hi);
+    cur += t.rows;
+    switch ((t.rows + 15) >> 4) {
+      case 8: run_tile(std::integral_constant<int, 8>{}, t); break;
+      case 7: run_tile(std::integral_constant<int, 7>{}, t); break;
+      case 6: run_tile(std::integral_constant<int, 6>{}, t); break;
+      case 5: run_tile(std::integral_constant<int, 5>{}, t); break;
+      case 4: run_tile(std::integral_constant<int, 4>{}, t); break;
+      case 3: run_tile(std::integral_constant<int, 3>{}, t); break;
+      case 2: run_tile(std::integral_constant<int, 2>{}, t); break;
+      default: run_tile(std::integral_constant<int, 1>{}, t); break;
+    }
+  }
+}
+
 static int gemm_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -756,6 +932,12 @@ static void tn_tile(int M, int N, int* bm, int* bn) {
 
 size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch);
 
+// the persistent row-share kernel serves every NT product whose N is a multiple of 128 (HIFIHR_GEMM_ROWS=0: the older kernels)
+static bool nt_rows(int N) {
+  static const int on = [] { const char* e = getenv("HIFIHR_GEMM_ROWS"); return e ? atoi(e) : 1; }();
+  return on && N % 128 == 0 && getenv("HIFIHR_GEMM_NT_TILE") == nullptr;
+}
+
 // which kernel instantiation a shape runs on, as rocprof names it (bench.py groups its roofline lines by this)
 void bgemm_describe(int tn, int M, int N, int K, char* out, int cap) {
   int bm, bn;
@@ -768,6 +950,7 @@ void bgemm_describe(int tn, int M, int N, int K, char* out, int cap) {
     if ((e = getenv("HIFIHR_GEMM_NT_TILE")) != nullptr) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (N % bn) bn = 64; }
   }
   const int nload = gemm_ws_loaders();
+  if (!tn && nt_rows(N)) { snprintf(out, cap, "bgemm_nt_rows_kernel"); return; }
   if (!tn && bm == 128 && bn == 128 && nload > 0 && bgemm_nt_workspace_bytes(M, N, K, 16) > 0) snprintf(out, cap, "bgemm_nt_sk_kernel<%d>", nload == 2 ? 2 : 4);
   else if (bm == 128 && bn == 128 && nload > 0) snprintf(out, cap, "bgemm_ws_kernel<128, 128, %s, %d>", tn ? "true" : "false", nload == 1 ? 1 : nload == 4 ? 4 : 2);
   else snprintf(out, cap, "%s<%d, %d>", tn ? "bgemm_tn_kernel" : "bgemm_nt_kernel", bm, bn);
@@ -782,6 +965,7 @@ static size_t sk_flag_bytes(int G) { return (size_t)((G + 1) * 4 * sizeof(unsign
 // kernel that needs none)
 size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch) {
   if (!bgemm_nt_supported(M, N, K) || batch <= 0 || gemm_ws_loaders() <= 0) return 0;
+  if (nt_rows(N)) return 0;                    // whole tiles only: nothing is exchanged between workgroups
   if (const char* e = getenv("HIFIHR_GEMM_SK")) { if (atoi(e) == 0) return 0; }
   int bm, bn;
   nt_tile(M, N, K, &bm, &bn);
@@ -804,6 +988,16 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
   BgemmArgs a{};
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
   a.sa = (long)M * K; a.sb = (long)N * K; a.sc = (long)M * N; a.batch = batch;
+  if (nt_rows(N)) {
+    a.tiles_n = N / 128; a.tiles_m = (M + 127) / 128; a.splits = 1; a.cps = K / 32; a.sc_split = 0;
+    const long total = (long)batch * a.tiles_n * M;
+    const int cus = gemm_cus();
+    long per = (total + cus - 1) / cus;
+    if (per < 16) per = 16;
+    const int G = (int)((total + per - 1) / per);
+    hipLaunchKernelGGL(bgemm_nt_rows_kernel, dim3(G), dim3(512), 0, st, a, per);
+    return hipGetLastError();
+  }
   int bm, bn;
   nt_tile(M, N, K, &bm, &bn);
   if (const char* e = getenv("HIFIHR_GEMM_NT_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (N % bn) bn = 64; }

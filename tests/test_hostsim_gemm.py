@@ -45,3 +45,12 @@ def test_bgemm_persistent_balanced_form(hostsim_lib, ws, monkeypatch):
     assert kc.bgemm_case(hostsim_lib, "cpu", 300, 128, 96, 3, seed=ws) == 0         # 9 tiles < 3 rounds: one workgroup per tile
     monkeypatch.setenv("HIFIHR_GEMM_SK", "0")
     assert kc.bgemm_case(hostsim_lib, "cpu", 300, 128, 96, 5, seed=ws) == 0         # switched off
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(300, 256, 96, 3), (50, 128, 32, 5), (129, 384, 64, 2), (17, 128, 160, 9), (1000, 128, 32, 1)])
+def test_bgemm_nt_row_shares(hostsim_lib, M, N, K, batch):
+    """bgemm_nt_rows_kernel (N % 128 == 0, the default NT path): persistent workgroups (4 on the emulator) over equal shares of the
+    (problem, column tile, row) space -- shares that end inside a tile (short tiles with 1..8 row blocks), that cross column-tile and
+    problem boundaries, and chunk streams that run across tile boundaries."""
+    assert hostsim_lib.bgemm_describe(False, M, N, K) == "bgemm_nt_rows_kernel"
+    assert kc.bgemm_case(hostsim_lib, "cpu", M, N, K, batch, seed=M + K) == 0        # no workspace

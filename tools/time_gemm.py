@@ -51,6 +51,11 @@ for H, C, K in shapes:
         clean = "" if wsk is None or float(wsk.abs().max()) == 0.0 else " WS-DIRTY"
         line += f" {tile // 1000}x{tile % 1000}/ws{ws_}/{'sk' if sk else 'tile'}: {t:6.1f} us ({gf / t * 1e3:5.1f} TF, err {err:.1e}{clean})"
     setenv("HIFIHR_GEMM_NT_TILE", None); setenv("HIFIHR_GEMM_WS", None); setenv("HIFIHR_GEMM_SK", None)
+    M.fill_(7.0)                                    # the default path: bgemm_nt_rows_kernel where N % 128 == 0
+    lib.wino_gemm(V, U, M, B, H, H, C, K)
+    err = float((M - ref).abs().max() / ref.abs().max())
+    t = timeit(lambda: lib.wino_gemm(V, U, M, B, H, H, C, K))
+    line += f" || default = {lib.bgemm_describe(False, T, K, C)}: {t:6.1f} us ({gf / t * 1e3:5.1f} TF, err {err:.1e})"
     print(line, flush=True)
 
 print("== TN: dU[16][K][C] = Y'[16][T][K]^T . V[16][T][C]   (slabs, summed by the dw transform)")
