@@ -742,6 +742,10 @@ __device__ __forceinline__ RowsTile rows_tile_at(const BgemmArgs& a, long cur, l
 }
 
 __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long per) {
+#if defined(HIFIHR_GEMM_STAMP)       // [0] cycles in the chunk loops, [1] 100 MHz ticks of them, [2] chunks, [3] at barriers, [4] workgroups,
+  const unsigned long long st_entry = __builtin_amdgcn_s_memtime();      // [5] entry -> exit, [6] epilogues, [7] entry -> barrier -1
+  unsigned long long st_loop = 0, st_real = 0, st_bar = 0, st_epi = 0, st_first = 0;
+#endif
   constexpr int STAGE = 256 * 32;                            // floats per stage: A rows 0..127, B rows 128..255
   __shared__ __attribute__((aligned(1024))) float lds[4 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -807,6 +811,9 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
     boff[h] = (128 + 32 * wave + r) * 128 + sw;
   }
   HIFIHR_RAW_BARRIER();                                      // barrier -1
+#if defined(HIFIHR_GEMM_STAMP)
+  st_first = __builtin_amdgcn_s_memtime() - st_entry;
+#endif
   long cur = s_lo;
   int gc = 0;
   auto run_tile = [&](auto nbc, const RowsTile& t) {
@@ -857,6 +864,9 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
     };
     read_half(gc, 0, 0);
     touch();
+#if defined(HIFIHR_GEMM_STAMP)
+    const unsigned long long l0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int c = 0; c < nch; ++c, ++gc) {
       read_half(gc, 1, 1);
       mfma_half(0);
@@ -867,8 +877,19 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
       interleave();
       HIFIHR_PIN();
       touch();
+#if defined(HIFIHR_GEMM_STAMP)
+      HIFIHR_TOUCH(acc[0][0][0]);
+      const unsigned long long b0 = __builtin_amdgcn_s_memtime();
+#endif
       HIFIHR_RAW_BARRIER();                                  // barrier gc
+#if defined(HIFIHR_GEMM_STAMP)
+      st_bar += __builtin_amdgcn_s_memtime() - b0;
+#endif
     }
+#if defined(HIFIHR_GEMM_STAMP)
+    const unsigned long long l1 = __builtin_amdgcn_s_memtime();
+    st_loop += l1 - l0; st_real += __builtin_amdgcn_s_memrealtime() - r0;
+#endif
     // register e of lane (r, g) of block (i, j) = C[m0 + 16 j + r][128 nt + 32 wave + 16 i + 4 g + e]
     float* C = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
 #pragma unroll
@@ -880,6 +901,9 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
         *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
       }
     }
+#if defined(HIFIHR_GEMM_STAMP)
+    st_epi += __builtin_amdgcn_s_memtime() - l1;
+#endif
   };
   for (int ti = 0; ti < ntiles; ++ti) {
     const RowsTile t = rows_tile_at(a, cur, s_hi);
@@ -895,6 +919,14 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
       default: run_tile(std::integral_constant<int, 1>{}, t); break;
     }
   }
+#if defined(HIFIHR_GEMM_STAMP)
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    atomicAdd(&g_gemm_stamp[0], st_loop); atomicAdd(&g_gemm_stamp[1], st_real); atomicAdd(&g_gemm_stamp[2], (unsigned long long)nchunks);
+    atomicAdd(&g_gemm_stamp[3], st_bar); atomicAdd(&g_gemm_stamp[4], 1ull); atomicAdd(&g_gemm_stamp[5], __builtin_amdgcn_s_memtime() - st_entry);
+    atomicAdd(&g_gemm_stamp[6], st_epi); atomicAdd(&g_gemm_stamp[7], st_first);
+  }
+#endif
 }
 
 static int gemm_cus() {

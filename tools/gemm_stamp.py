@@ -10,7 +10,7 @@ lib = HifihrLib(os.path.join(R, "tools", "_probe", "libhifihr_gemm_stamp.so"))
 read = lib.c.hifihr_gemm_stamp_read
 read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 B = 32
-for ws_ in (2, 4):
+for ws_ in (4,):
     os.environ["HIFIHR_GEMM_WS"] = str(ws_)
     for kind, H, C, K in (("nt", 14, 512, 512), ("tn", 14, 512, 512), ("nt", 14, 256, 256), ("tn", 14, 256, 256), ("nt", 28, 128, 128)):
         T = B * (H // 2) ** 2
@@ -33,6 +33,10 @@ for ws_ in (2, 4):
         v = list(buf)
         us = e0.elapsed_time(e1) / n * 1e3
         ch, waves = max(1, v[2]), max(1, v[4])
+        if v[0] == 0:
+            print(f'ws{ws_} {kind} H={H} C={C} K={K}: {us:.1f} us/launch; no stamps (raw {v}); kernel: {lib.bgemm_describe(kind == "tn", T if kind == "nt" else K, K if kind == "nt" else C, C if kind == "nt" else T)}', flush=True)
+            continue
         print(f"ws{ws_} {kind} H={H} C={C} K={K}: {us:.1f} us/launch ({2.0 * 16 * T * C * K / us / 1e6:.1f} TF); wave 0 of {waves // n} workgroups: "
               f"{v[0] / ch:.0f} cycles per chunk (ideal 4096), {v[3] / ch:.0f} of them at the barrier; clock {v[0] / max(1, v[1]) * 100:.0f} MHz; "
-              f"kernel entry -> end {v[5] / waves:.0f} cycles = {v[5] / waves / (v[0] / max(1, v[1]) * 100):.1f} us, main loop {v[0] / waves:.0f}", flush=True)
+              f"kernel entry -> end {v[5] / waves:.0f} cycles = {v[5] / waves / (v[0] / max(1, v[1]) * 100):.1f} us, main loop {v[0] / waves:.0f}"
+              + (f"; rows kernel: epilogues {v[6] / waves:.0f} cycles, entry -> first barrier {v[7] / waves:.0f}" if kind == "nt" else ""), flush=True)
