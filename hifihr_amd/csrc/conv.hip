@@ -798,6 +798,9 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   if (conv_halo_supported(g, bias)) {
     if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_halo(g, src, wgt, dst, stats, zeros, st);
   }
+  if (conv_stem_supported(g, bias)) {
+    if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_stem(g, src, wgt, dst, stats, zeros, st);
+  }
   const bool generic = (g.IC % 16) != 0 || g.R * g.S > 63;
   if (generic && g.dgrad && g.stride != 1) return hipErrorInvalidValue;   // strided dgrad needs source channels % 16 == 0
   int bk = (g.IC % 32 == 0) ? 32 : 16;

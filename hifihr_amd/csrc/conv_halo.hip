@@ -505,6 +505,180 @@ __global__ __launch_bounds__(256) void conv_halo_wgrad_reduce_kernel(const float
   dw[((size_t)k * kTaps + tp) * 64 + c] += s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The stem: 7x7 / stride 2 / pad 3 convolution of the NHWC4 image (3 channels + a zero one) to 64 channels (reference
+// network/res_encoder.py:364-373, conv1 of the vendored ResNet), forward (+ BN statistics).
+// As an implicit GEMM it is M = 401 408 x N = 64 x K = 196 with 16-byte taps: conv_igemm_kernel's generic gather runs it at 52 TFLOP/s
+// (134 us).  Here the whole filter lives in LDS for the life of a persistent workgroup -- [64 n][7 rows][8 tap slots][4 channels], the
+// 8th slot and the 4th channel zero, row pitch padded to 228 floats (58 KB) -- an output tile is the forward kernel's 8 x 14 pixels,
+// its 21 x 33-pixel input halo (12 KB at a 36-pixel pitch) is staged once by LDS-DMA (two buffers, one barrier per tile), and the
+// reduction is ordered (tap row, 4 taps, channel): one ds_read_b128 hands a lane the 4 channels of ONE tap, lane group g of an MFMA
+// k-step takes tap 4 KK + g, and the four MFMAs a b128 feeds are the four channels -- of which the padding channel is skipped, so a
+// tile costs 7 x 2 x 3 MFMAs per row block (294 per wave) against 343 for the dense 7 x 7 x 4 ordering.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kSWP = 228;                        // floats per filter row n in LDS: 7 * 8 * 4 = 224 + 4 (the 16 rows of an operand read spread over all banks)
+constexpr int kSHP = 36;                         // halo pitch in pixels (33 used)
+constexpr int kSHRows = 2 * kTH + 5;             // 21
+constexpr int kSHalo = kSHRows * kSHP * 4;       // floats per halo buffer: 3024 (12 KB)
+constexpr int kSPieces = (kSHalo * 4 + 1023) / 1024;        // 12 LDS-DMA pieces
+constexpr int kSHaloAl = kSPieces * 256;         // floats reserved per buffer (whole pieces)
+struct StemArgs {
+  const float* src;     // [N][IH][IW][4]
+  const float* wgt;     // [64][7][7][4]
+  float* dst;           // [N][OH][OW][64]
+  float* stats;
+  const float* zeros;
+  int N, IH, IW, OH, OW;
+  int ctiles, total, per;
+};
+}  // namespace
+
+__global__ __launch_bounds__(384) void conv_stem_kernel(StemArgs a) {
+  __shared__ __attribute__((aligned(1024))) float lds[64 * kSWP + 2 * kSHaloAl];
+  float* const wl = lds;
+  float* const halo = lds + 64 * kSWP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  HaloArgs sh;                                               // (tile_at reads H, ctiles only)
+  sh.H = a.OH; sh.ctiles = a.ctiles;
+  const int s_lo = wg * a.per, s_hi = min(s_lo + a.per, a.total);
+  int ntiles = 0;
+  for (int cur = s_lo; cur < s_hi; cur += tile_at(sh, cur, s_hi).rows) ++ntiles;
+  // the filter: [n][tr][slot][c] with slot 7 zero; every wave helps.  The 4th channel is the NHWC4 padding in the encoder (its filter
+  // taps are zero and its MFMAs are skipped); a caller with four real channels is detected here and gets all four.
+  __shared__ int c3_any;
+  if (tid == 0) c3_any = 0;
+  __syncthreads();
+  bool c3_mine = false;
+  for (int e = tid; e < 64 * 7 * 8; e += 384) {
+    const int n = e / 56, rem = e - n * 56, tr = rem >> 3, sl = rem & 7;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sl < 7) v = *reinterpret_cast<const float4*>(a.wgt + ((size_t)(n * 7 + tr) * 7 + sl) * 4);
+    c3_mine = c3_mine || v.w != 0.f;
+    *reinterpret_cast<float4*>(wl + n * kSWP + (tr * 8 + sl) * 4) = v;
+  }
+  if (c3_mine) c3_any = 1;
+
+  if (wave >= 4) {
+    // ---------------- loader (2 waves): the halo of the next tile ----------------
+    const int l = wave - 4;
+    auto issue_tile = [&](const Tile& t, int buf) {
+#pragma unroll 2
+      for (int i = 0; i < kSPieces / 2; ++i) {
+        const int q = l + 2 * i;
+        const int hp = 64 * q + lane;                        // halo pixel (16 bytes): row hp / 36, column hp % 36
+        const int hy = hp / kSHP, hx = hp - hy * kSHP;
+        const int iy = 2 * t.y0 - 3 + hy, ix = 2 * t.x0 - 3 + hx;
+        const bool ok = hy < kSHRows && hx < 2 * kTW + 5 && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+        const float* src = ok ? a.src + (((size_t)t.n * a.IH + iy) * a.IW + ix) * 4 : a.zeros;
+        HIFIHR_GLDS16(src, halo + buf * kSHaloAl + 256 * q, lane);
+      }
+    };
+    int cur = s_lo;
+    Tile t = tile_at(sh, cur, s_hi);
+    if (ntiles > 0) issue_tile(t, 0);
+    HIFIHR_WAIT_VM(0);
+    __syncthreads();                                         // barrier -1 (also orders the filter writes above)
+    for (int ti = 0; ti < ntiles; ++ti) {
+      cur += t.rows;
+      if (ti + 1 < ntiles) {
+        t = tile_at(sh, cur, s_hi);
+        issue_tile(t, (ti + 1) & 1);
+      }
+      HIFIHR_WAIT_VM(0);
+      HIFIHR_RAW_BARRIER();                                  // barrier ti
+    }
+    return;
+  }
+
+  // ---------------- MFMA waves: wave w = output channels 16 w .. 16 w + 15 ----------------
+  const int r = lane & 15, g = lane >> 4;
+  int hoff[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int p = 16 * j + r, ty = p / kTW;
+    hoff[j] = ((2 * ty) * kSHP + 2 * (p - ty * kTW) + g) * 16;
+  }
+  const int woff = (16 * wave + r) * (kSWP * 4) + g * 16;
+  const char* const wl_b = reinterpret_cast<const char*>(wl);
+  const char* const halo_b = reinterpret_cast<const char*>(halo);
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                           // barrier -1
+  const bool c3 = c3_any != 0;                               // (uniform)
+  int cur = s_lo;
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const Tile t = tile_at(sh, cur, s_hi);
+    cur += t.rows;
+    const char* const hb = halo_b + (ti & 1) * (kSHaloAl * 4);
+    floatx4 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float4 fw[2], fx[2][7];
+    auto read_step = [&](int st, int slot) {                 // step st = 2 tr + KK
+      const int tr = st >> 1, kk = st & 1;
+      fw[slot] = *reinterpret_cast<const float4*>(wl_b + woff + (tr * 8 + 4 * kk) * 16);
+      const char* hs = hb + (tr * kSHP + 4 * kk) * 16;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) fx[slot][j] = *reinterpret_cast<const float4*>(hs + hoff[j]);
+    };
+    auto mfma_step = [&](int slot) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot].x, fx[slot][j].x, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot].y, fx[slot][j].y, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot].z, fx[slot][j].z, acc[j], 0, 0, 0);
+      if (c3) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot].w, fx[slot][j].w, acc[j], 0, 0, 0);
+      }
+    };
+    auto interleave = [&]() {                                // 8 LDS reads of the next step between the 21 MFMAs of this one
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        HIFIHR_SCHED_GROUP(0x008, 2);
+        HIFIHR_SCHED_GROUP(0x100, 1);
+        HIFIHR_SCHED_GROUP(0x002, 1);
+      }
+      HIFIHR_SCHED_GROUP(0x008, 5);
+    };
+    read_step(0, 0);
+#pragma unroll
+    for (int st = 0; st < 14; st += 2) {
+      read_step(st + 1, 1);
+      mfma_step(0);
+      interleave();
+      HIFIHR_PIN();
+      read_step(st + 2 < 14 ? st + 2 : 13, 0);
+      mfma_step(1);
+      interleave();
+      HIFIHR_PIN();
+    }
+    HIFIHR_RAW_BARRIER();                                    // barrier ti
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int p = 16 * j + r, ty = p / kTW, tx = p - ty * kTW;
+      if (ty < t.rows) {
+        float* o = a.dst + (((size_t)t.n * a.OH + t.y0 + ty) * a.OW + t.x0 + tx) * 64 + 16 * wave + 4 * g;
+        *reinterpret_cast<float4*>(o) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ssum[e] += acc[j][e]; ssq[e] += acc[j][e] * acc[j][e]; }
+      }
+    }
+  }
+  if (a.stats != nullptr) {                                  // (uniform)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      for (int o = 1; o < 16; o <<= 1) { ssum[e] += __shfl_xor(ssum[e], o, 64); ssq[e] += __shfl_xor(ssq[e], o, 64); }
+    if (r == 0) {
+      float* sp = a.stats + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 16 * wave + 4 * g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { atomicAdd(sp + e, ssum[e]); atomicAdd(sp + 64 + e, ssq[e]); }
+    }
+  }
+}
+
 #if defined(HIFIHR_HALO_STAMP)
 }  // namespace hifihr
 extern "C" int hifihr_halo_stamp_read(unsigned long long* out8, int reset) {
@@ -601,6 +775,27 @@ hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float
   if (a.slabs == nullptr) return hipErrorNotReady;
   hipLaunchKernelGGL(conv_halo_wgrad_kernel, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
   hipLaunchKernelGGL(conv_halo_wgrad_reduce_kernel, dim3(kTaps * 64 * 64 / 256), dim3(256), 0, st, a.slabs, G, dw);
+  return hipGetLastError();
+}
+
+bool conv_stem_supported(const ConvGeom& g, const float* bias) {
+  static const int on = [] { const char* e = getenv("HIFIHR_CONV_STEM"); return e ? atoi(e) : 1; }();
+  return on && !g.dgrad && g.R == 7 && g.S == 7 && g.stride == 2 && g.pad == 3 && g.IC == 4 && g.OC == 64 && g.batch <= 1 && !g.relu &&
+         bias == nullptr && g.OW % kTW == 0 && (long)g.N * g.OH * g.OW * 64 < (1L << 31);
+}
+
+hipError_t launch_conv_stem(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st) {
+  if (!conv_stem_supported(g, nullptr) || zeros == nullptr) return hipErrorInvalidValue;
+  StemArgs a;
+  a.src = src; a.wgt = wgt; a.dst = dst; a.stats = stats; a.zeros = zeros;
+  a.N = g.N; a.IH = g.IH; a.IW = g.IW; a.OH = g.OH; a.OW = g.OW;
+  a.ctiles = g.OW / kTW;
+  a.total = g.N * a.ctiles * g.OH;
+  int G = halo_cus();
+  a.per = (a.total + G - 1) / G;
+  if (a.per < 4) a.per = 4;
+  G = (a.total + a.per - 1) / a.per;
+  hipLaunchKernelGGL(conv_stem_kernel, dim3(G), dim3(384), 0, st, a);
   return hipGetLastError();
 }
 

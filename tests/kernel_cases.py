@@ -251,11 +251,13 @@ def adam_case(lib, device, n, wd, steps, grad_scale=0.5, lr=1e-3):
 # ------------------------------------------------------------------------------------------------
 # convolution (NHWC implicit GEMM on the f32 matrix cores) vs plain PyTorch fp32 conv2d
 # ------------------------------------------------------------------------------------------------
-def conv_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0, bias=False, rtol=2e-5):
+def conv_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0, bias=False, rtol=2e-5, zero_last_channel=False):
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(seed)
     x = torch.randn(N, C, H, W, generator=gen)
     w = torch.randn(K, C, R, R, generator=gen) / (C * R * R) ** 0.5
+    if zero_last_channel:                       # the encoder's NHWC4 stem: channel 3 of the image and of the filter is padding
+        x[:, C - 1] = 0.0; w[:, C - 1] = 0.0
     b = torch.randn(K, generator=gen) if bias else None
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     y = F.conv2d(xr, wr, b, stride=stride, padding=pad)

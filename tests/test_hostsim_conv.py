@@ -57,3 +57,16 @@ def test_conv_halo_layer1_shape(hostsim_lib, N, H, W):
 
 def test_conv_halo_bnstats(hostsim_lib):
     kc.conv_bnstats_case(hostsim_lib, "cpu", 2, 12, 14, 64, 64, 3, 1, 1)
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 56, 56), (2, 20, 28), (3, 6, 84)])
+def test_conv_stem_kernel(hostsim_lib, N, H, W):
+    """7x7 / stride 2 / pad 3 on NHWC4 input to 64 channels with the output width a multiple of 14: conv_stem_kernel (filter resident in
+    LDS, halo staged once per tile); shares of 7 rows, partial tiles, 3-row outputs."""
+    assert hostsim_lib.conv2d_describe(N, H, W, 4, 64, 7, 7, 2, 3, 0) == "conv_stem_kernel"
+    kc.conv_case(hostsim_lib, "cpu", N, H, W, 4, 64, 7, 2, 3, seed=H + W)                                # four real channels
+    kc.conv_case(hostsim_lib, "cpu", N, H, W, 4, 64, 7, 2, 3, seed=H + W + 1, zero_last_channel=True)    # the encoder's case: padding channel skipped
+
+
+def test_conv_stem_bnstats(hostsim_lib):
+    kc.conv_bnstats_case(hostsim_lib, "cpu", 2, 28, 56, 4, 64, 7, 2, 3)
