@@ -854,6 +854,10 @@ hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy,
     const hipError_t e = launch_conv_halo_wgrad(g, x, dy, dw, st);
     if (e != hipErrorNotReady) return e;
   }
+  if (conv_stem_wgrad_supported(g)) {
+    const hipError_t e = launch_conv_stem_wgrad(g, x, dy, dw, st);
+    if (e != hipErrorNotReady) return e;
+  }
   // 0: 128x128 (4 resident per CU), 1: 64x128, n >= 2: 64x64 with n workgroups per CU.  Measured at B = 32 (tools/time_wgrad.py):
   // the atomic epilogue moves (workgroups x tile bytes), so below 512 output channels the 64x64 tile (a quarter of the atomic
   // volume, 8 per CU) wins by 5-15 %; the 29.6 GFLOP layer-4 shapes keep the 128x128 tile (100 vs 81 TF).

@@ -378,23 +378,35 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_wgrad_kernel(HaloWgr
   if (wave >= 4) {
     // ---------------- loader ----------------
     const int l = wave - 4;
+    // what a lane moves in piece i does not depend on the tile: packed once (halo: dy << 12 | dx << 8 | segment or -1; dy tile:
+    // row << 16 | column << 8 | segment), so a tile costs a few adds per piece instead of two divisions
+    int pk[kWgPer];
+#pragma unroll
+    for (int i = 0; i < kWgPer; ++i) {
+      const int q = l + kNL * i;
+      if (q < kHaloPieces) {
+        const int o = q * 1024 + lane * 16;
+        const int hp = o / (kPixF * 4), within = o - hp * (kPixF * 4);
+        pk[i] = (hp < kHaloPix && within < 256) ? ((hp >> 4) << 12) | ((hp & 15) << 8) | (within >> 4) : -1;
+      } else {
+        const int p = 4 * (q - kHaloPieces) + (lane >> 4), ty = p / kTW;
+        pk[i] = (ty << 16) | ((p - ty * kTW) << 8) | (lane & 15);
+      }
+    }
     auto issue_tile = [&](const Tile& t, int buf) {
       float* base = lds + buf * kWgBuf;
-#pragma unroll 2
+      const float* ximg = a.x + (size_t)t.n * a.H * a.W * 64;
+      const float* dyt = a.dy + (((size_t)t.n * a.H + t.y0) * a.W + t.x0) * 64;
+#pragma unroll
       for (int i = 0; i < kWgPer; ++i) {
         const int q = l + kNL * i;
         if (q < kHaloPieces) {                               // (uniform) halo piece: see conv_halo_kernel
-          const int o = q * 1024 + lane * 16;
-          const int hp = o / (kPixF * 4), within = o - hp * (kPixF * 4);
-          const int iy = t.y0 - 1 + (hp >> 4), ix = t.x0 - 1 + (hp & 15);
-          const bool ok = hp < kHaloPix && within < 256 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-          const float* src = ok ? a.x + (((size_t)t.n * a.H + iy) * a.W + ix) * 64 + (within >> 2) : a.zeros;
-          HIFIHR_GLDS16(src, base + 256 * q, lane);
+          const int iy = t.y0 - 1 + (pk[i] >> 12), ix = t.x0 - 1 + ((pk[i] >> 8) & 15);
+          const bool ok = pk[i] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          HIFIHR_GLDS16(ok ? ximg + (iy * a.W + ix) * 64 + (pk[i] & 15) * 4 : a.zeros, base + 256 * q, lane);
         } else if (q < kWgPieces) {                          // dy piece: tile pixels 4 (q - 43) .. + 3, rows past the tile read zeros
-          const int p = 4 * (q - kHaloPieces) + (lane >> 4);
-          const int ty = p / kTW, tx = p - ty * kTW;
-          const float* src = ty < t.rows ? a.dy + (((size_t)t.n * a.H + t.y0 + ty) * a.W + t.x0 + tx) * 64 + (lane & 15) * 4 : a.zeros;
-          HIFIHR_GLDS16(src, base + kHalo + 256 * (q - kHaloPieces), lane);
+          const int ty = pk[i] >> 16, tx = (pk[i] >> 8) & 255;
+          HIFIHR_GLDS16(ty < t.rows ? dyt + (ty * a.W + tx) * 64 + (pk[i] & 255) * 4 : a.zeros, base + kHalo + 256 * (q - kHaloPieces), lane);
         }
       }
     };
@@ -563,16 +575,19 @@ __global__ __launch_bounds__(384) void conv_stem_kernel(StemArgs a) {
   if (wave >= 4) {
     // ---------------- loader (2 waves): the halo of the next tile ----------------
     const int l = wave - 4;
+    int pk[kSPieces / 2];                                    // (row << 8 | column) of this lane's pixel in piece i, -1: padding of the LDS image
+#pragma unroll
+    for (int i = 0; i < kSPieces / 2; ++i) {
+      const int hp = 64 * (l + 2 * i) + lane, hy = hp / kSHP, hx = hp - hy * kSHP;
+      pk[i] = (hy < kSHRows && hx < 2 * kTW + 5) ? (hy << 8) | hx : -1;
+    }
     auto issue_tile = [&](const Tile& t, int buf) {
-#pragma unroll 2
+      const float* ximg = a.src + (size_t)t.n * a.IH * a.IW * 4;
+#pragma unroll
       for (int i = 0; i < kSPieces / 2; ++i) {
-        const int q = l + 2 * i;
-        const int hp = 64 * q + lane;                        // halo pixel (16 bytes): row hp / 36, column hp % 36
-        const int hy = hp / kSHP, hx = hp - hy * kSHP;
-        const int iy = 2 * t.y0 - 3 + hy, ix = 2 * t.x0 - 3 + hx;
-        const bool ok = hy < kSHRows && hx < 2 * kTW + 5 && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-        const float* src = ok ? a.src + (((size_t)t.n * a.IH + iy) * a.IW + ix) * 4 : a.zeros;
-        HIFIHR_GLDS16(src, halo + buf * kSHaloAl + 256 * q, lane);
+        const int iy = 2 * t.y0 - 3 + (pk[i] >> 8), ix = 2 * t.x0 - 3 + (pk[i] & 255);
+        const bool ok = pk[i] >= 0 && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+        HIFIHR_GLDS16(ok ? ximg + (iy * a.IW + ix) * 4 : a.zeros, halo + buf * kSHaloAl + 256 * (l + 2 * i), lane);
       }
     };
     int cur = s_lo;
@@ -679,6 +694,201 @@ __global__ __launch_bounds__(384) void conv_stem_kernel(StemArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The stem's weight gradient: dW[k][tr][s][c] += sum over output pixels dy[p][k] x[2 p + (tr, s) - 3][c].
+// Same persistent tiling as conv_stem_kernel, the x halo (22 rows here) and the dy tile staged once per tile.  An MFMA k-step is 4
+// output pixels; operand "A" = dy (lane r: channel 16 w + r of the wave's 16), operand "B" = one ds_read_b128 of x per (pixel, PAIR of
+// tap rows): lane r of a pair reads the 4 channels of tap (2 pair + r / 8, r % 8), and the b128's components feed the MFMAs of
+// channels 0, 1, 2 -- the padding channel is skipped, tap slot 7 and tap row 7 are never stored.  12 MFMAs per 5 LDS reads; the
+// wave's 16 x (4 pairs x 3 channels x 16 slots) result stays in 12 accumulator tiles for its whole share and goes to a per-workgroup
+// slab at the end; conv_stem_wgrad_reduce_kernel adds the slabs in order (bit-reproducible; conv_wgrad_kernel used float atomics).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kSWRows = 2 * kTH + 6;             // halo rows incl. the one tap row 7 of the last pair would touch: 22
+constexpr int kSWHalo = kSWRows * kSHP * 4;      // 3168 floats
+constexpr int kSWPieces = (kSWHalo * 4 + 1023) / 1024;      // 13
+constexpr int kSWHaloAl = kSWPieces * 256;       // 3328 floats
+constexpr int kSWBuf = kSWHaloAl + kDyT;         // floats per buffer: halo + dy tile
+constexpr int kSWAll = kSWPieces + kTH * kTW / 4;            // LDS-DMA pieces per tile: 13 + 28
+struct StemWgradArgs {
+  const float* x;       // [N][IH][IW][4]
+  const float* dy;      // [N][OH][OW][64]
+  float* slabs;         // [workgroups][64][7][7][4]
+  const float* zeros;
+  int N, IH, IW, OH, OW;
+  int ctiles, total, per;
+};
+}  // namespace
+
+__global__ __launch_bounds__(512) void conv_stem_wgrad_kernel(StemWgradArgs a) {
+  __shared__ __attribute__((aligned(1024))) float lds[2 * kSWBuf];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  HaloArgs sh;
+  sh.H = a.OH; sh.ctiles = a.ctiles;
+  const int s_lo = wg * a.per, s_hi = min(s_lo + a.per, a.total);
+  int ntiles = 0;
+  for (int cur = s_lo; cur < s_hi; cur += tile_at(sh, cur, s_hi).rows) ++ntiles;
+
+  if (wave >= 4) {
+    // ---------------- loader (4 waves: 41 pieces per tile, each with per-lane address arithmetic -- two waves were the bottleneck) ----------------
+    const int l = wave - 4;
+    // what a lane moves in piece i does not depend on the tile: packed once -- halo pieces (row << 8 | column, -1: padding of the
+    // image in LDS), dy pieces (tile row << 16 | tile column << 8 | 16-byte segment) -- so a tile costs a few adds per piece
+    constexpr int NPW = (kSWAll + 3) / 4;
+    int pk[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int q = l + 4 * i;
+      if (q < kSWPieces) {
+        const int hp = 64 * q + lane, hy = hp / kSHP, hx = hp - hy * kSHP;
+        pk[i] = (hy < kSWRows && hx < 2 * kTW + 5) ? (hy << 8) | hx : -1;
+      } else {
+        const int p = 4 * (q - kSWPieces) + (lane >> 4), ty = p / kTW;
+        pk[i] = (ty << 16) | ((p - ty * kTW) << 8) | (lane & 15);
+      }
+    }
+    auto issue_tile = [&](const Tile& t, int buf) {
+      float* base = lds + buf * kSWBuf;
+      const float* ximg = a.x + (size_t)t.n * a.IH * a.IW * 4;
+      const float* dyt = a.dy + (((size_t)t.n * a.OH + t.y0) * a.OW + t.x0) * 64;
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) {
+        const int q = l + 4 * i;
+        if (q < kSWPieces) {                                 // (uniform) halo piece: 64 pixels of 16 bytes
+          const int iy = 2 * t.y0 - 3 + (pk[i] >> 8), ix = 2 * t.x0 - 3 + (pk[i] & 255);
+          const bool ok = pk[i] >= 0 && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+          HIFIHR_GLDS16(ok ? ximg + (iy * a.IW + ix) * 4 : a.zeros, base + 256 * q, lane);
+        } else if (q < kSWAll) {                             // dy piece: 4 tile pixels; rows past the tile read zeros
+          const int ty = pk[i] >> 16, tx = (pk[i] >> 8) & 255;
+          HIFIHR_GLDS16(ty < t.rows ? dyt + (ty * a.OW + tx) * 64 + (pk[i] & 255) * 4 : a.zeros, base + kSWHaloAl + 256 * (q - kSWPieces), lane);
+        }
+      }
+    };
+    int cur = s_lo;
+    Tile t = tile_at(sh, cur, s_hi);
+    if (ntiles > 0) issue_tile(t, 0);
+    HIFIHR_WAIT_VM(0);
+    HIFIHR_RAW_BARRIER();                                    // barrier -1
+    for (int ti = 0; ti < ntiles; ++ti) {
+      cur += t.rows;
+      if (ti + 1 < ntiles) {
+        t = tile_at(sh, cur, s_hi);
+        issue_tile(t, (ti + 1) & 1);
+      }
+      HIFIHR_WAIT_VM(0);
+      HIFIHR_RAW_BARRIER();                                  // barrier ti
+    }
+    return;
+  }
+
+  // ---------------- MFMA waves: wave w = dy channels 16 w .. 16 w + 15 ----------------
+  const int r = lane & 15, g = lane >> 4;
+  floatx4 acc[4][4];                                         // [pair][channel]; channel 3 only moves when the input's 4th channel is not padding
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[pr][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const char* const lds_b = reinterpret_cast<const char*>(lds);
+  const int dy_lane = kSWHaloAl * 4 + (16 * wave + r) * 4;
+  const int hx_lane = ((r >> 3) * kSHP + (r & 7)) * 16;      // this lane's tap of a pair: (row r / 8, slot r % 8)
+  // 4-pixel groups repeat with period 7 (two output rows = 28 pixels): per-lane byte offsets of group q's pixel inside a 2-row block,
+  // so the inner loop has no division and is fully unrolled (84 MFMAs per block)
+  int gdy[7], ghx[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int tp = 4 * q + g, ty = tp / kTW;
+    gdy[q] = dy_lane + tp * 256;
+    ghx[q] = hx_lane + ((2 * ty) * kSHP + 2 * (tp - ty * kTW)) * 16;
+  }
+  HIFIHR_RAW_BARRIER();                                      // barrier -1
+  int cur = s_lo;
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const Tile t = tile_at(sh, cur, s_hi);
+    cur += t.rows;
+    const char* const buf = lds_b + (ti & 1) * (kSWBuf * 4);
+    const int nblk = (t.rows + 1) >> 1;                      // 2-row blocks (dy is zero past the tile's rows)
+    float fy[2];
+    float4 fx[2][4];
+    auto read_group = [&](int blk, int q, int slot) {        // (q: compile-time)
+      const char* base = buf + blk * (2 * kTW * 256);        // dy: 28 pixels per block
+      fy[slot] = *reinterpret_cast<const float*>(base + gdy[q]);
+      const char* hb = buf + blk * (4 * kSHP * 16) + ghx[q];  // halo: 4 input rows per block
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) fx[slot][pr] = *reinterpret_cast<const float4*>(hb + (2 * pr) * kSHP * 16);
+    };
+    // the 4th input channel is the NHWC4 padding in the encoder (exact zeros: its products are skipped); a caller with four real
+    // channels gets them: every wave scans the tile's halo once (13 LDS reads per lane) and takes the 4-channel loop if any is set
+    bool nz = false;
+    for (int e = lane; e < kSWRows * kSHP; e += 64) nz = nz || *reinterpret_cast<const float*>(buf + e * 16 + 12) != 0.f;
+    const bool c3 = __ballot(nz) != 0ull;                    // (wave-uniform)
+    auto run_blocks = [&](auto c3c) {
+      constexpr bool C3 = decltype(c3c)::value;
+      auto mfma_group = [&](int slot) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          acc[pr][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[slot], fx[slot][pr].x, acc[pr][0], 0, 0, 0);
+          acc[pr][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[slot], fx[slot][pr].y, acc[pr][1], 0, 0, 0);
+          acc[pr][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[slot], fx[slot][pr].z, acc[pr][2], 0, 0, 0);
+          if (C3) acc[pr][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[slot], fx[slot][pr].w, acc[pr][3], 0, 0, 0);
+        }
+      };
+      auto step = [&](int blk, int q, int rd_slot) {          // read group (blk, q) into rd_slot while the other slot is multiplied
+        read_group(blk, q, rd_slot);
+        mfma_group(rd_slot ^ 1);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {                        // 5 LDS reads between the 12 (16) MFMAs
+          HIFIHR_SCHED_GROUP(0x008, 2);
+          HIFIHR_SCHED_GROUP(0x100, 1);
+        }
+        HIFIHR_SCHED_GROUP(0x008, C3 ? 6 : 2);
+        HIFIHR_PIN();
+      };
+      read_group(0, 0, 0);
+      for (int blk = 0; blk < nblk; ++blk) {
+        const int nxt = min(blk + 1, kTH / 2 - 1);           // (past the last block: a valid address, never used)
+        step(blk, 1, 1); step(blk, 2, 0); step(blk, 3, 1); step(blk, 4, 0); step(blk, 5, 1); step(blk, 6, 0); step(nxt, 0, 1);
+        if (++blk >= nblk) break;                            // (7 groups per block: the slot parity flips from block to block)
+        const int nx2 = min(blk + 1, kTH / 2 - 1);
+        step(blk, 1, 0); step(blk, 2, 1); step(blk, 3, 0); step(blk, 4, 1); step(blk, 5, 0); step(blk, 6, 1); step(nx2, 0, 0);
+      }
+    };
+    if (c3) run_blocks(std::true_type{}); else run_blocks(std::false_type{});
+    HIFIHR_RAW_BARRIER();                                    // barrier ti
+  }
+  // register e of lane (r, g) of tile (pair, m) = dW[k = 16 wave + 4 g + e][tr = 2 pair + r / 8][s = r % 8][c = m]
+  float* slab = a.slabs + (size_t)wg * (64 * 196);
+  const int trl = r >> 3, sl = r & 7;
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) {
+    const int tr = 2 * pr + trl;
+    if (tr < 7 && sl < 7) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* o = slab + (((size_t)(16 * wave + 4 * g + e) * 7 + tr) * 7 + sl) * 4;
+        o[0] = acc[pr][0][e]; o[1] = acc[pr][1][e]; o[2] = acc[pr][2][e]; o[3] = acc[pr][3][e];
+      }
+    }
+  }
+}
+
+// dw[64][7][7][4] += sum over the slabs, in slab order
+__global__ __launch_bounds__(256) void conv_stem_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * 196) return;
+  float s = 0.f;
+  int z = 0;
+  for (; z + 32 <= nslab; z += 32) {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = slabs[(size_t)(z + u) * (64 * 196) + i];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s += v[u];
+  }
+  for (; z < nslab; ++z) s += slabs[(size_t)z * (64 * 196) + i];
+  dw[i] += s;
+}
+
 #if defined(HIFIHR_HALO_STAMP)
 }  // namespace hifihr
 extern "C" int hifihr_halo_stamp_read(unsigned long long* out8, int reset) {
@@ -752,6 +962,30 @@ static float* halo_wgrad_scratch(hipStream_t st, size_t bytes) {
   if (d.used >= kPool) return nullptr;
   d.owner[d.used] = st;
   return d.buf[d.used++];
+}
+
+bool conv_stem_wgrad_supported(const ConvGeom& g) {
+  static const int on = [] { const char* e = getenv("HIFIHR_CONV_STEM_WGRAD"); return e ? atoi(e) : 1; }();
+  return on && conv_stem_supported(g, nullptr);
+}
+
+hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {
+  if (!conv_stem_wgrad_supported(g)) return hipErrorInvalidValue;
+  const float* zeros = conv_halo_zero_page(st);
+  if (zeros == nullptr) return hipErrorNotReady;
+  StemWgradArgs a;
+  a.x = x; a.dy = dy; a.zeros = zeros; a.N = g.N; a.IH = g.IH; a.IW = g.IW; a.OH = g.OH; a.OW = g.OW;
+  a.ctiles = g.OW / kTW;
+  a.total = g.N * a.ctiles * g.OH;
+  int G = halo_cus();
+  a.per = (a.total + G - 1) / G;
+  if (a.per < 4) a.per = 4;
+  G = (a.total + a.per - 1) / a.per;
+  a.slabs = halo_wgrad_scratch(st, (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float));      // (the pool's buffers: 9 x 64 x 64 >= 64 x 196 floats each)
+  if (a.slabs == nullptr) return hipErrorNotReady;
+  hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(G), dim3(512), 0, st, a);
+  hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3(64 * 196 / 256), dim3(256), 0, st, a.slabs, G, dw);
+  return hipGetLastError();
 }
 
 bool conv_halo_wgrad_supported(const ConvGeom& g) {

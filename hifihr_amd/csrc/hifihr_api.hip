@@ -375,7 +375,7 @@ int hifihr_conv2d_describe(int N, int H, int W, int C, int K, int R, int S, int 
   if (!out || cap < 24 || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad)) return fail(HIFIHR_EINVAL, "hifihr_conv2d_describe: bad argument");
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
   const hifihr::ConvGeom g = dgrad == 1 ? hifihr::ConvGeom{N, OH, OW, K, H, W, C, R, S, stride, pad, 1} : hifihr::ConvGeom{N, H, W, C, OH, OW, K, R, S, stride, pad, 0};
-  if (dgrad == 2) snprintf(out, cap, "%s", hifihr::conv_halo_wgrad_supported(g) ? "conv_halo_wgrad_kernel" : "conv_wgrad_kernel");
+  if (dgrad == 2) snprintf(out, cap, "%s", hifihr::conv_halo_wgrad_supported(g) ? "conv_halo_wgrad_kernel" : hifihr::conv_stem_wgrad_supported(g) ? "conv_stem_wgrad_kernel" : "conv_wgrad_kernel");
   else snprintf(out, cap, "%s", hifihr::conv_halo_supported(g, nullptr) ? "conv_halo_kernel" : hifihr::conv_stem_supported(g, nullptr) ? "conv_stem_kernel" : "conv_igemm_kernel");
   return HIFIHR_OK;
 }

@@ -87,6 +87,8 @@ const float* conv_halo_zero_page(hipStream_t st);
 // the stem (7x7 / stride 2 / NHWC4 -> 64 channels) with the filter resident in LDS (csrc/conv_halo.hip); forward (+ BN statistics)
 bool conv_stem_supported(const ConvGeom& g, const float* bias);
 hipError_t launch_conv_stem(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st);
+bool conv_stem_wgrad_supported(const ConvGeom& g);
+hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
 bool conv_halo_wgrad_supported(const ConvGeom& g);
 // hipErrorNotReady: the scratch could not be set up now (first use inside a stream capture) -- use conv_wgrad_kernel for this launch
 hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
