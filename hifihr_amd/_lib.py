@@ -108,6 +108,9 @@ class HifihrLib:
         c.hifihr_bn_act_eval.argtypes = [_c_float_p] * 6 + [c_int, c_long, c_int, c_float, _c_float_p, c_void_p]
         c.hifihr_bn_act_bwd.argtypes = [_c_float_p] * 7 + [c_int, c_long, c_int] + [_c_float_p] * 5 + [c_void_p]
         c.hifihr_conv2d_bwd_weight.argtypes = [_c_float_p] * 3 + ci + [c_void_p]
+        c.hifihr_conv2d_bwd_weight_ws.argtypes = [_c_float_p] * 3 + ci + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_conv2d_wgrad_workspace_bytes.argtypes = ci
+        c.hifihr_conv2d_wgrad_workspace_bytes.restype = c_size_t
         c.hifihr_image_to_nhwc4.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_image_to_nhwc4_padded.argtypes = [_c_float_p, _c_float_p] + [c_int] * 8 + [c_void_p]
         c.hifihr_geom_loss_fwd.argtypes = [_c_float_p] * 6 + [_c_int_p] + [c_int] * 7 + [_c_float_p] * 3 + [c_void_p]
@@ -525,8 +528,12 @@ class HifihrLib:
         self.check(self.c.hifihr_conv2d_bwd_data(_fp(dy), _fp(w), _fp(dx), _fp(scratch), N, H, W, C, K, R, S, stride, pad,
                                                  *self._ws(ws), _stream_of(dy)), "hifihr_conv2d_bwd_data")
 
-    def conv2d_bwd_weight(self, x, dy, dw, N, H, W, C, K, R, S, stride, pad):
-        self.check(self.c.hifihr_conv2d_bwd_weight(_fp(x), _fp(dy), _fp(dw), N, H, W, C, K, R, S, stride, pad, _stream_of(x)),
+    def conv2d_wgrad_workspace_bytes(self, N, H, W, C, K, R, S, stride, pad):
+        return int(self.c.hifihr_conv2d_wgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad))
+
+    def conv2d_bwd_weight(self, x, dy, dw, N, H, W, C, K, R, S, stride, pad, ws=None):
+        p, n = self._ws(ws)
+        self.check(self.c.hifihr_conv2d_bwd_weight_ws(_fp(x), _fp(dy), _fp(dw), N, H, W, C, K, R, S, stride, pad, p, n, _stream_of(x)),
                    "hifihr_conv2d_bwd_weight")
 
     def image_to_nhwc4(self, images, out):

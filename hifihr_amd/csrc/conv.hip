@@ -846,16 +846,23 @@ static void launch_wgrad_tile(const ConvGeom& g, int Q, long M, int slots, const
                      dw, cps);
 }
 
-hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {
+size_t conv_wgrad_workspace_bytes(const ConvGeom& g) {
+  if (conv_halo_wgrad_supported(g)) return conv_halo_wgrad_slab_bytes();
+  if (conv_stem_wgrad_supported(g)) return conv_stem_wgrad_slab_bytes();
+  return 0;
+}
+
+hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
   const long M = (long)g.N * g.OH * g.OW;
   const int Q = g.R * g.S * g.IC;
   if (g.IC % 4 != 0 || g.OC % 4 != 0) return hipErrorInvalidValue;
+  // slab kernels: the caller's scratch (any contents) when it is large enough, else library-owned scratch (csrc/conv_halo.hip)
   if (conv_halo_wgrad_supported(g)) {
-    const hipError_t e = launch_conv_halo_wgrad(g, x, dy, dw, st);
+    const hipError_t e = launch_conv_halo_wgrad(g, x, dy, dw, ws_bytes >= conv_halo_wgrad_slab_bytes() ? static_cast<float*>(ws) : nullptr, st);
     if (e != hipErrorNotReady) return e;
   }
   if (conv_stem_wgrad_supported(g)) {
-    const hipError_t e = launch_conv_stem_wgrad(g, x, dy, dw, st);
+    const hipError_t e = launch_conv_stem_wgrad(g, x, dy, dw, ws_bytes >= conv_stem_wgrad_slab_bytes() ? static_cast<float*>(ws) : nullptr, st);
     if (e != hipErrorNotReady) return e;
   }
   // 0: 128x128 (4 resident per CU), 1: 64x128, n >= 2: 64x64 with n workgroups per CU.  Measured at B = 32 (tools/time_wgrad.py):

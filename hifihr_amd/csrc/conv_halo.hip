@@ -969,7 +969,9 @@ bool conv_stem_wgrad_supported(const ConvGeom& g) {
   return on && conv_stem_supported(g, nullptr);
 }
 
-hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {
+size_t conv_stem_wgrad_slab_bytes() { return (size_t)halo_cus() * 64 * 196 * sizeof(float); }
+
+hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* slabs, hipStream_t st) {
   if (!conv_stem_wgrad_supported(g)) return hipErrorInvalidValue;
   const float* zeros = conv_halo_zero_page(st);
   if (zeros == nullptr) return hipErrorNotReady;
@@ -981,7 +983,7 @@ hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float
   a.per = (a.total + G - 1) / G;
   if (a.per < 4) a.per = 4;
   G = (a.total + a.per - 1) / a.per;
-  a.slabs = halo_wgrad_scratch(st, (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float));      // (the pool's buffers: 9 x 64 x 64 >= 64 x 196 floats each)
+  a.slabs = slabs != nullptr ? slabs : halo_wgrad_scratch(st, (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float));      // (the pool's buffers: 9 x 64 x 64 >= 64 x 196 floats each)
   if (a.slabs == nullptr) return hipErrorNotReady;
   hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(G), dim3(512), 0, st, a);
   hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3(64 * 196 / 256), dim3(256), 0, st, a.slabs, G, dw);
@@ -993,7 +995,9 @@ bool conv_halo_wgrad_supported(const ConvGeom& g) {
   return on && conv_halo_supported(g, nullptr) && !g.dgrad;
 }
 
-hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {
+size_t conv_halo_wgrad_slab_bytes() { return (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float); }
+
+hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* slabs, hipStream_t st) {
   if (!conv_halo_wgrad_supported(g)) return hipErrorInvalidValue;
   const float* zeros = conv_halo_zero_page(st);
   if (zeros == nullptr) return hipErrorNotReady;
@@ -1005,7 +1009,7 @@ hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float
   a.per = (a.total + G - 1) / G;
   if (a.per < 4) a.per = 4;
   G = (a.total + a.per - 1) / a.per;
-  a.slabs = halo_wgrad_scratch(st, (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float));
+  a.slabs = slabs != nullptr ? slabs : halo_wgrad_scratch(st, (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float));
   if (a.slabs == nullptr) return hipErrorNotReady;
   hipLaunchKernelGGL(conv_halo_wgrad_kernel, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
   hipLaunchKernelGGL(conv_halo_wgrad_reduce_kernel, dim3(kTaps * 64 * 64 / 256), dim3(256), 0, st, a.slabs, G, dw);

@@ -419,10 +419,21 @@ int hifihr_weight_prep(const hifihr_prep_job* jobs, int njobs, int blocks_per_jo
 
 int hifihr_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, void* stream) {
+  return hifihr_conv2d_bwd_weight_ws(x, dy, dw, N, H, W, C, K, R, S, stride, pad, nullptr, 0, stream);
+}
+
+size_t hifihr_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+  if (!conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4 || K % 4) return 0;
+  hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
+  return hifihr::conv_wgrad_workspace_bytes(g);
+}
+
+int hifihr_conv2d_bwd_weight_ws(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                                int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !dw || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4 || K % 4)
     return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_weight: bad argument (C and K must be multiples of 4)");
   hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
-  HIP_TRY(hifihr::launch_conv_wgrad(g, x, dy, dw, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_conv_wgrad(g, x, dy, dw, ws, ws ? ws_bytes : 0, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
@@ -829,7 +840,7 @@ int hifihr_wino_wgrad_gemm(const float* V, const float* Y, float* dU_zeroed, int
   if (!V || !Y || !dU_zeroed || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0 || K < 4 || K % 4 != 0)
     return fail(HIFIHR_EINVAL, "hifihr_wino_wgrad_gemm: bad argument (C % 4 == 0, K % 4 == 0)");
   const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
-  HIP_TRY(hifihr::launch_conv_wgrad(wino_gemm_geom(T, C, K), V, Y, dU_zeroed, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_conv_wgrad(wino_gemm_geom(T, C, K), V, Y, dU_zeroed, nullptr, 0, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

@@ -88,10 +88,12 @@ const float* conv_halo_zero_page(hipStream_t st);
 bool conv_stem_supported(const ConvGeom& g, const float* bias);
 hipError_t launch_conv_stem(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st);
 bool conv_stem_wgrad_supported(const ConvGeom& g);
-hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
+size_t conv_stem_wgrad_slab_bytes();
+hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* slabs_or_null, hipStream_t st);
 bool conv_halo_wgrad_supported(const ConvGeom& g);
 // hipErrorNotReady: the scratch could not be set up now (first use inside a stream capture) -- use conv_wgrad_kernel for this launch
-hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
+size_t conv_halo_wgrad_slab_bytes();
+hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* slabs_or_null, hipStream_t st);
 hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st);
 // batch-norm (+ residual add + ReLU) on NHWC activations, x[M][C].  Statistics buffers are [kStatSlots][2][C]: partial
 // sums are spread over kStatSlots copies so that at most ~1/32 of the contributing workgroups hit one address with a
@@ -106,7 +108,10 @@ hipError_t launch_bn_act_eval(const float* x, const float* running_mean, const f
 hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, const float* save_mean, const float* save_invstd,
                              const float* gamma, const float* beta, int act, long M, int C, float* red, float* dx, float* dres,
                              float* dgamma_acc, float* dbeta_acc, hipStream_t st);
-hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
+// ws (may be NULL): scratch of conv_wgrad_workspace_bytes(g) bytes (any contents) for the shapes whose weight gradient is summed from
+// per-workgroup slabs (layer 1, stem); without it those shapes use library-owned scratch or, inside a stream capture, the atomics kernel
+size_t conv_wgrad_workspace_bytes(const ConvGeom& g);
+hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 hipError_t launch_weight_transpose(const float* w, float* wt, int K, int RS, int C, hipStream_t st);
 hipError_t launch_image_to_nhwc4(const float* img, float* out, int B, int H, int W, int OH, int OW, int pt, int pl, int normalize,
                                  hipStream_t st);

@@ -317,6 +317,23 @@ def _conv_ws(lib, device, geom, bwd):
 _WINO_SCRATCH = {}     # (device, name) -> grow-only scratch tensor shared by every Winograd convolution (stream-ordered reuse)
 
 
+_WGRAD_SLABS = {}       # (device, stream handle) -> per-workgroup slab scratch of the layer-1 / stem weight-gradient kernels
+
+
+def _wgrad_slabs(device, nbytes):
+    """Scratch for hifihr_conv2d_bwd_weight_ws, one buffer per STREAM the launch is issued on (the weight gradients may run on a side
+    stream beside the main one, and the captured step on a third): launches on one stream are ordered, so they can share it.  Allocated
+    through torch's caching allocator, which is legal inside a stream capture (the block then belongs to the graph's private pool)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _WGRAD_SLABS.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        if t is not None:
+            _RETIRED_SCRATCH.append(t)
+        t = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _WGRAD_SLABS[key] = t
+    return t
+
+
 _RETIRED_SCRATCH = []  # superseded scratch tensors stay allocated: a captured hipGraph may still replay launches that use their addresses
 
 
@@ -618,7 +635,9 @@ class _Conv2dMFMA(torch.autograd.Function):
             else:
                 if PROFILE.on:
                     PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "wgrad"))
-                go = lambda: PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, tgt, N, H, W, C, K, R, S, stride, pad))
+                nslab = lib.conv2d_wgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad)
+                go = lambda: PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(
+                    x, gy, tgt, N, H, W, C, K, R, S, stride, pad, ws=_wgrad_slabs(gy.device, nslab) if nslab else None))
                 keep = (gy, x, tgt)
             if _ASYNC_WGRAD.active and dw is None:
                 _ASYNC_WGRAD.launch(gy.device, go, keep)

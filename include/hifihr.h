@@ -222,6 +222,13 @@ int hifihr_conv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, flo
 /* dw[K][R][S][C] += sum over pixels (ACCUMULATES with fp32 atomics: zero it, or pass the gradient buffer). */
 int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, void* stream);
+/* The same with caller-provided scratch: layer 1's 3x3 and the stem's 7x7 weight gradients are summed from per-workgroup slabs in a
+ * fixed order (bit-reproducible, no atomics; csrc/conv_halo.hip).  ws: hifihr_conv2d_wgrad_workspace_bytes(...) bytes, any contents,
+ * not shared with a launch that may run concurrently on another stream; 0 bytes needed = the shape runs on the atomics kernel.
+ * Without it (hifihr_conv2d_bwd_weight) those shapes use scratch the library allocates on first use outside a stream capture. */
+size_t hifihr_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+int hifihr_conv2d_bwd_weight_ws(const float* x_d, const float* dy_d, float* dw_accumulate_d, int N, int H, int W, int C, int K, int R, int S,
+                                int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
 /* Winograd F(2x2, 3x3) path for stride-1, pad-1 3x3 convolutions with many channels (ResNet-18 layers 3-4): 2.25x fewer
  * multiplications than the direct kernel, same results up to a few ulp.  Forward:
  *   hifihr_wino_weight_transform(w[K][3][3][C], U[16][K][C], K, C, flip = 0)
