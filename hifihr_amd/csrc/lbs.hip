@@ -9,8 +9,9 @@
 //   v = sum_k w_k A_{idx_k} [v_shaped; 1]   (K <= 8 non-zero weights per vertex);   posed joints = tg_j.
 //   lbs_fwd_kernel      grid (ceil(V / 256), B): per-hand prologue in LDS (every workgroup redoes it: J Rodrigues + a J-step chain),
 //                       one vertex per lane; tables are structure-of-arrays over the vertex index (coalesced 256-byte rows).
-//   lbs_bwd_vert_kernel same grid: d(v_shaped) -> dbeta (wave dot products + one atomic per (workgroup, component)); d(A_j) summed in
-//                       LDS per wave, then one global atomic per (workgroup, joint, entry).
+//   lbs_bwd_vert_kernel same grid: d(v_shaped) -> dbeta (wave dot products + one atomic per (workgroup, component)); d(A_j) = a
+//                       (joints x vertices) . (vertices x 12) product summed on the matrix cores from a dense LDS image of the
+//                       workgroup's skin weights, then one global atomic per (workgroup, joint, entry).
 //   lbs_bwd_chain_kernel  one wave per hand: d(A), d(posed joints) -> reverse kinematic chain -> d(theta) (Rodrigues reverse mode),
 //                       d(J) -> dbeta.
 // HBM-bound / latency-bound like the MANO kernels: per hand 12 V bytes out + the tables once per launch (L2-resident).
@@ -21,6 +22,12 @@
 
 namespace hifihr {
 
+#if defined(HIFIHR_HOSTSIM)
+typedef hs_floatx4 hs_or_native_floatx4;
+#else
+typedef float hs_or_native_floatx4 __attribute__((ext_vector_type(4)));
+#endif
+
 struct LbsSmall {
   float beta[kLbsMaxS];
   float theta[kLbsMaxJ * 3];
@@ -30,6 +37,8 @@ struct LbsSmall {
   float tg[kLbsMaxJ * 3];
   float Ap[kLbsMaxJ * 12];
   int parent[kLbsMaxJ];
+  int depth[kLbsMaxJ];       // tree depth of a joint (root: 0)
+  int maxdepth;
 };
 
 // needs >= 128 threads; ends with a barrier
@@ -45,20 +54,35 @@ __device__ __forceinline__ void lbs_prologue(const LbsDev& t, const float* __res
     s.J[e] = acc;
   }
   if (tid < t.J) rodrigues_fwd(s.theta + 3 * tid, s.Rl + 9 * tid, nullptr);
-  __syncthreads();
-  if (tid == 0) {                                  // the chain is a dependent walk over <= 32 joints: one lane
-    for (int k = 0; k < 9; ++k) s.Rg[k] = s.Rl[k];
-    for (int k = 0; k < 3; ++k) s.tg[k] = s.J[k];
-    for (int i = 1; i < t.J; ++i) {
-      const int p = s.parent[i];
-      mat3_mul(s.Rg + 9 * p, s.Rl + 9 * i, s.Rg + 9 * i);
-      const float d[3] = {s.J[3 * i] - s.J[3 * p], s.J[3 * i + 1] - s.J[3 * p + 1], s.J[3 * i + 2] - s.J[3 * p + 2]};
-      float r[3];
-      mat3_vec(s.Rg + 9 * p, d, r);
-      for (int k = 0; k < 3; ++k) s.tg[3 * i + k] = r[k] + s.tg[3 * p + k];
-    }
+  if (tid == 0) s.maxdepth = 0;
+  int dep = 0;
+  if (tid >= 64 && tid < 64 + t.J) {                 // depth of joint tid - 64: a walk up the (LDS-resident) parent array
+    for (int p = s.parent[tid - 64]; p >= 0; p = s.parent[p]) ++dep;
+    s.depth[tid - 64] = dep;
   }
   __syncthreads();
+  if (tid >= 64 && tid < 64 + t.J) atomicMax(&s.maxdepth, dep);
+  __syncthreads();
+  // the kinematic chain level by level: the joints of one tree depth in parallel (a hand is 5-6 levels deep; one lane walking all
+  // joints paid ~30 dependent LDS round trips per joint)
+  const int nlev = s.maxdepth;
+  for (int l = 0; l <= nlev; ++l) {
+    if (tid < t.J && s.depth[tid] == l) {
+      const int i = tid;
+      if (l == 0) {
+        for (int k = 0; k < 9; ++k) s.Rg[9 * i + k] = s.Rl[9 * i + k];
+        for (int k = 0; k < 3; ++k) s.tg[3 * i + k] = s.J[3 * i + k];
+      } else {
+        const int p = s.parent[i];
+        mat3_mul(s.Rg + 9 * p, s.Rl + 9 * i, s.Rg + 9 * i);
+        const float d[3] = {s.J[3 * i] - s.J[3 * p], s.J[3 * i + 1] - s.J[3 * p + 1], s.J[3 * i + 2] - s.J[3 * p + 2]};
+        float r[3];
+        mat3_vec(s.Rg + 9 * p, d, r);
+        for (int k = 0; k < 3; ++k) s.tg[3 * i + k] = r[k] + s.tg[3 * p + k];
+      }
+    }
+    __syncthreads();
+  }
   if (tid < t.J) chain_make_ap(tid, s.J, s.Rg, s.tg, s.Ap);
   __syncthreads();
 }
@@ -92,18 +116,24 @@ __global__ __launch_bounds__(256) void lbs_fwd_kernel(LbsDev t, const float* __r
 }
 
 // gA[B][J][12], gbeta[B][S]: ZERO on entry, accumulated with float atomics
+// d(A_j)[r][c] = sum over the vertices of w_vj g_v[r] [vs_v; 1][c] is a (joints x vertices) . (vertices x 12) product with a sparse left
+// factor.  Summed with LDS float atomics it serialised on the joints a patch of skin shares (131 us at V = 5 990, B = 32); here the
+// workgroup spreads its 256 vertices' weights into a dense [256][32] LDS image (a vertex's row is private to its lane: no atomics),
+// writes the 12 outer-product entries per vertex next to it, and the matrix cores do the sum: 2 joint tiles x 16 k-steps of
+// v_mfma_f32_16x16x4_f32 per wave, the four waves' tiles added through LDS in a fixed order -- deterministic inside the workgroup.
 __global__ __launch_bounds__(256) void lbs_bwd_vert_kernel(LbsDev t, const float* __restrict__ theta, const float* __restrict__ beta,
                                                           const float* __restrict__ gverts, float* __restrict__ gA, float* __restrict__ gbeta) {
   __shared__ LbsSmall s;
-  __shared__ float accA[4][kLbsMaxJ * 12];
+  __shared__ __attribute__((aligned(16))) float Wd[256][kLbsMaxJ];      // dense skin weights of this workgroup's vertices (32 KB); later the waves' partial tiles
+  __shared__ __attribute__((aligned(16))) float X[256][16];             // g (x) [vs; 1], 12 entries + 4 zeros per vertex (16 KB)
   __shared__ float accB[4][kLbsMaxS];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   lbs_prologue(t, theta, beta, b, s);
-  for (int e = tid; e < 4 * kLbsMaxJ * 12; e += 256) (&accA[0][0])[e] = 0.f;
-  __syncthreads();
   const int v = blockIdx.x * 256 + tid;
   const bool ok = v < t.V;
   float vs[3] = {0.f, 0.f, 0.f}, g[3] = {0.f, 0.f, 0.f}, gvs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < kLbsMaxJ / 4; ++q) *reinterpret_cast<float4*>(&Wd[tid][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
   if (ok) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) vs[c] = t.tmpl[c * t.Vp + v];
@@ -118,16 +148,18 @@ __global__ __launch_bounds__(256) void lbs_bwd_vert_kernel(LbsDev t, const float
       const float w = t.wval[k * t.Vp + v];
       if (w == 0.f) continue;
       const int j = t.widx[k * t.Vp + v];
+      Wd[tid][j] = w;                                        // (a joint appears once per vertex: the tables are built from a dense row)
       const float* A = s.Ap + 12 * j;
-      float* a = accA[wave] + 12 * j;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const float wg = w * g[r];
-        atomicAdd(a + 4 * r, wg * vs[0]); atomicAdd(a + 4 * r + 1, wg * vs[1]); atomicAdd(a + 4 * r + 2, wg * vs[2]); atomicAdd(a + 4 * r + 3, wg);
         gvs[0] += wg * A[4 * r]; gvs[1] += wg * A[4 * r + 1]; gvs[2] += wg * A[4 * r + 2];
       }
     }
   }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) *reinterpret_cast<float4*>(&X[tid][4 * r]) = make_float4(g[r] * vs[0], g[r] * vs[1], g[r] * vs[2], g[r]);
+  *reinterpret_cast<float4*>(&X[tid][12]) = make_float4(0.f, 0.f, 0.f, 0.f);
   // dbeta[k] = sum_v gvs . shapedirs[k][:, v]
   for (int k = 0; k < t.S; ++k) {
     float p = 0.f;
@@ -139,9 +171,31 @@ __global__ __launch_bounds__(256) void lbs_bwd_vert_kernel(LbsDev t, const float
     if (lane == 0) accB[wave][k] = p;
   }
   __syncthreads();
-  for (int e = tid; e < t.J * 12; e += 256) {
-    const float x = accA[0][e] + accA[1][e] + accA[2][e] + accA[3][e];
-    if (x != 0.f) atomicAdd(gA + (size_t)b * t.J * 12 + e, x);
+  // out[j][e] = sum_v Wd[v][j] X[v][e]: wave w takes vertices 64 w .. 64 w + 63 (16 k-steps of 4), both joint tiles
+  {
+    const int r = lane & 15, gq = lane >> 4;
+    hs_or_native_floatx4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int st = 0; st < 16; ++st) {
+      const int vv = 64 * wave + 4 * st + gq;
+      const float xb = X[vv][r];
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wd[vv][r], xb, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wd[vv][16 + r], xb, d1, 0, 0, 0);
+    }
+    __syncthreads();                                         // every wave has read its rows of Wd: reuse it for the partial tiles
+    float* red = &Wd[0][0] + wave * 512;                     // [2 tiles][16 joints][16 entries]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[(4 * gq + e) * 16 + r] = d0[e];
+      red[256 + (4 * gq + e) * 16 + r] = d1[e];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < t.J * 12; i += 256) {
+    const int j = i / 12, e = i - 12 * j;
+    const float* red = &Wd[0][0] + j * 16 + e;               // tile j / 16 starts at 256 (j / 16): j * 16 covers both
+    const float x = red[0] + red[512] + red[1024] + red[1536];
+    if (x != 0.f) atomicAdd(gA + (size_t)b * t.J * 12 + i, x);
   }
   if (tid < t.S) atomicAdd(gbeta + (size_t)b * t.S + tid, accB[0][tid] + accB[1][tid] + accB[2][tid] + accB[3][tid]);
 }
@@ -160,21 +214,29 @@ __global__ __launch_bounds__(128) void lbs_bwd_chain_kernel(LbsDev t, const floa
   __syncthreads();
   if (tid < t.J) chain_make_ap_bwd(tid, s.J, s.Rg, gAp, gRg, gtg, gJ);     // joint-local: no two lanes touch the same entries
   __syncthreads();
-  if (tid == 0) {
-    for (int i = t.J - 1; i >= 1; --i) {
-      const int p = s.parent[i];
-      float tmp[9];
-      mat3_mul_nt(gRg + 9 * i, s.Rl + 9 * i, tmp);             // Rg_i = Rg_p Rl_i
-      for (int k = 0; k < 9; ++k) gRg[9 * p + k] += tmp[k];
-      mat3_mul_tn(s.Rg + 9 * p, gRg + 9 * i, gRl + 9 * i);
-      const float d[3] = {s.J[3 * i] - s.J[3 * p], s.J[3 * i + 1] - s.J[3 * p + 1], s.J[3 * i + 2] - s.J[3 * p + 2]};
-      const float* gt = gtg + 3 * i;                            // tg_i = Rg_p (J_i - J_p) + tg_p
-      for (int r = 0; r < 3; ++r)
-        for (int k = 0; k < 3; ++k) gRg[9 * p + 3 * r + k] += gt[r] * d[k];
-      float rt[3];
-      mat3t_vec(s.Rg + 9 * p, gt, rt);
-      for (int k = 0; k < 3; ++k) { gJ[3 * i + k] += rt[k]; gJ[3 * p + k] -= rt[k]; gtg[3 * p + k] += gt[k]; }
+  // reverse chain, deepest level first: the PARENTS of level l gather from their children (a child's gradients are complete once the
+  // level below has run; gathering instead of scattering needs no atomics and keeps the sums in a fixed order)
+  for (int l = s.maxdepth - 1; l >= 0; --l) {
+    if (tid < t.J && s.depth[tid] == l) {
+      const int p = tid;
+      for (int i = p + 1; i < t.J; ++i) {
+        if (s.parent[i] != p) continue;
+        float tmp[9];
+        mat3_mul_nt(gRg + 9 * i, s.Rl + 9 * i, tmp);             // Rg_i = Rg_p Rl_i
+        for (int k = 0; k < 9; ++k) gRg[9 * p + k] += tmp[k];
+        mat3_mul_tn(s.Rg + 9 * p, gRg + 9 * i, gRl + 9 * i);
+        const float d[3] = {s.J[3 * i] - s.J[3 * p], s.J[3 * i + 1] - s.J[3 * p + 1], s.J[3 * i + 2] - s.J[3 * p + 2]};
+        const float* gt = gtg + 3 * i;                            // tg_i = Rg_p (J_i - J_p) + tg_p
+        for (int r = 0; r < 3; ++r)
+          for (int k = 0; k < 3; ++k) gRg[9 * p + 3 * r + k] += gt[r] * d[k];
+        float rt[3];
+        mat3t_vec(s.Rg + 9 * p, gt, rt);
+        for (int k = 0; k < 3; ++k) { gJ[3 * i + k] += rt[k]; gJ[3 * p + k] -= rt[k]; gtg[3 * p + k] += gt[k]; }
+      }
     }
+    __syncthreads();
+  }
+  if (tid == 0) {
     for (int k = 0; k < 9; ++k) gRl[k] = gRg[k];                // root: Rg_0 = Rl_0, tg_0 = J_0
     for (int k = 0; k < 3; ++k) gJ[k] += gtg[k];
   }
