@@ -184,3 +184,34 @@ def test_resnet50_trunk_mfma_matches_torch_restatement():
             continue
         worst = max(worst, (float((p.grad.cpu() - q.grad).abs().max()) / float(q.grad.abs().max()), n))
     assert worst[0] < 5e-2, worst
+
+
+@pytest.mark.parametrize("B,H,W", [(32, 56, 56), (5, 28, 42)])
+def test_halo_kernels_are_bit_reproducible(lib, B, H, W):
+    """conv_halo_kernel / conv_halo_wgrad_kernel hold no atomics on their outputs: repeated launches on the same inputs agree bit for bit
+    (a loader / MFMA-wave synchronisation bug would show as run-to-run differences), and they match torch on the CPU."""
+    torch.manual_seed(B)
+    x = torch.randn(B, H, W, 64, device="cuda"); w = torch.randn(64, 3, 3, 64, device="cuda") / 24.0; gy = torch.randn(B, H, W, 64, device="cuda")
+    scratch = torch.empty(64 * 9 * 64, device="cuda")
+    outs = []
+    for _ in range(6):
+        out = torch.empty(B, H, W, 64, device="cuda"); dx = torch.empty_like(out); dw = torch.zeros(64, 3, 3, 64, device="cuda")
+        lib.conv2d_fwd(x, w, None, out, B, H, W, 64, 64, 3, 3, 1, 1)
+        lib.conv2d_bwd_data(gy, w, dx, scratch, B, H, W, 64, 64, 3, 3, 1, 1)
+        lib.conv2d_bwd_weight(x, gy, dw, B, H, W, 64, 64, 3, 3, 1, 1)
+        outs.append((out, dx, dw))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o[k], outs[0][k]) for o in outs for k in range(3))
+    xr = x.cpu().permute(0, 3, 1, 2).requires_grad_(True); wr = w.cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    y = torch.nn.functional.conv2d(xr, wr, None, 1, 1)
+    y.backward(gy.cpu().permute(0, 3, 1, 2))
+    rel = lambda a, b: float((a.cpu() - b).abs().max()) / float(b.abs().max())
+    assert rel(outs[0][0], y.detach().permute(0, 2, 3, 1)) < 3e-5 and rel(outs[0][1], xr.grad.permute(0, 2, 3, 1)) < 3e-5
+    assert rel(outs[0][2], wr.grad.permute(0, 2, 3, 1)) < 2e-4
+
+
+def test_stem_kernels_at_batch_32(lib):
+    """conv_stem_kernel / conv_stem_wgrad_kernel at the bench's size (32 x 224^2), the padding channel zero as in the encoder."""
+    assert lib.conv2d_describe(32, 224, 224, 4, 64, 7, 7, 2, 3, 0) == "conv_stem_kernel"
+    assert lib.conv2d_describe(32, 224, 224, 4, 64, 7, 7, 2, 3, 2) == "conv_stem_wgrad_kernel"
+    kc.conv_case(lib, "cuda", 32, 224, 224, 4, 64, 7, 2, 3, seed=3, zero_last_channel=True, rtol=3e-5)

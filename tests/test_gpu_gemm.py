@@ -34,3 +34,20 @@ def test_bgemm_tn_is_bit_reproducible(lib):
     c1 = torch.empty(parts, batch, M, N, device="cuda"); c2 = torch.empty_like(c1)
     lib.bgemm_tn(a, b, c1, M, N, T, batch, parts); lib.bgemm_tn(a, b, c2, M, N, T, batch, parts)
     assert torch.equal(c1, c2)
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(300, 256, 96, 3), (50, 128, 32, 5), (129, 384, 64, 2), (17, 128, 160, 9), (100000, 128, 32, 1),
+                                         (6272, 128, 128, 7), (2352, 256, 256, 16)])
+def test_bgemm_nt_row_shares(lib, M, N, K, batch):
+    """bgemm_nt_rows_kernel on 256 workgroups: shares ending inside tiles (1..8 row blocks), crossing column-tile and problem boundaries,
+    a B = 48-sized product and a very tall one."""
+    assert lib.bgemm_describe(False, M, N, K) == "bgemm_nt_rows_kernel"
+    assert kc.bgemm_case(lib, "cuda", M, N, K, batch, seed=M + K) == 0
+
+
+def test_bgemm_nt_rows_is_bit_reproducible(lib):
+    gen = torch.Generator().manual_seed(9)
+    a = torch.randn(16, 1568, 512, generator=gen).cuda(); b = torch.randn(16, 512, 512, generator=gen).cuda()
+    c1 = torch.empty(16, 1568, 512, device="cuda"); c2 = torch.empty_like(c1)
+    lib.bgemm_nt(a, b, c1, 1568, 512, 512, 16); lib.bgemm_nt(a, b, c2, 1568, 512, 512, 16)
+    assert torch.equal(c1, c2)
