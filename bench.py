@@ -150,31 +150,32 @@ def conv_path_rooflines(ops, lib, dev, nprof):
     for (geom, direction), cnt in Counter(ops.PROFILE.conv_log).items():
         per_step = cnt / nprof
         if direction in ("gemm", "gemm-tn"):
-            _, N_, H_, W_, C_, K_ = geom
-            T_ = N_ * ((H_ + 1) // 2) * ((W_ + 1) // 2)
-            V = torch.randn(16 * T_ * C_, device=dev)
+            _, N_, H_, W_, C_, K_, m_ = geom                    # m_: Winograd output-tile edge (2: 16 positions, 4: 36)
+            P_ = (m_ + 2) ** 2
+            T_ = N_ * ((H_ + m_ - 1) // m_) * ((W_ + m_ - 1) // m_)
+            V = torch.randn(P_ * T_ * C_, device=dev)
             if direction == "gemm":
-                U = torch.randn(16 * K_ * C_, device=dev) * 0.05; M = torch.empty(16 * T_ * K_, device=dev)
+                U = torch.randn(P_ * K_ * C_, device=dev) * 0.05; M = torch.empty(P_ * T_ * K_, device=dev)
                 name = lib.bgemm_describe(False, T_, K_, C_)
                 if not name:                       # shape outside csrc/gemm.hip: runs on the gather kernel
                     name = "conv_igemm_kernel"
-                nb = lib.wino_gemm_workspace_bytes(N_, H_, W_, C_, K_)
+                nb = lib.wino_gemm_workspace_bytes(N_, H_, W_, C_, K_, m_)
                 ws = torch.zeros(nb // 4 + 64, device=dev) if nb else None
-                us = hip_us(lambda: lib.wino_gemm(V, U, M, N_, H_, W_, C_, K_, ws=ws))
-                add(name, per_step, us, 2.0 * 16 * T_ * C_ * K_, 4.0 * 16 * (T_ * C_ + K_ * C_ + T_ * K_), f"16 x [{T_} x {C_}] . [{K_} x {C_}]^T")
+                us = hip_us(lambda: lib.wino_gemm(V, U, M, N_, H_, W_, C_, K_, ws=ws, m=m_))
+                add(name, per_step, us, 2.0 * P_ * T_ * C_ * K_, 4.0 * P_ * (T_ * C_ + K_ * C_ + T_ * K_), f"{P_} x [{T_} x {C_}] . [{K_} x {C_}]^T")
             else:
-                Y = torch.randn(16 * T_ * K_, device=dev)
-                parts = lib.wino_wgrad_parts(N_, H_, W_, C_, K_)
+                Y = torch.randn(P_ * T_ * K_, device=dev)
+                parts = lib.wino_wgrad_parts(N_, H_, W_, C_, K_, m_)
                 if parts > 0:
                     name = lib.bgemm_describe(True, K_, C_, T_)
-                    dU = torch.empty(parts * 16 * K_ * C_, device=dev)
-                    us = hip_us(lambda: lib.wino_wgrad_gemm_parts(V, Y, dU, N_, H_, W_, C_, K_, parts))
+                    dU = torch.empty(parts * P_ * K_ * C_, device=dev)
+                    us = hip_us(lambda: lib.wino_wgrad_gemm_parts(V, Y, dU, N_, H_, W_, C_, K_, parts, m_))
                 else:
                     name = "conv_wgrad_kernel"
                     dU = torch.zeros(16 * K_ * C_, device=dev)
                     us = hip_us(lambda: lib.wino_wgrad_gemm(V, Y, dU, N_, H_, W_, C_, K_))
-                add(name, per_step, us, 2.0 * 16 * T_ * C_ * K_, 4.0 * 16 * (T_ * C_ + T_ * K_ + max(parts, 1) * K_ * C_),
-                    f"16 x [{T_} x {K_}]^T . [{T_} x {C_}], {max(parts, 1)} slab(s)")
+                add(name, per_step, us, 2.0 * P_ * T_ * C_ * K_, 4.0 * P_ * (T_ * C_ + T_ * K_ + max(parts, 1) * K_ * C_),
+                    f"{P_} x [{T_} x {K_}]^T . [{T_} x {C_}], {max(parts, 1)} slab(s)")
             continue
         N_, H_, W_, C_, K_, R_, S_, st_, pd_ = geom
         OH_, OW_ = (H_ + 2 * pd_ - R_) // st_ + 1, (W_ + 2 * pd_ - S_) // st_ + 1

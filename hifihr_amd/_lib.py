@@ -153,6 +153,19 @@ class HifihrLib:
         c.hifihr_comm_allreduce_f32.argtypes = [c_void_p, _c_float_p, c_size_t, c_void_p]
         c.hifihr_comm_broadcast_f32.argtypes = [c_void_p, _c_float_p, c_size_t, c_int, c_void_p]
         c.hifihr_comm_destroy.argtypes = [c_void_p]
+        c.hifihr_wino_tile.argtypes = [c_int] * 5
+        c.hifihr_wino_gemm_workspace_bytes_m.argtypes = [c_int] * 6
+        c.hifihr_wino_gemm_workspace_bytes_m.restype = c_size_t
+        c.hifihr_wino_weight_transform_m.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
+        c.hifihr_wino_input_transform_m.argtypes = [_c_float_p, _c_float_p] + [c_int] * 5 + [c_void_p]
+        c.hifihr_wino_gemm_m.argtypes = [_c_float_p] * 3 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_wino_output_transform_m.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
+        c.hifihr_wino_output_transform_act_m.argtypes = [_c_float_p] * 3 + [c_int] * 6 + [c_void_p]
+        c.hifihr_wino_dy_transform_m.argtypes = [_c_float_p] * 2 + [c_int] * 5 + [c_void_p]
+        c.hifihr_wino_input_dy_transform_m.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
+        c.hifihr_wino_wgrad_parts_m.argtypes = [c_int] * 6
+        c.hifihr_wino_wgrad_gemm_parts_m.argtypes = [_c_float_p] * 3 + [c_int] * 7 + [c_void_p]
+        c.hifihr_wino_dw_transform_parts_m.argtypes = [_c_float_p, c_int, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_bgemm_describe.argtypes = [c_int] * 4 + [ctypes.c_char_p, c_int]
         c.hifihr_conv2d_describe.argtypes = [c_int] * 10 + [ctypes.c_char_p, c_int]
         c.hifihr_bgemm_tn_parts.argtypes = [c_int] * 4
@@ -339,20 +352,24 @@ class HifihrLib:
         self.check(self.c.hifihr_sil_post(_fp(rgba), _fp(imgs), B, H, W, _fp(re_sil), _fp(mask_rgbs), _stream_of(rgba)), "hifihr_sil_post")
 
     # ---- Winograd F(2x2, 3x3) ------------------------------------------
-    def wino_gemm_workspace_bytes(self, N, H, W, C, K):
-        return int(self.c.hifihr_wino_gemm_workspace_bytes(N, H, W, C, K))
+    # Winograd: m = output-tile edge (2: F(2x2, 3x3), 16 positions; 4: F(4x4, 3x3), 36 positions); wino_tile() = the library's choice
+    def wino_tile(self, N, H, W, C, K):
+        return int(self.c.hifihr_wino_tile(N, H, W, C, K))
 
-    def wino_weight_transform(self, w, U, K, C, flip):
-        self.check(self.c.hifihr_wino_weight_transform(_fp(w), _fp(U), K, C, int(flip), _stream_of(w)), "hifihr_wino_weight_transform")
+    def wino_gemm_workspace_bytes(self, N, H, W, C, K, m=2):
+        return int(self.c.hifihr_wino_gemm_workspace_bytes_m(N, H, W, C, K, m))
 
-    def wino_input_transform(self, x, V, N, H, W, C):
-        self.check(self.c.hifihr_wino_input_transform(_fp(x), _fp(V), N, H, W, C, _stream_of(x)), "hifihr_wino_input_transform")
+    def wino_weight_transform(self, w, U, K, C, flip, m=2):
+        self.check(self.c.hifihr_wino_weight_transform_m(_fp(w), _fp(U), K, C, int(flip), m, _stream_of(w)), "hifihr_wino_weight_transform")
 
-    def wino_gemm(self, V, U, M, N, H, W, C, K, ws=None):
-        self.check(self.c.hifihr_wino_gemm(_fp(V), _fp(U), _fp(M), N, H, W, C, K, *self._ws(ws), _stream_of(V)), "hifihr_wino_gemm")
+    def wino_input_transform(self, x, V, N, H, W, C, m=2):
+        self.check(self.c.hifihr_wino_input_transform_m(_fp(x), _fp(V), N, H, W, C, m, _stream_of(x)), "hifihr_wino_input_transform")
 
-    def wino_input_dy_transform(self, dy, V, Yt, N, H, W, K):
-        self.check(self.c.hifihr_wino_input_dy_transform(_fp(dy), _fp(V), _fp(Yt), N, H, W, K, _stream_of(dy)), "hifihr_wino_input_dy_transform")
+    def wino_gemm(self, V, U, M, N, H, W, C, K, ws=None, m=2):
+        self.check(self.c.hifihr_wino_gemm_m(_fp(V), _fp(U), _fp(M), N, H, W, C, K, m, *self._ws(ws), _stream_of(V)), "hifihr_wino_gemm")
+
+    def wino_input_dy_transform(self, dy, V, Yt, N, H, W, K, m=2):
+        self.check(self.c.hifihr_wino_input_dy_transform_m(_fp(dy), _fp(V), _fp(Yt), N, H, W, K, m, _stream_of(dy)), "hifihr_wino_input_dy_transform")
 
     def conv2d_bwd_data_pre(self, dy, wt, dx, N, H, W, C, K, R, S, stride, pad, ws=None):
         wsp, wsb = self._ws(ws)
@@ -382,16 +399,16 @@ class HifihrLib:
         self.check(self.c.hifihr_procrustes_error(_fp(pred), _fp(gt), B, N, _fp(aligned), _fp(err_sum), _stream_of(pred)),
                    "hifihr_procrustes_error")
 
-    def wino_output_transform(self, M, y, stats, N, H, W, K, bias=None, act=0):
+    def wino_output_transform(self, M, y, stats, N, H, W, K, bias=None, act=0, m=2):
         if bias is not None or act:
             assert stats is None
-            self.check(self.c.hifihr_wino_output_transform_act(_fp(M), _fp(y), _fp(bias), act, N, H, W, K, _stream_of(M)),
+            self.check(self.c.hifihr_wino_output_transform_act_m(_fp(M), _fp(y), _fp(bias), act, N, H, W, K, m, _stream_of(M)),
                        "hifihr_wino_output_transform_act")
             return
-        self.check(self.c.hifihr_wino_output_transform(_fp(M), _fp(y), _fp(stats), N, H, W, K, _stream_of(M)), "hifihr_wino_output_transform")
+        self.check(self.c.hifihr_wino_output_transform_m(_fp(M), _fp(y), _fp(stats), N, H, W, K, m, _stream_of(M)), "hifihr_wino_output_transform")
 
-    def wino_dy_transform(self, dy, Y, N, H, W, K):
-        self.check(self.c.hifihr_wino_dy_transform(_fp(dy), _fp(Y), N, H, W, K, _stream_of(dy)), "hifihr_wino_dy_transform")
+    def wino_dy_transform(self, dy, Y, N, H, W, K, m=2):
+        self.check(self.c.hifihr_wino_dy_transform_m(_fp(dy), _fp(Y), N, H, W, K, m, _stream_of(dy)), "hifihr_wino_dy_transform")
 
     def wino_wgrad_gemm(self, V, Y, dU_zeroed, N, H, W, C, K):
         self.check(self.c.hifihr_wino_wgrad_gemm(_fp(V), _fp(Y), _fp(dU_zeroed), N, H, W, C, K, _stream_of(V)), "hifihr_wino_wgrad_gemm")
@@ -447,15 +464,15 @@ class HifihrLib:
     def bgemm_tn(self, A, B, Cparts, M, N, T, batch, parts):
         self.check(self.c.hifihr_bgemm_tn(_fp(A), _fp(B), _fp(Cparts), M, N, T, batch, parts, _stream_of(A)), "hifihr_bgemm_tn")
 
-    def wino_wgrad_parts(self, N, H, W, C, K):
-        return int(self.c.hifihr_wino_wgrad_parts(N, H, W, C, K))
+    def wino_wgrad_parts(self, N, H, W, C, K, m=2):
+        return int(self.c.hifihr_wino_wgrad_parts_m(N, H, W, C, K, m))
 
-    def wino_wgrad_gemm_parts(self, V, Y, dU_parts, N, H, W, C, K, parts):
-        self.check(self.c.hifihr_wino_wgrad_gemm_parts(_fp(V), _fp(Y), _fp(dU_parts), N, H, W, C, K, parts, _stream_of(V)),
+    def wino_wgrad_gemm_parts(self, V, Y, dU_parts, N, H, W, C, K, parts, m=2):
+        self.check(self.c.hifihr_wino_wgrad_gemm_parts_m(_fp(V), _fp(Y), _fp(dU_parts), N, H, W, C, K, parts, m, _stream_of(V)),
                    "hifihr_wino_wgrad_gemm_parts")
 
-    def wino_dw_transform_parts(self, dU_parts, parts, dw_acc, K, C):
-        self.check(self.c.hifihr_wino_dw_transform_parts(_fp(dU_parts), parts, _fp(dw_acc), K, C, _stream_of(dU_parts)),
+    def wino_dw_transform_parts(self, dU_parts, parts, dw_acc, K, C, m=2):
+        self.check(self.c.hifihr_wino_dw_transform_parts_m(_fp(dU_parts), parts, _fp(dw_acc), K, C, m, _stream_of(dU_parts)),
                    "hifihr_wino_dw_transform_parts")
 
     def weight_transpose(self, w, wt, K, RS, C):

@@ -746,6 +746,31 @@ static bool use_bgemm() {
   return e == nullptr || atoi(e) != 0;
 }
 
+// Output-tile edge of the Winograd algorithm a layer of this geometry runs: 4 = F(4x4, 3x3) (csrc/wino4.hip: 36 positions, 4x fewer
+// multiplications than direct) where the batched GEMMs of csrc/gemm.hip take the shape in both directions, else 2 = F(2x2, 3x3).
+// HIFIHR_WINO_M=2 keeps every layer on F(2x2, 3x3).
+static int wino_m(int N, int H, int W, int C, int K) {
+  static const int pref = [] { const char* e = getenv("HIFIHR_WINO_M"); return e ? atoi(e) : 4; }();
+  if (pref != 4 || !use_bgemm() || H < 4 || W < 4) return 2;
+  const long T4 = (long)N * ((H + 3) / 4) * ((W + 3) / 4);
+  if (T4 >= (1L << 30)) return 2;
+  // forward (V U^T: rows T4, N = K, reduction C), backward-data (roles of C and K swapped), backward-weight (slabs of Y'^T V)
+  if (!hifihr::bgemm_nt_supported((int)T4, K, C) || !hifihr::bgemm_nt_supported((int)T4, C, K) || !hifihr::bgemm_tn_supported(K, C, (int)T4)) return 2;
+  return 4;
+}
+static long wino_T(int m, int N, int H, int W) { return (long)N * ((H + m - 1) / m) * ((W + m - 1) / m); }
+
+int hifihr_wino_tile(int N, int H, int W, int C, int K) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 2;
+  return wino_m(N, H, W, C, K);
+}
+
+size_t hifihr_wino_gemm_workspace_bytes_m(int N, int H, int W, int C, int K, int m) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
+  if (m == 4) return hifihr::bgemm_nt_workspace_bytes((int)wino_T(4, N, H, W), K, C, 36);
+  return hifihr_wino_gemm_workspace_bytes(N, H, W, C, K);
+}
+
 size_t hifihr_wino_gemm_workspace_bytes(int N, int H, int W, int C, int K) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
   const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
@@ -782,11 +807,31 @@ int hifihr_bgemm_tn(const float* A, const float* B, float* C_parts, int M, int N
   return HIFIHR_OK;
 }
 
+int hifihr_wino_wgrad_parts_m(int N, int H, int W, int C, int K, int m) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || !use_bgemm()) return 0;
+  if (m == 4) {
+    const long T4 = wino_T(4, N, H, W);
+    return (T4 < (1L << 30) && hifihr::bgemm_tn_supported(K, C, (int)T4)) ? hifihr::bgemm_tn_parts(K, C, (int)T4, 36) : 0;
+  }
+  return hifihr_wino_wgrad_parts(N, H, W, C, K);
+}
+
 int hifihr_wino_wgrad_parts(int N, int H, int W, int C, int K) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || !use_bgemm()) return 0;
   const long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
   if (T >= (1L << 30) || !hifihr::bgemm_tn_supported(K, C, (int)T)) return 0;
   return hifihr::bgemm_tn_parts(K, C, (int)T, 16);
+}
+
+int hifihr_wino_wgrad_gemm_parts_m(const float* V, const float* Y, float* dU_parts, int N, int H, int W, int C, int K, int parts, int m, void* stream) {
+  if (m != 4) return hifihr_wino_wgrad_gemm_parts(V, Y, dU_parts, N, H, W, C, K, parts, stream);
+  if (!V || !Y || !dU_parts || N <= 0 || H <= 0 || W <= 0 || parts <= 0)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_wgrad_gemm_parts: bad argument");
+  const long T4 = wino_T(4, N, H, W);
+  if (T4 >= (1L << 30) || !hifihr::bgemm_tn_supported(K, C, (int)T4) || parts != hifihr::bgemm_tn_parts(K, C, (int)T4, 36))
+    return fail(HIFIHR_EINVAL, "hifihr_wino_wgrad_gemm_parts: parts must be hifihr_wino_wgrad_parts_m(N, H, W, C, K, 4) > 0");
+  HIP_TRY(hifihr::launch_bgemm_tn(Y, V, dU_parts, K, C, (int)T4, 36, parts, (hipStream_t)stream));
+  return HIFIHR_OK;
 }
 
 int hifihr_wino_wgrad_gemm_parts(const float* V, const float* Y, float* dU_parts, int N, int H, int W, int C, int K, int parts, void* stream) {
@@ -799,16 +844,72 @@ int hifihr_wino_wgrad_gemm_parts(const float* V, const float* Y, float* dU_parts
   return HIFIHR_OK;
 }
 
-int hifihr_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw_acc, int K, int C, void* stream) {
-  if (!dU_parts || !dw_acc || parts <= 0 || K <= 0 || C < 4 || C % 4 != 0)
+int hifihr_wino_dw_transform_parts_m(const float* dU_parts, int parts, float* dw_acc, int K, int C, int m, void* stream) {
+  if (!dU_parts || !dw_acc || parts <= 0 || K <= 0 || C < 4 || C % 4 != 0 || (m != 2 && m != 4))
     return fail(HIFIHR_EINVAL, "hifihr_wino_dw_transform_parts: bad argument");
-  HIP_TRY(hifihr::launch_wino_dw_transform_parts(dU_parts, parts, dw_acc, K, C, (hipStream_t)stream));
+  if (m == 4) HIP_TRY(hifihr::launch_wino4_dw_transform_parts(dU_parts, parts, dw_acc, K, C, (hipStream_t)stream));
+  else HIP_TRY(hifihr::launch_wino_dw_transform_parts(dU_parts, parts, dw_acc, K, C, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw_acc, int K, int C, void* stream) {
+  return hifihr_wino_dw_transform_parts_m(dU_parts, parts, dw_acc, K, C, 2, stream);
+}
+
+int hifihr_wino_weight_transform_m(const float* w, float* U, int K, int C, int flip, int m, void* stream) {
+  if (!w || !U || K <= 0 || C < 4 || C % 4 != 0 || (m != 2 && m != 4)) return fail(HIFIHR_EINVAL, "hifihr_wino_weight_transform: bad argument (C % 4 == 0)");
+  if (m == 4) HIP_TRY(hifihr::launch_wino4_weight_transform(w, U, K, C, flip ? 1 : 0, (hipStream_t)stream));
+  else HIP_TRY(hifihr::launch_wino_weight_transform(w, U, K, C, flip ? 1 : 0, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
 int hifihr_wino_weight_transform(const float* w, float* U, int K, int C, int flip, void* stream) {
-  if (!w || !U || K <= 0 || C < 4 || C % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_weight_transform: bad argument (C % 4 == 0)");
-  HIP_TRY(hifihr::launch_wino_weight_transform(w, U, K, C, flip ? 1 : 0, (hipStream_t)stream));
+  return hifihr_wino_weight_transform_m(w, U, K, C, flip, 2, stream);
+}
+
+int hifihr_wino_input_transform_m(const float* x, float* V, int N, int H, int W, int C, int m, void* stream) {
+  if (m != 4) return hifihr_wino_input_transform(x, V, N, H, W, C, stream);
+  if (!x || !V || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_input_transform: bad argument");
+  HIP_TRY(hifihr::launch_wino4_input_transform(x, V, nullptr, N, H, W, C, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_gemm_m(const float* V, const float* U, float* M, int N, int H, int W, int C, int K, int m, void* ws, size_t ws_bytes, void* stream) {
+  if (m != 4) return hifihr_wino_gemm(V, U, M, N, H, W, C, K, ws, ws_bytes, stream);
+  const long T4 = (N > 0 && H > 0 && W > 0) ? wino_T(4, N, H, W) : 0;
+  if (!V || !U || !M || T4 <= 0 || T4 >= (1L << 30) || !hifihr::bgemm_nt_supported((int)T4, K, C))
+    return fail(HIFIHR_EINVAL, "hifihr_wino_gemm: bad argument (F(4x4, 3x3) needs C % 32 == 0, K % 64 == 0)");
+  HIP_TRY(hifihr::launch_bgemm_nt(V, U, M, (int)T4, K, C, 36, ws, ws_bytes, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_dy_transform_m(const float* dy, float* Y, int N, int H, int W, int K, int m, void* stream) {
+  if (m != 4) return hifihr_wino_dy_transform(dy, Y, N, H, W, K, stream);
+  if (!dy || !Y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_dy_transform: bad argument");
+  HIP_TRY(hifihr::launch_wino4_dy_transform(dy, Y, N, H, W, K, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_output_transform_m(const float* M, float* y, float* stats, int N, int H, int W, int K, int m, void* stream) {
+  if (m != 4) return hifihr_wino_output_transform(M, y, stats, N, H, W, K, stream);
+  if (!M || !y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform: bad argument");
+  HIP_TRY(hifihr::launch_wino4_output_transform(M, y, stats, nullptr, 0, N, H, W, K, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_input_dy_transform_m(const float* dy, float* V, float* Yt, int N, int H, int W, int K, int m, void* stream) {
+  if (m != 4) return hifihr_wino_input_dy_transform(dy, V, Yt, N, H, W, K, stream);
+  if (!dy || !V || !Yt || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_input_dy_transform: bad argument");
+  HIP_TRY(hifihr::launch_wino4_input_transform(dy, V, Yt, N, H, W, K, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_output_transform_act_m(const float* M, float* y, const float* bias, int act, int N, int H, int W, int K, int m, void* stream) {
+  if (m != 4) return hifihr_wino_output_transform_act(M, y, bias, act, N, H, W, K, stream);
+  if (!M || !y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0 || act < 0 || act > 1)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform_act: bad argument");
+  HIP_TRY(hifihr::launch_wino4_output_transform(M, y, nullptr, bias, act, N, H, W, K, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

@@ -230,6 +230,13 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
 int bgemm_tn_parts(int M, int N, int T, int batch);
 hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st);
 hipError_t launch_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st);
+// Winograd F(4x4, 3x3) glue (wino4.hip): 36 positions, T = N * ceil(H / 4) * ceil(W / 4)
+hipError_t launch_wino4_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st);
+hipError_t launch_wino4_input_transform(const float* x, float* V, float* Y /* or nullptr */, int N, int H, int W, int C, hipStream_t st);
+hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
+                                         hipStream_t st);
+hipError_t launch_wino4_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st);
+hipError_t launch_wino4_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st);
 
 hipError_t launch_texpca_fwd(const float* coef, const float* basis, const float* mean, int B, int K, long n, float* out, hipStream_t st);
 hipError_t launch_texpca_bwd(const float* g, const float* basis, int B, int K, long n, float* dcoef_zeroed, hipStream_t st);

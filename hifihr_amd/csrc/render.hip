@@ -217,52 +217,68 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
   int* wq = L.wq[wave];
   int qn = 0;                                    // entries queued by this wave (wave-uniform)
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int base = 0; base < total; base += kFwdThreads) {
-    const int c = base + tid;
-    bool survive = false;
-    int packed = 0;
-    if (c < total) {
-      int lo = 0, hi = n - 1;                    // largest k with coff[k] <= c
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (L.coff[mid] <= c) lo = mid; else hi = mid - 1;
-      }
-      const int k = lo;
-      const float* q = L.rec + k * kRecW;
-      const int info = __float_as_int(q[10]);
-      const int x0 = info & 15, y0 = (info >> 4) & 15, w = info >> 8;
-      const int local = c - L.coff[k];
-      const int dy = local / w, dx = local - dy * w;
-      const int cx = x0 + dx, cy = y0 + dy;
-      FaceXYZ f;
-      f.x0 = q[0]; f.y0 = q[1]; f.x1 = q[2]; f.y1 = q[3]; f.x2 = q[4]; f.y2 = q[5]; f.z0 = q[6]; f.z1 = q[7]; f.z2 = q[8];
-      survive = !square_misses_face(f, L.sxs[cx * AA + AA - 1], L.sxs[cx * AA], L.sys[cy * AA + AA - 1], L.sys[cy * AA]);
-      if (survive) {
-        const float znear = fminf(f.z0, fminf(f.z1, f.z2)) * (1.0f - 1e-5f);
-        bool behind = true;
+  // Stage A on kIlp candidates per lane per round, their binary searches advanced in lock step (fixed 9 probes: n <= 512): the probes
+  // of one search are dependent LDS reads (~9 x 64 cycles per round with nothing else to issue); four independent chains share that
+  // latency.  Results are identical: only the order in which (face, pixel) pairs are visited changes, and the 64-bit atomicMin on
+  // (depth, face id) does not depend on it.
+  constexpr int kIlp = 4;
+  for (int base = 0; base < total; base += kIlp * kFwdThreads) {
+    int cc[kIlp], lo[kIlp], hi[kIlp];
 #pragma unroll
-        for (int i = 0; i < AA; ++i)
+    for (int u = 0; u < kIlp; ++u) { cc[u] = base + u * kFwdThreads + tid; lo[u] = 0; hi[u] = n - 1; }
 #pragma unroll
-          for (int j = 0; j < AA; ++j) {
-            const unsigned long long key = L.zbuf[(cy * AA + i) * SW + cx * AA + j];
-            behind = behind && (key != ~0ull) && (__int_as_float((int)(unsigned)(key >> 32)) < znear);
-          }
-        survive = !behind;
+    for (int it = 0; it < 9; ++it) {
+#pragma unroll
+      for (int u = 0; u < kIlp; ++u) {                     // largest k with coff[k] <= c (idempotent once lo == hi)
+        const int mid = (lo[u] + hi[u] + 1) >> 1;
+        const bool le = L.coff[mid] <= min(cc[u], total - 1);
+        lo[u] = le ? mid : lo[u];
+        hi[u] = le ? hi[u] : mid - 1;
       }
-      packed = (k << 8) | (cy << 4) | cx;
     }
-    const unsigned long long m = __ballot(survive);
-    if (survive) wq[qn + __popcll(m & lt)] = packed;
-    qn += __popcll(m);
-    (void)__ballot(true);                        // wave-level rendezvous: this wave's LDS writes are ordered before the reads below
-    if (qn >= 64) {
-      stage_b(wq[lane]);
-      const int rest = qn - 64;
-      const int moved = lane < rest ? wq[64 + lane] : 0;
-      (void)__ballot(true);
-      if (lane < rest) wq[lane] = moved;
-      qn = rest;
-      (void)__ballot(true);
+#pragma unroll
+    for (int u = 0; u < kIlp; ++u) {
+      const int c = cc[u];
+      bool survive = false;
+      int packed = 0;
+      if (c < total) {
+        const int k = lo[u];
+        const float* q = L.rec + k * kRecW;
+        const int info = __float_as_int(q[10]);
+        const int x0 = info & 15, y0 = (info >> 4) & 15, w = info >> 8;
+        const int local = c - L.coff[k];
+        const int dy = local / w, dx = local - dy * w;
+        const int cx = x0 + dx, cy = y0 + dy;
+        FaceXYZ f;
+        f.x0 = q[0]; f.y0 = q[1]; f.x1 = q[2]; f.y1 = q[3]; f.x2 = q[4]; f.y2 = q[5]; f.z0 = q[6]; f.z1 = q[7]; f.z2 = q[8];
+        survive = !square_misses_face(f, L.sxs[cx * AA + AA - 1], L.sxs[cx * AA], L.sys[cy * AA + AA - 1], L.sys[cy * AA]);
+        if (survive) {
+          const float znear = fminf(f.z0, fminf(f.z1, f.z2)) * (1.0f - 1e-5f);
+          bool behind = true;
+#pragma unroll
+          for (int i = 0; i < AA; ++i)
+#pragma unroll
+            for (int j = 0; j < AA; ++j) {
+              const unsigned long long key = L.zbuf[(cy * AA + i) * SW + cx * AA + j];
+              behind = behind && (key != ~0ull) && (__int_as_float((int)(unsigned)(key >> 32)) < znear);
+            }
+          survive = !behind;
+        }
+        packed = (k << 8) | (cy << 4) | cx;
+      }
+      const unsigned long long m = __ballot(survive);
+      if (survive) wq[qn + __popcll(m & lt)] = packed;
+      qn += __popcll(m);
+      (void)__ballot(true);                      // wave-level rendezvous: this wave's LDS writes are ordered before the reads below
+      if (qn >= 64) {
+        stage_b(wq[lane]);
+        const int rest = qn - 64;
+        const int moved = lane < rest ? wq[64 + lane] : 0;
+        (void)__ballot(true);
+        if (lane < rest) wq[lane] = moved;
+        qn = rest;
+        (void)__ballot(true);
+      }
     }
   }
   if (lane < qn) stage_b(wq[lane]);

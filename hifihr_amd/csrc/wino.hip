@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "hifihr_internal.h"
+#include "wino4_math.h"
 
 namespace hifihr {
 
@@ -125,7 +126,9 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const PrepJob* __restr
   const PrepJob j = jobs[blockIdx.y];
   if (j.kind == 0) weight_transpose_body(j.src, j.dst, j.K, j.RS, j.C, blockIdx.x, gridDim.x);
   else if (j.kind == 1) wino_weight_transform_body(j.src, j.dst, j.K, j.C, 0, blockIdx.x, gridDim.x);
-  else wino_weight_transform_t_body(j.src, j.dst, j.K, j.C, blockIdx.x, gridDim.x, lds);
+  else if (j.kind == 2) wino_weight_transform_t_body(j.src, j.dst, j.K, j.C, blockIdx.x, gridDim.x, lds);
+  else if (j.kind == 3) w4::wino4_weight_transform_body(j.src, j.dst, j.K, j.C, blockIdx.x, gridDim.x);        // F(4x4, 3x3): U[36][K][C]
+  else w4::wino4_weight_transform_t_body(j.src, j.dst, j.K, j.C, blockIdx.x, gridDim.x, lds);                  // F(4x4, 3x3): U'[36][C][K]
 }
 
 // thread = (tile, 4 channels); x[N][H][W][C] -> V[16][T][C]

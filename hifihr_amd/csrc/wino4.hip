@@ -1,0 +1,296 @@
+// Winograd F(4x4, 3x3) transforms: the same pipeline as csrc/wino.hip (weight / input transform, batched GEMMs on csrc/gemm.hip, output
+// transform; backward-data on the rotated transposed filter; backward-weight as dw = G^T [ sum_t (A dy A^T) . (B^T d B) ] G) with 4x4
+// output tiles: 36 products per 16 outputs instead of 16 per 4, i.e. 4x fewer multiplications than the direct convolution where
+// F(2x2, 3x3) has 2.25x fewer -- the 36 batched GEMMs of a 28x28 layer do 0.56 of the work of its 16 F(2x2) ones, those of a 14x14
+// layer (4x4 tiles of a map padded to 16x16) 0.73, and the transformed tensors V / M / Y' shrink by the same factors.
+// Replaces (with the batched GEMM) the same cuDNN / MIOpen dispatches as conv.hip (reference network/res_encoder.py:364-373).
+// fp32 throughout.  The transform constants are Lavin & Gray's for the points {0, +-1, +-2, inf}:
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// Measured against an fp64 direct convolution on layer-sized problems (tools/wino43_error.py): 8-9e-6 of max |y| forward, 2-3e-6 of
+// max |dw| for the weight gradient -- inside the 3e-5 / 1e-4 the convolution tests allow (F(2x2, 3x3): ~1e-6).
+// Position index p = 6 * row + column; U[36][K][C], V[36][T][C], M[36][T][K], T = N * ceil(H / 4) * ceil(W / 4).
+#include <hip/hip_runtime.h>
+
+#include "hifihr_internal.h"
+#include "wino4_math.h"
+
+namespace hifihr {
+
+using namespace w4;
+
+__global__ __launch_bounds__(256) void wino4_weight_transform_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int flip) {
+  __shared__ float lds[64 * 9 * kWt4Ld];
+  if (flip) {
+    // flip = 1 here means: w is ALREADY the [K'][3][3][C'] transpose of the forward filter (what hifihr_weight_transpose produces); only
+    // the 180-degree rotation is left to do
+    const int C4 = C / 4;
+    const size_t total = (size_t)K * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+      const int cg = (int)(i % C4), k = (int)(i / C4);
+      V4 g[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) g[r][s] = ld4(w + (((size_t)k * 3 + (2 - r)) * 3 + (2 - s)) * C + cg * 4);
+      wino4_weight_tile(g, U, (size_t)K * C, (size_t)k * C + cg * 4);
+    }
+    (void)lds;
+  } else {
+    wino4_weight_transform_body(w, U, K, C, blockIdx.x, gridDim.x);
+  }
+}
+
+// thread = (tile, 4 channels); x[N][H][W][C] -> V[36][T][C].  DUAL: x is a gradient dy that backward-data (V = B^T d B of the padded 6x6
+// patch) AND backward-weight (Y' = A dy A^T of the patch's central 4x4 block = this tile's outputs) both consume: one read of dy.
+template <bool DUAL>
+__global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V, float* __restrict__ Y, int N,
+                                                                   int H, int W, int C, int TH, int TW) {
+  const int C4 = C / 4;
+  const size_t T = (size_t)N * TH * TW, total = T * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % C4);
+    const size_t t = i / C4;
+    const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+    V4 tt[6][6];                                            // tt = B^T d, built column by column
+    V4 ty[6][4];                                            // DUAL: A dy (6 x 4) of the central block
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int iw = 4 * tw - 1 + c;
+      const bool cok = iw >= 0 && iw < W;
+      V4 col[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int ih = 4 * th - 1 + r;
+        const bool ok = cok && ih >= 0 && ih < H;
+        const V4 v = ld4(x + (((size_t)n * H + (ok ? ih : 0)) * W + (ok ? iw : 0)) * C + cg * 4);
+        col[r] = ok ? v : zero4();
+      }
+      V4 o[6];
+      bt6(col, o);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) tt[r][c] = o[r];
+      if (DUAL && c >= 1 && c <= 4) {
+        V4 o2[6];
+        a4(col + 1, o2);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ty[r][c - 1] = o2[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      V4 o[6];
+      bt6(tt[r], o);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) st4(V + ((size_t)(r * 6 + c) * T + t) * C + cg * 4, o[c]);
+    }
+    if (DUAL) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        V4 o[6];
+        a4(ty[r], o);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) st4(Y + ((size_t)(r * 6 + c) * T + t) * C + cg * 4, o[c]);
+      }
+    }
+  }
+}
+
+// workgroup = 16 tile lanes x 16 float4 channel lanes (64 channels, blockIdx.y); M[36][T][K] -> y[N][H][W][K] (+ stats | bias, ReLU)
+__global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Mm, float* __restrict__ y, float* __restrict__ stats,
+                                                                    const float* __restrict__ bias, int relu, int N, int H, int W, int K,
+                                                                    int TH, int TW) {
+  __shared__ float4 red[2][16][16];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int k = blockIdx.y * 64 + cl * 4;
+  const bool kok = k < K;
+  const size_t T = (size_t)N * TH * TW;
+  V4 s1 = zero4(), s2 = zero4();
+  if (kok) {
+    const V4 bv = bias != nullptr ? ld4(bias + k) : zero4();
+    const float lo = relu ? 0.f : -3.402823466e38f;
+    for (size_t t = (size_t)blockIdx.x * 16 + tl; t < T; t += (size_t)gridDim.x * 16) {
+      const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+      V4 s[4][6];                                           // s = A^T m, built column by column
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        V4 col[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) col[r] = ld4(Mm + ((size_t)(r * 6 + c) * T + t) * K + k);
+        V4 o[4];
+        at6(col, o);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s[a][c] = o[a];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int oh = 4 * th + a;
+        V4 o[4];
+        at6(s[a], o);
+        if (oh < H) {
+          float* p = y + (((size_t)n * H + oh) * W + 4 * tw) * K + k;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            if (4 * tw + b < W) {
+              V4 v = o[b] + bv;
+              v = V4{fmaxf(v.x, lo), fmaxf(v.y, lo), fmaxf(v.z, lo), fmaxf(v.w, lo)};
+              st4(p + (size_t)b * K, v);
+              s1 = s1 + v;
+              s2 = V4{fmaf(v.x, v.x, s2.x), fmaf(v.y, v.y, s2.y), fmaf(v.z, v.z, s2.z), fmaf(v.w, v.w, s2.w)};
+            }
+          }
+        }
+      }
+    }
+  }
+  if (stats != nullptr) {                           // uniform
+    red[0][tl][cl] = make_float4(s1.x, s1.y, s1.z, s1.w); red[1][tl][cl] = make_float4(s2.x, s2.y, s2.z, s2.w);
+    __syncthreads();
+    if (tl == 0 && kok) {
+      float4 a1 = red[0][0][cl], a2 = red[1][0][cl];
+      for (int r = 1; r < 16; ++r) {
+        const float4 b1 = red[0][r][cl], b2 = red[1][r][cl];
+        a1 = make_float4(a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w);
+        a2 = make_float4(a2.x + b2.x, a2.y + b2.y, a2.z + b2.z, a2.w + b2.w);
+      }
+      float* sp = stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * K;
+      atomicAdd(sp + k, a1.x); atomicAdd(sp + k + 1, a1.y); atomicAdd(sp + k + 2, a1.z); atomicAdd(sp + k + 3, a1.w);
+      atomicAdd(sp + K + k, a2.x); atomicAdd(sp + K + k + 1, a2.y); atomicAdd(sp + K + k + 2, a2.z); atomicAdd(sp + K + k + 3, a2.w);
+    }
+  }
+}
+
+// backward-weight glue.  thread = (tile, 4 channels): Y'[36][T][K] = A dy A^T (dy outside the image = 0)
+__global__ __launch_bounds__(256) void wino4_dy_transform_kernel(const float* __restrict__ dy, float* __restrict__ Y, int N, int H, int W, int K, int TH,
+                                                                int TW) {
+  const int K4 = K / 4;
+  const size_t T = (size_t)N * TH * TW, total = T * K4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int kg = (int)(i % K4);
+    const size_t t = i / K4;
+    const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+    V4 ty[6][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      V4 col[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int oh = 4 * th + a, ow = 4 * tw + b;
+        const bool ok = oh < H && ow < W;
+        const V4 v = ld4(dy + (((size_t)n * H + (ok ? oh : 0)) * W + (ok ? ow : 0)) * K + kg * 4);
+        col[a] = ok ? v : zero4();
+      }
+      V4 o[6];
+      a4(col, o);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) ty[r][b] = o[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      V4 o[6];
+      a4(ty[r], o);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) st4(Y + ((size_t)(r * 6 + c) * T + t) * K + kg * 4, o[c]);
+    }
+  }
+}
+
+// dw[K][3][3][C] += G^T (sum over slabs of dU) G; dU_parts[part][36][K][C].  A workgroup takes 16 consecutive items (item = (k, channel
+// group): 256 contiguous bytes per position); thread (position lane pl, item il) sums positions pl, pl + 16, pl + 32 over the slabs, the
+// sums are exchanged through LDS, then 9 x 16 threads apply G^T . G.  Slabs are added in slab order: bit-reproducible, nothing to zero.
+__global__ __launch_bounds__(256) void wino4_dw_transform_parts_kernel(const float* __restrict__ dU, int parts, float* __restrict__ dw, int K, int C) {
+  __shared__ float4 su[36][16];
+  const int C4 = C / 4;
+  const size_t total = (size_t)K * C4, plane = (size_t)K * C, slab = 36 * plane;
+  const int il = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  for (size_t base = (size_t)blockIdx.x * 16; base < total; base += (size_t)gridDim.x * 16) {      // (uniform)
+    const size_t i = base + il;
+    const bool ok = i < total;
+    const int cg = ok ? (int)(i % C4) : 0, k = ok ? (int)(i / C4) : 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int pos = pl + 16 * q;
+      if (pos < 36) {
+        V4 a = zero4();
+        if (ok) {
+          const float* p = dU + (size_t)pos * plane + (size_t)k * C + cg * 4;
+          a = ld4(p);
+#pragma unroll 4
+          for (int z = 1; z < parts; ++z) a = a + ld4(p + z * slab);
+        }
+        su[pos][il] = make_float4(a.x, a.y, a.z, a.w);
+      }
+    }
+    __syncthreads();
+    if (ok && pl < 9) {
+      const int r = pl / 3, c2 = pl - 3 * r;
+      V4 tcol[6];                                           // row r of G^T u: tcol[j] = sum_i G^T[r][i] u[i][j]
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        V4 col[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { const float4 v = su[q * 6 + j][il]; col[q] = V4{v.x, v.y, v.z, v.w}; }
+        V4 o[3];
+        gt6(col, o);
+        tcol[j] = r == 0 ? o[0] : r == 1 ? o[1] : o[2];
+      }
+      V4 o[3];
+      gt6(tcol, o);
+      const V4 gq = c2 == 0 ? o[0] : c2 == 1 ? o[1] : o[2];
+      float* out = dw + (((size_t)k * 3 + r) * 3 + c2) * C + cg * 4;
+      st4(out, ld4(out) + gq);
+    }
+    __syncthreads();
+  }
+}
+
+static unsigned wino4_grid(size_t total) {
+  size_t b = (total + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+hipError_t launch_wino4_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(wino4_weight_transform_kernel, dim3(wino4_grid((size_t)K * (C / 4))), dim3(256), 0, st, w, U, K, C, flip);
+  return hipGetLastError();
+}
+
+hipError_t launch_wino4_input_transform(const float* x, float* V, float* Y, int N, int H, int W, int C, hipStream_t st) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
+  const size_t total = (size_t)N * TH * TW * (C / 4);
+  if (Y != nullptr) hipLaunchKernelGGL((wino4_input_transform_kernel<true>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, N, H, W, C, TH, TW);
+  else hipLaunchKernelGGL((wino4_input_transform_kernel<false>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, N, H, W, C, TH, TW);
+  return hipGetLastError();
+}
+
+hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
+                                         hipStream_t st) {
+  if (K % 4 != 0) return hipErrorInvalidValue;
+  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
+  const size_t T = (size_t)N * TH * TW;
+  size_t bx = (T + 15) / 16;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(wino4_output_transform_kernel, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, bias, relu, N, H, W, K, TH, TW);
+  return hipGetLastError();
+}
+
+hipError_t launch_wino4_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st) {
+  if (K % 4 != 0) return hipErrorInvalidValue;
+  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
+  hipLaunchKernelGGL(wino4_dy_transform_kernel, dim3(wino4_grid((size_t)N * TH * TW * (K / 4))), dim3(256), 0, st, dy, Y, N, H, W, K, TH, TW);
+  return hipGetLastError();
+}
+
+hipError_t launch_wino4_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st) {
+  if (C % 4 != 0 || parts < 1) return hipErrorInvalidValue;
+  size_t b = ((size_t)K * (C / 4) + 15) / 16;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(wino4_dw_transform_parts_kernel, dim3((unsigned)b), dim3(256), 0, st, dU_parts, parts, dw, K, C);
+  return hipGetLastError();
+}
+
+}  // namespace hifihr

@@ -1,0 +1,140 @@
+// Winograd F(4x4, 3x3) transform arithmetic shared by csrc/wino4.hip (the transform kernels) and csrc/wino.hip (weight_prep_kernel, which
+// re-lays every convolution weight of a step out in one launch).  Not part of the ABI.  Constants: see the header of wino4.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hifihr {
+namespace w4 {
+
+struct V4 {
+  float x, y, z, w;
+};
+__device__ __forceinline__ V4 operator+(const V4& a, const V4& b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ V4 operator-(const V4& a, const V4& b) { return V4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+__device__ __forceinline__ V4 operator*(float s, const V4& a) { return V4{s * a.x, s * a.y, s * a.z, s * a.w}; }
+__device__ __forceinline__ V4 ld4(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return V4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4(float* p, const V4& v) { *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ V4 zero4() { return V4{0.f, 0.f, 0.f, 0.f}; }
+
+// o[6] = B^T x[6]
+__device__ __forceinline__ void bt6(const V4* x, V4* o) {
+  o[0] = 4.f * x[0] - 5.f * x[2] + x[4];
+  o[1] = x[3] + x[4] - 4.f * (x[1] + x[2]);
+  o[2] = 4.f * (x[1] - x[2]) - x[3] + x[4];
+  o[3] = 2.f * (x[3] - x[1]) - x[2] + x[4];
+  o[4] = 2.f * (x[1] - x[3]) - x[2] + x[4];
+  o[5] = 4.f * x[1] - 5.f * x[3] + x[5];
+}
+// o[4] = A^T x[6]
+__device__ __forceinline__ void at6(const V4* x, V4* o) {
+  const V4 s12 = x[1] + x[2], d12 = x[1] - x[2], s34 = x[3] + x[4], d34 = x[3] - x[4];
+  o[0] = x[0] + s12 + s34;
+  o[1] = d12 + 2.f * d34;
+  o[2] = s12 + 4.f * s34;
+  o[3] = d12 + 8.f * d34 + x[5];
+}
+// o[6] = G x[3]
+__device__ __forceinline__ void g3(const V4* x, V4* o) {
+  const V4 s02 = x[0] + x[2];
+  o[0] = 0.25f * x[0];
+  o[1] = (-1.f / 6.f) * (s02 + x[1]);
+  o[2] = (-1.f / 6.f) * (s02 - x[1]);
+  const V4 a = (1.f / 24.f) * x[0] + (1.f / 6.f) * x[2], b = (1.f / 12.f) * x[1];
+  o[3] = a + b;
+  o[4] = a - b;
+  o[5] = x[2];
+}
+// o[6] = A x[4]   (A = (A^T)^T)
+__device__ __forceinline__ void a4(const V4* x, V4* o) {
+  const V4 s02 = x[0] + x[2], s13 = x[1] + x[3];
+  const V4 e = x[0] + 4.f * x[2], f = 2.f * x[1] + 8.f * x[3];
+  o[0] = x[0];
+  o[1] = s02 + s13;
+  o[2] = s02 - s13;
+  o[3] = e + f;
+  o[4] = e - f;
+  o[5] = x[3];
+}
+// o[3] = G^T x[6]
+__device__ __forceinline__ void gt6(const V4* x, V4* o) {
+  const V4 s12 = x[1] + x[2], d12 = x[2] - x[1], s34 = x[3] + x[4], d34 = x[3] - x[4];
+  o[0] = 0.25f * x[0] + (-1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+  o[1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+  o[2] = (-1.f / 6.f) * s12 + (1.f / 6.f) * s34 + x[5];
+}
+
+// u = G g G^T for one 3x3 filter (4 values per tap), stored to U[p][...]: U + p * plane + off
+__device__ __forceinline__ void wino4_weight_tile(const V4 (&g)[3][3], float* __restrict__ U, size_t plane, size_t off) {
+  V4 t[6][3];                                               // t = G g: column by column
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const V4 col[3] = {g[0][s], g[1][s], g[2][s]};
+    V4 o[6];
+    g3(col, o);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) t[r][s] = o[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    V4 o[6];
+    g3(t[r], o);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) st4(U + (size_t)(r * 6 + c) * plane + off, o[c]);
+  }
+}
+
+// thread = (output channel k, 4 input channels); w[K][3][3][C] -> U[36][K][C]
+__device__ __forceinline__ void wino4_weight_transform_body(const float* __restrict__ w, float* __restrict__ U, int K, int C, unsigned bid, unsigned nblk) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)K * C4;
+  for (size_t i = (size_t)bid * 256 + threadIdx.x; i < total; i += (size_t)nblk * 256) {
+    const int cg = (int)(i % C4), k = (int)(i / C4);
+    V4 g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) g[r][s] = ld4(w + (((size_t)k * 3 + r) * 3 + s) * C + cg * 4);
+    wino4_weight_tile(g, U, (size_t)K * C, (size_t)k * C + cg * 4);
+  }
+}
+
+// backward-data weights straight from w[K][3][3][C]: U'[36][C][K] = G g' G^T, g'[c][r][s][k] = w[k][2-r][2-s][c]; a (64 k) x (16 c) block
+// of w is staged through LDS (see wino_weight_transform_t_body in wino.hip)
+constexpr int kWt4Ld = 17;
+__device__ __forceinline__ void wino4_weight_transform_t_body(const float* __restrict__ w, float* __restrict__ U, int K, int C, unsigned bid, unsigned nblk,
+                                              float* __restrict__ lds /* [64 * 9 * kWt4Ld] */) {
+  const int kt = (K + 63) / 64, ct = (C + 15) / 16;
+  for (int tile = (int)bid; tile < kt * ct; tile += (int)nblk) {
+    const int k0 = (tile % kt) * 64, c0 = (tile / kt) * 16;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 9 * 4; i += 256) {
+      const int q = i & 3, row = i >> 2;
+      const int k = k0 + row / 9, c = c0 + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K && c < C) v = *reinterpret_cast<const float4*>(w + ((size_t)k * 9 + row % 9) * C + c);
+      float* d = lds + row * kWt4Ld + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int kg = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int k = k0 + kg * 4, c = c0 + cl;
+    if (k < K && c < C) {
+      V4 g[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+          const float* p = lds + ((kg * 4) * 9 + (2 - r) * 3 + (2 - s2)) * kWt4Ld + cl;
+          g[r][s2] = V4{p[0], p[9 * kWt4Ld], p[18 * kWt4Ld], p[27 * kWt4Ld]};
+        }
+      wino4_weight_tile(g, U, (size_t)C * K, (size_t)c * K + k);
+    }
+  }
+}
+
+
+}  // namespace w4
+}  // namespace hifihr

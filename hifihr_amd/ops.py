@@ -355,6 +355,20 @@ def _wino_ok(C, K, R, S, stride, pad):
     return R == 3 and S == 3 and stride == 1 and pad == 1 and C >= 128 and K >= 128 and C % 32 == 0 and K % 32 == 0
 
 
+_WINO_TILE = {}
+
+
+def _wino_tile(lib, N, H, W, C, K):
+    """Output-tile edge m of the Winograd algorithm this layer runs (hifihr_wino_tile: 4 = F(4x4, 3x3) with 36 positions where the
+    batched GEMMs take the shape, else 2 = F(2x2, 3x3) with 16); -> (m, positions, tiles)."""
+    key = (N, H, W, C, K)
+    m = _WINO_TILE.get(key)
+    if m is None:
+        m = lib.wino_tile(N, H, W, C, K)
+        _WINO_TILE[key] = m
+    return m, (m + 2) ** 2, N * ((H + m - 1) // m) * ((W + m - 1) // m)
+
+
 class _WeightPrep:
     """The per-step re-layouts of convolution weights (transpose for backward-data, Winograd U / U') as ONE launch
     (hifihr_weight_prep) instead of ~40 tiny ones.  The weights change once per optimizer step, so the step brackets its forward
@@ -375,7 +389,7 @@ class _WeightPrep:
         e = self.entries.get(key)
         if e is None:
             K, C, R, S = w.shape
-            n = K * C * R * S * (1 if kind == 0 else 16) // (1 if kind == 0 else 9)
+            n = K * C * R * S if kind == 0 else K * C * (16 if kind in (1, 2) else 36)      # kinds 1 / 2: F(2x2) U / U'; 3 / 4: F(4x4)
             self.entries[key] = [w, K, C, R * S, kind, torch.empty(n, device=w.device, dtype=torch.float32)]
             self.dirty = True
             return None
@@ -465,21 +479,22 @@ class prepared_weights:
         return False
 
 
-def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None, dy_out=None):
+def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None, dy_out=None, tile=None):
     """y[N][H][W][K] = conv3x3(x[N][H][W][C], w[K][3][3][C]) through weight / input transform, 16 batched GEMMs, output
     transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter).
     keep_v: return the transformed input V[16][T][C] in a tensor of its own (the Winograd weight gradient consumes it)."""
     dev = x.device
-    T = N * ((H + 1) // 2) * ((W + 1) // 2)
+    # `tile` = (m, positions, tiles) of the LAYER (backward-data runs with C and K swapped but must use the forward's tile edge)
+    m, P, T = tile if tile is not None else _wino_tile(lib, N, H, W, C, K)
     prepared = U is not None                          # Winograd-domain weights already computed by the step's weight_prep launch
     if not prepared:
-        U = _wino_scratch(dev, "U", 16 * K * C)
-    V = torch.empty(16 * T * C, device=dev, dtype=torch.float32) if keep_v else _wino_scratch(dev, "V", 16 * T * C)
-    M = _wino_scratch(dev, "M", 16 * T * K)
-    key = ("wino", N, H, W, C, K)
+        U = _wino_scratch(dev, "U", P * K * C)
+    V = torch.empty(P * T * C, device=dev, dtype=torch.float32) if keep_v else _wino_scratch(dev, "V", P * T * C)
+    M = _wino_scratch(dev, "M", P * T * K)
+    key = ("wino", N, H, W, C, K, m)
     nb = _CONV_WS_BYTES.get(key)
     if nb is None:
-        nb = lib.wino_gemm_workspace_bytes(N, H, W, C, K)
+        nb = lib.wino_gemm_workspace_bytes(N, H, W, C, K, m)
         _CONV_WS_BYTES[key] = nb
     ws = None
     if nb:
@@ -490,15 +505,15 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias
             ws = torch.zeros(max(nb, 32 << 20) // 4 + 64, dtype=torch.float32, device=dev)
             _CONV_WS[dev] = ws
     if PROFILE.on:
-        PROFILE.conv_log.append((("wino", N, H, W, C, K), "gemm"))
+        PROFILE.conv_log.append((("wino", N, H, W, C, K, m), "gemm"))
     if not prepared:
-        lib.wino_weight_transform(w_krsc, U, K, C, flip)
+        lib.wino_weight_transform(w_krsc, U, K, C, flip, m)
     if dy_out is not None:                            # backward: x is dy, the backward-weight transform Y' comes out of the same read
-        lib.wino_input_dy_transform(x, V, dy_out, N, H, W, C)
+        lib.wino_input_dy_transform(x, V, dy_out, N, H, W, C, m)
     else:
-        lib.wino_input_transform(x, V, N, H, W, C)
-    lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)          # csrc/gemm.hip (16x16x4 f32 MFMA); odd channel counts: conv.hip
-    lib.wino_output_transform(M, y, stats, N, H, W, K, bias=bias, act=act)
+        lib.wino_input_transform(x, V, N, H, W, C, m)
+    lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws, m=m)          # csrc/gemm.hip (16x16x4 f32 MFMA); odd channel counts: conv.hip
+    lib.wino_output_transform(M, y, stats, N, H, W, K, bias=bias, act=act, m=m)
     return V if keep_v else None
 
 
@@ -521,9 +536,10 @@ class _Conv2dMFMA(torch.autograd.Function):
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device) if want_stats else None
             keep = bool(ctx.needs_input_grad[1])
             box = []
-            U = _WEIGHT_PREP.get(w, wk, 1)
+            tile = _wino_tile(lib, N, H, W, C, K)
+            U = _WEIGHT_PREP.get(w, wk, 1 if tile[0] == 2 else 3)
             PROFILE.bracket("conv_fwd_wino", lambda: box.append(_wino_conv(lib, x, wk, y, stats, N, H, W, C, K, 0, keep_v=keep,
-                                                                            bias=bias, act=1 if relu else 0, U=U)))
+                                                                            bias=bias, act=1 if relu else 0, U=U, tile=tile)))
             v_saved = box[0]
         elif want_stats:       # per-channel sum / sum of squares of y from the conv epilogue, for the batch-norm that follows
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device)
@@ -571,19 +587,20 @@ class _Conv2dMFMA(torch.autograd.Function):
         if ctx.needs_input_grad[0] and _wino_ok(C, K, R, S, stride, pad):
             # backward-data of a stride-1 3x3 = the same Winograd pipeline on dy with the transposed, rotated filter
             dx = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32, memory_format=_CL)
-            U2 = _WEIGHT_PREP.get(ctx.w_param, wk, 2)
+            tile = _wino_tile(lib, N, H, W, C, K)
+            wm, wP, wT = tile
+            U2 = _WEIGHT_PREP.get(ctx.w_param, wk, 2 if wm == 2 else 4)
             if ctx.needs_input_grad[1] and v_saved is not None:      # the Winograd backward-weight below wants A dy A^T: same read of dy
-                T = N * ((H + 1) // 2) * ((W + 1) // 2)
                 # a side-stream weight gradient reads it while the next layer's backward-data already runs: a buffer of its own
-                Yt_done = _wino_scratch(gy.device, ("Yt", ctx.w_param.data_ptr()) if _ASYNC_WGRAD.active else "Yt", 16 * T * K)
+                Yt_done = _wino_scratch(gy.device, ("Yt", ctx.w_param.data_ptr()) if _ASYNC_WGRAD.active else "Yt", wP * wT * K)
 
             def run():
                 if U2 is not None:
-                    _wino_conv(lib, gy, None, dx, None, N, H, W, K, C, 1, U=U2, dy_out=Yt_done)
+                    _wino_conv(lib, gy, None, dx, None, N, H, W, K, C, 1, U=U2, dy_out=Yt_done, tile=tile)
                 else:
                     wt = _wino_scratch(gy.device, "wt", wk.numel())
                     lib.weight_transpose(wk, wt, K, R * S, C)
-                    _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1, dy_out=Yt_done)
+                    _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1, dy_out=Yt_done, tile=tile)
             PROFILE.bracket("conv_dgrad_wino", run)
         elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=_CL)
@@ -605,12 +622,12 @@ class _Conv2dMFMA(torch.autograd.Function):
                 tgt = dw
             # accumulates (fp32 atomics) straight into the flat gradient buffer when the parameter lives in one
             if v_saved is not None:
-                T = N * ((H + 1) // 2) * ((W + 1) // 2)
+                wm, wP, T = _wino_tile(lib, N, H, W, C, K)
                 Yt = Yt_done if Yt_done is not None else _wino_scratch(
-                    gy.device, ("Yt", w.data_ptr()) if _ASYNC_WGRAD.active else "Yt", 16 * T * K)
-                parts = lib.wino_wgrad_parts(N, H, W, C, K)      # > 0: the slab form on csrc/gemm.hip (no atomics, nothing to zero)
+                    gy.device, ("Yt", w.data_ptr()) if _ASYNC_WGRAD.active else "Yt", wP * T * K)
+                parts = lib.wino_wgrad_parts(N, H, W, C, K, wm)  # > 0: the slab form on csrc/gemm.hip (no atomics, nothing to zero)
                 if parts > 0:
-                    dU = _wino_scratch(gy.device, ("dUp", w.data_ptr()) if _ASYNC_WGRAD.active else "dUp", parts * 16 * K * C)
+                    dU = _wino_scratch(gy.device, ("dUp", w.data_ptr()) if _ASYNC_WGRAD.active else "dUp", parts * wP * K * C)
                 else:
                     key = (gy.device, "dU", 16 * K * C)
                     dU = _WINO_SCRATCH.get(key)
@@ -619,14 +636,14 @@ class _Conv2dMFMA(torch.autograd.Function):
                         _WINO_SCRATCH[key] = dU
 
                 if PROFILE.on:
-                    PROFILE.conv_log.append((("wino", N, H, W, C, K), "gemm-tn"))
+                    PROFILE.conv_log.append((("wino", N, H, W, C, K, wm), "gemm-tn"))
 
                 def run_w():
                     if Yt_done is None:
-                        lib.wino_dy_transform(gy, Yt, N, H, W, K)
+                        lib.wino_dy_transform(gy, Yt, N, H, W, K, wm)
                     if parts > 0:
-                        lib.wino_wgrad_gemm_parts(v_saved, Yt, dU, N, H, W, C, K, parts)
-                        lib.wino_dw_transform_parts(dU, parts, tgt, K, C)
+                        lib.wino_wgrad_gemm_parts(v_saved, Yt, dU, N, H, W, C, K, parts, wm)
+                        lib.wino_dw_transform_parts(dU, parts, tgt, K, C, wm)
                     else:
                         lib.wino_wgrad_gemm(v_saved, Yt, dU, N, H, W, C, K)
                         lib.wino_dw_transform(dU, tgt, K, C, clear=True)

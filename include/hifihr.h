@@ -257,6 +257,28 @@ int hifihr_wino_input_dy_transform(const float* dy_d, float* v_d, float* yt_d, i
  * (VGG19 layers of the perceptual loss, reference utils/perceptual_loss.py:27-36). */
 int hifihr_wino_output_transform_act(const float* m_d, float* y_d, const float* bias_d /* or NULL */, int act, int N, int H, int W,
                                      int K, void* stream);
+/* Winograd F(4x4, 3x3) (csrc/wino4.hip): the same pipeline with 4x4 output tiles -- 36 positions, T = N * ceil(H/4) * ceil(W/4), 4x fewer
+ * multiplications than the direct convolution (F(2x2, 3x3): 2.25x), results within 1e-5 of it.  Every entry point above has an `_m`
+ * form that takes the tile edge m (2 or 4; the plain names are m = 2); all calls of one layer must use the same m, and buffers are sized
+ * with P = (m + 2)^2 positions: U[P][K][C], V[P][T][C], M[P][T][K], Y'[P][T][K], du_parts[parts][P][K][C].
+ * hifihr_wino_tile(N, H, W, C, K) returns the m this library prefers for a layer: 4 where the batched GEMMs of csrc/gemm.hip take the
+ * shape in all three directions (C % 64 == 0, K % 64 == 0, H, W >= 4), else 2.  m = 4 has the slab form of backward-weight only
+ * (hifihr_wino_wgrad_parts_m > 0).  The per-step weight re-layout (hifihr_weight_prep) has job kinds 3 / 4 for U[36][K][C] / U'[36][C][K]. */
+int hifihr_wino_tile(int N, int H, int W, int C, int K);
+size_t hifihr_wino_gemm_workspace_bytes_m(int N, int H, int W, int C, int K, int m);
+int hifihr_wino_weight_transform_m(const float* w_d, float* u_d, int K, int C, int flip, int m, void* stream);
+int hifihr_wino_input_transform_m(const float* x_d, float* v_d, int N, int H, int W, int C, int m, void* stream);
+int hifihr_wino_gemm_m(const float* v_d, const float* u_d, float* m_d, int N, int H, int W, int C, int K, int m, void* ws_d, size_t ws_bytes,
+                       void* stream);
+int hifihr_wino_output_transform_m(const float* m_d, float* y_d, float* stats_d /* or NULL */, int N, int H, int W, int K, int m, void* stream);
+int hifihr_wino_output_transform_act_m(const float* m_d, float* y_d, const float* bias_d /* or NULL */, int act, int N, int H, int W, int K,
+                                       int m, void* stream);
+int hifihr_wino_dy_transform_m(const float* dy_d, float* yt_d, int N, int H, int W, int K, int m, void* stream);
+int hifihr_wino_input_dy_transform_m(const float* dy_d, float* v_d, float* yt_d, int N, int H, int W, int K, int m, void* stream);
+int hifihr_wino_wgrad_parts_m(int N, int H, int W, int C, int K, int m);
+int hifihr_wino_wgrad_gemm_parts_m(const float* v_d, const float* yt_d, float* du_parts_d, int N, int H, int W, int C, int K, int parts, int m,
+                                   void* stream);
+int hifihr_wino_dw_transform_parts_m(const float* du_parts_d, int parts, float* dw_acc_d, int K, int C, int m, void* stream);
 /* Batched fp32 GEMM on the f32 matrix cores (csrc/gemm.hip): the plain products a Winograd layer consists of -- the GEMM half of
  * the vendor-library call behind one conv2d of the reference (network/res_encoder.py:364-373).  hifihr_wino_gemm dispatches here
  * when the shape allows (C % 32 == 0, K % 64 == 0; hifihr_wino_gemm_workspace_bytes then returns 0).

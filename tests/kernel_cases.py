@@ -736,7 +736,9 @@ def se_case(lib, device, B, H, W, C, SQ, seed=0):
 # ------------------------------------------------------------------------------------------------
 # Winograd F(2x2, 3x3) path (csrc/wino.hip + the batched MFMA GEMM) vs torch conv2d, forward and backward-data
 # ------------------------------------------------------------------------------------------------
-def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
+def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True, m=2):
+    """m = 2: F(2x2, 3x3) (csrc/wino.hip, 16 positions); m = 4: F(4x4, 3x3) (csrc/wino4.hip, 36 positions, slab backward-weight only)."""
+    P = (m + 2) ** 2
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(seed)
     x = torch.randn(N, C, H, W, generator=gen); w = torch.randn(K, C, 3, 3, generator=gen) / (9 * C) ** 0.5
@@ -745,18 +747,18 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
     gy = torch.randn(y.shape, generator=gen)
     y.backward(gy)
     d = lambda t: t.to(device).contiguous()
-    T = N * ((H + 1) // 2) * ((W + 1) // 2)
+    T = N * ((H + m - 1) // m) * ((W + m - 1) // m)
     xd, wd, gyd = d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), d(gy.permute(0, 2, 3, 1))
-    nb = max(lib.wino_gemm_workspace_bytes(N, H, W, C, K), lib.wino_gemm_workspace_bytes(N, H, W, K, C)) if use_ws else 0
+    nb = max(lib.wino_gemm_workspace_bytes(N, H, W, C, K, m), lib.wino_gemm_workspace_bytes(N, H, W, K, C, m)) if use_ws else 0
     ws = torch.zeros(nb // 4, device=device) if nb else None
     # forward
-    U = torch.empty(16, K, C, device=device); V = torch.empty(16, T, C, device=device); M = torch.empty(16, T, K, device=device)
+    U = torch.empty(P, K, C, device=device); V = torch.empty(P, T, C, device=device); M = torch.empty(P, T, K, device=device)
     out = torch.full((N, H, W, K), 7.0, device=device)
     stats = torch.zeros(lib.bn_stats_floats(K), device=device) if with_stats else None
-    lib.wino_weight_transform(wd, U, K, C, 0)
-    lib.wino_input_transform(xd, V, N, H, W, C)
-    lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws)
-    lib.wino_output_transform(M, out, stats, N, H, W, K)
+    lib.wino_weight_transform(wd, U, K, C, 0, m)
+    lib.wino_input_transform(xd, V, N, H, W, C, m)
+    lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws, m=m)
+    lib.wino_output_transform(M, out, stats, N, H, W, K, m=m)
     ref = y.detach().permute(0, 2, 3, 1)
     err = float((out.cpu() - ref).abs().max())
     assert err <= 3e-5 * float(ref.abs().max()) + 1e-6, f"winograd fwd: {err} vs {float(ref.abs().max())}"
@@ -768,46 +770,48 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True):
     bias = torch.randn(K, generator=gen) * 0.3
     for act in (0, 1):
         out2 = torch.full((N, H, W, K), 7.0, device=device)
-        lib.wino_output_transform(M, out2, None, N, H, W, K, bias=d(bias), act=act)
+        lib.wino_output_transform(M, out2, None, N, H, W, K, bias=d(bias), act=act, m=m)
         ref2 = ref + bias
         ref2 = F.relu(ref2) if act else ref2
         assert float((out2.cpu() - ref2).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6, f"winograd bias/act epilogue (act={act})"
     # backward-data: the same pipeline on dy with the transposed, rotated filter
     wt = torch.empty(C, 3, 3, K, device=device)
     lib.weight_transpose(wd, wt, K, 9, C)
-    U2 = torch.empty(16, C, K, device=device); V2 = torch.empty(16, T, K, device=device); M2 = torch.empty(16, T, C, device=device)
+    U2 = torch.empty(P, C, K, device=device); V2 = torch.empty(P, T, K, device=device); M2 = torch.empty(P, T, C, device=device)
     dx = torch.full((N, H, W, C), 7.0, device=device)
-    lib.wino_weight_transform(wt, U2, C, K, 1)
-    lib.wino_input_transform(gyd, V2, N, H, W, K)
+    lib.wino_weight_transform(wt, U2, C, K, 1, m)
+    lib.wino_input_transform(gyd, V2, N, H, W, K, m)
     # one read of dy for both backward transforms == the two separate kernels, bit for bit
-    V2b = torch.full_like(V2, 7.0); Ytb = torch.full((16, T, K), 7.0, device=device); Yt_ref = torch.empty(16, T, K, device=device)
-    lib.wino_input_dy_transform(gyd, V2b, Ytb, N, H, W, K)
-    lib.wino_dy_transform(gyd, Yt_ref, N, H, W, K)
+    V2b = torch.full_like(V2, 7.0); Ytb = torch.full((P, T, K), 7.0, device=device); Yt_ref = torch.empty(P, T, K, device=device)
+    lib.wino_input_dy_transform(gyd, V2b, Ytb, N, H, W, K, m)
+    lib.wino_dy_transform(gyd, Yt_ref, N, H, W, K, m)
     assert torch.equal(V2b, V2) and torch.equal(Ytb, Yt_ref), "dual dy transform"
-    lib.wino_gemm(V2, U2, M2, N, H, W, K, C, ws=ws)
-    lib.wino_output_transform(M2, dx, None, N, H, W, C)
+    lib.wino_gemm(V2, U2, M2, N, H, W, K, C, ws=ws, m=m)
+    lib.wino_output_transform(M2, dx, None, N, H, W, C, m=m)
     refx = xr.grad.permute(0, 2, 3, 1)
     err = float((dx.cpu() - refx).abs().max())
     assert err <= 3e-5 * float(refx.abs().max()) + 1e-6, f"winograd bwd data: {err} vs {float(refx.abs().max())}"
     assert ws is None or float(ws.abs().max()) == 0.0
     # backward-weight: dU = sum over tiles of (A dy A^T) . (B^T d B), then dw += G^T dU G
-    lib.wino_input_transform(xd, V, N, H, W, C)
-    Yt = torch.empty(16, T, K, device=device); dU = torch.zeros(16, K, C, device=device)
-    lib.wino_dy_transform(gyd, Yt, N, H, W, K)
-    lib.wino_wgrad_gemm(V, Yt, dU, N, H, W, C, K)
-    dw = torch.full((K, 3, 3, C), 0.5, device=device)                    # accumulate semantics
-    lib.wino_dw_transform(dU, dw, K, C)
-    assert float(dU.abs().max()) == 0.0, "the dU accumulator must come back zeroed"
+    lib.wino_input_transform(xd, V, N, H, W, C, m)
+    Yt = torch.empty(P, T, K, device=device); dU = torch.zeros(P, K, C, device=device)
+    lib.wino_dy_transform(gyd, Yt, N, H, W, K, m)
     refw = wr.grad.permute(0, 2, 3, 1)
-    err = float((dw.cpu() - 0.5 - refw).abs().max())
-    assert err <= 1e-4 * float(refw.abs().max()) + 1e-6, f"winograd bwd weight: {err} vs {float(refw.abs().max())}"
+    if m == 2:                                                           # the atomics form exists for F(2x2, 3x3) only
+        lib.wino_wgrad_gemm(V, Yt, dU, N, H, W, C, K)
+        dw = torch.full((K, 3, 3, C), 0.5, device=device)                # accumulate semantics
+        lib.wino_dw_transform(dU, dw, K, C)
+        assert float(dU.abs().max()) == 0.0, "the dU accumulator must come back zeroed"
+        err = float((dw.cpu() - 0.5 - refw).abs().max())
+        assert err <= 1e-4 * float(refw.abs().max()) + 1e-6, f"winograd bwd weight: {err} vs {float(refw.abs().max())}"
     # the same reduction as slabs on csrc/gemm.hip (no atomics, nothing zero-initialised), summed by the slab form of the transform
-    parts = lib.wino_wgrad_parts(N, H, W, C, K)
+    parts = lib.wino_wgrad_parts(N, H, W, C, K, m)
+    assert m == 2 or parts > 0
     if parts > 0:
-        dUp = torch.full((parts, 16, K, C), 7.0, device=device)
-        lib.wino_wgrad_gemm_parts(V, Yt, dUp, N, H, W, C, K, parts)
+        dUp = torch.full((parts, P, K, C), 7.0, device=device)
+        lib.wino_wgrad_gemm_parts(V, Yt, dUp, N, H, W, C, K, parts, m)
         dw2 = torch.full((K, 3, 3, C), 0.5, device=device)
-        lib.wino_dw_transform_parts(dUp, parts, dw2, K, C)
+        lib.wino_dw_transform_parts(dUp, parts, dw2, K, C, m)
         err = float((dw2.cpu() - 0.5 - refw).abs().max())
         assert err <= 1e-4 * float(refw.abs().max()) + 1e-6, f"winograd bwd weight (slabs): {err} vs {float(refw.abs().max())}"
     return 0 if ws is None else 1
@@ -920,6 +924,11 @@ def weight_prep_case(lib, device, seed=0):
             lib.wino_weight_transform(wt, U2, C, K, 1)
             jobs.append((w, torch.full((16 * K * C,), 7.0, device=device), K, C, 9, 1)); want.append(U)
             jobs.append((w, torch.full((16 * K * C,), 7.0, device=device), K, C, 9, 2)); want.append(U2)
+            U4 = torch.empty(36 * K * C, device=device); U42 = torch.empty(36 * K * C, device=device)      # F(4x4, 3x3): kinds 3 / 4
+            lib.wino_weight_transform(w, U4, K, C, 0, 4)
+            lib.wino_weight_transform(wt, U42, C, K, 1, 4)
+            jobs.append((w, torch.full((36 * K * C,), 7.0, device=device), K, C, 9, 3)); want.append(U4)
+            jobs.append((w, torch.full((36 * K * C,), 7.0, device=device), K, C, 9, 4)); want.append(U42)
     table = lib.prep_jobs(jobs, device)
     lib.weight_prep(table, len(jobs), 3)
     for (_, dst, K, C, RS, kind), ref in zip(jobs, want):

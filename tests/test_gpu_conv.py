@@ -52,7 +52,10 @@ def test_resnet18_trunk_mfma_vs_reference_golden(golden_dir):
     x = ops.image_to_nhwc4(torch.tensor(g["x"]).cuda())
     low, feat = enc(x)
     np.testing.assert_allclose(low.detach().cpu().numpy(), g["low"], atol=5e-5, rtol=1e-4)
-    np.testing.assert_allclose(feat.detach().cpu().numpy(), g["feat"], atol=5e-5, rtol=1e-4)
+    # features: 2e-4 -- layers 2-4 run Winograd F(4x4, 3x3) (each convolution within 1e-5 of max |y| of the direct result, csrc/wino4.hip)
+    # and a batch of 2 through 20 train-mode batch-norms amplifies that rounding: 9e-5 observed on values of 0.4-2.6; with
+    # HIFIHR_WINO_M=2 (F(2x2, 3x3)) the same comparison holds at 5e-5.  The per-convolution parity is pinned shape by shape above.
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), g["feat"], atol=2e-4, rtol=1e-4)
     ((low * torch.tensor(g["wl"]).cuda()).sum() + (feat * torch.tensor(g["wf"]).cuda()).sum()).backward()
     for key, grad in (("g_conv1", net.conv1.weight.grad), ("g_bn1", net.bn1.weight.grad),
                       ("g_l4c2", net.layer4[1].conv2.weight.grad[:8]), ("g_l2ds", net.layer2[0].downsample[0].weight.grad)):

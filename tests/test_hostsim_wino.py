@@ -16,3 +16,17 @@ def test_winograd_fwd_bwd(hostsim_lib, N, H, W, C, K):
 
 def test_weight_prep_equals_separate_transforms(hostsim_lib):
     kc.weight_prep_case(hostsim_lib, "cpu")
+
+
+@pytest.mark.parametrize("N,H,W,C,K", [(2, 8, 8, 64, 64), (1, 7, 5, 64, 128), (3, 4, 4, 128, 64), (1, 14, 14, 64, 64), (2, 6, 9, 64, 64)])
+def test_winograd_f4_fwd_bwd(hostsim_lib, N, H, W, C, K):
+    """F(4x4, 3x3) (csrc/wino4.hip): forward (+ BN statistics, bias / ReLU epilogues), backward-data, the dual dy transform, backward-weight
+    as slabs -- image sizes that are and are not multiples of 4."""
+    assert hostsim_lib.wino_tile(N, H, W, C, K) == 4
+    kc.wino_case(hostsim_lib, "cpu", N, H, W, C, K, seed=C + K + H, m=4)
+
+
+def test_winograd_tile_choice(hostsim_lib):
+    assert hostsim_lib.wino_tile(2, 3, 8, 64, 64) == 2          # H < 4
+    assert hostsim_lib.wino_tile(2, 8, 8, 48, 64) == 2          # C not a multiple of 64: the slab GEMM does not take it
+    assert hostsim_lib.wino_tile(32, 14, 14, 512, 512) == 4

@@ -6,7 +6,7 @@ import torch
 import kernel_cases as kc
 from hifihr_amd._lib import get_lib
 from hifihr_amd.mano_tables import synthetic_mano_tables
-lib = get_lib()
+lib = get_lib() if not os.environ.get("RENDER_LIB") else __import__("hifihr_amd._lib", fromlist=["HifihrLib"]).HifihrLib(os.environ["RENDER_LIB"])
 t = synthetic_mano_tables(0)
 B, H, aa = 32, 224, 3
 verts, vcol, cam, lc, ld = (x.cuda().contiguous() for x in kc.make_render_inputs(t, B, 7, H))
