@@ -156,7 +156,7 @@ def conv_path_rooflines(ops, lib, dev, nprof):
             V = torch.randn(P_ * T_ * C_, device=dev)
             if direction == "gemm":
                 U = torch.randn(P_ * K_ * C_, device=dev) * 0.05; M = torch.empty(P_ * T_ * K_, device=dev)
-                name = lib.bgemm_describe(False, T_, K_, C_)
+                name = lib.bgemm_describe(False, T_, K_, C_, P_)
                 if not name:                       # shape outside csrc/gemm.hip: runs on the gather kernel
                     name = "conv_igemm_kernel"
                 nb = lib.wino_gemm_workspace_bytes(N_, H_, W_, C_, K_, m_)
@@ -167,7 +167,7 @@ def conv_path_rooflines(ops, lib, dev, nprof):
                 Y = torch.randn(P_ * T_ * K_, device=dev)
                 parts = lib.wino_wgrad_parts(N_, H_, W_, C_, K_, m_)
                 if parts > 0:
-                    name = lib.bgemm_describe(True, K_, C_, T_)
+                    name = lib.bgemm_describe(True, K_, C_, T_, P_)
                     dU = torch.empty(parts * P_ * K_ * C_, device=dev)
                     us = hip_us(lambda: lib.wino_wgrad_gemm_parts(V, Y, dU, N_, H_, W_, C_, K_, parts, m_))
                 else:

@@ -167,6 +167,7 @@ class HifihrLib:
         c.hifihr_wino_wgrad_gemm_parts_m.argtypes = [_c_float_p] * 3 + [c_int] * 7 + [c_void_p]
         c.hifihr_wino_dw_transform_parts_m.argtypes = [_c_float_p, c_int, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_bgemm_describe.argtypes = [c_int] * 4 + [ctypes.c_char_p, c_int]
+        c.hifihr_bgemm_describe_batch.argtypes = [c_int] * 5 + [ctypes.c_char_p, c_int]
         c.hifihr_conv2d_describe.argtypes = [c_int] * 10 + [ctypes.c_char_p, c_int]
         c.hifihr_bgemm_tn_parts.argtypes = [c_int] * 4
         c.hifihr_bgemm_tn.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
@@ -453,9 +454,9 @@ class HifihrLib:
         self.check(self.c.hifihr_conv2d_describe(N, H, W, C, K, R, S, stride, pad, int(direction), buf, 64), "hifihr_conv2d_describe")
         return buf.value.decode()
 
-    def bgemm_describe(self, tn, M, N, K):
+    def bgemm_describe(self, tn, M, N, K, batch=16):
         buf = ctypes.create_string_buffer(96)
-        self.check(self.c.hifihr_bgemm_describe(int(bool(tn)), M, N, K, buf, 96), "hifihr_bgemm_describe")
+        self.check(self.c.hifihr_bgemm_describe_batch(int(bool(tn)), M, N, K, batch, buf, 96), "hifihr_bgemm_describe_batch")
         return buf.value.decode()
 
     def bgemm_tn_parts(self, M, N, T, batch):

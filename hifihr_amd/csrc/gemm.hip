@@ -957,9 +957,18 @@ static void nt_tile(int M, int N, int K, int* bm, int* bn) {
   if (K >= 512 && N % 128 == 0) { *bm = 128; *bn = 128; }
   else { *bm = 64; *bn = 64; }
 }
-static void tn_tile(int M, int N, int* bm, int* bn) {
-  if ((long)M * N >= 512L * 256 && M % 128 == 0 && N % 128 == 0) { *bm = 128; *bn = 128; }
-  else { *bm = 64; *bn = 64; }
+static int gemm_cus();
+static void tn_tile(int M, int N, int batch, int* bm, int* bn) {
+  *bm = 64; *bn = 64;
+  if ((long)M * N >= 512L * 256 && M % 128 == 0 && N % 128 == 0) {
+    // 128x128 tiles run one workgroup per CU: more tiles than CUs only pays when the rounds come out nearly whole.  The 36 problems of a
+    // Winograd F(4x4, 3x3) layer give 288 / 576 tiles (1.125 / 2.25 rounds): the 64x64 kernel (several workgroups per CU) is faster there
+    // (tools/time_gemm_tn_f4.py: 85 -> 69 us at 256 x 512 channels, 136 -> 131 at 512 x 512)
+    const long t128 = (long)(M / 128) * (N / 128) * batch;
+    const int cus = gemm_cus();
+    const long rounds = (t128 + cus - 1) / cus;
+    if (t128 <= cus || (double)rounds * cus <= 1.15 * (double)t128) { *bm = 128; *bn = 128; }
+  }
 }
 
 size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch);
@@ -971,11 +980,13 @@ static bool nt_rows(int N) {
 }
 
 // which kernel instantiation a shape runs on, as rocprof names it (bench.py groups its roofline lines by this)
-void bgemm_describe(int tn, int M, int N, int K, char* out, int cap) {
+void bgemm_describe(int tn, int M, int N, int K, char* out, int cap) { bgemm_describe_batch(tn, M, N, K, 16, out, cap); }
+
+void bgemm_describe_batch(int tn, int M, int N, int K, int batch, char* out, int cap) {
   int bm, bn;
   const char* e;
   if (tn) {
-    tn_tile(M, N, &bm, &bn);
+    tn_tile(M, N, batch, &bm, &bn);
     if ((e = getenv("HIFIHR_GEMM_TN_TILE")) != nullptr) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (M % bm) bm = 64; if (N % bn) bn = 64; }
   } else {
     nt_tile(M, N, K, &bm, &bn);
@@ -1063,12 +1074,13 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
 int bgemm_tn_parts(int M, int N, int T, int batch) {
   if (const char* e = getenv("HIFIHR_GEMM_TN_PARTS")) { const int v = atoi(e); if (v > 0) return v; }
   int bm, bn;
-  tn_tile(M, N, &bm, &bn);
+  tn_tile(M, N, batch, &bm, &bn);
   if (const char* e = getenv("HIFIHR_GEMM_TN_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (M % bm) bm = 64; if (N % bn) bn = 64; }
   const int tiles = (M / bm) * (N / bn) * batch, nch = (T + 31) / 32;
   // 128x128 (one workgroup per CU): fill the CUs once; 64x64: ~2 workgroups per CU; at least 8 chunks per slab so that the slab
-  // round trip (written here, summed by wino_dw_transform_parts) stays small next to the reduction
-  int splits = ((bm == 128 && bn == 128) ? gemm_cus() : 2 * gemm_cus()) / tiles;
+  // round trip (written here, summed by wino_dw_transform_parts) stays small next to the reduction.  With the 36 problems of an
+  // F(4x4, 3x3) layer the 64x64 kernel does best at ~4.5 workgroups per CU (tools/time_gemm_tn_f4.py).
+  int splits = ((bm == 128 && bn == 128) ? gemm_cus() : batch > 16 ? (9 * gemm_cus() / 2 + tiles / 2) : 2 * gemm_cus()) / tiles;
   if (splits > nch / 8) splits = nch / 8;
   if (splits < 1) splits = 1;
   const int cps = (nch + splits - 1) / splits;
@@ -1081,7 +1093,7 @@ hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M,
   a.A = A; a.B = B; a.C = Cparts; a.M = M; a.N = N; a.K = T; a.lda = M; a.ldb = N; a.ldc = N;
   a.sa = (long)T * M; a.sb = (long)T * N; a.sc = (long)M * N; a.batch = batch;
   int bm, bn;
-  tn_tile(M, N, &bm, &bn);
+  tn_tile(M, N, batch, &bm, &bn);
   if (const char* e = getenv("HIFIHR_GEMM_TN_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (M % bm) bm = 64; if (N % bn) bn = 64; }
   a.tiles_m = M / bm; a.tiles_n = N / bn;
   const int nch = (T + 31) / 32;

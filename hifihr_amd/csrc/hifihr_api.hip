@@ -795,6 +795,13 @@ int hifihr_bgemm_describe(int tn, int M, int N, int K, char* out, int cap) {
   return HIFIHR_OK;
 }
 
+int hifihr_bgemm_describe_batch(int tn, int M, int N, int K, int batch, char* out, int cap) {
+  if (!out || cap < 8 || batch <= 0) return fail(HIFIHR_EINVAL, "hifihr_bgemm_describe_batch: bad argument");
+  if (tn ? !hifihr::bgemm_tn_supported(M, N, K) : !hifihr::bgemm_nt_supported(M, N, K)) { out[0] = 0; return HIFIHR_OK; }
+  hifihr::bgemm_describe_batch(tn, M, N, K, batch, out, cap);
+  return HIFIHR_OK;
+}
+
 int hifihr_bgemm_tn_parts(int M, int N, int T, int batch) {
   if (batch <= 0 || !hifihr::bgemm_tn_supported(M, N, T)) return 0;
   return hifihr::bgemm_tn_parts(M, N, T, batch);

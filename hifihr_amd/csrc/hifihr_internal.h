@@ -223,6 +223,7 @@ struct BgemmArgs {
   long sc_split;               // element stride between slabs of C
 };
 void bgemm_describe(int tn, int M, int N, int K, char* out, int cap);
+void bgemm_describe_batch(int tn, int M, int N, int K, int batch, char* out, int cap);
 bool bgemm_nt_supported(int M, int N, int K);
 bool bgemm_tn_supported(int M, int N, int T);
 size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch);

@@ -224,20 +224,22 @@ __global__ __launch_bounds__(256) void wino4_dw_transform_parts_kernel(const flo
     }
     __syncthreads();
     if (ok && pl < 9) {
+      // dw[r][c2] = sum_ij G^T[r][i] u[i][j] G^T[c2][j]: the two coefficient rows in registers (selected without indexing, so nothing
+      // lands in scratch), 42 multiply-adds per component
       const int r = pl / 3, c2 = pl - 3 * r;
-      V4 tcol[6];                                           // row r of G^T u: tcol[j] = sum_i G^T[r][i] u[i][j]
+      const float a1 = -1.f / 6.f;
+      const float cr[6] = {r == 0 ? 0.25f : 0.f, a1, r == 1 ? -a1 : a1, r == 0 ? 1.f / 24.f : r == 1 ? 1.f / 12.f : 1.f / 6.f,
+                           r == 0 ? 1.f / 24.f : r == 1 ? -1.f / 12.f : 1.f / 6.f, r == 2 ? 1.f : 0.f};
+      const float cc[6] = {c2 == 0 ? 0.25f : 0.f, a1, c2 == 1 ? -a1 : a1, c2 == 0 ? 1.f / 24.f : c2 == 1 ? 1.f / 12.f : 1.f / 6.f,
+                           c2 == 0 ? 1.f / 24.f : c2 == 1 ? -1.f / 12.f : 1.f / 6.f, c2 == 2 ? 1.f : 0.f};
+      V4 gq = zero4();
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        V4 col[6];
+        V4 t = zero4();
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { const float4 v = su[q * 6 + j][il]; col[q] = V4{v.x, v.y, v.z, v.w}; }
-        V4 o[3];
-        gt6(col, o);
-        tcol[j] = r == 0 ? o[0] : r == 1 ? o[1] : o[2];
+        for (int q = 0; q < 6; ++q) { const float4 v = su[q * 6 + j][il]; t = t + cr[q] * V4{v.x, v.y, v.z, v.w}; }
+        gq = gq + cc[j] * t;
       }
-      V4 o[3];
-      gt6(tcol, o);
-      const V4 gq = c2 == 0 ? o[0] : c2 == 1 ? o[1] : o[2];
       float* out = dw + (((size_t)k * 3 + r) * 3 + c2) * C + cg * 4;
       st4(out, ld4(out) + gq);
     }

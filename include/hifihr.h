@@ -295,7 +295,8 @@ int hifihr_bgemm_nt(const float* a_d, const float* b_d, float* c_d, int M, int N
                     void* ws_d /* zero-initialised, self-cleaning; or NULL */, size_t ws_bytes, void* stream);
 int hifihr_bgemm_tn_parts(int M, int N, int T, int batch);
 /* Name of the kernel instantiation a shape runs on, as a profiler lists it ("" when the shape is not supported): measurement only. */
-int hifihr_bgemm_describe(int tn, int M, int N, int K_or_T, char* out, int cap);
+int hifihr_bgemm_describe(int tn, int M, int N, int K_or_T, char* out, int cap);                       /* batch = 16 */
+int hifihr_bgemm_describe_batch(int tn, int M, int N, int K_or_T, int batch, char* out, int cap);
 int hifihr_bgemm_tn(const float* a_d, const float* b_d, float* c_parts_d, int M, int N, int T, int batch, int parts, void* stream);
 int hifihr_wino_wgrad_parts(int N, int H, int W, int C, int K);
 int hifihr_wino_wgrad_gemm_parts(const float* v_d, const float* yt_d, float* du_parts_d, int N, int H, int W, int C, int K, int parts,
