@@ -132,6 +132,14 @@ def test_winograd_path(lib, N, H, C, K):
     kc.wino_case(lib, "cuda", N, H, H, C, K, seed=C + K)
 
 
+@pytest.mark.parametrize("N,H,C,K", [(32, 14, 256, 256), (32, 14, 512, 512), (32, 28, 128, 128), (32, 14, 256, 512), (3, 9, 128, 192), (48, 56, 128, 128)])
+def test_winograd_f4_path(lib, N, H, C, K):
+    """Winograd F(4x4, 3x3) (csrc/wino4.hip, the default of layers 2-4): forward (+ BN statistics, bias / ReLU), backward-data, the dual
+    dy transform, slab backward-weight vs torch conv2d at the bench's sizes, a size that is not a multiple of 4 and a VGG-sized map."""
+    assert lib.wino_tile(N, H, H, C, K) == 4
+    kc.wino_case(lib, "cuda", N, H, H, C, K, seed=C + K + H, m=4)
+
+
 def test_weight_prep_equals_separate_transforms(lib):
     kc.weight_prep_case(lib, "cuda")
 
