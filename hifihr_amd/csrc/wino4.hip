@@ -208,6 +208,10 @@ __global__ __launch_bounds__(256) void wino4_dw_transform_parts_kernel(const flo
     const size_t i = base + il;
     const bool ok = i < total;
     const int cg = ok ? (int)(i % C4) : 0, k = ok ? (int)(i / C4) : 0;
+    // the read half of the dw += ... update goes out with the slab loads (it does not depend on them): one memory latency per pass less
+    float* const out = dw + (((size_t)k * 3 + (pl < 9 ? pl / 3 : 0)) * 3 + (pl < 9 ? pl % 3 : 0)) * C + cg * 4;
+    V4 dw_old = zero4();
+    if (ok && pl < 9) dw_old = ld4(out);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int pos = pl + 16 * q;
@@ -240,8 +244,7 @@ __global__ __launch_bounds__(256) void wino4_dw_transform_parts_kernel(const flo
         for (int q = 0; q < 6; ++q) { const float4 v = su[q * 6 + j][il]; t = t + cr[q] * V4{v.x, v.y, v.z, v.w}; }
         gq = gq + cc[j] * t;
       }
-      float* out = dw + (((size_t)k * 3 + r) * 3 + c2) * C + cg * 4;
-      st4(out, ld4(out) + gq);
+      st4(out, dw_old + gq);
     }
     __syncthreads();
   }
