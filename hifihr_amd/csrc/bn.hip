@@ -21,6 +21,7 @@
 // kernel that folds the slots writes the zeros back -- no memset launch per batch-norm (40 per ResNet-18 step).
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
 #include <cstdlib>
 
 #include "hifihr_internal.h"
@@ -471,6 +472,263 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The ResNet stem: MaxPool2d(3, 2, 1)(ReLU(BN(x))) (reference: vendored resnet.py conv1 -> bn1 -> relu -> maxpool) without the
+// full-resolution activation or its gradient ever reaching HBM.  At batch 32 that tensor is 103 MB: the separate kernels wrote it,
+// read it back for the pool, wrote its gradient in the pool's backward and read that twice in the batch-norm backward.
+//   forward : thread = (pooled pixel, 4 channels): nine taps of x through scale / shift / ReLU, maximum + winning tap (ATen's
+//             tie rule: the first in-range tap in scan order wins, a later one only if strictly greater)
+//   backward: thread = (input pixel, 4 channels): dy of the pool's backward gathered on the fly from the (at most four) windows
+//             whose winning tap is this pixel, then the ordinary batch-norm reduction / apply on it.
+// ------------------------------------------------------------------------------------------------
+struct StemPool {
+  int N, H, W, OH, OW;
+};
+
+__device__ __forceinline__ float4 bn_relu4(const float4& v, const float4& sc, const float4& sh) {
+  return make_float4(fmaxf(v.x * sc.x + sh.x, 0.f), fmaxf(v.y * sc.y + sh.y, 0.f), fmaxf(v.z * sc.z + sh.z, 0.f),
+                     fmaxf(v.w * sc.w + sh.w, 0.f));
+}
+
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, StemPool g,
+                                                              int C, float eps, float momentum, float* __restrict__ y,
+                                                              unsigned char* __restrict__ tap, float* __restrict__ save_mean,
+                                                              float* __restrict__ save_invstd, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var) {
+  __shared__ float s_sc[kFuseMaxC], s_sh[kFuseMaxC];
+  const long M = (long)g.N * g.H * g.W;
+  const float invM = 1.0f / (float)M;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s0, s1;
+    slot_sum2(stats, C, c, s0, s1);
+    const float mu = s0 * invM;
+    const float var = fmaxf(s1 * invM - mu * mu, 0.f);
+    const float is = 1.0f / sqrtf(var + eps);
+    const float sc = is * gamma[c];
+    s_sc[c] = sc;
+    s_sh[c] = beta[c] - mu * sc;
+    if (blockIdx.x == 0) {
+      save_mean[c] = mu;
+      save_invstd[c] = is;
+      if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        const float unbiased = (M > 1) ? var * ((float)M / (float)(M - 1)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+    }
+  }
+  __syncthreads();
+  const int C4 = C / 4, RL = 256 / C4;
+  const int cg = threadIdx.x % C4, rl = threadIdx.x / C4;
+  if (rl < RL) {
+    const float4 sc = *reinterpret_cast<const float4*>(&s_sc[cg * 4]), sh = *reinterpret_cast<const float4*>(&s_sh[cg * 4]);
+    const long Mo = (long)g.N * g.OH * g.OW;
+    for (long o = (long)blockIdx.x * RL + rl; o < Mo; o += (long)gridDim.x * RL) {
+      const int ow = (int)(o % g.OW);
+      const long r2 = o / g.OW;
+      const int oh = (int)(r2 % g.OH), n = (int)(r2 / g.OH);
+      // all nine loads issued before the first use (clamped addresses, validity kept aside)
+      float4 v[3][3];
+      bool ok[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int ih = oh * 2 - 1 + r;
+        const int ihc = ih < 0 ? 0 : (ih >= g.H ? g.H - 1 : ih);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int iw = ow * 2 - 1 + s;
+          const int iwc = iw < 0 ? 0 : (iw >= g.W ? g.W - 1 : iw);
+          ok[r][s] = ih == ihc && iw == iwc;
+          v[r][s] = *reinterpret_cast<const float4*>(x + (((size_t)n * g.H + ihc) * g.W + iwc) * C + cg * 4);
+        }
+      }
+      float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+      int4 mt = make_int4(0, 0, 0, 0);
+      bool first = true;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          if (!ok[r][s]) continue;
+          const float4 a = bn_relu4(v[r][s], sc, sh);
+          const int t = r * 3 + s;
+          if (first || a.x > m.x) { m.x = a.x; mt.x = t; }
+          if (first || a.y > m.y) { m.y = a.y; mt.y = t; }
+          if (first || a.z > m.z) { m.z = a.z; mt.z = t; }
+          if (first || a.w > m.w) { m.w = a.w; mt.w = t; }
+          first = false;
+        }
+      *reinterpret_cast<float4*>(y + (size_t)o * C + cg * 4) = m;
+      *reinterpret_cast<uchar4*>(tap + (size_t)o * C + cg * 4) =
+          make_uchar4((unsigned char)mt.x, (unsigned char)mt.y, (unsigned char)mt.z, (unsigned char)mt.w);
+    }
+  }
+  unsigned* cnt = reinterpret_cast<unsigned*>(stats + (size_t)(kStatSlots + 1) * 2 * C);
+  if (last_workgroup(cnt)) clear_slots(stats, C, cnt);
+}
+
+// Gradient of MaxPool2d(3, 2, 1) at input pixel m = (n, ih, iw), channels cg*4..+3.  Windows oh with oh * 2 - 1 + r == ih:
+// r = (ih + 1) % 2 + 2 j, j = 0, 1 -- two candidate rows x two candidate columns, all eight loads issued unconditionally.
+struct PoolTaps {
+  uchar4 t[2][2];
+  float4 g[2][2];
+  bool ok[2][2];
+  unsigned char me[2][2];
+};
+__device__ __forceinline__ void pool_taps_load(const float* __restrict__ gy, const unsigned char* __restrict__ tap, const StemPool& g, int C,
+                                               long m, int cg, PoolTaps& p) {
+  const int iw = (int)(m % g.W);
+  const long r2 = m / g.W;
+  const int ih = (int)(r2 % g.H), n = (int)(r2 / g.H);
+  int ohc[2], owc[2], rc[2], sc[2];
+  bool vh[2], vw[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    rc[j] = (ih + 1) % 2 + j * 2;
+    const int th = ih + 1 - rc[j];
+    vh[j] = rc[j] < 3 && th >= 0 && th / 2 < g.OH;
+    ohc[j] = vh[j] ? th / 2 : 0;
+    sc[j] = (iw + 1) % 2 + j * 2;
+    const int tw = iw + 1 - sc[j];
+    vw[j] = sc[j] < 3 && tw >= 0 && tw / 2 < g.OW;
+    owc[j] = vw[j] ? tw / 2 : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const size_t o = (((size_t)n * g.OH + ohc[j]) * g.OW + owc[k]) * C + cg * 4;
+      p.t[j][k] = *reinterpret_cast<const uchar4*>(tap + o);
+      p.g[j][k] = *reinterpret_cast<const float4*>(gy + o);
+      p.ok[j][k] = vh[j] && vw[k];
+      p.me[j][k] = (unsigned char)(rc[j] * 3 + sc[k]);
+    }
+}
+__device__ __forceinline__ float4 pool_taps_sum(const PoolTaps& p) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (p.ok[j][k] && p.t[j][k].x == p.me[j][k]) a.x += p.g[j][k].x;
+      if (p.ok[j][k] && p.t[j][k].y == p.me[j][k]) a.y += p.g[j][k].y;
+      if (p.ok[j][k] && p.t[j][k].z == p.me[j][k]) a.z += p.g[j][k].z;
+      if (p.ok[j][k] && p.t[j][k].w == p.me[j][k]) a.w += p.g[j][k].w;
+    }
+  return a;
+}
+
+constexpr int kPoolUnroll = 2;   // input pixels per trip: 2 x (8 gather loads + 1 x load) in flight per lane
+
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ tap,
+                                                                const float* __restrict__ x, const float* __restrict__ save_mean,
+                                                                const float* __restrict__ save_invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, StemPool g, int C,
+                                                                float* __restrict__ red) {
+  __shared__ float4 lds[2][256];
+  const BnMap mp = bn_map(C);
+  float4 s[kMaxNG], q[kMaxNG];
+#pragma unroll
+  for (int j = 0; j < kMaxNG; ++j) { s[j] = make_float4(0.f, 0.f, 0.f, 0.f); q[j] = s[j]; }
+  if (mp.active) {
+    const int cb = mp.cg0 * 4;
+    const float4 mu = *reinterpret_cast<const float4*>(save_mean + cb), is = *reinterpret_cast<const float4*>(save_invstd + cb);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + cb), be = *reinterpret_cast<const float4*>(beta + cb);
+    const float4 sc = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
+    const float4 sh = make_float4(be.x - mu.x * sc.x, be.y - mu.y * sc.y, be.z - mu.z * sc.z, be.w - mu.w * sc.w);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto accum = [&](const float4& gr, const float4& v) {
+      acc4(s[0], gr);
+      q[0].x += gr.x * ((v.x - mu.x) * is.x); q[0].y += gr.y * ((v.y - mu.y) * is.y);
+      q[0].z += gr.z * ((v.z - mu.z) * is.z); q[0].w += gr.w * ((v.w - mu.w) * is.w);
+    };
+    const long M = (long)g.N * g.H * g.W;
+    const long stride = (long)gridDim.x * mp.RL;
+    long m = (long)blockIdx.x * mp.RL + mp.rl;
+    for (; m + (kPoolUnroll - 1) * stride < M; m += kPoolUnroll * stride) {
+      PoolTaps p[kPoolUnroll];
+      float4 v[kPoolUnroll];
+#pragma unroll
+      for (int u = 0; u < kPoolUnroll; ++u) {
+        v[u] = *reinterpret_cast<const float4*>(x + (size_t)(m + u * stride) * C + cb);
+        pool_taps_load(gy, tap, g, C, m + u * stride, mp.cg0, p[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kPoolUnroll; ++u) accum(masked_grad(1, pool_taps_sum(p[u]), false, zero4, v[u], sc, sh), v[u]);
+    }
+    for (; m < M; m += stride) {
+      PoolTaps p;
+      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)m * C + cb);
+      pool_taps_load(gy, tap, g, C, m, mp.cg0, p);
+      accum(masked_grad(1, pool_taps_sum(p), false, zero4, v, sc, sh), v);
+    }
+  }
+  reduce_and_add(mp, C, s, q, lds, red);
+}
+
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ tap,
+                                                               const float* __restrict__ x, const float* __restrict__ save_mean,
+                                                               const float* __restrict__ save_invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ red, StemPool g, int C,
+                                                               float* __restrict__ dx, float* __restrict__ dgamma_acc,
+                                                               float* __restrict__ dbeta_acc) {
+  __shared__ float s_mg[kFuseMaxC], s_mgx[kFuseMaxC];
+  const BnMap mp = bn_map(C);
+  const long M = (long)g.N * g.H * g.W;
+  const float invM = 1.0f / (float)M;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sg, sgx;
+    slot_sum2(red, C, c, sg, sgx);
+    s_mg[c] = sg * invM;
+    s_mgx[c] = sgx * invM;
+    if (blockIdx.x == 0) {
+      if (dgamma_acc) dgamma_acc[c] += sgx;
+      if (dbeta_acc) dbeta_acc[c] += sg;
+    }
+  }
+  __syncthreads();
+  if (mp.active) {
+    const int cb = mp.cg0 * 4;
+    const float4 mu = *reinterpret_cast<const float4*>(save_mean + cb), is = *reinterpret_cast<const float4*>(save_invstd + cb);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + cb), be = *reinterpret_cast<const float4*>(beta + cb);
+    const float4 k1 = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
+    const float4 sh = make_float4(be.x - mu.x * k1.x, be.y - mu.y * k1.y, be.z - mu.z * k1.z, be.w - mu.w * k1.w);
+    const float4 mg = *reinterpret_cast<const float4*>(&s_mg[cb]), mgx = *reinterpret_cast<const float4*>(&s_mgx[cb]);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto emit = [&](const float4& gr, const float4& v, size_t o) {
+      float4 r;
+      r.x = k1.x * (gr.x - mg.x - (v.x - mu.x) * is.x * mgx.x);
+      r.y = k1.y * (gr.y - mg.y - (v.y - mu.y) * is.y * mgx.y);
+      r.z = k1.z * (gr.z - mg.z - (v.z - mu.z) * is.z * mgx.z);
+      r.w = k1.w * (gr.w - mg.w - (v.w - mu.w) * is.w * mgx.w);
+      *reinterpret_cast<float4*>(dx + o) = r;
+    };
+    const long stride = (long)gridDim.x * mp.RL;
+    long m = (long)blockIdx.x * mp.RL + mp.rl;
+    for (; m + (kPoolUnroll - 1) * stride < M; m += kPoolUnroll * stride) {
+      PoolTaps p[kPoolUnroll];
+      float4 v[kPoolUnroll];
+#pragma unroll
+      for (int u = 0; u < kPoolUnroll; ++u) {
+        v[u] = *reinterpret_cast<const float4*>(x + (size_t)(m + u * stride) * C + cb);
+        pool_taps_load(gy, tap, g, C, m + u * stride, mp.cg0, p[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kPoolUnroll; ++u)
+        emit(masked_grad(1, pool_taps_sum(p[u]), false, zero4, v[u], k1, sh), v[u], (size_t)(m + u * stride) * C + cb);
+    }
+    for (; m < M; m += stride) {
+      PoolTaps p;
+      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)m * C + cb);
+      pool_taps_load(gy, tap, g, C, m, mp.cg0, p);
+      emit(masked_grad(1, pool_taps_sum(p), false, zero4, v, k1, sh), v, (size_t)m * C + cb);
+    }
+  }
+  unsigned* cnt = reinterpret_cast<unsigned*>(red + (size_t)(kStatSlots + 1) * 2 * C);
+  if (last_workgroup(cnt)) clear_slots(red, C, cnt);
+}
+
 // Apply kernels: every workgroup re-reads the 32 x 2 x C slot partials (256 C bytes, L2-resident), so the grid is also bounded by
 // the tensor size: at most one workgroup per 128 rows (and at least 256 so that the GPU stays busy on small layers).
 static unsigned bn_grid(long M, int C, bool fused) {
@@ -547,6 +805,33 @@ hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, co
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_grid(M, C, false)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
                        red, act, M, C, dx, dres, dgamma_acc, dbeta_acc);
   }
+  return hipGetLastError();
+}
+
+static bool bn_pool_ok(int N, int H, int W, int C) { return N > 0 && H >= 2 && W >= 2 && C >= 4 && C % 4 == 0 && C <= kFuseMaxC; }
+
+bool bn_relu_maxpool_supported(int N, int H, int W, int C) { return bn_pool_ok(N, H, W, C); }
+
+hipError_t launch_bn_relu_maxpool_fwd(const float* x, float* stats, const float* gamma, const float* beta, int N, int H, int W, int C,
+                                      float eps, float momentum, float* y, unsigned char* tap, float* save_mean, float* save_invstd,
+                                      float* running_mean, float* running_var, hipStream_t st) {
+  if (!bn_pool_ok(N, H, W, C)) return hipErrorInvalidValue;
+  const StemPool g{N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(bn_grid((long)N * g.OH * g.OW, C, true)), dim3(256), 0, st, x, stats, gamma, beta, g, C, eps,
+                     momentum, y, tap, save_mean, save_invstd, running_mean, running_var);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_relu_maxpool_bwd(const float* gy, const unsigned char* tap, const float* x, const float* save_mean,
+                                      const float* save_invstd, const float* gamma, const float* beta, int N, int H, int W, int C, float* red,
+                                      float* dx, float* dgamma_acc, float* dbeta_acc, hipStream_t st) {
+  if (!bn_pool_ok(N, H, W, C)) return hipErrorInvalidValue;
+  const StemPool g{N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+  const long M = (long)N * H * W;
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(bn_reduce_grid(M, C)), dim3(256), 0, st, gy, tap, x, save_mean, save_invstd, gamma, beta, g,
+                     C, red);
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(bn_grid(M, C, true)), dim3(256), 0, st, gy, tap, x, save_mean, save_invstd, gamma, beta, red,
+                     g, C, dx, dgamma_acc, dbeta_acc);
   return hipGetLastError();
 }
 

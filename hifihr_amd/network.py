@@ -165,7 +165,7 @@ class Resnet_4C(nn.Module):
         from . import ops
         m = self.model
         h, st = _conv_bn(m.conv1, x, m.bn1)
-        x = ops.maxpool3x3s2(ops.bn_act(h, st, m.bn1, None, True))
+        x = ops.bn_relu_maxpool(h, st, m.bn1)
         x = m.layer1(x)
         x_low = m.layer2(x)
         x = m.layer4(m.layer3(x_low))

@@ -793,6 +793,66 @@ def bn_act(x, stats, bn: torch.nn.BatchNorm2d, residual=None, relu=True):
                         bn.running_mean, bn.running_var)
 
 
+class _BNReluMaxPool(torch.autograd.Function):
+    """MaxPool2d(3, 2, 1)(ReLU(BN(x))) in one forward and two backward launches (csrc/bn.hip: bn_relu_pool_fwd_kernel,
+    bn_pool_bwd_reduce_kernel, bn_pool_bwd_apply_kernel): keeps x, the pooled winners' taps and the batch statistics."""
+
+    @staticmethod
+    def forward(ctx, x, stats, gamma, beta, eps, momentum, running_mean, running_var):
+        require_cuda(x, stats, gamma, beta)
+        lib = get_lib()
+        x = x.contiguous(memory_format=_CL)
+        N, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, C, OH, OW), device=x.device, memory_format=_CL)
+        tap = torch.empty(N * OH * OW * C, dtype=torch.uint8, device=x.device)
+        save_mean = torch.empty(C, device=x.device)
+        save_invstd = torch.empty(C, device=x.device)
+        PROFILE.bracket("bn_pool_fwd", lambda: lib.bn_relu_maxpool_fwd(x, stats, gamma, beta, N, H, W, C, eps, momentum, y, tap, save_mean,
+                                                                      save_invstd, running_mean, running_var))
+        _ZERO_POOL.release(stats)
+        ctx.save_for_backward(x, tap, gamma, beta, save_mean, save_invstd)
+        ctx.gamma_param, ctx.beta_param = gamma, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, tap, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        lib = get_lib()
+        N, C, H, W = x.shape
+        gy = gy.contiguous(memory_format=_CL)
+        dx = torch.empty_like(x, memory_format=_CL)
+        red = _ZERO_POOL.acquire(lib.bn_stats_floats(C), x.device)
+        dg_t, dg_ret = _bn_acc_target(ctx.gamma_param, C, x.device)
+        db_t, db_ret = _bn_acc_target(ctx.beta_param, C, x.device)
+        PROFILE.bracket("bn_pool_bwd", lambda: lib.bn_relu_maxpool_bwd(gy, tap, x, save_mean, save_invstd, gamma, beta, N, H, W, C, red, dx,
+                                                                      dg_t, db_t))
+        _ZERO_POOL.release(red)
+        if dg_ret is None:
+            _grad_ready(ctx.gamma_param)
+        if db_ret is None:
+            _grad_ready(ctx.beta_param)
+        return dx, None, dg_ret, db_ret, None, None, None, None
+
+
+def _bn_acc_target(p, C, device):
+    if getattr(p, "_hifihr_direct_grad", False) and p.grad is not None:
+        return p.grad, None                 # accumulate straight into the flat gradient buffer
+    t = torch.zeros(C, device=device)
+    return t, t
+
+
+def bn_relu_maxpool(x, stats, bn: torch.nn.BatchNorm2d):
+    """nn.MaxPool2d(3, 2, 1)(relu(bn(x))): the ResNet stem behind conv1 (reference trunk: vendored resnet.py forward).  Training
+    mode with batch statistics from our convolution and C <= 256: the fused kernels; anything else: bn_act followed by maxpool3x3s2.
+    HIFIHR_BN_POOL=0 keeps the two-step path (A/B timing)."""
+    if bn.training and stats is not None and x.is_cuda and os.environ.get("HIFIHR_BN_POOL", "1") != "0":
+        N, C, H, W = x.shape
+        if get_lib().bn_relu_maxpool_supported(N, H, W, C):
+            return _BNReluMaxPool.apply(x, stats, bn.weight, bn.bias, float(bn.eps), float(bn.momentum), bn.running_mean, bn.running_var)
+    return maxpool3x3s2(bn_act(x, stats, bn, None, True))
+
+
 # ------------------------------------------------------------------------------------------------
 # fused losses (csrc/losses.hip)
 # ------------------------------------------------------------------------------------------------

@@ -363,6 +363,22 @@ int hifihr_bn_act_bwd(const float* dy_d, const float* y_d /* act 1; NULL: recomp
                       const float* save_invstd_d, const float* gamma_d, const float* beta_d /* act 2 */, int act, long M, int C,
                       float* red_scratch_d, float* dx_d, float* dres_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
 
+/* The ResNet stem, bn1 -> relu -> maxpool fused: pooled = MaxPool2d(3, 2, 1)(ReLU(BN(x))) on x[N][H][W][C] (reference: the
+ * vendored trunk utils/Freihand_GNN_mano/network/resnet.py forward, `x = self.maxpool(self.relu(self.bn1(self.conv1(x))))`, driven
+ * from network/res_encoder.py:364-373).  The full-resolution activation and its gradient never reach HBM: the forward reads the
+ * nine taps of x through scale / shift / ReLU (tie rule of nn.MaxPool2d: first tap in scan order), the backward gathers the
+ * pool's gradient from pooled_grad + tap on the fly inside the batch-norm reduction and apply kernels.  Same statistics-buffer
+ * contract (all zero on entry, all zero on return) and the same save_mean / save_invstd / running-statistics outputs as
+ * hifihr_bn_act_fwd; C % 4 == 0, C <= 256, H, W >= 2.  pooled_d [N][OH][OW][C], tap_d one byte per pooled element,
+ * OH = (H - 1) / 2 + 1. */
+int hifihr_bn_relu_maxpool_supported(int N, int H, int W, int C);
+int hifihr_bn_relu_maxpool_fwd(const float* x_d, float* stats_d, const float* gamma_d, const float* beta_d, int N, int H, int W, int C,
+                               float eps, float momentum, float* pooled_d, unsigned char* tap_d, float* save_mean_d, float* save_invstd_d,
+                               float* running_mean_d, float* running_var_d, void* stream);
+int hifihr_bn_relu_maxpool_bwd(const float* pooled_grad_d, const unsigned char* tap_d, const float* x_d, const float* save_mean_d,
+                               const float* save_invstd_d, const float* gamma_d, const float* beta_d, int N, int H, int W, int C,
+                               float* red_scratch_d, float* dx_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Depthwise convolution (groups == channels), NHWC fp32, k = 3 or 5, TensorFlow-style asymmetric zero padding.
  * Replaces the depthwise Conv2dStaticSamePadding of the reference's EfficientNet MBConv blocks

@@ -500,6 +500,64 @@ def mmpool_case(lib, device, B, H, W, C, p0=0.3, seed=0, ties=False):
     assert abs(float(dp.cpu()) - 0.25 - float(pr.grad)) <= 1e-4 * max(1.0, abs(float(pr.grad))), "mmpool dp (accumulates)"
 
 
+def bn_relu_maxpool_case(lib, device, N, H, W, C, seed=0):
+    """hifihr_bn_relu_maxpool_{fwd,bwd} vs (a) the unfused kernels of the same library (forward: the same bits; backward: to the
+    rounding of the slot atomics) and (b) plain PyTorch fp32 autograd of MaxPool2d(3, 2, 1)(relu(batch_norm(x)))."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    M = N * H * W
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = torch.randn(N, C, H, W, generator=gen) * 1.5 + 0.3
+    gamma = 1 + 0.1 * torch.randn(C, generator=gen); beta = 0.1 * torch.randn(C, generator=gen) - 0.3     # plenty of ReLU zeros: ties
+    rm0, rv0 = torch.randn(C, generator=gen) * 0.1, 1 + 0.1 * torch.rand(C, generator=gen)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    out = F.max_pool2d(F.relu(F.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)), 3, 2, 1)
+    gy = torch.randn(out.shape, generator=gen)
+    out.backward(gy)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(device)
+    xd, gd, bd, gyd = nhwc(x), gamma.to(device), beta.to(device), nhwc(gy)
+    assert lib.bn_relu_maxpool_supported(N, H, W, C)
+    # fused
+    stats = torch.zeros(lib.bn_stats_floats(C), device=device)
+    lib.bn_stats(xd, M, C, stats)
+    stats2 = stats.clone()
+    y = torch.empty(N, OH, OW, C, device=device); tap = torch.empty(N * OH * OW * C, dtype=torch.uint8, device=device)
+    sm = torch.empty(C, device=device); si = torch.empty(C, device=device)
+    rmd, rvd = rm0.clone().to(device), rv0.clone().to(device)
+    lib.bn_relu_maxpool_fwd(xd, stats, gd, bd, N, H, W, C, 1e-5, 0.1, y, tap, sm, si, rmd, rvd)
+    assert float(stats.abs().max()) == 0.0, "bn_relu_maxpool_fwd must leave the slots and arrival counters zeroed"
+    # unfused kernels of the same library
+    yf = torch.empty(N, H, W, C, device=device); sm2 = torch.empty(C, device=device); si2 = torch.empty(C, device=device)
+    lib.bn_act_fwd(xd, stats2, gd, bd, None, 1, M, C, 1e-5, 0.1, yf, sm2, si2, None, None)
+    y2 = torch.empty_like(y); tap2 = torch.empty_like(tap)
+    lib.maxpool2d_fwd(yf, N, H, W, C, 3, 2, 1, y2, tap2)
+    assert torch.equal(sm, sm2) and torch.equal(si, si2), "fused stem: batch statistics"
+    assert torch.equal(y, y2) and torch.equal(tap, tap2), "fused stem forward == bn_act_fwd + maxpool2d_fwd (bits, winning taps)"
+    ref = out.detach().permute(0, 2, 3, 1)
+    assert float((y.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), "fused stem fwd vs torch"
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
+    # backward
+    red = torch.zeros(lib.bn_stats_floats(C), device=device)
+    dx = torch.full((N, H, W, C), 7.0, device=device)
+    dg = torch.full((C,), 0.5, device=device); db = torch.full((C,), -0.25, device=device)
+    lib.bn_relu_maxpool_bwd(gyd, tap, xd, sm, si, gd, bd, N, H, W, C, red, dx, dg, db)
+    assert float(red.abs().max()) == 0.0, "bn_relu_maxpool_bwd must leave the slots and arrival counters zeroed"
+    dyf = torch.empty(N, H, W, C, device=device)
+    lib.maxpool2d_bwd(gyd, tap, N, H, W, C, 3, 2, 1, dyf)
+    dx2 = torch.empty_like(dx); dg2 = torch.zeros(C, device=device); db2 = torch.zeros(C, device=device)
+    lib.bn_act_bwd(dyf, None, xd, sm, si, gd, bd, 1, M, C, red, dx2, None, dg2, db2)
+    scale = float(dx2.abs().max())
+    assert float((dx - dx2).abs().max()) <= 2e-6 * scale + 1e-9, "fused stem backward vs maxpool2d_bwd + bn_act_bwd"
+    assert float((dg - 0.5 - dg2).abs().max()) <= 1e-5 * float(dg2.abs().max()) + 1e-6
+    assert float((db + 0.25 - db2).abs().max()) <= 1e-5 * float(db2.abs().max()) + 1e-6
+    refdx = xr.grad.permute(0, 2, 3, 1)
+    assert float((dx.cpu() - refdx).abs().max()) <= 2e-4 * float(refdx.abs().max()) + 1e-7, "fused stem dx vs torch"
+    assert float((dg.cpu() - 0.5 - gr.grad).abs().max()) <= 2e-4 * float(gr.grad.abs().max()) + 1e-5
+    assert float((db.cpu() + 0.25 - br.grad).abs().max()) <= 2e-4 * float(br.grad.abs().max()) + 1e-5
+
+
 def maxpool_case(lib, device, N, H, W, C, seed=0, ties=False, ksp=(3, 2, 1)):
     """nn.MaxPool2d(k, s, p) forward / backward on NHWC."""
     k, s_, p_ = ksp

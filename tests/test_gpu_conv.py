@@ -70,6 +70,11 @@ def test_bn_act_kernels(lib, C, relu, residual, N, H):
     kc.bn_act_case(lib, "cuda", N, H, H, C, relu, residual, seed=C + N)
 
 
+@pytest.mark.parametrize("N,H,W,C", [(32, 112, 112, 64), (3, 37, 21, 64), (2, 16, 16, 256), (5, 9, 8, 12)])
+def test_bn_relu_maxpool_stem(lib, N, H, W, C):
+    kc.bn_relu_maxpool_case(lib, "cuda", N, H, W, C, seed=N + C)
+
+
 def test_conv_epilogue_bn_statistics(lib):
     kc.conv_bnstats_case(lib, "cuda", 8, 56, 56, 64, 64, 3, 1, 1)
     kc.conv_bnstats_case(lib, "cuda", 4, 224, 224, 4, 64, 7, 2, 3)

@@ -15,6 +15,11 @@ def test_bn_act_fwd_bwd(hostsim_lib, C, relu, residual):
     kc.bn_act_case(hostsim_lib, "cpu", 3, 5, 7, C, relu, residual, seed=C)
 
 
+@pytest.mark.parametrize("N,H,W,C", [(2, 8, 10, 64), (1, 7, 9, 16), (3, 5, 2, 8), (1, 12, 12, 256)])
+def test_bn_relu_maxpool_stem(hostsim_lib, N, H, W, C):
+    kc.bn_relu_maxpool_case(hostsim_lib, "cpu", N, H, W, C, seed=H + C)
+
+
 def test_conv_epilogue_bn_statistics(hostsim_lib):
     kc.conv_bnstats_case(hostsim_lib, "cpu", 2, 9, 7, 16, 64, 3, 1, 1)
     kc.conv_bnstats_case(hostsim_lib, "cpu", 1, 16, 16, 4, 64, 7, 2, 3)
