@@ -138,6 +138,8 @@ class HifihrLib:
         c.hifihr_conv2d_bwd_data_pre.argtypes = [_c_float_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_weight_prep.argtypes = [c_void_p, c_int, c_int, c_void_p]
         c.hifihr_freihand_augment.argtypes = [c_void_p, c_void_p, _c_int_p, _c_int_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_freihand_batch.argtypes = ([c_void_p, c_void_p] + [_c_float_p] * 4 + [c_int, c_int, _c_int_p, c_int, c_int, c_int, _c_float_p,
+                                            _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p, c_void_p])
         c.hifihr_procrustes_error.argtypes = [_c_float_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_wino_output_transform_act.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_dy_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
@@ -403,6 +405,21 @@ class HifihrLib:
 
     def weight_prep(self, table, njobs, blocks_per_job=64):
         self.check(self.c.hifihr_weight_prep(c_void_p(table.data_ptr()), njobs, blocks_per_job, _stream_of(table)), "hifihr_weight_prep")
+
+    def freihand_batch(self, img_rgbx, mask, Ks, joints, verts, scales, packed, B, out):
+        """out: dict with any of imgs, masks, segms_gt, Ks, Ps, joints, verts, j2d_gt, scales, idxs (device tensors, contiguous)."""
+        n, H, W = img_rgbx.shape
+        J, V = joints.shape[1], verts.shape[1]
+        vp = lambda t: c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+        g = out.get
+        for k in ("segms_gt", "idxs"):
+            assert g(k) is None or g(k).dtype == torch.int64
+        for t in out.values():
+            assert t.is_contiguous()
+        self.check(self.c.hifihr_freihand_batch(vp(img_rgbx), vp(mask), _fp(Ks), _fp(joints), _fp(verts), _fp(scales), J, V, _ip(packed), B, H, W,
+                                                _fp(g("imgs")), _fp(g("masks")), vp(g("segms_gt")), _fp(g("Ks")), _fp(g("Ps")), _fp(g("joints")),
+                                                _fp(g("verts")), _fp(g("j2d_gt")), _fp(g("scales")), vp(g("idxs")), _stream_of(packed)),
+                   "hifihr_freihand_batch")
 
     def freihand_augment(self, img_rgbx, mask, idx, coef_fix, out_img, out_mask):
         """img_rgbx int32/uint8x4 [n,H,W], mask uint8 [n,H,W] (either None with its output), idx int32 [B], coef_fix int32 [B,6]."""

@@ -995,6 +995,18 @@ int hifihr_freihand_augment(const uint32_t* img_rgbx, const uint8_t* mask, const
   return HIFIHR_OK;
 }
 
+int hifihr_freihand_batch(const uint32_t* img_rgbx, const uint8_t* mask, const float* Ks, const float* joints, const float* verts,
+                          const float* scales, int J, int V, const int* packed, int B, int H, int W, float* out_img, float* out_mask,
+                          long long* out_segm, float* out_Ks, float* out_Ps, float* out_joints, float* out_verts, float* out_j2d,
+                          float* out_scales, long long* out_idxs, void* stream) {
+  if (!img_rgbx || !mask || !Ks || !scales || !packed || B <= 0 || H <= 0 || W <= 0 || (long)H * W >= (1L << 24) || J < 0 || V < 0 ||
+      (J > 0 && !joints) || (V > 0 && !verts) || (out_j2d && !out_joints && J > 0 && !joints))
+    return fail(HIFIHR_EINVAL, "hifihr_freihand_batch: bad argument");
+  HIP_TRY(hifihr::launch_freihand_batch(img_rgbx, mask, Ks, joints, verts, scales, J, V, packed, B, H, W, out_img, out_mask, out_segm, out_Ks,
+                                        out_Ps, out_joints, out_verts, out_j2d, out_scales, out_idxs, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_input_dy_transform(const float* dy, float* V, float* Yt, int N, int H, int W, int K, void* stream) {
   if (!dy || !V || !Yt || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0)
     return fail(HIFIHR_EINVAL, "hifihr_wino_input_dy_transform: bad argument");

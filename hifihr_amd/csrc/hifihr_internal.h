@@ -214,6 +214,10 @@ struct PrepJob {
 hipError_t launch_weight_prep(const PrepJob* jobs, int njobs, int blocks_per_job, hipStream_t st);
 hipError_t launch_freihand_augment(const uint32_t* img, const uint8_t* mask, const int* idx, const int* coef, int B, int H, int W,
                                    float* out_img, float* out_mask, hipStream_t st);
+hipError_t launch_freihand_batch(const uint32_t* img, const uint8_t* mask, const float* Ks, const float* joints, const float* verts,
+                                 const float* scales, int J, int V, const int* packed, int B, int H, int W, float* out_img, float* out_mask,
+                                 long long* out_segm, float* oKs, float* oPs, float* ojoints, float* overts, float* oj2d, float* oscales,
+                                 long long* oidx, hipStream_t st);
 hipError_t launch_procrustes(const float* pred, const float* gt, int B, int N, float* aligned, float* err_sum, hipStream_t st);
 hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
                                         hipStream_t st);

@@ -125,28 +125,61 @@ class FreiHandDeviceCache:
             self._slots[i] = torch.empty(nwords, dtype=torch.int32).pin_memory()
         return i, self._slots[i][:nwords]
 
-    def batch(self, idxs, rots=None, generator=None, out_images=None, out_masks=None):
-        """One training batch assembled on the device.  Host work: the affine coefficients (numpy, stacked) and ONE pinned
-        staging buffer (indices + 16.16 warp terms + the two 3x3 matrices per sample) that goes over in ONE asynchronous copy.
-        out_images / out_masks: write the warped planes straight into caller-owned tensors (the static inputs of a captured step)."""
+    def _packed_terms(self, idxs, rots, generator):
+        """Host side of one batch: affine coefficients (numpy, stacked) packed with the indices and the two 3x3 matrices per sample
+        into ONE pinned staging buffer that goes over in ONE asynchronous copy.  -> (B, packed int32 [25 B] on the device)."""
         idxs = torch.as_tensor(idxs, dtype=torch.int64)
         B = idxs.shape[0]
         if rots is None:                       # np.random.uniform(-max_rot, max_rot) per sample (data/dataset.py:237)
             rots = (2 * torch.rand(B, generator=generator, dtype=torch.float64) - 1) * self.max_rot
         rots = np.asarray(rots, dtype=np.float64)
         fixed, post, rmat = batch_affine_terms(np.asarray([self.W // 2, self.H // 2]), self.H, [self.H, self.W], rots)
-        dev = self.device
         slot, host = self._stage(25 * B)
         hv = host.numpy()
         hv[:B] = idxs.numpy().astype(np.int32)
         hv[B:7 * B] = fixed.reshape(-1)
         hv[7 * B:16 * B] = post.reshape(-1).view(np.int32)
         hv[16 * B:25 * B] = rmat.reshape(-1).view(np.int32)
-        packed = torch.empty(25 * B, dtype=torch.int32, device=dev)
+        packed = torch.empty(25 * B, dtype=torch.int32, device=self.device)
         packed.copy_(host, non_blocking=True)
-        ev = self._events[slot] or torch.cuda.Event()
-        ev.record()
-        self._events[slot] = ev
+        if self.device.type == "cuda":
+            ev = self._events[slot] or torch.cuda.Event()
+            ev.record()
+            self._events[slot] = ev
+        return B, packed
+
+    EXAMPLE_KEYS = ("imgs", "masks", "segms_gt", "Ks", "Ps", "joints", "verts", "j2d_gt", "scales", "idxs")
+
+    def batch_examples(self, idxs, rots=None, generator=None, out=None):
+        """`data_dic(self.batch(...), "FreiHand", "training", ...)` -- the `examples` dict of a training step (reference
+        utils/traineval_util.py:21-111 over data/dataset.py:223-275) -- from ONE staged copy and TWO launches
+        (hifihr_freihand_batch: warp + segmentation plane; camera / joint / vertex / projection terms).  The two-step form costs
+        ~30 small ATen launches and, in front of a captured step, one device copy per entry of the dict (0.3 ms of a 6.4 ms step).
+        out: a dict holding tensors for EXAMPLE_KEYS (the static inputs of traineval.GraphedTrainStep) to be written in place."""
+        B, packed = self._packed_terms(idxs, rots, generator)
+        dev, J, V = self.device, self.joints.shape[1], self.verts.shape[1]
+        if out is None:
+            f = lambda *shape: torch.empty(*shape, device=dev)
+            out = {"imgs": f(B, 3, self.H, self.W), "masks": f(B, 3, self.H, self.W),
+                   "segms_gt": torch.empty(B, self.H, self.W, dtype=torch.int64, device=dev), "Ks": f(B, 3, 3), "Ps": f(B, 3, 4),
+                   "joints": f(B, J, 3), "verts": f(B, V, 3), "j2d_gt": f(B, J, 2), "scales": f(B),
+                   "idxs": torch.empty(B, dtype=torch.int64, device=dev)}
+        else:
+            expect = {"imgs": (B, 3, self.H, self.W), "masks": (B, 3, self.H, self.W), "segms_gt": (B, self.H, self.W), "Ks": (B, 3, 3),
+                      "Ps": (B, 3, 4), "joints": (B, J, 3), "verts": (B, V, 3), "j2d_gt": (B, J, 2), "scales": (B,), "idxs": (B,)}
+            for k, shape in expect.items():
+                if k not in out or tuple(out[k].shape) != shape:
+                    raise ValueError(f"batch_examples(out=...): '{k}' must be a tensor of shape {shape}")
+            out = {k: out[k] for k in expect}
+        self.lib.freihand_batch(self.images, self.masks, self.Ks, self.joints, self.verts, self.scales, packed, B, out)
+        return out
+
+    def batch(self, idxs, rots=None, generator=None, out_images=None, out_masks=None):
+        """One training batch assembled on the device.  Host work: the affine coefficients (numpy, stacked) and ONE pinned
+        staging buffer (indices + 16.16 warp terms + the two 3x3 matrices per sample) that goes over in ONE asynchronous copy.
+        out_images / out_masks: write the warped planes straight into caller-owned tensors (the static inputs of a captured step)."""
+        B, packed = self._packed_terms(idxs, rots, generator)
+        dev = self.device
         idx_d, coef_d = packed[:B], packed[B:7 * B].view(B, 6)
         post_d = packed[7 * B:16 * B].view(torch.float32).view(B, 3, 3)
         rmat_d = packed[16 * B:25 * B].view(torch.float32).view(B, 3, 3)

@@ -549,6 +549,20 @@ int hifihr_procrustes_error(const float* pred_d, const float* gt_d, int B, int N
 int hifihr_freihand_augment(const uint32_t* img_rgbx_d, const uint8_t* mask_d, const int* idx_d, const int* coef_fix_d, int B, int H,
                             int W, float* out_img_d, float* out_mask_d, void* stream);
 
+/* One FreiHAND training batch in two launches: the warp above (plus segms = mask channel 0 as int64, the reference's
+ * `masks[:, 0].long()`, utils/traineval_util.py:104) and everything else the sample dict and data_dic hold
+ * (reference data/dataset.py:256-275 per sample, utils/traineval_util.py:21-111 per batch):
+ *   Ks = post_rot_trans . K[idx];  joints / verts = (R p^T)^T;  Ps = [Ks | 0];  j2d_gt = (Ks j)_xy / (Ks j)_z (fh_utils.py:30-39);
+ *   scales[idx];  idxs as int64.
+ * Cache (device): Ks_d[n][3][3], joints_d[n][J][3], verts_d[n][V][3], scales_d[n].
+ * packed_d[25 B] int32, ONE host-to-device copy per batch: idx[B], coef_fix[B][6], post_rot_trans[B][3][3] (float bits),
+ * rot_mat[B][3][3] (float bits).  Every output may be NULL.  Outputs: out_Ks[B][3][3], out_Ps[B][3][4], out_joints[B][J][3],
+ * out_verts[B][V][3], out_j2d[B][J][2], out_scales[B], out_idxs[B] (int64), out_segm[B][H][W] (int64). */
+int hifihr_freihand_batch(const uint32_t* img_rgbx_d, const uint8_t* mask_d, const float* Ks_d, const float* joints_d, const float* verts_d,
+                          const float* scales_d, int J, int V, const int* packed_d, int B, int H, int W, float* out_img_d,
+                          float* out_mask_d, long long* out_segm_d, float* out_Ks_d, float* out_Ps_d, float* out_joints_d,
+                          float* out_verts_d, float* out_j2d_d, float* out_scales_d, long long* out_idxs_d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -964,6 +964,44 @@ def augment_case(lib, device, golden_dir):
         np.testing.assert_array_equal(post.dot(g[f"K{i}"]).astype(np.float32), g[f"tK{i}"])
 
 
+def freihand_batch_case(lib, device, seed=0, B=5, n=7, res=32, J=21, V=50):
+    """hifihr_freihand_batch == hifihr_freihand_augment + the torch broadcast expressions of hifihr_amd/data.py:batch and
+    traineval.data_dic (Ks, Ps, joints, verts, j2d_gt, scales, idxs, segms_gt)."""
+    from hifihr_amd.data import batch_affine_terms
+    from hifihr_amd.traineval import proj_func
+    rng = np.random.default_rng(seed)
+    rgbx = rng.integers(0, 256, (n, res, res, 4), dtype=np.uint8)
+    mk = (rng.random((n, res, res)) > 0.5).astype(np.uint8) * 255
+    Ks = np.tile(np.array([[400.0, 0, 112], [0, 410.0, 108], [0, 0, 1]], np.float32), (n, 1, 1)) + rng.normal(0, 1, (n, 3, 3)).astype(np.float32)
+    joints = (rng.normal(0, 0.05, (n, J, 3)) + np.array([0, 0, 0.6])).astype(np.float32)
+    verts = (rng.normal(0, 0.05, (n, V, 3)) + np.array([0, 0, 0.6])).astype(np.float32)
+    scales = rng.random(n).astype(np.float32)
+    idx = rng.integers(0, n, B)
+    rots = rng.uniform(-np.pi, np.pi, B)
+    fixed, post, rmat = batch_affine_terms(np.asarray([res // 2, res // 2]), res, [res, res], rots)
+    packed = np.concatenate([idx.astype(np.int32), fixed.reshape(-1), post.reshape(-1).view(np.int32), rmat.reshape(-1).view(np.int32)])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    cache = d(rgbx).view(torch.int32).reshape(n, res, res)
+    f = lambda *shape: torch.full(shape, 7.0, device=device)
+    out = {"imgs": f(B, 3, res, res), "masks": f(B, 3, res, res), "segms_gt": torch.full((B, res, res), 7, dtype=torch.int64, device=device),
+           "Ks": f(B, 3, 3), "Ps": f(B, 3, 4), "joints": f(B, J, 3), "verts": f(B, V, 3), "j2d_gt": f(B, J, 2), "scales": f(B),
+           "idxs": torch.full((B,), 7, dtype=torch.int64, device=device)}
+    lib.freihand_batch(cache, d(mk), d(Ks), d(joints), d(verts), d(scales), d(packed), B, out)
+    wi, wm = f(B, 3, res, res), f(B, 3, res, res)
+    lib.freihand_augment(cache, d(mk), d(idx.astype(np.int32)), d(fixed), wi, wm)
+    assert torch.equal(out["imgs"], wi) and torch.equal(out["masks"], wm) and torch.equal(out["segms_gt"], wm[:, 0].long())
+    il = torch.from_numpy(idx).long()
+    post_t, rmat_t = torch.from_numpy(post), torch.from_numpy(rmat)
+    wK = (post_t.unsqueeze(3) * torch.from_numpy(Ks)[il].unsqueeze(1)).sum(2)
+    rot = lambda pts: (pts.unsqueeze(2) * rmat_t.unsqueeze(1)).sum(3)
+    wj, wv = rot(torch.from_numpy(joints)[il]), rot(torch.from_numpy(verts)[il])
+    close = lambda a, b, tol=2e-6: float((a.cpu() - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    assert close(out["Ks"], wK) and close(out["joints"], wj) and close(out["verts"], wv)
+    assert torch.equal(out["Ps"][:, :, :3], out["Ks"]) and float(out["Ps"][:, :, 3].abs().max()) == 0.0
+    assert close(out["j2d_gt"], proj_func(wj, wK), 1e-5)
+    assert torch.equal(out["scales"].cpu(), torch.from_numpy(scales)[il]) and torch.equal(out["idxs"].cpu(), il)
+
+
 # ------------------------------------------------------------------------------------------------
 # one-launch weight re-layout (hifihr_weight_prep) == the separate transpose / Winograd weight transforms, bit for bit
 # ------------------------------------------------------------------------------------------------

@@ -122,6 +122,42 @@ def test_device_cache_batch_matches_reference_sample(golden_dir):
     assert ex["imgs"].data_ptr() == s["trans_images"].data_ptr() and ex["segms_gt"].dtype == torch.int64     # no copies on the way
 
 
+def test_freihand_batch_two_launches(lib):
+    kc.freihand_batch_case(lib, "cuda", seed=1)
+    kc.freihand_batch_case(lib, "cuda", seed=3, B=32, n=40, res=224, J=21, V=778)
+
+
+def test_device_cache_batch_examples_matches_data_dic(golden_dir):
+    """FreiHandDeviceCache.batch_examples (one staged copy, two launches, optionally straight into a captured step's static inputs)
+    == data_dic(cache.batch(...)): pixels / masks / indices exact, camera / joint terms to fp32 rounding."""
+    import os
+    from hifihr_amd import options
+    from hifihr_amd.data import FreiHandDeviceCache
+    from hifihr_amd.traineval import data_dic
+    g = np.load(os.path.join(golden_dir, "data_path.npz"))
+    ids = [1, 2, 3]
+    rng = np.random.default_rng(0)
+    cache = FreiHandDeviceCache(np.stack([g[f"img{i}"] for i in ids]), np.stack([g[f"mask{i}"] for i in ids]),
+                                np.stack([g[f"K{i}"] for i in ids]), np.stack([g[f"joints{i}"] for i in ids]),
+                                (rng.normal(0, 0.05, (3, 778, 3)) + np.array([0, 0, 0.6])).astype(np.float32))
+    order, rots = [2, 0, 1, 1], [0.3, -1.2, 2.9, 0.0]
+    want = data_dic(cache.batch(order, rots=rots), "FreiHand", "training", options.make_args(), device="cuda")
+    got = cache.batch_examples(order, rots=rots)
+    assert set(got) == set(want) == set(FreiHandDeviceCache.EXAMPLE_KEYS)
+    static = {k: torch.full_like(v, 3) for k, v in want.items()}
+    static["extra"] = torch.zeros(1, device="cuda")
+    into = cache.batch_examples(order, rots=rots, out=static)
+    for res in (got, into):
+        for k in ("imgs", "masks", "segms_gt", "idxs", "scales"):
+            assert res[k].dtype == want[k].dtype and torch.equal(res[k], want[k]), k
+        for k in ("Ks", "Ps", "joints", "verts", "j2d_gt"):
+            assert res[k].shape == want[k].shape
+            assert float((res[k] - want[k]).abs().max()) <= 2e-6 * max(1.0, float(want[k].abs().max())) * (5 if k == "j2d_gt" else 1), k
+    assert all(into[k].data_ptr() == static[k].data_ptr() for k in into)
+    with pytest.raises(ValueError):
+        cache.batch_examples(order[:2], rots=rots[:2], out=static)
+
+
 def test_evaluator_summary_matches_formulas(golden_dir):
     """hifihr_amd.evaluate.Evaluator vs the formulas of train_hrnet.py:149-161, 227-243 written out with torch."""
     import os

@@ -11,3 +11,8 @@ def hostsim_lib():
 
 def test_freihand_augment_vs_reference_pil(hostsim_lib, golden_dir):
     kc.augment_case(hostsim_lib, "cpu", golden_dir)
+
+
+def test_freihand_batch_two_launches(hostsim_lib):
+    kc.freihand_batch_case(hostsim_lib, "cpu", seed=1)
+    kc.freihand_batch_case(hostsim_lib, "cpu", seed=2, B=1, J=21, V=778)

@@ -3,7 +3,8 @@
 
 Steps are delimited by the fused Adam kernel (one launch per training step); only the last N complete steps
 are aggregated, so MIOpen's solver search during warm-up does not pollute the numbers.
-usage: tools/trace_summary.py <kernel_trace.csv> [N=5] > profiles/<name>.md
+usage: tools/trace_summary.py <kernel_trace.csv> [N=5] [timeline.txt] > profiles/<name>.md
+With a third argument the launches of the LAST step are also written in order (start offset, duration, idle gap before the launch).
 """
 import csv
 import re
@@ -49,6 +50,19 @@ def main():
     print("|---|---|---|---|---|---|")
     for k, (n, d, regs) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
         print(f"| `{k}` | {n / nsteps:.1f} | {d / nsteps / 1e3:.1f} | {d / n / 1e3:.1f} | {100 * d / busy:.1f} | {regs} |")
+
+
+    if len(sys.argv) > 3:
+        last = rows[ends[-2] + 1:ends[-1] + 1]
+        base = int(last[0]["Start_Timestamp"])
+        prev_end = base
+        with open(sys.argv[3], "w") as f:
+            f.write("# start_us  dur_us  gap_us  kernel   (last step of the trace; gap = idle time on the device before the launch)\n")
+            for r in last:
+                st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                f.write(f"{(st - base) / 1e3:9.1f} {(en - st) / 1e3:8.1f} {max(0, st - prev_end) / 1e3:7.1f}  {short(r['Kernel_Name'])[:70]}"
+                        f"  grid={r.get('Grid_Size_X', '?')}x{r.get('Grid_Size_Y', '?')}x{r.get('Grid_Size_Z', '?')}\n")
+                prev_end = max(prev_end, en)
 
 
 if __name__ == "__main__":

@@ -178,7 +178,8 @@ def main(argv=None):
         per_step = B * world
         for lo in range(0, cache.n - per_step + 1, per_step):
             idx = perm[lo + rank * B: lo + (rank + 1) * B]
-            ex = data_dic(cache.batch(idx, generator=rot_gen), "FreiHand", "training", args, device=device)
+            # the batch is written straight into the captured step's static inputs (one staged copy + two launches)
+            ex = cache.batch_examples(idx, generator=rot_gen, out=stepper.static if stepper is not None else None)
             if cli.graph and stepper is None:
                 ok = 1
                 try:
@@ -196,7 +197,8 @@ def main(argv=None):
                         stepper.release()
                     stepper, cli.graph = None, 0
             if stepper is not None:
-                stepper.load_batch(ex)
+                if ex["imgs"].data_ptr() != stepper.static["imgs"].data_ptr():      # the batch the step was captured on
+                    stepper.load_batch(ex)
                 loss, dic = stepper()
             else:
                 loss, dic = train_step(model, loss_func, opt, ex, args, backward_hook=reducer.finish)
