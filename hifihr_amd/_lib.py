@@ -113,6 +113,8 @@ class HifihrLib:
         c.hifihr_conv2d_bwd_weight.argtypes = [_c_float_p] * 3 + ci + [c_void_p]
         c.hifihr_conv2d_bwd_weight_ws.argtypes = [_c_float_p] * 3 + ci + [c_void_p, c_size_t, c_void_p]
         c.hifihr_conv2d_wgrad_workspace_bytes.argtypes = ci
+        c.hifihr_conv2d_bwd_weight_c3_supported.argtypes = [c_int] * 8
+        c.hifihr_conv2d_bwd_weight_c3.argtypes = [_c_float_p] * 3 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_conv2d_wgrad_workspace_bytes.restype = c_size_t
         c.hifihr_image_to_nhwc4.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_image_to_nhwc4_padded.argtypes = [_c_float_p, _c_float_p] + [c_int] * 8 + [c_void_p]
@@ -315,6 +317,13 @@ class HifihrLib:
         self.check(self.c.hifihr_bn_relu_maxpool_bwd(_fp(gy), c_void_p(tap.data_ptr()), _fp(x), _fp(save_mean), _fp(save_invstd), _fp(gamma),
                                                      _fp(beta), N, H, W, C, _fp(red), _fp(dx), _fp(dgamma_acc), _fp(dbeta_acc),
                                                      _stream_of(gy)), "hifihr_bn_relu_maxpool_bwd")
+
+    def conv2d_bwd_weight_c3_supported(self, N, H, W, K, R, S, stride, pad):
+        return bool(self.c.hifihr_conv2d_bwd_weight_c3_supported(N, H, W, K, R, S, stride, pad))
+
+    def conv2d_bwd_weight_c3(self, x4, dy, dw3, N, H, W, K, R, S, stride, pad, ws):
+        self.check(self.c.hifihr_conv2d_bwd_weight_c3(_fp(x4), _fp(dy), _fp(dw3), N, H, W, K, R, S, stride, pad, c_void_p(ws.data_ptr()),
+                                                      c_size_t(ws.numel() * ws.element_size()), _stream_of(x4)), "hifihr_conv2d_bwd_weight_c3")
 
     def dwconv2d_fwd(self, x, w, y, N, H, W, C, OH, OW, K, stride, pt, pl, stats=None):
         self.check(self.c.hifihr_dwconv2d_fwd(_fp(x), _fp(w), _fp(y), _fp(stats), N, H, W, C, OH, OW, K, stride, pt, pl,

@@ -852,6 +852,14 @@ size_t conv_wgrad_workspace_bytes(const ConvGeom& g) {
   return 0;
 }
 
+// The stem with a 3-channel parameter (reference conv1 = nn.Conv2d(3, 64, 7, 2, 3)): x is NHWC4 with a zero fourth plane, dw3 is
+// [64][7][7][3].  Only the slab kernel writes that layout; the caller provides its scratch (conv_wgrad_workspace_bytes).
+bool conv_wgrad_c3_supported(const ConvGeom& g) { return g.IC == 4 && conv_stem_wgrad_supported(g); }
+hipError_t launch_conv_wgrad_c3(const ConvGeom& g, const float* x, const float* dy, float* dw3, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!conv_wgrad_c3_supported(g) || ws == nullptr || ws_bytes < conv_stem_wgrad_slab_bytes()) return hipErrorInvalidValue;
+  return launch_conv_stem_wgrad(g, x, dy, dw3, static_cast<float*>(ws), st, 3);
+}
+
 hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
   const long M = (long)g.N * g.OH * g.OW;
   const int Q = g.R * g.S * g.IC;

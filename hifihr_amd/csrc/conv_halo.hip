@@ -873,9 +873,12 @@ __global__ __launch_bounds__(512) void conv_stem_wgrad_kernel(StemWgradArgs a) {
 }
 
 // dw[64][7][7][4] += sum over the slabs, in slab order
-__global__ __launch_bounds__(256) void conv_stem_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dw) {
+// dwC = channels of the destination [64][7][7][dwC]: 4, or 3 = the reference's parameter (nn.Conv2d(3, 64, 7, 2, 3)) whose image
+// arrives here as NHWC4 with a zero fourth plane -- the gradient lands in the parameter's own layout, no padded temporary
+__global__ __launch_bounds__(256) void conv_stem_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dw,
+                                                                    int dwC) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 64 * 196) return;
+  if (i >= 64 * 196 || (i & 3) >= dwC) return;
   float s = 0.f;
   int z = 0;
   for (; z + 32 <= nslab; z += 32) {
@@ -886,7 +889,7 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_reduce_kernel(const float
     for (int u = 0; u < 32; ++u) s += v[u];
   }
   for (; z < nslab; ++z) s += slabs[(size_t)z * (64 * 196) + i];
-  dw[i] += s;
+  dw[(i >> 2) * dwC + (i & 3)] += s;
 }
 
 #if defined(HIFIHR_HALO_STAMP)
@@ -971,8 +974,8 @@ bool conv_stem_wgrad_supported(const ConvGeom& g) {
 
 size_t conv_stem_wgrad_slab_bytes() { return (size_t)halo_cus() * 64 * 196 * sizeof(float); }
 
-hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* slabs, hipStream_t st) {
-  if (!conv_stem_wgrad_supported(g)) return hipErrorInvalidValue;
+hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* slabs, hipStream_t st, int dw_channels) {
+  if (!conv_stem_wgrad_supported(g) || (dw_channels != 3 && dw_channels != 4)) return hipErrorInvalidValue;
   const float* zeros = conv_halo_zero_page(st);
   if (zeros == nullptr) return hipErrorNotReady;
   StemWgradArgs a;
@@ -986,7 +989,7 @@ hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float
   a.slabs = slabs != nullptr ? slabs : halo_wgrad_scratch(st, (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float));      // (the pool's buffers: 9 x 64 x 64 >= 64 x 196 floats each)
   if (a.slabs == nullptr) return hipErrorNotReady;
   hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(G), dim3(512), 0, st, a);
-  hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3(64 * 196 / 256), dim3(256), 0, st, a.slabs, G, dw);
+  hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3(64 * 196 / 256), dim3(256), 0, st, a.slabs, G, dw, dw_channels);
   return hipGetLastError();
 }
 

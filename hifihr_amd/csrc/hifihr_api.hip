@@ -437,6 +437,22 @@ int hifihr_conv2d_bwd_weight_ws(const float* x, const float* dy, float* dw, int 
   return HIFIHR_OK;
 }
 
+int hifihr_conv2d_bwd_weight_c3_supported(int N, int H, int W, int K, int R, int S, int stride, int pad) {
+  if (!conv_dims_ok(N, H, W, 4, K, R, S, stride, pad) || K % 4) return 0;
+  hifihr::ConvGeom g{N, H, W, 4, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
+  return hifihr::conv_wgrad_c3_supported(g) ? 1 : 0;
+}
+
+int hifihr_conv2d_bwd_weight_c3(const float* x4, const float* dy, float* dw3, int N, int H, int W, int K, int R, int S, int stride, int pad,
+                                void* ws, size_t ws_bytes, void* stream) {
+  if (!x4 || !dy || !dw3 || !ws || !hifihr_conv2d_bwd_weight_c3_supported(N, H, W, K, R, S, stride, pad))
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_weight_c3: only the 7x7 / stride 2 / 64-filter stem on NHWC4 images, with the workspace of "
+                               "hifihr_conv2d_wgrad_workspace_bytes (ask hifihr_conv2d_bwd_weight_c3_supported)");
+  hifihr::ConvGeom g{N, H, W, 4, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
+  HIP_TRY(hifihr::launch_conv_wgrad_c3(g, x4, dy, dw3, ws, ws_bytes, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_image_to_nhwc4(const float* images, float* out, int B, int H, int W, void* stream) {
   if (!images || !out || B <= 0 || H <= 0 || W <= 0) return fail(HIFIHR_EINVAL, "hifihr_image_to_nhwc4: bad argument");
   HIP_TRY(hifihr::launch_image_to_nhwc4(images, out, B, H, W, H, W, 0, 0, 1, (hipStream_t)stream));

@@ -89,7 +89,8 @@ bool conv_stem_supported(const ConvGeom& g, const float* bias);
 hipError_t launch_conv_stem(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st);
 bool conv_stem_wgrad_supported(const ConvGeom& g);
 size_t conv_stem_wgrad_slab_bytes();
-hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* slabs_or_null, hipStream_t st);
+hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* slabs_or_null, hipStream_t st,
+                                  int dw_channels = 4);
 bool conv_halo_wgrad_supported(const ConvGeom& g);
 // hipErrorNotReady: the scratch could not be set up now (first use inside a stream capture) -- use conv_wgrad_kernel for this launch
 size_t conv_halo_wgrad_slab_bytes();
@@ -120,6 +121,8 @@ hipError_t launch_bn_relu_maxpool_bwd(const float* gy, const unsigned char* tap,
 // per-workgroup slabs (layer 1, stem); without it those shapes use library-owned scratch or, inside a stream capture, the atomics kernel
 size_t conv_wgrad_workspace_bytes(const ConvGeom& g);
 hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+bool conv_wgrad_c3_supported(const ConvGeom& g);
+hipError_t launch_conv_wgrad_c3(const ConvGeom& g, const float* x, const float* dy, float* dw3, void* ws, size_t ws_bytes, hipStream_t st);
 hipError_t launch_weight_transpose(const float* w, float* wt, int K, int RS, int C, hipStream_t st);
 hipError_t launch_image_to_nhwc4(const float* img, float* out, int B, int H, int W, int OH, int OW, int pt, int pl, int normalize,
                                  hipStream_t st);

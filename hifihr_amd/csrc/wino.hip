@@ -115,6 +115,17 @@ __device__ __forceinline__ void weight_transpose_body(const float* __restrict__ 
   }
 }
 
+// kind 5: w[K][RS][C] -> wp[K][RS][C4], C4 = C rounded up to a multiple of 4, zero fill (the 3-channel stem filter for NHWC4 images)
+__device__ __forceinline__ void weight_pad_c4_body(const float* __restrict__ w, float* __restrict__ wp, int K, int RS, int C, unsigned bid,
+                                                   unsigned nblk) {
+  const int C4 = (C + 3) & ~3;
+  const size_t n = (size_t)K * RS * C4;
+  for (size_t i = (size_t)bid * 256 + threadIdx.x; i < n; i += (size_t)nblk * 256) {
+    const int c = (int)(i % C4);
+    wp[i] = c < C ? w[(i / C4) * C + c] : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int flip) {
   wino_weight_transform_body(w, U, K, C, flip, blockIdx.x, gridDim.x);
 }
@@ -128,7 +139,8 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const PrepJob* __restr
   else if (j.kind == 1) wino_weight_transform_body(j.src, j.dst, j.K, j.C, 0, blockIdx.x, gridDim.x);
   else if (j.kind == 2) wino_weight_transform_t_body(j.src, j.dst, j.K, j.C, blockIdx.x, gridDim.x, lds);
   else if (j.kind == 3) w4::wino4_weight_transform_body(j.src, j.dst, j.K, j.C, blockIdx.x, gridDim.x);        // F(4x4, 3x3): U[36][K][C]
-  else w4::wino4_weight_transform_t_body(j.src, j.dst, j.K, j.C, blockIdx.x, gridDim.x, lds);                  // F(4x4, 3x3): U'[36][C][K]
+  else if (j.kind == 4) w4::wino4_weight_transform_t_body(j.src, j.dst, j.K, j.C, blockIdx.x, gridDim.x, lds);  // F(4x4, 3x3): U'[36][C][K]
+  else weight_pad_c4_body(j.src, j.dst, j.K, j.RS, j.C, blockIdx.x, gridDim.x);
 }
 
 // thread = (tile, 4 channels); x[N][H][W][C] -> V[16][T][C]

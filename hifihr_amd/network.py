@@ -48,9 +48,7 @@ class Conv2dMFMA(nn.Module):
 
     def forward(self, x, want_stats=False):
         from . import ops
-        w = self.weight
-        if w.shape[1] % 4 != 0:                       # the 3-channel stem: input arrives as NHWC4, pad the weight
-            w = F.pad(w, (0, 0, 0, 0, 0, 4 - w.shape[1] % 4)).contiguous(memory_format=torch.channels_last)
+        w = self.weight          # the 3-channel stem: the input arrives as NHWC4; ops.conv2d pads the filter (and un-pads its gradient)
         if self.bias is not None:
             return ops.conv2d_bias_act(x, w, self.bias, self.stride, self.pad, self.relu)   # conv + bias (+ ReLU), one launch
         return ops.conv2d(x, w, self.stride, self.pad, want_stats)

@@ -389,7 +389,10 @@ class _WeightPrep:
         e = self.entries.get(key)
         if e is None:
             K, C, R, S = w.shape
-            n = K * C * R * S if kind == 0 else K * C * (16 if kind in (1, 2) else 36)      # kinds 1 / 2: F(2x2) U / U'; 3 / 4: F(4x4)
+            if kind == 5:                                      # channels zero-padded to a multiple of 4 (the 3-channel stem filter)
+                n = K * ((C + 3) // 4 * 4) * R * S
+            else:
+                n = K * C * R * S if kind == 0 else K * C * (16 if kind in (1, 2) else 36)  # kinds 1 / 2: F(2x2) U / U'; 3 / 4: F(4x4)
             self.entries[key] = [w, K, C, R * S, kind, torch.empty(n, device=w.device, dtype=torch.float32)]
             self.dirty = True
             return None
@@ -517,6 +520,34 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias
     return V if keep_v else None
 
 
+def _stem_c3_wgrad(lib, ctx, x, gy):
+    """Weight gradient of the 3-channel stem on an NHWC4 image.  The slab kernel writes the parameter's [K][R][S][3] layout itself
+    (hifihr_conv2d_bwd_weight_c3: straight into the flat gradient buffer); any other shape goes through a 4-channel temporary.
+    -> the gradient to return to autograd (None when it was accumulated in place)."""
+    N, H, W, C, K, R, S, stride, pad = ctx.geom
+    w, w3 = ctx.w_param, ctx.w3
+    Cw = w3.shape[1]
+    direct = getattr(w, "_hifihr_direct_grad", False) and w.grad is not None and w.grad.is_contiguous(memory_format=_CL)
+    if PROFILE.on:
+        PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "wgrad"))
+    if Cw == 3 and lib.conv2d_bwd_weight_c3_supported(N, H, W, K, R, S, stride, pad):
+        tgt = w.grad if direct else torch.zeros_like(w3, memory_format=_CL)
+        nslab = lib.conv2d_wgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad)
+        PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight_c3(x, gy, tgt, N, H, W, K, R, S, stride, pad, _wgrad_slabs(gy.device, nslab)))
+    else:
+        dw4 = torch.zeros((K, C, R, S), device=gy.device).contiguous(memory_format=_CL)
+        nslab = lib.conv2d_wgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad)
+        PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight(x, gy, dw4, N, H, W, C, K, R, S, stride, pad,
+                                                                     ws=_wgrad_slabs(gy.device, nslab) if nslab else None))
+        if not direct:
+            return dw4[:, :Cw].contiguous(memory_format=_CL)
+        w.grad.add_(dw4[:, :Cw])
+    if direct:
+        _grad_ready(w)
+        return None
+    return tgt
+
+
 class _Conv2dMFMA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, pad, want_stats=False, bias=None, relu=False):
@@ -526,7 +557,18 @@ class _Conv2dMFMA(torch.autograd.Function):
         wk = w.contiguous(memory_format=_CL)                      # physical [K][R][S][C]
         N, C, H, W = x.shape
         K, Cw, R, S = wk.shape
-        assert Cw == C and C % 4 == 0, (x.shape, w.shape)
+        ctx.w3 = None
+        if Cw != C:
+            # the 3-channel stem on an NHWC4 image (zero fourth plane): the kernels read a filter zero-padded to 4 channels -- from the
+            # step's weight_prep launch (kind 5) when there is one -- and the gradient goes back in the parameter's own 3-channel layout
+            assert Cw < C == (Cw + 3) // 4 * 4, (x.shape, w.shape)
+            ctx.w3 = wk
+            w4 = _WEIGHT_PREP.get(w, wk, 5)
+            if w4 is None:
+                w4 = torch.zeros(K, R, S, C, device=x.device)
+                w4[..., :Cw] = wk.permute(0, 2, 3, 1)
+            wk = w4.view(K, R, S, C).permute(0, 3, 1, 2)
+        assert C % 4 == 0, (x.shape, w.shape)
         OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
         stats = None
@@ -613,7 +655,9 @@ class _Conv2dMFMA(torch.autograd.Function):
             else:
                 scratch = torch.empty(wk.numel(), device=x.device, dtype=torch.float32)
                 PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data(gy, wk, dx, scratch, N, H, W, C, K, R, S, stride, pad, ws=ws))
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.w3 is not None:
+            dw = _stem_c3_wgrad(lib, ctx, x, gy)
+        elif ctx.needs_input_grad[1]:
             w = ctx.w_param
             tgt = w.grad if (getattr(w, "_hifihr_direct_grad", False) and w.grad is not None
                              and w.grad.is_contiguous(memory_format=_CL)) else None

@@ -229,6 +229,13 @@ int hifihr_conv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, i
 size_t hifihr_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 int hifihr_conv2d_bwd_weight_ws(const float* x_d, const float* dy_d, float* dw_accumulate_d, int N, int H, int W, int C, int K, int R, int S,
                                 int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
+/* The stem as the reference declares it, nn.Conv2d(3, 64, 7, 2, 3) (vendored resnet.py conv1): the image arrives as NHWC4 with a
+ * zero fourth plane (hifihr_image_to_nhwc4), the parameter and its gradient keep 3 channels, dw3_d[K][R][S][3] (accumulated into).
+ * Served by the slab kernel only (7x7, stride 2, pad 3, K = 64; ask _supported); ws as hifihr_conv2d_wgrad_workspace_bytes(.., C = 4, ..).
+ * The forward's padded filter [K][R][S][4] comes out of hifihr_weight_prep (job kind 5). */
+int hifihr_conv2d_bwd_weight_c3_supported(int N, int H, int W, int K, int R, int S, int stride, int pad);
+int hifihr_conv2d_bwd_weight_c3(const float* x4_d, const float* dy_d, float* dw3_d, int N, int H, int W, int K, int R, int S, int stride,
+                                int pad, void* ws_d, size_t ws_bytes, void* stream);
 /* Winograd F(2x2, 3x3) path for stride-1, pad-1 3x3 convolutions with many channels (ResNet-18 layers 3-4): 2.25x fewer
  * multiplications than the direct kernel, same results up to a few ulp.  Forward:
  *   hifihr_wino_weight_transform(w[K][3][3][C], U[16][K][C], K, C, flip = 0)
@@ -313,6 +320,8 @@ int hifihr_conv2d_bwd_data_pre(const float* dy_d, const float* wt_d, float* dx_d
  *   kind 0: dst[C][RS][K] = transpose of src[K][RS][C]                                   (= hifihr_weight_transpose)
  *   kind 1: dst = U[16][K][C] of src[K][3][3][C]                                         (= hifihr_wino_weight_transform, flip 0)
  *   kind 2: dst = U'[16][C][K], the backward-data weights of src[K][3][3][C]              (= weight_transpose + transform, flip 1)
+ *   kind 3 / 4: the F(4x4, 3x3) forms of 1 / 2, U[36][K][C] / U'[36][C][K]
+ *   kind 5: dst[K][RS][C4] = src[K][RS][C] with the channels zero-padded to C4 = the next multiple of 4 (the 3-channel stem filter)
  * blocks_per_job: workgroups per job (each job is a grid-stride loop). */
 typedef struct hifihr_prep_job {
   const float* src;

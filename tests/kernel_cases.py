@@ -1025,10 +1025,42 @@ def weight_prep_case(lib, device, seed=0):
             lib.wino_weight_transform(wt, U42, C, K, 1, 4)
             jobs.append((w, torch.full((36 * K * C,), 7.0, device=device), K, C, 9, 3)); want.append(U4)
             jobs.append((w, torch.full((36 * K * C,), 7.0, device=device), K, C, 9, 4)); want.append(U42)
+    for K, C, R in ((64, 3, 7), (8, 5, 3), (4, 1, 1)):          # kind 5: channels zero-padded to a multiple of 4
+        w = torch.randn(K, R, R, C, generator=gen)
+        C4 = (C + 3) // 4 * 4
+        ref = torch.zeros(K, R, R, C4); ref[..., :C] = w
+        jobs.append((w.to(device), torch.full((K * R * R * C4,), 7.0, device=device), K, C, R * R, 5)); want.append(ref.reshape(-1))
     table = lib.prep_jobs(jobs, device)
     lib.weight_prep(table, len(jobs), 3)
     for (_, dst, K, C, RS, kind), ref in zip(jobs, want):
         assert torch.equal(dst.cpu(), ref.cpu()), (K, C, RS, kind)
+
+
+def stem_c3_wgrad_case(lib, device, N=2, H=56, seed=0):
+    """hifihr_conv2d_bwd_weight_c3 (gradient in the 3-channel parameter's layout) == hifihr_conv2d_bwd_weight on the padded
+    problem, first three channels; accumulate semantics; bit-reproducible."""
+    gen = torch.Generator().manual_seed(seed)
+    K, R, stride, pad = 64, 7, 2, 3
+    assert lib.conv2d_bwd_weight_c3_supported(N, H, H, K, R, R, stride, pad)
+    assert not lib.conv2d_bwd_weight_c3_supported(N, H, H, K, 3, 3, 1, 1)
+    OH = (H + 2 * pad - R) // stride + 1
+    x = torch.randn(N, H, H, 4, generator=gen); x[..., 3] = 0
+    dy = torch.randn(N, OH, OH, K, generator=gen)
+    xd, dyd = x.to(device), dy.to(device)
+    nws = lib.conv2d_wgrad_workspace_bytes(N, H, H, 4, K, R, R, stride, pad)
+    assert nws > 0
+    ws = torch.empty(nws // 4, device=device)
+    dw4 = torch.zeros(K, R, R, 4, device=device)
+    lib.conv2d_bwd_weight(xd, dyd, dw4, N, H, H, 4, K, R, R, stride, pad, ws=ws)
+    dw3 = torch.full((K, R, R, 3), 0.25, device=device)
+    lib.conv2d_bwd_weight_c3(xd, dyd, dw3, N, H, H, K, R, R, stride, pad, ws)
+    assert torch.equal(dw3 - 0.25, (dw4[..., :3] + 0.25) - 0.25), "3-channel stem gradient == padded problem (same slabs, same order)"
+    again = torch.full((K, R, R, 3), 0.25, device=device)
+    lib.conv2d_bwd_weight_c3(xd, dyd, again, N, H, H, K, R, R, stride, pad, ws)
+    assert torch.equal(again, dw3)
+    ref = torch.nn.functional.conv2d(x[..., :3].permute(3, 0, 1, 2).contiguous(), dy.permute(3, 0, 1, 2).contiguous(), None, 1, pad, stride)
+    ref = ref[:, :, :R, :R].permute(1, 2, 3, 0)                   # [K][R][S][3]
+    assert float((dw3.cpu() - 0.25 - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -226,6 +226,11 @@ def test_halo_kernels_are_bit_reproducible(lib, B, H, W):
     assert rel(outs[0][2], wr.grad.permute(0, 2, 3, 1)) < 2e-4
 
 
+def test_conv_stem_wgrad_three_channel_parameter(lib):
+    kc.stem_c3_wgrad_case(lib, "cuda", N=32, H=224)
+    kc.stem_c3_wgrad_case(lib, "cuda", N=3, H=112, seed=2)
+
+
 def test_stem_kernels_at_batch_32(lib):
     """conv_stem_kernel / conv_stem_wgrad_kernel at the bench's size (32 x 224^2), the padding channel zero as in the encoder."""
     assert lib.conv2d_describe(32, 224, 224, 4, 64, 7, 7, 2, 3, 0) == "conv_stem_kernel"

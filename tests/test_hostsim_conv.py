@@ -68,5 +68,9 @@ def test_conv_stem_kernel(hostsim_lib, N, H, W):
     kc.conv_case(hostsim_lib, "cpu", N, H, W, 4, 64, 7, 2, 3, seed=H + W + 1, zero_last_channel=True)    # the encoder's case: padding channel skipped
 
 
+def test_conv_stem_wgrad_three_channel_parameter(hostsim_lib):
+    kc.stem_c3_wgrad_case(hostsim_lib, "cpu", N=1, H=56)
+
+
 def test_conv_stem_bnstats(hostsim_lib):
     kc.conv_bnstats_case(hostsim_lib, "cpu", 2, 28, 56, 4, 64, 7, 2, 3)

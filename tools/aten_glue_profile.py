@@ -26,4 +26,4 @@ for e in prof.key_averages(group_by_input_shape=True):
     if e.key.startswith("aten::") and e.device_time_total > 0:
         rows.append((e.device_time_total, e.count, e.key, str(e.input_shapes)[:110]))
 rows.sort(reverse=True)
-for r in rows[:45]: print(f"{r[0]:8.1f} us  x{r[1]:3d}  {r[2]:28s} {r[3]}")
+for r in rows[:80]: print(f"{r[0]:8.1f} us  x{r[1]:3d}  {r[2]:28s} {r[3]}")
