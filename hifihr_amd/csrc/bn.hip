@@ -11,7 +11,7 @@
 //   backward: ONE reduction kernel (sum g, sum g*xhat, activation derivative applied on the fly), ONE apply kernel that
 //             folds the slots the same way (workgroup 0 accumulates dgamma / dbeta straight into the flat gradient buffer)
 //             and writes dx (and the masked gradient of the identity branch).
-//   Up to 256 channels the separate one-thread-per-channel finalize launches of the first version (2 per layer, ~6.8 us
+//   Up to 512 channels the separate one-thread-per-channel finalize launches of the first version (2 per layer, ~6.8 us
 //   each in a replayed graph) are gone: the LAST workgroup of an apply kernel to finish -- elected through 32 + 1 arrival
 //   counters behind the slots -- zeroes the slots for the next producer.  Wider layers keep the finalize launch (kFuseMaxC).
 // All kernels are HBM-bound: every lane moves float4 (4 consecutive channels) and keeps the same channel group(s) for
@@ -153,7 +153,7 @@ __device__ __forceinline__ void slot_sum2(const float* __restrict__ buf, int C, 
 
 // Wide layers (C > kFuseMaxC): folding 256 C bytes of partials in EVERY workgroup costs more than it saves (EfficientNet's
 // 1392-channel layers: +1.2 ms per step measured), so they keep a one-thread-per-channel finalize launch that also cleans the slots.
-constexpr int kFuseMaxC = 256;
+constexpr int kFuseMaxC = 512;     // 256 -> 512 in round 2: ResNet-18's layer 4 loses its 10 finalize launches per step (6.19 -> 6.175 ms)
 
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(float* __restrict__ stats, long M, int C, float eps, float momentum,
                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,

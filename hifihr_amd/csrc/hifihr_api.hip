@@ -541,7 +541,7 @@ int hifihr_bn_relu_maxpool_fwd(const float* x, float* stats, const float* gamma,
                                float momentum, float* y, unsigned char* tap, float* save_mean, float* save_invstd, float* running_mean,
                                float* running_var, void* stream) {
   if (!x || !stats || !gamma || !beta || !y || !tap || !save_mean || !save_invstd || !hifihr::bn_relu_maxpool_supported(N, H, W, C))
-    return fail(HIFIHR_EINVAL, "hifihr_bn_relu_maxpool_fwd: bad argument (C % 4 == 0, C <= 256, H, W >= 2)");
+    return fail(HIFIHR_EINVAL, "hifihr_bn_relu_maxpool_fwd: bad argument (C % 4 == 0, C <= 512, H, W >= 2)");
   HIP_TRY(hifihr::launch_bn_relu_maxpool_fwd(x, stats, gamma, beta, N, H, W, C, eps, momentum, y, tap, save_mean, save_invstd, running_mean,
                                              running_var, (hipStream_t)stream));
   return HIFIHR_OK;
@@ -552,7 +552,7 @@ int hifihr_bn_relu_maxpool_bwd(const float* gy, const unsigned char* tap, const 
                                float* dgamma_acc, float* dbeta_acc, void* stream) {
   if (!gy || !tap || !x || !save_mean || !save_invstd || !gamma || !beta || !red_scratch || !dx ||
       !hifihr::bn_relu_maxpool_supported(N, H, W, C))
-    return fail(HIFIHR_EINVAL, "hifihr_bn_relu_maxpool_bwd: bad argument (C % 4 == 0, C <= 256, H, W >= 2)");
+    return fail(HIFIHR_EINVAL, "hifihr_bn_relu_maxpool_bwd: bad argument (C % 4 == 0, C <= 512, H, W >= 2)");
   HIP_TRY(hifihr::launch_bn_relu_maxpool_bwd(gy, tap, x, save_mean, save_invstd, gamma, beta, N, H, W, C, red_scratch, dx, dgamma_acc,
                                              dbeta_acc, (hipStream_t)stream));
   return HIFIHR_OK;

@@ -109,7 +109,7 @@ hipError_t launch_bn_act_eval(const float* x, const float* running_mean, const f
 hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, const float* save_mean, const float* save_invstd,
                              const float* gamma, const float* beta, int act, long M, int C, float* red, float* dx, float* dres,
                              float* dgamma_acc, float* dbeta_acc, hipStream_t st);
-// MaxPool2d(3, 2, 1)(ReLU(BN(x))) fused (the ResNet stem), C <= 256
+// MaxPool2d(3, 2, 1)(ReLU(BN(x))) fused (the ResNet stem), C <= 512
 bool bn_relu_maxpool_supported(int N, int H, int W, int C);
 hipError_t launch_bn_relu_maxpool_fwd(const float* x, float* stats, const float* gamma, const float* beta, int N, int H, int W, int C,
                                       float eps, float momentum, float* y, unsigned char* tap, float* save_mean, float* save_invstd,

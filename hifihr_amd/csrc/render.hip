@@ -31,7 +31,8 @@ constexpr int kFwdThreads = 512;     // forward tile kernel: 8 waves.  The kerne
                                      // per tile shorten exactly that critical path.  Staging, the scan and shading use the first 256 lanes.
 constexpr int kFwdWaves = kFwdThreads / 64;
 constexpr int kCap = 512;            // faces held in LDS per pass (2 per lane in the candidate expansion)
-constexpr int kRecW = 16;            // floats per face record in LDS
+constexpr int kRecW = 11;            // floats per face record in LDS: 3 x (x, y), 3 z, face id, candidate rectangle (odd pitch: no bank
+                                     // conflicts between lanes on different faces; 22 KB instead of 32 KB lets a third tile share the CU)
 
 __device__ __forceinline__ float wsum(float x) {
 #pragma unroll
@@ -148,7 +149,9 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
   {
     const int k = tid;
     if (k < n) {
-      const float xmin = L.rec[k * kRecW + 12], xmax = L.rec[k * kRecW + 13], ymin = L.rec[k * kRecW + 14], ymax = L.rec[k * kRecW + 15];
+      const float* q = L.rec + k * kRecW;
+      const float xmin = fminf(q[0], fminf(q[2], q[4])), xmax = fmaxf(q[0], fmaxf(q[2], q[4]));
+      const float ymin = fminf(q[1], fminf(q[3], q[5])), ymax = fmaxf(q[1], fmaxf(q[3], q[5]));
       int x0 = 16, x1 = -1, y0 = 16, y1 = -1;
       for (int c = 0; c < cols; ++c) {
         const float hi = L.sxs[c * AA], lo = L.sxs[c * AA + AA - 1];          // NDC decreases with the index
@@ -201,7 +204,8 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
     FaceXYZ f;
     f.x0 = q[0]; f.y0 = q[1]; f.x1 = q[2]; f.y1 = q[3]; f.x2 = q[4]; f.y2 = q[5]; f.z0 = q[6]; f.z1 = q[7]; f.z2 = q[8];
     const unsigned fidu = (unsigned)__float_as_int(q[9]);
-    const float xmin = q[12], xmax = q[13], ymin = q[14], ymax = q[15];
+    const float xmin = fminf(f.x0, fminf(f.x1, f.x2)), xmax = fmaxf(f.x0, fmaxf(f.x1, f.x2));
+    const float ymin = fminf(f.y0, fminf(f.y1, f.y2)), ymax = fmaxf(f.y0, fmaxf(f.y1, f.y2));
 #pragma unroll
     for (int i = 0; i < AA; ++i) {
 #pragma unroll
@@ -360,9 +364,7 @@ __global__ __launch_bounds__(kFwdThreads) void render_fwd_kernel(RenderDev r, co
       const float4 a = vb[r.faces[3 * f]], c = vb[r.faces[3 * f + 1]], d = vb[r.faces[3 * f + 2]];
       float* q = L.rec + (L.list_n + tid) * kRecW;
       q[0] = a.x; q[1] = a.y; q[2] = c.x; q[3] = c.y; q[4] = d.x; q[5] = d.y; q[6] = a.z; q[7] = c.z;
-      q[8] = d.z; q[9] = __int_as_float(f); q[10] = 0.f; q[11] = 0.f;
-      q[12] = fminf(a.x, fminf(c.x, d.x)); q[13] = fmaxf(a.x, fmaxf(c.x, d.x));
-      q[14] = fminf(a.y, fminf(c.y, d.y)); q[15] = fmaxf(a.y, fmaxf(c.y, d.y));
+      q[8] = d.z; q[9] = __int_as_float(f); q[10] = 0.f;
     }
     __syncthreads();
     const int n = L.list_n + cnt;

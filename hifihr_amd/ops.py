@@ -888,7 +888,7 @@ def _bn_acc_target(p, C, device):
 
 def bn_relu_maxpool(x, stats, bn: torch.nn.BatchNorm2d):
     """nn.MaxPool2d(3, 2, 1)(relu(bn(x))): the ResNet stem behind conv1 (reference trunk: vendored resnet.py forward).  Training
-    mode with batch statistics from our convolution and C <= 256: the fused kernels; anything else: bn_act followed by maxpool3x3s2.
+    mode with batch statistics from our convolution and C <= 512: the fused kernels; anything else: bn_act followed by maxpool3x3s2.
     HIFIHR_BN_POOL=0 keeps the two-step path (A/B timing)."""
     if bn.training and stats is not None and x.is_cuda and os.environ.get("HIFIHR_BN_POOL", "1") != "0":
         N, C, H, W = x.shape

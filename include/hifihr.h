@@ -378,7 +378,7 @@ int hifihr_bn_act_bwd(const float* dy_d, const float* y_d /* act 1; NULL: recomp
  * nine taps of x through scale / shift / ReLU (tie rule of nn.MaxPool2d: first tap in scan order), the backward gathers the
  * pool's gradient from pooled_grad + tap on the fly inside the batch-norm reduction and apply kernels.  Same statistics-buffer
  * contract (all zero on entry, all zero on return) and the same save_mean / save_invstd / running-statistics outputs as
- * hifihr_bn_act_fwd; C % 4 == 0, C <= 256, H, W >= 2.  pooled_d [N][OH][OW][C], tap_d one byte per pooled element,
+ * hifihr_bn_act_fwd; C % 4 == 0, C <= 512, H, W >= 2.  pooled_d [N][OH][OW][C], tap_d one byte per pooled element,
  * OH = (H - 1) / 2 + 1. */
 int hifihr_bn_relu_maxpool_supported(int N, int H, int W, int C);
 int hifihr_bn_relu_maxpool_fwd(const float* x_d, float* stats_d, const float* gamma_d, const float* beta_d, int N, int H, int W, int C,
