@@ -789,12 +789,52 @@ static void launch_sk(const SkPlan& p, const ConvGeom& g, const float* src, cons
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, BK, true>), dim3(wgs), dim3(256), 0, st, g, src, wgt, nullptr, dst, stats, a);
 }
 
+// A 1x1 convolution with stride 1 and no padding is a plain GEMM over the pixel rows (ResNet's stride-1 projection shortcut and every
+// conv1 / conv3 of a bottleneck block): it runs on the kernels of csrc/gemm.hip, 2-3x faster there than as an implicit GEMM with one tap
+// (tools/time_conv1x1.py).  HIFIHR_CONV1X1_GEMM=0 keeps the implicit-GEMM kernels (A/B timing).
+bool conv_is_gemm(const ConvGeom& g) {
+  static const int on = [] { const char* e = getenv("HIFIHR_CONV1X1_GEMM"); return e ? atoi(e) : 1; }();
+  const long M = (long)g.N * g.OH * g.OW;
+  return on && g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.batch <= 1 && g.OH == g.IH && g.OW == g.IW &&
+         M * (g.IC > g.OC ? g.IC : g.OC) < (1L << 31) && bgemm_nt_supported((int)M, g.OC, g.IC) && g.OC % 128 == 0;
+}
+
+// dw[i] += sum over the slabs, in slab order (bit-reproducible)
+__global__ __launch_bounds__(256) void slab_sum_acc_kernel(const float* __restrict__ slabs, int nslab, long n4, float* __restrict__ dw) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < nslab; ++z) {
+    const float4 v = reinterpret_cast<const float4*>(slabs)[(size_t)z * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float4 d = reinterpret_cast<float4*>(dw)[i];
+  d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+  reinterpret_cast<float4*>(dw)[i] = d;
+}
+
+static bool conv_wgrad_is_gemm(const ConvGeom& g) {
+  // a 64 x 256 filter is only four 64x64 tiles: 128 row slabs of it (71 us at 32 x 56 x 56) lose to conv_wgrad_kernel's atomics (55 us)
+  return conv_is_gemm(g) && (long)g.OC * g.IC >= 32768 && bgemm_tn_supported(g.OC, g.IC, (int)((long)g.N * g.OH * g.OW));
+}
+static size_t conv_wgrad_gemm_bytes(const ConvGeom& g) {
+  return (size_t)bgemm_tn_parts(g.OC, g.IC, (int)((long)g.N * g.OH * g.OW), 1) * g.OC * g.IC * sizeof(float);
+}
+
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
                              void* sk_ws, size_t sk_ws_bytes, hipStream_t st) {
   if (stats != nullptr && g.dgrad) return hipErrorInvalidValue;   // stats: all zero on entry (self-cleaning, see bn.hip)
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
   // the fast gather uses 32-bit element offsets (scaled by 4 in the address) and a 63-bit tap mask
   if ((long)g.N * g.IH * g.IW * g.IC >= (1L << 30) || (long)g.OC * g.R * g.S * g.IC >= (1L << 30)) return hipErrorInvalidValue;
+  if (conv_is_gemm(g) && bias == nullptr) {
+    // 1x1 / stride 1: y[M][OC] = x[M][IC] . w[OC][IC]^T, and backward-data the same product on (dy, w^T): the GEMM kernels of
+    // csrc/gemm.hip (bgemm_nt_rows_kernel at N % 128 == 0), then one statistics pass for a batch-norm consumer
+    const long M = (long)g.N * g.OH * g.OW;
+    const hipError_t e = launch_bgemm_nt(src, wgt, dst, (int)M, g.OC, g.IC, 1, nullptr, 0, st);
+    if (e != hipSuccess || stats == nullptr) return e;
+    return launch_bn_stats(dst, M, g.OC, stats, st);
+  }
   if (conv_halo_supported(g, bias)) {
     if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_halo(g, src, wgt, dst, stats, zeros, st);
   }
@@ -847,6 +887,7 @@ static void launch_wgrad_tile(const ConvGeom& g, int Q, long M, int slots, const
 }
 
 size_t conv_wgrad_workspace_bytes(const ConvGeom& g) {
+  if (conv_wgrad_is_gemm(g)) return conv_wgrad_gemm_bytes(g);
   if (conv_halo_wgrad_supported(g)) return conv_halo_wgrad_slab_bytes();
   if (conv_stem_wgrad_supported(g)) return conv_stem_wgrad_slab_bytes();
   return 0;
@@ -864,6 +905,15 @@ hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy,
   const long M = (long)g.N * g.OH * g.OW;
   const int Q = g.R * g.S * g.IC;
   if (g.IC % 4 != 0 || g.OC % 4 != 0) return hipErrorInvalidValue;
+  if (conv_wgrad_is_gemm(g) && ws != nullptr && ws_bytes >= conv_wgrad_gemm_bytes(g)) {
+    // 1x1 / stride 1: dw[OC][IC] += dy[M][OC]^T . x[M][IC] -- the TN product of csrc/gemm.hip over row slabs, summed in slab order
+    const int parts = bgemm_tn_parts(g.OC, g.IC, (int)M, 1);
+    const hipError_t e = launch_bgemm_tn(dy, x, static_cast<float*>(ws), g.OC, g.IC, (int)M, 1, parts, st);
+    if (e != hipSuccess) return e;
+    const long n4 = (long)g.OC * g.IC / 4;
+    hipLaunchKernelGGL(slab_sum_acc_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(ws), parts, n4, dw);
+    return hipGetLastError();
+  }
   // slab kernels: the caller's scratch (any contents) when it is large enough, else library-owned scratch (csrc/conv_halo.hip)
   if (conv_halo_wgrad_supported(g)) {
     const hipError_t e = launch_conv_halo_wgrad(g, x, dy, dw, ws_bytes >= conv_halo_wgrad_slab_bytes() ? static_cast<float*>(ws) : nullptr, st);

@@ -375,6 +375,13 @@ int hifihr_conv2d_describe(int N, int H, int W, int C, int K, int R, int S, int 
   if (!out || cap < 24 || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad)) return fail(HIFIHR_EINVAL, "hifihr_conv2d_describe: bad argument");
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
   const hifihr::ConvGeom g = dgrad == 1 ? hifihr::ConvGeom{N, OH, OW, K, H, W, C, R, S, stride, pad, 1} : hifihr::ConvGeom{N, H, W, C, OH, OW, K, R, S, stride, pad, 0};
+  if (hifihr::conv_is_gemm(g)) {          // 1x1 / stride 1: the GEMM kernels (the weight gradient needs the caller's workspace for that)
+    const long M = (long)N * OH * OW;
+    const bool wg = hifihr::conv_wgrad_workspace_bytes(g) > 0;      // (a 1x1 shape has no other slab kernel)
+    if (dgrad == 2 && wg) hifihr::bgemm_describe_batch(1, K, C, (int)M, 1, out, cap);
+    else if (dgrad != 2) hifihr::bgemm_describe_batch(0, (int)M, g.OC, g.IC, 1, out, cap);
+    if (dgrad != 2 || wg) return HIFIHR_OK;
+  }
   if (dgrad == 2) snprintf(out, cap, "%s", hifihr::conv_halo_wgrad_supported(g) ? "conv_halo_wgrad_kernel" : hifihr::conv_stem_wgrad_supported(g) ? "conv_stem_wgrad_kernel" : "conv_wgrad_kernel");
   else snprintf(out, cap, "%s", hifihr::conv_halo_supported(g, nullptr) ? "conv_halo_kernel" : hifihr::conv_stem_supported(g, nullptr) ? "conv_stem_kernel" : "conv_igemm_kernel");
   return HIFIHR_OK;

@@ -121,6 +121,7 @@ hipError_t launch_bn_relu_maxpool_bwd(const float* gy, const unsigned char* tap,
 // per-workgroup slabs (layer 1, stem); without it those shapes use library-owned scratch or, inside a stream capture, the atomics kernel
 size_t conv_wgrad_workspace_bytes(const ConvGeom& g);
 hipError_t launch_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+bool conv_is_gemm(const ConvGeom& g);                 // 1x1 / stride 1 / no padding on shapes the kernels of gemm.hip take
 bool conv_wgrad_c3_supported(const ConvGeom& g);
 hipError_t launch_conv_wgrad_c3(const ConvGeom& g, const float* x, const float* dy, float* dw3, void* ws, size_t ws_bytes, hipStream_t st);
 hipError_t launch_weight_transpose(const float* w, float* wt, int K, int RS, int C, hipStream_t st);

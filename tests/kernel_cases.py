@@ -283,6 +283,16 @@ def conv_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0, bias=False, rt
     # accumulation semantics: a second call adds
     lib.conv2d_bwd_weight(x_nhwc, gy_nhwc, dw, N, H, W, C, K, R, R, stride, pad)
     assert float((dw.cpu() - 2 * refw).abs().max()) <= 1e-4 * float(refw.abs().max()) + 1e-6, "conv bwd weight accumulate"
+    # slab forms of the weight gradient (caller's scratch, any contents): same gradient, bit-reproducible
+    nws = lib.conv2d_wgrad_workspace_bytes(N, H, W, C, K, R, R, stride, pad)
+    if nws:
+        wsw = torch.full((nws // 4,), 3.0, device=device)
+        dws = torch.full((K, R, R, C), 0.5, device=device)
+        lib.conv2d_bwd_weight(x_nhwc, gy_nhwc, dws, N, H, W, C, K, R, R, stride, pad, ws=wsw)
+        assert float((dws.cpu() - 0.5 - refw).abs().max()) <= 5 * rtol * float(refw.abs().max()) + 1e-6, "conv bwd weight (slabs)"
+        dws2 = torch.full((K, R, R, C), 0.5, device=device)
+        lib.conv2d_bwd_weight(x_nhwc, gy_nhwc, dws2, N, H, W, C, K, R, R, stride, pad, ws=wsw)
+        assert torch.equal(dws, dws2), "slab weight gradient must be bit-reproducible"
     # balanced (stream-K) schedule through a zero-initialised, self-cleaning workspace: same results, workspace zero again
     nb_f = lib.conv2d_workspace_bytes(N, H, W, C, K, R, R, stride, pad, False)
     nb_b = lib.conv2d_workspace_bytes(N, H, W, C, K, R, R, stride, pad, True)

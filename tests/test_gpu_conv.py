@@ -226,6 +226,14 @@ def test_halo_kernels_are_bit_reproducible(lib, B, H, W):
     assert rel(outs[0][2], wr.grad.permute(0, 2, 3, 1)) < 2e-4
 
 
+@pytest.mark.parametrize("N,H,C,K", [(32, 14, 256, 512), (8, 56, 256, 128), (4, 28, 512, 128), (2, 7, 2048, 512)])
+def test_conv_1x1_runs_on_the_gemm_kernels(lib, N, H, C, K):
+    assert lib.conv2d_describe(N, H, H, C, K, 1, 1, 1, 0, 0) == "bgemm_nt_rows_kernel"
+    assert lib.conv2d_describe(N, H, H, C, K, 1, 1, 1, 0, 2).startswith("bgemm_")
+    kc.conv_case(lib, "cuda", N, H, H, C, K, 1, 1, 0, seed=C + K)
+    kc.conv_bnstats_case(lib, "cuda", N, H, H, C, K, 1, 1, 0)
+
+
 def test_conv_stem_wgrad_three_channel_parameter(lib):
     kc.stem_c3_wgrad_case(lib, "cuda", N=32, H=224)
     kc.stem_c3_wgrad_case(lib, "cuda", N=3, H=112, seed=2)

@@ -68,6 +68,17 @@ def test_conv_stem_kernel(hostsim_lib, N, H, W):
     kc.conv_case(hostsim_lib, "cpu", N, H, W, 4, 64, 7, 2, 3, seed=H + W + 1, zero_last_channel=True)    # the encoder's case: padding channel skipped
 
 
+@pytest.mark.parametrize("N,H,W,C,K", [(2, 7, 5, 128, 256), (1, 9, 9, 64, 512), (3, 4, 4, 256, 128)])
+def test_conv_1x1_runs_on_the_gemm_kernels(hostsim_lib, N, H, W, C, K):
+    """1x1 / stride 1 convolutions (the stride-1 projection shortcut, bottleneck conv1 / conv3): forward and backward-data on
+    bgemm_nt_rows_kernel, the weight gradient on bgemm_tn_kernel slabs, batch statistics through the extra pass."""
+    assert hostsim_lib.conv2d_describe(N, H, W, C, K, 1, 1, 1, 0, 0) == "bgemm_nt_rows_kernel"
+    assert hostsim_lib.conv2d_describe(N, H, W, C, K, 1, 1, 1, 0, 2).startswith("bgemm_")
+    assert hostsim_lib.conv2d_wgrad_workspace_bytes(N, H, W, C, K, 1, 1, 1, 0) > 0
+    kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, 1, 1, 0, seed=C + K)
+    kc.conv_bnstats_case(hostsim_lib, "cpu", N, H, W, C, K, 1, 1, 0)
+
+
 def test_conv_stem_wgrad_three_channel_parameter(hostsim_lib):
     kc.stem_c3_wgrad_case(hostsim_lib, "cpu", N=1, H=56)
 
