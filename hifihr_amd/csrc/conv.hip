@@ -836,7 +836,7 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
     return launch_bn_stats(dst, M, g.OC, stats, st);
   }
   if (conv_halo_supported(g, bias)) {
-    if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_halo(g, src, wgt, dst, stats, zeros, st);
+    if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_halo(g, src, wgt, bias, dst, stats, zeros, st);
   }
   if (conv_stem_supported(g, bias)) {
     if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_stem(g, src, wgt, dst, stats, zeros, st);

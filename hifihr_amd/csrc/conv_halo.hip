@@ -53,6 +53,8 @@ struct HaloArgs {
   float* dst;           // [N][H][W][64]
   float* stats;         // [kStatSlots][2][64] or null
   const float* zeros;   // >= 16 bytes of zeros
+  const float* bias;    // [64] or null: added in the epilogue (VGG19's conv1_2 of the perceptual loss), then ReLU if `relu`
+  int relu;
   int N, H, W, sign;    // sign = +1: tap (r, s) reads (y + r - 1, x + s - 1); -1: (y + 1 - r, x + 1 - s)
   int ctiles, total, per;   // W / 14; N * ctiles * H strips ordered (n, column tile, y); strips per workgroup
 };
@@ -299,14 +301,17 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
     st_loop += l1 - l0; st_real += __builtin_amdgcn_s_memrealtime() - r0;
 #endif
     // epilogue: register e of lane (r, g) of block j = out[pixel 16 j + r][channel 16 wave + 4 g + e]
+    const float4 b4 = a.bias != nullptr ? *reinterpret_cast<const float4*>(a.bias + 16 * wave + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int p = 16 * j + r, ty = p / kTW, tx = p - ty * kTW;
       if (ty < t.rows) {
         float* o = a.dst + (((size_t)t.n * a.H + t.y0 + ty) * a.W + t.x0 + tx) * 64 + 16 * wave + 4 * g;
-        *reinterpret_cast<float4*>(o) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ssum[e] += acc[j][e]; ssq[e] += acc[j][e] * acc[j][e]; }
+        float4 v = make_float4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w);
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(o) = v;
+        ssum[0] += v.x; ssq[0] += v.x * v.x; ssum[1] += v.y; ssq[1] += v.y * v.y;
+        ssum[2] += v.z; ssq[2] += v.z * v.z; ssum[3] += v.w; ssq[3] += v.w * v.w;
       }
     }
 #if defined(HIFIHR_HALO_STAMP)
@@ -935,8 +940,9 @@ const float* conv_halo_zero_page(hipStream_t st) {
 
 bool conv_halo_supported(const ConvGeom& g, const float* bias) {
   static const int on = [] { const char* e = getenv("HIFIHR_CONV_HALO"); return e ? atoi(e) : 1; }();
-  return on && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.IC == 64 && g.OC == 64 && g.batch <= 1 && !g.relu && bias == nullptr &&
-         g.IH == g.OH && g.IW == g.OW && g.OW % kTW == 0 && (long)g.N * g.OH * g.OW * 64 < (1L << 31);
+  return on && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.IC == 64 && g.OC == 64 && g.batch <= 1 &&
+         !((g.relu || bias != nullptr) && g.dgrad) && g.IH == g.OH && g.IW == g.OW && g.OW % kTW == 0 &&
+         (long)g.N * g.OH * g.OW * 64 < (1L << 31);
 }
 
 // slabs of conv_halo_wgrad_kernel: library-owned scratch.  Weight gradients may run on a side stream beside the main one and the
@@ -1040,11 +1046,11 @@ hipError_t launch_conv_stem(const ConvGeom& g, const float* src, const float* wg
   return hipGetLastError();
 }
 
-hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros,
-                            hipStream_t st) {
-  if (!conv_halo_supported(g, nullptr) || zeros == nullptr || (stats != nullptr && g.dgrad)) return hipErrorInvalidValue;
+hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
+                            const float* zeros, hipStream_t st) {
+  if (!conv_halo_supported(g, bias) || zeros == nullptr || (stats != nullptr && g.dgrad)) return hipErrorInvalidValue;
   HaloArgs a;
-  a.src = src; a.wgt = wgt; a.dst = dst; a.stats = stats; a.zeros = zeros;
+  a.src = src; a.wgt = wgt; a.dst = dst; a.stats = stats; a.zeros = zeros; a.bias = bias; a.relu = g.relu;
   a.N = g.N; a.H = g.OH; a.W = g.OW; a.sign = g.dgrad ? -1 : 1;
   a.ctiles = g.OW / kTW;
   a.total = g.N * a.ctiles * g.OH;

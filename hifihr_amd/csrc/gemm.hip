@@ -1077,11 +1077,11 @@ int bgemm_tn_parts(int M, int N, int T, int batch) {
   tn_tile(M, N, batch, &bm, &bn);
   if (const char* e = getenv("HIFIHR_GEMM_TN_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (M % bm) bm = 64; if (N % bn) bn = 64; }
   const int tiles = (M / bm) * (N / bn) * batch, nch = (T + 31) / 32;
-  // 128x128 (one workgroup per CU): fill the CUs once; 64x64: ~2 workgroups per CU; at least 8 chunks per slab so that the slab
+  // 128x128 (one workgroup per CU): fill the CUs once; 64x64: ~2 workgroups per CU; at least 7 chunks per slab so that the slab
   // round trip (written here, summed by wino_dw_transform_parts) stays small next to the reduction.  With the 36 problems of an
   // F(4x4, 3x3) layer the 64x64 kernel does best at ~4.5 workgroups per CU (tools/time_gemm_tn_f4.py).
   int splits = ((bm == 128 && bn == 128) ? gemm_cus() : batch > 16 ? (9 * gemm_cus() / 2 + tiles / 2) : 2 * gemm_cus()) / tiles;
-  if (splits > nch / 8) splits = nch / 8;
+  if (splits > nch / 7) splits = nch / 7;      // (7, not 8: the 49 chunks of a 28 x 28 F(4x4) layer split 7 x 7 -- 30.6 -> 25.9 us)
   if (splits < 1) splits = 1;
   const int cps = (nch + splits - 1) / splits;
   return (nch + cps - 1) / cps;

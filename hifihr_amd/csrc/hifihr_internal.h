@@ -95,7 +95,8 @@ bool conv_halo_wgrad_supported(const ConvGeom& g);
 // hipErrorNotReady: the scratch could not be set up now (first use inside a stream capture) -- use conv_wgrad_kernel for this launch
 size_t conv_halo_wgrad_slab_bytes();
 hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* slabs_or_null, hipStream_t st);
-hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st);
+hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, const float* bias_or_null, float* dst, float* stats,
+                            const float* zeros, hipStream_t st);
 // batch-norm (+ residual add + ReLU) on NHWC activations, x[M][C].  Statistics buffers are [kStatSlots][2][C]: partial
 // sums are spread over kStatSlots copies so that at most ~1/32 of the contributing workgroups hit one address with a
 // float atomic (thousands of atomics on ONE address serialise at ~100 ns each: 200 us per reduction in round 1).

@@ -54,6 +54,24 @@ class _NormalizeToNHWC4(torch.autograd.Function):
         return (gy[:, :3] * _NormalizeToNHWC4._inv_std[gy.device]).contiguous()
 
 
+class _FeatureMSE(torch.autograd.Function):
+    """F.mse_loss(fake, real) with `real` constant, on channels_last feature maps.  ATen's mse backward wrote its gradient in a different
+    memory format from its inputs: a strided 0.66 ms kernel plus a 0.19 ms re-layout per step on the [48, 256, 56, 56] maps of
+    BASELINE configs[2].  Here the difference is kept (same layout as the inputs) and the backward is one dense scaling of it."""
+
+    @staticmethod
+    def forward(ctx, fake, real):
+        d = fake - real
+        ctx.save_for_backward(d)
+        nrm = torch.linalg.vector_norm(d)
+        return nrm * nrm / d.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        d, = ctx.saved_tensors
+        return d * (g * (2.0 / d.numel())), None
+
+
 class PerceptualLoss(nn.Module):
     def __init__(self, type="l2", reduction="mean", final_layer=14, seed=0):
         super().__init__()
@@ -122,5 +140,7 @@ class PerceptualLoss(nn.Module):
         if self.type == "l1":
             return F.l1_loss(f_fake, f_real, reduction=self.reduction)
         if self.type == "l2":
+            if self.reduction == "mean" and f_fake.requires_grad and f_fake.is_cuda and f_fake.stride() == f_real.stride():
+                return _FeatureMSE.apply(f_fake, f_real)
             return F.mse_loss(f_fake, f_real, reduction=self.reduction)
         return F.l1_loss(f_fake, f_real, reduction=self.reduction) + F.mse_loss(f_fake, f_real, reduction=self.reduction)

@@ -726,14 +726,14 @@ def linear_case(lib, device, B, I, O, act, bn, seed=0, need_dx=True):
         rel(dbt - 2.0, ber.grad, "dbeta")
 
 
-def conv_bias_relu_case(lib, device, N, H, W, C, K, R, stride, seed=0):
+def conv_bias_relu_case(lib, device, N, H, W, C, K, R, stride, seed=0, pad=0):
     """conv + bias + ReLU in one launch (act = 1) and its backward prologue bias_relu_bwd, vs torch."""
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(seed)
     x = torch.randn(N, C, H, W, generator=gen); w = torch.randn(K, C, R, R, generator=gen) / (C * R * R) ** 0.5
     b = torch.randn(K, generator=gen) * 0.3
     br = b.clone().requires_grad_(True)
-    z = F.conv2d(x, w, br, stride=stride)
+    z = F.conv2d(x, w, br, stride=stride, padding=pad)
     z.retain_grad()
     y = F.relu(z)
     gy = torch.randn(y.shape, generator=gen)
@@ -741,7 +741,7 @@ def conv_bias_relu_case(lib, device, N, H, W, C, K, R, stride, seed=0):
     OH, OW = y.shape[2], y.shape[3]
     d = lambda t: t.to(device).contiguous()
     out = torch.empty(N, OH, OW, K, device=device)
-    lib.conv2d_fwd(d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), d(b), out, N, H, W, C, K, R, R, stride, 0, act=1)
+    lib.conv2d_fwd(d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), d(b), out, N, H, W, C, K, R, R, stride, pad, act=1)
     ref = y.detach().permute(0, 2, 3, 1)
     assert float((out.cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6, "conv+bias+relu fwd"
     g = torch.full_like(out, 7.0); db = torch.full((K,), 0.5, device=device)

@@ -42,6 +42,12 @@ def test_linear_heads(lib, B, I, O, act, bn):
     kc.linear_case(lib, "cuda", B, I, O, act, bn, seed=I + O)
 
 
+def test_conv_halo_bias_relu_epilogue(lib):
+    """VGG19's conv1_2 of the perceptual loss (64 -> 64 on 224 x 224, bias + ReLU) runs on conv_halo_kernel."""
+    kc.conv_bias_relu_case(lib, "cuda", 4, 224, 224, 64, 64, 3, 1, seed=5, pad=1)
+    kc.conv_bias_relu_case(lib, "cuda", 3, 19, 42, 64, 64, 3, 1, seed=6, pad=1)
+
+
 @pytest.mark.parametrize("N,H,C,K,R,stride", [(32, 28, 128, 48, 1, 2), (32, 14, 48, 48, 3, 1), (32, 12, 48, 64, 3, 2), (32, 56, 32, 48, 1, 4)])
 def test_light_estimator_convs(lib, N, H, C, K, R, stride):
     kc.conv_bias_relu_case(lib, "cuda", N, H, H, C, K, R, stride, seed=C + K)

@@ -48,6 +48,12 @@ def test_conv_bias_relu(hostsim_lib, N, H, W, C, K, R, stride):
     kc.conv_bias_relu_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, seed=C + K)
 
 
+def test_conv_halo_bias_relu_epilogue(hostsim_lib):
+    """VGG19's conv1_2 of the perceptual loss (64 -> 64, bias + ReLU): the halo kernel's epilogue adds the bias and clamps."""
+    kc.conv_bias_relu_case(hostsim_lib, "cpu", 2, 10, 14, 64, 64, 3, 1, seed=5, pad=1)
+    kc.conv_bias_relu_case(hostsim_lib, "cpu", 1, 5, 28, 64, 64, 3, 1, seed=6, pad=1)
+
+
 @pytest.mark.parametrize("N,H,W", [(2, 10, 14), (1, 5, 28), (2, 24, 14), (1, 3, 42)])
 def test_conv_halo_layer1_shape(hostsim_lib, N, H, W):
     """3x3 / stride 1 / 64 -> 64 channels with W % 14 == 0: conv_halo_kernel (csrc/conv_halo.hip), forward and backward-data.
