@@ -789,6 +789,95 @@ static void launch_sk(const SkPlan& p, const ConvGeom& g, const float* src, cons
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, BK, true>), dim3(wgs), dim3(256), 0, st, g, src, wgt, nullptr, dst, stats, a);
 }
 
+// 3x3 / stride 1 / pad 1 onto FOUR output channels: the backward-data of a network's first layer on an NHWC4 image (VGG19 conv1_1 of the
+// perceptual loss, 64 -> 3 (+1) channels on 224 x 224 or 512 x 512: the gradient that flows back into the renderer).  As an implicit GEMM
+// its 4 output channels fill 1/16 of a 64-wide tile (1.7 ms at B = 48, 2.9 ms at 16 x 512 x 512).  Here: thread = output pixel, the
+// 4 x 9 x IC filter comes through the scalar cache (wave-uniform addresses), 16 VALU multiply-adds per 16-byte load of the source.
+// Lanes: four per output pixel (lane & 3 owns a quarter of the input channels, a contiguous 64 / 16 * IC bytes of every tap -- a wave reads
+// 16 pixels x IC channels as one contiguous run; one lane per pixel was bound by the cache-line rate of its 256-byte stride, 0.9 ms);
+// the filter lives in LDS as [quarter][tap][output channel][IC / 4]; the four partial sums meet through two DPP exchanges.
+template <int IC>
+__global__ __launch_bounds__(256) void conv3x3_oc4_kernel(const float* __restrict__ src, const float* __restrict__ wgt, float* __restrict__ dst,
+                                                         int N, int H, int W, int sign) {
+  constexpr int QC = IC / 4;                       // channels per lane
+  constexpr int QS = 36 * QC + 4;                  // floats per quarter in LDS (+4: the four quarters of one read land in different banks)
+  constexpr int U = 4;                             // pixels per lane (p, p + 64, ...): every filter value read from LDS feeds U multiply-adds
+  __shared__ __attribute__((aligned(16))) float wl[4 * QS];
+  for (int i = threadIdx.x; i < 4 * 36 * QC; i += 256) {
+    const int j = i % QC, c = (i / QC) & 3, tap = (i / (4 * QC)) % 9, q = i / (36 * QC);
+    wl[q * QS + (tap * 4 + c) * QC + j] = wgt[((size_t)c * 9 + tap) * IC + 16 * (j >> 2) + 4 * q + (j & 3)];      // lane q: channels 16 jj + 4 q + e
+  }
+  __syncthreads();
+  const int q = threadIdx.x & 3;
+  const float* wq = wl + q * QS;
+  // workgroup = 16 x 16 output pixels (the rows above / below are re-read from L1, not from L2: one contiguous run of pixels per workgroup
+  // made every vertical tap an L2 read, 0.76 ms); wave w, team t = (lane >> 2): pixels (x0 + t, y0 + 4 w + u), u = 0 .. 3
+  const int tx = W + 15 >> 4, ty = H + 15 >> 4;
+  const long tiles = (long)N * ty * tx;
+  const int t = (threadIdx.x & 63) >> 2, wv_ = threadIdx.x >> 6;
+  for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int txi = (int)(tile % tx);
+    const long r2 = tile / tx;
+    const int tyi = (int)(r2 % ty), n = (int)(r2 / ty);
+    const int x = txi * 16 + t, yb = tyi * 16 + 4 * wv_;
+    const bool xin = x < W;
+    const int xc = xin ? x : W - 1;
+    float acc[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.f;
+#pragma unroll 1                                           // (unrolled, the compiler hoists all 9 x U x QC / 4 loads: 891 spilled registers)
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, s = tap - 3 * r;
+      const int ix = sign > 0 ? xc + s - 1 : xc + 1 - s;
+      const bool okx = ix >= 0 && ix < W;
+      float4 v[U][QC / 4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int y = yb + u;
+        const int iy = sign > 0 ? y + r - 1 : y + 1 - r;
+        const bool ok = okx && iy >= 0 && iy < H;
+        // the four lanes of a team read 64 contiguous bytes per load (half a cache line), four such runs per tap
+        const float4* sp = reinterpret_cast<const float4*>(src + (((size_t)n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * IC) + q;
+#pragma unroll
+        for (int j = 0; j < QC / 4; ++j) {
+          const float4 tv = sp[4 * j];
+          v[u][j] = ok ? tv : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4* wp = reinterpret_cast<const float4*>(wq + (tap * 4 + c) * QC);
+#pragma unroll
+        for (int j = 0; j < QC / 4; ++j) {
+          const float4 wv = wp[j];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            // fused multiply-adds (the file is built with -ffp-contract=off: a separate multiply and add would double the VALU work)
+            acc[u][c] = __builtin_fmaf(v[u][j].x, wv.x, acc[u][c]); acc[u][c] = __builtin_fmaf(v[u][j].y, wv.y, acc[u][c]);
+            acc[u][c] = __builtin_fmaf(v[u][j].z, wv.z, acc[u][c]); acc[u][c] = __builtin_fmaf(v[u][j].w, wv.w, acc[u][c]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[u][c] += __shfl_xor(acc[u][c], 1, 64);
+        acc[u][c] += __shfl_xor(acc[u][c], 2, 64);
+      }
+      const int y = yb + u;
+      if (xin && y < H) dst[(((size_t)n * H + y) * W + x) * 4 + q] = q == 0 ? acc[u][0] : q == 1 ? acc[u][1] : q == 2 ? acc[u][2] : acc[u][3];
+    }
+  }
+}
+
+static bool conv_oc4_supported(const ConvGeom& g, const float* bias, const float* stats) {
+  static const int on = [] { const char* e = getenv("HIFIHR_CONV_OC4"); return e ? atoi(e) : 1; }();
+  return on && g.OC == 4 && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && (g.IC == 64 || g.IC == 32) && g.batch <= 1 && !g.relu &&
+         bias == nullptr && stats == nullptr && g.IH == g.OH && g.IW == g.OW;
+}
+
 // A 1x1 convolution with stride 1 and no padding is a plain GEMM over the pixel rows (ResNet's stride-1 projection shortcut and every
 // conv1 / conv3 of a bottleneck block): it runs on the kernels of csrc/gemm.hip, 2-3x faster there than as an implicit GEMM with one tap
 // (tools/time_conv1x1.py).  HIFIHR_CONV1X1_GEMM=0 keeps the implicit-GEMM kernels (A/B timing).
@@ -827,6 +916,15 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
   // the fast gather uses 32-bit element offsets (scaled by 4 in the address) and a 63-bit tap mask
   if ((long)g.N * g.IH * g.IW * g.IC >= (1L << 30) || (long)g.OC * g.R * g.S * g.IC >= (1L << 30)) return hipErrorInvalidValue;
+  if (conv_oc4_supported(g, bias, stats)) {
+    const long M = (long)g.N * g.OH * g.OW;
+    long blocks = (long)g.N * ((g.OH + 15) / 16) * ((g.OW + 15) / 16);     // 16 x 16-pixel tiles
+    const long cap = (long)device_cus() * 16;              // grid-stride: the filter goes to LDS once per workgroup
+    if (blocks > cap) blocks = cap;
+    if (g.IC == 64) hipLaunchKernelGGL(conv3x3_oc4_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, src, wgt, dst, g.N, g.OH, g.OW, g.dgrad ? -1 : 1);
+    else hipLaunchKernelGGL(conv3x3_oc4_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, src, wgt, dst, g.N, g.OH, g.OW, g.dgrad ? -1 : 1);
+    return hipGetLastError();
+  }
   if (conv_is_gemm(g) && bias == nullptr) {
     // 1x1 / stride 1: y[M][OC] = x[M][IC] . w[OC][IC]^T, and backward-data the same product on (dy, w^T): the GEMM kernels of
     // csrc/gemm.hip (bgemm_nt_rows_kernel at N % 128 == 0), then one statistics pass for a batch-norm consumer

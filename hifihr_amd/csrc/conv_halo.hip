@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int p = 16 * j + r, ty = p / kTW, tx = p - ty * kTW;
-      if (ty < t.rows) {
+      if (ty < t.rows && t.x0 + tx < a.W) {                  // (a ragged last column tile: W % 14 != 0, the loader read zeros there)
         float* o = a.dst + (((size_t)t.n * a.H + t.y0 + ty) * a.W + t.x0 + tx) * 64 + 16 * wave + 4 * g;
         float4 v = make_float4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w);
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -941,7 +941,7 @@ const float* conv_halo_zero_page(hipStream_t st) {
 bool conv_halo_supported(const ConvGeom& g, const float* bias) {
   static const int on = [] { const char* e = getenv("HIFIHR_CONV_HALO"); return e ? atoi(e) : 1; }();
   return on && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.IC == 64 && g.OC == 64 && g.batch <= 1 &&
-         !((g.relu || bias != nullptr) && g.dgrad) && g.IH == g.OH && g.IW == g.OW && g.OW % kTW == 0 &&
+         !((g.relu || bias != nullptr) && g.dgrad) && g.IH == g.OH && g.IW == g.OW && g.OW >= kTW &&
          (long)g.N * g.OH * g.OW * 64 < (1L << 31);
 }
 
@@ -1001,7 +1001,7 @@ hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float
 
 bool conv_halo_wgrad_supported(const ConvGeom& g) {
   static const int on = [] { const char* e = getenv("HIFIHR_CONV_HALO_WGRAD"); return e ? atoi(e) : 1; }();
-  return on && conv_halo_supported(g, nullptr) && !g.dgrad;
+  return on && conv_halo_supported(g, nullptr) && !g.dgrad && g.OW % kTW == 0;      // (the dy tiles of the weight gradient are not masked)
 }
 
 size_t conv_halo_wgrad_slab_bytes() { return (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float); }
@@ -1052,7 +1052,7 @@ hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wg
   HaloArgs a;
   a.src = src; a.wgt = wgt; a.dst = dst; a.stats = stats; a.zeros = zeros; a.bias = bias; a.relu = g.relu;
   a.N = g.N; a.H = g.OH; a.W = g.OW; a.sign = g.dgrad ? -1 : 1;
-  a.ctiles = g.OW / kTW;
+  a.ctiles = (g.OW + kTW - 1) / kTW;                         // the last column tile may be ragged (512 = 36 x 14 + 8)
   a.total = g.N * a.ctiles * g.OH;
   int G = halo_cus();
   a.per = (a.total + G - 1) / G;

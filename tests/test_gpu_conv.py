@@ -26,7 +26,9 @@ def test_resnet18_conv_shapes(lib, shape):
     kc.conv_case(lib, "cuda", 4, H, H, C, K, R, s, p, seed=H + C, rtol=3e-5)
 
 
-@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(3, 9, 7, 16, 64, 3, 1, 1), (1, 6, 6, 48, 48, 3, 1, 0), (32, 14, 14, 512, 512, 3, 1, 1)])
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(3, 9, 7, 16, 64, 3, 1, 1), (1, 6, 6, 48, 48, 3, 1, 0), (32, 14, 14, 512, 512, 3, 1, 1),
+                                                    (4, 224, 224, 4, 64, 3, 1, 1),      # VGG19 conv1_1: backward-data onto 4 channels (conv3x3_oc4_kernel)
+                                                    (2, 60, 500, 64, 64, 3, 1, 1)])     # conv_halo_kernel with a ragged last column tile
 def test_conv_edge_and_full_batch(lib, N, H, W, C, K, R, stride, pad):
     kc.conv_case(lib, "cuda", N, H, W, C, K, R, stride, pad, seed=1, bias=(K == 48), rtol=5e-5)
 

@@ -17,6 +17,8 @@ def hostsim_lib():
     (1, 6, 6, 48, 48, 3, 1, 0),     # K not a multiple of 64, no padding, bias
     (2, 5, 5, 24, 40, 1, 1, 0),     # EfficientNet-style 1x1 with C, K not multiples of 16 (generic gather, generic dgrad)
     (1, 7, 7, 136, 816, 1, 1, 0),   # 1x1 expand 136 -> 816
+    (2, 9, 11, 4, 64, 3, 1, 1),     # VGG19 conv1_1 on NHWC4: its backward-data has 4 output channels (conv3x3_oc4_kernel, flipped taps)
+    (1, 6, 5, 32, 4, 3, 1, 1),      # the same kernel in the forward direction
 ])
 def test_conv_fwd_bwd(hostsim_lib, N, H, W, C, K, R, stride, pad):
     kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, seed=H, bias=(K == 48))
@@ -54,15 +56,19 @@ def test_conv_halo_bias_relu_epilogue(hostsim_lib):
     kc.conv_bias_relu_case(hostsim_lib, "cpu", 1, 5, 28, 64, 64, 3, 1, seed=6, pad=1)
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 10, 14), (1, 5, 28), (2, 24, 14), (1, 3, 42)])
+@pytest.mark.parametrize("N,H,W", [(2, 10, 14), (1, 5, 28), (2, 24, 14), (1, 3, 42), (1, 6, 20), (2, 9, 31), (1, 4, 15)])
 def test_conv_halo_layer1_shape(hostsim_lib, N, H, W):
-    """3x3 / stride 1 / 64 -> 64 channels with W % 14 == 0: conv_halo_kernel (csrc/conv_halo.hip), forward and backward-data.
+    """3x3 / stride 1 / 64 -> 64 channels, W >= 14 (a ragged last column tile when W % 14 != 0): conv_halo_kernel (csrc/conv_halo.hip),
+    forward and backward-data; the weight gradient's slab kernel only at W % 14 == 0.
     hostsim reports 4 CUs: shares of 5 rows (one 7-block tile), shares that cross a column-tile boundary, 8 + 4 row tiles, 3-row images."""
+    assert hostsim_lib.conv2d_describe(N, H, W, 64, 64, 3, 3, 1, 1, 0) == "conv_halo_kernel"
+    assert hostsim_lib.conv2d_describe(N, H, W, 64, 64, 3, 3, 1, 1, 2) == ("conv_halo_wgrad_kernel" if W % 14 == 0 else "conv_wgrad_kernel")
     kc.conv_case(hostsim_lib, "cpu", N, H, W, 64, 64, 3, 1, 1, seed=H + W)
 
 
 def test_conv_halo_bnstats(hostsim_lib):
     kc.conv_bnstats_case(hostsim_lib, "cpu", 2, 12, 14, 64, 64, 3, 1, 1)
+    kc.conv_bnstats_case(hostsim_lib, "cpu", 1, 7, 19, 64, 64, 3, 1, 1)
 
 
 @pytest.mark.parametrize("N,H,W", [(1, 56, 56), (2, 20, 28), (3, 6, 84)])
