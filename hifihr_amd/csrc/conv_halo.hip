@@ -89,6 +89,9 @@ __device__ unsigned long long g_halo_stamp[8];
 #define HALO_BARRIER() HIFIHR_RAW_BARRIER()
 #endif
 
+// EPI: the epilogue adds a bias, applies ReLU and masks a ragged last column tile (the perceptual loss's VGG19 conv1_2; any W % 14 != 0).
+// The encoder's layer 1 runs the plain form: the extra epilogue work cost it 2.5 us per launch (rocprofv3, 69.9 -> 72.4 us).
+template <bool EPI>
 __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
 #if defined(HIFIHR_HALO_STAMP)
   const unsigned long long st_entry = HALO_T();
@@ -301,14 +304,20 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
     st_loop += l1 - l0; st_real += __builtin_amdgcn_s_memrealtime() - r0;
 #endif
     // epilogue: register e of lane (r, g) of block j = out[pixel 16 j + r][channel 16 wave + 4 g + e]
-    const float4 b4 = a.bias != nullptr ? *reinterpret_cast<const float4*>(a.bias + 16 * wave + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EPI) {
+      if (a.bias != nullptr) b4 = *reinterpret_cast<const float4*>(a.bias + 16 * wave + 4 * g);
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int p = 16 * j + r, ty = p / kTW, tx = p - ty * kTW;
-      if (ty < t.rows && t.x0 + tx < a.W) {                  // (a ragged last column tile: W % 14 != 0, the loader read zeros there)
+      if (ty < t.rows && (!EPI || t.x0 + tx < a.W)) {        // (EPI: a ragged last column tile, W % 14 != 0 -- the loader read zeros there)
         float* o = a.dst + (((size_t)t.n * a.H + t.y0 + ty) * a.W + t.x0 + tx) * 64 + 16 * wave + 4 * g;
-        float4 v = make_float4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w);
-        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        float4 v = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+        if constexpr (EPI) {
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
         *reinterpret_cast<float4*>(o) = v;
         ssum[0] += v.x; ssq[0] += v.x * v.x; ssum[1] += v.y; ssq[1] += v.y * v.y;
         ssum[2] += v.z; ssq[2] += v.z * v.z; ssum[3] += v.w; ssq[3] += v.w * v.w;
@@ -1058,7 +1067,8 @@ hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wg
   a.per = (a.total + G - 1) / G;
   if (a.per < 4) a.per = 4;                                  // tiny problems: fewer workgroups, tiles of >= 4 rows
   G = (a.total + a.per - 1) / a.per;
-  hipLaunchKernelGGL(conv_halo_kernel, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+  if (bias != nullptr || g.relu || g.OW % kTW != 0) hipLaunchKernelGGL(conv_halo_kernel<true>, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+  else hipLaunchKernelGGL(conv_halo_kernel<false>, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
   return hipGetLastError();
 }
 
