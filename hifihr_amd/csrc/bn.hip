@@ -525,9 +525,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
     const float4 sc = *reinterpret_cast<const float4*>(&s_sc[cg * 4]), sh = *reinterpret_cast<const float4*>(&s_sh[cg * 4]);
     const long Mo = (long)g.N * g.OH * g.OW;
     for (long o = (long)blockIdx.x * RL + rl; o < Mo; o += (long)gridDim.x * RL) {
-      const int ow = (int)(o % g.OW);
-      const long r2 = o / g.OW;
-      const int oh = (int)(r2 % g.OH), n = (int)(r2 / g.OH);
+      const unsigned ou = (unsigned)o;                       // (the launcher checks N * H * W < 2^31: 32-bit divisions, a 64-bit one costs ~100 instructions)
+      const unsigned r2 = ou / (unsigned)g.OW;
+      const int ow = (int)(ou - r2 * (unsigned)g.OW);
+      const int n = (int)(r2 / (unsigned)g.OH), oh = (int)(r2 - (unsigned)n * (unsigned)g.OH);
       // all nine loads issued before the first use (clamped addresses, validity kept aside)
       float4 v[3][3];
       bool ok[3][3];
@@ -578,9 +579,10 @@ struct PoolTaps {
 };
 __device__ __forceinline__ void pool_taps_load(const float* __restrict__ gy, const unsigned char* __restrict__ tap, const StemPool& g, int C,
                                                long m, int cg, PoolTaps& p) {
-  const int iw = (int)(m % g.W);
-  const long r2 = m / g.W;
-  const int ih = (int)(r2 % g.H), n = (int)(r2 / g.H);
+  const unsigned mu = (unsigned)m;                           // (N * H * W < 2^31, checked by the launcher)
+  const unsigned r2 = mu / (unsigned)g.W;
+  const int iw = (int)(mu - r2 * (unsigned)g.W);
+  const int n = (int)(r2 / (unsigned)g.H), ih = (int)(r2 - (unsigned)n * (unsigned)g.H);
   int ohc[2], owc[2], rc[2], sc[2];
   bool vh[2], vw[2];
 #pragma unroll
@@ -808,7 +810,9 @@ hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, co
   return hipGetLastError();
 }
 
-static bool bn_pool_ok(int N, int H, int W, int C) { return N > 0 && H >= 2 && W >= 2 && C >= 4 && C % 4 == 0 && C <= kFuseMaxC; }
+static bool bn_pool_ok(int N, int H, int W, int C) {
+  return N > 0 && H >= 2 && W >= 2 && C >= 4 && C % 4 == 0 && C <= kFuseMaxC && (long)N * H * W < (1L << 31);
+}
 
 bool bn_relu_maxpool_supported(int N, int H, int W, int C) { return bn_pool_ok(N, H, W, C); }
 

@@ -53,3 +53,25 @@ for name, H, C, res, cnt in (("stem", 112, 64, False, 1), ("layer1 bn1", 56, 64,
     tot_f += t_f * cnt; tot_b += t_b * cnt
     print(f"{name:16s} M={M:7d} C={C:4d}: fwd {t_f:6.1f} us {bf / t_f / 1e6:5.2f} TB/s | bwd (reduce + apply) {t_b:6.1f} us {bb / t_b / 1e6:5.2f} TB/s")
 print(f"per step (launch counts of ResNet-18): fwd {tot_f:.0f} us, bwd {tot_b:.0f} us")
+
+# the fused stem: bn1 + ReLU + MaxPool2d(3, 2, 1) (bn_relu_pool_fwd_kernel; bn_pool_bwd_reduce_kernel + bn_pool_bwd_apply_kernel)
+N, H, C = B, 112, 64
+OH = (H - 1) // 2 + 1
+x = torch.randn(N, H, H, C, device=dev); gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+stats0 = torch.zeros(lib.bn_stats_floats(C), device=dev)
+lib.bn_stats(x, N * H * H, C, stats0)
+stats = stats0.clone()
+pooled = torch.empty(N, OH, OH, C, device=dev); tap = torch.empty(N * OH * OH * C, dtype=torch.uint8, device=dev)
+mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+def fwd():
+    stats.copy_(stats0)
+    lib.bn_relu_maxpool_fwd(x, stats, gamma, beta, N, H, H, C, 1e-5, 0.1, pooled, tap, mean, invstd, None, None)
+t_copy = bench(lambda: stats.copy_(stats0))
+t_f = bench(fwd) - t_copy
+gy = torch.randn_like(pooled); red = torch.zeros(lib.bn_stats_floats(C), device=dev); dx = torch.empty_like(x)
+dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+t_b = bench(lambda: lib.bn_relu_maxpool_bwd(gy, tap, x, mean, invstd, gamma, beta, N, H, H, C, red, dx, dg, db))
+mb_f = (x.numel() * 4 + pooled.numel() * 5) / 1e6
+mb_b = (2 * x.numel() * 4 + 2 * pooled.numel() * 5 + x.numel() * 4) / 1e6
+print(f"fused stem (bn1 + ReLU + maxpool) B={B}: fwd {t_f:6.1f} us ({mb_f / t_f * 1e-3 * 1e3:5.2f} TB/s of {mb_f:.0f} MB)   "
+      f"bwd (reduce + apply) {t_b:6.1f} us ({mb_b / t_b * 1e-3 * 1e3:5.2f} TB/s of {mb_b:.0f} MB)")
