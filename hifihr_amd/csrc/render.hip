@@ -152,15 +152,23 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
       const float* q = L.rec + k * kRecW;
       const float xmin = fminf(q[0], fminf(q[2], q[4])), xmax = fmaxf(q[0], fmaxf(q[2], q[4]));
       const float ymin = fminf(q[1], fminf(q[3], q[5])), ymax = fmaxf(q[1], fmaxf(q[3], q[5]));
-      int x0 = 16, x1 = -1, y0 = 16, y1 = -1;
-      for (int c = 0; c < cols; ++c) {
-        const float hi = L.sxs[c * AA], lo = L.sxs[c * AA + AA - 1];          // NDC decreases with the index
-        if (!(xmin > hi || xmax < lo)) { x0 = min(x0, c); x1 = c; }
-      }
-      for (int c = 0; c < rows; ++c) {
-        const float hi = L.sys[c * AA], lo = L.sys[c * AA + AA - 1];
-        if (!(ymin > hi || ymax < lo)) { y0 = min(y0, c); y1 = c; }
-      }
+      // pixel c overlaps the box iff hi(c) >= min and lo(c) <= max, hi(c) = s[c AA], lo(c) = s[c AA + AA - 1] (NDC DEcreases with the
+      // index): the first holds on a prefix of the columns, the second on a suffix, so the overlapping pixels are [#{lo > max}, #{hi >= min})
+      // -- two 5-probe searches per axis instead of a 16-column scan (the scan was 3 us of a 512-face pass, tools/render_stamp.py)
+      const auto prefix = [](const float* sv, int off, int nn, float v, bool strict) {
+        int len = 0;
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1) {
+          const int t = len + step;
+          if (t <= nn) {
+            const float a = sv[(t - 1) * AA + off];
+            if (strict ? (a > v) : (a >= v)) len = t;
+          }
+        }
+        return len;
+      };
+      const int x0 = prefix(L.sxs, AA - 1, cols, xmax, true), x1 = prefix(L.sxs, 0, cols, xmin, false) - 1;
+      const int y0 = prefix(L.sys, AA - 1, rows, ymax, true), y1 = prefix(L.sys, 0, rows, ymin, false) - 1;
       const int w = x1 - x0 + 1, h = y1 - y0 + 1;
       if (w > 0 && h > 0) {
         cnt = w * h;
