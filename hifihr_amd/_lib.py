@@ -91,6 +91,8 @@ class HifihrLib:
         c.hifihr_ssim_fwd.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_float_p, _c_float_p,
                                       _c_float_p, c_void_p]
         c.hifihr_ssim_bwd.argtypes = [_c_float_p] * 7 + [c_int, c_int, c_int, _c_float_p, c_void_p]
+        c.hifihr_ssim_bwd_scaled.argtypes = [_c_float_p] * 7 + [c_float, c_int, c_int, c_int, _c_float_p, c_void_p]
+        c.hifihr_ssim_finish.argtypes = [_c_float_p, c_int, c_float, c_float, _c_float_p, c_void_p]
         ci = [c_int] * 9
         c.hifihr_conv2d_fwd.argtypes = [_c_float_p] * 3 + [c_int, _c_float_p] + ci + [c_void_p, c_size_t, c_void_p]
         c.hifihr_bias_relu_bwd.argtypes = [_c_float_p, _c_float_p, c_long, c_int, _c_float_p, _c_float_p, c_void_p]
@@ -616,6 +618,15 @@ class HifihrLib:
         planes, H, W = img1.shape[0] * img1.shape[1], img1.shape[2], img1.shape[3]
         self.check(self.c.hifihr_ssim_fwd(window, _fp(img1), _fp(img2), planes, H, W, _fp(partial), _fp(dA), _fp(dB), _fp(dC),
                                           _stream_of(img1)), "hifihr_ssim_fwd")
+
+    def ssim_finish(self, partial, scale, offset, out):
+        self.check(self.c.hifihr_ssim_finish(_fp(partial), partial.numel(), c_float(scale), c_float(offset), _fp(out), _stream_of(partial)),
+                   "hifihr_ssim_finish")
+
+    def ssim_bwd_scaled(self, window, img1, img2, dA, dB, dC, grad_out, out_scale, gimg1):
+        planes, H, W = img1.shape[0] * img1.shape[1], img1.shape[2], img1.shape[3]
+        self.check(self.c.hifihr_ssim_bwd_scaled(window, _fp(img1), _fp(img2), _fp(dA), _fp(dB), _fp(dC), _fp(grad_out), c_float(out_scale),
+                                                 planes, H, W, _fp(gimg1), _stream_of(img1)), "hifihr_ssim_bwd_scaled")
 
     def ssim_bwd(self, window, img1, img2, dA, dB, dC, grad_out, gimg1):
         planes, H, W = img1.shape[0] * img1.shape[1], img1.shape[2], img1.shape[3]

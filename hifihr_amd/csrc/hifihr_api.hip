@@ -501,6 +501,22 @@ int hifihr_ssim_bwd(const float* window11, const float* img1, const float* img2,
   return HIFIHR_OK;
 }
 
+int hifihr_ssim_bwd_scaled(const float* window11, const float* img1, const float* img2, const float* dA, const float* dB, const float* dC,
+                           const float* grad_out, float out_scale, int planes, int H, int W, float* gimg1, void* stream) {
+  if (!window11 || !img1 || !img2 || !dA || !dB || !dC || !grad_out || !gimg1 || planes <= 0 || H <= 0 || W <= 0)
+    return fail(HIFIHR_EINVAL, "hifihr_ssim_bwd_scaled: bad argument");
+  hifihr::SsimWindow win;
+  for (int k = 0; k < 11; ++k) win.g[k] = window11[k];
+  HIP_TRY(hifihr::launch_ssim_bwd(win, img1, img2, dA, dB, dC, grad_out, planes, H, W, gimg1, (hipStream_t)stream, out_scale));
+  return HIFIHR_OK;
+}
+
+int hifihr_ssim_finish(const float* partial, int count, float scale, float offset, float* out, void* stream) {
+  if (!partial || !out || count <= 0) return fail(HIFIHR_EINVAL, "hifihr_ssim_finish: bad argument");
+  HIP_TRY(hifihr::launch_ssim_finish(partial, count, scale, offset, out, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_bn_stats_floats(int C) { return C > 0 ? (hifihr::kStatSlots + 1) * 2 * C + 64 : 0; }   // slots, spare [2][C], 64 counter words
 
 static int bn_dims_ok(long M, int C) { return M > 0 && C >= 4 && C % 4 == 0 && C <= 4096; }

@@ -135,7 +135,8 @@ struct SsimWindow {
 hipError_t launch_ssim_fwd(const SsimWindow& win, const float* img1, const float* img2, int planes, int H, int W, float* partial,
                            float* dA, float* dB, float* dC, hipStream_t st);
 hipError_t launch_ssim_bwd(const SsimWindow& win, const float* img1, const float* img2, const float* dA, const float* dB,
-                           const float* dC, const float* gscale, int planes, int H, int W, float* gimg1, hipStream_t st);
+                           const float* dC, const float* gscale, int planes, int H, int W, float* gimg1, hipStream_t st, float out_scale = 1.0f);
+hipError_t launch_ssim_finish(const float* partial, int count, float scale, float offset, float* out, hipStream_t st);
 
 // depthwise convolution geometry: x[N][H][W][C] -> y[N][OH][OW][C], k x k taps, padding top/left = pt/pl
 struct DwGeom {

@@ -758,8 +758,12 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
 #endif
   hipError_t e = hipMemsetAsync(gvrec, 0, (size_t)B * r.V * 12 * sizeof(float), st);
   if (e != hipSuccess) return e;
-  if ((e = hipMemsetAsync(glight_color, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(glight_dir, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
+  if (glight_dir == glight_color + (size_t)B * 3) {           // adjacent (hifihr_amd/ops.py allocates them as one tensor): one fill
+    if ((e = hipMemsetAsync(glight_color, 0, (size_t)B * 6 * sizeof(float), st)) != hipSuccess) return e;
+  } else {
+    if ((e = hipMemsetAsync(glight_color, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(glight_dir, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
+  }
   const int tiles = (r.H + kTile - 1) / kTile;
   const dim3 grid(tiles, tiles, B);
   const size_t lds = (size_t)r.V * 12 * sizeof(float);

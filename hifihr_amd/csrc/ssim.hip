@@ -133,6 +133,24 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWindow win, const flo
   }
 }
 
+// out[0] = offset + scale * sum(partial[0 .. count)): the scalar behind the forward (SSIM = sum / n, or the ssim_tex loss term
+// lambda - lambda * sum / n) in one launch instead of a reduction, a fill and an add; fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void ssim_finish_kernel(const float* __restrict__ partial, int count, float scale, float offset,
+                                                         float* __restrict__ out) {
+  __shared__ float red[4];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = threadIdx.x;
+  for (; i + 768 < count; i += 1024) { s0 += partial[i]; s1 += partial[i + 256]; s2 += partial[i + 512]; s3 += partial[i + 768]; }
+  for (; i < count; i += 256) s0 += partial[i];
+  const float s = block_sum_256((s0 + s1) + (s2 + s3), red);
+  if (threadIdx.x == 0) out[0] = offset + scale * s;
+}
+
+hipError_t launch_ssim_finish(const float* partial, int count, float scale, float offset, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(256), 0, st, partial, count, scale, offset, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_ssim_fwd(const SsimWindow& win, const float* img1, const float* img2, int planes, int H, int W, float* partial,
                            float* dA, float* dB, float* dC, hipStream_t st) {
   const dim3 grid((W + kST - 1) / kST, (H + kST - 1) / kST, planes);
@@ -141,9 +159,9 @@ hipError_t launch_ssim_fwd(const SsimWindow& win, const float* img1, const float
 }
 
 hipError_t launch_ssim_bwd(const SsimWindow& win, const float* img1, const float* img2, const float* dA, const float* dB,
-                           const float* dC, const float* gscale, int planes, int H, int W, float* gimg1, hipStream_t st) {
+                           const float* dC, const float* gscale, int planes, int H, int W, float* gimg1, hipStream_t st, float out_scale) {
   const dim3 grid((W + kST - 1) / kST, (H + kST - 1) / kST, planes);
-  const float inv_n = 1.0f / ((float)planes * (float)H * (float)W);
+  const float inv_n = out_scale / ((float)planes * (float)H * (float)W);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, st, win, img1, img2, dA, dB, dC, gscale, inv_n, H, W, gimg1);
   return hipGetLastError();
 }

@@ -238,8 +238,8 @@ class _Render(torch.autograd.Function):
         gverts = torch.empty_like(verts)
         need_col = ctx.needs_input_grad[2]
         gvcol = torch.empty_like(verts) if need_col else None
-        glc = torch.empty(B, 3, device=verts.device)
-        gld = torch.empty(B, 3, device=verts.device)
+        gl = torch.empty(2, B, 3, device=verts.device)         # adjacent: the library zero-fills both with one launch
+        glc, gld = gl[0], gl[1]
         ws = ctx.ws                                  # holds this call's packed vertex records
         g = grad_rgba.contiguous()
         PROFILE.bracket("render_bwd", lambda: handle.lib.render_bwd(handle.h, verts, cam, light_color, light_dir, face_id, g,
@@ -1349,19 +1349,23 @@ class _SSIM(torch.autograd.Function):
         if need:
             ctx.save_for_backward(img1, img2, maps)
         n = float(B * C * H * W)
-        s = partial.sum()
+        out = torch.empty((), device=img1.device)
         if loss_lambda is None:
-            ctx.gscale = 1.0 / n
-            return s * ctx.gscale                                          # SSIM = sum / n
-        ctx.gscale = -loss_lambda / n
-        return torch.add(s.new_full((), loss_lambda), s, alpha=ctx.gscale)  # lambda - lambda * sum / n
+            ctx.out_scale = 1.0
+            lib.ssim_finish(partial, 1.0 / n, 0.0, out)                    # SSIM = sum / n
+        else:
+            ctx.out_scale = -loss_lambda
+            lib.ssim_finish(partial, -loss_lambda / n, loss_lambda, out)   # lambda - lambda * sum / n
+        return out
 
     @staticmethod
     def backward(ctx, g):
         img1, img2, maps = ctx.saved_tensors
         gimg1 = torch.empty_like(img1)
-        gs = (g * (ctx.gscale * float(img1.numel()))).reshape(1).float()   # the kernel divides by the element count itself
-        PROFILE.bracket("ssim_bwd", lambda: get_lib().ssim_bwd(_SSIM_WIN, img1, img2, maps[0], maps[1], maps[2], gs, gimg1))
+        # the kernel multiplies the incoming gradient by out_scale and divides by the element count itself
+        gs = g.reshape(1) if (g.dtype == torch.float32 and g.is_contiguous()) else g.reshape(1).float().contiguous()
+        PROFILE.bracket("ssim_bwd", lambda: get_lib().ssim_bwd_scaled(_SSIM_WIN, img1, img2, maps[0], maps[1], maps[2], gs, ctx.out_scale,
+                                                                       gimg1))
         return gimg1, None, None
 
 

@@ -448,6 +448,13 @@ int hifihr_ssim_fwd(const float* window11_h, const float* img1_d, const float* i
                     float* partial_d, float* dA_d, float* dB_d, float* dC_d, void* stream);
 int hifihr_ssim_bwd(const float* window11_h, const float* img1_d, const float* img2_d, const float* dA_d, const float* dB_d,
                     const float* dC_d, const float* grad_out_d, int planes, int H, int W, float* gimg1_d, void* stream);
+/* The scalar glue of the call site in two more entry points (reference losses.py:375-377, `lambda * (1 - ssim)`):
+ *   hifihr_ssim_finish: out_d[0] = offset + scale * sum(partial)   (SSIM: scale = 1 / n, offset = 0; the loss term: scale = -lambda / n,
+ *                       offset = lambda) -- one launch, fixed summation order;
+ *   hifihr_ssim_bwd_scaled: hifihr_ssim_bwd with the incoming gradient multiplied by out_scale (= -lambda for the loss term). */
+int hifihr_ssim_finish(const float* partial_d, int count, float scale, float offset, float* out_d, void* stream);
+int hifihr_ssim_bwd_scaled(const float* window11_h, const float* img1_d, const float* img2_d, const float* dA_d, const float* dB_d,
+                           const float* dC_d, const float* grad_out_d, float out_scale, int planes, int H, int W, float* gimg1_d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused training losses.  Replaces the torch-op evaluation of reference losses.py:226-453 (LossFunction.forward) and its

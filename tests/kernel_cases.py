@@ -359,6 +359,16 @@ def ssim_case(lib, device, a, b, ref_val=None, ref_grad=None):
     lib.ssim_bwd(win, da, db, maps[0], maps[1], maps[2], torch.full((1,), 2.0, device=device), g)
     ref = 2.0 * np.asarray(ref_grad)
     assert np.abs(g.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-10
+    # the call site's scalar glue: lambda * (1 - SSIM) in one finishing launch, the gradient scale folded into the backward
+    n, lam = B * C * H * W, 0.37
+    out = torch.full((), 7.0, device=device)
+    lib.ssim_finish(partial, 1.0 / n, 0.0, out)
+    assert abs(float(out) - val) <= 2e-6 * max(1.0, abs(val))
+    lib.ssim_finish(partial, -lam / n, lam, out)
+    assert abs(float(out) - lam * (1.0 - val)) <= 2e-6
+    g2 = torch.empty_like(da)
+    lib.ssim_bwd_scaled(win, da, db, maps[0], maps[1], maps[2], torch.full((1,), 2.0, device=device), -lam, g2)
+    assert float((g2 + lam * g).abs().max()) <= 1e-6 * float(g.abs().max()) + 1e-12
 
 
 # ------------------------------------------------------------------------------------------------

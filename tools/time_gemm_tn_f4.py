@@ -21,7 +21,7 @@ for H, C, K in ((28, 128, 128), (14, 256, 256), (14, 256, 512), (14, 512, 512)):
     V = torch.randn(36, T, C, device="cuda"); Y = torch.randn(36, T, K, device="cuda"); dw = torch.zeros(K, 3, 3, C, device="cuda")
     gf = 2.0 * 36 * T * C * K / 1e9
     line = f"T'={T:5d} C={C:3d} K={K:3d} {gf:5.2f} GF |"
-    for tile in (128128, 64064):
+    for tile in (128128, 128064, 64128, 64064):
         for parts_req in (None, 1, 2, 4, 7):
             setenv("HIFIHR_GEMM_TN_TILE", tile); setenv("HIFIHR_GEMM_TN_PARTS", parts_req)
             parts = lib.bgemm_tn_parts(K, C, T, 36)
@@ -33,6 +33,6 @@ for H, C, K in ((28, 128, 128), (14, 256, 256), (14, 256, 512), (14, 512, 512)):
             except Exception as e:
                 continue
             td = timeit(lambda: lib.wino_dw_transform_parts(dU, parts, dw, K, C, 4))
-            line += f" {tile // 1000}/{'auto' if parts_req is None else 'p'}{parts}: {tg:5.1f}+{td:4.1f}={tg + td:5.1f}"
+            line += f" {tile // 1000}x{tile % 1000}/{'auto' if parts_req is None else 'p'}{parts}: {tg:5.1f}+{td:4.1f}={tg + td:5.1f}"
     setenv("HIFIHR_GEMM_TN_TILE", None); setenv("HIFIHR_GEMM_TN_PARTS", None)
     print(line, flush=True)
