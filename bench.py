@@ -261,15 +261,22 @@ def main():
                      "100 B per sample + hifihr_freihand_batch: gather + affine warp, K / joint / vertex / projection terms of data_dic), "
                      "written straight into the captured step's static inputs")
     else:
-        pool = [data_dic(synth.to_ho3d_sample(synth.make_batch(model.hand_layer.handle, model.renderer_p3d, a.batch, first_index=(rank * 8 + i) * a.batch,
-                                                               device=dev, image_size=image_size), crop=image_size),
-                         "HO3D", "training", args_ns, device=dev, image_size=image_size) for i in range(4)]
-        turn = [0]
+        from hifihr_amd.data import HO3DDeviceCache
+        # the renderer that draws the synthetic 224 x 224 hands is the bench model's only when that renders at 224
+        from hifihr_amd import ops as _ops
+        draw = model.renderer_p3d if image_size == 224 else _ops.RendererHandle(tables.faces, int(tables.v_template.shape[0]), image_size=224, aa=3,
+                                                                                 ambient=(0.5,) * 3, mat_diffuse=(0.8,) * 3, specular=(0.04,) * 3,
+                                                                                 shininess=30.0, background=(1.0,) * 3)
+        ho_cache = HO3DDeviceCache(**synth.make_ho3d_frames(model.hand_layer.handle, draw, a.cache, first_index=rank * a.cache, device=dev), device=dev)
+        perm_gen = torch.Generator().manual_seed(100 + rank)
+        noise_gen = torch.Generator().manual_seed(300 + rank)
 
         def next_batch(out=None):
-            turn[0] += 1
-            return pool[turn[0] % len(pool)]
-        data_note = "every step copies one of 4 device-resident HO-3D-convention batches into the step's static inputs (no HO-3D device cache is built)"
+            idx = torch.randint(0, ho_cache.n, (a.batch,), generator=perm_gen)
+            return data_dic(ho_cache.batch(idx, generator=noise_gen), "HO3D", "training", args_ns, device=dev, image_size=image_size)
+        data_note = ("every step assembles a NEW HO-3D batch on the device from 480 x 640 uint8 frames resident in HBM (hifihr_ho3d_batch: the "
+                     "reference's hand crop window per sample, Pillow-exact crop + bilinear / bicubic resize to 224, K_crop / uv21_crop), data_dic, "
+                     "copy into the step's static inputs")
     examples = next_batch()
     torch.cuda.synchronize()
 

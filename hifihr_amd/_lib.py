@@ -142,6 +142,10 @@ class HifihrLib:
         c.hifihr_conv2d_bwd_data_pre.argtypes = [_c_float_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_weight_prep.argtypes = [c_void_p, c_int, c_int, c_void_p]
         c.hifihr_freihand_augment.argtypes = [c_void_p, c_void_p, _c_int_p, _c_int_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_ho3d_workspace_bytes.argtypes = [c_int, c_int]
+        c.hifihr_ho3d_workspace_bytes.restype = c_size_t
+        c.hifihr_ho3d_batch.argtypes = ([c_void_p, c_void_p] + [_c_float_p] * 3 + [c_int, c_int, _c_int_p, c_int, c_int, c_void_p, c_size_t] +
+                                        [_c_float_p] * 5 + [c_void_p])
         c.hifihr_freihand_batch.argtypes = ([c_void_p, c_void_p] + [_c_float_p] * 4 + [c_int, c_int, _c_int_p, c_int, c_int, c_int, _c_float_p,
                                             _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p, c_void_p])
         c.hifihr_procrustes_error.argtypes = [_c_float_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
@@ -431,6 +435,20 @@ class HifihrLib:
                                                 _fp(g("imgs")), _fp(g("masks")), vp(g("segms_gt")), _fp(g("Ks")), _fp(g("Ps")), _fp(g("joints")),
                                                 _fp(g("verts")), _fp(g("j2d_gt")), _fp(g("scales")), vp(g("idxs")), _stream_of(packed)),
                    "hifihr_freihand_batch")
+
+    def ho3d_workspace_bytes(self, B, out_size):
+        return int(self.c.hifihr_ho3d_workspace_bytes(B, out_size))
+
+    def ho3d_batch(self, img_rgbx, hand_mask, Ks, uv21, xyz21, packed, B, out_size, ws, out):
+        """out: dict with any of img_crop [B,3,S,S], hand_mask_crop [B,1,S,S], K_crop [B,3,3], uv21_crop [B,21,2], xyz21 [B,21,3]."""
+        n, FH, FW = img_rgbx.shape
+        vp = lambda t: c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+        g = out.get
+        for t in out.values():
+            assert t.is_contiguous() and t.dtype == torch.float32
+        self.check(self.c.hifihr_ho3d_batch(vp(img_rgbx), vp(hand_mask), _fp(Ks), _fp(uv21), _fp(xyz21), FH, FW, _ip(packed), B, out_size,
+                                            vp(ws), c_size_t(ws.numel() * ws.element_size()), _fp(g("img_crop")), _fp(g("hand_mask_crop")),
+                                            _fp(g("K_crop")), _fp(g("uv21_crop")), _fp(g("xyz21")), _stream_of(packed)), "hifihr_ho3d_batch")
 
     def freihand_augment(self, img_rgbx, mask, idx, coef_fix, out_img, out_mask):
         """img_rgbx int32/uint8x4 [n,H,W], mask uint8 [n,H,W] (either None with its output), idx int32 [B], coef_fix int32 [B,6]."""

@@ -115,6 +115,175 @@ __global__ __launch_bounds__(256) void freihand_batch_meta_kernel(BatchMeta m) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// HO-3D sample assembly (the HO-3D half): the hand crop of reference data/dataset.py:1105-1215 --
+// `func_transforms.resized_crop(image, y1, x1, size, size, [224, 224])` for the frame (bilinear) and for the hand mask (bicubic), i.e.
+// Pillow's Image.crop (box rounded half-to-even, zero fill outside the frame) followed by Image.resize for 8-bit images
+// (libImaging/Resample.c): a horizontal then a vertical pass, each a normalised filter of support (filter support x max(scale, 1))
+// evaluated in DOUBLE, quantised to 22-bit fixed point, accumulated in 32-bit integers with rounding and clipped to uint8 BETWEEN the passes.
+// The kernels follow that arithmetic step by step (IEEE double on the device, integer accumulation): bit-exact with Pillow
+// (tests/golden/ho3d_path.npz holds Pillow's own outputs).
+//   ho3d_coeff_kernel     (4 tables, B) x 256: table t = filter (t >> 1: bilinear, bicubic) x axis (t & 1: x, y): per output row / column its
+//                         first source index, tap count and <= kHoTaps fixed-point coefficients (Resample.c precompute_coeffs +
+//                         normalize_coeffs_8bpc)
+//   ho3d_resample_kernel  thread = output pixel: for each of its <= kHoTaps source rows the horizontal sum (rounded, clipped to 8 bits),
+//                         then the vertical sum of those; frame as u8 / 255 in three planes, mask as round(u8 / 255)
+//   ho3d_meta_kernel      uv21_crop = (uv21 - centre) * scale + 112, K_crop = T . S . K (:1186-1210), xyz21 gathered
+// ------------------------------------------------------------------------------------------------
+constexpr int kHoTaps = 16;          // taps per output element: 2 * ceil(support) + 1 <= 13 for a 640-pixel window with the bicubic filter
+constexpr int kHoBits = 32 - 8 - 2;  // PRECISION_BITS of Resample.c
+
+struct Ho3dTables {                  // per sample and table: bounds[out][2] = (first source index, taps), kk[out][kHoTaps]
+  int* bounds;
+  int* kk;
+};
+
+__device__ __forceinline__ double ho_filter(int bicubic, double x) {
+  x = x < 0.0 ? -x : x;
+  if (!bicubic) return x < 1.0 ? 1.0 - x : 0.0;
+  const double a = -0.5;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+
+__global__ __launch_bounds__(256) void ho3d_coeff_kernel(const int* __restrict__ boxes, int out_size, Ho3dTables tb) {
+  const int b = blockIdx.y, t = blockIdx.x;                  // table t: filter t >> 1, axis t & 1
+  const int xx = threadIdx.x;
+  if (xx >= out_size) return;
+  const int* box = boxes + b * 4;                            // x0, y0, x1, y1 of the rounded crop box
+  const int in_size = (t & 1) ? box[3] - box[1] : box[2] - box[0];
+  const int bicubic = t >> 1;
+  int* bo = tb.bounds + ((size_t)(b * 4 + t) * out_size + xx) * 2;
+  int* ko = tb.kk + ((size_t)(b * 4 + t) * out_size + xx) * kHoTaps;
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = (bicubic ? 2.0 : 1.0) * filterscale;
+  const double ss = 1.0 / filterscale;
+  const double center = 0.0 + (xx + 0.5) * scale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  if (xmax > kHoTaps) xmax = kHoTaps;                        // (cannot happen for windows <= 640 pixels; keeps the table in bounds)
+  if (xmax < 0) xmax = 0;
+  double k[kHoTaps];
+  double ww = 0.0;
+  for (int x = 0; x < kHoTaps; ++x) {
+    double w = 0.0;
+    if (x < xmax) { w = ho_filter(bicubic, (x + xmin - center + 0.5) * ss); ww += w; }
+    k[x] = w;
+  }
+  for (int x = 0; x < kHoTaps; ++x) {
+    double v = k[x];
+    if (x < xmax && ww != 0.0) v /= ww;
+    ko[x] = v < 0 ? (int)(-0.5 + v * (double)(1 << kHoBits)) : (int)(0.5 + v * (double)(1 << kHoBits));
+  }
+  bo[0] = xmin; bo[1] = xmax;
+}
+
+__device__ __forceinline__ int ho_clip8(int v) {
+  v >>= kHoBits;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// grid = (ceil(out^2 / 256), B, 2): z = 0 the frame (RGBX words, bilinear tables 0 / 1), z = 1 the hand mask (bytes, bicubic tables 2 / 3)
+__global__ __launch_bounds__(256) void ho3d_resample_kernel(const uint32_t* __restrict__ img, const uint8_t* __restrict__ mask,
+                                                           const int* __restrict__ idx, const int* __restrict__ boxes, int FH, int FW,
+                                                           int out_size, Ho3dTables tb, float* __restrict__ out_img,
+                                                           float* __restrict__ out_mask) {
+  const int b = blockIdx.y, which = blockIdx.z;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= out_size * out_size) return;
+  if ((which == 0 && out_img == nullptr) || (which == 1 && out_mask == nullptr)) return;
+  const int yy = p / out_size, xx = p - yy * out_size;
+  const int* box = boxes + b * 4;
+  const int bx0 = box[0], by0 = box[1];
+  const size_t tx = (size_t)(b * 4 + 2 * which) * out_size + xx, ty = (size_t)(b * 4 + 2 * which + 1) * out_size + yy;
+  const int x0 = tb.bounds[tx * 2], nx = tb.bounds[tx * 2 + 1], y0 = tb.bounds[ty * 2], ny = tb.bounds[ty * 2 + 1];
+  const int* kx = tb.kk + tx * kHoTaps;
+  const int* ky = tb.kk + ty * kHoTaps;
+  const size_t frame = (size_t)idx[b] * FH * FW;
+  const int half = 1 << (kHoBits - 1);
+  int v0 = half, v1 = half, v2 = half;
+  for (int j = 0; j < ny; ++j) {
+    const int fy = by0 + y0 + j;                             // frame row of cropped row y0 + j
+    const bool rok = fy >= 0 && fy < FH;
+    int h0 = half, h1 = half, h2 = half;
+    for (int i = 0; i < nx; ++i) {
+      const int fx = bx0 + x0 + i;
+      const bool ok = rok && fx >= 0 && fx < FW;             // Image.crop fills what lies outside the frame with zeros
+      const int w = kx[i];
+      if (which == 0) {
+        const uint32_t px = ok ? img[frame + (size_t)fy * FW + fx] : 0u;
+        h0 += (int)(px & 0xffu) * w; h1 += (int)((px >> 8) & 0xffu) * w; h2 += (int)((px >> 16) & 0xffu) * w;
+      } else {
+        h0 += (int)(ok ? mask[frame + (size_t)fy * FW + fx] : (uint8_t)0) * w;
+      }
+    }
+    const int w = ky[j];
+    v0 += ho_clip8(h0) * w;
+    if (which == 0) { v1 += ho_clip8(h1) * w; v2 += ho_clip8(h2) * w; }
+  }
+  const size_t plane = (size_t)out_size * out_size;
+  if (which == 0) {
+    float* o = out_img + (size_t)b * 3 * plane + p;
+    o[0] = (float)ho_clip8(v0) / 255.0f; o[plane] = (float)ho_clip8(v1) / 255.0f; o[2 * plane] = (float)ho_clip8(v2) / 255.0f;
+  } else {
+    out_mask[(size_t)b * plane + p] = ho_clip8(v0) >= 128 ? 1.0f : 0.0f;                 // to_tensor().round()
+  }
+}
+
+struct Ho3dMeta {
+  const float *Ks, *uv21, *xyz21;                // cache: [n][3][3], [n][21][2], [n][21][3]
+  const int* idx;
+  const float* win;                              // [B][3]: crop centre (u, v), scale
+  float *oK, *ouv, *oxyz;
+  float half_res;                                // inp_res // 2
+};
+__global__ __launch_bounds__(64) void ho3d_meta_kernel(Ho3dMeta m) {
+  const int b = blockIdx.x, t = threadIdx.x, id = m.idx[b];
+  const float cu = m.win[b * 3], cv = m.win[b * 3 + 1], s = m.win[b * 3 + 2];
+  if (t < 21) {
+    if (m.ouv) {
+      m.ouv[(b * 21 + t) * 2] = (m.uv21[((size_t)id * 21 + t) * 2] - cu) * s + m.half_res;
+      m.ouv[(b * 21 + t) * 2 + 1] = (m.uv21[((size_t)id * 21 + t) * 2 + 1] - cv) * s + m.half_res;
+    }
+    if (m.oxyz)
+      for (int c = 0; c < 3; ++c) m.oxyz[(b * 21 + t) * 3 + c] = m.xyz21[((size_t)id * 21 + t) * 3 + c];
+  }
+  if (t < 9 && m.oK) {
+    // K_crop = T . (S . K): S = diag(s, s, 1), T = [1 0 -t1; 0 1 -t2; 0 0 1], t = centre * s - inp_res // 2
+    const int i = t / 3, j = t - 3 * i;
+    const float* K = m.Ks + (size_t)id * 9;
+    const float sk = (i < 2 ? s : 1.0f) * K[i * 3 + j];
+    const float tr = i == 0 ? -(cu * s - m.half_res) : i == 1 ? -(cv * s - m.half_res) : 0.0f;
+    m.oK[b * 9 + t] = i < 2 ? sk + tr * (1.0f * K[6 + j]) : sk;
+  }
+}
+
+hipError_t launch_ho3d_batch(const uint32_t* img, const uint8_t* mask, const float* Ks, const float* uv21, const float* xyz21, int FH, int FW,
+                             const int* packed, int B, int out_size, void* ws, float* out_img, float* out_mask, float* out_K,
+                             float* out_uv, float* out_xyz, hipStream_t st) {
+  if (B <= 0 || FH <= 0 || FW <= 0 || out_size <= 0 || out_size > 256 || ws == nullptr) return hipErrorInvalidValue;
+  // packed: idx[B], boxes[B][4], window[B][3] (float bits)
+  const int* idx = packed;
+  const int* boxes = packed + B;
+  const float* win = reinterpret_cast<const float*>(packed + 5 * B);
+  Ho3dTables tb;
+  tb.bounds = static_cast<int*>(ws);
+  tb.kk = tb.bounds + (size_t)B * 4 * out_size * 2;
+  hipLaunchKernelGGL(ho3d_coeff_kernel, dim3(4, B), dim3(256), 0, st, boxes, out_size, tb);
+  hipLaunchKernelGGL(ho3d_resample_kernel, dim3((out_size * out_size + 255) / 256, B, 2), dim3(256), 0, st, img, mask, idx, boxes, FH, FW,
+                     out_size, tb, out_img, out_mask);
+  const Ho3dMeta m{Ks, uv21, xyz21, idx, win, out_K, out_uv, out_xyz, (float)(out_size / 2)};
+  hipLaunchKernelGGL(ho3d_meta_kernel, dim3(B), dim3(64), 0, st, m);
+  return hipGetLastError();
+}
+
+size_t ho3d_workspace_bytes(int B, int out_size) { return (size_t)B * 4 * out_size * (2 + kHoTaps) * sizeof(int); }
+
 hipError_t launch_freihand_augment(const uint32_t* img, const uint8_t* mask, const int* idx, const int* coef, int B, int H, int W,
                                    float* out_img, float* out_mask, hipStream_t st) {
   if (B <= 0 || H <= 0 || W <= 0 || (long)H * W >= (1L << 24)) return hipErrorInvalidValue;

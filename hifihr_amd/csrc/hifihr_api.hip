@@ -1059,6 +1059,21 @@ int hifihr_procrustes_error(const float* pred, const float* gt, int B, int N, fl
   return HIFIHR_OK;
 }
 
+size_t hifihr_ho3d_workspace_bytes(int B, int out_size) {
+  return (B > 0 && out_size > 0 && out_size <= 256) ? hifihr::ho3d_workspace_bytes(B, out_size) : 0;
+}
+
+int hifihr_ho3d_batch(const uint32_t* img_rgbx, const uint8_t* hand_mask, const float* Ks, const float* uv21, const float* xyz21, int FH,
+                      int FW, const int* packed, int B, int out_size, void* ws, size_t ws_bytes, float* out_img, float* out_mask,
+                      float* out_K, float* out_uv21, float* out_xyz21, void* stream) {
+  if (!packed || !ws || B <= 0 || FH <= 0 || FW <= 0 || out_size <= 0 || out_size > 256 || ws_bytes < hifihr::ho3d_workspace_bytes(B, out_size) ||
+      (out_img && !img_rgbx) || (out_mask && !hand_mask) || (out_K && !Ks) || (out_uv21 && !uv21) || (out_xyz21 && !xyz21))
+    return fail(HIFIHR_EINVAL, "hifihr_ho3d_batch: bad argument (out_size <= 256, workspace of hifihr_ho3d_workspace_bytes)");
+  HIP_TRY(hifihr::launch_ho3d_batch(img_rgbx, hand_mask, Ks, uv21, xyz21, FH, FW, packed, B, out_size, ws, out_img, out_mask, out_K, out_uv21,
+                                    out_xyz21, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_output_transform_act(const float* M, float* y, const float* bias, int act, int N, int H, int W, int K, void* stream) {
   if (!M || !y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0 || act < 0 || act > 1)
     return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform_act: bad argument");

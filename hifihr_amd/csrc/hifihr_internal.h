@@ -224,6 +224,10 @@ hipError_t launch_freihand_batch(const uint32_t* img, const uint8_t* mask, const
                                  const float* scales, int J, int V, const int* packed, int B, int H, int W, float* out_img, float* out_mask,
                                  long long* out_segm, float* oKs, float* oPs, float* ojoints, float* overts, float* oj2d, float* oscales,
                                  long long* oidx, hipStream_t st);
+size_t ho3d_workspace_bytes(int B, int out_size);
+hipError_t launch_ho3d_batch(const uint32_t* img, const uint8_t* mask, const float* Ks, const float* uv21, const float* xyz21, int FH, int FW,
+                             const int* packed, int B, int out_size, void* ws, float* out_img, float* out_mask, float* out_K,
+                             float* out_uv, float* out_xyz, hipStream_t st);
 hipError_t launch_procrustes(const float* pred, const float* gt, int B, int N, float* aligned, float* err_sum, hipStream_t st);
 hipError_t launch_wino_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
                                         hipStream_t st);

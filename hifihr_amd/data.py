@@ -195,3 +195,90 @@ class FreiHandDeviceCache:
             "trans_joints": rot(self.joints[idx_l]), "trans_verts": rot(self.verts[idx_l]),
             "scales": self.scales[idx_l], "idxs": idx_l,
         }
+
+
+# ------------------------------------------------------------------------------------------------
+# HO-3D (reference data/dataset.py:1023-1215): hand crop + resize on the device
+# ------------------------------------------------------------------------------------------------
+def ho3d_crop_windows(uv21, center_noise, scale_noise, inp_res=224, img_wh=(640.0, 480.0)):
+    """The crop window of every sample of a batch, the reference's float32 arithmetic (dataset.py:1106-1161, `ho_scope = 0`), stacked.
+    uv21 [B,21,2] projected joints (u, v); center_noise [B,2] = 5 * randn(2) per sample (:1120); scale_noise [B] =
+    (1 - 1.1) * rand(1) + 1 - 0.1 (:1126).  `int / tensor` is tensor.reciprocal() * int in torch, hence the two-step divisions.
+    -> crop_center [B,2], scale [B], size [B] (= crop_size_scales), box int32 [B,4] = the (x0, y0, x1, y1) Pillow's Image.crop makes of
+    (x1, y1, x1 + size, y1 + size): Python round(), half to even."""
+    f = np.float32
+    uv = np.asarray(uv21, dtype=f)
+    lo, hi = uv.min(1), uv.max(1)
+    center = (hi + lo) / f(2)
+    center = np.asarray(center_noise, dtype=f) + center
+    min_uv = np.maximum(lo, f(0)) - f(10.0)
+    max_uv = np.minimum(hi, np.asarray(img_wh, dtype=f)[None]) + f(10.0)
+    best = (f(4) * np.maximum(max_uv - center, center - min_uv)).max(1)
+    best = np.minimum(np.maximum(best, f(50.0)), f(640.0))
+    scale = f(inp_res) * (f(1) / best)
+    scale = np.minimum(scale, f(10.0))
+    scale = (scale * np.asarray(scale_noise, dtype=f)).astype(f)
+    size = (f(inp_res) * (f(1) / scale)).astype(f)
+    half = np.floor(size / f(2))
+    y1 = (center[:, 1] - half).astype(f)
+    x1 = (center[:, 0] - half).astype(f)
+    # Image.crop((left, top, left + width, top + height)) on Python floats (the reference passes .item() values)
+    x1d, y1d, sd = x1.astype(np.float64), y1.astype(np.float64), size.astype(np.float64)
+    box = np.stack([np.rint(x1d), np.rint(y1d), np.rint(x1d + sd), np.rint(y1d + sd)], 1).astype(np.int32)      # rint: half to even
+    return center.astype(f), scale, size, box
+
+
+class HO3DDeviceCache:
+    """The decoded HO-3D training frames resident in device memory + the per-batch hand crop on the device (reference
+    data/dataset.py:1023-1215).  images_u8 [n,480,640,3], hand_masks_u8 [n,480,640] (channel 0 of the reference's mask image, 0 / 255),
+    Ks [n,3,3] (camMat . cam_extr as the dataset forms it), xyz21 [n,21,3].  `batch(idxs)` returns the sample dict the HO3D branch of
+    `traineval.data_dic` reads -- img_crop, hand_mask_crop, K_crop, uv21_crop, xyz21 -- with every tensor on the device: one staged
+    copy of 32 bytes per sample and three launches (hifihr_ho3d_batch); pixels bit-exact with the reference's PIL path."""
+
+    def __init__(self, images_u8, hand_masks_u8, Ks, xyz21, device="cuda", inp_res=224):
+        images_u8 = torch.as_tensor(images_u8)
+        n, H, W, _ = images_u8.shape
+        rgbx = torch.zeros(n, H, W, 4, dtype=torch.uint8)
+        rgbx[..., :3] = images_u8
+        self.images = rgbx.to(device).view(torch.int32).reshape(n, H, W)
+        self.masks = torch.as_tensor(hand_masks_u8).contiguous().to(device)
+        require_cuda(self.images, self.masks)
+        Ks = torch.as_tensor(Ks, dtype=torch.float32)
+        xyz21 = torch.as_tensor(xyz21, dtype=torch.float32)
+        uvw = (xyz21.unsqueeze(2) * Ks.unsqueeze(1)).sum(3)                    # proj_func (fh_utils.py:30-39), dataset.py:1093
+        self.uv21_host = (uvw[:, :, :2] / uvw[:, :, 2:3]).numpy()
+        self.Ks, self.xyz21, self.uv21 = Ks.to(device), xyz21.to(device), torch.from_numpy(self.uv21_host).to(device)
+        self.n, self.H, self.W, self.device, self.inp_res = n, H, W, torch.device(device), inp_res
+        self.lib = get_lib()
+        self._ws = None
+
+    _RING = 8
+    _stage = FreiHandDeviceCache._stage
+
+    def batch(self, idxs, center_noise=None, scale_noise=None, generator=None):
+        idxs = torch.as_tensor(idxs, dtype=torch.int64)
+        B = idxs.shape[0]
+        if center_noise is None:               # dataset.py:1120 and :1126, per sample in that order
+            draws = [(5 * torch.randn(2, generator=generator), (1 - 1.1) * torch.rand(1, generator=generator) + 1 - 0.1) for _ in range(B)]
+            center_noise = torch.stack([d[0] for d in draws]).numpy()
+            scale_noise = torch.cat([d[1] for d in draws]).numpy()
+        center, scale, _, box = ho3d_crop_windows(self.uv21_host[idxs.numpy()], center_noise, scale_noise, self.inp_res, (float(self.W), float(self.H)))
+        slot, host = self._stage(8 * B)
+        hv = host.numpy()
+        hv[:B] = idxs.numpy().astype(np.int32)
+        hv[B:5 * B] = box.reshape(-1)
+        hv[5 * B:8 * B] = np.concatenate([center, scale[:, None]], 1).astype(np.float32).reshape(-1).view(np.int32)
+        packed = torch.empty(8 * B, dtype=torch.int32, device=self.device)
+        packed.copy_(host, non_blocking=True)
+        ev = self._events[slot] or torch.cuda.Event()
+        ev.record()
+        self._events[slot] = ev
+        nws = self.lib.ho3d_workspace_bytes(B, self.inp_res)
+        if self._ws is None or self._ws.numel() * 4 < nws:
+            self._ws = torch.empty(nws // 4 + 1, dtype=torch.int32, device=self.device)
+        S, dev = self.inp_res, self.device
+        out = {"img_crop": torch.empty(B, 3, S, S, device=dev), "hand_mask_crop": torch.empty(B, 1, S, S, device=dev),
+               "K_crop": torch.empty(B, 3, 3, device=dev), "uv21_crop": torch.empty(B, 21, 2, device=dev),
+               "xyz21": torch.empty(B, 21, 3, device=dev)}
+        self.lib.ho3d_batch(self.images, self.masks, self.Ks, self.uv21, self.xyz21, packed, B, S, self._ws, out)
+        return out

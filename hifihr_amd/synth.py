@@ -84,3 +84,32 @@ def to_ho3d_sample(sample: dict, crop: int = 448) -> dict:
         "hand_mask_crop": sample["trans_masks"],
         "idxs": sample["idxs"],
     }
+
+
+def make_ho3d_frames(mano_handle, renderer, n: int, first_index: int = 0, device="cuda", frame_hw=(480, 640)):
+    """Synthetic HO-3D-shaped raw frames for `data.HO3DDeviceCache`: the 224 x 224 synthetic hand of `make_batch` pasted into a 480 x 640
+    frame at a per-sample offset (grey background), the intrinsics moved with it, everything in the HO-3D loader's conventions
+    (reference data/dataset.py:1065-1068, 1093: `Ks = camMat . cam_extr` with the OpenGL flip, joints in the HO-3D order with y / z negated --
+    what utils/traineval_util.py:156-201 undoes).  -> images_u8 [n,480,640,3], hand_masks_u8 [n,480,640], Ks [n,3,3], xyz21 [n,21,3] (host)."""
+    from .traineval import Frei2HO3D
+    FH, FW = frame_hw
+    imgs = torch.full((n, FH, FW, 3), 96, dtype=torch.uint8)
+    masks = torch.zeros(n, FH, FW, dtype=torch.uint8)
+    Ks, xyz = torch.zeros(n, 3, 3), torch.zeros(n, 21, 3)
+    flip = torch.tensor([1.0, -1.0, -1.0])
+    step = 32
+    for lo in range(0, n, step):
+        m = min(step, n - lo)
+        b = make_batch(mano_handle, renderer, m, first_index=first_index + lo, device=device)
+        im = (b["trans_images"].clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).cpu()
+        mk = (b["trans_masks"][:, 0] > 0.5).to(torch.uint8).mul(255).cpu()
+        K, J = b["trans_Ks"].cpu(), b["trans_joints"].cpu()
+        for i in range(m):
+            g = torch.Generator().manual_seed(4321 + first_index + lo + i)
+            oy = int(torch.randint(0, FH - 224 + 1, (1,), generator=g)); ox = int(torch.randint(0, FW - 224 + 1, (1,), generator=g))
+            imgs[lo + i, oy:oy + 224, ox:ox + 224] = im[i]
+            masks[lo + i, oy:oy + 224, ox:ox + 224] = mk[i]
+            Kf = K[i].clone(); Kf[0, 2] += ox; Kf[1, 2] += oy
+            Ks[lo + i] = Kf * flip.view(1, 3)
+            xyz[lo + i] = Frei2HO3D((J[i] * flip.view(1, 3)).unsqueeze(0))[0]
+    return {"images_u8": imgs, "hand_masks_u8": masks, "Ks": Ks, "xyz21": xyz}

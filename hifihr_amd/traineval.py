@@ -73,6 +73,8 @@ def data_dic(sample, dat_name, set_name, args, device="cuda", image_size=224):
             ex["j2d_gt"] = HO3D2Frei(to(sample["uv21_crop"].float()))
         joints = HO3D2Frei(to(sample["xyz21"])) * flip.view(1, 1, 3) if "xyz21" in sample else None
         verts, masks = None, sample.get("hand_mask_crop")
+        if masks is not None and masks.shape[-1] != image_size:             # the loader's 224 crop at a build-side render resolution
+            masks = F.interpolate(to(masks), (image_size, image_size))
     elif dat_name == "RHD":
         # utils/traineval_util.py:204-256: cropped image and intrinsics as loaded, 2-D / 3-D joints re-ordered RHD -> FreiHAND,
         # keypoint_scale doubles as `scales`, visibility flags re-ordered; no vertices, no masks (the mask lines are commented out there)

@@ -579,6 +579,25 @@ int hifihr_freihand_batch(const uint32_t* img_rgbx_d, const uint8_t* mask_d, con
                           float* out_mask_d, long long* out_segm_d, float* out_Ks_d, float* out_Ps_d, float* out_joints_d,
                           float* out_verts_d, float* out_j2d_d, float* out_scales_d, long long* out_idxs_d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * HO-3D training sample assembly (the HO-3D half): the hand crop of reference data/dataset.py:1105-1215.
+ * Frames live in device memory as for FreiHAND (img_rgbx_d[n][FH][FW] uint32 R,G,B,X; hand_mask_d[n][FH][FW] uint8 = channel 0 of the
+ * reference's mask image); the host computes each sample's crop window from its projected joints (hifihr_amd/data.py:ho3d_crop_windows,
+ * the reference's float32 arithmetic) and ships ONE packed int32 buffer per batch:
+ *   packed_d[8 B]: idx[B], box[B][4] = the crop box (x0, y0, x1, y1) rounded as Pillow's Image.crop rounds it (half to even),
+ *                  window[B][3] = crop centre u, v and scale (float bits)
+ * Three launches: the resampling tables of Pillow's Image.resize (libImaging/Resample.c, evaluated in double on the device), the
+ * crop + resize of frame (bilinear) and hand mask (bicubic) = torchvision's resized_crop on PIL images, and the small tensors:
+ *   out_img_d[B][3][S][S] = u8 / 255 (`img_crop`), out_mask_d[B][1][S][S] = round(u8 / 255) (`hand_mask_crop`), S = out_size (224),
+ *   out_K_d[B][3][3] = T . S . K (`K_crop`, :1206-1210), out_uv21_d[B][21][2] = (uv21 - centre) * scale + S / 2 (`uv21_crop`, :1186-1188),
+ *   out_xyz21_d[B][21][3] = xyz21[idx].  Any output may be NULL.  Pixels bit-exact with Pillow (tests/golden/ho3d_path.npz).
+ * ws_d: hifihr_ho3d_workspace_bytes(B, out_size) bytes of scratch (any contents).
+ * ---------------------------------------------------------------------------------------------- */
+size_t hifihr_ho3d_workspace_bytes(int B, int out_size);
+int hifihr_ho3d_batch(const uint32_t* img_rgbx_d, const uint8_t* hand_mask_d, const float* Ks_d, const float* uv21_d, const float* xyz21_d,
+                      int FH, int FW, const int* packed_d, int B, int out_size, void* ws_d, size_t ws_bytes, float* out_img_d,
+                      float* out_mask_d, float* out_K_d, float* out_uv21_d, float* out_xyz21_d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

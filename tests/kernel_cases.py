@@ -1022,6 +1022,48 @@ def freihand_batch_case(lib, device, seed=0, B=5, n=7, res=32, J=21, V=50):
     assert torch.equal(out["scales"].cpu(), torch.from_numpy(scales)[il]) and torch.equal(out["idxs"].cpu(), il)
 
 
+def ho3d_batch_case(lib, device, golden_dir):
+    """hifihr_ho3d_batch vs tests/golden/ho3d_path.npz: Pillow's own crop + resize outputs (bit for bit) and the reference's uv21_crop /
+    K_crop lines; windows from hifihr_amd.data.ho3d_crop_windows, itself checked against the reference's window lines here."""
+    import os
+    from hifihr_amd.data import ho3d_crop_windows
+    g = np.load(os.path.join(golden_dir, "ho3d_path.npz"))
+    ids = [i for i in range(int(g["n"])) if f"img_crop{i}" in g.files]
+    allids = list(range(int(g["n"])))
+    center, scale, size, box = ho3d_crop_windows(np.stack([g[f"uv21_{i}"] for i in allids]), np.stack([g[f"noise{i}"] for i in allids]),
+                                                 np.concatenate([g[f"scale_noise{i}"] for i in allids]))
+    for k, i in enumerate(allids):
+        assert np.array_equal(center[k], g[f"crop_center{i}"]) and scale[k] == g[f"scale{i}"][0] and size[k] == g[f"size{i}"][0], i
+        x1, y1, sz = float(g[f"x1_{i}"].reshape(-1)[0]), float(g[f"y1_{i}"].reshape(-1)[0]), float(g[f"size{i}"].reshape(-1)[0])
+        assert tuple(box[k]) == tuple(int(round(v)) for v in (x1, y1, x1 + sz, y1 + sz)), i
+    FH, FW = g[f"img{ids[0]}"].shape[:2]
+    frames = np.zeros((len(ids) + 1, FH, FW, 4), np.uint8); masks = np.zeros((len(ids) + 1, FH, FW), np.uint8)
+    for k, i in enumerate(ids):
+        frames[k + 1, :, :, :3] = g[f"img{i}"]; masks[k + 1] = g[f"mask{i}"]
+    frames[0] = 200; masks[0] = 255
+    order = [2, 0, 3, 1]                                      # batch order != cache order: the gather index is exercised
+    sel = [ids[k] for k in order]
+    B, S = len(order), 224
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    packed = np.concatenate([np.asarray([k + 1 for k in order], np.int32), np.stack([box[i] for i in sel]).reshape(-1),
+                             np.concatenate([np.stack([center[i] for i in sel]), np.asarray([scale[i] for i in sel])[:, None]], 1)
+                             .astype(np.float32).reshape(-1).view(np.int32)])
+    Ks = np.stack([np.eye(3, dtype=np.float32)] + [g[f"K{i}"] for i in ids]); uv = np.stack([np.zeros((21, 2), np.float32)] + [g[f"uv21_{i}"] for i in ids])
+    xyz = np.random.default_rng(0).normal(size=(len(ids) + 1, 21, 3)).astype(np.float32)
+    ws = torch.empty(lib.ho3d_workspace_bytes(B, S) // 4 + 1, dtype=torch.int32, device=device)
+    f = lambda *shape: torch.full(shape, 7.0, device=device)
+    out = {"img_crop": f(B, 3, S, S), "hand_mask_crop": f(B, 1, S, S), "K_crop": f(B, 3, 3), "uv21_crop": f(B, 21, 2), "xyz21": f(B, 21, 3)}
+    lib.ho3d_batch(d(frames).view(torch.int32).reshape(len(ids) + 1, FH, FW), d(masks), d(Ks), d(uv), d(xyz), d(packed), B, S, ws, out)
+    for b, i in enumerate(sel):
+        want = torch.from_numpy(g[f"img_crop{i}"]).permute(2, 0, 1).float().div(255)
+        assert torch.equal(out["img_crop"][b].cpu(), want), f"frame crop {i}"
+        wm = torch.round(torch.from_numpy(g[f"mask_crop{i}"]).float().div(255))
+        assert torch.equal(out["hand_mask_crop"][b, 0].cpu(), wm), f"mask crop {i}"
+        assert torch.equal(out["uv21_crop"][b].cpu(), torch.from_numpy(g[f"uv21_crop{i}"])), f"uv21_crop {i}"
+        np.testing.assert_allclose(out["K_crop"][b].cpu().numpy(), g[f"K_crop{i}"], rtol=1e-6, atol=1e-4)
+        assert torch.equal(out["xyz21"][b].cpu(), torch.from_numpy(xyz[order[b] + 1]))
+
+
 # ------------------------------------------------------------------------------------------------
 # one-launch weight re-layout (hifihr_weight_prep) == the separate transpose / Winograd weight transforms, bit for bit
 # ------------------------------------------------------------------------------------------------

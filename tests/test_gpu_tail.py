@@ -164,6 +164,50 @@ def test_device_cache_batch_examples_matches_data_dic(golden_dir):
         cache.batch_examples(order[:2], rots=rots[:2], out=static)
 
 
+def test_ho3d_crop_resize_vs_pillow(lib, golden_dir):
+    kc.ho3d_batch_case(lib, "cuda", golden_dir)
+
+
+def test_ho3d_device_cache_matches_oracle_sample():
+    """hifihr_amd.data.HO3DDeviceCache.batch on full-size 480 x 640 frames == oracle/ho3d_oracle.ho3d_sample (the restatement pinned to
+    the reference's window lines and to Pillow): pixels and masks bit for bit, uv21_crop exact, K_crop to fp32 rounding; and it feeds the
+    HO3D branch of data_dic."""
+    from hifihr_amd import options
+    from hifihr_amd.data import HO3DDeviceCache
+    from hifihr_amd.traineval import data_dic
+    from oracle import ho3d_oracle as ho
+    rng = np.random.default_rng(3)
+    n = 3
+    imgs = rng.integers(0, 256, (n, 480, 640, 3), dtype=np.uint8)
+    masks = np.zeros((n, 480, 640), np.uint8)
+    Ks = np.tile(np.array([[614.6, 0, -320.1], [0, -614.2, -239.5], [0, 0, -1]], np.float32), (n, 1, 1))       # camMat . diag(1, -1, -1)
+    xyz = np.zeros((n, 21, 3), np.float32)
+    for i, (cx, cy, spread) in enumerate(((200.0, 150.0, 0.02), (520.0, 400.0, 0.05), (320.0, 240.0, 0.12))):
+        z = -0.6 - 0.1 * rng.random(21)
+        xyz[i, :, 2] = z
+        xyz[i, :, 0] = ((cx - 320.1) / 614.6 + spread * rng.normal(size=21)) * -z
+        xyz[i, :, 1] = -((cy - 239.5) / 614.2 + spread * rng.normal(size=21)) * -z
+        yy, xx = np.mgrid[:480, :640]
+        masks[i][(yy - cy) ** 2 + (xx - cx) ** 2 < (40 + 30 * i) ** 2] = 255
+    cache = HO3DDeviceCache(imgs, masks, Ks, xyz)
+    order = [2, 0, 1, 1]
+    noise = rng.normal(size=(4, 2)).astype(np.float32) * 5
+    snoise = (0.9 - 0.1 * rng.random(4)).astype(np.float32)
+    s = cache.batch(order, center_noise=noise, scale_noise=snoise)
+    for b, i in enumerate(order):
+        want = ho.ho3d_sample(imgs[i], masks[i], cache.uv21_host[i], Ks[i], noise[b], snoise[b])
+        assert torch.equal(s["img_crop"][b].cpu(), torch.from_numpy(want["img_crop"])), b
+        assert torch.equal(s["hand_mask_crop"][b].cpu(), torch.from_numpy(want["hand_mask_crop"])), b
+        assert torch.equal(s["uv21_crop"][b].cpu(), torch.from_numpy(want["uv21_crop"])), b
+        np.testing.assert_allclose(s["K_crop"][b].cpu().numpy(), want["K_crop"], rtol=1e-6, atol=1e-3)
+        assert torch.equal(s["xyz21"][b].cpu(), torch.from_numpy(xyz[i]))
+    assert 0.02 < float(s["hand_mask_crop"].mean()) < 0.9                       # the windows do contain the hand
+    ex = data_dic(s, "HO3D", "training", options.make_args(), device="cuda")
+    assert ex["imgs"].shape == (4, 3, 224, 224) and ex["segms_gt"].dtype == torch.int64 and ex["j2d_gt"].shape == (4, 21, 2)
+    r = cache.batch(order, generator=torch.Generator().manual_seed(1))          # the loader's own noise draws
+    assert r["img_crop"].shape == (4, 3, 224, 224) and torch.isfinite(r["K_crop"]).all()
+
+
 def test_evaluator_summary_matches_formulas(golden_dir):
     """hifihr_amd.evaluate.Evaluator vs the formulas of train_hrnet.py:149-161, 227-243 written out with torch."""
     import os

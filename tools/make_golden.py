@@ -341,6 +341,63 @@ def gen_data_path():
     print("data path ok")
 
 
+def gen_ho3d_path():
+    """tests/golden/ho3d_path.npz: the HO-3D sample assembly (data/dataset.py:1105-1215).
+    (1) the crop window, the cropped 2-D joints and K_crop: the reference's own lines (:1106-1162, :1186-1188, :1206-1210) executed from
+        source on seeded joints / intrinsics, with the torch RNG seeded so that its two noise draws can be regenerated;
+    (2) the image / mask crops: Pillow itself, `Image.crop(box).resize((224, 224), filter)` = the PIL backend of torchvision's
+        `resized_crop` (absent from this image; [recalled]) for the windows of (1) on seeded uint8 frames -- bilinear for the image
+        (:1164, the default), bicubic for the hand mask (:1175)."""
+    import textwrap
+    from PIL import Image
+    lines = open(os.path.join(REF, "data", "dataset.py")).read().split("\n")
+    win_src = textwrap.dedent("\n".join(lines[1105:1162]))
+    uv_src = textwrap.dedent("\n".join(lines[1185:1188]))
+    k_src = textwrap.dedent("\n".join(lines[1205:1210]))
+    assert "ho_scope = 0" in win_src and "sample['x2']=x2" in win_src and "uv21_crop = torch.stack" in uv_src and "K_crop = torch.mm" in k_src
+    rng = np.random.RandomState(5)
+    out = {}
+    H, W = 120, 160                                             # frames at a quarter of the HO-3D size keep the fixture small; the window code clamps at 640 x 480 as written
+    n = 6
+    for i in range(n):
+        cy, cx, r = rng.randint(40, 80), rng.randint(50, 110), rng.randint(10, 30)
+        yy, xx = np.mgrid[:H, :W]
+        # low-frequency content (keeps the fixture small) with a block of full-range noise around the hand (the resampler's rounding)
+        img = np.stack([127.5 + 127.5 * np.sin(xx / (9.0 + c) + i) * np.cos(yy / (7.0 + 2 * c)) for c in range(3)], 2).astype(np.uint8)
+        img[cy - 16:cy + 16, cx - 16:cx + 16] = rng.randint(0, 256, size=img[cy - 16:cy + 16, cx - 16:cx + 16].shape).astype(np.uint8)
+        mask = np.zeros((H, W), np.uint8)
+        mask[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = 255
+        spread = [6.0, 15.0, 30.0, 50.0, 2.5, 22.0][i]
+        uv21 = torch.tensor(np.stack([cx + rng.randn(21) * spread, cy + rng.randn(21) * spread], 1).astype(np.float32))
+        Ks = torch.tensor([[614.6 + i, 0, 320.1], [0, 614.2, 239.5 - i], [0, 0, 1]], dtype=torch.float32)
+
+        class _Self:
+            inp_res1 = 224
+        torch.manual_seed(100 + i)
+        ns = {"torch": torch, "uv21": uv21, "uv6": None, "self": _Self(), "sample": {}, "Ks": Ks}
+        exec(win_src, ns)
+        exec(uv_src, ns)
+        exec(k_src, ns)
+        torch.manual_seed(100 + i)                             # the same two draws, in the code's order (:1120, :1126)
+        noise = 5 * torch.randn([2])
+        scale_noise = (1 - 1.1) * torch.rand(1) + 1 - 0.1
+        y1, x1, size = ns["y1"].item(), ns["x1"].item(), ns["crop_size_scales"].item()
+        box = (x1, y1, x1 + size, y1 + size)
+        img_crop = np.asarray(Image.fromarray(img).crop(box).resize((224, 224), Image.BILINEAR))
+        mask_crop = np.asarray(Image.fromarray(mask).crop(box).resize((224, 224), Image.BICUBIC))
+        out.update({f"img{i}": img, f"mask{i}": mask, f"uv21_{i}": uv21.numpy(), f"K{i}": Ks.numpy(), f"noise{i}": noise.numpy(),
+                    f"scale_noise{i}": scale_noise.numpy(), f"crop_center{i}": ns["crop_center"].numpy(), f"scale{i}": ns["scale"].numpy(),
+                    f"size{i}": ns["crop_size_scales"].numpy(), f"x1_{i}": ns["x1"].numpy(), f"y1_{i}": ns["y1"].numpy(),
+                    f"uv21_crop{i}": ns["uv21_crop"].numpy(), f"K_crop{i}": ns["K_crop"].numpy()})
+        if i in (0, 1, 2, 5):                                  # pixel crops for an up-scaling, two near-1:1 and a down-scaling window
+            out.update({f"img_crop{i}": img_crop, f"mask_crop{i}": mask_crop})
+        else:
+            out.pop(f"img{i}"); out.pop(f"mask{i}")
+    out["n"] = np.int64(n)
+    np.savez_compressed(os.path.join(OUT, "ho3d_path.npz"), **out)
+    print("ho3d path ok", [float(out[f"size{i}"]) for i in range(n)])
+
+
 def gen_eval():
     """utils/train_utils.py align_w_scale (scipy orthogonal_procrustes) + the MPJPE / MPVPE reduction of
     train_hrnet.py:227-243, and the HO-3D joint maps of utils/fh_utils.py:604-629."""
@@ -496,11 +553,11 @@ def gen_model_tail():
 
 if __name__ == "__main__":
     only = os.environ.get("GOLDEN_ONLY")
-    if only in ("names", "data", "eval", "loss_dict", "model_tail"):
+    if only in ("names", "data", "eval", "loss_dict", "model_tail", "ho3d"):
         os.makedirs(OUT, exist_ok=True)
         install_standins()
         {"names": gen_state_dict_names, "data": gen_data_path, "eval": gen_eval, "loss_dict": gen_loss_dict,
-         "model_tail": gen_model_tail}[only]()
+         "model_tail": gen_model_tail, "ho3d": gen_ho3d_path}[only]()
     elif os.environ.get("GOLDEN_ONLY") == "losses":
         os.makedirs(OUT, exist_ok=True)
         gen_losses()
