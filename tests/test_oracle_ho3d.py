@@ -44,3 +44,23 @@ def test_resample_coefficients_are_normalised():
         ksize, bounds, kk = ho.precompute_coeffs(in_size, 0.0, float(in_size), out_size, name)
         assert kk.shape == (out_size, ksize) and np.abs(kk.sum(1) - (1 << ho.PRECISION_BITS)).max() <= ksize
         assert (bounds[:, 0] >= 0).all() and (bounds[:, 0] + bounds[:, 1] <= in_size).all()
+
+
+def test_product_window_code_matches_oracle_and_reference(g):
+    """hifihr_amd.data.ho3d_crop_windows (the batched host code the device path uses) == the oracle's per-sample restatement == the
+    reference's lines, on the golden joints and on random ones (windows larger than the frame, joints outside it, the 10x scale clamp)."""
+    from hifihr_amd.data import ho3d_crop_windows
+    rng = np.random.default_rng(7)
+    uv = [g[f"uv21_{i}"] for i in range(int(g["n"]))]
+    noise = [g[f"noise{i}"] for i in range(int(g["n"]))]
+    sn = [float(g[f"scale_noise{i}"][0]) for i in range(int(g["n"]))]
+    for spread, cx, cy in ((3.0, 320, 240), (80.0, 20, 460), (400.0, 600, 30), (1.0, -50, 500), (150.0, 320, 240)):
+        uv.append(np.stack([cx + rng.normal(size=21) * spread, cy + rng.normal(size=21) * spread], 1).astype(np.float32))
+        noise.append((rng.normal(size=2) * 5).astype(np.float32)); sn.append(float(np.float32(0.9 - 0.1 * rng.random())))
+    center, scale, size, box = ho3d_crop_windows(np.stack(uv), np.stack(noise), np.asarray(sn, np.float32))
+    for k in range(len(uv)):
+        win = ho.crop_window(uv[k], noise[k], sn[k])
+        assert np.array_equal(center[k], win["crop_center"]) and scale[k] == win["scale"] and size[k] == win["crop_size_scales"]
+        assert tuple(box[k]) == ho.pil_crop_box(float(win["x1"]), float(win["y1"]), float(size[k]), float(size[k]))
+    for i in range(int(g["n"])):
+        assert scale[i] == g[f"scale{i}"][0] and size[i] == g[f"size{i}"][0]

@@ -8,6 +8,8 @@ package's device-resident pieces:
   data        hifihr_amd.data.FreiHandDeviceCache -- the decoded set lives in HBM, a batch is one gather-and-warp launch.
               Source: --freihand_cache <npz with images u8 [n,224,224,3], masks u8, Ks, joints, verts> (pre-decoded by the user;
               JPEG decoding is outside the hot path) or, by default, a seeded synthetic FreiHAND-shaped set (--synthetic_size).
+              --dataset HO3D: hifihr_amd.data.HO3DDeviceCache -- 480 x 640 frames in HBM, the reference's hand crop (window from the
+              projected joints, Pillow-exact crop + resize to 224) on the device; --ho3d_cache <npz> or seeded synthetic frames.
   step        hifihr_amd.traineval.GraphedTrainStep (hipGraph replay) or the eager step (--graph 0)
   multi-GPU   one process per GPU under torch.distributed.run; rank r takes every world-th batch slice; RCCL all-reduce of the
               flat gradient buffer (hifihr_amd/dist.py).  Replaces nn.DataParallel (:560).
@@ -32,6 +34,10 @@ def parse(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--config_json", default=None)
     ap.add_argument("--freihand_cache", default=None, help="npz: images, masks, Ks, joints, verts [, eval_* counterparts]")
+    ap.add_argument("--dataset", default="FreiHand", choices=["FreiHand", "HO3D"],
+                    help="HO3D: train on 480 x 640 frames through hifihr_amd.data.HO3DDeviceCache (the reference's hand crop on the device)")
+    ap.add_argument("--ho3d_cache", default=None, help="npz: images u8 [n,480,640,3], hand_masks u8 [n,480,640], Ks [n,3,3] (camMat . cam_extr), "
+                                                       "xyz21 [n,21,3]; default: seeded synthetic frames")
     ap.add_argument("--synthetic_size", type=int, default=512)
     ap.add_argument("--mano_pkl", default=None, help="MANO_RIGHT.pkl (licensed, user supplied); default: synthetic MANO-shaped tables")
     ap.add_argument("--nimble_layer", choices=["mano-stand-in", "synthetic"], default="mano-stand-in",
@@ -94,6 +100,82 @@ def load_or_make_dataset(cli, model, device):
     return {k: v[:cut] for k, v in full.items()}, {k: v[cut:] for k, v in full.items()}
 
 
+def train_ho3d(cli, args, model, loss_func, opt, sched, reducer, current_epoch, rank, world, device, say):
+    """The epoch driver on HO-3D frames (reference train_hrnet.py:449-485 with dat_name 'HO3D'): batches from HO3DDeviceCache through the
+    HO3D branch of data_dic, copied into the captured step's static inputs."""
+    from hifihr_amd import options, synth
+    from hifihr_amd.checkpoint import save_model
+    from hifihr_amd.data import HO3DDeviceCache
+    from hifihr_amd.traineval import GraphedTrainStep, data_dic, train_step
+    if cli.ho3d_cache:
+        z = np.load(cli.ho3d_cache)
+        frames = {"images_u8": z["images"], "hand_masks_u8": z["hand_masks"], "Ks": z["Ks"], "xyz21": z["xyz21"]}
+    else:
+        from hifihr_amd import ops
+        from hifihr_amd.mano_tables import synthetic_mano_tables
+        mt = synthetic_mano_tables(0)
+        frames = synth.make_ho3d_frames(ops.ManoLayerHandle(mt), ops.RendererHandle(mt.faces, 778, image_size=224, aa=3), cli.synthetic_size,
+                                        device=device)
+    cache = HO3DDeviceCache(**frames, device=device)
+    say(f"[train_hrnet] HO3D: {cache.n} frames resident on {device}; world {world}; encoder {args.pretrain}; losses {args.losses}")
+    B = args.train_batch
+    gen = torch.Generator().manual_seed(1000 + current_epoch)
+    noise_gen = torch.Generator().manual_seed(77 + rank)
+    stepper, stepper_key, it, t_last = None, None, 0, time.perf_counter()
+    for epoch in range(1, args.total_epochs + 1 - current_epoch):
+        options.update_lambdas_for_epoch(args, epoch + current_epoch)
+        lam_key = (args.lambda_pose, args.lambda_j2d_gt, args.lambda_shape, args.lambda_tex_reg)
+        if stepper is not None and lam_key != stepper_key:
+            stepper.release()
+            stepper = None
+        perm = torch.randperm(cache.n, generator=gen)
+        per_step = B * world
+        for lo in range(0, cache.n - per_step + 1, per_step):
+            idx = perm[lo + rank * B: lo + (rank + 1) * B]
+            ex = data_dic(cache.batch(idx, generator=noise_gen), "HO3D", "training", args, device=device)
+            if cli.graph and stepper is None:
+                ok = 1
+                try:
+                    stepper = GraphedTrainStep(model, loss_func, opt, ex, args, dat_name="HO3D", reducer=reducer if world > 1 else None)
+                    stepper_key = lam_key
+                except Exception as e:            # noqa: BLE001
+                    say(f"[train_hrnet] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+                    ok = 0
+                if world > 1:
+                    flag = torch.tensor([ok], device=device, dtype=torch.int32)
+                    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                    ok = int(flag.item())
+                if not ok:
+                    if stepper is not None:
+                        stepper.release()
+                    stepper, cli.graph = None, 0
+            if stepper is not None:
+                stepper.load_batch(ex)
+                loss, dic = stepper()
+            else:
+                loss, dic = train_step(model, loss_func, opt, ex, args, dat_name="HO3D", backward_hook=reducer.finish)
+            it += 1
+            if it % cli.print_freq == 0 or it == cli.max_iters:
+                torch.cuda.synchronize()
+                dt, t_last = time.perf_counter() - t_last, time.perf_counter()
+                n_it = cli.print_freq if it % cli.print_freq == 0 else it % cli.print_freq
+                terms = " ".join(f"{k}={float(dic[k].detach()):.4g}" for k in args.losses)
+                say(f"[train_hrnet] epoch {epoch + current_epoch} it {it} loss {float(loss.detach()):.5f} ({terms}) {n_it * per_step / dt:.0f} img/s")
+            if cli.max_iters and it >= cli.max_iters:
+                break
+        if (epoch + current_epoch) % args.save_interval == 0 or (cli.max_iters and it >= cli.max_iters):
+            if rank == 0:
+                say("[train_hrnet] saved", save_model(model, opt, sched, epoch, current_epoch, args))
+        sched.step()
+        if cli.max_iters and it >= cli.max_iters:
+            break
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    say("Done!")
+    return 0
+
+
 def run_evaluation(model, cache, arrays, args, device):
     from hifihr_amd.evaluate import Evaluator
     from hifihr_amd.traineval import data_dic
@@ -151,6 +233,9 @@ def main(argv=None):
         opt.param_groups[0]["lr"] = args.force_init_lr
     loss_func = LossFunction()
 
+    dat_name = cli.dataset
+    if dat_name == "HO3D":
+        return train_ho3d(cli, args, model, loss_func, opt, sched, reducer, current_epoch, rank, world, device, say)
     train_arrays, eval_arrays = load_or_make_dataset(cli, model, device)
     cache = FreiHandDeviceCache(train_arrays["images"], train_arrays["masks"], train_arrays["Ks"], train_arrays["joints"],
                                 train_arrays["verts"], device=device)
