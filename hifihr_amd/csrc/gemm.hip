@@ -732,6 +732,7 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void bgemm_nt_sk_kernel(BgemmArgs
 // split the COLUMNS of a tile, 32 each, and take all of its 16-row blocks, so a short tile simply has fewer blocks); whole tiles
 // only: nothing is exchanged between workgroups and nothing needs a workspace.  LDS: 4 stages x (A 128x32 + B 128x32) = 128 KB.
 // ------------------------------------------------------------------------------------------------
+static int gemm_cus();
 struct RowsTile { int p, nt, m0, rows; };
 __device__ __forceinline__ RowsTile rows_tile_at(const BgemmArgs& a, long cur, long end) {
   const long col = cur / a.M;                                // (p, nt) pair
@@ -929,6 +930,199 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent row-share TN form: C[p][m][n] = sum_t A[p][t][m] B[p][t][n]  (backward-weight of the Winograd layers: A = Y'[P][T][K],
+// B = V[P][T][C]), N a multiple of 128, M a multiple of 16, T a multiple of 32.  The same schedule as bgemm_nt_rows_kernel -- one
+// workgroup per CU walks an equal share of the flattened (problem, 128-column tile, 16-row block) space as ONE continuous chunk stream,
+// four loader waves three chunks ahead across tile boundaries, four MFMA waves splitting a tile's columns -- with the operands in their
+// t-major layout: a chunk is 32 t rows x 128 floats of A (the tile's rows are A's columns) and of B.  Every tile covers the whole
+// reduction, so the result is complete (one slab: nothing for the consumer to sum) and bit-reproducible.  The plain 64x64 kernel ran
+// these 36-problem products at 0.52-0.57 of the peak (a pipeline fill and drain per 16-chunk tile, every wave issuing its own LDS-DMA).
+// LDS image of a chunk: A [32][128] at pitch 512 B; B [32][128] with the 16-byte segments of row t XOR-ed by 4 (t & 3) (on the source
+// address): lane (r, g) of a k-step reads B[t = 4 k + g][n = .. + r] as one ds_read_b32, and the four t rows of a wave would otherwise
+// hit the same 16 banks.  A fragments are ds_read_b128: lane r owns rows 4 r .. 4 r + 3 (and 64 + 4 r .. for 128-row tiles) of the
+// tile -- a row permutation the epilogue undoes.  Tiles are 128, 64, 32 or 16 rows (the tail of a share is cut into powers of two).
+// ------------------------------------------------------------------------------------------------
+struct TnTile { int p, nt, m0, nb; };
+__device__ __forceinline__ TnTile tn_tile_at(const BgemmArgs& a, long cur, long end) {
+  const int MB = a.M / 16;
+  const long col = cur / MB;                                 // (p, nt) pair
+  const int mb0 = (int)(cur - col * MB);
+  const int p = (int)(col / a.tiles_n), nt = (int)(col - (long)p * a.tiles_n);
+  const long lim = min((long)MB - mb0, end - cur);
+  return TnTile{p, nt, mb0 * 16, lim >= 8 ? 8 : lim >= 4 ? 4 : lim >= 2 ? 2 : 1};
+}
+
+__global__ __launch_bounds__(512) void bgemm_tn_rows_kernel(BgemmArgs a, long per) {
+  constexpr int STAGE = 256 * 32;                            // floats per stage: A rows t 0..31 (x 128), then B rows t 0..31 (x 128)
+  __shared__ __attribute__((aligned(1024))) float lds[4 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const long total = (long)a.batch * a.tiles_n * (a.M / 16);
+  const long s_lo = (long)wg * per, s_hi = min(s_lo + per, total);
+  if (s_lo >= s_hi) return;                                  // (uniform)
+  const int nch = a.K / 32;
+  int ntiles = 0;
+  for (long cur = s_lo; cur < s_hi; cur += tn_tile_at(a, cur, s_hi).nb) ++ntiles;
+  const int nchunks = ntiles * nch;
+
+  if (wave >= 4) {
+    // ---------------- loader: piece q = l + 4 i (i < 8) of a chunk: q < 16 rows t = 2 q, 2 q + 1 of A, else rows 2 (q - 16) .. of B;
+    //                  lane -> (row lane >> 5, physical 16-byte segment lane & 31) ----------------
+    const int l = wave - 4;
+    long cur = s_lo;
+    TnTile t = tn_tile_at(a, cur, s_hi);
+    const float* src[8];
+    size_t step[8];
+    auto bind = [&](const TnTile& tt) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = l + 4 * i;
+        const bool isA = q < 16;
+        const int trow = 2 * (q & 15) + (lane >> 5);
+        const int ps = lane & 31;
+        if (isA) {
+          int col = tt.m0 + 4 * ps;
+          col = col <= a.M - 4 ? col : a.M - 4;              // columns past the matrix: discarded rows of the tile
+          src[i] = a.A + (size_t)tt.p * a.sa + (size_t)trow * a.lda + col;
+          step[i] = (size_t)32 * a.lda;
+        } else {
+          const int seg = ps ^ (4 * (trow & 3));
+          src[i] = a.B + (size_t)tt.p * a.sb + (size_t)trow * a.ldb + tt.nt * 128 + 4 * seg;
+          step[i] = (size_t)32 * a.ldb;
+        }
+      }
+    };
+    bind(t);
+    int li = 0, lc = 0;
+    auto issue_next = [&](int gc) {
+      float* base = lds + (gc & 3) * STAGE;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) HIFIHR_GLDS16(src[i] + lc * step[i], base + 256 * (l + 4 * i), lane);
+      if (++lc == nch) {
+        lc = 0;
+        cur += t.nb;
+        if (++li < ntiles) { t = tn_tile_at(a, cur, s_hi); bind(t); }
+      }
+    };
+    issue_next(0);
+    if (nchunks > 1) issue_next(1);
+    if (nchunks > 2) issue_next(2);
+    if (nchunks > 2) HIFIHR_WAIT_VM(8); else HIFIHR_WAIT_VM(0);
+    HIFIHR_RAW_BARRIER();                                    // barrier -1
+    for (int gc = 0; gc < nchunks; ++gc) {
+      if (gc + 3 < nchunks) { issue_next(gc + 3); HIFIHR_WAIT_VM(8); }
+      else HIFIHR_WAIT_VM(0);
+      HIFIHR_RAW_BARRIER();                                  // barrier gc
+    }
+    return;
+  }
+
+  // ---------------- MFMA waves: wave w = columns 32 w .. 32 w + 31 of the tile, every row block ----------------
+  const int r = lane & 15, g = lane >> 4;
+  int boff[2];                                               // float offset inside a B row of this lane's two columns (swizzle of t & 3 = g applied)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int colb = 32 * wave + 16 * i + r;
+    boff[i] = 4 * ((colb >> 2) ^ (4 * g)) + (colb & 3);
+  }
+  HIFIHR_RAW_BARRIER();                                      // barrier -1
+  long cur = s_lo;
+  int gc = 0;
+  auto run_tile = [&](auto nbc, const TnTile& t) {
+    constexpr int NB = decltype(nbc)::value;
+    float fm[2][4][NB], fn[2][4][2];
+    auto read_half = [&](int gcc, int h, int slot) {        // k-steps 4 h .. 4 h + 3 of chunk gcc: t = 16 h + 4 k + g
+      const float* st = lds + (gcc & 3) * STAGE;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int trow = 16 * h + 4 * k + g;
+        const float* ar = st + trow * 128;
+        const float* br = st + 32 * 128 + trow * 128;
+        fn[slot][k][0] = br[boff[0]]; fn[slot][k][1] = br[boff[1]];
+        if constexpr (NB == 8) {
+          const float4 v0 = *reinterpret_cast<const float4*>(ar + 4 * r), v1 = *reinterpret_cast<const float4*>(ar + 64 + 4 * r);
+          fm[slot][k][0] = v0.x; fm[slot][k][1] = v0.y; fm[slot][k][2] = v0.z; fm[slot][k][3] = v0.w;
+          fm[slot][k][4] = v1.x; fm[slot][k][5] = v1.y; fm[slot][k][6] = v1.z; fm[slot][k][7] = v1.w;
+        } else if constexpr (NB == 4) {
+          const float4 v0 = *reinterpret_cast<const float4*>(ar + 4 * r);
+          fm[slot][k][0] = v0.x; fm[slot][k][1] = v0.y; fm[slot][k][2] = v0.z; fm[slot][k][3] = v0.w;
+        } else if constexpr (NB == 2) {
+          const float2 v0 = *reinterpret_cast<const float2*>(ar + 2 * r);
+          fm[slot][k][0] = v0.x; fm[slot][k][1] = v0.y;
+        } else {
+          fm[slot][k][0] = ar[r];
+        }
+      }
+    };
+    floatx4 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    auto mfma_half = [&](int slot) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fn[slot][k][i], fm[slot][k][j], acc[i][j], 0, 0, 0);
+    };
+    auto touch = [&]() {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        HIFIHR_TOUCH(fn[0][k][0]); HIFIHR_TOUCH(fn[0][k][1]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) HIFIHR_TOUCH(fm[0][k][j]);
+      }
+    };
+    auto interleave = [&]() {                                // the LDS reads of the next half spread between the 8 NB MFMAs of this one
+      constexpr int RH = 4 * (2 + (NB >= 4 ? NB / 4 : 1));   // reads per half
+      constexpr int MG = (8 * NB) / RH > 0 ? (8 * NB) / RH : 1;
+#pragma unroll
+      for (int i = 0; i < RH; ++i) {
+        HIFIHR_SCHED_GROUP(0x008, MG);
+        HIFIHR_SCHED_GROUP(0x100, 1);
+        HIFIHR_SCHED_GROUP(0x002, 1);
+      }
+      HIFIHR_SCHED_GROUP(0x008, 8 * NB - MG * RH > 0 ? 8 * NB - MG * RH : 0);
+    };
+    read_half(gc, 0, 0);
+    touch();
+    for (int c = 0; c < nch; ++c, ++gc) {
+      read_half(gc, 1, 1);
+      mfma_half(0);
+      interleave();
+      HIFIHR_PIN();
+      read_half(gc + 1, 0, 0);                               // (landed: barrier gc - 1; past the tile's last chunk: the next tile's first, or a
+      mfma_half(1);                                          //  stale stage that is never used)
+      interleave();
+      HIFIHR_PIN();
+      touch();
+      HIFIHR_RAW_BARRIER();                                  // barrier gc
+    }
+    // register e of lane (r, g) of block (i, j) = C[m0 + row(j, r)][128 nt + 32 wave + 16 i + 4 g + e]
+    float* C = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int m = NB == 8 ? 64 * (j >> 2) + 4 * r + (j & 3) : NB == 4 ? 4 * r + j : NB == 2 ? 2 * r + j : r;
+      float* row = C + (size_t)(t.m0 + m) * a.ldc;
+      *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
+      *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
+    }
+  };
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const TnTile t = tn_tile_at(a, cur, s_hi);
+    cur += t.nb;
+    switch (t.nb) {
+      case 8: run_tile(std::integral_constant<int, 8>{}, t); break;
+      case 4: run_tile(std::integral_constant<int, 4>{}, t); break;
+      case 2: run_tile(std::integral_constant<int, 2>{}, t); break;
+      default: run_tile(std::integral_constant<int, 1>{}, t); break;
+    }
+  }
+}
+
 static int gemm_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -979,6 +1173,15 @@ static bool nt_rows(int N) {
   return on && N % 128 == 0 && getenv("HIFIHR_GEMM_NT_TILE") == nullptr;
 }
 
+// the persistent row-share TN kernel: complete products (one slab) when every CU gets at least eight 16-row blocks (HIFIHR_GEMM_TN_ROWS=0:
+// the per-tile kernels with T-split slabs)
+static bool tn_rows(int M, int N, int T, int batch) {
+  static const int on = [] { const char* e = getenv("HIFIHR_GEMM_TN_ROWS"); return e ? atoi(e) : 1; }();
+  if (!on || N % 128 != 0 || M % 16 != 0 || T % 32 != 0 || T < 64) return false;
+  if (getenv("HIFIHR_GEMM_TN_TILE") != nullptr || getenv("HIFIHR_GEMM_TN_PARTS") != nullptr) return false;
+  return (long)batch * (N / 128) * (M / 16) >= 8L * gemm_cus();      // (256 x 256 channels, 4.5 blocks per CU: 38 us here, 35 on the 64x64 kernel)
+}
+
 // which kernel instantiation a shape runs on, as rocprof names it (bench.py groups its roofline lines by this)
 void bgemm_describe(int tn, int M, int N, int K, char* out, int cap) { bgemm_describe_batch(tn, M, N, K, 16, out, cap); }
 
@@ -994,6 +1197,7 @@ void bgemm_describe_batch(int tn, int M, int N, int K, int batch, char* out, int
   }
   const int nload = gemm_ws_loaders();
   if (!tn && nt_rows(N)) { snprintf(out, cap, "bgemm_nt_rows_kernel"); return; }
+  if (tn && tn_rows(M, N, K, batch)) { snprintf(out, cap, "bgemm_tn_rows_kernel"); return; }
   if (!tn && bm == 128 && bn == 128 && nload > 0 && bgemm_nt_workspace_bytes(M, N, K, 16) > 0) snprintf(out, cap, "bgemm_nt_sk_kernel<%d>", nload == 2 ? 2 : 4);
   else if (bm == 128 && bn == 128 && nload > 0) snprintf(out, cap, "bgemm_ws_kernel<128, 128, %s, %d>", tn ? "true" : "false", nload == 1 ? 1 : nload == 4 ? 4 : 2);
   else snprintf(out, cap, "%s<%d, %d>", tn ? "bgemm_tn_kernel" : "bgemm_nt_kernel", bm, bn);
@@ -1072,6 +1276,7 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
 
 // number of K-split slabs launch_bgemm_tn writes for this shape (the caller provides parts * batch * M * N floats)
 int bgemm_tn_parts(int M, int N, int T, int batch) {
+  if (tn_rows(M, N, T, batch)) return 1;
   if (const char* e = getenv("HIFIHR_GEMM_TN_PARTS")) { const int v = atoi(e); if (v > 0) return v; }
   int bm, bn;
   tn_tile(M, N, batch, &bm, &bn);
@@ -1092,6 +1297,17 @@ hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M,
   BgemmArgs a{};
   a.A = A; a.B = B; a.C = Cparts; a.M = M; a.N = N; a.K = T; a.lda = M; a.ldb = N; a.ldc = N;
   a.sa = (long)T * M; a.sb = (long)T * N; a.sc = (long)M * N; a.batch = batch;
+  if (tn_rows(M, N, T, batch)) {
+    if (parts != 1) return hipErrorInvalidValue;
+    a.tiles_n = N / 128; a.tiles_m = (M + 127) / 128; a.splits = 1; a.cps = T / 32; a.sc_split = 0;
+    const long total = (long)batch * a.tiles_n * (M / 16);
+    const int cus = gemm_cus();
+    long per = (total + cus - 1) / cus;
+    if (per < 4) per = 4;
+    const int G = (int)((total + per - 1) / per);
+    hipLaunchKernelGGL(bgemm_tn_rows_kernel, dim3(G), dim3(512), 0, st, a, per);
+    return hipGetLastError();
+  }
   int bm, bn;
   tn_tile(M, N, batch, &bm, &bn);
   if (const char* e = getenv("HIFIHR_GEMM_TN_TILE")) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (M % bm) bm = 64; if (N % bn) bn = 64; }

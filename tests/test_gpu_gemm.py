@@ -51,3 +51,16 @@ def test_bgemm_nt_rows_is_bit_reproducible(lib):
     c1 = torch.empty(16, 1568, 512, device="cuda"); c2 = torch.empty_like(c1)
     lib.bgemm_nt(a, b, c1, 1568, 512, 512, 16); lib.bgemm_nt(a, b, c2, 1568, 512, 512, 16)
     assert torch.equal(c1, c2)
+
+
+@pytest.mark.parametrize("M,N,T,batch", [(512, 512, 512, 36), (512, 256, 512, 36), (256, 512, 768, 36), (320, 384, 96, 40), (128, 128, 64, 300)])
+def test_bgemm_tn_row_shares(lib, M, N, T, batch):
+    """bgemm_tn_rows_kernel on 256 workgroups (the F(4x4, 3x3) backward-weight shapes of layer 4 and shapes whose shares end inside tiles:
+    64 / 32 / 16-row tail tiles, column-tile and problem boundaries): complete products in one slab, bit-reproducible."""
+    assert lib.bgemm_describe(True, M, N, T, batch) == "bgemm_tn_rows_kernel"
+    assert kc.bgemm_tn_case(lib, "cuda", M, N, T, batch, seed=M + T) == 1
+    gen = torch.Generator().manual_seed(3)
+    a = torch.randn(batch, T, M, generator=gen).cuda(); b = torch.randn(batch, T, N, generator=gen).cuda()
+    c1 = torch.empty(1, batch, M, N, device="cuda"); c2 = torch.full_like(c1, 7.0)
+    lib.bgemm_tn(a, b, c1, M, N, T, batch, 1); lib.bgemm_tn(a, b, c2, M, N, T, batch, 1)
+    assert torch.equal(c1, c2)

@@ -54,3 +54,11 @@ def test_bgemm_nt_row_shares(hostsim_lib, M, N, K, batch):
     problem boundaries, and chunk streams that run across tile boundaries."""
     assert hostsim_lib.bgemm_describe(False, M, N, K) == "bgemm_nt_rows_kernel"
     assert kc.bgemm_case(hostsim_lib, "cpu", M, N, K, batch, seed=M + K) == 0        # no workspace
+
+
+@pytest.mark.parametrize("M,N,T,batch", [(128, 128, 64, 4), (192, 256, 96, 2), (64, 128, 128, 8), (512, 128, 64, 1), (320, 128, 96, 3), (448, 384, 64, 1)])
+def test_bgemm_tn_row_shares(hostsim_lib, M, N, T, batch):
+    """bgemm_tn_rows_kernel (N % 128 == 0, M % 64 == 0, T % 32 == 0, at least eight 16-row blocks per CU; hostsim reports 4 CUs): shares that end
+    inside a 128-row tile, tails cut into 64 / 32 / 16-row tiles, tiles that cross problem boundaries, complete products in ONE slab."""
+    assert hostsim_lib.bgemm_describe(True, M, N, T, batch) == "bgemm_tn_rows_kernel"
+    assert kc.bgemm_tn_case(hostsim_lib, "cpu", M, N, T, batch, seed=M + T) == 1
