@@ -817,6 +817,26 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
 #endif
   long cur = s_lo;
   int gc = 0;
+  // batch-norm statistics of the output (a.stats != null): per-column sums of this wave's 32 columns, kept in registers over the tiles of
+  // one column tile (a share walks the rows of a column tile before it moves on), then folded over the 16 row lanes and added to the
+  // slot buffer -- the epilogue conv_igemm_kernel / conv_halo_kernel have, so a 1x1 convolution on this kernel needs no statistics pass
+  float ssum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  int stat_nt = -1;
+  auto flush_stats = [&]() {
+    if (stat_nt < 0) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float sa = ssum[i][e], sb = ssq[i][e];
+        for (int o = 1; o < 16; o <<= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+        if (r == 0) {
+          float* sp = a.stats + (size_t)(wg & (kStatSlots - 1)) * 2 * a.N + (size_t)stat_nt * 128 + 32 * wave + 16 * i + 4 * g + e;
+          atomicAdd(sp, sa); atomicAdd(sp + a.N, sb);
+        }
+        ssum[i][e] = 0.f; ssq[i][e] = 0.f;
+      }
+  };
   auto run_tile = [&](auto nbc, const RowsTile& t) {
     constexpr int NB = decltype(nbc)::value;
     float fm[2][NB][4], fn[2][2][4];
@@ -900,6 +920,12 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
         float* row = C + (size_t)(t.m0 + m) * a.ldc;
         *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
         *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
+        if (a.stats != nullptr) {                              // (uniform)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ssum[i][e] += acc[i][j][e]; ssq[i][e] += acc[i][j][e] * acc[i][j][e]; }
+        }
       }
     }
 #if defined(HIFIHR_GEMM_STAMP)
@@ -909,6 +935,7 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
   for (int ti = 0; ti < ntiles; ++ti) {
     const RowsTile t = rows_tile_at(a, cur, s_hi);
     cur += t.rows;
+    if (a.stats != nullptr && t.nt != stat_nt) { flush_stats(); stat_nt = t.nt; }       // (uniform; batch == 1: nt identifies the columns)
     switch ((t.rows + 15) >> 4) {
       case 8: run_tile(std::integral_constant<int, 8>{}, t); break;
       case 7: run_tile(std::integral_constant<int, 7>{}, t); break;
@@ -920,6 +947,7 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
       default: run_tile(std::integral_constant<int, 1>{}, t); break;
     }
   }
+  if (a.stats != nullptr) flush_stats();
 #if defined(HIFIHR_GEMM_STAMP)
   if (tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1229,12 +1257,15 @@ size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch) {
   return sk_flag_bytes(G) + (size_t)G * 128 * 128 * sizeof(float);
 }
 
-hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st) {
+hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
+                           float* stats) {
   if (!bgemm_nt_supported(M, N, K) || batch <= 0) return hipErrorInvalidValue;
+  if (stats != nullptr && (batch != 1 || !nt_rows(N))) return hipErrorInvalidValue;
   if ((long)M * K >= (1L << 31) || (long)N * K >= (1L << 31)) return hipErrorInvalidValue;      // 32-bit element offsets
   BgemmArgs a{};
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
   a.sa = (long)M * K; a.sb = (long)N * K; a.sc = (long)M * N; a.batch = batch;
+  a.stats = stats;
   if (nt_rows(N)) {
     a.tiles_n = N / 128; a.tiles_m = (M + 127) / 128; a.splits = 1; a.cps = K / 32; a.sc_split = 0;
     const long total = (long)batch * a.tiles_n * M;

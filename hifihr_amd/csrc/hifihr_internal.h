@@ -243,13 +243,16 @@ struct BgemmArgs {
   int batch, tiles_m, tiles_n;
   int splits, cps;             // TN: slabs of the t range, K chunks (32 rows) per slab
   long sc_split;               // element stride between slabs of C
+  float* stats = nullptr;      // bgemm_nt_rows_kernel, batch 1 (a 1x1 convolution in front of a batch-norm): per-column sum / sum of squares of C
+                               // added into the slot buffer [kStatSlots][2][N] (csrc/bn.hip), or null
 };
 void bgemm_describe(int tn, int M, int N, int K, char* out, int cap);
 void bgemm_describe_batch(int tn, int M, int N, int K, int batch, char* out, int cap);
 bool bgemm_nt_supported(int M, int N, int K);
 bool bgemm_tn_supported(int M, int N, int T);
 size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch);
-hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st);
+hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
+                           float* stats_or_null = nullptr);      // stats: only with N % 128 == 0 and batch == 1 (else hipErrorInvalidValue)
 int bgemm_tn_parts(int M, int N, int T, int batch);
 hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st);
 hipError_t launch_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st);
