@@ -42,3 +42,24 @@ def _run(T, tmp_path, capsys):
     assert T.main(["--config_json", str(f), "--synthetic_size", "16"]) == 0
     out = capsys.readouterr().out
     assert "[train_hrnet] evaluation:" in out and "pose_3d" in out
+
+
+def test_train_on_ho3d_frames(tmp_path, capsys):
+    """`train_hrnet.py --dataset HO3D`: synthetic 480 x 640 frames through HO3DDeviceCache (hand crop on the device), the HO3D branch of
+    data_dic, the captured step with dat_name 'HO3D' (absolute ground truth, train_hrnet.py:64-68), a checkpoint at the end."""
+    sys.path.insert(0, ROOT)
+    import train_hrnet as T
+    prev = torch.cuda.current_stream()
+    try:
+        cfg = json.load(open(os.path.join(ROOT, "tests", "data", "nimble_style_config.json")))
+        cfg.update(base_out_path=str(tmp_path / "run"), train_batch=8, val_batch=8, total_epochs=1, pretrain="res18", hand_model="mano",
+                   losses=["joint_3d", "mpose", "mshape", "texture", "mrgb", "sil", "ssim_tex"])
+        f = tmp_path / "cfg.json"
+        f.write_text(json.dumps(cfg))
+        assert T.main(["--config_json", str(f), "--dataset", "HO3D", "--synthetic_size", "32", "--print_freq", "2"]) == 0
+        out = capsys.readouterr().out
+        assert "HO3D: 32 frames resident" in out and "Done!" in out and "nan" not in out.lower()
+        assert (tmp_path / "run" / "model" / "texturehand_latest.t7").exists()
+    finally:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(prev)
