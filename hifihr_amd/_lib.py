@@ -206,6 +206,13 @@ class HifihrLib:
                                         _c_float_p, _c_int_p, c_void_p, c_void_p]
         c.hifihr_render_bwd.argtypes = [c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_int_p, _c_float_p, c_int,
                                         _c_float_p, _c_float_p, _c_float_p, _c_float_p, c_void_p, c_void_p]
+        c.hifihr_renderer_set_uv.argtypes = [c_void_p, _c_int_p, _c_float_p, c_int]
+        c.hifihr_render_uv_scratch_bytes.argtypes = [c_void_p, c_int]
+        c.hifihr_render_uv_scratch_bytes.restype = c_size_t
+        c.hifihr_render_fwd_uv.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, _c_float_p, c_int, _c_float_p,
+                                           _c_int_p, _c_float_p, c_void_p, c_void_p]
+        c.hifihr_render_bwd_uv.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, _c_float_p, _c_int_p, _c_float_p,
+                                           c_int] + [_c_float_p] * 6 + [c_void_p, c_void_p]
 
     # ------------------------------------------------------------------
     def check(self, rc: int, what: str):
@@ -702,6 +709,27 @@ class HifihrLib:
         self.check(self.c.hifihr_render_fwd(h, _fp(verts), _fp(vcolors), batched, _fp(cam), _fp(light_color), _fp(light_dir), B,
                                             _fp(rgba), _ip(face_id), c_void_p(ws.data_ptr()), _stream_of(verts)),
                    "hifihr_render_fwd")
+
+    def renderer_set_uv(self, h, faces_uvs, verts_uvs):
+        import numpy as np
+        fu = np.ascontiguousarray(faces_uvs, dtype=np.int32)
+        vu = np.ascontiguousarray(verts_uvs, dtype=np.float32)
+        self.check(self.c.hifihr_renderer_set_uv(h, fu.ctypes.data_as(_c_int_p), vu.ctypes.data_as(_c_float_p), vu.shape[0]),
+                   "hifihr_renderer_set_uv")
+
+    def render_uv_scratch_bytes(self, h, B):
+        return int(self.c.hifihr_render_uv_scratch_bytes(h, B))
+
+    def render_fwd_uv(self, h, verts, maps, cam, light_color, light_dir, rgba, face_id, texels, ws):
+        B, TH, TW = maps.shape[0], maps.shape[1], maps.shape[2]
+        self.check(self.c.hifihr_render_fwd_uv(h, _fp(verts), _fp(maps), TH, TW, _fp(cam), _fp(light_color), _fp(light_dir), B, _fp(rgba),
+                                               _ip(face_id), _fp(texels), c_void_p(ws.data_ptr()), _stream_of(verts)), "hifihr_render_fwd_uv")
+
+    def render_bwd_uv(self, h, verts, maps, cam, light_color, light_dir, face_id, grad_rgba, texels, gtexels, gverts, gmaps, glc, gld, ws):
+        B, TH, TW = maps.shape[0], maps.shape[1], maps.shape[2]
+        self.check(self.c.hifihr_render_bwd_uv(h, _fp(verts), _fp(maps), TH, TW, _fp(cam), _fp(light_color), _fp(light_dir), _ip(face_id),
+                                               _fp(grad_rgba), B, _fp(texels), _fp(gtexels), _fp(gverts), _fp(gmaps), _fp(glc), _fp(gld),
+                                               c_void_p(ws.data_ptr()), _stream_of(verts)), "hifihr_render_bwd_uv")
 
     def render_bwd(self, h, verts, cam, light_color, light_dir, face_id, grad_rgba, gverts, gvcolors, glc, gld, ws):
         B = verts.shape[0]

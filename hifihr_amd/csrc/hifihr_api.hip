@@ -57,6 +57,8 @@ struct hifihr_lbs {
 
 struct hifihr_renderer {
   DevBuf faces, vf_off, vf_idx;
+  DevBuf faces_uvs, verts_uvs;       // TexturesUV tables (hifihr_renderer_set_uv), empty otherwise
+  int n_uv = 0;
   hifihr::RenderDev dev;
 };
 
@@ -291,6 +293,58 @@ int hifihr_texture_pca_bwd(const float* gtex, const float* basis, int B, int K, 
 int hifihr_renderer_set_light_mode(hifihr_renderer_t* h, int point_lights) {
   if (!h || point_lights < 0 || point_lights > 1) return fail(HIFIHR_EINVAL, "hifihr_renderer_set_light_mode: bad argument");
   h->dev.sc.point_light = point_lights;
+  return HIFIHR_OK;
+}
+
+int hifihr_renderer_set_uv(hifihr_renderer_t* h, const int32_t* faces_uvs, const float* verts_uvs, int n_uv) {
+  if (!h || !faces_uvs || !verts_uvs || n_uv <= 0) return fail(HIFIHR_EINVAL, "hifihr_renderer_set_uv: bad argument");
+  for (int i = 0; i < 3 * h->dev.F; ++i)
+    if (faces_uvs[i] < 0 || faces_uvs[i] >= n_uv) return fail(HIFIHR_EINVAL, "hifihr_renderer_set_uv: uv index out of range");
+  DevBuf fu, vu;
+  HIP_TRY(hipMalloc(&fu.p, (size_t)3 * h->dev.F * sizeof(int)));
+  HIP_TRY(hipMemcpy(fu.p, faces_uvs, (size_t)3 * h->dev.F * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&vu.p, (size_t)2 * n_uv * sizeof(float)));
+  HIP_TRY(hipMemcpy(vu.p, verts_uvs, (size_t)2 * n_uv * sizeof(float), hipMemcpyHostToDevice));
+  std::swap(h->faces_uvs.p, fu.p);
+  std::swap(h->verts_uvs.p, vu.p);
+  h->n_uv = n_uv;
+  return HIFIHR_OK;
+}
+
+size_t hifihr_render_uv_scratch_bytes(const hifihr_renderer_t* h, int B) {
+  if (!h || B <= 0) return 0;
+  const size_t S = (size_t)h->dev.H * h->dev.aa;
+  return (size_t)B * S * S * 4 * sizeof(float);
+}
+
+int hifihr_render_fwd_uv(const hifihr_renderer_t* h, const float* verts, const float* maps, int TH, int TW, const float* cam,
+                         const float* light_color, const float* light_dir, int B, float* rgba, int32_t* face_id, float* texels_scratch,
+                         void* ws, void* stream) {
+  if (!h || !verts || !maps || TH < 1 || TW < 1 || !cam || !light_color || !light_dir || !rgba || !face_id || !texels_scratch || !ws || B < 0)
+    return fail(HIFIHR_EINVAL, "hifihr_render_fwd_uv: bad argument");
+  if (h->n_uv == 0) return fail(HIFIHR_EINVAL, "hifihr_render_fwd_uv: no UV tables (hifihr_renderer_set_uv)");
+  if (B == 0) return HIFIHR_OK;
+  const hifihr::TexUvPass uv{static_cast<const int*>(h->faces_uvs.p), static_cast<const float*>(h->verts_uvs.p), maps, nullptr, TH, TW,
+                             reinterpret_cast<float4*>(texels_scratch), nullptr};
+  // (the vertex-colour input of the tile kernel is not used in this mode: any [V][3] buffer serves, the vertices themselves here)
+  HIP_TRY(hifihr::launch_render_fwd(h->dev, verts, verts, (long)h->dev.V * 3, cam, light_color, light_dir, B, rgba, face_id, ws,
+                                    (hipStream_t)stream, &uv));
+  return HIFIHR_OK;
+}
+
+int hifihr_render_bwd_uv(const hifihr_renderer_t* h, const float* verts, const float* maps, int TH, int TW, const float* cam,
+                         const float* light_color, const float* light_dir, const int32_t* face_id, const float* grad_rgba, int B,
+                         const float* texels_scratch, float* gtexels_scratch, float* gverts, float* gmaps_acc, float* glight_color,
+                         float* glight_dir, void* ws, void* stream) {
+  if (!h || !verts || !maps || TH < 1 || TW < 1 || !cam || !light_color || !light_dir || !face_id || !grad_rgba || !texels_scratch ||
+      !gtexels_scratch || !gverts || !glight_color || !glight_dir || !ws || B < 0)
+    return fail(HIFIHR_EINVAL, "hifihr_render_bwd_uv: bad argument");
+  if (h->n_uv == 0) return fail(HIFIHR_EINVAL, "hifihr_render_bwd_uv: no UV tables (hifihr_renderer_set_uv)");
+  if (B == 0) return HIFIHR_OK;
+  const hifihr::TexUvPass uv{static_cast<const int*>(h->faces_uvs.p), static_cast<const float*>(h->verts_uvs.p), maps, gmaps_acc, TH, TW,
+                             reinterpret_cast<float4*>(const_cast<float*>(texels_scratch)), reinterpret_cast<float4*>(gtexels_scratch)};
+  HIP_TRY(hifihr::launch_render_bwd(h->dev, verts, cam, light_color, light_dir, face_id, grad_rgba, B, gverts, nullptr, glight_color,
+                                    glight_dir, ws, (hipStream_t)stream, &uv));
   return HIFIHR_OK;
 }
 

@@ -61,12 +61,23 @@ struct RenderDev {
 };
 
 size_t render_workspace_bytes(const RenderDev& r, int B);
+// TexturesUV mode of the renderer (csrc/render.hip texuv_*_kernel): per-face UV indices, UV coordinates, the texture maps of the batch,
+// per-sample scratch [B][S][S] float4 (texels: written by the forward, read by the backward; gtexels: backward only)
+struct TexUvPass {
+  const int* faces_uvs;        // [F][3]
+  const float* verts_uvs;      // [Vt][2]
+  const float* maps;           // [B][TH][TW][3]
+  float* gmaps;                // backward: [B][TH][TW][3], accumulated into; or null
+  int TH, TW;
+  float4* texels;
+  float4* gtexels;
+};
 hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float* vcolors, long vcol_bstride, const float* cam,
                              const float* light_color, const float* light_dir, int B, float* rgba, int* face_id, void* ws,
-                             hipStream_t st);
+                             hipStream_t st, const TexUvPass* uv = nullptr);
 hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float* cam, const float* light_color,
                              const float* light_dir, const int* face_id, const float* grad_rgba, int B, float* gverts,
-                             float* gvcolors, float* glight_color, float* glight_dir, void* ws, hipStream_t st);
+                             float* gvcolors, float* glight_color, float* glight_dir, void* ws, hipStream_t st, const TexUvPass* uv = nullptr);
 
 // Implicit-GEMM convolution geometry.  src [N][IH][IW][IC] is gathered, dst [N][OH][OW][OC] is written.
 // forward: src = x, dst = y (ih = oh*stride - pad + r); dgrad = 1: src = dy, dst = dx (ih = (oh + pad - r)/stride).

@@ -195,6 +195,10 @@ class RendererHandle:
         if point_lights:                      # PointLights: `light_dir` of render() is the location (models_res_nimble.py:191-198)
             self.lib.renderer_set_light_mode(self.h, True)
 
+    def set_uv(self, faces_uvs, verts_uvs):
+        """TexturesUV tables: faces_uvs [F,3] indices into verts_uvs [n,2] (u, v in [0, 1], v up: PyTorch3D's convention)."""
+        self.lib.renderer_set_uv(self.h, faces_uvs, verts_uvs)
+
     def workspace(self, B, device):
         # one scratch buffer per forward call (it carries the packed vertex records to that call's backward);
         # torch's caching allocator makes this a free-list pop, not a hipMalloc
@@ -247,6 +251,51 @@ class _Render(torch.autograd.Function):
         if need_col and not ctx.vcol_batched:
             gvcol = gvcol.sum(0)
         return None, gverts, gvcol, None, glc, gld
+
+
+class _RenderUV(torch.autograd.Function):
+    """The renderer with a TexturesUV texture (RendererHandle.set_uv): maps [B, TH, TW, 3] sampled per sample at the interpolated UV
+    (hifihr_render_fwd_uv / _bwd_uv); gradients to the vertices (incl. the path through uv), the texture maps and the light."""
+
+    @staticmethod
+    def forward(ctx, handle, verts, maps, cam, light_color, light_dir):
+        require_cuda(verts, maps, cam, light_color, light_dir)
+        verts, maps, cam = verts.contiguous(), maps.contiguous(), cam.contiguous()
+        light_color, light_dir = light_color.contiguous(), light_dir.contiguous()
+        B, H, S = verts.shape[0], handle.H, handle.H * handle.aa
+        rgba = torch.empty(B, 4, H, H, device=verts.device)
+        face_id = torch.empty(B, S, S, dtype=torch.int32, device=verts.device)
+        ws = handle.workspace(B, verts.device)
+        texels = torch.empty(B, S, S, 4, device=verts.device)
+        PROFILE.bracket("render_fwd_uv", lambda: handle.lib.render_fwd_uv(handle.h, verts, maps, cam, light_color, light_dir, rgba, face_id,
+                                                                         texels, ws))
+        ctx.handle, ctx.ws = handle, ws
+        ctx.save_for_backward(verts, maps, cam, light_color, light_dir, face_id, texels)
+        ctx.mark_non_differentiable(face_id)
+        ctx.set_materialize_grads(False)
+        return rgba, face_id
+
+    @staticmethod
+    def backward(ctx, grad_rgba, _):
+        if grad_rgba is None:
+            return (None,) * 6
+        verts, maps, cam, light_color, light_dir, face_id, texels = ctx.saved_tensors
+        handle = ctx.handle
+        B = verts.shape[0]
+        gverts = torch.empty_like(verts)
+        gmaps = torch.zeros_like(maps) if ctx.needs_input_grad[2] else None
+        gl = torch.empty(2, B, 3, device=verts.device)
+        gtexels = torch.empty_like(texels)
+        PROFILE.bracket("render_bwd_uv", lambda: handle.lib.render_bwd_uv(handle.h, verts, maps, cam, light_color, light_dir, face_id,
+                                                                         grad_rgba.contiguous(), texels, gtexels, gverts, gmaps, gl[0], gl[1],
+                                                                         ctx.ws))
+        return None, gverts, gmaps, None, gl[0], gl[1]
+
+
+def render_uv(handle: RendererHandle, verts, maps, cam, light_color, light_dir):
+    """renderer_p3d(Meshes(verts, faces, TexturesUV(maps, faces_uvs, verts_uvs)), cameras, lights) + avg_pool2d(aa): the texture image path of
+    reference models_res_nimble.py:203-211.  `handle.set_uv(faces_uvs, verts_uvs)` first.  -> rgba [B,4,H,H], face_id."""
+    return _RenderUV.apply(handle, verts, maps, cam, light_color, light_dir)
 
 
 def render(handle: RendererHandle, verts, vcolors, cam, light_color, light_dir):

@@ -141,7 +141,17 @@ def _interp(attr, faces, idx, bary):
     return (bary.unsqueeze(-1) * g).sum(-2)
 
 
-def render(verts, vcolors, cam, light_color, light_dir, faces, image_size=224, aa=3, consts=ShadeConsts(), point_lights=False):
+def sample_textures_uv(maps, faces_uvs, verts_uvs, idx, bary):
+    """TexturesUV.sample_textures [recalled, PyTorch3D renderer/mesh/textures.py]: pixel uv = barycentric interpolation of the face's three
+    uv coordinates; the maps are flipped vertically and sampled with F.grid_sample(2 uv - 1, bilinear, align_corners=True, padding border).
+    maps [B,TH,TW,3], faces_uvs Long [F,3], verts_uvs [n,2], idx Long [B,S,S] (clamped face index), bary [B,S,S,3] -> [B,S,S,3]."""
+    fu = verts_uvs[faces_uvs]                                   # [F,3,2]
+    uv = (bary.unsqueeze(-1) * fu[idx]).sum(-2)                  # [B,S,S,2]
+    tex = torch.flip(maps.permute(0, 3, 1, 2), [2])
+    return F.grid_sample(tex, uv * 2.0 - 1.0, mode="bilinear", align_corners=True, padding_mode="border").permute(0, 2, 3, 1)
+
+
+def render(verts, vcolors, cam, light_color, light_dir, faces, image_size=224, aa=3, consts=ShadeConsts(), point_lights=False, textures_uv=None):
     """verts [B,V,3] (view space), vcolors [B,V,3] (TexturesVertex stand-in), cam [B,4], light_color/dir [B,3],
     faces LongTensor [F,3].  -> rgba [B,4,H,H] after the aa x aa average pool, pix_to_face [B,S,S] (numpy)."""
     faces = torch.as_tensor(faces).long()
@@ -153,7 +163,11 @@ def render(verts, vcolors, cam, light_color, light_dir, faces, image_size=224, a
     normals = vertex_normals(verts, faces)
     P = _interp(verts, faces, idx, bary)
     N = _interp(normals, faces, idx, bary)
-    T = _interp(vcolors, faces, idx, bary)
+    if textures_uv is not None:                                  # (maps [B,TH,TW,3], faces_uvs [F,3], verts_uvs [n,2]); vcolors unused
+        maps, faces_uvs, verts_uvs = textures_uv
+        T = sample_textures_uv(maps, torch.as_tensor(faces_uvs).long(), verts_uvs, idx, bary)
+    else:
+        T = _interp(vcolors, faces, idx, bary)
     dt = verts.dtype
     amb = torch.tensor(consts.ambient, dtype=dt)
     md = torch.tensor(consts.mat_diffuse, dtype=dt)

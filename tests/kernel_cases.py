@@ -227,6 +227,58 @@ def render_case(lib, tables, device, B, seed, image_size, aa, check_grad=True, r
         lib.renderer_destroy(h)
 
 
+def synthetic_uv_tables(faces_np, V, seed=0):
+    """A UV layout for any mesh: one uv per (face, corner) -- faces_uvs = arange(3 F) -- placed by a seeded planar map of the vertex index
+    plus a per-face jitter, all inside [0.05, 0.95] (texture seams everywhere: the general TexturesUV case)."""
+    rng = np.random.default_rng(seed)
+    F_ = len(faces_np)
+    base = rng.random((V, 2)).astype(np.float32) * 0.8 + 0.1
+    uv = base[np.asarray(faces_np).reshape(-1)] + (rng.random((3 * F_, 2)).astype(np.float32) - 0.5) * 0.1
+    return np.arange(3 * F_, dtype=np.int32).reshape(F_, 3), np.clip(uv, 0.05, 0.95).astype(np.float32)
+
+
+def render_uv_case(lib, tables, device, B, seed, image_size, aa, TH=24, TW=40, rgb_atol=3e-5, gtol=3e-3):
+    """hifihr_render_fwd_uv / _bwd_uv vs oracle/render_oracle.render(textures_uv=...) ([recalled] PyTorch3D TexturesUV semantics through
+    torch's own grid_sample): face ids exact, pixels, and the gradients w.r.t. vertices (incl. the path through uv), texture maps, light."""
+    from oracle import render_oracle as ro
+    verts, _, cam, lc, ld = make_render_inputs(tables, B, seed, image_size)
+    faces_np, V = tables.faces, 778
+    faces = torch.as_tensor(faces_np).long()
+    fu, vu = synthetic_uv_tables(faces_np, V, seed)
+    gen = torch.Generator().manual_seed(seed + 3)
+    maps = torch.rand(B, TH, TW, 3, generator=gen)
+    vr, mr, lcr, ldr = (t.clone().requires_grad_(True) for t in (verts, maps, lc, ld))
+    rgba_ref, p2f_ref = ro.render(vr, None, cam, lcr, ldr, faces, image_size=image_size, aa=aa,
+                                  textures_uv=(mr, torch.from_numpy(fu).long(), torch.from_numpy(vu)))
+    S = image_size * aa
+    h = lib.renderer_create(faces_np, V, image_size=image_size, aa=aa)
+    try:
+        lib.renderer_set_uv(h, fu, vu)
+        ws = torch.empty(lib.render_workspace_bytes(h, B), dtype=torch.uint8, device=device)
+        d = lambda t: t.to(device).contiguous()
+        rgba = torch.empty(B, 4, image_size, image_size, device=device)
+        fid = torch.empty(B, S, S, dtype=torch.int32, device=device)
+        texels = torch.empty(B, S, S, 4, device=device); gtexels = torch.empty_like(texels)
+        assert lib.render_uv_scratch_bytes(h, B) == texels.numel() * 4
+        dv, dm, dcam, dlc, dld = d(verts), d(maps), d(cam), d(lc), d(ld)
+        lib.render_fwd_uv(h, dv, dm, dcam, dlc, dld, rgba, fid, texels, ws)
+        assert (p2f_ref >= 0).mean() > 0.02, "test mesh barely visible"
+        np.testing.assert_array_equal(fid.cpu().numpy(), p2f_ref)
+        np.testing.assert_allclose(rgba.cpu().numpy(), rgba_ref.detach().numpy(), atol=rgb_atol, rtol=0)
+        w = torch.randn(B, 4, image_size, image_size, generator=torch.Generator().manual_seed(seed + 1))
+        (rgba_ref * w).sum().backward()
+        gv = torch.empty(B, V, 3, device=device); gm = torch.zeros(B, TH, TW, 3, device=device)
+        glc = torch.empty(B, 3, device=device); gld = torch.empty(B, 3, device=device)
+        lib.render_bwd_uv(h, dv, dm, dcam, dlc, dld, fid, d(w), texels, gtexels, gv, gm, glc, gld, ws)
+        for name, got, ref in (("verts", gv, vr.grad), ("maps", gm, mr.grad), ("light_color", glc, lcr.grad), ("light_dir", gld, ldr.grad)):
+            ref = ref.numpy()
+            scale = np.abs(ref).max() + 1e-12
+            err = np.abs(got.cpu().numpy() - ref).max() / scale
+            assert err < gtol, f"grad {name}: max err / max |ref| = {err:.3e} (scale {scale:.3e})"
+    finally:
+        lib.renderer_destroy(h)
+
+
 # ------------------------------------------------------------------------------------------------
 # fused Adam
 # ------------------------------------------------------------------------------------------------

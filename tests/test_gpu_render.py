@@ -78,3 +78,10 @@ def test_render_mesh_behind_camera_is_empty(lib, synth_tables):
     rgba, fid, _ = _render(lib, h, verts, vcol, cam, lc, ld, H, aa)
     assert int(fid.max()) == -1 and float(rgba[:, 3].max()) == 0.0 and float(rgba[:, :3].min()) == 1.0
     lib.renderer_destroy(h)
+
+
+@pytest.mark.parametrize("B,image_size,aa", [(2, 224, 3), (3, 64, 2)])
+def test_render_textures_uv(lib, synth_tables, B, image_size, aa):
+    """TexturesUV mode of the renderer (two passes around the fused tile kernels) vs the oracle's grid_sample restatement: face ids exact,
+    pixels 1e-4, gradients w.r.t. vertices (incl. the path through uv), texture maps and light."""
+    kc.render_uv_case(lib, synth_tables, "cuda", B=B, seed=90 + image_size, image_size=image_size, aa=aa, rgb_atol=1e-4)

@@ -13,3 +13,9 @@ def hostsim_lib():
 @pytest.mark.parametrize("image_size,aa", [(32, 3), (40, 2), (24, 1)])
 def test_render_fwd_bwd(hostsim_lib, synth_tables, image_size, aa):
     kc.render_case(hostsim_lib, synth_tables, "cpu", B=2, seed=10 + aa, image_size=image_size, aa=aa)
+
+
+@pytest.mark.parametrize("image_size,aa", [(32, 3), (24, 2)])
+def test_render_textures_uv(hostsim_lib, synth_tables, image_size, aa):
+    """TexturesUV mode (texuv_fwd / texuv_bwd kernels around the tile kernels) vs the oracle's grid_sample restatement."""
+    kc.render_uv_case(hostsim_lib, synth_tables, "cpu", B=2, seed=30 + aa, image_size=image_size, aa=aa)
