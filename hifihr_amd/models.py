@@ -72,6 +72,10 @@ class MyNIMBLELayer(nn.Module):
         self.register_buffer("vreg_corner", corner.reshape(-1), persistent=False)
         self.register_buffer("vreg_bc", torch.as_tensor(t.mano_vreg_bc, dtype=torch.float32).view(1, 778, 3, 1), persistent=False)
         self.register_buffer("joint21", torch.as_tensor(t.joint21, dtype=torch.long), persistent=False)
+        self.uv_texture = t.faces_uvs is not None and t.tex_img_basis is not None
+        if self.uv_texture:                           # the texture is an IMAGE sampled through per-face UVs (TexturesUV), not vertex colours
+            self.register_buffer("tex_img_basis", pad4(t.tex_img_basis), persistent=False)
+            self.register_buffer("tex_img_mean", pad4(t.tex_img_mean), persistent=False)
 
     def forward(self, hand_params, handle_collision=True):
         B = hand_params["pose_params"].shape[0]
@@ -80,7 +84,10 @@ class MyNIMBLELayer(nn.Module):
         mano_verts = (verts.index_select(1, self.vreg_corner).view(B, 778, 3, 3) * self.vreg_bc).sum(2)
         out = {"nimble_joints": joints, "verts": verts, "faces": None, "mano_verts": mano_verts,
                "joints": joints.index_select(1, self.joint21), "rot": None}
-        if self.ifRender and hand_params.get("texture_params") is not None:
+        if self.ifRender and hand_params.get("texture_params") is not None and self.uv_texture:
+            TH, TW = self.tables.tex_hw
+            out["texture_maps"] = ops.texture_pca_decode(hand_params["texture_params"], self.tex_img_basis, self.tex_img_mean)[:, :TH * TW * 3].reshape(B, TH, TW, 3)
+        elif self.ifRender and hand_params.get("texture_params") is not None:
             out["textures"] = ops.texture_pca_decode(hand_params["texture_params"], self.tex_basis, self.tex_mean)[:, :self.V * 3].reshape(B, self.V, 3)
         return out
 
@@ -126,6 +133,8 @@ class Model(nn.Module):
             self.renderer_p3d = ops.RendererHandle(self.hand_layer.tables.faces, int(self.hand_layer.tables.v_template.shape[0]), image_size=image_size, aa=aa_factor, point_lights=not ifLight,
                                                    ambient=(0.5,) * 3, mat_diffuse=(0.8,) * 3, specular=(0.04,) * 3,
                                                    shininess=30.0, background=(1.0,) * 3)
+            if hand_model == "nimble" and self.hand_layer.uv_texture:
+                self.renderer_p3d.set_uv(self.hand_layer.tables.faces_uvs, self.hand_layer.tables.verts_uvs)
             self.register_buffer("vertex_colors", torch.tensor(SKIN_TONE).repeat(778, 1), persistent=False)
             if texture_stand_in:
                 self.register_buffer("texture_basis", texture_stand_in_basis(texture_stand_in), persistent=False)
@@ -221,7 +230,10 @@ class Model(nn.Module):
             else:
                 colors, directions = self._pl_color.expand(B, -1), self._pl_location.expand(B, -1)
             verts_cam = outputs["verts"] - pred_root + root_xyz                          # :203-205
-            rgba, face_id = ops.render(self.renderer_p3d, verts_cam, outputs["textures"], cam, colors, directions)
+            if "texture_maps" in outputs:             # TexturesUV (models_res_nimble.py:203-208): the texture image sampled per sample
+                rgba, face_id = ops.render_uv(self.renderer_p3d, verts_cam, outputs["texture_maps"], cam, colors, directions)
+            else:
+                rgba, face_id = ops.render(self.renderer_p3d, verts_cam, outputs["textures"], cam, colors, directions)
             outputs["re_img"], outputs["_rgba"] = rgba[:, :3], rgba
             outputs["re_sil"], outputs["maskRGBs"] = ops.sil_post(rgba, images)
             outputs["face_id"], outputs["skin_verts"] = face_id, verts_cam

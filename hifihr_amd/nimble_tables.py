@@ -40,6 +40,13 @@ class NimbleTables:
     mano_vreg_bc: np.ndarray    # [778,3]  barycentric coordinates on that face
     joint21: np.ndarray         # [21]     the 21 MANO-ordered joints among the J bones
     source: str = "user"
+    # optional TexturesUV data (NIMBLE textures are images: reference models_res_nimble.py:203-208 hands the layer's texture image to the
+    # renderer with per-face UV indices): uv per face corner, and a texture-IMAGE PCA instead of the per-vertex one
+    faces_uvs: np.ndarray | None = None       # [F,3]  int32 indices into verts_uvs
+    verts_uvs: np.ndarray | None = None       # [n,2]  (u, v) in [0, 1], v up (PyTorch3D's convention)
+    tex_img_basis: np.ndarray | None = None   # [T, TH*TW*3]   texture image = tex_img_mean + texture_params . tex_img_basis
+    tex_img_mean: np.ndarray | None = None    # [TH*TW*3]
+    tex_hw: tuple | None = None               # (TH, TW)
 
     def astype32(self):
         for k, v in self.__dict__.items():
@@ -139,4 +146,33 @@ def synthetic_nimble_tables(seed: int = 0) -> NimbleTables:
     t = NimbleTables(verts, shapedirs, jreg, weights, np.asarray(PARENTS), faces, pose_basis, pose_mean, tex_basis, tex_mean,
                      fidx, bc, np.asarray(JOINT21), source=f"synthetic(seed={seed})").astype32()
     t.check()
+    return t
+
+
+def add_synthetic_uv(t: NimbleTables, tex_hw=(64, 64), seed: int = 0) -> NimbleTables:
+    """Seeded TexturesUV data for any tables: a cylindrical unwrap of the template (u = azimuth, v = height), one uv per face corner so that
+    the faces crossing the azimuth seam stay un-stretched, and a texture-image PCA of smooth patterns around a skin tone."""
+    rng = np.random.RandomState(1000 + seed)
+    v = t.v_template - t.v_template.mean(0)
+    az = np.arctan2(v[:, 1] / (np.abs(v[:, 1]).max() + 1e-9), v[:, 0] / (np.abs(v[:, 0]).max() + 1e-9)) / (2 * np.pi) + 0.5      # [0, 1)
+    hz = (v[:, 2] - v[:, 2].min()) / (v[:, 2].max() - v[:, 2].min() + 1e-9)
+    F_ = t.faces.shape[0]
+    cu, cv = az[t.faces].copy(), hz[t.faces]                                            # [F,3]
+    wrap = (cu.max(1) - cu.min(1)) > 0.5
+    cu[wrap] = np.where(cu[wrap] < 0.5, cu[wrap] + 1.0, cu[wrap])                       # faces across the seam: unwrap ...
+    uv = np.stack([cu / 1.25 * 0.9 + 0.05, cv * 0.9 + 0.05], -1).reshape(-1, 2)         # ... and keep everything inside [0.05, 0.95]
+    TH, TW = tex_hw
+    yy, xx = np.mgrid[:TH, :TW]
+    tone = np.array([0.78, 0.60, 0.50])
+    mean = tone[None, None, :] + 0.05 * np.sin(xx / TW * 14.0)[..., None] * np.cos(yy / TH * 9.0)[..., None]
+    NT_ = t.tex_basis.shape[0]
+    basis = np.zeros((NT_, TH, TW, 3))
+    for k in range(NT_):
+        fx, fy, ph = rng.uniform(2.0, 12.0), rng.uniform(2.0, 12.0), rng.uniform(0, 2 * np.pi)
+        basis[k] = (np.sin(xx / TW * fx * 2 * np.pi + ph) * np.cos(yy / TH * fy * 2 * np.pi))[..., None] * (0.04 * rng.randn(3))
+    t.faces_uvs = np.arange(3 * F_, dtype=np.int32).reshape(F_, 3)
+    t.verts_uvs = uv.astype(np.float32)
+    t.tex_img_mean = mean.reshape(-1).astype(np.float32)
+    t.tex_img_basis = basis.reshape(NT_, -1).astype(np.float32)
+    t.tex_hw = (int(TH), int(TW))
     return t

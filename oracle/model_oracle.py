@@ -121,8 +121,15 @@ def nimble_forward_tail(t, hand_params, images, Ks, root_xyz, light, dat_name="F
     out["nimble_joints"] = out["nimble_joints"] - nroot
     cam = ro.ndc_camera_from_K(Ks, float(image_size))
     verts_cam = out["verts"] - pred_root + root_xyz
+    uv = None
+    if getattr(t, "faces_uvs", None) is not None and getattr(t, "tex_img_basis", None) is not None:
+        # TexturesUV (models_res_nimble.py:203-208): the texture IMAGE of the layer's texture PCA, sampled through per-face uvs
+        TH, TW = t.tex_hw
+        maps = (torch.as_tensor(t.tex_img_mean) + hand_params["texture_params"] @ torch.as_tensor(t.tex_img_basis)).reshape(-1, TH, TW, 3)
+        uv = (maps, torch.as_tensor(t.faces_uvs).long(), torch.as_tensor(t.verts_uvs))
+        out["texture_maps"] = maps
     rgba, p2f = ro.render(verts_cam, out["textures"], cam, light["colors"], light["directions"], torch.as_tensor(t.faces).long(),
-                          image_size=image_size, aa=aa, point_lights=point_lights)
+                          image_size=image_size, aa=aa, point_lights=point_lights, textures_uv=uv)
     out["re_img"], out["re_sil"], out["maskRGBs"] = ro.model_render_outputs(rgba, images)
     out["face_id"], out["skin_verts"] = torch.from_numpy(p2f), verts_cam
     return out

@@ -53,14 +53,19 @@ def _nimble_inputs(B, seed, image_size=224):
     return hp, images, Ks, root_xyz, light
 
 
-@pytest.mark.parametrize("dat_name,mode_train", [("FreiHand", True), ("HO3D", False)])
-def test_nimble_model_tail_matches_oracle(nimble_tables, synth_tables, dat_name, mode_train):
+@pytest.mark.parametrize("dat_name,mode_train,uv", [("FreiHand", True, False), ("HO3D", False, False), ("FreiHand", True, True)])
+def test_nimble_model_tail_matches_oracle(nimble_tables, synth_tables, dat_name, mode_train, uv):
     """hand layer -> Mano2Frei -> root-relative -> skin render: every output of the nimble branch against the oracle, and the gradient
     of a scalar of (joints, mano_verts, nimble_joints, re_img) with respect to pose / shape / texture parameters."""
     from hifihr_amd.models import Model
     from oracle import model_oracle as mor
     B = 2
+    if uv:                                   # the texture as an IMAGE sampled through per-face uvs (TexturesUV) instead of vertex colours
+        import copy
+        from hifihr_amd.nimble_tables import add_synthetic_uv
+        nimble_tables = add_synthetic_uv(copy.copy(nimble_tables))
     model = Model(True, "cuda", False, "nimble", False, "res18", nimble_tables=nimble_tables, mano_tables=synth_tables).cuda()
+    assert model.hand_layer.uv_texture == uv
     hp, images, Ks, root_xyz, light = _nimble_inputs(B, seed=11)
     hp_ref = {k: (v.clone().requires_grad_(True) if v is not None and k.endswith("_params") else v) for k, v in hp.items()}
     ref = mor.nimble_forward_tail(nimble_tables, hp_ref, images, Ks, root_xyz, light, dat_name=dat_name, mode_train=mode_train)

@@ -40,9 +40,10 @@ def parse(argv=None):
                                                        "xyz21 [n,21,3]; default: seeded synthetic frames")
     ap.add_argument("--synthetic_size", type=int, default=512)
     ap.add_argument("--mano_pkl", default=None, help="MANO_RIGHT.pkl (licensed, user supplied); default: synthetic MANO-shaped tables")
-    ap.add_argument("--nimble_layer", choices=["mano-stand-in", "synthetic"], default="mano-stand-in",
+    ap.add_argument("--nimble_layer", choices=["mano-stand-in", "synthetic", "synthetic-uv"], default="mano-stand-in",
                     help="what hand_model 'nimble' runs on: MANO + the vertex-colour texture stand-in, or the NIMBLE-shaped layer "
-                         "(csrc/lbs.hip: 25 joints, 5990 skin vertices, texture PCA) on seeded synthetic tables")
+                         "(csrc/lbs.hip: 25 joints, 5990 skin vertices, texture PCA) on seeded synthetic tables; synthetic-uv: the same "
+                         "layer with a texture IMAGE sampled through per-face uvs (TexturesUV, hifihr_render_fwd_uv)")
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--max_iters", type=int, default=0, help="stop after this many iterations (0 = run the epochs)")
     ap.add_argument("--print_freq", type=int, default=50)
@@ -62,7 +63,7 @@ def build_args(cli):
             setattr(args, k, v)
     args.state_output = os.path.join(args.base_out_path, "model")       # options/train_options.py:208-220
     args.texture_stand_in = 0
-    if args.hand_model == "nimble" and cli.nimble_layer == "synthetic":
+    if args.hand_model == "nimble" and cli.nimble_layer in ("synthetic", "synthetic-uv"):
         print("[train_hrnet] hand_model 'nimble': NIMBLE-shaped layer on seeded synthetic tables (hifihr_amd/nimble_tables.py); the real "
               "NIMBLE assets are not available (SURVEY.md section 8 A9)")
     elif args.hand_model == "nimble":
@@ -216,9 +217,14 @@ def main(argv=None):
 
     tables = load_mano_pkl(cli.mano_pkl) if cli.mano_pkl else synthetic_mano_tables(0)
     torch.manual_seed(0)
+    nimble_tables = None
+    if args.hand_model == "nimble" and cli.nimble_layer == "synthetic-uv":
+        from hifihr_amd.nimble_tables import add_synthetic_uv, synthetic_nimble_tables
+        nimble_tables = add_synthetic_uv(synthetic_nimble_tables(0))
     model = Model(ifRender=args.render, device=device, if_4c=args.four_channel, hand_model=args.hand_model,
                   use_mean_shape=args.use_mean_shape, pretrain=args.pretrain, root_id=args.ROOT, root_id_nimble=args.ROOT_NIMBLE,
-                  ifLight=args.light_estimation, mano_tables=tables, texture_stand_in=args.texture_stand_in).to(device).train()
+                  ifLight=args.light_estimation, mano_tables=tables, texture_stand_in=args.texture_stand_in,
+                  nimble_tables=nimble_tables).to(device).train()
     frozen = freeze_model_modules(model, args)          # only_train_regressor / only_train_texture (train_hrnet.py:566)
     if frozen:
         say("[train_hrnet] frozen:", ", ".join(frozen))
