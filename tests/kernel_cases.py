@@ -237,7 +237,7 @@ def synthetic_uv_tables(faces_np, V, seed=0):
     return np.arange(3 * F_, dtype=np.int32).reshape(F_, 3), np.clip(uv, 0.05, 0.95).astype(np.float32)
 
 
-def render_uv_case(lib, tables, device, B, seed, image_size, aa, TH=24, TW=40, rgb_atol=3e-5, gtol=3e-3):
+def render_uv_case(lib, tables, device, B, seed, image_size, aa, TH=24, TW=40, rgb_atol=3e-5, gtol=3e-3, uv_scale=1.0):
     """hifihr_render_fwd_uv / _bwd_uv vs oracle/render_oracle.render(textures_uv=...) ([recalled] PyTorch3D TexturesUV semantics through
     torch's own grid_sample): face ids exact, pixels, and the gradients w.r.t. vertices (incl. the path through uv), texture maps, light."""
     from oracle import render_oracle as ro
@@ -245,6 +245,9 @@ def render_uv_case(lib, tables, device, B, seed, image_size, aa, TH=24, TW=40, r
     faces_np, V = tables.faces, 778
     faces = torch.as_tensor(faces_np).long()
     fu, vu = synthetic_uv_tables(faces_np, V, seed)
+    if uv_scale != 1.0:                         # uvs outside [0, 1]: grid_sample's border padding (clamped coordinate, zero uv gradient there)
+        vu = ((vu - 0.5) * uv_scale + 0.5).astype(np.float32)
+        assert (vu < 0).any() and (vu > 1).any()
     gen = torch.Generator().manual_seed(seed + 3)
     maps = torch.rand(B, TH, TW, 3, generator=gen)
     vr, mr, lcr, ldr = (t.clone().requires_grad_(True) for t in (verts, maps, lc, ld))

@@ -85,3 +85,8 @@ def test_render_textures_uv(lib, synth_tables, B, image_size, aa):
     """TexturesUV mode of the renderer (two passes around the fused tile kernels) vs the oracle's grid_sample restatement: face ids exact,
     pixels 1e-4, gradients w.r.t. vertices (incl. the path through uv), texture maps and light."""
     kc.render_uv_case(lib, synth_tables, "cuda", B=B, seed=90 + image_size, image_size=image_size, aa=aa, rgb_atol=1e-4)
+
+
+def test_render_textures_uv_border_padding(lib, synth_tables):
+    """uvs outside [0, 1] (border padding: clamped coordinate, no uv gradient there) and a tiny odd-sized texture."""
+    kc.render_uv_case(lib, synth_tables, "cuda", B=2, seed=97, image_size=96, aa=3, TH=9, TW=5, rgb_atol=1e-4, uv_scale=1.5)

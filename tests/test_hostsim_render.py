@@ -19,3 +19,7 @@ def test_render_fwd_bwd(hostsim_lib, synth_tables, image_size, aa):
 def test_render_textures_uv(hostsim_lib, synth_tables, image_size, aa):
     """TexturesUV mode (texuv_fwd / texuv_bwd kernels around the tile kernels) vs the oracle's grid_sample restatement."""
     kc.render_uv_case(hostsim_lib, synth_tables, "cpu", B=2, seed=30 + aa, image_size=image_size, aa=aa)
+
+
+def test_render_textures_uv_border_padding(hostsim_lib, synth_tables):
+    kc.render_uv_case(hostsim_lib, synth_tables, "cpu", B=1, seed=41, image_size=32, aa=2, TH=9, TW=5, uv_scale=1.5)
