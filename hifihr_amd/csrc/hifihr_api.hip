@@ -312,20 +312,19 @@ int hifihr_renderer_set_uv(hifihr_renderer_t* h, const int32_t* faces_uvs, const
 }
 
 size_t hifihr_render_uv_scratch_bytes(const hifihr_renderer_t* h, int B) {
-  if (!h || B <= 0) return 0;
-  const size_t S = (size_t)h->dev.H * h->dev.aa;
-  return (size_t)B * S * S * 4 * sizeof(float);
+  (void)h; (void)B;
+  return 0;                       // the texture is sampled inside the tile kernels: no per-sample scratch
 }
 
 int hifihr_render_fwd_uv(const hifihr_renderer_t* h, const float* verts, const float* maps, int TH, int TW, const float* cam,
                          const float* light_color, const float* light_dir, int B, float* rgba, int32_t* face_id, float* texels_scratch,
                          void* ws, void* stream) {
-  if (!h || !verts || !maps || TH < 1 || TW < 1 || !cam || !light_color || !light_dir || !rgba || !face_id || !texels_scratch || !ws || B < 0)
+  if (!h || !verts || !maps || TH < 1 || TW < 1 || !cam || !light_color || !light_dir || !rgba || !face_id || !ws || B < 0)
     return fail(HIFIHR_EINVAL, "hifihr_render_fwd_uv: bad argument");
+  (void)texels_scratch;
   if (h->n_uv == 0) return fail(HIFIHR_EINVAL, "hifihr_render_fwd_uv: no UV tables (hifihr_renderer_set_uv)");
   if (B == 0) return HIFIHR_OK;
-  const hifihr::TexUvPass uv{static_cast<const int*>(h->faces_uvs.p), static_cast<const float*>(h->verts_uvs.p), maps, nullptr, TH, TW,
-                             reinterpret_cast<float4*>(texels_scratch), nullptr};
+  const hifihr::TexUvPass uv{static_cast<const int*>(h->faces_uvs.p), static_cast<const float*>(h->verts_uvs.p), maps, nullptr, TH, TW};
   // (the vertex-colour input of the tile kernel is not used in this mode: any [V][3] buffer serves, the vertices themselves here)
   HIP_TRY(hifihr::launch_render_fwd(h->dev, verts, verts, (long)h->dev.V * 3, cam, light_color, light_dir, B, rgba, face_id, ws,
                                     (hipStream_t)stream, &uv));
@@ -336,13 +335,13 @@ int hifihr_render_bwd_uv(const hifihr_renderer_t* h, const float* verts, const f
                          const float* light_color, const float* light_dir, const int32_t* face_id, const float* grad_rgba, int B,
                          const float* texels_scratch, float* gtexels_scratch, float* gverts, float* gmaps_acc, float* glight_color,
                          float* glight_dir, void* ws, void* stream) {
-  if (!h || !verts || !maps || TH < 1 || TW < 1 || !cam || !light_color || !light_dir || !face_id || !grad_rgba || !texels_scratch ||
-      !gtexels_scratch || !gverts || !glight_color || !glight_dir || !ws || B < 0)
+  if (!h || !verts || !maps || TH < 1 || TW < 1 || !cam || !light_color || !light_dir || !face_id || !grad_rgba || !gverts || !glight_color ||
+      !glight_dir || !ws || B < 0)
     return fail(HIFIHR_EINVAL, "hifihr_render_bwd_uv: bad argument");
+  (void)texels_scratch; (void)gtexels_scratch;
   if (h->n_uv == 0) return fail(HIFIHR_EINVAL, "hifihr_render_bwd_uv: no UV tables (hifihr_renderer_set_uv)");
   if (B == 0) return HIFIHR_OK;
-  const hifihr::TexUvPass uv{static_cast<const int*>(h->faces_uvs.p), static_cast<const float*>(h->verts_uvs.p), maps, gmaps_acc, TH, TW,
-                             reinterpret_cast<float4*>(const_cast<float*>(texels_scratch)), reinterpret_cast<float4*>(gtexels_scratch)};
+  const hifihr::TexUvPass uv{static_cast<const int*>(h->faces_uvs.p), static_cast<const float*>(h->verts_uvs.p), maps, gmaps_acc, TH, TW};
   HIP_TRY(hifihr::launch_render_bwd(h->dev, verts, cam, light_color, light_dir, face_id, grad_rgba, B, gverts, nullptr, glight_color,
                                     glight_dir, ws, (hipStream_t)stream, &uv));
   return HIFIHR_OK;

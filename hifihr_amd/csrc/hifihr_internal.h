@@ -61,16 +61,14 @@ struct RenderDev {
 };
 
 size_t render_workspace_bytes(const RenderDev& r, int B);
-// TexturesUV mode of the renderer (csrc/render.hip texuv_*_kernel): per-face UV indices, UV coordinates, the texture maps of the batch,
-// per-sample scratch [B][S][S] float4 (texels: written by the forward, read by the backward; gtexels: backward only)
+// TexturesUV mode of the renderer (csrc/render.hip, template flag UV of the tile kernels): per-face UV indices, UV coordinates, the
+// texture maps of the batch
 struct TexUvPass {
   const int* faces_uvs;        // [F][3]
   const float* verts_uvs;      // [Vt][2]
   const float* maps;           // [B][TH][TW][3]
   float* gmaps;                // backward: [B][TH][TW][3], accumulated into; or null
   int TH, TW;
-  float4* texels;
-  float4* gtexels;
 };
 hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float* vcolors, long vcol_bstride, const float* cam,
                              const float* light_color, const float* light_dir, int B, float* rgba, int* face_id, void* ws,

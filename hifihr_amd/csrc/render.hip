@@ -111,6 +111,59 @@ __global__ __launch_bounds__(256) void render_bin_kernel(RenderDev r, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// TexturesUV (PyTorch3D renderer/mesh/textures.py TexturesUV.sample_textures [recalled]; reference models_res_nimble.py:203-208 hands the
+// NIMBLE texture image to the renderer this way): per sample, uv = sum_k bary_k uv[faces_uvs[f][k]] with the rasteriser's
+// perspective-corrected barycentrics, then F.grid_sample(flip(maps, vertical), 2 uv - 1, bilinear, align_corners=True, padding border).
+// Fused into the tile kernels' per-sample shading (template flag UV: the vertex-colour instantiations are unchanged): the forward
+// interpolates the face's three uvs with the barycentrics it already has and fetches four texels; the backward scatters d loss / d texel
+// into the texture (float atomics) and adds d texel / d uv . uv_k to the barycentric gradient, so the path to the vertices runs through the
+// same bary_bwd and per-vertex accumulators as every other attribute.
+// ------------------------------------------------------------------------------------------------
+struct UvSample { int x0, x1, y0, y1; float wx, wy; bool in_x, in_y; };      // rows are those of the UNFLIPPED map
+__device__ __forceinline__ UvSample uv_sample(float u, float v, int TH, int TW) {
+  UvSample q;
+  float ix = ((2.f * u - 1.f) + 1.f) * 0.5f * (float)(TW - 1);                 // grid_sample, align_corners = True
+  float iy = ((2.f * v - 1.f) + 1.f) * 0.5f * (float)(TH - 1);                 // row of the flipped map
+  q.in_x = ix >= 0.f && ix <= (float)(TW - 1);                                   // border padding: coordinates clipped (zero gradient outside)
+  q.in_y = iy >= 0.f && iy <= (float)(TH - 1);
+  ix = fminf(fmaxf(ix, 0.f), (float)(TW - 1));
+  iy = fminf(fmaxf(iy, 0.f), (float)(TH - 1));
+  const float fx = floorf(ix), fy = floorf(iy);
+  q.wx = ix - fx; q.wy = iy - fy;
+  q.x0 = (int)fx; q.x1 = min(q.x0 + 1, TW - 1);
+  const int r0 = (int)fy, r1 = min(r0 + 1, TH - 1);
+  q.y0 = TH - 1 - r0; q.y1 = TH - 1 - r1;                                        // un-flip
+  return q;
+}
+
+struct TexUvDev {
+  const int* faces_uvs;        // [F][3]
+  const float* verts_uvs;      // [Vt][2]
+  const float* maps;           // [B][TH][TW][3]
+  float* gmaps;                // [B][TH][TW][3] (backward; accumulated into) or null
+  int TH, TW;
+};
+
+// bilinear texel at (u, v) and, if asked, its derivatives with respect to the (clamped) pixel coordinates ix, iy
+__device__ __forceinline__ void uv_fetch(const TexUvDev& t, int b, const UvSample& q, float (&T)[3], float* dix, float* diy) {
+  const float* m = t.maps + (size_t)b * t.TH * t.TW * 3;
+  const float* p00 = m + ((size_t)q.y0 * t.TW + q.x0) * 3;
+  const float* p01 = m + ((size_t)q.y0 * t.TW + q.x1) * 3;
+  const float* p10 = m + ((size_t)q.y1 * t.TW + q.x0) * 3;
+  const float* p11 = m + ((size_t)q.y1 * t.TW + q.x1) * 3;
+  const float w00 = (1.f - q.wx) * (1.f - q.wy), w01 = q.wx * (1.f - q.wy), w10 = (1.f - q.wx) * q.wy, w11 = q.wx * q.wy;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v00 = p00[c], v01 = p01[c], v10 = p10[c], v11 = p11[c];
+    T[c] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+    if (dix != nullptr) {
+      dix[c] = (v01 - v00) * (1.f - q.wy) + (v11 - v10) * q.wy;
+      diy[c] = (v10 - v00) * (1.f - q.wx) + (v11 - v01) * q.wx;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward: raster + shade + resolve
 // ------------------------------------------------------------------------------------------------
 template <int AA>
@@ -298,14 +351,14 @@ __device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols
   HIFIHR_RC_STAMP(2)
 }
 
-template <int AA>
+template <int AA, bool UV>
 __global__ __launch_bounds__(kFwdThreads) void render_fwd_kernel(RenderDev r, const float4* __restrict__ vndc,
                                                         const float4* __restrict__ vpos, const float4* __restrict__ vnrm,
                                                         const float4* __restrict__ vcol, const float* __restrict__ light_color,
                                                         const float* __restrict__ light_dir, float* __restrict__ rgba,
                                                         int* __restrict__ face_id, int* __restrict__ tile_cnt,
-                                                        const int* __restrict__ tile_list, const float4* __restrict__ texels) {
-  // texels (or null): the texture colour of every sample [B][S][S] (TexturesUV, texuv_fwd_kernel below) instead of interpolated vertex colours
+                                                        const int* __restrict__ tile_list, TexUvDev tuv) {
+  // UV: the colour of a sample is the texture at its interpolated uv (TexturesUV, see above) instead of the interpolated vertex colour
   HIP_DYNAMIC_SHARED(float4, smem_raw)
   FwdLds<AA>& L = *reinterpret_cast<FwdLds<AA>*>(smem_raw);
   constexpr int SW = kTile * AA;
@@ -415,6 +468,7 @@ __global__ __launch_bounds__(kFwdThreads) void render_fwd_kernel(RenderDev r, co
   int cur_f = -1;
   FaceXYZ fc;
   float4 p0, p1, p2, n0, n1, n2, c0, c1, c2;
+  float fu[3] = {0.f, 0.f, 0.f}, fv[3] = {0.f, 0.f, 0.f};
   fc.x0 = fc.y0 = fc.z0 = fc.x1 = fc.y1 = fc.z1 = fc.x2 = fc.y2 = fc.z2 = 0.f;
   p0 = p1 = p2 = n0 = n1 = n2 = c0 = c1 = c2 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -436,6 +490,10 @@ __global__ __launch_bounds__(kFwdThreads) void render_fwd_kernel(RenderDev r, co
         p0 = vpos[vo + i0]; p1 = vpos[vo + i1]; p2 = vpos[vo + i2];
         n0 = vnrm[vo + i0]; n1 = vnrm[vo + i1]; n2 = vnrm[vo + i2];
         c0 = vcol[vo + i0]; c1 = vcol[vo + i1]; c2 = vcol[vo + i2];
+        if constexpr (UV) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { const int iu = tuv.faces_uvs[3 * f + k]; fu[k] = tuv.verts_uvs[2 * iu]; fv[k] = tuv.verts_uvs[2 * iu + 1]; }
+        }
       }
       float bary[3];
       bary_of(fc, sx[j], sy[i], bary);
@@ -445,9 +503,9 @@ __global__ __launch_bounds__(kFwdThreads) void render_fwd_kernel(RenderDev r, co
                           bary[0] * n0.z + bary[1] * n1.z + bary[2] * n2.z};
       float T[3] = {bary[0] * c0.x + bary[1] * c1.x + bary[2] * c2.x, bary[0] * c0.y + bary[1] * c1.y + bary[2] * c2.y,
                     bary[0] * c0.z + bary[1] * c1.z + bary[2] * c2.z};
-      if (texels != nullptr) {                                 // (uniform)
-        const float4 tx = texels[((size_t)b * S + (py * AA + i)) * S + (px * AA + j)];
-        T[0] = tx.x; T[1] = tx.y; T[2] = tx.z;
+      if constexpr (UV) {
+        const float u = bary[0] * fu[0] + bary[1] * fu[1] + bary[2] * fu[2], v = bary[0] * fv[0] + bary[1] * fv[1] + bary[2] * fv[2];
+        uv_fetch(tuv, b, uv_sample(u, v, tuv.TH, tuv.TW), T, nullptr, nullptr);
       }
       float rgb[3];
       shade_fwd(r.sc, Ld, P, N, T, rgb, nullptr);
@@ -483,14 +541,14 @@ __device__ __forceinline__ void flush_face(float* __restrict__ gv, const int* id
   }
 }
 
-template <int AA>
+template <int AA, bool UV>
 __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const float4* __restrict__ vndc,
                                                         const float4* __restrict__ vpos, const float4* __restrict__ vnrm,
                                                         const float4* __restrict__ vcol, const float* __restrict__ light_color,
                                                         const float* __restrict__ light_dir, const int* __restrict__ face_id,
                                                         const float* __restrict__ grad_rgba, float* __restrict__ gvrec,
                                                         float* __restrict__ glight_color, float* __restrict__ glight_dir,
-                                                        int use_lds, const float4* __restrict__ texels, float4* __restrict__ gtexels
+                                                        int use_lds, TexUvDev tuv
 #ifdef HIFIHR_RENDER_STAMP
                                                         , int* __restrict__ dbg_tiles
 #endif
@@ -575,7 +633,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
           pos[k][0] = p.x; pos[k][1] = p.y; pos[k][2] = p.z;
           nrm[k][0] = n.x; nrm[k][1] = n.y; nrm[k][2] = n.z;
           col[k][0] = t.x; col[k][1] = t.y; col[k][2] = t.z;
-          if (texels != nullptr) { col[k][0] = 0.f; col[k][1] = 0.f; col[k][2] = 0.f; }      // TexturesUV: the colour is no function of these
+          if constexpr (UV) { col[k][0] = 0.f; col[k][1] = 0.f; col[k][2] = 0.f; }            // TexturesUV: the colour is no function of these
         }
         float P[3], N[3], T[3];
 #pragma unroll
@@ -584,16 +642,39 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
           N[c3] = bary[0] * nrm[0][c3] + bary[1] * nrm[1][c3] + bary[2] * nrm[2][c3];
           T[c3] = bary[0] * col[0][c3] + bary[1] * col[1][c3] + bary[2] * col[2][c3];
         }
-        const size_t smp = ((size_t)b * S + (py * AA + i)) * S + (px * AA + j);
-        if (texels != nullptr) { const float4 tx = texels[smp]; T[0] = tx.x; T[1] = tx.y; T[2] = tx.z; }
+        float fu[3] = {0.f, 0.f, 0.f}, fv[3] = {0.f, 0.f, 0.f}, dix[3], diy[3];
+        UvSample q{};
+        if constexpr (UV) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { const int iu = tuv.faces_uvs[3 * f + k]; fu[k] = tuv.verts_uvs[2 * iu]; fv[k] = tuv.verts_uvs[2 * iu + 1]; }
+          const float u = bary[0] * fu[0] + bary[1] * fu[1] + bary[2] * fu[2], v = bary[0] * fv[0] + bary[1] * fv[1] + bary[2] * fv[2];
+          q = uv_sample(u, v, tuv.TH, tuv.TW);
+          uv_fetch(tuv, b, q, T, dix, diy);
+        }
         float gP[3], gN[3], gT[3];
         shade_bwd(r.sc, Ld, P, N, T, g_rgb, gP, gN, gT, glc, gl);
-        if (gtexels != nullptr) gtexels[smp] = make_float4(gT[0], gT[1], gT[2], 0.f);           // texuv_bwd_kernel takes it from here
+        float guv[2] = {0.f, 0.f};                               // d loss / d (u, v) of this sample
+        if constexpr (UV) {
+          float gix = 0.f, giy = 0.f;
+          const float w00 = (1.f - q.wx) * (1.f - q.wy), w01 = q.wx * (1.f - q.wy), w10 = (1.f - q.wx) * q.wy, w11 = q.wx * q.wy;
+          float* gm = tuv.gmaps != nullptr ? tuv.gmaps + (size_t)b * tuv.TH * tuv.TW * 3 : nullptr;
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {
+            if (gm != nullptr && gT[c3] != 0.f) {
+              atomicAdd(gm + ((size_t)q.y0 * tuv.TW + q.x0) * 3 + c3, gT[c3] * w00); atomicAdd(gm + ((size_t)q.y0 * tuv.TW + q.x1) * 3 + c3, gT[c3] * w01);
+              atomicAdd(gm + ((size_t)q.y1 * tuv.TW + q.x0) * 3 + c3, gT[c3] * w10); atomicAdd(gm + ((size_t)q.y1 * tuv.TW + q.x1) * 3 + c3, gT[c3] * w11);
+            }
+            gix += gT[c3] * dix[c3]; giy += gT[c3] * diy[c3];
+          }
+          guv[0] = q.in_x ? gix * (float)(tuv.TW - 1) : 0.f;     // d ix / d u = TW - 1; zero where grid_sample clipped the coordinate
+          guv[1] = q.in_y ? giy * (float)(tuv.TH - 1) : 0.f;
+        }
         float gb[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           gb[k] = gP[0] * pos[k][0] + gP[1] * pos[k][1] + gP[2] * pos[k][2] + gN[0] * nrm[k][0] + gN[1] * nrm[k][1] +
                   gN[2] * nrm[k][2] + gT[0] * col[k][0] + gT[1] * col[k][1] + gT[2] * col[k][2];
+          if constexpr (UV) gb[k] += guv[0] * fu[k] + guv[1] * fv[k];                            // the texel's dependence on the barycentrics
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) {
             acc[k * 12 + 3 + c3] += bary[k] * gP[c3];
@@ -727,124 +808,6 @@ static void carve(const RenderDev& r, int B, void* ws, float4** vndc, float4** v
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// TexturesUV (PyTorch3D renderer/mesh/textures.py TexturesUV.sample_textures [recalled]; reference models_res_nimble.py:203-208 hands the
-// NIMBLE texture image to the renderer this way): per sample, uv = sum_k bary_k uv[faces_uvs[f][k]] with the rasteriser's
-// perspective-corrected barycentrics, then F.grid_sample(flip(maps, vertical), 2 uv - 1, bilinear, align_corners=True, padding border).
-// Two-pass form around the fused tile kernels (not fused into them): the forward rasterises (face ids), texuv_fwd_kernel writes one texel
-// per sample, the tile kernel runs again and shades with those; the backward's tile kernel leaves d loss / d texel per sample and
-// texuv_bwd_kernel scatters it into the texture (float atomics) and, through d texel / d uv, into the vertices' NDC gradients.
-// ------------------------------------------------------------------------------------------------
-struct UvSample { int x0, x1, y0, y1; float wx, wy; bool in_x, in_y; };      // rows are those of the UNFLIPPED map
-__device__ __forceinline__ UvSample uv_sample(float u, float v, int TH, int TW) {
-  UvSample q;
-  float ix = ((2.f * u - 1.f) + 1.f) * 0.5f * (float)(TW - 1);                 // grid_sample, align_corners = True
-  float iy = ((2.f * v - 1.f) + 1.f) * 0.5f * (float)(TH - 1);                 // row of the flipped map
-  q.in_x = ix >= 0.f && ix <= (float)(TW - 1);                                   // border padding: coordinates clipped (zero gradient outside)
-  q.in_y = iy >= 0.f && iy <= (float)(TH - 1);
-  ix = fminf(fmaxf(ix, 0.f), (float)(TW - 1));
-  iy = fminf(fmaxf(iy, 0.f), (float)(TH - 1));
-  const float fx = floorf(ix), fy = floorf(iy);
-  q.wx = ix - fx; q.wy = iy - fy;
-  q.x0 = (int)fx; q.x1 = min(q.x0 + 1, TW - 1);
-  const int r0 = (int)fy, r1 = min(r0 + 1, TH - 1);
-  q.y0 = TH - 1 - r0; q.y1 = TH - 1 - r1;                                        // un-flip
-  return q;
-}
-
-struct TexUvDev {
-  const int* faces_uvs;        // [F][3]
-  const float* verts_uvs;      // [Vt][2]
-  const float* maps;           // [B][TH][TW][3]
-  float* gmaps;                // [B][TH][TW][3] (backward; accumulated into) or null
-  int TH, TW;
-};
-
-__device__ __forceinline__ bool uv_of_sample(const RenderDev& r, const TexUvDev& t, const float4* __restrict__ vb, int f, float sx, float sy,
-                                             FaceXYZ& fc, float (&bary)[3], float (&fu)[3], float (&fv)[3], float& u, float& v) {
-  const float4 a = vb[r.faces[3 * f]], c = vb[r.faces[3 * f + 1]], d = vb[r.faces[3 * f + 2]];
-  fc.x0 = a.x; fc.y0 = a.y; fc.z0 = a.z; fc.x1 = c.x; fc.y1 = c.y; fc.z1 = c.z; fc.x2 = d.x; fc.y2 = d.y; fc.z2 = d.z;
-  bary_of(fc, sx, sy, bary);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { const int iu = t.faces_uvs[3 * f + k]; fu[k] = t.verts_uvs[2 * iu]; fv[k] = t.verts_uvs[2 * iu + 1]; }
-  u = bary[0] * fu[0] + bary[1] * fu[1] + bary[2] * fu[2];
-  v = bary[0] * fv[0] + bary[1] * fv[1] + bary[2] * fv[2];
-  return true;
-}
-
-// thread = sample; grid (ceil(S^2 / 256), B)
-__global__ __launch_bounds__(256) void texuv_fwd_kernel(RenderDev r, TexUvDev t, const float4* __restrict__ vndc, const int* __restrict__ face_id,
-                                                       int S, float4* __restrict__ texels) {
-  const int b = blockIdx.y;
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= S * S) return;
-  const int sy = s / S, sx = s - sy * S;
-  const int f = face_id[(size_t)b * S * S + s];
-  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (f >= 0) {
-    FaceXYZ fc;
-    float bary[3], fu[3], fv[3], u, v;
-    uv_of_sample(r, t, vndc + (size_t)b * r.V, f, pix_to_ndc(S - 1 - sx, S), pix_to_ndc(S - 1 - sy, S), fc, bary, fu, fv, u, v);
-    const UvSample q = uv_sample(u, v, t.TH, t.TW);
-    const float* m = t.maps + (size_t)b * t.TH * t.TW * 3;
-    const float* p00 = m + ((size_t)q.y0 * t.TW + q.x0) * 3;
-    const float* p01 = m + ((size_t)q.y0 * t.TW + q.x1) * 3;
-    const float* p10 = m + ((size_t)q.y1 * t.TW + q.x0) * 3;
-    const float* p11 = m + ((size_t)q.y1 * t.TW + q.x1) * 3;
-    const float w00 = (1.f - q.wx) * (1.f - q.wy), w01 = q.wx * (1.f - q.wy), w10 = (1.f - q.wx) * q.wy, w11 = q.wx * q.wy;
-    out.x = p00[0] * w00 + p01[0] * w01 + p10[0] * w10 + p11[0] * w11;
-    out.y = p00[1] * w00 + p01[1] * w01 + p10[1] * w10 + p11[1] * w11;
-    out.z = p00[2] * w00 + p01[2] * w01 + p10[2] * w10 + p11[2] * w11;
-  }
-  texels[(size_t)b * S * S + s] = out;
-}
-
-__global__ __launch_bounds__(256) void texuv_bwd_kernel(RenderDev r, TexUvDev t, const float4* __restrict__ vndc, const int* __restrict__ face_id,
-                                                       int S, const float4* __restrict__ gtexels, float* __restrict__ gvrec) {
-  const int b = blockIdx.y;
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= S * S) return;
-  const int f = face_id[(size_t)b * S * S + s];
-  if (f < 0) return;
-  const int sy = s / S, sx = s - sy * S;
-  const float4 g = gtexels[(size_t)b * S * S + s];
-  FaceXYZ fc;
-  float bary[3], fu[3], fv[3], u, v;
-  const float px = pix_to_ndc(S - 1 - sx, S), py = pix_to_ndc(S - 1 - sy, S);
-  uv_of_sample(r, t, vndc + (size_t)b * r.V, f, px, py, fc, bary, fu, fv, u, v);
-  const UvSample q = uv_sample(u, v, t.TH, t.TW);
-  const size_t mo = (size_t)b * t.TH * t.TW * 3;
-  const size_t o00 = ((size_t)q.y0 * t.TW + q.x0) * 3, o01 = ((size_t)q.y0 * t.TW + q.x1) * 3;
-  const size_t o10 = ((size_t)q.y1 * t.TW + q.x0) * 3, o11 = ((size_t)q.y1 * t.TW + q.x1) * 3;
-  const float w00 = (1.f - q.wx) * (1.f - q.wy), w01 = q.wx * (1.f - q.wy), w10 = (1.f - q.wx) * q.wy, w11 = q.wx * q.wy;
-  const float gc[3] = {g.x, g.y, g.z};
-  float gix = 0.f, giy = 0.f;
-  const float* m = t.maps + mo;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    if (t.gmaps != nullptr) {
-      atomicAdd(t.gmaps + mo + o00 + c, gc[c] * w00); atomicAdd(t.gmaps + mo + o01 + c, gc[c] * w01);
-      atomicAdd(t.gmaps + mo + o10 + c, gc[c] * w10); atomicAdd(t.gmaps + mo + o11 + c, gc[c] * w11);
-    }
-    const float v00 = m[o00 + c], v01 = m[o01 + c], v10 = m[o10 + c], v11 = m[o11 + c];
-    gix += gc[c] * ((v01 - v00) * (1.f - q.wy) + (v11 - v10) * q.wy);
-    giy += gc[c] * ((v10 - v00) * (1.f - q.wx) + (v11 - v01) * q.wx);
-  }
-  const float gu = q.in_x ? gix * (float)(t.TW - 1) : 0.f;      // d ix / d u = (TW - 1); zero where the coordinate was clipped
-  const float gv = q.in_y ? giy * (float)(t.TH - 1) : 0.f;
-  if (gu == 0.f && gv == 0.f) return;
-  const float gb[3] = {gu * fu[0] + gv * fv[0], gu * fu[1] + gv * fv[1], gu * fu[2] + gv * fv[2]};
-  float gn[9];
-  bary_bwd(fc, px, py, gb, gn);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float* dst = gvrec + ((size_t)b * r.V + r.faces[3 * f + k]) * 12;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      if (gn[3 * k + c] != 0.f) atomicAdd(dst + c, gn[3 * k + c]);
-  }
-}
-
 hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float* vcolors, long vcol_bstride, const float* cam,
                              const float* light_color, const float* light_dir, int B, float* rgba, int* face_id, void* ws,
                              hipStream_t st, const TexUvPass* uv) {
@@ -858,14 +821,13 @@ hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float
   const dim3 grid(tiles, tiles, B), bgrid((r.F + 255) / 256, B);
 #define HIFIHR_RENDER_FWD(AA_)                                                                                                          \
   hipLaunchKernelGGL(render_bin_kernel<AA_>, bgrid, dim3(256), 0, st, r, vndc, tile_cnt, tile_list);                                    \
-  hipLaunchKernelGGL(render_fwd_kernel<AA_>, grid, dim3(kFwdThreads), sizeof(FwdLds<AA_>), st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, \
-                     rgba, face_id, tile_cnt, tile_list, (const float4*)nullptr);                                                       \
   if (uv != nullptr) {                                                                                                                  \
     const TexUvDev td{uv->faces_uvs, uv->verts_uvs, uv->maps, nullptr, uv->TH, uv->TW};                                                 \
-    const int S_ = r.H * AA_;                                                                                                           \
-    hipLaunchKernelGGL(texuv_fwd_kernel, dim3((S_ * S_ + 255) / 256, B), dim3(256), 0, st, r, td, vndc, face_id, S_, uv->texels);       \
-    hipLaunchKernelGGL(render_fwd_kernel<AA_>, grid, dim3(kFwdThreads), sizeof(FwdLds<AA_>), st, r, vndc, vpos, vnrm, vcol, light_color, \
-                       light_dir, rgba, face_id, tile_cnt, tile_list, (const float4*)uv->texels);                                       \
+    hipLaunchKernelGGL((render_fwd_kernel<AA_, true>), grid, dim3(kFwdThreads), sizeof(FwdLds<AA_>), st, r, vndc, vpos, vnrm, vcol,      \
+                       light_color, light_dir, rgba, face_id, tile_cnt, tile_list, td);                                                 \
+  } else {                                                                                                                              \
+    hipLaunchKernelGGL((render_fwd_kernel<AA_, false>), grid, dim3(kFwdThreads), sizeof(FwdLds<AA_>), st, r, vndc, vpos, vnrm, vcol,     \
+                       light_color, light_dir, rgba, face_id, tile_cnt, tile_list, TexUvDev{});                                         \
   }
   switch (r.aa) {
     case 1: HIFIHR_RENDER_FWD(1) break;
@@ -903,19 +865,21 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
   const size_t lds = (size_t)r.V * 12 * sizeof(float);
   const int use_lds = lds <= 60 * 1024;               // MANO: 37 KB; larger meshes fall back to direct global atomics
   const size_t dyn = use_lds ? lds : 0;
-  const float4* tx_ = uv != nullptr ? uv->texels : nullptr;
-  float4* gtx_ = uv != nullptr ? uv->gtexels : nullptr;
+  const TexUvDev td = uv != nullptr ? TexUvDev{uv->faces_uvs, uv->verts_uvs, uv->maps, uv->gmaps, uv->TH, uv->TW} : TexUvDev{};
   switch (r.aa) {
-    case 1: hipLaunchKernelGGL(render_bwd_kernel<1>, grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, tx_, gtx_ HIFIHR_BWD_DBG); break;
-    case 2: hipLaunchKernelGGL(render_bwd_kernel<2>, grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, tx_, gtx_ HIFIHR_BWD_DBG); break;
-    case 3: hipLaunchKernelGGL(render_bwd_kernel<3>, grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, tx_, gtx_ HIFIHR_BWD_DBG); break;
+    case 1:
+      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<1, true>), grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      else hipLaunchKernelGGL((render_bwd_kernel<1, false>), grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      break;
+    case 2:
+      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<2, true>), grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      else hipLaunchKernelGGL((render_bwd_kernel<2, false>), grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      break;
+    case 3:
+      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<3, true>), grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      else hipLaunchKernelGGL((render_bwd_kernel<3, false>), grid, dim3(256), dyn, st, r, vndc, vpos, vnrm, vcol, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      break;
     default: return hipErrorInvalidValue;
-  }
-  if (uv != nullptr) {
-    const TexUvDev td{uv->faces_uvs, uv->verts_uvs, uv->maps, uv->gmaps, uv->TH, uv->TW};
-    const int S_ = r.H * r.aa;
-    hipLaunchKernelGGL(texuv_bwd_kernel, dim3((S_ * S_ + 255) / 256, B), dim3(256), 0, st, r, td, vndc, face_id, S_, (const float4*)uv->gtexels,
-                       gvrec);
   }
   hipLaunchKernelGGL(render_vertex_bwd_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, cam, vndc, vnrm, gvrec, gverts, gvcolors);
   return hipGetLastError();

@@ -266,11 +266,10 @@ class _RenderUV(torch.autograd.Function):
         rgba = torch.empty(B, 4, H, H, device=verts.device)
         face_id = torch.empty(B, S, S, dtype=torch.int32, device=verts.device)
         ws = handle.workspace(B, verts.device)
-        texels = torch.empty(B, S, S, 4, device=verts.device)
         PROFILE.bracket("render_fwd_uv", lambda: handle.lib.render_fwd_uv(handle.h, verts, maps, cam, light_color, light_dir, rgba, face_id,
-                                                                         texels, ws))
+                                                                         None, ws))
         ctx.handle, ctx.ws = handle, ws
-        ctx.save_for_backward(verts, maps, cam, light_color, light_dir, face_id, texels)
+        ctx.save_for_backward(verts, maps, cam, light_color, light_dir, face_id)
         ctx.mark_non_differentiable(face_id)
         ctx.set_materialize_grads(False)
         return rgba, face_id
@@ -279,15 +278,14 @@ class _RenderUV(torch.autograd.Function):
     def backward(ctx, grad_rgba, _):
         if grad_rgba is None:
             return (None,) * 6
-        verts, maps, cam, light_color, light_dir, face_id, texels = ctx.saved_tensors
+        verts, maps, cam, light_color, light_dir, face_id = ctx.saved_tensors
         handle = ctx.handle
         B = verts.shape[0]
         gverts = torch.empty_like(verts)
         gmaps = torch.zeros_like(maps) if ctx.needs_input_grad[2] else None
         gl = torch.empty(2, B, 3, device=verts.device)
-        gtexels = torch.empty_like(texels)
         PROFILE.bracket("render_bwd_uv", lambda: handle.lib.render_bwd_uv(handle.h, verts, maps, cam, light_color, light_dir, face_id,
-                                                                         grad_rgba.contiguous(), texels, gtexels, gverts, gmaps, gl[0], gl[1],
+                                                                         grad_rgba.contiguous(), None, None, gverts, gmaps, gl[0], gl[1],
                                                                          ctx.ws))
         return None, gverts, gmaps, None, gl[0], gl[1]
 

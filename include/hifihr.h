@@ -150,11 +150,10 @@ int hifihr_render_bwd(const hifihr_renderer_t* h, const float* verts_d, const fl
 /* TexturesUV mode (PyTorch3D renderer/mesh/textures.py TexturesUV.sample_textures [recalled]; the reference hands NIMBLE's texture image to
  * the renderer this way, models_res_nimble.py:203-208): per sample uv = sum_k bary_k * verts_uvs[faces_uvs[f][k]] with the rasteriser's
  * perspective-corrected barycentrics, texel = grid_sample(flip(maps, vertical), 2 uv - 1, bilinear, align_corners = True, border padding),
- * shaded like a vertex colour.  Two passes around the fused tile kernels: rasterise -> one texel per sample -> shade; the backward returns
+ * shaded like a vertex colour -- inside the fused tile kernels' per-sample shading (a template flag of theirs); the backward returns
  * d loss / d maps (float atomics into gmaps_acc_d, which the caller zeroes) and d loss / d verts including the path through uv.
  *   hifihr_renderer_set_uv(h, faces_uvs_h[F][3], verts_uvs_h[n_uv][2], n_uv)   once per renderer
- *   maps_d[B][TH][TW][3]; texels_scratch_d / gtexels_scratch_d: hifihr_render_uv_scratch_bytes(h, B) bytes each (the forward's texels are
- *   read again by the backward) */
+ *   maps_d[B][TH][TW][3]; texels_scratch_d / gtexels_scratch_d: reserved, pass NULL (hifihr_render_uv_scratch_bytes returns 0) */
 int hifihr_renderer_set_uv(hifihr_renderer_t* h, const int32_t* faces_uvs_h, const float* verts_uvs_h, int n_uv);
 size_t hifihr_render_uv_scratch_bytes(const hifihr_renderer_t* h, int B);
 int hifihr_render_fwd_uv(const hifihr_renderer_t* h, const float* verts_d, const float* maps_d, int TH, int TW, const float* cam_d,

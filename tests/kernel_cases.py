@@ -261,8 +261,8 @@ def render_uv_case(lib, tables, device, B, seed, image_size, aa, TH=24, TW=40, r
         d = lambda t: t.to(device).contiguous()
         rgba = torch.empty(B, 4, image_size, image_size, device=device)
         fid = torch.empty(B, S, S, dtype=torch.int32, device=device)
-        texels = torch.empty(B, S, S, 4, device=device); gtexels = torch.empty_like(texels)
-        assert lib.render_uv_scratch_bytes(h, B) == texels.numel() * 4
+        texels = gtexels = None                                     # (reserved arguments: the texture is sampled inside the tile kernels)
+        assert lib.render_uv_scratch_bytes(h, B) == 0
         dv, dm, dcam, dlc, dld = d(verts), d(maps), d(cam), d(lc), d(ld)
         lib.render_fwd_uv(h, dv, dm, dcam, dlc, dld, rgba, fid, texels, ws)
         assert (p2f_ref >= 0).mean() > 0.02, "test mesh barely visible"
