@@ -202,7 +202,7 @@ class FreiHandDeviceCache:
 # ------------------------------------------------------------------------------------------------
 def ho3d_crop_windows(uv21, center_noise, scale_noise, inp_res=224, img_wh=(640.0, 480.0)):
     """The crop window of every sample of a batch, the reference's float32 arithmetic (dataset.py:1106-1161, `ho_scope = 0`), stacked.
-    uv21 [B,21,2] projected joints (u, v); center_noise [B,2] = 5 * randn(2) per sample (:1120); scale_noise [B] =
+    uv21 [B,P,2] the points the window is formed from: the 21 projected joints (u, v), or the 2 corners of the evaluation split's hand box; center_noise [B,2] = 5 * randn(2) per sample (:1120); scale_noise [B] =
     (1 - 1.1) * rand(1) + 1 - 0.1 (:1126).  `int / tensor` is tensor.reciprocal() * int in torch, hence the two-step divisions.
     -> crop_center [B,2], scale [B], size [B] (= crop_size_scales), box int32 [B,4] = the (x0, y0, x1, y1) Pillow's Image.crop makes of
     (x1, y1, x1 + size, y1 + size): Python round(), half to even."""
@@ -235,7 +235,10 @@ class HO3DDeviceCache:
     `traineval.data_dic` reads -- img_crop, hand_mask_crop, K_crop, uv21_crop, xyz21 -- with every tensor on the device: one staged
     copy of 32 bytes per sample and three launches (hifihr_ho3d_batch); pixels bit-exact with the reference's PIL path."""
 
-    def __init__(self, images_u8, hand_masks_u8, Ks, xyz21, device="cuda", inp_res=224):
+    def __init__(self, images_u8, hand_masks_u8, Ks, xyz21, device="cuda", inp_res=224, bboxes=None, root_xyz=None):
+        """bboxes [n,2,2] ((x0, y0), (x1, y1)) + root_xyz [n,3]: the EVALUATION split, which carries a hand bounding box and the root joint
+        instead of 21 joints (dataset.py:1071-1080): the crop window is then formed from the box corners, and `batch` also returns
+        `root_xyz` with y / z negated as those lines do."""
         images_u8 = torch.as_tensor(images_u8)
         n, H, W, _ = images_u8.shape
         rgbx = torch.zeros(n, H, W, 4, dtype=torch.uint8)
@@ -247,6 +250,10 @@ class HO3DDeviceCache:
         xyz21 = torch.as_tensor(xyz21, dtype=torch.float32)
         uvw = (xyz21.unsqueeze(2) * Ks.unsqueeze(1)).sum(3)                    # proj_func (fh_utils.py:30-39), dataset.py:1093
         self.uv21_host = (uvw[:, :, :2] / uvw[:, :, 2:3]).numpy()
+        self.window_pts = np.asarray(bboxes, dtype=np.float32) if bboxes is not None else self.uv21_host     # what the crop window is formed from
+        self.root_xyz = None
+        if root_xyz is not None:                                                   # dataset.py:1078-1080
+            self.root_xyz = (torch.as_tensor(root_xyz, dtype=torch.float32) * torch.tensor([1.0, -1.0, -1.0])).to(device)
         self.Ks, self.xyz21, self.uv21 = Ks.to(device), xyz21.to(device), torch.from_numpy(self.uv21_host).to(device)
         self.n, self.H, self.W, self.device, self.inp_res = n, H, W, torch.device(device), inp_res
         self.lib = get_lib()
@@ -262,7 +269,7 @@ class HO3DDeviceCache:
             draws = [(5 * torch.randn(2, generator=generator), (1 - 1.1) * torch.rand(1, generator=generator) + 1 - 0.1) for _ in range(B)]
             center_noise = torch.stack([d[0] for d in draws]).numpy()
             scale_noise = torch.cat([d[1] for d in draws]).numpy()
-        center, scale, _, box = ho3d_crop_windows(self.uv21_host[idxs.numpy()], center_noise, scale_noise, self.inp_res, (float(self.W), float(self.H)))
+        center, scale, _, box = ho3d_crop_windows(self.window_pts[idxs.numpy()], center_noise, scale_noise, self.inp_res, (float(self.W), float(self.H)))
         slot, host = self._stage(8 * B)
         hv = host.numpy()
         hv[:B] = idxs.numpy().astype(np.int32)
@@ -281,4 +288,6 @@ class HO3DDeviceCache:
                "K_crop": torch.empty(B, 3, 3, device=dev), "uv21_crop": torch.empty(B, 21, 2, device=dev),
                "xyz21": torch.empty(B, 21, 3, device=dev)}
         self.lib.ho3d_batch(self.images, self.masks, self.Ks, self.uv21, self.xyz21, packed, B, S, self._ws, out)
+        if self.root_xyz is not None:
+            out["root_xyz"] = self.root_xyz[idxs.to(self.device)]
         return out

@@ -206,6 +206,17 @@ def test_ho3d_device_cache_matches_oracle_sample():
     assert ex["imgs"].shape == (4, 3, 224, 224) and ex["segms_gt"].dtype == torch.int64 and ex["j2d_gt"].shape == (4, 21, 2)
     r = cache.batch(order, generator=torch.Generator().manual_seed(1))          # the loader's own noise draws
     assert r["img_crop"].shape == (4, 3, 224, 224) and torch.isfinite(r["K_crop"]).all()
+    # evaluation split: the window comes from the hand bounding box, root_xyz is returned with y / z negated (dataset.py:1071-1080)
+    boxes = np.array([[[150.0, 100.0], [260.0, 210.0]], [[400.0, 300.0], [630.0, 470.0]], [[10.0, 20.0], [90.0, 140.0]]], np.float32)
+    roots = rng.normal(size=(n, 3)).astype(np.float32)
+    ev = HO3DDeviceCache(imgs, masks, Ks, xyz, bboxes=boxes, root_xyz=roots)
+    e = ev.batch(order, center_noise=noise, scale_noise=snoise)
+    for b, i in enumerate(order):
+        win = ho.crop_window(boxes[i], noise[b], float(snoise[b]))
+        top, left, size = float(win["y1"]), float(win["x1"]), float(win["crop_size_scales"])
+        want = ho.resized_crop_u8(imgs[i], top, left, size, size, 224, "bilinear").transpose(2, 0, 1).astype(np.float32) / np.float32(255)
+        assert torch.equal(e["img_crop"][b].cpu(), torch.from_numpy(want)), b
+        assert torch.equal(e["root_xyz"][b].cpu(), torch.from_numpy(roots[i] * np.array([1, -1, -1], np.float32)))
 
 
 def test_evaluator_summary_matches_formulas(golden_dir):
