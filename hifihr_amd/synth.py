@@ -13,8 +13,10 @@ from . import ops
 
 @torch.no_grad()
 def make_batch(mano_handle: ops.ManoLayerHandle, renderer: ops.RendererHandle, B: int, first_index: int = 0,
-               device="cuda", image_size=224):
-    """Deterministic in (first_index, B): sample i uses seed 1234 + first_index + i."""
+               device="cuda", image_size=224, images="noise"):
+    """Deterministic in (first_index, B): sample i uses seed 1234 + first_index + i.
+    images: "noise" (uniform noise, unrelated to the pose: timing / parity inputs) or "render" (the posed hand, lit, over dim noise:
+    an image the pose can be read from, for training runs that are expected to learn)."""
     rows = []
     for i in range(B):
         g = torch.Generator().manual_seed(1234 + first_index + i)
@@ -58,6 +60,13 @@ def make_batch(mano_handle: ops.ManoLayerHandle, renderer: ops.RendererHandle, B
     mask = (rgba[:, 3:4] > 0).float().repeat(1, 3, 1, 1)
     gi = torch.Generator(device="cpu").manual_seed(1234 + first_index)
     imgs = torch.rand(B, 3, image_size, image_size, generator=gi)
+    if images == "render":
+        lit, _ = ops.render(renderer, verts_w.contiguous(), col, cam, torch.full((B, 3), 0.7, device=device),
+                            torch.tensor([0.35, 0.35, -0.87], device=device).repeat(B, 1))
+        a = mask.cpu()
+        imgs = a * lit[:, :3].clamp(0, 1).cpu() + (1 - a) * 0.25 * imgs
+    elif images != "noise":
+        raise ValueError(f"images={images!r}")
     scales = (joints_w[:, 9] - joints_w[:, 10]).norm(dim=-1)
     return {
         "trans_images": imgs, "trans_Ks": Kp.cpu(), "trans_joints": joints_w.cpu(), "trans_verts": verts_w.cpu(),

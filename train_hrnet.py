@@ -92,7 +92,7 @@ def load_or_make_dataset(cli, model, device):
     else:
         mano, rend = model.hand_layer.handle, model.renderer_p3d
     for first in range(0, n, 64):
-        s = synth.make_batch(mano, rend, min(64, n - first), first_index=first, device=device)
+        s = synth.make_batch(mano, rend, min(64, n - first), first_index=first, device=device, images="render")
         parts.append({"images": (s["trans_images"].permute(0, 2, 3, 1) * 255).round().to(torch.uint8).numpy(),
                       "masks": (s["trans_masks"][:, 0] * 255).to(torch.uint8).numpy(), "Ks": s["trans_Ks"].numpy(),
                       "joints": s["trans_joints"].numpy(), "verts": s["trans_verts"].numpy()})
