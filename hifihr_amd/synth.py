@@ -95,7 +95,7 @@ def to_ho3d_sample(sample: dict, crop: int = 448) -> dict:
     }
 
 
-def make_ho3d_frames(mano_handle, renderer, n: int, first_index: int = 0, device="cuda", frame_hw=(480, 640)):
+def make_ho3d_frames(mano_handle, renderer, n: int, first_index: int = 0, device="cuda", frame_hw=(480, 640), images="noise"):
     """Synthetic HO-3D-shaped raw frames for `data.HO3DDeviceCache`: the 224 x 224 synthetic hand of `make_batch` pasted into a 480 x 640
     frame at a per-sample offset (grey background), the intrinsics moved with it, everything in the HO-3D loader's conventions
     (reference data/dataset.py:1065-1068, 1093: `Ks = camMat . cam_extr` with the OpenGL flip, joints in the HO-3D order with y / z negated --
@@ -109,7 +109,7 @@ def make_ho3d_frames(mano_handle, renderer, n: int, first_index: int = 0, device
     step = 32
     for lo in range(0, n, step):
         m = min(step, n - lo)
-        b = make_batch(mano_handle, renderer, m, first_index=first_index + lo, device=device)
+        b = make_batch(mano_handle, renderer, m, first_index=first_index + lo, device=device, images=images)
         im = (b["trans_images"].clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).cpu()
         mk = (b["trans_masks"][:, 0] > 0.5).to(torch.uint8).mul(255).cpu()
         K, J = b["trans_Ks"].cpu(), b["trans_joints"].cpu()

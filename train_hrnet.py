@@ -116,7 +116,7 @@ def train_ho3d(cli, args, model, loss_func, opt, sched, reducer, current_epoch, 
         from hifihr_amd.mano_tables import synthetic_mano_tables
         mt = synthetic_mano_tables(0)
         frames = synth.make_ho3d_frames(ops.ManoLayerHandle(mt), ops.RendererHandle(mt.faces, 778, image_size=224, aa=3), cli.synthetic_size,
-                                        device=device)
+                                        device=device, images="render")
     cache = HO3DDeviceCache(**frames, device=device)
     say(f"[train_hrnet] HO3D: {cache.n} frames resident on {device}; world {world}; encoder {args.pretrain}; losses {args.losses}")
     B = args.train_batch
