@@ -128,6 +128,9 @@ def _forward_backward(model, loss_func, optimizer, examples, args, dat_name):
     if any(k in args.losses for k in ("joint_2d", "bone_direc")):
         outputs["j2d"] = trans_proj_j2d(outputs, examples["Ks"], root_xyz=root_xyz)      # only these terms read it
     loss_dic = loss_func(ex, outputs, args.losses, dat_name, args)
+    missing = [k for k in args.losses if k not in loss_dic]
+    if missing:                              # e.g. 'mtex' on a hand layer without texture_params, 'vert_3d' on a dataset without vertices
+        raise KeyError(f"loss terms {missing} were requested but not produced for {dat_name}: their inputs are absent from the model outputs / examples")
     terms = [loss_dic[k] for k in args.losses]
     loss = terms[0] if len(terms) == 1 else torch.stack(terms).sum()      # 2 launches instead of a chain of adds
     loss_dic["loss"] = loss
