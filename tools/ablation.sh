@@ -1,0 +1,22 @@
+#!/bin/bash
+# What each dispatch decision buys on the FINAL tree: bench.py (BASELINE configs[1], hipGraph replay, 30 steps) with one switch off at a time.
+# usage (GPU box, through gpurun): bash tools/ablation.sh > gpurun_out/r02_ablation.txt
+cd $GRAFT_REPO_ROOT
+run() {   # label, then VAR=value assignments / bench flags
+  label=$1; shift
+  envs=(); flags=()
+  for a in "$@"; do if [[ $a == --* || $a =~ ^[0-9]+$ ]]; then flags+=("$a"); else envs+=("$a"); fi; done
+  ms=$(env "${envs[@]}" python3 bench.py --no-cpu-baseline --steps 30 --warmup 5 "${flags[@]}" 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3f ms/step  %.0f img/s' % (d['ms_per_step'], d['value']))")
+  printf "%-58s %s\n" "$label" "$ms"
+}
+run "default (final tree)"
+run "stem BN+ReLU+max-pool unfused (HIFIHR_BN_POOL=0)" HIFIHR_BN_POOL=0
+run "1x1 convolutions on the implicit GEMM (HIFIHR_CONV1X1_GEMM=0)" HIFIHR_CONV1X1_GEMM=0
+run "TN row-share kernel off (HIFIHR_GEMM_TN_ROWS=0)" HIFIHR_GEMM_TN_ROWS=0
+run "NT row-share kernel off (HIFIHR_GEMM_ROWS=0)" HIFIHR_GEMM_ROWS=0
+run "layer-1 halo kernel off (HIFIHR_CONV_HALO=0)" HIFIHR_CONV_HALO=0
+run "layer-1 halo weight gradient off (HIFIHR_CONV_HALO_WGRAD=0)" HIFIHR_CONV_HALO_WGRAD=0
+run "Winograd F(2x2) instead of F(4x4) (HIFIHR_WINO_M=2)" HIFIHR_WINO_M=2
+run "no Winograd at all (HIFIHR_WINOGRAD=0)" HIFIHR_WINOGRAD=0
+run "stem kernel off (HIFIHR_CONV_STEM=0)" HIFIHR_CONV_STEM=0
+run "eager launches, no hipGraph (--graph 0)" --graph 0
