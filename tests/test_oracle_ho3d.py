@@ -64,3 +64,18 @@ def test_product_window_code_matches_oracle_and_reference(g):
         assert tuple(box[k]) == ho.pil_crop_box(float(win["x1"]), float(win["y1"]), float(size[k]), float(size[k]))
     for i in range(int(g["n"])):
         assert scale[i] == g[f"scale{i}"][0] and size[i] == g[f"size{i}"][0]
+
+
+def test_product_window_from_hand_box_corners():
+    """The evaluation split (dataset.py:1071-1080) forms the window from the two corners of the hand bounding box: the batched host code on
+    [B, 2, 2] points == the oracle's lines on the same two points (boxes inside, across the border of and larger than the 640 x 480 frame)."""
+    from hifihr_amd.data import ho3d_crop_windows
+    rng = np.random.default_rng(11)
+    boxes = np.array([[[150, 100], [260, 210]], [[400, 300], [700, 520]], [[-30, -20], [90, 140]], [[0, 0], [640, 480]], [[300, 200], [304, 203]]], np.float32)
+    noise = (rng.normal(size=(len(boxes), 2)) * 5).astype(np.float32)
+    sn = (0.9 - 0.1 * rng.random(len(boxes))).astype(np.float32)
+    center, scale, size, box = ho3d_crop_windows(boxes, noise, sn)
+    for k in range(len(boxes)):
+        win = ho.crop_window(boxes[k], noise[k], float(sn[k]))
+        assert np.array_equal(center[k], win["crop_center"]) and scale[k] == win["scale"] and size[k] == win["crop_size_scales"]
+        assert tuple(box[k]) == ho.pil_crop_box(float(win["x1"]), float(win["y1"]), float(size[k]), float(size[k]))
