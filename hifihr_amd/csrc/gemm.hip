@@ -1257,6 +1257,8 @@ size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch) {
   return sk_flag_bytes(G) + (size_t)G * 128 * 128 * sizeof(float);
 }
 
+bool bgemm_nt_stats_supported(int N) { return nt_rows(N); }      // the statistics epilogue exists in the row-share kernel only
+
 hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
                            float* stats) {
   if (!bgemm_nt_supported(M, N, K) || batch <= 0) return hipErrorInvalidValue;

@@ -260,6 +260,7 @@ void bgemm_describe_batch(int tn, int M, int N, int K, int batch, char* out, int
 bool bgemm_nt_supported(int M, int N, int K);
 bool bgemm_tn_supported(int M, int N, int T);
 size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch);
+bool bgemm_nt_stats_supported(int N);      // launch_bgemm_nt(..., stats != null) is available for this N
 hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
                            float* stats_or_null = nullptr);      // stats: only with N % 128 == 0 and batch == 1 (else hipErrorInvalidValue)
 int bgemm_tn_parts(int M, int N, int T, int batch);
