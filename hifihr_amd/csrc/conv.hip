@@ -925,7 +925,8 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
     else hipLaunchKernelGGL(conv3x3_oc4_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, src, wgt, dst, g.N, g.OH, g.OW, g.dgrad ? -1 : 1);
     return hipGetLastError();
   }
-  if (conv_is_gemm(g) && bias == nullptr && (stats == nullptr || bgemm_nt_stats_supported(g.OC))) {
+  // (the GEMM kernels have no activation epilogue: a fused ReLU keeps the implicit-GEMM kernel)
+  if (conv_is_gemm(g) && bias == nullptr && !g.relu && (stats == nullptr || bgemm_nt_stats_supported(g.OC))) {
     // 1x1 / stride 1: y[M][OC] = x[M][IC] . w[OC][IC]^T, and backward-data the same product on (dy, w^T): the GEMM kernels of
     // csrc/gemm.hip (bgemm_nt_rows_kernel: N % 128 == 0; the statistics of a batch-norm consumer come out of its epilogue)
     const long M = (long)g.N * g.OH * g.OW;

@@ -29,6 +29,13 @@ _BN_EPS, _BN_MOM = 1e-3, 0.01
 _DROP_CONNECT = 0.2
 
 
+def _drop_connect_uniform(x):
+    """The per-sample uniform draw of utils.py:87 (`torch.rand([batch_size, 1, 1, 1], dtype, device)`), one per skip block in block
+    order.  A module-level hook so that a parity test can hand in the draws the reference made (its CPU generator under
+    torch.manual_seed(5)): tests/test_gpu_conv.py::test_efficientnet_b3_hip_vs_reference_golden."""
+    return torch.rand([x.shape[0], 1, 1, 1], dtype=x.dtype, device=x.device)
+
+
 def round_filters(f, width=_WIDTH, divisor=8):
     f *= width
     nf = max(divisor, int(f + divisor / 2) // divisor * divisor)
@@ -142,7 +149,7 @@ class MBConvBlock(nn.Module):
         if self.stride == 1 and self.cin == self.cout:
             if drop_connect_rate and self.training:                       # utils.py:82-91
                 keep = 1 - drop_connect_rate
-                mask = torch.floor(keep + torch.rand([x.shape[0], 1, 1, 1], dtype=x.dtype, device=x.device))
+                mask = torch.floor(keep + _drop_connect_uniform(x))
                 x = x / keep * mask
             x = x + inputs
         return x

@@ -791,6 +791,20 @@ def linear_case(lib, device, B, I, O, act, bn, seed=0, need_dx=True):
         rel(dbt - 2.0, ber.grad, "dbeta")
 
 
+def conv_relu_nobias_case(lib, device, N, H, W, C, K, R, stride, seed=0, pad=0):
+    """hifihr_conv2d_fwd(bias = NULL, act = 1): the output is clamped whatever kernel the shape dispatches to (the 1x1 / stride-1
+    shapes with K % 128 == 0 once took the GEMM kernels, which have no activation epilogue: round-2 advisor finding)."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=gen); w = torch.randn(K, C, R, R, generator=gen) / (C * R * R) ** 0.5
+    ref = F.relu(F.conv2d(x, w, None, stride=stride, padding=pad)).permute(0, 2, 3, 1)
+    d = lambda t: t.to(device).contiguous()
+    out = torch.full(tuple(ref.shape), -3.0, device=device)
+    lib.conv2d_fwd(d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), None, out, N, H, W, C, K, R, R, stride, pad, act=1)
+    assert float(out.min()) >= 0.0, "ReLU epilogue dropped"
+    assert float((out.cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6, "conv+relu fwd"
+
+
 def conv_bias_relu_case(lib, device, N, H, W, C, K, R, stride, seed=0, pad=0):
     """conv + bias + ReLU in one launch (act = 1) and its backward prologue bias_relu_bwd, vs torch."""
     import torch.nn.functional as F
@@ -1274,3 +1288,37 @@ def lbs_case(lib, device, tabs, B, seed, pose_scale=0.6, vtol=2e-6, gtol=2e-4):
             assert float((gbeta2.cpu() - be.grad).abs().max()) <= gtol * float(be.grad.abs().max())
     finally:
         lib.lbs_destroy(h)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference trunk's batch-of-8 fixture (tests/golden/resnet18_b8.npz, tools/make_golden.py:gen_resnet18_b8)
+# ------------------------------------------------------------------------------------------------
+def resnet18_b8_inputs(g):
+    """x, wl, wf regenerated from the generator seed the fixture was made with, verified against its float64 checksums."""
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.rand(8, 3, 64, 64, generator=gen)
+    wl = torch.randn(tuple(g["low"].shape), generator=gen); wf = torch.randn(tuple(g["feat"].shape), generator=gen)
+    got = np.array([x.double().sum().item(), wl.double().sum().item(), wf.double().sum().item()])
+    assert np.allclose(got, g["checksums"], rtol=0, atol=1e-9), "the CPU generator no longer reproduces the fixture's inputs"
+    return x, wl, wf
+
+
+def resnet18_b8_check(g, net, low, feat, out_atol, grad_rtol):
+    """net = a module with torchvision's ResNet attribute names whose .grad fields are filled; every gradient the fixture holds."""
+    np.testing.assert_allclose(low.detach().cpu().numpy(), g["low"], atol=out_atol, rtol=1e-4)
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), g["feat"], atol=out_atol, rtol=1e-4)
+    params = dict(net.named_parameters())
+    worst = {}
+    for key in g.files:
+        if not key.startswith("g_"):
+            continue
+        toks = key[2:].split("_")               # g_layer2_0_downsample_0_weight -> layer2.0.downsample.0.weight
+        name = ".".join(toks)
+        grad = params[name].grad.detach().cpu().numpy()
+        ref = g[key]
+        if grad.ndim == 4:
+            grad = grad[:8]
+        worst[name] = float(np.abs(grad - ref).max() / (np.abs(ref).max() + 1e-12))
+    bad = {k: v for k, v in worst.items() if v >= grad_rtol}
+    assert not bad, bad
+    return worst

@@ -68,6 +68,21 @@ def test_resnet18_trunk_vs_reference(golden_dir):
         assert np.abs(grad.numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-6, key
 
 
+def test_resnet18_trunk_vs_reference_batch8(golden_dir):
+    """The same restatement against the batch-of-8 fixture (fourteen gradients incl. both batch-norm parameters of the stem)."""
+    import kernel_cases as kc
+    from seeded_init import seeded_state_dict
+    from oracle.torch_modules import Resnet4CRef
+    g = np.load(os.path.join(golden_dir, "resnet18_b8.npz"))
+    x, wl, wf = kc.resnet18_b8_inputs(g)
+    enc = Resnet4CRef("res18")
+    enc.model.load_state_dict(seeded_state_dict(enc.model))
+    enc.train()
+    low, feat = enc(normalize_batch_3C(x))
+    ((low * wl).sum() + (feat * wf).sum()).backward()
+    kc.resnet18_b8_check(g, enc.model, low, feat, out_atol=2e-5, grad_rtol=2e-4)
+
+
 def test_options_json_overlay_and_lambda_schedules(tmp_path):
     p = tmp_path / "c.json"
     p.write_text('{"lambda_pose_list": [0.01, 0.001, 0.00001], "lambda_pose_steps": [10, 20], "losses": ["joint_3d"], "zzz": 1}')

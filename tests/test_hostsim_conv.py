@@ -50,6 +50,12 @@ def test_conv_bias_relu(hostsim_lib, N, H, W, C, K, R, stride):
     kc.conv_bias_relu_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, seed=C + K)
 
 
+@pytest.mark.parametrize("N,H,W,C,K,R", [(1, 8, 8, 32, 128, 1), (1, 8, 8, 32, 64, 1), (2, 6, 6, 64, 256, 1), (1, 6, 6, 32, 128, 3)])
+def test_conv_relu_without_bias(hostsim_lib, N, H, W, C, K, R):
+    """conv2d_fwd(bias=None, act=1): clamped on every dispatch path (1x1 with K % 128 == 0 must not take the activation-less GEMM)."""
+    kc.conv_relu_nobias_case(hostsim_lib, "cpu", N, H, W, C, K, R, 1, seed=K, pad=R // 2)
+
+
 def test_conv_halo_bias_relu_epilogue(hostsim_lib):
     """VGG19's conv1_2 of the perceptual loss (64 -> 64, bias + ReLU): the halo kernel's epilogue adds the bias and clamps."""
     kc.conv_bias_relu_case(hostsim_lib, "cpu", 2, 10, 14, 64, 64, 3, 1, seed=5, pad=1)
