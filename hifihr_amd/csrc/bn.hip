@@ -91,30 +91,50 @@ __device__ __forceinline__ void reduce_and_add(const BnMap& mp, int C, float4 (&
   }
 }
 
+// Forward statistics of a tensor whose producer is not one of our convolutions: shifted sums per thread (hifihr_internal.h, "FORWARD
+// statistics"), unshifted in fp64, folded over the row lanes through LDS and added to the double slots.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long M, int C, float* __restrict__ stats) {
-  __shared__ float4 lds[2][256];
+  __shared__ double lds[2][256][4];
   const BnMap mp = bn_map(C);
-  float4 s[kMaxNG], q[kMaxNG];
+  double* const slots = reinterpret_cast<double*>(stats) + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * C;
 #pragma unroll
-  for (int j = 0; j < kMaxNG; ++j) { s[j] = make_float4(0.f, 0.f, 0.f, 0.f); q[j] = s[j]; }
-  if (mp.active) {
-    for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
-#pragma unroll
-      for (int j = 0; j < kMaxNG; ++j) {
-        const int cg = mp.cg0 + 256 * j;
-        if (j < mp.NG && cg * 4 < C) {
-          const float4 v = *reinterpret_cast<const float4*>(x + m * C + cg * 4);
-          acc4(s[j], v);
-          q[j].x += v.x * v.x; q[j].y += v.y * v.y; q[j].z += v.z * v.z; q[j].w += v.w * v.w;
-        }
+  for (int j = 0; j < kMaxNG; ++j) {
+    if (j >= mp.NG) break;                                 // (uniform)
+    const int cg = mp.cg0 + 256 * j;
+    const bool mine = mp.active && cg * 4 < C;
+    float4 k = make_float4(0.f, 0.f, 0.f, 0.f), s = k, q = k;
+    int n = 0;
+    if (mine) {
+      for (long m = (long)blockIdx.x * mp.RL + mp.rl; m < M; m += (long)gridDim.x * mp.RL) {
+        const float4 v = *reinterpret_cast<const float4*>(x + m * C + cg * 4);
+        if (n == 0) k = v;
+        const float4 d = make_float4(v.x - k.x, v.y - k.y, v.z - k.z, v.w - k.w);
+        acc4(s, d);
+        q.x += d.x * d.x; q.y += d.y * d.y; q.z += d.z * d.z; q.w += d.w * d.w;
+        ++n;
       }
     }
+    double S1[4], S2[4];
+    stat_unshift(n, k.x, s.x, q.x, S1[0], S2[0]); stat_unshift(n, k.y, s.y, q.y, S1[1], S2[1]);
+    stat_unshift(n, k.z, s.z, q.z, S1[2], S2[2]); stat_unshift(n, k.w, s.w, q.w, S1[3], S2[3]);
+    if (mp.NG == 1 && mp.RL > 1) {                        // (uniform) fold the row lanes of a channel group
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lds[0][threadIdx.x][e] = S1[e]; lds[1][threadIdx.x][e] = S2[e]; }
+      __syncthreads();
+      if (mp.active && mp.rl == 0) {
+        for (int r = 1; r < mp.RL; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { S1[e] += lds[0][r * mp.CT + mp.cg0][e]; S2[e] += lds[1][r * mp.CT + mp.cg0][e]; }
+      }
+    }
+    if (mine && (mp.RL == 1 || mp.NG > 1 || mp.rl == 0)) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { stat_atomic_add(slots + cg * 4 + e, S1[e]); stat_atomic_add(slots + C + cg * 4 + e, S2[e]); }
+    }
   }
-  reduce_and_add(mp, C, s, q, lds, stats);
 }
 
 constexpr int kMaxC = 4 * 256 * kMaxNG;     // 4096 channels: scale / shift tables of the apply kernels (2 x 16 KB of LDS)
-constexpr int kBnCounters = 64;              // uint32 arrival counters stored behind the slot partials (33 used)
 
 // True in every thread of exactly ONE workgroup of the launch: the last one to get here.  Called after the workgroup's last
 // read of the slot buffer; the elected workgroup may then overwrite it.  32 first-level counters keep the same-address
@@ -151,6 +171,27 @@ __device__ __forceinline__ void slot_sum2(const float* __restrict__ buf, int C, 
   for (int sl = 0; sl < kStatSlots; ++sl) { s0 += a[sl]; s1 += b[sl]; }
 }
 
+// FORWARD statistics (double slots): mean and biased variance of channel c from the 32 slot partials, all 64 loads in flight
+__device__ __forceinline__ void slot_mean_var(const float* __restrict__ stats, int C, int c, long M, float& mu, float& var) {
+  const double* buf = reinterpret_cast<const double*>(stats);
+  double a[kStatSlots], b[kStatSlots];
+#pragma unroll
+  for (int sl = 0; sl < kStatSlots; ++sl) { a[sl] = buf[(size_t)sl * 2 * C + c]; b[sl] = buf[(size_t)sl * 2 * C + C + c]; }
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int sl = 0; sl < kStatSlots; ++sl) { s0 += a[sl]; s1 += b[sl]; }
+  const double m = s0 / (double)M;
+  const double v = s1 / (double)M - m * m;           // fp64: the cancellation costs 2^-53 mean^2 / var
+  mu = (float)m;
+  var = v > 0.0 ? (float)v : 0.f;
+}
+__device__ __forceinline__ void clear_slots_fwd(float* __restrict__ stats, int C, unsigned* __restrict__ cnt) {
+  float4* p = reinterpret_cast<float4*>(stats);
+  const int n4 = kStatSlots * 2 * C / 2;               // doubles: 8 bytes each
+  for (int i = threadIdx.x; i < n4; i += 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x < 33) cnt[threadIdx.x] = 0u;
+}
+
 // Wide layers (C > kFuseMaxC): folding 256 C bytes of partials in EVERY workgroup costs more than it saves (EfficientNet's
 // 1392-channel layers: +1.2 ms per step measured), so they keep a one-thread-per-channel finalize launch that also cleans the slots.
 constexpr int kFuseMaxC = 512;     // 256 -> 512 in round 2: ResNet-18's layer 4 loses its 10 finalize launches per step (6.19 -> 6.175 ms)
@@ -160,16 +201,17 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(float* __restrict_
                                                              float* __restrict__ running_mean, float* __restrict__ running_var) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const float invM = 1.0f / (float)M;
-  float s = 0.f, q = 0.f;
+  double* buf = reinterpret_cast<double*>(stats);
+  double s = 0.0, q = 0.0;
 #pragma unroll 8
   for (int sl = 0; sl < kStatSlots; ++sl) {
-    float* p = stats + (size_t)sl * 2 * C;
+    double* p = buf + (size_t)sl * 2 * C;
     s += p[c]; q += p[C + c];
-    p[c] = 0.f; p[C + c] = 0.f;
+    p[c] = 0.0; p[C + c] = 0.0;
   }
-  const float mu = s * invM;
-  const float var = fmaxf(q * invM - mu * mu, 0.f);
+  const double md = s / (double)M, vd = q / (double)M - md * md;
+  const float mu = (float)md;
+  const float var = vd > 0.0 ? (float)vd : 0.f;
   save_mean[c] = mu;
   save_invstd[c] = 1.0f / sqrtf(var + eps);
   if (running_mean) {
@@ -191,7 +233,7 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(float* __restrict_
     sg += p[c]; sgx += p[C + c];
     p[c] = 0.f; p[C + c] = 0.f;
   }
-  float* tot = red + (size_t)kStatSlots * 2 * C;
+  float* tot = stat_bwd_totals(red, C);
   tot[c] = sg;
   tot[C + c] = sgx;
   if (dgamma_acc) dgamma_acc[c] += sgx;
@@ -207,17 +249,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                         float* __restrict__ running_var) {
   __shared__ float s_sc[kMaxC], s_sh[kMaxC];
   const BnMap mp = bn_map(C);
-  const float invM = 1.0f / (float)M;
   for (int c = threadIdx.x; c < C; c += 256) {            // every workgroup folds the slot partials itself (L2-resident)
     float mu, is, var = 0.f;
     if (PRE) {
       mu = save_mean[c]; is = save_invstd[c];
       if (stats == nullptr) is = 1.0f / sqrtf(is + eps);       // evaluation mode: (running_mean, running_var) were passed in
     } else {
-      float s0, s1;
-      slot_sum2(stats, C, c, s0, s1);
-      mu = s0 * invM;
-      var = fmaxf(s1 * invM - mu * mu, 0.f);                              // biased batch variance
+      slot_mean_var(stats, C, c, M, mu, var);                               // biased batch variance (fp64 fold of the double slots)
       is = 1.0f / sqrtf(var + eps);
     }
     const float sc = is * gamma[c];
@@ -289,8 +327,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     }
   }
   if (!PRE) {
-    unsigned* cnt = reinterpret_cast<unsigned*>(stats + (size_t)(kStatSlots + 1) * 2 * C);
-    if (last_workgroup(cnt)) clear_slots(stats, C, cnt);
+    unsigned* cnt = stat_fwd_counters(stats, C);
+    if (last_workgroup(cnt)) clear_slots_fwd(stats, C, cnt);
   }
 }
 
@@ -392,7 +430,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   for (int c = threadIdx.x; c < C; c += 256) {
     float sg, sgx;
     if (PRE) {
-      const float* tot = red + (size_t)kStatSlots * 2 * C;
+      const float* tot = stat_bwd_totals(red, C);
       sg = tot[c]; sgx = tot[C + c];
     } else {
       slot_sum2(red, C, c, sg, sgx);
@@ -467,7 +505,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
   }
   if (!PRE) {
-    unsigned* cnt = reinterpret_cast<unsigned*>(red + (size_t)(kStatSlots + 1) * 2 * C);
+    unsigned* cnt = stat_bwd_counters(red, C);
     if (last_workgroup(cnt)) clear_slots(red, C, cnt);
   }
 }
@@ -498,12 +536,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
                                                               float* __restrict__ running_var) {
   __shared__ float s_sc[kFuseMaxC], s_sh[kFuseMaxC];
   const long M = (long)g.N * g.H * g.W;
-  const float invM = 1.0f / (float)M;
   for (int c = threadIdx.x; c < C; c += 256) {
-    float s0, s1;
-    slot_sum2(stats, C, c, s0, s1);
-    const float mu = s0 * invM;
-    const float var = fmaxf(s1 * invM - mu * mu, 0.f);
+    float mu, var;
+    slot_mean_var(stats, C, c, M, mu, var);
     const float is = 1.0f / sqrtf(var + eps);
     const float sc = is * gamma[c];
     s_sc[c] = sc;
@@ -565,8 +600,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
           make_uchar4((unsigned char)mt.x, (unsigned char)mt.y, (unsigned char)mt.z, (unsigned char)mt.w);
     }
   }
-  unsigned* cnt = reinterpret_cast<unsigned*>(stats + (size_t)(kStatSlots + 1) * 2 * C);
-  if (last_workgroup(cnt)) clear_slots(stats, C, cnt);
+  unsigned* cnt = stat_fwd_counters(stats, C);
+  if (last_workgroup(cnt)) clear_slots_fwd(stats, C, cnt);
 }
 
 // Gradient of MaxPool2d(3, 2, 1) at input pixel m = (n, ih, iw), channels cg*4..+3.  Windows oh with oh * 2 - 1 + r == ih:
@@ -727,7 +762,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
       emit(masked_grad(1, pool_taps_sum(p), false, zero4, v, k1, sh), v, (size_t)m * C + cb);
     }
   }
-  unsigned* cnt = reinterpret_cast<unsigned*>(red + (size_t)(kStatSlots + 1) * 2 * C);
+  unsigned* cnt = stat_bwd_counters(red, C);
   if (last_workgroup(cnt)) clear_slots(red, C, cnt);
 }
 

@@ -470,23 +470,30 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
         }
+        // batch-norm statistics: sums of d = y - ks, ks = the lane's first row of this column (hifihr_internal.h "FORWARD statistics")
+        const float ks = acc[i][j][0];
         float ssum = 0.f, ssq = 0.f;
+        int sn = 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = bm0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
           if (m < M && k < g.OC) {
             col[(size_t)m * g.OC] = acc[i][j][e];
-            ssum += acc[i][j][e];
-            ssq += acc[i][j][e] * acc[i][j][e];
+            const float d = acc[i][j][e] - ks;
+            ssum += d;
+            ssq += d * d;
+            ++sn;
           }
         }
         if (stats != nullptr) {                  // uniform
-          ssum += __shfl_down(ssum, 32, 64);     // lanes l and l + 32 hold the same channel, different rows
-          ssq += __shfl_down(ssq, 32, 64);
-          if (half == 0 && k < g.OC) {           // 32 consecutive channels: two 128-byte atomic segments per wave
-            float* sp = stats + (size_t)((tx * 2 + wm) & (kStatSlots - 1)) * 2 * g.OC;   // slot by row tile
-            atomicAdd(sp + k, ssum);
-            atomicAdd(sp + g.OC + k, ssq);
+          double S1, S2;
+          stat_unshift(sn, ks, ssum, ssq, S1, S2);
+          S1 += __shfl_down(S1, 32, 64);         // lanes l and l + 32 hold the same channel, different rows
+          S2 += __shfl_down(S2, 32, 64);
+          if (half == 0 && k < g.OC) {           // 32 consecutive channels
+            double* sp = reinterpret_cast<double*>(stats) + (size_t)((tx * 2 + wm) & (kStatSlots - 1)) * 2 * g.OC;   // slot by row tile
+            stat_atomic_add(sp + k, S1);
+            stat_atomic_add(sp + g.OC + k, S2);
           }
         }
       }

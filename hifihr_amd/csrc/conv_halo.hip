@@ -214,7 +214,9 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
   for (int h = 0; h < 2; ++h) woff[h] = (16 * wave + r) * 128 + (((g + 4 * h) ^ ((r >> 1) & 7)) * 16);
   const char* const halo_b = reinterpret_cast<const char*>(halo);
   const char* const wst_b = reinterpret_cast<const char*>(wst);
-  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  // batch-norm statistics: shifted sums (d = y - sk, sk = the lane's first output of each channel; hifihr_internal.h "FORWARD statistics")
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f}, sk[4] = {0.f, 0.f, 0.f, 0.f};
+  int sn = 0;
 
   HALO_BARRIER();                                            // barrier -1
   int cur = s_lo, gt = 0;
@@ -319,8 +321,11 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
           if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         }
         *reinterpret_cast<float4*>(o) = v;
-        ssum[0] += v.x; ssq[0] += v.x * v.x; ssum[1] += v.y; ssq[1] += v.y * v.y;
-        ssum[2] += v.z; ssq[2] += v.z * v.z; ssum[3] += v.w; ssq[3] += v.w * v.w;
+        if (sn == 0) { sk[0] = v.x; sk[1] = v.y; sk[2] = v.z; sk[3] = v.w; }
+        const float d0 = v.x - sk[0], d1 = v.y - sk[1], d2 = v.z - sk[2], d3 = v.w - sk[3];
+        ssum[0] += d0; ssq[0] += d0 * d0; ssum[1] += d1; ssq[1] += d1 * d1;
+        ssum[2] += d2; ssq[2] += d2 * d2; ssum[3] += d3; ssq[3] += d3 * d3;
+        ++sn;
       }
     }
 #if defined(HIFIHR_HALO_STAMP)
@@ -341,13 +346,16 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
   }
 #endif
   if (a.stats != nullptr) {                                  // (uniform)
+    double S1[4], S2[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      for (int o = 1; o < 16; o <<= 1) { ssum[e] += __shfl_xor(ssum[e], o, 64); ssq[e] += __shfl_xor(ssq[e], o, 64); }
+    for (int e = 0; e < 4; ++e) {
+      stat_unshift(sn, sk[e], ssum[e], ssq[e], S1[e], S2[e]);
+      for (int o = 1; o < 16; o <<= 1) { S1[e] += __shfl_xor(S1[e], o, 64); S2[e] += __shfl_xor(S2[e], o, 64); }
+    }
     if (r == 0) {
-      float* sp = a.stats + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 16 * wave + 4 * g;
+      double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 16 * wave + 4 * g;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { atomicAdd(sp + e, ssum[e]); atomicAdd(sp + 64 + e, ssq[e]); }
+      for (int e = 0; e < 4; ++e) { stat_atomic_add(sp + e, S1[e]); stat_atomic_add(sp + 64 + e, S2[e]); }
     }
   }
 }
@@ -632,7 +640,9 @@ __global__ __launch_bounds__(384) void conv_stem_kernel(StemArgs a) {
   const int woff = (16 * wave + r) * (kSWP * 4) + g * 16;
   const char* const wl_b = reinterpret_cast<const char*>(wl);
   const char* const halo_b = reinterpret_cast<const char*>(halo);
-  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  // batch-norm statistics: shifted sums (d = y - sk, sk = the lane's first output of each channel; hifihr_internal.h "FORWARD statistics")
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f}, sk[4] = {0.f, 0.f, 0.f, 0.f};
+  int sn = 0;
   __syncthreads();                                           // barrier -1
   const bool c3 = c3_any != 0;                               // (uniform)
   int cur = s_lo;
@@ -692,18 +702,26 @@ __global__ __launch_bounds__(384) void conv_stem_kernel(StemArgs a) {
         float* o = a.dst + (((size_t)t.n * a.OH + t.y0 + ty) * a.OW + t.x0 + tx) * 64 + 16 * wave + 4 * g;
         *reinterpret_cast<float4*>(o) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ssum[e] += acc[j][e]; ssq[e] += acc[j][e] * acc[j][e]; }
+        for (int e = 0; e < 4; ++e) {
+          if (sn == 0) sk[e] = acc[j][e];
+          const float d = acc[j][e] - sk[e];
+          ssum[e] += d; ssq[e] += d * d;
+        }
+        ++sn;
       }
     }
   }
   if (a.stats != nullptr) {                                  // (uniform)
+    double S1[4], S2[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      for (int o = 1; o < 16; o <<= 1) { ssum[e] += __shfl_xor(ssum[e], o, 64); ssq[e] += __shfl_xor(ssq[e], o, 64); }
+    for (int e = 0; e < 4; ++e) {
+      stat_unshift(sn, sk[e], ssum[e], ssq[e], S1[e], S2[e]);
+      for (int o = 1; o < 16; o <<= 1) { S1[e] += __shfl_xor(S1[e], o, 64); S2[e] += __shfl_xor(S2[e], o, 64); }
+    }
     if (r == 0) {
-      float* sp = a.stats + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 16 * wave + 4 * g;
+      double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 16 * wave + 4 * g;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { atomicAdd(sp + e, ssum[e]); atomicAdd(sp + 64 + e, ssq[e]); }
+      for (int e = 0; e < 4; ++e) { stat_atomic_add(sp + e, S1[e]); stat_atomic_add(sp + 64 + e, S2[e]); }
     }
   }
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* 
                                                         float* __restrict__ y, float* __restrict__ stats) {
   constexpr int KK = K * K, NC = (kPW - 1) * S + K;
   __shared__ float wl[KK][64];
-  __shared__ float4 red[2][16][16];
+  __shared__ double red[2][16][16][4];
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int c0 = blockIdx.y * 64, c = c0 + cl * 4;
   const bool cok = c < g.C;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* 
   __syncthreads();
   const int OWB = (g.OW + kPW - 1) / kPW;
   const long nb = (long)g.N * g.OH * OWB;
-  float4 s1 = zero4(), s2 = zero4();
+  Stat4 st;                                         // batch-norm statistics of y (hifihr_internal.h "FORWARD statistics")
   if (cok) {
     for (long pb = (long)blockIdx.x * 16 + pl; pb < nb; pb += (long)gridDim.x * 16) {
       const int owb = (int)(pb % OWB);
@@ -93,26 +93,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* 
       for (int p = 0; p < kPW; ++p) {
         if (ow0 + p < g.OW) {
           *reinterpret_cast<float4*>(y + (((size_t)n * g.OH + oh) * g.OW + ow0 + p) * g.C + c) = acc[p];
-          s1.x += acc[p].x; s1.y += acc[p].y; s1.z += acc[p].z; s1.w += acc[p].w;
-          s2 = fma4(acc[p], acc[p], s2);
+          st.add(acc[p]);
         }
       }
     }
   }
-  if (stats != nullptr) {                           // uniform: fold the 16 pixel lanes, one atomic per channel per workgroup
-    red[0][pl][cl] = s1; red[1][pl][cl] = s2;
-    __syncthreads();
-    if (pl == 0 && cok) {
-      for (int r = 1; r < 16; ++r) {
-        const float4 a = red[0][r][cl], b = red[1][r][cl];
-        s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-        s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
-      }
-      float* sp = stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * g.C;
-      atomicAdd(sp + c, s1.x); atomicAdd(sp + c + 1, s1.y); atomicAdd(sp + c + 2, s1.z); atomicAdd(sp + c + 3, s1.w);
-      atomicAdd(sp + g.C + c, s2.x); atomicAdd(sp + g.C + c + 1, s2.y); atomicAdd(sp + g.C + c + 2, s2.z); atomicAdd(sp + g.C + c + 3, s2.w);
-    }
-  }
+  if (stats != nullptr)                             // uniform: fold the 16 pixel lanes, one atomic per channel per workgroup
+    st.fold16(red, pl, cl, cok, reinterpret_cast<double*>(stats) + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * g.C + c, g.C);
 }
 
 // dx[n][ih][iw] = sum_{r,s} dy[n][(ih + pt - r)/S][(iw + pl - s)/S] * w[r][s] over the taps where the divisions are exact.

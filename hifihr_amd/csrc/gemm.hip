@@ -820,22 +820,28 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
   // batch-norm statistics of the output (a.stats != null): per-column sums of this wave's 32 columns, kept in registers over the tiles of
   // one column tile (a share walks the rows of a column tile before it moves on), then folded over the 16 row lanes and added to the
   // slot buffer -- the epilogue conv_igemm_kernel / conv_halo_kernel have, so a 1x1 convolution on this kernel needs no statistics pass
+  // (shifted sums: d = y - sk with sk the lane's first row of the column since the last flush; unshifted in fp64 at the flush --
+  //  hifihr_internal.h "FORWARD statistics")
   float ssum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  int stat_nt = -1;
+  float sk[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  int stat_nt = -1, sn = 0;
   auto flush_stats = [&]() {
     if (stat_nt < 0) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float sa = ssum[i][e], sb = ssq[i][e];
+        double sa, sb;
+        stat_unshift(sn, sk[i][e], ssum[i][e], ssq[i][e], sa, sb);
         for (int o = 1; o < 16; o <<= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
         if (r == 0) {
-          float* sp = a.stats + (size_t)(wg & (kStatSlots - 1)) * 2 * a.N + (size_t)stat_nt * 128 + 32 * wave + 16 * i + 4 * g + e;
-          atomicAdd(sp, sa); atomicAdd(sp + a.N, sb);
+          double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (kStatSlots - 1)) * 2 * a.N + (size_t)stat_nt * 128 + 32 * wave +
+                       16 * i + 4 * g + e;
+          stat_atomic_add(sp, sa); stat_atomic_add(sp + a.N, sb);
         }
         ssum[i][e] = 0.f; ssq[i][e] = 0.f;
       }
+    sn = 0;
   };
   auto run_tile = [&](auto nbc, const RowsTile& t) {
     constexpr int NB = decltype(nbc)::value;
@@ -924,7 +930,12 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { ssum[i][e] += acc[i][j][e]; ssq[i][e] += acc[i][j][e] * acc[i][j][e]; }
+            for (int e = 0; e < 4; ++e) {
+              if (sn == 0) sk[i][e] = acc[i][j][e];
+              const float d = acc[i][j][e] - sk[i][e];
+              ssum[i][e] += d; ssq[i][e] += d * d;
+            }
+          ++sn;
         }
       }
     }

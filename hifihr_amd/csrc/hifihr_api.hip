@@ -570,7 +570,7 @@ int hifihr_ssim_finish(const float* partial, int count, float scale, float offse
   return HIFIHR_OK;
 }
 
-int hifihr_bn_stats_floats(int C) { return C > 0 ? (hifihr::kStatSlots + 1) * 2 * C + 64 : 0; }   // slots, spare [2][C], 64 counter words
+int hifihr_bn_stats_floats(int C) { return C > 0 ? hifihr::stat_buffer_floats(C) : 0; }   // double slots + 64 counter words (hifihr_internal.h)
 
 static int bn_dims_ok(long M, int C) { return M > 0 && C >= 4 && C % 4 == 0 && C <= 4096; }
 

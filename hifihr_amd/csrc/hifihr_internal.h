@@ -110,6 +110,64 @@ hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wg
 // sums are spread over kStatSlots copies so that at most ~1/32 of the contributing workgroups hit one address with a
 // float atomic (thousands of atomics on ONE address serialise at ~100 ns each: 200 us per reduction in round 1).
 constexpr int kStatSlots = 32;
+// FORWARD statistics (round 3): the slots hold DOUBLES, double S[kStatSlots][2][C] = (sum y, sum y^2), followed by 64 uint32 arrival
+// counters.  A producer lane accumulates SHIFTED sums in fp32 -- d = y - k with k a value of its own (the first y it saw for that
+// channel), s = sum d, q = sum d^2 over its n values: q stays of the order of n var however large the mean is -- and converts ONCE,
+// when it hands its partial over, to the unshifted pair in fp64 (stat_unshift: exact identities sum y = n k + s, sum y^2 = q + 2 k s +
+// n k^2); partials are then folded and added to the slots in fp64, and the consumer forms var = S2 / M - (S1 / M)^2 in fp64, where the
+// cancellation costs 2^-53 mean^2 / var instead of 2^-24 mean^2 / var (round 2: E[y^2] - mean^2 in fp32 lost the variance of a channel
+// with mean 50 / std 0.1 entirely; PyTorch's batch_norm uses Welford sums).  The BACKWARD reductions (sum g, sum g xhat: no
+// cancellation) keep a float layout in the same buffer (below), which is sized for the larger.
+constexpr int kStatCounters = 64;
+__host__ __device__ inline size_t stat_fwd_doubles(int C) { return (size_t)kStatSlots * 2 * C; }
+__host__ __device__ inline unsigned* stat_fwd_counters(float* stats, int C) {
+  return reinterpret_cast<unsigned*>(reinterpret_cast<double*>(stats) + stat_fwd_doubles(C));
+}
+// backward layout inside the same buffer: float R[kStatSlots][2][C], 64 counters right behind, and -- wide layers only, written by the
+// finalize launch and left dirty -- the totals float tot[2][C] BEHIND the forward layout, where no producer ever adds
+__host__ __device__ inline unsigned* stat_bwd_counters(float* red, int C) { return reinterpret_cast<unsigned*>(red + (size_t)kStatSlots * 2 * C); }
+__host__ __device__ inline float* stat_bwd_totals(float* red, int C) { return red + (size_t)kStatSlots * 4 * C + kStatCounters; }
+__host__ __device__ inline int stat_buffer_floats(int C) { return kStatSlots * 4 * C + kStatCounters + 2 * C; }
+#if defined(__HIPCC__) || defined(HIFIHR_HOSTSIM)
+// (n, k, s, q) of one lane and channel -> its unshifted (sum y, sum y^2) in fp64
+__device__ __forceinline__ void stat_unshift(int n, float k, float s, float q, double& S1, double& S2) {
+  const double kd = (double)k, sd = (double)s, nd = (double)n;
+  S1 = nd * kd + sd;
+  S2 = (double)q + 2.0 * kd * sd + nd * kd * kd;
+}
+__device__ __forceinline__ void stat_atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }      // global_atomic_add_f64
+// The same for a thread that walks rows of 4 consecutive channels (the elementwise producers: Winograd output transforms, depthwise
+// convolution): add() per value, then fold16(): the 16 row lanes tl of a 16 x 16 thread arrangement (tl = tid >> 4, cl = tid & 15) meet in
+// LDS in fp64 and row lane 0 adds the 4 channels' (sum, sum of squares) to slot[0 .. 3] / slot[C .. C + 3].
+struct Stat4 {
+  float4 k, s, q;
+  int n;
+  __device__ __forceinline__ Stat4() : k(make_float4(0.f, 0.f, 0.f, 0.f)), s(k), q(k), n(0) {}
+  __device__ __forceinline__ void add(const float4& v) {
+    if (n == 0) k = v;
+    const float dx = v.x - k.x, dy = v.y - k.y, dz = v.z - k.z, dw = v.w - k.w;
+    s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+    q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+    ++n;
+  }
+  // red: __shared__ double[2][16][16][4]; every thread of the workgroup calls it (one barrier inside)
+  __device__ __forceinline__ void fold16(double (*red)[16][16][4], int tl, int cl, bool mine, double* slot, int C) const {
+    double S1[4], S2[4];
+    stat_unshift(n, k.x, s.x, q.x, S1[0], S2[0]); stat_unshift(n, k.y, s.y, q.y, S1[1], S2[1]);
+    stat_unshift(n, k.z, s.z, q.z, S1[2], S2[2]); stat_unshift(n, k.w, s.w, q.w, S1[3], S2[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][tl][cl][e] = S1[e]; red[1][tl][cl][e] = S2[e]; }
+    __syncthreads();
+    if (tl == 0 && mine) {
+      for (int r = 1; r < 16; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { S1[e] += red[0][r][cl][e]; S2[e] += red[1][r][cl][e]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { stat_atomic_add(slot + e, S1[e]); stat_atomic_add(slot + C + e, S2[e]); }
+    }
+  }
+};
+#endif
 hipError_t launch_bn_stats(const float* x, long M, int C, float* stats, hipStream_t st);
 hipError_t launch_bn_act_fwd(const float* x, float* stats, const float* gamma, const float* beta, const float* residual,
                              int relu, long M, int C, float eps, float momentum, float* y, float* save_mean, float* save_invstd,

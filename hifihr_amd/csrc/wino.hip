@@ -212,12 +212,12 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* 
 __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float* __restrict__ Mm, float* __restrict__ y, float* __restrict__ stats,
                                                                    const float* __restrict__ bias, int relu, int N, int H, int W, int K,
                                                                    int TH, int TW) {
-  __shared__ float4 red[2][16][16];
+  __shared__ double red[2][16][16][4];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int k = blockIdx.y * 64 + cl * 4;
   const bool kok = k < K;
   const size_t T = (size_t)N * TH * TW;
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  Stat4 st;                                         // batch-norm statistics of y (hifihr_internal.h "FORWARD statistics")
   if (kok) {
     const float4 bv = bias != nullptr ? *reinterpret_cast<const float4*>(bias + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float lo = relu ? 0.f : -3.402823466e38f;
@@ -244,27 +244,17 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
         if (oh < H) {
           float* p = y + (((size_t)n * H + oh) * W + 2 * tw) * K + k;
           *reinterpret_cast<float4*>(p) = o0;
-          s1 = add4(s1, o0);
-          s2.x = fmaf(o0.x, o0.x, s2.x); s2.y = fmaf(o0.y, o0.y, s2.y); s2.z = fmaf(o0.z, o0.z, s2.z); s2.w = fmaf(o0.w, o0.w, s2.w);
+          st.add(o0);
           if (2 * tw + 1 < W) {
             *reinterpret_cast<float4*>(p + K) = o1;
-            s1 = add4(s1, o1);
-            s2.x = fmaf(o1.x, o1.x, s2.x); s2.y = fmaf(o1.y, o1.y, s2.y); s2.z = fmaf(o1.z, o1.z, s2.z); s2.w = fmaf(o1.w, o1.w, s2.w);
+            st.add(o1);
           }
         }
       }
     }
   }
-  if (stats != nullptr) {                           // uniform
-    red[0][tl][cl] = s1; red[1][tl][cl] = s2;
-    __syncthreads();
-    if (tl == 0 && kok) {
-      for (int r = 1; r < 16; ++r) { s1 = add4(s1, red[0][r][cl]); s2 = add4(s2, red[1][r][cl]); }
-      float* sp = stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * K;
-      atomicAdd(sp + k, s1.x); atomicAdd(sp + k + 1, s1.y); atomicAdd(sp + k + 2, s1.z); atomicAdd(sp + k + 3, s1.w);
-      atomicAdd(sp + K + k, s2.x); atomicAdd(sp + K + k + 1, s2.y); atomicAdd(sp + K + k + 2, s2.z); atomicAdd(sp + K + k + 3, s2.w);
-    }
-  }
+  if (stats != nullptr)                             // uniform
+    st.fold16(red, tl, cl, kok, reinterpret_cast<double*>(stats) + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * K + k, K);
 }
 
 // backward-weight glue.  thread = (tile, 4 channels): Y'[16][T][K] = A dy A^T with A = [1 0; 1 1; 1 -1; 0 -1] (dy outside the image = 0)

@@ -101,12 +101,12 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
 __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Mm, float* __restrict__ y, float* __restrict__ stats,
                                                                     const float* __restrict__ bias, int relu, int N, int H, int W, int K,
                                                                     int TH, int TW) {
-  __shared__ float4 red[2][16][16];
+  __shared__ double red[2][16][16][4];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int k = blockIdx.y * 64 + cl * 4;
   const bool kok = k < K;
   const size_t T = (size_t)N * TH * TW;
-  V4 s1 = zero4(), s2 = zero4();
+  Stat4 st;                                                 // batch-norm statistics of y (hifihr_internal.h "FORWARD statistics")
   if (kok) {
     const V4 bv = bias != nullptr ? ld4(bias + k) : zero4();
     const float lo = relu ? 0.f : -3.402823466e38f;
@@ -136,29 +136,15 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
               V4 v = o[b] + bv;
               v = V4{fmaxf(v.x, lo), fmaxf(v.y, lo), fmaxf(v.z, lo), fmaxf(v.w, lo)};
               st4(p + (size_t)b * K, v);
-              s1 = s1 + v;
-              s2 = V4{fmaf(v.x, v.x, s2.x), fmaf(v.y, v.y, s2.y), fmaf(v.z, v.z, s2.z), fmaf(v.w, v.w, s2.w)};
+              st.add(make_float4(v.x, v.y, v.z, v.w));
             }
           }
         }
       }
     }
   }
-  if (stats != nullptr) {                           // uniform
-    red[0][tl][cl] = make_float4(s1.x, s1.y, s1.z, s1.w); red[1][tl][cl] = make_float4(s2.x, s2.y, s2.z, s2.w);
-    __syncthreads();
-    if (tl == 0 && kok) {
-      float4 a1 = red[0][0][cl], a2 = red[1][0][cl];
-      for (int r = 1; r < 16; ++r) {
-        const float4 b1 = red[0][r][cl], b2 = red[1][r][cl];
-        a1 = make_float4(a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w);
-        a2 = make_float4(a2.x + b2.x, a2.y + b2.y, a2.z + b2.z, a2.w + b2.w);
-      }
-      float* sp = stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * K;
-      atomicAdd(sp + k, a1.x); atomicAdd(sp + k + 1, a1.y); atomicAdd(sp + k + 2, a1.z); atomicAdd(sp + k + 3, a1.w);
-      atomicAdd(sp + K + k, a2.x); atomicAdd(sp + K + k + 1, a2.y); atomicAdd(sp + K + k + 2, a2.z); atomicAdd(sp + K + k + 3, a2.w);
-    }
-  }
+  if (stats != nullptr)                             // uniform
+    st.fold16(red, tl, cl, kok, reinterpret_cast<double*>(stats) + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * K + k, K);
 }
 
 // backward-weight glue.  thread = (tile, 4 channels): Y'[36][T][K] = A dy A^T (dy outside the image = 0)

@@ -363,8 +363,12 @@ int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, fl
  * (reference network/res_encoder.py:364-373; vendored BasicBlock utils/Freihand_GNN_mano/network/resnet.py).
  * C % 4 == 0, C <= 4096.  act: 0 = none, 1 = ReLU, 2 = swish (x * sigmoid(x); MemoryEfficientSwish of the reference's
  * EfficientNet, network/efficientnet_pt/utils.py:36-52; no residual with swish).  stats_d / red_scratch_d hold hifihr_bn_stats_floats(C) floats: partial (sum, sum of
- * squares) over the M rows, spread over several slots to keep float-atomic contention low (from
- * hifihr_conv2d_fwd_bnstats, or hifihr_bn_stats for any other producer).
+ * squares) over the M rows, spread over several slots to keep atomic contention low (from
+ * hifihr_conv2d_fwd_bnstats, or hifihr_bn_stats for any other producer).  Since round 3 the FORWARD partials are float64
+ * (double[32][2][C] at the start of the buffer, which must be 8-byte aligned): producers accumulate sums shifted by a value of their own
+ * in fp32 and hand them over unshifted in fp64, the consumer forms mean and variance in fp64 -- the batch variance of a channel with
+ * |mean| >> std is as good as a Welford pass (PyTorch's nn.BatchNorm2d), which `E[x^2] - mean^2` in fp32 was not.  The layout is private
+ * to the library: callers only allocate, zero once, and pass the buffer along.
  * SELF-CLEANING: producers (hifihr_conv2d_fwd_bnstats, hifihr_dwconv2d_fwd, hifihr_wino_output_transform, hifihr_bn_stats,
  * the reduction inside hifihr_bn_act_bwd) ADD into stats_d / red_scratch_d, which must be all zero on entry;
  * hifihr_bn_act_fwd / hifihr_bn_act_bwd fold the slots inside their apply kernel (no separate finalize launch) and the

@@ -73,13 +73,23 @@ static inline void __syncthreads() { ::hostsim::syncthreads(); }
 
 template <typename T>
 static inline T hs_shfl_(T v, int src) {
-  static_assert(sizeof(T) == 4, "4-byte shuffles only");
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  u = ::hostsim::wave_exchange(u, src);
-  T r;
-  std::memcpy(&r, &u, 4);
-  return r;
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- and 8-byte shuffles only");
+  if constexpr (sizeof(T) == 8) {                 // a 64-bit shuffle is two 32-bit ones (as on the device)
+    uint32_t u[2];
+    std::memcpy(u, &v, 8);
+    u[0] = ::hostsim::wave_exchange(u[0], src);
+    u[1] = ::hostsim::wave_exchange(u[1], src);
+    T r;
+    std::memcpy(&r, u, 8);
+    return r;
+  } else {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    u = ::hostsim::wave_exchange(u, src);
+    T r;
+    std::memcpy(&r, &u, 4);
+    return r;
+  }
 }
 template <typename T> static inline T __shfl(T v, int src, int w = 64) { return hs_shfl_(v, (::hostsim::lane_id() & ~(w - 1)) + (src & (w - 1))); }
 template <typename T> static inline T __shfl_down(T v, unsigned d, int w = 64) {
@@ -113,6 +123,19 @@ static inline float atomicAdd(float* p, float v) {
   std::memcpy(&f, &old, 4);
   return f;
 }
+static inline double atomicAdd(double* p, double v) {
+  uint64_t* ip = reinterpret_cast<uint64_t*>(p);
+  uint64_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), nw;
+  double f;
+  do {
+    std::memcpy(&f, &old, 8);
+    f += v;
+    std::memcpy(&nw, &f, 8);
+  } while (!__atomic_compare_exchange_n(ip, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  std::memcpy(&f, &old, 8);
+  return f;
+}
+static inline double unsafeAtomicAdd(double* p, double v) { return atomicAdd(p, v); }
 static inline float atomicExch(float* p, float v) {
   uint32_t nw, old;
   std::memcpy(&nw, &v, 4);

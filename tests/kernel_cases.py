@@ -18,8 +18,9 @@ HOSTSIM_LIB = os.path.join(HOSTSIM_DIR, "libhifihr_hostsim.so")
 
 
 def bn_slots(stats, C, slots=32):
-    """[slots][2][C] partial (sum, sum of squares) view of a batch-norm slot buffer (include/hifihr.h: hifihr_bn_stats_floats)."""
-    return stats[:slots * 2 * C].view(slots, 2, C)
+    """[slots][2][C] partial (sum, sum of squares) view of a batch-norm FORWARD statistics buffer: float64 since round 3
+    (include/hifihr.h: hifihr_bn_stats_floats; csrc/hifihr_internal.h "FORWARD statistics")."""
+    return stats[:slots * 2 * C * 2].view(torch.float64).view(slots, 2, C)
 
 
 def build_hostsim() -> HifihrLib:
@@ -460,7 +461,7 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
     y = torch.empty(N, H, W, C, device=device); sm = torch.empty(C, device=device); si = torch.empty(C, device=device)
     rmd, rvd = rm0.clone().to(device), rv0.clone().to(device)
     lib.bn_act_fwd(dx_in, stats, gamma.to(device), beta.to(device), nhwc(res) if residual else None, act, M, C, 1e-5, 0.1, y, sm, si, rmd, rvd)
-    assert float(bn_slots(stats, C).abs().max()) == 0.0 and float(stats[-64:].abs().max()) == 0.0, "bn_act_fwd must leave the slots and arrival counters zeroed"
+    assert float(stats.abs().max()) == 0.0, "bn_act_fwd must leave the slots and arrival counters zeroed"
     ref = out.detach().permute(0, 2, 3, 1)
     assert float((y.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), "bn fwd"
     np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
@@ -468,7 +469,7 @@ def bn_act_case(lib, device, N, H, W, C, relu, residual, seed=0, from_conv=False
     red = torch.zeros(lib.bn_stats_floats(C), device=device); dxo = torch.empty_like(y); dres = torch.empty_like(y) if residual else None
     dg = torch.full((C,), 0.5, device=device); db = torch.full((C,), -0.25, device=device)     # accumulate semantics
     lib.bn_act_bwd(nhwc(gy), y if act == 1 else None, dx_in, sm, si, gamma.to(device), beta.to(device), act, M, C, red, dxo, dres, dg, db)
-    assert float(bn_slots(red, C).abs().max()) == 0.0 and float(red[-64:].abs().max()) == 0.0, "bn_act_bwd must leave the slots and arrival counters zeroed"
+    assert float(red[:32 * 4 * C + 64].abs().max()) == 0.0, "bn_act_bwd must leave the slots and arrival counters zeroed"
     if act == 1 and not residual:       # ReLU mask recomputed from x instead of read from y: the same gradients (the slot sums
         #                                 are float atomics, so two launches agree to rounding, not to the bit)
         dxo2 = torch.full_like(dxo, 7.0); dg2 = torch.zeros_like(dg); db2 = torch.zeros_like(db)
@@ -1322,3 +1323,67 @@ def resnet18_b8_check(g, net, low, feat, out_atol, grad_rtol):
     bad = {k: v for k, v in worst.items() if v >= grad_rtol}
     assert not bad, bad
     return worst
+
+
+# ------------------------------------------------------------------------------------------------
+# batch statistics of activations with |mean| >> std (round-2 review: E[x^2] - mean^2 in fp32 loses the variance there)
+# ------------------------------------------------------------------------------------------------
+def bn_large_mean_case(lib, device, producer, seed=0, mean=50.0, std=0.1):
+    """A batch-norm whose input has mean 50 / std 0.1 per channel (mean^2 / var = 2.5e5: in fp32 `E[x^2] - mean^2` has no correct digit
+    left), statistics from every kind of producer, against F.batch_norm computed in float64 on the same values.
+    producer: "stats" (hifihr_bn_stats on the tensor), "conv3x3" (implicit-GEMM epilogue), "conv1x1" (GEMM row-share epilogue),
+    "halo" (layer-1 kernel), "wino4" / "wino2" (Winograd output transforms), "dw" (depthwise epilogue)."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    d = lambda t: t.to(device).contiguous()
+    if producer == "stats":
+        N, H, W, K = 4, 9, 7, 64
+        y = mean + std * torch.randn(N, K, H, W, generator=gen)
+        yd = d(y.permute(0, 2, 3, 1))
+        stats = torch.zeros(lib.bn_stats_floats(K), device=device)
+        lib.bn_stats(yd, N * H * W, K, stats)
+    elif producer == "dw":
+        N, H, W, K = 2, 9, 8, 64
+        x = mean + std * torch.randn(N, K, H, W, generator=gen)
+        w = torch.full((K, 1, 3, 3), 1.0 / 9) + 0.01 * torch.randn(K, 1, 3, 3, generator=gen)
+        y = F.conv2d(x.double(), w.double(), None, 1, 0, groups=K).float()
+        OH, OW = y.shape[2], y.shape[3]
+        yd = torch.empty(N, OH, OW, K, device=device); stats = torch.zeros(lib.bn_stats_floats(K), device=device)
+        lib.dwconv2d_fwd(d(x.permute(0, 2, 3, 1)), d(w.reshape(K, 3, 3)), yd, N, H, W, K, OH, OW, 3, 1, 0, 0, stats=stats)
+        H, W = OH, OW
+    else:
+        N, H, W, C, K, R = {"conv3x3": (2, 9, 7, 16, 64, 3), "conv1x1": (2, 8, 8, 32, 128, 1), "halo": (2, 10, 14, 64, 64, 3),
+                            "wino4": (2, 8, 8, 64, 64, 3), "wino2": (2, 8, 8, 64, 64, 3)}[producer]
+        # a strongly positive input and filters that are (almost) a positive centre tap: every output channel sits at a large mean with a
+        # small spread, at the zero-padded border too
+        x = mean + std * torch.randn(N, C, H, W, generator=gen)
+        w = 1e-4 * torch.randn(K, C, R, R, generator=gen) / C
+        w[:, :, R // 2, R // 2] = (1.0 + 0.05 * torch.randn(K, C, generator=gen)) / C
+        pad = R // 2
+        y = F.conv2d(x.double(), w.double(), None, 1, pad).float()
+        xd, wd = d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1))
+        yd = torch.empty(N, H, W, K, device=device); stats = torch.zeros(lib.bn_stats_floats(K), device=device)
+        if producer in ("wino4", "wino2"):
+            m = 4 if producer == "wino4" else 2
+            P, T = (m + 2) ** 2, N * ((H + m - 1) // m) * ((W + m - 1) // m)
+            U = torch.empty(P, K, C, device=device); V = torch.empty(P, T, C, device=device); Mm = torch.empty(P, T, K, device=device)
+            lib.wino_weight_transform(wd, U, K, C, 0, m); lib.wino_input_transform(xd, V, N, H, W, C, m)
+            lib.wino_gemm(V, U, Mm, N, H, W, C, K, ws=None, m=m); lib.wino_output_transform(Mm, yd, stats, N, H, W, K, m=m)
+        else:
+            lib.conv2d_fwd_bnstats(xd, wd, yd, stats, N, H, W, C, K, R, R, 1, pad)
+    # interior channel statistics as they are (what the kernel saw is its OWN y: compare against statistics of that tensor in float64)
+    yk = yd.cpu().double().reshape(-1, K)
+    mu64, var64 = yk.mean(0), yk.var(0, unbiased=False)
+    assert float((mu64.abs() / var64.sqrt()).min()) > 30.0, "the case is meant to have |mean| >> std"
+    gamma = 1 + 0.1 * torch.randn(K, generator=gen); beta = 0.1 * torch.randn(K, generator=gen)
+    out = torch.empty_like(yd); sm = torch.empty(K, device=device); si = torch.empty(K, device=device)
+    rm, rv = torch.zeros(K, device=device), torch.ones(K, device=device)
+    lib.bn_act_fwd(yd, stats, d(gamma), d(beta), None, 0, N * H * W, K, 1e-5, 0.1, out, sm, si, rm, rv)
+    assert float(stats.abs().max()) == 0.0
+    np.testing.assert_allclose(sm.cpu().double().numpy(), mu64.numpy(), rtol=2e-7, atol=0)
+    inv64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    np.testing.assert_allclose(si.cpu().double().numpy(), inv64.numpy(), rtol=2e-4, atol=0, err_msg=f"{producer}: 1/sqrt(var + eps)")
+    ref = ((yk - mu64) * inv64 * gamma.double() + beta.double()).float().reshape(out.shape)
+    # the normalised output amplifies the rounding of y and of the saved fp32 mean (ulp(50) / std = 4e-5 of a standard deviation each)
+    assert float((out.cpu() - ref).abs().max()) <= 2e-3, (producer, float((out.cpu() - ref).abs().max()))
+    np.testing.assert_allclose(rv.cpu().double().numpy(), (0.9 + 0.1 * var64 * (N * H * W) / (N * H * W - 1)).numpy(), rtol=2e-4)

@@ -99,6 +99,13 @@ def test_bn_relu_maxpool_stem(lib, N, H, W, C):
     kc.bn_relu_maxpool_case(lib, "cuda", N, H, W, C, seed=N + C)
 
 
+@pytest.mark.parametrize("producer", ["stats", "conv3x3", "conv1x1", "halo", "wino4", "wino2", "dw"])
+def test_bn_statistics_with_mean_much_larger_than_std(lib, producer):
+    """Round-2 review: channels with mean 50 / std 0.1.  Shifted sums per lane, fp64 slots, fp64 fold (csrc/hifihr_internal.h "FORWARD
+    statistics") against float64 statistics of the same tensor, for every kernel that produces batch statistics."""
+    kc.bn_large_mean_case(lib, "cuda", producer)
+
+
 def test_conv_epilogue_bn_statistics(lib):
     kc.conv_bnstats_case(lib, "cuda", 8, 56, 56, 64, 64, 3, 1, 1)
     kc.conv_bnstats_case(lib, "cuda", 4, 224, 224, 4, 64, 7, 2, 3)

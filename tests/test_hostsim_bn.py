@@ -23,3 +23,9 @@ def test_bn_relu_maxpool_stem(hostsim_lib, N, H, W, C):
 def test_conv_epilogue_bn_statistics(hostsim_lib):
     kc.conv_bnstats_case(hostsim_lib, "cpu", 2, 9, 7, 16, 64, 3, 1, 1)
     kc.conv_bnstats_case(hostsim_lib, "cpu", 1, 16, 16, 4, 64, 7, 2, 3)
+
+
+@pytest.mark.parametrize("producer", ["stats", "conv3x3", "conv1x1", "halo", "wino4", "wino2", "dw"])
+def test_bn_statistics_with_mean_much_larger_than_std(hostsim_lib, producer):
+    """mean 50 / std 0.1 channels: the shifted-sum / fp64-slot statistics of every producer against float64 statistics."""
+    kc.bn_large_mean_case(hostsim_lib, "cpu", producer)
