@@ -1304,12 +1304,13 @@ def resnet18_b8_inputs(g):
     return x, wl, wf
 
 
-def resnet18_b8_check(g, net, low, feat, out_atol, grad_rtol):
-    """net = a module with torchvision's ResNet attribute names whose .grad fields are filled; every gradient the fixture holds."""
+def resnet18_b8_check(g, net, low, feat, out_atol, grad_rtol, grad_l2=None):
+    """net = a module with torchvision's ResNet attribute names whose .grad fields are filled; every gradient the fixture holds:
+    max error / max |reference| < grad_rtol and, if given, relative L2 error < grad_l2."""
     np.testing.assert_allclose(low.detach().cpu().numpy(), g["low"], atol=out_atol, rtol=1e-4)
     np.testing.assert_allclose(feat.detach().cpu().numpy(), g["feat"], atol=out_atol, rtol=1e-4)
     params = dict(net.named_parameters())
-    worst = {}
+    worst, l2 = {}, {}
     for key in g.files:
         if not key.startswith("g_"):
             continue
@@ -1320,9 +1321,13 @@ def resnet18_b8_check(g, net, low, feat, out_atol, grad_rtol):
         if grad.ndim == 4:
             grad = grad[:8]
         worst[name] = float(np.abs(grad - ref).max() / (np.abs(ref).max() + 1e-12))
+        l2[name] = float(np.linalg.norm((grad - ref).ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30))
     bad = {k: v for k, v in worst.items() if v >= grad_rtol}
     assert not bad, bad
-    return worst
+    if grad_l2 is not None:
+        bad = {k: v for k, v in l2.items() if v >= grad_l2}
+        assert not bad, ("relative L2", bad)
+    return worst, l2
 
 
 # ------------------------------------------------------------------------------------------------

@@ -70,8 +70,13 @@ def test_resnet18_trunk_mfma_vs_reference_golden(golden_dir):
 
 def test_resnet18_trunk_mfma_vs_reference_golden_batch8(golden_dir):
     """Batch of 8 (tests/golden/resnet18_b8.npz: the reference's vendored ResNet executed by tools/make_golden.py:gen_resnet18_b8):
-    features 2e-4 absolute, all fourteen stored gradients (stem, every stage, both kinds of shortcut, batch-norm scale and shift)
-    within 2e-3 of their maximum."""
+    features and low features 2e-4 absolute (1e-5 of their range observed); all fourteen stored gradients (stem, every stage, both
+    kinds of shortcut, batch-norm scale and shift) within 1e-2 relative L2 / 2e-2 of their maximum.  Why not tighter: this network is
+    perfectly conditioned (PyTorch fp32 against float64: gradients 2e-6), but its gradient is DISCONTINUOUS in the ReLU signs, and a
+    forward that rounds differently (Winograd: 1e-5 of max |y|) moves a handful of the ~1e6 pre-activations across zero; one flipped
+    unit of a 4x4 map changes that channel's gradient by ~1/128 and the batch-norm backward spreads it (measured: 1.7e-3 .. 7e-3
+    of max depending on which units flip).  The arithmetic of the backward kernels themselves is held to 2e-4 by the next test,
+    which imposes one ReLU pattern on both sides."""
     import os, sys
     import numpy as np
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -85,8 +90,76 @@ def test_resnet18_trunk_mfma_vs_reference_golden_batch8(golden_dir):
     enc = enc.cuda().train()
     low, feat = enc(ops.image_to_nhwc4(x.cuda()))
     ((low * wl.cuda()).sum() + (feat * wf.cuda()).sum()).backward()
-    worst = kc.resnet18_b8_check(g, enc.model, low, feat, out_atol=2e-4, grad_rtol=2e-3)
-    print("resnet18 b8 gradient errors (relative to max):", {k: f"{v:.1e}" for k, v in worst.items()})
+    worst, l2 = kc.resnet18_b8_check(g, enc.model, low, feat, out_atol=2e-4, grad_rtol=2e-2, grad_l2=1e-2)
+    print("resnet18 b8 gradient errors (max / max|ref|):", {k: f"{v:.1e}" for k, v in worst.items()})
+    print("resnet18 b8 gradient errors (relative L2):", {k: f"{v:.1e}" for k, v in l2.items()})
+
+
+def test_resnet18_trunk_backward_given_the_same_relu_pattern(golden_dir):
+    """Backward ARITHMETIC of the whole MFMA trunk, isolated from ReLU sign flips.  Against reference-generated gradients the trunk
+    differs by up to ~5e-3 of a gradient's maximum on the batch-of-8 fixture although its activations agree to 1e-5: with ~1e6 ReLU
+    inputs a forward rounding error of 1e-5 (Winograd F(4x4, 3x3); 1e-6 for the direct kernels) lands a handful of pre-activations on
+    the other side of zero, and one flipped unit in a 4x4 map changes that channel's gradients by ~1 / 128 (tools/_probe/b8_bisect.py
+    counts them against a float64 run).  Here the oracle trunk (float64, CPU) is run with OUR ReLU patterns imposed -- every F.relu
+    becomes a multiplication by the mask the product's forward produced -- so that what is compared is the chain of backward-data /
+    backward-weight / batch-norm-backward kernels itself: every parameter gradient within 2e-4 of its maximum."""
+    import os, sys
+    import numpy as np
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from seeded_init import seeded_state_dict
+    from hifihr_amd import ops
+    from hifihr_amd.network import Resnet_4C
+    import oracle.torch_modules as tm
+    g = np.load(os.path.join(golden_dir, "resnet18_b8.npz"))
+    x, wl, wf = kc.resnet18_b8_inputs(g)
+    enc = Resnet_4C("res18")
+    enc.model.load_state_dict(seeded_state_dict(enc.model))
+    enc = enc.cuda().train()
+    masks = []
+    real_bn_act, real_stem = ops.bn_act, ops.bn_relu_maxpool
+
+    def rec_bn_act(xx, stats, bn, residual=None, relu=True):
+        y = real_bn_act(xx, stats, bn, residual, relu)
+        if relu is True:
+            masks.append((y.detach() > 0).cpu())
+        return y
+
+    def rec_stem(xx, stats, bn):
+        z = F.batch_norm(xx.detach().double(), None, None, bn.weight.detach().double(), bn.bias.detach().double(), True, 0.0, bn.eps)
+        masks.append((z > 0).cpu())
+        return real_stem(xx, stats, bn)
+    ops.bn_act, ops.bn_relu_maxpool = rec_bn_act, rec_stem
+    try:
+        low, feat = enc(ops.image_to_nhwc4(x.cuda()))
+    finally:
+        ops.bn_act, ops.bn_relu_maxpool = real_bn_act, real_stem
+    ((low * wl.cuda()).sum() + (feat * wf.cuda()).sum()).backward()
+    assert len(masks) == 17                                    # stem + 2 per BasicBlock
+    ref = tm.Resnet4CRef("res18")
+    ref.model.load_state_dict(seeded_state_dict(ref.model))
+    ref = ref.double().train()
+    it = iter(masks)
+    real_relu = tm.F.relu
+
+    def masked_relu(t, inplace=False):
+        m = next(it)
+        assert m.shape == t.shape
+        return t * m.to(t.dtype)
+    tm.F.relu = masked_relu
+    try:
+        low0, feat0 = ref(tm.normalize_batch_3C(x).double())
+    finally:
+        tm.F.relu = real_relu
+    ((low0 * wl.double()).sum() + (feat0 * wf.double()).sum()).backward()
+    assert float((feat.detach().cpu().double() - feat0.detach()).abs().max()) <= 1e-4 * float(feat0.detach().abs().max())
+    worst = {}
+    mine = dict(enc.model.named_parameters())
+    for n, p in ref.model.named_parameters():
+        worst[n] = float((mine[n].grad.detach().cpu().double() - p.grad).abs().max() / p.grad.abs().max())
+    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    print("largest gradient errors with the ReLU pattern imposed:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("C,relu,residual,N,H", [(64, True, False, 32, 56), (128, True, True, 8, 28), (512, False, False, 32, 14), (256, True, True, 4, 14)])

@@ -80,7 +80,7 @@ def test_resnet18_trunk_vs_reference_batch8(golden_dir):
     enc.train()
     low, feat = enc(normalize_batch_3C(x))
     ((low * wl).sum() + (feat * wf).sum()).backward()
-    kc.resnet18_b8_check(g, enc.model, low, feat, out_atol=2e-5, grad_rtol=2e-4)
+    kc.resnet18_b8_check(g, enc.model, low, feat, out_atol=2e-5, grad_rtol=2e-4, grad_l2=2e-4)
 
 
 def test_options_json_overlay_and_lambda_schedules(tmp_path):
