@@ -174,6 +174,8 @@ class HifihrLib:
         c.hifihr_wino_gemm_m.argtypes = [_c_float_p] * 3 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_wino_output_transform_m.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_output_transform_act_m.argtypes = [_c_float_p] * 3 + [c_int] * 6 + [c_void_p]
+        c.hifihr_wino_bn_input_supported.argtypes = [c_int, c_int]
+        c.hifihr_wino_bn_input_transform.argtypes = [_c_float_p] * 7 + [c_int] * 5 + [c_float, c_float] + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_wino_dy_transform_m.argtypes = [_c_float_p] * 2 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_input_dy_transform_m.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_wgrad_parts_m.argtypes = [c_int] * 6
@@ -406,6 +408,15 @@ class HifihrLib:
 
     def wino_input_transform(self, x, V, N, H, W, C, m=2):
         self.check(self.c.hifihr_wino_input_transform_m(_fp(x), _fp(V), N, H, W, C, m, _stream_of(x)), "hifihr_wino_input_transform")
+
+    def wino_bn_input_supported(self, C, m):
+        return bool(self.c.hifihr_wino_bn_input_supported(int(C), int(m)))
+
+    def wino_bn_input_transform(self, x, stats, gamma, beta, residual, out, V, N, H, W, C, m, eps, momentum, save_mean, save_invstd,
+                                running_mean, running_var):
+        self.check(self.c.hifihr_wino_bn_input_transform(_fp(x), _fp(stats), _fp(gamma), _fp(beta), _fp(residual), _fp(out), _fp(V), N, H, W, C, m,
+                                                         eps, momentum, _fp(save_mean), _fp(save_invstd), _fp(running_mean), _fp(running_var),
+                                                         _stream_of(x)), "hifihr_wino_bn_input_transform")
 
     def wino_gemm(self, V, U, M, N, H, W, C, K, ws=None, m=2):
         self.check(self.c.hifihr_wino_gemm_m(_fp(V), _fp(U), _fp(M), N, H, W, C, K, m, *self._ws(ws), _stream_of(V)), "hifihr_wino_gemm")

@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "hifihr_internal.h"
+#include "bn_fold.h"
 
 namespace hifihr {
 
@@ -135,62 +136,6 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 }
 
 constexpr int kMaxC = 4 * 256 * kMaxNG;     // 4096 channels: scale / shift tables of the apply kernels (2 x 16 KB of LDS)
-
-// True in every thread of exactly ONE workgroup of the launch: the last one to get here.  Called after the workgroup's last
-// read of the slot buffer; the elected workgroup may then overwrite it.  32 first-level counters keep the same-address
-// atomic traffic at <= grid / 32 per counter.
-__device__ __forceinline__ bool last_workgroup(unsigned* __restrict__ cnt) {
-  __shared__ int s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned slot = blockIdx.x & 31u, nslots = gridDim.x < 32u ? gridDim.x : 32u;
-    const unsigned in_slot = (gridDim.x + 31u - slot) / 32u;
-    int last = 0;
-    if (atomicAdd(cnt + slot, 1u) == in_slot - 1u) last = (atomicAdd(cnt + 32, 1u) == nslots - 1u) ? 1 : 0;
-    s_last = last;
-  }
-  __syncthreads();
-  return s_last != 0;
-}
-
-__device__ __forceinline__ void clear_slots(float* __restrict__ buf, int C, unsigned* __restrict__ cnt) {
-  float4* p = reinterpret_cast<float4*>(buf);
-  const int n4 = kStatSlots * 2 * C / 4;
-  for (int i = threadIdx.x; i < n4; i += 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (threadIdx.x < 33) cnt[threadIdx.x] = 0u;
-}
-
-// both statistics of channel c with all 64 loads in flight at once: this fold is the prologue of every workgroup of an apply kernel,
-// and in groups of 8 dependent-latency batches it cost ~5 us of the ~9 us a small layer's launch takes (tools/time_bn.py)
-__device__ __forceinline__ void slot_sum2(const float* __restrict__ buf, int C, int c, float& s0, float& s1) {
-  float a[kStatSlots], b[kStatSlots];
-#pragma unroll
-  for (int sl = 0; sl < kStatSlots; ++sl) { a[sl] = buf[(size_t)sl * 2 * C + c]; b[sl] = buf[(size_t)sl * 2 * C + C + c]; }
-  s0 = 0.f; s1 = 0.f;
-#pragma unroll
-  for (int sl = 0; sl < kStatSlots; ++sl) { s0 += a[sl]; s1 += b[sl]; }
-}
-
-// FORWARD statistics (double slots): mean and biased variance of channel c from the 32 slot partials, all 64 loads in flight
-__device__ __forceinline__ void slot_mean_var(const float* __restrict__ stats, int C, int c, long M, float& mu, float& var) {
-  const double* buf = reinterpret_cast<const double*>(stats);
-  double a[kStatSlots], b[kStatSlots];
-#pragma unroll
-  for (int sl = 0; sl < kStatSlots; ++sl) { a[sl] = buf[(size_t)sl * 2 * C + c]; b[sl] = buf[(size_t)sl * 2 * C + C + c]; }
-  double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-  for (int sl = 0; sl < kStatSlots; ++sl) { s0 += a[sl]; s1 += b[sl]; }
-  const double m = s0 / (double)M;
-  const double v = s1 / (double)M - m * m;           // fp64: the cancellation costs 2^-53 mean^2 / var
-  mu = (float)m;
-  var = v > 0.0 ? (float)v : 0.f;
-}
-__device__ __forceinline__ void clear_slots_fwd(float* __restrict__ stats, int C, unsigned* __restrict__ cnt) {
-  float4* p = reinterpret_cast<float4*>(stats);
-  const int n4 = kStatSlots * 2 * C / 2;               // doubles: 8 bytes each
-  for (int i = threadIdx.x; i < n4; i += 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (threadIdx.x < 33) cnt[threadIdx.x] = 0u;
-}
 
 // Wide layers (C > kFuseMaxC): folding 256 C bytes of partials in EVERY workgroup costs more than it saves (EfficientNet's
 // 1392-channel layers: +1.2 ms per step measured), so they keep a one-thread-per-channel finalize launch that also cleans the slots.

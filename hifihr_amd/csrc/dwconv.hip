@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* 
       for (int p = 0; p < kPW; ++p) {
         if (ow0 + p < g.OW) {
           *reinterpret_cast<float4*>(y + (((size_t)n * g.OH + oh) * g.OW + ow0 + p) * g.C + c) = acc[p];
+          if (p == 0) st.seed(acc[p]);
           st.add(acc[p]);
         }
       }

@@ -1019,6 +1019,19 @@ int hifihr_wino_output_transform_m(const float* M, float* y, float* stats, int N
   return HIFIHR_OK;
 }
 
+int hifihr_wino_bn_input_supported(int C, int m) { return (m == 4 && hifihr::wino4_bn_supported(C)) ? 1 : 0; }
+
+int hifihr_wino_bn_input_transform(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* out,
+                                   float* V, int N, int H, int W, int C, int m, float eps, float momentum, float* save_mean,
+                                   float* save_invstd, float* running_mean, float* running_var, void* stream) {
+  if (!x || !stats || !gamma || !beta || !V || !save_mean || !save_invstd || N <= 0 || H <= 0 || W <= 0 || ((residual == nullptr) != (out == nullptr)))
+    return fail(HIFIHR_EINVAL, "hifihr_wino_bn_input_transform: bad argument");
+  if (!hifihr_wino_bn_input_supported(C, m)) return fail(HIFIHR_EINVAL, "hifihr_wino_bn_input_transform: needs m = 4 and C % 4 == 0, C <= 512");
+  HIP_TRY(hifihr::launch_wino4_bn_input_transform(x, stats, gamma, beta, residual, out, V, N, H, W, C, eps, momentum, save_mean, save_invstd,
+                                                  running_mean, running_var, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_input_dy_transform_m(const float* dy, float* V, float* Yt, int N, int H, int W, int K, int m, void* stream) {
   if (m != 4) return hifihr_wino_input_dy_transform(dy, V, Yt, N, H, W, K, stream);
   if (!dy || !V || !Yt || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0)

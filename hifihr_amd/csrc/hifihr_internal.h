@@ -143,11 +143,15 @@ struct Stat4 {
   float4 k, s, q;
   int n;
   __device__ __forceinline__ Stat4() : k(make_float4(0.f, 0.f, 0.f, 0.f)), s(k), q(k), n(0) {}
-  __device__ __forceinline__ void add(const float4& v) {
+  // seed(): call with (any) one value before the first add() -- the callers do it at ONE fixed position of their tile, so the check is
+  // paid once per 16 values, not per value (the per-value form cost the Winograd output transform 0.9 us per launch)
+  __device__ __forceinline__ void seed(const float4& v) {
     if (n == 0) k = v;
+  }
+  __device__ __forceinline__ void add(const float4& v) {
     const float dx = v.x - k.x, dy = v.y - k.y, dz = v.z - k.z, dw = v.w - k.w;
     s.x += dx; s.y += dy; s.z += dz; s.w += dw;
-    q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+    q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
     ++n;
   }
   // red: __shared__ double[2][16][16][4]; every thread of the workgroup calls it (one barrier inside)
@@ -327,6 +331,11 @@ hipError_t launch_wino_dw_transform_parts(const float* dU_parts, int parts, floa
 // Winograd F(4x4, 3x3) glue (wino4.hip): 36 positions, T = N * ceil(H / 4) * ceil(W / 4)
 hipError_t launch_wino4_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st);
 hipError_t launch_wino4_input_transform(const float* x, float* V, float* Y /* or nullptr */, int N, int H, int W, int C, hipStream_t st);
+// csrc/wino4_bn.hip: batch-norm (+ residual) + ReLU applied on the fly inside the F(4x4, 3x3) input transform (C <= 512)
+bool wino4_bn_supported(int C);
+hipError_t launch_wino4_bn_input_transform(const float* x, float* stats, const float* gamma, const float* beta, const float* res, float* out,
+                                           float* V, int N, int H, int W, int C, float eps, float momentum, float* save_mean,
+                                           float* save_invstd, float* running_mean, float* running_var, hipStream_t st);
 hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
                                          hipStream_t st);
 hipError_t launch_wino4_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st);

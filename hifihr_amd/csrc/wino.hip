@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
         if (oh < H) {
           float* p = y + (((size_t)n * H + oh) * W + 2 * tw) * K + k;
           *reinterpret_cast<float4*>(p) = o0;
+          if (a == 0) st.seed(o0);
           st.add(o0);
           if (2 * tw + 1 < W) {
             *reinterpret_cast<float4*>(p + K) = o1;

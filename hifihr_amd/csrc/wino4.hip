@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
               V4 v = o[b] + bv;
               v = V4{fmaxf(v.x, lo), fmaxf(v.y, lo), fmaxf(v.z, lo), fmaxf(v.w, lo)};
               st4(p + (size_t)b * K, v);
+              if (a == 0 && b == 0) st.seed(make_float4(v.x, v.y, v.z, v.w));      // (a tile's first pixel is always inside the image)
               st.add(make_float4(v.x, v.y, v.z, v.w));
             }
           }

@@ -66,6 +66,23 @@ def _conv_bn(conv, x, bn):
     return conv(x), None
 
 
+class _PendingBN:
+    """A block output whose last batch-norm (+ identity + ReLU) has not been applied yet: (raw convolution output, its batch
+    statistics, the BatchNorm2d, the identity branch).  The next BasicBlock applies it inside the input transform of its first
+    convolution (ops.bn_act_wino_conv) when that convolution runs on the Winograd path, or materialises it (one bn_act launch)."""
+
+    def __init__(self, y, stats, bn, identity):
+        self.y, self.stats, self.bn, self.identity = y, stats, bn, identity
+
+    def materialize(self):
+        from . import ops
+        return ops.bn_act(self.y, self.stats, self.bn, self.identity, True)
+
+
+def _resolve(x):
+    return x.materialize() if isinstance(x, _PendingBN) else x
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -76,17 +93,32 @@ class BasicBlock(nn.Module):
         self.conv2 = _conv(planes, planes, 3, 1, 1)
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
+        self.lazy_out = False          # the trunk sets it where the next module takes a _PendingBN (Resnet_4C)
 
     def forward(self, x):
-        # conv (MFMA, BN statistics from its epilogue) -> fused BN (+ identity) + ReLU
+        # conv (MFMA, BN statistics from its epilogue) -> BN (+ identity) + ReLU, fused INTO the next convolution's Winograd input
+        # transform where there is one (csrc/wino4_bn.hip), else one fused launch of its own (csrc/bn.hip)
         from . import ops
-        out, st = _conv_bn(self.conv1, x, self.bn1)
-        out = ops.bn_act(out, st, self.bn1, None, True)
-        out, st = _conv_bn(self.conv2, out, self.bn2)
+        if isinstance(x, _PendingBN):
+            p = x
+            if p.bn.training and ops.bn_wino_fusable(p.y, self.conv1.weight, p.bn, self.conv1.stride, self.conv1.pad):
+                out, st, x = ops.bn_act_wino_conv(p.y, p.stats, p.bn, p.identity, self.conv1.weight, self.bn1.training)
+            else:
+                x = p.materialize()
+                out, st = _conv_bn(self.conv1, x, self.bn1)
+        else:
+            out, st = _conv_bn(self.conv1, x, self.bn1)
+        if st is not None and ops.bn_wino_fusable(out, self.conv2.weight, self.bn1, 1, 1):
+            out, st, _ = ops.bn_act_wino_conv(out, st, self.bn1, None, self.conv2.weight, self.bn2.training)
+        else:
+            out = ops.bn_act(out, st, self.bn1, None, True)
+            out, st = _conv_bn(self.conv2, out, self.bn2)
         idt = x
         if self.downsample is not None:
             idt, st2 = _conv_bn(self.downsample[0], x, self.downsample[1])
             idt = ops.bn_act(idt, st2, self.downsample[1], None, False)
+        if self.lazy_out and self.bn2.training:
+            return _PendingBN(out, st, self.bn2, idt)
         return ops.bn_act(out, st, self.bn2, idt, True)
 
 
@@ -108,6 +140,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         from . import ops
+        x = _resolve(x)
         out, st = _conv_bn(self.conv1, x, self.bn1)
         out = ops.bn_act(out, st, self.bn1, None, True)
         out, st = _conv_bn(self.conv2, out, self.bn2)
@@ -158,6 +191,13 @@ class Resnet_4C(nn.Module):
         if pretrain not in arch:
             raise NotImplementedError(f"encoder '{pretrain}' is not built (res18 / res50 / res101; the HRNet variants need timm)")
         self.model = ResNet18Trunk(in_ch=4 if if_4c else 3, layer4_stride=1, block=arch[pretrain][0], layers=arch[pretrain][1])
+        # BasicBlocks hand their output over un-normalised (a _PendingBN) wherever the next module is another BasicBlock: it applies the
+        # batch-norm inside its first convolution's input transform.  The two block outputs this module returns are materialised.
+        m = self.model
+        blocks = [b for layer in (m.layer1, m.layer2, m.layer3, m.layer4) for b in layer]
+        for b, nxt in zip(blocks, blocks[1:]):
+            if isinstance(b, BasicBlock) and isinstance(nxt, BasicBlock) and b is not m.layer2[-1]:
+                b.lazy_out = True
 
     def forward(self, x):
         from . import ops
@@ -165,8 +205,8 @@ class Resnet_4C(nn.Module):
         h, st = _conv_bn(m.conv1, x, m.bn1)
         x = ops.bn_relu_maxpool(h, st, m.bn1)
         x = m.layer1(x)
-        x_low = m.layer2(x)
-        x = m.layer4(m.layer3(x_low))
+        x_low = _resolve(m.layer2(x))
+        x = _resolve(m.layer4(m.layer3(x_low)))
         return x_low, x
 
 

@@ -852,6 +852,115 @@ class _BNActEval(torch.autograd.Function):
         return g * sc, (g * xhat).sum((0, 2, 3)), g.sum((0, 2, 3)), (g if ctx.has_res else None), None, None, None, None
 
 
+class _CtxShim:
+    """What _Conv2dMFMA.backward / _BNAct.backward read from their autograd context, for the fused functions that run those backward
+    passes on tensors they saved themselves."""
+
+    def __init__(self, saved, **kw):
+        self.saved_tensors = saved
+        self.__dict__.update(kw)
+
+
+def bn_wino_fusable(x, w, bn, stride, pad):
+    """A train-mode BatchNorm2d + ReLU in front of this convolution can run inside its Winograd input transform (csrc/wino4_bn.hip)."""
+    if os.environ.get("HIFIHR_BN_WINO_FUSE", "1") == "0" or not bn.training or not x.is_cuda:
+        return False
+    N, C, H, W = x.shape
+    K, Cw, R, S = w.shape
+    if Cw != C or not _wino_ok(C, K, R, S, stride, pad):
+        return False
+    lib = get_lib()
+    return _wino_tile(lib, N, H, W, C, K)[0] == 4 and lib.wino_bn_input_supported(C, 4)
+
+
+class _BNActWinoConv(torch.autograd.Function):
+    """conv3x3(relu(bn(x; batch statistics) (+ residual)), w) with the batch-norm applied inside the Winograd F(4x4, 3x3) input transform
+    (hifihr_wino_bn_input_transform): the activation is never written on its own.  With a residual the block output
+    relu(bn(x) + residual) is also returned (the next block's identity branch and shortcut convolution read it).
+    Replaces, per BasicBlock of the reference's ResNet (network/res_encoder.py:364-373, vendored resnet.py BasicBlock.forward), the
+    dispatches bn1 -> relu -> conv2 and bn2 -> += identity -> relu -> conv1 of the next block.
+    -> (y, stats of y or None, block output or None)."""
+
+    @staticmethod
+    def forward(ctx, x, stats, gamma, beta, residual, w, eps, momentum, running_mean, running_var, want_stats):
+        require_cuda(x, stats, gamma, beta, w)
+        lib = get_lib()
+        x = x.contiguous(memory_format=_CL)
+        wk = w.contiguous(memory_format=_CL)
+        N, C, H, W = x.shape
+        K = wk.shape[0]
+        dev = x.device
+        tile = _wino_tile(lib, N, H, W, C, K)
+        m, P, T = tile
+        assert m == 4
+        res = residual.contiguous(memory_format=_CL) if residual is not None else None
+        out = torch.empty_like(x, memory_format=_CL) if res is not None else None
+        save_mean, save_invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        U = _WEIGHT_PREP.get(w, wk, 3)
+        V = torch.empty(P * T * C, device=dev, dtype=torch.float32)       # kept: the Winograd weight gradient reduces Y' . V
+        y = torch.empty((N, K, H, W), device=dev, dtype=torch.float32, memory_format=_CL)
+        stats_next = _ZERO_POOL.acquire(lib.bn_stats_floats(K), dev) if want_stats else None
+
+        def run():
+            Uu = U
+            if Uu is None:
+                Uu = _wino_scratch(dev, "U", P * K * C)
+                lib.wino_weight_transform(wk, Uu, K, C, 0, m)
+            lib.wino_bn_input_transform(x, stats, gamma, beta, res, out, V, N, H, W, C, m, eps, momentum, save_mean, save_invstd,
+                                        running_mean, running_var)
+            M = _wino_scratch(dev, "M", P * T * K)
+            key = ("wino", N, H, W, C, K, m)
+            nb = _CONV_WS_BYTES.get(key)
+            if nb is None:
+                nb = lib.wino_gemm_workspace_bytes(N, H, W, C, K, m)
+                _CONV_WS_BYTES[key] = nb
+            ws = None
+            if nb:
+                ws = _CONV_WS.get(dev)
+                if ws is None or ws.numel() * 4 < nb:
+                    if ws is not None:
+                        _RETIRED_SCRATCH.append(ws)
+                    ws = torch.zeros(max(nb, 32 << 20) // 4 + 64, dtype=torch.float32, device=dev)
+                    _CONV_WS[dev] = ws
+            lib.wino_gemm(V, Uu, M, N, H, W, C, K, ws=ws, m=m)
+            lib.wino_output_transform(M, y, stats_next, N, H, W, K, m=m)
+        if PROFILE.on:
+            PROFILE.conv_log.append((("wino", N, H, W, C, K, m), "gemm"))
+        PROFILE.bracket("bn_conv_fwd_wino", run)
+        _ZERO_POOL.release(stats)                # consumed and zeroed by the fused transform
+        ctx.save_for_backward(x, out if out is not None else x.new_empty(0), gamma, beta, save_mean, save_invstd, wk, V)
+        ctx.geom = (N, H, W, C, K, 3, 3, 1, 1)
+        ctx.has_res = res is not None
+        ctx.w_param, ctx.gamma_param, ctx.beta_param = w, gamma, beta
+        ctx.set_materialize_grads(False)
+        if stats_next is not None:
+            ctx.mark_non_differentiable(stats_next)
+        return y, stats_next, out
+
+    @staticmethod
+    def backward(ctx, gy, _gstats, g_out):
+        x, out, gamma, beta, save_mean, save_invstd, wk, V = ctx.saved_tensors
+        N, H, W, C, K = ctx.geom[:5]
+        if gy is None:                            # the convolution's output went nowhere: only the identity branch brings a gradient
+            raise NotImplementedError("fused batch-norm + Winograd convolution whose convolution output is unused")
+        need = ctx.needs_input_grad
+        conv = _CtxShim((None, wk, None, V), geom=ctx.geom, w_param=ctx.w_param, b_param=None, relu=False, w3=None,
+                        needs_input_grad=(True, need[5], False, False, False, False, False))
+        d_a, dw = _Conv2dMFMA.backward(conv, gy)[:2]
+        if g_out is not None:
+            d_a = d_a + g_out                     # the identity branch of the next block
+        bn = _CtxShim((x, out if ctx.has_res else x.new_empty(0), gamma, beta, save_mean, save_invstd), act=1, has_res=ctx.has_res,
+                      M=N * H * W, C=C, gamma_param=ctx.gamma_param, beta_param=ctx.beta_param)
+        dx, _, dg, db, dres = _BNAct.backward(bn, d_a)[:5]
+        return dx, None, dg, db, dres, dw, None, None, None, None, None
+
+
+def bn_act_wino_conv(x, stats, bn: torch.nn.BatchNorm2d, residual, w, want_stats):
+    """See _BNActWinoConv; `bn` in training mode, `stats` from the producer of x (conv2d(..., want_stats=True))."""
+    return _BNActWinoConv.apply(x, stats, bn.weight, bn.bias, residual, w, float(bn.eps), float(bn.momentum), bn.running_mean,
+                                bn.running_var, want_stats)
+
+
 _ACT = {None: 0, False: 0, True: 1, "relu": 1, "swish": 2}
 
 

@@ -297,6 +297,18 @@ int hifihr_wino_output_transform_m(const float* m_d, float* y_d, float* stats_d 
 int hifihr_wino_output_transform_act_m(const float* m_d, float* y_d, const float* bias_d /* or NULL */, int act, int N, int H, int W, int K,
                                        int m, void* stream);
 int hifihr_wino_dy_transform_m(const float* dy_d, float* yt_d, int N, int H, int W, int K, int m, void* stream);
+/* Batch-norm fused into the F(4x4, 3x3) input transform (round 3, csrc/wino4_bn.hip).  For a BatchNorm2d whose consumer is a Winograd
+ * convolution (reference BasicBlock: conv1 -> bn1 -> relu -> conv2; bn2 -> += identity -> relu -> the next block's conv1,
+ * network/res_encoder.py:364-373 + vendored utils/Freihand_GNN_mano/network/resnet.py) this ONE launch replaces hifihr_bn_act_fwd followed by
+ * hifihr_wino_input_transform_m: x_d is the RAW output of the previous convolution, stats_d its batch statistics (consumed: zero on
+ * return, as in hifihr_bn_act_fwd, same save_mean / save_invstd / running-statistics semantics); the activation a = relu(bn(x) + residual?)
+ * is formed on the fly and only V = B^T a B is written.  With residual_d, out_d (same shape as x) receives a as well -- the next block's
+ * identity branch reads it; without, both are NULL and a is never stored (the backward recomputes the ReLU mask from x, as
+ * hifihr_bn_act_bwd does with y_d = NULL).  m = 4 and C % 4 == 0, C <= 512 (hifihr_wino_bn_input_supported). */
+int hifihr_wino_bn_input_supported(int C, int m);
+int hifihr_wino_bn_input_transform(const float* x_d, float* stats_d, const float* gamma_d, const float* beta_d, const float* residual_d,
+                                   float* out_d, float* v_d, int N, int H, int W, int C, int m, float eps, float momentum,
+                                   float* save_mean_d, float* save_invstd_d, float* running_mean_d, float* running_var_d, void* stream);
 int hifihr_wino_input_dy_transform_m(const float* dy_d, float* v_d, float* yt_d, int N, int H, int W, int K, int m, void* stream);
 int hifihr_wino_wgrad_parts_m(int N, int H, int W, int C, int K, int m);
 int hifihr_wino_wgrad_gemm_parts_m(const float* v_d, const float* yt_d, float* du_parts_d, int N, int H, int W, int C, int K, int parts, int m,

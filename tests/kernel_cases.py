@@ -1392,3 +1392,47 @@ def bn_large_mean_case(lib, device, producer, seed=0, mean=50.0, std=0.1):
     # the normalised output amplifies the rounding of y and of the saved fp32 mean (ulp(50) / std = 4e-5 of a standard deviation each)
     assert float((out.cpu() - ref).abs().max()) <= 2e-3, (producer, float((out.cpu() - ref).abs().max()))
     np.testing.assert_allclose(rv.cpu().double().numpy(), (0.9 + 0.1 * var64 * (N * H * W) / (N * H * W - 1)).numpy(), rtol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# batch-norm fused into the Winograd F(4x4, 3x3) input transform (csrc/wino4_bn.hip) vs the two separate launches
+# ------------------------------------------------------------------------------------------------
+def wino_bn_input_case(lib, device, N, H, W, C, residual, seed=0):
+    """hifihr_wino_bn_input_transform == hifihr_bn_act_fwd (ReLU, optional residual) followed by hifihr_wino_input_transform_m, bit for bit
+    (same scale / shift / residual / ReLU expression, same transform), and both against torch: V through the known input transform of a
+    torch-computed activation."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    d = lambda t: t.to(device).contiguous()
+    x = torch.randn(N, H, W, C, generator=gen) * 1.3 + 0.2
+    res = torch.randn(N, H, W, C, generator=gen) if residual else None
+    gamma = 1 + 0.1 * torch.randn(C, generator=gen); beta = 0.1 * torch.randn(C, generator=gen)
+    M = N * H * W
+    T = N * ((H + 3) // 4) * ((W + 3) // 4)
+
+    def fresh():
+        st = torch.zeros(lib.bn_stats_floats(C), device=device)
+        lib.bn_stats(d(x), M, C, st)
+        return st, torch.zeros(C, device=device), torch.ones(C, device=device), torch.empty(C, device=device), torch.empty(C, device=device)
+    # the two separate launches
+    st, rm0, rv0, sm0, si0 = fresh()
+    a0 = torch.empty(N, H, W, C, device=device)
+    lib.bn_act_fwd(d(x), st, d(gamma), d(beta), d(res) if residual else None, 1, M, C, 1e-5, 0.1, a0, sm0, si0, rm0, rv0)
+    V0 = torch.empty(36, T, C, device=device)
+    lib.wino_input_transform(a0, V0, N, H, W, C, 4)
+    # the fused launch
+    st, rm1, rv1, sm1, si1 = fresh()
+    V1 = torch.full((36, T, C), 7.0, device=device)
+    out = torch.full((N, H, W, C), 7.0, device=device) if residual else None
+    lib.wino_bn_input_transform(d(x), st, d(gamma), d(beta), d(res) if residual else None, out, V1, N, H, W, C, 4, 1e-5, 0.1, sm1, si1, rm1, rv1)
+    assert float(st.abs().max()) == 0.0, "statistics slots and counters must come back zeroed"
+    assert torch.equal(V1, V0), float((V1 - V0).abs().max())
+    assert torch.equal(sm1, sm0) and torch.equal(si1, si0) and torch.equal(rm1, rm0) and torch.equal(rv1, rv0)
+    if residual:
+        assert torch.equal(out, a0)
+    # and against torch
+    ref = F.batch_norm(x.permute(0, 3, 1, 2), None, None, gamma, beta, True, 0.0, 1e-5)
+    if residual:
+        ref = ref + res.permute(0, 3, 1, 2)
+    ref = F.relu(ref).permute(0, 2, 3, 1)
+    assert float((a0.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))

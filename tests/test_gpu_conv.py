@@ -129,11 +129,20 @@ def test_resnet18_trunk_backward_given_the_same_relu_pattern(golden_dir):
         z = F.batch_norm(xx.detach().double(), None, None, bn.weight.detach().double(), bn.bias.detach().double(), True, 0.0, bn.eps)
         masks.append((z > 0).cpu())
         return real_stem(xx, stats, bn)
-    ops.bn_act, ops.bn_relu_maxpool = rec_bn_act, rec_stem
+    real_fused = ops.bn_act_wino_conv
+
+    def rec_fused(xx, stats, bn, residual, w, want_stats):
+        # batch-norm (+ identity) + ReLU applied inside the next convolution's input transform: the activation is not stored
+        z = F.batch_norm(xx.detach().double(), None, None, bn.weight.detach().double(), bn.bias.detach().double(), True, 0.0, bn.eps)
+        if residual is not None:
+            z = z + residual.detach().double()
+        masks.append((z > 0).cpu())
+        return real_fused(xx, stats, bn, residual, w, want_stats)
+    ops.bn_act, ops.bn_relu_maxpool, ops.bn_act_wino_conv = rec_bn_act, rec_stem, rec_fused
     try:
         low, feat = enc(ops.image_to_nhwc4(x.cuda()))
     finally:
-        ops.bn_act, ops.bn_relu_maxpool = real_bn_act, real_stem
+        ops.bn_act, ops.bn_relu_maxpool, ops.bn_act_wino_conv = real_bn_act, real_stem, real_fused
     ((low * wl.cuda()).sum() + (feat * wf.cuda()).sum()).backward()
     assert len(masks) == 17                                    # stem + 2 per BasicBlock
     ref = tm.Resnet4CRef("res18")

@@ -30,3 +30,8 @@ def test_winograd_tile_choice(hostsim_lib):
     assert hostsim_lib.wino_tile(2, 3, 8, 64, 64) == 2          # H < 4
     assert hostsim_lib.wino_tile(2, 8, 8, 48, 64) == 2          # C not a multiple of 64: the slab GEMM does not take it
     assert hostsim_lib.wino_tile(32, 14, 14, 512, 512) == 4
+
+
+@pytest.mark.parametrize("N,H,W,C,residual", [(2, 8, 8, 64, False), (1, 7, 9, 32, True), (2, 4, 4, 128, True), (1, 14, 14, 24, False)])
+def test_bn_fused_into_winograd_input_transform(hostsim_lib, N, H, W, C, residual):
+    kc.wino_bn_input_case(hostsim_lib, "cpu", N, H, W, C, residual, seed=C + H)
