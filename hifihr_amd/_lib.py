@@ -176,6 +176,9 @@ class HifihrLib:
         c.hifihr_wino_output_transform_act_m.argtypes = [_c_float_p] * 3 + [c_int] * 6 + [c_void_p]
         c.hifihr_wino_bn_input_supported.argtypes = [c_int, c_int]
         c.hifihr_wino_bn_input_transform.argtypes = [_c_float_p] * 7 + [c_int] * 5 + [c_float, c_float] + [_c_float_p] * 4 + [c_void_p]
+        c.hifihr_wino_output_transform_bnred.argtypes = [_c_float_p] * 10 + [c_int] * 5 + [c_void_p]
+        c.hifihr_wino_bn_bwd_dual_transform.argtypes = [_c_float_p] * 8 + [c_int] * 5 + [_c_float_p] * 2 + [c_void_p]
+        c.hifihr_bn_bwd_apply.argtypes = [_c_float_p] * 5 + [c_long, c_int] + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_wino_dy_transform_m.argtypes = [_c_float_p] * 2 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_input_dy_transform_m.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_wgrad_parts_m.argtypes = [c_int] * 6
@@ -417,6 +420,20 @@ class HifihrLib:
         self.check(self.c.hifihr_wino_bn_input_transform(_fp(x), _fp(stats), _fp(gamma), _fp(beta), _fp(residual), _fp(out), _fp(V), N, H, W, C, m,
                                                          eps, momentum, _fp(save_mean), _fp(save_invstd), _fp(running_mean), _fp(running_var),
                                                          _stream_of(x)), "hifihr_wino_bn_input_transform")
+
+    def wino_output_transform_bnred(self, Mm, x, out, gadd, save_mean, save_invstd, gamma, beta, red, g, N, H, W, C, m):
+        self.check(self.c.hifihr_wino_output_transform_bnred(_fp(Mm), _fp(x), _fp(out), _fp(gadd), _fp(save_mean), _fp(save_invstd), _fp(gamma),
+                                                             _fp(beta), _fp(red), _fp(g), N, H, W, C, m, _stream_of(Mm)),
+                   "hifihr_wino_output_transform_bnred")
+
+    def wino_bn_bwd_dual_transform(self, g, y, save_mean, save_invstd, gamma, red, V, Yt, N, H, W, K, m, dgamma_acc, dbeta_acc):
+        self.check(self.c.hifihr_wino_bn_bwd_dual_transform(_fp(g), _fp(y), _fp(save_mean), _fp(save_invstd), _fp(gamma), _fp(red), _fp(V), _fp(Yt),
+                                                            N, H, W, K, m, _fp(dgamma_acc), _fp(dbeta_acc), _stream_of(g)),
+                   "hifihr_wino_bn_bwd_dual_transform")
+
+    def bn_bwd_apply(self, g, x, save_mean, save_invstd, gamma, M, C, red, dx, dgamma_acc, dbeta_acc):
+        self.check(self.c.hifihr_bn_bwd_apply(_fp(g), _fp(x), _fp(save_mean), _fp(save_invstd), _fp(gamma), M, C, _fp(red), _fp(dx),
+                                              _fp(dgamma_acc), _fp(dbeta_acc), _stream_of(g)), "hifihr_bn_bwd_apply")
 
     def wino_gemm(self, V, U, M, N, H, W, C, K, ws=None, m=2):
         self.check(self.c.hifihr_wino_gemm_m(_fp(V), _fp(U), _fp(M), N, H, W, C, K, m, *self._ws(ws), _stream_of(V)), "hifihr_wino_gemm")

@@ -790,6 +790,16 @@ hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, co
   return hipGetLastError();
 }
 
+// The apply half alone: g is ALREADY the masked gradient and red ALREADY holds its reduction sums (written by the fused output
+// transform of csrc/wino4_bn.hip); dx = gamma invstd (g - mean g - xhat mean(g xhat)), slots handed back zeroed.  C <= kFuseMaxC.
+hipError_t launch_bn_bwd_apply(const float* g, const float* x, const float* save_mean, const float* save_invstd, const float* gamma, long M,
+                               int C, float* red, float* dx, float* dgamma_acc, float* dbeta_acc, hipStream_t st) {
+  if (!bn_c_ok(C) || C > kFuseMaxC) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_grid(M, C, true)), dim3(256), 0, st, g, (const float*)nullptr, x, save_mean, save_invstd,
+                     gamma, (const float*)nullptr, red, 0, M, C, dx, (float*)nullptr, dgamma_acc, dbeta_acc);
+  return hipGetLastError();
+}
+
 static bool bn_pool_ok(int N, int H, int W, int C) {
   return N > 0 && H >= 2 && W >= 2 && C >= 4 && C % 4 == 0 && C <= kFuseMaxC && (long)N * H * W < (1L << 31);
 }

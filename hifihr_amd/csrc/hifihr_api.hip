@@ -1032,6 +1032,34 @@ int hifihr_wino_bn_input_transform(const float* x, float* stats, const float* ga
   return HIFIHR_OK;
 }
 
+int hifihr_wino_output_transform_bnred(const float* Mm, const float* x, const float* out, const float* gadd, const float* save_mean,
+                                       const float* save_invstd, const float* gamma, const float* beta, float* red, float* g, int N, int H, int W,
+                                       int C, int m, void* stream) {
+  if (!Mm || !x || !save_mean || !save_invstd || !gamma || !beta || !red || !g || N <= 0 || H <= 0 || W <= 0)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform_bnred: bad argument");
+  if (!hifihr_wino_bn_input_supported(C, m)) return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform_bnred: needs m = 4 and C % 4 == 0, C <= 512");
+  HIP_TRY(hifihr::launch_wino4_output_transform_bnred(Mm, x, out, gadd, save_mean, save_invstd, gamma, beta, red, g, N, H, W, C, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_bn_bwd_dual_transform(const float* g, const float* y, const float* save_mean, const float* save_invstd, const float* gamma,
+                                      float* red, float* V, float* Yt, int N, int H, int W, int K, int m, float* dgamma_acc, float* dbeta_acc,
+                                      void* stream) {
+  if (!g || !y || !save_mean || !save_invstd || !gamma || !red || !V || !Yt || N <= 0 || H <= 0 || W <= 0)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_bn_bwd_dual_transform: bad argument");
+  if (!hifihr_wino_bn_input_supported(K, m)) return fail(HIFIHR_EINVAL, "hifihr_wino_bn_bwd_dual_transform: needs m = 4 and K % 4 == 0, K <= 512");
+  HIP_TRY(hifihr::launch_wino4_bn_bwd_dual_transform(g, y, save_mean, save_invstd, gamma, red, V, Yt, N, H, W, K, dgamma_acc, dbeta_acc,
+                                                     (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_bn_bwd_apply(const float* g, const float* x, const float* save_mean, const float* save_invstd, const float* gamma, long M, int C,
+                        float* red, float* dx, float* dgamma_acc, float* dbeta_acc, void* stream) {
+  if (!g || !x || !save_mean || !save_invstd || !gamma || !red || !dx || M <= 0) return fail(HIFIHR_EINVAL, "hifihr_bn_bwd_apply: bad argument");
+  HIP_TRY(hifihr::launch_bn_bwd_apply(g, x, save_mean, save_invstd, gamma, M, C, red, dx, dgamma_acc, dbeta_acc, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_input_dy_transform_m(const float* dy, float* V, float* Yt, int N, int H, int W, int K, int m, void* stream) {
   if (m != 4) return hifihr_wino_input_dy_transform(dy, V, Yt, N, H, W, K, stream);
   if (!dy || !V || !Yt || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0)

@@ -336,6 +336,14 @@ bool wino4_bn_supported(int C);
 hipError_t launch_wino4_bn_input_transform(const float* x, float* stats, const float* gamma, const float* beta, const float* res, float* out,
                                            float* V, int N, int H, int W, int C, float eps, float momentum, float* save_mean,
                                            float* save_invstd, float* running_mean, float* running_var, hipStream_t st);
+hipError_t launch_wino4_output_transform_bnred(const float* Mm, const float* x, const float* outp, const float* gadd, const float* save_mean,
+                                               const float* save_invstd, const float* gamma, const float* beta, float* red, float* g, int N,
+                                               int H, int W, int C, hipStream_t st);
+hipError_t launch_wino4_bn_bwd_dual_transform(const float* g, const float* y, const float* save_mean, const float* save_invstd, const float* gamma,
+                                              float* red, float* V, float* Y, int N, int H, int W, int K, float* dgamma_acc, float* dbeta_acc,
+                                              hipStream_t st);
+hipError_t launch_bn_bwd_apply(const float* g, const float* x, const float* save_mean, const float* save_invstd, const float* gamma, long M,
+                               int C, float* red, float* dx, float* dgamma_acc, float* dbeta_acc, hipStream_t st);
 hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
                                          hipStream_t st);
 hipError_t launch_wino4_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st);

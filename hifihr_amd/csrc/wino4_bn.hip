@@ -142,6 +142,181 @@ __global__ __launch_bounds__(256) void wino4_bn_input_transform_kernel(const flo
   if (last_workgroup(cnt)) clear_slots_fwd(stats, C, cnt);
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, part 1: output transform of the backward-data product + ReLU mask (+ the identity branch's gradient) + the batch-norm
+// backward reduction.  workgroup = 16 tile lanes x 16 float4 channel lanes (64 channels, blockIdx.y); Mm[36][T][C] -> g[N][H][W][C],
+// red[kStatSlots][2][C] += (sum g, sum g xhat).  RES: the mask is (block output > 0); else z = x sc + sh > 0 recomputed by the forward's
+// expression (same bits: csrc/bn.hip masked_grad).  ADD: gadd = gradient that reached the block output through the identity branch.
+// ------------------------------------------------------------------------------------------------
+template <bool RES, bool ADD>
+__global__ __launch_bounds__(256) void wino4_output_transform_bnred_kernel(const float* __restrict__ Mm, const float* __restrict__ x,
+                                                                          const float* __restrict__ outp, const float* __restrict__ gadd,
+                                                                          const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                          float* __restrict__ red, float* __restrict__ g, int N, int H, int W, int C,
+                                                                          int TH, int TW) {
+  __shared__ float4 redl[2][16][16];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int k = blockIdx.y * 64 + cl * 4;
+  const bool kok = k < C;
+  const size_t T = (size_t)N * TH * TW;
+  V4 sg = zero4(), sq = zero4();
+  if (kok) {
+    const V4 mu = ld4(save_mean + k), is = ld4(save_invstd + k), ga = ld4(gamma + k), be = ld4(beta + k);
+    const V4 sc = V4{is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w};
+    const V4 sh = V4{be.x - mu.x * sc.x, be.y - mu.y * sc.y, be.z - mu.z * sc.z, be.w - mu.w * sc.w};
+    for (size_t t = (size_t)blockIdx.x * 16 + tl; t < T; t += (size_t)gridDim.x * 16) {
+      const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+      V4 s[4][6];                                           // s = A^T m, built column by column
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        V4 col[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) col[r] = ld4(Mm + ((size_t)(r * 6 + c) * T + t) * C + k);
+        V4 o[4];
+        at6(col, o);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s[a][c] = o[a];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int oh = 4 * th + a;
+        if (oh < H) {                                       // (the row's operands are requested before its transform)
+          const size_t o0 = (((size_t)n * H + oh) * W + 4 * tw) * C + k;
+          V4 xv[4], ov[4], av[4];
+          bool ok[4];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            ok[b] = 4 * tw + b < W;
+            const size_t o = o0 + (size_t)(ok[b] ? b : 0) * C;
+            xv[b] = ld4(x + o);
+            ov[b] = RES ? ld4(outp + o) : zero4();
+            av[b] = ADD ? ld4(gadd + o) : zero4();
+          }
+          V4 o[4];
+          at6(s[a], o);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            if (ok[b]) {
+              V4 d = o[b];
+              if (ADD) d = d + av[b];
+              V4 z;
+              if (RES) z = ov[b];
+              else z = V4{xv[b].x * sc.x + sh.x, xv[b].y * sc.y + sh.y, xv[b].z * sc.z + sh.z, xv[b].w * sc.w + sh.w};
+              const V4 gm = V4{z.x > 0.f ? d.x : 0.f, z.y > 0.f ? d.y : 0.f, z.z > 0.f ? d.z : 0.f, z.w > 0.f ? d.w : 0.f};
+              st4(g + o0 + (size_t)b * C, gm);
+              sg = sg + gm;
+              sq.x += gm.x * ((xv[b].x - mu.x) * is.x); sq.y += gm.y * ((xv[b].y - mu.y) * is.y);
+              sq.z += gm.z * ((xv[b].z - mu.z) * is.z); sq.w += gm.w * ((xv[b].w - mu.w) * is.w);
+            }
+          }
+        }
+      }
+    }
+  }
+  redl[0][tl][cl] = make_float4(sg.x, sg.y, sg.z, sg.w); redl[1][tl][cl] = make_float4(sq.x, sq.y, sq.z, sq.w);
+  __syncthreads();
+  if (tl == 0 && kok) {
+    float4 a1 = redl[0][0][cl], a2 = redl[1][0][cl];
+    for (int r = 1; r < 16; ++r) {
+      const float4 b1 = redl[0][r][cl], b2 = redl[1][r][cl];
+      a1 = make_float4(a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w);
+      a2 = make_float4(a2.x + b2.x, a2.y + b2.y, a2.z + b2.z, a2.w + b2.w);
+    }
+    float* sp = red + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * C;
+    atomicAdd(sp + k, a1.x); atomicAdd(sp + k + 1, a1.y); atomicAdd(sp + k + 2, a1.z); atomicAdd(sp + k + 3, a1.w);
+    atomicAdd(sp + C + k, a2.x); atomicAdd(sp + C + k + 1, a2.y); atomicAdd(sp + C + k + 2, a2.z); atomicAdd(sp + C + k + 3, a2.w);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 2: the batch-norm backward APPLY inside the dual input transform of the producer convolution's backward.
+// thread = (tile, 4 channels).  g = masked gradient [N][H][W][K], y = the convolution's raw output (the batch-norm's input), red = the
+// reduction sums part 1 left in the float slots (folded here; workgroup 0 accumulates dgamma / dbeta; the last workgroup to finish hands
+// the slots back zeroed).  dy = gamma invstd (g - mean g - xhat mean(g xhat)) -- bn_bwd_apply_kernel's expression -- goes straight into
+// V' = B^T dy B (backward-data) and Y' = A dy A^T (backward-weight).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                                         const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                                         const float* __restrict__ gamma, float* __restrict__ red,
+                                                                         float* __restrict__ V, float* __restrict__ Y, int N, int H, int W, int K,
+                                                                         int TH, int TW, float* __restrict__ dgamma_acc,
+                                                                         float* __restrict__ dbeta_acc) {
+  __shared__ float s_mg[kWbnMaxC], s_mgx[kWbnMaxC];
+  const float invM = 1.0f / (float)((long)N * H * W);
+  for (int c = threadIdx.x; c < K; c += 256) {
+    float sgv, sgx;
+    slot_sum2(red, K, c, sgv, sgx);
+    s_mg[c] = sgv * invM;
+    s_mgx[c] = sgx * invM;
+    if (blockIdx.x == 0) {
+      if (dgamma_acc) dgamma_acc[c] += sgx;
+      if (dbeta_acc) dbeta_acc[c] += sgv;
+    }
+  }
+  __syncthreads();
+  const int K4 = K / 4;
+  const size_t T = (size_t)N * TH * TW, total = T * K4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % K4);
+    const size_t t = i / K4;
+    const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+    const V4 mu = ld4(save_mean + cg * 4), is = ld4(save_invstd + cg * 4), ga = ld4(gamma + cg * 4);
+    const V4 k1 = V4{is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w};
+    const V4 mg = ld4(&s_mg[cg * 4]), mgx = ld4(&s_mgx[cg * 4]);
+    V4 tt[6][6];                                            // tt = B^T d, built column by column
+    V4 ty[6][4];                                            // A dy (6 x 4) of the central block
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int iw = 4 * tw - 1 + c;
+      const bool cok = iw >= 0 && iw < W;
+      V4 col[6], yv[6];
+      bool okr[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int ih = 4 * th - 1 + r;
+        okr[r] = cok && ih >= 0 && ih < H;
+        const size_t o = (((size_t)n * H + (okr[r] ? ih : 0)) * W + (okr[r] ? iw : 0)) * K + cg * 4;
+        col[r] = ld4(g + o);
+        yv[r] = ld4(y + o);
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const V4 gv = col[r], v = yv[r];
+        const V4 d = V4{k1.x * (gv.x - mg.x - (v.x - mu.x) * is.x * mgx.x), k1.y * (gv.y - mg.y - (v.y - mu.y) * is.y * mgx.y),
+                        k1.z * (gv.z - mg.z - (v.z - mu.z) * is.z * mgx.z), k1.w * (gv.w - mg.w - (v.w - mu.w) * is.w * mgx.w)};
+        col[r] = okr[r] ? d : zero4();
+      }
+      V4 o[6];
+      bt6(col, o);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) tt[r][c] = o[r];
+      if (c >= 1 && c <= 4) {
+        V4 o2[6];
+        a4(col + 1, o2);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ty[r][c - 1] = o2[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      V4 o[6];
+      bt6(tt[r], o);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) st4(V + ((size_t)(r * 6 + c) * T + t) * K + cg * 4, o[c]);
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      V4 o[6];
+      a4(ty[r], o);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) st4(Y + ((size_t)(r * 6 + c) * T + t) * K + cg * 4, o[c]);
+    }
+  }
+  unsigned* cnt = stat_bwd_counters(red, K);
+  if (last_workgroup(cnt)) clear_slots(red, K, cnt);
+}
+
 static unsigned wbn_grid(size_t total) {
   size_t b = (total + 255) / 256;
   if (b > 4096) b = 4096;
@@ -166,4 +341,37 @@ hipError_t launch_wino4_bn_input_transform(const float* x, float* stats, const f
   return hipGetLastError();
 }
 
+hipError_t launch_wino4_output_transform_bnred(const float* Mm, const float* x, const float* outp, const float* gadd, const float* save_mean,
+                                               const float* save_invstd, const float* gamma, const float* beta, float* red, float* g, int N,
+                                               int H, int W, int C, hipStream_t st) {
+  if (!wino4_bn_supported(C)) return hipErrorInvalidValue;
+  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
+  const size_t T = (size_t)N * TH * TW;
+  size_t bx = (T + 15) / 16;
+  if (bx > 1024) bx = 1024;
+  const dim3 grid((unsigned)bx, (C + 63) / 64);
+#define HIFIHR_BNRED(R_, A_)                                                                                                               \
+  hipLaunchKernelGGL((wino4_output_transform_bnred_kernel<R_, A_>), grid, dim3(256), 0, st, Mm, x, outp, gadd, save_mean, save_invstd, gamma, \
+                     beta, red, g, N, H, W, C, TH, TW)
+  if (outp != nullptr) {
+    if (gadd != nullptr) HIFIHR_BNRED(true, true); else HIFIHR_BNRED(true, false);
+  } else {
+    if (gadd != nullptr) HIFIHR_BNRED(false, true); else HIFIHR_BNRED(false, false);
+  }
+#undef HIFIHR_BNRED
+  return hipGetLastError();
+}
+
+hipError_t launch_wino4_bn_bwd_dual_transform(const float* g, const float* y, const float* save_mean, const float* save_invstd, const float* gamma,
+                                              float* red, float* V, float* Y, int N, int H, int W, int K, float* dgamma_acc, float* dbeta_acc,
+                                              hipStream_t st) {
+  if (!wino4_bn_supported(K)) return hipErrorInvalidValue;
+  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
+  const size_t total = (size_t)N * TH * TW * (K / 4);
+  hipLaunchKernelGGL(wino4_bn_bwd_dual_transform_kernel, dim3(wbn_grid(total)), dim3(256), 0, st, g, y, save_mean, save_invstd, gamma, red, V, Y, N, H,
+                     W, K, TH, TW, dgamma_acc, dbeta_acc);
+  return hipGetLastError();
+}
+
 }  // namespace hifihr
+

@@ -72,6 +72,7 @@ class GradReducer:
         self._done = [False] * n                         # a parameter may be reported twice (autograd hook + direct writer)
         self._handles = []
         self._paused = False
+        self._trace = [] if os.environ.get("HIFIHR_DP_TRACE") else None       # debugging: (event, parameter index, bucket, pending)
         if self.world > 1:
             for i, p in enumerate(flat.params):
                 hook = self._make_hook(i)
@@ -97,10 +98,20 @@ class GradReducer:
         def hook(_param):
             if self._paused or self._done[i]:
                 return
+            if getattr(_param, "_hifihr_grad_deferred", False):
+                # autograd fires this hook when the function that took the parameter as an input has run its backward -- also when it
+                # returned None for it.  A fused function that handed the batch-norm apply (and with it dgamma / dbeta) over to the
+                # PRODUCER's backward (ops._WinoLink) has not written the gradient yet: the producer reports it (ops._grad_ready).
+                return
             self._done[i] = True
             b = self.param_bucket[i]
             self._pending[b] -= 1
+            if self._trace is not None:
+                import traceback
+                self._trace.append(("ready", i, b, self._pending[b], [f"{f.name}:{f.lineno}" for f in traceback.extract_stack()[-5:-1]]))
             if self._pending[b] == 0 and not self._launched[b]:
+                if self._trace is not None:
+                    self._trace.append(("launch", b))
                 self._launch(b)
         return hook
 

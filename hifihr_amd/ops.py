@@ -870,19 +870,56 @@ def bn_wino_fusable(x, w, bn, stride, pad):
     if Cw != C or not _wino_ok(C, K, R, S, stride, pad):
         return False
     lib = get_lib()
-    return _wino_tile(lib, N, H, W, C, K)[0] == 4 and lib.wino_bn_input_supported(C, 4)
+    return (_wino_tile(lib, N, H, W, C, K)[0] == 4 and lib.wino_bn_input_supported(C, 4) and lib.wino_bn_input_supported(K, 4)
+            and lib.wino_wgrad_parts(N, H, W, C, K, 4) > 0)
+
+
+class _WinoLink:
+    """Hand-off between the backward passes of two fused functions, attached to the raw convolution output y that the first produced
+    and the second consumed: when the consumer's backward has the batch-norm's masked gradient g and its reduction sums, it does NOT
+    apply the batch-norm backward; it returns g in place of d loss / d y and leaves the sums here, and the producer's backward applies
+    dy = gamma invstd (g - mean g - xhat mean(g xhat)) inside its dual input transform (hifihr_wino_bn_bwd_dual_transform).  Valid only
+    because y has exactly one consumer (the fused function) -- BasicBlock guarantees that."""
+    __slots__ = ("lazy", "red", "save_mean", "save_invstd", "gamma", "gamma_param", "beta_param", "g")
+
+    def __init__(self):
+        self.lazy, self.red, self.g = False, None, None
+
+
+def _direct_grad(p):
+    return getattr(p, "_hifihr_direct_grad", False) and p.grad is not None
+
+
+def _wino_gemm_ws(lib, dev, N, H, W, C, K, m):
+    key = ("wino", N, H, W, C, K, m)
+    nb = _CONV_WS_BYTES.get(key)
+    if nb is None:
+        nb = lib.wino_gemm_workspace_bytes(N, H, W, C, K, m)
+        _CONV_WS_BYTES[key] = nb
+    if not nb:
+        return None
+    ws = _CONV_WS.get(dev)
+    if ws is None or ws.numel() * 4 < nb:
+        if ws is not None:
+            _RETIRED_SCRATCH.append(ws)
+        ws = torch.zeros(max(nb, 32 << 20) // 4 + 64, dtype=torch.float32, device=dev)
+        _CONV_WS[dev] = ws
+    return ws
 
 
 class _BNActWinoConv(torch.autograd.Function):
     """conv3x3(relu(bn(x; batch statistics) (+ residual)), w) with the batch-norm applied inside the Winograd F(4x4, 3x3) input transform
     (hifihr_wino_bn_input_transform): the activation is never written on its own.  With a residual the block output
     relu(bn(x) + residual) is also returned (the next block's identity branch and shortcut convolution read it).
+    Backward: ReLU mask, identity-branch gradient and the batch-norm reduction in the epilogue of the backward-data output transform
+    (hifihr_wino_output_transform_bnred); the batch-norm apply inside the PRODUCER's dual transform when x came from another fused
+    function (_WinoLink), else one hifihr_bn_bwd_apply launch.
     Replaces, per BasicBlock of the reference's ResNet (network/res_encoder.py:364-373, vendored resnet.py BasicBlock.forward), the
-    dispatches bn1 -> relu -> conv2 and bn2 -> += identity -> relu -> conv1 of the next block.
+    dispatches bn1 -> relu -> conv2 and bn2 -> += identity -> relu -> conv1 of the next block, and their autograd.
     -> (y, stats of y or None, block output or None)."""
 
     @staticmethod
-    def forward(ctx, x, stats, gamma, beta, residual, w, eps, momentum, running_mean, running_var, want_stats):
+    def forward(ctx, x, stats, gamma, beta, residual, w, eps, momentum, running_mean, running_var, want_stats, in_link, link):
         require_cuda(x, stats, gamma, beta, w)
         lib = get_lib()
         x = x.contiguous(memory_format=_CL)
@@ -909,29 +946,20 @@ class _BNActWinoConv(torch.autograd.Function):
             lib.wino_bn_input_transform(x, stats, gamma, beta, res, out, V, N, H, W, C, m, eps, momentum, save_mean, save_invstd,
                                         running_mean, running_var)
             M = _wino_scratch(dev, "M", P * T * K)
-            key = ("wino", N, H, W, C, K, m)
-            nb = _CONV_WS_BYTES.get(key)
-            if nb is None:
-                nb = lib.wino_gemm_workspace_bytes(N, H, W, C, K, m)
-                _CONV_WS_BYTES[key] = nb
-            ws = None
-            if nb:
-                ws = _CONV_WS.get(dev)
-                if ws is None or ws.numel() * 4 < nb:
-                    if ws is not None:
-                        _RETIRED_SCRATCH.append(ws)
-                    ws = torch.zeros(max(nb, 32 << 20) // 4 + 64, dtype=torch.float32, device=dev)
-                    _CONV_WS[dev] = ws
-            lib.wino_gemm(V, Uu, M, N, H, W, C, K, ws=ws, m=m)
+            lib.wino_gemm(V, Uu, M, N, H, W, C, K, ws=_wino_gemm_ws(lib, dev, N, H, W, C, K, m), m=m)
             lib.wino_output_transform(M, y, stats_next, N, H, W, K, m=m)
         if PROFILE.on:
             PROFILE.conv_log.append((("wino", N, H, W, C, K, m), "gemm"))
         PROFILE.bracket("bn_conv_fwd_wino", run)
         _ZERO_POOL.release(stats)                # consumed and zeroed by the fused transform
-        ctx.save_for_backward(x, out if out is not None else x.new_empty(0), gamma, beta, save_mean, save_invstd, wk, V)
+        ctx.save_for_backward(x, out if out is not None else x.new_empty(0), gamma, beta, save_mean, save_invstd, wk, V, y)
         ctx.geom = (N, H, W, C, K, 3, 3, 1, 1)
+        ctx.tile = tile
         ctx.has_res = res is not None
         ctx.w_param, ctx.gamma_param, ctx.beta_param = w, gamma, beta
+        ctx.in_link, ctx.link = in_link, link
+        if in_link is not None:
+            in_link.lazy = True                  # our backward may hand the batch-norm apply over to the producer of x
         ctx.set_materialize_grads(False)
         if stats_next is not None:
             ctx.mark_non_differentiable(stats_next)
@@ -939,26 +967,109 @@ class _BNActWinoConv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gstats, g_out):
-        x, out, gamma, beta, save_mean, save_invstd, wk, V = ctx.saved_tensors
+        x, out, gamma, beta, save_mean, save_invstd, wk, V, y = ctx.saved_tensors
         N, H, W, C, K = ctx.geom[:5]
         if gy is None:                            # the convolution's output went nowhere: only the identity branch brings a gradient
             raise NotImplementedError("fused batch-norm + Winograd convolution whose convolution output is unused")
+        lib = get_lib()
+        dev = x.device
+        m, P, T = ctx.tile
+        w = ctx.w_param
         need = ctx.needs_input_grad
-        conv = _CtxShim((None, wk, None, V), geom=ctx.geom, w_param=ctx.w_param, b_param=None, relu=False, w3=None,
-                        needs_input_grad=(True, need[5], False, False, False, False, False))
-        d_a, dw = _Conv2dMFMA.backward(conv, gy)[:2]
-        if g_out is not None:
-            d_a = d_a + g_out                     # the identity branch of the next block
-        bn = _CtxShim((x, out if ctx.has_res else x.new_empty(0), gamma, beta, save_mean, save_invstd), act=1, has_res=ctx.has_res,
-                      M=N * H * W, C=C, gamma_param=ctx.gamma_param, beta_param=ctx.beta_param)
-        dx, _, dg, db, dres = _BNAct.backward(bn, d_a)[:5]
-        return dx, None, dg, db, dres, dw, None, None, None, None, None
+        gy = gy.contiguous(memory_format=_CL)
+        link, in_link = ctx.link, ctx.in_link
+        if os.environ.get("HIFIHR_BN_WINO_BWD", "1") == "0":      # A/B: the unfused backward (Winograd pipeline, add, batch-norm backward)
+            conv = _CtxShim((None, wk, None, V), geom=ctx.geom, w_param=w, b_param=None, relu=False, w3=None,
+                            needs_input_grad=(True, need[5], False, False, False, False, False))
+            d_a, dw = _Conv2dMFMA.backward(conv, gy)[:2]
+            if g_out is not None:
+                d_a = d_a + g_out
+            bn = _CtxShim((x, out if ctx.has_res else x.new_empty(0), gamma, beta, save_mean, save_invstd), act=1, has_res=ctx.has_res,
+                          M=N * H * W, C=C, gamma_param=ctx.gamma_param, beta_param=ctx.beta_param)
+            dx, _, dg, db, dres = _BNAct.backward(bn, d_a)[:5]
+            return dx, None, dg, db, dres, dw, None, None, None, None, None, None, None
+
+        def acc_target(p, n):
+            if _direct_grad(p):
+                return p.grad, None
+            t = torch.zeros(n, device=dev)
+            return t, t
+        res_out = out if ctx.has_res else None
+        gadd = g_out.contiguous(memory_format=_CL) if g_out is not None else None
+        g_in = torch.empty_like(x, memory_format=_CL)
+        red = _ZERO_POOL.acquire(lib.bn_stats_floats(C), dev)
+        lazy_in = link.lazy and link.red is not None            # gy is the masked gradient of the NEXT batch-norm, un-applied
+        dw_box = [None]
+        direct_w = _direct_grad(w) and w.grad.is_contiguous(memory_format=_CL)
+
+        def run():
+            # 1. transforms of d loss / d y: V' (backward-data) and Y' (backward-weight)
+            V2 = _wino_scratch(dev, "V", P * T * K)
+            Yt = _wino_scratch(dev, "Yt", P * T * K)
+            if lazy_in:
+                lib.wino_bn_bwd_dual_transform(gy, y, link.save_mean, link.save_invstd, link.gamma, link.red, V2, Yt, N, H, W, K, m,
+                                               link.gamma_param.grad, link.beta_param.grad)
+            else:
+                lib.wino_input_dy_transform(gy, V2, Yt, N, H, W, K, m)
+            # 2. backward-data product on the rotated transposed filter
+            U2 = _WEIGHT_PREP.get(w, wk, 4)
+            if U2 is None:
+                wt = _wino_scratch(dev, "wt", wk.numel())
+                lib.weight_transpose(wk, wt, K, 9, C)
+                U2 = _wino_scratch(dev, "U", P * K * C)
+                lib.wino_weight_transform(wt, U2, C, K, 1, m)
+            M2 = _wino_scratch(dev, "M", P * T * C)
+            lib.wino_gemm(V2, U2, M2, N, H, W, K, C, ws=_wino_gemm_ws(lib, dev, N, H, W, K, C, m), m=m)
+            # 3. output transform + identity-branch gradient + ReLU mask + batch-norm reduction
+            lib.wino_output_transform_bnred(M2, x, res_out, gadd, save_mean, save_invstd, gamma, beta, red, g_in, N, H, W, C, m)
+            # 4. backward-weight: dU = Y'^T V over the tiles (slabs, fixed order), dw += G^T dU G
+            if need[5]:
+                tgt = w.grad if direct_w else torch.zeros_like(wk, memory_format=_CL)
+                parts = lib.wino_wgrad_parts(N, H, W, C, K, m)
+                dU = _wino_scratch(dev, "dUp", parts * P * K * C)
+                lib.wino_wgrad_gemm_parts(V, Yt, dU, N, H, W, C, K, parts, m)
+                lib.wino_dw_transform_parts(dU, parts, tgt, K, C, m)
+                dw_box[0] = None if direct_w else tgt
+        if PROFILE.on:
+            PROFILE.conv_log.append((("wino", N, H, W, K, C, m), "gemm"))
+            PROFILE.conv_log.append((("wino", N, H, W, C, K, m), "gemm-tn"))
+        PROFILE.bracket("bn_conv_bwd_wino", run)
+        if lazy_in:
+            _ZERO_POOL.release(link.red)         # folded and zeroed by the dual transform
+            link.red = link.g = None
+            link.gamma_param._hifihr_grad_deferred = link.beta_param._hifihr_grad_deferred = False
+            _grad_ready(link.gamma_param)
+            _grad_ready(link.beta_param)
+        if need[5] and direct_w:
+            _grad_ready(w)
+        # 5. the batch-norm apply: inside the producer's dual transform when x came from a fused function, else one launch here
+        dg_ret = db_ret = None
+        if in_link is not None and _direct_grad(ctx.gamma_param) and _direct_grad(ctx.beta_param):
+            in_link.red, in_link.save_mean, in_link.save_invstd, in_link.gamma = red, save_mean, save_invstd, gamma
+            in_link.gamma_param, in_link.beta_param, in_link.g = ctx.gamma_param, ctx.beta_param, g_in
+            # (the data-parallel reducer must not take autograd's "this function is done" for "dgamma / dbeta are written": dist.py)
+            ctx.gamma_param._hifihr_grad_deferred = ctx.beta_param._hifihr_grad_deferred = True
+            dx = g_in                            # NOT d loss / d x yet: see _WinoLink
+        else:
+            dx = torch.empty_like(x, memory_format=_CL)
+            dg_t, dg_ret = acc_target(ctx.gamma_param, C)
+            db_t, db_ret = acc_target(ctx.beta_param, C)
+            PROFILE.bracket("bn_bwd", lambda: lib.bn_bwd_apply(g_in, x, save_mean, save_invstd, gamma, N * H * W, C, red, dx, dg_t, db_t))
+            _ZERO_POOL.release(red)
+            if dg_ret is None:
+                _grad_ready(ctx.gamma_param)
+            if db_ret is None:
+                _grad_ready(ctx.beta_param)
+        return dx, None, dg_ret, db_ret, (g_in if ctx.has_res else None), dw_box[0], None, None, None, None, None, None, None
 
 
 def bn_act_wino_conv(x, stats, bn: torch.nn.BatchNorm2d, residual, w, want_stats):
     """See _BNActWinoConv; `bn` in training mode, `stats` from the producer of x (conv2d(..., want_stats=True))."""
-    return _BNActWinoConv.apply(x, stats, bn.weight, bn.bias, residual, w, float(bn.eps), float(bn.momentum), bn.running_mean,
-                                bn.running_var, want_stats)
+    link = _WinoLink()
+    y, st, out = _BNActWinoConv.apply(x, stats, bn.weight, bn.bias, residual, w, float(bn.eps), float(bn.momentum), bn.running_mean,
+                                      bn.running_var, want_stats, getattr(x, "_hifihr_link", None), link)
+    y._hifihr_link = link
+    return y, st, out
 
 
 _ACT = {None: 0, False: 0, True: 1, "relu": 1, "swish": 2}

@@ -309,6 +309,26 @@ int hifihr_wino_bn_input_supported(int C, int m);
 int hifihr_wino_bn_input_transform(const float* x_d, float* stats_d, const float* gamma_d, const float* beta_d, const float* residual_d,
                                    float* out_d, float* v_d, int N, int H, int W, int C, int m, float eps, float momentum,
                                    float* save_mean_d, float* save_invstd_d, float* running_mean_d, float* running_var_d, void* stream);
+/* The backward of that fusion (round 3): the batch-norm backward no longer makes passes of its own over the gradient.
+ *   hifihr_wino_output_transform_bnred: output transform of the backward-data product m_d[36][T][C] of the consuming convolution
+ *     = d loss / d a; in its epilogue + gadd_d (the gradient that reached the block output through the next block's identity
+ *     branch, or NULL), the ReLU mask (out_d > 0 when the forward added a residual, else recomputed from x_d), g_d = the masked
+ *     gradient written once, and the batch-norm backward REDUCTION (sum g, sum g xhat) added into red_d (hifihr_bn_stats_floats(C)
+ *     floats, all zero on entry).  Replaces hifihr_wino_output_transform_m + the autograd add + the reduction half of hifihr_bn_act_bwd.
+ *   then EITHER hifihr_bn_bwd_apply: the apply half of hifihr_bn_act_bwd on (g_d, red_d): dx, dgamma_acc += , dbeta_acc +=, red_d zeroed;
+ *   OR, when the batch-norm's input was itself produced by a Winograd convolution, hifihr_wino_bn_bwd_dual_transform in THAT
+ *     convolution's backward: dy = gamma invstd (g - mean g - xhat mean(g xhat)) is evaluated on the fly and only V' = B^T dy B and
+ *     Y' = A dy A^T are written (y_d = the convolution's raw output = the batch-norm's input; same dgamma / dbeta / red_d semantics).
+ * Mirrors, in one direction each, torch.autograd through nn.BatchNorm2d + ReLU + `+= identity` of the reference's BasicBlock
+ * (vendored utils/Freihand_GNN_mano/network/resnet.py).  m = 4, channels % 4 == 0 and <= 512. */
+int hifihr_wino_output_transform_bnred(const float* m_d, const float* x_d, const float* out_d /* or NULL */, const float* gadd_d /* or NULL */,
+                                       const float* save_mean_d, const float* save_invstd_d, const float* gamma_d, const float* beta_d,
+                                       float* red_d, float* g_d, int N, int H, int W, int C, int m, void* stream);
+int hifihr_wino_bn_bwd_dual_transform(const float* g_d, const float* y_d, const float* save_mean_d, const float* save_invstd_d,
+                                      const float* gamma_d, float* red_d, float* v_d, float* yt_d, int N, int H, int W, int K, int m,
+                                      float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
+int hifihr_bn_bwd_apply(const float* g_d, const float* x_d, const float* save_mean_d, const float* save_invstd_d, const float* gamma_d, long M,
+                        int C, float* red_d, float* dx_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
 int hifihr_wino_input_dy_transform_m(const float* dy_d, float* v_d, float* yt_d, int N, int H, int W, int K, int m, void* stream);
 int hifihr_wino_wgrad_parts_m(int N, int H, int W, int C, int K, int m);
 int hifihr_wino_wgrad_gemm_parts_m(const float* v_d, const float* yt_d, float* du_parts_d, int N, int H, int W, int C, int K, int parts, int m,

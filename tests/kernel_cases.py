@@ -1436,3 +1436,52 @@ def wino_bn_input_case(lib, device, N, H, W, C, residual, seed=0):
         ref = ref + res.permute(0, 3, 1, 2)
     ref = F.relu(ref).permute(0, 2, 3, 1)
     assert float((a0.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def wino_bn_bwd_case(lib, device, N, H, W, C, residual, addend, seed=0):
+    """The backward of the batch-norm / Winograd fusion (csrc/wino4_bn.hip) against the launches it replaces:
+      hifihr_wino_output_transform_bnred + hifihr_bn_bwd_apply  ==  hifihr_wino_output_transform_m (+ add) + hifihr_bn_act_bwd
+      hifihr_wino_bn_bwd_dual_transform                         ==  hifihr_bn_bwd_apply + hifihr_wino_input_dy_transform_m   (bit for bit)"""
+    gen = torch.Generator().manual_seed(seed)
+    d = lambda t: t.to(device).contiguous()
+    M = N * H * W
+    T = N * ((H + 3) // 4) * ((W + 3) // 4)
+    x = d(torch.randn(N, H, W, C, generator=gen) * 1.3 + 0.2)
+    res = d(torch.randn(N, H, W, C, generator=gen)) if residual else None
+    gadd = d(torch.randn(N, H, W, C, generator=gen)) if addend else None
+    gamma = d(1 + 0.1 * torch.randn(C, generator=gen)); beta = d(0.1 * torch.randn(C, generator=gen))
+    Mm = d(torch.randn(36, T, C, generator=gen))
+    # forward statistics and block output (for the mask)
+    st = torch.zeros(lib.bn_stats_floats(C), device=device)
+    lib.bn_stats(x, M, C, st)
+    out = torch.empty(N, H, W, C, device=device); sm = torch.empty(C, device=device); si = torch.empty(C, device=device)
+    lib.bn_act_fwd(x, st, gamma, beta, res, 1, M, C, 1e-5, 0.1, out, sm, si, None, None)
+    # the separate launches
+    dA = torch.empty(N, H, W, C, device=device)
+    lib.wino_output_transform(Mm, dA, None, N, H, W, C, m=4)
+    if addend:
+        dA = dA + gadd
+    red = torch.zeros(lib.bn_stats_floats(C), device=device)
+    dx0 = torch.empty_like(x); dres0 = torch.empty_like(x); dg0 = torch.zeros(C, device=device); db0 = torch.zeros(C, device=device)
+    lib.bn_act_bwd(dA, out if residual else None, x, sm, si, gamma, beta, 1, M, C, red, dx0, dres0, dg0, db0)
+    # fused part 1 + apply
+    g = torch.full((N, H, W, C), 7.0, device=device)
+    red1 = torch.zeros(lib.bn_stats_floats(C), device=device)
+    lib.wino_output_transform_bnred(Mm, x, out if residual else None, gadd, sm, si, gamma, beta, red1, g, N, H, W, C, 4)
+    assert torch.equal(g, dres0), float((g - dres0).abs().max())            # the masked gradient, bit for bit
+    red_keep = red1.clone()
+    dx1 = torch.empty_like(x); dg1 = torch.zeros(C, device=device); db1 = torch.zeros(C, device=device)
+    lib.bn_bwd_apply(g, x, sm, si, gamma, M, C, red1, dx1, dg1, db1)
+    assert float(red1[:32 * 4 * C + 64].abs().max()) == 0.0
+    tol = lambda ref: 2e-5 * float(ref.abs().max()) + 1e-7      # the reductions add in a different order
+    assert float((dx1 - dx0).abs().max()) <= tol(dx0), float((dx1 - dx0).abs().max())
+    assert float((dg1 - dg0).abs().max()) <= tol(dg0) and float((db1 - db0).abs().max()) <= tol(db0)
+    # fused part 2 == apply + dual transform on the SAME sums, bit for bit
+    V0 = torch.empty(36, T, C, device=device); Y0 = torch.empty(36, T, C, device=device)
+    lib.wino_input_dy_transform(dx1, V0, Y0, N, H, W, C, 4)
+    V1 = torch.full((36, T, C), 7.0, device=device); Y1 = torch.full((36, T, C), 7.0, device=device)
+    dg2 = torch.zeros(C, device=device); db2 = torch.zeros(C, device=device)
+    lib.wino_bn_bwd_dual_transform(g, x, sm, si, gamma, red_keep, V1, Y1, N, H, W, C, 4, dg2, db2)
+    assert float(red_keep[:32 * 4 * C + 64].abs().max()) == 0.0
+    assert torch.equal(V1, V0) and torch.equal(Y1, Y0), (float((V1 - V0).abs().max()), float((Y1 - Y0).abs().max()))
+    assert torch.equal(dg2, dg1) and torch.equal(db2, db1)

@@ -171,6 +171,44 @@ def test_resnet18_trunk_backward_given_the_same_relu_pattern(golden_dir):
     assert not bad, bad
 
 
+def test_trunk_gradients_identical_in_every_backward_form(golden_dir):
+    """The three forms the trunk's backward can take give the same gradients: (a) the unfused batch-norm backward
+    (HIFIHR_BN_WINO_BWD=0), (b) reduction in the output-transform epilogue + one apply launch (plain parameters), (c) additionally the
+    apply inside the producer's dual transform (parameters in a FlatParams: gradients accumulated straight into the flat buffer, which
+    is what the training step runs).  Same forward bits in all three; gradients within 5e-5 of their maximum (reduction order)."""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from seeded_init import seeded_state_dict
+    from hifihr_amd import ops
+    from hifihr_amd.network import Resnet_4C
+    from hifihr_amd.optim import FlatParams
+    g = np.load(os.path.join(golden_dir, "resnet18_b8.npz"))
+    x, wl, wf = kc.resnet18_b8_inputs(g)
+
+    def run(form):
+        enc = Resnet_4C("res18")
+        enc.model.load_state_dict(seeded_state_dict(enc.model))
+        enc = enc.cuda().train()
+        if form == "c":
+            flat = FlatParams(enc)
+            flat.zero_grad()
+        os.environ["HIFIHR_BN_WINO_BWD"] = "0" if form == "a" else "1"
+        try:
+            low, feat = enc(ops.image_to_nhwc4(x.cuda()))
+            ((low * wl.cuda()).sum() + (feat * wf.cuda()).sum()).backward()
+        finally:
+            os.environ.pop("HIFIHR_BN_WINO_BWD", None)
+        return feat.detach().clone(), {n: p.grad.detach().clone() for n, p in enc.model.named_parameters()}
+    fa, ga = run("a")
+    for form in ("b", "c"):
+        f, gr = run(form)
+        assert torch.equal(f, fa)
+        worst = max((float((gr[n] - ga[n]).abs().max() / (ga[n].abs().max() + 1e-30)), n) for n in ga)
+        print("form", form, "largest gradient difference from the unfused backward:", worst)
+        assert worst[0] <= 5e-5, (form, worst)
+
+
 @pytest.mark.parametrize("C,relu,residual,N,H", [(64, True, False, 32, 56), (128, True, True, 8, 28), (512, False, False, 32, 14), (256, True, True, 4, 14)])
 def test_bn_act_kernels(lib, C, relu, residual, N, H):
     kc.bn_act_case(lib, "cuda", N, H, H, C, relu, residual, seed=C + N)

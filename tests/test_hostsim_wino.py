@@ -35,3 +35,9 @@ def test_winograd_tile_choice(hostsim_lib):
 @pytest.mark.parametrize("N,H,W,C,residual", [(2, 8, 8, 64, False), (1, 7, 9, 32, True), (2, 4, 4, 128, True), (1, 14, 14, 24, False)])
 def test_bn_fused_into_winograd_input_transform(hostsim_lib, N, H, W, C, residual):
     kc.wino_bn_input_case(hostsim_lib, "cpu", N, H, W, C, residual, seed=C + H)
+
+
+@pytest.mark.parametrize("N,H,W,C,residual,addend", [(2, 8, 8, 64, False, False), (1, 7, 9, 32, True, True), (2, 4, 4, 128, True, False),
+                                                      (1, 14, 14, 24, False, True)])
+def test_bn_backward_fused_into_winograd_transforms(hostsim_lib, N, H, W, C, residual, addend):
+    kc.wino_bn_bwd_case(hostsim_lib, "cpu", N, H, W, C, residual, addend, seed=C + H)

@@ -55,6 +55,18 @@ err = float((flat.grad - summed).abs().max()) / max(float(summed.abs().max()), 1
 if rank == 0:
     print(f"eager hooks: reduced gradient vs sum of local gradients, relative max error = {err:.3e} "
           f"(run-to-run noise of one rank's own gradient: {noise:.3e} -- float atomics, amplified by train-mode batch-norm)")
+if not err < max(20 * noise, 1e-5) and rank == 0:          # which parameters were exchanged before their gradient was complete?
+    names = {id(p): n for n, p in model.named_parameters()}
+    scale = max(float(summed.abs().max()), 1e-12)
+    worst = sorted(((float((flat.grad[o:o + p.numel()] - summed[o:o + p.numel()]).abs().max()) / scale, names.get(id(p), "?"))
+                    for p, o in zip(flat.params, flat.offsets)), reverse=True)[:8]
+    print("parameters whose reduced gradient differs most:", worst)
+    if reducer._trace is not None:
+        idx = {id(p): i for i, p in enumerate(flat.params)}
+        pn = {idx[id(p)]: n for n, p in model.named_parameters() if id(p) in idx}
+        for ev in reducer._trace[-400:]:
+            if ev[0] == "launch" or "layer3.0" in pn.get(ev[1], "") or "layer3.1.conv1" in pn.get(ev[1], ""):
+                print("   trace", ev, pn.get(ev[1], "") if ev[0] == "ready" else "", reducer.buckets[ev[1]] if ev[0] == "launch" else "")
 assert err < max(20 * noise, 1e-5), (err, noise)
 # ... and == what ONE process computes for the global batch of 2 B with per-replica batch-norm statistics: rank 0 runs every rank's
 # half itself (same weights, no hooks) and averages
