@@ -1,0 +1,31 @@
+"""Per-phase cycle sums of render_fwd2_kernel over the busy tiles (diagnostic build: tools/build_render_probe2.sh)."""
+import ctypes, os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import torch
+import kernel_cases as kc
+from hifihr_amd._lib import HifihrLib
+from hifihr_amd.mano_tables import synthetic_mano_tables
+lib = HifihrLib(os.path.join(R, "tools", "_probe", "libhifihr_render_stamp2.so"))
+t = synthetic_mano_tables(0); B, H, aa, V = 32, 224, 3, 778
+verts, vcol, cam, lc, ld = (x.cuda().contiguous() for x in kc.make_render_inputs(t, B, 7, H))
+h = lib.renderer_create(t.faces, V, image_size=H, aa=aa)
+ws = torch.zeros(lib.render_workspace_bytes(h, B), dtype=torch.uint8, device="cuda")
+rgba = torch.empty(B, 4, H, H, device="cuda"); fid = torch.empty(B, H * aa, H * aa, dtype=torch.int32, device="cuda")
+buf = (ctypes.c_ulonglong * 16)()
+for _ in range(2):
+    lib.render_fwd(h, verts, vcol, cam, lc, ld, rgba, fid, ws)
+torch.cuda.synchronize()
+hist = (ctypes.c_uint * 32)()
+lib.c.hifihr_debug_render_stamps(buf, 1); lib.c.hifihr_debug_render_hist(hist, 1)
+lib.render_fwd(h, verts, vcol, cam, lc, ld, rgba, fid, ws)
+torch.cuda.synchronize()
+lib.c.hifihr_debug_render_stamps(buf, 0)
+v = list(buf)
+n = max(v[15], 1)
+names = ["init (sxs, zbuf) + barrier", "stage faces (global -> LDS)", "raster pass (all)", "resolve + compaction", "shading", "  pass: rect + scan", "  pass: stage A rounds", "  pass: stage B (final drain)"]
+print(f"busy tiles {v[15]}; per busy tile: faces {v[13] / n:.1f}, candidates {v[12] / n:.1f}, survivors (final drains) {v[11] / n:.1f}, busy pixels {v[14] / n:.1f}")
+for i, nm in enumerate(names):
+    print(f"  {nm:34s} {v[i] / n:9.0f} cycles = {v[i] / n / 2100:6.2f} us")
+lib.c.hifihr_debug_render_hist(hist, 0)
+print(f"slowest covered tile: {v[10] / 2100:.1f} us; covered tiles by duration (7.8 us buckets):", [int(x) for x in hist][:24])
