@@ -8,13 +8,14 @@
 //   render_bin_kernel         per (face, image): the face's screen bounding box against the tile grid; the face id is appended
 //                             to the list of every 16x16-pixel tile it overlaps (same predicate the tiles used to evaluate for
 //                             ALL faces: 196 tiles x 1538 faces x 3 gathers per image, most of the forward's time)
-//   render_fwd_kernel         one workgroup per 16x16 output-pixel tile (48x48 samples at aa=3): the tile's face list is
-//                             staged in LDS, (face, pixel) candidates are enumerated densely over the lanes (nearest depth,
-//                             ties keep the lower face index -- a 64-bit atomicMin on (depth, face id), so the list order
-//                             does not matter), winners are shaded, and the resolved RGBA pixel plus the per-sample face id
-//                             side buffer (the only per-sample HBM traffic: 4 B/sample) are written.  A tile with an empty
+//   render_fwd2_kernel        one 256-thread workgroup per 8x8 output-pixel tile (24x24 samples at aa=3): the tile's face list is
+//                             staged in LDS, (face, pixel) candidates are enumerated densely over the lanes, conservative rejects
+//                             (stage A) feed ONE survivor queue per workgroup, the exact sample tests (stage B) run on dense waves of
+//                             it (nearest depth, ties keep the lower face index -- a 64-bit LDS atomicMin on (depth, face id), so the
+//                             list order does not matter), then (busy pixel, sample row) items are shaded and resolved; the
+//                             per-sample face id side buffer (4 B/sample) is the only per-sample HBM traffic.  A tile with an empty
 //                             list writes background and leaves.
-//   render_bwd_kernel         same tiling, no rasterisation: reads the face ids, recomputes barycentrics and
+//   render_bwd_kernel         (csrc/render_bwd.hip) 16x16 tiles, no rasterisation: reads the face ids, recomputes barycentrics and
 //                             shading, back-propagates to per-vertex records with float atomics
 //   render_vertex_bwd_kernel  per vertex: folds NDC / position / normal gradients into d(verts)
 // Rounding-sensitive maths lives in render_math.h and matches oracle/raster_oracle.c operation for operation.
@@ -22,25 +23,12 @@
 
 #include <cstdlib>
 
-#include "hifihr_internal.h"
-#include "render_math.h"
+#include "render_common.h"
 
 namespace hifihr {
 
-constexpr int kTile = 16;            // output pixels per tile edge
-constexpr int kFwdThreads = 512;     // forward tile kernel: 8 waves.  The kernel's duration is its slowest tile (a tile where the hand's
-                                     // layers pile up holds 10-16 k (face, pixel) candidates); candidates are independent, so more waves
-                                     // per tile shorten exactly that critical path.  Staging, the scan and shading use the first 256 lanes.
-constexpr int kFwdWaves = kFwdThreads / 64;
-constexpr int kCap = 512;            // faces held in LDS per pass (2 per lane in the candidate expansion)
-constexpr int kRecW = 11;            // floats per face record in LDS: 3 x (x, y), 3 z, face id, candidate rectangle (odd pitch: no bank
-                                     // conflicts between lanes on different faces; 22 KB instead of 32 KB lets a third tile share the CU)
-
-__device__ __forceinline__ float wsum(float x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-  return x;
-}
+constexpr int kRecW = 11;            // floats per face record in LDS: 3 x (x, y), 3 z, face id, candidate rectangle (odd pitch: no bank conflicts
+                                     // between lanes on different faces)
 
 // ------------------------------------------------------------------------------------------------
 // vertex stage
@@ -84,7 +72,6 @@ __global__ __launch_bounds__(256) void render_vertex_kernel(RenderDev r, const f
 // Also packs the face's 12 vertex records (NDC, position, unit normal, colour of its three corners: kFaceRec float4 = 192 bytes) into
 // frec[b][f]: the tile kernels then fetch a winning face with ONE level of indirection and twelve independent 16-byte loads instead
 // of face -> three vertex indices -> twelve gathers (two dependent global latencies per distinct face of a pixel, ~2 us each).
-constexpr int kFaceRec = 12;
 template <int AA, int TILE>
 __global__ __launch_bounds__(256) void render_bin_kernel(RenderDev r, const float4* __restrict__ vndc, const float4* __restrict__ vpos,
                                                         const float4* __restrict__ vnrm, const float4* __restrict__ vcol,
@@ -110,7 +97,7 @@ __global__ __launch_bounds__(256) void render_bin_kernel(RenderDev r, const floa
   if (face_is_rejected(fc)) return;
   const float xmin = fminf(fc.x0, fminf(fc.x1, fc.x2)), xmax = fmaxf(fc.x0, fmaxf(fc.x1, fc.x2));
   const float ymin = fminf(fc.y0, fminf(fc.y1, fc.y2)), ymax = fmaxf(fc.y0, fmaxf(fc.y1, fc.y2));
-  // tile t spans samples [t * kTile * AA, t * kTile * AA + n * AA - 1]; its NDC bounds are the ones render_fwd_kernel tests against
+  // tile t spans samples [t * kTile * AA, t * kTile * AA + n * AA - 1]; its NDC bounds are the ones render_fwd2_kernel tests against
   // (index 0 holds the largest coordinate).  Negated comparisons keep a face with a NaN coordinate in every tile, as before.
   int tx0 = tiles, tx1 = -1, ty0 = tiles, ty1 = -1;
   for (int t = 0; t < tiles; ++t) {
@@ -125,422 +112,6 @@ __global__ __launch_bounds__(256) void render_bin_kernel(RenderDev r, const floa
       const int slot = atomicAdd(tile_cnt + tile, 1);
       tile_list[tile * r.F + slot] = f;
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// TexturesUV (PyTorch3D renderer/mesh/textures.py TexturesUV.sample_textures [recalled]; reference models_res_nimble.py:203-208 hands the
-// NIMBLE texture image to the renderer this way): per sample, uv = sum_k bary_k uv[faces_uvs[f][k]] with the rasteriser's
-// perspective-corrected barycentrics, then F.grid_sample(flip(maps, vertical), 2 uv - 1, bilinear, align_corners=True, padding border).
-// Fused into the tile kernels' per-sample shading (template flag UV: the vertex-colour instantiations are unchanged): the forward
-// interpolates the face's three uvs with the barycentrics it already has and fetches four texels; the backward scatters d loss / d texel
-// into the texture (float atomics) and adds d texel / d uv . uv_k to the barycentric gradient, so the path to the vertices runs through the
-// same bary_bwd and per-vertex accumulators as every other attribute.
-// ------------------------------------------------------------------------------------------------
-struct UvSample { int x0, x1, y0, y1; float wx, wy; bool in_x, in_y; };      // rows are those of the UNFLIPPED map
-__device__ __forceinline__ UvSample uv_sample(float u, float v, int TH, int TW) {
-  UvSample q;
-  float ix = ((2.f * u - 1.f) + 1.f) * 0.5f * (float)(TW - 1);                 // grid_sample, align_corners = True
-  float iy = ((2.f * v - 1.f) + 1.f) * 0.5f * (float)(TH - 1);                 // row of the flipped map
-  q.in_x = ix >= 0.f && ix <= (float)(TW - 1);                                   // border padding: coordinates clipped (zero gradient outside)
-  q.in_y = iy >= 0.f && iy <= (float)(TH - 1);
-  ix = fminf(fmaxf(ix, 0.f), (float)(TW - 1));
-  iy = fminf(fmaxf(iy, 0.f), (float)(TH - 1));
-  const float fx = floorf(ix), fy = floorf(iy);
-  q.wx = ix - fx; q.wy = iy - fy;
-  q.x0 = (int)fx; q.x1 = min(q.x0 + 1, TW - 1);
-  const int r0 = (int)fy, r1 = min(r0 + 1, TH - 1);
-  q.y0 = TH - 1 - r0; q.y1 = TH - 1 - r1;                                        // un-flip
-  return q;
-}
-
-struct TexUvDev {
-  const int* faces_uvs;        // [F][3]
-  const float* verts_uvs;      // [Vt][2]
-  const float* maps;           // [B][TH][TW][3]
-  float* gmaps;                // [B][TH][TW][3] (backward; accumulated into) or null
-  int TH, TW;
-};
-
-// bilinear texel at (u, v) and, if asked, its derivatives with respect to the (clamped) pixel coordinates ix, iy
-__device__ __forceinline__ void uv_fetch(const TexUvDev& t, int b, const UvSample& q, float (&T)[3], float* dix, float* diy) {
-  const float* m = t.maps + (size_t)b * t.TH * t.TW * 3;
-  const float* p00 = m + ((size_t)q.y0 * t.TW + q.x0) * 3;
-  const float* p01 = m + ((size_t)q.y0 * t.TW + q.x1) * 3;
-  const float* p10 = m + ((size_t)q.y1 * t.TW + q.x0) * 3;
-  const float* p11 = m + ((size_t)q.y1 * t.TW + q.x1) * 3;
-  const float w00 = (1.f - q.wx) * (1.f - q.wy), w01 = q.wx * (1.f - q.wy), w10 = (1.f - q.wx) * q.wy, w11 = q.wx * q.wy;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float v00 = p00[c], v01 = p01[c], v10 = p10[c], v11 = p11[c];
-    T[c] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
-    if (dix != nullptr) {
-      dix[c] = (v01 - v00) * (1.f - q.wy) + (v11 - v10) * q.wy;
-      diy[c] = (v10 - v00) * (1.f - q.wx) + (v11 - v01) * q.wx;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward: raster + shade + resolve
-// ------------------------------------------------------------------------------------------------
-template <int AA>
-struct FwdLds {
-  float rec[kCap * kRecW];                               // culled faces of this tile, in face order
-  unsigned long long zbuf[kTile * AA * kTile * AA];      // per sample: (depth bits << 32) | face id, min-reduced
-  int coff[kCap + 1];                                    // exclusive prefix sum of candidate pixels per listed face
-  float sxs[kTile * AA], sys[kTile * AA];                // NDC coordinates of the tile's sample columns / rows
-  int wave_cnt[4];
-  int wave_tot[kFwdWaves];
-  int list_n;
-  int wq[kFwdWaves][128];                                // per-wave queue of surviving (face, pixel) candidates
-#ifdef HIFIHR_RENDER_STAMP
-  long long dbg[4];     // cycles in candidate rectangles, scan, candidate loop; sum of `total`
-#endif
-};
-
-// Rasterise the n faces currently listed in LDS.  Work items are (face, candidate pixel) pairs -- the pixels of the
-// tile whose sample footprint overlaps the face's bounding box -- enumerated densely over the 256 lanes (prefix sum +
-// binary search), so a lane never idles on a face that is nowhere near its pixel (the per-pixel walk of the first
-// version ran at ~7 % SIMD efficiency).  Winners are merged with a 64-bit LDS atomicMin on (depth bits, face id):
-// nearest depth first, ties keep the lower face index = the oracle's rule.
-template <int AA>
-__device__ __forceinline__ void raster_candidates(FwdLds<AA>& L, int n, int cols, int rows) {
-  constexpr int SW = kTile * AA;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef HIFIHR_RENDER_STAMP
-  long long rc_t = clock64();
-#define HIFIHR_RC_STAMP(i) { const long long now_ = clock64(); if (tid == 0) L.dbg[i] += now_ - rc_t; rc_t = now_; }
-#else
-#define HIFIHR_RC_STAMP(i)
-#endif
-  // (1) candidate rectangle of every listed face (one face per lane: kCap == kFwdThreads), packed into rec[10]
-  static_assert(kCap == kFwdThreads, "one listed face per lane");
-  int cnt = 0;
-  {
-    const int k = tid;
-    if (k < n) {
-      const float* q = L.rec + k * kRecW;
-      const float xmin = fminf(q[0], fminf(q[2], q[4])), xmax = fmaxf(q[0], fmaxf(q[2], q[4]));
-      const float ymin = fminf(q[1], fminf(q[3], q[5])), ymax = fmaxf(q[1], fmaxf(q[3], q[5]));
-      // pixel c overlaps the box iff hi(c) >= min and lo(c) <= max, hi(c) = s[c AA], lo(c) = s[c AA + AA - 1] (NDC DEcreases with the
-      // index): the first holds on a prefix of the columns, the second on a suffix, so the overlapping pixels are [#{lo > max}, #{hi >= min})
-      // -- two 5-probe searches per axis instead of a 16-column scan (the scan was 3 us of a 512-face pass, tools/render_stamp.py)
-      const auto prefix = [](const float* sv, int off, int nn, float v, bool strict) {
-        int len = 0;
-#pragma unroll
-        for (int step = 16; step > 0; step >>= 1) {
-          const int t = len + step;
-          if (t <= nn) {
-            const float a = sv[(t - 1) * AA + off];
-            if (strict ? (a > v) : (a >= v)) len = t;
-          }
-        }
-        return len;
-      };
-      const int x0 = prefix(L.sxs, AA - 1, cols, xmax, true), x1 = prefix(L.sxs, 0, cols, xmin, false) - 1;
-      const int y0 = prefix(L.sys, AA - 1, rows, ymax, true), y1 = prefix(L.sys, 0, rows, ymin, false) - 1;
-      const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-      if (w > 0 && h > 0) {
-        cnt = w * h;
-        L.rec[k * kRecW + 10] = __int_as_float(x0 | (y0 << 4) | (w << 8));
-      }
-    }
-  }
-  HIFIHR_RC_STAMP(0)
-  // (2) block-wide exclusive scan of the counts
-  int incl = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
-  }
-  if (lane == 63) L.wave_tot[wave] = incl;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wave; ++w) base += L.wave_tot[w];
-  if (tid < n) L.coff[tid] = base + incl - cnt;
-  int total = 0;
-#pragma unroll
-  for (int w = 0; w < kFwdWaves; ++w) total += L.wave_tot[w];
-  if (tid == 0) L.coff[n] = total;
-  __syncthreads();
-  HIFIHR_RC_STAMP(1)
-#ifdef HIFIHR_RENDER_STAMP
-  if (tid == 0) L.dbg[3] += total;
-#endif
-  // (3) (face, pixel) candidates, one per lane per round, in two stages.  Stage A is cheap and runs on every candidate: find the
-  //     face (binary search in the prefix sums), then two conservative rejects -- the pixel's sample square misses the triangle
-  //     (render_math.h square_misses_face), or the face's nearest vertex lies behind what all aa x aa samples of the pixel already
-  //     hold (interpolated depth is a convex combination of the vertex depths; 1e-5 margin, strict, so a tie is never decided
-  //     here; a stale, farther depth only rejects less).  Survivors are compacted per wave into an LDS queue, and stage B -- the
-  //     aa x aa exact sample tests with their six IEEE divisions each, ~2500 instructions that a wave executes in full as soon as
-  //     ONE of its lanes needs them -- runs on dense waves of 64 survivors.  Overlapping layers (front / back of the hand, fingers
-  //     over the palm) made stage B the critical path of the whole kernel: a tile with 60 candidates per pixel took 280 us.
-  const auto stage_b = [&](int entry) {
-    const int k = entry >> 8, cy = (entry >> 4) & 15, cx = entry & 15;
-    const float* q = L.rec + k * kRecW;
-    FaceXYZ f;
-    f.x0 = q[0]; f.y0 = q[1]; f.x1 = q[2]; f.y1 = q[3]; f.x2 = q[4]; f.y2 = q[5]; f.z0 = q[6]; f.z1 = q[7]; f.z2 = q[8];
-    const unsigned fidu = (unsigned)__float_as_int(q[9]);
-    const float xmin = fminf(f.x0, fminf(f.x1, f.x2)), xmax = fmaxf(f.x0, fmaxf(f.x1, f.x2));
-    const float ymin = fminf(f.y0, fminf(f.y1, f.y2)), ymax = fmaxf(f.y0, fmaxf(f.y1, f.y2));
-#pragma unroll
-    for (int i = 0; i < AA; ++i) {
-#pragma unroll
-      for (int j = 0; j < AA; ++j) {
-        float bary[3], pz;
-        if (sample_face(f, xmin, xmax, ymin, ymax, L.sxs[cx * AA + j], L.sys[cy * AA + i], bary, &pz)) {
-          const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(pz) << 32) | fidu;   // pz >= 0
-          atomicMin(&L.zbuf[(cy * AA + i) * SW + cx * AA + j], key);
-        }
-      }
-    }
-  };
-  int* wq = L.wq[wave];
-  int qn = 0;                                    // entries queued by this wave (wave-uniform)
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  // Stage A on kIlp candidates per lane per round, their binary searches advanced in lock step (fixed 9 probes: n <= 512): the probes
-  // of one search are dependent LDS reads (~9 x 64 cycles per round with nothing else to issue); four independent chains share that
-  // latency.  Results are identical: only the order in which (face, pixel) pairs are visited changes, and the 64-bit atomicMin on
-  // (depth, face id) does not depend on it.
-  constexpr int kIlp = 4;
-  for (int base = 0; base < total; base += kIlp * kFwdThreads) {
-    int cc[kIlp], lo[kIlp], hi[kIlp];
-#pragma unroll
-    for (int u = 0; u < kIlp; ++u) { cc[u] = base + u * kFwdThreads + tid; lo[u] = 0; hi[u] = n - 1; }
-#pragma unroll
-    for (int it = 0; it < 9; ++it) {
-#pragma unroll
-      for (int u = 0; u < kIlp; ++u) {                     // largest k with coff[k] <= c (idempotent once lo == hi)
-        const int mid = (lo[u] + hi[u] + 1) >> 1;
-        const bool le = L.coff[mid] <= min(cc[u], total - 1);
-        lo[u] = le ? mid : lo[u];
-        hi[u] = le ? hi[u] : mid - 1;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kIlp; ++u) {
-      const int c = cc[u];
-      bool survive = false;
-      int packed = 0;
-      if (c < total) {
-        const int k = lo[u];
-        const float* q = L.rec + k * kRecW;
-        const int info = __float_as_int(q[10]);
-        const int x0 = info & 15, y0 = (info >> 4) & 15, w = info >> 8;
-        const int local = c - L.coff[k];
-        const int dy = local / w, dx = local - dy * w;
-        const int cx = x0 + dx, cy = y0 + dy;
-        FaceXYZ f;
-        f.x0 = q[0]; f.y0 = q[1]; f.x1 = q[2]; f.y1 = q[3]; f.x2 = q[4]; f.y2 = q[5]; f.z0 = q[6]; f.z1 = q[7]; f.z2 = q[8];
-        survive = !square_misses_face(f, L.sxs[cx * AA + AA - 1], L.sxs[cx * AA], L.sys[cy * AA + AA - 1], L.sys[cy * AA]);
-        if (survive) {
-          const float znear = fminf(f.z0, fminf(f.z1, f.z2)) * (1.0f - 1e-5f);
-          bool behind = true;
-#pragma unroll
-          for (int i = 0; i < AA; ++i)
-#pragma unroll
-            for (int j = 0; j < AA; ++j) {
-              const unsigned long long key = L.zbuf[(cy * AA + i) * SW + cx * AA + j];
-              behind = behind && (key != ~0ull) && (__int_as_float((int)(unsigned)(key >> 32)) < znear);
-            }
-          survive = !behind;
-        }
-        packed = (k << 8) | (cy << 4) | cx;
-      }
-      const unsigned long long m = __ballot(survive);
-      if (survive) wq[qn + __popcll(m & lt)] = packed;
-      qn += __popcll(m);
-      (void)__ballot(true);                      // wave-level rendezvous: this wave's LDS writes are ordered before the reads below
-      if (qn >= 64) {
-        stage_b(wq[lane]);
-        const int rest = qn - 64;
-        const int moved = lane < rest ? wq[64 + lane] : 0;
-        (void)__ballot(true);
-        if (lane < rest) wq[lane] = moved;
-        qn = rest;
-        (void)__ballot(true);
-      }
-    }
-  }
-  if (lane < qn) stage_b(wq[lane]);
-  __syncthreads();
-  HIFIHR_RC_STAMP(2)
-}
-
-template <int AA, bool UV>
-__global__ __launch_bounds__(kFwdThreads) void render_fwd_kernel(RenderDev r, const float4* __restrict__ vndc,
-                                                        const float4* __restrict__ vpos, const float4* __restrict__ vnrm,
-                                                        const float4* __restrict__ vcol, const float* __restrict__ light_color,
-                                                        const float* __restrict__ light_dir, float* __restrict__ rgba,
-                                                        int* __restrict__ face_id, int* __restrict__ tile_cnt,
-                                                        const int* __restrict__ tile_list, TexUvDev tuv) {
-  // UV: the colour of a sample is the texture at its interpolated uv (TexturesUV, see above) instead of the interpolated vertex colour
-  HIP_DYNAMIC_SHARED(float4, smem_raw)
-  FwdLds<AA>& L = *reinterpret_cast<FwdLds<AA>*>(smem_raw);
-  constexpr int SW = kTile * AA;
-  const int b = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = r.H, S = H * AA;
-  // each wave owns a compact 8x8-pixel quadrant of the tile (shading locality)
-  const int tx = (lane & 7) + 8 * (wave & 1), ty = (lane >> 3) + 8 * (wave >> 1);
-  const int ox = blockIdx.x * kTile, oy = blockIdx.y * kTile;
-  const int px = ox + tx, py = oy + ty;
-  const bool live = (tid < kTile * kTile) && (px < H) && (py < H);      // one pixel per lane of the first four waves
-  const int cols = min(kTile, H - ox), rows = min(kTile, H - oy);      // pixel columns / rows of the tile inside the image
-  const float4* vb = vndc + (size_t)b * r.V;
-  // ---- this tile's face list (render_bin_kernel); an empty one means background ----
-  const int tiles = (H + kTile - 1) / kTile;
-  const size_t tile = ((size_t)b * tiles + blockIdx.y) * tiles + blockIdx.x;
-  const int nlist = tile_cnt[tile];
-  const int* flist = tile_list + tile * r.F;
-#ifdef HIFIHR_RENDER_STAMP        // diagnostic build (tools/render_stamp.py): per-tile duration replaces the face count in the workspace
-  const long long stamp0 = clock64();
-  long long stamp_raster = 0, stamp_stage = 0, stamp_t;
-#define HIFIHR_STAMP_BEGIN stamp_t = clock64();
-#define HIFIHR_STAMP_END(acc) acc += clock64() - stamp_t;
-#else
-#define HIFIHR_STAMP_BEGIN
-#define HIFIHR_STAMP_END(acc)
-#endif
-  if (nlist == 0) {
-    if (!live) return;
-    float acc[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < AA; ++i)
-#pragma unroll
-      for (int j = 0; j < AA; ++j) {
-        face_id[((size_t)b * S + (py * AA + i)) * S + (px * AA + j)] = -1;
-        acc[0] += r.bg[0]; acc[1] += r.bg[1]; acc[2] += r.bg[2];          // the same sums the full path forms: bit-identical output
-      }
-    const float inv = (float)(AA * AA);
-    const size_t plane = (size_t)H * H;
-    float* o = rgba + (size_t)b * 4 * plane + (size_t)py * H + px;
-    o[0] = acc[0] / inv; o[plane] = acc[1] / inv; o[2 * plane] = acc[2] / inv; o[3 * plane] = 0.f / inv;
-    return;
-  }
-  // NDC coordinates of the tile's samples (indices past the image edge are clamped; they are never candidates)
-  for (int e = tid; e < 2 * SW; e += kFwdThreads) {
-    const int idx = e < SW ? e : e - SW;
-    const int g = min((e < SW ? ox : oy) * AA + idx, S - 1);
-    const float v = pix_to_ndc(S - 1 - g, S);
-    if (e < SW) L.sxs[idx] = v; else L.sys[idx] = v;
-  }
-  for (int e = tid; e < SW * SW; e += kFwdThreads) L.zbuf[e] = ~0ull;
-  if (tid == 0) L.list_n = 0;
-#ifdef HIFIHR_RENDER_STAMP
-  if (tid < 4) L.dbg[tid] = 0;
-#endif
-  __syncthreads();
-
-  for (int base = 0; base < nlist; base += 256) {
-    // ---- stage the next 256 listed faces in LDS (vertex gathers + bounding box) ----
-    HIFIHR_STAMP_BEGIN
-    const int k = base + tid;
-    const int cnt = min(256, nlist - base);
-    if (tid < 256 && k < nlist) {
-      const int f = flist[k];
-      const float4 a = vb[r.faces[3 * f]], c = vb[r.faces[3 * f + 1]], d = vb[r.faces[3 * f + 2]];
-      float* q = L.rec + (L.list_n + tid) * kRecW;
-      q[0] = a.x; q[1] = a.y; q[2] = c.x; q[3] = c.y; q[4] = d.x; q[5] = d.y; q[6] = a.z; q[7] = c.z;
-      q[8] = d.z; q[9] = __int_as_float(f); q[10] = 0.f;
-    }
-    __syncthreads();
-    const int n = L.list_n + cnt;
-    const bool last = (base + 256 >= nlist);
-    const bool flush = last || (n + 256 > kCap);
-    HIFIHR_STAMP_END(stamp_stage)
-    HIFIHR_STAMP_BEGIN
-    if (flush) raster_candidates<AA>(L, n, cols, rows);
-    __syncthreads();
-    HIFIHR_STAMP_END(stamp_raster)
-    if (tid == 0) L.list_n = flush ? 0 : n;
-    __syncthreads();
-  }
-
-  if (!live) return;
-  float sx[AA], sy[AA];
-  int best_f[AA * AA];
-#pragma unroll
-  for (int j = 0; j < AA; ++j) { sx[j] = L.sxs[tx * AA + j]; sy[j] = L.sys[ty * AA + j]; }
-#pragma unroll
-  for (int i = 0; i < AA; ++i)
-#pragma unroll
-    for (int j = 0; j < AA; ++j) {
-      const unsigned long long key = L.zbuf[(ty * AA + i) * SW + tx * AA + j];
-      best_f[i * AA + j] = (key == ~0ull) ? -1 : (int)(unsigned)(key & 0xffffffffull);
-    }
-
-  // ---- shade the winners, resolve, write ----
-  if (!live) return;
-  LightDir Ld;
-  {
-    const float raw[3] = {light_dir[3 * b], light_dir[3 * b + 1], light_dir[3 * b + 2]};
-    normalize3(raw, Ld.l, &Ld.inv_norm);
-    if (r.sc.point_light) { Ld.l[0] = raw[0]; Ld.l[1] = raw[1]; Ld.l[2] = raw[2]; }     // PointLights: the location, as given
-    Ld.lc[0] = light_color[3 * b]; Ld.lc[1] = light_color[3 * b + 1]; Ld.lc[2] = light_color[3 * b + 2];
-  }
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const size_t vo = (size_t)b * r.V;
-  int cur_f = -1;
-  FaceXYZ fc;
-  float4 p0, p1, p2, n0, n1, n2, c0, c1, c2;
-  float fu[3] = {0.f, 0.f, 0.f}, fv[3] = {0.f, 0.f, 0.f};
-  fc.x0 = fc.y0 = fc.z0 = fc.x1 = fc.y1 = fc.z1 = fc.x2 = fc.y2 = fc.z2 = 0.f;
-  p0 = p1 = p2 = n0 = n1 = n2 = c0 = c1 = c2 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int i = 0; i < AA; ++i) {
-#pragma unroll
-    for (int j = 0; j < AA; ++j) {
-      const int s = i * AA + j;
-      const int f = best_f[s];
-      face_id[((size_t)b * S + (py * AA + i)) * S + (px * AA + j)] = f;
-      if (f < 0) {
-        acc[0] += r.bg[0]; acc[1] += r.bg[1]; acc[2] += r.bg[2];
-        continue;
-      }
-      if (f != cur_f) {          // the aa x aa samples of an interior pixel share one face: its 12 vertex records are gathered once
-        cur_f = f;
-        const int i0 = r.faces[3 * f], i1 = r.faces[3 * f + 1], i2 = r.faces[3 * f + 2];
-        const float4 a = vndc[vo + i0], c = vndc[vo + i1], d = vndc[vo + i2];
-        fc.x0 = a.x; fc.y0 = a.y; fc.z0 = a.z; fc.x1 = c.x; fc.y1 = c.y; fc.z1 = c.z; fc.x2 = d.x; fc.y2 = d.y; fc.z2 = d.z;
-        p0 = vpos[vo + i0]; p1 = vpos[vo + i1]; p2 = vpos[vo + i2];
-        n0 = vnrm[vo + i0]; n1 = vnrm[vo + i1]; n2 = vnrm[vo + i2];
-        c0 = vcol[vo + i0]; c1 = vcol[vo + i1]; c2 = vcol[vo + i2];
-        if constexpr (UV) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) { const int iu = tuv.faces_uvs[3 * f + k]; fu[k] = tuv.verts_uvs[2 * iu]; fv[k] = tuv.verts_uvs[2 * iu + 1]; }
-        }
-      }
-      float bary[3];
-      bary_of(fc, sx[j], sy[i], bary);
-      const float P[3] = {bary[0] * p0.x + bary[1] * p1.x + bary[2] * p2.x, bary[0] * p0.y + bary[1] * p1.y + bary[2] * p2.y,
-                          bary[0] * p0.z + bary[1] * p1.z + bary[2] * p2.z};
-      const float N[3] = {bary[0] * n0.x + bary[1] * n1.x + bary[2] * n2.x, bary[0] * n0.y + bary[1] * n1.y + bary[2] * n2.y,
-                          bary[0] * n0.z + bary[1] * n1.z + bary[2] * n2.z};
-      float T[3] = {bary[0] * c0.x + bary[1] * c1.x + bary[2] * c2.x, bary[0] * c0.y + bary[1] * c1.y + bary[2] * c2.y,
-                    bary[0] * c0.z + bary[1] * c1.z + bary[2] * c2.z};
-      if constexpr (UV) {
-        const float u = bary[0] * fu[0] + bary[1] * fu[1] + bary[2] * fu[2], v = bary[0] * fv[0] + bary[1] * fv[1] + bary[2] * fv[2];
-        uv_fetch(tuv, b, uv_sample(u, v, tuv.TH, tuv.TW), T, nullptr, nullptr);
-      }
-      float rgb[3];
-      shade_fwd(r.sc, Ld, P, N, T, rgb, nullptr);
-      acc[0] += rgb[0]; acc[1] += rgb[1]; acc[2] += rgb[2]; acc[3] += 1.f;
-    }
-  }
-  const float inv = (float)(AA * AA);
-  const size_t plane = (size_t)H * H;
-  float* o = rgba + (size_t)b * 4 * plane + (size_t)py * H + px;
-  o[0] = acc[0] / inv; o[plane] = acc[1] / inv; o[2 * plane] = acc[2] / inv; o[3 * plane] = acc[3] / inv;
-#ifdef HIFIHR_RENDER_STAMP
-  if (tid == 0) {
-    tile_cnt[tile] = (nlist << 20) | (int)min((clock64() - stamp0) >> 6, (long long)0xfffff);    // faces, cycles / 64
-    int* dbg = const_cast<int*>(flist);
-    dbg[0] = (int)(stamp_stage >> 6); dbg[1] = (int)(stamp_raster >> 6);
-    dbg[2] = (int)(L.dbg[0] >> 6); dbg[3] = (int)(L.dbg[1] >> 6); dbg[4] = (int)(L.dbg[2] >> 6); dbg[5] = (int)L.dbg[3];
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,13 +145,6 @@ constexpr int kF2Threads = 256;
 constexpr int kF2Cap = 256;          // faces per pass
 constexpr int kQCap = 1024;          // survivor queue entries: a round appends at most 256
 
-#if defined(HIFIHR_HOSTSIM)
-__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
-__device__ __forceinline__ float fast_rsq(float x) { return 1.0f / sqrtf(x); }
-#else
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-#endif
 
 // shade_fwd (render_math.h) with contraction and approximate reciprocal square roots; integer shininess by repeated squaring
 __device__ __forceinline__ void shade_fwd_fast(const ShadeConsts& c, const LightDir& L, const float* P, const float* N, const float* T, float* rgb) {
@@ -988,286 +552,12 @@ __global__ __launch_bounds__(kF2Threads) void render_fwd2_kernel(RenderDev r, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void flush_face(float* __restrict__ gv, const int* idx, const float* acc) {
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float* dst = gv + (size_t)idx[k] * 12;
-#pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      const float v = acc[k * 12 + c];
-      if (v != 0.f) atomicAdd(dst + c, v);
-    }
-  }
-}
-
-template <int AA, bool UV>
-__global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const float4* __restrict__ frec,
-                                                        const float* __restrict__ light_color,
-                                                        const float* __restrict__ light_dir, const int* __restrict__ face_id,
-                                                        const float* __restrict__ grad_rgba, float* __restrict__ gvrec,
-                                                        float* __restrict__ glight_color, float* __restrict__ glight_dir,
-                                                        int use_lds, TexUvDev tuv
-#ifdef HIFIHR_RENDER_STAMP
-                                                        , int* __restrict__ dbg_tiles
-#endif
-                                                        ) {
-  // use_lds: the per-vertex gradient records of ONE image (V x 12 floats, 37 KB for MANO) are accumulated in LDS with
-  // ds_add_f32 and flushed once per tile with contiguous global atomics.  Scattering one global float atomic per lane
-  // per value instead (64 different rows per wave instruction) ran at ~0.08 TB/s and was 85 % of this kernel's time.
-  HIP_DYNAMIC_SHARED(float, lacc)
-  __shared__ float red[4 * 6];
-  __shared__ int any_hit[4];
-  const int b = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = r.H, S = H * AA;
-  const int px = blockIdx.x * kTile + (lane & 7) + 8 * (wave & 1), py = blockIdx.y * kTile + (lane >> 3) + 8 * (wave >> 1);
-  const bool live = (px < H) && (py < H);
-  // face ids of this lane's samples; tiles without any covered sample leave at once
-  int fid[AA * AA];
-  bool hit = false;
-#pragma unroll
-  for (int i = 0; i < AA; ++i)
-#pragma unroll
-    for (int j = 0; j < AA; ++j) {
-      const int f = live ? face_id[((size_t)b * S + (py * AA + i)) * S + (px * AA + j)] : -1;
-      fid[i * AA + j] = f;
-      hit = hit || (f >= 0);
-    }
-  const unsigned long long hm = __ballot(hit);
-  if (lane == 0) any_hit[wave] = (hm != 0ull);
-  __syncthreads();
-  if (!(any_hit[0] | any_hit[1] | any_hit[2] | any_hit[3])) return;
-#ifdef HIFIHR_RENDER_STAMP
-  const long long bs0 = clock64();
-  long long bs1 = 0, bs2 = 0;
-#endif
-  const int nacc = r.V * 12;
-  if (use_lds) {
-    for (int e = tid; e < nacc; e += 256) lacc[e] = 0.f;
-    __syncthreads();
-  }
-#ifdef HIFIHR_RENDER_STAMP
-  bs1 = clock64();
-#endif
-  float glc[3] = {0.f, 0.f, 0.f}, gl[3] = {0.f, 0.f, 0.f};
-  LightDir Ld;
-  const float raw[3] = {light_dir[3 * b], light_dir[3 * b + 1], light_dir[3 * b + 2]};
-  normalize3(raw, Ld.l, &Ld.inv_norm);
-  if (r.sc.point_light) { Ld.l[0] = raw[0]; Ld.l[1] = raw[1]; Ld.l[2] = raw[2]; }
-  Ld.lc[0] = light_color[3 * b]; Ld.lc[1] = light_color[3 * b + 1]; Ld.lc[2] = light_color[3 * b + 2];
-  if (live) {
-    const size_t plane = (size_t)H * H;
-    const float* g = grad_rgba + (size_t)b * 4 * plane + (size_t)py * H + px;
-    const float inv = (float)(AA * AA);
-    const float g_rgb[3] = {g[0] / inv, g[plane] / inv, g[2 * plane] / inv};
-    const size_t vo = (size_t)b * r.V;
-    float* gv = use_lds ? lacc : gvrec + vo * 12;
-    float acc[36];
-    int cur = -1, cidx[3] = {0, 0, 0};
-    FaceXYZ fc;
-    fc.x0 = fc.y0 = fc.z0 = fc.x1 = fc.y1 = fc.z1 = fc.x2 = fc.y2 = fc.z2 = 0.f;
-    float pos[3][3] = {}, nrm[3][3] = {}, col[3][3] = {};
-#pragma unroll
-    for (int i = 0; i < AA; ++i) {
-      const float syi = pix_to_ndc(S - 1 - (py * AA + i), S);
-#pragma unroll
-      for (int j = 0; j < AA; ++j) {
-        const int f = fid[i * AA + j];
-        if (f < 0) continue;
-        const float sxj = pix_to_ndc(S - 1 - (px * AA + j), S);
-        if (f != cur) {
-          if (cur >= 0) flush_face(gv, cidx, acc);
-          cur = f;
-          cidx[0] = r.faces[3 * f]; cidx[1] = r.faces[3 * f + 1]; cidx[2] = r.faces[3 * f + 2];
-#pragma unroll
-          for (int k = 0; k < 36; ++k) acc[k] = 0.f;
-          // the face's twelve vertex records, once per run of samples on this face: packed by the forward's render_bin_kernel (one level
-          // of indirection, independent 16-byte loads); round 2 re-gathered them through the vertex indices for every sample
-          const float4* q = frec + ((size_t)b * r.F + f) * kFaceRec;
-          const float4 a = q[0], c = q[1], d = q[2];
-          fc.x0 = a.x; fc.y0 = a.y; fc.z0 = a.z; fc.x1 = c.x; fc.y1 = c.y; fc.z1 = c.z; fc.x2 = d.x; fc.y2 = d.y; fc.z2 = d.z;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float4 p = q[3 + k], n = q[6 + k], t = q[9 + k];
-            pos[k][0] = p.x; pos[k][1] = p.y; pos[k][2] = p.z;
-            nrm[k][0] = n.x; nrm[k][1] = n.y; nrm[k][2] = n.z;
-            col[k][0] = t.x; col[k][1] = t.y; col[k][2] = t.z;
-            if constexpr (UV) { col[k][0] = 0.f; col[k][1] = 0.f; col[k][2] = 0.f; }          // TexturesUV: the colour is no function of these
-          }
-        }
-        float bary[3];
-        bary_of(fc, sxj, syi, bary);
-        float P[3], N[3], T[3];
-#pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
-          P[c3] = bary[0] * pos[0][c3] + bary[1] * pos[1][c3] + bary[2] * pos[2][c3];
-          N[c3] = bary[0] * nrm[0][c3] + bary[1] * nrm[1][c3] + bary[2] * nrm[2][c3];
-          T[c3] = bary[0] * col[0][c3] + bary[1] * col[1][c3] + bary[2] * col[2][c3];
-        }
-        float fu[3] = {0.f, 0.f, 0.f}, fv[3] = {0.f, 0.f, 0.f}, dix[3], diy[3];
-        UvSample q{};
-        if constexpr (UV) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) { const int iu = tuv.faces_uvs[3 * f + k]; fu[k] = tuv.verts_uvs[2 * iu]; fv[k] = tuv.verts_uvs[2 * iu + 1]; }
-          const float u = bary[0] * fu[0] + bary[1] * fu[1] + bary[2] * fu[2], v = bary[0] * fv[0] + bary[1] * fv[1] + bary[2] * fv[2];
-          q = uv_sample(u, v, tuv.TH, tuv.TW);
-          uv_fetch(tuv, b, q, T, dix, diy);
-        }
-        float gP[3], gN[3], gT[3];
-        shade_bwd(r.sc, Ld, P, N, T, g_rgb, gP, gN, gT, glc, gl);
-        float guv[2] = {0.f, 0.f};                               // d loss / d (u, v) of this sample
-        if constexpr (UV) {
-          float gix = 0.f, giy = 0.f;
-          const float w00 = (1.f - q.wx) * (1.f - q.wy), w01 = q.wx * (1.f - q.wy), w10 = (1.f - q.wx) * q.wy, w11 = q.wx * q.wy;
-          float* gm = tuv.gmaps != nullptr ? tuv.gmaps + (size_t)b * tuv.TH * tuv.TW * 3 : nullptr;
-#pragma unroll
-          for (int c3 = 0; c3 < 3; ++c3) {
-            if (gm != nullptr && gT[c3] != 0.f) {
-              atomicAdd(gm + ((size_t)q.y0 * tuv.TW + q.x0) * 3 + c3, gT[c3] * w00); atomicAdd(gm + ((size_t)q.y0 * tuv.TW + q.x1) * 3 + c3, gT[c3] * w01);
-              atomicAdd(gm + ((size_t)q.y1 * tuv.TW + q.x0) * 3 + c3, gT[c3] * w10); atomicAdd(gm + ((size_t)q.y1 * tuv.TW + q.x1) * 3 + c3, gT[c3] * w11);
-            }
-            gix += gT[c3] * dix[c3]; giy += gT[c3] * diy[c3];
-          }
-          guv[0] = q.in_x ? gix * (float)(tuv.TW - 1) : 0.f;     // d ix / d u = TW - 1; zero where grid_sample clipped the coordinate
-          guv[1] = q.in_y ? giy * (float)(tuv.TH - 1) : 0.f;
-        }
-        float gb[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          gb[k] = gP[0] * pos[k][0] + gP[1] * pos[k][1] + gP[2] * pos[k][2] + gN[0] * nrm[k][0] + gN[1] * nrm[k][1] +
-                  gN[2] * nrm[k][2] + gT[0] * col[k][0] + gT[1] * col[k][1] + gT[2] * col[k][2];
-          if constexpr (UV) gb[k] += guv[0] * fu[k] + guv[1] * fv[k];                            // the texel's dependence on the barycentrics
-#pragma unroll
-          for (int c3 = 0; c3 < 3; ++c3) {
-            acc[k * 12 + 3 + c3] += bary[k] * gP[c3];
-            acc[k * 12 + 6 + c3] += bary[k] * gN[c3];
-            acc[k * 12 + 9 + c3] += bary[k] * gT[c3];
-          }
-        }
-        float gn[9];
-        bary_bwd(fc, sxj, syi, gb, gn);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          acc[k * 12 + 0] += gn[3 * k]; acc[k * 12 + 1] += gn[3 * k + 1]; acc[k * 12 + 2] += gn[3 * k + 2];
-        }
-      }
-    }
-    if (cur >= 0) flush_face(gv, cidx, acc);
-  }
-  if (use_lds) {
-    __syncthreads();
-#ifdef HIFIHR_RENDER_STAMP
-    bs2 = clock64();
-#endif
-    float* gdst = gvrec + (size_t)b * r.V * 12;
-    for (int e = tid; e < nacc; e += 256) {
-      const float v = lacc[e];
-      if (v != 0.f) atomicAdd(gdst + e, v);
-    }
-  }
-  // ---- light gradients: workgroup reduction, one atomic set per tile ----
-  float v6[6] = {glc[0], glc[1], glc[2], gl[0], gl[1], gl[2]};
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const float s = wsum(v6[k]);
-    if (lane == 0) red[wave * 6 + k] = s;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float t[6];
-    for (int k = 0; k < 6; ++k) t[k] = red[k] + red[6 + k] + red[12 + k] + red[18 + k];
-    if (t[0] != 0.f || t[1] != 0.f || t[2] != 0.f || t[3] != 0.f || t[4] != 0.f || t[5] != 0.f) {
-      for (int k = 0; k < 3; ++k) atomicAdd(glight_color + 3 * b + k, t[k]);
-      float gd[3];
-      normalize3_bwd(raw, Ld.l, Ld.inv_norm, t + 3, gd);       // through F.normalize(direction)
-      for (int k = 0; k < 3; ++k) atomicAdd(glight_dir + 3 * b + k, gd[k]);
-    }
-#ifdef HIFIHR_RENDER_STAMP
-    const long long bs3 = clock64();
-    int* d = dbg_tiles + (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
-    d[0] = (int)((bs1 - bs0) >> 6); d[1] = (int)((bs2 - bs1) >> 6); d[2] = (int)((bs3 - bs2) >> 6); d[3] = 1;
-#endif
-  }
-}
-
-// per vertex: fold the per-vertex gradient records into d(verts) (and d(vertex colours))
-__global__ __launch_bounds__(256) void render_vertex_bwd_kernel(RenderDev r, const float* __restrict__ verts,
-                                                               const float* __restrict__ cam, const float4* __restrict__ vndc,
-                                                               const float4* __restrict__ vnrm, const float* __restrict__ gvrec,
-                                                               float* __restrict__ gverts, float* __restrict__ gvcolors) {
-  const int b = blockIdx.y;
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= r.V) return;
-  const size_t vo = (size_t)b * r.V;
-  const float* vb = verts + vo * 3;
-  const float* g = gvrec + (vo + v) * 12;
-  const float Z = vb[3 * v + 2];
-  const float fx = cam[4 * b], fy = cam[4 * b + 1], px = cam[4 * b + 2], py = cam[4 * b + 3];
-  const float4 nd = vndc[vo + v];
-  // x = (X fx + Z px) / Z ; y likewise ; z = Z
-  float gx = g[3] + g[0] * fx / Z;
-  float gy = g[4] + g[1] * fy / Z;
-  float gz = g[5] + g[2] + g[0] * (px - nd.x) / Z + g[1] * (py - nd.y) / Z;
-  // vertex normals: n = normalize(sum_f cross(v2 - v1, v0 - v1))
-  for (int e = r.vf_off[v]; e < r.vf_off[v + 1]; ++e) {
-    const int f = r.vf_idx[e] >> 2, role = r.vf_idx[e] & 3;
-    const int id[3] = {r.faces[3 * f], r.faces[3 * f + 1], r.faces[3 * f + 2]};
-    float gfn[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float4 n = vnrm[vo + id[k]];
-      const float* gk = gvrec + (vo + id[k]) * 12 + 6;
-      const float gn[3] = {gk[0], gk[1], gk[2]};
-      if (n.w < 1.0f / kNormEps) {
-        const float d = n.x * gn[0] + n.y * gn[1] + n.z * gn[2];
-        gfn[0] += (gn[0] - n.x * d) * n.w; gfn[1] += (gn[1] - n.y * d) * n.w; gfn[2] += (gn[2] - n.z * d) * n.w;
-      } else {
-        gfn[0] += gn[0] * n.w; gfn[1] += gn[1] * n.w; gfn[2] += gn[2] * n.w;
-      }
-    }
-    const float* q0 = vb + 3 * id[0];
-    const float* q1 = vb + 3 * id[1];
-    const float* q2 = vb + 3 * id[2];
-    const float A[3] = {q2[0] - q1[0], q2[1] - q1[1], q2[2] - q1[2]};
-    const float Bv[3] = {q0[0] - q1[0], q0[1] - q1[1], q0[2] - q1[2]};
-    // fn = A x Bv :  gA = Bv x gfn ,  gB = gfn x A
-    const float gA[3] = {Bv[1] * gfn[2] - Bv[2] * gfn[1], Bv[2] * gfn[0] - Bv[0] * gfn[2], Bv[0] * gfn[1] - Bv[1] * gfn[0]};
-    const float gB[3] = {gfn[1] * A[2] - gfn[2] * A[1], gfn[2] * A[0] - gfn[0] * A[2], gfn[0] * A[1] - gfn[1] * A[0]};
-    if (role == 0) { gx += gB[0]; gy += gB[1]; gz += gB[2]; }
-    else if (role == 2) { gx += gA[0]; gy += gA[1]; gz += gA[2]; }
-    else { gx -= gA[0] + gB[0]; gy -= gA[1] + gB[1]; gz -= gA[2] + gB[2]; }
-  }
-  float* o = gverts + (vo + v) * 3;
-  o[0] = gx; o[1] = gy; o[2] = gz;
-  if (gvcolors) {
-    float* oc = gvcolors + (vo + v) * 3;
-    oc[0] = g[9]; oc[1] = g[10]; oc[2] = g[11];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 // workspace: four float4[B][V] vertex arrays, the float[B][V][12] gradient records of the backward, then the forward's per-tile face
 // lists: int cnt[B][tiles^2] and int list[B][tiles^2][F] (worst case: the whole mesh inside one tile)
-static size_t vertex_part_bytes(const RenderDev& r, int B) { return (size_t)B * r.V * (4 * sizeof(float4) + 12 * sizeof(float)); }
-
-static int render_tile() {                // tile edge of the forward (8: see render_fwd2_kernel; HIFIHR_RENDER_TILE=16 for the A/B)
-  static const int v = [] { const char* e = getenv("HIFIHR_RENDER_TILE"); return (e && atoi(e) == 16) ? 16 : 8; }();
-  return v;
-}
-static size_t list_part_bytes(const RenderDev& r, int B) {
-  const size_t tiles = (size_t)((r.H + 7) / 8) * ((r.H + 7) / 8);                 // the finest grid either form uses
-  return ((size_t)B * tiles * sizeof(int) * (1 + (size_t)r.F) + 255) / 256 * 256;
-}
-// ... then the packed face records float4[B][F][kFaceRec] (written by render_bin_kernel, read by both tile kernels)
 size_t render_workspace_bytes(const RenderDev& r, int B) {
   return vertex_part_bytes(r, B) + list_part_bytes(r, B) + (size_t)B * r.F * kFaceRec * sizeof(float4);
-}
-static float4* face_records(const RenderDev& r, int B, void* ws) {
-  return reinterpret_cast<float4*>(reinterpret_cast<char*>(ws) + vertex_part_bytes(r, B) + list_part_bytes(r, B));
 }
 #if defined(HIFIHR_RENDER_STAMP2)
 extern "C" int hifihr_debug_render_stamps(unsigned long long* out16, int reset) {
@@ -1281,23 +571,6 @@ extern "C" int hifihr_debug_render_hist(unsigned* out32, int reset) {
   return 0;
 }
 #endif
-static int render_version() {
-  static const int v = [] { const char* e = getenv("HIFIHR_RENDER_V"); return e ? atoi(e) : 2; }();
-  return v;
-}
-
-static void carve(const RenderDev& r, int B, void* ws, float4** vndc, float4** vpos, float4** vnrm, float4** vcol, float** gvrec,
-                  int** tile_cnt = nullptr, int** tile_list = nullptr, int tile_edge = kTile) {
-  float4* p = reinterpret_cast<float4*>(ws);
-  const size_t n = (size_t)B * r.V;
-  *vndc = p; *vpos = p + n; *vnrm = p + 2 * n; *vcol = p + 3 * n;
-  *gvrec = reinterpret_cast<float*>(p + 4 * n);
-  if (tile_cnt != nullptr) {
-    const size_t tiles = (size_t)((r.H + tile_edge - 1) / tile_edge) * ((r.H + tile_edge - 1) / tile_edge);
-    *tile_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + vertex_part_bytes(r, B));
-    *tile_list = *tile_cnt + (size_t)B * tiles;
-  }
-}
 
 hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float* vcolors, long vcol_bstride, const float* cam,
                              const float* light_color, const float* light_dir, int B, float* rgba, int* face_id, void* ws,
@@ -1305,15 +578,14 @@ hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float
   float4 *vndc, *vpos, *vnrm, *vcol;
   float* gvrec;
   int *tile_cnt, *tile_list;
-  const bool v2 = render_version() >= 2;
-  const int te = v2 ? render_tile() : kTile;
+  const int te = render_tile();
   carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec, &tile_cnt, &tile_list, te);
   const int tiles = (r.H + te - 1) / te;
   hipLaunchKernelGGL(render_vertex_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, vcolors, vcol_bstride, cam,
                      vndc, vpos, vnrm, vcol, tile_cnt, tiles * tiles);
-  const dim3 grid(tiles, tiles, B), bgrid((r.F + 255) / 256, B);
+  const dim3 bgrid((r.F + 255) / 256, B);
   static const int xm = [] { const char* e = getenv("HIFIHR_RENDER_XCD"); return e ? atoi(e) : 0; }();      // A/B: images pinned to XCDs
-  const dim3 grid1((unsigned)((xm ? 8 * ((B + 7) / 8) : B) * tiles * tiles));          // v2: 1-D
+  const dim3 grid1((unsigned)((xm ? 8 * ((B + 7) / 8) : B) * tiles * tiles));
   float4* frec = face_records(r, B, ws);
   const TexUvDev td = uv != nullptr ? TexUvDev{uv->faces_uvs, uv->verts_uvs, uv->maps, nullptr, uv->TH, uv->TW} : TexUvDev{};
 #define HIFIHR_RENDER_FWD2(AA_, T_)                                                                                                      \
@@ -1326,18 +598,7 @@ hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float
       hipLaunchKernelGGL((render_fwd2_kernel<AA_, T_, false>), grid1, dim3(kF2Threads), sizeof(Fwd2Lds<AA_, T_>), st, r, frec,           \
                          light_color, light_dir, rgba, face_id, tile_cnt, tile_list, td, B, xm);                                        \
   }
-#define HIFIHR_RENDER_FWD(AA_)                                                                                                          \
-  if (v2) {                                                                                                                             \
-    if (te == 8) HIFIHR_RENDER_FWD2(AA_, 8) else HIFIHR_RENDER_FWD2(AA_, 16)                                                            \
-  } else {                                                                                                                              \
-    hipLaunchKernelGGL((render_bin_kernel<AA_, kTile>), bgrid, dim3(256), 0, st, r, vndc, vpos, vnrm, vcol, frec, tile_cnt, tile_list);  \
-    if (uv != nullptr)                                                                                                                  \
-      hipLaunchKernelGGL((render_fwd_kernel<AA_, true>), grid, dim3(kFwdThreads), sizeof(FwdLds<AA_>), st, r, vndc, vpos, vnrm, vcol,    \
-                         light_color, light_dir, rgba, face_id, tile_cnt, tile_list, td);                                               \
-    else                                                                                                                                \
-      hipLaunchKernelGGL((render_fwd_kernel<AA_, false>), grid, dim3(kFwdThreads), sizeof(FwdLds<AA_>), st, r, vndc, vpos, vnrm, vcol,   \
-                         light_color, light_dir, rgba, face_id, tile_cnt, tile_list, td);                                               \
-  }
+#define HIFIHR_RENDER_FWD(AA_) if (te == 8) HIFIHR_RENDER_FWD2(AA_, 8) else HIFIHR_RENDER_FWD2(AA_, 16)
   switch (r.aa) {
     case 1: HIFIHR_RENDER_FWD(1) break;
     case 2: HIFIHR_RENDER_FWD(2) break;
@@ -1346,53 +607,6 @@ hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float
   }
 #undef HIFIHR_RENDER_FWD
 #undef HIFIHR_RENDER_FWD2
-  return hipGetLastError();
-}
-
-hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float* cam, const float* light_color,
-                             const float* light_dir, const int* face_id, const float* grad_rgba, int B, float* gverts,
-                             float* gvcolors, float* glight_color, float* glight_dir, void* ws, hipStream_t st, const TexUvPass* uv) {
-  float4 *vndc, *vpos, *vnrm, *vcol;
-  float* gvrec;
-#ifdef HIFIHR_RENDER_STAMP
-  int *dbg_cnt, *dbg_list;
-  carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec, &dbg_cnt, &dbg_list);
-#define HIFIHR_BWD_DBG , dbg_list
-#else
-  carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec);
-#define HIFIHR_BWD_DBG
-#endif
-  hipError_t e = hipMemsetAsync(gvrec, 0, (size_t)B * r.V * 12 * sizeof(float), st);
-  if (e != hipSuccess) return e;
-  if (glight_dir == glight_color + (size_t)B * 3) {           // adjacent (hifihr_amd/ops.py allocates them as one tensor): one fill
-    if ((e = hipMemsetAsync(glight_color, 0, (size_t)B * 6 * sizeof(float), st)) != hipSuccess) return e;
-  } else {
-    if ((e = hipMemsetAsync(glight_color, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(glight_dir, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
-  }
-  const int tiles = (r.H + kTile - 1) / kTile;
-  const dim3 grid(tiles, tiles, B);
-  const float4* frec = face_records(r, B, ws);                // written by the forward of the same (handle, workspace, batch)
-  const size_t lds = (size_t)r.V * 12 * sizeof(float);
-  const int use_lds = lds <= 60 * 1024;               // MANO: 37 KB; larger meshes fall back to direct global atomics
-  const size_t dyn = use_lds ? lds : 0;
-  const TexUvDev td = uv != nullptr ? TexUvDev{uv->faces_uvs, uv->verts_uvs, uv->maps, uv->gmaps, uv->TH, uv->TW} : TexUvDev{};
-  switch (r.aa) {
-    case 1:
-      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<1, true>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      else hipLaunchKernelGGL((render_bwd_kernel<1, false>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      break;
-    case 2:
-      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<2, true>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      else hipLaunchKernelGGL((render_bwd_kernel<2, false>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      break;
-    case 3:
-      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<3, true>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      else hipLaunchKernelGGL((render_bwd_kernel<3, false>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      break;
-    default: return hipErrorInvalidValue;
-  }
-  hipLaunchKernelGGL(render_vertex_bwd_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, cam, vndc, vnrm, gvrec, gverts, gvcolors);
   return hipGetLastError();
 }
 

@@ -1,0 +1,315 @@
+// Backward of the hard rasteriser + Phong shader (see csrc/render.hip for the pipeline): render_bwd_kernel reads the forward's face ids, recomputes barycentrics and shading, back-propagates to per-vertex
+// records; render_vertex_bwd_kernel folds them into d(verts).  Replaces autograd through PyTorch3D's rasterize_meshes /
+// interpolate_face_attributes / phong_shading / hard_rgb_blend + avg_pool2d (reference models_res_nimble.py:208-211).
+#include "render_common.h"
+
+namespace hifihr {
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flush_face(float* __restrict__ gv, const int* idx, const float* acc) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float* dst = gv + (size_t)idx[k] * 12;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      const float v = acc[k * 12 + c];
+      if (v != 0.f) atomicAdd(dst + c, v);
+    }
+  }
+}
+
+template <int AA, bool UV>
+__global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const float4* __restrict__ frec,
+                                                        const float* __restrict__ light_color,
+                                                        const float* __restrict__ light_dir, const int* __restrict__ face_id,
+                                                        const float* __restrict__ grad_rgba, float* __restrict__ gvrec,
+                                                        float* __restrict__ glight_color, float* __restrict__ glight_dir,
+                                                        int use_lds, TexUvDev tuv
+#ifdef HIFIHR_RENDER_STAMP
+                                                        , int* __restrict__ dbg_tiles
+#endif
+                                                        ) {
+  // use_lds: the per-vertex gradient records of ONE image (V x 12 floats, 37 KB for MANO) are accumulated in LDS with
+  // ds_add_f32 and flushed once per tile with contiguous global atomics.  Scattering one global float atomic per lane
+  // per value instead (64 different rows per wave instruction) ran at ~0.08 TB/s and was 85 % of this kernel's time.
+  HIP_DYNAMIC_SHARED(float, lacc)
+  __shared__ float red[4 * 6];
+  __shared__ int any_hit[4];
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = r.H, S = H * AA;
+  const int px = blockIdx.x * kTile + (lane & 7) + 8 * (wave & 1), py = blockIdx.y * kTile + (lane >> 3) + 8 * (wave >> 1);
+  const bool live = (px < H) && (py < H);
+  // face ids of this lane's samples; tiles without any covered sample leave at once
+  int fid[AA * AA];
+  bool hit = false;
+#pragma unroll
+  for (int i = 0; i < AA; ++i)
+#pragma unroll
+    for (int j = 0; j < AA; ++j) {
+      const int f = live ? face_id[((size_t)b * S + (py * AA + i)) * S + (px * AA + j)] : -1;
+      fid[i * AA + j] = f;
+      hit = hit || (f >= 0);
+    }
+  const unsigned long long hm = __ballot(hit);
+  if (lane == 0) any_hit[wave] = (hm != 0ull);
+  __syncthreads();
+  if (!(any_hit[0] | any_hit[1] | any_hit[2] | any_hit[3])) return;
+#ifdef HIFIHR_RENDER_STAMP
+  const long long bs0 = clock64();
+  long long bs1 = 0, bs2 = 0;
+#endif
+  const int nacc = r.V * 12;
+  if (use_lds) {
+    for (int e = tid; e < nacc; e += 256) lacc[e] = 0.f;
+    __syncthreads();
+  }
+#ifdef HIFIHR_RENDER_STAMP
+  bs1 = clock64();
+#endif
+  float glc[3] = {0.f, 0.f, 0.f}, gl[3] = {0.f, 0.f, 0.f};
+  LightDir Ld;
+  const float raw[3] = {light_dir[3 * b], light_dir[3 * b + 1], light_dir[3 * b + 2]};
+  normalize3(raw, Ld.l, &Ld.inv_norm);
+  if (r.sc.point_light) { Ld.l[0] = raw[0]; Ld.l[1] = raw[1]; Ld.l[2] = raw[2]; }
+  Ld.lc[0] = light_color[3 * b]; Ld.lc[1] = light_color[3 * b + 1]; Ld.lc[2] = light_color[3 * b + 2];
+  if (live) {
+    const size_t plane = (size_t)H * H;
+    const float* g = grad_rgba + (size_t)b * 4 * plane + (size_t)py * H + px;
+    const float inv = (float)(AA * AA);
+    const float g_rgb[3] = {g[0] / inv, g[plane] / inv, g[2 * plane] / inv};
+    const size_t vo = (size_t)b * r.V;
+    float* gv = use_lds ? lacc : gvrec + vo * 12;
+    float acc[36];
+    int cur = -1, cidx[3] = {0, 0, 0};
+    FaceXYZ fc;
+    fc.x0 = fc.y0 = fc.z0 = fc.x1 = fc.y1 = fc.z1 = fc.x2 = fc.y2 = fc.z2 = 0.f;
+    float pos[3][3] = {}, nrm[3][3] = {}, col[3][3] = {};
+#pragma unroll
+    for (int i = 0; i < AA; ++i) {
+      const float syi = pix_to_ndc(S - 1 - (py * AA + i), S);
+#pragma unroll
+      for (int j = 0; j < AA; ++j) {
+        const int f = fid[i * AA + j];
+        if (f < 0) continue;
+        const float sxj = pix_to_ndc(S - 1 - (px * AA + j), S);
+        if (f != cur) {
+          if (cur >= 0) flush_face(gv, cidx, acc);
+          cur = f;
+          cidx[0] = r.faces[3 * f]; cidx[1] = r.faces[3 * f + 1]; cidx[2] = r.faces[3 * f + 2];
+#pragma unroll
+          for (int k = 0; k < 36; ++k) acc[k] = 0.f;
+          // the face's twelve vertex records, once per run of samples on this face: packed by the forward's render_bin_kernel (one level
+          // of indirection, independent 16-byte loads); round 2 re-gathered them through the vertex indices for every sample
+          const float4* q = frec + ((size_t)b * r.F + f) * kFaceRec;
+          const float4 a = q[0], c = q[1], d = q[2];
+          fc.x0 = a.x; fc.y0 = a.y; fc.z0 = a.z; fc.x1 = c.x; fc.y1 = c.y; fc.z1 = c.z; fc.x2 = d.x; fc.y2 = d.y; fc.z2 = d.z;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float4 p = q[3 + k], n = q[6 + k], t = q[9 + k];
+            pos[k][0] = p.x; pos[k][1] = p.y; pos[k][2] = p.z;
+            nrm[k][0] = n.x; nrm[k][1] = n.y; nrm[k][2] = n.z;
+            col[k][0] = t.x; col[k][1] = t.y; col[k][2] = t.z;
+            if constexpr (UV) { col[k][0] = 0.f; col[k][1] = 0.f; col[k][2] = 0.f; }          // TexturesUV: the colour is no function of these
+          }
+        }
+        float bary[3];
+        bary_of(fc, sxj, syi, bary);
+        float P[3], N[3], T[3];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+          P[c3] = bary[0] * pos[0][c3] + bary[1] * pos[1][c3] + bary[2] * pos[2][c3];
+          N[c3] = bary[0] * nrm[0][c3] + bary[1] * nrm[1][c3] + bary[2] * nrm[2][c3];
+          T[c3] = bary[0] * col[0][c3] + bary[1] * col[1][c3] + bary[2] * col[2][c3];
+        }
+        float fu[3] = {0.f, 0.f, 0.f}, fv[3] = {0.f, 0.f, 0.f}, dix[3], diy[3];
+        UvSample q{};
+        if constexpr (UV) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { const int iu = tuv.faces_uvs[3 * f + k]; fu[k] = tuv.verts_uvs[2 * iu]; fv[k] = tuv.verts_uvs[2 * iu + 1]; }
+          const float u = bary[0] * fu[0] + bary[1] * fu[1] + bary[2] * fu[2], v = bary[0] * fv[0] + bary[1] * fv[1] + bary[2] * fv[2];
+          q = uv_sample(u, v, tuv.TH, tuv.TW);
+          uv_fetch(tuv, b, q, T, dix, diy);
+        }
+        float gP[3], gN[3], gT[3];
+        shade_bwd(r.sc, Ld, P, N, T, g_rgb, gP, gN, gT, glc, gl);
+        float guv[2] = {0.f, 0.f};                               // d loss / d (u, v) of this sample
+        if constexpr (UV) {
+          float gix = 0.f, giy = 0.f;
+          const float w00 = (1.f - q.wx) * (1.f - q.wy), w01 = q.wx * (1.f - q.wy), w10 = (1.f - q.wx) * q.wy, w11 = q.wx * q.wy;
+          float* gm = tuv.gmaps != nullptr ? tuv.gmaps + (size_t)b * tuv.TH * tuv.TW * 3 : nullptr;
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {
+            if (gm != nullptr && gT[c3] != 0.f) {
+              atomicAdd(gm + ((size_t)q.y0 * tuv.TW + q.x0) * 3 + c3, gT[c3] * w00); atomicAdd(gm + ((size_t)q.y0 * tuv.TW + q.x1) * 3 + c3, gT[c3] * w01);
+              atomicAdd(gm + ((size_t)q.y1 * tuv.TW + q.x0) * 3 + c3, gT[c3] * w10); atomicAdd(gm + ((size_t)q.y1 * tuv.TW + q.x1) * 3 + c3, gT[c3] * w11);
+            }
+            gix += gT[c3] * dix[c3]; giy += gT[c3] * diy[c3];
+          }
+          guv[0] = q.in_x ? gix * (float)(tuv.TW - 1) : 0.f;     // d ix / d u = TW - 1; zero where grid_sample clipped the coordinate
+          guv[1] = q.in_y ? giy * (float)(tuv.TH - 1) : 0.f;
+        }
+        float gb[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          gb[k] = gP[0] * pos[k][0] + gP[1] * pos[k][1] + gP[2] * pos[k][2] + gN[0] * nrm[k][0] + gN[1] * nrm[k][1] +
+                  gN[2] * nrm[k][2] + gT[0] * col[k][0] + gT[1] * col[k][1] + gT[2] * col[k][2];
+          if constexpr (UV) gb[k] += guv[0] * fu[k] + guv[1] * fv[k];                            // the texel's dependence on the barycentrics
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {
+            acc[k * 12 + 3 + c3] += bary[k] * gP[c3];
+            acc[k * 12 + 6 + c3] += bary[k] * gN[c3];
+            acc[k * 12 + 9 + c3] += bary[k] * gT[c3];
+          }
+        }
+        float gn[9];
+        bary_bwd(fc, sxj, syi, gb, gn);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          acc[k * 12 + 0] += gn[3 * k]; acc[k * 12 + 1] += gn[3 * k + 1]; acc[k * 12 + 2] += gn[3 * k + 2];
+        }
+      }
+    }
+    if (cur >= 0) flush_face(gv, cidx, acc);
+  }
+  if (use_lds) {
+    __syncthreads();
+#ifdef HIFIHR_RENDER_STAMP
+    bs2 = clock64();
+#endif
+    float* gdst = gvrec + (size_t)b * r.V * 12;
+    for (int e = tid; e < nacc; e += 256) {
+      const float v = lacc[e];
+      if (v != 0.f) atomicAdd(gdst + e, v);
+    }
+  }
+  // ---- light gradients: workgroup reduction, one atomic set per tile ----
+  float v6[6] = {glc[0], glc[1], glc[2], gl[0], gl[1], gl[2]};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float s = wsum(v6[k]);
+    if (lane == 0) red[wave * 6 + k] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float t[6];
+    for (int k = 0; k < 6; ++k) t[k] = red[k] + red[6 + k] + red[12 + k] + red[18 + k];
+    if (t[0] != 0.f || t[1] != 0.f || t[2] != 0.f || t[3] != 0.f || t[4] != 0.f || t[5] != 0.f) {
+      for (int k = 0; k < 3; ++k) atomicAdd(glight_color + 3 * b + k, t[k]);
+      float gd[3];
+      normalize3_bwd(raw, Ld.l, Ld.inv_norm, t + 3, gd);       // through F.normalize(direction)
+      for (int k = 0; k < 3; ++k) atomicAdd(glight_dir + 3 * b + k, gd[k]);
+    }
+#ifdef HIFIHR_RENDER_STAMP
+    const long long bs3 = clock64();
+    int* d = dbg_tiles + (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+    d[0] = (int)((bs1 - bs0) >> 6); d[1] = (int)((bs2 - bs1) >> 6); d[2] = (int)((bs3 - bs2) >> 6); d[3] = 1;
+#endif
+  }
+}
+
+// per vertex: fold the per-vertex gradient records into d(verts) (and d(vertex colours))
+__global__ __launch_bounds__(256) void render_vertex_bwd_kernel(RenderDev r, const float* __restrict__ verts,
+                                                               const float* __restrict__ cam, const float4* __restrict__ vndc,
+                                                               const float4* __restrict__ vnrm, const float* __restrict__ gvrec,
+                                                               float* __restrict__ gverts, float* __restrict__ gvcolors) {
+  const int b = blockIdx.y;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= r.V) return;
+  const size_t vo = (size_t)b * r.V;
+  const float* vb = verts + vo * 3;
+  const float* g = gvrec + (vo + v) * 12;
+  const float Z = vb[3 * v + 2];
+  const float fx = cam[4 * b], fy = cam[4 * b + 1], px = cam[4 * b + 2], py = cam[4 * b + 3];
+  const float4 nd = vndc[vo + v];
+  // x = (X fx + Z px) / Z ; y likewise ; z = Z
+  float gx = g[3] + g[0] * fx / Z;
+  float gy = g[4] + g[1] * fy / Z;
+  float gz = g[5] + g[2] + g[0] * (px - nd.x) / Z + g[1] * (py - nd.y) / Z;
+  // vertex normals: n = normalize(sum_f cross(v2 - v1, v0 - v1))
+  for (int e = r.vf_off[v]; e < r.vf_off[v + 1]; ++e) {
+    const int f = r.vf_idx[e] >> 2, role = r.vf_idx[e] & 3;
+    const int id[3] = {r.faces[3 * f], r.faces[3 * f + 1], r.faces[3 * f + 2]};
+    float gfn[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 n = vnrm[vo + id[k]];
+      const float* gk = gvrec + (vo + id[k]) * 12 + 6;
+      const float gn[3] = {gk[0], gk[1], gk[2]};
+      if (n.w < 1.0f / kNormEps) {
+        const float d = n.x * gn[0] + n.y * gn[1] + n.z * gn[2];
+        gfn[0] += (gn[0] - n.x * d) * n.w; gfn[1] += (gn[1] - n.y * d) * n.w; gfn[2] += (gn[2] - n.z * d) * n.w;
+      } else {
+        gfn[0] += gn[0] * n.w; gfn[1] += gn[1] * n.w; gfn[2] += gn[2] * n.w;
+      }
+    }
+    const float* q0 = vb + 3 * id[0];
+    const float* q1 = vb + 3 * id[1];
+    const float* q2 = vb + 3 * id[2];
+    const float A[3] = {q2[0] - q1[0], q2[1] - q1[1], q2[2] - q1[2]};
+    const float Bv[3] = {q0[0] - q1[0], q0[1] - q1[1], q0[2] - q1[2]};
+    // fn = A x Bv :  gA = Bv x gfn ,  gB = gfn x A
+    const float gA[3] = {Bv[1] * gfn[2] - Bv[2] * gfn[1], Bv[2] * gfn[0] - Bv[0] * gfn[2], Bv[0] * gfn[1] - Bv[1] * gfn[0]};
+    const float gB[3] = {gfn[1] * A[2] - gfn[2] * A[1], gfn[2] * A[0] - gfn[0] * A[2], gfn[0] * A[1] - gfn[1] * A[0]};
+    if (role == 0) { gx += gB[0]; gy += gB[1]; gz += gB[2]; }
+    else if (role == 2) { gx += gA[0]; gy += gA[1]; gz += gA[2]; }
+    else { gx -= gA[0] + gB[0]; gy -= gA[1] + gB[1]; gz -= gA[2] + gB[2]; }
+  }
+  float* o = gverts + (vo + v) * 3;
+  o[0] = gx; o[1] = gy; o[2] = gz;
+  if (gvcolors) {
+    float* oc = gvcolors + (vo + v) * 3;
+    oc[0] = g[9]; oc[1] = g[10]; oc[2] = g[11];
+  }
+}
+
+hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float* cam, const float* light_color,
+                             const float* light_dir, const int* face_id, const float* grad_rgba, int B, float* gverts,
+                             float* gvcolors, float* glight_color, float* glight_dir, void* ws, hipStream_t st, const TexUvPass* uv) {
+  float4 *vndc, *vpos, *vnrm, *vcol;
+  float* gvrec;
+#ifdef HIFIHR_RENDER_STAMP
+  int *dbg_cnt, *dbg_list;
+  carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec, &dbg_cnt, &dbg_list);
+#define HIFIHR_BWD_DBG , dbg_list
+#else
+  carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec);
+#define HIFIHR_BWD_DBG
+#endif
+  hipError_t e = hipMemsetAsync(gvrec, 0, (size_t)B * r.V * 12 * sizeof(float), st);
+  if (e != hipSuccess) return e;
+  if (glight_dir == glight_color + (size_t)B * 3) {           // adjacent (hifihr_amd/ops.py allocates them as one tensor): one fill
+    if ((e = hipMemsetAsync(glight_color, 0, (size_t)B * 6 * sizeof(float), st)) != hipSuccess) return e;
+  } else {
+    if ((e = hipMemsetAsync(glight_color, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(glight_dir, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
+  }
+  const int tiles = (r.H + kTile - 1) / kTile;
+  const dim3 grid(tiles, tiles, B);
+  const float4* frec = face_records(r, B, ws);                // written by the forward of the same (handle, workspace, batch)
+  const size_t lds = (size_t)r.V * 12 * sizeof(float);
+  const int use_lds = lds <= 60 * 1024;               // MANO: 37 KB; larger meshes fall back to direct global atomics
+  const size_t dyn = use_lds ? lds : 0;
+  const TexUvDev td = uv != nullptr ? TexUvDev{uv->faces_uvs, uv->verts_uvs, uv->maps, uv->gmaps, uv->TH, uv->TW} : TexUvDev{};
+  switch (r.aa) {
+    case 1:
+      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<1, true>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      else hipLaunchKernelGGL((render_bwd_kernel<1, false>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      break;
+    case 2:
+      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<2, true>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      else hipLaunchKernelGGL((render_bwd_kernel<2, false>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      break;
+    case 3:
+      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<3, true>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      else hipLaunchKernelGGL((render_bwd_kernel<3, false>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
+      break;
+    default: return hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(render_vertex_bwd_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, cam, vndc, vnrm, gvrec, gverts, gvcolors);
+  return hipGetLastError();
+}
+
+}  // namespace hifihr

@@ -20,6 +20,8 @@
 // wino4_math.h.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "bn_fold.h"
 #include "hifihr_internal.h"
 #include "wino4_math.h"
@@ -236,17 +238,21 @@ __global__ __launch_bounds__(256) void wino4_output_transform_bnred_kernel(const
 // the slots back zeroed).  dy = gamma invstd (g - mean g - xhat mean(g xhat)) -- bn_bwd_apply_kernel's expression -- goes straight into
 // V' = B^T dy B (backward-data) and Y' = A dy A^T (backward-weight).
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                                          const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                                          const float* __restrict__ gamma, float* __restrict__ red,
                                                                          float* __restrict__ V, float* __restrict__ Y, int N, int H, int W, int K,
                                                                          int TH, int TW, float* __restrict__ dgamma_acc,
                                                                          float* __restrict__ dbeta_acc) {
+  // T = V4: thread = (tile, 4 channels); T = float: thread = (tile, channel) -- four times the threads with a quarter of the serial
+  // work each (these launches are latency-bound: 130-250 workgroups of 36 loads + 72 stores per lane at T = V4)
+  constexpr int VW = VecWidth<T>::n;
   __shared__ float s_mg[kWbnMaxC], s_mgx[kWbnMaxC];
   const float invM = 1.0f / (float)((long)N * H * W);
   for (int c = threadIdx.x; c < K; c += 256) {
     float sgv, sgx;
-    slot_sum2(red, K, c, sgv, sgx);
+    slot_sum2(red, K, c, sgv, sgx);                        // (fold ~2 us + the election below ~1.5 us of a 16-28 us launch: HIFIHR_DBG_NOFOLD experiment, round 3)
     s_mg[c] = sgv * invM;
     s_mgx[c] = sgx * invM;
     if (blockIdx.x == 0) {
@@ -255,44 +261,42 @@ __global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const 
     }
   }
   __syncthreads();
-  const int K4 = K / 4;
-  const size_t T = (size_t)N * TH * TW, total = T * K4;
+  const int KV = K / VW;
+  const size_t Tn = (size_t)N * TH * TW, total = Tn * KV;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cg = (int)(i % K4);
-    const size_t t = i / K4;
+    const int cg = (int)(i % KV);
+    const size_t t = i / KV;
     const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
-    const V4 mu = ld4(save_mean + cg * 4), is = ld4(save_invstd + cg * 4), ga = ld4(gamma + cg * 4);
-    const V4 k1 = V4{is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w};
-    const V4 mg = ld4(&s_mg[cg * 4]), mgx = ld4(&s_mgx[cg * 4]);
-    V4 tt[6][6];                                            // tt = B^T d, built column by column
-    V4 ty[6][4];                                            // A dy (6 x 4) of the central block
+    const T mu = ldT<T>(save_mean + cg * VW), is = ldT<T>(save_invstd + cg * VW), ga = ldT<T>(gamma + cg * VW);
+    const T k1 = is * ga;
+    const T mg = ldT<T>(&s_mg[cg * VW]), mgx = ldT<T>(&s_mgx[cg * VW]);
+    T tt[6][6];                                             // tt = B^T d, built column by column
+    T ty[6][4];                                             // A dy (6 x 4) of the central block
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const int iw = 4 * tw - 1 + c;
       const bool cok = iw >= 0 && iw < W;
-      V4 col[6], yv[6];
+      T col[6], yv[6];
       bool okr[6];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const int ih = 4 * th - 1 + r;
         okr[r] = cok && ih >= 0 && ih < H;
-        const size_t o = (((size_t)n * H + (okr[r] ? ih : 0)) * W + (okr[r] ? iw : 0)) * K + cg * 4;
-        col[r] = ld4(g + o);
-        yv[r] = ld4(y + o);
+        const size_t o = (((size_t)n * H + (okr[r] ? ih : 0)) * W + (okr[r] ? iw : 0)) * K + cg * VW;
+        col[r] = ldT<T>(g + o);
+        yv[r] = ldT<T>(y + o);
       }
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        const V4 gv = col[r], v = yv[r];
-        const V4 d = V4{k1.x * (gv.x - mg.x - (v.x - mu.x) * is.x * mgx.x), k1.y * (gv.y - mg.y - (v.y - mu.y) * is.y * mgx.y),
-                        k1.z * (gv.z - mg.z - (v.z - mu.z) * is.z * mgx.z), k1.w * (gv.w - mg.w - (v.w - mu.w) * is.w * mgx.w)};
-        col[r] = okr[r] ? d : zero4();
+        const T d = k1 * (col[r] - mg - (yv[r] - mu) * is * mgx);          // bn_bwd_apply_kernel's expression, operation for operation
+        col[r] = okr[r] ? d : zeroT<T>();
       }
-      V4 o[6];
+      T o[6];
       bt6(col, o);
 #pragma unroll
       for (int r = 0; r < 6; ++r) tt[r][c] = o[r];
       if (c >= 1 && c <= 4) {
-        V4 o2[6];
+        T o2[6];
         a4(col + 1, o2);
 #pragma unroll
         for (int r = 0; r < 6; ++r) ty[r][c - 1] = o2[r];
@@ -300,17 +304,17 @@ __global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const 
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      V4 o[6];
+      T o[6];
       bt6(tt[r], o);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) st4(V + ((size_t)(r * 6 + c) * T + t) * K + cg * 4, o[c]);
+      for (int c = 0; c < 6; ++c) stT(V + ((size_t)(r * 6 + c) * Tn + t) * K + cg * VW, o[c]);
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      V4 o[6];
+      T o[6];
       a4(ty[r], o);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) st4(Y + ((size_t)(r * 6 + c) * T + t) * K + cg * 4, o[c]);
+      for (int c = 0; c < 6; ++c) stT(Y + ((size_t)(r * 6 + c) * Tn + t) * K + cg * VW, o[c]);
     }
   }
   unsigned* cnt = stat_bwd_counters(red, K);
@@ -322,6 +326,15 @@ static unsigned wbn_grid(size_t total) {
   if (b > 4096) b = 4096;
   if (b < 1) b = 1;
   return (unsigned)b;
+}
+
+// one channel per thread instead of four while the four-channel form would not even give every SIMD two waves (HIFIHR_WINO_VEC=4 / 1
+// force a form: A/B)
+static bool wbn_scalar(size_t items_v4) {
+  static const int force = [] { const char* e = getenv("HIFIHR_WINO_VEC"); return e ? atoi(e) : 0; }();
+  if (force == 1) return true;
+  if (force == 4) return false;
+  return items_v4 < (size_t)256 * 2048;
 }
 
 bool wino4_bn_supported(int C) { return C >= 4 && C % 4 == 0 && C <= kWbnMaxC; }
@@ -368,8 +381,12 @@ hipError_t launch_wino4_bn_bwd_dual_transform(const float* g, const float* y, co
   if (!wino4_bn_supported(K)) return hipErrorInvalidValue;
   const int TH = (H + 3) / 4, TW = (W + 3) / 4;
   const size_t total = (size_t)N * TH * TW * (K / 4);
-  hipLaunchKernelGGL(wino4_bn_bwd_dual_transform_kernel, dim3(wbn_grid(total)), dim3(256), 0, st, g, y, save_mean, save_invstd, gamma, red, V, Y, N, H,
-                     W, K, TH, TW, dgamma_acc, dbeta_acc);
+  if (wbn_scalar(total))
+    hipLaunchKernelGGL(wino4_bn_bwd_dual_transform_kernel<float>, dim3(wbn_grid(total * 4)), dim3(256), 0, st, g, y, save_mean, save_invstd, gamma,
+                       red, V, Y, N, H, W, K, TH, TW, dgamma_acc, dbeta_acc);
+  else
+    hipLaunchKernelGGL(wino4_bn_bwd_dual_transform_kernel<V4>, dim3(wbn_grid(total)), dim3(256), 0, st, g, y, save_mean, save_invstd, gamma, red,
+                       V, Y, N, H, W, K, TH, TW, dgamma_acc, dbeta_acc);
   return hipGetLastError();
 }
 

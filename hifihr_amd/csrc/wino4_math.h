@@ -18,9 +18,24 @@ __device__ __forceinline__ V4 ld4(const float* p) {
 }
 __device__ __forceinline__ void st4(float* p, const V4& v) { *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ V4 zero4() { return V4{0.f, 0.f, 0.f, 0.f}; }
+// element-type generic access: T = V4 (four consecutive channels per thread) or float (one channel per thread: four times the threads,
+// a quarter of the serial work each -- the small layers' transform launches are latency-bound, not bandwidth-bound)
+template <typename T> __device__ __forceinline__ T ldT(const float* p);
+template <> __device__ __forceinline__ V4 ldT<V4>(const float* p) { return ld4(p); }
+template <> __device__ __forceinline__ float ldT<float>(const float* p) { return *p; }
+__device__ __forceinline__ void stT(float* p, const V4& v) { st4(p, v); }
+__device__ __forceinline__ void stT(float* p, float v) { *p = v; }
+template <typename T> __device__ __forceinline__ T zeroT();
+template <> __device__ __forceinline__ V4 zeroT<V4>() { return zero4(); }
+template <> __device__ __forceinline__ float zeroT<float>() { return 0.f; }
+template <typename T> struct VecWidth;
+template <> struct VecWidth<V4> { static constexpr int n = 4; };
+template <> struct VecWidth<float> { static constexpr int n = 1; };
+__device__ __forceinline__ V4 operator*(const V4& a, const V4& b) { return V4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
 
 // o[6] = B^T x[6]
-__device__ __forceinline__ void bt6(const V4* x, V4* o) {
+template <typename T>
+__device__ __forceinline__ void bt6(const T* x, T* o) {
   o[0] = 4.f * x[0] - 5.f * x[2] + x[4];
   o[1] = x[3] + x[4] - 4.f * (x[1] + x[2]);
   o[2] = 4.f * (x[1] - x[2]) - x[3] + x[4];
@@ -29,28 +44,31 @@ __device__ __forceinline__ void bt6(const V4* x, V4* o) {
   o[5] = 4.f * x[1] - 5.f * x[3] + x[5];
 }
 // o[4] = A^T x[6]
-__device__ __forceinline__ void at6(const V4* x, V4* o) {
-  const V4 s12 = x[1] + x[2], d12 = x[1] - x[2], s34 = x[3] + x[4], d34 = x[3] - x[4];
+template <typename T>
+__device__ __forceinline__ void at6(const T* x, T* o) {
+  const T s12 = x[1] + x[2], d12 = x[1] - x[2], s34 = x[3] + x[4], d34 = x[3] - x[4];
   o[0] = x[0] + s12 + s34;
   o[1] = d12 + 2.f * d34;
   o[2] = s12 + 4.f * s34;
   o[3] = d12 + 8.f * d34 + x[5];
 }
 // o[6] = G x[3]
-__device__ __forceinline__ void g3(const V4* x, V4* o) {
-  const V4 s02 = x[0] + x[2];
+template <typename T>
+__device__ __forceinline__ void g3(const T* x, T* o) {
+  const T s02 = x[0] + x[2];
   o[0] = 0.25f * x[0];
   o[1] = (-1.f / 6.f) * (s02 + x[1]);
   o[2] = (-1.f / 6.f) * (s02 - x[1]);
-  const V4 a = (1.f / 24.f) * x[0] + (1.f / 6.f) * x[2], b = (1.f / 12.f) * x[1];
+  const T a = (1.f / 24.f) * x[0] + (1.f / 6.f) * x[2], b = (1.f / 12.f) * x[1];
   o[3] = a + b;
   o[4] = a - b;
   o[5] = x[2];
 }
 // o[6] = A x[4]   (A = (A^T)^T)
-__device__ __forceinline__ void a4(const V4* x, V4* o) {
-  const V4 s02 = x[0] + x[2], s13 = x[1] + x[3];
-  const V4 e = x[0] + 4.f * x[2], f = 2.f * x[1] + 8.f * x[3];
+template <typename T>
+__device__ __forceinline__ void a4(const T* x, T* o) {
+  const T s02 = x[0] + x[2], s13 = x[1] + x[3];
+  const T e = x[0] + 4.f * x[2], f = 2.f * x[1] + 8.f * x[3];
   o[0] = x[0];
   o[1] = s02 + s13;
   o[2] = s02 - s13;
@@ -59,8 +77,9 @@ __device__ __forceinline__ void a4(const V4* x, V4* o) {
   o[5] = x[3];
 }
 // o[3] = G^T x[6]
-__device__ __forceinline__ void gt6(const V4* x, V4* o) {
-  const V4 s12 = x[1] + x[2], d12 = x[2] - x[1], s34 = x[3] + x[4], d34 = x[3] - x[4];
+template <typename T>
+__device__ __forceinline__ void gt6(const T* x, T* o) {
+  const T s12 = x[1] + x[2], d12 = x[2] - x[1], s34 = x[3] + x[4], d34 = x[3] - x[4];
   o[0] = 0.25f * x[0] + (-1.f / 6.f) * s12 + (1.f / 24.f) * s34;
   o[1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
   o[2] = (-1.f / 6.f) * s12 + (1.f / 6.f) * s34 + x[5];
