@@ -46,7 +46,7 @@ def parse():
                          "stand-in for the unavailable NIMBLE layer in both; not headline lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=-1, help="0: eager; -1 or 1: hipGraph replay (N = 1: whole step; N > 1: forward + backward, then all-reduce + Adam); 2: force the N > 1 form")
-    ap.add_argument("--cpu-batch", type=int, default=16, help="sample size of the CPU baseline (images)")
+    ap.add_argument("--cpu-batch", type=int, default=32, help="sample size of the CPU baseline (images; SURVEY 8d: the batch of 32)")
     ap.add_argument("--cache", type=int, default=256, help="synthetic samples in the device-resident uint8 cache")
     ap.add_argument("--aa", type=int, default=3, help="renderer anti-aliasing factor (config 5 also reports aa = 1)")
     return ap.parse_args()
@@ -72,6 +72,64 @@ def hip_us(fn, n=10, warm=3, groups=3):
     return best
 
 
+def _norm_kernel(name):
+    """'void hifihr::bgemm_tn_kernel<64, 64>(hifihr::BgemmArgs)' -> 'bgemm_tn_kernel<64,64>' (the form csrc's *_describe entry points use)."""
+    n = name.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    depth, cut = 0, len(n)
+    for i, ch in enumerate(n):                      # cut at the argument list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    return n[:cut].replace("hifihr::", "").replace(" ", "")
+
+
+def instep_kernel_times(step_fn, nsteps=3):
+    """Per-kernel device time INSIDE the training step: roctracer (torch.profiler) over `nsteps` eager steps -- every kernel of the step
+    in its real order, with the caches in the state the step leaves them in (a bracket around back-to-back launches of one entry point
+    times warm tables and, for entries that launch helper kernels, more than the kernel).  -> {normalised kernel name: (launches per
+    step, us per step)} or None when the profiler is unavailable."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(nsteps):
+                step_fn()
+            torch.cuda.synchronize()
+        acc = {}
+        for e in prof.events():
+            if e.device_type != torch.autograd.DeviceType.CUDA:
+                continue
+            nm = _norm_kernel(e.name)
+            if not nm or nm.lower().startswith(("memcpy", "memset")) or "Memcpy" in nm or "Memset" in nm:
+                continue
+            dur = getattr(e, "device_time", None)
+            if dur is None:
+                dur = e.cuda_time
+            c, t = acc.get(nm, (0, 0.0))
+            acc[nm] = (c + 1, t + float(dur))
+        return {k: (c / nsteps, t / nsteps) for k, (c, t) in acc.items()} or None
+    except Exception as ex:                          # measurement aid only
+        print(f"[bench] in-step kernel profile unavailable: {type(ex).__name__}: {ex}", file=sys.stderr)
+        return None
+
+
+def instep_lookup(prof, name):
+    """(launches per step, us per step) of every profiled kernel whose normalised name starts with `name` (template arguments included
+    when `name` carries them), or None."""
+    if not prof:
+        return None
+    key = name.replace(" ", "")
+    hits = [(c, t) for k, (c, t) in prof.items() if k == key or k.startswith(key + "<") or k.startswith(key)]
+    if not hits:
+        return None
+    return sum(c for c, _ in hits), sum(t for _, t in hits)
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -82,9 +140,12 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(args_ns, examples, tables, nimg):
+def cpu_baseline(args_ns, examples, tables, nimg, render_frames=8):
     """The oracle training step (oracle/model_oracle.py) on the host cores, on `nimg` images of the same batch: one untimed
-    warm-up step, then whole steps until >= 10 s have been timed (at most 3)."""
+    warm-up step, then three timed steps (B = 32, warm-up + timed iterations, all host cores) -- and the renderer
+    alone (oracle/render_oracle.render: the C rasteriser of oracle/raster_oracle.c + torch shading / resolve), forward and
+    forward + backward, on `render_frames` meshes of the batch, as milliseconds per frame."""
+    from oracle import render_oracle as ro
     from oracle.model_oracle import OracleModel, oracle_step
     torch.manual_seed(0)
     model = OracleModel(tables).train()
@@ -92,14 +153,37 @@ def cpu_baseline(args_ns, examples, tables, nimg):
     ex = {k: (v[:nimg].detach().cpu() if torch.is_tensor(v) else v) for k, v in examples.items()}
     oracle_step(model, ex, args_ns, opt)                   # warm-up (allocator, OpenMP pools, oneDNN primitives)
     t0, nstep = time.time(), 0
-    while nstep < 3 and time.time() - t0 < 10.0:
+    while nstep < 3:
         oracle_step(model, ex, args_ns, opt)
         nstep += 1
     dt = time.time() - t0
-    return {"value": nimg * nstep / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model_name(),
-            "sample": f"1 warm-up + {nstep} timed oracle training step(s) (torch-CPU encoder and heads, oracle MANO LBS, the C rasteriser of "
-                      f"oracle/raster_oracle.c (OpenMP over sample rows, all host threads) + torch shading / losses, torch Adam) on {nimg} images "
-                      f"of the same synthetic batch, {dt:.1f} s timed"}
+    out = {"value": nimg * nstep / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model_name(),
+           "sample": f"1 warm-up + {nstep} timed oracle training steps (torch-CPU encoder and heads, oracle MANO LBS, the C rasteriser of "
+                     f"oracle/raster_oracle.c (OpenMP over sample rows, all host threads) + torch shading / losses, torch Adam) on {nimg} images "
+                     f"of the same synthetic batch, {dt:.1f} s timed"}
+    # the renderer alone, on the ground-truth meshes of the first frames of the batch (camera space, the size the hands have on screen)
+    verts = ex["verts"][:render_frames].float()
+    nf = verts.shape[0]
+    cam = ro.ndc_camera_from_K(ex["Ps"][:nf], 224.0)
+    faces = torch.as_tensor(tables.faces.astype("int64"))
+    col = torch.full_like(verts, 0.7); lc = torch.full((nf, 3), 0.6); ld = torch.tensor([[0.0, 0.0, -1.0]]).repeat(nf, 1)
+
+    def fwd(need_grad):
+        v = verts.clone().requires_grad_(need_grad)
+        return v, ro.render(v, col, cam, lc, ld, faces, image_size=224, aa=3)[0]
+    fwd(False)
+    t0 = time.time()
+    for _ in range(2):
+        fwd(False)
+    t_f = (time.time() - t0) / 2
+    v, img = fwd(True); img.sum().backward()
+    t0 = time.time()
+    for _ in range(2):
+        v, img = fwd(True); img.sum().backward()
+    t_fb = (time.time() - t0) / 2
+    out["render_ms_per_frame"] = {"fwd": t_f / nf * 1e3, "fwd+bwd": t_fb / nf * 1e3, "frames": nf, "image_size": 224, "aa": 3,
+                                  "note": "oracle/render_oracle.render (C rasteriser with OpenMP + torch shading, autograd backward), 1 warm-up + 2 timed calls"}
+    return out
 
 
 def build_cache(model, n, first_index, dev):
@@ -127,10 +211,15 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+_TRAFFIC_OK = True        # main() clears it when the workload is not the one the counter file was measured on (B = 32, res18, config 2)
+
+
 def measured_traffic(kernel_key):
     """HBM bytes per launch from the PMC counters (separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes over this command,
-    tools/kernel_traffic.sh -> profiles/r02_kernel_traffic.json), or None when no measurement of this tree's kernels exists."""
-    f = os.path.join(REPO, "profiles", "r02_kernel_traffic.json")
+    tools/kernel_traffic.sh -> profiles/r03_kernel_traffic.json), or None when no measurement of this tree's kernels exists."""
+    if not _TRAFFIC_OK:
+        return None
+    f = os.path.join(REPO, "profiles", "r03_kernel_traffic.json")
     if not os.path.exists(f):
         return None
     j = json.load(open(f))
@@ -139,7 +228,7 @@ def measured_traffic(kernel_key):
     return j.get("traffic_bytes_per_launch", {}).get(kernel_key)
 
 
-def conv_path_rooflines(ops, lib, dev, nprof):
+def conv_path_rooflines(ops, lib, dev, nprof, prof=None):
     """Every MFMA kernel of the convolution path: each distinct (shape, direction) the profiled steps launched is timed with HIP
     events over 10 back-to-back launches on tensors of that shape and weighted by launches per step.  FLOPs are the ones the kernel
     EXECUTES (Winograd GEMMs: 2 M N K per product).  Returns {kernel name as rocprof lists it: entry}."""
@@ -204,11 +293,22 @@ def conv_path_rooflines(ops, lib, dev, nprof):
             f"{direction} N{N_} {H_}x{W_} C{C_}->K{K_} {R_}x{S_} s{st_}")
     out = {}
     for name, e in table.items():
-        ach = e["flop_per_step"] / (e["us_per_step"] * 1e-6) / 1e12
         n = max(e["launches_per_step"], 1e-9)
+        entry_us = e["us_per_step"]
+        # KERNEL time inside the step (roctracer over eager steps) where the profile has this kernel; the back-to-back bracket around the
+        # C-ABI entry point (which may launch helper kernels: transposes, slab reductions, statistics) is kept beside it as `entry_*`
+        hit = instep_lookup(prof, name)
+        us_step, timing = entry_us, "entry point: HIP events over 10 back-to-back launches per shape (helper kernels of the entry included)"
+        if hit is not None and hit[0] > 0:
+            us_step, timing = hit[1] * (e["launches_per_step"] / hit[0]) if abs(hit[0] - e["launches_per_step"]) > 0.01 else hit[1], \
+                "kernel time inside the step: roctracer (torch.profiler) over 3 eager steps, this kernel's launches only"
+        ach = e["flop_per_step"] / (us_step * 1e-6) / 1e12
         out[name] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF,
                      "traffic": measured_traffic(name), "kernel": name, "launches_per_step": e["launches_per_step"],
-                     "avg_us": e["us_per_step"] / n, "us_per_step": e["us_per_step"], "executed_flop_per_launch": e["flop_per_step"] / n,
+                     "avg_us": us_step / n, "us_per_step": us_step, "timing": timing,
+                     "entry_avg_us": entry_us / n, "entry_us_per_step": entry_us,
+                     "instep_launches_per_step": hit[0] if hit else None,
+                     "executed_flop_per_launch": e["flop_per_step"] / n,
                      "compulsory_bytes_per_launch": e["compulsory_bytes_per_step"] / n, "shapes": e["shapes"]}
     return out
 
@@ -242,6 +342,8 @@ def main():
         args_ns = options.baseline_config5_args(train_batch=a.batch)
     else:
         args_ns = options.baseline_config2_args(train_batch=a.batch)
+    global _TRAFFIC_OK
+    _TRAFFIC_OK = (a.config == 2 and a.encoder == "res18" and a.batch == 32 and a.aa == 3)
     tables = synthetic_mano_tables(0)
     torch.manual_seed(0)
     model = Model(ifRender=True, device=dev, if_4c=False, hand_model="mano", use_mean_shape=False, pretrain=a.encoder,
@@ -301,7 +403,8 @@ def main():
     B = a.batch
     extra = {}
     if rank == 0:
-        roofs = conv_path_rooflines(ops, lib, dev, nprof)
+        kprof = instep_kernel_times(eager_resident, nsteps=3)
+        roofs = conv_path_rooflines(ops, lib, dev, nprof, kprof)
         # ---- the north star's HBM-bound kernels: rasteriser (forward / backward) and MANO LBS, 20 back-to-back launches each
         if ops.PROFILE.last_render is not None:
             h_r, v_r, c_r, cam_r, lc_r, ld_r = ops.PROFILE.last_render
@@ -316,13 +419,20 @@ def main():
             # + RGBA out H^2*16 + face-id side buffer S^2*4;  bwd = side buffer + grad RGBA in + grad verts / colours out
             alg_f = Vn * 12 + Fn * 12 + Vn * 24 + Hr * Hr * 16 + Sr * Sr * 4
             alg_b = Sr * Sr * 4 + Hr * Hr * 16 + Vn * 24
-            for key, us, alg, kname in (("roofline_render_fwd", us_f, alg_f, f"render_fwd_kernel<{h_r.aa}> (+ render_vertex_kernel, render_bin_kernel)"),
-                                        ("roofline_render_bwd", us_b, alg_b, f"render_bwd_kernel<{h_r.aa}> (+ render_vertex_bwd_kernel)")):
+            for key, us, alg, kname, kk in (("roofline_render_fwd", us_f, alg_f, f"render_fwd2_kernel<{h_r.aa}, 8> (+ render_vertex_kernel, render_bin_kernel)", "render_fwd2_kernel"),
+                                            ("roofline_render_bwd", us_b, alg_b, f"render_bwd_kernel<{h_r.aa}> (+ render_vertex_bwd_kernel)", "render_bwd_kernel")):
                 ach = alg * Br / (us * 1e-6) / 1e9
+                hit = instep_lookup(kprof, kk)
                 extra[key] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                               "traffic": measured_traffic(key.replace("roofline_", "")), "kernel": kname, "avg_us": us,
                               "algorithmic_bytes_per_launch": alg * Br,
-                              "timing": "HIP events over 20 back-to-back launches on this batch's meshes (the launch's helper kernels included)"}
+                              "timing": "HIP events over 20 back-to-back launches of the C-ABI entry on this batch's meshes (the launch's helper kernels and "
+                                        "memsets included)"}
+                if hit is not None and hit[0] > 0:
+                    k_us = hit[1] / hit[0]
+                    extra[key]["tile_kernel_in_step"] = {"avg_us": k_us, "achieved": alg * Br / (k_us * 1e-6) / 1e9,
+                                                         "frac": alg * Br / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                         "timing": "the tile kernel alone inside the step (roctracer over 3 eager steps)"}
             extra["render_ms_per_frame"] = {"fwd": us_f / Br / 1e3, "fwd+bwd": (us_f + us_b) / Br / 1e3, "image_size": Hr, "aa": h_r.aa}
         mh = model.hand_layer.handle
         pose = torch.randn(B, 48, device=dev) * 0.5; beta = torch.randn(B, 10, device=dev) * 0.5
@@ -340,13 +450,18 @@ def main():
             "avg_us": us_mf, "algorithmic_bytes_per_launch": alg_mf,
             "backward": {"kernel": "mano_bwd_kernel", "avg_us": us_mb, "algorithmic_bytes_per_launch": alg_mb,
                          "achieved": alg_mb / (us_mb * 1e-6) / 1e9, "frac": alg_mb / (us_mb * 1e-6) / 1e9 / HBM_PEAK_GBS},
+            "in_step": (lambda hf, hb: {"fwd_avg_us": hf[1] / hf[0] if hf and hf[0] else None, "bwd_avg_us": hb[1] / hb[0] if hb and hb[0] else None,
+                                        "fwd_frac": (alg_mf / (hf[1] / hf[0] * 1e-6) / 1e9 / HBM_PEAK_GBS) if hf and hf[0] else None,
+                                        "timing": "kernel time inside the step (roctracer over 3 eager steps): tables cold in L2, unlike the "
+                                                  "back-to-back figure above"})(instep_lookup(kprof, "mano_fwd_kernel"), instep_lookup(kprof, "mano_bwd_kernel")),
             "note": f"B = {B} hands: 1.43 MB of tables + 9.8 KB per hand; a launch this small is latency-bound (one dependent chain per hand: "
                     "PCA -> 16 Rodrigues -> kinematic chain -> blend), the HBM fraction says how little memory it touches, not how slow it moves bytes"}
         if roofs:
             dom = max(roofs.values(), key=lambda e: e["us_per_step"])
-            extra["roofline"] = dict({k: v for k, v in dom.items() if k != "shapes"}, timing="HIP events over 10 back-to-back launches (smallest of 3 such brackets) of every distinct (shape, direction) this kernel ran in "
-                                                 "the step, weighted by launches per step; FLOPs = the products the kernel executes")
-            extra["roofline_kernels"] = {k: {kk: v[kk] for kk in ("achieved", "frac", "launches_per_step", "avg_us", "us_per_step", "traffic", "shapes")}
+            extra["roofline"] = dict({k: v for k, v in dom.items() if k != "shapes"},
+                                     flops="the products the kernel executes (2 M N K per Winograd GEMM), per shape x launches per step")
+            extra["roofline_kernels"] = {k: {kk: v[kk] for kk in ("achieved", "frac", "launches_per_step", "avg_us", "us_per_step", "timing", "entry_avg_us",
+                                                                   "entry_us_per_step", "traffic", "shapes")}
                                          for k, v in roofs.items()}
             tot_f = sum(v["executed_flop_per_launch"] * v["launches_per_step"] for v in roofs.values())
             tot_us = sum(v["us_per_step"] for v in roofs.values())
