@@ -309,9 +309,12 @@ __device__ __forceinline__ void raster_pass2(Fwd2Lds<AA, TILE>& L, int n, int co
       const int cx = x0 + dx, cy = y0 + dy;
       FaceXYZ f;
       f.x0 = q[0]; f.y0 = q[1]; f.x1 = q[2]; f.y1 = q[3]; f.x2 = q[4]; f.y2 = q[5]; f.z0 = q[6]; f.z1 = q[7]; f.z2 = q[8];
-      survive = !square_misses_face(f, L.sxs[cx * AA + AA - 1], L.sxs[cx * AA], L.sys[cy * AA + AA - 1], L.sys[cy * AA]);
-      if (survive) {
-        const float znear = fminf(f.z0, fminf(f.z1, f.z2)) * (1.0f - 1e-5f);
+      // both conservative rejects argue from a face wholly in front of the camera (inside <=> inside the 2-D triangle; depth = a convex
+      // combination of the vertex depths); a face with a vertex at / behind the camera plane skips them (render_math.h sample_face)
+      const float zmin_f = fminf(f.z0, fminf(f.z1, f.z2));
+      survive = zmin_f <= 0.f || !square_misses_face(f, L.sxs[cx * AA + AA - 1], L.sxs[cx * AA], L.sys[cy * AA + AA - 1], L.sys[cy * AA]);
+      if (survive && zmin_f > 0.f) {
+        const float znear = zmin_f * (1.0f - 1e-5f);
         bool behind = true;
 #pragma unroll
         for (int i = 0; i < AA; ++i)

@@ -55,7 +55,7 @@ HIFIHR_HD bool face_is_rejected(const FaceXYZ& f) {
 
 // One sample against one face.  Returns true when the sample is covered; then bary[3] are the
 // perspective-corrected barycentrics and *pz the interpolated depth.  Exactly the sequence of
-// oracle/raster_oracle.c (bbox test, strict w>0 test on the divided barycentrics, pz >= 0).
+// oracle/raster_oracle.c (bbox test, divided and perspective-corrected barycentrics, pz >= 0, strict b > 0).
 HIFIHR_HD bool sample_face(const FaceXYZ& f, float xmin, float xmax, float ymin, float ymax, float px, float py,
                            float* bary, float* pz) {
   if (px > xmax || px < xmin || py > ymax || py < ymin) return false;
@@ -63,11 +63,17 @@ HIFIHR_HD bool sample_face(const FaceXYZ& f, float xmin, float xmax, float ymin,
   const float e0 = edge_fn(px, py, f.x1, f.y1, f.x2, f.y2);
   const float e1 = edge_fn(px, py, f.x2, f.y2, f.x0, f.y0);
   const float e2 = edge_fn(px, py, f.x0, f.y0, f.x1, f.y1);
-  // cheap exact pre-test: e/area > 0 is impossible when e == 0 or sign(e) != sign(area)
-  const bool pos = area > 0.f;
-  if (pos ? (e0 <= 0.f || e1 <= 0.f || e2 <= 0.f) : (e0 >= 0.f || e1 >= 0.f || e2 >= 0.f)) return false;
+  // The inside test is on the perspective-CORRECTED barycentrics b_i = w_i z_j z_k / denom (PyTorch3D CheckPixelInsideFace [recalled];
+  // round 3).  For a face wholly in front of the camera (z0, z1, z2 > 0, denom > 0) b_i > 0 needs w_i = e_i / area > 0, which is
+  // impossible when e_i == 0 or sign(e_i) != sign(area): a cheap exact early-out before the six divisions.  With a vertex at or behind
+  // the camera plane the signs decouple (a sample OUTSIDE the 2-D triangle can have all b_i > 0) and every sample of the bounding box
+  // goes through the full arithmetic.
+  const bool all_front = fminf(f.z0, fminf(f.z1, f.z2)) > 0.f;
+  if (all_front) {
+    const bool pos = area > 0.f;
+    if (pos ? (e0 <= 0.f || e1 <= 0.f || e2 <= 0.f) : (e0 >= 0.f || e1 >= 0.f || e2 >= 0.f)) return false;
+  }
   const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
-  if (!(w0 > 0.f && w1 > 0.f && w2 > 0.f)) return false;
   const float t0 = w0 * f.z1 * f.z2;
   const float t1 = f.z0 * w1 * f.z2;
   const float t2 = f.z0 * f.z1 * w2;
@@ -75,6 +81,7 @@ HIFIHR_HD bool sample_face(const FaceXYZ& f, float xmin, float xmax, float ymin,
   const float b0 = t0 / denom, b1 = t1 / denom, b2 = t2 / denom;
   const float z = b0 * f.z0 + b1 * f.z1 + b2 * f.z2;
   if (z < 0.f) return false;
+  if (!(b0 > 0.f && b1 > 0.f && b2 > 0.f)) return false;
   bary[0] = b0; bary[1] = b1; bary[2] = b2;
   *pz = z;
   return true;

@@ -7,7 +7,7 @@
  * PyTorch3D is a pip dependency of the reference (README.md:70-71, unpinned git HEAD, a 0.7.x snapshot);
  * its source is not under /root/reference, so this file restates its published algorithm from memory:
  * PARITY UNPINNED at the PyTorch3D boundary.  The rule set itself (sample centres, bounding-box test,
- * strict w > 0, perspective correction with the 1e-8 clamp, nearest depth with the lower face index on ties, zero-area and
+ * strict barycentric > 0 on the perspective-corrected weights, perspective correction with the 1e-8 clamp, nearest depth with the lower face index on ties, zero-area and
  * behind-the-plane faces) is pinned by hand-derived known answers: tests/golden/raster_known.json, derived in exact rational
  * arithmetic from the statement of SURVEY.md A12 by tools/make_raster_known.py (not from this file).  It IS the bit-exact target for the
  * HIP rasteriser's face indices: both are built with -ffp-contract=off and evaluate the same fp32
@@ -68,8 +68,6 @@ void raster_oracle(const float* verts_ndc, const int32_t* faces, int B, int V, i
           const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
           const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
           const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
-          /* inside test on the un-corrected barycentrics, strict (blur_radius = 0) */
-          if (!(w0 > 0.0f && w1 > 0.0f && w2 > 0.0f)) continue;
           /* BarycentricPerspectiveCorrectionForward */
           const float t0 = w0 * z1 * z2;
           const float t1 = z0 * w1 * z2;
@@ -78,6 +76,10 @@ void raster_oracle(const float* verts_ndc, const int32_t* faces, int B, int V, i
           const float b0 = t0 / denom, b1 = t1 / denom, b2 = t2 / denom;
           const float pz = b0 * z0 + b1 * z1 + b2 * z2;
           if (pz < 0.0f) continue;
+          /* inside test, strict (blur_radius = 0), on the perspective-CORRECTED barycentrics: PyTorch3D's CheckPixelInsideFace tests
+           * `bary` (= the corrected ones under perspective_correct), not `bary0` [recalled; decided in round 3, DESIGN.md section 5].
+           * Same decisions as the un-corrected test of rounds 1-2 whenever z0, z1, z2 > 0. */
+          if (!(b0 > 0.0f && b1 > 0.0f && b2 > 0.0f)) continue;
           /* faces_per_pixel = 1: keep the nearest; on equal depth the earlier face stays */
           if (best_f < 0 || pz < best_z) {
             best_f = f; best_z = pz; bb0 = b0; bb1 = b1; bb2 = b2;

@@ -22,6 +22,7 @@ import os
 from fractions import Fraction as Fr
 
 EPS = Fr(1, 10 ** 8)
+ALTERNATIVE_RULE = False       # True: the inside test on the UN-corrected barycentrics (rounds 1-2); only cases 6 and 7 depend on it
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "raster_known.json")
 
 
@@ -59,13 +60,22 @@ def rasterise(verts_cam, faces, S, margin_check=True):
                     m = abs(wi)
                     if m > 0 and (margin is None or m < margin):
                         margin = m
-                if not (w[0] > 0 and w[1] > 0 and w[2] > 0):
-                    continue
                 t = [w[0] * z1 * z2, z0 * w[1] * z2, z0 * z1 * w[2]]
                 d = max(t[0] + t[1] + t[2], EPS)
                 bb = [ti / d for ti in t]
                 pz = bb[0] * z0 + bb[1] * z1 + bb[2] * z2
                 if pz < 0:
+                    continue
+                # INSIDE TEST ON THE PERSPECTIVE-CORRECTED BARYCENTRICS (round 3).  PyTorch3D's CheckPixelInsideFace /
+                # RasterizeMeshesNaiveCpu [recalled]: bary0 = BarycentricCoordsForward, bary = perspective_correct ?
+                # BarycentricPerspectiveCorrectionForward(bary0, z) : bary0, pz from bary, `if (pz < 0) continue`, then
+                # `inside = bary.x > 0 && bary.y > 0 && bary.z > 0` -- on `bary`, not `bary0`.  With every z > 0 (a hand in front of the
+                # camera) the two have the same signs and nothing changes; with a vertex behind the camera they do not (cases 6, 7).
+                # Rounds 1-2 tested the un-corrected w (`ALTERNATIVE_RULE` below keeps that reading for the record).
+                if ALTERNATIVE_RULE:
+                    if not (w[0] > 0 and w[1] > 0 and w[2] > 0):
+                        continue
+                elif not (bb[0] > 0 and bb[1] > 0 and bb[2] > 0):
                     continue
                 if best is None or pz < best[1]:
                     best = (f, pz, bb, w)
@@ -141,10 +151,24 @@ def main():
     #    z = (-1, -1, 1): t = (-w0, -w1, w2), denom = max(w2 - w0 - w1, 1e-8), pz = 1 / denom > 0: the whole interior is a hit, with depth
     #    1 / (2 w2 - 1) where w2 > 1/2 and 1e8 elsewhere.
     b2 = [(F(-3, 4) * -1, F(-3, 4) * -1, F(-1)), (F(3, 4) * -1, F(-3, 4) * -1, F(-1)), (F(0), F(3, 4), F(1))]
-    c6 = case("two_vertices_behind_camera", "z = (-1, -1, 1): kept by the zmax rule; interior samples ARE hits (depth 1 / max(2 w2 - 1, 1e-8))",
+    #    The inside test decides: on the perspective-CORRECTED barycentrics (PyTorch3D, built since round 3) two of the three are
+    #    negative over the triangle's interior (b0 = -w0 / denom, b1 = -w1 / denom) -> nothing is drawn; on the un-corrected ones
+    #    (rounds 1-2, ALTERNATIVE_RULE) the interior was a hit.
+    c6 = case("two_vertices_behind_camera", "z = (-1, -1, 1): kept by the zmax rule, but over the triangle's interior two corrected barycentrics are "
+              "negative: nothing is drawn (the un-corrected inside test of rounds 1-2 drew the interior at depth 1 / max(2 w2 - 1, 1e-8))",
               b2, [(0, 1, 2)], 8, 3, picks=[(6, 12), (15, 12)])
-    assert c6["covered"] > 0
+    assert c6["covered"] == (0 if not ALTERNATIVE_RULE else c6["covered"]) and (ALTERNATIVE_RULE or c6["covered"] == 0)
     cases.append(c6)
+    # 7. the other side of the same rule: a thin triangle whose only front vertex v2 lies strictly INSIDE its own bounding box.  In the
+    #    wedge opposite the triangle at v2 (w0 < 0, w1 < 0, w2 > 1) all three corrected barycentrics are positive (t = (-w0, -w1, w2) with
+    #    z = (-1, -1, 1)) and pz = 1 / (w2 - w0 - w1) > 0: PyTorch3D draws the face THERE, outside its 2-D triangle (the artefact its
+    #    z-clipping option exists for), and nowhere inside it.  NDC triangle (-7/8, -3/4), (7/8, 3/4), apex (0, 1/4) between them.
+    b3 = [(F(-7, 8) * -1, F(-3, 4) * -1, F(-1)), (F(7, 8) * -1, F(3, 4) * -1, F(-1)), (F(0), F(1, 4), F(1))]
+    c7 = case("straddling_face_opposite_wedge", "z = (-1, -1, 1), front vertex inside the bounding box: covered samples lie in the wedge beyond "
+              "that vertex (all corrected barycentrics > 0), none inside the 2-D triangle", b3, [(0, 1, 2)], 8, 3, picks=[(4, 11), (12, 12)])
+    if not ALTERNATIVE_RULE:
+        assert c7["covered"] > 0
+    cases.append(c7)
     with open(OUT, "w") as fh:
         json.dump({"rule": "SURVEY.md section 8 A12", "cases": cases}, fh)
     for c in cases:
