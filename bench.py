@@ -44,6 +44,10 @@ def parse():
                     help="2 = BASELINE configs[1] (headline); 3 = configs[2] full_rhd_freihand.json: effb3, batch 48, texture + "
                          "perceptual losses; 5 = configs[4] HO-3D weak supervision, 512^2 render, batch 16 per GPU (MANO + texture "
                          "stand-in for the unavailable NIMBLE layer in both; not headline lines)")
+    ap.add_argument("--hand", default="mano", choices=["mano", "nimble-synthetic", "nimble-synthetic-uv"],
+                    help="configs 3 / 5 only: the hand layer.  mano = MANO + vertex-colour texture stand-in; nimble-synthetic = the NIMBLE-SHAPED layer "
+                         "(5 990 skin vertices / 11 976 faces, 25 joints, 20 / 30 / 10 PCA) on seeded synthetic tables; -uv = its texture as an "
+                         "image sampled through per-face uvs (TexturesUV).  The real NIMBLE tables are absent: parity unpinned, declared")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=-1, help="0: eager; -1 or 1: hipGraph replay (N = 1: whole step; N > 1: forward + backward, then all-reduce + Adam); 2: force the N > 1 form")
     ap.add_argument("--cpu-batch", type=int, default=32, help="sample size of the CPU baseline (images; SURVEY 8d: the batch of 32)")
@@ -193,7 +197,8 @@ def build_cache(model, n, first_index, dev):
     from hifihr_amd.data import FreiHandDeviceCache
     imgs, masks, Ks, joints, verts = [], [], [], [], []
     for lo in range(0, n, 64):
-        s = synth.make_batch(model.hand_layer.handle, model.renderer_p3d, min(64, n - lo), first_index=first_index + lo, device=dev)
+        s = synth.make_batch(getattr(model, "data_mano", None) or model.hand_layer.handle, getattr(model, "data_renderer", None) or model.renderer_p3d,
+                             min(64, n - lo), first_index=first_index + lo, device=dev)
         imgs.append((s["trans_images"].permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8))
         masks.append((s["trans_masks"][:, 0] * 255.0).to(torch.uint8))
         Ks.append(s["trans_Ks"]); joints.append(s["trans_joints"]); verts.append(s["trans_verts"])
@@ -332,22 +337,35 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
     image_size, dat_name = 224, "FreiHand"
+    nimble = a.hand != "mano"
+    assert not nimble or a.config in (3, 5), "--hand nimble-* belongs to configs 3 / 5 (BASELINE configs[2] / [4])"
+    hm = "nimble" if nimble else "mano"
     if a.config == 3:
         a.encoder, a.no_cpu_baseline = "effb3", True
         a.batch = 48 if a.batch == 32 else a.batch
-        args_ns = options.baseline_config3_args(train_batch=a.batch)
+        args_ns = options.baseline_config3_args(train_batch=a.batch, hand_model=hm)
     elif a.config == 5:
         a.encoder, a.no_cpu_baseline, image_size, dat_name = "effb3", True, 512, "HO3D"
         a.batch = 16 if a.batch == 32 else a.batch
-        args_ns = options.baseline_config5_args(train_batch=a.batch)
+        args_ns = options.baseline_config5_args(train_batch=a.batch, hand_model=hm)
     else:
         args_ns = options.baseline_config2_args(train_batch=a.batch)
     global _TRAFFIC_OK
     _TRAFFIC_OK = (a.config == 2 and a.encoder == "res18" and a.batch == 32 and a.aa == 3)
     tables = synthetic_mano_tables(0)
     torch.manual_seed(0)
-    model = Model(ifRender=True, device=dev, if_4c=False, hand_model="mano", use_mean_shape=False, pretrain=a.encoder,
-                  texture_stand_in=10 if a.config in (3, 5) else 0, mano_tables=tables, image_size=image_size, aa_factor=a.aa).to(dev).train()
+    if nimble:
+        from hifihr_amd.nimble_tables import add_synthetic_uv, synthetic_nimble_tables
+        ntab = synthetic_nimble_tables(0)
+        if a.hand.endswith("-uv"):
+            ntab = add_synthetic_uv(ntab)
+        model = Model(ifRender=True, device=dev, if_4c=False, hand_model="nimble", use_mean_shape=False, pretrain=a.encoder,
+                      mano_tables=tables, nimble_tables=ntab, image_size=image_size, aa_factor=a.aa).to(dev).train()
+        model.data_mano = ops.ManoLayerHandle(tables)       # the DATA side stays MANO (FreiHAND / HO-3D ground truth is MANO)
+        model.data_renderer = ops.RendererHandle(tables.faces, 778, image_size=224, aa=3)
+    else:
+        model = Model(ifRender=True, device=dev, if_4c=False, hand_model="mano", use_mean_shape=False, pretrain=a.encoder,
+                      texture_stand_in=10 if a.config in (3, 5) else 0, mano_tables=tables, image_size=image_size, aa_factor=a.aa).to(dev).train()
     flat = FlatParams(model)
     hdist.broadcast_params(flat)
     reducer = hdist.GradReducer(flat, num_buckets=4)
@@ -371,10 +389,10 @@ def main():
         from hifihr_amd.data import HO3DDeviceCache
         # the renderer that draws the synthetic 224 x 224 hands is the bench model's only when that renders at 224
         from hifihr_amd import ops as _ops
-        draw = model.renderer_p3d if image_size == 224 else _ops.RendererHandle(tables.faces, int(tables.v_template.shape[0]), image_size=224, aa=3,
+        draw = model.renderer_p3d if (image_size == 224 and not nimble) else _ops.RendererHandle(tables.faces, int(tables.v_template.shape[0]), image_size=224, aa=3,
                                                                                  ambient=(0.5,) * 3, mat_diffuse=(0.8,) * 3, specular=(0.04,) * 3,
                                                                                  shininess=30.0, background=(1.0,) * 3)
-        ho_cache = HO3DDeviceCache(**synth.make_ho3d_frames(model.hand_layer.handle, draw, a.cache, first_index=rank * a.cache, device=dev), device=dev)
+        ho_cache = HO3DDeviceCache(**synth.make_ho3d_frames(getattr(model, "data_mano", None) or model.hand_layer.handle, draw, a.cache, first_index=rank * a.cache, device=dev), device=dev)
         perm_gen = torch.Generator().manual_seed(100 + rank)
         noise_gen = torch.Generator().manual_seed(300 + rank)
 
@@ -434,7 +452,7 @@ def main():
                                                          "frac": alg * Br / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                                          "timing": "the tile kernel alone inside the step (roctracer over 3 eager steps)"}
             extra["render_ms_per_frame"] = {"fwd": us_f / Br / 1e3, "fwd+bwd": (us_f + us_b) / Br / 1e3, "image_size": Hr, "aa": h_r.aa}
-        mh = model.hand_layer.handle
+        mh = getattr(model, "data_mano", None) or model.hand_layer.handle
         pose = torch.randn(B, 48, device=dev) * 0.5; beta = torch.randn(B, 10, device=dev) * 0.5
         verts = torch.empty(B, 778, 3, device=dev); jtr = torch.empty(B, 21, 3, device=dev); saved = torch.empty(B, 778, 3, device=dev)
         us_mf = hip_us(lambda: lib.mano_lbs_fwd(mh.h, pose, beta, verts, jtr, saved), n=20)
@@ -562,6 +580,12 @@ def main():
                  "weights), MANO + vertex-colour texture stand-in for the unavailable NIMBLE layer [NOT the headline config]",
               5: f"BASELINE configs[4] composition: HO-3D weak supervision (weak_rhd_ho3d.json losses), {image_size}^2 render at aa={a.aa}, batch 16/GPU, "
                  "EfficientNet-b3 on a 224^2 resize of the crop, MANO + texture stand-in for NIMBLE [NOT the headline config]"}[a.config]
+        if nimble:
+            wl = wl.replace("MANO + vertex-colour texture stand-in for the unavailable NIMBLE layer", "the NIMBLE-SHAPED layer on seeded synthetic tables").replace(
+                "MANO + texture stand-in for NIMBLE", "the NIMBLE-SHAPED layer on seeded synthetic tables")
+            wl += (f" [hand layer: {a.hand}: 5 990 skin vertices / 11 976 faces rendered, 25 joints, 20 / 30 / 10 PCA"
+                   + (", TexturesUV sampling of a 64 x 64 texture image" if a.hand.endswith("-uv") else ", per-vertex texture") +
+                   "; synthetic tables -- the real NIMBLE assets are absent, parity unpinned]")
         if a.config == 2 and a.encoder != "res18":
             wl += f" [encoder swapped to {a.encoder}: NOT the headline config]"
         out = {

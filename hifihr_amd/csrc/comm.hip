@@ -28,18 +28,25 @@ struct Rccl {
   char err[256] = {0};
 };
 
+// Resolved once, thread-safely (function-local static initialised by a lambda: C++11 guarantees one initialisation; the round-2
+// version set a plain `tried` flag before the symbols were resolved, so a second thread could see a half-filled table).
+static void rccl_load(Rccl& r);
+Rccl& rccl_table() {
+  static Rccl r = [] { Rccl t; rccl_load(t); return t; }();
+  return r;
+}
 Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r.lib ? &r : nullptr;
-  tried = true;
+  Rccl& r = rccl_table();
+  return r.lib ? &r : nullptr;
+}
+static void rccl_load(Rccl& r) {
   const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {                        // a copy that is already mapped wins (one RCCL per process)
     r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     if (r.lib) break;
   }
   for (int i = 0; !r.lib && i < 3; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-  if (!r.lib) { snprintf(r.err, sizeof(r.err), "librccl not found: %s", dlerror()); return nullptr; }
+  if (!r.lib) { const char* e = dlerror(); snprintf(r.err, sizeof(r.err), "librccl not found: %s", e ? e : "(no dlerror text)"); return; }
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
@@ -47,18 +54,20 @@ Rccl* rccl() {
   r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast) {
-    snprintf(r.err, sizeof(r.err), "librccl lacks an expected symbol");
+    snprintf(r.err, sizeof(r.err), "librccl lacks an expected symbol (ncclGetUniqueId / CommInitRank / CommDestroy / AllReduce / Broadcast)");
+    dlclose(r.lib);
     r.lib = nullptr;
-    return nullptr;
   }
-  return &r;
 }
 
 thread_local char g_comm_err[320];
 int comm_fail(int code, const char* what, ncclResult_t res = ncclSuccess) {
   Rccl* r = rccl();
-  snprintf(g_comm_err, sizeof(g_comm_err), "%s%s%s", what, res != ncclSuccess ? ": " : "",
-           res != ncclSuccess && r && r->GetErrorString ? r->GetErrorString(res) : "");
+  if (r == nullptr)                                      // the library itself is missing / incomplete: say why (dlopen / dlsym text)
+    snprintf(g_comm_err, sizeof(g_comm_err), "%s: %s", what, rccl_table().err);
+  else
+    snprintf(g_comm_err, sizeof(g_comm_err), "%s%s%s", what, res != ncclSuccess ? ": " : "",
+             res != ncclSuccess && r->GetErrorString ? r->GetErrorString(res) : "");
   return code;
 }
 

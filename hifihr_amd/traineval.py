@@ -87,7 +87,7 @@ def data_dic(sample, dat_name, set_name, args, device="cuda", image_size=224):
             ex["keypoint_scale"] = to(sample["keypoint_scale"])
             ex["scales"] = ex["keypoint_scale"]
         if "uv_vis" in sample:
-            ex["uv_vis"] = RHD2Frei(sample["uv_vis"])
+            ex["uv_vis"] = RHD2Frei(to(sample["uv_vis"]))           # on the device like every other entry (a captured step copies them all)
         if "open_2dj" in sample:
             ex["open_2dj"], ex["open_2dj_con"] = to(sample["open_2dj_crop"]), to(sample["open_2dj_con"])
         verts, masks = None, None
