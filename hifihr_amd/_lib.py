@@ -179,6 +179,8 @@ class HifihrLib:
         c.hifihr_wino_output_transform_bnred.argtypes = [_c_float_p] * 10 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_bn_bwd_dual_transform.argtypes = [_c_float_p] * 8 + [c_int] * 5 + [_c_float_p] * 2 + [c_void_p]
         c.hifihr_bn_bwd_apply.argtypes = [_c_float_p] * 5 + [c_long, c_int] + [_c_float_p] * 4 + [c_void_p]
+        c.hifihr_joint_terms_fwd.argtypes = [_c_float_p] * 4 + [c_int] * 3 + [POINTER(c_float), _c_float_p, c_void_p]
+        c.hifihr_joint_terms_bwd.argtypes = [_c_float_p] * 4 + [c_int] * 3 + [POINTER(c_float)] + [_c_float_p] * 3 + [c_void_p]
         c.hifihr_wino_dy_transform_m.argtypes = [_c_float_p] * 2 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_input_dy_transform_m.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_wgrad_parts_m.argtypes = [c_int] * 6
@@ -358,6 +360,17 @@ class HifihrLib:
     @staticmethod
     def _lambda5(lam):
         return (c_float * 5)(*[float(v) for v in lam])
+
+    def joint_terms_fwd(self, j2d, j2d_gt, joints, joints_gt, mse, lam3, out):
+        ref = j2d if j2d is not None else joints
+        self.check(self.c.hifihr_joint_terms_fwd(_fp(j2d), _fp(j2d_gt), _fp(joints), _fp(joints_gt), ref.shape[0], ref.shape[1], int(mse),
+                                                 (c_float * 3)(*[float(v) for v in lam3]), _fp(out), _stream_of(ref)), "hifihr_joint_terms_fwd")
+
+    def joint_terms_bwd(self, j2d, j2d_gt, joints, joints_gt, mse, lam3, gout, g_j2d, g_joints):
+        ref = j2d if j2d is not None else joints
+        self.check(self.c.hifihr_joint_terms_bwd(_fp(j2d), _fp(j2d_gt), _fp(joints), _fp(joints_gt), ref.shape[0], ref.shape[1], int(mse),
+                                                 (c_float * 3)(*[float(v) for v in lam3]), _fp(gout), _fp(g_j2d), _fp(g_joints),
+                                                 _stream_of(ref)), "hifihr_joint_terms_bwd")
 
     def geom_loss_fwd(self, joints, joints_gt, verts, verts_gt, shape, pose, faces, mse, lam, partial, out):
         B, J, V = joints.shape[0], joints.shape[1], verts.shape[1]

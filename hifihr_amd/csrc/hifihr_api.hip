@@ -725,6 +725,23 @@ int hifihr_geom_loss_fwd(const float* joints, const float* joints_gt, const floa
   return HIFIHR_OK;
 }
 
+int hifihr_joint_terms_fwd(const float* j2d, const float* j2d_gt, const float* joints, const float* joints_gt, int B, int J, int mse,
+                           const float* lam3_host, float* out3, void* stream) {
+  if ((!j2d && !joints) || (j2d && !j2d_gt) || (joints && !joints_gt) || !lam3_host || !out3 || B <= 0 || J != 21)
+    return fail(HIFIHR_EINVAL, "hifihr_joint_terms_fwd: bad argument (J must be 21)");
+  HIP_TRY(hifihr::launch_joint_terms_fwd(j2d, j2d_gt, joints, joints_gt, B, J, mse, lam3_host, out3, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_joint_terms_bwd(const float* j2d, const float* j2d_gt, const float* joints, const float* joints_gt, int B, int J, int mse,
+                           const float* lam3_host, const float* gout3, float* g_j2d, float* g_joints, void* stream) {
+  if ((!j2d && !joints) || (j2d && !j2d_gt) || (joints && !joints_gt) || !lam3_host || !gout3 || B <= 0 || J != 21 || (g_j2d && !j2d) ||
+      (g_joints && !joints))
+    return fail(HIFIHR_EINVAL, "hifihr_joint_terms_bwd: bad argument (J must be 21)");
+  HIP_TRY(hifihr::launch_joint_terms_bwd(j2d, j2d_gt, joints, joints_gt, B, J, mse, lam3_host, gout3, g_j2d, g_joints, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_geom_loss_bwd(const float* joints, const float* joints_gt, const float* verts, const float* verts_gt, const float* shape,
                          const float* pose, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_idx, int B, int J, int V,
                          int F, int NS, int NP, int mse, const float* lambda5, const float* gout, float* gj, float* gv, float* gshape,

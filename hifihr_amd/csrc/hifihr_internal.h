@@ -354,4 +354,10 @@ hipError_t launch_texpca_bwd(const float* g, const float* basis, int B, int K, l
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st);
 
+// joint_2d / bone_direc / bone_direc_3d of LossFunction (csrc/losses.hip): J = 21; either the 2-D or the 3-D pair may be NULL
+hipError_t launch_joint_terms_fwd(const float* j2d, const float* j2d_gt, const float* j3d, const float* j3d_gt, int B, int J, int mse,
+                                  const float* lam3, float* out3, hipStream_t st);
+hipError_t launch_joint_terms_bwd(const float* j2d, const float* j2d_gt, const float* j3d, const float* j3d_gt, int B, int J, int mse,
+                                  const float* lam3, const float* gout3, float* g_j2d, float* g_j3d, hipStream_t st);
+
 }  // namespace hifihr

@@ -284,4 +284,126 @@ hipError_t launch_sil_post(const float* rgba, const float* imgs, int B, int HW, 
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The supervised joint terms of the weak-supervision configs (reference losses.py:267-282): joint_2d = base(j2d_gt, j2d),
+// bone_direc = bone_direction_loss(j2d, j2d_gt), bone_direc_3d = bone_direction_loss(joints, joints_gt)
+// (utils/losses_util.py:217-283 with confidence 1: unit bone vectors v / (|v| + 1e-4) of the 20 bones of the 21-joint skeleton, mean over
+// batch and bones of the squared difference).  Round 2 left them to ~25 small ATen launches; one single-workgroup launch per direction
+// (B x 21 joints is a few KB).  out[3] = lambda-weighted terms; backward: g_j2d / g_joints (either may be NULL) from gout[3].
+// ------------------------------------------------------------------------------------------------
+struct JointTermArgs {
+  const float* j2d; const float* j2d_gt; const float* j3d; const float* j3d_gt;
+  int B, J, mse;
+  float lam[3];
+};
+__constant__ unsigned char kBoneParent[20] = {0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 0, 13, 14, 15, 0, 17, 18, 19};
+__constant__ unsigned char kBoneChild[20] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20};
+
+template <int D>
+__device__ __forceinline__ float bone_term(const float* j, const float* jg, int bone, float* dn /* [D] = vn - vgn */, float* inv_len, float* vn_out) {
+  const int p = kBoneParent[bone], c = kBoneChild[bone];
+  float v[D], vg[D], n2 = 0.f, g2 = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) { v[d] = j[c * D + d] - j[p * D + d]; vg[d] = jg[c * D + d] - jg[p * D + d]; n2 += v[d] * v[d]; g2 += vg[d] * vg[d]; }
+  const float n = sqrtf(n2), il = 1.0f / (n + 1e-4f), ig = 1.0f / (sqrtf(g2) + 1e-4f);
+  float t = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) { vn_out[d] = v[d] * il; dn[d] = vn_out[d] - vg[d] * ig; t += dn[d] * dn[d]; }
+  *inv_len = il;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void joint_terms_fwd_kernel(JointTermArgs a, float* __restrict__ out) {
+  __shared__ float lds[3 * 4];
+  float s[3] = {0.f, 0.f, 0.f};
+  if (a.j2d != nullptr) {
+    for (int i = threadIdx.x; i < a.B * a.J * 2; i += 256) s[0] += base_term(a.mse, a.j2d_gt[i] - a.j2d[i]);
+    for (int i = threadIdx.x; i < a.B * 20; i += 256) {
+      const int b = i / 20, bone = i - b * 20;
+      float dn[2], il, vn[2];
+      s[1] += bone_term<2>(a.j2d + (size_t)b * a.J * 2, a.j2d_gt + (size_t)b * a.J * 2, bone, dn, &il, vn);
+    }
+  }
+  if (a.j3d != nullptr) {
+    for (int i = threadIdx.x; i < a.B * 20; i += 256) {
+      const int b = i / 20, bone = i - b * 20;
+      float dn[3], il, vn[3];
+      s[2] += bone_term<3>(a.j3d + (size_t)b * a.J * 3, a.j3d_gt + (size_t)b * a.J * 3, bone, dn, &il, vn);
+    }
+  }
+  block_sum<3>(s, lds);
+  if (threadIdx.x == 0) {
+    out[0] = a.lam[0] * s[0] / (float)(a.B * a.J * 2);
+    out[1] = a.lam[1] * s[1] / (float)(a.B * 20);
+    out[2] = a.lam[2] * s[2] / (float)(a.B * 20);
+  }
+}
+
+// thread = (batch element): its 21 joints' gradients are private to it (no atomics); d/dv of |vn - vgn|^2 with vn = v / (|v| + eps):
+// (2 / (|v| + eps)) (dn - vn (dn . v) / |v|)  (for |v| = 0 the second term vanishes)
+__global__ __launch_bounds__(64) void joint_terms_bwd_kernel(JointTermArgs a, const float* __restrict__ gout, float* __restrict__ g_j2d,
+                                                            float* __restrict__ g_j3d) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  if (g_j2d != nullptr) {
+    float g[21 * 2];
+    const float c0 = gout[0] * a.lam[0] / (float)(a.B * a.J * 2), c1 = gout[1] * a.lam[1] / (float)(a.B * 20);
+    const float* j = a.j2d + (size_t)b * a.J * 2;
+    const float* jg = a.j2d_gt + (size_t)b * a.J * 2;
+    for (int i = 0; i < a.J * 2; ++i) g[i] = -c0 * base_grad(a.mse, jg[i] - j[i]);          // d base(gt - pred) / d pred
+    for (int bone = 0; bone < 20; ++bone) {
+      float dn[2], il, vn[2];
+      bone_term<2>(j, jg, bone, dn, &il, vn);
+      const float dot = dn[0] * vn[0] + dn[1] * vn[1];             // (dn . v) / (|v| + eps)
+      const int p = kBoneParent[bone], c = kBoneChild[bone];
+      float n2 = 0.f;
+      for (int d = 0; d < 2; ++d) { const float vd = j[c * 2 + d] - j[p * 2 + d]; n2 += vd * vd; }
+      const float n = sqrtf(n2);
+      for (int d = 0; d < 2; ++d) {
+        const float vd = j[c * 2 + d] - j[p * 2 + d];
+        const float gv = 2.f * c1 * il * (dn[d] - (n > 0.f ? dot * vd / n : 0.f));
+        g[c * 2 + d] += gv; g[p * 2 + d] -= gv;
+      }
+    }
+    for (int i = 0; i < a.J * 2; ++i) g_j2d[(size_t)b * a.J * 2 + i] = g[i];
+  }
+  if (g_j3d != nullptr) {
+    float g[21 * 3];
+    const float c2 = gout[2] * a.lam[2] / (float)(a.B * 20);
+    const float* j = a.j3d + (size_t)b * a.J * 3;
+    const float* jg = a.j3d_gt + (size_t)b * a.J * 3;
+    for (int i = 0; i < a.J * 3; ++i) g[i] = 0.f;
+    for (int bone = 0; bone < 20; ++bone) {
+      float dn[3], il, vn[3];
+      bone_term<3>(j, jg, bone, dn, &il, vn);
+      const float dot = dn[0] * vn[0] + dn[1] * vn[1] + dn[2] * vn[2];
+      const int p = kBoneParent[bone], c = kBoneChild[bone];
+      float n2 = 0.f;
+      for (int d = 0; d < 3; ++d) { const float vd = j[c * 3 + d] - j[p * 3 + d]; n2 += vd * vd; }
+      const float n = sqrtf(n2);
+      for (int d = 0; d < 3; ++d) {
+        const float vd = j[c * 3 + d] - j[p * 3 + d];
+        const float gv = 2.f * c2 * il * (dn[d] - (n > 0.f ? dot * vd / n : 0.f));
+        g[c * 3 + d] += gv; g[p * 3 + d] -= gv;
+      }
+    }
+    for (int i = 0; i < a.J * 3; ++i) g_j3d[(size_t)b * a.J * 3 + i] = g[i];
+  }
+}
+
+hipError_t launch_joint_terms_fwd(const float* j2d, const float* j2d_gt, const float* j3d, const float* j3d_gt, int B, int J, int mse,
+                                  const float* lam3, float* out3, hipStream_t st) {
+  if (J != 21 || B <= 0) return hipErrorInvalidValue;
+  JointTermArgs a{j2d, j2d_gt, j3d, j3d_gt, B, J, mse, {lam3[0], lam3[1], lam3[2]}};
+  hipLaunchKernelGGL(joint_terms_fwd_kernel, dim3(1), dim3(256), 0, st, a, out3);
+  return hipGetLastError();
+}
+hipError_t launch_joint_terms_bwd(const float* j2d, const float* j2d_gt, const float* j3d, const float* j3d_gt, int B, int J, int mse,
+                                  const float* lam3, const float* gout3, float* g_j2d, float* g_j3d, hipStream_t st) {
+  if (J != 21 || B <= 0) return hipErrorInvalidValue;
+  JointTermArgs a{j2d, j2d_gt, j3d, j3d_gt, B, J, mse, {lam3[0], lam3[1], lam3[2]}};
+  hipLaunchKernelGGL(joint_terms_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, st, a, gout3, g_j2d, g_j3d);
+  return hipGetLastError();
+}
+
 }  // namespace hifihr

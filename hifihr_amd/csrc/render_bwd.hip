@@ -8,33 +8,56 @@ namespace hifihr {
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void flush_face(float* __restrict__ gv, const int* idx, const float* acc) {
+// Per-tile gradient accumulators.  A tile touches a few dozen vertices of the mesh: their 12-float gradient records live in a small
+// open-addressing hash table in LDS (key = vertex index, claimed with atomicCAS on first touch), added to with ds_add_f32 and flushed once
+// per tile with contiguous global atomics.  Round 2 kept a record for EVERY vertex of the mesh in LDS (V x 12 floats = 37 KB for MANO:
+// four workgroups per CU, 37 KB to zero and to scan per tile, and no LDS path at all for a 5 990-vertex skin, whose gradients went
+// out as one global float atomic per lane per value -- 64 rows per wave instruction, ~0.08 TB/s).  A vertex that finds the table
+// full (a tile with more distinct vertices than slots) falls back to global atomics for that record.
+template <int HT>
+struct BwdAcc {
+  int keys[HT];
+  float rec[HT][12];
+};
+template <int HT>
+__device__ __forceinline__ int acc_slot(BwdAcc<HT>& A, int v) {
+  unsigned s = ((unsigned)v * 2654435761u) >> 16;
+#pragma unroll 1
+  for (int probe = 0; probe < 16; ++probe) {
+    s &= (unsigned)(HT - 1);
+    const int old = atomicCAS(&A.keys[s], -1, v);
+    if (old == -1 || old == v) return (int)s;
+    ++s;
+  }
+  return -1;
+}
+template <int HT>
+__device__ __forceinline__ void flush_face(BwdAcc<HT>& A, float* __restrict__ gglobal, const int* idx, const float* acc) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float* dst = gv + (size_t)idx[k] * 12;
+    const int s = acc_slot(A, idx[k]);
+    float* dst = s >= 0 ? A.rec[s] : gglobal + (size_t)idx[k] * 12;
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
       const float v = acc[k * 12 + c];
-      if (v != 0.f) atomicAdd(dst + c, v);
+      if (v != 0.f) atomicAdd(dst + c, v);        // (all of these LDS atomics together: ~50 of the launch's ~140 us -- measured by compiling them out)
     }
   }
 }
 
+// 16 x 16-pixel tiles, one pixel per lane (its AA x AA samples in turn).  Measured alternative (round 3): 8 x 8-pixel tiles with the three
+// sample rows of a pixel on separate lanes (a third of the serial work per lane, four times the tiles in flight, the rows' per-face
+// records combined by shuffles before the LDS atomics): 199 us against 173 for this form at B = 32 -- the kernel is bound by its
+// instruction and LDS-atomic throughput, not by its slowest tile: every row lane gathers and sets up its face again.
 template <int AA, bool UV>
 __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const float4* __restrict__ frec,
                                                         const float* __restrict__ light_color,
                                                         const float* __restrict__ light_dir, const int* __restrict__ face_id,
                                                         const float* __restrict__ grad_rgba, float* __restrict__ gvrec,
                                                         float* __restrict__ glight_color, float* __restrict__ glight_dir,
-                                                        int use_lds, TexUvDev tuv
-#ifdef HIFIHR_RENDER_STAMP
-                                                        , int* __restrict__ dbg_tiles
-#endif
-                                                        ) {
-  // use_lds: the per-vertex gradient records of ONE image (V x 12 floats, 37 KB for MANO) are accumulated in LDS with
-  // ds_add_f32 and flushed once per tile with contiguous global atomics.  Scattering one global float atomic per lane
-  // per value instead (64 different rows per wave instruction) ran at ~0.08 TB/s and was 85 % of this kernel's time.
-  HIP_DYNAMIC_SHARED(float, lacc)
+                                                        TexUvDev tuv) {
+  constexpr int HT = 512;                                  // hash slots: > 2x the distinct vertices of a typical tile (BwdAcc)
+  __shared__ BwdAcc<HT> A;
   __shared__ float red[4 * 6];
   __shared__ int any_hit[4];
   const int b = blockIdx.z;
@@ -57,33 +80,24 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
   if (lane == 0) any_hit[wave] = (hm != 0ull);
   __syncthreads();
   if (!(any_hit[0] | any_hit[1] | any_hit[2] | any_hit[3])) return;
-#ifdef HIFIHR_RENDER_STAMP
-  const long long bs0 = clock64();
-  long long bs1 = 0, bs2 = 0;
-#endif
-  const int nacc = r.V * 12;
-  if (use_lds) {
-    for (int e = tid; e < nacc; e += 256) lacc[e] = 0.f;
-    __syncthreads();
-  }
-#ifdef HIFIHR_RENDER_STAMP
-  bs1 = clock64();
-#endif
+  for (int e = tid; e < HT; e += 256) A.keys[e] = -1;
+  for (int e = tid; e < HT * 12; e += 256) (&A.rec[0][0])[e] = 0.f;
+  __syncthreads();
   float glc[3] = {0.f, 0.f, 0.f}, gl[3] = {0.f, 0.f, 0.f};
   LightDir Ld;
   const float raw[3] = {light_dir[3 * b], light_dir[3 * b + 1], light_dir[3 * b + 2]};
   normalize3(raw, Ld.l, &Ld.inv_norm);
   if (r.sc.point_light) { Ld.l[0] = raw[0]; Ld.l[1] = raw[1]; Ld.l[2] = raw[2]; }
   Ld.lc[0] = light_color[3 * b]; Ld.lc[1] = light_color[3 * b + 1]; Ld.lc[2] = light_color[3 * b + 2];
+  const size_t vo = (size_t)b * r.V;
+  float* gv = gvrec + vo * 12;                               // this image's global records (table overflow, final flush)
+  float acc[36];
+  int cur = -1, cidx[3] = {0, 0, 0};
   if (live) {
     const size_t plane = (size_t)H * H;
     const float* g = grad_rgba + (size_t)b * 4 * plane + (size_t)py * H + px;
     const float inv = (float)(AA * AA);
     const float g_rgb[3] = {g[0] / inv, g[plane] / inv, g[2 * plane] / inv};
-    const size_t vo = (size_t)b * r.V;
-    float* gv = use_lds ? lacc : gvrec + vo * 12;
-    float acc[36];
-    int cur = -1, cidx[3] = {0, 0, 0};
     FaceXYZ fc;
     fc.x0 = fc.y0 = fc.z0 = fc.x1 = fc.y1 = fc.z1 = fc.x2 = fc.y2 = fc.z2 = 0.f;
     float pos[3][3] = {}, nrm[3][3] = {}, col[3][3] = {};
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
         if (f < 0) continue;
         const float sxj = pix_to_ndc(S - 1 - (px * AA + j), S);
         if (f != cur) {
-          if (cur >= 0) flush_face(gv, cidx, acc);
+          if (cur >= 0) flush_face(A, gv, cidx, acc);
           cur = f;
           cidx[0] = r.faces[3 * f]; cidx[1] = r.faces[3 * f + 1]; cidx[2] = r.faces[3 * f + 2];
 #pragma unroll
@@ -172,17 +186,14 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
         }
       }
     }
-    if (cur >= 0) flush_face(gv, cidx, acc);
   }
-  if (use_lds) {
-    __syncthreads();
-#ifdef HIFIHR_RENDER_STAMP
-    bs2 = clock64();
-#endif
-    float* gdst = gvrec + (size_t)b * r.V * 12;
-    for (int e = tid; e < nacc; e += 256) {
-      const float v = lacc[e];
-      if (v != 0.f) atomicAdd(gdst + e, v);
+  if (cur >= 0) flush_face(A, gv, cidx, acc);
+  __syncthreads();
+  for (int e = tid; e < HT * 12; e += 256) {
+    const int key = A.keys[e / 12];
+    if (key >= 0) {
+      const float v = (&A.rec[0][0])[e];
+      if (v != 0.f) atomicAdd(gv + (size_t)key * 12 + (e % 12), v);
     }
   }
   // ---- light gradients: workgroup reduction, one atomic set per tile ----
@@ -202,11 +213,6 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
       normalize3_bwd(raw, Ld.l, Ld.inv_norm, t + 3, gd);       // through F.normalize(direction)
       for (int k = 0; k < 3; ++k) atomicAdd(glight_dir + 3 * b + k, gd[k]);
     }
-#ifdef HIFIHR_RENDER_STAMP
-    const long long bs3 = clock64();
-    int* d = dbg_tiles + (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
-    d[0] = (int)((bs1 - bs0) >> 6); d[1] = (int)((bs2 - bs1) >> 6); d[2] = (int)((bs3 - bs2) >> 6); d[3] = 1;
-#endif
   }
 }
 
@@ -270,14 +276,8 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
                              float* gvcolors, float* glight_color, float* glight_dir, void* ws, hipStream_t st, const TexUvPass* uv) {
   float4 *vndc, *vpos, *vnrm, *vcol;
   float* gvrec;
-#ifdef HIFIHR_RENDER_STAMP
-  int *dbg_cnt, *dbg_list;
-  carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec, &dbg_cnt, &dbg_list);
-#define HIFIHR_BWD_DBG , dbg_list
-#else
   carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec);
-#define HIFIHR_BWD_DBG
-#endif
+  (void)vpos; (void)vcol;
   hipError_t e = hipMemsetAsync(gvrec, 0, (size_t)B * r.V * 12 * sizeof(float), st);
   if (e != hipSuccess) return e;
   if (glight_dir == glight_color + (size_t)B * 3) {           // adjacent (hifihr_amd/ops.py allocates them as one tensor): one fill
@@ -289,25 +289,17 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
   const int tiles = (r.H + kTile - 1) / kTile;
   const dim3 grid(tiles, tiles, B);
   const float4* frec = face_records(r, B, ws);                // written by the forward of the same (handle, workspace, batch)
-  const size_t lds = (size_t)r.V * 12 * sizeof(float);
-  const int use_lds = lds <= 60 * 1024;               // MANO: 37 KB; larger meshes fall back to direct global atomics
-  const size_t dyn = use_lds ? lds : 0;
   const TexUvDev td = uv != nullptr ? TexUvDev{uv->faces_uvs, uv->verts_uvs, uv->maps, uv->gmaps, uv->TH, uv->TW} : TexUvDev{};
+#define HIFIHR_RENDER_BWD(AA_, UV_)                                                                                                      \
+  hipLaunchKernelGGL((render_bwd_kernel<AA_, UV_>), grid, dim3(256), 0, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec,   \
+                     glight_color, glight_dir, td)
   switch (r.aa) {
-    case 1:
-      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<1, true>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      else hipLaunchKernelGGL((render_bwd_kernel<1, false>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      break;
-    case 2:
-      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<2, true>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      else hipLaunchKernelGGL((render_bwd_kernel<2, false>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      break;
-    case 3:
-      if (uv != nullptr) hipLaunchKernelGGL((render_bwd_kernel<3, true>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      else hipLaunchKernelGGL((render_bwd_kernel<3, false>), grid, dim3(256), dyn, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec, glight_color, glight_dir, use_lds, td HIFIHR_BWD_DBG);
-      break;
+    case 1: if (uv != nullptr) { HIFIHR_RENDER_BWD(1, true); } else { HIFIHR_RENDER_BWD(1, false); } break;
+    case 2: if (uv != nullptr) { HIFIHR_RENDER_BWD(2, true); } else { HIFIHR_RENDER_BWD(2, false); } break;
+    case 3: if (uv != nullptr) { HIFIHR_RENDER_BWD(3, true); } else { HIFIHR_RENDER_BWD(3, false); } break;
     default: return hipErrorInvalidValue;
   }
+#undef HIFIHR_RENDER_BWD
   hipLaunchKernelGGL(render_vertex_bwd_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, cam, vndc, vnrm, gvrec, gverts, gvcolors);
   return hipGetLastError();
 }

@@ -3,8 +3,8 @@
 
 ONE path: the step's terms run as fused HIP kernels -- SSIM (csrc/ssim.hip), the photometric block and the joint / vertex /
 edge-length / shape / pose terms (csrc/losses.hip: two launches per group instead of ~250 ATen launches) -- on GPU tensors; a CPU
-tensor raises (no fallback).  The rarely used terms (joint_2d, bone_direc, mscale, scale, iou, mtex and the self-supervised
-`*_self` terms) are a handful of torch ops on the same GPU tensors.  The torch restatement of the whole function that the tests
+tensor raises (no fallback).  joint_2d / bone_direc / bone_direc_3d: one more kernel pair (round 3).  The rarely used terms (mscale, scale,
+iou, mtex and the self-supervised `*_self` terms) are a handful of torch ops on the same GPU tensors.  The torch restatement of the whole function that the tests
 compare against is oracle/loss_oracle.py (pinned by the reference's own LossFunction.__call__, tests/golden/loss_dict.npz).
 """
 from __future__ import annotations
@@ -83,12 +83,17 @@ class LossFunction:
         if any(k in loss_used for k in ("joint_3d", "vert_3d", "edge_length", "mshape", "mpose")):
             self._fused_geometry(examples, outputs, loss_used, args, loss_dic)
             loss_used = [k for k in loss_used if k not in loss_dic]
-        if "joint_2d" in loss_used:
-            loss_dic["joint_2d"] = args.lambda_j2d_gt * base(examples["j2d_gt"], outputs["j2d"])
-        if "bone_direc" in loss_used:
-            loss_dic["bone_direc"] = args.lambda_bone_direc * bone_direction_loss(outputs["j2d"], examples["j2d_gt"])
-        if "bone_direc_3d" in loss_used:
-            loss_dic["bone_direc_3d"] = args.lambda_bone_direc_3d * bone_direction_loss(outputs["joints"], examples["joints"])
+        want = [k in loss_used for k in ("joint_2d", "bone_direc", "bone_direc_3d")]
+        if any(want):
+            # one kernel pair for the three supervised joint terms (csrc/losses.hip joint_terms_*; 21-joint skeleton)
+            two, three = want[0] or want[1], want[2]
+            lam3 = (args.lambda_j2d_gt if want[0] else 0.0, args.lambda_bone_direc if want[1] else 0.0, args.lambda_bone_direc_3d if want[2] else 0.0)
+            vals = ops.joint_terms(outputs["j2d"] if two else None, examples["j2d_gt"] if two else None,
+                                   outputs["joints"] if three else None, examples["joints"] if three else None,
+                                   args.base_loss_fn != "L1", lam3).unbind(0)
+            for k, w, v in zip(("joint_2d", "bone_direc", "bone_direc_3d"), want, vals):
+                if w:
+                    loss_dic[k] = v
         if "mscale" in loss_used:
             bl = torch.sqrt(torch.sum((outputs["joints"][:, 9] - outputs["joints"][:, 10]) ** 2, 1))
             loss_dic["mscale"] = args.lambda_mscale * F.l1_loss(bl, torch.ones_like(bl) * 0.0282)

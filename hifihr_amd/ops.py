@@ -1229,6 +1229,37 @@ def geom_losses(joints, joints_gt, verts, verts_gt, shape, pose, faces, mse, lam
     return _GeomLoss.apply(joints, joints_gt, verts, verts_gt, shape, pose, faces, bool(mse), tuple(float(v) for v in lam))
 
 
+class _JointTerms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, j2d, j2d_gt, joints, joints_gt, mse, lam3):
+        lib = get_lib()
+        prep = lambda t: t.contiguous().float() if t is not None else None
+        j2d, j2d_gt, joints, joints_gt = prep(j2d), prep(j2d_gt), prep(joints), prep(joints_gt)
+        require_cuda(*(t for t in (j2d, joints) if t is not None))
+        ref = j2d if j2d is not None else joints
+        out = torch.empty(3, device=ref.device)
+        PROFILE.bracket("joint_terms_fwd", lambda: lib.joint_terms_fwd(j2d, j2d_gt, joints, joints_gt, mse, lam3, out))
+        ctx.save_for_backward(*(t if t is not None else ref.new_empty(0) for t in (j2d, j2d_gt, joints, joints_gt)))
+        ctx.has2, ctx.has3, ctx.mse, ctx.lam3 = j2d is not None, joints is not None, mse, lam3
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        j2d, j2d_gt, joints, joints_gt = (t if t.numel() else None for t in ctx.saved_tensors)
+        lib = get_lib()
+        g2 = torch.empty_like(j2d) if (ctx.has2 and ctx.needs_input_grad[0]) else None
+        g3 = torch.empty_like(joints) if (ctx.has3 and ctx.needs_input_grad[2]) else None
+        if g2 is not None or g3 is not None:
+            PROFILE.bracket("joint_terms_bwd", lambda: lib.joint_terms_bwd(j2d, j2d_gt, joints, joints_gt, ctx.mse, ctx.lam3, gout.contiguous(), g2, g3))
+        return g2, None, g3, None, None, None
+
+
+def joint_terms(j2d, j2d_gt, joints, joints_gt, mse, lam3):
+    """[3] = lambda-weighted (joint_2d, bone_direc, bone_direc_3d) of reference losses.py:267-282 in one launch (csrc/losses.hip);
+    (j2d, j2d_gt) [B,21,2] or (None, None), (joints, joints_gt) [B,21,3] or (None, None); lam3 = the three lambdas (0 = unused)."""
+    return _JointTerms.apply(j2d, j2d_gt, joints, joints_gt, bool(mse), tuple(float(v) for v in lam3))
+
+
 class _PhotoLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgba, imgs, seg, l_tex, l_mrgb, l_sil):

@@ -531,6 +531,15 @@ int hifihr_ssim_bwd_scaled(const float* window11_h, const float* img1_d, const f
 int hifihr_geom_loss_fwd(const float* joints_d, const float* joints_gt_d, const float* verts_d, const float* verts_gt_d,
                          const float* shape_d, const float* pose_d, const int32_t* faces_d, int B, int J, int V, int F, int NS,
                          int NP, int mse, const float* lambda5_h, float* partial_d, float* out_d, void* stream);
+/* joint_2d, bone_direc, bone_direc_3d of LossFunction.__call__ (reference losses.py:267-282; bone_direction_loss of
+ * utils/losses_util.py:217-283 with confidence 1) in ONE launch per direction: j2d / j2d_gt [B][21][2] (or both NULL), joints /
+ * joints_gt [B][21][3] (or both NULL); lam3_host = (lambda_j2d_gt, lambda_bone_direc, lambda_bone_direc_3d), host memory; out3_d =
+ * the three lambda-weighted terms (a term whose inputs are NULL is 0).  bwd: g_j2d_d / g_joints_d (either may be NULL) = gradient of
+ * sum_k gout3_d[k] out3[k]. */
+int hifihr_joint_terms_fwd(const float* j2d_d, const float* j2d_gt_d, const float* joints_d, const float* joints_gt_d, int B, int J, int mse,
+                           const float* lam3_host, float* out3_d, void* stream);
+int hifihr_joint_terms_bwd(const float* j2d_d, const float* j2d_gt_d, const float* joints_d, const float* joints_gt_d, int B, int J, int mse,
+                           const float* lam3_host, const float* gout3_d, float* g_j2d_d, float* g_joints_d, void* stream);
 int hifihr_geom_loss_bwd(const float* joints_d, const float* joints_gt_d, const float* verts_d, const float* verts_gt_d,
                          const float* shape_d, const float* pose_d, const int32_t* faces_d, const int32_t* vf_off_d,
                          const int32_t* vf_idx_d, int B, int J, int V, int F, int NS, int NP, int mse, const float* lambda5_h,

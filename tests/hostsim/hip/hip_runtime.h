@@ -152,6 +152,10 @@ static inline unsigned long long atomicMin(unsigned long long* p, unsigned long 
   while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return old;
 }
+static inline int atomicCAS(int* p, int expected, int desired) {
+  __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+  return expected;                                   // the value found (== the old `expected` on success)
+}
 static inline int atomicMax(int* p, int v) {
   int old = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}

@@ -1485,3 +1485,36 @@ def wino_bn_bwd_case(lib, device, N, H, W, C, residual, addend, seed=0):
     assert float(red_keep[:32 * 4 * C + 64].abs().max()) == 0.0
     assert torch.equal(V1, V0) and torch.equal(Y1, Y0), (float((V1 - V0).abs().max()), float((Y1 - Y0).abs().max()))
     assert torch.equal(dg2, dg1) and torch.equal(db2, db1)
+
+
+# ------------------------------------------------------------------------------------------------
+# joint_2d / bone_direc / bone_direc_3d (csrc/losses.hip joint_terms_*) vs the torch restatement pinned by tests/golden/losses.npz
+# ------------------------------------------------------------------------------------------------
+def joint_terms_case(lib, device, B, mse, seed=0, use2=True, use3=True):
+    import torch.nn.functional as F
+    from oracle.loss_oracle import bone_direction_loss
+    gen = torch.Generator().manual_seed(seed)
+    j2d = (torch.rand(B, 21, 2, generator=gen) * 224).requires_grad_(True); j2d_gt = torch.rand(B, 21, 2, generator=gen) * 224
+    j3d = (torch.randn(B, 21, 3, generator=gen) * 0.05).requires_grad_(True); j3d_gt = torch.randn(B, 21, 3, generator=gen) * 0.05
+    lam = (0.7, 1.3, 2.1)
+    base = F.mse_loss if mse else F.l1_loss
+    one = torch.ones(B, 21, 1)
+    ref = [lam[0] * base(j2d_gt, j2d), lam[1] * bone_direction_loss(j2d, j2d_gt, one), lam[2] * bone_direction_loss(j3d, j3d_gt, one)]
+    w = torch.tensor([0.9, -1.1, 0.6])
+    tot = sum(wi * r for wi, r, u in zip(w, ref, (use2, use2, use3)) if u)
+    tot.backward()
+    d = lambda t: t.detach().to(device).contiguous()
+    out = torch.empty(3, device=device)
+    a2 = (d(j2d), d(j2d_gt)) if use2 else (None, None)
+    a3 = (d(j3d), d(j3d_gt)) if use3 else (None, None)
+    lib.joint_terms_fwd(a2[0], a2[1], a3[0], a3[1], mse, lam, out)
+    for k, u in enumerate((use2, use2, use3)):
+        want = float(ref[k]) if u else 0.0
+        assert abs(float(out[k]) - want) <= 2e-5 * max(1.0, abs(want)), (k, float(out[k]), want)
+    g2 = torch.full((B, 21, 2), 7.0, device=device) if use2 else None
+    g3 = torch.full((B, 21, 3), 7.0, device=device) if use3 else None
+    lib.joint_terms_bwd(a2[0], a2[1], a3[0], a3[1], mse, lam, d(w), g2, g3)
+    if use2:
+        assert float((g2.cpu() - j2d.grad).abs().max()) <= 1e-5 * float(j2d.grad.abs().max()) + 1e-9
+    if use3:
+        assert float((g3.cpu() - j3d.grad).abs().max()) <= 1e-5 * float(j3d.grad.abs().max()) + 1e-9

@@ -18,3 +18,8 @@ def test_geom_losses(hostsim_lib, B, V, F, mse):
 @pytest.mark.parametrize("B,H,W,with_g", [(2, 16, 16, True), (3, 12, 20, False), (1, 4, 4, True)])
 def test_photo_losses(hostsim_lib, B, H, W, with_g):
     kc.photo_loss_case(hostsim_lib, "cpu", B, H, W, seed=H * W, with_g=with_g)
+
+
+@pytest.mark.parametrize("B,mse,use2,use3", [(3, False, True, True), (48, True, True, False), (2, False, False, True)])
+def test_joint_terms(hostsim_lib, B, mse, use2, use3):
+    kc.joint_terms_case(hostsim_lib, "cpu", B, mse, seed=B, use2=use2, use3=use3)
