@@ -49,7 +49,9 @@ def parse():
                          "(5 990 skin vertices / 11 976 faces, 25 joints, 20 / 30 / 10 PCA) on seeded synthetic tables; -uv = its texture as an "
                          "image sampled through per-face uvs (TexturesUV).  The real NIMBLE tables are absent: parity unpinned, declared")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=-1, help="0: eager; -1 or 1: hipGraph replay (N = 1: whole step; N > 1: forward + backward, then all-reduce + Adam); 2: force the N > 1 form")
+    ap.add_argument("--graph", type=int, default=-1, help="0: eager; -1 or 1: hipGraph replay (N = 1: whole step; N > 1: the fastest of the data-parallel forms in a "
+                    "short trial); 2: force the N > 1 form (one graph, then all-reduce + Adam); 3: force the segmented form (backward as one graph "
+                    "launch per trunk segment, each bucket exchanged beside the next segment)")
     ap.add_argument("--cpu-batch", type=int, default=32, help="sample size of the CPU baseline (images; SURVEY 8d: the batch of 32)")
     ap.add_argument("--cache", type=int, default=256, help="synthetic samples in the device-resident uint8 cache")
     ap.add_argument("--aa", type=int, default=3, help="renderer anti-aliasing factor (config 5 also reports aa = 1)")
@@ -489,13 +491,19 @@ def main():
 
     # ---- the step forms
     use_graph = a.graph != 0
-    split = world > 1 or a.graph == 2        # data parallel: graph = forward + backward, then all-reduce + Adam eagerly
+    split = world > 1 or a.graph in (2, 3)   # data parallel: graph = forward + backward, then all-reduce + Adam eagerly
     graph_note, gstep = "eager", None
+    seg_step = None
     if use_graph:
         try:
-            gstep = GraphedTrainStep(model, loss_func, opt, examples, args_ns, dat_name=dat_name, reducer=reducer if split else None)
-            graph_note = ("hipGraph replay of forward + backward, then bucketed all-reduce + fused Adam" if split
-                          else "hipGraph replay (whole step captured)")
+            if a.graph == 3:
+                from hifihr_amd.traineval import SegmentedGraphedTrainStep
+                gstep = SegmentedGraphedTrainStep(model, loss_func, opt, examples, args_ns, reducer, dat_name=dat_name)
+                graph_note = "hipGraph replays: forward, then one backward graph per trunk segment with that segment's bucket all-reduced beside the next, fused Adam"
+            else:
+                gstep = GraphedTrainStep(model, loss_func, opt, examples, args_ns, dat_name=dat_name, reducer=reducer if split else None)
+                graph_note = ("hipGraph replay of forward + backward, then bucketed all-reduce + fused Adam" if split
+                              else "hipGraph replay (whole step captured)")
         except Exception as e:                          # capture is an optimisation; never fail the bench on it (state is restored)
             graph_note = f"eager (hipGraph capture failed: {type(e).__name__}: {str(e)[:200]})"
             torch.cuda.synchronize()
@@ -537,6 +545,24 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item()) / n
         t_graph = timed(step_streamed)
+        # third candidate: the segmented form (ResNet trunks), whose exchange overlaps backward under graph replays
+        t_seg = None
+        try:
+            from hifihr_amd.traineval import SegmentedGraphedTrainStep
+            gstep.release()
+            seg_step = SegmentedGraphedTrainStep(model, loss_func, opt, examples, args_ns, reducer, dat_name=dat_name)
+            whole_step, gstep = gstep, seg_step
+            t_seg = timed(step_streamed)
+            if t_seg < t_graph:
+                graph_note = (f"hipGraph replays, backward in one graph launch per trunk segment with its bucket all-reduced beside the next (chosen over the "
+                              f"single-graph form: {t_seg * 1e3:.2f} vs {t_graph * 1e3:.2f} ms/step in a 3-step trial)")
+                t_graph = t_seg
+            else:
+                seg_step.release()
+                gstep = whole_step
+                reducer.pause_hooks(True)
+        except Exception as e:                       # noqa: BLE001 -- other encoders: the single-graph form stays
+            seg_step = None
         reducer.pause_hooks(False)
         t_eager = timed(eager_streamed)
         if t_eager < t_graph:

@@ -131,6 +131,17 @@ class GradReducer:
         self._paused = paused
         self.reset()
 
+    def all_reduce_params_async(self, lo: int, hi: int):
+        """SUM all-reduce of the gradients of parameters [lo, hi) (registration order: one contiguous slice of the flat buffer),
+        asynchronous: the collective is ordered behind everything enqueued on the current stream so far and runs beside what is
+        enqueued after it (traineval.SegmentedGraphedTrainStep launches the next backward segment meanwhile).  -> handle or None."""
+        if self.world <= 1 or hi <= lo:
+            return None
+        n = len(self.flat.params)
+        e_lo = self.flat.offsets[lo]
+        e_hi = self.flat.offsets[hi] if hi < n else self.flat.numel
+        return dist.all_reduce(self.flat.grad[e_lo:e_hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def all_reduce_flat(self):
         """SUM all-reduce of the whole flat gradient buffer, one asynchronous call per bucket (pipelined), then wait."""
         if self.world > 1:

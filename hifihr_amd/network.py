@@ -206,7 +206,15 @@ class Resnet_4C(nn.Module):
         x = ops.bn_relu_maxpool(h, st, m.bn1)
         x = m.layer1(x)
         x_low = _resolve(m.layer2(x))
-        x = _resolve(m.layer4(m.layer3(x_low)))
+        cut = getattr(self, "segment_cut", None)
+        if cut is None:
+            x = _resolve(m.layer4(m.layer3(x_low)))
+            return x_low, x
+        # segmented backward (traineval.SegmentedGraphedTrainStep): the autograd graph is cut at the layer boundaries, so that the
+        # backward of each segment is a graph launch of its own and its gradient bucket can be exchanged while the next one runs
+        x_low = cut("layer2", x_low)
+        x3 = cut("layer3", _resolve(m.layer3(x_low)))
+        x = cut("layer4", _resolve(m.layer4(x3)))
         return x_low, x
 
 

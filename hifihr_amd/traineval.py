@@ -244,3 +244,149 @@ class GraphedTrainStep:
             self.opt.prepare_step()
             self.graph.replay()
         return self.loss, self.loss_dic
+
+
+class SegmentedGraphedTrainStep:
+    """Data-parallel step whose gradient exchange OVERLAPS backward although every launch is a graph replay (round 3; review item 8).
+
+    The autograd graph of the ResNet trunk is cut at the layer boundaries (network.Resnet_4C.segment_cut: the boundary tensor is
+    detached and re-enters as a leaf), which makes backward a sequence of independent calls -- loss.backward() stops at the layer-4
+    output, layer4_out.backward(grad) at the layer-3 output, ... -- and each call is captured into a hipGraph of its own (one shared
+    memory pool).  A step is then: replay forward; replay backward segment k; enqueue the all-reduce of the parameters segment k
+    completed (RCCL runs it on its own stream, ordered behind the replay just enqueued); replay segment k - 1 meanwhile; ...; wait;
+    fused Adam.  Graph BRANCHES were measured to cost more than they hide on this runtime: the overlap comes
+    from separate launches, no collective is captured.
+
+    Segments (parameters in registration order): [mmpool .. layer2] (exchanged last), [layer3], [layer4], [heads: hand encoder, light
+    estimator] (first).  Same arithmetic as GraphedTrainStep(reducer=...): the kernels and their order inside a segment are unchanged
+    (only layer3 -> layer4 hands its output over materialised instead of un-normalised)."""
+
+    def __init__(self, model, loss_func, optimizer, examples, args, reducer, dat_name="FreiHand", warmup=3):
+        enc = getattr(getattr(model, "base_encoder", None), "encoder1", None)
+        if enc is None or not hasattr(enc, "model") or not hasattr(enc.model, "layer3"):
+            raise NotImplementedError("segmented backward is built for the ResNet trunks")
+        self.model, self.loss_func, self.opt, self.args, self.dat_name, self.reducer = model, loss_func, optimizer, args, dat_name, reducer
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in examples.items()}
+        flat = optimizer.flatp
+        idx = {id(p): i for i, p in enumerate(flat.params)}
+
+        def span(mods):
+            ids = [idx[id(p)] for m in mods for p in m.parameters() if id(p) in idx]
+            return (min(ids), max(ids) + 1) if ids else (0, 0)
+        trunk = enc.model
+        lo3, hi3 = span([trunk.layer3])
+        lo4, hi4 = span([trunk.layer4])
+        n = len(flat.params)
+        # exchanged after segment:     heads            layer4       layer3       stem .. layer2 (+ whatever precedes it in the buffer)
+        self.ranges = [(hi4, n), (lo4, hi4), (lo3, hi3), (0, lo3)]
+        assert 0 < lo3 <= hi3 == lo4 <= hi4 <= n, (lo3, hi3, lo4, hi4, n)
+        snap = (flat.flat.clone(), optimizer.exp_avg.clone(), optimizer.exp_avg_sq.clone(), optimizer.step_count,
+                [b.clone() for b in model.buffers()])
+        reducer.pause_hooks(True)
+        self._enc = enc
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._eager_segmented()
+                    reducer.all_reduce_flat()
+                    optimizer.step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            pool = torch.cuda.graph_pool_handle()
+            self.graphs = []
+            stages = self._stages()
+            for stage in stages:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    stage()
+                self.graphs.append(g)
+        except BaseException:
+            reducer.pause_hooks(False)
+            enc.segment_cut = None
+            self._restore(snap)
+            raise
+        enc.segment_cut = None
+        self._restore(snap)
+
+    # -- the step as five callables: forward (+ zero_grad), then the four backward segments; state shared through self._b
+    def _stages(self):
+        from .ops import _WEIGHT_PREP, prepared_weights
+
+        def fwd():
+            self._b = {}
+
+            def cut(name, t):
+                leaf = t.detach().requires_grad_(True)
+                self._b[name] = (t, leaf)
+                return leaf
+            self._enc.segment_cut = cut
+            # the weight re-layout scope spans all five stages: entered here, left after the last backward segment
+            self._scope = prepared_weights(async_wgrad=False)
+            self._scope.__enter__()
+            root_xyz = self.static["joints"][:, self.args.ROOT, :].unsqueeze(1)
+            self.loss, self.loss_dic = _forward_only(self.model, self.loss_func, self.opt, self.static, self.args, self.dat_name, root_xyz)
+
+        def bwd_heads():
+            self.loss.backward()
+
+        def bwd(name):
+            def run():
+                t, leaf = self._b[name]
+                t.backward(leaf.grad)
+            return run
+
+        def bwd_last():
+            bwd("layer2")()
+            self._scope.__exit__(None, None, None)
+        return [fwd, bwd_heads, bwd("layer4"), bwd("layer3"), bwd_last]
+
+    def _eager_segmented(self):
+        for stage in self._stages():
+            stage()
+
+    def _restore(self, snap):
+        GraphedTrainStep._restore(self, snap)
+
+    def release(self):
+        self.reducer.pause_hooks(False)
+
+    def load_batch(self, examples):
+        for k, v in examples.items():
+            if torch.is_tensor(v):
+                self.static[k].copy_(v, non_blocking=True)
+
+    def __call__(self):
+        self.graphs[0].replay()
+        handles = []
+        for g, (lo, hi) in zip(self.graphs[1:], self.ranges):
+            g.replay()
+            h = self.reducer.all_reduce_params_async(lo, hi)
+            if h is not None:
+                handles.append(h)
+        for h in handles:
+            h.wait()
+        self.opt.step()
+        return self.loss, self.loss_dic
+
+
+def _forward_only(model, loss_func, optimizer, examples, args, dat_name, root_xyz):
+    """_forward_backward without the backward call (the segmented step runs backward in pieces)."""
+    outputs = model(dat_name, True, examples["imgs"], Ks=examples["Ps"], root_xyz=root_xyz)
+    ex = dict(examples)
+    if dat_name != "HO3D":
+        ex["joints"] = examples["joints"] - root_xyz
+        if "verts" in examples:
+            ex["verts"] = examples["verts"] - root_xyz
+    if any(k in args.losses for k in ("joint_2d", "bone_direc")):
+        outputs["j2d"] = trans_proj_j2d(outputs, examples["Ks"], root_xyz=root_xyz)
+    loss_dic = loss_func(ex, outputs, args.losses, dat_name, args)
+    missing = [k for k in args.losses if k not in loss_dic]
+    if missing:
+        raise KeyError(f"loss terms {missing} were requested but not produced for {dat_name}")
+    terms = [loss_dic[k] for k in args.losses]
+    loss = terms[0] if len(terms) == 1 else torch.stack(terms).sum()
+    loss_dic["loss"] = loss
+    optimizer.zero_grad(set_to_none=True)
+    return loss, loss_dic

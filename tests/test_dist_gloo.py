@@ -87,7 +87,35 @@ def _worker(rank, world, port, ret):
     torch.nn.functional.mse_loss(model(xs), ys).backward()
     red.all_reduce_flat()
     assert torch.allclose(flat.grad * red.grad_scale, hooked, atol=1e-7), "paused hooks + all_reduce_flat differs"
+    # the segmented form (traineval.SegmentedGraphedTrainStep): the autograd graph cut at a boundary, backward in two calls, the
+    # parameters each call completed exchanged by range while the next call runs -- the same gradient again
+    flat.zero_grad()
+    h1 = model.net[2](model.net[1](model.net[0](xs)))
+    leaf = h1.detach().requires_grad_(True)
+    out = _DirectGradScale.apply(model.net[4](model.net[3](leaf)), model.scale)
+    torch.nn.functional.mse_loss(out, ys).backward()                    # stops at the boundary
+    idx = {id(p): i for i, p in enumerate(flat.params)}
+    cut = idx[id(model.net[4].weight)]                                   # parameters [cut, n) belong to the second segment
+    handles = [red.all_reduce_params_async(cut, len(flat.params))]
+    h1.backward(leaf.grad)                                              # the first segment, beside the exchange
+    handles.append(red.all_reduce_params_async(0, cut))
+    for h in handles:
+        if h is not None:
+            h.wait()
+    assert torch.allclose(flat.grad * red.grad_scale, hooked, atol=1e-7), "segmented backward + per-range exchange differs"
     red.pause_hooks(False)
+    # a gradient that a LATER function's backward writes (ops._WinoLink): autograd's hook for the parameter must not count while it
+    # is flagged deferred; the writer reports it
+    p0 = flat.params[0]
+    red.reset()
+    p0._hifihr_grad_deferred = True
+    before = list(red._pending)
+    p0._hifihr_grad_ready(p0)
+    assert red._pending == before, "a deferred parameter was counted"
+    p0._hifihr_grad_deferred = False
+    p0._hifihr_grad_ready(p0)
+    assert red._pending[red.param_bucket[0]] == before[red.param_bucket[0]] - 1
+    red.reset()
     ret[rank] = hooked.numpy(), flat.flat.clone().numpy()
     dist.destroy_process_group()
 

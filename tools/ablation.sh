@@ -1,6 +1,6 @@
 #!/bin/bash
 # What each dispatch decision buys on the FINAL tree: bench.py (BASELINE configs[1], hipGraph replay, 30 steps) with one switch off at a time.
-# usage (GPU box, through gpurun): bash tools/ablation.sh > gpurun_out/r02_ablation.txt
+# usage (GPU box, through gpurun): bash tools/ablation.sh > gpurun_out/r03_ablation.txt
 cd $GRAFT_REPO_ROOT
 run() {   # label, then VAR=value assignments / bench flags
   label=$1; shift
@@ -10,6 +10,9 @@ run() {   # label, then VAR=value assignments / bench flags
   printf "%-58s %s\n" "$label" "$ms"
 }
 run "default (final tree)"
+run "batch-norm NOT fused into the Winograd transforms (HIFIHR_BN_WINO_FUSE=0)" HIFIHR_BN_WINO_FUSE=0
+run "batch-norm backward unfused, forward fused (HIFIHR_BN_WINO_BWD=0)" HIFIHR_BN_WINO_BWD=0
+run "rasteriser forward on 16x16 tiles (HIFIHR_RENDER_TILE=16)" HIFIHR_RENDER_TILE=16
 run "stem BN+ReLU+max-pool unfused (HIFIHR_BN_POOL=0)" HIFIHR_BN_POOL=0
 run "1x1 convolutions on the implicit GEMM (HIFIHR_CONV1X1_GEMM=0)" HIFIHR_CONV1X1_GEMM=0
 run "TN row-share kernel off (HIFIHR_GEMM_TN_ROWS=0)" HIFIHR_GEMM_TN_ROWS=0

@@ -10,7 +10,7 @@ from hifihr_amd.losses import LossFunction
 from hifihr_amd.mano_tables import synthetic_mano_tables
 from hifihr_amd.models import Model
 from hifihr_amd.optim import FlatParams, FusedAdam
-from hifihr_amd.traineval import GraphedTrainStep, data_dic, forward_backward, train_step
+from hifihr_amd.traineval import GraphedTrainStep, SegmentedGraphedTrainStep, data_dic, forward_backward, train_step
 
 rank, local_rank, world = hdist.init_process_group_from_env()
 dev = torch.device("cuda", 0)
@@ -89,6 +89,22 @@ g = GraphedTrainStep(model, lf, opt, ex, args, reducer=reducer)
 for _ in range(3):
     g()
 params_in_sync("graph form, 3 steps")
+# third form (round 3): backward as separate graph launches per trunk segment, each segment's bucket exchanged while the next one runs
+g.release()
+sg = SegmentedGraphedTrainStep(model, lf, opt, ex, args, reducer)
+reducer.pause_hooks(True)
+forward_backward(model, lf, opt, ex, args)
+whole = flat.grad.detach().clone()
+sg._eager_segmented()
+seg = flat.grad.detach().clone()
+e_seg = float((seg - whole).abs().max()) / max(float(whole.abs().max()), 1e-12)
+if rank == 0:
+    print(f"segmented backward vs whole backward (local gradient): relative max difference = {e_seg:.3e}")
+assert e_seg < max(50 * noise, 5e-5), (e_seg, noise)
+for _ in range(3):
+    sg()
+params_in_sync("segmented graph form, 3 steps")
+sg.release()
 reducer.pause_hooks(False)
 for _ in range(2):
     train_step(model, lf, opt, ex, args, backward_hook=reducer.finish)
