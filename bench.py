@@ -279,6 +279,12 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None):
                     f"{P_} x [{T_} x {K_}]^T . [{T_} x {C_}], {max(parts, 1)} slab(s)")
             continue
         N_, H_, W_, C_, K_, R_, S_, st_, pd_ = geom
+        if direction in ("fwd-wino2", "dgrad-wino2"):          # conv_wino2_kernel: one launch, 2 x 16 x (tiles x 64 x 64) executed products
+            x = torch.randn(N_, H_, W_, 64, device=dev); U = torch.randn(16 * 64 * 64, device=dev) * 0.05; y = torch.empty(N_, H_, W_, 64, device=dev)
+            us = hip_us(lambda: lib.conv3x3_c64_wino(x, U, None, False, y, None, N_, H_, W_))
+            add("conv_wino2_kernel", per_step, us, 2.0 * 16 * (N_ * H_ * W_ / 4) * 64 * 64, 4.0 * (2 * N_ * H_ * W_ * 64 + 16 * 64 * 64),
+                f"{direction} N{N_} {H_}x{W_} 64->64 3x3 as F(2x2, 3x3), transforms in registers")
+            continue
         OH_, OW_ = (H_ + 2 * pd_ - R_) // st_ + 1, (W_ + 2 * pd_ - S_) // st_ + 1
         x = torch.randn(N_, H_, W_, C_, device=dev); w = torch.randn(K_, R_, S_, C_, device=dev) * 0.05
         y = torch.randn(N_, OH_, OW_, K_, device=dev)

@@ -174,6 +174,8 @@ class HifihrLib:
         c.hifihr_wino_gemm_m.argtypes = [_c_float_p] * 3 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_wino_output_transform_m.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_output_transform_act_m.argtypes = [_c_float_p] * 3 + [c_int] * 6 + [c_void_p]
+        c.hifihr_conv3x3_c64_wino_supported.argtypes = [c_int] * 5
+        c.hifihr_conv3x3_c64_wino.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_wino_bn_input_supported.argtypes = [c_int, c_int]
         c.hifihr_wino_bn_input_transform.argtypes = [_c_float_p] * 7 + [c_int] * 5 + [c_float, c_float] + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_wino_output_transform_bnred.argtypes = [_c_float_p] * 10 + [c_int] * 5 + [c_void_p]
@@ -424,6 +426,14 @@ class HifihrLib:
 
     def wino_input_transform(self, x, V, N, H, W, C, m=2):
         self.check(self.c.hifihr_wino_input_transform_m(_fp(x), _fp(V), N, H, W, C, m, _stream_of(x)), "hifihr_wino_input_transform")
+
+    def conv3x3_c64_wino_supported(self, N, H, W, C, K):
+        return bool(self.c.hifihr_conv3x3_c64_wino_supported(int(N), int(H), int(W), int(C), int(K)))
+
+    def conv3x3_c64_wino(self, x, U, bias, relu, y, stats, N, H, W):
+        """64 -> 64 channel 3x3 / stride 1 / pad 1 convolution as register-resident Winograd F(2x2, 3x3) (include/hifihr.h)."""
+        self.check(self.c.hifihr_conv3x3_c64_wino(_fp(x), _fp(U), _fp(bias), int(bool(relu)), _fp(y), _fp(stats), N, H, W, _stream_of(x)),
+                   "hifihr_conv3x3_c64_wino")
 
     def wino_bn_input_supported(self, C, m):
         return bool(self.c.hifihr_wino_bn_input_supported(int(C), int(m)))

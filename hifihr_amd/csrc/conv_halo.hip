@@ -61,6 +61,14 @@ struct HaloArgs {
 
 struct Tile { int n, x0, y0, rows; };
 
+// rows of the tile that starts at strip `cur` of a share ending at `end`; the tile itself (strips are ordered (n, column tile, y))
+__device__ __forceinline__ int tile_rows(int H, int cur, int end) { return min(min(kTH, H - cur % H), end - cur); }
+__device__ __forceinline__ Tile tile_of(int H, int ctiles, int cur, int end) {
+  const int col = cur / H, y = cur - col * H;
+  const int n = col / ctiles, ct = col - n * ctiles;
+  return Tile{n, ct * kTW, y, min(min(kTH, H - y), end - cur)};
+}
+
 // the tile that starts at strip `cur` of a share ending at `end`
 __device__ __forceinline__ Tile tile_at(const HaloArgs& a, int cur, int end) {
   const int col = cur / a.H, y = cur - col * a.H;
@@ -356,6 +364,376 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
       double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 16 * wave + 4 * g;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { stat_atomic_add(sp + e, S1[e]); stat_atomic_add(sp + 64 + e, S2[e]); }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same layer as Winograd F(2x2, 3x3) WITHOUT transform-domain tensors in HBM (round 3).
+// csrc/wino.hip / wino4.hip write V = B^T d B and read M back through HBM (2.25x / 4x the activation each way), which is why layer 1
+// (64 channels at 56 x 56: the largest activations of the trunk) stayed on the direct kernel above.  Here the 16 transform positions
+// xi = (i, j) take the place of the 9 taps in the same skeleton -- halo staged once per 8 x 14 tile, 4 loader waves, a 4-stage ring of
+// 16 KB weight stages (stage = U[xi][64 n][64 c], the layout hifihr_weight_prep kinds 1 / 2 already produce), one raw barrier per
+// stage -- and the transforms live in registers:
+//   * input: the B operand of an MFMA k-step is V_xi[c][tile] = (d[ra][ca] +- d[ra][cb]) +- (d[rb][ca] +- d[rb][cb]), four halo pixels of
+//     the tile's 4 x 4 patch (B^T has two non-zeros per row): 4 ds_read_b128 + 12 VALU per 16 channels instead of 1 read;
+//   * output: M_xi (one accumulator tile per column block) is added with its sign to the <= 4 outputs of the 2 x 2 tile it feeds
+//     (A^T = [1 1 1 0; 0 1 -1 -1]) after its 64-channel reduction: 4 running outputs per lane, nothing leaves the registers.
+// A tile is 4 x 7 = 28 Winograd tiles = 2 MFMA row blocks: MFMA wave w owns row block w >> 1 and the two 16-channel column blocks of
+// half w & 1 (NCB = 2); a tile of <= 4 rows (14 tiles, 1 row block) gives wave w the single column block 2 (w & 1) + (w >> 1) (NCB = 1).
+// Per 8 x 14 tile and wave: 16 x 16 x 2 = 512 MFMAs against the direct kernel's 9 x 16 x 7 = 1008; LDS reads 24 per 32 MFMAs.
+// Rows and shares are even (launcher); W % 14 == 0.  Backward-data = the same kernel on dy with U' (kind 2: transposed, rotated filter).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kXi = 16;
+static_assert(2 * (kXi - 3) >= kHaloPer, "the next tile's halo must land two stages before the tile ends");
+struct Wino2Args {
+  const float* src;     // [N][H][W][64]
+  const float* U;       // [16][64 n][64 c]
+  float* dst;           // [N][H][W][64]
+  float* stats;         // forward statistics slots or null
+  const float* zeros;
+  const float* bias;    // [64] or null (EPI)
+  int relu;
+  int N, H, W;
+  int ctiles, total, per;
+};
+// B^T row i = +d[kBa[i]] + kBs[i] d[kBb[i]]
+__device__ constexpr int kBa[4] = {0, 1, 2, 1}, kBb[4] = {2, 2, 1, 3};
+__device__ constexpr int kBneg[4] = {1, 0, 1, 1};          // second term subtracted
+// A^T[p][i]
+__device__ constexpr int kAt[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+}  // namespace
+
+// HIFIHR_W2_ABLATE (timing experiments only, results are wrong; tools/build_wino2_probe.sh): 1 = no loader waves and no barriers, 2 = also no
+// LDS reads, 3 = loaders and barriers kept, LDS reads removed, 4 = everything kept except the input-transform arithmetic
+#ifndef HIFIHR_W2_ABLATE
+#define HIFIHR_W2_ABLATE 0
+#endif
+#if HIFIHR_W2_ABLATE == 1 || HIFIHR_W2_ABLATE == 2
+#define W2_BARRIER() ((void)0)
+#else
+#define W2_BARRIER() HIFIHR_RAW_BARRIER()
+#endif
+template <bool EPI>
+__global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a) {
+#if defined(HIFIHR_HALO_STAMP)
+  const unsigned long long st_entry = HALO_T();
+  unsigned long long st_loop = 0, st_real = 0, st_bar = 0, st_epi = 0, st_vm = 0;
+#endif
+  __shared__ __attribute__((aligned(1024))) float lds[2 * kHalo + kStages * kWStage];
+  float* const halo = lds;
+  float* const wst = lds + 2 * kHalo;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int s_lo = wg * a.per, s_hi = min(s_lo + a.per, a.total);
+  if (s_lo >= s_hi) return;                                  // (uniform)
+  int ntiles = 0;
+  for (int cur = s_lo; cur < s_hi; cur += tile_rows(a.H, cur, s_hi)) ++ntiles;
+  const int nst = ntiles * kXi;                              // iterations of this workgroup: one per (tile, xi)
+
+  if (wave >= 4) {
+    if (HIFIHR_W2_ABLATE == 1 || HIFIHR_W2_ABLATE == 2) return;
+    // ---------------- loader: conv_halo_kernel's, with a stage = one transform position ----------------
+    const int l = wave - 4;
+    unsigned woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = l + kNL * i;
+      const int row = 8 * (q & 7) + (lane >> 3);
+      woff[i] = (unsigned)row * 64u + (unsigned)((q >> 3) * 32) + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 4);
+    }
+    auto issue_w = [&](int gt) {                             // global stage gt -> ring slot gt & 3
+      float* base = wst + (gt & (kStages - 1)) * kWStage;
+      const float* src = a.U + (gt & (kXi - 1)) * 4096;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) HIFIHR_GLDS16(src + woff[i], base + 256 * (l + kNL * i), lane);
+    };
+    int hpk[kHaloPer];
+#pragma unroll
+    for (int i = 0; i < kHaloPer; ++i) {
+      const int o = (l + kNL * i) * 1024 + lane * 16;
+      const int hp = o / (kPixF * 4), within = o - hp * (kPixF * 4);
+      hpk[i] = (hp < kHaloPix && within < 256) ? ((hp >> 4) << 12) | ((hp & 15) << 8) | (within >> 4) : -1;
+    }
+    auto issue_h1 = [&](const Tile& t, int buf, int i) {
+      const int hq = l + kNL * i;
+      const int pk = hpk[i];
+      const int iy = t.y0 - 1 + (pk >> 12), ix = t.x0 - 1 + ((pk >> 8) & 15);
+      const bool ok = pk >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float* src = ok ? a.src + (((size_t)t.n * a.H + iy) * a.W + ix) * 64 + (pk & 15) * 4 : a.zeros;
+      HIFIHR_GLDS16(src, halo + buf * kHalo + 256 * hq, lane);
+    };
+    const int nh = (kHaloPieces - l + kNL - 1) / kNL;
+    int cur = s_lo;
+    Tile t = tile_of(a.H, a.ctiles, cur, s_hi);
+#pragma unroll
+    for (int i = 0; i < kHaloPer; ++i)
+      if (i < nh) issue_h1(t, 0, i);
+    issue_w(0);
+    issue_w(1);
+    issue_w(2);
+    HIFIHR_WAIT_VM(4);
+    HIFIHR_RAW_BARRIER();                                    // barrier -1
+    int gt = 0;
+    for (int ti = 0; ti < ntiles; ++ti) {
+      cur += t.rows;
+      const bool more = ti + 1 < ntiles;
+      Tile nt = t;
+      if (more) nt = tile_of(a.H, a.ctiles, cur, s_hi);
+      const int nbuf = (ti + 1) & 1;
+#pragma unroll
+      for (int xi = 0; xi < kXi; ++xi, ++gt) {
+        const bool w = gt + 3 < nst;
+        if (w) issue_w(gt + 3);
+        int hcnt = 0;
+        if (more && 2 * xi < kHaloPer) {
+          issue_h1(nt, nbuf, 2 * xi);
+          hcnt = 1;
+          if (2 * xi + 1 < nh) { issue_h1(nt, nbuf, 2 * xi + 1); hcnt = 2; }
+        }
+        const int out = (w ? 4 : 0) + hcnt;
+#if defined(HIFIHR_HALO_STAMP)
+        const unsigned long long v0 = HALO_T();
+#endif
+        if (out == 6) HIFIHR_WAIT_VM(6);
+        else if (out == 5) HIFIHR_WAIT_VM(5);
+        else if (out == 4) HIFIHR_WAIT_VM(4);
+        else if (out == 2) HIFIHR_WAIT_VM(2);
+        else if (out == 1) HIFIHR_WAIT_VM(1);
+        else HIFIHR_WAIT_VM(0);
+#if defined(HIFIHR_HALO_STAMP)
+        st_vm += HALO_T() - v0;
+#endif
+        HIFIHR_RAW_BARRIER();                                // barrier gt
+      }
+      t = nt;
+    }
+#if defined(HIFIHR_HALO_STAMP)
+    if (tid == 256) atomicAdd(&g_halo_stamp[7], st_vm);
+#endif
+    return;
+  }
+
+  // ---------------- MFMA waves ----------------
+  const int r = lane & 15, g = lane >> 4;
+  const int rbw = wave >> 1, chw = wave & 1;
+  auto patch_off = [&](int tt) {                             // halo byte offset of tile tt's 4 x 4 patch origin, this lane's 16-byte segment
+    const int ty2 = tt / 7, tx2 = tt - 7 * ty2;
+    return (2 * ty2 * kHP + 2 * tx2) * (kPixF * 4) + g * 16;
+  };
+  const int hoff_full = patch_off(min(16 * rbw + r, 27)), hoff_half = patch_off(min(r, 13));
+  const int wswz[2] = {((g) ^ ((r >> 1) & 7)) * 16, ((g + 4) ^ ((r >> 1) & 7)) * 16};
+  const char* const halo_b = reinterpret_cast<const char*>(halo);
+  const char* const wst_b = reinterpret_cast<const char*>(wst);
+  // batch-norm statistics (shifted sums): set s = the lane's channels 32 chw + 16 s + 4 g .. + 3
+  float ssum[2][4] = {}, ssq[2][4] = {}, sk[2][4] = {};
+  int sn[2] = {0, 0};
+
+  W2_BARRIER();                                      // barrier -1
+  int cur = s_lo, gt = 0;
+  auto run_tile = [&](auto ncbc, const Tile& t, int hbuf) {
+    constexpr int NCB = decltype(ncbc)::value;
+    const int tt = NCB == 2 ? 16 * rbw + r : r;
+    const int hoff = hbuf * (kHalo * 4) + (NCB == 2 ? hoff_full : hoff_half);
+    const int cb0 = NCB == 2 ? 2 * chw : 2 * chw + rbw;
+    const int wrow = (16 * cb0 + r) * 128;
+    // Software pipeline over the tile's 64 quarters Q = 4 xi + qd (16 input channels each), three deep: the patch reads of quarter Q + 2 and
+    // the weight reads of Q + 1 are issued, the input transform of Q + 1 runs on the VALU, the MFMAs of Q run -- interleaved by the
+    // scheduler hints so that the matrix pipe never waits for the 12 transform instructions of its own quarter (measured with the transform
+    // in front of its MFMAs: 59 us per layer-1 launch, of which 11 were the exposed VALU).
+    float4 pr[2][4], wv[3][NCB];
+    float v[2][4];
+    auto read_raw = [&](int Q, int slot) {                    // (Q, slot: compile-time after unrolling)
+      if (HIFIHR_W2_ABLATE == 2 || HIFIHR_W2_ABLATE == 3) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { HIFIHR_TOUCH(pr[slot][q].x); HIFIHR_TOUCH(pr[slot][q].y); HIFIHR_TOUCH(pr[slot][q].z); HIFIHR_TOUCH(pr[slot][q].w); }
+        return;
+      }
+      const int xi = (Q >> 2) & (kXi - 1), qd = Q & 3;
+      const int i = xi >> 2, j = xi & 3;
+      const char* hb = halo_b + hoff + qd * 64;
+      pr[slot][0] = *reinterpret_cast<const float4*>(hb + (kBa[i] * kHP + kBa[j]) * (kPixF * 4));
+      pr[slot][1] = *reinterpret_cast<const float4*>(hb + (kBa[i] * kHP + kBb[j]) * (kPixF * 4));
+      pr[slot][2] = *reinterpret_cast<const float4*>(hb + (kBb[i] * kHP + kBa[j]) * (kPixF * 4));
+      pr[slot][3] = *reinterpret_cast<const float4*>(hb + (kBb[i] * kHP + kBb[j]) * (kPixF * 4));
+    };
+    auto read_w = [&](int gst, int qd, int slot) {            // weights of quarter qd of global stage gst
+      if (HIFIHR_W2_ABLATE == 2 || HIFIHR_W2_ABLATE == 3) {
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) { HIFIHR_TOUCH(wv[slot][c].x); HIFIHR_TOUCH(wv[slot][c].y); HIFIHR_TOUCH(wv[slot][c].z); HIFIHR_TOUCH(wv[slot][c].w); }
+        return;
+      }
+      const char* wb = wst_b + (gst & (kStages - 1)) * (kWStage * 4) + (qd >> 1) * 8192 + wrow + wswz[qd & 1];
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) wv[slot][c] = *reinterpret_cast<const float4*>(wb + c * (16 * 128));
+    };
+    auto transform = [&](int Q, int slot) {                   // v[slot] = this lane's four channels of V_xi for quarter Q (patch values in pr[Q & 1])
+      const int rs = Q & 1;
+      const int xi = (Q >> 2) & (kXi - 1);
+      const int i = xi >> 2, j = xi & 3;
+      const float* p0 = reinterpret_cast<const float*>(&pr[rs][0]);
+      const float* p1 = reinterpret_cast<const float*>(&pr[rs][1]);
+      const float* p2 = reinterpret_cast<const float*>(&pr[rs][2]);
+      const float* p3 = reinterpret_cast<const float*>(&pr[rs][3]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float top = kBneg[j] ? p0[k] - p1[k] : p0[k] + p1[k];
+        const float bot = kBneg[j] ? p2[k] - p3[k] : p2[k] + p3[k];
+        v[slot][k] = kBneg[i] ? top - bot : top + bot;
+        if (HIFIHR_W2_ABLATE == 4) v[slot][k] = p0[k];
+      }
+    };
+    floatx4 Y[4][NCB], M[2][NCB];
+#if HIFIHR_W2_ABLATE == 5
+    floatx4 M2[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) M2[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+#endif
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) Y[p][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+    auto fold = [&](int xi) {                                 // M_xi into the outputs it feeds: A^T[p >> 1][i] A^T[p & 1][j]
+      const int i = xi >> 2, j = xi & 3;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int co = kAt[p >> 1][i] * kAt[p & 1][j];
+        if (co == 1) {
+#pragma unroll
+          for (int c = 0; c < NCB; ++c) Y[p][c] += M[xi & 1][c];
+        } else if (co == -1) {
+#pragma unroll
+          for (int c = 0; c < NCB; ++c) Y[p][c] -= M[xi & 1][c];
+        }
+      }
+    };
+    read_w(gt, 0, 0);
+    read_w(gt, 1, 1);
+    read_raw(0, 0);
+    read_raw(1, 1);
+    transform(0, 0);
+#if defined(HIFIHR_HALO_STAMP)
+    const unsigned long long l0 = HALO_T(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+    for (int xi = 0; xi < kXi; ++xi, ++gt) {
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) M[xi & 1][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int Q = 4 * xi + qd;
+        // LDS reads, one per MFMA slot: first the patch values of quarter Q + 2 (the transform at the head of the next iteration consumes
+        // them: >= 4 MFMA slots later), then the weights of Q + 2 (past qd = 1 they belong to the next stage: landed, confirmed at barrier
+        // gt - 1) -- read two quarters ahead, the head of the next iteration's MFMAs would otherwise wait for a read issued 2 slots earlier
+        read_raw(Q + 2, Q & 1);                               // (past the tile's end: addresses stay inside the halo, values never used)
+        if (qd < 2) read_w(gt, qd + 2, (Q + 2) % 3);
+        else read_w(gt + 1, qd - 2, (Q + 2) % 3);
+        transform(Q + 1, (Q + 1) & 1);
+        if (qd == 1 && xi > 0) fold(xi - 1);                  // the previous position's accumulators: its MFMAs retired long ago
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int c = 0; c < NCB; ++c) {
+#if HIFIHR_W2_ABLATE == 5
+            floatx4& acc = (k & 1) ? M2[c] : M[xi & 1][c];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(&wv[Q % 3][c])[k], v[Q & 1][k], acc, 0, 0, 0);
+#else
+            M[xi & 1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(&wv[Q % 3][c])[k], v[Q & 1][k], M[xi & 1][c], 0, 0, 0);
+#endif
+          }
+        // one LDS read and two or three VALU instructions behind every MFMA
+#pragma unroll
+        for (int n = 0; n < (HIFIHR_W2_ABLATE == 6 ? 0 : 4 + NCB); ++n) {
+          HIFIHR_SCHED_GROUP(0x008, 1);
+          HIFIHR_SCHED_GROUP(0x100, 1);
+          HIFIHR_SCHED_GROUP(0x002, NCB == 2 ? 2 : 5);
+        }
+#if HIFIHR_W2_ABLATE != 6
+        if (NCB == 2) HIFIHR_SCHED_GROUP(0x008, 2);
+        HIFIHR_PIN();
+#endif
+      }
+#if defined(HIFIHR_HALO_STAMP)
+      HIFIHR_TOUCH(M[xi & 1][0][0]);
+      const unsigned long long b0 = HALO_T();
+#endif
+      W2_BARRIER();                                  // barrier gt
+#if defined(HIFIHR_HALO_STAMP)
+      st_bar += HALO_T() - b0;
+#endif
+    }
+#if defined(HIFIHR_HALO_STAMP)
+    const unsigned long long l1 = HALO_T();
+    st_loop += l1 - l0; st_real += __builtin_amdgcn_s_memrealtime() - r0;
+#endif
+    fold(kXi - 1);
+#if HIFIHR_W2_ABLATE == 5
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) Y[0][c] += M2[c];
+#endif
+    // epilogue: register e of Y[2 py + px][c] = out[y0 + 2 ty2 + py][x0 + 2 tx2 + px][16 (cb0 + c) + 4 g + e]
+    if (tt < (t.rows >> 1) * 7) {
+      const int ty2 = tt / 7, tx2 = tt - 7 * ty2;
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        const int ch = 16 * (cb0 + c) + 4 * g;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (EPI) {
+          if (a.bias != nullptr) b4 = *reinterpret_cast<const float4*>(a.bias + ch);
+        }
+        auto put = [&](float (&k4)[4], float (&s4)[4], float (&q4)[4], int& n) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            float* o = a.dst + (((size_t)t.n * a.H + t.y0 + 2 * ty2 + (p >> 1)) * a.W + t.x0 + 2 * tx2 + (p & 1)) * 64 + ch;
+            float4 v = make_float4(Y[p][c][0], Y[p][c][1], Y[p][c][2], Y[p][c][3]);
+            if constexpr (EPI) {
+              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+              if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            *reinterpret_cast<float4*>(o) = v;
+            if (n == 0) { k4[0] = v.x; k4[1] = v.y; k4[2] = v.z; k4[3] = v.w; }
+            const float d0 = v.x - k4[0], d1 = v.y - k4[1], d2 = v.z - k4[2], d3 = v.w - k4[3];
+            s4[0] += d0; q4[0] += d0 * d0; s4[1] += d1; q4[1] += d1 * d1;
+            s4[2] += d2; q4[2] += d2 * d2; s4[3] += d3; q4[3] += d3 * d3;
+            ++n;
+          }
+        };
+        if (NCB == 2 ? c == 0 : rbw == 0) put(sk[0], ssum[0], ssq[0], sn[0]);
+        else put(sk[1], ssum[1], ssq[1], sn[1]);
+      }
+    }
+#if defined(HIFIHR_HALO_STAMP)
+    st_epi += HALO_T() - l1;
+#endif
+  };
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const Tile t = tile_of(a.H, a.ctiles, cur, s_hi);
+    cur += t.rows;
+    if (t.rows > 4) run_tile(std::integral_constant<int, 2>{}, t, ti & 1);
+    else run_tile(std::integral_constant<int, 1>{}, t, ti & 1);
+  }
+#if defined(HIFIHR_HALO_STAMP)
+  if (tid == 0) {
+    atomicAdd(&g_halo_stamp[0], st_loop); atomicAdd(&g_halo_stamp[1], st_real); atomicAdd(&g_halo_stamp[2], (unsigned long long)nst);
+    atomicAdd(&g_halo_stamp[3], st_bar); atomicAdd(&g_halo_stamp[4], 1ull); atomicAdd(&g_halo_stamp[5], HALO_T() - st_entry);
+    atomicAdd(&g_halo_stamp[6], st_epi);
+  }
+#endif
+  if (a.stats != nullptr) {                                  // (uniform)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      double S1[4], S2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        stat_unshift(sn[s], sk[s][e], ssum[s][e], ssq[s][e], S1[e], S2[e]);
+        for (int o = 1; o < 16; o <<= 1) { S1[e] += __shfl_xor(S1[e], o, 64); S2[e] += __shfl_xor(S2[e], o, 64); }
+      }
+      if (r == 0) {
+        double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 32 * chw + 16 * s + 4 * g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { stat_atomic_add(sp + e, S1[e]); stat_atomic_add(sp + 64 + e, S2[e]); }
+      }
     }
   }
 }
@@ -1087,6 +1465,32 @@ hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wg
   G = (a.total + a.per - 1) / a.per;
   if (bias != nullptr || g.relu || g.OW % kTW != 0) hipLaunchKernelGGL(conv_halo_kernel<true>, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
   else hipLaunchKernelGGL(conv_halo_kernel<false>, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+  return hipGetLastError();
+}
+
+// conv_wino2_kernel: the 64 -> 64 stride-1 3x3 layers with even H and W % 14 == 0 (ResNet layer 1 at 56 x 56, VGG19 conv1_2 at 224 x 224)
+bool conv_wino2_supported(int N, int H, int W, int C, int K) {
+  static const int on = [] { const char* e = getenv("HIFIHR_CONV_WINO2"); return e ? atoi(e) : 1; }();
+  return on && C == 64 && K == 64 && N > 0 && H >= 2 && H % 2 == 0 && W >= kTW && W % kTW == 0 && (long)N * H * W * 64 < (1L << 31);
+}
+
+hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias, int relu, float* dst, float* stats, int N, int H, int W,
+                             hipStream_t st) {
+  if (!conv_wino2_supported(N, H, W, 64, 64)) return hipErrorInvalidValue;
+  const float* zeros = conv_halo_zero_page(st);
+  if (zeros == nullptr) return hipErrorNotReady;
+  Wino2Args a;
+  a.src = src; a.U = U; a.dst = dst; a.stats = stats; a.zeros = zeros; a.bias = bias; a.relu = relu;
+  a.N = N; a.H = H; a.W = W;
+  a.ctiles = W / kTW;
+  a.total = N * a.ctiles * H;
+  int G = halo_cus();
+  a.per = (a.total + G - 1) / G;
+  if (a.per < 4) a.per = 4;
+  a.per = (a.per + 1) & ~1;                                  // even shares: every tile is whole 2 x 2 Winograd tiles
+  G = (a.total + a.per - 1) / a.per;
+  if (bias != nullptr || relu) hipLaunchKernelGGL(conv_wino2_kernel<true>, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+  else hipLaunchKernelGGL(conv_wino2_kernel<false>, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
   return hipGetLastError();
 }
 

@@ -1036,6 +1036,16 @@ int hifihr_wino_output_transform_m(const float* M, float* y, float* stats, int N
   return HIFIHR_OK;
 }
 
+int hifihr_conv3x3_c64_wino_supported(int N, int H, int W, int C, int K) { return hifihr::conv_wino2_supported(N, H, W, C, K) ? 1 : 0; }
+
+int hifihr_conv3x3_c64_wino(const float* x, const float* u, const float* bias, int relu, float* y, float* stats, int N, int H, int W, void* stream) {
+  if (!x || !u || !y) return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_wino: null pointer");
+  if (!hifihr::conv_wino2_supported(N, H, W, 64, 64))
+    return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_wino: needs even H and W % 14 == 0 (or HIFIHR_CONV_WINO2=0 is set)");
+  HIP_TRY(hifihr::launch_conv_wino2(x, u, bias, relu, y, stats, N, H, W, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_bn_input_supported(int C, int m) { return (m == 4 && hifihr::wino4_bn_supported(C)) ? 1 : 0; }
 
 int hifihr_wino_bn_input_transform(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* out,

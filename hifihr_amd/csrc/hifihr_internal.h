@@ -104,6 +104,10 @@ bool conv_halo_wgrad_supported(const ConvGeom& g);
 // hipErrorNotReady: the scratch could not be set up now (first use inside a stream capture) -- use conv_wgrad_kernel for this launch
 size_t conv_halo_wgrad_slab_bytes();
 hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* slabs_or_null, hipStream_t st);
+// the same layers as Winograd F(2x2, 3x3) with the transforms in registers (conv_halo.hip: conv_wino2_kernel); U[16][64][64] = kind 1 / 2
+bool conv_wino2_supported(int N, int H, int W, int C, int K);
+hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias_or_null, int relu, float* dst, float* stats_or_null, int N,
+                             int H, int W, hipStream_t st);
 hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, const float* bias_or_null, float* dst, float* stats,
                             const float* zeros, hipStream_t st);
 // batch-norm (+ residual add + ReLU) on NHWC activations, x[M][C].  Statistics buffers are [kStatSlots][2][C]: partial

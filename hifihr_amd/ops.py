@@ -402,6 +402,13 @@ def _wino_ok(C, K, R, S, stride, pad):
     return R == 3 and S == 3 and stride == 1 and pad == 1 and C >= 128 and K >= 128 and C % 32 == 0 and K % 32 == 0
 
 
+def _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad):
+    """The 64 -> 64 stride-1 3x3 layers (ResNet layer 1, VGG19 conv1_2) as register-resident Winograd F(2x2, 3x3), one launch
+    (hifihr_conv3x3_c64_wino; HIFIHR_CONV_WINO2=0 keeps them on the direct halo kernel)."""
+    return (R == 3 and S == 3 and stride == 1 and pad == 1 and C == 64 and K == 64 and os.environ.get("HIFIHR_WINOGRAD", "1") != "0"
+            and lib.conv3x3_c64_wino_supported(N, H, W, C, K))
+
+
 _WINO_TILE = {}
 
 
@@ -621,7 +628,15 @@ class _Conv2dMFMA(torch.autograd.Function):
         stats = None
         wino = _wino_ok(C, K, R, S, stride, pad) and not (want_stats and (bias is not None or relu))
         v_saved = None
-        if wino:
+        # 64 -> 64: Winograd with the transforms in registers, when the step's weight_prep launch has U (kind 1) ready
+        U64 = _WEIGHT_PREP.get(w, wk, 1) if (Cw == C and _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad)
+                                             and not (want_stats and (bias is not None or relu))) else None
+        if U64 is not None:
+            stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device) if want_stats else None
+            if PROFILE.on:
+                PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "fwd-wino2"))
+            PROFILE.bracket("conv_fwd", lambda: lib.conv3x3_c64_wino(x, U64, bias, relu, y, stats, N, H, W))
+        elif wino:
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device) if want_stats else None
             keep = bool(ctx.needs_input_grad[1])
             box = []
@@ -638,7 +653,7 @@ class _Conv2dMFMA(torch.autograd.Function):
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), False) if (bias is None and not relu) else None
             PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd(x, wk, bias, y, N, H, W, C, K, R, S, stride, pad, ws=ws,
                                                               act=1 if relu else 0))
-        if PROFILE.on and not wino:
+        if PROFILE.on and not wino and U64 is None:
             PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "fwd"))
         ctx.geom = (N, H, W, C, K, R, S, stride, pad)
         # Winograd layers keep the transformed input V (4x the size of x, 288 GB of HBM do not care) instead of x: the weight
@@ -691,6 +706,14 @@ class _Conv2dMFMA(torch.autograd.Function):
                     lib.weight_transpose(wk, wt, K, R * S, C)
                     _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1, dy_out=Yt_done, tile=tile)
             PROFILE.bracket("conv_dgrad_wino", run)
+        elif ctx.needs_input_grad[0] and ctx.w3 is None and _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad) and \
+                _WEIGHT_PREP.get(ctx.w_param, wk, 2) is not None:
+            # 64 -> 64: the same one-launch Winograd kernel on dy with U' (kind 2: transposed, rotated filter)
+            dx = torch.empty_like(x, memory_format=_CL)
+            U2 = _WEIGHT_PREP.get(ctx.w_param, wk, 2)
+            if PROFILE.on:
+                PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "dgrad-wino2"))
+            PROFILE.bracket("conv_dgrad", lambda: lib.conv3x3_c64_wino(gy, U2, None, False, dx, None, N, H, W))
         elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=_CL)
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), True)

@@ -297,6 +297,16 @@ int hifihr_wino_output_transform_m(const float* m_d, float* y_d, float* stats_d 
 int hifihr_wino_output_transform_act_m(const float* m_d, float* y_d, const float* bias_d /* or NULL */, int act, int N, int H, int W, int K,
                                        int m, void* stream);
 int hifihr_wino_dy_transform_m(const float* dy_d, float* yt_d, int N, int H, int W, int K, int m, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels as Winograd F(2x2, 3x3) in ONE launch, the transforms in
+ * registers and nothing of the transform domain in HBM (round 3, csrc/conv_halo.hip: conv_wino2_kernel) -- ResNet layer 1 (reference
+ * network/res_encoder.py:364-373 -> torchvision BasicBlock conv1 / conv2 of layer1) and VGG19 conv1_2 of the perceptual loss (reference
+ * utils/perceptual_loss.py:27-36).  u_d = U[16][64][64]: hifihr_wino_weight_transform(w, u, 64, 64, 0) or hifihr_weight_prep kind 1 for
+ * the forward; kind 2 (the transposed, rotated filter) with x_d = dy gives backward-data.  bias_d / relu: epilogue (VGG19); stats_d: the
+ * forward statistics slots of the batch norm that follows (hifihr_bn_stats_floats(64) floats, zeroed) or NULL.  H even, W % 14 == 0
+ * (hifihr_conv3x3_c64_wino_supported); results within 1e-5 (relative to the output scale) of the direct convolution. */
+int hifihr_conv3x3_c64_wino_supported(int N, int H, int W, int C, int K);
+int hifihr_conv3x3_c64_wino(const float* x_d, const float* u_d, const float* bias_d /* or NULL */, int relu, float* y_d,
+                            float* stats_d /* or NULL */, int N, int H, int W, void* stream);
 /* Batch-norm fused into the F(4x4, 3x3) input transform (round 3, csrc/wino4_bn.hip).  For a BatchNorm2d whose consumer is a Winograd
  * convolution (reference BasicBlock: conv1 -> bn1 -> relu -> conv2; bn2 -> += identity -> relu -> the next block's conv1,
  * network/res_encoder.py:364-373 + vendored utils/Freihand_GNN_mano/network/resnet.py) this ONE launch replaces hifihr_bn_act_fwd followed by

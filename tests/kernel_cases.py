@@ -806,6 +806,47 @@ def conv_relu_nobias_case(lib, device, N, H, W, C, K, R, stride, seed=0, pad=0):
     assert float((out.cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6, "conv+relu fwd"
 
 
+def conv_wino2_case(lib, device, N, H, W, seed=0, bias_relu=False, rtol=2e-5):
+    """hifihr_conv3x3_c64_wino (conv_wino2_kernel: 64 -> 64, 3x3 / stride 1 / pad 1 as Winograd F(2x2, 3x3) with the transforms in registers)
+    vs F.conv2d: forward (+ bias + ReLU, + batch-norm statistics slots) and backward-data through U' of the transposed, rotated filter."""
+    import torch.nn.functional as F
+    assert lib.conv3x3_c64_wino_supported(N, H, W, 64, 64)
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, 64, H, W, generator=gen) + 0.5
+    w = torch.randn(64, 64, 3, 3, generator=gen) / 24.0
+    b = torch.randn(64, generator=gen) * 0.3 if bias_relu else None
+    xr = x.clone().requires_grad_(True)
+    z = F.conv2d(xr, w, b, padding=1)
+    y = F.relu(z) if bias_relu else z
+    gy = torch.randn(z.shape, generator=gen)
+    z.backward(gy)
+    d = lambda t: t.to(device).contiguous()
+    w_krsc = d(w.permute(0, 2, 3, 1))
+    U = torch.empty(16 * 64 * 64, device=device)
+    lib.wino_weight_transform(w_krsc, U, 64, 64, 0)
+    out = torch.full((N, H, W, 64), 7.0, device=device)
+    stats = None if bias_relu else torch.zeros(lib.bn_stats_floats(64), device=device)
+    lib.conv3x3_c64_wino(d(x.permute(0, 2, 3, 1)), U, d(b) if bias_relu else None, bias_relu, out, stats, N, H, W)
+    ref = y.detach().permute(0, 2, 3, 1)
+    err = float((out.cpu() - ref).abs().max())
+    assert err <= rtol * float(ref.abs().max()) + 1e-6, f"wino2 conv fwd: {err}"
+    if stats is not None:
+        sl = bn_slots(stats.cpu(), 64).sum(0)
+        r2 = ref.double().reshape(-1, 64)
+        assert float((sl[0] - r2.sum(0)).abs().max()) <= 2e-5 * float(r2.abs().sum(0).max()), "wino2 conv: channel sums"
+        assert float((sl[1] - (r2 * r2).sum(0)).abs().max()) <= 2e-5 * float((r2 * r2).sum(0).max()), "wino2 conv: channel sums of squares"
+    if not bias_relu:
+        # backward-data: U' from the [C][R][S][K] transpose with flip (what hifihr_weight_prep kind 2 produces from w directly)
+        wt = d(w.permute(1, 2, 3, 0))
+        U2 = torch.empty(16 * 64 * 64, device=device)
+        lib.wino_weight_transform(wt, U2, 64, 64, 1)
+        dx = torch.full((N, H, W, 64), 7.0, device=device)
+        lib.conv3x3_c64_wino(d(gy.permute(0, 2, 3, 1)), U2, None, False, dx, None, N, H, W)
+        refx = xr.grad.permute(0, 2, 3, 1)
+        err = float((dx.cpu() - refx).abs().max())
+        assert err <= rtol * float(refx.abs().max()) + 1e-6, f"wino2 conv bwd data: {err}"
+
+
 def conv_bias_relu_case(lib, device, N, H, W, C, K, R, stride, seed=0, pad=0):
     """conv + bias + ReLU in one launch (act = 1) and its backward prologue bias_relu_bwd, vs torch."""
     import torch.nn.functional as F

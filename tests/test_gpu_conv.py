@@ -369,6 +369,19 @@ def test_resnet50_trunk_mfma_matches_torch_restatement():
     assert worst[0] < 5e-2, worst
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W", [(1, 8, 14), (2, 12, 28), (32, 56, 56), (3, 2, 14), (2, 30, 42), (1, 224, 224)])
+def test_conv_wino2_kernel(lib, N, H, W):
+    """conv_wino2_kernel (64 -> 64, 3x3 / stride 1 as Winograd F(2x2, 3x3) with the transforms in registers): forward + statistics and
+    backward-data vs F.conv2d at layer 1's size, VGG19 conv1_2's and the tile shapes of tests/test_hostsim_conv.py."""
+    kc.conv_wino2_case(lib, "cuda", N, H, W, seed=H + W)
+
+
+@pytest.mark.gpu
+def test_conv_wino2_bias_relu_epilogue(lib):
+    kc.conv_wino2_case(lib, "cuda", 2, 28, 28, seed=3, bias_relu=True)
+
+
 @pytest.mark.parametrize("B,H,W", [(32, 56, 56), (5, 28, 42)])
 def test_halo_kernels_are_bit_reproducible(lib, B, H, W):
     """conv_halo_kernel / conv_halo_wgrad_kernel hold no atomics on their outputs: repeated launches on the same inputs agree bit for bit
