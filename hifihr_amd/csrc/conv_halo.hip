@@ -62,11 +62,15 @@ struct HaloArgs {
 struct Tile { int n, x0, y0, rows; };
 
 // rows of the tile that starts at strip `cur` of a share ending at `end`; the tile itself (strips are ordered (n, column tile, y))
-__device__ __forceinline__ int tile_rows(int H, int cur, int end) { return min(min(kTH, H - cur % H), end - cur); }
-__device__ __forceinline__ Tile tile_of(int H, int ctiles, int cur, int end) {
+// `lead`: the row limit of the share's FIRST tile (strip `first`), kTH elsewhere -- odd workgroups of conv_wino2_kernel start with a 4-row
+// tile so that the tile ends (output bursts) of neighbouring workgroups do not coincide
+__device__ __forceinline__ int tile_rows(int H, int cur, int end, int first = -1, int lead = kTH) {
+  return min(min(cur == first ? lead : kTH, H - cur % H), end - cur);
+}
+__device__ __forceinline__ Tile tile_of(int H, int ctiles, int cur, int end, int first = -1, int lead = kTH) {
   const int col = cur / H, y = cur - col * H;
   const int n = col / ctiles, ct = col - n * ctiles;
-  return Tile{n, ct * kTW, y, min(min(kTH, H - y), end - cur)};
+  return Tile{n, ct * kTW, y, min(min(cur == first ? lead : kTH, H - y), end - cur)};
 }
 
 // the tile that starts at strip `cur` of a share ending at `end`
@@ -371,22 +375,37 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
 // ------------------------------------------------------------------------------------------------
 // The same layer as Winograd F(2x2, 3x3) WITHOUT transform-domain tensors in HBM (round 3).
 // csrc/wino.hip / wino4.hip write V = B^T d B and read M back through HBM (2.25x / 4x the activation each way), which is why layer 1
-// (64 channels at 56 x 56: the largest activations of the trunk) stayed on the direct kernel above.  Here the 16 transform positions
-// xi = (i, j) take the place of the 9 taps in the same skeleton -- halo staged once per 8 x 14 tile, 4 loader waves, a 4-stage ring of
-// 16 KB weight stages (stage = U[xi][64 n][64 c], the layout hifihr_weight_prep kinds 1 / 2 already produce), one raw barrier per
-// stage -- and the transforms live in registers:
-//   * input: the B operand of an MFMA k-step is V_xi[c][tile] = (d[ra][ca] +- d[ra][cb]) +- (d[rb][ca] +- d[rb][cb]), four halo pixels of
-//     the tile's 4 x 4 patch (B^T has two non-zeros per row): 4 ds_read_b128 + 12 VALU per 16 channels instead of 1 read;
-//   * output: M_xi (one accumulator tile per column block) is added with its sign to the <= 4 outputs of the 2 x 2 tile it feeds
-//     (A^T = [1 1 1 0; 0 1 -1 -1]) after its 64-channel reduction: 4 running outputs per lane, nothing leaves the registers.
+// (64 channels at 56 x 56: the largest activations of the trunk) stayed on the direct kernel above.  Here the transforms live in the
+// registers of the MFMA waves and the skeleton is the direct kernel's: halo staged once per 8 x 14 tile (two buffers), 4 loader waves,
+// weights streamed through LDS, raw barriers.
+//   * A STAGE is one row i of the 4 x 4 transform positions xi = 4 i + j and one half h of the input channels: U[4 i + j][64 n][32 h ..
+//     + 31] for j = 0..3 (4 x 8 KB; U[16][64 n][64 c] is what hifihr_weight_prep kinds 1 / 2 already produce), a ring of two stages;
+//     8 stages and 8 barriers per tile (the first version had one position per stage: 16 barriers, 1 450 cycles per 1 024 of MFMA).
+//   * input transform: B^T has two non-zeros per row, so the four positions of row i share R[c'] = d[ra][c'] +- d[rb][c'] (c' = 0..3:
+//     8 patch reads of 16 channels, 4 packed-pair adds each) and V_j = R[ca] +- R[cb]: 2 VALU instructions per operand register
+//     where one position at a time needs 3 -- it matters: a wave's VALU instructions do NOT hide behind its own MFMAs on this part
+//     (measured: removing the 12 transform instructions per 8 MFMAs took 17 % off the launch);
+//   * output transform: M_xi (accumulated over both channel halves) is added with its sign to the <= 4 outputs of the 2 x 2 tile it
+//     feeds (A^T = [1 1 1 0; 0 1 -1 -1]) when row i is complete: 4 running outputs per lane, nothing leaves the registers.
 // A tile is 4 x 7 = 28 Winograd tiles = 2 MFMA row blocks: MFMA wave w owns row block w >> 1 and the two 16-channel column blocks of
 // half w & 1 (NCB = 2); a tile of <= 4 rows (14 tiles, 1 row block) gives wave w the single column block 2 (w & 1) + (w >> 1) (NCB = 1).
-// Per 8 x 14 tile and wave: 16 x 16 x 2 = 512 MFMAs against the direct kernel's 9 x 16 x 7 = 1008; LDS reads 24 per 32 MFMAs.
+// Per 8 x 14 tile and wave: 16 x 16 x 2 = 512 MFMAs against the direct kernel's 9 x 16 x 7 = 1008; per stage 64 MFMAs, 32 LDS reads.
 // Rows and shares are even (launcher); W % 14 == 0.  Backward-data = the same kernel on dy with U' (kind 2: transposed, rotated filter).
+// Measured at layer 1 (B = 32, 56 x 56; the direct kernel: 77 us): one position per stage, transform in front of its MFMAs 59 us; three-deep
+// software pipeline of the same 58; this form 54 (in-kernel stamps: 2 400 cycles of an MFMA wave per 2 048-cycle stage + 120-200 at the
+// barrier, 4 000-5 000 per tile in the epilogue, where every workgroup stores at the same moment).  Dead ends, all measured: (1) handing
+// the tile's output to the loader waves through the dead halo buffer (stores spread over the next tile): the in-order vmcnt makes the
+// weight stages wait for the stores to RETIRE (~2 us each): 700-1 300 cycles at every barrier, 57 us; (2) two loader + two output waves:
+// a wave issues one LDS-DMA instruction per ~200 cycles, so 16 pieces per loader wave and stage take 3 500 cycles: 65 us (108 when the
+// unrolled loader spilled: a scratch reload in a loader costs microseconds); (3) four accumulator chains instead of two, scheduler hints
+// removed: +-0; (4) odd workgroups starting with a 4-row tile so that tile ends do not coincide (HIFIHR_W2_STAGGER): +-0 at B = 32, 18 -> 22 us at
+// B = 8 -- the epilogue's cost is the issue of its 8 stores per lane, not a burst on the fabric.  profiles/r03_time_conv_wino2.txt, r03_wino2_stamps.txt.
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr int kXi = 16;
-static_assert(2 * (kXi - 3) >= kHaloPer, "the next tile's halo must land two stages before the tile ends");
+constexpr int kW2Stages = 8;                     // per tile: (row i of positions, channel half h)
+constexpr int kW2Stage = 4 * 64 * 32;            // floats per weight stage: [4 j][64 n][32 c] (32 KB)
+static_assert(2 * kW2Stage == kStages * kWStage, "the two weight stages take the direct kernel's ring");
+static_assert(2 * 6 >= kHaloPer, "the next tile's halo is issued two pieces per stage in stages 0..5 and waited for in stage 6");
 struct Wino2Args {
   const float* src;     // [N][H][W][64]
   const float* U;       // [16][64 n][64 c]
@@ -398,22 +417,31 @@ struct Wino2Args {
   int N, H, W;
   int ctiles, total, per;
 };
-// B^T row i = +d[kBa[i]] + kBs[i] d[kBb[i]]
+// B^T row i = +d[kBa[i]] + (kBneg[i] ? -1 : +1) d[kBb[i]]
 __device__ constexpr int kBa[4] = {0, 1, 2, 1}, kBb[4] = {2, 2, 1, 3};
-__device__ constexpr int kBneg[4] = {1, 0, 1, 1};          // second term subtracted
+__device__ constexpr int kBneg[4] = {1, 0, 1, 1};
 // A^T[p][i]
 __device__ constexpr int kAt[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+#if defined(HIFIHR_HOSTSIM)
+typedef float floatx2 __attribute__((vector_size(8)));
+#else
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+#endif
+struct F4 { floatx2 lo, hi; };                   // four channels as two packed pairs (v_pk_add_f32)
+__device__ __forceinline__ F4 ld_f4(const char* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return F4{floatx2{v.x, v.y}, floatx2{v.z, v.w}};
+}
+__device__ __forceinline__ F4 addsub(const F4& a, const F4& b, bool neg) { return neg ? F4{a.lo - b.lo, a.hi - b.hi} : F4{a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ float comp(const F4& a, int k) { return k < 2 ? a.lo[k] : a.hi[k - 2]; }
 }  // namespace
 
-// HIFIHR_W2_ABLATE (timing experiments only, results are wrong; tools/build_wino2_probe.sh): 1 = no loader waves and no barriers, 2 = also no
-// LDS reads, 3 = loaders and barriers kept, LDS reads removed, 4 = everything kept except the input-transform arithmetic
+// HIFIHR_W2_ABLATE (timing experiments only, results are wrong; tools/build_wino2_probe.sh): 4 = the input-transform arithmetic removed
 #ifndef HIFIHR_W2_ABLATE
 #define HIFIHR_W2_ABLATE 0
 #endif
-#if HIFIHR_W2_ABLATE == 1 || HIFIHR_W2_ABLATE == 2
-#define W2_BARRIER() ((void)0)
-#else
-#define W2_BARRIER() HIFIHR_RAW_BARRIER()
+#ifndef HIFIHR_W2_STAGGER
+#define HIFIHR_W2_STAGGER 0
 #endif
 template <bool EPI>
 __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a) {
@@ -421,7 +449,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
   const unsigned long long st_entry = HALO_T();
   unsigned long long st_loop = 0, st_real = 0, st_bar = 0, st_epi = 0, st_vm = 0;
 #endif
-  __shared__ __attribute__((aligned(1024))) float lds[2 * kHalo + kStages * kWStage];
+  __shared__ __attribute__((aligned(1024))) float lds[2 * kHalo + 2 * kW2Stage];
   float* const halo = lds;
   float* const wst = lds + 2 * kHalo;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -429,25 +457,28 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
   const int s_lo = wg * a.per, s_hi = min(s_lo + a.per, a.total);
   if (s_lo >= s_hi) return;                                  // (uniform)
   int ntiles = 0;
-  for (int cur = s_lo; cur < s_hi; cur += tile_rows(a.H, cur, s_hi)) ++ntiles;
-  const int nst = ntiles * kXi;                              // iterations of this workgroup: one per (tile, xi)
+  const int lead = HIFIHR_W2_STAGGER && (wg & 1) ? 4 : kTH;
+  for (int cur = s_lo; cur < s_hi; cur += tile_rows(a.H, cur, s_hi, s_lo, lead)) ++ntiles;
+  const int nst = ntiles * kW2Stages;                        // iterations of this workgroup: one per (tile, stage)
 
   if (wave >= 4) {
-    if (HIFIHR_W2_ABLATE == 1 || HIFIHR_W2_ABLATE == 2) return;
-    // ---------------- loader: conv_halo_kernel's, with a stage = one transform position ----------------
+    // ---------------- loader ----------------
     const int l = wave - 4;
-    unsigned woff[4];
+    // weights of a stage: 32 pieces of 1 KiB; piece pq = l + 4 m: position j = pq >> 3, rows 8 (pq & 7) .. + 7 of that [64 n][32 c] block;
+    // lane -> (row, physical 16-byte segment), which holds logical segment (lane & 7) ^ ((row >> 1) & 7)
+    unsigned woff[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = l + kNL * i;
-      const int row = 8 * (q & 7) + (lane >> 3);
-      woff[i] = (unsigned)row * 64u + (unsigned)((q >> 3) * 32) + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 4);
+    for (int m = 0; m < 8; ++m) {
+      const int pq = l + kNL * m;
+      const int row = 8 * (pq & 7) + (lane >> 3);
+      woff[m] = (unsigned)(pq >> 3) * 4096u + (unsigned)row * 64u + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 4);
     }
-    auto issue_w = [&](int gt) {                             // global stage gt -> ring slot gt & 3
-      float* base = wst + (gt & (kStages - 1)) * kWStage;
-      const float* src = a.U + (gt & (kXi - 1)) * 4096;
+    auto issue_w = [&](int gs) {                             // global stage gs -> ring slot gs & 1
+      float* base = wst + (gs & 1) * kW2Stage;
+      const int s = gs & (kW2Stages - 1);
+      const float* src = a.U + (s >> 1) * (4 * 4096) + (s & 1) * 32;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) HIFIHR_GLDS16(src + woff[i], base + 256 * (l + kNL * i), lane);
+      for (int m = 0; m < 8; ++m) HIFIHR_GLDS16(src + woff[m], base + 256 * (l + kNL * m), lane);
     };
     int hpk[kHaloPer];
 #pragma unroll
@@ -466,46 +497,41 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
     };
     const int nh = (kHaloPieces - l + kNL - 1) / kNL;
     int cur = s_lo;
-    Tile t = tile_of(a.H, a.ctiles, cur, s_hi);
+    Tile t = tile_of(a.H, a.ctiles, cur, s_hi, s_lo, lead);
 #pragma unroll
     for (int i = 0; i < kHaloPer; ++i)
       if (i < nh) issue_h1(t, 0, i);
     issue_w(0);
-    issue_w(1);
-    issue_w(2);
-    HIFIHR_WAIT_VM(4);
+    HIFIHR_WAIT_VM(0);
     HIFIHR_RAW_BARRIER();                                    // barrier -1
-    int gt = 0;
+    int gs = 0;
     for (int ti = 0; ti < ntiles; ++ti) {
       cur += t.rows;
       const bool more = ti + 1 < ntiles;
       Tile nt = t;
-      if (more) nt = tile_of(a.H, a.ctiles, cur, s_hi);
+      if (more) nt = tile_of(a.H, a.ctiles, cur, s_hi, s_lo, lead);
       const int nbuf = (ti + 1) & 1;
 #pragma unroll
-      for (int xi = 0; xi < kXi; ++xi, ++gt) {
-        const bool w = gt + 3 < nst;
-        if (w) issue_w(gt + 3);
+      for (int s = 0; s < kW2Stages; ++s, ++gs) {
+        // stage gs + 1 into the slot stage gs - 1 was read from (released by barrier gs - 1); it must have landed before barrier gs,
+        // after which the MFMA waves read it.  Loads land in order: only this iteration's halo pieces (issued after it) may stay in flight.
+        if (gs + 1 < nst) issue_w(gs + 1);
         int hcnt = 0;
-        if (more && 2 * xi < kHaloPer) {
-          issue_h1(nt, nbuf, 2 * xi);
+        if (more && 2 * s < kHaloPer) {
+          issue_h1(nt, nbuf, 2 * s);
           hcnt = 1;
-          if (2 * xi + 1 < nh) { issue_h1(nt, nbuf, 2 * xi + 1); hcnt = 2; }
+          if (2 * s + 1 < nh) { issue_h1(nt, nbuf, 2 * s + 1); hcnt = 2; }
         }
-        const int out = (w ? 4 : 0) + hcnt;
 #if defined(HIFIHR_HALO_STAMP)
         const unsigned long long v0 = HALO_T();
 #endif
-        if (out == 6) HIFIHR_WAIT_VM(6);
-        else if (out == 5) HIFIHR_WAIT_VM(5);
-        else if (out == 4) HIFIHR_WAIT_VM(4);
-        else if (out == 2) HIFIHR_WAIT_VM(2);
-        else if (out == 1) HIFIHR_WAIT_VM(1);
+        if (hcnt == 2) HIFIHR_WAIT_VM(2);
+        else if (hcnt == 1) HIFIHR_WAIT_VM(1);
         else HIFIHR_WAIT_VM(0);
 #if defined(HIFIHR_HALO_STAMP)
         st_vm += HALO_T() - v0;
 #endif
-        HIFIHR_RAW_BARRIER();                                // barrier gt
+        HIFIHR_RAW_BARRIER();                                // barrier gs
       }
       t = nt;
     }
@@ -530,135 +556,103 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
   float ssum[2][4] = {}, ssq[2][4] = {}, sk[2][4] = {};
   int sn[2] = {0, 0};
 
-  W2_BARRIER();                                      // barrier -1
-  int cur = s_lo, gt = 0;
+  HIFIHR_RAW_BARRIER();                                      // barrier -1
+  int cur = s_lo, gs = 0;
   auto run_tile = [&](auto ncbc, const Tile& t, int hbuf) {
     constexpr int NCB = decltype(ncbc)::value;
     const int tt = NCB == 2 ? 16 * rbw + r : r;
     const int hoff = hbuf * (kHalo * 4) + (NCB == 2 ? hoff_full : hoff_half);
     const int cb0 = NCB == 2 ? 2 * chw : 2 * chw + rbw;
     const int wrow = (16 * cb0 + r) * 128;
-    // Software pipeline over the tile's 64 quarters Q = 4 xi + qd (16 input channels each), three deep: the patch reads of quarter Q + 2 and
-    // the weight reads of Q + 1 are issued, the input transform of Q + 1 runs on the VALU, the MFMAs of Q run -- interleaved by the
-    // scheduler hints so that the matrix pipe never waits for the 12 transform instructions of its own quarter (measured with the transform
-    // in front of its MFMAs: 59 us per layer-1 launch, of which 11 were the exposed VALU).
-    float4 pr[2][4], wv[3][NCB];
-    float v[2][4];
-    auto read_raw = [&](int Q, int slot) {                    // (Q, slot: compile-time after unrolling)
-      if (HIFIHR_W2_ABLATE == 2 || HIFIHR_W2_ABLATE == 3) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { HIFIHR_TOUCH(pr[slot][q].x); HIFIHR_TOUCH(pr[slot][q].y); HIFIHR_TOUCH(pr[slot][q].z); HIFIHR_TOUCH(pr[slot][q].w); }
-        return;
-      }
-      const int xi = (Q >> 2) & (kXi - 1), qd = Q & 3;
-      const int i = xi >> 2, j = xi & 3;
-      const char* hb = halo_b + hoff + qd * 64;
-      pr[slot][0] = *reinterpret_cast<const float4*>(hb + (kBa[i] * kHP + kBa[j]) * (kPixF * 4));
-      pr[slot][1] = *reinterpret_cast<const float4*>(hb + (kBa[i] * kHP + kBb[j]) * (kPixF * 4));
-      pr[slot][2] = *reinterpret_cast<const float4*>(hb + (kBb[i] * kHP + kBa[j]) * (kPixF * 4));
-      pr[slot][3] = *reinterpret_cast<const float4*>(hb + (kBb[i] * kHP + kBb[j]) * (kPixF * 4));
-    };
-    auto read_w = [&](int gst, int qd, int slot) {            // weights of quarter qd of global stage gst
-      if (HIFIHR_W2_ABLATE == 2 || HIFIHR_W2_ABLATE == 3) {
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) { HIFIHR_TOUCH(wv[slot][c].x); HIFIHR_TOUCH(wv[slot][c].y); HIFIHR_TOUCH(wv[slot][c].z); HIFIHR_TOUCH(wv[slot][c].w); }
-        return;
-      }
-      const char* wb = wst_b + (gst & (kStages - 1)) * (kWStage * 4) + (qd >> 1) * 8192 + wrow + wswz[qd & 1];
-#pragma unroll
-      for (int c = 0; c < NCB; ++c) wv[slot][c] = *reinterpret_cast<const float4*>(wb + c * (16 * 128));
-    };
-    auto transform = [&](int Q, int slot) {                   // v[slot] = this lane's four channels of V_xi for quarter Q (patch values in pr[Q & 1])
-      const int rs = Q & 1;
-      const int xi = (Q >> 2) & (kXi - 1);
-      const int i = xi >> 2, j = xi & 3;
-      const float* p0 = reinterpret_cast<const float*>(&pr[rs][0]);
-      const float* p1 = reinterpret_cast<const float*>(&pr[rs][1]);
-      const float* p2 = reinterpret_cast<const float*>(&pr[rs][2]);
-      const float* p3 = reinterpret_cast<const float*>(&pr[rs][3]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float top = kBneg[j] ? p0[k] - p1[k] : p0[k] + p1[k];
-        const float bot = kBneg[j] ? p2[k] - p3[k] : p2[k] + p3[k];
-        v[slot][k] = kBneg[i] ? top - bot : top + bot;
-        if (HIFIHR_W2_ABLATE == 4) v[slot][k] = p0[k];
-      }
-    };
-    floatx4 Y[4][NCB], M[2][NCB];
-#if HIFIHR_W2_ABLATE == 5
-    floatx4 M2[NCB];
-#pragma unroll
-    for (int c = 0; c < NCB; ++c) M2[c] = floatx4{0.f, 0.f, 0.f, 0.f};
-#endif
+    F4 raw[8];                                                // patch rows (ra, rb) x columns 0..3 of one 16-channel quarter
+    F4 V[4];                                                  // the four positions' operands of a quarter
+    float4 wv[2][NCB];                                        // weights of one position of a quarter, two buffers (j & 1)
+    floatx4 Y[4][NCB], M[4][NCB];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int c = 0; c < NCB; ++c) Y[p][c] = floatx4{0.f, 0.f, 0.f, 0.f};
-    auto fold = [&](int xi) {                                 // M_xi into the outputs it feeds: A^T[p >> 1][i] A^T[p & 1][j]
-      const int i = xi >> 2, j = xi & 3;
+    // quarter Q = 2 s + q of the tile: stage s = (i = s >> 1, h = s & 1), channels 32 h + 16 q + 4 g .. + 3
+    auto read_raw = [&](int Q) {
+      const int i = (Q >> 2) & 3, qd = Q & 3;                 // qd = 2 h + q: the quarter's channel offset
+      const char* hb = halo_b + hoff + qd * 64;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int co = kAt[p >> 1][i] * kAt[p & 1][j];
-        if (co == 1) {
-#pragma unroll
-          for (int c = 0; c < NCB; ++c) Y[p][c] += M[xi & 1][c];
-        } else if (co == -1) {
-#pragma unroll
-          for (int c = 0; c < NCB; ++c) Y[p][c] -= M[xi & 1][c];
-        }
+      for (int c = 0; c < 4; ++c) {
+        raw[c] = ld_f4(hb + (kBa[i] * kHP + c) * (kPixF * 4));
+        raw[4 + c] = ld_f4(hb + (kBb[i] * kHP + c) * (kPixF * 4));
       }
     };
-    read_w(gt, 0, 0);
-    read_w(gt, 1, 1);
-    read_raw(0, 0);
-    read_raw(1, 1);
-    transform(0, 0);
+    auto read_w = [&](int gst, int q, int j) {                // weights of position j, quarter q of global stage gst
+      const char* wb = wst_b + (gst & 1) * (kW2Stage * 4) + j * 8192 + wrow + wswz[q];
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) wv[j & 1][c] = *reinterpret_cast<const float4*>(wb + c * (16 * 128));
+    };
+    auto transform = [&](int Q) {                             // raw -> V
+      const int i = (Q >> 2) & 3;
+      F4 R[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) R[c] = addsub(raw[c], raw[4 + c], kBneg[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        V[j] = addsub(R[kBa[j]], R[kBb[j]], kBneg[j]);
+        if (HIFIHR_W2_ABLATE == 4) V[j] = raw[j];
+      }
+    };
+    auto fold = [&](int i) {                                  // row i's accumulators into the outputs they feed: A^T[p >> 1][i] A^T[p & 1][j]
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int co = kAt[p >> 1][i] * kAt[p & 1][j];
+          if (co == 1) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) Y[p][c] += M[j][c];
+          } else if (co == -1) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) Y[p][c] -= M[j][c];
+          }
+        }
+    };
+    read_raw(0);
 #if defined(HIFIHR_HALO_STAMP)
     const unsigned long long l0 = HALO_T(), r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll
-    for (int xi = 0; xi < kXi; ++xi, ++gt) {
+    for (int s = 0; s < kW2Stages; ++s, ++gs) {
 #pragma unroll
-      for (int c = 0; c < NCB; ++c) M[xi & 1][c] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int Q = 4 * xi + qd;
-        // LDS reads, one per MFMA slot: first the patch values of quarter Q + 2 (the transform at the head of the next iteration consumes
-        // them: >= 4 MFMA slots later), then the weights of Q + 2 (past qd = 1 they belong to the next stage: landed, confirmed at barrier
-        // gt - 1) -- read two quarters ahead, the head of the next iteration's MFMAs would otherwise wait for a read issued 2 slots earlier
-        read_raw(Q + 2, Q & 1);                               // (past the tile's end: addresses stay inside the halo, values never used)
-        if (qd < 2) read_w(gt, qd + 2, (Q + 2) % 3);
-        else read_w(gt + 1, qd - 2, (Q + 2) % 3);
-        transform(Q + 1, (Q + 1) & 1);
-        if (qd == 1 && xi > 0) fold(xi - 1);                  // the previous position's accumulators: its MFMAs retired long ago
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int c = 0; c < NCB; ++c) {
-#if HIFIHR_W2_ABLATE == 5
-            floatx4& acc = (k & 1) ? M2[c] : M[xi & 1][c];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(&wv[Q % 3][c])[k], v[Q & 1][k], acc, 0, 0, 0);
-#else
-            M[xi & 1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(&wv[Q % 3][c])[k], v[Q & 1][k], M[xi & 1][c], 0, 0, 0);
-#endif
-          }
-        // one LDS read and two or three VALU instructions behind every MFMA
-#pragma unroll
-        for (int n = 0; n < (HIFIHR_W2_ABLATE == 6 ? 0 : 4 + NCB); ++n) {
-          HIFIHR_SCHED_GROUP(0x008, 1);
-          HIFIHR_SCHED_GROUP(0x100, 1);
-          HIFIHR_SCHED_GROUP(0x002, NCB == 2 ? 2 : 5);
+      for (int q = 0; q < 2; ++q) {
+        const int Q = 2 * s + q;
+        if (q == 0) {
+          read_w(gs, 0, 0);                                   // (stage gs landed: confirmed at barrier gs - 1)
+          if ((s & 1) == 0 && s > 0) fold((s >> 1) - 1);      // the previous row: its MFMAs retired before the barrier
         }
-#if HIFIHR_W2_ABLATE != 6
-        if (NCB == 2) HIFIHR_SCHED_GROUP(0x008, 2);
-        HIFIHR_PIN();
-#endif
+        transform(Q);
+        if (Q + 1 < 2 * kW2Stages) read_raw(Q + 1);           // lands behind this quarter's MFMAs (the next tile's first quarter is read
+                                                              // at its start: another halo buffer)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < 3) read_w(gs, q, j + 1);
+          else if (q == 0) read_w(gs, 1, 0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+              // the row's first quarter starts from zero
+              const floatx4 acc = ((Q & 3) == 0 && k == 0) ? floatx4{0.f, 0.f, 0.f, 0.f} : M[j][c];
+              M[j][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(&wv[j & 1][c])[k], comp(V[j], k), acc, 0, 0, 0);
+            }
+          // the prefetch FIRST: left alone the scheduler sinks it below this position's MFMAs (the two weight buffers then share
+          // registers) and the next position starts by waiting for the LDS -- 8 exposed latencies per stage
+          HIFIHR_SCHED_GROUP(0x100, NCB);
+          HIFIHR_SCHED_GROUP(0x008, 4 * NCB);
+          HIFIHR_PIN();
+        }
       }
 #if defined(HIFIHR_HALO_STAMP)
-      HIFIHR_TOUCH(M[xi & 1][0][0]);
+      HIFIHR_TOUCH(M[0][0][0]);
       const unsigned long long b0 = HALO_T();
 #endif
-      W2_BARRIER();                                  // barrier gt
+      HIFIHR_RAW_BARRIER();                                  // barrier gs
 #if defined(HIFIHR_HALO_STAMP)
       st_bar += HALO_T() - b0;
 #endif
@@ -667,11 +661,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
     const unsigned long long l1 = HALO_T();
     st_loop += l1 - l0; st_real += __builtin_amdgcn_s_memrealtime() - r0;
 #endif
-    fold(kXi - 1);
-#if HIFIHR_W2_ABLATE == 5
-#pragma unroll
-    for (int c = 0; c < NCB; ++c) Y[0][c] += M2[c];
-#endif
+    fold(3);
     // epilogue: register e of Y[2 py + px][c] = out[y0 + 2 ty2 + py][x0 + 2 tx2 + px][16 (cb0 + c) + 4 g + e]
     if (tt < (t.rows >> 1) * 7) {
       const int ty2 = tt / 7, tx2 = tt - 7 * ty2;
@@ -692,11 +682,13 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
               if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
             *reinterpret_cast<float4*>(o) = v;
+#if HIFIHR_W2_ABLATE != 7
             if (n == 0) { k4[0] = v.x; k4[1] = v.y; k4[2] = v.z; k4[3] = v.w; }
             const float d0 = v.x - k4[0], d1 = v.y - k4[1], d2 = v.z - k4[2], d3 = v.w - k4[3];
             s4[0] += d0; q4[0] += d0 * d0; s4[1] += d1; q4[1] += d1 * d1;
             s4[2] += d2; q4[2] += d2 * d2; s4[3] += d3; q4[3] += d3 * d3;
             ++n;
+#endif
           }
         };
         if (NCB == 2 ? c == 0 : rbw == 0) put(sk[0], ssum[0], ssq[0], sn[0]);
@@ -708,7 +700,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
 #endif
   };
   for (int ti = 0; ti < ntiles; ++ti) {
-    const Tile t = tile_of(a.H, a.ctiles, cur, s_hi);
+    const Tile t = tile_of(a.H, a.ctiles, cur, s_hi, s_lo, lead);
     cur += t.rows;
     if (t.rows > 4) run_tile(std::integral_constant<int, 2>{}, t, ti & 1);
     else run_tile(std::integral_constant<int, 1>{}, t, ti & 1);

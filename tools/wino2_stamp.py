@@ -6,7 +6,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import torch
 from hifihr_amd._lib import HifihrLib
-lib = HifihrLib(os.path.join(R, "tools", "_probe", "libhifihr_halo_stamp.so"))
+lib = HifihrLib(os.environ.get("STAMP_LIB") or os.path.join(R, "tools", "_probe", "libhifihr_halo_stamp.so"))
 read = lib.c.hifihr_halo_stamp_read
 read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 for (B, H, W) in ((32, 56, 56), (48, 224, 224)):
@@ -27,6 +27,6 @@ for (B, H, W) in ((32, 56, 56), (48, 224, 224)):
     us = e0.elapsed_time(e1) / n * 1e3
     ch, wgs = max(1, v[2]), max(1, v[4])
     mhz = v[0] / max(1, v[1]) * 100
-    print(f"B={B} {H}x{W}: {us:.1f} us/launch; {wgs // n} workgroups; {v[0] / ch:.0f} cycles per stage in the loops (ideal 1024 on a full tile), {v[3] / ch:.0f} of "
+    print(f"B={B} {H}x{W}: {us:.1f} us/launch; {wgs // n} workgroups; {v[0] / ch:.0f} cycles per stage in the loops (ideal 2048 on a full tile: 64 MFMAs), {v[3] / ch:.0f} of "
           f"them at the barrier; clock {mhz:.0f} MHz; per workgroup: entry -> exit {v[5] / wgs:.0f} cycles = {v[5] / wgs / mhz:.1f} us, stage loops {v[0] / wgs:.0f}, "
           f"epilogues {v[6] / wgs:.0f}; loader wave 0 waits on vmcnt {v[7] / wgs:.0f} cycles per workgroup")
