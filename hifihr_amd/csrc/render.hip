@@ -72,45 +72,78 @@ __global__ __launch_bounds__(256) void render_vertex_kernel(RenderDev r, const f
 // Also packs the face's 12 vertex records (NDC, position, unit normal, colour of its three corners: kFaceRec float4 = 192 bytes) into
 // frec[b][f]: the tile kernels then fetch a winning face with ONE level of indirection and twelve independent 16-byte loads instead
 // of face -> three vertex indices -> twelve gathers (two dependent global latencies per distinct face of a pixel, ~2 us each).
+// Round 3, second form: a workgroup is 256 faces x 4 lanes.  The four lanes of a face pack three of its twelve vertex records each (192
+// contiguous bytes per face); lane 0 bins: the face's tile range by two binary searches per axis over the SAME predicates the linear scan
+// evaluated (28 tiles per axis at 224^2: 10 evaluations instead of 56), the appends counted in LDS first -- one global atomic per
+// (workgroup, touched tile) reserves the workgroup's run of list slots, where every (face, tile) pair used to pay a returning atomic on
+// the ~60 counters the hand covers (3 000 per image on ~10 cache lines).  44 -> see profiles/r03_time_render.txt.
+constexpr int kBinFaces = 256;
 template <int AA, int TILE>
-__global__ __launch_bounds__(256) void render_bin_kernel(RenderDev r, const float4* __restrict__ vndc, const float4* __restrict__ vpos,
-                                                        const float4* __restrict__ vnrm, const float4* __restrict__ vcol,
-                                                        float4* __restrict__ frec, int* __restrict__ tile_cnt,
-                                                        int* __restrict__ tile_list) {
+__global__ __launch_bounds__(4 * kBinFaces) void render_bin_kernel(RenderDev r, const float4* __restrict__ vndc, const float4* __restrict__ vpos,
+                                                                  const float4* __restrict__ vnrm, const float4* __restrict__ vcol,
+                                                                  float4* __restrict__ frec, int* __restrict__ tile_cnt,
+                                                                  int* __restrict__ tile_list) {
+  HIP_DYNAMIC_SHARED(int, s_bin)                       // [tiles^2] counts of this workgroup, then [tiles^2] the reserved list offsets
   const int b = blockIdx.y;
-  const int f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= r.F) return;
-  const int H = r.H, S = H * AA, tiles = (H + TILE - 1) / TILE;
-  const float4* vb = vndc + (size_t)b * r.V;
-  const int i0 = r.faces[3 * f], i1 = r.faces[3 * f + 1], i2 = r.faces[3 * f + 2];
-  const float4 a = vb[i0], c = vb[i1], d = vb[i2];
-  if (frec != nullptr) {
-    const size_t vo = (size_t)b * r.V;
-    float4* q = frec + ((size_t)b * r.F + f) * kFaceRec;
-    q[0] = a; q[1] = c; q[2] = d;
-    q[3] = vpos[vo + i0]; q[4] = vpos[vo + i1]; q[5] = vpos[vo + i2];
-    q[6] = vnrm[vo + i0]; q[7] = vnrm[vo + i1]; q[8] = vnrm[vo + i2];
-    q[9] = vcol[vo + i0]; q[10] = vcol[vo + i1]; q[11] = vcol[vo + i2];
+  const int part = threadIdx.x & 3;
+  const int f = blockIdx.x * kBinFaces + (threadIdx.x >> 2);
+  const int H = r.H, S = H * AA, tiles = (H + TILE - 1) / TILE, nt = tiles * tiles;
+  int* const s_cnt = s_bin;
+  int* const s_base = s_bin + nt;
+  for (int t = threadIdx.x; t < nt; t += 4 * kBinFaces) s_cnt[t] = 0;
+  const bool live = f < r.F;
+  int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+  if (live) {
+    const float4* vb = vndc + (size_t)b * r.V;
+    const int i0 = r.faces[3 * f], i1 = r.faces[3 * f + 1], i2 = r.faces[3 * f + 2];
+    if (frec != nullptr) {
+      const size_t vo = (size_t)b * r.V;
+      const float4* src = part == 0 ? vndc : (part == 1 ? vpos : (part == 2 ? vnrm : vcol));
+      float4* q = frec + ((size_t)b * r.F + f) * kFaceRec + 3 * part;
+      q[0] = src[vo + i0]; q[1] = src[vo + i1]; q[2] = src[vo + i2];
+    }
+    if (part == 0) {
+      const float4 a = vb[i0], c = vb[i1], d = vb[i2];
+      FaceXYZ fc;
+      fc.x0 = a.x; fc.y0 = a.y; fc.z0 = a.z; fc.x1 = c.x; fc.y1 = c.y; fc.z1 = c.z; fc.x2 = d.x; fc.y2 = d.y; fc.z2 = d.z;
+      if (!face_is_rejected(fc)) {
+        const float xmin = fminf(fc.x0, fminf(fc.x1, fc.x2)), xmax = fmaxf(fc.x0, fmaxf(fc.x1, fc.x2));
+        const float ymin = fminf(fc.y0, fminf(fc.y1, fc.y2)), ymax = fmaxf(fc.y0, fmaxf(fc.y1, fc.y2));
+        // tile t spans samples [t * TILE * AA, t * TILE * AA + n * AA - 1]; its NDC bounds are the ones render_fwd2_kernel tests against
+        // (index 0 holds the largest coordinate, so both bounds fall with t).  A tile is listed when !(vmin > hi_t) && !(vmax < lo_t): the
+        // first holds for t <= T1, the second for t >= T0 (negated comparisons: a NaN coordinate lists the face in every tile, as before).
+        const auto hi_of = [&](int t) { return pix_to_ndc(S - 1 - min(t * TILE * AA, S - 1), S); };
+        const auto lo_of = [&](int t) { const int o = t * TILE, n = min(TILE, H - o); return pix_to_ndc(S - 1 - min(o * AA + n * AA - 1, S - 1), S); };
+        const auto last_le_hi = [&](float vmin) {        // largest t with !(vmin > hi_t), -1 if none
+          int lo = -1, hi = tiles - 1;
+          while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (!(vmin > hi_of(m))) lo = m; else hi = m - 1; }
+          return lo;
+        };
+        const auto first_ge_lo = [&](float vmax) {       // smallest t with !(vmax < lo_t), tiles if none
+          int lo = 0, hi = tiles;
+          while (lo < hi) { const int m = (lo + hi) >> 1; if (!(vmax < lo_of(m))) hi = m; else lo = m + 1; }
+          return lo;
+        };
+        tx0 = first_ge_lo(xmax); tx1 = last_le_hi(xmin);
+        ty0 = first_ge_lo(ymax); ty1 = last_le_hi(ymin);
+      }
+    }
   }
-  FaceXYZ fc;
-  fc.x0 = a.x; fc.y0 = a.y; fc.z0 = a.z; fc.x1 = c.x; fc.y1 = c.y; fc.z1 = c.z; fc.x2 = d.x; fc.y2 = d.y; fc.z2 = d.z;
-  if (face_is_rejected(fc)) return;
-  const float xmin = fminf(fc.x0, fminf(fc.x1, fc.x2)), xmax = fmaxf(fc.x0, fmaxf(fc.x1, fc.x2));
-  const float ymin = fminf(fc.y0, fminf(fc.y1, fc.y2)), ymax = fmaxf(fc.y0, fmaxf(fc.y1, fc.y2));
-  // tile t spans samples [t * kTile * AA, t * kTile * AA + n * AA - 1]; its NDC bounds are the ones render_fwd2_kernel tests against
-  // (index 0 holds the largest coordinate).  Negated comparisons keep a face with a NaN coordinate in every tile, as before.
-  int tx0 = tiles, tx1 = -1, ty0 = tiles, ty1 = -1;
-  for (int t = 0; t < tiles; ++t) {
-    const int o = t * TILE, n = min(TILE, H - o);
-    const float hi = pix_to_ndc(S - 1 - min(o * AA, S - 1), S), lo = pix_to_ndc(S - 1 - min(o * AA + n * AA - 1, S - 1), S);
-    if (!(xmin > hi || xmax < lo)) { tx0 = min(tx0, t); tx1 = t; }
-    if (!(ymin > hi || ymax < lo)) { ty0 = min(ty0, t); ty1 = t; }
+  __syncthreads();
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&s_cnt[ty * tiles + tx], 1);
+  __syncthreads();
+  for (int t = threadIdx.x; t < nt; t += 4 * kBinFaces) {
+    const int c = s_cnt[t];
+    if (c > 0) s_base[t] = atomicAdd(tile_cnt + (size_t)b * nt + t, c);
+    s_cnt[t] = 0;
   }
+  __syncthreads();
   for (int ty = ty0; ty <= ty1; ++ty)
     for (int tx = tx0; tx <= tx1; ++tx) {
-      const size_t tile = ((size_t)b * tiles + ty) * tiles + tx;
-      const int slot = atomicAdd(tile_cnt + tile, 1);
-      tile_list[tile * r.F + slot] = f;
+      const int t = ty * tiles + tx;
+      const int slot = s_base[t] + atomicAdd(&s_cnt[t], 1);
+      tile_list[((size_t)b * nt + t) * r.F + slot] = f;
     }
 }
 
@@ -586,14 +619,15 @@ hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float
   const int tiles = (r.H + te - 1) / te;
   hipLaunchKernelGGL(render_vertex_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, vcolors, vcol_bstride, cam,
                      vndc, vpos, vnrm, vcol, tile_cnt, tiles * tiles);
-  const dim3 bgrid((r.F + 255) / 256, B);
+  const dim3 bgrid((r.F + kBinFaces - 1) / kBinFaces, B);
   static const int xm = [] { const char* e = getenv("HIFIHR_RENDER_XCD"); return e ? atoi(e) : 0; }();      // A/B: images pinned to XCDs
   const dim3 grid1((unsigned)((xm ? 8 * ((B + 7) / 8) : B) * tiles * tiles));
   float4* frec = face_records(r, B, ws);
   const TexUvDev td = uv != nullptr ? TexUvDev{uv->faces_uvs, uv->verts_uvs, uv->maps, nullptr, uv->TH, uv->TW} : TexUvDev{};
 #define HIFIHR_RENDER_FWD2(AA_, T_)                                                                                                      \
   {                                                                                                                                     \
-    hipLaunchKernelGGL((render_bin_kernel<AA_, T_>), bgrid, dim3(256), 0, st, r, vndc, vpos, vnrm, vcol, frec, tile_cnt, tile_list);     \
+    hipLaunchKernelGGL((render_bin_kernel<AA_, T_>), bgrid, dim3(4 * kBinFaces), (size_t)2 * tiles * tiles * sizeof(int), st, r, vndc,     \
+                       vpos, vnrm, vcol, frec, tile_cnt, tile_list);                                                                    \
     if (uv != nullptr)                                                                                                                  \
       hipLaunchKernelGGL((render_fwd2_kernel<AA_, T_, true>), grid1, dim3(kF2Threads), sizeof(Fwd2Lds<AA_, T_>), st, r, frec, light_color, \
                          light_dir, rgba, face_id, tile_cnt, tile_list, td, B, xm);                                                     \
