@@ -4,6 +4,8 @@ import json
 import os
 import sys
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -60,6 +62,17 @@ def test_train_on_ho3d_frames(tmp_path, capsys):
         out = capsys.readouterr().out
         assert "HO3D: 32 frames resident" in out and "Done!" in out and "nan" not in out.lower()
         assert (tmp_path / "run" / "model" / "texturehand_latest.t7").exists()
+        # the periodic test of the epoch driver = the challenge dump of the evaluation split (box-derived crops, root joint): 32 frames,
+        # 21 joints in the HO-3D order and 778 vertices each (reference train_hrnet.py:124-136, 286-293)
+        assert "[train_hrnet] HO3D test:" in out
+        dump = json.load(open(tmp_path / "run" / "json" / "test" / "1" / "pred.json"))
+        assert len(dump) == 2 and len(dump[0]) == 32 and len(dump[1]) == 32
+        assert np.asarray(dump[0]).shape == (32, 21, 3) and np.asarray(dump[1]).shape == (32, 778, 3) and np.isfinite(np.asarray(dump[0])).all()
+        # evaluation-only mode on the same frames
+        cfg["mode"] = ["evaluation"]
+        f.write_text(json.dumps(cfg))
+        assert T.main(["--config_json", str(f), "--dataset", "HO3D", "--synthetic_size", "16"]) == 0
+        assert "[train_hrnet] HO3D evaluation:" in capsys.readouterr().out
     finally:
         torch.cuda.synchronize()
         torch.cuda.set_stream(prev)

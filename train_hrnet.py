@@ -9,7 +9,9 @@ package's device-resident pieces:
               Source: --freihand_cache <npz with images u8 [n,224,224,3], masks u8, Ks, joints, verts> (pre-decoded by the user;
               JPEG decoding is outside the hot path) or, by default, a seeded synthetic FreiHAND-shaped set (--synthetic_size).
               --dataset HO3D: hifihr_amd.data.HO3DDeviceCache -- 480 x 640 frames in HBM, the reference's hand crop (window from the
-              projected joints, Pillow-exact crop + resize to 224) on the device; --ho3d_cache <npz> or seeded synthetic frames.
+              projected joints, Pillow-exact crop + resize to 224) on the device; --ho3d_cache <npz> or seeded synthetic frames.  The epoch
+              driver's periodic test and the evaluation mode write the challenge dump `<base_out_path>/json/test/<epoch>/pred.json` from the
+              evaluation split (--ho3d_eval_cache <npz>: hand boxes + root joints; reference train_hrnet.py:124-136, 286-293).
   step        hifihr_amd.traineval.GraphedTrainStep (hipGraph replay) or the eager step (--graph 0)
   multi-GPU   one process per GPU under torch.distributed.run; rank r takes every world-th batch slice; RCCL all-reduce of the
               flat gradient buffer (hifihr_amd/dist.py).  Replaces nn.DataParallel (:560).
@@ -36,6 +38,9 @@ def parse(argv=None):
     ap.add_argument("--freihand_cache", default=None, help="npz: images, masks, Ks, joints, verts [, eval_* counterparts]")
     ap.add_argument("--dataset", default="FreiHand", choices=["FreiHand", "HO3D"],
                     help="HO3D: train on 480 x 640 frames through hifihr_amd.data.HO3DDeviceCache (the reference's hand crop on the device)")
+    ap.add_argument("--ho3d_eval_cache", default=None, help="npz of the HO-3D EVALUATION split: images u8 [n,480,640,3], Ks [n,3,3], bboxes "
+                    "[n,2,2] ((x0, y0), (x1, y1)), root_xyz [n,3] (the split has a hand box and the root joint, no 21 joints: dataset.py:1071-1080); "
+                    "without it the evaluation pass runs on the training frames with boxes / roots derived from their joints")
     ap.add_argument("--ho3d_cache", default=None, help="npz: images u8 [n,480,640,3], hand_masks u8 [n,480,640], Ks [n,3,3] (camMat . cam_extr), "
                                                        "xyz21 [n,21,3]; default: seeded synthetic frames")
     ap.add_argument("--synthetic_size", type=int, default=512)
@@ -62,6 +67,7 @@ def build_args(cli):
         if not hasattr(args, k):
             setattr(args, k, v)
     args.state_output = os.path.join(args.base_out_path, "model")       # options/train_options.py:208-220
+    args.pred_output = os.path.join(args.base_out_path, "json")         # :214 (the pred.json dumps)
     args.texture_stand_in = 0
     if args.hand_model == "nimble" and cli.nimble_layer in ("synthetic", "synthetic-uv"):
         print("[train_hrnet] hand_model 'nimble': NIMBLE-shaped layer on seeded synthetic tables (hifihr_amd/nimble_tables.py); the real "
@@ -119,6 +125,11 @@ def train_ho3d(cli, args, model, loss_func, opt, sched, reducer, current_epoch, 
                                         device=device, images="render")
     cache = HO3DDeviceCache(**frames, device=device)
     say(f"[train_hrnet] HO3D: {cache.n} frames resident on {device}; world {world}; encoder {args.pretrain}; losses {args.losses}")
+    eval_cache = ho3d_eval_cache(cli, frames, device) if rank == 0 else None
+    if "training" not in args.mode:                       # evaluation only (reference train_hrnet.py:487-496)
+        if rank == 0:
+            say("[train_hrnet] HO3D evaluation:", run_evaluation_ho3d(model, eval_cache, args, device, current_epoch))
+        return 0
     B = args.train_batch
     gen = torch.Generator().manual_seed(1000 + current_epoch)
     noise_gen = torch.Generator().manual_seed(77 + rank)
@@ -175,6 +186,8 @@ def train_ho3d(cli, args, model, loss_func, opt, sched, reducer, current_epoch, 
         if (epoch + current_epoch) % args.save_interval == 0 or (cli.max_iters and it >= cli.max_iters):
             if rank == 0:
                 say("[train_hrnet] saved", save_model(model, opt, sched, epoch, current_epoch, args))
+                # the periodic test of the reference's epoch driver (:470-480): on HO-3D it is the challenge dump
+                say("[train_hrnet] HO3D test:", run_evaluation_ho3d(model, eval_cache, args, device, epoch + current_epoch))
         sched.step()
         if cli.max_iters and it >= cli.max_iters:
             break
@@ -183,6 +196,45 @@ def train_ho3d(cli, args, model, loss_func, opt, sched, reducer, current_epoch, 
         torch.distributed.destroy_process_group()
     say("Done!")
     return 0
+
+
+def ho3d_eval_cache(cli, frames, device):
+    """The HO-3D evaluation split as an HO3DDeviceCache (crop window from the hand box, root joint instead of 21 joints: reference
+    data/dataset.py:1071-1080).  From --ho3d_eval_cache, else derived from the training frames: box = the projected joints' bounds,
+    root = joint 0 of the HO-3D order."""
+    from hifihr_amd.data import HO3DDeviceCache
+    if cli.ho3d_eval_cache:
+        z = np.load(cli.ho3d_eval_cache)
+        n = z["images"].shape[0]
+        masks = z["hand_masks"] if "hand_masks" in z else np.zeros((n,) + z["images"].shape[1:3], np.uint8)
+        return HO3DDeviceCache(z["images"], masks, z["Ks"], np.zeros((n, 21, 3), np.float32) + z["root_xyz"][:, None], device=device,
+                               bboxes=z["bboxes"], root_xyz=z["root_xyz"])
+    Ks, xyz = np.asarray(frames["Ks"], np.float32), np.asarray(frames["xyz21"], np.float32)
+    uvw = np.einsum("nij,nkj->nki", Ks, xyz)
+    uv = uvw[..., :2] / uvw[..., 2:3]
+    boxes = np.stack([uv.min(1), uv.max(1)], 1)
+    return HO3DDeviceCache(frames["images_u8"], frames["hand_masks_u8"], Ks, xyz, device=device, bboxes=boxes, root_xyz=xyz[:, 0])
+
+
+def run_evaluation_ho3d(model, cache, args, device, epoch):
+    """The reference's HO-3D evaluation pass (train_hrnet.py:55-64 the evaluation queries, :124-136 joints back in the HO-3D order and
+    OpenGL axes, :286-293 `pred.json` for the challenge server; texture metrics when rendering): no ground truth exists for this split,
+    the product is the dump.  -> (path, n, texture metrics)."""
+    from hifihr_amd.evaluate import Evaluator
+    from hifihr_amd.traineval import data_dic
+    ev = Evaluator()
+    model.eval()
+    with torch.no_grad():
+        for lo in range(0, cache.n, args.val_batch):
+            idx = torch.arange(lo, min(cache.n, lo + args.val_batch))
+            zeros = np.zeros((len(idx), 2), np.float32)
+            ex = data_dic(cache.batch(idx, center_noise=zeros, scale_noise=np.ones(len(idx), np.float32)), "HO3D", "evaluation", args, device=device)
+            out = model("HO3D", False, ex["imgs"], Ks=ex["Ps"], root_xyz=ex["root_xyz"].unsqueeze(1))
+            ev.collect(out, ex, "HO3D", render=args.render)
+    model.train()
+    path = os.path.join(args.pred_output, "test", str(epoch), "pred.json")                     # train_hrnet.py:286-290
+    n, _ = ev.dump(path)
+    return path, n, ev.summary()
 
 
 def run_evaluation(model, cache, arrays, args, device):
