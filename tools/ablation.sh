@@ -11,6 +11,7 @@ run() {   # label, then VAR=value assignments / bench flags
 }
 run "default (final tree)"
 run "batch-norm NOT fused into the Winograd transforms (HIFIHR_BN_WINO_FUSE=0)" HIFIHR_BN_WINO_FUSE=0
+run "layer 1 on the direct halo kernel, not the one-launch Winograd (HIFIHR_CONV_WINO2=0)" HIFIHR_CONV_WINO2=0
 run "batch-norm backward unfused, forward fused (HIFIHR_BN_WINO_BWD=0)" HIFIHR_BN_WINO_BWD=0
 run "rasteriser forward on 16x16 tiles (HIFIHR_RENDER_TILE=16)" HIFIHR_RENDER_TILE=16
 run "stem BN+ReLU+max-pool unfused (HIFIHR_BN_POOL=0)" HIFIHR_BN_POOL=0

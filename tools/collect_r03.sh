@@ -24,6 +24,8 @@ bash tools/kernel_traffic.sh > /dev/null 2>&1; cp gpurun_out/r03_kernel_traffic.
 bash tools/pmc_probe.sh render "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" render_only.py > $O/r03_pmc_render_sq_counters.txt 2>&1
 python3 tools/time_render.py 2>&1 | grep -v amdgpu.ids > $O/r03_time_render.txt
 python3 tools/time_wino_bn.py 2>&1 | grep "H =" > $O/r03_time_wino_bn.txt
+python3 tools/time_conv_wino2.py 2>&1 | grep -v amdgpu.ids > $O/r03_time_conv_wino2.txt
+if [ -f tools/_probe/libhifihr_halo_stamp.so ]; then python3 tools/wino2_stamp.py 2>&1 | grep -v amdgpu.ids > $O/r03_wino2_stamps.txt; fi
 if [ -f tools/_probe/libhifihr_render_stamp2.so ]; then python3 tools/render_stamp2.py 2>&1 | grep -v amdgpu.ids > $O/r03_render_fwd_phase_stamps.txt; fi
 if [ "${1:-}" != quick ]; then bash tools/ablation.sh > $O/r03_ablation.txt 2>&1; fi
 ls -la $O | tail -40
