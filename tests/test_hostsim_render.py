@@ -10,7 +10,7 @@ def hostsim_lib():
     return kc.build_hostsim()
 
 
-@pytest.mark.parametrize("image_size,aa", [(32, 3), (40, 2), (24, 1)])
+@pytest.mark.parametrize("image_size,aa", [(32, 3), (40, 2), (24, 1), (36, 2), (20, 3)])     # 36, 20: a ragged last 8-pixel tile (binning by binary search)
 def test_render_fwd_bwd(hostsim_lib, synth_tables, image_size, aa):
     kc.render_case(hostsim_lib, synth_tables, "cpu", B=2, seed=10 + aa, image_size=image_size, aa=aa)
 
