@@ -100,11 +100,16 @@ def instep_kernel_times(step_fn, nsteps=3):
     in its real order, with the caches in the state the step leaves them in (a bracket around back-to-back launches of one entry point
     times warm tables and, for entries that launch helper kernels, more than the kernel).  -> {normalised kernel name: (launches per
     step, us per step)} or None when the profiler is unavailable."""
+    done = [0]
+
+    def counted():
+        done[0] += 1                                 # (before the call: a step that raised has issued some of its collectives)
+        return step_fn()
     try:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             for _ in range(nsteps):
-                step_fn()
+                counted()
             torch.cuda.synchronize()
         acc = {}
         for e in prof.events():
@@ -121,6 +126,8 @@ def instep_kernel_times(step_fn, nsteps=3):
         return {k: (c / nsteps, t / nsteps) for k, (c, t) in acc.items()} or None
     except Exception as ex:                          # measurement aid only
         print(f"[bench] in-step kernel profile unavailable: {type(ex).__name__}: {ex}", file=sys.stderr)
+        while done[0] < nsteps:                      # data parallel: the other ranks run exactly `nsteps` steps beside this one
+            counted()
         return None
 
 
@@ -428,6 +435,9 @@ def main():
     lib = ops.get_lib()
     B = a.batch
     extra = {}
+    if rank != 0:
+        for _ in range(3):                           # the steps rank 0 profiles hold the gradient exchange: every rank runs them
+            eager_resident()
     if rank == 0:
         kprof = instep_kernel_times(eager_resident, nsteps=3)
         roofs = conv_path_rooflines(ops, lib, dev, nprof, kprof)
@@ -512,10 +522,13 @@ def main():
                               else "hipGraph replay (whole step captured)")
         except Exception as e:                          # capture is an optimisation; never fail the bench on it (state is restored)
             graph_note = f"eager (hipGraph capture failed: {type(e).__name__}: {str(e)[:200]})"
+            print(f"[bench] rank {rank}: {graph_note}", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             gstep = None
         if world > 1:
-            # every rank must take the same form of the step (the two forms issue their bucket all-reduces in different orders)
+            # every rank must take the same form of the step (the forms issue their bucket all-reduces in different orders).  This is the
+            # FIRST collective after the constructors above, whose warm-up and capture are collective-free: a one-sided failure meets
+            # the other ranks here
             ok = torch.tensor([1.0 if gstep is not None else 0.0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if float(ok.item()) == 0.0 and gstep is not None:
@@ -553,10 +566,21 @@ def main():
         t_graph = timed(step_streamed)
         # third candidate: the segmented form (ResNet trunks), whose exchange overlaps backward under graph replays
         t_seg = None
+        gstep.release()
         try:
             from hifihr_amd.traineval import SegmentedGraphedTrainStep
-            gstep.release()
+            if os.environ.get("HIFIHR_DP_SEGMENTED", "1") == "0":
+                raise NotImplementedError("HIFIHR_DP_SEGMENTED=0")
             seg_step = SegmentedGraphedTrainStep(model, loss_func, opt, examples, args_ns, reducer, dat_name=dat_name)
+        except Exception as e:                       # noqa: BLE001 -- other encoders, capture failures: the single-graph form stays
+            print(f"[bench] rank {rank}: segmented step not available ({type(e).__name__}: {str(e)[:200]})", file=sys.stderr, flush=True)
+            seg_step = None
+        ok = torch.tensor([1.0 if seg_step is not None else 0.0], device=dev)      # (collective-free constructor: the ranks meet here)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0 and seg_step is not None:
+            seg_step.release()
+            seg_step = None
+        if seg_step is not None:
             whole_step, gstep = gstep, seg_step
             t_seg = timed(step_streamed)
             if t_seg < t_graph:
@@ -566,9 +590,6 @@ def main():
             else:
                 seg_step.release()
                 gstep = whole_step
-                reducer.pause_hooks(True)
-        except Exception as e:                       # noqa: BLE001 -- other encoders: the single-graph form stays
-            seg_step = None
         reducer.pause_hooks(False)
         t_eager = timed(eager_streamed)
         if t_eager < t_graph:

@@ -184,8 +184,11 @@ class GraphedTrainStep:
             with torch.cuda.stream(side):                       # warm-up on a side stream (allocator / workspace growth)
                 for _ in range(warmup):
                     if split:
+                        # NO collective in the warm-up (nor in the capture): a rank whose warm-up or capture raises can then meet the
+                        # others in the caller's agreement all-reduce, the first collective after this constructor -- with the bucket
+                        # all-reduces here, a one-sided failure left the other ranks inside collectives the failing rank never joined.
+                        # The state is restored below, so ranks stepping on local gradients meanwhile is harmless.
                         forward_backward(model, loss_func, optimizer, self.static, args, dat_name)
-                        reducer.all_reduce_flat()
                         optimizer.step()
                     else:
                         optimizer.prepare_step()
@@ -288,9 +291,8 @@ class SegmentedGraphedTrainStep:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(warmup):
+                for _ in range(warmup):                        # (collective-free, like GraphedTrainStep's: see there)
                     self._eager_segmented()
-                    reducer.all_reduce_flat()
                     optimizer.step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()

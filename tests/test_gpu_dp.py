@@ -23,6 +23,27 @@ def test_two_ranks_on_one_gpu_stay_in_sync():
     assert r.returncode == 0 and "dp sync check ok" in r.stdout
 
 
+def test_bench_multi_rank_path_runs_end_to_end():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU) -- here two ranks on the one GPU over gloo,
+    a functional run only: every rank must issue the same collectives in the same order through the profiled steps, the three step
+    forms' constructors (collective-free) with their agreement all-reduces, the timing trial and the timed region.  Round 3 found the
+    in-step kernel profile running its extra steps (which hold the gradient exchange) on rank 0 only: a collective mismatch that no
+    single-process run can see."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HIFIHR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--batch", "8"], env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-2000:]); print(r.stderr[-3000:])
+    assert r.returncode == 0
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["rccl"]["world_size"] == 2 and len(d["rccl"]["allreduce_us_per_bucket"]) == d["rccl"]["buckets"]
+    assert "trial" in d["launch_mode"]
+
+
 def test_rccl_wrapper_single_rank_roundtrip():
     """csrc/comm.hip through the C ABI: a world-size-1 communicator on this GPU; the SUM all-reduce and the broadcast leave the buffer
     unchanged (the multi-rank path is the same calls; 8-GPU runs are the driver's)."""

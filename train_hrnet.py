@@ -151,15 +151,10 @@ def train_ho3d(cli, args, model, loss_func, opt, sched, reducer, current_epoch, 
                     stepper = GraphedTrainStep(model, loss_func, opt, ex, args, dat_name="HO3D", reducer=reducer if world > 1 else None)
                     stepper_key = lam_key
                 except Exception as e:            # noqa: BLE001
-                    if world > 1:
-                        # Under data parallelism a capture failure on ONE rank cannot fall back: the warm-up inside GraphedTrainStep
-                        # already runs bucket all-reduces, so the other ranks may be inside collectives this rank never joins -- a
-                        # flag all-reduce issued from here would be matched against them (round-2 advisor finding).  Fail loudly;
-                        # torch.distributed.run tears the other ranks down.  (--graph 0 runs the eager overlapped step.)
-                        print(f"[train_hrnet] rank {rank}: hipGraph capture failed under data parallelism ({type(e).__name__}: {e}); aborting",
-                              file=sys.stderr, flush=True)
-                        raise SystemExit(3)
-                    say(f"[train_hrnet] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+                    # GraphedTrainStep's warm-up and capture are collective-free (round 3; the round-2 advisor found the bucket all-reduces
+                    # of the old warm-up left the other ranks inside collectives a failing rank never joined), so a one-sided failure
+                    # meets the other ranks in the flag all-reduce below and every rank falls back to the eager step together
+                    print(f"[train_hrnet] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
                     ok = 0
                 if world > 1:
                     flag = torch.tensor([ok], device=device, dtype=torch.int32)
@@ -337,11 +332,8 @@ def main(argv=None):
                     stepper = GraphedTrainStep(model, loss_func, opt, ex, args, reducer=reducer if world > 1 else None)
                     stepper_key = lam_key
                 except Exception as e:            # noqa: BLE001  -- report and continue eagerly (GraphedTrainStep restored the state)
-                    if world > 1:                 # see the HO-3D loop above: no collective-safe fallback exists from here
-                        print(f"[train_hrnet] rank {rank}: hipGraph capture failed under data parallelism ({type(e).__name__}: {e}); aborting",
-                              file=sys.stderr, flush=True)
-                        raise SystemExit(3)
-                    say(f"[train_hrnet] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+                    # (collective-free constructor: the ranks meet in the flag all-reduce below -- see the HO-3D loop above)
+                    print(f"[train_hrnet] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
                     ok = 0
                 if world > 1:                     # the two step forms issue their bucket all-reduces in different orders: all ranks
                     flag = torch.tensor([ok], device=device, dtype=torch.int32)       # must take the same one
