@@ -44,6 +44,28 @@ def test_bench_multi_rank_path_runs_end_to_end():
     assert "trial" in d["launch_mode"]
 
 
+@pytest.mark.parametrize("dataset", ["FreiHand", "HO3D"])
+def test_train_front_end_multi_rank(tmp_path, dataset):
+    """train_hrnet.py under torch.distributed.run with two ranks (one GPU, gloo): graph capture agreed between the ranks, the captured
+    step + bucket exchange + Adam, periodic test / challenge dump and checkpoint on rank 0, clean shutdown."""
+    import json
+    cfg = json.load(open(os.path.join(ROOT, "tests", "data", "nimble_style_config.json")))
+    cfg.update(base_out_path=str(tmp_path / "run"), train_batch=4, val_batch=8, total_epochs=1, pretrain="res18", hand_model="mano",
+               losses=["joint_3d", "mpose", "mshape", "texture", "mrgb", "sil", "ssim_tex"])
+    f = tmp_path / "cfg.json"
+    f.write_text(json.dumps(cfg))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HIFIHR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "train_hrnet.py"), "--config_json", str(f), "--synthetic_size", "32", "--print_freq", "2"]
+    if dataset == "HO3D":
+        cmd += ["--dataset", "HO3D"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:]); print(r.stderr[-3000:])
+    assert r.returncode == 0 and "Done!" in r.stdout and "nan" not in r.stdout.lower()
+    assert (tmp_path / "run" / "model" / "texturehand_latest.t7").exists()
+
+
 def test_rccl_wrapper_single_rank_roundtrip():
     """csrc/comm.hip through the C ABI: a world-size-1 communicator on this GPU; the SUM all-reduce and the broadcast leave the buffer
     unchanged (the multi-rank path is the same calls; 8-GPU runs are the driver's)."""
