@@ -530,7 +530,8 @@ int hifihr_image_to_nhwc4_padded(const float* images, float* out, int B, int H, 
 
 int hifihr_ssim_partial_count(int planes, int H, int W) {
   if (planes <= 0 || H <= 0 || W <= 0) return 0;
-  return planes * ((H + 15) / 16) * ((W + 15) / 16);
+  const int t = hifihr::ssim_tile_edge();
+  return planes * ((H + t - 1) / t) * ((W + t - 1) / t);
 }
 
 int hifihr_ssim_fwd(const float* window11, const float* img1, const float* img2, int planes, int H, int W, float* partial,

@@ -207,6 +207,7 @@ hipError_t launch_image_to_nhwc4(const float* img, float* out, int B, int H, int
 struct SsimWindow {
   float g[11];      // normalised 1-D gaussian (sigma 1.5), as pytorch_ssim.gaussian builds it
 };
+int ssim_tile_edge();           // output tile edge of the SSIM kernels: one partial sum per tile (hifihr_ssim_partial_count)
 hipError_t launch_ssim_fwd(const SsimWindow& win, const float* img1, const float* img2, int planes, int H, int W, float* partial,
                            float* dA, float* dB, float* dC, hipStream_t st);
 hipError_t launch_ssim_bwd(const SsimWindow& win, const float* img1, const float* img2, const float* dA, const float* dB,

@@ -4,7 +4,7 @@
 // F.conv2d calls, ~10 elementwise launches and a mean in the forward, and their autograd in the backward
 // (8 MIOpen convolutions of ~1 ms each on [32,3,224,224] in the un-fused step) with one HBM-bound launch per
 // direction:
-//   ssim_fwd_kernel  one workgroup per 16x16 tile of one (batch, channel) plane: the 26x26 halo of both images is
+//   ssim_fwd_kernel  one workgroup per 32x32 tile of one (batch, channel) plane (four outputs per thread): the 42x42 halo of both images is
 //                    staged in LDS, the five windowed moments are formed separably (row pass into LDS, column pass
 //                    in registers), the SSIM value is reduced per workgroup (deterministic partial sums) and the
 //                    three derivative maps dS/dmu1, dS/dE[x^2], dS/dE[xy] are saved for the backward pass.
@@ -15,9 +15,11 @@
 
 namespace hifihr {
 
-constexpr int kST = 16;             // tile edge
+constexpr int kST = 32;             // tile edge (round 3: 16 -> 32, four outputs per thread: the 26 x 26 halo of a 16 x 16 tile cost 2.6 loads per
+                                    // output and 18 816 three-barrier workgroups per launch; 42 x 42 per 32 x 32 is 1.7)
+constexpr int kSO = kST * kST / 256; // outputs per thread
 constexpr int kSR = 5;              // window radius (11 taps)
-constexpr int kSH = kST + 2 * kSR;  // 26
+constexpr int kSH = kST + 2 * kSR;  // 42
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
 #pragma unroll
@@ -59,9 +61,12 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWindow win, const flo
     hq[0][r][c] = m1; hq[1][r][c] = m2; hq[2][r][c] = e11; hq[3][r][c] = e22; hq[4][r][c] = e12;
   }
   __syncthreads();
-  const int tx = tid % kST, ty = tid / kST;
-  const int x = ox + tx, y = oy + ty;
   float val = 0.f;
+#pragma unroll
+  for (int o4 = 0; o4 < kSO; ++o4) {
+  const int idx = tid + 256 * o4;
+  const int tx = idx % kST, ty = idx / kST;
+  const int x = ox + tx, y = oy + ty;
   if (x < W && y < H) {
     float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
@@ -74,14 +79,16 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWindow win, const flo
     const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
     const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
     const float a1 = 2.f * mu12 + C1, a2 = 2.f * s12 + C2, b1 = mu1_sq + mu2_sq + C1, b2 = s1 + s2 + C2;
-    val = (a1 * a2) / (b1 * b2);
+    const float sv = (a1 * a2) / (b1 * b2);
+    val += sv;
     if (dA) {
       const size_t o = (size_t)plane * H * W + (size_t)y * W + x;
       const float inv = 1.f / (b1 * b2);
-      dA[o] = 2.f * mu2 * (a2 - a1) * inv - 2.f * mu1 * val / b1 + 2.f * mu1 * val / b2;   // d s / d mu1 (total)
-      dB[o] = -val / b2;                                                                  // d s / d E[x^2]
+      dA[o] = 2.f * mu2 * (a2 - a1) * inv - 2.f * mu1 * sv / b1 + 2.f * mu1 * sv / b2;     // d s / d mu1 (total)
+      dB[o] = -sv / b2;                                                                   // d s / d E[x^2]
       dC[o] = 2.f * a1 * inv;                                                             // d s / d E[xy]
     }
+  }
   }
   const float tot = block_sum_256(val, red);
   if (tid == 0) partial[((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
@@ -118,18 +125,22 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWindow win, const flo
     hq[0][r][c] = a; hq[1][r][c] = b; hq[2][r][c] = cc;
   }
   __syncthreads();
-  const int tx = tid % kST, ty = tid / kST;
-  const int x = ox + tx, y = oy + ty;
-  if (x < W && y < H) {
-    float a = 0.f, b = 0.f, cc = 0.f;
+  const float sc = gscale[0] * inv_n;
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = win.g[k];
-      a += w * hq[0][ty + k][tx]; b += w * hq[1][ty + k][tx]; cc += w * hq[2][ty + k][tx];
+  for (int o4 = 0; o4 < kSO; ++o4) {
+    const int idx = tid + 256 * o4;
+    const int tx = idx % kST, ty = idx / kST;
+    const int x = ox + tx, y = oy + ty;
+    if (x < W && y < H) {
+      float a = 0.f, b = 0.f, cc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float w = win.g[k];
+        a += w * hq[0][ty + k][tx]; b += w * hq[1][ty + k][tx]; cc += w * hq[2][ty + k][tx];
+      }
+      const size_t o = po + (size_t)y * W + x;
+      gimg1[o] = sc * (a + 2.f * img1[o] * b + img2[o] * cc);
     }
-    const size_t o = po + (size_t)y * W + x;
-    const float sc = gscale[0] * inv_n;
-    gimg1[o] = sc * (a + 2.f * img1[o] * b + img2[o] * cc);
   }
 }
 
@@ -145,6 +156,8 @@ __global__ __launch_bounds__(256) void ssim_finish_kernel(const float* __restric
   const float s = block_sum_256((s0 + s1) + (s2 + s3), red);
   if (threadIdx.x == 0) out[0] = offset + scale * s;
 }
+
+int ssim_tile_edge() { return kST; }
 
 hipError_t launch_ssim_finish(const float* partial, int count, float scale, float offset, float* out, hipStream_t st) {
   hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(256), 0, st, partial, count, scale, offset, out);
