@@ -92,11 +92,13 @@ __global__ __launch_bounds__(256) void geom_loss_bwd_kernel(GeomLossArgs a, cons
   const float ce = (a.F > 0) ? gout[2] * a.lambda[2] / ((float)a.B * a.F * 3) : 0.f;
   const float cs = gout[3] * a.lambda[3] * 2.f / ((float)a.B * a.NS), cp = gout[4] * a.lambda[4] * 2.f / ((float)a.B * a.NP);
   const float* j = a.joints + (size_t)b * a.J * 3, *jg = a.joints_gt + (size_t)b * a.J * 3;
-  if (gj)
+  // blockIdx.y splits the sample's vertices (round 3: one workgroup per sample = 32 workgroups walked three vertices per thread, each a chain
+  // of dependent gathers: 28 us); the small outputs are written by the first split
+  if (gj && blockIdx.y == 0)
     for (int i = threadIdx.x; i < a.J * 3; i += 256) gj[(size_t)b * a.J * 3 + i] = cj * base_grad(a.mse, j[i] - jg[i]);
   const float* v = a.verts + (size_t)b * a.V * 3, *vg = a.verts_gt + (size_t)b * a.V * 3;
   if (gv) {
-    for (int vi = threadIdx.x; vi < a.V; vi += 256) {
+    for (int vi = blockIdx.y * 256 + threadIdx.x; vi < a.V; vi += 256 * gridDim.y) {
       float g[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) g[d] = cv * base_grad(a.mse, v[3 * vi + d] - vg[3 * vi + d]);
@@ -120,9 +122,9 @@ __global__ __launch_bounds__(256) void geom_loss_bwd_kernel(GeomLossArgs a, cons
       for (int d = 0; d < 3; ++d) gv[((size_t)b * a.V + vi) * 3 + d] = g[d];
     }
   }
-  if (gshape)
+  if (gshape && blockIdx.y == 0)
     for (int i = threadIdx.x; i < a.NS; i += 256) gshape[(size_t)b * a.NS + i] = cs * a.shape[(size_t)b * a.NS + i];
-  if (gpose)
+  if (gpose && blockIdx.y == 0)
     for (int i = threadIdx.x; i < a.NP; i += 256) gpose[(size_t)b * a.NP + i] = cp * a.pose[(size_t)b * a.NP + i];
 }
 
@@ -134,7 +136,7 @@ hipError_t launch_geom_loss_fwd(const GeomLossArgs& a, float* partial, float* ou
 
 hipError_t launch_geom_loss_bwd(const GeomLossArgs& a, const float* gout, float* gj, float* gv, float* gshape, float* gpose,
                                 hipStream_t st) {
-  hipLaunchKernelGGL(geom_loss_bwd_kernel, dim3(a.B), dim3(256), 0, st, a, gout, gj, gv, gshape, gpose);
+  hipLaunchKernelGGL(geom_loss_bwd_kernel, dim3(a.B, gv != nullptr ? (a.V + 255) / 256 : 1), dim3(256), 0, st, a, gout, gj, gv, gshape, gpose);
   return hipGetLastError();
 }
 
