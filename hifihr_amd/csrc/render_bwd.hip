@@ -49,6 +49,11 @@ __device__ __forceinline__ void flush_face(BwdAcc<HT>& A, float* __restrict__ gg
 // sample rows of a pixel on separate lanes (a third of the serial work per lane, four times the tiles in flight, the rows' per-face
 // records combined by shuffles before the LDS atomics): 199 us against 173 for this form at B = 32 -- the kernel is bound by its
 // instruction and LDS-atomic throughput, not by its slowest tile: every row lane gathers and sets up its face again.
+// Second measured alternative (round 3, late): FACE-parallel -- a workgroup per tile of the forward's binning, lane k takes listed face k,
+// loads its records once, walks the samples of its bounding box in the tile (ids staged in LDS), accumulates the whole face-in-tile
+// gradient in 36 registers without atomics, lanes of a wave converging on the gradient body each round: parity green, 1 290 us (8 x 8
+// tiles; 2 500 at 16 x 16; 1 830 with scattered global atomics instead of the LDS records).  A face holds ~45 samples where a pixel holds
+// 9: five times the serial depth per lane on no more lanes (118 k (face, tile) pairs against 132 k covered pixels).
 template <int AA, bool UV>
 __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const float4* __restrict__ frec,
                                                         const float* __restrict__ light_color,
