@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
 // A tile is 4 x 7 = 28 Winograd tiles = 2 MFMA row blocks: MFMA wave w owns row block w >> 1 and the two 16-channel column blocks of
 // half w & 1 (NCB = 2); a tile of <= 4 rows (14 tiles, 1 row block) gives wave w the single column block 2 (w & 1) + (w >> 1) (NCB = 1).
 // Per 8 x 14 tile and wave: 16 x 16 x 2 = 512 MFMAs against the direct kernel's 9 x 16 x 7 = 1008; per stage 64 MFMAs, 32 LDS reads.
-// Rows and shares are even (launcher); W % 14 == 0.  Backward-data = the same kernel on dy with U' (kind 2: transposed, rotated filter).
+// Rows and shares are even (launcher), W even (a ragged last column tile is masked in the epilogue).  Backward-data = the same kernel on dy with U' (kind 2: transposed, rotated filter).
 // Measured at layer 1 (B = 32, 56 x 56; the direct kernel: 77 us): one position per stage, transform in front of its MFMAs 59 us; three-deep
 // software pipeline of the same 58; this form 54 (in-kernel stamps: 2 400 cycles of an MFMA wave per 2 048-cycle stage + 120-200 at the
 // barrier, 4 000-5 000 per tile in the epilogue, where every workgroup stores at the same moment).  Dead ends, all measured: (1) handing
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
 #endif
     fold(3);
     // epilogue: register e of Y[2 py + px][c] = out[y0 + 2 ty2 + py][x0 + 2 tx2 + px][16 (cb0 + c) + 4 g + e]
-    if (tt < (t.rows >> 1) * 7) {
+    if (tt < (t.rows >> 1) * 7 && t.x0 + 2 * (tt % 7) < a.W) {      // (a ragged last column tile: the loader read zeros there)
       const int ty2 = tt / 7, tx2 = tt - 7 * ty2;
 #pragma unroll
       for (int c = 0; c < NCB; ++c) {
@@ -1460,10 +1460,11 @@ hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wg
   return hipGetLastError();
 }
 
-// conv_wino2_kernel: the 64 -> 64 stride-1 3x3 layers with even H and W % 14 == 0 (ResNet layer 1 at 56 x 56, VGG19 conv1_2 at 224 x 224)
+// conv_wino2_kernel: the 64 -> 64 stride-1 3x3 layers with even H and W (ResNet layer 1 at 56 x 56, VGG19 conv1_2 at 224 x 224 and, with a ragged
+// last column tile, at 512 x 512 = 36 x 14 + 8)
 bool conv_wino2_supported(int N, int H, int W, int C, int K) {
   static const int on = [] { const char* e = getenv("HIFIHR_CONV_WINO2"); return e ? atoi(e) : 1; }();
-  return on && C == 64 && K == 64 && N > 0 && H >= 2 && H % 2 == 0 && W >= kTW && W % kTW == 0 && (long)N * H * W * 64 < (1L << 31);
+  return on && C == 64 && K == 64 && N > 0 && H >= 2 && H % 2 == 0 && W >= kTW && W % 2 == 0 && (long)N * H * W * 64 < (1L << 31);
 }
 
 hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias, int relu, float* dst, float* stats, int N, int H, int W,
@@ -1474,7 +1475,7 @@ hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias
   Wino2Args a;
   a.src = src; a.U = U; a.dst = dst; a.stats = stats; a.zeros = zeros; a.bias = bias; a.relu = relu;
   a.N = N; a.H = H; a.W = W;
-  a.ctiles = W / kTW;
+  a.ctiles = (W + kTW - 1) / kTW;                           // the last column tile may be ragged (W even: whole 2 x 2 tiles)
   a.total = N * a.ctiles * H;
   int G = halo_cus();
   a.per = (a.total + G - 1) / G;

@@ -1042,7 +1042,7 @@ int hifihr_conv3x3_c64_wino_supported(int N, int H, int W, int C, int K) { retur
 int hifihr_conv3x3_c64_wino(const float* x, const float* u, const float* bias, int relu, float* y, float* stats, int N, int H, int W, void* stream) {
   if (!x || !u || !y) return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_wino: null pointer");
   if (!hifihr::conv_wino2_supported(N, H, W, 64, 64))
-    return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_wino: needs even H and W % 14 == 0 (or HIFIHR_CONV_WINO2=0 is set)");
+    return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_wino: needs even H and even W >= 14 (or HIFIHR_CONV_WINO2=0 is set)");
   HIP_TRY(hifihr::launch_conv_wino2(x, u, bias, relu, y, stats, N, H, W, (hipStream_t)stream));
   return HIFIHR_OK;
 }

@@ -302,7 +302,7 @@ int hifihr_wino_dy_transform_m(const float* dy_d, float* yt_d, int N, int H, int
  * network/res_encoder.py:364-373 -> torchvision BasicBlock conv1 / conv2 of layer1) and VGG19 conv1_2 of the perceptual loss (reference
  * utils/perceptual_loss.py:27-36).  u_d = U[16][64][64]: hifihr_wino_weight_transform(w, u, 64, 64, 0) or hifihr_weight_prep kind 1 for
  * the forward; kind 2 (the transposed, rotated filter) with x_d = dy gives backward-data.  bias_d / relu: epilogue (VGG19); stats_d: the
- * forward statistics slots of the batch norm that follows (hifihr_bn_stats_floats(64) floats, zeroed) or NULL.  H even, W % 14 == 0
+ * forward statistics slots of the batch norm that follows (hifihr_bn_stats_floats(64) floats, zeroed) or NULL.  H even, W even and >= 14
  * (hifihr_conv3x3_c64_wino_supported); results within 1e-5 (relative to the output scale) of the direct convolution. */
 int hifihr_conv3x3_c64_wino_supported(int N, int H, int W, int C, int K);
 int hifihr_conv3x3_c64_wino(const float* x_d, const float* u_d, const float* bias_d /* or NULL */, int relu, float* y_d,

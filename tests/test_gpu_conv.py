@@ -370,7 +370,7 @@ def test_resnet50_trunk_mfma_matches_torch_restatement():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,H,W", [(1, 8, 14), (2, 12, 28), (32, 56, 56), (3, 2, 14), (2, 30, 42), (1, 224, 224)])
+@pytest.mark.parametrize("N,H,W", [(1, 8, 14), (2, 12, 28), (32, 56, 56), (3, 2, 14), (2, 30, 42), (1, 224, 224), (1, 64, 512), (2, 20, 36)])
 def test_conv_wino2_kernel(lib, N, H, W):
     """conv_wino2_kernel (64 -> 64, 3x3 / stride 1 as Winograd F(2x2, 3x3) with the transforms in registers): forward + statistics and
     backward-data vs F.conv2d at layer 1's size, VGG19 conv1_2's and the tile shapes of tests/test_hostsim_conv.py."""

@@ -72,10 +72,11 @@ def test_conv_halo_layer1_shape(hostsim_lib, N, H, W):
     kc.conv_case(hostsim_lib, "cpu", N, H, W, 64, 64, 3, 1, 1, seed=H + W)
 
 
-@pytest.mark.parametrize("N,H,W", [(1, 8, 14), (2, 12, 14), (1, 4, 28), (2, 6, 28), (1, 30, 14), (3, 2, 14)])
+@pytest.mark.parametrize("N,H,W", [(1, 8, 14), (2, 12, 14), (1, 4, 28), (2, 6, 28), (1, 30, 14), (3, 2, 14), (1, 8, 20), (2, 4, 30), (1, 10, 36)])
 def test_conv_wino2_layer1_shape(hostsim_lib, N, H, W):
     """conv_wino2_kernel (csrc/conv_halo.hip): 8-row tiles (two MFMA row blocks), 4- and 2-row tiles (one row block, one column block per
-    wave), 6-row tiles, shares that cross column tiles and images (hostsim reports 4 CUs), forward + statistics and backward-data."""
+    wave), 6-row tiles, shares that cross column tiles and images (hostsim reports 4 CUs), ragged last column tiles (W = 20, 30, 36: the
+    512 x 512 perceptual loss is 36 x 14 + 8), forward + statistics and backward-data."""
     kc.conv_wino2_case(hostsim_lib, "cpu", N, H, W, seed=H + W)
 
 

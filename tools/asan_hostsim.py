@@ -13,7 +13,7 @@ lib = HifihrLib(os.path.join(R, "tests", "hostsim", "libhifihr_hostsim_asan.so")
 
 
 def conv():
-    for (N, H, W) in [(1, 8, 14), (2, 12, 14), (1, 4, 28), (3, 2, 14)]:
+    for (N, H, W) in [(1, 8, 14), (2, 12, 14), (1, 4, 28), (3, 2, 14), (1, 8, 20), (2, 4, 30)]:         # (20, 30: a ragged last column tile)
         kc.conv_wino2_case(lib, "cpu", N, H, W, seed=H + W)
     kc.conv_wino2_case(lib, "cpu", 2, 10, 14, seed=3, bias_relu=True)
     for (N, H, W) in [(2, 10, 14), (1, 6, 20), (1, 4, 15)]:
