@@ -892,7 +892,8 @@ bool conv_is_gemm(const ConvGeom& g) {
   static const int on = [] { const char* e = getenv("HIFIHR_CONV1X1_GEMM"); return e ? atoi(e) : 1; }();
   const long M = (long)g.N * g.OH * g.OW;
   return on && g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.batch <= 1 && g.OH == g.IH && g.OW == g.IW &&
-         M * (g.IC > g.OC ? g.IC : g.OC) < (1L << 31) && bgemm_nt_supported((int)M, g.OC, g.IC) && g.OC % 128 == 0;
+         M * (g.IC > g.OC ? g.IC : g.OC) < (1L << 31) &&
+         ((bgemm_nt_supported((int)M, g.OC, g.IC) && g.OC % 128 == 0) || bgemm_nt_ragged_supported((int)M, g.OC, g.IC));
 }
 
 // dw[i] += sum over the slabs, in slab order (bit-reproducible)

@@ -742,6 +742,11 @@ __device__ __forceinline__ RowsTile rows_tile_at(const BgemmArgs& a, long cur, l
   return RowsTile{p, nt, m0, (int)min(128L, lim)};
 }
 
+// RAGGED (round 3): N need not be a multiple of 128 nor K of 32 (both of 4) -- EfficientNet's 1x1 convolutions (24, 40, 48, 96, 136, 144,
+// 232, 288, 816, 1392 channels).  The loader reads the 16-byte operand segments that fall past row N of B or past column K from a page of
+// zeros, the epilogue stores and counts only columns < N; the MFMA waves are the same.  A template flag: the square Winograd products keep the
+// plain loader.
+template <bool RAGGED>
 __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long per) {
 #if defined(HIFIHR_GEMM_STAMP)       // [0] cycles in the chunk loops, [1] 100 MHz ticks of them, [2] chunks, [3] at barriers, [4] workgroups,
   const unsigned long long st_entry = __builtin_amdgcn_s_memtime();      // [5] entry -> exit, [6] epilogues, [7] entry -> barrier -1
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
   const long total = (long)a.batch * a.tiles_n * a.M;
   const long s_lo = (long)wg * per, s_hi = min(s_lo + per, total);
   if (s_lo >= s_hi) return;                                  // (uniform)
-  const int nch = a.K / 32;
+  const int nch = RAGGED ? (a.K + 31) / 32 : a.K / 32;
   int ntiles = 0;
   for (long cur = s_lo; cur < s_hi; cur += rows_tile_at(a, cur, s_hi).rows) ++ntiles;
   const int nchunks = ntiles * nch;
@@ -765,6 +770,7 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
     long cur = s_lo;
     RowsTile t = rows_tile_at(a, cur, s_hi);
     const float* src[8];
+    int kseg[8];                                             // RAGGED: first k of this lane's segment within a chunk, or 1 << 30 for a B row >= N
     auto bind = [&](const RowsTile& tt) {                    // per-lane source row of every piece for this tile (k offset added per chunk)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -774,6 +780,7 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
         const int seg = (lane & 7) ^ ((row >> 1) & 7);
         if (isA) src[i] = a.A + (size_t)tt.p * a.sa + (size_t)(tt.m0 + min(row, tt.rows - 1)) * a.lda + seg * 4;   // rows past the tile: discarded
         else src[i] = a.B + (size_t)tt.p * a.sb + (size_t)(tt.nt * 128 + row) * a.ldb + seg * 4;
+        if (RAGGED) kseg[i] = (!isA && tt.nt * 128 + row >= a.N) ? (1 << 30) : seg * 4;
       }
     };
     bind(t);
@@ -781,7 +788,11 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
     auto issue_next = [&](int gc) {
       float* base = lds + (gc & 3) * STAGE;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) HIFIHR_GLDS16(src[i] + lc * 32, base + 256 * (l + 4 * i), lane);
+      for (int i = 0; i < 8; ++i) {
+        const float* s = src[i] + lc * 32;
+        if (RAGGED) s = (kseg[i] + lc * 32 < a.K) ? s : a.zeros;       // (a row >= N: 1 << 30; the last chunk's segments past column K)
+        HIFIHR_GLDS16(s, base + 256 * (l + 4 * i), lane);
+      }
       if (++lc == nch) {
         lc = 0;
         cur += t.rows;
@@ -834,7 +845,7 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
         double sa, sb;
         stat_unshift(sn, sk[i][e], ssum[i][e], ssq[i][e], sa, sb);
         for (int o = 1; o < 16; o <<= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
-        if (r == 0) {
+        if (r == 0 && (!RAGGED || stat_nt * 128 + 32 * wave + 16 * i + 4 * g + e < a.N)) {      // (columns >= N hold zeros: no slot)
           double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (kStatSlots - 1)) * 2 * a.N + (size_t)stat_nt * 128 + 32 * wave +
                        16 * i + 4 * g + e;
           stat_atomic_add(sp, sa); stat_atomic_add(sp + a.N, sb);
@@ -919,13 +930,14 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
 #endif
     // register e of lane (r, g) of block (i, j) = C[m0 + 16 j + r][128 nt + 32 wave + 16 i + 4 g + e]
     float* C = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
+    const int col0 = t.nt * 128 + 32 * wave + 4 * g;         // (RAGGED: the lane's column blocks col0 .. + 3 and col0 + 16 .. + 19 against N)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int m = 16 * j + r;
       if (m < t.rows) {
         float* row = C + (size_t)(t.m0 + m) * a.ldc;
-        *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
-        *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
+        if (!RAGGED || col0 < a.N) *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
+        if (!RAGGED || col0 + 16 < a.N) *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
         if (a.stats != nullptr) {                              // (uniform)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -1235,7 +1247,7 @@ void bgemm_describe_batch(int tn, int M, int N, int K, int batch, char* out, int
     if ((e = getenv("HIFIHR_GEMM_NT_TILE")) != nullptr) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (N % bn) bn = 64; }
   }
   const int nload = gemm_ws_loaders();
-  if (!tn && nt_rows(N)) { snprintf(out, cap, "bgemm_nt_rows_kernel"); return; }
+  if (!tn && (nt_rows(N) || bgemm_nt_ragged_supported(M, N, K))) { snprintf(out, cap, "bgemm_nt_rows_kernel"); return; }
   if (tn && tn_rows(M, N, K, batch)) { snprintf(out, cap, "bgemm_tn_rows_kernel"); return; }
   if (!tn && bm == 128 && bn == 128 && nload > 0 && bgemm_nt_workspace_bytes(M, N, K, 16) > 0) snprintf(out, cap, "bgemm_nt_sk_kernel<%d>", nload == 2 ? 2 : 4);
   else if (bm == 128 && bn == 128 && nload > 0) snprintf(out, cap, "bgemm_ws_kernel<128, 128, %s, %d>", tn ? "true" : "false", nload == 1 ? 1 : nload == 4 ? 4 : 2);
@@ -1268,17 +1280,42 @@ size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch) {
   return sk_flag_bytes(G) + (size_t)G * 128 * 128 * sizeof(float);
 }
 
-bool bgemm_nt_stats_supported(int N) { return nt_rows(N); }      // the statistics epilogue exists in the row-share kernel only
+// ragged N / K on the row-share kernel (EfficientNet's 1x1 convolutions).  Measured at batch 48 against conv_igemm_kernel
+// (tools/time_conv1x1.py with EFFNET=1, HIFIHR_GEMM_RAGGED=0 for the other side): a wash on most shapes -- these products are 20-50 us
+// launches on 2 352-9 408 rows, bounded by their size, and the implicit GEMM's 64-column tiles waste less of a 136- or 232-wide output --
+// a win where the 128-column tiles are >= 90 % full and the reduction is long (1392 -> 384: 45 -> 35 us, 232 -> 1392: 28.5 -> 25.7), a loss
+// below (32 -> 192: 45 -> 54, 576 -> 136: 30 -> 35).  Hence: tiles >= 90 % full and K >= 128 (HIFIHR_GEMM_RAGGED=2: every shape the kernel
+// can take, for the A/B).
+bool bgemm_nt_ragged_supported(int M, int N, int K) {
+  static const int on = [] { const char* e = getenv("HIFIHR_GEMM_RAGGED"); return e ? atoi(e) : 1; }();
+  if (!on || !nt_rows(128) || M <= 0 || N < 96 || N % 4 != 0 || K < 16 || K % 4 != 0 || (N % 128 == 0 && K % 32 == 0)) return false;
+  if (on >= 2) return true;
+  return K >= 128 && 10L * N >= 9L * ((N + 127) / 128 * 128);
+}
+bool bgemm_nt_stats_supported(int N) { return nt_rows(N) || (nt_rows(128) && N >= 96 && N % 4 == 0); }      // the statistics epilogue exists in the row-share kernel only
 
 hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
                            float* stats) {
-  if (!bgemm_nt_supported(M, N, K) || batch <= 0) return hipErrorInvalidValue;
-  if (stats != nullptr && (batch != 1 || !nt_rows(N))) return hipErrorInvalidValue;
+  const bool ragged = bgemm_nt_ragged_supported(M, N, K);
+  if ((!bgemm_nt_supported(M, N, K) && !ragged) || batch <= 0) return hipErrorInvalidValue;
+  if (stats != nullptr && (batch != 1 || !(nt_rows(N) || ragged))) return hipErrorInvalidValue;
   if ((long)M * K >= (1L << 31) || (long)N * K >= (1L << 31)) return hipErrorInvalidValue;      // 32-bit element offsets
   BgemmArgs a{};
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
   a.sa = (long)M * K; a.sb = (long)N * K; a.sc = (long)M * N; a.batch = batch;
   a.stats = stats;
+  if (ragged) {
+    a.zeros = conv_halo_zero_page(st);                       // (allocated on first use outside a capture: csrc/conv_halo.hip)
+    if (a.zeros == nullptr) return hipErrorNotReady;
+    a.tiles_n = (N + 127) / 128; a.tiles_m = (M + 127) / 128; a.splits = 1; a.cps = (K + 31) / 32; a.sc_split = 0;
+    const long total = (long)batch * a.tiles_n * M;
+    const int cus = gemm_cus();
+    long per = (total + cus - 1) / cus;
+    if (per < 16) per = 16;
+    const int G = (int)((total + per - 1) / per);
+    hipLaunchKernelGGL(bgemm_nt_rows_kernel<true>, dim3(G), dim3(512), 0, st, a, per);
+    return hipGetLastError();
+  }
   if (nt_rows(N)) {
     a.tiles_n = N / 128; a.tiles_m = (M + 127) / 128; a.splits = 1; a.cps = K / 32; a.sc_split = 0;
     const long total = (long)batch * a.tiles_n * M;
@@ -1286,7 +1323,7 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
     long per = (total + cus - 1) / cus;
     if (per < 16) per = 16;
     const int G = (int)((total + per - 1) / per);
-    hipLaunchKernelGGL(bgemm_nt_rows_kernel, dim3(G), dim3(512), 0, st, a, per);
+    hipLaunchKernelGGL(bgemm_nt_rows_kernel<false>, dim3(G), dim3(512), 0, st, a, per);
     return hipGetLastError();
   }
   int bm, bn;

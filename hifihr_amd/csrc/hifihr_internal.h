@@ -319,6 +319,7 @@ struct BgemmArgs {
   int batch, tiles_m, tiles_n;
   int splits, cps;             // TN: slabs of the t range, K chunks (32 rows) per slab
   long sc_split;               // element stride between slabs of C
+  const float* zeros = nullptr;   // bgemm_nt_rows_kernel<true> (ragged N / K): >= 16 zero bytes that out-of-range operand segments are read from
   float* stats = nullptr;      // bgemm_nt_rows_kernel, batch 1 (a 1x1 convolution in front of a batch-norm): per-column sum / sum of squares of C
                                // added into the slot buffer [kStatSlots][2][N] (csrc/bn.hip), or null
 };
@@ -328,6 +329,7 @@ bool bgemm_nt_supported(int M, int N, int K);
 bool bgemm_tn_supported(int M, int N, int T);
 size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch);
 bool bgemm_nt_stats_supported(int N);      // launch_bgemm_nt(..., stats != null) is available for this N
+bool bgemm_nt_ragged_supported(int M, int N, int K);   // bgemm_nt_rows_kernel<true>: N % 4 == 0, K % 4 == 0, N not a multiple of 128 or K not of 32
 hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
                            float* stats_or_null = nullptr);      // stats: only with N % 128 == 0 and batch == 1 (else hipErrorInvalidValue)
 int bgemm_tn_parts(int M, int N, int T, int batch);

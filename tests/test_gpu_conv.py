@@ -414,6 +414,15 @@ def test_conv_1x1_runs_on_the_gemm_kernels(lib, N, H, C, K):
     kc.conv_bnstats_case(lib, "cuda", N, H, H, C, K, 1, 1, 0)
 
 
+@pytest.mark.parametrize("N,H,C,K", [(48, 7, 1392, 384), (48, 7, 232, 1392), (48, 14, 136, 816), (8, 14, 144, 240)])
+def test_conv_1x1_ragged_channels_on_the_gemm_kernel(lib, N, H, C, K):
+    """EfficientNet-b3's 1x1 convolutions whose channel counts are multiples of 4 but not of 32 / 128, at the configs[2] batch:
+    bgemm_nt_rows_kernel<RAGGED> (zero-page operand segments past row N / column K, masked epilogue and statistics)."""
+    assert lib.conv2d_describe(N, H, H, C, K, 1, 1, 1, 0, 0) == "bgemm_nt_rows_kernel"
+    kc.conv_case(lib, "cuda", N, H, H, C, K, 1, 1, 0, seed=C + K)
+    kc.conv_bnstats_case(lib, "cuda", N, H, H, C, K, 1, 1, 0)
+
+
 def test_conv_stem_wgrad_three_channel_parameter(lib):
     kc.stem_c3_wgrad_case(lib, "cuda", N=32, H=224)
     kc.stem_c3_wgrad_case(lib, "cuda", N=3, H=112, seed=2)

@@ -109,6 +109,17 @@ def test_conv_1x1_runs_on_the_gemm_kernels(hostsim_lib, N, H, W, C, K):
     kc.conv_bnstats_case(hostsim_lib, "cpu", N, H, W, C, K, 1, 1, 0)
 
 
+@pytest.mark.parametrize("N,H,W,C,K", [(1, 6, 6, 136, 232), (1, 5, 5, 144, 240), (2, 4, 4, 232, 1392), (1, 6, 6, 1392, 384), (2, 7, 5, 136, 816)])
+def test_conv_1x1_ragged_channels_run_on_the_gemm_kernel(hostsim_lib, N, H, W, C, K):
+    """EfficientNet's 1x1 convolutions (channel counts that are multiples of 4, not of 32 / 128): forward and backward-data on
+    bgemm_nt_rows_kernel<RAGGED> -- operand segments past row N / column K come from a page of zeros, the epilogue stores and counts
+    columns < N only -- with the batch-norm statistics from its epilogue.  (Taken where the 128-column tiles are >= 90 % full and the
+    reduction has >= 128 channels: csrc/gemm.hip bgemm_nt_ragged_supported.)"""
+    assert hostsim_lib.conv2d_describe(N, H, W, C, K, 1, 1, 1, 0, 0) == "bgemm_nt_rows_kernel"
+    kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, 1, 1, 0, seed=C + K)
+    kc.conv_bnstats_case(hostsim_lib, "cpu", N, H, W, C, K, 1, 1, 0)
+
+
 def test_conv_stem_wgrad_three_channel_parameter(hostsim_lib):
     kc.stem_c3_wgrad_case(hostsim_lib, "cpu", N=1, H=56)
 

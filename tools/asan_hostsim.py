@@ -21,6 +21,8 @@ def conv():
     kc.conv_case(lib, "cpu", 1, 20, 28, 4, 64, 7, 2, 3, seed=1)                              # stem kernels
     kc.conv_case(lib, "cpu", 2, 9, 7, 16, 64, 3, 1, 1, seed=2)                               # implicit GEMM
     kc.conv_case(lib, "cpu", 2, 7, 5, 128, 256, 1, 1, 0, seed=3)                             # 1x1 on the GEMM kernels
+    kc.conv_case(lib, "cpu", 1, 6, 6, 136, 232, 1, 1, 0, seed=4)                             # ... with ragged N and K (zero-page segments)
+    kc.conv_bnstats_case(lib, "cpu", 1, 6, 6, 1392, 384, 1, 1, 0)
     kc.conv_bnstats_case(lib, "cpu", 2, 12, 14, 64, 64, 3, 1, 1)
 
 

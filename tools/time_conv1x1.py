@@ -19,7 +19,10 @@ def timeit(fn, n=30):
 
 print("mode:", "implicit GEMM" if os.environ.get("HIFIHR_CONV1X1_GEMM") == "0" else "gemm.hip kernels")
 # ResNet-18 layer4.0 projection; ResNet-50 bottleneck conv1 / conv3 shapes (layer 1 .. 4, layer-4 stride 1)
-for N, H, C, K in [(32, 14, 256, 512), (32, 56, 64, 256), (32, 56, 256, 128), (32, 28, 128, 512), (32, 28, 512, 128), (32, 14, 256, 1024),
+EFF = os.environ.get("EFFNET") == "1"            # EFFNET=1: EfficientNet-b3's 1x1 shapes at batch 48 (ragged channel counts); HIFIHR_GEMM_RAGGED=0 for the A/B
+SHAPES_EFF = [(48, 112, 24, 144), (48, 56, 32, 192), (48, 28, 48, 288), (48, 14, 96, 576), (48, 14, 576, 136), (48, 14, 136, 816), (48, 14, 816, 136),
+              (48, 7, 816, 232), (48, 7, 232, 1392), (48, 7, 1392, 232), (48, 7, 1392, 384), (48, 7, 384, 2304), (48, 7, 384, 1536)]
+for N, H, C, K in SHAPES_EFF if EFF else [(32, 14, 256, 512), (32, 56, 64, 256), (32, 56, 256, 128), (32, 28, 128, 512), (32, 28, 512, 128), (32, 14, 256, 1024),
                    (32, 14, 1024, 256), (32, 14, 512, 2048), (32, 14, 2048, 512)]:
     M = N * H * H
     x = torch.randn(N, H, H, C, device=dev); w = torch.randn(K, 1, 1, C, device=dev) / C ** 0.5
