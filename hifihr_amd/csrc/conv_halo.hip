@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
     if (HIFIHR_HALO_ABLATE == 1 || HIFIHR_HALO_ABLATE == 2) return;
     // ---------------- loader ----------------
     const int l = wave - 4;
+    HIFIHR_SET_LOADER_PRIO();
     // weights of one tap: 16 pieces; piece q = l + 4 i: channel half q >> 3, rows 8 (q & 7) .. + 7 of that [64][32] half;
     // lane -> (row, physical 16-byte segment), which holds logical segment (lane & 7) ^ ((row >> 1) & 7)
     unsigned woff[4];
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
   if (wave >= 4) {
     // ---------------- loader ----------------
     const int l = wave - 4;
+    HIFIHR_SET_LOADER_PRIO();
     // weights of a stage: 32 pieces of 1 KiB; piece pq = l + 4 m: position j = pq >> 3, rows 8 (pq & 7) .. + 7 of that [64 n][32 c] block;
     // lane -> (row, physical 16-byte segment), which holds logical segment (lane & 7) ^ ((row >> 1) & 7)
     unsigned woff[8];
@@ -770,6 +772,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_wgrad_kernel(HaloWgr
   if (wave >= 4) {
     // ---------------- loader ----------------
     const int l = wave - 4;
+    HIFIHR_SET_LOADER_PRIO();
     // what a lane moves in piece i does not depend on the tile: packed once (halo: dy << 12 | dx << 8 | segment or -1; dy tile:
     // row << 16 | column << 8 | segment), so a tile costs a few adds per piece instead of two divisions
     int pk[kWgPer];
@@ -965,6 +968,7 @@ __global__ __launch_bounds__(384) void conv_stem_kernel(StemArgs a) {
   if (c3_mine) c3_any = 1;
 
   if (wave >= 4) {
+    HIFIHR_SET_LOADER_PRIO();
     // ---------------- loader (2 waves): the halo of the next tile ----------------
     const int l = wave - 4;
     int pk[kSPieces / 2];                                    // (row << 8 | column) of this lane's pixel in piece i, -1: padding of the LDS image
@@ -1133,6 +1137,7 @@ __global__ __launch_bounds__(512) void conv_stem_wgrad_kernel(StemWgradArgs a) {
   for (int cur = s_lo; cur < s_hi; cur += tile_at(sh, cur, s_hi).rows) ++ntiles;
 
   if (wave >= 4) {
+    HIFIHR_SET_LOADER_PRIO();
     // ---------------- loader (4 waves: 41 pieces per tile, each with per-lane address arithmetic -- two waves were the bottleneck) ----------------
     const int l = wave - 4;
     // what a lane moves in piece i does not depend on the tile: packed once -- halo pieces (row << 8 | column, -1: padding of the

@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void bgemm_ws_kernel(BgemmArgs a)
   if (nch <= 0) return;                                      // (uniform over the workgroup)
 
   if (wave >= 4) {
+    HIFIHR_SET_LOADER_PRIO();
     // ---------------- loader ----------------
     const int l = wave - 4;
     unsigned goff[PL];
@@ -534,6 +535,7 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void bgemm_nt_sk_kernel(BgemmArgs
   const int tile0 = (int)(it0 / nch), c0 = (int)(it0 - (long)tile0 * nch);
 
   if (wave >= 4) {
+    HIFIHR_SET_LOADER_PRIO();
     // ---------------- loader ----------------
     const int l = wave - 4;
     unsigned goff[PL];
@@ -767,6 +769,7 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
   if (wave >= 4) {
     // ---------------- loader: piece q = l + 4 i (i < 8) of a chunk: q < 16 rows 8 q .. + 7 of A, else rows 8 (q - 16) .. of B ----------------
     const int l = wave - 4;
+    HIFIHR_SET_LOADER_PRIO();
     long cur = s_lo;
     RowsTile t = rows_tile_at(a, cur, s_hi);
     const float* src[8];
@@ -1018,6 +1021,7 @@ __global__ __launch_bounds__(512) void bgemm_tn_rows_kernel(BgemmArgs a, long pe
   const int nchunks = ntiles * nch;
 
   if (wave >= 4) {
+    HIFIHR_SET_LOADER_PRIO();
     // ---------------- loader: piece q = l + 4 i (i < 8) of a chunk: q < 16 rows t = 2 q, 2 q + 1 of A, else rows 2 (q - 16) .. of B;
     //                  lane -> (row lane >> 5, physical 16-byte segment lane & 31) ----------------
     const int l = wave - 4;

@@ -35,6 +35,19 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+// Wave priority for the instruction arbiter of a SIMD that two waves share (s_setprio).  The loader waves of the wave-specialised kernels
+// are the second-dispatched half of their 512-thread workgroup and lose the arbitration against the MFMA wave of their SIMD at equal
+// priority (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): their few LDS-DMA issues then start late and the MFMA waves wait at the
+// stage barrier.  One static raise at the top of the loader branch: 5.79 -> 5.755 ms/step (priority 1 and 3 alike; -DHIFIHR_LOADER_PRIO=0
+// for the A/B).
+#ifndef HIFIHR_LOADER_PRIO
+#define HIFIHR_LOADER_PRIO 1
+#endif
+#if defined(HIFIHR_HOSTSIM) || HIFIHR_LOADER_PRIO == 0
+#define HIFIHR_SET_LOADER_PRIO() ((void)0)
+#else
+#define HIFIHR_SET_LOADER_PRIO() __builtin_amdgcn_s_setprio(HIFIHR_LOADER_PRIO)
+#endif
 #if defined(HIFIHR_HOSTSIM)
 #define HIFIHR_RAW_BARRIER() __syncthreads()
 #define HIFIHR_WAIT_VM(n) ((void)0)
