@@ -428,7 +428,8 @@ typedef float floatx2 __attribute__((vector_size(8)));
 #else
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 #endif
-struct F4 { floatx2 lo, hi; };                   // four channels as two packed pairs (v_pk_add_f32)
+struct F4 { floatx2 lo, hi; };                   // four channels as two packed pairs (v_pk_add_f32; scalar adds under -fno-slp-vectorize, which the
+                                                 // guide's constants table suggests beside MFMAs, measured 55.7 vs 54.8 us here: kept packed)
 __device__ __forceinline__ F4 ld_f4(const char* p) {
   const float4 v = *reinterpret_cast<const float4*>(p);
   return F4{floatx2{v.x, v.y}, floatx2{v.z, v.w}};
