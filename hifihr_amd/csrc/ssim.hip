@@ -1,4 +1,5 @@
-// Fused SSIM (11x11 gaussian window, zero padding) forward and backward for gfx950.
+// Fused SSIM (11x11 gaussian window, zero padding) forward and backward for gfx950.  The window sums are explicit fused multiply-adds
+// (round 3: the kernels are VALU-bound -- 11 x 5 products per output in each pass -- and the library is built with -ffp-contract=off).
 //
 // Replaces pytorch_ssim.ssim (reference utils/pytorch_ssim/__init__.py:17-37,65-73): five depthwise 11x11
 // F.conv2d calls, ~10 elementwise launches and a mean in the forward, and their autograd in the backward
@@ -49,46 +50,61 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWindow win, const flo
     ys[r][c] = in ? p2[(size_t)y * W + x] : 0.f;
   }
   __syncthreads();
-  // row pass: for every halo row, 16 output columns, five moments
-  for (int e = tid; e < kSH * kST; e += 256) {
-    const int r = e / kST, c = e - r * kST;
-    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  // row pass: for every halo row, 32 output columns, five moments.  A work item is four adjacent outputs of a row: their 14 inputs are read
+  // once into registers (28 LDS reads for 4 outputs where one output per item read 22 each); same summation order per output as before
+  for (int e = tid; e < kSH * (kST / 4); e += 256) {
+    const int r = e / (kST / 4), c0 = 4 * (e - r * (kST / 4));
+    float a[14], b[14];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = win.g[k], a = xs[r][c + k], b = ys[r][c + k];
-      m1 += w * a; m2 += w * b; e11 += w * (a * a); e22 += w * (b * b); e12 += w * (a * b);
+    for (int k = 0; k < 14; ++k) { a[k] = xs[r][c0 + k]; b[k] = ys[r][c0 + k]; }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float w = win.g[k], av = a[o + k], bv = b[o + k];
+        m1 = fmaf(w, av, m1); m2 = fmaf(w, bv, m2); e11 = fmaf(w, av * av, e11); e22 = fmaf(w, bv * bv, e22); e12 = fmaf(w, av * bv, e12);
+      }
+      hq[0][r][c0 + o] = m1; hq[1][r][c0 + o] = m2; hq[2][r][c0 + o] = e11; hq[3][r][c0 + o] = e22; hq[4][r][c0 + o] = e12;
     }
-    hq[0][r][c] = m1; hq[1][r][c] = m2; hq[2][r][c] = e11; hq[3][r][c] = e22; hq[4][r][c] = e12;
   }
   __syncthreads();
+  // column pass: a thread takes kSO vertically adjacent outputs of one column -- their kSO + 10 moment rows are read once
   float val = 0.f;
+  {
+    const int tx = tid % kST, ty0 = (tid / kST) * kSO;
+    const int x = ox + tx;
+    float h[5][kSO + 10];
 #pragma unroll
-  for (int o4 = 0; o4 < kSO; ++o4) {
-  const int idx = tid + 256 * o4;
-  const int tx = idx % kST, ty = idx / kST;
-  const int x = ox + tx, y = oy + ty;
-  if (x < W && y < H) {
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    for (int q = 0; q < 5; ++q)
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = win.g[k];
-      mu1 += w * hq[0][ty + k][tx]; mu2 += w * hq[1][ty + k][tx]; e11 += w * hq[2][ty + k][tx];
-      e22 += w * hq[3][ty + k][tx]; e12 += w * hq[4][ty + k][tx];
+      for (int k = 0; k < kSO + 10; ++k) h[q][k] = hq[q][ty0 + k][tx];
+#pragma unroll
+    for (int o4 = 0; o4 < kSO; ++o4) {
+      const int y = oy + ty0 + o4;
+      if (x < W && y < H) {
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+          const float w = win.g[k];
+          mu1 = fmaf(w, h[0][o4 + k], mu1); mu2 = fmaf(w, h[1][o4 + k], mu2); e11 = fmaf(w, h[2][o4 + k], e11);
+          e22 = fmaf(w, h[3][o4 + k], e22); e12 = fmaf(w, h[4][o4 + k], e12);
+        }
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+        const float a1 = 2.f * mu12 + C1, a2 = 2.f * s12 + C2, b1 = mu1_sq + mu2_sq + C1, b2 = s1 + s2 + C2;
+        const float sv = (a1 * a2) / (b1 * b2);
+        val += sv;
+        if (dA) {
+          const size_t o = (size_t)plane * H * W + (size_t)y * W + x;
+          const float inv = 1.f / (b1 * b2);
+          dA[o] = 2.f * mu2 * (a2 - a1) * inv - 2.f * mu1 * sv / b1 + 2.f * mu1 * sv / b2;     // d s / d mu1 (total)
+          dB[o] = -sv / b2;                                                                   // d s / d E[x^2]
+          dC[o] = 2.f * a1 * inv;                                                             // d s / d E[xy]
+        }
+      }
     }
-    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-    const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-    const float a1 = 2.f * mu12 + C1, a2 = 2.f * s12 + C2, b1 = mu1_sq + mu2_sq + C1, b2 = s1 + s2 + C2;
-    const float sv = (a1 * a2) / (b1 * b2);
-    val += sv;
-    if (dA) {
-      const size_t o = (size_t)plane * H * W + (size_t)y * W + x;
-      const float inv = 1.f / (b1 * b2);
-      dA[o] = 2.f * mu2 * (a2 - a1) * inv - 2.f * mu1 * sv / b1 + 2.f * mu1 * sv / b2;     // d s / d mu1 (total)
-      dB[o] = -sv / b2;                                                                   // d s / d E[x^2]
-      dC[o] = 2.f * a1 * inv;                                                             // d s / d E[xy]
-    }
-  }
   }
   const float tot = block_sum_256(val, red);
   if (tid == 0) partial[((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
@@ -114,29 +130,40 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWindow win, const flo
     tc[r][c] = in ? dC[o] : 0.f;
   }
   __syncthreads();
-  for (int e = tid; e < kSH * kST; e += 256) {
-    const int r = e / kST, c = e - r * kST;
-    float a = 0.f, b = 0.f, cc = 0.f;
+  for (int e = tid; e < kSH * (kST / 4); e += 256) {        // (four adjacent outputs per item, as in the forward)
+    const int r = e / (kST / 4), c0 = 4 * (e - r * (kST / 4));
+    float va[14], vb[14], vc[14];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = win.g[k];
-      a += w * ta[r][c + k]; b += w * tb[r][c + k]; cc += w * tc[r][c + k];
+    for (int k = 0; k < 14; ++k) { va[k] = ta[r][c0 + k]; vb[k] = tb[r][c0 + k]; vc[k] = tc[r][c0 + k]; }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float a = 0.f, b = 0.f, cc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float w = win.g[k];
+        a = fmaf(w, va[o + k], a); b = fmaf(w, vb[o + k], b); cc = fmaf(w, vc[o + k], cc);
+      }
+      hq[0][r][c0 + o] = a; hq[1][r][c0 + o] = b; hq[2][r][c0 + o] = cc;
     }
-    hq[0][r][c] = a; hq[1][r][c] = b; hq[2][r][c] = cc;
   }
   __syncthreads();
   const float sc = gscale[0] * inv_n;
+  const int tx = tid % kST, ty0 = (tid / kST) * kSO;
+  const int x = ox + tx;
+  float h[3][kSO + 10];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int k = 0; k < kSO + 10; ++k) h[q][k] = hq[q][ty0 + k][tx];
 #pragma unroll
   for (int o4 = 0; o4 < kSO; ++o4) {
-    const int idx = tid + 256 * o4;
-    const int tx = idx % kST, ty = idx / kST;
-    const int x = ox + tx, y = oy + ty;
+    const int y = oy + ty0 + o4;
     if (x < W && y < H) {
       float a = 0.f, b = 0.f, cc = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
         const float w = win.g[k];
-        a += w * hq[0][ty + k][tx]; b += w * hq[1][ty + k][tx]; cc += w * hq[2][ty + k][tx];
+        a = fmaf(w, h[0][o4 + k], a); b = fmaf(w, h[1][o4 + k], b); cc = fmaf(w, h[2][o4 + k], cc);
       }
       const size_t o = po + (size_t)y * W + x;
       gimg1[o] = sc * (a + 2.f * img1[o] * b + img2[o] * cc);
