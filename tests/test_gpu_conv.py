@@ -378,6 +378,33 @@ def test_conv_wino2_kernel(lib, N, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,epi", [(32, 56, 56, False), (48, 224, 224, True), (16, 512, 512, True)])
+def test_conv_wino2_agrees_with_the_direct_kernel_at_config_sizes(lib, N, H, W, epi):
+    """The one-launch Winograd kernel against the direct halo kernel on the SAME inputs at BASELINE's sizes (layer 1 at batch 32; VGG19 conv1_2
+    of the perceptual loss at 48 x 224^2 and, with a ragged last column tile, at 16 x 512^2), plus linearity in the input: sizes at which
+    the CPU oracle is not run."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(N + H)
+    x = torch.randn(N, H, W, 64, device="cuda", generator=g) + 0.3
+    x2 = torch.randn(N, H, W, 64, device="cuda", generator=g)
+    w = torch.randn(64, 3, 3, 64, device="cuda", generator=g) / 24.0
+    b = torch.randn(64, device="cuda", generator=g) * 0.3 if epi else None
+    U = torch.empty(16 * 64 * 64, device="cuda")
+    lib.wino_weight_transform(w, U, 64, 64, 0)
+    y_direct = torch.empty(N, H, W, 64, device="cuda"); y_wino = torch.empty_like(y_direct)
+    lib.conv2d_fwd(x, w, b, y_direct, N, H, W, 64, 64, 3, 3, 1, 1, act=1 if epi else 0)
+    lib.conv3x3_c64_wino(x, U, b, epi, y_wino, None, N, H, W)
+    scale = float(y_direct.abs().max())
+    assert float((y_wino - y_direct).abs().max()) <= 2e-5 * scale
+    # linearity (without the epilogue): conv(x + x2) = conv(x) + conv(x2)
+    ya = torch.empty_like(y_wino); yb = torch.empty_like(y_wino); yc = torch.empty_like(y_wino)
+    lib.conv3x3_c64_wino(x, U, None, False, ya, None, N, H, W)
+    lib.conv3x3_c64_wino(x2, U, None, False, yb, None, N, H, W)
+    lib.conv3x3_c64_wino((x + x2).contiguous(), U, None, False, yc, None, N, H, W)
+    assert float((yc - ya - yb).abs().max()) <= 2e-5 * float(yc.abs().max())
+
+
+@pytest.mark.gpu
 def test_conv_wino2_bias_relu_epilogue(lib):
     kc.conv_wino2_case(lib, "cuda", 2, 28, 28, seed=3, bias_relu=True)
 
