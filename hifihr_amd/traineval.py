@@ -148,6 +148,15 @@ def train_step(model, loss_func, optimizer, examples, args, dat_name="FreiHand",
     return loss, loss_dic
 
 
+def _injected_capture_failure():
+    """Test hook (tests/test_gpu_dp.py): HIFIHR_TEST_FAIL_CAPTURE_RANK=<r> makes the graphed steps' constructors fail on rank r only, to
+    exercise the collective-safe fallback -- a one-sided capture failure must send every rank to the eager step."""
+    import os
+    r = os.environ.get("HIFIHR_TEST_FAIL_CAPTURE_RANK")
+    if r is not None and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_rank() == int(r):
+        raise RuntimeError("injected capture failure (HIFIHR_TEST_FAIL_CAPTURE_RANK)")
+
+
 class GraphedTrainStep:
     """The training iteration captured once into a hipGraph and replayed: ~350 kernel launches per step collapse into one
     graph launch, which removes the host-side launch gaps (the eager step is launch-bound in places: DESIGN.md section 6).
@@ -179,6 +188,7 @@ class GraphedTrainStep:
         else:
             optimizer.enable_graph_mode()
         try:
+            _injected_capture_failure()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                       # warm-up on a side stream (allocator / workspace growth)

@@ -44,6 +44,21 @@ def test_bench_multi_rank_path_runs_end_to_end():
     assert "trial" in d["launch_mode"]
 
 
+def test_one_sided_capture_failure_falls_back_on_every_rank():
+    """Rank 1's hipGraph capture fails (injected), rank 0's succeeds: the constructors are collective-free, so both meet in the agreement
+    all-reduce and BOTH run the eager step -- no mismatched collective, the bench line says why."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HIFIHR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", HIFIHR_TEST_FAIL_CAPTURE_RANK="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--batch", "8"], env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-1500:]); print(r.stderr[-3000:])
+    assert r.returncode == 0
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["launch_mode"].startswith("eager") and "another rank" in d["launch_mode"]
+
+
 @pytest.mark.parametrize("dataset", ["FreiHand", "HO3D"])
 def test_train_front_end_multi_rank(tmp_path, dataset):
     """train_hrnet.py under torch.distributed.run with two ranks (one GPU, gloo): graph capture agreed between the ranks, the captured
