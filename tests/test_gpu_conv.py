@@ -1,5 +1,7 @@
 """GPU parity: MFMA implicit-GEMM convolution through the C ABI vs plain PyTorch fp32 conv2d (CPU), on every
 distinct (Cin,Cout,k,stride,HW) shape of the modified ResNet-18 plus edge cases."""
+import os
+
 import pytest
 import torch
 
@@ -308,6 +310,8 @@ def test_winograd_path(lib, N, H, C, K):
 def test_winograd_f4_path(lib, N, H, C, K):
     """Winograd F(4x4, 3x3) (csrc/wino4.hip, the default of layers 2-4): forward (+ BN statistics, bias / ReLU), backward-data, the dual
     dy transform, slab backward-weight vs torch conv2d at the bench's sizes, a size that is not a multiple of 4 and a VGG-sized map."""
+    if os.environ.get("HIFIHR_WINO_M") == "2":
+        pytest.skip("HIFIHR_WINO_M=2 selects F(2x2, 3x3) for every layer")
     assert lib.wino_tile(N, H, H, C, K) == 4
     kc.wino_case(lib, "cuda", N, H, H, C, K, seed=C + K + H, m=4)
 
@@ -374,6 +378,8 @@ def test_resnet50_trunk_mfma_matches_torch_restatement():
 def test_conv_wino2_kernel(lib, N, H, W):
     """conv_wino2_kernel (64 -> 64, 3x3 / stride 1 as Winograd F(2x2, 3x3) with the transforms in registers): forward + statistics and
     backward-data vs F.conv2d at layer 1's size, VGG19 conv1_2's and the tile shapes of tests/test_hostsim_conv.py."""
+    if os.environ.get("HIFIHR_CONV_WINO2") == "0":
+        pytest.skip("HIFIHR_CONV_WINO2=0 switches the entry point off")
     kc.conv_wino2_case(lib, "cuda", N, H, W, seed=H + W)
 
 
@@ -384,6 +390,8 @@ def test_conv_wino2_agrees_with_the_direct_kernel_at_config_sizes(lib, N, H, W, 
     of the perceptual loss at 48 x 224^2 and, with a ragged last column tile, at 16 x 512^2), plus linearity in the input: sizes at which
     the CPU oracle is not run."""
     import torch
+    if os.environ.get("HIFIHR_CONV_WINO2") == "0":
+        pytest.skip("HIFIHR_CONV_WINO2=0 switches the entry point off")
     g = torch.Generator(device="cuda").manual_seed(N + H)
     x = torch.randn(N, H, W, 64, device="cuda", generator=g) + 0.3
     x2 = torch.randn(N, H, W, 64, device="cuda", generator=g)
@@ -406,6 +414,8 @@ def test_conv_wino2_agrees_with_the_direct_kernel_at_config_sizes(lib, N, H, W, 
 
 @pytest.mark.gpu
 def test_conv_wino2_bias_relu_epilogue(lib):
+    if os.environ.get("HIFIHR_CONV_WINO2") == "0":
+        pytest.skip("HIFIHR_CONV_WINO2=0 switches the entry point off")
     kc.conv_wino2_case(lib, "cuda", 2, 28, 28, seed=3, bias_relu=True)
 
 
