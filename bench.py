@@ -2,7 +2,7 @@
 """Headline benchmark: training-step images/sec on FreiHAND-shaped 224x224 batches (BASELINE.json configs[1]:
 batch 32 per GPU, ResNet-18 encoder + MANO LBS + render + silhouette/texture losses), one process per GPU.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts the N ranks itself, `launch_ranks`)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -333,8 +333,53 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None):
     return out
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N rank processes of this script, one per GPU, and hand back rank 0's
+    JSON line.  The parent never touches the GPU (no HIP call is made before this point: `import torch` alone does not initialise the
+    runtime) and nothing is re-exec'd: the ranks are fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what
+    `python -m torch.distributed.run --nproc-per-node N` would give them (replaces the reference's in-process nn.DataParallel,
+    reference train_hrnet.py:560).  Returns the exit code: non-zero when any rank failed."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    base = dict(os.environ, WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), HIFIHR_BENCH_CHILD="1")
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(a.gpus):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            # rank 0's stdout is the JSON line; the other ranks print nothing there, every rank's stderr passes through
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies leaves the others waiting in a collective: stop them all as soon as one fails
+        codes = [None] * a.gpus
+        while any(c is None for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = p.poll()
+            if any(c not in (None, 0) for c in codes):
+                time.sleep(2.0)
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.kill()                      # exactly the children started above
+                        codes[r] = p.wait()
+                break
+            time.sleep(0.2)
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"[bench] rank(s) failed (rank, exit code): {bad}", file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     from hifihr_amd import dist as hdist, ops, options, synth
     from hifihr_amd.losses import LossFunction
     from hifihr_amd.mano_tables import synthetic_mano_tables
@@ -343,7 +388,7 @@ def main():
     from hifihr_amd.traineval import GraphedTrainStep, data_dic, train_step
 
     rank, local_rank, world = hdist.init_process_group_from_env()
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: the line would report the wrong n_gpus"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP hot path has no CPU fallback)"
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
@@ -653,7 +698,7 @@ def main():
             out["resident_batch"] = {"ms_per_step": resident_ms, "images_per_sec": world * B / (resident_ms * 1e-3),
                                      "note": "the same captured step replayed on one resident batch (no batch assembly, no copies): round 1's timed region"}
         if world > 1:
-            out["rccl"] = {"world_size": world, "backend": dist.get_backend(), "buckets": len(reducer.buckets),
+            out["rccl"] = {"world_size": dist.get_world_size(), "launched_by": "bench.py itself (one child process per GPU)" if os.environ.get("HIFIHR_BENCH_CHILD") else "external launcher (torch.distributed.run)", "backend": dist.get_backend(), "buckets": len(reducer.buckets),
                            "bucket_bytes": [int(4 * (e_hi - e_lo)) for (_, _, e_lo, e_hi) in reducer.buckets],
                            "allreduce_us_per_bucket": bucket_us}
         out.update(extra)

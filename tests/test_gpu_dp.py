@@ -44,6 +44,23 @@ def test_bench_multi_rank_path_runs_end_to_end():
     assert "trial" in d["launch_mode"]
 
 
+def test_bench_gpus_2_plain_invocation_starts_two_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the form the driver uses at N = 1): bench.py must start the two ranks itself -- fresh
+    child processes, the parent never touching the GPU -- and print ONE line with n_gpus == 2.  (Round 3's bench silently ran one rank.)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HIFIHR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--batch", "8"], env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-2000:]); print(r.stderr[-3000:])
+    assert r.returncode == 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert d["rccl"]["world_size"] == 2 and "bench.py itself" in d["rccl"]["launched_by"]
+
+
 def test_one_sided_capture_failure_falls_back_on_every_rank():
     """Rank 1's hipGraph capture fails (injected), rank 0's succeeds: the constructors are collective-free, so both meet in the agreement
     all-reduce and BOTH run the eager step -- no mismatched collective, the bench line says why."""

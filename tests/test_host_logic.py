@@ -298,3 +298,25 @@ def test_train_front_end_reads_reference_configs(tmp_path):
     assert args.state_output == os.path.join(str(tmp_path), "model") and args.mode == ["training"] and args.optimizer == "AdamW"
     d = T.build_args(T.parse([]))
     assert d.hand_model == "mano" and d.texture_stand_in == 0 and d.pretrain == "res18" and d.if_test is True
+
+
+def test_bench_gpus_n_launches_n_ranks_and_fails_loudly_when_one_dies():
+    """`python bench.py --gpus 2` outside a launcher starts two rank processes itself (bench.launch_ranks).  Without a GPU every rank
+    refuses to run (the HIP path has no CPU fallback), so here the launcher's failure path is what runs: both children started with
+    their own RANK, the parent exits non-zero and names the ranks -- it must never print a line claiming n_gpus == 1."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("the GPU form of this test is tests/test_gpu_dp.py::test_bench_gpus_2_plain_invocation_starts_two_ranks")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIFIHR_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "rank(s) failed" in r.stderr and "(0," in r.stderr and "(1," in r.stderr
+    assert "bench.py needs a GPU" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
