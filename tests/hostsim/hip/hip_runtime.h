@@ -108,6 +108,7 @@ static inline int __any(int p) { return __ballot(p) != 0ull; }
 static inline int __all(int p) { return ::hostsim::wave_ballot(p == 0) == 0ull; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 

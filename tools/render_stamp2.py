@@ -17,7 +17,8 @@ for _ in range(2):
     lib.render_fwd(h, verts, vcol, cam, lc, ld, rgba, fid, ws)
 torch.cuda.synchronize()
 hist = (ctypes.c_uint * 32)()
-lib.c.hifihr_debug_render_stamps(buf, 1); lib.c.hifihr_debug_render_hist(hist, 1)
+tm = (ctypes.c_ulonglong * 16)()
+lib.c.hifihr_debug_render_stamps(buf, 1); lib.c.hifihr_debug_render_hist(hist, 1); lib.c.hifihr_debug_render_times(tm, 1)
 lib.render_fwd(h, verts, vcol, cam, lc, ld, rgba, fid, ws)
 torch.cuda.synchronize()
 lib.c.hifihr_debug_render_stamps(buf, 0)
@@ -29,3 +30,12 @@ for i, nm in enumerate(names):
     print(f"  {nm:34s} {v[i] / n:9.0f} cycles = {v[i] / n / 2100:6.2f} us")
 lib.c.hifihr_debug_render_hist(hist, 0)
 print(f"slowest covered tile: {v[10] / 2100:.1f} us; covered tiles by duration (7.8 us buckets):", [int(x) for x in hist][:24])
+lib.c.hifihr_debug_render_times(tm, 0)
+tv = list(tm)
+if tv[10] > 0:                                     # render_fwd3_kernel ran: the launch's timeline on the chip-wide 100 MHz clock
+    t0 = tv[0]
+    print(f"third form: {tv[10]} items ({tv[11]} of them parts of split tiles); relative to the first workgroup's start (us):")
+    for c, nm in enumerate((">= 96 faces per part", "48-95", "24-47", "< 24")):
+        if tv[1 + c]:
+            print(f"  class {c} ({nm:20s}): last item STARTED at {(tv[5 + c] - t0) / 100:7.1f}, last item ENDED at {(tv[1 + c] - t0) / 100:7.1f}")
+    print(f"  last workgroup (background strips included) ended at {(tv[9] - t0) / 100:7.1f}")
