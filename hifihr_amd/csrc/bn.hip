@@ -70,7 +70,7 @@ __device__ __forceinline__ float act_grad(int act, float z, float y) {
 // block-level reduction of the per-thread (sum, sumsq)-like pairs over the row lanes + slot-spread atomics
 __device__ __forceinline__ void reduce_and_add(const BnMap& mp, int C, float4 (&s)[kMaxNG], float4 (&q)[kMaxNG],
                                                float4 (*lds)[256], float* __restrict__ out) {
-  const int slot = blockIdx.x & (kStatSlots - 1);
+  const int slot = blockIdx.x & (stat_slots_used(C) - 1);
   float* base = out + (size_t)slot * 2 * C;
   if (mp.NG == 1 && mp.RL > 1) {
     lds[0][threadIdx.x] = s[0]; lds[1][threadIdx.x] = q[0];
@@ -97,7 +97,7 @@ __device__ __forceinline__ void reduce_and_add(const BnMap& mp, int C, float4 (&
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long M, int C, float* __restrict__ stats) {
   __shared__ double lds[2][256][4];
   const BnMap mp = bn_map(C);
-  double* const slots = reinterpret_cast<double*>(stats) + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * C;
+  double* const slots = reinterpret_cast<double*>(stats) + (size_t)(blockIdx.x & (stat_slots_used(C) - 1)) * 2 * C;
 #pragma unroll
   for (int j = 0; j < kMaxNG; ++j) {
     if (j >= mp.NG) break;                                 // (uniform)
@@ -148,8 +148,9 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(float* __restrict_
   if (c >= C) return;
   double* buf = reinterpret_cast<double*>(stats);
   double s = 0.0, q = 0.0;
+  const int ns = stat_slots_used(C);
 #pragma unroll 8
-  for (int sl = 0; sl < kStatSlots; ++sl) {
+  for (int sl = 0; sl < ns; ++sl) {
     double* p = buf + (size_t)sl * 2 * C;
     s += p[c]; q += p[C + c];
     p[c] = 0.0; p[C + c] = 0.0;
@@ -172,8 +173,9 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(float* __restrict_
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float sg = 0.f, sgx = 0.f;
+  const int ns = stat_slots_used(C);
 #pragma unroll 8
-  for (int sl = 0; sl < kStatSlots; ++sl) {
+  for (int sl = 0; sl < ns; ++sl) {
     float* p = red + (size_t)sl * 2 * C;
     sg += p[c]; sgx += p[C + c];
     p[c] = 0.f; p[C + c] = 0.f;

@@ -27,31 +27,47 @@ __device__ __forceinline__ bool last_workgroup(unsigned* __restrict__ cnt) {
 
 __device__ __forceinline__ void clear_slots(float* __restrict__ buf, int C, unsigned* __restrict__ cnt) {
   float4* p = reinterpret_cast<float4*>(buf);
-  const int n4 = kStatSlots * 2 * C / 4;
+  const int n4 = stat_slots_used(C) * 2 * C / 4;         // (the other slots were never written)
   for (int i = threadIdx.x; i < n4; i += 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (threadIdx.x < 33) cnt[threadIdx.x] = 0u;
 }
 
-// both statistics of channel c with all 64 loads in flight at once: this fold is the prologue of every workgroup of an apply kernel,
-// and in groups of 8 dependent-latency batches it cost ~5 us of the ~9 us a small layer's launch takes (tools/time_bn.py)
-__device__ __forceinline__ void slot_sum2(const float* __restrict__ buf, int C, int c, float& s0, float& s1) {
-  float a[kStatSlots], b[kStatSlots];
+// both statistics of channel c with all loads in flight at once: this fold is the prologue of every workgroup of an apply kernel,
+// and in groups of 8 dependent-latency batches it cost ~5 us of the ~9 us a small layer's launch takes (tools/time_bn.py).  Only the
+// slots the layer's producers use are read (stat_slots_used: 8 / 16 / 32 by channel count).
+template <int NS>
+__device__ __forceinline__ void slot_sum2_n(const float* __restrict__ buf, int C, int c, float& s0, float& s1) {
+  float a[NS], b[NS];
 #pragma unroll
-  for (int sl = 0; sl < kStatSlots; ++sl) { a[sl] = buf[(size_t)sl * 2 * C + c]; b[sl] = buf[(size_t)sl * 2 * C + C + c]; }
+  for (int sl = 0; sl < NS; ++sl) { a[sl] = buf[(size_t)sl * 2 * C + c]; b[sl] = buf[(size_t)sl * 2 * C + C + c]; }
   s0 = 0.f; s1 = 0.f;
 #pragma unroll
-  for (int sl = 0; sl < kStatSlots; ++sl) { s0 += a[sl]; s1 += b[sl]; }
+  for (int sl = 0; sl < NS; ++sl) { s0 += a[sl]; s1 += b[sl]; }
+}
+__device__ __forceinline__ void slot_sum2(const float* __restrict__ buf, int C, int c, float& s0, float& s1) {
+  const int ns = stat_slots_used(C);                      // (uniform)
+  if (ns == 8) slot_sum2_n<8>(buf, C, c, s0, s1);
+  else if (ns == 16) slot_sum2_n<16>(buf, C, c, s0, s1);
+  else slot_sum2_n<kStatSlots>(buf, C, c, s0, s1);
 }
 
-// FORWARD statistics (double slots): mean and biased variance of channel c from the 32 slot partials, all 64 loads in flight
+// FORWARD statistics (double slots): mean and biased variance of channel c from the slot partials, all loads in flight
+template <int NS>
+__device__ __forceinline__ void slot_sums_fwd_n(const double* __restrict__ buf, int C, int c, double& s0, double& s1) {
+  double a[NS], b[NS];
+#pragma unroll
+  for (int sl = 0; sl < NS; ++sl) { a[sl] = buf[(size_t)sl * 2 * C + c]; b[sl] = buf[(size_t)sl * 2 * C + C + c]; }
+  s0 = 0.0; s1 = 0.0;
+#pragma unroll
+  for (int sl = 0; sl < NS; ++sl) { s0 += a[sl]; s1 += b[sl]; }
+}
 __device__ __forceinline__ void slot_mean_var(const float* __restrict__ stats, int C, int c, long M, float& mu, float& var) {
   const double* buf = reinterpret_cast<const double*>(stats);
-  double a[kStatSlots], b[kStatSlots];
-#pragma unroll
-  for (int sl = 0; sl < kStatSlots; ++sl) { a[sl] = buf[(size_t)sl * 2 * C + c]; b[sl] = buf[(size_t)sl * 2 * C + C + c]; }
-  double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-  for (int sl = 0; sl < kStatSlots; ++sl) { s0 += a[sl]; s1 += b[sl]; }
+  double s0, s1;
+  const int ns = stat_slots_used(C);                      // (uniform)
+  if (ns == 8) slot_sums_fwd_n<8>(buf, C, c, s0, s1);
+  else if (ns == 16) slot_sums_fwd_n<16>(buf, C, c, s0, s1);
+  else slot_sums_fwd_n<kStatSlots>(buf, C, c, s0, s1);
   const double m = s0 / (double)M;
   const double v = s1 / (double)M - m * m;           // fp64: the cancellation costs 2^-53 mean^2 / var
   mu = (float)m;
@@ -59,7 +75,7 @@ __device__ __forceinline__ void slot_mean_var(const float* __restrict__ stats, i
 }
 __device__ __forceinline__ void clear_slots_fwd(float* __restrict__ stats, int C, unsigned* __restrict__ cnt) {
   float4* p = reinterpret_cast<float4*>(stats);
-  const int n4 = kStatSlots * 2 * C / 2;               // doubles: 8 bytes each
+  const int n4 = stat_slots_used(C) * 2 * C / 2;       // doubles: 8 bytes each (the other slots were never written)
   for (int i = threadIdx.x; i < n4; i += 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (threadIdx.x < 33) cnt[threadIdx.x] = 0u;
 }

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
           S1 += __shfl_down(S1, 32, 64);         // lanes l and l + 32 hold the same channel, different rows
           S2 += __shfl_down(S2, 32, 64);
           if (half == 0 && k < g.OC) {           // 32 consecutive channels
-            double* sp = reinterpret_cast<double*>(stats) + (size_t)((tx * 2 + wm) & (kStatSlots - 1)) * 2 * g.OC;   // slot by row tile
+            double* sp = reinterpret_cast<double*>(stats) + (size_t)((tx * 2 + wm) & (stat_slots_used(g.OC) - 1)) * 2 * g.OC;   // slot by row tile
             stat_atomic_add(sp + k, S1);
             stat_atomic_add(sp + g.OC + k, S2);
           }

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_kernel(HaloArgs a) {
       for (int o = 1; o < 16; o <<= 1) { S1[e] += __shfl_xor(S1[e], o, 64); S2[e] += __shfl_xor(S2[e], o, 64); }
     }
     if (r == 0) {
-      double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 16 * wave + 4 * g;
+      double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (stat_slots_used(64) - 1)) * 2 * 64 + 16 * wave + 4 * g;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { stat_atomic_add(sp + e, S1[e]); stat_atomic_add(sp + 64 + e, S2[e]); }
     }
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
         for (int o = 1; o < 16; o <<= 1) { S1[e] += __shfl_xor(S1[e], o, 64); S2[e] += __shfl_xor(S2[e], o, 64); }
       }
       if (r == 0) {
-        double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 32 * chw + 16 * s + 4 * g;
+        double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (stat_slots_used(64) - 1)) * 2 * 64 + 32 * chw + 16 * s + 4 * g;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { stat_atomic_add(sp + e, S1[e]); stat_atomic_add(sp + 64 + e, S2[e]); }
       }
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(384) void conv_stem_kernel(StemArgs a) {
       for (int o = 1; o < 16; o <<= 1) { S1[e] += __shfl_xor(S1[e], o, 64); S2[e] += __shfl_xor(S2[e], o, 64); }
     }
     if (r == 0) {
-      double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (kStatSlots - 1)) * 2 * 64 + 16 * wave + 4 * g;
+      double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (stat_slots_used(64) - 1)) * 2 * 64 + 16 * wave + 4 * g;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { stat_atomic_add(sp + e, S1[e]); stat_atomic_add(sp + 64 + e, S2[e]); }
     }

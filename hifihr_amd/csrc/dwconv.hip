@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* 
     }
   }
   if (stats != nullptr)                             // uniform: fold the 16 pixel lanes, one atomic per channel per workgroup
-    st.fold16(red, pl, cl, cok, reinterpret_cast<double*>(stats) + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * g.C + c, g.C);
+    st.fold16(red, pl, cl, cok, reinterpret_cast<double*>(stats) + (size_t)(blockIdx.x & (stat_slots_used(g.C) - 1)) * 2 * g.C + c, g.C);
 }
 
 // dx[n][ih][iw] = sum_{r,s} dy[n][(ih + pt - r)/S][(iw + pl - s)/S] * w[r][s] over the taps where the divisions are exact.

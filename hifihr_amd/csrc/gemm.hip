@@ -849,7 +849,7 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
         stat_unshift(sn, sk[i][e], ssum[i][e], ssq[i][e], sa, sb);
         for (int o = 1; o < 16; o <<= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
         if (r == 0 && (!RAGGED || stat_nt * 128 + 32 * wave + 16 * i + 4 * g + e < a.N)) {      // (columns >= N hold zeros: no slot)
-          double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (kStatSlots - 1)) * 2 * a.N + (size_t)stat_nt * 128 + 32 * wave +
+          double* sp = reinterpret_cast<double*>(a.stats) + (size_t)(wg & (stat_slots_used(a.N) - 1)) * 2 * a.N + (size_t)stat_nt * 128 + 32 * wave +
                        16 * i + 4 * g + e;
           stat_atomic_add(sp, sa); stat_atomic_add(sp + a.N, sb);
         }

@@ -114,6 +114,11 @@ hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wg
 // sums are spread over kStatSlots copies so that at most ~1/32 of the contributing workgroups hit one address with a
 // float atomic (thousands of atomics on ONE address serialise at ~100 ns each: 200 us per reduction in round 1).
 constexpr int kStatSlots = 32;
+// Slots a layer actually USES (the others stay zero; the layout keeps all 32): a consumer folds the slots of every channel in the prologue
+// of every workgroup (csrc/bn_fold.h) -- 512 B of L2 reads per channel and workgroup at 32 double slots, 67 MB per launch of a
+// 512-channel layer's fused transform, as much as the transform itself moves -- while the same-address atomic traffic the slots exist
+// to spread falls with the channel count (a wide layer has few rows per channel: <= 32 adders per address at 8 slots).
+__host__ __device__ inline int stat_slots_used(int C) { return C >= 512 ? 8 : (C >= 256 ? 16 : 32); }
 // FORWARD statistics (round 3): the slots hold DOUBLES, double S[kStatSlots][2][C] = (sum y, sum y^2), followed by 64 uint32 arrival
 // counters.  A producer lane accumulates SHIFTED sums in fp32 -- d = y - k with k a value of its own (the first y it saw for that
 // channel), s = sum d, q = sum d^2 over its n values: q stays of the order of n var however large the mean is -- and converts ONCE,

@@ -192,7 +192,28 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
       }
     }
   }
-  if (cur >= 0) flush_face(A, gv, cidx, acc);
+  // The last run of every lane is flushed HERE, at a wave-uniform point -- and that is where the LDS atomics met 64 ways: the lanes of a
+  // wave are an 8 x 8 block of pixels, a face covers ~5 x 5 of them, and all of its lanes added to the same 36 addresses at once (the
+  // flushes inside the sample loop run with a few lanes each).  Lanes of one pixel row that hold the same face are neighbours: a
+  // segmented sum over the row (three DPP steps per value, no LDS) leaves one lane per (row, face) to add.
+  {
+    const int face = cur;
+    const int prev = row_shr1_i32(face, -2);
+    const bool head = ((lane & 7) == 0) || (prev != face);
+    const unsigned long long heads = __ballot(head);
+    const unsigned after = (unsigned)((heads >> 1) >> lane);          // bit k: lane + 1 + k starts a segment
+    const int room = 7 - (lane & 7);                                   // lanes to the right inside the 8-pixel row
+    const bool ok1 = room >= 1 && (after & 1u) == 0u, ok2 = room >= 2 && (after & 3u) == 0u, ok4 = room >= 4 && (after & 15u) == 0u;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+      float v = (cur >= 0) ? acc[k] : 0.f;
+      const float t1 = row_shl_f32<1>(v); v += ok1 ? t1 : 0.f;
+      const float t2 = row_shl_f32<2>(v); v += ok2 ? t2 : 0.f;
+      const float t4 = row_shl_f32<4>(v); v += ok4 ? t4 : 0.f;
+      acc[k] = v;
+    }
+    if (head && cur >= 0) flush_face(A, gv, cidx, acc);
+  }
   __syncthreads();
   for (int e = tid; e < HT * 12; e += 256) {
     const int key = A.keys[e / 12];

@@ -19,6 +19,26 @@ __device__ __forceinline__ float wsum(float x) {
   return x;
 }
 
+// value of lane + D inside the 16-lane row (0 past the end of the row): one VALU instruction with a DPP operand on the device
+template <int D>
+__device__ __forceinline__ float row_shl_f32(float v) {
+#if defined(HIFIHR_HOSTSIM)
+  const float t = __shfl_down(v, D, 64);
+  return ((::hostsim::lane_id() & 15) + D < 16) ? t : 0.f;
+#else
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + D, 0xf, 0xf, true));
+#endif
+}
+// value of lane - 1 inside the 16-lane row (`fill` at the start of a row)
+__device__ __forceinline__ int row_shr1_i32(int v, int fill) {
+#if defined(HIFIHR_HOSTSIM)
+  const int t = __shfl_up(v, 1, 64);
+  return (::hostsim::lane_id() & 15) >= 1 ? t : fill;
+#else
+  return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false);
+#endif
+}
+
 #if defined(HIFIHR_HOSTSIM)
 __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float fast_rsq(float x) { return 1.0f / sqrtf(x); }

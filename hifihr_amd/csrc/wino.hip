@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
     }
   }
   if (stats != nullptr)                             // uniform
-    st.fold16(red, tl, cl, kok, reinterpret_cast<double*>(stats) + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * K + k, K);
+    st.fold16(red, tl, cl, kok, reinterpret_cast<double*>(stats) + (size_t)(blockIdx.x & (stat_slots_used(K) - 1)) * 2 * K + k, K);
 }
 
 // backward-weight glue.  thread = (tile, 4 channels): Y'[16][T][K] = A dy A^T with A = [1 0; 1 1; 1 -1; 0 -1] (dy outside the image = 0)

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void wino4_output_transform_bnred_kernel(const
       a1 = make_float4(a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w);
       a2 = make_float4(a2.x + b2.x, a2.y + b2.y, a2.z + b2.z, a2.w + b2.w);
     }
-    float* sp = red + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * C;
+    float* sp = red + (size_t)(blockIdx.x & (stat_slots_used(C) - 1)) * 2 * C;
     atomicAdd(sp + k, a1.x); atomicAdd(sp + k + 1, a1.y); atomicAdd(sp + k + 2, a1.z); atomicAdd(sp + k + 3, a1.w);
     atomicAdd(sp + C + k, a2.x); atomicAdd(sp + C + k + 1, a2.y); atomicAdd(sp + C + k + 2, a2.z); atomicAdd(sp + C + k + 3, a2.w);
   }
