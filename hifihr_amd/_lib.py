@@ -199,6 +199,9 @@ class HifihrLib:
         c.hifihr_se_pool.argtypes = [_c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_scale.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_bwd_gate.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
+        c.hifihr_se_mlp_supported.argtypes = [c_int, c_int]
+        c.hifihr_se_mlp_fwd.argtypes = [_c_float_p] * 5 + [c_int] * 3 + [_c_float_p] * 4 + [c_void_p]
+        c.hifihr_se_mlp_bwd.argtypes = [_c_float_p] * 7 + [c_int] * 3 + [_c_float_p] * 7 + [c_void_p]
         c.hifihr_mmpool_fwd.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mmpool_bwd.argtypes = [_c_float_p, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p,
                                         _c_float_p, c_void_p]
@@ -605,6 +608,17 @@ class HifihrLib:
 
     def se_scale(self, x, gate, add, add_scale, B, HW, C, y):
         self.check(self.c.hifihr_se_scale(_fp(x), _fp(gate), _fp(add), float(add_scale), B, HW, C, _fp(y), _stream_of(x)), "hifihr_se_scale")
+
+    def se_mlp_supported(self, C, SQ):
+        return bool(self.c.hifihr_se_mlp_supported(int(C), int(SQ)))
+
+    def se_mlp_fwd(self, mean_acc, w1, b1, w2t, b2, B, C, SQ, mean, z1, h1, gate):
+        self.check(self.c.hifihr_se_mlp_fwd(_fp(mean_acc), _fp(w1), _fp(b1), _fp(w2t), _fp(b2), B, C, SQ, _fp(mean), _fp(z1), _fp(h1), _fp(gate),
+                                            _stream_of(mean_acc)), "hifihr_se_mlp_fwd")
+
+    def se_mlp_bwd(self, dgate_acc, gate, z1, h1, mean, w1, w2t, B, C, SQ, dz2, dz1, dmean, dw1, db1, dw2, db2):
+        self.check(self.c.hifihr_se_mlp_bwd(_fp(dgate_acc), _fp(gate), _fp(z1), _fp(h1), _fp(mean), _fp(w1), _fp(w2t), B, C, SQ, _fp(dz2), _fp(dz1),
+                                            _fp(dmean), _fp(dw1), _fp(db1), _fp(dw2), _fp(db2), _stream_of(dgate_acc)), "hifihr_se_mlp_bwd")
 
     def se_bwd_gate(self, dy, x, B, HW, C, dgate_zeroed):
         self.check(self.c.hifihr_se_bwd_gate(_fp(dy), _fp(x), B, HW, C, _fp(dgate_zeroed), _stream_of(x)), "hifihr_se_bwd_gate")

@@ -861,6 +861,27 @@ int hifihr_se_bwd_gate(const float* dy, const float* x, int B, int HW, int C, fl
   return HIFIHR_OK;
 }
 
+int hifihr_se_mlp_supported(int C, int SQ) { return hifihr::se_mlp_supported(C, SQ) ? 1 : 0; }
+
+int hifihr_se_mlp_fwd(float* mean_acc, const float* w1, const float* b1, const float* w2t, const float* b2, int B, int C, int SQ, float* mean,
+                      float* z1, float* h1, float* gate, void* stream) {
+  if (!mean_acc || !w1 || !b1 || !w2t || !b2 || !mean || !z1 || !h1 || !gate || B <= 0 || !hifihr::se_mlp_supported(C, SQ))
+    return fail(HIFIHR_EINVAL, "hifihr_se_mlp_fwd: bad argument (C % 4 == 0, C <= 4096, SQ <= 256)");
+  HIP_TRY(hifihr::launch_se_mlp_fwd(mean_acc, w1, b1, w2t, b2, B, C, SQ, mean, z1, h1, gate, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_se_mlp_bwd(float* dgate_acc, const float* gate, const float* z1, const float* h1, const float* mean, const float* w1, const float* w2t,
+                      int B, int C, int SQ, float* dz2, float* dz1, float* dmean, float* dw1_acc, float* db1_acc, float* dw2_acc, float* db2_acc,
+                      void* stream) {
+  if (!dgate_acc || !gate || !z1 || !h1 || !mean || !w1 || !w2t || !dz2 || !dz1 || !dmean || !dw1_acc || !db1_acc || !dw2_acc || !db2_acc ||
+      B <= 0 || !hifihr::se_mlp_supported(C, SQ))
+    return fail(HIFIHR_EINVAL, "hifihr_se_mlp_bwd: bad argument (C % 4 == 0, C <= 4096, SQ <= 256)");
+  HIP_TRY(hifihr::launch_se_mlp_bwd(dgate_acc, gate, z1, h1, mean, w1, w2t, B, C, SQ, dz2, dz1, dmean, dw1_acc, db1_acc, dw2_acc, db2_acc,
+                                    (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_weight_transpose(const float* w, float* wt, int K, int RS, int C, void* stream) {
   if (!w || !wt || K <= 0 || RS <= 0 || C <= 0) return fail(HIFIHR_EINVAL, "hifihr_weight_transpose: bad argument");
   HIP_TRY(hifihr::launch_weight_transpose(w, wt, K, RS, C, (hipStream_t)stream));

@@ -287,6 +287,13 @@ hipError_t launch_linear_bwd(const LinearArgs& a, const LinearGrads& g, hipStrea
 hipError_t launch_se_pool(const float* x, int B, int HW, int C, float* mean_zeroed, hipStream_t st);
 hipError_t launch_se_bwd_gate(const float* dy, const float* x, int B, int HW, int C, float* dgate_zeroed, hipStream_t st);
 hipError_t launch_se_scale(const float* x, const float* gate, const float* add, float ascale, int B, int HW, int C, float* y, hipStream_t st);
+// the two layers between pooling and scaling, fused (se.hip): W1[SQ][C], W2T[SQ][C] = the transposed W2[C][SQ]
+bool se_mlp_supported(int C, int SQ);
+hipError_t launch_se_mlp_fwd(float* mean_acc, const float* W1, const float* b1, const float* W2T, const float* b2, int B, int C, int SQ,
+                             float* mean_out, float* z1, float* h1, float* gate, hipStream_t st);
+hipError_t launch_se_mlp_bwd(float* dgate_acc, const float* gate, const float* z1, const float* h1, const float* mean, const float* W1,
+                             const float* W2T, int B, int C, int SQ, float* dz2, float* dz1, float* dmean, float* dW1_acc, float* db1_acc,
+                             float* dW2_acc, float* db2_acc, hipStream_t st);
 
 // Winograd F(2x2, 3x3) glue (wino.hip)
 hipError_t launch_wino_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st);

@@ -1485,7 +1485,18 @@ def linear(x, lin: torch.nn.Linear, act=None, bn: torch.nn.BatchNorm1d | None = 
 # ------------------------------------------------------------------------------------------------
 # squeeze-and-excitation (csrc/se.hip + the small-batch linear kernels)
 # ------------------------------------------------------------------------------------------------
+def _se_w2t(w2):
+    """The expand weight W2[C][SQ] transposed to [SQ][C] (the fused kernels read it coalesced over the channels): from the per-step
+    re-layout launch inside `prepared_weights()`, by one ATen transpose outside it (evaluation, the first step)."""
+    C, SQ = w2.shape[0], w2.shape[1]
+    t = _WEIGHT_PREP.get(w2, w2, 0) if w2.dim() == 4 else None
+    return t if t is not None else w2.reshape(C, SQ).t().contiguous()
+
+
 class _SqueezeExcite(torch.autograd.Function):
+    """Pooling -> the two layers in ONE launch (csrc/se.hip se_mlp_fwd_kernel) -> scaling: 3 launches forward, 4 backward, no fills (round
+    3: 5 + 7 with the layers on the head kernels; HIFIHR_SE_FUSED=0 keeps that form for the A/B)."""
+
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
         require_cuda(x, w1, w2)
@@ -1494,11 +1505,21 @@ class _SqueezeExcite(torch.autograd.Function):
         B, C, H, W = x.shape
         HW, SQ = H * W, w1.shape[0]
         dev = x.device
-        mean = torch.zeros(B, C, device=dev)
-        PROFILE.bracket("se_pool", lambda: lib.se_pool(x, B, HW, C, mean))
+        fused = _SE_FUSED and lib.se_mlp_supported(C, SQ)
+        ctx.fused = fused
         h1, z1, gate = torch.empty(B, SQ, device=dev), torch.empty(B, SQ, device=dev), torch.empty(B, C, device=dev)
-        PROFILE.bracket("linear_fwd", lambda: lib.linear_fwd(mean, w1, b1, 2, h1, z=z1))          # swish
-        PROFILE.bracket("linear_fwd", lambda: lib.linear_fwd(h1, w2, b2, 3, gate))                 # sigmoid
+        if fused:
+            acc = _ZERO_POOL.acquire(B * C, dev)                  # handed back zeroed by se_mlp_fwd
+            PROFILE.bracket("se_pool", lambda: lib.se_pool(x, B, HW, C, acc))
+            mean = torch.empty(B, C, device=dev)
+            w2t = _se_w2t(w2)
+            PROFILE.bracket("se_mlp_fwd", lambda: lib.se_mlp_fwd(acc, w1, b1, w2t, b2, B, C, SQ, mean, z1, h1, gate))
+            _ZERO_POOL.release(acc)
+        else:
+            mean = torch.zeros(B, C, device=dev)
+            PROFILE.bracket("se_pool", lambda: lib.se_pool(x, B, HW, C, mean))
+            PROFILE.bracket("linear_fwd", lambda: lib.linear_fwd(mean, w1, b1, 2, h1, z=z1))          # swish
+            PROFILE.bracket("linear_fwd", lambda: lib.linear_fwd(h1, w2, b2, 3, gate))                 # sigmoid
         y = torch.empty_like(x, memory_format=_CL)
         PROFILE.bracket("se_scale", lambda: lib.se_scale(x, gate, None, 0.0, B, HW, C, y))
         ctx.save_for_backward(x, mean, h1, z1, gate, w1, w2)
@@ -1514,17 +1535,26 @@ class _SqueezeExcite(torch.autograd.Function):
         B, C, H, W = x.shape
         HW, SQ = H * W, w1.shape[0]
         dev = x.device
-        dgate = torch.zeros(B, C, device=dev)
-        PROFILE.bracket("se_bwd_gate", lambda: lib.se_bwd_gate(dy, x, B, HW, C, dgate))
         rets = []
         tgts = []
         for p in (pw1, pb1, pw2, pb2):
             t, r = _acc_target(p, p.shape, dev)
             tgts.append(t); rets.append(r)
-        dh1, dmean = torch.empty(B, SQ, device=dev), torch.empty(B, C, device=dev)
+        dmean = torch.empty(B, C, device=dev)
         dz2, dz1 = torch.empty(B, C, device=dev), torch.empty(B, SQ, device=dev)
-        PROFILE.bracket("linear_bwd", lambda: lib.linear_bwd(dgate, gate, h1, w2, 3, dz2, tgts[2], tgts[3], dh1))
-        PROFILE.bracket("linear_bwd", lambda: lib.linear_bwd(dh1, None, mean, w1, 2, dz1, tgts[0], tgts[1], dmean, z=z1))
+        if ctx.fused:
+            dgate = _ZERO_POOL.acquire(B * C, dev)                # handed back zeroed by se_mlp_bwd
+            PROFILE.bracket("se_bwd_gate", lambda: lib.se_bwd_gate(dy, x, B, HW, C, dgate))
+            w2t = _se_w2t(pw2)
+            PROFILE.bracket("se_mlp_bwd", lambda: lib.se_mlp_bwd(dgate, gate, z1, h1, mean, w1, w2t, B, C, SQ, dz2, dz1, dmean, tgts[0], tgts[1],
+                                                                 tgts[2], tgts[3]))
+            _ZERO_POOL.release(dgate)
+        else:
+            dgate = torch.zeros(B, C, device=dev)
+            PROFILE.bracket("se_bwd_gate", lambda: lib.se_bwd_gate(dy, x, B, HW, C, dgate))
+            dh1 = torch.empty(B, SQ, device=dev)
+            PROFILE.bracket("linear_bwd", lambda: lib.linear_bwd(dgate, gate, h1, w2, 3, dz2, tgts[2], tgts[3], dh1))
+            PROFILE.bracket("linear_bwd", lambda: lib.linear_bwd(dh1, None, mean, w1, 2, dz1, tgts[0], tgts[1], dmean, z=z1))
         dx = torch.empty_like(x, memory_format=_CL)
         PROFILE.bracket("se_bwd_dx", lambda: lib.se_scale(dy, gate, dmean, 1.0 / HW, B, HW, C, dx))
         for p, r in zip((pw1, pb1, pw2, pb2), rets):
@@ -1533,9 +1563,12 @@ class _SqueezeExcite(torch.autograd.Function):
         return dx, rets[0], rets[1], rets[2], rets[3]
 
 
+_SE_FUSED = os.environ.get("HIFIHR_SE_FUSED", "1") != "0"
+
+
 def squeeze_excite(x, reduce_conv, expand_conv):
     """x * sigmoid(expand(swish(reduce(mean_hw(x))))) for channels_last x; reduce / expand are the block's 1x1 nn.Conv2d with
-    bias (reference network/efficientnet_pt/model.py:82-86): 4 launches forward, 7 backward."""
+    bias (reference network/efficientnet_pt/model.py:82-86): 3 launches forward, 4 backward."""
     return _SqueezeExcite.apply(x, reduce_conv.weight, reduce_conv.bias, expand_conv.weight, expand_conv.bias)
 
 

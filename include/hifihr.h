@@ -610,6 +610,20 @@ int hifihr_se_pool(const float* x_d, int B, int HW, int C, float* mean_zeroed_d,
 int hifihr_se_scale(const float* x_d, const float* gate_d, const float* add_d /* or NULL */, float add_scale, int B, int HW, int C,
                     float* y_d, void* stream);
 int hifihr_se_bwd_gate(const float* dy_d, const float* x_d, int B, int HW, int C, float* dgate_zeroed_d, void* stream);
+/* The two layers as ONE launch forward and TWO backward (round 4; replaces the four hifihr_linear_* calls per block and direction of
+ * reference network/efficientnet_pt/model.py:83-86).  w1_d[SQ][C], w2t_d[SQ][C] = the TRANSPOSE of the expand weight W2[C][SQ]
+ * (hifihr_weight_prep kind 0 provides it once per step), C % 4 == 0, C <= 4096, SQ <= 256 (hifihr_se_mlp_supported).
+ * fwd: reads the pooled means from mean_acc_d[B][C] (what hifihr_se_pool accumulated) and hands that buffer back ZEROED; writes
+ *      mean_d[B][C], z1_d[B][SQ] (pre-activation), h1_d[B][SQ] = swish(z1), gate_d[B][C] = sigmoid(h1 W2^T + b2).
+ * bwd: reads dgate_acc_d[B][C] (hifihr_se_bwd_gate's sums; handed back ZEROED); writes dz2_d[B][C], dz1_d[B][SQ] (scratch) and
+ *      dmean_d[B][C]; ACCUMULATES (+=) dW1[SQ][C], db1[SQ], dW2[C][SQ], db2[C] -- each element summed over the batch by one thread in a
+ *      fixed order (bit-reproducible). */
+int hifihr_se_mlp_supported(int C, int SQ);
+int hifihr_se_mlp_fwd(float* mean_acc_d, const float* w1_d, const float* b1_d, const float* w2t_d, const float* b2_d, int B, int C, int SQ,
+                      float* mean_d, float* z1_d, float* h1_d, float* gate_d, void* stream);
+int hifihr_se_mlp_bwd(float* dgate_acc_d, const float* gate_d, const float* z1_d, const float* h1_d, const float* mean_d, const float* w1_d,
+                      const float* w2t_d, int B, int C, int SQ, float* dz2_d, float* dz1_d, float* dmean_d, float* dw1_acc_d, float* db1_acc_d,
+                      float* dw2_acc_d, float* db2_acc_d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Evaluation: Procrustes-with-scale alignment of pred_d[B][N][3] to gt_d[B][N][3] and the

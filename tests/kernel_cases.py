@@ -920,6 +920,27 @@ def se_case(lib, device, B, H, W, C, SQ, seed=0):
         assert err <= t * mag + 1e-7, f"se {name}: {err} vs {mag}"
     rel(dx, xr.grad.permute(0, 2, 3, 1), "dx")
     rel(dw1, w1r.grad, "dw1"); rel(db1, b1r.grad, "db1"); rel(dw2, w2r.grad, "dw2"); rel(db2, b2r.grad, "db2")
+    # ---- the two layers fused (se_mlp_fwd / se_mlp_bwd): same numbers, accumulators handed back zeroed, gradients ACCUMULATED
+    assert lib.se_mlp_supported(C, SQ)
+    acc = torch.zeros(B, C, device=device)
+    lib.se_pool(xd, B, HW, C, acc)
+    w2t = d(w2.t())
+    mean2, z2, h2, g2 = torch.empty(B, C, device=device), torch.empty(B, SQ, device=device), torch.empty(B, SQ, device=device), torch.empty(B, C, device=device)
+    lib.se_mlp_fwd(acc, w1d, b1d, w2t, b2d, B, C, SQ, mean2, z2, h2, g2)
+    assert float(acc.abs().max()) == 0.0, "se_mlp_fwd hands the accumulator back zeroed"
+    assert float((mean2.cpu() - m.detach()).abs().max()) <= 1e-5 and float((g2.cpu() - gate.detach()).abs().max()) <= 2e-5, "fused se gate"
+    assert float((z2.cpu() - z1.detach()).abs().max()) <= 2e-5 and float((h2.cpu() - h1.detach()).abs().max()) <= 2e-5
+    dacc = torch.zeros(B, C, device=device)
+    lib.se_bwd_gate(gyd, xd, B, HW, C, dacc)
+    pre = 0.25                                                    # the gradient buffers already hold something: += semantics
+    fw1, fb1, fw2, fb2 = (torch.full_like(t, pre) for t in (w1d, b1d, w2d, b2d))
+    dz2f, dz1f, dmeanf = torch.empty(B, C, device=device), torch.empty(B, SQ, device=device), torch.empty(B, C, device=device)
+    lib.se_mlp_bwd(dacc, g2, z2, h2, mean2, w1d, w2t, B, C, SQ, dz2f, dz1f, dmeanf, fw1, fb1, fw2, fb2)
+    assert float(dacc.abs().max()) == 0.0, "se_mlp_bwd hands the accumulator back zeroed"
+    dx2 = torch.empty(B, H, W, C, device=device)
+    lib.se_scale(gyd, g2, dmeanf, 1.0 / HW, B, HW, C, dx2)
+    rel(dx2, xr.grad.permute(0, 2, 3, 1), "fused dx")
+    rel(fw1 - pre, w1r.grad, "fused dw1"); rel(fb1 - pre, b1r.grad, "fused db1"); rel(fw2 - pre, w2r.grad, "fused dw2"); rel(fb2 - pre, b2r.grad, "fused db2")
 
 
 # ------------------------------------------------------------------------------------------------
