@@ -200,6 +200,7 @@ class HifihrLib:
         c.hifihr_se_scale.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_bwd_gate.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_mlp_supported.argtypes = [c_int, c_int]
+        c.hifihr_drop_connect_add.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_size_t, _c_float_p, c_void_p]
         c.hifihr_se_mlp_fwd.argtypes = [_c_float_p] * 5 + [c_int] * 3 + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_se_mlp_bwd.argtypes = [_c_float_p] * 7 + [c_int] * 3 + [_c_float_p] * 7 + [c_void_p]
         c.hifihr_mmpool_fwd.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, _c_int_p, _c_float_p, _c_float_p, c_void_p]
@@ -207,6 +208,8 @@ class HifihrLib:
                                         _c_float_p, c_void_p]
         c.hifihr_maxpool2d_fwd.argtypes = [_c_float_p] + [c_int] * 7 + [_c_float_p, c_void_p, c_void_p]
         c.hifihr_maxpool2d_bwd.argtypes = [_c_float_p, c_void_p] + [c_int] * 7 + [_c_float_p, c_void_p]
+        c.hifihr_maxpool2d_bwd_relu.argtypes = [_c_float_p, c_void_p, _c_float_p] + [c_int] * 7 + [_c_float_p, c_void_p]
+        c.hifihr_wino_output_transform_mask_m.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_adam_step.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
                                        c_float, c_float, c_float, c_int, c_void_p]
         c.hifihr_adam_step_dyn.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
@@ -524,7 +527,12 @@ class HifihrLib:
         self.check(self.c.hifihr_procrustes_error(_fp(pred), _fp(gt), B, N, _fp(aligned), _fp(err_sum), _stream_of(pred)),
                    "hifihr_procrustes_error")
 
-    def wino_output_transform(self, M, y, stats, N, H, W, K, bias=None, act=0, m=2):
+    def wino_output_transform(self, M, y, stats, N, H, W, K, bias=None, act=0, m=2, mask=None):
+        if mask is not None:
+            assert stats is None and bias is None and not act and m == 4
+            self.check(self.c.hifihr_wino_output_transform_mask_m(_fp(M), _fp(y), _fp(mask), N, H, W, K, m, _stream_of(M)),
+                       "hifihr_wino_output_transform_mask_m")
+            return
         if bias is not None or act:
             assert stats is None
             self.check(self.c.hifihr_wino_output_transform_act_m(_fp(M), _fp(y), _fp(bias), act, N, H, W, K, m, _stream_of(M)),
@@ -609,6 +617,10 @@ class HifihrLib:
     def se_scale(self, x, gate, add, add_scale, B, HW, C, y):
         self.check(self.c.hifihr_se_scale(_fp(x), _fp(gate), _fp(add), float(add_scale), B, HW, C, _fp(y), _stream_of(x)), "hifihr_se_scale")
 
+    def drop_connect_add(self, x, skip, u, keep, B, per_sample, out):
+        self.check(self.c.hifihr_drop_connect_add(_fp(x), _fp(skip), _fp(u), float(keep), B, int(per_sample), _fp(out), _stream_of(x)),
+                   "hifihr_drop_connect_add")
+
     def se_mlp_supported(self, C, SQ):
         return bool(self.c.hifihr_se_mlp_supported(int(C), int(SQ)))
 
@@ -673,7 +685,11 @@ class HifihrLib:
         self.check(self.c.hifihr_maxpool2d_fwd(_fp(x), N, H, W, C, k, s, p, _fp(y), c_void_p(tap.data_ptr()), _stream_of(x)),
                    "hifihr_maxpool2d_fwd")
 
-    def maxpool2d_bwd(self, gy, tap, N, H, W, C, k, s, p, dx):
+    def maxpool2d_bwd(self, gy, tap, N, H, W, C, k, s, p, dx, relu_y=None):
+        if relu_y is not None:
+            self.check(self.c.hifihr_maxpool2d_bwd_relu(_fp(gy), c_void_p(tap.data_ptr()), _fp(relu_y), N, H, W, C, k, s, p, _fp(dx),
+                                                        _stream_of(gy)), "hifihr_maxpool2d_bwd_relu")
+            return
         self.check(self.c.hifihr_maxpool2d_bwd(_fp(gy), c_void_p(tap.data_ptr()), N, H, W, C, k, s, p, _fp(dx), _stream_of(gy)),
                    "hifihr_maxpool2d_bwd")
 

@@ -692,7 +692,15 @@ int hifihr_maxpool2d_bwd(const float* gy, const unsigned char* tap, int N, int H
                          void* stream) {
   if (!gy || !tap || !dx || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0 || !pool_ok(k, s, p) || H + 2 * p < k || W + 2 * p < k)
     return fail(HIFIHR_EINVAL, "hifihr_maxpool2d_bwd: bad argument (C % 4 == 0; (k,s,p) in {(3,2,1), (3,1,1), (2,2,0)})");
-  HIP_TRY(hifihr::launch_maxpool_bwd(gy, tap, N, H, W, C, k, s, p, dx, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_maxpool_bwd(gy, tap, nullptr, N, H, W, C, k, s, p, dx, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_maxpool2d_bwd_relu(const float* gy, const unsigned char* tap, const float* y, int N, int H, int W, int C, int k, int s, int p,
+                              float* dx, void* stream) {
+  if (!gy || !tap || !y || !dx || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0 || !pool_ok(k, s, p) || H + 2 * p < k || W + 2 * p < k)
+    return fail(HIFIHR_EINVAL, "hifihr_maxpool2d_bwd_relu: bad argument (C % 4 == 0; (k,s,p) in {(3,2,1), (3,1,1), (2,2,0)})");
+  HIP_TRY(hifihr::launch_maxpool_bwd(gy, tap, y, N, H, W, C, k, s, p, dx, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
@@ -862,6 +870,13 @@ int hifihr_se_bwd_gate(const float* dy, const float* x, int B, int HW, int C, fl
 }
 
 int hifihr_se_mlp_supported(int C, int SQ) { return hifihr::se_mlp_supported(C, SQ) ? 1 : 0; }
+
+int hifihr_drop_connect_add(const float* x, const float* skip, const float* u, float keep, int B, size_t per_sample, float* out, void* stream) {
+  if (!x || !u || !out || B <= 0 || per_sample == 0 || per_sample % 4 != 0 || !(keep > 0.f))
+    return fail(HIFIHR_EINVAL, "hifihr_drop_connect_add: bad argument (per_sample % 4 == 0, keep > 0)");
+  HIP_TRY(hifihr::launch_drop_connect_add(x, skip, u, keep, B, per_sample, out, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
 
 int hifihr_se_mlp_fwd(float* mean_acc, const float* w1, const float* b1, const float* w2t, const float* b2, int B, int C, int SQ, float* mean,
                       float* z1, float* h1, float* gate, void* stream) {
@@ -1054,7 +1069,7 @@ int hifihr_wino_dy_transform_m(const float* dy, float* Y, int N, int H, int W, i
 int hifihr_wino_output_transform_m(const float* M, float* y, float* stats, int N, int H, int W, int K, int m, void* stream) {
   if (m != 4) return hifihr_wino_output_transform(M, y, stats, N, H, W, K, stream);
   if (!M || !y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform: bad argument");
-  HIP_TRY(hifihr::launch_wino4_output_transform(M, y, stats, nullptr, 0, N, H, W, K, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_wino4_output_transform(M, y, stats, nullptr, 0, nullptr, N, H, W, K, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
@@ -1121,7 +1136,15 @@ int hifihr_wino_output_transform_act_m(const float* M, float* y, const float* bi
   if (m != 4) return hifihr_wino_output_transform_act(M, y, bias, act, N, H, W, K, stream);
   if (!M || !y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0 || act < 0 || act > 1)
     return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform_act: bad argument");
-  HIP_TRY(hifihr::launch_wino4_output_transform(M, y, nullptr, bias, act, N, H, W, K, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_wino4_output_transform(M, y, nullptr, bias, act, nullptr, N, H, W, K, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_wino_output_transform_mask_m(const float* M, float* y, const float* mask, int N, int H, int W, int K, int m, void* stream) {
+  if (m != 4) return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform_mask_m: the F(4x4, 3x3) pipeline only (m == 4)");
+  if (!M || !y || !mask || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_wino_output_transform_mask_m: bad argument");
+  HIP_TRY(hifihr::launch_wino4_output_transform(M, y, nullptr, nullptr, 0, mask, N, H, W, K, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

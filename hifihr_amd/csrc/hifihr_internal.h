@@ -234,7 +234,7 @@ hipError_t launch_mmpool_bwd(const float* gy, const float* p, const int* argmax,
 // nn.MaxPool2d(k, s, p) for (k, s, p) in {(3, 2, 1), (3, 1, 1), (2, 2, 0)}
 hipError_t launch_maxpool_fwd(const float* x, int N, int H, int W, int C, int k, int s, int p, float* y, unsigned char* tap,
                               hipStream_t st);
-hipError_t launch_maxpool_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, int k, int s, int p, float* dx,
+hipError_t launch_maxpool_bwd(const float* gy, const unsigned char* tap, const float* ymask, int N, int H, int W, int C, int k, int s, int p, float* dx,
                               hipStream_t st);
 // g = dy * (y > 0), db_acc[c] += sum over rows of g   (conv + bias + ReLU backward; g may alias dy)
 hipError_t launch_bias_relu_bwd(const float* dy, const float* y, long M, int C, float* g, float* db_acc, hipStream_t st);
@@ -287,6 +287,8 @@ hipError_t launch_linear_bwd(const LinearArgs& a, const LinearGrads& g, hipStrea
 hipError_t launch_se_pool(const float* x, int B, int HW, int C, float* mean_zeroed, hipStream_t st);
 hipError_t launch_se_bwd_gate(const float* dy, const float* x, int B, int HW, int C, float* dgate_zeroed, hipStream_t st);
 hipError_t launch_se_scale(const float* x, const float* gate, const float* add, float ascale, int B, int HW, int C, float* y, hipStream_t st);
+hipError_t launch_drop_connect_add(const float* x, const float* skip, const float* u, float keep, int B, size_t per_sample, float* out,
+                                   hipStream_t st);
 // the two layers between pooling and scaling, fused (se.hip): W1[SQ][C], W2T[SQ][C] = the transposed W2[C][SQ]
 bool se_mlp_supported(int C, int SQ);
 hipError_t launch_se_mlp_fwd(float* mean_acc, const float* W1, const float* b1, const float* W2T, const float* b2, int B, int C, int SQ,
@@ -363,7 +365,7 @@ hipError_t launch_wino4_bn_bwd_dual_transform(const float* g, const float* y, co
                                               hipStream_t st);
 hipError_t launch_bn_bwd_apply(const float* g, const float* x, const float* save_mean, const float* save_invstd, const float* gamma, long M,
                                int C, float* red, float* dx, float* dgamma_acc, float* dbeta_acc, hipStream_t st);
-hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
+hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, const float* mask, int N, int H, int W, int K,
                                          hipStream_t st);
 hipError_t launch_wino4_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st);
 hipError_t launch_wino4_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st);

@@ -160,9 +160,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 }
 
 // thread = (input pixel, 4 channels): sum gy over the windows whose winning tap is this pixel
+// ymask (round 4): the pool's own OUTPUT when its input was a ReLU's output -- a window's gradient then passes only where the pooled value
+// is positive (the winning tap holds the window's maximum, and relu'(z) = [relu(z) > 0] there; the other taps get nothing anyway), i.e.
+// the ReLU's backward without a pass over the four-times larger pre-pool tensors
 template <int K, int S, int P>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ tap, int N, int H,
-                                                         int W, int C, int OH, int OW, float* __restrict__ dx) {
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ tap,
+                                                         const float* __restrict__ ymask, int N, int H, int W, int C, int OH, int OW,
+                                                         float* __restrict__ dx) {
   const int C4 = C / 4;
   const size_t total = (size_t)N * H * W * C4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -197,6 +201,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         const size_t o = ((((size_t)n * OH + ohc[j]) * OW + owc[k]) * C4 + cg) * 4;
         t[j][k] = *reinterpret_cast<const uchar4*>(tap + o);
         g[j][k] = *reinterpret_cast<const float4*>(gy + o);
+        if (ymask != nullptr) {                             // (uniform)
+          const float4 m = *reinterpret_cast<const float4*>(ymask + o);
+          g[j][k].x = m.x > 0.f ? g[j][k].x : 0.f; g[j][k].y = m.y > 0.f ? g[j][k].y : 0.f;
+          g[j][k].z = m.z > 0.f ? g[j][k].z : 0.f; g[j][k].w = m.w > 0.f ? g[j][k].w : 0.f;
+        }
       }
 #pragma unroll
     for (int j = 0; j < NR; ++j)
@@ -232,14 +241,14 @@ hipError_t launch_maxpool_fwd(const float* x, int N, int H, int W, int C, int k,
   return hipGetLastError();
 }
 
-hipError_t launch_maxpool_bwd(const float* gy, const unsigned char* tap, int N, int H, int W, int C, int k, int s, int p, float* dx,
+hipError_t launch_maxpool_bwd(const float* gy, const unsigned char* tap, const float* ymask, int N, int H, int W, int C, int k, int s, int p, float* dx,
                               hipStream_t st) {
   if (C % 4 != 0) return hipErrorInvalidValue;
   const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
   const dim3 grid(pool_grid((size_t)N * H * W * (C / 4)));
-  if (k == 3 && s == 2 && p == 1) hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, st, gy, tap, N, H, W, C, OH, OW, dx);
-  else if (k == 3 && s == 1 && p == 1) hipLaunchKernelGGL((maxpool_bwd_kernel<3, 1, 1>), grid, dim3(256), 0, st, gy, tap, N, H, W, C, OH, OW, dx);
-  else if (k == 2 && s == 2 && p == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<2, 2, 0>), grid, dim3(256), 0, st, gy, tap, N, H, W, C, OH, OW, dx);
+  if (k == 3 && s == 2 && p == 1) hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, st, gy, tap, ymask, N, H, W, C, OH, OW, dx);
+  else if (k == 3 && s == 1 && p == 1) hipLaunchKernelGGL((maxpool_bwd_kernel<3, 1, 1>), grid, dim3(256), 0, st, gy, tap, ymask, N, H, W, C, OH, OW, dx);
+  else if (k == 2 && s == 2 && p == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<2, 2, 0>), grid, dim3(256), 0, st, gy, tap, ymask, N, H, W, C, OH, OW, dx);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

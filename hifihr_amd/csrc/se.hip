@@ -287,6 +287,35 @@ hipError_t launch_se_mlp_bwd(float* dgate_acc, const float* gate, const float* z
   return hipGetLastError();
 }
 
+// drop-connect + skip of an MBConv block (reference network/efficientnet_pt/utils.py:82-91, model.py:91-94) in ONE pass:
+//   out = x / keep * floor(keep + u[b]) (+ skip),  u[b] the block's per-sample uniform draw;  the backward is the same kernel on dy
+// without a skip.  ATen ran six launches forward (add, floor, div, mul on broadcast shapes, add) and four backward per skip block.
+__global__ __launch_bounds__(256) void drop_connect_add_kernel(const float* __restrict__ x, const float* __restrict__ skip, const float* __restrict__ u,
+                                                              float keep, int B, size_t per4, float* __restrict__ out) {
+  const float inv_keep = 1.0f / keep;
+  const size_t total = (size_t)B * per4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int b = (int)(i / per4);
+    const float m = floorf(keep + u[b]);
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    float4 r = make_float4(v.x * inv_keep * m, v.y * inv_keep * m, v.z * inv_keep * m, v.w * inv_keep * m);
+    if (skip != nullptr) {
+      const float4 a = *reinterpret_cast<const float4*>(skip + i * 4);
+      r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = r;
+  }
+}
+
+hipError_t launch_drop_connect_add(const float* x, const float* skip, const float* u, float keep, int B, size_t per_sample, float* out,
+                                   hipStream_t st) {
+  if (per_sample % 4 != 0 || !(keep > 0.f)) return hipErrorInvalidValue;
+  size_t blocks = ((size_t)B * (per_sample / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(drop_connect_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, skip, u, keep, B, per_sample / 4, out);
+  return hipGetLastError();
+}
+
 static dim3 se_reduce_grid(int B, int HW, int C) {
   const int cb = (C + 63) / 64;
   int z = (512 + B * cb - 1) / (B * cb);

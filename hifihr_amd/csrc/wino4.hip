@@ -98,9 +98,11 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
 }
 
 // workgroup = 16 tile lanes x 16 float4 channel lanes (64 channels, blockIdx.y); M[36][T][K] -> y[N][H][W][K] (+ stats | bias, ReLU)
+// mask (backward-data of a layer whose INPUT is a ReLU's output, round 4): y = mask > 0 ? v : 0 -- the ReLU's backward applied where its
+// gradient is produced, instead of a bias_relu_bwd pass over (dy, y) in front of the previous layer's backward
 __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Mm, float* __restrict__ y, float* __restrict__ stats,
-                                                                    const float* __restrict__ bias, int relu, int N, int H, int W, int K,
-                                                                    int TH, int TW) {
+                                                                    const float* __restrict__ bias, int relu, const float* __restrict__ mask,
+                                                                    int N, int H, int W, int K, int TH, int TW) {
   __shared__ double red[2][16][16][4];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int k = blockIdx.y * 64 + cl * 4;
@@ -129,12 +131,19 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
         V4 o[4];
         at6(s[a], o);
         if (oh < H) {
-          float* p = y + (((size_t)n * H + oh) * W + 4 * tw) * K + k;
+          const size_t po = (((size_t)n * H + oh) * W + 4 * tw) * K + k;
+          float* p = y + po;
+          V4 mk[4];
+          if (mask != nullptr) {                            // (uniform) the row's mask values requested together
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mk[b] = ld4(mask + po + (size_t)(4 * tw + b < W ? b : 0) * K);
+          }
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
             if (4 * tw + b < W) {
               V4 v = o[b] + bv;
               v = V4{fmaxf(v.x, lo), fmaxf(v.y, lo), fmaxf(v.z, lo), fmaxf(v.w, lo)};
+              if (mask != nullptr) v = V4{mk[b].x > 0.f ? v.x : 0.f, mk[b].y > 0.f ? v.y : 0.f, mk[b].z > 0.f ? v.z : 0.f, mk[b].w > 0.f ? v.w : 0.f};
               st4(p + (size_t)b * K, v);
               if (a == 0 && b == 0) st.seed(make_float4(v.x, v.y, v.z, v.w));      // (a tile's first pixel is always inside the image)
               st.add(make_float4(v.x, v.y, v.z, v.w));
@@ -244,14 +253,14 @@ hipError_t launch_wino4_input_transform(const float* x, float* V, float* Y, int 
   return hipGetLastError();
 }
 
-hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, int N, int H, int W, int K,
+hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, const float* mask, int N, int H, int W, int K,
                                          hipStream_t st) {
   if (K % 4 != 0) return hipErrorInvalidValue;
   const int TH = (H + 3) / 4, TW = (W + 3) / 4;
   const size_t T = (size_t)N * TH * TW;
   size_t bx = (T + 15) / 16;
   if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(wino4_output_transform_kernel, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, bias, relu, N, H, W, K, TH, TW);
+  hipLaunchKernelGGL(wino4_output_transform_kernel, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, bias, relu, mask, N, H, W, K, TH, TW);
   return hipGetLastError();
 }
 

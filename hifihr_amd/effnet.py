@@ -147,10 +147,8 @@ class MBConvBlock(nn.Module):
         x = ops.squeeze_excite(x, self._se_reduce, self._se_expand)        # pool + 2 small linears + scale, fused
         x = _conv_bn_swish(self._project_conv, self._bn2, x, act=False)
         if self.stride == 1 and self.cin == self.cout:
-            if drop_connect_rate and self.training:                       # utils.py:82-91
-                keep = 1 - drop_connect_rate
-                mask = torch.floor(keep + _drop_connect_uniform(x))
-                x = x / keep * mask
+            if drop_connect_rate and self.training:                       # utils.py:82-91: x / keep * floor(keep + u) + inputs, one launch
+                return ops.drop_connect_add(x, inputs, _drop_connect_uniform(x), 1 - drop_connect_rate)
             x = x + inputs
         return x
 

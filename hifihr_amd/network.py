@@ -46,11 +46,12 @@ class Conv2dMFMA(nn.Module):
             bound = 1.0 / (cin * k * k) ** 0.5
             self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
 
-    def forward(self, x, want_stats=False):
+    def forward(self, x, want_stats=False, grad_premasked=False, mask_input_grad=False):
         from . import ops
         w = self.weight          # the 3-channel stem: the input arrives as NHWC4; ops.conv2d pads the filter (and un-pads its gradient)
         if self.bias is not None:
-            return ops.conv2d_bias_act(x, w, self.bias, self.stride, self.pad, self.relu)   # conv + bias (+ ReLU), one launch
+            return ops.conv2d_bias_act(x, w, self.bias, self.stride, self.pad, self.relu,   # conv + bias (+ ReLU), one launch
+                                       grad_premasked=grad_premasked and not self.bias.requires_grad, mask_input_grad=mask_input_grad)
         return ops.conv2d(x, w, self.stride, self.pad, want_stats)
 
 

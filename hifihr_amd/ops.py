@@ -536,7 +536,7 @@ class prepared_weights:
         return False
 
 
-def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None, dy_out=None, tile=None):
+def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None, dy_out=None, tile=None, mask=None):
     """y[N][H][W][K] = conv3x3(x[N][H][W][C], w[K][3][3][C]) through weight / input transform, 16 batched GEMMs, output
     transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter).
     keep_v: return the transformed input V[16][T][C] in a tensor of its own (the Winograd weight gradient consumes it)."""
@@ -570,7 +570,7 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias
     else:
         lib.wino_input_transform(x, V, N, H, W, C, m)
     lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws, m=m)          # csrc/gemm.hip (16x16x4 f32 MFMA); odd channel counts: conv.hip
-    lib.wino_output_transform(M, y, stats, N, H, W, K, bias=bias, act=act, m=m)
+    lib.wino_output_transform(M, y, stats, N, H, W, K, bias=bias, act=act, m=m, mask=mask)      # mask: y = mask > 0 ? y : 0 (m == 4)
     return V if keep_v else None
 
 
@@ -604,11 +604,17 @@ def _stem_c3_wgrad(lib, ctx, x, gy):
 
 class _Conv2dMFMA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, pad, want_stats=False, bias=None, relu=False):
+    def forward(ctx, x, w, stride, pad, want_stats=False, bias=None, relu=False, grad_premasked=False, mask_input_grad=False):
+        """grad_premasked (relu=True, frozen bias): the gradient reaches this layer ALREADY multiplied by [y > 0] -- its consumer applied
+        this layer's ReLU backward where it produced the gradient (a convolution with mask_input_grad, or a max-pool with relu_input).
+        mask_input_grad: x is a ReLU's output; dx is returned multiplied by [x > 0] (fused into the F(4x4, 3x3) output transform of the
+        backward-data product, else one bias_relu_bwd pass), so the producer of x can be told grad_premasked.  (VGG19 of the perceptual
+        loss: the ReLU backward passes over (dy, y) of its 150-620 MB maps were 1.3 ms per step at batch 48.)"""
         require_cuda(x, w)
         lib = get_lib()
         x = x.contiguous(memory_format=_CL)
         wk = w.contiguous(memory_format=_CL)                      # physical [K][R][S][C]
+        ctx.grad_premasked, ctx.mask_input_grad = bool(grad_premasked), bool(mask_input_grad)
         N, C, H, W = x.shape
         K, Cw, R, S = wk.shape
         ctx.w3 = None
@@ -658,7 +664,7 @@ class _Conv2dMFMA(torch.autograd.Function):
         ctx.geom = (N, H, W, C, K, R, S, stride, pad)
         # Winograd layers keep the transformed input V (4x the size of x, 288 GB of HBM do not care) instead of x: the weight
         # gradient reduces Y' . V in the transform domain and backward-data needs neither
-        ctx.save_for_backward(x if v_saved is None else None, wk, y if relu else None, v_saved)
+        ctx.save_for_backward(x if (v_saved is None or mask_input_grad) else None, wk, y if (relu and not grad_premasked) else None, v_saved)
         ctx.w_param, ctx.b_param, ctx.relu = w, bias, relu
         ctx.set_materialize_grads(False)         # no zero-fill launch for the (non-differentiable) stats output
         if want_stats:
@@ -679,7 +685,9 @@ class _Conv2dMFMA(torch.autograd.Function):
             # conv + bias (+ ReLU) epilogue: masked gradient and the bias gradient in one small launch
             b = ctx.b_param
             db_t, db_ret = _acc_target(b, b.shape, gy.device) if (b is not None and ctx.needs_input_grad[5]) else (None, None)
-            if ctx.relu:
+            if ctx.relu and ctx.grad_premasked:
+                assert db_t is None, "grad_premasked needs a frozen bias (the bias gradient comes out of the masking pass)"
+            elif ctx.relu:
                 g = torch.empty_like(gy, memory_format=_CL)
                 M = gy.numel() // K
                 PROFILE.bracket("bias_relu_bwd", lambda: lib.bias_relu_bwd(gy, y, M, K, g, db_t))
@@ -688,11 +696,14 @@ class _Conv2dMFMA(torch.autograd.Function):
                 raise NotImplementedError("gradient of a conv bias without ReLU")   # only the frozen VGG19 has such a layer
             if b is not None and db_t is not None and db_ret is None:
                 _grad_ready(b)
+        masked = False
         if ctx.needs_input_grad[0] and _wino_ok(C, K, R, S, stride, pad):
             # backward-data of a stride-1 3x3 = the same Winograd pipeline on dy with the transposed, rotated filter
             dx = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32, memory_format=_CL)
             tile = _wino_tile(lib, N, H, W, C, K)
             wm, wP, wT = tile
+            mk = x if (ctx.mask_input_grad and wm == 4) else None         # [x > 0] applied in the output transform
+            masked = mk is not None
             U2 = _WEIGHT_PREP.get(ctx.w_param, wk, 2 if wm == 2 else 4)
             if ctx.needs_input_grad[1] and v_saved is not None:      # the Winograd backward-weight below wants A dy A^T: same read of dy
                 # a side-stream weight gradient reads it while the next layer's backward-data already runs: a buffer of its own
@@ -700,11 +711,11 @@ class _Conv2dMFMA(torch.autograd.Function):
 
             def run():
                 if U2 is not None:
-                    _wino_conv(lib, gy, None, dx, None, N, H, W, K, C, 1, U=U2, dy_out=Yt_done, tile=tile)
+                    _wino_conv(lib, gy, None, dx, None, N, H, W, K, C, 1, U=U2, dy_out=Yt_done, tile=tile, mask=mk)
                 else:
                     wt = _wino_scratch(gy.device, "wt", wk.numel())
                     lib.weight_transpose(wk, wt, K, R * S, C)
-                    _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1, dy_out=Yt_done, tile=tile)
+                    _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1, dy_out=Yt_done, tile=tile, mask=mk)
             PROFILE.bracket("conv_dgrad_wino", run)
         elif ctx.needs_input_grad[0] and ctx.w3 is None and _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad) and \
                 _WEIGHT_PREP.get(ctx.w_param, wk, 2) is not None:
@@ -725,6 +736,10 @@ class _Conv2dMFMA(torch.autograd.Function):
             else:
                 scratch = torch.empty(wk.numel(), device=x.device, dtype=torch.float32)
                 PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data(gy, wk, dx, scratch, N, H, W, C, K, R, S, stride, pad, ws=ws))
+        if ctx.mask_input_grad and dx is not None and not masked:
+            dxm = torch.empty_like(dx, memory_format=_CL)
+            PROFILE.bracket("bias_relu_bwd", lambda: lib.bias_relu_bwd(dx, x, dx.numel() // C, C, dxm, None))
+            dx = dxm
         if ctx.needs_input_grad[1] and ctx.w3 is not None:
             dw = _stem_c3_wgrad(lib, ctx, x, gy)
         elif ctx.needs_input_grad[1]:
@@ -776,13 +791,14 @@ class _Conv2dMFMA(torch.autograd.Function):
                 go()
             if dw is None:
                 _grad_ready(w)
-        return dx, dw, None, None, None, db_ret, None
+        return dx, dw, None, None, None, db_ret, None, None, None
 
 
-def conv2d_bias_act(x, w, bias, stride=1, pad=0, relu=True):
+def conv2d_bias_act(x, w, bias, stride=1, pad=0, relu=True, grad_premasked=False, mask_input_grad=False):
     """F.conv2d(x, w, bias, stride, pad) followed by ReLU if `relu`, in one launch (LightEstimator, reference
-    network/res_encoder.py:150-210; VGG19 features of the perceptual loss, utils/perceptual_loss.py:27-36)."""
-    return _Conv2dMFMA.apply(x, w, stride, pad, False, bias, relu)
+    network/res_encoder.py:150-210; VGG19 features of the perceptual loss, utils/perceptual_loss.py:27-36).
+    grad_premasked / mask_input_grad: where the ReLU backward of a conv + ReLU chain runs (see _Conv2dMFMA.forward)."""
+    return _Conv2dMFMA.apply(x, w, stride, pad, False, bias, relu, grad_premasked, mask_input_grad)
 
 
 def conv2d_bias_relu(x, w, bias, stride=1, pad=0):
@@ -1566,6 +1582,37 @@ class _SqueezeExcite(torch.autograd.Function):
 _SE_FUSED = os.environ.get("HIFIHR_SE_FUSED", "1") != "0"
 
 
+class _DropConnectAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, skip, u, keep):
+        require_cuda(x, skip, u)
+        x, skip = x.contiguous(memory_format=_CL), skip.contiguous(memory_format=_CL)
+        u = u.reshape(-1).contiguous().float()
+        B = x.shape[0]
+        out = torch.empty_like(x, memory_format=_CL)
+        PROFILE.bracket("drop_connect_add", lambda: get_lib().drop_connect_add(x, skip, u, keep, B, x.numel() // B, out))
+        ctx.save_for_backward(u)
+        ctx.keep = keep
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (u,) = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=_CL)
+        B = dy.shape[0]
+        dx = torch.empty_like(dy, memory_format=_CL)
+        PROFILE.bracket("drop_connect_add", lambda: get_lib().drop_connect_add(dy, None, u, ctx.keep, B, dy.numel() // B, dx))
+        return dx, dy, None, None
+
+
+def drop_connect_add(x, skip, u, keep):
+    """x / keep * floor(keep + u[b]) + skip: the drop-connect and the skip connection of an MBConv block (reference
+    network/efficientnet_pt/utils.py:82-91, model.py:91-94) as one launch per direction (u: the block's per-sample uniform draws)."""
+    if x.numel() // x.shape[0] % 4 != 0:
+        return x / keep * torch.floor(keep + u.reshape(-1, 1, 1, 1)) + skip
+    return _DropConnectAdd.apply(x, skip, u, float(keep))
+
+
 def squeeze_excite(x, reduce_conv, expand_conv):
     """x * sigmoid(expand(swish(reduce(mean_hw(x))))) for channels_last x; reduce / expand are the block's 1x1 nn.Conv2d with
     bias (reference network/efficientnet_pt/model.py:82-86): 3 launches forward, 4 backward."""
@@ -1621,7 +1668,7 @@ def mmpool(x, p):
 
 class _MaxPool2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, k, s, p):
+    def forward(ctx, x, k, s, p, relu_input=False):
         require_cuda(x)
         x = x.contiguous(memory_format=_CL)
         N, C, H, W = x.shape
@@ -1629,23 +1676,25 @@ class _MaxPool2d(torch.autograd.Function):
         y = torch.empty((N, C, OH, OW), device=x.device, memory_format=_CL)
         tap = torch.empty(N * OH * OW * C, dtype=torch.uint8, device=x.device)
         PROFILE.bracket("maxpool_fwd", lambda: get_lib().maxpool2d_fwd(x, N, H, W, C, k, s, p, y, tap))
-        ctx.save_for_backward(tap)
+        ctx.save_for_backward(tap, y if relu_input else None)
         ctx.cfg = (N, C, H, W, k, s, p)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        tap, = ctx.saved_tensors
+        tap, y = ctx.saved_tensors
         N, C, H, W, k, s, p = ctx.cfg
         gy = gy.contiguous(memory_format=_CL)
         dx = torch.empty((N, C, H, W), device=gy.device, memory_format=_CL)
-        PROFILE.bracket("maxpool_bwd", lambda: get_lib().maxpool2d_bwd(gy, tap, N, H, W, C, k, s, p, dx))
-        return dx, None, None, None
+        PROFILE.bracket("maxpool_bwd", lambda: get_lib().maxpool2d_bwd(gy, tap, N, H, W, C, k, s, p, dx, relu_y=y))
+        return dx, None, None, None, None
 
 
-def maxpool2d(x, k, s, p):
-    """nn.MaxPool2d(k, s, p) on channels_last activations, (k, s, p) in {(3,2,1), (3,1,1), (2,2,0)}."""
-    return _MaxPool2d.apply(x, k, s, p)
+def maxpool2d(x, k, s, p, relu_input=False):
+    """nn.MaxPool2d(k, s, p) on channels_last activations, (k, s, p) in {(3,2,1), (3,1,1), (2,2,0)}.  relu_input: x is a ReLU's output and
+    the gradient returned is ALSO multiplied by the ReLU's [x > 0] (only the winning taps receive anything, and there x = the pooled
+    value): the producer of x is then told `grad_premasked`."""
+    return _MaxPool2d.apply(x, k, s, p, relu_input)
 
 
 def maxpool3x3s2(x):

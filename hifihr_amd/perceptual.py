@@ -122,15 +122,23 @@ class PerceptualLoss(nn.Module):
         from . import ops
         x = _NormalizeToNHWC4.apply(images)
         skip = False
-        for m, (_, kind, _, _) in zip(self.model, self.layout):
+        kinds = [k for (_, k, _, _) in self.layout]
+        # Where a conv + ReLU is followed by another convolution or by a pool, the ReLU's backward runs inside THAT layer's backward
+        # (the F(4x4, 3x3) output transform / the pool's scatter mask the gradient they produce), and the convolution in front is told
+        # that its gradient arrives masked: four of the six bias_relu_bwd passes over (dy, y) of 150-620 MB each are gone.
+        relu_before = False                    # x is the output of a fused conv + ReLU
+        for j, (m, kind) in enumerate(zip(self.model, kinds)):
             if kind == "conv":
-                x = m(x)                       # bias + ReLU inside the convolution's epilogue when a ReLU follows
-                skip = m.relu
+                nxt = kinds[j + 2] if (m.relu and j + 2 < len(kinds)) else None        # what consumes relu(conv(x))
+                x = m(x, grad_premasked=nxt in ("conv", "pool"), mask_input_grad=relu_before)
+                skip = m.relu                  # bias + ReLU inside the convolution's epilogue when a ReLU follows
+                relu_before = m.relu
             elif kind == "relu":
                 assert skip
                 skip = False
             else:
-                x = ops.maxpool2d(x, 2, 2, 0)
+                x = ops.maxpool2d(x, 2, 2, 0, relu_input=relu_before)
+                relu_before = False
         return x
 
     def forward(self, fakeIm, realIm):

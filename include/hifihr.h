@@ -296,6 +296,10 @@ int hifihr_wino_gemm_m(const float* v_d, const float* u_d, float* m_d, int N, in
 int hifihr_wino_output_transform_m(const float* m_d, float* y_d, float* stats_d /* or NULL */, int N, int H, int W, int K, int m, void* stream);
 int hifihr_wino_output_transform_act_m(const float* m_d, float* y_d, const float* bias_d /* or NULL */, int act, int N, int H, int W, int K,
                                        int m, void* stream);
+/* Output transform of a BACKWARD-DATA product whose layer input was a ReLU's output (VGG19 conv + ReLU -> conv): y_d = mask_d > 0 ? A^T m A : 0
+ * with mask_d[N][H][W][K] = that ReLU output (the layer's saved input) -- the ReLU's backward where its gradient is produced, instead of a
+ * hifihr_bias_relu_bwd pass in front of the previous layer's backward.  m == 4 only. */
+int hifihr_wino_output_transform_mask_m(const float* m_d, float* y_d, const float* mask_d, int N, int H, int W, int K, int m, void* stream);
 int hifihr_wino_dy_transform_m(const float* dy_d, float* yt_d, int N, int H, int W, int K, int m, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels as Winograd F(2x2, 3x3) in ONE launch, the transforms in
  * registers and nothing of the transform domain in HBM (round 3, csrc/conv_halo.hip: conv_wino2_kernel) -- ResNet layer 1 (reference
@@ -485,6 +489,12 @@ int hifihr_maxpool2d_fwd(const float* x_d, int N, int H, int W, int C, int k, in
                          void* stream);
 int hifihr_maxpool2d_bwd(const float* gy_d, const unsigned char* tap_d, int N, int H, int W, int C, int k, int s, int p,
                          float* dx_d, void* stream);
+/* The same backward for a pool whose INPUT was a ReLU's output (VGG19: conv + ReLU -> MaxPool2d, reference utils/perceptual_loss.py:27-36
+ * over torchvision's features): y_d = the pool's own output; a window's gradient passes only where y > 0, which IS the ReLU's backward at
+ * the winning tap (the other taps receive nothing) -- dx_d is then the gradient of the convolution output, no pass over (dy, relu output)
+ * of the four-times larger pre-pool tensor is needed. */
+int hifihr_maxpool2d_bwd_relu(const float* gy_d, const unsigned char* tap_d, const float* y_d, int N, int H, int W, int C, int k, int s, int p,
+                              float* dx_d, void* stream);
 
 /* normalize_batch_3C (reference network/res_encoder.py:212-216) fused with NCHW[B][3][H][W] -> NHWC4 [B][H][W][4]
  * (4th channel zero) for the first convolution. */
@@ -619,6 +629,11 @@ int hifihr_se_bwd_gate(const float* dy_d, const float* x_d, int B, int HW, int C
  *      dmean_d[B][C]; ACCUMULATES (+=) dW1[SQ][C], db1[SQ], dW2[C][SQ], db2[C] -- each element summed over the batch by one thread in a
  *      fixed order (bit-reproducible). */
 int hifihr_se_mlp_supported(int C, int SQ);
+/* Drop-connect + skip connection of an MBConv block in one pass (reference network/efficientnet_pt/utils.py:82-91 `drop_connect`,
+ * model.py:91-94): out_d = x_d / keep * floor(keep + u_d[b]) (+ skip_d when not NULL); x / skip / out [B][per_sample], per_sample % 4 == 0,
+ * u_d[B] the per-sample uniform draws.  The backward is the same call on dy with skip_d = NULL. */
+int hifihr_drop_connect_add(const float* x_d, const float* skip_d /* or NULL */, const float* u_d, float keep, int B, size_t per_sample,
+                            float* out_d, void* stream);
 int hifihr_se_mlp_fwd(float* mean_acc_d, const float* w1_d, const float* b1_d, const float* w2t_d, const float* b2_d, int B, int C, int SQ,
                       float* mean_d, float* z1_d, float* h1_d, float* gate_d, void* stream);
 int hifihr_se_mlp_bwd(float* dgate_acc_d, const float* gate_d, const float* z1_d, const float* h1_d, const float* mean_d, const float* w1_d,
