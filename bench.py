@@ -500,7 +500,8 @@ def main():
             # + RGBA out H^2*16 + face-id side buffer S^2*4;  bwd = side buffer + grad RGBA in + grad verts / colours out
             alg_f = Vn * 12 + Fn * 12 + Vn * 24 + Hr * Hr * 16 + Sr * Sr * 4
             alg_b = Sr * Sr * 4 + Hr * Hr * 16 + Vn * 24
-            for key, us, alg, kname, kk in (("roofline_render_fwd", us_f, alg_f, f"render_fwd2_kernel<{h_r.aa}, 8> (+ render_vertex_kernel, render_bin_kernel)", "render_fwd2_kernel"),
+            for key, us, alg, kname, kk in (("roofline_render_fwd", us_f, alg_f, f"render_fwd3_kernel<{h_r.aa}> (+ render_vertex_kernel, render_bin_kernel)",
+                                             "render_fwd3_kernel" if instep_lookup(kprof, "render_fwd3_kernel") else "render_fwd2_kernel"),
                                             ("roofline_render_bwd", us_b, alg_b, f"render_bwd_kernel<{h_r.aa}> (+ render_vertex_bwd_kernel)", "render_bwd_kernel")):
                 ach = alg * Br / (us * 1e-6) / 1e9
                 hit = instep_lookup(kprof, kk)

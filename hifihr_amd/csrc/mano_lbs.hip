@@ -70,10 +70,15 @@ __device__ __forceinline__ void mano_prologue(const ManoDev& t, const float* __r
   __syncthreads();
 }
 
-constexpr int kFwdTiles = 4;
-constexpr int kFwdTileV = 195;   // 4 x 195 = 780 >= 778
+// Round 4: 7 tiles of 112 vertices on 128-thread workgroups (round 3: 4 tiles of 195 on 256 threads).  The kernel is a chain of load
+// latencies per workgroup -- the per-hand prologue, then 145 table rows per vertex -- and a batch of 32 hands gave the 256-CU chip 128
+// workgroups; 224 smaller ones with all 27 rows of a group of pose blend shapes in flight per lane (5 groups instead of 27 of 5) shorten
+// the chain.  Every workgroup redoes the prologue (16 Rodrigues + the kinematic chain: ~2 us).
+constexpr int kFwdTiles = 7;
+constexpr int kFwdTileV = 112;   // 7 x 112 = 784 >= 778
+constexpr int kFwdThreads = 128;
 
-__global__ __launch_bounds__(256) void mano_fwd_kernel(ManoDev t, const float* __restrict__ pose,
+__global__ __launch_bounds__(kFwdThreads) void mano_fwd_kernel(ManoDev t, const float* __restrict__ pose,
                                                       const float* __restrict__ beta, float* __restrict__ verts,
                                                       float* __restrict__ jtr, float* __restrict__ saved_vposed) {
   __shared__ ManoSmall s;
@@ -101,11 +106,19 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(ManoDev t, const float* _
     const float* row = t.sd + (size_t)k * 3 * kNVP + v;
     vp[0] += row[0] * bk; vp[1] += row[kNVP] * bk; vp[2] += row[2 * kNVP] * bk;
   }
-#pragma unroll 5
-  for (int p = 0; p < kNP; ++p) {
-    const float pk = s.pm[p];
-    const float* row = t.pd + (size_t)p * 3 * kNVP + v;
-    vp[0] += row[0] * pk; vp[1] += row[kNVP] * pk; vp[2] += row[2 * kNVP] * pk;
+  static_assert(kNP % 27 == 0, "pose blend shapes in groups of 27");
+  for (int p0 = 0; p0 < kNP; p0 += 27) {
+    float r[27][3];
+#pragma unroll
+    for (int u = 0; u < 27; ++u) {                        // 81 independent loads, then the multiply-adds in the table's order
+      const float* row = t.pd + (size_t)(p0 + u) * 3 * kNVP + v;
+      r[u][0] = row[0]; r[u][1] = row[kNVP]; r[u][2] = row[2 * kNVP];
+    }
+#pragma unroll
+    for (int u = 0; u < 27; ++u) {
+      const float pk = s.pm[p0 + u];
+      vp[0] += r[u][0] * pk; vp[1] += r[u][1] * pk; vp[2] += r[u][2] * pk;
+    }
   }
   // T = sum_i w_i A'_i ; vert = T [v_posed;1]                        (my_mano.py:441-451)
   float T[12];
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(256) void mano_joints_bwd_kernel(ManoDev t, const f
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_mano_fwd(const ManoDev& t, const float* pose, const float* beta, int B, float* verts, float* jtr,
                            float* saved, hipStream_t st) {
-  hipLaunchKernelGGL(mano_fwd_kernel, dim3(kFwdTiles, B), dim3(256), 0, st, t, pose, beta, verts, jtr, saved);
+  hipLaunchKernelGGL(mano_fwd_kernel, dim3(kFwdTiles, B), dim3(kFwdThreads), 0, st, t, pose, beta, verts, jtr, saved);
   return hipGetLastError();
 }
 

@@ -95,8 +95,14 @@ class MyNIMBLELayer(nn.Module):
 class Model(nn.Module):
     def __init__(self, ifRender, device, if_4c, hand_model, use_mean_shape, pretrain, root_id=9, root_id_nimble=11,
                  ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3, texture_stand_in=0,
-                 nimble_tables: NimbleTables | None = None):
+                 nimble_tables: NimbleTables | None = None, conv_precision="fast"):
+        """conv_precision: "fast" (default) -- the encoder's stride-1 3x3 convolutions run as Winograd F(4x4, 3x3) / F(2x2, 3x3); "reference"
+        -- on the direct kernels, whose outputs round like a plain fp32 convolution: the trunk's gradient then stays within ~5e-4 of the
+        reference's instead of ~5e-3 (the ReLU sign flips of README "Precision of the default dispatch") for ~40 % more time per step.
+        Per model, not per process."""
         super().__init__()
+        ops.conv_precision(conv_precision)               # (validates the name)
+        self.conv_precision = conv_precision
         if hand_model not in ("mano", "nimble"):
             raise NotImplementedError(f"hand_model='{hand_model}': 'mano' and 'nimble' are built")
         self.hand_model, self.root_id, self.root_id_nimble = hand_model, root_id, root_id_nimble
@@ -169,7 +175,8 @@ class Model(nn.Module):
         HO-3D branch resizes the crop, utils/traineval_util.py:157)."""
         if images.shape[-1] != self.ENCODER_SIZE:
             images = torch.nn.functional.interpolate(images, (self.ENCODER_SIZE, self.ENCODER_SIZE))
-        return self.base_encoder(images)
+        with ops.conv_precision(self.conv_precision):
+            return self.base_encoder(images)
 
     def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):
         low_features, features = self.encode(images)

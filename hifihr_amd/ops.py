@@ -394,18 +394,47 @@ def _wino_scratch(device, name, numel):
     return t
 
 
-def _wino_ok(C, K, R, S, stride, pad):
+_CONV_PRECISION = ["fast"]
+
+
+class conv_precision:
+    """`with conv_precision("reference"):` -- the convolutions called inside run on the DIRECT kernels (implicit GEMM / halo), no Winograd
+    transform arithmetic: their outputs then round like a plain fp32 convolution (1e-6 of max |y| instead of Winograd F(4x4, 3x3)'s 1e-5),
+    which keeps the ReLU pattern -- and with it the trunk's gradient -- on the reference's side of the discontinuity (README, "Precision of
+    the default dispatch").  "fast" (default): Winograd where it pays.  Per call site, not per process: `Model(conv_precision=...)` wraps its
+    encoder in it; each convolution remembers the mode of its forward for its backward.  (HIFIHR_WINOGRAD=0 is the process-wide form.)"""
+
+    def __init__(self, mode):
+        if mode not in ("fast", "reference"):
+            raise ValueError(f"conv_precision: 'fast' or 'reference', not {mode!r}")
+        self.mode = mode
+
+    def __enter__(self):
+        _CONV_PRECISION.append(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _CONV_PRECISION.pop()
+        return False
+
+
+def _wino_allowed():
+    return _CONV_PRECISION[-1] != "reference" and os.environ.get("HIFIHR_WINOGRAD", "1") != "0"
+
+
+def _wino_ok(C, K, R, S, stride, pad, allowed=None):
     """Winograd F(2x2, 3x3) instead of the direct kernel: stride-1, pad-1 3x3 with >= 128 channels on both sides (measured at
-    B = 32, tools/time_wino.py: 295 -> 180 us at 512 channels, 91 -> 69 at 256, 97 -> 81 at 128; HIFIHR_WINOGRAD=0 disables)."""
-    if os.environ.get("HIFIHR_WINOGRAD", "1") == "0":
+    B = 32, tools/time_wino.py: 295 -> 180 us at 512 channels, 91 -> 69 at 256, 97 -> 81 at 128; HIFIHR_WINOGRAD=0 or
+    conv_precision("reference") disable).  `allowed`: the mode a convolution recorded in its forward (its backward must follow it)."""
+    if not (_wino_allowed() if allowed is None else allowed):
         return False
     return R == 3 and S == 3 and stride == 1 and pad == 1 and C >= 128 and K >= 128 and C % 32 == 0 and K % 32 == 0
 
 
-def _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad):
+def _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad, allowed=None):
     """The 64 -> 64 stride-1 3x3 layers (ResNet layer 1, VGG19 conv1_2) as register-resident Winograd F(2x2, 3x3), one launch
     (hifihr_conv3x3_c64_wino; HIFIHR_CONV_WINO2=0 keeps them on the direct halo kernel)."""
-    return (R == 3 and S == 3 and stride == 1 and pad == 1 and C == 64 and K == 64 and os.environ.get("HIFIHR_WINOGRAD", "1") != "0"
+    return (R == 3 and S == 3 and stride == 1 and pad == 1 and C == 64 and K == 64 and (_wino_allowed() if allowed is None else allowed)
             and lib.conv3x3_c64_wino_supported(N, H, W, C, K))
 
 
@@ -615,6 +644,7 @@ class _Conv2dMFMA(torch.autograd.Function):
         x = x.contiguous(memory_format=_CL)
         wk = w.contiguous(memory_format=_CL)                      # physical [K][R][S][C]
         ctx.grad_premasked, ctx.mask_input_grad = bool(grad_premasked), bool(mask_input_grad)
+        ctx.wino_allowed = _wino_allowed()                        # the backward runs outside any conv_precision scope: it follows the forward
         N, C, H, W = x.shape
         K, Cw, R, S = wk.shape
         ctx.w3 = None
@@ -697,7 +727,7 @@ class _Conv2dMFMA(torch.autograd.Function):
             if b is not None and db_t is not None and db_ret is None:
                 _grad_ready(b)
         masked = False
-        if ctx.needs_input_grad[0] and _wino_ok(C, K, R, S, stride, pad):
+        if ctx.needs_input_grad[0] and _wino_ok(C, K, R, S, stride, pad, ctx.wino_allowed):
             # backward-data of a stride-1 3x3 = the same Winograd pipeline on dy with the transposed, rotated filter
             dx = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32, memory_format=_CL)
             tile = _wino_tile(lib, N, H, W, C, K)
@@ -717,7 +747,7 @@ class _Conv2dMFMA(torch.autograd.Function):
                     lib.weight_transpose(wk, wt, K, R * S, C)
                     _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1, dy_out=Yt_done, tile=tile, mask=mk)
             PROFILE.bracket("conv_dgrad_wino", run)
-        elif ctx.needs_input_grad[0] and ctx.w3 is None and _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad) and \
+        elif ctx.needs_input_grad[0] and ctx.w3 is None and _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad, ctx.wino_allowed) and \
                 _WEIGHT_PREP.get(ctx.w_param, wk, 2) is not None:
             # 64 -> 64: the same one-launch Winograd kernel on dy with U' (kind 2: transposed, rotated filter)
             dx = torch.empty_like(x, memory_format=_CL)
