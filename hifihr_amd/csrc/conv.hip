@@ -943,6 +943,11 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   if (conv_halo_supported(g, bias)) {
     if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_halo(g, src, wgt, bias, dst, stats, zeros, st);
   }
+  if (conv_rows_supported(g, bias) && (stats == nullptr || bgemm_nt_stats_supported(g.OC))) {
+    // strided 3x3 / 1x1 forward: the row-share GEMM with the patch gather in its loader waves (csrc/gemm.hip); without the zero page
+    // (first use inside a stream capture) the implicit-GEMM kernel below takes the launch
+    if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_rows(g, src, wgt, dst, stats, zeros, st);
+  }
   if (conv_stem_supported(g, bias)) {
     if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_stem(g, src, wgt, dst, stats, zeros, st);
   }

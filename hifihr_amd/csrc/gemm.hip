@@ -748,8 +748,17 @@ __device__ __forceinline__ RowsTile rows_tile_at(const BgemmArgs& a, long cur, l
 // 232, 288, 816, 1392 channels).  The loader reads the 16-byte operand segments that fall past row N of B or past column K from a page of
 // zeros, the epilogue stores and counts only columns < N; the MFMA waves are the same.  A template flag: the square Winograd products keep the
 // plain loader.
-template <bool RAGGED>
+// MODE 2 (round 4): the A operand is GATHERED -- a forward convolution as this GEMM (the strided 3x3 and the stride-2 1x1 layers of the
+// ResNet trunks sat on conv_igemm_kernel at 0.2-0.45 of the peak: 64 x 64 tiles, the gather through registers into LDS by the MFMA waves
+// themselves).  Row m of A is the patch of output pixel m = (n, oh, ow) in (r, s, c) order; a chunk of 32 k-values is 32 channels of ONE
+// tap, so a loader lane's 16-byte piece is a contiguous 16 bytes of the image -- the per-lane source address LDS-DMA takes anyway -- or
+// the zero page when the tap falls outside the image.  The loader keeps the pixel's base pointer and top-left coordinate per piece (bound
+// once per tile: two integer divisions per lane and piece) and walks (r, s, channel block) incrementally; the MFMA waves, the chunk stream
+// across tile boundaries, the statistics epilogue are the plain kernel's.
+template <int MODE>
 __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long per) {
+  constexpr bool RAGGED = MODE == 1;
+  constexpr bool CONVG = MODE == 2;
 #if defined(HIFIHR_GEMM_STAMP)       // [0] cycles in the chunk loops, [1] 100 MHz ticks of them, [2] chunks, [3] at barriers, [4] workgroups,
   const unsigned long long st_entry = __builtin_amdgcn_s_memtime();      // [5] entry -> exit, [6] epilogues, [7] entry -> barrier -1
   unsigned long long st_loop = 0, st_real = 0, st_bar = 0, st_epi = 0, st_first = 0;
@@ -774,6 +783,7 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
     RowsTile t = rows_tile_at(a, cur, s_hi);
     const float* src[8];
     int kseg[8];                                             // RAGGED: first k of this lane's segment within a chunk, or 1 << 30 for a B row >= N
+    int ih0[4] = {0, 0, 0, 0}, iw0[4] = {0, 0, 0, 0};        // CONVG: image coordinate of tap (0, 0) of the pixel of A piece i (i < 4: l + 4 i < 16)
     auto bind = [&](const RowsTile& tt) {                    // per-lane source row of every piece for this tile (k offset added per chunk)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -781,23 +791,39 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
         const bool isA = q < 16;
         const int row = 8 * (q & 15) + (lane >> 3);
         const int seg = (lane & 7) ^ ((row >> 1) & 7);
-        if (isA) src[i] = a.A + (size_t)tt.p * a.sa + (size_t)(tt.m0 + min(row, tt.rows - 1)) * a.lda + seg * 4;   // rows past the tile: discarded
+        if (isA && CONVG) {
+          const int m = tt.m0 + min(row, tt.rows - 1);       // output pixel (n, oh, ow); rows past the tile: discarded
+          const int n = m / (a.cOH * a.cOW), rem = m - n * (a.cOH * a.cOW), oh = rem / a.cOW, ow = rem - oh * a.cOW;
+          ih0[i & 3] = oh * a.cStride - a.cPad; iw0[i & 3] = ow * a.cStride - a.cPad;
+          // (formed with signed arithmetic: a pointer in front of the image is never dereferenced, the zero page is read instead)
+          src[i] = a.A + (((long)n * a.cIH + ih0[i & 3]) * a.cIW + iw0[i & 3]) * a.cC + seg * 4;
+        } else if (isA) src[i] = a.A + (size_t)tt.p * a.sa + (size_t)(tt.m0 + min(row, tt.rows - 1)) * a.lda + seg * 4;   // rows past the tile: discarded
         else src[i] = a.B + (size_t)tt.p * a.sb + (size_t)(tt.nt * 128 + row) * a.ldb + seg * 4;
         if (RAGGED) kseg[i] = (!isA && tt.nt * 128 + row >= a.N) ? (1 << 30) : seg * 4;
       }
     };
     bind(t);
     int li = 0, lc = 0;                                      // tile / chunk-in-tile the NEXT issue belongs to
+    int tr = 0, ts = 0, tcb = 0;                             // CONVG: tap (r, s) and 32-channel block of chunk lc
+    const int cpb = CONVG ? a.cC / 32 : 1;
     auto issue_next = [&](int gc) {
       float* base = lds + (gc & 3) * STAGE;
+      const long aoff = CONVG ? ((long)tr * a.cIW + ts) * a.cC + tcb * 32 : 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float* s = src[i] + lc * 32;
         if (RAGGED) s = (kseg[i] + lc * 32 < a.K) ? s : a.zeros;       // (a row >= N: 1 << 30; the last chunk's segments past column K)
+        if (CONVG && i < 4) {
+          const int ih = ih0[i] + tr, iw = iw0[i] + ts;
+          s = ((unsigned)ih < (unsigned)a.cIH && (unsigned)iw < (unsigned)a.cIW) ? src[i] + aoff : a.zeros;
+        }
         HIFIHR_GLDS16(s, base + 256 * (l + 4 * i), lane);
       }
+      if (CONVG) {
+        if (++tcb == cpb) { tcb = 0; if (++ts == a.cS) { ts = 0; ++tr; } }
+      }
       if (++lc == nch) {
-        lc = 0;
+        lc = 0; tr = 0; ts = 0; tcb = 0;
         cur += t.rows;
         if (++li < ntiles) { t = rows_tile_at(a, cur, s_hi); bind(t); }
       }
@@ -1298,6 +1324,36 @@ bool bgemm_nt_ragged_supported(int M, int N, int K) {
 }
 bool bgemm_nt_stats_supported(int N) { return nt_rows(N) || (nt_rows(128) && N >= 96 && N % 4 == 0); }      // the statistics epilogue exists in the row-share kernel only
 
+// ---- forward convolutions on the row-share kernel with the gather in its loader waves (MODE 2) ----
+bool conv_rows_supported(const ConvGeom& g, const float* bias) {
+  static const int on = [] { const char* e = getenv("HIFIHR_CONV_ROWS"); return e ? atoi(e) : 1; }();
+  if (!on || !nt_rows(128) || g.dgrad || bias != nullptr || g.relu || g.batch > 1) return false;
+  if (g.IC % 32 != 0 || g.OC % 128 != 0 || g.R != g.S || (g.R != 1 && g.R != 3)) return false;
+  const long M = (long)g.N * g.OH * g.OW;
+  if (M >= (1L << 31) || (long)g.N * g.IH * g.IW * g.IC >= (1L << 31)) return false;
+  if (on >= 2) return true;                                  // (every shape the kernel takes: the A/B)
+  return g.stride == 2;                                      // stride 1: 1x1 is a plain GEMM already, 3x3 runs as Winograd / on the halo kernel
+}
+
+hipError_t launch_conv_rows(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st) {
+  if (!conv_rows_supported(g, nullptr) || zeros == nullptr) return hipErrorInvalidValue;
+  BgemmArgs a{};
+  const long M = (long)g.N * g.OH * g.OW;
+  a.A = src; a.B = wgt; a.C = dst; a.M = (int)M; a.N = g.OC; a.K = g.R * g.S * g.IC;
+  a.lda = 0; a.ldb = a.K; a.ldc = g.OC; a.sa = 0; a.sb = 0; a.sc = 0; a.batch = 1;
+  a.stats = stats; a.zeros = zeros;
+  a.cIH = g.IH; a.cIW = g.IW; a.cC = g.IC; a.cOH = g.OH; a.cOW = g.OW; a.cR = g.R; a.cS = g.S; a.cStride = g.stride; a.cPad = g.pad;
+  a.tiles_n = g.OC / 128; a.tiles_m = (int)((M + 127) / 128); a.splits = 1; a.cps = a.K / 32; a.sc_split = 0;
+  const long total = (long)a.tiles_n * M;
+  const int cus = gemm_cus();
+  long per = (total + cus - 1) / cus;
+  per = (per + 15) / 16 * 16;                               // whole 16-row blocks per share
+  if (per < 16) per = 16;
+  const int G = (int)((total + per - 1) / per);
+  hipLaunchKernelGGL(bgemm_nt_rows_kernel<2>, dim3(G), dim3(512), 0, st, a, per);
+  return hipGetLastError();
+}
+
 hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
                            float* stats) {
   const bool ragged = bgemm_nt_ragged_supported(M, N, K);
@@ -1317,7 +1373,7 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
     long per = (total + cus - 1) / cus;
     if (per < 16) per = 16;
     const int G = (int)((total + per - 1) / per);
-    hipLaunchKernelGGL(bgemm_nt_rows_kernel<true>, dim3(G), dim3(512), 0, st, a, per);
+    hipLaunchKernelGGL(bgemm_nt_rows_kernel<1>, dim3(G), dim3(512), 0, st, a, per);
     return hipGetLastError();
   }
   if (nt_rows(N)) {
@@ -1327,7 +1383,7 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
     long per = (total + cus - 1) / cus;
     if (per < 16) per = 16;
     const int G = (int)((total + per - 1) / per);
-    hipLaunchKernelGGL(bgemm_nt_rows_kernel<false>, dim3(G), dim3(512), 0, st, a, per);
+    hipLaunchKernelGGL(bgemm_nt_rows_kernel<0>, dim3(G), dim3(512), 0, st, a, per);
     return hipGetLastError();
   }
   int bm, bn;

@@ -333,7 +333,10 @@ struct BgemmArgs {
   int batch, tiles_m, tiles_n;
   int splits, cps;             // TN: slabs of the t range, K chunks (32 rows) per slab
   long sc_split;               // element stride between slabs of C
-  const float* zeros = nullptr;   // bgemm_nt_rows_kernel<true> (ragged N / K): >= 16 zero bytes that out-of-range operand segments are read from
+  const float* zeros = nullptr;   // bgemm_nt_rows_kernel<1 / 2> (ragged N / K; convolution gather): >= 16 zero bytes that out-of-range operand segments are read from
+  // bgemm_nt_rows_kernel<2>: A is an NHWC image x[n][ih][iw][cC] and row m of the product is the (r, s, c)-ordered patch of output pixel
+  // m = (n, oh, ow), gathered by the loader waves (K = cR * cS * cC, cC % 32 == 0; B = the filter [N][cR][cS][cC])
+  int cIH = 0, cIW = 0, cC = 0, cOH = 0, cOW = 0, cR = 0, cS = 0, cStride = 1, cPad = 0;
   float* stats = nullptr;      // bgemm_nt_rows_kernel, batch 1 (a 1x1 convolution in front of a batch-norm): per-column sum / sum of squares of C
                                // added into the slot buffer [kStatSlots][2][N] (csrc/bn.hip), or null
 };
@@ -343,6 +346,9 @@ bool bgemm_nt_supported(int M, int N, int K);
 bool bgemm_tn_supported(int M, int N, int T);
 size_t bgemm_nt_workspace_bytes(int M, int N, int K, int batch);
 bool bgemm_nt_stats_supported(int N);      // launch_bgemm_nt(..., stats != null) is available for this N
+// forward convolution as the row-share GEMM with the patch gather in its loader waves (csrc/gemm.hip, bgemm_nt_rows_kernel<2>)
+bool conv_rows_supported(const ConvGeom& g, const float* bias);
+hipError_t launch_conv_rows(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st);
 bool bgemm_nt_ragged_supported(int M, int N, int K);   // bgemm_nt_rows_kernel<true>: N % 4 == 0, K % 4 == 0, N not a multiple of 128 or K not of 32
 hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
                            float* stats_or_null = nullptr);      // stats: only with N % 128 == 0 and batch == 1 (else hipErrorInvalidValue)

@@ -1048,7 +1048,8 @@ class _BNActWinoConv(torch.autograd.Function):
         gy = gy.contiguous(memory_format=_CL)
         link, in_link = ctx.link, ctx.in_link
         if os.environ.get("HIFIHR_BN_WINO_BWD", "1") == "0":      # A/B: the unfused backward (Winograd pipeline, add, batch-norm backward)
-            conv = _CtxShim((None, wk, None, V), geom=ctx.geom, w_param=w, b_param=None, relu=False, w3=None,
+            conv = _CtxShim((None, wk, None, V), geom=ctx.geom, w_param=w, b_param=None, relu=False, w3=None, wino_allowed=True,
+                            grad_premasked=False, mask_input_grad=False,
                             needs_input_grad=(True, need[5], False, False, False, False, False))
             d_a, dw = _Conv2dMFMA.backward(conv, gy)[:2]
             if g_out is not None:

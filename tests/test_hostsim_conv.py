@@ -126,3 +126,16 @@ def test_conv_stem_wgrad_three_channel_parameter(hostsim_lib):
 
 def test_conv_stem_bnstats(hostsim_lib):
     kc.conv_bnstats_case(hostsim_lib, "cpu", 2, 28, 56, 4, 64, 7, 2, 3)
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [
+    (2, 12, 12, 64, 128, 3, 2, 1),    # ResNet layer2.0 conv1's shape class: 3x3 / stride 2, taps outside the image on every side
+    (1, 9, 11, 32, 128, 3, 2, 1),     # odd sizes, one 32-channel block per tap
+    (2, 10, 10, 64, 256, 1, 2, 0),    # the stride-2 1x1 projection shortcut, two column tiles
+    (1, 7, 5, 96, 128, 3, 2, 1),      # three channel blocks per tap
+])
+def test_conv_rows_gather_forward(hostsim_lib, N, H, W, C, K, R, stride, pad):
+    """bgemm_nt_rows_kernel<2>: the strided forward convolutions as the row-share GEMM with the patch gather in its loader waves (zero page
+    for taps outside the image), forward + batch-norm statistics; the other directions of the same call stay on their kernels."""
+    kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, seed=K + C)
+    kc.conv_bnstats_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, use_ws=False)
