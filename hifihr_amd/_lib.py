@@ -200,6 +200,7 @@ class HifihrLib:
         c.hifihr_se_scale.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_bwd_gate.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_mlp_supported.argtypes = [c_int, c_int]
+        c.hifihr_zero_page_ready.argtypes = [c_void_p]
         c.hifihr_drop_connect_add.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_size_t, _c_float_p, c_void_p]
         c.hifihr_se_mlp_fwd.argtypes = [_c_float_p] * 5 + [c_int] * 3 + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_se_mlp_bwd.argtypes = [_c_float_p] * 7 + [c_int] * 3 + [_c_float_p] * 7 + [c_void_p]
@@ -432,6 +433,10 @@ class HifihrLib:
 
     def wino_input_transform(self, x, V, N, H, W, C, m=2):
         self.check(self.c.hifihr_wino_input_transform_m(_fp(x), _fp(V), N, H, W, C, m, _stream_of(x)), "hifihr_wino_input_transform")
+
+    def zero_page_ready(self, device=None):
+        import torch
+        return bool(self.c.hifihr_zero_page_ready(c_void_p(torch.cuda.current_stream(device).cuda_stream)))
 
     def conv3x3_c64_wino_supported(self, N, H, W, C, K):
         return bool(self.c.hifihr_conv3x3_c64_wino_supported(int(N), int(H), int(W), int(C), int(K)))

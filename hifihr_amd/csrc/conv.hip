@@ -938,7 +938,10 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
     // 1x1 / stride 1: y[M][OC] = x[M][IC] . w[OC][IC]^T, and backward-data the same product on (dy, w^T): the GEMM kernels of
     // csrc/gemm.hip (bgemm_nt_rows_kernel: N % 128 == 0; the statistics of a batch-norm consumer come out of its epilogue)
     const long M = (long)g.N * g.OH * g.OW;
-    return launch_bgemm_nt(src, wgt, dst, (int)M, g.OC, g.IC, 1, nullptr, 0, st, stats);      // (statistics: the row-share kernel's epilogue)
+    const hipError_t e = launch_bgemm_nt(src, wgt, dst, (int)M, g.OC, g.IC, 1, nullptr, 0, st, stats);      // (statistics: the row-share kernel's epilogue)
+    // hipErrorNotReady: the ragged form wants the zero page and this is its first use inside a stream capture -- the implicit-GEMM
+    // kernel below takes the launch, as for the halo and stem kernels
+    if (e != hipErrorNotReady) return e;
   }
   if (conv_halo_supported(g, bias)) {
     if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_halo(g, src, wgt, bias, dst, stats, zeros, st);

@@ -1075,6 +1075,8 @@ int hifihr_wino_output_transform_m(const float* M, float* y, float* stats, int N
 
 int hifihr_conv3x3_c64_wino_supported(int N, int H, int W, int C, int K) { return hifihr::conv_wino2_supported(N, H, W, C, K) ? 1 : 0; }
 
+int hifihr_zero_page_ready(void* stream) { return hifihr::conv_halo_zero_page((hipStream_t)stream) != nullptr ? 1 : 0; }
+
 int hifihr_conv3x3_c64_wino(const float* x, const float* u, const float* bias, int relu, float* y, float* stats, int N, int H, int W, void* stream) {
   if (!x || !u || !y) return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_wino: null pointer");
   if (!hifihr::conv_wino2_supported(N, H, W, 64, 64))

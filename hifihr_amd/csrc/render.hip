@@ -80,6 +80,7 @@ constexpr int kF3SplitSlots = 128;    // split tiles per image that get a merge 
 constexpr int kF3Classes = 4;
 constexpr int kF3CtlInts = 64;        // [2..5] items per class; then [kF3CtlInts + b] = bin workgroups of image b that have finished (all zeroed by render_vertex_kernel)
 struct F3Ws {
+  int part_faces;                    // target faces per part of a split tile (kF3Cap .. : see f3_part_faces)
   int* ctl;                          // [kF3CtlInts]
   int2* queue;                       // [kF3Classes][cap]: (b << 18 | tile << 6 | part << 3 | P - 1, split slot or -1)
   int* arrive;                       // [B][kF3SplitSlots]
@@ -102,6 +103,12 @@ static inline F3Ws f3_carve(const RenderDev& r, int B, void* ws) {
   char* p = reinterpret_cast<char*>(face_records(r, B, ws)) + (size_t)B * r.F * kFaceRec * sizeof(float4);
   p = reinterpret_cast<char*>(((uintptr_t)p + 255) / 256 * 256);
   F3Ws w;
+  // Faces per part: a part starts with an EMPTY depth buffer, so the conservative depth reject of stage A sees nothing of what the other
+  // parts hold -- cutting a list finer than it must be multiplies the exact sample tests.  On the MANO mesh (41 faces per covered tile on
+  // average, a few tiles of 300-600) parts of 128 shorten the launch's tail; on a dense skin (11 976 faces: hundreds per tile everywhere)
+  // they made the launch 18 % longer than one workgroup per tile (838 vs 710 us at B = 48): the target grows with the mesh.
+  static const int forced = [] { const char* e = getenv("HIFIHR_RENDER_PART"); return e ? atoi(e) : 0; }();
+  w.part_faces = forced > 0 ? forced : (r.F <= 2048 ? kF3Cap : (r.F <= 8192 ? 2 * kF3Cap : 4 * kF3Cap));
   w.cap = (int)f3_queue_cap(r, B);
   const size_t sw2 = (size_t)(8 * r.aa) * (8 * r.aa);
   w.gz = reinterpret_cast<unsigned long long*>(p); p += (size_t)B * kF3SplitSlots * sw2 * 8;
@@ -136,7 +143,7 @@ __device__ __forceinline__ void f3_sched_image(const RenderDev& r, int* __restri
     if (t < nt) {
       const int n = atomicAdd(&tile_cnt[(size_t)b * nt + t], 0);
       if (n > 0) {
-        int P = min(kF3Parts, (n + kF3Cap - 1) / kF3Cap);
+        int P = min(kF3Parts, (n + w.part_faces - 1) / w.part_faces);
         if (P > 1) {
           const int sl = atomicAdd(&s_nslot, 1);
           if (sl < kF3SplitSlots) slot_of[k] = sl; else P = 1;

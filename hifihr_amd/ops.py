@@ -435,7 +435,7 @@ def _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad, allowed=None):
     """The 64 -> 64 stride-1 3x3 layers (ResNet layer 1, VGG19 conv1_2) as register-resident Winograd F(2x2, 3x3), one launch
     (hifihr_conv3x3_c64_wino; HIFIHR_CONV_WINO2=0 keeps them on the direct halo kernel)."""
     return (R == 3 and S == 3 and stride == 1 and pad == 1 and C == 64 and K == 64 and (_wino_allowed() if allowed is None else allowed)
-            and lib.conv3x3_c64_wino_supported(N, H, W, C, K))
+            and lib.conv3x3_c64_wino_supported(N, H, W, C, K) and lib.zero_page_ready())   # (no zero page inside a capture: the halo kernel)
 
 
 _WINO_TILE = {}

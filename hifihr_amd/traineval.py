@@ -297,7 +297,9 @@ class SegmentedGraphedTrainStep:
                 [b.clone() for b in model.buffers()])
         reducer.pause_hooks(True)
         self._enc = enc
+        self._scope = None
         try:
+            _injected_capture_failure()                        # (test hook: the one-sided failure of tests/test_gpu_dp.py)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -317,6 +319,9 @@ class SegmentedGraphedTrainStep:
         except BaseException:
             reducer.pause_hooks(False)
             enc.segment_cut = None
+            if self._scope is not None:                        # a stage raised between `fwd` (which enters the weight re-layout scope) and
+                self._scope.__exit__(None, None, None)         # `bwd_last` (which leaves it): without this _WEIGHT_PREP stays active and a
+                self._scope = None                             # later forward outside any scope reads last step's re-laid-out weights
             self._restore(snap)
             raise
         enc.segment_cut = None
@@ -352,6 +357,7 @@ class SegmentedGraphedTrainStep:
         def bwd_last():
             bwd("layer2")()
             self._scope.__exit__(None, None, None)
+            self._scope = None
         return [fwd, bwd_heads, bwd("layer4"), bwd("layer3"), bwd_last]
 
     def _eager_segmented(self):

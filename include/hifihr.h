@@ -309,6 +309,10 @@ int hifihr_wino_dy_transform_m(const float* dy_d, float* yt_d, int N, int H, int
  * forward statistics slots of the batch norm that follows (hifihr_bn_stats_floats(64) floats, zeroed) or NULL.  H even, W even and >= 14
  * (hifihr_conv3x3_c64_wino_supported); results within 1e-5 (relative to the output scale) of the direct convolution. */
 int hifihr_conv3x3_c64_wino_supported(int N, int H, int W, int C, int K);
+/* 1 when the library's page of zeros for this device exists (or could be allocated now: `stream` is not capturing).  The kernels whose
+ * loaders read out-of-image taps from it (hifihr_conv3x3_c64_wino, the ragged / gathering row-share GEMM) cannot allocate it inside a stream
+ * capture: a caller that is about to capture asks here first and otherwise picks the kernels that do not need it. */
+int hifihr_zero_page_ready(void* stream);
 int hifihr_conv3x3_c64_wino(const float* x_d, const float* u_d, const float* bias_d /* or NULL */, int relu, float* y_d,
                             float* stats_d /* or NULL */, int N, int H, int W, void* stream);
 /* Batch-norm fused into the F(4x4, 3x3) input transform (round 3, csrc/wino4_bn.hip).  For a BatchNorm2d whose consumer is a Winograd

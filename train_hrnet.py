@@ -129,6 +129,9 @@ def train_ho3d(cli, args, model, loss_func, opt, sched, reducer, current_epoch, 
     if "training" not in args.mode:                       # evaluation only (reference train_hrnet.py:487-496)
         if rank == 0:
             say("[train_hrnet] HO3D evaluation:", run_evaluation_ho3d(model, eval_cache, args, device, current_epoch))
+        if world > 1:                                      # the other ranks leave together with rank 0, not while it still evaluates
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         return 0
     B = args.train_batch
     gen = torch.Generator().manual_seed(1000 + current_epoch)
@@ -183,6 +186,10 @@ def train_ho3d(cli, args, model, loss_func, opt, sched, reducer, current_epoch, 
                 say("[train_hrnet] saved", save_model(model, opt, sched, epoch, current_epoch, args))
                 # the periodic test of the reference's epoch driver (:470-480): on HO-3D it is the challenge dump
                 say("[train_hrnet] HO3D test:", run_evaluation_ho3d(model, eval_cache, args, device, epoch + current_epoch))
+            if world > 1:
+                # rank 0 alone walks the evaluation split: the others wait HERE, not inside the next epoch's gradient all-reduce (where a
+                # long evaluation reads as step time and can run into the process group's collective timeout)
+                torch.distributed.barrier()
         sched.step()
         if cli.max_iters and it >= cli.max_iters:
             break
