@@ -1355,7 +1355,24 @@ hipError_t launch_conv_rows(const ConvGeom& g, const float* src, const float* wg
 }
 
 hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
-                           float* stats) {
+                           float* stats, int M_alloc) {
+  // M_alloc > M: the problems of the batch are M_alloc rows apart in A and C, only the first M of each are computed (the mosaic tile
+  // count of the F(4x4, 3x3) pipeline is rounded up for the backward-weight products; the row-share kernel walks the real rows)
+  if (M_alloc > M && nt_rows(N) && !bgemm_nt_ragged_supported(M, N, K) && bgemm_nt_supported(M_alloc, N, K) && batch > 0 && stats == nullptr &&
+      (long)M_alloc * K < (1L << 31) && (long)N * K < (1L << 31)) {
+    BgemmArgs a{};
+    a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
+    a.sa = (long)M_alloc * K; a.sb = (long)N * K; a.sc = (long)M_alloc * N; a.batch = batch;
+    a.tiles_n = N / 128; a.tiles_m = (M + 127) / 128; a.splits = 1; a.cps = K / 32; a.sc_split = 0;
+    const long total = (long)batch * a.tiles_n * M;
+    const int cus = gemm_cus();
+    long per = (total + cus - 1) / cus;
+    if (per < 16) per = 16;
+    const int G = (int)((total + per - 1) / per);
+    hipLaunchKernelGGL(bgemm_nt_rows_kernel<0>, dim3(G), dim3(512), 0, st, a, per);
+    return hipGetLastError();
+  }
+  if (M_alloc > M) M = M_alloc;
   const bool ragged = bgemm_nt_ragged_supported(M, N, K);
   if ((!bgemm_nt_supported(M, N, K) && !ragged) || batch <= 0) return hipErrorInvalidValue;
   if (stats != nullptr && (batch != 1 || !(nt_rows(N) || ragged))) return hipErrorInvalidValue;

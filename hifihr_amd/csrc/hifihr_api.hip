@@ -921,13 +921,15 @@ static bool use_bgemm() {
 static int wino_m(int N, int H, int W, int C, int K) {
   static const int pref = [] { const char* e = getenv("HIFIHR_WINO_M"); return e ? atoi(e) : 4; }();
   if (pref != 4 || !use_bgemm() || H < 4 || W < 4) return 2;
-  const long T4 = (long)N * ((H + 3) / 4) * ((W + 3) / 4);
+  const long T4 = hifihr::wino4_tiles(N, H, W);
   if (T4 >= (1L << 30)) return 2;
   // forward (V U^T: rows T4, N = K, reduction C), backward-data (roles of C and K swapped), backward-weight (slabs of Y'^T V)
   if (!hifihr::bgemm_nt_supported((int)T4, K, C) || !hifihr::bgemm_nt_supported((int)T4, C, K) || !hifihr::bgemm_tn_supported(K, C, (int)T4)) return 2;
   return 4;
 }
-static long wino_T(int m, int N, int H, int W) { return (long)N * ((H + m - 1) / m) * ((W + m - 1) / m); }
+static long wino_T(int m, int N, int H, int W) { return m == 4 ? hifihr::wino4_tiles(N, H, W) : (long)N * ((H + m - 1) / m) * ((W + m - 1) / m); }
+
+long hifihr_wino_tiles(int N, int H, int W, int m) { return (N > 0 && H > 0 && W > 0 && (m == 2 || m == 4)) ? wino_T(m, N, H, W) : 0; }
 
 int hifihr_wino_tile(int N, int H, int W, int C, int K) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 2;
@@ -1055,7 +1057,9 @@ int hifihr_wino_gemm_m(const float* V, const float* U, float* M, int N, int H, i
   const long T4 = (N > 0 && H > 0 && W > 0) ? wino_T(4, N, H, W) : 0;
   if (!V || !U || !M || T4 <= 0 || T4 >= (1L << 30) || !hifihr::bgemm_nt_supported((int)T4, K, C))
     return fail(HIFIHR_EINVAL, "hifihr_wino_gemm: bad argument (F(4x4, 3x3) needs C % 32 == 0, K % 64 == 0)");
-  HIP_TRY(hifihr::launch_bgemm_nt(V, U, M, (int)T4, K, C, 36, ws, ws_bytes, (hipStream_t)stream));
+  const long Tr = hifihr::wino4_tiles_real(N, H, W);       // mosaic tiles: the rows behind the last mosaic are padding (zeros in V, unread in M)
+  if (Tr < T4) HIP_TRY(hifihr::launch_bgemm_nt(V, U, M, (int)Tr, K, C, 36, ws, ws_bytes, (hipStream_t)stream, nullptr, (int)T4));
+  else HIP_TRY(hifihr::launch_bgemm_nt(V, U, M, (int)T4, K, C, 36, ws, ws_bytes, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

@@ -118,7 +118,13 @@ constexpr int kStatSlots = 32;
 // of every workgroup (csrc/bn_fold.h) -- 512 B of L2 reads per channel and workgroup at 32 double slots, 67 MB per launch of a
 // 512-channel layer's fused transform, as much as the transform itself moves -- while the same-address atomic traffic the slots exist
 // to spread falls with the channel count (a wide layer has few rows per channel: <= 32 adders per address at 8 slots).
+// (Round 4, second step: 8 slots from 64 channels up -- a producer grid of <= 1 024 workgroups then meets <= 128 ways on an address, spread
+// over its whole run; the 32-slot fold of a 128-channel layer was ~2 us of every consumer launch.  HIFIHR_STAT_SLOTS_OLD for the A/B.)
+#if defined(HIFIHR_STAT_SLOTS_OLD)
 __host__ __device__ inline int stat_slots_used(int C) { return C >= 512 ? 8 : (C >= 256 ? 16 : 32); }
+#else
+__host__ __device__ inline int stat_slots_used(int C) { return C >= 64 ? 8 : 32; }
+#endif
 // FORWARD statistics (round 3): the slots hold DOUBLES, double S[kStatSlots][2][C] = (sum y, sum y^2), followed by 64 uint32 arrival
 // counters.  A producer lane accumulates SHIFTED sums in fp32 -- d = y - k with k a value of its own (the first y it saw for that
 // channel), s = sum d, q = sum d^2 over its n values: q stays of the order of n var however large the mean is -- and converts ONCE,
@@ -351,11 +357,14 @@ bool conv_rows_supported(const ConvGeom& g, const float* bias);
 hipError_t launch_conv_rows(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st);
 bool bgemm_nt_ragged_supported(int M, int N, int K);   // bgemm_nt_rows_kernel<true>: N % 4 == 0, K % 4 == 0, N not a multiple of 128 or K not of 32
 hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
-                           float* stats_or_null = nullptr);      // stats: only with N % 128 == 0 and batch == 1 (else hipErrorInvalidValue)
+                           float* stats_or_null = nullptr, int M_alloc = 0);      // stats: only with N % 128 == 0 and batch == 1 (else hipErrorInvalidValue)
 int bgemm_tn_parts(int M, int N, int T, int batch);
 hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st);
 hipError_t launch_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st);
-// Winograd F(4x4, 3x3) glue (wino4.hip): 36 positions, T = N * ceil(H / 4) * ceil(W / 4)
+// Winograd F(4x4, 3x3) glue (wino4.hip): 36 positions, T = wino4_tiles(N, H, W) tiles (N * ceil(H / 4) * ceil(W / 4), or fewer where 16
+// images share a mosaic: wino4_math.h TileGeo)
+long wino4_tiles(int N, int H, int W);
+long wino4_tiles_real(int N, int H, int W);               // without the rounding of the mosaic form: the rows the forward / backward-data products compute
 hipError_t launch_wino4_weight_transform(const float* w, float* U, int K, int C, int flip, hipStream_t st);
 hipError_t launch_wino4_input_transform(const float* x, float* V, float* Y /* or nullptr */, int N, int H, int W, int C, hipStream_t st);
 // csrc/wino4_bn.hip: batch-norm (+ residual) + ReLU applied on the fly inside the F(4x4, 3x3) input transform (C <= 512)

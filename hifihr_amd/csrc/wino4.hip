@@ -45,26 +45,28 @@ __global__ __launch_bounds__(256) void wino4_weight_transform_kernel(const float
 // thread = (tile, 4 channels); x[N][H][W][C] -> V[36][T][C].  DUAL: x is a gradient dy that backward-data (V = B^T d B of the padded 6x6
 // patch) AND backward-weight (Y' = A dy A^T of the patch's central 4x4 block = this tile's outputs) both consume: one read of dy.
 template <bool DUAL>
-__global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V, float* __restrict__ Y, int N,
-                                                                   int H, int W, int C, int TH, int TW) {
+__global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V, float* __restrict__ Y,
+                                                                   TileGeo geo, int C) {
   const int C4 = C / 4;
-  const size_t T = (size_t)N * TH * TW, total = T * C4;
+  const size_t T = tile_count(geo), total = T * C4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int cg = (int)(i % C4);
     const size_t t = i / C4;
-    const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+    const TileAt at = tile_at(geo, t);
+    AxisPx ry[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) ry[r] = axis_px(geo, at.y0 - 1 + r, geo.H);
     V4 tt[6][6];                                            // tt = B^T d, built column by column
     V4 ty[6][4];                                            // DUAL: A dy (6 x 4) of the central block
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const int iw = 4 * tw - 1 + c;
-      const bool cok = iw >= 0 && iw < W;
+      const AxisPx cx = axis_px(geo, at.x0 - 1 + c, geo.W);
       V4 col[6];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        const int ih = 4 * th - 1 + r;
-        const bool ok = cok && ih >= 0 && ih < H;
-        const V4 v = ld4(x + (((size_t)n * H + (ok ? ih : 0)) * W + (ok ? iw : 0)) * C + cg * 4);
+        bool ok;
+        const size_t px = tile_pixel(geo, at, ry[r], cx, ok);
+        const V4 v = ld4(x + px * C + cg * 4);
         col[r] = ok ? v : zero4();
       }
       V4 o[6];
@@ -102,18 +104,21 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
 // gradient is produced, instead of a bias_relu_bwd pass over (dy, y) in front of the previous layer's backward
 __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Mm, float* __restrict__ y, float* __restrict__ stats,
                                                                     const float* __restrict__ bias, int relu, const float* __restrict__ mask,
-                                                                    int N, int H, int W, int K, int TH, int TW) {
+                                                                    TileGeo geo, int K) {
   __shared__ double red[2][16][16][4];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int k = blockIdx.y * 64 + cl * 4;
   const bool kok = k < K;
-  const size_t T = (size_t)N * TH * TW;
+  const size_t T = tile_count(geo);
   Stat4 st;                                                 // batch-norm statistics of y (hifihr_internal.h "FORWARD statistics")
   if (kok) {
     const V4 bv = bias != nullptr ? ld4(bias + k) : zero4();
     const float lo = relu ? 0.f : -3.402823466e38f;
     for (size_t t = (size_t)blockIdx.x * 16 + tl; t < T; t += (size_t)gridDim.x * 16) {
-      const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+      const TileAt at = tile_at(geo, t);
+      AxisPx cx[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) cx[b] = axis_px(geo, at.x0 + b, geo.W);
       V4 s[4][6];                                           // s = A^T m, built column by column
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
@@ -127,26 +132,28 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const int oh = 4 * th + a;
+        const AxisPx ry = axis_px(geo, at.y0 + a, geo.H);
         V4 o[4];
         at6(s[a], o);
-        if (oh < H) {
-          const size_t po = (((size_t)n * H + oh) * W + 4 * tw) * K + k;
-          float* p = y + po;
+        if (ry.ok) {
+          size_t po[4];
+          bool okb[4];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) po[b] = tile_pixel(geo, at, ry, cx[b], okb[b]) * K + k;
           V4 mk[4];
           if (mask != nullptr) {                            // (uniform) the row's mask values requested together
 #pragma unroll
-            for (int b = 0; b < 4; ++b) mk[b] = ld4(mask + po + (size_t)(4 * tw + b < W ? b : 0) * K);
+            for (int b = 0; b < 4; ++b) mk[b] = ld4(mask + po[b]);
           }
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            if (4 * tw + b < W) {
+            if (okb[b]) {
               V4 v = o[b] + bv;
               v = V4{fmaxf(v.x, lo), fmaxf(v.y, lo), fmaxf(v.z, lo), fmaxf(v.w, lo)};
               if (mask != nullptr) v = V4{mk[b].x > 0.f ? v.x : 0.f, mk[b].y > 0.f ? v.y : 0.f, mk[b].z > 0.f ? v.z : 0.f, mk[b].w > 0.f ? v.w : 0.f};
-              st4(p + (size_t)b * K, v);
-              if (a == 0 && b == 0) st.seed(make_float4(v.x, v.y, v.z, v.w));      // (a tile's first pixel is always inside the image)
-              st.add(make_float4(v.x, v.y, v.z, v.w));
+              st4(y + po[b], v);
+              if (a <= 1 && b <= 1) st.seed(make_float4(v.x, v.y, v.z, v.w));      // (a tile's first pixel INSIDE an image is one of these four:
+              st.add(make_float4(v.x, v.y, v.z, v.w));                              //  a mosaic tile may start on a line of zeros)
             }
           }
         }
@@ -158,23 +165,26 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
 }
 
 // backward-weight glue.  thread = (tile, 4 channels): Y'[36][T][K] = A dy A^T (dy outside the image = 0)
-__global__ __launch_bounds__(256) void wino4_dy_transform_kernel(const float* __restrict__ dy, float* __restrict__ Y, int N, int H, int W, int K, int TH,
-                                                                int TW) {
+__global__ __launch_bounds__(256) void wino4_dy_transform_kernel(const float* __restrict__ dy, float* __restrict__ Y, TileGeo geo, int K) {
   const int K4 = K / 4;
-  const size_t T = (size_t)N * TH * TW, total = T * K4;
+  const size_t T = tile_count(geo), total = T * K4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int kg = (int)(i % K4);
     const size_t t = i / K4;
-    const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+    const TileAt at = tile_at(geo, t);
+    AxisPx ry[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) ry[a] = axis_px(geo, at.y0 + a, geo.H);
     V4 ty[6][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
+      const AxisPx cx = axis_px(geo, at.x0 + b, geo.W);
       V4 col[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const int oh = 4 * th + a, ow = 4 * tw + b;
-        const bool ok = oh < H && ow < W;
-        const V4 v = ld4(dy + (((size_t)n * H + (ok ? oh : 0)) * W + (ok ? ow : 0)) * K + kg * 4);
+        bool ok;
+        const size_t px = tile_pixel(geo, at, ry[a], cx, ok);
+        const V4 v = ld4(dy + px * K + kg * 4);
         col[a] = ok ? v : zero4();
       }
       V4 o[6];
@@ -244,30 +254,41 @@ hipError_t launch_wino4_weight_transform(const float* w, float* U, int K, int C,
   return hipGetLastError();
 }
 
+// the tile geometry of a layer: every launcher of the F(4x4, 3x3) pipeline and the products' row count come through here
+TileGeo wino4_geo(int N, int H, int W) {
+  static const int on = [] { const char* e = getenv("HIFIHR_WINO_MOSAIC"); return e ? atoi(e) : 1; }();
+  return make_tile_geo(N, H, W, on != 0);
+}
+long wino4_tiles(int N, int H, int W) { return (long)tile_count(wino4_geo(N, H, W)); }
+long wino4_tiles_real(int N, int H, int W) {
+  const TileGeo g = wino4_geo(N, H, W);
+  return g.G ? (long)(g.N / (g.G * g.G)) * g.TH * g.TW : (long)tile_count(g);
+}
+
 hipError_t launch_wino4_input_transform(const float* x, float* V, float* Y, int N, int H, int W, int C, hipStream_t st) {
   if (C % 4 != 0) return hipErrorInvalidValue;
-  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
-  const size_t total = (size_t)N * TH * TW * (C / 4);
-  if (Y != nullptr) hipLaunchKernelGGL((wino4_input_transform_kernel<true>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, N, H, W, C, TH, TW);
-  else hipLaunchKernelGGL((wino4_input_transform_kernel<false>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, N, H, W, C, TH, TW);
+  const TileGeo geo = wino4_geo(N, H, W);
+  const size_t total = tile_count(geo) * (C / 4);
+  if (Y != nullptr) hipLaunchKernelGGL((wino4_input_transform_kernel<true>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, geo, C);
+  else hipLaunchKernelGGL((wino4_input_transform_kernel<false>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, geo, C);
   return hipGetLastError();
 }
 
 hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats, const float* bias, int relu, const float* mask, int N, int H, int W, int K,
                                          hipStream_t st) {
   if (K % 4 != 0) return hipErrorInvalidValue;
-  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
-  const size_t T = (size_t)N * TH * TW;
+  const TileGeo geo = wino4_geo(N, H, W);
+  const size_t T = tile_count(geo);
   size_t bx = (T + 15) / 16;
   if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(wino4_output_transform_kernel, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, bias, relu, mask, N, H, W, K, TH, TW);
+  hipLaunchKernelGGL(wino4_output_transform_kernel, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, bias, relu, mask, geo, K);
   return hipGetLastError();
 }
 
 hipError_t launch_wino4_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st) {
   if (K % 4 != 0) return hipErrorInvalidValue;
-  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
-  hipLaunchKernelGGL(wino4_dy_transform_kernel, dim3(wino4_grid((size_t)N * TH * TW * (K / 4))), dim3(256), 0, st, dy, Y, N, H, W, K, TH, TW);
+  const TileGeo geo = wino4_geo(N, H, W);
+  hipLaunchKernelGGL(wino4_dy_transform_kernel, dim3(wino4_grid(tile_count(geo) * (K / 4))), dim3(256), 0, st, dy, Y, geo, K);
   return hipGetLastError();
 }
 

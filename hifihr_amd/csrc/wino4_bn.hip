@@ -30,93 +30,110 @@ namespace hifihr {
 
 using namespace w4;
 
+TileGeo wino4_geo(int N, int H, int W);                    // csrc/wino4.hip: plain tiles, or 16 images per mosaic
+
 constexpr int kWbnMaxC = 512;        // scale / shift tables in LDS (every workgroup folds all C channels: 256 C bytes from L2)
 
-__device__ __forceinline__ V4 bn_res_relu(const V4& v, const V4& sc, const V4& sh, const V4& r, bool has_res) {
-  V4 z = V4{v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w};
+__device__ __forceinline__ V4 relu0(const V4& z) { return V4{fmaxf(z.x, 0.f), fmaxf(z.y, 0.f), fmaxf(z.z, 0.f), fmaxf(z.w, 0.f)}; }
+__device__ __forceinline__ float relu0(float z) { return fmaxf(z, 0.f); }
+
+template <typename T>
+__device__ __forceinline__ T bn_res_relu(const T& v, const T& sc, const T& sh, const T& r, bool has_res) {
+  T z = v * sc + sh;
   if (has_res) z = z + r;
-  return V4{fmaxf(z.x, 0.f), fmaxf(z.y, 0.f), fmaxf(z.z, 0.f), fmaxf(z.w, 0.f)};
+  return relu0(z);
 }
 
-// One (tile, 4 channels) item: the 6 x 6 patch of raw values (and of the identity branch) in registers.
-template <bool RES>
+// One (tile, VW channels) item: the 6 x 6 patch of raw values (and of the identity branch) in registers.  T = V4: four consecutive
+// channels per thread; T = float: one -- four times the threads with a quarter of the serial work each (round 4: these launches put
+// 784 waves on the chip's 1 024 SIMDs and every wave spends half its life waiting for its 36-72 loads: profiles/r04_pmc_wino_bn.txt).
+template <bool RES, typename T>
 struct WbnPatch {
-  V4 v[6][6];
-  V4 r[RES ? 6 : 1][RES ? 6 : 1];
-  unsigned long long ok;                                    // bit 6 * row + column: the pixel is inside the image
-  int n, th, tw, cg;
+  T v[6][6];
+  T r[RES ? 6 : 1][RES ? 6 : 1];
+  unsigned long long ok;                                    // bit 6 * row + column: the pixel is inside an image
+  int cg;
   size_t t;
+  size_t own[4][4];                                         // RES: pixel index of the tile's own 4 x 4 pixels (the block output is written there)
 };
 
-template <bool RES>
-__device__ __forceinline__ void wbn_load(WbnPatch<RES>& p, size_t i, const float* __restrict__ x, const float* __restrict__ res, int H, int W,
-                                         int C, int TH, int TW) {
-  const int C4 = C / 4;
-  p.cg = (int)(i % C4);
-  p.t = i / C4;
-  p.tw = (int)(p.t % TW); p.th = (int)((p.t / TW) % TH); p.n = (int)(p.t / ((size_t)TW * TH));
+template <bool RES, typename T>
+__device__ __forceinline__ void wbn_load(WbnPatch<RES, T>& p, size_t i, const float* __restrict__ x, const float* __restrict__ res,
+                                         const TileGeo& geo, int C) {
+  constexpr int VW = VecWidth<T>::n;
+  const int CV = C / VW;
+  p.cg = (int)(i % CV);
+  p.t = i / CV;
+  const TileAt at = tile_at(geo, p.t);
+  AxisPx ry[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) ry[r] = axis_px(geo, at.y0 - 1 + r, geo.H);
   p.ok = 0ull;
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
-    const int iw = 4 * p.tw - 1 + c;
-    const bool cok = iw >= 0 && iw < W;
+    const AxisPx cx = axis_px(geo, at.x0 - 1 + c, geo.W);
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const int ih = 4 * p.th - 1 + r;
-      const bool ok = cok && ih >= 0 && ih < H;
-      const size_t o = (((size_t)p.n * H + (ok ? ih : 0)) * W + (ok ? iw : 0)) * C + p.cg * 4;
-      p.v[r][c] = ld4(x + o);
-      if constexpr (RES) p.r[r][c] = ld4(res + o);
+      bool ok;
+      const size_t px = tile_pixel(geo, at, ry[r], cx, ok);
+      const size_t o = px * C + p.cg * VW;
+      p.v[r][c] = ldT<T>(x + o);
+      if constexpr (RES) {
+        p.r[r][c] = ldT<T>(res + o);
+        if (r >= 1 && r <= 4 && c >= 1 && c <= 4) p.own[r - 1][c - 1] = px;
+      }
       p.ok |= ok ? (1ull << (6 * r + c)) : 0ull;               // (r, c are compile-time: folds into per-position predicates)
     }
   }
 }
 
-template <bool RES>
-__device__ __forceinline__ void wbn_emit(const WbnPatch<RES>& p, const float* s_sc, const float* s_sh, float* __restrict__ out,
-                                         float* __restrict__ V, int H, int W, int C, size_t T) {
-  const V4 sc = ld4(&s_sc[p.cg * 4]), sh = ld4(&s_sh[p.cg * 4]);
-  V4 tt[6][6];                                              // tt = B^T a, built column by column
+template <bool RES, typename T>
+__device__ __forceinline__ void wbn_emit(const WbnPatch<RES, T>& p, const float* s_sc, const float* s_sh, float* __restrict__ out,
+                                         float* __restrict__ V, int C, size_t Tn) {
+  constexpr int VW = VecWidth<T>::n;
+  const T sc = ldT<T>(&s_sc[p.cg * VW]), sh = ldT<T>(&s_sh[p.cg * VW]);
+  T tt[6][6];                                               // tt = B^T a, built column by column
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
-    V4 col[6];
+    T col[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const bool ok = (p.ok >> (6 * r + c)) & 1ull;
-      const V4 a = bn_res_relu(p.v[r][c], sc, sh, RES ? p.r[RES ? r : 0][RES ? c : 0] : zero4(), RES);
-      col[r] = ok ? a : zero4();                            // the convolution pads the ACTIVATION with zeros
+      const T a = bn_res_relu<T>(p.v[r][c], sc, sh, RES ? p.r[RES ? r : 0][RES ? c : 0] : zeroT<T>(), RES);
+      col[r] = ok ? a : zeroT<T>();                         // the convolution pads the ACTIVATION with zeros
       if (RES && r >= 1 && r <= 4 && c >= 1 && c <= 4 && ok)                // this tile's own 4 x 4 pixels: the block output
-        st4(out + (((size_t)p.n * H + (4 * p.th - 1 + r)) * W + (4 * p.tw - 1 + c)) * C + p.cg * 4, a);
+        stT(out + p.own[RES ? r - 1 : 0][RES ? c - 1 : 0] * C + p.cg * VW, a);
     }
-    V4 o[6];
+    T o[6];
     bt6(col, o);
 #pragma unroll
     for (int r = 0; r < 6; ++r) tt[r][c] = o[r];
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
-    V4 o[6];
+    T o[6];
     bt6(tt[r], o);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) st4(V + ((size_t)(r * 6 + c) * T + p.t) * C + p.cg * 4, o[c]);
+    for (int c = 0; c < 6; ++c) stT(V + ((size_t)(r * 6 + c) * Tn + p.t) * C + p.cg * VW, o[c]);
   }
 }
 
-// thread = (tile, 4 channels).  x: raw convolution output [N][H][W][C]; res / out (RES): identity branch and block output.
-// These launches are small (one item per thread, 130-250 workgroups on layers 2-4) and latency-bound: 16-25 us against 8-14 for the plain
-// transform plus 9-12 for the bn_act_fwd launch it absorbs.  (Requesting the thread's whole patch BEFORE the slot fold, so that the
-// fold's L2 round trip runs under the patch's latency, measured slower: 19.4 / 23.2 us against 17.4 / 22.4 -- 228 registers.)
-template <bool RES>
+// thread = (tile, VW channels).  x: raw convolution output [N][H][W][C]; res / out (RES): identity branch and block output.
+// These launches are small (one item per thread, 130-250 workgroups on layers 2-4 at four channels per thread) and latency-bound: 16-25 us
+// against 8-14 for the plain transform plus 9-12 for the bn_act_fwd launch it absorbs.  (Requesting the thread's whole patch BEFORE the
+// slot fold, so that the fold's L2 round trip runs under the patch's latency, measured slower: 19.4 / 23.2 us against 17.4 / 22.4 -- 228
+// registers.)
+template <bool RES, typename T>
 __global__ __launch_bounds__(256) void wino4_bn_input_transform_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                          const float* __restrict__ res, float* __restrict__ out,
-                                                                         float* __restrict__ V, int N, int H, int W, int C, int TH, int TW,
+                                                                         float* __restrict__ V, TileGeo geo, int C,
                                                                          float eps, float momentum, float* __restrict__ save_mean,
                                                                          float* __restrict__ save_invstd, float* __restrict__ running_mean,
                                                                          float* __restrict__ running_var) {
   __shared__ float s_sc[kWbnMaxC], s_sh[kWbnMaxC];
-  const long M = (long)N * H * W;
-  const size_t T = (size_t)N * TH * TW, total = T * (C / 4);
+  const long M = (long)geo.N * geo.H * geo.W;
+  const size_t Tn = tile_count(geo), total = Tn * (C / VecWidth<T>::n);
   for (int c = threadIdx.x; c < C; c += 256) {            // every workgroup folds the slot partials itself (L2-resident)
     float mu, var;
     slot_mean_var(stats, C, c, M, mu, var);
@@ -136,9 +153,9 @@ __global__ __launch_bounds__(256) void wino4_bn_input_transform_kernel(const flo
   }
   __syncthreads();
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    WbnPatch<RES> p;
-    wbn_load<RES>(p, i, x, res, H, W, C, TH, TW);
-    wbn_emit<RES>(p, s_sc, s_sh, out, V, H, W, C, T);
+    WbnPatch<RES, T> p;
+    wbn_load<RES, T>(p, i, x, res, geo, C);
+    wbn_emit<RES, T>(p, s_sc, s_sh, out, V, C, Tn);
   }
   unsigned* cnt = stat_fwd_counters(stats, C);
   if (last_workgroup(cnt)) clear_slots_fwd(stats, C, cnt);
@@ -155,20 +172,22 @@ __global__ __launch_bounds__(256) void wino4_output_transform_bnred_kernel(const
                                                                           const float* __restrict__ outp, const float* __restrict__ gadd,
                                                                           const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                          float* __restrict__ red, float* __restrict__ g, int N, int H, int W, int C,
-                                                                          int TH, int TW) {
+                                                                          float* __restrict__ red, float* __restrict__ g, TileGeo geo, int C) {
   __shared__ float4 redl[2][16][16];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int k = blockIdx.y * 64 + cl * 4;
   const bool kok = k < C;
-  const size_t T = (size_t)N * TH * TW;
+  const size_t T = tile_count(geo);
   V4 sg = zero4(), sq = zero4();
   if (kok) {
     const V4 mu = ld4(save_mean + k), is = ld4(save_invstd + k), ga = ld4(gamma + k), be = ld4(beta + k);
     const V4 sc = V4{is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w};
     const V4 sh = V4{be.x - mu.x * sc.x, be.y - mu.y * sc.y, be.z - mu.z * sc.z, be.w - mu.w * sc.w};
     for (size_t t = (size_t)blockIdx.x * 16 + tl; t < T; t += (size_t)gridDim.x * 16) {
-      const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+      const TileAt at = tile_at(geo, t);
+      AxisPx cx[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) cx[b] = axis_px(geo, at.x0 + b, geo.W);
       V4 s[4][6];                                           // s = A^T m, built column by column
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
@@ -182,15 +201,15 @@ __global__ __launch_bounds__(256) void wino4_output_transform_bnred_kernel(const
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const int oh = 4 * th + a;
-        if (oh < H) {                                       // (the row's operands are requested before its transform)
-          const size_t o0 = (((size_t)n * H + oh) * W + 4 * tw) * C + k;
+        const AxisPx ry = axis_px(geo, at.y0 + a, geo.H);
+        if (ry.ok) {                                        // (the row's operands are requested before its transform)
           V4 xv[4], ov[4], av[4];
           bool ok[4];
+          size_t ob[4];
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            ok[b] = 4 * tw + b < W;
-            const size_t o = o0 + (size_t)(ok[b] ? b : 0) * C;
+            ob[b] = tile_pixel(geo, at, ry, cx[b], ok[b]) * C + k;
+            const size_t o = ob[b];
             xv[b] = ld4(x + o);
             ov[b] = RES ? ld4(outp + o) : zero4();
             av[b] = ADD ? ld4(gadd + o) : zero4();
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(256) void wino4_output_transform_bnred_kernel(const
               if (RES) z = ov[b];
               else z = V4{xv[b].x * sc.x + sh.x, xv[b].y * sc.y + sh.y, xv[b].z * sc.z + sh.z, xv[b].w * sc.w + sh.w};
               const V4 gm = V4{z.x > 0.f ? d.x : 0.f, z.y > 0.f ? d.y : 0.f, z.z > 0.f ? d.z : 0.f, z.w > 0.f ? d.w : 0.f};
-              st4(g + o0 + (size_t)b * C, gm);
+              st4(g + ob[b], gm);
               sg = sg + gm;
               sq.x += gm.x * ((xv[b].x - mu.x) * is.x); sq.y += gm.y * ((xv[b].y - mu.y) * is.y);
               sq.z += gm.z * ((xv[b].z - mu.z) * is.z); sq.w += gm.w * ((xv[b].w - mu.w) * is.w);
@@ -242,14 +261,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                                          const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                                          const float* __restrict__ gamma, float* __restrict__ red,
-                                                                         float* __restrict__ V, float* __restrict__ Y, int N, int H, int W, int K,
-                                                                         int TH, int TW, float* __restrict__ dgamma_acc,
-                                                                         float* __restrict__ dbeta_acc) {
+                                                                         float* __restrict__ V, float* __restrict__ Y, TileGeo geo, int K,
+                                                                         float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
   // T = V4: thread = (tile, 4 channels); T = float: thread = (tile, channel) -- four times the threads with a quarter of the serial
   // work each (these launches are latency-bound: 130-250 workgroups of 36 loads + 72 stores per lane at T = V4)
   constexpr int VW = VecWidth<T>::n;
   __shared__ float s_mg[kWbnMaxC], s_mgx[kWbnMaxC];
-  const float invM = 1.0f / (float)((long)N * H * W);
+  const float invM = 1.0f / (float)((long)geo.N * geo.H * geo.W);
   for (int c = threadIdx.x; c < K; c += 256) {
     float sgv, sgx;
     slot_sum2(red, K, c, sgv, sgx);                        // (fold ~2 us + the election below ~1.5 us of a 16-28 us launch: HIFIHR_DBG_NOFOLD experiment, round 3)
@@ -262,11 +280,14 @@ __global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const 
   }
   __syncthreads();
   const int KV = K / VW;
-  const size_t Tn = (size_t)N * TH * TW, total = Tn * KV;
+  const size_t Tn = tile_count(geo), total = Tn * KV;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int cg = (int)(i % KV);
     const size_t t = i / KV;
-    const int tw = (int)(t % TW), th = (int)((t / TW) % TH), n = (int)(t / ((size_t)TW * TH));
+    const TileAt at = tile_at(geo, t);
+    AxisPx ry[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) ry[r] = axis_px(geo, at.y0 - 1 + r, geo.H);
     const T mu = ldT<T>(save_mean + cg * VW), is = ldT<T>(save_invstd + cg * VW), ga = ldT<T>(gamma + cg * VW);
     const T k1 = is * ga;
     const T mg = ldT<T>(&s_mg[cg * VW]), mgx = ldT<T>(&s_mgx[cg * VW]);
@@ -274,15 +295,12 @@ __global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const 
     T ty[6][4];                                             // A dy (6 x 4) of the central block
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const int iw = 4 * tw - 1 + c;
-      const bool cok = iw >= 0 && iw < W;
+      const AxisPx cx = axis_px(geo, at.x0 - 1 + c, geo.W);
       T col[6], yv[6];
       bool okr[6];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        const int ih = 4 * th - 1 + r;
-        okr[r] = cok && ih >= 0 && ih < H;
-        const size_t o = (((size_t)n * H + (okr[r] ? ih : 0)) * W + (okr[r] ? iw : 0)) * K + cg * VW;
+        const size_t o = tile_pixel(geo, at, ry[r], cx, okr[r]) * K + cg * VW;
         col[r] = ldT<T>(g + o);
         yv[r] = ldT<T>(y + o);
       }
@@ -343,14 +361,16 @@ hipError_t launch_wino4_bn_input_transform(const float* x, float* stats, const f
                                            float* V, int N, int H, int W, int C, float eps, float momentum, float* save_mean,
                                            float* save_invstd, float* running_mean, float* running_var, hipStream_t st) {
   if (!wino4_bn_supported(C) || ((res == nullptr) != (out == nullptr))) return hipErrorInvalidValue;
-  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
-  const size_t total = (size_t)N * TH * TW * (C / 4);
-  if (res != nullptr)
-    hipLaunchKernelGGL((wino4_bn_input_transform_kernel<true>), dim3(wbn_grid(total)), dim3(256), 0, st, x, stats, gamma, beta, res, out, V, N, H,
-                       W, C, TH, TW, eps, momentum, save_mean, save_invstd, running_mean, running_var);
-  else
-    hipLaunchKernelGGL((wino4_bn_input_transform_kernel<false>), dim3(wbn_grid(total)), dim3(256), 0, st, x, stats, gamma, beta, res, out, V, N, H,
-                       W, C, TH, TW, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+  const TileGeo geo = wino4_geo(N, H, W);
+  const size_t total = tile_count(geo) * (C / 4);
+  static const int in_scalar = [] { const char* e = getenv("HIFIHR_WINO_IN_VEC"); return e ? atoi(e) : 0; }();   // 1: one channel per thread; 4: four (A/B)
+  const bool scalar = in_scalar == 1;      // (measured: no gain -- 18.3 / 13.6 / 19.6 us against 16.2 / 13.1 / 17.2 at four channels per thread)
+#define HIFIHR_WBN_IN(R_, T_, TOT_)                                                                                                        \
+  hipLaunchKernelGGL((wino4_bn_input_transform_kernel<R_, T_>), dim3(wbn_grid(TOT_)), dim3(256), 0, st, x, stats, gamma, beta, res, out, V, geo, \
+                     C, eps, momentum, save_mean, save_invstd, running_mean, running_var)
+  if (res != nullptr) { if (scalar) HIFIHR_WBN_IN(true, float, total * 4); else HIFIHR_WBN_IN(true, V4, total); }
+  else { if (scalar) HIFIHR_WBN_IN(false, float, total * 4); else HIFIHR_WBN_IN(false, V4, total); }
+#undef HIFIHR_WBN_IN
   return hipGetLastError();
 }
 
@@ -358,14 +378,14 @@ hipError_t launch_wino4_output_transform_bnred(const float* Mm, const float* x, 
                                                const float* save_invstd, const float* gamma, const float* beta, float* red, float* g, int N,
                                                int H, int W, int C, hipStream_t st) {
   if (!wino4_bn_supported(C)) return hipErrorInvalidValue;
-  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
-  const size_t T = (size_t)N * TH * TW;
+  const TileGeo geo = wino4_geo(N, H, W);
+  const size_t T = tile_count(geo);
   size_t bx = (T + 15) / 16;
   if (bx > 1024) bx = 1024;
   const dim3 grid((unsigned)bx, (C + 63) / 64);
 #define HIFIHR_BNRED(R_, A_)                                                                                                               \
   hipLaunchKernelGGL((wino4_output_transform_bnred_kernel<R_, A_>), grid, dim3(256), 0, st, Mm, x, outp, gadd, save_mean, save_invstd, gamma, \
-                     beta, red, g, N, H, W, C, TH, TW)
+                     beta, red, g, geo, C)
   if (outp != nullptr) {
     if (gadd != nullptr) HIFIHR_BNRED(true, true); else HIFIHR_BNRED(true, false);
   } else {
@@ -379,14 +399,14 @@ hipError_t launch_wino4_bn_bwd_dual_transform(const float* g, const float* y, co
                                               float* red, float* V, float* Y, int N, int H, int W, int K, float* dgamma_acc, float* dbeta_acc,
                                               hipStream_t st) {
   if (!wino4_bn_supported(K)) return hipErrorInvalidValue;
-  const int TH = (H + 3) / 4, TW = (W + 3) / 4;
-  const size_t total = (size_t)N * TH * TW * (K / 4);
+  const TileGeo geo = wino4_geo(N, H, W);
+  const size_t total = tile_count(geo) * (K / 4);
   if (wbn_scalar(total))
     hipLaunchKernelGGL(wino4_bn_bwd_dual_transform_kernel<float>, dim3(wbn_grid(total * 4)), dim3(256), 0, st, g, y, save_mean, save_invstd, gamma,
-                       red, V, Y, N, H, W, K, TH, TW, dgamma_acc, dbeta_acc);
+                       red, V, Y, geo, K, dgamma_acc, dbeta_acc);
   else
     hipLaunchKernelGGL(wino4_bn_bwd_dual_transform_kernel<V4>, dim3(wbn_grid(total)), dim3(256), 0, st, g, y, save_mean, save_invstd, gamma, red,
-                       V, Y, N, H, W, K, TH, TW, dgamma_acc, dbeta_acc);
+                       V, Y, geo, K, dgamma_acc, dbeta_acc);
   return hipGetLastError();
 }
 

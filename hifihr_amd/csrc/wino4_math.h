@@ -9,6 +9,50 @@ namespace w4 {
 struct V4 {
   float x, y, z, w;
 };
+
+// ------------------------------------------------------------------------------------------------
+// Tile geometry of the F(4x4, 3x3) pipeline.  Plain: image n is cut into ceil(H / 4) x ceil(W / 4) tiles of its own -- a 14 x 14 map
+// (ResNet layers 3-4: 60 % of the trunk's multiplications) pays for a 16 x 16 one, 23 % of the batched products and of V / M / Y' are
+// padding.  MOSAIC (round 4; G = 4): G x G images are laid out as ONE map with a single line of zeros between neighbours (stride H + 1:
+// the line is the bottom padding of one image and the top padding of the next, so every pixel still sees its own zero border) and the
+// 4 x 4 tiles are cut from that map: (4 (H + 1) / 4)^2 = 225 tiles per 16 images at 14 x 14 instead of 256 (-12 %), 196 instead of 256 at
+// 13 x 13.  Only the tile -> pixel mapping of the transform kernels changes (tile_at / axis_px below); the products see fewer rows.
+// Used when it saves tiles: H == W, H % 4 in {1, 2}, N a multiple of 16 (HIFIHR_WINO_MOSAIC=0 switches it off).
+// ------------------------------------------------------------------------------------------------
+struct TileGeo {
+  int N, H, W, TH, TW, G;                                   // G = 0: plain; else images per mosaic side.  TH x TW tiles per image / per mosaic
+};
+__host__ __device__ inline bool tile_mosaic_shape(int N, int H, int W) { return H == W && (H % 4 == 1 || H % 4 == 2) && N % 16 == 0 && N > 0; }
+__host__ __device__ inline TileGeo make_tile_geo(int N, int H, int W, bool mosaic) {
+  TileGeo g{N, H, W, (H + 3) / 4, (W + 3) / 4, 0};
+  if (mosaic && tile_mosaic_shape(N, H, W)) { g.G = 4; g.TH = H + 1; g.TW = W + 1; }          // 4 (H + 1) / 4 tiles per side
+  return g;
+}
+// rows of V / M / Y' per position.  Mosaic: rounded up to a multiple of 32 (the backward-weight products walk the tiles 32 at a time);
+// the tiles past the last mosaic belong to no image: the input transforms write zeros for them, the output transforms nothing.
+__host__ __device__ inline size_t tile_count(const TileGeo& g) {
+  if (!g.G) return (size_t)g.N * g.TH * g.TW;
+  const size_t t = (size_t)(g.N / (g.G * g.G)) * g.TH * g.TW;
+  return (t + 31) / 32 * 32;
+}
+struct TileAt { int n, y0, x0; };                           // first image (mosaic: of the group), output coordinate of the tile's first pixel
+__device__ __forceinline__ TileAt tile_at(const TileGeo& g, size_t t) {
+  const int tw = (int)(t % g.TW), th = (int)((t / g.TW) % g.TH), q = (int)(t / ((size_t)g.TW * g.TH));
+  return TileAt{g.G ? q * g.G * g.G : q, 4 * th, 4 * tw};
+}
+struct AxisPx { bool ok; int img, p; };                     // along one axis: inside an image?  which image of the mosaic row / column, coordinate in it
+__device__ __forceinline__ AxisPx axis_px(const TileGeo& g, int m, int L) {
+  if (!g.G) return AxisPx{m >= 0 && m < L, 0, m};
+  if (m < 0) return AxisPx{false, 0, 0};
+  const int i = m / (L + 1), p = m - i * (L + 1);
+  return AxisPx{p < L && i < g.G, i, p};
+}
+// pixel index (n H + y) W + x of the pixel at (row r, column c) of the axes, 0 when it is not a pixel of an image (ok = false)
+__device__ __forceinline__ size_t tile_pixel(const TileGeo& g, const TileAt& a, const AxisPx& r, const AxisPx& c, bool& ok) {
+  const int n = a.n + (g.G ? r.img * g.G + c.img : 0);
+  ok = r.ok && c.ok && n < g.N;                             // (n >= N: the padding tiles behind the last mosaic)
+  return ok ? ((size_t)n * g.H + r.p) * g.W + c.p : (size_t)0;
+}
 __device__ __forceinline__ V4 operator+(const V4& a, const V4& b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 __device__ __forceinline__ V4 operator-(const V4& a, const V4& b) { return V4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
 __device__ __forceinline__ V4 operator*(float s, const V4& a) { return V4{s * a.x, s * a.y, s * a.z, s * a.w}; }

@@ -445,11 +445,12 @@ def _wino_tile(lib, N, H, W, C, K):
     """Output-tile edge m of the Winograd algorithm this layer runs (hifihr_wino_tile: 4 = F(4x4, 3x3) with 36 positions where the
     batched GEMMs take the shape, else 2 = F(2x2, 3x3) with 16); -> (m, positions, tiles)."""
     key = (N, H, W, C, K)
-    m = _WINO_TILE.get(key)
-    if m is None:
+    e = _WINO_TILE.get(key)
+    if e is None:
         m = lib.wino_tile(N, H, W, C, K)
-        _WINO_TILE[key] = m
-    return m, (m + 2) ** 2, N * ((H + m - 1) // m) * ((W + m - 1) // m)
+        e = (m, (m + 2) ** 2, lib.wino_tiles(N, H, W, m))        # (tiles: the library's count -- mosaics of 16 images at 14 x 14)
+        _WINO_TILE[key] = e
+    return e
 
 
 class _WeightPrep:

@@ -288,6 +288,11 @@ int hifihr_wino_output_transform_act(const float* m_d, float* y_d, const float* 
  * shape in all three directions (C % 64 == 0, K % 64 == 0, H, W >= 4), else 2.  m = 4 has the slab form of backward-weight only
  * (hifihr_wino_wgrad_parts_m > 0).  The per-step weight re-layout (hifihr_weight_prep) has job kinds 3 / 4 for U[36][K][C] / U'[36][C][K]. */
 int hifihr_wino_tile(int N, int H, int W, int C, int K);
+/* T, the tiles (rows per position of V / M / Y') a layer has at tile edge m: N * ceil(H / m) * ceil(W / m) -- or, at m = 4 on square maps
+ * with H % 4 in {1, 2} and N % 16 == 0, the tiles of the 4 x 4-image MOSAICS the transforms cut (16 images share one map with single
+ * lines of zeros between them: 225 tiles per 16 images of 14 x 14 instead of 256), rounded up to a multiple of 32.  Every buffer of the
+ * pipeline is sized with it.  (HIFIHR_WINO_MOSAIC=0: always the first form.) */
+long hifihr_wino_tiles(int N, int H, int W, int m);
 size_t hifihr_wino_gemm_workspace_bytes_m(int N, int H, int W, int C, int K, int m);
 int hifihr_wino_weight_transform_m(const float* w_d, float* u_d, int K, int C, int flip, int m, void* stream);
 int hifihr_wino_input_transform_m(const float* x_d, float* v_d, int N, int H, int W, int C, int m, void* stream);

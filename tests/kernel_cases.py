@@ -957,7 +957,7 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True, 
     gy = torch.randn(y.shape, generator=gen)
     y.backward(gy)
     d = lambda t: t.to(device).contiguous()
-    T = N * ((H + m - 1) // m) * ((W + m - 1) // m)
+    T = lib.wino_tiles(N, H, W, m)               # (the library's count: 16 images share a mosaic of tiles at m = 4, H % 4 in {1, 2})
     xd, wd, gyd = d(x.permute(0, 2, 3, 1)), d(w.permute(0, 2, 3, 1)), d(gy.permute(0, 2, 3, 1))
     nb = max(lib.wino_gemm_workspace_bytes(N, H, W, C, K, m), lib.wino_gemm_workspace_bytes(N, H, W, K, C, m)) if use_ws else 0
     ws = torch.zeros(nb // 4, device=device) if nb else None
@@ -1432,7 +1432,7 @@ def bn_large_mean_case(lib, device, producer, seed=0, mean=50.0, std=0.1):
         yd = torch.empty(N, H, W, K, device=device); stats = torch.zeros(lib.bn_stats_floats(K), device=device)
         if producer in ("wino4", "wino2"):
             m = 4 if producer == "wino4" else 2
-            P, T = (m + 2) ** 2, N * ((H + m - 1) // m) * ((W + m - 1) // m)
+            P, T = (m + 2) ** 2, lib.wino_tiles(N, H, W, m)
             U = torch.empty(P, K, C, device=device); V = torch.empty(P, T, C, device=device); Mm = torch.empty(P, T, K, device=device)
             lib.wino_weight_transform(wd, U, K, C, 0, m); lib.wino_input_transform(xd, V, N, H, W, C, m)
             lib.wino_gemm(V, U, Mm, N, H, W, C, K, ws=None, m=m); lib.wino_output_transform(Mm, yd, stats, N, H, W, K, m=m)
@@ -1470,7 +1470,7 @@ def wino_bn_input_case(lib, device, N, H, W, C, residual, seed=0):
     res = torch.randn(N, H, W, C, generator=gen) if residual else None
     gamma = 1 + 0.1 * torch.randn(C, generator=gen); beta = 0.1 * torch.randn(C, generator=gen)
     M = N * H * W
-    T = N * ((H + 3) // 4) * ((W + 3) // 4)
+    T = lib.wino_tiles(N, H, W, 4)
 
     def fresh():
         st = torch.zeros(lib.bn_stats_floats(C), device=device)
@@ -1507,7 +1507,7 @@ def wino_bn_bwd_case(lib, device, N, H, W, C, residual, addend, seed=0):
     gen = torch.Generator().manual_seed(seed)
     d = lambda t: t.to(device).contiguous()
     M = N * H * W
-    T = N * ((H + 3) // 4) * ((W + 3) // 4)
+    T = lib.wino_tiles(N, H, W, 4)
     x = d(torch.randn(N, H, W, C, generator=gen) * 1.3 + 0.2)
     res = d(torch.randn(N, H, W, C, generator=gen)) if residual else None
     gadd = d(torch.randn(N, H, W, C, generator=gen)) if addend else None

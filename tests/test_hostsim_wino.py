@@ -41,3 +41,27 @@ def test_bn_fused_into_winograd_input_transform(hostsim_lib, N, H, W, C, residua
                                                       (1, 14, 14, 24, False, True)])
 def test_bn_backward_fused_into_winograd_transforms(hostsim_lib, N, H, W, C, residual, addend):
     kc.wino_bn_bwd_case(hostsim_lib, "cpu", N, H, W, C, residual, addend, seed=C + H)
+
+
+# ---- the tile MOSAIC (round 4): 16 images share one map with single lines of zeros between them (H % 4 in {1, 2}, N % 16 == 0)
+def test_winograd_mosaic_tile_count(hostsim_lib):
+    assert hostsim_lib.wino_tiles(32, 14, 14, 4) == 480            # 2 x 15 x 15 = 450, rounded up to a multiple of 32 (plain: 512)
+    assert hostsim_lib.wino_tiles(16, 6, 6, 4) == 64               # 7 x 7 = 49 -> 64 (plain: 16 x 4 = 64: no loss either)
+    assert hostsim_lib.wino_tiles(16, 13, 13, 4) == 224            # 14 x 14 = 196 -> 224 (plain: 256)
+    assert hostsim_lib.wino_tiles(8, 14, 14, 4) == 8 * 16          # N % 16 != 0: plain tiles
+    assert hostsim_lib.wino_tiles(16, 28, 28, 4) == 16 * 49        # H % 4 == 0: plain tiles
+    assert hostsim_lib.wino_tiles(16, 14, 14, 2) == 16 * 49        # F(2x2, 3x3): plain tiles
+
+
+@pytest.mark.parametrize("N,H,C,K", [(16, 6, 64, 64), (16, 5, 64, 128), (32, 6, 64, 64)])
+def test_winograd_f4_mosaic_fwd_bwd(hostsim_lib, N, H, C, K):
+    """The whole F(4x4, 3x3) pipeline on mosaic tiles (forward + statistics + epilogues, backward-data, dual transform, backward-weight
+    slabs) against torch conv2d: only the tile -> pixel mapping of the transform kernels differs from the plain form."""
+    assert hostsim_lib.wino_tile(N, H, H, C, K) == 4 and hostsim_lib.wino_tiles(N, H, H, 4) < N * ((H + 3) // 4) ** 2 + 32
+    kc.wino_case(hostsim_lib, "cpu", N, H, H, C, K, seed=C + K + H, m=4)
+
+
+@pytest.mark.parametrize("N,H,C,residual,addend", [(16, 6, 64, False, False), (16, 5, 32, True, True)])
+def test_bn_fusions_on_mosaic_tiles(hostsim_lib, N, H, C, residual, addend):
+    kc.wino_bn_input_case(hostsim_lib, "cpu", N, H, H, C, residual, seed=C + H)
+    kc.wino_bn_bwd_case(hostsim_lib, "cpu", N, H, H, C, residual, addend, seed=C + H)

@@ -14,7 +14,7 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) * 1e3 / n
 N = 32
 for (H, C) in ((28, 128), (14, 256), (14, 512)):
-    M = N * H * H; T = N * ((H + 3) // 4) ** 2
+    M = N * H * H; T = lib.wino_tiles(N, H, H, 4)
     x = torch.randn(N, H, H, C, device="cuda"); res = torch.randn_like(x); g = torch.randn_like(x); out = torch.empty_like(x)
     gamma = torch.ones(C, device="cuda"); beta = torch.zeros(C, device="cuda")
     sm = torch.zeros(C, device="cuda"); si = torch.ones(C, device="cuda"); rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda")
