@@ -260,7 +260,7 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None):
         if direction in ("gemm", "gemm-tn"):
             _, N_, H_, W_, C_, K_, m_ = geom                    # m_: Winograd output-tile edge (2: 16 positions, 4: 36)
             P_ = (m_ + 2) ** 2
-            T_ = N_ * ((H_ + m_ - 1) // m_) * ((W_ + m_ - 1) // m_)
+            T_ = lib.wino_tiles(N_, H_, W_, m_)                 # (mosaic tiles on the 14 x 14 layers: 480 rows allocated, 450 computed)
             V = torch.randn(P_ * T_ * C_, device=dev)
             if direction == "gemm":
                 U = torch.randn(P_ * K_ * C_, device=dev) * 0.05; M = torch.empty(P_ * T_ * K_, device=dev)
@@ -270,7 +270,8 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None):
                 nb = lib.wino_gemm_workspace_bytes(N_, H_, W_, C_, K_, m_)
                 ws = torch.zeros(nb // 4 + 64, device=dev) if nb else None
                 us = hip_us(lambda: lib.wino_gemm(V, U, M, N_, H_, W_, C_, K_, ws=ws, m=m_))
-                add(name, per_step, us, 2.0 * P_ * T_ * C_ * K_, 4.0 * P_ * (T_ * C_ + K_ * C_ + T_ * K_), f"{P_} x [{T_} x {C_}] . [{K_} x {C_}]^T")
+                Tc = lib.wino_tiles_computed(N_, H_, W_, m_)    # rows the product walks (the mosaic count before its rounding)
+                add(name, per_step, us, 2.0 * P_ * Tc * C_ * K_, 4.0 * P_ * (Tc * C_ + K_ * C_ + Tc * K_), f"{P_} x [{Tc} x {C_}] . [{K_} x {C_}]^T")
             else:
                 Y = torch.randn(P_ * T_ * K_, device=dev)
                 parts = lib.wino_wgrad_parts(N_, H_, W_, C_, K_, m_)

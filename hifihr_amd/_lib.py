@@ -202,6 +202,8 @@ class HifihrLib:
         c.hifihr_se_mlp_supported.argtypes = [c_int, c_int]
         c.hifihr_wino_tiles.argtypes = [c_int] * 4
         c.hifihr_wino_tiles.restype = c_long
+        c.hifihr_wino_tiles_computed.argtypes = [c_int] * 4
+        c.hifihr_wino_tiles_computed.restype = c_long
         c.hifihr_zero_page_ready.argtypes = [c_void_p]
         c.hifihr_drop_connect_add.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_size_t, _c_float_p, c_void_p]
         c.hifihr_se_mlp_fwd.argtypes = [_c_float_p] * 5 + [c_int] * 3 + [_c_float_p] * 4 + [c_void_p]
@@ -630,6 +632,9 @@ class HifihrLib:
 
     def wino_tiles(self, N, H, W, m):
         return int(self.c.hifihr_wino_tiles(int(N), int(H), int(W), int(m)))
+
+    def wino_tiles_computed(self, N, H, W, m):
+        return int(self.c.hifihr_wino_tiles_computed(int(N), int(H), int(W), int(m)))
 
     def se_mlp_supported(self, C, SQ):
         return bool(self.c.hifihr_se_mlp_supported(int(C), int(SQ)))

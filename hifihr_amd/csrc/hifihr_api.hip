@@ -436,7 +436,8 @@ int hifihr_conv2d_describe(int N, int H, int W, int C, int K, int R, int S, int 
     if (dgrad != 2 || wg) return HIFIHR_OK;
   }
   if (dgrad == 2) snprintf(out, cap, "%s", hifihr::conv_halo_wgrad_supported(g) ? "conv_halo_wgrad_kernel" : hifihr::conv_stem_wgrad_supported(g) ? "conv_stem_wgrad_kernel" : "conv_wgrad_kernel");
-  else snprintf(out, cap, "%s", hifihr::conv_halo_supported(g, nullptr) ? "conv_halo_kernel" : hifihr::conv_stem_supported(g, nullptr) ? "conv_stem_kernel" : "conv_igemm_kernel");
+  else snprintf(out, cap, "%s", hifihr::conv_halo_supported(g, nullptr) ? "conv_halo_kernel" : hifihr::conv_stem_supported(g, nullptr) ? "conv_stem_kernel" :
+                (dgrad == 0 && hifihr::conv_rows_supported(g, nullptr)) ? "bgemm_nt_rows_kernel" : "conv_igemm_kernel");      // (strided forward: the gathering row-share GEMM)
   return HIFIHR_OK;
 }
 
@@ -930,6 +931,10 @@ static int wino_m(int N, int H, int W, int C, int K) {
 static long wino_T(int m, int N, int H, int W) { return m == 4 ? hifihr::wino4_tiles(N, H, W) : (long)N * ((H + m - 1) / m) * ((W + m - 1) / m); }
 
 long hifihr_wino_tiles(int N, int H, int W, int m) { return (N > 0 && H > 0 && W > 0 && (m == 2 || m == 4)) ? wino_T(m, N, H, W) : 0; }
+long hifihr_wino_tiles_computed(int N, int H, int W, int m) {
+  if (!(N > 0 && H > 0 && W > 0 && (m == 2 || m == 4))) return 0;
+  return m == 4 ? hifihr::wino4_tiles_real(N, H, W) : wino_T(m, N, H, W);
+}
 
 int hifihr_wino_tile(int N, int H, int W, int C, int K) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 2;

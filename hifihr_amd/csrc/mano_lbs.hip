@@ -229,36 +229,52 @@ __global__ __launch_bounds__(kBwdThreads) void mano_bwd_kernel(ManoDev t, const 
       for (int j = 0; j < 21; ++j) acc += gjtr[((size_t)b * 21 + j) * 3 + tid];
     L.gcenter[tid] = -acc;        // d/d(centre): every output had the centre subtracted
   }
-  // ---- phase 2a: gAp[i][4r+c] = sum_v w[v,i] gv[r][v] [vp;1][c][v]  (192 sums x 4 lanes each: a quarter of the vertices per
-  //      lane, fixed order, folded with two shuffles -- a single lane per sum was a 778-step chain) ----
-  constexpr int k2aThreads = kNJ * 12 * 4;
-  if (tid < k2aThreads) {
-    const int d = tid >> 2, q = tid & 3;
-    const int i = d / 12, k = d % 12, r = k / 4, c = k % 4;
-    const float* wrow = t.w + i * kNVP;
-    const float* gr = L.gv + r * kNVP;
-    constexpr int kQ = (kNV + 3) / 4;
-    const int v0 = q * kQ, v1 = (v0 + kQ < kNV) ? v0 + kQ : kNV;
-    float acc = 0.f;
-    if (c < 3) {
-      const float* pc = L.vp + c * kNVP;
-#pragma unroll 8
-      for (int v = v0; v < v1; ++v) acc += wrow[v] * gr[v] * pc[v];
-    } else {
-#pragma unroll 8
-      for (int v = v0; v < v1; ++v) acc += wrow[v] * gr[v];
+  // ---- phase 2a: gAp[i][4r+c] = sum_v w[v,i] gv[r][v] [vp;1][c][v].  Round 4: one WAVE per joint -- its weight row is read once (13
+  //      coalesced loads per lane, all in flight) and feeds the joint's 12 sums, each folded by a wave reduction.  (Round 3: 192 sums x 4
+  //      lanes, each lane walking a quarter of the vertices with its own loads of the weight row: ~25 dependent L2 round trips.) ----
+  {
+    constexpr int kIt = (kNV + 63) / 64;
+    static_assert(kBwdThreads / 64 >= kNJ, "a wave per joint");
+    if (wave < kNJ) {
+      const float* wrow = t.w + wave * kNVP;
+      float wv[kIt];
+#pragma unroll
+      for (int i = 0; i < kIt; ++i) { const int v = lane + 64 * i; wv[i] = v < kNV ? wrow[v] : 0.f; }
+      float acc[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int i = 0; i < kIt; ++i) {
+        const int v = lane + 64 * i;
+        if (v < kNV) {
+          const float w = wv[i];
+          const float p[4] = {L.vp[v], L.vp[kNVP + v], L.vp[2 * kNVP + v], 1.f};
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const float wg = w * L.gv[r * kNVP + v];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[4 * r + c] += wg * p[c];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const float r = wave_sum(acc[k]);
+        if (lane == 0) L.gAp[wave * 12 + k] = r;
+      }
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    if (q == 0) L.gAp[d] = acc;
   }
-  // ---- phase 2b: gvp[v] = sum_i w[v,i] Rg_i^T gv[v]  (the remaining threads, so both halves overlap) ----
-  for (int v = (tid >= k2aThreads) ? tid - k2aThreads : kNVP; v < kNVP; v += kBwdThreads - k2aThreads) {
+  // ---- phase 2b: gvp[v] = sum_i w[v,i] Rg_i^T gv[v]  (a vertex per thread, its 16 weights in flight together) ----
+  for (int v = tid; v < kNVP; v += kBwdThreads) {
     float o[3] = {0.f, 0.f, 0.f};
     if (v < kNV) {
       const float g[3] = {L.gv[v], L.gv[kNVP + v], L.gv[2 * kNVP + v]};
+      float wv[kNJ];
+#pragma unroll
+      for (int i = 0; i < kNJ; ++i) wv[i] = t.w[i * kNVP + v];
+#pragma unroll
       for (int i = 0; i < kNJ; ++i) {
-        const float w = t.w[i * kNVP + v];
+        const float w = wv[i];
         const float* R = L.s.Rg + 9 * i;
         o[0] += w * (R[0] * g[0] + R[3] * g[1] + R[6] * g[2]);
         o[1] += w * (R[1] * g[0] + R[4] * g[1] + R[7] * g[2]);
@@ -269,32 +285,43 @@ __global__ __launch_bounds__(kBwdThreads) void mano_bwd_kernel(ManoDev t, const 
   }
   __syncthreads();
 
-  // ---- phase 3: blend-shape transposes: gpm[p] = <posedirs row p, gvp>, gbeta[k] = <shapedirs row k, gvp> ----
+  // ---- phase 3: blend-shape transposes: gpm[p] = <posedirs row p, gvp>, gbeta[k] = <shapedirs row k, gvp>.  A wave walks its rows two at
+  //      a time (20 float4 per lane in flight): the rows come from L2 / HBM (1.4 MB of tables per hand-workgroup) and every trip is one
+  //      memory latency ----
   {
     constexpr int kRow4 = 3 * kNVP / 4;     // float4 per table row
     const float4* g4 = reinterpret_cast<const float4*>(L.gvp);
-    for (int row = wave; row < kNP + kNB; row += kBwdThreads / 64) {
-      const float* base = (row < kNP) ? t.pd + (size_t)row * 3 * kNVP : t.sd + (size_t)(row - kNP) * 3 * kNVP;
-      const float4* r4 = reinterpret_cast<const float4*>(base);
-      constexpr int kIt = (kRow4 + 63) / 64;       // 10 float4 per lane per row: all issued before the first is used
-      float4 a[kIt];
+    constexpr int kIt = (kRow4 + 63) / 64;       // 10 float4 per lane per row: all issued before the first is used
+    constexpr int kW = kBwdThreads / 64;
+    for (int row0 = wave; row0 < kNP + kNB; row0 += 2 * kW) {
+      const int row1 = row0 + kW;
+      const bool two = row1 < kNP + kNB;
+      const float* base0 = (row0 < kNP) ? t.pd + (size_t)row0 * 3 * kNVP : t.sd + (size_t)(row0 - kNP) * 3 * kNVP;
+      const float* base1 = !two ? base0 : ((row1 < kNP) ? t.pd + (size_t)row1 * 3 * kNVP : t.sd + (size_t)(row1 - kNP) * 3 * kNVP);
+      const float4* r40 = reinterpret_cast<const float4*>(base0);
+      const float4* r41 = reinterpret_cast<const float4*>(base1);
+      float4 a0[kIt], a1[kIt];
 #pragma unroll
       for (int i = 0; i < kIt; ++i) {
         const int e = lane + 64 * i;
-        a[i] = r4[e < kRow4 ? e : kRow4 - 1];
+        a0[i] = r40[e < kRow4 ? e : kRow4 - 1];
+        a1[i] = r41[e < kRow4 ? e : kRow4 - 1];
       }
-      float acc = 0.f;
+      float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
       for (int i = 0; i < kIt; ++i) {
         const int e = lane + 64 * i;
         if (e < kRow4) {
           const float4 g = g4[e];
-          acc += a[i].x * g.x + a[i].y * g.y + a[i].z * g.z + a[i].w * g.w;
+          acc0 += a0[i].x * g.x + a0[i].y * g.y + a0[i].z * g.z + a0[i].w * g.w;
+          acc1 += a1[i].x * g.x + a1[i].y * g.y + a1[i].z * g.z + a1[i].w * g.w;
         }
       }
-      acc = wave_sum(acc);
+      acc0 = wave_sum(acc0);
+      acc1 = wave_sum(acc1);
       if (lane == 0) {
-        if (row < kNP) L.gpm[row] = acc; else L.gbeta_blend[row - kNP] = acc;
+        if (row0 < kNP) L.gpm[row0] = acc0; else L.gbeta_blend[row0 - kNP] = acc0;
+        if (two) { if (row1 < kNP) L.gpm[row1] = acc1; else L.gbeta_blend[row1 - kNP] = acc1; }
       }
     }
   }
@@ -369,13 +396,23 @@ __global__ __launch_bounds__(kJointsFwdThreads) void mano_joints_fwd_kernel(Mano
     sv[v] = p[0]; sv[kNVP + v] = p[1]; sv[2 * kNVP + v] = p[2];
   }
   __syncthreads();
-  for (int o = wave; o < kNJ * 3; o += kJointsFwdThreads / 64) {   // 48 dot products of length 778, one wave each
-    const int j = o / 3, c = o % 3;
-    const float* jr = t.jreg + j * kNVP;
-    float acc = 0.f;
-    for (int v = lane; v < kNV; v += 64) acc += jr[v] * sv[c * kNVP + v];
-    acc = wave_sum(acc);
-    if (lane == 0) j16[o] = acc;
+  // one wave per regressed joint: its regressor row is read once (13 coalesced loads per lane, all in flight) and feeds the three
+  // coordinate sums (round 3: 48 wave dot products in three rounds, each with its own walk over the row)
+  static_assert(kJointsFwdThreads / 64 >= kNJ, "a wave per joint");
+  if (wave < kNJ) {
+    constexpr int kIt = (kNV + 63) / 64;
+    const float* jr = t.jreg + wave * kNVP;
+    float rv[kIt];
+#pragma unroll
+    for (int i = 0; i < kIt; ++i) { const int v = lane + 64 * i; rv[i] = v < kNV ? jr[v] : 0.f; }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kIt; ++i) {
+      const int v = lane + 64 * i;
+      if (v < kNV) { a0 += rv[i] * sv[v]; a1 += rv[i] * sv[kNVP + v]; a2 += rv[i] * sv[2 * kNVP + v]; }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) { j16[wave * 3] = a0; j16[wave * 3 + 1] = a1; j16[wave * 3 + 2] = a2; }
   }
   __syncthreads();
   if (tid < 63) {

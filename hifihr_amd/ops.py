@@ -555,7 +555,7 @@ class prepared_weights:
             _WEIGHT_PREP.begin()
         # not inside a hipGraph capture: forked branches of a replayed graph ran SLOWER here (8.03 vs 7.74 ms/step) while the same
         # fork in the eager step gains (7.69 vs 7.83)
-        _ASYNC_WGRAD.active = self.async_wgrad and not torch.cuda.is_current_stream_capturing()
+        _ASYNC_WGRAD.active = self.async_wgrad and (not torch.cuda.is_current_stream_capturing() or os.environ.get("HIFIHR_ASYNC_WGRAD_GRAPH") == "1")
         return self
 
     def __exit__(self, *exc):

@@ -293,6 +293,8 @@ int hifihr_wino_tile(int N, int H, int W, int C, int K);
  * lines of zeros between them: 225 tiles per 16 images of 14 x 14 instead of 256), rounded up to a multiple of 32.  Every buffer of the
  * pipeline is sized with it.  (HIFIHR_WINO_MOSAIC=0: always the first form.) */
 long hifihr_wino_tiles(int N, int H, int W, int m);
+/* ... and the rows of them the forward / backward-data products actually compute (the mosaic count before the rounding; else the same). */
+long hifihr_wino_tiles_computed(int N, int H, int W, int m);
 size_t hifihr_wino_gemm_workspace_bytes_m(int N, int H, int W, int C, int K, int m);
 int hifihr_wino_weight_transform_m(const float* w_d, float* u_d, int K, int C, int flip, int m, void* stream);
 int hifihr_wino_input_transform_m(const float* x_d, float* v_d, int N, int H, int W, int C, int m, void* stream);
