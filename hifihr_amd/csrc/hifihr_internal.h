@@ -118,13 +118,9 @@ constexpr int kStatSlots = 32;
 // of every workgroup (csrc/bn_fold.h) -- 512 B of L2 reads per channel and workgroup at 32 double slots, 67 MB per launch of a
 // 512-channel layer's fused transform, as much as the transform itself moves -- while the same-address atomic traffic the slots exist
 // to spread falls with the channel count (a wide layer has few rows per channel: <= 32 adders per address at 8 slots).
-// (Round 4, second step: 8 slots from 64 channels up -- a producer grid of <= 1 024 workgroups then meets <= 128 ways on an address, spread
-// over its whole run; the 32-slot fold of a 128-channel layer was ~2 us of every consumer launch.  HIFIHR_STAT_SLOTS_OLD for the A/B.)
-#if defined(HIFIHR_STAT_SLOTS_OLD)
+// (Tried: 8 slots from 64 channels up.  bn_bwd_reduce_kernel went from 16.9 to 25.2 us per launch: its <= 2 048 workgroups then meet 256
+// ways on each address of a 64-channel layer.  The slot count follows the channel count because the adders per address fall with it.)
 __host__ __device__ inline int stat_slots_used(int C) { return C >= 512 ? 8 : (C >= 256 ? 16 : 32); }
-#else
-__host__ __device__ inline int stat_slots_used(int C) { return C >= 64 ? 8 : 32; }
-#endif
 // FORWARD statistics (round 3): the slots hold DOUBLES, double S[kStatSlots][2][C] = (sum y, sum y^2), followed by 64 uint32 arrival
 // counters.  A producer lane accumulates SHIFTED sums in fp32 -- d = y - k with k a value of its own (the first y it saw for that
 // channel), s = sum d, q = sum d^2 over its n values: q stays of the order of n var however large the mean is -- and converts ONCE,
