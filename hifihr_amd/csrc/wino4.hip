@@ -44,28 +44,32 @@ __global__ __launch_bounds__(256) void wino4_weight_transform_kernel(const float
 
 // thread = (tile, 4 channels); x[N][H][W][C] -> V[36][T][C].  DUAL: x is a gradient dy that backward-data (V = B^T d B of the padded 6x6
 // patch) AND backward-weight (Y' = A dy A^T of the patch's central 4x4 block = this tile's outputs) both consume: one read of dy.
-template <bool DUAL>
+// MOS: the mosaic tile geometry (a template flag: with G known to be 0 the plain form keeps round 3's index arithmetic -- as a run-time
+// field the extra selects cost the 28 x 28 layers' launches 1-1.5 us each)
+template <bool DUAL, bool MOS>
 __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V, float* __restrict__ Y,
                                                                    TileGeo geo, int C) {
+  if (!MOS) geo.G = 0;
   const int C4 = C / 4;
   const size_t T = tile_count(geo), total = T * C4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int cg = (int)(i % C4);
     const size_t t = i / C4;
     const TileAt at = tile_at(geo, t);
+    const AxisBase by_ = axis_base(geo, at.y0, geo.H), bx_ = axis_base(geo, at.x0, geo.W);
     AxisPx ry[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) ry[r] = axis_px(geo, at.y0 - 1 + r, geo.H);
+    for (int r = 0; r < 6; ++r) ry[r] = row_px(geo, at, by_, r - 1);
     V4 tt[6][6];                                            // tt = B^T d, built column by column
     V4 ty[6][4];                                            // DUAL: A dy (6 x 4) of the central block
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const AxisPx cx = axis_px(geo, at.x0 - 1 + c, geo.W);
+      const AxisPx cx = col_px(geo, bx_, c - 1);
       V4 col[6];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         bool ok;
-        const size_t px = tile_pixel(geo, at, ry[r], cx, ok);
+        const size_t px = tile_pixel(ry[r], cx, ok);
         const V4 v = ld4(x + px * C + cg * 4);
         col[r] = ok ? v : zero4();
       }
@@ -102,9 +106,11 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
 // workgroup = 16 tile lanes x 16 float4 channel lanes (64 channels, blockIdx.y); M[36][T][K] -> y[N][H][W][K] (+ stats | bias, ReLU)
 // mask (backward-data of a layer whose INPUT is a ReLU's output, round 4): y = mask > 0 ? v : 0 -- the ReLU's backward applied where its
 // gradient is produced, instead of a bias_relu_bwd pass over (dy, y) in front of the previous layer's backward
+template <bool MOS>
 __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Mm, float* __restrict__ y, float* __restrict__ stats,
                                                                     const float* __restrict__ bias, int relu, const float* __restrict__ mask,
                                                                     TileGeo geo, int K) {
+  if (!MOS) geo.G = 0;
   __shared__ double red[2][16][16][4];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int k = blockIdx.y * 64 + cl * 4;
@@ -116,9 +122,10 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
     const float lo = relu ? 0.f : -3.402823466e38f;
     for (size_t t = (size_t)blockIdx.x * 16 + tl; t < T; t += (size_t)gridDim.x * 16) {
       const TileAt at = tile_at(geo, t);
+    const AxisBase by_ = axis_base(geo, at.y0, geo.H), bx_ = axis_base(geo, at.x0, geo.W);
       AxisPx cx[4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) cx[b] = axis_px(geo, at.x0 + b, geo.W);
+      for (int b = 0; b < 4; ++b) cx[b] = col_px(geo, bx_, b);
       V4 s[4][6];                                           // s = A^T m, built column by column
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
@@ -132,14 +139,14 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const AxisPx ry = axis_px(geo, at.y0 + a, geo.H);
+        const AxisPx ry = row_px(geo, at, by_, a);
         V4 o[4];
         at6(s[a], o);
         if (ry.ok) {
           size_t po[4];
           bool okb[4];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) po[b] = tile_pixel(geo, at, ry, cx[b], okb[b]) * K + k;
+          for (int b = 0; b < 4; ++b) po[b] = tile_pixel(ry, cx[b], okb[b]) * K + k;
           V4 mk[4];
           if (mask != nullptr) {                            // (uniform) the row's mask values requested together
 #pragma unroll
@@ -165,25 +172,28 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
 }
 
 // backward-weight glue.  thread = (tile, 4 channels): Y'[36][T][K] = A dy A^T (dy outside the image = 0)
+template <bool MOS>
 __global__ __launch_bounds__(256) void wino4_dy_transform_kernel(const float* __restrict__ dy, float* __restrict__ Y, TileGeo geo, int K) {
+  if (!MOS) geo.G = 0;
   const int K4 = K / 4;
   const size_t T = tile_count(geo), total = T * K4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int kg = (int)(i % K4);
     const size_t t = i / K4;
     const TileAt at = tile_at(geo, t);
+    const AxisBase by_ = axis_base(geo, at.y0, geo.H), bx_ = axis_base(geo, at.x0, geo.W);
     AxisPx ry[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) ry[a] = axis_px(geo, at.y0 + a, geo.H);
+    for (int a = 0; a < 4; ++a) ry[a] = row_px(geo, at, by_, a);
     V4 ty[6][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const AxisPx cx = axis_px(geo, at.x0 + b, geo.W);
+      const AxisPx cx = col_px(geo, bx_, b);
       V4 col[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         bool ok;
-        const size_t px = tile_pixel(geo, at, ry[a], cx, ok);
+        const size_t px = tile_pixel(ry[a], cx, ok);
         const V4 v = ld4(dy + px * K + kg * 4);
         col[a] = ok ? v : zero4();
       }
@@ -269,8 +279,13 @@ hipError_t launch_wino4_input_transform(const float* x, float* V, float* Y, int 
   if (C % 4 != 0) return hipErrorInvalidValue;
   const TileGeo geo = wino4_geo(N, H, W);
   const size_t total = tile_count(geo) * (C / 4);
-  if (Y != nullptr) hipLaunchKernelGGL((wino4_input_transform_kernel<true>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, geo, C);
-  else hipLaunchKernelGGL((wino4_input_transform_kernel<false>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, geo, C);
+  if (geo.G) {
+    if (Y != nullptr) hipLaunchKernelGGL((wino4_input_transform_kernel<true, true>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, geo, C);
+    else hipLaunchKernelGGL((wino4_input_transform_kernel<false, true>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, geo, C);
+  } else {
+    if (Y != nullptr) hipLaunchKernelGGL((wino4_input_transform_kernel<true, false>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, geo, C);
+    else hipLaunchKernelGGL((wino4_input_transform_kernel<false, false>), dim3(wino4_grid(total)), dim3(256), 0, st, x, V, Y, geo, C);
+  }
   return hipGetLastError();
 }
 
@@ -281,14 +296,16 @@ hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats
   const size_t T = tile_count(geo);
   size_t bx = (T + 15) / 16;
   if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(wino4_output_transform_kernel, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, bias, relu, mask, geo, K);
+  if (geo.G) hipLaunchKernelGGL(wino4_output_transform_kernel<true>, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, bias, relu, mask, geo, K);
+  else hipLaunchKernelGGL(wino4_output_transform_kernel<false>, dim3((unsigned)bx, (K + 63) / 64), dim3(256), 0, st, Mm, y, stats, bias, relu, mask, geo, K);
   return hipGetLastError();
 }
 
 hipError_t launch_wino4_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st) {
   if (K % 4 != 0) return hipErrorInvalidValue;
   const TileGeo geo = wino4_geo(N, H, W);
-  hipLaunchKernelGGL(wino4_dy_transform_kernel, dim3(wino4_grid(tile_count(geo) * (K / 4))), dim3(256), 0, st, dy, Y, geo, K);
+  if (geo.G) hipLaunchKernelGGL(wino4_dy_transform_kernel<true>, dim3(wino4_grid(tile_count(geo) * (K / 4))), dim3(256), 0, st, dy, Y, geo, K);
+  else hipLaunchKernelGGL(wino4_dy_transform_kernel<false>, dim3(wino4_grid(tile_count(geo) * (K / 4))), dim3(256), 0, st, dy, Y, geo, K);
   return hipGetLastError();
 }
 

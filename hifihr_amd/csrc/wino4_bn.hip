@@ -65,17 +65,18 @@ __device__ __forceinline__ void wbn_load(WbnPatch<RES, T>& p, size_t i, const fl
   p.cg = (int)(i % CV);
   p.t = i / CV;
   const TileAt at = tile_at(geo, p.t);
+    const AxisBase by_ = axis_base(geo, at.y0, geo.H), bx_ = axis_base(geo, at.x0, geo.W);
   AxisPx ry[6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) ry[r] = axis_px(geo, at.y0 - 1 + r, geo.H);
+  for (int r = 0; r < 6; ++r) ry[r] = row_px(geo, at, by_, r - 1);
   p.ok = 0ull;
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
-    const AxisPx cx = axis_px(geo, at.x0 - 1 + c, geo.W);
+    const AxisPx cx = col_px(geo, bx_, c - 1);
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       bool ok;
-      const size_t px = tile_pixel(geo, at, ry[r], cx, ok);
+      const size_t px = tile_pixel(ry[r], cx, ok);
       const size_t o = px * C + p.cg * VW;
       p.v[r][c] = ldT<T>(x + o);
       if constexpr (RES) {
@@ -123,7 +124,7 @@ __device__ __forceinline__ void wbn_emit(const WbnPatch<RES, T>& p, const float*
 // against 8-14 for the plain transform plus 9-12 for the bn_act_fwd launch it absorbs.  (Requesting the thread's whole patch BEFORE the
 // slot fold, so that the fold's L2 round trip runs under the patch's latency, measured slower: 19.4 / 23.2 us against 17.4 / 22.4 -- 228
 // registers.)
-template <bool RES, typename T>
+template <bool RES, typename T, bool MOS>
 __global__ __launch_bounds__(256) void wino4_bn_input_transform_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                          const float* __restrict__ res, float* __restrict__ out,
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void wino4_bn_input_transform_kernel(const flo
                                                                          float eps, float momentum, float* __restrict__ save_mean,
                                                                          float* __restrict__ save_invstd, float* __restrict__ running_mean,
                                                                          float* __restrict__ running_var) {
+  if (!MOS) geo.G = 0;                                     // (compile-time in the plain form: csrc/wino4.hip wino4_input_transform_kernel)
   __shared__ float s_sc[kWbnMaxC], s_sh[kWbnMaxC];
   const long M = (long)geo.N * geo.H * geo.W;
   const size_t Tn = tile_count(geo), total = Tn * (C / VecWidth<T>::n);
@@ -167,12 +169,13 @@ __global__ __launch_bounds__(256) void wino4_bn_input_transform_kernel(const flo
 // red[kStatSlots][2][C] += (sum g, sum g xhat).  RES: the mask is (block output > 0); else z = x sc + sh > 0 recomputed by the forward's
 // expression (same bits: csrc/bn.hip masked_grad).  ADD: gadd = gradient that reached the block output through the identity branch.
 // ------------------------------------------------------------------------------------------------
-template <bool RES, bool ADD>
+template <bool RES, bool ADD, bool MOS>
 __global__ __launch_bounds__(256) void wino4_output_transform_bnred_kernel(const float* __restrict__ Mm, const float* __restrict__ x,
                                                                           const float* __restrict__ outp, const float* __restrict__ gadd,
                                                                           const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                           float* __restrict__ red, float* __restrict__ g, TileGeo geo, int C) {
+  if (!MOS) geo.G = 0;
   __shared__ float4 redl[2][16][16];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int k = blockIdx.y * 64 + cl * 4;
@@ -185,9 +188,10 @@ __global__ __launch_bounds__(256) void wino4_output_transform_bnred_kernel(const
     const V4 sh = V4{be.x - mu.x * sc.x, be.y - mu.y * sc.y, be.z - mu.z * sc.z, be.w - mu.w * sc.w};
     for (size_t t = (size_t)blockIdx.x * 16 + tl; t < T; t += (size_t)gridDim.x * 16) {
       const TileAt at = tile_at(geo, t);
+    const AxisBase by_ = axis_base(geo, at.y0, geo.H), bx_ = axis_base(geo, at.x0, geo.W);
       AxisPx cx[4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) cx[b] = axis_px(geo, at.x0 + b, geo.W);
+      for (int b = 0; b < 4; ++b) cx[b] = col_px(geo, bx_, b);
       V4 s[4][6];                                           // s = A^T m, built column by column
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
@@ -201,14 +205,14 @@ __global__ __launch_bounds__(256) void wino4_output_transform_bnred_kernel(const
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const AxisPx ry = axis_px(geo, at.y0 + a, geo.H);
+        const AxisPx ry = row_px(geo, at, by_, a);
         if (ry.ok) {                                        // (the row's operands are requested before its transform)
           V4 xv[4], ov[4], av[4];
           bool ok[4];
           size_t ob[4];
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            ob[b] = tile_pixel(geo, at, ry, cx[b], ok[b]) * C + k;
+            ob[b] = tile_pixel(ry, cx[b], ok[b]) * C + k;
             const size_t o = ob[b];
             xv[b] = ld4(x + o);
             ov[b] = RES ? ld4(outp + o) : zero4();
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void wino4_output_transform_bnred_kernel(const
 // the slots back zeroed).  dy = gamma invstd (g - mean g - xhat mean(g xhat)) -- bn_bwd_apply_kernel's expression -- goes straight into
 // V' = B^T dy B (backward-data) and Y' = A dy A^T (backward-weight).
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool MOS>
 __global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                                          const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                                          const float* __restrict__ gamma, float* __restrict__ red,
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const 
   // T = V4: thread = (tile, 4 channels); T = float: thread = (tile, channel) -- four times the threads with a quarter of the serial
   // work each (these launches are latency-bound: 130-250 workgroups of 36 loads + 72 stores per lane at T = V4)
   constexpr int VW = VecWidth<T>::n;
+  if (!MOS) geo.G = 0;
   __shared__ float s_mg[kWbnMaxC], s_mgx[kWbnMaxC];
   const float invM = 1.0f / (float)((long)geo.N * geo.H * geo.W);
   for (int c = threadIdx.x; c < K; c += 256) {
@@ -285,9 +290,10 @@ __global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const 
     const int cg = (int)(i % KV);
     const size_t t = i / KV;
     const TileAt at = tile_at(geo, t);
+    const AxisBase by_ = axis_base(geo, at.y0, geo.H), bx_ = axis_base(geo, at.x0, geo.W);
     AxisPx ry[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) ry[r] = axis_px(geo, at.y0 - 1 + r, geo.H);
+    for (int r = 0; r < 6; ++r) ry[r] = row_px(geo, at, by_, r - 1);
     const T mu = ldT<T>(save_mean + cg * VW), is = ldT<T>(save_invstd + cg * VW), ga = ldT<T>(gamma + cg * VW);
     const T k1 = is * ga;
     const T mg = ldT<T>(&s_mg[cg * VW]), mgx = ldT<T>(&s_mgx[cg * VW]);
@@ -295,12 +301,12 @@ __global__ __launch_bounds__(256) void wino4_bn_bwd_dual_transform_kernel(const 
     T ty[6][4];                                             // A dy (6 x 4) of the central block
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const AxisPx cx = axis_px(geo, at.x0 - 1 + c, geo.W);
+      const AxisPx cx = col_px(geo, bx_, c - 1);
       T col[6], yv[6];
       bool okr[6];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        const size_t o = tile_pixel(geo, at, ry[r], cx, okr[r]) * K + cg * VW;
+        const size_t o = tile_pixel(ry[r], cx, okr[r]) * K + cg * VW;
         col[r] = ldT<T>(g + o);
         yv[r] = ldT<T>(y + o);
       }
@@ -365,12 +371,14 @@ hipError_t launch_wino4_bn_input_transform(const float* x, float* stats, const f
   const size_t total = tile_count(geo) * (C / 4);
   static const int in_scalar = [] { const char* e = getenv("HIFIHR_WINO_IN_VEC"); return e ? atoi(e) : 0; }();   // 1: one channel per thread; 4: four (A/B)
   const bool scalar = in_scalar == 1;      // (measured: no gain -- 18.3 / 13.6 / 19.6 us against 16.2 / 13.1 / 17.2 at four channels per thread)
-#define HIFIHR_WBN_IN(R_, T_, TOT_)                                                                                                        \
-  hipLaunchKernelGGL((wino4_bn_input_transform_kernel<R_, T_>), dim3(wbn_grid(TOT_)), dim3(256), 0, st, x, stats, gamma, beta, res, out, V, geo, \
-                     C, eps, momentum, save_mean, save_invstd, running_mean, running_var)
-  if (res != nullptr) { if (scalar) HIFIHR_WBN_IN(true, float, total * 4); else HIFIHR_WBN_IN(true, V4, total); }
-  else { if (scalar) HIFIHR_WBN_IN(false, float, total * 4); else HIFIHR_WBN_IN(false, V4, total); }
+#define HIFIHR_WBN_IN2(R_, T_, M_, TOT_)                                                                                                       \
+  hipLaunchKernelGGL((wino4_bn_input_transform_kernel<R_, T_, M_>), dim3(wbn_grid(TOT_)), dim3(256), 0, st, x, stats, gamma, beta, res, out, V, \
+                     geo, C, eps, momentum, save_mean, save_invstd, running_mean, running_var)
+#define HIFIHR_WBN_IN(R_, T_, TOT_) { if (geo.G) HIFIHR_WBN_IN2(R_, T_, true, TOT_); else HIFIHR_WBN_IN2(R_, T_, false, TOT_); }
+  if (res != nullptr) { if (scalar) HIFIHR_WBN_IN(true, float, total * 4) else HIFIHR_WBN_IN(true, V4, total) }
+  else { if (scalar) HIFIHR_WBN_IN(false, float, total * 4) else HIFIHR_WBN_IN(false, V4, total) }
 #undef HIFIHR_WBN_IN
+#undef HIFIHR_WBN_IN2
   return hipGetLastError();
 }
 
@@ -383,15 +391,17 @@ hipError_t launch_wino4_output_transform_bnred(const float* Mm, const float* x, 
   size_t bx = (T + 15) / 16;
   if (bx > 1024) bx = 1024;
   const dim3 grid((unsigned)bx, (C + 63) / 64);
-#define HIFIHR_BNRED(R_, A_)                                                                                                               \
-  hipLaunchKernelGGL((wino4_output_transform_bnred_kernel<R_, A_>), grid, dim3(256), 0, st, Mm, x, outp, gadd, save_mean, save_invstd, gamma, \
+#define HIFIHR_BNRED2(R_, A_, M_)                                                                                                          \
+  hipLaunchKernelGGL((wino4_output_transform_bnred_kernel<R_, A_, M_>), grid, dim3(256), 0, st, Mm, x, outp, gadd, save_mean, save_invstd, gamma, \
                      beta, red, g, geo, C)
+#define HIFIHR_BNRED(R_, A_) { if (geo.G) HIFIHR_BNRED2(R_, A_, true); else HIFIHR_BNRED2(R_, A_, false); }
   if (outp != nullptr) {
-    if (gadd != nullptr) HIFIHR_BNRED(true, true); else HIFIHR_BNRED(true, false);
+    if (gadd != nullptr) HIFIHR_BNRED(true, true) else HIFIHR_BNRED(true, false)
   } else {
-    if (gadd != nullptr) HIFIHR_BNRED(false, true); else HIFIHR_BNRED(false, false);
+    if (gadd != nullptr) HIFIHR_BNRED(false, true) else HIFIHR_BNRED(false, false)
   }
 #undef HIFIHR_BNRED
+#undef HIFIHR_BNRED2
   return hipGetLastError();
 }
 
@@ -401,12 +411,12 @@ hipError_t launch_wino4_bn_bwd_dual_transform(const float* g, const float* y, co
   if (!wino4_bn_supported(K)) return hipErrorInvalidValue;
   const TileGeo geo = wino4_geo(N, H, W);
   const size_t total = tile_count(geo) * (K / 4);
-  if (wbn_scalar(total))
-    hipLaunchKernelGGL(wino4_bn_bwd_dual_transform_kernel<float>, dim3(wbn_grid(total * 4)), dim3(256), 0, st, g, y, save_mean, save_invstd, gamma,
-                       red, V, Y, geo, K, dgamma_acc, dbeta_acc);
-  else
-    hipLaunchKernelGGL(wino4_bn_bwd_dual_transform_kernel<V4>, dim3(wbn_grid(total)), dim3(256), 0, st, g, y, save_mean, save_invstd, gamma, red,
-                       V, Y, geo, K, dgamma_acc, dbeta_acc);
+#define HIFIHR_WBN_DUAL(T_, M_, TOT_)                                                                                                       \
+  hipLaunchKernelGGL((wino4_bn_bwd_dual_transform_kernel<T_, M_>), dim3(wbn_grid(TOT_)), dim3(256), 0, st, g, y, save_mean, save_invstd, gamma, \
+                     red, V, Y, geo, K, dgamma_acc, dbeta_acc)
+  if (wbn_scalar(total)) { if (geo.G) HIFIHR_WBN_DUAL(float, true, total * 4); else HIFIHR_WBN_DUAL(float, false, total * 4); }
+  else { if (geo.G) HIFIHR_WBN_DUAL(V4, true, total); else HIFIHR_WBN_DUAL(V4, false, total); }
+#undef HIFIHR_WBN_DUAL
   return hipGetLastError();
 }
 

@@ -40,18 +40,32 @@ __device__ __forceinline__ TileAt tile_at(const TileGeo& g, size_t t) {
   const int tw = (int)(t % g.TW), th = (int)((t / g.TW) % g.TH), q = (int)(t / ((size_t)g.TW * g.TH));
   return TileAt{g.G ? q * g.G * g.G : q, 4 * th, 4 * tw};
 }
-struct AxisPx { bool ok; int img, p; };                     // along one axis: inside an image?  which image of the mosaic row / column, coordinate in it
-__device__ __forceinline__ AxisPx axis_px(const TileGeo& g, int m, int L) {
-  if (!g.G) return AxisPx{m >= 0 && m < L, 0, m};
-  if (m < 0) return AxisPx{false, 0, 0};
-  const int i = m / (L + 1), p = m - i * (L + 1);
-  return AxisPx{p < L && i < g.G, i, p};
+// A pixel of the patch = (row part) + (column part): ok flags and pixel-index offsets prepared ONCE per tile row / column (one integer
+// division per axis and tile in the mosaic form, none in the plain form), so that the 36 pixels of a patch cost one addition and one AND
+// each.  (The first version resolved every pixel through the mosaic arithmetic: 1-3 us per transform launch, more than the mosaic saved.)
+struct AxisPx { bool ok; int off; };                        // rows: ((n0 + img G) H + y) W;  columns: img H W + x   (pixel index = row.off + col.off)
+struct AxisBase { int i0, p0; };                            // image index and in-image coordinate of the tile's first OUTPUT row / column
+__device__ __forceinline__ AxisBase axis_base(const TileGeo& g, int m0, int L) {
+  if (!g.G) return AxisBase{0, m0};
+  const int i = m0 / (L + 1);
+  return AxisBase{i, m0 - i * (L + 1)};
 }
-// pixel index (n H + y) W + x of the pixel at (row r, column c) of the axes, 0 when it is not a pixel of an image (ok = false)
-__device__ __forceinline__ size_t tile_pixel(const TileGeo& g, const TileAt& a, const AxisPx& r, const AxisPx& c, bool& ok) {
-  const int n = a.n + (g.G ? r.img * g.G + c.img : 0);
-  ok = r.ok && c.ok && n < g.N;                             // (n >= N: the padding tiles behind the last mosaic)
-  return ok ? ((size_t)n * g.H + r.p) * g.W + c.p : (size_t)0;
+// d places after the tile's first row (d = -1 .. 4: the 6-wide input patch; 0 .. 3: the tile's outputs)
+__device__ __forceinline__ AxisPx row_px(const TileGeo& g, const TileAt& a, const AxisBase& b, int d) {
+  int p = b.p0 + d, i = b.i0;
+  if (g.G && p > g.H) { p -= g.H + 1; ++i; }                // past this image's zero line: the next image (d <= 4 < H + 1: at most once)
+  const bool ok = p >= 0 && p < g.H && i < (g.G ? g.G : 1) && a.n < g.N;     // (a.n >= N: the padding tiles behind the last mosaic)
+  return AxisPx{ok, ok ? ((a.n + i * g.G) * g.H + p) * g.W : 0};
+}
+__device__ __forceinline__ AxisPx col_px(const TileGeo& g, const AxisBase& b, int d) {
+  int p = b.p0 + d, i = b.i0;
+  if (g.G && p > g.W) { p -= g.W + 1; ++i; }
+  const bool ok = p >= 0 && p < g.W && i < (g.G ? g.G : 1);
+  return AxisPx{ok, ok ? i * g.H * g.W + p : 0};
+}
+__device__ __forceinline__ size_t tile_pixel(const AxisPx& r, const AxisPx& c, bool& ok) {
+  ok = r.ok && c.ok;
+  return ok ? (size_t)(r.off + c.off) : (size_t)0;
 }
 __device__ __forceinline__ V4 operator+(const V4& a, const V4& b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 __device__ __forceinline__ V4 operator-(const V4& a, const V4& b) { return V4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
