@@ -44,11 +44,19 @@ __device__ __forceinline__ void slot_sum2_n(const float* __restrict__ buf, int C
 #pragma unroll
   for (int sl = 0; sl < NS; ++sl) { s0 += a[sl]; s1 += b[sl]; }
 }
+// One case per slot count, each behind a compiler barrier: without it the optimiser hoists the loads of the slots all cases share (0 .. 7)
+// in front of the branch and the 32-slot case -- the 64- / 128-channel layers -- waits for them before it issues the other 48: two to
+// three memory latencies instead of one, +2.3 us per apply launch (seen in the ISA: 16 + 16 + 48 loads per wait instead of 64).
+#if defined(HIFIHR_HOSTSIM)
+#define HIFIHR_NO_HOIST() ((void)0)
+#else
+#define HIFIHR_NO_HOIST() asm volatile("" ::: "memory")
+#endif
 __device__ __forceinline__ void slot_sum2(const float* __restrict__ buf, int C, int c, float& s0, float& s1) {
   const int ns = stat_slots_used(C);                      // (uniform)
-  if (ns == 8) slot_sum2_n<8>(buf, C, c, s0, s1);
-  else if (ns == 16) slot_sum2_n<16>(buf, C, c, s0, s1);
-  else slot_sum2_n<kStatSlots>(buf, C, c, s0, s1);
+  if (ns == kStatSlots) { HIFIHR_NO_HOIST(); slot_sum2_n<kStatSlots>(buf, C, c, s0, s1); }
+  else if (ns == 16) { HIFIHR_NO_HOIST(); slot_sum2_n<16>(buf, C, c, s0, s1); }
+  else { HIFIHR_NO_HOIST(); slot_sum2_n<8>(buf, C, c, s0, s1); }
 }
 
 // FORWARD statistics (double slots): mean and biased variance of channel c from the slot partials, all loads in flight
@@ -65,9 +73,9 @@ __device__ __forceinline__ void slot_mean_var(const float* __restrict__ stats, i
   const double* buf = reinterpret_cast<const double*>(stats);
   double s0, s1;
   const int ns = stat_slots_used(C);                      // (uniform)
-  if (ns == 8) slot_sums_fwd_n<8>(buf, C, c, s0, s1);
-  else if (ns == 16) slot_sums_fwd_n<16>(buf, C, c, s0, s1);
-  else slot_sums_fwd_n<kStatSlots>(buf, C, c, s0, s1);
+  if (ns == kStatSlots) { HIFIHR_NO_HOIST(); slot_sums_fwd_n<kStatSlots>(buf, C, c, s0, s1); }
+  else if (ns == 16) { HIFIHR_NO_HOIST(); slot_sums_fwd_n<16>(buf, C, c, s0, s1); }
+  else { HIFIHR_NO_HOIST(); slot_sums_fwd_n<8>(buf, C, c, s0, s1); }
   const double m = s0 / (double)M;
   const double v = s1 / (double)M - m * m;           // fp64: the cancellation costs 2^-53 mean^2 / var
   mu = (float)m;

@@ -36,13 +36,66 @@ __device__ __forceinline__ void flush_face(BwdAcc<HT>& A, float* __restrict__ gg
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int s = acc_slot(A, idx[k]);
-    float* dst = s >= 0 ? A.rec[s] : gglobal + (size_t)idx[k] * 12;
+    if (s >= 0) {                                  // (two bodies: an address that may be LDS or global compiles to FLAT atomics)
 #pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      const float v = acc[k * 12 + c];
-      if (v != 0.f) atomicAdd(dst + c, v);        // (all of these LDS atomics together: ~50 of the launch's ~140 us -- measured by compiling them out)
+      for (int c = 0; c < 12; ++c) {
+        const float v = acc[k * 12 + c];
+        if (v != 0.f) atomicAdd(&A.rec[s][c], v);  // (all of these LDS atomics together: ~50 of the launch's ~140 us -- measured by compiling them out)
+      }
+    } else {
+      float* dst = gglobal + (size_t)idx[k] * 12;
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        const float v = acc[k * 12 + c];
+        if (v != 0.f) atomicAdd(dst + c, v);
+      }
     }
   }
+}
+
+// TexturesUV: d loss / d texel.  Round 3 sent every sample's 4 texels x 3 channels to the texture gradient as global float atomics --
+// 12 per sample, 78 M per launch at B = 48 on a 64 x 64 map where ~30 samples of an image meet in every texel: 1.95 ms, 0.008 of the HBM
+// roof.  Now (a) a lane keeps the texel QUAD of its current sample in 12 registers and adds to it while consecutive samples fall into the
+// same quad (a coarse map: most of a pixel's AA x AA samples), (b) a quad that is left goes to a per-tile open-addressing table in LDS
+// keyed by the texel index (ds_add_f32; the table full: global atomics for that texel), (c) the table is flushed once per tile.
+template <int TT>
+struct TexAcc {
+  int keys[TT];
+  float rec[TT][3];
+};
+template <int TT>
+__device__ __forceinline__ int tex_slot(TexAcc<TT>& A, int t) {
+  unsigned s = ((unsigned)t * 2654435761u) >> 14;
+#pragma unroll 1
+  for (int probe = 0; probe < 16; ++probe) {
+    s &= (unsigned)(TT - 1);
+    const int old = atomicCAS(&A.keys[s], -1, t);
+    if (old == -1 || old == t) return (int)s;
+    ++s;
+  }
+  return -1;
+}
+template <int TT>
+__device__ __forceinline__ void flush_texel(TexAcc<TT>& A, float* __restrict__ gm, int texel, const float* v) {
+  if (v[0] == 0.f && v[1] == 0.f && v[2] == 0.f) return;
+  const int s = tex_slot(A, texel);
+  if (s >= 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) atomicAdd(&A.rec[s][c], v[c]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) atomicAdd(gm + (size_t)texel * 3 + c, v[c]);
+  }
+}
+// the quad (x0, x1, y0, y1) a lane has been adding to: its four texels to the table
+template <int TT>
+__device__ __forceinline__ void flush_quad(TexAcc<TT>& A, float* __restrict__ gm, int TW, const int* qd, float* tacc) {
+  flush_texel(A, gm, qd[2] * TW + qd[0], tacc);
+  flush_texel(A, gm, qd[2] * TW + qd[1], tacc + 3);
+  flush_texel(A, gm, qd[3] * TW + qd[0], tacc + 6);
+  flush_texel(A, gm, qd[3] * TW + qd[1], tacc + 9);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) tacc[k] = 0.f;
 }
 
 // 16 x 16-pixel tiles, one pixel per lane (its AA x AA samples in turn).  Measured alternative (round 3): 8 x 8-pixel tiles with the three
@@ -62,7 +115,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
                                                         float* __restrict__ glight_color, float* __restrict__ glight_dir,
                                                         TexUvDev tuv) {
   constexpr int HT = 512;                                  // hash slots: > 2x the distinct vertices of a typical tile (BwdAcc)
+  constexpr int TT = UV ? 2048 : 1;                       // texel slots (TexAcc; vertex-colour instantiations carry a dummy)
   __shared__ BwdAcc<HT> A;
+  __shared__ TexAcc<TT> TA;
   __shared__ float red[4 * 6];
   __shared__ int any_hit[4];
   const int b = blockIdx.z;
@@ -87,6 +142,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
   if (!(any_hit[0] | any_hit[1] | any_hit[2] | any_hit[3])) return;
   for (int e = tid; e < HT; e += 256) A.keys[e] = -1;
   for (int e = tid; e < HT * 12; e += 256) (&A.rec[0][0])[e] = 0.f;
+  if constexpr (UV) {
+    for (int e = tid; e < TT; e += 256) TA.keys[e] = -1;
+    for (int e = tid; e < TT * 3; e += 256) (&TA.rec[0][0])[e] = 0.f;
+  }
   __syncthreads();
   float glc[3] = {0.f, 0.f, 0.f}, gl[3] = {0.f, 0.f, 0.f};
   LightDir Ld;
@@ -98,6 +157,11 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
   float* gv = gvrec + vo * 12;                               // this image's global records (table overflow, final flush)
   float acc[36];
   int cur = -1, cidx[3] = {0, 0, 0};
+  float tacc[12];                                           // (UV) gradient of the texel quad qd = (x0, x1, y0, y1) held by this lane
+  int qd[4] = {-1, -1, -1, -1};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) tacc[k] = 0.f;
+  float* const gm = (UV && tuv.gmaps != nullptr) ? tuv.gmaps + (size_t)b * tuv.TH * tuv.TW * 3 : nullptr;
   if (live) {
     const size_t plane = (size_t)H * H;
     const float* g = grad_rgba + (size_t)b * 4 * plane + (size_t)py * H + px;
@@ -106,6 +170,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
     FaceXYZ fc;
     fc.x0 = fc.y0 = fc.z0 = fc.x1 = fc.y1 = fc.z1 = fc.x2 = fc.y2 = fc.z2 = 0.f;
     float pos[3][3] = {}, nrm[3][3] = {}, col[3][3] = {};
+    float fu[3] = {0.f, 0.f, 0.f}, fv[3] = {0.f, 0.f, 0.f};  // (UV) the face's three texture coordinates: loaded with the face
 #pragma unroll
     for (int i = 0; i < AA; ++i) {
       const float syi = pix_to_ndc(S - 1 - (py * AA + i), S);
@@ -133,6 +198,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
             col[k][0] = t.x; col[k][1] = t.y; col[k][2] = t.z;
             if constexpr (UV) { col[k][0] = 0.f; col[k][1] = 0.f; col[k][2] = 0.f; }          // TexturesUV: the colour is no function of these
           }
+          if constexpr (UV) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const int iu = tuv.faces_uvs[3 * f + k]; fu[k] = tuv.verts_uvs[2 * iu]; fv[k] = tuv.verts_uvs[2 * iu + 1]; }
+          }
         }
         float bary[3];
         bary_of(fc, sxj, syi, bary);
@@ -143,11 +212,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
           N[c3] = bary[0] * nrm[0][c3] + bary[1] * nrm[1][c3] + bary[2] * nrm[2][c3];
           T[c3] = bary[0] * col[0][c3] + bary[1] * col[1][c3] + bary[2] * col[2][c3];
         }
-        float fu[3] = {0.f, 0.f, 0.f}, fv[3] = {0.f, 0.f, 0.f}, dix[3], diy[3];
+        float dix[3], diy[3];
         UvSample q{};
         if constexpr (UV) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) { const int iu = tuv.faces_uvs[3 * f + k]; fu[k] = tuv.verts_uvs[2 * iu]; fv[k] = tuv.verts_uvs[2 * iu + 1]; }
           const float u = bary[0] * fu[0] + bary[1] * fu[1] + bary[2] * fu[2], v = bary[0] * fv[0] + bary[1] * fv[1] + bary[2] * fv[2];
           q = uv_sample(u, v, tuv.TH, tuv.TW);
           uv_fetch(tuv, b, q, T, dix, diy);
@@ -158,13 +225,18 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
         if constexpr (UV) {
           float gix = 0.f, giy = 0.f;
           const float w00 = (1.f - q.wx) * (1.f - q.wy), w01 = q.wx * (1.f - q.wy), w10 = (1.f - q.wx) * q.wy, w11 = q.wx * q.wy;
-          float* gm = tuv.gmaps != nullptr ? tuv.gmaps + (size_t)b * tuv.TH * tuv.TW * 3 : nullptr;
+          if (gm != nullptr) {
+            if (q.x0 != qd[0] || q.y0 != qd[2] || q.x1 != qd[1] || q.y1 != qd[3]) {
+              if (qd[0] >= 0) flush_quad(TA, gm, tuv.TW, qd, tacc);
+              qd[0] = q.x0; qd[1] = q.x1; qd[2] = q.y0; qd[3] = q.y1;
+            }
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) {
+              tacc[c3] += gT[c3] * w00; tacc[3 + c3] += gT[c3] * w01; tacc[6 + c3] += gT[c3] * w10; tacc[9 + c3] += gT[c3] * w11;
+            }
+          }
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) {
-            if (gm != nullptr && gT[c3] != 0.f) {
-              atomicAdd(gm + ((size_t)q.y0 * tuv.TW + q.x0) * 3 + c3, gT[c3] * w00); atomicAdd(gm + ((size_t)q.y0 * tuv.TW + q.x1) * 3 + c3, gT[c3] * w01);
-              atomicAdd(gm + ((size_t)q.y1 * tuv.TW + q.x0) * 3 + c3, gT[c3] * w10); atomicAdd(gm + ((size_t)q.y1 * tuv.TW + q.x1) * 3 + c3, gT[c3] * w11);
-            }
             gix += gT[c3] * dix[c3]; giy += gT[c3] * diy[c3];
           }
           guv[0] = q.in_x ? gix * (float)(tuv.TW - 1) : 0.f;     // d ix / d u = TW - 1; zero where grid_sample clipped the coordinate
@@ -214,7 +286,21 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
     }
     if (head && cur >= 0) flush_face(A, gv, cidx, acc);
   }
+  if constexpr (UV) {
+    if (gm != nullptr && qd[0] >= 0) flush_quad(TA, gm, tuv.TW, qd, tacc);
+  }
   __syncthreads();
+  if constexpr (UV) {
+    if (gm != nullptr) {
+      for (int e = tid; e < TT * 3; e += 256) {
+        const int key = TA.keys[e / 3];
+        if (key >= 0) {
+          const float v = (&TA.rec[0][0])[e];
+          if (v != 0.f) atomicAdd(gm + (size_t)key * 3 + (e % 3), v);
+        }
+      }
+    }
+  }
   for (int e = tid; e < HT * 12; e += 256) {
     const int key = A.keys[e / 12];
     if (key >= 0) {

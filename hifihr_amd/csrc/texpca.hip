@@ -45,13 +45,17 @@ __global__ __launch_bounds__(256) void texpca_fwd_kernel(const float* __restrict
   }
 }
 
-// dcoef[B][K] (zero on entry) += sum_n g[b][n] basis[k][n]
+// dcoef[B][K] (zero on entry) += sum_n g[b][n] basis[k][n].  grid = (pieces of n, batch tiles): a workgroup takes one piece of n for the
+// images of its batch tile in turn, so a small texture (64 x 64 x 3: 12 pieces) still fills the chip -- round 3 walked the whole batch
+// serially inside 12 workgroups, 374 us at B = 48 -- and a large one (1024^2 x 3) streams its basis from HBM once per batch tile.
 __global__ __launch_bounds__(256) void texpca_bwd_kernel(const float* __restrict__ g, const float* __restrict__ basis, int B, int K, long n,
                                                         float* __restrict__ dcoef) {
   __shared__ float red[4][kTexMaxK];
   const long n4 = n / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b = 0; b < B; ++b) {
+  const int bt = (B + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int b_lo = (int)blockIdx.y * bt, b_hi = min(B, b_lo + bt);
+  for (int b = b_lo; b < b_hi; ++b) {
     float part[kTexMaxK];
 #pragma unroll
     for (int k = 0; k < kTexMaxK; ++k) part[k] = 0.f;
@@ -91,7 +95,11 @@ hipError_t launch_texpca_bwd(const float* g, const float* basis, int B, int K, l
   if (K < 1 || K > kTexMaxK || n < 4 || n % 4 != 0 || B < 1) return hipErrorInvalidValue;
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 512) blocks = 512;           // (workgroups x B x K) float atomics at the end: keep them few
-  hipLaunchKernelGGL(texpca_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, basis, B, K, n, dcoef_zeroed);
+  // batch tiles: one image per workgroup while pieces x B stays a few waves of the chip (the basis of such a texture sits in L2 / the
+  // Infinity Cache); larger textures take tiles of images so that the basis crosses the fabric B / tile times
+  long tiles = B;
+  while (tiles > 1 && blocks * tiles > 4096) tiles = (tiles + 1) / 2;
+  hipLaunchKernelGGL(texpca_bwd_kernel, dim3((unsigned)blocks, (unsigned)tiles), dim3(256), 0, st, g, basis, B, K, n, dcoef_zeroed);
   return hipGetLastError();
 }
 
