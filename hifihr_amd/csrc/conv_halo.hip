@@ -894,23 +894,28 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_wgrad_kernel(HaloWgr
     }
 }
 
-// dw[k][tap][c] += sum over the slabs, in slab order
+// dw[k][tap][c] += sum over the slabs, in a fixed order (bit-reproducible).  A workgroup takes 64 gradient elements; wave w sums slabs
+// 64 q + 16 w .. + 15 (q = 0, 1, ..) with its 16 loads of a trip in flight, the four waves' partial sums meet in LDS.  (Round 3: one
+// thread per element walking every slab, 32 loads in flight -- 144 workgroups, 8 dependent trips for 256 slabs: 10 us for 38 MB.)
 __global__ __launch_bounds__(256) void conv_halo_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dw) {
-  const int i = blockIdx.x * 256 + threadIdx.x;              // index into a slab: (tap * 64 + k) * 64 + c
-  if (i >= kTaps * 64 * 64) return;
-  // 32 independent loads in flight per lane (the slabs are 147 KB apart: with 8 the launch was latency-bound at ~20 us for 38 MB)
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;                      // index into a slab: (tap * 64 + k) * 64 + c
+  constexpr size_t kSlab = (size_t)kTaps * 64 * 64;
   float s = 0.f;
-  int z = 0;
-  for (; z + 32 <= nslab; z += 32) {
-    float v[32];
+  for (int z0 = 16 * w; z0 < nslab; z0 += 64) {
+    float v[16];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) v[u] = slabs[(size_t)(z + u) * (kTaps * 64 * 64) + i];
+    for (int u = 0; u < 16; ++u) v[u] = (z0 + u < nslab) ? slabs[(size_t)(z0 + u) * kSlab + i] : 0.f;
 #pragma unroll
-    for (int u = 0; u < 32; ++u) s += v[u];
+    for (int u = 0; u < 16; ++u) s += v[u];
   }
-  for (; z < nslab; ++z) s += slabs[(size_t)z * (kTaps * 64 * 64) + i];
-  const int c = i & 63, k = (i >> 6) & 63, tp = i >> 12;
-  dw[((size_t)k * kTaps + tp) * 64 + c] += s;
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0) {
+    const int c = i & 63, k = (i >> 6) & 63, tp = i >> 12;
+    dw[((size_t)k * kTaps + tp) * 64 + c] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1285,19 +1290,22 @@ __global__ __launch_bounds__(512) void conv_stem_wgrad_kernel(StemWgradArgs a) {
 // arrives here as NHWC4 with a zero fourth plane -- the gradient lands in the parameter's own layout, no padded temporary
 __global__ __launch_bounds__(256) void conv_stem_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dw,
                                                                     int dwC) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 64 * 196 || (i & 3) >= dwC) return;
+  // (the slabs split over the four waves of a 64-element workgroup, as conv_halo_wgrad_reduce_kernel: 49 workgroups walked 256 slabs
+  //  in 8 dependent trips, 9 us for 12.8 MB)
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   float s = 0.f;
-  int z = 0;
-  for (; z + 32 <= nslab; z += 32) {
-    float v[32];
+  for (int z0 = 16 * w; z0 < nslab; z0 += 64) {
+    float v[16];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) v[u] = slabs[(size_t)(z + u) * (64 * 196) + i];
+    for (int u = 0; u < 16; ++u) v[u] = (z0 + u < nslab) ? slabs[(size_t)(z0 + u) * (64 * 196) + i] : 0.f;
 #pragma unroll
-    for (int u = 0; u < 32; ++u) s += v[u];
+    for (int u = 0; u < 16; ++u) s += v[u];
   }
-  for (; z < nslab; ++z) s += slabs[(size_t)z * (64 * 196) + i];
-  dw[(i >> 2) * dwC + (i & 3)] += s;
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && (i & 3) < dwC) dw[(i >> 2) * dwC + (i & 3)] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 #if defined(HIFIHR_HALO_STAMP)
@@ -1398,7 +1406,7 @@ hipError_t launch_conv_stem_wgrad(const ConvGeom& g, const float* x, const float
   a.slabs = slabs != nullptr ? slabs : halo_wgrad_scratch(st, (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float));      // (the pool's buffers: 9 x 64 x 64 >= 64 x 196 floats each)
   if (a.slabs == nullptr) return hipErrorNotReady;
   hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(G), dim3(512), 0, st, a);
-  hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3(64 * 196 / 256), dim3(256), 0, st, a.slabs, G, dw, dw_channels);
+  hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3(64 * 196 / 64), dim3(256), 0, st, a.slabs, G, dw, dw_channels);
   return hipGetLastError();
 }
 
@@ -1424,7 +1432,7 @@ hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float
   a.slabs = slabs != nullptr ? slabs : halo_wgrad_scratch(st, (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float));
   if (a.slabs == nullptr) return hipErrorNotReady;
   hipLaunchKernelGGL(conv_halo_wgrad_kernel, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
-  hipLaunchKernelGGL(conv_halo_wgrad_reduce_kernel, dim3(kTaps * 64 * 64 / 256), dim3(256), 0, st, a.slabs, G, dw);
+  hipLaunchKernelGGL(conv_halo_wgrad_reduce_kernel, dim3(kTaps * 64 * 64 / 64), dim3(256), 0, st, a.slabs, G, dw);
   return hipGetLastError();
 }
 

@@ -251,6 +251,60 @@ __global__ __launch_bounds__(256) void wino4_dw_transform_parts_kernel(const flo
   }
 }
 
+// The same transform for SMALL layers (128 x 128 channels: 4 096 items = 16 workgroups of the kernel above, every thread walking 36
+// positions x `parts` slabs as 6 x parts dependent load batches: 18 us of latency for 17 MB, three times per step).  Wide form: a
+// workgroup is 32 items x 6 position columns; thread (item, jc) sums column jc over the slabs with its loads in flight together, applies
+// G^T down the column and leaves the three values in LDS; threads jc < 3 then finish row jc of the item.  Slabs are still added in slab
+// order (bit-reproducible).
+__global__ __launch_bounds__(192) void wino4_dw_transform_parts_wide_kernel(const float* __restrict__ dU, int parts, float* __restrict__ dw, int K, int C) {
+  __shared__ V4 s_t[32][3][6];
+  const int C4 = C / 4;
+  const size_t total = (size_t)K * C4, plane = (size_t)K * C, slab = 36 * plane;
+  const int il = threadIdx.x & 31, jc = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + il;
+  const bool live = i < total;
+  const int cg = live ? (int)(i % C4) : 0, k = live ? (int)(i / C4) : 0;
+  const float* p = dU + (size_t)k * C + cg * 4;
+  float* const out = dw + (size_t)k * 9 * C + cg * 4;
+  V4 old[3];
+  if (live && jc < 3) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) old[c] = ld4(out + (size_t)(jc * 3 + c) * C);
+  }
+  if (live) {
+    V4 col[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) col[r] = ld4(p + (size_t)(r * 6 + jc) * plane);
+    int z = 1;
+    for (; z + 1 < parts; z += 2) {                           // two slabs per trip: twelve loads in flight
+      V4 a[6], b[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        a[r] = ld4(p + (size_t)z * slab + (size_t)(r * 6 + jc) * plane);
+        b[r] = ld4(p + (size_t)(z + 1) * slab + (size_t)(r * 6 + jc) * plane);
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) col[r] = (col[r] + a[r]) + b[r];
+    }
+    for (; z < parts; ++z) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) col[r] = col[r] + ld4(p + (size_t)z * slab + (size_t)(r * 6 + jc) * plane);
+    }
+    V4 o[3];
+    gt6(col, o);
+    s_t[il][0][jc] = o[0]; s_t[il][1][jc] = o[1]; s_t[il][2][jc] = o[2];
+  }
+  __syncthreads();
+  if (live && jc < 3) {
+    V4 t[6], o[3];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) t[c] = s_t[il][jc][c];
+    gt6(t, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st4(out + (size_t)(jc * 3 + c) * C, old[c] + o[c]);
+  }
+}
+
 static unsigned wino4_grid(size_t total) {
   size_t b = (total + 255) / 256;
   if (b > 4096) b = 4096;
@@ -311,7 +365,12 @@ hipError_t launch_wino4_dy_transform(const float* dy, float* Y, int N, int H, in
 
 hipError_t launch_wino4_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st) {
   if (C % 4 != 0 || parts < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(wino4_dw_transform_parts_kernel, dim3(wino4_grid((size_t)K * (C / 4))), dim3(256), 0, st, dU_parts, parts, dw, K, C);
+  const size_t total = (size_t)K * (C / 4);
+  static const int wide_on = [] { const char* e = getenv("HIFIHR_WINO_DW_WIDE"); return e ? atoi(e) : 1; }();
+  if (wide_on && total <= 8192)
+    hipLaunchKernelGGL(wino4_dw_transform_parts_wide_kernel, dim3((unsigned)((total + 31) / 32)), dim3(192), 0, st, dU_parts, parts, dw, K, C);
+  else
+    hipLaunchKernelGGL(wino4_dw_transform_parts_kernel, dim3(wino4_grid(total)), dim3(256), 0, st, dU_parts, parts, dw, K, C);
   return hipGetLastError();
 }
 
