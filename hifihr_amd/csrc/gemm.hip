@@ -735,10 +735,6 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void bgemm_nt_sk_kernel(BgemmArgs
 // only: nothing is exchanged between workgroups and nothing needs a workspace.  LDS: 4 stages x (A 128x32 + B 128x32) = 128 KB.
 // ------------------------------------------------------------------------------------------------
 static int gemm_cus();
-static int gemm_defer() {
-  static const int on = [] { const char* e = getenv("HIFIHR_GEMM_DEFER"); return e ? atoi(e) : 1; }();
-  return on;
-}
 struct RowsTile { int p, nt, m0, rows; };
 __device__ __forceinline__ RowsTile rows_tile_at(const BgemmArgs& a, long cur, long end) {
   const long col = cur / a.M;                                // (p, nt) pair
@@ -887,28 +883,6 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
       }
     sn = 0;
   };
-  // DEFERRED OUTPUT (round 4).  A finished tile is not stored where it ends -- there the four MFMA waves of every workgroup issued their
-  // 16 stores back to back with the matrix pipe idle (3 000 of a 128-channel tile's 19 000 cycles: a wave gets one vector-memory
-  // instruction accepted per 200-400 cycles) -- but kept in `pend` and stored a few rows per chunk from inside the NEXT tile's chunk
-  // loop, between MFMA blocks that are already queued; the share's last tile is flushed after the loop.  The MFMA waves never wait on
-  // vmcnt (their operands come through LDS), so the stores retire behind them.
-  // Registers: acc (64) + the double-buffered fragments (80) leave room for HALF a tile: row blocks kPD .. 7 are deferred, 0 .. kPD - 1
-  // are stored at the tile's end as before (all eight in `pend`: 256 registers and 80 spilled).
-  constexpr int kPD = 4;
-  floatx4 pend[2][8 - kPD];
-  float* pend_row = nullptr;                                 // lane's address of (row r, first column block) of the pending tile, or null
-  int pend_rows = 0, pend_col0 = 0;
-  auto put_rows = [&](int j_lo, int j_hi) {                  // row blocks [j_lo, j_hi) of the pending tile (uniform bounds)
-#pragma unroll
-    for (int j = kPD; j < 8; ++j) {
-      if (j >= j_lo && j < j_hi && 16 * j + r < pend_rows) {
-        float* row = pend_row + (size_t)(16 * j) * a.ldc;
-        if (!RAGGED || pend_col0 < a.N) *reinterpret_cast<float4*>(row) = make_float4(pend[0][j - kPD][0], pend[0][j - kPD][1], pend[0][j - kPD][2], pend[0][j - kPD][3]);
-        if (!RAGGED || pend_col0 + 16 < a.N) *reinterpret_cast<float4*>(row + 16) = make_float4(pend[1][j - kPD][0], pend[1][j - kPD][1], pend[1][j - kPD][2], pend[1][j - kPD][3]);
-      }
-    }
-  };
-  const int put_per = (8 - kPD + nch - 1) / nch;             // row blocks per chunk: the pending half is out after min(nch, 8 - kPD) chunks
   auto run_tile = [&](auto nbc, const RowsTile& t) {
     constexpr int NB = decltype(nbc)::value;
     float fm[2][NB][4], fn[2][2][4];
@@ -961,10 +935,6 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
     const unsigned long long l0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int c = 0; c < nch; ++c, ++gc) {
-      if (pend_row != nullptr && kPD + c * put_per < 8) {    // (uniform) the previous tile's deferred rows, a few row blocks per chunk
-        put_rows(kPD + c * put_per, kPD + (c + 1) * put_per);
-        HIFIHR_PIN();
-      }
       read_half(gc, 1, 1);
       mfma_half(0);
       interleave();
@@ -987,25 +957,16 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
     const unsigned long long l1 = __builtin_amdgcn_s_memtime();
     st_loop += l1 - l0; st_real += __builtin_amdgcn_s_memrealtime() - r0;
 #endif
-    // register e of lane (r, g) of block (i, j) = C[m0 + 16 j + r][128 nt + 32 wave + 16 i + 4 g + e]: handed to `pend` (stored from the
-    // next tile's chunk loop, or after the share's last tile)
-    pend_row = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g + (size_t)(t.m0 + r) * a.ldc;
-    pend_rows = t.rows;
-    pend_col0 = t.nt * 128 + 32 * wave + 4 * g;              // (RAGGED: the lane's column blocks col0 .. + 3 and col0 + 16 .. + 19 against N)
-#pragma unroll
-    for (int j = kPD; j < NB; ++j) { pend[0][j - kPD] = acc[0][j]; pend[1][j - kPD] = acc[1][j]; }
-    if (NB <= kPD) pend_row = nullptr;                        // (a short tile: nothing deferred)
-    else if (!a.defer) { put_rows(kPD, 8); pend_row = nullptr; }     // (uniform; the A/B switch)
+    // register e of lane (r, g) of block (i, j) = C[m0 + 16 j + r][128 nt + 32 wave + 16 i + 4 g + e]
+    float* C = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
+    const int col0 = t.nt * 128 + 32 * wave + 4 * g;         // (RAGGED: the lane's column blocks col0 .. + 3 and col0 + 16 .. + 19 against N)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int m = 16 * j + r;
       if (m < t.rows) {
-        if (j < kPD) {
-          float* row = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g + (size_t)(t.m0 + m) * a.ldc;
-          const int col0 = t.nt * 128 + 32 * wave + 4 * g;
-          if (!RAGGED || col0 < a.N) *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
-          if (!RAGGED || col0 + 16 < a.N) *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
-        }
+        float* row = C + (size_t)(t.m0 + m) * a.ldc;
+        if (!RAGGED || col0 < a.N) *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
+        if (!RAGGED || col0 + 16 < a.N) *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
         if (a.stats != nullptr) {                              // (uniform)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -1038,7 +999,6 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
       default: run_tile(std::integral_constant<int, 1>{}, t); break;
     }
   }
-  if (pend_row != nullptr) put_rows(kPD, 8);                 // the share's last tile
   if (a.stats != nullptr) flush_stats();
 #if defined(HIFIHR_GEMM_STAMP)
   if (tid == 0) {
@@ -1390,7 +1350,6 @@ hipError_t launch_conv_rows(const ConvGeom& g, const float* src, const float* wg
   per = (per + 15) / 16 * 16;                               // whole 16-row blocks per share
   if (per < 16) per = 16;
   const int G = (int)((total + per - 1) / per);
-  a.defer = gemm_defer();
   hipLaunchKernelGGL(bgemm_nt_rows_kernel<2>, dim3(G), dim3(512), 0, st, a, per);
   return hipGetLastError();
 }
@@ -1410,7 +1369,6 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
     long per = (total + cus - 1) / cus;
     if (per < 16) per = 16;
     const int G = (int)((total + per - 1) / per);
-    a.defer = gemm_defer();
     hipLaunchKernelGGL(bgemm_nt_rows_kernel<0>, dim3(G), dim3(512), 0, st, a, per);
     return hipGetLastError();
   }
@@ -1432,7 +1390,6 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
     long per = (total + cus - 1) / cus;
     if (per < 16) per = 16;
     const int G = (int)((total + per - 1) / per);
-    a.defer = gemm_defer();
     hipLaunchKernelGGL(bgemm_nt_rows_kernel<1>, dim3(G), dim3(512), 0, st, a, per);
     return hipGetLastError();
   }
@@ -1443,7 +1400,6 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
     long per = (total + cus - 1) / cus;
     if (per < 16) per = 16;
     const int G = (int)((total + per - 1) / per);
-    a.defer = gemm_defer();
     hipLaunchKernelGGL(bgemm_nt_rows_kernel<0>, dim3(G), dim3(512), 0, st, a, per);
     return hipGetLastError();
   }

@@ -339,7 +339,6 @@ struct BgemmArgs {
   // bgemm_nt_rows_kernel<2>: A is an NHWC image x[n][ih][iw][cC] and row m of the product is the (r, s, c)-ordered patch of output pixel
   // m = (n, oh, ow), gathered by the loader waves (K = cR * cS * cC, cC % 32 == 0; B = the filter [N][cR][cS][cC])
   int cIH = 0, cIW = 0, cC = 0, cOH = 0, cOW = 0, cR = 0, cS = 0, cStride = 1, cPad = 0;
-  int defer = 1;               // bgemm_nt_rows_kernel: the upper half of a finished tile is stored from inside the next tile's chunk loop (HIFIHR_GEMM_DEFER=0: at the tile's end)
   float* stats = nullptr;      // bgemm_nt_rows_kernel, batch 1 (a 1x1 convolution in front of a batch-norm): per-column sum / sum of squares of C
                                // added into the slot buffer [kStatSlots][2][N] (csrc/bn.hip), or null
 };
