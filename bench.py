@@ -230,19 +230,19 @@ _TRAFFIC_OK = True        # main() clears it when the workload is not the one th
 
 def measured_traffic(kernel_key):
     """HBM bytes per launch from the PMC counters (separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes over this command,
-    tools/kernel_traffic.sh -> profiles/r03_kernel_traffic.json), or None when no measurement of this tree's kernels exists."""
+    tools/kernel_traffic.sh -> profiles/r<NN>_kernel_traffic.json), or None when no measurement of this tree's kernels exists."""
     if not _TRAFFIC_OK:
         return None
-    f = os.path.join(REPO, "profiles", "r03_kernel_traffic.json")
-    if not os.path.exists(f):
-        return None
-    j = json.load(open(f))
-    if j.get("csrc_digest") != csrc_digest():
-        return None
-    return j.get("traffic_bytes_per_launch", {}).get(kernel_key)
+    import glob
+    dig = csrc_digest()
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_kernel_traffic.json")), reverse=True):      # newest round first
+        j = json.load(open(f))
+        if j.get("csrc_digest") == dig:
+            return j.get("traffic_bytes_per_launch", {}).get(kernel_key)
+    return None
 
 
-def conv_path_rooflines(ops, lib, dev, nprof, prof=None):
+def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (torch.profiler) over 3 eager steps"):
     """Every MFMA kernel of the convolution path: each distinct (shape, direction) the profiled steps launched is timed with HIP
     events over 10 back-to-back launches on tensors of that shape and weighted by launches per step.  FLOPs are the ones the kernel
     EXECUTES (Winograd GEMMs: 2 M N K per product).  Returns {kernel name as rocprof lists it: entry}."""
@@ -322,7 +322,7 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None):
         us_step, timing = entry_us, "entry point: HIP events over 10 back-to-back launches per shape (helper kernels of the entry included)"
         if hit is not None and hit[0] > 0:
             us_step, timing = hit[1] * (e["launches_per_step"] / hit[0]) if abs(hit[0] - e["launches_per_step"]) > 0.01 else hit[1], \
-                "kernel time inside the step: roctracer (torch.profiler) over 3 eager steps, this kernel's launches only"
+                "kernel time inside the step: " + prof_how + ", this kernel's launches only"
         ach = e["flop_per_step"] / (us_step * 1e-6) / 1e12
         out[name] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF,
                      "traffic": measured_traffic(name), "kernel": name, "launches_per_step": e["launches_per_step"],
@@ -481,77 +481,6 @@ def main():
     lib = ops.get_lib()
     B = a.batch
     extra = {}
-    if rank != 0:
-        for _ in range(3):                           # the steps rank 0 profiles hold the gradient exchange: every rank runs them
-            eager_resident()
-    if rank == 0:
-        kprof = instep_kernel_times(eager_resident, nsteps=3)
-        roofs = conv_path_rooflines(ops, lib, dev, nprof, kprof)
-        # ---- the north star's HBM-bound kernels: rasteriser (forward / backward) and MANO LBS, 20 back-to-back launches each
-        if ops.PROFILE.last_render is not None:
-            h_r, v_r, c_r, cam_r, lc_r, ld_r = ops.PROFILE.last_render
-            Br, Hr, Sr, Vn, Fn = v_r.shape[0], h_r.H, h_r.H * h_r.aa, v_r.shape[1], int(h_r.F)
-            rgba_r = torch.empty(Br, 4, Hr, Hr, device=dev); fid_r = torch.empty(Br, Sr, Sr, dtype=torch.int32, device=dev)
-            ws_r = h_r.workspace(Br, dev)
-            us_f = hip_us(lambda: h_r.lib.render_fwd(h_r.h, v_r, c_r, cam_r, lc_r, ld_r, rgba_r, fid_r, ws_r), n=20)
-            g_r = torch.randn(Br, 4, Hr, Hr, device=dev); gv = torch.empty_like(v_r); gc = torch.empty_like(v_r)
-            glc = torch.empty(Br, 3, device=dev); gld = torch.empty(Br, 3, device=dev)
-            us_b = hip_us(lambda: h_r.lib.render_bwd(h_r.h, v_r, cam_r, lc_r, ld_r, fid_r, g_r, gv, gc, glc, gld, ws_r), n=20)
-            # algorithmic bytes per image (SURVEY.md 8d / DESIGN.md section 4): fwd = verts V*12 + faces F*12 + per-vertex attributes V*24
-            # + RGBA out H^2*16 + face-id side buffer S^2*4;  bwd = side buffer + grad RGBA in + grad verts / colours out
-            alg_f = Vn * 12 + Fn * 12 + Vn * 24 + Hr * Hr * 16 + Sr * Sr * 4
-            alg_b = Sr * Sr * 4 + Hr * Hr * 16 + Vn * 24
-            for key, us, alg, kname, kk in (("roofline_render_fwd", us_f, alg_f, f"render_fwd3_kernel<{h_r.aa}> (+ render_vertex_kernel, render_bin_kernel)",
-                                             "render_fwd3_kernel" if instep_lookup(kprof, "render_fwd3_kernel") else "render_fwd2_kernel"),
-                                            ("roofline_render_bwd", us_b, alg_b, f"render_bwd_kernel<{h_r.aa}> (+ render_vertex_bwd_kernel)", "render_bwd_kernel")):
-                ach = alg * Br / (us * 1e-6) / 1e9
-                hit = instep_lookup(kprof, kk)
-                extra[key] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                              "traffic": measured_traffic(key.replace("roofline_", "")), "kernel": kname, "avg_us": us,
-                              "algorithmic_bytes_per_launch": alg * Br,
-                              "timing": "HIP events over 20 back-to-back launches of the C-ABI entry on this batch's meshes (the launch's helper kernels and "
-                                        "memsets included)"}
-                if hit is not None and hit[0] > 0:
-                    k_us = hit[1] / hit[0]
-                    extra[key]["tile_kernel_in_step"] = {"avg_us": k_us, "achieved": alg * Br / (k_us * 1e-6) / 1e9,
-                                                         "frac": alg * Br / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                                         "timing": "the tile kernel alone inside the step (roctracer over 3 eager steps)"}
-            extra["render_ms_per_frame"] = {"fwd": us_f / Br / 1e3, "fwd+bwd": (us_f + us_b) / Br / 1e3, "image_size": Hr, "aa": h_r.aa}
-        mh = getattr(model, "data_mano", None) or model.hand_layer.handle
-        pose = torch.randn(B, 48, device=dev) * 0.5; beta = torch.randn(B, 10, device=dev) * 0.5
-        verts = torch.empty(B, 778, 3, device=dev); jtr = torch.empty(B, 21, 3, device=dev); saved = torch.empty(B, 778, 3, device=dev)
-        us_mf = hip_us(lambda: lib.mano_lbs_fwd(mh.h, pose, beta, verts, jtr, saved), n=20)
-        gvv = torch.randn(B, 778, 3, device=dev); gj = torch.randn(B, 21, 3, device=dev)
-        gp = torch.empty(B, 48, device=dev); gb = torch.empty(B, 10, device=dev)
-        us_mb = hip_us(lambda: lib.mano_lbs_bwd(mh.h, pose, beta, saved, gvv, gj, gp, gb), n=20)
-        tbl = 4 * (3 * 800 + 10 * 3 * 800 + 135 * 3 * 800 + 16 * 800 * 2 + 45 * 45 + 45)        # the padded SoA tables one launch reads
-        alg_mf = tbl + B * (232 + 778 * 12 + 21 * 12)
-        alg_mb = tbl + B * (232 + 778 * 12 * 2 + 21 * 12 + 232)
-        extra["roofline_mano_lbs"] = {
-            "bound": "hbm", "achieved": alg_mf / (us_mf * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": alg_mf / (us_mf * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic("mano_fwd_kernel"), "kernel": "mano_fwd_kernel",
-            "avg_us": us_mf, "algorithmic_bytes_per_launch": alg_mf,
-            "backward": {"kernel": "mano_bwd_kernel", "avg_us": us_mb, "algorithmic_bytes_per_launch": alg_mb,
-                         "achieved": alg_mb / (us_mb * 1e-6) / 1e9, "frac": alg_mb / (us_mb * 1e-6) / 1e9 / HBM_PEAK_GBS},
-            "in_step": (lambda hf, hb: {"fwd_avg_us": hf[1] / hf[0] if hf and hf[0] else None, "bwd_avg_us": hb[1] / hb[0] if hb and hb[0] else None,
-                                        "fwd_frac": (alg_mf / (hf[1] / hf[0] * 1e-6) / 1e9 / HBM_PEAK_GBS) if hf and hf[0] else None,
-                                        "timing": "kernel time inside the step (roctracer over 3 eager steps): tables cold in L2, unlike the "
-                                                  "back-to-back figure above"})(instep_lookup(kprof, "mano_fwd_kernel"), instep_lookup(kprof, "mano_bwd_kernel")),
-            "note": f"B = {B} hands: 1.43 MB of tables + 9.8 KB per hand; a launch this small is latency-bound (one dependent chain per hand: "
-                    "PCA -> 16 Rodrigues -> kinematic chain -> blend), the HBM fraction says how little memory it touches, not how slow it moves bytes"}
-        if roofs:
-            dom = max(roofs.values(), key=lambda e: e["us_per_step"])
-            extra["roofline"] = dict({k: v for k, v in dom.items() if k != "shapes"},
-                                     flops="the products the kernel executes (2 M N K per Winograd GEMM), per shape x launches per step")
-            extra["roofline_kernels"] = {k: {kk: v[kk] for kk in ("achieved", "frac", "launches_per_step", "avg_us", "us_per_step", "timing", "entry_avg_us",
-                                                                   "entry_us_per_step", "traffic", "shapes")}
-                                         for k, v in roofs.items()}
-            tot_f = sum(v["executed_flop_per_launch"] * v["launches_per_step"] for v in roofs.values())
-            tot_us = sum(v["us_per_step"] for v in roofs.values())
-            extra["conv_path"] = {"executed_flop_per_step": tot_f, "mfma_kernel_us_per_step": tot_us,
-                                  "achieved": tot_f / (tot_us * 1e-6) / 1e12, "frac": tot_f / (tot_us * 1e-6) / 1e12 / MFMA_PEAK_TF,
-                                  "note": "all MFMA kernels of the convolution path together (direct, Winograd GEMMs, weight gradients)"}
-
     # ---- the step forms
     use_graph = a.graph != 0
     split = world > 1 or a.graph in (2, 3)   # data parallel: graph = forward + backward, then all-reduce + Adam eagerly
@@ -673,6 +602,90 @@ def main():
     dt, (loss, loss_dic) = timed_region(step, a.steps)
 
     bucket_us = reducer.time_buckets() if world > 1 else None        # a collective: every rank takes part
+    # ---- rooflines.  Kernel times come from the form of the step the timed region ran: three REPLAYS of the captured graph under roctracer
+    # (single process), where every kernel runs alone on the stream in the graph's order -- the eager profile steps launch weight gradients on a
+    # side stream beside other kernels, which inflated them (round-3 review).  Data parallel / eager runs: three eager steps, on every rank.
+    if world > 1:
+        reducer.pause_hooks(False)                   # (the eager profile steps below exchange gradients through the hooks)
+    if rank != 0:
+        for _ in range(3):                           # the steps rank 0 profiles hold the gradient exchange: every rank runs them
+            eager_resident()
+    if rank == 0:
+        kprof, kprof_how = None, "roctracer (torch.profiler) over 3 eager steps"
+        if world == 1 and gstep is not None and step is step_streamed:
+            kprof = instep_kernel_times(gstep, nsteps=3)
+            if kprof and instep_lookup(kprof, "adam_kernel"):
+                kprof_how = "roctracer (torch.profiler) over 3 replays of the captured step (the graph the timed region replays)"
+            else:
+                kprof = None
+        if kprof is None:
+            kprof = instep_kernel_times(eager_resident, nsteps=3)
+        roofs = conv_path_rooflines(ops, lib, dev, nprof, kprof, kprof_how)
+        # ---- the north star's HBM-bound kernels: rasteriser (forward / backward) and MANO LBS, 20 back-to-back launches each
+        if ops.PROFILE.last_render is not None:
+            h_r, v_r, c_r, cam_r, lc_r, ld_r = ops.PROFILE.last_render
+            Br, Hr, Sr, Vn, Fn = v_r.shape[0], h_r.H, h_r.H * h_r.aa, v_r.shape[1], int(h_r.F)
+            rgba_r = torch.empty(Br, 4, Hr, Hr, device=dev); fid_r = torch.empty(Br, Sr, Sr, dtype=torch.int32, device=dev)
+            ws_r = h_r.workspace(Br, dev)
+            us_f = hip_us(lambda: h_r.lib.render_fwd(h_r.h, v_r, c_r, cam_r, lc_r, ld_r, rgba_r, fid_r, ws_r), n=20)
+            g_r = torch.randn(Br, 4, Hr, Hr, device=dev); gv = torch.empty_like(v_r); gc = torch.empty_like(v_r)
+            glc = torch.empty(Br, 3, device=dev); gld = torch.empty(Br, 3, device=dev)
+            us_b = hip_us(lambda: h_r.lib.render_bwd(h_r.h, v_r, cam_r, lc_r, ld_r, fid_r, g_r, gv, gc, glc, gld, ws_r), n=20)
+            # algorithmic bytes per image (SURVEY.md 8d / DESIGN.md section 4): fwd = verts V*12 + faces F*12 + per-vertex attributes V*24
+            # + RGBA out H^2*16 + face-id side buffer S^2*4;  bwd = side buffer + grad RGBA in + grad verts / colours out
+            alg_f = Vn * 12 + Fn * 12 + Vn * 24 + Hr * Hr * 16 + Sr * Sr * 4
+            alg_b = Sr * Sr * 4 + Hr * Hr * 16 + Vn * 24
+            for key, us, alg, kname, kk in (("roofline_render_fwd", us_f, alg_f, f"render_fwd3_kernel<{h_r.aa}> (+ render_vertex_kernel, render_bin_kernel)",
+                                             "render_fwd3_kernel" if instep_lookup(kprof, "render_fwd3_kernel") else "render_fwd2_kernel"),
+                                            ("roofline_render_bwd", us_b, alg_b, f"render_bwd_kernel<{h_r.aa}> (+ render_vertex_bwd_kernel)", "render_bwd_kernel")):
+                ach = alg * Br / (us * 1e-6) / 1e9
+                hit = instep_lookup(kprof, kk)
+                extra[key] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                              "traffic": measured_traffic(key.replace("roofline_", "")), "kernel": kname, "avg_us": us,
+                              "algorithmic_bytes_per_launch": alg * Br,
+                              "timing": "HIP events over 20 back-to-back launches of the C-ABI entry on this batch's meshes (the launch's helper kernels and "
+                                        "memsets included)"}
+                if hit is not None and hit[0] > 0:
+                    k_us = hit[1] / hit[0]
+                    extra[key]["tile_kernel_in_step"] = {"avg_us": k_us, "achieved": alg * Br / (k_us * 1e-6) / 1e9,
+                                                         "frac": alg * Br / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                         "timing": "the tile kernel alone inside the step: " + kprof_how}
+            extra["render_ms_per_frame"] = {"fwd": us_f / Br / 1e3, "fwd+bwd": (us_f + us_b) / Br / 1e3, "image_size": Hr, "aa": h_r.aa}
+        mh = getattr(model, "data_mano", None) or model.hand_layer.handle
+        pose = torch.randn(B, 48, device=dev) * 0.5; beta = torch.randn(B, 10, device=dev) * 0.5
+        verts = torch.empty(B, 778, 3, device=dev); jtr = torch.empty(B, 21, 3, device=dev); saved = torch.empty(B, 778, 3, device=dev)
+        us_mf = hip_us(lambda: lib.mano_lbs_fwd(mh.h, pose, beta, verts, jtr, saved), n=20)
+        gvv = torch.randn(B, 778, 3, device=dev); gj = torch.randn(B, 21, 3, device=dev)
+        gp = torch.empty(B, 48, device=dev); gb = torch.empty(B, 10, device=dev)
+        us_mb = hip_us(lambda: lib.mano_lbs_bwd(mh.h, pose, beta, saved, gvv, gj, gp, gb), n=20)
+        tbl = 4 * (3 * 800 + 10 * 3 * 800 + 135 * 3 * 800 + 16 * 800 * 2 + 45 * 45 + 45)        # the padded SoA tables one launch reads
+        alg_mf = tbl + B * (232 + 778 * 12 + 21 * 12)
+        alg_mb = tbl + B * (232 + 778 * 12 * 2 + 21 * 12 + 232)
+        extra["roofline_mano_lbs"] = {
+            "bound": "hbm", "achieved": alg_mf / (us_mf * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg_mf / (us_mf * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic("mano_fwd_kernel"), "kernel": "mano_fwd_kernel",
+            "avg_us": us_mf, "algorithmic_bytes_per_launch": alg_mf,
+            "backward": {"kernel": "mano_bwd_kernel", "avg_us": us_mb, "algorithmic_bytes_per_launch": alg_mb,
+                         "achieved": alg_mb / (us_mb * 1e-6) / 1e9, "frac": alg_mb / (us_mb * 1e-6) / 1e9 / HBM_PEAK_GBS},
+            "in_step": (lambda hf, hb: {"fwd_avg_us": hf[1] / hf[0] if hf and hf[0] else None, "bwd_avg_us": hb[1] / hb[0] if hb and hb[0] else None,
+                                        "fwd_frac": (alg_mf / (hf[1] / hf[0] * 1e-6) / 1e9 / HBM_PEAK_GBS) if hf and hf[0] else None,
+                                        "timing": "kernel time inside the step (" + kprof_how + "): tables cold in L2, unlike the "
+                                                  "back-to-back figure above"})(instep_lookup(kprof, "mano_fwd_kernel"), instep_lookup(kprof, "mano_bwd_kernel")),
+            "note": f"B = {B} hands: 1.43 MB of tables + 9.8 KB per hand; a launch this small is latency-bound (one dependent chain per hand: "
+                    "PCA -> 16 Rodrigues -> kinematic chain -> blend), the HBM fraction says how little memory it touches, not how slow it moves bytes"}
+        if roofs:
+            dom = max(roofs.values(), key=lambda e: e["us_per_step"])
+            extra["roofline"] = dict({k: v for k, v in dom.items() if k != "shapes"},
+                                     flops="the products the kernel executes (2 M N K per Winograd GEMM), per shape x launches per step")
+            extra["roofline_kernels"] = {k: {kk: v[kk] for kk in ("achieved", "frac", "launches_per_step", "avg_us", "us_per_step", "timing", "entry_avg_us",
+                                                                   "entry_us_per_step", "traffic", "shapes")}
+                                         for k, v in roofs.items()}
+            tot_f = sum(v["executed_flop_per_launch"] * v["launches_per_step"] for v in roofs.values())
+            tot_us = sum(v["us_per_step"] for v in roofs.values())
+            extra["conv_path"] = {"executed_flop_per_step": tot_f, "mfma_kernel_us_per_step": tot_us,
+                                  "achieved": tot_f / (tot_us * 1e-6) / 1e12, "frac": tot_f / (tot_us * 1e-6) / 1e12 / MFMA_PEAK_TF,
+                                  "note": "all MFMA kernels of the convolution path together (direct, Winograd GEMMs, weight gradients)"}
+
     if rank == 0:
         ms = dt / a.steps * 1e3
         wl = {2: "BASELINE configs[1]: FreiHAND batch=32/GPU, ResNet-18 encoder + MANO LBS + silhouette/texture render losses, 224x224, aa=3 (672^2 samples)",

@@ -445,7 +445,9 @@ __device__ __forceinline__ float comp(const F4& a, int k) { return k < 2 ? a.lo[
 #ifndef HIFIHR_W2_STAGGER
 #define HIFIHR_W2_STAGGER 0
 #endif
-template <bool EPI>
+// STATS: the batch-norm statistics epilogue of the forward (24 registers of shifted sums) is compiled in -- the kernel sits at the 256-register
+// limit of its 512-thread workgroup, and backward-data launches do without them
+template <bool EPI, bool STATS>
 __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a) {
 #if defined(HIFIHR_HALO_STAMP)
   const unsigned long long st_entry = HALO_T();
@@ -685,6 +687,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
               if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
             *reinterpret_cast<float4*>(o) = v;
+            if constexpr (STATS) {
 #if HIFIHR_W2_ABLATE != 7
             if (n == 0) { k4[0] = v.x; k4[1] = v.y; k4[2] = v.z; k4[3] = v.w; }
             const float d0 = v.x - k4[0], d1 = v.y - k4[1], d2 = v.z - k4[2], d3 = v.w - k4[3];
@@ -692,6 +695,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
             s4[2] += d2; q4[2] += d2 * d2; s4[3] += d3; q4[3] += d3 * d3;
             ++n;
 #endif
+            }
           }
         };
         if (NCB == 2 ? c == 0 : rbw == 0) put(sk[0], ssum[0], ssq[0], sn[0]);
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
     atomicAdd(&g_halo_stamp[6], st_epi);
   }
 #endif
-  if (a.stats != nullptr) {                                  // (uniform)
+  if (STATS && a.stats != nullptr) {                         // (uniform)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       double S1[4], S2[4];
@@ -1496,8 +1500,13 @@ hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias
   if (a.per < 4) a.per = 4;
   a.per = (a.per + 1) & ~1;                                  // even shares: every tile is whole 2 x 2 Winograd tiles
   G = (a.total + a.per - 1) / a.per;
-  if (bias != nullptr || relu) hipLaunchKernelGGL(conv_wino2_kernel<true>, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
-  else hipLaunchKernelGGL(conv_wino2_kernel<false>, dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+  if (bias != nullptr || relu) {
+    if (stats != nullptr) hipLaunchKernelGGL((conv_wino2_kernel<true, true>), dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+    else hipLaunchKernelGGL((conv_wino2_kernel<true, false>), dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+  } else {
+    if (stats != nullptr) hipLaunchKernelGGL((conv_wino2_kernel<false, true>), dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+    else hipLaunchKernelGGL((conv_wino2_kernel<false, false>), dim3(G), dim3(256 + 64 * kNL), 0, st, a);
+  }
   return hipGetLastError();
 }
 
