@@ -1277,7 +1277,8 @@ void bgemm_describe_batch(int tn, int M, int N, int K, int batch, char* out, int
     if ((e = getenv("HIFIHR_GEMM_NT_TILE")) != nullptr) { const int v = atoi(e); bm = v / 1000; bn = v % 1000; if (N % bn) bn = 64; }
   }
   const int nload = gemm_ws_loaders();
-  if (!tn && (nt_rows(N) || bgemm_nt_ragged_supported(M, N, K))) { snprintf(out, cap, "bgemm_nt_rows_kernel"); return; }
+  // (the instantiation rocprof lists: <0> plain, <1> ragged N / K; <2> = the gathering form, named by hifihr_conv2d_describe)
+  if (!tn && (nt_rows(N) || bgemm_nt_ragged_supported(M, N, K))) { snprintf(out, cap, "bgemm_nt_rows_kernel<%d>", bgemm_nt_ragged_supported(M, N, K) ? 1 : 0); return; }
   if (tn && tn_rows(M, N, K, batch)) { snprintf(out, cap, "bgemm_tn_rows_kernel"); return; }
   if (!tn && bm == 128 && bn == 128 && nload > 0 && bgemm_nt_workspace_bytes(M, N, K, 16) > 0) snprintf(out, cap, "bgemm_nt_sk_kernel<%d>", nload == 2 ? 2 : 4);
   else if (bm == 128 && bn == 128 && nload > 0) snprintf(out, cap, "bgemm_ws_kernel<128, 128, %s, %d>", tn ? "true" : "false", nload == 1 ? 1 : nload == 4 ? 4 : 2);

@@ -437,7 +437,7 @@ int hifihr_conv2d_describe(int N, int H, int W, int C, int K, int R, int S, int 
   }
   if (dgrad == 2) snprintf(out, cap, "%s", hifihr::conv_halo_wgrad_supported(g) ? "conv_halo_wgrad_kernel" : hifihr::conv_stem_wgrad_supported(g) ? "conv_stem_wgrad_kernel" : "conv_wgrad_kernel");
   else snprintf(out, cap, "%s", hifihr::conv_halo_supported(g, nullptr) ? "conv_halo_kernel" : hifihr::conv_stem_supported(g, nullptr) ? "conv_stem_kernel" :
-                (dgrad == 0 && hifihr::conv_rows_supported(g, nullptr)) ? "bgemm_nt_rows_kernel" : "conv_igemm_kernel");      // (strided forward: the gathering row-share GEMM)
+                (dgrad == 0 && hifihr::conv_rows_supported(g, nullptr)) ? "bgemm_nt_rows_kernel<2>" : "conv_igemm_kernel");      // (strided forward: the gathering row-share GEMM)
   return HIFIHR_OK;
 }
 

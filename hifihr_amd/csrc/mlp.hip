@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "hifihr_internal.h"
+#include "lds_dma.h"
 
 namespace hifihr {
 
@@ -57,8 +58,17 @@ __device__ __forceinline__ void linear_fwd_body(const LinearArgs& a, const int b
   const int o0 = bx * kFT, row0 = by * RB;
   const int nrow = min(RB, a.B - row0);
   float acc[KR];
+  // Round 4: the products on the matrix cores.  The FMA loop read 12 KB of LDS per 4 096 flops (one float4 of W and KR of x per 4 KR
+  // fused multiply-adds per thread): a workgroup was bound by its LDS bandwidth -- 20 us for the 1024 -> 512 layer on 32 workgroups.
+  // v_mfma_f32_16x16x4_f32 takes the same operands at 1 / 12 of the LDS traffic: wave w multiplies the chunk's k-groups w, w + 4, ..
+  // (16 k-values each: one ds_read_b128 of W and RB / 16 of x feed 4 x RB / 16 MFMAs); the four waves' partial sums meet in LDS in a
+  // fixed order, and the thread -> (feature, rows) ownership of the epilogue below is unchanged.
+  constexpr int NRB = RB / 16;                    // 16-row blocks
+  __shared__ float part[4][RB][kFT + 1];
+  const int lane = tid & 63, mw = tid >> 6, mr = lane & 15, mg = lane >> 4;
+  floatx4 macc[NRB];
 #pragma unroll
-  for (int k = 0; k < KR; ++k) acc[k] = 0.f;
+  for (int j = 0; j < NRB; ++j) macc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
   constexpr int CPR = C::IC / 4;                  // float4 per LDS row
   const bool al4 = (a.I & 3) == 0;
   for (int i0 = 0; i0 < a.I; i0 += C::IC) {
@@ -87,17 +97,32 @@ __device__ __forceinline__ void linear_fwd_body(const LinearArgs& a, const int b
       *reinterpret_cast<float4*>(&ws[r * C::LD + c4]) = wr[p];
     }
     __syncthreads();
-#pragma unroll 4
-    for (int kk = 0; kk < ilen; kk += 4) {
-      const float4 w = *reinterpret_cast<const float4*>(&ws[ol * C::LD + kk]);
+    // (rows >= nrow, features >= O and columns >= ilen of the chunk hold zeros in LDS: whole 16-wide k-groups, no masks)
+    const int nkq = (ilen + 15) >> 4;
+#pragma unroll 2
+    for (int kq = mw; kq < nkq; kq += 4) {
+      const float4 w4 = *reinterpret_cast<const float4*>(&ws[mr * C::LD + 16 * kq + 4 * mg]);
+      float4 x4[NRB];
 #pragma unroll
-      for (int k = 0; k < KR; ++k) {
-        const float4 x = *reinterpret_cast<const float4*>(&xs[(rg + 16 * k) * C::LD + kk]);
-        acc[k] = fmaf(x.x, w.x, acc[k]); acc[k] = fmaf(x.y, w.y, acc[k]); acc[k] = fmaf(x.z, w.z, acc[k]); acc[k] = fmaf(x.w, w.w, acc[k]);
-      }
+      for (int j = 0; j < NRB; ++j) x4[j] = *reinterpret_cast<const float4*>(&xs[(16 * j + mr) * C::LD + 16 * kq + 4 * mg]);
+      const float wc[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NRB; ++j) {
+          const float xc = c == 0 ? x4[j].x : (c == 1 ? x4[j].y : (c == 2 ? x4[j].z : x4[j].w));
+          macc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[c], xc, macc[j], 0, 0, 0);      // D[feature 4 mg + e][row 16 j + mr]
+        }
     }
     __syncthreads();
   }
+#pragma unroll
+  for (int j = 0; j < NRB; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[mw][16 * j + mr][4 * mg + e] = macc[j][e];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < KR; ++k) acc[k] = (part[0][rg + 16 * k][ol] + part[1][rg + 16 * k][ol]) + (part[2][rg + 16 * k][ol] + part[3][rg + 16 * k][ol]);
   const int o = o0 + ol;
   const bool ook = o < a.O;
   const float bias = (a.b != nullptr && ook) ? a.b[o] : 0.f;
@@ -248,17 +273,19 @@ __device__ __forceinline__ void linear_bwd_w_body(const LinearArgs& a, const Lin
       g.db_acc[o0 + tid] += s;
     }
     if (g.dW_acc == nullptr) { __syncthreads(); continue; }
-    // dW[o0 + 4*og + j][i] += sum_r dz[r][4*og + j] * x[r][i];  thread = (i lane 0..63, feature group og 0..3)
-    const int il = tid & 63, og = tid >> 6;
+    // dW[o0 + f][i] += sum_r dz[r][f] * x[r][i] on the matrix cores (round 4; the FMA form read one float of x from LDS per four
+    // multiply-adds: LDS-bound, 23 us for a 1024 x 512 layer).  Wave w owns the 128 inputs 128 w .. of the slice as eight 16-input
+    // column blocks; an MFMA k-step is four batch rows: A = dz[row 4 kk + mg][feature mr] (8 registers per 32-row group), B = x[row 4 kk
+    // + mg][input 16 t + mr] from LDS; D register e of lane (mr, mg) = dW[feature 4 mg + e][input 16 t + mr].
+    const int lane = tid & 63, mw = tid >> 6, mr = lane & 15, mg = lane >> 4;
     {
       const int i0 = by * kWC;
       const int ilen = min(kWC, a.I - i0);
-      float w[kWC / 64][4];
+      constexpr int NT = kWC / 64;                   // column blocks per wave
+      floatx4 wacc[NT];
 #pragma unroll
-      for (int c = 0; c < kWC / 64; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[c][j] = 0.f;
-      for (int rh = 0; rh < nrow; rh += 32) {        // 32 rows of x at a time through LDS, their dz in registers
+      for (int c = 0; c < NT; ++c) wacc[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int rh = 0; rh < nrow; rh += 32) {        // 32 rows of x at a time through LDS, their dz fragments in registers
         const int nr = min(32, nrow - rh);
         float4 xr[16];
 #pragma unroll
@@ -272,33 +299,29 @@ __device__ __forceinline__ void linear_bwd_w_body(const LinearArgs& a, const Lin
           const int e = tid + 256 * p, r = e / (kWC / 4), c4 = (e % (kWC / 4)) * 4;
           *reinterpret_cast<float4*>(&xs[r * kWLD + c4]) = xr[p];
         }
-        float dzr[32][4];
+        float dzf[8];                                // (rows >= nrow of dzs hold zeros; rh + 31 < kRowsMax)
 #pragma unroll
-        for (int r = 0; r < 32; ++r)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) dzr[r][j] = (r < nr) ? dzs[rh + r][og * 4 + j] : 0.f;
+        for (int kk = 0; kk < 8; ++kk) dzf[kk] = dzs[rh + 4 * kk + mg][mr];
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < kWC / 64; ++c) {
-          if (c * 64 < ilen) {
+        for (int c = 0; c < NT; ++c) {
+          const int t = NT * mw + c;
+          if (16 * t < ilen) {                       // (uniform per wave)
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-              const float xv = xs[r * kWLD + c * 64 + il];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) w[c][j] = fmaf(dzr[r][j], xv, w[c][j]);
-            }
+            for (int kk = 0; kk < 8; ++kk)
+              wacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzf[kk], xs[(4 * kk + mg) * kWLD + 16 * t + mr], wacc[c], 0, 0, 0);
           }
         }
         __syncthreads();
       }
 #pragma unroll
-      for (int c = 0; c < kWC / 64; ++c) {
-        const int i = i0 + c * 64 + il;
+      for (int c = 0; c < NT; ++c) {
+        const int i = i0 + 16 * (NT * mw + c) + mr;
         if (i < a.I) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int oo = o0 + og * 4 + j;
-            if (oo < a.O) g.dW_acc[(size_t)oo * a.I + i] += w[c][j];
+          for (int e = 0; e < 4; ++e) {
+            const int oo = o0 + 4 * mg + e;
+            if (oo < a.O) g.dW_acc[(size_t)oo * a.I + i] += wacc[c][e];
           }
         }
       }
@@ -308,13 +331,26 @@ __device__ __forceinline__ void linear_bwd_w_body(const LinearArgs& a, const Lin
 
 constexpr int kOS = 64;       // output features per split of the dx kernel
 
-// dx[b][i] += sum_{o in split} dz[b][o] * W[o][i];  workgroup = 64 input features x one split; thread = (i, row group 0..3)
+// dx[b][i] += sum_{o in split} dz[b][o] * W[o][i];  workgroup = 64 input features x one split of 64 output features.
+// Round 4: on the matrix cores (the FMA form read one float of dz from LDS per multiply-add: LDS-bound, 15 us per base layer).  Wave w owns
+// the 16 inputs 16 w .. of the workgroup and all (<= 4) 16-row blocks.  k = output feature, in groups of 16: lane (mr, mg) holds
+// dz[row 16 j + mr][16 q + 4 mg + c] (one ds_read_b128: c = 0..3 are four MFMAs) and W[os0 + 16 q + 4 mg + c][i] (four coalesced dword loads,
+// all 16 of a split in flight); D register e of lane (mr, mg) = dx[row 16 j + 4 mg + e][input 16 w + mr].
 __device__ __forceinline__ void linear_bwd_x_body(const LinearArgs& a, const LinearGrads& g, const int bx, const int by) {
-  __shared__ float dzs[kRowsMax][kOS + 1];
-  const int tid = threadIdx.x, il = tid & 63, rg = tid >> 6;
-  const int i = bx * 64 + il;
+  constexpr int kDL = kOS + 4;                    // row stride of the dz image: float4 reads of 16 rows spread over the banks
+  __shared__ __attribute__((aligned(16))) float dzs[kRowsMax][kDL];
+  const int tid = threadIdx.x, lane = tid & 63, mw = tid >> 6, mr = lane & 15, mg = lane >> 4;
+  const int i = bx * 64 + 16 * mw + mr;
   const int ic = i < a.I ? i : a.I - 1;           // clamped: the loads below stay unconditional
   const int os0 = by * kOS, on = min(kOS, a.O - os0);
+  float wv[kOS / 16][4];                          // W[os0 + 16 q + 4 mg + c][i]; rows past `on` re-read the last row (dz is 0 there)
+#pragma unroll
+  for (int q = 0; q < kOS / 16; ++q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int o = os0 + 16 * q + 4 * mg + c;
+      wv[q][c] = a.W[(size_t)(o < a.O ? o : a.O - 1) * a.I + ic];
+    }
   for (int row0 = 0; row0 < a.B; row0 += kRowsMax) {
     const int nrow = min(kRowsMax, a.B - row0);
     for (int e = tid; e < kRowsMax * kOS; e += 256) {
@@ -322,28 +358,33 @@ __device__ __forceinline__ void linear_bwd_x_body(const LinearArgs& a, const Lin
       dzs[r][c] = (r < nrow && c < on) ? g.dz[(size_t)(row0 + r) * a.O + os0 + c] : 0.f;
     }
     __syncthreads();
-    float acc[16];
+    constexpr int NRB = kRowsMax / 16;
+    floatx4 acc[NRB];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-#pragma unroll 1
-    for (int c0 = 0; c0 < on; c0 += 16) {
-      float wv[16];
+    for (int j = 0; j < NRB; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {              // 16 independent loads in flight (rows past `on` re-read the last row: dz is 0 there)
-        const int oc = os0 + c0 + c < a.O ? os0 + c0 + c : a.O - 1;
-        wv[c] = a.W[(size_t)oc * a.I + ic];
+    for (int q = 0; q < kOS / 16; ++q) {
+      if (16 * q < on) {                          // (uniform)
+#pragma unroll
+        for (int j = 0; j < NRB; ++j) {
+          if (16 * j < nrow) {                    // (uniform)
+            const float4 d4 = *reinterpret_cast<const float4*>(&dzs[16 * j + mr][16 * q + 4 * mg]);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(d4.x, wv[q][0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(d4.y, wv[q][1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(d4.z, wv[q][2], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(d4.w, wv[q][3], acc[j], 0, 0, 0);
+          }
+        }
       }
-#pragma unroll
-      for (int c = 0; c < 16; ++c)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] = fmaf(dzs[rg + 4 * k][c0 + c], wv[c], acc[k]);
     }
     if (i < a.I) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int r = rg + 4 * k;
-        if (r < nrow) atomicAdd(g.dx + (size_t)(row0 + r) * a.I + i, acc[k]);
-      }
+      for (int j = 0; j < NRB; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 16 * j + 4 * mg + e;
+          if (r < nrow) atomicAdd(g.dx + (size_t)(row0 + r) * a.I + i, acc[j][e]);
+        }
     }
     __syncthreads();
   }

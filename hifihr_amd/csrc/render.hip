@@ -826,7 +826,10 @@ __device__ __forceinline__ void f3_fill_strip(const RenderDev& r, const int* __r
   }
 }
 
-template <int AA, bool UV>
+// CAP: faces per rasterisation pass.  128 for hand-sized meshes (41 faces per covered tile on the MANO mesh: one pass nearly everywhere, 36 KB of
+// LDS, four workgroups per CU); 256 for dense skins (hundreds of faces per tile everywhere: the per-pass chain of barriers, scans and queue
+// rounds is what a tile costs there, and half the passes beat a fourth workgroup per CU -- HIFIHR_RENDER_CAP forces either).
+template <int AA, bool UV, int CAP>
 __global__ __launch_bounds__(kF2Threads) void render_fwd3_kernel(RenderDev r, const float4* __restrict__ frec,
                                                                  const float* __restrict__ light_color, const float* __restrict__ light_dir,
                                                                  float* __restrict__ rgba, int* __restrict__ face_id,
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(kF2Threads) void render_fwd3_kernel(RenderDev r, co
                                                                  TexUvDev tuv, int nB, F3Ws w) {
   constexpr int TILE = 8, SW = TILE * AA;
   HIP_DYNAMIC_SHARED(float4, smem_raw)
-  Fwd2Lds<AA, TILE, kF3Cap>& L = *reinterpret_cast<Fwd2Lds<AA, TILE, kF3Cap>*>(smem_raw);
+  Fwd2Lds<AA, TILE, CAP>& L = *reinterpret_cast<Fwd2Lds<AA, TILE, CAP>*>(smem_raw);
   const int tid = threadIdx.x;
   const int H = r.H, S = H * AA;
   const int tiles = (H + TILE - 1) / TILE, nt = tiles * tiles;
@@ -874,8 +877,8 @@ __global__ __launch_bounds__(kF2Threads) void render_fwd3_kernel(RenderDev r, co
     }
     for (int e = tid; e < SW * SW; e += kF2Threads) L.zbuf[e] = ~0ull;
     const float4* fr = frec + (size_t)b * r.F * kFaceRec;
-    for (int base = lo; base < hi; base += kF3Cap) {
-      const int n = min(kF3Cap, hi - base);
+    for (int base = lo; base < hi; base += CAP) {
+      const int n = min(CAP, hi - base);
       __syncthreads();                                       // (previous pass done with rec; first pass: sxs / zbuf written)
       if (tid < n) {
         const int f = flist[base + tid];
@@ -885,7 +888,7 @@ __global__ __launch_bounds__(kF2Threads) void render_fwd3_kernel(RenderDev r, co
         q[8] = d.z; q[9] = __int_as_float(f); q[10] = 0.f;
       }
       __syncthreads();
-      raster_pass2<AA, TILE, kF3Cap>(L, n, cols, rows);
+      raster_pass2<AA, TILE, CAP>(L, n, cols, rows);
     }
     bool resolve = true;
     if (P > 1) {
@@ -910,7 +913,7 @@ __global__ __launch_bounds__(kF2Threads) void render_fwd3_kernel(RenderDev r, co
 #if defined(HIFIHR_RENDER_STAMP2)
     if (tid == 0) L.stamp_nlist = hi - lo;
 #endif
-    if (resolve) resolve_shade2<AA, TILE, UV, kF3Cap>(L, r, fr, light_color, light_dir, rgba, face_id, tuv, b, ox, oy);
+    if (resolve) resolve_shade2<AA, TILE, UV, CAP>(L, r, fr, light_color, light_dir, rgba, face_id, tuv, b, ox, oy);
     __syncthreads();                                         // everyone is done with this item's LDS
 #if defined(HIFIHR_RENDER_STAMP2)
     if (tid == 0) {
@@ -996,15 +999,23 @@ hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float
     }();
     static const int per_cu = [] { const char* e = getenv("HIFIHR_RENDER_WGS"); const int v = e ? atoi(e) : 16; return v > 0 ? v : 16; }();
     const dim3 grid3((unsigned)(cus * per_cu));
+    static const int cap_forced = [] { const char* e = getenv("HIFIHR_RENDER_CAP"); return e ? atoi(e) : 0; }();
+    const int cap3 = cap_forced == 128 || cap_forced == 256 ? cap_forced : (r.F > 2048 ? 256 : kF3Cap);
 #define HIFIHR_RENDER_FWD3(AA_)                                                                                                          \
     {                                                                                                                                   \
       hipLaunchKernelGGL((render_bin_kernel<AA_, 8>), bgrid, dim3(4 * kBinFaces), (size_t)2 * tiles * tiles * sizeof(int), st, r, vndc,   \
                          vpos, vnrm, vcol, frec, tile_cnt, tile_list, w3, 1);                                                           \
-      if (uv != nullptr)                                                                                                                \
-        hipLaunchKernelGGL((render_fwd3_kernel<AA_, true>), grid3, dim3(kF2Threads), sizeof(Fwd2Lds<AA_, 8, kF3Cap>), st, r, frec,        \
+      if (uv != nullptr && cap3 == 256)                                                                                                 \
+        hipLaunchKernelGGL((render_fwd3_kernel<AA_, true, 256>), grid3, dim3(kF2Threads), sizeof(Fwd2Lds<AA_, 8, 256>), st, r, frec,      \
+                           light_color, light_dir, rgba, face_id, tile_cnt, tile_list, td, B, w3);                                      \
+      else if (uv != nullptr)                                                                                                           \
+        hipLaunchKernelGGL((render_fwd3_kernel<AA_, true, kF3Cap>), grid3, dim3(kF2Threads), sizeof(Fwd2Lds<AA_, 8, kF3Cap>), st, r, frec, \
+                           light_color, light_dir, rgba, face_id, tile_cnt, tile_list, td, B, w3);                                      \
+      else if (cap3 == 256)                                                                                                             \
+        hipLaunchKernelGGL((render_fwd3_kernel<AA_, false, 256>), grid3, dim3(kF2Threads), sizeof(Fwd2Lds<AA_, 8, 256>), st, r, frec,     \
                            light_color, light_dir, rgba, face_id, tile_cnt, tile_list, td, B, w3);                                      \
       else                                                                                                                              \
-        hipLaunchKernelGGL((render_fwd3_kernel<AA_, false>), grid3, dim3(kF2Threads), sizeof(Fwd2Lds<AA_, 8, kF3Cap>), st, r, frec,       \
+        hipLaunchKernelGGL((render_fwd3_kernel<AA_, false, kF3Cap>), grid3, dim3(kF2Threads), sizeof(Fwd2Lds<AA_, 8, kF3Cap>), st, r, frec,\
                            light_color, light_dir, rgba, face_id, tile_cnt, tile_list, td, B, w3);                                      \
     }
     switch (r.aa) {

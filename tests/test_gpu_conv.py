@@ -520,7 +520,7 @@ def test_halo_kernels_are_bit_reproducible(lib, B, H, W):
 
 @pytest.mark.parametrize("N,H,C,K", [(32, 14, 256, 512), (8, 56, 256, 128), (4, 28, 512, 128), (2, 7, 2048, 512)])
 def test_conv_1x1_runs_on_the_gemm_kernels(lib, N, H, C, K):
-    assert lib.conv2d_describe(N, H, H, C, K, 1, 1, 1, 0, 0) == "bgemm_nt_rows_kernel"
+    assert lib.conv2d_describe(N, H, H, C, K, 1, 1, 1, 0, 0) .startswith("bgemm_nt_rows_kernel<")
     assert lib.conv2d_describe(N, H, H, C, K, 1, 1, 1, 0, 2).startswith("bgemm_")
     kc.conv_case(lib, "cuda", N, H, H, C, K, 1, 1, 0, seed=C + K)
     kc.conv_bnstats_case(lib, "cuda", N, H, H, C, K, 1, 1, 0)
@@ -530,7 +530,7 @@ def test_conv_1x1_runs_on_the_gemm_kernels(lib, N, H, C, K):
 def test_conv_1x1_ragged_channels_on_the_gemm_kernel(lib, N, H, C, K):
     """EfficientNet-b3's 1x1 convolutions whose channel counts are multiples of 4 but not of 32 / 128, at the configs[2] batch:
     bgemm_nt_rows_kernel<RAGGED> (zero-page operand segments past row N / column K, masked epilogue and statistics)."""
-    assert lib.conv2d_describe(N, H, H, C, K, 1, 1, 1, 0, 0) == "bgemm_nt_rows_kernel"
+    assert lib.conv2d_describe(N, H, H, C, K, 1, 1, 1, 0, 0) .startswith("bgemm_nt_rows_kernel<")
     kc.conv_case(lib, "cuda", N, H, H, C, K, 1, 1, 0, seed=C + K)
     kc.conv_bnstats_case(lib, "cuda", N, H, H, C, K, 1, 1, 0)
 

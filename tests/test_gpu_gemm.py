@@ -41,7 +41,7 @@ def test_bgemm_tn_is_bit_reproducible(lib):
 def test_bgemm_nt_row_shares(lib, M, N, K, batch):
     """bgemm_nt_rows_kernel on 256 workgroups: shares ending inside tiles (1..8 row blocks), crossing column-tile and problem boundaries,
     a B = 48-sized product and a very tall one."""
-    assert lib.bgemm_describe(False, M, N, K) == "bgemm_nt_rows_kernel"
+    assert lib.bgemm_describe(False, M, N, K) .startswith("bgemm_nt_rows_kernel<")
     assert kc.bgemm_case(lib, "cuda", M, N, K, batch, seed=M + K) == 0
 
 

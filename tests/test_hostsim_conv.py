@@ -102,7 +102,7 @@ def test_conv_stem_kernel(hostsim_lib, N, H, W):
 def test_conv_1x1_runs_on_the_gemm_kernels(hostsim_lib, N, H, W, C, K):
     """1x1 / stride 1 convolutions (the stride-1 projection shortcut, bottleneck conv1 / conv3): forward and backward-data on
     bgemm_nt_rows_kernel, the weight gradient on bgemm_tn_kernel slabs, batch statistics through the extra pass."""
-    assert hostsim_lib.conv2d_describe(N, H, W, C, K, 1, 1, 1, 0, 0) == "bgemm_nt_rows_kernel"
+    assert hostsim_lib.conv2d_describe(N, H, W, C, K, 1, 1, 1, 0, 0) .startswith("bgemm_nt_rows_kernel<")
     assert hostsim_lib.conv2d_describe(N, H, W, C, K, 1, 1, 1, 0, 2).startswith("bgemm_")
     assert hostsim_lib.conv2d_wgrad_workspace_bytes(N, H, W, C, K, 1, 1, 1, 0) > 0
     kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, 1, 1, 0, seed=C + K)
@@ -115,7 +115,7 @@ def test_conv_1x1_ragged_channels_run_on_the_gemm_kernel(hostsim_lib, N, H, W, C
     bgemm_nt_rows_kernel<RAGGED> -- operand segments past row N / column K come from a page of zeros, the epilogue stores and counts
     columns < N only -- with the batch-norm statistics from its epilogue.  (Taken where the 128-column tiles are >= 90 % full and the
     reduction has >= 128 channels: csrc/gemm.hip bgemm_nt_ragged_supported.)"""
-    assert hostsim_lib.conv2d_describe(N, H, W, C, K, 1, 1, 1, 0, 0) == "bgemm_nt_rows_kernel"
+    assert hostsim_lib.conv2d_describe(N, H, W, C, K, 1, 1, 1, 0, 0) .startswith("bgemm_nt_rows_kernel<")
     kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, 1, 1, 0, seed=C + K)
     kc.conv_bnstats_case(hostsim_lib, "cpu", N, H, W, C, K, 1, 1, 0)
 

@@ -3,7 +3,7 @@
 # /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (the TCC block cannot
 # hold both), eager step so that every dispatch is counted on its own; gfx950 correction (FETCH_SIZE x 2) applied by
 # tools/kernel_traffic_summary.py, which also stamps the digest of the kernel sources so that bench.py only uses a measurement of
-# THIS tree.  usage (GPU box, through gpurun): bash tools/kernel_traffic.sh   -> gpurun_out/r03_kernel_traffic.json
+# THIS tree.  usage (GPU box, through gpurun): bash tools/kernel_traffic.sh   -> gpurun_out/${ROUND_TAG:-r03}_kernel_traffic.json
 set -u
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
@@ -14,6 +14,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
   find $OUT/$C -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $OUT/$C.csv
   rm -rf $OUT/$C
 done
-python3 $GRAFT_REPO_ROOT/tools/kernel_traffic_summary.py $OUT > $GRAFT_REPO_ROOT/gpurun_out/r03_kernel_traffic.json
+python3 $GRAFT_REPO_ROOT/tools/kernel_traffic_summary.py $OUT > $GRAFT_REPO_ROOT/gpurun_out/${ROUND_TAG:-r03}_kernel_traffic.json
 rm -f $OUT/FETCH_SIZE.csv $OUT/WRITE_SIZE.csv
-head -c 1500 $GRAFT_REPO_ROOT/gpurun_out/r03_kernel_traffic.json
+head -c 1500 $GRAFT_REPO_ROOT/gpurun_out/${ROUND_TAG:-r03}_kernel_traffic.json
