@@ -49,6 +49,8 @@ def parse():
                          "(5 990 skin vertices / 11 976 faces, 25 joints, 20 / 30 / 10 PCA) on seeded synthetic tables; -uv = its texture as an "
                          "image sampled through per-face uvs (TexturesUV).  The real NIMBLE tables are absent: parity unpinned, declared")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rooflines", action="store_true",
+                    help="skip the roofline block behind the timed region (tools/profile_bench.sh: the rocprofv3 trace then ends with the timed replays)")
     ap.add_argument("--graph", type=int, default=-1, help="0: eager; -1 or 1: hipGraph replay (N = 1: whole step; N > 1: the fastest of the data-parallel forms in a "
                     "short trial); 2: force the N > 1 form (one graph, then all-reduce + Adam); 3: force the segmented form (backward as one graph "
                     "launch per trunk segment, each bucket exchanged beside the next segment)")
@@ -605,12 +607,12 @@ def main():
     # ---- rooflines.  Kernel times come from the form of the step the timed region ran: three REPLAYS of the captured graph under roctracer
     # (single process), where every kernel runs alone on the stream in the graph's order -- the eager profile steps launch weight gradients on a
     # side stream beside other kernels, which inflated them (round-3 review).  Data parallel / eager runs: three eager steps, on every rank.
-    if world > 1:
+    if world > 1 and not a.no_rooflines:
         reducer.pause_hooks(False)                   # (the eager profile steps below exchange gradients through the hooks)
-    if rank != 0:
+    if rank != 0 and not a.no_rooflines:
         for _ in range(3):                           # the steps rank 0 profiles hold the gradient exchange: every rank runs them
             eager_resident()
-    if rank == 0:
+    if rank == 0 and not a.no_rooflines:
         kprof, kprof_how = None, "roctracer (torch.profiler) over 3 eager steps"
         if world == 1 and gstep is not None and step is step_streamed:
             kprof = instep_kernel_times(gstep, nsteps=3)

@@ -27,6 +27,15 @@ namespace hifihr {
 
 constexpr int kPW = 4;        // outputs per thread per step (horizontally adjacent)
 
+// kRowAtATime (k = 5, forward and backward-data): the loop over the window's rows is NOT unrolled.  Unrolled, the scheduler hoists the
+// loads of all k rows in front of the first multiply-add (40 float4 at k = 5): 290-366 registers, ONE 256-thread workgroup per CU, and
+// the ~900 workgroups of a 7 x 7 or 14 x 14 layer run as 3-4 rounds that each pay the whole load latency (tools/time_dwconv.py: 0.17-0.30
+// of a 5 TB/s stream).  One row of loads in flight per thread at 104-122 registers: 816 channels at 14 x 14 67 -> 39 us forward, 44 -> 25
+// backward-data; per EfficientNet-b3 step at batch 48 forward 1 186 -> ~960 us, backward-data 975 -> ~760.  k = 3 keeps the unrolled
+// form (102-183 registers unrolled; row at a time it lost on the 112 x 112 layers: 73 -> 95 us), and so does backward-weight (its 25
+// accumulators need static indices; the row-at-a-time form with a uniform branch per candidate row measured 1 253 -> 1 345 us per step).
+// (An `asm volatile("" ::: "memory")` between the rows does not stop the hoisting: the loads are from const __restrict__ pointers.)
+
 __device__ __forceinline__ float4 fma4(const float4& a, const float4& b, const float4& c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
@@ -76,8 +85,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* 
       float4 acc[kPW];
 #pragma unroll
       for (int p = 0; p < kPW; ++p) acc[p] = zero4();
-#pragma unroll
-      for (int r = 0; r < K; ++r) {
+      auto row = [&](int r) {
         const int ih = oh * S - g.pt + r;
         const bool rowok = ih >= 0 && ih < g.H;
         float4 v[NC];
@@ -88,6 +96,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* 
 #pragma unroll
           for (int p = 0; p < kPW; ++p) acc[p] = fma4(v[p * S + s], wt, acc[p]);
         }
+      };
+      if constexpr (K >= 5) {                         // (see kRowAtATime)
+#pragma unroll 1
+        for (int r = 0; r < K; ++r) row(r);
+      } else {
+#pragma unroll
+        for (int r = 0; r < K; ++r) row(r);
       }
 #pragma unroll
       for (int p = 0; p < kPW; ++p) {
@@ -116,8 +131,7 @@ __device__ __forceinline__ void dgrad_block(const DwGeom& g, const float* __rest
   float4 acc[kPW];
 #pragma unroll
   for (int p = 0; p < kPW; ++p) acc[p] = zero4();
-#pragma unroll
-  for (int r = 0; r < K; ++r) {
+  auto row = [&](int r) {
     const int th = ih + g.pt - r;
     const bool rowok = th >= 0 && (S == 1 || (th & 1) == 0) && (th / S) < g.OH;
     const int oh = rowok ? th / S : 0;
@@ -136,6 +150,13 @@ __device__ __forceinline__ void dgrad_block(const DwGeom& g, const float* __rest
         }
       }
     }
+  };
+  if constexpr (K >= 5) {                             // (see kRowAtATime)
+#pragma unroll 1
+    for (int r = 0; r < K; ++r) row(r);
+  } else {
+#pragma unroll
+    for (int r = 0; r < K; ++r) row(r);
   }
 #pragma unroll
   for (int p = 0; p < kPW; ++p)
@@ -250,13 +271,16 @@ static unsigned dw_grid_x(long nb, long cap) {
 hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, float* stats, hipStream_t st) {
   const long nb = (long)g.N * g.OH * ((g.OW + kPW - 1) / kPW);
   // with statistics every workgroup ends with 128 float atomics: bound (workgroups x channels) like bn.hip does
-  const dim3 grid(dw_grid_x(nb, stats != nullptr ? 256 : 2048), (g.C + 63) / 64);
+  static const long cap_stats = [] { const char* e = getenv("HIFIHR_DW_FWD_CAP"); return e && atol(e) > 0 ? atol(e) : 256L; }();
+  static const long cap_plain = [] { const char* e = getenv("HIFIHR_DW_CAP"); return e && atol(e) > 0 ? atol(e) : 2048L; }();
+  const dim3 grid(dw_grid_x(nb, stats != nullptr ? cap_stats : cap_plain), (g.C + 63) / 64);
   HIFIHR_DW_DISPATCH(dwconv_fwd_kernel, grid, g, x, w, y, stats);
   return hipGetLastError();
 }
 hipError_t launch_dwconv_bwd_data(const DwGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
   const long nb = (long)g.N * g.H * ((g.W + kPW - 1) / kPW);
-  const dim3 grid(dw_grid_x(nb, 2048), (g.C + 63) / 64);
+  static const long cap_plain = [] { const char* e = getenv("HIFIHR_DW_CAP"); return e && atol(e) > 0 ? atol(e) : 2048L; }();
+  const dim3 grid(dw_grid_x(nb, cap_plain), (g.C + 63) / 64);
   HIFIHR_DW_DISPATCH(dwconv_bwd_data_kernel, grid, g, dy, w, dx);
   return hipGetLastError();
 }

@@ -174,7 +174,8 @@ __device__ __forceinline__ void linear_fwd_body(const LinearArgs& a, const int b
 }
 
 // per 16 output features: dz = BN'(dy * act'(y)); db, dgamma, dbeta, dW += dz^T x; writes dz[B][O]; zero-fills dx
-constexpr int kWC = 512;      // input features per x chunk of the dW phase (32 rows x 512 in LDS)
+constexpr int kWC = 128;      // input features per slice (grid.y) of the dW phase: 32 rows x kWC of x in LDS.  (512 until round 4: 64 workgroups on the
+                              // 1024 x 512 layer; the matrix-core form has nothing to amortise over a wide slice, and 256 workgroups cover the chip)
 constexpr int kWLD = kWC + 4;
 constexpr int kRowsMax = 64;  // rows per pass (batch-norm layers: one pass)
 
@@ -274,7 +275,7 @@ __device__ __forceinline__ void linear_bwd_w_body(const LinearArgs& a, const Lin
     }
     if (g.dW_acc == nullptr) { __syncthreads(); continue; }
     // dW[o0 + f][i] += sum_r dz[r][f] * x[r][i] on the matrix cores (round 4; the FMA form read one float of x from LDS per four
-    // multiply-adds: LDS-bound, 23 us for a 1024 x 512 layer).  Wave w owns the 128 inputs 128 w .. of the slice as eight 16-input
+    // multiply-adds: LDS-bound, 23 us for a 1024 x 512 layer).  Wave w owns the inputs 16 NT w .. of the slice as NT 16-input
     // column blocks; an MFMA k-step is four batch rows: A = dz[row 4 kk + mg][feature mr] (8 registers per 32-row group), B = x[row 4 kk
     // + mg][input 16 t + mr] from LDS; D register e of lane (mr, mg) = dW[feature 4 mg + e][input 16 t + mr].
     const int lane = tid & 63, mw = tid >> 6, mr = lane & 15, mg = lane >> 4;
@@ -287,15 +288,16 @@ __device__ __forceinline__ void linear_bwd_w_body(const LinearArgs& a, const Lin
       for (int c = 0; c < NT; ++c) wacc[c] = floatx4{0.f, 0.f, 0.f, 0.f};
       for (int rh = 0; rh < nrow; rh += 32) {        // 32 rows of x at a time through LDS, their dz fragments in registers
         const int nr = min(32, nrow - rh);
-        float4 xr[16];
+        constexpr int kWP = kWC / 32;                // float4 of the 32 x kWC image per thread
+        float4 xr[kWP];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
+        for (int p = 0; p < kWP; ++p) {
           const int e = tid + 256 * p, r = e / (kWC / 4), c4 = (e % (kWC / 4)) * 4;
           xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (r < nr && c4 < ilen) xr[p] = load4_guarded(a.x + (size_t)(row0 + rh + r) * a.I + i0, c4, ilen, al4);
         }
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
+        for (int p = 0; p < kWP; ++p) {
           const int e = tid + 256 * p, r = e / (kWC / 4), c4 = (e % (kWC / 4)) * 4;
           *reinterpret_cast<float4*>(&xs[r * kWLD + c4]) = xr[p];
         }

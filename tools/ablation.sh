@@ -6,7 +6,7 @@ run() {   # label, then VAR=value assignments / bench flags
   label=$1; shift
   envs=(); flags=()
   for a in "$@"; do if [[ $a == --* || $a =~ ^[0-9]+$ ]]; then flags+=("$a"); else envs+=("$a"); fi; done
-  ms=$(env "${envs[@]}" python3 bench.py --no-cpu-baseline --steps 30 --warmup 5 "${flags[@]}" 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3f ms/step  %.0f img/s' % (d['ms_per_step'], d['value']))")
+  ms=$(env "${envs[@]}" python3 bench.py --no-cpu-baseline --no-rooflines --steps 30 --warmup 5 "${flags[@]}" 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3f ms/step  %.0f img/s' % (d['ms_per_step'], d['value']))")
   printf "%-58s %s\n" "$label" "$ms"
 }
 run "default (final tree)"

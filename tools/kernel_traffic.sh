@@ -10,7 +10,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
 mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline > $OUT/$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-rooflines > $OUT/$C.log 2>&1
   find $OUT/$C -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $OUT/$C.csv
   rm -rf $OUT/$C
 done

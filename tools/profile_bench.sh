@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/bench_under_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rooflines "$@" > $OUT/bench_under_prof.log 2>&1
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python3 $GRAFT_REPO_ROOT/tools/trace_summary.py "$T" 5 $OUT/timeline.txt > $OUT/steady.md 2>&1
