@@ -61,7 +61,7 @@ __device__ __forceinline__ void acc4(float4& a, const float4& b) { a.x += b.x; a
 __device__ __forceinline__ float act_grad(int act, float z, float y) {
   if (act == 1) return y > 0.f ? 1.f : 0.f;
   if (act == 2) {
-    const float s = 1.0f / (1.0f + expf(-z));
+    const float s = fast_sigmoid(z);
     return s * (1.f + z * (1.f - s));
   }
   return 1.f;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
       if (act == 1) {
         r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
       } else if (act == 2) {
-        r.x = r.x / (1.f + expf(-r.x)); r.y = r.y / (1.f + expf(-r.y)); r.z = r.z / (1.f + expf(-r.z)); r.w = r.w / (1.f + expf(-r.w));
+        r.x = r.x * fast_sigmoid(r.x); r.y = r.y * fast_sigmoid(r.y); r.z = r.z * fast_sigmoid(r.z); r.w = r.w * fast_sigmoid(r.w);
       }
       *reinterpret_cast<float4*>(y + o) = r;
     };

@@ -260,6 +260,18 @@ hipError_t launch_photo_loss_bwd(const float* rgba, const float* re_img_m, const
 hipError_t launch_sil_post(const float* rgba, const float* imgs, int B, int HW, float* re_sil, float* mask_rgbs, hipStream_t st);
 
 // small-batch fully connected layer (mlp.hip): y[B][O] = act(BN1d?(x[B][I] W[O][I]^T + b)); gamma == nullptr: no batch-norm
+// sigmoid(z) for the swish / sigmoid activations of EfficientNet (batch-norm + swish passes, squeeze-excite gates): v_exp_f32 of z log2(e) and
+// v_rcp_f32 -- ~4 instructions where expf + an IEEE division are ~30, and the swish passes of csrc/bn.hip were bound by exactly those
+// (bn_bwd_reduce at 0.45 of a 5 TB/s stream on EfficientNet-b3's 78 batch-norms).  Error <= ~3 ulp of the result (1 ulp each from the
+// exponential, the reciprocal and the argument's rounding at |z| < 16): 3e-7 relative, against the 2e-4 / 2e-3 the EfficientNet golden test
+// holds.  The emulator build keeps the libm expression.
+__device__ __forceinline__ float fast_sigmoid(float z) {
+#if defined(HIFIHR_HOSTSIM)
+  return 1.0f / (1.0f + expf(-z));
+#else
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+#endif
+}
 struct LinearArgs {
   const float *x, *W, *b;
   float *y, *z;                         // z[B][O]: pre-batch-norm output (batch-norm layers only)

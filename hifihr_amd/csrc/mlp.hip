@@ -166,8 +166,8 @@ __device__ __forceinline__ void linear_fwd_body(const LinearArgs& a, const int b
       const size_t off = (size_t)(row0 + r) * a.O + o;
       float v = acc[k];
       if (a.act == 1) v = fmaxf(v, 0.f);
-      else if (a.act == 2) { if (a.gamma == nullptr) a.z[off] = v; v = v / (1.f + expf(-v)); }     // swish keeps z for the backward
-      else if (a.act == 3) v = 1.f / (1.f + expf(-v));
+      else if (a.act == 2) { if (a.gamma == nullptr) a.z[off] = v; v = v * fast_sigmoid(v); }      // swish keeps z for the backward
+      else if (a.act == 3) v = fast_sigmoid(v);
       a.y[off] = v;
     }
   }
@@ -218,7 +218,7 @@ __device__ __forceinline__ void linear_bwd_w_body(const LinearArgs& a, const Lin
         const size_t off = (size_t)(row0 + r) * a.O + o;
         v = g.dy[off];
         if (a.act == 1) { if (!(a.y[off] > 0.f)) v = 0.f; }
-        else if (a.act == 2) { const float z = a.z[off], sg = 1.f / (1.f + expf(-z)); v *= sg * (1.f + z * (1.f - sg)); }
+        else if (a.act == 2) { const float z = a.z[off], sg = fast_sigmoid(z); v *= sg * (1.f + z * (1.f - sg)); }
         else if (a.act == 3) { const float yy = a.y[off]; v *= yy * (1.f - yy); }
       }
       gv[k] = v;

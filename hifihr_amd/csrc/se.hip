@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_kernel(float* __restric
     const float acc = se_wave_dot(W1 + (size_t)j * C, s_mean, C / 4, lane);
     if (lane == 0) {
       const float z = acc + b1[j];
-      const float h = z / (1.f + expf(-z));                 // swish (csrc/mlp.hip act 2: same expression)
+      const float h = z * fast_sigmoid(z);                  // swish (csrc/mlp.hip act 2: same expression)
       z1[(size_t)b * SQ + j] = z;
       h1[(size_t)b * SQ + j] = h;
       s_h1[j] = h;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_kernel(float* __restric
   __syncthreads();
   for (int c = tid; c < C; c += kSeThreads) {
     const float v = se_col_dot(W2T, s_h1, C, SQ, c) + b2[c];
-    gate[(size_t)b * C + c] = 1.f / (1.f + expf(-v));       // sigmoid (act 3)
+    gate[(size_t)b * C + c] = fast_sigmoid(v);              // sigmoid (act 3)
   }
 }
 
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_x_kernel(float* __restr
   for (int j = wave; j < SQ; j += kSeThreads / 64) {
     const float acc = se_wave_dot(W2T + (size_t)j * C, s_dz2, C / 4, lane);
     if (lane == 0) {
-      const float z = z1[(size_t)b * SQ + j], sg = 1.f / (1.f + expf(-z));
+      const float z = z1[(size_t)b * SQ + j], sg = fast_sigmoid(z);
       const float v = acc * (sg * (1.f + z * (1.f - sg)));  // swish' (act 2)
       s_dz1[j] = v;
       dz1[(size_t)b * SQ + j] = v;
