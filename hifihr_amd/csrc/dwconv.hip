@@ -78,9 +78,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* 
   Stat4 st;                                         // batch-norm statistics of y (hifihr_internal.h "FORWARD statistics")
   if (cok) {
     for (long pb = (long)blockIdx.x * 16 + pl; pb < nb; pb += (long)gridDim.x * 16) {
-      const int owb = (int)(pb % OWB);
-      const long q = pb / OWB;
-      const int oh = (int)(q % g.OH), n = (int)(q / g.OH);
+      int owb, oh, n;
+      if (g.vorder) { oh = (int)(pb % g.OH); const long q = pb / g.OH; owb = (int)(q % OWB); n = (int)(q / OWB); }
+      else { owb = (int)(pb % OWB); const long q = pb / OWB; oh = (int)(q % g.OH); n = (int)(q / g.OH); }
       const int ow0 = owb * kPW;
       float4 acc[kPW];
 #pragma unroll
@@ -177,38 +177,34 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(DwGeom g, const fl
   const long nb = (long)g.N * g.H * WB;
   const bool odd = ((g.pl - (K - 1)) & 1) != 0;      // parity of base (iw0 is a multiple of 4); uniform
   for (long pb = (long)blockIdx.x * 16 + pl; pb < nb; pb += (long)gridDim.x * 16) {
-    const int iwb = (int)(pb % WB);
-    const long q = pb / WB;
-    const int ih = (int)(q % g.H), n = (int)(q / g.H);
+    int iwb, ih, n;
+    if (g.vorder) { ih = (int)(pb % g.H); const long q = pb / g.H; iwb = (int)(q % WB); n = (int)(q / WB); }
+    else { iwb = (int)(pb % WB); const long q = pb / WB; ih = (int)(q % g.H); n = (int)(q / g.H); }
     if (S == 1 || !odd) dgrad_block<K, S, 0>(g, dy, wl, cl, n, ih, iwb * kPW, c, dx);
     else dgrad_block<K, S, 1>(g, dy, wl, cl, n, ih, iwb * kPW, c, dx);
   }
 }
 
-// dw[c][r][s] += sum over output pixels of dy * x.  blockIdx.z = tap row r (round 4): a workgroup accumulates the K taps of ONE filter row --
-// K float4 accumulators, one input row and the dy block in flight (<= 80 registers: six waves per SIMD) where all K x K taps per thread
-// took 139-354 registers (one workgroup per CU at k = 5) and ran at 0.2-0.35 of a 5 TB/s stream; dy is read K times (L2 hits).
+// dw[c][r][s] += sum over output pixels of dy * x.  (Round 4 measured a workgroup per filter ROW -- blockIdx.z = r, K accumulators, 64-92
+// registers instead of 139-354: 1 247 -> 1 291 us per EfficientNet-b3 step, dy and x are then re-read K times from L2; not kept.)
 template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwGeom g, const float* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ dw) {
   constexpr int KK = K * K, NC = (kPW - 1) * S + K;
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int c = blockIdx.y * 64 + cl * 4;
-  const int r = blockIdx.z;
   const bool cok = c < g.C;
   const int OWB = (g.OW + kPW - 1) / kPW;
   const long nb = (long)g.N * g.OH * OWB;
-  float4 acc[K];
+  float4 acc[KK];
 #pragma unroll
-  for (int t = 0; t < K; ++t) acc[t] = zero4();
+  for (int t = 0; t < KK; ++t) acc[t] = zero4();
   if (cok) {
     for (long pb = (long)blockIdx.x * 16 + pl; pb < nb; pb += (long)gridDim.x * 16) {
-      const int owb = (int)(pb % OWB);
-      const long q = pb / OWB;
-      const int oh = (int)(q % g.OH), n = (int)(q / g.OH);
+      int owb, oh, n;
+      if (g.vorder) { oh = (int)(pb % g.OH); const long q = pb / g.OH; owb = (int)(q % OWB); n = (int)(q / OWB); }
+      else { owb = (int)(pb % OWB); const long q = pb / OWB; oh = (int)(q % g.OH); n = (int)(q / g.OH); }
       const int ow0 = owb * kPW;
-      const int ih = oh * S - g.pt + r;
-      if (ih < 0 || ih >= g.H) continue;              // (the whole row of taps falls outside the image: nothing to add)
       float4 d[kPW];
       {
         const float* dp = dy + (((size_t)n * g.OH + oh) * g.OW) * g.C + c;
@@ -219,38 +215,48 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwGeom g, const 
           d[p] = ok ? t : zero4();
         }
       }
-      float4 v[NC];
-      load_row<NC>(x + ((size_t)n * g.H + ih) * g.W * g.C + c, true, ow0 * S - g.pl, g.W, g.C, v);
 #pragma unroll
-      for (int s = 0; s < K; ++s)
+      for (int r = 0; r < K; ++r) {
+        const int ih = oh * S - g.pt + r;
+        const bool rowok = ih >= 0 && ih < g.H;
+        float4 v[NC];
+        load_row<NC>(x + ((size_t)n * g.H + (rowok ? ih : 0)) * g.W * g.C + c, rowok, ow0 * S - g.pl, g.W, g.C, v);
 #pragma unroll
-        for (int p = 0; p < kPW; ++p) acc[s] = fma4(d[p], v[p * S + s], acc[s]);
+        for (int s = 0; s < K; ++s)
+#pragma unroll
+          for (int p = 0; p < kPW; ++p) acc[r * K + s] = fma4(d[p], v[p * S + s], acc[r * K + s]);
+      }
     }
   }
-  // Fold the 16 pixel lanes: the 4 lanes of a wave with shuffles, the 4 waves through LDS (one barrier), then the K x 16 (tap, channel
-  // group) sums are spread over the threads for the atomics.
-  __shared__ float4 red[4][K][16];
+  // Fold the 16 pixel lanes: the 4 lanes of a wave with shuffles, the 4 waves through LDS (one barrier), then the k*k x 16
+  // (tap, channel group) sums are spread over the threads for the atomics (the first version walked the taps one by one:
+  // 2 barriers per tap and 100 atomics in a row from 16 threads).
+  __shared__ float4 red[4][KK][16];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-  for (int t = 0; t < K; ++t) {
+  for (int t = 0; t < KK; ++t) {
     float4 a = acc[t];
     a.x += __shfl_down(a.x, 32, 64); a.y += __shfl_down(a.y, 32, 64); a.z += __shfl_down(a.z, 32, 64); a.w += __shfl_down(a.w, 32, 64);
     a.x += __shfl_down(a.x, 16, 64); a.y += __shfl_down(a.y, 16, 64); a.z += __shfl_down(a.z, 16, 64); a.w += __shfl_down(a.w, 16, 64);
     if (lane < 16) red[wave][t][lane] = a;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < K * 16; e += 256) {
+  for (int e = threadIdx.x; e < KK * 16; e += 256) {
     const int t = e >> 4, l = e & 15;
     const int cc = blockIdx.y * 64 + l * 4;
     if (cc < g.C) {
       const float4 a0 = red[0][t][l], a1 = red[1][t][l], a2 = red[2][t][l], a3 = red[3][t][l];
-      float* o = dw + (size_t)cc * KK + r * K + t;
+      float* o = dw + (size_t)cc * KK + t;
       atomicAdd(o, (a0.x + a1.x) + (a2.x + a3.x)); atomicAdd(o + KK, (a0.y + a1.y) + (a2.y + a3.y));
       atomicAdd(o + 2 * KK, (a0.z + a1.z) + (a2.z + a3.z)); atomicAdd(o + 3 * KK, (a0.w + a1.w) + (a2.w + a3.w));
     }
   }
 }
 
+static int dw_vorder() {
+  static const int v = [] { const char* e = getenv("HIFIHR_DW_VORDER"); return e ? atoi(e) : 0; }();
+  return v;
+}
 static unsigned dw_grid_x(long nb, long cap) {
   long b = (nb + 15) / 16;
   if (b > cap) b = cap;
@@ -267,7 +273,9 @@ static unsigned dw_grid_x(long nb, long cap) {
     else return hipErrorInvalidValue;                                                                           \
   } while (0)
 
-hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, float* stats, hipStream_t st) {
+hipError_t launch_dwconv_fwd(const DwGeom& g_in, const float* x, const float* w, float* y, float* stats, hipStream_t st) {
+  DwGeom g = g_in;
+  g.vorder = dw_vorder();
   const long nb = (long)g.N * g.OH * ((g.OW + kPW - 1) / kPW);
   // with statistics every workgroup ends with 128 float atomics: bound (workgroups x channels) like bn.hip does
   static const long cap_stats = [] { const char* e = getenv("HIFIHR_DW_FWD_CAP"); return e && atol(e) > 0 ? atol(e) : 256L; }();
@@ -276,26 +284,25 @@ hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, fl
   HIFIHR_DW_DISPATCH(dwconv_fwd_kernel, grid, g, x, w, y, stats);
   return hipGetLastError();
 }
-hipError_t launch_dwconv_bwd_data(const DwGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
+hipError_t launch_dwconv_bwd_data(const DwGeom& g_in, const float* dy, const float* w, float* dx, hipStream_t st) {
+  DwGeom g = g_in;
+  g.vorder = dw_vorder();
   const long nb = (long)g.N * g.H * ((g.W + kPW - 1) / kPW);
   static const long cap_plain = [] { const char* e = getenv("HIFIHR_DW_CAP"); return e && atol(e) > 0 ? atol(e) : 2048L; }();
   const dim3 grid(dw_grid_x(nb, cap_plain), (g.C + 63) / 64);
   HIFIHR_DW_DISPATCH(dwconv_bwd_data_kernel, grid, g, dy, w, dx);
   return hipGetLastError();
 }
-hipError_t launch_dwconv_bwd_weight(const DwGeom& g, const float* x, const float* dy, float* dw, hipStream_t st) {
+hipError_t launch_dwconv_bwd_weight(const DwGeom& g_in, const float* x, const float* dy, float* dw, hipStream_t st) {
+  DwGeom g = g_in;
+  g.vorder = dw_vorder();
   const long nb = (long)g.N * g.OH * ((g.OW + kPW - 1) / kPW);
   // every workgroup ends with k*k x 64 atomics: give each pixel lane ~8 steps before that, between 8 and 128 workgroups per block
   long gx = nb / (16 * 8);
   if (const char* e = getenv("HIFIHR_DW_WGRAD_STEPS")) gx = nb / (16 * (atoi(e) > 0 ? atoi(e) : 8));
   if (gx < 8) gx = 8;
-  // cap: 128 workgroups per (channel block, tap row), more where that leaves the chip under-filled (24 / 40 channels: one block)
-  const long blocks = (long)((g.C + 63) / 64) * g.K;
-  long cap = 128;
-  static const long want = [] { const char* e = getenv("HIFIHR_DW_WGRAD_WGS"); return e && atol(e) > 0 ? atol(e) : 2048L; }();
-  if (cap * blocks < want) cap = (want + blocks - 1) / blocks;
-  if (gx > cap) gx = cap;
-  const dim3 grid((unsigned)gx, (g.C + 63) / 64, g.K);
+  if (gx > 128) gx = 128;
+  const dim3 grid((unsigned)gx, (g.C + 63) / 64);
   HIFIHR_DW_DISPATCH(dwconv_bwd_weight_kernel, grid, g, x, dy, dw);
   return hipGetLastError();
 }

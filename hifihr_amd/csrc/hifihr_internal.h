@@ -224,6 +224,9 @@ hipError_t launch_ssim_finish(const float* partial, int count, float scale, floa
 // depthwise convolution geometry: x[N][H][W][C] -> y[N][OH][OW][C], k x k taps, padding top/left = pt/pl
 struct DwGeom {
   int N, H, W, C, OH, OW, K, stride, pt, pl;
+  int vorder = 0;      // 1 (HIFIHR_DW_VORDER=1): pixel blocks numbered row-fastest -- the 16 pixel lanes of a workgroup are 16 consecutive ROWS of one
+                       // 4-pixel column block, whose windows share K - 1 of K input rows in L1.  Measured per EfficientNet-b3 step (tools/time_dwconv.py):
+                       // forward 940 -> 913 us, backward-data 750 -> 732, backward-weight 1 306 -> 1 506; single shapes +-25 % either way: off
 };
 hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, float* stats, hipStream_t st);
 hipError_t launch_dwconv_bwd_data(const DwGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
