@@ -68,7 +68,8 @@ __device__ __forceinline__ float act_grad(int act, float z, float y) {
 }
 
 // block-level reduction of the per-thread (sum, sumsq)-like pairs over the row lanes + slot-spread atomics
-__device__ __forceinline__ void reduce_and_add(const BnMap& mp, int C, float4 (&s)[kMaxNG], float4 (&q)[kMaxNG],
+template <int MNG>
+__device__ __forceinline__ void reduce_and_add(const BnMap& mp, int C, float4 (&s)[MNG], float4 (&q)[MNG],
                                                float4 (*lds)[256], float* __restrict__ out) {
   const int slot = blockIdx.x & (stat_slots_used(C) - 1);
   float* base = out + (size_t)slot * 2 * C;
@@ -82,7 +83,7 @@ __device__ __forceinline__ void reduce_and_add(const BnMap& mp, int C, float4 (&
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < kMaxNG; ++j) {
+    for (int j = 0; j < MNG; ++j) {
       const int cg = mp.cg0 + 256 * j;
       if (j < mp.NG && cg * 4 < C && mp.active) {
         atomic_add4(base + cg * 4, s[j]);
@@ -188,7 +189,9 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(float* __restrict_
 }
 
 // PRE = true: mean / invstd (forward) or the totals behind the slots (backward) were produced by a finalize launch
-template <bool PRE>
+// MNG: channel groups per thread the registers are sized for (1: C <= 1024 -- every ResNet layer -- 80-100 registers less than the
+// general form, i.e. 4-5 waves per SIMD instead of 2-3; kMaxNG: up to 4096 channels)
+template <bool PRE, int MNG>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ residual, int act, long M,
                                                         int C, float eps, float momentum, float* __restrict__ y, float* __restrict__ save_mean,
@@ -220,9 +223,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
   __syncthreads();
   if (mp.active) {
-    float4 scale[kMaxNG], shift[kMaxNG];
+    float4 scale[MNG], shift[MNG];
 #pragma unroll
-    for (int j = 0; j < kMaxNG; ++j) {
+    for (int j = 0; j < MNG; ++j) {
       const int cg = mp.cg0 + 256 * j;
       if (j < mp.NG && cg * 4 < C) {
         scale[j] = *reinterpret_cast<const float4*>(&s_sc[cg * 4]);
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     }
     for (; m < M; m += stride) {
 #pragma unroll
-      for (int j = 0; j < kMaxNG; ++j) {
+      for (int j = 0; j < MNG; ++j) {
         const int cg = mp.cg0 + 256 * j;
         if (j < mp.NG && cg * 4 < C) {
           const size_t o = (size_t)m * C + cg * 4;
@@ -298,6 +301,7 @@ __device__ __forceinline__ float4 masked_grad(int act, const float4& dy, bool ha
 }
 
 // red[kStatSlots][2][C] += (sum g, sum g * xhat)
+template <int MNG>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ x, const float* __restrict__ save_mean,
                                                            const float* __restrict__ save_invstd, const float* __restrict__ gamma,
@@ -305,9 +309,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                            float* __restrict__ red) {
   __shared__ float4 lds[2][256];
   const BnMap mp = bn_map(C);
-  float4 s[kMaxNG], q[kMaxNG], mu[kMaxNG], is[kMaxNG], sc[kMaxNG], sh[kMaxNG];
+  float4 s[MNG], q[MNG], mu[MNG], is[MNG], sc[MNG], sh[MNG];
 #pragma unroll
-  for (int j = 0; j < kMaxNG; ++j) {
+  for (int j = 0; j < MNG; ++j) {
     s[j] = make_float4(0.f, 0.f, 0.f, 0.f); q[j] = s[j]; mu[j] = s[j]; is[j] = s[j]; sc[j] = s[j]; sh[j] = s[j];
     const int cg = mp.cg0 + 256 * j;
     if (j < mp.NG && cg * 4 < C && mp.active) {
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
     for (; m < M; m += stride) {
 #pragma unroll
-      for (int j = 0; j < kMaxNG; ++j) {
+      for (int j = 0; j < MNG; ++j) {
         const int cg = mp.cg0 + 256 * j;
         if (j < mp.NG && cg * 4 < C) {
           const size_t o = (size_t)m * C + cg * 4;
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  dres = g (when the block has an identity branch).
 // Every workgroup folds the slot partials of the reduction into mean(g), mean(g * xhat) in LDS; workgroup 0 accumulates
 // dgamma / dbeta; the last workgroup to finish zeroes the slots.
-template <bool PRE>
+template <bool PRE, int MNG>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                           const float* __restrict__ x, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, const float* __restrict__ gamma,
@@ -391,9 +395,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
   __syncthreads();
   if (mp.active) {
-    float4 mu[kMaxNG], is[kMaxNG], k1[kMaxNG], mg[kMaxNG], mgx[kMaxNG], sh[kMaxNG];
+    float4 mu[MNG], is[MNG], k1[MNG], mg[MNG], mgx[MNG], sh[MNG];
 #pragma unroll
-    for (int j = 0; j < kMaxNG; ++j) {
+    for (int j = 0; j < MNG; ++j) {
       const int cg = mp.cg0 + 256 * j;
       if (j < mp.NG && cg * 4 < C) {
         mu[j] = *reinterpret_cast<const float4*>(save_mean + cg * 4);
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
     for (; m < M; m += stride) {
 #pragma unroll
-      for (int j = 0; j < kMaxNG; ++j) {
+      for (int j = 0; j < MNG; ++j) {
         const int cg = mp.cg0 + 256 * j;
         if (j < mp.NG && cg * 4 < C) {
           const size_t o = (size_t)m * C + cg * 4;
@@ -754,12 +758,16 @@ hipError_t launch_bn_act_fwd(const float* x, float* stats, const float* gamma, c
                              float* running_mean, float* running_var, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
   if (C <= kFuseMaxC) {
-    hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(bn_grid(M, C, true)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
+    if (C <= 1024) hipLaunchKernelGGL((bn_act_fwd_kernel<false, 1>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
+                       momentum, y, save_mean, save_invstd, running_mean, running_var);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<false, kMaxNG>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
                        momentum, y, save_mean, save_invstd, running_mean, running_var);
   } else {
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, M, C, eps, momentum, save_mean,
                        save_invstd, running_mean, running_var);
-    hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(bn_grid(M, C, false)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
+    if (C <= 1024) hipLaunchKernelGGL((bn_act_fwd_kernel<true, 1>), dim3(bn_grid(M, C, false)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
+                       momentum, y, save_mean, save_invstd, running_mean, running_var);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<true, kMaxNG>), dim3(bn_grid(M, C, false)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
                        momentum, y, save_mean, save_invstd, running_mean, running_var);
   }
   return hipGetLastError();
@@ -769,7 +777,9 @@ hipError_t launch_bn_act_fwd(const float* x, float* stats, const float* gamma, c
 hipError_t launch_bn_act_eval(const float* x, const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                               const float* residual, int act, long M, int C, float eps, float* y, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(bn_grid(M, C, false)), dim3(256), 0, st, x, (float*)nullptr, gamma, beta, residual, act, M, C,
+  if (C <= 1024) hipLaunchKernelGGL((bn_act_fwd_kernel<true, 1>), dim3(bn_grid(M, C, false)), dim3(256), 0, st, x, (float*)nullptr, gamma, beta, residual, act, M, C,
+                     eps, 0.f, y, const_cast<float*>(running_mean), const_cast<float*>(running_var), (float*)nullptr, (float*)nullptr);
+  else hipLaunchKernelGGL((bn_act_fwd_kernel<true, kMaxNG>), dim3(bn_grid(M, C, false)), dim3(256), 0, st, x, (float*)nullptr, gamma, beta, residual, act, M, C,
                      eps, 0.f, y, const_cast<float*>(running_mean), const_cast<float*>(running_var), (float*)nullptr, (float*)nullptr);
   return hipGetLastError();
 }
@@ -779,14 +789,20 @@ hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, co
                              float* dgamma_acc, float* dbeta_acc, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
   // red: kStatSlots slot partials + arrival counters (all zero on entry, all zero again on return)
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(bn_reduce_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta, act,
+  if (C <= 1024) hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(bn_reduce_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta, act,
+                     M, C, red);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<kMaxNG>), dim3(bn_reduce_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta, act,
                      M, C, red);
   if (C <= kFuseMaxC) {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_grid(M, C, true)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
+    if (C <= 1024) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 1>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
+                       red, act, M, C, dx, dres, dgamma_acc, dbeta_acc);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, kMaxNG>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
                        red, act, M, C, dx, dres, dgamma_acc, dbeta_acc);
   } else {
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, red, C, dgamma_acc, dbeta_acc);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_grid(M, C, false)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
+    if (C <= 1024) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, 1>), dim3(bn_grid(M, C, false)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
+                       red, act, M, C, dx, dres, dgamma_acc, dbeta_acc);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<true, kMaxNG>), dim3(bn_grid(M, C, false)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
                        red, act, M, C, dx, dres, dgamma_acc, dbeta_acc);
   }
   return hipGetLastError();
@@ -797,7 +813,9 @@ hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, co
 hipError_t launch_bn_bwd_apply(const float* g, const float* x, const float* save_mean, const float* save_invstd, const float* gamma, long M,
                                int C, float* red, float* dx, float* dgamma_acc, float* dbeta_acc, hipStream_t st) {
   if (!bn_c_ok(C) || C > kFuseMaxC) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_grid(M, C, true)), dim3(256), 0, st, g, (const float*)nullptr, x, save_mean, save_invstd,
+  if (C <= 1024) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 1>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, g, (const float*)nullptr, x, save_mean, save_invstd,
+                     gamma, (const float*)nullptr, red, 0, M, C, dx, (float*)nullptr, dgamma_acc, dbeta_acc);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, kMaxNG>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, g, (const float*)nullptr, x, save_mean, save_invstd,
                      gamma, (const float*)nullptr, red, 0, M, C, dx, (float*)nullptr, dgamma_acc, dbeta_acc);
   return hipGetLastError();
 }
