@@ -125,15 +125,15 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
   const int H = r.H, S = H * AA;
   const int px = blockIdx.x * kTile + (lane & 7) + 8 * (wave & 1), py = blockIdx.y * kTile + (lane >> 3) + 8 * (wave >> 1);
   const bool live = (px < H) && (py < H);
-  // face ids of this lane's samples; tiles without any covered sample leave at once
-  int fid[AA * AA];
+  // face ids of this lane's samples; tiles without any covered sample leave at once.  (The ids are read again inside the sample loop --
+  // L1 / L2 hits -- instead of being kept: the loop is not unrolled, see kRolled below.)
+  const int* const fid_px = face_id + ((size_t)b * S + (size_t)py * AA) * S + (size_t)px * AA;       // sample (0, 0) of this lane's pixel
   bool hit = false;
 #pragma unroll
   for (int i = 0; i < AA; ++i)
 #pragma unroll
     for (int j = 0; j < AA; ++j) {
-      const int f = live ? face_id[((size_t)b * S + (py * AA + i)) * S + (px * AA + j)] : -1;
-      fid[i * AA + j] = f;
+      const int f = live ? fid_px[(size_t)i * S + j] : -1;
       hit = hit || (f >= 0);
     }
   const unsigned long long hm = __ballot(hit);
@@ -171,13 +171,13 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
     fc.x0 = fc.y0 = fc.z0 = fc.x1 = fc.y1 = fc.z1 = fc.x2 = fc.y2 = fc.z2 = 0.f;
     float pos[3][3] = {}, nrm[3][3] = {}, col[3][3] = {};
     float fu[3] = {0.f, 0.f, 0.f}, fv[3] = {0.f, 0.f, 0.f};  // (UV) the face's three texture coordinates: loaded with the face
-#pragma unroll
-    for (int i = 0; i < AA; ++i) {
-      const float syi = pix_to_ndc(S - 1 - (py * AA + i), S);
-#pragma unroll
-      for (int j = 0; j < AA; ++j) {
-        const int f = fid[i * AA + j];
-        if (f < 0) continue;
+    // kRolled (TexturesUV only, below): the AA x AA sample loop is NOT unrolled.  Unrolled (round 3) the nine copies of the body cost 198 registers
+    // without and 296 with TexturesUV -- two, resp. ONE 256-thread workgroup per CU for a kernel that waits on LDS atomics and gathers.
+    auto sample = [&](int i, int j) {
+      {
+        const int f = fid_px[(size_t)i * S + j];
+        if (f < 0) return;
+        const float syi = pix_to_ndc(S - 1 - (py * AA + i), S);
         const float sxj = pix_to_ndc(S - 1 - (px * AA + j), S);
         if (f != cur) {
           if (cur >= 0) flush_face(A, gv, cidx, acc);
@@ -262,6 +262,17 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
           acc[k * 12 + 0] += gn[3 * k]; acc[k * 12 + 1] += gn[3 * k + 1]; acc[k * 12 + 2] += gn[3 * k + 2];
         }
       }
+    };
+    if constexpr (UV) {                                       // (rolled: 296 -> 234 registers, two workgroups per CU instead of one:
+#pragma unroll 1                                              //  NIMBLE-shaped mesh, B = 48: 465 -> 400 us)
+      for (int i = 0; i < AA; ++i)
+#pragma unroll 1
+        for (int j = 0; j < AA; ++j) sample(i, j);
+    } else {                                                  // (vertex colours: 198 registers unrolled, 188 rolled -- two workgroups per CU either
+#pragma unroll                                                //  way, and rolled measured 165 -> 176 us at B = 32)
+      for (int i = 0; i < AA; ++i)
+#pragma unroll
+        for (int j = 0; j < AA; ++j) sample(i, j);
     }
   }
   // The last run of every lane is flushed HERE, at a wave-uniform point -- and that is where the LDS atomics met 64 ways: the lanes of a
