@@ -128,12 +128,14 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
   // face ids of this lane's samples; tiles without any covered sample leave at once.  (The ids are read again inside the sample loop --
   // L1 / L2 hits -- instead of being kept: the loop is not unrolled, see kRolled below.)
   const int* const fid_px = face_id + ((size_t)b * S + (size_t)py * AA) * S + (size_t)px * AA;       // sample (0, 0) of this lane's pixel
+  int fid[AA * AA];                                          // (kept by the unrolled, vertex-colour form only)
   bool hit = false;
 #pragma unroll
   for (int i = 0; i < AA; ++i)
 #pragma unroll
     for (int j = 0; j < AA; ++j) {
       const int f = live ? fid_px[(size_t)i * S + j] : -1;
+      fid[i * AA + j] = f;
       hit = hit || (f >= 0);
     }
   const unsigned long long hm = __ballot(hit);
@@ -173,9 +175,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
     float fu[3] = {0.f, 0.f, 0.f}, fv[3] = {0.f, 0.f, 0.f};  // (UV) the face's three texture coordinates: loaded with the face
     // kRolled (TexturesUV only, below): the AA x AA sample loop is NOT unrolled.  Unrolled (round 3) the nine copies of the body cost 198 registers
     // without and 296 with TexturesUV -- two, resp. ONE 256-thread workgroup per CU for a kernel that waits on LDS atomics and gathers.
-    auto sample = [&](int i, int j) {
+    auto sample = [&](int i, int j, int f) {
       {
-        const int f = fid_px[(size_t)i * S + j];
         if (f < 0) return;
         const float syi = pix_to_ndc(S - 1 - (py * AA + i), S);
         const float sxj = pix_to_ndc(S - 1 - (px * AA + j), S);
@@ -267,12 +268,12 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
 #pragma unroll 1                                              //  NIMBLE-shaped mesh, B = 48: 465 -> 400 us)
       for (int i = 0; i < AA; ++i)
 #pragma unroll 1
-        for (int j = 0; j < AA; ++j) sample(i, j);
+        for (int j = 0; j < AA; ++j) sample(i, j, fid_px[(size_t)i * S + j]);
     } else {                                                  // (vertex colours: 198 registers unrolled, 188 rolled -- two workgroups per CU either
 #pragma unroll                                                //  way, and rolled measured 165 -> 176 us at B = 32)
       for (int i = 0; i < AA; ++i)
 #pragma unroll
-        for (int j = 0; j < AA; ++j) sample(i, j);
+        for (int j = 0; j < AA; ++j) sample(i, j, fid[i * AA + j]);
     }
   }
   // The last run of every lane is flushed HERE, at a wave-uniform point -- and that is where the LDS atomics met 64 ways: the lanes of a
