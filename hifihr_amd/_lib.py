@@ -140,6 +140,7 @@ class HifihrLib:
         c.hifihr_linear_bwd_group.argtypes = [POINTER(_LinearDesc), c_int, c_void_p]
         c.hifihr_wino_input_dy_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
         c.hifihr_conv2d_bwd_data_pre.argtypes = [_c_float_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_conv2d_bwd_data_pre_res.argtypes = [_c_float_p] * 4 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_weight_prep.argtypes = [c_void_p, c_int, c_int, c_void_p]
         c.hifihr_freihand_augment.argtypes = [c_void_p, c_void_p, _c_int_p, _c_int_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_ho3d_workspace_bytes.argtypes = [c_int, c_int]
@@ -176,6 +177,7 @@ class HifihrLib:
         c.hifihr_wino_output_transform_act_m.argtypes = [_c_float_p] * 3 + [c_int] * 6 + [c_void_p]
         c.hifihr_conv3x3_c64_wino_supported.argtypes = [c_int] * 5
         c.hifihr_conv3x3_c64_wino.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+        c.hifihr_conv3x3_c64_wino_res.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_wino_bn_input_supported.argtypes = [c_int, c_int]
         c.hifihr_wino_bn_input_transform.argtypes = [_c_float_p] * 7 + [c_int] * 5 + [c_float, c_float] + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_wino_output_transform_bnred.argtypes = [_c_float_p] * 10 + [c_int] * 5 + [c_void_p]
@@ -450,6 +452,10 @@ class HifihrLib:
         self.check(self.c.hifihr_conv3x3_c64_wino(_fp(x), _fp(U), _fp(bias), int(bool(relu)), _fp(y), _fp(stats), N, H, W, _stream_of(x)),
                    "hifihr_conv3x3_c64_wino")
 
+    def conv3x3_c64_wino_res(self, x, U, res, y, N, H, W):
+        """conv3x3_c64_wino with y = product + res (backward-data + the gradient of the input's other consumer; include/hifihr.h)."""
+        self.check(self.c.hifihr_conv3x3_c64_wino_res(_fp(x), _fp(U), _fp(res), _fp(y), N, H, W, _stream_of(x)), "hifihr_conv3x3_c64_wino_res")
+
     def wino_bn_input_supported(self, C, m):
         return bool(self.c.hifihr_wino_bn_input_supported(int(C), int(m)))
 
@@ -483,6 +489,12 @@ class HifihrLib:
         wsp, wsb = self._ws(ws)
         self.check(self.c.hifihr_conv2d_bwd_data_pre(_fp(dy), _fp(wt), _fp(dx), N, H, W, C, K, R, S, stride, pad, wsp, wsb, _stream_of(dy)),
                    "hifihr_conv2d_bwd_data_pre")
+
+    def conv2d_bwd_data_pre_res(self, dy, wt, res, dx, N, H, W, C, K, R, S, stride, pad, ws=None):
+        """conv2d_bwd_data_pre with dx = product + res (include/hifihr.h)."""
+        wsp, wsb = self._ws(ws)
+        self.check(self.c.hifihr_conv2d_bwd_data_pre_res(_fp(dy), _fp(wt), _fp(res), _fp(dx), N, H, W, C, K, R, S, stride, pad, wsp, wsb,
+                                                         _stream_of(dy)), "hifihr_conv2d_bwd_data_pre_res")
 
     @staticmethod
     def prep_jobs(jobs, device):

@@ -459,6 +459,16 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
       for (int j = 0; j < TN; ++j) {
         const int k = bn0 + wn * (BN / 2) + j * 32 + r31;
         float* col = dst + k;
+        if (g.residual != nullptr) {        // uniform (backward-data + the other consumer's gradient): all 16 loads first, one wait
+          float rv[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = bm0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            rv[e] = (m < M && k < g.OC) ? g.residual[(size_t)bz * g.dst_bs + (size_t)m * g.OC + k] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += rv[e];
+        }
         if (bias != nullptr) {              // uniform; the bias-free path below contains no load at all
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
@@ -516,6 +526,13 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int k = bn0 + wn * (BN / 2) + j * 32 + r31;
+        if (g.residual != nullptr) {        // uniform: the parity classes write disjoint pixels, each adds its own pixels' residual
+          float rv[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) rv[e] = (rok[e] && k < g.OC) ? g.residual[(size_t)bz * g.dst_bs + rowoff[e] + k] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += rv[e];
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e)
           if (rok[e] && k < g.OC) dst[rowoff[e] + k] = acc[i][j][e];
@@ -938,7 +955,9 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
   // the fast gather uses 32-bit element offsets (scaled by 4 in the address) and a 63-bit tap mask
   if ((long)g.N * g.IH * g.IW * g.IC >= (1L << 30) || (long)g.OC * g.R * g.S * g.IC >= (1L << 30)) return hipErrorInvalidValue;
-  if (conv_oc4_supported(g, bias, stats)) {
+  const bool res = g.residual != nullptr;                    // (only conv_igemm_kernel's epilogue adds one: the specialised kernels are skipped)
+  if (res && !g.dgrad) return hipErrorInvalidValue;
+  if (!res && conv_oc4_supported(g, bias, stats)) {
     const long M = (long)g.N * g.OH * g.OW;
     long blocks = (long)g.N * ((g.OH + 15) / 16) * ((g.OW + 15) / 16);     // 16 x 16-pixel tiles
     const long cap = (long)device_cus() * 16;              // grid-stride: the filter goes to LDS once per workgroup
@@ -948,7 +967,7 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
     return hipGetLastError();
   }
   // (the GEMM kernels have no activation epilogue: a fused ReLU keeps the implicit-GEMM kernel)
-  if (conv_is_gemm(g) && bias == nullptr && !g.relu && (stats == nullptr || bgemm_nt_stats_supported(g.OC))) {
+  if (!res && conv_is_gemm(g) && bias == nullptr && !g.relu && (stats == nullptr || bgemm_nt_stats_supported(g.OC))) {
     // 1x1 / stride 1: y[M][OC] = x[M][IC] . w[OC][IC]^T, and backward-data the same product on (dy, w^T): the GEMM kernels of
     // csrc/gemm.hip (bgemm_nt_rows_kernel: N % 128 == 0; the statistics of a batch-norm consumer come out of its epilogue)
     const long M = (long)g.N * g.OH * g.OW;
@@ -957,7 +976,7 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
     // kernel below takes the launch, as for the halo and stem kernels
     if (e != hipErrorNotReady) return e;
   }
-  if (conv_halo_supported(g, bias)) {
+  if (!res && conv_halo_supported(g, bias)) {
     if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_halo(g, src, wgt, bias, dst, stats, zeros, st);
   }
   if (conv_rows_supported(g, bias) && (stats == nullptr || bgemm_nt_stats_supported(g.OC))) {

@@ -414,6 +414,7 @@ struct Wino2Args {
   float* stats;         // forward statistics slots or null
   const float* zeros;
   const float* bias;    // [64] or null (EPI)
+  const float* res;     // [N][H][W][64] or null (EPI): added to the output (backward-data + the gradient of the input's other consumer)
   int relu;
   int N, H, W;
   int ctiles, total, per;
@@ -674,8 +675,14 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
       for (int c = 0; c < NCB; ++c) {
         const int ch = 16 * (cb0 + c) + 4 * g;
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 r4[4] = {b4, b4, b4, b4};
         if constexpr (EPI) {
           if (a.bias != nullptr) b4 = *reinterpret_cast<const float4*>(a.bias + ch);
+          if (a.res != nullptr) {                             // (uniform) the four loads of this column block in flight together
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+              r4[p] = *reinterpret_cast<const float4*>(a.res + (((size_t)t.n * a.H + t.y0 + 2 * ty2 + (p >> 1)) * a.W + t.x0 + 2 * tx2 + (p & 1)) * 64 + ch);
+          }
         }
         auto put = [&](float (&k4)[4], float (&s4)[4], float (&q4)[4], int& n) {
 #pragma unroll
@@ -683,7 +690,7 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
             float* o = a.dst + (((size_t)t.n * a.H + t.y0 + 2 * ty2 + (p >> 1)) * a.W + t.x0 + 2 * tx2 + (p & 1)) * 64 + ch;
             float4 v = make_float4(Y[p][c][0], Y[p][c][1], Y[p][c][2], Y[p][c][3]);
             if constexpr (EPI) {
-              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+              v.x += b4.x + r4[p].x; v.y += b4.y + r4[p].y; v.z += b4.z + r4[p].z; v.w += b4.w + r4[p].w;
               if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
             *reinterpret_cast<float4*>(o) = v;
@@ -1486,12 +1493,12 @@ bool conv_wino2_supported(int N, int H, int W, int C, int K) {
 }
 
 hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias, int relu, float* dst, float* stats, int N, int H, int W,
-                             hipStream_t st) {
+                             hipStream_t st, const float* res) {
   if (!conv_wino2_supported(N, H, W, 64, 64)) return hipErrorInvalidValue;
   const float* zeros = conv_halo_zero_page(st);
   if (zeros == nullptr) return hipErrorNotReady;
   Wino2Args a;
-  a.src = src; a.U = U; a.dst = dst; a.stats = stats; a.zeros = zeros; a.bias = bias; a.relu = relu;
+  a.src = src; a.U = U; a.dst = dst; a.stats = stats; a.zeros = zeros; a.bias = bias; a.relu = relu; a.res = res;
   a.N = N; a.H = H; a.W = W;
   a.ctiles = (W + kTW - 1) / kTW;                           // the last column tile may be ragged (W even: whole 2 x 2 tiles)
   a.total = N * a.ctiles * H;
@@ -1500,7 +1507,7 @@ hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias
   if (a.per < 4) a.per = 4;
   a.per = (a.per + 1) & ~1;                                  // even shares: every tile is whole 2 x 2 Winograd tiles
   G = (a.total + a.per - 1) / a.per;
-  if (bias != nullptr || relu) {
+  if (bias != nullptr || relu || res != nullptr) {
     if (stats != nullptr) hipLaunchKernelGGL((conv_wino2_kernel<true, true>), dim3(G), dim3(256 + 64 * kNL), 0, st, a);
     else hipLaunchKernelGGL((conv_wino2_kernel<true, false>), dim3(G), dim3(256 + 64 * kNL), 0, st, a);
   } else {

@@ -471,6 +471,17 @@ int hifihr_conv2d_bwd_data_pre(const float* dy, const float* wt, float* dx, int 
   return HIFIHR_OK;
 }
 
+int hifihr_conv2d_bwd_data_pre_res(const float* dy, const float* wt, const float* res, float* dx, int N, int H, int W, int C, int K, int R, int S,
+                                   int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !wt || !dx || !res || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || K % 4 || (K % 16 && stride != 1))
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_data_pre_res: bad argument (K % 4 == 0; K % 16 == 0 when stride > 1)");
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+  hifihr::ConvGeom g{N, OH, OW, K, H, W, C, R, S, stride, pad, 1};
+  g.residual = res;
+  HIP_TRY(hifihr::launch_conv_igemm(g, dy, wt, nullptr, dx, nullptr, ws, ws_bytes, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_weight_prep(const hifihr_prep_job* jobs, int njobs, int blocks_per_job, void* stream) {
   static_assert(sizeof(hifihr_prep_job) == sizeof(hifihr::PrepJob), "hifihr_prep_job layout");
   if (!jobs || njobs <= 0 || blocks_per_job <= 0) return fail(HIFIHR_EINVAL, "hifihr_weight_prep: bad argument");
@@ -1091,6 +1102,14 @@ int hifihr_conv3x3_c64_wino(const float* x, const float* u, const float* bias, i
   if (!hifihr::conv_wino2_supported(N, H, W, 64, 64))
     return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_wino: needs even H and even W >= 14 (or HIFIHR_CONV_WINO2=0 is set)");
   HIP_TRY(hifihr::launch_conv_wino2(x, u, bias, relu, y, stats, N, H, W, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_conv3x3_c64_wino_res(const float* x, const float* u, const float* res, float* y, int N, int H, int W, void* stream) {
+  if (!x || !u || !y || !res) return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_wino_res: null pointer");
+  if (!hifihr::conv_wino2_supported(N, H, W, 64, 64))
+    return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_wino_res: needs even H and even W >= 14 (or HIFIHR_CONV_WINO2=0 is set)");
+  HIP_TRY(hifihr::launch_conv_wino2(x, u, nullptr, 0, y, nullptr, N, H, W, (hipStream_t)stream, res));
   return HIFIHR_OK;
 }
 

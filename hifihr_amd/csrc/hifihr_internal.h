@@ -85,6 +85,10 @@ struct ConvGeom {
   // batched GEMM use (Winograd): `batch` independent problems of this geometry, element strides between them
   int batch;
   long src_bs, wgt_bs, dst_bs;
+  // backward-data only (conv_igemm_kernel's epilogue): dst = product + residual (dst's layout) -- the gradient of the OTHER consumer of the
+  // layer's input (a block's identity branch, a second convolution of the same tensor) added where this one is produced, instead of an
+  // elementwise pass over both afterwards (round 4; ops._Conv2dMFMA fork)
+  const float* residual = nullptr;
 };
 // sk_ws (may be NULL): zero-initialised, self-cleaning workspace of conv_sk_workspace_bytes(g) bytes for the balanced schedule
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
@@ -107,7 +111,7 @@ hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float
 // the same layers as Winograd F(2x2, 3x3) with the transforms in registers (conv_halo.hip: conv_wino2_kernel); U[16][64][64] = kind 1 / 2
 bool conv_wino2_supported(int N, int H, int W, int C, int K);
 hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias_or_null, int relu, float* dst, float* stats_or_null, int N,
-                             int H, int W, hipStream_t st);
+                             int H, int W, hipStream_t st, const float* res_or_null = nullptr);
 hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, const float* bias_or_null, float* dst, float* stats,
                             const float* zeros, hipStream_t st);
 // batch-norm (+ residual add + ReLU) on NHWC activations, x[M][C].  Statistics buffers are [kStatSlots][2][C]: partial

@@ -16,6 +16,7 @@ oracle/torch_modules.EfficientNetB3Ref (pinned by the reference's own network/ef
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -84,9 +85,9 @@ class PointwiseConvMFMA(nn.Module):
         self.weight = nn.Parameter(torch.empty(cout, cin, 1, 1).contiguous(memory_format=torch.channels_last))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))          # nn.Conv2d's default initialisation
 
-    def forward(self, x, want_stats=False):
+    def forward(self, x, want_stats=False, fork=False):
         from . import ops
-        return ops.conv2d(x, self.weight, 1, 0, want_stats)
+        return ops.conv2d(x, self.weight, 1, 0, want_stats, fork)
 
 
 class DepthwiseConvHIP(nn.Module):
@@ -111,10 +112,17 @@ def _bn(c):
     return nn.BatchNorm2d(c, momentum=_BN_MOM, eps=_BN_EPS)
 
 
-def _conv_bn_swish(conv, bn, x, act=True):
+def _conv_bn_swish(conv, bn, x, act=True, fork=False):
     """conv -> BN -> swish: batch statistics from the convolution's epilogue in training mode (none requested in evaluation mode:
-    only a training batch-norm consumes and cleans the slot buffer), BN + swish one fused launch."""
+    only a training batch-norm consumes and cleans the slot buffer), BN + swish one fused launch.  fork: -> (result, alias of x for x's
+    other consumer -- the block's skip connection; its gradient is added inside the convolution's backward-data launch, ops._Conv2dMFMA)."""
     from . import ops
+    if fork:
+        if bn.training:
+            y, st, xa = conv(x, want_stats=True, fork=True)
+        else:
+            (y, xa), st = conv(x, fork=True), None
+        return ops.bn_act(y, st, bn, None, "swish" if act else None), xa
     if bn.training:
         y, st = conv(x, want_stats=True)
     else:
@@ -140,9 +148,16 @@ class MBConvBlock(nn.Module):
 
     def forward(self, inputs, drop_connect_rate=None):
         x = inputs
-        if self.expand != 1:
-            x = _conv_bn_swish(self._expand_conv, self._bn0, x)
         from . import ops
+        if self.expand != 1:
+            # (the skip connection's gradient joins the expand convolution's backward-data launch -- which then runs on conv_igemm_kernel,
+            #  the only epilogue that adds one, instead of the row-share GEMM: config 3 35.09 / 35.14 -> 35.05 / 35.06 ms/step and 19 launches
+            #  fewer; HIFIHR_EFFNET_FORK=0 leaves the sum to autograd)
+            skip = self.stride == 1 and self.cin == self.cout
+            if skip and inputs.requires_grad and torch.is_grad_enabled() and os.environ.get("HIFIHR_EFFNET_FORK", "1") != "0":
+                x, inputs = _conv_bn_swish(self._expand_conv, self._bn0, x, fork=True)
+            else:
+                x = _conv_bn_swish(self._expand_conv, self._bn0, x)
         x = _conv_bn_swish(self._depthwise_conv, self._bn1, x)             # statistics from the depthwise kernel's epilogue
         x = ops.squeeze_excite(x, self._se_reduce, self._se_expand)        # pool + 2 small linears + scale, fused
         x = _conv_bn_swish(self._project_conv, self._bn2, x, act=False)

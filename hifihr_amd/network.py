@@ -46,13 +46,13 @@ class Conv2dMFMA(nn.Module):
             bound = 1.0 / (cin * k * k) ** 0.5
             self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
 
-    def forward(self, x, want_stats=False, grad_premasked=False, mask_input_grad=False):
+    def forward(self, x, want_stats=False, grad_premasked=False, mask_input_grad=False, fork=False):
         from . import ops
         w = self.weight          # the 3-channel stem: the input arrives as NHWC4; ops.conv2d pads the filter (and un-pads its gradient)
         if self.bias is not None:
             return ops.conv2d_bias_act(x, w, self.bias, self.stride, self.pad, self.relu,   # conv + bias (+ ReLU), one launch
                                        grad_premasked=grad_premasked and not self.bias.requires_grad, mask_input_grad=mask_input_grad)
-        return ops.conv2d(x, w, self.stride, self.pad, want_stats)
+        return ops.conv2d(x, w, self.stride, self.pad, want_stats, fork)
 
 
 def _conv(cin, cout, k, stride, pad):
@@ -65,6 +65,19 @@ def _conv_bn(conv, x, bn):
     if bn.training:
         return conv(x, want_stats=True)
     return conv(x), None
+
+
+def _conv_bn_fork(conv, x, bn):
+    """_conv_bn for an x that has a second consumer: -> (conv(x), statistics or None, the alias of x that consumer must read) -- its
+    gradient is then added inside the convolution's backward-data launch (ops._Conv2dMFMA, `fork`)."""
+    from . import ops
+    if not (x.requires_grad and torch.is_grad_enabled() and ops.conv_fork_enabled()):
+        out, st = _conv_bn(conv, x, bn)
+        return out, st, x
+    if bn.training:
+        return conv(x, want_stats=True, fork=True)
+    out, xa = conv(x, fork=True)
+    return out, None, xa
 
 
 class _PendingBN:
@@ -106,9 +119,9 @@ class BasicBlock(nn.Module):
                 out, st, x = ops.bn_act_wino_conv(p.y, p.stats, p.bn, p.identity, self.conv1.weight, self.bn1.training)
             else:
                 x = p.materialize()
-                out, st = _conv_bn(self.conv1, x, self.bn1)
+                out, st, x = _conv_bn_fork(self.conv1, x, self.bn1)       # (x: from here on the alias the identity branch reads)
         else:
-            out, st = _conv_bn(self.conv1, x, self.bn1)
+            out, st, x = _conv_bn_fork(self.conv1, x, self.bn1)
         if st is not None and ops.bn_wino_fusable(out, self.conv2.weight, self.bn1, 1, 1):
             out, st, _ = ops.bn_act_wino_conv(out, st, self.bn1, None, self.conv2.weight, self.bn2.training)
         else:

@@ -634,8 +634,12 @@ def _stem_c3_wgrad(lib, ctx, x, gy):
 
 class _Conv2dMFMA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, pad, want_stats=False, bias=None, relu=False, grad_premasked=False, mask_input_grad=False):
-        """grad_premasked (relu=True, frozen bias): the gradient reaches this layer ALREADY multiplied by [y > 0] -- its consumer applied
+    def forward(ctx, x, w, stride, pad, want_stats=False, bias=None, relu=False, grad_premasked=False, mask_input_grad=False, fork=False):
+        """fork (round 4): the input has a SECOND consumer (a residual block's identity branch, the downsample convolution of a stage's first
+        block).  The function then returns an alias of x as an extra output; that consumer reads the alias, its gradient comes back to THIS
+        backward and is added where the backward-data product is stored (hifihr_conv3x3_c64_wino_res / hifihr_conv2d_bwd_data_pre_res)
+        instead of in an elementwise pass of autograd's (5 of them per ResNet-18 step: 52 us).
+        grad_premasked (relu=True, frozen bias): the gradient reaches this layer ALREADY multiplied by [y > 0] -- its consumer applied
         this layer's ReLU backward where it produced the gradient (a convolution with mask_input_grad, or a max-pool with relu_input).
         mask_input_grad: x is a ReLU's output; dx is returned multiplied by [x > 0] (fused into the F(4x4, 3x3) output transform of the
         backward-data product, else one bias_relu_bwd pass), so the producer of x can be told grad_premasked.  (VGG19 of the perceptual
@@ -645,6 +649,8 @@ class _Conv2dMFMA(torch.autograd.Function):
         x = x.contiguous(memory_format=_CL)
         wk = w.contiguous(memory_format=_CL)                      # physical [K][R][S][C]
         ctx.grad_premasked, ctx.mask_input_grad = bool(grad_premasked), bool(mask_input_grad)
+        ctx.fork, ctx.want_stats = bool(fork), bool(want_stats)
+        assert not (fork and mask_input_grad), "fork and mask_input_grad are not combined"
         ctx.wino_allowed = _wino_allowed()                        # the backward runs outside any conv_precision scope: it follows the forward
         N, C, H, W = x.shape
         K, Cw, R, S = wk.shape
@@ -698,18 +704,24 @@ class _Conv2dMFMA(torch.autograd.Function):
         ctx.save_for_backward(x if (v_saved is None or mask_input_grad) else None, wk, y if (relu and not grad_premasked) else None, v_saved)
         ctx.w_param, ctx.b_param, ctx.relu = w, bias, relu
         ctx.set_materialize_grads(False)         # no zero-fill launch for the (non-differentiable) stats output
+        outs = [y]
         if want_stats:
             ctx.mark_non_differentiable(stats)
-            return y, stats
-        return y
+            outs.append(stats)
+        if fork:
+            outs.append(x.view_as(x))
+        return tuple(outs) if len(outs) > 1 else y
 
     @staticmethod
-    def backward(ctx, gy, _gstats=None):
+    def backward(ctx, gy, *rest):
         x, wk, y, v_saved = ctx.saved_tensors
         lib = get_lib()
         N, H, W, C, K, R, S, stride, pad = ctx.geom
+        g_fork = rest[-1] if (getattr(ctx, "fork", False) and rest) else None      # gradient of the input's other consumer (None: it had none; _CtxShim: no fork)
+        if g_fork is not None:
+            g_fork = g_fork.contiguous(memory_format=_CL)
         if gy is None:
-            return (None,) * 7
+            return (g_fork,) + (None,) * 9
         gy = gy.contiguous(memory_format=_CL)
         dx = dw = db_ret = Yt_done = None
         if ctx.relu or ctx.b_param is not None:
@@ -748,6 +760,8 @@ class _Conv2dMFMA(torch.autograd.Function):
                     lib.weight_transpose(wk, wt, K, R * S, C)
                     _wino_conv(lib, gy, wt, dx, None, N, H, W, K, C, 1, dy_out=Yt_done, tile=tile, mask=mk)
             PROFILE.bracket("conv_dgrad_wino", run)
+            if g_fork is not None:
+                dx = dx + g_fork
         elif ctx.needs_input_grad[0] and ctx.w3 is None and _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad, ctx.wino_allowed) and \
                 _WEIGHT_PREP.get(ctx.w_param, wk, 2) is not None:
             # 64 -> 64: the same one-launch Winograd kernel on dy with U' (kind 2: transposed, rotated filter)
@@ -755,18 +769,25 @@ class _Conv2dMFMA(torch.autograd.Function):
             U2 = _WEIGHT_PREP.get(ctx.w_param, wk, 2)
             if PROFILE.on:
                 PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "dgrad-wino2"))
-            PROFILE.bracket("conv_dgrad", lambda: lib.conv3x3_c64_wino(gy, U2, None, False, dx, None, N, H, W))
+            if g_fork is not None:
+                PROFILE.bracket("conv_dgrad", lambda: lib.conv3x3_c64_wino_res(gy, U2, g_fork, dx, N, H, W))
+            else:
+                PROFILE.bracket("conv_dgrad", lambda: lib.conv3x3_c64_wino(gy, U2, None, False, dx, None, N, H, W))
         elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=_CL)
             ws = _conv_ws(lib, x.device, (N, H, W, C, K, R, S, stride, pad), True)
             if PROFILE.on:
                 PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "dgrad"))
             wt = _WEIGHT_PREP.get(ctx.w_param, wk, 0)
-            if wt is not None:                     # [C][R][S][K] transpose from the step's weight_prep launch
+            if wt is not None and g_fork is not None:
+                PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data_pre_res(gy, wt, g_fork, dx, N, H, W, C, K, R, S, stride, pad, ws=ws))
+            elif wt is not None:                   # [C][R][S][K] transpose from the step's weight_prep launch
                 PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data_pre(gy, wt, dx, N, H, W, C, K, R, S, stride, pad, ws=ws))
             else:
                 scratch = torch.empty(wk.numel(), device=x.device, dtype=torch.float32)
                 PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data(gy, wk, dx, scratch, N, H, W, C, K, R, S, stride, pad, ws=ws))
+                if g_fork is not None:
+                    dx = dx + g_fork
         if ctx.mask_input_grad and dx is not None and not masked:
             dxm = torch.empty_like(dx, memory_format=_CL)
             PROFILE.bracket("bias_relu_bwd", lambda: lib.bias_relu_bwd(dx, x, dx.numel() // C, C, dxm, None))
@@ -822,7 +843,9 @@ class _Conv2dMFMA(torch.autograd.Function):
                 go()
             if dw is None:
                 _grad_ready(w)
-        return dx, dw, None, None, None, db_ret, None, None, None
+        if dx is None and g_fork is not None:
+            dx = g_fork
+        return dx, dw, None, None, None, db_ret, None, None, None, None
 
 
 def conv2d_bias_act(x, w, bias, stride=1, pad=0, relu=True, grad_premasked=False, mask_input_grad=False):
@@ -836,10 +859,16 @@ def conv2d_bias_relu(x, w, bias, stride=1, pad=0):
     return conv2d_bias_act(x, w, bias, stride, pad, True)
 
 
-def conv2d(x, w, stride=1, pad=0, want_stats=False):
+def conv2d(x, w, stride=1, pad=0, want_stats=False, fork=False):
     """F.conv2d(x, w, None, stride, pad) for channels_last fp32 tensors (reference network/res_encoder.py:364-373).
-    want_stats=True additionally returns the [2,K] (sum, sum of squares) of the output for `bn_act`."""
-    return _Conv2dMFMA.apply(x, w, stride, pad, want_stats)
+    want_stats=True additionally returns the [2,K] (sum, sum of squares) of the output for `bn_act`; fork=True an alias of x as the
+    LAST output, for x's other consumer (see _Conv2dMFMA.forward)."""
+    return _Conv2dMFMA.apply(x, w, stride, pad, want_stats, None, False, False, False, fork)
+
+
+def conv_fork_enabled():
+    """HIFIHR_CONV_FORK=0: residual blocks leave the sum of their input's two gradients to autograd (the A/B switch of `fork`)."""
+    return os.environ.get("HIFIHR_CONV_FORK", "1") != "0"
 
 
 class _BNAct(torch.autograd.Function):

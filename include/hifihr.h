@@ -322,6 +322,10 @@ int hifihr_conv3x3_c64_wino_supported(int N, int H, int W, int C, int K);
 int hifihr_zero_page_ready(void* stream);
 int hifihr_conv3x3_c64_wino(const float* x_d, const float* u_d, const float* bias_d /* or NULL */, int relu, float* y_d,
                             float* stats_d /* or NULL */, int N, int H, int W, void* stream);
+/* The same launch with y = product + res_d[N][H][W][64] (round 4).  Backward-data of a layer whose input has a SECOND consumer -- the
+ * identity branch of a residual block (reference torchvision BasicBlock: `out += identity`, network/res_encoder.py:364-373): autograd adds
+ * the two gradients of that input in an elementwise pass of its own; here the other consumer's gradient is added where this one is produced. */
+int hifihr_conv3x3_c64_wino_res(const float* x_d, const float* u_d, const float* res_d, float* y_d, int N, int H, int W, void* stream);
 /* Batch-norm fused into the F(4x4, 3x3) input transform (round 3, csrc/wino4_bn.hip).  For a BatchNorm2d whose consumer is a Winograd
  * convolution (reference BasicBlock: conv1 -> bn1 -> relu -> conv2; bn2 -> += identity -> relu -> the next block's conv1,
  * network/res_encoder.py:364-373 + vendored utils/Freihand_GNN_mano/network/resnet.py) this ONE launch replaces hifihr_bn_act_fwd followed by
@@ -387,6 +391,10 @@ int hifihr_weight_transpose(const float* w_d, float* wt_d, int K, int RS, int C,
 /* hifihr_conv2d_bwd_data on weights that are ALREADY transposed to [C][R][S][K] (hifihr_weight_transpose / hifihr_weight_prep). */
 int hifihr_conv2d_bwd_data_pre(const float* dy_d, const float* wt_d, float* dx_d, int N, int H, int W, int C, int K, int R, int S,
                                int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
+/* dx = backward-data + res_d[N][H][W][C] (round 4; see hifihr_conv3x3_c64_wino_res): the first block of a ResNet stage sends its input to
+ * the strided 3x3 convolution AND the 1x1 downsample convolution -- the second backward-data adds the first one's result as it stores. */
+int hifihr_conv2d_bwd_data_pre_res(const float* dy_d, const float* wt_d, const float* res_d, float* dx_d, int N, int H, int W, int C, int K,
+                                   int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
 /* Every per-step weight re-layout of a model in ONE launch.  The weights change once per optimizer step; a ResNet-18 step
  * otherwise spends ~40 tiny launches (~5 us of launch floor each) on transposes and Winograd weight transforms.
  * jobs_d: DEVICE array of njobs descriptors (src / dst are device pointers);

@@ -24,4 +24,7 @@ run "layer-1 halo weight gradient off (HIFIHR_CONV_HALO_WGRAD=0)" HIFIHR_CONV_HA
 run "Winograd F(2x2) instead of F(4x4) (HIFIHR_WINO_M=2)" HIFIHR_WINO_M=2
 run "no Winograd at all (HIFIHR_WINOGRAD=0)" HIFIHR_WINOGRAD=0
 run "stem kernel off (HIFIHR_CONV_STEM=0)" HIFIHR_CONV_STEM=0
+run "plain F(4x4) tile geometry, no mosaic (HIFIHR_WINO_MOSAIC=0)" HIFIHR_WINO_MOSAIC=0
+run "F(4x4) weight-gradient transform of small layers, narrow form (HIFIHR_WINO_DW_WIDE=0)" HIFIHR_WINO_DW_WIDE=0
+run "strided forward convolutions on the implicit GEMM (HIFIHR_CONV_ROWS=0)" HIFIHR_CONV_ROWS=0
 run "eager launches, no hipGraph (--graph 0)" --graph 0

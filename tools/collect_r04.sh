@@ -31,5 +31,8 @@ python3 tools/time_wino_bn.py 2>&1 | grep "H =" > $O/r04_time_wino_bn.txt
 python3 tools/time_conv_wino2.py 2>&1 | grep -v amdgpu.ids > $O/r04_time_conv_wino2.txt
 if [ -f tools/_probe/libhifihr_halo_stamp.so ]; then python3 tools/wino2_stamp.py 2>&1 | grep -v amdgpu.ids > $O/r04_wino2_stamps.txt; fi
 if [ -f tools/_probe/libhifihr_render_stamp2.so ]; then python3 tools/render_stamp2.py 2>&1 | grep -v amdgpu.ids > $O/r04_render_fwd_phase_stamps.txt; fi
+python3 tools/time_dwconv.py 2>/dev/null > $O/r04_time_dwconv.txt
+# trunk gradient error vs the reference by dispatch (README "Precision of the default dispatch")
+python3 -m pytest tests/test_gpu_conv.py -q -s -k "precision_reference_knob or gradient_error_by_dispatch" 2>&1 | grep -E "fixture|HIFIHR_|passed|failed" > $O/r04_precision_by_dispatch.txt
 if [ "${1:-}" != quick ]; then bash tools/ablation.sh > $O/r04_ablation.txt 2>&1; fi
 ls -la $O | tail -40
