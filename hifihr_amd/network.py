@@ -377,4 +377,7 @@ class LightEstimator(nn.Module):
         flat = base.reshape(base.shape[0], -1)
         lights = ops.linear(ops.linear(flat, self.light_reg[0], act=True), self.light_reg[2])
         # the reference checks `torch.any(colors.isnan())` here with a host sync every step (:205); omitted on purpose
+        if lights.is_cuda and lights.requires_grad:
+            colors, directions = ops.light_split(lights)           # hardtanh + the two slices as one autograd node (ops._LightSplit)
+            return {"colors": colors, "directions": directions}
         return {"colors": self.hardtanh(lights[:, :3]), "directions": lights[:, 3:]}

@@ -1538,6 +1538,30 @@ def texture_pca_decode(coef, basis, mean=None):
     return _TexturePCA.apply(coef, basis, mean)
 
 
+class _LightSplit(torch.autograd.Function):
+    """lights [B, 6] -> (hardtanh(lights[:, :3]), lights[:, 3:]) as two CONTIGUOUS tensors (reference network/res_encoder.py:205-210:
+    `colors = self.hardtanh(lights[:, :3]); directions = lights[:, 3:]`).  As separate autograd nodes the two slices cost seven launches
+    in the backward (hardtanh_backward, two slice_backward = zero fill + copy each, the sum of the two) and a contiguous() copy of the
+    direction slice in the renderer; here: two launches forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, lights):
+        x3 = lights[:, :3]
+        ctx.save_for_backward(x3)
+        return torch.clamp(x3, -1.0, 1.0), lights[:, 3:].contiguous()
+
+    @staticmethod
+    def backward(ctx, gc, gd):
+        x3, = ctx.saved_tensors
+        gc = torch.zeros_like(x3) if gc is None else torch.ops.aten.hardtanh_backward(gc, x3, -1.0, 1.0)
+        gd = torch.zeros_like(x3) if gd is None else gd
+        return torch.cat([gc, gd], 1)
+
+
+def light_split(lights):
+    return _LightSplit.apply(lights)
+
+
 def affine(x, w, b):
     """x[B, I] . w[O, I]^T + b[O] with constant (buffer) w and b, one launch of the small-batch linear kernel."""
     return _Linear.apply(x, w, b, None, None, 0, 0.0, 0.0, None, None)

@@ -107,6 +107,9 @@ def data_dic(sample, dat_name, set_name, args, device="cuda", image_size=224):
     return ex
 
 
+_BACKWARD_SEED = {}
+
+
 def forward_backward(model, loss_func, optimizer, examples, args, dat_name="FreiHand"):
     """Forward, losses, zero_grad and backward of one iteration (train_hrnet.py:50-104).  Returns (loss, loss_dic)."""
     from .ops import prepared_weights
@@ -135,7 +138,10 @@ def _forward_backward(model, loss_func, optimizer, examples, args, dat_name):
     loss = terms[0] if len(terms) == 1 else torch.stack(terms).sum()      # 2 launches instead of a chain of adds
     loss_dic["loss"] = loss
     optimizer.zero_grad(set_to_none=True)
-    loss.backward()
+    seed = _BACKWARD_SEED.get(loss.device)             # d loss / d loss = 1: a constant kept per device (autograd's ones_like is a fill launch per step)
+    if seed is None or seed.dtype != loss.dtype or seed.shape != loss.shape:
+        seed = _BACKWARD_SEED[loss.device] = torch.ones_like(loss)
+    loss.backward(seed)
     return loss, loss_dic
 
 
