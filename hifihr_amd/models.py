@@ -97,9 +97,9 @@ class Model(nn.Module):
                  ifLight=True, mano_tables: ManoTables | None = None, image_size=224, aa_factor=3, texture_stand_in=0,
                  nimble_tables: NimbleTables | None = None, conv_precision="fast"):
         """conv_precision: "fast" (default) -- the encoder's stride-1 3x3 convolutions run as Winograd F(4x4, 3x3) / F(2x2, 3x3); "reference"
-        -- on the direct kernels, whose outputs round like a plain fp32 convolution: the trunk's gradient then stays within ~5e-4 of the
-        reference's instead of ~5e-3 (the ReLU sign flips of README "Precision of the default dispatch") for ~40 % more time per step.
-        Per model, not per process."""
+        -- on the direct kernels, whose outputs round like a plain fp32 convolution: features within 5e-6 of the reference's instead of
+        1.3e-5, for ~50 % more time per step.  The trunk's GRADIENT error against the reference (~1e-2 of a gradient's maximum on the
+        batch-of-8 fixture: ReLU sign flips) does not shrink with it (README "Precision of the default dispatch").  Per model, not per process."""
         super().__init__()
         ops.conv_precision(conv_precision)               # (validates the name)
         self.conv_precision = conv_precision

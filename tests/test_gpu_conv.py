@@ -120,9 +120,13 @@ def _b8_errors(golden_dir, precision="fast"):
 
 def test_conv_precision_reference_knob_reaches_reference_grade_gradients(golden_dir):
     """`conv_precision("reference")` (what `Model(conv_precision="reference")` wraps its encoder in) sends the stride-1 3x3 layers to the direct
-    kernels IN THIS PROCESS, per call site: on the batch-of-8 fixture the fourteen stored gradients then agree with the reference's to
-    <= 1.5e-3 of their maximum / 1e-3 relative L2 (observed 2e-4 .. 6e-4: no Winograd rounding, far fewer ReLU sign flips), against the
-    1e-2 the default dispatch is held to.  The default is measured beside it, so the trade is on file with every run."""
+    kernels IN THIS PROCESS, per call site.  MEASURED on the batch-of-8 fixture (profiles/r04_precision_by_dispatch.txt): the features
+    then agree with the reference's to 5e-6 of their maximum instead of 1.3e-5 -- but the fourteen stored gradients do NOT get closer:
+    worst max error 1.1e-2 / relative L2 8.9e-3 on the direct kernels against 8.1e-3 / 7.9e-3 on the default dispatch (and 6.3e-3 with
+    F(2x2) everywhere).  The gradient differences are ReLU sign flips of pre-activations within rounding distance of zero, and ANY fp32
+    summation order other than the reference's own flips a handful of them -- the direct MFMA kernels' order as much as Winograd's.  What
+    pins the backward arithmetic is test_resnet18_trunk_backward_given_the_same_relu_pattern (2e-4).  Both dispatches are measured here so
+    that the numbers are on file with every run."""
     m_ref, l2_ref, f_ref = _b8_errors(golden_dir, "reference")
     m_fast, l2_fast, f_fast = _b8_errors(golden_dir, "fast")
     print(f"batch-of-8 trunk fixture, worst of 14 gradients vs the reference (max / max|ref|, relative L2), feature error / max: "
@@ -133,9 +137,10 @@ def test_conv_precision_reference_knob_reaches_reference_grade_gradients(golden_
 
 @pytest.mark.parametrize("env,max_tol,l2_tol", [({"HIFIHR_WINO_M": "2"}, 2e-2, 1e-2), ({"HIFIHR_WINOGRAD": "0"}, 2e-2, 1e-2)])
 def test_trunk_gradient_error_by_dispatch_switch(golden_dir, env, max_tol, l2_tol):
-    """What the process-wide switches buy on the same fixture (a subprocess per setting: HIFIHR_WINO_M is read once by the library):
-    F(2x2, 3x3) everywhere (HIFIHR_WINO_M=2, +0.5 ms/step) and no Winograd at all (HIFIHR_WINOGRAD=0, +2.8 ms/step).  The errors are
-    printed and asserted at what they reach; README "Precision of the default dispatch" holds the table."""
+    """The process-wide switches on the same fixture (a subprocess per setting: HIFIHR_WINO_M is read once by the library): F(2x2, 3x3)
+    everywhere (HIFIHR_WINO_M=2, +0.6 ms/step) and no Winograd at all (HIFIHR_WINOGRAD=0, +2.9 ms/step).  Measured: 6.3e-3 / 6.5e-3 and
+    1.1e-2 / 8.9e-3 (max / relative L2) -- no dispatch brings the gradients closer than ~6e-3 on this fixture; README "Precision of the
+    default dispatch" holds the table."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import json, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_conv as t; "
