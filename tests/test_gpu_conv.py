@@ -550,3 +550,28 @@ def test_stem_kernels_at_batch_32(lib):
     assert lib.conv2d_describe(32, 224, 224, 4, 64, 7, 7, 2, 3, 0) == "conv_stem_kernel"
     assert lib.conv2d_describe(32, 224, 224, 4, 64, 7, 7, 2, 3, 2) == "conv_stem_wgrad_kernel"
     kc.conv_case(lib, "cuda", 32, 224, 224, 4, 64, 7, 2, 3, seed=3, zero_last_channel=True, rtol=3e-5)
+
+
+def test_conv_fork_residual_sum_equals_autograd_sum(monkeypatch):
+    """ops._Conv2dMFMA(fork=True): the gradient of a block input's second consumer added inside the backward-data launch (conv_wino2_kernel /
+    conv_igemm_kernel epilogues) gives the SAME parameter gradients as autograd's own elementwise sum (HIFIHR_CONV_FORK=0): same operands,
+    one rounding either way."""
+    import torch
+    from hifihr_amd import ops
+    from hifihr_amd.network import Resnet_4C
+    torch.manual_seed(3)
+    x = torch.randn(4, 3, 224, 224)
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HIFIHR_CONV_FORK", mode)
+        torch.manual_seed(5)
+        enc = Resnet_4C("res18").cuda().train()
+        low, feat = enc(ops.image_to_nhwc4(x.cuda()))
+        (low.square().mean() + feat.square().mean()).backward()
+        grads[mode] = {n: p.grad.detach().clone() for n, p in enc.named_parameters() if p.grad is not None}
+    assert grads["1"].keys() == grads["0"].keys() and len(grads["1"]) > 40
+    for n in grads["1"]:
+        a, b = grads["1"][n], grads["0"][n]
+        # (not bit-identical: the batch-norm reductions and weight gradients in between use float atomics, whose order differs run to run --
+        #  ~1e-5 of a gradient's maximum between two runs of the SAME mode; a wrong residual sum would be O(1))
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-12, n

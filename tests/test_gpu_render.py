@@ -90,3 +90,9 @@ def test_render_textures_uv(lib, synth_tables, B, image_size, aa):
 def test_render_textures_uv_border_padding(lib, synth_tables):
     """uvs outside [0, 1] (border padding: clamped coordinate, no uv gradient there) and a tiny odd-sized texture."""
     kc.render_uv_case(lib, synth_tables, "cuda", B=2, seed=97, image_size=96, aa=3, TH=9, TW=5, rgb_atol=1e-4, uv_scale=1.5)
+
+
+def test_render_textures_uv_texel_table_overflow(lib, synth_tables):
+    """A texture fine enough that a 16 x 16-pixel tile of the backward touches more distinct texels than its LDS table holds (2 048 slots:
+    csrc/render_bwd.hip TexAcc): the texels that find the table full go out as global atomics -- same gradients either way."""
+    kc.render_uv_case(lib, synth_tables, "cuda", B=2, seed=131, image_size=224, aa=3, TH=512, TW=512, rgb_atol=1e-4)

@@ -294,3 +294,27 @@ def test_hand_encoder_module_matches_torch_restatement(B, in_dim, train):
 def test_texture_pca_decode(lib, B, K, n):
     """csrc/texpca.hip: the stand-in's 778 x 3 vertex colours and UV-map sizes (NIMBLE's texture maps are 1024^2 [recalled])."""
     kc.texture_pca_case(lib, "cuda", B, K, n, seed=K + B)
+
+
+def test_light_split_matches_hardtanh_and_slices():
+    """ops.light_split (one autograd node for `hardtanh(lights[:, :3])`, `lights[:, 3:]`, reference network/res_encoder.py:205-210) against
+    the plain torch expression, values and gradients; outputs contiguous (the renderer takes them without a copy)."""
+    import torch
+    from hifihr_amd import ops
+    torch.manual_seed(0)
+    x = (torch.randn(32, 6, device="cuda") * 2).requires_grad_(True)
+    c, d = ops.light_split(x)
+    assert c.is_contiguous() and d.is_contiguous()
+    wc, wd = torch.randn_like(c), torch.randn_like(d)
+    ((c * wc).sum() + (d * wd).sum()).backward()
+    g = x.grad.clone(); x.grad = None
+    c2, d2 = torch.nn.functional.hardtanh(x[:, :3]), x[:, 3:]
+    ((c2 * wc).sum() + (d2 * wd).sum()).backward()
+    assert torch.equal(c, c2) and torch.equal(d, d2) and torch.equal(g, x.grad)
+
+
+@pytest.mark.parametrize("B,K,n", [(48, 10, 64 * 64 * 3), (5, 10, 512 * 512 * 3), (48, 30, 80)])
+def test_texture_pca_backward_batch_tiles(lib, B, K, n):
+    """texpca_bwd_kernel's (pieces of n, batch tiles) grid: one image per workgroup for a small texture, tiles of images for a large one,
+    a batch that does not divide into the tiles."""
+    kc.texture_pca_case(lib, "cuda", B, K, n, seed=B + K)

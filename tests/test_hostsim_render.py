@@ -75,3 +75,8 @@ def test_render_fwd3_equals_second_form(hostsim_lib, synth_tables, monkeypatch):
         np.testing.assert_allclose(rgba.numpy(), rgba_ref.numpy(), atol=2e-5, rtol=0)
     finally:
         hostsim_lib.renderer_destroy(h)
+
+
+def test_render_textures_uv_texel_table_overflow(hostsim_lib, synth_tables):
+    """More distinct texels per backward tile than the LDS table has slots (csrc/render_bwd.hip TexAcc): the overflow path (global atomics)."""
+    kc.render_uv_case(hostsim_lib, synth_tables, "cpu", B=1, seed=43, image_size=32, aa=3, TH=384, TW=384)
