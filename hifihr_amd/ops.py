@@ -428,7 +428,13 @@ def _wino_ok(C, K, R, S, stride, pad, allowed=None):
     conv_precision("reference") disable).  `allowed`: the mode a convolution recorded in its forward (its backward must follow it)."""
     if not (_wino_allowed() if allowed is None else allowed):
         return False
-    return R == 3 and S == 3 and stride == 1 and pad == 1 and C >= 128 and K >= 128 and C % 32 == 0 and K % 32 == 0
+    if not (R == 3 and S == 3 and stride == 1 and pad == 1 and C % 32 == 0 and K % 32 == 0):
+        return False
+    # both sides >= 128 channels -- or (round 4) 64 on one side and >= 128 on the other: VGG19's conv2_1 (64 -> 128 at 112 x 112, three
+    # launches of 858 us on the implicit GEMM per config-3 step; HIFIHR_WINO_MIXED=0 keeps it there).  64 -> 64 is conv_wino2_kernel's.
+    if C >= 128 and K >= 128:
+        return True
+    return min(C, K) >= 64 and max(C, K) >= 128 and os.environ.get("HIFIHR_WINO_MIXED", "1") != "0"
 
 
 def _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad, allowed=None):
