@@ -896,6 +896,101 @@ __global__ __launch_bounds__(256) void conv3x3_oc4_kernel(const float* __restric
   }
 }
 
+// The same convolution with the input HALO of an output tile staged in LDS (round 4).  The kernel above re-reads every input pixel for each
+// of its nine taps, and a 16 x 16-pixel tile of 64 channels (65 KB) does not fit the 32 KB L1: the nine reads go to L2 -- 9 x 616 MB at
+// batch 48, 682 us where the tensors' single pass is 131 us at 5 TB/s.  Here a workgroup stages the 18 x 10-pixel halo of a 16 x 8-pixel
+// output tile once (57.6 KB at a pitch of 80 floats per pixel: the two teams of an 8-lane LDS access land in different banks; zeros
+// outside the image), two workgroups per CU so that one stages while the other multiplies, and the taps read LDS.  Same lane roles (four
+// lanes per output pixel, a quarter of the channels each), same filter image, same summation order per lane as the kernel above.
+template <int IC>
+__global__ __launch_bounds__(256) void conv3x3_oc4_tile_kernel(const float* __restrict__ src, const float* __restrict__ wgt, float* __restrict__ dst,
+                                                              int N, int H, int W, int sign) {
+  constexpr int QC = IC / 4, QS = 36 * QC + 4;
+  constexpr int TW = 16, TH = 8, HP = TW + 2, HR = TH + 2, PS = IC + 16;      // tile, halo pitch (pixels), halo rows, floats per halo pixel
+  constexpr int U = TH / 4;                                                  // output rows per lane (wave w: rows U w .. U w + U - 1)
+  constexpr int SEG = IC / 4;                                                // float4 per pixel
+  constexpr int NL = (HR * HP * SEG + 255) / 256;                            // staging loads per thread
+  __shared__ __attribute__((aligned(16))) float wl[4 * QS];
+  __shared__ __attribute__((aligned(16))) float hl[HR * HP * PS];
+  for (int i = threadIdx.x; i < 4 * 36 * QC; i += 256) {
+    const int j = i % QC, c = (i / QC) & 3, tap = (i / (4 * QC)) % 9, q = i / (36 * QC);
+    wl[q * QS + (tap * 4 + c) * QC + j] = wgt[((size_t)c * 9 + tap) * IC + 16 * (j >> 2) + 4 * q + (j & 3)];
+  }
+  const int q = threadIdx.x & 3;
+  const float* wq = wl + q * QS;
+  const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
+  const long tiles = (long)N * ty * tx;
+  const int t = (threadIdx.x & 63) >> 2, wv_ = threadIdx.x >> 6;
+  for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int txi = (int)(tile % tx);
+    const long r2 = tile / tx;
+    const int tyi = (int)(r2 % ty), n = (int)(r2 / ty);
+    const int x0 = txi * TW, y0 = tyi * TH;
+    // ---- stage the halo: every load of the tile in flight, then the LDS stores ----
+    float4 hv[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      const int px = e / SEG, seg = e - px * SEG;
+      const int hy = px / HP, hx = px - hy * HP;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = e < HR * HP * SEG && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const float4 tv = *reinterpret_cast<const float4*>(src + (((size_t)n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * IC + seg * 4);
+      hv[k] = ok ? tv : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();                                        // (the previous tile's taps are read; first trip: the filter image is written)
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      if (e < HR * HP * SEG) {
+        const int px = e / SEG, seg = e - px * SEG;
+        *reinterpret_cast<float4*>(&hl[px * PS + seg * 4]) = hv[k];
+      }
+    }
+    __syncthreads();
+    float acc[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.f;
+#pragma unroll 3
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, s = tap - 3 * r;
+      const int hx = t + 1 + (sign > 0 ? s - 1 : 1 - s);
+      float4 v[U][QC / 4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int hy = U * wv_ + u + 1 + (sign > 0 ? r - 1 : 1 - r);
+        const float* hp = hl + (hy * HP + hx) * PS + 4 * q;
+#pragma unroll
+        for (int j = 0; j < QC / 4; ++j) v[u][j] = *reinterpret_cast<const float4*>(hp + 16 * j);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4* wp = reinterpret_cast<const float4*>(wq + (tap * 4 + c) * QC);
+#pragma unroll
+        for (int j = 0; j < QC / 4; ++j) {
+          const float4 wv = wp[j];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            acc[u][c] = __builtin_fmaf(v[u][j].x, wv.x, acc[u][c]); acc[u][c] = __builtin_fmaf(v[u][j].y, wv.y, acc[u][c]);
+            acc[u][c] = __builtin_fmaf(v[u][j].z, wv.z, acc[u][c]); acc[u][c] = __builtin_fmaf(v[u][j].w, wv.w, acc[u][c]);
+          }
+        }
+      }
+    }
+    const int x = x0 + t;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[u][c] += __shfl_xor(acc[u][c], 1, 64);
+        acc[u][c] += __shfl_xor(acc[u][c], 2, 64);
+      }
+      const int y = y0 + U * wv_ + u;
+      if (x < W && y < H) dst[(((size_t)n * H + y) * W + x) * 4 + q] = q == 0 ? acc[u][0] : q == 1 ? acc[u][1] : q == 2 ? acc[u][2] : acc[u][3];
+    }
+  }
+}
+
 static bool conv_oc4_supported(const ConvGeom& g, const float* bias, const float* stats) {
   static const int on = [] { const char* e = getenv("HIFIHR_CONV_OC4"); return e ? atoi(e) : 1; }();
   return on && g.OC == 4 && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && (g.IC == 64 || g.IC == 32) && g.batch <= 1 && !g.relu &&
@@ -962,7 +1057,12 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
     long blocks = (long)g.N * ((g.OH + 15) / 16) * ((g.OW + 15) / 16);     // 16 x 16-pixel tiles
     const long cap = (long)device_cus() * 16;              // grid-stride: the filter goes to LDS once per workgroup
     if (blocks > cap) blocks = cap;
-    if (g.IC == 64) hipLaunchKernelGGL(conv3x3_oc4_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, src, wgt, dst, g.N, g.OH, g.OW, g.dgrad ? -1 : 1);
+    static const int tiled = [] { const char* e = getenv("HIFIHR_OC4_TILE"); return e ? atoi(e) : 1; }();
+    if (g.IC == 64 && tiled) {
+      long tb = (long)g.N * ((g.OH + 7) / 8) * ((g.OW + 15) / 16);             // 16 x 8-pixel tiles, two workgroups per CU
+      if (tb > (long)device_cus() * 2) tb = (long)device_cus() * 2;
+      hipLaunchKernelGGL(conv3x3_oc4_tile_kernel<64>, dim3((unsigned)tb), dim3(256), 0, st, src, wgt, dst, g.N, g.OH, g.OW, g.dgrad ? -1 : 1);
+    } else if (g.IC == 64) hipLaunchKernelGGL(conv3x3_oc4_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, src, wgt, dst, g.N, g.OH, g.OW, g.dgrad ? -1 : 1);
     else hipLaunchKernelGGL(conv3x3_oc4_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, src, wgt, dst, g.N, g.OH, g.OW, g.dgrad ? -1 : 1);
     return hipGetLastError();
   }
