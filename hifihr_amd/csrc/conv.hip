@@ -770,7 +770,11 @@ static SkPlan sk_plan(const ConvGeom& g) {
   const int slots = device_cus() * p.v.occ;
   int minch = kSkMinChunks;
   if (const char* e = getenv("HIFIHR_CONV_SK_MINCH")) minch = atoi(e);
-  if (p.nch * p.v.bk < minch * 32 || p.tiles < slots / 4) return p;
+  // (fewer tiles than a quarter of the slots stay data-parallel: the balanced schedule for EfficientNet's 7 x 7 / 14 x 14 pointwise layers --
+  //  37-150 tiles -- measured 34.04 vs 33.82 ms per config-3 step, HIFIHR_CONV_SK_TILEDIV=32: the workspace round trip costs more than the
+  //  idle CUs; those products are bound by each workgroup streaming the whole weight panel for 16-64 rows)
+  static const int min_tile_div = [] { const char* e = getenv("HIFIHR_CONV_SK_TILEDIV"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
+  if (p.nch * p.v.bk < minch * 32 || p.tiles < slots / min_tile_div) return p;
   // rounds the data-parallel grid costs vs the balanced share: only switch when > 5 % is on the table
   const double dp = (double)((p.tiles + slots - 1) / slots), sk = (double)p.tiles / slots;
   if (dp < 1.05 * sk && p.v.bm == 64) return p;
