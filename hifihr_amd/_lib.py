@@ -66,6 +66,7 @@ class HifihrLib:
                 f"(or `make -C hifihr_amd/csrc`). The HIP extension is mandatory; there is no fallback path.")
         self.path = path
         self.c = ctypes.CDLL(path)
+        self._zero_page = set()                # devices whose zero page exists (zero_page_ready)
         c = self.c
         c.hifihr_last_error.restype = c_char_p
         c.hifihr_version.restype = c_int
@@ -441,8 +442,18 @@ class HifihrLib:
         self.check(self.c.hifihr_wino_input_transform_m(_fp(x), _fp(V), N, H, W, C, m, _stream_of(x)), "hifihr_wino_input_transform")
 
     def zero_page_ready(self, device=None):
+        """The 256 zero bytes the halo / Winograd kernels read out-of-image pixels from exist on `device` (allocated at the first call
+        OUTSIDE a stream capture; the steppers call this before they capture).  A positive answer is cached per device."""
         import torch
-        return bool(self.c.hifihr_zero_page_ready(c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        idx = torch.cuda.current_device() if idx is None else idx
+        if idx in self._zero_page:
+            return True
+        with torch.cuda.device(idx):
+            ok = bool(self.c.hifihr_zero_page_ready(c_void_p(torch.cuda.current_stream(idx).cuda_stream)))
+        if ok:
+            self._zero_page.add(idx)
+        return ok
 
     def conv3x3_c64_wino_supported(self, N, H, W, C, K):
         return bool(self.c.hifihr_conv3x3_c64_wino_supported(int(N), int(H), int(W), int(C), int(K)))

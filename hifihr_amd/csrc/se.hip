@@ -275,12 +275,18 @@ hipError_t launch_se_mlp_bwd(float* dgate_acc, const float* gate, const float* z
   if (!se_mlp_supported(C, SQ)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(se_mlp_bwd_x_kernel, dim3(B), dim3(kSeThreads), 0, st, dgate_acc, gate, z1, W2T, C, SQ, dz2, dz1);
   const size_t lds = (size_t)(2 * kSeWB * SQ + 2 * kSeWB * kSeWC + SQ * kSeWC) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(se_mlp_bwd_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((2 * kSeWB * kSeMaxSQ + 2 * kSeWB * kSeWC + kSeMaxSQ * kSeWC) * sizeof(float)));
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  // the attribute is per DEVICE: a process-wide "already set" flag left the second GPU of a process without it; a launch that fits the
+  // default 64 KB needs no attribute at all (and nothing is then issued inside a stream capture)
+  if (lds > 64 * 1024) {
+    static bool attr_set[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidValue;
+    if (!attr_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(se_mlp_bwd_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)((2 * kSeWB * kSeMaxSQ + 2 * kSeWB * kSeWC + kSeMaxSQ * kSeWC) * sizeof(float)));
+      if (e != hipSuccess) return e;
+      attr_set[dev] = true;
+    }
   }
   hipLaunchKernelGGL(se_mlp_bwd_w_kernel, dim3((C + kSeWC - 1) / kSeWC), dim3(256), lds, st, dz2, dz1, h1, mean, W1, B, C, SQ, dmean, dW1_acc, db1_acc,
                      dW2_acc, db2_acc);

@@ -11,6 +11,7 @@ large enough to run at link bandwidth.  Works unchanged on the gloo backend (CPU
 """
 from __future__ import annotations
 
+import datetime
 import os
 
 import torch
@@ -19,8 +20,10 @@ import torch.distributed as dist
 from .optim import FlatParams
 
 
-def init_process_group_from_env(backend: str | None = None):
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, local_rank, world)."""
+def init_process_group_from_env(backend: str | None = None, timeout_min: float | None = None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, local_rank, world).
+    `timeout_min` (or HIFIHR_DIST_TIMEOUT_MIN): the process group's collective timeout.  Every collective runs under it, barriers
+    included, so it must cover the longest stretch one rank works alone (rank 0's evaluation pass between epochs)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -31,7 +34,10 @@ def init_process_group_from_env(backend: str | None = None):
             backend = os.environ.get("HIFIHR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if timeout_min is None and os.environ.get("HIFIHR_DIST_TIMEOUT_MIN"):
+            timeout_min = float(os.environ["HIFIHR_DIST_TIMEOUT_MIN"])
+        kw = {} if timeout_min is None else {"timeout": datetime.timedelta(minutes=float(timeout_min))}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
 

@@ -5,6 +5,7 @@ Every op here runs ONLY on the GPU through libhifihr.so; a CPU tensor raises (th
 from __future__ import annotations
 
 import os
+import threading
 
 import torch
 
@@ -394,15 +395,27 @@ def _wino_scratch(device, name, numel):
     return t
 
 
-_CONV_PRECISION = ["fast"]
+class _PrecisionStack(threading.local):                # one stack per THREAD: a scope entered in one thread never changes another's dispatch
+    def __init__(self):
+        self.stack = ["fast"]
+
+
+_CONV_PRECISION = _PrecisionStack()
+_WINOGRAD_ENV = os.environ.get("HIFIHR_WINOGRAD", "1") != "0"          # read once: the process-wide switch (tests set it per subprocess)
 
 
 class conv_precision:
     """`with conv_precision("reference"):` -- the convolutions called inside run on the DIRECT kernels (implicit GEMM / halo), no Winograd
     transform arithmetic: their outputs then round like a plain fp32 convolution (1e-6 of max |y| instead of Winograd F(4x4, 3x3)'s 1e-5),
     which keeps the ReLU pattern -- and with it the trunk's gradient -- on the reference's side of the discontinuity (README, "Precision of
-    the default dispatch").  "fast" (default): Winograd where it pays.  Per call site, not per process: `Model(conv_precision=...)` wraps its
-    encoder in it; each convolution remembers the mode of its forward for its backward.  (HIFIHR_WINOGRAD=0 is the process-wide form.)"""
+    the default dispatch").  "fast" (default): Winograd where it pays.  Per call site and per thread, not per process: `Model(conv_precision=...)`
+    wraps its encoder in it; each convolution remembers the mode of its forward for its backward.  (HIFIHR_WINOGRAD=0, read at import, is the
+    process-wide form.)
+
+    What the knob buys, MEASURED (profiles/r04_precision_by_dispatch.txt, batch-of-8 ResNet-18 fixture): "reference" costs +2.95 ms per
+    B = 32 step (5.4 -> 8.3 ms) and brings the FEATURES 2.5 x closer to the reference's (5e-6 of their maximum instead of 1.3e-5); the trunk
+    GRADIENTS do not get closer (worst 1.1e-2 against 8.1e-3 on the default dispatch): those differences are ReLU sign flips that any fp32
+    summation order other than the reference's own produces.  Use it for feature-level comparisons, not to chase gradient parity."""
 
     def __init__(self, mode):
         if mode not in ("fast", "reference"):
@@ -410,16 +423,16 @@ class conv_precision:
         self.mode = mode
 
     def __enter__(self):
-        _CONV_PRECISION.append(self.mode)
+        _CONV_PRECISION.stack.append(self.mode)
         return self
 
     def __exit__(self, *exc):
-        _CONV_PRECISION.pop()
+        _CONV_PRECISION.stack.pop()
         return False
 
 
 def _wino_allowed():
-    return _CONV_PRECISION[-1] != "reference" and os.environ.get("HIFIHR_WINOGRAD", "1") != "0"
+    return _WINOGRAD_ENV and _CONV_PRECISION.stack[-1] != "reference"
 
 
 def _wino_ok(C, K, R, S, stride, pad, allowed=None):
@@ -437,11 +450,11 @@ def _wino_ok(C, K, R, S, stride, pad, allowed=None):
     return min(C, K) >= 64 and max(C, K) >= 128 and os.environ.get("HIFIHR_WINO_MIXED", "1") != "0"
 
 
-def _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad, allowed=None):
+def _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad, allowed=None, device=None):
     """The 64 -> 64 stride-1 3x3 layers (ResNet layer 1, VGG19 conv1_2) as register-resident Winograd F(2x2, 3x3), one launch
     (hifihr_conv3x3_c64_wino; HIFIHR_CONV_WINO2=0 keeps them on the direct halo kernel)."""
     return (R == 3 and S == 3 and stride == 1 and pad == 1 and C == 64 and K == 64 and (_wino_allowed() if allowed is None else allowed)
-            and lib.conv3x3_c64_wino_supported(N, H, W, C, K) and lib.zero_page_ready())   # (no zero page inside a capture: the halo kernel)
+            and lib.conv3x3_c64_wino_supported(N, H, W, C, K) and lib.zero_page_ready(device))   # (no zero page inside a capture: the halo kernel)
 
 
 _WINO_TILE = {}
@@ -678,7 +691,7 @@ class _Conv2dMFMA(torch.autograd.Function):
         wino = _wino_ok(C, K, R, S, stride, pad) and not (want_stats and (bias is not None or relu))
         v_saved = None
         # 64 -> 64: Winograd with the transforms in registers, when the step's weight_prep launch has U (kind 1) ready
-        U64 = _WEIGHT_PREP.get(w, wk, 1) if (Cw == C and _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad)
+        U64 = _WEIGHT_PREP.get(w, wk, 1) if (Cw == C and _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad, device=x.device)
                                              and not (want_stats and (bias is not None or relu))) else None
         if U64 is not None:
             stats = _ZERO_POOL.acquire(lib.bn_stats_floats(K), x.device) if want_stats else None
@@ -768,7 +781,7 @@ class _Conv2dMFMA(torch.autograd.Function):
             PROFILE.bracket("conv_dgrad_wino", run)
             if g_fork is not None:
                 dx = dx + g_fork
-        elif ctx.needs_input_grad[0] and ctx.w3 is None and _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad, ctx.wino_allowed) and \
+        elif ctx.needs_input_grad[0] and ctx.w3 is None and _wino2_fused_ok(lib, N, H, W, C, K, R, S, stride, pad, ctx.wino_allowed, device=gy.device) and \
                 _WEIGHT_PREP.get(ctx.w_param, wk, 2) is not None:
             # 64 -> 64: the same one-launch Winograd kernel on dy with U' (kind 2: transposed, rotated filter)
             dx = torch.empty_like(x, memory_format=_CL)

@@ -110,6 +110,28 @@ def data_dic(sample, dat_name, set_name, args, device="cuda", image_size=224):
 _BACKWARD_SEED = {}
 
 
+def _backward_seed(loss):
+    """d loss / d loss = 1 as a constant kept per device (autograd's own ones_like is a fill launch per step).  Never CREATED inside a
+    stream capture: there the fill would only be recorded and the tensor would live in that graph's private pool -- later graphs and
+    eager steps would read memory that holds 1.0 only after the first graph has replayed.  The steppers create it before they capture
+    (`_prime_for_capture`); a capture that still finds the cache empty gets autograd's default seed (None)."""
+    seed = _BACKWARD_SEED.get(loss.device)
+    if seed is None or seed.dtype != loss.dtype or seed.shape != loss.shape:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        seed = _BACKWARD_SEED[loss.device] = torch.ones_like(loss)
+    return seed
+
+
+def _prime_for_capture(device):
+    """What a capture must find ready (neither may be allocated while capturing): the backward seed and the library's zero page."""
+    from ._lib import get_lib
+    dev = torch.device(device)
+    if dev not in _BACKWARD_SEED:
+        _BACKWARD_SEED[dev] = torch.ones((), device=dev, dtype=torch.float32)
+    get_lib().zero_page_ready(dev)
+
+
 def forward_backward(model, loss_func, optimizer, examples, args, dat_name="FreiHand"):
     """Forward, losses, zero_grad and backward of one iteration (train_hrnet.py:50-104).  Returns (loss, loss_dic)."""
     from .ops import prepared_weights
@@ -138,10 +160,7 @@ def _forward_backward(model, loss_func, optimizer, examples, args, dat_name):
     loss = terms[0] if len(terms) == 1 else torch.stack(terms).sum()      # 2 launches instead of a chain of adds
     loss_dic["loss"] = loss
     optimizer.zero_grad(set_to_none=True)
-    seed = _BACKWARD_SEED.get(loss.device)             # d loss / d loss = 1: a constant kept per device (autograd's ones_like is a fill launch per step)
-    if seed is None or seed.dtype != loss.dtype or seed.shape != loss.shape:
-        seed = _BACKWARD_SEED[loss.device] = torch.ones_like(loss)
-    loss.backward(seed)
+    loss.backward(_backward_seed(loss))
     return loss, loss_dic
 
 
@@ -195,6 +214,7 @@ class GraphedTrainStep:
             optimizer.enable_graph_mode()
         try:
             _injected_capture_failure()
+            _prime_for_capture(flat.flat.device)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                       # warm-up on a side stream (allocator / workspace growth)
@@ -306,6 +326,7 @@ class SegmentedGraphedTrainStep:
         self._scope = None
         try:
             _injected_capture_failure()                        # (test hook: the one-sided failure of tests/test_gpu_dp.py)
+            _prime_for_capture(flat.flat.device)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):

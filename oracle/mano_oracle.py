@@ -9,7 +9,7 @@ It restates, in plain torch-CPU ops so that autograd supplies the reference grad
   * dense_pose_Trainer.xyz_from_vertice    reference utils/Freihand_GNN_mano/Freihand_trainer_mano_fullsup.py:175-215
   * root-relative step of Model.forward    reference models_res_nimble.py:160-166
 
-Pinned: tests/test_oracle_golden.py checks it against tests/golden/mano_*.npz, which
+Pinned: tests/test_oracle_mano.py checks it against tests/golden/mano_*.npz, which
 tools/make_golden.py produced by running the reference's own ManoLayer in the build container.
 """
 from __future__ import annotations

@@ -118,7 +118,7 @@ def _b8_errors(golden_dir, precision="fast"):
     return max(worst.values()), max(l2.values()), ferr
 
 
-def test_conv_precision_reference_knob_reaches_reference_grade_gradients(golden_dir):
+def test_conv_precision_knob_feature_and_gradient_errors_of_both_dispatches(golden_dir):
     """`conv_precision("reference")` (what `Model(conv_precision="reference")` wraps its encoder in) sends the stride-1 3x3 layers to the direct
     kernels IN THIS PROCESS, per call site.  MEASURED on the batch-of-8 fixture (profiles/r04_precision_by_dispatch.txt): the features
     then agree with the reference's to 5e-6 of their maximum instead of 1.3e-5 -- but the fourteen stored gradients do NOT get closer:

@@ -10,7 +10,23 @@ import kernel_cases as kc
 pytestmark = pytest.mark.gpu
 
 
-def _setup(B):
+def graded_images(imgs):
+    """Uniform-noise images differ from one another only in their noise, so the pooled features of the samples of a batch are
+    nearly equal and the head's BatchNorm1d divides by a tiny across-sample variance: a 1e-7 rounding difference becomes 1e-4 of
+    the loss.  Real photographs are not like that.  Give every sample its own brightness, contrast and a low-frequency ramp of
+    its own orientation (still in [0, 1)), which conditions the batch statistics the way distinct photographs do."""
+    B, _, H, W = imgs.shape
+    i = torch.arange(B, dtype=torch.float32).view(B, 1, 1, 1)
+    gain = 0.25 + 0.6 * i / max(B - 1, 1)
+    ang = 2.399963 * i                                                   # golden angle: orientations spread over the circle
+    yy = torch.linspace(-1, 1, H).view(1, 1, H, 1); xx = torch.linspace(-1, 1, W).view(1, 1, 1, W)
+    ramp = 0.5 + 0.5 * (torch.cos(ang) * xx + torch.sin(ang) * yy) / 1.4143
+    tint = torch.stack([0.5 + 0.5 * torch.cos(ang.view(B) + c * 2.0944) for c in range(3)], 1).view(B, 3, 1, 1)
+    out = gain * imgs.cpu() + (1 - gain) * ramp * tint
+    return out.clamp_(0, 0.999999).to(imgs.device)
+
+
+def _setup(B, graded=False):
     from hifihr_amd import options, synth
     from hifihr_amd.mano_tables import synthetic_mano_tables
     from hifihr_amd.models import Model
@@ -25,6 +41,8 @@ def _setup(B):
     missing, unexpected = ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=False)
     assert not missing, missing
     sample = synth.make_batch(model.hand_layer.handle, model.renderer_p3d, B, first_index=0, device=dev)
+    if graded:
+        sample["trans_images"] = graded_images(sample["trans_images"])
     ex = data_dic(sample, "FreiHand", "training", args, device=dev)
     ex_cpu = {k: v.cpu() for k, v in ex.items()}
     return tables, args, model, ref, ex, ex_cpu
@@ -148,6 +166,30 @@ def test_ssim_kernel_full_size(golden_dir):
     assert float((ac.grad - ar.grad).abs().max()) <= 5e-4 * float(ar.grad.abs().max())
 
 
+# Bounds of the graph-vs-eager tests, against what tools/noise_floor.py MEASURES between two EAGER replicas that start from identical
+# weights (gpurun_out/noise_*.txt, round 5; float-atomic ordering in backward, which Adam turns into +-lr steps of the weights whose
+# gradient is rounding noise):
+#   uniform-noise images, B = 8:  loss spread 1.6e-5 / 2.6e-4 / 5.4e-4 after 1 / 2 / 3 steps -- the old 2e-4 bound sat INSIDE the noise
+#   graded images (graded_images), B = 8:  5.9e-6 / 6.7e-6 / 9.2e-6;  graph vs eager 1.9e-6 / 5.5e-6 / 4.2e-6 / 1.1e-5
+# so the tests run on graded images and assert 2e-4: >= 18 x the worst graph-vs-eager value observed.  Every comparison prints
+# observed / bound.
+_GRAPH_LOSS_RTOL = 2e-4
+
+
+def _check(tag, observed, bound):
+    print(f"[margin] {tag}: observed {observed:.3e}  bound {bound:.3e}  observed/bound {observed / bound:.3f}")
+    assert observed <= bound, (tag, observed, bound)
+
+
+def _weights_agree(flat, flat2, lr, steps):
+    # Adam moves a weight by at most ~lr per step whatever its gradient: replicas whose rounding-noise gradients have opposite signs
+    # part by <= 2 lr per step (observed: 3.2e-6 ... 6.1e-6 after 4 steps at lr 1e-6 -- by construction near the limit, so the max is
+    # asserted at TWICE the limit and only catches gross corruption); the MEAN is the sensitive quantity: observed 1.2e-9 ... 1.6e-8
+    d = (flat.flat - flat2.flat).abs()
+    _check("max |w_eager - w_graph|", float(d.max()), 4 * lr * steps)
+    _check("mean |w_eager - w_graph|", float(d.mean()), 0.15 * lr)
+
+
 def test_graphed_step_matches_eager_step():
     """The hipGraph-replayed training step performs the same update as the eager step (same weights, same batch)."""
     from hifihr_amd.losses import LossFunction
@@ -157,14 +199,12 @@ def test_graphed_step_matches_eager_step():
     prev = torch.cuda.current_stream()
     torch.cuda.set_stream(torch.cuda.Stream())            # never the legacy default stream before a capture
     try:
-        # B = 8: with 4 samples the BatchNorm1d of the head amplifies float-atomic ordering noise (conv statistics, wgrad,
-        # head dx) to ~5e-4 of the loss between two EAGER runs (tools/debug_graph_noise.py); at 8 it is ~2e-5
-        B = 8
-        tables, args, model, ref, ex, ex_cpu = _setup(B)
+        B, lr = 8, 1e-6                                    # tiny lr: isolates the graph mechanics from Adam's sign noise
+        tables, args, model, ref, ex, ex_cpu = _setup(B, graded=True)
         model2 = Model(True, torch.device("cuda"), False, "mano", False, "res18", mano_tables=tables).cuda().train()
         model2.load_state_dict(model.state_dict())
-        flat = FlatParams(model); opt = FusedAdam(flat, lr=1e-6)     # tiny lr: isolates the graph mechanics from Adam's sign noise
-        flat2 = FlatParams(model2); opt2 = FusedAdam(flat2, lr=1e-6)
+        flat = FlatParams(model); opt = FusedAdam(flat, lr=lr)
+        flat2 = FlatParams(model2); opt2 = FusedAdam(flat2, lr=lr)
         before = flat2.flat.clone()
         rm_before = model2.base_encoder.encoder1.model.bn1.running_mean.clone()
         g = GraphedTrainStep(model2, LossFunction(), opt2, ex, args, warmup=3)
@@ -172,15 +212,12 @@ def test_graphed_step_matches_eager_step():
         # warm-up + capture are free of side effects: weights, Adam state, step counter, batch-norm running statistics
         assert torch.equal(flat2.flat, before) and opt2.step_count == 0 and float(opt2.exp_avg.abs().max()) == 0.0
         assert torch.equal(model2.base_encoder.encoder1.model.bn1.running_mean, rm_before)
-        for _ in range(2):
+        for step in range(2):
             loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
             loss_g, _ = g()
             torch.cuda.synchronize()
-            assert abs(float(loss_e) - float(loss_g)) <= 2e-4 * max(1.0, abs(float(loss_e))), (float(loss_e), float(loss_g))
-        # Adam normalises every gradient to ~+-lr per step, so weights whose gradient is rounding noise (float atomics
-        # order) may move in opposite directions: bound = 2 * lr * steps for those, tiny on average
-        d = (flat.flat - flat2.flat).abs()
-        assert float(d.max()) <= 4.01e-6 and float(d.mean()) <= 2e-7, (float(d.max()), float(d.mean()))
+            _check(f"step {step} |loss_eager - loss_graph| / loss", abs(float(loss_e) - float(loss_g)) / max(1.0, abs(float(loss_e))), _GRAPH_LOSS_RTOL)
+        _weights_agree(flat, flat2, lr, 2)
         assert opt2.step_count == 2 and opt.step_count == 2
     finally:
         torch.cuda.set_stream(prev)
@@ -189,7 +226,9 @@ def test_graphed_step_matches_eager_step():
 def test_graph_replay_survives_an_evaluation_pass_in_between():
     """train (graph) -> evaluate (model.eval(), a LARGER batch) -> train (graph) == the same sequence on the eager step.
     An evaluation forward must not disturb what the captured graph holds: it requests no batch-norm statistics buffer (round 1
-    leaked a dirty one into the pool whose address the graph had baked in) and scratch that grows keeps the old tensor alive."""
+    leaked a dirty one into the pool whose address the graph had baked in) and scratch that grows keeps the old tensor alive.
+    A SECOND eager replica walks the same sequence: its distance from the first is the noise floor of this very run, printed next to
+    every graph-vs-eager distance (the assertion itself is the absolute bound above, >= 18 x the floor measured on graded images)."""
     from hifihr_amd import synth
     from hifihr_amd.losses import LossFunction
     from hifihr_amd.models import Model
@@ -198,14 +237,21 @@ def test_graph_replay_survives_an_evaluation_pass_in_between():
     prev = torch.cuda.current_stream()
     torch.cuda.set_stream(torch.cuda.Stream())
     try:
-        B = 8
-        tables, args, model, ref, ex, ex_cpu = _setup(B)
-        model2 = Model(True, torch.device("cuda"), False, "mano", False, "res18", mano_tables=tables).cuda().train()
-        model2.load_state_dict(model.state_dict())
-        big = data_dic(synth.make_batch(model.hand_layer.handle, model.renderer_p3d, 2 * B, first_index=100, device=torch.device("cuda")),
-                       "FreiHand", "training", args, device=torch.device("cuda"))
-        flat = FlatParams(model); opt = FusedAdam(flat, lr=1e-6)
-        flat2 = FlatParams(model2); opt2 = FusedAdam(flat2, lr=1e-6)
+        B, lr = 8, 1e-6
+        tables, args, model, ref, ex, ex_cpu = _setup(B, graded=True)
+        dev = torch.device("cuda")
+
+        def replica():
+            m = Model(True, dev, False, "mano", False, "res18", mano_tables=tables).cuda().train()
+            m.load_state_dict(model.state_dict())
+            f = FlatParams(m)
+            return m, f, FusedAdam(f, lr=lr)
+        model2, flat2, opt2 = replica()                    # the graphed one
+        model3, flat3, opt3 = replica()                    # eager, like `model`: the noise floor
+        big = synth.make_batch(model.hand_layer.handle, model.renderer_p3d, 2 * B, first_index=100, device=dev)
+        big["trans_images"] = graded_images(big["trans_images"])
+        big = data_dic(big, "FreiHand", "training", args, device=dev)
+        flat = FlatParams(model); opt = FusedAdam(flat, lr=lr)
         g = GraphedTrainStep(model2, LossFunction(), opt2, ex, args)
 
         def evaluate(m):
@@ -215,19 +261,22 @@ def test_graph_replay_survives_an_evaluation_pass_in_between():
                 out = m("FreiHand", False, big["imgs"], Ks=big["Ps"], root_xyz=root)
             m.train()
             return out["joints"]
-        for rnd in range(2):
+
+        def step(tag):
             loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
+            loss_f, _ = train_step(model3, LossFunction(), opt3, ex, args)
             loss_g, _ = g()
             torch.cuda.synchronize()
-            assert abs(float(loss_e) - float(loss_g)) <= 2e-4 * max(1.0, abs(float(loss_e))), (rnd, float(loss_e), float(loss_g))
-            je, jg = evaluate(model), evaluate(model2)
-            assert float((je - jg).abs().max()) <= 1e-4, float((je - jg).abs().max())
-        loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
-        loss_g, _ = g()
-        torch.cuda.synchronize()
-        assert abs(float(loss_e) - float(loss_g)) <= 2e-4 * max(1.0, abs(float(loss_e))), (float(loss_e), float(loss_g))
-        d = (flat.flat - flat2.flat).abs()
-        assert float(d.max()) <= 6.01e-6 and float(d.mean()) <= 3e-7, (float(d.max()), float(d.mean()))
+            ref_ = max(1.0, abs(float(loss_e)))
+            print(f"[floor] {tag}: eager-vs-eager {abs(float(loss_e) - float(loss_f)) / ref_:.3e}")
+            _check(f"{tag} |loss_eager - loss_graph| / loss", abs(float(loss_e) - float(loss_g)) / ref_, _GRAPH_LOSS_RTOL)
+        for rnd in range(2):
+            step(f"round {rnd}")
+            je, jf, jg = evaluate(model), evaluate(model3), evaluate(model2)
+            print(f"[floor] round {rnd} evaluation joints: eager-vs-eager {float((je - jf).abs().max()):.3e}")
+            _check(f"round {rnd} evaluation joints max diff", float((je - jg).abs().max()), 1e-4)
+        step("after the evaluations")
+        _weights_agree(flat, flat2, lr, 3)
     finally:
         torch.cuda.set_stream(prev)
 

@@ -55,11 +55,16 @@ for k in per["FETCH_SIZE"]:
 for fam, (n, b) in groups.items():
     traffic.setdefault(fam, b / n)
 # the launch-level keys of bench.py's HBM-bound lines (main kernel + its helpers)
-for key, names in (("render_fwd", ("render_fwd_kernel", "render_vertex_kernel", "render_bin_kernel")),
+# (names are kernel FAMILIES, i.e. the text before the template arguments; a family that matches nothing in the trace is an error:
+# r04 kept summing a kernel that had been renamed and under-reported the forward rasteriser's traffic 7 x)
+for key, names in (("render_fwd", ("render_fwd3_kernel", "render_vertex_kernel", "render_bin_kernel")),
                    ("render_bwd", ("render_bwd_kernel", "render_vertex_bwd_kernel"))):
-    tot = sum(groups[n][1] for n in names if n in groups)
-    if tot:
-        traffic[key] = tot / max(groups[names[0]][0], 1)
+    absent = [n for n in names if n not in groups]
+    if absent:
+        sys.exit(f"kernel_traffic_summary: {key}: no launch of {absent} in the traced step (renamed kernel?) -- have "
+                 f"{sorted(g for g in groups if g.startswith('render'))}")
+    tot = sum(groups[n][1] for n in names)
+    traffic[key] = tot / max(groups[names[0]][0], 1)
 whole = sum(v[1] for v in per["FETCH_SIZE"].values()) * 2048 + sum(v[1] for v in per["WRITE_SIZE"].values()) * 1024
 print(json.dumps({"csrc_digest": digest(), "workload": "BASELINE configs[1] training step, B = 32, eager (one counter pass each)",
                   "collected_with": "rocprofv3 --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE (tools/kernel_traffic.sh); last complete step",

@@ -52,6 +52,8 @@ def parse(argv=None):
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--max_iters", type=int, default=0, help="stop after this many iterations (0 = run the epochs)")
     ap.add_argument("--print_freq", type=int, default=50)
+    ap.add_argument("--dist_timeout_min", type=float, default=60.0, help="collective timeout of the process group: has to cover rank 0's "
+                    "evaluation pass, during which the other ranks wait in a barrier")
     ap.add_argument("--override", default=None, help='JSON object of option overrides, e.g. \'{"total_epochs": 2}\'')
     return ap.parse_args(argv)
 
@@ -187,8 +189,9 @@ def train_ho3d(cli, args, model, loss_func, opt, sched, reducer, current_epoch, 
                 # the periodic test of the reference's epoch driver (:470-480): on HO-3D it is the challenge dump
                 say("[train_hrnet] HO3D test:", run_evaluation_ho3d(model, eval_cache, args, device, epoch + current_epoch))
             if world > 1:
-                # rank 0 alone walks the evaluation split: the others wait HERE, not inside the next epoch's gradient all-reduce (where a
-                # long evaluation reads as step time and can run into the process group's collective timeout)
+                # rank 0 alone walks the evaluation split: the others wait HERE, so that the evaluation is not booked as step time of the
+                # next epoch.  This barrier is a collective like any other: it runs under the process group's timeout (`--dist_timeout_min`,
+                # set at init_process_group), which therefore has to cover the longest evaluation pass.
                 torch.distributed.barrier()
         sched.step()
         if cli.max_iters and it >= cli.max_iters:
@@ -269,7 +272,7 @@ def main(argv=None):
     from hifihr_amd.optim import FlatParams, FusedAdam
     from hifihr_amd.traineval import GraphedTrainStep, data_dic, train_step
 
-    rank, local_rank, world = hdist.init_process_group_from_env()
+    rank, local_rank, world = hdist.init_process_group_from_env(timeout_min=cli.dist_timeout_min)
     assert torch.cuda.is_available(), "the hot path has no CPU fallback"
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
