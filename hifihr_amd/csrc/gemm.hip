@@ -1183,7 +1183,9 @@ __global__ __launch_bounds__(512) void bgemm_tn_rows_kernel(BgemmArgs a, long pe
       HIFIHR_RAW_BARRIER();                                  // barrier gc
     }
     // register e of lane (r, g) of block (i, j) = C[m0 + row(j, r)][128 nt + 32 wave + 16 i + 4 g + e]
-    float* C = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
+    // (T-split, a.splits > 1: "problem" t.p is part t.p % splits of problem t.p / splits; its result is that problem's tile of slab `part`)
+    const int preal = a.splits > 1 ? t.p / a.splits : t.p, part = t.p - preal * (a.splits > 1 ? a.splits : 1);
+    float* C = a.C + (size_t)part * a.sc_split + (size_t)preal * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int m = NB == 8 ? 64 * (j >> 2) + 4 * r + (j & 3) : NB == 4 ? 4 * r + j : NB == 2 ? 2 * r + j : r;
@@ -1263,6 +1265,28 @@ static bool tn_rows(int M, int N, int T, int batch) {
   return (long)batch * (N / 128) * (M / 16) >= 8L * gemm_cus();      // (256 x 256 channels, 4.5 blocks per CU: 38 us here, 35 on the 64x64 kernel)
 }
 
+// T-split on the same kernel (round 5): a product with too few 16-row blocks for the row-share schedule -- the 1x1 backward-weight
+// [6272 x 512]^T . [6272 x 256] is 64 blocks, the 36 products of a 128-channel F(4x4) layer 288 -- is cut along T into P parts that
+// the kernel walks as P problems of their own (part s of problem p starts at A + (p P + s) T' M: the plain problem stride), each
+// landing in slab s; the consumers sum the slabs in slab order, as they do behind the per-tile kernels these shapes ran on
+// (bgemm_ws_kernel<128,128,true>: 30 TF on the 1x1 product; bgemm_tn_kernel<64,64>: 0.43 of the peak).  P = the smallest divisor of
+// the chunk count that gives every CU ~7 blocks with at least 4 chunks per part.  HIFIHR_GEMM_TN_SPLIT=0: the per-tile kernels.
+// MEASURED (tools/time_gemm_tn_split.py, gpurun_out/tn_split_*.txt): the 36 products of a 128-channel F(4x4) layer 26.7 -> 25.4 us, of a
+// 256-channel one 35.8 -> 31.6 us; SINGLE products lose (1x1 backward-weight 256 -> 512 at 14 x 14: 22.9 -> 25.4 us, 512 -> 512: 36.8 ->
+// 42.3 us: 28 / 14 slabs of a whole filter each) -- batched products only.
+static int tn_rows_split(int M, int N, int T, int batch) {
+  if (batch < 2) return 0;
+  static const int on = [] { const char* e = getenv("HIFIHR_GEMM_TN_SPLIT"); return e ? atoi(e) : 1; }();
+  static const int on_rows = [] { const char* e = getenv("HIFIHR_GEMM_TN_ROWS"); return e ? atoi(e) : 1; }();
+  if (!on || !on_rows || N % 128 != 0 || M % 16 != 0 || T % 32 != 0 || T < 64) return 0;
+  if (getenv("HIFIHR_GEMM_TN_TILE") != nullptr || getenv("HIFIHR_GEMM_TN_PARTS") != nullptr) return 0;
+  const int nch = T / 32;
+  const long blocks = (long)batch * (N / 128) * (M / 16), need = 7L * gemm_cus();
+  for (int P = 2; P <= nch / 4; ++P)
+    if (nch % P == 0 && blocks * P >= need) return P;
+  return 0;
+}
+
 // which kernel instantiation a shape runs on, as rocprof names it (bench.py groups its roofline lines by this)
 void bgemm_describe(int tn, int M, int N, int K, char* out, int cap) { bgemm_describe_batch(tn, M, N, K, 16, out, cap); }
 
@@ -1279,7 +1303,7 @@ void bgemm_describe_batch(int tn, int M, int N, int K, int batch, char* out, int
   const int nload = gemm_ws_loaders();
   // (the instantiation rocprof lists: <0> plain, <1> ragged N / K; <2> = the gathering form, named by hifihr_conv2d_describe)
   if (!tn && (nt_rows(N) || bgemm_nt_ragged_supported(M, N, K))) { snprintf(out, cap, "bgemm_nt_rows_kernel<%d>", bgemm_nt_ragged_supported(M, N, K) ? 1 : 0); return; }
-  if (tn && tn_rows(M, N, K, batch)) { snprintf(out, cap, "bgemm_tn_rows_kernel"); return; }
+  if (tn && (tn_rows(M, N, K, batch) || tn_rows_split(M, N, K, batch))) { snprintf(out, cap, "bgemm_tn_rows_kernel"); return; }
   if (!tn && bm == 128 && bn == 128 && nload > 0 && bgemm_nt_workspace_bytes(M, N, K, 16) > 0) snprintf(out, cap, "bgemm_nt_sk_kernel<%d>", nload == 2 ? 2 : 4);
   else if (bm == 128 && bn == 128 && nload > 0) snprintf(out, cap, "bgemm_ws_kernel<128, 128, %s, %d>", tn ? "true" : "false", nload == 1 ? 1 : nload == 4 ? 4 : 2);
   else snprintf(out, cap, "%s<%d, %d>", tn ? "bgemm_tn_kernel" : "bgemm_nt_kernel", bm, bn);
@@ -1436,6 +1460,7 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
 // number of K-split slabs launch_bgemm_tn writes for this shape (the caller provides parts * batch * M * N floats)
 int bgemm_tn_parts(int M, int N, int T, int batch) {
   if (tn_rows(M, N, T, batch)) return 1;
+  if (const int P = tn_rows_split(M, N, T, batch)) return P;
   if (const char* e = getenv("HIFIHR_GEMM_TN_PARTS")) { const int v = atoi(e); if (v > 0) return v; }
   int bm, bn;
   tn_tile(M, N, batch, &bm, &bn);
@@ -1456,10 +1481,13 @@ hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M,
   BgemmArgs a{};
   a.A = A; a.B = B; a.C = Cparts; a.M = M; a.N = N; a.K = T; a.lda = M; a.ldb = N; a.ldc = N;
   a.sa = (long)T * M; a.sb = (long)T * N; a.sc = (long)M * N; a.batch = batch;
-  if (tn_rows(M, N, T, batch)) {
-    if (parts != 1) return hipErrorInvalidValue;
-    a.tiles_n = N / 128; a.tiles_m = (M + 127) / 128; a.splits = 1; a.cps = T / 32; a.sc_split = 0;
-    const long total = (long)batch * a.tiles_n * (M / 16);
+  const int P = tn_rows(M, N, T, batch) ? 1 : tn_rows_split(M, N, T, batch);
+  if (P > 0) {
+    if (parts != P) return hipErrorInvalidValue;
+    const int Tp = T / P;                                    // (P == 1: the whole reduction per tile, one slab)
+    a.K = Tp; a.sa = (long)Tp * M; a.sb = (long)Tp * N; a.batch = batch * P;
+    a.tiles_n = N / 128; a.tiles_m = (M + 127) / 128; a.splits = P; a.cps = Tp / 32; a.sc_split = P > 1 ? (long)batch * M * N : 0;
+    const long total = (long)a.batch * a.tiles_n * (M / 16);
     const int cus = gemm_cus();
     long per = (total + cus - 1) / cus;
     if (per < 4) per = 4;

