@@ -9,6 +9,8 @@ compare against is oracle/loss_oracle.py (pinned by the reference's own LossFunc
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -50,6 +52,12 @@ def iou(s_gt, s_est):
     return 1 - torch.mean(mul / (add - mul))
 
 
+# MEASURED (round 5, B = 32, gpurun_out/gb*.json): the geometry terms on a branch of their own make the captured step SLOWER, 5.31 -> 5.38
+# ms/step -- a fork / join pair of the replayed graph costs more than the ~30 us of launches this branch hides (the light estimator's ~28
+# launches are worth it: 5.38 -> 5.32).  Off by default; HIFIHR_GEOM_BRANCH=1 to re-measure.
+_GEOM_BRANCH = os.environ.get("HIFIHR_GEOM_BRANCH", "0") != "0"
+
+
 class LossFunction:
     def __init__(self, perceptual=None):
         # PerceptualLoss instance; None = built on first use (hifihr_amd/perceptual.py: seeded torchvision-style
@@ -70,13 +78,28 @@ class LossFunction:
         # a term that is not requested has weight 0: any tensor of the right shape serves as its (absent) ground truth
         joints_gt = examples["joints"] if "joints" in examples else outputs["joints"].detach()
         verts_gt = examples["verts"] if "verts" in examples else outputs["mano_verts"].detach()
-        vals = ops.geom_losses(outputs["joints"], joints_gt, outputs["mano_verts"], verts_gt,
-                               outputs["shape_params"], outputs["pose_params"], faces, args.base_loss_fn != "L1", lam).unbind(0)
-        for k, v in zip(ops.GEOM_TERMS, vals):
+        # the geometry terms need nothing of the renderer: on a side stream they (and their backward) run beside the render / photometric
+        # chain (ops.side_branch); __call__ joins the branch when every term is enqueued
+        with ops.side_branch(outputs["joints"], "geom", enabled=_GEOM_BRANCH and "re_img" in outputs,
+                             inputs=(joints_gt, outputs["mano_verts"], verts_gt, outputs["shape_params"], outputs["pose_params"])) as br:
+            vec = ops.geom_losses(outputs["joints"], joints_gt, outputs["mano_verts"], verts_gt,
+                                  outputs["shape_params"], outputs["pose_params"], faces, args.base_loss_fn != "L1", lam)
+        self._pending_join = (br, vec)
+        for k, v in zip(ops.GEOM_TERMS, vec.unbind(0)):
             if k in loss_used:
                 loss_dic[k] = v
 
     def __call__(self, examples, outputs, loss_used, dat_name, args) -> dict:
+        self._pending_join = None
+        try:
+            return self._terms(examples, outputs, loss_used, dat_name, args)
+        finally:
+            if self._pending_join is not None:          # the geometry branch meets the main stream behind the last term
+                br, vec = self._pending_join
+                br.join(vec)
+                self._pending_join = None
+
+    def _terms(self, examples, outputs, loss_used, dat_name, args) -> dict:
         from . import ops
         loss_dic = {}
         base = F.l1_loss if args.base_loss_fn == "L1" else F.mse_loss

@@ -14,6 +14,8 @@ gradient exist.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -29,6 +31,9 @@ def texture_stand_in_basis(ncomp: int) -> torch.Tensor:
     """[ncomp, 778*3] fixed linear map texture_params -> per-vertex colour offsets of the NIMBLE texture stand-in."""
     gen = torch.Generator().manual_seed(7)
     return 0.05 * torch.randn(int(ncomp), 778 * 3, generator=gen)
+
+
+_LIGHT_BRANCH = os.environ.get("HIFIHR_LIGHT_BRANCH", "1") != "0"
 
 
 class MyMANOLayer(nn.Module):
@@ -184,11 +189,18 @@ class Model(nn.Module):
 
     def forward_from_features(self, dat_name, mode_train, images, low_features, features, Ks=None, root_xyz=None):
         """Everything after the image encoder (models_res_nimble.py:118-225)."""
+        br = None
         if self.ifLight:
-            light_params = self.light_estimator(low_features)
+            # The light estimator (3 small convolutions, 2 pools, 2 linears: ~10 launches forward, ~18 backward, each a few microseconds
+            # of work on a handful of CUs) and the chain hand encoder -> MANO -> joints are independent until the renderer: on a side
+            # stream the two latency chains overlap (ops.side_branch).  HIFIHR_LIGHT_BRANCH=0: one stream.
+            with ops.side_branch(low_features, "light", enabled=_LIGHT_BRANCH and self.ifRender) as br:
+                light_params = self.light_estimator(low_features)
         hand_params = self.hand_encoder(features)
         outputs = self.hand_layer(hand_params, handle_collision=False)
         outputs.update(hand_params)
+        if br is not None and self.hand_model == "nimble":
+            br.join(*light_params.values())
         if self.hand_model == "nimble":
             return self._nimble_tail(dat_name, mode_train, images, outputs, light_params if self.ifLight else None, Ks, root_xyz)
         # joints regressed from the posed verts + root-relative (models_res_nimble.py:150-166), one HIP launch
@@ -197,6 +209,8 @@ class Model(nn.Module):
         outputs["joints"], outputs["mano_verts"] = joints, mano_verts
         if self.ifRender:
             cam = self.camera_from_K(Ks)                                  # PerspectiveCameras(focal_length=-fcl, principal_point=prp)
+            if br is not None:
+                br.join(*light_params.values())                           # the light branch meets the main chain at the renderer
             if self.ifLight:
                 colors, directions = light_params["colors"], light_params["directions"]
             else:
