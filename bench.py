@@ -444,7 +444,7 @@ def main():
 
         def next_batch(out=None):
             idx = torch.randint(0, cache.n, (a.batch,), generator=perm_gen)
-            return cache.batch_examples(idx, generator=rot_gen, out=out)
+            return cache.batch_examples(idx, generator=rot_gen, out=out, root_id=args_ns.ROOT)
         data_note = ("every step assembles a NEW batch on the device from the uint8 sample cache resident in HBM (one staged H2D copy of "
                      "100 B per sample + hifihr_freihand_batch: gather + affine warp, K / joint / vertex / projection terms of data_dic), "
                      "written straight into the captured step's static inputs")

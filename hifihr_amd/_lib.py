@@ -77,6 +77,8 @@ class HifihrLib:
         c.hifihr_mano_lbs_bwd.argtypes = [c_void_p] + [_c_float_p] * 5 + [c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mano_joints_fwd.argtypes = [c_void_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mano_joints_bwd.argtypes = [c_void_p, _c_float_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p, c_void_p]
+        c.hifihr_mano_full_fwd.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p]
+        c.hifihr_mano_full_bwd.argtypes = [c_void_p] + [_c_float_p] * 7 + [c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_lbs_create.argtypes = [POINTER(c_void_p), c_int, c_int, c_int] + [_c_float_p] * 4 + [_c_int_p]
         c.hifihr_lbs_destroy.argtypes = [c_void_p]
         c.hifihr_lbs_fwd.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, _c_float_p, _c_float_p, c_void_p]
@@ -150,6 +152,8 @@ class HifihrLib:
                                         [_c_float_p] * 5 + [c_void_p])
         c.hifihr_freihand_batch.argtypes = ([c_void_p, c_void_p] + [_c_float_p] * 4 + [c_int, c_int, _c_int_p, c_int, c_int, c_int, _c_float_p,
                                             _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p, c_void_p])
+        c.hifihr_freihand_batch_step.argtypes = ([c_void_p, c_void_p] + [_c_float_p] * 4 + [c_int, c_int, _c_int_p, c_int, c_int, c_int, _c_float_p,
+                                                 _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p, c_int, c_float] + [_c_float_p] * 4 + [c_void_p])
         c.hifihr_procrustes_error.argtypes = [_c_float_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_wino_output_transform_act.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_dy_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
@@ -274,6 +278,19 @@ class HifihrLib:
         self.check(self.c.hifihr_mano_joints_bwd(h, _fp(gjoints_rel), _fp(gverts_rel), _fp(groot), B, root_id,
                                                  _fp(gverts), _stream_of(gverts)), "hifihr_mano_joints_bwd")
 
+    def mano_full_fwd(self, h, pose, beta, root_id, root_xyz, counters, verts, joints_rel, verts_rel, verts_cam, root, saved):
+        """hifihr_mano_full_fwd: the layer + joint regression + root-relative step + camera-space offset, one launch.
+        counters: int32 [B] tensor, all zero on entry (left all zero)."""
+        B = pose.shape[0]
+        assert counters.dtype == torch.int32 and counters.is_contiguous() and counters.numel() >= B
+        self.check(self.c.hifihr_mano_full_fwd(h, _fp(pose), _fp(beta), B, int(root_id), _fp(root_xyz), c_void_p(counters.data_ptr()),
+                                               _fp(verts), _fp(joints_rel), _fp(verts_rel), _fp(verts_cam), _fp(root), _fp(saved),
+                                               _stream_of(pose)), "hifihr_mano_full_fwd")
+
+    def mano_full_bwd(self, h, pose, beta, saved, gjoints_rel, gverts_rel, gverts_cam, groot, root_id, gpose, gbeta):
+        B = pose.shape[0]
+        self.check(self.c.hifihr_mano_full_bwd(h, _fp(pose), _fp(beta), _fp(saved), _fp(gjoints_rel), _fp(gverts_rel), _fp(gverts_cam),
+                                               _fp(groot), B, int(root_id), _fp(gpose), _fp(gbeta), _stream_of(pose)), "hifihr_mano_full_bwd")
 
     # ---- generic LBS (NIMBLE-shaped layer) -----------------------------
     def lbs_create(self, v_template, shapedirs, j_regressor, weights, parents) -> c_void_p:
@@ -517,8 +534,9 @@ class HifihrLib:
     def weight_prep(self, table, njobs, blocks_per_job=64):
         self.check(self.c.hifihr_weight_prep(c_void_p(table.data_ptr()), njobs, blocks_per_job, _stream_of(table)), "hifihr_weight_prep")
 
-    def freihand_batch(self, img_rgbx, mask, Ks, joints, verts, scales, packed, B, out):
-        """out: dict with any of imgs, masks, segms_gt, Ks, Ps, joints, verts, j2d_gt, scales, idxs (device tensors, contiguous)."""
+    def freihand_batch(self, img_rgbx, mask, Ks, joints, verts, scales, packed, B, out, root_id=None, image_size=None):
+        """out: dict with any of imgs, masks, segms_gt, Ks, Ps, joints, verts, j2d_gt, scales, idxs (device tensors, contiguous);
+        root_id given: also root_xyz [B,1,3], joints_rel, verts_rel, cam_ndc [B,4] (hifihr_freihand_batch_step)."""
         n, H, W = img_rgbx.shape
         J, V = joints.shape[1], verts.shape[1]
         vp = lambda t: c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
@@ -527,10 +545,18 @@ class HifihrLib:
             assert g(k) is None or g(k).dtype == torch.int64
         for t in out.values():
             assert t.is_contiguous()
-        self.check(self.c.hifihr_freihand_batch(vp(img_rgbx), vp(mask), _fp(Ks), _fp(joints), _fp(verts), _fp(scales), J, V, _ip(packed), B, H, W,
-                                                _fp(g("imgs")), _fp(g("masks")), vp(g("segms_gt")), _fp(g("Ks")), _fp(g("Ps")), _fp(g("joints")),
-                                                _fp(g("verts")), _fp(g("j2d_gt")), _fp(g("scales")), vp(g("idxs")), _stream_of(packed)),
-                   "hifihr_freihand_batch")
+        if root_id is None:
+            self.check(self.c.hifihr_freihand_batch(vp(img_rgbx), vp(mask), _fp(Ks), _fp(joints), _fp(verts), _fp(scales), J, V, _ip(packed), B, H, W,
+                                                    _fp(g("imgs")), _fp(g("masks")), vp(g("segms_gt")), _fp(g("Ks")), _fp(g("Ps")), _fp(g("joints")),
+                                                    _fp(g("verts")), _fp(g("j2d_gt")), _fp(g("scales")), vp(g("idxs")), _stream_of(packed)),
+                       "hifihr_freihand_batch")
+            return
+        # + the terms every training iteration derives from the batch: root_xyz, root-relative ground truth, the NDC camera
+        self.check(self.c.hifihr_freihand_batch_step(vp(img_rgbx), vp(mask), _fp(Ks), _fp(joints), _fp(verts), _fp(scales), J, V, _ip(packed), B, H, W,
+                                                     _fp(g("imgs")), _fp(g("masks")), vp(g("segms_gt")), _fp(g("Ks")), _fp(g("Ps")), _fp(g("joints")),
+                                                     _fp(g("verts")), _fp(g("j2d_gt")), _fp(g("scales")), vp(g("idxs")), int(root_id), float(image_size or H),
+                                                     _fp(g("root_xyz")), _fp(g("joints_rel")), _fp(g("verts_rel")), _fp(g("cam_ndc")), _stream_of(packed)),
+                   "hifihr_freihand_batch_step")
 
     def ho3d_workspace_bytes(self, B, out_size):
         return int(self.c.hifihr_ho3d_workspace_bytes(B, out_size))

@@ -61,9 +61,10 @@ struct BatchMeta {
   int B, J, V;
   float *oKs, *oPs, *ojoints, *overts, *oj2d, *oscales;
   long long* oidx;
+  BatchStepOut x;                                  // what the training step derives from the batch on every iteration (all optional)
 };
 __global__ __launch_bounds__(256) void freihand_batch_meta_kernel(BatchMeta m) {
-  __shared__ float sK[9], sR[9];
+  __shared__ float sK[9], sR[9], sRoot[3];
   const int b = blockIdx.x, t = threadIdx.x;
   const int id = m.packed[b];
   const float* post = reinterpret_cast<const float*>(m.packed + 7 * m.B) + b * 9;
@@ -85,6 +86,26 @@ __global__ __launch_bounds__(256) void freihand_batch_meta_kernel(BatchMeta m) {
     if (m.oidx) m.oidx[b] = id;
   }
   __syncthreads();
+  // the step's own terms (train_hrnet.py:62-68; models_res_nimble.py:228-235): root = joints[:, root_id] of the ROTATED joints, the
+  // root-relative ground truth, the NDC camera (-2 fx / s, -2 fy / s, 1 - 2 cx / s, 1 - 2 cy / s) of the rotated intrinsics
+  if (t < 3) {
+    float a = 0.f;
+    if (m.x.root_id >= 0 && m.x.root_id < m.J) {
+      const float* src = m.joints + ((size_t)id * m.J + m.x.root_id) * 3;
+      a = src[0] * sR[t * 3 + 0];
+      a += src[1] * sR[t * 3 + 1];
+      a += src[2] * sR[t * 3 + 2];
+    }
+    sRoot[t] = a;
+    if (m.x.oroot) m.x.oroot[b * 3 + t] = a;
+  }
+  if (t >= 64 && t < 68 && m.x.ocam) {
+    const int e = t - 64;
+    const float sc = -2.0f / m.x.image_size;
+    const float k = e == 0 ? sK[0] : e == 1 ? sK[4] : e == 2 ? sK[2] : sK[5];
+    m.x.ocam[b * 4 + e] = (e < 2 ? 0.f : 1.f) + k * sc;
+  }
+  __syncthreads();
   for (int p = t; p < m.J + m.V; p += 256) {
     const bool isj = p < m.J;
     const float* src = isj ? m.joints + ((size_t)id * m.J + p) * 3 : m.verts + ((size_t)id * m.V + (p - m.J)) * 3;
@@ -100,6 +121,9 @@ __global__ __launch_bounds__(256) void freihand_batch_meta_kernel(BatchMeta m) {
     float* dst = isj ? (m.ojoints ? m.ojoints + ((size_t)b * m.J + p) * 3 : nullptr)
                      : (m.overts ? m.overts + ((size_t)b * m.V + (p - m.J)) * 3 : nullptr);
     if (dst) { dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2]; }
+    float* rel = isj ? (m.x.ojoints_rel ? m.x.ojoints_rel + ((size_t)b * m.J + p) * 3 : nullptr)
+                     : (m.x.overts_rel ? m.x.overts_rel + ((size_t)b * m.V + (p - m.J)) * 3 : nullptr);
+    if (rel) { rel[0] = r[0] - sRoot[0]; rel[1] = r[1] - sRoot[1]; rel[2] = r[2] - sRoot[2]; }
     if (isj && m.oj2d) {
       float uv[3];
 #pragma unroll
@@ -295,11 +319,11 @@ hipError_t launch_freihand_augment(const uint32_t* img, const uint8_t* mask, con
 hipError_t launch_freihand_batch(const uint32_t* img, const uint8_t* mask, const float* Ks, const float* joints, const float* verts,
                                  const float* scales, int J, int V, const int* packed, int B, int H, int W, float* out_img, float* out_mask,
                                  long long* out_segm, float* oKs, float* oPs, float* ojoints, float* overts, float* oj2d, float* oscales,
-                                 long long* oidx, hipStream_t st) {
+                                 long long* oidx, const BatchStepOut& step, hipStream_t st) {
   if (B <= 0 || H <= 0 || W <= 0 || (long)H * W >= (1L << 24) || J < 0 || V < 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(freihand_augment_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, img, mask, packed, packed + B, H, W, out_img,
                      out_mask, out_segm);
-  const BatchMeta m{Ks, joints, verts, scales, packed, B, J, V, oKs, oPs, ojoints, overts, oj2d, oscales, oidx};
+  const BatchMeta m{Ks, joints, verts, scales, packed, B, J, V, oKs, oPs, ojoints, overts, oj2d, oscales, oidx, step};
   hipLaunchKernelGGL(freihand_batch_meta_kernel, dim3(B), dim3(256), 0, st, m);
   return hipGetLastError();
 }

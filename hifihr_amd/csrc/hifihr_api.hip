@@ -226,6 +226,28 @@ int hifihr_mano_lbs_bwd(const hifihr_mano_t* h, const float* pose, const float* 
   return HIFIHR_OK;
 }
 
+int hifihr_mano_full_fwd(const hifihr_mano_t* h, const float* pose, const float* beta, int B, int root_id, const float* root_xyz,
+                         unsigned* counters, float* verts, float* joints_rel, float* verts_rel, float* verts_cam, float* root, float* saved,
+                         void* stream) {
+  if (!h || !pose || !beta || !counters || !verts || !joints_rel || !verts_rel || B < 0 || root_id >= 21)
+    return fail(HIFIHR_EINVAL, "hifihr_mano_full_fwd: bad argument");
+  if (B == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_mano_full_fwd(h->dev, pose, beta, B, root_id, root_xyz, counters, verts, joints_rel, verts_rel, verts_cam, root, saved,
+                                       (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_mano_full_bwd(const hifihr_mano_t* h, const float* pose, const float* beta, const float* saved, const float* gjoints_rel,
+                         const float* gverts_rel, const float* gverts_cam, const float* groot, int B, int root_id, float* gpose,
+                         float* gbeta, void* stream) {
+  if (!h || !pose || !beta || !saved || !gpose || !gbeta || B < 0 || root_id >= 21)
+    return fail(HIFIHR_EINVAL, "hifihr_mano_full_bwd: bad argument");
+  if (B == 0) return HIFIHR_OK;
+  HIP_TRY(hifihr::launch_mano_full_bwd(h->dev, pose, beta, saved, gjoints_rel, gverts_rel, gverts_cam, groot, B, root_id, gpose, gbeta,
+                                       (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_mano_joints_fwd(const hifihr_mano_t* h, const float* verts, int B, int root_id, float* joints_rel,
                            float* verts_rel, float* root, void* stream) {
   if (!h || !verts || !joints_rel || B < 0 || root_id >= 21) return fail(HIFIHR_EINVAL, "hifihr_mano_joints_fwd: bad argument");
@@ -1238,7 +1260,23 @@ int hifihr_freihand_batch(const uint32_t* img_rgbx, const uint8_t* mask, const f
       (J > 0 && !joints) || (V > 0 && !verts) || (out_j2d && !out_joints && J > 0 && !joints))
     return fail(HIFIHR_EINVAL, "hifihr_freihand_batch: bad argument");
   HIP_TRY(hifihr::launch_freihand_batch(img_rgbx, mask, Ks, joints, verts, scales, J, V, packed, B, H, W, out_img, out_mask, out_segm, out_Ks,
-                                        out_Ps, out_joints, out_verts, out_j2d, out_scales, out_idxs, (hipStream_t)stream));
+                                        out_Ps, out_joints, out_verts, out_j2d, out_scales, out_idxs, hifihr::BatchStepOut{-1, 1.f, nullptr, nullptr, nullptr, nullptr},
+                                        (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_freihand_batch_step(const uint32_t* img_rgbx, const uint8_t* mask, const float* Ks, const float* joints, const float* verts,
+                               const float* scales, int J, int V, const int* packed, int B, int H, int W, float* out_img, float* out_mask,
+                               long long* out_segm, float* out_Ks, float* out_Ps, float* out_joints, float* out_verts, float* out_j2d,
+                               float* out_scales, long long* out_idxs, int root_id, float image_size, float* out_root,
+                               float* out_joints_rel, float* out_verts_rel, float* out_cam_ndc, void* stream) {
+  if (!img_rgbx || !mask || !Ks || !scales || !packed || B <= 0 || H <= 0 || W <= 0 || (long)H * W >= (1L << 24) || J < 0 || V < 0 ||
+      (J > 0 && !joints) || (V > 0 && !verts) || root_id >= J || !(image_size > 0.f))
+    return fail(HIFIHR_EINVAL, "hifihr_freihand_batch_step: bad argument");
+  HIP_TRY(hifihr::launch_freihand_batch(img_rgbx, mask, Ks, joints, verts, scales, J, V, packed, B, H, W, out_img, out_mask, out_segm, out_Ks,
+                                        out_Ps, out_joints, out_verts, out_j2d, out_scales, out_idxs,
+                                        hifihr::BatchStepOut{root_id, image_size, out_root, out_joints_rel, out_verts_rel, out_cam_ndc},
+                                        (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

@@ -29,6 +29,12 @@ hipError_t launch_mano_fwd(const ManoDev& t, const float* pose, const float* bet
                            float* saved, hipStream_t st);
 hipError_t launch_mano_bwd(const ManoDev& t, const float* pose, const float* beta, const float* saved,
                            const float* gverts, const float* gjtr, int B, float* gpose, float* gbeta, hipStream_t st);
+hipError_t launch_mano_full_fwd(const ManoDev& t, const float* pose, const float* beta, int B, int root_id, const float* root_xyz,
+                                unsigned* counters, float* verts, float* joints_rel, float* verts_rel, float* verts_cam, float* root_out,
+                                float* saved, hipStream_t st);
+hipError_t launch_mano_full_bwd(const ManoDev& t, const float* pose, const float* beta, const float* saved, const float* gjoints_rel,
+                                const float* gverts_rel, const float* gverts_cam, const float* groot, int B, int root_id, float* gpose,
+                                float* gbeta, hipStream_t st);
 hipError_t launch_mano_joints_fwd(const ManoDev& t, const float* verts, int B, int root_id, float* joints_rel,
                                   float* verts_rel, float* root, hipStream_t st);
 hipError_t launch_mano_joints_bwd(const ManoDev& t, const float* gjoints_rel, const float* gverts_rel,
@@ -331,10 +337,15 @@ struct PrepJob {
 hipError_t launch_weight_prep(const PrepJob* jobs, int njobs, int blocks_per_job, hipStream_t st);
 hipError_t launch_freihand_augment(const uint32_t* img, const uint8_t* mask, const int* idx, const int* coef, int B, int H, int W,
                                    float* out_img, float* out_mask, hipStream_t st);
+struct BatchStepOut {          // hifihr_freihand_batch_step: per-iteration terms of the training step, all optional
+  int root_id;                 // joint the ground truth is made relative to (args.ROOT); < 0: root = 0
+  float image_size;            // s of get_ndc_fx_fy_cx_cy
+  float *oroot, *ojoints_rel, *overts_rel, *ocam;
+};
 hipError_t launch_freihand_batch(const uint32_t* img, const uint8_t* mask, const float* Ks, const float* joints, const float* verts,
                                  const float* scales, int J, int V, const int* packed, int B, int H, int W, float* out_img, float* out_mask,
                                  long long* out_segm, float* oKs, float* oPs, float* ojoints, float* overts, float* oj2d, float* oscales,
-                                 long long* oidx, hipStream_t st);
+                                 long long* oidx, const BatchStepOut& step, hipStream_t st);
 size_t ho3d_workspace_bytes(int B, int out_size);
 hipError_t launch_ho3d_batch(const uint32_t* img, const uint8_t* mask, const float* Ks, const float* uv21, const float* xyz21, int FH, int FW,
                              const int* packed, int B, int out_size, void* ws, float* out_img, float* out_mask, float* out_K,

@@ -74,14 +74,47 @@ __device__ __forceinline__ void mano_prologue(const ManoDev& t, const float* __r
 // latencies per workgroup -- the per-hand prologue, then 145 table rows per vertex -- and a batch of 32 hands gave the 256-CU chip 128
 // workgroups; 224 smaller ones with all 27 rows of a group of pose blend shapes in flight per lane (5 groups instead of 27 of 5) shorten
 // the chain.  Every workgroup redoes the prologue (16 Rodrigues + the kinematic chain: ~2 us).
+__device__ __forceinline__ float wave_sum_fwd(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+  return x;
+}
+
 constexpr int kFwdTiles = 7;
 constexpr int kFwdTileV = 112;   // 7 x 112 = 784 >= 778
 constexpr int kFwdThreads = 128;
 
+// The joint regression + root-relative step that follows the layer in Model.forward (mano_joints_fwd_kernel below) as the TAIL of this
+// launch (round 5): `tail.counters` != null -> the tile workgroup of a hand that finishes LAST (device-scope arrival counter, left zero)
+// reads the hand's 778 vertices back (agent-scope loads: they were written by other CUs) and writes joints_rel / verts_rel / root and
+// verts_cam = verts_rel + root_xyz (the `skin_meshes.offset_verts_(root_xyz)` of models_res_nimble.py:203-205) -- one launch and one
+// elementwise add fewer on the step's critical path (a chain of ~5 us launches there).
+struct ManoFwdTail {
+  unsigned* counters;          // [B], all zero on entry, all zero on exit; null = no tail
+  int root_id;                 // 0..20, or < 0: no subtraction
+  const float* root_xyz;       // [B][3] or null
+  float* joints_rel;           // [B][21][3]
+  float* verts_rel;            // [B][778][3]
+  float* verts_cam;            // [B][778][3] or null
+  float* root_out;             // [B][3] or null
+};
+
+__device__ __forceinline__ float agent_load(const float* p) {
+#if defined(HIFIHR_HOSTSIM)
+  return *p;                                                        // (the emulator runs the workgroups of a grid one after another)
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bypasses this CU's vector L1
+#endif
+}
+
 __global__ __launch_bounds__(kFwdThreads) void mano_fwd_kernel(ManoDev t, const float* __restrict__ pose,
                                                       const float* __restrict__ beta, float* __restrict__ verts,
-                                                      float* __restrict__ jtr, float* __restrict__ saved_vposed) {
+                                                      float* __restrict__ jtr, float* __restrict__ saved_vposed, ManoFwdTail tail) {
   __shared__ ManoSmall s;
+  __shared__ float tl_sv[3 * kNVP];
+  __shared__ float tl_j16[kNJ * 3];
+  __shared__ float tl_j21[21 * 3];
+  __shared__ int tl_last;
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   mano_prologue(t, pose, beta, b, s);
@@ -95,7 +128,7 @@ __global__ __launch_bounds__(kFwdThreads) void mano_fwd_kernel(ManoDev t, const 
     }
   }
   const int v = blockIdx.x * kFwdTileV + tid;
-  if (tid >= kFwdTileV || v >= kNV) return;
+  if (tid < kFwdTileV && v < kNV) {
 
   // v_posed = v_template + shapedirs.beta + posedirs.pose_map      (my_mano.py:386-393)
   float vp[3];
@@ -147,6 +180,66 @@ __global__ __launch_bounds__(kFwdThreads) void mano_fwd_kernel(ManoDev t, const 
       oj[0] = o[0]; oj[1] = o[1]; oj[2] = o[2];
     }
   }
+  }   // (vertex lanes)
+  if (tail.counters == nullptr) return;                             // (uniform)
+
+  // ---------------- tail: the last tile of hand b to arrive regresses the joints ----------------
+  __threadfence();                                                  // this workgroup's vertices: visible device-wide before it is counted
+  __syncthreads();
+  if (tid == 0) tl_last = (atomicAdd(tail.counters + b, 1u) == (unsigned)(kFwdTiles - 1)) ? 1 : 0;
+  __syncthreads();
+  if (!tl_last) return;                                             // (uniform)
+  if (tid == 0) tail.counters[b] = 0u;                              // self-cleaning: the next launch finds zeros
+  __threadfence();
+  for (int e = tid; e < kNV * 3; e += kFwdThreads) {
+    const int vv = e / 3, c = e - 3 * vv;
+    tl_sv[c * kNVP + vv] = agent_load(verts + (size_t)b * kNV * 3 + e);
+  }
+  __syncthreads();
+  {
+    // a wave takes 8 of the 16 regressed joints; the 8 regressor rows are all in flight before the first is used (one memory latency)
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int kIt = (kNV + 63) / 64;
+    constexpr int kJW = kNJ / (kFwdThreads / 64);
+    static_assert(kNJ % (kFwdThreads / 64) == 0, "joints split evenly over the waves");
+    float rv[kJW][kIt];
+#pragma unroll
+    for (int q = 0; q < kJW; ++q) {
+      const float* jr = t.jreg + (wave * kJW + q) * kNVP;
+#pragma unroll
+      for (int i = 0; i < kIt; ++i) { const int vv = lane + 64 * i; rv[q][i] = vv < kNV ? jr[vv] : 0.f; }
+    }
+#pragma unroll
+    for (int q = 0; q < kJW; ++q) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < kIt; ++i) {
+        const int vv = lane + 64 * i;
+        if (vv < kNV) { a0 += rv[q][i] * tl_sv[vv]; a1 += rv[q][i] * tl_sv[kNVP + vv]; a2 += rv[q][i] * tl_sv[2 * kNVP + vv]; }
+      }
+      a0 = wave_sum_fwd(a0); a1 = wave_sum_fwd(a1); a2 = wave_sum_fwd(a2);
+      if (lane == 0) { const int j = wave * kJW + q; tl_j16[j * 3] = a0; tl_j16[j * 3 + 1] = a1; tl_j16[j * 3 + 2] = a2; }
+    }
+  }
+  __syncthreads();
+  if (tid < 63) {
+    const int sl = tid / 3, c = tid % 3;
+    const int src = c_xyz_src[sl];
+    tl_j21[tid] = (src >= 0) ? tl_j16[src * 3 + c] : tl_sv[c * kNVP + (-src - 1)];
+  }
+  __syncthreads();
+  float rr[3] = {0.f, 0.f, 0.f};
+  if (tail.root_id >= 0) { rr[0] = tl_j21[tail.root_id * 3]; rr[1] = tl_j21[tail.root_id * 3 + 1]; rr[2] = tl_j21[tail.root_id * 3 + 2]; }
+  if (tid < 63) tail.joints_rel[(size_t)b * 63 + tid] = tl_j21[tid] - rr[tid % 3];
+  if (tid < 3 && tail.root_out) tail.root_out[b * 3 + tid] = rr[tid];
+  float off[3] = {0.f, 0.f, 0.f};
+  if (tail.root_xyz) { off[0] = tail.root_xyz[b * 3]; off[1] = tail.root_xyz[b * 3 + 1]; off[2] = tail.root_xyz[b * 3 + 2]; }
+  for (int e = tid; e < kNV * 3; e += kFwdThreads) {
+    const int vv = e / 3, c = e - 3 * vv;
+    const float rel = tl_sv[c * kNVP + vv] - rr[c];
+    tail.verts_rel[(size_t)b * kNV * 3 + e] = rel;
+    if (tail.verts_cam) tail.verts_cam[(size_t)b * kNV * 3 + e] = rel + off[c];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -171,6 +264,18 @@ struct ManoBwdLds {
   float root_acc[5 * 15];  // per finger: gRg0[9], gtg0[3], gJ0[3]
   float gcenter[3];
   float red[kBwdThreads / 64 * 3];
+  float gj21[63];          // fused head (ManoBwdHead): gradient wrt the 21 root-relative joints (+ the root's share)
+  float gj16[kNJ * 3];     //   ... folded onto the 16 regressed joints
+  float gr[3];             //   ... wrt the root joint
+};
+
+// gradient inputs of the fused tail (mano_fwd_kernel's ManoFwdTail); on == 0: the plain layer (gverts / gjtr)
+struct ManoBwdHead {
+  int on, root_id;
+  const float* gjoints_rel;    // [B][21][3] or null
+  const float* gverts_rel;     // [B][778][3] or null
+  const float* gverts_cam;     // [B][778][3] or null
+  const float* groot;          // [B][3] or null
 };
 
 __device__ __forceinline__ float wave_sum(float x) {
@@ -184,7 +289,7 @@ __global__ __launch_bounds__(kBwdThreads) void mano_bwd_kernel(ManoDev t, const 
                                                              const float* __restrict__ saved_vposed,
                                                              const float* __restrict__ gverts,
                                                              const float* __restrict__ gjtr,
-                                                             float* __restrict__ gpose, float* __restrict__ gbeta) {
+                                                             float* __restrict__ gpose, float* __restrict__ gbeta, ManoBwdHead head) {
   HIP_DYNAMIC_SHARED(float4, smem_raw)   // float4: 16-byte aligned base (ds_read_b128 in phase 3)
   ManoBwdLds& L = *reinterpret_cast<ManoBwdLds*>(smem_raw);
   const int b = blockIdx.x;
@@ -192,12 +297,63 @@ __global__ __launch_bounds__(kBwdThreads) void mano_bwd_kernel(ManoDev t, const 
   const int lane = tid & 63, wave = tid >> 6;
   mano_prologue(t, pose, beta, b, L.s);
 
+  // ---- phase 0 (head.on): the gradient of mano_fwd_kernel's TAIL, i.e. mano_joints_bwd_kernel folded in: from (gjoints_rel, gverts_rel,
+  //      gverts_cam, groot) to the gradient wrt the layer's vertices, formed per vertex in registers and handed to phase 1 ----
+  float g0[3] = {0.f, 0.f, 0.f};
+  if (head.on) {                                                    // (uniform)
+    static_assert(kBwdThreads >= kNVP, "a vertex per thread");
+    const int v = tid;
+    if (v < kNV) {
+      if (head.gverts_rel) { const float* p = head.gverts_rel + ((size_t)b * kNV + v) * 3; g0[0] = p[0]; g0[1] = p[1]; g0[2] = p[2]; }
+      if (head.gverts_cam) { const float* p = head.gverts_cam + ((size_t)b * kNV + v) * 3; g0[0] += p[0]; g0[1] += p[1]; g0[2] += p[2]; }
+    }
+    if (tid < 63) L.gj21[tid] = head.gjoints_rel ? head.gjoints_rel[(size_t)b * 63 + tid] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float r = wave_sum(g0[c]);
+      if (lane == 0) L.red[wave * 3 + c] = r;
+    }
+    __syncthreads();
+    if (tid < 3) {                                                  // gradient wrt the root joint: groot - sum gjoints_rel - sum (gverts_rel + gverts_cam)
+      float a = 0.f;
+      if (head.root_id >= 0) {
+        a = head.groot ? head.groot[b * 3 + tid] : 0.f;
+        for (int w = 0; w < kBwdThreads / 64; ++w) a -= L.red[w * 3 + tid];
+        for (int j = 0; j < 21; ++j) a -= L.gj21[j * 3 + tid];
+      }
+      L.gr[tid] = a;
+    }
+    __syncthreads();
+    if (tid < 3 && head.root_id >= 0) L.gj21[head.root_id * 3 + tid] += L.gr[tid];
+    __syncthreads();
+    if (tid < kNJ * 3) {
+      const int j = tid / 3, c = tid % 3;
+      float a = 0.f;
+      for (int sl = 0; sl < 21; ++sl)
+        if (c_xyz_src[sl] == j) a += L.gj21[sl * 3 + c];
+      L.gj16[tid] = a;
+    }
+    __syncthreads();
+    if (v < kNV) {
+      float wj[kNJ];
+#pragma unroll
+      for (int j = 0; j < kNJ; ++j) wj[j] = t.jreg[j * kNVP + v];
+#pragma unroll
+      for (int j = 0; j < kNJ; ++j) { g0[0] += wj[j] * L.gj16[j * 3]; g0[1] += wj[j] * L.gj16[j * 3 + 1]; g0[2] += wj[j] * L.gj16[j * 3 + 2]; }
+      for (int sl = 4; sl < 21; sl += 4)
+        if (-c_xyz_src[sl] - 1 == v) { g0[0] += L.gj21[sl * 3]; g0[1] += L.gj21[sl * 3 + 1]; g0[2] += L.gj21[sl * 3 + 2]; }
+    }
+    __syncthreads();                                                // (L.red is reused by phase 1)
+  }
+
   // ---- phase 1: stage gv (+ tip gradients) and v_posed; centre gradient = -(sum gverts + sum gjtr) ----
   float csum[3] = {0.f, 0.f, 0.f};
   for (int v = tid; v < kNVP; v += kBwdThreads) {
     float g[3] = {0.f, 0.f, 0.f}, p[3] = {0.f, 0.f, 0.f};
     if (v < kNV) {
-      if (gverts) {
+      if (head.on) {
+        g[0] = g0[0]; g[1] = g0[1]; g[2] = g0[2];                   // (one trip of this loop: v == tid)
+      } else if (gverts) {
         const float* gp = gverts + ((size_t)b * kNV + v) * 3;
         g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
       }
@@ -501,21 +657,47 @@ __global__ __launch_bounds__(256) void mano_joints_bwd_kernel(ManoDev t, const f
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_mano_fwd(const ManoDev& t, const float* pose, const float* beta, int B, float* verts, float* jtr,
                            float* saved, hipStream_t st) {
-  hipLaunchKernelGGL(mano_fwd_kernel, dim3(kFwdTiles, B), dim3(kFwdThreads), 0, st, t, pose, beta, verts, jtr, saved);
+  hipLaunchKernelGGL(mano_fwd_kernel, dim3(kFwdTiles, B), dim3(kFwdThreads), 0, st, t, pose, beta, verts, jtr, saved, ManoFwdTail{});
   return hipGetLastError();
+}
+
+hipError_t launch_mano_full_fwd(const ManoDev& t, const float* pose, const float* beta, int B, int root_id, const float* root_xyz,
+                                unsigned* counters, float* verts, float* joints_rel, float* verts_rel, float* verts_cam, float* root_out,
+                                float* saved, hipStream_t st) {
+  ManoFwdTail tail{counters, root_id, root_xyz, joints_rel, verts_rel, verts_cam, root_out};
+  hipLaunchKernelGGL(mano_fwd_kernel, dim3(kFwdTiles, B), dim3(kFwdThreads), 0, st, t, pose, beta, verts, nullptr, saved, tail);
+  return hipGetLastError();
+}
+
+static hipError_t mano_bwd_attr() {
+  if (sizeof(ManoBwdLds) <= 64 * 1024) return hipSuccess;
+  static bool attr_set[16] = {};                                   // per DEVICE (the attribute is)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidValue;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mano_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ManoBwdLds));
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_mano_bwd(const ManoDev& t, const float* pose, const float* beta, const float* saved,
                            const float* gverts, const float* gjtr, int B, float* gpose, float* gbeta, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mano_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ManoBwdLds));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = mano_bwd_attr()) return e;
   hipLaunchKernelGGL(mano_bwd_kernel, dim3(B), dim3(kBwdThreads), sizeof(ManoBwdLds), st, t, pose, beta, saved,
-                     gverts, gjtr, gpose, gbeta);
+                     gverts, gjtr, gpose, gbeta, ManoBwdHead{});
+  return hipGetLastError();
+}
+
+hipError_t launch_mano_full_bwd(const ManoDev& t, const float* pose, const float* beta, const float* saved, const float* gjoints_rel,
+                                const float* gverts_rel, const float* gverts_cam, const float* groot, int B, int root_id, float* gpose,
+                                float* gbeta, hipStream_t st) {
+  if (hipError_t e = mano_bwd_attr()) return e;
+  ManoBwdHead head{1, root_id, gjoints_rel, gverts_rel, gverts_cam, groot};
+  hipLaunchKernelGGL(mano_bwd_kernel, dim3(B), dim3(kBwdThreads), sizeof(ManoBwdLds), st, t, pose, beta, saved,
+                     nullptr, nullptr, gpose, gbeta, head);
   return hipGetLastError();
 }
 

@@ -150,12 +150,17 @@ class FreiHandDeviceCache:
 
     EXAMPLE_KEYS = ("imgs", "masks", "segms_gt", "Ks", "Ps", "joints", "verts", "j2d_gt", "scales", "idxs")
 
-    def batch_examples(self, idxs, rots=None, generator=None, out=None):
+    STEP_KEYS = ("root_xyz", "joints_rel", "verts_rel", "cam_ndc")      # what a training iteration derives from the batch (root_id given)
+
+    def batch_examples(self, idxs, rots=None, generator=None, out=None, root_id=None):
         """`data_dic(self.batch(...), "FreiHand", "training", ...)` -- the `examples` dict of a training step (reference
         utils/traineval_util.py:21-111 over data/dataset.py:223-275) -- from ONE staged copy and TWO launches
         (hifihr_freihand_batch: warp + segmentation plane; camera / joint / vertex / projection terms).  The two-step form costs
         ~30 small ATen launches and, in front of a captured step, one device copy per entry of the dict (0.3 ms of a 6.4 ms step).
-        out: a dict holding tensors for EXAMPLE_KEYS (the static inputs of traineval.GraphedTrainStep) to be written in place."""
+        out: a dict holding tensors for EXAMPLE_KEYS (the static inputs of traineval.GraphedTrainStep) to be written in place.
+        root_id (= args.ROOT): the same two launches also emit STEP_KEYS -- root_xyz [B,1,3] = joints[:, root_id], joints_rel / verts_rel
+        (train_hrnet.py:62-68) and cam_ndc [B,4] (models_res_nimble.py:184-186,228-235) -- which traineval.forward_backward and
+        Model.forward pick up instead of four elementwise launches per step."""
         B, packed = self._packed_terms(idxs, rots, generator)
         dev, J, V = self.device, self.joints.shape[1], self.verts.shape[1]
         if out is None:
@@ -164,14 +169,22 @@ class FreiHandDeviceCache:
                    "segms_gt": torch.empty(B, self.H, self.W, dtype=torch.int64, device=dev), "Ks": f(B, 3, 3), "Ps": f(B, 3, 4),
                    "joints": f(B, J, 3), "verts": f(B, V, 3), "j2d_gt": f(B, J, 2), "scales": f(B),
                    "idxs": torch.empty(B, dtype=torch.int64, device=dev)}
+            if root_id is not None:
+                out.update({"root_xyz": f(B, 1, 3), "joints_rel": f(B, J, 3), "verts_rel": f(B, V, 3), "cam_ndc": f(B, 4)})
         else:
             expect = {"imgs": (B, 3, self.H, self.W), "masks": (B, 3, self.H, self.W), "segms_gt": (B, self.H, self.W), "Ks": (B, 3, 3),
                       "Ps": (B, 3, 4), "joints": (B, J, 3), "verts": (B, V, 3), "j2d_gt": (B, J, 2), "scales": (B,), "idxs": (B,)}
+            if root_id is not None or all(k in out for k in self.STEP_KEYS):
+                expect.update({"root_xyz": (B, 1, 3), "joints_rel": (B, J, 3), "verts_rel": (B, V, 3), "cam_ndc": (B, 4)})
+                root_id = getattr(self, "_root_id", 9) if root_id is None else root_id
             for k, shape in expect.items():
                 if k not in out or tuple(out[k].shape) != shape:
                     raise ValueError(f"batch_examples(out=...): '{k}' must be a tensor of shape {shape}")
             out = {k: out[k] for k in expect}
-        self.lib.freihand_batch(self.images, self.masks, self.Ks, self.joints, self.verts, self.scales, packed, B, out)
+        if root_id is not None:
+            self._root_id = root_id                              # (a later in-place call on the same dict keeps the step terms current)
+        self.lib.freihand_batch(self.images, self.masks, self.Ks, self.joints, self.verts, self.scales, packed, B, out,
+                                root_id=root_id, image_size=self.H)
         return out
 
     def batch(self, idxs, rots=None, generator=None, out_images=None, out_masks=None):

@@ -33,6 +33,7 @@ def texture_stand_in_basis(ncomp: int) -> torch.Tensor:
     return 0.05 * torch.randn(int(ncomp), 778 * 3, generator=gen)
 
 
+_MANO_FUSED = os.environ.get("HIFIHR_MANO_FUSED", "1") != "0"
 _LIGHT_BRANCH = os.environ.get("HIFIHR_LIGHT_BRANCH", "1") != "0"
 
 
@@ -183,12 +184,15 @@ class Model(nn.Module):
         with ops.conv_precision(self.conv_precision):
             return self.base_encoder(images)
 
-    def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None):
-        low_features, features = self.encode(images)
-        return self.forward_from_features(dat_name, mode_train, images, low_features, features, Ks=Ks, root_xyz=root_xyz)
+    accepts_cam_ndc = True      # forward(..., cam_ndc=): the NDC camera terms precomputed by the batch kernel (superset of the reference's signature)
 
-    def forward_from_features(self, dat_name, mode_train, images, low_features, features, Ks=None, root_xyz=None):
-        """Everything after the image encoder (models_res_nimble.py:118-225)."""
+    def forward(self, dat_name, mode_train, images, Ks=None, root_xyz=None, cam_ndc=None):
+        low_features, features = self.encode(images)
+        return self.forward_from_features(dat_name, mode_train, images, low_features, features, Ks=Ks, root_xyz=root_xyz, cam_ndc=cam_ndc)
+
+    def forward_from_features(self, dat_name, mode_train, images, low_features, features, Ks=None, root_xyz=None, cam_ndc=None):
+        """Everything after the image encoder (models_res_nimble.py:118-225).  cam_ndc [B,4]: cat([-fcl, prp]) of get_ndc_fx_fy_cx_cy
+        (Ks) when the caller already holds it (data.FreiHandDeviceCache.batch_examples emits it with the batch)."""
         br = None
         if self.ifLight:
             # The light estimator (3 small convolutions, 2 pools, 2 linears: ~10 launches forward, ~18 backward, each a few microseconds
@@ -197,18 +201,28 @@ class Model(nn.Module):
             with ops.side_branch(low_features, "light", enabled=_LIGHT_BRANCH and self.ifRender) as br:
                 light_params = self.light_estimator(low_features)
         hand_params = self.hand_encoder(features)
-        outputs = self.hand_layer(hand_params, handle_collision=False)
-        outputs.update(hand_params)
-        if br is not None and self.hand_model == "nimble":
-            br.join(*light_params.values())
-        if self.hand_model == "nimble":
-            return self._nimble_tail(dat_name, mode_train, images, outputs, light_params if self.ifLight else None, Ks, root_xyz)
-        # joints regressed from the posed verts + root-relative (models_res_nimble.py:150-166), one HIP launch
         root_id = 0 if (dat_name == "HO3D" and not mode_train) else self.root_id
-        joints, mano_verts, pred_root = ops.mano_joints_root_relative(self.hand_layer.handle, outputs["mano_verts"], root_id)
+        verts_cam = None
+        if self.hand_model == "mano" and _MANO_FUSED and features.is_cuda:
+            # ManoLayer.forward, the joint regression, the root-relative step and the camera-space offset of the mesh: ONE launch
+            # (ops.mano_full; HIFIHR_MANO_FUSED=0: the layer, then ops.mano_joints_root_relative, then an elementwise add)
+            joints, mano_verts, verts_cam, pred_root = ops.mano_full(self.hand_layer.handle, hand_params["pose_params"], hand_params["shape_params"],
+                                                                     root_id, root_xyz if self.ifRender else None)
+            outputs = {"skin_verts": mano_verts}
+        else:
+            outputs = self.hand_layer(hand_params, handle_collision=False)
+        outputs.update(hand_params)
+        if self.hand_model == "nimble":
+            if br is not None:
+                br.join(*light_params.values())
+            return self._nimble_tail(dat_name, mode_train, images, outputs, light_params if self.ifLight else None, Ks, root_xyz)
+        if verts_cam is None:
+            # joints regressed from the posed verts + root-relative (models_res_nimble.py:150-166), one HIP launch
+            joints, mano_verts, pred_root = ops.mano_joints_root_relative(self.hand_layer.handle, outputs["mano_verts"], root_id)
+            verts_cam = (mano_verts + root_xyz) if self.ifRender else None   # skin_meshes.offset_verts_(-pred_root); .offset_verts_(+root_xyz)  (:203-205)
         outputs["joints"], outputs["mano_verts"] = joints, mano_verts
         if self.ifRender:
-            cam = self.camera_from_K(Ks)                                  # PerspectiveCameras(focal_length=-fcl, principal_point=prp)
+            cam = cam_ndc if cam_ndc is not None else self.camera_from_K(Ks)   # PerspectiveCameras(focal_length=-fcl, principal_point=prp)
             if br is not None:
                 br.join(*light_params.values())                           # the light branch meets the main chain at the renderer
             if self.ifLight:
@@ -217,8 +231,6 @@ class Model(nn.Module):
                 # PointLights() defaults (models_res_nimble.py:191-198; PyTorch3D [recalled]: ambient .5, diffuse .3, specular .2,
                 # location (0, 1, 0)): constant, the renderer was created in point-light mode and reads `directions` as the location
                 colors, directions = self._pl_color.expand(images.shape[0], -1), self._pl_location.expand(images.shape[0], -1)
-            # skin_meshes.offset_verts_(-pred_root); .offset_verts_(+root_xyz)   (models_res_nimble.py:203-205)
-            verts_cam = mano_verts + root_xyz
             vcolors = self.vertex_colors
             if self.ncomps[2]:                   # texture stand-in: per-sample vertex colours = skin tone + basis . texture_params
                 # the texture-PCA decode kernel (csrc/texpca.hip): skin tone + texture_params . basis, [B, T] x [T, 778 * 3 (+ 2 pad)]

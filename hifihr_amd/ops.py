@@ -89,6 +89,7 @@ class _ManoLBS(torch.autograd.Function):
         PROFILE.bracket("mano_lbs_fwd", lambda: handle.lib.mano_lbs_fwd(handle.h, pose, beta, verts, jtr, saved))
         ctx.handle = handle
         ctx.save_for_backward(pose, beta, saved)
+        ctx.set_materialize_grads(False)                      # an unused output's gradient arrives as None, not as a zero-filled tensor
         return verts, jtr
 
     @staticmethod
@@ -119,15 +120,62 @@ class _ManoJoints(torch.autograd.Function):
         root = torch.empty(B, 3, device=verts.device)
         PROFILE.bracket("mano_joints_fwd", lambda: handle.lib.mano_joints_fwd(handle.h, verts, root_id, joints_rel, verts_rel, root))
         ctx.handle, ctx.root_id, ctx.B = handle, root_id, B
+        ctx.set_materialize_grads(False)
         return joints_rel, verts_rel, root
 
     @staticmethod
     def backward(ctx, gj, gv, gr):
+        if gj is None and gv is None and gr is None:
+            return None, None, None
         dev = (gj if gj is not None else gv if gv is not None else gr).device
         gverts = torch.empty(ctx.B, 778, 3, device=dev)
         c = lambda t: t.contiguous() if t is not None else None
         PROFILE.bracket("mano_joints_bwd", lambda: ctx.handle.lib.mano_joints_bwd(ctx.handle.h, c(gj), c(gv), c(gr), ctx.root_id, gverts))
         return None, gverts, None
+
+
+class _ManoFull(torch.autograd.Function):
+    """ManoLayer.forward + xyz_from_vertice + root-relative step + camera-space offset: ONE launch per direction
+    (hifihr_mano_full_fwd / _bwd).  The separate forms above cost two launches forward, two backward, an elementwise add for
+    verts_cam and, in backward, its AddBackward, the accumulation of verts_rel's two gradients and two zero fills of unused outputs."""
+    _counters = {}
+
+    @staticmethod
+    def forward(ctx, handle, pose, beta, root_id, root_xyz):
+        require_cuda(pose, beta)
+        pose, beta = pose.contiguous().float(), beta.contiguous().float()
+        B, dev = pose.shape[0], pose.device
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream if torch.cuda.current_stream(dev).cuda_stream in BRANCH_STREAMS else 0)
+        cnt = _ManoFull._counters.get(key)
+        if cnt is None or cnt.numel() < B:                      # arrival counters: zero on entry, left zero (stream-ordered reuse)
+            if cnt is not None:
+                _RETIRED_SCRATCH.append(cnt)
+            cnt = _ManoFull._counters[key] = torch.zeros(max(B, 256), dtype=torch.int32, device=dev)
+        f = lambda *shape: torch.empty(*shape, device=dev)
+        verts, joints_rel, verts_rel, root, saved = f(B, 778, 3), f(B, 21, 3), f(B, 778, 3), f(B, 3), f(B, 778, 3)
+        rx = root_xyz.reshape(B, 3).contiguous().float() if root_xyz is not None else None
+        verts_cam = f(B, 778, 3)                                # (root_xyz None: = verts_rel)
+        PROFILE.bracket("mano_lbs_fwd", lambda: handle.lib.mano_full_fwd(handle.h, pose, beta, root_id, rx, cnt, verts, joints_rel, verts_rel,
+                                                                         verts_cam, root, saved))
+        ctx.handle, ctx.root_id = handle, root_id
+        ctx.save_for_backward(pose, beta, saved)
+        ctx.set_materialize_grads(False)                        # unused outputs: None, not zero-filled tensors
+        return joints_rel, verts_rel, verts_cam, root
+
+    @staticmethod
+    def backward(ctx, gj, gv, gc, gr):
+        pose, beta, saved = ctx.saved_tensors
+        B = pose.shape[0]
+        gpose, gbeta = torch.empty(B, 48, device=pose.device), torch.empty(B, 10, device=pose.device)
+        c = lambda t: t.contiguous() if t is not None else None
+        PROFILE.bracket("mano_lbs_bwd", lambda: ctx.handle.lib.mano_full_bwd(ctx.handle.h, pose, beta, saved, c(gj), c(gv), c(gc), c(gr),
+                                                                             ctx.root_id, gpose, gbeta))
+        return None, gpose, gbeta, None, None
+
+
+def mano_full(handle: ManoLayerHandle, pose, beta, root_id=9, root_xyz=None):
+    """-> joints_rel [B,21,3], verts_rel [B,778,3], verts_cam [B,778,3] (= verts_rel + root_xyz; only with root_xyz), pred_root [B,3]."""
+    return _ManoFull.apply(handle, pose, beta, root_id, root_xyz)
 
 
 def mano_joints_root_relative(handle: ManoLayerHandle, verts, root_id=9):

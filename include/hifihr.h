@@ -78,6 +78,23 @@ int hifihr_mano_joints_fwd(const hifihr_mano_t* h, const float* verts_d, int B, 
 int hifihr_mano_joints_bwd(const hifihr_mano_t* h, const float* gjoints_rel_d, const float* gverts_rel_d,
                            const float* groot_d, int B, int root_id, float* gverts_d, void* stream);
 
+/* The two steps above in ONE launch per direction (round 5): ManoLayer.forward, xyz_from_vertice, the root-relative step AND the mesh
+ * offset `skin_meshes.offset_verts_(-pred_root); .offset_verts_(root_xyz)` that precedes the renderer
+ * (reference utils/my_mano.py:315-483; Freihand_trainer_mano_fullsup.py:175-215; models_res_nimble.py:153,160-166,203-205):
+ *   verts = layer(pose, beta); joints21 = regress(verts); root = joints21[:, root_id];
+ *   joints_rel = joints21 - root; verts_rel = verts - root; verts_cam = verts_rel + root_xyz.
+ * counters_d[B] (uint32): ALL ZERO on entry, all zero again on exit (the arrival counters of a hand's tile workgroups; caller-owned so that
+ * the call stays re-entrant).  verts_d[B][778][3] receives the layer's (absolute, centred) vertices.  root_xyz_d[B][3] / verts_cam_d /
+ * root_d may be NULL.  saved_vposed_d as in hifihr_mano_lbs_fwd.  Results are bit-identical to the two-call form. */
+int hifihr_mano_full_fwd(const hifihr_mano_t* h, const float* pose_d, const float* beta_d, int B, int root_id,
+                         const float* root_xyz_d, unsigned* counters_d, float* verts_d, float* joints_rel_d,
+                         float* verts_rel_d, float* verts_cam_d, float* root_d, float* saved_vposed_d, void* stream);
+/* Gradient: gjoints_rel[B][21][3], gverts_rel[B][778][3], gverts_cam[B][778][3], groot[B][3] (any may be NULL = zero) ->
+ * gpose[B][48], gbeta[B][10] (overwritten).  Deterministic (no float atomics). */
+int hifihr_mano_full_bwd(const hifihr_mano_t* h, const float* pose_d, const float* beta_d, const float* saved_vposed_d,
+                         const float* gjoints_rel_d, const float* gverts_rel_d, const float* gverts_cam_d,
+                         const float* groot_d, int B, int root_id, float* gpose_d, float* gbeta_d, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Generic linear-blend skinning (any mesh size / kinematic tree): the NIMBLE-shaped hand layer.
  * Replaces the skinning step of  self.hand_layer(hand_params, handle_collision=False)  when `hand_model: "nimble"`
@@ -697,6 +714,17 @@ int hifihr_freihand_batch(const uint32_t* img_rgbx_d, const uint8_t* mask_d, con
                           const float* scales_d, int J, int V, const int* packed_d, int B, int H, int W, float* out_img_d,
                           float* out_mask_d, long long* out_segm_d, float* out_Ks_d, float* out_Ps_d, float* out_joints_d,
                           float* out_verts_d, float* out_j2d_d, float* out_scales_d, long long* out_idxs_d, void* stream);
+/* The same two launches, which additionally emit what every training iteration derives from the batch before the model runs
+ * (reference train_hrnet.py:62-68: root_xyz = joints[:, ROOT]; joints -= root; verts -= root;  models_res_nimble.py:184-186,228-235:
+ * the NDC camera terms of PerspectiveCameras(focal_length=-fcl, principal_point=prp)):
+ *   out_root[B][3] = joints[:, root_id] (root_id < 0: zeros), out_joints_rel[B][J][3], out_verts_rel[B][V][3],
+ *   out_cam_ndc[B][4] = (-2 fx / s, -2 fy / s, 1 - 2 cx / s, 1 - 2 cy / s) with s = image_size, from out_Ks.  Any may be NULL. */
+int hifihr_freihand_batch_step(const uint32_t* img_rgbx_d, const uint8_t* mask_d, const float* Ks_d, const float* joints_d,
+                               const float* verts_d, const float* scales_d, int J, int V, const int* packed_d, int B, int H, int W,
+                               float* out_img_d, float* out_mask_d, long long* out_segm_d, float* out_Ks_d, float* out_Ps_d,
+                               float* out_joints_d, float* out_verts_d, float* out_j2d_d, float* out_scales_d, long long* out_idxs_d,
+                               int root_id, float image_size, float* out_root_d, float* out_joints_rel_d, float* out_verts_rel_d,
+                               float* out_cam_ndc_d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HO-3D training sample assembly (the HO-3D half): the hand crop of reference data/dataset.py:1105-1215.

@@ -97,6 +97,59 @@ def mano_joints_case(lib, tables, device, B, seed, root_id=9):
         lib.mano_destroy(h)
 
 
+def mano_full_case(lib, tables, device, B, seed, root_id=9, with_cam=True):
+    """hifihr_mano_full_fwd / _bwd (layer + joint regression + root-relative step + camera-space offset in one launch per direction)
+    against the ORACLE chain (oracle/mano_oracle.py: mano_forward -> xyz_from_vertice -> root_relative -> + root_xyz) and, bit for bit in
+    the forward direction, against the two-call form of the same library."""
+    gen = torch.Generator().manual_seed(seed)
+    pose = (0.6 * torch.randn(B, 48, generator=gen)).requires_grad_(True)
+    beta = (0.7 * torch.randn(B, 10, generator=gen)).requires_grad_(True)
+    root_xyz = torch.randn(B, 3, generator=gen) * 0.3
+    verts, _, _ = mo.mano_forward(tables, pose, beta)
+    j = mo.xyz_from_vertice(tables, verts)
+    if root_id >= 0:
+        jr, vr, root = mo.root_relative(j, verts, root_id)
+    else:
+        jr, vr, root = j, verts, torch.zeros(B, 1, 3)
+    vc = vr + root_xyz.unsqueeze(1)
+    wj, wv, wc, wr = (torch.randn(B, 21, 3, generator=gen), torch.randn(B, 778, 3, generator=gen), torch.randn(B, 778, 3, generator=gen),
+                      torch.randn(B, 3, generator=gen))
+    tot = (jr * wj).sum() + (vr * wv).sum() + (root.reshape(B, 3) * wr).sum()
+    if with_cam:
+        tot = tot + (vc * wc).sum()
+    tot.backward()
+    h = lib.mano_create(tables)
+    try:
+        f = lambda *shape: torch.empty(*shape, device=device)
+        pd, bd = _dev(pose.detach(), device), _dev(beta.detach(), device)
+        cnt = torch.zeros(B + 3, dtype=torch.int32, device=device)
+        o_verts, o_j, o_v, o_c, o_r, saved = f(B, 778, 3), f(B, 21, 3), f(B, 778, 3), f(B, 778, 3), f(B, 3), f(B, 778, 3)
+        for _ in range(2):                                   # twice: the arrival counters must come back zero
+            lib.mano_full_fwd(h, pd, bd, root_id, _dev(root_xyz, device), cnt, o_verts, o_j, o_v, o_c, o_r, saved)
+            assert int(cnt.abs().sum()) == 0, "arrival counters not left zero"
+        np.testing.assert_allclose(o_j.cpu().numpy(), jr.detach().numpy(), atol=5e-6)
+        np.testing.assert_allclose(o_v.cpu().numpy(), vr.detach().numpy(), atol=5e-6)
+        np.testing.assert_allclose(o_c.cpu().numpy(), vc.detach().numpy(), atol=5e-6)
+        np.testing.assert_allclose(o_r.cpu().numpy(), root.detach().reshape(B, 3).numpy(), atol=5e-6)
+        # the two-call form of the same library: identical bits
+        t_verts, t_jtr, t_saved, t_j, t_v, t_r = f(B, 778, 3), f(B, 21, 3), f(B, 778, 3), f(B, 21, 3), f(B, 778, 3), f(B, 3)
+        lib.mano_lbs_fwd(h, pd, bd, t_verts, t_jtr, t_saved)
+        lib.mano_joints_fwd(h, t_verts, root_id, t_j, t_v, t_r)
+        assert torch.equal(t_verts, o_verts) and torch.equal(t_saved, saved) and torch.equal(t_j, o_j) and torch.equal(t_v, o_v) and torch.equal(t_r, o_r)
+        gp, gb = f(B, 48), f(B, 10)
+        lib.mano_full_bwd(h, pd, bd, saved, _dev(wj, device), _dev(wv, device), _dev(wc, device) if with_cam else None,
+                          _dev(wr, device) if root_id >= 0 else None, root_id, gp, gb)
+        eg = float(np.abs(gp.cpu().numpy() - pose.grad.numpy()).max() / np.abs(pose.grad.numpy()).max())
+        eb = float(np.abs(gb.cpu().numpy() - beta.grad.numpy()).max() / np.abs(beta.grad.numpy()).max())
+        assert eg <= 3e-4 and eb <= 3e-4, (eg, eb)
+        gp2, gb2 = f(B, 48), f(B, 10)                         # deterministic: no float atomics
+        lib.mano_full_bwd(h, pd, bd, saved, _dev(wj, device), _dev(wv, device), _dev(wc, device) if with_cam else None,
+                          _dev(wr, device) if root_id >= 0 else None, root_id, gp2, gb2)
+        assert torch.equal(gp, gp2) and torch.equal(gb, gb2)
+    finally:
+        lib.mano_destroy(h)
+
+
 # ------------------------------------------------------------------------------------------------
 # renderer
 # ------------------------------------------------------------------------------------------------
@@ -1155,6 +1208,20 @@ def freihand_batch_case(lib, device, seed=0, B=5, n=7, res=32, J=21, V=50):
     assert torch.equal(out["Ps"][:, :, :3], out["Ks"]) and float(out["Ps"][:, :, 3].abs().max()) == 0.0
     assert close(out["j2d_gt"], proj_func(wj, wK), 1e-5)
     assert torch.equal(out["scales"].cpu(), torch.from_numpy(scales)[il]) and torch.equal(out["idxs"].cpu(), il)
+    # hifihr_freihand_batch_step: the same outputs bit for bit + what a training iteration derives from them (train_hrnet.py:62-68,
+    # models_res_nimble.py:228-235), for a root inside the skeleton and for "no root"
+    for root_id in (min(9, J - 1), 0, -1):
+        out2 = {k: torch.full_like(v, 7) for k, v in out.items()}
+        out2.update({"root_xyz": f(B, 1, 3), "joints_rel": f(B, J, 3), "verts_rel": f(B, V, 3), "cam_ndc": f(B, 4)})
+        lib.freihand_batch(cache, d(mk), d(Ks), d(joints), d(verts), d(scales), d(packed), B, out2, root_id=root_id, image_size=res)
+        for k in out:
+            assert torch.equal(out[k], out2[k]), k
+        root = out["joints"][:, root_id:root_id + 1] if root_id >= 0 else torch.zeros(B, 1, 3, device=device)
+        assert torch.equal(out2["root_xyz"], root)
+        assert torch.equal(out2["joints_rel"], out["joints"] - root) and torch.equal(out2["verts_rel"], out["verts"] - root)
+        K = out["Ks"].cpu()
+        cam = torch.stack([-2 * K[:, 0, 0] / res, -2 * K[:, 1, 1] / res, 1 - 2 * K[:, 0, 2] / res, 1 - 2 * K[:, 1, 2] / res], 1)
+        assert close(out2["cam_ndc"], cam, 1e-6)
 
 
 def ho3d_batch_case(lib, device, golden_dir):

@@ -32,6 +32,12 @@ def test_mano_joints(lib, synth_tables, root_id):
     kc.mano_joints_case(lib, synth_tables, "cuda", B=33, seed=3, root_id=root_id)
 
 
+@pytest.mark.parametrize("B,root_id,with_cam", [(1, 9, True), (32, 9, True), (33, 0, True), (256, 9, False), (5, -1, True)])
+def test_mano_full_one_launch_per_direction(lib, synth_tables, B, root_id, with_cam):
+    """The step's form of the MANO rows (A7 + A8 + A10): layer + joints + root-relative + camera offset in one launch each way."""
+    kc.mano_full_case(lib, synth_tables, "cuda", B=B, seed=700 + B, root_id=root_id, with_cam=with_cam)
+
+
 def test_mano_bwd_is_deterministic(lib, synth_tables):
     h = lib.mano_create(synth_tables)
     B = 64

@@ -26,3 +26,8 @@ def test_mano_kernels_vs_oracle_random(hostsim_lib, synth_tables):
 @pytest.mark.parametrize("root_id", [9, 0, -1])
 def test_mano_joints_kernels(hostsim_lib, synth_tables, root_id):
     kc.mano_joints_case(hostsim_lib, synth_tables, "cpu", B=2, seed=3, root_id=root_id)
+
+
+@pytest.mark.parametrize("B,root_id,with_cam", [(3, 9, True), (2, 0, False), (2, -1, True)])
+def test_mano_full_kernels(hostsim_lib, synth_tables, B, root_id, with_cam):
+    kc.mano_full_case(hostsim_lib, synth_tables, "cpu", B=B, seed=41 + B, root_id=root_id, with_cam=with_cam)

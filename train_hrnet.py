@@ -335,7 +335,7 @@ def main(argv=None):
         for lo in range(0, cache.n - per_step + 1, per_step):
             idx = perm[lo + rank * B: lo + (rank + 1) * B]
             # the batch is written straight into the captured step's static inputs (one staged copy + two launches)
-            ex = cache.batch_examples(idx, generator=rot_gen, out=stepper.static if stepper is not None else None)
+            ex = cache.batch_examples(idx, generator=rot_gen, out=stepper.static if stepper is not None else None, root_id=args.ROOT)
             if cli.graph and stepper is None:
                 ok = 1
                 try:
