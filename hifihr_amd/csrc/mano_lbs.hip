@@ -99,11 +99,11 @@ struct ManoFwdTail {
   float* root_out;             // [B][3] or null
 };
 
-__device__ __forceinline__ float agent_load(const float* p) {
+__device__ __forceinline__ void agent_acquire() {
 #if defined(HIFIHR_HOSTSIM)
-  return *p;                                                        // (the emulator runs the workgroups of a grid one after another)
+  __threadfence();                                                  // (the emulator runs the workgroups of a grid one after another)
 #else
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bypasses this CU's vector L1
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
 }
 
@@ -190,10 +190,21 @@ __global__ __launch_bounds__(kFwdThreads) void mano_fwd_kernel(ManoDev t, const 
   __syncthreads();
   if (!tl_last) return;                                             // (uniform)
   if (tid == 0) tail.counters[b] = 0u;                              // self-cleaning: the next launch finds zeros
-  __threadfence();
-  for (int e = tid; e < kNV * 3; e += kFwdThreads) {
-    const int vv = e / 3, c = e - 3 * vv;
-    tl_sv[c * kNVP + vv] = agent_load(verts + (size_t)b * kNV * 3 + e);
+  // acquire at device scope (invalidates this CU's vector L1), then PLAIN loads, all of a lane's 19 in flight together: the first form
+  // read the 2 334 floats through relaxed agent-scope atomic loads, which the compiler issues one at a time -- 18 dependent L2 round
+  // trips, 21 us of a 39 us launch (profiles/r05: mano_fwd_kernel 17 + joints 5 -> 39 us fused; now the tail is one round trip)
+  agent_acquire();
+  {
+    constexpr int kPer = (kNV * 3 + kFwdThreads - 1) / kFwdThreads;
+    const float* src = verts + (size_t)b * kNV * 3;
+    float tmp[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) { const int e = tid + i * kFwdThreads; tmp[i] = e < kNV * 3 ? src[e] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = tid + i * kFwdThreads;
+      if (e < kNV * 3) { const int vv = e / 3, c = e - 3 * vv; tl_sv[c * kNVP + vv] = tmp[i]; }
+    }
   }
   __syncthreads();
   {

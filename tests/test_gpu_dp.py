@@ -61,6 +61,23 @@ def test_bench_gpus_2_plain_invocation_starts_two_ranks():
     assert d["rccl"]["world_size"] == 2 and "bench.py itself" in d["rccl"]["launched_by"]
 
 
+def test_bench_gpus_4_four_ranks_on_one_gpu():
+    """`python bench.py --gpus 4 --batch 2`: FOUR ranks (gloo, one GPU) so that the first 8-GPU run is not the first run with more than two
+    ranks -- bucket boundaries, the agreement all-reduces and the timing trial with an even world size > 2."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HIFIHR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--batch", "2"], env=env, capture_output=True, text=True, timeout=1200)
+    print(r.stdout[-2000:]); print(r.stderr[-3000:])
+    assert r.returncode == 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp4" and d["scaling"] == "weak"
+    assert d["rccl"]["world_size"] == 4 and d["rccl"]["buckets"] == 4 and len(d["rccl"]["allreduce_us_per_bucket"]) == 4
+
+
 def test_one_sided_capture_failure_falls_back_on_every_rank():
     """Rank 1's hipGraph capture fails (injected), rank 0's succeeds: the constructors are collective-free, so both meet in the agreement
     all-reduce and BOTH run the eager step -- no mismatched collective, the bench line says why."""
