@@ -77,7 +77,7 @@ class HifihrLib:
         c.hifihr_mano_lbs_bwd.argtypes = [c_void_p] + [_c_float_p] * 5 + [c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mano_joints_fwd.argtypes = [c_void_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mano_joints_bwd.argtypes = [c_void_p, _c_float_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p, c_void_p]
-        c.hifihr_mano_full_fwd.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p]
+        c.hifihr_mano_full_fwd.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p] + [_c_float_p] * 6 + [c_void_p]
         c.hifihr_mano_full_bwd.argtypes = [c_void_p] + [_c_float_p] * 7 + [c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_lbs_create.argtypes = [POINTER(c_void_p), c_int, c_int, c_int] + [_c_float_p] * 4 + [_c_int_p]
         c.hifihr_lbs_destroy.argtypes = [c_void_p]
@@ -106,6 +106,9 @@ class HifihrLib:
         for fn in (c.hifihr_dwconv2d_bwd_data, c.hifihr_dwconv2d_bwd_weight):
             fn.argtypes = [_c_float_p] * 3 + [c_int] * 10 + [c_void_p]
         c.hifihr_dwconv2d_fwd.argtypes = [_c_float_p] * 4 + [c_int] * 10 + [c_void_p]
+        c.hifihr_dwconv2d_fwd_bnswish.argtypes = [_c_float_p] * 8 + [c_int] * 10 + [c_void_p]
+        c.hifihr_dwconv2d_bwd_weight_bnswish.argtypes = [_c_float_p] * 7 + [c_int] * 10 + [c_void_p]
+        c.hifihr_bn_finalize_fwd.argtypes = [_c_float_p, c_long, c_int, c_float, c_float] + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_bn_stats_floats.argtypes = [c_int]
         c.hifihr_bn_stats_floats.restype = c_int
         c.hifihr_bn_stats.argtypes = [_c_float_p, c_long, c_int, _c_float_p, c_void_p]
@@ -278,14 +281,11 @@ class HifihrLib:
         self.check(self.c.hifihr_mano_joints_bwd(h, _fp(gjoints_rel), _fp(gverts_rel), _fp(groot), B, root_id,
                                                  _fp(gverts), _stream_of(gverts)), "hifihr_mano_joints_bwd")
 
-    def mano_full_fwd(self, h, pose, beta, root_id, root_xyz, counters, verts, joints_rel, verts_rel, verts_cam, root, saved):
-        """hifihr_mano_full_fwd: the layer + joint regression + root-relative step + camera-space offset, one launch.
-        counters: int32 [B] tensor, all zero on entry (left all zero)."""
+    def mano_full_fwd(self, h, pose, beta, root_id, root_xyz, verts, joints_rel, verts_rel, verts_cam, root, saved):
+        """hifihr_mano_full_fwd: the layer, then joint regression + root-relative step + camera-space offset."""
         B = pose.shape[0]
-        assert counters.dtype == torch.int32 and counters.is_contiguous() and counters.numel() >= B
-        self.check(self.c.hifihr_mano_full_fwd(h, _fp(pose), _fp(beta), B, int(root_id), _fp(root_xyz), c_void_p(counters.data_ptr()),
-                                               _fp(verts), _fp(joints_rel), _fp(verts_rel), _fp(verts_cam), _fp(root), _fp(saved),
-                                               _stream_of(pose)), "hifihr_mano_full_fwd")
+        self.check(self.c.hifihr_mano_full_fwd(h, _fp(pose), _fp(beta), B, int(root_id), _fp(root_xyz), _fp(verts), _fp(joints_rel), _fp(verts_rel),
+                                               _fp(verts_cam), _fp(root), _fp(saved), _stream_of(pose)), "hifihr_mano_full_fwd")
 
     def mano_full_bwd(self, h, pose, beta, saved, gjoints_rel, gverts_rel, gverts_cam, groot, root_id, gpose, gbeta):
         B = pose.shape[0]
@@ -381,6 +381,18 @@ class HifihrLib:
     def dwconv2d_fwd(self, x, w, y, N, H, W, C, OH, OW, K, stride, pt, pl, stats=None):
         self.check(self.c.hifihr_dwconv2d_fwd(_fp(x), _fp(w), _fp(y), _fp(stats), N, H, W, C, OH, OW, K, stride, pt, pl,
                                               _stream_of(x)), "hifihr_dwconv2d_fwd")
+
+    def dwconv2d_fwd_bnswish(self, x, mean, invstd, gamma, beta, w, y, N, H, W, C, OH, OW, K, stride, pt, pl, stats=None):
+        self.check(self.c.hifihr_dwconv2d_fwd_bnswish(_fp(x), _fp(mean), _fp(invstd), _fp(gamma), _fp(beta), _fp(w), _fp(y), _fp(stats), N, H, W, C,
+                                                      OH, OW, K, stride, pt, pl, _stream_of(x)), "hifihr_dwconv2d_fwd_bnswish")
+
+    def dwconv2d_bwd_weight_bnswish(self, x, mean, invstd, gamma, beta, dy, dw, N, H, W, C, OH, OW, K, stride, pt, pl):
+        self.check(self.c.hifihr_dwconv2d_bwd_weight_bnswish(_fp(x), _fp(mean), _fp(invstd), _fp(gamma), _fp(beta), _fp(dy), _fp(dw), N, H, W, C,
+                                                             OH, OW, K, stride, pt, pl, _stream_of(x)), "hifihr_dwconv2d_bwd_weight_bnswish")
+
+    def bn_finalize_fwd(self, stats, M, C, eps, momentum, save_mean, save_invstd, rmean, rvar):
+        self.check(self.c.hifihr_bn_finalize_fwd(_fp(stats), c_long(M), C, c_float(eps), c_float(momentum), _fp(save_mean), _fp(save_invstd),
+                                                 _fp(rmean), _fp(rvar), _stream_of(stats)), "hifihr_bn_finalize_fwd")
 
     def dwconv2d_bwd_data(self, dy, w, dx, N, H, W, C, OH, OW, K, stride, pt, pl):
         self.check(self.c.hifihr_dwconv2d_bwd_data(_fp(dy), _fp(w), _fp(dx), N, H, W, C, OH, OW, K, stride, pt, pl, _stream_of(dy)),

@@ -773,6 +773,14 @@ hipError_t launch_bn_act_fwd(const float* x, float* stats, const float* gamma, c
   return hipGetLastError();
 }
 
+hipError_t launch_bn_finalize_fwd(float* stats, long M, int C, float eps, float momentum, float* save_mean, float* save_invstd,
+                                  float* running_mean, float* running_var, hipStream_t st) {
+  if (!bn_c_ok(C) || M <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, M, C, eps, momentum, save_mean, save_invstd,
+                     running_mean, running_var);
+  return hipGetLastError();
+}
+
 // evaluation mode (module.eval(): running statistics, nothing updated): y = act((x - running_mean) / sqrt(running_var + eps) * gamma + beta + residual)
 hipError_t launch_bn_act_eval(const float* x, const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                               const float* residual, int act, long M, int C, float eps, float* y, hipStream_t st) {

@@ -62,9 +62,42 @@ __device__ __forceinline__ void load_row(const float* __restrict__ base, bool ro
   }
 }
 
-template <int K, int S>
+// PRE (round 5): the kernel's input is the RAW output e of the block's expand convolution and the batch-norm + swish that precede the
+// depthwise convolution in an MBConv block (reference network/efficientnet_pt/model.py:73-80: x = swish(bn0(expand_conv(x))); x =
+// depthwise_conv(x)) are applied as the rows are loaded: a = swish(e * sc + sh), zero where the window leaves the image (the padding
+// is of a, not of e).  The activated tensor -- six times the block's input, the largest tensor of the network -- is then neither written
+// by a batch-norm launch nor read back here.  sc / sh: this thread's four channels, from the layer's (mean, invstd, gamma, beta).
+struct DwPre {
+  const float *mean, *invstd, *gamma, *beta;
+};
+__device__ __forceinline__ void dw_pre_affine(const DwPre& p, int c, bool cok, float4& sc, float4& sh) {
+  sc = zero4(); sh = zero4();
+  if (!cok) return;
+  const float4 mu = *reinterpret_cast<const float4*>(p.mean + c), is = *reinterpret_cast<const float4*>(p.invstd + c);
+  const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c), be = *reinterpret_cast<const float4*>(p.beta + c);
+  sc = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);          // (the expressions of bn_act_fwd_kernel: same bits)
+  sh = make_float4(be.x - mu.x * sc.x, be.y - mu.y * sc.y, be.z - mu.z * sc.z, be.w - mu.w * sc.w);
+}
+__device__ __forceinline__ float4 dw_swish_affine(const float4& t, const float4& sc, const float4& sh) {
+  float4 r = make_float4(t.x * sc.x + sh.x, t.y * sc.y + sh.y, t.z * sc.z + sh.z, t.w * sc.w + sh.w);
+  r.x = r.x * fast_sigmoid(r.x); r.y = r.y * fast_sigmoid(r.y); r.z = r.z * fast_sigmoid(r.z); r.w = r.w * fast_sigmoid(r.w);
+  return r;
+}
+template <int NC>
+__device__ __forceinline__ void load_row_pre(const float* __restrict__ base, bool rowok, int iw0, int W, int C, const float4& sc,
+                                             const float4& sh, float4 (&v)[NC]) {
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int iw = iw0 + j;
+    const bool ok = rowok && iw >= 0 && iw < W;
+    const float4 t = *reinterpret_cast<const float4*>(base + (size_t)(ok ? iw : 0) * C);
+    v[j] = ok ? dw_swish_affine(t, sc, sh) : zero4();
+  }
+}
+
+template <int K, int S, bool PRE>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* __restrict__ x, const float* __restrict__ w,
-                                                        float* __restrict__ y, float* __restrict__ stats) {
+                                                        float* __restrict__ y, float* __restrict__ stats, DwPre pre) {
   constexpr int KK = K * K, NC = (kPW - 1) * S + K;
   __shared__ float wl[KK][64];
   __shared__ double red[2][16][16][4];
@@ -72,6 +105,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* 
   const int c0 = blockIdx.y * 64, c = c0 + cl * 4;
   const bool cok = c < g.C;
   stage_weights<KK>(w, g.C, c0, wl);
+  float4 psc = zero4(), psh = zero4();
+  if constexpr (PRE) dw_pre_affine(pre, c, cok, psc, psh);
   __syncthreads();
   const int OWB = (g.OW + kPW - 1) / kPW;
   const long nb = (long)g.N * g.OH * OWB;
@@ -89,7 +124,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwGeom g, const float* 
         const int ih = oh * S - g.pt + r;
         const bool rowok = ih >= 0 && ih < g.H;
         float4 v[NC];
-        load_row<NC>(x + ((size_t)n * g.H + (rowok ? ih : 0)) * g.W * g.C + c, rowok, ow0 * S - g.pl, g.W, g.C, v);
+        if constexpr (PRE) load_row_pre<NC>(x + ((size_t)n * g.H + (rowok ? ih : 0)) * g.W * g.C + c, rowok, ow0 * S - g.pl, g.W, g.C, psc, psh, v);
+        else load_row<NC>(x + ((size_t)n * g.H + (rowok ? ih : 0)) * g.W * g.C + c, rowok, ow0 * S - g.pl, g.W, g.C, v);
 #pragma unroll
         for (int s = 0; s < K; ++s) {
           const float4 wt = *reinterpret_cast<const float4*>(&wl[r * K + s][cl * 4]);
@@ -187,13 +223,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(DwGeom g, const fl
 
 // dw[c][r][s] += sum over output pixels of dy * x.  (Round 4 measured a workgroup per filter ROW -- blockIdx.z = r, K accumulators, 64-92
 // registers instead of 139-354: 1 247 -> 1 291 us per EfficientNet-b3 step, dy and x are then re-read K times from L2; not kept.)
-template <int K, int S>
+template <int K, int S, bool PRE>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwGeom g, const float* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ dw) {
+                                                               float* __restrict__ dw, DwPre pre) {
   constexpr int KK = K * K, NC = (kPW - 1) * S + K;
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int c = blockIdx.y * 64 + cl * 4;
   const bool cok = c < g.C;
+  float4 psc = zero4(), psh = zero4();
+  if constexpr (PRE) dw_pre_affine(pre, c, cok, psc, psh);
   const int OWB = (g.OW + kPW - 1) / kPW;
   const long nb = (long)g.N * g.OH * OWB;
   float4 acc[KK];
@@ -220,7 +258,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwGeom g, const 
         const int ih = oh * S - g.pt + r;
         const bool rowok = ih >= 0 && ih < g.H;
         float4 v[NC];
-        load_row<NC>(x + ((size_t)n * g.H + (rowok ? ih : 0)) * g.W * g.C + c, rowok, ow0 * S - g.pl, g.W, g.C, v);
+        if constexpr (PRE) load_row_pre<NC>(x + ((size_t)n * g.H + (rowok ? ih : 0)) * g.W * g.C + c, rowok, ow0 * S - g.pl, g.W, g.C, psc, psh, v);
+        else load_row<NC>(x + ((size_t)n * g.H + (rowok ? ih : 0)) * g.W * g.C + c, rowok, ow0 * S - g.pl, g.W, g.C, v);
 #pragma unroll
         for (int s = 0; s < K; ++s)
 #pragma unroll
@@ -272,8 +311,17 @@ static unsigned dw_grid_x(long nb, long cap) {
     else if (g.K == 5 && g.stride == 2) hipLaunchKernelGGL((KERNEL<5, 2>), GRID, dim3(256), 0, st, __VA_ARGS__); \
     else return hipErrorInvalidValue;                                                                           \
   } while (0)
+#define HIFIHR_DW_DISPATCH_PRE(KERNEL, PRE_, GRID, ...)                                                              \
+  do {                                                                                                                \
+    if (g.K == 3 && g.stride == 1) hipLaunchKernelGGL((KERNEL<3, 1, PRE_>), GRID, dim3(256), 0, st, __VA_ARGS__);      \
+    else if (g.K == 3 && g.stride == 2) hipLaunchKernelGGL((KERNEL<3, 2, PRE_>), GRID, dim3(256), 0, st, __VA_ARGS__); \
+    else if (g.K == 5 && g.stride == 1) hipLaunchKernelGGL((KERNEL<5, 1, PRE_>), GRID, dim3(256), 0, st, __VA_ARGS__); \
+    else if (g.K == 5 && g.stride == 2) hipLaunchKernelGGL((KERNEL<5, 2, PRE_>), GRID, dim3(256), 0, st, __VA_ARGS__); \
+    else return hipErrorInvalidValue;                                                                                 \
+  } while (0)
 
-hipError_t launch_dwconv_fwd(const DwGeom& g_in, const float* x, const float* w, float* y, float* stats, hipStream_t st) {
+hipError_t launch_dwconv_fwd(const DwGeom& g_in, const float* x, const float* w, float* y, float* stats, hipStream_t st, const float* pre_mean,
+                             const float* pre_invstd, const float* pre_gamma, const float* pre_beta) {
   DwGeom g = g_in;
   g.vorder = dw_vorder();
   const long nb = (long)g.N * g.OH * ((g.OW + kPW - 1) / kPW);
@@ -281,7 +329,9 @@ hipError_t launch_dwconv_fwd(const DwGeom& g_in, const float* x, const float* w,
   static const long cap_stats = [] { const char* e = getenv("HIFIHR_DW_FWD_CAP"); return e && atol(e) > 0 ? atol(e) : 256L; }();
   static const long cap_plain = [] { const char* e = getenv("HIFIHR_DW_CAP"); return e && atol(e) > 0 ? atol(e) : 2048L; }();
   const dim3 grid(dw_grid_x(nb, stats != nullptr ? cap_stats : cap_plain), (g.C + 63) / 64);
-  HIFIHR_DW_DISPATCH(dwconv_fwd_kernel, grid, g, x, w, y, stats);
+  const DwPre pre{pre_mean, pre_invstd, pre_gamma, pre_beta};
+  if (pre_mean != nullptr) { HIFIHR_DW_DISPATCH_PRE(dwconv_fwd_kernel, true, grid, g, x, w, y, stats, pre); }
+  else { HIFIHR_DW_DISPATCH_PRE(dwconv_fwd_kernel, false, grid, g, x, w, y, stats, pre); }
   return hipGetLastError();
 }
 hipError_t launch_dwconv_bwd_data(const DwGeom& g_in, const float* dy, const float* w, float* dx, hipStream_t st) {
@@ -293,7 +343,8 @@ hipError_t launch_dwconv_bwd_data(const DwGeom& g_in, const float* dy, const flo
   HIFIHR_DW_DISPATCH(dwconv_bwd_data_kernel, grid, g, dy, w, dx);
   return hipGetLastError();
 }
-hipError_t launch_dwconv_bwd_weight(const DwGeom& g_in, const float* x, const float* dy, float* dw, hipStream_t st) {
+hipError_t launch_dwconv_bwd_weight(const DwGeom& g_in, const float* x, const float* dy, float* dw, hipStream_t st, const float* pre_mean,
+                                    const float* pre_invstd, const float* pre_gamma, const float* pre_beta) {
   DwGeom g = g_in;
   g.vorder = dw_vorder();
   const long nb = (long)g.N * g.OH * ((g.OW + kPW - 1) / kPW);
@@ -303,7 +354,9 @@ hipError_t launch_dwconv_bwd_weight(const DwGeom& g_in, const float* x, const fl
   if (gx < 8) gx = 8;
   if (gx > 128) gx = 128;
   const dim3 grid((unsigned)gx, (g.C + 63) / 64);
-  HIFIHR_DW_DISPATCH(dwconv_bwd_weight_kernel, grid, g, x, dy, dw);
+  const DwPre pre{pre_mean, pre_invstd, pre_gamma, pre_beta};
+  if (pre_mean != nullptr) { HIFIHR_DW_DISPATCH_PRE(dwconv_bwd_weight_kernel, true, grid, g, x, dy, dw, pre); }
+  else { HIFIHR_DW_DISPATCH_PRE(dwconv_bwd_weight_kernel, false, grid, g, x, dy, dw, pre); }
   return hipGetLastError();
 }
 

@@ -227,12 +227,11 @@ int hifihr_mano_lbs_bwd(const hifihr_mano_t* h, const float* pose, const float* 
 }
 
 int hifihr_mano_full_fwd(const hifihr_mano_t* h, const float* pose, const float* beta, int B, int root_id, const float* root_xyz,
-                         unsigned* counters, float* verts, float* joints_rel, float* verts_rel, float* verts_cam, float* root, float* saved,
-                         void* stream) {
-  if (!h || !pose || !beta || !counters || !verts || !joints_rel || !verts_rel || B < 0 || root_id >= 21)
+                         float* verts, float* joints_rel, float* verts_rel, float* verts_cam, float* root, float* saved, void* stream) {
+  if (!h || !pose || !beta || !verts || !joints_rel || !verts_rel || B < 0 || root_id >= 21)
     return fail(HIFIHR_EINVAL, "hifihr_mano_full_fwd: bad argument");
   if (B == 0) return HIFIHR_OK;
-  HIP_TRY(hifihr::launch_mano_full_fwd(h->dev, pose, beta, B, root_id, root_xyz, counters, verts, joints_rel, verts_rel, verts_cam, root, saved,
+  HIP_TRY(hifihr::launch_mano_full_fwd(h->dev, pose, beta, B, root_id, root_xyz, verts, joints_rel, verts_rel, verts_cam, root, saved,
                                        (hipStream_t)stream));
   return HIFIHR_OK;
 }
@@ -678,6 +677,34 @@ int hifihr_dwconv2d_fwd(const float* x, const float* w, float* y, float* stats, 
   if (!x || !w || !y || !dw_ok(N, H, W, C, OH, OW, K, stride, pad_top, pad_left)) return fail(HIFIHR_EINVAL, "hifihr_dwconv2d_fwd: bad argument");
   hifihr::DwGeom g{N, H, W, C, OH, OW, K, stride, pad_top, pad_left};
   HIP_TRY(hifihr::launch_dwconv_fwd(g, x, w, y, stats, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_dwconv2d_fwd_bnswish(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                const float* w, float* y, float* stats, int N, int H, int W, int C, int OH, int OW, int K, int stride,
+                                int pad_top, int pad_left, void* stream) {
+  if (!x || !mean || !invstd || !gamma || !beta || !w || !y || !dw_ok(N, H, W, C, OH, OW, K, stride, pad_top, pad_left))
+    return fail(HIFIHR_EINVAL, "hifihr_dwconv2d_fwd_bnswish: bad argument");
+  hifihr::DwGeom g{N, H, W, C, OH, OW, K, stride, pad_top, pad_left};
+  HIP_TRY(hifihr::launch_dwconv_fwd(g, x, w, y, stats, (hipStream_t)stream, mean, invstd, gamma, beta));
+  return HIFIHR_OK;
+}
+
+int hifihr_dwconv2d_bwd_weight_bnswish(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                       const float* dy, float* dw, int N, int H, int W, int C, int OH, int OW, int K, int stride,
+                                       int pad_top, int pad_left, void* stream) {
+  if (!x || !mean || !invstd || !gamma || !beta || !dy || !dw || !dw_ok(N, H, W, C, OH, OW, K, stride, pad_top, pad_left))
+    return fail(HIFIHR_EINVAL, "hifihr_dwconv2d_bwd_weight_bnswish: bad argument");
+  hifihr::DwGeom g{N, H, W, C, OH, OW, K, stride, pad_top, pad_left};
+  HIP_TRY(hifihr::launch_dwconv_bwd_weight(g, x, dy, dw, (hipStream_t)stream, mean, invstd, gamma, beta));
+  return HIFIHR_OK;
+}
+
+int hifihr_bn_finalize_fwd(float* stats, long M, int C, float eps, float momentum, float* save_mean, float* save_invstd,
+                           float* running_mean, float* running_var, void* stream) {
+  if (!stats || !save_mean || !save_invstd || M <= 0 || C < 4 || C % 4 != 0 || (running_mean == nullptr) != (running_var == nullptr))
+    return fail(HIFIHR_EINVAL, "hifihr_bn_finalize_fwd: bad argument");
+  HIP_TRY(hifihr::launch_bn_finalize_fwd(stats, M, C, eps, momentum, save_mean, save_invstd, running_mean, running_var, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

@@ -30,8 +30,8 @@ hipError_t launch_mano_fwd(const ManoDev& t, const float* pose, const float* bet
 hipError_t launch_mano_bwd(const ManoDev& t, const float* pose, const float* beta, const float* saved,
                            const float* gverts, const float* gjtr, int B, float* gpose, float* gbeta, hipStream_t st);
 hipError_t launch_mano_full_fwd(const ManoDev& t, const float* pose, const float* beta, int B, int root_id, const float* root_xyz,
-                                unsigned* counters, float* verts, float* joints_rel, float* verts_rel, float* verts_cam, float* root_out,
-                                float* saved, hipStream_t st);
+                                float* verts, float* joints_rel, float* verts_rel, float* verts_cam, float* root_out, float* saved,
+                                hipStream_t st);
 hipError_t launch_mano_full_bwd(const ManoDev& t, const float* pose, const float* beta, const float* saved, const float* gjoints_rel,
                                 const float* gverts_rel, const float* gverts_cam, const float* groot, int B, int root_id, float* gpose,
                                 float* gbeta, hipStream_t st);
@@ -238,9 +238,17 @@ struct DwGeom {
                        // 4-pixel column block, whose windows share K - 1 of K input rows in L1.  Measured per EfficientNet-b3 step (tools/time_dwconv.py):
                        // forward 940 -> 913 us, backward-data 750 -> 732, backward-weight 1 306 -> 1 506; single shapes +-25 % either way: off
 };
-hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, float* stats, hipStream_t st);
+// pre_* (all four or none): x is the raw output of the preceding convolution; swish(batch_norm(x)) is applied as it is loaded
+hipError_t launch_dwconv_fwd(const DwGeom& g, const float* x, const float* w, float* y, float* stats, hipStream_t st,
+                             const float* pre_mean = nullptr, const float* pre_invstd = nullptr, const float* pre_gamma = nullptr,
+                             const float* pre_beta = nullptr);
 hipError_t launch_dwconv_bwd_data(const DwGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
-hipError_t launch_dwconv_bwd_weight(const DwGeom& g, const float* x, const float* dy, float* dw, hipStream_t st);
+hipError_t launch_dwconv_bwd_weight(const DwGeom& g, const float* x, const float* dy, float* dw, hipStream_t st,
+                                    const float* pre_mean = nullptr, const float* pre_invstd = nullptr, const float* pre_gamma = nullptr,
+                                    const float* pre_beta = nullptr);
+// the statistics half of a training batch-norm alone: slots -> (save_mean, save_invstd), running statistics, slots handed back zeroed
+hipError_t launch_bn_finalize_fwd(float* stats, long M, int C, float eps, float momentum, float* save_mean, float* save_invstd,
+                                  float* running_mean, float* running_var, hipStream_t st);
 
 hipError_t launch_mmpool_fwd(const float* x, const float* p, int B, int HW, int C, float* y, int* argmax, float* xmax, float* xavg,
                              hipStream_t st);

@@ -74,47 +74,14 @@ __device__ __forceinline__ void mano_prologue(const ManoDev& t, const float* __r
 // latencies per workgroup -- the per-hand prologue, then 145 table rows per vertex -- and a batch of 32 hands gave the 256-CU chip 128
 // workgroups; 224 smaller ones with all 27 rows of a group of pose blend shapes in flight per lane (5 groups instead of 27 of 5) shorten
 // the chain.  Every workgroup redoes the prologue (16 Rodrigues + the kinematic chain: ~2 us).
-__device__ __forceinline__ float wave_sum_fwd(float x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-  return x;
-}
-
 constexpr int kFwdTiles = 7;
 constexpr int kFwdTileV = 112;   // 7 x 112 = 784 >= 778
 constexpr int kFwdThreads = 128;
 
-// The joint regression + root-relative step that follows the layer in Model.forward (mano_joints_fwd_kernel below) as the TAIL of this
-// launch (round 5): `tail.counters` != null -> the tile workgroup of a hand that finishes LAST (device-scope arrival counter, left zero)
-// reads the hand's 778 vertices back (agent-scope loads: they were written by other CUs) and writes joints_rel / verts_rel / root and
-// verts_cam = verts_rel + root_xyz (the `skin_meshes.offset_verts_(root_xyz)` of models_res_nimble.py:203-205) -- one launch and one
-// elementwise add fewer on the step's critical path (a chain of ~5 us launches there).
-struct ManoFwdTail {
-  unsigned* counters;          // [B], all zero on entry, all zero on exit; null = no tail
-  int root_id;                 // 0..20, or < 0: no subtraction
-  const float* root_xyz;       // [B][3] or null
-  float* joints_rel;           // [B][21][3]
-  float* verts_rel;            // [B][778][3]
-  float* verts_cam;            // [B][778][3] or null
-  float* root_out;             // [B][3] or null
-};
-
-__device__ __forceinline__ void agent_acquire() {
-#if defined(HIFIHR_HOSTSIM)
-  __threadfence();                                                  // (the emulator runs the workgroups of a grid one after another)
-#else
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-}
-
 __global__ __launch_bounds__(kFwdThreads) void mano_fwd_kernel(ManoDev t, const float* __restrict__ pose,
                                                       const float* __restrict__ beta, float* __restrict__ verts,
-                                                      float* __restrict__ jtr, float* __restrict__ saved_vposed, ManoFwdTail tail) {
+                                                      float* __restrict__ jtr, float* __restrict__ saved_vposed) {
   __shared__ ManoSmall s;
-  __shared__ float tl_sv[3 * kNVP];
-  __shared__ float tl_j16[kNJ * 3];
-  __shared__ float tl_j21[21 * 3];
-  __shared__ int tl_last;
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   mano_prologue(t, pose, beta, b, s);
@@ -181,76 +148,6 @@ __global__ __launch_bounds__(kFwdThreads) void mano_fwd_kernel(ManoDev t, const 
     }
   }
   }   // (vertex lanes)
-  if (tail.counters == nullptr) return;                             // (uniform)
-
-  // ---------------- tail: the last tile of hand b to arrive regresses the joints ----------------
-  __threadfence();                                                  // this workgroup's vertices: visible device-wide before it is counted
-  __syncthreads();
-  if (tid == 0) tl_last = (atomicAdd(tail.counters + b, 1u) == (unsigned)(kFwdTiles - 1)) ? 1 : 0;
-  __syncthreads();
-  if (!tl_last) return;                                             // (uniform)
-  if (tid == 0) tail.counters[b] = 0u;                              // self-cleaning: the next launch finds zeros
-  // acquire at device scope (invalidates this CU's vector L1), then PLAIN loads, all of a lane's 19 in flight together: the first form
-  // read the 2 334 floats through relaxed agent-scope atomic loads, which the compiler issues one at a time -- 18 dependent L2 round
-  // trips, 21 us of a 39 us launch (profiles/r05: mano_fwd_kernel 17 + joints 5 -> 39 us fused; now the tail is one round trip)
-  agent_acquire();
-  {
-    constexpr int kPer = (kNV * 3 + kFwdThreads - 1) / kFwdThreads;
-    const float* src = verts + (size_t)b * kNV * 3;
-    float tmp[kPer];
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) { const int e = tid + i * kFwdThreads; tmp[i] = e < kNV * 3 ? src[e] : 0.f; }
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-      const int e = tid + i * kFwdThreads;
-      if (e < kNV * 3) { const int vv = e / 3, c = e - 3 * vv; tl_sv[c * kNVP + vv] = tmp[i]; }
-    }
-  }
-  __syncthreads();
-  {
-    // a wave takes 8 of the 16 regressed joints; the 8 regressor rows are all in flight before the first is used (one memory latency)
-    const int lane = tid & 63, wave = tid >> 6;
-    constexpr int kIt = (kNV + 63) / 64;
-    constexpr int kJW = kNJ / (kFwdThreads / 64);
-    static_assert(kNJ % (kFwdThreads / 64) == 0, "joints split evenly over the waves");
-    float rv[kJW][kIt];
-#pragma unroll
-    for (int q = 0; q < kJW; ++q) {
-      const float* jr = t.jreg + (wave * kJW + q) * kNVP;
-#pragma unroll
-      for (int i = 0; i < kIt; ++i) { const int vv = lane + 64 * i; rv[q][i] = vv < kNV ? jr[vv] : 0.f; }
-    }
-#pragma unroll
-    for (int q = 0; q < kJW; ++q) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < kIt; ++i) {
-        const int vv = lane + 64 * i;
-        if (vv < kNV) { a0 += rv[q][i] * tl_sv[vv]; a1 += rv[q][i] * tl_sv[kNVP + vv]; a2 += rv[q][i] * tl_sv[2 * kNVP + vv]; }
-      }
-      a0 = wave_sum_fwd(a0); a1 = wave_sum_fwd(a1); a2 = wave_sum_fwd(a2);
-      if (lane == 0) { const int j = wave * kJW + q; tl_j16[j * 3] = a0; tl_j16[j * 3 + 1] = a1; tl_j16[j * 3 + 2] = a2; }
-    }
-  }
-  __syncthreads();
-  if (tid < 63) {
-    const int sl = tid / 3, c = tid % 3;
-    const int src = c_xyz_src[sl];
-    tl_j21[tid] = (src >= 0) ? tl_j16[src * 3 + c] : tl_sv[c * kNVP + (-src - 1)];
-  }
-  __syncthreads();
-  float rr[3] = {0.f, 0.f, 0.f};
-  if (tail.root_id >= 0) { rr[0] = tl_j21[tail.root_id * 3]; rr[1] = tl_j21[tail.root_id * 3 + 1]; rr[2] = tl_j21[tail.root_id * 3 + 2]; }
-  if (tid < 63) tail.joints_rel[(size_t)b * 63 + tid] = tl_j21[tid] - rr[tid % 3];
-  if (tid < 3 && tail.root_out) tail.root_out[b * 3 + tid] = rr[tid];
-  float off[3] = {0.f, 0.f, 0.f};
-  if (tail.root_xyz) { off[0] = tail.root_xyz[b * 3]; off[1] = tail.root_xyz[b * 3 + 1]; off[2] = tail.root_xyz[b * 3 + 2]; }
-  for (int e = tid; e < kNV * 3; e += kFwdThreads) {
-    const int vv = e / 3, c = e - 3 * vv;
-    const float rel = tl_sv[c * kNVP + vv] - rr[c];
-    tail.verts_rel[(size_t)b * kNV * 3 + e] = rel;
-    if (tail.verts_cam) tail.verts_cam[(size_t)b * kNV * 3 + e] = rel + off[c];
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,7 +177,7 @@ struct ManoBwdLds {
   float gr[3];             //   ... wrt the root joint
 };
 
-// gradient inputs of the fused tail (mano_fwd_kernel's ManoFwdTail); on == 0: the plain layer (gverts / gjtr)
+// gradient inputs of the fused form (hifihr_mano_full_bwd): the joint regression's backward as the head of this kernel; on == 0: the plain layer (gverts / gjtr)
 struct ManoBwdHead {
   int on, root_id;
   const float* gjoints_rel;    // [B][21][3] or null
@@ -308,7 +205,7 @@ __global__ __launch_bounds__(kBwdThreads) void mano_bwd_kernel(ManoDev t, const 
   const int lane = tid & 63, wave = tid >> 6;
   mano_prologue(t, pose, beta, b, L.s);
 
-  // ---- phase 0 (head.on): the gradient of mano_fwd_kernel's TAIL, i.e. mano_joints_bwd_kernel folded in: from (gjoints_rel, gverts_rel,
+  // ---- phase 0 (head.on): mano_joints_bwd_kernel folded in: from (gjoints_rel, gverts_rel,
   //      gverts_cam, groot) to the gradient wrt the layer's vertices, formed per vertex in registers and handed to phase 1 ----
   float g0[3] = {0.f, 0.f, 0.f};
   if (head.on) {                                                    // (uniform)
@@ -553,7 +450,8 @@ constexpr int kJointsFwdThreads = 1024;   // 16 waves: the 48 regressor dot prod
                                           // workgroup per hand is all the parallelism a batch of 32 offers, so the kernel is a latency chain
 __global__ __launch_bounds__(kJointsFwdThreads) void mano_joints_fwd_kernel(ManoDev t, const float* __restrict__ verts, int root_id,
                                                              float* __restrict__ joints_rel, float* __restrict__ verts_rel,
-                                                             float* __restrict__ root_out) {
+                                                             float* __restrict__ root_out, const float* __restrict__ root_xyz,
+                                                             float* __restrict__ verts_cam) {
   __shared__ float sv[3 * kNVP];
   __shared__ float j16[kNJ * 3];
   __shared__ float j21[21 * 3];
@@ -592,10 +490,16 @@ __global__ __launch_bounds__(kJointsFwdThreads) void mano_joints_fwd_kernel(Mano
   if (root_id >= 0) { r[0] = j21[root_id * 3]; r[1] = j21[root_id * 3 + 1]; r[2] = j21[root_id * 3 + 2]; }
   if (tid < 63) joints_rel[(size_t)b * 63 + tid] = j21[tid] - r[tid % 3];
   if (tid < 3 && root_out) root_out[b * 3 + tid] = r[tid];
-  if (verts_rel) {
+  // verts_cam = verts_rel + root_xyz: the `skin_meshes.offset_verts_(-pred_root); .offset_verts_(root_xyz)` in front of the renderer
+  // (models_res_nimble.py:203-205), here instead of an elementwise launch of its own
+  float off[3] = {0.f, 0.f, 0.f};
+  if (root_xyz) { off[0] = root_xyz[b * 3]; off[1] = root_xyz[b * 3 + 1]; off[2] = root_xyz[b * 3 + 2]; }
+  if (verts_rel || verts_cam) {
     for (int e = tid; e < kNV * 3; e += kJointsFwdThreads) {
       const int v = e / 3, c = e % 3;
-      verts_rel[(size_t)b * kNV * 3 + e] = sv[c * kNVP + v] - r[c];
+      const float rel = sv[c * kNVP + v] - r[c];
+      if (verts_rel) verts_rel[(size_t)b * kNV * 3 + e] = rel;
+      if (verts_cam) verts_cam[(size_t)b * kNV * 3 + e] = rel + off[c];
     }
   }
 }
@@ -668,15 +572,21 @@ __global__ __launch_bounds__(256) void mano_joints_bwd_kernel(ManoDev t, const f
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_mano_fwd(const ManoDev& t, const float* pose, const float* beta, int B, float* verts, float* jtr,
                            float* saved, hipStream_t st) {
-  hipLaunchKernelGGL(mano_fwd_kernel, dim3(kFwdTiles, B), dim3(kFwdThreads), 0, st, t, pose, beta, verts, jtr, saved, ManoFwdTail{});
+  hipLaunchKernelGGL(mano_fwd_kernel, dim3(kFwdTiles, B), dim3(kFwdThreads), 0, st, t, pose, beta, verts, jtr, saved);
   return hipGetLastError();
 }
 
+// Forward of the fused form: TWO launches (layer, then joint regression + root-relative step + camera-space offset).  MEASURED dead end
+// (round 5): the joint regression as the tail of mano_fwd_kernel -- the last of a hand's seven tile workgroups to arrive (device-scope
+// arrival counter, release / acquire fences) reads the hand's vertices back and regresses the joints on its 128 threads -- ran 33.6 us
+// against 17.3 + 5.4 us for the two launches (38.8 before its loads were taken off relaxed atomics): the fences and a 2-wave
+// regression cost more than the launch they save.  The BACKWARD is one launch (mano_bwd_kernel's ManoBwdHead).
 hipError_t launch_mano_full_fwd(const ManoDev& t, const float* pose, const float* beta, int B, int root_id, const float* root_xyz,
-                                unsigned* counters, float* verts, float* joints_rel, float* verts_rel, float* verts_cam, float* root_out,
-                                float* saved, hipStream_t st) {
-  ManoFwdTail tail{counters, root_id, root_xyz, joints_rel, verts_rel, verts_cam, root_out};
-  hipLaunchKernelGGL(mano_fwd_kernel, dim3(kFwdTiles, B), dim3(kFwdThreads), 0, st, t, pose, beta, verts, nullptr, saved, tail);
+                                float* verts, float* joints_rel, float* verts_rel, float* verts_cam, float* root_out, float* saved,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(mano_fwd_kernel, dim3(kFwdTiles, B), dim3(kFwdThreads), 0, st, t, pose, beta, verts, (float*)nullptr, saved);
+  hipLaunchKernelGGL(mano_joints_fwd_kernel, dim3(B), dim3(kJointsFwdThreads), 0, st, t, (const float*)verts, root_id, joints_rel, verts_rel,
+                     root_out, root_xyz, verts_cam);
   return hipGetLastError();
 }
 
@@ -714,7 +624,8 @@ hipError_t launch_mano_full_bwd(const ManoDev& t, const float* pose, const float
 
 hipError_t launch_mano_joints_fwd(const ManoDev& t, const float* verts, int B, int root_id, float* joints_rel,
                                   float* verts_rel, float* root, hipStream_t st) {
-  hipLaunchKernelGGL(mano_joints_fwd_kernel, dim3(B), dim3(kJointsFwdThreads), 0, st, t, verts, root_id, joints_rel, verts_rel, root);
+  hipLaunchKernelGGL(mano_joints_fwd_kernel, dim3(B), dim3(kJointsFwdThreads), 0, st, t, verts, root_id, joints_rel, verts_rel, root,
+                     (const float*)nullptr, (float*)nullptr);
   return hipGetLastError();
 }
 

@@ -66,6 +66,9 @@ def b3_block_table():
     return out
 
 
+_FUSE_BN0 = os.environ.get("HIFIHR_EFFNET_FUSE_BN0", "1") != "0"
+
+
 class SqueezeExciteConv(nn.Conv2d):
     """The 1x1 `_se_reduce` / `_se_expand` convolutions: parameter holders with nn.Conv2d's state-dict names (weight, bias);
     the arithmetic runs inside ops.squeeze_excite."""
@@ -149,7 +152,16 @@ class MBConvBlock(nn.Module):
     def forward(self, inputs, drop_connect_rate=None):
         x = inputs
         from . import ops
-        if self.expand != 1:
+        fused_expand = None
+        if self.expand != 1 and _FUSE_BN0 and self._bn0.training and x.is_cuda:
+            # (HIFIHR_EFFNET_FUSE_BN0=0: bn0 + swish as a launch of its own, the activated tensor materialised)
+            skip = self.stride == 1 and self.cin == self.cout
+            if skip and inputs.requires_grad and torch.is_grad_enabled() and os.environ.get("HIFIHR_EFFNET_FORK", "1") != "0":
+                e, st0, inputs = self._expand_conv(x, want_stats=True, fork=True)
+            else:
+                e, st0 = self._expand_conv(x, want_stats=True)
+            fused_expand = (e, st0)
+        elif self.expand != 1:
             # (the skip connection's gradient joins the expand convolution's backward-data launch -- which then runs on conv_igemm_kernel,
             #  the only epilogue that adds one, instead of the row-share GEMM: config 3 35.09 / 35.14 -> 35.05 / 35.06 ms/step and 19 launches
             #  fewer; HIFIHR_EFFNET_FORK=0 leaves the sum to autograd)
@@ -158,7 +170,14 @@ class MBConvBlock(nn.Module):
                 x, inputs = _conv_bn_swish(self._expand_conv, self._bn0, x, fork=True)
             else:
                 x = _conv_bn_swish(self._expand_conv, self._bn0, x)
-        x = _conv_bn_swish(self._depthwise_conv, self._bn1, x)             # statistics from the depthwise kernel's epilogue
+        if fused_expand is not None:
+            # expand convolution -> [bn0 + swish applied inside the depthwise kernel's loads] -> depthwise convolution (ops._BNSwishDwConv)
+            e, st0 = fused_expand
+            dwc = self._depthwise_conv
+            y, st = ops.bn_swish_dwconv(e, st0, self._bn0, dwc.weight, dwc.stride, dwc.pad4, want_stats=True)
+            x = ops.bn_act(y, st, self._bn1, None, "swish")
+        else:
+            x = _conv_bn_swish(self._depthwise_conv, self._bn1, x)         # statistics from the depthwise kernel's epilogue
         x = ops.squeeze_excite(x, self._se_reduce, self._se_expand)        # pool + 2 small linears + scale, fused
         x = _conv_bn_swish(self._project_conv, self._bn2, x, act=False)
         if self.stride == 1 and self.cin == self.cout:

@@ -135,27 +135,20 @@ class _ManoJoints(torch.autograd.Function):
 
 
 class _ManoFull(torch.autograd.Function):
-    """ManoLayer.forward + xyz_from_vertice + root-relative step + camera-space offset: ONE launch per direction
-    (hifihr_mano_full_fwd / _bwd).  The separate forms above cost two launches forward, two backward, an elementwise add for
-    verts_cam and, in backward, its AddBackward, the accumulation of verts_rel's two gradients and two zero fills of unused outputs."""
-    _counters = {}
+    """ManoLayer.forward + xyz_from_vertice + root-relative step + camera-space offset (hifihr_mano_full_fwd / _bwd): two launches
+    forward, ONE backward.  The separate forms above cost two launches forward, two backward, an elementwise add for verts_cam and, in
+    backward, its AddBackward, the accumulation of verts_rel's two gradients and two zero fills of unused outputs."""
 
     @staticmethod
     def forward(ctx, handle, pose, beta, root_id, root_xyz):
         require_cuda(pose, beta)
         pose, beta = pose.contiguous().float(), beta.contiguous().float()
         B, dev = pose.shape[0], pose.device
-        key = (dev, torch.cuda.current_stream(dev).cuda_stream if torch.cuda.current_stream(dev).cuda_stream in BRANCH_STREAMS else 0)
-        cnt = _ManoFull._counters.get(key)
-        if cnt is None or cnt.numel() < B:                      # arrival counters: zero on entry, left zero (stream-ordered reuse)
-            if cnt is not None:
-                _RETIRED_SCRATCH.append(cnt)
-            cnt = _ManoFull._counters[key] = torch.zeros(max(B, 256), dtype=torch.int32, device=dev)
         f = lambda *shape: torch.empty(*shape, device=dev)
         verts, joints_rel, verts_rel, root, saved = f(B, 778, 3), f(B, 21, 3), f(B, 778, 3), f(B, 3), f(B, 778, 3)
         rx = root_xyz.reshape(B, 3).contiguous().float() if root_xyz is not None else None
         verts_cam = f(B, 778, 3)                                # (root_xyz None: = verts_rel)
-        PROFILE.bracket("mano_lbs_fwd", lambda: handle.lib.mano_full_fwd(handle.h, pose, beta, root_id, rx, cnt, verts, joints_rel, verts_rel,
+        PROFILE.bracket("mano_lbs_fwd", lambda: handle.lib.mano_full_fwd(handle.h, pose, beta, root_id, rx, verts, joints_rel, verts_rel,
                                                                          verts_cam, root, saved))
         ctx.handle, ctx.root_id = handle, root_id
         ctx.save_for_backward(pose, beta, saved)
@@ -2039,6 +2032,85 @@ class _DwConv(torch.autograd.Function):
             if dw is None:
                 _grad_ready(p)
         return dx, dw, None, None, None
+
+
+class _BNSwishDwConv(torch.autograd.Function):
+    """depthwise_conv(swish(bn(e))) of an MBConv block (reference network/efficientnet_pt/model.py:73-80) WITHOUT the activated tensor:
+    e = the expand convolution's raw output and `stats` its slot buffer.  Forward: hifihr_bn_finalize_fwd (one tiny launch: mean / invstd,
+    running statistics) + hifihr_dwconv2d_fwd_bnswish (batch-norm + swish applied as the rows are loaded).  Backward: the weight gradient
+    from e the same way; d a = dwconv_bwd_data(gy); then the ordinary fused batch-norm backward with act = swish on (d a, e), which
+    recomputes the activation's derivative from e.  Against `bn_act` + `dwconv2d`: one pass over the block's largest tensor less in
+    forward (read e + write a: 2.4 GB per EfficientNet-b3 step at batch 48) and that tensor is never allocated."""
+
+    @staticmethod
+    def forward(ctx, e, stats, gamma, beta, eps, momentum, running_mean, running_var, w, stride, pad4, want_stats):
+        require_cuda(e, stats, gamma, beta, w)
+        lib = get_lib()
+        e = e.contiguous(memory_format=_CL)
+        w = w.contiguous()
+        N, C, H, W = e.shape
+        K = w.shape[-1]
+        pl, pr, pt, pb = pad4
+        OH, OW = (H + pt + pb - K) // stride + 1, (W + pl + pr - K) // stride + 1
+        save_mean, save_invstd = torch.empty(C, device=e.device), torch.empty(C, device=e.device)
+        PROFILE.bracket("bn_fwd", lambda: lib.bn_finalize_fwd(stats, N * H * W, C, eps, momentum, save_mean, save_invstd, running_mean, running_var))
+        _ZERO_POOL.release(stats)                 # consumed and zeroed
+        y = torch.empty((N, C, OH, OW), device=e.device, dtype=torch.float32, memory_format=_CL)
+        ystats = _ZERO_POOL.acquire(lib.bn_stats_floats(C), e.device) if want_stats else None
+        geom = (N, H, W, C, OH, OW, K, stride, pt, pl)
+        PROFILE.bracket("dwconv_fwd", lambda: lib.dwconv2d_fwd_bnswish(e, save_mean, save_invstd, gamma, beta, w, y, *geom, stats=ystats))
+        ctx.geom, ctx.M, ctx.C = geom, N * H * W, C
+        ctx.save_for_backward(e, w, gamma, beta, save_mean, save_invstd)
+        ctx.w_param, ctx.gamma_param, ctx.beta_param = w, gamma, beta
+        ctx.set_materialize_grads(False)
+        if want_stats:
+            ctx.mark_non_differentiable(ystats)
+            return y, ystats
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, _gstats=None):
+        if gy is None:
+            return (None,) * 12
+        e, w, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        lib = get_lib()
+        gy = gy.contiguous(memory_format=_CL)
+        dw = None
+        if ctx.needs_input_grad[8]:
+            p = ctx.w_param
+            tgt = p.grad if (getattr(p, "_hifihr_direct_grad", False) and p.grad is not None and p.grad.is_contiguous()) else None
+            if tgt is None:
+                dw = torch.zeros_like(w)
+                tgt = dw
+            PROFILE.bracket("dwconv_wgrad", lambda: lib.dwconv2d_bwd_weight_bnswish(e, save_mean, save_invstd, gamma, beta, gy, tgt, *ctx.geom))
+            if dw is None:
+                _grad_ready(p)
+        da = torch.empty_like(e, memory_format=_CL)
+        PROFILE.bracket("dwconv_dgrad", lambda: lib.dwconv2d_bwd_data(gy, w, da, *ctx.geom))
+        de = torch.empty_like(e, memory_format=_CL)
+        red = _ZERO_POOL.acquire(lib.bn_stats_floats(ctx.C), e.device)
+
+        def acc_target(p):
+            if getattr(p, "_hifihr_direct_grad", False) and p.grad is not None:
+                return p.grad, None
+            t = torch.zeros(ctx.C, device=e.device)
+            return t, t
+        dg_t, dg_ret = acc_target(ctx.gamma_param)
+        db_t, db_ret = acc_target(ctx.beta_param)
+        PROFILE.bracket("bn_bwd", lambda: lib.bn_act_bwd(da, None, e, save_mean, save_invstd, gamma, beta, 2, ctx.M, ctx.C, red, de, None, dg_t, db_t))
+        _ZERO_POOL.release(red)
+        if dg_ret is None:
+            _grad_ready(ctx.gamma_param)
+        if db_ret is None:
+            _grad_ready(ctx.beta_param)
+        return de, None, dg_ret, db_ret, None, None, None, None, dw, None, None, None
+
+
+def bn_swish_dwconv(e, stats, bn: torch.nn.BatchNorm2d, w, stride, pad4, want_stats=False):
+    """dwconv2d(bn_act(e, stats, bn, None, "swish"), w, stride, pad4, want_stats) in training mode, without the activated tensor."""
+    assert bn.training and stats is not None
+    return _BNSwishDwConv.apply(e, stats, bn.weight, bn.bias, float(bn.eps), float(bn.momentum), bn.running_mean, bn.running_var, w, stride,
+                                tuple(pad4), want_stats)
 
 
 def dwconv2d(x, w, stride, pad4, want_stats=False):

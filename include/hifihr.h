@@ -78,17 +78,17 @@ int hifihr_mano_joints_fwd(const hifihr_mano_t* h, const float* verts_d, int B, 
 int hifihr_mano_joints_bwd(const hifihr_mano_t* h, const float* gjoints_rel_d, const float* gverts_rel_d,
                            const float* groot_d, int B, int root_id, float* gverts_d, void* stream);
 
-/* The two steps above in ONE launch per direction (round 5): ManoLayer.forward, xyz_from_vertice, the root-relative step AND the mesh
- * offset `skin_meshes.offset_verts_(-pred_root); .offset_verts_(root_xyz)` that precedes the renderer
+/* The two steps above as ONE call per direction (round 5), with the mesh offset `skin_meshes.offset_verts_(-pred_root);
+ * .offset_verts_(root_xyz)` that precedes the renderer folded in
  * (reference utils/my_mano.py:315-483; Freihand_trainer_mano_fullsup.py:175-215; models_res_nimble.py:153,160-166,203-205):
  *   verts = layer(pose, beta); joints21 = regress(verts); root = joints21[:, root_id];
  *   joints_rel = joints21 - root; verts_rel = verts - root; verts_cam = verts_rel + root_xyz.
- * counters_d[B] (uint32): ALL ZERO on entry, all zero again on exit (the arrival counters of a hand's tile workgroups; caller-owned so that
- * the call stays re-entrant).  verts_d[B][778][3] receives the layer's (absolute, centred) vertices.  root_xyz_d[B][3] / verts_cam_d /
- * root_d may be NULL.  saved_vposed_d as in hifihr_mano_lbs_fwd.  Results are bit-identical to the two-call form. */
+ * Forward: two launches (the layer; regression + offsets); backward: ONE launch (the regression's backward is the head of the layer's).
+ * verts_d[B][778][3] receives the layer's (absolute, centred) vertices.  root_xyz_d[B][3] / verts_cam_d / root_d may be NULL.
+ * saved_vposed_d as in hifihr_mano_lbs_fwd.  Results are bit-identical to the two-call form. */
 int hifihr_mano_full_fwd(const hifihr_mano_t* h, const float* pose_d, const float* beta_d, int B, int root_id,
-                         const float* root_xyz_d, unsigned* counters_d, float* verts_d, float* joints_rel_d,
-                         float* verts_rel_d, float* verts_cam_d, float* root_d, float* saved_vposed_d, void* stream);
+                         const float* root_xyz_d, float* verts_d, float* joints_rel_d, float* verts_rel_d, float* verts_cam_d,
+                         float* root_d, float* saved_vposed_d, void* stream);
 /* Gradient: gjoints_rel[B][21][3], gverts_rel[B][778][3], gverts_cam[B][778][3], groot[B][3] (any may be NULL = zero) ->
  * gpose[B][48], gbeta[B][10] (overwritten).  Deterministic (no float atomics). */
 int hifihr_mano_full_bwd(const hifihr_mano_t* h, const float* pose_d, const float* beta_d, const float* saved_vposed_d,
@@ -505,6 +505,24 @@ int hifihr_dwconv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, i
                              int stride, int pad_top, int pad_left, void* stream);
 int hifihr_dwconv2d_bwd_weight(const float* x_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int OH, int OW,
                                int K, int stride, int pad_top, int pad_left, void* stream);
+/* The expand half of an MBConv block without its activated tensor (round 5): reference network/efficientnet_pt/model.py:73-80,
+ *   x = swish(bn0(expand_conv(x)));  x = depthwise_conv(x)
+ * x_d is the RAW output of the expand convolution; a = swish(x * gamma invstd + (beta - mean gamma invstd)) is formed as the depthwise
+ * kernels load their rows (zero outside the image: the padding is of a) and never reaches HBM.  mean_d / invstd_d [C]: the batch
+ * statistics of x (hifihr_bn_finalize_fwd below makes them from the convolution's slot buffer).  fwd: y, stats as hifihr_dwconv2d_fwd;
+ * bwd_weight: dw += sum dy * a.  The gradient with respect to x is hifihr_dwconv2d_bwd_data followed by hifihr_bn_act_bwd(act = swish)
+ * on (that, x): the batch-norm backward recomputes the activation's derivative from x alone. */
+int hifihr_dwconv2d_fwd_bnswish(const float* x_d, const float* mean_d, const float* invstd_d, const float* gamma_d, const float* beta_d,
+                                const float* w_d, float* y_d, float* stats_d /* or NULL */, int N, int H, int W, int C, int OH, int OW,
+                                int K, int stride, int pad_top, int pad_left, void* stream);
+int hifihr_dwconv2d_bwd_weight_bnswish(const float* x_d, const float* mean_d, const float* invstd_d, const float* gamma_d,
+                                       const float* beta_d, const float* dy_d, float* dw_d, int N, int H, int W, int C, int OH, int OW,
+                                       int K, int stride, int pad_top, int pad_left, void* stream);
+/* The statistics half of a training-mode batch-norm on its own (what hifihr_bn_act_fwd does before it applies): the slot buffer of a
+ * producer -> save_mean[C], save_invstd[C] (biased variance, eps inside the root), running statistics updated with `momentum`
+ * (NULL: not kept), slots handed back all zero.  reference: nn.BatchNorm2d in training mode (model.py:73-76). */
+int hifihr_bn_finalize_fwd(float* stats_d, long M, int C, float eps, float momentum, float* save_mean_d, float* save_invstd_d,
+                           float* running_mean_d /* or NULL */, float* running_var_d /* or NULL */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pooling on NHWC fp32 activations (C % 4 == 0).

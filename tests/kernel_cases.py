@@ -98,7 +98,7 @@ def mano_joints_case(lib, tables, device, B, seed, root_id=9):
 
 
 def mano_full_case(lib, tables, device, B, seed, root_id=9, with_cam=True):
-    """hifihr_mano_full_fwd / _bwd (layer + joint regression + root-relative step + camera-space offset in one launch per direction)
+    """hifihr_mano_full_fwd / _bwd (layer + joint regression + root-relative step + camera-space offset; the backward in one launch)
     against the ORACLE chain (oracle/mano_oracle.py: mano_forward -> xyz_from_vertice -> root_relative -> + root_xyz) and, bit for bit in
     the forward direction, against the two-call form of the same library."""
     gen = torch.Generator().manual_seed(seed)
@@ -122,11 +122,8 @@ def mano_full_case(lib, tables, device, B, seed, root_id=9, with_cam=True):
     try:
         f = lambda *shape: torch.empty(*shape, device=device)
         pd, bd = _dev(pose.detach(), device), _dev(beta.detach(), device)
-        cnt = torch.zeros(B + 3, dtype=torch.int32, device=device)
         o_verts, o_j, o_v, o_c, o_r, saved = f(B, 778, 3), f(B, 21, 3), f(B, 778, 3), f(B, 778, 3), f(B, 3), f(B, 778, 3)
-        for _ in range(2):                                   # twice: the arrival counters must come back zero
-            lib.mano_full_fwd(h, pd, bd, root_id, _dev(root_xyz, device), cnt, o_verts, o_j, o_v, o_c, o_r, saved)
-            assert int(cnt.abs().sum()) == 0, "arrival counters not left zero"
+        lib.mano_full_fwd(h, pd, bd, root_id, _dev(root_xyz, device), o_verts, o_j, o_v, o_c, o_r, saved)
         np.testing.assert_allclose(o_j.cpu().numpy(), jr.detach().numpy(), atol=5e-6)
         np.testing.assert_allclose(o_v.cpu().numpy(), vr.detach().numpy(), atol=5e-6)
         np.testing.assert_allclose(o_c.cpu().numpy(), vc.detach().numpy(), atol=5e-6)
@@ -598,6 +595,77 @@ def dwconv_case(lib, device, N, H, W, C, K, stride, seed=0):
     lib.dwconv2d_bwd_weight(xd, gyd, dw, N, H, W, C, OH, OW, K, stride, pt, pl)
     refw = wr.grad.reshape(C, K, K)
     assert float((dw.cpu() - refw).abs().max()) <= 1e-4 * float(refw.abs().max()) + 1e-6, "dw bwd weight"
+
+
+def dwconv_bnswish_case(lib, device, N, H, W, C, K, stride, seed=0, mean=0.3, std=1.5):
+    """The expand half of an MBConv block without its activated tensor (hifihr_bn_finalize_fwd + hifihr_dwconv2d_fwd_bnswish /
+    _bwd_weight_bnswish + hifihr_dwconv2d_bwd_data + hifihr_bn_act_bwd(swish)) vs plain PyTorch: nn.BatchNorm2d (training mode, eps
+    1e-3, momentum 0.01 as the reference's blocks) -> x * sigmoid(x) -> F.pad + grouped F.conv2d, forward, every gradient, the
+    running statistics; and bit for bit against the library's own unfused pair hifihr_bn_act_fwd + hifihr_dwconv2d_fwd."""
+    import torch.nn.functional as F
+    from hifihr_amd.effnet import static_same_pad
+    gen = torch.Generator().manual_seed(seed)
+    pl, pr, pt, pb = static_same_pad(K, stride)
+    e = torch.randn(N, C, H, W, generator=gen) * std + mean
+    w = torch.randn(C, 1, K, K, generator=gen) / K
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.3
+    eps, mom = 1e-3, 0.01
+    bn = torch.nn.BatchNorm2d(C, eps=eps, momentum=mom).train()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    er, wr = e.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    z = bn(er)
+    a = z * torch.sigmoid(z)
+    y = F.conv2d(F.pad(a, (pl, pr, pt, pb)), wr, None, stride, 0, 1, C)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    OH, OW = y.shape[2], y.shape[3]
+    M = N * H * W
+    d = lambda t: t.to(device).contiguous()
+    ed, wd, gyd, gd, bd = d(e.permute(0, 2, 3, 1)), d(w.reshape(C, K, K)), d(gy.permute(0, 2, 3, 1)), d(gamma), d(beta)
+    f = lambda *shape: torch.empty(*shape, device=device)
+    # statistics of e as its producer leaves them (the slot buffer), consumed by the finalize call
+    stats = torch.zeros(lib.bn_stats_floats(C), device=device)
+    lib.bn_stats(ed, M, C, stats)
+    stats2 = stats.clone()
+    mean_d, invstd_d, rm, rv = f(C), f(C), torch.zeros(C, device=device), torch.ones(C, device=device)
+    lib.bn_finalize_fwd(stats, M, C, eps, mom, mean_d, invstd_d, rm, rv)
+    assert float(stats.abs().max()) == 0.0, "finalize must hand the slots back zeroed"
+    np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    out = f(N, OH, OW, C)
+    ystats = torch.zeros(lib.bn_stats_floats(C), device=device)
+    lib.dwconv2d_fwd_bnswish(ed, mean_d, invstd_d, gd, bd, wd, out, N, H, W, C, OH, OW, K, stride, pt, pl, stats=ystats)
+    ref = y.detach().permute(0, 2, 3, 1)
+    err = float((out.cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 3e-5, f"dw fwd (bn + swish on load): {err}"
+    st = bn_slots(ystats, C).sum(0).cpu()
+    flat = ref.reshape(-1, C)
+    np.testing.assert_allclose(st[0].numpy(), flat.sum(0).numpy(), rtol=2e-4, atol=5e-3)
+    np.testing.assert_allclose(st[1].numpy(), (flat ** 2).sum(0).numpy(), rtol=2e-4, atol=5e-3)
+    # the unfused pair of the same library: bn_act_fwd (swish) then dwconv2d_fwd -- the same bits
+    a_d, m2, i2 = f(N, H, W, C), f(C), f(C)
+    lib.bn_act_fwd(ed, stats2, gd, bd, None, 2, M, C, eps, mom, a_d, m2, i2, None, None)
+    assert torch.equal(m2, mean_d) and torch.equal(i2, invstd_d)
+    out_u = f(N, OH, OW, C)
+    lib.dwconv2d_fwd(a_d, wd, out_u, N, H, W, C, OH, OW, K, stride, pt, pl)
+    eu = float((out_u - out).abs().max()) / float(ref.abs().max())
+    assert eu <= 2e-6, f"fused vs unfused forward: {eu}"
+    # weight gradient from e
+    dw = torch.zeros(C, K, K, device=device)
+    lib.dwconv2d_bwd_weight_bnswish(ed, mean_d, invstd_d, gd, bd, gyd, dw, N, H, W, C, OH, OW, K, stride, pt, pl)
+    refw = wr.grad.reshape(C, K, K)
+    assert float((dw.cpu() - refw).abs().max()) <= 2e-4 * float(refw.abs().max()) + 1e-6, "dw bwd weight (bn + swish on load)"
+    # gradient wrt e, gamma, beta: dwconv_bwd_data then the fused batch-norm backward with act = swish on (d a, e)
+    da = f(N, H, W, C)
+    lib.dwconv2d_bwd_data(gyd, wd, da, N, H, W, C, OH, OW, K, stride, pt, pl)
+    red = torch.zeros(lib.bn_stats_floats(C), device=device)
+    de, dg, db = f(N, H, W, C), torch.zeros(C, device=device), torch.zeros(C, device=device)
+    lib.bn_act_bwd(da, None, ed, mean_d, invstd_d, gd, bd, 2, M, C, red, de, None, dg, db)
+    refe = er.grad.permute(0, 2, 3, 1)
+    assert float((de.cpu() - refe).abs().max()) <= 3e-4 * float(refe.abs().max()) + 1e-7, "d e"
+    assert float((dg.cpu() - bn.weight.grad).abs().max()) <= 3e-4 * float(bn.weight.grad.abs().max()) + 1e-5, "d gamma"
+    assert float((db.cpu() - bn.bias.grad).abs().max()) <= 3e-4 * float(bn.bias.grad.abs().max()) + 1e-5, "d beta"
 
 
 # ------------------------------------------------------------------------------------------------

@@ -347,6 +347,12 @@ def test_dwconv_kernels(lib, N, H, C, K, stride):
     kc.dwconv_case(lib, "cuda", N, H, H, C, K, stride, seed=C + K)
 
 
+@pytest.mark.parametrize("N,H,C,K,stride", [(16, 56, 192, 3, 1), (16, 56, 192, 5, 2), (8, 14, 816, 5, 1), (32, 7, 2304, 3, 1), (4, 112, 144, 3, 2)])
+def test_dwconv_with_batchnorm_and_swish_on_load(lib, N, H, C, K, stride):
+    """The expand half of an MBConv block without its activated tensor (network/efficientnet_pt/model.py:73-80)."""
+    kc.dwconv_bnswish_case(lib, "cuda", N, H, H, C, K, stride, seed=C + K + 1)
+
+
 @pytest.mark.parametrize("N,H,C,K", [(32, 14, 512, 512), (32, 28, 128, 128), (32, 14, 256, 256), (32, 56, 64, 64)])
 def test_balanced_schedule_full_batch(lib, N, H, C, K):
     """The stream-K schedule at BASELINE's batch: forward and backward-data through the shared workspace."""
