@@ -326,8 +326,10 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
             us_step, timing = hit[1] * (e["launches_per_step"] / hit[0]) if abs(hit[0] - e["launches_per_step"]) > 0.01 else hit[1], \
                 "kernel time inside the step: " + prof_how + ", this kernel's launches only"
         ach = e["flop_per_step"] / (us_step * 1e-6) / 1e12
+        tr = measured_traffic(name)
         out[name] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF,
-                     "traffic": measured_traffic(name), "kernel": name, "launches_per_step": e["launches_per_step"],
+                     "traffic": tr, "traffic_ratio": (tr / (e["compulsory_bytes_per_step"] / n)) if tr else None,       # counter bytes / compulsory bytes
+                     "kernel": name, "launches_per_step": e["launches_per_step"],
                      "avg_us": us_step / n, "us_per_step": us_step, "timing": timing,
                      "entry_avg_us": entry_us / n, "entry_us_per_step": entry_us,
                      "instep_launches_per_step": hit[0] if hit else None,
@@ -642,8 +644,9 @@ def main():
                                             ("roofline_render_bwd", us_b, alg_b, f"render_bwd_kernel<{h_r.aa}> (+ render_vertex_bwd_kernel)", "render_bwd_kernel")):
                 ach = alg * Br / (us * 1e-6) / 1e9
                 hit = instep_lookup(kprof, kk)
+                tr_r = measured_traffic(key.replace("roofline_", ""))
                 extra[key] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                              "traffic": measured_traffic(key.replace("roofline_", "")), "kernel": kname, "avg_us": us,
+                              "traffic": tr_r, "traffic_ratio": (tr_r / (alg * Br)) if tr_r else None, "kernel": kname, "avg_us": us,
                               "algorithmic_bytes_per_launch": alg * Br,
                               "timing": "HIP events over 20 back-to-back launches of the C-ABI entry on this batch's meshes (the launch's helper kernels and "
                                         "memsets included)"}
@@ -680,7 +683,7 @@ def main():
             extra["roofline"] = dict({k: v for k, v in dom.items() if k != "shapes"},
                                      flops="the products the kernel executes (2 M N K per Winograd GEMM), per shape x launches per step")
             extra["roofline_kernels"] = {k: {kk: v[kk] for kk in ("achieved", "frac", "launches_per_step", "avg_us", "us_per_step", "timing", "entry_avg_us",
-                                                                   "entry_us_per_step", "traffic", "shapes")}
+                                                                   "entry_us_per_step", "traffic", "traffic_ratio", "compulsory_bytes_per_launch", "shapes")}
                                          for k, v in roofs.items()}
             tot_f = sum(v["executed_flop_per_launch"] * v["launches_per_step"] for v in roofs.values())
             tot_us = sum(v["us_per_step"] for v in roofs.values())

@@ -66,7 +66,13 @@ def b3_block_table():
     return out
 
 
-_FUSE_BN0 = os.environ.get("HIFIHR_EFFNET_FUSE_BN0", "1") != "0"
+# bn0 + swish inside the depthwise kernels' loads (ops._BNSwishDwConv; built and parity-tested in round 5) is OFF by default: MEASURED
+# slower (profiles/r05_time_dw_bnswish.txt, batch 48: forward 1 542 -> 1 623 us per step, backward-weight 1 033 -> 3 089 us; config 3
+# 34.45 -> 36.80 ms/step).  The streaming depthwise kernels load every input element 1.7-10 x (the window overlap) and each load then
+# pays a v_exp + v_rcp: they turn from L1-bound into VALU-bound, and the weight gradient -- which needs the ACTIVATED tensor again --
+# pays it a second time.  What would work is a depthwise kernel that stages an input tile in LDS (each element activated once) for
+# forward and weight gradient both; not built.  HIFIHR_EFFNET_FUSE_BN0=1 turns the fused path on.
+_FUSE_BN0 = os.environ.get("HIFIHR_EFFNET_FUSE_BN0", "0") != "0"
 
 
 class SqueezeExciteConv(nn.Conv2d):
