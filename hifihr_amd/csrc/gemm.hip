@@ -1274,8 +1274,10 @@ static bool tn_rows(int M, int N, int T, int batch) {
 // MEASURED (tools/time_gemm_tn_split.py, gpurun_out/tn_split_*.txt): the 36 products of a 128-channel F(4x4) layer 26.7 -> 25.4 us, of a
 // 256-channel one 35.8 -> 31.6 us; SINGLE products lose (1x1 backward-weight 256 -> 512 at 14 x 14: 22.9 -> 25.4 us, 512 -> 512: 36.8 ->
 // 42.3 us: 28 / 14 slabs of a whole filter each) -- batched products only.
+// Long reductions (VGG19's layers at 112 x 112 / 56 x 56: T = 9 408 ... 37 632) stay on the per-tile kernels too: config 3 measured
+// 34.41 ms/step without the split against 34.49 / 34.53 with it (gpurun_out/c3_*.json).
 static int tn_rows_split(int M, int N, int T, int batch) {
-  if (batch < 2) return 0;
+  if (batch < 2 || T > 4096) return 0;
   static const int on = [] { const char* e = getenv("HIFIHR_GEMM_TN_SPLIT"); return e ? atoi(e) : 1; }();
   static const int on_rows = [] { const char* e = getenv("HIFIHR_GEMM_TN_ROWS"); return e ? atoi(e) : 1; }();
   if (!on || !on_rows || N % 128 != 0 || M % 16 != 0 || T % 32 != 0 || T < 64) return 0;
