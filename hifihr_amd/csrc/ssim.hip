@@ -12,8 +12,6 @@
 //   ssim_bwd_kernel  d mean(SSIM) / d img1 = G * A + 2 img1 (G * B) + img2 (G * C)   (G symmetric), same tiling.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "hifihr_internal.h"
 
 namespace hifihr {
@@ -39,53 +37,25 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// Round 5: PERSISTENT over the tiles of the launch (<= 3 workgroups per CU, each walks tiles blockIdx.x, + gridDim.x, ...) with the NEXT
-// tile's halo in flight while this one is computed: a tile is 7 scalar loads per lane and image, then three barriers of LDS work -- with
-// one tile per workgroup every tile paid the memory latency in front of its first barrier and the three co-resident workgroups of a CU
-// ran it in lockstep (VALU-bound estimate 23 us, measured 60 at [32,3,224,224]).
-constexpr int kSL = (kSH * kSH + 255) / 256;   // halo loads per lane and image: 7
-
-struct SsimTile { int plane, ox, oy; };
-__device__ __forceinline__ SsimTile ssim_tile(int t, int tx_n, int ty_n) {
-  const int per = tx_n * ty_n, plane = t / per, r = t - plane * per, by = r / tx_n;
-  return SsimTile{plane, (r - by * tx_n) * kST, by * kST};
-}
-template <int NI>
-__device__ __forceinline__ void ssim_halo_load(const SsimTile& t, int H, int W, const float* const (&img)[NI], float (&v)[NI][kSL]) {
-  const size_t po = (size_t)t.plane * H * W;
-#pragma unroll
-  for (int i = 0; i < kSL; ++i) {
-    const int e = threadIdx.x + 256 * i;
-    const int r = e / kSH, c = e - r * kSH;
-    const int y = t.oy + r - kSR, x = t.ox + c - kSR;
-    const bool in = (e < kSH * kSH) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
-    const size_t o = po + (size_t)(in ? y : 0) * W + (in ? x : 0);
-#pragma unroll
-    for (int q = 0; q < NI; ++q) { const float t0 = img[q][in ? o : 0]; v[q][i] = in ? t0 : 0.f; }      // unconditional, clamped
-  }
-}
-
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWindow win, const float* __restrict__ img1, const float* __restrict__ img2,
-                                                      int H, int W, int ntiles, int tx_n, int ty_n, float* __restrict__ partial,
-                                                      float* __restrict__ dA, float* __restrict__ dB, float* __restrict__ dC) {
+                                                      int H, int W, float* __restrict__ partial, float* __restrict__ dA,
+                                                      float* __restrict__ dB, float* __restrict__ dC) {
   __shared__ float xs[kSH][kSH + 1], ys[kSH][kSH + 1];
   __shared__ float hq[5][kSH][kST + 1];
   __shared__ float red[4];
+  const int plane = blockIdx.z;
+  const int ox = blockIdx.x * kST, oy = blockIdx.y * kST;
   const int tid = threadIdx.x;
-  const float* const imgs[2] = {img1, img2};
-  float pre[2][kSL];
-  int t = blockIdx.x;
-  if (t < ntiles) ssim_halo_load<2>(ssim_tile(t, tx_n, ty_n), H, W, imgs, pre);
-  for (; t < ntiles; t += gridDim.x) {
-    const SsimTile tl = ssim_tile(t, tx_n, ty_n);
-    const int plane = tl.plane, ox = tl.ox, oy = tl.oy;
-#pragma unroll
-    for (int i = 0; i < kSL; ++i) {
-      const int e = tid + 256 * i;
-      if (e < kSH * kSH) { const int r = e / kSH, c = e - r * kSH; xs[r][c] = pre[0][i]; ys[r][c] = pre[1][i]; }
-    }
-    __syncthreads();
-    if (t + (int)gridDim.x < ntiles) ssim_halo_load<2>(ssim_tile(t + gridDim.x, tx_n, ty_n), H, W, imgs, pre);     // in flight behind this tile's work
+  const float* p1 = img1 + (size_t)plane * H * W;
+  const float* p2 = img2 + (size_t)plane * H * W;
+  for (int e = tid; e < kSH * kSH; e += 256) {
+    const int r = e / kSH, c = e - r * kSH;
+    const int y = oy + r - kSR, x = ox + c - kSR;
+    const bool in = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+    xs[r][c] = in ? p1[(size_t)y * W + x] : 0.f;
+    ys[r][c] = in ? p2[(size_t)y * W + x] : 0.f;
+  }
+  __syncthreads();
   // row pass: for every halo row, 32 output columns, five moments.  A work item is four adjacent outputs of a row: their 14 inputs are read
   // once into registers (28 LDS reads for 4 outputs where one output per item read 22 each); same summation order per output as before
   for (int e = tid; e < kSH * (kST / 4); e += 256) {
@@ -143,35 +113,30 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWindow win, const flo
       }
     }
   }
-  const float tot = block_sum_256(val, red);      // (its barrier also orders this tile's reads of hq before the next tile's row pass)
-  if (tid == 0) partial[t] = tot;                 // tile order = (plane, tile row, tile column): the order the finish kernel sums in
-  __syncthreads();                                // red[] is read by every thread: not rewritten before they all have
-  }
+  const float tot = block_sum_256(val, red);
+  if (tid == 0) partial[((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
 }
 
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWindow win, const float* __restrict__ img1, const float* __restrict__ img2,
                                                       const float* __restrict__ dA, const float* __restrict__ dB,
                                                       const float* __restrict__ dC, const float* __restrict__ gscale, float inv_n,
-                                                      int H, int W, int ntiles, int tx_n, int ty_n, float* __restrict__ gimg1) {
+                                                      int H, int W, float* __restrict__ gimg1) {
   __shared__ float ta[kSH][kSH + 1], tb[kSH][kSH + 1], tc[kSH][kSH + 1];
   __shared__ float hq[3][kSH][kST + 1];
+  const int plane = blockIdx.z;
+  const int ox = blockIdx.x * kST, oy = blockIdx.y * kST;
   const int tid = threadIdx.x;
-  const float* const maps[3] = {dA, dB, dC};
-  float pre[3][kSL];
-  int t = blockIdx.x;
-  if (t < ntiles) ssim_halo_load<3>(ssim_tile(t, tx_n, ty_n), H, W, maps, pre);
-  const float sc = gscale[0] * inv_n;
-  for (; t < ntiles; t += gridDim.x) {                       // (persistent, the next tile's halo in flight: see ssim_fwd_kernel)
-    const SsimTile tl = ssim_tile(t, tx_n, ty_n);
-    const int ox = tl.ox, oy = tl.oy;
-    const size_t po = (size_t)tl.plane * H * W;
-#pragma unroll
-    for (int i = 0; i < kSL; ++i) {
-      const int e = tid + 256 * i;
-      if (e < kSH * kSH) { const int r = e / kSH, c = e - r * kSH; ta[r][c] = pre[0][i]; tb[r][c] = pre[1][i]; tc[r][c] = pre[2][i]; }
-    }
-    __syncthreads();
-    if (t + (int)gridDim.x < ntiles) ssim_halo_load<3>(ssim_tile(t + gridDim.x, tx_n, ty_n), H, W, maps, pre);
+  const size_t po = (size_t)plane * H * W;
+  for (int e = tid; e < kSH * kSH; e += 256) {
+    const int r = e / kSH, c = e - r * kSH;
+    const int y = oy + r - kSR, x = ox + c - kSR;
+    const bool in = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+    const size_t o = po + (size_t)y * W + x;
+    ta[r][c] = in ? dA[o] : 0.f;
+    tb[r][c] = in ? dB[o] : 0.f;
+    tc[r][c] = in ? dC[o] : 0.f;
+  }
+  __syncthreads();
   for (int e = tid; e < kSH * (kST / 4); e += 256) {        // (four adjacent outputs per item, as in the forward)
     const int r = e / (kST / 4), c0 = 4 * (e - r * (kST / 4));
     float va[14], vb[14], vc[14];
@@ -189,6 +154,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWindow win, const flo
     }
   }
   __syncthreads();
+  const float sc = gscale[0] * inv_n;
   const int tx = tid % kST, ty0 = (tid / kST) * kSO;
   const int x = ox + tx;
   float h[3][kSO + 10];
@@ -210,8 +176,6 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWindow win, const flo
       gimg1[o] = sc * (a + 2.f * img1[o] * b + img2[o] * cc);
     }
   }
-  __syncthreads();                                          // this tile's reads of hq before the next tile's row pass writes it
-  }
 }
 
 // out[0] = offset + scale * sum(partial[0 .. count)): the scalar behind the forward (SSIM = sum / n, or the ssim_tex loss term
@@ -229,28 +193,6 @@ __global__ __launch_bounds__(256) void ssim_finish_kernel(const float* __restric
 
 int ssim_tile_edge() { return kST; }
 
-// workgroups of the persistent kernels: HIFIHR_SSIM_WGS_PER_CU (default 3: what 42-48 KB of LDS allow) x the CUs, at most one per tile;
-// 0 = one workgroup per tile (the round-4 form, for the A/B)
-static int ssim_cus() {
-  static const int cus = [] {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    const bool ok = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0;
-    return ok ? prop.multiProcessorCount : 256;
-  }();
-  return cus;
-}
-static unsigned ssim_grid(long ntiles) {
-  static const int per_cu = [] { const char* e = getenv("HIFIHR_SSIM_WGS_PER_CU"); return e ? atoi(e) : 3; }();
-  if (const char* e = getenv("HIFIHR_SSIM_GRID")) {          // (tests: a fixed number of workgroups, so that each walks several tiles)
-    const long g = atol(e);
-    if (g > 0) return (unsigned)(g < ntiles ? g : ntiles);
-  }
-  if (per_cu <= 0) return (unsigned)ntiles;
-  const long g = (long)ssim_cus() * per_cu;
-  return (unsigned)(g < ntiles ? g : ntiles);
-}
-
 hipError_t launch_ssim_finish(const float* partial, int count, float scale, float offset, float* out, hipStream_t st) {
   hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(256), 0, st, partial, count, scale, offset, out);
   return hipGetLastError();
@@ -258,21 +200,16 @@ hipError_t launch_ssim_finish(const float* partial, int count, float scale, floa
 
 hipError_t launch_ssim_fwd(const SsimWindow& win, const float* img1, const float* img2, int planes, int H, int W, float* partial,
                            float* dA, float* dB, float* dC, hipStream_t st) {
-  const int tx_n = (W + kST - 1) / kST, ty_n = (H + kST - 1) / kST;
-  const long ntiles = (long)tx_n * ty_n * planes;
-  if (ntiles <= 0 || ntiles >= (1L << 31)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ssim_grid(ntiles)), dim3(256), 0, st, win, img1, img2, H, W, (int)ntiles, tx_n, ty_n, partial, dA, dB, dC);
+  const dim3 grid((W + kST - 1) / kST, (H + kST - 1) / kST, planes);
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, st, win, img1, img2, H, W, partial, dA, dB, dC);
   return hipGetLastError();
 }
 
 hipError_t launch_ssim_bwd(const SsimWindow& win, const float* img1, const float* img2, const float* dA, const float* dB,
                            const float* dC, const float* gscale, int planes, int H, int W, float* gimg1, hipStream_t st, float out_scale) {
-  const int tx_n = (W + kST - 1) / kST, ty_n = (H + kST - 1) / kST;
-  const long ntiles = (long)tx_n * ty_n * planes;
-  if (ntiles <= 0 || ntiles >= (1L << 31)) return hipErrorInvalidValue;
+  const dim3 grid((W + kST - 1) / kST, (H + kST - 1) / kST, planes);
   const float inv_n = out_scale / ((float)planes * (float)H * (float)W);
-  hipLaunchKernelGGL(ssim_bwd_kernel, dim3(ssim_grid(ntiles)), dim3(256), 0, st, win, img1, img2, dA, dB, dC, gscale, inv_n, H, W, (int)ntiles, tx_n,
-                     ty_n, gimg1);
+  hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, st, win, img1, img2, dA, dB, dC, gscale, inv_n, H, W, gimg1);
   return hipGetLastError();
 }
 
