@@ -27,4 +27,8 @@ run "stem kernel off (HIFIHR_CONV_STEM=0)" HIFIHR_CONV_STEM=0
 run "plain F(4x4) tile geometry, no mosaic (HIFIHR_WINO_MOSAIC=0)" HIFIHR_WINO_MOSAIC=0
 run "F(4x4) weight-gradient transform of small layers, narrow form (HIFIHR_WINO_DW_WIDE=0)" HIFIHR_WINO_DW_WIDE=0
 run "strided forward convolutions on the implicit GEMM (HIFIHR_CONV_ROWS=0)" HIFIHR_CONV_ROWS=0
+run "light estimator on the main stream, no side branch (HIFIHR_LIGHT_BRANCH=0)" HIFIHR_LIGHT_BRANCH=0
+run "geometry loss terms on a side branch too (HIFIHR_GEOM_BRANCH=1)" HIFIHR_GEOM_BRANCH=1
+run "MANO layer / joint regression as separate autograd nodes (HIFIHR_MANO_FUSED=0)" HIFIHR_MANO_FUSED=0
+run "batched TN products with short reductions on the per-tile kernels (HIFIHR_GEMM_TN_SPLIT=0)" HIFIHR_GEMM_TN_SPLIT=0
 run "eager launches, no hipGraph (--graph 0)" --graph 0
