@@ -176,7 +176,11 @@ class FreiHandDeviceCache:
                       "Ps": (B, 3, 4), "joints": (B, J, 3), "verts": (B, V, 3), "j2d_gt": (B, J, 2), "scales": (B,), "idxs": (B,)}
             if root_id is not None or all(k in out for k in self.STEP_KEYS):
                 expect.update({"root_xyz": (B, 1, 3), "joints_rel": (B, J, 3), "verts_rel": (B, V, 3), "cam_ndc": (B, 4)})
-                root_id = getattr(self, "_root_id", 9) if root_id is None else root_id
+                if root_id is None:
+                    root_id = getattr(self, "_root_id", None)
+                    if root_id is None:
+                        raise ValueError("batch_examples(out=...): `out` holds the step terms (root_xyz, joints_rel, ...) but no root_id was "
+                                         "given here or in an earlier call")
             for k, shape in expect.items():
                 if k not in out or tuple(out[k].shape) != shape:
                     raise ValueError(f"batch_examples(out=...): '{k}' must be a tensor of shape {shape}")

@@ -181,6 +181,15 @@ def train_step(model, loss_func, optimizer, examples, args, dat_name="FreiHand",
     return loss, loss_dic
 
 
+def _check_step_terms(static, examples):
+    """A captured step whose inputs include the batch-derived terms (root_xyz, joints_rel, verts_rel, cam_ndc: data.FreiHandDeviceCache.
+    batch_examples(root_id=...)) reads THEM, not joints / Ks: a batch that arrives without them would leave the previous batch's in place."""
+    missing = [k for k in ("root_xyz", "joints_rel", "verts_rel", "cam_ndc") if k in static and k not in examples]
+    if missing:
+        raise KeyError(f"load_batch: the captured step was built on a batch that carries {missing}; pass batches from the same source "
+                       f"(batch_examples(..., root_id=args.ROOT)) or capture the step on a batch without them")
+
+
 def _injected_capture_failure():
     """Test hook (tests/test_gpu_dp.py): HIFIHR_TEST_FAIL_CAPTURE_RANK=<r> makes the graphed steps' constructors fail on rank r only, to
     exercise the collective-safe fallback -- a one-sided capture failure must send every rank to the eager step."""
@@ -278,6 +287,7 @@ class GraphedTrainStep:
             self.opt.disable_graph_mode()
 
     def load_batch(self, examples):
+        _check_step_terms(self.static, examples)
         for k, v in examples.items():
             if torch.is_tensor(v):
                 self.static[k].copy_(v, non_blocking=True)
@@ -406,6 +416,7 @@ class SegmentedGraphedTrainStep:
         self.reducer.pause_hooks(False)
 
     def load_batch(self, examples):
+        _check_step_terms(self.static, examples)
         for k, v in examples.items():
             if torch.is_tensor(v):
                 self.static[k].copy_(v, non_blocking=True)

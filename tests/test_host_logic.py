@@ -320,3 +320,16 @@ def test_bench_gpus_n_launches_n_ranks_and_fails_loudly_when_one_dies():
     assert "rank(s) failed" in r.stderr and "(0," in r.stderr and "(1," in r.stderr
     assert "bench.py needs a GPU" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_captured_step_refuses_a_batch_without_its_step_terms():
+    """A captured step built on a batch that carries root_xyz / joints_rel / verts_rel / cam_ndc reads those: load_batch must not leave the
+    previous batch's in place when a batch arrives without them."""
+    import pytest
+    import torch
+    from hifihr_amd.traineval import _check_step_terms
+    static = {"imgs": torch.zeros(1), "joints": torch.zeros(1), "joints_rel": torch.zeros(1), "cam_ndc": torch.zeros(1)}
+    _check_step_terms(static, {"imgs": torch.zeros(1), "joints": torch.zeros(1), "joints_rel": torch.zeros(1), "cam_ndc": torch.zeros(1)})
+    _check_step_terms({"imgs": torch.zeros(1)}, {"imgs": torch.zeros(1)})
+    with pytest.raises(KeyError, match="joints_rel"):
+        _check_step_terms(static, {"imgs": torch.zeros(1), "joints": torch.zeros(1)})
