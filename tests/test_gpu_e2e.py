@@ -190,6 +190,39 @@ def _weights_agree(flat, flat2, lr, steps):
     _check("mean |w_eager - w_graph|", float(d.mean()), 0.15 * lr)
 
 
+def _warm_eager(model, opt, ex, args):
+    """The FIRST eager step of a model runs before the per-step weight re-layout has its Winograd-domain filters, i.e. on other kernels
+    than every later step (tools/determinism_probe.py).  One forward + backward without an optimizer step, batch-norm buffers put back:
+    from here on the eager step dispatches exactly what a captured step replays."""
+    from hifihr_amd.losses import LossFunction
+    from hifihr_amd.traineval import forward_backward
+    bufs = [b.clone() for b in model.buffers()]
+    forward_backward(model, LossFunction(), opt, ex, args)
+    with torch.no_grad():
+        for b, s0 in zip(model.buffers(), bufs):
+            b.copy_(s0)
+    torch.cuda.synchronize()
+
+
+def _sync_state(dst, src):
+    """(model, flat, opt) <- (model, flat, opt): weights, Adam moments, step counter, every module buffer."""
+    (dm, df, do), (sm, sf, so) = dst, src
+    with torch.no_grad():
+        df.flat.copy_(sf.flat); do.exp_avg.copy_(so.exp_avg); do.exp_avg_sq.copy_(so.exp_avg_sq)
+        for b, s0 in zip(dm.buffers(), sm.buffers()):
+            b.copy_(s0)
+    do.step_count = so.step_count
+    torch.cuda.synchronize()
+
+
+def _assert_same_bits(tag, dic_a, dic_b, terms):
+    """The FORWARD of the step is bit-reproducible (no float atomics on it that survive rounding: the batch-norm statistics are fp64
+    sums): from identical weights and the same batch a replayed graph and the eager step must produce identical loss terms."""
+    bad = [k for k in terms if not torch.equal(dic_a[k].detach(), dic_b[k].detach())]
+    print(f"[exact] {tag}: {len(terms) - len(bad)} of {len(terms)} loss terms bit-identical" + (f"; differing: {bad}" if bad else ""))
+    assert not bad, (tag, {k: (float(dic_a[k]), float(dic_b[k])) for k in bad})
+
+
 def test_graphed_step_matches_eager_step():
     """The hipGraph-replayed training step performs the same update as the eager step (same weights, same batch)."""
     from hifihr_amd.losses import LossFunction
@@ -212,10 +245,13 @@ def test_graphed_step_matches_eager_step():
         # warm-up + capture are free of side effects: weights, Adam state, step counter, batch-norm running statistics
         assert torch.equal(flat2.flat, before) and opt2.step_count == 0 and float(opt2.exp_avg.abs().max()) == 0.0
         assert torch.equal(model2.base_encoder.encoder1.model.bn1.running_mean, rm_before)
+        _warm_eager(model, opt, ex, args)
         for step in range(2):
-            loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
-            loss_g, _ = g()
+            loss_e, dic_e = train_step(model, LossFunction(), opt, ex, args)
+            loss_g, dic_g = g()
             torch.cuda.synchronize()
+            if step == 0:          # identical weights: the forward must agree bit for bit (later steps start from weights that differ by backward's atomic noise)
+                _assert_same_bits("step 0, graph vs eager", dic_e, dic_g, list(args.losses) + ["loss"])
             _check(f"step {step} |loss_eager - loss_graph| / loss", abs(float(loss_e) - float(loss_g)) / max(1.0, abs(float(loss_e))), _GRAPH_LOSS_RTOL)
         _weights_agree(flat, flat2, lr, 2)
         assert opt2.step_count == 2 and opt.step_count == 2
@@ -262,21 +298,32 @@ def test_graph_replay_survives_an_evaluation_pass_in_between():
             m.train()
             return out["joints"]
 
-        def step(tag):
-            loss_e, _ = train_step(model, LossFunction(), opt, ex, args)
+        _warm_eager(model, opt, ex, args)
+        _warm_eager(model3, opt3, ex, args)
+
+        def step(tag, exact=False):
+            loss_e, dic_e = train_step(model, LossFunction(), opt, ex, args)
             loss_f, _ = train_step(model3, LossFunction(), opt3, ex, args)
-            loss_g, _ = g()
+            loss_g, dic_g = g()
             torch.cuda.synchronize()
+            if exact:
+                _assert_same_bits(f"{tag}, graph vs eager from identical state", dic_e, dic_g, list(args.losses) + ["loss"])
             ref_ = max(1.0, abs(float(loss_e)))
             print(f"[floor] {tag}: eager-vs-eager {abs(float(loss_e) - float(loss_f)) / ref_:.3e}")
             _check(f"{tag} |loss_eager - loss_graph| / loss", abs(float(loss_e) - float(loss_g)) / ref_, _GRAPH_LOSS_RTOL)
         for rnd in range(2):
-            step(f"round {rnd}")
+            step(f"round {rnd}", exact=(rnd == 0))
             je, jf, jg = evaluate(model), evaluate(model3), evaluate(model2)
             print(f"[floor] round {rnd} evaluation joints: eager-vs-eager {float((je - jf).abs().max()):.3e}")
             _check(f"round {rnd} evaluation joints max diff", float((je - jg).abs().max()), 1e-4)
         step("after the evaluations")
         _weights_agree(flat, flat2, lr, 3)
+        # ... and the BIT-EXACT form of the same statement: put the graphed replica into the eager one's state (weights, Adam moments, step
+        # counter, batch-norm buffers) behind ANOTHER evaluation pass of both, then step both -- the replayed forward must reproduce the eager
+        # one bit for bit.  A dirty statistics buffer or a stale scratch address baked into the graph shows up here with no tolerance to hide in.
+        evaluate(model); evaluate(model2)
+        _sync_state((model2, flat2, opt2), (model, flat, opt))
+        step("after an evaluation pass", exact=True)
     finally:
         torch.cuda.set_stream(prev)
 

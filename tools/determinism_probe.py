@@ -63,6 +63,7 @@ def compare(tag, a, b):
         print(f"    {r:.2e}  {n}")
 
 
+run_eager()          # warm-up: the FIRST eager step of a model runs before the weight re-layout has its Winograd-domain filters (other kernels)
 eager = [run_eager() for _ in range(RUNS)]
 for i in range(1, RUNS):
     compare(f"eager 0 vs eager {i}", eager[0], eager[i])
