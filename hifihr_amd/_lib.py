@@ -78,7 +78,7 @@ class HifihrLib:
         c.hifihr_mano_joints_fwd.argtypes = [c_void_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_mano_joints_bwd.argtypes = [c_void_p, _c_float_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_mano_full_fwd.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, c_int, _c_float_p] + [_c_float_p] * 6 + [c_void_p]
-        c.hifihr_mano_full_bwd.argtypes = [c_void_p] + [_c_float_p] * 7 + [c_int, c_int, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_mano_full_bwd.argtypes = [c_void_p] + [_c_float_p] * 9 + [c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_lbs_create.argtypes = [POINTER(c_void_p), c_int, c_int, c_int] + [_c_float_p] * 4 + [_c_int_p]
         c.hifihr_lbs_destroy.argtypes = [c_void_p]
         c.hifihr_lbs_fwd.argtypes = [c_void_p, _c_float_p, _c_float_p, c_int, _c_float_p, _c_float_p, c_void_p]
@@ -157,6 +157,8 @@ class HifihrLib:
                                             _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p, c_void_p])
         c.hifihr_freihand_batch_step.argtypes = ([c_void_p, c_void_p] + [_c_float_p] * 4 + [c_int, c_int, _c_int_p, c_int, c_int, c_int, _c_float_p,
                                                  _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p, c_int, c_float] + [_c_float_p] * 4 + [c_void_p])
+        c.hifihr_loss_total_fwd.argtypes = [POINTER(_c_float_p), POINTER(c_int), c_int, _c_float_p, c_void_p]
+        c.hifihr_loss_total_bwd.argtypes = [_c_float_p, POINTER(_c_float_p), POINTER(c_int), POINTER(c_int), c_int, c_void_p]
         c.hifihr_procrustes_error.argtypes = [_c_float_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_wino_output_transform_act.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_wino_dy_transform.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, c_int, c_void_p]
@@ -287,10 +289,12 @@ class HifihrLib:
         self.check(self.c.hifihr_mano_full_fwd(h, _fp(pose), _fp(beta), B, int(root_id), _fp(root_xyz), _fp(verts), _fp(joints_rel), _fp(verts_rel),
                                                _fp(verts_cam), _fp(root), _fp(saved), _stream_of(pose)), "hifihr_mano_full_fwd")
 
-    def mano_full_bwd(self, h, pose, beta, saved, gjoints_rel, gverts_rel, gverts_cam, groot, root_id, gpose, gbeta):
+    def mano_full_bwd(self, h, pose, beta, saved, gjoints_rel, gverts_rel, gverts_cam, groot, root_id, gpose, gbeta, gpose_add=None,
+                      gbeta_add=None):
         B = pose.shape[0]
         self.check(self.c.hifihr_mano_full_bwd(h, _fp(pose), _fp(beta), _fp(saved), _fp(gjoints_rel), _fp(gverts_rel), _fp(gverts_cam),
-                                               _fp(groot), B, int(root_id), _fp(gpose), _fp(gbeta), _stream_of(pose)), "hifihr_mano_full_bwd")
+                                               _fp(groot), _fp(gpose_add), _fp(gbeta_add), B, int(root_id), _fp(gpose), _fp(gbeta),
+                                               _stream_of(pose)), "hifihr_mano_full_bwd")
 
     # ---- generic LBS (NIMBLE-shaped layer) -----------------------------
     def lbs_create(self, v_template, shapedirs, j_regressor, weights, parents) -> c_void_p:
@@ -401,6 +405,18 @@ class HifihrLib:
     def dwconv2d_bwd_weight(self, x, dy, dw, N, H, W, C, OH, OW, K, stride, pt, pl):
         self.check(self.c.hifihr_dwconv2d_bwd_weight(_fp(x), _fp(dy), _fp(dw), N, H, W, C, OH, OW, K, stride, pt, pl, _stream_of(x)),
                    "hifihr_dwconv2d_bwd_weight")
+
+    def loss_total_fwd(self, parts, counts, total):
+        n = len(parts)
+        arr = (_c_float_p * n)(*[_fp(t) for t in parts])
+        self.check(self.c.hifihr_loss_total_fwd(arr, (c_int * n)(*[int(c) for c in counts]), n, _fp(total), _stream_of(total)),
+                   "hifihr_loss_total_fwd")
+
+    def loss_total_bwd(self, gtotal, grads, counts):
+        n = len(grads)
+        arr = (_c_float_p * n)(*[_fp(t) for t in grads])
+        self.check(self.c.hifihr_loss_total_bwd(_fp(gtotal), arr, (c_int * n)(*[int(c) for c in counts]),
+                                                (c_int * n)(*[int(t.numel()) for t in grads]), n, _stream_of(gtotal)), "hifihr_loss_total_bwd")
 
     @staticmethod
     def _lambda5(lam):

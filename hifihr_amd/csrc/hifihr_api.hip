@@ -237,13 +237,13 @@ int hifihr_mano_full_fwd(const hifihr_mano_t* h, const float* pose, const float*
 }
 
 int hifihr_mano_full_bwd(const hifihr_mano_t* h, const float* pose, const float* beta, const float* saved, const float* gjoints_rel,
-                         const float* gverts_rel, const float* gverts_cam, const float* groot, int B, int root_id, float* gpose,
-                         float* gbeta, void* stream) {
+                         const float* gverts_rel, const float* gverts_cam, const float* groot, const float* gpose_add,
+                         const float* gbeta_add, int B, int root_id, float* gpose, float* gbeta, void* stream) {
   if (!h || !pose || !beta || !saved || !gpose || !gbeta || B < 0 || root_id >= 21)
     return fail(HIFIHR_EINVAL, "hifihr_mano_full_bwd: bad argument");
   if (B == 0) return HIFIHR_OK;
-  HIP_TRY(hifihr::launch_mano_full_bwd(h->dev, pose, beta, saved, gjoints_rel, gverts_rel, gverts_cam, groot, B, root_id, gpose, gbeta,
-                                       (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_mano_full_bwd(h->dev, pose, beta, saved, gjoints_rel, gverts_rel, gverts_cam, groot, gpose_add, gbeta_add, B, root_id,
+                                       gpose, gbeta, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 
@@ -849,6 +849,29 @@ int hifihr_sil_post(const float* rgba, const float* imgs, int B, int H, int W, f
   if (!rgba || !re_sil || (mask_rgbs && !imgs) || B <= 0 || H <= 0 || W <= 0 || (H * W) % 4 != 0)
     return fail(HIFIHR_EINVAL, "hifihr_sil_post: bad argument (H*W % 4 == 0)");
   HIP_TRY(hifihr::launch_sil_post(rgba, imgs, B, H * W, re_sil, mask_rgbs, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_loss_total_fwd(const float* const* parts, const int* counts, int nparts, float* total, void* stream) {
+  if (!parts || !counts || !total || nparts < 1 || nparts > hifihr::kLossTotalParts) return fail(HIFIHR_EINVAL, "hifihr_loss_total_fwd: 1 .. 4 parts");
+  hifihr::LossTotalParts p{};
+  for (int i = 0; i < nparts; ++i) {
+    if (!parts[i] || counts[i] < 0 || counts[i] > 64) return fail(HIFIHR_EINVAL, "hifihr_loss_total_fwd: bad part");
+    p.v[i] = parts[i]; p.n[i] = counts[i];
+  }
+  HIP_TRY(hifihr::launch_loss_total_fwd(p, total, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_loss_total_bwd(const float* gtotal, float* const* grads, const int* counts, const int* lengths, int nparts, void* stream) {
+  if (!gtotal || !grads || !counts || !lengths || nparts < 1 || nparts > hifihr::kLossTotalParts)
+    return fail(HIFIHR_EINVAL, "hifihr_loss_total_bwd: 1 .. 4 parts");
+  hifihr::LossTotalGrads q{};
+  for (int i = 0; i < nparts; ++i) {
+    if (!grads[i] || counts[i] < 0 || lengths[i] < counts[i] || lengths[i] > 64) return fail(HIFIHR_EINVAL, "hifihr_loss_total_bwd: bad part");
+    q.g[i] = grads[i]; q.n[i] = counts[i]; q.len[i] = lengths[i];
+  }
+  HIP_TRY(hifihr::launch_loss_total_bwd(gtotal, q, (hipStream_t)stream));
   return HIFIHR_OK;
 }
 

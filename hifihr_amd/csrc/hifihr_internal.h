@@ -33,8 +33,8 @@ hipError_t launch_mano_full_fwd(const ManoDev& t, const float* pose, const float
                                 float* verts, float* joints_rel, float* verts_rel, float* verts_cam, float* root_out, float* saved,
                                 hipStream_t st);
 hipError_t launch_mano_full_bwd(const ManoDev& t, const float* pose, const float* beta, const float* saved, const float* gjoints_rel,
-                                const float* gverts_rel, const float* gverts_cam, const float* groot, int B, int root_id, float* gpose,
-                                float* gbeta, hipStream_t st);
+                                const float* gverts_rel, const float* gverts_cam, const float* groot, const float* gpose_add,
+                                const float* gbeta_add, int B, int root_id, float* gpose, float* gbeta, hipStream_t st);
 hipError_t launch_mano_joints_fwd(const ManoDev& t, const float* verts, int B, int root_id, float* joints_rel,
                                   float* verts_rel, float* root, hipStream_t st);
 hipError_t launch_mano_joints_bwd(const ManoDev& t, const float* gjoints_rel, const float* gverts_rel,
@@ -279,6 +279,11 @@ hipError_t launch_photo_loss_bwd(const float* rgba, const float* re_img_m, const
                                  const float* gout, const float* fwd_out, int B, int HW, float l_tex, float l_mrgb, float* grad_rgba,
                                  hipStream_t st);
 hipError_t launch_sil_post(const float* rgba, const float* imgs, int B, int HW, float* re_sil, float* mask_rgbs, hipStream_t st);
+constexpr int kLossTotalParts = 4;
+struct LossTotalParts { const float* v[kLossTotalParts]; int n[kLossTotalParts]; };          // sum of v[i][0 .. n[i])
+struct LossTotalGrads { float* g[kLossTotalParts]; int n[kLossTotalParts]; int len[kLossTotalParts]; };
+hipError_t launch_loss_total_fwd(const LossTotalParts& p, float* total, hipStream_t st);
+hipError_t launch_loss_total_bwd(const float* gtotal, const LossTotalGrads& q, hipStream_t st);
 
 // small-batch fully connected layer (mlp.hip): y[B][O] = act(BN1d?(x[B][I] W[O][I]^T + b)); gamma == nullptr: no batch-norm
 // sigmoid(z) for the swish / sigmoid activations of EfficientNet (batch-norm + swish passes, squeeze-excite gates): v_exp_f32 of z log2(e) and

@@ -280,6 +280,34 @@ hipError_t launch_photo_loss_bwd(const float* rgba, const float* re_img_m, const
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// loss = sum of the selected terms (reference train_hrnet.py:98-104: `loss = sum(loss_dic[k] for k in args.losses)`) when the terms sit in
+// the small output vectors of the fused loss kernels: ONE launch each way instead of stack + sum forward and, in backward, a `cat` per
+// vector plus a zero fill (autograd's UnbindBackward).  Part i contributes its first n[i] entries, in part order (fixed summation order).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void loss_total_fwd_kernel(LossTotalParts p, float* __restrict__ total) {
+  if (threadIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < kLossTotalParts; ++i)
+    for (int j = 0; j < p.n[i]; ++j) s += p.v[i][j];
+  total[0] = s;
+}
+// g[i][j] = d loss / d part i entry j = gtotal for the n[i] summed entries, 0 for the rest of the vector (len[i] entries)
+__global__ __launch_bounds__(64) void loss_total_bwd_kernel(const float* __restrict__ gtotal, LossTotalGrads q) {
+  const float g = gtotal[0];
+  for (int i = 0; i < kLossTotalParts; ++i)
+    for (int j = threadIdx.x; j < q.len[i]; j += 64) q.g[i][j] = j < q.n[i] ? g : 0.f;
+}
+
+hipError_t launch_loss_total_fwd(const LossTotalParts& p, float* total, hipStream_t st) {
+  hipLaunchKernelGGL(loss_total_fwd_kernel, dim3(1), dim3(64), 0, st, p, total);
+  return hipGetLastError();
+}
+hipError_t launch_loss_total_bwd(const float* gtotal, const LossTotalGrads& q, hipStream_t st) {
+  hipLaunchKernelGGL(loss_total_bwd_kernel, dim3(1), dim3(64), 0, st, gtotal, q);
+  return hipGetLastError();
+}
+
 hipError_t launch_sil_post(const float* rgba, const float* imgs, int B, int HW, float* re_sil, float* mask_rgbs, hipStream_t st) {
   if (HW % 4 != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sil_post_kernel, dim3(photo_grid(B, HW) * 4), dim3(256), 0, st, rgba, imgs, B, HW, re_sil, mask_rgbs);

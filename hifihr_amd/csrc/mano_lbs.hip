@@ -184,6 +184,8 @@ struct ManoBwdHead {
   const float* gverts_rel;     // [B][778][3] or null
   const float* gverts_cam;     // [B][778][3] or null
   const float* groot;          // [B][3] or null
+  const float* gpose_add;      // [B][48] or null: added to gpose (the gradient that reaches `pose` through its OTHER consumer,
+  const float* gbeta_add;      // [B][10] or null   e.g. the mpose / mshape regularisers: autograd's accumulation launches folded in)
 };
 
 __device__ __forceinline__ float wave_sum(float x) {
@@ -429,17 +431,17 @@ __global__ __launch_bounds__(kBwdThreads) void mano_bwd_kernel(ManoDev t, const 
   __syncthreads();
   // ---- phase 5: PCA transpose and shape gradient ----
   if (tid < 3) {
-    gpose[b * 48 + tid] = L.gfp[tid];
+    gpose[b * 48 + tid] = L.gfp[tid] + (head.gpose_add ? head.gpose_add[b * 48 + tid] : 0.f);
   } else if (tid < 48) {
     const int k = tid - 3;
     float acc = 0.f;
     for (int j = 0; j < kNPCA; ++j) acc += t.comps[k * kNPCA + j] * L.gfp[3 + j];
-    gpose[b * 48 + tid] = acc;
+    gpose[b * 48 + tid] = acc + (head.gpose_add ? head.gpose_add[b * 48 + tid] : 0.f);
   } else if (tid >= 64 && tid < 64 + kNB) {
     const int k = tid - 64;
     float acc = L.gbeta_blend[k];
     for (int e = 0; e < kNJ * 3; ++e) acc += t.jsd[e * kNB + k] * L.gJ[e];
-    gbeta[b * kNB + k] = acc;
+    gbeta[b * kNB + k] = acc + (head.gbeta_add ? head.gbeta_add[b * kNB + k] : 0.f);
   }
 }
 
@@ -613,10 +615,10 @@ hipError_t launch_mano_bwd(const ManoDev& t, const float* pose, const float* bet
 }
 
 hipError_t launch_mano_full_bwd(const ManoDev& t, const float* pose, const float* beta, const float* saved, const float* gjoints_rel,
-                                const float* gverts_rel, const float* gverts_cam, const float* groot, int B, int root_id, float* gpose,
-                                float* gbeta, hipStream_t st) {
+                                const float* gverts_rel, const float* gverts_cam, const float* groot, const float* gpose_add,
+                                const float* gbeta_add, int B, int root_id, float* gpose, float* gbeta, hipStream_t st) {
   if (hipError_t e = mano_bwd_attr()) return e;
-  ManoBwdHead head{1, root_id, gjoints_rel, gverts_rel, gverts_cam, groot};
+  ManoBwdHead head{1, root_id, gjoints_rel, gverts_rel, gverts_cam, groot, gpose_add, gbeta_add};
   hipLaunchKernelGGL(mano_bwd_kernel, dim3(B), dim3(kBwdThreads), sizeof(ManoBwdLds), st, t, pose, beta, saved,
                      nullptr, nullptr, gpose, gbeta, head);
   return hipGetLastError();

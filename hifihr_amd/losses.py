@@ -88,9 +88,14 @@ class LossFunction:
         for k, v in zip(ops.GEOM_TERMS, vec.unbind(0)):
             if k in loss_used:
                 loss_dic[k] = v
+        # (every entry of the vector is a term: the ones that were not asked for carry weight 0)
+        self._total_parts.append((vec, 5, [k for k in ops.GEOM_TERMS if k in loss_used]))
 
     def __call__(self, examples, outputs, loss_used, dat_name, args) -> dict:
         self._pending_join = None
+        # (vector, leading entries that are terms, their names): the terms that live in the fused kernels' output vectors; `total` sums
+        # them in one launch when they are exactly the requested list
+        self._total_parts = []
         try:
             return self._terms(examples, outputs, loss_used, dat_name, args)
         finally:
@@ -98,6 +103,18 @@ class LossFunction:
                 br, vec = self._pending_join
                 br.join(vec)
                 self._pending_join = None
+
+    def total(self, loss_dic, losses):
+        """sum(loss_dic[k] for k in losses) (reference train_hrnet.py:98-104) -- in ONE launch when the requested terms are exactly the
+        ones the fused kernels of the last __call__ hold in their output vectors, else as a stack + sum."""
+        from . import ops
+        parts = getattr(self, "_total_parts", [])
+        covered = [k for _, _, names in parts for k in names]
+        if (parts and len(parts) <= 4 and sorted(covered) == sorted(losses) and all(p.is_cuda for p, _, _ in parts)
+                and all(loss_dic.get(k) is not None for k in losses) and os.environ.get("HIFIHR_LOSS_TOTAL", "1") != "0"):
+            return ops.loss_total([(p, n) for p, n, _ in parts])
+        terms = [loss_dic[k] for k in losses]
+        return terms[0] if len(terms) == 1 else torch.stack(terms).sum()      # 2 launches instead of a chain of adds
 
     def _terms(self, examples, outputs, loss_used, dat_name, args) -> dict:
         from . import ops
@@ -146,6 +163,10 @@ class LossFunction:
             loss_dic["ssim_tex"] = ops.ssim_loss(re_img, mask_rgbs, args.lambda_ssim_tex)   # lambda * (1 - ssim), scalar glue folded in
             if "sil" in loss_used:
                 loss_dic["sil"] = sil
+                self._total_parts.append((out, 3, ["texture", "mrgb", "sil"]))
+            else:
+                self._total_parts.append((out, 2, ["texture", "mrgb"]))
+            self._total_parts.append((loss_dic["ssim_tex"], 1, ["ssim_tex"]))
         if "perceptual" in loss_used:
             if self.perceptual_loss is None:
                 from .perceptual import PerceptualLoss

@@ -208,12 +208,14 @@ class Model(nn.Module):
         if self.hand_model == "mano" and _MANO_FUSED and features.is_cuda:
             # ManoLayer.forward, the joint regression, the root-relative step and the camera-space offset of the mesh: ONE launch
             # (ops.mano_full; HIFIHR_MANO_FUSED=0: the layer, then ops.mano_joints_root_relative, then an elementwise add)
-            joints, mano_verts, verts_cam, pred_root = ops.mano_full(self.hand_layer.handle, hand_params["pose_params"], hand_params["shape_params"],
-                                                                     root_id, root_xyz if self.ifRender else None)
+            joints, mano_verts, verts_cam, pred_root, pose_o, shape_o = ops.mano_full(
+                self.hand_layer.handle, hand_params["pose_params"], hand_params["shape_params"], root_id, root_xyz if self.ifRender else None)
             outputs = {"skin_verts": mano_verts}
+            outputs.update(hand_params)
+            outputs["pose_params"], outputs["shape_params"] = pose_o, shape_o      # (aliases: the regularisers' gradient joins the layer's backward)
         else:
             outputs = self.hand_layer(hand_params, handle_collision=False)
-        outputs.update(hand_params)
+            outputs.update(hand_params)
         if self.hand_model == "nimble":
             if br is not None:
                 br.join(*light_params.values())

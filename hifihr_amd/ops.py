@@ -153,21 +153,25 @@ class _ManoFull(torch.autograd.Function):
         ctx.handle, ctx.root_id = handle, root_id
         ctx.save_for_backward(pose, beta, saved)
         ctx.set_materialize_grads(False)                        # unused outputs: None, not zero-filled tensors
-        return joints_rel, verts_rel, verts_cam, root
+        # pose / beta are handed back as OUTPUTS (aliases): a consumer that reads them from here -- the mpose / mshape regularisers -- sends
+        # its gradient into THIS node's backward, where the kernel adds it to the layer's own (autograd otherwise accumulates the two
+        # gradients of each head output with an elementwise launch of its own)
+        return joints_rel, verts_rel, verts_cam, root, pose.view_as(pose), beta.view_as(beta)
 
     @staticmethod
-    def backward(ctx, gj, gv, gc, gr):
+    def backward(ctx, gj, gv, gc, gr, gp_add, gb_add):
         pose, beta, saved = ctx.saved_tensors
         B = pose.shape[0]
         gpose, gbeta = torch.empty(B, 48, device=pose.device), torch.empty(B, 10, device=pose.device)
         c = lambda t: t.contiguous() if t is not None else None
         PROFILE.bracket("mano_lbs_bwd", lambda: ctx.handle.lib.mano_full_bwd(ctx.handle.h, pose, beta, saved, c(gj), c(gv), c(gc), c(gr),
-                                                                             ctx.root_id, gpose, gbeta))
+                                                                             ctx.root_id, gpose, gbeta, c(gp_add), c(gb_add)))
         return None, gpose, gbeta, None, None
 
 
 def mano_full(handle: ManoLayerHandle, pose, beta, root_id=9, root_xyz=None):
-    """-> joints_rel [B,21,3], verts_rel [B,778,3], verts_cam [B,778,3] (= verts_rel + root_xyz; only with root_xyz), pred_root [B,3]."""
+    """-> joints_rel [B,21,3], verts_rel [B,778,3], verts_cam [B,778,3] (= verts_rel + root_xyz), pred_root [B,3], and aliases of pose /
+    beta for their other consumers (see _ManoFull.forward)."""
     return _ManoFull.apply(handle, pose, beta, root_id, root_xyz)
 
 
@@ -1440,6 +1444,33 @@ def geom_losses(joints, joints_gt, verts, verts_gt, shape, pose, faces, mse, lam
     """[5] = lambda-weighted (joint_3d, vert_3d, edge_length, mshape, mpose) of reference losses.py:259-266, 283-284,
     398-406 in one launch (+ finisher); `faces` [F,3] int32 or None, `lam` the five lambdas (0 for unused terms)."""
     return _GeomLoss.apply(joints, joints_gt, verts, verts_gt, shape, pose, faces, bool(mse), tuple(float(v) for v in lam))
+
+
+class _LossTotal(torch.autograd.Function):
+    """sum of the first counts[i] entries of each part (the fused loss kernels' output vectors / scalars): one launch each way
+    (hifihr_loss_total_fwd / _bwd) instead of stack + sum and, in backward, a cat per vector plus a zero fill."""
+
+    @staticmethod
+    def forward(ctx, counts, *parts):
+        require_cuda(*parts)
+        ctx.orig = [p.shape for p in parts]
+        parts = [p.contiguous().reshape(-1) for p in parts]
+        total = torch.empty((), device=parts[0].device)
+        PROFILE.bracket("loss_total", lambda: get_lib().loss_total_fwd(parts, counts, total))
+        ctx.counts, ctx.shapes = counts, [p.shape for p in parts]
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        grads = [torch.empty(s, device=g.device) for s in ctx.shapes]
+        PROFILE.bracket("loss_total", lambda: get_lib().loss_total_bwd(g, grads, ctx.counts))
+        return (None, *[gr.reshape(s) for gr, s in zip(grads, ctx.orig)])
+
+
+def loss_total(parts):
+    """parts: [(vector or 0-d tensor, how many of its leading entries are loss terms)] -> their sum as a 0-d tensor."""
+    return _LossTotal.apply(tuple(int(n) for _, n in parts), *[p for p, _ in parts])
 
 
 class _JointTerms(torch.autograd.Function):

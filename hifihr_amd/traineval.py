@@ -164,8 +164,11 @@ def _forward_backward(model, loss_func, optimizer, examples, args, dat_name):
     missing = [k for k in args.losses if k not in loss_dic]
     if missing:                              # e.g. 'mtex' on a hand layer without texture_params, 'vert_3d' on a dataset without vertices
         raise KeyError(f"loss terms {missing} were requested but not produced for {dat_name}: their inputs are absent from the model outputs / examples")
-    terms = [loss_dic[k] for k in args.losses]
-    loss = terms[0] if len(terms) == 1 else torch.stack(terms).sum()      # 2 launches instead of a chain of adds
+    if hasattr(loss_func, "total"):
+        loss = loss_func.total(loss_dic, args.losses)          # one launch when the terms sit in the fused kernels' vectors
+    else:
+        terms = [loss_dic[k] for k in args.losses]
+        loss = terms[0] if len(terms) == 1 else torch.stack(terms).sum()      # 2 launches instead of a chain of adds
     loss_dic["loss"] = loss
     optimizer.zero_grad(set_to_none=True)
     loss.backward(_backward_seed(loss))

@@ -90,10 +90,13 @@ int hifihr_mano_full_fwd(const hifihr_mano_t* h, const float* pose_d, const floa
                          const float* root_xyz_d, float* verts_d, float* joints_rel_d, float* verts_rel_d, float* verts_cam_d,
                          float* root_d, float* saved_vposed_d, void* stream);
 /* Gradient: gjoints_rel[B][21][3], gverts_rel[B][778][3], gverts_cam[B][778][3], groot[B][3] (any may be NULL = zero) ->
- * gpose[B][48], gbeta[B][10] (overwritten).  Deterministic (no float atomics). */
+ * gpose[B][48], gbeta[B][10] (overwritten).  gpose_add_d[B][48] / gbeta_add_d[B][10] (may be NULL) are ADDED to the results: the
+ * gradient that reaches pose / beta through their other consumer (the mpose / mshape terms of losses.py:283-284), so that the sum
+ * costs no launch of its own.  Deterministic (no float atomics). */
 int hifihr_mano_full_bwd(const hifihr_mano_t* h, const float* pose_d, const float* beta_d, const float* saved_vposed_d,
                          const float* gjoints_rel_d, const float* gverts_rel_d, const float* gverts_cam_d,
-                         const float* groot_d, int B, int root_id, float* gpose_d, float* gbeta_d, void* stream);
+                         const float* groot_d, const float* gpose_add_d, const float* gbeta_add_d, int B, int root_id,
+                         float* gpose_d, float* gbeta_d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Generic linear-blend skinning (any mesh size / kinematic tree): the NIMBLE-shaped hand layer.
@@ -627,6 +630,13 @@ int hifihr_photo_loss_bwd(const float* rgba_d, const float* re_img_m_d, const fl
                           float* grad_rgba_d, void* stream);
 int hifihr_sil_post(const float* rgba_d, const float* imgs_d, int B, int H, int W, float* re_sil_d, float* mask_rgbs_d,
                     void* stream);
+/* loss = sum of the selected terms (reference train_hrnet.py:98-104: the sum over args.losses of loss_dic) when the terms are entries of
+ * the fused loss kernels' small output vectors: total_d[0] = sum_i sum_{j < counts[i]} parts[i][j], parts in order (fixed summation
+ * order); nparts <= 4, counts <= 64.  `parts` / `grads` are HOST arrays of DEVICE pointers.
+ * bwd: grads[i][j] = gtotal_d[0] for j < counts[i], 0 for counts[i] <= j < lengths[i] (the vectors' full lengths). */
+int hifihr_loss_total_fwd(const float* const* parts, const int* counts, int nparts, float* total_d, void* stream);
+int hifihr_loss_total_bwd(const float* gtotal_d, float* const* grads, const int* counts, const int* lengths, int nparts,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small-batch fully connected layer of the regression heads: y[B][O] = act( BN1d?( x[B][I] W[O][I]^T + b ) ).

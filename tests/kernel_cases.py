@@ -143,6 +143,11 @@ def mano_full_case(lib, tables, device, B, seed, root_id=9, with_cam=True):
         lib.mano_full_bwd(h, pd, bd, saved, _dev(wj, device), _dev(wv, device), _dev(wc, device) if with_cam else None,
                           _dev(wr, device) if root_id >= 0 else None, root_id, gp2, gb2)
         assert torch.equal(gp, gp2) and torch.equal(gb, gb2)
+        # gradients that reach pose / beta through their other consumer are added inside the launch
+        ap, ab = torch.randn(B, 48, generator=gen), torch.randn(B, 10, generator=gen)
+        lib.mano_full_bwd(h, pd, bd, saved, _dev(wj, device), _dev(wv, device), _dev(wc, device) if with_cam else None,
+                          _dev(wr, device) if root_id >= 0 else None, root_id, gp2, gb2, gpose_add=_dev(ap, device), gbeta_add=_dev(ab, device))
+        assert torch.equal(gp2.cpu(), gp.cpu() + ap) and torch.equal(gb2.cpu(), gb.cpu() + ab)
     finally:
         lib.mano_destroy(h)
 
@@ -818,6 +823,27 @@ def geom_loss_case(lib, device, B, V, F, mse, seed=0, J=21, NS=10, NP=48):
     lib.geom_loss_bwd(*args, d(torch.from_numpy(off)) if F else None, d(torch.from_numpy(idx)) if F else None, mse, lam, d(gout), gj, gv, gs, gp)
     for got, want, name in ((gj, jr.grad, "joints"), (gv, vr.grad, "verts"), (gs, sr.grad, "shape"), (gp, pr.grad, "pose")):
         assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-9, f"geom loss grad {name}"
+
+
+def loss_total_case(lib, device, seed=0):
+    """hifihr_loss_total_fwd / _bwd: the sum of the leading entries of up to four small vectors, and its gradient (reference
+    train_hrnet.py:98-104: loss = sum of the selected loss_dic entries)."""
+    gen = torch.Generator().manual_seed(seed)
+    parts = [torch.randn(5, generator=gen), torch.randn(4, generator=gen), torch.randn(1, generator=gen)]
+    counts = [5, 3, 1]
+    d = [p.to(device) for p in parts]
+    total = torch.full((), 7.0, device=device)
+    lib.loss_total_fwd(d, counts, total)
+    want = sum(float(p[:n].double().sum()) for p, n in zip(parts, counts))
+    assert abs(float(total) - want) <= 1e-6 * max(1.0, abs(want))
+    g = torch.tensor(1.75, device=device)
+    grads = [torch.full_like(p, 9.0) for p in d]
+    lib.loss_total_bwd(g, grads, counts)
+    for gr, n in zip(grads, counts):
+        assert torch.equal(gr.cpu()[:n], torch.full((n,), 1.75)) and float(gr.cpu()[n:].abs().sum()) == 0.0
+    one = torch.randn(1, generator=gen).to(device)
+    lib.loss_total_fwd([one], [1], total)
+    assert float(total) == float(one)
 
 
 def photo_loss_case(lib, device, B, H, W, seed=0, with_g=True):

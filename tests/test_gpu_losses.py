@@ -42,3 +42,21 @@ def test_loss_function_matches_reference_vectors(golden_dir, name):
                 ref = g[key]
                 err = np.abs(t.grad.cpu().numpy() - ref).max()
                 assert err <= 2e-4 * np.abs(ref).max() + 1e-12, (name, k, err, np.abs(ref).max())
+        # the step's form of the sum: LossFunction.total (one launch each way when the requested terms are exactly the fused kernels'
+        # vectors -- cfg2 -- else stack + sum): the same value and the same gradients
+        for t in leaves.values():
+            t.grad = None
+        lf = LossFunction()
+        d2 = lf(ex, out, args.losses, dat, args)
+        if all(k in d2 for k in args.losses):
+            tot = lf.total(d2, args.losses)
+            want = sum(float(d2[k].detach()) for k in args.losses)
+            assert abs(float(tot.detach()) - want) <= 1e-6 * max(1.0, abs(want)), (float(tot.detach()), want)
+            tot.backward()
+            torch.cuda.synchronize()
+            for k, t in leaves.items():
+                key = f"{name}/grad/{k}"
+                if key in g.files:
+                    ref = g[key]
+                    err = np.abs(t.grad.cpu().numpy() - ref).max()
+                    assert err <= 2e-4 * np.abs(ref).max() + 1e-12, ("total", name, k, err, np.abs(ref).max())

@@ -23,3 +23,7 @@ def test_photo_losses(hostsim_lib, B, H, W, with_g):
 @pytest.mark.parametrize("B,mse,use2,use3", [(3, False, True, True), (48, True, True, False), (2, False, False, True)])
 def test_joint_terms(hostsim_lib, B, mse, use2, use3):
     kc.joint_terms_case(hostsim_lib, "cpu", B, mse, seed=B, use2=use2, use3=use3)
+
+
+def test_loss_total_kernels(hostsim_lib):
+    kc.loss_total_case(hostsim_lib, "cpu")
