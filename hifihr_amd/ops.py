@@ -1629,16 +1629,26 @@ class _LinearGroup(torch.autograd.Function):
         lib = get_lib()
         dxs, dws, dbs = [None] * n, [None] * n, [None] * n
         members, ready = [], []
+        shared = {}                                    # input storage -> the ONE dx its members add into
         for i in range(n):
             if dys[i] is None:
                 continue
             dy = dys[i].contiguous()
-            dx = torch.empty_like(xs[i]) if ctx.needs_input_grad[2 + i] else None
+            dx = None
+            if ctx.needs_input_grad[2 + i]:
+                # members that read the SAME input (the heads' first layers all read the base features) share one dx: the backward-weight
+                # kernel zero-fills it, the backward-data kernel adds every member's product into it with atomics -- autograd would
+                # otherwise sum the members' gradients with an elementwise launch per extra member
+                key = (xs[i].data_ptr(), tuple(xs[i].shape))
+                dx = shared.get(key)
+                first = dx is None
+                if first:
+                    dx = shared[key] = torch.empty_like(xs[i])
             dw_t, dws[i] = _acc_target(pws[i], pws[i].shape, dy.device)
             db_t = None
             if pbs[i] is not None:
                 db_t, dbs[i] = _acc_target(pbs[i], pbs[i].shape, dy.device)
-            dxs[i] = dx
+            dxs[i] = dx if (dx is not None and first) else None          # (returned once: the shared buffer holds the sum)
             members.append(dict(x=xs[i], w=ws_c[i], y=ys[i], act=ctx.acts[i], dy=dy, dz=torch.empty_like(dy), dW=dw_t, db=db_t, dx=dx))
             ready += [p for p, ret in ((pws[i], dws[i]), (pbs[i], dbs[i])) if p is not None and ret is None]
         if members:

@@ -1450,6 +1450,16 @@ def linear_group_case(lib, device, B=32, seed=0):
         assert float((m["dW"] - r[1]).abs().max()) <= 1e-5 * float(r[1].abs().max()) and float((m["db"] - r[2]).abs().max()) <= 1e-4, i
         if m["dx"] is not None:
             assert float((m["dx"] - r[3]).abs().max()) <= 1e-5 * float(r[3].abs().max()) + 1e-6, i
+    # members that read the SAME input may share ONE dx (ops._LinearGroup.backward does for the heads' first layers): it then holds the sum
+    shared = torch.full((B, 512), 7.0, device=device)
+    mem[1]["x"] = mem[0]["x"]
+    lib.linear_bwd_group([dict(mem[0], dx=shared, dW=torch.zeros_like(mem[0]["dW"]), db=torch.zeros_like(mem[0]["db"])),
+                          dict(mem[1], dx=shared, dW=torch.zeros_like(mem[1]["dW"]), db=torch.zeros_like(mem[1]["db"]))])
+    dx0, dx1 = torch.empty(B, 512, device=device), torch.empty(B, 512, device=device)
+    lib.linear_bwd_group([dict(mem[0], dx=dx0, dW=torch.zeros_like(mem[0]["dW"]), db=torch.zeros_like(mem[0]["db"])),
+                          dict(mem[1], dx=dx1, dW=torch.zeros_like(mem[1]["dW"]), db=torch.zeros_like(mem[1]["db"]))])
+    want = dx0 + dx1
+    assert float((shared - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6, "shared dx"
 
 
 MANO_PARENTS16 = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14]     # ManoLayer's tree in its re-ordered joint index space (my_mano.py:395-434)
