@@ -157,6 +157,8 @@ class HifihrLib:
                                             _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p, c_void_p])
         c.hifihr_freihand_batch_step.argtypes = ([c_void_p, c_void_p] + [_c_float_p] * 4 + [c_int, c_int, _c_int_p, c_int, c_int, c_int, _c_float_p,
                                                  _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p, c_int, c_float] + [_c_float_p] * 4 + [c_void_p])
+        c.hifihr_light_split_fwd.argtypes = [_c_float_p, c_int, _c_float_p, _c_float_p, c_void_p]
+        c.hifihr_light_split_bwd.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_int, _c_float_p, c_void_p]
         c.hifihr_loss_total_fwd.argtypes = [POINTER(_c_float_p), POINTER(c_int), c_int, _c_float_p, c_void_p]
         c.hifihr_loss_total_bwd.argtypes = [_c_float_p, POINTER(_c_float_p), POINTER(c_int), POINTER(c_int), c_int, c_void_p]
         c.hifihr_procrustes_error.argtypes = [_c_float_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
@@ -405,6 +407,14 @@ class HifihrLib:
     def dwconv2d_bwd_weight(self, x, dy, dw, N, H, W, C, OH, OW, K, stride, pt, pl):
         self.check(self.c.hifihr_dwconv2d_bwd_weight(_fp(x), _fp(dy), _fp(dw), N, H, W, C, OH, OW, K, stride, pt, pl, _stream_of(x)),
                    "hifihr_dwconv2d_bwd_weight")
+
+    def light_split_fwd(self, lights, colors, directions):
+        self.check(self.c.hifihr_light_split_fwd(_fp(lights), lights.shape[0], _fp(colors), _fp(directions), _stream_of(lights)),
+                   "hifihr_light_split_fwd")
+
+    def light_split_bwd(self, lights, gcolors, gdirections, glights):
+        self.check(self.c.hifihr_light_split_bwd(_fp(lights), _fp(gcolors), _fp(gdirections), lights.shape[0], _fp(glights),
+                                                 _stream_of(lights)), "hifihr_light_split_bwd")
 
     def loss_total_fwd(self, parts, counts, total):
         n = len(parts)

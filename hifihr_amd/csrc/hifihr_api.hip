@@ -852,6 +852,18 @@ int hifihr_sil_post(const float* rgba, const float* imgs, int B, int H, int W, f
   return HIFIHR_OK;
 }
 
+int hifihr_light_split_fwd(const float* lights, int B, float* colors, float* directions, void* stream) {
+  if (!lights || !colors || !directions || B <= 0) return fail(HIFIHR_EINVAL, "hifihr_light_split_fwd: bad argument");
+  HIP_TRY(hifihr::launch_light_split_fwd(lights, B, colors, directions, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_light_split_bwd(const float* lights, const float* gcolors, const float* gdirections, int B, float* glights, void* stream) {
+  if (!lights || !glights || B <= 0) return fail(HIFIHR_EINVAL, "hifihr_light_split_bwd: bad argument");
+  HIP_TRY(hifihr::launch_light_split_bwd(lights, gcolors, gdirections, B, glights, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_loss_total_fwd(const float* const* parts, const int* counts, int nparts, float* total, void* stream) {
   if (!parts || !counts || !total || nparts < 1 || nparts > hifihr::kLossTotalParts) return fail(HIFIHR_EINVAL, "hifihr_loss_total_fwd: 1 .. 4 parts");
   hifihr::LossTotalParts p{};

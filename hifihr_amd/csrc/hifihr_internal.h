@@ -261,6 +261,8 @@ hipError_t launch_maxpool_bwd(const float* gy, const unsigned char* tap, const f
                               hipStream_t st);
 // g = dy * (y > 0), db_acc[c] += sum over rows of g   (conv + bias + ReLU backward; g may alias dy)
 hipError_t launch_bias_relu_bwd(const float* dy, const float* y, long M, int C, float* g, float* db_acc, hipStream_t st);
+hipError_t launch_light_split_fwd(const float* lights, int B, float* colors, float* dirs, hipStream_t st);
+hipError_t launch_light_split_bwd(const float* lights, const float* gcolors, const float* gdirs, int B, float* glights, hipStream_t st);
 
 // geometry loss terms (losses.hip): k = 0 joint_3d, 1 vert_3d, 2 edge_length, 3 mshape, 4 mpose
 struct GeomLossArgs {

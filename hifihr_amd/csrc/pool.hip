@@ -294,4 +294,36 @@ hipError_t launch_bias_relu_bwd(const float* dy, const float* y, long M, int C, 
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// LightEstimator's output split (reference network/res_encoder.py:205-210): lights[B][6] -> colors = hardtanh(lights[:, :3]) and
+// directions = lights[:, 3:] as two contiguous [B][3] tensors, one launch each way (as separate ATen calls: clamp + copy forward,
+// hardtanh_backward + cat backward).  nn.Hardtanh: clamp to [-1, 1], gradient 1 strictly inside and 0 at / beyond the ends.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void light_split_fwd_kernel(const float* __restrict__ lights, int B, float* __restrict__ colors,
+                                                             float* __restrict__ dirs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * 3) return;
+  const int b = i / 3, c = i - 3 * b;
+  const float x = lights[b * 6 + c];
+  colors[i] = fminf(fmaxf(x, -1.f), 1.f);
+  dirs[i] = lights[b * 6 + 3 + c];
+}
+__global__ __launch_bounds__(256) void light_split_bwd_kernel(const float* __restrict__ lights, const float* __restrict__ gcolors,
+                                                             const float* __restrict__ gdirs, int B, float* __restrict__ glights) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * 3) return;
+  const int b = i / 3, c = i - 3 * b;
+  const float x = lights[b * 6 + c];
+  glights[b * 6 + c] = (gcolors != nullptr && x > -1.f && x < 1.f) ? gcolors[i] : 0.f;
+  glights[b * 6 + 3 + c] = gdirs != nullptr ? gdirs[i] : 0.f;
+}
+hipError_t launch_light_split_fwd(const float* lights, int B, float* colors, float* dirs, hipStream_t st) {
+  hipLaunchKernelGGL(light_split_fwd_kernel, dim3((B * 3 + 255) / 256), dim3(256), 0, st, lights, B, colors, dirs);
+  return hipGetLastError();
+}
+hipError_t launch_light_split_bwd(const float* lights, const float* gcolors, const float* gdirs, int B, float* glights, hipStream_t st) {
+  hipLaunchKernelGGL(light_split_bwd_kernel, dim3((B * 3 + 255) / 256), dim3(256), 0, st, lights, gcolors, gdirs, B, glights);
+  return hipGetLastError();
+}
+
 }  // namespace hifihr

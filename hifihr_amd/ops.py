@@ -1694,22 +1694,27 @@ def texture_pca_decode(coef, basis, mean=None):
 
 class _LightSplit(torch.autograd.Function):
     """lights [B, 6] -> (hardtanh(lights[:, :3]), lights[:, 3:]) as two CONTIGUOUS tensors (reference network/res_encoder.py:205-210:
-    `colors = self.hardtanh(lights[:, :3]); directions = lights[:, 3:]`).  As separate autograd nodes the two slices cost seven launches
-    in the backward (hardtanh_backward, two slice_backward = zero fill + copy each, the sum of the two) and a contiguous() copy of the
-    direction slice in the renderer; here: two launches forward, two backward."""
+    `colors = self.hardtanh(lights[:, :3]); directions = lights[:, 3:]`): one launch each way (hifihr_light_split_fwd / _bwd; round 4:
+    clamp + copy forward, hardtanh_backward + cat backward; as separate autograd nodes seven launches in the backward)."""
 
     @staticmethod
     def forward(ctx, lights):
-        x3 = lights[:, :3]
-        ctx.save_for_backward(x3)
-        return torch.clamp(x3, -1.0, 1.0), lights[:, 3:].contiguous()
+        require_cuda(lights)
+        lights = lights.contiguous()
+        B = lights.shape[0]
+        colors, directions = torch.empty(B, 3, device=lights.device), torch.empty(B, 3, device=lights.device)
+        get_lib().light_split_fwd(lights, colors, directions)
+        ctx.save_for_backward(lights)
+        ctx.set_materialize_grads(False)
+        return colors, directions
 
     @staticmethod
     def backward(ctx, gc, gd):
-        x3, = ctx.saved_tensors
-        gc = torch.zeros_like(x3) if gc is None else torch.ops.aten.hardtanh_backward(gc, x3, -1.0, 1.0)
-        gd = torch.zeros_like(x3) if gd is None else gd
-        return torch.cat([gc, gd], 1)
+        lights, = ctx.saved_tensors
+        gl = torch.empty_like(lights)
+        c = lambda t: t.contiguous() if t is not None else None
+        get_lib().light_split_bwd(lights, c(gc), c(gd), gl)
+        return gl
 
 
 def light_split(lights):

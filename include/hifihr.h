@@ -252,6 +252,12 @@ int hifihr_conv2d_fwd(const float* x_d, const float* w_d, const float* bias_d /*
                       int H, int W, int C, int K, int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
 int hifihr_bias_relu_bwd(const float* dy_d, const float* y_d, long M, int C, float* g_d, float* db_acc_d /* or NULL */,
                          void* stream);
+/* LightEstimator.forward's last two lines (reference network/res_encoder.py:205-210): lights[B][6] ->
+ * colors[B][3] = hardtanh(lights[:, :3]) (nn.Hardtanh: clamp to [-1, 1]), directions[B][3] = lights[:, 3:], contiguous, one launch;
+ * bwd: glights[B][6] = [gcolors where -1 < lights < 1 else 0, gdirections] (either gradient may be NULL = zero). */
+int hifihr_light_split_fwd(const float* lights_d, int B, float* colors_d, float* directions_d, void* stream);
+int hifihr_light_split_bwd(const float* lights_d, const float* gcolors_d, const float* gdirections_d, int B, float* glights_d,
+                           void* stream);
 /* dx[N][H][W][C] (overwritten).  wt_scratch_d: K*R*S*C floats of scratch (receives the [C][R][S][K] transpose). */
 int hifihr_conv2d_bwd_data(const float* dy_d, const float* w_d, float* dx_d, float* wt_scratch_d, int N, int H, int W, int C,
                            int K, int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);

@@ -825,6 +825,29 @@ def geom_loss_case(lib, device, B, V, F, mse, seed=0, J=21, NS=10, NP=48):
         assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-9, f"geom loss grad {name}"
 
 
+def light_split_case(lib, device, B=7, seed=0):
+    """hifihr_light_split_fwd / _bwd vs torch: colors = hardtanh(lights[:, :3]), directions = lights[:, 3:] and their gradient, incl.
+    values exactly at the clamp ends (gradient 0 there, as nn.Hardtanh) and absent gradients."""
+    gen = torch.Generator().manual_seed(seed)
+    l = (torch.randn(B, 6, generator=gen) * 1.5)
+    l[0, 0] = 1.0; l[min(1, B - 1), 1] = -1.0
+    l.requires_grad_(True)
+    c = torch.nn.functional.hardtanh(l[:, :3]); dd = l[:, 3:]
+    gc, gd = torch.randn(B, 3, generator=gen), torch.randn(B, 3, generator=gen)
+    ((c * gc).sum() + (dd * gd).sum()).backward()
+    ld = l.detach().to(device).contiguous()
+    oc, od = torch.full((B, 3), 7.0, device=device), torch.full((B, 3), 7.0, device=device)
+    lib.light_split_fwd(ld, oc, od)
+    assert torch.equal(oc.cpu(), c.detach()) and torch.equal(od.cpu(), dd.detach().contiguous())
+    gl = torch.full((B, 6), 7.0, device=device)
+    lib.light_split_bwd(ld, gc.to(device), gd.to(device), gl)
+    assert torch.equal(gl.cpu(), l.grad)
+    lib.light_split_bwd(ld, None, gd.to(device), gl)
+    assert float(gl.cpu()[:, :3].abs().max()) == 0.0 and torch.equal(gl.cpu()[:, 3:], gd)
+    lib.light_split_bwd(ld, gc.to(device), None, gl)
+    assert float(gl.cpu()[:, 3:].abs().max()) == 0.0
+
+
 def loss_total_case(lib, device, seed=0):
     """hifihr_loss_total_fwd / _bwd: the sum of the leading entries of up to four small vectors, and its gradient (reference
     train_hrnet.py:98-104: loss = sum of the selected loss_dic entries)."""

@@ -54,6 +54,13 @@ def test_light_estimator_convs(lib, N, H, C, K, R, stride):
     kc.conv_case(lib, "cuda", N, H, H, C, K, R, stride, 0, seed=K)          # dgrad / wgrad of the same geometry
 
 
+def test_light_split_and_loss_total(lib):
+    """The LightEstimator's output split (network/res_encoder.py:205-210) and the sum of the loss terms (train_hrnet.py:98-104), one launch
+    each way each."""
+    kc.light_split_case(lib, "cuda", B=32)
+    kc.loss_total_case(lib, "cuda")
+
+
 @pytest.mark.parametrize("N,H,C,ksp", [(32, 12, 48, (3, 1, 1)), (32, 5, 64, (2, 2, 0))])
 def test_light_estimator_pools(lib, N, H, C, ksp):
     kc.maxpool_case(lib, "cuda", N, H, H, C, seed=C, ties=True, ksp=ksp)

@@ -27,3 +27,8 @@ def test_joint_terms(hostsim_lib, B, mse, use2, use3):
 
 def test_loss_total_kernels(hostsim_lib):
     kc.loss_total_case(hostsim_lib, "cpu")
+
+
+def test_light_split_kernels(hostsim_lib):
+    kc.light_split_case(hostsim_lib, "cpu")
+    kc.light_split_case(hostsim_lib, "cpu", B=300, seed=3)
