@@ -199,8 +199,9 @@ class Model(nn.Module):
             # of work on a handful of CUs) and the chain hand encoder -> MANO -> joints are independent until the renderer: on a side
             # stream the two latency chains overlap (ops.side_branch).  HIFIHR_LIGHT_BRANCH=0: one stream.
             # MEASURED: ResNet-18 step (B = 32) 5.38 -> 5.32 ms; EfficientNet-b3 config 3 (B = 48) 34.11 -> 34.49 ms -- there the branch
-            # runs beside the perceptual loss's large kernels and only delays them: ResNet trunks only.
-            with ops.side_branch(low_features, "light", enabled=_LIGHT_BRANCH and self.ifRender and self.low_feat_dim != 32) as br:
+            # runs beside the perceptual loss's large kernels and only delays them; ResNet-50 (512-channel low features: the branch's first
+            # convolution is no longer small) 15.73 -> 15.82 ms.  The ResNet-18 trunk (128-channel low features) only.
+            with ops.side_branch(low_features, "light", enabled=_LIGHT_BRANCH and self.ifRender and self.low_feat_dim == 128) as br:
                 light_params = self.light_estimator(low_features)
         hand_params = self.hand_encoder(features)
         root_id = 0 if (dat_name == "HO3D" and not mode_train) else self.root_id
