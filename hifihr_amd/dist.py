@@ -98,6 +98,18 @@ class GradReducer:
     def _launch(self, b):
         _, _, e_lo, e_hi = self.buckets[b]
         self._launched[b] = True
+        if self.flat.grad.is_cuda:
+            # part of the bucket's gradients may have been enqueued on a side-branch stream (ops.side_branch: the light estimator runs beside
+            # the main chain); the collective is ordered behind the CURRENT stream only, so make that stream wait for the branches first
+            # (and a hook that fires on a BRANCH stream must wait for the step's own stream likewise)
+            from .ops import side_branch
+            cur = torch.cuda.current_stream(self.flat.grad.device)
+            for key, st in side_branch._streams.items():
+                if key[0] != self.flat.grad.device:
+                    continue
+                for other in (st, side_branch._home.get(key)):
+                    if other is not None and other.cuda_stream != cur.cuda_stream:
+                        cur.wait_stream(other)
         self._handles.append(dist.all_reduce(self.flat.grad[e_lo:e_hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _make_hook(self, i):

@@ -391,6 +391,7 @@ class side_branch:
     beside the hand encoder / MANO chain 5.38 -> 5.32 ms/step.  One stream per (device, name), created once.
     `enabled=False` (or HIFIHR_BRANCHES=0) makes the block run inline."""
     _streams = {}
+    _home = {}          # (device, name) -> the stream the branch last forked from (the step's own stream)
 
     def __init__(self, like, name, enabled=True, inputs=()):
         self.on = bool(enabled) and _BRANCHES and like.is_cuda
@@ -406,6 +407,7 @@ class side_branch:
             st = side_branch._streams[key] = torch.cuda.Stream(device=dev)
             BRANCH_STREAMS.add(st.cuda_stream)
         self.cur, self.side = torch.cuda.current_stream(dev), st
+        side_branch._home[key] = self.cur
         st.wait_stream(self.cur)
         for t in (self.like,) + tuple(self.inputs):
             if torch.is_tensor(t) and t.is_cuda:
