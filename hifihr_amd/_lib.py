@@ -159,6 +159,7 @@ class HifihrLib:
                                                  _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p, c_int, c_float] + [_c_float_p] * 4 + [c_void_p])
         c.hifihr_light_split_fwd.argtypes = [_c_float_p, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_light_split_bwd.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_int, _c_float_p, c_void_p]
+        c.hifihr_wino4_bwd_gemm_pair.argtypes = [_c_float_p] * 6 + [c_int] * 6 + [c_void_p]
         c.hifihr_loss_total_fwd.argtypes = [POINTER(_c_float_p), POINTER(c_int), c_int, _c_float_p, c_void_p]
         c.hifihr_loss_total_bwd.argtypes = [_c_float_p, POINTER(_c_float_p), POINTER(c_int), POINTER(c_int), c_int, c_void_p]
         c.hifihr_procrustes_error.argtypes = [_c_float_p, _c_float_p, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
@@ -489,6 +490,11 @@ class HifihrLib:
 
     def wino_gemm_workspace_bytes(self, N, H, W, C, K, m=2):
         return int(self.c.hifihr_wino_gemm_workspace_bytes_m(N, H, W, C, K, m))
+
+    def wino4_bwd_gemm_pair(self, V2, U2, M2, Vx, Yt, dU_parts, N, H, W, C, K, parts):
+        """Backward-data and backward-weight products of one F(4x4, 3x3) layer (C -> K channels) in one launch."""
+        self.check(self.c.hifihr_wino4_bwd_gemm_pair(_fp(V2), _fp(U2), _fp(M2), _fp(Vx), _fp(Yt), _fp(dU_parts), N, H, W, C, K, int(parts),
+                                                     _stream_of(V2)), "hifihr_wino4_bwd_gemm_pair")
 
     def wino_weight_transform(self, w, U, K, C, flip, m=2):
         self.check(self.c.hifihr_wino_weight_transform_m(_fp(w), _fp(U), K, C, int(flip), m, _stream_of(w)), "hifihr_wino_weight_transform")

@@ -755,8 +755,9 @@ __device__ __forceinline__ RowsTile rows_tile_at(const BgemmArgs& a, long cur, l
 // the zero page when the tap falls outside the image.  The loader keeps the pixel's base pointer and top-left coordinate per piece (bound
 // once per tile: two integer divisions per lane and piece) and walks (r, s, channel block) incrementally; the MFMA waves, the chunk stream
 // across tile boundaries, the statistics epilogue are the plain kernel's.
+// (body + thin kernel: bgemm_nt_tn_pair_kernel below runs this body and the TN one side by side in ONE launch)
 template <int MODE>
-__global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long per) {
+__device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float* __restrict__ lds, int bid, int nblk) {
   constexpr bool RAGGED = MODE == 1;
   constexpr bool CONVG = MODE == 2;
 #if defined(HIFIHR_GEMM_STAMP)       // [0] cycles in the chunk loops, [1] 100 MHz ticks of them, [2] chunks, [3] at barriers, [4] workgroups,
@@ -764,9 +765,8 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
   unsigned long long st_loop = 0, st_real = 0, st_bar = 0, st_epi = 0, st_first = 0;
 #endif
   constexpr int STAGE = 256 * 32;                            // floats per stage: A rows 0..127, B rows 128..255
-  __shared__ __attribute__((aligned(1024))) float lds[4 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int wg = xcd_remap(bid, nblk);
   const long total = (long)a.batch * a.tiles_n * a.M;
   const long s_lo = (long)wg * per, s_hi = min(s_lo + per, total);
   if (s_lo >= s_hi) return;                                  // (uniform)
@@ -1010,6 +1010,13 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
 #endif
 }
 
+constexpr int kRowsStage = 256 * 32;                         // floats per LDS stage of the row-share kernels (4 stages = 128 KB)
+template <int MODE>
+__global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long per) {
+  __shared__ __attribute__((aligned(1024))) float lds[4 * kRowsStage];
+  nt_rows_body<MODE>(a, per, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Persistent row-share TN form: C[p][m][n] = sum_t A[p][t][m] B[p][t][n]  (backward-weight of the Winograd layers: A = Y'[P][T][K],
 // B = V[P][T][C]), N a multiple of 128, M a multiple of 16, T a multiple of 32.  The same schedule as bgemm_nt_rows_kernel -- one
@@ -1033,11 +1040,10 @@ __device__ __forceinline__ TnTile tn_tile_at(const BgemmArgs& a, long cur, long 
   return TnTile{p, nt, mb0 * 16, lim >= 8 ? 8 : lim >= 4 ? 4 : lim >= 2 ? 2 : 1};
 }
 
-__global__ __launch_bounds__(512) void bgemm_tn_rows_kernel(BgemmArgs a, long per) {
+__device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float* __restrict__ lds, int bid, int nblk) {
   constexpr int STAGE = 256 * 32;                            // floats per stage: A rows t 0..31 (x 128), then B rows t 0..31 (x 128)
-  __shared__ __attribute__((aligned(1024))) float lds[4 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int wg = xcd_remap(bid, nblk);
   const long total = (long)a.batch * a.tiles_n * (a.M / 16);
   const long s_lo = (long)wg * per, s_hi = min(s_lo + per, total);
   if (s_lo >= s_hi) return;                                  // (uniform)
@@ -1204,6 +1210,25 @@ __global__ __launch_bounds__(512) void bgemm_tn_rows_kernel(BgemmArgs a, long pe
       default: run_tile(std::integral_constant<int, 1>{}, t); break;
     }
   }
+}
+
+__global__ __launch_bounds__(512) void bgemm_tn_rows_kernel(BgemmArgs a, long per) {
+  __shared__ __attribute__((aligned(1024))) float lds[4 * kRowsStage];
+  tn_rows_body(a, per, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// An NT product and a TN product that do not depend on each other -- the backward-data product V2 . U'^T and the backward-weight product
+// Y'^T . V of ONE Winograd layer -- in ONE launch (round 5): workgroups [0, ga) walk the NT shares, [ga, gridDim.x) the TN shares.  A
+// launch of these kernels on the narrow layers is shaped by its ends (256 workgroups ask for their first three
+// chunks at once, ~4 us before the first MFMA; the last tiles' stores drain with nothing to overlap them; ~4 us of launch floor): side by
+// side the two products share one start and one end, and every workgroup owns twice the tiles.  Same bodies, same per-tile arithmetic:
+// results identical to the separate launches.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void bgemm_nt_tn_pair_kernel(BgemmArgs a, long per_a, int ga, BgemmArgs b, long per_b) {
+  __shared__ __attribute__((aligned(1024))) float lds[4 * kRowsStage];
+  if ((int)blockIdx.x < ga) nt_rows_body<0>(a, per_a, lds, (int)blockIdx.x, ga);
+  else tn_rows_body(b, per_b, lds, (int)blockIdx.x - ga, (int)gridDim.x - ga);
 }
 
 static int gemm_cus() {
@@ -1518,6 +1543,48 @@ hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M,
   else if (bm == 64 && bn == 128) hipLaunchKernelGGL((bgemm_tn_kernel<64, 128>), grid, dim3(256), 0, st, a);
   else if (bm == 64 && bn == 64) hipLaunchKernelGGL((bgemm_tn_kernel<64, 64>), grid, dim3(256), 0, st, a);
   else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// The pair launch (bgemm_nt_tn_pair_kernel): C[p][m][n] = sum_k A[p][m][k] B[p][n][k] (plain row-share form: N % 128 == 0, K % 32 == 0) AND
+// C2parts = A2^T . B2 (row-share TN form, one slab or the T-split) in ONE launch.  hipErrorNotSupported: one of the two is not on its
+// row-share kernel (the caller then launches them separately).  The CUs are divided in proportion to the products' flops, the NT side
+// weighted by HIFIHR_GEMM_PAIR_NT_WEIGHT / 100 (default 115: it runs at a lower fraction of the peak on the narrow layers).
+hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int M, int M_alloc, int N, int K, int batch, const float* A2,
+                                   const float* B2, float* C2parts, int M2, int N2, int T2, int batch2, int parts2, hipStream_t st) {
+  static const int on = [] { const char* e = getenv("HIFIHR_GEMM_PAIR"); return e ? atoi(e) : 1; }();
+  if (M_alloc < M) M_alloc = M;                               // (M_alloc > M: problems M_alloc rows apart, M of them computed -- see launch_bgemm_nt)
+  if (!on || !nt_rows(N) || bgemm_nt_ragged_supported(M, N, K) || !bgemm_nt_supported(M_alloc, N, K) || batch <= 0 ||
+      (long)M_alloc * K >= (1L << 31) || (long)N * K >= (1L << 31))
+    return hipErrorNotSupported;
+  if (!bgemm_tn_supported(M2, N2, T2) || batch2 <= 0 || parts2 <= 0) return hipErrorNotSupported;
+  const int P = tn_rows(M2, N2, T2, batch2) ? 1 : tn_rows_split(M2, N2, T2, batch2);
+  if (P <= 0 || P != parts2) return hipErrorNotSupported;
+  BgemmArgs a{};
+  a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
+  a.sa = (long)M_alloc * K; a.sb = (long)N * K; a.sc = (long)M_alloc * N; a.batch = batch;
+  a.tiles_n = N / 128; a.tiles_m = (M + 127) / 128; a.splits = 1; a.cps = K / 32; a.sc_split = 0;
+  BgemmArgs b{};
+  const int Tp = T2 / P;
+  b.A = A2; b.B = B2; b.C = C2parts; b.M = M2; b.N = N2; b.K = Tp; b.lda = M2; b.ldb = N2; b.ldc = N2;
+  b.sa = (long)Tp * M2; b.sb = (long)Tp * N2; b.sc = (long)M2 * N2; b.batch = batch2 * P;
+  b.tiles_n = N2 / 128; b.tiles_m = (M2 + 127) / 128; b.splits = P; b.cps = Tp / 32; b.sc_split = P > 1 ? (long)batch2 * M2 * N2 : 0;
+  static const int wnt = [] { const char* e = getenv("HIFIHR_GEMM_PAIR_NT_WEIGHT"); const int v = e ? atoi(e) : 115; return v > 0 ? v : 115; }();
+  const double fa = 2.0 * batch * (double)M * N * K * (wnt / 100.0), fb = 2.0 * batch2 * (double)M2 * N2 * T2;
+  const int cus = gemm_cus();
+  int ga = (int)(cus * fa / (fa + fb) + 0.5);
+  if (ga < 8) ga = 8;
+  if (ga > cus - 8) ga = cus - 8;
+  int gb = cus - ga;
+  const long total_a = (long)batch * a.tiles_n * M;
+  long per_a = (total_a + ga - 1) / ga;
+  if (per_a < 16) per_a = 16;
+  ga = (int)((total_a + per_a - 1) / per_a);
+  const long total_b = (long)b.batch * b.tiles_n * (M2 / 16);
+  long per_b = (total_b + gb - 1) / gb;
+  if (per_b < 4) per_b = 4;
+  gb = (int)((total_b + per_b - 1) / per_b);
+  hipLaunchKernelGGL(bgemm_nt_tn_pair_kernel, dim3(ga + gb), dim3(512), 0, st, a, per_a, ga, b, per_b);
   return hipGetLastError();
 }
 

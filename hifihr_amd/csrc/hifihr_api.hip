@@ -1163,6 +1163,24 @@ int hifihr_wino_gemm_m(const float* V, const float* U, float* M, int N, int H, i
   return HIFIHR_OK;
 }
 
+int hifihr_wino4_bwd_gemm_pair(const float* V2, const float* U2, float* M2, const float* Vx, const float* Yt, float* dU_parts, int N, int H,
+                               int W, int C, int K, int parts, void* stream) {
+  const long T4 = (N > 0 && H > 0 && W > 0) ? wino_T(4, N, H, W) : 0;
+  if (!V2 || !U2 || !M2 || !Vx || !Yt || !dU_parts || T4 <= 0 || T4 >= (1L << 30) || parts <= 0 || !hifihr::bgemm_nt_supported((int)T4, C, K) ||
+      !hifihr::bgemm_tn_supported(K, C, (int)T4) || parts != hifihr::bgemm_tn_parts(K, C, (int)T4, 36))
+    return fail(HIFIHR_EINVAL, "hifihr_wino4_bwd_gemm_pair: bad argument (C, K % 64 == 0; parts = hifihr_wino_wgrad_parts_m(N, H, W, C, K, 4))");
+  const long Tr = hifihr::wino4_tiles_real(N, H, W);
+  const hipError_t e = hifihr::launch_bgemm_nt_tn_pair(V2, U2, M2, (int)(Tr < T4 ? Tr : T4), (int)T4, C, K, 36, Yt, Vx, dU_parts, K, C, (int)T4, 36,
+                                                       parts, (hipStream_t)stream);
+  if (e == hipSuccess) return HIFIHR_OK;
+  if (e != hipErrorNotSupported) HIP_TRY(e);
+  // not a pair of row-share products: the two launches of hifihr_wino_gemm_m (with C and K exchanged) / hifihr_wino_wgrad_gemm_parts_m
+  if (Tr < T4) HIP_TRY(hifihr::launch_bgemm_nt(V2, U2, M2, (int)Tr, C, K, 36, nullptr, 0, (hipStream_t)stream, nullptr, (int)T4));
+  else HIP_TRY(hifihr::launch_bgemm_nt(V2, U2, M2, (int)T4, C, K, 36, nullptr, 0, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_bgemm_tn(Yt, Vx, dU_parts, K, C, (int)T4, 36, parts, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_dy_transform_m(const float* dy, float* Y, int N, int H, int W, int K, int m, void* stream) {
   if (m != 4) return hifihr_wino_dy_transform(dy, Y, N, H, W, K, stream);
   if (!dy || !Y || N <= 0 || H <= 0 || W <= 0 || K < 4 || K % 4 != 0) return fail(HIFIHR_EINVAL, "hifihr_wino_dy_transform: bad argument");

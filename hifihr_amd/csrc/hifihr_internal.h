@@ -401,6 +401,9 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
                            float* stats_or_null = nullptr, int M_alloc = 0);      // stats: only with N % 128 == 0 and batch == 1 (else hipErrorInvalidValue)
 int bgemm_tn_parts(int M, int N, int T, int batch);
 hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st);
+// an NT and an independent TN product on the row-share kernels in ONE launch (csrc/gemm.hip); hipErrorNotSupported: launch them separately
+hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int M, int M_alloc, int N, int K, int batch, const float* A2,
+                                   const float* B2, float* C2parts, int M2, int N2, int T2, int batch2, int parts2, hipStream_t st);
 hipError_t launch_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st);
 // Winograd F(4x4, 3x3) glue (wino4.hip): 36 positions, T = wino4_tiles(N, H, W) tiles (N * ceil(H / 4) * ceil(W / 4), or fewer where 16
 // images share a mosaic: wino4_math.h TileGeo)

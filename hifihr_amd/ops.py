@@ -433,6 +433,7 @@ class side_branch:
 
 
 _BRANCHES = os.environ.get("HIFIHR_BRANCHES", "1") != "0"
+_GEMM_PAIR = os.environ.get("HIFIHR_GEMM_PAIR", "1") != "0"
 BRANCH_STREAMS = set() # raw handles of side streams that run convolutions BESIDE the main stream (models.Model's light branch)
 _CONV_WS = {}          # (device, branch stream or 0) -> zero-initialised, self-cleaning workspace of the balanced convolution schedule
 _CONV_WS_BYTES = {}    # (geometry, direction) -> bytes the library wants for it
@@ -1238,15 +1239,24 @@ class _BNActWinoConv(torch.autograd.Function):
                 U2 = _wino_scratch(dev, "U", P * K * C)
                 lib.wino_weight_transform(wt, U2, C, K, 1, m)
             M2 = _wino_scratch(dev, "M", P * T * C)
-            lib.wino_gemm(V2, U2, M2, N, H, W, K, C, ws=_wino_gemm_ws(lib, dev, N, H, W, K, C, m), m=m)
+            pair = need[5] and m == 4 and _GEMM_PAIR
+            if pair:
+                # 2 + 4a. the backward-data product and the backward-weight product do not depend on each other: ONE launch whose
+                # workgroups split between them (hifihr_wino4_bwd_gemm_pair; HIFIHR_GEMM_PAIR=0: two launches)
+                parts = lib.wino_wgrad_parts(N, H, W, C, K, m)
+                dU = _wino_scratch(dev, "dUp", parts * P * K * C)
+                lib.wino4_bwd_gemm_pair(V2, U2, M2, V, Yt, dU, N, H, W, C, K, parts)
+            else:
+                lib.wino_gemm(V2, U2, M2, N, H, W, K, C, ws=_wino_gemm_ws(lib, dev, N, H, W, K, C, m), m=m)
             # 3. output transform + identity-branch gradient + ReLU mask + batch-norm reduction
             lib.wino_output_transform_bnred(M2, x, res_out, gadd, save_mean, save_invstd, gamma, beta, red, g_in, N, H, W, C, m)
             # 4. backward-weight: dU = Y'^T V over the tiles (slabs, fixed order), dw += G^T dU G
             if need[5]:
                 tgt = w.grad if direct_w else torch.zeros_like(wk, memory_format=_CL)
-                parts = lib.wino_wgrad_parts(N, H, W, C, K, m)
-                dU = _wino_scratch(dev, "dUp", parts * P * K * C)
-                lib.wino_wgrad_gemm_parts(V, Yt, dU, N, H, W, C, K, parts, m)
+                if not pair:
+                    parts = lib.wino_wgrad_parts(N, H, W, C, K, m)
+                    dU = _wino_scratch(dev, "dUp", parts * P * K * C)
+                    lib.wino_wgrad_gemm_parts(V, Yt, dU, N, H, W, C, K, parts, m)
                 lib.wino_dw_transform_parts(dU, parts, tgt, K, C, m)
                 dw_box[0] = None if direct_w else tgt
         if PROFILE.on:

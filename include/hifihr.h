@@ -388,6 +388,14 @@ int hifihr_wino_input_dy_transform_m(const float* dy_d, float* v_d, float* yt_d,
 int hifihr_wino_wgrad_parts_m(int N, int H, int W, int C, int K, int m);
 int hifihr_wino_wgrad_gemm_parts_m(const float* v_d, const float* yt_d, float* du_parts_d, int N, int H, int W, int C, int K, int parts, int m,
                                    void* stream);
+/* The two products of a Winograd F(4x4, 3x3) layer's backward that do not depend on each other, in ONE launch (round 5):
+ *   backward-data   M2[36][T][C] = V2[36][T][K] . U2[36][C][K]^T      (= hifihr_wino_gemm_m(V2, U2, M2, N, H, W, K, C, 4, ...))
+ *   backward-weight dU_parts     = Yt[36][T][K]^T . Vx[36][T][C]      (= hifihr_wino_wgrad_gemm_parts_m(Vx, Yt, dU_parts, ..., parts, 4))
+ * with V2 / Yt the two transforms of dy and Vx the forward's transformed input (the layer maps C -> K channels).  Workgroups of one
+ * launch split between the two (a short launch of these kernels is shaped by its start and its end); falls back to the two launches
+ * for shapes that are not on the row-share kernels.  Results identical to the separate calls. */
+int hifihr_wino4_bwd_gemm_pair(const float* V2_d, const float* U2_d, float* M2_d, const float* Vx_d, const float* Yt_d, float* dU_parts_d,
+                               int N, int H, int W, int C, int K, int parts, void* stream);
 int hifihr_wino_dw_transform_parts_m(const float* du_parts_d, int parts, float* dw_acc_d, int K, int C, int m, void* stream);
 /* Batched fp32 GEMM on the f32 matrix cores (csrc/gemm.hip): the plain products a Winograd layer consists of -- the GEMM half of
  * the vendor-library call behind one conv2d of the reference (network/res_encoder.py:364-373).  hifihr_wino_gemm dispatches here

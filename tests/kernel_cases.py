@@ -1197,6 +1197,15 @@ def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True, 
         lib.wino_dw_transform_parts(dUp, parts, dw2, K, C, m)
         err = float((dw2.cpu() - 0.5 - refw).abs().max())
         assert err <= 1e-4 * float(refw.abs().max()) + 1e-6, f"winograd bwd weight (slabs): {err} vs {float(refw.abs().max())}"
+        if m == 4 and C % 64 == 0 and K % 64 == 0:
+            # the two backward products in ONE launch (hifihr_wino4_bwd_gemm_pair): the same bits as the two separate launches
+            M2p = torch.full_like(M2, 7.0); dUq = torch.full_like(dUp, 7.0)
+            lib.wino4_bwd_gemm_pair(V2, U2, M2p, V, Yt, dUq, N, H, W, C, K, parts)
+            M2s = torch.full_like(M2, 7.0)
+            lib.wino_gemm(V2, U2, M2s, N, H, W, K, C, ws=None, m=m)            # (same kernel family as the pair: no balanced-schedule workspace)
+            Tr = lib.wino_tiles_computed(N, H, W, m)                            # (rows behind the last mosaic tile are padding: never written)
+            assert torch.equal(M2p[:, :Tr], M2s[:, :Tr]), "pair launch: backward-data product"
+            assert torch.equal(dUq, dUp), "pair launch: backward-weight slabs"
     return 0 if ws is None else 1
 
 
