@@ -1549,7 +1549,7 @@ hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M,
 // The pair launch (bgemm_nt_tn_pair_kernel): C[p][m][n] = sum_k A[p][m][k] B[p][n][k] (plain row-share form: N % 128 == 0, K % 32 == 0) AND
 // C2parts = A2^T . B2 (row-share TN form, one slab or the T-split) in ONE launch.  hipErrorNotSupported: one of the two is not on its
 // row-share kernel (the caller then launches them separately).  The CUs are divided in proportion to the products' flops, the NT side
-// weighted by HIFIHR_GEMM_PAIR_NT_WEIGHT / 100 (default 115: it runs at a lower fraction of the peak on the narrow layers).
+// weighted by HIFIHR_GEMM_PAIR_NT_WEIGHT / 100 (default 100; measured on the ResNet-18 step: 70 -> 5.33 ms, 85 -> 5.21, 100 -> 5.17, 110 -> 5.22, 130 -> 5.50; separate launches 5.27).
 hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int M, int M_alloc, int N, int K, int batch, const float* A2,
                                    const float* B2, float* C2parts, int M2, int N2, int T2, int batch2, int parts2, hipStream_t st) {
   static const int on = [] { const char* e = getenv("HIFIHR_GEMM_PAIR"); return e ? atoi(e) : 1; }();
@@ -1569,7 +1569,7 @@ hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int
   b.A = A2; b.B = B2; b.C = C2parts; b.M = M2; b.N = N2; b.K = Tp; b.lda = M2; b.ldb = N2; b.ldc = N2;
   b.sa = (long)Tp * M2; b.sb = (long)Tp * N2; b.sc = (long)M2 * N2; b.batch = batch2 * P;
   b.tiles_n = N2 / 128; b.tiles_m = (M2 + 127) / 128; b.splits = P; b.cps = Tp / 32; b.sc_split = P > 1 ? (long)batch2 * M2 * N2 : 0;
-  static const int wnt = [] { const char* e = getenv("HIFIHR_GEMM_PAIR_NT_WEIGHT"); const int v = e ? atoi(e) : 115; return v > 0 ? v : 115; }();
+  static const int wnt = [] { const char* e = getenv("HIFIHR_GEMM_PAIR_NT_WEIGHT"); const int v = e ? atoi(e) : 100; return v > 0 ? v : 100; }();
   const double fa = 2.0 * batch * (double)M * N * K * (wnt / 100.0), fb = 2.0 * batch2 * (double)M2 * N2 * T2;
   const int cus = gemm_cus();
   int ga = (int)(cus * fa / (fa + fb) + 0.5);

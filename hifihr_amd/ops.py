@@ -686,7 +686,8 @@ class prepared_weights:
         return False
 
 
-def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None, dy_out=None, tile=None, mask=None):
+def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias=None, act=0, U=None, dy_out=None, tile=None, mask=None,
+               pair=None):
     """y[N][H][W][K] = conv3x3(x[N][H][W][C], w[K][3][3][C]) through weight / input transform, 16 batched GEMMs, output
     transform (csrc/wino.hip).  flip = 1: w is the [K'][3][3][C'] transpose used by backward-data (rotated filter).
     keep_v: return the transformed input V[16][T][C] in a tensor of its own (the Winograd weight gradient consumes it)."""
@@ -719,7 +720,13 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias
         lib.wino_input_dy_transform(x, V, dy_out, N, H, W, C, m)
     else:
         lib.wino_input_transform(x, V, N, H, W, C, m)
-    lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws, m=m)          # csrc/gemm.hip (16x16x4 f32 MFMA); odd channel counts: conv.hip
+    if pair is not None:
+        # backward of a layer that maps K -> C channels in THIS call's naming: its backward-weight product rides in the same launch
+        # (pair = (the forward's transformed input, the slab buffer, parts); hifihr_wino4_bwd_gemm_pair)
+        vx, dU, parts = pair
+        lib.wino4_bwd_gemm_pair(V, U, M, vx, dy_out, dU, N, H, W, K, C, parts)
+    else:
+        lib.wino_gemm(V, U, M, N, H, W, C, K, ws=ws, m=m)      # csrc/gemm.hip (16x16x4 f32 MFMA); odd channel counts: conv.hip
     lib.wino_output_transform(M, y, stats, N, H, W, K, bias=bias, act=act, m=m, mask=mask)      # mask: y = mask > 0 ? y : 0 (m == 4)
     return V if keep_v else None
 
@@ -843,7 +850,7 @@ class _Conv2dMFMA(torch.autograd.Function):
         if gy is None:
             return (g_fork,) + (None,) * 9
         gy = gy.contiguous(memory_format=_CL)
-        dx = dw = db_ret = Yt_done = None
+        dx = dw = db_ret = Yt_done = pair_done = None
         if ctx.relu or ctx.b_param is not None:
             # conv + bias (+ ReLU) epilogue: masked gradient and the bias gradient in one small launch
             b = ctx.b_param
@@ -871,10 +878,16 @@ class _Conv2dMFMA(torch.autograd.Function):
             if ctx.needs_input_grad[1] and v_saved is not None:      # the Winograd backward-weight below wants A dy A^T: same read of dy
                 # a side-stream weight gradient reads it while the next layer's backward-data already runs: a buffer of its own
                 Yt_done = _wino_scratch(gy.device, ("Yt", ctx.w_param.data_ptr()) if _ASYNC_WGRAD.active else "Yt", wP * wT * K)
+            # both gradients wanted, F(4x4), prepared filter, weight gradient on THIS stream: the two products share one launch
+            if (Yt_done is not None and wm == 4 and U2 is not None and _GEMM_PAIR and not _ASYNC_WGRAD.active
+                    and min(C, K) % 64 == 0):
+                pparts = lib.wino_wgrad_parts(N, H, W, C, K, wm)
+                if pparts > 0:
+                    pair_done = (v_saved, _wino_scratch(gy.device, "dUp", pparts * wP * K * C), pparts)
 
             def run():
                 if U2 is not None:
-                    _wino_conv(lib, gy, None, dx, None, N, H, W, K, C, 1, U=U2, dy_out=Yt_done, tile=tile, mask=mk)
+                    _wino_conv(lib, gy, None, dx, None, N, H, W, K, C, 1, U=U2, dy_out=Yt_done, tile=tile, mask=mk, pair=pair_done)
                 else:
                     wt = _wino_scratch(gy.device, "wt", wk.numel())
                     lib.weight_transpose(wk, wt, K, R * S, C)
@@ -942,7 +955,9 @@ class _Conv2dMFMA(torch.autograd.Function):
                 def run_w():
                     if Yt_done is None:
                         lib.wino_dy_transform(gy, Yt, N, H, W, K, wm)
-                    if parts > 0:
+                    if pair_done is not None:              # the product already ran beside backward-data (same slab buffer)
+                        lib.wino_dw_transform_parts(pair_done[1], pair_done[2], tgt, K, C, wm)
+                    elif parts > 0:
                         lib.wino_wgrad_gemm_parts(v_saved, Yt, dU, N, H, W, C, K, parts, wm)
                         lib.wino_dw_transform_parts(dU, parts, tgt, K, C, wm)
                     else:
