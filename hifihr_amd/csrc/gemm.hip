@@ -1571,6 +1571,10 @@ hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int
   b.tiles_n = N2 / 128; b.tiles_m = (M2 + 127) / 128; b.splits = P; b.cps = Tp / 32; b.sc_split = P > 1 ? (long)batch2 * M2 * N2 : 0;
   static const int wnt = [] { const char* e = getenv("HIFIHR_GEMM_PAIR_NT_WEIGHT"); const int v = e ? atoi(e) : 100; return v > 0 ? v : 100; }();
   const double fa = 2.0 * batch * (double)M * N * K * (wnt / 100.0), fb = 2.0 * batch2 * (double)M2 * N2 * T2;
+  // Long products gain nothing from sharing a launch (their ends are a small part of them): VGG19's layers at 112 x 112 / 56 x 56 (22-44
+  // GFLOP each) measured 33.71 ms/step apart against 33.75 paired (config 3); the ResNet layers (1.9-8.5 GFLOP) 5.25 -> 5.16 ms/step.
+  static const double max_gf = [] { const char* e = getenv("HIFIHR_GEMM_PAIR_MAX_GFLOP"); const double v = e ? atof(e) : 12.0; return v > 0 ? v : 12.0; }();
+  if (2.0 * batch * (double)M * N * K > max_gf * 1e9) return hipErrorNotSupported;
   const int cus = gemm_cus();
   int ga = (int)(cus * fa / (fa + fb) + 0.5);
   if (ga < 8) ga = 8;
