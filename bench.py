@@ -259,6 +259,20 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
         e["shapes"].append({"shape": what, "launches_per_step": per_step, "us": round(us, 1), "TFLOPs": round(flop / us / 1e6, 1)})
     for (geom, direction), cnt in Counter(ops.PROFILE.conv_log).items():
         per_step = cnt / nprof
+        if direction == "gemm-pair":
+            # backward-data + backward-weight products of one F(4x4) layer (C_ -> K_ channels) in ONE launch (bgemm_nt_tn_pair_kernel); a
+            # product the library declines to pair (too long) falls back to the two launches inside the same entry point: priced the same way
+            _, N_, H_, W_, C_, K_, m_ = geom
+            P_ = (m_ + 2) ** 2
+            T_ = lib.wino_tiles(N_, H_, W_, m_); Tc = lib.wino_tiles_computed(N_, H_, W_, m_)
+            parts = lib.wino_wgrad_parts(N_, H_, W_, C_, K_, m_)
+            V2 = torch.randn(P_ * T_ * K_, device=dev); U2 = torch.randn(P_ * C_ * K_, device=dev) * 0.05; M2 = torch.empty(P_ * T_ * C_, device=dev)
+            Vx = torch.randn(P_ * T_ * C_, device=dev); Yt = torch.randn(P_ * T_ * K_, device=dev); dU = torch.empty(parts * P_ * K_ * C_, device=dev)
+            us = hip_us(lambda: lib.wino4_bwd_gemm_pair(V2, U2, M2, Vx, Yt, dU, N_, H_, W_, C_, K_, parts))
+            add("bgemm_nt_tn_pair_kernel", per_step, us, 2.0 * P_ * (Tc + T_) * C_ * K_,
+                4.0 * P_ * ((Tc * K_ + C_ * K_ + Tc * C_) + (T_ * C_ + T_ * K_ + parts * K_ * C_)),
+                f"{P_} x ([{Tc} x {K_}] . [{C_} x {K_}]^T  +  [{T_} x {K_}]^T . [{T_} x {C_}], {parts} slab(s))")
+            continue
         if direction in ("gemm", "gemm-tn"):
             _, N_, H_, W_, C_, K_, m_ = geom                    # m_: Winograd output-tile edge (2: 16 positions, 4: 36)
             P_ = (m_ + 2) ** 2

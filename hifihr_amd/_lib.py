@@ -67,6 +67,7 @@ class HifihrLib:
         self.path = path
         self.c = ctypes.CDLL(path)
         self._zero_page = set()                # devices whose zero page exists (zero_page_ready)
+        self._pair_ok = {}                     # (N, H, W, C, K) -> hifihr_wino4_bwd_gemm_pair_supported
         c = self.c
         c.hifihr_last_error.restype = c_char_p
         c.hifihr_version.restype = c_int
@@ -159,6 +160,7 @@ class HifihrLib:
                                                  _c_float_p, c_void_p] + [_c_float_p] * 6 + [c_void_p, c_int, c_float] + [_c_float_p] * 4 + [c_void_p])
         c.hifihr_light_split_fwd.argtypes = [_c_float_p, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_light_split_bwd.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_int, _c_float_p, c_void_p]
+        c.hifihr_wino4_bwd_gemm_pair_supported.argtypes = [c_int] * 5
         c.hifihr_wino4_bwd_gemm_pair.argtypes = [_c_float_p] * 6 + [c_int] * 6 + [c_void_p]
         c.hifihr_loss_total_fwd.argtypes = [POINTER(_c_float_p), POINTER(c_int), c_int, _c_float_p, c_void_p]
         c.hifihr_loss_total_bwd.argtypes = [_c_float_p, POINTER(_c_float_p), POINTER(c_int), POINTER(c_int), c_int, c_void_p]
@@ -490,6 +492,13 @@ class HifihrLib:
 
     def wino_gemm_workspace_bytes(self, N, H, W, C, K, m=2):
         return int(self.c.hifihr_wino_gemm_workspace_bytes_m(N, H, W, C, K, m))
+
+    def wino4_bwd_gemm_pair_supported(self, N, H, W, C, K):
+        key = (N, H, W, C, K)
+        hit = self._pair_ok.get(key)
+        if hit is None:
+            hit = self._pair_ok[key] = bool(self.c.hifihr_wino4_bwd_gemm_pair_supported(int(N), int(H), int(W), int(C), int(K)))
+        return hit
 
     def wino4_bwd_gemm_pair(self, V2, U2, M2, Vx, Yt, dU_parts, N, H, W, C, K, parts):
         """Backward-data and backward-weight products of one F(4x4, 3x3) layer (C -> K channels) in one launch."""

@@ -1550,16 +1550,26 @@ hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M,
 // C2parts = A2^T . B2 (row-share TN form, one slab or the T-split) in ONE launch.  hipErrorNotSupported: one of the two is not on its
 // row-share kernel (the caller then launches them separately).  The CUs are divided in proportion to the products' flops, the NT side
 // weighted by HIFIHR_GEMM_PAIR_NT_WEIGHT / 100 (default 100; measured on the ResNet-18 step: 70 -> 5.33 ms, 85 -> 5.21, 100 -> 5.17, 110 -> 5.22, 130 -> 5.50; separate launches 5.27).
-hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int M, int M_alloc, int N, int K, int batch, const float* A2,
-                                   const float* B2, float* C2parts, int M2, int N2, int T2, int batch2, int parts2, hipStream_t st) {
+bool bgemm_nt_tn_pair_supported(int M, int M_alloc, int N, int K, int batch, int M2, int N2, int T2, int batch2, int parts2) {
   static const int on = [] { const char* e = getenv("HIFIHR_GEMM_PAIR"); return e ? atoi(e) : 1; }();
-  if (M_alloc < M) M_alloc = M;                               // (M_alloc > M: problems M_alloc rows apart, M of them computed -- see launch_bgemm_nt)
+  if (M_alloc < M) M_alloc = M;
   if (!on || !nt_rows(N) || bgemm_nt_ragged_supported(M, N, K) || !bgemm_nt_supported(M_alloc, N, K) || batch <= 0 ||
       (long)M_alloc * K >= (1L << 31) || (long)N * K >= (1L << 31))
-    return hipErrorNotSupported;
-  if (!bgemm_tn_supported(M2, N2, T2) || batch2 <= 0 || parts2 <= 0) return hipErrorNotSupported;
+    return false;
+  if (!bgemm_tn_supported(M2, N2, T2) || batch2 <= 0 || parts2 <= 0) return false;
   const int P = tn_rows(M2, N2, T2, batch2) ? 1 : tn_rows_split(M2, N2, T2, batch2);
-  if (P <= 0 || P != parts2) return hipErrorNotSupported;
+  if (P <= 0 || P != parts2) return false;
+  // Long products gain nothing from sharing a launch (their ends are a small part of them): VGG19's layers at 112 x 112 / 56 x 56 (22-44
+  // GFLOP each) measured 33.71 ms/step apart against 33.75 paired (config 3); the ResNet layers (1.9-8.5 GFLOP) 5.25 -> 5.16 ms/step.
+  static const double max_gf = [] { const char* e = getenv("HIFIHR_GEMM_PAIR_MAX_GFLOP"); const double v = e ? atof(e) : 12.0; return v > 0 ? v : 12.0; }();
+  return 2.0 * batch * (double)M * N * K <= max_gf * 1e9;
+}
+
+hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int M, int M_alloc, int N, int K, int batch, const float* A2,
+                                   const float* B2, float* C2parts, int M2, int N2, int T2, int batch2, int parts2, hipStream_t st) {
+  if (!bgemm_nt_tn_pair_supported(M, M_alloc, N, K, batch, M2, N2, T2, batch2, parts2)) return hipErrorNotSupported;
+  if (M_alloc < M) M_alloc = M;                               // (M_alloc > M: problems M_alloc rows apart, M of them computed -- see launch_bgemm_nt)
+  const int P = parts2;
   BgemmArgs a{};
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
   a.sa = (long)M_alloc * K; a.sb = (long)N * K; a.sc = (long)M_alloc * N; a.batch = batch;
@@ -1571,10 +1581,6 @@ hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int
   b.tiles_n = N2 / 128; b.tiles_m = (M2 + 127) / 128; b.splits = P; b.cps = Tp / 32; b.sc_split = P > 1 ? (long)batch2 * M2 * N2 : 0;
   static const int wnt = [] { const char* e = getenv("HIFIHR_GEMM_PAIR_NT_WEIGHT"); const int v = e ? atoi(e) : 100; return v > 0 ? v : 100; }();
   const double fa = 2.0 * batch * (double)M * N * K * (wnt / 100.0), fb = 2.0 * batch2 * (double)M2 * N2 * T2;
-  // Long products gain nothing from sharing a launch (their ends are a small part of them): VGG19's layers at 112 x 112 / 56 x 56 (22-44
-  // GFLOP each) measured 33.71 ms/step apart against 33.75 paired (config 3); the ResNet layers (1.9-8.5 GFLOP) 5.25 -> 5.16 ms/step.
-  static const double max_gf = [] { const char* e = getenv("HIFIHR_GEMM_PAIR_MAX_GFLOP"); const double v = e ? atof(e) : 12.0; return v > 0 ? v : 12.0; }();
-  if (2.0 * batch * (double)M * N * K > max_gf * 1e9) return hipErrorNotSupported;
   const int cus = gemm_cus();
   int ga = (int)(cus * fa / (fa + fb) + 0.5);
   if (ga < 8) ga = 8;

@@ -1163,6 +1163,13 @@ int hifihr_wino_gemm_m(const float* V, const float* U, float* M, int N, int H, i
   return HIFIHR_OK;
 }
 
+int hifihr_wino4_bwd_gemm_pair_supported(int N, int H, int W, int C, int K) {
+  const long T4 = (N > 0 && H > 0 && W > 0) ? wino_T(4, N, H, W) : 0;
+  if (T4 <= 0 || T4 >= (1L << 30) || C <= 0 || K <= 0 || !hifihr::bgemm_nt_supported((int)T4, C, K) || !hifihr::bgemm_tn_supported(K, C, (int)T4)) return 0;
+  const long Tr = hifihr::wino4_tiles_real(N, H, W);
+  return hifihr::bgemm_nt_tn_pair_supported((int)(Tr < T4 ? Tr : T4), (int)T4, C, K, 36, K, C, (int)T4, 36, hifihr::bgemm_tn_parts(K, C, (int)T4, 36)) ? 1 : 0;
+}
+
 int hifihr_wino4_bwd_gemm_pair(const float* V2, const float* U2, float* M2, const float* Vx, const float* Yt, float* dU_parts, int N, int H,
                                int W, int C, int K, int parts, void* stream) {
   const long T4 = (N > 0 && H > 0 && W > 0) ? wino_T(4, N, H, W) : 0;

@@ -401,6 +401,7 @@ hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int 
                            float* stats_or_null = nullptr, int M_alloc = 0);      // stats: only with N % 128 == 0 and batch == 1 (else hipErrorInvalidValue)
 int bgemm_tn_parts(int M, int N, int T, int batch);
 hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st);
+bool bgemm_nt_tn_pair_supported(int M, int M_alloc, int N, int K, int batch, int M2, int N2, int T2, int batch2, int parts2);
 // an NT and an independent TN product on the row-share kernels in ONE launch (csrc/gemm.hip); hipErrorNotSupported: launch them separately
 hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int M, int M_alloc, int N, int K, int batch, const float* A2,
                                    const float* B2, float* C2parts, int M2, int N2, int T2, int batch2, int parts2, hipStream_t st);

@@ -712,8 +712,8 @@ def _wino_conv(lib, x, w_krsc, y, stats, N, H, W, C, K, flip, keep_v=False, bias
                 _RETIRED_SCRATCH.append(ws)
             ws = torch.zeros(max(nb, 32 << 20) // 4 + 64, dtype=torch.float32, device=dev)
             _CONV_WS[dev] = ws
-    if PROFILE.on:
-        PROFILE.conv_log.append((("wino", N, H, W, C, K, m), "gemm"))
+    if PROFILE.on:            # (pair: the layer maps K -> C channels in this call's naming; bench.py times the pair launch for it)
+        PROFILE.conv_log.append((("wino", N, H, W, K, C, m), "gemm-pair") if pair is not None else (("wino", N, H, W, C, K, m), "gemm"))
     if not prepared:
         lib.wino_weight_transform(w_krsc, U, K, C, flip, m)
     if dy_out is not None:                            # backward: x is dy, the backward-weight transform Y' comes out of the same read
@@ -879,11 +879,13 @@ class _Conv2dMFMA(torch.autograd.Function):
                 # a side-stream weight gradient reads it while the next layer's backward-data already runs: a buffer of its own
                 Yt_done = _wino_scratch(gy.device, ("Yt", ctx.w_param.data_ptr()) if _ASYNC_WGRAD.active else "Yt", wP * wT * K)
             # both gradients wanted, F(4x4), prepared filter, weight gradient on THIS stream: the two products share one launch
-            if (Yt_done is not None and wm == 4 and U2 is not None and _GEMM_PAIR and not _ASYNC_WGRAD.active
-                    and min(C, K) % 64 == 0):
+            if (Yt_done is not None and wm == 4 and U2 is not None and _GEMM_PAIR and min(C, K) % 64 == 0
+                    and lib.wino4_bwd_gemm_pair_supported(N, H, W, C, K)):
                 pparts = lib.wino_wgrad_parts(N, H, W, C, K, wm)
                 if pparts > 0:
-                    pair_done = (v_saved, _wino_scratch(gy.device, "dUp", pparts * wP * K * C), pparts)
+                    # (a side-stream weight-gradient transform reads the slabs while the next layer's pair already runs: a buffer of its own)
+                    pair_done = (v_saved, _wino_scratch(gy.device, ("dUp", ctx.w_param.data_ptr()) if _ASYNC_WGRAD.active else "dUp",
+                                                        pparts * wP * K * C), pparts)
 
             def run():
                 if U2 is not None:
@@ -949,7 +951,7 @@ class _Conv2dMFMA(torch.autograd.Function):
                         dU = torch.zeros(16 * K * C, device=gy.device, dtype=torch.float32)
                         _WINO_SCRATCH[key] = dU
 
-                if PROFILE.on:
+                if PROFILE.on and pair_done is None:
                     PROFILE.conv_log.append((("wino", N, H, W, C, K, wm), "gemm-tn"))
 
                 def run_w():
@@ -1254,7 +1256,7 @@ class _BNActWinoConv(torch.autograd.Function):
                 U2 = _wino_scratch(dev, "U", P * K * C)
                 lib.wino_weight_transform(wt, U2, C, K, 1, m)
             M2 = _wino_scratch(dev, "M", P * T * C)
-            pair = need[5] and m == 4 and _GEMM_PAIR
+            pair = need[5] and m == 4 and _GEMM_PAIR and lib.wino4_bwd_gemm_pair_supported(N, H, W, C, K)
             if pair:
                 # 2 + 4a. the backward-data product and the backward-weight product do not depend on each other: ONE launch whose
                 # workgroups split between them (hifihr_wino4_bwd_gemm_pair; HIFIHR_GEMM_PAIR=0: two launches)
@@ -1275,8 +1277,11 @@ class _BNActWinoConv(torch.autograd.Function):
                 lib.wino_dw_transform_parts(dU, parts, tgt, K, C, m)
                 dw_box[0] = None if direct_w else tgt
         if PROFILE.on:
-            PROFILE.conv_log.append((("wino", N, H, W, K, C, m), "gemm"))
-            PROFILE.conv_log.append((("wino", N, H, W, C, K, m), "gemm-tn"))
+            if need[5] and m == 4 and _GEMM_PAIR and lib.wino4_bwd_gemm_pair_supported(N, H, W, C, K):
+                PROFILE.conv_log.append((("wino", N, H, W, C, K, m), "gemm-pair"))
+            else:
+                PROFILE.conv_log.append((("wino", N, H, W, K, C, m), "gemm"))
+                PROFILE.conv_log.append((("wino", N, H, W, C, K, m), "gemm-tn"))
         PROFILE.bracket("bn_conv_bwd_wino", run)
         if lazy_in:
             _ZERO_POOL.release(link.red)         # folded and zeroed by the dual transform

@@ -394,6 +394,7 @@ int hifihr_wino_wgrad_gemm_parts_m(const float* v_d, const float* yt_d, float* d
  * with V2 / Yt the two transforms of dy and Vx the forward's transformed input (the layer maps C -> K channels).  Workgroups of one
  * launch split between the two (a short launch of these kernels is shaped by its start and its end); falls back to the two launches
  * for shapes that are not on the row-share kernels.  Results identical to the separate calls. */
+int hifihr_wino4_bwd_gemm_pair_supported(int N, int H, int W, int C, int K);   /* 1: the call below pairs; 0: it makes the two launches */
 int hifihr_wino4_bwd_gemm_pair(const float* V2_d, const float* U2_d, float* M2_d, const float* Vx_d, const float* Yt_d, float* dU_parts_d,
                                int N, int H, int W, int C, int K, int parts, void* stream);
 int hifihr_wino_dw_transform_parts_m(const float* du_parts_d, int parts, float* dw_acc_d, int K, int C, int m, void* stream);
