@@ -309,6 +309,14 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
             add("conv_wino2_kernel", per_step, us, 2.0 * 16 * (N_ * H_ * W_ / 4) * 64 * 64, 4.0 * (2 * N_ * H_ * W_ * 64 + 16 * 64 * 64),
                 f"{direction} N{N_} {H_}x{W_} 64->64 3x3 as F(2x2, 3x3), transforms in registers")
             continue
+        if direction == "c64-pair":            # conv_c64_bwd_pair_kernel: F(2x2) data gradient + direct (9-tap) weight gradient in one launch
+            x = torch.randn(N_, H_, W_, 64, device=dev); U = torch.randn(16 * 64 * 64, device=dev) * 0.05; gy = torch.randn(N_, H_, W_, 64, device=dev)
+            dx = torch.empty(N_, H_, W_, 64, device=dev); dw = torch.zeros(64, 3, 3, 64, device=dev)
+            us = hip_us(lambda: lib.conv3x3_c64_bwd_pair(gy, U, None, dx, x, dw, N_, H_, W_))
+            add("conv_c64_bwd_pair_kernel", per_step, us, 2.0 * 16 * (N_ * H_ * W_ / 4) * 64 * 64 + 2.0 * N_ * H_ * W_ * 64 * 9 * 64,
+                4.0 * (3 * N_ * H_ * W_ * 64 + 16 * 64 * 64 + 9 * 64 * 64),
+                f"N{N_} {H_}x{W_} 64->64 3x3: data gradient as F(2x2, 3x3) + weight gradient (9 taps, pixel reduction), one launch")
+            continue
         OH_, OW_ = (H_ + 2 * pd_ - R_) // st_ + 1, (W_ + 2 * pd_ - S_) // st_ + 1
         x = torch.randn(N_, H_, W_, C_, device=dev); w = torch.randn(K_, R_, S_, C_, device=dev) * 0.05
         y = torch.randn(N_, OH_, OW_, K_, device=dev)

@@ -193,6 +193,8 @@ class HifihrLib:
         c.hifihr_conv3x3_c64_wino_supported.argtypes = [c_int] * 5
         c.hifihr_conv3x3_c64_wino.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_conv3x3_c64_wino_res.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+        c.hifihr_conv3x3_c64_bwd_pair_supported.argtypes = [c_int] * 3
+        c.hifihr_conv3x3_c64_bwd_pair.argtypes = [c_void_p] * 7 + [c_size_t] + [c_int] * 3 + [c_void_p]
         c.hifihr_wino_bn_input_supported.argtypes = [c_int, c_int]
         c.hifihr_wino_bn_input_transform.argtypes = [_c_float_p] * 7 + [c_int] * 5 + [c_float, c_float] + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_wino_output_transform_bnred.argtypes = [_c_float_p] * 10 + [c_int] * 5 + [c_void_p]
@@ -536,6 +538,15 @@ class HifihrLib:
     def conv3x3_c64_wino_res(self, x, U, res, y, N, H, W):
         """conv3x3_c64_wino with y = product + res (backward-data + the gradient of the input's other consumer; include/hifihr.h)."""
         self.check(self.c.hifihr_conv3x3_c64_wino_res(_fp(x), _fp(U), _fp(res), _fp(y), N, H, W, _stream_of(x)), "hifihr_conv3x3_c64_wino_res")
+
+    def conv3x3_c64_bwd_pair_supported(self, N, H, W):
+        return bool(self.c.hifihr_conv3x3_c64_bwd_pair_supported(int(N), int(H), int(W)))
+
+    def conv3x3_c64_bwd_pair(self, dy, U_bwd, res, dx, x, dw, N, H, W, ws=None):
+        """dx = conv3x3_c64_wino[_res](dy, U_bwd[, res]) and dw += conv2d_bwd_weight(x, dy) in ONE launch + the slab sum (include/hifihr.h)."""
+        self.check(self.c.hifihr_conv3x3_c64_bwd_pair(_fp(dy), _fp(U_bwd), _fp(res), _fp(dx), _fp(x), _fp(dw), _fp(ws),
+                                                      0 if ws is None else ws.numel() * ws.element_size(), N, H, W, _stream_of(dy)),
+                   "hifihr_conv3x3_c64_bwd_pair")
 
     def wino_bn_input_supported(self, C, m):
         return bool(self.c.hifihr_wino_bn_input_supported(int(C), int(m)))

@@ -448,17 +448,17 @@ __device__ __forceinline__ float comp(const F4& a, int k) { return k < 2 ? a.lo[
 #endif
 // STATS: the batch-norm statistics epilogue of the forward (24 registers of shifted sums) is compiled in -- the kernel sits at the 256-register
 // limit of its 512-thread workgroup, and backward-data launches do without them
+// (the body, so that conv_c64_bwd_pair_kernel can run it on a SHARE of a launch's workgroups: bid of nblk)
 template <bool EPI, bool STATS>
-__global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a) {
+__device__ __forceinline__ void wino2_body(const Wino2Args& a, float* __restrict__ lds, int bid, int nblk) {
 #if defined(HIFIHR_HALO_STAMP)
   const unsigned long long st_entry = HALO_T();
   unsigned long long st_loop = 0, st_real = 0, st_bar = 0, st_epi = 0, st_vm = 0;
 #endif
-  __shared__ __attribute__((aligned(1024))) float lds[2 * kHalo + 2 * kW2Stage];
   float* const halo = lds;
   float* const wst = lds + 2 * kHalo;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int wg = xcd_remap(bid, nblk);
   const int s_lo = wg * a.per, s_hi = min(s_lo + a.per, a.total);
   if (s_lo >= s_hi) return;                                  // (uniform)
   int ntiles = 0;
@@ -744,6 +744,12 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a)
   }
 }
 
+template <bool EPI, bool STATS>
+__global__ __launch_bounds__(256 + 64 * kNL) void conv_wino2_kernel(Wino2Args a) {
+  __shared__ __attribute__((aligned(1024))) float lds[2 * kHalo + 2 * kW2Stage];
+  wino2_body<EPI, STATS>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Backward-weight of the same layer: dW[k][tap][c] += sum over pixels dy[p][k] x[p + tap][c].
 // The reduction runs over PIXELS, so a workgroup keeps the whole 9 x 64 x 64 gradient in its accumulators (MFMA wave w: the 16 output
@@ -771,10 +777,9 @@ struct HaloWgradArgs {
 };
 }  // namespace
 
-__global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_wgrad_kernel(HaloWgradArgs a) {
-  __shared__ __attribute__((aligned(1024))) float lds[2 * kWgBuf];
+__device__ __forceinline__ void halo_wgrad_body(const HaloWgradArgs& a, float* __restrict__ lds, int bid, int nblk) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int wg = xcd_remap(bid, nblk);
   HaloArgs sh;                                               // (tile_at only reads H, ctiles)
   sh.H = a.H; sh.ctiles = a.ctiles;
   const int s_lo = wg * a.per, s_hi = min(s_lo + a.per, a.total);
@@ -903,6 +908,25 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_wgrad_kernel(HaloWgr
       const int k = 4 * (4 * g + e) + wave;
       *reinterpret_cast<float4*>(slab + ((size_t)tp * 64 + k) * 64 + 4 * r) = make_float4(acc[tp][0][e], acc[tp][1][e], acc[tp][2][e], acc[tp][3][e]);
     }
+}
+
+__global__ __launch_bounds__(256 + 64 * kNL) void conv_halo_wgrad_kernel(HaloWgradArgs a) {
+  __shared__ __attribute__((aligned(1024))) float lds[2 * kWgBuf];
+  halo_wgrad_body(a, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Layer 1's backward has two independent halves per convolution -- the data gradient (conv_wino2_kernel with the transposed filters)
+// and the weight gradient (conv_halo_wgrad_kernel) -- both persistent, both ~30..45 us at the config batch, i.e. short enough that the
+// launch's two ends (ramp-up, and the tail where the last workgroups run alone) are a visible share of each.  ONE launch runs both: the
+// first `ga` workgroups take the data gradient, the others the weight gradient, each with its own share arithmetic (bit-identical to
+// the separate launches of the same share sizes).  Same idea as bgemm_nt_tn_pair_kernel (gemm.hip).
+template <bool EPI>
+__global__ __launch_bounds__(256 + 64 * kNL) void conv_c64_bwd_pair_kernel(Wino2Args d, int ga, HaloWgradArgs w) {
+  constexpr int kPairLds = 2 * kHalo + 2 * kW2Stage > 2 * kWgBuf ? 2 * kHalo + 2 * kW2Stage : 2 * kWgBuf;
+  __shared__ __attribute__((aligned(1024))) float lds[kPairLds];
+  const int b = (int)blockIdx.x;
+  if (b < ga) wino2_body<EPI, false>(d, lds, b, ga);         // (uniform per workgroup)
+  else halo_wgrad_body(w, lds, b - ga, (int)gridDim.x - ga);
 }
 
 // dw[k][tap][c] += sum over the slabs, in a fixed order (bit-reproducible).  A workgroup takes 64 gradient elements; wave w sums slabs
@@ -1514,6 +1538,52 @@ hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias
     if (stats != nullptr) hipLaunchKernelGGL((conv_wino2_kernel<false, true>), dim3(G), dim3(256 + 64 * kNL), 0, st, a);
     else hipLaunchKernelGGL((conv_wino2_kernel<false, false>), dim3(G), dim3(256 + 64 * kNL), 0, st, a);
   }
+  return hipGetLastError();
+}
+
+// Data gradient + weight gradient of one 64 -> 64 3x3 stride-1 layer in ONE launch (conv_c64_bwd_pair_kernel), then the slab reduction.
+//   dx = conv(dy, U_bwd) [+ res]      (launch_conv_wino2's arguments: U_bwd = the Winograd-domain filters of the transposed convolution)
+//   dw += sum_p dy[p] x[p + tap]      (launch_conv_halo_wgrad's)
+// The workgroups are split in proportion to the two kernels' measured times at the config batch (HIFIHR_C64_PAIR_DGRAD_PCT, default 44).
+bool conv_c64_bwd_pair_supported(int N, int H, int W) {
+  static const int on = [] { const char* e = getenv("HIFIHR_C64_PAIR"); return e ? atoi(e) : 1; }();
+  ConvGeom g{};
+  g.N = N; g.IH = H; g.IW = W; g.IC = 64; g.OC = 64; g.R = 3; g.S = 3; g.stride = 1; g.pad = 1; g.OH = H; g.OW = W; g.dgrad = 0; g.batch = 1;
+  return on && conv_wino2_supported(N, H, W, 64, 64) && conv_halo_wgrad_supported(g) && halo_cus() >= 2;
+}
+
+hipError_t launch_conv_c64_bwd_pair(const float* dy, const float* U_bwd, const float* res, float* dx, const float* x, float* dw, float* slabs,
+                                    int N, int H, int W, hipStream_t st) {
+  if (!conv_c64_bwd_pair_supported(N, H, W)) return hipErrorInvalidValue;
+  const float* zeros = conv_halo_zero_page(st);
+  if (zeros == nullptr) return hipErrorNotReady;
+  static const int pct = [] { const char* e = getenv("HIFIHR_C64_PAIR_DGRAD_PCT"); int v = e ? atoi(e) : 44; return v < 5 ? 5 : (v > 95 ? 95 : v); }();
+  const int cus = halo_cus();
+  int ga = (cus * pct + 50) / 100;
+  if (ga < 1) ga = 1;
+  if (ga > cus - 1) ga = cus - 1;
+  int gb = cus - ga;
+  Wino2Args d;
+  d.src = dy; d.U = U_bwd; d.dst = dx; d.stats = nullptr; d.zeros = zeros; d.bias = nullptr; d.relu = 0; d.res = res;
+  d.N = N; d.H = H; d.W = W;
+  d.ctiles = (W + kTW - 1) / kTW;
+  d.total = N * d.ctiles * H;
+  d.per = (d.total + ga - 1) / ga;
+  if (d.per < 4) d.per = 4;
+  d.per = (d.per + 1) & ~1;
+  ga = (d.total + d.per - 1) / d.per;
+  HaloWgradArgs w;
+  w.x = x; w.dy = dy; w.zeros = zeros; w.N = N; w.H = H; w.W = W;
+  w.ctiles = W / kTW;
+  w.total = N * w.ctiles * H;
+  w.per = (w.total + gb - 1) / gb;
+  if (w.per < 4) w.per = 4;
+  gb = (w.total + w.per - 1) / w.per;
+  w.slabs = slabs != nullptr ? slabs : halo_wgrad_scratch(st, (size_t)halo_cus() * kTaps * 64 * 64 * sizeof(float));
+  if (w.slabs == nullptr) return hipErrorNotReady;
+  if (res != nullptr) hipLaunchKernelGGL((conv_c64_bwd_pair_kernel<true>), dim3(ga + gb), dim3(256 + 64 * kNL), 0, st, d, ga, w);
+  else hipLaunchKernelGGL((conv_c64_bwd_pair_kernel<false>), dim3(ga + gb), dim3(256 + 64 * kNL), 0, st, d, ga, w);
+  hipLaunchKernelGGL(conv_halo_wgrad_reduce_kernel, dim3(kTaps * 64 * 64 / 64), dim3(256), 0, st, w.slabs, gb, dw);
   return hipGetLastError();
 }
 

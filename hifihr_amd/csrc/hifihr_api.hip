@@ -1222,6 +1222,19 @@ int hifihr_conv3x3_c64_wino_res(const float* x, const float* u, const float* res
   return HIFIHR_OK;
 }
 
+int hifihr_conv3x3_c64_bwd_pair_supported(int N, int H, int W) { return hifihr::conv_c64_bwd_pair_supported(N, H, W) ? 1 : 0; }
+
+int hifihr_conv3x3_c64_bwd_pair(const float* dy, const float* u_bwd, const float* res, float* dx, const float* x, float* dw, void* ws,
+                                size_t ws_bytes, int N, int H, int W, void* stream) {
+  if (!dy || !u_bwd || !dx || !x || !dw) return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_bwd_pair: null pointer");
+  if (!hifihr::conv_c64_bwd_pair_supported(N, H, W))
+    return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_bwd_pair: unsupported shape (ask hifihr_conv3x3_c64_bwd_pair_supported)");
+  HIP_TRY(hifihr::launch_conv_c64_bwd_pair(dy, u_bwd, res, dx, x, dw,
+                                           (ws && ws_bytes >= hifihr::conv_halo_wgrad_slab_bytes()) ? static_cast<float*>(ws) : nullptr, N, H, W,
+                                           (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_bn_input_supported(int C, int m) { return (m == 4 && hifihr::wino4_bn_supported(C)) ? 1 : 0; }
 
 int hifihr_wino_bn_input_transform(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* out,

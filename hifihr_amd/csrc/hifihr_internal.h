@@ -118,6 +118,11 @@ hipError_t launch_conv_halo_wgrad(const ConvGeom& g, const float* x, const float
 bool conv_wino2_supported(int N, int H, int W, int C, int K);
 hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias_or_null, int relu, float* dst, float* stats_or_null, int N,
                              int H, int W, hipStream_t st, const float* res_or_null = nullptr);
+// data gradient (launch_conv_wino2 with the transposed filters, + res_or_null) and weight gradient (launch_conv_halo_wgrad) of one such layer in
+// ONE launch + the slab reduction (conv_halo.hip: conv_c64_bwd_pair_kernel)
+bool conv_c64_bwd_pair_supported(int N, int H, int W);
+hipError_t launch_conv_c64_bwd_pair(const float* dy, const float* U_bwd, const float* res_or_null, float* dx, const float* x, float* dw,
+                                    float* slabs_or_null, int N, int H, int W, hipStream_t st);
 hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, const float* bias_or_null, float* dst, float* stats,
                             const float* zeros, hipStream_t st);
 // batch-norm (+ residual add + ReLU) on NHWC activations, x[M][C].  Statistics buffers are [kStatSlots][2][C]: partial

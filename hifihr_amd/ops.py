@@ -434,6 +434,8 @@ class side_branch:
 
 _BRANCHES = os.environ.get("HIFIHR_BRANCHES", "1") != "0"
 _GEMM_PAIR = os.environ.get("HIFIHR_GEMM_PAIR", "1") != "0"
+# the same for the 64 -> 64 layers (ResNet layer 1): Winograd F(2x2) data gradient + pixel-reduction weight gradient in one launch
+_C64_PAIR = os.environ.get("HIFIHR_C64_PAIR", "1") != "0"
 BRANCH_STREAMS = set() # raw handles of side streams that run convolutions BESIDE the main stream (models.Model's light branch)
 _CONV_WS = {}          # (device, branch stream or 0) -> zero-initialised, self-cleaning workspace of the balanced convolution schedule
 _CONV_WS_BYTES = {}    # (geometry, direction) -> bytes the library wants for it
@@ -851,6 +853,7 @@ class _Conv2dMFMA(torch.autograd.Function):
             return (g_fork,) + (None,) * 9
         gy = gy.contiguous(memory_format=_CL)
         dx = dw = db_ret = Yt_done = pair_done = None
+        c64_pair_done = False
         if ctx.relu or ctx.b_param is not None:
             # conv + bias (+ ReLU) epilogue: masked gradient and the bias gradient in one small launch
             b = ctx.b_param
@@ -902,9 +905,26 @@ class _Conv2dMFMA(torch.autograd.Function):
             # 64 -> 64: the same one-launch Winograd kernel on dy with U' (kind 2: transposed, rotated filter)
             dx = torch.empty_like(x, memory_format=_CL)
             U2 = _WEIGHT_PREP.get(ctx.w_param, wk, 2)
-            if PROFILE.on:
+            if ctx.needs_input_grad[1] and v_saved is None and _C64_PAIR and lib.conv3x3_c64_bwd_pair_supported(N, H, W):
+                # both gradients wanted: the data gradient and the pixel-reduction weight gradient share ONE launch (csrc/conv_halo.hip
+                # conv_c64_bwd_pair_kernel; on this stream also when weight gradients otherwise go to the side stream)
+                w = ctx.w_param
+                tgt = w.grad if (getattr(w, "_hifihr_direct_grad", False) and w.grad is not None
+                                 and w.grad.is_contiguous(memory_format=_CL)) else None
+                if tgt is None:
+                    dw = torch.zeros_like(wk, memory_format=_CL)
+                    tgt = dw
+                if PROFILE.on:
+                    PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "c64-pair"))
+                nslab = lib.conv2d_wgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad)
+                slabs = _wgrad_slabs(gy.device, nslab) if nslab else None
+                PROFILE.bracket("conv_dgrad", lambda: lib.conv3x3_c64_bwd_pair(gy, U2, g_fork, dx, x, tgt, N, H, W, ws=slabs))
+                c64_pair_done = True
+            elif PROFILE.on:
                 PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "dgrad-wino2"))
-            if g_fork is not None:
+            if c64_pair_done:
+                pass
+            elif g_fork is not None:
                 PROFILE.bracket("conv_dgrad", lambda: lib.conv3x3_c64_wino_res(gy, U2, g_fork, dx, N, H, W))
             else:
                 PROFILE.bracket("conv_dgrad", lambda: lib.conv3x3_c64_wino(gy, U2, None, False, dx, None, N, H, W))
@@ -929,6 +949,9 @@ class _Conv2dMFMA(torch.autograd.Function):
             dx = dxm
         if ctx.needs_input_grad[1] and ctx.w3 is not None:
             dw = _stem_c3_wgrad(lib, ctx, x, gy)
+        elif c64_pair_done:
+            if dw is None:
+                _grad_ready(ctx.w_param)
         elif ctx.needs_input_grad[1]:
             w = ctx.w_param
             tgt = w.grad if (getattr(w, "_hifihr_direct_grad", False) and w.grad is not None

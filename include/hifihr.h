@@ -352,6 +352,17 @@ int hifihr_conv3x3_c64_wino(const float* x_d, const float* u_d, const float* bia
  * identity branch of a residual block (reference torchvision BasicBlock: `out += identity`, network/res_encoder.py:364-373): autograd adds
  * the two gradients of that input in an elementwise pass of its own; here the other consumer's gradient is added where this one is produced. */
 int hifihr_conv3x3_c64_wino_res(const float* x_d, const float* u_d, const float* res_d, float* y_d, int N, int H, int W, void* stream);
+/* Both gradients of one such layer in ONE launch (round 5): dx_d = hifihr_conv3x3_c64_wino[_res](dy_d, u_bwd_d [, res_d or NULL]) -- u_bwd_d the
+ * Winograd-domain filters of the transposed convolution (hifihr_weight_prep kind 2) -- and dw_d[64][3][3][64] += the weight gradient of
+ * hifihr_conv2d_bwd_weight(x_d, dy_d) (the pixel-reduction slab kernel + its fixed-order slab sum).  The two halves are independent,
+ * ~50 and ~65 us at the config batch: separately each pays its own ramp-up and tail, here the workgroups of one launch are split between
+ * them.  Results are those of the separate calls up to the summation order over workgroup shares (the weight gradient stays
+ * bit-reproducible run to run).  ws_d: scratch of hifihr_conv2d_bwd_weight_ws_bytes or NULL (library-owned).  Replaces, for ResNet layer 1
+ * (reference utils/Freihand_GNN_mano/network/resnet.py BasicBlock convs at 56 x 56 x 64), the pair of autograd nodes
+ * cudnn_convolution_backward_input / _weight. */
+int hifihr_conv3x3_c64_bwd_pair_supported(int N, int H, int W);
+int hifihr_conv3x3_c64_bwd_pair(const float* dy_d, const float* u_bwd_d, const float* res_d /* or NULL */, float* dx_d, const float* x_d,
+                                float* dw_d, void* ws_d, size_t ws_bytes, int N, int H, int W, void* stream);
 /* Batch-norm fused into the F(4x4, 3x3) input transform (round 3, csrc/wino4_bn.hip).  For a BatchNorm2d whose consumer is a Winograd
  * convolution (reference BasicBlock: conv1 -> bn1 -> relu -> conv2; bn2 -> += identity -> relu -> the next block's conv1,
  * network/res_encoder.py:364-373 + vendored utils/Freihand_GNN_mano/network/resnet.py) this ONE launch replaces hifihr_bn_act_fwd followed by

@@ -1017,6 +1017,49 @@ def conv_wino2_case(lib, device, N, H, W, seed=0, bias_relu=False, rtol=2e-5):
         assert err <= rtol * float(refx.abs().max()) + 1e-6, f"wino2 conv bwd data: {err}"
 
 
+def conv_c64_bwd_pair_case(lib, device, N, H, W, seed=0, with_res=False):
+    """hifihr_conv3x3_c64_bwd_pair (conv_c64_bwd_pair_kernel: data gradient + weight gradient of a 64 -> 64 3x3 layer in one launch) vs the two
+    separate calls it replaces: dx bit for bit (every output element is computed the same way whatever the workgroup's share), dw within
+    the summation-order difference of the slab split and equal to itself on a second launch; both vs F.conv2d's gradients."""
+    import torch.nn.functional as F
+    assert lib.conv3x3_c64_bwd_pair_supported(N, H, W)
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, 64, H, W, generator=gen) + 0.5
+    w = torch.randn(64, 64, 3, 3, generator=gen) / 24.0
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    z = F.conv2d(xr, wr, None, padding=1)
+    gy = torch.randn(z.shape, generator=gen)
+    z.backward(gy)
+    res = torch.randn(N, H, W, 64, generator=gen) if with_res else None
+    d = lambda t: t.to(device).contiguous()
+    U2 = torch.empty(16 * 64 * 64, device=device)
+    lib.wino_weight_transform(d(w.permute(1, 2, 3, 0)), U2, 64, 64, 1)
+    x_d, gy_d = d(x.permute(0, 2, 3, 1)), d(gy.permute(0, 2, 3, 1))
+    res_d = d(res) if with_res else None
+    dx0 = torch.full((N, H, W, 64), 7.0, device=device)
+    if with_res:
+        lib.conv3x3_c64_wino_res(gy_d, U2, res_d, dx0, N, H, W)
+    else:
+        lib.conv3x3_c64_wino(gy_d, U2, None, False, dx0, None, N, H, W)
+    dw0 = torch.full((64, 3, 3, 64), 0.25, device=device)
+    lib.conv2d_bwd_weight(x_d, gy_d, dw0, N, H, W, 64, 64, 3, 3, 1, 1)
+    outs = []
+    for _ in range(2):
+        dx = torch.full((N, H, W, 64), 7.0, device=device); dw = torch.full((64, 3, 3, 64), 0.25, device=device)
+        lib.conv3x3_c64_bwd_pair(gy_d, U2, res_d, dx, x_d, dw, N, H, W)
+        outs.append((dx, dw))
+    assert torch.equal(outs[0][0], dx0), "pair: dx differs from the separate launch"
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "pair: not bit-reproducible"
+    refw = wr.grad.permute(0, 2, 3, 1)
+    err = float((outs[0][1].cpu() - 0.25 - refw).abs().max())
+    assert err <= 2e-4 * float(refw.abs().max()) + 1e-6, f"pair: dw vs torch {err}"
+    err0 = float((outs[0][1] - dw0).abs().max())
+    assert err0 <= 2e-5 * float(refw.abs().max()) + 1e-6, f"pair: dw vs the separate launch {err0}"
+    refx = xr.grad.permute(0, 2, 3, 1) + (res if with_res else 0.0)
+    err = float((outs[0][0].cpu() - refx).abs().max())
+    assert err <= 2e-5 * float(refx.abs().max()) + 1e-6, f"pair: dx vs torch {err}"
+
+
 def conv_bias_relu_case(lib, device, N, H, W, C, K, R, stride, seed=0, pad=0):
     """conv + bias + ReLU in one launch (act = 1) and its backward prologue bias_relu_bwd, vs torch."""
     import torch.nn.functional as F

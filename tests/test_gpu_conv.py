@@ -506,6 +506,12 @@ def test_conv_wino2_bias_relu_epilogue(lib):
     kc.conv_wino2_case(lib, "cuda", 2, 28, 28, seed=3, bias_relu=True)
 
 
+@pytest.mark.parametrize("N,H,W,res", [(32, 56, 56, True), (32, 56, 56, False), (5, 28, 42, False), (1, 6, 14, True)])
+def test_conv_c64_bwd_pair_equals_the_separate_launches(lib, N, H, W, res):
+    """ResNet layer 1's backward at the config batch (and ragged shares): data gradient + weight gradient in one launch."""
+    kc.conv_c64_bwd_pair_case(lib, "cuda", N, H, W, seed=N + W, with_res=res)
+
+
 @pytest.mark.parametrize("B,H,W", [(32, 56, 56), (5, 28, 42)])
 def test_halo_kernels_are_bit_reproducible(lib, B, H, W):
     """conv_halo_kernel / conv_halo_wgrad_kernel hold no atomics on their outputs: repeated launches on the same inputs agree bit for bit

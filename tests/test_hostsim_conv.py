@@ -80,6 +80,12 @@ def test_conv_wino2_layer1_shape(hostsim_lib, N, H, W):
     kc.conv_wino2_case(hostsim_lib, "cpu", N, H, W, seed=H + W)
 
 
+@pytest.mark.parametrize("N,H,W,res", [(2, 10, 14, False), (3, 8, 28, True)])
+def test_conv_c64_bwd_pair(hostsim_lib, N, H, W, res):
+    """conv_c64_bwd_pair_kernel: both bodies in one launch, on the emulator's (small) CU count."""
+    kc.conv_c64_bwd_pair_case(hostsim_lib, "cpu", N, H, W, seed=N + H, with_res=res)
+
+
 def test_conv_wino2_bias_relu_epilogue(hostsim_lib):
     kc.conv_wino2_case(hostsim_lib, "cpu", 2, 10, 14, seed=3, bias_relu=True)
 

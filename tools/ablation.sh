@@ -31,4 +31,6 @@ run "light estimator on the main stream, no side branch (HIFIHR_LIGHT_BRANCH=0)"
 run "geometry loss terms on a side branch too (HIFIHR_GEOM_BRANCH=1)" HIFIHR_GEOM_BRANCH=1
 run "MANO layer / joint regression as separate autograd nodes (HIFIHR_MANO_FUSED=0)" HIFIHR_MANO_FUSED=0
 run "batched TN products with short reductions on the per-tile kernels (HIFIHR_GEMM_TN_SPLIT=0)" HIFIHR_GEMM_TN_SPLIT=0
+run "F(4x4) backward-data and backward-weight products as two launches (HIFIHR_GEMM_PAIR=0)" HIFIHR_GEMM_PAIR=0
+run "layer 1 data gradient and weight gradient as two launches (HIFIHR_C64_PAIR=0)" HIFIHR_C64_PAIR=0
 run "eager launches, no hipGraph (--graph 0)" --graph 0
