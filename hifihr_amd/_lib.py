@@ -236,6 +236,9 @@ class HifihrLib:
         c.hifihr_wino_output_transform_mask_m.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_adam_step.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
                                        c_float, c_float, c_float, c_int, c_void_p]
+        c.hifihr_adam_state_bytes.restype = c_size_t
+        c.hifihr_adam_state_bytes.argtypes = []
+        c.hifihr_adam_step_counted.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float, c_void_p, c_void_p]
         c.hifihr_adam_step_dyn.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
                                            c_float, c_float, _c_float_p, c_void_p]
         c.hifihr_renderer_destroy.argtypes = [c_void_p]
@@ -612,14 +615,14 @@ class HifihrLib:
         if root_id is None:
             self.check(self.c.hifihr_freihand_batch(vp(img_rgbx), vp(mask), _fp(Ks), _fp(joints), _fp(verts), _fp(scales), J, V, _ip(packed), B, H, W,
                                                     _fp(g("imgs")), _fp(g("masks")), vp(g("segms_gt")), _fp(g("Ks")), _fp(g("Ps")), _fp(g("joints")),
-                                                    _fp(g("verts")), _fp(g("j2d_gt")), _fp(g("scales")), vp(g("idxs")), _stream_of(packed)),
+                                                    _fp(g("verts")), _fp(g("j2d_gt")), _fp(g("scales")), vp(g("idxs")), _stream_of(img_rgbx)),
                        "hifihr_freihand_batch")
             return
         # + the terms every training iteration derives from the batch: root_xyz, root-relative ground truth, the NDC camera
         self.check(self.c.hifihr_freihand_batch_step(vp(img_rgbx), vp(mask), _fp(Ks), _fp(joints), _fp(verts), _fp(scales), J, V, _ip(packed), B, H, W,
                                                      _fp(g("imgs")), _fp(g("masks")), vp(g("segms_gt")), _fp(g("Ks")), _fp(g("Ps")), _fp(g("joints")),
                                                      _fp(g("verts")), _fp(g("j2d_gt")), _fp(g("scales")), vp(g("idxs")), int(root_id), float(image_size or H),
-                                                     _fp(g("root_xyz")), _fp(g("joints_rel")), _fp(g("verts_rel")), _fp(g("cam_ndc")), _stream_of(packed)),
+                                                     _fp(g("root_xyz")), _fp(g("joints_rel")), _fp(g("verts_rel")), _fp(g("cam_ndc")), _stream_of(img_rgbx)),
                    "hifihr_freihand_batch_step")
 
     def ho3d_workspace_bytes(self, B, out_size):
@@ -634,7 +637,7 @@ class HifihrLib:
             assert t.is_contiguous() and t.dtype == torch.float32
         self.check(self.c.hifihr_ho3d_batch(vp(img_rgbx), vp(hand_mask), _fp(Ks), _fp(uv21), _fp(xyz21), FH, FW, _ip(packed), B, out_size,
                                             vp(ws), c_size_t(ws.numel() * ws.element_size()), _fp(g("img_crop")), _fp(g("hand_mask_crop")),
-                                            _fp(g("K_crop")), _fp(g("uv21_crop")), _fp(g("xyz21")), _stream_of(packed)), "hifihr_ho3d_batch")
+                                            _fp(g("K_crop")), _fp(g("uv21_crop")), _fp(g("xyz21")), _stream_of(img_rgbx)), "hifihr_ho3d_batch")
 
     def freihand_augment(self, img_rgbx, mask, idx, coef_fix, out_img, out_mask):
         """img_rgbx int32/uint8x4 [n,H,W], mask uint8 [n,H,W] (either None with its output), idx int32 [B], coef_fix int32 [B,6]."""
@@ -874,6 +877,21 @@ class HifihrLib:
         self.check(self.c.hifihr_adam_step(_fp(p), _fp(g), _fp(m), _fp(v), c_size_t(n), c_float(grad_scale), c_float(lr),
                                            c_float(beta1), c_float(beta2), c_float(eps), c_float(weight_decay), int(step),
                                            _stream_of(p)), "hifihr_adam_step")
+
+    @staticmethod
+    def adam_state_image(lr, beta1, beta2, step):
+        """The 48 bytes of hifihr_adam_step_counted's state (include/hifihr.h) as a uint8 CPU tensor:
+        f64 lr, beta1, beta2, beta1^step, beta2^step, i32 step, i32 0."""
+        import struct
+        b1, b2 = float(beta1), float(beta2)
+        return torch.frombuffer(bytearray(struct.pack("<dddddii", float(lr), b1, b2, b1 ** int(step), b2 ** int(step), int(step), 0)),
+                                dtype=torch.uint8).clone()
+
+    def adam_step_counted(self, p, g, m, v, grad_scale, eps, weight_decay, state):
+        n = p.numel()
+        assert state.dtype == torch.uint8 and state.numel() == int(self.c.hifihr_adam_state_bytes()) and state.device == p.device
+        self.check(self.c.hifihr_adam_step_counted(_fp(p), _fp(g), _fp(m), _fp(v), c_size_t(n), c_float(grad_scale), c_float(eps),
+                                                   c_float(weight_decay), c_void_p(state.data_ptr()), _stream_of(p)), "hifihr_adam_step_counted")
 
     def adam_step_dyn(self, p, g, m, v, grad_scale, beta1, beta2, eps, weight_decay, dyn):
         n = p.numel()

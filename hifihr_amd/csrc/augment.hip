@@ -48,6 +48,69 @@ __global__ __launch_bounds__(256) void freihand_augment_kernel(const uint32_t* _
     out_segm[(size_t)b * plane + p] = ((in ? mask[src] : (uint8_t)0) >= 128) ? 1ll : 0ll;
 }
 
+// The same, four consecutive pixels of a row per thread (W % 4 == 0, 16-byte aligned planes): the outputs are seven planes of 4 (8) bytes
+// per pixel -- one float4 (two longlong2) store per plane instead of four scalar ones (round 5; DESIGN.md section 0 has the times;
+// the arithmetic per pixel is the scalar kernel's).
+__global__ __launch_bounds__(256) void freihand_augment4_kernel(const uint32_t* __restrict__ img, const uint8_t* __restrict__ mask,
+                                                               const int* __restrict__ idx, const int* __restrict__ coef, int H, int W,
+                                                               float* __restrict__ out_img, float* __restrict__ out_mask,
+                                                               long long* __restrict__ out_segm) {
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;            // group of four pixels
+  const int W4 = W >> 2;
+  if (q >= H * W4) return;
+  const int y = q / W4, x0 = (q - y * W4) << 2;
+  const int* c = coef + b * 6;
+  const int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+  const size_t base = (size_t)idx[b] * H;
+  const size_t plane = (size_t)H * W;
+  const int p = y * W + x0;
+  uint32_t v[4];
+  uint8_t mk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int x = x0 + i;
+    const int xin = (c2 + x * c0 + y * c1) >> 16;
+    const int yin = (c5 + x * c3 + y * c4) >> 16;
+    const bool in = xin >= 0 && xin < W && yin >= 0 && yin < H;
+    const size_t src = (base + (in ? yin : 0)) * W + (in ? xin : 0);
+    v[i] = (out_img != nullptr && in) ? img[src] : 0u;
+    mk[i] = ((out_mask != nullptr || out_segm != nullptr) && in) ? mask[src] : (uint8_t)0;
+  }
+  if (out_img != nullptr) {
+    float* o = out_img + (size_t)b * 3 * plane + p;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      *reinterpret_cast<float4*>(o + ch * plane) = make_float4((float)((v[0] >> (8 * ch)) & 0xffu) / 255.0f, (float)((v[1] >> (8 * ch)) & 0xffu) / 255.0f,
+                                                               (float)((v[2] >> (8 * ch)) & 0xffu) / 255.0f, (float)((v[3] >> (8 * ch)) & 0xffu) / 255.0f);
+  }
+  if (out_mask != nullptr) {
+    const float4 m = make_float4(mk[0] >= 128 ? 1.0f : 0.0f, mk[1] >= 128 ? 1.0f : 0.0f, mk[2] >= 128 ? 1.0f : 0.0f, mk[3] >= 128 ? 1.0f : 0.0f);
+    float* o = out_mask + (size_t)b * 3 * plane + p;
+    *reinterpret_cast<float4*>(o) = m;
+    *reinterpret_cast<float4*>(o + plane) = m;
+    *reinterpret_cast<float4*>(o + 2 * plane) = m;
+  }
+  if (out_segm != nullptr) {
+    struct alignas(16) Pair { long long a, b; };               // one 16-byte store
+    Pair* o = reinterpret_cast<Pair*>(out_segm + (size_t)b * plane + p);
+    o[0] = Pair{mk[0] >= 128 ? 1ll : 0ll, mk[1] >= 128 ? 1ll : 0ll};
+    o[1] = Pair{mk[2] >= 128 ? 1ll : 0ll, mk[3] >= 128 ? 1ll : 0ll};
+  }
+}
+
+static void launch_augment_planes(const uint32_t* img, const uint8_t* mask, const int* idx, const int* coef, int B, int H, int W, float* out_img,
+                                  float* out_mask, long long* out_segm, hipStream_t st) {
+  static const int vec = [] { const char* e = getenv("HIFIHR_AUGMENT_VEC4"); return e ? atoi(e) : 1; }();
+  const bool aligned = ((reinterpret_cast<uintptr_t>(out_img) | reinterpret_cast<uintptr_t>(out_mask) | reinterpret_cast<uintptr_t>(out_segm)) & 15) == 0;
+  if (vec && W % 4 == 0 && aligned)
+    hipLaunchKernelGGL(freihand_augment4_kernel, dim3((H * (W / 4) + 255) / 256, B), dim3(256), 0, st, img, mask, idx, coef, H, W, out_img, out_mask,
+                       out_segm);
+  else
+    hipLaunchKernelGGL(freihand_augment_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, img, mask, idx, coef, H, W, out_img, out_mask,
+                       out_segm);
+}
+
 // Everything else a FreiHAND training batch holds (reference data/dataset.py:256-275 per sample + utils/traineval_util.py:21-111
 // data_dic per batch), one workgroup per sample:
 //   Ks     = post_rot_trans . K[idx]                          (:258-260)
@@ -311,8 +374,7 @@ size_t ho3d_workspace_bytes(int B, int out_size) { return (size_t)B * 4 * out_si
 hipError_t launch_freihand_augment(const uint32_t* img, const uint8_t* mask, const int* idx, const int* coef, int B, int H, int W,
                                    float* out_img, float* out_mask, hipStream_t st) {
   if (B <= 0 || H <= 0 || W <= 0 || (long)H * W >= (1L << 24)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(freihand_augment_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, img, mask, idx, coef, H, W, out_img, out_mask,
-                     (long long*)nullptr);
+  launch_augment_planes(img, mask, idx, coef, B, H, W, out_img, out_mask, nullptr, st);
   return hipGetLastError();
 }
 
@@ -321,8 +383,7 @@ hipError_t launch_freihand_batch(const uint32_t* img, const uint8_t* mask, const
                                  long long* out_segm, float* oKs, float* oPs, float* ojoints, float* overts, float* oj2d, float* oscales,
                                  long long* oidx, const BatchStepOut& step, hipStream_t st) {
   if (B <= 0 || H <= 0 || W <= 0 || (long)H * W >= (1L << 24) || J < 0 || V < 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(freihand_augment_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, img, mask, packed, packed + B, H, W, out_img,
-                     out_mask, out_segm);
+  launch_augment_planes(img, mask, packed, packed + B, B, H, W, out_img, out_mask, out_segm, st);
   const BatchMeta m{Ks, joints, verts, scales, packed, B, J, V, oKs, oPs, ojoints, overts, oj2d, oscales, oidx, step};
   hipLaunchKernelGGL(freihand_batch_meta_kernel, dim3(B), dim3(256), 0, st, m);
   return hipGetLastError();

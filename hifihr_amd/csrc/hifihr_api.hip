@@ -412,6 +412,17 @@ int hifihr_adam_step(float* params, const float* grads, float* exp_avg, float* e
   return HIFIHR_OK;
 }
 
+size_t hifihr_adam_state_bytes(void) { return hifihr::adam_state_bytes(); }
+
+int hifihr_adam_step_counted(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float grad_scale, float eps,
+                             float weight_decay, void* state_d, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !state_d) return fail(HIFIHR_EINVAL, "hifihr_adam_step_counted: bad argument");
+  if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) || ((uintptr_t)state_d & 7))
+    return fail(HIFIHR_EINVAL, "hifihr_adam_step_counted: buffers must be 16-byte aligned (the state: 8)");
+  HIP_TRY(hifihr::launch_adam_counted(params, grads, exp_avg, exp_avg_sq, n, grad_scale, eps, weight_decay, state_d, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_adam_step_dyn(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float grad_scale,
                          float beta1, float beta2, float eps, float weight_decay, const float* dyn_d, void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !dyn_d) return fail(HIFIHR_EINVAL, "hifihr_adam_step_dyn: bad argument");

@@ -437,6 +437,9 @@ hipError_t launch_wino4_dw_transform_parts(const float* dU_parts, int parts, flo
 
 hipError_t launch_texpca_fwd(const float* coef, const float* basis, const float* mean, int B, int K, long n, float* out, hipStream_t st);
 hipError_t launch_texpca_bwd(const float* g, const float* basis, int B, int K, long n, float* dcoef_zeroed, hipStream_t st);
+size_t adam_state_bytes();
+hipError_t launch_adam_counted(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float eps, float weight_decay,
+                               void* state, hipStream_t st);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float grad_scale, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, const float* dyn, hipStream_t st);
 

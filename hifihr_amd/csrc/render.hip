@@ -38,9 +38,15 @@ __global__ __launch_bounds__(256) void render_vertex_kernel(RenderDev r, const f
                                                            const float* __restrict__ cam, float4* __restrict__ vndc,
                                                            float4* __restrict__ vpos, float4* __restrict__ vnrm,
                                                            float4* __restrict__ vcol, int* __restrict__ tile_cnt, int ntiles,
-                                                           int* __restrict__ qctl) {
+                                                           int* __restrict__ qctl, float* __restrict__ gvrec, float* __restrict__ glrec) {
   const int b = blockIdx.y;
   const int v = blockIdx.x * 256 + threadIdx.x;
+  // the backward's accumulators start at zero (render_common.h: render_ws_mark_clean)
+  if (blockIdx.x == 0 && threadIdx.x < 3) { glrec[3 * b + threadIdx.x] = 0.f; glrec[3 * (gridDim.y + b) + threadIdx.x] = 0.f; }
+  if (v < r.V) {
+    float4* g4 = reinterpret_cast<float4*>(gvrec + ((size_t)b * r.V + v) * 12);
+    g4[0] = g4[1] = g4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (qctl != nullptr && blockIdx.x == 0) {                  // render_fwd3_kernel's class counts; this image's arrival counter
     if (b == 0 && threadIdx.x < 64) qctl[threadIdx.x] = 0;
     if (threadIdx.x == 64) qctl[64 + b] = 0;
@@ -946,6 +952,23 @@ __global__ __launch_bounds__(kF2Threads) void render_fwd3_kernel(RenderDev r, co
 // ------------------------------------------------------------------------------------------------
 // workspace: four float4[B][V] vertex arrays, the float[B][V][12] gradient records of the backward, then the forward's per-tile face
 // lists: int cnt[B][tiles^2] and int list[B][tiles^2][F] (worst case: the whole mesh inside one tile)
+namespace {
+struct WsClean { void* ws; bool clean; };
+WsClean g_ws_clean[32] = {};
+int g_ws_clean_next = 0;
+}  // namespace
+void render_ws_mark_clean(void* ws, bool clean) {
+  for (auto& e : g_ws_clean)
+    if (e.ws == ws) { e.clean = clean; return; }
+  g_ws_clean[g_ws_clean_next] = WsClean{ws, clean};           // (round robin: an evicted workspace just gets its memsets back)
+  g_ws_clean_next = (g_ws_clean_next + 1) % 32;
+}
+bool render_ws_take_clean(void* ws) {
+  for (auto& e : g_ws_clean)
+    if (e.ws == ws) { const bool c = e.clean; e.clean = false; return c; }
+  return false;
+}
+
 size_t render_workspace_bytes(const RenderDev& r, int B) {
   return vertex_part_bytes(r, B) + list_part_bytes(r, B) + (size_t)B * r.F * kFaceRec * sizeof(float4) + f3_part_bytes(r, B);
 }
@@ -984,7 +1007,8 @@ hipError_t launch_render_fwd(const RenderDev& r, const float* verts, const float
   const bool f3 = use3 != 0 && f3_supported(r, B);
   const F3Ws w3 = f3_carve(r, B, ws);
   hipLaunchKernelGGL(render_vertex_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, vcolors, vcol_bstride, cam,
-                     vndc, vpos, vnrm, vcol, tile_cnt, tiles * tiles, f3 ? w3.ctl : nullptr);
+                     vndc, vpos, vnrm, vcol, tile_cnt, tiles * tiles, f3 ? w3.ctl : nullptr, gvrec, light_records(r, B, ws));
+  render_ws_mark_clean(ws, true);
   const dim3 bgrid((r.F + kBinFaces - 1) / kBinFaces, B);
   static const int xm = [] { const char* e = getenv("HIFIHR_RENDER_XCD"); return e ? atoi(e) : 0; }();      // A/B: images pinned to XCDs
   const dim3 grid1((unsigned)((xm ? 8 * ((B + 7) / 8) : B) * tiles * tiles));

@@ -344,9 +344,15 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
 __global__ __launch_bounds__(256) void render_vertex_bwd_kernel(RenderDev r, const float* __restrict__ verts,
                                                                const float* __restrict__ cam, const float4* __restrict__ vndc,
                                                                const float4* __restrict__ vnrm, const float* __restrict__ gvrec,
-                                                               float* __restrict__ gverts, float* __restrict__ gvcolors) {
+                                                               float* __restrict__ gverts, float* __restrict__ gvcolors,
+                                                               const float* __restrict__ glrec, float* __restrict__ glight_color,
+                                                               float* __restrict__ glight_dir) {
   const int b = blockIdx.y;
   const int v = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 3) {                  // the light gradients leave the workspace's accumulators
+    glight_color[3 * b + threadIdx.x] = glrec[3 * b + threadIdx.x];
+    glight_dir[3 * b + threadIdx.x] = glrec[3 * (gridDim.y + b) + threadIdx.x];
+  }
   if (v >= r.V) return;
   const size_t vo = (size_t)b * r.V;
   const float* vb = verts + vo * 3;
@@ -402,13 +408,13 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
   float* gvrec;
   carve(r, B, ws, &vndc, &vpos, &vnrm, &vcol, &gvrec);
   (void)vpos; (void)vcol;
-  hipError_t e = hipMemsetAsync(gvrec, 0, (size_t)B * r.V * 12 * sizeof(float), st);
-  if (e != hipSuccess) return e;
-  if (glight_dir == glight_color + (size_t)B * 3) {           // adjacent (hifihr_amd/ops.py allocates them as one tensor): one fill
-    if ((e = hipMemsetAsync(glight_color, 0, (size_t)B * 6 * sizeof(float), st)) != hipSuccess) return e;
-  } else {
-    if ((e = hipMemsetAsync(glight_color, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(glight_dir, 0, (size_t)B * 3 * sizeof(float), st)) != hipSuccess) return e;
+  // the tile kernel accumulates (atomics) into the gradient records and into light accumulators [B][3] + [B][3] in the workspace; the forward's
+  // vertex kernel left both zeroed unless this is a second backward after one forward (render_common.h: render_ws_mark_clean)
+  float* const glrec = light_records(r, B, ws);
+  if (!render_ws_take_clean(ws)) {
+    hipError_t e = hipMemsetAsync(gvrec, 0, (size_t)B * r.V * 12 * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(glrec, 0, (size_t)B * 6 * sizeof(float), st)) != hipSuccess) return e;
   }
   const int tiles = (r.H + kTile - 1) / kTile;
   const dim3 grid(tiles, tiles, B);
@@ -416,7 +422,7 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
   const TexUvDev td = uv != nullptr ? TexUvDev{uv->faces_uvs, uv->verts_uvs, uv->maps, uv->gmaps, uv->TH, uv->TW} : TexUvDev{};
 #define HIFIHR_RENDER_BWD(AA_, UV_)                                                                                                      \
   hipLaunchKernelGGL((render_bwd_kernel<AA_, UV_>), grid, dim3(256), 0, st, r, frec, light_color, light_dir, face_id, grad_rgba, gvrec,   \
-                     glight_color, glight_dir, td)
+                     glrec, glrec + (size_t)3 * B, td)
   switch (r.aa) {
     case 1: if (uv != nullptr) { HIFIHR_RENDER_BWD(1, true); } else { HIFIHR_RENDER_BWD(1, false); } break;
     case 2: if (uv != nullptr) { HIFIHR_RENDER_BWD(2, true); } else { HIFIHR_RENDER_BWD(2, false); } break;
@@ -424,7 +430,8 @@ hipError_t launch_render_bwd(const RenderDev& r, const float* verts, const float
     default: return hipErrorInvalidValue;
   }
 #undef HIFIHR_RENDER_BWD
-  hipLaunchKernelGGL(render_vertex_bwd_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, cam, vndc, vnrm, gvrec, gverts, gvcolors);
+  hipLaunchKernelGGL(render_vertex_bwd_kernel, dim3((r.V + 255) / 256, B), dim3(256), 0, st, r, verts, cam, vndc, vnrm, gvrec, gverts, gvcolors,
+                     glrec, glight_color, glight_dir);
   return hipGetLastError();
 }
 

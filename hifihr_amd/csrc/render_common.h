@@ -104,7 +104,18 @@ __device__ __forceinline__ void uv_fetch(const TexUvDev& t, int b, const UvSampl
 // workspace: four float4[B][V] vertex arrays, the float[B][V][12] gradient records of the backward, the forward's per-tile face lists
 // int cnt[B][tiles^2] and int list[B][tiles^2][F] (worst case: the whole mesh inside one tile; sized for the 8-pixel grid), then the
 // packed face records float4[B][F][kFaceRec] (written by render_bin_kernel, read by both tile kernels)
-static inline size_t vertex_part_bytes(const RenderDev& r, int B) { return (size_t)B * r.V * (4 * sizeof(float4) + 12 * sizeof(float)); }
+// (+ 8 floats per image behind the gradient records: the backward's light-colour / light-direction accumulators [B][3] + [B][3])
+static inline size_t vertex_part_bytes(const RenderDev& r, int B) {
+  return (size_t)B * r.V * (4 * sizeof(float4) + 12 * sizeof(float)) + (size_t)B * 8 * sizeof(float);
+}
+static inline float* light_records(const RenderDev& r, int B, void* ws) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)B * r.V * (4 * sizeof(float4) + 12 * sizeof(float)));
+}
+// The backward ACCUMULATES into the gradient records and the light accumulators (atomics): they must start at zero.  The forward's vertex
+// kernel zeroes them (every backward follows a forward on the same workspace: the face records it reads are the forward's), and says so
+// here; a backward that finds its workspace not marked -- a second backward after one forward -- clears them itself (two memsets).
+void render_ws_mark_clean(void* ws, bool clean);
+bool render_ws_take_clean(void* ws);
 
 static inline int render_tile() {                // tile edge of the forward (8: see render_fwd2_kernel; HIFIHR_RENDER_TILE=16 for the A/B)
   static const int v = [] { const char* e = getenv("HIFIHR_RENDER_TILE"); return (e && atoi(e) == 16) ? 16 : 8; }();

@@ -18,7 +18,12 @@ import math
 import numpy as np
 import torch
 
+import os
+
 from ._lib import get_lib, require_cuda
+
+# 1: the batch kernels read their per-sample parameters straight from the pinned staging slot; 0: one staged H2D copy in front of them (A/B)
+_DIRECT_PARAMS = os.environ.get("HIFIHR_BATCH_DIRECT_PARAMS", "1") != "0"
 
 
 def _no_rot(center, scale, res):
@@ -113,21 +118,28 @@ class FreiHandDeviceCache:
         self.n, self.H, self.W, self.device, self.max_rot = n, H, W, torch.device(device), max_rot
         self.lib = get_lib()
 
-    _RING = 8          # pinned staging slots (an asynchronous copy reads its slot when the GPU gets to it)
+    _RING = 32         # pinned staging slots (the device reads a slot when it gets to it, possibly many host steps later)
+    _GROUP = 8         # ... released in groups: ONE event per _GROUP steps (an event record is a barrier packet between the batch kernels and the step)
 
     def _stage(self, nwords):
         if not hasattr(self, "_slots"):
-            self._slots, self._events, self._turn = [None] * self._RING, [None] * self._RING, 0
+            # every slot of the ring now: a pinned allocation is a driver call of a millisecond or more, and the first trip round the ring
+            # would otherwise pay one per step (bench.py's default warm-up is shorter than the ring: the last allocations landed in the timed
+            # region, +0.1 ms/step over 30 steps every time it happened)
+            pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
+            self._slots = [pin(torch.empty(nwords, dtype=torch.int32)) for _ in range(self._RING)]
+            self._events, self._turn = [None] * (self._RING // self._GROUP), 0
         i = self._turn = (self._turn + 1) % self._RING
-        if self._events[i] is not None:
-            self._events[i].synchronize()            # the copy that last read this slot has completed
+        if i % self._GROUP == 0 and self._events[i // self._GROUP] is not None:
+            self._events[i // self._GROUP].synchronize()        # every launch that read a slot of this group has completed
         if self._slots[i] is None or self._slots[i].numel() < nwords:
             self._slots[i] = torch.empty(nwords, dtype=torch.int32).pin_memory()
         return i, self._slots[i][:nwords]
 
-    def _packed_terms(self, idxs, rots, generator):
+    def _packed_terms(self, idxs, rots, generator, direct=False):
         """Host side of one batch: affine coefficients (numpy, stacked) packed with the indices and the two 3x3 matrices per sample
-        into ONE pinned staging buffer that goes over in ONE asynchronous copy.  -> (B, packed int32 [25 B] on the device)."""
+        into ONE pinned staging buffer that goes over in ONE asynchronous copy.  -> (B, packed int32 [25 B] on the device, slot);
+        direct=True: the pinned buffer itself (see below)."""
         idxs = torch.as_tensor(idxs, dtype=torch.int64)
         B = idxs.shape[0]
         if rots is None:                       # np.random.uniform(-max_rot, max_rot) per sample (data/dataset.py:237)
@@ -140,13 +152,23 @@ class FreiHandDeviceCache:
         hv[B:7 * B] = fixed.reshape(-1)
         hv[7 * B:16 * B] = post.reshape(-1).view(np.int32)
         hv[16 * B:25 * B] = rmat.reshape(-1).view(np.int32)
+        if direct:
+            # the kernels read the pinned slot THEMSELVES (hipHostMalloc memory is mapped into the device's address space: 100 B per sample
+            # over the host link, once, by the workgroups that need them): no staging copy -- a blit kernel of its own on this runtime, with a
+            # hand-over on either side, in front of every step.  The caller releases the slot behind its launches (_release).
+            return B, host, slot
         packed = torch.empty(25 * B, dtype=torch.int32, device=self.device)
         packed.copy_(host, non_blocking=True)
-        if self.device.type == "cuda":
-            ev = self._events[slot] or torch.cuda.Event()
+        self._release(slot)
+        return B, packed, slot
+
+    def _release(self, slot):
+        """The stream is done with the slot once it gets here; recorded behind the LAST slot of a group (the slots are used in order)."""
+        if self.device.type == "cuda" and slot % self._GROUP == self._GROUP - 1:
+            g = slot // self._GROUP
+            ev = self._events[g] or torch.cuda.Event()
             ev.record()
-            self._events[slot] = ev
-        return B, packed
+            self._events[g] = ev
 
     EXAMPLE_KEYS = ("imgs", "masks", "segms_gt", "Ks", "Ps", "joints", "verts", "j2d_gt", "scales", "idxs")
 
@@ -161,7 +183,7 @@ class FreiHandDeviceCache:
         root_id (= args.ROOT): the same two launches also emit STEP_KEYS -- root_xyz [B,1,3] = joints[:, root_id], joints_rel / verts_rel
         (train_hrnet.py:62-68) and cam_ndc [B,4] (models_res_nimble.py:184-186,228-235) -- which traineval.forward_backward and
         Model.forward pick up instead of four elementwise launches per step."""
-        B, packed = self._packed_terms(idxs, rots, generator)
+        B, packed, slot = self._packed_terms(idxs, rots, generator, direct=_DIRECT_PARAMS and self.device.type == "cuda")
         dev, J, V = self.device, self.joints.shape[1], self.verts.shape[1]
         if out is None:
             f = lambda *shape: torch.empty(*shape, device=dev)
@@ -189,13 +211,14 @@ class FreiHandDeviceCache:
             self._root_id = root_id                              # (a later in-place call on the same dict keeps the step terms current)
         self.lib.freihand_batch(self.images, self.masks, self.Ks, self.joints, self.verts, self.scales, packed, B, out,
                                 root_id=root_id, image_size=self.H)
+        self._release(slot)
         return out
 
     def batch(self, idxs, rots=None, generator=None, out_images=None, out_masks=None):
         """One training batch assembled on the device.  Host work: the affine coefficients (numpy, stacked) and ONE pinned
         staging buffer (indices + 16.16 warp terms + the two 3x3 matrices per sample) that goes over in ONE asynchronous copy.
         out_images / out_masks: write the warped planes straight into caller-owned tensors (the static inputs of a captured step)."""
-        B, packed = self._packed_terms(idxs, rots, generator)
+        B, packed, _ = self._packed_terms(idxs, rots, generator)
         dev = self.device
         idx_d, coef_d = packed[:B], packed[B:7 * B].view(B, 6)
         post_d = packed[7 * B:16 * B].view(torch.float32).view(B, 3, 3)
@@ -276,8 +299,9 @@ class HO3DDeviceCache:
         self.lib = get_lib()
         self._ws = None
 
-    _RING = 8
+    _RING, _GROUP = FreiHandDeviceCache._RING, FreiHandDeviceCache._GROUP
     _stage = FreiHandDeviceCache._stage
+    _release = FreiHandDeviceCache._release
 
     def batch(self, idxs, center_noise=None, scale_noise=None, generator=None):
         idxs = torch.as_tensor(idxs, dtype=torch.int64)
@@ -292,11 +316,11 @@ class HO3DDeviceCache:
         hv[:B] = idxs.numpy().astype(np.int32)
         hv[B:5 * B] = box.reshape(-1)
         hv[5 * B:8 * B] = np.concatenate([center, scale[:, None]], 1).astype(np.float32).reshape(-1).view(np.int32)
-        packed = torch.empty(8 * B, dtype=torch.int32, device=self.device)
-        packed.copy_(host, non_blocking=True)
-        ev = self._events[slot] or torch.cuda.Event()
-        ev.record()
-        self._events[slot] = ev
+        if _DIRECT_PARAMS:
+            packed = host                          # read by the kernels straight from the pinned slot (FreiHandDeviceCache._packed_terms)
+        else:
+            packed = torch.empty(8 * B, dtype=torch.int32, device=self.device)
+            packed.copy_(host, non_blocking=True)
         nws = self.lib.ho3d_workspace_bytes(B, self.inp_res)
         if self._ws is None or self._ws.numel() * 4 < nws:
             self._ws = torch.empty(nws // 4 + 1, dtype=torch.int32, device=self.device)
@@ -305,6 +329,7 @@ class HO3DDeviceCache:
                "K_crop": torch.empty(B, 3, 3, device=dev), "uv21_crop": torch.empty(B, 21, 2, device=dev),
                "xyz21": torch.empty(B, 21, 3, device=dev)}
         self.lib.ho3d_batch(self.images, self.masks, self.Ks, self.uv21, self.xyz21, packed, B, S, self._ws, out)
+        self._release(slot)
         if self.root_xyz is not None:
             out["root_xyz"] = self.root_xyz[idxs.to(self.device)]
         return out

@@ -9,6 +9,8 @@ Semantics: torch.optim.Adam as configured at reference train_hrnet.py:546-551.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import get_lib, require_cuda
@@ -67,18 +69,40 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__([flat.flat], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
-        self.step_count = 0
+        self._step_count = 0
         self.grad_scale = grad_scale
         self._lib = None
-        # graph mode: the per-step scalars live in device memory and are refreshed by prepare_step() outside the graph
+        # graph mode: the step counter and the learning rate live in device memory (hifihr_adam_step_counted: the kernel derives the bias
+        # corrections and advances the counter itself), uploaded by prepare_step() only when the host's view of them changed -- a scheduler
+        # step, a restored checkpoint.  HIFIHR_ADAM_COUNTED=0: the two per-step scalars uploaded before every replay (hifihr_adam_step_dyn).
         self.graph_mode = False
+        self._counted = os.environ.get("HIFIHR_ADAM_COUNTED", "1") != "0"
+        self._state = None                  # device image of (lr, betas, step)
+        self._state_sig = None              # (lr, betas, completed steps) the device holds
         self._dyn = None
         self._dyn_host = None
+
+    @property
+    def step_count(self):
+        return self._step_count
+
+    @step_count.setter
+    def step_count(self, value):
+        # (a restored snapshot / checkpoint: the device's counter is refreshed by the next prepare_step)
+        self._step_count = int(value)
+        self._state_sig = None
 
     _RING = 32        # pinned staging slots for the per-step scalars
 
     def enable_graph_mode(self):
         self.graph_mode = True
+        if self._counted and self.flatp.flat.is_cuda:
+            if self._lib is None:
+                self._lib = get_lib()
+            self._state = torch.zeros(int(self._lib.c.hifihr_adam_state_bytes()), dtype=torch.uint8, device=self.flatp.flat.device)
+            self._state_sig = None
+        else:
+            self._counted = False
         self._dyn = torch.zeros(2, device=self.flatp.flat.device)
         cuda = self.flatp.flat.is_cuda
         self._dyn_host = torch.zeros(self._RING, 2).pin_memory() if cuda else torch.zeros(self._RING, 2)
@@ -94,8 +118,15 @@ class FusedAdam(torch.optim.Optimizer):
         writes a slot of its own (ring), and a slot is rewritten only after the copy that read it has completed (event) --
         a single staging buffer let a pending copy pick up a LATER step's scalars when the host ran ahead."""
         g = self.param_groups[0]
-        self.step_count += 1
+        self._step_count += 1
         b1, b2 = g["betas"]
+        if self._counted:
+            # the device advances its own counter: upload only when what it holds is not what this step needs
+            want = (float(g["lr"]), float(b1), float(b2), self._step_count - 1)
+            if self._state_sig != want:
+                self._state.copy_(self._lib.adam_state_image(*want))        # (pageable source: a blocking, stream-ordered copy; rare)
+            self._state_sig = (want[0], want[1], want[2], self._step_count)     # after the replay that follows
+            return
         slot = self.step_count % self._RING
         ev = self._dyn_events[slot]
         if ev is not None:
@@ -117,11 +148,15 @@ class FusedAdam(torch.optim.Optimizer):
             self._lib = get_lib()
         require_cuda(self.flatp.flat)
         g = self.param_groups[0]
+        if self.graph_mode and self._counted:
+            self._lib.adam_step_counted(self.flatp.flat, self.flatp.grad, self.exp_avg, self.exp_avg_sq, self.grad_scale, g["eps"],
+                                        g["weight_decay"], self._state)
+            return
         if self.graph_mode:
             self._lib.adam_step_dyn(self.flatp.flat, self.flatp.grad, self.exp_avg, self.exp_avg_sq, self.grad_scale,
                                     g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._dyn)
             return
-        self.step_count += 1
+        self._step_count += 1
         from .ops import PROFILE
         PROFILE.bracket("adam", lambda: self._lib.adam_step(self.flatp.flat, self.flatp.grad, self.exp_avg, self.exp_avg_sq,
                                                             self.grad_scale, g["lr"], g["betas"][0], g["betas"][1], g["eps"],

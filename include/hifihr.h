@@ -226,6 +226,15 @@ int hifihr_adam_step(float* params_d, const float* grads_d, float* exp_avg_d, fl
 /* Same update with the two per-step scalars read from DEVICE memory, dyn_d[2] = { lr / (1 - beta1^t),
  * 1 / sqrt(1 - beta2^t) }: the launch can be captured in a hipGraph and replayed while the host refreshes dyn_d
  * (a 8-byte async copy) outside the graph before each replay. */
+/* The same update with the step counter and the learning rate in DEVICE memory (round 5): state_d is hifihr_adam_state_bytes() = 48 bytes,
+ *   f64 lr, f64 beta1, f64 beta2, f64 beta1^step, f64 beta2^step, i32 step (completed steps), i32 0
+ * written once by the caller (and again whenever lr or the counter changes: a scheduler step, a restored checkpoint).  The launch computes
+ * lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t), t = step + 1, in double precision on the device (from the running products) and advances
+ * `step` and the products when its last workgroup finishes: a captured training step replays with nothing to refresh from the host in between (hifihr_adam_step_dyn needs a 2-float upload
+ * in front of every replay).  One launch at a time per state. */
+size_t hifihr_adam_state_bytes(void);
+int hifihr_adam_step_counted(float* params_d, const float* grads_d, float* exp_avg_d, float* exp_avg_sq_d, size_t n, float grad_scale,
+                             float eps, float weight_decay, void* state_d, void* stream);
 int hifihr_adam_step_dyn(float* params_d, const float* grads_d, float* exp_avg_d, float* exp_avg_sq_d, size_t n,
                          float grad_scale, float beta1, float beta2, float eps, float weight_decay, const float* dyn_d,
                          void* stream);

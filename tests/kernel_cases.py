@@ -279,6 +279,13 @@ def render_case(lib, tables, device, B, seed, image_size, aa, check_grad=True, r
             scale = np.abs(ref).max() + 1e-12
             err = np.abs(got.cpu().numpy() - ref).max() / scale
             assert err < gtol, f"grad {name}: max err / max |ref| = {err:.3e} (scale {scale:.3e})"
+        # a SECOND backward after the one forward: the accumulators the forward's vertex kernel zeroed are dirty now, the launcher clears them
+        gv2 = torch.full((B, V, 3), 7.0, device=device); gc2 = torch.full((B, V, 3), 7.0, device=device)
+        glc2 = torch.full((B, 3), 7.0, device=device); gld2 = torch.full((B, 3), 7.0, device=device)
+        lib.render_bwd(h, dv, dcam, dlc, dld, fid, d(w), gv2, gc2, glc2, gld2, ws)
+        for name, a, b2 in (("verts", gv, gv2), ("vcolors", gc, gc2), ("light_color", glc, glc2), ("light_dir", gld, gld2)):
+            scale = float(a.abs().max()) + 1e-12
+            assert float((a - b2).abs().max()) <= 1e-5 * scale, f"second backward on one forward's workspace: grad {name} differs"
     finally:
         lib.renderer_destroy(h)
 
@@ -357,6 +364,24 @@ def adam_case(lib, device, n, wd, steps, grad_scale=0.5, lr=1e-3):
             dyn = torch.tensor([lr / (1 - 0.9 ** s), 1.0 / (1 - 0.999 ** s) ** 0.5], dtype=torch.float32).to(device)
             lib.adam_step_dyn(p, g.to(device), m, v, grad_scale, 0.9, 0.999, 1e-8, wd, dyn)
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-5)
+    # the counted variant (step counter and lr in device memory, bias corrections derived by the kernel): the same trajectory, and the counter
+    # the last workgroup advances ends at `steps`; started from a state image at step 1 to cover a restored counter
+    gen = torch.Generator().manual_seed(n)
+    torch.randn(n, generator=gen)
+    pc = p0.clone().to(device); mc = torch.zeros(n, device=device); vc = torch.zeros(n, device=device)
+    state = None
+    for s in range(1, steps + 1):
+        g = torch.randn(n, generator=gen)
+        if s == 1:
+            lib.adam_step(pc, g.to(device), mc, vc, grad_scale, lr, 0.9, 0.999, 1e-8, wd, 1)
+            state = lib.adam_state_image(lr, 0.9, 0.999, 1).to(device)
+        else:
+            lib.adam_step_counted(pc, g.to(device), mc, vc, grad_scale, 1e-8, wd, state)
+    np.testing.assert_allclose(pc.cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-5)
+    import struct
+    lr_d, b1_d, b2_d, p1_d, p2_d, step_d, done_d = struct.unpack("<dddddii", bytes(state.cpu().numpy().tobytes()))
+    assert (lr_d, step_d, done_d) == (lr, steps, 0), (lr_d, step_d, done_d)
+    assert abs(p1_d - 0.9 ** steps) <= 1e-14 and abs(p2_d - 0.999 ** steps) <= 1e-14
 
 
 # ------------------------------------------------------------------------------------------------
