@@ -59,7 +59,7 @@ struct AdamState {          // 48 bytes (include/hifihr.h: hifihr_adam_step_coun
   int step;                 // completed steps
   int done;                 // workgroups of the running launch that have finished (zero between launches)
 };
-__global__ __launch_bounds__(256) void adam_counted_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adam_kernel_counted(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, size_t n, float grad_scale, float eps, float weight_decay,
                                                           AdamState* __restrict__ st) {
   __shared__ float sc[4];
@@ -124,7 +124,7 @@ hipError_t launch_adam_counted(float* p, const float* g, float* m, float* v, siz
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_counted_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, grad_scale, eps, weight_decay,
+  hipLaunchKernelGGL(adam_kernel_counted, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, grad_scale, eps, weight_decay,
                      static_cast<AdamState*>(state));
   return hipGetLastError();
 }

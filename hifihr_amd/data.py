@@ -22,8 +22,10 @@ import os
 
 from ._lib import get_lib, require_cuda
 
-# 1: the batch kernels read their per-sample parameters straight from the pinned staging slot; 0: one staged H2D copy in front of them (A/B)
-_DIRECT_PARAMS = os.environ.get("HIFIHR_BATCH_DIRECT_PARAMS", "1") != "0"
+# 1: the batch kernels read their per-sample parameters straight from the pinned staging slot (no staged H2D copy in front of them).  Measured
+# 10 us/step faster on a fresh box and 0.2 ms/step SLOWER in a process that follows a long host-side job (the -m gpu suite) on the same box:
+# device reads of host memory depend on the state of the host's memory.  Off: one staged copy (profiles/r05_batch_params_ab.txt).
+_DIRECT_PARAMS = os.environ.get("HIFIHR_BATCH_DIRECT_PARAMS", "0") != "0"
 
 
 def _no_rot(center, scale, res):

@@ -169,6 +169,18 @@ def test_device_cache_batch_examples_matches_data_dic(golden_dir):
     assert all(into[k].data_ptr() == static[k].data_ptr() for k in into)
     with pytest.raises(ValueError):
         cache.batch_examples(order[:2], rots=rots[:2], out=static)
+    # the A/B form whose kernels read the parameters from the pinned host slot themselves (HIFIHR_BATCH_DIRECT_PARAMS=1): the same bits;
+    # more batches than the staging ring has slots (the grouped release events)
+    from hifihr_amd import data as data_mod
+    prev = data_mod._DIRECT_PARAMS
+    try:
+        data_mod._DIRECT_PARAMS = True
+        for _ in range(FreiHandDeviceCache._RING + 3):
+            direct = cache.batch_examples(order, rots=rots)
+        torch.cuda.synchronize()
+        assert all(torch.equal(direct[k], got[k]) for k in got)
+    finally:
+        data_mod._DIRECT_PARAMS = prev
 
 
 def test_ho3d_crop_resize_vs_pillow(lib, golden_dir):
