@@ -232,6 +232,8 @@ class HifihrLib:
                                         _c_float_p, c_void_p]
         c.hifihr_maxpool2d_fwd.argtypes = [_c_float_p] + [c_int] * 7 + [_c_float_p, c_void_p, c_void_p]
         c.hifihr_maxpool2d_bwd.argtypes = [_c_float_p, c_void_p] + [c_int] * 7 + [_c_float_p, c_void_p]
+        c.hifihr_maxpool2d_fwd_flat.argtypes = [_c_float_p] + [c_int] * 7 + [_c_float_p, c_void_p, c_void_p]
+        c.hifihr_maxpool2d_bwd_flat.argtypes = [_c_float_p, c_void_p] + [c_int] * 7 + [_c_float_p, c_void_p]
         c.hifihr_maxpool2d_bwd_relu.argtypes = [_c_float_p, c_void_p, _c_float_p] + [c_int] * 7 + [_c_float_p, c_void_p]
         c.hifihr_wino_output_transform_mask_m.argtypes = [_c_float_p] * 3 + [c_int] * 5 + [c_void_p]
         c.hifihr_adam_step.argtypes = [_c_float_p, _c_float_p, _c_float_p, _c_float_p, c_size_t, c_float, c_float, c_float,
@@ -815,6 +817,15 @@ class HifihrLib:
         assert tap.dtype == torch.uint8 and tap.is_contiguous()
         self.check(self.c.hifihr_maxpool2d_fwd(_fp(x), N, H, W, C, k, s, p, _fp(y), c_void_p(tap.data_ptr()), _stream_of(x)),
                    "hifihr_maxpool2d_fwd")
+
+    def maxpool2d_fwd_flat(self, x, N, H, W, C, k, s, p, y_flat, tap):
+        """maxpool2d_fwd with the output as the [N, C * OH * OW] matrix of `y.view(N, -1)` (NCHW order; include/hifihr.h)."""
+        self.check(self.c.hifihr_maxpool2d_fwd_flat(_fp(x), N, H, W, C, k, s, p, _fp(y_flat), c_void_p(tap.data_ptr()), _stream_of(x)),
+                   "hifihr_maxpool2d_fwd_flat")
+
+    def maxpool2d_bwd_flat(self, gy_flat, tap, N, H, W, C, k, s, p, dx):
+        self.check(self.c.hifihr_maxpool2d_bwd_flat(_fp(gy_flat), c_void_p(tap.data_ptr()), N, H, W, C, k, s, p, _fp(dx), _stream_of(gy_flat)),
+                   "hifihr_maxpool2d_bwd_flat")
 
     def maxpool2d_bwd(self, gy, tap, N, H, W, C, k, s, p, dx, relu_y=None):
         if relu_y is not None:

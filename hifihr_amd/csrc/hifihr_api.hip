@@ -768,6 +768,20 @@ int hifihr_maxpool2d_bwd(const float* gy, const unsigned char* tap, int N, int H
   return HIFIHR_OK;
 }
 
+int hifihr_maxpool2d_fwd_flat(const float* x, int N, int H, int W, int C, int k, int s, int p, float* y_flat, unsigned char* tap, void* stream) {
+  if (!x || !y_flat || !tap || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_maxpool2d_fwd_flat: bad argument (C % 4 == 0; (k,s,p) in {(3,2,1), (3,1,1), (2,2,0)})");
+  HIP_TRY(hifihr::launch_maxpool_flat(x, tap, N, H, W, C, k, s, p, y_flat, 0, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
+int hifihr_maxpool2d_bwd_flat(const float* gy_flat, const unsigned char* tap, int N, int H, int W, int C, int k, int s, int p, float* dx, void* stream) {
+  if (!gy_flat || !dx || !tap || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0)
+    return fail(HIFIHR_EINVAL, "hifihr_maxpool2d_bwd_flat: bad argument (C % 4 == 0; (k,s,p) in {(3,2,1), (3,1,1), (2,2,0)})");
+  HIP_TRY(hifihr::launch_maxpool_flat(gy_flat, const_cast<unsigned char*>(tap), N, H, W, C, k, s, p, dx, 1, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_maxpool2d_bwd_relu(const float* gy, const unsigned char* tap, const float* y, int N, int H, int W, int C, int k, int s, int p,
                               float* dx, void* stream) {
   if (!gy || !tap || !y || !dx || N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 != 0 || !pool_ok(k, s, p) || H + 2 * p < k || W + 2 * p < k)

@@ -260,6 +260,8 @@ hipError_t launch_mmpool_fwd(const float* x, const float* p, int B, int HW, int 
 hipError_t launch_mmpool_bwd(const float* gy, const float* p, const int* argmax, const float* xmax, const float* xavg, int B, int HW,
                              int C, float* dx, float* dp_acc, hipStream_t st);
 // nn.MaxPool2d(k, s, p) for (k, s, p) in {(3, 2, 1), (3, 1, 1), (2, 2, 0)}
+hipError_t launch_maxpool_flat(const float* x_or_gy, unsigned char* tap, int N, int H, int W, int C, int k, int s, int p, float* y_or_dx, int bwd,
+                               hipStream_t st);
 hipError_t launch_maxpool_fwd(const float* x, int N, int H, int W, int C, int k, int s, int p, float* y, unsigned char* tap,
                               hipStream_t st);
 hipError_t launch_maxpool_bwd(const float* gy, const unsigned char* tap, const float* ymask, int N, int H, int W, int C, int k, int s, int p, float* dx,

@@ -123,7 +123,10 @@ hipError_t launch_mmpool_bwd(const float* gy, const float* p, const int* argmax,
 // ------------------------------------------------------------------------------------------------
 // MaxPool2d(K, S, P): thread = (output pixel, 4 channels)
 // ------------------------------------------------------------------------------------------------
-template <int K, int S, int P>
+// FLAT (round 5): y is written in NCHW order, i.e. as the [N][C * OH * OW] matrix that `x.view(B, -1)` of the reference makes of the pooled
+// tensor (network/res_encoder.py:199-201: the light estimator's last pool feeds a Linear) -- a reshape of the channels-last tensor is a copy
+// kernel forward and another one for the gradient; the tap indices stay in the kernels' own [N][OH][OW][C] order.
+template <int K, int S, int P, bool FLAT = false>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int OH, int OW,
                                                          float* __restrict__ y, unsigned char* __restrict__ tap) {
   const int C4 = C / 4;
@@ -154,7 +157,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         first = false;
       }
     }
-    *reinterpret_cast<float4*>(y + i * 4) = m;
+    if (FLAT) {
+      float* o = y + (((size_t)n * C + cg * 4) * OH + oh) * OW + ow;
+      const size_t pl = (size_t)OH * OW;
+      o[0] = m.x; o[pl] = m.y; o[2 * pl] = m.z; o[3 * pl] = m.w;
+    } else {
+      *reinterpret_cast<float4*>(y + i * 4) = m;
+    }
     *reinterpret_cast<uchar4*>(tap + i * 4) = make_uchar4((unsigned char)mt.x, (unsigned char)mt.y, (unsigned char)mt.z, (unsigned char)mt.w);
   }
 }
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 // ymask (round 4): the pool's own OUTPUT when its input was a ReLU's output -- a window's gradient then passes only where the pooled value
 // is positive (the winning tap holds the window's maximum, and relu'(z) = [relu(z) > 0] there; the other taps get nothing anyway), i.e.
 // the ReLU's backward without a pass over the four-times larger pre-pool tensors
-template <int K, int S, int P>
+template <int K, int S, int P, bool FLAT = false>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ tap,
                                                          const float* __restrict__ ymask, int N, int H, int W, int C, int OH, int OW,
                                                          float* __restrict__ dx) {
@@ -200,7 +209,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
       for (int k = 0; k < NR; ++k) {
         const size_t o = ((((size_t)n * OH + ohc[j]) * OW + owc[k]) * C4 + cg) * 4;
         t[j][k] = *reinterpret_cast<const uchar4*>(tap + o);
-        g[j][k] = *reinterpret_cast<const float4*>(gy + o);
+        if (FLAT) {                                         // gy in NCHW order (the gradient of the flattened matrix)
+          const float* q = gy + (((size_t)n * C + cg * 4) * OH + ohc[j]) * OW + owc[k];
+          const size_t pl = (size_t)OH * OW;
+          g[j][k] = make_float4(q[0], q[pl], q[2 * pl], q[3 * pl]);
+        } else {
+          g[j][k] = *reinterpret_cast<const float4*>(gy + o);
+        }
         if (ymask != nullptr) {                             // (uniform)
           const float4 m = *reinterpret_cast<const float4*>(ymask + o);
           g[j][k].x = m.x > 0.f ? g[j][k].x : 0.f; g[j][k].y = m.y > 0.f ? g[j][k].y : 0.f;
@@ -227,6 +242,27 @@ static unsigned pool_grid(size_t total) {
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
+}
+
+hipError_t launch_maxpool_flat(const float* x_or_gy, unsigned char* tap, int N, int H, int W, int C, int k, int s, int p, float* y_or_dx, int bwd,
+                               hipStream_t st) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+  if (!bwd) {
+    const dim3 grid(pool_grid((size_t)N * OH * OW * (C / 4)));
+    if (k == 3 && s == 2 && p == 1) hipLaunchKernelGGL((maxpool_fwd_kernel<3, 2, 1, true>), grid, dim3(256), 0, st, x_or_gy, N, H, W, C, OH, OW, y_or_dx, tap);
+    else if (k == 3 && s == 1 && p == 1) hipLaunchKernelGGL((maxpool_fwd_kernel<3, 1, 1, true>), grid, dim3(256), 0, st, x_or_gy, N, H, W, C, OH, OW, y_or_dx, tap);
+    else if (k == 2 && s == 2 && p == 0) hipLaunchKernelGGL((maxpool_fwd_kernel<2, 2, 0, true>), grid, dim3(256), 0, st, x_or_gy, N, H, W, C, OH, OW, y_or_dx, tap);
+    else return hipErrorInvalidValue;
+  } else {
+    const dim3 grid(pool_grid((size_t)N * H * W * (C / 4)));
+    const float* none = nullptr;
+    if (k == 3 && s == 2 && p == 1) hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2, 1, true>), grid, dim3(256), 0, st, x_or_gy, tap, none, N, H, W, C, OH, OW, y_or_dx);
+    else if (k == 3 && s == 1 && p == 1) hipLaunchKernelGGL((maxpool_bwd_kernel<3, 1, 1, true>), grid, dim3(256), 0, st, x_or_gy, tap, none, N, H, W, C, OH, OW, y_or_dx);
+    else if (k == 2 && s == 2 && p == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<2, 2, 0, true>), grid, dim3(256), 0, st, x_or_gy, tap, none, N, H, W, C, OH, OW, y_or_dx);
+    else return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_maxpool_fwd(const float* x, int N, int H, int W, int C, int k, int s, int p, float* y, unsigned char* tap,

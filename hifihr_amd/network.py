@@ -373,8 +373,11 @@ class LightEstimator(nn.Module):
         bl = self.base_layers
         x = bl[2](bl[0](low_features))                      # conv + bias + ReLU each (the nn.ReLU entries only keep the indices)
         x = bl[5](ops.maxpool2d(x, 3, 1, 1))
-        base = ops.maxpool2d(x, 2, 2, 0)
-        flat = base.reshape(base.shape[0], -1)
+        if x.is_cuda and x.shape[1] % 4 == 0:
+            flat = ops.maxpool2d_flatten(x, 2, 2, 0)        # pool + the reference's `.view(B, -1)` (NCHW order) in one launch each way
+        else:
+            base = ops.maxpool2d(x, 2, 2, 0)
+            flat = base.reshape(base.shape[0], -1)
         lights = ops.linear(ops.linear(flat, self.light_reg[0], act=True), self.light_reg[2])
         # the reference checks `torch.any(colors.isnan())` here with a host sync every step (:205); omitted on purpose
         if lights.is_cuda and lights.requires_grad:

@@ -1996,6 +1996,38 @@ def maxpool2d(x, k, s, p, relu_input=False):
     return _MaxPool2d.apply(x, k, s, p, relu_input)
 
 
+class _MaxPool2dFlat(torch.autograd.Function):
+    """nn.MaxPool2d(k, s, p)(x).view(N, -1): the pooled tensor leaves as the NCHW-ordered matrix the reference's flatten makes (and the
+    gradient arrives as one) -- a reshape of the channels-last tensor is a copy kernel in each direction (hifihr_maxpool2d_fwd_flat)."""
+
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        require_cuda(x)
+        x = x.contiguous(memory_format=_CL)
+        N, C, H, W = x.shape
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        y = torch.empty((N, C * OH * OW), device=x.device)
+        tap = torch.empty(N * OH * OW * C, dtype=torch.uint8, device=x.device)
+        PROFILE.bracket("maxpool_fwd", lambda: get_lib().maxpool2d_fwd_flat(x, N, H, W, C, k, s, p, y, tap))
+        ctx.save_for_backward(tap)
+        ctx.cfg = (N, C, H, W, k, s, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (tap,) = ctx.saved_tensors
+        N, C, H, W, k, s, p = ctx.cfg
+        gy = gy.contiguous()
+        dx = torch.empty((N, C, H, W), device=gy.device, memory_format=_CL)
+        PROFILE.bracket("maxpool_bwd", lambda: get_lib().maxpool2d_bwd_flat(gy, tap, N, H, W, C, k, s, p, dx))
+        return dx, None, None, None
+
+
+def maxpool2d_flatten(x, k, s, p):
+    """nn.MaxPool2d(k, s, p)(x).view(x.shape[0], -1) without the reshape's copy (see _MaxPool2dFlat); C % 4 == 0."""
+    return _MaxPool2dFlat.apply(x, k, s, p)
+
+
 def maxpool3x3s2(x):
     """nn.MaxPool2d(3, 2, 1) on channels_last activations (the ResNet stem pool)."""
     return _MaxPool2d.apply(x, 3, 2, 1)

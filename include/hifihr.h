@@ -587,6 +587,13 @@ int hifihr_maxpool2d_bwd(const float* gy_d, const unsigned char* tap_d, int N, i
  * of the four-times larger pre-pool tensor is needed. */
 int hifihr_maxpool2d_bwd_relu(const float* gy_d, const unsigned char* tap_d, const float* y_d, int N, int H, int W, int C, int k, int s, int p,
                               float* dx_d, void* stream);
+/* The pool whose output is FLATTENED next (LightEstimator: `base_layers(x).view(B, -1)` -> Linear, network/res_encoder.py:199-201): y_flat_d is
+ * the [N][C * OH * OW] matrix in the reference's NCHW order, gy_flat_d its gradient; x / dx stay channels-last.  Saves the copy kernel a
+ * reshape of the channels-last tensor costs in each direction. */
+int hifihr_maxpool2d_fwd_flat(const float* x_d, int N, int H, int W, int C, int k, int s, int p, float* y_flat_d, unsigned char* tap_d,
+                              void* stream);
+int hifihr_maxpool2d_bwd_flat(const float* gy_flat_d, const unsigned char* tap_d, int N, int H, int W, int C, int k, int s, int p, float* dx_d,
+                              void* stream);
 
 /* normalize_batch_3C (reference network/res_encoder.py:212-216) fused with NCHW[B][3][H][W] -> NHWC4 [B][H][W][4]
  * (4th channel zero) for the first convolution. */

@@ -807,6 +807,14 @@ def maxpool_case(lib, device, N, H, W, C, seed=0, ties=False, ksp=(3, 2, 1)):
     refdx = xr.grad.permute(0, 2, 3, 1)
     # overlapping windows (stride < kernel): several gradients are summed per input pixel, in a different order than ATen
     assert float((dx.cpu() - refdx).abs().max()) <= 1e-6 + 2e-6 * float(refdx.abs().max()), "maxpool bwd"
+    # the flattening form: y as the [N, C * OH * OW] matrix of `y.view(N, -1)` (NCHW order), gy likewise -- the same bits as the form above
+    if hasattr(lib, "maxpool2d_fwd_flat"):
+        flat = torch.full((N, C * OH * OW), 7.0, device=device); tap2 = torch.empty_like(tap)
+        lib.maxpool2d_fwd_flat(xd, N, H, W, C, k, s_, p_, flat, tap2)
+        assert torch.equal(flat.cpu(), y.detach().reshape(N, -1)) and torch.equal(tap2, tap), "maxpool fwd, flattened output"
+        dx2 = torch.full((N, H, W, C), 7.0, device=device)
+        lib.maxpool2d_bwd_flat(gy.reshape(N, -1).contiguous().to(device), tap2, N, H, W, C, k, s_, p_, dx2)
+        assert torch.equal(dx2, dx), "maxpool bwd from the flattened gradient"
 
 
 # ------------------------------------------------------------------------------------------------
