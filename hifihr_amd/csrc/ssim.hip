@@ -22,6 +22,44 @@ constexpr int kSO = kST * kST / 256; // outputs per thread
 constexpr int kSR = 5;              // window radius (11 taps)
 constexpr int kSH = kST + 2 * kSR;  // 42
 
+constexpr int kSF = 48;             // width of the staged frame: image columns [ox - 8, ox + 40), the halo [ox - 5, ox + 37) is frame columns 3 .. 44
+
+// One halo plane into LDS.  VEC (W % 4 == 0, 16-byte aligned planes): the frame starts 8 columns left of the tile, so every group of four
+// columns is one aligned float4 that lies wholly inside or wholly outside the image -- 504 vector loads per plane for the workgroup (two per
+// thread) and one 16-byte LDS store each; the scalar form is 1 764 loads with ~13 VALU instructions of index arithmetic apiece, which was a
+// quarter of the forward kernel's instruction count (round 5: the kernels are VALU-bound by instruction COUNT: ~1 500 per thread per tile).
+template <bool VEC>
+__device__ __forceinline__ void ssim_stage(float (*__restrict__ dst)[kSF], const float* __restrict__ p, int H, int W, int ox, int oy, int tid) {
+  if (VEC) {
+    for (int e = tid; e < kSH * (kSF / 4); e += 256) {
+      const int r = e / (kSF / 4), sg = e - r * (kSF / 4);
+      const int y = oy + r - kSR, x0 = ox - 8 + 4 * sg;
+      const bool in = (y >= 0) && (y < H) && (x0 >= 0) && (x0 + 3 < W);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) v = *reinterpret_cast<const float4*>(p + (size_t)y * W + x0);
+      *reinterpret_cast<float4*>(&dst[r][4 * sg]) = v;
+    }
+  } else {
+    for (int e = tid; e < kSH * kSH; e += 256) {
+      const int r = e / kSH, c = e - r * kSH;
+      const int y = oy + r - kSR, x = ox + c - kSR;
+      const bool in = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+      dst[r][c + 3] = in ? p[(size_t)y * W + x] : 0.f;
+    }
+  }
+}
+// the 14 inputs of four adjacent outputs of halo row r (frame columns c0 + 3 .. c0 + 16) as five 16-byte LDS reads
+__device__ __forceinline__ void ssim_row14(const float (*__restrict__ src)[kSF], int r, int c0, float* __restrict__ a) {
+  float f[20];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(&src[r][c0 + 4 * q]);
+    f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 14; ++k) a[k] = f[3 + k];
+}
+
 #if defined(HIFIHR_HOSTSIM)
 __device__ __forceinline__ float ssim_rcp(float x) { return 1.0f / x; }
 #else
@@ -37,10 +75,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWindow win, const float* __restrict__ img1, const float* __restrict__ img2,
                                                       int H, int W, float* __restrict__ partial, float* __restrict__ dA,
                                                       float* __restrict__ dB, float* __restrict__ dC) {
-  __shared__ float xs[kSH][kSH + 1], ys[kSH][kSH + 1];
+  __shared__ __attribute__((aligned(16))) float xs[kSH][kSF], ys[kSH][kSF];
   __shared__ float hq[5][kSH][kST + 1];
   __shared__ float red[4];
   const int plane = blockIdx.z;
@@ -48,28 +87,26 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWindow win, const flo
   const int tid = threadIdx.x;
   const float* p1 = img1 + (size_t)plane * H * W;
   const float* p2 = img2 + (size_t)plane * H * W;
-  for (int e = tid; e < kSH * kSH; e += 256) {
-    const int r = e / kSH, c = e - r * kSH;
-    const int y = oy + r - kSR, x = ox + c - kSR;
-    const bool in = (y >= 0) && (y < H) && (x >= 0) && (x < W);
-    xs[r][c] = in ? p1[(size_t)y * W + x] : 0.f;
-    ys[r][c] = in ? p2[(size_t)y * W + x] : 0.f;
-  }
+  ssim_stage<VEC>(xs, p1, H, W, ox, oy, tid);
+  ssim_stage<VEC>(ys, p2, H, W, ox, oy, tid);
   __syncthreads();
   // row pass: for every halo row, 32 output columns, five moments.  A work item is four adjacent outputs of a row: their 14 inputs are read
   // once into registers (28 LDS reads for 4 outputs where one output per item read 22 each); same summation order per output as before
   for (int e = tid; e < kSH * (kST / 4); e += 256) {
     const int r = e / (kST / 4), c0 = 4 * (e - r * (kST / 4));
-    float a[14], b[14];
+    float a[14], b[14], aa[14], bb[14], ab[14];
+    ssim_row14(xs, r, c0, a);
+    ssim_row14(ys, r, c0, b);
 #pragma unroll
-    for (int k = 0; k < 14; ++k) { a[k] = xs[r][c0 + k]; b[k] = ys[r][c0 + k]; }
+    for (int k = 0; k < 14; ++k) { aa[k] = a[k] * a[k]; bb[k] = b[k] * b[k]; ab[k] = a[k] * b[k]; }        // once per input, not once per (output, tap)
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
-        const float w = win.g[k], av = a[o + k], bv = b[o + k];
-        m1 = fmaf(w, av, m1); m2 = fmaf(w, bv, m2); e11 = fmaf(w, av * av, e11); e22 = fmaf(w, bv * bv, e22); e12 = fmaf(w, av * bv, e12);
+        const float w = win.g[k];
+        m1 = fmaf(w, a[o + k], m1); m2 = fmaf(w, b[o + k], m2); e11 = fmaf(w, aa[o + k], e11); e22 = fmaf(w, bb[o + k], e22);
+        e12 = fmaf(w, ab[o + k], e12);
       }
       hq[0][r][c0 + o] = m1; hq[1][r][c0 + o] = m2; hq[2][r][c0 + o] = e11; hq[3][r][c0 + o] = e22; hq[4][r][c0 + o] = e12;
     }
@@ -117,31 +154,27 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWindow win, const flo
   if (tid == 0) partial[((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWindow win, const float* __restrict__ img1, const float* __restrict__ img2,
                                                       const float* __restrict__ dA, const float* __restrict__ dB,
                                                       const float* __restrict__ dC, const float* __restrict__ gscale, float inv_n,
                                                       int H, int W, float* __restrict__ gimg1) {
-  __shared__ float ta[kSH][kSH + 1], tb[kSH][kSH + 1], tc[kSH][kSH + 1];
+  __shared__ __attribute__((aligned(16))) float ta[kSH][kSF], tb[kSH][kSF], tc[kSH][kSF];
   __shared__ float hq[3][kSH][kST + 1];
   const int plane = blockIdx.z;
   const int ox = blockIdx.x * kST, oy = blockIdx.y * kST;
   const int tid = threadIdx.x;
   const size_t po = (size_t)plane * H * W;
-  for (int e = tid; e < kSH * kSH; e += 256) {
-    const int r = e / kSH, c = e - r * kSH;
-    const int y = oy + r - kSR, x = ox + c - kSR;
-    const bool in = (y >= 0) && (y < H) && (x >= 0) && (x < W);
-    const size_t o = po + (size_t)y * W + x;
-    ta[r][c] = in ? dA[o] : 0.f;
-    tb[r][c] = in ? dB[o] : 0.f;
-    tc[r][c] = in ? dC[o] : 0.f;
-  }
+  ssim_stage<VEC>(ta, dA + po, H, W, ox, oy, tid);
+  ssim_stage<VEC>(tb, dB + po, H, W, ox, oy, tid);
+  ssim_stage<VEC>(tc, dC + po, H, W, ox, oy, tid);
   __syncthreads();
   for (int e = tid; e < kSH * (kST / 4); e += 256) {        // (four adjacent outputs per item, as in the forward)
     const int r = e / (kST / 4), c0 = 4 * (e - r * (kST / 4));
     float va[14], vb[14], vc[14];
-#pragma unroll
-    for (int k = 0; k < 14; ++k) { va[k] = ta[r][c0 + k]; vb[k] = tb[r][c0 + k]; vc[k] = tc[r][c0 + k]; }
+    ssim_row14(ta, r, c0, va);
+    ssim_row14(tb, r, c0, vb);
+    ssim_row14(tc, r, c0, vc);
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       float a = 0.f, b = 0.f, cc = 0.f;
@@ -193,6 +226,12 @@ __global__ __launch_bounds__(256) void ssim_finish_kernel(const float* __restric
 
 int ssim_tile_edge() { return kST; }
 
+// vector staging: whole float4 groups inside or outside the image, planes 16-byte aligned (plane stride H * W floats with W % 4 == 0)
+static bool ssim_vec_ok(int W, const float* a, const float* b, const float* c) {
+  static const int on = [] { const char* e = getenv("HIFIHR_SSIM_VEC"); return e ? atoi(e) : 1; }();
+  return on && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
 hipError_t launch_ssim_finish(const float* partial, int count, float scale, float offset, float* out, hipStream_t st) {
   hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(256), 0, st, partial, count, scale, offset, out);
   return hipGetLastError();
@@ -201,7 +240,10 @@ hipError_t launch_ssim_finish(const float* partial, int count, float scale, floa
 hipError_t launch_ssim_fwd(const SsimWindow& win, const float* img1, const float* img2, int planes, int H, int W, float* partial,
                            float* dA, float* dB, float* dC, hipStream_t st) {
   const dim3 grid((W + kST - 1) / kST, (H + kST - 1) / kST, planes);
-  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, st, win, img1, img2, H, W, partial, dA, dB, dC);
+  if (ssim_vec_ok(W, img1, img2, nullptr))
+    hipLaunchKernelGGL(ssim_fwd_kernel<true>, grid, dim3(256), 0, st, win, img1, img2, H, W, partial, dA, dB, dC);
+  else
+    hipLaunchKernelGGL(ssim_fwd_kernel<false>, grid, dim3(256), 0, st, win, img1, img2, H, W, partial, dA, dB, dC);
   return hipGetLastError();
 }
 
@@ -209,7 +251,10 @@ hipError_t launch_ssim_bwd(const SsimWindow& win, const float* img1, const float
                            const float* dC, const float* gscale, int planes, int H, int W, float* gimg1, hipStream_t st, float out_scale) {
   const dim3 grid((W + kST - 1) / kST, (H + kST - 1) / kST, planes);
   const float inv_n = out_scale / ((float)planes * (float)H * (float)W);
-  hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, st, win, img1, img2, dA, dB, dC, gscale, inv_n, H, W, gimg1);
+  if (ssim_vec_ok(W, dA, dB, dC))
+    hipLaunchKernelGGL(ssim_bwd_kernel<true>, grid, dim3(256), 0, st, win, img1, img2, dA, dB, dC, gscale, inv_n, H, W, gimg1);
+  else
+    hipLaunchKernelGGL(ssim_bwd_kernel<false>, grid, dim3(256), 0, st, win, img1, img2, dA, dB, dC, gscale, inv_n, H, W, gimg1);
   return hipGetLastError();
 }
 
