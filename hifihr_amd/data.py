@@ -14,11 +14,10 @@ fixed-point chain as the reference, which makes the device warp bit-exact with P
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
-
-import os
 
 from ._lib import get_lib, require_cuda
 
