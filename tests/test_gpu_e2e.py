@@ -297,7 +297,7 @@ def test_training_step_runs_on_the_hand_written_kernels():
         assert not other, other
         # (this batch comes from data_dic, not from the batch kernel that emits the step's own terms: index_select / sub for root_xyz and
         # the root-relative ground truth are ATen here.  roctracer drops a share of the records: no lower bound beyond "a whole step")
-        assert len(aten) <= 8, sorted(set(aten))
+        assert len(aten) <= 12, sorted(set(aten))            # 7 observed
         assert 100 <= len(kernels) <= 260, len(kernels)
     finally:
         torch.cuda.set_stream(prev)
