@@ -333,3 +333,62 @@ def test_captured_step_refuses_a_batch_without_its_step_terms():
     _check_step_terms({"imgs": torch.zeros(1)}, {"imgs": torch.zeros(1)})
     with pytest.raises(KeyError, match="joints_rel"):
         _check_step_terms(static, {"imgs": torch.zeros(1), "joints": torch.zeros(1)})
+
+
+def test_adam_device_state_is_uploaded_only_when_the_host_view_changes():
+    """hifihr_amd.optim.FusedAdam in graph mode with the step counter on the device (hifihr_adam_step_counted): prepare_step() uploads the
+    48-byte state when the device does not hold what the coming step needs -- first use, a scheduler step, a restored counter -- and not
+    in between (the kernel advances its own counter).  Host logic only: the library is a stub that records the uploads."""
+    import struct
+    import torch
+    from hifihr_amd._lib import HifihrLib
+    from hifihr_amd.optim import FlatParams, FusedAdam
+    net = torch.nn.Linear(4, 3)
+    opt = FusedAdam(FlatParams(net), lr=1e-3)
+
+    class Stub:
+        adam_state_image = staticmethod(HifihrLib.adam_state_image)
+    uploads = []
+
+    class State:                                        # stands in for the device tensor
+        def copy_(self, image):
+            uploads.append(struct.unpack("<dddddii", bytes(image.numpy().tobytes())))
+    opt.graph_mode, opt._counted, opt._lib, opt._state = True, True, Stub(), State()
+    for _ in range(3):
+        opt.prepare_step()
+    assert len(uploads) == 1 and uploads[0][0] == 1e-3 and uploads[0][5] == 0 and opt.step_count == 3      # (lr, ..., completed steps = 0)
+    opt.param_groups[0]["lr"] = 5e-4                    # MultiStepLR fires
+    opt.prepare_step(); opt.prepare_step()
+    assert len(uploads) == 2 and uploads[1][0] == 5e-4 and uploads[1][5] == 3
+    assert abs(uploads[1][3] - 0.9 ** 3) < 1e-15 and abs(uploads[1][4] - 0.999 ** 3) < 1e-15                # the running products beta^t
+    opt.step_count = 40                                 # a restored snapshot / checkpoint
+    opt.prepare_step()
+    assert len(uploads) == 3 and uploads[2][5] == 40 and opt.step_count == 41
+    opt.prepare_step()
+    assert len(uploads) == 3
+
+
+def test_staging_ring_releases_its_slots_in_groups():
+    """hifihr_amd.data.FreiHandDeviceCache._stage / _release (host side of the batch parameters): every pinned slot exists after the first call,
+    the slots are handed out in ring order, and a release event is recorded behind the LAST slot of each group only (one barrier packet per
+    _GROUP steps instead of one per step) -- on a CPU 'device' nothing is recorded, the bookkeeping is the same."""
+    import torch
+    from hifihr_amd.data import FreiHandDeviceCache as C
+
+    class Probe:
+        _RING, _GROUP = C._RING, C._GROUP
+        _stage, _release = C._stage, C._release
+        device = torch.device("cpu")
+    p = Probe()
+    order = []
+    for _ in range(C._RING + 5):
+        slot, host = p._stage(25 * 4)
+        assert host.numel() == 100 and host.dtype == torch.int32
+        order.append(slot)
+        p._release(slot)
+    assert len(p._slots) == C._RING and all(s is not None and s.numel() >= 100 for s in p._slots)
+    assert order == [(i + 1) % C._RING for i in range(C._RING + 5)]
+    assert C._RING % C._GROUP == 0 and len(p._events) == C._RING // C._GROUP
+    # a larger batch later: the slot grows, the others stay
+    slot, host = p._stage(25 * 64)
+    assert host.numel() == 1600 and p._slots[slot].numel() >= 1600
