@@ -127,15 +127,18 @@ class FreiHandDeviceCache:
             # every slot of the ring now: a pinned allocation is a driver call of a millisecond or more, and the first trip round the ring
             # would otherwise pay one per step (bench.py's default warm-up is shorter than the ring: the last allocations landed in the timed
             # region, +0.1 ms/step over 30 steps every time it happened)
-            pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
-            self._slots = [pin(torch.empty(nwords, dtype=torch.int32)) for _ in range(self._RING)]
+            self._slots = [self._pinned(nwords) for _ in range(self._RING)]
             self._events, self._turn = [None] * (self._RING // self._GROUP), 0
         i = self._turn = (self._turn + 1) % self._RING
         if i % self._GROUP == 0 and self._events[i // self._GROUP] is not None:
             self._events[i // self._GROUP].synchronize()        # every launch that read a slot of this group has completed
         if self._slots[i] is None or self._slots[i].numel() < nwords:
-            self._slots[i] = torch.empty(nwords, dtype=torch.int32).pin_memory()
+            self._slots[i] = self._pinned(nwords)                # (a larger batch than the ring was made for)
         return i, self._slots[i][:nwords]
+
+    def _pinned(self, nwords):
+        t = torch.empty(nwords, dtype=torch.int32)
+        return t.pin_memory() if self.device.type == "cuda" else t
 
     def _packed_terms(self, idxs, rots, generator, direct=False):
         """Host side of one batch: affine coefficients (numpy, stacked) packed with the indices and the two 3x3 matrices per sample
@@ -302,6 +305,7 @@ class HO3DDeviceCache:
 
     _RING, _GROUP = FreiHandDeviceCache._RING, FreiHandDeviceCache._GROUP
     _stage = FreiHandDeviceCache._stage
+    _pinned = FreiHandDeviceCache._pinned
     _release = FreiHandDeviceCache._release
 
     def batch(self, idxs, center_noise=None, scale_noise=None, generator=None):

@@ -377,7 +377,7 @@ def test_staging_ring_releases_its_slots_in_groups():
 
     class Probe:
         _RING, _GROUP = C._RING, C._GROUP
-        _stage, _release = C._stage, C._release
+        _stage, _release, _pinned = C._stage, C._release, C._pinned
         device = torch.device("cpu")
     p = Probe()
     order = []
