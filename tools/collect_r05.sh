@@ -38,5 +38,10 @@ python3 tools/time_dwconv.py 2>/dev/null > $O/r05_time_dwconv.txt
 # trunk gradient error vs the reference by dispatch (README "Precision of the default dispatch")
 python3 -m pytest tests/test_gpu_conv.py -q -s -k "precision_knob or gradient_error_by_dispatch" 2>&1 | grep -E "fixture|HIFIHR_|passed|failed" > $O/r05_precision_by_dispatch.txt
 if [ "${1:-}" != quick ]; then bash tools/ablation.sh > $O/r05_ablation.txt 2>&1; fi
+# the headline line once more, now that THIS tree's counter file exists (bench.py reads profiles/r*_kernel_traffic.json by source digest): the
+# line with `traffic` populated is the one to commit as r05_bench_default.json; the second run shows the box's drift
+cp $O/r05_kernel_traffic.json profiles/r05_kernel_traffic.json 2>/dev/null
+python3 bench.py > $O/bench_default_a.log 2>&1; last $O/bench_default_a.log $O/r05_bench_default.json
+python3 bench.py > $O/bench_default_b.log 2>&1; last $O/bench_default_b.log $O/r05_bench_default_second_run.json
 ls -la $O | tail -40
 if grep -l "Traceback (most recent call last)" $O/* 2>/dev/null; then echo "collect_r05: the files above hold a Python traceback: NOT evidence" >&2; exit 1; fi
