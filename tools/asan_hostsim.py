@@ -40,7 +40,25 @@ def wino():
     kc.wino_bn_bwd_case(lib, "cpu", 1, 9, 7, 64, True, True, seed=4)
 
 
-GROUPS = {"conv": conv, "render": render, "wino": wino}
+def round5():
+    """Kernels written or re-indexed in round 5: the layer-1 pair launch, the flattening pool, SSIM's 48-column frame (vector and scalar
+    staging, ragged image sizes), the four-pixel warp kernel through the batch entry, Adam with the counter on the device."""
+    import numpy as np
+    import torch
+    for (N, H, W, res) in [(2, 10, 14, False), (3, 8, 28, True), (1, 6, 14, True)]:
+        kc.conv_c64_bwd_pair_case(lib, "cpu", N, H, W, seed=N + H, with_res=res)
+    for ksp in ((3, 2, 1), (3, 1, 1), (2, 2, 0)):
+        kc.maxpool_case(lib, "cpu", 2, 12, 10, 8, seed=ksp[0], ties=True, ksp=ksp)
+    gen = torch.Generator().manual_seed(5)
+    for (H, W) in [(64, 64), (40, 36), (33, 30), (70, 44)]:          # W % 4 == 0: vector staging; 30: the scalar form; partial tiles
+        a = torch.rand(2, 3, H, W, generator=gen).numpy(); b = torch.rand(2, 3, H, W, generator=gen).numpy()
+        kc.ssim_case(lib, "cpu", a, b, None, None)
+    kc.freihand_batch_case(lib, "cpu", seed=1)
+    kc.freihand_batch_case(lib, "cpu", seed=2, B=3, n=5, res=32, J=21, V=50)
+    kc.adam_case(lib, "cpu", n=4099, wd=0.01, steps=4)
+
+
+GROUPS = {"conv": conv, "render": render, "wino": wino, "round5": round5}
 for g in (sys.argv[1:] or list(GROUPS)):
     GROUPS[g]()
     print(f"asan: {g} clean", flush=True)
