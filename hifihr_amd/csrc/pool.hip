@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void light_split_fwd_kernel(const float* __res
   if (i >= B * 3) return;
   const int b = i / 3, c = i - 3 * b;
   const float x = lights[b * 6 + c];
-  colors[i] = fminf(fmaxf(x, -1.f), 1.f);
+  colors[i] = x != x ? x : fminf(fmaxf(x, -1.f), 1.f);      // (a NaN colour stays NaN, as torch's hardtanh leaves it)
   dirs[i] = lights[b * 6 + 3 + c];
 }
 __global__ __launch_bounds__(256) void light_split_bwd_kernel(const float* __restrict__ lights, const float* __restrict__ gcolors,
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void light_split_bwd_kernel(const float* __res
   if (i >= B * 3) return;
   const int b = i / 3, c = i - 3 * b;
   const float x = lights[b * 6 + c];
-  glights[b * 6 + c] = (gcolors != nullptr && x > -1.f && x < 1.f) ? gcolors[i] : 0.f;
+  glights[b * 6 + c] = (gcolors != nullptr && !(x <= -1.f || x >= 1.f)) ? gcolors[i] : 0.f;   // hardtanh_backward's own predicate (NaN passes)
   glights[b * 6 + 3 + c] = gdirs != nullptr ? gdirs[i] : 0.f;
 }
 hipError_t launch_light_split_fwd(const float* lights, int B, float* colors, float* dirs, hipStream_t st) {

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 
 #include "render_common.h"
 
@@ -956,14 +957,18 @@ namespace {
 struct WsClean { void* ws; bool clean; };
 WsClean g_ws_clean[32] = {};
 int g_ws_clean_next = 0;
+// forward runs on the caller's thread, backward on autograd's device worker thread (one per device): the table is shared by all of them
+std::mutex g_ws_clean_mu;
 }  // namespace
 void render_ws_mark_clean(void* ws, bool clean) {
+  std::lock_guard<std::mutex> lock(g_ws_clean_mu);
   for (auto& e : g_ws_clean)
     if (e.ws == ws) { e.clean = clean; return; }
   g_ws_clean[g_ws_clean_next] = WsClean{ws, clean};           // (round robin: an evicted workspace just gets its memsets back)
   g_ws_clean_next = (g_ws_clean_next + 1) % 32;
 }
 bool render_ws_take_clean(void* ws) {
+  std::lock_guard<std::mutex> lock(g_ws_clean_mu);
   for (auto& e : g_ws_clean)
     if (e.ws == ws) { const bool c = e.clean; e.clean = false; return c; }
   return false;

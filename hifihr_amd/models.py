@@ -211,7 +211,8 @@ class Model(nn.Module):
             # (ops.mano_full; HIFIHR_MANO_FUSED=0: the layer, then ops.mano_joints_root_relative, then an elementwise add)
             joints, mano_verts, verts_cam, pred_root, pose_o, shape_o = ops.mano_full(
                 self.hand_layer.handle, hand_params["pose_params"], hand_params["shape_params"], root_id, root_xyz if self.ifRender else None)
-            outputs = {"skin_verts": mano_verts}
+            # (the layer's dict holds the ABSOLUTE posed vertices under 'skin_verts'; with the renderer on it is overwritten below)
+            outputs = {"skin_verts": mano_verts if self.ifRender else mano_verts + pred_root.reshape(-1, 1, 3)}
             outputs.update(hand_params)
             outputs["pose_params"], outputs["shape_params"] = pose_o, shape_o      # (aliases: the regularisers' gradient joins the layer's backward)
         else:

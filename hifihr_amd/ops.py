@@ -392,6 +392,7 @@ class side_branch:
     `enabled=False` (or HIFIHR_BRANCHES=0) makes the block run inline."""
     _streams = {}
     _home = {}          # (device, name) -> the stream the branch last forked from (the step's own stream)
+    _pending = set()    # branches entered since the last join_pending(): their BACKWARD may still be running on the side stream
 
     def __init__(self, like, name, enabled=True, inputs=()):
         self.on = bool(enabled) and _BRANCHES and like.is_cuda
@@ -408,6 +409,7 @@ class side_branch:
             BRANCH_STREAMS.add(st.cuda_stream)
         self.cur, self.side = torch.cuda.current_stream(dev), st
         side_branch._home[key] = self.cur
+        side_branch._pending.add(key)
         st.wait_stream(self.cur)
         for t in (self.like,) + tuple(self.inputs):
             if torch.is_tensor(t) and t.is_cuda:
@@ -430,6 +432,24 @@ class side_branch:
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(self.cur)
             self.cur.wait_stream(self.side)
+
+    @staticmethod
+    def join_pending():
+        """Join every branch entered since the last call into the current stream (and the stream it forked from).  `join` orders the
+        FORWARD; in backward autograd runs the branch's nodes on the side stream again, and the only thing that orders them before what
+        follows on the main stream is the first branch node's input gradient reaching a main-stream node.  With a frozen / detached
+        trunk there is no such gradient, while the branch's convolutions still write their weight gradients straight into the flat
+        gradient buffer (_hifihr_direct_grad: no AccumulateGrad, so autograd does not sync the side stream as a leaf stream either):
+        zero_grad / Adam of the main stream would race them, and a capture would end with an un-joined stream.  prepared_weights.__exit__
+        calls this after backward, so the optimizer always runs behind the branch."""
+        for key in list(side_branch._pending):
+            st, home = side_branch._streams.get(key), side_branch._home.get(key)
+            if st is not None:
+                cur = torch.cuda.current_stream(key[0])
+                cur.wait_stream(st)
+                if home is not None and home != cur:
+                    home.wait_stream(st)
+        side_branch._pending.clear()
 
 
 _BRANCHES = os.environ.get("HIFIHR_BRANCHES", "1") != "0"
@@ -673,6 +693,12 @@ class prepared_weights:
         self.async_wgrad = bool(async_wgrad) and os.environ.get("HIFIHR_ASYNC_WGRAD", "1") != "0"
 
     def __enter__(self):
+        # branches left over from a forward outside any scope (evaluation): joined now -- or, when this scope opens inside a capture, dropped
+        # (torch.cuda.graph synchronises the device before it starts capturing; a capturing stream must not wait on an un-captured one)
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            side_branch._pending.clear()
+        else:
+            side_branch.join_pending()
         if os.environ.get("HIFIHR_WEIGHT_PREP", "1") != "0":
             _WEIGHT_PREP.begin()
         # not inside a hipGraph capture: forked branches of a replayed graph ran SLOWER here (8.03 vs 7.74 ms/step) while the same
@@ -682,6 +708,7 @@ class prepared_weights:
 
     def __exit__(self, *exc):
         _WEIGHT_PREP.end()
+        side_branch.join_pending()
         if _ASYNC_WGRAD.active:
             _ASYNC_WGRAD.active = False
             _ASYNC_WGRAD.join()

@@ -81,6 +81,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._state_sig = None              # (lr, betas, completed steps) the device holds
         self._dyn = None
         self._dyn_host = None
+        self._prepared = False              # prepare_step() ran and the launch / replay it announced has not been noted yet
 
     @property
     def step_count(self):
@@ -91,26 +92,41 @@ class FusedAdam(torch.optim.Optimizer):
         # (a restored snapshot / checkpoint: the device's counter is refreshed by the next prepare_step)
         self._step_count = int(value)
         self._state_sig = None
+        self._prepared = False
 
     _RING = 32        # pinned staging slots for the per-step scalars
 
     def enable_graph_mode(self):
+        """The device-side state is allocated ONCE per optimizer: a graph captured after an earlier enable_graph_mode() has the
+        buffers' addresses baked in, and a second call (a re-capture after a lambda schedule fired) must not free them under it."""
         self.graph_mode = True
+        self._prepared = False
+        self._state_sig = None
         if self._counted and self.flatp.flat.is_cuda:
             if self._lib is None:
                 self._lib = get_lib()
-            self._state = torch.zeros(int(self._lib.c.hifihr_adam_state_bytes()), dtype=torch.uint8, device=self.flatp.flat.device)
-            self._state_sig = None
+            if self._state is None:
+                self._state = torch.zeros(int(self._lib.c.hifihr_adam_state_bytes()), dtype=torch.uint8, device=self.flatp.flat.device)
         else:
             self._counted = False
-        self._dyn = torch.zeros(2, device=self.flatp.flat.device)
-        cuda = self.flatp.flat.is_cuda
-        self._dyn_host = torch.zeros(self._RING, 2).pin_memory() if cuda else torch.zeros(self._RING, 2)
-        self._dyn_events = [None] * self._RING
+        if self._dyn is None:
+            self._dyn = torch.zeros(2, device=self.flatp.flat.device)
+            cuda = self.flatp.flat.is_cuda
+            self._dyn_host = torch.zeros(self._RING, 2).pin_memory() if cuda else torch.zeros(self._RING, 2)
+            self._dyn_events = [None] * self._RING
 
     def disable_graph_mode(self):
         """Back to the eager step (scalars passed by value, step counter advanced by step())."""
         self.graph_mode = False
+        self._prepared = False
+        self._state_sig = None              # whatever the device counter holds is re-uploaded if graph mode comes back
+
+    def note_step_done(self):
+        """The launch / replay announced by the last prepare_step() has been enqueued (GraphedTrainStep.__call__ after graph.replay(),
+        step() for an eager launch in graph mode).  A prepare_step() that finds the previous one un-noted -- the replay never ran:
+        an exception, a caller that prepared twice -- takes its count back and re-uploads the device state, so the host counter
+        (bias correction, state_dict()['step']) stays the number of steps that were actually enqueued."""
+        self._prepared = False
 
     def prepare_step(self):
         """Graph mode: advance the step counter and upload {lr/(1-b1^t), 1/sqrt(1-b2^t)}; call before each replay.
@@ -118,6 +134,10 @@ class FusedAdam(torch.optim.Optimizer):
         writes a slot of its own (ring), and a slot is rewritten only after the copy that read it has completed (event) --
         a single staging buffer let a pending copy pick up a LATER step's scalars when the host ran ahead."""
         g = self.param_groups[0]
+        if self._prepared:                  # the step announced last time was never enqueued
+            self._step_count -= 1
+            self._state_sig = None
+        self._prepared = True
         self._step_count += 1
         b1, b2 = g["betas"]
         if self._counted:
@@ -148,6 +168,13 @@ class FusedAdam(torch.optim.Optimizer):
             self._lib = get_lib()
         require_cuda(self.flatp.flat)
         g = self.param_groups[0]
+        if self.graph_mode:
+            capturing = self.flatp.flat.is_cuda and torch.cuda.is_current_stream_capturing()
+            if not capturing:               # an eager launch in graph mode (the warm-up steps): it consumes its prepare_step()
+                if not self._prepared:
+                    raise RuntimeError("FusedAdam.step() in graph mode without prepare_step(): the device-side step counter / the uploaded "
+                                       "bias corrections would be those of the previous step")
+                self._prepared = False
         if self.graph_mode and self._counted:
             self._lib.adam_step_counted(self.flatp.flat, self.flatp.grad, self.exp_avg, self.exp_avg_sq, self.grad_scale, g["eps"],
                                         g["weight_decay"], self._state)

@@ -147,7 +147,13 @@ def _forward_backward(model, loss_func, optimizer, examples, args, dat_name):
     # (root_xyz, the root-relative ground truth, the NDC camera): four elementwise launches fewer per step
     pre = dat_name != "HO3D" and "joints_rel" in examples and "root_xyz" in examples
     root_xyz = examples["root_xyz"] if pre else examples["joints"][:, args.ROOT, :].unsqueeze(1)
-    kw = {"cam_ndc": examples["cam_ndc"]} if ("cam_ndc" in examples and getattr(model, "accepts_cam_ndc", False)) else {}
+    if pre and "verts" in examples and "verts_rel" not in examples:
+        # a hand-built dict with some of the step terms only: the vertex ground truth must be root-relative like the joints'
+        examples = dict(examples, verts_rel=examples["verts"] - root_xyz)
+    # the batch kernel's NDC camera is scaled with the CACHE's image size (= the size of `imgs` it produced); Model.camera_from_K uses the
+    # model's.  When the two differ the precomputed camera is not the model's own: fall back to camera_from_K(Ks)
+    same_size = getattr(model, "image_size", None) in (None, examples["imgs"].shape[-1])
+    kw = {"cam_ndc": examples["cam_ndc"]} if ("cam_ndc" in examples and getattr(model, "accepts_cam_ndc", False) and same_size) else {}
     outputs = model(dat_name, True, examples["imgs"], Ks=examples["Ps"], root_xyz=root_xyz, **kw)
     ex = dict(examples)
     if pre:
@@ -303,6 +309,7 @@ class GraphedTrainStep:
         else:
             self.opt.prepare_step()
             self.graph.replay()
+            self.opt.note_step_done()
         return self.loss, self.loss_dic
 
 

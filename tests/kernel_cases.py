@@ -864,6 +864,7 @@ def light_split_case(lib, device, B=7, seed=0):
     gen = torch.Generator().manual_seed(seed)
     l = (torch.randn(B, 6, generator=gen) * 1.5)
     l[0, 0] = 1.0; l[min(1, B - 1), 1] = -1.0
+    l[B - 1, 2] = float("nan")                         # a NaN colour stays NaN and passes its gradient, exactly as torch's hardtanh
     l.requires_grad_(True)
     c = torch.nn.functional.hardtanh(l[:, :3]); dd = l[:, 3:]
     gc, gd = torch.randn(B, 3, generator=gen), torch.randn(B, 3, generator=gen)
@@ -871,10 +872,11 @@ def light_split_case(lib, device, B=7, seed=0):
     ld = l.detach().to(device).contiguous()
     oc, od = torch.full((B, 3), 7.0, device=device), torch.full((B, 3), 7.0, device=device)
     lib.light_split_fwd(ld, oc, od)
-    assert torch.equal(oc.cpu(), c.detach()) and torch.equal(od.cpu(), dd.detach().contiguous())
+    same = lambda a, b: bool(((a == b) | (a.isnan() & b.isnan())).all())
+    assert same(oc.cpu(), c.detach()) and bool(oc.cpu()[B - 1, 2].isnan()) and torch.equal(od.cpu(), dd.detach().contiguous())
     gl = torch.full((B, 6), 7.0, device=device)
     lib.light_split_bwd(ld, gc.to(device), gd.to(device), gl)
-    assert torch.equal(gl.cpu(), l.grad)
+    assert same(gl.cpu(), l.grad) and float(gl.cpu()[B - 1, 2]) == float(gc[B - 1, 2])
     lib.light_split_bwd(ld, None, gd.to(device), gl)
     assert float(gl.cpu()[:, :3].abs().max()) == 0.0 and torch.equal(gl.cpu()[:, 3:], gd)
     lib.light_split_bwd(ld, gc.to(device), None, gl)

@@ -259,6 +259,60 @@ def test_graphed_step_matches_eager_step():
         torch.cuda.set_stream(prev)
 
 
+def test_light_branch_is_joined_after_backward_with_a_detached_trunk():
+    """ops.side_branch (the light estimator beside the hand-encoder / MANO chain) with a trunk whose features do NOT require grad
+    (heads-only fine-tuning): the branch's convolutions write their weight gradients straight into the flat gradient buffer on the
+    side stream and no input gradient carries the join back to the main stream -- prepared_weights.__exit__ must join the branch
+    explicitly (ops.side_branch.join_pending), eager AND captured (an un-joined stream fails the capture).  Light-estimator
+    gradients with the branch equal those of the single-stream step; the captured step replays and moves the light estimator."""
+    from hifihr_amd import ops
+    from hifihr_amd.losses import LossFunction
+    from hifihr_amd.optim import FlatParams, FusedAdam
+    from hifihr_amd.traineval import GraphedTrainStep, forward_backward
+    prev = torch.cuda.current_stream()
+    torch.cuda.set_stream(torch.cuda.Stream())
+    try:
+        tables, args, model, ref, ex, ex_cpu = _setup(4, graded=True)
+        enc = model.encode
+        model.encode = lambda images: tuple(t.detach() for t in enc(images))      # low_features / features carry no gradient
+        flat = FlatParams(model); opt = FusedAdam(flat, lr=1e-4)
+        light = [p for p in model.light_estimator.parameters()]
+        _warm_eager(model, opt, ex, args)
+
+        def light_grads(branches):
+            old = ops._BRANCHES
+            ops._BRANCHES = branches
+            try:
+                forward_backward(model, LossFunction(), opt, ex, args)
+                # what Adam would read, on the step's own stream, with no device-wide synchronisation in between
+                g = torch.cat([p.grad.reshape(-1).clone() for p in light])
+            finally:
+                ops._BRANCHES = old
+            torch.cuda.synchronize()
+            return g
+        assert ops._BRANCHES, "the branch is on by default"
+        g_off = light_grads(False)
+        for rep in range(3):
+            g_on = light_grads(True)
+            assert not ops.side_branch._pending, "prepared_weights.__exit__ left a branch un-joined"
+            _check(f"rep {rep} |g_light(branch) - g_light(inline)| / max|g|", float((g_on - g_off).abs().max()) / float(g_off.abs().max()), 1e-4)
+        assert float(g_off.abs().max()) > 0
+        trunk_g = [p.grad for p in model.base_encoder.parameters() if p.grad is not None]
+        assert all(float(t.abs().max()) == 0.0 for t in trunk_g)                    # the detached trunk received nothing
+        # captured: the constructor raises if the capture ends with an un-joined side stream
+        w0 = torch.cat([p.detach().reshape(-1).clone() for p in light])
+        step = GraphedTrainStep(model, LossFunction(), opt, ex, args, warmup=2)
+        for _ in range(2):
+            loss, dic = step()
+        torch.cuda.synchronize()
+        assert np.isfinite(float(loss))
+        w1 = torch.cat([p.detach().reshape(-1) for p in light])
+        assert float((w1 - w0).abs().max()) > 0, "the replayed step did not update the light estimator"
+        step.release()
+    finally:
+        torch.cuda.set_stream(prev)
+
+
 def test_training_step_runs_on_the_hand_written_kernels():
     """What the device executes during one (warmed, eager) training step of BASELINE configs[1] at its batch: kernels of libhifihr.so --
     no Tensile / rocBLAS / hipBLASLt / MIOpen kernel (a silent library fallback would pass every parity test), at most a handful of ATen

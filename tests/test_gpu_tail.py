@@ -309,6 +309,23 @@ def test_hand_encoder_module_matches_torch_restatement(B, in_dim, train):
         assert float((hip.base_layers[1].running_mean.cpu() - ref.base_layers[1].running_mean).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("name", ["he_mano512", "he_nimble1536", "le512", "le32", "mmpool"])
+def test_head_modules_match_reference_fixture(name, train):
+    """The product HandEncoder / LightEstimator / MMPool (csrc/mlp.hip, conv epilogues, csrc/pool.hip) against what the REFERENCE's own
+    classes (network/res_encoder.py:53-167, :169-209, :247-265) computed on the same seeded weights and input
+    (tests/golden/heads.npz, tools/make_golden.gen_heads): every output, the gradient wrt the input and every parameter, the running
+    statistics.  tests/test_oracle_heads.py pins the torch restatements the other tests use to the same file."""
+    import heads_fixture as hf
+    from test_oracle_heads import compare_with_fixture
+    from hifihr_amd import network
+    cls, cargs, _ = hf.CASES[name]
+    torch.manual_seed(0)
+    mod = getattr(network, cls)(*cargs)
+    worst = compare_with_fixture(mod, name, train, "cuda", 2e-4, 2e-3)
+    print(f"{name} train={train}: worst observed / bound = {worst:.3g}")
+
+
 @pytest.mark.parametrize("B,K,n", [(32, 10, 2336), (48, 10, 1024 * 1024 * 3), (16, 10, 256 * 256 * 3)])
 def test_texture_pca_decode(lib, B, K, n):
     """csrc/texpca.hip: the stand-in's 778 x 3 vertex colours and UV-map sizes (NIMBLE's texture maps are 1024^2 [recalled])."""

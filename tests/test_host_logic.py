@@ -354,18 +354,37 @@ def test_adam_device_state_is_uploaded_only_when_the_host_view_changes():
         def copy_(self, image):
             uploads.append(struct.unpack("<dddddii", bytes(image.numpy().tobytes())))
     opt.graph_mode, opt._counted, opt._lib, opt._state = True, True, Stub(), State()
+    def replayed_step():
+        opt.prepare_step(); opt.note_step_done()        # (GraphedTrainStep.__call__: prepare, graph.replay(), note)
     for _ in range(3):
-        opt.prepare_step()
+        replayed_step()
     assert len(uploads) == 1 and uploads[0][0] == 1e-3 and uploads[0][5] == 0 and opt.step_count == 3      # (lr, ..., completed steps = 0)
     opt.param_groups[0]["lr"] = 5e-4                    # MultiStepLR fires
-    opt.prepare_step(); opt.prepare_step()
+    replayed_step(); replayed_step()
     assert len(uploads) == 2 and uploads[1][0] == 5e-4 and uploads[1][5] == 3
     assert abs(uploads[1][3] - 0.9 ** 3) < 1e-15 and abs(uploads[1][4] - 0.999 ** 3) < 1e-15                # the running products beta^t
     opt.step_count = 40                                 # a restored snapshot / checkpoint
-    opt.prepare_step()
+    replayed_step()
     assert len(uploads) == 3 and uploads[2][5] == 40 and opt.step_count == 41
+    replayed_step()
+    assert len(uploads) == 3 and opt.step_count == 42
+    # a prepared step whose replay never ran (an exception in between, a caller that prepares twice): the next prepare_step takes the
+    # count back and re-uploads -- the host counter stays the number of steps enqueued, the device counter is put right
     opt.prepare_step()
-    assert len(uploads) == 3
+    assert opt.step_count == 43
+    opt.prepare_step()
+    assert opt.step_count == 43 and len(uploads) == 4 and uploads[3][5] == 42
+    opt.note_step_done()
+    replayed_step()
+    assert len(uploads) == 4 and opt.step_count == 44
+    # an eager launch in graph mode must have been prepared
+    import pytest
+    opt.flatp.flat.data = opt.flatp.flat.data                      # (CPU tensors: step() stops at require_cuda before any launch)
+    with pytest.raises(Exception):
+        opt.step()
+    # leaving graph mode forgets what the device holds
+    opt.disable_graph_mode()
+    assert opt._state_sig is None and not opt._prepared
 
 
 def test_staging_ring_releases_its_slots_in_groups():

@@ -11,7 +11,7 @@ output vectors it writes are committed.  What is imported from the reference, un
   network/efficientnet_pt     EfficientNet.from_name('efficientnet-b3')  -> effnet_b3_small.npz, state_dict_names.json
   utils/handutils.py          get_affine_transform, transform_img  -> data_path.npz
   (from source, see _extract_functions / _extract_defs: loss helpers, align_w_scale, HO3D2Frei / Frei2HO3D, and the
-   HandEncoder / LightEstimator / MMPool classes for their state-dict names)
+   HandEncoder / LightEstimator / MMPool classes: state-dict names, and outputs + gradients on seeded weights -> heads.npz)
   losses.py                   LossFunction.__call__ (:226-453) + utils/perceptual_loss.py PerceptualLoss, from source
                               (torchvision's VGG19 replaced by a seeded VGG19-shaped stack)        -> loss_dict.npz
   models_res_nimble.py        the resolve / re_sil / maskRGBs lines (:209-220) and get_ndc_fx_fy_cx_cy (:228-235) -> model_tail.npz
@@ -32,7 +32,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("HIFIHR_REFERENCE", "/root/reference")
-OUT = os.path.join(REPO, "tests", "golden")
+OUT = os.environ.get("HIFIHR_GOLDEN_OUT") or os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, REPO)
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(REPO, "tools"))
@@ -265,6 +265,7 @@ def main():
     gen_losses()
     gen_effnet()
     gen_state_dict_names()
+    gen_heads()
     gen_data_path()
     gen_eval()
     gen_loss_dict()
@@ -352,6 +353,37 @@ def gen_state_dict_names():
     with open(os.path.join(OUT, "state_dict_names.json"), "w") as fh:
         json.dump(out, fh)
     print("state dict names", {k: len(v["state"]) for k, v in out.items()})
+
+
+def gen_heads():
+    """tests/golden/heads.npz: the reference's HandEncoder / LightEstimator / MMPool (network/res_encoder.py:53-167, :169-209, :247-265),
+    executed from source (the module imports torchvision / timm at its top), on the weights and inputs of tests/heads_fixture.py:
+    every output, the (sampled) gradients of a fixed random projection wrt the input and every parameter, the advanced running
+    statistics -- train and eval mode."""
+    import io
+    import contextlib
+    from torch import nn
+    from torch.nn import init
+    import torch.nn.functional as F
+    import heads_fixture as hf
+    ns = {"torch": torch, "nn": nn, "init": init, "F": F}
+    _extract_defs(os.path.join(REF, "network", "res_encoder.py"), {"HandEncoder", "LightEstimator", "MMPool", "weights_init"}, ns)
+    out = {}
+    for name, (cls, cargs, _) in hf.CASES.items():
+        for train in (True, False):
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = ns[cls](*cargs)
+            hf.fill_state(m, name)
+            outs, grads, bufs = hf.run_case(m, name, train)
+            tag = f"{name}/{'train' if train else 'eval'}"
+            for k, v in outs.items():
+                out[f"{tag}/out/{k}"] = v.detach().numpy()
+            for k, v in grads.items():
+                out[f"{tag}/grad/{k}"] = hf.sample(v)
+            for k, v in bufs.items():
+                out[f"{tag}/buf/{k}"] = v.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "heads.npz"), **out)
+    print("heads ok", len(out), "arrays,", sum(v.size for v in out.values()), "values")
 
 
 def gen_data_path():
@@ -591,11 +623,18 @@ def gen_model_tail():
 
 if __name__ == "__main__":
     only = os.environ.get("GOLDEN_ONLY")
-    if only in ("names", "data", "eval", "loss_dict", "model_tail", "ho3d"):
+    if only in ("names", "heads", "data", "eval", "loss_dict", "model_tail", "ho3d"):
         os.makedirs(OUT, exist_ok=True)
         install_standins()
-        {"names": gen_state_dict_names, "data": gen_data_path, "eval": gen_eval, "loss_dict": gen_loss_dict,
+        {"names": gen_state_dict_names, "heads": gen_heads, "data": gen_data_path, "eval": gen_eval, "loss_dict": gen_loss_dict,
          "model_tail": gen_model_tail, "ho3d": gen_ho3d_path}[only]()
+    elif only == "mano_real":                   # the real tables (container only; the output is derived MANO data: never committed)
+        os.makedirs(OUT, exist_ok=True)
+        install_standins()
+        m = types.ModuleType("utils.mano.webuser.smpl_handpca_wrapper_HAND_only")
+        m.ready_arguments = _ready_arguments
+        sys.modules[m.__name__] = m
+        gen_mano("mano_real.npz", load_mano_pkl(os.environ.get("HIFIHR_MANO_PKL") or os.path.join(REF, "data", "MANO_RIGHT.pkl")), seed=1)
     elif os.environ.get("GOLDEN_ONLY") == "losses":
         os.makedirs(OUT, exist_ok=True)
         gen_losses()
