@@ -55,6 +55,9 @@ def parse():
                     "short trial); 2: force the N > 1 form (one graph, then all-reduce + Adam); 3: force the segmented form (backward as one graph "
                     "launch per trunk segment, each bucket exchanged beside the next segment)")
     ap.add_argument("--cpu-batch", type=int, default=32, help="sample size of the CPU baseline (images; SURVEY 8d: the batch of 32)")
+    ap.add_argument("--cpu-steps", default="1,3", help="warm-up,timed oracle steps of the CPU baseline.  SURVEY 8d names 3,10: at ~21 s per B = 32 "
+                    "step on the GPU box's host that is ~4.5 minutes, against the contract's bounded sample (10-30 s of CPU work) and a default "
+                    "run that ends within minutes; the default times 3 steps after 1 and reports their spread")
     ap.add_argument("--cache", type=int, default=256, help="synthetic samples in the device-resident uint8 cache")
     ap.add_argument("--aa", type=int, default=3, help="renderer anti-aliasing factor (config 5 also reports aa = 1)")
     return ap.parse_args()
@@ -155,9 +158,10 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(args_ns, examples, tables, nimg, render_frames=8):
-    """The oracle training step (oracle/model_oracle.py) on the host cores, on `nimg` images of the same batch: one untimed
-    warm-up step, then three timed steps (B = 32, warm-up + timed iterations, all host cores) -- and the renderer
+def cpu_baseline(args_ns, examples, tables, nimg, render_frames=8, steps=(1, 3)):
+    """The oracle training step (oracle/model_oracle.py) on the host cores, on `nimg` images of the same batch: `steps[0]` untimed
+    warm-up steps, then `steps[1]` timed ones, each timed on its own so the line carries their spread (B = 32, all host
+    cores, 3 + 10 iterations = `--cpu-steps 3,10`; the default 1 + 3 keeps the default run within minutes) -- and the renderer
     alone (oracle/render_oracle.render: the C rasteriser of oracle/raster_oracle.c + torch shading / resolve), forward and
     forward + backward, on `render_frames` meshes of the batch, as milliseconds per frame."""
     from oracle import render_oracle as ro
@@ -166,16 +170,21 @@ def cpu_baseline(args_ns, examples, tables, nimg, render_frames=8):
     model = OracleModel(tables).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-6)
     ex = {k: (v[:nimg].detach().cpu() if torch.is_tensor(v) else v) for k, v in examples.items()}
-    oracle_step(model, ex, args_ns, opt)                   # warm-up (allocator, OpenMP pools, oneDNN primitives)
-    t0, nstep = time.time(), 0
-    while nstep < 3:
+    nwarm, ntimed = max(1, int(steps[0])), max(1, int(steps[1]))
+    for _ in range(nwarm):
+        oracle_step(model, ex, args_ns, opt)               # warm-up (allocator, OpenMP pools, oneDNN primitives)
+    per = []
+    for _ in range(ntimed):
+        t0 = time.time()
         oracle_step(model, ex, args_ns, opt)
-        nstep += 1
-    dt = time.time() - t0
+        per.append(time.time() - t0)
+    dt, nstep = sum(per), len(per)
     out = {"value": nimg * nstep / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model_name(),
-           "sample": f"1 warm-up + {nstep} timed oracle training steps (torch-CPU encoder and heads, oracle MANO LBS, the C rasteriser of "
+           "step_s": [round(t, 3) for t in per], "spread": round((max(per) - min(per)) / (dt / nstep), 4),
+           "sample": f"{nwarm} warm-up + {nstep} timed oracle training steps (torch-CPU encoder and heads, oracle MANO LBS, the C rasteriser of "
                      f"oracle/raster_oracle.c (OpenMP over sample rows, all host threads) + torch shading / losses, torch Adam) on {nimg} images "
-                     f"of the same synthetic batch, {dt:.1f} s timed"}
+                     f"of the same synthetic batch, {dt:.1f} s timed, per-step times in `step_s` ((max - min) / mean = `spread`)"
+                     + ("; SURVEY 8d's 3 + 10 would be ~4.5 min of CPU work in the default run: `--cpu-steps 3,10` runs it" if (nwarm, nstep) != (3, 10) else "")}
     # the renderer alone, on the ground-truth meshes of the first frames of the batch (camera space, the size the hands have on screen)
     verts = ex["verts"][:render_frames].float()
     nf = verts.shape[0]
@@ -251,11 +260,14 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
     from collections import Counter
     table = {}
 
-    def add(name, per_step, us, flop, nbytes, what=""):
-        e = table.setdefault(name, {"launches_per_step": 0.0, "us_per_step": 0.0, "flop_per_step": 0.0, "compulsory_bytes_per_step": 0.0,
-                                    "shapes": []})
+    def add(name, per_step, us, flop, nbytes, what="", useful=None):
+        """flop: what the kernel EXECUTES; useful: the part of it that lands in rows carrying data (the TN products of the mosaic layers
+        walk the 480 allocated rows of which 450 hold tiles: the padding rows are zeros) -- defaults to flop."""
+        e = table.setdefault(name, {"launches_per_step": 0.0, "us_per_step": 0.0, "flop_per_step": 0.0, "useful_flop_per_step": 0.0,
+                                    "compulsory_bytes_per_step": 0.0, "shapes": []})
         e["launches_per_step"] += per_step; e["us_per_step"] += us * per_step
         e["flop_per_step"] += flop * per_step; e["compulsory_bytes_per_step"] += nbytes * per_step
+        e["useful_flop_per_step"] += (flop if useful is None else useful) * per_step
         e["shapes"].append({"shape": what, "launches_per_step": per_step, "us": round(us, 1), "TFLOPs": round(flop / us / 1e6, 1)})
     for (geom, direction), cnt in Counter(ops.PROFILE.conv_log).items():
         per_step = cnt / nprof
@@ -271,7 +283,8 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
             us = hip_us(lambda: lib.wino4_bwd_gemm_pair(V2, U2, M2, Vx, Yt, dU, N_, H_, W_, C_, K_, parts))
             add("bgemm_nt_tn_pair_kernel", per_step, us, 2.0 * P_ * (Tc + T_) * C_ * K_,
                 4.0 * P_ * ((Tc * K_ + C_ * K_ + Tc * C_) + (T_ * C_ + T_ * K_ + parts * K_ * C_)),
-                f"{P_} x ([{Tc} x {K_}] . [{C_} x {K_}]^T  +  [{T_} x {K_}]^T . [{T_} x {C_}], {parts} slab(s))")
+                f"{P_} x ([{Tc} x {K_}] . [{C_} x {K_}]^T  +  [{T_} x {K_}]^T . [{T_} x {C_}], {parts} slab(s))",
+                useful=2.0 * P_ * (Tc + Tc) * C_ * K_)
             continue
         if direction in ("gemm", "gemm-tn"):
             _, N_, H_, W_, C_, K_, m_ = geom                    # m_: Winograd output-tile edge (2: 16 positions, 4: 36)
@@ -300,7 +313,8 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
                     dU = torch.zeros(16 * K_ * C_, device=dev)
                     us = hip_us(lambda: lib.wino_wgrad_gemm(V, Y, dU, N_, H_, W_, C_, K_))
                 add(name, per_step, us, 2.0 * P_ * T_ * C_ * K_, 4.0 * P_ * (T_ * C_ + T_ * K_ + max(parts, 1) * K_ * C_),
-                    f"{P_} x [{T_} x {K_}]^T . [{T_} x {C_}], {max(parts, 1)} slab(s)")
+                    f"{P_} x [{T_} x {K_}]^T . [{T_} x {C_}], {max(parts, 1)} slab(s)",
+                    useful=2.0 * P_ * lib.wino_tiles_computed(N_, H_, W_, m_) * C_ * K_)
             continue
         N_, H_, W_, C_, K_, R_, S_, st_, pd_ = geom
         if direction in ("fwd-wino2", "dgrad-wino2"):          # conv_wino2_kernel: one launch, 2 x 16 x (tiles x 64 x 64) executed products
@@ -361,6 +375,9 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
                      "entry_avg_us": entry_us / n, "entry_us_per_step": entry_us,
                      "instep_launches_per_step": hit[0] if hit else None,
                      "executed_flop_per_launch": e["flop_per_step"] / n,
+                     # rows of zero padding are executed, not useful: frac_useful = frac x useful_flop_frac
+                     "useful_flop_frac": e["useful_flop_per_step"] / max(e["flop_per_step"], 1e-9),
+                     "frac_useful": ach / MFMA_PEAK_TF * e["useful_flop_per_step"] / max(e["flop_per_step"], 1e-9),
                      "compulsory_bytes_per_launch": e["compulsory_bytes_per_step"] / n, "shapes": e["shapes"]}
     return out
 
@@ -710,11 +727,13 @@ def main():
             extra["roofline"] = dict({k: v for k, v in dom.items() if k != "shapes"},
                                      flops="the products the kernel executes (2 M N K per Winograd GEMM), per shape x launches per step")
             extra["roofline_kernels"] = {k: {kk: v[kk] for kk in ("achieved", "frac", "launches_per_step", "avg_us", "us_per_step", "timing", "entry_avg_us",
-                                                                   "entry_us_per_step", "traffic", "traffic_ratio", "compulsory_bytes_per_launch", "shapes")}
+                                                                   "entry_us_per_step", "traffic", "traffic_ratio", "compulsory_bytes_per_launch", "useful_flop_frac", "frac_useful", "shapes")}
                                          for k, v in roofs.items()}
             tot_f = sum(v["executed_flop_per_launch"] * v["launches_per_step"] for v in roofs.values())
             tot_us = sum(v["us_per_step"] for v in roofs.values())
-            extra["conv_path"] = {"executed_flop_per_step": tot_f, "mfma_kernel_us_per_step": tot_us,
+            tot_u = sum(v["executed_flop_per_launch"] * v["useful_flop_frac"] * v["launches_per_step"] for v in roofs.values())
+            extra["conv_path"] = {"executed_flop_per_step": tot_f, "useful_flop_per_step": tot_u, "frac_useful": tot_u / (tot_us * 1e-6) / 1e12 / MFMA_PEAK_TF,
+                                  "mfma_kernel_us_per_step": tot_us,
                                   "achieved": tot_f / (tot_us * 1e-6) / 1e12, "frac": tot_f / (tot_us * 1e-6) / 1e12 / MFMA_PEAK_TF,
                                   "note": "all MFMA kernels of the convolution path together (direct, Winograd GEMMs, weight gradients)"}
 
@@ -750,7 +769,7 @@ def main():
                            "allreduce_us_per_bucket": bucket_us}
         out.update(extra)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args_ns, examples, tables, a.cpu_batch)
+            out["cpu_baseline"] = cpu_baseline(args_ns, examples, tables, a.cpu_batch, steps=tuple(int(x) for x in a.cpu_steps.split(",")))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -119,6 +119,7 @@ class HifihrLib:
         c.hifihr_bn_relu_maxpool_supported.argtypes = [c_int] * 4
         c.hifihr_bn_relu_maxpool_fwd.argtypes = [_c_float_p] * 4 + [c_int] * 4 + [c_float, c_float, _c_float_p, c_void_p] + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_bn_relu_maxpool_bwd.argtypes = [_c_float_p, c_void_p] + [_c_float_p] * 5 + [c_int] * 4 + [_c_float_p] * 4 + [c_void_p]
+        c.hifihr_bn_relu_maxpool_bwd_y.argtypes = [_c_float_p, _c_float_p, c_void_p] + [_c_float_p] * 5 + [c_int] * 4 + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_conv2d_bwd_weight.argtypes = [_c_float_p] * 3 + ci + [c_void_p]
         c.hifihr_conv2d_bwd_weight_ws.argtypes = [_c_float_p] * 3 + ci + [c_void_p, c_size_t, c_void_p]
         c.hifihr_conv2d_wgrad_workspace_bytes.argtypes = ci
@@ -381,6 +382,11 @@ class HifihrLib:
         self.check(self.c.hifihr_bn_relu_maxpool_fwd(_fp(x), _fp(stats), _fp(gamma), _fp(beta), N, H, W, C, c_float(eps), c_float(momentum),
                                                      _fp(pooled), c_void_p(tap.data_ptr()), _fp(save_mean), _fp(save_invstd),
                                                      _fp(running_mean), _fp(running_var), _stream_of(x)), "hifihr_bn_relu_maxpool_fwd")
+
+    def bn_relu_maxpool_bwd_y(self, gy, pooled, tap, x, save_mean, save_invstd, gamma, beta, N, H, W, C, red, dx, dgamma_acc, dbeta_acc):
+        self.check(self.c.hifihr_bn_relu_maxpool_bwd_y(_fp(gy), _fp(pooled), c_void_p(tap.data_ptr()), _fp(x), _fp(save_mean), _fp(save_invstd),
+                                                       _fp(gamma), _fp(beta), N, H, W, C, _fp(red), _fp(dx), _fp(dgamma_acc), _fp(dbeta_acc),
+                                                       _stream_of(gy)), "hifihr_bn_relu_maxpool_bwd_y")
 
     def bn_relu_maxpool_bwd(self, gy, tap, x, save_mean, save_invstd, gamma, beta, N, H, W, C, red, dx, dgamma_acc, dbeta_acc):
         self.check(self.c.hifihr_bn_relu_maxpool_bwd(_fp(gy), c_void_p(tap.data_ptr()), _fp(x), _fp(save_mean), _fp(save_invstd), _fp(gamma),

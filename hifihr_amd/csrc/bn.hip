@@ -655,6 +655,76 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __
   reduce_and_add(mp, C, s, q, lds, red);
 }
 
+// The same reduction walked over the POOLED grid (round 6): dy of the pool's backward is non-zero only at a window's winning tap, and only
+// where the ReLU passed -- i.e. where the pooled output z = max relu(x sc + sh) is > 0 -- so
+//   sum_m g_m = sum_o gy_o [z_o > 0],   sum_m g_m xhat_m = sum_o gy_o [z_o > 0] xhat(winner of o)
+// and the winner's xhat follows from z itself: z = gamma xhat + beta  =>  xhat = (z - beta) / gamma.  The pass then reads gy and the pooled
+// output (2 x 25.7 MB at B = 32) instead of x, gy and the taps of every input pixel (215 MB by the counters: 43.7 us of the step).  The
+// recovered xhat carries the rounding of z (|beta| eps / |gamma|): channels whose |gamma| is below kGammaGather fetch the winner's x
+// through the saved tap instead and use (x - mean) invstd like the pass above (exact; rare: batch-norm scales sit near 1).
+constexpr float kGammaGather = 1e-3f;
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_y_kernel(const float* __restrict__ gy, const float* __restrict__ ypool,
+                                                                  const unsigned char* __restrict__ tap, const float* __restrict__ x,
+                                                                  const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, StemPool g,
+                                                                  int C, float* __restrict__ red) {
+  __shared__ float4 lds[2][256];
+  const BnMap mp = bn_map(C);
+  float4 s[kMaxNG], q[kMaxNG];
+#pragma unroll
+  for (int j = 0; j < kMaxNG; ++j) { s[j] = make_float4(0.f, 0.f, 0.f, 0.f); q[j] = s[j]; }
+  if (mp.active) {
+    const int cb = mp.cg0 * 4;
+    const float4 mu = *reinterpret_cast<const float4*>(save_mean + cb), is = *reinterpret_cast<const float4*>(save_invstd + cb);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + cb), be = *reinterpret_cast<const float4*>(beta + cb);
+    const bool far[4] = {fabsf(ga.x) >= kGammaGather, fabsf(ga.y) >= kGammaGather, fabsf(ga.z) >= kGammaGather, fabsf(ga.w) >= kGammaGather};
+    const float rg[4] = {far[0] ? 1.0f / ga.x : 0.f, far[1] ? 1.0f / ga.y : 0.f, far[2] ? 1.0f / ga.z : 0.f, far[3] ? 1.0f / ga.w : 0.f};
+    const bool all_far = far[0] && far[1] && far[2] && far[3];
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w}, bev[4] = {be.x, be.y, be.z, be.w};
+    auto accum = [&](const float4& gr4, const float4& z4, long o) {
+      const float gr[4] = {gr4.x, gr4.y, gr4.z, gr4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w};
+      float xh[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xh[k] = (z[k] - bev[k]) * rg[k];
+      if (!all_far) {                                         // (per thread: its four channels; uniform over the rows it walks)
+        const unsigned ou = (unsigned)o;
+        const unsigned r2 = ou / (unsigned)g.OW;
+        const int ow = (int)(ou - r2 * (unsigned)g.OW);
+        const int n = (int)(r2 / (unsigned)g.OH), oh = (int)(r2 - (unsigned)n * (unsigned)g.OH);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (!far[k]) {
+            const int t = tap[(size_t)o * C + cb + k];
+            const int ih = oh * 2 - 1 + t / 3, iw = ow * 2 - 1 + t % 3;
+            xh[k] = (x[(((size_t)n * g.H + ih) * g.W + iw) * C + cb + k] - muv[k]) * isv[k];
+          }
+      }
+      float sv[4] = {0.f, 0.f, 0.f, 0.f}, qv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (z[k] > 0.f) { sv[k] = gr[k]; qv[k] = gr[k] * xh[k]; }
+      s[0].x += sv[0]; s[0].y += sv[1]; s[0].z += sv[2]; s[0].w += sv[3];
+      q[0].x += qv[0]; q[0].y += qv[1]; q[0].z += qv[2]; q[0].w += qv[3];
+    };
+    const long Mo = (long)g.N * g.OH * g.OW;
+    const long stride = (long)gridDim.x * mp.RL;
+    long o = (long)blockIdx.x * mp.RL + mp.rl;
+    for (; o + (kBnUnroll - 1) * stride < Mo; o += kBnUnroll * stride) {
+      float4 gr[kBnUnroll], z[kBnUnroll];
+#pragma unroll
+      for (int u = 0; u < kBnUnroll; ++u) {
+        gr[u] = *reinterpret_cast<const float4*>(gy + (size_t)(o + u * stride) * C + cb);
+        z[u] = *reinterpret_cast<const float4*>(ypool + (size_t)(o + u * stride) * C + cb);
+      }
+#pragma unroll
+      for (int u = 0; u < kBnUnroll; ++u) accum(gr[u], z[u], o + u * stride);
+    }
+    for (; o < Mo; o += stride)
+      accum(*reinterpret_cast<const float4*>(gy + (size_t)o * C + cb), *reinterpret_cast<const float4*>(ypool + (size_t)o * C + cb), o);
+  }
+  reduce_and_add(mp, C, s, q, lds, red);
+}
+
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ tap,
                                                                const float* __restrict__ x, const float* __restrict__ save_mean,
                                                                const float* __restrict__ save_invstd, const float* __restrict__ gamma,
@@ -846,12 +916,17 @@ hipError_t launch_bn_relu_maxpool_fwd(const float* x, float* stats, const float*
 
 hipError_t launch_bn_relu_maxpool_bwd(const float* gy, const unsigned char* tap, const float* x, const float* save_mean,
                                       const float* save_invstd, const float* gamma, const float* beta, int N, int H, int W, int C, float* red,
-                                      float* dx, float* dgamma_acc, float* dbeta_acc, hipStream_t st) {
+                                      float* dx, float* dgamma_acc, float* dbeta_acc, hipStream_t st, const float* pooled) {
   if (!bn_pool_ok(N, H, W, C)) return hipErrorInvalidValue;
   const StemPool g{N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
   const long M = (long)N * H * W;
-  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(bn_reduce_grid(M, C)), dim3(256), 0, st, gy, tap, x, save_mean, save_invstd, gamma, beta, g,
-                     C, red);
+  // pooled != null (C <= 1024: one channel group per thread): the reduction over the pooled grid (bn_pool_bwd_reduce_y_kernel)
+  if (pooled != nullptr && C <= 1024)
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_y_kernel, dim3(bn_reduce_grid((long)N * g.OH * g.OW, C)), dim3(256), 0, st, gy, pooled, tap, x, save_mean,
+                       save_invstd, gamma, beta, g, C, red);
+  else
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(bn_reduce_grid(M, C)), dim3(256), 0, st, gy, tap, x, save_mean, save_invstd, gamma, beta, g,
+                       C, red);
   hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(bn_grid(M, C, true)), dim3(256), 0, st, gy, tap, x, save_mean, save_invstd, gamma, beta, red,
                      g, C, dx, dgamma_acc, dbeta_acc);
   return hipGetLastError();

@@ -679,6 +679,17 @@ int hifihr_bn_relu_maxpool_bwd(const float* gy, const unsigned char* tap, const 
   return HIFIHR_OK;
 }
 
+int hifihr_bn_relu_maxpool_bwd_y(const float* gy, const float* pooled, const unsigned char* tap, const float* x, const float* save_mean,
+                                 const float* save_invstd, const float* gamma, const float* beta, int N, int H, int W, int C, float* red_scratch,
+                                 float* dx, float* dgamma_acc, float* dbeta_acc, void* stream) {
+  if (!gy || !pooled || !tap || !x || !save_mean || !save_invstd || !gamma || !beta || !red_scratch || !dx ||
+      !hifihr::bn_relu_maxpool_supported(N, H, W, C))
+    return fail(HIFIHR_EINVAL, "hifihr_bn_relu_maxpool_bwd_y: bad argument (C % 4 == 0, C <= 512, H, W >= 2)");
+  HIP_TRY(hifihr::launch_bn_relu_maxpool_bwd(gy, tap, x, save_mean, save_invstd, gamma, beta, N, H, W, C, red_scratch, dx, dgamma_acc,
+                                             dbeta_acc, (hipStream_t)stream, pooled));
+  return HIFIHR_OK;
+}
+
 static int dw_ok(int N, int H, int W, int C, int OH, int OW, int K, int stride, int pt, int pl) {
   return N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && OH > 0 && OW > 0 && (K == 3 || K == 5) && (stride == 1 || stride == 2) && pt >= 0 && pl >= 0;
 }

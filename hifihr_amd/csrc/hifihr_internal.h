@@ -214,7 +214,7 @@ hipError_t launch_bn_relu_maxpool_fwd(const float* x, float* stats, const float*
                                       float* running_mean, float* running_var, hipStream_t st);
 hipError_t launch_bn_relu_maxpool_bwd(const float* gy, const unsigned char* tap, const float* x, const float* save_mean,
                                       const float* save_invstd, const float* gamma, const float* beta, int N, int H, int W, int C, float* red,
-                                      float* dx, float* dgamma_acc, float* dbeta_acc, hipStream_t st);
+                                      float* dx, float* dgamma_acc, float* dbeta_acc, hipStream_t st, const float* pooled = nullptr);
 // ws (may be NULL): scratch of conv_wgrad_workspace_bytes(g) bytes (any contents) for the shapes whose weight gradient is summed from
 // per-workgroup slabs (layer 1, stem); without it those shapes use library-owned scratch or, inside a stream capture, the atomics kernel
 size_t conv_wgrad_workspace_bytes(const ConvGeom& g);

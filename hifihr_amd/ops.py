@@ -453,6 +453,7 @@ class side_branch:
 
 
 _BRANCHES = os.environ.get("HIFIHR_BRANCHES", "1") != "0"
+_STEM_REDUCE_Y = os.environ.get("HIFIHR_STEM_REDUCE_Y", "1") != "0"       # the stem's batch-norm backward reduction over the pooled grid
 _GEMM_PAIR = os.environ.get("HIFIHR_GEMM_PAIR", "1") != "0"
 # the same for the 64 -> 64 layers (ResNet layer 1): Winograd F(2x2) data gradient + pixel-reduction weight gradient in one launch
 _C64_PAIR = os.environ.get("HIFIHR_C64_PAIR", "1") != "0"
@@ -1421,13 +1422,15 @@ class _BNReluMaxPool(torch.autograd.Function):
         PROFILE.bracket("bn_pool_fwd", lambda: lib.bn_relu_maxpool_fwd(x, stats, gamma, beta, N, H, W, C, eps, momentum, y, tap, save_mean,
                                                                       save_invstd, running_mean, running_var))
         _ZERO_POOL.release(stats)
-        ctx.save_for_backward(x, tap, gamma, beta, save_mean, save_invstd)
+        # the pooled output itself goes back into backward: the batch-norm reduction walks IT instead of every input pixel
+        # (hifihr_bn_relu_maxpool_bwd_y; HIFIHR_STEM_REDUCE_Y=0: the pass over x).  It is the next convolution's saved input anyway.
+        ctx.save_for_backward(x, tap, gamma, beta, save_mean, save_invstd, y if _STEM_REDUCE_Y else None)
         ctx.gamma_param, ctx.beta_param = gamma, beta
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, tap, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        x, tap, gamma, beta, save_mean, save_invstd, y = ctx.saved_tensors
         lib = get_lib()
         N, C, H, W = x.shape
         gy = gy.contiguous(memory_format=_CL)
@@ -1435,8 +1438,12 @@ class _BNReluMaxPool(torch.autograd.Function):
         red = _ZERO_POOL.acquire(lib.bn_stats_floats(C), x.device)
         dg_t, dg_ret = _bn_acc_target(ctx.gamma_param, C, x.device)
         db_t, db_ret = _bn_acc_target(ctx.beta_param, C, x.device)
-        PROFILE.bracket("bn_pool_bwd", lambda: lib.bn_relu_maxpool_bwd(gy, tap, x, save_mean, save_invstd, gamma, beta, N, H, W, C, red, dx,
-                                                                      dg_t, db_t))
+        if y is not None:
+            PROFILE.bracket("bn_pool_bwd", lambda: lib.bn_relu_maxpool_bwd_y(gy, y, tap, x, save_mean, save_invstd, gamma, beta, N, H, W, C, red, dx,
+                                                                            dg_t, db_t))
+        else:
+            PROFILE.bracket("bn_pool_bwd", lambda: lib.bn_relu_maxpool_bwd(gy, tap, x, save_mean, save_invstd, gamma, beta, N, H, W, C, red, dx,
+                                                                          dg_t, db_t))
         _ZERO_POOL.release(red)
         if dg_ret is None:
             _grad_ready(ctx.gamma_param)

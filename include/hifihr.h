@@ -527,6 +527,13 @@ int hifihr_bn_relu_maxpool_fwd(const float* x_d, float* stats_d, const float* ga
 int hifihr_bn_relu_maxpool_bwd(const float* pooled_grad_d, const unsigned char* tap_d, const float* x_d, const float* save_mean_d,
                                const float* save_invstd_d, const float* gamma_d, const float* beta_d, int N, int H, int W, int C,
                                float* red_scratch_d, float* dx_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
+/* The same backward with the forward's pooled OUTPUT handed back (pooled_d [N][OH][OW][C]): the batch-norm reduction then walks the pooled
+ * grid -- the pool's gradient lives at the winning taps only and the winner's normalised value follows from the pooled value itself,
+ * xhat = (z - beta) / gamma (channels with |gamma| < 1e-3 fetch the winner's x through tap_d) -- a quarter of the bytes of the pass over
+ * every input pixel.  Results equal hifihr_bn_relu_maxpool_bwd's to the rounding of the sums. */
+int hifihr_bn_relu_maxpool_bwd_y(const float* pooled_grad_d, const float* pooled_d, const unsigned char* tap_d, const float* x_d,
+                                 const float* save_mean_d, const float* save_invstd_d, const float* gamma_d, const float* beta_d, int N, int H, int W,
+                                 int C, float* red_scratch_d, float* dx_d, float* dgamma_acc_d, float* dbeta_acc_d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Depthwise convolution (groups == channels), NHWC fp32, k = 3 or 5, TensorFlow-style asymmetric zero padding.

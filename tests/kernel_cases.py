@@ -736,6 +736,8 @@ def bn_relu_maxpool_case(lib, device, N, H, W, C, seed=0):
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     x = torch.randn(N, C, H, W, generator=gen) * 1.5 + 0.3
     gamma = 1 + 0.1 * torch.randn(C, generator=gen); beta = 0.1 * torch.randn(C, generator=gen) - 0.3     # plenty of ReLU zeros: ties
+    gamma[1] = 2e-4; beta[1] = 0.05                      # a near-zero scale (positive shift: every tap passes the ReLU)
+    gamma[2] = -0.8                                      # a negative scale: the winner is the SMALLEST x of the window
     rm0, rv0 = torch.randn(C, generator=gen) * 0.1, 1 + 0.1 * torch.rand(C, generator=gen)
     xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     rm, rv = rm0.clone(), rv0.clone()
@@ -783,6 +785,17 @@ def bn_relu_maxpool_case(lib, device, N, H, W, C, seed=0):
     assert float((dx.cpu() - refdx).abs().max()) <= 2e-4 * float(refdx.abs().max()) + 1e-7, "fused stem dx vs torch"
     assert float((dg.cpu() - 0.5 - gr.grad).abs().max()) <= 2e-4 * float(gr.grad.abs().max()) + 1e-5
     assert float((db.cpu() + 0.25 - br.grad).abs().max()) <= 2e-4 * float(br.grad.abs().max()) + 1e-5
+    # the same backward with the reduction walked over the POOLED grid (hifihr_bn_relu_maxpool_bwd_y: xhat of a window's winner recovered
+    # from the pooled value; channels with |gamma| < 1e-3 -- channel 1 of this case -- gather the winner's x through the tap)
+    dx3 = torch.full((N, H, W, C), 7.0, device=device)
+    dg3 = torch.full((C,), 0.5, device=device); db3 = torch.full((C,), -0.25, device=device)
+    lib.bn_relu_maxpool_bwd_y(gyd, y, tap, xd, sm, si, gd, bd, N, H, W, C, red, dx3, dg3, db3)
+    assert float(red.abs().max()) == 0.0, "bn_relu_maxpool_bwd_y must leave the slots and arrival counters zeroed"
+    assert float((dx3 - dx).abs().max()) <= 5e-6 * scale + 1e-9, "pooled-grid reduction vs the pass over x (dx)"
+    assert float((dg3 - dg).abs().max()) <= 2e-5 * float(dg2.abs().max()) + 1e-6
+    assert float((db3 - db).abs().max()) <= 2e-5 * float(db2.abs().max()) + 1e-6
+    assert float((dx3.cpu() - refdx).abs().max()) <= 2e-4 * float(refdx.abs().max()) + 1e-7, "pooled-grid stem dx vs torch"
+    assert float((dg3.cpu() - 0.5 - gr.grad).abs().max()) <= 2e-4 * float(gr.grad.abs().max()) + 1e-5
 
 
 def maxpool_case(lib, device, N, H, W, C, seed=0, ties=False, ksp=(3, 2, 1)):
