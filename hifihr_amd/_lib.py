@@ -216,6 +216,7 @@ class HifihrLib:
         c.hifihr_wino_wgrad_parts.argtypes = [c_int] * 5
         c.hifihr_wino_wgrad_gemm_parts.argtypes = [_c_float_p] * 3 + [c_int] * 6 + [c_void_p]
         c.hifihr_wino_dw_transform_parts.argtypes = [_c_float_p, c_int, _c_float_p, c_int, c_int, c_void_p]
+        c.hifihr_wino4_dw_transform_multi.argtypes = [c_void_p, c_int, c_void_p]
         c.hifihr_se_pool.argtypes = [_c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_scale.argtypes = [_c_float_p, _c_float_p, _c_float_p, c_float, c_int, c_int, c_int, _c_float_p, c_void_p]
         c.hifihr_se_bwd_gate.argtypes = [_c_float_p, _c_float_p, c_int, c_int, c_int, _c_float_p, c_void_p]
@@ -736,6 +737,16 @@ class HifihrLib:
     def wino_wgrad_gemm_parts(self, V, Y, dU_parts, N, H, W, C, K, parts, m=2):
         self.check(self.c.hifihr_wino_wgrad_gemm_parts_m(_fp(V), _fp(Y), _fp(dU_parts), N, H, W, C, K, parts, m, _stream_of(V)),
                    "hifihr_wino_wgrad_gemm_parts")
+
+    def wino4_dw_transform_multi(self, jobs):
+        """jobs: [(dU_parts tensor, parts, dw_acc tensor, K, C)] -- the F(4x4) weight-gradient transforms of several layers in one launch
+        (hifihr_wino4_dw_transform_multi: a host array of hifihr_wino_dw_job, 32 bytes each, passed in the kernel arguments)."""
+        import ctypes
+        import struct
+        raw = b"".join(struct.pack("<QQiiii", du.data_ptr(), dw.data_ptr(), int(parts), int(K), int(C), 0) for du, parts, dw, K, C in jobs)
+        buf = ctypes.create_string_buffer(raw, len(raw))
+        self.check(self.c.hifihr_wino4_dw_transform_multi(ctypes.cast(buf, c_void_p), len(jobs), _stream_of(jobs[0][0])),
+                   "hifihr_wino4_dw_transform_multi")
 
     def wino_dw_transform_parts(self, dU_parts, parts, dw_acc, K, C, m=2):
         self.check(self.c.hifihr_wino_dw_transform_parts_m(_fp(dU_parts), parts, _fp(dw_acc), K, C, m, _stream_of(dU_parts)),

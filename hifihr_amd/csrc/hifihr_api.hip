@@ -1166,6 +1166,16 @@ int hifihr_wino_dw_transform_parts_m(const float* dU_parts, int parts, float* dw
   return HIFIHR_OK;
 }
 
+int hifihr_wino4_dw_transform_multi(const hifihr_wino_dw_job* jobs, int njobs, void* stream) {
+  static_assert(sizeof(hifihr_wino_dw_job) == sizeof(hifihr::WinoDwJob), "job layouts");
+  if (!jobs || njobs <= 0) return fail(HIFIHR_EINVAL, "hifihr_wino4_dw_transform_multi: bad argument");
+  for (int i = 0; i < njobs; ++i)
+    if (!jobs[i].du_parts_d || !jobs[i].dw_acc_d || jobs[i].parts < 1 || jobs[i].K <= 0 || jobs[i].C < 4 || jobs[i].C % 4 != 0)
+      return fail(HIFIHR_EINVAL, "hifihr_wino4_dw_transform_multi: bad job (pointers, parts >= 1, K > 0, C % 4 == 0)");
+  HIP_TRY(hifihr::launch_wino4_dw_transform_multi(reinterpret_cast<const hifihr::WinoDwJob*>(jobs), njobs, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw_acc, int K, int C, void* stream) {
   return hifihr_wino_dw_transform_parts_m(dU_parts, parts, dw_acc, K, C, 2, stream);
 }

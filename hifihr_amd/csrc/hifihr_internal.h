@@ -436,6 +436,8 @@ hipError_t launch_wino4_output_transform(const float* Mm, float* y, float* stats
                                          hipStream_t st);
 hipError_t launch_wino4_dy_transform(const float* dy, float* Y, int N, int H, int W, int K, hipStream_t st);
 hipError_t launch_wino4_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st);
+struct WinoDwJob { const float* dU; float* dw; int parts, K, C; };       // = hifihr_wino_dw_job (include/hifihr.h)
+hipError_t launch_wino4_dw_transform_multi(const WinoDwJob* jobs, int njobs, hipStream_t st);
 
 hipError_t launch_texpca_fwd(const float* coef, const float* basis, const float* mean, int B, int K, long n, float* out, hipStream_t st);
 hipError_t launch_texpca_bwd(const float* g, const float* basis, int B, int K, long n, float* dcoef_zeroed, hipStream_t st);

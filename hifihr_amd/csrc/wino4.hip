@@ -217,10 +217,11 @@ __global__ __launch_bounds__(256) void wino4_dy_transform_kernel(const float* __
 // together, G^T is applied column by column (18 intermediate values per item stay in registers), then row by row.  No LDS, no barrier:
 // the first form exchanged the position sums through LDS between 16 x 16 threads and ran at 2.2 TB/s (26 us for 512 x 512 channels).
 // Slabs are added in slab order: bit-reproducible, nothing to zero.
-__global__ __launch_bounds__(256) void wino4_dw_transform_parts_kernel(const float* __restrict__ dU, int parts, float* __restrict__ dw, int K, int C) {
+// (body + thin kernel: wino4_dw_transform_multi_kernel below runs it on a RANGE of a launch's workgroups -- item i0 first, `stride` apart)
+__device__ __forceinline__ void dw_parts_items(const float* __restrict__ dU, int parts, float* __restrict__ dw, int K, int C, size_t i0, size_t stride) {
   const int C4 = C / 4;
   const size_t total = (size_t)K * C4, plane = (size_t)K * C, slab = 36 * plane;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+  for (size_t i = i0; i < total; i += stride) {
     const int cg = (int)(i % C4), k = (int)(i / C4);
     const float* p = dU + (size_t)k * C + cg * 4;
     float* const out = dw + (size_t)k * 9 * C + cg * 4;
@@ -251,18 +252,23 @@ __global__ __launch_bounds__(256) void wino4_dw_transform_parts_kernel(const flo
   }
 }
 
+__global__ __launch_bounds__(256) void wino4_dw_transform_parts_kernel(const float* __restrict__ dU, int parts, float* __restrict__ dw, int K, int C) {
+  dw_parts_items(dU, parts, dw, K, C, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
 // The same transform for SMALL layers (128 x 128 channels: 4 096 items = 16 workgroups of the kernel above, every thread walking 36
 // positions x `parts` slabs as 6 x parts dependent load batches: 18 us of latency for 17 MB, three times per step).  Wide form: a
 // workgroup is 32 items x 6 position columns; thread (item, jc) sums column jc over the slabs with its loads in flight together, applies
 // G^T down the column and leaves the three values in LDS; threads jc < 3 then finish row jc of the item.  Slabs are still added in slab
 // order (bit-reproducible).
-__global__ __launch_bounds__(192) void wino4_dw_transform_parts_wide_kernel(const float* __restrict__ dU, int parts, float* __restrict__ dw, int K, int C) {
-  __shared__ V4 s_t[32][3][6];
+// (body: workgroup `blk` of the layer, threads 0 .. 191 of a workgroup that may be larger; every thread of the workgroup reaches the barrier)
+__device__ __forceinline__ void dw_parts_wide_block(const float* __restrict__ dU, int parts, float* __restrict__ dw, int K, int C, int blk,
+                                                    V4 (*s_t)[3][6]) {
   const int C4 = C / 4;
   const size_t total = (size_t)K * C4, plane = (size_t)K * C, slab = 36 * plane;
   const int il = threadIdx.x & 31, jc = threadIdx.x >> 5;
-  const size_t i = (size_t)blockIdx.x * 32 + il;
-  const bool live = i < total;
+  const size_t i = (size_t)blk * 32 + il;
+  const bool live = i < total && jc < 6;
   const int cg = live ? (int)(i % C4) : 0, k = live ? (int)(i / C4) : 0;
   const float* p = dU + (size_t)k * C + cg * 4;
   float* const out = dw + (size_t)k * 9 * C + cg * 4;
@@ -303,6 +309,37 @@ __global__ __launch_bounds__(192) void wino4_dw_transform_parts_wide_kernel(cons
 #pragma unroll
     for (int c = 0; c < 3; ++c) st4(out + (size_t)(jc * 3 + c) * C, old[c] + o[c]);
   }
+}
+__global__ __launch_bounds__(192) void wino4_dw_transform_parts_wide_kernel(const float* __restrict__ dU, int parts, float* __restrict__ dw, int K, int C) {
+  __shared__ V4 s_t[32][3][6];
+  dw_parts_wide_block(dU, parts, dw, K, C, (int)blockIdx.x, s_t);
+}
+
+// The weight-gradient transforms of SEVERAL layers in ONE launch (round 6).  dw is needed by the optimizer only, so a step may collect the
+// (slabs, target) pairs of its F(4x4) layers during backward and run them all here, right before Adam: ten 5-11 us launches that sat
+// between the backward products at 3.9 TB/s (each a prologue and two or three trips of loads: hifihr_wino_dw_transform_parts_m) become
+// one stream over the same 298 MB.  The jobs travel BY VALUE in the kernel arguments (no device table: nothing to upload, nothing a
+// captured graph could find stale); job j owns workgroups [wg0_j, wg0_{j+1}); layers of <= 8 192 items keep the wide form above.
+struct DwJob {
+  const float* dU;
+  float* dw;
+  int parts, K, C, wg0;
+};
+constexpr int kDwMaxJobs = 24;
+struct DwJobs {
+  DwJob j[kDwMaxJobs];
+  int n;
+};
+__host__ __device__ inline bool dw_job_wide(int K, int C) { return (size_t)K * (C / 4) <= 8192; }
+__global__ __launch_bounds__(256) void wino4_dw_transform_multi_kernel(DwJobs js) {
+  __shared__ V4 s_t[32][3][6];
+  int jb = 0;
+  for (int q = 1; q < js.n; ++q)
+    if ((int)blockIdx.x >= js.j[q].wg0) jb = q;             // (uniform; wg0 ascending)
+  const DwJob job = js.j[jb];
+  const int wb = (int)blockIdx.x - job.wg0;
+  if (dw_job_wide(job.K, job.C)) dw_parts_wide_block(job.dU, job.parts, job.dw, job.K, job.C, wb, s_t);
+  else dw_parts_items(job.dU, job.parts, job.dw, job.K, job.C, (size_t)wb * 256 + threadIdx.x, ~(size_t)0 >> 1);   // (one item per thread)
 }
 
 static unsigned wino4_grid(size_t total) {
@@ -360,6 +397,24 @@ hipError_t launch_wino4_dy_transform(const float* dy, float* Y, int N, int H, in
   const TileGeo geo = wino4_geo(N, H, W);
   if (geo.G) hipLaunchKernelGGL(wino4_dy_transform_kernel<true>, dim3(wino4_grid(tile_count(geo) * (K / 4))), dim3(256), 0, st, dy, Y, geo, K);
   else hipLaunchKernelGGL(wino4_dy_transform_kernel<false>, dim3(wino4_grid(tile_count(geo) * (K / 4))), dim3(256), 0, st, dy, Y, geo, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_wino4_dw_transform_multi(const WinoDwJob* jobs, int njobs, hipStream_t st) {
+  for (int base = 0; base < njobs; base += kDwMaxJobs) {
+    DwJobs js;
+    js.n = njobs - base < kDwMaxJobs ? njobs - base : kDwMaxJobs;
+    long wg = 0;
+    for (int q = 0; q < js.n; ++q) {
+      const WinoDwJob& in = jobs[base + q];
+      if (in.dU == nullptr || in.dw == nullptr || in.parts < 1 || in.K <= 0 || in.C < 4 || in.C % 4 != 0) return hipErrorInvalidValue;
+      const size_t total = (size_t)in.K * (in.C / 4);
+      js.j[q] = DwJob{in.dU, in.dw, in.parts, in.K, in.C, (int)wg};
+      wg += (long)(dw_job_wide(in.K, in.C) ? (total + 31) / 32 : (total + 255) / 256);
+      if (wg >= (1L << 30)) return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(wino4_dw_transform_multi_kernel, dim3((unsigned)wg), dim3(256), 0, st, js);
+  }
   return hipGetLastError();
 }
 

@@ -648,6 +648,36 @@ class _WeightPrep:
 _WEIGHT_PREP = _WeightPrep()
 
 
+class _DeferredDw:
+    """The F(4x4) weight-gradient transforms (dw += G^T dU G, hifihr_wino_dw_transform_parts_m) of a step's layers, collected during
+    backward and run as ONE launch when the `prepared_weights()` scope closes -- the weight gradients are read by the optimizer only,
+    and ten 5-11 us launches between the backward products (3.9 TB/s each) stream better as one (hifihr_wino4_dw_transform_multi).
+    A layer defers only when (a) a scope is open, (b) its gradient is accumulated straight into the flat gradient buffer (nothing is
+    returned to autograd), (c) no data-parallel hook waits for the parameter (the bucketed all-reduce overlaps backward: those steps keep
+    the immediate launches) and (d) weight gradients are not on the side stream.  A deferred layer's slabs live in a buffer of its own.
+    HIFIHR_DEFER_DW=0: immediate launches."""
+
+    def __init__(self):
+        self.on = os.environ.get("HIFIHR_DEFER_DW", "1") != "0"
+        self.active = False
+        self.jobs = []
+
+    def wants(self, w, direct):
+        return (self.on and self.active and direct and not _ASYNC_WGRAD.active and getattr(w, "_hifihr_grad_ready", None) is None)
+
+    def add(self, dU, parts, tgt, K, C):
+        self.jobs.append((dU, int(parts), tgt, int(K), int(C)))
+
+    def flush(self):
+        jobs, self.jobs = self.jobs, []
+        if jobs:
+            lib = get_lib()
+            PROFILE.bracket("wino_dw_multi", lambda: lib.wino4_dw_transform_multi(jobs))
+
+
+_DEFER_DW = _DeferredDw()
+
+
 class _AsyncWgrad:
     """Weight gradients on a second HIP stream.  In backward the data gradient is the critical path (the previous layer waits for
     it); the weight gradient of a layer is needed only by the optimizer.  Launched on a side stream, the MFMA-bound backward-
@@ -702,6 +732,8 @@ class prepared_weights:
             side_branch.join_pending()
         if os.environ.get("HIFIHR_WEIGHT_PREP", "1") != "0":
             _WEIGHT_PREP.begin()
+        _DEFER_DW.jobs.clear()
+        _DEFER_DW.active = True
         # not inside a hipGraph capture: forked branches of a replayed graph ran SLOWER here (8.03 vs 7.74 ms/step) while the same
         # fork in the eager step gains (7.69 vs 7.83)
         _ASYNC_WGRAD.active = self.async_wgrad and (not torch.cuda.is_current_stream_capturing() or os.environ.get("HIFIHR_ASYNC_WGRAD_GRAPH") == "1")
@@ -709,6 +741,11 @@ class prepared_weights:
 
     def __exit__(self, *exc):
         _WEIGHT_PREP.end()
+        _DEFER_DW.active = False
+        if exc[0] is None:
+            _DEFER_DW.flush()                 # the step's deferred weight-gradient transforms, one launch (in front of the optimizer)
+        else:
+            _DEFER_DW.jobs.clear()
         side_branch.join_pending()
         if _ASYNC_WGRAD.active:
             _ASYNC_WGRAD.active = False
@@ -915,7 +952,8 @@ class _Conv2dMFMA(torch.autograd.Function):
                 pparts = lib.wino_wgrad_parts(N, H, W, C, K, wm)
                 if pparts > 0:
                     # (a side-stream weight-gradient transform reads the slabs while the next layer's pair already runs: a buffer of its own)
-                    pair_done = (v_saved, _wino_scratch(gy.device, ("dUp", ctx.w_param.data_ptr()) if _ASYNC_WGRAD.active else "dUp",
+                    own = _ASYNC_WGRAD.active or _DEFER_DW.wants(ctx.w_param, _direct_grad(ctx.w_param) and ctx.w_param.grad.is_contiguous(memory_format=_CL))
+                    pair_done = (v_saved, _wino_scratch(gy.device, ("dUp", ctx.w_param.data_ptr()) if own else "dUp",
                                                         pparts * wP * K * C), pparts)
 
             def run():
@@ -993,8 +1031,9 @@ class _Conv2dMFMA(torch.autograd.Function):
                 Yt = Yt_done if Yt_done is not None else _wino_scratch(
                     gy.device, ("Yt", w.data_ptr()) if _ASYNC_WGRAD.active else "Yt", wP * T * K)
                 parts = lib.wino_wgrad_parts(N, H, W, C, K, wm)  # > 0: the slab form on csrc/gemm.hip (no atomics, nothing to zero)
+                defer = wm == 4 and parts > 0 and _DEFER_DW.wants(w, dw is None)
                 if parts > 0:
-                    dU = _wino_scratch(gy.device, ("dUp", w.data_ptr()) if _ASYNC_WGRAD.active else "dUp", parts * wP * K * C)
+                    dU = _wino_scratch(gy.device, ("dUp", w.data_ptr()) if (_ASYNC_WGRAD.active or defer) else "dUp", parts * wP * K * C)
                 else:
                     key = (gy.device, "dU", 16 * K * C)
                     dU = _WINO_SCRATCH.get(key)
@@ -1009,10 +1048,16 @@ class _Conv2dMFMA(torch.autograd.Function):
                     if Yt_done is None:
                         lib.wino_dy_transform(gy, Yt, N, H, W, K, wm)
                     if pair_done is not None:              # the product already ran beside backward-data (same slab buffer)
-                        lib.wino_dw_transform_parts(pair_done[1], pair_done[2], tgt, K, C, wm)
+                        if defer:
+                            _DEFER_DW.add(pair_done[1], pair_done[2], tgt, K, C)
+                        else:
+                            lib.wino_dw_transform_parts(pair_done[1], pair_done[2], tgt, K, C, wm)
                     elif parts > 0:
                         lib.wino_wgrad_gemm_parts(v_saved, Yt, dU, N, H, W, C, K, parts, wm)
-                        lib.wino_dw_transform_parts(dU, parts, tgt, K, C, wm)
+                        if defer:
+                            _DEFER_DW.add(dU, parts, tgt, K, C)
+                        else:
+                            lib.wino_dw_transform_parts(dU, parts, tgt, K, C, wm)
                     else:
                         lib.wino_wgrad_gemm(v_saved, Yt, dU, N, H, W, C, K)
                         lib.wino_dw_transform(dU, tgt, K, C, clear=True)
@@ -1308,11 +1353,13 @@ class _BNActWinoConv(torch.autograd.Function):
                 lib.wino_weight_transform(wt, U2, C, K, 1, m)
             M2 = _wino_scratch(dev, "M", P * T * C)
             pair = need[5] and m == 4 and _GEMM_PAIR and lib.wino4_bwd_gemm_pair_supported(N, H, W, C, K)
+            defer = need[5] and m == 4 and _DEFER_DW.wants(w, direct_w)       # dw += G^T dU G joins the step's one deferred launch
+            slab_key = ("dUp", w.data_ptr()) if defer else "dUp"
             if pair:
                 # 2 + 4a. the backward-data product and the backward-weight product do not depend on each other: ONE launch whose
                 # workgroups split between them (hifihr_wino4_bwd_gemm_pair; HIFIHR_GEMM_PAIR=0: two launches)
                 parts = lib.wino_wgrad_parts(N, H, W, C, K, m)
-                dU = _wino_scratch(dev, "dUp", parts * P * K * C)
+                dU = _wino_scratch(dev, slab_key, parts * P * K * C)
                 lib.wino4_bwd_gemm_pair(V2, U2, M2, V, Yt, dU, N, H, W, C, K, parts)
             else:
                 lib.wino_gemm(V2, U2, M2, N, H, W, K, C, ws=_wino_gemm_ws(lib, dev, N, H, W, K, C, m), m=m)
@@ -1323,9 +1370,12 @@ class _BNActWinoConv(torch.autograd.Function):
                 tgt = w.grad if direct_w else torch.zeros_like(wk, memory_format=_CL)
                 if not pair:
                     parts = lib.wino_wgrad_parts(N, H, W, C, K, m)
-                    dU = _wino_scratch(dev, "dUp", parts * P * K * C)
+                    dU = _wino_scratch(dev, slab_key, parts * P * K * C)
                     lib.wino_wgrad_gemm_parts(V, Yt, dU, N, H, W, C, K, parts, m)
-                lib.wino_dw_transform_parts(dU, parts, tgt, K, C, m)
+                if defer and parts > 0:
+                    _DEFER_DW.add(dU, parts, tgt, K, C)
+                else:
+                    lib.wino_dw_transform_parts(dU, parts, tgt, K, C, m)
                 dw_box[0] = None if direct_w else tgt
         if PROFILE.on:
             if need[5] and m == 4 and _GEMM_PAIR and lib.wino4_bwd_gemm_pair_supported(N, H, W, C, K):

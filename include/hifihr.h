@@ -418,6 +418,17 @@ int hifihr_wino4_bwd_gemm_pair_supported(int N, int H, int W, int C, int K);   /
 int hifihr_wino4_bwd_gemm_pair(const float* V2_d, const float* U2_d, float* M2_d, const float* Vx_d, const float* Yt_d, float* dU_parts_d,
                                int N, int H, int W, int C, int K, int parts, void* stream);
 int hifihr_wino_dw_transform_parts_m(const float* du_parts_d, int parts, float* dw_acc_d, int K, int C, int m, void* stream);
+/* The same F(4x4, 3x3) weight-gradient transform (m = 4) for SEVERAL layers in one launch: dw_acc_d[K][3][3][C] += G^T (sum of the `parts`
+ * slabs du_parts_d[parts][36][K][C]) G per job, jobs independent of each other.  `jobs` is a HOST array (its pointers are device pointers);
+ * the entries travel in the kernel arguments, so nothing is uploaded and a captured launch keeps them.  Results identical to one
+ * hifihr_wino_dw_transform_parts_m(..., 4, ...) call per job.  A training step whose weight gradients are only read by the optimizer
+ * collects its layers' jobs during backward and makes this one call in front of the optimizer (reference train_hrnet.py:104-105). */
+typedef struct hifihr_wino_dw_job {
+  const float* du_parts_d;
+  float* dw_acc_d;
+  int parts, K, C;
+} hifihr_wino_dw_job;
+int hifihr_wino4_dw_transform_multi(const hifihr_wino_dw_job* jobs, int njobs, void* stream);
 /* Batched fp32 GEMM on the f32 matrix cores (csrc/gemm.hip): the plain products a Winograd layer consists of -- the GEMM half of
  * the vendor-library call behind one conv2d of the reference (network/res_encoder.py:364-373).  hifihr_wino_gemm dispatches here
  * when the shape allows (C % 32 == 0, K % 64 == 0; hifihr_wino_gemm_workspace_bytes then returns 0).

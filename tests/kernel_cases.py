@@ -1207,6 +1207,26 @@ def se_case(lib, device, B, H, W, C, SQ, seed=0):
 # ------------------------------------------------------------------------------------------------
 # Winograd F(2x2, 3x3) path (csrc/wino.hip + the batched MFMA GEMM) vs torch conv2d, forward and backward-data
 # ------------------------------------------------------------------------------------------------
+def wino4_dw_multi_case(lib, device, seed=0):
+    """hifihr_wino4_dw_transform_multi: the F(4x4) weight-gradient transforms of several layers in one launch == one
+    hifihr_wino_dw_transform_parts_m(..., 4) call per layer, bit for bit (same per-item arithmetic, slabs in slab order) -- wide-form layers
+    (<= 8 192 items), item-per-thread layers, 1 .. 7 slabs, a layer whose item count is not a multiple of the workgroup's, accumulation
+    into non-zero targets; more jobs than one launch's argument block holds (24)."""
+    gen = torch.Generator().manual_seed(seed)
+    shapes = [(64, 64, 3), (128, 128, 7), (256, 128, 1), (72, 100, 2), (264, 128, 2)] + [(16, 8 + 4 * i, 1 + i % 3) for i in range(22)]
+    jobs, want = [], []
+    for K, C, parts in shapes:
+        dU = torch.randn(parts * 36 * K * C, generator=gen).to(device)
+        base = torch.randn(K * 9 * C, generator=gen).to(device)
+        single = base.clone()
+        lib.wino_dw_transform_parts(dU, parts, single, K, C, 4)
+        tgt = base.clone()
+        jobs.append((dU, parts, tgt, K, C)); want.append(single)
+    lib.wino4_dw_transform_multi(jobs)
+    for (dU, parts, tgt, K, C), single in zip(jobs, want):
+        assert torch.equal(tgt, single), (K, C, parts, float((tgt - single).abs().max()))
+
+
 def wino_case(lib, device, N, H, W, C, K, seed=0, with_stats=True, use_ws=True, m=2):
     """m = 2: F(2x2, 3x3) (csrc/wino.hip, 16 positions); m = 4: F(4x4, 3x3) (csrc/wino4.hip, 36 positions, slab backward-weight only)."""
     P = (m + 2) ** 2

@@ -588,3 +588,8 @@ def test_conv_fork_residual_sum_equals_autograd_sum(monkeypatch):
         # (not bit-identical: the batch-norm reductions and weight gradients in between use float atomics, whose order differs run to run --
         #  ~1e-5 of a gradient's maximum between two runs of the SAME mode; a wrong residual sum would be O(1))
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-12, n
+
+
+def test_weight_gradient_transforms_of_several_layers_in_one_launch(lib):
+    """hifihr_wino4_dw_transform_multi (the step's deferred F(4x4) weight-gradient transforms, ops._DeferredDw) == the per-layer launches."""
+    kc.wino4_dw_multi_case(lib, "cuda")

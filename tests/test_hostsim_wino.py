@@ -65,3 +65,7 @@ def test_winograd_f4_mosaic_fwd_bwd(hostsim_lib, N, H, C, K):
 def test_bn_fusions_on_mosaic_tiles(hostsim_lib, N, H, C, residual, addend):
     kc.wino_bn_input_case(hostsim_lib, "cpu", N, H, H, C, residual, seed=C + H)
     kc.wino_bn_bwd_case(hostsim_lib, "cpu", N, H, H, C, residual, addend, seed=C + H)
+
+
+def test_weight_gradient_transforms_of_several_layers_in_one_launch(hostsim_lib):
+    kc.wino4_dw_multi_case(hostsim_lib, "cpu")
