@@ -885,6 +885,59 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
   };
   auto run_tile = [&](auto nbc, const RowsTile& t) {
     constexpr int NB = decltype(nbc)::value;
+#if defined(HIFIHR_PROBE_SPLIT_BF16)
+    if constexpr (MODE == 3) {
+      // PROBE (tools/split_bf16_probe.py; not in libhifihr.so): the operands are SPLIT bf16 -- the 128 bytes of a row's 32-deep chunk hold the
+      // 32 leading pieces hi = bf16(x) (segments 0 .. 3) and the 32 remainders lo = bf16(x - hi) (segments 4 .. 7): the same bytes and the
+      // same LDS image as f32, so the loader waves above are untouched, and the 16 bytes lane (r, g) reads at segment g (+ 4 for lo) ARE
+      // its operand of v_mfma_f32_16x16x32_bf16 (k = 8 g .. 8 g + 7).  Per chunk: hi.hi, hi.lo, lo.hi = 3 x 2 NB MFMAs of 16 cycles (768 for
+      // NB = 8) where the f32 form spends 4 096.  hi of the NEXT chunk is prefetched under the cross terms (two register sets for hi).
+      typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+      bf8 ahi[2][NB], alo[NB], bhi[2][2], blo[2];
+      auto rd = [&](int gcc, int h, bf8 (&a)[NB], bf8 (&b)[2]) {
+        const char* st = lds_b + (gcc & 3) * (STAGE * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const bf8*>(st + boff[h] + i * 2048);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[j] = *reinterpret_cast<const bf8*>(st + aoff[h] + j * 2048);
+      };
+      floatx4 acc[2][NB];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+      auto mm = [&](bf8 (&b)[2], bf8 (&a)[NB]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[i], a[j], acc[i][j], 0, 0, 0);
+      };
+      rd(gc, 0, ahi[0], bhi[0]);
+      for (int c = 0; c < nch; c += 2) {                       // (nch even: the probe's K % 64 == 0)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          rd(gc, 1, alo, blo);
+          mm(bhi[u], ahi[u]);                                  // hi . hi
+          rd(gc + 1, 0, ahi[u ^ 1], bhi[u ^ 1]);               // (landed: barrier gc - 1; past the tile's last chunk: re-read at the next tile's start)
+          mm(bhi[u], alo);                                     // hi . lo  (n-side hi, m-side lo)
+          mm(blo, ahi[u]);                                     // lo . hi
+          HIFIHR_RAW_BARRIER();                                // barrier gc
+          ++gc;
+        }
+      }
+      float* C = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int m = 16 * j + r;
+        if (m < t.rows) {
+          float* row = C + (size_t)(t.m0 + m) * a.ldc;
+          *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
+          *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
+        }
+      }
+      return;
+    }
+#endif
     float fm[2][NB][4], fn[2][2][4];
     auto read_half = [&](int gcc, int h, int slot) {
       const char* st = lds_b + (gcc & 3) * (STAGE * 4);
@@ -1598,6 +1651,25 @@ hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int
   return hipGetLastError();
 }
 
+
+#if defined(HIFIHR_PROBE_SPLIT_BF16)
+// PROBE build only (tools/build_split_bf16_probe.sh): x[rows][K] f32 -> the split image of nt_rows_body<3> (per row and 32-deep chunk: 32 bf16
+// leading pieces, then the 32 bf16 remainders; round-to-nearest-even both), and the product on it.
+__global__ __launch_bounds__(256) void probe_split_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;                  // element (row, k): chunk k / 32, position k % 32
+  if (i >= n) return;
+  const float v = x[i];
+  const __bf16 hi = (__bf16)v;
+  const __bf16 lo = (__bf16)(v - (float)hi);
+  const size_t chunk = i >> 5, pos = i & 31;
+  out[chunk * 64 + pos] = hi;
+  out[chunk * 64 + 32 + pos] = lo;
+}
+__global__ __launch_bounds__(512) void bgemm_nt_rows_bf16x3_kernel(BgemmArgs a, long per) {
+  __shared__ __attribute__((aligned(1024))) float lds[4 * kRowsStage];
+  nt_rows_body<3>(a, per, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+#endif
 }  // namespace hifihr
 
 #if defined(HIFIHR_GEMM_STAMP)
@@ -1608,5 +1680,27 @@ extern "C" int hifihr_gemm_stamp_read(unsigned long long* out8, int reset) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(hifihr::g_gemm_stamp), z, sizeof(z)) != hipSuccess) return 1;
   }
   return 0;
+}
+#endif
+
+#if defined(HIFIHR_PROBE_SPLIT_BF16)
+extern "C" int hifihr_probe_split_bf16(const float* x, void* out, long n, void* stream) {
+  hipLaunchKernelGGL(hifihr::probe_split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<__bf16*>(out), (size_t)n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// c[b][M][N] = a[b][M][K] . b[b][N][K]^T on the split images (same byte sizes and strides as the f32 operands); N % 128 == 0, K % 64 == 0
+extern "C" int hifihr_probe_bgemm_nt_bf16x3(const void* A, const void* B, float* C, int M, int N, int K, int batch, void* stream) {
+  if (N % 128 != 0 || K % 64 != 0 || M <= 0 || batch <= 0) return -1;
+  hifihr::BgemmArgs a{};
+  a.A = reinterpret_cast<const float*>(A); a.B = reinterpret_cast<const float*>(B); a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
+  a.sa = (long)M * K; a.sb = (long)N * K; a.sc = (long)M * N; a.batch = batch;
+  a.tiles_n = N / 128; a.tiles_m = (M + 127) / 128; a.splits = 1; a.cps = K / 32; a.sc_split = 0;
+  const long total = (long)batch * a.tiles_n * M;
+  const int cus = hifihr::gemm_cus();
+  long per = (total + cus - 1) / cus;
+  if (per < 16) per = 16;
+  const int G = (int)((total + per - 1) / per);
+  hipLaunchKernelGGL(hifihr::bgemm_nt_rows_bf16x3_kernel, dim3(G), dim3(512), 0, (hipStream_t)stream, a, per);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 #endif
