@@ -1208,6 +1208,13 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
 #pragma unroll
           for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fn[slot][k][i], fm[slot][k][j], acc[i][j], 0, 0, 0);
     };
+    // rows t >= k_valid of the problem are zero in both operands (BgemmArgs::k_valid): k-steps (4 rows each) wholly behind them add nothing
+    int kv_steps = nch * 8;                                   // k-steps of this tile's reduction that carry data
+    if (a.k_valid > 0) {
+      const int part = a.splits > 1 ? t.p % a.splits : 0;
+      const int valid = min(max(a.k_valid - part * a.K, 0), a.K);
+      kv_steps = (valid + 3) >> 2;
+    }
     auto touch = [&]() {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1229,7 +1236,8 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
     };
     read_half(gc, 0, 0);
     touch();
-    for (int c = 0; c < nch; ++c, ++gc) {
+    const int nfull = min(nch, kv_steps >> 3);               // chunks whose eight k-steps all carry data
+    for (int c = 0; c < nfull; ++c, ++gc) {
       read_half(gc, 1, 1);
       mfma_half(0);
       interleave();
@@ -1239,6 +1247,40 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
       interleave();
       HIFIHR_PIN();
       touch();
+      HIFIHR_RAW_BARRIER();                                  // barrier gc
+    }
+    // The tail: a chunk that runs into the zero rows (its first `rem` k-steps carry data: 450 real rows = 14 chunks + 2 rows) and chunks of
+    // zeros only.  The loader waves stream them like any other chunk (the chunk stream and its barriers are theirs to keep); here a ROLLED
+    // loop takes the live k-steps straight from LDS -- no second register set, no schedule: a few hundred cycles per tile -- and the rest
+    // only meets the barriers.
+    for (int c = nfull; c < nch; ++c, ++gc) {
+      const int rem = c == nfull ? kv_steps - 8 * nfull : 0;
+      const float* st = lds + (gc & 3) * STAGE;
+#pragma unroll 1
+      for (int kk = 0; kk < rem; ++kk) {
+        const int trow = 4 * kk + g;
+        const float* ar = st + trow * 128;
+        const float* br = st + 32 * 128 + trow * 128;
+        const float b0 = br[boff[0]], b1 = br[boff[1]];
+        float am[NB];
+        if constexpr (NB == 8) {
+          const float4 v0 = *reinterpret_cast<const float4*>(ar + 4 * r), v1 = *reinterpret_cast<const float4*>(ar + 64 + 4 * r);
+          am[0] = v0.x; am[1] = v0.y; am[2] = v0.z; am[3] = v0.w; am[4] = v1.x; am[5] = v1.y; am[6] = v1.z; am[7] = v1.w;
+        } else if constexpr (NB == 4) {
+          const float4 v0 = *reinterpret_cast<const float4*>(ar + 4 * r);
+          am[0] = v0.x; am[1] = v0.y; am[2] = v0.z; am[3] = v0.w;
+        } else if constexpr (NB == 2) {
+          const float2 v0 = *reinterpret_cast<const float2*>(ar + 2 * r);
+          am[0] = v0.x; am[1] = v0.y;
+        } else {
+          am[0] = ar[r];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, am[j], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, am[j], acc[1][j], 0, 0, 0);
+        }
+      }
       HIFIHR_RAW_BARRIER();                                  // barrier gc
     }
     // register e of lane (r, g) of block (i, j) = C[m0 + row(j, r)][128 nt + 32 wave + 16 i + 4 g + e]
@@ -1556,9 +1598,11 @@ int bgemm_tn_parts(int M, int N, int T, int batch) {
   return (nch + cps - 1) / cps;
 }
 
-hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st) {
-  if (!bgemm_tn_supported(M, N, T) || batch <= 0 || parts <= 0) return hipErrorInvalidValue;
+hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st, int T_valid) {
+  if (!bgemm_tn_supported(M, N, T) || batch <= 0 || parts <= 0 || T_valid < 0 || T_valid > T) return hipErrorInvalidValue;
   BgemmArgs a{};
+  static const int skip_on = [] { const char* e = getenv("HIFIHR_GEMM_TN_SKIP"); return e ? atoi(e) : 1; }();      // (0: walk the zero rows too, A/B timing)
+  a.k_valid = (skip_on && T_valid < T) ? T_valid : 0;        // (row-share kernel only: the per-tile kernels walk every row)
   a.A = A; a.B = B; a.C = Cparts; a.M = M; a.N = N; a.K = T; a.lda = M; a.ldb = N; a.ldc = N;
   a.sa = (long)T * M; a.sb = (long)T * N; a.sc = (long)M * N; a.batch = batch;
   const int P = tn_rows(M, N, T, batch) ? 1 : tn_rows_split(M, N, T, batch);
@@ -1619,8 +1663,9 @@ bool bgemm_nt_tn_pair_supported(int M, int M_alloc, int N, int K, int batch, int
 }
 
 hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int M, int M_alloc, int N, int K, int batch, const float* A2,
-                                   const float* B2, float* C2parts, int M2, int N2, int T2, int batch2, int parts2, hipStream_t st) {
+                                   const float* B2, float* C2parts, int M2, int N2, int T2, int batch2, int parts2, hipStream_t st, int T2_valid) {
   if (!bgemm_nt_tn_pair_supported(M, M_alloc, N, K, batch, M2, N2, T2, batch2, parts2)) return hipErrorNotSupported;
+  if (T2_valid < 0 || T2_valid > T2) return hipErrorInvalidValue;
   if (M_alloc < M) M_alloc = M;                               // (M_alloc > M: problems M_alloc rows apart, M of them computed -- see launch_bgemm_nt)
   const int P = parts2;
   BgemmArgs a{};
@@ -1632,8 +1677,11 @@ hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int
   b.A = A2; b.B = B2; b.C = C2parts; b.M = M2; b.N = N2; b.K = Tp; b.lda = M2; b.ldb = N2; b.ldc = N2;
   b.sa = (long)Tp * M2; b.sb = (long)Tp * N2; b.sc = (long)M2 * N2; b.batch = batch2 * P;
   b.tiles_n = N2 / 128; b.tiles_m = (M2 + 127) / 128; b.splits = P; b.cps = Tp / 32; b.sc_split = P > 1 ? (long)batch2 * M2 * N2 : 0;
+  static const int skip_on = [] { const char* e = getenv("HIFIHR_GEMM_TN_SKIP"); return e ? atoi(e) : 1; }();
+  b.k_valid = (skip_on && T2_valid > 0 && T2_valid < T2) ? T2_valid : 0;
+  const int T2w = b.k_valid > 0 ? (b.k_valid + 3) / 4 * 4 : T2;          // rows whose k-steps run (the split of the CUs follows the work)
   static const int wnt = [] { const char* e = getenv("HIFIHR_GEMM_PAIR_NT_WEIGHT"); const int v = e ? atoi(e) : 100; return v > 0 ? v : 100; }();
-  const double fa = 2.0 * batch * (double)M * N * K * (wnt / 100.0), fb = 2.0 * batch2 * (double)M2 * N2 * T2;
+  const double fa = 2.0 * batch * (double)M * N * K * (wnt / 100.0), fb = 2.0 * batch2 * (double)M2 * N2 * T2w;
   const int cus = gemm_cus();
   int ga = (int)(cus * fa / (fa + fb) + 0.5);
   if (ga < 8) ga = 8;

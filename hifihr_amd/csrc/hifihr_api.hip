@@ -1144,7 +1144,8 @@ int hifihr_wino_wgrad_gemm_parts_m(const float* V, const float* Y, float* dU_par
   const long T4 = wino_T(4, N, H, W);
   if (T4 >= (1L << 30) || !hifihr::bgemm_tn_supported(K, C, (int)T4) || parts != hifihr::bgemm_tn_parts(K, C, (int)T4, 36))
     return fail(HIFIHR_EINVAL, "hifihr_wino_wgrad_gemm_parts: parts must be hifihr_wino_wgrad_parts_m(N, H, W, C, K, 4) > 0");
-  HIP_TRY(hifihr::launch_bgemm_tn(Y, V, dU_parts, K, C, (int)T4, 36, parts, (hipStream_t)stream));
+  // (the rows behind the last tile mosaic are zero in V and Y: the row-share kernel skips their k-steps)
+  HIP_TRY(hifihr::launch_bgemm_tn(Y, V, dU_parts, K, C, (int)T4, 36, parts, (hipStream_t)stream, (int)hifihr::wino4_tiles_real(N, H, W)));
   return HIFIHR_OK;
 }
 
@@ -1224,13 +1225,13 @@ int hifihr_wino4_bwd_gemm_pair(const float* V2, const float* U2, float* M2, cons
     return fail(HIFIHR_EINVAL, "hifihr_wino4_bwd_gemm_pair: bad argument (C, K % 64 == 0; parts = hifihr_wino_wgrad_parts_m(N, H, W, C, K, 4))");
   const long Tr = hifihr::wino4_tiles_real(N, H, W);
   const hipError_t e = hifihr::launch_bgemm_nt_tn_pair(V2, U2, M2, (int)(Tr < T4 ? Tr : T4), (int)T4, C, K, 36, Yt, Vx, dU_parts, K, C, (int)T4, 36,
-                                                       parts, (hipStream_t)stream);
+                                                       parts, (hipStream_t)stream, (int)(Tr < T4 ? Tr : T4));
   if (e == hipSuccess) return HIFIHR_OK;
   if (e != hipErrorNotSupported) HIP_TRY(e);
   // not a pair of row-share products: the two launches of hifihr_wino_gemm_m (with C and K exchanged) / hifihr_wino_wgrad_gemm_parts_m
   if (Tr < T4) HIP_TRY(hifihr::launch_bgemm_nt(V2, U2, M2, (int)Tr, C, K, 36, nullptr, 0, (hipStream_t)stream, nullptr, (int)T4));
   else HIP_TRY(hifihr::launch_bgemm_nt(V2, U2, M2, (int)T4, C, K, 36, nullptr, 0, (hipStream_t)stream));
-  HIP_TRY(hifihr::launch_bgemm_tn(Yt, Vx, dU_parts, K, C, (int)T4, 36, parts, (hipStream_t)stream));
+  HIP_TRY(hifihr::launch_bgemm_tn(Yt, Vx, dU_parts, K, C, (int)T4, 36, parts, (hipStream_t)stream, (int)(Tr < T4 ? Tr : T4)));
   return HIFIHR_OK;
 }
 

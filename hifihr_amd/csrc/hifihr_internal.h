@@ -391,6 +391,8 @@ struct BgemmArgs {
   // bgemm_nt_rows_kernel<2>: A is an NHWC image x[n][ih][iw][cC] and row m of the product is the (r, s, c)-ordered patch of output pixel
   // m = (n, oh, ow), gathered by the loader waves (K = cR * cS * cC, cC % 32 == 0; B = the filter [N][cR][cS][cC])
   int cIH = 0, cIW = 0, cC = 0, cOH = 0, cOW = 0, cR = 0, cS = 0, cStride = 1, cPad = 0;
+  int k_valid = 0;             // bgemm_tn_rows_kernel: rows t >= k_valid of every problem are ZERO in both operands (the padding behind the last
+                               // tile mosaic of an F(4x4) layer: 450 real rows in 480) -- their k-steps are skipped; 0: every row counts
   float* stats = nullptr;      // bgemm_nt_rows_kernel, batch 1 (a 1x1 convolution in front of a batch-norm): per-column sum / sum of squares of C
                                // added into the slot buffer [kStatSlots][2][N] (csrc/bn.hip), or null
 };
@@ -407,11 +409,11 @@ bool bgemm_nt_ragged_supported(int M, int N, int K);   // bgemm_nt_rows_kernel<t
 hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
                            float* stats_or_null = nullptr, int M_alloc = 0);      // stats: only with N % 128 == 0 and batch == 1 (else hipErrorInvalidValue)
 int bgemm_tn_parts(int M, int N, int T, int batch);
-hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st);
+hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st, int T_valid = 0);
 bool bgemm_nt_tn_pair_supported(int M, int M_alloc, int N, int K, int batch, int M2, int N2, int T2, int batch2, int parts2);
 // an NT and an independent TN product on the row-share kernels in ONE launch (csrc/gemm.hip); hipErrorNotSupported: launch them separately
 hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int M, int M_alloc, int N, int K, int batch, const float* A2,
-                                   const float* B2, float* C2parts, int M2, int N2, int T2, int batch2, int parts2, hipStream_t st);
+                                   const float* B2, float* C2parts, int M2, int N2, int T2, int batch2, int parts2, hipStream_t st, int T2_valid = 0);
 hipError_t launch_wino_dw_transform_parts(const float* dU_parts, int parts, float* dw, int K, int C, hipStream_t st);
 // Winograd F(4x4, 3x3) glue (wino4.hip): 36 positions, T = wino4_tiles(N, H, W) tiles (N * ceil(H / 4) * ceil(W / 4), or fewer where 16
 // images share a mosaic: wino4_math.h TileGeo)

@@ -452,7 +452,7 @@ __device__ __forceinline__ void raster_pass2(Fwd2Lds<AA, TILE, CAP>& L, int n, i
   __syncthreads();
   R2_STAMP(5)
 #if defined(HIFIHR_RENDER_STAMP2)
-  (void)0;
+  if (tid == 0) atomicAdd(&g_r2_stamp[12], (unsigned long long)total);        // (face, pixel) candidates of this pass
 #endif
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (int cb = 0; cb < total; cb += kF2Threads) {
@@ -520,7 +520,7 @@ __device__ __forceinline__ void raster_pass2(Fwd2Lds<AA, TILE, CAP>& L, int n, i
   {
     const int qn = L.qn;
 #if defined(HIFIHR_RENDER_STAMP2)
-    (void)0;
+    if (tid == 0) atomicAdd(&g_r2_stamp[11], (unsigned long long)qn);         // survivors of stage A that reach the final drain
 #endif
     for (int e = tid; e < qn; e += kF2Threads) stage_b2<AA, TILE, CAP>(L, (int)L.u.r.q[e]);
   }
@@ -650,6 +650,7 @@ __device__ __forceinline__ void resolve_shade2(Fwd2Lds<AA, TILE, CAP>& L, const 
   if (tid == 0) {
     const unsigned long long dur = __builtin_amdgcn_s_memtime() - L.stamp_begin;
     atomicMax(&g_r2_stamp[10], dur);
+    atomicAdd(&g_r2_stamp[9], dur);                                 // sum over the resolving items: the phases above must add up to it
     atomicAdd(&g_r2_hist[min(31, (int)(dur >> 14))], 1u);          // buckets of 16384 cycles (~7.8 us)
   }
   if (tid == 0) { atomicAdd(&g_r2_stamp[15], 1ull); atomicAdd(&g_r2_stamp[14], (unsigned long long)nbusy); atomicAdd(&g_r2_stamp[13], (unsigned long long)L.stamp_nlist); }
@@ -876,6 +877,7 @@ __global__ __launch_bounds__(kF2Threads) void render_fwd3_kernel(RenderDev r, co
     const int nlist = tile_cnt[tile];
     const int* flist = tile_list + tile * r.F;
     const int lo = (int)((long)nlist * part / P), hi = (int)((long)nlist * (part + 1) / P);
+    R2_T0
     for (int e = tid; e < 2 * SW; e += kF2Threads) {
       const int idx = e < SW ? e : e - SW;
       const int g = min((e < SW ? ox : oy) * AA + idx, S - 1);
@@ -887,6 +889,7 @@ __global__ __launch_bounds__(kF2Threads) void render_fwd3_kernel(RenderDev r, co
     for (int base = lo; base < hi; base += CAP) {
       const int n = min(CAP, hi - base);
       __syncthreads();                                       // (previous pass done with rec; first pass: sxs / zbuf written)
+      R2_STAMP(0)
       if (tid < n) {
         const int f = flist[base + tid];
         const float4 a = fr[(size_t)f * kFaceRec], c = fr[(size_t)f * kFaceRec + 1], d = fr[(size_t)f * kFaceRec + 2];
@@ -895,7 +898,9 @@ __global__ __launch_bounds__(kF2Threads) void render_fwd3_kernel(RenderDev r, co
         q[8] = d.z; q[9] = __int_as_float(f); q[10] = 0.f;
       }
       __syncthreads();
+      R2_STAMP(1)
       raster_pass2<AA, TILE, CAP>(L, n, cols, rows);
+      R2_STAMP(2)
     }
     bool resolve = true;
     if (P > 1) {

@@ -28,6 +28,13 @@ names = ["init (sxs, zbuf) + barrier", "stage faces (global -> LDS)", "raster pa
 print(f"busy tiles {v[15]}; per busy tile: faces {v[13] / n:.1f}, candidates {v[12] / n:.1f}, survivors (final drains) {v[11] / n:.1f}, busy pixels {v[14] / n:.1f}")
 for i, nm in enumerate(names):
     print(f"  {nm:34s} {v[i] / n:9.0f} cycles = {v[i] / n / 2100:6.2f} us")
+# evidence check (round 5 filed a stamps file whose first three phases and both counters read 0): the phases must account
+# for the items' own durations, and the counters must be alive
+top = sum(v[i] for i in range(5))
+if v[15] == 0 or v[12] == 0 or v[11] == 0 or any(v[i] == 0 for i in range(8)) or (v[9] > 0 and top < 0.5 * v[9]):
+    print(f"STAMPS INCOMPLETE: phases sum {top / n:.0f} cycles per tile against {v[9] / n:.0f} measured per resolving item; raw {v}")
+    sys.exit(1)
+print(f"  phases above (0-4) sum to {top / n:.0f} cycles per busy tile; the items' own clock: {v[9] / n:.0f} (a split tile's resolving part only)")
 lib.c.hifihr_debug_render_hist(hist, 0)
 print(f"slowest covered tile: {v[10] / 2100:.1f} us; covered tiles by duration (7.8 us buckets):", [int(x) for x in hist][:24])
 lib.c.hifihr_debug_render_times(tm, 0)
