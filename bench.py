@@ -281,9 +281,12 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
             V2 = torch.randn(P_ * T_ * K_, device=dev); U2 = torch.randn(P_ * C_ * K_, device=dev) * 0.05; M2 = torch.empty(P_ * T_ * C_, device=dev)
             Vx = torch.randn(P_ * T_ * C_, device=dev); Yt = torch.randn(P_ * T_ * K_, device=dev); dU = torch.empty(parts * P_ * K_ * C_, device=dev)
             us = hip_us(lambda: lib.wino4_bwd_gemm_pair(V2, U2, M2, Vx, Yt, dU, N_, H_, W_, C_, K_, parts))
-            add("bgemm_nt_tn_pair_kernel", per_step, us, 2.0 * P_ * (Tc + T_) * C_ * K_,
+            # the TN half skips the k-steps (4 rows each) of the zero rows behind the last tile mosaic (round 6): it EXECUTES ceil(Tc / 4) * 4
+            # of the T_ allocated rows (HIFIHR_GEMM_TN_SKIP=0: all of them)
+            Tx = T_ if os.environ.get("HIFIHR_GEMM_TN_SKIP", "1") == "0" else min(T_, (Tc + 3) // 4 * 4)
+            add("bgemm_nt_tn_pair_kernel", per_step, us, 2.0 * P_ * (Tc + Tx) * C_ * K_,
                 4.0 * P_ * ((Tc * K_ + C_ * K_ + Tc * C_) + (T_ * C_ + T_ * K_ + parts * K_ * C_)),
-                f"{P_} x ([{Tc} x {K_}] . [{C_} x {K_}]^T  +  [{T_} x {K_}]^T . [{T_} x {C_}], {parts} slab(s))",
+                f"{P_} x ([{Tc} x {K_}] . [{C_} x {K_}]^T  +  [{Tx} of {T_} x {K_}]^T . [{Tx} of {T_} x {C_}], {parts} slab(s))",
                 useful=2.0 * P_ * (Tc + Tc) * C_ * K_)
             continue
         if direction in ("gemm", "gemm-tn"):
@@ -312,9 +315,11 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
                     name = "conv_wgrad_kernel"
                     dU = torch.zeros(16 * K_ * C_, device=dev)
                     us = hip_us(lambda: lib.wino_wgrad_gemm(V, Y, dU, N_, H_, W_, C_, K_))
-                add(name, per_step, us, 2.0 * P_ * T_ * C_ * K_, 4.0 * P_ * (T_ * C_ + T_ * K_ + max(parts, 1) * K_ * C_),
-                    f"{P_} x [{T_} x {K_}]^T . [{T_} x {C_}], {max(parts, 1)} slab(s)",
-                    useful=2.0 * P_ * lib.wino_tiles_computed(N_, H_, W_, m_) * C_ * K_)
+                Tc = lib.wino_tiles_computed(N_, H_, W_, m_)
+                Tx = min(T_, (Tc + 3) // 4 * 4) if (name == "bgemm_tn_rows_kernel" and m_ == 4 and os.environ.get("HIFIHR_GEMM_TN_SKIP", "1") != "0") else T_
+                add(name, per_step, us, 2.0 * P_ * Tx * C_ * K_, 4.0 * P_ * (T_ * C_ + T_ * K_ + max(parts, 1) * K_ * C_),
+                    f"{P_} x [{Tx} of {T_} x {K_}]^T . [{Tx} of {T_} x {C_}], {max(parts, 1)} slab(s)",
+                    useful=2.0 * P_ * Tc * C_ * K_)
             continue
         N_, H_, W_, C_, K_, R_, S_, st_, pd_ = geom
         if direction in ("fwd-wino2", "dgrad-wino2"):          # conv_wino2_kernel: one launch, 2 x 16 x (tiles x 64 x 64) executed products

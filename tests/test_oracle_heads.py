@@ -19,6 +19,13 @@ def _ref_module(name):
     return {"HandEncoder": tm.HandEncoderRef, "LightEstimator": tm.LightEstimatorRef, "MMPool": tm.MMPoolRef}[cls](*cargs)
 
 
+# In training mode the bias of a Linear that feeds a BatchNorm1d has NO gradient (the batch mean is subtracted again): what either side
+# computes for it is rounding noise around zero (~1e-6 here, changing with the order of the float atomics from run to run).  These entries
+# are compared against an absolute floor instead of a bound relative to their own (noise) magnitude.
+NOISE_GRADS_TRAIN = ("base_layers.0.bias", "base_layers.3.bias")
+NOISE_FLOOR = 2e-5
+
+
 def compare_with_fixture(module, name, train, device, rtol_out, rtol_grad, gold=None, skip_grads=()):
     """Every stored array of one (case, mode) against a module of the same state-dict layout; returns the worst ratio observed / bound."""
     g = gold if gold is not None else np.load(GOLD)
@@ -28,6 +35,7 @@ def compare_with_fixture(module, name, train, device, rtol_out, rtol_grad, gold=
     hf.fill_state(module, name)
     outs, grads, bufs = hf.run_case(module, name, train, device)
     worst = 0.0
+    worst_key = [""]
     seen = set()
     for k in keys:
         kind, sub = k[len(tag) + 1:].split("/", 1)
@@ -44,12 +52,17 @@ def compare_with_fixture(module, name, train, device, rtol_out, rtol_grad, gold=
         seen.add((kind, sub))
         assert got.shape == want.shape, (k, got.shape, want.shape)
         bound = tol * max(float(np.abs(want).max()), 1e-3)
+        if kind == "grad" and train and name.startswith("he_") and sub in NOISE_GRADS_TRAIN:
+            assert float(np.abs(want).max()) <= NOISE_FLOOR, (k, float(np.abs(want).max()))      # the reference's own value is noise too
+            bound = NOISE_FLOOR
         err = float(np.abs(got - want).max())
         assert err <= bound, f"{k}: |diff| {err:.3e} > {bound:.3e}"
-        worst = max(worst, err / bound)
+        if err / bound > worst:
+            worst, worst_key[0] = err / bound, k
     # nothing the module produces may be missing from the reference's record either (e.g. an extra head)
     for sub in outs:
         assert ("out", sub) in seen, f"{tag}: output {sub} is not in the reference's record"
+    print(f"[margin] {tag}: worst observed / bound {worst:.3g} at {worst_key[0]}")
     return worst
 
 
