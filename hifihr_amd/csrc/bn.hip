@@ -191,11 +191,7 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(float* __restrict_
 // PRE = true: mean / invstd (forward) or the totals behind the slots (backward) were produced by a finalize launch
 // MNG: channel groups per thread the registers are sized for (1: C <= 1024 -- every ResNet layer -- 80-100 registers less than the
 // general form, i.e. 4-5 waves per SIMD instead of 2-3; kMaxNG: up to 4096 channels)
-// PF (round 6, one channel group per thread only): the first trip's rows are requested BEFORE the slot fold -- the fold is one dependent L2
-// round trip (+ fp64 sums, a square root) at the head of every workgroup of a launch that otherwise only streams; with the trip's
-// 4-8 loads already in flight the stream starts under it.  (The Winograd input transform measured the same idea slower, at 228
-// registers; these kernels have 64-80.)
-template <bool PRE, int MNG, bool PF = false>
+template <bool PRE, int MNG>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ residual, int act, long M,
                                                         int C, float eps, float momentum, float* __restrict__ y, float* __restrict__ save_mean,
@@ -203,20 +199,6 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                         float* __restrict__ running_var) {
   __shared__ float s_sc[kMaxC], s_sh[kMaxC];
   const BnMap mp = bn_map(C);
-  float4 pv[kBnUnroll], prs[kBnUnroll];
-  bool pf = false;
-  if constexpr (PF && MNG == 1) {
-    const long stride0 = (long)gridDim.x * mp.RL, m0 = (long)blockIdx.x * mp.RL + mp.rl;
-    pf = mp.active && mp.NG == 1 && m0 + (kBnUnroll - 1) * stride0 < M;
-    if (pf) {
-#pragma unroll
-      for (int u = 0; u < kBnUnroll; ++u) {
-        const size_t o = (size_t)(m0 + u * stride0) * C + mp.cg0 * 4;
-        pv[u] = *reinterpret_cast<const float4*>(x + o);
-        prs[u] = residual ? *reinterpret_cast<const float4*>(residual + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  }
   for (int c = threadIdx.x; c < C; c += 256) {            // every workgroup folds the slot partials itself (L2-resident)
     float mu, is, var = 0.f;
     if (PRE) {
@@ -266,15 +248,6 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
       // deep layers latency-bound (kBnUnroll independent 16-byte loads per lane instead)
       const float4 sc = scale[0], sh = shift[0];
       const int cb = mp.cg0 * 4;
-      if constexpr (PF && MNG == 1) {
-        if (pf) {                                              // the trip whose loads went out in front of the fold
-#pragma unroll
-          for (int u = 0; u < kBnUnroll; ++u)
-            finish(make_float4(pv[u].x * sc.x + sh.x, pv[u].y * sc.y + sh.y, pv[u].z * sc.z + sh.z, pv[u].w * sc.w + sh.w), prs[u],
-                   (size_t)(m + u * stride) * C + cb);
-          m += kBnUnroll * stride;
-        }
-      }
       for (; m + (kBnUnroll - 1) * stride < M; m += kBnUnroll * stride) {
         float4 v[kBnUnroll], rs[kBnUnroll];
 #pragma unroll
@@ -395,7 +368,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  dres = g (when the block has an identity branch).
 // Every workgroup folds the slot partials of the reduction into mean(g), mean(g * xhat) in LDS; workgroup 0 accumulates
 // dgamma / dbeta; the last workgroup to finish zeroes the slots.
-template <bool PRE, int MNG, bool PF = false>
+template <bool PRE, int MNG>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                           const float* __restrict__ x, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, const float* __restrict__ gamma,
@@ -405,22 +378,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   __shared__ float s_mg[kMaxC], s_mgx[kMaxC];
   const BnMap mp = bn_map(C);
   const float invM = 1.0f / (float)M;
-  float4 pv[kBnUnroll], pd[kBnUnroll], py[kBnUnroll];       // PF: the first trip, requested in front of the slot fold (bn_act_fwd_kernel)
-  bool pf = false;
-  if constexpr (PF && MNG == 1) {
-    const long stride0 = (long)gridDim.x * mp.RL, m0 = (long)blockIdx.x * mp.RL + mp.rl;
-    pf = mp.active && mp.NG == 1 && m0 + (kBnUnroll - 1) * stride0 < M;
-    if (pf) {
-      const bool hy = act == 1 && y != nullptr;
-#pragma unroll
-      for (int u = 0; u < kBnUnroll; ++u) {
-        const size_t o = (size_t)(m0 + u * stride0) * C + mp.cg0 * 4;
-        pv[u] = *reinterpret_cast<const float4*>(x + o);
-        pd[u] = *reinterpret_cast<const float4*>(dy + o);
-        py[u] = hy ? *reinterpret_cast<const float4*>(y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  }
   for (int c = threadIdx.x; c < C; c += 256) {
     float sg, sgx;
     if (PRE) {
@@ -471,14 +428,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     long m = (long)blockIdx.x * mp.RL + mp.rl;
     if (mp.NG == 1) {
       const int cb = mp.cg0 * 4;
-      if constexpr (PF && MNG == 1) {
-        if (pf) {
-#pragma unroll
-          for (int u = 0; u < kBnUnroll; ++u)
-            emit(0, masked_grad(act, pd[u], have_y, py[u], pv[u], k1[0], sh[0]), pv[u], (size_t)(m + u * stride) * C + cb);
-          m += kBnUnroll * stride;
-        }
-      }
       for (; m + (kBnUnroll - 1) * stride < M; m += kBnUnroll * stride) {
         float4 v[kBnUnroll], d[kBnUnroll], yv[kBnUnroll];
 #pragma unroll
@@ -867,10 +816,6 @@ static unsigned bn_reduce_grid(long M, int C) {
   return (unsigned)blocks;
 }
 static bool bn_c_ok(int C) { return C >= 4 && C % 4 == 0 && C <= 4 * 256 * kMaxNG; }
-static bool bn_prefetch_on() {       // HIFIHR_BN_PREFETCH=0: the apply kernels without the first trip in front of the slot fold (A/B timing)
-  static const int on = [] { const char* e = getenv("HIFIHR_BN_PREFETCH"); return e ? atoi(e) : 1; }();
-  return on != 0;
-}
 
 hipError_t launch_bn_stats(const float* x, long M, int C, float* stats, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
@@ -883,9 +828,7 @@ hipError_t launch_bn_act_fwd(const float* x, float* stats, const float* gamma, c
                              float* running_mean, float* running_var, hipStream_t st) {
   if (!bn_c_ok(C)) return hipErrorInvalidValue;
   if (C <= kFuseMaxC) {
-    if (C <= 1024 && bn_prefetch_on()) hipLaunchKernelGGL((bn_act_fwd_kernel<false, 1, true>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, x, stats, gamma, beta,
-                       residual, act, M, C, eps, momentum, y, save_mean, save_invstd, running_mean, running_var);
-    else if (C <= 1024) hipLaunchKernelGGL((bn_act_fwd_kernel<false, 1>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
+    if (C <= 1024) hipLaunchKernelGGL((bn_act_fwd_kernel<false, 1>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
                        momentum, y, save_mean, save_invstd, running_mean, running_var);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<false, kMaxNG>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, x, stats, gamma, beta, residual, act, M, C, eps,
                        momentum, y, save_mean, save_invstd, running_mean, running_var);
@@ -929,9 +872,7 @@ hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, co
   else hipLaunchKernelGGL((bn_bwd_reduce_kernel<kMaxNG>), dim3(bn_reduce_grid(M, C)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta, act,
                      M, C, red);
   if (C <= kFuseMaxC) {
-    if (C <= 1024 && bn_prefetch_on()) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 1, true>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd,
-                       gamma, beta, red, act, M, C, dx, dres, dgamma_acc, dbeta_acc);
-    else if (C <= 1024) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 1>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
+    if (C <= 1024) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 1>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
                        red, act, M, C, dx, dres, dgamma_acc, dbeta_acc);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, kMaxNG>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, beta,
                        red, act, M, C, dx, dres, dgamma_acc, dbeta_acc);
@@ -950,9 +891,7 @@ hipError_t launch_bn_act_bwd(const float* dy, const float* y, const float* x, co
 hipError_t launch_bn_bwd_apply(const float* g, const float* x, const float* save_mean, const float* save_invstd, const float* gamma, long M,
                                int C, float* red, float* dx, float* dgamma_acc, float* dbeta_acc, hipStream_t st) {
   if (!bn_c_ok(C) || C > kFuseMaxC) return hipErrorInvalidValue;
-  if (C <= 1024 && bn_prefetch_on()) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 1, true>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, g, (const float*)nullptr, x,
-                     save_mean, save_invstd, gamma, (const float*)nullptr, red, 0, M, C, dx, (float*)nullptr, dgamma_acc, dbeta_acc);
-  else if (C <= 1024) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 1>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, g, (const float*)nullptr, x, save_mean, save_invstd,
+  if (C <= 1024) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 1>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, g, (const float*)nullptr, x, save_mean, save_invstd,
                      gamma, (const float*)nullptr, red, 0, M, C, dx, (float*)nullptr, dgamma_acc, dbeta_acc);
   else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, kMaxNG>), dim3(bn_grid(M, C, true)), dim3(256), 0, st, g, (const float*)nullptr, x, save_mean, save_invstd,
                      gamma, (const float*)nullptr, red, 0, M, C, dx, (float*)nullptr, dgamma_acc, dbeta_acc);
