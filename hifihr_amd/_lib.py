@@ -196,6 +196,8 @@ class HifihrLib:
         c.hifihr_conv3x3_c64_wino_res.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
         c.hifihr_conv3x3_c64_bwd_pair_supported.argtypes = [c_int] * 3
         c.hifihr_conv3x3_c64_bwd_pair.argtypes = [c_void_p] * 7 + [c_size_t] + [c_int] * 3 + [c_void_p]
+        c.hifihr_conv3x3_c64_bwd_pair_slabs.argtypes = [c_void_p] * 6 + [c_size_t] + [c_int] * 3 + [c_void_p, c_void_p]
+        c.hifihr_conv_halo_wgrad_reduce_multi.argtypes = [c_void_p, c_int, c_void_p]
         c.hifihr_wino_bn_input_supported.argtypes = [c_int, c_int]
         c.hifihr_wino_bn_input_transform.argtypes = [_c_float_p] * 7 + [c_int] * 5 + [c_float, c_float] + [_c_float_p] * 4 + [c_void_p]
         c.hifihr_wino_output_transform_bnred.argtypes = [_c_float_p] * 10 + [c_int] * 5 + [c_void_p]
@@ -559,6 +561,23 @@ class HifihrLib:
         self.check(self.c.hifihr_conv3x3_c64_bwd_pair(_fp(dy), _fp(U_bwd), _fp(res), _fp(dx), _fp(x), _fp(dw), _fp(ws),
                                                       0 if ws is None else ws.numel() * ws.element_size(), N, H, W, _stream_of(dy)),
                    "hifihr_conv3x3_c64_bwd_pair")
+
+    def conv3x3_c64_bwd_pair_slabs(self, dy, U_bwd, res, dx, x, slabs, N, H, W):
+        """hifihr_conv3x3_c64_bwd_pair without its slab sum: -> number of weight-gradient slabs left in `slabs` (hifihr_conv_halo_wgrad_reduce_multi)."""
+        import ctypes
+        n = ctypes.c_int(0)
+        self.check(self.c.hifihr_conv3x3_c64_bwd_pair_slabs(_fp(dy), _fp(U_bwd), _fp(res), _fp(dx), _fp(x), _fp(slabs), slabs.numel() * slabs.element_size(),
+                                                            N, H, W, ctypes.cast(ctypes.pointer(n), c_void_p), _stream_of(dy)), "hifihr_conv3x3_c64_bwd_pair_slabs")
+        return n.value
+
+    def conv_halo_wgrad_reduce_multi(self, jobs):
+        """jobs: [(slabs tensor, nslab, dw_acc tensor)] -- the slab sums of several 64 -> 64 layers in one launch."""
+        import ctypes
+        import struct
+        raw = b"".join(struct.pack("<QQii", sl.data_ptr(), dw.data_ptr(), int(n), 0) for sl, n, dw in jobs)
+        buf = ctypes.create_string_buffer(raw, len(raw))
+        self.check(self.c.hifihr_conv_halo_wgrad_reduce_multi(ctypes.cast(buf, c_void_p), len(jobs), _stream_of(jobs[0][0])),
+                   "hifihr_conv_halo_wgrad_reduce_multi")
 
     def wino_bn_input_supported(self, C, m):
         return bool(self.c.hifihr_wino_bn_input_supported(int(C), int(m)))

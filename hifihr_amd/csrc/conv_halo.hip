@@ -932,10 +932,10 @@ __global__ __launch_bounds__(256 + 64 * kNL) void conv_c64_bwd_pair_kernel(Wino2
 // dw[k][tap][c] += sum over the slabs, in a fixed order (bit-reproducible).  A workgroup takes 64 gradient elements; wave w sums slabs
 // 64 q + 16 w .. + 15 (q = 0, 1, ..) with its 16 loads of a trip in flight, the four waves' partial sums meet in LDS.  (Round 3: one
 // thread per element walking every slab, 32 loads in flight -- 144 workgroups, 8 dependent trips for 256 slabs: 10 us for 38 MB.)
-__global__ __launch_bounds__(256) void conv_halo_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dw) {
+__device__ __forceinline__ void halo_wgrad_reduce_body(const float* __restrict__ slabs, int nslab, float* __restrict__ dw, int blk) {
   __shared__ float part[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;                      // index into a slab: (tap * 64 + k) * 64 + c
+  const int i = blk * 64 + lane;                             // index into a slab: (tap * 64 + k) * 64 + c
   constexpr size_t kSlab = (size_t)kTaps * 64 * 64;
   float s = 0.f;
   for (int z0 = 16 * w; z0 < nslab; z0 += 64) {
@@ -951,6 +951,21 @@ __global__ __launch_bounds__(256) void conv_halo_wgrad_reduce_kernel(const float
     const int c = i & 63, k = (i >> 6) & 63, tp = i >> 12;
     dw[((size_t)k * kTaps + tp) * 64 + c] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
   }
+}
+__global__ __launch_bounds__(256) void conv_halo_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dw) {
+  halo_wgrad_reduce_body(slabs, nslab, dw, (int)blockIdx.x);
+}
+// the slab sums of SEVERAL 64 -> 64 layers in one launch (round 6; blockIdx.y = layer): a step whose weight gradients are read by the
+// optimizer only runs them all in front of it (hifihr_conv_halo_wgrad_reduce_multi; jobs in the kernel arguments)
+constexpr int kHaloReduceMaxJobs = 16;
+struct HaloReduceJobs {
+  const float* slabs[kHaloReduceMaxJobs];
+  float* dw[kHaloReduceMaxJobs];
+  int nslab[kHaloReduceMaxJobs];
+};
+__global__ __launch_bounds__(256) void conv_halo_wgrad_reduce_multi_kernel(HaloReduceJobs js) {
+  const int j = blockIdx.y;
+  halo_wgrad_reduce_body(js.slabs[j], js.nslab[j], js.dw[j], (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1552,8 +1567,22 @@ bool conv_c64_bwd_pair_supported(int N, int H, int W) {
   return on && conv_wino2_supported(N, H, W, 64, 64) && conv_halo_wgrad_supported(g) && halo_cus() >= 2;
 }
 
+hipError_t launch_conv_halo_wgrad_reduce_multi(const HaloReduceJob* jobs, int njobs, hipStream_t st) {
+  for (int base = 0; base < njobs; base += kHaloReduceMaxJobs) {
+    HaloReduceJobs js;
+    const int n = njobs - base < kHaloReduceMaxJobs ? njobs - base : kHaloReduceMaxJobs;
+    for (int q = 0; q < n; ++q) {
+      if (jobs[base + q].slabs == nullptr || jobs[base + q].dw == nullptr || jobs[base + q].nslab <= 0) return hipErrorInvalidValue;
+      js.slabs[q] = jobs[base + q].slabs; js.dw[q] = jobs[base + q].dw; js.nslab[q] = jobs[base + q].nslab;
+    }
+    hipLaunchKernelGGL(conv_halo_wgrad_reduce_multi_kernel, dim3(kTaps * 64 * 64 / 64, n), dim3(256), 0, st, js);
+  }
+  return hipGetLastError();
+}
+
+// nslab_out != null: the slab sum is LEFT to the caller (launch_conv_halo_wgrad_reduce_multi); *nslab_out = slabs written into `slabs`
 hipError_t launch_conv_c64_bwd_pair(const float* dy, const float* U_bwd, const float* res, float* dx, const float* x, float* dw, float* slabs,
-                                    int N, int H, int W, hipStream_t st) {
+                                    int N, int H, int W, hipStream_t st, int* nslab_out) {
   if (!conv_c64_bwd_pair_supported(N, H, W)) return hipErrorInvalidValue;
   const float* zeros = conv_halo_zero_page(st);
   if (zeros == nullptr) return hipErrorNotReady;
@@ -1583,7 +1612,8 @@ hipError_t launch_conv_c64_bwd_pair(const float* dy, const float* U_bwd, const f
   if (w.slabs == nullptr) return hipErrorNotReady;
   if (res != nullptr) hipLaunchKernelGGL((conv_c64_bwd_pair_kernel<true>), dim3(ga + gb), dim3(256 + 64 * kNL), 0, st, d, ga, w);
   else hipLaunchKernelGGL((conv_c64_bwd_pair_kernel<false>), dim3(ga + gb), dim3(256 + 64 * kNL), 0, st, d, ga, w);
-  hipLaunchKernelGGL(conv_halo_wgrad_reduce_kernel, dim3(kTaps * 64 * 64 / 64), dim3(256), 0, st, w.slabs, gb, dw);
+  if (nslab_out != nullptr) *nslab_out = gb;
+  else hipLaunchKernelGGL(conv_halo_wgrad_reduce_kernel, dim3(kTaps * 64 * 64 / 64), dim3(256), 0, st, w.slabs, gb, dw);
   return hipGetLastError();
 }
 

@@ -1282,6 +1282,24 @@ int hifihr_conv3x3_c64_bwd_pair(const float* dy, const float* u_bwd, const float
   return HIFIHR_OK;
 }
 
+int hifihr_conv3x3_c64_bwd_pair_slabs(const float* dy, const float* u_bwd, const float* res, float* dx, const float* x, void* slabs, size_t slab_bytes,
+                                      int N, int H, int W, int* nslab, void* stream) {
+  if (!dy || !u_bwd || !dx || !x || !slabs || !nslab) return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_bwd_pair_slabs: null pointer");
+  if (!hifihr::conv_c64_bwd_pair_supported(N, H, W) || slab_bytes < hifihr::conv_halo_wgrad_slab_bytes())
+    return fail(HIFIHR_EINVAL, "hifihr_conv3x3_c64_bwd_pair_slabs: unsupported shape, or fewer than hifihr_conv2d_wgrad_workspace_bytes slab bytes");
+  HIP_TRY(hifihr::launch_conv_c64_bwd_pair(dy, u_bwd, res, dx, x, nullptr, static_cast<float*>(slabs), N, H, W, (hipStream_t)stream, nslab));
+  return HIFIHR_OK;
+}
+
+int hifihr_conv_halo_wgrad_reduce_multi(const hifihr_halo_reduce_job* jobs, int njobs, void* stream) {
+  static_assert(sizeof(hifihr_halo_reduce_job) == sizeof(hifihr::HaloReduceJob), "job layouts");
+  if (!jobs || njobs <= 0) return fail(HIFIHR_EINVAL, "hifihr_conv_halo_wgrad_reduce_multi: bad argument");
+  for (int i = 0; i < njobs; ++i)
+    if (!jobs[i].slabs_d || !jobs[i].dw_acc_d || jobs[i].nslab <= 0) return fail(HIFIHR_EINVAL, "hifihr_conv_halo_wgrad_reduce_multi: bad job");
+  HIP_TRY(hifihr::launch_conv_halo_wgrad_reduce_multi(reinterpret_cast<const hifihr::HaloReduceJob*>(jobs), njobs, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_wino_bn_input_supported(int C, int m) { return (m == 4 && hifihr::wino4_bn_supported(C)) ? 1 : 0; }
 
 int hifihr_wino_bn_input_transform(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* out,

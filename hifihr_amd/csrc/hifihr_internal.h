@@ -122,7 +122,9 @@ hipError_t launch_conv_wino2(const float* src, const float* U, const float* bias
 // ONE launch + the slab reduction (conv_halo.hip: conv_c64_bwd_pair_kernel)
 bool conv_c64_bwd_pair_supported(int N, int H, int W);
 hipError_t launch_conv_c64_bwd_pair(const float* dy, const float* U_bwd, const float* res_or_null, float* dx, const float* x, float* dw,
-                                    float* slabs_or_null, int N, int H, int W, hipStream_t st);
+                                    float* slabs_or_null, int N, int H, int W, hipStream_t st, int* nslab_out = nullptr);
+struct HaloReduceJob { const float* slabs; float* dw; int nslab; };       // = hifihr_halo_reduce_job (include/hifihr.h)
+hipError_t launch_conv_halo_wgrad_reduce_multi(const HaloReduceJob* jobs, int njobs, hipStream_t st);
 hipError_t launch_conv_halo(const ConvGeom& g, const float* src, const float* wgt, const float* bias_or_null, float* dst, float* stats,
                             const float* zeros, hipStream_t st);
 // batch-norm (+ residual add + ReLU) on NHWC activations, x[M][C].  Statistics buffers are [kStatSlots][2][C]: partial

@@ -661,6 +661,7 @@ class _DeferredDw:
         self.on = os.environ.get("HIFIHR_DEFER_DW", "1") != "0"
         self.active = False
         self.jobs = []
+        self.halo = []
 
     def wants(self, w, direct):
         return (self.on and self.active and direct and not _ASYNC_WGRAD.active and getattr(w, "_hifihr_grad_ready", None) is None)
@@ -668,10 +669,20 @@ class _DeferredDw:
     def add(self, dU, parts, tgt, K, C):
         self.jobs.append((dU, int(parts), tgt, int(K), int(C)))
 
+    def add_halo(self, slabs, nslab, tgt):
+        """the slab sum of a 64 -> 64 layer's pixel-reduction weight gradient (hifihr_conv3x3_c64_bwd_pair_slabs left it to us)"""
+        self.halo.append((slabs, int(nslab), tgt))
+
+    def clear(self):
+        self.jobs.clear(); self.halo.clear()
+
     def flush(self):
         jobs, self.jobs = self.jobs, []
+        halo, self.halo = self.halo, []
+        lib = get_lib() if (jobs or halo) else None
+        if halo:
+            PROFILE.bracket("halo_reduce_multi", lambda: lib.conv_halo_wgrad_reduce_multi(halo))
         if jobs:
-            lib = get_lib()
             PROFILE.bracket("wino_dw_multi", lambda: lib.wino4_dw_transform_multi(jobs))
 
 
@@ -732,7 +743,7 @@ class prepared_weights:
             side_branch.join_pending()
         if os.environ.get("HIFIHR_WEIGHT_PREP", "1") != "0":
             _WEIGHT_PREP.begin()
-        _DEFER_DW.jobs.clear()
+        _DEFER_DW.clear()
         _DEFER_DW.active = True
         # not inside a hipGraph capture: forked branches of a replayed graph ran SLOWER here (8.03 vs 7.74 ms/step) while the same
         # fork in the eager step gains (7.69 vs 7.83)
@@ -745,7 +756,7 @@ class prepared_weights:
         if exc[0] is None:
             _DEFER_DW.flush()                 # the step's deferred weight-gradient transforms, one launch (in front of the optimizer)
         else:
-            _DEFER_DW.jobs.clear()
+            _DEFER_DW.clear()
         side_branch.join_pending()
         if _ASYNC_WGRAD.active:
             _ASYNC_WGRAD.active = False
@@ -983,8 +994,15 @@ class _Conv2dMFMA(torch.autograd.Function):
                 if PROFILE.on:
                     PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "c64-pair"))
                 nslab = lib.conv2d_wgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad)
-                slabs = _wgrad_slabs(gy.device, nslab) if nslab else None
-                PROFILE.bracket("conv_dgrad", lambda: lib.conv3x3_c64_bwd_pair(gy, U2, g_fork, dx, x, tgt, N, H, W, ws=slabs))
+                if nslab and dw is None and _DEFER_DW.wants(w, True):
+                    # the slab sum joins the step's deferred launches (one per step in front of the optimizer): slabs in a buffer of the layer's own
+                    own = _wino_scratch(gy.device, ("c64slabs", w.data_ptr()), (nslab + 3) // 4)
+                    box = []
+                    PROFILE.bracket("conv_dgrad", lambda: box.append(lib.conv3x3_c64_bwd_pair_slabs(gy, U2, g_fork, dx, x, own, N, H, W)))
+                    _DEFER_DW.add_halo(own, box[-1], tgt)
+                else:
+                    slabs = _wgrad_slabs(gy.device, nslab) if nslab else None
+                    PROFILE.bracket("conv_dgrad", lambda: lib.conv3x3_c64_bwd_pair(gy, U2, g_fork, dx, x, tgt, N, H, W, ws=slabs))
                 c64_pair_done = True
             elif PROFILE.on:
                 PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "dgrad-wino2"))

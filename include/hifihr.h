@@ -372,6 +372,18 @@ int hifihr_conv3x3_c64_wino_res(const float* x_d, const float* u_d, const float*
 int hifihr_conv3x3_c64_bwd_pair_supported(int N, int H, int W);
 int hifihr_conv3x3_c64_bwd_pair(const float* dy_d, const float* u_bwd_d, const float* res_d /* or NULL */, float* dx_d, const float* x_d,
                                 float* dw_d, void* ws_d, size_t ws_bytes, int N, int H, int W, void* stream);
+/* The same pair launch with the slab sum LEFT to the caller: the weight-gradient slabs stay in slabs_d ([*nslab][9][64][64], slab_bytes >=
+ * hifihr_conv2d_wgrad_workspace_bytes of the layer) and hifihr_conv_halo_wgrad_reduce_multi adds the slabs of several layers to their
+ * dw_acc_d[64][3][3][64] in ONE launch, slabs in slab order (bit-identical to the sum hifihr_conv3x3_c64_bwd_pair makes itself).  A step
+ * whose weight gradients are read by the optimizer only defers the sums of its 64 -> 64 layers to one call in front of it. */
+int hifihr_conv3x3_c64_bwd_pair_slabs(const float* dy_d, const float* u_bwd_d, const float* res_d /* or NULL */, float* dx_d, const float* x_d,
+                                      void* slabs_d, size_t slab_bytes, int N, int H, int W, int* nslab /* host, out */, void* stream);
+typedef struct hifihr_halo_reduce_job {
+  const float* slabs_d;
+  float* dw_acc_d;
+  int nslab;
+} hifihr_halo_reduce_job;
+int hifihr_conv_halo_wgrad_reduce_multi(const hifihr_halo_reduce_job* jobs /* host array */, int njobs, void* stream);
 /* Batch-norm fused into the F(4x4, 3x3) input transform (round 3, csrc/wino4_bn.hip).  For a BatchNorm2d whose consumer is a Winograd
  * convolution (reference BasicBlock: conv1 -> bn1 -> relu -> conv2; bn2 -> += identity -> relu -> the next block's conv1,
  * network/res_encoder.py:364-373 + vendored utils/Freihand_GNN_mano/network/resnet.py) this ONE launch replaces hifihr_bn_act_fwd followed by

@@ -1106,6 +1106,19 @@ def conv_c64_bwd_pair_case(lib, device, N, H, W, seed=0, with_res=False):
     refx = xr.grad.permute(0, 2, 3, 1) + (res if with_res else 0.0)
     err = float((outs[0][0].cpu() - refx).abs().max())
     assert err <= 2e-5 * float(refx.abs().max()) + 1e-6, f"pair: dx vs torch {err}"
+    # the same launch with the slab sum left to hifihr_conv_halo_wgrad_reduce_multi (the step's deferred form): two "layers" in one reduce launch,
+    # each bit-identical to the sum the pair call makes itself
+    nb = lib.conv2d_wgrad_workspace_bytes(N, H, W, 64, 64, 3, 3, 1, 1)
+    jobs, dxs = [], []
+    for rep in range(2):
+        slabs = torch.full(((nb + 3) // 4,), float("nan"), device=device)
+        dx = torch.full((N, H, W, 64), 7.0, device=device); dw = torch.full((64, 3, 3, 64), 0.25, device=device)
+        ns = lib.conv3x3_c64_bwd_pair_slabs(gy_d, U2, res_d, dx, x_d, slabs, N, H, W)
+        assert ns > 0
+        jobs.append((slabs, ns, dw)); dxs.append(dx)
+    lib.conv_halo_wgrad_reduce_multi(jobs)
+    for (slabs, ns, dw), dx in zip(jobs, dxs):
+        assert torch.equal(dx, outs[0][0]) and torch.equal(dw, outs[0][1]), "deferred slab sum differs from the pair call's own"
 
 
 def conv_bias_relu_case(lib, device, N, H, W, C, K, R, stride, seed=0, pad=0):
