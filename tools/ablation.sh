@@ -34,3 +34,6 @@ run "batched TN products with short reductions on the per-tile kernels (HIFIHR_G
 run "F(4x4) backward-data and backward-weight products as two launches (HIFIHR_GEMM_PAIR=0)" HIFIHR_GEMM_PAIR=0
 run "layer 1 data gradient and weight gradient as two launches (HIFIHR_C64_PAIR=0)" HIFIHR_C64_PAIR=0
 run "eager launches, no hipGraph (--graph 0)" --graph 0
+run "round 6: stem batch-norm reduction over every input pixel (HIFIHR_STEM_REDUCE_Y=0)" HIFIHR_STEM_REDUCE_Y=0
+run "round 6: weight-gradient transforms / slab sums per layer, not deferred (HIFIHR_DEFER_DW=0)" HIFIHR_DEFER_DW=0
+run "round 6: TN products walk the zero rows behind the tile mosaic (HIFIHR_GEMM_TN_SKIP=0)" HIFIHR_GEMM_TN_SKIP=0
