@@ -1093,16 +1093,54 @@ __device__ __forceinline__ TnTile tn_tile_at(const BgemmArgs& a, long cur, long 
   return TnTile{p, nt, mb0 * 16, lim >= 8 ? 8 : lim >= 4 ? 4 : lim >= 2 ? 2 : 1};
 }
 
+// The tiles of one workgroup, in order: `nr` ranges [lo0 + i step, + len) of the flattened (problem, 128-column tile, 16-row block) space -- its
+// slices of the rounds of the XCD-coherent schedule (BgemmArgs::co_r) -- then one range [tail_lo, tail_hi): the contiguous share (all of
+// the work when nr == 0).  Every range is cut into tiles by tn_tile_at.
+struct TnWalk {
+  int nr, ri;
+  long lo0, step, len, tail_lo, tail_hi, cur, end;
+  __device__ __forceinline__ bool next(const BgemmArgs& a, TnTile& t) {
+    while (cur >= end) {
+      if (ri < nr) { cur = lo0 + (long)ri * step; end = cur + len; }
+      else if (ri == nr && tail_lo < tail_hi) { cur = tail_lo; end = tail_hi; }
+      else return false;
+      ++ri;
+    }
+    t = tn_tile_at(a, cur, end);
+    cur += t.nb;
+    return true;
+  }
+};
+__device__ __forceinline__ TnWalk tn_walk(const BgemmArgs& a, long per, int wg, int nblk) {
+  TnWalk w;
+  w.ri = 0; w.cur = 0; w.end = 0;
+  const long total = (long)a.batch * a.tiles_n * (a.M / 16);
+  if (a.co_rounds > 0) {
+    const int W = nblk >> 3, x = wg / W, j = wg - x * W;      // (nblk % 8 == 0: xcd_remap hands an XCD W consecutive workgroup ids)
+    const long bpp = (long)a.tiles_n * (a.M / 16), bw = a.co_r * bpp / W;
+    w.nr = a.co_rounds; w.step = 8L * a.co_r * bpp; w.lo0 = (long)x * a.co_r * bpp + (long)j * bw; w.len = bw;
+    const long t0 = (long)a.co_rounds * w.step, rest = total - t0, pt = (rest + nblk - 1) / nblk;
+    w.tail_lo = min(t0 + (long)wg * pt, total); w.tail_hi = min(w.tail_lo + pt, total);
+  } else {
+    w.nr = 0; w.lo0 = 0; w.step = 0; w.len = 0;
+    w.tail_lo = min((long)wg * per, total); w.tail_hi = min(w.tail_lo + per, total);
+  }
+  return w;
+}
+
 __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float* __restrict__ lds, int bid, int nblk) {
   constexpr int STAGE = 256 * 32;                            // floats per stage: A rows t 0..31 (x 128), then B rows t 0..31 (x 128)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wg = xcd_remap(bid, nblk);
-  const long total = (long)a.batch * a.tiles_n * (a.M / 16);
-  const long s_lo = (long)wg * per, s_hi = min(s_lo + per, total);
-  if (s_lo >= s_hi) return;                                  // (uniform)
+  const TnWalk walk = tn_walk(a, per, wg, nblk);
   const int nch = a.K / 32;
   int ntiles = 0;
-  for (long cur = s_lo; cur < s_hi; cur += tn_tile_at(a, cur, s_hi).nb) ++ntiles;
+  {
+    TnWalk c = walk;
+    TnTile tt;
+    while (c.next(a, tt)) ++ntiles;
+  }
+  if (ntiles == 0) return;                                   // (uniform)
   const int nchunks = ntiles * nch;
 
   if (wave >= 4) {
@@ -1110,8 +1148,9 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
     // ---------------- loader: piece q = l + 4 i (i < 8) of a chunk: q < 16 rows t = 2 q, 2 q + 1 of A, else rows 2 (q - 16) .. of B;
     //                  lane -> (row lane >> 5, physical 16-byte segment lane & 31) ----------------
     const int l = wave - 4;
-    long cur = s_lo;
-    TnTile t = tn_tile_at(a, cur, s_hi);
+    TnWalk lw = walk;
+    TnTile t;
+    lw.next(a, t);
     const float* src[8];
     size_t step[8];
     auto bind = [&](const TnTile& tt) {
@@ -1141,8 +1180,7 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
       for (int i = 0; i < 8; ++i) HIFIHR_GLDS16(src[i] + lc * step[i], base + 256 * (l + 4 * i), lane);
       if (++lc == nch) {
         lc = 0;
-        cur += t.nb;
-        if (++li < ntiles) { t = tn_tile_at(a, cur, s_hi); bind(t); }
+        if (++li < ntiles) { lw.next(a, t); bind(t); }
       }
     };
     issue_next(0);
@@ -1167,7 +1205,7 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
     boff[i] = 4 * ((colb >> 2) ^ (4 * g)) + (colb & 3);
   }
   HIFIHR_RAW_BARRIER();                                      // barrier -1
-  long cur = s_lo;
+  TnWalk mw = walk;
   int gc = 0;
   auto run_tile = [&](auto nbc, const TnTile& t) {
     constexpr int NB = decltype(nbc)::value;
@@ -1296,8 +1334,8 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
     }
   };
   for (int ti = 0; ti < ntiles; ++ti) {
-    const TnTile t = tn_tile_at(a, cur, s_hi);
-    cur += t.nb;
+    TnTile t;
+    mw.next(a, t);
     switch (t.nb) {
       case 8: run_tile(std::integral_constant<int, 8>{}, t); break;
       case 4: run_tile(std::integral_constant<int, 4>{}, t); break;
@@ -1327,6 +1365,8 @@ __global__ __launch_bounds__(512) void bgemm_nt_tn_pair_kernel(BgemmArgs a, long
 }
 
 static int gemm_cus() {
+  // HIFIHR_GEMM_CUS (tests: the emulator reports 4 compute units, and the XCD-coherent TN schedule needs a multiple of 8 workgroups)
+  if (const char* e = getenv("HIFIHR_GEMM_CUS")) { const int v = atoi(e); if (v > 0) return v; }
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
@@ -1598,6 +1638,25 @@ int bgemm_tn_parts(int M, int N, int T, int batch) {
   return (nch + cps - 1) / cps;
 }
 
+// XCD-coherent schedule of the TN row-share kernel for G workgroups (BgemmArgs::co_r): the smallest number r of problems per XCD and round
+// that gives every workgroup of the XCD at least one whole 128-row tile per round, while the operands of those r problems fit the XCD's L2
+// and at least one full round exists.  HIFIHR_GEMM_TN_COHERENT=0: contiguous shares.
+static void tn_coherent(BgemmArgs& a, int G) {
+  static const int on = [] { const char* e = getenv("HIFIHR_GEMM_TN_COHERENT"); return e ? atoi(e) : 1; }();
+  a.co_r = 0; a.co_rounds = 0;
+  if (!on || G < 8 || G % 8 != 0 || a.M % 16 != 0) return;
+  const int W = G / 8;
+  const long bpp = (long)a.tiles_n * (a.M / 16);
+  if (bpp <= 8) return;                                     // one tile per problem: no two workgroups share a panel
+  const double mb_per_problem = 4.0 * a.K * ((double)a.M + 128.0 * a.tiles_n) / (1 << 20);
+  for (int r = 1; r <= 8; ++r) {
+    if ((r * bpp) % W != 0 || r * bpp / W < 8) continue;
+    if (r * mb_per_problem > 3.5 || a.batch / (8 * r) < 1) return;
+    a.co_r = r; a.co_rounds = a.batch / (8 * r);
+    return;
+  }
+}
+
 hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M, int N, int T, int batch, int parts, hipStream_t st, int T_valid) {
   if (!bgemm_tn_supported(M, N, T) || batch <= 0 || parts <= 0 || T_valid < 0 || T_valid > T) return hipErrorInvalidValue;
   BgemmArgs a{};
@@ -1616,6 +1675,7 @@ hipError_t launch_bgemm_tn(const float* A, const float* B, float* Cparts, int M,
     long per = (total + cus - 1) / cus;
     if (per < 4) per = 4;
     const int G = (int)((total + per - 1) / per);
+    tn_coherent(a, G);
     hipLaunchKernelGGL(bgemm_tn_rows_kernel, dim3(G), dim3(512), 0, st, a, per);
     return hipGetLastError();
   }
@@ -1695,6 +1755,7 @@ hipError_t launch_bgemm_nt_tn_pair(const float* A, const float* B, float* C, int
   long per_b = (total_b + gb - 1) / gb;
   if (per_b < 4) per_b = 4;
   gb = (int)((total_b + per_b - 1) / per_b);
+  tn_coherent(b, gb);
   hipLaunchKernelGGL(bgemm_nt_tn_pair_kernel, dim3(ga + gb), dim3(512), 0, st, a, per_a, ga, b, per_b);
   return hipGetLastError();
 }

@@ -393,6 +393,12 @@ struct BgemmArgs {
   // bgemm_nt_rows_kernel<2>: A is an NHWC image x[n][ih][iw][cC] and row m of the product is the (r, s, c)-ordered patch of output pixel
   // m = (n, oh, ow), gathered by the loader waves (K = cR * cS * cC, cC % 32 == 0; B = the filter [N][cR][cS][cC])
   int cIH = 0, cIW = 0, cC = 0, cOH = 0, cOW = 0, cR = 0, cS = 0, cStride = 1, cPad = 0;
+  // bgemm_tn_rows_kernel, XCD-coherent schedule (round 6; 0: one contiguous share per workgroup).  The tiles of ONE problem read the same two
+  // operand panels; with contiguous shares the 16 workgroups of an XCD sit in 4-5 different problems at any time (9 MB of operands against a
+  // 4 MB L2: every panel was fetched ~4 x).  Here the chip walks the problems in `co_rounds` rounds of 8 * co_r: in a round XCD x owns co_r
+  // consecutive problems and its workgroups split THEIR blocks evenly (whole tiles), so an XCD's L2 holds the operands of co_r problems;
+  // the problems left over behind the last full round are shared out as before.
+  int co_r = 0, co_rounds = 0;
   int k_valid = 0;             // bgemm_tn_rows_kernel: rows t >= k_valid of every problem are ZERO in both operands (the padding behind the last
                                // tile mosaic of an F(4x4) layer: 450 real rows in 480) -- their k-steps are skipped; 0: every row counts
   float* stats = nullptr;      // bgemm_nt_rows_kernel, batch 1 (a 1x1 convolution in front of a batch-norm): per-column sum / sum of squares of C

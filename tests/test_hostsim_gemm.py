@@ -62,3 +62,22 @@ def test_bgemm_tn_row_shares(hostsim_lib, M, N, T, batch):
     inside a 128-row tile, tails cut into 64 / 32 / 16-row tiles, tiles that cross problem boundaries, complete products in ONE slab."""
     assert hostsim_lib.bgemm_describe(True, M, N, T, batch) == "bgemm_tn_rows_kernel"
     assert kc.bgemm_tn_case(hostsim_lib, "cpu", M, N, T, batch, seed=M + T) == 1
+
+
+@pytest.mark.parametrize("M,N,T,batch,cus", [(256, 128, 64, 20, 16), (256, 256, 64, 18, 16), (128, 256, 96, 9, 8)])
+def test_bgemm_tn_xcd_coherent_schedule(hostsim_lib, monkeypatch, M, N, T, batch, cus):
+    """bgemm_tn_rows_kernel on the XCD-coherent schedule (BgemmArgs::co_r: rounds in which the workgroups of one XCD split the tiles of the
+    same problem(s), then a contiguous tail over the problems behind the last full round) -- the emulator is told `cus` compute units so that
+    the workgroup count is a multiple of 8: whole-tile slices, problem boundaries inside a round, a tail of short tiles, and the contiguous
+    schedule (HIFIHR_GEMM_TN_COHERENT=0) giving the SAME bits (every output element is one complete reduction either way)."""
+    import torch
+    monkeypatch.setenv("HIFIHR_GEMM_CUS", str(cus))
+    assert hostsim_lib.bgemm_describe(True, M, N, T, batch) == "bgemm_tn_rows_kernel"
+    assert kc.bgemm_tn_case(hostsim_lib, "cpu", M, N, T, batch, seed=M + T + batch) == 1
+    gen = torch.Generator().manual_seed(5)
+    a = torch.randn(batch, T, M, generator=gen); b = torch.randn(batch, T, N, generator=gen)
+    c1 = torch.full((1, batch, M, N), 7.0); c0 = torch.full((1, batch, M, N), 7.0)
+    hostsim_lib.bgemm_tn(a, b, c1, M, N, T, batch, 1)
+    monkeypatch.setenv("HIFIHR_GEMM_CUS", "4")               # 4 workgroups: never coherent
+    hostsim_lib.bgemm_tn(a, b, c0, M, N, T, batch, 1)
+    assert torch.equal(c0, c1)
