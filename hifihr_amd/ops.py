@@ -662,23 +662,30 @@ class _DeferredDw:
         self.active = False
         self.jobs = []
         self.halo = []
+        self.pending = set()               # gradient targets with a job in the lists
 
     def wants(self, w, direct):
-        return (self.on and self.active and direct and not _ASYNC_WGRAD.active and getattr(w, "_hifihr_grad_ready", None) is None)
+        # (a layer that already holds a pending job -- a second backward inside one scope -- takes the immediate path: its own slab buffer
+        #  must stay as the first backward left it until the flush)
+        return (self.on and self.active and direct and not _ASYNC_WGRAD.active and getattr(w, "_hifihr_grad_ready", None) is None
+                and (w.grad is None or w.grad.data_ptr() not in self.pending))
 
     def add(self, dU, parts, tgt, K, C):
         self.jobs.append((dU, int(parts), tgt, int(K), int(C)))
+        self.pending.add(tgt.data_ptr())
 
     def add_halo(self, slabs, nslab, tgt):
         """the slab sum of a 64 -> 64 layer's pixel-reduction weight gradient (hifihr_conv3x3_c64_bwd_pair_slabs left it to us)"""
         self.halo.append((slabs, int(nslab), tgt))
+        self.pending.add(tgt.data_ptr())
 
     def clear(self):
-        self.jobs.clear(); self.halo.clear()
+        self.jobs.clear(); self.halo.clear(); self.pending.clear()
 
     def flush(self):
         jobs, self.jobs = self.jobs, []
         halo, self.halo = self.halo, []
+        self.pending.clear()
         lib = get_lib() if (jobs or halo) else None
         if halo:
             PROFILE.bracket("halo_reduce_multi", lambda: lib.conv_halo_wgrad_reduce_multi(halo))

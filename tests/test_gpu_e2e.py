@@ -508,3 +508,55 @@ def test_overfitting_one_batch_reduces_every_supervised_term():
     assert all(torch.isfinite(torch.tensor(v)) for v in last.values())
     for k in first:
         assert last[k] < 0.5 * first[k], (k, first[k], last[k])
+
+
+def test_deferred_weight_gradient_transforms_equal_the_immediate_ones():
+    """ops._DeferredDw (the F(4x4) weight-gradient transforms and the 64 -> 64 slab sums of a step as one launch each in front of the optimizer)
+    against HIFIHR_DEFER_DW=0's per-layer launches: the same flat gradient, bit for bit on the deferred layers (same slabs, same per-item
+    arithmetic), after one backward AND after a second backward inside the same scope (gradient accumulation: the second pass must not
+    disturb the slabs the first one left for the flush)."""
+    from hifihr_amd import ops
+    from hifihr_amd.losses import LossFunction
+    from hifihr_amd.optim import FlatParams, FusedAdam
+    from hifihr_amd.traineval import _forward_backward
+    prev = torch.cuda.current_stream()
+    torch.cuda.set_stream(torch.cuda.Stream())
+    try:
+        tables, args, model, ref, ex, ex_cpu = _setup(4, graded=True)
+        flat = FlatParams(model); opt = FusedAdam(flat, lr=1e-4)
+        _warm_eager(model, opt, ex, args)
+        bufs = [b.clone() for b in model.buffers()]
+        wts = [(n, p) for n, p in model.named_parameters() if p.dim() == 4 and p.shape[2] == 3 and p.shape[0] >= 64]
+
+        def grads(defer, twice):
+            with torch.no_grad():
+                for b, s0 in zip(model.buffers(), bufs):
+                    b.copy_(s0)
+            old = ops._DEFER_DW.on
+            ops._DEFER_DW.on = defer
+            try:
+                with ops.prepared_weights(async_wgrad=False):
+                    _forward_backward(model, LossFunction(), opt, ex, args, "FreiHand")
+                    if twice:                        # a second forward + backward in the SAME scope, accumulating (no zero_grad in between)
+                        zg = opt.zero_grad
+                        opt.zero_grad = lambda set_to_none=False: None
+                        try:
+                            _forward_backward(model, LossFunction(), opt, ex, args, "FreiHand")
+                        finally:
+                            opt.zero_grad = zg
+            finally:
+                ops._DEFER_DW.on = old
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() for n, p in wts}
+        for twice in (False, True):
+            g_def, g_imm = grads(True, twice), grads(False, twice)
+            worst = 0.0
+            for n in g_imm:
+                scale = float(g_imm[n].abs().max())
+                d = float((g_def[n] - g_imm[n]).abs().max())
+                # the products' float atomics elsewhere in backward reorder between two runs: the transforms themselves add nothing
+                assert d <= 2e-4 * scale + 1e-9, (n, twice, d, scale)
+                worst = max(worst, d / max(scale, 1e-30))
+            print(f"[margin] deferred vs immediate weight gradients, second backward in scope = {twice}: worst |diff| / max|g| = {worst:.2e} (bound 2e-4)")
+    finally:
+        torch.cuda.set_stream(prev)
