@@ -58,7 +58,28 @@ def round5():
     kc.adam_case(lib, "cpu", n=4099, wd=0.01, steps=4)
 
 
-GROUPS = {"conv": conv, "render": render, "wino": wino, "round5": round5}
+def round6():
+    """Kernels written or re-indexed in round 6: the multi-layer weight-gradient transform and slab sum, the stem's batch-norm reduction over
+    the pooled grid (incl. the tap-gather path of a near-zero scale), the TN row-share kernel's zero-row tail and XCD-coherent schedule, the
+    light split with a NaN colour."""
+    import torch
+    kc.wino4_dw_multi_case(lib, "cpu")
+    for (N, H, W, res) in [(2, 10, 14, False), (1, 6, 14, True)]:
+        kc.conv_c64_bwd_pair_case(lib, "cpu", N, H, W, seed=N + H, with_res=res)      # (+ the _slabs form and the multi-layer slab sum)
+    for (N, H, W, C) in [(2, 9, 11, 8), (3, 12, 12, 64), (1, 7, 8, 16)]:
+        kc.bn_relu_maxpool_case(lib, "cpu", N, H, W, C, seed=H + C)
+    for m in (4,):                                                               # F(4x4): mosaic layers (zero rows behind the last mosaic)
+        kc.wino_case(lib, "cpu", 16, 14, 14, 64, 128, seed=3, m=m)
+    os.environ["HIFIHR_GEMM_CUS"] = "16"
+    try:
+        kc.bgemm_tn_case(lib, "cpu", 256, 128, 64, 20, seed=7)                    # coherent rounds + a tail of short tiles
+        kc.bgemm_tn_case(lib, "cpu", 128, 256, 96, 9, seed=8)
+    finally:
+        del os.environ["HIFIHR_GEMM_CUS"]
+    kc.light_split_case(lib, "cpu", B=5)
+
+
+GROUPS = {"conv": conv, "render": render, "wino": wino, "round5": round5, "round6": round6}
 for g in (sys.argv[1:] or list(GROUPS)):
     GROUPS[g]()
     print(f"asan: {g} clean", flush=True)
