@@ -104,6 +104,8 @@ class HifihrLib:
         c.hifihr_conv2d_workspace_bytes.restype = c_size_t
         c.hifihr_conv2d_bwd_data.argtypes = [_c_float_p] * 4 + ci + [c_void_p, c_size_t, c_void_p]
         c.hifihr_conv2d_fwd_bnstats.argtypes = [_c_float_p] * 4 + ci + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_conv2d_fwd_bnstats_pair_supported.argtypes = [c_int] * 11
+        c.hifihr_conv2d_fwd_bnstats_pair.argtypes = [_c_float_p] * 4 + [c_int] * 3 + [_c_float_p] * 3 + [c_int] * 8 + [c_void_p]
         for fn in (c.hifihr_dwconv2d_bwd_data, c.hifihr_dwconv2d_bwd_weight):
             fn.argtypes = [_c_float_p] * 3 + [c_int] * 10 + [c_void_p]
         c.hifihr_dwconv2d_fwd.argtypes = [_c_float_p] * 4 + [c_int] * 10 + [c_void_p]
@@ -356,6 +358,14 @@ class HifihrLib:
     def conv2d_fwd_bnstats(self, x, w, y, stats, N, H, W, C, K, R, S, stride, pad, ws=None):
         self.check(self.c.hifihr_conv2d_fwd_bnstats(_fp(x), _fp(w), _fp(y), _fp(stats), N, H, W, C, K, R, S, stride, pad,
                                                     *self._ws(ws), _stream_of(x)), "hifihr_conv2d_fwd_bnstats")
+
+    def conv2d_fwd_bnstats_pair_supported(self, N, H, W, C, stride, K1, R1, pad1, K2, R2, pad2):
+        return bool(self.c.hifihr_conv2d_fwd_bnstats_pair_supported(N, H, W, C, stride, K1, R1, pad1, K2, R2, pad2))
+
+    def conv2d_fwd_bnstats_pair(self, x, w1, y1, stats1, K1, R1, pad1, w2, y2, stats2, K2, R2, pad2, N, H, W, C, stride):
+        """two convolutions of the same input (+ their batch-norm statistics) in one launch (include/hifihr.h)"""
+        self.check(self.c.hifihr_conv2d_fwd_bnstats_pair(_fp(x), _fp(w1), _fp(y1), _fp(stats1), K1, R1, pad1, _fp(w2), _fp(y2), _fp(stats2), K2, R2, pad2,
+                                                         N, H, W, C, stride, _stream_of(x)), "hifihr_conv2d_fwd_bnstats_pair")
 
     def bn_stats_floats(self, C):
         return int(self.c.hifihr_bn_stats_floats(int(C)))

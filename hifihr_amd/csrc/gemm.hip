@@ -1522,8 +1522,7 @@ bool conv_rows_supported(const ConvGeom& g, const float* bias) {
   return g.stride == 2;                                      // stride 1: 1x1 is a plain GEMM already, 3x3 runs as Winograd / on the halo kernel
 }
 
-hipError_t launch_conv_rows(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st) {
-  if (!conv_rows_supported(g, nullptr) || zeros == nullptr) return hipErrorInvalidValue;
+static BgemmArgs conv_rows_args(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros) {
   BgemmArgs a{};
   const long M = (long)g.N * g.OH * g.OW;
   a.A = src; a.B = wgt; a.C = dst; a.M = (int)M; a.N = g.OC; a.K = g.R * g.S * g.IC;
@@ -1531,13 +1530,54 @@ hipError_t launch_conv_rows(const ConvGeom& g, const float* src, const float* wg
   a.stats = stats; a.zeros = zeros;
   a.cIH = g.IH; a.cIW = g.IW; a.cC = g.IC; a.cOH = g.OH; a.cOW = g.OW; a.cR = g.R; a.cS = g.S; a.cStride = g.stride; a.cPad = g.pad;
   a.tiles_n = g.OC / 128; a.tiles_m = (int)((M + 127) / 128); a.splits = 1; a.cps = a.K / 32; a.sc_split = 0;
-  const long total = (long)a.tiles_n * M;
-  const int cus = gemm_cus();
+  return a;
+}
+// shares of `cus` workgroups over the flattened (column tile, row) space of a gathered product, whole 16-row blocks each
+static int conv_rows_shares(const BgemmArgs& a, int cus, long* per_out) {
+  const long total = (long)a.tiles_n * a.M;
   long per = (total + cus - 1) / cus;
-  per = (per + 15) / 16 * 16;                               // whole 16-row blocks per share
+  per = (per + 15) / 16 * 16;
   if (per < 16) per = 16;
-  const int G = (int)((total + per - 1) / per);
+  *per_out = per;
+  return (int)((total + per - 1) / per);
+}
+
+hipError_t launch_conv_rows(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st) {
+  if (!conv_rows_supported(g, nullptr) || zeros == nullptr) return hipErrorInvalidValue;
+  const BgemmArgs a = conv_rows_args(g, src, wgt, dst, stats, zeros);
+  long per;
+  const int G = conv_rows_shares(a, gemm_cus(), &per);
   hipLaunchKernelGGL(bgemm_nt_rows_kernel<2>, dim3(G), dim3(512), 0, st, a, per);
+  return hipGetLastError();
+}
+
+// TWO gathered products on the same image in ONE launch (round 6): the strided 3x3 convolution of a residual stage's first block and the
+// stride-2 1x1 convolution of its downsample branch read the same x and do not depend on each other; the 1x1 one is a 10-15 us launch that is
+// all ends (0.4 GFLOP on the whole chip).  Workgroups [0, ga) walk the first product's shares, the rest the second's, ga in proportion
+// to the flops: same per-tile arithmetic, results identical to the separate launches.  HIFIHR_CONV_ROWS_PAIR=0: two launches.
+__global__ __launch_bounds__(512) void bgemm_nt_rows_pair2_kernel(BgemmArgs a, long per_a, int ga, BgemmArgs b, long per_b) {
+  __shared__ __attribute__((aligned(1024))) float lds[4 * kRowsStage];
+  if ((int)blockIdx.x < ga) nt_rows_body<2>(a, per_a, lds, (int)blockIdx.x, ga);
+  else nt_rows_body<2>(b, per_b, lds, (int)blockIdx.x - ga, (int)gridDim.x - ga);
+}
+bool conv_rows_pair_supported(const ConvGeom& g1, const ConvGeom& g2) {
+  static const int on = [] { const char* e = getenv("HIFIHR_CONV_ROWS_PAIR"); return e ? atoi(e) : 1; }();
+  return on && conv_rows_supported(g1, nullptr) && conv_rows_supported(g2, nullptr) && g1.N == g2.N && g1.IH == g2.IH && g1.IW == g2.IW &&
+         g1.IC == g2.IC && gemm_cus() >= 16;
+}
+hipError_t launch_conv_rows_pair(const ConvGeom& g1, const float* src, const float* w1, float* y1, float* stats1, const ConvGeom& g2, const float* w2,
+                                 float* y2, float* stats2, const float* zeros, hipStream_t st) {
+  if (!conv_rows_pair_supported(g1, g2) || zeros == nullptr) return hipErrorInvalidValue;
+  const BgemmArgs a = conv_rows_args(g1, src, w1, y1, stats1, zeros), b = conv_rows_args(g2, src, w2, y2, stats2, zeros);
+  const double fa = (double)a.M * a.N * a.K, fb = (double)b.M * b.N * b.K;
+  const int cus = gemm_cus();
+  int ga = (int)(cus * fa / (fa + fb) + 0.5);
+  if (ga < 8) ga = 8;
+  if (ga > cus - 8) ga = cus - 8;
+  long per_a, per_b;
+  ga = conv_rows_shares(a, ga, &per_a);
+  const int gb = conv_rows_shares(b, cus - ga, &per_b);
+  hipLaunchKernelGGL(bgemm_nt_rows_pair2_kernel, dim3(ga + gb), dim3(512), 0, st, a, per_a, ga, b, per_b);
   return hipGetLastError();
 }
 

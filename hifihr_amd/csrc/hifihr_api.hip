@@ -473,6 +473,29 @@ int hifihr_conv2d_describe(int N, int H, int W, int C, int K, int R, int S, int 
   return HIFIHR_OK;
 }
 
+static bool pair_geoms(int N, int H, int W, int C, int stride, int K1, int R1, int pad1, int K2, int R2, int pad2, hifihr::ConvGeom* g1, hifihr::ConvGeom* g2) {
+  if (!conv_dims_ok(N, H, W, C, K1, R1, R1, stride, pad1) || !conv_dims_ok(N, H, W, C, K2, R2, R2, stride, pad2) || C % 4) return false;
+  *g1 = hifihr::ConvGeom{N, H, W, C, (H + 2 * pad1 - R1) / stride + 1, (W + 2 * pad1 - R1) / stride + 1, K1, R1, R1, stride, pad1, 0};
+  *g2 = hifihr::ConvGeom{N, H, W, C, (H + 2 * pad2 - R2) / stride + 1, (W + 2 * pad2 - R2) / stride + 1, K2, R2, R2, stride, pad2, 0};
+  return true;
+}
+int hifihr_conv2d_fwd_bnstats_pair_supported(int N, int H, int W, int C, int stride, int K1, int R1, int pad1, int K2, int R2, int pad2) {
+  hifihr::ConvGeom g1, g2;
+  return (pair_geoms(N, H, W, C, stride, K1, R1, pad1, K2, R2, pad2, &g1, &g2) && hifihr::conv_rows_pair_supported(g1, g2) &&
+          hifihr::bgemm_nt_stats_supported(K1) && hifihr::bgemm_nt_stats_supported(K2)) ? 1 : 0;
+}
+int hifihr_conv2d_fwd_bnstats_pair(const float* x, const float* w1, float* y1, float* stats1, int K1, int R1, int pad1, const float* w2, float* y2,
+                                   float* stats2, int K2, int R2, int pad2, int N, int H, int W, int C, int stride, void* stream) {
+  hifihr::ConvGeom g1, g2;
+  if (!x || !w1 || !y1 || !stats1 || !w2 || !y2 || !stats2 || !pair_geoms(N, H, W, C, stride, K1, R1, pad1, K2, R2, pad2, &g1, &g2) ||
+      !hifihr_conv2d_fwd_bnstats_pair_supported(N, H, W, C, stride, K1, R1, pad1, K2, R2, pad2))
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_fwd_bnstats_pair: bad argument or unsupported pair (ask hifihr_conv2d_fwd_bnstats_pair_supported)");
+  const float* zeros = hifihr::conv_halo_zero_page((hipStream_t)stream);
+  if (zeros == nullptr) return fail(HIFIHR_EINVAL, "hifihr_conv2d_fwd_bnstats_pair: the zero page is not available inside a capture (call once outside)");
+  HIP_TRY(hifihr::launch_conv_rows_pair(g1, x, w1, y1, stats1, g2, w2, y2, stats2, zeros, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_conv2d_fwd_bnstats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int C, int K, int R,
                               int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !w || !y || !stats || !conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4)

@@ -413,6 +413,9 @@ bool bgemm_nt_stats_supported(int N);      // launch_bgemm_nt(..., stats != null
 // forward convolution as the row-share GEMM with the patch gather in its loader waves (csrc/gemm.hip, bgemm_nt_rows_kernel<2>)
 bool conv_rows_supported(const ConvGeom& g, const float* bias);
 hipError_t launch_conv_rows(const ConvGeom& g, const float* src, const float* wgt, float* dst, float* stats, const float* zeros, hipStream_t st);
+bool conv_rows_pair_supported(const ConvGeom& g1, const ConvGeom& g2);
+hipError_t launch_conv_rows_pair(const ConvGeom& g1, const float* src, const float* w1, float* y1, float* stats1, const ConvGeom& g2, const float* w2,
+                                 float* y2, float* stats2, const float* zeros, hipStream_t st);
 bool bgemm_nt_ragged_supported(int M, int N, int K);   // bgemm_nt_rows_kernel<true>: N % 4 == 0, K % 4 == 0, N not a multiple of 128 or K not of 32
 hipError_t launch_bgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int batch, void* ws, size_t ws_bytes, hipStream_t st,
                            float* stats_or_null = nullptr, int M_alloc = 0);      // stats: only with N % 128 == 0 and batch == 1 (else hipErrorInvalidValue)

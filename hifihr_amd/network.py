@@ -113,22 +113,32 @@ class BasicBlock(nn.Module):
         # conv (MFMA, BN statistics from its epilogue) -> BN (+ identity) + ReLU, fused INTO the next convolution's Winograd input
         # transform where there is one (csrc/wino4_bn.hip), else one fused launch of its own (csrc/bn.hip)
         from . import ops
+        idt_raw = st_ds = None
+        fused = False
         if isinstance(x, _PendingBN):
             p = x
             if p.bn.training and ops.bn_wino_fusable(p.y, self.conv1.weight, p.bn, self.conv1.stride, self.conv1.pad):
                 out, st, x = ops.bn_act_wino_conv(p.y, p.stats, p.bn, p.identity, self.conv1.weight, self.bn1.training)
+                fused = True
             else:
                 x = p.materialize()
+        if not fused:
+            ds = self.downsample
+            if (ds is not None and self.bn1.training and ds[1].training and self.conv1.stride == 2 and torch.is_grad_enabled()
+                    and ops.conv2d_pair_ok(x, self.conv1.weight, ds[0].weight, 2)):
+                # conv1 and the downsample branch's 1x1 read the same x: ONE launch (ops.conv2d_pair)
+                out, st, idt_raw, st_ds = ops.conv2d_pair(x, self.conv1.weight, ds[0].weight, 2)
+            else:
                 out, st, x = _conv_bn_fork(self.conv1, x, self.bn1)       # (x: from here on the alias the identity branch reads)
-        else:
-            out, st, x = _conv_bn_fork(self.conv1, x, self.bn1)
         if st is not None and ops.bn_wino_fusable(out, self.conv2.weight, self.bn1, 1, 1):
             out, st, _ = ops.bn_act_wino_conv(out, st, self.bn1, None, self.conv2.weight, self.bn2.training)
         else:
             out = ops.bn_act(out, st, self.bn1, None, True)
             out, st = _conv_bn(self.conv2, out, self.bn2)
         idt = x
-        if self.downsample is not None:
+        if idt_raw is not None:
+            idt = ops.bn_act(idt_raw, st_ds, self.downsample[1], None, False)
+        elif self.downsample is not None:
             idt, st2 = _conv_bn(self.downsample[0], x, self.downsample[1])
             idt = ops.bn_act(idt, st2, self.downsample[1], None, False)
         if self.lazy_out and self.bn2.training:

@@ -1124,6 +1124,71 @@ def conv2d(x, w, stride=1, pad=0, want_stats=False, fork=False):
     return _Conv2dMFMA.apply(x, w, stride, pad, want_stats, None, False, False, False, fork)
 
 
+class _Conv2dPair(torch.autograd.Function):
+    """y1 = conv(x, w1; 3x3, pad 1), y2 = conv(x, w2; 1x1, pad 0), both with `stride` and their batch-norm statistics, in ONE launch
+    (hifihr_conv2d_fwd_bnstats_pair): conv1 and downsample[0] of a residual stage's first block read the same x.  The backward runs the two
+    convolutions' own backward passes (_Conv2dMFMA.backward on shims): the downsample branch's first, its data gradient then enters the 3x3
+    convolution's backward-data launch as the `fork` residual -- exactly what the two separate functions did."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, stride):
+        require_cuda(x, w1, w2)
+        lib = get_lib()
+        x = x.contiguous(memory_format=_CL)
+        wk1, wk2 = w1.contiguous(memory_format=_CL), w2.contiguous(memory_format=_CL)
+        N, C, H, W = x.shape
+        K1, K2 = wk1.shape[0], wk2.shape[0]
+        OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        y1 = torch.empty((N, K1, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
+        y2 = torch.empty((N, K2, OH, OW), device=x.device, dtype=torch.float32, memory_format=_CL)
+        st1 = _ZERO_POOL.acquire(lib.bn_stats_floats(K1), x.device)
+        st2 = _ZERO_POOL.acquire(lib.bn_stats_floats(K2), x.device)
+        if PROFILE.on:
+            PROFILE.conv_log.append(((N, H, W, C, K1, 3, 3, stride, 1), "fwd"))
+            PROFILE.conv_log.append(((N, H, W, C, K2, 1, 1, stride, 0), "fwd"))
+        PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd_bnstats_pair(x, wk1, y1, st1, K1, 3, 1, wk2, y2, st2, K2, 1, 0, N, H, W, C, stride))
+        ctx.geom1, ctx.geom2 = (N, H, W, C, K1, 3, 3, stride, 1), (N, H, W, C, K2, 1, 1, stride, 0)
+        ctx.save_for_backward(x, wk1, wk2)
+        ctx.w1, ctx.w2 = w1, w2
+        ctx.wino_allowed = _wino_allowed()
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(st1, st2)
+        return y1, st1, y2, st2
+
+    @staticmethod
+    def backward(ctx, gy1, _gs1, gy2, _gs2):
+        x, wk1, wk2 = ctx.saved_tensors
+        need_x, need_w1, need_w2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+
+        def shim(wk, geom, w, need_w, fork):
+            return _CtxShim((x, wk, None, None), geom=geom, w_param=w, b_param=None, relu=False, w3=None, wino_allowed=ctx.wino_allowed,
+                            grad_premasked=False, mask_input_grad=False, fork=fork,
+                            needs_input_grad=(need_x, need_w, False, False, False, False, False, False, False, False))
+        dx2 = dw2 = dx = dw1 = None
+        if gy2 is not None:
+            dx2, dw2 = _Conv2dMFMA.backward(shim(wk2, ctx.geom2, ctx.w2, need_w2, False), gy2)[:2]
+        if gy1 is not None:
+            dx, dw1 = _Conv2dMFMA.backward(shim(wk1, ctx.geom1, ctx.w1, need_w1, True), gy1, dx2)[:2]      # (dx2 enters as the fork residual)
+        else:
+            dx = dx2
+        return dx, dw1, dw2, None
+
+
+def conv2d_pair_ok(x, w1, w2, stride):
+    """conv1 (3x3, pad 1) and downsample[0] (1x1, pad 0) of a stage's first block can share ONE forward launch (training mode: both feed a
+    batch-norm that wants statistics).  HIFIHR_CONV_ROWS_PAIR=0 (read by the library) keeps the two launches."""
+    if not (x.is_cuda and torch.is_tensor(x) and w1.shape[2:] == (3, 3) and w2.shape[2:] == (1, 1) and w1.shape[1] == x.shape[1] == w2.shape[1]):
+        return False
+    lib = get_lib()
+    N, C, H, W = x.shape
+    return lib.zero_page_ready(x.device) and lib.conv2d_fwd_bnstats_pair_supported(N, H, W, C, stride, w1.shape[0], 3, 1, w2.shape[0], 1, 0)
+
+
+def conv2d_pair(x, w1, w2, stride):
+    """-> (conv(x, w1), its batch statistics, conv(x, w2), its batch statistics)"""
+    return _Conv2dPair.apply(x, w1, w2, stride)
+
+
 def conv_fork_enabled():
     """HIFIHR_CONV_FORK=0: residual blocks leave the sum of their input's two gradients to autograd (the A/B switch of `fork`)."""
     return os.environ.get("HIFIHR_CONV_FORK", "1") != "0"

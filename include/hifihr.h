@@ -499,6 +499,15 @@ int hifihr_conv2d_describe(int N, int H, int W, int C, int K, int R, int S, int 
  * follows needs no pass over y. */
 int hifihr_conv2d_fwd_bnstats(const float* x_d, const float* w_d, float* y_d, float* stats_d, int N, int H, int W, int C, int K,
                               int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
+/* Two convolutions of the SAME input in one launch (round 6): y1 = conv(x, w1; R1 x R1, pad1), y2 = conv(x, w2; R2 x R2, pad2), both with
+ * `stride` and with their batch-norm statistics (stats1_d / stats2_d: the slot-buffer contract of hifihr_conv2d_fwd_bnstats) -- the strided
+ * 3x3 convolution of a residual stage's first block and the 1x1 convolution of its downsample branch (torchvision BasicBlock.conv1 +
+ * downsample[0], reference network/res_encoder.py:364-373), whose short 1x1 launch otherwise pays its start and end alone.  Results
+ * identical to two hifihr_conv2d_fwd_bnstats calls.  _supported: both shapes run on the gathering row-share GEMM (C % 32 == 0,
+ * K % 128 == 0, R in {1, 3}, stride 2). */
+int hifihr_conv2d_fwd_bnstats_pair_supported(int N, int H, int W, int C, int stride, int K1, int R1, int pad1, int K2, int R2, int pad2);
+int hifihr_conv2d_fwd_bnstats_pair(const float* x_d, const float* w1_d, float* y1_d, float* stats1_d, int K1, int R1, int pad1, const float* w2_d,
+                                   float* y2_d, float* stats2_d, int K2, int R2, int pad2, int N, int H, int W, int C, int stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Train-mode BatchNorm2d fused with the residual add and ReLU of a ResNet BasicBlock, NHWC: x[M][C], M = N*H*W.

@@ -589,6 +589,33 @@ def conv_bnstats_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0, use_ws
     np.testing.assert_allclose(st[1].cpu().numpy(), (s_ref ** 2).sum(1).numpy(), rtol=1e-4, atol=2e-3)
 
 
+def conv_fwd_pair_case(lib, device, N, H, W, C, K1, K2, seed=0):
+    """hifihr_conv2d_fwd_bnstats_pair: the strided 3x3 convolution of a residual stage's first block and the stride-2 1x1 convolution of its
+    downsample branch in ONE launch == the two hifihr_conv2d_fwd_bnstats calls: outputs bit for bit, folded statistics to fp64 rounding."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=gen); w1 = torch.randn(K1, C, 3, 3, generator=gen) / (9 * C) ** 0.5; w2 = torch.randn(K2, C, 1, 1, generator=gen) / C ** 0.5
+    r1, r2 = F.conv2d(x, w1, None, 2, 1), F.conv2d(x, w2, None, 2, 0)
+    OH, OW = r1.shape[2], r1.shape[3]
+    assert r2.shape[2:] == r1.shape[2:]
+    d = lambda t: t.to(device).contiguous()
+    xd, w1d, w2d = d(x.permute(0, 2, 3, 1)), d(w1.permute(0, 2, 3, 1)), d(w2.permute(0, 2, 3, 1))
+    assert lib.conv2d_fwd_bnstats_pair_supported(N, H, W, C, 2, K1, 3, 1, K2, 1, 0)
+    ya, yb = torch.full((N, OH, OW, K1), 7.0, device=device), torch.full((N, OH, OW, K2), 7.0, device=device)
+    sa, sb = torch.zeros(lib.bn_stats_floats(K1), device=device), torch.zeros(lib.bn_stats_floats(K2), device=device)
+    lib.conv2d_fwd_bnstats_pair(xd, w1d, ya, sa, K1, 3, 1, w2d, yb, sb, K2, 1, 0, N, H, W, C, 2)
+    y1, y2 = torch.empty_like(ya), torch.empty_like(yb)
+    s1, s2 = torch.zeros_like(sa), torch.zeros_like(sb)
+    lib.conv2d_fwd_bnstats(xd, w1d, y1, s1, N, H, W, C, K1, 3, 3, 2, 1)
+    lib.conv2d_fwd_bnstats(xd, w2d, y2, s2, N, H, W, C, K2, 1, 1, 2, 0)
+    assert torch.equal(ya, y1) and torch.equal(yb, y2), "pair: outputs differ from the separate launches"
+    for K, p, q in ((K1, sa, s1), (K2, sb, s2)):
+        a, b = bn_slots(p, K).sum(0).double().cpu(), bn_slots(q, K).sum(0).double().cpu()
+        assert float((a - b).abs().max()) <= 1e-9 * float(b.abs().max()) + 1e-12
+    assert float((ya.cpu() - r1.permute(0, 2, 3, 1)).abs().max()) <= 3e-5 * float(r1.abs().max()) + 1e-6
+    assert float((yb.cpu() - r2.permute(0, 2, 3, 1)).abs().max()) <= 3e-5 * float(r2.abs().max()) + 1e-6
+
+
 # ------------------------------------------------------------------------------------------------
 # depthwise convolution (EfficientNet MBConv) vs plain PyTorch fp32 (F.pad + grouped F.conv2d autograd)
 # ------------------------------------------------------------------------------------------------

@@ -593,3 +593,9 @@ def test_conv_fork_residual_sum_equals_autograd_sum(monkeypatch):
 def test_weight_gradient_transforms_of_several_layers_in_one_launch(lib):
     """hifihr_wino4_dw_transform_multi (the step's deferred F(4x4) weight-gradient transforms, ops._DeferredDw) == the per-layer launches."""
     kc.wino4_dw_multi_case(lib, "cuda")
+
+
+@pytest.mark.parametrize("N,H,C,K1,K2", [(32, 56, 64, 128, 128), (32, 28, 128, 256, 256), (3, 30, 32, 128, 256)])
+def test_strided_conv_and_downsample_conv_in_one_launch(lib, N, H, C, K1, K2):
+    """hifihr_conv2d_fwd_bnstats_pair: conv1 (3x3 stride 2) + downsample[0] (1x1 stride 2) of layer2.0 / layer3.0 at B = 32, and a ragged size."""
+    kc.conv_fwd_pair_case(lib, "cuda", N, H, H, C, K1, K2, seed=H + C)

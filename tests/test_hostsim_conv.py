@@ -145,3 +145,11 @@ def test_conv_rows_gather_forward(hostsim_lib, N, H, W, C, K, R, stride, pad):
     for taps outside the image), forward + batch-norm statistics; the other directions of the same call stay on their kernels."""
     kc.conv_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, seed=K + C)
     kc.conv_bnstats_case(hostsim_lib, "cpu", N, H, W, C, K, R, stride, pad, use_ws=False)
+
+
+def test_strided_conv_and_downsample_conv_in_one_launch(hostsim_lib, monkeypatch):
+    """hifihr_conv2d_fwd_bnstats_pair (bgemm_nt_rows_pair2_kernel) == the two separate launches; the emulator is told 16 compute units (the pair
+    wants at least 8 workgroups per side)."""
+    monkeypatch.setenv("HIFIHR_GEMM_CUS", "16")
+    kc.conv_fwd_pair_case(hostsim_lib, "cpu", 2, 12, 12, 32, 128, 128, seed=3)
+    kc.conv_fwd_pair_case(hostsim_lib, "cpu", 1, 10, 14, 64, 128, 256, seed=4)
