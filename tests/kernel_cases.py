@@ -591,7 +591,7 @@ def conv_bnstats_case(lib, device, N, H, W, C, K, R, stride, pad, seed=0, use_ws
 
 def conv_fwd_pair_case(lib, device, N, H, W, C, K1, K2, seed=0):
     """hifihr_conv2d_fwd_bnstats_pair: the strided 3x3 convolution of a residual stage's first block and the stride-2 1x1 convolution of its
-    downsample branch in ONE launch == the two hifihr_conv2d_fwd_bnstats calls: outputs bit for bit, folded statistics to fp64 rounding."""
+    downsample branch in ONE launch == the two hifihr_conv2d_fwd_bnstats calls: outputs bit for bit, folded statistics to the f32 rounding of the per-share partial sums."""
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(seed)
     x = torch.randn(N, C, H, W, generator=gen); w1 = torch.randn(K1, C, 3, 3, generator=gen) / (9 * C) ** 0.5; w2 = torch.randn(K2, C, 1, 1, generator=gen) / C ** 0.5
@@ -611,7 +611,9 @@ def conv_fwd_pair_case(lib, device, N, H, W, C, K1, K2, seed=0):
     assert torch.equal(ya, y1) and torch.equal(yb, y2), "pair: outputs differ from the separate launches"
     for K, p, q in ((K1, sa, s1), (K2, sb, s2)):
         a, b = bn_slots(p, K).sum(0).double().cpu(), bn_slots(q, K).sum(0).double().cpu()
-        assert float((a - b).abs().max()) <= 1e-9 * float(b.abs().max()) + 1e-12
+        # (the shifted partial sums are f32 inside a workgroup's share, and the shares differ between the two forms: equal to f32 rounding of the
+        #  per-share partials, observed 3e-8 of the largest sum)
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-9
     assert float((ya.cpu() - r1.permute(0, 2, 3, 1)).abs().max()) <= 3e-5 * float(r1.abs().max()) + 1e-6
     assert float((yb.cpu() - r2.permute(0, 2, 3, 1)).abs().max()) <= 3e-5 * float(r2.abs().max()) + 1e-6
 
