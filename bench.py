@@ -321,6 +321,17 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
                     f"{P_} x [{Tx} of {T_} x {K_}]^T . [{Tx} of {T_} x {C_}], {max(parts, 1)} slab(s)",
                     useful=2.0 * P_ * Tc * C_ * K_)
             continue
+        if direction == "fwd-pair":            # bgemm_nt_rows_pair2_kernel: conv1 (3x3, pad 1) + downsample[0] (1x1) of a stage's first block, one launch
+            _, N_, H_, W_, C_, K1_, K2_, st_ = geom
+            OH_, OW_ = (H_ + 2 - 3) // st_ + 1, (W_ + 2 - 3) // st_ + 1
+            x = torch.randn(N_, H_, W_, C_, device=dev); w1 = torch.randn(K1_, 3, 3, C_, device=dev) * 0.05; w2 = torch.randn(K2_, 1, 1, C_, device=dev) * 0.05
+            y1 = torch.empty(N_, OH_, OW_, K1_, device=dev); y2 = torch.empty(N_, OH_, OW_, K2_, device=dev)
+            s1 = torch.zeros(lib.bn_stats_floats(K1_), device=dev); s2 = torch.zeros(lib.bn_stats_floats(K2_), device=dev)
+            us = hip_us(lambda: lib.conv2d_fwd_bnstats_pair(x, w1, y1, s1, K1_, 3, 1, w2, y2, s2, K2_, 1, 0, N_, H_, W_, C_, st_))
+            add("bgemm_nt_rows_pair2_kernel", per_step, us, 2.0 * N_ * OH_ * OW_ * C_ * (9 * K1_ + K2_),
+                4.0 * (N_ * H_ * W_ * C_ + (9 * K1_ + K2_) * C_ + N_ * OH_ * OW_ * (K1_ + K2_)),
+                f"fwd N{N_} {H_}x{W_} C{C_}: 3x3 s{st_} ->K{K1_}  +  1x1 s{st_} ->K{K2_}, one launch")
+            continue
         N_, H_, W_, C_, K_, R_, S_, st_, pd_ = geom
         if direction in ("fwd-wino2", "dgrad-wino2"):          # conv_wino2_kernel: one launch, 2 x 16 x (tiles x 64 x 64) executed products
             x = torch.randn(N_, H_, W_, 64, device=dev); U = torch.randn(16 * 64 * 64, device=dev) * 0.05; y = torch.empty(N_, H_, W_, 64, device=dev)

@@ -1144,8 +1144,7 @@ class _Conv2dPair(torch.autograd.Function):
         st1 = _ZERO_POOL.acquire(lib.bn_stats_floats(K1), x.device)
         st2 = _ZERO_POOL.acquire(lib.bn_stats_floats(K2), x.device)
         if PROFILE.on:
-            PROFILE.conv_log.append(((N, H, W, C, K1, 3, 3, stride, 1), "fwd"))
-            PROFILE.conv_log.append(((N, H, W, C, K2, 1, 1, stride, 0), "fwd"))
+            PROFILE.conv_log.append((("pair", N, H, W, C, K1, K2, stride), "fwd-pair"))
         PROFILE.bracket("conv_fwd", lambda: lib.conv2d_fwd_bnstats_pair(x, wk1, y1, st1, K1, 3, 1, wk2, y2, st2, K2, 1, 0, N, H, W, C, stride))
         ctx.geom1, ctx.geom2 = (N, H, W, C, K1, 3, 3, stride, 1), (N, H, W, C, K2, 1, 1, stride, 0)
         ctx.save_for_backward(x, wk1, wk2)
