@@ -270,10 +270,35 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderDev r, const floa
 #pragma unroll 1
         for (int j = 0; j < AA; ++j) sample(i, j, fid_px[(size_t)i * S + j]);
     } else {                                                  // (vertex colours: 198 registers unrolled, 188 rolled -- two workgroups per CU either
-#pragma unroll                                                //  way, and rolled measured 165 -> 176 us at B = 32)
+                                                              //  way, and rolled measured 165 -> 176 us at B = 32)
+#if !defined(HIFIHR_RBWD_SCAN_ORDER)
+      // Round 6: the pixel's samples are walked in FACE order (keys (face, sample index) through an odd-even transposition network in
+      // registers): a pixel that an edge crosses reads A A B / A B B / B B B in scan order -- four runs, i.e. three in-loop flushes into the
+      // tile's vertex table and three reloads of twelve face records, each executed under divergence -- and two runs when sorted.  Entry point
+      // at B = 32: 163 -> 145 us (timing-only builds without the in-loop flushes: 114).  -DHIFIHR_RBWD_SCAN_ORDER: the scan order (A/B builds).
+      constexpr int NS = AA * AA;
+      unsigned key[NS];
+#pragma unroll
+      for (int t = 0; t < NS; ++t) key[t] = ((fid[t] >= 0 ? (unsigned)fid[t] : 0x0FFFFFFFu) << 4) | (unsigned)t;
+#pragma unroll
+      for (int rnd = 0; rnd < NS; ++rnd)
+#pragma unroll
+        for (int t = rnd & 1; t + 1 < NS; t += 2) {
+          const unsigned lo = min(key[t], key[t + 1]), hi = max(key[t], key[t + 1]);
+          key[t] = lo; key[t + 1] = hi;
+        }
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        const unsigned fk = key[t] >> 4;
+        const int idx = (int)(key[t] & 15u);
+        sample(idx / AA, idx - (idx / AA) * AA, fk == 0x0FFFFFFFu ? -1 : (int)fk);
+      }
+#else
+#pragma unroll
       for (int i = 0; i < AA; ++i)
 #pragma unroll
         for (int j = 0; j < AA; ++j) sample(i, j, fid[i * AA + j]);
+#endif
     }
   }
   // The last run of every lane is flushed HERE, at a wave-uniform point -- and that is where the LDS atomics met 64 ways: the lanes of a
