@@ -65,7 +65,7 @@ def pytest_configure(config):
 # Order of the -m gpu suite: the per-row parity files (one kernel family each, deterministic inputs, tight bounds) run FIRST,
 # the whole-step / multi-process / front-end files LAST, so that under `-x` a failure in a composite test can no longer hide
 # the parity evidence of every row behind it (GPUTEST_r04: one whole-step tolerance hid 125 kernel tests).
-_FILE_ORDER = ["test_gpu_mano", "test_gpu_render", "test_raster_known", "test_gpu_losses", "test_gpu_tail", "test_gpu_gemm",
+_FILE_ORDER = ["test_gpu_mano", "test_gpu_render", "test_raster_known", "test_shade_known", "test_gpu_losses", "test_gpu_tail", "test_gpu_gemm",
                "test_gpu_nimble", "test_gpu_conv", "test_gpu_e2e", "test_gpu_frontend", "test_gpu_dp"]
 
 
