@@ -663,34 +663,71 @@ class _DeferredDw:
         self.jobs = []
         self.halo = []
         self.pending = set()               # gradient targets with a job in the lists
+        self.early = os.environ.get("HIFIHR_DEFER_EARLY", "1") != "0"
+        self.side, self.home, self._streams, self.n_early = None, None, {}, 0
 
     def wants(self, w, direct):
         # (a layer that already holds a pending job -- a second backward inside one scope -- takes the immediate path: its own slab buffer
         #  must stay as the first backward left it until the flush)
+        if self.side is not None and w.grad is not None and w.grad.data_ptr() in self.pending:
+            torch.cuda.current_stream(self.side.device).wait_stream(self.side)     # its early flush may still be adding into w.grad beside us
         return (self.on and self.active and direct and not _ASYNC_WGRAD.active and getattr(w, "_hifihr_grad_ready", None) is None
                 and (w.grad is None or w.grad.data_ptr() not in self.pending))
 
     def add(self, dU, parts, tgt, K, C):
-        self.jobs.append((dU, int(parts), tgt, int(K), int(C)))
+        self.jobs.append((dU, int(parts), tgt, int(K), int(C), torch.cuda.current_stream(tgt.device).cuda_stream))
         self.pending.add(tgt.data_ptr())
 
     def add_halo(self, slabs, nslab, tgt):
         """the slab sum of a 64 -> 64 layer's pixel-reduction weight gradient (hifihr_conv3x3_c64_bwd_pair_slabs left it to us)"""
-        self.halo.append((slabs, int(nslab), tgt))
+        self.halo.append((slabs, int(nslab), tgt, torch.cuda.current_stream(tgt.device).cuda_stream))
         self.pending.add(tgt.data_ptr())
 
     def clear(self):
         self.jobs.clear(); self.halo.clear(); self.pending.clear()
+        if self.side is not None:                   # a scope that failed behind its early flush
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(self.side.device).wait_stream(self.side)
+            self.side = None
+
+    def _run(self, jobs, halo):
+        lib = get_lib() if (jobs or halo) else None
+        if halo:
+            PROFILE.bracket("halo_reduce_multi", lambda: lib.conv_halo_wgrad_reduce_multi([h[:3] for h in halo]))
+        if jobs:
+            PROFILE.bracket("wino_dw_multi", lambda: lib.wino4_dw_transform_multi([j[:5] for j in jobs]))
 
     def flush(self):
         jobs, self.jobs = self.jobs, []
         halo, self.halo = self.halo, []
         self.pending.clear()
-        lib = get_lib() if (jobs or halo) else None
-        if halo:
-            PROFILE.bracket("halo_reduce_multi", lambda: lib.conv_halo_wgrad_reduce_multi(halo))
-        if jobs:
-            PROFILE.bracket("wino_dw_multi", lambda: lib.wino4_dw_transform_multi(jobs))
+        self._run(jobs, halo)
+        if self.side is not None:                   # an early flush is still running beside the step's stream: the optimizer is next
+            cur = torch.cuda.current_stream(self.side.device)
+            cur.wait_stream(self.side)
+            if self.home is not None and self.home != cur:
+                self.home.wait_stream(self.side)
+            self.side = None
+
+    def flush_early(self, device):
+        """Called where the backward has only the stem left (ops._BNReluMaxPool.backward): what the step's layers deferred ON THIS STREAM is
+        complete, and nothing but the optimizer reads it -- the one launch goes to a side stream beside the stem's pooling backward and
+        weight gradient instead of behind them; `flush` (the scope's exit) joins it.  HIFIHR_DEFER_EARLY=0: only the flush at the exit."""
+        if not (self.early and self.active and self.side is None and (self.jobs or self.halo)):
+            return
+        cur = torch.cuda.current_stream(device)
+        h = cur.cuda_stream
+        jobs, halo = [j for j in self.jobs if j[5] == h], [j for j in self.halo if j[3] == h]
+        if not (jobs or halo):
+            return
+        self.jobs, self.halo = [j for j in self.jobs if j[5] != h], [j for j in self.halo if j[3] != h]
+        st = self._streams.get(device)             # (`pending` keeps these layers until the flush: a second backward of one of them takes the immediate path)
+        if st is None:
+            st = self._streams[device] = torch.cuda.Stream(device=device)
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            self._run(jobs, halo)
+        self.side, self.home, self.n_early = st, cur, self.n_early + 1
 
 
 _DEFER_DW = _DeferredDw()
@@ -1573,6 +1610,7 @@ class _BNReluMaxPool(torch.autograd.Function):
         lib = get_lib()
         N, C, H, W = x.shape
         gy = gy.contiguous(memory_format=_CL)
+        _DEFER_DW.flush_early(x.device)           # behind the stem's pooling only the stem is left: the deferred weight-gradient launch runs beside it
         dx = torch.empty_like(x, memory_format=_CL)
         red = _ZERO_POOL.acquire(lib.bn_stats_floats(C), x.device)
         dg_t, dg_ret = _bn_acc_target(ctx.gamma_param, C, x.device)

@@ -528,12 +528,12 @@ def test_deferred_weight_gradient_transforms_equal_the_immediate_ones():
         bufs = [b.clone() for b in model.buffers()]
         wts = [(n, p) for n, p in model.named_parameters() if p.dim() == 4 and p.shape[2] == 3 and p.shape[0] >= 64]
 
-        def grads(defer, twice):
+        def grads(defer, twice, early=True):
             with torch.no_grad():
                 for b, s0 in zip(model.buffers(), bufs):
                     b.copy_(s0)
-            old = ops._DEFER_DW.on
-            ops._DEFER_DW.on = defer
+            old, old_early = ops._DEFER_DW.on, ops._DEFER_DW.early
+            ops._DEFER_DW.on, ops._DEFER_DW.early = defer, early
             try:
                 with ops.prepared_weights(async_wgrad=False):
                     _forward_backward(model, LossFunction(), opt, ex, args, "FreiHand")
@@ -545,18 +545,26 @@ def test_deferred_weight_gradient_transforms_equal_the_immediate_ones():
                         finally:
                             opt.zero_grad = zg
             finally:
-                ops._DEFER_DW.on = old
+                ops._DEFER_DW.on, ops._DEFER_DW.early = old, old_early
             torch.cuda.synchronize()
             return {n: p.grad.clone() for n, p in wts}
         for twice in (False, True):
-            g_def, g_imm = grads(True, twice), grads(False, twice)
+            # early: the launch forks to a side stream where the backward reaches the stem's pooling (ops._DeferredDw.flush_early) and is
+            # joined in front of the optimizer; not early: one launch at the scope's exit
+            n0 = ops._DEFER_DW.n_early
+            g_early = grads(True, twice, early=True)
+            assert ops._DEFER_DW.n_early > n0, "the early flush never ran: the ResNet stem's pooling backward should trigger it"
+            n1 = ops._DEFER_DW.n_early
+            g_late, g_imm = grads(True, twice, early=False), grads(False, twice)
+            assert ops._DEFER_DW.n_early == n1
             worst = 0.0
             for n in g_imm:
                 scale = float(g_imm[n].abs().max())
-                d = float((g_def[n] - g_imm[n]).abs().max())
-                # the products' float atomics elsewhere in backward reorder between two runs: the transforms themselves add nothing
-                assert d <= 2e-4 * scale + 1e-9, (n, twice, d, scale)
-                worst = max(worst, d / max(scale, 1e-30))
-            print(f"[margin] deferred vs immediate weight gradients, second backward in scope = {twice}: worst |diff| / max|g| = {worst:.2e} (bound 2e-4)")
+                for g_def in (g_early, g_late):
+                    d = float((g_def[n] - g_imm[n]).abs().max())
+                    # the products' float atomics elsewhere in backward reorder between two runs: the transforms themselves add nothing
+                    assert d <= 2e-4 * scale + 1e-9, (n, twice, d, scale)
+                    worst = max(worst, d / max(scale, 1e-30))
+            print(f"[margin] deferred (early and late flush) vs immediate weight gradients, second backward in scope = {twice}: worst |diff| / max|g| = {worst:.2e} (bound 2e-4)")
     finally:
         torch.cuda.set_stream(prev)

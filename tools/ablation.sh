@@ -36,6 +36,7 @@ run "layer 1 data gradient and weight gradient as two launches (HIFIHR_C64_PAIR=
 run "eager launches, no hipGraph (--graph 0)" --graph 0
 run "round 6: stem batch-norm reduction over every input pixel (HIFIHR_STEM_REDUCE_Y=0)" HIFIHR_STEM_REDUCE_Y=0
 run "round 6: weight-gradient transforms / slab sums per layer, not deferred (HIFIHR_DEFER_DW=0)" HIFIHR_DEFER_DW=0
+run "round 6: the deferred launch at the scope exit, not beside the stem backward (HIFIHR_DEFER_EARLY=0)" HIFIHR_DEFER_EARLY=0
 run "round 6: TN products walk the zero rows behind the tile mosaic (HIFIHR_GEMM_TN_SKIP=0)" HIFIHR_GEMM_TN_SKIP=0
 run "round 6: strided 3x3 + downsample 1x1 as two forward launches (HIFIHR_CONV_ROWS_PAIR=0)" HIFIHR_CONV_ROWS_PAIR=0
 run "round 6: TN products on contiguous shares, not XCD-coherent (HIFIHR_GEMM_TN_COHERENT=0)" HIFIHR_GEMM_TN_COHERENT=0
