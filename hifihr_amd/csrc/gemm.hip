@@ -736,13 +736,40 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void bgemm_nt_sk_kernel(BgemmArgs
 // ------------------------------------------------------------------------------------------------
 static int gemm_cus();
 struct RowsTile { int p, nt, m0, rows; };
-__device__ __forceinline__ RowsTile rows_tile_at(const BgemmArgs& a, long cur, long end) {
-  const long col = cur / a.M;                                // (p, nt) pair
-  const int m0 = (int)(cur - col * a.M);
-  const int p = (int)(col / a.tiles_n), nt = (int)(col - (long)p * a.tiles_n);
-  const long lim = min((long)a.M - m0, end - cur);
-  return RowsTile{p, nt, m0, (int)min(128L, lim)};
+// q = n / d, r = n - q d for 0 <= n, 0 < d < 2^31: one 32-bit unsigned division when n fits (every shape of the step does; ~30 instructions),
+// the 64-bit sequence (several hundred cycles of dependent VALU work) otherwise
+__device__ __forceinline__ void divmod_pos(long n, int d, long& q, int& r) {
+  if (n < (1L << 32)) {
+    const unsigned nn = (unsigned)n, qq = nn / (unsigned)d;
+    q = (long)qq; r = (int)(nn - qq * (unsigned)d);
+  } else {
+    q = n / d; r = (int)(n - q * d);
+  }
 }
+// The tiles of a share [cur, end) of the flattened (problem p, 128-column tile nt, row) space, in order.  The position is kept as (p, nt, m0) and
+// moved on by additions: the two 64-bit divisions per tile the first form paid (cur / M, col / tiles_n -- in the counting loop, in the
+// loader's bind and between the MFMA waves' tiles: ~1 000 cycles each, 3 000 before a workgroup's first load was issued) are now one 32-bit
+// pair per wave at entry (round 6; tools/gemm_stamp4.py: entry -> first barrier 6 900 cycles, 1 900 between two tiles at the 128-channel shape).
+struct RowsWalk {
+  int p, nt, m0;
+  long cur, end;
+  __device__ __forceinline__ RowsWalk(const BgemmArgs& a, long lo, long hi) : cur(lo), end(hi) {
+    long col; int pp;
+    divmod_pos(lo, a.M, col, m0);
+    long pl;
+    divmod_pos(col, a.tiles_n, pl, nt);
+    pp = (int)pl; p = pp;
+  }
+  __device__ __forceinline__ bool done() const { return cur >= end; }
+  __device__ __forceinline__ RowsTile next(const BgemmArgs& a) {
+    const long lim = min((long)a.M - m0, end - cur);
+    const int rows = (int)min(128L, lim);
+    const RowsTile t{p, nt, m0, rows};
+    cur += rows; m0 += rows;
+    if (m0 == a.M) { m0 = 0; if (++nt == a.tiles_n) { nt = 0; ++p; } }
+    return t;
+  }
+};
 
 // RAGGED (round 3): N need not be a multiple of 128 nor K of 32 (both of 4) -- EfficientNet's 1x1 convolutions (24, 40, 48, 96, 136, 144,
 // 232, 288, 816, 1392 channels).  The loader reads the 16-byte operand segments that fall past row N of B or past column K from a page of
@@ -772,15 +799,16 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
   if (s_lo >= s_hi) return;                                  // (uniform)
   const int nch = RAGGED ? (a.K + 31) / 32 : a.K / 32;
   int ntiles = 0;
-  for (long cur = s_lo; cur < s_hi; cur += rows_tile_at(a, cur, s_hi).rows) ++ntiles;
+  const RowsWalk walk0(a, s_lo, s_hi);
+  for (RowsWalk c = walk0; !c.done(); c.next(a)) ++ntiles;
   const int nchunks = ntiles * nch;
 
   if (wave >= 4) {
     // ---------------- loader: piece q = l + 4 i (i < 8) of a chunk: q < 16 rows 8 q .. + 7 of A, else rows 8 (q - 16) .. of B ----------------
     const int l = wave - 4;
     HIFIHR_SET_LOADER_PRIO();
-    long cur = s_lo;
-    RowsTile t = rows_tile_at(a, cur, s_hi);
+    RowsWalk lw = walk0;
+    RowsTile t = lw.next(a);
     const float* src[8];
     int kseg[8];                                             // RAGGED: first k of this lane's segment within a chunk, or 1 << 30 for a B row >= N
     int ih0[4] = {0, 0, 0, 0}, iw0[4] = {0, 0, 0, 0};        // CONVG: image coordinate of tap (0, 0) of the pixel of A piece i (i < 4: l + 4 i < 16)
@@ -824,8 +852,7 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
       }
       if (++lc == nch) {
         lc = 0; tr = 0; ts = 0; tcb = 0;
-        cur += t.rows;
-        if (++li < ntiles) { t = rows_tile_at(a, cur, s_hi); bind(t); }
+        if (++li < ntiles) { t = lw.next(a); bind(t); }
       }
     };
     issue_next(0);
@@ -855,7 +882,7 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
 #if defined(HIFIHR_GEMM_STAMP)
   st_first = __builtin_amdgcn_s_memtime() - st_entry;
 #endif
-  long cur = s_lo;
+  RowsWalk mw = walk0;
   int gc = 0;
   // batch-norm statistics of the output (a.stats != null): per-column sums of this wave's 32 columns, kept in registers over the tiles of
   // one column tile (a share walks the rows of a column tile before it moves on), then folded over the 16 row lanes and added to the
@@ -1038,8 +1065,7 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
 #endif
   };
   for (int ti = 0; ti < ntiles; ++ti) {
-    const RowsTile t = rows_tile_at(a, cur, s_hi);
-    cur += t.rows;
+    const RowsTile t = mw.next(a);
     if (a.stats != nullptr && t.nt != stat_nt) { flush_stats(); stat_nt = t.nt; }       // (uniform; batch == 1: nt identifies the columns)
     switch ((t.rows + 15) >> 4) {
       case 8: run_tile(std::integral_constant<int, 8>{}, t); break;
@@ -1084,36 +1110,40 @@ __global__ __launch_bounds__(512) void bgemm_nt_rows_kernel(BgemmArgs a, long pe
 // tile -- a row permutation the epilogue undoes.  Tiles are 128, 64, 32 or 16 rows (the tail of a share is cut into powers of two).
 // ------------------------------------------------------------------------------------------------
 struct TnTile { int p, nt, m0, nb; };
-__device__ __forceinline__ TnTile tn_tile_at(const BgemmArgs& a, long cur, long end) {
-  const int MB = a.M / 16;
-  const long col = cur / MB;                                 // (p, nt) pair
-  const int mb0 = (int)(cur - col * MB);
-  const int p = (int)(col / a.tiles_n), nt = (int)(col - (long)p * a.tiles_n);
-  const long lim = min((long)MB - mb0, end - cur);
-  return TnTile{p, nt, mb0 * 16, lim >= 8 ? 8 : lim >= 4 ? 4 : lim >= 2 ? 2 : 1};
-}
 
 // The tiles of one workgroup, in order: `nr` ranges [lo0 + i step, + len) of the flattened (problem, 128-column tile, 16-row block) space -- its
 // slices of the rounds of the XCD-coherent schedule (BgemmArgs::co_r) -- then one range [tail_lo, tail_hi): the contiguous share (all of
-// the work when nr == 0).  Every range is cut into tiles by tn_tile_at.
+// the work when nr == 0).  Every range is cut into tiles of 8, 4, 2 or 1 row blocks (TnWalk::next).
+// (position (p, nt, mb0) of `cur` kept by additions inside a range, divisions -- 32-bit, divmod_pos -- only where a new range starts: see RowsWalk)
 struct TnWalk {
   int nr, ri;
   long lo0, step, len, tail_lo, tail_hi, cur, end;
+  int p, nt, mb0;
   __device__ __forceinline__ bool next(const BgemmArgs& a, TnTile& t) {
-    while (cur >= end) {
-      if (ri < nr) { cur = lo0 + (long)ri * step; end = cur + len; }
-      else if (ri == nr && tail_lo < tail_hi) { cur = tail_lo; end = tail_hi; }
-      else return false;
-      ++ri;
+    const int MB = a.M / 16;
+    if (cur >= end) {
+      do {
+        if (ri < nr) { cur = lo0 + (long)ri * step; end = cur + len; }
+        else if (ri == nr && tail_lo < tail_hi) { cur = tail_lo; end = tail_hi; }
+        else return false;
+        ++ri;
+      } while (cur >= end);
+      long col, pl;
+      divmod_pos(cur, MB, col, mb0);
+      divmod_pos(col, a.tiles_n, pl, nt);
+      p = (int)pl;
     }
-    t = tn_tile_at(a, cur, end);
-    cur += t.nb;
+    const long lim = min((long)MB - mb0, end - cur);
+    const int nb = lim >= 8 ? 8 : lim >= 4 ? 4 : lim >= 2 ? 2 : 1;
+    t = TnTile{p, nt, mb0 * 16, nb};
+    cur += nb; mb0 += nb;
+    if (mb0 == MB) { mb0 = 0; if (++nt == a.tiles_n) { nt = 0; ++p; } }
     return true;
   }
 };
 __device__ __forceinline__ TnWalk tn_walk(const BgemmArgs& a, long per, int wg, int nblk) {
   TnWalk w;
-  w.ri = 0; w.cur = 0; w.end = 0;
+  w.ri = 0; w.cur = 0; w.end = 0; w.p = 0; w.nt = 0; w.mb0 = 0;
   const long total = (long)a.batch * a.tiles_n * (a.M / 16);
   if (a.co_rounds > 0) {
     const int W = nblk >> 3, x = wg / W, j = wg - x * W;      // (nblk % 8 == 0: xcd_remap hands an XCD W consecutive workgroup ids)
