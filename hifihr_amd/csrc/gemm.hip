@@ -802,6 +802,7 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
   const RowsWalk walk0(a, s_lo, s_hi);
   for (RowsWalk c = walk0; !c.done(); c.next(a)) ++ntiles;
   const int nchunks = ntiles * nch;
+  const bool head1 = MODE == 0 && nch >= 2;                  // (uniform) chunk 1 belongs to the first tile and is issued by the MFMA waves
 
   if (wave >= 4) {
     // ---------------- loader: piece q = l + 4 i (i < 8) of a chunk: q < 16 rows 8 q .. + 7 of A, else rows 8 (q - 16) .. of B ----------------
@@ -834,18 +835,20 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
     int li = 0, lc = 0;                                      // tile / chunk-in-tile the NEXT issue belongs to
     int tr = 0, ts = 0, tcb = 0;                             // CONVG: tap (r, s) and 32-channel block of chunk lc
     const int cpb = CONVG ? a.cC / 32 : 1;
-    auto issue_next = [&](int gc) {
+    auto issue_next = [&](int gc, bool issue = true) {     // issue == false: chunk gc is somebody else's (chunk 1, below) -- only move on
       float* base = lds + (gc & 3) * STAGE;
       const long aoff = CONVG ? ((long)tr * a.cIW + ts) * a.cC + tcb * 32 : 0;
+      if (issue) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float* s = src[i] + lc * 32;
-        if (RAGGED) s = (kseg[i] + lc * 32 < a.K) ? s : a.zeros;       // (a row >= N: 1 << 30; the last chunk's segments past column K)
-        if (CONVG && i < 4) {
-          const int ih = ih0[i] + tr, iw = iw0[i] + ts;
-          s = ((unsigned)ih < (unsigned)a.cIH && (unsigned)iw < (unsigned)a.cIW) ? src[i] + aoff : a.zeros;
+        for (int i = 0; i < 8; ++i) {
+          const float* s = src[i] + lc * 32;
+          if (RAGGED) s = (kseg[i] + lc * 32 < a.K) ? s : a.zeros;       // (a row >= N: 1 << 30; the last chunk's segments past column K)
+          if (CONVG && i < 4) {
+            const int ih = ih0[i] + tr, iw = iw0[i] + ts;
+            s = ((unsigned)ih < (unsigned)a.cIH && (unsigned)iw < (unsigned)a.cIW) ? src[i] + aoff : a.zeros;
+          }
+          HIFIHR_GLDS16(s, base + 256 * (l + 4 * i), lane);
         }
-        HIFIHR_GLDS16(s, base + 256 * (l + 4 * i), lane);
       }
       if (CONVG) {
         if (++tcb == cpb) { tcb = 0; if (++ts == a.cS) { ts = 0; ++tr; } }
@@ -855,10 +858,14 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
         if (++li < ntiles) { t = lw.next(a); bind(t); }
       }
     };
+    // The first chunks.  A wave gets an LDS-DMA instruction out every ~200 cycles, so three chunks in a row from the loader waves put 3 200
+    // cycles + the memory latency in front of the first MFMA (tools/gemm_stamp4.py: entry -> first barrier 6 900 cycles, 14 % of a
+    // workgroup's life at the 128-channel shape).  `head1`: chunk 1 -- the second chunk of the share's first tile -- is issued by the MFMA
+    // waves, which have nothing else to do yet (wave w = loader w's pieces, below), beside chunk 0 here.
     issue_next(0);
-    if (nchunks > 1) issue_next(1);
+    if (nchunks > 1) issue_next(1, !head1);
     if (nchunks > 2) issue_next(2);
-    if (nchunks > 2) HIFIHR_WAIT_VM(8); else HIFIHR_WAIT_VM(0);      // chunks 0 and 1 landed
+    if (nchunks > 2) HIFIHR_WAIT_VM(8); else HIFIHR_WAIT_VM(0);      // chunks 0 and 1 landed (head1: chunk 0; chunk 1 is waited for by its issuers)
     HIFIHR_RAW_BARRIER();                                    // barrier -1
     for (int gc = 0; gc < nchunks; ++gc) {
       if (gc + 3 < nchunks) { issue_next(gc + 3); HIFIHR_WAIT_VM(8); }   // chunk gc + 2 landed; only chunk gc + 3's pieces in flight
@@ -877,6 +884,22 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
     const int sw = ((g + 4 * h) ^ ((r >> 1) & 7)) * 16;
     aoff[h] = r * 128 + sw;
     boff[h] = (128 + 32 * wave + r) * 128 + sw;
+  }
+  if (head1) {
+    // chunk 1 of the first tile: MFMA wave w issues the pieces of loader wave w (the loader's bind() for a plain tile, k offset 32)
+    RowsWalk hw = walk0;
+    const RowsTile tt = hw.next(a);
+    float* base = lds + STAGE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = wave + 4 * i;
+      const int row = 8 * (q & 15) + (lane >> 3);
+      const int seg = (lane & 7) ^ ((row >> 1) & 7);
+      const float* s = q < 16 ? a.A + (size_t)tt.p * a.sa + (size_t)(tt.m0 + min(row, tt.rows - 1)) * a.lda + seg * 4
+                              : a.B + (size_t)tt.p * a.sb + (size_t)(tt.nt * 128 + row) * a.ldb + seg * 4;
+      HIFIHR_GLDS16(s + 32, base + 256 * q, lane);
+    }
+    HIFIHR_WAIT_VM(0);
   }
   HIFIHR_RAW_BARRIER();                                      // barrier -1
 #if defined(HIFIHR_GEMM_STAMP)
@@ -1172,6 +1195,7 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
   }
   if (ntiles == 0) return;                                   // (uniform)
   const int nchunks = ntiles * nch;
+  const bool head1 = nch >= 2;                               // (uniform) chunk 1 = the first tile's second chunk: issued by the MFMA waves
 
   if (wave >= 4) {
     HIFIHR_SET_LOADER_PRIO();
@@ -1204,17 +1228,19 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
     };
     bind(t);
     int li = 0, lc = 0;
-    auto issue_next = [&](int gc) {
+    auto issue_next = [&](int gc, bool issue = true) {       // issue == false: chunk 1, issued by the MFMA waves (see nt_rows_body)
       float* base = lds + (gc & 3) * STAGE;
+      if (issue) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) HIFIHR_GLDS16(src[i] + lc * step[i], base + 256 * (l + 4 * i), lane);
+        for (int i = 0; i < 8; ++i) HIFIHR_GLDS16(src[i] + lc * step[i], base + 256 * (l + 4 * i), lane);
+      }
       if (++lc == nch) {
         lc = 0;
         if (++li < ntiles) { lw.next(a, t); bind(t); }
       }
     };
     issue_next(0);
-    if (nchunks > 1) issue_next(1);
+    if (nchunks > 1) issue_next(1, !head1);
     if (nchunks > 2) issue_next(2);
     if (nchunks > 2) HIFIHR_WAIT_VM(8); else HIFIHR_WAIT_VM(0);
     HIFIHR_RAW_BARRIER();                                    // barrier -1
@@ -1233,6 +1259,30 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
   for (int i = 0; i < 2; ++i) {
     const int colb = 32 * wave + 16 * i + r;
     boff[i] = 4 * ((colb >> 2) ^ (4 * g)) + (colb & 3);
+  }
+  if (head1) {
+    // chunk 1 of the first tile beside the loaders' chunk 0 (nt_rows_body): MFMA wave w issues loader wave w's pieces
+    TnWalk hw = walk;
+    TnTile tt;
+    hw.next(a, tt);
+    float* base = lds + STAGE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = wave + 4 * i;
+      const int trow = 2 * (q & 15) + (lane >> 5);
+      const int ps = lane & 31;
+      const float* sp;
+      if (q < 16) {
+        int col = tt.m0 + 4 * ps;
+        col = col <= a.M - 4 ? col : a.M - 4;
+        sp = a.A + (size_t)tt.p * a.sa + (size_t)(trow + 32) * a.lda + col;
+      } else {
+        const int seg = ps ^ (4 * (trow & 3));
+        sp = a.B + (size_t)tt.p * a.sb + (size_t)(trow + 32) * a.ldb + tt.nt * 128 + 4 * seg;
+      }
+      HIFIHR_GLDS16(sp, base + 256 * q, lane);
+    }
+    HIFIHR_WAIT_VM(0);
   }
   HIFIHR_RAW_BARRIER();                                      // barrier -1
   TnWalk mw = walk;
