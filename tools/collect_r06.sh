@@ -5,7 +5,7 @@
 # one made round 4 file a Python traceback as evidence -- and the script fails when any collected file holds a traceback.
 set -u
 cd $GRAFT_REPO_ROOT
-for b in tools/build_render_probe2.sh tools/build_halo_probe.sh tools/build_split_bf16_probe.sh; do [ -f $b ] && bash $b > /dev/null 2>&1; done
+for b in tools/build_render_probe2.sh tools/build_halo_probe.sh tools/build_split_bf16_probe.sh tools/build_gemm_probe.sh; do [ -f $b ] && bash $b > /dev/null 2>&1; done
 O=gpurun_out/r06; mkdir -p $O
 export TMPDIR=/tmp
 last() { tail -1 "$1" > "$2"; }
@@ -42,6 +42,9 @@ if [ -f tools/_probe/libhifihr_split_bf16.so ]; then
   (python3 tools/split_bf16_probe.py 2>&1 | grep -v amdgpu.ids; echo; echo "--- standalone plain LDS-tiled kernel (tools/split_bf16_probe.hip), bf16x3 and bf16x6 ---"; tools/_probe/split_bf16_probe hifihr_amd/libhifihr.so) > $O/r06_split_bf16_probe.txt 2>&1
 fi
 python3 tools/time_dwconv.py 2>/dev/null > $O/r06_time_dwconv.txt
+# where a workgroup of the row-share GEMM spends its life at the step's F(4x4) shapes (stamped build), and what a store costs by pattern
+if [ -f tools/_probe/libhifihr_gemm_stamp.so ]; then python3 tools/gemm_stamp4.py 2>&1 | grep -v amdgpu.ids > $O/r06_gemm_stamp4.txt; fi
+[ -x tools/_probe/store_pattern ] && tools/_probe/store_pattern > $O/r06_store_pattern.txt 2>&1
 # trunk gradient error vs the reference by dispatch (README "Precision of the default dispatch")
 python3 -m pytest tests/test_gpu_conv.py -q -s -k "precision_knob or gradient_error_by_dispatch" 2>&1 | grep -E "fixture|HIFIHR_|passed|failed" > $O/r06_precision_by_dispatch.txt
 if [ "${1:-}" != quick ]; then bash tools/ablation.sh > $O/r06_ablation.txt 2>&1; fi
