@@ -1037,13 +1037,24 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
 #if defined(HIFIHR_GEMM_STAMP)
     const unsigned long long l0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int c = 0; c < nch; ++c, ++gc) {
+    // register e of lane (r, g) of block (i, j) = C[m0 + 16 j + r][128 nt + 32 wave + 16 i + 4 g + e]
+    float* C = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
+    const int col0 = t.nt * 128 + 32 * wave + 4 * g;         // (RAGGED: the lane's column blocks col0 .. + 3 and col0 + 16 .. + 19 against N)
+    auto store_block = [&](int j) {
+      const int m = 16 * j + r;
+      if (m < t.rows) {
+        float* row = C + (size_t)(t.m0 + m) * a.ldc;
+        if (!RAGGED || col0 < a.N) *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
+        if (!RAGGED || col0 + 16 < a.N) *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
+      }
+    };
+    for (int c = 0; c < nch - 1; ++c, ++gc) {
       read_half(gc, 1, 1);
       mfma_half(0);
       interleave();
       HIFIHR_PIN();
-      read_half(gc + 1, 0, 0);                               // (landed: barrier gc - 1; past the tile's last chunk: the next tile's first, or a
-      mfma_half(1);                                          //  stale stage that is never used) -- unconditional, see bgemm_ws_kernel
+      read_half(gc + 1, 0, 0);                               // (landed: barrier gc - 1)
+      mfma_half(1);
       interleave();
       HIFIHR_PIN();
       touch();
@@ -1056,21 +1067,47 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
       st_bar += __builtin_amdgcn_s_memtime() - b0;
 #endif
     }
+    {
+      // The tile's LAST chunk runs row block by row block, both halves of the chunk per block (every accumulator still sums k in ascending
+      // order: the same bits), so that block j is final sixteen MFMAs after block j - 1 and the stores of block j - 1 -- two per lane -- go out
+      // between the MFMAs of the blocks behind it: the 16 stores of a tile back to back took 3 500 cycles (a wave that waits to issue a
+      // store issues no MFMA; tools/gemm_stamp4.py: 15 % of a workgroup's life at the 128-channel shape), spread over the chunk's 4 096
+      // cycles of matrix work most of them find the address path free.  (No prefetch of the next tile's first half here: slot 0 is in use
+      // until the last block; every tile starts with that read anyway.)
+      read_half(gc, 1, 1);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fn[h][i][k], fm[h][j][k], acc[i][j], 0, 0, 0);
+        HIFIHR_PIN();
+        if (j > 0) {
+          store_block(j - 1);
+          HIFIHR_PIN();
+        }
+      }
+      store_block(NB - 1);
+#if defined(HIFIHR_GEMM_STAMP)
+      HIFIHR_TOUCH(acc[0][0][0]);
+      const unsigned long long b0 = __builtin_amdgcn_s_memtime();
+#endif
+      HIFIHR_RAW_BARRIER();                                  // barrier gc
+#if defined(HIFIHR_GEMM_STAMP)
+      st_bar += __builtin_amdgcn_s_memtime() - b0;
+#endif
+      ++gc;
+    }
 #if defined(HIFIHR_GEMM_STAMP)
     const unsigned long long l1 = __builtin_amdgcn_s_memtime();
     st_loop += l1 - l0; st_real += __builtin_amdgcn_s_memrealtime() - r0;
 #endif
-    // register e of lane (r, g) of block (i, j) = C[m0 + 16 j + r][128 nt + 32 wave + 16 i + 4 g + e]
-    float* C = a.C + (size_t)t.p * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
-    const int col0 = t.nt * 128 + 32 * wave + 4 * g;         // (RAGGED: the lane's column blocks col0 .. + 3 and col0 + 16 .. + 19 against N)
+    if (a.stats != nullptr) {                                // (uniform) the statistics of the tile, from the accumulators the stores left in place
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int m = 16 * j + r;
-      if (m < t.rows) {
-        float* row = C + (size_t)(t.m0 + m) * a.ldc;
-        if (!RAGGED || col0 < a.N) *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
-        if (!RAGGED || col0 + 16 < a.N) *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
-        if (a.stats != nullptr) {                              // (uniform)
+      for (int j = 0; j < NB; ++j) {
+        if (16 * j + r < t.rows) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
