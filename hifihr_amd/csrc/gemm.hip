@@ -1389,27 +1389,90 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
       }
       HIFIHR_SCHED_GROUP(0x008, 8 * NB - MG * RH > 0 ? 8 * NB - MG * RH : 0);
     };
+    // register e of lane (r, g) of block (i, j) = C[m0 + row(j, r)][128 nt + 32 wave + 16 i + 4 g + e]
+    // (T-split, a.splits > 1: "problem" t.p is part t.p % splits of problem t.p / splits; its result is that problem's tile of slab `part`)
+    const int preal = a.splits > 1 ? t.p / a.splits : t.p, part = t.p - preal * (a.splits > 1 ? a.splits : 1);
+    float* C = a.C + (size_t)part * a.sc_split + (size_t)preal * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
+    auto store_block = [&](int j) {
+      const int m = NB == 8 ? 64 * (j >> 2) + 4 * r + (j & 3) : NB == 4 ? 4 * r + j : NB == 2 ? 2 * r + j : r;
+      float* row = C + (size_t)(t.m0 + m) * a.ldc;
+      *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
+      *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
+    };
     read_half(gc, 0, 0);
     touch();
     const int nfull = min(nch, kv_steps >> 3);               // chunks whose eight k-steps all carry data
-    for (int c = 0; c < nfull; ++c, ++gc) {
+    const int rem0 = nfull < nch ? kv_steps - 8 * nfull : 0; // live k-steps of the chunk behind them (450 real rows = 14 chunks + 2 rows: 1)
+    // `fused`: the tile's last full chunk runs row block by row block (nt_rows_body: the stores of block j - 1 between the MFMAs of the blocks
+    // behind it), together with the ONE live k-step of the chunk behind it, taken straight from LDS (landed: barrier gc - 1) -- every
+    // accumulator still sums k in ascending order.  More than one live k-step behind the full chunks, or no full chunk: the plain form.
+    const bool fused = nfull >= 1 && rem0 <= 1;              // (uniform)
+    const int nplain = fused ? nfull - 1 : nfull;
+    for (int c = 0; c < nplain; ++c, ++gc) {
       read_half(gc, 1, 1);
       mfma_half(0);
       interleave();
       HIFIHR_PIN();
-      read_half(gc + 1, 0, 0);                               // (landed: barrier gc - 1; past the tile's last chunk: the next tile's first, or a
-      mfma_half(1);                                          //  stale stage that is never used)
+      read_half(gc + 1, 0, 0);                               // (landed: barrier gc - 1)
+      mfma_half(1);
       interleave();
       HIFIHR_PIN();
       touch();
       HIFIHR_RAW_BARRIER();                                  // barrier gc
+    }
+    if (fused) {
+      read_half(gc, 1, 1);
+      float tb0 = 0.f, tb1 = 0.f, tam[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) tam[j] = 0.f;
+      if (rem0 == 1) {                                       // k-step 0 of chunk gc + 1 (rows t = g)
+        const float* st = lds + ((gc + 1) & 3) * STAGE;
+        const float* ar = st + g * 128;
+        const float* br = st + 32 * 128 + g * 128;
+        tb0 = br[boff[0]]; tb1 = br[boff[1]];
+        if constexpr (NB == 8) {
+          const float4 v0 = *reinterpret_cast<const float4*>(ar + 4 * r), v1 = *reinterpret_cast<const float4*>(ar + 64 + 4 * r);
+          tam[0] = v0.x; tam[1] = v0.y; tam[2] = v0.z; tam[3] = v0.w; tam[4] = v1.x; tam[5] = v1.y; tam[6] = v1.z; tam[7] = v1.w;
+        } else if constexpr (NB == 4) {
+          const float4 v0 = *reinterpret_cast<const float4*>(ar + 4 * r);
+          tam[0] = v0.x; tam[1] = v0.y; tam[2] = v0.z; tam[3] = v0.w;
+        } else if constexpr (NB == 2) {
+          const float2 v0 = *reinterpret_cast<const float2*>(ar + 2 * r);
+          tam[0] = v0.x; tam[1] = v0.y;
+        } else {
+          tam[0] = ar[r];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fn[h][k][i], fm[h][k][j], acc[i][j], 0, 0, 0);
+        if (rem0 == 1) {                                     // (uniform)
+          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tb0, tam[j], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tb1, tam[j], acc[1][j], 0, 0, 0);
+        }
+        HIFIHR_PIN();
+        if (j > 0) {
+          store_block(j - 1);
+          HIFIHR_PIN();
+        }
+      }
+      store_block(NB - 1);
+      HIFIHR_RAW_BARRIER();                                  // barrier gc
+      ++gc;
+      for (int c = nfull; c < nch; ++c, ++gc) HIFIHR_RAW_BARRIER();      // the chunks behind: their live k-step is done, the rest is zeros
+      return;
     }
     // The tail: a chunk that runs into the zero rows (its first `rem` k-steps carry data: 450 real rows = 14 chunks + 2 rows) and chunks of
     // zeros only.  The loader waves stream them like any other chunk (the chunk stream and its barriers are theirs to keep); here a ROLLED
     // loop takes the live k-steps straight from LDS -- no second register set, no schedule: a few hundred cycles per tile -- and the rest
     // only meets the barriers.
     for (int c = nfull; c < nch; ++c, ++gc) {
-      const int rem = c == nfull ? kv_steps - 8 * nfull : 0;
+      const int rem = c == nfull ? rem0 : 0;
       const float* st = lds + (gc & 3) * STAGE;
 #pragma unroll 1
       for (int kk = 0; kk < rem; ++kk) {
@@ -1438,17 +1501,8 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
       }
       HIFIHR_RAW_BARRIER();                                  // barrier gc
     }
-    // register e of lane (r, g) of block (i, j) = C[m0 + row(j, r)][128 nt + 32 wave + 16 i + 4 g + e]
-    // (T-split, a.splits > 1: "problem" t.p is part t.p % splits of problem t.p / splits; its result is that problem's tile of slab `part`)
-    const int preal = a.splits > 1 ? t.p / a.splits : t.p, part = t.p - preal * (a.splits > 1 ? a.splits : 1);
-    float* C = a.C + (size_t)part * a.sc_split + (size_t)preal * a.sc + (size_t)t.nt * 128 + 32 * wave + 4 * g;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int m = NB == 8 ? 64 * (j >> 2) + 4 * r + (j & 3) : NB == 4 ? 4 * r + j : NB == 2 ? 2 * r + j : r;
-      float* row = C + (size_t)(t.m0 + m) * a.ldc;
-      *reinterpret_cast<float4*>(row) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
-      *reinterpret_cast<float4*>(row + 16) = make_float4(acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]);
-    }
+    for (int j = 0; j < NB; ++j) store_block(j);
   };
   for (int ti = 0; ti < ntiles; ++ti) {
     TnTile t;
