@@ -1068,8 +1068,8 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
 #endif
     }
     {
-      // The tile's LAST chunk runs row block by row block, both halves of the chunk per block (every accumulator still sums k in ascending
-      // order: the same bits), so that block j is final sixteen MFMAs after block j - 1 and the stores of block j - 1 -- two per lane -- go out
+      // The tile's LAST chunk runs row block by row block, both halves of the chunk per block (every accumulator still sums its k-steps in the plain
+      // loop's order: the same bits -- tests/test_hostsim_gemm.py::test_row_share_kernels_keep_the_summation_order), so that block j is final sixteen MFMAs after block j - 1 and the stores of block j - 1 -- two per lane -- go out
       // between the MFMAs of the blocks behind it: the 16 stores of a tile back to back took 3 500 cycles (a wave that waits to issue a
       // store issues no MFMA; tools/gemm_stamp4.py: 15 % of a workgroup's life at the 128-channel shape), spread over the chunk's 4 096
       // cycles of matrix work most of them find the address path free.  (No prefetch of the next tile's first half here: slot 0 is in use

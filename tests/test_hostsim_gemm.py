@@ -81,3 +81,63 @@ def test_bgemm_tn_xcd_coherent_schedule(hostsim_lib, monkeypatch, M, N, T, batch
     monkeypatch.setenv("HIFIHR_GEMM_CUS", "4")               # 4 workgroups: never coherent
     hostsim_lib.bgemm_tn(a, b, c0, M, N, T, batch, 1)
     assert torch.equal(c0, c1)
+
+
+def _fma32(a, b, d):
+    """round-to-nearest float32 of a * b + d for float32 arrays (the emulator's MFMA is a chain of fmaf): the product of two 24-bit
+    significands is exact in the 64-bit significand of a long double, the sum is rounded once to it and once to float32 -- a double rounding
+    that differs from fmaf with probability ~2^-40 per operation on random operands"""
+    import numpy as np
+    return (a.astype(np.longdouble) * b.astype(np.longdouble) + d.astype(np.longdouble)).astype(np.float32)
+
+
+def test_row_share_kernels_keep_the_summation_order(hostsim_lib):
+    """The row-share kernels finish a tile block by block (round 6: the last chunk runs row block by row block so that a block's stores go out
+    between the MFMAs of the blocks behind it; the TN body also takes the live k-step of the zero-row tail from LDS inside that loop).  Whatever
+    the order of the MFMAs across row blocks, every accumulator must see its k-steps in the SAME order as in the plain loop (TN: t ascending;
+    NT: chunks ascending, inside a chunk the fixed order of the fragment layout): on the emulator (v_mfma = four chained fmaf) the result then
+    equals, bit for bit, a plain chain of fmaf in that order per output element -- for tiles of every height (1 .. 8 row blocks), shares that
+    cross problems, and a TN product behind a tile mosaic whose last rows are zero (the skipped k-steps would add exact zeros)."""
+    import numpy as np
+    import torch
+    assert np.finfo(np.longdouble).nmant >= 63, "needs an x87 long double"
+    gen = torch.Generator().manual_seed(11)
+    # NT: C[m][n] = sum_k A[m][k] B[n][k]
+    for M, N, K, batch in ((300, 128, 96, 3), (50, 256, 64, 2), (129, 128, 32, 1)):
+        a = torch.randn(batch, M, K, generator=gen); b = torch.randn(batch, N, K, generator=gen)
+        assert hostsim_lib.bgemm_describe(False, M, N, K).startswith("bgemm_nt_rows_kernel<")
+        c = torch.full((batch, M, N), 7.0)
+        hostsim_lib.bgemm_nt(a, b, c, M, N, K, batch)
+        an, bn = a.numpy(), b.numpy()
+        ref = np.zeros((batch, M, N), np.float32)
+        # (the NT body's order inside a 32-deep chunk: half h, component kc of the lanes' 16-byte fragments, lane group g -> k = 16 h + 4 g + kc)
+        for k in [32 * ch + 16 * h + 4 * g + kc for ch in range(K // 32) for h in range(2) for kc in range(4) for g in range(4)]:
+            ref = _fma32(an[:, :, k, None], bn[:, None, :, k], ref)
+        assert np.array_equal(c.numpy(), ref), (M, N, K, batch, float(np.abs(c.numpy() - ref).max()))
+    # TN: C[m][n] = sum_t A[t][m] B[t][n]
+    for M, N, T, batch in ((128, 128, 96, 4), (192, 256, 96, 2), (320, 128, 64, 3)):
+        a = torch.randn(batch, T, M, generator=gen); b = torch.randn(batch, T, N, generator=gen)
+        assert hostsim_lib.bgemm_describe(True, M, N, T, batch) == "bgemm_tn_rows_kernel"
+        c = torch.full((1, batch, M, N), 7.0)
+        hostsim_lib.bgemm_tn(a, b, c, M, N, T, batch, 1)
+        an, bn = a.numpy(), b.numpy()
+        ref = np.zeros((batch, M, N), np.float32)
+        for t in range(T):
+            ref = _fma32(an[:, t, :, None], bn[:, t, None, :], ref)
+        assert np.array_equal(c.numpy()[0], ref), (M, N, T, batch, float(np.abs(c.numpy()[0] - ref).max()))
+    # TN behind a tile mosaic: 16 images of 13 x 13 share 196 F(4x4) tiles in 224 allocated rows; rows 196 .. 223 of both operands are zero
+    # and their k-steps are skipped (BgemmArgs::k_valid) -- 6 full chunks + ONE live k-step: the fused form of the last full chunk
+    Nn, H, C, K = 16, 13, 128, 64
+    T4, Tr = hostsim_lib.wino_tiles(Nn, H, H, 4), hostsim_lib.wino_tiles_computed(Nn, H, H, 4)
+    assert (T4, Tr) == (224, 196) and hostsim_lib.bgemm_describe(True, K, C, T4, 36) == "bgemm_tn_rows_kernel"
+    parts = hostsim_lib.wino_wgrad_parts(Nn, H, H, C, K, 4)
+    assert parts == 1
+    V = torch.randn(36, T4, C, generator=gen); Y = torch.randn(36, T4, K, generator=gen)
+    V[:, Tr:] = 0; Y[:, Tr:] = 0
+    dU = torch.full((parts, 36, K, C), 7.0)
+    hostsim_lib.wino_wgrad_gemm_parts(V, Y, dU, Nn, H, H, C, K, parts, m=4)
+    vn, yn = V.numpy(), Y.numpy()
+    ref = np.zeros((36, K, C), np.float32)
+    for t in range(Tr):
+        ref = _fma32(yn[:, t, :, None], vn[:, t, None, :], ref)
+    assert np.array_equal(dU.numpy()[0], ref), float(np.abs(dU.numpy()[0] - ref).max())
