@@ -1068,12 +1068,13 @@ __device__ __forceinline__ void nt_rows_body(const BgemmArgs& a, long per, float
 #endif
     }
     {
-      // The tile's LAST chunk runs row block by row block, both halves of the chunk per block (every accumulator still sums its k-steps in the plain
-      // loop's order: the same bits -- tests/test_hostsim_gemm.py::test_row_share_kernels_keep_the_summation_order), so that block j is final sixteen MFMAs after block j - 1 and the stores of block j - 1 -- two per lane -- go out
-      // between the MFMAs of the blocks behind it: the 16 stores of a tile back to back took 3 500 cycles (a wave that waits to issue a
-      // store issues no MFMA; tools/gemm_stamp4.py: 15 % of a workgroup's life at the 128-channel shape), spread over the chunk's 4 096
-      // cycles of matrix work most of them find the address path free.  (No prefetch of the next tile's first half here: slot 0 is in use
-      // until the last block; every tile starts with that read anyway.)
+      // The tile's LAST chunk runs row block by row block, both halves of the chunk per block (every accumulator still sums its k-steps in
+      // the plain loop's order: the same bits -- tests/test_hostsim_gemm.py::test_row_share_kernels_keep_the_summation_order), so that
+      // block j is final sixteen MFMAs after block j - 1 and the stores of block j - 1 -- two per lane -- go out between the MFMAs of
+      // the blocks behind it: the 16 stores of a tile back to back took 3 500 cycles (a wave that waits to issue a store issues no MFMA;
+      // tools/gemm_stamp4.py: 15 % of a workgroup's life at the 128-channel shape), spread over the chunk's 4 096 cycles of matrix work
+      // most of them find the address path free.  (No prefetch of the next tile's first half here: slot 0 is in use until the last
+      // block; every tile starts with that read anyway.)
       read_half(gc, 1, 1);
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
@@ -1405,7 +1406,7 @@ __device__ __forceinline__ void tn_rows_body(const BgemmArgs& a, long per, float
     const int rem0 = nfull < nch ? kv_steps - 8 * nfull : 0; // live k-steps of the chunk behind them (450 real rows = 14 chunks + 2 rows: 1)
     // `fused`: the tile's last full chunk runs row block by row block (nt_rows_body: the stores of block j - 1 between the MFMAs of the blocks
     // behind it), together with the ONE live k-step of the chunk behind it, taken straight from LDS (landed: barrier gc - 1) -- every
-    // accumulator still sums k in ascending order.  More than one live k-step behind the full chunks, or no full chunk: the plain form.
+    // accumulator still sums its k-steps in the plain loop's order (t ascending).  More than one live k-step behind the full chunks, or no full chunk: the plain form.
     const bool fused = nfull >= 1 && rem0 <= 1;              // (uniform)
     const int nplain = fused ? nfull - 1 : nfull;
     for (int c = 0; c < nplain; ++c, ++gc) {
