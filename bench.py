@@ -357,6 +357,13 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
             us = hip_us(lambda: lib.conv2d_bwd_weight(x, y, dw, N_, H_, W_, C_, K_, R_, S_, st_, pd_))
             add(lib.conv2d_describe(N_, H_, W_, C_, K_, R_, S_, st_, pd_, 2), per_step, us, flop, nbytes, f"wgrad N{N_} {H_}x{W_} C{C_}->K{K_} {R_}x{S_} s{st_}")
             continue
+        if direction == "dgrad+1x1":           # conv_igemm_kernel: the strided 3x3 backward-data with the downsample 1x1's as a tap of class (0, 0)
+            wt = torch.empty(w.numel(), device=dev); lib.weight_transpose(w, wt, K_, R_ * S_, C_)
+            y2 = torch.randn(N_, OH_, OW_, K_, device=dev); wt2 = torch.randn(C_, K_, device=dev) * 0.05
+            us = hip_us(lambda: lib.conv2d_bwd_data_pre_plus1x1(y, wt, y2, wt2, x, N_, H_, W_, C_, K_, R_, S_, st_, pd_))
+            add(lib.conv2d_describe(N_, H_, W_, C_, K_, R_, S_, st_, pd_, True), per_step, us, flop + 2.0 * N_ * OH_ * OW_ * K_ * C_,
+                nbytes + 4.0 * (N_ * OH_ * OW_ * K_ + K_ * C_), f"dgrad N{N_} {H_}x{W_} C{C_}->K{K_} {R_}x{S_} s{st_}  +  1x1 s{st_} of the same input, one launch")
+            continue
         ws = ops._conv_ws(lib, dev, geom, direction == "dgrad")
         if direction == "fwd":
             fn = lambda: lib.conv2d_fwd(x, w, None, y, N_, H_, W_, C_, K_, R_, S_, st_, pd_, ws=ws)

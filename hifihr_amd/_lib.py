@@ -151,6 +151,8 @@ class HifihrLib:
         c.hifihr_wino_input_dy_transform.argtypes = [_c_float_p] * 3 + [c_int] * 4 + [c_void_p]
         c.hifihr_conv2d_bwd_data_pre.argtypes = [_c_float_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_conv2d_bwd_data_pre_res.argtypes = [_c_float_p] * 4 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]
+        c.hifihr_conv2d_bwd_data_pre_plus1x1.argtypes = [_c_float_p] * 5 + [c_int] * 9 + [c_void_p]
+        c.hifihr_conv2d_bwd_data_pre_plus1x1_supported.argtypes = [c_int] * 9
         c.hifihr_weight_prep.argtypes = [c_void_p, c_int, c_int, c_void_p]
         c.hifihr_freihand_augment.argtypes = [c_void_p, c_void_p, _c_int_p, _c_int_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_ho3d_workspace_bytes.argtypes = [c_int, c_int]
@@ -628,6 +630,15 @@ class HifihrLib:
         wsp, wsb = self._ws(ws)
         self.check(self.c.hifihr_conv2d_bwd_data_pre_res(_fp(dy), _fp(wt), _fp(res), _fp(dx), N, H, W, C, K, R, S, stride, pad, wsp, wsb,
                                                          _stream_of(dy)), "hifihr_conv2d_bwd_data_pre_res")
+
+    def conv2d_bwd_data_pre_plus1x1_supported(self, N, H, W, C, K, R, S, stride, pad):
+        return bool(self.c.hifihr_conv2d_bwd_data_pre_plus1x1_supported(int(N), int(H), int(W), int(C), int(K), int(R), int(S), int(stride), int(pad)))
+
+    def conv2d_bwd_data_pre_plus1x1(self, dy, wt, dy2, wt2, dx, N, H, W, C, K, R, S, stride, pad):
+        """dx = backward-data of the strided convolution (dy, wt) + backward-data of a 1x1 / same stride / pad 0 convolution of the same input
+        (dy2 [N][OH][OW][K], wt2 [C][K]) in one launch (include/hifihr.h)."""
+        self.check(self.c.hifihr_conv2d_bwd_data_pre_plus1x1(_fp(dy), _fp(wt), _fp(dy2), _fp(wt2), _fp(dx), N, H, W, C, K, R, S, stride, pad,
+                                                             _stream_of(dy)), "hifihr_conv2d_bwd_data_pre_plus1x1")
 
     @staticmethod
     def prep_jobs(jobs, device):

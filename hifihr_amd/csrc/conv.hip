@@ -150,11 +150,14 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, r31 = lane & 31;
-  const GatherPlan P = make_plan(g, (SK || g.batch > 1) ? 0 : blockIdx.z);
+  const int cls = (SK || g.batch > 1) ? 0 : (int)blockIdx.z;
+  const GatherPlan P = make_plan(g, cls);
+  // the second convolution's tap (ConvGeom::src2): class (0, 0) of a strided backward-data launch only (never SK, never GENERIC, batch 1)
+  const bool extra = !SK && !GENERIC && g.src2 != nullptr && g.dgrad && cls == 0;
   const int M = g.N * P.OHs * P.OWs;
   const int Qw = g.R * g.S * g.IC;                // row length of the weight matrix
   const int lrow = tid / SEGS, seg = (tid % SEGS) * 4;
-  const int nch_tile = GENERIC ? (Qw + BK - 1) / BK : P.nr * P.ns * (g.IC / BK);
+  const int nch_tile = GENERIC ? (Qw + BK - 1) / BK : P.nr * P.ns * (g.IC / BK) + (extra ? g.IC / BK : 0);
   __shared__ int sk_last;
   int wg = blockIdx.x;
   int it = 0, it_end = 0, tile_base = 0, L = 0;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
   // in the K loop (the loop was VALU-bound on address arithmetic: 75 vector instructions per 16 MFMAs in round 1).
   // Rows past M and output channels past OC read valid memory and produce values nobody stores; only padding taps must
   // contribute exact zeros, which the mask takes care of at LDS-store time.
-  int a_off[AL], w_off[BL];
+  int a_off[AL], w_off[BL], w_off2[BL];
   unsigned long long a_mask[AL];
   if (!GENERIC) {
 #pragma unroll
@@ -233,12 +236,13 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
       for (int r = 0; r < P.nr; ++r) { const int ih = a_h[i] + P.sign * r; if (ih >= 0 && ih < g.IH) rbits |= 1u << r; }
       for (int c = 0; c < P.ns; ++c) { const int iw = a_w[i] + P.sign * c; if (iw >= 0 && iw < g.IW) cbits |= 1ull << c; }
       for (int r = 0; r < P.nr; ++r) if ((rbits >> r) & 1u) m |= cbits << (r * P.ns);
-      a_mask[i] = a_ok[i] ? (m & 0x7fffffffffffffffull) : 0ull;   // bit 63 stays clear: the "no tap" bit of prefetches past the end
-    }
+      a_mask[i] = a_ok[i] ? ((m & 0x3fffffffffffffffull) | (1ull << 62)) : 0ull;   // bit 63 stays clear: the "no tap" bit of prefetches past the
+    }                                                                             // end; bit 62 = the row exists: the second convolution's tap
 #pragma unroll
     for (int j = 0; j < BL; ++j) {
       const int k = bn0 + lrow + RP * j;
       w_off[j] = (k < g.OC ? k : 0) * Qw + seg;
+      w_off2[j] = (k < g.OC ? k : 0) * g.IC + seg;          // (the second convolution's filter: rows of IC floats)
     }
   }
 
@@ -285,21 +289,26 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
     } else {
       const bool qok = issued < nch;         // false for the prefetches issued past the last chunk (their data is never used;
       ++issued;                              // a parity class can also have nr > 0 but ns == 0: no chunk at all)
-      const int tbit = qok ? jr * P.ns + js : 63;                                               // wave-uniform (SALU)
-      const int toff = qok ? P.sign * (jr * g.IW + js) * g.IC + c0 : 0;
-      const int wq = qok ? ((P.r0 + P.rstep * jr) * g.S + (P.s0 + P.rstep * js)) * g.IC + c0 : 0;
+      // (extra: behind the class's own taps, jr == P.nr, come the IC / BK chunks of the second convolution: its dy at the class pixel itself,
+      //  its filter row of IC floats)
+      const bool ex = extra && qok && jr >= P.nr;                                                // wave-uniform
+      const int tbit = !qok ? 63 : ex ? 62 : jr * P.ns + js;                                     // wave-uniform (SALU)
+      const int toff = !qok ? 0 : ex ? c0 - (P.aofh * g.IW + P.aofw) * g.IC : P.sign * (jr * g.IW + js) * g.IC + c0;
+      const int wq = !qok ? 0 : ex ? c0 : ((P.r0 + P.rstep * jr) * g.S + (P.s0 + P.rstep * js)) * g.IC + c0;
+      const float* __restrict__ sp = ex ? g.src2 : src;
+      const float* __restrict__ wp = ex ? g.wgt2 : wgt;
       c0 += BK;
-      if (c0 >= g.IC) { c0 = 0; if (++js == P.ns) { js = 0; ++jr; } }
+      if (c0 >= g.IC) { c0 = 0; if (++js == P.ns || ex) { js = 0; ++jr; } }
 #pragma unroll
       for (int i = 0; i < AL; ++i) {
         const bool ok = ((a_mask[i] >> tbit) & 1ull) != 0;
         const unsigned off = ok ? (unsigned)(a_off[i] + toff) : 0u;
-        ra[st][i] = *reinterpret_cast<const float4*>(src + off);
+        ra[st][i] = *reinterpret_cast<const float4*>(sp + off);
         va[st][i] = ok;
       }
 #pragma unroll
       for (int j = 0; j < BL; ++j) {
-        rb[st][j] = *reinterpret_cast<const float4*>(wgt + (unsigned)(w_off[j] + wq));
+        rb[st][j] = *reinterpret_cast<const float4*>(wp + (unsigned)((ex ? w_off2[j] : w_off[j]) + wq));
         vb[st][j] = true;
       }
     }
@@ -1054,7 +1063,8 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   if (g.IC % 4 != 0) return hipErrorInvalidValue;
   // the fast gather uses 32-bit element offsets (scaled by 4 in the address) and a 63-bit tap mask
   if ((long)g.N * g.IH * g.IW * g.IC >= (1L << 30) || (long)g.OC * g.R * g.S * g.IC >= (1L << 30)) return hipErrorInvalidValue;
-  const bool res = g.residual != nullptr;                    // (only conv_igemm_kernel's epilogue adds one: the specialised kernels are skipped)
+  const bool res = g.residual != nullptr || g.src2 != nullptr;   // (only conv_igemm_kernel adds a residual / runs a second convolution's tap: the specialised kernels are skipped)
+  if (g.src2 != nullptr && (!g.dgrad || g.stride < 2 || g.wgt2 == nullptr || g.batch > 1 || g.IC % 16 != 0 || g.R * g.S > 62)) return hipErrorInvalidValue;
   if (res && !g.dgrad) return hipErrorInvalidValue;
   if (!res && conv_oc4_supported(g, bias, stats)) {
     const long M = (long)g.N * g.OH * g.OW;
@@ -1091,7 +1101,7 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   if (conv_stem_supported(g, bias)) {
     if (const float* zeros = conv_halo_zero_page(st)) return launch_conv_stem(g, src, wgt, dst, stats, zeros, st);
   }
-  const bool generic = (g.IC % 16) != 0 || g.R * g.S > 63;
+  const bool generic = (g.IC % 16) != 0 || g.R * g.S > 62;   // (62 tap bits + the row bit + the "no tap" bit of the gather's mask)
   if (generic && g.dgrad && g.stride != 1) return hipErrorInvalidValue;   // strided dgrad needs source channels % 16 == 0
   int bk = (g.IC % 32 == 0) ? 32 : 16;
   if (const char* e = getenv("HIFIHR_CONV_BK")) bk = (atoi(e) == 32 && g.IC % 32 == 0) ? 32 : 16;   // tuning override
@@ -1100,7 +1110,7 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
   const int st_ = g.dgrad ? g.stride : 1;
   const long Mmax = (long)g.N * ((g.OH + st_ - 1) / st_) * ((g.OW + st_ - 1) / st_);   // rows of the largest class
   const int tile = pick_tile(Mmax * classes, g.OC, generic);
-  if (sk_ws != nullptr && tile == 2 && bk == 32 && bias == nullptr) {
+  if (sk_ws != nullptr && tile == 2 && bk == 32 && bias == nullptr && g.src2 == nullptr) {
     const SkPlan p = sk_plan(g);
     if (p.use && sk_ws_bytes >= conv_sk_workspace_bytes(g)) {
       if (p.v.bm == 64) launch_sk<64, 64, 32>(p, g, src, wgt, dst, stats, sk_ws, st);

@@ -537,6 +537,28 @@ int hifihr_conv2d_bwd_data_pre_res(const float* dy, const float* wt, const float
   return HIFIHR_OK;
 }
 
+int hifihr_conv2d_bwd_data_pre_plus1x1_supported(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+  // the fast (non-generic) gather of conv_igemm_kernel on parity classes: K % 16 == 0; a stride that makes classes; pad < the filter; the
+  // 1x1 / same stride / pad 0 convolution's outputs are the 3x3's (same OH x OW)
+  if (!conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || stride < 2 || K % 16 || C % 4 || R * S > 62) return 0;
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+  if (OH != (H - 1) / stride + 1 || OW != (W - 1) / stride + 1) return 0;
+  if ((long)N * OH * OW * K >= (1L << 30) || (long)C * R * S * K >= (1L << 30)) return 0;
+  static const int on = [] { const char* e = getenv("HIFIHR_DGRAD_PLUS1X1"); return e ? atoi(e) : 1; }();
+  return on;
+}
+
+int hifihr_conv2d_bwd_data_pre_plus1x1(const float* dy, const float* wt, const float* dy2, const float* wt2, float* dx, int N, int H, int W, int C,
+                                       int K, int R, int S, int stride, int pad, void* stream) {
+  if (!dy || !wt || !dy2 || !wt2 || !dx || !hifihr_conv2d_bwd_data_pre_plus1x1_supported(N, H, W, C, K, R, S, stride, pad))
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_data_pre_plus1x1: bad argument (see hifihr_conv2d_bwd_data_pre_plus1x1_supported)");
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+  hifihr::ConvGeom g{N, OH, OW, K, H, W, C, R, S, stride, pad, 1};
+  g.src2 = dy2; g.wgt2 = wt2;
+  HIP_TRY(hifihr::launch_conv_igemm(g, dy, wt, nullptr, dx, nullptr, nullptr, 0, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_weight_prep(const hifihr_prep_job* jobs, int njobs, int blocks_per_job, void* stream) {
   static_assert(sizeof(hifihr_prep_job) == sizeof(hifihr::PrepJob), "hifihr_prep_job layout");
   if (!jobs || njobs <= 0 || blocks_per_job <= 0) return fail(HIFIHR_EINVAL, "hifihr_weight_prep: bad argument");

@@ -95,6 +95,12 @@ struct ConvGeom {
   // layer's input (a block's identity branch, a second convolution of the same tensor) added where this one is produced, instead of an
   // elementwise pass over both afterwards (round 4; ops._Conv2dMFMA fork)
   const float* residual = nullptr;
+  // backward-data only (conv_igemm_kernel, stride > 1, round 6): a SECOND convolution of the same input -- 1x1, the same stride, pad 0, the same
+  // channel counts (a residual stage's downsample branch) -- whose data gradient lands on the pixels of parity class (0, 0) only: it rides in
+  // that class as one more tap, src2 = its dy [N][OH][OW][IC], wgt2 = its transposed filter [OC][IC], instead of a launch of its own whose
+  // stride-times-stride larger, mostly zero result would come back in as `residual`
+  const float* src2 = nullptr;
+  const float* wgt2 = nullptr;
 };
 // sk_ws (may be NULL): zero-initialised, self-cleaning workspace of conv_sk_workspace_bytes(g) bytes for the balanced schedule
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,

@@ -1062,7 +1062,13 @@ class _Conv2dMFMA(torch.autograd.Function):
             if PROFILE.on:
                 PROFILE.conv_log.append(((N, H, W, C, K, R, S, stride, pad), "dgrad"))
             wt = _WEIGHT_PREP.get(ctx.w_param, wk, 0)
-            if wt is not None and g_fork is not None:
+            plus = getattr(ctx, "plus1x1", None)          # (dy, transposed filter) of a 1x1 convolution of the same input (_Conv2dPair.backward)
+            if plus is not None:
+                assert wt is not None and g_fork is None
+                if PROFILE.on:
+                    PROFILE.conv_log[-1] = ((N, H, W, C, K, R, S, stride, pad), "dgrad+1x1")
+                PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data_pre_plus1x1(gy, wt, plus[0], plus[1], dx, N, H, W, C, K, R, S, stride, pad))
+            elif wt is not None and g_fork is not None:
                 PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data_pre_res(gy, wt, g_fork, dx, N, H, W, C, K, R, S, stride, pad, ws=ws))
             elif wt is not None:                   # [C][R][S][K] transpose from the step's weight_prep launch
                 PROFILE.bracket("conv_dgrad", lambda: lib.conv2d_bwd_data_pre(gy, wt, dx, N, H, W, C, K, R, S, stride, pad, ws=ws))
@@ -1201,6 +1207,25 @@ class _Conv2dPair(torch.autograd.Function):
                             grad_premasked=False, mask_input_grad=False, fork=fork,
                             needs_input_grad=(need_x, need_w, False, False, False, False, False, False, False, False))
         dx2 = dw2 = dx = dw1 = None
+        # Both gradients present and the step's re-laid-out filters at hand: the 1x1 convolution's data gradient -- it lands on the pixels
+        # (stride i, stride j) only -- rides in the 3x3 convolution's backward-data launch as one more tap of that parity class
+        # (hifihr_conv2d_bwd_data_pre_plus1x1), instead of a launch of its own whose mostly-zero result comes back in as the fork residual.
+        N, H, W, C, K1, R, S, stride, pad = ctx.geom1
+        plus = None
+        if gy1 is not None and gy2 is not None and need_x and wk2.shape[0] == K1:
+            lib = get_lib()
+            if lib.conv2d_bwd_data_pre_plus1x1_supported(N, H, W, C, K1, R, S, stride, pad):
+                wt1, wt2 = _WEIGHT_PREP.get(ctx.w1, wk1, 0), _WEIGHT_PREP.get(ctx.w2, wk2, 0)
+                if wt1 is not None and wt2 is not None:
+                    plus = (gy2.contiguous(memory_format=_CL), wt2)
+        if plus is not None:
+            s2 = shim(wk2, ctx.geom2, ctx.w2, need_w2, False)
+            s2.needs_input_grad = (False,) + tuple(s2.needs_input_grad[1:])          # its weight gradient only
+            dw2 = _Conv2dMFMA.backward(s2, gy2)[1]
+            s1 = shim(wk1, ctx.geom1, ctx.w1, need_w1, False)
+            s1.plus1x1 = plus
+            dx, dw1 = _Conv2dMFMA.backward(s1, gy1)[:2]
+            return dx, dw1, dw2, None
         if gy2 is not None:
             dx2, dw2 = _Conv2dMFMA.backward(shim(wk2, ctx.geom2, ctx.w2, need_w2, False), gy2)[:2]
         if gy1 is not None:

@@ -473,6 +473,15 @@ int hifihr_conv2d_bwd_data_pre(const float* dy_d, const float* wt_d, float* dx_d
  * the strided 3x3 convolution AND the 1x1 downsample convolution -- the second backward-data adds the first one's result as it stores. */
 int hifihr_conv2d_bwd_data_pre_res(const float* dy_d, const float* wt_d, const float* res_d, float* dx_d, int N, int H, int W, int C, int K,
                                    int R, int S, int stride, int pad, void* ws_d, size_t ws_bytes, void* stream);
+/* dx = backward-data of the strided convolution (dy_d, wt_d as in hifihr_conv2d_bwd_data_pre) + backward-data of a SECOND convolution of the same
+ * input: 1x1, the same stride, pad 0, the same channel counts (dy2_d [N][OH][OW][K], wt2_d [C][K] = its transposed filter) -- the downsample
+ * branch of a residual stage's first block (reference: vendored torchvision BasicBlock, network/res_encoder.py:364-373 runs both through
+ * cuDNN / MIOpen and autograd adds the two gradients).  The 1x1 convolution's gradient lands on the pixels (stride i, stride j) only: it is one
+ * more tap of that parity class of the strided launch instead of a launch of its own plus a residual pass (round 6).
+ * _supported: 1 when the shape runs on that path (stride >= 2, K % 16 == 0, equal output grids); HIFIHR_DGRAD_PLUS1X1=0 switches it off. */
+int hifihr_conv2d_bwd_data_pre_plus1x1_supported(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+int hifihr_conv2d_bwd_data_pre_plus1x1(const float* dy_d, const float* wt_d, const float* dy2_d, const float* wt2_d, float* dx_d, int N, int H,
+                                       int W, int C, int K, int R, int S, int stride, int pad, void* stream);
 /* Every per-step weight re-layout of a model in ONE launch.  The weights change once per optimizer step; a ResNet-18 step
  * otherwise spends ~40 tiny launches (~5 us of launch floor each) on transposes and Winograd weight transforms.
  * jobs_d: DEVICE array of njobs descriptors (src / dst are device pointers);

@@ -618,6 +618,46 @@ def conv_fwd_pair_case(lib, device, N, H, W, C, K1, K2, seed=0):
     assert float((yb.cpu() - r2.permute(0, 2, 3, 1)).abs().max()) <= 3e-5 * float(r2.abs().max()) + 1e-6
 
 
+def conv_dgrad_plus1x1_case(lib, device, N, H, W, C, K, stride=2, seed=0):
+    """hifihr_conv2d_bwd_data_pre_plus1x1: backward-data of the strided 3x3 convolution with the data gradient of the 1x1 / same stride / pad 0
+    convolution of the same input as one more tap of parity class (0, 0) == torch autograd of conv(x, w1) + conv(x, w2) wrt x, and ==
+    the two separate launches (hifihr_conv2d_bwd_data_pre on the 1x1, its result as the residual of hifihr_conv2d_bwd_data_pre_res on the
+    3x3) to the rounding of one more term per pixel of that class."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=gen).requires_grad_(True)
+    w1 = torch.randn(K, C, 3, 3, generator=gen) / (9 * C) ** 0.5; w2 = torch.randn(K, C, 1, 1, generator=gen) / C ** 0.5
+    y1, y2 = F.conv2d(x, w1, None, stride, 1), F.conv2d(x, w2, None, stride, 0)
+    assert y1.shape == y2.shape
+    g1, g2 = torch.randn(y1.shape, generator=gen), torch.randn(y2.shape, generator=gen)
+    (y1 * g1).sum().backward(retain_graph=True)
+    ref1 = x.grad.clone()
+    x.grad = None
+    ((y1 * g1).sum() + (y2 * g2).sum()).backward()
+    ref = x.grad.permute(0, 2, 3, 1)
+    d = lambda t: t.to(device).contiguous()
+    g1d, g2d = d(g1.permute(0, 2, 3, 1)), d(g2.permute(0, 2, 3, 1))
+    w1d, w2d = d(w1.permute(0, 2, 3, 1)), d(w2.permute(0, 2, 3, 1))                   # [K][R][S][C]
+    wt1, wt2 = torch.empty(w1d.numel(), device=device), torch.empty(w2d.numel(), device=device)
+    lib.weight_transpose(w1d, wt1, K, 9, C); lib.weight_transpose(w2d, wt2, K, 1, C)  # [C][R][S][K]
+    assert lib.conv2d_bwd_data_pre_plus1x1_supported(N, H, W, C, K, 3, 3, stride, 1)
+    dx = torch.full((N, H, W, C), 7.0, device=device)
+    lib.conv2d_bwd_data_pre_plus1x1(g1d, wt1, g2d, wt2, dx, N, H, W, C, K, 3, 3, stride, 1)
+    scale = float(ref.abs().max())
+    assert float((dx.cpu() - ref).abs().max()) <= 3e-5 * scale + 1e-6, float((dx.cpu() - ref).abs().max())
+    # the two-launch form it replaces
+    dx2 = torch.full((N, H, W, C), 7.0, device=device); dxs = torch.full((N, H, W, C), 7.0, device=device)
+    lib.conv2d_bwd_data_pre(g2d, wt2, dx2, N, H, W, C, K, 1, 1, stride, 0)
+    lib.conv2d_bwd_data_pre_res(g1d, wt1, dx2, dxs, N, H, W, C, K, 3, 3, stride, 1)
+    assert float((dx - dxs).abs().max()) <= 2e-6 * scale + 1e-7, float((dx - dxs).abs().max())
+    # the pixels off class (0, 0) carry the 3x3 convolution's gradient alone: bit for bit what the plain launch gives
+    dx1 = torch.full((N, H, W, C), 7.0, device=device)
+    lib.conv2d_bwd_data_pre(g1d, wt1, dx1, N, H, W, C, K, 3, 3, stride, 1)
+    off = torch.ones(H, W, dtype=torch.bool); off[::stride, ::stride] = False
+    assert torch.equal(dx.cpu()[:, off], dx1.cpu()[:, off])
+    assert float((dx1.cpu() - ref1.permute(0, 2, 3, 1)).abs().max()) <= 3e-5 * scale + 1e-6
+
+
 # ------------------------------------------------------------------------------------------------
 # depthwise convolution (EfficientNet MBConv) vs plain PyTorch fp32 (F.pad + grouped F.conv2d autograd)
 # ------------------------------------------------------------------------------------------------

@@ -599,3 +599,10 @@ def test_weight_gradient_transforms_of_several_layers_in_one_launch(lib):
 def test_strided_conv_and_downsample_conv_in_one_launch(lib, N, H, C, K1, K2):
     """hifihr_conv2d_fwd_bnstats_pair: conv1 (3x3 stride 2) + downsample[0] (1x1 stride 2) of layer2.0 / layer3.0 at B = 32, and a ragged size."""
     kc.conv_fwd_pair_case(lib, "cuda", N, H, H, C, K1, K2, seed=H + C)
+
+
+@pytest.mark.parametrize("N,H,C,K", [(32, 56, 64, 128), (32, 28, 128, 256), (3, 31, 32, 48)])
+def test_strided_dgrad_with_the_downsample_1x1_as_a_tap(lib, N, H, C, K):
+    """hifihr_conv2d_bwd_data_pre_plus1x1: the backward-data of layer2.0 / layer3.0's conv1 with downsample[0]'s as a tap of parity class
+    (0, 0), at B = 32 and at an odd size."""
+    kc.conv_dgrad_plus1x1_case(lib, "cuda", N, H, H, C, K, seed=H + C)

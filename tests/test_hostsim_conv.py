@@ -153,3 +153,11 @@ def test_strided_conv_and_downsample_conv_in_one_launch(hostsim_lib, monkeypatch
     monkeypatch.setenv("HIFIHR_GEMM_CUS", "16")
     kc.conv_fwd_pair_case(hostsim_lib, "cpu", 2, 12, 12, 32, 128, 128, seed=3)
     kc.conv_fwd_pair_case(hostsim_lib, "cpu", 1, 10, 14, 64, 128, 256, seed=4)
+
+
+def test_strided_dgrad_with_the_downsample_1x1_as_a_tap(hostsim_lib):
+    """conv_igemm_kernel with ConvGeom::src2: the 1x1 / stride 2 convolution's data gradient inside parity class (0, 0) of the 3x3 / stride 2
+    launch (even and odd image sizes, channel counts of one and of several 32-deep chunks per tap)."""
+    kc.conv_dgrad_plus1x1_case(hostsim_lib, "cpu", 2, 12, 12, 32, 64, seed=5)
+    kc.conv_dgrad_plus1x1_case(hostsim_lib, "cpu", 1, 9, 13, 16, 32, seed=6)
+    kc.conv_dgrad_plus1x1_case(hostsim_lib, "cpu", 1, 8, 10, 64, 48, seed=7)

@@ -39,4 +39,5 @@ run "round 6: weight-gradient transforms / slab sums per layer, not deferred (HI
 run "round 6: the deferred launch at the scope exit, not beside the stem backward (HIFIHR_DEFER_EARLY=0)" HIFIHR_DEFER_EARLY=0
 run "round 6: TN products walk the zero rows behind the tile mosaic (HIFIHR_GEMM_TN_SKIP=0)" HIFIHR_GEMM_TN_SKIP=0
 run "round 6: strided 3x3 + downsample 1x1 as two forward launches (HIFIHR_CONV_ROWS_PAIR=0)" HIFIHR_CONV_ROWS_PAIR=0
+run "round 6: the downsample 1x1 data gradient as a launch + residual, not a tap of the strided 3x3 launch (HIFIHR_DGRAD_PLUS1X1=0)" HIFIHR_DGRAD_PLUS1X1=0
 run "round 6: TN products on contiguous shares, not XCD-coherent (HIFIHR_GEMM_TN_COHERENT=0)" HIFIHR_GEMM_TN_COHERENT=0
