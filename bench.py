@@ -352,6 +352,12 @@ def conv_path_rooflines(ops, lib, dev, nprof, prof=None, prof_how="roctracer (to
         y = torch.randn(N_, OH_, OW_, K_, device=dev)
         flop = 2.0 * N_ * OH_ * OW_ * K_ * R_ * S_ * (3 if C_ == 4 else C_)          # the NHWC4 stem has 3 real channels
         nbytes = 4.0 * (N_ * H_ * W_ * C_ + K_ * R_ * S_ * C_ + N_ * OH_ * OW_ * K_)     # input, weights, output once each
+        if direction == "wgrad+1x1":           # conv_wgrad_kernel: the strided 3x3 weight gradient with the downsample 1x1's column tiles in the same launch
+            dw = torch.zeros(K_, R_, S_, C_, device=dev); dw2 = torch.zeros(K_, C_, device=dev); y2 = torch.randn(N_, OH_, OW_, K_, device=dev)
+            us = hip_us(lambda: lib.conv2d_bwd_weight_plus1x1(x, y, dw, y2, dw2, N_, H_, W_, C_, K_, R_, S_, st_, pd_))
+            add(lib.conv2d_describe(N_, H_, W_, C_, K_, R_, S_, st_, pd_, 2), per_step, us, flop + 2.0 * N_ * OH_ * OW_ * K_ * C_,
+                nbytes + 4.0 * (N_ * OH_ * OW_ * K_ + K_ * C_), f"wgrad N{N_} {H_}x{W_} C{C_}->K{K_} {R_}x{S_} s{st_}  +  1x1 s{st_} of the same input, one launch")
+            continue
         if direction == "wgrad":
             dw = torch.zeros(K_, R_, S_, C_, device=dev)
             us = hip_us(lambda: lib.conv2d_bwd_weight(x, y, dw, N_, H_, W_, C_, K_, R_, S_, st_, pd_))

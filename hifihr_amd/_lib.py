@@ -153,6 +153,8 @@ class HifihrLib:
         c.hifihr_conv2d_bwd_data_pre_res.argtypes = [_c_float_p] * 4 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]
         c.hifihr_conv2d_bwd_data_pre_plus1x1.argtypes = [_c_float_p] * 5 + [c_int] * 9 + [c_void_p]
         c.hifihr_conv2d_bwd_data_pre_plus1x1_supported.argtypes = [c_int] * 9
+        c.hifihr_conv2d_bwd_weight_plus1x1.argtypes = [_c_float_p] * 5 + [c_int] * 9 + [c_void_p]
+        c.hifihr_conv2d_bwd_weight_plus1x1_supported.argtypes = [c_int] * 9
         c.hifihr_weight_prep.argtypes = [c_void_p, c_int, c_int, c_void_p]
         c.hifihr_freihand_augment.argtypes = [c_void_p, c_void_p, _c_int_p, _c_int_p, c_int, c_int, c_int, _c_float_p, _c_float_p, c_void_p]
         c.hifihr_ho3d_workspace_bytes.argtypes = [c_int, c_int]
@@ -639,6 +641,14 @@ class HifihrLib:
         (dy2 [N][OH][OW][K], wt2 [C][K]) in one launch (include/hifihr.h)."""
         self.check(self.c.hifihr_conv2d_bwd_data_pre_plus1x1(_fp(dy), _fp(wt), _fp(dy2), _fp(wt2), _fp(dx), N, H, W, C, K, R, S, stride, pad,
                                                              _stream_of(dy)), "hifihr_conv2d_bwd_data_pre_plus1x1")
+
+    def conv2d_bwd_weight_plus1x1_supported(self, N, H, W, C, K, R, S, stride, pad):
+        return bool(self.c.hifihr_conv2d_bwd_weight_plus1x1_supported(int(N), int(H), int(W), int(C), int(K), int(R), int(S), int(stride), int(pad)))
+
+    def conv2d_bwd_weight_plus1x1(self, x, dy, dw, dy2, dw2, N, H, W, C, K, R, S, stride, pad):
+        """dw += weight gradient of the strided convolution, dw2 += that of the 1x1 / same stride / pad 0 convolution of the same input, one launch."""
+        self.check(self.c.hifihr_conv2d_bwd_weight_plus1x1(_fp(x), _fp(dy), _fp(dw), _fp(dy2), _fp(dw2), N, H, W, C, K, R, S, stride, pad,
+                                                           _stream_of(x)), "hifihr_conv2d_bwd_weight_plus1x1")
 
     @staticmethod
     def prep_jobs(jobs, device):

@@ -554,9 +554,14 @@ __global__ __launch_bounds__(256) HIFIHR_WAVES_PER_EU((SK && BM == 64) ? 4 : 1) 
 // ------------------------------------------------------------------------------------------------
 // backward weight
 // ------------------------------------------------------------------------------------------------
+// dy2 / dw2 / qtiles1 (round 6; null / 0: off): the weight gradient of a SECOND convolution of the same input -- 1x1, the same stride, pad 0, the
+// same output channels (a residual stage's downsample branch) -- in the same launch: its patch column is tap (pad, pad) of this one, so the
+// column tiles blockIdx.x >= qtiles1 run dW2[k][c] = sum_m dy2[m][k] x[m, tap (pad, pad)][c] with everything else unchanged (a 17 us launch
+// of 0.4 GFLOP otherwise)
 template <int BM, int BN, int BKW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float* __restrict__ x, const float* __restrict__ dy,
-                                                        float* __restrict__ dw, int chunks_per_split) {
+                                                        float* __restrict__ dw, int chunks_per_split, const float* __restrict__ dy2,
+                                                        float* __restrict__ dw2, int qtiles1) {
   // GEMM: dW[k][q] (BM x BN tile) = sum over pixels m of dy[m][k] * patch[m][q];  g describes the FORWARD conv
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int LA = BM + 4, LB = BN + 4;
@@ -566,9 +571,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, r31 = lane & 31;
   const int M = g.N * g.OH * g.OW;
-  const int Q = g.R * g.S * g.IC;
+  const bool second = dy2 != nullptr && (int)blockIdx.x >= qtiles1;      // (uniform) a column tile of the second convolution
+  if (second) { dy = dy2; dw = dw2; }
+  const int Q = second ? g.IC : g.R * g.S * g.IC;                         // row length of this tile's dW
   const int K = g.OC;
-  const int bq0 = blockIdx.x * BN, bk0 = blockIdx.y * BM;
+  const int bq0 = (second ? (int)blockIdx.x - qtiles1 : (int)blockIdx.x) * BN, bk0 = blockIdx.y * BM;
   const int nch_total = (M + BKW - 1) / BKW;
   int zsplit = blockIdx.z;
   if (g.batch > 1) {                               // batched use (Winograd weight gradient): blockIdx.z = batch * splits + split
@@ -590,7 +597,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, const float
   const int q = bq0 + b_col;
   const bool qok = q < Q;
   int qr = 0, qs = 0, qc = 0;
-  if (qok) {
+  if (qok && second) {
+    qc = q; qr = g.pad; qs = g.pad;                  // x[oh stride, ow stride]: this convolution's tap (pad, pad)
+  } else if (qok) {
     const int t = q / g.IC;
     qc = q - t * g.IC;
     qr = t / g.S;
@@ -1129,10 +1138,12 @@ hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* w
 }
 
 template <int BM, int BN, int BKW>
-static void launch_wgrad_tile(const ConvGeom& g, int Q, long M, int slots, const float* x, const float* dy, float* dw, hipStream_t st) {
+static void launch_wgrad_tile(const ConvGeom& g, int Q, long M, int slots, const float* x, const float* dy, float* dw, hipStream_t st,
+                              const float* dy2 = nullptr, float* dw2 = nullptr) {
   const int nch = (int)((M + BKW - 1) / BKW);
   const int nbatch = g.batch > 1 ? g.batch : 1;
-  const int tiles = ((g.OC + BM - 1) / BM) * ((Q + BN - 1) / BN) * nbatch;
+  const int qtiles1 = (Q + BN - 1) / BN, qtiles2 = dy2 != nullptr ? (g.IC + BN - 1) / BN : 0;
+  const int tiles = ((g.OC + BM - 1) / BM) * (qtiles1 + qtiles2) * nbatch;
   // tiles * splits workgroups: stay at or just below the resident slots so that every CU gets the same number (the
   // dispatcher spreads a grid evenly; 1152 workgroups on 1024 slots cost five rounds on some CUs: tools/conv_quant_probe.py)
   int splits = slots / tiles;
@@ -1142,8 +1153,23 @@ static void launch_wgrad_tile(const ConvGeom& g, int Q, long M, int slots, const
   if (splits < 1) splits = 1;
   const int cps = (nch + splits - 1) / splits;
   splits = (nch + cps - 1) / cps;
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, BKW>), dim3((Q + BN - 1) / BN, (g.OC + BM - 1) / BM, splits * nbatch), dim3(256), 0, st, g, x, dy,
-                     dw, cps);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, BKW>), dim3(qtiles1 + qtiles2, (g.OC + BM - 1) / BM, splits * nbatch), dim3(256), 0, st, g, x, dy,
+                     dw, cps, dy2, dw2, qtiles1);
+}
+
+// dw += the weight gradient of the strided convolution g, dw2 += the weight gradient of the 1x1 / same stride / pad 0 convolution of the same
+// input with the same output channels, in ONE launch of conv_wgrad_kernel (see its header)
+bool conv_wgrad_plus1x1_supported(const ConvGeom& g) {
+  static const int on = [] { const char* e = getenv("HIFIHR_WGRAD_PLUS1X1"); return e ? atoi(e) : 1; }();
+  return on && !g.dgrad && g.stride >= 2 && g.pad < g.R && g.pad < g.S && g.batch <= 1 && g.IC % 4 == 0 && g.OC % 4 == 0 &&
+         g.OH == (g.IH - 1) / g.stride + 1 && g.OW == (g.IW - 1) / g.stride + 1 && !conv_halo_wgrad_supported(g) && !conv_stem_wgrad_supported(g) &&
+         !conv_wgrad_is_gemm(g);
+}
+hipError_t launch_conv_wgrad_plus1x1(const ConvGeom& g, const float* x, const float* dy, float* dw, const float* dy2, float* dw2, hipStream_t st) {
+  if (!conv_wgrad_plus1x1_supported(g) || dy2 == nullptr || dw2 == nullptr) return hipErrorInvalidValue;
+  const long M = (long)g.N * g.OH * g.OW;
+  launch_wgrad_tile<64, 64, 16>(g, g.R * g.S * g.IC, M, device_cus() * 8, x, dy, dw, st, dy2, dw2);
+  return hipGetLastError();
 }
 
 size_t conv_wgrad_workspace_bytes(const ConvGeom& g) {

@@ -559,6 +559,21 @@ int hifihr_conv2d_bwd_data_pre_plus1x1(const float* dy, const float* wt, const f
   return HIFIHR_OK;
 }
 
+int hifihr_conv2d_bwd_weight_plus1x1_supported(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+  if (!conv_dims_ok(N, H, W, C, K, R, S, stride, pad) || C % 4 || K % 4) return 0;
+  hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
+  return hifihr::conv_wgrad_plus1x1_supported(g) ? 1 : 0;
+}
+
+int hifihr_conv2d_bwd_weight_plus1x1(const float* x, const float* dy, float* dw, const float* dy2, float* dw2, int N, int H, int W, int C, int K,
+                                     int R, int S, int stride, int pad, void* stream) {
+  if (!x || !dy || !dw || !dy2 || !dw2 || !hifihr_conv2d_bwd_weight_plus1x1_supported(N, H, W, C, K, R, S, stride, pad))
+    return fail(HIFIHR_EINVAL, "hifihr_conv2d_bwd_weight_plus1x1: bad argument (see hifihr_conv2d_bwd_weight_plus1x1_supported)");
+  hifihr::ConvGeom g{N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K, R, S, stride, pad, 0};
+  HIP_TRY(hifihr::launch_conv_wgrad_plus1x1(g, x, dy, dw, dy2, dw2, (hipStream_t)stream));
+  return HIFIHR_OK;
+}
+
 int hifihr_weight_prep(const hifihr_prep_job* jobs, int njobs, int blocks_per_job, void* stream) {
   static_assert(sizeof(hifihr_prep_job) == sizeof(hifihr::PrepJob), "hifihr_prep_job layout");
   if (!jobs || njobs <= 0 || blocks_per_job <= 0) return fail(HIFIHR_EINVAL, "hifihr_weight_prep: bad argument");

@@ -106,6 +106,8 @@ struct ConvGeom {
 hipError_t launch_conv_igemm(const ConvGeom& g, const float* src, const float* wgt, const float* bias, float* dst, float* stats,
                              void* sk_ws, size_t sk_ws_bytes, hipStream_t st);
 size_t conv_sk_workspace_bytes(const ConvGeom& g);
+bool conv_wgrad_plus1x1_supported(const ConvGeom& g);
+hipError_t launch_conv_wgrad_plus1x1(const ConvGeom& g, const float* x, const float* dy, float* dw, const float* dy2, float* dw2, hipStream_t st);
 // 3x3 / stride 1 / 64 -> 64 channels with the input halo staged once per tile (csrc/conv_halo.hip); forward (+ BN statistics) and dgrad
 bool conv_halo_supported(const ConvGeom& g, const float* bias);
 const float* conv_halo_zero_page(hipStream_t st);

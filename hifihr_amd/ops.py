@@ -1219,13 +1219,35 @@ class _Conv2dPair(torch.autograd.Function):
                 if wt1 is not None and wt2 is not None:
                     plus = (gy2.contiguous(memory_format=_CL), wt2)
         if plus is not None:
-            s2 = shim(wk2, ctx.geom2, ctx.w2, need_w2, False)
-            s2.needs_input_grad = (False,) + tuple(s2.needs_input_grad[1:])          # its weight gradient only
-            dw2 = _Conv2dMFMA.backward(s2, gy2)[1]
-            s1 = shim(wk1, ctx.geom1, ctx.w1, need_w1, False)
+            # the two weight gradients likewise: the 1x1 convolution's patch column is tap (pad, pad) of the 3x3's -- its column tiles join the
+            # 3x3's launch (hifihr_conv2d_bwd_weight_plus1x1) unless weight gradients run on the side stream
+            w_both = (need_w1 and need_w2 and not _ASYNC_WGRAD.active
+                      and lib.conv2d_bwd_weight_plus1x1_supported(N, H, W, C, K1, R, S, stride, pad))
+            if w_both:
+                gy1c = gy1.contiguous(memory_format=_CL)
+
+                def target(w, wk):
+                    if getattr(w, "_hifihr_direct_grad", False) and w.grad is not None and w.grad.is_contiguous(memory_format=_CL):
+                        return w.grad, None
+                    t = torch.zeros_like(wk, memory_format=_CL)
+                    return t, t
+                t1, dw1 = target(ctx.w1, wk1)
+                t2, dw2 = target(ctx.w2, wk2)
+                if PROFILE.on:
+                    PROFILE.conv_log.append(((N, H, W, C, K1, R, S, stride, pad), "wgrad+1x1"))
+                PROFILE.bracket("conv_wgrad", lambda: lib.conv2d_bwd_weight_plus1x1(x, gy1c, t1, plus[0], t2, N, H, W, C, K1, R, S, stride, pad))
+                if dw1 is None:
+                    _grad_ready(ctx.w1)
+                if dw2 is None:
+                    _grad_ready(ctx.w2)
+            else:
+                s2 = shim(wk2, ctx.geom2, ctx.w2, need_w2, False)
+                s2.needs_input_grad = (False,) + tuple(s2.needs_input_grad[1:])      # its weight gradient only
+                dw2 = _Conv2dMFMA.backward(s2, gy2)[1]
+            s1 = shim(wk1, ctx.geom1, ctx.w1, need_w1 and not w_both, False)
             s1.plus1x1 = plus
-            dx, dw1 = _Conv2dMFMA.backward(s1, gy1)[:2]
-            return dx, dw1, dw2, None
+            dx, dw1b = _Conv2dMFMA.backward(s1, gy1)[:2]
+            return dx, (dw1 if w_both else dw1b), dw2, None
         if gy2 is not None:
             dx2, dw2 = _Conv2dMFMA.backward(shim(wk2, ctx.geom2, ctx.w2, need_w2, False), gy2)[:2]
         if gy1 is not None:

@@ -482,6 +482,13 @@ int hifihr_conv2d_bwd_data_pre_res(const float* dy_d, const float* wt_d, const f
 int hifihr_conv2d_bwd_data_pre_plus1x1_supported(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 int hifihr_conv2d_bwd_data_pre_plus1x1(const float* dy_d, const float* wt_d, const float* dy2_d, const float* wt2_d, float* dx_d, int N, int H,
                                        int W, int C, int K, int R, int S, int stride, int pad, void* stream);
+/* dw_d[K][R][S][C] += weight gradient of the strided convolution, dw2_d[K][C] += weight gradient of the 1x1 / same stride / pad 0 convolution of
+ * the same input with the same output channels (dy2_d [N][OH][OW][K]), in ONE launch: the second convolution's patch column is tap (pad, pad)
+ * of the first (round 6; the downsample branch of a residual stage's first block, as hifihr_conv2d_bwd_data_pre_plus1x1).  Float atomics, like
+ * hifihr_conv2d_bwd_weight on these shapes.  _supported: 1 when the shape runs on that path; HIFIHR_WGRAD_PLUS1X1=0 switches it off. */
+int hifihr_conv2d_bwd_weight_plus1x1_supported(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+int hifihr_conv2d_bwd_weight_plus1x1(const float* x_d, const float* dy_d, float* dw_d, const float* dy2_d, float* dw2_d, int N, int H, int W,
+                                     int C, int K, int R, int S, int stride, int pad, void* stream);
 /* Every per-step weight re-layout of a model in ONE launch.  The weights change once per optimizer step; a ResNet-18 step
  * otherwise spends ~40 tiny launches (~5 us of launch floor each) on transposes and Winograd weight transforms.
  * jobs_d: DEVICE array of njobs descriptors (src / dst are device pointers);

@@ -658,6 +658,32 @@ def conv_dgrad_plus1x1_case(lib, device, N, H, W, C, K, stride=2, seed=0):
     assert float((dx1.cpu() - ref1.permute(0, 2, 3, 1)).abs().max()) <= 3e-5 * scale + 1e-6
 
 
+def conv_wgrad_plus1x1_case(lib, device, N, H, W, C, K, stride=2, seed=0):
+    """hifihr_conv2d_bwd_weight_plus1x1: the weight gradients of the strided 3x3 convolution and of the 1x1 / same stride / pad 0 convolution
+    of the same input in one launch == torch autograd, and == hifihr_conv2d_bwd_weight on each (float atomics: to rounding); both ACCUMULATE."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=gen)
+    w1 = (torch.randn(K, C, 3, 3, generator=gen) / (9 * C) ** 0.5).requires_grad_(True); w2 = (torch.randn(K, C, 1, 1, generator=gen) / C ** 0.5).requires_grad_(True)
+    y1, y2 = F.conv2d(x, w1, None, stride, 1), F.conv2d(x, w2, None, stride, 0)
+    g1, g2 = torch.randn(y1.shape, generator=gen), torch.randn(y2.shape, generator=gen)
+    ((y1 * g1).sum() + (y2 * g2).sum()).backward()
+    r1, r2 = w1.grad.permute(0, 2, 3, 1), w2.grad.permute(0, 2, 3, 1)
+    d = lambda t: t.to(device).contiguous()
+    xd, g1d, g2d = d(x.permute(0, 2, 3, 1)), d(g1.permute(0, 2, 3, 1)), d(g2.permute(0, 2, 3, 1))
+    assert lib.conv2d_bwd_weight_plus1x1_supported(N, H, W, C, K, 3, 3, stride, 1)
+    dw1 = torch.full((K, 3, 3, C), 0.5, device=device); dw2 = torch.full((K, 1, 1, C), -0.25, device=device)     # accumulated into
+    lib.conv2d_bwd_weight_plus1x1(xd, g1d, dw1, g2d, dw2, N, H, W, C, K, 3, 3, stride, 1)
+    for got, ref, base in ((dw1, r1, 0.5), (dw2, r2, -0.25)):
+        sc = float(ref.abs().max())
+        assert float((got.cpu() - base - ref).abs().max()) <= 3e-5 * sc + 1e-5, float((got.cpu() - base - ref).abs().max())
+    s1 = torch.zeros(K, 3, 3, C, device=device); s2 = torch.zeros(K, 1, 1, C, device=device)
+    lib.conv2d_bwd_weight(xd, g1d, s1, N, H, W, C, K, 3, 3, stride, 1)
+    lib.conv2d_bwd_weight(xd, g2d, s2, N, H, W, C, K, 1, 1, stride, 0)
+    assert float((dw1 - 0.5 - s1).abs().max()) <= 1e-5 * float(s1.abs().max()) + 1e-6
+    assert float((dw2 + 0.25 - s2).abs().max()) <= 1e-5 * float(s2.abs().max()) + 1e-6
+
+
 # ------------------------------------------------------------------------------------------------
 # depthwise convolution (EfficientNet MBConv) vs plain PyTorch fp32 (F.pad + grouped F.conv2d autograd)
 # ------------------------------------------------------------------------------------------------

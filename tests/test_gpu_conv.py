@@ -606,3 +606,9 @@ def test_strided_dgrad_with_the_downsample_1x1_as_a_tap(lib, N, H, C, K):
     """hifihr_conv2d_bwd_data_pre_plus1x1: the backward-data of layer2.0 / layer3.0's conv1 with downsample[0]'s as a tap of parity class
     (0, 0), at B = 32 and at an odd size."""
     kc.conv_dgrad_plus1x1_case(lib, "cuda", N, H, H, C, K, seed=H + C)
+
+
+@pytest.mark.parametrize("N,H,C,K", [(32, 56, 64, 128), (32, 28, 128, 256), (3, 31, 32, 48)])
+def test_strided_wgrad_with_the_downsample_1x1_in_the_same_launch(lib, N, H, C, K):
+    """hifihr_conv2d_bwd_weight_plus1x1: the weight gradients of layer2.0 / layer3.0's conv1 and downsample[0] in one launch, at B = 32 and odd."""
+    kc.conv_wgrad_plus1x1_case(lib, "cuda", N, H, H, C, K, seed=H + C + 1)

@@ -161,3 +161,11 @@ def test_strided_dgrad_with_the_downsample_1x1_as_a_tap(hostsim_lib):
     kc.conv_dgrad_plus1x1_case(hostsim_lib, "cpu", 2, 12, 12, 32, 64, seed=5)
     kc.conv_dgrad_plus1x1_case(hostsim_lib, "cpu", 1, 9, 13, 16, 32, seed=6)
     kc.conv_dgrad_plus1x1_case(hostsim_lib, "cpu", 1, 8, 10, 64, 48, seed=7)
+
+
+def test_strided_wgrad_with_the_downsample_1x1_in_the_same_launch(hostsim_lib):
+    """conv_wgrad_kernel with dy2 / dw2: the column tiles of the 1x1 / stride 2 convolution's weight gradient behind the 3x3's (channel counts
+    below, at and above one 64-column tile; odd sizes; several pixel splits)."""
+    kc.conv_wgrad_plus1x1_case(hostsim_lib, "cpu", 2, 12, 12, 32, 64, seed=8)
+    kc.conv_wgrad_plus1x1_case(hostsim_lib, "cpu", 1, 9, 13, 16, 40, seed=9)
+    kc.conv_wgrad_plus1x1_case(hostsim_lib, "cpu", 1, 8, 10, 96, 48, seed=10)

@@ -40,4 +40,5 @@ run "round 6: the deferred launch at the scope exit, not beside the stem backwar
 run "round 6: TN products walk the zero rows behind the tile mosaic (HIFIHR_GEMM_TN_SKIP=0)" HIFIHR_GEMM_TN_SKIP=0
 run "round 6: strided 3x3 + downsample 1x1 as two forward launches (HIFIHR_CONV_ROWS_PAIR=0)" HIFIHR_CONV_ROWS_PAIR=0
 run "round 6: the downsample 1x1 data gradient as a launch + residual, not a tap of the strided 3x3 launch (HIFIHR_DGRAD_PLUS1X1=0)" HIFIHR_DGRAD_PLUS1X1=0
+run "round 6: the downsample 1x1 weight gradient as a launch of its own (HIFIHR_WGRAD_PLUS1X1=0)" HIFIHR_WGRAD_PLUS1X1=0
 run "round 6: TN products on contiguous shares, not XCD-coherent (HIFIHR_GEMM_TN_COHERENT=0)" HIFIHR_GEMM_TN_COHERENT=0
