@@ -77,6 +77,20 @@ def round6():
     finally:
         del os.environ["HIFIHR_GEMM_CUS"]
     kc.light_split_case(lib, "cpu", B=5)
+    # the row-share GEMM bodies after this round's changes (division-free walkers, head chunk, the row-block-wise last chunk with the stores
+    # between the MFMAs, the TN body's fused mosaic tail): tiles of several heights, shares across problems, 16 images of 13 x 13 on a mosaic
+    kc.bgemm_case(lib, "cpu", 300, 128, 96, 3, seed=1)
+    kc.bgemm_case(lib, "cpu", 50, 256, 64, 2, seed=2)
+    kc.bgemm_tn_case(lib, "cpu", 192, 256, 96, 2, seed=3)
+    kc.wino_case(lib, "cpu", 16, 13, 13, 64, 128, seed=4, m=4)
+    # the strided blocks' backward with the downsample 1x1 convolution folded in (conv_igemm_kernel's second source, conv_wgrad_kernel's extra tiles)
+    kc.conv_dgrad_plus1x1_case(lib, "cpu", 1, 9, 13, 16, 32, seed=6)
+    kc.conv_wgrad_plus1x1_case(lib, "cpu", 1, 9, 13, 16, 40, seed=9)
+    os.environ["HIFIHR_GEMM_CUS"] = "16"                                          # (the pair wants at least 8 workgroups per side)
+    try:
+        kc.conv_fwd_pair_case(lib, "cpu", 2, 12, 12, 32, 128, 128, seed=3)
+    finally:
+        del os.environ["HIFIHR_GEMM_CUS"]
 
 
 GROUPS = {"conv": conv, "render": render, "wino": wino, "round5": round5, "round6": round6}
